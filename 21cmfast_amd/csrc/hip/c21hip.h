@@ -1,0 +1,133 @@
+/*
+ * c21hip.h -- the thin C layer between the C host drivers (csrc/host/ *.c) and the
+ * hand-written CDNA4 kernels (csrc/hip/ *.hip).  Plain pointers and sizes only.
+ * Every function enqueues work on `stream` (a hipStream_t carried as void*) and
+ * returns 0 or a c21cm_status code; nothing here synchronises unless it says so.
+ *
+ * Grid layouts (reference: src/py21cmfast/src/indexing.h:84-100):
+ *   dense  float[nx][ny][nz]
+ *   padded float[nx][ny][2*(nz/2+1)]  == complex float2[nx][ny][nz/2+1]
+ */
+#ifndef C21HIP_H
+#define C21HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime.hip : memory, residency, workspace, timing ---- */
+int c21hip_device_count(void);
+int c21hip_is_device_ptr(const void *p);     /* 1 = MI355X HBM, 0 = host          */
+void *c21hip_ws(int slot, size_t bytes);     /* cached device scratch, NULL = OOM */
+void c21hip_ws_release(void);
+int c21hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int c21hip_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int c21hip_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int c21hip_memset(void *dst, int byte, size_t bytes, void *stream);
+int c21hip_sync(void *stream);
+int c21hip_device_sync(void);
+void *c21hip_event_create(void);
+void c21hip_event_destroy(void *ev);
+int c21hip_event_record(void *ev, void *stream);
+float c21hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
+void c21hip_set_error(const char *fmt, ...);
+const char *c21hip_get_error(void);
+
+/* ---- fft.hip : in-place padded real 3-D transforms (reference: dft.c:18-72) ---- */
+int c21hip_fft_r2c(float *padded, int nx, int ny, int nz, void *stream);
+int c21hip_fft_c2r(float *padded, int nx, int ny, int nz, void *stream);
+void c21hip_fft_release(void);
+/* 1 when the hand-written power-of-two transform is used, 0 for rocFFT */
+int c21hip_fft_is_native(int nx, int ny, int nz);
+
+/* ---- grid_kernels.hip : generic sweeps ---- */
+/* padded[l][k] = clip(dense[l][k] * factor, lo, hi); pad columns zeroed.
+ * reference: IonisationBox.c:333-350 */
+int c21hip_pack_clip(const float *dense, float *padded, int nx, int ny, int nz, double factor,
+                     double lo, double hi, void *stream);
+/* dense[l][k] = padded[l][k] * scale (scale applied in float) */
+int c21hip_unpack_scale(const float *padded, float *dense, int nx, int ny, int nz, float scale,
+                        void *stream);
+/* buf[i] /= divisor, float arithmetic (reference: IonisationBox.c:356-359) */
+int c21hip_divide_inplace(float *buf, size_t n, float divisor, void *stream);
+/* buf[i] = (float)(buf[i] / divisor), double arithmetic (reference: filtering.c:422-424) */
+int c21hip_divide_inplace_f64(float *buf, size_t n, double divisor, void *stream);
+int c21hip_fill(float *buf, size_t n, float value, void *stream);
+/* out[i] = (double)in[i] */
+int c21hip_widen(const float *in, double *out, size_t n, void *stream);
+
+/* dst = src * W(kR), the fused memcpy + filter_box of copy_filter_transform.
+ * reference: IonisationBox.c:577-631 + filtering.c:308-394.  `apply` = 0 copies only. */
+int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int ny, int nz, double box_len,
+                       double box_len_z, int filter_type, float R, float R_param, int apply,
+                       void *stream);
+
+/* ---- ionize_kernels.hip ---- */
+typedef struct c21hip_ionize_args {
+    int nx, ny, nz;
+    int r_index;        /* 0 = last (cell-scale) radius: partial ionisation branch */
+    int lagrangian;     /* stars grid divides by rhocrit_omb*(1+delta)             */
+    int mass_dep_zeta;  /* floor f at f_limit                                      */
+    int use_ts_fluct;
+    int minimize_memory;
+    int first_snapshot; /* previous z_reion treated as -1                          */
+    int fix_mean;
+    double mean_f_coll; /* fix_mean numerator                                      */
+    double f_limit;
+    double ion_eff_factor;
+    double rhocrit_omb;
+    double photoncons_factor;
+    double redshift;
+    double TK_nofluct, adia_TK_term, T_re;
+} c21hip_ionize_args;
+
+/* All reductions are two-stage and deterministic: `partials` is device scratch of
+ * C21HIP_PARTIALS doubles, the result lands in a device double. */
+#define C21HIP_PARTIALS 4096
+
+/* min/max of the filtered delta (the clip of :689 is applied in registers by the
+ * consumers).  reference: IonisationBox.c:668-699.  minmax_out = {min, max}. */
+int c21hip_clip_minmax(float *delta_fil, int nx, int ny, int nz, double *partials,
+                       double *minmax_out, void *stream);
+/* Eulerian source models: f_coll(delta_R) -> unnormalised_nion (dense) and sum(f_coll).
+ * mode: enum c21cm_fcoll_mode (ERFC / TABLE_LINEAR / TABLE_EXP).
+ * reference: IonisationBox.c:773-962 */
+int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, int nx, int ny, int nz,
+                          int mode, double growthf, double sigma_min, double sigma_max,
+                          double delta_c, double tab_min, double tab_width,
+                          const float *table_dev, double *partials, double *sum_out,
+                          void *stream);
+/* Lagrangian source grids: sum(stars) + barrier test + partial ionisation, one sweep.
+ * first_cross != NULL switches to shard mode (records the radius index instead of
+ * touching xH / z_reion).  reference: IonisationBox.c:821-837,1008-1201 */
+int c21hip_ionise_stars(const c21hip_ionize_args *a, const float *delta_fil,
+                        const float *stars_fil, const float *xe_fil, const float *density,
+                        const float *prev_z_reion, const float *kinetic_temp_neutral, float *xH,
+                        float *z_reion, float *kinetic_temperature, unsigned char *first_cross,
+                        double *partials, double *sum_out, void *stream);
+/* Eulerian barrier test; mean_dev holds the clamped grid mean (fix_mean denominator).
+ * reference: IonisationBox.c:1008-1201 */
+int c21hip_ionise_eulerian(const c21hip_ionize_args *a, const float *nion_dense,
+                           const float *xe_fil, const float *density, const float *prev_z_reion,
+                           const float *kinetic_temp_neutral, const double *mean_dev, float *xH,
+                           float *z_reion, float *kinetic_temperature,
+                           unsigned char *first_cross, void *stream);
+/* mean = clamp(sum/N): reference IonisationBox.c:960,1566-1576 */
+int c21hip_finish_mean(const double *sum_dev, double ntot, int mass_dep_zeta, double f_limit,
+                       double *mean_dev, void *stream);
+/* Ionised-cell temperatures + sum(xH) + NaN flag.  reference: IonisationBox.c:1203-1256,1597-1608 */
+int c21hip_finalize(const c21hip_ionize_args *a, double stored_redshift, const float *density,
+                    const float *kinetic_temp_neutral, const float *xH, const float *z_reion,
+                    float *kinetic_temperature, size_t ntot, double *partials, double *sum_out,
+                    int *flag_out, void *stream);
+/* xH/z_reion from a max-reduced first_cross mask (multi-GPU tail). */
+int c21hip_apply_first_cross(const unsigned char *first_cross, const float *prev_z_reion,
+                             int first_snapshot, double redshift, float *xH, float *z_reion,
+                             size_t ntot, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,146 @@
+// fft.hip -- in-place, padded, unnormalised real 3-D transforms on HBM.
+//
+// Replaces dft_r2c_cube / dft_c2r_cube (reference: src/py21cmfast/src/dft.c:18-72),
+// which build and destroy an FFTW plan on every call.  Here plans are created once per
+// (nx, ny, nz, direction) and cached for the life of the process.
+//
+// Two engines:
+//   * power-of-two cubes/boxes (each axis a power of two, 16..2048): the hand-written
+//     LDS-staged line transforms of fft_native.hip;
+//   * any other size (the reference's tests use 35, 50, 70, 150): rocFFT with the
+//     FFTW-compatible padded strides.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "c21hip.h"
+#include "c21cm_abi.h"
+
+extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz);
+extern "C" int c21hip_native_fft_r2c(float *padded, int nx, int ny, int nz, void *stream);
+extern "C" int c21hip_native_fft_c2r(float *padded, int nx, int ny, int nz, void *stream);
+
+namespace {
+struct Plan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void *work = nullptr;
+    size_t work_bytes = 0;
+};
+using Key = std::tuple<int, int, int, int>;
+std::map<Key, Plan> g_plans;
+std::mutex g_mutex;
+bool g_setup = false;
+
+int make_plan(Plan &p, int nx, int ny, int nz, int inverse) {
+    if (!g_setup) {
+        if (rocfft_setup() != rocfft_status_success) {
+            c21hip_set_error("rocfft_setup failed");
+            return C21CM_IO_ERROR;
+        }
+        g_setup = true;
+    }
+    const size_t nzc = (size_t)nz / 2 + 1;
+    // rocFFT lists the fastest dimension first
+    size_t lengths[3] = {(size_t)nz, (size_t)ny, (size_t)nx};
+    size_t rstride[3] = {1, 2 * nzc, 2 * nzc * (size_t)ny};
+    size_t cstride[3] = {1, nzc, nzc * (size_t)ny};
+    rocfft_plan_description desc = nullptr;
+    rocfft_status st = rocfft_plan_description_create(&desc);
+    if (st == rocfft_status_success) {
+        if (!inverse)
+            st = rocfft_plan_description_set_data_layout(
+                desc, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr,
+                nullptr, 3, rstride, 0, 3, cstride, 0);
+        else
+            st = rocfft_plan_description_set_data_layout(
+                desc, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr,
+                nullptr, 3, cstride, 0, 3, rstride, 0);
+    }
+    if (st == rocfft_status_success)
+        st = rocfft_plan_create(&p.plan, rocfft_placement_inplace,
+                                inverse ? rocfft_transform_type_real_inverse
+                                        : rocfft_transform_type_real_forward,
+                                rocfft_precision_single, 3, lengths, 1, desc);
+    if (desc) rocfft_plan_description_destroy(desc);
+    if (st != rocfft_status_success) {
+        c21hip_set_error("rocFFT plan creation failed (%dx%dx%d, inverse=%d, status %d)", nx, ny,
+                         nz, inverse, (int)st);
+        return C21CM_IO_ERROR;
+    }
+    rocfft_plan_get_work_buffer_size(p.plan, &p.work_bytes);
+    rocfft_execution_info_create(&p.info);
+    if (p.work_bytes) {
+        if (hipMalloc(&p.work, p.work_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            c21hip_set_error("rocFFT work buffer of %zu bytes could not be allocated",
+                             p.work_bytes);
+            return C21CM_MEMORY_ALLOC_ERROR;
+        }
+        rocfft_execution_info_set_work_buffer(p.info, p.work, p.work_bytes);
+    }
+    return 0;
+}
+
+int run_rocfft(float *padded, int nx, int ny, int nz, int inverse, void *stream) {
+    Plan *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        Key key(nx, ny, nz, inverse);
+        auto it = g_plans.find(key);
+        if (it == g_plans.end()) {
+            Plan fresh;
+            int st = make_plan(fresh, nx, ny, nz, inverse);
+            if (st) return st;
+            it = g_plans.emplace(key, fresh).first;
+        }
+        p = &it->second;
+    }
+    rocfft_execution_info_set_stream(p->info, stream);
+    void *bufs[1] = {padded};
+    rocfft_status st = rocfft_execute(p->plan, bufs, nullptr, p->info);
+    if (st != rocfft_status_success) {
+        c21hip_set_error("rocfft_execute failed with status %d", (int)st);
+        return C21CM_IO_ERROR;
+    }
+    return 0;
+}
+
+bool native_enabled() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char *e = getenv("C21CM_FFT");
+        cached = (e && e[0] == 'r') ? 0 : 1;  // C21CM_FFT=rocfft forces the library path
+    }
+    return cached == 1;
+}
+}  // namespace
+
+extern "C" int c21hip_fft_is_native(int nx, int ny, int nz) {
+    return native_enabled() && c21hip_native_fft_supported(nx, ny, nz);
+}
+
+extern "C" int c21hip_fft_r2c(float *padded, int nx, int ny, int nz, void *stream) {
+    if (c21hip_fft_is_native(nx, ny, nz)) return c21hip_native_fft_r2c(padded, nx, ny, nz, stream);
+    return run_rocfft(padded, nx, ny, nz, 0, stream);
+}
+
+extern "C" int c21hip_fft_c2r(float *padded, int nx, int ny, int nz, void *stream) {
+    if (c21hip_fft_is_native(nx, ny, nz)) return c21hip_native_fft_c2r(padded, nx, ny, nz, stream);
+    return run_rocfft(padded, nx, ny, nz, 1, stream);
+}
+
+extern "C" void c21hip_fft_release(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto &kv : g_plans) {
+        Plan &p = kv.second;
+        if (p.info) rocfft_execution_info_destroy(p.info);
+        if (p.plan) rocfft_plan_destroy(p.plan);
+        if (p.work) (void)hipFree(p.work);
+    }
+    g_plans.clear();
+}

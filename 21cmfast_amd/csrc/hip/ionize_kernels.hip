@@ -1,0 +1,649 @@
+// ionize_kernels.hip -- the per-radius real-space sweeps of ComputeIonizedBox.
+//
+// reference loops being replaced (src/py21cmfast/src/IonisationBox.c):
+//   clip_and_get_extrema   :668-699    -> clip_minmax_kernel
+//   calculate_fcoll_grid   :773-962    -> fcoll_eulerian_kernel / fused into ionise_stars_kernel
+//   find_ionised_regions   :1008-1201  -> ionise_stars_kernel / ionise_eulerian_kernel
+//   set_ionized_temperatures + sum(xH) :1203-1256,1597-1608 -> finalize_kernel
+//
+// Design (HBM-bound, no MFMA):
+//   * the reference writes the clipped filtered grids back and re-reads them in the
+//     next loop; here the clips happen in registers and the filtered grids are only
+//     ever READ by these kernels -- for Lagrangian source grids the f_coll sum, the
+//     barrier test and the partial-ionisation branch are one sweep;
+//   * each thread owns two z-neighbours (float2 from the padded grids, whose rows are
+//     only 8-byte aligned, and float2 from the dense grids);
+//   * global sums are two-stage and deterministic: wavefront shuffle -> LDS -> one
+//     partial per workgroup -> a single-workgroup finishing kernel that adds the
+//     partials in index order (no float atomics, bit-reproducible run to run);
+//   * outputs (xH, z_reion, T_k) are written only where the reference writes them.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "c21hip.h"
+#include "c21cm_abi.h"
+#include "c21cm_grid.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 256 * 8;
+constexpr double kFractFloatErr = 1e-7;  // reference: Constants.h FRACT_FLOAT_ERR
+constexpr double kTiny = 1e-30;          // reference: Constants.h TINY
+constexpr double kMinDensityLowLimit = 9e-8;  // reference: thermochem.c:16
+
+inline int grid_for(size_t work_items) {
+    size_t b = (work_items + kBlock - 1) / kBlock;
+    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define LAUNCH_CHECK()                                                                  \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            c21hip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                       \
+            return C21CM_IO_ERROR;                                                      \
+        }                                                                               \
+    } while (0)
+
+// ---- reductions -----------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// one partial per workgroup
+__device__ __forceinline__ void block_sum_to(double v, double *partials) {
+    __shared__ double lds[kBlock / 64];
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) s += lds[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
+// op: 0 sum, 1 min, 2 max.  Single workgroup, fixed summation order.
+__global__ void __launch_bounds__(kBlock)
+finish_reduce_kernel(const double *__restrict__ partials, int n, int op, double *out) {
+    __shared__ double lds[kBlock];
+    double acc = (op == 0) ? 0. : partials[0];
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        double p = partials[i];
+        acc = (op == 0) ? acc + p : (op == 1 ? fmin(acc, p) : fmax(acc, p));
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            double a = lds[threadIdx.x], b = lds[threadIdx.x + s];
+            lds[threadIdx.x] = (op == 0) ? a + b : (op == 1 ? fmin(a, b) : fmax(a, b));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = lds[0];
+}
+
+// mean = sum/N with the clamp of IonisationBox.c:1566-1576
+__global__ void finish_mean_kernel(const double *sum, double ntot, int mass_dep_zeta,
+                                   double f_limit, double *mean_out) {
+    double m = *sum / ntot;
+    if (mass_dep_zeta) {
+        if (m <= f_limit) m = f_limit;
+    } else {
+        if (m <= kFractFloatErr) m = kFractFloatErr;
+    }
+    *mean_out = m;
+}
+
+// ---- per-cell physics -------------------------------------------------------------
+// reference: thermochem.c:58-63 (all three arguments arrive as float)
+__device__ __forceinline__ float partially_ionized_T(float T_HI, float res_xH, float T_re) {
+    if (res_xH <= 0.f) return T_re;
+    if (res_xH >= 1.f) return T_HI;
+    return (float)((double)__fmul_rn(T_HI, res_xH) + (double)T_re * (1. - (double)res_xH));
+}
+
+// reference: thermochem.c:31-56
+__device__ float fully_ionized_T(float z_re, float z, float delta, float T_re) {
+    float result, delta_re;
+    if (fabs((double)(z - z_re)) < 1e-4) {
+        result = 1.f;
+    } else {
+        delta_re = (float)((double)delta * (1. + (double)z) / (1. + (double)z_re));
+        if (delta_re <= -1.f) delta_re = (float)(-1. + kMinDensityLowLimit);
+        if (delta <= -1.f) delta = (float)(-1. + kMinDensityLowLimit);
+        result = (float)pow((1. + (double)delta) / (1. + (double)delta_re), 1.1333);
+        result = (float)((double)result * pow((1. + (double)z) / (1. + (double)z_re), 3.4));
+        result = __fmul_rn(result, expf((float)(pow((1. + (double)z) / 7.1, 2.5) -
+                                                pow((1. + (double)z_re) / 7.1, 2.5))));
+    }
+    result = (float)((double)result * pow((double)T_re, 1.7));
+    result = (float)((double)result +
+                     pow(1e4 * ((1. + (double)z) / 4.), 1.7) * (double)(1.f + delta));
+    result = (float)pow((double)result, 0.5882);
+    return result;
+}
+
+// reference: hmf.c:1187-1203 (float in, double polynomial, float out)
+__device__ __forceinline__ float erfcc_f(float x) {
+    const double q = fabs((double)x);
+    const double t = 1.0 / (1.0 + 0.5 * q);
+    const double ans =
+        t * exp(-q * q - 1.2655122 +
+                t * (1.0000237 +
+                     t * (0.374092 +
+                          t * (0.0967842 +
+                               t * (-0.1862881 +
+                                    t * (0.2788681 +
+                                         t * (-1.13520398 +
+                                              t * (1.4885159 +
+                                                   t * (-0.82215223 + t * 0.17087277)))))))));
+    return (float)(x >= 0.0f ? ans : 2.0 - ans);
+}
+
+// reference: hmf.c:1205-1241.  sig (from the float sigmas) is precomputed on the host.
+__device__ __forceinline__ double fgtrm_bias_fast(float growthf, float del_bias, double sig,
+                                                  double delta_c) {
+    const double del = (delta_c - (double)del_bias) / (double)growthf;
+    const double x = del / (sqrt(2.) * sig);
+    if (x < 0) return 1.0;
+    return (double)erfcc_f((float)x);
+}
+
+// reference: interpolation.c:123-131
+__device__ __forceinline__ double eval_table_f(double x, double x_min, double x_width,
+                                               const float *y_arr) {
+    const int idx = (int)floor((x - x_min) / x_width);
+    const double table_val = x_min + x_width * (double)(float)idx;
+    const double interp_point = (x - table_val) / x_width;
+    return (double)y_arr[idx] * (1 - interp_point) + (double)y_arr[idx + 1] * interp_point;
+}
+
+// both clips applied to the filtered density, IonisationBox.c:689 then :803
+__device__ __forceinline__ float clip_delta_eulerian(float v) {
+    v = fmaxf((float)fmin((double)v, 1e6), -1.f);
+    return fmaxf(v, (float)(-1. + kFractFloatErr));
+}
+__device__ __forceinline__ float clip_delta(float v) {
+    return fmaxf(v, (float)(-1. + kFractFloatErr));
+}
+__device__ __forceinline__ float clip_xe(float v) { return fminf(fmaxf(v, 0.f), 0.999f); }
+
+// ---- index helper: item i -> (padded element index, dense element index), VEC cells each
+template <int VEC>
+struct CellIndex {
+    size_t padded;  // in units of VEC floats
+    size_t dense;   // in units of VEC floats
+};
+template <int VEC>
+__device__ __forceinline__ CellIndex<VEC> cell_index(size_t i, int nz_items, int zpad_items) {
+    const size_t line = i / (size_t)nz_items;
+    const int k = (int)(i - line * (size_t)nz_items);
+    return CellIndex<VEC>{line * (size_t)zpad_items + k, i};
+}
+
+template <int VEC>
+struct Pack;
+template <>
+struct Pack<1> {
+    float v[1];
+    __device__ __forceinline__ static Pack load(const float *p, size_t i) { return Pack{{p[i]}}; }
+    __device__ __forceinline__ void store(float *p, size_t i) const { p[i] = v[0]; }
+};
+template <>
+struct Pack<2> {
+    float v[2];
+    __device__ __forceinline__ static Pack load(const float *p, size_t i) {
+        float2 t = reinterpret_cast<const float2 *>(p)[i];
+        return Pack{{t.x, t.y}};
+    }
+    __device__ __forceinline__ void store(float *p, size_t i) const {
+        reinterpret_cast<float2 *>(p)[i] = make_float2(v[0], v[1]);
+    }
+};
+
+// ---- clip_and_get_extrema ------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+minmax_kernel(const float *__restrict__ delta_fil, size_t nitems, int nz_items, int zpad_items,
+              double *__restrict__ pmin, double *__restrict__ pmax) {
+    // the reference seeds min/max with cell 0 (IonisationBox.c:672-673)
+    double lo = (double)delta_fil[0], hi = lo;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const auto ci = cell_index<VEC>(i, nz_items, zpad_items);
+        const auto d = Pack<VEC>::load(delta_fil, ci.padded);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            lo = fmin(lo, (double)d.v[e]);
+            hi = fmax(hi, (double)d.v[e]);
+        }
+    }
+    __shared__ double lds_lo[kBlock / 64], lds_hi[kBlock / 64];
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        lds_lo[wave] = lo;
+        lds_hi[wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) {
+            lo = fmin(lo, lds_lo[w]);
+            hi = fmax(hi, lds_hi[w]);
+        }
+        pmin[blockIdx.x] = lo;
+        pmax[blockIdx.x] = hi;
+    }
+}
+
+// ---- calculate_fcoll_grid, Eulerian source models -------------------------------------
+struct FcollParams {
+    int mode;  // enum c21cm_fcoll_mode
+    float growthf;
+    double sig;  // sqrt(sig_small^2 - sig_large^2) from the float sigmas; <0: equal sigmas
+    double delta_c;
+    double tab_min, tab_width;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ nion_dense,
+                      size_t nitems, int nz_items, int zpad_items, FcollParams fp,
+                      const float *__restrict__ table, double *__restrict__ partials) {
+    __shared__ float tab[C21CM_NDELTA_TABLE];
+    if (fp.mode >= C21CM_FCOLL_TABLE_LINEAR) {
+        for (int t = threadIdx.x; t < C21CM_NDELTA_TABLE; t += kBlock) tab[t] = table[t];
+        __syncthreads();
+    }
+    double acc = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const auto ci = cell_index<VEC>(i, nz_items, zpad_items);
+        const auto d = Pack<VEC>::load(delta_fil, ci.padded);
+        Pack<VEC> out;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const float dens = clip_delta_eulerian(d.v[e]);
+            double f;
+            if (fp.mode == C21CM_FCOLL_ERFC) {
+                f = (fp.sig < 0) ? 0. : fgtrm_bias_fast(fp.growthf, dens, fp.sig, fp.delta_c);
+            } else if (fp.mode == C21CM_FCOLL_TABLE_LINEAR) {
+                f = eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab);
+            } else {
+                f = exp(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
+            }
+            out.v[e] = (float)f;  // box->unnormalised_nion is float (IonisationBox.c:951)
+            acc += f;
+        }
+        out.store(nion_dense, ci.dense);
+    }
+    block_sum_to(acc, partials);
+}
+
+// ---- find_ionised_regions ---------------------------------------------------------------
+struct IoniseParams {
+    c21hip_ionize_args a;
+    size_t nitems;
+    int nz_items, zpad_items;
+};
+
+// Lagrangian source grids: f_coll sum + barrier + partial ionisation in ONE sweep.
+template <int VEC, bool LAST, bool TS>
+__global__ void __launch_bounds__(kBlock)
+ionise_stars_kernel(IoniseParams p, const float *__restrict__ delta_fil,
+                    const float *__restrict__ stars_fil, const float *__restrict__ xe_fil,
+                    const float *__restrict__ density, const float *__restrict__ prev_z_reion,
+                    const float *__restrict__ Tneutral, float *__restrict__ xH,
+                    float *__restrict__ z_reion, float *__restrict__ Tk,
+                    unsigned char *__restrict__ first_cross, double *__restrict__ partials) {
+    const c21hip_ionize_args &a = p.a;
+    double acc = 0.;
+    const float z_now = (float)a.redshift;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < p.nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const auto ci = cell_index<VEC>(i, p.nz_items, p.zpad_items);
+        const auto st = Pack<VEC>::load(stars_fil, ci.padded);
+        Pack<VEC> dl, xe, de;
+        if (!LAST) dl = Pack<VEC>::load(delta_fil, ci.padded);
+        if (TS) xe = Pack<VEC>::load(xe_fil, ci.padded);
+        if (LAST) de = Pack<VEC>::load(density, ci.dense);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const size_t idx = ci.dense * VEC + e;
+            const float stars = fmaxf(st.v[e], 0.f);  // IonisationBox.c:822-823
+            acc += (double)stars;
+            // IonisationBox.c:1048-1052
+            const double curr_dens = LAST ? (double)de.v[e] * a.photoncons_factor
+                                          : (double)clip_delta(dl.v[e]);
+            double curr_fcoll = (double)stars;
+            curr_fcoll *= 1 / (a.rhocrit_omb * (1 + curr_dens));  // :1066-1067
+            if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;  // :1077
+            const double x_e = TS ? (double)clip_xe(xe.v[e]) : 0.;
+            if (curr_fcoll * a.ion_eff_factor > (1. - x_e)) {  // :1118 (rec = 0)
+                if (first_cross) {
+                    if (first_cross[idx] == 0) first_cross[idx] = (unsigned char)a.r_index;
+                } else {
+                    const float pz = a.first_snapshot ? -1.f : prev_z_reion[idx];
+                    z_reion[idx] = (pz < 0.f) ? z_now : pz;  // :1143-1147
+                    xH[idx] = 0.f;                           // :1151
+                }
+            } else if (LAST) {
+                if ((double)xH[idx] > kTiny) {  // :1161
+                    double res_xH = 1. - curr_fcoll * a.ion_eff_factor;
+                    if (!a.minimize_memory) {
+                        const float T_HI =
+                            TS ? Tneutral[idx]
+                               : (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)de.v[e]));
+                        Tk[idx] = partially_ionized_T(T_HI, (float)res_xH, (float)a.T_re);
+                    }
+                    res_xH -= x_e;
+                    if (res_xH < 0)
+                        res_xH = 0;
+                    else if (res_xH > 1)
+                        res_xH = 1;
+                    xH[idx] = (float)res_xH;
+                }
+            }
+        }
+    }
+    block_sum_to(acc, partials);
+}
+
+// Eulerian source models: f_coll comes from the dense unnormalised_nion grid.
+template <int VEC, bool LAST, bool TS>
+__global__ void __launch_bounds__(kBlock)
+ionise_eulerian_kernel(IoniseParams p, const float *__restrict__ nion_dense,
+                       const float *__restrict__ xe_fil, const float *__restrict__ density,
+                       const float *__restrict__ prev_z_reion,
+                       const float *__restrict__ Tneutral, const double *__restrict__ mean_dev,
+                       float *__restrict__ xH, float *__restrict__ z_reion,
+                       float *__restrict__ Tk, unsigned char *__restrict__ first_cross) {
+    const c21hip_ionize_args &a = p.a;
+    const double mean_fix = a.fix_mean ? a.mean_f_coll / *mean_dev : 1.;  // :1022-1023
+    const float z_now = (float)a.redshift;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < p.nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const auto ci = cell_index<VEC>(i, p.nz_items, p.zpad_items);
+        const auto fc = Pack<VEC>::load(nion_dense, ci.dense);
+        Pack<VEC> xe, de;
+        if (TS) xe = Pack<VEC>::load(xe_fil, ci.padded);
+        if (LAST) de = Pack<VEC>::load(density, ci.dense);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const size_t idx = ci.dense * VEC + e;
+            double curr_fcoll = mean_fix * (double)fc.v[e];
+            if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
+            const double x_e = TS ? (double)clip_xe(xe.v[e]) : 0.;
+            if (curr_fcoll * a.ion_eff_factor > (1. - x_e)) {
+                if (first_cross) {
+                    if (first_cross[idx] == 0) first_cross[idx] = (unsigned char)a.r_index;
+                } else {
+                    const float pz = a.first_snapshot ? -1.f : prev_z_reion[idx];
+                    z_reion[idx] = (pz < 0.f) ? z_now : pz;
+                    xH[idx] = 0.f;
+                }
+            } else if (LAST) {
+                if ((double)xH[idx] > kTiny) {
+                    double res_xH = 1. - curr_fcoll * a.ion_eff_factor;
+                    if (!a.minimize_memory) {
+                        const float T_HI =
+                            TS ? Tneutral[idx]
+                               : (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)de.v[e]));
+                        Tk[idx] = partially_ionized_T(T_HI, (float)res_xH, (float)a.T_re);
+                    }
+                    res_xH -= x_e;
+                    if (res_xH < 0)
+                        res_xH = 0;
+                    else if (res_xH > 1)
+                        res_xH = 1;
+                    xH[idx] = (float)res_xH;
+                }
+            }
+        }
+    }
+}
+
+// ---- post-loop: ionised temperatures, sum(xH), non-finite flag -------------------------
+__global__ void __launch_bounds__(kBlock)
+finalize_kernel(c21hip_ionize_args a, float stored_z, const float *__restrict__ density,
+                const float *__restrict__ Tneutral, const float *__restrict__ xH,
+                const float *__restrict__ z_reion, float *__restrict__ Tk, size_t ntot,
+                double *__restrict__ partials, int *__restrict__ flag) {
+    double acc = 0.;
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const float x = xH[i];
+        acc += (double)x;
+        if (!a.minimize_memory) {
+            const float zr = z_reion[i];
+            float T = Tk[i];
+            if (zr > 0.f && (double)x < kTiny) {  // IonisationBox.c:1218
+                const float dens = density[i];
+                T = fully_ionized_T(zr, stored_z, dens, (float)a.T_re);
+                const float floorT =
+                    a.use_ts_fluct ? Tneutral[i]
+                                   : (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)dens));
+                if (T < floorT) T = floorT;
+                Tk[i] = T;
+            }
+            if (!isfinite(T)) bad = 1;  // :1245
+        }
+    }
+    if (bad) atomicOr(flag, 1);
+    block_sum_to(acc, partials);
+}
+
+__global__ void __launch_bounds__(kBlock)
+apply_first_cross_kernel(const unsigned char *__restrict__ fc,
+                         const float *__restrict__ prev_z_reion, int first_snapshot, float z_now,
+                         float *__restrict__ xH, float *__restrict__ z_reion, size_t ntot) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        if (fc[i]) {
+            const float pz = first_snapshot ? -1.f : prev_z_reion[i];
+            z_reion[i] = (pz < 0.f) ? z_now : pz;
+            xH[i] = 0.f;
+        }
+    }
+}
+
+IoniseParams make_params(const c21hip_ionize_args *a, int vec) {
+    IoniseParams p;
+    p.a = *a;
+    const int zpad = 2 * (a->nz / 2 + 1);
+    p.nz_items = a->nz / vec;
+    p.zpad_items = zpad / vec;
+    p.nitems = (size_t)a->nx * a->ny * p.nz_items;
+    return p;
+}
+}  // namespace
+
+extern "C" int c21hip_clip_minmax(float *delta_fil, int nx, int ny, int nz, double *partials,
+                                  double *minmax_out, void *stream) {
+    const int vec = (nz % 2 == 0) ? 2 : 1;
+    const int zpad = 2 * (nz / 2 + 1);
+    const size_t nitems = (size_t)nx * ny * (nz / vec);
+    const int blocks = grid_for(nitems);
+    double *pmin = partials, *pmax = partials + kMaxBlocks;
+    if (vec == 2)
+        hipLaunchKernelGGL(minmax_kernel<2>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           delta_fil, nitems, nz / 2, zpad / 2, pmin, pmax);
+    else
+        hipLaunchKernelGGL(minmax_kernel<1>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           delta_fil, nitems, nz, zpad, pmin, pmax);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pmin,
+                       blocks, 1, minmax_out);
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, pmax,
+                       blocks, 2, minmax_out + 1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, int nx, int ny,
+                                     int nz, int mode, double growthf, double sigma_min,
+                                     double sigma_max, double delta_c, double tab_min,
+                                     double tab_width, const float *table_dev, double *partials,
+                                     double *sum_out, void *stream) {
+    FcollParams fp;
+    fp.mode = mode;
+    fp.growthf = (float)growthf;
+    fp.delta_c = delta_c;
+    fp.tab_min = tab_min;
+    fp.tab_width = tab_width;
+    fp.sig = -1.;
+    if (mode == C21CM_FCOLL_ERFC) {
+        // hmf.c:1221-1232: float sigmas, float products, double sqrt
+        const float ss = (float)sigma_min, sl = (float)sigma_max;
+        if (sl > ss) {
+            c21hip_set_error("FgtrM requested in a region where M_min > M_max (sigma %g > %g)",
+                             (double)sl, (double)ss);
+            return C21CM_VALUE_ERROR;
+        }
+        if (sl != ss) {
+            const float d = ss * ss - sl * sl;
+            fp.sig = sqrt((double)d);
+        }
+    }
+    const int vec = (nz % 2 == 0) ? 2 : 1;
+    const int zpad = 2 * (nz / 2 + 1);
+    const size_t nitems = (size_t)nx * ny * (nz / vec);
+    const int blocks = grid_for(nitems);
+    if (vec == 2)
+        hipLaunchKernelGGL(fcoll_eulerian_kernel<2>, dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, delta_fil, nion_dense, nitems, nz / 2, zpad / 2, fp,
+                           table_dev, partials);
+    else
+        hipLaunchKernelGGL(fcoll_eulerian_kernel<1>, dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, delta_fil, nion_dense, nitems, nz, zpad, fp,
+                           table_dev, partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, blocks, 0, sum_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_finish_mean(const double *sum_dev, double ntot, int mass_dep_zeta,
+                                  double f_limit, double *mean_dev, void *stream) {
+    hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sum_dev, ntot,
+                       mass_dep_zeta, f_limit, mean_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+#define DISPATCH_IONISE(KERNEL, ...)                                                          \
+    do {                                                                                      \
+        const bool last = (a->r_index == 0);                                                  \
+        const bool ts = a->use_ts_fluct != 0;                                                 \
+        if (vec == 2) {                                                                       \
+            if (last && ts)                                                                   \
+                hipLaunchKernelGGL((KERNEL<2, true, true>), dim3(blocks), dim3(kBlock), 0,    \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+            else if (last)                                                                    \
+                hipLaunchKernelGGL((KERNEL<2, true, false>), dim3(blocks), dim3(kBlock), 0,   \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+            else if (ts)                                                                      \
+                hipLaunchKernelGGL((KERNEL<2, false, true>), dim3(blocks), dim3(kBlock), 0,   \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+            else                                                                              \
+                hipLaunchKernelGGL((KERNEL<2, false, false>), dim3(blocks), dim3(kBlock), 0,  \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+        } else {                                                                              \
+            if (last && ts)                                                                   \
+                hipLaunchKernelGGL((KERNEL<1, true, true>), dim3(blocks), dim3(kBlock), 0,    \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+            else if (last)                                                                    \
+                hipLaunchKernelGGL((KERNEL<1, true, false>), dim3(blocks), dim3(kBlock), 0,   \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+            else if (ts)                                                                      \
+                hipLaunchKernelGGL((KERNEL<1, false, true>), dim3(blocks), dim3(kBlock), 0,   \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+            else                                                                              \
+                hipLaunchKernelGGL((KERNEL<1, false, false>), dim3(blocks), dim3(kBlock), 0,  \
+                                   (hipStream_t)stream, __VA_ARGS__);                         \
+        }                                                                                     \
+    } while (0)
+
+extern "C" int c21hip_ionise_stars(const c21hip_ionize_args *a, const float *delta_fil,
+                                   const float *stars_fil, const float *xe_fil,
+                                   const float *density, const float *prev_z_reion,
+                                   const float *kinetic_temp_neutral, float *xH, float *z_reion,
+                                   float *kinetic_temperature, unsigned char *first_cross,
+                                   double *partials, double *sum_out, void *stream) {
+    const int vec = (a->nz % 2 == 0) ? 2 : 1;
+    const IoniseParams p = make_params(a, vec);
+    const int blocks = grid_for(p.nitems);
+    DISPATCH_IONISE(ionise_stars_kernel, p, delta_fil, stars_fil, xe_fil, density, prev_z_reion,
+                    kinetic_temp_neutral, xH, z_reion, kinetic_temperature, first_cross, partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, blocks, 0, sum_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_ionise_eulerian(const c21hip_ionize_args *a, const float *nion_dense,
+                                      const float *xe_fil, const float *density,
+                                      const float *prev_z_reion,
+                                      const float *kinetic_temp_neutral, const double *mean_dev,
+                                      float *xH, float *z_reion, float *kinetic_temperature,
+                                      unsigned char *first_cross, void *stream) {
+    const int vec = (a->nz % 2 == 0) ? 2 : 1;
+    const IoniseParams p = make_params(a, vec);
+    const int blocks = grid_for(p.nitems);
+    DISPATCH_IONISE(ionise_eulerian_kernel, p, nion_dense, xe_fil, density, prev_z_reion,
+                    kinetic_temp_neutral, mean_dev, xH, z_reion, kinetic_temperature,
+                    first_cross);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_finalize(const c21hip_ionize_args *a, double stored_redshift,
+                               const float *density, const float *kinetic_temp_neutral,
+                               const float *xH, const float *z_reion, float *kinetic_temperature,
+                               size_t ntot, double *partials, double *sum_out, int *flag_out,
+                               void *stream) {
+    const int blocks = grid_for(ntot);
+    hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, *a,
+                       (float)stored_redshift, density, kinetic_temp_neutral, xH, z_reion,
+                       kinetic_temperature, ntot, partials, flag_out);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, blocks, 0, sum_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_apply_first_cross(const unsigned char *first_cross,
+                                        const float *prev_z_reion, int first_snapshot,
+                                        double redshift, float *xH, float *z_reion, size_t ntot,
+                                        void *stream) {
+    hipLaunchKernelGGL(apply_first_cross_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
+                       (hipStream_t)stream, first_cross, prev_z_reion, first_snapshot,
+                       (float)redshift, xH, z_reion, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,144 @@
+// runtime.hip -- device plumbing behind c21hip.h: pointer residency, cached HBM
+// scratch ("workspace slots"), copies, events, last-error string.
+//
+// The reference allocates and frees its FFTW grids inside every Compute* call
+// (src/py21cmfast/src/IonisationBox.c:229-319).  On MI355X a hipMalloc/hipFree
+// pair of several GB costs milliseconds and 288 GB of HBM is plentiful, so
+// scratch is kept in numbered slots that only ever grow and are reused by the
+// next call; c21cm_release_device_cache() returns them.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "c21hip.h"
+#include "c21cm_abi.h"
+
+namespace {
+constexpr int kMaxSlots = 64;
+struct Slot {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+Slot g_slots[kMaxSlots];
+std::mutex g_mutex;
+thread_local char g_error[512] = "";
+}  // namespace
+
+extern "C" void c21hip_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    if (getenv("C21CM_VERBOSE")) fprintf(stderr, "[21cmfast_hip] %s\n", g_error);
+}
+
+extern "C" const char *c21hip_get_error(void) { return g_error; }
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            c21hip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                             __LINE__);                                                   \
+            return (e_ == hipErrorOutOfMemory) ? C21CM_MEMORY_ALLOC_ERROR : C21CM_IO_ERROR; \
+        }                                                                                 \
+    } while (0)
+
+extern "C" int c21hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int c21hip_is_device_ptr(const void *p) {
+    if (!p) return 0;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain malloc'd host memory: not an error for us
+        return 0;
+    }
+    return attr.type == hipMemoryTypeDevice ? 1 : 0;
+}
+
+extern "C" void *c21hip_ws(int slot, size_t bytes) {
+    if (slot < 0 || slot >= kMaxSlots) return nullptr;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    Slot &s = g_slots[slot];
+    if (s.bytes >= bytes && s.ptr) return s.ptr;
+    if (s.ptr) {
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.bytes = 0;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c21hip_set_error("hipMalloc of %zu bytes for workspace slot %d failed: %s", bytes, slot,
+                         hipGetErrorString(e));
+        return nullptr;
+    }
+    s.ptr = p;
+    s.bytes = bytes;
+    return p;
+}
+
+extern "C" void c21hip_ws_release(void) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (auto &s : g_slots) {
+        if (s.ptr) (void)hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.bytes = 0;
+    }
+}
+
+extern "C" int c21hip_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int c21hip_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int c21hip_d2d(void *dst, const void *src, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int c21hip_memset(void *dst, int byte, size_t bytes, void *stream) {
+    HIP_TRY(hipMemsetAsync(dst, byte, bytes, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int c21hip_sync(void *stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+extern "C" int c21hip_device_sync(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" void *c21hip_event_create(void) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return (void *)ev;
+}
+extern "C" void c21hip_event_destroy(void *ev) {
+    if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+extern "C" int c21hip_event_record(void *ev, void *stream) {
+    HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return 0;
+}
+extern "C" float c21hip_event_elapsed_ms(void *start, void *stop) {
+    float ms = -1.f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+    return ms;
+}

@@ -1,0 +1,572 @@
+/*
+ * ionize_driver.c -- C host driver of the ComputeIonizedBox grid algorithm on MI355X.
+ *
+ * Orchestrates the HIP launchers of csrc/hip/c21hip.h in the order of the
+ * reference's ComputeIonizedBox (src/py21cmfast/src/IonisationBox.c:1477-1628):
+ *   pre-loop   pack+clip -> r2c -> /N for every grid that is filtered   (:323-360)
+ *   R loop     fused copy x W(kR) -> c2r per grid                       (:572-664)
+ *              [Eulerian] min/max -> host table -> f_coll + sum         (:702-962)
+ *              barrier / partial-ionisation sweep                       (:1008-1201)
+ *   post-loop  ionised temperatures, sum(xH)                            (:1203-1256,1597-1608)
+ * Everything stays resident in HBM for the whole call; the only host round trips
+ * inside the loop are the two doubles + 400-float table of the TABLE modes, which
+ * the reference's design requires (the table range depends on the filtered extrema).
+ *
+ * Data layout in HBM: 2*G padded k-space grids (unfiltered spectra kept for all
+ * radii + one filtered working copy each), the dense inputs/outputs, and a small
+ * block of doubles for reductions.  Host arrays (numpy through CFFI) are staged
+ * into workspace slots; device arrays (torch) are used in place.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../hip/c21hip.h"
+#include "c21cm_grid.h"
+
+/* workspace slots */
+enum {
+    WS_DELTA_UNF = 0,
+    WS_DELTA_FIL,
+    WS_STARS_UNF,
+    WS_STARS_FIL,
+    WS_XE_UNF,
+    WS_XE_FIL,
+    WS_DENSITY,
+    WS_NION,
+    WS_XE_DENSE,
+    WS_TNEUTRAL,
+    WS_PREV_ZRE,
+    WS_XH,
+    WS_ZRE,
+    WS_TK,
+    WS_NION_DENSE,
+    WS_SCALARS,
+    WS_TABLE,
+    WS_FIRST_CROSS
+};
+
+#define MAX_COPYBACK 8
+typedef struct {
+    void *host[MAX_COPYBACK];
+    void *dev[MAX_COPYBACK];
+    size_t bytes[MAX_COPYBACK];
+    int n;
+} copyback_list;
+
+/* device scalar block layout (doubles) */
+#define SC_PARTIALS 0
+#define SC_SUMS (C21HIP_PARTIALS)
+#define SC_MEANS (SC_SUMS + C21CM_MAX_RADII)
+#define SC_MINMAX (SC_MEANS + C21CM_MAX_RADII)
+#define SC_XHSUM (SC_MINMAX + 2)
+#define SC_FLAG (SC_XHSUM + 1) /* an int stored in a double-sized cell */
+#define SC_COUNT (SC_FLAG + 1)
+
+#define TRY(expr)                   \
+    do {                            \
+        int st_ = (expr);           \
+        if (st_) {                  \
+            status = st_;           \
+            goto done;              \
+        }                           \
+    } while (0)
+
+static const float *stage_in(int slot, const float *p, size_t bytes, void *stream, int *status) {
+    if (!p || *status) return NULL;
+    if (c21hip_is_device_ptr(p)) return p;
+    void *d = c21hip_ws(slot, bytes);
+    if (!d) {
+        *status = C21CM_MEMORY_ALLOC_ERROR;
+        return NULL;
+    }
+    int st = c21hip_h2d(d, p, bytes, stream);
+    if (st) *status = st;
+    return (const float *)d;
+}
+
+/* in/out array: upload the caller's initial contents, remember to copy back */
+static float *stage_inout(int slot, float *p, size_t bytes, int upload, copyback_list *cb,
+                          void *stream, int *status) {
+    if (!p || *status) return NULL;
+    if (c21hip_is_device_ptr(p)) return p;
+    void *d = c21hip_ws(slot, bytes);
+    if (!d) {
+        *status = C21CM_MEMORY_ALLOC_ERROR;
+        return NULL;
+    }
+    if (upload) {
+        int st = c21hip_h2d(d, p, bytes, stream);
+        if (st) *status = st;
+    }
+    if (cb->n < MAX_COPYBACK) {
+        cb->host[cb->n] = p;
+        cb->dev[cb->n] = d;
+        cb->bytes[cb->n] = bytes;
+        cb->n++;
+    }
+    return (float *)d;
+}
+
+static int validate_spec(const c21cm_ionize_spec *s, const PerturbedField *pf,
+                         const HaloBox *halos, const TsBox *ts, const IonizedBox *box) {
+    if (!s || !pf || !box) {
+        c21hip_set_error("ionize: NULL spec / perturbed_field / box");
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->hii_dim < 2 || s->hii_dim_z < 2 || s->n_radii < 1 || s->n_radii > C21CM_MAX_RADII ||
+        s->n_radii > 255 || s->r_lowest < 0) {
+        c21hip_set_error("ionize: bad geometry or radius count (dim %d/%d, n_radii %d)",
+                         s->hii_dim, s->hii_dim_z, s->n_radii);
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->recomb_model != C21CM_RECOMB_NONE) {
+        c21hip_set_error("ionize: recombination models are not implemented on the device yet");
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->fcoll_mode < C21CM_FCOLL_STARS_GRID || s->fcoll_mode > C21CM_FCOLL_TABLE_EXP) {
+        c21hip_set_error("ionize: unknown fcoll_mode %d", s->fcoll_mode);
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->fcoll_mode >= C21CM_FCOLL_TABLE_LINEAR && !s->table_fn) {
+        c21hip_set_error("ionize: TABLE fcoll_mode needs table_fn");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!pf->density || !box->neutral_fraction || !box->z_reion) {
+        c21hip_set_error("ionize: density / neutral_fraction / z_reion arrays are required");
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->fcoll_mode == C21CM_FCOLL_STARS_GRID && (!halos || !halos->n_ion)) {
+        c21hip_set_error("ionize: Lagrangian source model needs HaloBox.n_ion");
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->fcoll_mode != C21CM_FCOLL_STARS_GRID && !box->unnormalised_nion) {
+        c21hip_set_error("ionize: Eulerian source model needs IonizedBox.unnormalised_nion");
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->use_ts_fluct &&
+        (!ts || !ts->xray_ionised_fraction || (!s->minimize_memory && !ts->kinetic_temp_neutral))) {
+        c21hip_set_error("ionize: USE_TS_FLUCT needs the TsBox arrays");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!s->minimize_memory && !box->kinetic_temperature) {
+        c21hip_set_error("ionize: kinetic_temperature is required unless MINIMIZE_MEMORY");
+        return C21CM_VALUE_ERROR;
+    }
+    return 0;
+}
+
+static void fill_args(c21hip_ionize_args *a, const c21cm_ionize_spec *s, int r_index) {
+    memset(a, 0, sizeof(*a));
+    a->nx = s->hii_dim;
+    a->ny = s->hii_dim;
+    a->nz = s->hii_dim_z;
+    a->r_index = r_index;
+    a->lagrangian = (s->fcoll_mode == C21CM_FCOLL_STARS_GRID);
+    a->mass_dep_zeta = s->mass_dep_zeta;
+    a->use_ts_fluct = s->use_ts_fluct;
+    a->minimize_memory = s->minimize_memory;
+    a->first_snapshot = s->first_snapshot;
+    a->fix_mean = s->fix_mean;
+    a->mean_f_coll = s->mean_f_coll;
+    a->f_limit = s->f_limit_acg;
+    a->ion_eff_factor = s->ion_eff_factor;
+    a->rhocrit_omb = s->rhocrit_omb;
+    a->photoncons_factor = s->photoncons_adjustment_factor;
+    a->redshift = s->redshift;
+    a->TK_nofluct = s->TK_nofluct;
+    a->adia_TK_term = s->adia_TK_term;
+    a->T_re = s->T_re;
+}
+
+/* State shared by the single-GPU driver and the two shard phases. */
+typedef struct {
+    const c21cm_ionize_spec *s;
+    void *stream;
+    int nx, ny, nz;
+    size_t ntot, npad;
+    int lagrangian;
+    /* k-space grids */
+    float *delta_unf, *delta_fil, *stars_unf, *stars_fil, *xe_unf, *xe_fil;
+    /* dense inputs */
+    const float *density, *n_ion, *xe_dense, *Tneutral, *prev_zre;
+    /* dense outputs */
+    float *xH, *zre, *Tk, *nion_dense;
+    double *scalars;
+    float *table_dev;
+    copyback_list cb;
+} ion_ctx;
+
+static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedField *pf,
+                     const IonizedBox *prev, const TsBox *ts, const HaloBox *halos,
+                     IonizedBox *box, int need_outputs, void *stream) {
+    int status = 0;
+    memset(c, 0, sizeof(*c));
+    c->s = s;
+    c->stream = stream;
+    c->nx = s->hii_dim;
+    c->ny = s->hii_dim;
+    c->nz = s->hii_dim_z;
+    c->ntot = (size_t)c->nx * c->ny * c->nz;
+    c->npad = (size_t)c->nx * c->ny * 2 * (size_t)(c->nz / 2 + 1);
+    c->lagrangian = (s->fcoll_mode == C21CM_FCOLL_STARS_GRID);
+    const size_t gbytes = c->npad * sizeof(float), dbytes = c->ntot * sizeof(float);
+
+    c->delta_unf = (float *)c21hip_ws(WS_DELTA_UNF, gbytes);
+    c->delta_fil = (float *)c21hip_ws(WS_DELTA_FIL, gbytes);
+    if (!c->delta_unf || !c->delta_fil) return C21CM_MEMORY_ALLOC_ERROR;
+    if (c->lagrangian) {
+        c->stars_unf = (float *)c21hip_ws(WS_STARS_UNF, gbytes);
+        c->stars_fil = (float *)c21hip_ws(WS_STARS_FIL, gbytes);
+        if (!c->stars_unf || !c->stars_fil) return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    if (s->use_ts_fluct) {
+        c->xe_unf = (float *)c21hip_ws(WS_XE_UNF, gbytes);
+        c->xe_fil = (float *)c21hip_ws(WS_XE_FIL, gbytes);
+        if (!c->xe_unf || !c->xe_fil) return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    c->scalars = (double *)c21hip_ws(WS_SCALARS, SC_COUNT * sizeof(double));
+    c->table_dev = (float *)c21hip_ws(WS_TABLE, C21CM_NDELTA_TABLE * sizeof(float));
+    if (!c->scalars || !c->table_dev) return C21CM_MEMORY_ALLOC_ERROR;
+    status = c21hip_memset(c->scalars, 0, SC_COUNT * sizeof(double), stream);
+    if (status) return status;
+
+    c->density = stage_in(WS_DENSITY, pf->density, dbytes, stream, &status);
+    if (c->lagrangian) c->n_ion = stage_in(WS_NION, halos->n_ion, dbytes, stream, &status);
+    if (s->use_ts_fluct) {
+        c->xe_dense = stage_in(WS_XE_DENSE, ts->xray_ionised_fraction, dbytes, stream, &status);
+        if (!s->minimize_memory)
+            c->Tneutral = stage_in(WS_TNEUTRAL, ts->kinetic_temp_neutral, dbytes, stream, &status);
+    }
+    if (!s->first_snapshot && prev && prev->z_reion)
+        c->prev_zre = stage_in(WS_PREV_ZRE, prev->z_reion, dbytes, stream, &status);
+    if (!s->first_snapshot && !c->prev_zre && !status) {
+        c21hip_set_error("ionize: previous z_reion is required after the first snapshot");
+        return C21CM_VALUE_ERROR;
+    }
+    if (need_outputs) {
+        c->xH = stage_inout(WS_XH, box->neutral_fraction, dbytes, 1, &c->cb, stream, &status);
+        c->zre = stage_inout(WS_ZRE, box->z_reion, dbytes, 0, &c->cb, stream, &status);
+        if (!s->minimize_memory)
+            c->Tk = stage_inout(WS_TK, box->kinetic_temperature, dbytes, 1, &c->cb, stream,
+                                &status);
+    }
+    if (!c->lagrangian)
+        c->nion_dense = stage_inout(WS_NION_DENSE, box->unnormalised_nion, dbytes, 0, &c->cb,
+                                    stream, &status);
+    return status;
+}
+
+/* Identity of the inputs whose unfiltered spectra currently sit in the workspace.  Lets
+ * c21cm_ionize_shard_finish reuse the spectra left by c21cm_ionize_shard_radii in the same
+ * process instead of repeating the pre-loop transforms. */
+static struct {
+    int valid, nx, nz, ts;
+    const void *density, *n_ion, *xe;
+    double factor;
+} g_spectra;
+
+static int spectra_match(const ion_ctx *c, const PerturbedField *pf, const HaloBox *halos,
+                         const TsBox *ts) {
+    return g_spectra.valid && g_spectra.nx == c->nx && g_spectra.nz == c->nz &&
+           g_spectra.ts == c->s->use_ts_fluct && g_spectra.density == (const void *)pf->density &&
+           g_spectra.n_ion == (const void *)(c->lagrangian ? halos->n_ion : NULL) &&
+           g_spectra.xe == (const void *)(c->s->use_ts_fluct ? ts->xray_ionised_fraction : NULL) &&
+           g_spectra.factor == c->s->photoncons_adjustment_factor;
+}
+
+static void spectra_remember(const ion_ctx *c, const PerturbedField *pf, const HaloBox *halos,
+                             const TsBox *ts) {
+    g_spectra.valid = 1;
+    g_spectra.nx = c->nx;
+    g_spectra.nz = c->nz;
+    g_spectra.ts = c->s->use_ts_fluct;
+    g_spectra.density = pf->density;
+    g_spectra.n_ion = c->lagrangian ? halos->n_ion : NULL;
+    g_spectra.xe = c->s->use_ts_fluct ? ts->xray_ionised_fraction : NULL;
+    g_spectra.factor = c->s->photoncons_adjustment_factor;
+}
+
+/* prepare_box_for_filtering: IonisationBox.c:323-360 */
+static int prepare_grid(ion_ctx *c, const float *dense, float *cgrid, double factor, double lo,
+                        double hi) {
+    int status = 0;
+    TRY(c21hip_pack_clip(dense, cgrid, c->nx, c->ny, c->nz, factor, lo, hi, c->stream));
+    TRY(c21hip_fft_r2c(cgrid, c->nx, c->ny, c->nz, c->stream));
+    TRY(c21hip_divide_inplace(cgrid, c->npad, (float)c->ntot, c->stream));
+done:
+    return status;
+}
+
+static int preloop(ion_ctx *c) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    /* IonisationBox.c:1480-1513 */
+    TRY(prepare_grid(c, c->density, c->delta_unf, s->photoncons_adjustment_factor, -1., 1e6));
+    if (c->lagrangian) TRY(prepare_grid(c, c->n_ion, c->stars_unf, 1., 0., 1e20));
+    if (s->use_ts_fluct) TRY(prepare_grid(c, c->xe_dense, c->xe_unf, 1., 0., 1.));
+done:
+    return status;
+}
+
+/* One filter radius: IonisationBox.c:1546-1580.  first_cross != NULL = shard mode. */
+static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    const int apply = R_ct > 0; /* copy_filter_transform skips filter_box at R_index 0 (:606) */
+    const float R = (float)s->R[R_ct];
+    double *partials = c->scalars + SC_PARTIALS;
+    double *sum_dev = c->scalars + SC_SUMS + R_ct;
+    double *mean_dev = c->scalars + SC_MEANS + R_ct;
+    c21hip_ionize_args args;
+    fill_args(&args, s, R_ct);
+
+    TRY(c21hip_copy_filter(c->delta_unf, c->delta_fil, c->nx, c->ny, c->nz, s->box_len,
+                           s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+    TRY(c21hip_fft_c2r(c->delta_fil, c->nx, c->ny, c->nz, c->stream));
+    if (c->lagrangian) {
+        TRY(c21hip_copy_filter(c->stars_unf, c->stars_fil, c->nx, c->ny, c->nz, s->box_len,
+                               s->box_len_z, s->stars_filter, R, (float)s->mfp_meandens, apply,
+                               c->stream));
+        TRY(c21hip_fft_c2r(c->stars_fil, c->nx, c->ny, c->nz, c->stream));
+    }
+    if (s->use_ts_fluct) {
+        TRY(c21hip_copy_filter(c->xe_unf, c->xe_fil, c->nx, c->ny, c->nz, s->box_len,
+                               s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+        TRY(c21hip_fft_c2r(c->xe_fil, c->nx, c->ny, c->nz, c->stream));
+    }
+
+    if (c->lagrangian) {
+        TRY(c21hip_ionise_stars(&args, c->delta_fil, c->stars_fil, c->xe_fil, c->density,
+                                c->prev_zre, c->Tneutral, c->xH, c->zre, c->Tk, first_cross,
+                                partials, sum_dev, c->stream));
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               mean_dev, c->stream));
+    } else {
+        double tab_min = 0., tab_width = 1.;
+        if (s->fcoll_mode >= C21CM_FCOLL_TABLE_LINEAR) {
+            /* setup_integration_tables: IonisationBox.c:702-768 */
+            double mm[2];
+            float table[C21CM_NDELTA_TABLE];
+            TRY(c21hip_clip_minmax(c->delta_fil, c->nx, c->ny, c->nz, partials,
+                                   c->scalars + SC_MINMAX, c->stream));
+            TRY(c21hip_d2h(mm, c->scalars + SC_MINMAX, sizeof(mm), c->stream));
+            TRY(c21hip_sync(c->stream));
+            const double min_density = mm[0] - 0.001, max_density = mm[1] + 0.001;
+            int tst = s->table_fn(R_ct, min_density, max_density, table, s->table_user);
+            if (tst) {
+                c21hip_set_error("ionize: table_fn failed with status %d at radius %d", tst, R_ct);
+                status = tst;
+                goto done;
+            }
+            tab_min = min_density;
+            tab_width = (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.);
+            TRY(c21hip_h2d(c->table_dev, table, sizeof(table), c->stream));
+            TRY(c21hip_sync(c->stream)); /* `table` is a stack buffer */
+        }
+        TRY(c21hip_fcoll_eulerian(c->delta_fil, c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
+                                  s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
+                                  s->delta_c, tab_min, tab_width, c->table_dev, partials, sum_dev,
+                                  c->stream));
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               mean_dev, c->stream));
+        TRY(c21hip_ionise_eulerian(&args, c->nion_dense, c->xe_fil, c->density, c->prev_zre,
+                                   c->Tneutral, mean_dev, c->xH, c->zre, c->Tk, first_cross,
+                                   c->stream));
+    }
+done:
+    return status;
+}
+
+/* post-loop + result collection: IonisationBox.c:1589-1628 */
+static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    c21hip_ionize_args args;
+    fill_args(&args, s, 0);
+    double host_sc[SC_COUNT - SC_SUMS];
+    int *flag_dev = (int *)(c->scalars + SC_FLAG);
+    TRY(c21hip_finalize(&args, s->stored_redshift, c->density, c->Tneutral, c->xH, c->zre, c->Tk,
+                        c->ntot, c->scalars + SC_PARTIALS, c->scalars + SC_XHSUM, flag_dev,
+                        c->stream));
+    TRY(c21hip_d2h(host_sc, c->scalars + SC_SUMS, sizeof(host_sc), c->stream));
+    for (int i = 0; i < c->cb.n; i++)
+        TRY(c21hip_d2h(c->cb.host[i], c->cb.dev[i], c->cb.bytes[i], c->stream));
+    TRY(c21hip_sync(c->stream));
+    {
+        const double *means = host_sc + (SC_MEANS - SC_SUMS);
+        double global_xH = host_sc[SC_XHSUM - SC_SUMS];
+        int flag;
+        memcpy(&flag, &host_sc[SC_FLAG - SC_SUMS], sizeof(int));
+        global_xH /= (float)c->ntot; /* IonisationBox.c:1607 */
+        if (flag || !isfinite(global_xH)) {
+            c21hip_set_error("ionize: non-finite %s",
+                             flag ? "kinetic temperature" : "neutral fraction");
+            status = C21CM_INFINITY_OR_NAN_ERROR;
+            goto done;
+        }
+        const int last = s->r_lowest < s->n_radii ? s->r_lowest : s->n_radii - 1;
+        const double mean_out = s->fix_mean ? s->mean_f_coll : means[last];
+        box->mean_f_coll = mean_out; /* IonisationBox.c:1623-1628 */
+        box->mean_f_coll_MINI = 0.;
+        if (report) {
+            for (int r = 0; r < s->n_radii; r++) report->f_coll_grid_mean[r] = means[r];
+            report->global_xH = global_xH;
+            report->mean_f_coll_out = mean_out;
+        }
+    }
+done:
+    return status;
+}
+
+static int init_output_grids(ion_ctx *c, const IonizedBox *prev) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    /* IonisationBox.c:1372-1378 */
+    TRY(c21hip_fill(c->zre, c->ntot, -1.0f, c->stream));
+    /* IonisationBox.c:365-386: the caller's zeroed previous box receives z_reion = -1 */
+    if (s->first_snapshot && prev && prev->z_reion) {
+        if (c21hip_is_device_ptr(prev->z_reion)) {
+            TRY(c21hip_fill(prev->z_reion, c->ntot, -1.0f, c->stream));
+        } else {
+            for (size_t i = 0; i < c->ntot; i++) prev->z_reion[i] = -1.0f;
+        }
+    }
+done:
+    return status;
+}
+
+int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
+                       const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                       const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                       void *stream) {
+    int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
+    if (status) return status;
+    ion_ctx c;
+    void *ev[4] = {NULL, NULL, NULL, NULL};
+    g_spectra.valid = 0;
+    TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1,
+                  stream));
+    for (int i = 0; i < 4; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    TRY(init_output_grids(&c, previous_ionize_box));
+    TRY(preloop(&c));
+    TRY(c21hip_event_record(ev[1], stream));
+    for (int R_ct = spec->n_radii; R_ct--;) {
+        if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
+        TRY(one_radius(&c, R_ct, NULL));
+    }
+    TRY(c21hip_event_record(ev[2], stream));
+    TRY(postloop(&c, box, report));
+    TRY(c21hip_event_record(ev[3], stream));
+    if (report) {
+        report->ms_preloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+        report->ms_postloop = c21hip_event_elapsed_ms(ev[2], ev[3]);
+    }
+done:
+    for (int i = 0; i < 4; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}
+
+/* ---- R-loop sharding ------------------------------------------------- */
+int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
+                             const PerturbedField *perturbed_field,
+                             const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                             const HaloBox *halos, unsigned char *first_cross,
+                             c21cm_ionize_report *report, void *stream) {
+    IonizedBox dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    int status = 0;
+    if (!first_cross || !c21hip_is_device_ptr(first_cross) || world < 1 || rank < 0 ||
+        rank >= world) {
+        c21hip_set_error("ionize shard: first_cross must be a device array, 0 <= rank < world");
+        return C21CM_VALUE_ERROR;
+    }
+    if (spec && spec->fcoll_mode != C21CM_FCOLL_STARS_GRID) {
+        /* Eulerian models need unnormalised_nion scratch; give the ctx a slot-backed one */
+        dummy.unnormalised_nion = (float *)c21hip_ws(
+            WS_NION_DENSE, (size_t)spec->hii_dim * spec->hii_dim * spec->hii_dim_z * sizeof(float));
+    }
+    /* validate with stand-in outputs: the shard phase never touches xH / z_reion / T_k */
+    {
+        IonizedBox probe = dummy;
+        float sentinel;
+        probe.neutral_fraction = &sentinel;
+        probe.z_reion = &sentinel;
+        probe.kinetic_temperature = &sentinel;
+        status = validate_spec(spec, perturbed_field, halos, spin_temp, &probe);
+        if (status) return status;
+    }
+    ion_ctx c;
+    void *ev[3] = {NULL, NULL, NULL};
+    TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, &dummy, 0,
+                  stream));
+    for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    TRY(c21hip_memset(first_cross, 0, c.ntot, stream));
+    g_spectra.valid = 0;
+    TRY(preloop(&c));
+    spectra_remember(&c, perturbed_field, halos, spin_temp);
+    TRY(c21hip_event_record(ev[1], stream));
+    /* radii n-1 .. 1 dealt round-robin, largest first; index 0 belongs to the finish step */
+    for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
+        if (R_ct < spec->r_lowest) break;
+        TRY(one_radius(&c, R_ct, first_cross));
+    }
+    TRY(c21hip_event_record(ev[2], stream));
+    if (report) {
+        double means[C21CM_MAX_RADII];
+        TRY(c21hip_d2h(means, c.scalars + SC_MEANS, sizeof(means), stream));
+        TRY(c21hip_sync(stream));
+        for (int r = 0; r < spec->n_radii; r++) report->f_coll_grid_mean[r] = means[r];
+        report->ms_preloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+        report->ms_postloop = 0.;
+    }
+done:
+    for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}
+
+int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char *first_cross,
+                              const PerturbedField *perturbed_field,
+                              const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                              const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                              void *stream) {
+    int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
+    if (status) return status;
+    if (!first_cross || !c21hip_is_device_ptr(first_cross)) {
+        c21hip_set_error("ionize shard: first_cross must be a device array");
+        return C21CM_VALUE_ERROR;
+    }
+    ion_ctx c;
+    void *ev[3] = {NULL, NULL, NULL};
+    /* When this process ran c21cm_ionize_shard_radii on the same input arrays just before,
+     * its unfiltered spectra are still in the workspace and are reused; otherwise the
+     * pre-loop transforms are redone. */
+    TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1,
+                  stream));
+    for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    TRY(init_output_grids(&c, previous_ionize_box));
+    TRY(c21hip_apply_first_cross(first_cross, c.prev_zre, spec->first_snapshot, spec->redshift,
+                                 c.xH, c.zre, c.ntot, stream));
+    if (spec->r_lowest == 0) {
+        if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
+        g_spectra.valid = 0;
+        TRY(one_radius(&c, 0, NULL));
+    }
+    TRY(c21hip_event_record(ev[1], stream));
+    TRY(postloop(&c, box, report));
+    TRY(c21hip_event_record(ev[2], stream));
+    if (report) {
+        report->ms_preloop = 0.;
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_postloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+    }
+done:
+    for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}

@@ -1,0 +1,87 @@
+/*
+ * params.c -- process-global parameter pointers of the drop-in ABI.
+ *
+ * reference: src/py21cmfast/src/InputParameters.c:11-90.  py21cmfast installs the
+ * five cffi parameter structs once per configuration through
+ * Broadcast_struct_global_all (drivers/_global_initialization.py:98-112) and keeps the
+ * backing memory alive; the Compute* entry points then read them through these
+ * globals.  CosmoTables is the one struct that is deep-copied.  Unlike the reference
+ * (which copies the tables only the first time) every broadcast refreshes the copy,
+ * so a changed sigma_8 is never missed.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "c21cm_abi.h"
+
+SimulationOptions *simulation_options_global = NULL;
+MatterOptions *matter_options_global = NULL;
+CosmoParams *cosmo_params_global = NULL;
+AstroParams *astro_params_global = NULL;
+AstroOptions *astro_options_global = NULL;
+CosmoTables *cosmo_tables_global = NULL;
+ConfigSettings config_settings = {1.0, false, NULL, NULL};
+
+static Table1D *clone_table(const Table1D *src) {
+    if (!src || src->size <= 0 || !src->x_values || !src->y_values) return NULL;
+    Table1D *t = (Table1D *)malloc(sizeof(Table1D));
+    if (!t) return NULL;
+    t->size = src->size;
+    t->x_values = (double *)malloc(sizeof(double) * (size_t)src->size);
+    t->y_values = (double *)malloc(sizeof(double) * (size_t)src->size);
+    if (!t->x_values || !t->y_values) {
+        free(t->x_values);
+        free(t->y_values);
+        free(t);
+        return NULL;
+    }
+    memcpy(t->x_values, src->x_values, sizeof(double) * (size_t)src->size);
+    memcpy(t->y_values, src->y_values, sizeof(double) * (size_t)src->size);
+    return t;
+}
+
+static void free_table(Table1D *t) {
+    if (!t) return;
+    free(t->x_values);
+    free(t->y_values);
+    free(t);
+}
+
+/* reference: InputParameters.c:64-80 */
+void Free_cosmo_tables_global(void) {
+    if (!cosmo_tables_global) return;
+    free_table(cosmo_tables_global->transfer_density);
+    free_table(cosmo_tables_global->transfer_vcb);
+    free(cosmo_tables_global);
+    cosmo_tables_global = NULL;
+}
+
+void Broadcast_struct_global_all(SimulationOptions *simulation_options,
+                                 MatterOptions *matter_options, CosmoParams *cosmo_params,
+                                 AstroParams *astro_params, AstroOptions *astro_options,
+                                 CosmoTables *cosmo_tables) {
+    simulation_options_global = simulation_options;
+    matter_options_global = matter_options;
+    cosmo_params_global = cosmo_params;
+    astro_params_global = astro_params;
+    astro_options_global = astro_options;
+    Free_cosmo_tables_global();
+    if (!cosmo_tables) return;
+    cosmo_tables_global = (CosmoTables *)calloc(1, sizeof(CosmoTables));
+    if (!cosmo_tables_global) return;
+    cosmo_tables_global->ps_norm = cosmo_tables->ps_norm;
+    cosmo_tables_global->USE_SIGMA_8 = cosmo_tables->USE_SIGMA_8;
+    cosmo_tables_global->V_CB_AVG = cosmo_tables->V_CB_AVG;
+    if (matter_options && matter_options->POWER_SPECTRUM == C21CM_PS_CLASS) {
+        cosmo_tables_global->transfer_density = clone_table(cosmo_tables->transfer_density);
+        if (matter_options->V_CB_MODEL == C21CM_VCB_FLUCTS)
+            cosmo_tables_global->transfer_vcb = clone_table(cosmo_tables->transfer_vcb);
+    }
+}
+
+void Broadcast_struct_global_noastro(SimulationOptions *simulation_options,
+                                     MatterOptions *matter_options, CosmoParams *cosmo_params) {
+    simulation_options_global = simulation_options;
+    matter_options_global = matter_options;
+    cosmo_params_global = cosmo_params;
+}

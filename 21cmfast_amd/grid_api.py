@@ -1,0 +1,161 @@
+"""Python front-end of the explicit-scalar entry points (``include/c21cm_grid.h``).
+
+Inputs may be numpy arrays (host memory -- the library stages them, which is the
+py21cmfast/CFFI situation) or torch CUDA tensors (HBM -- used in place).  Outputs are
+created in the same kind of memory as ``density``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import structs as S
+from ._lib import check, load
+
+
+def _is_torch(a) -> bool:
+    return a is not None and type(a).__module__.startswith("torch")
+
+
+def _fptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        assert a.is_contiguous() and a.dtype.is_floating_point and a.element_size() == 4
+        return C.cast(a.data_ptr(), S.c_float_p)
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(S.c_float_p)
+
+
+def _vptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _new_like(ref, fill: float, dtype=None):
+    if _is_torch(ref):
+        import torch
+
+        return torch.full(ref.shape, fill, dtype=dtype or torch.float32, device=ref.device)
+    return np.full(ref.shape, fill, dtype or np.float32)
+
+
+def _stream(stream):
+    if stream is not None:
+        return C.c_void_p(stream)
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    except Exception:
+        pass
+    return C.c_void_p(0)
+
+
+def fft_r2c(padded, nx, ny, nz, stream=None):
+    check(load().c21cm_fft_r2c(_vptr(padded), nx, ny, nz, _stream(stream)), "c21cm_fft_r2c")
+
+
+def fft_c2r(padded, nx, ny, nz, stream=None):
+    check(load().c21cm_fft_c2r(_vptr(padded), nx, ny, nz, _stream(stream)), "c21cm_fft_c2r")
+
+
+def filter_grid(box, box_len, filter_type, R, R_param=0.0, box_len_z=None, stream=None):
+    """r2c -> /N -> W(kR) -> c2r of one box (reference: filtering.c:397-445)."""
+    nx, ny, nz = box.shape
+    out = _new_like(box, 0.0)
+    check(
+        load().c21cm_filter_grid(_vptr(box), _vptr(out), nx, ny, nz, box_len,
+                                 box_len if box_len_z is None else box_len_z, filter_type, R,
+                                 R_param, _stream(stream)),
+        "c21cm_filter_grid",
+    )
+    return out
+
+
+class IonizeBuffers:
+    """Owns the output arrays of one IonizedBox (what ``IonizedBox.new`` allocates in
+    py21cmfast, reference: src/py21cmfast/wrapper/outputs.py:1475-1545)."""
+
+    def __init__(self, density, need_nion: bool = False, minimize_memory: bool = False):
+        self.neutral_fraction = _new_like(density, 1.0)  # initialised to ones (:1524-1527)
+        self.z_reion = _new_like(density, 0.0)
+        self.kinetic_temperature = None if minimize_memory else _new_like(density, 0.0)
+        self.unnormalised_nion = _new_like(density, 0.0) if need_nion else None
+
+    def reset(self):
+        self.neutral_fraction[...] = 1.0
+        self.z_reion[...] = 0.0
+        if self.kinetic_temperature is not None:
+            self.kinetic_temperature[...] = 0.0
+
+    def struct(self) -> S.IonizedBoxStruct:
+        return S.IonizedBoxStruct(
+            neutral_fraction=_fptr(self.neutral_fraction), z_reion=_fptr(self.z_reion),
+            kinetic_temperature=_fptr(self.kinetic_temperature),
+            unnormalised_nion=_fptr(self.unnormalised_nion),
+        )
+
+
+def _input_structs(density, n_ion, xe, Tneutral, prev_z_reion):
+    pf = S.PerturbedFieldStruct(density=_fptr(density))
+    prev = S.IonizedBoxStruct(z_reion=_fptr(prev_z_reion))
+    ts = S.TsBoxStruct(xray_ionised_fraction=_fptr(xe), kinetic_temp_neutral=_fptr(Tneutral))
+    hb = S.HaloBoxStruct(n_ion=_fptr(n_ion))
+    return pf, prev, ts, hb
+
+
+def ionize_grids(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=None,
+                 prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None):
+    """One ComputeIonizedBox grid pass on the MI355X.  Returns (buffers, box_struct, report)."""
+    if buffers is None:
+        buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
+                                minimize_memory=bool(spec.minimize_memory))
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion)
+    box = buffers.struct()
+    rep = S.IonizeReport()
+    check(
+        load().c21cm_ionize_grids(C.byref(spec), C.byref(pf), C.byref(prev), C.byref(ts),
+                                  C.byref(hb), C.byref(box), C.byref(rep), _stream(stream)),
+        "c21cm_ionize_grids",
+    )
+    return buffers, box, rep
+
+
+def ionize_shard_radii(spec, rank, world, first_cross, density, n_ion=None, xe=None,
+                       Tneutral=None, prev_z_reion=None, stream=None):
+    """Shard phase: this rank's radii -> ``first_cross`` (uint8 CUDA tensor)."""
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion)
+    rep = S.IonizeReport()
+    check(
+        load().c21cm_ionize_shard_radii(C.byref(spec), rank, world, C.byref(pf), C.byref(prev),
+                                        C.byref(ts), C.byref(hb),
+                                        C.c_void_p(first_cross.data_ptr()), C.byref(rep),
+                                        _stream(stream)),
+        "c21cm_ionize_shard_radii",
+    )
+    return rep
+
+
+def ionize_shard_finish(spec, first_cross, density, n_ion=None, xe=None, Tneutral=None,
+                        prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None):
+    """Finish phase on the owning rank: apply the reduced mask, radius 0, post-loop."""
+    if buffers is None:
+        buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
+                                minimize_memory=bool(spec.minimize_memory))
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion)
+    box = buffers.struct()
+    rep = S.IonizeReport()
+    check(
+        load().c21cm_ionize_shard_finish(C.byref(spec), C.c_void_p(first_cross.data_ptr()),
+                                         C.byref(pf), C.byref(prev), C.byref(ts), C.byref(hb),
+                                         C.byref(box), C.byref(rep), _stream(stream)),
+        "c21cm_ionize_shard_finish",
+    )
+    return buffers, box, rep

@@ -1,0 +1,420 @@
+"""ctypes mirrors of the C ABI structs in ``include/c21cm_abi.h`` / ``c21cm_grid.h``.
+
+py21cmfast reaches the same structs through CFFI (``wrapper/structs.py:48-93`` builds
+``ffi.new("struct X*")`` and fills it field by field); this module is the equivalent
+for callers that do not have CFFI (tests, bench.py, the stand-alone host mirror in
+``single_field.py``).  Field order and C types must stay in lock-step with the
+headers; ``tests/test_abi_layout.py`` checks sizes and offsets against values the C
+compiler reports.
+
+Default values are the ones that arrive in the C structs after py21cmfast's
+Python-side transforms (reference: src/py21cmfast/wrapper/inputs.py, SURVEY.md
+Appendix A).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+MAX_RADII = 256
+NDELTA_TABLE = 400
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+
+
+class _Base(C.Structure):
+    """Structure with keyword construction + dict export."""
+
+    def update(self, **kw):
+        for k, v in kw.items():
+            if not any(k == f[0] for f in self._fields_):
+                raise AttributeError(f"{type(self).__name__} has no field {k!r}")
+            setattr(self, k, v)
+        return self
+
+    def asdict(self):
+        out = {}
+        for name, typ in self._fields_:
+            val = getattr(self, name)
+            if isinstance(val, (int, float, bool)):
+                out[name] = val
+        return out
+
+
+class CosmoParams(_Base):
+    _fields_ = [
+        ("hlittle", C.c_float),
+        ("OMm", C.c_float),
+        ("OMl", C.c_float),
+        ("OMb", C.c_float),
+        ("POWER_INDEX", C.c_float),
+        ("OMn", C.c_float),
+        ("OMk", C.c_float),
+        ("OMr", C.c_float),
+        ("OMtot", C.c_float),
+        ("Y_He", C.c_float),
+        ("wl", C.c_float),
+    ]
+
+
+class SimulationOptions(_Base):
+    _fields_ = [
+        ("HII_DIM", C.c_int),
+        ("DIM", C.c_int),
+        ("BOX_LEN", C.c_float),
+        ("NON_CUBIC_FACTOR", C.c_float),
+        ("N_THREADS", C.c_int),
+        ("Z_HEAT_MAX", C.c_double),
+        ("ZPRIME_STEP_FACTOR", C.c_double),
+        ("SAMPLER_MIN_MASS", C.c_float),
+        ("SAMPLER_BUFFER_FACTOR", C.c_double),
+        ("N_COND_INTERP", C.c_int),
+        ("N_PROB_INTERP", C.c_int),
+        ("MIN_LOGPROB", C.c_double),
+        ("HALOMASS_CORRECTION", C.c_double),
+        ("PARKINSON_G0", C.c_double),
+        ("PARKINSON_y1", C.c_double),
+        ("PARKINSON_y2", C.c_double),
+        ("INITIAL_REDSHIFT", C.c_float),
+        ("DELTA_R_FACTOR", C.c_double),
+        ("DENSITY_SMOOTH_RADIUS", C.c_double),
+        ("DEXM_OPTIMIZE_MINMASS", C.c_double),
+        ("DEXM_R_OVERLAP", C.c_double),
+        ("CORR_STAR", C.c_double),
+        ("CORR_SFR", C.c_double),
+        ("CORR_LX", C.c_double),
+        ("MIN_XE_FOR_FCOLL_IN_TAUX", C.c_double),
+    ]
+
+
+class MatterOptions(_Base):
+    _fields_ = [
+        ("USE_FFTW_WISDOM", C.c_bool),
+        ("HMF", C.c_int),
+        ("V_CB_MODEL", C.c_int),
+        ("POWER_SPECTRUM", C.c_int),
+        ("USE_INTERPOLATION_TABLES", C.c_int),
+        ("PERTURB_ON_HIGH_RES", C.c_bool),
+        ("PERTURB_ALGORITHM", C.c_int),
+        ("MINIMIZE_MEMORY", C.c_bool),
+        ("KEEP_3D_VELOCITIES", C.c_bool),
+        ("DEXM_OPTIMIZE", C.c_bool),
+        ("FILTER", C.c_int),
+        ("HALO_FILTER", C.c_int),
+        ("SMOOTH_EVOLVED_DENSITY_FIELD", C.c_bool),
+        ("SOURCE_MODEL", C.c_int),
+        ("SAMPLE_METHOD", C.c_int),
+    ]
+
+
+class AstroParams(_Base):
+    _fields_ = [
+        ("HII_EFF_FACTOR", C.c_float),
+        ("F_STAR10", C.c_float),
+        ("ALPHA_STAR", C.c_float),
+        ("ALPHA_STAR_MINI", C.c_float),
+        ("SIGMA_STAR", C.c_float),
+        ("UPPER_STELLAR_TURNOVER_MASS", C.c_double),
+        ("UPPER_STELLAR_TURNOVER_INDEX", C.c_double),
+        ("F_STAR7_MINI", C.c_float),
+        ("t_STAR", C.c_float),
+        ("SIGMA_SFR_INDEX", C.c_double),
+        ("SIGMA_SFR_LIM", C.c_double),
+        ("L_X", C.c_double),
+        ("L_X_MINI", C.c_double),
+        ("SIGMA_LX", C.c_double),
+        ("F_ESC10", C.c_float),
+        ("ALPHA_ESC", C.c_float),
+        ("F_ESC7_MINI", C.c_float),
+        ("T_RE", C.c_float),
+        ("M_TURN", C.c_float),
+        ("R_BUBBLE_MAX", C.c_float),
+        ("ION_Tvir_MIN", C.c_float),
+        ("F_H2_SHIELD", C.c_double),
+        ("NU_X_THRESH", C.c_float),
+        ("X_RAY_SPEC_INDEX", C.c_float),
+        ("X_RAY_Tvir_MIN", C.c_float),
+        ("A_LW", C.c_double),
+        ("BETA_LW", C.c_double),
+        ("A_VCB", C.c_double),
+        ("BETA_VCB", C.c_double),
+        ("V_CB_AVG_DEBUG", C.c_double),
+        ("POP2_ION", C.c_double),
+        ("POP3_ION", C.c_double),
+        ("PHOTONCONS_CALIBRATION_END", C.c_double),
+        ("CLUMPING_FACTOR", C.c_double),
+        ("ALPHA_UVB", C.c_double),
+        ("R_MAX_TS", C.c_float),
+        ("N_STEP_TS", C.c_int),
+        ("DELTA_R_HII_FACTOR", C.c_double),
+        ("R_BUBBLE_MIN", C.c_float),
+        ("MAX_DVDR", C.c_double),
+        ("NU_X_MAX", C.c_double),
+        ("NU_X_BAND_MAX", C.c_double),
+    ]
+
+
+class AstroOptions(_Base):
+    _fields_ = [
+        ("USE_MINI_HALOS", C.c_bool),
+        ("USE_X_RAY_HEATING", C.c_bool),
+        ("USE_CMB_HEATING", C.c_bool),
+        ("USE_LYA_HEATING", C.c_bool),
+        ("RECOMB_MODEL", C.c_int),
+        ("USE_TS_FLUCT", C.c_bool),
+        ("M_MIN_in_Mass", C.c_bool),
+        ("USE_EXP_FILTER", C.c_bool),
+        ("CELL_RECOMB", C.c_bool),
+        ("LYA_MULTIPLE_SCATTERING", C.c_bool),
+        ("USE_ADIABATIC_FLUCTUATIONS", C.c_bool),
+        ("PHOTON_CONS_TYPE", C.c_int),
+        ("USE_UPPER_STELLAR_TURNOVER", C.c_bool),
+        ("HALO_SCALING_RELATIONS_MEDIAN", C.c_bool),
+        ("HII_FILTER", C.c_int),
+        ("HEAT_FILTER", C.c_int),
+        ("IONISE_ENTIRE_SPHERE", C.c_bool),
+        ("INTEGRATION_METHOD_ATOMIC", C.c_int),
+        ("INTEGRATION_METHOD_MINI", C.c_int),
+    ]
+
+
+class Table1D(_Base):
+    _fields_ = [("size", C.c_int), ("x_values", c_double_p), ("y_values", c_double_p)]
+
+
+class CosmoTables(_Base):
+    _fields_ = [
+        ("transfer_density", C.POINTER(Table1D)),
+        ("transfer_vcb", C.POINTER(Table1D)),
+        ("ps_norm", C.c_double),
+        ("USE_SIGMA_8", C.c_bool),
+        ("V_CB_AVG", C.c_double),
+    ]
+
+
+class ConfigSettings(_Base):
+    _fields_ = [
+        ("HALO_CATALOG_MEM_FACTOR", C.c_double),
+        ("EXTRA_HALOBOX_FIELDS", C.c_bool),
+        ("external_table_path", C.c_char_p),
+        ("wisdoms_path", C.c_char_p),
+    ]
+
+
+class InitialConditionsStruct(_Base):
+    _fields_ = [
+        (n, c_float_p)
+        for n in (
+            "lowres_density", "lowres_vx", "lowres_vy", "lowres_vz",
+            "lowres_vx_2LPT", "lowres_vy_2LPT", "lowres_vz_2LPT",
+            "hires_density", "hires_vx", "hires_vy", "hires_vz",
+            "hires_vx_2LPT", "hires_vy_2LPT", "hires_vz_2LPT",
+            "lowres_vcb",
+        )
+    ]
+
+
+class PerturbedFieldStruct(_Base):
+    _fields_ = [(n, c_float_p) for n in ("density", "velocity_x", "velocity_y", "velocity_z")]
+
+
+class HaloBoxStruct(_Base):
+    _fields_ = [
+        (n, c_float_p)
+        for n in (
+            "halo_mass", "halo_stars", "halo_stars_mini", "count", "n_ion", "halo_sfr",
+            "halo_xray", "halo_sfr_mini", "whalo_sfr",
+        )
+    ] + [("log10_Mcrit_ACG_ave", C.c_double), ("log10_Mcrit_MCG_ave", C.c_double)]
+
+
+class TsBoxStruct(_Base):
+    _fields_ = [
+        (n, c_float_p)
+        for n in ("spin_temperature", "xray_ionised_fraction", "kinetic_temp_neutral", "J_21_LW")
+    ] + [("Q_HI", C.c_double)]
+
+
+class IonizedBoxStruct(_Base):
+    _fields_ = [
+        ("mean_f_coll", C.c_double),
+        ("mean_f_coll_MINI", C.c_double),
+        ("log10_Mturnover_ave", C.c_double),
+        ("log10_Mturnover_MINI_ave", C.c_double),
+    ] + [
+        (n, c_float_p)
+        for n in (
+            "neutral_fraction", "ionisation_rate_G12", "mean_free_path", "z_reion",
+            "cumulative_recombinations", "kinetic_temperature", "unnormalised_nion",
+            "unnormalised_nion_mini",
+        )
+    ]
+
+
+TABLE_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.c_double, c_float_p, C.c_void_p)
+
+
+class IonizeSpec(_Base):
+    """``c21cm_ionize_spec`` (include/c21cm_grid.h)."""
+
+    _fields_ = [
+        ("hii_dim", C.c_int),
+        ("hii_dim_z", C.c_int),
+        ("box_len", C.c_double),
+        ("box_len_z", C.c_double),
+        ("n_radii", C.c_int),
+        ("r_lowest", C.c_int),
+        ("R", C.c_double * MAX_RADII),
+        ("sigma_maxmass", C.c_double * MAX_RADII),
+        ("hii_filter", C.c_int),
+        ("stars_filter", C.c_int),
+        ("mfp_meandens", C.c_double),
+        ("fcoll_mode", C.c_int),
+        ("fix_mean", C.c_int),
+        ("mass_dep_zeta", C.c_int),
+        ("table_fn", TABLE_FN),
+        ("table_user", C.c_void_p),
+        ("use_ts_fluct", C.c_int),
+        ("recomb_model", C.c_int),
+        ("cell_recomb", C.c_int),
+        ("minimize_memory", C.c_int),
+        ("first_snapshot", C.c_int),
+        ("redshift", C.c_double),
+        ("stored_redshift", C.c_double),
+        ("photoncons_adjustment_factor", C.c_double),
+        ("ion_eff_factor", C.c_double),
+        ("mean_f_coll", C.c_double),
+        ("f_limit_acg", C.c_double),
+        ("gamma_prefactor", C.c_double),
+        ("rhocrit_omb", C.c_double),
+        ("growth_factor", C.c_double),
+        ("sigma_minmass", C.c_double),
+        ("delta_c", C.c_double),
+        ("TK_nofluct", C.c_double),
+        ("adia_TK_term", C.c_double),
+        ("T_re", C.c_double),
+        ("fabs_dtdz", C.c_double),
+        ("dz", C.c_double),
+    ]
+
+
+class IonizeReport(_Base):
+    _fields_ = [
+        ("f_coll_grid_mean", C.c_double * MAX_RADII),
+        ("global_xH", C.c_double),
+        ("mean_f_coll_out", C.c_double),
+        ("ms_preloop", C.c_double),
+        ("ms_rloop", C.c_double),
+        ("ms_postloop", C.c_double),
+    ]
+
+
+class PerturbSpec(_Base):
+    _fields_ = [
+        ("dim", C.c_int),
+        ("dim_z", C.c_int),
+        ("hii_dim", C.c_int),
+        ("hii_dim_z", C.c_int),
+        ("box_len", C.c_double),
+        ("box_len_z", C.c_double),
+        ("perturb_algorithm", C.c_int),
+        ("perturb_on_high_res", C.c_int),
+        ("keep_3d_velocities", C.c_int),
+        ("smooth_evolved_density", C.c_int),
+        ("density_smooth_radius", C.c_double),
+        ("growth_factor", C.c_double),
+        ("init_growth_factor", C.c_double),
+        ("displacement_factor_2LPT", C.c_double),
+        ("init_displacement_factor_2LPT", C.c_double),
+        ("dDdt_over_D", C.c_double),
+    ]
+
+
+class IcsSpec(_Base):
+    _fields_ = [
+        ("dim", C.c_int),
+        ("dim_z", C.c_int),
+        ("hii_dim", C.c_int),
+        ("hii_dim_z", C.c_int),
+        ("box_len", C.c_double),
+        ("box_len_z", C.c_double),
+        ("perturb_algorithm", C.c_int),
+        ("perturb_on_high_res", C.c_int),
+        ("n_pk", C.c_int),
+        ("lnk", c_double_p),
+        ("lnpk", c_double_p),
+        ("seed", C.c_ulonglong),
+        ("density_is_input", C.c_int),
+    ]
+
+
+# --------------------------------------------------------------------------------------
+# Defaults (what lands in the C structs for py21cmfast's default inputs).
+# reference: src/py21cmfast/wrapper/inputs.py:492-601 (cosmo), :1014-1111 (simulation),
+#            :766-830 (matter), :1302-1355 (astro options), :1569-1680 (astro params).
+# --------------------------------------------------------------------------------------
+def default_cosmo_params(**kw) -> CosmoParams:
+    p = CosmoParams(
+        hlittle=0.6766, OMm=0.30966, OMl=1.0 - 0.30966, OMb=0.04897, POWER_INDEX=0.9665,
+        OMn=0.0, OMk=0.0, OMr=8.6e-5, OMtot=1.0, Y_He=0.24, wl=-1.0,
+    )
+    return p.update(**kw)
+
+
+def default_simulation_options(**kw) -> SimulationOptions:
+    hii_dim = kw.get("HII_DIM", 256)
+    p = SimulationOptions(
+        HII_DIM=hii_dim, DIM=3 * hii_dim, BOX_LEN=1.5 * hii_dim, NON_CUBIC_FACTOR=1.0,
+        N_THREADS=1, Z_HEAT_MAX=35.0, ZPRIME_STEP_FACTOR=1.02, SAMPLER_MIN_MASS=1e8,
+        SAMPLER_BUFFER_FACTOR=2.0, N_COND_INTERP=200, N_PROB_INTERP=400, MIN_LOGPROB=-12.0,
+        HALOMASS_CORRECTION=0.89, PARKINSON_G0=1.0, PARKINSON_y1=0.0, PARKINSON_y2=0.0,
+        INITIAL_REDSHIFT=300.0, DELTA_R_FACTOR=1.1, DENSITY_SMOOTH_RADIUS=0.2,
+        DEXM_OPTIMIZE_MINMASS=1e11, DEXM_R_OVERLAP=2.0, CORR_STAR=0.5, CORR_SFR=0.2,
+        CORR_LX=0.2, MIN_XE_FOR_FCOLL_IN_TAUX=1e-3,
+    )
+    return p.update(**kw)
+
+
+def default_matter_options(**kw) -> MatterOptions:
+    p = MatterOptions(
+        USE_FFTW_WISDOM=False, HMF=1, V_CB_MODEL=0, POWER_SPECTRUM=0, USE_INTERPOLATION_TABLES=2,
+        PERTURB_ON_HIGH_RES=False, PERTURB_ALGORITHM=2, MINIMIZE_MEMORY=False,
+        KEEP_3D_VELOCITIES=False, DEXM_OPTIMIZE=False, FILTER=0, HALO_FILTER=0,
+        SMOOTH_EVOLVED_DENSITY_FIELD=False, SOURCE_MODEL=4, SAMPLE_METHOD=0,
+    )
+    return p.update(**kw)
+
+
+def default_astro_params(**kw) -> AstroParams:
+    p = AstroParams(
+        HII_EFF_FACTOR=30.0, F_STAR10=10 ** -1.3, ALPHA_STAR=0.5, ALPHA_STAR_MINI=0.0,
+        SIGMA_STAR=0.25, UPPER_STELLAR_TURNOVER_MASS=10 ** 11.447,
+        UPPER_STELLAR_TURNOVER_INDEX=-0.6, F_STAR7_MINI=10 ** -2.0, t_STAR=0.5,
+        SIGMA_SFR_INDEX=-0.12, SIGMA_SFR_LIM=0.19, L_X=10 ** 40.5, L_X_MINI=10 ** 40.5,
+        SIGMA_LX=0.5, F_ESC10=10 ** -1.0, ALPHA_ESC=-0.5, F_ESC7_MINI=10 ** -2.0, T_RE=2e4,
+        M_TURN=10 ** 8.7, R_BUBBLE_MAX=15.0, ION_Tvir_MIN=10 ** 4.69897, F_H2_SHIELD=0.0,
+        NU_X_THRESH=500.0, X_RAY_SPEC_INDEX=1.0, X_RAY_Tvir_MIN=10 ** 4.69897, A_LW=2.0,
+        BETA_LW=0.6, A_VCB=1.0, BETA_VCB=1.8, V_CB_AVG_DEBUG=25.86, POP2_ION=5000.0,
+        POP3_ION=44021.0, PHOTONCONS_CALIBRATION_END=3.5, CLUMPING_FACTOR=2.0, ALPHA_UVB=5.0,
+        R_MAX_TS=500.0, N_STEP_TS=40, DELTA_R_HII_FACTOR=1.1, R_BUBBLE_MIN=0.620350491,
+        MAX_DVDR=0.2, NU_X_MAX=10000.0, NU_X_BAND_MAX=2000.0,
+    )
+    return p.update(**kw)
+
+
+def default_astro_options(**kw) -> AstroOptions:
+    p = AstroOptions(
+        USE_MINI_HALOS=False, USE_X_RAY_HEATING=True, USE_CMB_HEATING=True, USE_LYA_HEATING=True,
+        RECOMB_MODEL=0, USE_TS_FLUCT=False, M_MIN_in_Mass=True, USE_EXP_FILTER=True,
+        CELL_RECOMB=True, LYA_MULTIPLE_SCATTERING=False, USE_ADIABATIC_FLUCTUATIONS=True,
+        PHOTON_CONS_TYPE=0, USE_UPPER_STELLAR_TURNOVER=True, HALO_SCALING_RELATIONS_MEDIAN=False,
+        HII_FILTER=0, HEAT_FILTER=0, IONISE_ENTIRE_SPHERE=False, INTEGRATION_METHOD_ATOMIC=1,
+        INTEGRATION_METHOD_MINI=1,
+    )
+    return p.update(**kw)
+
+
+def default_cosmo_tables(**kw) -> CosmoTables:
+    p = CosmoTables(ps_norm=0.8102, USE_SIGMA_8=True, V_CB_AVG=25.86)
+    return p.update(**kw)

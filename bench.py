@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- IonizeBox cells/sec on MI355X (BASELINE.json metric).
+
+A "step" is ONE ComputeIonizedBox grid pass (c21cm_ionize_grids through the C ABI) over
+the synthetic config-3 workload of SURVEY.md 8(d): HII_DIM = 512, BOX_LEN = 768 Mpc,
+40 filter radii (0.9305 .. 38.29 Mpc), G = 2 filtered grids (delta with the real-space
+top-hat, n_ion with the exponential-MFP top-hat), first-snapshot path, inputs already
+resident in HBM when the timed region starts.
+
+  python bench.py                      # N = 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1 shards the R loop over ranks (radius index r belongs to rank (n_radii-1-r) % N),
+max-reduces the per-cell first-crossing mask (uint8) onto the rank that owns radius 0
+with one RCCL reduce over xGMI, and that rank finishes (partial ionisation, temperatures,
+sum xH).  Total work is fixed as N grows -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      algorithmic bytes / measured time of the dominant unit, vs 8 TB/s HBM3E
+  cpu_baseline  the CPU oracle (oracle/liboracle21.so, "port") timed on this host on a
+                bounded sample of the same workload (smaller box, same 40 radii)
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--hii-dim", type=int, default=512)
+    ap.add_argument("--r-bubble-max", type=float, default=40.0)
+    ap.add_argument("--mode", choices=["stars", "erfc"], default="stars")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-dim", type=int, default=192,
+                    help="box size of the CPU-oracle sample (same radii count)")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_radius(n_cells: int, G: int) -> float:
+    """B_alg(R) = G*5S + 8N ~ (20G + 8) N bytes, S = one padded grid."""
+    return (20.0 * G + 8.0) * n_cells
+
+
+def cpu_baseline(args, W):
+    """Time the oracle on a bounded sample: same radii ladder, smaller box."""
+    import numpy as np
+
+    oracle = importlib.import_module("oracle.oracle")
+    oracle.load()
+    n = args.cpu_dim
+    mode = W.FCOLL_STARS if args.mode == "stars" else W.FCOLL_ERFC
+    # keep 1.5 Mpc cells * (512/n) so that the radius ladder (40 radii) is identical
+    spec = W.ionize_spec(n, box_len=1.5 * args.hii_dim, mode=mode, r_bubble_max=args.r_bubble_max)
+    full = W.ionize_spec(args.hii_dim, mode=mode, r_bubble_max=args.r_bubble_max)
+    spec.n_radii = full.n_radii
+    for i in range(full.n_radii):
+        spec.R[i] = full.R[i]
+        spec.sigma_maxmass[i] = full.sigma_maxmass[i]
+    density = W.density_field_numpy(n, seed=12345)
+    n_ion = W.nion_from_density(density) if mode == W.FCOLL_STARS else None
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    oracle.ionize_grids(spec, density, n_ion, need_nion=mode != W.FCOLL_STARS)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": n**3 / dt, "unit": "cells/s", "cores": cores, "kind": "port",
+        "sample": f"CPU oracle (C/OpenMP restatement, {cores} threads, own FFT) on a {n}^3 box, "
+                  f"{spec.n_radii} radii, G={2 if mode == W.FCOLL_STARS else 1}; {dt:.2f} s",
+        "cpu_model": model,
+    }
+
+
+def kernel_roofline(api, W, args, spec, torch):
+    """Live HIP-event timing of the dominant hand-written unit, on torch's current stream
+    (the stream every kernel of the step is launched on)."""
+    n = args.hii_dim
+    npad = n * n * 2 * (n // 2 + 1)
+    lib = importlib.import_module("21cmfast_amd").load()
+    import ctypes as C
+
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = torch.randn(npad, device="cuda")
+    reps = 10
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    # one c2r transform of a padded grid: ideal traffic = read S + write S
+    for _ in range(2):
+        lib.c21cm_fft_c2r(C.c_void_p(a.data_ptr()), n, n, n, stream)
+    ev[0].record()
+    for _ in range(reps):
+        lib.c21cm_fft_c2r(C.c_void_p(a.data_ptr()), n, n, n, stream)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / reps
+    S = npad * 4.0
+    return {"kernel": "fft_c2r_512 (one padded grid, in place)", "ms": ms,
+            "alg_bytes": 2 * S, "GBs": 2 * S / ms / 1e6}
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("21cmfast_amd")
+    pkg.load(require_gpu=True)
+    W = importlib.import_module("21cmfast_amd.workloads")
+    api = importlib.import_module("21cmfast_amd.grid_api")
+
+    n = args.hii_dim
+    mode = W.FCOLL_STARS if args.mode == "stars" else W.FCOLL_ERFC
+    G = 2 if mode == W.FCOLL_STARS else 1
+    spec = W.ionize_spec(n, mode=mode, r_bubble_max=args.r_bubble_max)
+    density = W.density_field_torch(n, seed=12345)
+    n_ion = W.nion_from_density(density) if mode == W.FCOLL_STARS else None
+    buffers = api.IonizeBuffers(density, need_nion=mode != W.FCOLL_STARS)
+    owner = (spec.n_radii - 1) % world
+    first_cross = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda") if world > 1 else None
+    last_report = {}
+
+    def step():
+        buffers.reset()
+        if world == 1:
+            _, _, rep = api.ionize_grids(spec, density, n_ion, buffers=buffers)
+            last_report["rep"] = rep
+        else:
+            api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion)
+            dist.reduce(first_cross, dst=owner, op=dist.ReduceOp.MAX)
+            if rank == owner:
+                _, _, rep = api.ionize_shard_finish(spec, first_cross, density, n_ion,
+                                                    buffers=buffers)
+                last_report["rep"] = rep
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    cells = float(n) ** 3
+    value = cells / (ms_per_step * 1e-3)
+
+    out = None
+    if rank == 0:
+        alg_loop = algorithmic_bytes_per_radius(cells, G) * spec.n_radii
+        roof = {
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None,
+            "scope": "R loop of one step (all radii), algorithmic bytes (20G+8)*N per radius",
+        }
+        rep = last_report.get("rep")
+        if world == 1 and rep is not None and rep.ms_rloop > 0:
+            roof["achieved"] = alg_loop / (rep.ms_rloop * 1e-3) / 1e9
+            roof["ms_rloop"] = rep.ms_rloop
+            roof["ms_preloop"] = rep.ms_preloop
+            roof["ms_postloop"] = rep.ms_postloop
+        else:
+            roof["achieved"] = alg_loop / (ms_per_step * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        if world == 1 and not args.no_kernel_roofline:
+            k = kernel_roofline(api, W, args, spec, torch)
+            roof["dominant_kernel"] = k
+        out = {
+            "metric": "IonizeBox cells/sec (512^3 HII_DIM, 40 filter radii)",
+            "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"ComputeIonizedBox single-z, HII_DIM={n}, {spec.n_radii} filter "
+                            f"steps, G={G} ({'delta tophat + n_ion exp-MFP' if G == 2 else 'delta sharp-k, erfc f_coll'}), "
+                            "first snapshot, device-resident inputs",
+                "hii_dim": n, "n_radii": spec.n_radii, "filtered_grids": G,
+                "parallelism": "single GPU" if world == 1 else f"R-loop sharded x{world} + RCCL uint8 max-reduce",
+                "fft": "native" if pkg.load().c21hip_fft_is_native(n, n, n) else "rocfft",
+                "global_xH": None if rep is None else rep.global_xH,
+            },
+            "roofline": roof,
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, W)
+        out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

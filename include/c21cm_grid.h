@@ -1,0 +1,187 @@
+/*
+ * c21cm_grid.h -- explicit-scalar ("grid level") entry points of lib21cmfast_hip.so.
+ *
+ * The drop-in entry points of c21cm_abi.h read their physics scalars from the
+ * process-global parameter structs and from host-side cosmology / HMF
+ * integrals.  Everything they do on the GRIDS is delegated to the functions
+ * declared here, which take every scalar explicitly.  These are what
+ * bench.py and the parity tests call: the grid work can then be compared with
+ * the CPU oracle on identical numbers, independent of host-integral numerics
+ * ("mean_f_coll, f_limit supplied as fixed scalars").
+ *
+ * Pointer arguments may address host memory or MI355X HBM; the library detects
+ * which (hipPointerGetAttributes) and stages host arrays through device
+ * scratch.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Every function returns a c21cm_status code.
+ */
+#ifndef C21CM_GRID_H
+#define C21CM_GRID_H
+
+#include "c21cm_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C21CM_MAX_RADII 256
+#define C21CM_NDELTA_TABLE 400 /* reference: src/py21cmfast/src/interp_tables.c:27,34 */
+
+/* How the per-cell collapsed fraction is obtained inside the R loop
+ * (reference: src/py21cmfast/src/IonisationBox.c:821-881). */
+enum c21cm_fcoll_mode {
+    C21CM_FCOLL_STARS_GRID = 0,   /* Lagrangian source grids: f = filtered HaloBox.n_ion    */
+    C21CM_FCOLL_ERFC = 1,         /* CONST-ION-EFF, no tables: FgtrM_bias_fast closed form  */
+    C21CM_FCOLL_TABLE_LINEAR = 2, /* CONST-ION-EFF with tables: lerp(table, delta)          */
+    C21CM_FCOLL_TABLE_EXP = 3     /* E-INTEGRAL: exp(lerp(table, delta))                    */
+};
+
+/* Host callback used by the two TABLE modes: fill `table[C21CM_NDELTA_TABLE]`
+ * (float, like the reference's RGTable1D_f) for filter radius index `r_index`
+ * on the regular delta grid x_i = dens_min + i*(dens_max-dens_min)/(NDELTA-1).
+ * reference: src/py21cmfast/src/IonisationBox.c:702-768. */
+typedef int (*c21cm_table_fn)(int r_index, double dens_min, double dens_max, float *table,
+                              void *user);
+
+/* All scalars of one ComputeIonizedBox call.
+ * reference: struct IonBoxConstants / RadiusSpec, src/py21cmfast/src/IonisationBox.c:38-102. */
+typedef struct c21cm_ionize_spec {
+    /* geometry */
+    int hii_dim;      /* cells along x and y                          */
+    int hii_dim_z;    /* cells along z (= NON_CUBIC_FACTOR * HII_DIM) */
+    double box_len;   /* Mpc, x and y                                 */
+    double box_len_z; /* Mpc, z                                       */
+
+    /* filter radii, ascending; index 0 is the cell-scale radius (setup_radii :964-1006) */
+    int n_radii;
+    int r_lowest; /* lowest radius index that is processed (0 unless M_min > RtoM(R) breaks :1537) */
+    double R[C21CM_MAX_RADII];
+    double sigma_maxmass[C21CM_MAX_RADII]; /* sigma_z0(RtoM(R)); ERFC / TABLE_LINEAR modes */
+
+    /* filters (copy_filter_transform :572-664) */
+    int hii_filter;      /* delta, x_e, N_rec grids                 */
+    int stars_filter;    /* n_ion, whalo_sfr grids (3 = exp-MFP)    */
+    double mfp_meandens; /* R_param of filter 3                     */
+
+    /* source model */
+    int fcoll_mode;   /* enum c21cm_fcoll_mode                                         */
+    int fix_mean;     /* rescale grid f_coll to mean_f_coll (Eulerian models)          */
+    int mass_dep_zeta; /* floor f at f_limit_acg (:1077-1082) and mean clamp (:1566)  */
+    c21cm_table_fn table_fn;
+    void *table_user;
+
+    /* option flags */
+    int use_ts_fluct;          /* filter TsBox.xray_ionised_fraction, partial T from Ts    */
+    int recomb_model;          /* enum C21CM_RECOMB_*                                      */
+    int cell_recomb;           /* AstroOptions.CELL_RECOMB                                 */
+    int minimize_memory;       /* skip kinetic_temperature / mean_free_path                */
+    int first_snapshot;        /* prev_redshift < 1: previous z_reion := -1 (:365-401)     */
+
+    /* redshift / astro scalars (set_ionbox_constants :125-227) */
+    double redshift;        /* written into z_reion on first crossing  */
+    double stored_redshift; /* used by the ionised-temperature formula */
+    double photoncons_adjustment_factor;
+    double ion_eff_factor;  /* zeta applied to the per-cell f_coll     */
+    double mean_f_coll;     /* global expectation (fix_mean numerator) */
+    double f_limit_acg;
+    double gamma_prefactor;
+    double rhocrit_omb; /* RHOcrit * OMb, Lagrangian absorber normalisation (:1066) */
+    double growth_factor;
+    double sigma_minmass;
+    double delta_c; /* physconst.delta_c_sph = 1.686 */
+    double TK_nofluct;
+    double adia_TK_term;
+    double T_re;
+    double fabs_dtdz;
+    double dz;
+} c21cm_ionize_spec;
+
+/* Per-call diagnostics returned by the grid-level ionisation driver. */
+typedef struct c21cm_ionize_report {
+    double f_coll_grid_mean[C21CM_MAX_RADII]; /* after the clamp of :1566-1576 */
+    double global_xH;
+    double mean_f_coll_out; /* what ComputeIonizedBox leaves in box->mean_f_coll */
+    double ms_preloop, ms_rloop, ms_postloop; /* device timings (hip events)     */
+} c21cm_ionize_report;
+
+/* The whole ComputeIonizedBox grid algorithm (pre-loop r2c, R loop, post-loop).
+ * reference: src/py21cmfast/src/IonisationBox.c:1477-1628. */
+int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
+                       const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                       const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                       void *stream);
+
+/* R-loop sharding over GPUs.  Each rank runs the radii
+ * r = n_radii-1-rank, n_radii-1-rank-world, ... > 0 and records in
+ * `first_cross[N]` (uint8, device) the largest 1-based radius index whose
+ * barrier the cell crossed (0 = none).  The caller max-reduces first_cross over
+ * ranks (RCCL), then the rank that owns the outputs calls the finish step, which
+ * applies the mask, runs radius index 0 (partial ionisation) and the post-loop. */
+int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
+                             const PerturbedField *perturbed_field,
+                             const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                             const HaloBox *halos, unsigned char *first_cross,
+                             c21cm_ionize_report *report, void *stream);
+int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char *first_cross,
+                              const PerturbedField *perturbed_field,
+                              const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                              const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                              void *stream);
+
+/* filter_box on an explicit geometry: r2c, /N, W(kR) multiply, c2r.
+ * reference: src/py21cmfast/src/filtering.c:308-445 (filter_box / test_filter). */
+int c21cm_filter_grid(const float *input, float *output, int nx, int ny, int nz, double box_len,
+                      double box_len_z, int filter_type, double R, double R_param, void *stream);
+
+/* In-place padded real FFTs (reference: src/py21cmfast/src/dft.c:18-72).
+ * `box` is float[nx][ny][2*(nz/2+1)] on the device. */
+int c21cm_fft_r2c(float *box, int nx, int ny, int nz, void *stream);
+int c21cm_fft_c2r(float *box, int nx, int ny, int nz, void *stream);
+
+/* Scalars of one ComputePerturbedField call
+ * (reference: src/py21cmfast/src/PerturbedField.c:24-135,389-496, map_mass.c:146-208). */
+typedef struct c21cm_perturb_spec {
+    int dim, dim_z;         /* hi-res particle grid         */
+    int hii_dim, hii_dim_z; /* low-res output grid          */
+    double box_len, box_len_z;
+    int perturb_algorithm;  /* enum C21CM_PERTURB_*         */
+    int perturb_on_high_res;
+    int keep_3d_velocities;
+    int smooth_evolved_density;
+    double density_smooth_radius; /* in output cells, SimulationOptions.DENSITY_SMOOTH_RADIUS */
+    double growth_factor;         /* D(z)                   */
+    double init_growth_factor;    /* D(z_init)              */
+    double displacement_factor_2LPT;      /* see map_mass.c:161-164 */
+    double init_displacement_factor_2LPT;
+    double dDdt_over_D;           /* ddickedt(z)/dicke(z)   */
+} c21cm_perturb_spec;
+
+int c21cm_perturb_grids(const c21cm_perturb_spec *spec, const InitialConditions *ics,
+                        PerturbedField *pf, void *stream);
+
+/* Scalars of one ComputeInitialConditions call
+ * (reference: src/py21cmfast/src/InitialConditions.c:547-772). */
+typedef struct c21cm_ics_spec {
+    int dim, dim_z;
+    int hii_dim, hii_dim_z;
+    double box_len, box_len_z;
+    int perturb_algorithm;
+    int perturb_on_high_res;
+    int n_pk;            /* size of the tabulated P(k) */
+    const double *lnk;   /* ln k, ascending, host      */
+    const double *lnpk;  /* ln P(k), host; sample_modes interpolates linearly in ln-ln */
+    unsigned long long seed;
+    int density_is_input; /* regenerate everything from boxes->hires_density (:620-663) */
+} c21cm_ics_spec;
+
+int c21cm_ics_grids(const c21cm_ics_spec *spec, InitialConditions *ics, void *stream);
+
+/* Library management */
+const char *c21cm_version(void);
+int c21cm_device_synchronize(void);
+void c21cm_release_device_cache(void); /* drop cached rocFFT plans and scratch */
+const char *c21cm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* C21CM_GRID_H */

@@ -1,0 +1,65 @@
+/*
+ * oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C + OpenMP) of the reference's grid algorithms for the
+ * IC -> PerturbedField -> IonizedBox hot path.  It exists to CHECK the HIP
+ * path: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load liboracle21.so.  Nothing under 21cmfast_amd/ links, imports or
+ * calls it; the product fails loudly when its HIP library is missing.
+ *
+ * Pinning status: the reference itself cannot be built in this image (FFTW and
+ * GSL headers/libraries are absent, Python is 3.10 < 3.12), so
+ * the oracle is pinned by the reference's analytic known-answer tests
+ * (tests/test_filtering.py:111-236, tests/test_perturb.py:108-135,
+ * tests/test_initial_conditions.py:153-178) restated in tests/test_oracle_*.py.
+ * Per-cell xH parity with upstream is "parity unpinned" (no upstream test pins
+ * per-cell values either).
+ *
+ * The oracle shares the public struct definitions of include/c21cm_grid.h so
+ * that one spec drives both implementations.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "c21cm_grid.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* oracle_fft.c -- reference: src/py21cmfast/src/dft.c:18-72 */
+void oracle_fft_r2c(float *box, int nx, int ny, int nz);
+void oracle_fft_c2r(float *box, int nx, int ny, int nz);
+
+/* oracle_filter.c -- reference: src/py21cmfast/src/filtering.c:18-117,308-445 */
+double oracle_filter_window(int filter_type, double k, float R, float R_param);
+int oracle_filter_box(float *cbox, int nx, int ny, int nz, double box_len, double box_len_z,
+                      int filter_type, float R, float R_param);
+int oracle_filter_grid(const float *input, float *output, int nx, int ny, int nz, double box_len,
+                       double box_len_z, int filter_type, double R, double R_param);
+int oracle_test_filter(const float *input, int nx, int ny, int nz, double box_len,
+                       double box_len_z, double R, double R_param, int filter_type,
+                       double *result);
+
+/* oracle_ionize.c -- reference: src/py21cmfast/src/IonisationBox.c:323-360,572-1256,1477-1628 */
+int oracle_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
+                        const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                        const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report);
+float oracle_fully_ionized_temperature(float z_re, float z, float delta, float T_re);
+float oracle_partially_ionized_temperature(float T_HI, float res_xH, float T_re);
+double oracle_fgtrm_bias_fast(float growthf, float del_bias, float sig_small, float sig_large,
+                              double delta_c);
+
+/* oracle_perturb.c -- reference: src/py21cmfast/src/PerturbedField.c, map_mass.c:23-208 */
+int oracle_perturb_grids(const c21cm_perturb_spec *spec, const InitialConditions *ics,
+                         PerturbedField *pf);
+
+/* oracle_ics.c -- reference: src/py21cmfast/src/InitialConditions.c */
+int oracle_ics_grids(const c21cm_ics_spec *spec, InitialConditions *ics);
+
+void oracle_set_threads(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,148 @@
+"""ctypes front-end of the CPU oracle (``oracle/liboracle21.so``).
+
+TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.  Nothing under ``21cmfast_amd/`` imports it.
+
+Parity pinning: see ``oracle/oracle.h`` -- the reference cannot be built or imported in
+this image, so the oracle is pinned by the reference's analytic known-answer tests
+(restated in ``tests/test_oracle_*.py``); per-cell xH parity with upstream is unpinned.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "liboracle21.so"
+S = importlib.import_module("21cmfast_amd.structs")
+
+_lib = None
+
+
+def build(force: bool = False) -> None:
+    if force or not LIB_PATH.exists():
+        subprocess.run(["make", "-C", str(_HERE)] + (["-B"] if force else []), check=True,
+                       stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(str(LIB_PATH))
+        vp, i32, f64, f32 = C.c_void_p, C.c_int, C.c_double, C.c_float
+        P = C.POINTER
+        lib.oracle_fft_r2c.restype = None
+        lib.oracle_fft_r2c.argtypes = [vp, i32, i32, i32]
+        lib.oracle_fft_c2r.restype = None
+        lib.oracle_fft_c2r.argtypes = [vp, i32, i32, i32]
+        lib.oracle_filter_window.restype = f64
+        lib.oracle_filter_window.argtypes = [i32, f64, f32, f32]
+        lib.oracle_filter_grid.restype = i32
+        lib.oracle_filter_grid.argtypes = [vp, vp, i32, i32, i32, f64, f64, i32, f64, f64]
+        lib.oracle_test_filter.restype = i32
+        lib.oracle_test_filter.argtypes = [vp, i32, i32, i32, f64, f64, f64, f64, i32, vp]
+        lib.oracle_ionize_grids.restype = i32
+        lib.oracle_ionize_grids.argtypes = [
+            P(S.IonizeSpec), P(S.PerturbedFieldStruct), P(S.IonizedBoxStruct), P(S.TsBoxStruct),
+            P(S.HaloBoxStruct), P(S.IonizedBoxStruct), P(S.IonizeReport),
+        ]
+        lib.oracle_fully_ionized_temperature.restype = f32
+        lib.oracle_fully_ionized_temperature.argtypes = [f32, f32, f32, f32]
+        lib.oracle_partially_ionized_temperature.restype = f32
+        lib.oracle_partially_ionized_temperature.argtypes = [f32, f32, f32]
+        lib.oracle_fgtrm_bias_fast.restype = f64
+        lib.oracle_fgtrm_bias_fast.argtypes = [f32, f32, f32, f32, f64]
+        lib.oracle_set_threads.restype = None
+        lib.oracle_set_threads.argtypes = [i32]
+        for name, argt in (
+            ("oracle_perturb_grids", [P(S.PerturbSpec), P(S.InitialConditionsStruct),
+                                      P(S.PerturbedFieldStruct)]),
+            ("oracle_ics_grids", [P(S.IcsSpec), P(S.InitialConditionsStruct)]),
+        ):
+            if hasattr(lib, name):
+                getattr(lib, name).restype = i32
+                getattr(lib, name).argtypes = argt
+        _lib = lib
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def fft_r2c(dense: np.ndarray) -> np.ndarray:
+    """Forward transform of a dense float32 box; returns the complex64 half-spectrum."""
+    nx, ny, nz = dense.shape
+    pad = np.zeros((nx, ny, 2 * (nz // 2 + 1)), np.float32)
+    pad[:, :, :nz] = dense
+    load().oracle_fft_r2c(_ptr(pad), nx, ny, nz)
+    return pad.view(np.complex64).reshape(nx, ny, nz // 2 + 1)
+
+
+def fft_c2r(spec: np.ndarray, nz: int) -> np.ndarray:
+    nx, ny, nzc = spec.shape
+    pad = np.ascontiguousarray(spec.astype(np.complex64)).view(np.float32).reshape(nx, ny, 2 * nzc)
+    pad = pad.copy()
+    load().oracle_fft_c2r(_ptr(pad), nx, ny, nz)
+    return pad[:, :, :nz].copy()
+
+
+def filter_grid(box: np.ndarray, box_len: float, filter_type: int, R: float, R_param: float = 0.0,
+                box_len_z: float | None = None) -> np.ndarray:
+    box = np.ascontiguousarray(box, np.float32)
+    nx, ny, nz = box.shape
+    out = np.empty_like(box)
+    st = load().oracle_filter_grid(_ptr(box), _ptr(out), nx, ny, nz, box_len,
+                                   box_len if box_len_z is None else box_len_z, filter_type, R,
+                                   R_param)
+    if st:
+        raise RuntimeError(f"oracle_filter_grid status {st}")
+    return out
+
+
+def window(filter_type: int, k: float, R: float, R_param: float = 0.0) -> float:
+    return load().oracle_filter_window(filter_type, k, R, R_param)
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(S.c_float_p)
+
+
+def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion=None,
+                 need_nion=False):
+    """Run the oracle's ComputeIonizedBox grid algorithm on numpy inputs.
+
+    Returns a dict of output arrays plus the report struct.
+    """
+    shape = density.shape
+    out = {
+        "neutral_fraction": np.ones(shape, np.float32),
+        "z_reion": np.zeros(shape, np.float32),
+        "kinetic_temperature": np.zeros(shape, np.float32),
+    }
+    if need_nion:
+        out["unnormalised_nion"] = np.zeros(shape, np.float32)
+    pf = S.PerturbedFieldStruct(density=fptr(density))
+    prev = S.IonizedBoxStruct(z_reion=fptr(prev_z_reion))
+    ts = S.TsBoxStruct(xray_ionised_fraction=fptr(xe), kinetic_temp_neutral=fptr(Tneutral))
+    hb = S.HaloBoxStruct(n_ion=fptr(n_ion))
+    box = S.IonizedBoxStruct(
+        neutral_fraction=fptr(out["neutral_fraction"]), z_reion=fptr(out["z_reion"]),
+        kinetic_temperature=fptr(out["kinetic_temperature"]),
+        unnormalised_nion=fptr(out.get("unnormalised_nion")),
+    )
+    rep = S.IonizeReport()
+    st = load().oracle_ionize_grids(C.byref(spec), C.byref(pf), C.byref(prev), C.byref(ts),
+                                    C.byref(hb), C.byref(box), C.byref(rep))
+    if st:
+        raise RuntimeError(f"oracle_ionize_grids status {st}")
+    out["mean_f_coll"] = box.mean_f_coll
+    out["report"] = rep
+    return out

@@ -1,0 +1,365 @@
+/*
+ * oracle_ionize.c -- TEST INFRASTRUCTURE ONLY (CPU oracle).
+ *
+ * The grid algorithm of ComputeIonizedBox with every physics scalar supplied
+ * through c21cm_ionize_spec.
+ * reference: src/py21cmfast/src/IonisationBox.c
+ *   :323-360   prepare_box_for_filtering  (scale, clip, pack, r2c, /N)
+ *   :365-401   setup_first_z_prevbox      (previous z_reion := -1)
+ *   :572-664   copy_filter_transform      (memcpy, filter_box, c2r per grid)
+ *   :668-699   clip_and_get_extrema
+ *   :702-768   setup_integration_tables   (table range = extrema -/+ 0.001)
+ *   :773-962   calculate_fcoll_grid
+ *   :1008-1201 find_ionised_regions
+ *   :1203-1256 set_ionized_temperatures
+ *   :1531-1628 the R loop, global sums, returned mean_f_coll
+ * plus src/py21cmfast/src/thermochem.c:31-63 (temperatures),
+ *      src/py21cmfast/src/hmf.c:1187-1241 (erfcc / FgtrM_bias_fast),
+ *      src/py21cmfast/src/interpolation.c:123-131 (EvaluateRGTable1D_f).
+ *
+ * Not restated (returns C21CM_VALUE_ERROR): USE_MINI_HALOS with Eulerian
+ * sources (2-D tables), recombination models (MHR00 splines),
+ * IONISE_ENTIRE_SPHERE -- all non-default, SURVEY.md section 2a.
+ */
+#include <math.h>
+#include <omp.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "oracle.h"
+
+#define FRACT_FLOAT_ERR ((double)1e-7) /* reference: Constants.h */
+#define TINY ((double)1e-30)
+#define MIN_DENSITY_LOW_LIMIT (9e-8) /* reference: thermochem.c:16 */
+
+/* thermochem.c:31-56 */
+float oracle_fully_ionized_temperature(float z_re, float z, float delta, float T_re) {
+    float result, delta_re;
+    if (fabs(z - z_re) < 1e-4)
+        result = 1;
+    else {
+        delta_re = delta * (1. + z) / (1. + z_re);
+        if (delta_re <= -1) delta_re = -1. + MIN_DENSITY_LOW_LIMIT;
+        if (delta <= -1) delta = -1. + MIN_DENSITY_LOW_LIMIT;
+        result = pow((1. + delta) / (1. + delta_re), 1.1333);
+        result *= pow((1. + z) / (1. + z_re), 3.4);
+        result *= expf(pow((1. + z) / 7.1, 2.5) - pow((1. + z_re) / 7.1, 2.5));
+    }
+    result *= pow(T_re, 1.7);
+    result += pow(1e4 * ((1. + z) / 4.), 1.7) * (1 + delta);
+    result = pow(result, 0.5882);
+    return result;
+}
+
+/* thermochem.c:58-63 */
+float oracle_partially_ionized_temperature(float T_HI, float res_xH, float T_re) {
+    if (res_xH <= 0.) return T_re;
+    if (res_xH >= 1) return T_HI;
+    return T_HI * res_xH + T_re * (1. - res_xH);
+}
+
+/* hmf.c:1187-1203 */
+static float erfcc(float x) {
+    double t, q, ans;
+    q = fabs(x);
+    t = 1.0 / (1.0 + 0.5 * q);
+    ans = t * exp(-q * q - 1.2655122 +
+                  t * (1.0000237 +
+                       t * (0.374092 +
+                            t * (0.0967842 +
+                                 t * (-0.1862881 +
+                                      t * (0.2788681 +
+                                           t * (-1.13520398 +
+                                                t * (1.4885159 +
+                                                     t * (-0.82215223 + t * 0.17087277)))))))));
+    return x >= 0.0 ? ans : 2.0 - ans;
+}
+
+/* hmf.c:1205-1241; NAN signals the reference's Throw(ValueError) */
+double oracle_fgtrm_bias_fast(float growthf, float del_bias, float sig_small, float sig_large,
+                              double delta_c) {
+    double del, sig;
+    if (sig_large > sig_small) return NAN;
+    if (sig_large == sig_small) return 0.;
+    sig = sqrt(sig_small * sig_small - sig_large * sig_large);
+    del = (delta_c - del_bias) / growthf;
+    double x = del / (sqrt(2) * sig);
+    if (x < 0) return 1.0;
+    return erfcc(x);
+}
+
+/* interpolation.c:123-131 */
+static double eval_table_f(double x, double x_min, double x_width, const float *y_arr) {
+    int idx = (int)floor((x - x_min) / x_width);
+    double table_val = x_min + x_width * (float)idx;
+    double interp_point = (x - table_val) / x_width;
+    return y_arr[idx] * (1 - interp_point) + y_arr[idx + 1] * (interp_point);
+}
+
+/* IonisationBox.c:323-360 */
+static void prepare_box(const float *input, float *cbox, int nx, int ny, int nz, double factor,
+                        double lo, double hi) {
+    const size_t zpad = 2 * (size_t)(nz / 2 + 1);
+    const size_t npad = (size_t)nx * ny * zpad;
+    memset(cbox, 0, sizeof(float) * npad);
+#pragma omp parallel for schedule(static)
+    for (long l = 0; l < (long)nx * ny; l++) {
+        for (int k = 0; k < nz; k++) {
+            double curr_cell = input[(size_t)l * nz + k] * factor;
+            cbox[(size_t)l * zpad + k] = fmax(fmin(curr_cell, hi), lo);
+        }
+    }
+    oracle_fft_r2c(cbox, nx, ny, nz);
+    const float ntot = (float)((size_t)nx * ny * nz);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)npad; i++) cbox[i] /= ntot;
+}
+
+/* one grid of copy_filter_transform: IonisationBox.c:577-663 */
+static int copy_filter_c2r(const float *unfiltered, float *filtered, const c21cm_ionize_spec *s,
+                           int r_index, int filter_type, double R_param) {
+    const int nx = s->hii_dim, ny = s->hii_dim, nz = s->hii_dim_z;
+    const size_t npad = (size_t)nx * ny * 2 * (size_t)(nz / 2 + 1);
+    memcpy(filtered, unfiltered, sizeof(float) * npad);
+    if (r_index > 0) {
+        /* filter_box takes float R, float R_param: filtering.c:308 */
+        int st = oracle_filter_box(filtered, nx, ny, nz, s->box_len, s->box_len_z, filter_type,
+                                   (float)s->R[r_index], (float)R_param);
+        if (st) return st;
+    }
+    oracle_fft_c2r(filtered, nx, ny, nz);
+    return C21CM_OK;
+}
+
+int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
+                        const IonizedBox *prev, const TsBox *ts, const HaloBox *halos,
+                        IonizedBox *box, c21cm_ionize_report *report) {
+    if (s->recomb_model != C21CM_RECOMB_NONE) return C21CM_VALUE_ERROR;
+    if (s->n_radii < 1 || s->n_radii > C21CM_MAX_RADII) return C21CM_VALUE_ERROR;
+    const int nx = s->hii_dim, ny = s->hii_dim, nz = s->hii_dim_z;
+    const size_t zpad = 2 * (size_t)(nz / 2 + 1);
+    const size_t npad = (size_t)nx * ny * zpad;
+    const size_t ntot = (size_t)nx * ny * nz;
+    const int lagrangian = (s->fcoll_mode == C21CM_FCOLL_STARS_GRID);
+    const int use_table =
+        (s->fcoll_mode == C21CM_FCOLL_TABLE_LINEAR || s->fcoll_mode == C21CM_FCOLL_TABLE_EXP);
+    if (use_table && !s->table_fn) return C21CM_VALUE_ERROR;
+    if (!lagrangian && !box->unnormalised_nion) return C21CM_VALUE_ERROR;
+    int status = C21CM_OK;
+
+    /* IonisationBox.c:1372-1378 */
+#pragma omp parallel for schedule(static)
+    for (long ct = 0; ct < (long)ntot; ct++) box->z_reion[ct] = -1.0;
+
+    /* IonisationBox.c:365-386: on the first snapshot the (caller-zeroed) previous box
+     * gets z_reion = -1 written INTO it */
+    if (s->first_snapshot && prev && prev->z_reion) {
+#pragma omp parallel for schedule(static)
+        for (long ct = 0; ct < (long)ntot; ct++) prev->z_reion[ct] = -1.0;
+    }
+
+    float *delta_unf = (float *)malloc(sizeof(float) * npad);
+    float *delta_fil = (float *)malloc(sizeof(float) * npad);
+    float *stars_unf = NULL, *stars_fil = NULL, *xe_unf = NULL, *xe_fil = NULL;
+    if (lagrangian) {
+        stars_unf = (float *)malloc(sizeof(float) * npad);
+        stars_fil = (float *)malloc(sizeof(float) * npad);
+    }
+    if (s->use_ts_fluct) {
+        xe_unf = (float *)malloc(sizeof(float) * npad);
+        xe_fil = (float *)malloc(sizeof(float) * npad);
+    }
+    float table[C21CM_NDELTA_TABLE];
+
+    /* IonisationBox.c:1480-1513 */
+    prepare_box(pf->density, delta_unf, nx, ny, nz, s->photoncons_adjustment_factor, -1., 1e6);
+    if (lagrangian) prepare_box(halos->n_ion, stars_unf, nx, ny, nz, 1., 0., 1e20);
+    if (s->use_ts_fluct) prepare_box(ts->xray_ionised_fraction, xe_unf, nx, ny, nz, 1., 0, 1.);
+
+    double last_mean = 0.;
+    for (int R_ct = s->n_radii; R_ct--;) {
+        if (R_ct < s->r_lowest) break; /* IonisationBox.c:1537-1541 */
+
+        status = copy_filter_c2r(delta_unf, delta_fil, s, R_ct, s->hii_filter, 0.);
+        if (!status && lagrangian)
+            status = copy_filter_c2r(stars_unf, stars_fil, s, R_ct, s->stars_filter,
+                                     s->mfp_meandens);
+        if (!status && s->use_ts_fluct)
+            status = copy_filter_c2r(xe_unf, xe_fil, s, R_ct, s->hii_filter, 0.);
+        if (status) break;
+
+        double tab_min = 0., tab_width = 1.;
+        if (!lagrangian) {
+            /* clip_and_get_extrema(delta_filtered, -1, 1e6): IonisationBox.c:668-699,711-713 */
+            double min_buf = delta_fil[0], max_buf = delta_fil[0];
+#pragma omp parallel for schedule(static) reduction(max : max_buf) reduction(min : min_buf)
+            for (long l = 0; l < (long)nx * ny; l++) {
+                for (int k = 0; k < nz; k++) {
+                    float curr = delta_fil[(size_t)l * zpad + k];
+                    delta_fil[(size_t)l * zpad + k] = fmaxf(fmin(curr, 1e6), -1);
+                    if (curr < min_buf) min_buf = curr;
+                    if (curr > max_buf) max_buf = curr;
+                }
+            }
+            double min_density = min_buf - 0.001, max_density = max_buf + 0.001;
+            if (use_table) {
+                status = s->table_fn(R_ct, min_density, max_density, table, s->table_user);
+                if (status) break;
+                tab_min = min_density;
+                tab_width = (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.);
+            }
+        }
+
+        /* calculate_fcoll_grid: IonisationBox.c:773-962 */
+        double f_coll_total = 0.;
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : f_coll_total) reduction(| : bad)
+        for (long l = 0; l < (long)nx * ny; l++) {
+            for (int k = 0; k < nz; k++) {
+                const size_t index_f = (size_t)l * zpad + k;
+                const size_t index_r = (size_t)l * nz + k;
+                delta_fil[index_f] = fmaxf(delta_fil[index_f], -1. + FRACT_FLOAT_ERR);
+                if (s->use_ts_fluct) {
+                    xe_fil[index_f] = fmaxf(xe_fil[index_f], 0.);
+                    xe_fil[index_f] = fminf(xe_fil[index_f], 0.999);
+                }
+                double Splined_Fcoll;
+                if (lagrangian) {
+                    stars_fil[index_f] = fmaxf(stars_fil[index_f], 0.0);
+                    Splined_Fcoll = stars_fil[index_f];
+                } else {
+                    double curr_dens = delta_fil[index_f];
+                    if (s->fcoll_mode == C21CM_FCOLL_ERFC) {
+                        Splined_Fcoll =
+                            oracle_fgtrm_bias_fast(s->growth_factor, curr_dens, s->sigma_minmass,
+                                                   s->sigma_maxmass[R_ct], s->delta_c);
+                        if (isnan(Splined_Fcoll)) bad |= 1;
+                    } else if (s->fcoll_mode == C21CM_FCOLL_TABLE_LINEAR) {
+                        Splined_Fcoll = eval_table_f(curr_dens, tab_min, tab_width, table);
+                    } else {
+                        Splined_Fcoll = exp(eval_table_f(curr_dens, tab_min, tab_width, table));
+                    }
+                    box->unnormalised_nion[index_r] = Splined_Fcoll;
+                }
+                f_coll_total += Splined_Fcoll;
+            }
+        }
+        if (bad) {
+            status = C21CM_VALUE_ERROR;
+            break;
+        }
+        double f_coll_grid_mean = f_coll_total / ntot;
+        /* IonisationBox.c:1566-1576 */
+        if (s->mass_dep_zeta) {
+            if (f_coll_grid_mean <= s->f_limit_acg) f_coll_grid_mean = s->f_limit_acg;
+        } else {
+            if (f_coll_grid_mean <= FRACT_FLOAT_ERR) f_coll_grid_mean = FRACT_FLOAT_ERR;
+        }
+        if (report) report->f_coll_grid_mean[R_ct] = f_coll_grid_mean;
+        last_mean = f_coll_grid_mean;
+
+        /* find_ionised_regions: IonisationBox.c:1008-1201 */
+        double mean_fix_term_acg = 1.;
+        if (s->fix_mean) mean_fix_term_acg = s->mean_f_coll / f_coll_grid_mean;
+#pragma omp parallel for schedule(static)
+        for (long l = 0; l < (long)nx * ny; l++) {
+            for (int k = 0; k < nz; k++) {
+                const size_t index_f = (size_t)l * zpad + k;
+                const size_t index_r = (size_t)l * nz + k;
+                double curr_dens, curr_fcoll, rec = 0., xHII_from_xrays, res_xH;
+                if (R_ct == 0)
+                    curr_dens = pf->density[index_r] * s->photoncons_adjustment_factor;
+                else
+                    curr_dens = delta_fil[index_f];
+                if (lagrangian)
+                    curr_fcoll = stars_fil[index_f];
+                else
+                    curr_fcoll = box->unnormalised_nion[index_r];
+                curr_fcoll = mean_fix_term_acg * curr_fcoll;
+                if (lagrangian) curr_fcoll *= 1 / (s->rhocrit_omb * (1 + curr_dens));
+                if (s->mass_dep_zeta) {
+                    if (curr_fcoll < s->f_limit_acg) curr_fcoll = s->f_limit_acg;
+                }
+                xHII_from_xrays = s->use_ts_fluct ? xe_fil[index_f] : 0.;
+
+                if (curr_fcoll * s->ion_eff_factor > (1. - xHII_from_xrays) * (1.0 + rec)) {
+                    float prev_zre = (s->first_snapshot || !prev || !prev->z_reion)
+                                         ? -1.0f
+                                         : prev->z_reion[index_r];
+                    if (prev_zre < 0)
+                        box->z_reion[index_r] = s->redshift;
+                    else
+                        box->z_reion[index_r] = prev_zre;
+                    box->neutral_fraction[index_r] = 0;
+                } else if (R_ct == 0 && (box->neutral_fraction[index_r] > TINY)) {
+                    res_xH = 1. - curr_fcoll * s->ion_eff_factor;
+                    if (!s->minimize_memory) {
+                        if (s->use_ts_fluct) {
+                            box->kinetic_temperature[index_r] =
+                                oracle_partially_ionized_temperature(
+                                    ts->kinetic_temp_neutral[index_r], res_xH, s->T_re);
+                        } else {
+                            box->kinetic_temperature[index_r] =
+                                oracle_partially_ionized_temperature(
+                                    s->TK_nofluct *
+                                        (1 + s->adia_TK_term * pf->density[index_r]),
+                                    res_xH, s->T_re);
+                        }
+                    }
+                    res_xH -= xHII_from_xrays;
+                    if (res_xH < 0)
+                        res_xH = 0;
+                    else if (res_xH > 1)
+                        res_xH = 1;
+                    box->neutral_fraction[index_r] = res_xH;
+                }
+            }
+        }
+    }
+
+    if (!status && !s->minimize_memory) {
+        /* set_ionized_temperatures: IonisationBox.c:1203-1256 */
+        int nonfinite = 0;
+#pragma omp parallel for schedule(static) reduction(| : nonfinite)
+        for (long idx = 0; idx < (long)ntot; idx++) {
+            if ((box->z_reion[idx] > 0) && (box->neutral_fraction[idx] < TINY)) {
+                box->kinetic_temperature[idx] = oracle_fully_ionized_temperature(
+                    box->z_reion[idx], s->stored_redshift, pf->density[idx], s->T_re);
+                if (s->use_ts_fluct) {
+                    if (box->kinetic_temperature[idx] < ts->kinetic_temp_neutral[idx])
+                        box->kinetic_temperature[idx] = ts->kinetic_temp_neutral[idx];
+                } else {
+                    float thistk = s->TK_nofluct * (1 + s->adia_TK_term * pf->density[idx]);
+                    if (box->kinetic_temperature[idx] < thistk)
+                        box->kinetic_temperature[idx] = thistk;
+                }
+            }
+            if (isfinite(box->kinetic_temperature[idx]) == 0) nonfinite |= 1;
+        }
+        if (nonfinite) status = C21CM_INFINITY_OR_NAN_ERROR;
+    }
+
+    if (!status) {
+        /* IonisationBox.c:1594-1615 */
+        double global_xH = 0;
+#pragma omp parallel for schedule(static) reduction(+ : global_xH)
+        for (long ct = 0; ct < (long)ntot; ct++) global_xH += box->neutral_fraction[ct];
+        global_xH /= (float)ntot;
+        if (isfinite(global_xH) == 0) status = C21CM_INFINITY_OR_NAN_ERROR;
+        if (report) {
+            report->global_xH = global_xH;
+            /* IonisationBox.c:1623-1628 */
+            report->mean_f_coll_out = s->fix_mean ? s->mean_f_coll : last_mean;
+        }
+        box->mean_f_coll = s->fix_mean ? s->mean_f_coll : last_mean;
+        box->mean_f_coll_MINI = 0.;
+    }
+
+    free(delta_unf);
+    free(delta_fil);
+    free(stars_unf);
+    free(stars_fil);
+    free(xe_unf);
+    free(xe_fil);
+    return status;
+}

@@ -1,0 +1,96 @@
+"""GPU parity: device FFT and k-space filters vs the CPU oracle (through the C ABI)."""
+
+import importlib
+
+import numpy as np
+import pytest
+
+from test_oracle_fft_filter import HII_DIM, BOX_LEN, delta_function_checks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(gpu_lib):
+    return importlib.import_module("21cmfast_amd.grid_api")
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (35, 35, 35), (50, 50, 50), (64, 64, 64),
+                                   (70, 70, 35), (128, 128, 128), (150, 150, 150)])
+def test_fft_roundtrip_and_spectrum(api, oracle, shape):
+    import torch
+
+    nx, ny, nz = shape
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal(shape).astype(np.float32)
+    pad = np.zeros((nx, ny, 2 * (nz // 2 + 1)), np.float32)
+    pad[:, :, :nz] = a
+    d = torch.from_numpy(pad).cuda()
+    api.fft_r2c(d, nx, ny, nz)
+    spec = d.cpu().numpy().view(np.complex64).reshape(nx, ny, nz // 2 + 1)
+    ref = oracle.fft_r2c(a)
+    scale = np.abs(ref).max()
+    assert np.abs(spec - ref).max() <= 2e-5 * scale  # float32 FFT vs float32 FFT
+    api.fft_c2r(d, nx, ny, nz)
+    back = d.cpu().numpy()[:, :, :nz] / (nx * ny * nz)
+    np.testing.assert_allclose(back, a, atol=2e-5)
+
+
+def test_fft_linearity_large(api):
+    """Size-independent property at a bench-scale box: FFT(a + 2b) = FFT(a) + 2 FFT(b)."""
+    import torch
+
+    n = 256
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.randn((n, n, n + 2), generator=g, device="cuda")
+    b = torch.randn((n, n, n + 2), generator=g, device="cuda")
+    c = a + 2 * b
+    for t in (a, b, c):
+        api.fft_r2c(t, n, n, n)
+    err = (c - (a + 2 * b)).abs().max().item()
+    assert err <= 1e-4 * c.abs().max().item()
+
+
+@pytest.mark.parametrize("R", [1.5, 5.0, 10.0, 20.0])
+@pytest.mark.parametrize("filter_type", [0, 1, 2, 3, 4])
+def test_delta_function_known_answer_device(api, filter_type, R):
+    """The reference's analytic filter test (tests/test_filtering.py:111-236) on the HIP path."""
+    delta_function_checks(api.filter_grid, filter_type, R)
+
+
+@pytest.mark.parametrize("shape", [(50, 50, 50), (64, 64, 64), (48, 48, 96)])
+@pytest.mark.parametrize("filter_type,R,R_param", [(0, 3.0, 0.0), (0, 12.0, 0.0), (1, 6.0, 0.0),
+                                                   (2, 4.0, 0.0), (3, 7.5, 37.66), (4, 5.0, 9.0)])
+def test_filter_matches_oracle_random_box(api, oracle, shape, filter_type, R, R_param):
+    rng = np.random.default_rng(11)
+    box = rng.standard_normal(shape).astype(np.float32)
+    box_len = 1.5 * shape[0]
+    box_len_z = box_len * shape[2] / shape[0]
+    got = api.filter_grid(box, box_len, filter_type, R, R_param, box_len_z=box_len_z)
+    ref = oracle.filter_grid(box, box_len, filter_type, R, R_param, box_len_z=box_len_z)
+    # tolerance: float32 FFT round-off on O(1)-amplitude data (rtol 1e-5 of the field scale)
+    np.testing.assert_allclose(got, ref, atol=2e-5 * np.abs(ref).max() + 1e-7, rtol=1e-4)
+
+
+def test_exported_test_filter_hook(gpu_lib, oracle, pkg):
+    """`test_filter` through the reference ABI: broadcast globals, float in, double out."""
+    import ctypes as C
+
+    S = pkg.structs
+    n = 32
+    so = S.default_simulation_options(HII_DIM=n, DIM=2 * n, BOX_LEN=48.0)
+    mo, cp = S.default_matter_options(), S.default_cosmo_params()
+    ap, ao, ct = S.default_astro_params(), S.default_astro_options(), S.default_cosmo_tables()
+    gpu_lib.Broadcast_struct_global_all(C.byref(so), C.byref(mo), C.byref(cp), C.byref(ap),
+                                        C.byref(ao), C.byref(ct))
+    rng = np.random.default_rng(2)
+    box = rng.standard_normal((n, n, n)).astype(np.float32)
+    res = np.zeros((n, n, n), np.float64)
+    st = gpu_lib.test_filter(box.ctypes.data_as(C.c_void_p), 5.0, 0.0, 0.0, 0,
+                             res.ctypes.data_as(C.c_void_p))
+    assert st == 0
+    ref = oracle.filter_grid(box, 48.0, 0, 5.0)
+    np.testing.assert_allclose(res, ref, atol=2e-5 * np.abs(ref).max())
+    # undefined filter -> ValueError code 3 (reference Throw(ValueError), filtering.c:42-44)
+    assert gpu_lib.test_filter(box.ctypes.data_as(C.c_void_p), 5.0, 0.0, 0.0, 7,
+                               res.ctypes.data_as(C.c_void_p)) == 3
