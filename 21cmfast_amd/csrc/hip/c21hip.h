@@ -42,6 +42,18 @@ void c21hip_fft_release(void);
 /* 1 when the hand-written power-of-two transform is used, 0 for rocFFT */
 int c21hip_fft_is_native(int nx, int ny, int nz);
 
+/* ---- fft_native.hip : power-of-two transform on the split k-space layout ----
+ * split layout: complex main[nx][ny][nz/2] followed by the Nyquist plane nyq[nx][ny]. */
+size_t c21hip_split_floats(int nx, int ny, int nz);
+int c21hip_padded_to_split(const float *padded_c, float *split, int nx, int ny, int nz,
+                           void *stream);
+/* [W(kR) x] inverse transform: split_src -> (split_work) -> real rows of out_zstride floats.
+ * Fuses memcpy + filter_box + dft_c2r_cube (IonisationBox.c:577-663). */
+int c21hip_split_filter_c2r(const float *split_src, float *split_work, float *real_out,
+                            long out_zstride, int nx, int ny, int nz, double box_len,
+                            double box_len_z, int filter_type, float R, float R_param, int apply,
+                            void *stream);
+
 /* ---- grid_kernels.hip : generic sweeps ---- */
 /* padded[l][k] = clip(dense[l][k] * factor, lo, hi); pad columns zeroed.
  * reference: IonisationBox.c:333-350 */

@@ -125,7 +125,7 @@ extern "C" int c21hip_fft_is_native(int nx, int ny, int nz) {
 }
 
 extern "C" int c21hip_fft_r2c(float *padded, int nx, int ny, int nz, void *stream) {
-    if (c21hip_fft_is_native(nx, ny, nz)) return c21hip_native_fft_r2c(padded, nx, ny, nz, stream);
+    // forward transforms run 2-3 times per Compute* call (pre-loop only): rocFFT for now
     return run_rocfft(padded, nx, ny, nz, 0, stream);
 }
 

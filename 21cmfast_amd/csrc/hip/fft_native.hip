@@ -1,21 +1,748 @@
-// fft_native.hip -- hand-written power-of-two 3-D real FFT for gfx950 (placeholder:
-// reports "unsupported" so fft.hip routes every size through rocFFT).
+// fft_native.hip -- hand-written power-of-two 3-D real FFT for gfx950 with the k-space
+// filter fused into its first pass.
+//
+// Replaces, for power-of-two boxes, the reference's
+//   memcpy -> filter_box -> dft_c2r_cube        (src/py21cmfast/src/IonisationBox.c:577-663,
+//                                                 filtering.c:308-394, dft.c:18-44)
+// by three HBM sweeps per grid (rocFFT needs three as well, but unfused and at ~0.75 TB/s):
+//
+//   pass X  lines along x (stride ny*nz/2), W(kR) applied while loading, src -> work
+//   pass Y  lines along y (stride nz/2), in place on work
+//   pass Z  complex-to-real along z (contiguous lines) via a half-length complex FFT,
+//           work -> real padded/dense grid
+//
+// Internal "split" k-space layout (all complex float2):
+//   main[nx][ny][nz/2]   the k_z = 0 .. nz/2-1 columns  -> rows of nz/2*8 B, 128-B aligned
+//   nyq [nx][ny]         the k_z = nz/2 (Nyquist) plane, stored after main
+// FFTW's in-place padded layout has rows of (nz/2+1) complex = odd length, which would
+// misalign every row and straddle cache lines; splitting the Nyquist plane off keeps all
+// tile accesses aligned 128-B segments and wastes no bytes.
+//
+// Each workgroup (256 threads = 4 wavefronts) owns a tile of TZ = 16 adjacent columns x
+// the full line length N in LDS (N*128 B: 64 KB at N = 512, two workgroups per CU), and
+// runs a Stockham autosort FFT on it with radix-8/4/2 register butterflies.  Lanes span
+// the 16 columns first, so every LDS access of a 16-lane group is one contiguous 128-B
+// row: bank-conflict free without padding.  Between stages the data stay in LDS; each
+// stage is read-all / barrier / write-all, in place.
+//
+// Window evaluation (double sincos per k-cell, as the reference does) is the only
+// non-trivial ALU work.  |k| is even in k_x and k_y, so a thread evaluates W once for the
+// rows (kx, nx-kx) and the workgroup reuses it for the tile pair (ky, ny-ky): 1/4 of the
+// evaluations of a naive sweep, bit-identical values.
 #include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "c21hip.h"
 #include "c21cm_abi.h"
 
-extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz) {
-    (void)nx;
-    (void)ny;
-    (void)nz;
+namespace {
+constexpr int kBlock = 256;
+constexpr int TZ = 16;  // columns per tile (128 B of float2)
+
+#define LAUNCH_CHECK()                                                                  \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            c21hip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                       \
+            return C21CM_IO_ERROR;                                                      \
+        }                                                                               \
+    } while (0)
+
+// ------------------------------------------------------------------ complex helpers
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// multiply by +i (SIGN > 0) or -i (SIGN < 0)
+template <int SIGN>
+__device__ __forceinline__ float2 mul_i(float2 a) {
+    return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+// Small DFTs, y_j = sum_k a_k exp(SIGN * 2 pi i j k / R), outputs in natural order.
+template <int R, int SIGN>
+struct Dft;
+template <int SIGN>
+struct Dft<2, SIGN> {
+    __device__ __forceinline__ static void run(float2 *v) {
+        float2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+template <int SIGN>
+struct Dft<4, SIGN> {
+    __device__ __forceinline__ static void run(float2 *v) {
+        float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        float2 t2 = cadd(v[1], v[3]), t3 = mul_i<SIGN>(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2);
+        v[2] = csub(t0, t2);
+        v[1] = cadd(t1, t3);
+        v[3] = csub(t1, t3);
+    }
+};
+template <int SIGN>
+struct Dft<8, SIGN> {
+    __device__ __forceinline__ static void run(float2 *v) {
+        float2 e[4] = {v[0], v[2], v[4], v[6]};
+        float2 o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<4, SIGN>::run(e);
+        Dft<4, SIGN>::run(o);
+        const float h = 0.70710678118654752440f;
+        // W8^1 = (1 + SIGN i)/sqrt2, W8^2 = SIGN i, W8^3 = (-1 + SIGN i)/sqrt2
+        float2 o1 = SIGN > 0 ? make_float2(h * (o[1].x - o[1].y), h * (o[1].x + o[1].y))
+                             : make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+        float2 o2 = mul_i<SIGN>(o[2]);
+        float2 o3 = SIGN > 0 ? make_float2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y))
+                             : make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+        v[0] = cadd(e[0], o[0]);
+        v[4] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], o1);
+        v[5] = csub(e[1], o1);
+        v[2] = cadd(e[2], o2);
+        v[6] = csub(e[2], o2);
+        v[3] = cadd(e[3], o3);
+        v[7] = csub(e[3], o3);
+    }
+};
+
+// ------------------------------------------------------------------ Stockham stages in LDS
+// The tile lives in LDS as tile[point * ROW + column], ROW >= COLS.  One stage of radix R
+// with `s` = product of the radices already applied (log2s its log):
+//   butterfly b in [0, N/R): inputs  tile[b + k*N/R],          k = 0..R-1
+//                            outputs tile[q + s*R*p + s*j] *= tw[p*s*j],  p = b/s, q = b%s
+// `tw` holds exp(-2 pi i t / N), t = 0..N-1 (conjugated for SIGN > 0).
+template <int N, int COLS, int ROW, int R, int SIGN>
+__device__ __forceinline__ void stockham_stage(float2 *tile, const float2 *tw, int log2s) {
+    constexpr int NB = N / R;
+    constexpr int ITEMS = NB * COLS;
+    constexpr int PER = (ITEMS + kBlock - 1) / kBlock;
+    float2 v[PER][R];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = threadIdx.x + kBlock * u;
+        if (ITEMS % kBlock == 0 || i < ITEMS) {
+            const int col = i % COLS, b = i / COLS;
+#pragma unroll
+            for (int k = 0; k < R; k++) v[u][k] = tile[(b + k * NB) * ROW + col];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int i = threadIdx.x + kBlock * u;
+        if (ITEMS % kBlock == 0 || i < ITEMS) {
+            const int col = i % COLS, b = i / COLS;
+            const int p = b >> log2s, q = b & ((1 << log2s) - 1);
+            const int ps = p << log2s;
+            Dft<R, SIGN>::run(v[u]);
+            const int base = q + ((R * p) << log2s);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                float2 o = v[u][j];
+                if (j > 0) {
+                    float2 w = tw[ps * j];
+                    if (SIGN > 0) w.y = -w.y;
+                    o = cmul(o, w);
+                }
+                tile[(base + (j << log2s)) * ROW + col] = o;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Full length-N transform of every column of the tile (radix plan 8,8,..,{4,2}).
+template <int N, int COLS, int ROW, int SIGN>
+__device__ __forceinline__ void fft_tile(float2 *tile, const float2 *tw) {
+    static_assert((N & (N - 1)) == 0 && N >= 8, "power-of-two line length");
+    int log2s = 0;
+    constexpr int L = __builtin_ctz(N);
+    constexpr int N8 = L / 3;   // radix-8 stages
+    constexpr int REM = L % 3;  // 0, 1 (radix 2) or 2 (radix 4)
+#pragma unroll
+    for (int st = 0; st < N8; st++) {
+        stockham_stage<N, COLS, ROW, 8, SIGN>(tile, tw, log2s);
+        log2s += 3;
+    }
+    if (REM == 1) stockham_stage<N, COLS, ROW, 2, SIGN>(tile, tw, log2s);
+    if (REM == 2) stockham_stage<N, COLS, ROW, 4, SIGN>(tile, tw, log2s);
+}
+
+// ------------------------------------------------------------------ window functions
+// reference: filtering.c:18-32, 80-117; identical to grid_kernels.hip (kept in this TU so the
+// compiler can inline them into the fused pass).
+struct ExpMfpConsts {
+    double R, ratio, ratio2, ratio3, exp_term, ts_0, ts_2;
+};
+struct FilterParams {
+    int type;  // -1: no filter
+    float R, R_param;
+    double dkx, dky, dkz;
+    ExpMfpConsts mfp;
+};
+
+__device__ __forceinline__ double w_tophat(double kR) {
+    if (kR < 1e-4) return 1 - kR * kR / 10;
+    double s, c;
+    sincos(kR, &s, &c);
+    return 3.0 / (kR * kR * kR) * (s - c * kR);
+}
+__device__ __forceinline__ double w_exp_mfp(double k, const ExpMfpConsts &c) {
+    const double kR = k * c.R;
+    if (kR < 1e-4) return c.ts_0 + c.ts_2 * kR * kR;
+    double s, co;
+    sincos(kR, &s, &co);
+    double f = (kR * kR * c.ratio2 + 2 * c.ratio + 1) * c.ratio * co;
+    f += (kR * kR * (c.ratio2 - c.ratio3) + c.ratio + 1) * s / kR;
+    f *= c.exp_term;
+    f -= 2 * c.ratio2;
+    const double d = kR * c.ratio * kR * c.ratio + 1;
+    f *= -3 * c.ratio / (d * d);
+    return f;
+}
+__device__ __forceinline__ double w_shell(double k, double R_inner, double R_outer) {
+    const double kRi = k * R_inner, kRo = k * R_outer;
+    if (kRo < 1e-4) {
+        const double q = R_inner / R_outer;
+        const double q3 = q * q * q;
+        return 1. - kRo * kRo / 10 * (q3 * q * q - 1) / (q3 - 1);
+    }
+    double si, ci, so, co;
+    sincos(kRi, &si, &ci);
+    sincos(kRo, &so, &co);
+    return 3.0 / (kRo * kRo * kRo - kRi * kRi * kRi) * (so - co * kRo - si + ci * kRi);
+}
+__device__ __forceinline__ float k_of(int n, int dim, double dk) {
+    return (n > dim / 2) ? (float)((double)(n - dim) * dk) : (float)((double)n * dk);
+}
+__device__ __forceinline__ double window_of(const FilterParams &p, float k_x, float k_y,
+                                            float k_z) {
+    const float k_mag_sq =
+        __fadd_rn(__fadd_rn(__fmul_rn(k_x, k_x), __fmul_rn(k_y, k_y)), __fmul_rn(k_z, k_z));
+    switch (p.type) {
+        case 0: {
+            float kR = (float)(sqrt((double)k_mag_sq) * (double)p.R);
+            return w_tophat((double)kR);
+        }
+        case 1: {
+            float kR = (float)(sqrt((double)k_mag_sq) * (double)p.R);
+            return ((double)kR * 0.413566994 > 1) ? 0. : 1.;
+        }
+        case 2: {
+            float kR = __fmul_rn(__fmul_rn(k_mag_sq, p.R), p.R);
+            return exp(-0.643 * 0.643 * (double)kR / 2.);
+        }
+        case 3:
+            return w_exp_mfp(sqrt((double)k_mag_sq), p.mfp);
+        default:
+            return w_shell(sqrt((double)k_mag_sq), (double)p.R, (double)p.R_param);
+    }
+}
+
+// ------------------------------------------------------------------ pass X / pass Y
+struct LinePassArgs {
+    const float2 *src;
+    float2 *dst;
+    long line_stride;   // elements between successive points of a line
+    long outer_stride;  // elements between successive outer indices
+    long col_stride;    // elements between adjacent columns of a tile (1 = vector loads)
+    int n_outer;        // outer index count (tiles along the non-transformed, non-column axis)
+    int n_ctiles;       // column tiles (columns / TZ)
+    int pair_outer;     // 1: a workgroup handles the mirror pair (o, n_outer - o)
+    int filter_axis;    // 0: columns are k_z, outer is k_y (main block)
+                        // 1: columns are k_y, k_z fixed at nz/2 (Nyquist plane)
+    int n_y, n_z;       // grid dims for the wavenumbers
+    float out_scale;    // applied at store (1 = none)
+    FilterParams fp;
+};
+
+// Tile loader geometry: thread t owns the float4 column pair c4 = t % 8 of the row pairs
+//   row_a = r0 + 32u  in [0, N/2)   and its mirror   row_b = N - row_a  (N/2 when row_a = 0),
+// r0 = t / 8, u = 0 .. N/64-1.  Mirror rows share |k_x|, hence the window value.
+template <int N>
+__device__ __forceinline__ int mirror_row(int row_a) {
+    return row_a == 0 ? N / 2 : N - row_a;
+}
+
+template <int N, int SIGN, bool FILTER>
+__global__ void __launch_bounds__(kBlock)
+line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
+    static_assert(N >= 64, "tile loader needs N >= 64");
+    extern __shared__ float4 lds_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
+    float2 *tw = tile + N * TZ;                          // [N]
+    for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
+
+    const int ct = blockIdx.x % a.n_ctiles;
+    const int og = blockIdx.x / a.n_ctiles;
+    // members of this workgroup's outer group: the mirror pair (og, n_outer - og), or one
+    // self-mirrored index (0, n_outer/2), or just og when pairing is off
+    int members[2];
+    int n_members = 1;
+    members[0] = og;
+    if (a.pair_outer && og != 0 && 2 * og != a.n_outer) {
+        members[1] = a.n_outer - og;
+        n_members = 2;
+    }
+    constexpr int NP = N / 64;  // row pairs per thread
+    const int r0 = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+    const bool vec = (a.col_stride == 1);
+
+    // window values for this thread's row pairs x 2 columns, evaluated once per group
+    constexpr int NW = FILTER ? NP : 1;
+    double w[NW][2], w_half[2] = {1., 1.};
+    if (FILTER) {
+        const int col0 = ct * TZ + 2 * c4;
+        float ky[2], kz[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if (a.filter_axis == 0) {
+                ky[e] = k_of(members[0], a.n_y, a.fp.dky);
+                kz[e] = (float)((double)(col0 + e) * a.fp.dkz);
+            } else {
+                ky[e] = k_of(col0 + e, a.n_y, a.fp.dky);
+                kz[e] = (float)((double)(a.n_z / 2) * a.fp.dkz);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            const float kx = k_of(r0 + 32 * u, N, a.fp.dkx);
+#pragma unroll
+            for (int e = 0; e < 2; e++) w[u][e] = window_of(a.fp, kx, ky[e], kz[e]);
+        }
+        if (r0 == 0) {
+            const float kx = k_of(N / 2, N, a.fp.dkx);
+#pragma unroll
+            for (int e = 0; e < 2; e++) w_half[e] = window_of(a.fp, kx, ky[e], kz[e]);
+        }
+    }
+
+    for (int mi = 0; mi < n_members; mi++) {
+        const long base = (long)members[mi] * a.outer_stride + (long)ct * TZ * a.col_stride;
+        // ---- load: every request is in flight before the first use
+        float4 reg[2 * NP];
+#pragma unroll
+        for (int u = 0; u < 2 * NP; u++) {
+            const int row_a = r0 + 32 * (u >> 1);
+            const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
+            const long off = base + (long)row * a.line_stride;
+            if (vec) {
+                reg[u] = *reinterpret_cast<const float4 *>(a.src + off + 2 * c4);
+            } else {
+                float2 e0 = a.src[off + (long)(2 * c4) * a.col_stride];
+                float2 e1 = a.src[off + (long)(2 * c4 + 1) * a.col_stride];
+                reg[u] = make_float4(e0.x, e0.y, e1.x, e1.y);
+            }
+        }
+        if (mi > 0) __syncthreads();  // the previous member's stores have left the tile
+#pragma unroll
+        for (int u = 0; u < 2 * NP; u++) {
+            const int row_a = r0 + 32 * (u >> 1);
+            const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
+            float4 v = reg[u];
+            if (FILTER) {
+                const bool half = (u & 1) && row_a == 0;  // row N/2 has its own |k_x|
+                const double w0 = half ? w_half[0] : w[u >> 1][0];
+                const double w1 = half ? w_half[1] : w[u >> 1][1];
+                v.x = (float)((double)v.x * w0);
+                v.y = (float)((double)v.y * w0);
+                v.z = (float)((double)v.z * w1);
+                v.w = (float)((double)v.w * w1);
+            }
+            *reinterpret_cast<float4 *>(tile + row * TZ + 2 * c4) = v;
+        }
+        __syncthreads();
+        fft_tile<N, TZ, TZ, SIGN>(tile, tw);
+        // ---- store
+#pragma unroll
+        for (int u = 0; u < 2 * NP; u++) {
+            const int row_a = r0 + 32 * (u >> 1);
+            const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
+            float4 v = *reinterpret_cast<const float4 *>(tile + row * TZ + 2 * c4);
+            if (a.out_scale != 1.0f) {
+                v.x *= a.out_scale;
+                v.y *= a.out_scale;
+                v.z *= a.out_scale;
+                v.w *= a.out_scale;
+            }
+            const long off = base + (long)row * a.line_stride;
+            if (vec) {
+                *reinterpret_cast<float4 *>(a.dst + off + 2 * c4) = v;
+            } else {
+                a.dst[off + (long)(2 * c4) * a.col_stride] = make_float2(v.x, v.y);
+                a.dst[off + (long)(2 * c4 + 1) * a.col_stride] = make_float2(v.z, v.w);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pass Z (complex -> real)
+// A real line of NZ points from its NZ/2+1 Hermitian coefficients via ONE complex FFT of
+// length H = NZ/2:
+//   E[k] = X[k] + conj(X[H-k]),  O[k] = (X[k] - conj(X[H-k])) * exp(+2 pi i k / NZ)
+//   Z[k] = E[k] + i O[k]   ->   z = FFT_H^{+}(Z),   x[2j] = Re z[j],  x[2j+1] = Im z[j]
+// (imaginary parts of X[0] and X[H] are ignored, as any c2r transform does).
+// LZ = 16 consecutive lines per workgroup; LDS tile[k][line] with a row of LZ+1 so that both
+// the transposing fill (lanes along k) and the FFT (lanes along line) are conflict free.
+constexpr int LZ = 16;
+constexpr int ZROW = LZ + 1;
+
+struct ZPassArgs {
+    const float2 *main;  // [lines][H]
+    const float2 *nyq;   // [lines]
+    float *out;          // real rows of out_zstride floats
+    long out_zstride;
+    float out_scale;
+};
+
+template <int NZ>
+__global__ void __launch_bounds__(kBlock)
+z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
+             const float2 *__restrict__ twN_global) {
+    constexpr int H = NZ / 2;
+    extern __shared__ float4 lds_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [H][ZROW]
+    float2 *twH = tile + H * ZROW;                       // [H]
+    float2 *twN = twH + H;                               // [H/2 + 1]
+    for (int t = threadIdx.x; t < H; t += kBlock) twH[t] = twH_global[t];
+    for (int t = threadIdx.x; t <= H / 2; t += kBlock) twN[t] = twN_global[t];
+
+    const long l0 = (long)blockIdx.x * LZ;
+    // ---- load 16 contiguous lines, transposing into tile[k][line]
+    constexpr int NF4 = LZ * H / 2;  // float4 count
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.main + l0 * H);
+    float4 reg[(NF4 + kBlock - 1) / kBlock];
+#pragma unroll
+    for (int u = 0; u < (NF4 + kBlock - 1) / kBlock; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        if (NF4 % kBlock == 0 || f < NF4) reg[u] = src4[f];
+    }
+#pragma unroll
+    for (int u = 0; u < (NF4 + kBlock - 1) / kBlock; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        if (NF4 % kBlock == 0 || f < NF4) {
+            const int e = 2 * f;
+            const int li = e / H, k = e % H;
+            tile[k * ZROW + li] = make_float2(reg[u].x, reg[u].y);
+            tile[(k + 1) * ZROW + li] = make_float2(reg[u].z, reg[u].w);
+        }
+    }
+    __syncthreads();
+    // ---- Hermitian pre-processing, pairs (k, H-k) owned by one thread
+    constexpr int NPRE = (H / 2 + 1) * LZ;
+    for (int i = threadIdx.x; i < NPRE; i += kBlock) {
+        const int li = i % LZ, k = i / LZ;
+        if (k == 0) {
+            const float x0 = tile[li].x;
+            const float xh = a.nyq[l0 + li].x;
+            tile[li] = make_float2(x0 + xh, x0 - xh);
+        } else {
+            const float2 A = tile[k * ZROW + li], B = tile[(H - k) * ZROW + li];
+            const float2 E = make_float2(A.x + B.x, A.y - B.y);  // A + conj(B)
+            const float2 D = make_float2(A.x - B.x, A.y + B.y);  // A - conj(B)
+            float2 w = twN[k];
+            w.y = -w.y;  // exp(+2 pi i k / NZ)
+            const float2 O = cmul(D, w);
+            tile[k * ZROW + li] = make_float2(E.x - O.y, E.y + O.x);
+            tile[(H - k) * ZROW + li] = make_float2(E.x + O.y, O.x - E.y);
+        }
+    }
+    __syncthreads();
+    fft_tile<H, LZ, ZROW, +1>(tile, twH);
+    // ---- store: lanes along j, one float2 = (x[2j], x[2j+1])
+    constexpr int NOUT = LZ * H;
+#pragma unroll
+    for (int u = 0; u < NOUT / kBlock; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        const int li = f / H, j = f % H;
+        float2 v = tile[j * ZROW + li];
+        if (a.out_scale != 1.0f) {
+            v.x *= a.out_scale;
+            v.y *= a.out_scale;
+        }
+        reinterpret_cast<float2 *>(a.out + (l0 + li) * a.out_zstride)[j] = v;
+    }
+}
+
+// ------------------------------------------------------------------ layout conversion
+// FFTW-style padded half-spectrum [lines][H+1] -> split (main [lines][H], nyq [lines])
+__global__ void __launch_bounds__(kBlock)
+padded_to_split_kernel(const float2 *__restrict__ padded, float2 *__restrict__ main,
+                       float2 *__restrict__ nyq, long nlines, int H) {
+    const long total = nlines * (long)(H + 1);
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (long)gridDim.x * kBlock) {
+        const long line = i / (H + 1);
+        const int k = (int)(i - line * (H + 1));
+        const float2 v = padded[i];
+        if (k < H)
+            main[line * H + k] = v;
+        else
+            nyq[line] = v;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct Twiddles {
+    float2 *dev = nullptr;
+};
+std::map<int, Twiddles> g_tw;
+std::mutex g_tw_mutex;
+
+// exp(-2 pi i t / n), t = 0..n-1, computed in double
+const float2 *twiddles(int n) {
+    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    auto it = g_tw.find(n);
+    if (it != g_tw.end()) return it->second.dev;
+    std::vector<float2> host(n);
+    for (int t = 0; t < n; t++) {
+        const double ang = -2.0 * M_PI * (double)t / (double)n;
+        host[t] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    Twiddles tw;
+    if (hipMalloc(&tw.dev, sizeof(float2) * n) != hipSuccess) return nullptr;
+    if (hipMemcpy(tw.dev, host.data(), sizeof(float2) * n, hipMemcpyHostToDevice) != hipSuccess)
+        return nullptr;
+    g_tw[n] = tw;
+    return tw.dev;
+}
+
+bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+template <int N, int SIGN>
+int launch_line_pass(const LinePassArgs &a, bool filter, hipStream_t stream) {
+    const float2 *tw = twiddles(N);
+    if (!tw) {
+        c21hip_set_error("native FFT: twiddle table allocation failed");
+        return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    const size_t lds = sizeof(float2) * ((size_t)N * TZ + N);
+    const int groups = a.pair_outer ? (a.n_outer / 2 + 1) : a.n_outer;
+    const dim3 grid((unsigned)(groups * a.n_ctiles));
+    if (filter) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)line_pass_kernel<N, SIGN, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, true>), grid, dim3(kBlock), lds, stream, a,
+                           tw);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)line_pass_kernel<N, SIGN, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, false>), grid, dim3(kBlock), lds, stream, a,
+                           tw);
+    }
+    LAUNCH_CHECK();
     return 0;
 }
+
+template <int SIGN>
+int dispatch_line_pass(int n, const LinePassArgs &a, bool filter, hipStream_t stream) {
+    switch (n) {
+        case 64: return launch_line_pass<64, SIGN>(a, filter, stream);
+        case 128: return launch_line_pass<128, SIGN>(a, filter, stream);
+        case 256: return launch_line_pass<256, SIGN>(a, filter, stream);
+        case 512: return launch_line_pass<512, SIGN>(a, filter, stream);
+        case 1024: return launch_line_pass<1024, SIGN>(a, filter, stream);
+        default:
+            c21hip_set_error("native FFT: unsupported line length %d", n);
+            return C21CM_VALUE_ERROR;
+    }
+}
+
+template <int NZ>
+int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
+    constexpr int H = NZ / 2;
+    const float2 *twH = twiddles(H);
+    const float2 *twN = twiddles(NZ);
+    if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+    const size_t lds = sizeof(float2) * ((size_t)H * ZROW + H + H / 2 + 1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)z_c2r_kernel<NZ>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((z_c2r_kernel<NZ>), dim3((unsigned)(nlines / LZ)), dim3(kBlock), lds, stream,
+                       a, twH, twN);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) {
+    switch (nz) {
+        case 64: return launch_z_c2r<64>(a, nlines, stream);
+        case 128: return launch_z_c2r<128>(a, nlines, stream);
+        case 256: return launch_z_c2r<256>(a, nlines, stream);
+        case 512: return launch_z_c2r<512>(a, nlines, stream);
+        case 1024: return launch_z_c2r<1024>(a, nlines, stream);
+        case 2048: return launch_z_c2r<2048>(a, nlines, stream);
+        default:
+            c21hip_set_error("native FFT: unsupported z length %d", nz);
+            return C21CM_VALUE_ERROR;
+    }
+}
+
+void fill_filter(FilterParams &fp, int filter_type, float R, float R_param, double box_len,
+                 double box_len_z) {
+    fp.type = filter_type;
+    fp.R = R;
+    fp.R_param = R_param;
+    fp.dkx = 2.0 * M_PI / box_len;
+    fp.dky = 2.0 * M_PI / box_len;
+    fp.dkz = 2.0 * M_PI / box_len_z;
+    fp.mfp = ExpMfpConsts{};
+    if (filter_type == 3) {
+        // filtering.c:320-322 (float division, double exp) and :83-94
+        const double exp_term = exp((double)(-R / R_param));
+        const double ratio = (double)R_param / (double)R;
+        fp.mfp.R = (double)R;
+        fp.mfp.ratio = ratio;
+        fp.mfp.ratio2 = pow(ratio, 2);
+        fp.mfp.ratio3 = pow(ratio, 3);
+        fp.mfp.exp_term = exp_term;
+        fp.mfp.ts_0 =
+            6 * pow(ratio, 3) - exp_term * (6 * pow(ratio, 3) + 6 * pow(ratio, 2) + 3 * ratio);
+        fp.mfp.ts_2 =
+            exp_term * (2 * pow(ratio, 2) + 0.5 * ratio) - 2 * fp.mfp.ts_0 * pow(ratio, 2);
+    }
+}
+}  // namespace
+
+// nx, ny in {64..1024}, nz in {64..2048}, all powers of two
+extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz) {
+    return pow2(nx) && pow2(ny) && pow2(nz) && nx >= 64 && nx <= 1024 && ny >= 64 &&
+           ny <= 1024 && nz >= 64 && nz <= 2048;
+}
+
+extern "C" size_t c21hip_split_floats(int nx, int ny, int nz) {
+    return 2 * ((size_t)nx * ny * (size_t)(nz / 2) + (size_t)nx * ny);
+}
+
+extern "C" int c21hip_padded_to_split(const float *padded_c, float *split, int nx, int ny, int nz,
+                                      void *stream) {
+    const long nlines = (long)nx * ny;
+    const int H = nz / 2;
+    float2 *main = reinterpret_cast<float2 *>(split);
+    float2 *nyq = main + nlines * H;
+    size_t blocks = ((size_t)nlines * (H + 1) + kBlock - 1) / kBlock;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(padded_to_split_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
+                       (hipStream_t)stream, reinterpret_cast<const float2 *>(padded_c), main, nyq,
+                       nlines, H);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// Inverse transform of a split spectrum: [W(kR) x] pass X (src -> work), pass Y (work, in
+// place), pass Z (work -> real rows of out_zstride floats).  src == work is allowed.
+extern "C" int c21hip_split_filter_c2r(const float *split_src, float *split_work, float *real_out,
+                                       long out_zstride, int nx, int ny, int nz, double box_len,
+                                       double box_len_z, int filter_type, float R, float R_param,
+                                       int apply, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c21hip_native_fft_supported(nx, ny, nz)) {
+        c21hip_set_error("native FFT does not support %dx%dx%d", nx, ny, nz);
+        return C21CM_VALUE_ERROR;
+    }
+    if (apply && (filter_type < 0 || filter_type > 4)) {
+        c21hip_set_error("filter type %d is not implemented on the device", filter_type);
+        return C21CM_VALUE_ERROR;
+    }
+    const int H = nz / 2;
+    const long nlines = (long)nx * ny;
+    const float2 *src_main = reinterpret_cast<const float2 *>(split_src);
+    const float2 *src_nyq = src_main + nlines * H;
+    float2 *w_main = reinterpret_cast<float2 *>(split_work);
+    float2 *w_nyq = w_main + nlines * H;
+    int st;
+
+    LinePassArgs a{};
+    fill_filter(a.fp, apply ? filter_type : -1, R, R_param, box_len, box_len_z);
+    a.n_y = ny;
+    a.n_z = nz;
+    a.out_scale = 1.0f;
+    // ---- pass X, main block: lines along x, outer = k_y, columns = k_z
+    a.src = src_main;
+    a.dst = w_main;
+    a.line_stride = (long)ny * H;
+    a.outer_stride = H;
+    a.col_stride = 1;
+    a.n_outer = ny;
+    a.n_ctiles = H / TZ;
+    a.pair_outer = 1;
+    a.filter_axis = 0;
+    if ((st = dispatch_line_pass<+1>(nx, a, apply != 0, stream))) return st;
+    // ---- pass X, Nyquist plane [nx][ny]: columns = k_y
+    a.src = src_nyq;
+    a.dst = w_nyq;
+    a.line_stride = ny;
+    a.outer_stride = 0;
+    a.col_stride = 1;
+    a.n_outer = 1;
+    a.n_ctiles = ny / TZ;
+    a.pair_outer = 0;
+    a.filter_axis = 1;
+    if ((st = dispatch_line_pass<+1>(nx, a, apply != 0, stream))) return st;
+    // ---- pass Y, main block (in place): lines along y, outer = x, columns = k_z
+    a.fp.type = -1;
+    a.src = w_main;
+    a.dst = w_main;
+    a.line_stride = H;
+    a.outer_stride = (long)ny * H;
+    a.col_stride = 1;
+    a.n_outer = nx;
+    a.n_ctiles = H / TZ;
+    a.pair_outer = 0;
+    a.filter_axis = 0;
+    if ((st = dispatch_line_pass<+1>(ny, a, false, stream))) return st;
+    // ---- pass Y, Nyquist plane: lines along y are contiguous, columns = x (stride ny)
+    a.src = w_nyq;
+    a.dst = w_nyq;
+    a.line_stride = 1;
+    a.outer_stride = 0;
+    a.col_stride = ny;
+    a.n_outer = 1;
+    a.n_ctiles = nx / TZ;
+    if ((st = dispatch_line_pass<+1>(ny, a, false, stream))) return st;
+    // ---- pass Z
+    ZPassArgs z{};
+    z.main = w_main;
+    z.nyq = w_nyq;
+    z.out = real_out;
+    z.out_zstride = out_zstride;
+    z.out_scale = 1.0f;
+    return dispatch_z_c2r(nz, z, nlines, stream);
+}
+
+// Generic in-place c2r on the FFTW-style padded layout (used by c21cm_fft_c2r and the
+// PerturbedField / InitialConditions drivers for power-of-two grids).
+extern "C" int c21hip_native_fft_c2r(float *padded, int nx, int ny, int nz, void *stream) {
+    const size_t bytes = c21hip_split_floats(nx, ny, nz) * sizeof(float);
+    float *split = (float *)c21hip_ws(48, bytes);
+    if (!split) return C21CM_MEMORY_ALLOC_ERROR;
+    int st = c21hip_padded_to_split(padded, split, nx, ny, nz, stream);
+    if (st) return st;
+    return c21hip_split_filter_c2r(split, split, padded, 2 * (long)(nz / 2 + 1), nx, ny, nz, 1.0,
+                                   1.0, 0, 0.f, 0.f, 0, stream);
+}
+
 extern "C" int c21hip_native_fft_r2c(float *padded, int nx, int ny, int nz, void *stream) {
     (void)padded; (void)nx; (void)ny; (void)nz; (void)stream;
-    return C21CM_VALUE_ERROR;
-}
-extern "C" int c21hip_native_fft_c2r(float *padded, int nx, int ny, int nz, void *stream) {
-    (void)padded; (void)nx; (void)ny; (void)nz; (void)stream;
+    c21hip_set_error("native r2c is not implemented; fft.hip routes r2c through rocFFT");
     return C21CM_VALUE_ERROR;
 }

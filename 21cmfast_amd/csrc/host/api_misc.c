@@ -56,10 +56,22 @@ static int filter_common(const float *input, float *out_f32, double *out_f64, in
     if ((st = c21hip_pack_clip(d_in, unf, nx, ny, nz, 1.0, -1e300, 1e300, stream))) return st;
     if ((st = c21hip_fft_r2c(unf, nx, ny, nz, stream))) return st;
     if ((st = c21hip_divide_inplace_f64(unf, npad, (double)ntot, stream))) return st;
-    if ((st = c21hip_copy_filter(unf, fil, nx, ny, nz, box_len, box_len_z, filter_type, (float)R,
-                                 (float)R_param, 1, stream)))
-        return st;
-    if ((st = c21hip_fft_c2r(fil, nx, ny, nz, stream))) return st;
+    if (c21hip_fft_is_native(nx, ny, nz)) {
+        /* split-layout transform with the window fused into its first pass */
+        if ((st = c21hip_padded_to_split(unf, fil, nx, ny, nz, stream))) return st;
+        if ((st = c21hip_split_filter_c2r(fil, fil, unf, 2 * (long)(nz / 2 + 1), nx, ny, nz,
+                                          box_len, box_len_z, filter_type, (float)R,
+                                          (float)R_param, 1, stream)))
+            return st;
+        float *swap = unf;
+        unf = fil;
+        fil = swap;
+    } else {
+        if ((st = c21hip_copy_filter(unf, fil, nx, ny, nz, box_len, box_len_z, filter_type,
+                                     (float)R, (float)R_param, 1, stream)))
+            return st;
+        if ((st = c21hip_fft_c2r(fil, nx, ny, nz, stream))) return st;
+    }
     if (out_f32) {
         float *d_out = out_f32;
         const int host = !c21hip_is_device_ptr(out_f32);

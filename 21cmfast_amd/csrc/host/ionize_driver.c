@@ -44,7 +44,10 @@ enum {
     WS_NION_DENSE,
     WS_SCALARS,
     WS_TABLE,
-    WS_FIRST_CROSS
+    WS_FIRST_CROSS,
+    WS_DELTA_WORK,
+    WS_STARS_WORK,
+    WS_XE_WORK
 };
 
 #define MAX_COPYBACK 8
@@ -187,8 +190,12 @@ typedef struct {
     int nx, ny, nz;
     size_t ntot, npad;
     int lagrangian;
-    /* k-space grids */
+    int native; /* hand-written split-layout FFT with the filter fused into pass X */
+    /* k-space grids: *_unf unfiltered spectra (padded layout with rocFFT, split layout with
+     * the native FFT), *_work split-layout scratch of the native passes, *_fil filtered
+     * real-space grids (padded rows) */
     float *delta_unf, *delta_fil, *stars_unf, *stars_fil, *xe_unf, *xe_fil;
+    float *delta_work, *stars_work, *xe_work;
     /* dense inputs */
     const float *density, *n_ion, *xe_dense, *Tneutral, *prev_zre;
     /* dense outputs */
@@ -213,18 +220,25 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->lagrangian = (s->fcoll_mode == C21CM_FCOLL_STARS_GRID);
     const size_t gbytes = c->npad * sizeof(float), dbytes = c->ntot * sizeof(float);
 
+    c->native = c21hip_fft_is_native(c->nx, c->ny, c->nz);
     c->delta_unf = (float *)c21hip_ws(WS_DELTA_UNF, gbytes);
     c->delta_fil = (float *)c21hip_ws(WS_DELTA_FIL, gbytes);
     if (!c->delta_unf || !c->delta_fil) return C21CM_MEMORY_ALLOC_ERROR;
+    if (c->native && !(c->delta_work = (float *)c21hip_ws(WS_DELTA_WORK, gbytes)))
+        return C21CM_MEMORY_ALLOC_ERROR;
     if (c->lagrangian) {
         c->stars_unf = (float *)c21hip_ws(WS_STARS_UNF, gbytes);
         c->stars_fil = (float *)c21hip_ws(WS_STARS_FIL, gbytes);
         if (!c->stars_unf || !c->stars_fil) return C21CM_MEMORY_ALLOC_ERROR;
+        if (c->native && !(c->stars_work = (float *)c21hip_ws(WS_STARS_WORK, gbytes)))
+            return C21CM_MEMORY_ALLOC_ERROR;
     }
     if (s->use_ts_fluct) {
         c->xe_unf = (float *)c21hip_ws(WS_XE_UNF, gbytes);
         c->xe_fil = (float *)c21hip_ws(WS_XE_FIL, gbytes);
         if (!c->xe_unf || !c->xe_fil) return C21CM_MEMORY_ALLOC_ERROR;
+        if (c->native && !(c->xe_work = (float *)c21hip_ws(WS_XE_WORK, gbytes)))
+            return C21CM_MEMORY_ALLOC_ERROR;
     }
     c->scalars = (double *)c21hip_ws(WS_SCALARS, SC_COUNT * sizeof(double));
     c->table_dev = (float *)c21hip_ws(WS_TABLE, C21CM_NDELTA_TABLE * sizeof(float));
@@ -288,13 +302,35 @@ static void spectra_remember(const ion_ctx *c, const PerturbedField *pf, const H
     g_spectra.factor = c->s->photoncons_adjustment_factor;
 }
 
-/* prepare_box_for_filtering: IonisationBox.c:323-360 */
-static int prepare_grid(ion_ctx *c, const float *dense, float *cgrid, double factor, double lo,
-                        double hi) {
+/* prepare_box_for_filtering: IonisationBox.c:323-360.  `scratch` is the grid's *_fil buffer:
+ * with the native FFT the padded spectrum is built there and re-laid-out into cgrid. */
+static int prepare_grid(ion_ctx *c, const float *dense, float *cgrid, float *scratch,
+                        double factor, double lo, double hi) {
     int status = 0;
-    TRY(c21hip_pack_clip(dense, cgrid, c->nx, c->ny, c->nz, factor, lo, hi, c->stream));
-    TRY(c21hip_fft_r2c(cgrid, c->nx, c->ny, c->nz, c->stream));
-    TRY(c21hip_divide_inplace(cgrid, c->npad, (float)c->ntot, c->stream));
+    float *padded = c->native ? scratch : cgrid;
+    TRY(c21hip_pack_clip(dense, padded, c->nx, c->ny, c->nz, factor, lo, hi, c->stream));
+    TRY(c21hip_fft_r2c(padded, c->nx, c->ny, c->nz, c->stream));
+    TRY(c21hip_divide_inplace(padded, c->npad, (float)c->ntot, c->stream));
+    if (c->native) TRY(c21hip_padded_to_split(padded, cgrid, c->nx, c->ny, c->nz, c->stream));
+done:
+    return status;
+}
+
+/* one grid of copy_filter_transform (IonisationBox.c:577-663): unfiltered spectrum ->
+ * filtered real-space grid with padded rows */
+static int filter_to_real(ion_ctx *c, const float *unf, float *work, float *fil, int filter_type,
+                          float R, float R_param, int apply) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    if (c->native) {
+        TRY(c21hip_split_filter_c2r(unf, work, fil, 2 * (long)(c->nz / 2 + 1), c->nx, c->ny, c->nz,
+                                    s->box_len, s->box_len_z, filter_type, R, R_param, apply,
+                                    c->stream));
+    } else {
+        TRY(c21hip_copy_filter(unf, fil, c->nx, c->ny, c->nz, s->box_len, s->box_len_z,
+                               filter_type, R, R_param, apply, c->stream));
+        TRY(c21hip_fft_c2r(fil, c->nx, c->ny, c->nz, c->stream));
+    }
 done:
     return status;
 }
@@ -303,9 +339,10 @@ static int preloop(ion_ctx *c) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     /* IonisationBox.c:1480-1513 */
-    TRY(prepare_grid(c, c->density, c->delta_unf, s->photoncons_adjustment_factor, -1., 1e6));
-    if (c->lagrangian) TRY(prepare_grid(c, c->n_ion, c->stars_unf, 1., 0., 1e20));
-    if (s->use_ts_fluct) TRY(prepare_grid(c, c->xe_dense, c->xe_unf, 1., 0., 1.));
+    TRY(prepare_grid(c, c->density, c->delta_unf, c->delta_fil, s->photoncons_adjustment_factor,
+                     -1., 1e6));
+    if (c->lagrangian) TRY(prepare_grid(c, c->n_ion, c->stars_unf, c->stars_fil, 1., 0., 1e20));
+    if (s->use_ts_fluct) TRY(prepare_grid(c, c->xe_dense, c->xe_unf, c->xe_fil, 1., 0., 1.));
 done:
     return status;
 }
@@ -322,20 +359,13 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross) {
     c21hip_ionize_args args;
     fill_args(&args, s, R_ct);
 
-    TRY(c21hip_copy_filter(c->delta_unf, c->delta_fil, c->nx, c->ny, c->nz, s->box_len,
-                           s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
-    TRY(c21hip_fft_c2r(c->delta_fil, c->nx, c->ny, c->nz, c->stream));
-    if (c->lagrangian) {
-        TRY(c21hip_copy_filter(c->stars_unf, c->stars_fil, c->nx, c->ny, c->nz, s->box_len,
-                               s->box_len_z, s->stars_filter, R, (float)s->mfp_meandens, apply,
-                               c->stream));
-        TRY(c21hip_fft_c2r(c->stars_fil, c->nx, c->ny, c->nz, c->stream));
-    }
-    if (s->use_ts_fluct) {
-        TRY(c21hip_copy_filter(c->xe_unf, c->xe_fil, c->nx, c->ny, c->nz, s->box_len,
-                               s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
-        TRY(c21hip_fft_c2r(c->xe_fil, c->nx, c->ny, c->nz, c->stream));
-    }
+    TRY(filter_to_real(c, c->delta_unf, c->delta_work, c->delta_fil, s->hii_filter, R, 0.f,
+                       apply));
+    if (c->lagrangian)
+        TRY(filter_to_real(c, c->stars_unf, c->stars_work, c->stars_fil, s->stars_filter, R,
+                           (float)s->mfp_meandens, apply));
+    if (s->use_ts_fluct)
+        TRY(filter_to_real(c, c->xe_unf, c->xe_work, c->xe_fil, s->hii_filter, R, 0.f, apply));
 
     if (c->lagrangian) {
         TRY(c21hip_ionise_stars(&args, c->delta_fil, c->stars_fil, c->xe_fil, c->density,

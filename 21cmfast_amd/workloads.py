@@ -125,7 +125,7 @@ def density_field_numpy(shape, seed: int = 12345, sigma: float = 0.25) -> np.nda
     k2[0, 0, 0] = 1.0
     wk *= 1.0 / np.sqrt(k2)  # amplitude ~ k^-1  ->  P ~ k^-2
     wk[0, 0, 0] = 0.0
-    field = np.fft.irfftn(wk, s=shape).astype(np.float32)
+    field = np.fft.irfftn(wk, s=shape, axes=(0, 1, 2)).astype(np.float32)
     field *= sigma / field.std()
     np.maximum(field, -0.95, out=field)
     return np.ascontiguousarray(field, np.float32)

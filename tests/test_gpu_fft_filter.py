@@ -58,7 +58,8 @@ def test_delta_function_known_answer_device(api, filter_type, R):
     delta_function_checks(api.filter_grid, filter_type, R)
 
 
-@pytest.mark.parametrize("shape", [(50, 50, 50), (64, 64, 64), (48, 48, 96)])
+@pytest.mark.parametrize("shape", [(50, 50, 50), (64, 64, 64), (48, 48, 96), (64, 64, 128),
+                                   (128, 128, 64)])
 @pytest.mark.parametrize("filter_type,R,R_param", [(0, 3.0, 0.0), (0, 12.0, 0.0), (1, 6.0, 0.0),
                                                    (2, 4.0, 0.0), (3, 7.5, 37.66), (4, 5.0, 9.0)])
 def test_filter_matches_oracle_random_box(api, oracle, shape, filter_type, R, R_param):

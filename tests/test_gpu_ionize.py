@@ -29,11 +29,16 @@ def compare(got, ref, spec, flag_tol=2e-4):
     mismatch = np.mean(ion_g != ion_r)
     assert mismatch <= flag_tol, f"ionisation flag mismatch fraction {mismatch}"
     same = ion_g == ion_r
-    np.testing.assert_allclose(xg[same], xr[same], rtol=1e-4, atol=1e-6)
+    # xH = 1 - f*zeta cancels near the barrier: float32-FFT round-off of ~1e-6 relative in f is
+    # an ABSOLUTE ~1e-6 in xH, hence the atol next to the north-star rtol of 1e-4
+    np.testing.assert_allclose(xg[same], xr[same], rtol=1e-4, atol=5e-6)
     np.testing.assert_array_equal(got["z_reion"][same], ref["z_reion"][same])
     if not spec.minimize_memory:
+        # partial-ionisation T_k = T_HI*xH + T_re*(1-xH) is linear in xH with slope ~T_re, so
+        # the xH tolerance (rtol 1e-4 at xH ~ 1) maps onto atol = 1e-4 * T_re
         np.testing.assert_allclose(got["kinetic_temperature"][same],
-                                   ref["kinetic_temperature"][same], rtol=1e-4, atol=1e-4)
+                                   ref["kinetic_temperature"][same], rtol=1e-4,
+                                   atol=1e-4 * spec.T_re)
     n = spec.n_radii
     np.testing.assert_allclose(np.array(got["report"].f_coll_grid_mean[:n]),
                                np.array(ref["report"].f_coll_grid_mean[:n]), rtol=1e-5)
@@ -66,7 +71,8 @@ def run_device(api, spec, density, n_ion=None, device_resident=False, **kw):
     return out
 
 
-@pytest.mark.parametrize("n,device_resident", [(32, False), (64, True), (50, False), (35, True)])
+@pytest.mark.parametrize("n,device_resident", [(32, False), (64, True), (50, False), (35, True),
+                                               (128, True)])
 def test_lagrangian_two_grid_parity(api, oracle, n, device_resident):
     """Config-3 semantics (G = 2: delta top-hat + n_ion exp-MFP) at oracle-sized boxes,
     including the odd sizes the reference's test-suite uses (35, 50)."""
@@ -81,7 +87,7 @@ def test_lagrangian_two_grid_parity(api, oracle, n, device_resident):
     assert got["mean_f_coll"] == pytest.approx(ref["mean_f_coll"], rel=1e-5)
 
 
-@pytest.mark.parametrize("n", [32, 50])
+@pytest.mark.parametrize("n", [32, 50, 64])
 def test_const_ion_eff_erfc_parity(api, oracle, n):
     """G = 1 variant: CONST-ION-EFF closed-form erfc, sharp-k filter, fix_mean."""
     spec = W.ionize_spec(n, mode=W.FCOLL_ERFC, r_bubble_max=20.0)
