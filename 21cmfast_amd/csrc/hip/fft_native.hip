@@ -119,10 +119,11 @@ struct Dft<8, SIGN> {
 //   butterfly b in [0, N/R): inputs  tile[b + k*N/R],          k = 0..R-1
 //                            outputs tile[q + s*R*p + s*j] *= tw[p*s*j],  p = b/s, q = b%s
 // `tw` holds exp(-2 pi i t / N), t = 0..N-1 (conjugated for SIGN > 0).
-template <int N, int COLS, int ROW, int R, int SIGN>
+template <int N, int COLS, int ROW, int R, int SIGN, bool LAST, int THREADS>
 __device__ __forceinline__ void stockham_stage(float2 *tile, const float2 *tw, int log2s) {
     constexpr int NB = N / R;
     constexpr int ITEMS = NB * COLS;
+    constexpr int kBlock = THREADS;
     constexpr int PER = (ITEMS + kBlock - 1) / kBlock;
     float2 v[PER][R];
 #pragma unroll
@@ -144,11 +145,26 @@ __device__ __forceinline__ void stockham_stage(float2 *tile, const float2 *tw, i
             const int ps = p << log2s;
             Dft<R, SIGN>::run(v[u]);
             const int base = q + ((R * p) << log2s);
+            // twiddles tw[ps*j], j = 1..R-1: three table reads (j = 1, 2, 4), the rest as
+            // single products of exact table values
+            float2 wj[R];
+            wj[0] = make_float2(1.f, 0.f);
+            if (!LAST && R >= 2) wj[1] = tw[ps];
+            if (!LAST && R >= 4) {
+                wj[2] = tw[ps * 2];
+                wj[3] = cmul(wj[1], wj[2]);
+            }
+            if (!LAST && R >= 8) {
+                wj[4] = tw[ps * 4];
+                wj[5] = cmul(wj[1], wj[4]);
+                wj[6] = cmul(wj[2], wj[4]);
+                wj[7] = cmul(wj[3], wj[4]);
+            }
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 float2 o = v[u][j];
-                if (j > 0) {
-                    float2 w = tw[ps * j];
+                if (!LAST && j > 0) {  // the final stage has p = 0: all twiddles are 1
+                    float2 w = wj[j];
                     if (SIGN > 0) w.y = -w.y;
                     o = cmul(o, w);
                 }
@@ -160,7 +176,7 @@ __device__ __forceinline__ void stockham_stage(float2 *tile, const float2 *tw, i
 }
 
 // Full length-N transform of every column of the tile (radix plan 8,8,..,{4,2}).
-template <int N, int COLS, int ROW, int SIGN>
+template <int N, int COLS, int ROW, int SIGN, int THREADS>
 __device__ __forceinline__ void fft_tile(float2 *tile, const float2 *tw) {
     static_assert((N & (N - 1)) == 0 && N >= 8, "power-of-two line length");
     int log2s = 0;
@@ -169,11 +185,14 @@ __device__ __forceinline__ void fft_tile(float2 *tile, const float2 *tw) {
     constexpr int REM = L % 3;  // 0, 1 (radix 2) or 2 (radix 4)
 #pragma unroll
     for (int st = 0; st < N8; st++) {
-        stockham_stage<N, COLS, ROW, 8, SIGN>(tile, tw, log2s);
+        if (REM == 0 && st == N8 - 1)
+            stockham_stage<N, COLS, ROW, 8, SIGN, true, THREADS>(tile, tw, log2s);
+        else
+            stockham_stage<N, COLS, ROW, 8, SIGN, false, THREADS>(tile, tw, log2s);
         log2s += 3;
     }
-    if (REM == 1) stockham_stage<N, COLS, ROW, 2, SIGN>(tile, tw, log2s);
-    if (REM == 2) stockham_stage<N, COLS, ROW, 4, SIGN>(tile, tw, log2s);
+    if (REM == 1) stockham_stage<N, COLS, ROW, 2, SIGN, true, THREADS>(tile, tw, log2s);
+    if (REM == 2) stockham_stage<N, COLS, ROW, 4, SIGN, true, THREADS>(tile, tw, log2s);
 }
 
 // ------------------------------------------------------------------ window functions
@@ -272,80 +291,107 @@ __device__ __forceinline__ int mirror_row(int row_a) {
     return row_a == 0 ? N / 2 : N - row_a;
 }
 
+// Persistent workgroups: each loops over (outer group, column tile) work items with a
+// grid stride.  Within the loop the global loads of the NEXT tile are issued before the
+// LDS transform of the current one, and the window values are computed while the first
+// tile's loads are in flight, so HBM latency hides behind the LDS/ALU phase.
+// THREADS = 512 (one workgroup per CU at N >= 256, 2 waves per SIMD, <= 256 VGPRs) keeps the
+// per-thread working set small enough for the register prefetch of the next tile.
+template <int N>
+struct LineThreads {
+    static constexpr int value = (N >= 128) ? 512 : 256;
+};
+
 template <int N, int SIGN, bool FILTER>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(LineThreads<N>::value, LineThreads<N>::value / 256)
 line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     static_assert(N >= 64, "tile loader needs N >= 64");
+    constexpr int kBlock = LineThreads<N>::value;
+    constexpr int RSTEP = kBlock / 8;  // rows covered by one sweep of the workgroup
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
     float2 *tw = tile + N * TZ;                          // [N]
     for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
 
-    const int ct = blockIdx.x % a.n_ctiles;
-    const int og = blockIdx.x / a.n_ctiles;
-    // members of this workgroup's outer group: the mirror pair (og, n_outer - og), or one
-    // self-mirrored index (0, n_outer/2), or just og when pairing is off
-    int members[2];
-    int n_members = 1;
-    members[0] = og;
-    if (a.pair_outer && og != 0 && 2 * og != a.n_outer) {
-        members[1] = a.n_outer - og;
-        n_members = 2;
-    }
-    constexpr int NP = N / 64;  // row pairs per thread
+    constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
     const int r0 = threadIdx.x >> 3, c4 = threadIdx.x & 7;
     const bool vec = (a.col_stride == 1);
+    const int n_groups = a.pair_outer ? (a.n_outer / 2 + 1) : a.n_outer;
+    const int n_work = n_groups * a.n_ctiles;
 
-    // window values for this thread's row pairs x 2 columns, evaluated once per group
-    constexpr int NW = FILTER ? NP : 1;
-    double w[NW][2], w_half[2] = {1., 1.};
-    if (FILTER) {
-        const int col0 = ct * TZ + 2 * c4;
-        float ky[2], kz[2];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            if (a.filter_axis == 0) {
-                ky[e] = k_of(members[0], a.n_y, a.fp.dky);
-                kz[e] = (float)((double)(col0 + e) * a.fp.dkz);
-            } else {
-                ky[e] = k_of(col0 + e, a.n_y, a.fp.dky);
-                kz[e] = (float)((double)(a.n_z / 2) * a.fp.dkz);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NP; u++) {
-            const float kx = k_of(r0 + 32 * u, N, a.fp.dkx);
-#pragma unroll
-            for (int e = 0; e < 2; e++) w[u][e] = window_of(a.fp, kx, ky[e], kz[e]);
-        }
-        if (r0 == 0) {
-            const float kx = k_of(N / 2, N, a.fp.dkx);
-#pragma unroll
-            for (int e = 0; e < 2; e++) w_half[e] = window_of(a.fp, kx, ky[e], kz[e]);
-        }
-    }
-
-    for (int mi = 0; mi < n_members; mi++) {
-        const long base = (long)members[mi] * a.outer_stride + (long)ct * TZ * a.col_stride;
-        // ---- load: every request is in flight before the first use
-        float4 reg[2 * NP];
+    // Addressing: a wave-uniform 64-bit tile base (SGPRs) plus 32-bit per-thread element
+    // offsets.  Rows < N/2 are addressed from the tile base, mirror rows from the row-N/2
+    // base, so offsets stay below 2^31 elements even at 1024^3.
+    const unsigned ls = (unsigned)a.line_stride, cs = (unsigned)a.col_stride;
+    const long half_off = (long)(N / 2) * a.line_stride;
+    float4 reg[2 * NP];
+    auto issue_loads = [&](long base) {
+        const float2 *lo = a.src + base;
+        const float2 *hi = lo + half_off;
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
-            const int row_a = r0 + 32 * (u >> 1);
-            const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
-            const long off = base + (long)row * a.line_stride;
+            const int row_a = r0 + RSTEP * (u >> 1);
+            // mirror row N - row_a = N/2 + (N/2 - row_a); row_a = 0 pairs with N/2 itself
+            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : (unsigned)(N / 2 - row_a) * ls)
+                                          : (unsigned)row_a * ls;
+            const float2 *p = (u & 1) ? hi : lo;
             if (vec) {
-                reg[u] = *reinterpret_cast<const float4 *>(a.src + off + 2 * c4);
+                reg[u] = *reinterpret_cast<const float4 *>(p + (roff + 2u * c4));
             } else {
-                float2 e0 = a.src[off + (long)(2 * c4) * a.col_stride];
-                float2 e1 = a.src[off + (long)(2 * c4 + 1) * a.col_stride];
+                float2 e0 = p[roff + (unsigned)(2 * c4) * cs];
+                float2 e1 = p[roff + (unsigned)(2 * c4 + 1) * cs];
                 reg[u] = make_float4(e0.x, e0.y, e1.x, e1.y);
             }
         }
-        if (mi > 0) __syncthreads();  // the previous member's stores have left the tile
+    };
+    auto tile_base = [&](int outer, int ct) {
+        return (long)outer * a.outer_stride + (long)ct * TZ * a.col_stride;
+    };
+
+    int work = blockIdx.x;
+    if (work >= n_work) return;
+    // members of a group: the mirror pair (og, n_outer - og), or a single index
+    int og = work / a.n_ctiles, ct = work % a.n_ctiles;
+    int n_members = (a.pair_outer && og != 0 && 2 * og != a.n_outer) ? 2 : 1;
+    int mi = 0;
+    issue_loads(tile_base(og, ct));
+
+    constexpr int NW = FILTER ? NP : 1;
+    double w[NW][2], w_half[2] = {1., 1.};
+    bool first = true;
+    while (true) {
+        if (FILTER && mi == 0) {
+            // window values of this thread's row pairs x 2 columns, once per group
+            const int col0 = ct * TZ + 2 * c4;
+            float ky[2], kz[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (a.filter_axis == 0) {
+                    ky[e] = k_of(og, a.n_y, a.fp.dky);
+                    kz[e] = (float)((double)(col0 + e) * a.fp.dkz);
+                } else {
+                    ky[e] = k_of(col0 + e, a.n_y, a.fp.dky);
+                    kz[e] = (float)((double)(a.n_z / 2) * a.fp.dkz);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NP; u++) {
+                const float kx = k_of(r0 + RSTEP * u, N, a.fp.dkx);
+#pragma unroll
+                for (int e = 0; e < 2; e++) w[u][e] = window_of(a.fp, kx, ky[e], kz[e]);
+            }
+            if (r0 == 0) {
+                const float kx = k_of(N / 2, N, a.fp.dkx);
+#pragma unroll
+                for (int e = 0; e < 2; e++) w_half[e] = window_of(a.fp, kx, ky[e], kz[e]);
+            }
+        }
+        const long base = tile_base(mi == 0 ? og : a.n_outer - og, ct);
+        if (!first) __syncthreads();  // the previous tile's LDS reads are done
+        first = false;
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
-            const int row_a = r0 + 32 * (u >> 1);
+            const int row_a = r0 + RSTEP * (u >> 1);
             const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
             float4 v = reg[u];
             if (FILTER) {
@@ -360,11 +406,26 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             *reinterpret_cast<float4 *>(tile + row * TZ + 2 * c4) = v;
         }
         __syncthreads();
-        fft_tile<N, TZ, TZ, SIGN>(tile, tw);
+        // ---- advance to the next tile and put its loads in flight
+        int n_og = og, n_ct = ct, n_mi = mi + 1, n_nm = n_members;
+        bool more = true;
+        if (n_mi >= n_members) {
+            work += gridDim.x;
+            more = work < n_work;
+            if (more) {
+                n_og = work / a.n_ctiles;
+                n_ct = work % a.n_ctiles;
+                n_nm = (a.pair_outer && n_og != 0 && 2 * n_og != a.n_outer) ? 2 : 1;
+                n_mi = 0;
+            }
+        }
+        if (more) issue_loads(tile_base(n_mi == 0 ? n_og : a.n_outer - n_og, n_ct));
+
+        fft_tile<N, TZ, TZ, SIGN, kBlock>(tile, tw);
         // ---- store
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
-            const int row_a = r0 + 32 * (u >> 1);
+            const int row_a = r0 + RSTEP * (u >> 1);
             const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
             float4 v = *reinterpret_cast<const float4 *>(tile + row * TZ + 2 * c4);
             if (a.out_scale != 1.0f) {
@@ -373,14 +434,21 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 v.z *= a.out_scale;
                 v.w *= a.out_scale;
             }
-            const long off = base + (long)row * a.line_stride;
+            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : (unsigned)(N / 2 - row_a) * ls)
+                                          : (unsigned)row_a * ls;
+            float2 *p = a.dst + base + ((u & 1) ? half_off : 0);
             if (vec) {
-                *reinterpret_cast<float4 *>(a.dst + off + 2 * c4) = v;
+                *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
             } else {
-                a.dst[off + (long)(2 * c4) * a.col_stride] = make_float2(v.x, v.y);
-                a.dst[off + (long)(2 * c4 + 1) * a.col_stride] = make_float2(v.z, v.w);
+                p[roff + (unsigned)(2 * c4) * cs] = make_float2(v.x, v.y);
+                p[roff + (unsigned)(2 * c4 + 1) * cs] = make_float2(v.z, v.w);
             }
         }
+        if (!more) break;
+        og = n_og;
+        ct = n_ct;
+        mi = n_mi;
+        n_members = n_nm;
     }
 }
 
@@ -456,7 +524,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         }
     }
     __syncthreads();
-    fft_tile<H, LZ, ZROW, +1>(tile, twH);
+    fft_tile<H, LZ, ZROW, +1, kBlock>(tile, twH);
     // ---- store: lanes along j, one float2 = (x[2j], x[2j+1])
     constexpr int NOUT = LZ * H;
 #pragma unroll
@@ -526,7 +594,14 @@ int launch_line_pass(const LinePassArgs &a, bool filter, hipStream_t stream) {
     }
     const size_t lds = sizeof(float2) * ((size_t)N * TZ + N);
     const int groups = a.pair_outer ? (a.n_outer / 2 + 1) : a.n_outer;
-    const dim3 grid((unsigned)(groups * a.n_ctiles));
+    const int n_work = groups * a.n_ctiles;
+    // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
+    int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+    const int by_waves = 8 / (LineThreads<N>::value / 64);  // 2 waves per SIMD budget
+    if (per_cu > by_waves) per_cu = by_waves;
+    int nblocks = 256 * per_cu;
+    if (nblocks > n_work) nblocks = n_work;
+    const dim3 grid((unsigned)nblocks);
     if (filter) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -534,8 +609,8 @@ int launch_line_pass(const LinePassArgs &a, bool filter, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
-        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, true>), grid, dim3(kBlock), lds, stream, a,
-                           tw);
+        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, true>), grid, dim3(LineThreads<N>::value),
+                           lds, stream, a, tw);
     } else {
         static bool attr_done = false;
         if (!attr_done) {
@@ -543,8 +618,8 @@ int launch_line_pass(const LinePassArgs &a, bool filter, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
-        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, false>), grid, dim3(kBlock), lds, stream, a,
-                           tw);
+        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, false>), grid, dim3(LineThreads<N>::value),
+                           lds, stream, a, tw);
     }
     LAUNCH_CHECK();
     return 0;

@@ -76,7 +76,8 @@ def cpu_baseline(args, W):
         spec.sigma_maxmass[i] = full.sigma_maxmass[i]
     density = W.density_field_numpy(n, seed=12345)
     n_ion = W.nion_from_density(density) if mode == W.FCOLL_STARS else None
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
+    oracle.set_threads(cores)
     t0 = time.perf_counter()
     oracle.ionize_grids(spec, density, n_ion, need_nion=mode != W.FCOLL_STARS)
     dt = time.perf_counter() - t0

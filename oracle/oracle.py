@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import importlib
+import os
 import subprocess
 from pathlib import Path
 
@@ -68,8 +69,14 @@ def load():
             if hasattr(lib, name):
                 getattr(lib, name).restype = i32
                 getattr(lib, name).argtypes = argt
+        # small test boxes: a few threads beat 256 (fork/join cost dominates tiny loops)
+        lib.oracle_set_threads(min(16, os.cpu_count() or 1))
         _lib = lib
     return _lib
+
+
+def set_threads(n: int) -> None:
+    load().oracle_set_threads(int(n))
 
 
 def _ptr(a: np.ndarray):
