@@ -54,6 +54,21 @@ int c21hip_split_filter_c2r(const float *split_src, float *split_work, float *re
                             double box_len_z, int filter_type, float R, float R_param, int apply,
                             void *stream);
 
+int c21hip_split_filter_xy(const float *split_src, float *split_work, int nx, int ny, int nz,
+                           double box_len, double box_len_z, int filter_type, float R,
+                           float R_param, int apply, void *stream);
+int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstride, int nx, int ny,
+                       int nz, void *stream);
+/* Fused pass Z of delta_R and the filtered emissivity + sum(stars) + ionisation barrier for
+ * Lagrangian source grids at radius index > 0; writes only first_cross (uint8 [N]).
+ * partials: nx*ny/16 doubles.  reference: IonisationBox.c:634-638,821-837,1054-1151 */
+int c21hip_split_z_ionise_stars(const float *delta_work, const float *stars_work,
+                                unsigned char *first_cross, double *partials, double *sum_out,
+                                int nx, int ny, int nz, int r_index, double rhocrit_omb,
+                                double ion_eff, int mass_dep_zeta, double f_limit, void *stream);
+/* deterministic single-workgroup sum of n doubles (ionize_kernels.hip) */
+int c21hip_reduce_sum(const double *partials, int n, double *out, void *stream);
+
 /* ---- grid_kernels.hip : generic sweeps ---- */
 /* padded[l][k] = clip(dense[l][k] * factor, lo, hi); pad columns zeroed.
  * reference: IonisationBox.c:333-350 */

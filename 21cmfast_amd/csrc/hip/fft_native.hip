@@ -471,30 +471,35 @@ struct ZPassArgs {
     float out_scale;
 };
 
+// --- building blocks shared by the plain and the fused pass-Z kernels
 template <int NZ>
-__global__ void __launch_bounds__(kBlock)
-z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
-             const float2 *__restrict__ twN_global) {
-    constexpr int H = NZ / 2;
-    extern __shared__ float4 lds_raw[];
-    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [H][ZROW]
-    float2 *twH = tile + H * ZROW;                       // [H]
-    float2 *twN = twH + H;                               // [H/2 + 1]
-    for (int t = threadIdx.x; t < H; t += kBlock) twH[t] = twH_global[t];
-    for (int t = threadIdx.x; t <= H / 2; t += kBlock) twN[t] = twN_global[t];
+struct ZGeom {
+    static constexpr int H = NZ / 2;
+    static constexpr int NF4 = LZ * H / 2;                       // float4 per 16-line block
+    static constexpr int NLOAD = (NF4 + kBlock - 1) / kBlock;    // float4 loads per thread
+    static constexpr int NOUT = LZ * H / kBlock;                 // float2 outputs per thread
+};
 
-    const long l0 = (long)blockIdx.x * LZ;
-    // ---- load 16 contiguous lines, transposing into tile[k][line]
-    constexpr int NF4 = LZ * H / 2;  // float4 count
-    const float4 *src4 = reinterpret_cast<const float4 *>(a.main + l0 * H);
-    float4 reg[(NF4 + kBlock - 1) / kBlock];
+template <int NZ>
+__device__ __forceinline__ void z_issue_loads(const float2 *main, long l0,
+                                              float4 (&reg)[ZGeom<NZ>::NLOAD]) {
+    constexpr int H = ZGeom<NZ>::H, NF4 = ZGeom<NZ>::NF4;
+    const float4 *src4 = reinterpret_cast<const float4 *>(main + l0 * H);
 #pragma unroll
-    for (int u = 0; u < (NF4 + kBlock - 1) / kBlock; u++) {
+    for (int u = 0; u < ZGeom<NZ>::NLOAD; u++) {
         const int f = threadIdx.x + kBlock * u;
         if (NF4 % kBlock == 0 || f < NF4) reg[u] = src4[f];
     }
+}
+
+// registers -> tile[k][line] (transposing), Hermitian pre-processing, length-H inverse FFT
+template <int NZ>
+__device__ __forceinline__ void z_transform(float2 *tile, const float2 *twH, const float2 *twN,
+                                            const float4 (&reg)[ZGeom<NZ>::NLOAD],
+                                            const float2 *nyq, long l0) {
+    constexpr int H = ZGeom<NZ>::H, NF4 = ZGeom<NZ>::NF4;
 #pragma unroll
-    for (int u = 0; u < (NF4 + kBlock - 1) / kBlock; u++) {
+    for (int u = 0; u < ZGeom<NZ>::NLOAD; u++) {
         const int f = threadIdx.x + kBlock * u;
         if (NF4 % kBlock == 0 || f < NF4) {
             const int e = 2 * f;
@@ -504,13 +509,13 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         }
     }
     __syncthreads();
-    // ---- Hermitian pre-processing, pairs (k, H-k) owned by one thread
+    // pairs (k, H-k) are owned by one thread
     constexpr int NPRE = (H / 2 + 1) * LZ;
     for (int i = threadIdx.x; i < NPRE; i += kBlock) {
         const int li = i % LZ, k = i / LZ;
         if (k == 0) {
             const float x0 = tile[li].x;
-            const float xh = a.nyq[l0 + li].x;
+            const float xh = nyq[l0 + li].x;
             tile[li] = make_float2(x0 + xh, x0 - xh);
         } else {
             const float2 A = tile[k * ZROW + li], B = tile[(H - k) * ZROW + li];
@@ -525,10 +530,27 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     }
     __syncthreads();
     fft_tile<H, LZ, ZROW, +1, kBlock>(tile, twH);
+}
+
+template <int NZ>
+__global__ void __launch_bounds__(kBlock)
+z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
+             const float2 *__restrict__ twN_global) {
+    constexpr int H = NZ / 2;
+    extern __shared__ float4 lds_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [H][ZROW]
+    float2 *twH = tile + H * ZROW;                       // [H]
+    float2 *twN = twH + H;                               // [H/2 + 1]
+    for (int t = threadIdx.x; t < H; t += kBlock) twH[t] = twH_global[t];
+    for (int t = threadIdx.x; t <= H / 2; t += kBlock) twN[t] = twN_global[t];
+
+    const long l0 = (long)blockIdx.x * LZ;
+    float4 reg[ZGeom<NZ>::NLOAD];
+    z_issue_loads<NZ>(a.main, l0, reg);
+    z_transform<NZ>(tile, twH, twN, reg, a.nyq, l0);
     // ---- store: lanes along j, one float2 = (x[2j], x[2j+1])
-    constexpr int NOUT = LZ * H;
 #pragma unroll
-    for (int u = 0; u < NOUT / kBlock; u++) {
+    for (int u = 0; u < ZGeom<NZ>::NOUT; u++) {
         const int f = threadIdx.x + kBlock * u;
         const int li = f / H, j = f % H;
         float2 v = tile[j * ZROW + li];
@@ -537,6 +559,98 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             v.y *= a.out_scale;
         }
         reinterpret_cast<float2 *>(a.out + (l0 + li) * a.out_zstride)[j] = v;
+    }
+}
+
+// ------------------------------------------------------------------ fused pass Z + barrier
+// Lagrangian source grids, radius index > 0: the z-lines of BOTH filtered grids (delta_R and
+// the filtered emissivity) are transformed in one workgroup and consumed in registers:
+//   sum(max(stars,0))                        calculate_fcoll_grid   IonisationBox.c:821-837,954
+//   stars*zeta / (rho_b (1+delta_R)) > 1     find_ionised_regions   IonisationBox.c:1054-1082,1118
+// The filtered real-space grids are never written to HBM.  The only output is the per-cell
+// first-crossing radius index (uint8, read-modify-write of full rows) from which the
+// driver derives xH = 0 / z_reion after the loop; because radii are visited largest first,
+// "mask == 0 ? r : mask" records the first crossing exactly like the reference's in-loop
+// xH / z_reion writes.  The barrier is evaluated division-free, stars*zeta > rho_b(1+delta)
+// (and the f_limit floor as a uniform predicate), which is the same inequality in exact
+// arithmetic and differs from the reference's rounding only for cells within 1 ulp (double)
+// of the barrier.
+struct ZFusedArgs {
+    const float2 *d_main, *d_nyq;  // filtered density spectrum after passes X, Y
+    const float2 *s_main, *s_nyq;  // filtered emissivity spectrum
+    unsigned char *first_cross;    // [lines][NZ]
+    double *partials;              // one per workgroup
+    double rhocrit_omb, ion_eff, f_limit;
+    int mass_dep_zeta, r_index;
+};
+
+template <int NZ>
+__global__ void __launch_bounds__(kBlock)
+z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
+                    const float2 *__restrict__ twN_global) {
+    constexpr int H = NZ / 2;
+    constexpr int NOUT = ZGeom<NZ>::NOUT;
+    extern __shared__ float4 lds_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(lds_raw);
+    float2 *twH = tile + H * ZROW;
+    float2 *twN = twH + H;
+    for (int t = threadIdx.x; t < H; t += kBlock) twH[t] = twH_global[t];
+    for (int t = threadIdx.x; t <= H / 2; t += kBlock) twN[t] = twN_global[t];
+
+    const long l0 = (long)blockIdx.x * LZ;
+    float4 reg_d[ZGeom<NZ>::NLOAD], reg_s[ZGeom<NZ>::NLOAD];
+    z_issue_loads<NZ>(a.d_main, l0, reg_d);
+    z_issue_loads<NZ>(a.s_main, l0, reg_s);  // in flight during the first transform
+    // the mask rows of this block, also early
+    uchar2 old[NOUT];
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        const int li = f / H, j = f % H;
+        old[u] = reinterpret_cast<const uchar2 *>(a.first_cross + (l0 + li) * NZ)[j];
+    }
+    z_transform<NZ>(tile, twH, twN, reg_d, a.d_nyq, l0);
+    float2 dens[NOUT];
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        const int li = f / H, j = f % H;
+        dens[u] = tile[j * ZROW + li];
+    }
+    __syncthreads();
+    z_transform<NZ>(tile, twH, twN, reg_s, a.s_nyq, l0);
+
+    const bool floor_ionises = a.mass_dep_zeta && (a.f_limit * a.ion_eff > 1.);
+    const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
+    double acc = 0.;
+#pragma unroll
+    for (int u = 0; u < NOUT; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        const int li = f / H, j = f % H;
+        const float2 st = tile[j * ZROW + li];
+        const float s0 = fmaxf(st.x, 0.f), s1 = fmaxf(st.y, 0.f);
+        acc += (double)s0;
+        acc += (double)s1;
+        const double D0 = a.rhocrit_omb * (1. + (double)fmaxf(dens[u].x, dmin));
+        const double D1 = a.rhocrit_omb * (1. + (double)fmaxf(dens[u].y, dmin));
+        const bool i0 = floor_ionises || ((double)s0 * a.ion_eff > D0);
+        const bool i1 = floor_ionises || ((double)s1 * a.ion_eff > D1);
+        uchar2 m = old[u];
+        if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
+        if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
+        reinterpret_cast<uchar2 *>(a.first_cross + (l0 + li) * NZ)[j] = m;
+    }
+    // workgroup partial of sum(stars)
+    __shared__ double red[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) sum += red[w];
+        a.partials[blockIdx.x] = sum;
     }
 }
 
@@ -658,6 +772,38 @@ int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
     return 0;
 }
 
+template <int NZ>
+int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
+    constexpr int H = NZ / 2;
+    const float2 *twH = twiddles(H);
+    const float2 *twN = twiddles(NZ);
+    if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+    const size_t lds = sizeof(float2) * ((size_t)H * ZROW + H + H / 2 + 1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)z_c2r_ionise_kernel<NZ>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((z_c2r_ionise_kernel<NZ>), dim3((unsigned)(nlines / LZ)), dim3(kBlock), lds,
+                       stream, a, twH, twN);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream) {
+    switch (nz) {
+        case 64: return launch_z_fused<64>(a, nlines, stream);
+        case 128: return launch_z_fused<128>(a, nlines, stream);
+        case 256: return launch_z_fused<256>(a, nlines, stream);
+        case 512: return launch_z_fused<512>(a, nlines, stream);
+        case 1024: return launch_z_fused<1024>(a, nlines, stream);
+        default:
+            c21hip_set_error("native FFT: unsupported z length %d for the fused pass", nz);
+            return C21CM_VALUE_ERROR;
+    }
+}
+
 int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) {
     switch (nz) {
         case 64: return launch_z_c2r<64>(a, nlines, stream);
@@ -723,13 +869,11 @@ extern "C" int c21hip_padded_to_split(const float *padded_c, float *split, int n
     return 0;
 }
 
-// Inverse transform of a split spectrum: [W(kR) x] pass X (src -> work), pass Y (work, in
-// place), pass Z (work -> real rows of out_zstride floats).  src == work is allowed.
-extern "C" int c21hip_split_filter_c2r(const float *split_src, float *split_work, float *real_out,
-                                       long out_zstride, int nx, int ny, int nz, double box_len,
-                                       double box_len_z, int filter_type, float R, float R_param,
-                                       int apply, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// [W(kR) x] pass X (src -> work) and pass Y (work, in place) of the inverse transform of a
+// split spectrum.  src == work is allowed.
+extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work, int nx, int ny,
+                                      int nz, double box_len, double box_len_z, int filter_type,
+                                      float R, float R_param, int apply, void *stream_) {
     if (!c21hip_native_fft_supported(nx, ny, nz)) {
         c21hip_set_error("native FFT does not support %dx%dx%d", nx, ny, nz);
         return C21CM_VALUE_ERROR;
@@ -738,6 +882,7 @@ extern "C" int c21hip_split_filter_c2r(const float *split_src, float *split_work
         c21hip_set_error("filter type %d is not implemented on the device", filter_type);
         return C21CM_VALUE_ERROR;
     }
+    hipStream_t stream = (hipStream_t)stream_;
     const int H = nz / 2;
     const long nlines = (long)nx * ny;
     const float2 *src_main = reinterpret_cast<const float2 *>(split_src);
@@ -793,15 +938,56 @@ extern "C" int c21hip_split_filter_c2r(const float *split_src, float *split_work
     a.col_stride = ny;
     a.n_outer = 1;
     a.n_ctiles = nx / TZ;
-    if ((st = dispatch_line_pass<+1>(ny, a, false, stream))) return st;
-    // ---- pass Z
+    return dispatch_line_pass<+1>(ny, a, false, stream);
+}
+
+// Pass Z: split_work -> real rows of out_zstride floats.
+extern "C" int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstride,
+                                  int nx, int ny, int nz, void *stream) {
+    const long nlines = (long)nx * ny;
     ZPassArgs z{};
-    z.main = w_main;
-    z.nyq = w_nyq;
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
     z.out = real_out;
     z.out_zstride = out_zstride;
     z.out_scale = 1.0f;
-    return dispatch_z_c2r(nz, z, nlines, stream);
+    return dispatch_z_c2r(nz, z, nlines, (hipStream_t)stream);
+}
+
+// Inverse transform of a split spectrum: passes X, Y, Z.
+extern "C" int c21hip_split_filter_c2r(const float *split_src, float *split_work, float *real_out,
+                                       long out_zstride, int nx, int ny, int nz, double box_len,
+                                       double box_len_z, int filter_type, float R, float R_param,
+                                       int apply, void *stream) {
+    int st = c21hip_split_filter_xy(split_src, split_work, nx, ny, nz, box_len, box_len_z,
+                                    filter_type, R, R_param, apply, stream);
+    if (st) return st;
+    return c21hip_split_z_c2r(split_work, real_out, out_zstride, nx, ny, nz, stream);
+}
+
+// Fused pass Z of the density and emissivity grids + f_coll sum + ionisation barrier
+// (Lagrangian source grids, radius index > 0).  partials: nx*ny/16 doubles.
+extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float *stars_work,
+                                           unsigned char *first_cross, double *partials,
+                                           double *sum_out, int nx, int ny, int nz, int r_index,
+                                           double rhocrit_omb, double ion_eff, int mass_dep_zeta,
+                                           double f_limit, void *stream) {
+    const long nlines = (long)nx * ny;
+    ZFusedArgs a{};
+    a.d_main = reinterpret_cast<const float2 *>(delta_work);
+    a.d_nyq = a.d_main + nlines * (nz / 2);
+    a.s_main = reinterpret_cast<const float2 *>(stars_work);
+    a.s_nyq = a.s_main + nlines * (nz / 2);
+    a.first_cross = first_cross;
+    a.partials = partials;
+    a.rhocrit_omb = rhocrit_omb;
+    a.ion_eff = ion_eff;
+    a.f_limit = f_limit;
+    a.mass_dep_zeta = mass_dep_zeta;
+    a.r_index = r_index;
+    int st = dispatch_z_fused(nz, a, nlines, (hipStream_t)stream);
+    if (st) return st;
+    return c21hip_reduce_sum(partials, (int)(nlines / LZ), sum_out, stream);
 }
 
 // Generic in-place c2r on the FFTW-style padded layout (used by c21cm_fft_c2r and the

@@ -546,6 +546,13 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
     return 0;
 }
 
+extern "C" int c21hip_reduce_sum(const double *partials, int n, double *out, void *stream) {
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, n, 0, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int c21hip_finish_mean(const double *sum_dev, double ntot, int mass_dep_zeta,
                                   double f_limit, double *mean_dev, void *stream) {
     hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sum_dev, ntot,

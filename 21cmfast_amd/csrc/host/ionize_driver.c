@@ -47,7 +47,8 @@ enum {
     WS_FIRST_CROSS,
     WS_DELTA_WORK,
     WS_STARS_WORK,
-    WS_XE_WORK
+    WS_XE_WORK,
+    WS_PARTIALS
 };
 
 #define MAX_COPYBACK 8
@@ -59,8 +60,7 @@ typedef struct {
 } copyback_list;
 
 /* device scalar block layout (doubles) */
-#define SC_PARTIALS 0
-#define SC_SUMS (C21HIP_PARTIALS)
+#define SC_SUMS 0
 #define SC_MEANS (SC_SUMS + C21CM_MAX_RADII)
 #define SC_MINMAX (SC_MEANS + C21CM_MAX_RADII)
 #define SC_XHSUM (SC_MINMAX + 2)
@@ -201,7 +201,10 @@ typedef struct {
     /* dense outputs */
     float *xH, *zre, *Tk, *nion_dense;
     double *scalars;
+    double *partials; /* >= max(C21HIP_PARTIALS, nx*ny/16) doubles */
     float *table_dev;
+    unsigned char *mask; /* internal first-crossing mask of the fused single-GPU path */
+    int fused;           /* fused pass Z + barrier available for radius index > 0 */
     copyback_list cb;
 } ion_ctx;
 
@@ -240,6 +243,15 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
         if (c->native && !(c->xe_work = (float *)c21hip_ws(WS_XE_WORK, gbytes)))
             return C21CM_MEMORY_ALLOC_ERROR;
     }
+    {
+        size_t np = (size_t)c->nx * c->ny / 16;
+        if (np < C21HIP_PARTIALS) np = C21HIP_PARTIALS;
+        c->partials = (double *)c21hip_ws(WS_PARTIALS, np * sizeof(double));
+        if (!c->partials) return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    /* Lagrangian grids without the x_e grid: passes Z of both grids, the f_coll sum and the
+     * barrier test run as one kernel that only updates a uint8 first-crossing mask */
+    c->fused = c->native && c->lagrangian && !s->use_ts_fluct;
     c->scalars = (double *)c21hip_ws(WS_SCALARS, SC_COUNT * sizeof(double));
     c->table_dev = (float *)c21hip_ws(WS_TABLE, C21CM_NDELTA_TABLE * sizeof(float));
     if (!c->scalars || !c->table_dev) return C21CM_MEMORY_ALLOC_ERROR;
@@ -353,12 +365,26 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross) {
     const c21cm_ionize_spec *s = c->s;
     const int apply = R_ct > 0; /* copy_filter_transform skips filter_box at R_index 0 (:606) */
     const float R = (float)s->R[R_ct];
-    double *partials = c->scalars + SC_PARTIALS;
+    double *partials = c->partials;
     double *sum_dev = c->scalars + SC_SUMS + R_ct;
     double *mean_dev = c->scalars + SC_MEANS + R_ct;
     c21hip_ionize_args args;
     fill_args(&args, s, R_ct);
 
+    if (c->fused && first_cross && R_ct > 0) {
+        TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
+                                   s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+        TRY(c21hip_split_filter_xy(c->stars_unf, c->stars_work, c->nx, c->ny, c->nz, s->box_len,
+                                   s->box_len_z, s->stars_filter, R, (float)s->mfp_meandens,
+                                   apply, c->stream));
+        TRY(c21hip_split_z_ionise_stars(c->delta_work, c->stars_work, first_cross, partials,
+                                        sum_dev, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
+                                        s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
+                                        c->stream));
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               mean_dev, c->stream));
+        goto done;
+    }
     TRY(filter_to_real(c, c->delta_unf, c->delta_work, c->delta_fil, s->hii_filter, R, 0.f,
                        apply));
     if (c->lagrangian)
@@ -418,8 +444,7 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
     double host_sc[SC_COUNT - SC_SUMS];
     int *flag_dev = (int *)(c->scalars + SC_FLAG);
     TRY(c21hip_finalize(&args, s->stored_redshift, c->density, c->Tneutral, c->xH, c->zre, c->Tk,
-                        c->ntot, c->scalars + SC_PARTIALS, c->scalars + SC_XHSUM, flag_dev,
-                        c->stream));
+                        c->ntot, c->partials, c->scalars + SC_XHSUM, flag_dev, c->stream));
     TRY(c21hip_d2h(host_sc, c->scalars + SC_SUMS, sizeof(host_sc), c->stream));
     for (int i = 0; i < c->cb.n; i++)
         TRY(c21hip_d2h(c->cb.host[i], c->cb.dev[i], c->cb.bytes[i], c->stream));
@@ -483,9 +508,29 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
     TRY(init_output_grids(&c, previous_ionize_box));
     TRY(preloop(&c));
     TRY(c21hip_event_record(ev[1], stream));
-    for (int R_ct = spec->n_radii; R_ct--;) {
-        if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
-        TRY(one_radius(&c, R_ct, NULL));
+    if (c.fused) {
+        c.mask = (unsigned char *)c21hip_ws(WS_FIRST_CROSS, c.ntot);
+        if (!c.mask) {
+            status = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+        TRY(c21hip_memset(c.mask, 0, c.ntot, stream));
+    }
+    {
+        int mask_pending = c.fused;
+        for (int R_ct = spec->n_radii; R_ct--;) {
+            if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
+            if (R_ct == 0 && mask_pending) {
+                /* the cell-scale radius tests xH > TINY: materialise the mask first */
+                TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot,
+                                             spec->redshift, c.xH, c.zre, c.ntot, stream));
+                mask_pending = 0;
+            }
+            TRY(one_radius(&c, R_ct, (R_ct > 0 && c.fused) ? c.mask : NULL));
+        }
+        if (mask_pending)
+            TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot, spec->redshift,
+                                         c.xH, c.zre, c.ntot, stream));
     }
     TRY(c21hip_event_record(ev[2], stream));
     TRY(postloop(&c, box, report));
