@@ -61,7 +61,7 @@ int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstrid
                        int nz, void *stream);
 /* Fused pass Z of delta_R and the filtered emissivity + sum(stars) + ionisation barrier for
  * Lagrangian source grids at radius index > 0; writes only first_cross (uint8 [N]).
- * partials: nx*ny/16 doubles.  reference: IonisationBox.c:634-638,821-837,1054-1151 */
+ * partials: nx*ny/8 doubles.  reference: IonisationBox.c:634-638,821-837,1054-1151 */
 int c21hip_split_z_ionise_stars(const float *delta_work, const float *stars_work,
                                 unsigned char *first_cross, double *partials, double *sum_out,
                                 int nx, int ny, int nz, int r_index, double rhocrit_omb,

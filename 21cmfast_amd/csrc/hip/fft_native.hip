@@ -203,31 +203,49 @@ struct ExpMfpConsts {
 };
 struct FilterParams {
     int type;  // -1: no filter
+    int libm_trig;  // 1: general-range library sincos instead of fast_sincos (A/B switch)
     float R, R_param;
     double dkx, dky, dkz;
     ExpMfpConsts mfp;
 };
 
-__device__ __forceinline__ double w_tophat(double kR) {
-    if (kR < 1e-4) return 1 - kR * kR / 10;
-    double s, c;
-    sincos(kR, &s, &c);
-    return 3.0 / (kR * kR * kR) * (s - c * kR);
+// sin and cos of a non-negative argument below ~1e6 (kR never exceeds a few hundred here):
+// two-constant Cody-Waite reduction with FMA (r = x - n*pi/2 to < 1 ulp) followed by the
+// classic minimax kernels on [-pi/4, pi/4].  Results agree with a correctly rounded libm
+// to ~1 ulp (double) at about a quarter of the instructions of the general-range routine,
+// whose huge-argument path these kernels never need.
+__device__ __forceinline__ void fast_sincos(double x, double *sn, double *cs) {
+    const double n = rint(x * 6.36619772367581382433e-01);  // 2/pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);       // pi/2 high
+    r = fma(-n, 6.12323399573676603587e-17, r);              // pi/2 low
+    const double z = r * r;
+    const double ps = 8.33333333332248946124e-03 +
+                      z * (-1.98412698298579493134e-04 +
+                           z * (2.75573137070700676789e-06 +
+                                z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 +
+                           z * (-1.38888888888741095749e-03 +
+                                z * (2.48015872894767294178e-05 +
+                                     z * (-2.75573143513906633035e-07 +
+                                          z * (2.08757232129817482790e-09 +
+                                               z * -1.13596475577881948265e-11)))));
+    const double c = 1.0 - (0.5 * z - z * pc);
+    const int q = (int)n & 3;
+    const double ss = (q & 1) ? c : s;
+    const double cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
 }
-__device__ __forceinline__ double w_exp_mfp(double k, const ExpMfpConsts &c) {
-    const double kR = k * c.R;
-    if (kR < 1e-4) return c.ts_0 + c.ts_2 * kR * kR;
-    double s, co;
-    sincos(kR, &s, &co);
-    double f = (kR * kR * c.ratio2 + 2 * c.ratio + 1) * c.ratio * co;
-    f += (kR * kR * (c.ratio2 - c.ratio3) + c.ratio + 1) * s / kR;
-    f *= c.exp_term;
-    f -= 2 * c.ratio2;
-    const double d = kR * c.ratio * kR * c.ratio + 1;
-    f *= -3 * c.ratio / (d * d);
-    return f;
+
+__device__ __forceinline__ void sincos_sel(int libm, double x, double *s, double *c) {
+    if (libm)
+        sincos(x, s, c);
+    else
+        fast_sincos(x, s, c);
 }
-__device__ __forceinline__ double w_shell(double k, double R_inner, double R_outer) {
+
+__device__ __forceinline__ double w_shell(double k, double R_inner, double R_outer, int libm) {
     const double kRi = k * R_inner, kRo = k * R_outer;
     if (kRo < 1e-4) {
         const double q = R_inner / R_outer;
@@ -235,34 +253,76 @@ __device__ __forceinline__ double w_shell(double k, double R_inner, double R_out
         return 1. - kRo * kRo / 10 * (q3 * q * q - 1) / (q3 - 1);
     }
     double si, ci, so, co;
-    sincos(kRi, &si, &ci);
-    sincos(kRo, &so, &co);
+    sincos_sel(libm, kRi, &si, &ci);
+    sincos_sel(libm, kRo, &so, &co);
     return 3.0 / (kRo * kRo * kRo - kRi * kRi * kRi) * (so - co * kRo - si + ci * kRi);
 }
 __device__ __forceinline__ float k_of(int n, int dim, double dk) {
     return (n > dim / 2) ? (float)((double)(n - dim) * dk) : (float)((double)n * dk);
 }
-__device__ __forceinline__ double window_of(const FilterParams &p, float k_x, float k_y,
-                                            float k_z) {
-    const float k_mag_sq =
-        __fadd_rn(__fadd_rn(__fmul_rn(k_x, k_x), __fmul_rn(k_y, k_y)), __fmul_rn(k_z, k_z));
-    switch (p.type) {
-        case 0: {
-            float kR = (float)(sqrt((double)k_mag_sq) * (double)p.R);
-            return w_tophat((double)kR);
+// Window values for NE modes at once.  The filter-type switch is hoisted out of the
+// per-mode work and every step is written as a loop over the NE independent values, so
+// the fp64 dependency chains (sqrt -> reduce -> polynomial -> divide) of different modes
+// interleave instead of running back to back: with only two waves per SIMD in the line
+// pass, instruction-level parallelism is what hides the fp64 latency.
+template <int NE>
+__device__ __forceinline__ void window_batch(const FilterParams &p, const float (&kx)[NE],
+                                             const float (&ky)[NE], const float (&kz)[NE],
+                                             double (&w)[NE]) {
+    float ksq[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++)
+        ksq[i] = __fadd_rn(__fadd_rn(__fmul_rn(kx[i], kx[i]), __fmul_rn(ky[i], ky[i])),
+                           __fmul_rn(kz[i], kz[i]));
+    if (p.type == 2) {  // Gaussian: kR^2 held in float (filtering.c:369)
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const float kR = __fmul_rn(__fmul_rn(ksq[i], p.R), p.R);
+            w[i] = exp(-0.643 * 0.643 * (double)kR / 2.);
         }
-        case 1: {
-            float kR = (float)(sqrt((double)k_mag_sq) * (double)p.R);
-            return ((double)kR * 0.413566994 > 1) ? 0. : 1.;
+        return;
+    }
+    double k[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) k[i] = sqrt((double)ksq[i]);
+    if (p.type == 4) {
+#pragma unroll
+        for (int i = 0; i < NE; i++)
+            w[i] = w_shell(k[i], (double)p.R, (double)p.R_param, p.libm_trig);
+        return;
+    }
+    // types 0, 1 hold kR in float (filtering.c:331,357,364); type 3 keeps it in double (:83)
+    double x[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++)
+        x[i] = (p.type == 3) ? k[i] * p.mfp.R : (double)(float)(k[i] * (double)p.R);
+    if (p.type == 1) {
+#pragma unroll
+        for (int i = 0; i < NE; i++) w[i] = (x[i] * 0.413566994 > 1) ? 0. : 1.;
+        return;
+    }
+    double sn[NE], cs[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) sincos_sel(p.libm_trig, x[i], &sn[i], &cs[i]);
+    if (p.type == 0) {
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const double kR = x[i];
+            w[i] = (kR < 1e-4) ? 1 - kR * kR / 10 : 3.0 / (kR * kR * kR) * (sn[i] - cs[i] * kR);
         }
-        case 2: {
-            float kR = __fmul_rn(__fmul_rn(k_mag_sq, p.R), p.R);
-            return exp(-0.643 * 0.643 * (double)kR / 2.);
+    } else {  // type 3, filtering.c:80-104
+        const ExpMfpConsts &c = p.mfp;
+#pragma unroll
+        for (int i = 0; i < NE; i++) {
+            const double kR = x[i];
+            double f = (kR * kR * c.ratio2 + 2 * c.ratio + 1) * c.ratio * cs[i];
+            f += (kR * kR * (c.ratio2 - c.ratio3) + c.ratio + 1) * sn[i] / kR;
+            f *= c.exp_term;
+            f -= 2 * c.ratio2;
+            const double d = kR * c.ratio * kR * c.ratio + 1;
+            f *= -3 * c.ratio / (d * d);
+            w[i] = (kR < 1e-4) ? c.ts_0 + c.ts_2 * kR * kR : f;
         }
-        case 3:
-            return w_exp_mfp(sqrt((double)k_mag_sq), p.mfp);
-        default:
-            return w_shell(sqrt((double)k_mag_sq), (double)p.R, (double)p.R_param);
     }
 }
 
@@ -374,16 +434,30 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                     kz[e] = (float)((double)(a.n_z / 2) * a.fp.dkz);
                 }
             }
+            {
+                float kxs[2 * NP], kys[2 * NP], kzs[2 * NP];
+                double ws[2 * NP];
 #pragma unroll
-            for (int u = 0; u < NP; u++) {
-                const float kx = k_of(r0 + RSTEP * u, N, a.fp.dkx);
+                for (int u = 0; u < NP; u++) {
+                    const float kx = k_of(r0 + RSTEP * u, N, a.fp.dkx);
 #pragma unroll
-                for (int e = 0; e < 2; e++) w[u][e] = window_of(a.fp, kx, ky[e], kz[e]);
-            }
-            if (r0 == 0) {
-                const float kx = k_of(N / 2, N, a.fp.dkx);
+                    for (int e = 0; e < 2; e++) {
+                        kxs[2 * u + e] = kx;
+                        kys[2 * u + e] = ky[e];
+                        kzs[2 * u + e] = kz[e];
+                    }
+                }
+                window_batch<2 * NP>(a.fp, kxs, kys, kzs, ws);
 #pragma unroll
-                for (int e = 0; e < 2; e++) w_half[e] = window_of(a.fp, kx, ky[e], kz[e]);
+                for (int u = 0; u < NP; u++) {
+                    w[u][0] = ws[2 * u];
+                    w[u][1] = ws[2 * u + 1];
+                }
+                if (r0 == 0) {  // row N/2 (paired with row 0) has its own |k_x|: lanes 0-7 of wave 0
+                    const float kxh = k_of(N / 2, N, a.fp.dkx);
+                    float kx2[2] = {kxh, kxh};
+                    window_batch<2>(a.fp, kx2, ky, kz, w_half);
+                }
             }
         }
         const long base = tile_base(mi == 0 ? og : a.n_outer - og, ct);
@@ -460,8 +534,8 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
 // (imaginary parts of X[0] and X[H] are ignored, as any c2r transform does).
 // LZ = 16 consecutive lines per workgroup; LDS tile[k][line] with a row of LZ+1 so that both
 // the transposing fill (lanes along k) and the FFT (lanes along line) are conflict free.
-constexpr int LZ = 16;
-constexpr int ZROW = LZ + 1;
+constexpr int LZ_PLAIN = 16;  // lines per workgroup, plain pass Z
+constexpr int LZ_FUSED = 8;   // fused pass Z: smaller blocks -> 8 workgroups per CU
 
 struct ZPassArgs {
     const float2 *main;  // [lines][H]
@@ -472,34 +546,35 @@ struct ZPassArgs {
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
-template <int NZ>
+template <int NZ, int LZ>
 struct ZGeom {
     static constexpr int H = NZ / 2;
+    static constexpr int ZROW = LZ + 1;
     static constexpr int NF4 = LZ * H / 2;                       // float4 per 16-line block
     static constexpr int NLOAD = (NF4 + kBlock - 1) / kBlock;    // float4 loads per thread
     static constexpr int NOUT = LZ * H / kBlock;                 // float2 outputs per thread
 };
 
-template <int NZ>
+template <int NZ, int LZ>
 __device__ __forceinline__ void z_issue_loads(const float2 *main, long l0,
-                                              float4 (&reg)[ZGeom<NZ>::NLOAD]) {
-    constexpr int H = ZGeom<NZ>::H, NF4 = ZGeom<NZ>::NF4;
+                                              float4 (&reg)[ZGeom<NZ, LZ>::NLOAD]) {
+    constexpr int H = ZGeom<NZ, LZ>::H, NF4 = ZGeom<NZ, LZ>::NF4;
     const float4 *src4 = reinterpret_cast<const float4 *>(main + l0 * H);
 #pragma unroll
-    for (int u = 0; u < ZGeom<NZ>::NLOAD; u++) {
+    for (int u = 0; u < ZGeom<NZ, LZ>::NLOAD; u++) {
         const int f = threadIdx.x + kBlock * u;
         if (NF4 % kBlock == 0 || f < NF4) reg[u] = src4[f];
     }
 }
 
 // registers -> tile[k][line] (transposing), Hermitian pre-processing, length-H inverse FFT
-template <int NZ>
+template <int NZ, int LZ>
 __device__ __forceinline__ void z_transform(float2 *tile, const float2 *twH, const float2 *twN,
-                                            const float4 (&reg)[ZGeom<NZ>::NLOAD],
+                                            const float4 (&reg)[ZGeom<NZ, LZ>::NLOAD],
                                             const float2 *nyq, long l0) {
-    constexpr int H = ZGeom<NZ>::H, NF4 = ZGeom<NZ>::NF4;
+    constexpr int H = ZGeom<NZ, LZ>::H, NF4 = ZGeom<NZ, LZ>::NF4, ZROW = LZ + 1;
 #pragma unroll
-    for (int u = 0; u < ZGeom<NZ>::NLOAD; u++) {
+    for (int u = 0; u < ZGeom<NZ, LZ>::NLOAD; u++) {
         const int f = threadIdx.x + kBlock * u;
         if (NF4 % kBlock == 0 || f < NF4) {
             const int e = 2 * f;
@@ -536,7 +611,7 @@ template <int NZ>
 __global__ void __launch_bounds__(kBlock)
 z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
              const float2 *__restrict__ twN_global) {
-    constexpr int H = NZ / 2;
+    constexpr int H = NZ / 2, LZ = LZ_PLAIN, ZROW = LZ + 1;
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [H][ZROW]
     float2 *twH = tile + H * ZROW;                       // [H]
@@ -545,12 +620,12 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     for (int t = threadIdx.x; t <= H / 2; t += kBlock) twN[t] = twN_global[t];
 
     const long l0 = (long)blockIdx.x * LZ;
-    float4 reg[ZGeom<NZ>::NLOAD];
-    z_issue_loads<NZ>(a.main, l0, reg);
-    z_transform<NZ>(tile, twH, twN, reg, a.nyq, l0);
+    float4 reg[ZGeom<NZ, LZ>::NLOAD];
+    z_issue_loads<NZ, LZ>(a.main, l0, reg);
+    z_transform<NZ, LZ>(tile, twH, twN, reg, a.nyq, l0);
     // ---- store: lanes along j, one float2 = (x[2j], x[2j+1])
 #pragma unroll
-    for (int u = 0; u < ZGeom<NZ>::NOUT; u++) {
+    for (int u = 0; u < ZGeom<NZ, LZ>::NOUT; u++) {
         const int f = threadIdx.x + kBlock * u;
         const int li = f / H, j = f % H;
         float2 v = tile[j * ZROW + li];
@@ -579,7 +654,7 @@ struct ZFusedArgs {
     const float2 *d_main, *d_nyq;  // filtered density spectrum after passes X, Y
     const float2 *s_main, *s_nyq;  // filtered emissivity spectrum
     unsigned char *first_cross;    // [lines][NZ]
-    double *partials;              // one per workgroup
+    double *partials;              // one per workgroup (nx*ny/LZ_FUSED)
     double rhocrit_omb, ion_eff, f_limit;
     int mass_dep_zeta, r_index;
 };
@@ -588,8 +663,8 @@ template <int NZ>
 __global__ void __launch_bounds__(kBlock)
 z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                     const float2 *__restrict__ twN_global) {
-    constexpr int H = NZ / 2;
-    constexpr int NOUT = ZGeom<NZ>::NOUT;
+    constexpr int H = NZ / 2, LZ = LZ_FUSED, ZROW = LZ + 1;
+    constexpr int NOUT = ZGeom<NZ, LZ>::NOUT;
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);
     float2 *twH = tile + H * ZROW;
@@ -598,9 +673,9 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     for (int t = threadIdx.x; t <= H / 2; t += kBlock) twN[t] = twN_global[t];
 
     const long l0 = (long)blockIdx.x * LZ;
-    float4 reg_d[ZGeom<NZ>::NLOAD], reg_s[ZGeom<NZ>::NLOAD];
-    z_issue_loads<NZ>(a.d_main, l0, reg_d);
-    z_issue_loads<NZ>(a.s_main, l0, reg_s);  // in flight during the first transform
+    float4 reg_d[ZGeom<NZ, LZ>::NLOAD], reg_s[ZGeom<NZ, LZ>::NLOAD];
+    z_issue_loads<NZ, LZ>(a.d_main, l0, reg_d);
+    z_issue_loads<NZ, LZ>(a.s_main, l0, reg_s);  // in flight during the first transform
     // the mask rows of this block, also early
     uchar2 old[NOUT];
 #pragma unroll
@@ -609,7 +684,7 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         const int li = f / H, j = f % H;
         old[u] = reinterpret_cast<const uchar2 *>(a.first_cross + (l0 + li) * NZ)[j];
     }
-    z_transform<NZ>(tile, twH, twN, reg_d, a.d_nyq, l0);
+    z_transform<NZ, LZ>(tile, twH, twN, reg_d, a.d_nyq, l0);
     float2 dens[NOUT];
 #pragma unroll
     for (int u = 0; u < NOUT; u++) {
@@ -618,7 +693,7 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         dens[u] = tile[j * ZROW + li];
     }
     __syncthreads();
-    z_transform<NZ>(tile, twH, twN, reg_s, a.s_nyq, l0);
+    z_transform<NZ, LZ>(tile, twH, twN, reg_s, a.s_nyq, l0);
 
     const bool floor_ionises = a.mass_dep_zeta && (a.f_limit * a.ion_eff > 1.);
     const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
@@ -759,14 +834,14 @@ int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
     const float2 *twH = twiddles(H);
     const float2 *twN = twiddles(NZ);
     if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
-    const size_t lds = sizeof(float2) * ((size_t)H * ZROW + H + H / 2 + 1);
+    const size_t lds = sizeof(float2) * ((size_t)H * (LZ_PLAIN + 1) + H + H / 2 + 1);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)z_c2r_kernel<NZ>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((z_c2r_kernel<NZ>), dim3((unsigned)(nlines / LZ)), dim3(kBlock), lds, stream,
+    hipLaunchKernelGGL((z_c2r_kernel<NZ>), dim3((unsigned)(nlines / LZ_PLAIN)), dim3(kBlock), lds, stream,
                        a, twH, twN);
     LAUNCH_CHECK();
     return 0;
@@ -778,14 +853,14 @@ int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
     const float2 *twH = twiddles(H);
     const float2 *twN = twiddles(NZ);
     if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
-    const size_t lds = sizeof(float2) * ((size_t)H * ZROW + H + H / 2 + 1);
+    const size_t lds = sizeof(float2) * ((size_t)H * (LZ_FUSED + 1) + H + H / 2 + 1);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)z_c2r_ionise_kernel<NZ>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((z_c2r_ionise_kernel<NZ>), dim3((unsigned)(nlines / LZ)), dim3(kBlock), lds,
+    hipLaunchKernelGGL((z_c2r_ionise_kernel<NZ>), dim3((unsigned)(nlines / LZ_FUSED)), dim3(kBlock), lds,
                        stream, a, twH, twN);
     LAUNCH_CHECK();
     return 0;
@@ -821,6 +896,14 @@ int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) 
 void fill_filter(FilterParams &fp, int filter_type, float R, float R_param, double box_len,
                  double box_len_z) {
     fp.type = filter_type;
+    {
+        static int libm = -1;
+        if (libm < 0) {
+            const char *e = getenv("C21CM_TRIG");
+            libm = (e && e[0] == 'l') ? 1 : 0;  // C21CM_TRIG=libm
+        }
+        fp.libm_trig = libm;
+    }
     fp.R = R;
     fp.R_param = R_param;
     fp.dkx = 2.0 * M_PI / box_len;
@@ -966,7 +1049,7 @@ extern "C" int c21hip_split_filter_c2r(const float *split_src, float *split_work
 }
 
 // Fused pass Z of the density and emissivity grids + f_coll sum + ionisation barrier
-// (Lagrangian source grids, radius index > 0).  partials: nx*ny/16 doubles.
+// (Lagrangian source grids, radius index > 0).  partials: nx*ny/8 doubles.
 extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float *stars_work,
                                            unsigned char *first_cross, double *partials,
                                            double *sum_out, int nx, int ny, int nz, int r_index,
@@ -987,7 +1070,7 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
     a.r_index = r_index;
     int st = dispatch_z_fused(nz, a, nlines, (hipStream_t)stream);
     if (st) return st;
-    return c21hip_reduce_sum(partials, (int)(nlines / LZ), sum_out, stream);
+    return c21hip_reduce_sum(partials, (int)(nlines / LZ_FUSED), sum_out, stream);
 }
 
 // Generic in-place c2r on the FFTW-style padded layout (used by c21cm_fft_c2r and the

@@ -122,8 +122,9 @@ __device__ __forceinline__ float partially_ionized_T(float T_HI, float res_xH, f
     return (float)((double)__fmul_rn(T_HI, res_xH) + (double)T_re * (1. - (double)res_xH));
 }
 
-// reference: thermochem.c:31-56
-__device__ float fully_ionized_T(float z_re, float z, float delta, float T_re) {
+// reference: thermochem.c:31-56.  pow_Tre = pow(T_re, 1.7) and pow_z = pow(1e4*((1+z)/4), 1.7)
+// do not depend on the cell and are passed in (same double values the reference computes).
+__device__ float fully_ionized_T(float z_re, float z, float delta, double pow_Tre, double pow_z) {
     float result, delta_re;
     if (fabs((double)(z - z_re)) < 1e-4) {
         result = 1.f;
@@ -136,9 +137,8 @@ __device__ float fully_ionized_T(float z_re, float z, float delta, float T_re) {
         result = __fmul_rn(result, expf((float)(pow((1. + (double)z) / 7.1, 2.5) -
                                                 pow((1. + (double)z_re) / 7.1, 2.5))));
     }
-    result = (float)((double)result * pow((double)T_re, 1.7));
-    result = (float)((double)result +
-                     pow(1e4 * ((1. + (double)z) / 4.), 1.7) * (double)(1.f + delta));
+    result = (float)((double)result * pow_Tre);
+    result = (float)((double)result + pow_z * (double)(1.f + delta));
     result = (float)pow((double)result, 0.5882);
     return result;
 }
@@ -432,6 +432,8 @@ finalize_kernel(c21hip_ionize_args a, float stored_z, const float *__restrict__ 
                 double *__restrict__ partials, int *__restrict__ flag) {
     double acc = 0.;
     int bad = 0;
+    const double pow_Tre = pow((double)(float)a.T_re, 1.7);
+    const double pow_z = pow(1e4 * ((1. + (double)stored_z) / 4.), 1.7);
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
          i += (size_t)gridDim.x * kBlock) {
         const float x = xH[i];
@@ -441,7 +443,7 @@ finalize_kernel(c21hip_ionize_args a, float stored_z, const float *__restrict__ 
             float T = Tk[i];
             if (zr > 0.f && (double)x < kTiny) {  // IonisationBox.c:1218
                 const float dens = density[i];
-                T = fully_ionized_T(zr, stored_z, dens, (float)a.T_re);
+                T = fully_ionized_T(zr, stored_z, dens, pow_Tre, pow_z);
                 const float floorT =
                     a.use_ts_fluct ? Tneutral[i]
                                    : (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)dens));
@@ -546,7 +548,43 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
     return 0;
 }
 
+// chunked first level for long partial arrays: block b sums partials[b*chunk .. ), fixed order
+__global__ void __launch_bounds__(kBlock)
+chunk_reduce_kernel(const double *__restrict__ partials, int n, int chunk,
+                    double *__restrict__ out) {
+    __shared__ double lds[kBlock];
+    const int lo = blockIdx.x * chunk;
+    const int hi = min(n, lo + chunk);
+    double acc = 0.;
+    for (int i = lo + threadIdx.x; i < hi; i += kBlock) acc += partials[i];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = lds[0];
+}
+
+// Deterministic sum of n doubles.  Long inputs are reduced in place in two levels (the
+// first level overwrites partials[0 .. n/1024)).
 extern "C" int c21hip_reduce_sum(const double *partials, int n, double *out, void *stream) {
+    if (n > 4096) {
+        const int chunk = 1024;
+        const int nb = (n + chunk - 1) / chunk;
+        // level 1 writes into the tail-safe front of the same buffer: block b only reads
+        // indices >= b*1024 and writes index b <= its own first read, after all reads of
+        // lower blocks' ranges are irrelevant to it -- but to stay race-free regardless of
+        // scheduling, stage through the second half of the scratch instead
+        double *stage = const_cast<double *>(partials) + n;
+        hipLaunchKernelGGL(chunk_reduce_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                           partials, n, chunk, stage);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                           stage, nb, 0, out);
+        LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
                        partials, n, 0, out);
     LAUNCH_CHECK();

@@ -201,7 +201,7 @@ typedef struct {
     /* dense outputs */
     float *xH, *zre, *Tk, *nion_dense;
     double *scalars;
-    double *partials; /* >= max(C21HIP_PARTIALS, nx*ny/16) doubles */
+    double *partials; /* >= max(C21HIP_PARTIALS, nx*ny/8) doubles */
     float *table_dev;
     unsigned char *mask; /* internal first-crossing mask of the fused single-GPU path */
     int fused;           /* fused pass Z + barrier available for radius index > 0 */
@@ -244,7 +244,8 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             return C21CM_MEMORY_ALLOC_ERROR;
     }
     {
-        size_t np = (size_t)c->nx * c->ny / 16;
+        size_t np = (size_t)c->nx * c->ny / 8;
+        np += np / 1024 + 2; /* stage area of the two-level reduction */
         if (np < C21HIP_PARTIALS) np = C21HIP_PARTIALS;
         c->partials = (double *)c21hip_ws(WS_PARTIALS, np * sizeof(double));
         if (!c->partials) return C21CM_MEMORY_ALLOC_ERROR;
