@@ -326,6 +326,58 @@ __device__ __forceinline__ void window_batch(const FilterParams &p, const float 
     }
 }
 
+// ------------------------------------------------------------------ 1-D window table
+// On a cubic grid |k|^2 = dk^2 * m with the integer m = nx^2 + ny^2 + nz^2 <= 3 (N/2)^2, so
+// the window takes at most 3(N/2)^2 + 1 distinct values per (filter, R): ~2e5 evaluations
+// instead of the reference's N^3/2 (6.7e7 at 512^3).  The reference, however, holds
+// k_x, k_y, k_z and |k|^2 in float (filtering.c:331-350), so its |k|^2 differs from
+// dk^2 * m by float rounding (~1e-7 relative).  The table therefore stores
+//     { W(m), dW/d(k^2)(m) }
+// and pass X evaluates  W(m) + dW/d(k^2) * (ksq_float - dk^2 m)  with ksq_float computed
+// exactly as the reference does: first order in a 1e-7 perturbation, i.e. equal to the
+// direct evaluation to ~1e-13.  What is NOT replicated is the additional float rounding
+// of the product kR for filter types 0/1 (filtering.c:357): |dW| <= 3e-8 |x W'(x)| < 1e-7,
+// far inside the float32 noise of the transforms.  Opt-in with C21CM_WINDOW=table: the
+// per-mode evaluation is the default (and faster, see window_table_enabled()).
+__device__ double window_exact(const FilterParams &p, double ksq) {
+    const double k = sqrt(ksq);
+    double s, c;
+    if (p.type == 0) {
+        const double x = k * (double)p.R;
+        if (x < 1e-4) return 1 - x * x / 10;
+        sincos(x, &s, &c);
+        return 3.0 / (x * x * x) * (s - c * x);
+    }
+    if (p.type == 3) {
+        const ExpMfpConsts &m = p.mfp;
+        const double x = k * m.R;
+        if (x < 1e-4) return m.ts_0 + m.ts_2 * x * x;
+        sincos(x, &s, &c);
+        double f = (x * x * m.ratio2 + 2 * m.ratio + 1) * m.ratio * c;
+        f += (x * x * (m.ratio2 - m.ratio3) + m.ratio + 1) * s / x;
+        f *= m.exp_term;
+        f -= 2 * m.ratio2;
+        const double d = x * m.ratio * x * m.ratio + 1;
+        return f * (-3 * m.ratio / (d * d));
+    }
+    return w_shell(k, (double)p.R, (double)p.R_param, 1);
+}
+
+__global__ void __launch_bounds__(kBlock)
+window_table_kernel(FilterParams p, double dk2, int mmax, double2 *__restrict__ table) {
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    if (m > mmax) return;
+    const double ksq = (double)m * dk2;
+    const double w0 = window_exact(p, ksq);
+    double slope = 0.;
+    if (m > 0) {
+        const double h = 9.5367431640625e-07;  // 2^-20
+        slope = (window_exact(p, ksq * (1 + h)) - window_exact(p, ksq * (1 - h))) /
+                (2 * h * ksq);
+    }
+    table[m] = make_double2(w0, slope);
+}
+
 // ------------------------------------------------------------------ pass X / pass Y
 struct LinePassArgs {
     const float2 *src;
@@ -340,6 +392,8 @@ struct LinePassArgs {
                         // 1: columns are k_y, k_z fixed at nz/2 (Nyquist plane)
     int n_y, n_z;       // grid dims for the wavenumbers
     float out_scale;    // applied at store (1 = none)
+    const double2 *wtable;  // FMODE 2: {W, dW/d(k^2)} indexed by nx^2 + ny^2 + nz^2
+    double dk2;             // FMODE 2: (2 pi / L)^2
     FilterParams fp;
 };
 
@@ -357,16 +411,20 @@ __device__ __forceinline__ int mirror_row(int row_a) {
 // tile's loads are in flight, so HBM latency hides behind the LDS/ALU phase.
 // THREADS = 512 (one workgroup per CU at N >= 256, 2 waves per SIMD, <= 256 VGPRs) keeps the
 // per-thread working set small enough for the register prefetch of the next tile.
-template <int N>
+// FMODE 1 (per-mode window evaluation) runs 1024 threads: half the evaluations per thread
+// and 4 waves per SIMD to hide the fp64 latency of the window math.
+template <int N, int FMODE = 0>
 struct LineThreads {
-    static constexpr int value = (N >= 128) ? 512 : 256;
+    static constexpr int value = (FMODE == 1 && N >= 256) ? 1024 : ((N >= 128) ? 512 : 256);
 };
 
-template <int N, int SIGN, bool FILTER>
-__global__ void __launch_bounds__(LineThreads<N>::value, LineThreads<N>::value / 256)
+// FMODE: 0 no filter, 1 per-mode window evaluation, 2 window table lookup
+template <int N, int SIGN, int FMODE>
+__global__ void __launch_bounds__((LineThreads<N, FMODE>::value), (LineThreads<N, FMODE>::value / 256))
 line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
+    constexpr bool FILTER = (FMODE == 1);
     static_assert(N >= 64, "tile loader needs N >= 64");
-    constexpr int kBlock = LineThreads<N>::value;
+    constexpr int kBlock = LineThreads<N, FMODE>::value;
     constexpr int RSTEP = kBlock / 8;  // rows covered by one sweep of the workgroup
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
@@ -463,6 +521,55 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const long base = tile_base(mi == 0 ? og : a.n_outer - og, ct);
         if (!first) __syncthreads();  // the previous tile's LDS reads are done
         first = false;
+        if (FMODE == 2) {
+            // table lookup: one {W, slope} fetch per (row pair, column), shared by the mirror row
+            const int col0 = ct * TZ + 2 * c4;
+            const int outer = (mi == 0) ? og : a.n_outer - og;
+            int nya[2], nza[2];
+            float kyf[2], kzf[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (a.filter_axis == 0) {
+                    nya[e] = min(outer, a.n_y - outer);
+                    nza[e] = col0 + e;
+                } else {
+                    nya[e] = min(col0 + e, a.n_y - (col0 + e));
+                    nza[e] = a.n_z / 2;
+                }
+                kyf[e] = (float)((double)nya[e] * a.fp.dky);
+                kzf[e] = (float)((double)nza[e] * a.fp.dkz);
+            }
+            auto lookup = [&](int nxa, int e) {
+                const float kxf = (float)((double)nxa * a.fp.dkx);
+                const float ksq = __fadd_rn(__fadd_rn(__fmul_rn(kxf, kxf), __fmul_rn(kyf[e], kyf[e])),
+                                            __fmul_rn(kzf[e], kzf[e]));
+                const int m = nxa * nxa + nya[e] * nya[e] + nza[e] * nza[e];
+                const double2 t = a.wtable[m];
+                return fma(t.y, (double)ksq - (double)m * a.dk2, t.x);
+            };
+#pragma unroll
+            for (int up = 0; up < NP; up++) {
+                const int row_a = r0 + RSTEP * up;
+                const double w0 = lookup(row_a, 0), w1 = lookup(row_a, 1);
+                double h0 = w0, h1 = w1;
+                if (row_a == 0) {  // the mirror of row 0 is row N/2 with its own |k_x|
+                    h0 = lookup(N / 2, 0);
+                    h1 = lookup(N / 2, 1);
+                }
+                float4 v = reg[2 * up];
+                v.x = (float)((double)v.x * w0);
+                v.y = (float)((double)v.y * w0);
+                v.z = (float)((double)v.z * w1);
+                v.w = (float)((double)v.w * w1);
+                *reinterpret_cast<float4 *>(tile + row_a * TZ + 2 * c4) = v;
+                v = reg[2 * up + 1];
+                v.x = (float)((double)v.x * h0);
+                v.y = (float)((double)v.y * h0);
+                v.z = (float)((double)v.z * h1);
+                v.w = (float)((double)v.w * h1);
+                *reinterpret_cast<float4 *>(tile + mirror_row<N>(row_a) * TZ + 2 * c4) = v;
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
@@ -478,6 +585,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 v.w = (float)((double)v.w * w1);
             }
             *reinterpret_cast<float4 *>(tile + row * TZ + 2 * c4) = v;
+        }
         }
         __syncthreads();
         // ---- advance to the next tile and put its loads in flight
@@ -774,8 +882,20 @@ const float2 *twiddles(int n) {
 
 bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-template <int N, int SIGN>
-int launch_line_pass(const LinePassArgs &a, bool filter, hipStream_t stream) {
+bool window_table_enabled() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char *e = getenv("C21CM_WINDOW");
+        // Default: per-mode evaluation.  C21CM_WINDOW=table selects the 1-D table; measured
+        // on MI355X at 512^3 it is SLOWER (422 vs 365 us per pass): 16 scattered 16-byte
+        // gathers per thread and tile bottleneck the vector L1 at one line per clock.
+        cached = (e && e[0] == 't') ? 1 : 0;
+    }
+    return cached == 1;
+}
+
+template <int N, int SIGN, int FMODE>
+int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
     const float2 *tw = twiddles(N);
     if (!tw) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
@@ -786,42 +906,37 @@ int launch_line_pass(const LinePassArgs &a, bool filter, hipStream_t stream) {
     const int n_work = groups * a.n_ctiles;
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
     int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-    const int by_waves = 8 / (LineThreads<N>::value / 64);  // 2 waves per SIMD budget
+    const int by_waves = (LineThreads<N, FMODE>::value >= 512) ? 1 : 2;
     if (per_cu > by_waves) per_cu = by_waves;
     int nblocks = 256 * per_cu;
     if (nblocks > n_work) nblocks = n_work;
-    const dim3 grid((unsigned)nblocks);
-    if (filter) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)line_pass_kernel<N, SIGN, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, true>), grid, dim3(LineThreads<N>::value),
-                           lds, stream, a, tw);
-    } else {
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void *)line_pass_kernel<N, SIGN, false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((line_pass_kernel<N, SIGN, false>), grid, dim3(LineThreads<N>::value),
-                           lds, stream, a, tw);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)line_pass_kernel<N, SIGN, FMODE>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
     }
+    hipLaunchKernelGGL((line_pass_kernel<N, SIGN, FMODE>), dim3((unsigned)nblocks),
+                       dim3(LineThreads<N, FMODE>::value), lds, stream, a, tw);
     LAUNCH_CHECK();
     return 0;
 }
 
+template <int N, int SIGN>
+int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
+    if (fmode == 2) return launch_line_pass_mode<N, SIGN, 2>(a, stream);
+    if (fmode == 1) return launch_line_pass_mode<N, SIGN, 1>(a, stream);
+    return launch_line_pass_mode<N, SIGN, 0>(a, stream);
+}
+
 template <int SIGN>
-int dispatch_line_pass(int n, const LinePassArgs &a, bool filter, hipStream_t stream) {
+int dispatch_line_pass(int n, const LinePassArgs &a, int fmode, hipStream_t stream) {
     switch (n) {
-        case 64: return launch_line_pass<64, SIGN>(a, filter, stream);
-        case 128: return launch_line_pass<128, SIGN>(a, filter, stream);
-        case 256: return launch_line_pass<256, SIGN>(a, filter, stream);
-        case 512: return launch_line_pass<512, SIGN>(a, filter, stream);
-        case 1024: return launch_line_pass<1024, SIGN>(a, filter, stream);
+        case 64: return launch_line_pass<64, SIGN>(a, fmode, stream);
+        case 128: return launch_line_pass<128, SIGN>(a, fmode, stream);
+        case 256: return launch_line_pass<256, SIGN>(a, fmode, stream);
+        case 512: return launch_line_pass<512, SIGN>(a, fmode, stream);
+        case 1024: return launch_line_pass<1024, SIGN>(a, fmode, stream);
         default:
             c21hip_set_error("native FFT: unsupported line length %d", n);
             return C21CM_VALUE_ERROR;
@@ -979,6 +1094,19 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
     a.n_y = ny;
     a.n_z = nz;
     a.out_scale = 1.0f;
+    int fmode = apply ? 1 : 0;
+    if (apply && window_table_enabled() && nx == ny && ny == nz && box_len == box_len_z &&
+        (filter_type == 0 || filter_type == 3 || filter_type == 4)) {
+        const int mmax = 3 * (nx / 2) * (nx / 2);
+        double2 *table = (double2 *)c21hip_ws(49, sizeof(double2) * (size_t)(mmax + 1));
+        if (!table) return C21CM_MEMORY_ALLOC_ERROR;
+        a.dk2 = a.fp.dkx * a.fp.dkx;
+        hipLaunchKernelGGL(window_table_kernel, dim3((unsigned)((mmax + kBlock) / kBlock)),
+                           dim3(kBlock), 0, stream, a.fp, a.dk2, mmax, table);
+        LAUNCH_CHECK();
+        a.wtable = table;
+        fmode = 2;
+    }
     // ---- pass X, main block: lines along x, outer = k_y, columns = k_z
     a.src = src_main;
     a.dst = w_main;
@@ -989,7 +1117,7 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
     a.n_ctiles = H / TZ;
     a.pair_outer = 1;
     a.filter_axis = 0;
-    if ((st = dispatch_line_pass<+1>(nx, a, apply != 0, stream))) return st;
+    if ((st = dispatch_line_pass<+1>(nx, a, fmode, stream))) return st;
     // ---- pass X, Nyquist plane [nx][ny]: columns = k_y
     a.src = src_nyq;
     a.dst = w_nyq;
@@ -1000,7 +1128,7 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
     a.n_ctiles = ny / TZ;
     a.pair_outer = 0;
     a.filter_axis = 1;
-    if ((st = dispatch_line_pass<+1>(nx, a, apply != 0, stream))) return st;
+    if ((st = dispatch_line_pass<+1>(nx, a, fmode, stream))) return st;
     // ---- pass Y, main block (in place): lines along y, outer = x, columns = k_z
     a.fp.type = -1;
     a.src = w_main;
@@ -1012,7 +1140,7 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
     a.n_ctiles = H / TZ;
     a.pair_outer = 0;
     a.filter_axis = 0;
-    if ((st = dispatch_line_pass<+1>(ny, a, false, stream))) return st;
+    if ((st = dispatch_line_pass<+1>(ny, a, 0, stream))) return st;
     // ---- pass Y, Nyquist plane: lines along y are contiguous, columns = x (stride ny)
     a.src = w_nyq;
     a.dst = w_nyq;
@@ -1021,7 +1149,7 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
     a.col_stride = ny;
     a.n_outer = 1;
     a.n_ctiles = nx / TZ;
-    return dispatch_line_pass<+1>(ny, a, false, stream);
+    return dispatch_line_pass<+1>(ny, a, 0, stream);
 }
 
 // Pass Z: split_work -> real rows of out_zstride floats.
