@@ -82,6 +82,7 @@ int c21hip_divide_inplace(float *buf, size_t n, float divisor, void *stream);
 /* buf[i] = (float)(buf[i] / divisor), double arithmetic (reference: filtering.c:422-424) */
 int c21hip_divide_inplace_f64(float *buf, size_t n, double divisor, void *stream);
 int c21hip_fill(float *buf, size_t n, float value, void *stream);
+int c21hip_add_scalar(float *buf, size_t n, float value, void *stream); /* buf[i] += value */
 /* out[i] = (double)in[i] */
 int c21hip_widen(const float *in, double *out, size_t n, void *stream);
 
@@ -90,6 +91,27 @@ int c21hip_widen(const float *in, double *out, size_t n, void *stream);
 int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int ny, int nz, double box_len,
                        double box_len_z, int filter_type, float R, float R_param, int apply,
                        void *stream);
+
+/* ---- perturb_kernels.hip ---- */
+/* move_grid_masses: map_mass.c:146-208.  `out` (double[out_dim]) must be zeroed by the caller. */
+int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3], const float *const vel[3],
+                       const float *const vel2[3], const int vel_dim[3], double *out,
+                       const int out_dim[3], double box_len, double box_len_z, double growth,
+                       double init_growth, int lpt2, void *stream);
+/* double grid -> padded float [, *= mass_factor, -= 1]: PerturbedField.c:115-128,180-210 */
+int c21hip_widen_normalise(const double *in, float *padded, int nx, int ny, int nz, int normalise,
+                           double mass_factor, void *stream);
+/* padded = (float)(factor * dense): PerturbedField.c:64-80 */
+int c21hip_scale_pack(const float *dense, float *padded, int nx, int ny, int nz, double factor,
+                      void *stream);
+/* nearest-index gather from a padded real grid [, /divisor][, clip at -1+1e-7] into a dense
+ * (or padded) low-res grid: PerturbedField.c:162-177,251-276,367-383,450-464 */
+int c21hip_gather(const float *src_padded, const int src_dim[3], float *dst, const int lo_dim[3],
+                  int dst_padded, float divisor, int clip, void *stream);
+/* grid = saved * (dD/dt / D) i k_axis / k^2 / N: PerturbedField.c:320-350 */
+int c21hip_velocity_kspace(const float *saved_c, float *grid_c, int nx, int ny, int nz,
+                           double box_len, double box_len_z, int axis, double dDdt_over_D,
+                           void *stream);
 
 /* ---- ionize_kernels.hip ---- */
 typedef struct c21hip_ionize_args {

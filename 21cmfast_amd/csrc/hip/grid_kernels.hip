@@ -88,6 +88,13 @@ divide_f64_kernel(float2 *__restrict__ buf, size_t n2, double divisor) {
     }
 }
 
+__global__ void __launch_bounds__(kBlock)
+add_scalar_kernel(float *__restrict__ buf, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock)
+        buf[i] = __fadd_rn(buf[i], v);
+}
+
 __global__ void __launch_bounds__(kBlock) fill_kernel(float *__restrict__ buf, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
          i += (size_t)gridDim.x * kBlock)
@@ -180,7 +187,7 @@ __device__ __forceinline__ double window_of(const FilterParams &p, float k_mag_s
 // float2's.  dst = (float)(src * W) per component (complex float times double).
 template <bool APPLY>
 __global__ void __launch_bounds__(kBlock)
-copy_filter_kernel(const float2 *__restrict__ src, float2 *__restrict__ dst, FilterParams p) {
+copy_filter_kernel(const float2 *src, float2 *dst, FilterParams p) {  // src may equal dst
     const size_t total = (size_t)p.nx * p.ny * p.nzc;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
          i += (size_t)gridDim.x * kBlock) {
@@ -235,6 +242,13 @@ extern "C" int c21hip_divide_inplace(float *buf, size_t n, float divisor, void *
 extern "C" int c21hip_divide_inplace_f64(float *buf, size_t n, double divisor, void *stream) {
     hipLaunchKernelGGL(divide_f64_kernel, dim3(grid_for(n / 2)), dim3(kBlock), 0,
                        (hipStream_t)stream, (float2 *)buf, n / 2, divisor);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_add_scalar(float *buf, size_t n, float value, void *stream) {
+    hipLaunchKernelGGL(add_scalar_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       buf, n, value);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,301 @@
+// perturb_kernels.hip -- ComputePerturbedField sweeps on MI355X.
+//
+// reference loops being replaced:
+//   move_grid_masses + do_cic_interpolation_double   src/py21cmfast/src/map_mass.c:23-60,146-208
+//   double -> padded float, normalise_delta_grid      src/py21cmfast/src/PerturbedField.c:115-128,180-210
+//   /N, clip, copy-out                                PerturbedField.c:251-276,450-464
+//   compute_perturbed_velocities k-space multiply     PerturbedField.c:320-350
+//   resample_index gathers                            PerturbedField.c:162-177,367-383
+//
+// The mass deposit is the only non-streaming kernel of the whole path.  One thread moves
+// one hi-res particle: it gathers the displacement from the (coarser or equal) velocity
+// grids at the nearest index, and deposits 1 + delta*D_i onto the 8 neighbouring cells
+// of the output grid with fp64 atomics, like the reference's `#pragma omp atomic` on a
+// double grid.  MI355X executes `global_atomic_add_f64` in the L2, so no CAS loop is
+// involved (unsafeAtomicAdd).  Threads of a wavefront walk z fastest: their 8 targets
+// fall into a handful of cache lines of the output grid, which keeps the atomic traffic
+// inside L2; summation order is the only non-determinism (1e-16 relative).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "c21hip.h"
+#include "c21cm_abi.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 256 * 8;
+
+inline int grid_for(size_t work_items) {
+    size_t b = (work_items + kBlock - 1) / kBlock;
+    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define LAUNCH_CHECK()                                                                  \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            c21hip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                       \
+            return C21CM_IO_ERROR;                                                      \
+        }                                                                               \
+    } while (0)
+
+__device__ __forceinline__ int wrap_idx(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+
+struct CicParams {
+    int dens_dim[3], vel_dim[3], out_dim[3];
+    double dim_ratio_vel, dim_ratio_out;
+    double vdf[3], vdf2[3];  // displacement factors, map_mass.c:165-173
+    double init_growth;
+    int lpt2;
+};
+
+__global__ void __launch_bounds__(kBlock)
+cic_scatter_kernel(CicParams p, const float *__restrict__ dens, const float *__restrict__ vx,
+                   const float *__restrict__ vy, const float *__restrict__ vz,
+                   const float *__restrict__ v2x, const float *__restrict__ v2y,
+                   const float *__restrict__ v2z, double *__restrict__ out) {
+    const size_t total = (size_t)p.dens_dim[0] * p.dens_dim[1] * p.dens_dim[2];
+    const size_t plane = (size_t)p.dens_dim[1] * p.dens_dim[2];
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const int i = (int)(t / plane);
+        const size_t rem = t - (size_t)i * plane;
+        const int j = (int)(rem / (size_t)p.dens_dim[2]);
+        const int k = (int)(rem - (size_t)j * p.dens_dim[2]);
+        const int src[3] = {i, j, k};
+        // resample_index + wrap_coord (indexing.h:110-114)
+        int ip[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            ip[a] = wrap_idx((int)((double)src[a] * p.dim_ratio_vel + 0.5), p.vel_dim[a]);
+        const size_t vi =
+            (size_t)ip[2] + (size_t)p.vel_dim[2] * ((size_t)ip[1] + (size_t)p.vel_dim[1] * ip[0]);
+        const float v[3] = {vx[vi], vy[vi], vz[vi]};
+        float v2[3] = {0.f, 0.f, 0.f};
+        if (p.lpt2) {
+            v2[0] = v2x[vi];
+            v2[1] = v2y[vi];
+            v2[2] = v2z[vi];
+        }
+        int i0[3], i1[3];
+        double w0[3], w1[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            double pos = (double)src[a];
+            pos += (double)v[a] * p.vdf[a];
+            if (p.lpt2) pos -= (double)v2[a] * p.vdf2[a];
+            pos *= p.dim_ratio_out;
+            const double fl = floor(pos);
+            const int ipos = (int)fl;
+            const double dist = pos - (double)ipos;
+            i0[a] = wrap_idx(ipos, p.out_dim[a]);
+            i1[a] = wrap_idx(ipos + 1, p.out_dim[a]);
+            w0[a] = 1. - dist;
+            w1[a] = dist;
+        }
+        const double mass = 1.0 + (double)dens[t] * p.init_growth;
+        const size_t sy = (size_t)p.out_dim[2], sx = (size_t)p.out_dim[1] * p.out_dim[2];
+        const size_t bx[2] = {(size_t)i0[0] * sx, (size_t)i1[0] * sx};
+        const size_t by[2] = {(size_t)i0[1] * sy, (size_t)i1[1] * sy};
+        const size_t bz[2] = {(size_t)i0[2], (size_t)i1[2]};
+        const double wx[2] = {w0[0], w1[0]}, wy[2] = {w0[1], w1[1]}, wz[2] = {w0[2], w1[2]};
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+                    unsafeAtomicAdd(out + bx[a] + by[b] + bz[c], mass * (wx[a] * wy[b] * wz[c]));
+    }
+}
+
+// double grid -> padded float, then (optionally) *= mass_factor; -= 1
+__global__ void __launch_bounds__(kBlock)
+widen_normalise_kernel(const double *__restrict__ in, float *__restrict__ padded, size_t nlines,
+                       int nz, int zpad, int normalise, double mass_factor) {
+    const size_t total = nlines * (size_t)zpad;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * kBlock) {
+        const size_t line = i / (size_t)zpad;
+        const int k = (int)(i - line * (size_t)zpad);
+        float v = 0.f;
+        if (k < nz) {
+            v = (float)in[line * (size_t)nz + k];  // PerturbedField.c:124
+            if (normalise) {
+                v = (float)((double)v * mass_factor);  // :201
+                v = v - 1.f;                           // :202
+            }
+        }
+        padded[i] = v;
+    }
+}
+
+// padded real -> (optionally /divisor, clip at -1 + 1e-7) -> dense, with nearest-index
+// resampling from a (possibly finer) source grid.  Covers PerturbedField.c:162-177 (hi->lo,
+// divide), :251-276 + :450-464 (divide, clip, copy out) and :367-383 (velocity gather).
+struct GatherParams {
+    int lo_dim[3], src_dim[3];
+    int src_zpad;
+    double dim_ratio;
+    float divisor;  // 0: no division
+    int clip;
+    int dst_zstride;  // row length of the destination (dense: lo_dim[2], padded: zpad)
+};
+
+__global__ void __launch_bounds__(kBlock)
+gather_kernel(GatherParams p, const float *__restrict__ src, float *__restrict__ dst) {
+    const size_t total = (size_t)p.lo_dim[0] * p.lo_dim[1] * p.lo_dim[2];
+    const size_t plane = (size_t)p.lo_dim[1] * p.lo_dim[2];
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const int i = (int)(t / plane);
+        const size_t rem = t - (size_t)i * plane;
+        const int j = (int)(rem / (size_t)p.lo_dim[2]);
+        const int k = (int)(rem - (size_t)j * p.lo_dim[2]);
+        const int hi = (int)((double)i * p.dim_ratio + 0.5);
+        const int hj = (int)((double)j * p.dim_ratio + 0.5);
+        const int hk = (int)((double)k * p.dim_ratio + 0.5);
+        float v = src[(size_t)hk + (size_t)p.src_zpad * ((size_t)hj + (size_t)p.src_dim[1] * hi)];
+        if (p.divisor != 0.f) v = __fdiv_rn(v, p.divisor);
+        if (p.clip && (double)v < -1.0 + 1e-7) v = (float)(-1.0 + 1e-7);
+        dst[(size_t)k + (size_t)p.dst_zstride * ((size_t)j + (size_t)p.lo_dim[1] * i)] = v;
+    }
+}
+
+// padded = (float)(factor * dense): the LINEAR branch, PerturbedField.c:64-80
+__global__ void __launch_bounds__(kBlock)
+scale_pack_kernel(const float *__restrict__ dense, float *__restrict__ padded, size_t nlines,
+                  int nz, int zpad, double factor) {
+    const size_t total = nlines * (size_t)zpad;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * kBlock) {
+        const size_t line = i / (size_t)zpad;
+        const int k = (int)(i - line * (size_t)zpad);
+        padded[i] = (k < nz) ? (float)(factor * (double)dense[line * (size_t)nz + k]) : 0.f;
+    }
+}
+
+// index_to_k: indexing.h:116-120
+__device__ __forceinline__ float index_to_k(int idx, double len, int dim) {
+    const double buf = (idx <= dim / 2) ? (double)idx : (double)(idx - dim);
+    return (float)(buf * 2. * M_PI / len);
+}
+
+// v_k = delta_k * (dD/dt / D) * i k_axis / k^2 / N, DC := 0.  PerturbedField.c:320-350
+__global__ void __launch_bounds__(kBlock)
+velocity_kernel(const float2 *__restrict__ saved, float2 *__restrict__ grid, int nx, int ny,
+                int nz, double len_x, double len_y, double len_z, int axis, double dDdt_over_D) {
+    const int nzc = nz / 2 + 1;
+    const size_t total = (size_t)nx * ny * nzc;
+    const double n_r_pixels = (double)((size_t)nx * ny * nz);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * kBlock) {
+        const size_t line = i / (size_t)nzc;
+        const int n_z = (int)(i - line * (size_t)nzc);
+        const int n_x = (int)(line / (size_t)ny);
+        const int n_y = (int)(line - (size_t)n_x * ny);
+        float kvec[3];
+        kvec[0] = index_to_k(n_x, len_x, nx);
+        kvec[1] = index_to_k(n_y, len_y, ny);
+        kvec[2] = index_to_k(n_z, len_z, nz);
+        const float k_sq = __fadd_rn(
+            __fadd_rn(__fmul_rn(kvec[0], kvec[0]), __fmul_rn(kvec[1], kvec[1])),
+            __fmul_rn(kvec[2], kvec[2]));
+        float2 v = make_float2(0.f, 0.f);
+        if (i != 0) {
+            const float2 s = saved[i];
+            const double c = dDdt_over_D * (double)kvec[axis] / (double)k_sq / n_r_pixels;
+            v.x = (float)(-(double)s.y * c);
+            v.y = (float)((double)s.x * c);
+        }
+        grid[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3],
+                                  const float *const vel[3], const float *const vel2[3],
+                                  const int vel_dim[3], double *out, const int out_dim[3],
+                                  double box_len, double box_len_z, double growth,
+                                  double init_growth, int lpt2, void *stream) {
+    CicParams p;
+    const double box_size[3] = {box_len, box_len, box_len_z};
+    const double d2 = -(3.0 / 7.0) * growth * growth;
+    const double id2 = -(3.0 / 7.0) * init_growth * init_growth;
+    for (int a = 0; a < 3; a++) {
+        p.dens_dim[a] = dens_dim[a];
+        p.vel_dim[a] = vel_dim[a];
+        p.out_dim[a] = out_dim[a];
+        p.vdf[a] = (growth - init_growth) / box_size[a] * dens_dim[a];
+        p.vdf2[a] = (d2 - id2) / box_size[a] * dens_dim[a];
+    }
+    p.dim_ratio_vel = (double)vel_dim[0] / (double)dens_dim[0];
+    p.dim_ratio_out = (double)out_dim[0] / (double)dens_dim[0];
+    p.init_growth = init_growth;
+    p.lpt2 = lpt2;
+    const size_t total = (size_t)dens_dim[0] * dens_dim[1] * dens_dim[2];
+    hipLaunchKernelGGL(cic_scatter_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
+                       (hipStream_t)stream, p, hires_density, vel[0], vel[1], vel[2],
+                       lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr,
+                       lpt2 ? vel2[2] : nullptr, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_widen_normalise(const double *in, float *padded, int nx, int ny, int nz,
+                                      int normalise, double mass_factor, void *stream) {
+    const int zpad = 2 * (nz / 2 + 1);
+    const size_t nlines = (size_t)nx * ny;
+    hipLaunchKernelGGL(widen_normalise_kernel, dim3(grid_for(nlines * zpad)), dim3(kBlock), 0,
+                       (hipStream_t)stream, in, padded, nlines, nz, zpad, normalise, mass_factor);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_scale_pack(const float *dense, float *padded, int nx, int ny, int nz,
+                                 double factor, void *stream) {
+    const int zpad = 2 * (nz / 2 + 1);
+    const size_t nlines = (size_t)nx * ny;
+    hipLaunchKernelGGL(scale_pack_kernel, dim3(grid_for(nlines * zpad)), dim3(kBlock), 0,
+                       (hipStream_t)stream, dense, padded, nlines, nz, zpad, factor);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_gather(const float *src_padded, const int src_dim[3], float *dst,
+                             const int lo_dim[3], int dst_padded, float divisor, int clip,
+                             void *stream) {
+    GatherParams p;
+    for (int a = 0; a < 3; a++) {
+        p.lo_dim[a] = lo_dim[a];
+        p.src_dim[a] = src_dim[a];
+    }
+    p.src_zpad = 2 * (src_dim[2] / 2 + 1);
+    p.dim_ratio = src_dim[0] / (double)lo_dim[0];
+    p.divisor = divisor;
+    p.clip = clip;
+    p.dst_zstride = dst_padded ? 2 * (lo_dim[2] / 2 + 1) : lo_dim[2];
+    const size_t total = (size_t)lo_dim[0] * lo_dim[1] * lo_dim[2];
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
+                       p, src_padded, dst);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_velocity_kspace(const float *saved_c, float *grid_c, int nx, int ny, int nz,
+                                      double box_len, double box_len_z, int axis,
+                                      double dDdt_over_D, void *stream) {
+    const size_t total = (size_t)nx * ny * (nz / 2 + 1);
+    hipLaunchKernelGGL(velocity_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
+                       (hipStream_t)stream, (const float2 *)saved_c, (float2 *)grid_c, nx, ny, nz,
+                       box_len, box_len, box_len_z, axis, dDdt_over_D);
+    LAUNCH_CHECK();
+    return 0;
+}

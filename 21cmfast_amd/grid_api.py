@@ -159,3 +159,42 @@ def ionize_shard_finish(spec, first_cross, density, n_ion=None, xe=None, Tneutra
         "c21cm_ionize_shard_finish",
     )
     return buffers, box, rep
+
+
+IC_FIELDS = ("lowres_density", "lowres_vx", "lowres_vy", "lowres_vz", "lowres_vx_2LPT",
+             "lowres_vy_2LPT", "lowres_vz_2LPT", "hires_density", "hires_vx", "hires_vy",
+             "hires_vz", "hires_vx_2LPT", "hires_vy_2LPT", "hires_vz_2LPT", "lowres_vcb")
+
+
+def ics_struct(ics: dict) -> S.InitialConditionsStruct:
+    """InitialConditions struct over a dict of numpy arrays / torch tensors (missing -> NULL)."""
+    return S.InitialConditionsStruct(**{k: _fptr(ics.get(k)) for k in IC_FIELDS})
+
+
+def perturb_grids(spec: S.PerturbSpec, ics: dict, stream=None) -> dict:
+    """ComputePerturbedField grid algorithm on the MI355X.
+
+    Outputs live where ``ics['hires_density']`` (or lowres_density for LINEAR) lives.
+    Shapes as py21cmfast's PerturbedField.new (reference: wrapper/outputs.py:689-719).
+    """
+    ref = ics.get("hires_density")
+    if ref is None:
+        ref = ics["lowres_density"]
+    lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
+
+    def new():
+        if _is_torch(ref):
+            import torch
+
+            return torch.zeros(lo, dtype=torch.float32, device=ref.device)
+        return np.zeros(lo, np.float32)
+
+    out = {"density": new(), "velocity_z": new()}
+    if spec.keep_3d_velocities:
+        out["velocity_x"] = new()
+        out["velocity_y"] = new()
+    pf = S.PerturbedFieldStruct(**{k: _fptr(v) for k, v in out.items()})
+    icss = ics_struct(ics)
+    check(load().c21cm_perturb_grids(C.byref(spec), C.byref(icss), C.byref(pf), _stream(stream)),
+          "c21cm_perturb_grids")
+    return out

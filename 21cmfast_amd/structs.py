@@ -322,11 +322,9 @@ class PerturbSpec(_Base):
         ("perturb_on_high_res", C.c_int),
         ("keep_3d_velocities", C.c_int),
         ("smooth_evolved_density", C.c_int),
-        ("density_smooth_radius", C.c_double),
+        ("density_smooth_radius_mpc", C.c_double),
         ("growth_factor", C.c_double),
         ("init_growth_factor", C.c_double),
-        ("displacement_factor_2LPT", C.c_double),
-        ("init_displacement_factor_2LPT", C.c_double),
         ("dDdt_over_D", C.c_double),
     ]
 

@@ -140,19 +140,17 @@ int c21cm_fft_c2r(float *box, int nx, int ny, int nz, void *stream);
 /* Scalars of one ComputePerturbedField call
  * (reference: src/py21cmfast/src/PerturbedField.c:24-135,389-496, map_mass.c:146-208). */
 typedef struct c21cm_perturb_spec {
-    int dim, dim_z;         /* hi-res particle grid         */
-    int hii_dim, hii_dim_z; /* low-res output grid          */
+    int dim, dim_z;         /* hi-res particle grid (DIM, D_PARA)                         */
+    int hii_dim, hii_dim_z; /* low-res output grid (HII_DIM, HII_D_PARA)                  */
     double box_len, box_len_z;
-    int perturb_algorithm;  /* enum C21CM_PERTURB_*         */
+    int perturb_algorithm;  /* enum C21CM_PERTURB_*                                       */
     int perturb_on_high_res;
     int keep_3d_velocities;
     int smooth_evolved_density;
-    double density_smooth_radius; /* in output cells, SimulationOptions.DENSITY_SMOOTH_RADIUS */
-    double growth_factor;         /* D(z)                   */
-    double init_growth_factor;    /* D(z_init)              */
-    double displacement_factor_2LPT;      /* see map_mass.c:161-164 */
-    double init_displacement_factor_2LPT;
-    double dDdt_over_D;           /* ddickedt(z)/dicke(z)   */
+    double density_smooth_radius_mpc; /* Gaussian R handed to filter_box (PerturbedField.c:222-225) */
+    double growth_factor;      /* dicke(z)                                                */
+    double init_growth_factor; /* dicke(INITIAL_REDSHIFT)                                 */
+    double dDdt_over_D;        /* ddickedt(z)/dicke(z)                                    */
 } c21cm_perturb_spec;
 
 int c21cm_perturb_grids(const c21cm_perturb_spec *spec, const InitialConditions *ics,

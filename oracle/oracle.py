@@ -153,3 +153,27 @@ def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion
     out["mean_f_coll"] = box.mean_f_coll
     out["report"] = rep
     return out
+
+
+IC_FIELDS = ("lowres_density", "lowres_vx", "lowres_vy", "lowres_vz", "lowres_vx_2LPT",
+             "lowres_vy_2LPT", "lowres_vz_2LPT", "hires_density", "hires_vx", "hires_vy",
+             "hires_vz", "hires_vx_2LPT", "hires_vy_2LPT", "hires_vz_2LPT", "lowres_vcb")
+
+
+def ics_struct(ics: dict):
+    """InitialConditions struct over a dict of numpy arrays (missing fields -> NULL)."""
+    return S.InitialConditionsStruct(**{k: fptr(ics.get(k)) for k in IC_FIELDS})
+
+
+def perturb_grids(spec, ics: dict):
+    """Oracle ComputePerturbedField grid algorithm; returns dict(density, velocity_*)."""
+    lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
+    out = {"density": np.zeros(lo, np.float32), "velocity_z": np.zeros(lo, np.float32)}
+    if spec.keep_3d_velocities:
+        out["velocity_x"] = np.zeros(lo, np.float32)
+        out["velocity_y"] = np.zeros(lo, np.float32)
+    pf = S.PerturbedFieldStruct(**{k: fptr(v) for k, v in out.items()})
+    st = load().oracle_perturb_grids(C.byref(spec), C.byref(ics_struct(ics)), C.byref(pf))
+    if st:
+        raise RuntimeError(f"oracle_perturb_grids status {st}")
+    return out
