@@ -113,6 +113,20 @@ int c21hip_velocity_kspace(const float *saved_c, float *grid_c, int nx, int ny, 
                            double box_len, double box_len_z, int axis, double dDdt_over_D,
                            void *stream);
 
+/* ---- ics_kernels.hip ---- */
+/* delta_k = sqrt(V P/2)(a + ib) with Hermitian planes: InitialConditions.c:26-139 */
+int c21hip_sample_modes(float *cbox, int nx, int ny, int nz, const double *pk_by_m_dev,
+                        float volume, unsigned long long seed, void *stream);
+/* axis1 < 0: out = in*i*k_axis0/k^2 (:240-267); else out = -k_axis0*k_axis1*in/k^2 (:269-297) */
+int c21hip_kspace_op(const float *in_c, float *out_c, int nx, int ny, int nz, double box_len,
+                     double box_len_z, int axis0, int axis1, void *stream);
+/* padded = dense * VOLUME / N (:637-653) */
+int c21hip_pack_density(const float *dense, float *padded, int nx, int ny, int nz, float volume,
+                        void *stream);
+/* box += phi_ii*phi_jj; box -= phi_ij^2 (:451-482) */
+int c21hip_lpt2_accumulate(float *box, const float *phi_ij_padded, const float *diag_i,
+                           const float *diag_j, int nx, int ny, int nz, void *stream);
+
 /* ---- ionize_kernels.hip ---- */
 typedef struct c21hip_ionize_args {
     int nx, ny, nz;

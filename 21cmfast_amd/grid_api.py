@@ -198,3 +198,35 @@ def perturb_grids(spec: S.PerturbSpec, ics: dict, stream=None) -> dict:
     check(load().c21cm_perturb_grids(C.byref(spec), C.byref(icss), C.byref(pf), _stream(stream)),
           "c21cm_perturb_grids")
     return out
+
+
+def new_ics_arrays(spec: S.IcsSpec, device=None) -> dict:
+    """Zeroed arrays as ``InitialConditions.new`` allocates them
+    (reference: src/py21cmfast/wrapper/outputs.py:534-581)."""
+    lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
+    hi = (spec.dim, spec.dim, spec.dim_z)
+
+    def new(shape):
+        if device is not None:
+            import torch
+
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        return np.zeros(shape, np.float32)
+
+    ics = {"hires_density": new(hi), "lowres_density": new(lo)}
+    shape = hi if spec.perturb_on_high_res else lo
+    pre = "hires" if spec.perturb_on_high_res else "lowres"
+    for ax in "xyz":
+        ics[f"{pre}_v{ax}"] = new(shape)
+        if spec.perturb_algorithm == 2:
+            ics[f"{pre}_v{ax}_2LPT"] = new(shape)
+    return ics
+
+
+def ics_grids(spec: S.IcsSpec, ics: dict | None = None, device=None, stream=None) -> dict:
+    """ComputeInitialConditions grid algorithm on the MI355X; fills and returns ``ics``."""
+    if ics is None:
+        ics = new_ics_arrays(spec, device)
+    icss = ics_struct(ics)
+    check(load().c21cm_ics_grids(C.byref(spec), C.byref(icss), _stream(stream)), "c21cm_ics_grids")
+    return ics

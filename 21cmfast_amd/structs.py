@@ -337,13 +337,13 @@ class IcsSpec(_Base):
         ("hii_dim_z", C.c_int),
         ("box_len", C.c_double),
         ("box_len_z", C.c_double),
+        ("volume", C.c_float),
         ("perturb_algorithm", C.c_int),
         ("perturb_on_high_res", C.c_int),
-        ("n_pk", C.c_int),
-        ("lnk", c_double_p),
-        ("lnpk", c_double_p),
-        ("seed", C.c_ulonglong),
         ("density_is_input", C.c_int),
+        ("n_m", C.c_int),
+        ("pk_by_m", c_double_p),
+        ("seed", C.c_ulonglong),
     ]
 
 

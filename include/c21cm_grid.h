@@ -159,16 +159,18 @@ int c21cm_perturb_grids(const c21cm_perturb_spec *spec, const InitialConditions 
 /* Scalars of one ComputeInitialConditions call
  * (reference: src/py21cmfast/src/InitialConditions.c:547-772). */
 typedef struct c21cm_ics_spec {
-    int dim, dim_z;
-    int hii_dim, hii_dim_z;
+    int dim, dim_z;         /* DIM, D_PARA                                                   */
+    int hii_dim, hii_dim_z; /* HII_DIM, HII_D_PARA                                           */
     double box_len, box_len_z;
-    int perturb_algorithm;
+    float volume;           /* VOLUME macro: float product BOX_LEN^3 * NON_CUBIC_FACTOR      */
+    int perturb_algorithm;  /* 2LPT fields only when == C21CM_PERTURB_2LPT                   */
     int perturb_on_high_res;
-    int n_pk;            /* size of the tabulated P(k) */
-    const double *lnk;   /* ln k, ascending, host      */
-    const double *lnpk;  /* ln P(k), host; sample_modes interpolates linearly in ln-ln */
+    int density_is_input;   /* regenerate everything from boxes->hires_density (:620-663)    */
+    /* mode sampling (density_is_input == 0), cubic grids only: P(k) tabulated at
+     * k = (2 pi / L) sqrt(m), m = 0 .. 3 (DIM/2)^2, in Mpc^3 (power_in_k, cosmology.c:278) */
+    int n_m;
+    const double *pk_by_m; /* host array */
     unsigned long long seed;
-    int density_is_input; /* regenerate everything from boxes->hires_density (:620-663) */
 } c21cm_ics_spec;
 
 int c21cm_ics_grids(const c21cm_ics_spec *spec, InitialConditions *ics, void *stream);

@@ -177,3 +177,37 @@ def perturb_grids(spec, ics: dict):
     if st:
         raise RuntimeError(f"oracle_perturb_grids status {st}")
     return out
+
+
+def new_ics_arrays(spec, with_hires_vel=False):
+    """Zeroed arrays as InitialConditions.new allocates them (wrapper/outputs.py:534-581)."""
+    lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
+    hi = (spec.dim, spec.dim, spec.dim_z)
+    ics = {"hires_density": np.zeros(hi, np.float32), "lowres_density": np.zeros(lo, np.float32)}
+    shape = hi if spec.perturb_on_high_res else lo
+    pre = "hires" if spec.perturb_on_high_res else "lowres"
+    for ax in "xyz":
+        ics[f"{pre}_v{ax}"] = np.zeros(shape, np.float32)
+        if spec.perturb_algorithm == 2:
+            ics[f"{pre}_v{ax}_2LPT"] = np.zeros(shape, np.float32)
+    return ics
+
+
+def ics_grids(spec, ics: dict | None = None):
+    """Oracle ComputeInitialConditions grid algorithm (fills and returns the dict)."""
+    if ics is None:
+        ics = new_ics_arrays(spec)
+    st = load().oracle_ics_grids(C.byref(spec), C.byref(ics_struct(ics)))
+    if st:
+        raise RuntimeError(f"oracle_ics_grids status {st}")
+    return ics
+
+
+def gaussian_pair(counter: int, seed: int):
+    lib = load()
+    lib.oracle_gaussian_pair.restype = None
+    lib.oracle_gaussian_pair.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double)]
+    a, b = C.c_double(), C.c_double()
+    lib.oracle_gaussian_pair(counter, seed, C.byref(a), C.byref(b))
+    return a.value, b.value
