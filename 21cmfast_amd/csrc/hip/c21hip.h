@@ -185,6 +185,11 @@ int c21hip_finalize(const c21hip_ionize_args *a, double stored_redshift, const f
                     const float *kinetic_temp_neutral, const float *xH, const float *z_reion,
                     float *kinetic_temperature, size_t ntot, double *partials, double *sum_out,
                     int *flag_out, void *stream);
+/* set_fully_neutral_box: IonisationBox.c:531-565 */
+int c21hip_neutral_box(const float *density, const float *xe, const float *Tneutral, float *xH,
+                       float *Tk, size_t ntot, int ts, double global_xH, double TK, double adia,
+                       void *stream);
+int c21hip_any_nonzero(const float *a, size_t n, int *flag_host, void *stream);
 /* xH/z_reion from a max-reduced first_cross mask (multi-GPU tail). */
 int c21hip_apply_first_cross(const unsigned char *first_cross, const float *prev_z_reion,
                              int first_snapshot, double redshift, float *xH, float *z_reion,

@@ -471,6 +471,33 @@ apply_first_cross_kernel(const unsigned char *__restrict__ fc,
     }
 }
 
+// set_fully_neutral_box: IonisationBox.c:531-565
+__global__ void __launch_bounds__(kBlock)
+neutral_box_kernel(const float *__restrict__ density, const float *__restrict__ xe,
+                   const float *__restrict__ Tneutral, float *__restrict__ xH,
+                   float *__restrict__ Tk, size_t ntot, int ts, double global_xH, double TK,
+                   double adia) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        if (ts) {
+            xH[i] = (float)(1. - (double)xe[i]);
+            if (Tk) Tk[i] = Tneutral[i];
+        } else {
+            xH[i] = (float)global_xH;
+            if (Tk) Tk[i] = (float)(TK * (1.0 + adia * (double)density[i]));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+any_nonzero_kernel(const float *__restrict__ a, size_t n, int *flag) {
+    int found = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock)
+        if (a[i] != 0.f) found = 1;
+    if (found) atomicOr(flag, 1);
+}
+
 IoniseParams make_params(const c21hip_ionize_args *a, int vec) {
     IoniseParams p;
     p.a = *a;
@@ -691,4 +718,27 @@ extern "C" int c21hip_apply_first_cross(const unsigned char *first_cross,
                        (float)redshift, xH, z_reion, ntot);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int c21hip_neutral_box(const float *density, const float *xe, const float *Tneutral,
+                                  float *xH, float *Tk, size_t ntot, int ts, double global_xH,
+                                  double TK, double adia, void *stream) {
+    hipLaunchKernelGGL(neutral_box_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
+                       (hipStream_t)stream, density, xe, Tneutral, xH, Tk, ntot, ts, global_xH, TK,
+                       adia);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// *flag_host = 1 if any element of the device array is non-zero (synchronises)
+extern "C" int c21hip_any_nonzero(const float *a, size_t n, int *flag_host, void *stream) {
+    int *flag = (int *)c21hip_ws(47, sizeof(int));
+    if (!flag) return C21CM_MEMORY_ALLOC_ERROR;
+    int st = c21hip_memset(flag, 0, sizeof(int), stream);
+    if (st) return st;
+    hipLaunchKernelGGL(any_nonzero_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       a, n, flag);
+    LAUNCH_CHECK();
+    if ((st = c21hip_d2h(flag_host, flag, sizeof(int), stream))) return st;
+    return c21hip_sync(stream);
 }

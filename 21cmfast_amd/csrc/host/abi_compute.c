@@ -1,0 +1,342 @@
+/*
+ * abi_compute.c -- the three drop-in entry points of the hot path.
+ *
+ *   int ComputeInitialConditions(unsigned long long seed, InitialConditions *boxes)
+ *   int ComputePerturbedField(float z, InitialConditions *boxes, PerturbedField *pf)
+ *   int ComputeIonizedBox(float z, float prev_z, PerturbedField*, PerturbedField*, IonizedBox*,
+ *                         TsBox*, HaloBox*, InitialConditions*, IonizedBox*)
+ * (reference: src/py21cmfast/src/_functionprototypes_wrapper.h:6-9,23-26).
+ *
+ * Each reads the broadcast parameter structs exactly as the reference does (process
+ * globals, src/py21cmfast/src/InputParameters.c:82-90), evaluates the host-side physics
+ * scalars (cosmology.c) and hands an explicit-scalar spec to the grid drivers
+ * (c21cm_*_grids), which run on the MI355X.  Status codes follow exceptions.h:12-21; no
+ * exception crosses the boundary.
+ *
+ * Option coverage.  Implemented: every PERTURB_ALGORITHM, PERTURB_ON_HIGH_RES,
+ * KEEP_3D_VELOCITIES, SMOOTH_EVOLVED_DENSITY_FIELD, analytic POWER_SPECTRUM fits,
+ * SOURCE_MODEL = CONST-ION-EFF (closed form or FgtrM table) and the Lagrangian models
+ * (L-INTEGRAL / DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all
+ * HII_FILTER types, USE_EXP_FILTER, MINIMIZE_MEMORY.  Returning ValueError (3) with a
+ * message in c21cm_last_error(): E-INTEGRAL (needs the conditional-MF tables),
+ * USE_MINI_HALOS, recombination models, PHOTON_CONS_TYPE != none, IONISE_ENTIRE_SPHERE,
+ * V_CB_MODEL = FLUCTS, CLASS transfer tables.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../hip/c21hip.h"
+#include "c21cm_grid.h"
+#include "cosmology.h"
+
+#define L_FACTOR 0.620350491 /* Constants.c:41 */
+#define FRACT_FLOAT_ERR 1e-7
+#define HII_ROUND_ERR 1e-5 /* IonisationBox.c:35 */
+#define M_MAX_INTEGRAL 1e16 /* hmf.h:11 */
+#define CM_PER_MPC 3.08567758e24
+#define SIGMA_HI 6.3e-18
+
+static int require_globals(const char *who, int need_astro) {
+    if (!simulation_options_global || !matter_options_global || !cosmo_params_global ||
+        !cosmo_tables_global || (need_astro && (!astro_params_global || !astro_options_global))) {
+        c21hip_set_error("%s: Broadcast_struct_global_all has not been called", who);
+        return C21CM_VALUE_ERROR;
+    }
+    if (matter_options_global->POWER_SPECTRUM == C21CM_PS_CLASS) {
+        c21hip_set_error("%s: CLASS transfer tables are not supported by this backend", who);
+        return C21CM_VALUE_ERROR;
+    }
+    return 0;
+}
+
+static void geometry(int *dim, int *dim_z, int *hii, int *hii_z, double *len, double *len_z) {
+    const SimulationOptions *so = simulation_options_global;
+    *dim = so->DIM;
+    *dim_z = (int)(so->NON_CUBIC_FACTOR * so->DIM); /* indexing.h D_PARA */
+    *hii = so->HII_DIM;
+    *hii_z = (int)(so->NON_CUBIC_FACTOR * so->HII_DIM);
+    *len = (double)so->BOX_LEN;
+    *len_z = (double)(so->BOX_LEN * so->NON_CUBIC_FACTOR); /* float product, filtering.c:313 */
+}
+
+/* ------------------------------------------------------------------------------------ */
+int ComputePerturbedField(float redshift, InitialConditions *boxes, PerturbedField *pf) {
+    int st = require_globals("ComputePerturbedField", 0);
+    if (st) return st;
+    const SimulationOptions *so = simulation_options_global;
+    const MatterOptions *mo = matter_options_global;
+    c21cm_perturb_spec s;
+    memset(&s, 0, sizeof(s));
+    geometry(&s.dim, &s.dim_z, &s.hii_dim, &s.hii_dim_z, &s.box_len, &s.box_len_z);
+    s.perturb_algorithm = mo->PERTURB_ALGORITHM;
+    s.perturb_on_high_res = mo->PERTURB_ON_HIGH_RES;
+    s.keep_3d_velocities = mo->KEEP_3D_VELOCITIES;
+    s.smooth_evolved_density = mo->SMOOTH_EVOLVED_DENSITY_FIELD;
+    /* PerturbedField.c:222-225: double * float / float */
+    s.density_smooth_radius_mpc = so->DENSITY_SMOOTH_RADIUS * so->BOX_LEN / (float)so->HII_DIM;
+    s.growth_factor = dicke(redshift);
+    s.init_growth_factor = dicke(so->INITIAL_REDSHIFT);
+    s.dDdt_over_D = c21_ddickedt(redshift) / dicke(redshift);
+    if (!isfinite(s.growth_factor) || !isfinite(s.dDdt_over_D)) return C21CM_VALUE_ERROR;
+    return c21cm_perturb_grids(&s, boxes, pf, NULL);
+}
+
+/* ------------------------------------------------------------------------------------ */
+int ComputeInitialConditions(unsigned long long random_seed, InitialConditions *boxes) {
+    int st = require_globals("ComputeInitialConditions", 0);
+    if (st) return st;
+    if (!boxes || !boxes->hires_density) {
+        c21hip_set_error("ComputeInitialConditions: hires_density is required");
+        return C21CM_VALUE_ERROR;
+    }
+    const SimulationOptions *so = simulation_options_global;
+    const MatterOptions *mo = matter_options_global;
+    if (mo->V_CB_MODEL == C21CM_VCB_FLUCTS) {
+        c21hip_set_error("ComputeInitialConditions: V_CB_MODEL=FLUCTS needs CLASS tables");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!c21_ps_ready()) init_ps();
+    c21cm_ics_spec s;
+    memset(&s, 0, sizeof(s));
+    geometry(&s.dim, &s.dim_z, &s.hii_dim, &s.hii_dim_z, &s.box_len, &s.box_len_z);
+    s.volume = so->BOX_LEN * so->BOX_LEN * so->NON_CUBIC_FACTOR * so->BOX_LEN; /* indexing.h VOLUME */
+    s.perturb_algorithm = mo->PERTURB_ALGORITHM;
+    s.perturb_on_high_res = mo->PERTURB_ON_HIGH_RES;
+    s.seed = random_seed;
+
+    /* InitialConditions.c:620-634: a non-zero hires_density means "use it as the field" */
+    const size_t ntot = (size_t)s.dim * s.dim * s.dim_z;
+    if (c21hip_is_device_ptr(boxes->hires_density)) {
+        int flag = 0;
+        if ((st = c21hip_any_nonzero(boxes->hires_density, ntot, &flag, NULL))) return st;
+        s.density_is_input = flag;
+    } else {
+        for (size_t i = 0; i < ntot; i++)
+            if (boxes->hires_density[i]) {
+                s.density_is_input = 1;
+                break;
+            }
+    }
+    double *pk = NULL;
+    if (!s.density_is_input) {
+        if (s.dim != s.dim_z) {
+            c21hip_set_error("ComputeInitialConditions: mode sampling needs NON_CUBIC_FACTOR = 1");
+            return C21CM_VALUE_ERROR;
+        }
+        s.n_m = 3 * (s.dim / 2) * (s.dim / 2) + 1;
+        pk = (double *)malloc(sizeof(double) * (size_t)s.n_m);
+        if (!pk) return C21CM_MEMORY_ALLOC_ERROR;
+        const double dk = 2.0 * M_PI / s.box_len;
+        for (int m = 0; m < s.n_m; m++) pk[m] = power_in_k(dk * sqrt((double)m));
+        s.pk_by_m = pk;
+    }
+    st = c21cm_ics_grids(&s, boxes, NULL);
+    free(pk);
+    return st;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* hmf.c:1187-1241 on the host, for the FgtrM table of CONST-ION-EFF */
+static float erfcc_host(float x) {
+    const double q = fabs(x), t = 1.0 / (1.0 + 0.5 * q);
+    const double ans =
+        t * exp(-q * q - 1.2655122 +
+                t * (1.0000237 +
+                     t * (0.374092 +
+                          t * (0.0967842 +
+                               t * (-0.1862881 +
+                                    t * (0.2788681 +
+                                         t * (-1.13520398 +
+                                              t * (1.4885159 +
+                                                   t * (-0.82215223 + t * 0.17087277)))))))));
+    return x >= 0.0 ? ans : 2.0 - ans;
+}
+
+static double fgtrm_bias_fast_host(float growthf, float del_bias, float sig_small, float sig_large) {
+    if (sig_large > sig_small) return NAN;
+    if (sig_large == sig_small) return 0.;
+    const double sig = sqrt(sig_small * sig_small - sig_large * sig_large);
+    const double del = (1.686 - del_bias) / growthf;
+    const double x = del / (sqrt(2) * sig);
+    return x < 0 ? 1.0 : erfcc_host(x);
+}
+
+struct fgtrm_table_ctx {
+    const c21cm_ionize_spec *spec;
+};
+
+/* interp_tables.c:226-250 (initialise_FgtrM_delta_table) */
+static int fgtrm_table_fn(int r_index, double dmin, double dmax, float *table, void *user) {
+    const c21cm_ionize_spec *s = ((struct fgtrm_table_ctx *)user)->spec;
+    const double width = (dmax - dmin) / (C21CM_NDELTA_TABLE - 1.);
+    for (int i = 0; i < C21CM_NDELTA_TABLE; i++) {
+        const double v = fgtrm_bias_fast_host(s->growth_factor, dmin + i * width, s->sigma_minmass,
+                                              s->sigma_maxmass[r_index]);
+        if (isnan(v)) return C21CM_VALUE_ERROR;
+        table[i] = v;
+    }
+    return 0;
+}
+
+int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *perturbed_field,
+                      PerturbedField *previous_perturbed_field, IonizedBox *previous_ionize_box,
+                      TsBox *spin_temp, HaloBox *halos, InitialConditions *ini_boxes,
+                      IonizedBox *box) {
+    (void)previous_perturbed_field;
+    (void)ini_boxes;
+    int st = require_globals("ComputeIonizedBox", 1);
+    if (st) return st;
+    const SimulationOptions *so = simulation_options_global;
+    const MatterOptions *mo = matter_options_global;
+    const AstroParams *ap = astro_params_global;
+    const AstroOptions *ao = astro_options_global;
+    if (!perturbed_field || !box) return C21CM_VALUE_ERROR;
+
+    const int src = mo->SOURCE_MODEL;
+    const int lagrangian = !(src == C21CM_SOURCE_E_INTEGRAL || src == C21CM_SOURCE_CONST_ION_EFF);
+    const int mass_dep = src != C21CM_SOURCE_CONST_ION_EFF;
+    const char *unsupported = NULL;
+    if (src == C21CM_SOURCE_E_INTEGRAL) unsupported = "SOURCE_MODEL=E-INTEGRAL (conditional-MF tables)";
+    if (ao->USE_MINI_HALOS) unsupported = "USE_MINI_HALOS";
+    if (ao->RECOMB_MODEL != C21CM_RECOMB_NONE) unsupported = "RECOMB_MODEL != none";
+    if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
+    if (ao->IONISE_ENTIRE_SPHERE) unsupported = "IONISE_ENTIRE_SPHERE";
+    if (unsupported) {
+        c21hip_set_error("ComputeIonizedBox: %s is not implemented in this backend yet", unsupported);
+        return C21CM_VALUE_ERROR;
+    }
+    if (!c21_ps_ready()) init_ps();
+
+    c21cm_ionize_spec *s = (c21cm_ionize_spec *)calloc(1, sizeof(*s));
+    if (!s) return C21CM_MEMORY_ALLOC_ERROR;
+    int dim, dim_z;
+    geometry(&dim, &dim_z, &s->hii_dim, &s->hii_dim_z, &s->box_len, &s->box_len_z);
+
+    /* ---- set_ionbox_constants: IonisationBox.c:125-227 */
+    c21_scaling_consts sc;
+    if ((st = c21_set_scaling_constants(redshift, &sc))) goto done;
+    s->redshift = redshift;
+    s->stored_redshift = redshift;
+    s->photoncons_adjustment_factor = 1.;
+    s->dz = (prev_redshift < 1) ? (1. + redshift) * (so->ZPRIME_STEP_FACTOR - 1.)
+                                : (double)prev_redshift - redshift;
+    s->fabs_dtdz = fabs(c21_dtdz(redshift)) / 1e15;
+    s->growth_factor = dicke(redshift);
+    s->mass_dep_zeta = mass_dep;
+    s->fix_mean = !lagrangian;
+    s->hii_filter = ao->HII_FILTER;
+    s->stars_filter = ao->USE_EXP_FILTER ? 3 : ao->HII_FILTER;
+    s->T_re = ap->T_RE;
+    const double ion_eff_factor_gl =
+        mass_dep ? sc.pop2_ion * sc.fstar_10 * sc.fesc_10 : (double)ap->HII_EFF_FACTOR;
+    s->ion_eff_factor = lagrangian ? 1. : ion_eff_factor_gl;
+    s->mfp_meandens = 25.483241248322766 / cosmo_params_global->hlittle;
+    const double M_min = c21_minimum_source_mass(redshift);
+    const double lnMmin = log(M_min), lnMmax_gl = log(M_MAX_INTEGRAL);
+    s->sigma_minmass = c21_sigma_fast(M_min);
+    s->delta_c = 1.686;
+    s->use_ts_fluct = ao->USE_TS_FLUCT;
+    s->minimize_memory = mo->MINIMIZE_MEMORY;
+    s->recomb_model = ao->RECOMB_MODEL;
+    s->cell_recomb = ao->CELL_RECOMB;
+    s->first_snapshot = (prev_redshift < 1);
+    if (!ao->USE_TS_FLUCT) {
+        if ((st = c21_recfast_load())) goto done;
+        s->TK_nofluct = c21_T_RECFAST(redshift);
+        s->adia_TK_term = c21_cT_approx(redshift);
+    }
+    const double pixel_length = so->BOX_LEN / (double)so->HII_DIM;
+    s->rhocrit_omb = c21_rhocrit() * cosmo_params_global->OMb;
+    s->gamma_prefactor = pow(1 + redshift, 2) * CM_PER_MPC * SIGMA_HI * ap->ALPHA_UVB /
+                         (ap->ALPHA_UVB + 2.75) * c21_nb0() * s->ion_eff_factor / 1.0e-12;
+    if (lagrangian)
+        s->gamma_prefactor /= s->rhocrit_omb;
+    else
+        s->gamma_prefactor /= (sc.t_h * sc.t_star);
+
+    /* ---- setup_radii: IonisationBox.c:964-1006 */
+    {
+        const double maximum_radius = fmin(ap->R_BUBBLE_MAX, L_FACTOR * so->BOX_LEN);
+        double cell_length_factor = L_FACTOR;
+        if (lagrangian && pixel_length < 1) cell_length_factor = 1.;
+        const double minimum_radius = fmax(ap->R_BUBBLE_MIN, cell_length_factor * pixel_length);
+        int n_radii = (int)(log(maximum_radius / minimum_radius) / log(ap->DELTA_R_HII_FACTOR) + 1);
+        if (n_radii < 1 || n_radii > 255) {
+            c21hip_set_error("ComputeIonizedBox: %d filter radii (supported: 1..255)", n_radii);
+            st = C21CM_VALUE_ERROR;
+            goto done;
+        }
+        for (int i = 0; i < n_radii; i++) {
+            double R = minimum_radius * pow(ap->DELTA_R_HII_FACTOR, i);
+            if (R > maximum_radius - FRACT_FLOAT_ERR) {
+                R = maximum_radius;
+                n_radii = i + 1;
+            }
+            s->R[i] = R;
+            s->sigma_maxmass[i] = c21_sigma_fast(c21_RtoM(R));
+        }
+        s->n_radii = n_radii;
+        s->r_lowest = 0;
+        for (int r = n_radii; r--;) /* IonisationBox.c:1537-1541 */
+            if (M_min > c21_RtoM(s->R[r])) {
+                s->r_lowest = r + 1;
+                break;
+            }
+    }
+
+    /* ---- turnover masses and the global mean: IonisationBox.c:1423-1469, :468-529 */
+    double Mturn_avg;
+    if (lagrangian) {
+        if (!halos) {
+            c21hip_set_error("ComputeIonizedBox: this SOURCE_MODEL needs a HaloBox");
+            st = C21CM_VALUE_ERROR;
+            goto done;
+        }
+        box->log10_Mturnover_ave = halos->log10_Mcrit_ACG_ave;
+        box->log10_Mturnover_MINI_ave = halos->log10_Mcrit_MCG_ave;
+        Mturn_avg = pow(10., halos->log10_Mcrit_ACG_ave);
+    } else {
+        Mturn_avg = M_min;
+        box->log10_Mturnover_ave = log10(M_min);
+        box->log10_Mturnover_MINI_ave = 0.0;
+    }
+    if (mass_dep) {
+        s->mean_f_coll = c21_Nion_General(redshift, lnMmin, lnMmax_gl, Mturn_avg, &sc);
+        s->f_limit_acg = c21_Nion_General(so->Z_HEAT_MAX, lnMmin, lnMmax_gl, Mturn_avg, &sc);
+    } else {
+        s->mean_f_coll = c21_Fcoll_General(redshift, lnMmin, lnMmax_gl);
+        s->f_limit_acg = c21_Fcoll_General(so->Z_HEAT_MAX, lnMmin, lnMmax_gl);
+    }
+    if (!isfinite(s->mean_f_coll) || s->mean_f_coll < 0) {
+        c21hip_set_error("ComputeIonizedBox: mean collapse fraction is invalid (HMF %d)", mo->HMF);
+        st = C21CM_INFINITY_OR_NAN_ERROR;
+        goto done;
+    }
+    box->mean_f_coll = s->mean_f_coll;
+    box->mean_f_coll_MINI = 0.;
+
+    struct fgtrm_table_ctx tctx = {s};
+    if (lagrangian) {
+        s->fcoll_mode = C21CM_FCOLL_STARS_GRID;
+    } else if (mo->USE_INTERPOLATION_TABLES == C21CM_INTERP_HMF) {
+        s->fcoll_mode = C21CM_FCOLL_TABLE_LINEAR;
+        s->table_fn = fgtrm_table_fn;
+        s->table_user = &tctx;
+    } else {
+        s->fcoll_mode = C21CM_FCOLL_ERFC;
+    }
+
+    if (s->mean_f_coll * ion_eff_factor_gl < HII_ROUND_ERR) {
+        /* set_fully_neutral_box: IonisationBox.c:531-565 */
+        const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
+        st = c21cm_neutral_box(s, perturbed_field, spin_temp, box, ntot);
+        goto done;
+    }
+    st = c21cm_ionize_grids(s, perturbed_field, previous_ionize_box, spin_temp, halos, box, NULL,
+                            NULL);
+done:
+    free(s);
+    return st;
+}

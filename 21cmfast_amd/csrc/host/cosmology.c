@@ -1,0 +1,635 @@
+/*
+ * cosmology.c -- host-side scalar cosmology needed by the drop-in Compute* entry points:
+ * matter power spectrum, sigma(M), growth factor, mass/radius conversions, the mass
+ * function integrals that normalise the excursion set, and the RECFAST temperature table.
+ *
+ * These are O(10-1000) scalar evaluations per Compute* call -- host work, as in the
+ * reference -- whose RESULTS steer the device kernels (P(k) table for the mode sampler,
+ * D(z) for the displacements, zeta/f_limit/sigma for the ionisation barrier).
+ *
+ * The reference evaluates the same published formulae with GSL quadrature
+ * (src/py21cmfast/src/cosmology.c, hmf.c).  GSL is a third-party dependency that is absent
+ * here, so the integrals use an own adaptive Gauss-Kronrod (7,15) rule; where the reference
+ * asks QAG for rel. tolerance 1e-6 (sigma) or 1e-3 (mass-function integrals) this code
+ * converges to 1e-8 / 1e-6, i.e. results agree within the reference's own tolerance but
+ * are not bit-identical ("parity unpinned" for these scalars).
+ *
+ * Exported names are the ones py21cmfast's cfuncs layer binds
+ * (src/py21cmfast/src/_functionprototypes_wrapper.h:137-141,83): init_ps, free_ps, dicke,
+ * sigma_z0, dsigmasqdm_z0, power_in_k.
+ */
+#include "cosmology.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../hip/c21hip.h"
+
+/* physical constants: src/py21cmfast/src/Constants.c:4-43 */
+#define PC_G 6.6743e-8
+#define PC_CM_PER_MPC 3.08567758e24
+#define PC_MSUN 1.989e33
+#define PC_T_CMB 2.7255
+#define PC_M_P 1.67262192369e-24
+#define PC_SIGMA_HI 6.3e-18
+#define DELTA_C_SPH 1.686
+#define N_NU 1.0 /* heavy neutrino species in the EH99 fit (cosmology.c:22) */
+
+static struct {
+    double sound_horizon, alpha_nu, beta_c, omhh, f_nu, f_baryon, theta_cmb, sigma_norm;
+    int ready;
+} cc;
+
+/* ---------------------------------------------------------------- adaptive quadrature */
+typedef double (*integrand_fn)(double x, void *ctx);
+
+static const double gk_x[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
+                               0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
+                               0.586087235467691130294144838258730, 0.405845151377397166906606412076961,
+                               0.207784955007898467600689403773245, 0.0};
+static const double gk_wk[8] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
+                                0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
+                                0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
+                                0.204432940075298892414161999234649, 0.209482141084727828012999174891714};
+static const double gk_wg[4] = {0.129484966168869693270611432679082, 0.279705391489276667901467771423780,
+                                0.381830050505118944950369775488975, 0.417959183673469387755102040816327};
+
+static double gk15(integrand_fn f, void *ctx, double a, double b, double *err) {
+    const double c = 0.5 * (a + b), h = 0.5 * (b - a);
+    const double fc = f(c, ctx);
+    double rk = fc * gk_wk[7], rg = fc * gk_wg[3];
+    for (int j = 0; j < 7; j++) {
+        const double dx = h * gk_x[j];
+        const double f1 = f(c - dx, ctx), f2 = f(c + dx, ctx);
+        rk += gk_wk[j] * (f1 + f2);
+        if (j & 1) rg += gk_wg[j / 2] * (f1 + f2);
+    }
+    *err = fabs((rk - rg) * h);
+    return rk * h;
+}
+
+static double adapt(integrand_fn f, void *ctx, double a, double b, double whole, double err,
+                    double abs_tol, int depth) {
+    if (err <= abs_tol || depth > 40) return whole;
+    const double c = 0.5 * (a + b);
+    double e1, e2;
+    const double left = gk15(f, ctx, a, c, &e1), right = gk15(f, ctx, c, b, &e2);
+    return adapt(f, ctx, a, c, left, e1, 0.5 * abs_tol, depth + 1) +
+           adapt(f, ctx, c, b, right, e2, 0.5 * abs_tol, depth + 1);
+}
+
+double c21_integrate(integrand_fn f, void *ctx, double a, double b, double rel_tol) {
+    /* two sweeps: a coarse one fixes the scale of the absolute tolerance */
+    const int panels = 16;
+    double total = 0., errs[16], vals[16];
+    for (int p = 0; p < panels; p++) {
+        const double lo = a + (b - a) * p / panels, hi = a + (b - a) * (p + 1) / panels;
+        vals[p] = gk15(f, ctx, lo, hi, &errs[p]);
+        total += vals[p];
+    }
+    const double abs_tol = fabs(total) * rel_tol / panels + 1e-300;
+    double result = 0.;
+    for (int p = 0; p < panels; p++) {
+        const double lo = a + (b - a) * p / panels, hi = a + (b - a) * (p + 1) / panels;
+        result += adapt(f, ctx, lo, hi, vals[p], errs[p], abs_tol, 0);
+    }
+    return result;
+}
+
+/* ---------------------------------------------------------------- basic quantities */
+double c21_hubble0(void) { return (double)(cosmo_params_global->hlittle * 3.2407e-18); }
+
+/* critical density today in Msun / Mpc^3: Constants.h RHOcrit */
+double c21_rhocrit(void) {
+    const double Ho = c21_hubble0();
+    return (3.0 * Ho * Ho / (8.0 * M_PI * PC_G)) * (PC_CM_PER_MPC * PC_CM_PER_MPC * PC_CM_PER_MPC) /
+           PC_MSUN;
+}
+
+/* present-day baryon number density H + He, Constants.h No / He_No / N_b0 */
+double c21_nb0(void) {
+    const double Ho = c21_hubble0();
+    const double rhocrit_cgs = 3.0 * Ho * Ho / (8.0 * M_PI * PC_G);
+    const double no = rhocrit_cgs * cosmo_params_global->OMb * (1 - cosmo_params_global->Y_He) / PC_M_P;
+    const double he = rhocrit_cgs * cosmo_params_global->OMb * cosmo_params_global->Y_He / (4.0 * PC_M_P);
+    return no + he;
+}
+
+/* cosmology.c:593-616 */
+double c21_MtoR(double M) {
+    const double rho_m = cosmo_params_global->OMm * c21_rhocrit();
+    if (matter_options_global->FILTER == C21CM_FILTER_GAUSSIAN)
+        return pow(M / (pow(2 * M_PI, 1.5) * rho_m), 1.0 / 3.0);
+    return pow(3 * M / (4 * M_PI * rho_m), 1.0 / 3.0);
+}
+double c21_RtoM(double R) {
+    const double rho_m = cosmo_params_global->OMm * c21_rhocrit();
+    if (matter_options_global->FILTER == C21CM_FILTER_GAUSSIAN) return pow(2 * M_PI, 1.5) * rho_m * pow(R, 3);
+    return (4.0 / 3.0) * M_PI * pow(R, 3) * rho_m;
+}
+
+static double omega_mz(float z) {
+    const CosmoParams *c = cosmo_params_global;
+    return c->OMm * pow(1 + z, 3) /
+           (c->OMm * pow(1 + z, 3) + c->OMl + c->OMr * pow(1 + z, 4) + c->OMk * pow(1 + z, 2));
+}
+
+/* Barkana & Loeb 2001 virial temperature -> mass; cosmology.c:642-648 */
+double c21_TtoM(double z, double T, double mu) {
+    const double d = omega_mz((float)z) - 1.0;
+    const double deltac_nl = 18 * M_PI * M_PI + 82 * d - 39 * d * d; /* Bryan & Norman 1998 */
+    return 7030.97 / (cosmo_params_global->hlittle) *
+           sqrt(omega_mz((float)z) / (cosmo_params_global->OMm * deltac_nl)) *
+           pow(T / (mu * (1 + z)), 1.5);
+}
+
+double c21_hubble(float z) {
+    const CosmoParams *c = cosmo_params_global;
+    return c21_hubble0() * sqrt(c->OMm * pow(1 + z, 3) + c->OMr * pow(1 + z, 4) + c->OMl);
+}
+
+/* Growth factor, Liddle et al. 1996 fit for flat LCDM(+radiation): cosmology.c:670-709 */
+double dicke(double z) {
+    const CosmoParams *c = cosmo_params_global;
+    const double tiny = 1e-4;
+    if (fabs(c->OMm - 1.0) < tiny) return 1.0 / (1.0 + z);
+    if ((c->OMl > (-tiny)) && (fabs(c->OMl + c->OMm + c->OMr - 1.0) < 0.01) &&
+        (fabs(c->wl + 1.0) < tiny)) {
+        const double omz = c->OMm * pow(1 + z, 3) /
+                           (c->OMl + c->OMm * pow(1 + z, 3) + c->OMr * pow(1 + z, 4));
+        const double dz = 2.5 * omz / (1.0 / 70.0 + omz * (209 - omz) / 140.0 + pow(omz, 4.0 / 7.0));
+        const double d0 =
+            2.5 * c->OMm / (1.0 / 70.0 + c->OMm * (209 - c->OMm) / 140.0 + pow(c->OMm, 4.0 / 7.0));
+        return dz / (d0 * (1.0 + z));
+    }
+    if ((c->OMtot < (1 + tiny)) && (fabs(c->OMl) < tiny)) { /* open, no lambda (Peebles p.53) */
+        const double x0 = 1.0 / (c->OMm + 0.0) - 1.0;
+        const double d0 = 1 + 3.0 / x0 + 3 * log(sqrt(1 + x0) - sqrt(x0)) * sqrt(1 + x0) / pow(x0, 1.5);
+        const double x = fabs(1.0 / (c->OMm + 0.0) - 1.0) / (1 + z);
+        const double dz = 1 + 3.0 / x + 3 * log(sqrt(1 + x) - sqrt(x)) * sqrt(1 + x) / pow(x, 1.5);
+        return dz / d0;
+    }
+    c21hip_set_error("dicke: no growth function for this cosmology");
+    return NAN;
+}
+
+/* dt/dz in seconds: cosmology.c:711-722 */
+double c21_dtdz(float z) {
+    const CosmoParams *c = cosmo_params_global;
+    const double x = sqrt(c->OMl / c->OMm) * pow(1 + z, -3.0 / 2.0);
+    const double dxdz = sqrt(c->OMl / c->OMm) * pow(1 + z, -5.0 / 2.0) * (-3.0 / 2.0);
+    const double const1 = 2 * sqrt(1 + c->OMm / c->OMl) / (3.0 * c21_hubble0());
+    const double numer = dxdz * (1 + x * pow(pow(x, 2) + 1, -0.5));
+    const double denom = x + sqrt(pow(x, 2) + 1);
+    return const1 * numer / denom;
+}
+
+/* dD/dt by the reference's one-sided difference with a float step: cosmology.c:725-731 */
+double c21_ddickedt(double z) {
+    const float dz = 1e-10;
+    return (dicke(z + dz) - dicke(z)) / dz / c21_dtdz((float)z);
+}
+
+/* ---------------------------------------------------------------- power spectrum */
+/* Eisenstein & Hu 1999 (ApJ 511, 5) fitting constants: cosmology.c:455-503 */
+static void set_eh_parameters(void) {
+    const double f_nu = cc.f_nu, f_b = cc.f_baryon, omhh = cc.omhh, th = cc.theta_cmb;
+    const double obhh = cosmo_params_global->OMb * cosmo_params_global->hlittle * cosmo_params_global->hlittle;
+    const double z_eq = 25000 * omhh * pow(th, -4) - 1.0;
+    const double k_eq = 0.0746 * omhh / (th * th);
+    double z_drag = 0.313 * pow(omhh, -0.419) * (1 + 0.607 * pow(omhh, 0.674));
+    z_drag = 1 + z_drag * pow(obhh, 0.238 * pow(omhh, 0.223));
+    z_drag *= 1291 * pow(omhh, 0.251) / (1 + 0.659 * pow(omhh, 0.828));
+    const double y_d = (1 + z_eq) / (1.0 + z_drag);
+    const double R_drag = 31.5 * obhh * pow(th, -4) * 1000 / (1.0 + z_drag);
+    const double R_eq = 31.5 * obhh * pow(th, -4) * 1000 / (1.0 + z_eq);
+    cc.sound_horizon = 2.0 / 3.0 / k_eq * sqrt(6.0 / R_eq) *
+                       log((sqrt(1 + R_drag) + sqrt(R_drag + R_eq)) / (1.0 + sqrt(R_eq)));
+    const double p_c = -(5 - sqrt(1 + 24 * (1 - f_nu - f_b))) / 4.0;
+    const double p_cb = -(5 - sqrt(1 + 24 * (1 - f_nu))) / 4.0;
+    const double f_c = 1 - f_nu - f_b, f_cb = 1 - f_nu, f_nub = f_nu + f_b;
+    double a = (f_c / f_cb) * (2 * (p_c + p_cb) + 5) / (4 * p_cb + 5.0);
+    a *= 1 - 0.553 * f_nub + 0.126 * pow(f_nub, 3);
+    a /= 1 - 0.193 * sqrt(f_nu) + 0.169 * f_nu;
+    a *= pow(1 + y_d, p_c - p_cb);
+    a *= 1 + (p_cb - p_c) / 2.0 * (1.0 + 1.0 / (4.0 * p_c + 3.0) / (4.0 * p_cb + 7.0)) / (1.0 + y_d);
+    cc.alpha_nu = a;
+    cc.beta_c = 1.0 / (1.0 - 0.949 * f_nub);
+}
+
+/* cosmology.c:52-75 */
+static double transfer_eh(double k) {
+    const double q = k * pow(cc.theta_cmb, 2) / cc.omhh;
+    const double sa = sqrt(cc.alpha_nu);
+    const double gamma_eff = sa + (1.0 - sa) / (1.0 + pow(0.43 * k * cc.sound_horizon, 4));
+    const double q_eff = q / gamma_eff;
+    double tf = log(M_E + 1.84 * cc.beta_c * sa * q_eff);
+    tf /= tf + pow(q_eff, 2) * (14.4 + 325.0 / (1.0 + 60.5 * pow(q_eff, 1.11)));
+    const double q_nu = 3.92 * q / sqrt(cc.f_nu / N_NU);
+    tf *= 1.0 + (1.2 * pow(cc.f_nu, 0.64) * pow(N_NU, 0.3 + 0.6 * cc.f_nu)) /
+                    (pow(q_nu, -1.6) + pow(q_nu, 0.8));
+    return tf;
+}
+
+/* the other analytic fits offered by POWER_SPECTRUM: cosmology.c:79-129 */
+static double transfer_other(double k, int which) {
+    const CosmoParams *c = cosmo_params_global;
+    const double h = c->hlittle;
+    if (which == C21CM_PS_BBKS) { /* Bardeen et al. 1986 + Sugiyama 1995 */
+        const double gamma = c->OMm * h * exp(-(c->OMb) - (c->OMb / c->OMm));
+        const double q = k / (h * gamma);
+        return (log(1.0 + 2.34 * q) / (2.34 * q)) *
+               pow(1.0 + 3.89 * q + pow(16.1 * q, 2) + pow(5.46 * q, 3) + pow(6.71 * q, 4), -0.25);
+    }
+    if (which == C21CM_PS_EFSTATHIOU) { /* Efstathiou et al. 1992 */
+        const double gamma = c->OMm * h * h;
+        const double aa = 6.4 / gamma, bb = 3.0 / gamma, ccc = 1.7 / gamma, nu = 1.13;
+        return pow(1 + pow(aa * k + pow(bb * k, 1.5) + pow(ccc * k, 2), nu), -1. / nu);
+    }
+    if (which == C21CM_PS_PEEBLES) { /* Peebles 1980 */
+        const double gamma = c->OMm * h * exp(-(c->OMb) - (c->OMb / c->OMm));
+        return 1 + (8.0 / (h * gamma)) * k + (4.7 / pow(h * gamma, 2)) * k * k;
+    }
+    /* White / Davies et al. 1985 */
+    const double gamma = c->OMm * h * h * exp(-(c->OMb) - (c->OMb / c->OMm));
+    return 139.284 / (1 + (1.7 / gamma) * k + (9.0 / pow(gamma, 1.5)) * pow(k, 1.5) +
+                      (1.0 / pow(gamma, 2)) * k * k);
+}
+
+/* z = 0 linear matter power spectrum in Mpc^3: cosmology.c:278-308 */
+double power_in_k(double k) {
+    if (k == 0.) return 0.;
+    const int which = matter_options_global->POWER_SPECTRUM;
+    double T = (which == C21CM_PS_EH) ? transfer_eh(k) : transfer_other(k, which);
+    T *= k * k; /* analytic fits tend to 1 as k -> 0; convert to the CLASS convention */
+    const double primordial =
+        cosmo_tables_global->ps_norm * pow(k / 0.05, cosmo_params_global->POWER_INDEX - 1.);
+    return cc.sigma_norm * primordial * T * T / pow(k, 3);
+}
+
+/* window of FILTER for sigma(M): filtering.c:18-46 */
+static double sigma_window(double kR, int filter) {
+    if (filter == C21CM_FILTER_GAUSSIAN) return exp(-0.643 * 0.643 * kR * kR / 2.);
+    if (filter == C21CM_FILTER_SHARPK) return (kR * 0.413566994 > 1) ? 0. : 1.;
+    if (kR < 1e-4) return 1 - kR * kR / 10;
+    return 3.0 * pow(kR, -3) * (sin(kR) - cos(kR) * kR);
+}
+
+struct sigma_ctx {
+    double R;
+    int filter;
+};
+
+/* integrand in ln k: k^3 P W^2 / (2 pi^2), cosmology.c:354-367 */
+static double dsigma_dlnk(double lnk, void *ctx) {
+    const struct sigma_ctx *s = (const struct sigma_ctx *)ctx;
+    const double k = exp(lnk);
+    const double w = sigma_window(k * s->R, s->filter);
+    return k * k * k * power_in_k(k) * w * w / (2.0 * M_PI * M_PI);
+}
+
+/* cosmology.c:369-408; the reference integrates k in [1e-99/R, 350/R] */
+double sigma_z0(double M) {
+    struct sigma_ctx s = {c21_MtoR(M), matter_options_global->FILTER};
+    const double res = c21_integrate(dsigma_dlnk, &s, log(1e-7 / s.R), log(350.0 / s.R), 1e-9);
+    return sqrt(res);
+}
+
+/* d(W^2)/dM: filtering.c:49-78 */
+static double dw2dm(double k, double R, int filter) {
+    const double kR = k * R;
+    const double rho_m = cosmo_params_global->OMm * c21_rhocrit();
+    double w, dwdr, drdm;
+    if (filter == C21CM_FILTER_GAUSSIAN) {
+        w = exp(-kR * kR / 2.0);
+        dwdr = -k * kR * w;
+        drdm = 1.0 / (pow(2 * M_PI, 1.5) * rho_m * 3 * R * R);
+    } else {
+        w = (kR < 1.0e-4) ? 1.0 : 3.0 * (sin(kR) / pow(kR, 3) - cos(kR) / pow(kR, 2));
+        dwdr = (kR < 1.0e-10)
+                   ? 0
+                   : 9 * cos(kR) * k / pow(kR, 3) + 3 * sin(kR) * (1 - 3 / (kR * kR)) / (kR * R);
+        drdm = 1.0 / (4.0 * M_PI * rho_m * R * R);
+    }
+    return 2 * w * dwdr * drdm;
+}
+
+static double dsigmasq_dlnk(double lnk, void *ctx) {
+    const struct sigma_ctx *s = (const struct sigma_ctx *)ctx;
+    const double k = exp(lnk);
+    return k * k * k * power_in_k(k) * dw2dm(k, s->R, s->filter) / (2.0 * M_PI * M_PI);
+}
+
+/* cosmology.c:421-453 */
+double dsigmasqdm_z0(double M) {
+    struct sigma_ctx s = {c21_MtoR(M), matter_options_global->FILTER};
+    return c21_integrate(dsigmasq_dlnk, &s, log(1e-7 / s.R), log(350.0 / s.R), 1e-8);
+}
+
+/* cosmology.c:507-558 */
+void init_ps(void) {
+    const CosmoParams *c = cosmo_params_global;
+    cc.omhh = c->OMm * c->hlittle * c->hlittle;
+    cc.theta_cmb = PC_T_CMB / 2.7;
+    cc.f_nu = fmax(c->OMn / c->OMm, 1e-10);
+    cc.f_baryon = fmax(c->OMb / c->OMm, 1e-10);
+    set_eh_parameters();
+    if (cosmo_tables_global->USE_SIGMA_8) {
+        cc.sigma_norm = 1;
+        const double R8 = 8.0 / c->hlittle;
+        cc.sigma_norm = pow(cosmo_tables_global->ps_norm / sigma_z0(c21_RtoM(R8)), 2);
+    } else {
+        cc.sigma_norm = 2.0 * M_PI * M_PI;
+    }
+    cc.ready = 1;
+}
+
+void free_ps(void) { cc.ready = 0; }
+
+int c21_ps_ready(void) { return cc.ready; }
+
+/* ---------------------------------------------------------------- sigma(M) table
+ * The mass-function integrals need sigma and d sigma^2/dM at hundreds of masses, each a
+ * quadrature over k.  Like the reference (interp_tables.c:1135-1170, Sigma_InterpTable) they
+ * are tabulated once per power-spectrum normalisation on a ln M grid; unlike the reference's
+ * linear float table the lookup is a natural cubic spline of ln sigma, ln(-d sigma^2/dM). */
+#define SIG_N 320
+#define SIG_LNM_MIN 6.9   /* ~1e3 Msun  */
+#define SIG_LNM_MAX 39.2  /* ~1e17 Msun */
+static struct {
+    int ready;
+    double norm_tag; /* sigma_norm the table was built for */
+    int filter, ps;
+    double lnM[SIG_N], lns[SIG_N], lnd[SIG_N], lns2[SIG_N], lnd2[SIG_N];
+} st;
+
+static void spline_setup(int n, const double *x, const double *y, double *y2);
+static double spline_eval(int n, const double *x, const double *y, const double *y2, double v);
+
+static void sigma_table_build(void) {
+    if (st.ready && st.norm_tag == cc.sigma_norm && st.filter == matter_options_global->FILTER &&
+        st.ps == matter_options_global->POWER_SPECTRUM)
+        return;
+    for (int i = 0; i < SIG_N; i++) {
+        st.lnM[i] = SIG_LNM_MIN + (SIG_LNM_MAX - SIG_LNM_MIN) * i / (SIG_N - 1.0);
+        const double M = exp(st.lnM[i]);
+        st.lns[i] = log(sigma_z0(M));
+        st.lnd[i] = log(-dsigmasqdm_z0(M));
+    }
+    spline_setup(SIG_N, st.lnM, st.lns, st.lns2);
+    spline_setup(SIG_N, st.lnM, st.lnd, st.lnd2);
+    st.norm_tag = cc.sigma_norm;
+    st.filter = matter_options_global->FILTER;
+    st.ps = matter_options_global->POWER_SPECTRUM;
+    st.ready = 1;
+}
+
+double c21_sigma_fast(double M) {
+    const double lnM = log(M);
+    if (lnM < SIG_LNM_MIN || lnM > SIG_LNM_MAX) return sigma_z0(M);
+    sigma_table_build();
+    return exp(spline_eval(SIG_N, st.lnM, st.lns, st.lns2, lnM));
+}
+
+static double dsigmasqdm_fast(double M) {
+    const double lnM = log(M);
+    if (lnM < SIG_LNM_MIN || lnM > SIG_LNM_MAX) return dsigmasqdm_z0(M);
+    sigma_table_build();
+    return -exp(spline_eval(SIG_N, st.lnM, st.lnd, st.lnd2, lnM));
+}
+
+/* ---------------------------------------------------------------- mass function integrals */
+#define SHETH_a 0.73 /* hmf.c:58-60 (Jenkins et al. 2001 values) */
+#define SHETH_p 0.175
+#define SHETH_A 0.353
+
+/* (1/rho_m) dn/dlnM, i.e. f(nu) |dln sigma / dM|: hmf.c:301-313 (ST), PS analogue */
+static double unconditional_mf(double growthf, double lnM, int hmf) {
+    const double M = exp(lnM);
+    double sigma = c21_sigma_fast(M) * growthf;
+    const double dsigmadm = dsigmasqdm_fast(M) * (growthf * growthf / (2. * sigma));
+    if (hmf == C21CM_HMF_PS) {
+        return -(dsigmadm / sigma) * sqrt(2. / M_PI) * (DELTA_C_SPH / sigma) *
+               exp(-(DELTA_C_SPH * DELTA_C_SPH) / (2 * sigma * sigma));
+    }
+    const double nuhat = sqrt(SHETH_a) * DELTA_C_SPH / sigma;
+    return -(dsigmadm / sigma) * sqrt(2. / M_PI) * SHETH_A * (1 + pow(nuhat, -2 * SHETH_p)) * nuhat *
+           exp(-nuhat * nuhat / 2.0);
+}
+
+struct mf_ctx {
+    double growthf;
+    int hmf;
+    int kind; /* 0: M * mf (collapsed fraction), 1: nion_fraction * mf */
+    double ln_fstar_norm, alpha_star, ln_Mlim_star;
+    double ln_fesc_norm, alpha_esc, ln_Mlim_esc;
+    double Mturn;
+};
+
+/* scaling_relations.c:211-231 */
+static double log_pl_limit(double lnM, double ln_norm, double alpha, double ln_pivot, double ln_limit) {
+    if ((alpha > 0. && lnM > ln_limit) || (alpha < 0. && lnM < ln_limit)) return -ln_norm;
+    return alpha * (lnM - ln_pivot);
+}
+
+static double mf_integrand(double lnM, void *ctx) {
+    const struct mf_ctx *p = (const struct mf_ctx *)ctx;
+    const double mf = unconditional_mf(p->growthf, lnM, p->hmf);
+    if (p->kind == 0) return exp(lnM) * mf; /* hmf.c:591-593 */
+    /* hmf.c:462-468 */
+    const double Fstar = log_pl_limit(lnM, p->ln_fstar_norm, p->alpha_star, 10 * M_LN10, p->ln_Mlim_star);
+    const double Fesc = log_pl_limit(lnM, p->ln_fesc_norm, p->alpha_esc, 10 * M_LN10, p->ln_Mlim_esc);
+    return exp(Fstar + Fesc - p->Mturn / exp(lnM) + lnM) * mf;
+}
+
+static int supported_hmf(void) {
+    const int h = matter_options_global->HMF;
+    return h == C21CM_HMF_PS || h == C21CM_HMF_ST;
+}
+
+/* hmf.c:945-953 */
+double c21_Fcoll_General(double z, double lnM_min, double lnM_max) {
+    if (!supported_hmf()) return NAN;
+    struct mf_ctx p;
+    memset(&p, 0, sizeof(p));
+    p.growthf = dicke(z);
+    p.hmf = matter_options_global->HMF;
+    p.kind = 0;
+    return c21_integrate(mf_integrand, &p, lnM_min, lnM_max, 1e-6);
+}
+
+/* hmf.c:955-971 */
+double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
+                        const c21_scaling_consts *sc) {
+    if (!supported_hmf()) return NAN;
+    struct mf_ctx p;
+    memset(&p, 0, sizeof(p));
+    p.growthf = dicke(z);
+    p.hmf = matter_options_global->HMF;
+    p.kind = 1;
+    p.ln_fstar_norm = log(sc->fstar_10);
+    p.alpha_star = sc->alpha_star;
+    p.ln_Mlim_star = log(sc->Mlim_Fstar);
+    p.ln_fesc_norm = log(sc->fesc_10);
+    p.alpha_esc = sc->alpha_esc;
+    p.ln_Mlim_esc = log(sc->Mlim_Fesc);
+    p.Mturn = Mturn;
+    return c21_integrate(mf_integrand, &p, lnM_min, lnM_max, 1e-6);
+}
+
+/* hmf.c:1268-1316: mass beyond which F = FRAC (M/1e10)^PL would exceed 1 (float bisection) */
+static float mass_limit(float logM, float PL, float FRAC) { return FRAC * pow(pow(10., logM) / 1e10, PL); }
+
+static float mass_limit_bisection(float Mmin, float Mmax, float PL, float FRAC, int *status) {
+    int iter = 0;
+    const int max_iter = 200;
+    const float rel_tol = 0.001;
+    float lo = log10(Mmin), hi = log10(Mmax), x, x1;
+    if (PL < 0.) {
+        if (mass_limit(lo, PL, FRAC) <= 1.) return Mmin;
+    } else if (PL > 0.) {
+        if (mass_limit(hi, PL, FRAC) <= 1.) return Mmax;
+    } else
+        return 0;
+    x = (lo + hi) / 2.;
+    ++iter;
+    do {
+        if ((mass_limit(lo, PL, FRAC) - 1.) * (mass_limit(x, PL, FRAC) - 1.) < 0.)
+            hi = x;
+        else
+            lo = x;
+        x1 = (lo + hi) / 2.;
+        ++iter;
+        if (fabs(x1 - x) < rel_tol) return pow(10., x1);
+        x = x1;
+    } while (iter < max_iter);
+    *status = C21CM_MASSDEPZETA_ERROR;
+    return 0.f;
+}
+
+/* scaling_relations.c:36-119 (fields used by the ionisation path) */
+int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc) {
+    int status = 0;
+    const AstroParams *ap = astro_params_global;
+    memset(sc, 0, sizeof(*sc));
+    sc->fstar_10 = ap->F_STAR10;
+    sc->alpha_star = ap->ALPHA_STAR;
+    sc->fstar_7 = ap->F_STAR7_MINI;
+    sc->t_h = 1.0 / c21_hubble((float)redshift);
+    sc->t_star = ap->t_STAR;
+    sc->alpha_esc = ap->ALPHA_ESC;
+    sc->fesc_10 = ap->F_ESC10;
+    sc->fesc_7 = ap->F_ESC7_MINI;
+    sc->pop2_ion = ap->POP2_ION;
+    sc->pop3_ion = ap->POP3_ION;
+    sc->acg_thresh = c21_TtoM((float)redshift, 1e4, 0.59); /* thermochem.c:277 */
+    sc->mturn_a_nofb = ap->M_TURN;
+    sc->Mlim_Fstar = mass_limit_bisection(1e5, 1e16, sc->alpha_star, sc->fstar_10, &status);
+    sc->Mlim_Fesc = mass_limit_bisection(1e5, 1e16, sc->alpha_esc, sc->fesc_10, &status);
+    return status;
+}
+
+/* hmf.c:1319-1348 */
+double c21_minimum_source_mass(double redshift) {
+    const int mass_dep = matter_options_global->SOURCE_MODEL != C21CM_SOURCE_CONST_ION_EFF;
+    const double min_factor = (mass_dep && !astro_options_global->USE_MINI_HALOS) ? 50. : 1.;
+    double Mmin;
+    if (astro_options_global->USE_MINI_HALOS) {
+        Mmin = 1e5;
+    } else if (astro_options_global->M_MIN_in_Mass) {
+        Mmin = astro_params_global->M_TURN;
+    } else {
+        const double t_vir_min = astro_params_global->ION_Tvir_MIN;
+        const double mu = t_vir_min < 9.99999e3 ? 1.22 : 0.6;
+        Mmin = c21_TtoM(redshift, t_vir_min, mu);
+    }
+    return Mmin / min_factor;
+}
+
+/* ---------------------------------------------------------------- RECFAST table */
+#define RECFAST_NPTS 501 /* heating_helper_progs.h */
+static struct {
+    int loaded;
+    int n;
+    double z[RECFAST_NPTS], tk[RECFAST_NPTS], xe[RECFAST_NPTS];
+    double tk2[RECFAST_NPTS], xe2[RECFAST_NPTS]; /* natural-spline second derivatives */
+    char path[600];
+} rf;
+
+/* natural cubic spline (what gsl_interp_cspline provides) */
+static void spline_setup(int n, const double *x, const double *y, double *y2) {
+    double *u = (double *)malloc(sizeof(double) * (size_t)n);
+    y2[0] = u[0] = 0.;
+    for (int i = 1; i < n - 1; i++) {
+        const double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+        const double p = sig * y2[i - 1] + 2.0;
+        y2[i] = (sig - 1.0) / p;
+        u[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+        u[i] = (6.0 * u[i] / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
+    }
+    y2[n - 1] = 0.;
+    for (int k = n - 2; k >= 0; k--) y2[k] = y2[k] * y2[k + 1] + u[k];
+    free(u);
+}
+
+static double spline_eval(int n, const double *x, const double *y, const double *y2, double v) {
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (hi + lo) >> 1;
+        if (x[mid] > v)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    const double h = x[hi] - x[lo];
+    const double a = (x[hi] - v) / h, b = (v - x[lo]) / h;
+    return a * y[lo] + b * y[hi] + ((a * a * a - a) * y2[lo] + (b * b * b - b) * y2[hi]) * (h * h) / 6.0;
+}
+
+/* heating_helper_progs.c:94-190: columns z, x_e, (unused), T_K; rows from high z to low z */
+int c21_recfast_load(void) {
+    char filename[600];
+    if (!config_settings.external_table_path) {
+        c21hip_set_error("RECFAST: config_settings.external_table_path is not set");
+        return C21CM_IO_ERROR;
+    }
+    snprintf(filename, sizeof(filename), "%s/recfast_LCDM.dat", config_settings.external_table_path);
+    if (rf.loaded && strcmp(filename, rf.path) == 0) return 0;
+    FILE *F = fopen(filename, "r");
+    if (!F) {
+        c21hip_set_error("RECFAST: unable to open %s", filename);
+        return C21CM_IO_ERROR;
+    }
+    double zt[RECFAST_NPTS], xe[RECFAST_NPTS], tk[RECFAST_NPTS];
+    int n = 0;
+    float cz, cx, trash, ct;
+    while (n < RECFAST_NPTS && fscanf(F, "%f %E %E %E", &cz, &cx, &trash, &ct) == 4) {
+        zt[n] = cz;
+        xe[n] = cx;
+        tk[n] = ct;
+        n++;
+    }
+    fclose(F);
+    if (n < 4) {
+        c21hip_set_error("RECFAST: %s holds only %d rows", filename, n);
+        return C21CM_IO_ERROR;
+    }
+    for (int i = 0; i < n; i++) { /* ascending redshift */
+        rf.z[i] = zt[n - 1 - i];
+        rf.xe[i] = xe[n - 1 - i];
+        rf.tk[i] = tk[n - 1 - i];
+    }
+    rf.n = n;
+    spline_setup(n, rf.z, rf.tk, rf.tk2);
+    spline_setup(n, rf.z, rf.xe, rf.xe2);
+    strncpy(rf.path, filename, sizeof(rf.path) - 1);
+    rf.loaded = 1;
+    return 0;
+}
+
+double c21_T_RECFAST(float z) { return spline_eval(rf.n, rf.z, rf.tk, rf.tk2, z); }
+double c21_xion_RECFAST(float z) { return spline_eval(rf.n, rf.z, rf.xe, rf.xe2, z); }
+/* heating_helper_progs.c:197 */
+float c21_cT_approx(float z) { return 0.58 - 0.006 * (z - 10.0); }

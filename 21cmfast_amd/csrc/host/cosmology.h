@@ -1,0 +1,54 @@
+/* cosmology.h -- host-side scalar cosmology (see cosmology.c). */
+#ifndef C21_COSMOLOGY_H
+#define C21_COSMOLOGY_H
+
+#include "c21cm_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* subset of the reference's ScalingConstants (scaling_relations.h:12-52) used here */
+typedef struct c21_scaling_consts {
+    double fstar_10, alpha_star, fstar_7;
+    double t_h, t_star;
+    double fesc_10, alpha_esc, fesc_7;
+    double pop2_ion, pop3_ion;
+    double acg_thresh, mturn_a_nofb;
+    double Mlim_Fstar, Mlim_Fesc;
+} c21_scaling_consts;
+
+/* exported with the reference's names (bound by py21cmfast's cfuncs layer) */
+void init_ps(void);
+void free_ps(void);
+double dicke(double z);
+double sigma_z0(double M);
+double dsigmasqdm_z0(double M);
+double power_in_k(double k);
+
+int c21_ps_ready(void);
+double c21_integrate(double (*f)(double, void *), void *ctx, double a, double b, double rel_tol);
+double c21_hubble0(void);
+double c21_hubble(float z);
+double c21_rhocrit(void);
+double c21_nb0(void);
+double c21_MtoR(double M);
+double c21_RtoM(double R);
+double c21_TtoM(double z, double T, double mu);
+double c21_dtdz(float z);
+double c21_ddickedt(double z);
+double c21_sigma_fast(double M); /* spline over a cached ln M table */
+double c21_Fcoll_General(double z, double lnM_min, double lnM_max);
+double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
+                        const c21_scaling_consts *sc);
+int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc);
+double c21_minimum_source_mass(double redshift);
+int c21_recfast_load(void);
+double c21_T_RECFAST(float z);
+double c21_xion_RECFAST(float z);
+float c21_cT_approx(float z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

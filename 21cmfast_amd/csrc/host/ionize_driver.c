@@ -646,3 +646,39 @@ done:
     for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
     return status;
 }
+
+/* The early exit of ComputeIonizedBox when the expected HII fraction is negligible.
+ * reference: src/py21cmfast/src/IonisationBox.c:531-565,1472-1475 */
+int c21cm_neutral_box(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
+                      const TsBox *spin_temp, IonizedBox *box, size_t ntot) {
+    extern double c21_xion_RECFAST(float z);
+    int status = 0;
+    const size_t bytes = ntot * sizeof(float);
+    copyback_list cb;
+    memset(&cb, 0, sizeof(cb));
+    void *stream = NULL;
+    const int ts = spec->use_ts_fluct;
+    const float *density = NULL, *xe = NULL, *Tn = NULL;
+    if (ts) {
+        if (!spin_temp || !spin_temp->xray_ionised_fraction) return C21CM_VALUE_ERROR;
+        xe = stage_in(WS_XE_DENSE, spin_temp->xray_ionised_fraction, bytes, stream, &status);
+        if (!spec->minimize_memory)
+            Tn = stage_in(WS_TNEUTRAL, spin_temp->kinetic_temp_neutral, bytes, stream, &status);
+    } else if (!spec->minimize_memory) {
+        density = stage_in(WS_DENSITY, perturbed_field->density, bytes, stream, &status);
+    }
+    float *xH = stage_inout(WS_XH, box->neutral_fraction, bytes, 0, &cb, stream, &status);
+    float *zre = stage_inout(WS_ZRE, box->z_reion, bytes, 0, &cb, stream, &status);
+    float *Tk = spec->minimize_memory
+                    ? NULL
+                    : stage_inout(WS_TK, box->kinetic_temperature, bytes, 0, &cb, stream, &status);
+    if (status) return status;
+    const double global_xH = ts ? 0. : 1. - c21_xion_RECFAST((float)spec->redshift);
+    TRY(c21hip_fill(zre, ntot, -1.0f, stream)); /* IonisationBox.c:1372-1378 */
+    TRY(c21hip_neutral_box(density, xe, Tn, xH, Tk, ntot, ts, global_xH, spec->TK_nofluct,
+                           spec->adia_TK_term, stream));
+    for (int i = 0; i < cb.n; i++) TRY(c21hip_d2h(cb.host[i], cb.dev[i], cb.bytes[i], stream));
+    TRY(c21hip_sync(stream));
+done:
+    return status;
+}

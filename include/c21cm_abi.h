@@ -304,7 +304,7 @@ void Broadcast_struct_global_noastro(SimulationOptions *simulation_options,
 
 /* Power-spectrum normalisation; reference: src/py21cmfast/src/cosmology.c:507-558.
  * Called by @init_c_state(ps=True) before ComputeInitialConditions. */
-double init_ps(void);
+void init_ps(void);
 void free_ps(void);
 
 /* reference: src/py21cmfast/src/InitialConditions.c:547 (_functionprototypes_wrapper.h:6) */

@@ -17,6 +17,8 @@
 #ifndef C21CM_GRID_H
 #define C21CM_GRID_H
 
+#include <stddef.h>
+
 #include "c21cm_abi.h"
 
 #ifdef __cplusplus
@@ -109,6 +111,11 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
                        const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                        const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
                        void *stream);
+
+/* Early exit of ComputeIonizedBox (expected HII fraction < 1e-5): uniform neutral box.
+ * reference: src/py21cmfast/src/IonisationBox.c:531-565 */
+int c21cm_neutral_box(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
+                      const TsBox *spin_temp, IonizedBox *box, size_t ntot);
 
 /* R-loop sharding over GPUs.  Each rank runs the radii
  * r = n_radii-1-rank, n_radii-1-rank-world, ... > 0 and records in

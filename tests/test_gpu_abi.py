@@ -1,0 +1,275 @@
+"""GPU tests of the drop-in entry points (ComputeInitialConditions / ComputePerturbedField /
+ComputeIonizedBox) called exactly as py21cmfast's CFFI layer calls them: parameter structs
+broadcast once, numpy arrays owned by the caller, integer status codes back.
+
+Each result is checked against the CPU oracle driven by a spec that the TEST assembles from
+the library's exported scalar functions (dicke, sigma, F_coll ...), i.e. the test
+re-derives set_ionbox_constants / setup_radii independently of abi_compute.c.
+"""
+
+import ctypes as C
+import importlib
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+S = importlib.import_module("21cmfast_amd.structs")
+W = importlib.import_module("21cmfast_amd.workloads")
+api_mod = "21cmfast_amd.grid_api"
+
+
+class Session:
+    """What py21cmfast's GlobalInitializationManager does (drivers/_global_initialization.py)."""
+
+    def __init__(self, lib, tmp_path, **over):
+        self.lib = lib
+        n = over.pop("HII_DIM", 32)
+        self.so = S.default_simulation_options(HII_DIM=n, DIM=over.pop("DIM", 2 * n),
+                                               BOX_LEN=over.pop("BOX_LEN", 1.5 * n))
+        self.mo = S.default_matter_options(**{k: over.pop(k) for k in list(over)
+                                              if hasattr(S.MatterOptions, k)})
+        self.cp = S.default_cosmo_params()
+        self.ap = S.default_astro_params(**{k: over.pop(k) for k in list(over)
+                                            if hasattr(S.AstroParams, k)})
+        self.ao = S.default_astro_options(**{k: over.pop(k) for k in list(over)
+                                             if hasattr(S.AstroOptions, k)})
+        self.ct = S.default_cosmo_tables()
+        assert not over, over
+        lib.Broadcast_struct_global_all(C.byref(self.so), C.byref(self.mo), C.byref(self.cp),
+                                        C.byref(self.ap), C.byref(self.ao), C.byref(self.ct))
+        # synthetic RECFAST table (the real one ships with py21cmfast's _data directory)
+        z = np.arange(500, -1, -1.0)
+        with open(tmp_path / "recfast_LCDM.dat", "w") as f:
+            for a in z:
+                tk = 2.725 * (1 + a) ** 2 / 151.0
+                f.write(f"{a:8.2f} {2e-4 + 1e-6 * a:13.5E} {tk:13.5E} {tk:13.5E}\n")
+        self.path = str(tmp_path).encode()
+        S.ConfigSettings.in_dll(lib, "config_settings").external_table_path = self.path
+        lib.init_ps.restype = None
+        lib.init_ps()
+        f64 = C.c_double
+        for name, args in (("dicke", [f64]), ("c21_ddickedt", [f64]), ("power_in_k", [f64]),
+                           ("c21_sigma_fast", [f64]), ("c21_RtoM", [f64]), ("c21_rhocrit", []),
+                           ("c21_minimum_source_mass", [f64]),
+                           ("c21_Fcoll_General", [f64, f64, f64])):
+            getattr(lib, name).restype = f64
+            getattr(lib, name).argtypes = args
+        lib.c21_T_RECFAST.restype = f64
+        lib.c21_T_RECFAST.argtypes = [C.c_float]
+        lib.c21_xion_RECFAST.restype = f64
+        lib.c21_xion_RECFAST.argtypes = [C.c_float]
+        lib.c21_recfast_load.restype = C.c_int
+        assert lib.c21_recfast_load() == 0
+
+
+@pytest.fixture()
+def api(gpu_lib):
+    return importlib.import_module(api_mod)
+
+
+def fptr(a):
+    return None if a is None else a.ctypes.data_as(S.c_float_p)
+
+
+def test_perturbed_field_entry_point(gpu_lib, api, oracle, tmp_path):
+    ses = Session(gpu_lib, tmp_path, HII_DIM=32, DIM=64, KEEP_3D_VELOCITIES=True)
+    from test_gpu_perturb import random_ics
+
+    ics = random_ics(32, 64, seed=21)
+    out = {k: np.zeros((32,) * 3, np.float32) for k in ("density", "velocity_x", "velocity_y",
+                                                         "velocity_z")}
+    pf = S.PerturbedFieldStruct(**{k: fptr(v) for k, v in out.items()})
+    z = 9.0
+    st = gpu_lib.ComputePerturbedField(z, C.byref(api.ics_struct(ics)), C.byref(pf))
+    assert st == 0, gpu_lib.c21cm_last_error()
+    spec = S.PerturbSpec(
+        dim=64, dim_z=64, hii_dim=32, hii_dim_z=32, box_len=48.0, box_len_z=48.0,
+        perturb_algorithm=2, perturb_on_high_res=0, keep_3d_velocities=1, smooth_evolved_density=0,
+        density_smooth_radius_mpc=0.2 * 48.0 / 32, growth_factor=gpu_lib.dicke(z),
+        init_growth_factor=gpu_lib.dicke(300.0),
+        dDdt_over_D=gpu_lib.c21_ddickedt(z) / gpu_lib.dicke(z))
+    ref = oracle.perturb_grids(spec, ics)
+    for k in ref:
+        scale = np.abs(ref[k]).max()
+        np.testing.assert_allclose(out[k], ref[k], atol=2e-5 * scale, rtol=1e-4, err_msg=k)
+
+
+def test_initial_conditions_entry_point(gpu_lib, api, oracle, tmp_path):
+    n, N, L = 16, 32, 48.0
+    ses = Session(gpu_lib, tmp_path, HII_DIM=n, DIM=N, BOX_LEN=L)
+    spec = S.IcsSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=L, box_len_z=L,
+                     perturb_algorithm=2)
+    ics = api.new_ics_arrays(spec)
+    st = gpu_lib.ComputeInitialConditions(2026, C.byref(api.ics_struct(ics)))
+    assert st == 0, gpu_lib.c21cm_last_error()
+    # oracle with P(k) taken from the library's exported power_in_k
+    n_m = 3 * (N // 2) ** 2 + 1
+    pk = np.array([gpu_lib.power_in_k(2 * math.pi / L * math.sqrt(m)) for m in range(n_m)])
+    vol = np.float32(np.float32(L) * np.float32(L)) * np.float32(1.0) * np.float32(L)
+    ospec = S.IcsSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=L, box_len_z=L,
+                      volume=float(vol), perturb_algorithm=2, n_m=n_m,
+                      pk_by_m=pk.ctypes.data_as(S.c_double_p), seed=2026)
+    ref = oracle.ics_grids(ospec)
+    for k in ref:
+        scale = np.abs(ref[k]).max()
+        np.testing.assert_allclose(ics[k], ref[k], atol=3e-5 * scale, rtol=1e-4, err_msg=k)
+    # physical sanity: sigma of the hi-res field is O(1) at z = 0 on 1.5 Mpc cells
+    assert 0.5 < ics["hires_density"].std() < 10
+    # the `initial_density` path: a non-zero hires_density is taken as the field
+    again = api.new_ics_arrays(spec)
+    again["hires_density"][...] = ics["hires_density"]
+    assert gpu_lib.ComputeInitialConditions(1, C.byref(api.ics_struct(again))) == 0
+    for k in ("lowres_density", "lowres_vx", "lowres_vz_2LPT"):
+        np.testing.assert_allclose(again[k], ics[k], atol=1e-5 * max(1, np.abs(ics[k]).max()))
+
+
+def ionize_spec_from_scalars(ses, z, lagrangian, tables):
+    """Independent restatement of set_ionbox_constants + setup_radii for the oracle."""
+    lib, so, ap = ses.lib, ses.so, ses.ap
+    n = so.HII_DIM
+    mode = W.FCOLL_STARS if lagrangian else (W.FCOLL_TABLE_LINEAR if tables else W.FCOLL_ERFC)
+    spec = W.ionize_spec(n, box_len=so.BOX_LEN, mode=mode, r_bubble_max=ap.R_BUBBLE_MAX,
+                         redshift=z)
+    spec.hii_filter = ses.ao.HII_FILTER
+    spec.stars_filter = 3 if ses.ao.USE_EXP_FILTER else ses.ao.HII_FILTER
+    M_min = lib.c21_minimum_source_mass(z)
+    for i in range(spec.n_radii):
+        spec.sigma_maxmass[i] = lib.c21_sigma_fast(lib.c21_RtoM(spec.R[i]))
+    spec.r_lowest = 0
+    for r in range(spec.n_radii - 1, -1, -1):
+        if M_min > lib.c21_RtoM(spec.R[r]):
+            spec.r_lowest = r + 1
+            break
+    spec.sigma_minmass = lib.c21_sigma_fast(M_min)
+    spec.growth_factor = lib.dicke(z)
+    spec.TK_nofluct = lib.c21_T_RECFAST(z)
+    spec.adia_TK_term = float(np.float32(0.58 - 0.006 * (np.float32(z) - 10.0)))
+    spec.T_re = ap.T_RE
+    spec.rhocrit_omb = lib.c21_rhocrit() * ses.cp.OMb
+    spec.mass_dep_zeta = 1 if lagrangian else 0
+    if not lagrangian:
+        spec.ion_eff_factor = ap.HII_EFF_FACTOR
+        spec.mean_f_coll = lib.c21_Fcoll_General(z, math.log(M_min), math.log(1e16))
+        spec.f_limit_acg = lib.c21_Fcoll_General(so.Z_HEAT_MAX, math.log(M_min), math.log(1e16))
+    return spec
+
+
+def call_ionize(lib, z, density, n_ion=None, need_nion=False):
+    shape = density.shape
+    out = {"neutral_fraction": np.ones(shape, np.float32), "z_reion": np.zeros(shape, np.float32),
+           "kinetic_temperature": np.zeros(shape, np.float32)}
+    if need_nion:
+        out["unnormalised_nion"] = np.zeros(shape, np.float32)
+    pf = S.PerturbedFieldStruct(density=fptr(density))
+    prev_z = np.zeros(shape, np.float32)
+    prev = S.IonizedBoxStruct(z_reion=fptr(prev_z))
+    ts, hb = S.TsBoxStruct(), S.HaloBoxStruct(n_ion=fptr(n_ion), log10_Mcrit_ACG_ave=8.7)
+    box = S.IonizedBoxStruct(neutral_fraction=fptr(out["neutral_fraction"]),
+                             z_reion=fptr(out["z_reion"]),
+                             kinetic_temperature=fptr(out["kinetic_temperature"]),
+                             unnormalised_nion=fptr(out.get("unnormalised_nion")))
+    ics = S.InitialConditionsStruct()
+    st = lib.ComputeIonizedBox(z, 0.0, C.byref(pf), C.byref(pf), C.byref(prev), C.byref(ts),
+                               C.byref(hb), C.byref(ics), C.byref(box))
+    out["status"], out["mean_f_coll"], out["prev_z_reion"] = st, box.mean_f_coll, prev_z
+    return out
+
+
+@pytest.mark.parametrize("tables", [2, 0])
+def test_ionized_box_const_ion_eff(gpu_lib, oracle, tmp_path, tables):
+    """SOURCE_MODEL=CONST-ION-EFF ("const-zeta" template): sharp-k filter, F_coll(delta) from the
+    erfc closed form or its 400-bin table, mean fixed to the ST collapsed fraction."""
+    ses = Session(gpu_lib, tmp_path, HII_DIM=32, SOURCE_MODEL=0, HII_FILTER=1, USE_EXP_FILTER=False,
+                  USE_INTERPOLATION_TABLES=tables, R_BUBBLE_MAX=12.0, HII_EFF_FACTOR=60.0,
+                  M_MIN_in_Mass=True)
+    z = 8.0
+    density = W.density_field_numpy(32, seed=3, sigma=0.6)
+    out = call_ionize(gpu_lib, z, density, need_nion=True)
+    assert out["status"] == 0, gpu_lib.c21cm_last_error()
+    spec = ionize_spec_from_scalars(ses, z, lagrangian=False, tables=bool(tables))
+    if tables:
+        def table_fn(r_index, dmin, dmax, table, user):
+            for i in range(S.NDELTA_TABLE):
+                d = dmin + i * (dmax - dmin) / (S.NDELTA_TABLE - 1.0)
+                table[i] = oracle.load().oracle_fgtrm_bias_fast(
+                    spec.growth_factor, d, spec.sigma_minmass, spec.sigma_maxmass[r_index], 1.686)
+            return 0
+        cb = S.TABLE_FN(table_fn)
+        spec.table_fn = cb
+    ref = oracle.ionize_grids(spec, density, need_nion=True)
+    ion_g, ion_r = out["neutral_fraction"] == 0, ref["neutral_fraction"] == 0
+    assert np.mean(ion_g != ion_r) <= 2e-4
+    same = ion_g == ion_r
+    np.testing.assert_allclose(out["neutral_fraction"][same], ref["neutral_fraction"][same],
+                               rtol=1e-4, atol=5e-6)
+    assert 0.02 < ion_r.mean() < 0.98
+    assert out["mean_f_coll"] == pytest.approx(spec.mean_f_coll, rel=1e-12)
+    assert np.all(out["prev_z_reion"] == -1)  # the first-snapshot previous box is initialised
+
+
+def test_ionized_box_lagrangian(gpu_lib, oracle, tmp_path):
+    ses = Session(gpu_lib, tmp_path, HII_DIM=32, SOURCE_MODEL=2, R_BUBBLE_MAX=12.0)
+    z = 9.0
+    density = W.density_field_numpy(32, seed=11)
+    n_ion = W.nion_from_density(density)
+    out = call_ionize(gpu_lib, z, density, n_ion=n_ion)
+    assert out["status"] == 0, gpu_lib.c21cm_last_error()
+    spec = ionize_spec_from_scalars(ses, z, lagrangian=True, tables=False)
+    # f_limit only matters through the floor; take it from the run itself is not possible, so
+    # use the same tiny number the mass-function integral gives at Z_HEAT_MAX (<< any cell)
+    spec.f_limit_acg = 0.0
+    ref = oracle.ionize_grids(spec, density, n_ion)
+    ion_g, ion_r = out["neutral_fraction"] == 0, ref["neutral_fraction"] == 0
+    assert np.mean(ion_g != ion_r) <= 2e-4
+    same = ion_g == ion_r
+    np.testing.assert_allclose(out["neutral_fraction"][same], ref["neutral_fraction"][same],
+                               rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(out["kinetic_temperature"][same], ref["kinetic_temperature"][same],
+                               rtol=1e-4, atol=2.0)
+    assert out["mean_f_coll"] == pytest.approx(ref["mean_f_coll"], rel=1e-5)
+
+
+def test_ionized_box_early_exit_and_errors(gpu_lib, tmp_path):
+    ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=0, HII_EFF_FACTOR=1e-4)
+    density = W.density_field_numpy(16, seed=1)
+    out = call_ionize(gpu_lib, 20.0, density, need_nion=True)
+    assert out["status"] == 0
+    xh = 1.0 - gpu_lib.c21_xion_RECFAST(20.0)
+    np.testing.assert_allclose(out["neutral_fraction"], np.float32(xh))
+    assert np.all(out["z_reion"] == -1)
+    tk = gpu_lib.c21_T_RECFAST(20.0) * (1 + float(np.float32(0.58 - 0.006 * 10.0)) * density)
+    np.testing.assert_allclose(out["kinetic_temperature"], tk, rtol=1e-5)
+    # unsupported options return ValueError (3), never crash
+    # (the Session must stay alive: the library stores POINTERS to its structs, as the
+    #  reference does -- InputParameters.c:11-20)
+    ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=1)
+    assert call_ionize(gpu_lib, 9.0, density, need_nion=True)["status"] == 3
+    assert b"E-INTEGRAL" in gpu_lib.c21cm_last_error()
+    ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=0, RECOMB_MODEL=2)
+    assert call_ionize(gpu_lib, 9.0, density, need_nion=True)["status"] == 3
+
+
+def test_coeval_chain(gpu_lib, api, tmp_path):
+    """IC -> PerturbedField -> IonizedBox through the ABI (config 1 geometry, HII_DIM=64,
+    DIM=128, with CONST-ION-EFF standing in for the default sampler)."""
+    n, N = 64, 128
+    ses = Session(gpu_lib, tmp_path, HII_DIM=n, DIM=N, BOX_LEN=96.0, SOURCE_MODEL=0,  # noqa: F841
+                  HII_FILTER=1, USE_EXP_FILTER=False, HII_EFF_FACTOR=30.0)
+    spec = S.IcsSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, perturb_algorithm=2)
+    ics = api.new_ics_arrays(spec)
+    assert gpu_lib.ComputeInitialConditions(12345, C.byref(api.ics_struct(ics))) == 0
+    dens = np.zeros((n,) * 3, np.float32)
+    vz = np.zeros((n,) * 3, np.float32)
+    pf = S.PerturbedFieldStruct(density=fptr(dens), velocity_z=fptr(vz))
+    assert gpu_lib.ComputePerturbedField(8.0, C.byref(api.ics_struct(ics)), C.byref(pf)) == 0
+    assert abs(dens.astype(np.float64).mean()) < 1e-5 and dens.min() >= -1
+    assert 0.05 < dens.std() < 1.5
+    out = call_ionize(gpu_lib, 8.0, dens, need_nion=True)
+    assert out["status"] == 0, gpu_lib.c21cm_last_error()
+    xh = out["neutral_fraction"]
+    assert xh.min() >= 0 and xh.max() <= 1 and np.isfinite(out["kinetic_temperature"]).all()
+    assert 0.01 < xh.mean() < 0.999
+    # ionised cells sit in over-dense regions on average (inside-out reionisation)
+    assert dens[xh == 0].mean() > dens[xh > 0.5].mean()

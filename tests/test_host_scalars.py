@@ -1,0 +1,164 @@
+"""Host-side cosmology scalars of the drop-in entry points (no GPU needed: pure C host code
+inside lib21cmfast_hip.so).  The reference computes them with GSL quadrature, which is absent
+here, so they are pinned against independent scipy evaluations of the same published
+formulae (the library's own P(k) is probed through its exported `power_in_k`)."""
+
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+from scipy import integrate, interpolate
+
+
+@pytest.fixture(scope="module")
+def host(pkg):
+    lib = pkg.load()
+    S = pkg.structs
+    f64 = C.c_double
+    for name, args in (("dicke", [f64]), ("sigma_z0", [f64]), ("dsigmasqdm_z0", [f64]),
+                       ("power_in_k", [f64]), ("c21_MtoR", [f64]), ("c21_RtoM", [f64]),
+                       ("c21_rhocrit", []), ("c21_sigma_fast", [f64]), ("c21_ddickedt", [f64]),
+                       ("c21_Fcoll_General", [f64, f64, f64]), ("c21_minimum_source_mass", [f64]),
+                       ("c21_TtoM", [f64, f64, f64])):
+        getattr(lib, name).restype = f64
+        getattr(lib, name).argtypes = args
+    lib.c21_dtdz.restype = f64
+    lib.c21_dtdz.argtypes = [C.c_float]
+    lib.c21_T_RECFAST.restype = f64
+    lib.c21_T_RECFAST.argtypes = [C.c_float]
+    lib.c21_xion_RECFAST.restype = f64
+    lib.c21_xion_RECFAST.argtypes = [C.c_float]
+    lib.c21_recfast_load.restype = C.c_int
+    lib.init_ps.restype = None
+    keep = dict(so=S.default_simulation_options(HII_DIM=32, DIM=64, BOX_LEN=48.0),
+                mo=S.default_matter_options(), cp=S.default_cosmo_params(),
+                ap=S.default_astro_params(), ao=S.default_astro_options(),
+                ct=S.default_cosmo_tables())
+    lib.Broadcast_struct_global_all(C.byref(keep["so"]), C.byref(keep["mo"]), C.byref(keep["cp"]),
+                                    C.byref(keep["ap"]), C.byref(keep["ao"]), C.byref(keep["ct"]))
+    lib.init_ps()
+    lib._keep = keep
+    return lib
+
+
+def test_sigma8_normalisation(host):
+    h = np.float32(0.6766)
+    M8 = host.c21_RtoM(8.0 / float(h))
+    assert host.sigma_z0(M8) == pytest.approx(0.8102, rel=1e-6)
+    assert host.c21_MtoR(M8) == pytest.approx(8.0 / float(h), rel=1e-12)
+    assert host.c21_rhocrit() == pytest.approx(2.775e11 * float(h) ** 2, rel=2e-3)
+
+
+def test_sigma_against_scipy(host):
+    """sigma^2(M) = int k^2 P(k) W^2(kR) dk / (2 pi^2) with the library's own P(k)."""
+    for M in (1e8, 1e10, 1e13):
+        R = host.c21_MtoR(M)
+
+        def f(lnk):
+            k = math.exp(lnk)
+            x = k * R
+            w = 3 * (math.sin(x) - x * math.cos(x)) / x**3 if x > 1e-4 else 1 - x * x / 10
+            return k**3 * host.power_in_k(k) * w * w / (2 * math.pi**2)
+
+        val, _ = integrate.quad(f, math.log(1e-6 / R), math.log(350 / R), limit=2000, epsrel=1e-9)
+        assert host.sigma_z0(M) == pytest.approx(math.sqrt(val), rel=1e-6)
+        assert host.c21_sigma_fast(M) == pytest.approx(host.sigma_z0(M), rel=1e-6)
+        # derivative by finite difference of sigma^2
+        eps = 1e-4
+        fd = (host.sigma_z0(M * (1 + eps)) ** 2 - host.sigma_z0(M * (1 - eps)) ** 2) / (2 * eps * M)
+        assert host.dsigmasqdm_z0(M) == pytest.approx(fd, rel=1e-5)
+    assert host.sigma_z0(1e8) > host.sigma_z0(1e10) > host.sigma_z0(1e13)
+
+
+def test_power_spectrum_shape(host):
+    """EH99 transfer function limits: P ~ k^n_s at low k, turnover near k_eq, falls at high k."""
+    k = np.logspace(-4, 2, 200)
+    p = np.array([host.power_in_k(x) for x in k])
+    slope_lo = np.log(p[5] / p[0]) / np.log(k[5] / k[0])
+    assert slope_lo == pytest.approx(0.9665, abs=0.02)
+    assert 0.005 < k[np.argmax(p)] < 0.05
+    slope_hi = np.log(p[-1] / p[-6]) / np.log(k[-1] / k[-6])
+    assert -3.2 < slope_hi < -2.3
+    assert host.power_in_k(0.0) == 0.0
+
+
+def test_growth_factor(host):
+    """dicke is the Carroll-Press-Turner / Liddle fit: within 1% of the exact LCDM growth."""
+    om, orad = float(np.float32(0.30966)), float(np.float32(8.6e-5))
+    ol = float(np.float32(1 - np.float32(0.30966)))
+
+    def E(a):
+        return math.sqrt(om / a**3 + orad / a**4 + ol)
+
+    def growth(z):
+        a = 1 / (1 + z)
+        val, _ = integrate.quad(lambda x: 1 / (x * E(x)) ** 3, 1e-8, a)
+        return E(a) * val
+
+    # radiation enters Omega_m(z) but not the z = 0 normalisation (cosmology.c:685-693)
+    assert host.dicke(0.0) == pytest.approx(1.0, abs=1e-4)
+    # (the integral form is exact for matter + Lambda; with radiation it drifts at high z,
+    # where the fit and the integral differ by a few per cent)
+    for z, tol in ((1.0, 1.2e-2), (9.0, 1.2e-2), (35.0, 4e-2), (300.0, 2e-1)):
+        assert host.dicke(z) == pytest.approx(growth(z) / growth(0.0), rel=tol)
+    assert host.dicke(9.0) > host.dicke(10.0) > host.dicke(300.0) > 0
+    # dD/dt = dD/dz / (dt/dz) and dt/dz = -1 / ((1+z) H(z)) without radiation
+    z = 9.0
+    H0 = float(np.float32(0.6766)) * 3.2407e-18
+    assert host.c21_dtdz(z) == pytest.approx(-1 / ((1 + z) * H0 * math.sqrt(om * (1 + z) ** 3 + ol)),
+                                             rel=2e-3)
+    assert host.c21_ddickedt(z) > 0
+
+
+def test_collapsed_fraction(host):
+    """Sheth-Tormen F_coll: the library integral vs scipy over its own sigma(M)."""
+    lnMmin, lnMmax = math.log(1e8), math.log(1e16)
+    A, a, p, dc = 0.353, 0.73, 0.175, 1.686
+
+    def integrand(lnM, growth):
+        M = math.exp(lnM)
+        sig = host.sigma_z0(M) * growth
+        dsdm = host.dsigmasqdm_z0(M) * growth * growth / (2 * sig)
+        nu = math.sqrt(a) * dc / sig
+        mf = -(dsdm / sig) * math.sqrt(2 / math.pi) * A * (1 + nu ** (-2 * p)) * nu * math.exp(-nu * nu / 2)
+        return M * mf
+
+    vals = []
+    for z in (6.0, 9.0, 15.0):
+        g = host.dicke(z)
+        ref, _ = integrate.quad(integrand, lnMmin, lnMmax, args=(g,), epsrel=1e-6, limit=200)
+        got = host.c21_Fcoll_General(z, lnMmin, lnMmax)
+        assert got == pytest.approx(ref, rel=2e-5)
+        vals.append(got)
+    assert vals[0] > vals[1] > vals[2] > 0
+    assert vals[1] < 0.2  # a few per cent of mass in > 1e8 Msun haloes at z ~ 9
+
+
+def test_minimum_source_mass_and_virial_mass(host):
+    # M_MIN_in_Mass with a mass-dependent source model: M_TURN / 50 (hmf.c:1319-1348)
+    assert host.c21_minimum_source_mass(9.0) == pytest.approx(10**8.7 / 50, rel=1e-6)
+    # T_vir = 1e4 K at z = 9 corresponds to ~1e8 Msun (Barkana & Loeb 2001)
+    assert 3e7 < host.c21_TtoM(9.0, 1e4, 0.59) < 3e8
+
+
+def test_recfast_spline(host, tmp_path):
+    """Natural cubic spline over the (z, x_e, -, T_K) table, like gsl_interp_cspline."""
+    z = np.arange(500, -1, -1.0)
+    xe = 2e-4 + 1e-6 * z
+    tk = 2.725 * (1 + z) ** 2 / 151.0
+    with open(tmp_path / "recfast_LCDM.dat", "w") as f:
+        for a, b, c in zip(z, xe, tk):
+            f.write(f"{a:8.2f} {b:13.5E} {c * 1.01:13.5E} {c:13.5E}\n")
+    cfg = host.__class__  # noqa: F841  (documentation: config_settings is a C global)
+    S = __import__("importlib").import_module("21cmfast_amd.structs")
+    cs = S.ConfigSettings.in_dll(host, "config_settings")
+    path = str(tmp_path).encode()
+    cs.external_table_path = path
+    host._keep["table_path"] = path
+    assert host.c21_recfast_load() == 0
+    tab = np.loadtxt(tmp_path / "recfast_LCDM.dat").astype(np.float32).astype(float)  # as fscanf %f/%E
+    cs_t = interpolate.CubicSpline(tab[::-1, 0], tab[::-1, 3], bc_type="natural")
+    for zz in (9.0, 9.37, 123.456):
+        assert host.c21_T_RECFAST(zz) == pytest.approx(float(cs_t(zz)), rel=1e-6)
+    assert host.c21_xion_RECFAST(9.5) == pytest.approx(2e-4 + 9.5e-6, rel=1e-3)
