@@ -1,0 +1,54 @@
+"""R-loop sharding of ComputeIonizedBox over the GPUs of one node.
+
+One process per GPU.  Every rank holds the (replicated) density / emissivity grids, filters
+its share of the radii and records, per cell, the largest radius index whose barrier was
+crossed (uint8, 0 = none).  ONE collective combines the shards: a max-reduce of that uint8
+grid onto the rank that owns radius index 0, which then applies the mask, runs the
+cell-scale radius (partial ionisation) and the post-loop.  "Largest radius that ionises the
+cell" is order independent, so the result is identical to the sequential loop
+(reference: src/py21cmfast/src/IonisationBox.c:1531-1588).
+
+``torch.distributed`` is the plumbing: backend "nccl" (= RCCL over xGMI) on the MI355X
+node, "gloo" in the CPU tests.
+"""
+
+from __future__ import annotations
+
+
+def radii_of_rank(n_radii: int, rank: int, world: int, r_lowest: int = 0) -> list[int]:
+    """Radius indices (descending, all >= 1) processed by `rank` in the shard phase:
+    indices n_radii-1 ... 1 dealt round-robin, largest first (matches
+    c21cm_ionize_shard_radii in csrc/host/ionize_driver.c)."""
+    out = []
+    r = n_radii - 1 - rank
+    while r >= 1 and r >= r_lowest:
+        out.append(r)
+        r -= world
+    return out
+
+
+def owner_rank(n_radii: int, world: int) -> int:
+    """The rank that the round-robin deal would hand radius index 0 to: it has the fewest
+    shard radii, so it also runs the finish step and is the destination of the reduce."""
+    return (n_radii - 1) % world
+
+
+def reduce_first_cross(first_cross, owner: int, group=None):
+    """Max-reduce the uint8 first-crossing grids onto `owner` (in place on that rank)."""
+    import torch.distributed as dist
+
+    dist.reduce(first_cross, dst=owner, op=dist.ReduceOp.MAX, group=group)
+    return first_cross
+
+
+def sharded_ionize(spec, density, n_ion, buffers, first_cross, rank: int, world: int, group=None):
+    """One sharded ComputeIonizedBox pass; returns the report on the owner rank, else None."""
+    from . import grid_api as api
+
+    owner = owner_rank(spec.n_radii, world)
+    api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion)
+    reduce_first_cross(first_cross, owner, group)
+    if rank == owner:
+        _, _, rep = api.ionize_shard_finish(spec, first_cross, density, n_ion, buffers=buffers)
+        return rep
+    return None

@@ -152,7 +152,8 @@ def main():
     density = W.density_field_torch(n, seed=12345)
     n_ion = W.nion_from_density(density) if mode == W.FCOLL_STARS else None
     buffers = api.IonizeBuffers(density, need_nion=mode != W.FCOLL_STARS)
-    owner = (spec.n_radii - 1) % world
+    D = importlib.import_module("21cmfast_amd.distributed")
+    owner = D.owner_rank(spec.n_radii, world)
     first_cross = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda") if world > 1 else None
     last_report = {}
 
@@ -162,11 +163,8 @@ def main():
             _, _, rep = api.ionize_grids(spec, density, n_ion, buffers=buffers)
             last_report["rep"] = rep
         else:
-            api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion)
-            dist.reduce(first_cross, dst=owner, op=dist.ReduceOp.MAX)
-            if rank == owner:
-                _, _, rep = api.ionize_shard_finish(spec, first_cross, density, n_ion,
-                                                    buffers=buffers)
+            rep = D.sharded_ionize(spec, density, n_ion, buffers, first_cross, rank, world)
+            if rep is not None:
                 last_report["rep"] = rep
 
     def fence():

@@ -1,0 +1,88 @@
+"""CPU checks of the drop-in boundary: the shared library loads without a GPU, exports every
+symbol that include/*.h declares, and the ctypes mirrors in 21cmfast_amd/structs.py agree
+byte for byte with what the C compiler lays out for the headers."""
+
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADERS = [ROOT / "include" / "c21cm_abi.h", ROOT / "include" / "c21cm_grid.h"]
+
+
+def declared_functions():
+    names = set()
+    for h in HEADERS:
+        text = re.sub(r"/\*.*?\*/", "", h.read_text(), flags=re.S)
+        text = re.sub(r"typedef[^;]*\(\*[^;]*;", "", text)  # function-pointer typedefs
+        for m in re.finditer(r"^[A-Za-z_][\w \*]*?\b(\w+)\s*\([^;{]*\)\s*;", text, flags=re.M):
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def test_library_loads_without_gpu_and_exports_every_declared_symbol(pkg):
+    lib = pkg.load()
+    names = declared_functions()
+    assert {"ComputeInitialConditions", "ComputePerturbedField", "ComputeIonizedBox",
+            "Broadcast_struct_global_all", "test_filter", "init_ps", "c21cm_ionize_grids",
+            "c21cm_perturb_grids", "c21cm_ics_grids", "c21cm_ionize_shard_radii"} <= set(names)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    for g in ("simulation_options_global", "matter_options_global", "cosmo_params_global",
+              "astro_params_global", "astro_options_global", "cosmo_tables_global",
+              "config_settings"):
+        C.c_void_p.in_dll(lib, g)
+    assert lib.c21cm_version().startswith(b"21cmfast_amd")
+
+
+STRUCTS = ["CosmoParams", "SimulationOptions", "MatterOptions", "AstroParams", "AstroOptions",
+           "CosmoTables", "ConfigSettings", "InitialConditions", "PerturbedField", "HaloBox",
+           "TsBox", "IonizedBox", "c21cm_ionize_spec", "c21cm_ionize_report", "c21cm_perturb_spec",
+           "c21cm_ics_spec"]
+PY_NAMES = {"InitialConditions": "InitialConditionsStruct", "PerturbedField": "PerturbedFieldStruct",
+            "HaloBox": "HaloBoxStruct", "TsBox": "TsBoxStruct", "IonizedBox": "IonizedBoxStruct",
+            "c21cm_ionize_spec": "IonizeSpec", "c21cm_ionize_report": "IonizeReport",
+            "c21cm_perturb_spec": "PerturbSpec", "c21cm_ics_spec": "IcsSpec"}
+
+
+def test_ctypes_mirrors_match_compiler_layout(pkg, tmp_path):
+    S = pkg.structs
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "c21cm_grid.h"', "int main(void){"]
+    for name in STRUCTS:
+        cls = getattr(S, PY_NAMES.get(name, name))
+        lines.append(f'printf("{name} size %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        name, field, value = line.split()
+        cls = getattr(S, PY_NAMES.get(name, name))
+        if field == "size":
+            assert C.sizeof(cls) == int(value), name
+        else:
+            assert getattr(cls, field).offset == int(value), f"{name}.{field}"
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under 21cmfast_amd/ may reference it."""
+    for path in (ROOT / "21cmfast_amd").rglob("*"):
+        if path.suffix in {".py", ".c", ".h", ".hip"} or path.name == "Makefile":
+            text = path.read_text(errors="ignore")
+            assert "liboracle" not in text and "oracle_" not in text, path
+            assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), path
+
+
+def test_missing_extension_fails_loudly(pkg, monkeypatch, tmp_path):
+    lib_mod = __import__("importlib").import_module("21cmfast_amd._lib")
+    monkeypatch.setattr(lib_mod, "_lib", None)
+    monkeypatch.setattr(lib_mod, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        lib_mod.load()
