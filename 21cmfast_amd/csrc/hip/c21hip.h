@@ -66,6 +66,10 @@ int c21hip_split_z_ionise_stars(const float *delta_work, const float *stars_work
                                 unsigned char *first_cross, double *partials, double *sum_out,
                                 int nx, int ny, int nz, int r_index, double rhocrit_omb,
                                 double ion_eff, int mass_dep_zeta, double f_limit, void *stream);
+/* time `reps` launches of one pass kernel with HIP events on `stream` (bench.py roofline leg);
+ * kind: 0 pass X (+window if filter_type >= 0), 1 pass Y, 2 fused pass Z, 3 plain pass Z */
+int c21hip_bench_pass(int kind, int n, int filter_type, float R, float R_param, double box_len,
+                      int reps, void *stream, float *ms_out);
 /* deterministic single-workgroup sum of n doubles (ionize_kernels.hip) */
 int c21hip_reduce_sum(const double *partials, int n, double *out, void *stream);
 

@@ -1201,6 +1201,93 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
     return c21hip_reduce_sum(partials, (int)(nlines / LZ_FUSED), sum_out, stream);
 }
 
+// ------------------------------------------------------------------ single-kernel timing hook
+// bench.py's roofline leg: `reps` launches of ONE pass kernel on the caller's stream,
+// bracketed by HIP events recorded on that same stream.  Buffers hold pseudo-random data
+// (zero-filled operands clock higher and would flatter the number).
+__global__ void __launch_bounds__(kBlock)
+pattern_fill_kernel(float *__restrict__ buf, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock) {
+        unsigned h = (unsigned)i * 2654435761u;
+        h ^= h >> 15;
+        h *= 2246822519u;
+        h ^= h >> 13;
+        buf[i] = ((float)(h & 0xFFFFFF) * (1.0f / 16777216.0f) - 0.5f) * 2e-3f;
+    }
+}
+
+// kind: 0 pass X main block (filter_type >= 0: fused window), 1 pass Y main block,
+//       2 fused pass Z + barrier (two grids), 3 plain pass Z
+extern "C" int c21hip_bench_pass(int kind, int n, int filter_type, float R, float R_param,
+                                 double box_len, int reps, void *stream_, float *ms_out) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c21hip_native_fft_supported(n, n, n)) return C21CM_VALUE_ERROR;
+    const size_t nf = c21hip_split_floats(n, n, n);
+    float *a = (float *)c21hip_ws(58, nf * sizeof(float));
+    float *b = (float *)c21hip_ws(59, nf * sizeof(float));
+    float *real = (float *)c21hip_ws(60, (size_t)n * n * (n + 2) * sizeof(float));
+    unsigned char *mask = (unsigned char *)c21hip_ws(61, (size_t)n * n * n);
+    double *partials = (double *)c21hip_ws(62, ((size_t)n * n / 4 + 64) * sizeof(double));
+    if (!a || !b || !real || !mask || !partials) return C21CM_MEMORY_ALLOC_ERROR;
+    hipLaunchKernelGGL(pattern_fill_kernel, dim3(2048), dim3(kBlock), 0, stream, a, nf);
+    hipLaunchKernelGGL(pattern_fill_kernel, dim3(2048), dim3(kBlock), 0, stream, b, nf);
+    (void)hipMemsetAsync(mask, 0, (size_t)n * n * n, stream);
+    const int H = n / 2;
+    const long nlines = (long)n * n;
+    LinePassArgs la{};
+    fill_filter(la.fp, filter_type, R, R_param, box_len, box_len);
+    la.n_y = n;
+    la.n_z = n;
+    la.out_scale = 1.0f;
+    la.src = reinterpret_cast<const float2 *>(a);
+    la.dst = reinterpret_cast<float2 *>(b);
+    la.col_stride = 1;
+    la.n_ctiles = H / TZ;
+    la.n_outer = n;
+    if (kind == 0) {
+        la.line_stride = (long)n * H;
+        la.outer_stride = H;
+        la.pair_outer = 1;
+    } else {
+        la.src = la.dst;
+        la.line_stride = H;
+        la.outer_stride = (long)n * H;
+        la.pair_outer = 0;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return C21CM_IO_ERROR;
+    int st = 0;
+    for (int r = -2; r < reps && !st; r++) {  // two warm-up launches
+        if (r == 0) (void)hipEventRecord(e0, stream);
+        if (kind == 0)
+            st = dispatch_line_pass<+1>(n, la, filter_type >= 0 ? 1 : 0, stream);
+        else if (kind == 1)
+            st = dispatch_line_pass<+1>(n, la, 0, stream);
+        else if (kind == 2)
+            st = c21hip_split_z_ionise_stars(a, b, mask, partials, partials + nlines / LZ_FUSED + 40,
+                                             n, n, n, 5, 6.2e9, 1.0, 1, 1e-9, stream);
+        else {
+            ZPassArgs z{};
+            z.main = reinterpret_cast<const float2 *>(a);
+            z.nyq = z.main + nlines * H;
+            z.out = real;
+            z.out_zstride = n + 2;
+            z.out_scale = 1.0f;
+            st = dispatch_z_c2r(n, z, nlines, stream);
+        }
+    }
+    (void)hipEventRecord(e1, stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_out = ms / (float)reps;
+    return st;
+}
+
 // Generic in-place c2r on the FFTW-style padded layout (used by c21cm_fft_c2r and the
 // PerturbedField / InitialConditions drivers for power-of-two grids).
 extern "C" int c21hip_native_fft_c2r(float *padded, int nx, int ny, int nz, void *stream) {

@@ -97,30 +97,51 @@ def cpu_baseline(args, W):
     }
 
 
-def kernel_roofline(api, W, args, spec, torch):
-    """Live HIP-event timing of the dominant hand-written unit, on torch's current stream
-    (the stream every kernel of the step is launched on)."""
-    n = args.hii_dim
-    npad = n * n * 2 * (n // 2 + 1)
-    lib = importlib.import_module("21cmfast_amd").load()
+PASS_KERNELS = {
+    0: "line_pass_kernel<512,+1,1>  (pass X: x-lines, fused W(kR) window, 1 grid)",
+    1: "line_pass_kernel<512,+1,0>  (pass Y: y-lines, 1 grid)",
+    2: "z_c2r_ionise_kernel<512>    (pass Z of both grids + f_coll sum + barrier)",
+}
+
+
+def kernel_roofline(args, spec, torch):
+    """Live HIP-event timing of each hand-written pass kernel of the R loop, on torch's current
+    stream (the stream every kernel of the step is launched on), with its ALGORITHMIC bytes:
+      pass X / pass Y  read + write of one split k-space grid         2 * S
+      fused pass Z     read of both grids + uint8 mask read + write   2 * S + 2 * N
+    S = 8 * (N/2 + nx*ny) bytes (split layout), N = cells."""
     import ctypes as C
 
+    n = args.hii_dim
+    lib = importlib.import_module("21cmfast_amd").load()
+    lib.c21hip_bench_pass.restype = C.c_int
+    lib.c21hip_bench_pass.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double,
+                                      C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    a = torch.randn(npad, device="cuda")
-    reps = 10
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    # one c2r transform of a padded grid: ideal traffic = read S + write S
-    for _ in range(2):
-        lib.c21cm_fft_c2r(C.c_void_p(a.data_ptr()), n, n, n, stream)
-    ev[0].record()
-    for _ in range(reps):
-        lib.c21cm_fft_c2r(C.c_void_p(a.data_ptr()), n, n, n, stream)
-    ev[1].record()
-    torch.cuda.synchronize()
-    ms = ev[0].elapsed_time(ev[1]) / reps
-    S = npad * 4.0
-    return {"kernel": "fft_c2r_512 (one padded grid, in place)", "ms": ms,
-            "alg_bytes": 2 * S, "GBs": 2 * S / ms / 1e6}
+    N = float(n) ** 3
+    S = 8.0 * (N / 2 + n * n)
+    alg = {0: 2 * S, 1: 2 * S, 2: 2 * S + 2 * N}
+    R_mid = spec.R[spec.n_radii // 2]
+    out = {}
+    for kind in (0, 1, 2):
+        ms = C.c_float()
+        st = lib.c21hip_bench_pass(kind, n, 0 if kind == 0 else -1, R_mid, 0.0, spec.box_len, 20,
+                                   stream, C.byref(ms))
+        if st != 0:
+            return None
+        out[kind] = {"kernel": PASS_KERNELS[kind], "ms": ms.value, "alg_bytes": alg[kind],
+                     "GBs": alg[kind] / ms.value / 1e6}
+    return out
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes
+    (profiles/pmc_r01.json, produced by tools/collect_pmc.py); None if absent."""
+    path = ROOT / "profiles" / "pmc_r01.json"
+    try:
+        return json.loads(path.read_text())
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -190,23 +211,38 @@ def main():
 
     out = None
     if rank == 0:
+        native = bool(pkg.load().c21hip_fft_is_native(n, n, n))
         alg_loop = algorithmic_bytes_per_radius(cells, G) * spec.n_radii
-        roof = {
-            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None,
-            "scope": "R loop of one step (all radii), algorithmic bytes (20G+8)*N per radius",
-        }
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None}
+        kern = None if (world > 1 or args.no_kernel_roofline or not native) else \
+            kernel_roofline(args, spec, torch)
+        if kern:
+            # dominant kernel = the pass-X line transform with the fused window (2 launches per
+            # radius; the largest share of the R loop in profiles/)
+            dom = kern[0]
+            roof.update({"kernel": dom["kernel"], "achieved": dom["GBs"],
+                         "frac": dom["GBs"] / HBM_PEAK_GBS, "ms_per_launch": dom["ms"],
+                         "alg_bytes_per_launch": dom["alg_bytes"],
+                         "other_kernels": [kern[1], kern[2]]})
+            pmc = pmc_traffic()
+            if pmc:
+                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = pmc.get("source")
         rep = last_report.get("rep")
+        # whole R loop against the SURVEY 8(d) contract: (20G + 8) * N bytes per radius
+        loop = {"alg_bytes": alg_loop,
+                "definition": "R loop of one step, (20G+8)*N algorithmic bytes per radius"}
         if world == 1 and rep is not None and rep.ms_rloop > 0:
-            roof["achieved"] = alg_loop / (rep.ms_rloop * 1e-3) / 1e9
-            roof["ms_rloop"] = rep.ms_rloop
-            roof["ms_preloop"] = rep.ms_preloop
-            roof["ms_postloop"] = rep.ms_postloop
+            loop.update({"ms": rep.ms_rloop, "ms_preloop": rep.ms_preloop,
+                         "ms_postloop": rep.ms_postloop,
+                         "GBs": alg_loop / (rep.ms_rloop * 1e-3) / 1e9})
         else:
-            roof["achieved"] = alg_loop / (ms_per_step * 1e-3) / 1e9
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-        if world == 1 and not args.no_kernel_roofline:
-            k = kernel_roofline(api, W, args, spec, torch)
-            roof["dominant_kernel"] = k
+            loop.update({"ms": ms_per_step, "GBs": alg_loop / (ms_per_step * 1e-3) / 1e9})
+        loop["frac"] = loop["GBs"] / HBM_PEAK_GBS
+        roof["r_loop"] = loop
+        if "achieved" not in roof:
+            roof.update({"kernel": "R loop (all kernels)", "achieved": loop["GBs"],
+                         "frac": loop["frac"]})
         out = {
             "metric": "IonizeBox cells/sec (512^3 HII_DIM, 40 filter radii)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
@@ -218,7 +254,7 @@ def main():
                             "first snapshot, device-resident inputs",
                 "hii_dim": n, "n_radii": spec.n_radii, "filtered_grids": G,
                 "parallelism": "single GPU" if world == 1 else f"R-loop sharded x{world} + RCCL uint8 max-reduce",
-                "fft": "native" if pkg.load().c21hip_fft_is_native(n, n, n) else "rocfft",
+                "fft": "native" if native else "rocfft",
                 "global_xH": None if rep is None else rep.global_xH,
             },
             "roofline": roof,
