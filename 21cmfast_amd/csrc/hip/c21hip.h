@@ -54,6 +54,10 @@ int c21hip_split_filter_c2r(const float *split_src, float *split_work, float *re
                             double box_len_z, int filter_type, float R, float R_param, int apply,
                             void *stream);
 
+/* forward transform of real rows into the split layout, scale-and-clip fused into the load
+ * (lo > hi disables the clip), result times out_scale: IonisationBox.c:323-360 in 3 sweeps */
+int c21hip_split_r2c(const float *real_in, long in_zstride, float *split_out, int nx, int ny,
+                     int nz, double factor, double lo, double hi, float out_scale, void *stream);
 int c21hip_split_filter_xy(const float *split_src, float *split_work, int nx, int ny, int nz,
                            double box_len, double box_len_z, int filter_type, float R,
                            float R_param, int apply, void *stream);

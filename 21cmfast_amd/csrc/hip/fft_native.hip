@@ -745,6 +745,78 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     }
 }
 
+// ------------------------------------------------------------------ pass Z (real -> complex)
+// Forward counterpart: z[j] = x[2j] + i x[2j+1], Zf = FFT_H^{-}(z), then
+//   X[k]   = E - i w_k D,   X[H-k] = conj(E) - i conj(w_k D),   w_k = exp(-2 pi i k / NZ),
+//   E = (Zf[k] + conj Zf[H-k]) / 2,  D = (Zf[k] - conj Zf[H-k]) / 2,
+//   X[0] = Re Zf[0] + Im Zf[0],  X[H] = Re Zf[0] - Im Zf[0]  (-> Nyquist plane).
+// The dense input is read with the scale-and-clip of prepare_box_for_filtering
+// (IonisationBox.c:333-350) applied on load, so no packing sweep is needed.
+struct ZFwdArgs {
+    const float *in;  // real rows of in_zstride floats
+    long in_zstride;
+    float2 *main, *nyq;
+    double factor, lo, hi;  // v = clip(in*factor, lo, hi); clip disabled when lo > hi
+};
+
+template <int NZ>
+__global__ void __launch_bounds__(kBlock)
+z_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
+             const float2 *__restrict__ twN_global) {
+    constexpr int H = NZ / 2, LZ = LZ_PLAIN, ZROW = LZ + 1;
+    extern __shared__ float4 lds_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [H][ZROW]
+    float2 *twH = tile + H * ZROW;
+    float2 *twN = twH + H;
+    for (int t = threadIdx.x; t < H; t += kBlock) twH[t] = twH_global[t];
+    for (int t = threadIdx.x; t <= H / 2; t += kBlock) twN[t] = twN_global[t];
+
+    const long l0 = (long)blockIdx.x * LZ;
+    const bool clip = a.lo <= a.hi;
+    constexpr int NIN = LZ * H / kBlock;  // float2 per thread
+#pragma unroll
+    for (int u = 0; u < NIN; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        const int li = f / H, j = f % H;
+        float2 v = reinterpret_cast<const float2 *>(a.in + (l0 + li) * a.in_zstride)[j];
+        if (clip) {
+            v.x = (float)fmax(fmin((double)v.x * a.factor, a.hi), a.lo);
+            v.y = (float)fmax(fmin((double)v.y * a.factor, a.hi), a.lo);
+        } else if (a.factor != 1.0) {
+            v.x = (float)((double)v.x * a.factor);
+            v.y = (float)((double)v.y * a.factor);
+        }
+        tile[j * ZROW + li] = v;
+    }
+    __syncthreads();
+    fft_tile<H, LZ, ZROW, -1, kBlock>(tile, twH);
+    // Hermitian post-processing, pairs (k, H-k) owned by one thread
+    constexpr int NPRE = (H / 2 + 1) * LZ;
+    for (int i = threadIdx.x; i < NPRE; i += kBlock) {
+        const int li = i % LZ, k = i / LZ;
+        if (k == 0) {
+            const float2 z0 = tile[li];
+            tile[li] = make_float2(z0.x + z0.y, 0.f);
+            a.nyq[l0 + li] = make_float2(z0.x - z0.y, 0.f);
+        } else {
+            const float2 A = tile[k * ZROW + li], B = tile[(H - k) * ZROW + li];
+            const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+            const float2 D = make_float2(0.5f * (A.x - B.x), 0.5f * (A.y + B.y));
+            const float2 wD = cmul(D, twN[k]);  // w_k D
+            // X[k] = E - i wD ; X[H-k] = conj(E) - i conj(wD)
+            tile[k * ZROW + li] = make_float2(E.x + wD.y, E.y - wD.x);
+            tile[(H - k) * ZROW + li] = make_float2(E.x - wD.y, -E.y - wD.x);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NIN; u++) {
+        const int f = threadIdx.x + kBlock * u;
+        const int li = f / H, k = f % H;
+        a.main[(l0 + li) * H + k] = tile[k * ZROW + li];
+    }
+}
+
 // ------------------------------------------------------------------ fused pass Z + barrier
 // Lagrangian source grids, radius index > 0: the z-lines of BOTH filtered grids (delta_R and
 // the filtered emissivity) are transformed in one workgroup and consumed in registers:
@@ -994,6 +1066,39 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
     }
 }
 
+template <int NZ>
+int launch_z_r2c(const ZFwdArgs &a, long nlines, hipStream_t stream) {
+    constexpr int H = NZ / 2;
+    const float2 *twH = twiddles(H);
+    const float2 *twN = twiddles(NZ);
+    if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+    const size_t lds = sizeof(float2) * ((size_t)H * (LZ_PLAIN + 1) + H + H / 2 + 1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)z_r2c_kernel<NZ>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((z_r2c_kernel<NZ>), dim3((unsigned)(nlines / LZ_PLAIN)), dim3(kBlock), lds,
+                       stream, a, twH, twN);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
+    switch (nz) {
+        case 64: return launch_z_r2c<64>(a, nlines, stream);
+        case 128: return launch_z_r2c<128>(a, nlines, stream);
+        case 256: return launch_z_r2c<256>(a, nlines, stream);
+        case 512: return launch_z_r2c<512>(a, nlines, stream);
+        case 1024: return launch_z_r2c<1024>(a, nlines, stream);
+        case 2048: return launch_z_r2c<2048>(a, nlines, stream);
+        default:
+            c21hip_set_error("native FFT: unsupported z length %d", nz);
+            return C21CM_VALUE_ERROR;
+    }
+}
+
 int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) {
     switch (nz) {
         case 64: return launch_z_c2r<64>(a, nlines, stream);
@@ -1150,6 +1255,74 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
     a.n_outer = 1;
     a.n_ctiles = nx / TZ;
     return dispatch_line_pass<+1>(ny, a, 0, stream);
+}
+
+// Forward transform into the split layout: real rows (in_zstride floats, scale-and-clip on
+// load; pass lo > hi to disable the clip) -> pass Z r2c -> pass Y -> pass X, the result
+// multiplied by out_scale (1/N for prepare_box_for_filtering, exact for power-of-two N).
+extern "C" int c21hip_split_r2c(const float *real_in, long in_zstride, float *split_out, int nx,
+                                int ny, int nz, double factor, double lo, double hi,
+                                float out_scale, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!c21hip_native_fft_supported(nx, ny, nz)) {
+        c21hip_set_error("native FFT does not support %dx%dx%d", nx, ny, nz);
+        return C21CM_VALUE_ERROR;
+    }
+    const int H = nz / 2;
+    const long nlines = (long)nx * ny;
+    float2 *o_main = reinterpret_cast<float2 *>(split_out);
+    float2 *o_nyq = o_main + nlines * H;
+    ZFwdArgs z{};
+    z.in = real_in;
+    z.in_zstride = in_zstride;
+    z.main = o_main;
+    z.nyq = o_nyq;
+    z.factor = factor;
+    z.lo = lo;
+    z.hi = hi;
+    int st = dispatch_z_r2c(nz, z, nlines, stream);
+    if (st) return st;
+    LinePassArgs a{};
+    a.fp.type = -1;
+    a.n_y = ny;
+    a.n_z = nz;
+    a.out_scale = 1.0f;
+    // pass Y, main block and Nyquist plane
+    a.src = o_main;
+    a.dst = o_main;
+    a.line_stride = H;
+    a.outer_stride = (long)ny * H;
+    a.col_stride = 1;
+    a.n_outer = nx;
+    a.n_ctiles = H / TZ;
+    if ((st = dispatch_line_pass<-1>(ny, a, 0, stream))) return st;
+    a.src = o_nyq;
+    a.dst = o_nyq;
+    a.line_stride = 1;
+    a.outer_stride = 0;
+    a.col_stride = ny;
+    a.n_outer = 1;
+    a.n_ctiles = nx / TZ;
+    if ((st = dispatch_line_pass<-1>(ny, a, 0, stream))) return st;
+    // pass X with the normalisation folded into its store
+    a.out_scale = out_scale;
+    a.src = o_main;
+    a.dst = o_main;
+    a.line_stride = (long)ny * H;
+    a.outer_stride = H;
+    a.col_stride = 1;
+    a.n_outer = ny;
+    a.n_ctiles = H / TZ;
+    a.pair_outer = 1;
+    if ((st = dispatch_line_pass<-1>(nx, a, 0, stream))) return st;
+    a.src = o_nyq;
+    a.dst = o_nyq;
+    a.line_stride = ny;
+    a.outer_stride = 0;
+    a.n_outer = 1;
+    a.n_ctiles = ny / TZ;
+    a.pair_outer = 0;
+    return dispatch_line_pass<-1>(nx, a, 0, stream);
 }
 
 // Pass Z: split_work -> real rows of out_zstride floats.

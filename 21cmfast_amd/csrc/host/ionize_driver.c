@@ -320,11 +320,17 @@ static void spectra_remember(const ion_ctx *c, const PerturbedField *pf, const H
 static int prepare_grid(ion_ctx *c, const float *dense, float *cgrid, float *scratch,
                         double factor, double lo, double hi) {
     int status = 0;
-    float *padded = c->native ? scratch : cgrid;
+    (void)scratch;
+    if (c->native) {
+        /* clip+scale on load, r2c in three sweeps, 1/N (exact: N is a power of two) on store */
+        TRY(c21hip_split_r2c(dense, c->nz, cgrid, c->nx, c->ny, c->nz, factor, lo, hi,
+                             1.0f / (float)c->ntot, c->stream));
+        goto done;
+    }
+    float *padded = cgrid;
     TRY(c21hip_pack_clip(dense, padded, c->nx, c->ny, c->nz, factor, lo, hi, c->stream));
     TRY(c21hip_fft_r2c(padded, c->nx, c->ny, c->nz, c->stream));
     TRY(c21hip_divide_inplace(padded, c->npad, (float)c->ntot, c->stream));
-    if (c->native) TRY(c21hip_padded_to_split(padded, cgrid, c->nx, c->ny, c->nz, c->stream));
 done:
     return status;
 }
