@@ -135,6 +135,10 @@ int c21hip_pack_density(const float *dense, float *padded, int nx, int ny, int n
 int c21hip_lpt2_accumulate(float *box, const float *phi_ij_padded, const float *diag_i,
                            const float *diag_j, int nx, int ny, int nz, void *stream);
 
+int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny, int nz,
+                             double box_len, double box_len_z, int filter_type, float R,
+                             float R_param, void *stream);
+
 /* ---- ionize_kernels.hip ---- */
 typedef struct c21hip_ionize_args {
     int nx, ny, nz;

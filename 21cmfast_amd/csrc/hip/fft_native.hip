@@ -415,7 +415,7 @@ __device__ __forceinline__ int mirror_row(int row_a) {
 // and 4 waves per SIMD to hide the fp64 latency of the window math.
 template <int N, int FMODE = 0>
 struct LineThreads {
-    static constexpr int value = (FMODE == 1 && N >= 256) ? 1024 : ((N >= 128) ? 512 : 256);
+    static constexpr int value = ((FMODE == 1 && N >= 256) || N >= 1024) ? 1024 : ((N >= 128) ? 512 : 256);
 };
 
 // FMODE: 0 no filter, 1 per-mode window evaluation, 2 window table lookup
@@ -429,6 +429,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
     float2 *tw = tile + N * TZ;                          // [N]
+    // FMODE 1: the window values of the current outer group, wlds[|k_x| row 0..N/2][TZ], kept
+    // in LDS between the two members of a mirror pair.  Each thread only ever reads the slots
+    // it wrote, so no barrier is needed; holding them in registers instead spilled to
+    // scratch (visible as +22 % HBM traffic in the PMC counters).
+    double *wlds = reinterpret_cast<double *>(tw + N);
     for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
@@ -474,8 +479,6 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     int mi = 0;
     issue_loads(tile_base(og, ct));
 
-    constexpr int NW = FILTER ? NP : 1;
-    double w[NW][2], w_half[2] = {1., 1.};
     bool first = true;
     while (true) {
         if (FILTER && mi == 0) {
@@ -507,14 +510,16 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 }
                 window_batch<2 * NP>(a.fp, kxs, kys, kzs, ws);
 #pragma unroll
-                for (int u = 0; u < NP; u++) {
-                    w[u][0] = ws[2 * u];
-                    w[u][1] = ws[2 * u + 1];
-                }
+                for (int u = 0; u < NP; u++)
+                    *reinterpret_cast<double2 *>(wlds + (r0 + RSTEP * u) * TZ + 2 * c4) =
+                        make_double2(ws[2 * u], ws[2 * u + 1]);
                 if (r0 == 0) {  // row N/2 (paired with row 0) has its own |k_x|: lanes 0-7 of wave 0
                     const float kxh = k_of(N / 2, N, a.fp.dkx);
                     float kx2[2] = {kxh, kxh};
-                    window_batch<2>(a.fp, kx2, ky, kz, w_half);
+                    double wh[2];
+                    window_batch<2>(a.fp, kx2, ky, kz, wh);
+                    *reinterpret_cast<double2 *>(wlds + (N / 2) * TZ + 2 * c4) =
+                        make_double2(wh[0], wh[1]);
                 }
             }
         }
@@ -577,8 +582,9 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             float4 v = reg[u];
             if (FILTER) {
                 const bool half = (u & 1) && row_a == 0;  // row N/2 has its own |k_x|
-                const double w0 = half ? w_half[0] : w[u >> 1][0];
-                const double w1 = half ? w_half[1] : w[u >> 1][1];
+                const double2 wv =
+                    *reinterpret_cast<const double2 *>(wlds + (half ? N / 2 : row_a) * TZ + 2 * c4);
+                const double w0 = wv.x, w1 = wv.y;
                 v.x = (float)((double)v.x * w0);
                 v.y = (float)((double)v.y * w0);
                 v.z = (float)((double)v.z * w1);
@@ -973,7 +979,8 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
         return C21CM_MEMORY_ALLOC_ERROR;
     }
-    const size_t lds = sizeof(float2) * ((size_t)N * TZ + N);
+    const size_t lds = sizeof(float2) * ((size_t)N * TZ + N) +
+                       (FMODE == 1 ? sizeof(double) * (size_t)(N / 2 + 1) * TZ : 0);
     const int groups = a.pair_outer ? (a.n_outer / 2 + 1) : a.n_outer;
     const int n_work = groups * a.n_ctiles;
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
@@ -1200,7 +1207,17 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
     a.n_z = nz;
     a.out_scale = 1.0f;
     int fmode = apply ? 1 : 0;
-    if (apply && window_table_enabled() && nx == ny && ny == nz && box_len == box_len_z &&
+    if (apply && nx >= 1024) {
+        // a 1024-point x-line tile (128 KB) leaves no LDS for the window slice: filter in a
+        // separate sweep, then run the passes unfused
+        int fst = c21hip_copy_filter_split(split_src, split_work, nx, ny, nz, box_len, box_len_z,
+                                           filter_type, R, R_param, stream_);
+        if (fst) return fst;
+        src_main = reinterpret_cast<const float2 *>(split_work);
+        src_nyq = src_main + nlines * H;
+        fmode = 0;
+    }
+    if (apply && fmode == 1 && window_table_enabled() && nx == ny && ny == nz && box_len == box_len_z &&
         (filter_type == 0 || filter_type == 3 || filter_type == 4)) {
         const int mmax = 3 * (nx / 2) * (nx / 2);
         double2 *table = (double2 *)c21hip_ws(49, sizeof(double2) * (size_t)(mmax + 1));

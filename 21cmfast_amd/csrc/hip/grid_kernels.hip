@@ -150,6 +150,7 @@ __device__ __forceinline__ double w_shell(double k, double R_inner, double R_out
 
 struct FilterParams {
     int nx, ny, nzc;
+    int nz0;  // k_z index of column 0 (non-zero for the Nyquist plane of the split layout)
     int type;
     float R, R_param;
     double dkx, dky, dkz;
@@ -199,7 +200,7 @@ copy_filter_kernel(const float2 *src, float2 *dst, FilterParams p) {  // src may
             const int n_y = (int)(line - (size_t)n_x * p.ny);
             const float k_x = k_of(n_x, p.nx, p.dkx);
             const float k_y = k_of(n_y, p.ny, p.dky);
-            const float k_z = (float)((double)n_z * p.dkz);
+            const float k_z = (float)((double)(n_z + p.nz0) * p.dkz);
             // float adds/muls exactly as written in the reference (no FMA contraction)
             const float k_mag_sq = __fadd_rn(
                 __fadd_rn(__fmul_rn(k_x, k_x), __fmul_rn(k_y, k_y)), __fmul_rn(k_z, k_z));
@@ -267,9 +268,32 @@ extern "C" int c21hip_widen(const float *in, double *out, size_t n, void *stream
     return 0;
 }
 
+static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, int nzc, int nz0,
+                            double box_len, double box_len_z, int filter_type, float R,
+                            float R_param, int apply, void *stream);
+
 extern "C" int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int ny, int nz,
                                   double box_len, double box_len_z, int filter_type, float R,
                                   float R_param, int apply, void *stream) {
+    return copy_filter_impl(src_c, dst_c, nx, ny, nz / 2 + 1, 0, box_len, box_len_z, filter_type, R,
+                            R_param, apply, stream);
+}
+
+// Same sweep on the split k-space layout (main block [nx][ny][nz/2] + Nyquist plane).
+extern "C" int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny,
+                                        int nz, double box_len, double box_len_z, int filter_type,
+                                        float R, float R_param, void *stream) {
+    const size_t main_floats = 2 * (size_t)nx * ny * (size_t)(nz / 2);
+    int st = copy_filter_impl(src_split, dst_split, nx, ny, nz / 2, 0, box_len, box_len_z,
+                              filter_type, R, R_param, 1, stream);
+    if (st) return st;
+    return copy_filter_impl(src_split + main_floats, dst_split + main_floats, nx, ny, 1, nz / 2,
+                            box_len, box_len_z, filter_type, R, R_param, 1, stream);
+}
+
+static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, int nzc, int nz0,
+                            double box_len, double box_len_z, int filter_type, float R,
+                            float R_param, int apply, void *stream) {
     if (apply && (filter_type < 0 || filter_type > 4)) {
         c21hip_set_error("filter type %d is not implemented on the device", filter_type);
         return C21CM_VALUE_ERROR;
@@ -277,7 +301,8 @@ extern "C" int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int 
     FilterParams p;
     p.nx = nx;
     p.ny = ny;
-    p.nzc = nz / 2 + 1;
+    p.nzc = nzc;
+    p.nz0 = nz0;
     p.type = filter_type;
     p.R = R;
     p.R_param = R_param;

@@ -87,6 +87,20 @@ def test_lagrangian_two_grid_parity(api, oracle, n, device_resident):
     assert got["mean_f_coll"] == pytest.approx(ref["mean_f_coll"], rel=1e-5)
 
 
+def test_long_lines_non_cubic_parity(api, oracle):
+    """1024-point x/y lines (config-4 line length; unfused window path) on a thin non-cubic box
+    1024 x 1024 x 64 so that the oracle still finishes in seconds."""
+    oracle.set_threads(32)
+    spec = W.ionize_spec(1024, hii_dim_z=64, r_bubble_max=2.6)
+    assert spec.n_radii >= 8
+    density = W.density_field_numpy((1024, 1024, 64), seed=31)
+    n_ion = W.nion_from_density(density)
+    ref = oracle.ionize_grids(spec, density, n_ion)
+    got = run_device(api, spec, density, n_ion, device_resident=True)
+    compare(got, ref, spec)
+    oracle.set_threads(16)
+
+
 @pytest.mark.parametrize("n", [32, 50, 64])
 def test_const_ion_eff_erfc_parity(api, oracle, n):
     """G = 1 variant: CONST-ION-EFF closed-form erfc, sharp-k filter, fix_mean."""
