@@ -61,6 +61,11 @@ int c21hip_split_r2c(const float *real_in, long in_zstride, float *split_out, in
 int c21hip_split_filter_xy(const float *split_src, float *split_work, int nx, int ny, int nz,
                            double box_len, double box_len_z, int filter_type, float R,
                            float R_param, int apply, void *stream);
+/* two grids (density, emissivity) of one radius in one sweep, each with its own window */
+int c21hip_split_filter_xy2(const float *src_a, float *work_a, int filter_a, float R_param_a,
+                            const float *src_b, float *work_b, int filter_b, float R_param_b,
+                            int nx, int ny, int nz, double box_len, double box_len_z, float R,
+                            int apply, void *stream);
 int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstride, int nx, int ny,
                        int nz, void *stream);
 /* Fused pass Z of delta_R and the filtered emissivity + sum(stars) + ionisation barrier for
@@ -70,10 +75,12 @@ int c21hip_split_z_ionise_stars(const float *delta_work, const float *stars_work
                                 unsigned char *first_cross, double *partials, double *sum_out,
                                 int nx, int ny, int nz, int r_index, double rhocrit_omb,
                                 double ion_eff, int mass_dep_zeta, double f_limit, void *stream);
-/* time `reps` launches of one pass kernel with HIP events on `stream` (bench.py roofline leg);
- * kind: 0 pass X (+window if filter_type >= 0), 1 pass Y, 2 fused pass Z, 3 plain pass Z */
-int c21hip_bench_pass(int kind, int n, int filter_type, float R, float R_param, double box_len,
-                      int reps, void *stream, float *ms_out);
+/* time `reps` launches of one pass with HIP events on `stream` (bench.py roofline leg);
+ * kind: 0 pass X and 1 pass Y as the excursion-set loop launches them (two grids, windows
+ * filter_a / filter_b streamed from the per-radius tables), 2 fused pass Z, 3 plain pass Z,
+ * 4 the window-table kernel */
+int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, float R, float R_param_b,
+                      double box_len, int reps, void *stream, float *ms_out);
 /* deterministic single-workgroup sum of n doubles (ionize_kernels.hip) */
 int c21hip_reduce_sum(const double *partials, int n, double *out, void *stream);
 
@@ -134,10 +141,6 @@ int c21hip_pack_density(const float *dense, float *padded, int nx, int ny, int n
 /* box += phi_ii*phi_jj; box -= phi_ij^2 (:451-482) */
 int c21hip_lpt2_accumulate(float *box, const float *phi_ij_padded, const float *diag_i,
                            const float *diag_j, int nx, int ny, int nz, void *stream);
-
-int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny, int nz,
-                             double box_len, double box_len_z, int filter_type, float R,
-                             float R_param, void *stream);
 
 /* ---- ionize_kernels.hip ---- */
 typedef struct c21hip_ionize_args {

@@ -260,6 +260,19 @@ __device__ __forceinline__ double w_shell(double k, double R_inner, double R_out
 __device__ __forceinline__ float k_of(int n, int dim, double dk) {
     return (n > dim / 2) ? (float)((double)(n - dim) * dk) : (float)((double)n * dk);
 }
+// filtering.c:357-361 (real-space top-hat) and :80-104 (top-hat x exp(-r/mfp)) given sin/cos
+__device__ __forceinline__ double w_tophat(double kR, double sn, double cs) {
+    return (kR < 1e-4) ? 1 - kR * kR / 10 : 3.0 / (kR * kR * kR) * (sn - cs * kR);
+}
+__device__ __forceinline__ double w_expmfp(const ExpMfpConsts &c, double kR, double sn, double cs) {
+    double f = (kR * kR * c.ratio2 + 2 * c.ratio + 1) * c.ratio * cs;
+    f += (kR * kR * (c.ratio2 - c.ratio3) + c.ratio + 1) * sn / kR;
+    f *= c.exp_term;
+    f -= 2 * c.ratio2;
+    const double d = kR * c.ratio * kR * c.ratio + 1;
+    f *= -3 * c.ratio / (d * d);
+    return (kR < 1e-4) ? c.ts_0 + c.ts_2 * kR * kR : f;
+}
 // Window values for NE modes at once.  The filter-type switch is hoisted out of the
 // per-mode work and every step is written as a loop over the NE independent values, so
 // the fp64 dependency chains (sqrt -> reduce -> polynomial -> divide) of different modes
@@ -306,82 +319,117 @@ __device__ __forceinline__ void window_batch(const FilterParams &p, const float 
     for (int i = 0; i < NE; i++) sincos_sel(p.libm_trig, x[i], &sn[i], &cs[i]);
     if (p.type == 0) {
 #pragma unroll
-        for (int i = 0; i < NE; i++) {
-            const double kR = x[i];
-            w[i] = (kR < 1e-4) ? 1 - kR * kR / 10 : 3.0 / (kR * kR * kR) * (sn[i] - cs[i] * kR);
-        }
-    } else {  // type 3, filtering.c:80-104
-        const ExpMfpConsts &c = p.mfp;
+        for (int i = 0; i < NE; i++) w[i] = w_tophat(x[i], sn[i], cs[i]);
+    } else {
 #pragma unroll
-        for (int i = 0; i < NE; i++) {
-            const double kR = x[i];
-            double f = (kR * kR * c.ratio2 + 2 * c.ratio + 1) * c.ratio * cs[i];
-            f += (kR * kR * (c.ratio2 - c.ratio3) + c.ratio + 1) * sn[i] / kR;
-            f *= c.exp_term;
-            f -= 2 * c.ratio2;
-            const double d = kR * c.ratio * kR * c.ratio + 1;
-            f *= -3 * c.ratio / (d * d);
-            w[i] = (kR < 1e-4) ? c.ts_0 + c.ts_2 * kR * kR : f;
-        }
+        for (int i = 0; i < NE; i++) w[i] = w_expmfp(p.mfp, x[i], sn[i], cs[i]);
     }
 }
 
-// ------------------------------------------------------------------ 1-D window table
-// On a cubic grid |k|^2 = dk^2 * m with the integer m = nx^2 + ny^2 + nz^2 <= 3 (N/2)^2, so
-// the window takes at most 3(N/2)^2 + 1 distinct values per (filter, R): ~2e5 evaluations
-// instead of the reference's N^3/2 (6.7e7 at 512^3).  The reference, however, holds
-// k_x, k_y, k_z and |k|^2 in float (filtering.c:331-350), so its |k|^2 differs from
-// dk^2 * m by float rounding (~1e-7 relative).  The table therefore stores
-//     { W(m), dW/d(k^2)(m) }
-// and pass X evaluates  W(m) + dW/d(k^2) * (ksq_float - dk^2 m)  with ksq_float computed
-// exactly as the reference does: first order in a 1e-7 perturbation, i.e. equal to the
-// direct evaluation to ~1e-13.  What is NOT replicated is the additional float rounding
-// of the product kR for filter types 0/1 (filtering.c:357): |dW| <= 3e-8 |x W'(x)| < 1e-7,
-// far inside the float32 noise of the transforms.  Opt-in with C21CM_WINDOW=table: the
-// per-mode evaluation is the default (and faster, see window_table_enabled()).
-__device__ double window_exact(const FilterParams &p, double ksq) {
-    const double k = sqrt(ksq);
-    double s, c;
-    if (p.type == 0) {
-        const double x = k * (double)p.R;
-        if (x < 1e-4) return 1 - x * x / 10;
-        sincos(x, &s, &c);
-        return 3.0 / (x * x * x) * (s - c * x);
+// Two windows of the same modes (the density grid's HII_FILTER and the emissivity grid's
+// exp-MFP filter of one radius).  Top-hat + exp-MFP share |k| and one sincos: the top-hat
+// argument is kR rounded to float (filtering.c:357), the exp-MFP one is kR in double (:83),
+// so sin/cos of the second follow from the first by a third-order rotation through their
+// difference d <= 2^-24 kR (error d^4/24 < 1e-20 for kR of a few hundred).
+template <int NE>
+__device__ __forceinline__ void window_batch_dual(const FilterParams &pa, const FilterParams &pb,
+                                                  const float (&kx)[NE], const float (&ky)[NE],
+                                                  const float (&kz)[NE], double (&wa)[NE],
+                                                  double (&wb)[NE]) {
+    if (!(pa.type == 0 && pb.type == 3 && !pa.libm_trig)) {
+        window_batch<NE>(pa, kx, ky, kz, wa);
+        window_batch<NE>(pb, kx, ky, kz, wb);
+        return;
     }
-    if (p.type == 3) {
-        const ExpMfpConsts &m = p.mfp;
-        const double x = k * m.R;
-        if (x < 1e-4) return m.ts_0 + m.ts_2 * x * x;
-        sincos(x, &s, &c);
-        double f = (x * x * m.ratio2 + 2 * m.ratio + 1) * m.ratio * c;
-        f += (x * x * (m.ratio2 - m.ratio3) + m.ratio + 1) * s / x;
-        f *= m.exp_term;
-        f -= 2 * m.ratio2;
-        const double d = x * m.ratio * x * m.ratio + 1;
-        return f * (-3 * m.ratio / (d * d));
+    double x0[NE], x3[NE], sn[NE], cs[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+        const float ksq = __fadd_rn(__fadd_rn(__fmul_rn(kx[i], kx[i]), __fmul_rn(ky[i], ky[i])),
+                                    __fmul_rn(kz[i], kz[i]));
+        const double k = sqrt((double)ksq);
+        x0[i] = (double)(float)(k * (double)pa.R);
+        x3[i] = k * pb.mfp.R;
     }
-    return w_shell(k, (double)p.R, (double)p.R_param, 1);
+#pragma unroll
+    for (int i = 0; i < NE; i++) fast_sincos(x0[i], &sn[i], &cs[i]);
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+        wa[i] = w_tophat(x0[i], sn[i], cs[i]);
+        const double d = x3[i] - x0[i], d3 = d * (1.0 / 3.0);
+        const double s3 = sn[i] + d * (cs[i] - 0.5 * d * (sn[i] + d3 * cs[i]));
+        const double c3 = cs[i] - d * (sn[i] + 0.5 * d * (cs[i] - d3 * sn[i]));
+        wb[i] = w_expmfp(pb.mfp, x3[i], s3, c3);
+    }
 }
+
+// ------------------------------------------------------------------ window table of one radius
+// W(kR) depends on (|k_x|, |k_y|, k_z) only, so one radius needs (nx/2+1)(ny/2+1)(nz/2+1)
+// values -- a quarter of the modes pass X multiplies.  They are evaluated here, at full
+// occupancy, into
+//     main [|k_y|][|k_x|][k_z < nz/2]   and   nyq [|k_x|][|k_y|]   (k_z = nz/2),
+// laid out so that pass X streams them exactly like its data tiles (rows of 16 k_z values =
+// 128 contiguous bytes).  An earlier version evaluated W inside pass X (once per mirror pair,
+// kept in LDS): the same total time at 512^3, but 28 KB more LDS and 1024-thread workgroups,
+// and no room for a 1024-point tile.
+struct WTableArgs {
+    FilterParams pa, pb;
+    int dual;  // 1: also fill the b tables with window pb
+    int nx, ny, nz;
+    double *main_a, *nyq_a, *main_b, *nyq_b;
+};
 
 __global__ void __launch_bounds__(kBlock)
-window_table_kernel(FilterParams p, double dk2, int mmax, double2 *__restrict__ table) {
-    const int m = blockIdx.x * kBlock + threadIdx.x;
-    if (m > mmax) return;
-    const double ksq = (double)m * dk2;
-    const double w0 = window_exact(p, ksq);
-    double slope = 0.;
-    if (m > 0) {
-        const double h = 9.5367431640625e-07;  // 2^-20
-        slope = (window_exact(p, ksq * (1 + h)) - window_exact(p, ksq * (1 - h))) /
-                (2 * h * ksq);
+window_table_kernel(WTableArgs t) {
+    const int nxh = t.nx / 2 + 1, nyh = t.ny / 2 + 1, H = t.nz / 2, H4 = H / 4;
+    const long n4 = (long)nyh * nxh * H4;
+    const long id = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (id < n4) {
+        const int l4 = (int)(id % H4);
+        const long r = id / H4;
+        const int i = (int)(r % nxh), j = (int)(r / nxh);
+        float kx[4], ky[4], kz[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            kx[e] = k_of(i, t.nx, t.pa.dkx);
+            ky[e] = k_of(j, t.ny, t.pa.dky);
+            kz[e] = (float)((double)(4 * l4 + e) * t.pa.dkz);
+        }
+        double wa[4], wb[4];
+        if (t.dual)
+            window_batch_dual<4>(t.pa, t.pb, kx, ky, kz, wa, wb);
+        else
+            window_batch<4>(t.pa, kx, ky, kz, wa);
+        double2 *oa = reinterpret_cast<double2 *>(t.main_a + r * H + 4 * l4);
+        oa[0] = make_double2(wa[0], wa[1]);
+        oa[1] = make_double2(wa[2], wa[3]);
+        if (t.dual) {
+            double2 *ob = reinterpret_cast<double2 *>(t.main_b + r * H + 4 * l4);
+            ob[0] = make_double2(wb[0], wb[1]);
+            ob[1] = make_double2(wb[2], wb[3]);
+        }
+    } else if (id - n4 < (long)nxh * nyh) {
+        const long q = id - n4;
+        const int i = (int)(q / nyh), j = (int)(q % nyh);
+        float kx[1] = {k_of(i, t.nx, t.pa.dkx)}, ky[1] = {k_of(j, t.ny, t.pa.dky)};
+        float kz[1] = {(float)((double)(t.nz / 2) * t.pa.dkz)};
+        double wa[1], wb[1];
+        if (t.dual)
+            window_batch_dual<1>(t.pa, t.pb, kx, ky, kz, wa, wb);
+        else
+            window_batch<1>(t.pa, kx, ky, kz, wa);
+        t.nyq_a[q] = wa[0];
+        if (t.dual) t.nyq_b[q] = wb[0];
     }
-    table[m] = make_double2(w0, slope);
 }
 
 // ------------------------------------------------------------------ pass X / pass Y
-struct LinePassArgs {
-    const float2 *src;
-    float2 *dst;
+// One launch covers up to two GEOMETRIES (the main block [nx][ny][nz/2] and the k_z = nz/2
+// Nyquist plane [nx][ny]) and up to two GRIDS of identical shape (density and emissivity
+// spectra), so a filter radius costs one pass-X and one pass-Y launch, and the window
+// W(kR) -- the same for both grids -- is evaluated once per mode.
+struct LineGeo {
+    const float2 *src[2];  // per grid
+    float2 *dst[2];
     long line_stride;   // elements between successive points of a line
     long outer_stride;  // elements between successive outer indices
     long col_stride;    // elements between adjacent columns of a tile (1 = vector loads)
@@ -390,12 +438,25 @@ struct LinePassArgs {
     int pair_outer;     // 1: a workgroup handles the mirror pair (o, n_outer - o)
     int filter_axis;    // 0: columns are k_z, outer is k_y (main block)
                         // 1: columns are k_y, k_z fixed at nz/2 (Nyquist plane)
-    int n_y, n_z;       // grid dims for the wavenumbers
-    float out_scale;    // applied at store (1 = none)
-    const double2 *wtable;  // FMODE 2: {W, dW/d(k^2)} indexed by nx^2 + ny^2 + nz^2
-    double dk2;             // FMODE 2: (2 pi / L)^2
-    FilterParams fp;
 };
+
+struct LinePassArgs {
+    LineGeo g0, g1;
+    int n_geo;    // 1: g0 only, 2: g0 then g1
+    int g1_strided;  // g1 has col_stride != 1 (y-lines of the Nyquist plane): epilogue tiles
+    int n_grids;  // 1 or 2
+    int n_y, n_z;  // grid dims for the wavenumbers
+    float out_scale;  // applied at store (1 = none)
+    // FMODE 3: window tables of this radius (window_table_kernel), per window
+    const double *wt_main[2];  // [ny/2+1][nx/2+1][nz/2]
+    const double *wt_nyq[2];   // [nx/2+1][ny/2+1]
+    int dual;                  // FMODE 3: grid 1 uses window 1 (else both grids use window 0)
+    FilterParams fp;           // the window of grid 0 (host side: table construction)
+};
+
+static inline int geo_items(const LineGeo &g) {
+    return (g.pair_outer ? (g.n_outer / 2 + 1) : g.n_outer) * g.n_ctiles;
+}
 
 // Tile loader geometry: thread t owns the float4 column pair c4 = t % 8 of the row pairs
 //   row_a = r0 + 32u  in [0, N/2)   and its mirror   row_b = N - row_a  (N/2 when row_a = 0),
@@ -406,51 +467,123 @@ __device__ __forceinline__ int mirror_row(int row_a) {
 }
 
 // Persistent workgroups: each loops over (outer group, column tile) work items with a
-// grid stride.  Within the loop the global loads of the NEXT tile are issued before the
-// LDS transform of the current one, and the window values are computed while the first
-// tile's loads are in flight, so HBM latency hides behind the LDS/ALU phase.
-// THREADS = 512 (one workgroup per CU at N >= 256, 2 waves per SIMD, <= 256 VGPRs) keeps the
-// per-thread working set small enough for the register prefetch of the next tile.
-// FMODE 1 (per-mode window evaluation) runs 1024 threads: half the evaluations per thread
-// and 4 waves per SIMD to hide the fp64 latency of the window math.
+// grid stride; a work item is the group's tiles (mirror pair x grids).  Within the loop the
+// global loads of the NEXT tile are issued before the LDS transform of the current one, and
+// the window values are computed while the first tile's loads are in flight, so HBM latency
+// hides behind the LDS/ALU phase.
+// THREADS = 512 at N >= 128 (one workgroup per CU at N >= 256, 2 waves per SIMD, <= 256
+// VGPRs: room for the two register sets), 1024 at N = 1024 (a 128 KB tile), else 256.
 template <int N, int FMODE = 0>
 struct LineThreads {
-    static constexpr int value = ((FMODE == 1 && N >= 256) || N >= 1024) ? 1024 : ((N >= 128) ? 512 : 256);
+    static constexpr int value = (N >= 1024) ? 1024 : ((N >= 128) ? 512 : 256);
 };
 
-// FMODE: 0 no filter, 1 per-mode window evaluation, 2 window table lookup
+// the geometry of one work item, in wave-uniform registers
+struct LineItem {
+    const float2 *src0, *src1;
+    float2 *dst0, *dst1;
+    long line_stride, outer_stride, col_stride;
+    int n_outer, filter_axis;
+    int og, ct, npair;
+    const double *wt0, *wt1;  // FMODE 3: window tables of this geometry
+};
+
+// FMODE: 0 no window, 3 window streamed from the per-radius tables
 template <int N, int SIGN, int FMODE>
 __global__ void __launch_bounds__((LineThreads<N, FMODE>::value), (LineThreads<N, FMODE>::value / 256))
 line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
-    constexpr bool FILTER = (FMODE == 1);
     static_assert(N >= 64, "tile loader needs N >= 64");
     constexpr int kBlock = LineThreads<N, FMODE>::value;
     constexpr int RSTEP = kBlock / 8;  // rows covered by one sweep of the workgroup
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
     float2 *tw = tile + N * TZ;                          // [N]
-    // FMODE 1: the window values of the current outer group, wlds[|k_x| row 0..N/2][TZ], kept
-    // in LDS between the two members of a mirror pair.  Each thread only ever reads the slots
-    // it wrote, so no barrier is needed; holding them in registers instead spilled to
-    // scratch (visible as +22 % HBM traffic in the PMC counters).
-    double *wlds = reinterpret_cast<double *>(tw + N);
     for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
     const int r0 = threadIdx.x >> 3, c4 = threadIdx.x & 7;
-    const bool vec = (a.col_stride == 1);
-    const int n_groups = a.pair_outer ? (a.n_outer / 2 + 1) : a.n_outer;
-    const int n_work = n_groups * a.n_ctiles;
+    const int n_work0 = (a.g0.pair_outer ? (a.g0.n_outer / 2 + 1) : a.g0.n_outer) * a.g0.n_ctiles;
+    const int n_work1 =
+        (a.n_geo > 1) ? (a.g1.pair_outer ? (a.g1.n_outer / 2 + 1) : a.g1.n_outer) * a.g1.n_ctiles : 0;
+    // A strided g1 is handled after the pipelined loop, whose global loads and stores are all
+    // 16-byte vectors in fixed numbers: mixing the two forms inside the loop made the
+    // compiler wait with vmcnt(0) (i.e. also for the stores just issued) before every tile.
+    const int n_work = n_work0 + (a.g1_strided ? 0 : n_work1);
+
+    // explicit selects (not an indexed kernel-argument array, which would be copied to scratch)
+    auto decode = [&](int w) {
+        LineItem it;
+        const bool s = w >= n_work0;
+        const int ww = s ? w - n_work0 : w;
+        it.src0 = s ? a.g1.src[0] : a.g0.src[0];
+        it.src1 = s ? a.g1.src[1] : a.g0.src[1];
+        it.dst0 = s ? a.g1.dst[0] : a.g0.dst[0];
+        it.dst1 = s ? a.g1.dst[1] : a.g0.dst[1];
+        it.line_stride = s ? a.g1.line_stride : a.g0.line_stride;
+        it.outer_stride = s ? a.g1.outer_stride : a.g0.outer_stride;
+        it.col_stride = s ? a.g1.col_stride : a.g0.col_stride;
+        it.n_outer = s ? a.g1.n_outer : a.g0.n_outer;
+        it.filter_axis = s ? a.g1.filter_axis : a.g0.filter_axis;
+        it.wt0 = (it.filter_axis == 1) ? a.wt_nyq[0] : a.wt_main[0];
+        it.wt1 = (it.filter_axis == 1) ? a.wt_nyq[1] : a.wt_main[1];
+        const int nct = s ? a.g1.n_ctiles : a.g0.n_ctiles;
+        const int po = s ? a.g1.pair_outer : a.g0.pair_outer;
+        it.og = ww / nct;
+        it.ct = ww - it.og * nct;
+        it.npair = (po && it.og != 0 && 2 * it.og != it.n_outer) ? 2 : 1;
+        return it;
+    };
+    // member m of an item: grid = m / npair, mirror index = m % npair
+    auto member_grid = [](const LineItem &it, int m) { return it.npair == 2 ? (m >> 1) : m; };
+    auto member_base = [](const LineItem &it, int m) {
+        const int mi = it.npair == 2 ? (m & 1) : 0;
+        const int outer = mi == 0 ? it.og : it.n_outer - it.og;
+        return (long)outer * it.outer_stride + (long)it.ct * TZ * it.col_stride;
+    };
 
     // Addressing: a wave-uniform 64-bit tile base (SGPRs) plus 32-bit per-thread element
     // offsets.  Rows < N/2 are addressed from the tile base, mirror rows from the row-N/2
     // base, so offsets stay below 2^31 elements even at 1024^3.
-    const unsigned ls = (unsigned)a.line_stride, cs = (unsigned)a.col_stride;
-    const long half_off = (long)(N / 2) * a.line_stride;
-    float4 reg[2 * NP];
-    auto issue_loads = [&](long base) {
-        const float2 *lo = a.src + base;
-        const float2 *hi = lo + half_off;
+    // Two register sets: while tile t is transformed in LDS, the loads of tiles t+1 AND t+2
+    // are in flight (a single set left HBM idle between a tile's arrival and the issue of the
+    // next loads: 4.5 TB/s against the 6.3 TB/s a plain copy reaches).
+    constexpr bool TWO_SETS = (N < 1024);
+    float4 reg_a[2 * NP], reg_b[2 * NP];
+    // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
+    // of the member that starts a new window, `cur` serves the members after it
+    double2 wpre[NP], wcur[NP], wpre_half, wcur_half;
+    auto w_reload = [&](const LineItem &it, int m) {
+        const int mi = it.npair == 2 ? (m & 1) : 0;
+        return m == 0 || (a.dual && mi == 0);
+    };
+    auto issue_wloads = [&](const LineItem &it, int m) {
+        const double *t = (a.dual && member_grid(it, m)) ? it.wt1 : it.wt0;
+        if (it.filter_axis == 0) {
+            const unsigned wc = (unsigned)(a.n_z / 2);
+            const double *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+                wpre[u] = *reinterpret_cast<const double2 *>(b + (unsigned)(r0 + RSTEP * u) * wc);
+            wpre_half = *reinterpret_cast<const double2 *>(b + (unsigned)(N / 2) * wc);
+        } else {
+            const int c0 = it.ct * TZ + 2 * c4;
+            const unsigned nyh = (unsigned)(a.n_y / 2 + 1);
+            const unsigned j0 = (unsigned)min(c0, a.n_y - c0), j1 = (unsigned)min(c0 + 1, a.n_y - c0 - 1);
+#pragma unroll
+            for (int u = 0; u < NP; u++) {
+                const double *r = t + (unsigned)(r0 + RSTEP * u) * nyh;
+                wpre[u] = make_double2(r[j0], r[j1]);
+            }
+            {
+                const double *r = t + (unsigned)(N / 2) * nyh;
+                wpre_half = make_double2(r[j0], r[j1]);
+            }
+        }
+    };
+    auto issue_loads = [&](float4(&reg)[2 * NP], const LineItem &it, int m) {
+        const unsigned ls = (unsigned)it.line_stride;
+        const float2 *lo = (member_grid(it, m) ? it.src1 : it.src0) + member_base(it, m);
+        const float2 *hi = lo + (long)(N / 2) * it.line_stride;
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
@@ -458,156 +591,74 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : (unsigned)(N / 2 - row_a) * ls)
                                           : (unsigned)row_a * ls;
             const float2 *p = (u & 1) ? hi : lo;
-            if (vec) {
-                reg[u] = *reinterpret_cast<const float4 *>(p + (roff + 2u * c4));
-            } else {
-                float2 e0 = p[roff + (unsigned)(2 * c4) * cs];
-                float2 e1 = p[roff + (unsigned)(2 * c4 + 1) * cs];
-                reg[u] = make_float4(e0.x, e0.y, e1.x, e1.y);
-            }
+            reg[u] = *reinterpret_cast<const float4 *>(p + (roff + 2u * c4));
         }
     };
-    auto tile_base = [&](int outer, int ct) {
-        return (long)outer * a.outer_stride + (long)ct * TZ * a.col_stride;
-    };
 
-    int work = blockIdx.x;
-    if (work >= n_work) return;
-    // members of a group: the mirror pair (og, n_outer - og), or a single index
-    int og = work / a.n_ctiles, ct = work % a.n_ctiles;
-    int n_members = (a.pair_outer && og != 0 && 2 * og != a.n_outer) ? 2 : 1;
-    int mi = 0;
-    issue_loads(tile_base(og, ct));
+    // the tile sequence of this workgroup: members of an item, then the next item
+    struct TileRef {
+        LineItem it;
+        int m, work, valid;
+    };
+    auto next_tile = [&](const TileRef &t) {
+        // past the end: valid = 0, but (it, m) keep naming the last tile, so loads issued for
+        // such a reference stay in bounds
+        TileRef n = t;
+        if (!t.valid) return n;
+        if (t.m + 1 < t.it.npair * a.n_grids) {
+            n.m = t.m + 1;
+        } else {
+            n.work = t.work + (int)gridDim.x;
+            n.valid = n.work < n_work;
+            if (n.valid) {
+                n.m = 0;
+                n.it = decode(n.work);
+            }
+        }
+        return n;
+    };
 
     bool first = true;
-    while (true) {
-        if (FILTER && mi == 0) {
-            // window values of this thread's row pairs x 2 columns, once per group
-            const int col0 = ct * TZ + 2 * c4;
-            float ky[2], kz[2];
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                if (a.filter_axis == 0) {
-                    ky[e] = k_of(og, a.n_y, a.fp.dky);
-                    kz[e] = (float)((double)(col0 + e) * a.fp.dkz);
-                } else {
-                    ky[e] = k_of(col0 + e, a.n_y, a.fp.dky);
-                    kz[e] = (float)((double)(a.n_z / 2) * a.fp.dkz);
-                }
-            }
-            {
-                float kxs[2 * NP], kys[2 * NP], kzs[2 * NP];
-                double ws[2 * NP];
-#pragma unroll
-                for (int u = 0; u < NP; u++) {
-                    const float kx = k_of(r0 + RSTEP * u, N, a.fp.dkx);
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        kxs[2 * u + e] = kx;
-                        kys[2 * u + e] = ky[e];
-                        kzs[2 * u + e] = kz[e];
-                    }
-                }
-                window_batch<2 * NP>(a.fp, kxs, kys, kzs, ws);
-#pragma unroll
-                for (int u = 0; u < NP; u++)
-                    *reinterpret_cast<double2 *>(wlds + (r0 + RSTEP * u) * TZ + 2 * c4) =
-                        make_double2(ws[2 * u], ws[2 * u + 1]);
-                if (r0 == 0) {  // row N/2 (paired with row 0) has its own |k_x|: lanes 0-7 of wave 0
-                    const float kxh = k_of(N / 2, N, a.fp.dkx);
-                    float kx2[2] = {kxh, kxh};
-                    double wh[2];
-                    window_batch<2>(a.fp, kx2, ky, kz, wh);
-                    *reinterpret_cast<double2 *>(wlds + (N / 2) * TZ + 2 * c4) =
-                        make_double2(wh[0], wh[1]);
-                }
-            }
-        }
-        const long base = tile_base(mi == 0 ? og : a.n_outer - og, ct);
+    // One tile: registers (x window) -> LDS, refill the register set with tile `refill`,
+    // transform, store.  `nxt` is the tile after `cur` (its window loads are issued here).
+    auto process = [&](float4(&reg)[2 * NP], const TileRef &cur, const TileRef &nxt,
+                       const TileRef &refill) {
+        const LineItem &it = cur.it;
+        const int m = cur.m;
+        // store target of the tile now in registers
+        float2 *const st_lo = (member_grid(it, m) ? it.dst1 : it.dst0) + member_base(it, m);
+        const long st_half = (long)(N / 2) * it.line_stride;
+        const unsigned st_ls = (unsigned)it.line_stride;
         if (!first) __syncthreads();  // the previous tile's LDS reads are done
         first = false;
-        if (FMODE == 2) {
-            // table lookup: one {W, slope} fetch per (row pair, column), shared by the mirror row
-            const int col0 = ct * TZ + 2 * c4;
-            const int outer = (mi == 0) ? og : a.n_outer - og;
-            int nya[2], nza[2];
-            float kyf[2], kzf[2];
+        if (FMODE == 3 && w_reload(it, m)) {
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                if (a.filter_axis == 0) {
-                    nya[e] = min(outer, a.n_y - outer);
-                    nza[e] = col0 + e;
-                } else {
-                    nya[e] = min(col0 + e, a.n_y - (col0 + e));
-                    nza[e] = a.n_z / 2;
-                }
-                kyf[e] = (float)((double)nya[e] * a.fp.dky);
-                kzf[e] = (float)((double)nza[e] * a.fp.dkz);
-            }
-            auto lookup = [&](int nxa, int e) {
-                const float kxf = (float)((double)nxa * a.fp.dkx);
-                const float ksq = __fadd_rn(__fadd_rn(__fmul_rn(kxf, kxf), __fmul_rn(kyf[e], kyf[e])),
-                                            __fmul_rn(kzf[e], kzf[e]));
-                const int m = nxa * nxa + nya[e] * nya[e] + nza[e] * nza[e];
-                const double2 t = a.wtable[m];
-                return fma(t.y, (double)ksq - (double)m * a.dk2, t.x);
-            };
-#pragma unroll
-            for (int up = 0; up < NP; up++) {
-                const int row_a = r0 + RSTEP * up;
-                const double w0 = lookup(row_a, 0), w1 = lookup(row_a, 1);
-                double h0 = w0, h1 = w1;
-                if (row_a == 0) {  // the mirror of row 0 is row N/2 with its own |k_x|
-                    h0 = lookup(N / 2, 0);
-                    h1 = lookup(N / 2, 1);
-                }
-                float4 v = reg[2 * up];
-                v.x = (float)((double)v.x * w0);
-                v.y = (float)((double)v.y * w0);
-                v.z = (float)((double)v.z * w1);
-                v.w = (float)((double)v.w * w1);
-                *reinterpret_cast<float4 *>(tile + row_a * TZ + 2 * c4) = v;
-                v = reg[2 * up + 1];
-                v.x = (float)((double)v.x * h0);
-                v.y = (float)((double)v.y * h0);
-                v.z = (float)((double)v.z * h1);
-                v.w = (float)((double)v.w * h1);
-                *reinterpret_cast<float4 *>(tile + mirror_row<N>(row_a) * TZ + 2 * c4) = v;
-            }
-        } else {
+            for (int u = 0; u < NP; u++) wcur[u] = wpre[u];
+            wcur_half = wpre_half;
+        }
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
             const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
+            const bool half = (u & 1) && row_a == 0;  // row N/2 has its own |k_x|
             float4 v = reg[u];
-            if (FILTER) {
-                const bool half = (u & 1) && row_a == 0;  // row N/2 has its own |k_x|
-                const double2 wv =
-                    *reinterpret_cast<const double2 *>(wlds + (half ? N / 2 : row_a) * TZ + 2 * c4);
-                const double w0 = wv.x, w1 = wv.y;
-                v.x = (float)((double)v.x * w0);
-                v.y = (float)((double)v.y * w0);
-                v.z = (float)((double)v.z * w1);
-                v.w = (float)((double)v.w * w1);
+            if (FMODE == 3) {
+                const double2 wv = half ? wcur_half : wcur[u >> 1];
+                v.x = (float)((double)v.x * wv.x);
+                v.y = (float)((double)v.y * wv.x);
+                v.z = (float)((double)v.z * wv.y);
+                v.w = (float)((double)v.w * wv.y);
             }
             *reinterpret_cast<float4 *>(tile + row * TZ + 2 * c4) = v;
         }
-        }
         __syncthreads();
-        // ---- advance to the next tile and put its loads in flight
-        int n_og = og, n_ct = ct, n_mi = mi + 1, n_nm = n_members;
-        bool more = true;
-        if (n_mi >= n_members) {
-            work += gridDim.x;
-            more = work < n_work;
-            if (more) {
-                n_og = work / a.n_ctiles;
-                n_ct = work % a.n_ctiles;
-                n_nm = (a.pair_outer && n_og != 0 && 2 * n_og != a.n_outer) ? 2 : 1;
-                n_mi = 0;
-            }
-        }
-        if (more) issue_loads(tile_base(n_mi == 0 ? n_og : a.n_outer - n_og, n_ct));
+        // ---- the register set is free: put the loads of the tile after next in flight
+        // (unconditionally -- past the end of the sequence the last tile is simply read
+        // again -- so that the number of loads in flight is static and the compiler can wait
+        // with vmcnt(n > 0) for exactly this register set instead of draining everything)
+        // (a TileRef past the end still names the last tile, see next_tile)
+        if (FMODE == 3 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
+        issue_loads(reg, refill.it, refill.m);
 
         fft_tile<N, TZ, TZ, SIGN, kBlock>(tile, tw);
         // ---- store
@@ -622,21 +673,86 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 v.z *= a.out_scale;
                 v.w *= a.out_scale;
             }
-            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : (unsigned)(N / 2 - row_a) * ls)
-                                          : (unsigned)row_a * ls;
-            float2 *p = a.dst + base + ((u & 1) ? half_off : 0);
-            if (vec) {
-                *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
-            } else {
-                p[roff + (unsigned)(2 * c4) * cs] = make_float2(v.x, v.y);
-                p[roff + (unsigned)(2 * c4 + 1) * cs] = make_float2(v.z, v.w);
+            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : (unsigned)(N / 2 - row_a) * st_ls)
+                                          : (unsigned)row_a * st_ls;
+            float2 *p = st_lo + ((u & 1) ? st_half : 0);
+            *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
+        }
+    };
+
+    if ((int)blockIdx.x < n_work) {
+        TileRef ta;
+        ta.work = blockIdx.x;
+        ta.valid = 1;
+        ta.m = 0;
+        ta.it = decode(ta.work);
+        if (FMODE == 3) issue_wloads(ta.it, 0);
+        issue_loads(reg_a, ta.it, 0);
+        TileRef tb = next_tile(ta);
+        if (!TWO_SETS) {  // 1024-point lines: registers for one set only
+            while (true) {
+                process(reg_a, ta, tb, tb);
+                if (!tb.valid) break;
+                ta = tb;
+                tb = next_tile(ta);
+            }
+            goto main_done;
+        }
+        issue_loads(reg_b, tb.it, tb.m);
+        // The first tile is peeled so that at the loop head the memory operations in flight
+        // are the same on entry and on the back edge (the other set's 8 loads + 8 stores): the
+        // compiler then waits with the exact vmcnt for one register set, never for the stores.
+        TileRef tc = next_tile(tb);
+        process(reg_a, ta, tb, tc);
+        while (tb.valid) {
+            const TileRef td = next_tile(tc);
+            process(reg_b, tb, tc, td);
+            if (!tc.valid) break;
+            const TileRef te = next_tile(td);
+            process(reg_a, tc, td, te);
+            tb = td;
+            tc = te;
+        }
+    }
+main_done:
+    if (!(a.n_geo > 1 && a.g1_strided)) return;
+    // ---- epilogue: the strided tiles of g1 (no window, not pipelined: 2 * nx/16 tiles in
+    // all), taken by the workgroups at the end of the grid, which have the fewest main items
+    for (int w = (int)(gridDim.x - 1 - blockIdx.x); w < n_work1; w += (int)gridDim.x) {
+        const unsigned ls = (unsigned)a.g1.line_stride, cs = (unsigned)a.g1.col_stride;
+        const int nct = a.g1.n_ctiles;
+        const int og = w / nct, ct = w - og * nct;
+        const long base = (long)og * a.g1.outer_stride + (long)ct * TZ * a.g1.col_stride;
+        for (int g = 0; g < a.n_grids; g++) {
+            const float2 *src = (g ? a.g1.src[1] : a.g1.src[0]) + base;
+            float2 *dst = (g ? a.g1.dst[1] : a.g1.dst[0]) + base;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2 * NP; u++) {
+                const int row_a = r0 + RSTEP * (u >> 1);
+                const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
+                const float2 e0 = src[(unsigned)row * ls + (unsigned)(2 * c4) * cs];
+                const float2 e1 = src[(unsigned)row * ls + (unsigned)(2 * c4 + 1) * cs];
+                *reinterpret_cast<float4 *>(tile + row * TZ + 2 * c4) =
+                    make_float4(e0.x, e0.y, e1.x, e1.y);
+            }
+            __syncthreads();
+            fft_tile<N, TZ, TZ, SIGN, kBlock>(tile, tw);
+#pragma unroll
+            for (int u = 0; u < 2 * NP; u++) {
+                const int row_a = r0 + RSTEP * (u >> 1);
+                const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
+                float4 v = *reinterpret_cast<const float4 *>(tile + row * TZ + 2 * c4);
+                if (a.out_scale != 1.0f) {
+                    v.x *= a.out_scale;
+                    v.y *= a.out_scale;
+                    v.z *= a.out_scale;
+                    v.w *= a.out_scale;
+                }
+                dst[(unsigned)row * ls + (unsigned)(2 * c4) * cs] = make_float2(v.x, v.y);
+                dst[(unsigned)row * ls + (unsigned)(2 * c4 + 1) * cs] = make_float2(v.z, v.w);
             }
         }
-        if (!more) break;
-        og = n_og;
-        ct = n_ct;
-        mi = n_mi;
-        n_members = n_nm;
     }
 }
 
@@ -960,16 +1076,51 @@ const float2 *twiddles(int n) {
 
 bool pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
-bool window_table_enabled() {
-    static int cached = -1;
-    if (cached < 0) {
-        const char *e = getenv("C21CM_WINDOW");
-        // Default: per-mode evaluation.  C21CM_WINDOW=table selects the 1-D table; measured
-        // on MI355X at 512^3 it is SLOWER (422 vs 365 us per pass): 16 scattered 16-byte
-        // gathers per thread and tile bottleneck the vector L1 at one line per clock.
-        cached = (e && e[0] == 't') ? 1 : 0;
-    }
-    return cached == 1;
+// The four line geometries of the split layout; `main` points at the [nx][ny][H] block of a
+// grid (its Nyquist plane follows at main + nx*ny*H).  src/dst of grid g go to slot g.
+void geo_ptrs(LineGeo &g, int grid, const float2 *src, float2 *dst) {
+    g.src[grid] = src;
+    g.dst[grid] = dst;
+}
+LineGeo geo_x_main(int ny, int H) {  // lines along x, outer = k_y (mirror-paired), columns = k_z
+    LineGeo g{};
+    g.line_stride = (long)ny * H;
+    g.outer_stride = H;
+    g.col_stride = 1;
+    g.n_outer = ny;
+    g.n_ctiles = H / TZ;
+    g.pair_outer = 1;
+    g.filter_axis = 0;
+    return g;
+}
+LineGeo geo_x_nyq(int ny) {  // Nyquist plane [nx][ny]: lines along x, columns = k_y
+    LineGeo g{};
+    g.line_stride = ny;
+    g.outer_stride = 0;
+    g.col_stride = 1;
+    g.n_outer = 1;
+    g.n_ctiles = ny / TZ;
+    g.pair_outer = 0;
+    g.filter_axis = 1;
+    return g;
+}
+LineGeo geo_y_main(int nx, int ny, int H) {  // lines along y, outer = x, columns = k_z
+    LineGeo g{};
+    g.line_stride = H;
+    g.outer_stride = (long)ny * H;
+    g.col_stride = 1;
+    g.n_outer = nx;
+    g.n_ctiles = H / TZ;
+    return g;
+}
+LineGeo geo_y_nyq(int nx, int ny) {  // Nyquist plane: lines along y contiguous, columns = x
+    LineGeo g{};
+    g.line_stride = 1;
+    g.outer_stride = 0;
+    g.col_stride = ny;
+    g.n_outer = 1;
+    g.n_ctiles = nx / TZ;
+    return g;
 }
 
 template <int N, int SIGN, int FMODE>
@@ -979,10 +1130,8 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
         return C21CM_MEMORY_ALLOC_ERROR;
     }
-    const size_t lds = sizeof(float2) * ((size_t)N * TZ + N) +
-                       (FMODE == 1 ? sizeof(double) * (size_t)(N / 2 + 1) * TZ : 0);
-    const int groups = a.pair_outer ? (a.n_outer / 2 + 1) : a.n_outer;
-    const int n_work = groups * a.n_ctiles;
+    const size_t lds = sizeof(float2) * ((size_t)N * TZ + N);
+    const int n_work = geo_items(a.g0) + (a.n_geo > 1 ? geo_items(a.g1) : 0);
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
     int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
     const int by_waves = (LineThreads<N, FMODE>::value >= 512) ? 1 : 2;
@@ -1003,8 +1152,7 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
 
 template <int N, int SIGN>
 int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
-    if (fmode == 2) return launch_line_pass_mode<N, SIGN, 2>(a, stream);
-    if (fmode == 1) return launch_line_pass_mode<N, SIGN, 1>(a, stream);
+    if (SIGN > 0 && fmode == 3) return launch_line_pass_mode<N, +1, 3>(a, stream);
     return launch_line_pass_mode<N, SIGN, 0>(a, stream);
 }
 
@@ -1179,99 +1327,115 @@ extern "C" int c21hip_padded_to_split(const float *padded_c, float *split, int n
     return 0;
 }
 
-// [W(kR) x] pass X (src -> work) and pass Y (work, in place) of the inverse transform of a
-// split spectrum.  src == work is allowed.
-extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work, int nx, int ny,
-                                      int nz, double box_len, double box_len_z, int filter_type,
-                                      float R, float R_param, int apply, void *stream_) {
+// [W(kR) x] pass X (src -> work) and pass Y (work, in place) of the inverse transform of one
+// or two split spectra.  src == work is allowed.  Grid g is filtered with window
+// (filter_type[g], R, R_param[g]).
+static int filter_xy(const float *const split_src[2], float *const split_work[2], int n_grids,
+                     int nx, int ny, int nz, double box_len, double box_len_z,
+                     const int filter_type[2], float R, const float R_param[2], int apply,
+                     void *stream_, int phases = 7) {
+    // phases: 1 window table, 2 pass X, 4 pass Y (the timing hook runs them one at a time)
     if (!c21hip_native_fft_supported(nx, ny, nz)) {
         c21hip_set_error("native FFT does not support %dx%dx%d", nx, ny, nz);
         return C21CM_VALUE_ERROR;
     }
-    if (apply && (filter_type < 0 || filter_type > 4)) {
-        c21hip_set_error("filter type %d is not implemented on the device", filter_type);
-        return C21CM_VALUE_ERROR;
-    }
+    for (int g = 0; g < n_grids; g++)
+        if (apply && (filter_type[g] < 0 || filter_type[g] > 4)) {
+            c21hip_set_error("filter type %d is not implemented on the device", filter_type[g]);
+            return C21CM_VALUE_ERROR;
+        }
     hipStream_t stream = (hipStream_t)stream_;
     const int H = nz / 2;
     const long nlines = (long)nx * ny;
-    const float2 *src_main = reinterpret_cast<const float2 *>(split_src);
-    const float2 *src_nyq = src_main + nlines * H;
-    float2 *w_main = reinterpret_cast<float2 *>(split_work);
-    float2 *w_nyq = w_main + nlines * H;
+    // the window's parameters beyond (type, R): R_param matters for types 3 and 4 only
+    const bool dual = apply && n_grids == 2 &&
+                      (filter_type[0] != filter_type[1] ||
+                       ((filter_type[0] == 3 || filter_type[0] == 4) && R_param[0] != R_param[1]));
     int st;
-
     LinePassArgs a{};
-    fill_filter(a.fp, apply ? filter_type : -1, R, R_param, box_len, box_len_z);
+    fill_filter(a.fp, apply ? filter_type[0] : -1, R, R_param[0], box_len, box_len_z);
     a.n_y = ny;
     a.n_z = nz;
     a.out_scale = 1.0f;
-    int fmode = apply ? 1 : 0;
-    if (apply && nx >= 1024) {
-        // a 1024-point x-line tile (128 KB) leaves no LDS for the window slice: filter in a
-        // separate sweep, then run the passes unfused
-        int fst = c21hip_copy_filter_split(split_src, split_work, nx, ny, nz, box_len, box_len_z,
-                                           filter_type, R, R_param, stream_);
-        if (fst) return fst;
-        src_main = reinterpret_cast<const float2 *>(split_work);
-        src_nyq = src_main + nlines * H;
-        fmode = 0;
+    const int fmode = apply ? 3 : 0;
+    if (fmode == 3) {
+        const size_t n_main = (size_t)(ny / 2 + 1) * (nx / 2 + 1) * H;
+        const size_t n_nyq = (size_t)(nx / 2 + 1) * (ny / 2 + 1);
+        const size_t per = (n_main + n_nyq + 1) & ~(size_t)1;  // keep table b 16-byte aligned
+        double *tab = (double *)c21hip_ws(49, sizeof(double) * per * (dual ? 2 : 1));
+        if (!tab) return C21CM_MEMORY_ALLOC_ERROR;
+        WTableArgs t{};
+        t.pa = a.fp;
+        t.dual = dual ? 1 : 0;
+        if (dual) fill_filter(t.pb, filter_type[1], R, R_param[1], box_len, box_len_z);
+        t.nx = nx;
+        t.ny = ny;
+        t.nz = nz;
+        t.main_a = tab;
+        t.nyq_a = tab + n_main;
+        t.main_b = dual ? tab + per : tab;
+        t.nyq_b = t.main_b + n_main;
+        const size_t n_threads = n_main / 4 + n_nyq;
+        if (phases & 1) {
+            hipLaunchKernelGGL(window_table_kernel,
+                               dim3((unsigned)((n_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                               stream, t);
+            LAUNCH_CHECK();
+        }
+        a.wt_main[0] = t.main_a;
+        a.wt_nyq[0] = t.nyq_a;
+        a.wt_main[1] = t.main_b;
+        a.wt_nyq[1] = t.nyq_b;
+        a.dual = t.dual;
     }
-    if (apply && fmode == 1 && window_table_enabled() && nx == ny && ny == nz && box_len == box_len_z &&
-        (filter_type == 0 || filter_type == 3 || filter_type == 4)) {
-        const int mmax = 3 * (nx / 2) * (nx / 2);
-        double2 *table = (double2 *)c21hip_ws(49, sizeof(double2) * (size_t)(mmax + 1));
-        if (!table) return C21CM_MEMORY_ALLOC_ERROR;
-        a.dk2 = a.fp.dkx * a.fp.dkx;
-        hipLaunchKernelGGL(window_table_kernel, dim3((unsigned)((mmax + kBlock) / kBlock)),
-                           dim3(kBlock), 0, stream, a.fp, a.dk2, mmax, table);
-        LAUNCH_CHECK();
-        a.wtable = table;
-        fmode = 2;
+    // ---- pass X: main block + Nyquist plane (x grids) in one launch
+    a.n_geo = 2;
+    a.n_grids = n_grids;
+    a.g0 = geo_x_main(ny, H);
+    a.g1 = geo_x_nyq(ny);
+    for (int g = 0; g < n_grids; g++) {
+        const float2 *src = reinterpret_cast<const float2 *>(split_src[g]);
+        float2 *work = reinterpret_cast<float2 *>(split_work[g]);
+        geo_ptrs(a.g0, g, src, work);
+        geo_ptrs(a.g1, g, src + nlines * H, work + nlines * H);
     }
-    // ---- pass X, main block: lines along x, outer = k_y, columns = k_z
-    a.src = src_main;
-    a.dst = w_main;
-    a.line_stride = (long)ny * H;
-    a.outer_stride = H;
-    a.col_stride = 1;
-    a.n_outer = ny;
-    a.n_ctiles = H / TZ;
-    a.pair_outer = 1;
-    a.filter_axis = 0;
-    if ((st = dispatch_line_pass<+1>(nx, a, fmode, stream))) return st;
-    // ---- pass X, Nyquist plane [nx][ny]: columns = k_y
-    a.src = src_nyq;
-    a.dst = w_nyq;
-    a.line_stride = ny;
-    a.outer_stride = 0;
-    a.col_stride = 1;
-    a.n_outer = 1;
-    a.n_ctiles = ny / TZ;
-    a.pair_outer = 0;
-    a.filter_axis = 1;
-    if ((st = dispatch_line_pass<+1>(nx, a, fmode, stream))) return st;
-    // ---- pass Y, main block (in place): lines along y, outer = x, columns = k_z
+    if ((phases & 2) && (st = dispatch_line_pass<+1>(nx, a, fmode, stream))) return st;
+    if (!(phases & 4)) return 0;
+    // ---- pass Y (in place)
     a.fp.type = -1;
-    a.src = w_main;
-    a.dst = w_main;
-    a.line_stride = H;
-    a.outer_stride = (long)ny * H;
-    a.col_stride = 1;
-    a.n_outer = nx;
-    a.n_ctiles = H / TZ;
-    a.pair_outer = 0;
-    a.filter_axis = 0;
-    if ((st = dispatch_line_pass<+1>(ny, a, 0, stream))) return st;
-    // ---- pass Y, Nyquist plane: lines along y are contiguous, columns = x (stride ny)
-    a.src = w_nyq;
-    a.dst = w_nyq;
-    a.line_stride = 1;
-    a.outer_stride = 0;
-    a.col_stride = ny;
-    a.n_outer = 1;
-    a.n_ctiles = nx / TZ;
+    a.g0 = geo_y_main(nx, ny, H);
+    a.g1 = geo_y_nyq(nx, ny);
+    a.g1_strided = 1;
+    for (int g = 0; g < n_grids; g++) {
+        float2 *work = reinterpret_cast<float2 *>(split_work[g]);
+        geo_ptrs(a.g0, g, work, work);
+        geo_ptrs(a.g1, g, work + nlines * H, work + nlines * H);
+    }
     return dispatch_line_pass<+1>(ny, a, 0, stream);
+}
+
+extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work, int nx, int ny,
+                                      int nz, double box_len, double box_len_z, int filter_type,
+                                      float R, float R_param, int apply, void *stream_) {
+    const float *src[2] = {split_src, nullptr};
+    float *work[2] = {split_work, nullptr};
+    const int ft[2] = {filter_type, 0};
+    const float rp[2] = {R_param, 0.f};
+    return filter_xy(src, work, 1, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_);
+}
+
+// Two grids of the same shape in one sweep (the density and emissivity spectra of the
+// excursion-set loop), each with its own window of the same radius.
+extern "C" int c21hip_split_filter_xy2(const float *src_a, float *work_a, int filter_a,
+                                       float R_param_a, const float *src_b, float *work_b,
+                                       int filter_b, float R_param_b, int nx, int ny, int nz,
+                                       double box_len, double box_len_z, float R, int apply,
+                                       void *stream_) {
+    const float *src[2] = {src_a, src_b};
+    float *work[2] = {work_a, work_b};
+    const int ft[2] = {filter_a, filter_b};
+    const float rp[2] = {R_param_a, R_param_b};
+    return filter_xy(src, work, 2, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_);
 }
 
 // Forward transform into the split layout: real rows (in_zstride floats, scale-and-clip on
@@ -1304,41 +1468,22 @@ extern "C" int c21hip_split_r2c(const float *real_in, long in_zstride, float *sp
     a.n_y = ny;
     a.n_z = nz;
     a.out_scale = 1.0f;
+    a.n_geo = 2;
+    a.n_grids = 1;
     // pass Y, main block and Nyquist plane
-    a.src = o_main;
-    a.dst = o_main;
-    a.line_stride = H;
-    a.outer_stride = (long)ny * H;
-    a.col_stride = 1;
-    a.n_outer = nx;
-    a.n_ctiles = H / TZ;
-    if ((st = dispatch_line_pass<-1>(ny, a, 0, stream))) return st;
-    a.src = o_nyq;
-    a.dst = o_nyq;
-    a.line_stride = 1;
-    a.outer_stride = 0;
-    a.col_stride = ny;
-    a.n_outer = 1;
-    a.n_ctiles = nx / TZ;
+    a.g0 = geo_y_main(nx, ny, H);
+    a.g1 = geo_y_nyq(nx, ny);
+    a.g1_strided = 1;
+    geo_ptrs(a.g0, 0, o_main, o_main);
+    geo_ptrs(a.g1, 0, o_nyq, o_nyq);
     if ((st = dispatch_line_pass<-1>(ny, a, 0, stream))) return st;
     // pass X with the normalisation folded into its store
     a.out_scale = out_scale;
-    a.src = o_main;
-    a.dst = o_main;
-    a.line_stride = (long)ny * H;
-    a.outer_stride = H;
-    a.col_stride = 1;
-    a.n_outer = ny;
-    a.n_ctiles = H / TZ;
-    a.pair_outer = 1;
-    if ((st = dispatch_line_pass<-1>(nx, a, 0, stream))) return st;
-    a.src = o_nyq;
-    a.dst = o_nyq;
-    a.line_stride = ny;
-    a.outer_stride = 0;
-    a.n_outer = 1;
-    a.n_ctiles = ny / TZ;
-    a.pair_outer = 0;
+    a.g0 = geo_x_main(ny, H);
+    a.g1 = geo_x_nyq(ny);
+    a.g1_strided = 0;
+    geo_ptrs(a.g0, 0, o_main, o_main);
+    geo_ptrs(a.g1, 0, o_nyq, o_nyq);
     return dispatch_line_pass<-1>(nx, a, 0, stream);
 }
 
@@ -1407,54 +1552,48 @@ pattern_fill_kernel(float *__restrict__ buf, size_t n) {
     }
 }
 
-// kind: 0 pass X main block (filter_type >= 0: fused window), 1 pass Y main block,
-//       2 fused pass Z + barrier (two grids), 3 plain pass Z
-extern "C" int c21hip_bench_pass(int kind, int n, int filter_type, float R, float R_param,
-                                 double box_len, int reps, void *stream_, float *ms_out) {
+// kind: 0 pass X and 1 pass Y exactly as the excursion-set loop launches them (two grids,
+//       main block + Nyquist plane; pass X streams the window tables of filter_a / filter_b),
+//       2 fused pass Z + barrier (two grids), 3 plain pass Z (one grid),
+//       4 the window-table kernel of one radius (both windows)
+extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, float R,
+                                 float R_param_b, double box_len, int reps, void *stream_,
+                                 float *ms_out) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!c21hip_native_fft_supported(n, n, n)) return C21CM_VALUE_ERROR;
     const size_t nf = c21hip_split_floats(n, n, n);
     float *a = (float *)c21hip_ws(58, nf * sizeof(float));
     float *b = (float *)c21hip_ws(59, nf * sizeof(float));
-    float *real = (float *)c21hip_ws(60, (size_t)n * n * (n + 2) * sizeof(float));
+    float *real = (float *)c21hip_ws(60, nf * sizeof(float));
+    float *real2 = (float *)c21hip_ws(63, nf * sizeof(float));
     unsigned char *mask = (unsigned char *)c21hip_ws(61, (size_t)n * n * n);
     double *partials = (double *)c21hip_ws(62, ((size_t)n * n / 4 + 64) * sizeof(double));
-    if (!a || !b || !real || !mask || !partials) return C21CM_MEMORY_ALLOC_ERROR;
+    if (!a || !b || !real || !real2 || !mask || !partials) return C21CM_MEMORY_ALLOC_ERROR;
     hipLaunchKernelGGL(pattern_fill_kernel, dim3(2048), dim3(kBlock), 0, stream, a, nf);
     hipLaunchKernelGGL(pattern_fill_kernel, dim3(2048), dim3(kBlock), 0, stream, b, nf);
     (void)hipMemsetAsync(mask, 0, (size_t)n * n * n, stream);
     const int H = n / 2;
     const long nlines = (long)n * n;
-    LinePassArgs la{};
-    fill_filter(la.fp, filter_type, R, R_param, box_len, box_len);
-    la.n_y = n;
-    la.n_z = n;
-    la.out_scale = 1.0f;
-    la.src = reinterpret_cast<const float2 *>(a);
-    la.dst = reinterpret_cast<float2 *>(b);
-    la.col_stride = 1;
-    la.n_ctiles = H / TZ;
-    la.n_outer = n;
-    if (kind == 0) {
-        la.line_stride = (long)n * H;
-        la.outer_stride = H;
-        la.pair_outer = 1;
-    } else {
-        la.src = la.dst;
-        la.line_stride = H;
-        la.outer_stride = (long)n * H;
-        la.pair_outer = 0;
-    }
+    const float *src[2] = {a, b};
+    float *work[2] = {real, real2};
+    const int ft[2] = {filter_a, filter_b};
+    const float rp[2] = {0.f, R_param_b};
+    int st = 0;
+    if (kind == 0)  // tables for pass X
+        st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 1);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         return C21CM_IO_ERROR;
-    int st = 0;
     for (int r = -2; r < reps && !st; r++) {  // two warm-up launches
         if (r == 0) (void)hipEventRecord(e0, stream);
         if (kind == 0)
-            st = dispatch_line_pass<+1>(n, la, filter_type >= 0 ? 1 : 0, stream);
+            st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 2);
         else if (kind == 1)
-            st = dispatch_line_pass<+1>(n, la, 0, stream);
+            st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 4);
+        else if (kind == 4)
+            st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 1);
+        else if (kind == 5)  // pass X without a window (diagnostic)
+            st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 0, stream_, 2);
         else if (kind == 2)
             st = c21hip_split_z_ionise_stars(a, b, mask, partials, partials + nlines / LZ_FUSED + 40,
                                              n, n, n, 5, 6.2e9, 1.0, 1, 1e-9, stream);

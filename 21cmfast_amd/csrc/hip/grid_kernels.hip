@@ -279,18 +279,6 @@ extern "C" int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int 
                             R_param, apply, stream);
 }
 
-// Same sweep on the split k-space layout (main block [nx][ny][nz/2] + Nyquist plane).
-extern "C" int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny,
-                                        int nz, double box_len, double box_len_z, int filter_type,
-                                        float R, float R_param, void *stream) {
-    const size_t main_floats = 2 * (size_t)nx * ny * (size_t)(nz / 2);
-    int st = copy_filter_impl(src_split, dst_split, nx, ny, nz / 2, 0, box_len, box_len_z,
-                              filter_type, R, R_param, 1, stream);
-    if (st) return st;
-    return copy_filter_impl(src_split + main_floats, dst_split + main_floats, nx, ny, 1, nz / 2,
-                            box_len, box_len_z, filter_type, R, R_param, 1, stream);
-}
-
 static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, int nzc, int nz0,
                             double box_len, double box_len_z, int filter_type, float R,
                             float R_param, int apply, void *stream) {

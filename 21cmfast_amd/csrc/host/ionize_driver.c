@@ -379,11 +379,9 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross) {
     fill_args(&args, s, R_ct);
 
     if (c->fused && first_cross && R_ct > 0) {
-        TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
-                                   s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
-        TRY(c21hip_split_filter_xy(c->stars_unf, c->stars_work, c->nx, c->ny, c->nz, s->box_len,
-                                   s->box_len_z, s->stars_filter, R, (float)s->mfp_meandens,
-                                   apply, c->stream));
+        TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->stars_unf,
+                                    c->stars_work, s->stars_filter, (float)s->mfp_meandens, c->nx,
+                                    c->ny, c->nz, s->box_len, s->box_len_z, R, apply, c->stream));
         TRY(c21hip_split_z_ionise_stars(c->delta_work, c->stars_work, first_cross, partials,
                                         sum_dev, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
                                         s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,

@@ -98,35 +98,38 @@ def cpu_baseline(args, W):
 
 
 PASS_KERNELS = {
-    0: "line_pass_kernel<512,+1,1>  (pass X: x-lines, fused W(kR) window, 1 grid)",
-    1: "line_pass_kernel<512,+1,0>  (pass Y: y-lines, 1 grid)",
+    0: "line_pass_kernel<512,+1,3>  (pass X: x-lines of both grids x streamed W(kR) tables)",
+    1: "line_pass_kernel<512,+1,0>  (pass Y: y-lines of both grids)",
     2: "z_c2r_ionise_kernel<512>    (pass Z of both grids + f_coll sum + barrier)",
+    4: "window_table_kernel         (W(kR) of one radius for both windows; fp64 ALU bound)",
 }
 
 
 def kernel_roofline(args, spec, torch):
     """Live HIP-event timing of each hand-written pass kernel of the R loop, on torch's current
     stream (the stream every kernel of the step is launched on), with its ALGORITHMIC bytes:
-      pass X / pass Y  read + write of one split k-space grid         2 * S
+      pass X / pass Y  read + write of both split k-space grids       2 * 2 * S
       fused pass Z     read of both grids + uint8 mask read + write   2 * S + 2 * N
-    S = 8 * (N/2 + nx*ny) bytes (split layout), N = cells."""
+    S = 8 * (N/2 + nx*ny) bytes (split layout), N = cells.  The window tables pass X also
+    reads (2 x 8 (n/2+1)^3 bytes) are overhead, not algorithmic bytes."""
     import ctypes as C
 
     n = args.hii_dim
     lib = importlib.import_module("21cmfast_amd").load()
     lib.c21hip_bench_pass.restype = C.c_int
-    lib.c21hip_bench_pass.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double,
-                                      C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    lib.c21hip_bench_pass.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     N = float(n) ** 3
     S = 8.0 * (N / 2 + n * n)
-    alg = {0: 2 * S, 1: 2 * S, 2: 2 * S + 2 * N}
+    alg = {0: 4 * S, 1: 4 * S, 2: 2 * S + 2 * N, 4: 0.0}
     R_mid = spec.R[spec.n_radii // 2]
     out = {}
-    for kind in (0, 1, 2):
+    for kind in (0, 1, 2, 4):
         ms = C.c_float()
-        st = lib.c21hip_bench_pass(kind, n, 0 if kind == 0 else -1, R_mid, 0.0, spec.box_len, 20,
-                                   stream, C.byref(ms))
+        st = lib.c21hip_bench_pass(kind, n, int(spec.hii_filter), int(spec.stars_filter), R_mid,
+                                   float(spec.mfp_meandens) or 1.0, spec.box_len, 20, stream,
+                                   C.byref(ms))
         if st != 0:
             return None
         out[kind] = {"kernel": PASS_KERNELS[kind], "ms": ms.value, "alg_bytes": alg[kind],
@@ -217,13 +220,13 @@ def main():
         kern = None if (world > 1 or args.no_kernel_roofline or not native) else \
             kernel_roofline(args, spec, torch)
         if kern:
-            # dominant kernel = the pass-X line transform with the fused window (2 launches per
-            # radius; the largest share of the R loop in profiles/)
+            # dominant kernel = the pass-X line transform of both grids with the window multiply
+            # (one launch per radius; the largest share of the R loop in profiles/)
             dom = kern[0]
             roof.update({"kernel": dom["kernel"], "achieved": dom["GBs"],
                          "frac": dom["GBs"] / HBM_PEAK_GBS, "ms_per_launch": dom["ms"],
                          "alg_bytes_per_launch": dom["alg_bytes"],
-                         "other_kernels": [kern[1], kern[2]]})
+                         "other_kernels": [kern[1], kern[2], kern[4]]})
             pmc = pmc_traffic()
             if pmc:
                 roof["traffic"] = pmc.get("hbm_bytes_per_launch")
