@@ -31,6 +31,8 @@ int c21hip_device_sync(void);
 void *c21hip_event_create(void);
 void c21hip_event_destroy(void *ev);
 int c21hip_event_record(void *ev, void *stream);
+int c21hip_stream_wait_event(void *stream, void *ev);
+void *c21hip_aux_stream(void); /* library-owned non-blocking side stream, NULL on failure */
 float c21hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
 void c21hip_set_error(const char *fmt, ...);
 const char *c21hip_get_error(void);
@@ -61,11 +63,16 @@ int c21hip_split_r2c(const float *real_in, long in_zstride, float *split_out, in
 int c21hip_split_filter_xy(const float *split_src, float *split_work, int nx, int ny, int nz,
                            double box_len, double box_len_z, int filter_type, float R,
                            float R_param, int apply, void *stream);
-/* two grids (density, emissivity) of one radius in one sweep, each with its own window */
+/* two grids (density, emissivity) of one radius in one sweep, each with its own window;
+ * tables_ready: the W(kR) tables were prebuilt into buffer table_slot (0/1) */
 int c21hip_split_filter_xy2(const float *src_a, float *work_a, int filter_a, float R_param_a,
                             const float *src_b, float *work_b, int filter_b, float R_param_b,
                             int nx, int ny, int nz, double box_len, double box_len_z, float R,
-                            int apply, void *stream);
+                            int apply, int table_slot, int tables_ready, void *stream);
+/* W(kR) tables of one radius for c21hip_split_filter_xy2, on any stream */
+int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
+                         float R_param_b, int nx, int ny, int nz, double box_len,
+                         double box_len_z, float R, void *stream);
 int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstride, int nx, int ny,
                        int nz, void *stream);
 /* Fused pass Z of delta_R and the filtered emissivity + sum(stars) + ionisation barrier for

@@ -383,10 +383,15 @@ window_table_kernel(WTableArgs t) {
     const int nxh = t.nx / 2 + 1, nyh = t.ny / 2 + 1, H = t.nz / 2, H4 = H / 4;
     const long n4 = (long)nyh * nxh * H4;
     const long id = (long)blockIdx.x * kBlock + threadIdx.x;
+    // nx == ny (x and y share the box length): W is symmetric in (|k_x|, |k_y|), so only
+    // i <= j is evaluated and written to both places (wave-uniform: a wave shares (i, j))
+    const bool sym = (t.nx == t.ny);
     if (id < n4) {
         const int l4 = (int)(id % H4);
         const long r = id / H4;
         const int i = (int)(r % nxh), j = (int)(r / nxh);
+        if (sym && i > j) return;
+        const long rT = (long)i * nxh + j;  // the mirrored row [i][j]
         float kx[4], ky[4], kz[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -399,17 +404,21 @@ window_table_kernel(WTableArgs t) {
             window_batch_dual<4>(t.pa, t.pb, kx, ky, kz, wa, wb);
         else
             window_batch<4>(t.pa, kx, ky, kz, wa);
-        double2 *oa = reinterpret_cast<double2 *>(t.main_a + r * H + 4 * l4);
-        oa[0] = make_double2(wa[0], wa[1]);
-        oa[1] = make_double2(wa[2], wa[3]);
-        if (t.dual) {
-            double2 *ob = reinterpret_cast<double2 *>(t.main_b + r * H + 4 * l4);
-            ob[0] = make_double2(wb[0], wb[1]);
-            ob[1] = make_double2(wb[2], wb[3]);
+        for (int rep = 0; rep < ((sym && i != j) ? 2 : 1); rep++) {
+            const long rr = rep ? rT : r;
+            double2 *oa = reinterpret_cast<double2 *>(t.main_a + rr * H + 4 * l4);
+            oa[0] = make_double2(wa[0], wa[1]);
+            oa[1] = make_double2(wa[2], wa[3]);
+            if (t.dual) {
+                double2 *ob = reinterpret_cast<double2 *>(t.main_b + rr * H + 4 * l4);
+                ob[0] = make_double2(wb[0], wb[1]);
+                ob[1] = make_double2(wb[2], wb[3]);
+            }
         }
     } else if (id - n4 < (long)nxh * nyh) {
         const long q = id - n4;
         const int i = (int)(q / nyh), j = (int)(q % nyh);
+        if (sym && i > j) return;
         float kx[1] = {k_of(i, t.nx, t.pa.dkx)}, ky[1] = {k_of(j, t.ny, t.pa.dky)};
         float kz[1] = {(float)((double)(t.nz / 2) * t.pa.dkz)};
         double wa[1], wb[1];
@@ -419,6 +428,10 @@ window_table_kernel(WTableArgs t) {
             window_batch<1>(t.pa, kx, ky, kz, wa);
         t.nyq_a[q] = wa[0];
         if (t.dual) t.nyq_b[q] = wb[0];
+        if (sym && i != j) {
+            t.nyq_a[(long)j * nyh + i] = wa[0];
+            if (t.dual) t.nyq_b[(long)j * nyh + i] = wb[0];
+        }
     }
 }
 
@@ -1333,8 +1346,10 @@ extern "C" int c21hip_padded_to_split(const float *padded_c, float *split, int n
 static int filter_xy(const float *const split_src[2], float *const split_work[2], int n_grids,
                      int nx, int ny, int nz, double box_len, double box_len_z,
                      const int filter_type[2], float R, const float R_param[2], int apply,
-                     void *stream_, int phases = 7) {
-    // phases: 1 window table, 2 pass X, 4 pass Y (the timing hook runs them one at a time)
+                     void *stream_, int phases = 7, int table_slot = 0) {
+    // phases: 1 window table, 2 pass X, 4 pass Y (the timing hook runs them one at a time; the
+    // excursion-set driver builds the tables of the next radius on a second stream).
+    // table_slot 0 / 1: which of the two table buffers this radius uses.
     if (!c21hip_native_fft_supported(nx, ny, nz)) {
         c21hip_set_error("native FFT does not support %dx%dx%d", nx, ny, nz);
         return C21CM_VALUE_ERROR;
@@ -1362,7 +1377,7 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
         const size_t n_main = (size_t)(ny / 2 + 1) * (nx / 2 + 1) * H;
         const size_t n_nyq = (size_t)(nx / 2 + 1) * (ny / 2 + 1);
         const size_t per = (n_main + n_nyq + 1) & ~(size_t)1;  // keep table b 16-byte aligned
-        double *tab = (double *)c21hip_ws(49, sizeof(double) * per * (dual ? 2 : 1));
+        double *tab = (double *)c21hip_ws(table_slot ? 46 : 49, sizeof(double) * per * (dual ? 2 : 1));
         if (!tab) return C21CM_MEMORY_ALLOC_ERROR;
         WTableArgs t{};
         t.pa = a.fp;
@@ -1388,6 +1403,7 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
         a.wt_nyq[1] = t.nyq_b;
         a.dual = t.dual;
     }
+    if (!(phases & 6)) return 0;
     // ---- pass X: main block + Nyquist plane (x grids) in one launch
     a.n_geo = 2;
     a.n_grids = n_grids;
@@ -1425,17 +1441,32 @@ extern "C" int c21hip_split_filter_xy(const float *split_src, float *split_work,
 }
 
 // Two grids of the same shape in one sweep (the density and emissivity spectra of the
-// excursion-set loop), each with its own window of the same radius.
+// excursion-set loop), each with its own window of the same radius.  tables_ready != 0: the
+// window tables were already built into buffer `table_slot` by c21hip_window_tables.
 extern "C" int c21hip_split_filter_xy2(const float *src_a, float *work_a, int filter_a,
                                        float R_param_a, const float *src_b, float *work_b,
                                        int filter_b, float R_param_b, int nx, int ny, int nz,
                                        double box_len, double box_len_z, float R, int apply,
-                                       void *stream_) {
+                                       int table_slot, int tables_ready, void *stream_) {
     const float *src[2] = {src_a, src_b};
     float *work[2] = {work_a, work_b};
     const int ft[2] = {filter_a, filter_b};
     const float rp[2] = {R_param_a, R_param_b};
-    return filter_xy(src, work, 2, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_);
+    return filter_xy(src, work, 2, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_,
+                     tables_ready ? 6 : 7, table_slot);
+}
+
+// The window tables of one radius for the two-grid sweep, into buffer `table_slot`, on
+// `stream_` (any stream: they depend on no grid data).
+extern "C" int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
+                                    float R_param_b, int nx, int ny, int nz, double box_len,
+                                    double box_len_z, float R, void *stream_) {
+    const float *src[2] = {nullptr, nullptr};
+    float *work[2] = {nullptr, nullptr};
+    const int ft[2] = {filter_a, filter_b};
+    const float rp[2] = {R_param_a, R_param_b};
+    return filter_xy(src, work, 2, nx, ny, nz, box_len, box_len_z, ft, R, rp, 1, stream_, 1,
+                     table_slot);
 }
 
 // Forward transform into the split layout: real rows (in_zstride floats, scale-and-clip on

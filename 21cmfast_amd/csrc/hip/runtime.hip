@@ -136,6 +136,17 @@ extern "C" int c21hip_event_record(void *ev, void *stream) {
     HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
     return 0;
 }
+extern "C" int c21hip_stream_wait_event(void *stream, void *ev) {
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    return 0;
+}
+// A library-owned non-blocking side stream (created once) for work that depends on no grid
+// data of the caller's stream, e.g. the window tables of the next filter radius.
+extern "C" void *c21hip_aux_stream(void) {
+    static hipStream_t aux = nullptr;
+    if (!aux && hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) aux = nullptr;
+    return aux;
+}
 extern "C" float c21hip_event_elapsed_ms(void *start, void *stop) {
     float ms = -1.f;
     if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;

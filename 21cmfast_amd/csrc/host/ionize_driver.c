@@ -205,6 +205,7 @@ typedef struct {
     float *table_dev;
     unsigned char *mask; /* internal first-crossing mask of the fused single-GPU path */
     int fused;           /* fused pass Z + barrier available for radius index > 0 */
+    int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     copyback_list cb;
 } ion_ctx;
 
@@ -366,8 +367,46 @@ done:
     return status;
 }
 
-/* One filter radius: IonisationBox.c:1546-1580.  first_cross != NULL = shard mode. */
-static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross) {
+/* The W(kR) tables of a radius depend on no grid data, so those of the NEXT radius are built on
+ * a side stream while the current radius runs its passes (the table kernel is fp64-ALU work,
+ * the passes are memory/LDS work).  Two table buffers alternate; ev_table[b] = buffer b is
+ * filled, ev_used[b] = the pass X that read buffer b has been issued on the caller's stream.
+ * C21CM_ASYNC_TABLES=0 builds them inline on the caller's stream instead. */
+static struct {
+    int init, enabled;
+    void *aux, *ev_table[2], *ev_used[2], *ev_sync;
+} g_tab;
+
+static void tab_init(void) {
+    if (g_tab.init) return;
+    g_tab.init = 1;
+    const char *e = getenv("C21CM_ASYNC_TABLES");
+    if (e && e[0] == '0') return;
+    g_tab.aux = c21hip_aux_stream();
+    g_tab.ev_sync = c21hip_event_create();
+    for (int b = 0; b < 2; b++) {
+        g_tab.ev_table[b] = c21hip_event_create();
+        g_tab.ev_used[b] = c21hip_event_create();
+    }
+    g_tab.enabled = g_tab.aux && g_tab.ev_sync && g_tab.ev_table[0] && g_tab.ev_table[1] &&
+                    g_tab.ev_used[0] && g_tab.ev_used[1];
+}
+
+static int tab_build_async(ion_ctx *c, int R_ct, int buf) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    TRY(c21hip_stream_wait_event(g_tab.aux, g_tab.ev_used[buf]));
+    TRY(c21hip_window_tables(buf, s->hii_filter, 0.f, s->stars_filter, (float)s->mfp_meandens,
+                             c->nx, c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_ct],
+                             g_tab.aux));
+    TRY(c21hip_event_record(g_tab.ev_table[buf], g_tab.aux));
+done:
+    return status;
+}
+
+/* One filter radius: IonisationBox.c:1546-1580.  first_cross != NULL = shard mode.
+ * next_R: the radius index this process handles after R_ct (-1: none / unknown). */
+static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     const int apply = R_ct > 0; /* copy_filter_transform skips filter_box at R_index 0 (:606) */
@@ -379,9 +418,27 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross) {
     fill_args(&args, s, R_ct);
 
     if (c->fused && first_cross && R_ct > 0) {
+        int buf = 0, ready = 0;
+        tab_init();
+        if (g_tab.enabled) {
+            buf = c->tab_seq & 1;
+            ready = 1;
+            if (c->tab_seq == 0) {
+                /* first fused radius of this call: order the side stream after whatever the
+                 * caller's stream still runs on the table buffers, then build this radius */
+                TRY(c21hip_event_record(g_tab.ev_sync, c->stream));
+                TRY(c21hip_stream_wait_event(g_tab.aux, g_tab.ev_sync));
+                TRY(tab_build_async(c, R_ct, buf));
+            }
+            if (next_R >= 1) TRY(tab_build_async(c, next_R, buf ^ 1));
+            TRY(c21hip_stream_wait_event(c->stream, g_tab.ev_table[buf]));
+        }
         TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->stars_unf,
                                     c->stars_work, s->stars_filter, (float)s->mfp_meandens, c->nx,
-                                    c->ny, c->nz, s->box_len, s->box_len_z, R, apply, c->stream));
+                                    c->ny, c->nz, s->box_len, s->box_len_z, R, apply, buf, ready,
+                                    c->stream));
+        if (g_tab.enabled) TRY(c21hip_event_record(g_tab.ev_used[buf], c->stream));
+        c->tab_seq++;
         TRY(c21hip_split_z_ionise_stars(c->delta_work, c->stars_work, first_cross, partials,
                                         sum_dev, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
                                         s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
@@ -531,7 +588,8 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
                                              spec->redshift, c.xH, c.zre, c.ntot, stream));
                 mask_pending = 0;
             }
-            TRY(one_radius(&c, R_ct, (R_ct > 0 && c.fused) ? c.mask : NULL));
+            TRY(one_radius(&c, R_ct, (R_ct > 0 && c.fused) ? c.mask : NULL,
+                           (R_ct - 1 >= spec->r_lowest) ? R_ct - 1 : -1));
         }
         if (mask_pending)
             TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot, spec->redshift,
@@ -593,7 +651,7 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
     /* radii n-1 .. 1 dealt round-robin, largest first; index 0 belongs to the finish step */
     for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
         if (R_ct < spec->r_lowest) break;
-        TRY(one_radius(&c, R_ct, first_cross));
+        TRY(one_radius(&c, R_ct, first_cross, R_ct - world));
     }
     TRY(c21hip_event_record(ev[2], stream));
     if (report) {
@@ -636,7 +694,7 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
     if (spec->r_lowest == 0) {
         if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
         g_spectra.valid = 0;
-        TRY(one_radius(&c, 0, NULL));
+        TRY(one_radius(&c, 0, NULL, -1));
     }
     TRY(c21hip_event_record(ev[1], stream));
     TRY(postloop(&c, box, report));
