@@ -213,6 +213,13 @@ int c21hip_neutral_box(const float *density, const float *xe, const float *Tneut
                        void *stream);
 int c21hip_any_nonzero(const float *a, size_t n, int *flag_host, void *stream);
 /* xH/z_reion from a max-reduced first_cross mask (multi-GPU tail). */
+/* mask of radii > 0 + radius index 0 + post-loop sweep of the fused Lagrangian path in one pass
+ * (IonisationBox.c:1031-1256,1597-1608); partials: 2 * 2048 doubles; writes every z_reion */
+int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
+                       const unsigned char *first_cross, const float *stars_fil,
+                       const float *density, const float *prev_z_reion, float *xH, float *z_reion,
+                       float *kinetic_temperature, double *partials, double *sum_stars_out,
+                       double *sum_xh_out, int *flag_out, void *stream);
 int c21hip_apply_first_cross(const unsigned char *first_cross, const float *prev_z_reion,
                              int first_snapshot, double redshift, float *xH, float *z_reion,
                              size_t ntot, void *stream);

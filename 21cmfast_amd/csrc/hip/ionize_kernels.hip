@@ -457,6 +457,105 @@ finalize_kernel(c21hip_ionize_args a, float stored_z, const float *__restrict__ 
     block_sum_to(acc, partials);
 }
 
+// ---- last step of the fused Lagrangian path: mask of the radii > 0, the cell-scale radius
+// (index 0, IonisationBox.c:1031-1200 with LAST_FILTER_STEP) and the post-loop sweep
+// (:1203-1256, 1597-1608) in ONE pass over the cells.  Equivalent to apply_first_cross_kernel
+// -> ionise_stars_kernel<VEC, true, false> -> finalize_kernel, which move xH / z_reion / T_k
+// through HBM three times.  z_reion is written for every cell (-1 where never ionised, the
+// value IonisationBox.c:1372-1378 initialises it to), so the caller need not pre-fill it.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restrict__ first_cross,
+                   const float *__restrict__ stars_fil, const float *__restrict__ density,
+                   const float *__restrict__ prev_z_reion, float *__restrict__ xH,
+                   float *__restrict__ z_reion, float *__restrict__ Tk,
+                   double *__restrict__ partials_stars, double *__restrict__ partials_xh,
+                   int *__restrict__ flag) {
+    constexpr int U = 2;  // items per thread and trip, loads issued before any arithmetic
+    const c21hip_ionize_args &a = p.a;
+    const float z_now = (float)a.redshift;
+    const double pow_Tre = pow((double)(float)a.T_re, 1.7);
+    const double pow_z = pow(1e4 * ((1. + (double)stored_z) / 4.), 1.7);
+    double acc_s = 0., acc_x = 0.;
+    int bad = 0;
+    for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < p.nitems;
+         i0 += (size_t)gridDim.x * kBlock * U) {
+        Pack<VEC> st[U], de[U], x0[U], T0[U], pz[U];
+        unsigned char m[U][VEC];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = i0 + (size_t)u * kBlock;
+            ok[u] = i < p.nitems;
+            if (!ok[u]) continue;
+            const auto ci = cell_index<VEC>(i, p.nz_items, p.zpad_items);
+            st[u] = Pack<VEC>::load(stars_fil, ci.padded);
+            de[u] = Pack<VEC>::load(density, ci.dense);
+            x0[u] = Pack<VEC>::load(xH, ci.dense);
+            if (!a.minimize_memory) T0[u] = Pack<VEC>::load(Tk, ci.dense);
+            if (!a.first_snapshot) pz[u] = Pack<VEC>::load(prev_z_reion, ci.dense);
+#pragma unroll
+            for (int e = 0; e < VEC; e++) m[u][e] = first_cross[ci.dense * VEC + e];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!ok[u]) continue;
+            const size_t i = i0 + (size_t)u * kBlock;
+            Pack<VEC> xo, zo, To;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const float stars = fmaxf(st[u].v[e], 0.f);  // IonisationBox.c:822-823
+                acc_s += (double)stars;
+                const float dens = de[u].v[e];
+                const double curr_dens = (double)dens * a.photoncons_factor;  // :1048
+                double curr_fcoll = (double)stars;
+                curr_fcoll *= 1 / (a.rhocrit_omb * (1 + curr_dens));  // :1066-1067
+                if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;  // :1077
+                float x = x0[u].v[e];
+                float T = a.minimize_memory ? 0.f : T0[u].v[e];
+                float zr = -1.f;
+                const bool ionised = m[u][e] != 0 || (curr_fcoll * a.ion_eff_factor > 1.);  // :1118
+                if (ionised) {
+                    const float pzv = a.first_snapshot ? -1.f : pz[u].v[e];
+                    zr = (pzv < 0.f) ? z_now : pzv;  // :1143-1147
+                    x = 0.f;                         // :1151
+                } else if ((double)x > kTiny) {      // :1161
+                    double res_xH = 1. - curr_fcoll * a.ion_eff_factor;
+                    if (!a.minimize_memory) {
+                        const float T_HI = (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)dens));
+                        T = partially_ionized_T(T_HI, (float)res_xH, (float)a.T_re);
+                    }
+                    if (res_xH < 0)
+                        res_xH = 0;
+                    else if (res_xH > 1)
+                        res_xH = 1;
+                    x = (float)res_xH;
+                }
+                acc_x += (double)x;
+                if (!a.minimize_memory) {
+                    if (zr > 0.f && (double)x < kTiny) {  // :1218
+                        T = fully_ionized_T(zr, stored_z, dens, pow_Tre, pow_z);
+                        const float floorT =
+                            (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)dens));
+                        if (T < floorT) T = floorT;
+                    }
+                    if (!isfinite(T)) bad = 1;  // :1245
+                }
+                xo.v[e] = x;
+                zo.v[e] = zr;
+                To.v[e] = T;
+            }
+            xo.store(xH, i);
+            zo.store(z_reion, i);
+            if (!a.minimize_memory) To.store(Tk, i);
+        }
+    }
+    if (bad) atomicOr(flag, 1);
+    block_sum_to(acc_s, partials_stars);
+    __syncthreads();
+    block_sum_to(acc_x, partials_xh);
+}
+
 __global__ void __launch_bounds__(kBlock)
 apply_first_cross_kernel(const unsigned char *__restrict__ fc,
                          const float *__restrict__ prev_z_reion, int first_snapshot, float z_now,
@@ -705,6 +804,35 @@ extern "C" int c21hip_finalize(const c21hip_ionize_args *a, double stored_redshi
     LAUNCH_CHECK();
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
                        partials, blocks, 0, sum_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
+                                  const unsigned char *first_cross, const float *stars_fil,
+                                  const float *density, const float *prev_z_reion, float *xH,
+                                  float *z_reion, float *kinetic_temperature, double *partials,
+                                  double *sum_stars_out, double *sum_xh_out, int *flag_out,
+                                  void *stream) {
+    const int vec = (a->nz % 2 == 0) ? 2 : 1;
+    const IoniseParams p = make_params(a, vec);
+    const int blocks = grid_for((p.nitems + 1) / 2);
+    double *ps = partials, *px = partials + kMaxBlocks;
+    if (vec == 2)
+        hipLaunchKernelGGL(final_sweep_kernel<2>, dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, stars_fil,
+                           density, prev_z_reion, xH, z_reion, kinetic_temperature, ps, px,
+                           flag_out);
+    else
+        hipLaunchKernelGGL(final_sweep_kernel<1>, dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, stars_fil,
+                           density, prev_z_reion, xH, z_reion, kinetic_temperature, ps, px,
+                           flag_out);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, ps,
+                       blocks, 0, sum_stars_out);
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, px,
+                       blocks, 0, sum_xh_out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -206,6 +206,7 @@ typedef struct {
     unsigned char *mask; /* internal first-crossing mask of the fused single-GPU path */
     int fused;           /* fused pass Z + barrier available for radius index > 0 */
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
+    int finalised;       /* the post-loop sweep already ran inside final_step() */
     copyback_list cb;
 } ion_ctx;
 
@@ -497,6 +498,29 @@ done:
     return status;
 }
 
+/* Fused Lagrangian path, radius index 0 reached: the cell-scale step only needs the emissivity
+ * grid in real space (the density it tests is the unfiltered one, IonisationBox.c:1048), and
+ * the mask of the larger radii, the barrier / partial ionisation at index 0 and the post-loop
+ * sweep are one pass over the cells (c21hip_final_sweep). */
+static int final_step(ion_ctx *c, const unsigned char *mask) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    c21hip_ionize_args args;
+    fill_args(&args, s, 0);
+    TRY(c21hip_split_filter_c2r(c->stars_unf, c->stars_work, c->stars_fil,
+                                2 * (long)(c->nz / 2 + 1), c->nx, c->ny, c->nz, s->box_len,
+                                s->box_len_z, s->stars_filter, (float)s->R[0],
+                                (float)s->mfp_meandens, 0, c->stream));
+    TRY(c21hip_final_sweep(&args, s->stored_redshift, mask, c->stars_fil, c->density, c->prev_zre,
+                           c->xH, c->zre, c->Tk, c->partials, c->scalars + SC_SUMS,
+                           c->scalars + SC_XHSUM, (int *)(c->scalars + SC_FLAG), c->stream));
+    TRY(c21hip_finish_mean(c->scalars + SC_SUMS, (double)c->ntot, s->mass_dep_zeta,
+                           s->f_limit_acg, c->scalars + SC_MEANS, c->stream));
+    c->finalised = 1;
+done:
+    return status;
+}
+
 /* post-loop + result collection: IonisationBox.c:1589-1628 */
 static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
     int status = 0;
@@ -505,8 +529,10 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
     fill_args(&args, s, 0);
     double host_sc[SC_COUNT - SC_SUMS];
     int *flag_dev = (int *)(c->scalars + SC_FLAG);
-    TRY(c21hip_finalize(&args, s->stored_redshift, c->density, c->Tneutral, c->xH, c->zre, c->Tk,
-                        c->ntot, c->partials, c->scalars + SC_XHSUM, flag_dev, c->stream));
+    if (!c->finalised)
+        TRY(c21hip_finalize(&args, s->stored_redshift, c->density, c->Tneutral, c->xH, c->zre,
+                            c->Tk, c->ntot, c->partials, c->scalars + SC_XHSUM, flag_dev,
+                            c->stream));
     TRY(c21hip_d2h(host_sc, c->scalars + SC_SUMS, sizeof(host_sc), c->stream));
     for (int i = 0; i < c->cb.n; i++)
         TRY(c21hip_d2h(c->cb.host[i], c->cb.dev[i], c->cb.bytes[i], c->stream));
@@ -540,8 +566,8 @@ done:
 static int init_output_grids(ion_ctx *c, const IonizedBox *prev) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
-    /* IonisationBox.c:1372-1378 */
-    TRY(c21hip_fill(c->zre, c->ntot, -1.0f, c->stream));
+    /* IonisationBox.c:1372-1378 (final_step writes every cell, -1 included) */
+    if (!(c->fused && s->r_lowest == 0)) TRY(c21hip_fill(c->zre, c->ntot, -1.0f, c->stream));
     /* IonisationBox.c:365-386: the caller's zeroed previous box receives z_reion = -1 */
     if (s->first_snapshot && prev && prev->z_reion) {
         if (c21hip_is_device_ptr(prev->z_reion)) {
@@ -583,10 +609,9 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         for (int R_ct = spec->n_radii; R_ct--;) {
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
-                /* the cell-scale radius tests xH > TINY: materialise the mask first */
-                TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot,
-                                             spec->redshift, c.xH, c.zre, c.ntot, stream));
+                TRY(final_step(&c, c.mask));
                 mask_pending = 0;
+                break;
             }
             TRY(one_radius(&c, R_ct, (R_ct > 0 && c.fused) ? c.mask : NULL,
                            (R_ct - 1 >= spec->r_lowest) ? R_ct - 1 : -1));
@@ -689,12 +714,16 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
     for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
     TRY(c21hip_event_record(ev[0], stream));
     TRY(init_output_grids(&c, previous_ionize_box));
-    TRY(c21hip_apply_first_cross(first_cross, c.prev_zre, spec->first_snapshot, spec->redshift,
-                                 c.xH, c.zre, c.ntot, stream));
     if (spec->r_lowest == 0) {
         if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
         g_spectra.valid = 0;
-        TRY(one_radius(&c, 0, NULL, -1));
+    }
+    if (c.fused && spec->r_lowest == 0) {
+        TRY(final_step(&c, first_cross));
+    } else {
+        TRY(c21hip_apply_first_cross(first_cross, c.prev_zre, spec->first_snapshot,
+                                     spec->redshift, c.xH, c.zre, c.ntot, stream));
+        if (spec->r_lowest == 0) TRY(one_radius(&c, 0, NULL, -1));
     }
     TRY(c21hip_event_record(ev[1], stream));
     TRY(postloop(&c, box, report));

@@ -4,7 +4,7 @@ MI355X guide prescribes) into profiles/pmc_rNN.json.
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -o pmc -- python bench.py ...
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_WRITE_SIZE -o pmc -- python bench.py ...
-  python tools/collect_pmc.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/pmc_r01.json
+  python tools/collect_pmc.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE profiles/pmc_r01.json profiles/r01_pmc
 
 Units and corrections (/opt/skills/guides/MI355X_MICROARCH.md, section HBM): the counters are
 in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming
@@ -17,27 +17,64 @@ import sys
 from collections import defaultdict
 
 KERNELS = {
-    "pass_x_window": ("line_pass_kernel<512, 1, 1>", 1000),
-    "pass_y": ("line_pass_kernel<512, 1, 0>", 1000),
-    "pass_z_fused": ("z_c2r_ionise_kernel<512>", 1000),
+    "pass_x_window": "line_pass_kernel<512, 1, 3>",
+    "pass_y": "line_pass_kernel<512, 1, 0>",
+    "pass_z_fused": "z_c2r_ionise_kernel<512>",
+    "window_tables": "window_table_kernel",
 }
+
+
+def short_name(kernel_name):
+    """'void (anonymous namespace)::line_pass_kernel<512, 1, 3>((anonymous ...' -> 'line_pass_kernel<512, 1, 3>'"""
+    name = kernel_name
+    if name.startswith("void "):
+        name = name[5:]
+    if name.startswith("(anonymous namespace)::"):
+        name = name[len("(anonymous namespace)::"):]
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
+def rows(directory, counter):
+    with open(f"{directory}/pmc_counter_collection.csv") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == counter:
+                yield row
 
 
 def averages(directory, counter):
     acc = defaultdict(list)
-    with open(f"{directory}/pmc_counter_collection.csv") as f:
-        for row in csv.DictReader(f):
-            if row["Counter_Name"] != counter:
-                continue
-            for key, (needle, min_grid) in KERNELS.items():
-                # main-block launches only (the Nyquist-plane launches use tiny grids)
-                if needle in row["Kernel_Name"] and int(row["Grid_Size"]) >= 100000:
-                    acc[key].append(float(row["Counter_Value"]))
+    for row in rows(directory, counter):
+        for key, needle in KERNELS.items():
+            if needle in row["Kernel_Name"]:
+                acc[key].append(float(row["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def per_kernel_csv(directory, counter, out):
+    """compact per-kernel summary (launches, mean, total of the raw counter, KiB)"""
+    acc = defaultdict(list)
+    for row in rows(directory, counter):
+        acc[short_name(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", f"mean_{counter}_KiB", f"total_{counter}_KiB"])
+        for name, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([name, len(v), f"{sum(v) / len(v):.1f}", f"{sum(v):.1f}"])
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    if len(sys.argv) > 4:  # prefix for the compact per-kernel CSVs
+        per_kernel_csv(fetch_dir, "FETCH_SIZE", f"{sys.argv[4]}_FETCH_SIZE_per_kernel.csv")
+        per_kernel_csv(write_dir, "WRITE_SIZE", f"{sys.argv[4]}_WRITE_SIZE_per_kernel.csv")
     fetch = averages(fetch_dir, "FETCH_SIZE")
     write = averages(write_dir, "WRITE_SIZE")
     result = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), "
