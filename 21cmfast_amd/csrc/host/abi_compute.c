@@ -15,12 +15,14 @@
  *
  * Option coverage.  Implemented: every PERTURB_ALGORITHM, PERTURB_ON_HIGH_RES,
  * KEEP_3D_VELOCITIES, SMOOTH_EVOLVED_DENSITY_FIELD, analytic POWER_SPECTRUM fits,
- * SOURCE_MODEL = CONST-ION-EFF (closed form or FgtrM table) and the Lagrangian models
- * (L-INTEGRAL / DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all
- * HII_FILTER types, USE_EXP_FILTER, MINIMIZE_MEMORY.  Returning ValueError (3) with a
- * message in c21cm_last_error(): E-INTEGRAL (needs the conditional-MF tables),
- * USE_MINI_HALOS, recombination models, PHOTON_CONS_TYPE != none, IONISE_ENTIRE_SPHERE,
- * V_CB_MODEL = FLUCTS, CLASS transfer tables.
+ * SOURCE_MODEL = CONST-ION-EFF (closed form or FgtrM table), E-INTEGRAL (conditional
+ * mass-function tables per radius, PS / ST, Gauss-Legendre or adaptive quadrature; needs
+ * USE_INTERPOLATION_TABLES = hmf-interpolation) and the Lagrangian models (L-INTEGRAL /
+ * DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all HII_FILTER types,
+ * USE_EXP_FILTER, MINIMIZE_MEMORY.  Returning ValueError (3) with a message in
+ * c21cm_last_error(): E-INTEGRAL without interpolation tables or with the Gamma-function
+ * approximation, USE_MINI_HALOS, recombination models, PHOTON_CONS_TYPE != none,
+ * IONISE_ENTIRE_SPHERE, V_CB_MODEL = FLUCTS, CLASS transfer tables.
  */
 #include <math.h>
 #include <stdio.h>
@@ -180,6 +182,24 @@ static int fgtrm_table_fn(int r_index, double dmin, double dmax, float *table, v
     return 0;
 }
 
+/* E-INTEGRAL: ln N_ion(delta | M(R)) per filter radius, IonisationBox.c:702-765 with
+ * interp_tables.c:291-405 (no mini-halos: the 1-D table, turnover mass M_TURN) */
+struct nion_table_ctx {
+    const c21cm_ionize_spec *spec;
+    c21_scaling_consts sc;
+    double lnMmin;
+    int method;
+};
+
+static int nion_table_fn(int r_index, double dmin, double dmax, float *table, void *user) {
+    const struct nion_table_ctx *t = (const struct nion_table_ctx *)user;
+    const c21cm_ionize_spec *s = t->spec;
+    const double M_max_R = c21_RtoM(s->R[r_index]);
+    return c21_Nion_Conditional_table(s->growth_factor, t->lnMmin, log(M_max_R), log(M_max_R),
+                                      c21_sigma_fast(M_max_R), dmin, dmax, t->sc.mturn_a_nofb,
+                                      &t->sc, t->method, table, C21CM_NDELTA_TABLE);
+}
+
 int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *perturbed_field,
                       PerturbedField *previous_perturbed_field, IonizedBox *previous_ionize_box,
                       TsBox *spin_temp, HaloBox *halos, InitialConditions *ini_boxes,
@@ -198,7 +218,10 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     const int lagrangian = !(src == C21CM_SOURCE_E_INTEGRAL || src == C21CM_SOURCE_CONST_ION_EFF);
     const int mass_dep = src != C21CM_SOURCE_CONST_ION_EFF;
     const char *unsupported = NULL;
-    if (src == C21CM_SOURCE_E_INTEGRAL) unsupported = "SOURCE_MODEL=E-INTEGRAL (conditional-MF tables)";
+    if (src == C21CM_SOURCE_E_INTEGRAL && mo->USE_INTERPOLATION_TABLES != C21CM_INTERP_HMF)
+        unsupported = "SOURCE_MODEL=E-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation";
+    if (src == C21CM_SOURCE_E_INTEGRAL && ao->INTEGRATION_METHOD_ATOMIC > 1)
+        unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
     if (ao->USE_MINI_HALOS) unsupported = "USE_MINI_HALOS";
     if (ao->RECOMB_MODEL != C21CM_RECOMB_NONE) unsupported = "RECOMB_MODEL != none";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
@@ -318,8 +341,17 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     box->mean_f_coll_MINI = 0.;
 
     struct fgtrm_table_ctx tctx = {s};
+    struct nion_table_ctx nctx;
     if (lagrangian) {
         s->fcoll_mode = C21CM_FCOLL_STARS_GRID;
+    } else if (src == C21CM_SOURCE_E_INTEGRAL) {
+        nctx.spec = s;
+        nctx.sc = sc;
+        nctx.lnMmin = lnMmin;
+        nctx.method = ao->INTEGRATION_METHOD_ATOMIC;
+        s->fcoll_mode = C21CM_FCOLL_TABLE_EXP;
+        s->table_fn = nion_table_fn;
+        s->table_user = &nctx;
     } else if (mo->USE_INTERPOLATION_TABLES == C21CM_INTERP_HMF) {
         s->fcoll_mode = C21CM_FCOLL_TABLE_LINEAR;
         s->table_fn = fgtrm_table_fn;

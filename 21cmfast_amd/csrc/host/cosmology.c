@@ -35,6 +35,7 @@
 #define PC_M_P 1.67262192369e-24
 #define PC_SIGMA_HI 6.3e-18
 #define DELTA_C_SPH 1.686
+#define FRACT_FLOAT_ERR 1e-7 /* Constants.h */
 #define N_NU 1.0 /* heavy neutrino species in the EH99 fit (cosmology.c:22) */
 
 static struct {
@@ -477,6 +478,241 @@ double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
     p.ln_Mlim_esc = log(sc->Mlim_Fesc);
     p.Mturn = Mturn;
     return c21_integrate(mf_integrand, &p, lnM_min, lnM_max, 1e-6);
+}
+
+/* ---------------------------------------------------------------- conditional mass function
+ * The E-INTEGRAL source model evaluates, per filter radius, N_ion(delta | M_cond = M(R)) on a
+ * grid of 400 overdensities (interp_tables.c:291-405) as a Gauss-Legendre sum over ln M of
+ * n_ion(M) x conditional mass function (hmf.c:1106-1140, 703-730). */
+#define JENKINS_a 0.73 /* hmf.c:48-50 */
+#define JENKINS_b 0.34
+#define JENKINS_c 0.81
+#define MAX_DELTAC_FRAC ((float)0.99) /* hmf.h:8 */
+#define NGL_INT 100                   /* hmf.c:87 */
+
+/* hmf.c:151-154 */
+static double sheth_delc_fixed(double del, double sig) {
+    return sqrt(JENKINS_a) * del * (1. + JENKINS_b * pow(sig * sig / (JENKINS_a * del * del), JENKINS_c));
+}
+
+/* hmf.c:166-171 (Delos not supported here) */
+static double get_delta_crit(int hmf, double sigma, double growthf) {
+    if (hmf == C21CM_HMF_ST) return sheth_delc_fixed(DELTA_C_SPH / growthf, sigma) * growthf;
+    return DELTA_C_SPH;
+}
+
+/* hmf.c:234-267: Taylor expansion of the moving barrier about sigma_cond */
+static double st_taylor_factor(double sig, double sig_cond, double growthf, double *zeroth_order) {
+    const double a = JENKINS_a, alpha = JENKINS_c, beta = JENKINS_b;
+    const double del = DELTA_C_SPH / growthf;
+    const double sigsq = sig * sig, sigsq_inv = 1. / sigsq, sigcsq = sig_cond * sig_cond;
+    const double sigdiff = sig == sig_cond ? 1e-6 : sigsq - sigcsq;
+    double t_array[6];
+    t_array[0] = 1.;
+    for (int i = 1; i < 6; i++)
+        t_array[i] = t_array[i - 1] * (-sigdiff) / i * (alpha - i + 1) * sigsq_inv;
+    double result = 0.;
+    for (int i = 5; i >= 0; i--) result += t_array[i];
+    const double prefactor_1 = sqrt(a) * del;
+    const double prefactor_2 = beta * pow(sigsq_inv * (a * del * del), -alpha);
+    result = prefactor_1 * (1 + prefactor_2 * result);
+    *zeroth_order = prefactor_1 * (1 + prefactor_2);
+    return result;
+}
+
+/* hmf.c:270-285 (Sheth-Mo-Tormen) and :317-330 (extended Press-Schechter) */
+static double conditional_mf(double growthf, double lnM, double delta_cond, double sigma_cond,
+                             int hmf) {
+    const double M = exp(lnM);
+    const double sigma1 = c21_sigma_fast(M);
+    const double dsigmasqdm = dsigmasqdm_fast(M);
+    if (sigma1 < sigma_cond) return 0.;
+    const double sigdiff_inv =
+        sigma1 == sigma_cond ? 1e6 : 1 / (sigma1 * sigma1 - sigma_cond * sigma_cond);
+    if (hmf == C21CM_HMF_ST) {
+        double Barrier;
+        const double delta_0 = delta_cond / growthf;
+        const double factor = st_taylor_factor(sigma1, sigma_cond, growthf, &Barrier) - delta_0;
+        return -dsigmasqdm * factor * pow(sigdiff_inv, 1.5) *
+               exp(-(Barrier - delta_0) * (Barrier - delta_0) * 0.5 * sigdiff_inv) / sqrt(2. * M_PI);
+    }
+    const double del = (DELTA_C_SPH - delta_cond) / growthf;
+    return -del * dsigmasqdm * pow(sigdiff_inv, 1.5) * exp(-del * del * 0.5 * sigdiff_inv) /
+           sqrt(2. * M_PI);
+}
+
+/* hmf.c:664-700 (gauleg, Numerical-Recipes form, 1-based) */
+static void gauleg(double x1, double x2, double *x, double *w, int n) {
+    const int m = (n + 1) / 2;
+    const double xm = 0.5 * (x2 + x1), xl = 0.5 * (x2 - x1);
+    for (int i = 1; i <= m; i++) {
+        double z = cos(3.141592654 * (i - 0.25) / (n + 0.5)), z1, pp;
+        do {
+            double p1 = 1.0, p2 = 0.0;
+            for (int j = 1; j <= n; j++) {
+                const double p3 = p2;
+                p2 = p1;
+                p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+            }
+            pp = n * (z * p1 - p2) / (z * z - 1.0);
+            z1 = z;
+            z = z1 - p1 / pp;
+        } while (fabs(z - z1) > 3.0e-11);
+        x[i] = xm - xl * z;
+        x[n + 1 - i] = xm + xl * z;
+        w[i] = 2.0 * xl / ((1.0 - z * z) * pp * pp);
+        w[n + 1 - i] = w[i];
+    }
+}
+
+static struct {
+    double lo, hi;
+    int ready;
+    double x[NGL_INT + 1], w[NGL_INT + 1];
+} gl;
+
+static void initialise_GL(double lnM_min, double lnM_max) { /* hmf.c:703-711 */
+    if (gl.ready && lnM_min == gl.lo && lnM_max == gl.hi) return;
+    gauleg(lnM_min, lnM_max, gl.x, gl.w, NGL_INT);
+    gl.lo = lnM_min;
+    gl.hi = lnM_max;
+    gl.ready = 1;
+}
+
+struct cmf_ctx {
+    struct mf_ctx m;
+    double delta, sigma_cond;
+};
+
+static double cnion_integrand(double lnM, void *ctx) { /* hmf.c:541-543 */
+    const struct cmf_ctx *c = (const struct cmf_ctx *)ctx;
+    const struct mf_ctx *p = &c->m;
+    const double Fstar = log_pl_limit(lnM, p->ln_fstar_norm, p->alpha_star, 10 * M_LN10, p->ln_Mlim_star);
+    const double Fesc = log_pl_limit(lnM, p->ln_fesc_norm, p->alpha_esc, 10 * M_LN10, p->ln_Mlim_esc);
+    return exp(Fstar + Fesc - p->Mturn / exp(lnM) + lnM) *
+           conditional_mf(p->growthf, lnM, c->delta, c->sigma_cond, p->hmf);
+}
+
+/* hmf.c:1106-1140.  method: 0 adaptive quadrature (the reference: GSL QAG, rel 1e-3), 1
+ * Gauss-Legendre with NGL_INT points over [lnM1, lnM2] (the default).  The Gamma-function
+ * approximation (method 2) is not provided. */
+double c21_Nion_ConditionalM(double growthf, double lnM1, double lnM2, double lnM_cond,
+                             double sigma2, double delta2, double Mturn,
+                             const c21_scaling_consts *sc, int method) {
+    struct cmf_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.m.growthf = growthf;
+    c.m.hmf = matter_options_global->HMF;
+    c.m.kind = 1;
+    c.m.ln_fstar_norm = log(sc->fstar_10);
+    c.m.alpha_star = sc->alpha_star;
+    c.m.ln_Mlim_star = log(sc->Mlim_Fstar);
+    c.m.ln_fesc_norm = log(sc->fesc_10);
+    c.m.alpha_esc = sc->alpha_esc;
+    c.m.ln_Mlim_esc = log(sc->Mlim_Fesc);
+    c.m.Mturn = Mturn;
+    c.delta = delta2;
+    c.sigma_cond = sigma2;
+    if (lnM1 >= lnM_cond) return 0.;
+    if (delta2 > MAX_DELTAC_FRAC * get_delta_crit(c.m.hmf, sigma2, growthf)) {
+        /* one halo at the condition mass when the cell itself has collapsed */
+        if (lnM_cond * (1 - FRACT_FLOAT_ERR) <= lnM2) {
+            const double Fstar = log_pl_limit(lnM_cond, c.m.ln_fstar_norm, c.m.alpha_star,
+                                              10 * M_LN10, c.m.ln_Mlim_star);
+            const double Fesc = log_pl_limit(lnM_cond, c.m.ln_fesc_norm, c.m.alpha_esc, 10 * M_LN10,
+                                             c.m.ln_Mlim_esc);
+            return exp(Fstar + Fesc - Mturn / exp(lnM_cond) + lnM_cond) / exp(lnM_cond);
+        }
+        return 0.;
+    }
+    if (c.m.hmf != C21CM_HMF_PS && c.m.hmf != C21CM_HMF_ST) c.m.hmf = C21CM_HMF_PS;
+    if (method == 1) {
+        initialise_GL(lnM1, lnM2);
+        double integral = 0;
+        for (int i = 1; i < NGL_INT + 1; i++) integral += gl.w[i] * cnion_integrand(gl.x[i], &c);
+        return integral;
+    }
+    return c21_integrate(cnion_integrand, &c, lnM1, lnM2, 1e-4);
+}
+
+/* interp_tables.c:291-405 (1-D case): table[i] = max(ln N_ion(delta_i | M_cond), -40) on
+ * n_delta overdensities from dmin to dmax.  With the Gauss-Legendre method everything that does
+ * not depend on delta (sigma, d sigma^2/dM, n_ion(M), the barrier expansion) is evaluated once per
+ * node, which leaves one exp per (node, delta): the values equal c21_Nion_ConditionalM's. */
+int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                               double sigma_cond, double dmin, double dmax, double Mturn,
+                               const c21_scaling_consts *sc, int method, float *table,
+                               int n_delta) {
+    int hmf = matter_options_global->HMF;
+    const int fast = (method == 1) && lnMmin < lnMcond;
+    double node_pref[NGL_INT + 1], node_factor[NGL_INT + 1], node_barrier[NGL_INT + 1],
+        node_sdi[NGL_INT + 1];
+    if (hmf != C21CM_HMF_PS && hmf != C21CM_HMF_ST) hmf = C21CM_HMF_PS;
+    if (fast) {
+        struct mf_ctx m;
+        memset(&m, 0, sizeof(m));
+        m.ln_fstar_norm = log(sc->fstar_10);
+        m.alpha_star = sc->alpha_star;
+        m.ln_Mlim_star = log(sc->Mlim_Fstar);
+        m.ln_fesc_norm = log(sc->fesc_10);
+        m.alpha_esc = sc->alpha_esc;
+        m.ln_Mlim_esc = log(sc->Mlim_Fesc);
+        initialise_GL(lnMmin, lnMmax);
+        for (int i = 1; i < NGL_INT + 1; i++) {
+            const double lnM = gl.x[i], M = exp(lnM);
+            const double sigma1 = c21_sigma_fast(M), dsigmasqdm = dsigmasqdm_fast(M);
+            const double Fstar = log_pl_limit(lnM, m.ln_fstar_norm, m.alpha_star, 10 * M_LN10, m.ln_Mlim_star);
+            const double Fesc = log_pl_limit(lnM, m.ln_fesc_norm, m.alpha_esc, 10 * M_LN10, m.ln_Mlim_esc);
+            const double nion = exp(Fstar + Fesc - Mturn / exp(lnM) + lnM);
+            if (sigma1 < sigma_cond) { /* conditional_mf returns 0 */
+                node_pref[i] = 0.;
+                node_factor[i] = node_barrier[i] = node_sdi[i] = 0.;
+                continue;
+            }
+            const double sdi = sigma1 == sigma_cond ? 1e6 : 1 / (sigma1 * sigma1 - sigma_cond * sigma_cond);
+            node_sdi[i] = sdi;
+            node_pref[i] = nion * dsigmasqdm; /* the sign and the remaining factors follow below */
+            if (hmf == C21CM_HMF_ST)
+                node_factor[i] = st_taylor_factor(sigma1, sigma_cond, growthf, &node_barrier[i]);
+            else
+                node_factor[i] = node_barrier[i] = 0.;
+        }
+    }
+    for (int k = 0; k < n_delta; k++) {
+        const double delta = dmin + (float)k / ((float)n_delta - 1.) * (dmax - dmin);
+        double v;
+        if (!fast || delta > MAX_DELTAC_FRAC * get_delta_crit(hmf, sigma_cond, growthf)) {
+            v = c21_Nion_ConditionalM(growthf, lnMmin, lnMmax, lnMcond, sigma_cond, delta, Mturn, sc,
+                                      method);
+        } else {
+            double integral = 0;
+            for (int i = 1; i < NGL_INT + 1; i++) {
+                if (node_pref[i] == 0.) {
+                    integral += gl.w[i] * 0.;
+                    continue;
+                }
+                const double sdi = node_sdi[i];
+                double cmf;
+                if (hmf == C21CM_HMF_ST) {
+                    const double delta_0 = delta / growthf;
+                    const double factor = node_factor[i] - delta_0;
+                    const double B = node_barrier[i];
+                    cmf = factor * pow(sdi, 1.5) * exp(-(B - delta_0) * (B - delta_0) * 0.5 * sdi) /
+                          sqrt(2. * M_PI);
+                } else {
+                    const double del = (DELTA_C_SPH - delta) / growthf;
+                    cmf = del * pow(sdi, 1.5) * exp(-del * del * 0.5 * sdi) / sqrt(2. * M_PI);
+                }
+                integral += gl.w[i] * (-node_pref[i] * cmf);
+            }
+            v = integral;
+        }
+        double lv = log(v);
+        if (lv < -40.) lv = -40.;
+        if (!isfinite(lv)) return C21CM_TABLE_GENERATION_ERROR;
+        table[k] = (float)lv;
+    }
+    return 0;
 }
 
 /* hmf.c:1268-1316: mass beyond which F = FRAC (M/1e10)^PL would exceed 1 (float bisection) */

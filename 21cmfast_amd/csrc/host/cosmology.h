@@ -41,6 +41,17 @@ double c21_sigma_fast(double M); /* spline over a cached ln M table */
 double c21_Fcoll_General(double z, double lnM_min, double lnM_max);
 double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
                         const c21_scaling_consts *sc);
+/* N_ion per unit mass of a region of mass exp(lnM_cond), sigma2 and overdensity delta2
+ * (hmf.c:1106-1140); method 0 adaptive, 1 Gauss-Legendre (100 points) */
+double c21_Nion_ConditionalM(double growthf, double lnM1, double lnM2, double lnM_cond,
+                             double sigma2, double delta2, double Mturn,
+                             const c21_scaling_consts *sc, int method);
+/* ln N_ion(delta | M_cond) on n_delta overdensities in [dmin, dmax], floored at -40
+ * (interp_tables.c:291-405, 1-D table) */
+int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                               double sigma_cond, double dmin, double dmax, double Mturn,
+                               const c21_scaling_consts *sc, int method, float *table,
+                               int n_delta);
 int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc);
 double c21_minimum_source_mass(double redshift);
 int c21_recfast_load(void);

@@ -209,6 +209,65 @@ def test_ionized_box_const_ion_eff(gpu_lib, oracle, tmp_path, tables):
     assert np.all(out["prev_z_reion"] == -1)  # the first-snapshot previous box is initialised
 
 
+class ScalingConsts(C.Structure):
+    """mirror of c21_scaling_consts (csrc/host/cosmology.h)"""
+    _fields_ = [(k, C.c_double) for k in
+                ("fstar_10", "alpha_star", "fstar_7", "t_h", "t_star", "fesc_10", "alpha_esc",
+                 "fesc_7", "pop2_ion", "pop3_ion", "acg_thresh", "mturn_a_nofb", "Mlim_Fstar",
+                 "Mlim_Fesc")]
+
+
+def test_ionized_box_e_integral(gpu_lib, oracle, tmp_path):
+    """SOURCE_MODEL=E-INTEGRAL (the reference's `simple` template and its test-suite default,
+    tests/conftest.py:129-133): mass-dependent zeta, f_coll(delta) = exp(lerp(ln N_ion table)),
+    one 400-bin conditional-mass-function table per filter radius built on the host."""
+    lib = gpu_lib
+    ses = Session(lib, tmp_path, HII_DIM=32, SOURCE_MODEL=1, HII_FILTER=1, USE_EXP_FILTER=False,
+                  CELL_RECOMB=False, R_BUBBLE_MAX=12.0)
+    f64 = C.c_double
+    lib.c21_set_scaling_constants.restype = C.c_int
+    lib.c21_set_scaling_constants.argtypes = [f64, C.POINTER(ScalingConsts)]
+    lib.c21_Nion_General.restype = f64
+    lib.c21_Nion_General.argtypes = [f64, f64, f64, f64, C.POINTER(ScalingConsts)]
+    lib.c21_Nion_Conditional_table.restype = C.c_int
+    lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int,
+                                                           C.POINTER(C.c_float), C.c_int]
+    z = 9.0
+    density = W.density_field_numpy(32, seed=5, sigma=0.6)
+    out = call_ionize(lib, z, density, need_nion=True)
+    assert out["status"] == 0, lib.c21cm_last_error()
+
+    spec = ionize_spec_from_scalars(ses, z, lagrangian=False, tables=True)
+    sc = ScalingConsts()
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    M_min = lib.c21_minimum_source_mass(z)
+    assert M_min == pytest.approx(ses.ap.M_TURN / 50.0)
+    spec.fcoll_mode = W.FCOLL_TABLE_EXP
+    spec.mass_dep_zeta = 1
+    spec.ion_eff_factor = sc.pop2_ion * sc.fstar_10 * sc.fesc_10
+    spec.mean_f_coll = lib.c21_Nion_General(z, math.log(M_min), math.log(1e16), M_min, C.byref(sc))
+    spec.f_limit_acg = lib.c21_Nion_General(ses.so.Z_HEAT_MAX, math.log(M_min), math.log(1e16),
+                                            M_min, C.byref(sc))
+    spec.sigma_minmass = lib.c21_sigma_fast(M_min)
+
+    def table_fn(r_index, dmin, dmax, table, user):
+        M_R = lib.c21_RtoM(spec.R[r_index])
+        return lib.c21_Nion_Conditional_table(spec.growth_factor, math.log(M_min), math.log(M_R),
+                                              math.log(M_R), lib.c21_sigma_fast(M_R), dmin, dmax,
+                                              sc.mturn_a_nofb, C.byref(sc), 1, table,
+                                              S.NDELTA_TABLE)
+    cb = S.TABLE_FN(table_fn)
+    spec.table_fn = cb
+    ref = oracle.ionize_grids(spec, density, need_nion=True)
+    ion_g, ion_r = out["neutral_fraction"] == 0, ref["neutral_fraction"] == 0
+    assert np.mean(ion_g != ion_r) <= 2e-4
+    same = ion_g == ion_r
+    np.testing.assert_allclose(out["neutral_fraction"][same], ref["neutral_fraction"][same],
+                               rtol=1e-4, atol=5e-6)
+    assert 0.02 < ion_r.mean() < 0.98
+    assert out["mean_f_coll"] == pytest.approx(spec.mean_f_coll, rel=1e-12)
+
+
 def test_ionized_box_lagrangian(gpu_lib, oracle, tmp_path):
     ses = Session(gpu_lib, tmp_path, HII_DIM=32, SOURCE_MODEL=2, R_BUBBLE_MAX=12.0)
     z = 9.0
@@ -244,7 +303,7 @@ def test_ionized_box_early_exit_and_errors(gpu_lib, tmp_path):
     # unsupported options return ValueError (3), never crash
     # (the Session must stay alive: the library stores POINTERS to its structs, as the
     #  reference does -- InputParameters.c:11-20)
-    ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=1)
+    ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=1, USE_INTERPOLATION_TABLES=0)
     assert call_ionize(gpu_lib, 9.0, density, need_nion=True)["status"] == 3
     assert b"E-INTEGRAL" in gpu_lib.c21cm_last_error()
     ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=0, RECOMB_MODEL=2)

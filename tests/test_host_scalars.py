@@ -162,3 +162,112 @@ def test_recfast_spline(host, tmp_path):
     for zz in (9.0, 9.37, 123.456):
         assert host.c21_T_RECFAST(zz) == pytest.approx(float(cs_t(zz)), rel=1e-6)
     assert host.c21_xion_RECFAST(9.5) == pytest.approx(2e-4 + 9.5e-6, rel=1e-3)
+
+
+# ---- conditional mass function / E-INTEGRAL tables --------------------------
+class ScalingConsts(C.Structure):
+    """mirror of c21_scaling_consts (csrc/host/cosmology.h)"""
+    _fields_ = [(k, C.c_double) for k in
+                ("fstar_10", "alpha_star", "fstar_7", "t_h", "t_star", "fesc_10", "alpha_esc",
+                 "fesc_7", "pop2_ion", "pop3_ion", "acg_thresh", "mturn_a_nofb", "Mlim_Fstar",
+                 "Mlim_Fesc")]
+
+
+def _bind_conditional(lib):
+    f64 = C.c_double
+    lib.c21_Nion_ConditionalM.restype = f64
+    lib.c21_Nion_ConditionalM.argtypes = [f64] * 7 + [C.POINTER(ScalingConsts), C.c_int]
+    lib.c21_Nion_Conditional_table.restype = C.c_int
+    lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int,
+                                                           C.POINTER(C.c_float), C.c_int]
+    lib.c21_set_scaling_constants.restype = C.c_int
+    lib.c21_set_scaling_constants.argtypes = [f64, C.POINTER(ScalingConsts)]
+
+
+def _rebroadcast(host, pkg, **matter):
+    S = pkg.structs
+    keep = host._keep
+    keep["mo"] = S.default_matter_options(**matter)
+    host.Broadcast_struct_global_all(C.byref(keep["so"]), C.byref(keep["mo"]), C.byref(keep["cp"]),
+                                     C.byref(keep["ap"]), C.byref(keep["ao"]), C.byref(keep["ct"]))
+    host.init_ps()
+
+
+def test_conditional_collapsed_fraction_is_the_eps_erfc(host, pkg):
+    """With the Press-Schechter conditional mass function, n_ion(M) = M (flat f_*, f_esc = 1, no
+    turnover) makes Nion_ConditionalM the conditional collapsed fraction, whose closed form is
+    erfc((delta_c - delta) / D / sqrt(2 (sigma_min^2 - sigma_cond^2)))  (Bond+91, Lacey&Cole 93)."""
+    _bind_conditional(host)
+    _rebroadcast(host, pkg, HMF=0)
+    try:
+        sc = ScalingConsts(fstar_10=1.0, alpha_star=0.0, fesc_10=1.0, alpha_esc=0.0,
+                           Mlim_Fstar=1e30, Mlim_Fesc=1e30)
+        D = host.dicke(8.0)
+        Mmin, Mcond = 1e8, host.c21_RtoM(6.0)
+        s_min, s_c = host.c21_sigma_fast(Mmin), host.c21_sigma_fast(Mcond)
+        for delta in (-0.5, 0.0, 0.4, 0.9):
+            want = math.erfc((1.686 - delta) / D / math.sqrt(2 * (s_min**2 - s_c**2)))
+            for method, tol in ((0, 2e-4), (1, 2e-3)):
+                got = host.c21_Nion_ConditionalM(D, math.log(Mmin), math.log(Mcond),
+                                                 math.log(Mcond), s_c, delta, 0.0, C.byref(sc),
+                                                 method)
+                assert got == pytest.approx(want, rel=tol), (delta, method)
+    finally:
+        _rebroadcast(host, pkg)
+
+
+def test_conditional_nion_against_scipy(host, pkg):
+    """Sheth-Tormen conditional mass function (Taylor-expanded moving barrier) x the n_ion(M)
+    scaling relations, integrated by scipy with the library's own sigma(M)."""
+    _bind_conditional(host)
+    sc = ScalingConsts()
+    assert host.c21_set_scaling_constants(8.0, C.byref(sc)) == 0
+    D = host.dicke(8.0)
+    Mmin, Mcond, Mturn = 10**8.7 / 50, host.c21_RtoM(4.0), 10**8.7
+    s_c = host.c21_sigma_fast(Mcond)
+    a, b, c = 0.73, 0.34, 0.81
+
+    def cmf(lnM, delta):
+        M = math.exp(lnM)
+        s1, ds = host.c21_sigma_fast(M), host.dsigmasqdm_z0(M)
+        if s1 < s_c:
+            return 0.0
+        diff = s1 * s1 - s_c * s_c
+        dl = 1.686 / D
+        series, term = 0.0, 1.0
+        terms = [1.0]
+        for i in range(1, 6):
+            term = term * (-diff) / i * (c - i + 1) / (s1 * s1)
+            terms.append(term)
+        series = sum(reversed(terms))
+        p2 = b * (a * dl * dl / (s1 * s1)) ** (-c)
+        factor = math.sqrt(a) * dl * (1 + p2 * series) - delta / D
+        barrier = math.sqrt(a) * dl * (1 + p2)
+        return (-ds * factor * diff**-1.5 * math.exp(-((barrier - delta / D) ** 2) * 0.5 / diff)
+                / math.sqrt(2 * math.pi))
+
+    def nion(lnM):
+        def pl(norm, alpha, lim):
+            if (alpha > 0 and lnM > math.log(lim)) or (alpha < 0 and lnM < math.log(lim)):
+                return -math.log(norm)
+            return alpha * (lnM - 10 * math.log(10))
+        return math.exp(pl(sc.fstar_10, sc.alpha_star, sc.Mlim_Fstar)
+                        + pl(sc.fesc_10, sc.alpha_esc, sc.Mlim_Fesc) - Mturn / math.exp(lnM) + lnM)
+
+    for delta in (-0.6, 0.0, 0.7):
+        want, _ = integrate.quad(lambda x: nion(x) * cmf(x, delta), math.log(Mmin),
+                                 math.log(Mcond), limit=400, epsrel=1e-8)
+        for method, tol in ((0, 3e-4), (1, 2e-3)):
+            got = host.c21_Nion_ConditionalM(D, math.log(Mmin), math.log(Mcond), math.log(Mcond),
+                                             s_c, delta, Mturn, C.byref(sc), method)
+            assert got == pytest.approx(want, rel=tol), (delta, method)
+    # the 400-bin table (what calculate_fcoll_grid interpolates) holds ln of the same numbers
+    tab = (C.c_float * 400)()
+    assert host.c21_Nion_Conditional_table(D, math.log(Mmin), math.log(Mcond), math.log(Mcond), s_c,
+                                           -0.8, 1.4, Mturn, C.byref(sc), 1, tab, 400) == 0
+    for k in (0, 57, 200, 399):
+        delta = -0.8 + np.float32(k) / (np.float32(400) - 1.0) * 2.2
+        direct = host.c21_Nion_ConditionalM(D, math.log(Mmin), math.log(Mcond), math.log(Mcond),
+                                            s_c, float(delta), Mturn, C.byref(sc), 1)
+        assert tab[k] == pytest.approx(max(math.log(direct), -40.0), rel=2e-6, abs=2e-6)
+    assert np.all(np.diff(np.array(tab[:300])) > 0)  # more collapse in denser regions (delta < 0.85)
