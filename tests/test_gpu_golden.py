@@ -1,0 +1,53 @@
+"""GPU: the HIP path against the committed golden fixtures (tests/golden/*.npz) -- a fixed target
+that does not depend on rebuilding the oracle on the GPU box.  Tolerances are those of the
+parity tests (tests/test_gpu_ionize.py, test_gpu_fft_filter.py, test_gpu_perturb.py)."""
+
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+sys.path.insert(0, str(GOLDEN))
+import cases  # noqa: E402
+from test_golden import check_ionize  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def api(gpu_lib):
+    return importlib.import_module("21cmfast_amd.grid_api")
+
+
+@pytest.mark.parametrize("kind", ["lagrangian", "erfc"])
+def test_hip_ionize_matches_golden(api, kind):
+    gold = np.load(GOLDEN / f"ionize_{kind}_{cases.N_ION}.npz")
+    inp = {"density": gold["density"], "n_ion": gold["n_ion"]}
+
+    def run(spec, density, n_ion, need_nion):
+        buf, box, rep = api.ionize_grids(spec, density, n_ion)
+        return {"neutral_fraction": buf.neutral_fraction, "z_reion": buf.z_reion,
+                "kinetic_temperature": buf.kinetic_temperature, "report": rep}
+
+    out = cases.ionize_outputs(run, kind, inp)
+    check_ionize(out, gold, flag_tol=2e-4, rtol=1e-4, atol=5e-6)
+
+
+def test_hip_filters_match_golden(api):
+    gold = np.load(GOLDEN / "filters_delta.npz")
+    out = cases.filter_outputs(lambda box, L, ft, R, Rp: api.filter_grid(box, L, ft, R, Rp))
+    for k in gold.files:
+        scale = np.abs(gold[k]).max()
+        np.testing.assert_allclose(out[k], gold[k], rtol=1e-4, atol=3e-6 * scale, err_msg=k)
+
+
+def test_hip_ics_perturb_match_golden(api):
+    gold = np.load(GOLDEN / "ics_perturb.npz")
+    out = cases.ics_perturb_outputs(api.new_ics_arrays, api.ics_grids, api.perturb_grids,
+                                    gold["hires_density"])
+    for k, v in out.items():
+        scale = np.abs(gold[k]).max()
+        np.testing.assert_allclose(v, gold[k], rtol=1e-4, atol=3e-5 * scale, err_msg=k)
