@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "c21hip.h"
 #include "c21cm_abi.h"
@@ -113,6 +114,131 @@ cic_scatter_kernel(CicParams p, const float *__restrict__ dens, const float *__r
 #pragma unroll
                 for (int a = 0; a < 2; a++)
                     unsafeAtomicAdd(out + bx[a] + by[b] + bz[c], mass * (wx[a] * wy[b] * wz[c]));
+    }
+}
+
+// The same deposit with an LDS accumulation tile.  A workgroup owns a brick of SB[0] x SB[1] x
+// SB[2] source cells; their displaced positions mostly land within `halo` output cells of the
+// brick's own footprint, so the 8 weights of a particle go to an fp64 tile in LDS (ds_add_f64)
+// and the tile is flushed once with one global atomic per touched cell: with DIM = 2 HII_DIM
+// that is ~30x fewer global atomics, which at 38 G/s were 97 % of ComputePerturbedField.
+// Particles displaced beyond the halo take the direct global path, so the result does not
+// depend on the halo (fp64 summation order aside, as before).
+struct CicTileParams {
+    CicParams c;
+    int sb[3];       // brick size in source cells
+    int nb[3];       // bricks per axis
+    int td[3];       // tile extent in output cells (incl. halo and the +1 CIC neighbour)
+    int halo;
+};
+
+__global__ void __launch_bounds__(kBlock)
+cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
+                         const float *__restrict__ vx, const float *__restrict__ vy,
+                         const float *__restrict__ vz, const float *__restrict__ v2x,
+                         const float *__restrict__ v2y, const float *__restrict__ v2z,
+                         double *__restrict__ out) {
+    extern __shared__ double tile[];
+    const CicParams &p = q.c;
+    const int tcells = q.td[0] * q.td[1] * q.td[2];
+    const size_t sy = (size_t)p.out_dim[2], sx = (size_t)p.out_dim[1] * p.out_dim[2];
+    const int n_bricks = q.nb[0] * q.nb[1] * q.nb[2];
+    const int per_brick = q.sb[0] * q.sb[1] * q.sb[2];
+    for (int brick = blockIdx.x; brick < n_bricks; brick += gridDim.x) {
+        const int b0 = brick / (q.nb[1] * q.nb[2]);
+        const int b1 = (brick / q.nb[2]) % q.nb[1];
+        const int b2 = brick % q.nb[2];
+        const int s0[3] = {b0 * q.sb[0], b1 * q.sb[1], b2 * q.sb[2]};
+        int t0[3];  // output coordinate (unwrapped) of tile cell 0
+#pragma unroll
+        for (int a = 0; a < 3; a++) t0[a] = (int)floor((double)s0[a] * p.dim_ratio_out) - q.halo;
+        for (int c = threadIdx.x; c < tcells; c += kBlock) tile[c] = 0.;
+        __syncthreads();
+        for (int e = threadIdx.x; e < per_brick; e += kBlock) {
+            const int l0 = e / (q.sb[1] * q.sb[2]);
+            const int l1 = (e / q.sb[2]) % q.sb[1];
+            const int l2 = e % q.sb[2];
+            const int src[3] = {s0[0] + l0, s0[1] + l1, s0[2] + l2};
+            if (src[0] >= p.dens_dim[0] || src[1] >= p.dens_dim[1] || src[2] >= p.dens_dim[2])
+                continue;  // ragged last brick
+            const size_t t = (size_t)src[2] +
+                             (size_t)p.dens_dim[2] * ((size_t)src[1] + (size_t)p.dens_dim[1] * src[0]);
+            int ip[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+                ip[a] = wrap_idx((int)((double)src[a] * p.dim_ratio_vel + 0.5), p.vel_dim[a]);
+            const size_t vi = (size_t)ip[2] +
+                              (size_t)p.vel_dim[2] * ((size_t)ip[1] + (size_t)p.vel_dim[1] * ip[0]);
+            const float v[3] = {vx[vi], vy[vi], vz[vi]};
+            float v2[3] = {0.f, 0.f, 0.f};
+            if (p.lpt2) {
+                v2[0] = v2x[vi];
+                v2[1] = v2y[vi];
+                v2[2] = v2z[vi];
+            }
+            int ipos[3];
+            double w0[3], w1[3];
+            bool inside = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                double pos = (double)src[a];
+                pos += (double)v[a] * p.vdf[a];
+                if (p.lpt2) pos -= (double)v2[a] * p.vdf2[a];
+                pos *= p.dim_ratio_out;
+                const double fl = floor(pos);
+                ipos[a] = (int)fl;
+                const double dist = pos - (double)ipos[a];
+                w0[a] = 1. - dist;
+                w1[a] = dist;
+                const int rel = ipos[a] - t0[a];
+                inside = inside && rel >= 0 && rel + 1 < q.td[a];
+            }
+            const double mass = 1.0 + (double)dens[t] * p.init_growth;
+            const double wx[2] = {w0[0], w1[0]}, wy[2] = {w0[1], w1[1]}, wz[2] = {w0[2], w1[2]};
+            if (inside) {
+                const int base = ((ipos[0] - t0[0]) * q.td[1] + (ipos[1] - t0[1])) * q.td[2] +
+                                 (ipos[2] - t0[2]);
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int c = 0; c < 2; c++)
+                            __hip_atomic_fetch_add(&tile[base + (a * q.td[1] + b) * q.td[2] + c],
+                                                   mass * (wx[a] * wy[b] * wz[c]), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                size_t bx[2], by[2], bz[2];
+                bx[0] = (size_t)wrap_idx(ipos[0], p.out_dim[0]) * sx;
+                bx[1] = (size_t)wrap_idx(ipos[0] + 1, p.out_dim[0]) * sx;
+                by[0] = (size_t)wrap_idx(ipos[1], p.out_dim[1]) * sy;
+                by[1] = (size_t)wrap_idx(ipos[1] + 1, p.out_dim[1]) * sy;
+                bz[0] = (size_t)wrap_idx(ipos[2], p.out_dim[2]);
+                bz[1] = (size_t)wrap_idx(ipos[2] + 1, p.out_dim[2]);
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int a = 0; a < 2; a++)
+                            unsafeAtomicAdd(out + bx[a] + by[b] + bz[c],
+                                            mass * (wx[a] * wy[b] * wz[c]));
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < tcells; c += kBlock) {
+            const double val = tile[c];
+            if (val != 0.) {
+                const int c2 = c % q.td[2];
+                const int c1 = (c / q.td[2]) % q.td[1];
+                const int c0 = c / (q.td[1] * q.td[2]);
+                unsafeAtomicAdd(out + (size_t)wrap_idx(t0[0] + c0, p.out_dim[0]) * sx +
+                                    (size_t)wrap_idx(t0[1] + c1, p.out_dim[1]) * sy +
+                                    (size_t)wrap_idx(t0[2] + c2, p.out_dim[2]),
+                                val);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -241,6 +367,39 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
     p.init_growth = init_growth;
     p.lpt2 = lpt2;
     const size_t total = (size_t)dens_dim[0] * dens_dim[1] * dens_dim[2];
+    {
+        // LDS-tiled deposit unless disabled (C21CM_CIC=direct) or the grids are tiny
+        static int direct = -1;
+        if (direct < 0) {
+            const char *e = getenv("C21CM_CIC");
+            direct = (e && e[0] == 'd') ? 1 : 0;
+        }
+        if (!direct && total >= (size_t)1 << 15) {
+            CicTileParams q;
+            q.c = p;
+            q.halo = 2;
+            const int sb[3] = {16, 16, 32};
+            size_t tcells = 1;
+            int n_bricks = 1;
+            for (int a = 0; a < 3; a++) {
+                q.sb[a] = sb[a] < dens_dim[a] ? sb[a] : dens_dim[a];
+                q.nb[a] = (dens_dim[a] + q.sb[a] - 1) / q.sb[a];
+                q.td[a] = (int)ceil(q.sb[a] * p.dim_ratio_out) + 2 + 2 * q.halo;
+                tcells *= (size_t)q.td[a];
+                n_bricks *= q.nb[a];
+            }
+            const size_t lds = tcells * sizeof(double);
+            if (lds <= 64 * 1024) {
+                int blocks = n_bricks < 256 * 8 ? n_bricks : 256 * 8;
+                hipLaunchKernelGGL(cic_scatter_tiled_kernel, dim3(blocks), dim3(kBlock), lds,
+                                   (hipStream_t)stream, q, hires_density, vel[0], vel[1], vel[2],
+                                   lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr,
+                                   lpt2 ? vel2[2] : nullptr, out);
+                LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
     hipLaunchKernelGGL(cic_scatter_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
                        (hipStream_t)stream, p, hires_density, vel[0], vel[1], vel[2],
                        lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr,
