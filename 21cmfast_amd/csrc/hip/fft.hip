@@ -21,7 +21,6 @@
 #include "c21cm_abi.h"
 
 extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz);
-extern "C" int c21hip_native_fft_r2c(float *padded, int nx, int ny, int nz, void *stream);
 extern "C" int c21hip_native_fft_c2r(float *padded, int nx, int ny, int nz, void *stream);
 
 namespace {

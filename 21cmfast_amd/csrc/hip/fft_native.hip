@@ -1660,8 +1660,3 @@ extern "C" int c21hip_native_fft_c2r(float *padded, int nx, int ny, int nz, void
                                    1.0, 0, 0.f, 0.f, 0, stream);
 }
 
-extern "C" int c21hip_native_fft_r2c(float *padded, int nx, int ny, int nz, void *stream) {
-    (void)padded; (void)nx; (void)ny; (void)nz; (void)stream;
-    c21hip_set_error("native r2c is not implemented; fft.hip routes r2c through rocFFT");
-    return C21CM_VALUE_ERROR;
-}
