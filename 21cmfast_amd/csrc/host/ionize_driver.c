@@ -292,6 +292,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
  * process instead of repeating the pre-loop transforms. */
 static struct {
     int valid, nx, nz, ts;
+    int stars_r0_ready; /* stars_fil already holds the unfiltered emissivity in real space */
     const void *density, *n_ion, *xe;
     double factor;
 } g_spectra;
@@ -308,6 +309,7 @@ static int spectra_match(const ion_ctx *c, const PerturbedField *pf, const HaloB
 static void spectra_remember(const ion_ctx *c, const PerturbedField *pf, const HaloBox *halos,
                              const TsBox *ts) {
     g_spectra.valid = 1;
+    g_spectra.stars_r0_ready = 0;
     g_spectra.nx = c->nx;
     g_spectra.nz = c->nz;
     g_spectra.ts = c->s->use_ts_fluct;
@@ -502,15 +504,20 @@ done:
  * grid in real space (the density it tests is the unfiltered one, IonisationBox.c:1048), and
  * the mask of the larger radii, the barrier / partial ionisation at index 0 and the post-loop
  * sweep are one pass over the cells (c21hip_final_sweep). */
-static int final_step(ion_ctx *c, const unsigned char *mask) {
+static int final_prepare(ion_ctx *c) {
+    const c21cm_ionize_spec *s = c->s;
+    return c21hip_split_filter_c2r(c->stars_unf, c->stars_work, c->stars_fil,
+                                   2 * (long)(c->nz / 2 + 1), c->nx, c->ny, c->nz, s->box_len,
+                                   s->box_len_z, s->stars_filter, (float)s->R[0],
+                                   (float)s->mfp_meandens, 0, c->stream);
+}
+
+static int final_step(ion_ctx *c, const unsigned char *mask, int stars_ready) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     c21hip_ionize_args args;
     fill_args(&args, s, 0);
-    TRY(c21hip_split_filter_c2r(c->stars_unf, c->stars_work, c->stars_fil,
-                                2 * (long)(c->nz / 2 + 1), c->nx, c->ny, c->nz, s->box_len,
-                                s->box_len_z, s->stars_filter, (float)s->R[0],
-                                (float)s->mfp_meandens, 0, c->stream));
+    if (!stars_ready) TRY(final_prepare(c));
     TRY(c21hip_final_sweep(&args, s->stored_redshift, mask, c->stars_fil, c->density, c->prev_zre,
                            c->xH, c->zre, c->Tk, c->partials, c->scalars + SC_SUMS,
                            c->scalars + SC_XHSUM, (int *)(c->scalars + SC_FLAG), c->stream));
@@ -609,7 +616,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         for (int R_ct = spec->n_radii; R_ct--;) {
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
-                TRY(final_step(&c, c.mask));
+                TRY(final_step(&c, c.mask, 0));
                 mask_pending = 0;
                 break;
             }
@@ -678,6 +685,13 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
         if (R_ct < spec->r_lowest) break;
         TRY(one_radius(&c, R_ct, first_cross, R_ct - world));
     }
+    /* The rank that will run the finish step has one radius fewer than the busiest ranks: it
+     * uses that slack to transform the unfiltered emissivity for the cell-scale step, so that
+     * after the reduce only the final sweep remains. */
+    if (c.fused && spec->r_lowest == 0 && rank == (spec->n_radii - 1) % world) {
+        TRY(final_prepare(&c));
+        g_spectra.stars_r0_ready = 1;
+    }
     TRY(c21hip_event_record(ev[2], stream));
     if (report) {
         double means[C21CM_MAX_RADII];
@@ -714,12 +728,16 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
     for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
     TRY(c21hip_event_record(ev[0], stream));
     TRY(init_output_grids(&c, previous_ionize_box));
+    int stars_ready = 0;
     if (spec->r_lowest == 0) {
-        if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
+        if (spectra_match(&c, perturbed_field, halos, spin_temp))
+            stars_ready = g_spectra.stars_r0_ready;
+        else
+            TRY(preloop(&c));
         g_spectra.valid = 0;
     }
     if (c.fused && spec->r_lowest == 0) {
-        TRY(final_step(&c, first_cross));
+        TRY(final_step(&c, first_cross, stars_ready));
     } else {
         TRY(c21hip_apply_first_cross(first_cross, c.prev_zre, spec->first_snapshot,
                                      spec->redshift, c.xH, c.zre, c.ntot, stream));

@@ -215,6 +215,15 @@ def test_shard_phases_equal_single_pass(api):
     assert torch.equal(buf.kinetic_temperature, buf2.kinetic_temperature)
     assert rep.global_xH == rep2.global_xH
     assert box.mean_f_coll == box2.mean_f_coll
+    # world = 1: the only rank is the owner, so it transforms the emissivity for the cell-scale
+    # step at the end of its shard phase and the finish step reuses it
+    fc = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
+    api.ionize_shard_radii(spec, 0, 1, fc, density, n_ion)
+    buf3, box3, rep3 = api.ionize_shard_finish(spec, fc, density, n_ion)
+    torch.cuda.synchronize()
+    assert torch.equal(buf.neutral_fraction, buf3.neutral_fraction)
+    assert torch.equal(buf.kinetic_temperature, buf3.kinetic_temperature)
+    assert rep.global_xH == rep3.global_xH
 
 
 def test_full_size_properties(api):
