@@ -220,6 +220,10 @@ int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
                        const float *density, const float *prev_z_reion, float *xH, float *z_reion,
                        float *kinetic_temperature, double *partials, double *sum_stars_out,
                        double *sum_xh_out, int *flag_out, void *stream);
+/* delta_T (and tau_21) per cell + their sum (BrightnessTemperatureBox.c:58-87); partials: 2048 */
+int c21hip_brightness_temp(const float *density, const float *xH, const float *Ts, float *bt,
+                           float *tau, size_t n, float const_factor, float T_rad, double redshift,
+                           int use_ts, double *partials, double *sum_out, void *stream);
 int c21hip_apply_first_cross(const unsigned char *first_cross, const float *prev_z_reion,
                              int first_snapshot, double redshift, float *xH, float *z_reion,
                              size_t ntot, void *stream);

@@ -597,6 +597,30 @@ any_nonzero_kernel(const float *__restrict__ a, size_t n, int *flag) {
     if (found) atomicOr(flag, 1);
 }
 
+// ---- ComputeBrightnessTemp: BrightnessTemperatureBox.c:58-87 --------------------------------
+__global__ void __launch_bounds__(kBlock)
+brightness_kernel(const float *__restrict__ density, const float *__restrict__ xH,
+                  const float *__restrict__ Ts, float *__restrict__ bt, float *__restrict__ tau,
+                  size_t n, float const_factor, float T_rad, double redshift, int use_ts,
+                  double *__restrict__ partials) {
+    double acc = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock) {
+        // float arithmetic, left to right: (const_factor * x_HI) * (1 + delta)
+        float v = __fmul_rn(__fmul_rn(const_factor, xH[i]), __fadd_rn(1.f, density[i]));
+        if (use_ts) {
+            const float ts = Ts[i];
+            v = (float)((double)v * ((1. + redshift) / (1000. * (double)ts)));
+            tau[i] = v;
+            v = (float)((1. - exp(-(double)v)) * 1000. * (double)__fsub_rn(ts, T_rad) /
+                        (1. + redshift));
+        }
+        bt[i] = v;
+        acc += (double)v;
+    }
+    block_sum_to(acc, partials);
+}
+
 IoniseParams make_params(const c21hip_ionize_args *a, int vec) {
     IoniseParams p;
     p.a = *a;
@@ -833,6 +857,21 @@ extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_red
                        blocks, 0, sum_stars_out);
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, px,
                        blocks, 0, sum_xh_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_brightness_temp(const float *density, const float *xH, const float *Ts,
+                                      float *bt, float *tau, size_t n, float const_factor,
+                                      float T_rad, double redshift, int use_ts, double *partials,
+                                      double *sum_out, void *stream) {
+    const int blocks = grid_for(n);
+    hipLaunchKernelGGL(brightness_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                       density, xH, Ts, bt, tau, n, const_factor, T_rad, redshift, use_ts,
+                       partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, blocks, 0, sum_out);
     LAUNCH_CHECK();
     return 0;
 }

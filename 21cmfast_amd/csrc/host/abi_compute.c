@@ -19,7 +19,8 @@
  * mass-function tables per radius, PS / ST, Gauss-Legendre or adaptive quadrature; needs
  * USE_INTERPOLATION_TABLES = hmf-interpolation) and the Lagrangian models (L-INTEGRAL /
  * DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all HII_FILTER types,
- * USE_EXP_FILTER, MINIMIZE_MEMORY.  Returning ValueError (3) with a message in
+ * USE_EXP_FILTER, MINIMIZE_MEMORY; ComputeBrightnessTemp with or without spin temperatures.
+ * Returning ValueError (3) with a message in
  * c21cm_last_error(): E-INTEGRAL without interpolation tables or with the Gamma-function
  * approximation, USE_MINI_HALOS, recombination models, PHOTON_CONS_TYPE != none,
  * IONISE_ENTIRE_SPHERE, V_CB_MODEL = FLUCTS, CLASS transfer tables.
@@ -371,4 +372,26 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
 done:
     free(s);
     return st;
+}
+
+/* reference: src/py21cmfast/src/BrightnessTemperatureBox.c:22-105 */
+int ComputeBrightnessTemp(float redshift, TsBox *spin_temp, IonizedBox *ionized_box,
+                          PerturbedField *perturb_field, BrightnessTemp *box) {
+    int st = require_globals("ComputeBrightnessTemp", 1);
+    if (st) return st;
+    if (!ionized_box || !perturb_field || !box) return C21CM_VALUE_ERROR;
+    const SimulationOptions *so = simulation_options_global;
+    const CosmoParams *cp = cosmo_params_global;
+    c21cm_brightness_spec s;
+    memset(&s, 0, sizeof(s));
+    s.n_cells = (size_t)so->HII_DIM * so->HII_DIM * (size_t)(so->NON_CUBIC_FACTOR * so->HII_DIM);
+    s.redshift = redshift;
+    s.use_ts_fluct = astro_options_global->USE_TS_FLUCT;
+    s.T_rad = (float)(2.7255 * (1 + redshift)); /* physconst.T_cmb, Constants.c:25 */
+    s.const_factor = (float)(27 * (cp->OMb * cp->hlittle * cp->hlittle / 0.023) *
+                             sqrt((0.15 / (cp->OMm) / (cp->hlittle) / (cp->hlittle)) *
+                                  (1. + redshift) / 10.0));
+    return c21cm_brightness_grids(&s, perturb_field->density, ionized_box->neutral_fraction,
+                                  spin_temp ? spin_temp->spin_temperature : NULL,
+                                  box->brightness_temp, box->tau_21, NULL, NULL);
 }

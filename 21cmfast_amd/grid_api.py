@@ -230,3 +230,20 @@ def ics_grids(spec: S.IcsSpec, ics: dict | None = None, device=None, stream=None
     icss = ics_struct(ics)
     check(load().c21cm_ics_grids(C.byref(spec), C.byref(icss), _stream(stream)), "c21cm_ics_grids")
     return ics
+
+
+def brightness_grids(spec: S.BrightnessSpec, density, neutral_fraction, spin_temperature=None,
+                     stream=None) -> dict:
+    """ComputeBrightnessTemp sweep on the MI355X (reference:
+    src/py21cmfast/src/BrightnessTemperatureBox.c:22-105).  Outputs live where ``density`` lives.
+    Returns dict(brightness_temp[, tau_21], mean)."""
+    out = {"brightness_temp": _new_like(density, 0.0)}
+    if spec.use_ts_fluct:
+        out["tau_21"] = _new_like(density, 0.0)
+    mean = C.c_double()
+    check(load().c21cm_brightness_grids(C.byref(spec), _vptr(density), _vptr(neutral_fraction),
+                                        _vptr(spin_temperature), _vptr(out["brightness_temp"]),
+                                        _vptr(out.get("tau_21")), C.byref(mean), _stream(stream)),
+          "c21cm_brightness_grids")
+    out["mean"] = mean.value
+    return out

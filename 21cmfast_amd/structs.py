@@ -252,6 +252,37 @@ class IonizedBoxStruct(_Base):
     ]
 
 
+class BrightnessTempStruct(_Base):
+    _fields_ = [("brightness_temp", c_float_p), ("tau_21", c_float_p)]
+
+
+class BrightnessSpec(_Base):
+    """``c21cm_brightness_spec`` (include/c21cm_grid.h)."""
+
+    _fields_ = [
+        ("n_cells", C.c_size_t),
+        ("redshift", C.c_double),
+        ("const_factor", C.c_float),
+        ("T_rad", C.c_float),
+        ("use_ts_fluct", C.c_int),
+    ]
+
+
+def brightness_spec(n_cells, redshift, cosmo=None, use_ts_fluct=False) -> "BrightnessSpec":
+    """The two float constants of BrightnessTemperatureBox.c:43-49 for a CosmoParams struct
+    (default cosmology if None)."""
+    import numpy as np
+
+    cp = cosmo if cosmo is not None else default_cosmo_params()
+    z = np.float32(redshift)
+    omb, h, omm = np.float32(cp.OMb), np.float32(cp.hlittle), np.float32(cp.OMm)
+    const = 27 * (float(omb * h * h) / 0.023) * np.sqrt(
+        (0.15 / float(omm) / float(h) / float(h)) * (1.0 + float(z)) / 10.0)
+    t_rad = np.float32(2.7255 * float(np.float32(1) + z))
+    return BrightnessSpec(n_cells=n_cells, redshift=float(z), const_factor=float(np.float32(const)),
+                          T_rad=float(t_rad), use_ts_fluct=int(bool(use_ts_fluct)))
+
+
 TABLE_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.c_double, c_float_p, C.c_void_p)
 
 

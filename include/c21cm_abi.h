@@ -288,6 +288,11 @@ typedef struct IonizedBox { /* :87-100 */
     float *unnormalised_nion_mini;
 } IonizedBox;
 
+typedef struct BrightnessTemp { /* :102-105 */
+    float *brightness_temp;
+    float *tau_21; /* only with USE_TS_FLUCT */
+} BrightnessTemp;
+
 /* ------------------------------------------------------------------ */
 /* Exported entry points                                              */
 /* ------------------------------------------------------------------ */
@@ -319,6 +324,10 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
                       PerturbedField *previous_perturbed_field, IonizedBox *previous_ionize_box,
                       TsBox *spin_temp, HaloBox *halos, InitialConditions *ini_boxes,
                       IonizedBox *box);
+
+/* reference: src/py21cmfast/src/BrightnessTemperatureBox.c:22 (_functionprototypes_wrapper.h:28-29) */
+int ComputeBrightnessTemp(float redshift, TsBox *spin_temp, IonizedBox *ionized_box,
+                          PerturbedField *perturb_field, BrightnessTemp *box);
 
 /* reference: src/py21cmfast/src/filtering.c:397 (_functionprototypes_wrapper.h:130-131).
  * r2c -> /N -> filter_box -> c2r of one HII_DIM^3 box; `result` is float64[N]. */

@@ -182,6 +182,22 @@ typedef struct c21cm_ics_spec {
 
 int c21cm_ics_grids(const c21cm_ics_spec *spec, InitialConditions *ics, void *stream);
 
+/* ---- ComputeBrightnessTemp grid algorithm (BrightnessTemperatureBox.c:22-105) -----------
+ * delta_T = const_factor * x_HI * (1 + delta) [mK]; with spin temperatures additionally the
+ * optical depth tau_21 and (1 - exp(-tau)) (T_S - T_rad)/(1+z).  Arrays may be host or device.
+ * mean_out (optional): the box average the reference logs and checks for finiteness. */
+typedef struct c21cm_brightness_spec {
+    size_t n_cells;
+    double redshift;
+    float const_factor; /* 27 (Ob h^2/0.023) sqrt(0.15/(Om h^2) (1+z)/10), float as in :44-49 */
+    float T_rad;        /* T_cmb (1+z), float */
+    int use_ts_fluct;
+} c21cm_brightness_spec;
+
+int c21cm_brightness_grids(const c21cm_brightness_spec *spec, const float *density,
+                           const float *neutral_fraction, const float *spin_temperature,
+                           float *brightness_temp, float *tau_21, double *mean_out, void *stream);
+
 /* Library management */
 const char *c21cm_version(void);
 int c21cm_device_synchronize(void);

@@ -57,6 +57,11 @@ int oracle_perturb_grids(const c21cm_perturb_spec *spec, const InitialConditions
 /* oracle_ics.c -- reference: src/py21cmfast/src/InitialConditions.c */
 int oracle_ics_grids(const c21cm_ics_spec *spec, InitialConditions *ics);
 
+/* oracle_brightness.c -- reference: src/py21cmfast/src/BrightnessTemperatureBox.c:22-105 */
+int oracle_brightness_grids(const c21cm_brightness_spec *spec, const float *density,
+                            const float *neutral_fraction, const float *spin_temperature,
+                            float *brightness_temp, float *tau_21, double *mean_out);
+
 void oracle_set_threads(int n);
 
 #ifdef __cplusplus

@@ -59,6 +59,8 @@ def load():
         lib.oracle_partially_ionized_temperature.argtypes = [f32, f32, f32]
         lib.oracle_fgtrm_bias_fast.restype = f64
         lib.oracle_fgtrm_bias_fast.argtypes = [f32, f32, f32, f32, f64]
+        lib.oracle_brightness_grids.restype = i32
+        lib.oracle_brightness_grids.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         lib.oracle_set_threads.restype = None
         lib.oracle_set_threads.argtypes = [i32]
         for name, argt in (
@@ -201,6 +203,21 @@ def ics_grids(spec, ics: dict | None = None):
     if st:
         raise RuntimeError(f"oracle_ics_grids status {st}")
     return ics
+
+
+def brightness_grids(spec, density, neutral_fraction, spin_temperature=None):
+    """Oracle ComputeBrightnessTemp sweep; returns dict(brightness_temp[, tau_21], mean)."""
+    out = {"brightness_temp": np.zeros(density.shape, np.float32)}
+    if spec.use_ts_fluct:
+        out["tau_21"] = np.zeros(density.shape, np.float32)
+    mean = C.c_double()
+    st = load().oracle_brightness_grids(C.byref(spec), fptr(density), fptr(neutral_fraction),
+                                        fptr(spin_temperature), fptr(out["brightness_temp"]),
+                                        fptr(out.get("tau_21")), C.byref(mean))
+    if st:
+        raise RuntimeError(f"oracle_brightness_grids status {st}")
+    out["mean"] = mean.value
+    return out
 
 
 def gaussian_pair(counter: int, seed: int):
