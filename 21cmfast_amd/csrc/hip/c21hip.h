@@ -73,6 +73,15 @@ int c21hip_split_filter_xy2(const float *src_a, float *work_a, int filter_a, flo
 int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
                          float R_param_b, int nx, int ny, int nz, double box_len,
                          double box_len_z, float R, void *stream);
+/* pass Z of the filtered density + its extrema on the device (minmax_out[2]);
+ * partials: 2 * nx*ny/16 doubles (IonisationBox.c:668-699) */
+int c21hip_split_z_c2r_minmax(const float *split_work, float *real_out, long out_zstride, int nx,
+                              int ny, int nz, double *partials, double *minmax_out, void *stream);
+/* pass Z fused with the CONST-ION-EFF closed-form f_coll(delta_R): dense f_coll grid + sum
+ * (IonisationBox.c:785-961, hmf.c:1205-1241); partials: 2 * nx*ny/16 doubles */
+int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_dense, int nx, int ny, int nz,
+                              double growthf, double sigma_min, double sigma_max, double delta_c,
+                              double *partials, double *sum_out, void *stream);
 int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstride, int nx, int ny,
                        int nz, void *stream);
 /* Fused pass Z of delta_R and the filtered emissivity + sum(stars) + ionisation barrier for
@@ -90,6 +99,8 @@ int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, float R, floa
                       double box_len, int reps, void *stream, float *ms_out);
 /* deterministic single-workgroup sum of n doubles (ionize_kernels.hip) */
 int c21hip_reduce_sum(const double *partials, int n, double *out, void *stream);
+/* op 1 = min, 2 = max of n doubles */
+int c21hip_reduce_op(const double *partials, int n, int op, double *out, void *stream);
 
 /* ---- grid_kernels.hip : generic sweeps ---- */
 /* padded[l][k] = clip(dense[l][k] * factor, lo, hi); pad columns zeroed.
@@ -213,6 +224,10 @@ int c21hip_neutral_box(const float *density, const float *xe, const float *Tneut
                        void *stream);
 int c21hip_any_nonzero(const float *a, size_t n, int *flag_host, void *stream);
 /* xH/z_reion from a max-reduced first_cross mask (multi-GPU tail). */
+/* Eulerian barrier test on the dense f_coll grid, first crossing into a uint8 mask
+ * (radius index > 0, no x_e grid; IonisationBox.c:1022-1027,1077,1118) */
+int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
+                         const double *mean_dev, unsigned char *first_cross, void *stream);
 /* mask of radii > 0 + radius index 0 + post-loop sweep of the fused Lagrangian path in one pass
  * (IonisationBox.c:1031-1256,1597-1608); partials: 2 * 2048 doubles; writes every z_reion */
 int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,

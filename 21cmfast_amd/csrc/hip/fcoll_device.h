@@ -1,0 +1,55 @@
+// fcoll_device.h -- per-cell collapsed-fraction helpers of the Eulerian source models, shared by
+// ionize_kernels.hip (stand-alone sweep) and fft_native.hip (fused into pass Z).
+#ifndef C21HIP_FCOLL_DEVICE_H
+#define C21HIP_FCOLL_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+namespace {
+constexpr double kFractFloatErr = 1e-7;  // reference: Constants.h FRACT_FLOAT_ERR
+
+// reference: hmf.c:1187-1203 (float in, double polynomial, float out)
+__device__ __forceinline__ float erfcc_f(float x) {
+    const double q = fabs((double)x);
+    const double t = 1.0 / (1.0 + 0.5 * q);
+    const double ans =
+        t * exp(-q * q - 1.2655122 +
+                t * (1.0000237 +
+                     t * (0.374092 +
+                          t * (0.0967842 +
+                               t * (-0.1862881 +
+                                    t * (0.2788681 +
+                                         t * (-1.13520398 +
+                                              t * (1.4885159 +
+                                                   t * (-0.82215223 + t * 0.17087277)))))))));
+    return (float)(x >= 0.0f ? ans : 2.0 - ans);
+}
+
+// reference: hmf.c:1205-1241.  sig (from the float sigmas) is precomputed on the host.
+__device__ __forceinline__ double fgtrm_bias_fast(float growthf, float del_bias, double sig,
+                                                  double delta_c) {
+    const double del = (delta_c - (double)del_bias) / (double)growthf;
+    const double x = del / (sqrt(2.) * sig);
+    if (x < 0) return 1.0;
+    return (double)erfcc_f((float)x);
+}
+
+// reference: interpolation.c:123-131
+__device__ __forceinline__ double eval_table_f(double x, double x_min, double x_width,
+                                               const float *y_arr) {
+    const int idx = (int)floor((x - x_min) / x_width);
+    const double table_val = x_min + x_width * (double)(float)idx;
+    const double interp_point = (x - table_val) / x_width;
+    return (double)y_arr[idx] * (1 - interp_point) + (double)y_arr[idx + 1] * interp_point;
+}
+
+// both clips applied to the filtered density, IonisationBox.c:689 then :803
+__device__ __forceinline__ float clip_delta_eulerian(float v) {
+    v = fmaxf((float)fmin((double)v, 1e6), -1.f);
+    return fmaxf(v, (float)(-1. + kFractFloatErr));
+}
+__device__ __forceinline__ float clip_delta(float v) {
+    return fmaxf(v, (float)(-1. + kFractFloatErr));
+}
+}  // namespace
+#endif

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "c21hip.h"
+#include "fcoll_device.h"
 #include "c21cm_abi.h"
 
 namespace {
@@ -786,6 +787,11 @@ struct ZPassArgs {
     float *out;          // real rows of out_zstride floats
     long out_zstride;
     float out_scale;
+    // epilogues of the Eulerian source models (EPI 1, 2)
+    double *p0, *p1;     // per-workgroup partials: EPI 1 min / max, EPI 2 sum (p0)
+    float *f_out;        // EPI 2: dense f_coll grid [lines][NZ]
+    float growthf;       // EPI 2: FgtrM_bias_fast parameters (hmf.c:1205-1241)
+    double sig, delta_c;
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -850,7 +856,12 @@ __device__ __forceinline__ void z_transform(float2 *tile, const float2 *twH, con
     fft_tile<H, LZ, ZROW, +1, kBlock>(tile, twH);
 }
 
-template <int NZ>
+// EPI 0: store the real lines.  EPI 1: store them and emit the workgroup's min / max (the
+// extrema the host needs for the per-radius f_coll table, IonisationBox.c:668-699).  EPI 2:
+// CONST-ION-EFF closed form: f_coll(delta_R) per cell straight from the tile (clips of
+// :689,803, FgtrM_bias_fast) to the dense grid + the workgroup's partial of its sum (:785-961);
+// the filtered density itself is never written.
+template <int NZ, int EPI>
 __global__ void __launch_bounds__(kBlock)
 z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
              const float2 *__restrict__ twN_global) {
@@ -867,6 +878,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     z_issue_loads<NZ, LZ>(a.main, l0, reg);
     z_transform<NZ, LZ>(tile, twH, twN, reg, a.nyq, l0);
     // ---- store: lanes along j, one float2 = (x[2j], x[2j+1])
+    double acc0 = 0., acc1 = 0.;
 #pragma unroll
     for (int u = 0; u < ZGeom<NZ, LZ>::NOUT; u++) {
         const int f = threadIdx.x + kBlock * u;
@@ -876,7 +888,44 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             v.x *= a.out_scale;
             v.y *= a.out_scale;
         }
-        reinterpret_cast<float2 *>(a.out + (l0 + li) * a.out_zstride)[j] = v;
+        if (EPI == 2) {
+            const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast(a.growthf, clip_delta_eulerian(v.x), a.sig, a.delta_c);
+            const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast(a.growthf, clip_delta_eulerian(v.y), a.sig, a.delta_c);
+            acc0 += f0;
+            acc0 += f1;
+            reinterpret_cast<float2 *>(a.f_out + (l0 + li) * NZ)[j] = make_float2((float)f0, (float)f1);
+        } else {
+            reinterpret_cast<float2 *>(a.out + (l0 + li) * a.out_zstride)[j] = v;
+            if (EPI == 1) {
+                const double lo = fmin((double)v.x, (double)v.y), hi = fmax((double)v.x, (double)v.y);
+                acc0 = (u == 0) ? lo : fmin(acc0, lo);
+                acc1 = (u == 0) ? hi : fmax(acc1, hi);
+            }
+        }
+    }
+    if (EPI != 0) {
+        __shared__ double red0[kBlock / 64], red1[kBlock / 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
+            acc0 = (EPI == 2) ? acc0 + o0 : fmin(acc0, o0);
+            acc1 = fmax(acc1, o1);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red0[threadIdx.x >> 6] = acc0;
+            red1[threadIdx.x >> 6] = acc1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r0 = red0[0], r1 = red1[0];
+#pragma unroll
+            for (int w = 1; w < kBlock / 64; w++) {
+                r0 = (EPI == 2) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r1 = fmax(r1, red1[w]);
+            }
+            a.p0[blockIdx.x] = r0;
+            if (EPI == 1) a.p1[blockIdx.x] = r1;
+        }
     }
 }
 
@@ -1183,7 +1232,7 @@ int dispatch_line_pass(int n, const LinePassArgs &a, int fmode, hipStream_t stre
     }
 }
 
-template <int NZ>
+template <int NZ, int EPI = 0>
 int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
     constexpr int H = NZ / 2;
     const float2 *twH = twiddles(H);
@@ -1192,12 +1241,12 @@ int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
     const size_t lds = sizeof(float2) * ((size_t)H * (LZ_PLAIN + 1) + H + H / 2 + 1);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)z_c2r_kernel<NZ>,
+        (void)hipFuncSetAttribute((const void *)z_c2r_kernel<NZ, EPI>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((z_c2r_kernel<NZ>), dim3((unsigned)(nlines / LZ_PLAIN)), dim3(kBlock), lds, stream,
-                       a, twH, twN);
+    hipLaunchKernelGGL((z_c2r_kernel<NZ, EPI>), dim3((unsigned)(nlines / LZ_PLAIN)), dim3(kBlock),
+                       lds, stream, a, twH, twN);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1267,14 +1316,15 @@ int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
     }
 }
 
+template <int EPI = 0>
 int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) {
     switch (nz) {
-        case 64: return launch_z_c2r<64>(a, nlines, stream);
-        case 128: return launch_z_c2r<128>(a, nlines, stream);
-        case 256: return launch_z_c2r<256>(a, nlines, stream);
-        case 512: return launch_z_c2r<512>(a, nlines, stream);
-        case 1024: return launch_z_c2r<1024>(a, nlines, stream);
-        case 2048: return launch_z_c2r<2048>(a, nlines, stream);
+        case 64: return launch_z_c2r<64, EPI>(a, nlines, stream);
+        case 128: return launch_z_c2r<128, EPI>(a, nlines, stream);
+        case 256: return launch_z_c2r<256, EPI>(a, nlines, stream);
+        case 512: return launch_z_c2r<512, EPI>(a, nlines, stream);
+        case 1024: return launch_z_c2r<1024, EPI>(a, nlines, stream);
+        case 2048: return launch_z_c2r<2048, EPI>(a, nlines, stream);
         default:
             c21hip_set_error("native FFT: unsupported z length %d", nz);
             return C21CM_VALUE_ERROR;
@@ -1529,6 +1579,58 @@ extern "C" int c21hip_split_z_c2r(const float *split_work, float *real_out, long
     z.out_zstride = out_zstride;
     z.out_scale = 1.0f;
     return dispatch_z_c2r(nz, z, nlines, (hipStream_t)stream);
+}
+
+// Pass Z of the filtered density + its extrema (Eulerian source models with a per-radius
+// table).  partials: 2 * nx*ny/16 doubles; minmax_out[2] on the device.
+extern "C" int c21hip_split_z_c2r_minmax(const float *split_work, float *real_out,
+                                         long out_zstride, int nx, int ny, int nz,
+                                         double *partials, double *minmax_out, void *stream) {
+    const long nlines = (long)nx * ny;
+    const int nb = (int)(nlines / LZ_PLAIN);
+    ZPassArgs z{};
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out = real_out;
+    z.out_zstride = out_zstride;
+    z.out_scale = 1.0f;
+    z.p0 = partials;
+    z.p1 = partials + nb;
+    int st = dispatch_z_c2r<1>(nz, z, nlines, (hipStream_t)stream);
+    if (st) return st;
+    if ((st = c21hip_reduce_op(z.p0, nb, 1, minmax_out, stream))) return st;
+    return c21hip_reduce_op(z.p1, nb, 2, minmax_out + 1, stream);
+}
+
+// Pass Z of the filtered density fused with the CONST-ION-EFF closed-form f_coll(delta_R):
+// writes the dense f_coll grid and its sum.  partials: >= 2 * nx*ny/16 doubles.
+extern "C" int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_dense, int nx,
+                                         int ny, int nz, double growthf, double sigma_min,
+                                         double sigma_max, double delta_c, double *partials,
+                                         double *sum_out, void *stream) {
+    const long nlines = (long)nx * ny;
+    ZPassArgs z{};
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out_scale = 1.0f;
+    z.f_out = nion_dense;
+    z.p0 = partials;
+    z.growthf = (float)growthf;
+    z.delta_c = delta_c;
+    z.sig = -1.;
+    {
+        // hmf.c:1221-1232: float sigmas, float products, double sqrt
+        const float ss = (float)sigma_min, sl = (float)sigma_max;
+        if (sl > ss) {
+            c21hip_set_error("FgtrM requested in a region where M_min > M_max (sigma %g > %g)",
+                             (double)sl, (double)ss);
+            return C21CM_VALUE_ERROR;
+        }
+        if (sl != ss) z.sig = sqrt((double)(ss * ss - sl * sl));
+    }
+    int st = dispatch_z_c2r<2>(nz, z, nlines, (hipStream_t)stream);
+    if (st) return st;
+    return c21hip_reduce_sum(partials, (int)(nlines / LZ_PLAIN), sum_out, stream);
 }
 
 // Inverse transform of a split spectrum: passes X, Y, Z.

@@ -24,11 +24,11 @@
 #include "c21hip.h"
 #include "c21cm_abi.h"
 #include "c21cm_grid.h"
+#include "fcoll_device.h"
 
 namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 256 * 8;
-constexpr double kFractFloatErr = 1e-7;  // reference: Constants.h FRACT_FLOAT_ERR
 constexpr double kTiny = 1e-30;          // reference: Constants.h TINY
 constexpr double kMinDensityLowLimit = 9e-8;  // reference: thermochem.c:16
 
@@ -143,49 +143,6 @@ __device__ float fully_ionized_T(float z_re, float z, float delta, double pow_Tr
     return result;
 }
 
-// reference: hmf.c:1187-1203 (float in, double polynomial, float out)
-__device__ __forceinline__ float erfcc_f(float x) {
-    const double q = fabs((double)x);
-    const double t = 1.0 / (1.0 + 0.5 * q);
-    const double ans =
-        t * exp(-q * q - 1.2655122 +
-                t * (1.0000237 +
-                     t * (0.374092 +
-                          t * (0.0967842 +
-                               t * (-0.1862881 +
-                                    t * (0.2788681 +
-                                         t * (-1.13520398 +
-                                              t * (1.4885159 +
-                                                   t * (-0.82215223 + t * 0.17087277)))))))));
-    return (float)(x >= 0.0f ? ans : 2.0 - ans);
-}
-
-// reference: hmf.c:1205-1241.  sig (from the float sigmas) is precomputed on the host.
-__device__ __forceinline__ double fgtrm_bias_fast(float growthf, float del_bias, double sig,
-                                                  double delta_c) {
-    const double del = (delta_c - (double)del_bias) / (double)growthf;
-    const double x = del / (sqrt(2.) * sig);
-    if (x < 0) return 1.0;
-    return (double)erfcc_f((float)x);
-}
-
-// reference: interpolation.c:123-131
-__device__ __forceinline__ double eval_table_f(double x, double x_min, double x_width,
-                                               const float *y_arr) {
-    const int idx = (int)floor((x - x_min) / x_width);
-    const double table_val = x_min + x_width * (double)(float)idx;
-    const double interp_point = (x - table_val) / x_width;
-    return (double)y_arr[idx] * (1 - interp_point) + (double)y_arr[idx + 1] * interp_point;
-}
-
-// both clips applied to the filtered density, IonisationBox.c:689 then :803
-__device__ __forceinline__ float clip_delta_eulerian(float v) {
-    v = fmaxf((float)fmin((double)v, 1e6), -1.f);
-    return fmaxf(v, (float)(-1. + kFractFloatErr));
-}
-__device__ __forceinline__ float clip_delta(float v) {
-    return fmaxf(v, (float)(-1. + kFractFloatErr));
-}
 __device__ __forceinline__ float clip_xe(float v) { return fminf(fmaxf(v, 0.f), 0.999f); }
 
 // ---- index helper: item i -> (padded element index, dense element index), VEC cells each
@@ -421,6 +378,44 @@ ionise_eulerian_kernel(IoniseParams p, const float *__restrict__ nion_dense,
                 }
             }
         }
+    }
+}
+
+// Eulerian source models, radius index > 0, no x_e grid: the barrier test of
+// find_ionised_regions (IonisationBox.c:1022-1027,1077,1118) on the dense f_coll grid, recording
+// only the first crossing (uint8 mask) like the fused Lagrangian path.  4 cells per thread.
+__global__ void __launch_bounds__(kBlock)
+eulerian_mask_kernel(c21hip_ionize_args a, const float *__restrict__ nion_dense,
+                     const double *__restrict__ mean_dev, unsigned char *__restrict__ first_cross,
+                     size_t ntot) {
+    const double mean_fix = a.fix_mean ? a.mean_f_coll / *mean_dev : 1.;
+    const size_t n4 = ntot / 4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * kBlock) {
+        const float4 f = reinterpret_cast<const float4 *>(nion_dense)[i];
+        uchar4 m = reinterpret_cast<const uchar4 *>(first_cross)[i];
+        const float fv[4] = {f.x, f.y, f.z, f.w};
+        unsigned char mv[4] = {m.x, m.y, m.z, m.w};
+        bool changed = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            double curr_fcoll = mean_fix * (double)fv[e];
+            if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
+            if (curr_fcoll * a.ion_eff_factor > 1. && mv[e] == 0) {
+                mv[e] = (unsigned char)a.r_index;
+                changed = true;
+            }
+        }
+        if (changed)
+            reinterpret_cast<uchar4 *>(first_cross)[i] = make_uchar4(mv[0], mv[1], mv[2], mv[3]);
+    }
+    // ragged tail (ntot not a multiple of 4)
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        double curr_fcoll = mean_fix * (double)nion_dense[i];
+        if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
+        if (curr_fcoll * a.ion_eff_factor > 1. && first_cross[i] == 0)
+            first_cross[i] = (unsigned char)a.r_index;
     }
 }
 
@@ -741,6 +736,14 @@ extern "C" int c21hip_reduce_sum(const double *partials, int n, double *out, voi
     return 0;
 }
 
+// op 1 = min, 2 = max over n doubles (single workgroup)
+extern "C" int c21hip_reduce_op(const double *partials, int n, int op, double *out, void *stream) {
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, n, op, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int c21hip_finish_mean(const double *sum_dev, double ntot, int mass_dep_zeta,
                                   double f_limit, double *mean_dev, void *stream) {
     hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sum_dev, ntot,
@@ -812,6 +815,16 @@ extern "C" int c21hip_ionise_eulerian(const c21hip_ionize_args *a, const float *
     DISPATCH_IONISE(ionise_eulerian_kernel, p, nion_dense, xe_fil, density, prev_z_reion,
                     kinetic_temp_neutral, mean_dev, xH, z_reion, kinetic_temperature,
                     first_cross);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
+                                    const double *mean_dev, unsigned char *first_cross,
+                                    void *stream) {
+    const size_t ntot = (size_t)a->nx * a->ny * a->nz;
+    hipLaunchKernelGGL(eulerian_mask_kernel, dim3(grid_for(ntot / 4 + 1)), dim3(kBlock), 0,
+                       (hipStream_t)stream, *a, nion_dense, mean_dev, first_cross, ntot);
     LAUNCH_CHECK();
     return 0;
 }

@@ -207,6 +207,9 @@ typedef struct {
     int fused;           /* fused pass Z + barrier available for radius index > 0 */
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
+    int eul_mask;        /* Eulerian models on the native passes without an x_e grid: radii > 0
+                          * run pass Z fused with f_coll (or its extrema) and only update the
+                          * first-crossing mask */
     copyback_list cb;
 } ion_ctx;
 
@@ -255,6 +258,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     /* Lagrangian grids without the x_e grid: passes Z of both grids, the f_coll sum and the
      * barrier test run as one kernel that only updates a uint8 first-crossing mask */
     c->fused = c->native && c->lagrangian && !s->use_ts_fluct;
+    c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct;
     c->scalars = (double *)c21hip_ws(WS_SCALARS, SC_COUNT * sizeof(double));
     c->table_dev = (float *)c21hip_ws(WS_TABLE, C21CM_NDELTA_TABLE * sizeof(float));
     if (!c->scalars || !c->table_dev) return C21CM_MEMORY_ALLOC_ERROR;
@@ -450,6 +454,42 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                mean_dev, c->stream));
         goto done;
     }
+    if (c->eul_mask && first_cross && R_ct > 0) {
+        const int zs = 2 * (c->nz / 2 + 1);
+        TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
+                                   s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+        if (s->fcoll_mode == C21CM_FCOLL_ERFC) {
+            TRY(c21hip_split_z_fcoll_erfc(c->delta_work, c->nion_dense, c->nx, c->ny, c->nz,
+                                          s->growth_factor, s->sigma_minmass,
+                                          s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev,
+                                          c->stream));
+        } else {
+            double mm[2];
+            float table[C21CM_NDELTA_TABLE];
+            TRY(c21hip_split_z_c2r_minmax(c->delta_work, c->delta_fil, zs, c->nx, c->ny, c->nz,
+                                          partials, c->scalars + SC_MINMAX, c->stream));
+            TRY(c21hip_d2h(mm, c->scalars + SC_MINMAX, sizeof(mm), c->stream));
+            TRY(c21hip_sync(c->stream));
+            const double min_density = mm[0] - 0.001, max_density = mm[1] + 0.001;
+            int tst = s->table_fn(R_ct, min_density, max_density, table, s->table_user);
+            if (tst) {
+                c21hip_set_error("ionize: table_fn failed with status %d at radius %d", tst, R_ct);
+                status = tst;
+                goto done;
+            }
+            TRY(c21hip_h2d(c->table_dev, table, sizeof(table), c->stream));
+            TRY(c21hip_sync(c->stream)); /* `table` is a stack buffer */
+            TRY(c21hip_fcoll_eulerian(c->delta_fil, c->nion_dense, c->nx, c->ny, c->nz,
+                                      s->fcoll_mode, s->growth_factor, s->sigma_minmass,
+                                      s->sigma_maxmass[R_ct], s->delta_c, min_density,
+                                      (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
+                                      c->table_dev, partials, sum_dev, c->stream));
+        }
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               mean_dev, c->stream));
+        TRY(c21hip_eulerian_mask(&args, c->nion_dense, mean_dev, first_cross, c->stream));
+        goto done;
+    }
     TRY(filter_to_real(c, c->delta_unf, c->delta_work, c->delta_fil, s->hii_filter, R, 0.f,
                        apply));
     if (c->lagrangian)
@@ -603,7 +643,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
     TRY(init_output_grids(&c, previous_ionize_box));
     TRY(preloop(&c));
     TRY(c21hip_event_record(ev[1], stream));
-    if (c.fused) {
+    if (c.fused || c.eul_mask) {
         c.mask = (unsigned char *)c21hip_ws(WS_FIRST_CROSS, c.ntot);
         if (!c.mask) {
             status = C21CM_MEMORY_ALLOC_ERROR;
@@ -612,15 +652,21 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         TRY(c21hip_memset(c.mask, 0, c.ntot, stream));
     }
     {
-        int mask_pending = c.fused;
+        const int use_mask = c.fused || c.eul_mask;
+        int mask_pending = use_mask;
         for (int R_ct = spec->n_radii; R_ct--;) {
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
-                TRY(final_step(&c, c.mask, 0));
                 mask_pending = 0;
-                break;
+                if (c.fused) {
+                    TRY(final_step(&c, c.mask, 0));
+                    break;
+                }
+                /* the cell-scale radius tests xH > TINY: materialise the mask first */
+                TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot,
+                                             spec->redshift, c.xH, c.zre, c.ntot, stream));
             }
-            TRY(one_radius(&c, R_ct, (R_ct > 0 && c.fused) ? c.mask : NULL,
+            TRY(one_radius(&c, R_ct, (R_ct > 0 && use_mask) ? c.mask : NULL,
                            (R_ct - 1 >= spec->r_lowest) ? R_ct - 1 : -1));
         }
         if (mask_pending)
