@@ -34,6 +34,17 @@ __device__ __forceinline__ double fgtrm_bias_fast(float growthf, float del_bias,
     return (double)erfcc_f((float)x);
 }
 
+// The same with the two cell-independent divisions turned into multiplications by
+// inv = 1 / (growthf * sqrt(2) * sig), computed once on the host in double: the argument x
+// agrees with the two-division form to 2 ulp (double) before it is rounded to float, so the
+// float handed to erfcc differs for about one cell in 1e8.  The sweep is fp64-ALU bound and
+// a division costs as much as the whole polynomial.
+__device__ __forceinline__ double fgtrm_bias_fast_inv(float del_bias, double inv, double delta_c) {
+    const double x = (delta_c - (double)del_bias) * inv;
+    if (x < 0) return 1.0;
+    return (double)erfcc_f((float)x);
+}
+
 // reference: interpolation.c:123-131
 __device__ __forceinline__ double eval_table_f(double x, double x_min, double x_width,
                                                const float *y_arr) {

@@ -790,8 +790,8 @@ struct ZPassArgs {
     // epilogues of the Eulerian source models (EPI 1, 2)
     double *p0, *p1;     // per-workgroup partials: EPI 1 min / max, EPI 2 sum (p0)
     float *f_out;        // EPI 2: dense f_coll grid [lines][NZ]
-    float growthf;       // EPI 2: FgtrM_bias_fast parameters (hmf.c:1205-1241)
-    double sig, delta_c;
+    double sig, delta_c;  // EPI 2: FgtrM_bias_fast (hmf.c:1205-1241); sig holds
+                          // 1 / (growthf sqrt(2) sigma), < 0 when the sigmas coincide
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -889,8 +889,8 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             v.y *= a.out_scale;
         }
         if (EPI == 2) {
-            const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast(a.growthf, clip_delta_eulerian(v.x), a.sig, a.delta_c);
-            const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast(a.growthf, clip_delta_eulerian(v.y), a.sig, a.delta_c);
+            const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
+            const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
             acc0 += f0;
             acc0 += f1;
             reinterpret_cast<float2 *>(a.f_out + (l0 + li) * NZ)[j] = make_float2((float)f0, (float)f1);
@@ -1615,7 +1615,6 @@ extern "C" int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_de
     z.out_scale = 1.0f;
     z.f_out = nion_dense;
     z.p0 = partials;
-    z.growthf = (float)growthf;
     z.delta_c = delta_c;
     z.sig = -1.;
     {
@@ -1626,7 +1625,8 @@ extern "C" int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_de
                              (double)sl, (double)ss);
             return C21CM_VALUE_ERROR;
         }
-        if (sl != ss) z.sig = sqrt((double)(ss * ss - sl * sl));
+        if (sl != ss)
+            z.sig = 1.0 / ((double)(float)growthf * (sqrt(2.) * sqrt((double)(ss * ss - sl * sl))));
     }
     int st = dispatch_z_c2r<2>(nz, z, nlines, (hipStream_t)stream);
     if (st) return st;
