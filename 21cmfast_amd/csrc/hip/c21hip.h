@@ -99,8 +99,9 @@ int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, float R, floa
                       double box_len, int reps, void *stream, float *ms_out);
 /* deterministic single-workgroup sum of n doubles (ionize_kernels.hip) */
 int c21hip_reduce_sum(const double *partials, int n, double *out, void *stream);
-/* op 1 = min, 2 = max of n doubles */
-int c21hip_reduce_op(const double *partials, int n, int op, double *out, void *stream);
+/* op 1 = min, 2 = max of n doubles; stage: >= n/1024 + 1 doubles of scratch for long inputs */
+int c21hip_reduce_op(const double *partials, int n, int op, double *stage, double *out,
+                     void *stream);
 
 /* ---- grid_kernels.hip : generic sweeps ---- */
 /* padded[l][k] = clip(dense[l][k] * factor, lo, hi); pad columns zeroed.

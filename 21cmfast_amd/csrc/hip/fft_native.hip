@@ -1582,7 +1582,7 @@ extern "C" int c21hip_split_z_c2r(const float *split_work, float *real_out, long
 }
 
 // Pass Z of the filtered density + its extrema (Eulerian source models with a per-radius
-// table).  partials: 2 * nx*ny/16 doubles; minmax_out[2] on the device.
+// table).  partials: 2 * nx*ny/16 + 2 * (nx*ny/16384 + 2) doubles; minmax_out[2] on the device.
 extern "C" int c21hip_split_z_c2r_minmax(const float *split_work, float *real_out,
                                          long out_zstride, int nx, int ny, int nz,
                                          double *partials, double *minmax_out, void *stream) {
@@ -1598,8 +1598,9 @@ extern "C" int c21hip_split_z_c2r_minmax(const float *split_work, float *real_ou
     z.p1 = partials + nb;
     int st = dispatch_z_c2r<1>(nz, z, nlines, (hipStream_t)stream);
     if (st) return st;
-    if ((st = c21hip_reduce_op(z.p0, nb, 1, minmax_out, stream))) return st;
-    return c21hip_reduce_op(z.p1, nb, 2, minmax_out + 1, stream);
+    double *stage = partials + 2 * (size_t)nb;  // beyond both partial arrays
+    if ((st = c21hip_reduce_op(z.p0, nb, 1, stage, minmax_out, stream))) return st;
+    return c21hip_reduce_op(z.p1, nb, 2, stage + nb / 1024 + 2, minmax_out + 1, stream);
 }
 
 // Pass Z of the filtered density fused with the CONST-ION-EFF closed-form f_coll(delta_R):

@@ -234,26 +234,36 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
         __syncthreads();
     }
     double acc = 0.;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems;
-         i += (size_t)gridDim.x * kBlock) {
-        const auto ci = cell_index<VEC>(i, nz_items, zpad_items);
-        const auto d = Pack<VEC>::load(delta_fil, ci.padded);
-        Pack<VEC> out;
+    constexpr int U = 4;  // items per thread and trip, loads issued before the arithmetic
+    for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < nitems;
+         i0 += (size_t)gridDim.x * kBlock * U) {
+        Pack<VEC> d[U];
 #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            const float dens = clip_delta_eulerian(d.v[e]);
-            double f;
-            if (fp.mode == C21CM_FCOLL_ERFC) {
-                f = (fp.sig < 0) ? 0. : fgtrm_bias_fast(fp.growthf, dens, fp.sig, fp.delta_c);
-            } else if (fp.mode == C21CM_FCOLL_TABLE_LINEAR) {
-                f = eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab);
-            } else {
-                f = exp(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
-            }
-            out.v[e] = (float)f;  // box->unnormalised_nion is float (IonisationBox.c:951)
-            acc += f;
+        for (int u = 0; u < U; u++) {
+            const size_t i = i0 + (size_t)u * kBlock;
+            if (i < nitems) d[u] = Pack<VEC>::load(delta_fil, cell_index<VEC>(i, nz_items, zpad_items).padded);
         }
-        out.store(nion_dense, ci.dense);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = i0 + (size_t)u * kBlock;
+            if (i >= nitems) continue;
+            Pack<VEC> out;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                const float dens = clip_delta_eulerian(d[u].v[e]);
+                double f;
+                if (fp.mode == C21CM_FCOLL_ERFC) {
+                    f = (fp.sig < 0) ? 0. : fgtrm_bias_fast(fp.growthf, dens, fp.sig, fp.delta_c);
+                } else if (fp.mode == C21CM_FCOLL_TABLE_LINEAR) {
+                    f = eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab);
+                } else {
+                    f = exp(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
+                }
+                out.v[e] = (float)f;  // box->unnormalised_nion is float (IonisationBox.c:951)
+                acc += f;
+            }
+            out.store(nion_dense, i);
+        }
     }
     block_sum_to(acc, partials);
 }
@@ -677,7 +687,7 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
     const int vec = (nz % 2 == 0) ? 2 : 1;
     const int zpad = 2 * (nz / 2 + 1);
     const size_t nitems = (size_t)nx * ny * (nz / vec);
-    const int blocks = grid_for(nitems);
+    const int blocks = grid_for((nitems + 3) / 4);
     if (vec == 2)
         hipLaunchKernelGGL(fcoll_eulerian_kernel<2>, dim3(blocks), dim3(kBlock), 0,
                            (hipStream_t)stream, delta_fil, nion_dense, nitems, nz / 2, zpad / 2, fp,
@@ -695,17 +705,23 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
 
 // chunked first level for long partial arrays: block b sums partials[b*chunk .. ), fixed order
 __global__ void __launch_bounds__(kBlock)
-chunk_reduce_kernel(const double *__restrict__ partials, int n, int chunk,
+chunk_reduce_kernel(const double *__restrict__ partials, int n, int chunk, int op,
                     double *__restrict__ out) {
     __shared__ double lds[kBlock];
     const int lo = blockIdx.x * chunk;
     const int hi = min(n, lo + chunk);
-    double acc = 0.;
-    for (int i = lo + threadIdx.x; i < hi; i += kBlock) acc += partials[i];
+    double acc = (op == 0) ? 0. : partials[lo];
+    for (int i = lo + threadIdx.x; i < hi; i += kBlock) {
+        const double p = partials[i];
+        acc = (op == 0) ? acc + p : (op == 1 ? fmin(acc, p) : fmax(acc, p));
+    }
     lds[threadIdx.x] = acc;
     __syncthreads();
     for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+        if (threadIdx.x < s) {
+            const double a = lds[threadIdx.x], b = lds[threadIdx.x + s];
+            lds[threadIdx.x] = (op == 0) ? a + b : (op == 1 ? fmin(a, b) : fmax(a, b));
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) out[blockIdx.x] = lds[0];
@@ -723,7 +739,7 @@ extern "C" int c21hip_reduce_sum(const double *partials, int n, double *out, voi
         // scheduling, stage through the second half of the scratch instead
         double *stage = const_cast<double *>(partials) + n;
         hipLaunchKernelGGL(chunk_reduce_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
-                           partials, n, chunk, stage);
+                           partials, n, chunk, 0, stage);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
                            stage, nb, 0, out);
@@ -736,8 +752,18 @@ extern "C" int c21hip_reduce_sum(const double *partials, int n, double *out, voi
     return 0;
 }
 
-// op 1 = min, 2 = max over n doubles (single workgroup)
-extern "C" int c21hip_reduce_op(const double *partials, int n, int op, double *out, void *stream) {
+// op 1 = min, 2 = max over n doubles; `stage` (>= n/1024 + 1 doubles) is used for long inputs
+extern "C" int c21hip_reduce_op(const double *partials, int n, int op, double *stage, double *out,
+                                void *stream) {
+    if (n > 4096 && stage) {
+        const int chunk = 1024;
+        const int nb = (n + chunk - 1) / chunk;
+        hipLaunchKernelGGL(chunk_reduce_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                           partials, n, chunk, op, stage);
+        LAUNCH_CHECK();
+        partials = stage;
+        n = nb;
+    }
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
                        partials, n, op, out);
     LAUNCH_CHECK();

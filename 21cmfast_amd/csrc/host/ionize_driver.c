@@ -250,7 +250,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     }
     {
         size_t np = (size_t)c->nx * c->ny / 8;
-        np += np / 1024 + 2; /* stage area of the two-level reduction */
+        np += np / 512 + 16; /* stage areas of the two-level reductions */
         if (np < C21HIP_PARTIALS) np = C21HIP_PARTIALS;
         c->partials = (double *)c21hip_ws(WS_PARTIALS, np * sizeof(double));
         if (!c->partials) return C21CM_MEMORY_ALLOC_ERROR;

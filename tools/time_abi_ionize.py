@@ -1,0 +1,65 @@
+"""Time ComputeIonizedBox through the reference's entry point with device-resident arrays for
+the Eulerian source models (E-INTEGRAL = `simple` template, CONST-ION-EFF = `const-zeta`), i.e.
+what a py21cmfast user of those templates gets (diagnostic; GPU box only).
+
+    PYTHONPATH=. python tools/time_abi_ionize.py [HII_DIM] [SOURCE_MODEL 0|1] [z]
+"""
+import ctypes as C
+import importlib
+import json
+import pathlib
+import sys
+import tempfile
+import time
+
+import torch
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tests"))
+from test_gpu_abi import Session  # noqa: E402
+
+S = importlib.import_module("21cmfast_amd.structs")
+W = importlib.import_module("21cmfast_amd.workloads")
+pkg = importlib.import_module("21cmfast_amd")
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+src = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+z = float(sys.argv[3]) if len(sys.argv) > 3 else 9.0
+lib = pkg.load(require_gpu=True)
+tmp = pathlib.Path(tempfile.mkdtemp())
+ses = Session(lib, tmp, HII_DIM=n, SOURCE_MODEL=src, HII_FILTER=1, USE_EXP_FILTER=False,
+              CELL_RECOMB=False, R_BUBBLE_MAX=40.0)
+
+density = W.density_field_torch(n, seed=5, sigma=0.6)
+shape = density.shape
+f32p = C.POINTER(C.c_float)
+
+
+def p(t):
+    return C.cast(t.data_ptr(), f32p)
+
+
+def run():
+    xH = torch.ones(shape, device="cuda")
+    zre = torch.zeros(shape, device="cuda")
+    tk = torch.zeros(shape, device="cuda")
+    nion = torch.zeros(shape, device="cuda")
+    prev = torch.zeros(shape, device="cuda")
+    pf = S.PerturbedFieldStruct(density=p(density))
+    prevb = S.IonizedBoxStruct(z_reion=p(prev))
+    box = S.IonizedBoxStruct(neutral_fraction=p(xH), z_reion=p(zre), kinetic_temperature=p(tk),
+                             unnormalised_nion=p(nion))
+    ts, hb, ics = S.TsBoxStruct(), S.HaloBoxStruct(), S.InitialConditionsStruct()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = lib.ComputeIonizedBox(z, 0.0, C.byref(pf), C.byref(pf), C.byref(prevb), C.byref(ts),
+                               C.byref(hb), C.byref(ics), C.byref(box))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert st == 0, lib.c21cm_last_error()
+    return dt, float(xH.mean())
+
+
+run()
+times = [run() for _ in range(3)]
+print(json.dumps({"hii_dim": n, "source_model": src, "z": z, "ms": min(t for t, _ in times) * 1e3,
+                  "global_xH": times[0][1]}))
