@@ -32,6 +32,8 @@ void *c21hip_event_create(void);
 void c21hip_event_destroy(void *ev);
 int c21hip_event_record(void *ev, void *stream);
 int c21hip_stream_wait_event(void *stream, void *ev);
+int c21hip_event_synchronize(void *ev); /* host waits for the event */
+void *c21hip_pinned_host(size_t bytes);  /* library-owned pinned staging buffer (one, reused) */
 void *c21hip_aux_stream(void); /* library-owned non-blocking side stream, NULL on failure */
 float c21hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
 void c21hip_set_error(const char *fmt, ...);

@@ -136,6 +136,25 @@ extern "C" int c21hip_event_record(void *ev, void *stream) {
     HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
     return 0;
 }
+// A small library-owned pinned host buffer (grown on demand, kept until the device cache is
+// released): asynchronous copies to or from pageable memory may block the calling thread on
+// the stream, which defeats host/device overlap.
+extern "C" void *c21hip_pinned_host(size_t bytes) {
+    static void *buf = nullptr;
+    static size_t cap = 0;
+    if (bytes > cap) {
+        if (buf) (void)hipHostFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (hipHostMalloc(&buf, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        cap = bytes;
+    }
+    return buf;
+}
+extern "C" int c21hip_event_synchronize(void *ev) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t)ev));
+    return 0;
+}
 extern "C" int c21hip_stream_wait_event(void *stream, void *ev) {
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
     return 0;

@@ -638,7 +638,8 @@ double c21_Nion_ConditionalM(double growthf, double lnM1, double lnM2, double ln
 /* interp_tables.c:291-405 (1-D case): table[i] = max(ln N_ion(delta_i | M_cond), -40) on
  * n_delta overdensities from dmin to dmax.  With the Gauss-Legendre method everything that does
  * not depend on delta (sigma, d sigma^2/dM, n_ion(M), the barrier expansion) is evaluated once per
- * node, which leaves one exp per (node, delta): the values equal c21_Nion_ConditionalM's. */
+ * node, which leaves one exp per (node, delta): the values equal c21_Nion_ConditionalM's to
+ * rounding (1e-15). */
 int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
                                double sigma_cond, double dmin, double dmax, double Mturn,
                                const c21_scaling_consts *sc, int method, float *table,
@@ -671,7 +672,9 @@ int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, dou
             }
             const double sdi = sigma1 == sigma_cond ? 1e6 : 1 / (sigma1 * sigma1 - sigma_cond * sigma_cond);
             node_sdi[i] = sdi;
-            node_pref[i] = nion * dsigmasqdm; /* the sign and the remaining factors follow below */
+            /* n_ion(M) d sigma^2/dM (sigma1^2 - sigma_c^2)^-3/2 / sqrt(2 pi): everything of the
+             * integrand that does not depend on delta (the sign follows below) */
+            node_pref[i] = nion * dsigmasqdm * pow(sdi, 1.5) / sqrt(2. * M_PI);
             if (hmf == C21CM_HMF_ST)
                 node_factor[i] = st_taylor_factor(sigma1, sigma_cond, growthf, &node_barrier[i]);
             else
@@ -697,11 +700,10 @@ int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, dou
                     const double delta_0 = delta / growthf;
                     const double factor = node_factor[i] - delta_0;
                     const double B = node_barrier[i];
-                    cmf = factor * pow(sdi, 1.5) * exp(-(B - delta_0) * (B - delta_0) * 0.5 * sdi) /
-                          sqrt(2. * M_PI);
+                    cmf = factor * exp(-(B - delta_0) * (B - delta_0) * 0.5 * sdi);
                 } else {
                     const double del = (DELTA_C_SPH - delta) / growthf;
-                    cmf = del * pow(sdi, 1.5) * exp(-del * del * 0.5 * sdi) / sqrt(2. * M_PI);
+                    cmf = del * exp(-del * del * 0.5 * sdi);
                 }
                 integral += gl.w[i] * (-node_pref[i] * cmf);
             }

@@ -63,7 +63,7 @@ typedef struct {
 #define SC_SUMS 0
 #define SC_MEANS (SC_SUMS + C21CM_MAX_RADII)
 #define SC_MINMAX (SC_MEANS + C21CM_MAX_RADII)
-#define SC_XHSUM (SC_MINMAX + 2)
+#define SC_XHSUM (SC_MINMAX + 4) /* two (min, max) pairs: the table loop is double-buffered */
 #define SC_FLAG (SC_XHSUM + 1) /* an int stored in a double-sized cell */
 #define SC_COUNT (SC_FLAG + 1)
 
@@ -260,7 +260,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->fused = c->native && c->lagrangian && !s->use_ts_fluct;
     c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct;
     c->scalars = (double *)c21hip_ws(WS_SCALARS, SC_COUNT * sizeof(double));
-    c->table_dev = (float *)c21hip_ws(WS_TABLE, C21CM_NDELTA_TABLE * sizeof(float));
+    c->table_dev = (float *)c21hip_ws(WS_TABLE, 2 * C21CM_NDELTA_TABLE * sizeof(float));
     if (!c->scalars || !c->table_dev) return C21CM_MEMORY_ALLOC_ERROR;
     status = c21hip_memset(c->scalars, 0, SC_COUNT * sizeof(double), stream);
     if (status) return status;
@@ -540,6 +540,77 @@ done:
     return status;
 }
 
+/* Eulerian source models with a per-radius f_coll table (E-INTEGRAL, CONST-ION-EFF with
+ * interpolation tables): the table of radius R needs the extrema of delta_R
+ * (IonisationBox.c:702-765), i.e. a device -> host round trip and ~0.5 ms of host quadrature
+ * per radius.  The loop is software-pipelined over two delta_R buffers: stage A (window, passes
+ * X, Y, Z + extrema, async copy of the two numbers) of the NEXT radius is queued before the
+ * host waits for this radius' extrema and builds its table, so the GPU transforms while the
+ * host integrates; stage B (f_coll sweep, mean, barrier into the mask) follows in radius
+ * order.  Barrier results only depend on the radius order of stage B, which is unchanged. */
+static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *mm_host, void *ev) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
+                               s->box_len_z, s->hii_filter, (float)s->R[R_ct], 0.f, 1, c->stream));
+    TRY(c21hip_split_z_c2r_minmax(c->delta_work, delta_fil, 2 * (c->nz / 2 + 1), c->nx, c->ny,
+                                  c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf,
+                                  c->stream));
+    TRY(c21hip_d2h(mm_host, c->scalars + SC_MINMAX + 2 * buf, 2 * sizeof(double), c->stream));
+    TRY(c21hip_event_record(ev, c->stream));
+done:
+    return status;
+}
+
+static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *mask) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    /* pinned host staging: [2][2] extrema, then [2][NDELTA] table floats */
+    double(*mm)[2] = (double(*)[2])c21hip_pinned_host(4 * sizeof(double) +
+                                                      2 * C21CM_NDELTA_TABLE * sizeof(float));
+    float(*table)[C21CM_NDELTA_TABLE] = mm ? (float(*)[C21CM_NDELTA_TABLE])(mm + 2) : NULL;
+    void *ev[2] = {c21hip_event_create(), c21hip_event_create()};
+    float *dfil[2] = {c->delta_fil, NULL};
+    if (n <= 0) goto done;
+    dfil[1] = (float *)c21hip_ws(WS_XE_FIL, c->npad * sizeof(float)); /* free without an x_e grid */
+    if (!ev[0] || !ev[1] || !dfil[1] || !mm) {
+        status = C21CM_MEMORY_ALLOC_ERROR;
+        goto done;
+    }
+    TRY(eul_stage_a(c, radii[0], 0, dfil[0], mm[0], ev[0]));
+    for (int i = 0; i < n; i++) {
+        const int b = i & 1, R_ct = radii[i];
+        if (i + 1 < n) TRY(eul_stage_a(c, radii[i + 1], b ^ 1, dfil[b ^ 1], mm[b ^ 1], ev[b ^ 1]));
+        TRY(c21hip_event_synchronize(ev[b]));
+        const double min_density = mm[b][0] - 0.001, max_density = mm[b][1] + 0.001;
+        int tst = s->table_fn(R_ct, min_density, max_density, table[b], s->table_user);
+        if (tst) {
+            c21hip_set_error("ionize: table_fn failed with status %d at radius %d", tst, R_ct);
+            status = tst;
+            goto done;
+        }
+        float *table_dev = c->table_dev + b * C21CM_NDELTA_TABLE;
+        TRY(c21hip_h2d(table_dev, table[b], C21CM_NDELTA_TABLE * sizeof(float), c->stream));
+        double *sum_dev = c->scalars + SC_SUMS + R_ct, *mean_dev = c->scalars + SC_MEANS + R_ct;
+        c21hip_ionize_args args;
+        fill_args(&args, s, R_ct);
+        TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
+                                  s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
+                                  s->delta_c, min_density,
+                                  (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
+                                  table_dev, c->partials, sum_dev, c->stream));
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               mean_dev, c->stream));
+        TRY(c21hip_eulerian_mask(&args, c->nion_dense, mean_dev, mask, c->stream));
+    }
+    /* the pinned staging buffer is shared: make sure the last copies have left it */
+    TRY(c21hip_sync(c->stream));
+done:
+    c21hip_event_destroy(ev[0]);
+    c21hip_event_destroy(ev[1]);
+    return status;
+}
+
 /* Fused Lagrangian path, radius index 0 reached: the cell-scale step only needs the emissivity
  * grid in real space (the density it tests is the unfiltered one, IonisationBox.c:1048), and
  * the mask of the larger radii, the barrier / partial ionisation at index 0 and the post-loop
@@ -654,7 +725,15 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
     {
         const int use_mask = c.fused || c.eul_mask;
         int mask_pending = use_mask;
-        for (int R_ct = spec->n_radii; R_ct--;) {
+        int R_start = spec->n_radii;
+        if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC) {
+            int radii[C21CM_MAX_RADII], n = 0;
+            for (int R_ct = spec->n_radii - 1; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct--)
+                radii[n++] = R_ct;
+            TRY(eul_table_loop(&c, radii, n, c.mask));
+            R_start = 1; /* only the cell-scale radius is left */
+        }
+        for (int R_ct = R_start; R_ct--;) {
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
                 mask_pending = 0;
@@ -727,9 +806,16 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
     spectra_remember(&c, perturbed_field, halos, spin_temp);
     TRY(c21hip_event_record(ev[1], stream));
     /* radii n-1 .. 1 dealt round-robin, largest first; index 0 belongs to the finish step */
-    for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
-        if (R_ct < spec->r_lowest) break;
-        TRY(one_radius(&c, R_ct, first_cross, R_ct - world));
+    if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC) {
+        int radii[C21CM_MAX_RADII], n = 0;
+        for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct -= world)
+            radii[n++] = R_ct;
+        TRY(eul_table_loop(&c, radii, n, first_cross));
+    } else {
+        for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
+            if (R_ct < spec->r_lowest) break;
+            TRY(one_radius(&c, R_ct, first_cross, R_ct - world));
+        }
     }
     /* The rank that will run the finish step has one radius fewer than the busiest ranks: it
      * uses that slack to transform the unfiltered emissivity for the cell-scale step, so that
