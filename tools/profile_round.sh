@@ -9,11 +9,11 @@ REPO=$PWD
 export TMPDIR=/tmp
 mkdir -p $REPO/gpurun_out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats -o $TAG -- \
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats -o $TAG -- \
     python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline \
     > $REPO/gpurun_out/prof_stats_bench.json 2> $REPO/gpurun_out/prof_stats.err
 for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_$C -o pmc -- \
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_$C -o pmc -- \
         python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-roofline \
         > /dev/null 2> $REPO/gpurun_out/pmc_$C.err
 done
