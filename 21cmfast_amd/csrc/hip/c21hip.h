@@ -135,6 +135,18 @@ int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3], const 
                        const int out_dim[3], double box_len, double box_len_z, double growth,
                        double init_growth, int lpt2, void *stream);
 /* double grid -> padded float [, *= mass_factor, -= 1]: PerturbedField.c:115-128,180-210 */
+/* ComputeHaloBox deposit (map_mass.c:214-344): exp(lerp(ln-table, delta*D)) * prefactor for the
+ * two tables in tables_dev[2][NDELTA], CIC-deposited at the displaced positions (double grids) */
+int c21hip_halobox_scatter(const float *src_density, const int dens_dim[3],
+                           const float *const vel[3], const float *const vel2[3],
+                           const int vel_dim[3], double *out_nion, double *out_sfr,
+                           const int out_dim[3], double box_len, double box_len_z, double growth,
+                           double init_growth, int lpt2, const float *tables_dev, double tab_min,
+                           double tab_width, double pref_nion, double pref_sfr, void *stream);
+int c21hip_narrow(const double *in, float *out, float *out_scaled, double scale, size_t n,
+                  void *stream);
+/* {min, max} of n floats into out2 (device); partials: 2 * 2048 doubles */
+int c21hip_minmax_dense(const float *a, size_t n, double *partials, double *out2, void *stream);
 int c21hip_widen_normalise(const double *in, float *padded, int nx, int ny, int nz, int normalise,
                            double mass_factor, void *stream);
 /* padded = (float)(factor * dense): PerturbedField.c:64-80 */

@@ -22,6 +22,8 @@
 
 #include "c21hip.h"
 #include "c21cm_abi.h"
+#include "c21cm_grid.h"
+#include "fcoll_device.h"
 
 namespace {
 constexpr int kBlock = 256;
@@ -130,17 +132,29 @@ struct CicTileParams {
     int nb[3];       // bricks per axis
     int td[3];       // tile extent in output cells (incl. halo and the +1 CIC neighbour)
     int halo;
+    // NV == 2 (ComputeHaloBox, map_mass.c:214-344): per-cell values from two ln-tables of
+    // delta = density * growth; table_dev = [2][C21CM_NDELTA_TABLE] floats (ln N_ion, ln SFRD)
+    double growth, tab_min, tab_width, pref[2];
 };
 
+// NV = 1: the deposited value is the particle mass 1 + delta * D_init (PerturbedField).
+// NV = 2: two values per source cell, exp(lerp(table, delta * D)) * prefactor (HaloBox n_ion and
+// halo_sfr), accumulated in two tiles / two output grids.
+template <int NV>
 __global__ void __launch_bounds__(kBlock)
 cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
                          const float *__restrict__ vx, const float *__restrict__ vy,
                          const float *__restrict__ vz, const float *__restrict__ v2x,
                          const float *__restrict__ v2y, const float *__restrict__ v2z,
-                         double *__restrict__ out) {
+                         const float *__restrict__ table_dev, double *__restrict__ out,
+                         double *__restrict__ out_b) {
     extern __shared__ double tile[];
     const CicParams &p = q.c;
     const int tcells = q.td[0] * q.td[1] * q.td[2];
+    float *tab = reinterpret_cast<float *>(tile + NV * tcells);  // NV == 2: [2][NDELTA]
+    if (NV == 2) {
+        for (int t = threadIdx.x; t < 2 * C21CM_NDELTA_TABLE; t += kBlock) tab[t] = table_dev[t];
+    }
     const size_t sy = (size_t)p.out_dim[2], sx = (size_t)p.out_dim[1] * p.out_dim[2];
     const int n_bricks = q.nb[0] * q.nb[1] * q.nb[2];
     const int per_brick = q.sb[0] * q.sb[1] * q.sb[2];
@@ -152,7 +166,7 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
         int t0[3];  // output coordinate (unwrapped) of tile cell 0
 #pragma unroll
         for (int a = 0; a < 3; a++) t0[a] = (int)floor((double)s0[a] * p.dim_ratio_out) - q.halo;
-        for (int c = threadIdx.x; c < tcells; c += kBlock) tile[c] = 0.;
+        for (int c = threadIdx.x; c < NV * tcells; c += kBlock) tile[c] = 0.;
         __syncthreads();
         for (int e = threadIdx.x; e < per_brick; e += kBlock) {
             const int l0 = e / (q.sb[1] * q.sb[2]);
@@ -193,7 +207,15 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
                 const int rel = ipos[a] - t0[a];
                 inside = inside && rel >= 0 && rel + 1 < q.td[a];
             }
-            const double mass = 1.0 + (double)dens[t] * p.init_growth;
+            double val[NV];
+            if (NV == 1) {
+                val[0] = 1.0 + (double)dens[t] * p.init_growth;
+            } else {
+                const double curr_dens = (double)dens[t] * q.growth;  // map_mass.c:283
+                val[0] = exp(eval_table_f(curr_dens, q.tab_min, q.tab_width, tab)) * q.pref[0];
+                val[NV - 1] = exp(eval_table_f(curr_dens, q.tab_min, q.tab_width,
+                                               tab + C21CM_NDELTA_TABLE)) * q.pref[NV - 1];
+            }
             const double wx[2] = {w0[0], w1[0]}, wy[2] = {w0[1], w1[1]}, wz[2] = {w0[2], w1[2]};
             if (inside) {
                 const int base = ((ipos[0] - t0[0]) * q.td[1] + (ipos[1] - t0[1])) * q.td[2] +
@@ -203,10 +225,14 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
 #pragma unroll
                     for (int b = 0; b < 2; b++)
 #pragma unroll
-                        for (int c = 0; c < 2; c++)
-                            __hip_atomic_fetch_add(&tile[base + (a * q.td[1] + b) * q.td[2] + c],
-                                                   mass * (wx[a] * wy[b] * wz[c]), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (int c = 0; c < 2; c++) {
+                            const double w = wx[a] * wy[b] * wz[c];
+#pragma unroll
+                            for (int v = 0; v < NV; v++)
+                                __hip_atomic_fetch_add(
+                                    &tile[v * tcells + base + (a * q.td[1] + b) * q.td[2] + c],
+                                    val[v] * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
             } else {
                 size_t bx[2], by[2], bz[2];
                 bx[0] = (size_t)wrap_idx(ipos[0], p.out_dim[0]) * sx;
@@ -220,22 +246,25 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
 #pragma unroll
                     for (int b = 0; b < 2; b++)
 #pragma unroll
-                        for (int a = 0; a < 2; a++)
-                            unsafeAtomicAdd(out + bx[a] + by[b] + bz[c],
-                                            mass * (wx[a] * wy[b] * wz[c]));
+                        for (int a = 0; a < 2; a++) {
+                            const double w = wx[a] * wy[b] * wz[c];
+                            unsafeAtomicAdd(out + bx[a] + by[b] + bz[c], val[0] * w);
+                            if (NV == 2) unsafeAtomicAdd(out_b + bx[a] + by[b] + bz[c], val[NV - 1] * w);
+                        }
             }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < tcells; c += kBlock) {
-            const double val = tile[c];
-            if (val != 0.) {
+            const double v0 = tile[c], v1 = (NV == 2) ? tile[tcells + c] : 0.;
+            if (v0 != 0. || v1 != 0.) {
                 const int c2 = c % q.td[2];
                 const int c1 = (c / q.td[2]) % q.td[1];
                 const int c0 = c / (q.td[1] * q.td[2]);
-                unsafeAtomicAdd(out + (size_t)wrap_idx(t0[0] + c0, p.out_dim[0]) * sx +
-                                    (size_t)wrap_idx(t0[1] + c1, p.out_dim[1]) * sy +
-                                    (size_t)wrap_idx(t0[2] + c2, p.out_dim[2]),
-                                val);
+                const size_t o = (size_t)wrap_idx(t0[0] + c0, p.out_dim[0]) * sx +
+                                 (size_t)wrap_idx(t0[1] + c1, p.out_dim[1]) * sy +
+                                 (size_t)wrap_idx(t0[2] + c2, p.out_dim[2]);
+                unsafeAtomicAdd(out + o, v0);
+                if (NV == 2) unsafeAtomicAdd(out_b + o, v1);
             }
         }
         __syncthreads();
@@ -346,12 +375,98 @@ velocity_kernel(const float2 *__restrict__ saved, float2 *__restrict__ grid, int
 }
 }  // namespace
 
-extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3],
-                                  const float *const vel[3], const float *const vel2[3],
-                                  const int vel_dim[3], double *out, const int out_dim[3],
-                                  double box_len, double box_len_z, double growth,
-                                  double init_growth, int lpt2, void *stream) {
-    CicParams p;
+namespace {
+// double accumulation grid -> the caller's float grid (optionally a second, scaled copy)
+__global__ void __launch_bounds__(kBlock)
+narrow_kernel(const double *__restrict__ in, float *__restrict__ out, float *__restrict__ out_scaled,
+              double scale, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock) {
+        const float v = (float)in[i];
+        out[i] = v;
+        if (out_scaled) out_scaled[i] = (float)((double)v * scale);
+    }
+}
+
+// min and max of a dense float array, seeded with 0 like HaloBox.c:303-304,357-366 when
+// seed_zero, else with the first element; one (min, max) pair per workgroup
+__global__ void __launch_bounds__(kBlock)
+minmax_dense_kernel(const float *__restrict__ a, size_t n, double *__restrict__ pmin,
+                    double *__restrict__ pmax) {
+    double lo = (double)a[0], hi = lo;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock) {
+        const double v = (double)a[i];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+    __shared__ double slo[kBlock / 64], shi[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, off, 64));
+        hi = fmax(hi, __shfl_down(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) {
+            lo = fmin(lo, slo[w]);
+            hi = fmax(hi, shi[w]);
+        }
+        pmin[blockIdx.x] = lo;
+        pmax[blockIdx.x] = hi;
+    }
+}
+}  // namespace
+
+extern "C" int c21hip_narrow(const double *in, float *out, float *out_scaled, double scale,
+                             size_t n, void *stream) {
+    hipLaunchKernelGGL(narrow_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, in,
+                       out, out_scaled, scale, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// partials: 2 * 2048 doubles; out2 (device): {min, max}
+extern "C" int c21hip_minmax_dense(const float *a, size_t n, double *partials, double *out2,
+                                   void *stream) {
+    const int blocks = grid_for(n);
+    hipLaunchKernelGGL(minmax_dense_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, a,
+                       n, partials, partials + kMaxBlocks);
+    LAUNCH_CHECK();
+    int st = c21hip_reduce_op(partials, blocks, 1, nullptr, out2, stream);
+    if (st) return st;
+    return c21hip_reduce_op(partials + kMaxBlocks, blocks, 2, nullptr, out2 + 1, stream);
+}
+
+namespace {
+// brick / tile geometry of the LDS-tiled deposit: bricks of ~8 x 8 x 16 OUTPUT cells worth of
+// sources (16 x 16 x 32 source cells at DIM = 2 HII_DIM), 2 output cells of halo
+bool tile_setup(const CicParams &p, int nv, CicTileParams &q, size_t *lds, int *blocks) {
+    q.c = p;
+    q.halo = 2;
+    const int ob[3] = {8, 8, 16};
+    size_t tcells = 1;
+    long n_bricks = 1;
+    for (int a = 0; a < 3; a++) {
+        int sb = (int)floor(ob[a] / p.dim_ratio_out + 0.5);
+        if (sb < 1) sb = 1;
+        q.sb[a] = sb < p.dens_dim[a] ? sb : p.dens_dim[a];
+        q.nb[a] = (p.dens_dim[a] + q.sb[a] - 1) / q.sb[a];
+        q.td[a] = (int)ceil(q.sb[a] * p.dim_ratio_out) + 2 + 2 * q.halo;
+        tcells *= (size_t)q.td[a];
+        n_bricks *= q.nb[a];
+    }
+    *lds = tcells * sizeof(double) * nv + (nv == 2 ? 2 * C21CM_NDELTA_TABLE * sizeof(float) : 0);
+    *blocks = (int)(n_bricks < 256 * 8 ? n_bricks : 256 * 8);
+    return *lds <= 96 * 1024;
+}
+
+void fill_cic_params(CicParams &p, const int dens_dim[3], const int vel_dim[3], const int out_dim[3],
+                     double box_len, double box_len_z, double growth, double init_growth, int lpt2) {
     const double box_size[3] = {box_len, box_len, box_len_z};
     const double d2 = -(3.0 / 7.0) * growth * growth;
     const double id2 = -(3.0 / 7.0) * init_growth * init_growth;
@@ -366,6 +481,53 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
     p.dim_ratio_out = (double)out_dim[0] / (double)dens_dim[0];
     p.init_growth = init_growth;
     p.lpt2 = lpt2;
+}
+}  // namespace
+
+// ComputeHaloBox deposit (map_mass.c:214-344): two values per source cell from the two
+// ln-tables, CIC-deposited at the displaced positions into two double grids.
+extern "C" int c21hip_halobox_scatter(const float *src_density, const int dens_dim[3],
+                                      const float *const vel[3], const float *const vel2[3],
+                                      const int vel_dim[3], double *out_nion, double *out_sfr,
+                                      const int out_dim[3], double box_len, double box_len_z,
+                                      double growth, double init_growth, int lpt2,
+                                      const float *tables_dev, double tab_min, double tab_width,
+                                      double pref_nion, double pref_sfr, void *stream) {
+    CicParams p;
+    fill_cic_params(p, dens_dim, vel_dim, out_dim, box_len, box_len_z, growth, init_growth, lpt2);
+    CicTileParams q;
+    size_t lds;
+    int blocks;
+    if (!tile_setup(p, 2, q, &lds, &blocks)) {
+        c21hip_set_error("halobox deposit: tile of %zu bytes does not fit the LDS", lds);
+        return C21CM_VALUE_ERROR;
+    }
+    q.growth = growth;
+    q.tab_min = tab_min;
+    q.tab_width = tab_width;
+    q.pref[0] = pref_nion;
+    q.pref[1] = pref_sfr;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)cic_scatter_tiled_kernel<2>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(cic_scatter_tiled_kernel<2>, dim3(blocks), dim3(kBlock), lds,
+                       (hipStream_t)stream, q, src_density, vel[0], vel[1], vel[2],
+                       lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr, lpt2 ? vel2[2] : nullptr,
+                       tables_dev, out_nion, out_sfr);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3],
+                                  const float *const vel[3], const float *const vel2[3],
+                                  const int vel_dim[3], double *out, const int out_dim[3],
+                                  double box_len, double box_len_z, double growth,
+                                  double init_growth, int lpt2, void *stream) {
+    CicParams p;
+    fill_cic_params(p, dens_dim, vel_dim, out_dim, box_len, box_len_z, growth, init_growth, lpt2);
     const size_t total = (size_t)dens_dim[0] * dens_dim[1] * dens_dim[2];
     {
         // LDS-tiled deposit unless disabled (C21CM_CIC=direct) or the grids are tiny
@@ -376,25 +538,14 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
         }
         if (!direct && total >= (size_t)1 << 15) {
             CicTileParams q;
-            q.c = p;
-            q.halo = 2;
-            const int sb[3] = {16, 16, 32};
-            size_t tcells = 1;
-            int n_bricks = 1;
-            for (int a = 0; a < 3; a++) {
-                q.sb[a] = sb[a] < dens_dim[a] ? sb[a] : dens_dim[a];
-                q.nb[a] = (dens_dim[a] + q.sb[a] - 1) / q.sb[a];
-                q.td[a] = (int)ceil(q.sb[a] * p.dim_ratio_out) + 2 + 2 * q.halo;
-                tcells *= (size_t)q.td[a];
-                n_bricks *= q.nb[a];
-            }
-            const size_t lds = tcells * sizeof(double);
-            if (lds <= 64 * 1024) {
-                int blocks = n_bricks < 256 * 8 ? n_bricks : 256 * 8;
-                hipLaunchKernelGGL(cic_scatter_tiled_kernel, dim3(blocks), dim3(kBlock), lds,
+            size_t lds;
+            int blocks;
+            if (tile_setup(p, 1, q, &lds, &blocks)) {
+                hipLaunchKernelGGL(cic_scatter_tiled_kernel<1>, dim3(blocks), dim3(kBlock), lds,
                                    (hipStream_t)stream, q, hires_density, vel[0], vel[1], vel[2],
                                    lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr,
-                                   lpt2 ? vel2[2] : nullptr, out);
+                                   lpt2 ? vel2[2] : nullptr, (const float *)nullptr, out,
+                                   (double *)nullptr);
                 LAUNCH_CHECK();
                 return 0;
             }

@@ -198,7 +198,7 @@ static int nion_table_fn(int r_index, double dmin, double dmax, float *table, vo
     const double M_max_R = c21_RtoM(s->R[r_index]);
     return c21_Nion_Conditional_table(s->growth_factor, t->lnMmin, log(M_max_R), log(M_max_R),
                                       c21_sigma_fast(M_max_R), dmin, dmax, t->sc.mturn_a_nofb,
-                                      &t->sc, t->method, table, C21CM_NDELTA_TABLE);
+                                      &t->sc, t->method, -40., table, C21CM_NDELTA_TABLE);
 }
 
 int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *perturbed_field,
@@ -394,4 +394,105 @@ int ComputeBrightnessTemp(float redshift, TsBox *spin_temp, IonizedBox *ionized_
     return c21cm_brightness_grids(&s, perturb_field->density, ionized_box->neutral_fraction,
                                   spin_temp ? spin_temp->spin_temperature : NULL,
                                   box->brightness_temp, box->tau_21, NULL, NULL);
+}
+
+/* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436.  Only the
+ * integrated branch without mini-halos, X-ray sources or the extra fields. */
+int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
+                   TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids) {
+    (void)halos;
+    (void)previous_spin_temp;
+    (void)previous_ionize_box;
+    int st = require_globals("ComputeHaloBox", 1);
+    if (st) return st;
+    if (!ini_boxes || !grids) return C21CM_VALUE_ERROR;
+    const SimulationOptions *so = simulation_options_global;
+    const MatterOptions *mo = matter_options_global;
+    const AstroOptions *ao = astro_options_global;
+    const char *unsupported = NULL;
+    if (mo->SOURCE_MODEL != C21CM_SOURCE_L_INTEGRAL)
+        unsupported = "a SOURCE_MODEL other than L-INTEGRAL (halo catalogues)";
+    if (mo->USE_INTERPOLATION_TABLES != C21CM_INTERP_HMF)
+        unsupported = "L-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation";
+    if (ao->USE_MINI_HALOS) unsupported = "USE_MINI_HALOS";
+    if (ao->USE_TS_FLUCT) unsupported = "USE_TS_FLUCT (X-ray source grid)";
+    if (ao->HALO_SCALING_RELATIONS_MEDIAN) unsupported = "HALO_SCALING_RELATIONS_MEDIAN";
+    if (ao->INTEGRATION_METHOD_ATOMIC > 1) unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
+    if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
+    if (config_settings.EXTRA_HALOBOX_FIELDS) unsupported = "EXTRA_HALOBOX_FIELDS";
+    if (mo->HMF != C21CM_HMF_PS && mo->HMF != C21CM_HMF_ST)
+        unsupported = "an HMF without conditional mass function (mean-fixed grids)";
+    if (unsupported) {
+        c21hip_set_error("ComputeHaloBox: %s is not implemented in this backend yet", unsupported);
+        return C21CM_VALUE_ERROR;
+    }
+    if (!c21_ps_ready()) init_ps();
+
+    c21cm_halobox_spec s;
+    memset(&s, 0, sizeof(s));
+    int dim, dim_z;
+    geometry(&dim, &dim_z, &s.hii_dim, &s.hii_dim_z, &s.box_len, &s.box_len_z);
+    s.dim = dim;
+    s.dim_z = dim_z;
+    s.perturb_on_high_res = mo->PERTURB_ON_HIGH_RES;
+    s.lpt2 = (mo->PERTURB_ALGORITHM == C21CM_PERTURB_2LPT);
+    s.growth_factor = dicke(redshift);
+    s.init_growth_factor = dicke(so->INITIAL_REDSHIFT);
+
+    c21_scaling_consts sc, sc_sfrd;
+    if ((st = c21_set_scaling_constants(redshift, &sc))) return st;
+    sc_sfrd = sc; /* scaling_relations.c:122-131 */
+    sc_sfrd.fesc_10 = 1.;
+    sc_sfrd.fesc_7 = 1.;
+    sc_sfrd.alpha_esc = 0.;
+    sc_sfrd.Mlim_Fesc = 0.;
+
+    const double M_min = c21_minimum_source_mass(redshift), M_max = M_MAX_INTEGRAL;
+    const size_t n_src = s.perturb_on_high_res ? (size_t)dim * dim * dim_z
+                                                : (size_t)s.hii_dim * s.hii_dim * s.hii_dim_z;
+    const size_t n_out = (size_t)s.hii_dim * s.hii_dim * s.hii_dim_z;
+    const double volume = s.box_len * s.box_len * s.box_len_z;
+    const double M_cell = c21_rhocrit() * cosmo_params_global->OMm * volume / (double)n_src;
+    const double sigma_cell = sigma_z0(M_cell); /* HaloBox.c:45 */
+    const float *dens = s.perturb_on_high_res ? ini_boxes->hires_density : ini_boxes->lowres_density;
+    if (!dens) {
+        c21hip_set_error("ComputeHaloBox: the InitialConditions density grid is missing");
+        return C21CM_VALUE_ERROR;
+    }
+    /* table range: extrema of density * D, seeded with 0, widened by 0.1 % (HaloBox.c:303-381) */
+    double mm[2];
+    if ((st = c21cm_grid_minmax(dens, n_src, mm, NULL))) return st;
+    double min_density = fmin(0., mm[0] * s.growth_factor) * 1.001;
+    double max_density = fmax(0., mm[1] * s.growth_factor) * 1.001;
+    if (!(max_density > min_density)) max_density = min_density + 1e-6;
+    static float tab_nion[C21CM_NDELTA_TABLE], tab_sfrd[C21CM_NDELTA_TABLE];
+    const int method = ao->INTEGRATION_METHOD_ATOMIC;
+    if ((st = c21_Nion_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
+                                         sigma_cell, min_density, max_density, sc.mturn_a_nofb, &sc,
+                                         method, -40., tab_nion, C21CM_NDELTA_TABLE)))
+        return st;
+    if ((st = c21_Nion_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
+                                         sigma_cell, min_density, max_density, sc_sfrd.mturn_a_nofb,
+                                         &sc_sfrd, method, -50., tab_sfrd, C21CM_NDELTA_TABLE)))
+        return st;
+    s.tab_min = min_density;
+    s.tab_width = (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.);
+    s.ln_nion_table = tab_nion;
+    s.ln_sfrd_table = tab_sfrd;
+    /* map_mass.c:223-239 */
+    const double vol_ratio_out = (double)n_out / (double)n_src;
+    const double prefactor_stars = c21_rhocrit() * cosmo_params_global->OMb * sc.fstar_10 * vol_ratio_out;
+    s.prefactor_sfr = prefactor_stars / sc.t_star / sc.t_h;
+    s.prefactor_nion = prefactor_stars * sc.fesc_10 * sc.pop2_ion;
+    s.prefactor_wsfr = 1 / sc.t_h / sc.t_star;
+    /* get_log10_turnovers without mini-halos (HaloBox.c:467-470) */
+    grids->log10_Mcrit_ACG_ave = log10(sc.mturn_a_nofb);
+    grids->log10_Mcrit_MCG_ave = log10(0.);
+    if (!(M_min < M_max)) { /* :619 -- nothing to integrate: the grids stay zero */
+        c21hip_set_error("ComputeHaloBox: M_min >= M_max");
+        return C21CM_VALUE_ERROR;
+    }
+    HaloBox g = *grids;
+    if (ao->RECOMB_MODEL == C21CM_RECOMB_NONE) g.whalo_sfr = NULL; /* map_mass.c:342 */
+    return c21cm_halobox_grids(&s, ini_boxes, &g, NULL);
 }

@@ -635,15 +635,16 @@ double c21_Nion_ConditionalM(double growthf, double lnM1, double lnM2, double ln
     return c21_integrate(cnion_integrand, &c, lnM1, lnM2, 1e-4);
 }
 
-/* interp_tables.c:291-405 (1-D case): table[i] = max(ln N_ion(delta_i | M_cond), -40) on
+/* interp_tables.c:291-405 (1-D case; ln_floor = -40) and :415-494 (SFRD table: the same integral
+ * with f_esc = 1, ln_floor = -50): table[i] = max(ln N_ion(delta_i | M_cond), ln_floor) on
  * n_delta overdensities from dmin to dmax.  With the Gauss-Legendre method everything that does
  * not depend on delta (sigma, d sigma^2/dM, n_ion(M), the barrier expansion) is evaluated once per
  * node, which leaves one exp per (node, delta): the values equal c21_Nion_ConditionalM's to
  * rounding (1e-15). */
 int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
                                double sigma_cond, double dmin, double dmax, double Mturn,
-                               const c21_scaling_consts *sc, int method, float *table,
-                               int n_delta) {
+                               const c21_scaling_consts *sc, int method, double ln_floor,
+                               float *table, int n_delta) {
     int hmf = matter_options_global->HMF;
     const int fast = (method == 1) && lnMmin < lnMcond;
     double node_pref[NGL_INT + 1], node_factor[NGL_INT + 1], node_barrier[NGL_INT + 1],
@@ -710,7 +711,7 @@ int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, dou
             v = integral;
         }
         double lv = log(v);
-        if (lv < -40.) lv = -40.;
+        if (lv < ln_floor) lv = ln_floor;
         if (!isfinite(lv)) return C21CM_TABLE_GENERATION_ERROR;
         table[k] = (float)lv;
     }

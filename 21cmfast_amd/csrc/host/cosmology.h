@@ -46,12 +46,12 @@ double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
 double c21_Nion_ConditionalM(double growthf, double lnM1, double lnM2, double lnM_cond,
                              double sigma2, double delta2, double Mturn,
                              const c21_scaling_consts *sc, int method);
-/* ln N_ion(delta | M_cond) on n_delta overdensities in [dmin, dmax], floored at -40
- * (interp_tables.c:291-405, 1-D table) */
+/* ln N_ion(delta | M_cond) on n_delta overdensities in [dmin, dmax], floored at ln_floor
+ * (interp_tables.c:291-405 with -40; the SFRD table :415-494 is the same with f_esc = 1, -50) */
 int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
                                double sigma_cond, double dmin, double dmax, double Mturn,
-                               const c21_scaling_consts *sc, int method, float *table,
-                               int n_delta);
+                               const c21_scaling_consts *sc, int method, double ln_floor,
+                               float *table, int n_delta);
 int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc);
 double c21_minimum_source_mass(double redshift);
 int c21_recfast_load(void);

@@ -247,3 +247,35 @@ def brightness_grids(spec: S.BrightnessSpec, density, neutral_fraction, spin_tem
           "c21cm_brightness_grids")
     out["mean"] = mean.value
     return out
+
+
+def halobox_grids(spec: S.HaloBoxSpec, ics: dict, with_whalo=False, stream=None) -> dict:
+    """ComputeHaloBox's integrated branch on the MI355X (reference: src/py21cmfast/src/HaloBox.c:
+    302-436, map_mass.c:214-344).  Outputs live where the source density lives.
+    Returns dict(n_ion, halo_sfr[, whalo_sfr])."""
+    ref = ics["hires_density" if spec.perturb_on_high_res else "lowres_density"]
+    lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
+
+    def new():
+        if _is_torch(ref):
+            import torch
+
+            return torch.zeros(lo, dtype=torch.float32, device=ref.device)
+        return np.zeros(lo, np.float32)
+
+    out = {"n_ion": new(), "halo_sfr": new()}
+    if with_whalo:
+        out["whalo_sfr"] = new()
+    hb = S.HaloBoxStruct(**{k: _fptr(v) for k, v in out.items()})
+    icss = ics_struct(ics)
+    check(load().c21cm_halobox_grids(C.byref(spec), C.byref(icss), C.byref(hb), _stream(stream)),
+          "c21cm_halobox_grids")
+    return out
+
+
+def grid_minmax(values, stream=None):
+    mm = (C.c_double * 2)()
+    n = values.numel() if _is_torch(values) else values.size
+    check(load().c21cm_grid_minmax(_vptr(values), C.c_size_t(n), mm, _stream(stream)),
+          "c21cm_grid_minmax")
+    return mm[0], mm[1]

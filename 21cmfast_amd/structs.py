@@ -252,6 +252,21 @@ class IonizedBoxStruct(_Base):
     ]
 
 
+class HaloBoxSpec(_Base):
+    """``c21cm_halobox_spec`` (include/c21cm_grid.h)."""
+
+    _fields_ = [
+        ("dim", C.c_int), ("dim_z", C.c_int), ("hii_dim", C.c_int), ("hii_dim_z", C.c_int),
+        ("box_len", C.c_double), ("box_len_z", C.c_double),
+        ("perturb_on_high_res", C.c_int), ("lpt2", C.c_int),
+        ("growth_factor", C.c_double), ("init_growth_factor", C.c_double),
+        ("tab_min", C.c_double), ("tab_width", C.c_double),
+        ("ln_nion_table", c_float_p), ("ln_sfrd_table", c_float_p),
+        ("prefactor_nion", C.c_double), ("prefactor_sfr", C.c_double),
+        ("prefactor_wsfr", C.c_double),
+    ]
+
+
 class BrightnessTempStruct(_Base):
     _fields_ = [("brightness_temp", c_float_p), ("tau_21", c_float_p)]
 

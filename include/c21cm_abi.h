@@ -325,6 +325,12 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
                       TsBox *spin_temp, HaloBox *halos, InitialConditions *ini_boxes,
                       IonizedBox *box);
 
+/* reference: src/py21cmfast/src/HaloBox.c:563 (_functionprototypes_wrapper.h:31-32).  Only the
+ * integrated branch (SOURCE_MODEL = L-INTEGRAL) is provided; `halos` is not read. */
+typedef struct HaloCatalog HaloCatalog;
+int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
+                   TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids);
+
 /* reference: src/py21cmfast/src/BrightnessTemperatureBox.c:22 (_functionprototypes_wrapper.h:28-29) */
 int ComputeBrightnessTemp(float redshift, TsBox *spin_temp, IonizedBox *ionized_box,
                           PerturbedField *perturb_field, BrightnessTemp *box);

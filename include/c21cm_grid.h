@@ -198,6 +198,33 @@ int c21cm_brightness_grids(const c21cm_brightness_spec *spec, const float *densi
                            const float *neutral_fraction, const float *spin_temperature,
                            float *brightness_temp, float *tau_21, double *mean_out, void *stream);
 
+/* ---- ComputeHaloBox, integrated ("fixed grid") branch: HaloBox.c:302-436 + map_mass.c:214-344 --
+ * Each cell of the Lagrangian grid (`hires_density` with PERTURB_ON_HIGH_RES, else
+ * `lowres_density`, times the growth factor) gets its expected emissivity and star-formation
+ * rate from two 400-bin conditional-mass-function tables (ln N_ion(delta), ln SFRD(delta));
+ * the values are moved with the 1LPT/2LPT displacement and CIC-deposited on the HII_DIM grid. */
+typedef struct c21cm_halobox_spec {
+    int dim, dim_z;         /* grid of the source cells (DIM or HII_DIM) */
+    int hii_dim, hii_dim_z; /* output grid */
+    double box_len, box_len_z;
+    int perturb_on_high_res; /* sources = hires_density + hires_v*, else lowres_density + lowres_v* */
+    int lpt2;                /* PERTURB_ALGORITHM == 2LPT */
+    double growth_factor, init_growth_factor;
+    /* tables over delta = density * growth_factor in [tab_min, tab_min + 399 tab_width]
+     * (interp_tables.c:291-405,415-494), evaluated as exp(lerp) */
+    double tab_min, tab_width;
+    const float *ln_nion_table; /* host, C21CM_NDELTA_TABLE floats */
+    const float *ln_sfrd_table; /* host, C21CM_NDELTA_TABLE floats */
+    double prefactor_nion, prefactor_sfr; /* map_mass.c:228-239 */
+    double prefactor_wsfr;                /* 1 / t_h / t_star, used when whalo_sfr != NULL (:340-346) */
+} c21cm_halobox_spec;
+
+int c21cm_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions *ics,
+                        HaloBox *grids, void *stream);
+
+/* min and max of n floats (host or device array), e.g. the table range of the above */
+int c21cm_grid_minmax(const float *values, size_t n, double out_minmax[2], void *stream);
+
 /* Library management */
 const char *c21cm_version(void);
 int c21cm_device_synchronize(void);

@@ -62,6 +62,10 @@ int oracle_brightness_grids(const c21cm_brightness_spec *spec, const float *dens
                             const float *neutral_fraction, const float *spin_temperature,
                             float *brightness_temp, float *tau_21, double *mean_out);
 
+/* oracle_halobox.c -- reference: src/py21cmfast/src/HaloBox.c:244-436, map_mass.c:62-98,214-344 */
+int oracle_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions *ics,
+                         HaloBox *grids);
+
 void oracle_set_threads(int n);
 
 #ifdef __cplusplus

@@ -59,6 +59,8 @@ def load():
         lib.oracle_partially_ionized_temperature.argtypes = [f32, f32, f32]
         lib.oracle_fgtrm_bias_fast.restype = f64
         lib.oracle_fgtrm_bias_fast.argtypes = [f32, f32, f32, f32, f64]
+        lib.oracle_halobox_grids.restype = i32
+        lib.oracle_halobox_grids.argtypes = [vp, vp, vp]
         lib.oracle_brightness_grids.restype = i32
         lib.oracle_brightness_grids.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         lib.oracle_set_threads.restype = None
@@ -203,6 +205,19 @@ def ics_grids(spec, ics: dict | None = None):
     if st:
         raise RuntimeError(f"oracle_ics_grids status {st}")
     return ics
+
+
+def halobox_grids(spec, ics: dict, with_whalo=False):
+    """Oracle ComputeHaloBox integrated branch; returns dict(n_ion, halo_sfr[, whalo_sfr])."""
+    lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
+    out = {"n_ion": np.zeros(lo, np.float32), "halo_sfr": np.zeros(lo, np.float32)}
+    if with_whalo:
+        out["whalo_sfr"] = np.zeros(lo, np.float32)
+    hb = S.HaloBoxStruct(**{k: fptr(v) for k, v in out.items()})
+    st = load().oracle_halobox_grids(C.byref(spec), C.byref(ics_struct(ics)), C.byref(hb))
+    if st:
+        raise RuntimeError(f"oracle_halobox_grids status {st}")
+    return out
 
 
 def brightness_grids(spec, density, neutral_fraction, spin_temperature=None):

@@ -230,7 +230,7 @@ def test_ionized_box_e_integral(gpu_lib, oracle, tmp_path):
     lib.c21_Nion_General.restype = f64
     lib.c21_Nion_General.argtypes = [f64, f64, f64, f64, C.POINTER(ScalingConsts)]
     lib.c21_Nion_Conditional_table.restype = C.c_int
-    lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int,
+    lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int, f64,
                                                            C.POINTER(C.c_float), C.c_int]
     z = 9.0
     density = W.density_field_numpy(32, seed=5, sigma=0.6)
@@ -254,7 +254,7 @@ def test_ionized_box_e_integral(gpu_lib, oracle, tmp_path):
         M_R = lib.c21_RtoM(spec.R[r_index])
         return lib.c21_Nion_Conditional_table(spec.growth_factor, math.log(M_min), math.log(M_R),
                                               math.log(M_R), lib.c21_sigma_fast(M_R), dmin, dmax,
-                                              sc.mturn_a_nofb, C.byref(sc), 1, table,
+                                              sc.mturn_a_nofb, C.byref(sc), 1, -40.0, table,
                                               S.NDELTA_TABLE)
     cb = S.TABLE_FN(table_fn)
     spec.table_fn = cb

@@ -1,0 +1,120 @@
+"""GPU: ComputeHaloBox's integrated branch on the MI355X vs the CPU oracle (the oracle adds
+floats atomically like the reference, the device accumulates in double and narrows once:
+atol 3e-6 * max|field|), the grid extrema helper, and the L-INTEGRAL chain
+ComputeHaloBox -> ComputeIonizedBox through the reference's entry points."""
+
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from test_oracle_halobox import halobox_spec, make_tables, random_ics
+
+pytestmark = pytest.mark.gpu
+S = importlib.import_module("21cmfast_amd.structs")
+
+
+@pytest.fixture(scope="module")
+def api(gpu_lib):
+    return importlib.import_module("21cmfast_amd.grid_api")
+
+
+def compare(got, ref):
+    for k in ref:
+        g = got[k].cpu().numpy() if hasattr(got[k], "cpu") else got[k]
+        scale = np.abs(ref[k]).max()
+        np.testing.assert_allclose(g, ref[k], rtol=2e-5, atol=3e-6 * scale, err_msg=k)
+
+
+@pytest.mark.parametrize("n,N,hires,vscale,device", [(16, 32, False, 1.0, False),
+                                                     (32, 64, True, 1.0, True),
+                                                     (24, 72, True, 8.0, False),
+                                                     (40, 40, False, 25.0, True),
+                                                     (33, 66, True, 3.0, False)])
+def test_halobox_matches_oracle(api, oracle, n, N, hires, vscale, device):
+    tables = make_tables()
+    spec = halobox_spec(n, N, hires, tables)
+    ics = random_ics(n, N, hires, seed=n + N, vscale=vscale)
+    ref = oracle.halobox_grids(spec, ics, with_whalo=True)
+    if device:
+        import torch
+
+        ics = {k: torch.from_numpy(v).cuda() for k, v in ics.items()}
+    got = api.halobox_grids(spec, ics, with_whalo=True)
+    compare(got, ref)
+
+
+def test_grid_minmax(api):
+    import torch
+
+    a = np.random.default_rng(3).standard_normal(100003).astype(np.float32)
+    assert api.grid_minmax(a) == (float(a.min()), float(a.max()))
+    assert api.grid_minmax(torch.from_numpy(a).cuda()) == (float(a.min()), float(a.max()))
+
+
+def test_l_integral_chain_entry_points(gpu_lib, oracle, tmp_path):
+    """SOURCE_MODEL = L-INTEGRAL: ComputeHaloBox fills n_ion from the initial conditions, and
+    ComputeIonizedBox consumes it (two filtered grids, the benchmark path)."""
+    from test_gpu_abi import Session, call_ionize, fptr, ionize_spec_from_scalars
+
+    lib = gpu_lib
+    n, N = 32, 64
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=N, SOURCE_MODEL=2, R_BUBBLE_MAX=12.0)
+    z = 8.0
+    ics = random_ics(n, N, False, seed=9)
+    ics["lowres_density"] = (ics["lowres_density"] * 0.5).astype(np.float32)
+    out = {k: np.zeros((n, n, n), np.float32) for k in ("n_ion", "halo_sfr")}
+    hb = S.HaloBoxStruct(n_ion=fptr(out["n_ion"]), halo_sfr=fptr(out["halo_sfr"]))
+    icss = S.InitialConditionsStruct(**{k: fptr(v) for k, v in ics.items()})
+    lib.ComputeHaloBox.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
+    st = lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb))
+    assert st == 0, lib.c21cm_last_error()
+    assert hb.log10_Mcrit_ACG_ave == pytest.approx(np.log10(ses.ap.M_TURN))
+    assert out["n_ion"].min() >= 0 and out["n_ion"].max() > 0 and out["halo_sfr"].max() > 0
+    # the same call restated through the grid API with host-side tables from the library
+    from test_host_scalars import ScalingConsts
+
+    f64 = C.c_double
+    lib.c21_set_scaling_constants.restype = C.c_int
+    lib.c21_set_scaling_constants.argtypes = [f64, C.POINTER(ScalingConsts)]
+    lib.c21_Nion_Conditional_table.restype = C.c_int
+    lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int, f64,
+                                                           C.POINTER(C.c_float), C.c_int]
+    lib.sigma_z0.restype = f64
+    lib.sigma_z0.argtypes = [f64]
+    sc = ScalingConsts()
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    sc_sfrd = ScalingConsts.from_buffer_copy(sc)
+    sc_sfrd.fesc_10, sc_sfrd.fesc_7, sc_sfrd.alpha_esc, sc_sfrd.Mlim_Fesc = 1.0, 1.0, 0.0, 0.0
+    D = lib.dicke(z)
+    d = ics["lowres_density"].astype(np.float64) * D
+    dmin, dmax = min(0.0, d.min()) * 1.001, max(0.0, d.max()) * 1.001
+    M_min = lib.c21_minimum_source_mass(z)
+    M_cell = lib.c21_rhocrit() * ses.cp.OMm * ses.so.BOX_LEN**3 / n**3
+    tabs = [(C.c_float * S.NDELTA_TABLE)(), (C.c_float * S.NDELTA_TABLE)()]
+    for tab, consts, floor in ((tabs[0], sc, -40.0), (tabs[1], sc_sfrd, -50.0)):
+        assert lib.c21_Nion_Conditional_table(D, np.log(M_min), np.log(1e16), np.log(M_cell),
+                                              lib.sigma_z0(M_cell), dmin, dmax, sc.mturn_a_nofb,
+                                              C.byref(consts), 1, floor, tab, S.NDELTA_TABLE) == 0
+    pre_stars = lib.c21_rhocrit() * ses.cp.OMb * sc.fstar_10
+    spec = S.HaloBoxSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=ses.so.BOX_LEN,
+                         box_len_z=ses.so.BOX_LEN, perturb_on_high_res=0, lpt2=1, growth_factor=D,
+                         init_growth_factor=lib.dicke(ses.so.INITIAL_REDSHIFT), tab_min=dmin,
+                         tab_width=(dmax - dmin) / (S.NDELTA_TABLE - 1.0),
+                         ln_nion_table=C.cast(tabs[0], S.c_float_p),
+                         ln_sfrd_table=C.cast(tabs[1], S.c_float_p),
+                         prefactor_nion=pre_stars * sc.fesc_10 * sc.pop2_ion,
+                         prefactor_sfr=pre_stars / sc.t_star / sc.t_h, prefactor_wsfr=0.0)
+    ref = oracle.halobox_grids(spec, ics)
+    compare(out, ref)
+    # feed it to ComputeIonizedBox; the oracle runs the same two-grid algorithm on the same n_ion
+    density = (0.4 * np.random.default_rng(2).standard_normal((n, n, n))).astype(np.float32)
+    got = call_ionize(lib, z, density, n_ion=out["n_ion"])
+    assert got["status"] == 0, lib.c21cm_last_error()
+    ispec = ionize_spec_from_scalars(ses, z, lagrangian=True, tables=False)
+    ispec.f_limit_acg = 0.0
+    iref = oracle.ionize_grids(ispec, density, out["n_ion"])
+    ion_g, ion_r = got["neutral_fraction"] == 0, iref["neutral_fraction"] == 0
+    assert np.mean(ion_g != ion_r) <= 2e-4

@@ -178,7 +178,7 @@ def _bind_conditional(lib):
     lib.c21_Nion_ConditionalM.restype = f64
     lib.c21_Nion_ConditionalM.argtypes = [f64] * 7 + [C.POINTER(ScalingConsts), C.c_int]
     lib.c21_Nion_Conditional_table.restype = C.c_int
-    lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int,
+    lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int, f64,
                                                            C.POINTER(C.c_float), C.c_int]
     lib.c21_set_scaling_constants.restype = C.c_int
     lib.c21_set_scaling_constants.argtypes = [f64, C.POINTER(ScalingConsts)]
@@ -264,7 +264,7 @@ def test_conditional_nion_against_scipy(host, pkg):
     # the 400-bin table (what calculate_fcoll_grid interpolates) holds ln of the same numbers
     tab = (C.c_float * 400)()
     assert host.c21_Nion_Conditional_table(D, math.log(Mmin), math.log(Mcond), math.log(Mcond), s_c,
-                                           -0.8, 1.4, Mturn, C.byref(sc), 1, tab, 400) == 0
+                                           -0.8, 1.4, Mturn, C.byref(sc), 1, -40.0, tab, 400) == 0
     for k in (0, 57, 200, 399):
         delta = -0.8 + np.float32(k) / (np.float32(400) - 1.0) * 2.2
         direct = host.c21_Nion_ConditionalM(D, math.log(Mmin), math.log(Mcond), math.log(Mcond),
