@@ -115,6 +115,32 @@ struct Dft<8, SIGN> {
 };
 
 // ------------------------------------------------------------------ Stockham stages in LDS
+template <int SIGN>
+struct Dft<16, SIGN> {
+    __device__ __forceinline__ static void run(float2 *v) {
+        float2 e[8], o[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            e[i] = v[2 * i];
+            o[i] = v[2 * i + 1];
+        }
+        Dft<8, SIGN>::run(e);
+        Dft<8, SIGN>::run(o);
+        // W16^k = exp(SIGN 2 pi i k / 16), k = 0..7
+        const float c = 0.92387953251128675613f, s = 0.38268343236508977173f;
+        const float h = 0.70710678118654752440f;
+        const float wr[8] = {1.f, c, h, s, 0.f, -s, -h, -c};
+        const float wi[8] = {0.f, s, h, c, 1.f, c, h, s};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float2 w = make_float2(wr[k], SIGN > 0 ? wi[k] : -wi[k]);
+            const float2 t = (k == 0) ? o[0] : cmul(o[k], w);
+            v[k] = cadd(e[k], t);
+            v[k + 8] = csub(e[k], t);
+        }
+    }
+};
+
 // The tile lives in LDS as tile[point * ROW + column], ROW >= COLS.  One stage of radix R
 // with `s` = product of the radices already applied (log2s its log):
 //   butterfly b in [0, N/R): inputs  tile[b + k*N/R],          k = 0..R-1
@@ -1251,6 +1277,133 @@ int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
     return 0;
 }
 
+// ---- fused pass Z, 512-point lines: wave-level transform -------------------------------------
+// H = 256 = 16 x 16.  Sixteen lanes own one line (four lines per wave, sixteen per workgroup);
+// lane b holds the points 16a + b, a = 0..15, in registers.  Per grid: Hermitian pre-processing
+// (the partner X[H-k] comes back from the line's LDS copy), a 16-point DFT in registers, the
+// twiddle w^(bc), one transposition through LDS (rows padded to 17 so that both the column
+// write and the row read are conflict free), a second 16-point DFT.  Lane c then holds
+// z[c + 16 d], d = 0..15, i.e. cells (2j, 2j+1) for sixteen contiguous j per d across the
+// sixteen lanes: the mask is read and written straight from registers.  Everything is
+// wave-synchronous -- LDS operations of a wave execute in order -- so there is no workgroup
+// barrier in the transform, and a line costs ~80 LDS operations per lane x 16 lanes against
+// ~2500 lane-operations in the tile version.
+constexpr int ZW_LINES = 16;           // lines per workgroup
+constexpr int ZW_LINE_LDS = 16 * 17 + 4;  // float2 per line region (17-padded rows + skew)
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// x[a] = X[16 a + b] of one line (a = 0..15), xh = Re X[H]; returns z[c + 16 d] in x[d] for
+// c = b.  L: this line's LDS region, twH / twN: exp(-2 pi i t / 256), exp(-2 pi i t / 512).
+__device__ __forceinline__ void wave_c2r_256(float2 (&x)[16], float xh, float2 *L,
+                                             const float2 *twH, const float2 *twN, int b) {
+    constexpr int H = 256;
+#pragma unroll
+    for (int a = 0; a < 16; a++) L[a * 17 + b] = x[a];
+    wave_fence();
+    // Z[k] = E + i O, E = X[k] + conj(X[H-k]), O = (X[k] - conj(X[H-k])) exp(+2 pi i k / 512)
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        const int k = 16 * a + b;
+        const int kp = (H - k) & (H - 1);  // k = 0 pairs with the Nyquist value below
+        const float2 A = x[a];
+        float2 B = L[(kp >> 4) * 17 + (kp & 15)];
+        if (k == 0) B = make_float2(xh, 0.f);
+        const float2 E = make_float2(A.x + B.x, A.y - B.y);
+        const float2 D = make_float2(A.x - B.x, A.y + B.y);
+        float2 w = twN[k];
+        w.y = -w.y;
+        const float2 O = cmul(D, w);
+        x[a] = (k == 0) ? make_float2(A.x + xh, A.x - xh) : make_float2(E.x - O.y, E.y + O.x);
+    }
+    Dft<16, +1>::run(x);  // over a: Y_b[c]
+    wave_fence();         // the partner reads are done before the region is overwritten
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        float2 w = twH[c * b];
+        w.y = -w.y;
+        L[c * 17 + b] = (c == 0) ? x[0] : cmul(x[c], w);
+    }
+    wave_fence();
+#pragma unroll
+    for (int bb = 0; bb < 16; bb++) x[bb] = L[b * 17 + bb];  // lane c = b reads its row
+    Dft<16, +1>::run(x);  // over b: z[c + 16 d] in x[d]
+}
+
+__global__ void __launch_bounds__(kBlock)
+zw_ionise_kernel_512(ZFusedArgs a, const float2 *__restrict__ twH_global,
+                     const float2 *__restrict__ twN_global) {
+    constexpr int NZ = 512, H = 256;
+    __shared__ float2 lines[ZW_LINES * ZW_LINE_LDS];
+    __shared__ float2 twH[H], twN[H];
+    __shared__ double red[kBlock / 64];
+    for (int t = threadIdx.x; t < H; t += kBlock) {
+        twH[t] = twH_global[t];
+        twN[t] = twN_global[t];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, b = lane & 15;
+    const int lw = wave * 4 + g;
+    const long line = (long)blockIdx.x * ZW_LINES + lw;
+    float2 *L = lines + lw * ZW_LINE_LDS;
+    const float2 *dm = a.d_main + line * H, *sm = a.s_main + line * H;
+    float2 xd[16], xs[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) xd[q] = dm[16 * q + b];
+#pragma unroll
+    for (int q = 0; q < 16; q++) xs[q] = sm[16 * q + b];
+    const float dh = a.d_nyq[line].x, sh = a.s_nyq[line].x;
+    uchar2 old[16];
+    unsigned char *mrow = a.first_cross + line * NZ;
+#pragma unroll
+    for (int d = 0; d < 16; d++) old[d] = reinterpret_cast<const uchar2 *>(mrow)[b + 16 * d];
+    __syncthreads();  // twiddle tables
+    wave_c2r_256(xd, dh, L, twH, twN, b);
+    wave_fence();
+    wave_c2r_256(xs, sh, L, twH, twN, b);
+
+    const bool floor_ionises = a.mass_dep_zeta && (a.f_limit * a.ion_eff > 1.);
+    const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
+    double acc = 0.;
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+        const float s0 = fmaxf(xs[d].x, 0.f), s1 = fmaxf(xs[d].y, 0.f);
+        acc += (double)s0;
+        acc += (double)s1;
+        const double D0 = a.rhocrit_omb * (1. + (double)fmaxf(xd[d].x, dmin));
+        const double D1 = a.rhocrit_omb * (1. + (double)fmaxf(xd[d].y, dmin));
+        const bool i0 = floor_ionises || ((double)s0 * a.ion_eff > D0);
+        const bool i1 = floor_ionises || ((double)s1 * a.ion_eff > D1);
+        uchar2 m = old[d];
+        if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
+        if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
+        reinterpret_cast<uchar2 *>(mrow)[b + 16 * d] = m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) sum += red[w];
+        a.partials[blockIdx.x] = sum;
+    }
+}
+
+bool zw_enabled() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char *e = getenv("C21CM_ZPASS");
+        cached = (e && e[0] == 't') ? 0 : 1;  // C21CM_ZPASS=tile selects the tile version
+    }
+    return cached == 1;
+}
+
 template <int NZ>
 int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
     constexpr int H = NZ / 2;
@@ -1270,7 +1423,19 @@ int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
     return 0;
 }
 
-int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream) {
+// *n_partials: how many workgroup partials of sum(stars) the launch wrote
+int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream, int *n_partials) {
+    *n_partials = (int)(nlines / LZ_FUSED);
+    if (nz == 512 && zw_enabled() && nlines % ZW_LINES == 0) {
+        const float2 *twH = twiddles(256);
+        const float2 *twN = twiddles(512);
+        if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+        *n_partials = (int)(nlines / ZW_LINES);
+        hipLaunchKernelGGL(zw_ionise_kernel_512, dim3((unsigned)(nlines / ZW_LINES)), dim3(kBlock),
+                           0, stream, a, twH, twN);
+        LAUNCH_CHECK();
+        return 0;
+    }
     switch (nz) {
         case 64: return launch_z_fused<64>(a, nlines, stream);
         case 128: return launch_z_fused<128>(a, nlines, stream);
@@ -1665,9 +1830,10 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
     a.f_limit = f_limit;
     a.mass_dep_zeta = mass_dep_zeta;
     a.r_index = r_index;
-    int st = dispatch_z_fused(nz, a, nlines, (hipStream_t)stream);
+    int n_partials = 0;
+    int st = dispatch_z_fused(nz, a, nlines, (hipStream_t)stream, &n_partials);
     if (st) return st;
-    return c21hip_reduce_sum(partials, (int)(nlines / LZ_FUSED), sum_out, stream);
+    return c21hip_reduce_sum(partials, n_partials, sum_out, stream);
 }
 
 // ------------------------------------------------------------------ single-kernel timing hook

@@ -101,6 +101,39 @@ def test_long_lines_non_cubic_parity(api, oracle):
     oracle.set_threads(16)
 
 
+@pytest.mark.parametrize("zpass", ["wave", "tile"])
+def test_512_point_z_lines_parity(api, oracle, zpass, monkeypatch):
+    """The benchmark's z-line length (512 points: the wave-level fused pass Z, or the tile version
+    with C21CM_ZPASS=tile) on a 64 x 64 x 512 box the oracle finishes in seconds."""
+    import subprocess
+    import sys
+
+    if zpass == "tile":
+        # the choice is cached per process: run the other variant in a child process
+        code = ("import importlib, numpy as np, sys; sys.path.insert(0, 'tests');"
+                "import test_gpu_ionize as t; api = importlib.import_module('21cmfast_amd.grid_api');"
+                "oracle = importlib.import_module('oracle.oracle'); oracle.load();"
+                "t.check_512_lines(api, oracle); print('OK-512')")
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                             env={**__import__("os").environ, "C21CM_ZPASS": "tile"})
+        assert "OK-512" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+        return
+    check_512_lines(api, oracle)
+
+
+def check_512_lines(api, oracle):
+    oracle.set_threads(32)
+    spec = W.ionize_spec(64, hii_dim_z=512, r_bubble_max=12.0)
+    assert spec.n_radii >= 10
+    density = W.density_field_numpy((64, 64, 512), seed=77)
+    n_ion = W.nion_from_density(density)
+    ref = oracle.ionize_grids(spec, density, n_ion)
+    got = run_device(api, spec, density, n_ion, device_resident=True)
+    compare(got, ref, spec)
+    oracle.set_threads(16)
+    assert 0.05 < (ref["neutral_fraction"] == 0).mean() < 0.95
+
+
 @pytest.mark.parametrize("n", [32, 50, 64])
 def test_const_ion_eff_erfc_parity(api, oracle, n):
     """G = 1 variant: CONST-ION-EFF closed-form erfc, sharp-k filter, fix_mean."""
