@@ -42,7 +42,10 @@
 
 namespace {
 constexpr int kBlock = 256;
-constexpr int TZ = 16;  // columns per tile (128 B of float2)
+constexpr int TZ = 16;  // columns per tile (128 B of float2) for lines up to 512 points
+// 1024-point lines use 8 columns (64-byte row segments): a 16-column tile is 128 KB, and with
+// 1024 threads and the 128-VGPR budget that implies the kernel spilled 300-600 bytes per lane
+constexpr int line_tile_cols(int n) { return n >= 1024 ? 8 : TZ; }
 
 #define LAUNCH_CHECK()                                                                  \
     do {                                                                                \
@@ -512,10 +515,10 @@ __device__ __forceinline__ int mirror_row(int row_a) {
 // the window values are computed while the first tile's loads are in flight, so HBM latency
 // hides behind the LDS/ALU phase.
 // THREADS = 512 at N >= 128 (one workgroup per CU at N >= 256, 2 waves per SIMD, <= 256
-// VGPRs: room for the two register sets), 1024 at N = 1024 (a 128 KB tile), else 256.
+// VGPRs: room for the two register sets), else 256.
 template <int N, int FMODE = 0>
 struct LineThreads {
-    static constexpr int value = (N >= 1024) ? 1024 : ((N >= 128) ? 512 : 256);
+    static constexpr int value = (N >= 128) ? 512 : 256;
 };
 
 // the geometry of one work item, in wave-uniform registers
@@ -534,14 +537,16 @@ __global__ void __launch_bounds__((LineThreads<N, FMODE>::value), (LineThreads<N
 line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     static_assert(N >= 64, "tile loader needs N >= 64");
     constexpr int kBlock = LineThreads<N, FMODE>::value;
-    constexpr int RSTEP = kBlock / 8;  // rows covered by one sweep of the workgroup
+    constexpr int TZ = line_tile_cols(N);  // shadows the namespace constant: this kernel's tile
+    constexpr int CPAIR = TZ / 2;          // float4 (column pairs) per row
+    constexpr int RSTEP = kBlock / CPAIR;  // rows covered by one sweep of the workgroup
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
     float2 *tw = tile + N * TZ;                          // [N]
     for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
-    const int r0 = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+    const int r0 = threadIdx.x / CPAIR, c4 = threadIdx.x % CPAIR;
     const int n_work0 = (a.g0.pair_outer ? (a.g0.n_outer / 2 + 1) : a.g0.n_outer) * a.g0.n_ctiles;
     const int n_work1 =
         (a.n_geo > 1) ? (a.g1.pair_outer ? (a.g1.n_outer / 2 + 1) : a.g1.n_outer) * a.g1.n_ctiles : 0;
@@ -587,7 +592,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // Two register sets: while tile t is transformed in LDS, the loads of tiles t+1 AND t+2
     // are in flight (a single set left HBM idle between a tile's arrival and the issue of the
     // next loads: 4.5 TB/s against the 6.3 TB/s a plain copy reaches).
-    constexpr bool TWO_SETS = (N < 1024);
+    constexpr bool TWO_SETS = true;
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
@@ -1170,44 +1175,44 @@ void geo_ptrs(LineGeo &g, int grid, const float2 *src, float2 *dst) {
     g.src[grid] = src;
     g.dst[grid] = dst;
 }
-LineGeo geo_x_main(int ny, int H) {  // lines along x, outer = k_y (mirror-paired), columns = k_z
+LineGeo geo_x_main(int ny, int H, int tz) {  // lines along x, outer = k_y (mirror-paired), columns = k_z
     LineGeo g{};
     g.line_stride = (long)ny * H;
     g.outer_stride = H;
     g.col_stride = 1;
     g.n_outer = ny;
-    g.n_ctiles = H / TZ;
+    g.n_ctiles = H / tz;
     g.pair_outer = 1;
     g.filter_axis = 0;
     return g;
 }
-LineGeo geo_x_nyq(int ny) {  // Nyquist plane [nx][ny]: lines along x, columns = k_y
+LineGeo geo_x_nyq(int ny, int tz) {  // Nyquist plane [nx][ny]: lines along x, columns = k_y
     LineGeo g{};
     g.line_stride = ny;
     g.outer_stride = 0;
     g.col_stride = 1;
     g.n_outer = 1;
-    g.n_ctiles = ny / TZ;
+    g.n_ctiles = ny / tz;
     g.pair_outer = 0;
     g.filter_axis = 1;
     return g;
 }
-LineGeo geo_y_main(int nx, int ny, int H) {  // lines along y, outer = x, columns = k_z
+LineGeo geo_y_main(int nx, int ny, int H, int tz) {  // lines along y, outer = x, columns = k_z
     LineGeo g{};
     g.line_stride = H;
     g.outer_stride = (long)ny * H;
     g.col_stride = 1;
     g.n_outer = nx;
-    g.n_ctiles = H / TZ;
+    g.n_ctiles = H / tz;
     return g;
 }
-LineGeo geo_y_nyq(int nx, int ny) {  // Nyquist plane: lines along y contiguous, columns = x
+LineGeo geo_y_nyq(int nx, int ny, int tz) {  // Nyquist plane: lines along y contiguous, columns = x
     LineGeo g{};
     g.line_stride = 1;
     g.outer_stride = 0;
     g.col_stride = ny;
     g.n_outer = 1;
-    g.n_ctiles = nx / TZ;
+    g.n_ctiles = nx / tz;
     return g;
 }
 
@@ -1218,7 +1223,7 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
         return C21CM_MEMORY_ALLOC_ERROR;
     }
-    const size_t lds = sizeof(float2) * ((size_t)N * TZ + N);
+    const size_t lds = sizeof(float2) * ((size_t)N * line_tile_cols(N) + N);
     const int n_work = geo_items(a.g0) + (a.n_geo > 1 ? geo_items(a.g1) : 0);
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
     int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
@@ -1622,8 +1627,8 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     // ---- pass X: main block + Nyquist plane (x grids) in one launch
     a.n_geo = 2;
     a.n_grids = n_grids;
-    a.g0 = geo_x_main(ny, H);
-    a.g1 = geo_x_nyq(ny);
+    a.g0 = geo_x_main(ny, H, line_tile_cols(nx));
+    a.g1 = geo_x_nyq(ny, line_tile_cols(nx));
     for (int g = 0; g < n_grids; g++) {
         const float2 *src = reinterpret_cast<const float2 *>(split_src[g]);
         float2 *work = reinterpret_cast<float2 *>(split_work[g]);
@@ -1634,8 +1639,8 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     if (!(phases & 4)) return 0;
     // ---- pass Y (in place)
     a.fp.type = -1;
-    a.g0 = geo_y_main(nx, ny, H);
-    a.g1 = geo_y_nyq(nx, ny);
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny));
+    a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
     a.g1_strided = 1;
     for (int g = 0; g < n_grids; g++) {
         float2 *work = reinterpret_cast<float2 *>(split_work[g]);
@@ -1717,16 +1722,16 @@ extern "C" int c21hip_split_r2c(const float *real_in, long in_zstride, float *sp
     a.n_geo = 2;
     a.n_grids = 1;
     // pass Y, main block and Nyquist plane
-    a.g0 = geo_y_main(nx, ny, H);
-    a.g1 = geo_y_nyq(nx, ny);
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny));
+    a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
     a.g1_strided = 1;
     geo_ptrs(a.g0, 0, o_main, o_main);
     geo_ptrs(a.g1, 0, o_nyq, o_nyq);
     if ((st = dispatch_line_pass<-1>(ny, a, 0, stream))) return st;
     // pass X with the normalisation folded into its store
     a.out_scale = out_scale;
-    a.g0 = geo_x_main(ny, H);
-    a.g1 = geo_x_nyq(ny);
+    a.g0 = geo_x_main(ny, H, line_tile_cols(nx));
+    a.g1 = geo_x_nyq(ny, line_tile_cols(nx));
     a.g1_strided = 0;
     geo_ptrs(a.g0, 0, o_main, o_main);
     geo_ptrs(a.g1, 0, o_nyq, o_nyq);
