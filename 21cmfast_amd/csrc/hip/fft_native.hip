@@ -47,6 +47,21 @@ constexpr int TZ = 16;  // columns per tile (128 B of float2) for lines up to 51
 // 1024 threads and the 128-VGPR budget that implies the kernel spilled 300-600 bytes per lane
 constexpr int line_tile_cols(int n) { return n >= 1024 ? 8 : TZ; }
 
+// x-blocked split layout.  The main block is stored as [x / XB][y][x % XB][k_z] with
+// XB = 2^xb_log2(nx): 1 (the plain [x][y][k_z]) up to 512-point x-lines, 16 for 1024.  At 1024^3 the
+// rows of a pass-X tile would otherwise lie ny*nz/2*8 B = 4 MB apart, one page each, and 42 % of
+// the pass's L1-TLB requests missed; blocked, 16 consecutive x are 4 KB apart and a tile
+// touches 64 pages instead of 1024.  Memory line m = (x / XB * ny + y) * XB + x % XB holds the
+// k_z row of the logical line x * ny + y; the Nyquist plane stays [x][y].
+__host__ __device__ constexpr int split_xb_log2(int nx) { return nx >= 1024 ? 4 : 0; }
+__host__ __device__ __forceinline__ long logical_line(long m, int ny, int lb) {
+    if (lb == 0) return m;
+    const long blk = (long)ny << lb;
+    const long xbk = m / blk, rem = m - xbk * blk;
+    const long y = rem >> lb, xi = rem & ((1 << lb) - 1);
+    return ((xbk << lb) + xi) * ny + y;
+}
+
 #define LAUNCH_CHECK()                                                                  \
     do {                                                                                \
         hipError_t e_ = hipGetLastError();                                              \
@@ -473,8 +488,11 @@ window_table_kernel(WTableArgs t) {
 struct LineGeo {
     const float2 *src[2];  // per grid
     float2 *dst[2];
-    long line_stride;   // elements between successive points of a line
-    long outer_stride;  // elements between successive outer indices
+    // offset of index i along the line / the outer axis: (i >> lb) * bstride + (i & (2^lb - 1)) *
+    // stride; lb = 0 (unblocked): i * bstride
+    long line_stride, line_bstride;
+    long outer_stride, outer_bstride;
+    int line_lb, outer_lb;
     long col_stride;    // elements between adjacent columns of a tile (1 = vector loads)
     int n_outer;        // outer index count (tiles along the non-transformed, non-column axis)
     int n_ctiles;       // column tiles (columns / TZ)
@@ -525,7 +543,8 @@ struct LineThreads {
 struct LineItem {
     const float2 *src0, *src1;
     float2 *dst0, *dst1;
-    long line_stride, outer_stride, col_stride;
+    long line_stride, line_bstride, outer_stride, outer_bstride, col_stride;
+    int line_lb, outer_lb;
     int n_outer, filter_axis;
     int og, ct, npair;
     const double *wt0, *wt1;  // FMODE 3: window tables of this geometry
@@ -565,7 +584,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         it.dst0 = s ? a.g1.dst[0] : a.g0.dst[0];
         it.dst1 = s ? a.g1.dst[1] : a.g0.dst[1];
         it.line_stride = s ? a.g1.line_stride : a.g0.line_stride;
+        it.line_bstride = s ? a.g1.line_bstride : a.g0.line_bstride;
+        it.line_lb = s ? a.g1.line_lb : a.g0.line_lb;
         it.outer_stride = s ? a.g1.outer_stride : a.g0.outer_stride;
+        it.outer_bstride = s ? a.g1.outer_bstride : a.g0.outer_bstride;
+        it.outer_lb = s ? a.g1.outer_lb : a.g0.outer_lb;
         it.col_stride = s ? a.g1.col_stride : a.g0.col_stride;
         it.n_outer = s ? a.g1.n_outer : a.g0.n_outer;
         it.filter_axis = s ? a.g1.filter_axis : a.g0.filter_axis;
@@ -583,7 +606,14 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     auto member_base = [](const LineItem &it, int m) {
         const int mi = it.npair == 2 ? (m & 1) : 0;
         const int outer = mi == 0 ? it.og : it.n_outer - it.og;
-        return (long)outer * it.outer_stride + (long)it.ct * TZ * it.col_stride;
+        return (long)(outer >> it.outer_lb) * it.outer_bstride +
+               (long)(outer & ((1 << it.outer_lb) - 1)) * it.outer_stride +
+               (long)it.ct * TZ * it.col_stride;
+    };
+    // element offset of row r (< N/2 + 1) of a line from the line's first point
+    auto row_off = [](const LineItem &it, int r) {
+        return (unsigned)(r >> it.line_lb) * (unsigned)it.line_bstride +
+               (unsigned)(r & ((1 << it.line_lb) - 1)) * (unsigned)it.line_stride;
     };
 
     // Addressing: a wave-uniform 64-bit tile base (SGPRs) plus 32-bit per-thread element
@@ -626,15 +656,14 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         }
     };
     auto issue_loads = [&](float4(&reg)[2 * NP], const LineItem &it, int m) {
-        const unsigned ls = (unsigned)it.line_stride;
         const float2 *lo = (member_grid(it, m) ? it.src1 : it.src0) + member_base(it, m);
-        const float2 *hi = lo + (long)(N / 2) * it.line_stride;
+        const float2 *hi = lo + (long)((N / 2) >> it.line_lb) * it.line_bstride;
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
             // mirror row N - row_a = N/2 + (N/2 - row_a); row_a = 0 pairs with N/2 itself
-            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : (unsigned)(N / 2 - row_a) * ls)
-                                          : (unsigned)row_a * ls;
+            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : row_off(it, N / 2 - row_a))
+                                          : row_off(it, row_a);
             const float2 *p = (u & 1) ? hi : lo;
             reg[u] = *reinterpret_cast<const float4 *>(p + (roff + 2u * c4));
         }
@@ -672,8 +701,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const int m = cur.m;
         // store target of the tile now in registers
         float2 *const st_lo = (member_grid(it, m) ? it.dst1 : it.dst0) + member_base(it, m);
-        const long st_half = (long)(N / 2) * it.line_stride;
-        const unsigned st_ls = (unsigned)it.line_stride;
+        const long st_half = (long)((N / 2) >> it.line_lb) * it.line_bstride;
         if (!first) __syncthreads();  // the previous tile's LDS reads are done
         first = false;
         if (FMODE == 3 && w_reload(it, m)) {
@@ -718,8 +746,8 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 v.z *= a.out_scale;
                 v.w *= a.out_scale;
             }
-            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : (unsigned)(N / 2 - row_a) * st_ls)
-                                          : (unsigned)row_a * st_ls;
+            const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : row_off(it, N / 2 - row_a))
+                                          : row_off(it, row_a);
             float2 *p = st_lo + ((u & 1) ? st_half : 0);
             *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
         }
@@ -764,10 +792,11 @@ main_done:
     // ---- epilogue: the strided tiles of g1 (no window, not pipelined: 2 * nx/16 tiles in
     // all), taken by the workgroups at the end of the grid, which have the fewest main items
     for (int w = (int)(gridDim.x - 1 - blockIdx.x); w < n_work1; w += (int)gridDim.x) {
-        const unsigned ls = (unsigned)a.g1.line_stride, cs = (unsigned)a.g1.col_stride;
+        // (the strided geometry is the unblocked Nyquist plane: offsets are i * bstride)
+        const unsigned ls = (unsigned)a.g1.line_bstride, cs = (unsigned)a.g1.col_stride;
         const int nct = a.g1.n_ctiles;
         const int og = w / nct, ct = w - og * nct;
-        const long base = (long)og * a.g1.outer_stride + (long)ct * TZ * a.g1.col_stride;
+        const long base = (long)og * a.g1.outer_bstride + (long)ct * TZ * a.g1.col_stride;
         for (int g = 0; g < a.n_grids; g++) {
             const float2 *src = (g ? a.g1.src[1] : a.g1.src[0]) + base;
             float2 *dst = (g ? a.g1.dst[1] : a.g1.dst[0]) + base;
@@ -818,6 +847,7 @@ struct ZPassArgs {
     float *out;          // real rows of out_zstride floats
     long out_zstride;
     float out_scale;
+    int ny, lb;          // x-blocked layout: memory line -> logical line (logical_line())
     // epilogues of the Eulerian source models (EPI 1, 2)
     double *p0, *p1;     // per-workgroup partials: EPI 1 min / max, EPI 2 sum (p0)
     float *f_out;        // EPI 2: dense f_coll grid [lines][NZ]
@@ -851,7 +881,7 @@ __device__ __forceinline__ void z_issue_loads(const float2 *main, long l0,
 template <int NZ, int LZ>
 __device__ __forceinline__ void z_transform(float2 *tile, const float2 *twH, const float2 *twN,
                                             const float4 (&reg)[ZGeom<NZ, LZ>::NLOAD],
-                                            const float2 *nyq, long l0) {
+                                            const float2 *nyq, long l0, int ny, int lb) {
     constexpr int H = ZGeom<NZ, LZ>::H, NF4 = ZGeom<NZ, LZ>::NF4, ZROW = LZ + 1;
 #pragma unroll
     for (int u = 0; u < ZGeom<NZ, LZ>::NLOAD; u++) {
@@ -870,7 +900,7 @@ __device__ __forceinline__ void z_transform(float2 *tile, const float2 *twH, con
         const int li = i % LZ, k = i / LZ;
         if (k == 0) {
             const float x0 = tile[li].x;
-            const float xh = nyq[l0 + li].x;
+            const float xh = nyq[logical_line(l0 + li, ny, lb)].x;
             tile[li] = make_float2(x0 + xh, x0 - xh);
         } else {
             const float2 A = tile[k * ZROW + li], B = tile[(H - k) * ZROW + li];
@@ -907,7 +937,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     const long l0 = (long)blockIdx.x * LZ;
     float4 reg[ZGeom<NZ, LZ>::NLOAD];
     z_issue_loads<NZ, LZ>(a.main, l0, reg);
-    z_transform<NZ, LZ>(tile, twH, twN, reg, a.nyq, l0);
+    z_transform<NZ, LZ>(tile, twH, twN, reg, a.nyq, l0, a.ny, a.lb);
     // ---- store: lanes along j, one float2 = (x[2j], x[2j+1])
     double acc0 = 0., acc1 = 0.;
 #pragma unroll
@@ -924,9 +954,10 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
             acc0 += f0;
             acc0 += f1;
-            reinterpret_cast<float2 *>(a.f_out + (l0 + li) * NZ)[j] = make_float2((float)f0, (float)f1);
+            reinterpret_cast<float2 *>(a.f_out + logical_line(l0 + li, a.ny, a.lb) * NZ)[j] =
+                make_float2((float)f0, (float)f1);
         } else {
-            reinterpret_cast<float2 *>(a.out + (l0 + li) * a.out_zstride)[j] = v;
+            reinterpret_cast<float2 *>(a.out + logical_line(l0 + li, a.ny, a.lb) * a.out_zstride)[j] = v;
             if (EPI == 1) {
                 const double lo = fmin((double)v.x, (double)v.y), hi = fmax((double)v.x, (double)v.y);
                 acc0 = (u == 0) ? lo : fmin(acc0, lo);
@@ -972,6 +1003,7 @@ struct ZFwdArgs {
     long in_zstride;
     float2 *main, *nyq;
     double factor, lo, hi;  // v = clip(in*factor, lo, hi); clip disabled when lo > hi
+    int ny, lb;             // x-blocked layout (logical_line())
 };
 
 template <int NZ>
@@ -993,7 +1025,7 @@ z_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
     for (int u = 0; u < NIN; u++) {
         const int f = threadIdx.x + kBlock * u;
         const int li = f / H, j = f % H;
-        float2 v = reinterpret_cast<const float2 *>(a.in + (l0 + li) * a.in_zstride)[j];
+        float2 v = reinterpret_cast<const float2 *>(a.in + logical_line(l0 + li, a.ny, a.lb) * a.in_zstride)[j];
         if (clip) {
             v.x = (float)fmax(fmin((double)v.x * a.factor, a.hi), a.lo);
             v.y = (float)fmax(fmin((double)v.y * a.factor, a.hi), a.lo);
@@ -1012,7 +1044,7 @@ z_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
         if (k == 0) {
             const float2 z0 = tile[li];
             tile[li] = make_float2(z0.x + z0.y, 0.f);
-            a.nyq[l0 + li] = make_float2(z0.x - z0.y, 0.f);
+            a.nyq[logical_line(l0 + li, a.ny, a.lb)] = make_float2(z0.x - z0.y, 0.f);
         } else {
             const float2 A = tile[k * ZROW + li], B = tile[(H - k) * ZROW + li];
             const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
@@ -1052,6 +1084,7 @@ struct ZFusedArgs {
     double *partials;              // one per workgroup (nx*ny/LZ_FUSED)
     double rhocrit_omb, ion_eff, f_limit;
     int mass_dep_zeta, r_index;
+    int ny, lb;  // x-blocked layout (logical_line())
 };
 
 template <int NZ>
@@ -1077,9 +1110,9 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     for (int u = 0; u < NOUT; u++) {
         const int f = threadIdx.x + kBlock * u;
         const int li = f / H, j = f % H;
-        old[u] = reinterpret_cast<const uchar2 *>(a.first_cross + (l0 + li) * NZ)[j];
+        old[u] = reinterpret_cast<const uchar2 *>(a.first_cross + logical_line(l0 + li, a.ny, a.lb) * NZ)[j];
     }
-    z_transform<NZ, LZ>(tile, twH, twN, reg_d, a.d_nyq, l0);
+    z_transform<NZ, LZ>(tile, twH, twN, reg_d, a.d_nyq, l0, a.ny, a.lb);
     float2 dens[NOUT];
 #pragma unroll
     for (int u = 0; u < NOUT; u++) {
@@ -1088,7 +1121,7 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         dens[u] = tile[j * ZROW + li];
     }
     __syncthreads();
-    z_transform<NZ, LZ>(tile, twH, twN, reg_s, a.s_nyq, l0);
+    z_transform<NZ, LZ>(tile, twH, twN, reg_s, a.s_nyq, l0, a.ny, a.lb);
 
     const bool floor_ionises = a.mass_dep_zeta && (a.f_limit * a.ion_eff > 1.);
     const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
@@ -1108,7 +1141,7 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         uchar2 m = old[u];
         if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
         if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
-        reinterpret_cast<uchar2 *>(a.first_cross + (l0 + li) * NZ)[j] = m;
+        reinterpret_cast<uchar2 *>(a.first_cross + logical_line(l0 + li, a.ny, a.lb) * NZ)[j] = m;
     }
     // workgroup partial of sum(stars)
     __shared__ double red[kBlock / 64];
@@ -1128,17 +1161,21 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
 // FFTW-style padded half-spectrum [lines][H+1] -> split (main [lines][H], nyq [lines])
 __global__ void __launch_bounds__(kBlock)
 padded_to_split_kernel(const float2 *__restrict__ padded, float2 *__restrict__ main,
-                       float2 *__restrict__ nyq, long nlines, int H) {
+                       float2 *__restrict__ nyq, long nlines, int H, int ny, int lb) {
     const long total = nlines * (long)(H + 1);
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < total;
          i += (long)gridDim.x * kBlock) {
         const long line = i / (H + 1);
         const int k = (int)(i - line * (H + 1));
         const float2 v = padded[i];
-        if (k < H)
-            main[line * H + k] = v;
-        else
+        if (k < H) {
+            // logical line x * ny + y -> memory line (x / XB * ny + y) * XB + x % XB
+            const long x = line / ny, y = line - x * ny;
+            const long m = lb ? (((x >> lb) * ny + y) << lb) + (x & ((1 << lb) - 1)) : line;
+            main[m * H + k] = v;
+        } else {
             nyq[line] = v;
+        }
     }
 }
 
@@ -1175,10 +1212,21 @@ void geo_ptrs(LineGeo &g, int grid, const float2 *src, float2 *dst) {
     g.src[grid] = src;
     g.dst[grid] = dst;
 }
-LineGeo geo_x_main(int ny, int H, int tz) {  // lines along x, outer = k_y (mirror-paired), columns = k_z
+// offsets are (i >> lb) * bstride + (i & (2^lb - 1)) * stride; unblocked axes use lb = 0
+void geo_axes(LineGeo &g, int line_lb, long line_stride, long line_bstride, int outer_lb,
+              long outer_stride, long outer_bstride) {
+    g.line_lb = line_lb;
+    g.line_stride = line_stride;
+    g.line_bstride = line_bstride;
+    g.outer_lb = outer_lb;
+    g.outer_stride = outer_stride;
+    g.outer_bstride = outer_bstride;
+}
+// main block [x / XB][y][x % XB][k_z], XB = 2^lb (lb = split_xb_log2(nx))
+LineGeo geo_x_main(int ny, int H, int tz, int lb) {  // lines along x, outer = k_y (mirror-paired), columns = k_z
     LineGeo g{};
-    g.line_stride = (long)ny * H;
-    g.outer_stride = H;
+    const long xb = 1L << lb;
+    geo_axes(g, lb, H, (long)ny * xb * H, 0, 0, xb * H);
     g.col_stride = 1;
     g.n_outer = ny;
     g.n_ctiles = H / tz;
@@ -1188,8 +1236,7 @@ LineGeo geo_x_main(int ny, int H, int tz) {  // lines along x, outer = k_y (mirr
 }
 LineGeo geo_x_nyq(int ny, int tz) {  // Nyquist plane [nx][ny]: lines along x, columns = k_y
     LineGeo g{};
-    g.line_stride = ny;
-    g.outer_stride = 0;
+    geo_axes(g, 0, 0, ny, 0, 0, 0);
     g.col_stride = 1;
     g.n_outer = 1;
     g.n_ctiles = ny / tz;
@@ -1197,10 +1244,10 @@ LineGeo geo_x_nyq(int ny, int tz) {  // Nyquist plane [nx][ny]: lines along x, c
     g.filter_axis = 1;
     return g;
 }
-LineGeo geo_y_main(int nx, int ny, int H, int tz) {  // lines along y, outer = x, columns = k_z
+LineGeo geo_y_main(int nx, int ny, int H, int tz, int lb) {  // lines along y, outer = x, columns = k_z
     LineGeo g{};
-    g.line_stride = H;
-    g.outer_stride = (long)ny * H;
+    const long xb = 1L << lb;
+    geo_axes(g, 0, 0, xb * H, lb, H, (long)ny * xb * H);
     g.col_stride = 1;
     g.n_outer = nx;
     g.n_ctiles = H / tz;
@@ -1208,8 +1255,7 @@ LineGeo geo_y_main(int nx, int ny, int H, int tz) {  // lines along y, outer = x
 }
 LineGeo geo_y_nyq(int nx, int ny, int tz) {  // Nyquist plane: lines along y contiguous, columns = x
     LineGeo g{};
-    g.line_stride = 1;
-    g.outer_stride = 0;
+    geo_axes(g, 0, 0, 1, 0, 0, 0);
     g.col_stride = ny;
     g.n_outer = 1;
     g.n_ctiles = nx / tz;
@@ -1361,9 +1407,10 @@ zw_ionise_kernel_512(ZFusedArgs a, const float2 *__restrict__ twH_global,
     for (int q = 0; q < 16; q++) xd[q] = dm[16 * q + b];
 #pragma unroll
     for (int q = 0; q < 16; q++) xs[q] = sm[16 * q + b];
-    const float dh = a.d_nyq[line].x, sh = a.s_nyq[line].x;
+    const long lline = logical_line(line, a.ny, a.lb);
+    const float dh = a.d_nyq[lline].x, sh = a.s_nyq[lline].x;
     uchar2 old[16];
-    unsigned char *mrow = a.first_cross + line * NZ;
+    unsigned char *mrow = a.first_cross + lline * NZ;
 #pragma unroll
     for (int d = 0; d < 16; d++) old[d] = reinterpret_cast<const uchar2 *>(mrow)[b + 16 * d];
     __syncthreads();  // twiddle tables
@@ -1555,7 +1602,7 @@ extern "C" int c21hip_padded_to_split(const float *padded_c, float *split, int n
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(padded_to_split_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
                        (hipStream_t)stream, reinterpret_cast<const float2 *>(padded_c), main, nyq,
-                       nlines, H);
+                       nlines, H, ny, split_xb_log2(nx));
     LAUNCH_CHECK();
     return 0;
 }
@@ -1627,7 +1674,7 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     // ---- pass X: main block + Nyquist plane (x grids) in one launch
     a.n_geo = 2;
     a.n_grids = n_grids;
-    a.g0 = geo_x_main(ny, H, line_tile_cols(nx));
+    a.g0 = geo_x_main(ny, H, line_tile_cols(nx), split_xb_log2(nx));
     a.g1 = geo_x_nyq(ny, line_tile_cols(nx));
     for (int g = 0; g < n_grids; g++) {
         const float2 *src = reinterpret_cast<const float2 *>(split_src[g]);
@@ -1639,7 +1686,7 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     if (!(phases & 4)) return 0;
     // ---- pass Y (in place)
     a.fp.type = -1;
-    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny));
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
     a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
     a.g1_strided = 1;
     for (int g = 0; g < n_grids; g++) {
@@ -1705,6 +1752,8 @@ extern "C" int c21hip_split_r2c(const float *real_in, long in_zstride, float *sp
     float2 *o_main = reinterpret_cast<float2 *>(split_out);
     float2 *o_nyq = o_main + nlines * H;
     ZFwdArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
     z.in = real_in;
     z.in_zstride = in_zstride;
     z.main = o_main;
@@ -1722,7 +1771,7 @@ extern "C" int c21hip_split_r2c(const float *real_in, long in_zstride, float *sp
     a.n_geo = 2;
     a.n_grids = 1;
     // pass Y, main block and Nyquist plane
-    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny));
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
     a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
     a.g1_strided = 1;
     geo_ptrs(a.g0, 0, o_main, o_main);
@@ -1730,7 +1779,7 @@ extern "C" int c21hip_split_r2c(const float *real_in, long in_zstride, float *sp
     if ((st = dispatch_line_pass<-1>(ny, a, 0, stream))) return st;
     // pass X with the normalisation folded into its store
     a.out_scale = out_scale;
-    a.g0 = geo_x_main(ny, H, line_tile_cols(nx));
+    a.g0 = geo_x_main(ny, H, line_tile_cols(nx), split_xb_log2(nx));
     a.g1 = geo_x_nyq(ny, line_tile_cols(nx));
     a.g1_strided = 0;
     geo_ptrs(a.g0, 0, o_main, o_main);
@@ -1743,6 +1792,8 @@ extern "C" int c21hip_split_z_c2r(const float *split_work, float *real_out, long
                                   int nx, int ny, int nz, void *stream) {
     const long nlines = (long)nx * ny;
     ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
     z.main = reinterpret_cast<const float2 *>(split_work);
     z.nyq = z.main + nlines * (nz / 2);
     z.out = real_out;
@@ -1759,6 +1810,8 @@ extern "C" int c21hip_split_z_c2r_minmax(const float *split_work, float *real_ou
     const long nlines = (long)nx * ny;
     const int nb = (int)(nlines / LZ_PLAIN);
     ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
     z.main = reinterpret_cast<const float2 *>(split_work);
     z.nyq = z.main + nlines * (nz / 2);
     z.out = real_out;
@@ -1781,6 +1834,8 @@ extern "C" int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_de
                                          double *sum_out, void *stream) {
     const long nlines = (long)nx * ny;
     ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
     z.main = reinterpret_cast<const float2 *>(split_work);
     z.nyq = z.main + nlines * (nz / 2);
     z.out_scale = 1.0f;
@@ -1824,6 +1879,8 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
                                            double f_limit, void *stream) {
     const long nlines = (long)nx * ny;
     ZFusedArgs a{};
+    a.ny = ny;
+    a.lb = split_xb_log2(nx);
     a.d_main = reinterpret_cast<const float2 *>(delta_work);
     a.d_nyq = a.d_main + nlines * (nz / 2);
     a.s_main = reinterpret_cast<const float2 *>(stars_work);
@@ -1904,6 +1961,8 @@ extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, fl
                                              n, n, n, 5, 6.2e9, 1.0, 1, 1e-9, stream);
         else {
             ZPassArgs z{};
+            z.ny = n;
+            z.lb = split_xb_log2(n);
             z.main = reinterpret_cast<const float2 *>(a);
             z.nyq = z.main + nlines * H;
             z.out = real;
