@@ -159,6 +159,42 @@ struct Dft<16, SIGN> {
     }
 };
 
+template <int SIGN>
+struct Dft<32, SIGN> {
+    __device__ __forceinline__ static void run(float2 *v) {
+        float2 e[16], o[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            e[i] = v[2 * i];
+            o[i] = v[2 * i + 1];
+        }
+        Dft<16, SIGN>::run(e);
+        Dft<16, SIGN>::run(o);
+        // W32^k = exp(SIGN 2 pi i k / 32), k = 0..15
+        const float wr[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f,
+                              0.83146961230254523708f, 0.70710678118654752440f,
+                              0.55557023301960222474f, 0.38268343236508977173f,
+                              0.19509032201612826785f, 0.f, -0.19509032201612826785f,
+                              -0.38268343236508977173f, -0.55557023301960222474f,
+                              -0.70710678118654752440f, -0.83146961230254523708f,
+                              -0.92387953251128675613f, -0.98078528040323044913f};
+        const float wi[16] = {0.f, 0.19509032201612826785f, 0.38268343236508977173f,
+                              0.55557023301960222474f, 0.70710678118654752440f,
+                              0.83146961230254523708f, 0.92387953251128675613f,
+                              0.98078528040323044913f, 1.f, 0.98078528040323044913f,
+                              0.92387953251128675613f, 0.83146961230254523708f,
+                              0.70710678118654752440f, 0.55557023301960222474f,
+                              0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float2 w = make_float2(wr[k], SIGN > 0 ? wi[k] : -wi[k]);
+            const float2 t = (k == 0) ? o[0] : cmul(o[k], w);
+            v[k] = cadd(e[k], t);
+            v[k + 16] = csub(e[k], t);
+        }
+    }
+};
+
 // The tile lives in LDS as tile[point * ROW + column], ROW >= COLS.  One stage of radix R
 // with `s` = product of the radices already applied (log2s its log):
 //   butterfly b in [0, N/R): inputs  tile[b + k*N/R],          k = 0..R-1
@@ -1339,8 +1375,7 @@ int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
 // wave-synchronous -- LDS operations of a wave execute in order -- so there is no workgroup
 // barrier in the transform, and a line costs ~80 LDS operations per lane x 16 lanes against
 // ~2500 lane-operations in the tile version.
-constexpr int ZW_LINES = 16;           // lines per workgroup
-constexpr int ZW_LINE_LDS = 16 * 17 + 4;  // float2 per line region (17-padded rows + skew)
+constexpr int ZW_LINES = 16;  // lines per workgroup
 
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1348,48 +1383,57 @@ __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// x[a] = X[16 a + b] of one line (a = 0..15), xh = Re X[H]; returns z[c + 16 d] in x[d] for
-// c = b.  L: this line's LDS region, twH / twN: exp(-2 pi i t / 256), exp(-2 pi i t / 512).
-__device__ __forceinline__ void wave_c2r_256(float2 (&x)[16], float xh, float2 *L,
-                                             const float2 *twH, const float2 *twN, int b) {
-    constexpr int H = 256;
+// One line of H = 16 A complex points (A = 16: 512-point z-lines, A = 32: 1024-point ones).
+// In: x[a] = X[16 a + b] (a < A), xh = Re X[H].  Out: x[16 r + d] = z[(b + 16 r) + A d],
+// r < A / 16, d < 16.  L: this line's LDS region (A rows of 17), twH / twN:
+// exp(-2 pi i t / H) and exp(-2 pi i t / 2H), t < H.
+template <int A>
+__device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, const float2 *twH,
+                                         const float2 *twN, int b) {
+    constexpr int H = 16 * A;
 #pragma unroll
-    for (int a = 0; a < 16; a++) L[a * 17 + b] = x[a];
+    for (int a = 0; a < A; a++) L[a * 17 + b] = x[a];
     wave_fence();
-    // Z[k] = E + i O, E = X[k] + conj(X[H-k]), O = (X[k] - conj(X[H-k])) exp(+2 pi i k / 512)
+    // Z[k] = E + i O, E = X[k] + conj(X[H-k]), O = (X[k] - conj(X[H-k])) exp(+2 pi i k / 2H)
 #pragma unroll
-    for (int a = 0; a < 16; a++) {
+    for (int a = 0; a < A; a++) {
         const int k = 16 * a + b;
         const int kp = (H - k) & (H - 1);  // k = 0 pairs with the Nyquist value below
-        const float2 A = x[a];
+        const float2 Xk = x[a];
         float2 B = L[(kp >> 4) * 17 + (kp & 15)];
         if (k == 0) B = make_float2(xh, 0.f);
-        const float2 E = make_float2(A.x + B.x, A.y - B.y);
-        const float2 D = make_float2(A.x - B.x, A.y + B.y);
+        const float2 E = make_float2(Xk.x + B.x, Xk.y - B.y);
+        const float2 D = make_float2(Xk.x - B.x, Xk.y + B.y);
         float2 w = twN[k];
         w.y = -w.y;
         const float2 O = cmul(D, w);
-        x[a] = (k == 0) ? make_float2(A.x + xh, A.x - xh) : make_float2(E.x - O.y, E.y + O.x);
+        x[a] = (k == 0) ? make_float2(Xk.x + xh, Xk.x - xh) : make_float2(E.x - O.y, E.y + O.x);
     }
-    Dft<16, +1>::run(x);  // over a: Y_b[c]
-    wave_fence();         // the partner reads are done before the region is overwritten
+    Dft<A, +1>::run(x);  // over a: Y_b[c]
+    wave_fence();        // the partner reads are done before the region is overwritten
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
+    for (int c = 0; c < A; c++) {
         float2 w = twH[c * b];
         w.y = -w.y;
         L[c * 17 + b] = (c == 0) ? x[0] : cmul(x[c], w);
     }
     wave_fence();
 #pragma unroll
-    for (int bb = 0; bb < 16; bb++) x[bb] = L[b * 17 + bb];  // lane c = b reads its row
-    Dft<16, +1>::run(x);  // over b: z[c + 16 d] in x[d]
+    for (int r = 0; r < A / 16; r++) {  // this lane's rows c = b + 16 r
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++) x[16 * r + bb] = L[(b + 16 * r) * 17 + bb];
+        Dft<16, +1>::run(x + 16 * r);  // over b
+    }
 }
 
+// Fused pass Z + f_coll sum + barrier, wave-level transform (A = 16 or 32, see wave_c2r).
+template <int A>
 __global__ void __launch_bounds__(kBlock)
-zw_ionise_kernel_512(ZFusedArgs a, const float2 *__restrict__ twH_global,
-                     const float2 *__restrict__ twN_global) {
-    constexpr int NZ = 512, H = 256;
-    __shared__ float2 lines[ZW_LINES * ZW_LINE_LDS];
+zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
+                 const float2 *__restrict__ twN_global) {
+    constexpr int H = 16 * A, NZ = 2 * H;
+    constexpr int LINE_LDS = A * 17 + 4;  // float2 per line region (17-padded rows + skew)
+    __shared__ float2 lines[ZW_LINES * LINE_LDS];
     __shared__ float2 twH[H], twN[H];
     __shared__ double red[kBlock / 64];
     for (int t = threadIdx.x; t < H; t += kBlock) {
@@ -1400,40 +1444,50 @@ zw_ionise_kernel_512(ZFusedArgs a, const float2 *__restrict__ twH_global,
     const int g = lane >> 4, b = lane & 15;
     const int lw = wave * 4 + g;
     const long line = (long)blockIdx.x * ZW_LINES + lw;
-    float2 *L = lines + lw * ZW_LINE_LDS;
+    float2 *L = lines + lw * LINE_LDS;
     const float2 *dm = a.d_main + line * H, *sm = a.s_main + line * H;
-    float2 xd[16], xs[16];
+    float2 xd[A], xs[A];
 #pragma unroll
-    for (int q = 0; q < 16; q++) xd[q] = dm[16 * q + b];
+    for (int q = 0; q < A; q++) xd[q] = dm[16 * q + b];
+    if (A == 16) {  // both grids in flight from the start; A = 32 has no registers to spare
 #pragma unroll
-    for (int q = 0; q < 16; q++) xs[q] = sm[16 * q + b];
+        for (int q = 0; q < A; q++) xs[q] = sm[16 * q + b];
+    }
     const long lline = logical_line(line, a.ny, a.lb);
     const float dh = a.d_nyq[lline].x, sh = a.s_nyq[lline].x;
-    uchar2 old[16];
     unsigned char *mrow = a.first_cross + lline * NZ;
+    uchar2 old[A == 16 ? 16 : 1];
+    if (A == 16) {  // mask rows early too
 #pragma unroll
-    for (int d = 0; d < 16; d++) old[d] = reinterpret_cast<const uchar2 *>(mrow)[b + 16 * d];
+        for (int d = 0; d < 16; d++) old[d] = reinterpret_cast<const uchar2 *>(mrow)[b + 16 * d];
+    }
     __syncthreads();  // twiddle tables
-    wave_c2r_256(xd, dh, L, twH, twN, b);
+    wave_c2r<A>(xd, dh, L, twH, twN, b);
+    if (A != 16) {
+#pragma unroll
+        for (int q = 0; q < A; q++) xs[q] = sm[16 * q + b];
+    }
     wave_fence();
-    wave_c2r_256(xs, sh, L, twH, twN, b);
+    wave_c2r<A>(xs, sh, L, twH, twN, b);
 
     const bool floor_ionises = a.mass_dep_zeta && (a.f_limit * a.ion_eff > 1.);
     const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
     double acc = 0.;
 #pragma unroll
-    for (int d = 0; d < 16; d++) {
-        const float s0 = fmaxf(xs[d].x, 0.f), s1 = fmaxf(xs[d].y, 0.f);
+    for (int q = 0; q < A; q++) {
+        // x[16 r + d] holds the cells (2j, 2j + 1), j = (b + 16 r) + A d
+        const int j = (b + 16 * (q / 16)) + A * (q % 16);
+        const float s0 = fmaxf(xs[q].x, 0.f), s1 = fmaxf(xs[q].y, 0.f);
         acc += (double)s0;
         acc += (double)s1;
-        const double D0 = a.rhocrit_omb * (1. + (double)fmaxf(xd[d].x, dmin));
-        const double D1 = a.rhocrit_omb * (1. + (double)fmaxf(xd[d].y, dmin));
+        const double D0 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].x, dmin));
+        const double D1 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].y, dmin));
         const bool i0 = floor_ionises || ((double)s0 * a.ion_eff > D0);
         const bool i1 = floor_ionises || ((double)s1 * a.ion_eff > D1);
-        uchar2 m = old[d];
+        uchar2 m = (A == 16) ? old[q % 16] : reinterpret_cast<const uchar2 *>(mrow)[j];
         if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
         if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
-        reinterpret_cast<uchar2 *>(mrow)[b + 16 * d] = m;
+        reinterpret_cast<uchar2 *>(mrow)[j] = m;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -1478,13 +1532,17 @@ int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
 // *n_partials: how many workgroup partials of sum(stars) the launch wrote
 int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream, int *n_partials) {
     *n_partials = (int)(nlines / LZ_FUSED);
-    if (nz == 512 && zw_enabled() && nlines % ZW_LINES == 0) {
-        const float2 *twH = twiddles(256);
-        const float2 *twN = twiddles(512);
+    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0) {
+        const float2 *twH = twiddles(nz / 2);
+        const float2 *twN = twiddles(nz);
         if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
         *n_partials = (int)(nlines / ZW_LINES);
-        hipLaunchKernelGGL(zw_ionise_kernel_512, dim3((unsigned)(nlines / ZW_LINES)), dim3(kBlock),
-                           0, stream, a, twH, twN);
+        if (nz == 512)
+            hipLaunchKernelGGL(zw_ionise_kernel<16>, dim3((unsigned)(nlines / ZW_LINES)),
+                               dim3(kBlock), 0, stream, a, twH, twN);
+        else
+            hipLaunchKernelGGL(zw_ionise_kernel<32>, dim3((unsigned)(nlines / ZW_LINES)),
+                               dim3(kBlock), 0, stream, a, twH, twN);
         LAUNCH_CHECK();
         return 0;
     }

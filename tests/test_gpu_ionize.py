@@ -101,10 +101,11 @@ def test_long_lines_non_cubic_parity(api, oracle):
     oracle.set_threads(16)
 
 
-@pytest.mark.parametrize("zpass", ["wave", "tile"])
+@pytest.mark.parametrize("zpass", ["wave", "tile", "wave1024"])
 def test_512_point_z_lines_parity(api, oracle, zpass, monkeypatch):
     """The benchmark's z-line length (512 points: the wave-level fused pass Z, or the tile version
-    with C21CM_ZPASS=tile) on a 64 x 64 x 512 box the oracle finishes in seconds."""
+    with C21CM_ZPASS=tile) on a 64 x 64 x 512 box the oracle finishes in seconds; and the
+    1024-point variant of the wave-level kernel on 64 x 64 x 1024."""
     import subprocess
     import sys
 
@@ -118,14 +119,14 @@ def test_512_point_z_lines_parity(api, oracle, zpass, monkeypatch):
                              env={**__import__("os").environ, "C21CM_ZPASS": "tile"})
         assert "OK-512" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
         return
-    check_512_lines(api, oracle)
+    check_512_lines(api, oracle, *((64, 1024) if zpass == "wave1024" else (64, 512)))
 
 
-def check_512_lines(api, oracle):
+def check_512_lines(api, oracle, n=64, nz=512):
     oracle.set_threads(32)
-    spec = W.ionize_spec(64, hii_dim_z=512, r_bubble_max=12.0)
+    spec = W.ionize_spec(n, hii_dim_z=nz, r_bubble_max=12.0)
     assert spec.n_radii >= 10
-    density = W.density_field_numpy((64, 64, 512), seed=77)
+    density = W.density_field_numpy((n, n, nz), seed=77)
     n_ion = W.nion_from_density(density)
     ref = oracle.ionize_grids(spec, density, n_ion)
     got = run_device(api, spec, density, n_ion, device_resident=True)
