@@ -72,11 +72,20 @@ def _declare(lib):
         ("c21cm_perturb_grids", [P(S.PerturbSpec), P(S.InitialConditionsStruct),
                                  P(S.PerturbedFieldStruct), vp]),
         ("c21cm_ics_grids", [P(S.IcsSpec), P(S.InitialConditionsStruct), vp]),
+        ("UpdateXraySourceBox", [P(S.HaloBoxStruct), f64, f64, i32, f64, P(S.XraySourceBoxStruct)]),
+        ("c21cm_fill_Rbox_grids", [P(S.RboxSpec), vp, vp, vp, vp, vp, vp]),
+        ("c21cm_annular_filter_grids", [P(S.AnnularSpec), vp, vp, vp, vp, vp]),
     ):
         if hasattr(lib, name):
             fn = getattr(lib, name)
             fn.restype = i32
             fn.argtypes = argt
+    for name, argt in (("compute_mu_for_multiple_scattering", [f64]),
+                       ("compute_eta_for_multiple_scattering", [f64]),
+                       ("hyper_2F3", [f64, f64, f64])):
+        if hasattr(lib, name):
+            getattr(lib, name).restype = f64
+            getattr(lib, name).argtypes = argt
     if hasattr(lib, "init_ps"):
         lib.init_ps.restype = f64
         lib.free_ps.restype = None

@@ -71,6 +71,12 @@ int c21hip_split_filter_xy2(const float *src_a, float *work_a, int filter_a, flo
                             const float *src_b, float *work_b, int filter_b, float R_param_b,
                             int nx, int ny, int nz, double box_len, double box_len_z, float R,
                             int apply, int table_slot, int tables_ready, void *stream);
+/* one or two grids of one shell (windows 4 = spherical shell / 5 = multiple scattering between
+ * R_inner and R_outer; SpinTemperatureBox.c:698-700) */
+int c21hip_split_filter_shell(const float *src_a, float *work_a, int filter_a, const float *src_b,
+                              float *work_b, int filter_b, int n_grids, int nx, int ny, int nz,
+                              double box_len, double box_len_z, float R_inner, float R_outer,
+                              float R_star, int apply, void *stream);
 /* W(kR) tables of one radius for c21hip_split_filter_xy2, on any stream */
 int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
                          float R_param_b, int nx, int ny, int nz, double box_len,
@@ -84,6 +90,17 @@ int c21hip_split_z_c2r_minmax(const float *split_work, float *real_out, long out
 int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_dense, int nx, int ny, int nz,
                               double growthf, double sigma_min, double sigma_max, double delta_c,
                               double *partials, double *sum_out, void *stream);
+/* pass Z with out = max(v, min_value) * const_factor into dense rows and stats_out[3] =
+ * {min, max, sum} of the stored values on the device (SpinTemperatureBox.c:606-629);
+ * partials: 3 * nx*ny/16 + 2 * (nx*ny/16384 + 2) doubles */
+int c21hip_split_z_c2r_stats(const float *split_work, float *real_out, long out_zstride, int nx,
+                             int ny, int nz, double min_value, double const_factor,
+                             double *partials, double *stats_out, void *stream);
+/* the same store + statistics from real rows of in_zstride floats (generic sizes; out may be
+ * NULL for the statistics alone); partials: 3 * C21HIP_PARTIALS doubles */
+int c21hip_floor_scale_stats(const float *in, long in_zstride, float *out, int nx, int ny, int nz,
+                             double min_value, double const_factor, double *partials,
+                             double *stats_out, void *stream);
 int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstride, int nx, int ny,
                        int nz, void *stream);
 /* Fused pass Z of delta_R and the filtered emissivity + sum(stars) + ionisation barrier for
@@ -127,6 +144,10 @@ int c21hip_widen(const float *in, double *out, size_t n, void *stream);
 int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int ny, int nz, double box_len,
                        double box_len_z, int filter_type, float R, float R_param, int apply,
                        void *stream);
+/* the same with filter_box's full argument list: R_star of the multiple-scattering window 5 */
+int c21hip_copy_filter_star(const float *src_c, float *dst_c, int nx, int ny, int nz,
+                            double box_len, double box_len_z, int filter_type, float R,
+                            float R_param, float R_star, int apply, void *stream);
 
 /* ---- perturb_kernels.hip ---- */
 /* move_grid_masses: map_mass.c:146-208.  `out` (double[out_dim]) must be zeroed by the caller. */

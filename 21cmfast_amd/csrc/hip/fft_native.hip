@@ -38,6 +38,7 @@
 
 #include "c21hip.h"
 #include "fcoll_device.h"
+#include "ms_window.h"
 #include "c21cm_abi.h"
 
 namespace {
@@ -457,8 +458,29 @@ struct WTableArgs {
     int dual;  // 1: also fill the b tables with window pb
     int nx, ny, nz;
     double *main_a, *nyq_a, *main_b, *nyq_b;
+    MsConsts ms_a, ms_b;  // windows of type 5 (multiple scattering), MS kernel variant only
 };
 
+// type 5 keeps |k|^2 in float like every other window (filtering.c:347-381)
+template <int NE>
+__device__ __forceinline__ void window_batch_ms(const FilterParams &p, const MsConsts &ms,
+                                                const float (&kx)[NE], const float (&ky)[NE],
+                                                const float (&kz)[NE], double (&w)[NE]) {
+    if (p.type != 5) {
+        window_batch<NE>(p, kx, ky, kz, w);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+        const float ksq = __fadd_rn(__fadd_rn(__fmul_rn(kx[i], kx[i]), __fmul_rn(ky[i], ky[i])),
+                                    __fmul_rn(kz[i], kz[i]));
+        w[i] = ms_window(sqrt((double)ksq), ms);
+    }
+}
+
+// MS = true: the variant that knows the multiple-scattering window; kept apart so that its
+// series loop does not weigh on the registers of the excursion-set loop's table kernel.
+template <bool MS>
 __global__ void __launch_bounds__(kBlock)
 window_table_kernel(WTableArgs t) {
     const int nxh = t.nx / 2 + 1, nyh = t.ny / 2 + 1, H = t.nz / 2, H4 = H / 4;
@@ -481,7 +503,10 @@ window_table_kernel(WTableArgs t) {
             kz[e] = (float)((double)(4 * l4 + e) * t.pa.dkz);
         }
         double wa[4], wb[4];
-        if (t.dual)
+        if (MS) {
+            window_batch_ms<4>(t.pa, t.ms_a, kx, ky, kz, wa);
+            if (t.dual) window_batch_ms<4>(t.pb, t.ms_b, kx, ky, kz, wb);
+        } else if (t.dual)
             window_batch_dual<4>(t.pa, t.pb, kx, ky, kz, wa, wb);
         else
             window_batch<4>(t.pa, kx, ky, kz, wa);
@@ -503,7 +528,10 @@ window_table_kernel(WTableArgs t) {
         float kx[1] = {k_of(i, t.nx, t.pa.dkx)}, ky[1] = {k_of(j, t.ny, t.pa.dky)};
         float kz[1] = {(float)((double)(t.nz / 2) * t.pa.dkz)};
         double wa[1], wb[1];
-        if (t.dual)
+        if (MS) {
+            window_batch_ms<1>(t.pa, t.ms_a, kx, ky, kz, wa);
+            if (t.dual) window_batch_ms<1>(t.pb, t.ms_b, kx, ky, kz, wb);
+        } else if (t.dual)
             window_batch_dual<1>(t.pa, t.pb, kx, ky, kz, wa, wb);
         else
             window_batch<1>(t.pa, kx, ky, kz, wa);
@@ -889,6 +917,10 @@ struct ZPassArgs {
     float *f_out;        // EPI 2: dense f_coll grid [lines][NZ]
     double sig, delta_c;  // EPI 2: FgtrM_bias_fast (hmf.c:1205-1241); sig holds
                           // 1 / (growthf sqrt(2) sigma), < 0 when the sigmas coincide
+    // EPI 3 (fill_Rbox_table / one_annular_filter, SpinTemperatureBox.c:606-629,713-731):
+    // out = max(v, min_value) * const_factor, partials p0 min / p1 max / p2 sum of out
+    double *p2;
+    double min_value, const_factor;
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -957,7 +989,8 @@ __device__ __forceinline__ void z_transform(float2 *tile, const float2 *twH, con
 // extrema the host needs for the per-radius f_coll table, IonisationBox.c:668-699).  EPI 2:
 // CONST-ION-EFF closed form: f_coll(delta_R) per cell straight from the tile (clips of
 // :689,803, FgtrM_bias_fast) to the dense grid + the workgroup's partial of its sum (:785-961);
-// the filtered density itself is never written.
+// the filtered density itself is never written.  EPI 3: the floor-and-scale store of the
+// spin-temperature filter tables with min / max / sum of the stored values.
 template <int NZ, int EPI>
 __global__ void __launch_bounds__(kBlock)
 z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
@@ -975,7 +1008,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     z_issue_loads<NZ, LZ>(a.main, l0, reg);
     z_transform<NZ, LZ>(tile, twH, twN, reg, a.nyq, l0, a.ny, a.lb);
     // ---- store: lanes along j, one float2 = (x[2j], x[2j+1])
-    double acc0 = 0., acc1 = 0.;
+    double acc0 = 0., acc1 = 0., acc2 = 0.;
 #pragma unroll
     for (int u = 0; u < ZGeom<NZ, LZ>::NOUT; u++) {
         const int f = threadIdx.x + kBlock * u;
@@ -984,6 +1017,15 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         if (a.out_scale != 1.0f) {
             v.x *= a.out_scale;
             v.y *= a.out_scale;
+        }
+        if (EPI == 3) {
+            // float compared with the double floor, float x double product rounded to float
+            if ((double)v.x < a.min_value) v.x = (float)a.min_value;
+            if ((double)v.y < a.min_value) v.y = (float)a.min_value;
+            v.x = (float)((double)v.x * a.const_factor);
+            v.y = (float)((double)v.y * a.const_factor);
+            acc2 += (double)v.x;
+            acc2 += (double)v.y;
         }
         if (EPI == 2) {
             const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
@@ -994,7 +1036,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
                 make_float2((float)f0, (float)f1);
         } else {
             reinterpret_cast<float2 *>(a.out + logical_line(l0 + li, a.ny, a.lb) * a.out_zstride)[j] = v;
-            if (EPI == 1) {
+            if (EPI == 1 || EPI == 3) {
                 const double lo = fmin((double)v.x, (double)v.y), hi = fmax((double)v.x, (double)v.y);
                 acc0 = (u == 0) ? lo : fmin(acc0, lo);
                 acc1 = (u == 0) ? hi : fmax(acc1, hi);
@@ -1002,27 +1044,31 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         }
     }
     if (EPI != 0) {
-        __shared__ double red0[kBlock / 64], red1[kBlock / 64];
+        __shared__ double red0[kBlock / 64], red1[kBlock / 64], red2[kBlock / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
             acc0 = (EPI == 2) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
+            if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
         if ((threadIdx.x & 63) == 0) {
             red0[threadIdx.x >> 6] = acc0;
             red1[threadIdx.x >> 6] = acc1;
+            red2[threadIdx.x >> 6] = acc2;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double r0 = red0[0], r1 = red1[0];
+            double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
                 r0 = (EPI == 2) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
+                r2 += red2[w];
             }
             a.p0[blockIdx.x] = r0;
-            if (EPI == 1) a.p1[blockIdx.x] = r1;
+            if (EPI == 1 || EPI == 3) a.p1[blockIdx.x] = r1;
+            if (EPI == 3) a.p2[blockIdx.x] = r2;
         }
     }
 }
@@ -1671,7 +1717,7 @@ extern "C" int c21hip_padded_to_split(const float *padded_c, float *split, int n
 static int filter_xy(const float *const split_src[2], float *const split_work[2], int n_grids,
                      int nx, int ny, int nz, double box_len, double box_len_z,
                      const int filter_type[2], float R, const float R_param[2], int apply,
-                     void *stream_, int phases = 7, int table_slot = 0) {
+                     void *stream_, int phases = 7, int table_slot = 0, float R_star = 0.f) {
     // phases: 1 window table, 2 pass X, 4 pass Y (the timing hook runs them one at a time; the
     // excursion-set driver builds the tables of the next radius on a second stream).
     // table_slot 0 / 1: which of the two table buffers this radius uses.
@@ -1680,7 +1726,7 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
         return C21CM_VALUE_ERROR;
     }
     for (int g = 0; g < n_grids; g++)
-        if (apply && (filter_type[g] < 0 || filter_type[g] > 4)) {
+        if (apply && (filter_type[g] < 0 || filter_type[g] > 5)) {
             c21hip_set_error("filter type %d is not implemented on the device", filter_type[g]);
             return C21CM_VALUE_ERROR;
         }
@@ -1690,7 +1736,7 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     // the window's parameters beyond (type, R): R_param matters for types 3 and 4 only
     const bool dual = apply && n_grids == 2 &&
                       (filter_type[0] != filter_type[1] ||
-                       ((filter_type[0] == 3 || filter_type[0] == 4) && R_param[0] != R_param[1]));
+                       (filter_type[0] >= 3 && R_param[0] != R_param[1]));
     int st;
     LinePassArgs a{};
     fill_filter(a.fp, apply ? filter_type[0] : -1, R, R_param[0], box_len, box_len_z);
@@ -1716,10 +1762,17 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
         t.main_b = dual ? tab + per : tab;
         t.nyq_b = t.main_b + n_main;
         const size_t n_threads = n_main / 4 + n_nyq;
+        const bool ms = filter_type[0] == 5 || (dual && filter_type[1] == 5);
+        if (ms) {
+            if (filter_type[0] == 5) ms_fill(t.ms_a, R, R_param[0], R_star);
+            if (dual && filter_type[1] == 5) ms_fill(t.ms_b, R, R_param[1], R_star);
+        }
         if (phases & 1) {
-            hipLaunchKernelGGL(window_table_kernel,
-                               dim3((unsigned)((n_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                               stream, t);
+            const dim3 tgrid((unsigned)((n_threads + kBlock - 1) / kBlock));
+            if (ms)
+                hipLaunchKernelGGL(window_table_kernel<true>, tgrid, dim3(kBlock), 0, stream, t);
+            else
+                hipLaunchKernelGGL(window_table_kernel<false>, tgrid, dim3(kBlock), 0, stream, t);
             LAUNCH_CHECK();
         }
         a.wt_main[0] = t.main_a;
@@ -1779,6 +1832,21 @@ extern "C" int c21hip_split_filter_xy2(const float *src_a, float *work_a, int fi
     const float rp[2] = {R_param_a, R_param_b};
     return filter_xy(src, work, 2, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_,
                      tables_ready ? 6 : 7, table_slot);
+}
+
+// One or two grids of one shell of the spin-temperature filters: windows 4 (spherical shell)
+// or 5 (multiple scattering) between R_inner and R_outer (SpinTemperatureBox.c:698-700).
+extern "C" int c21hip_split_filter_shell(const float *src_a, float *work_a, int filter_a,
+                                         const float *src_b, float *work_b, int filter_b,
+                                         int n_grids, int nx, int ny, int nz, double box_len,
+                                         double box_len_z, float R_inner, float R_outer,
+                                         float R_star, int apply, void *stream_) {
+    const float *src[2] = {src_a, src_b};
+    float *work[2] = {work_a, work_b};
+    const int ft[2] = {filter_a, filter_b};
+    const float rp[2] = {R_outer, R_outer};
+    return filter_xy(src, work, n_grids, nx, ny, nz, box_len, box_len_z, ft, R_inner, rp, apply,
+                     stream_, 7, 0, R_star);
 }
 
 // The window tables of one radius for the two-grid sweep, into buffer `table_slot`, on
@@ -1882,6 +1950,38 @@ extern "C" int c21hip_split_z_c2r_minmax(const float *split_work, float *real_ou
     double *stage = partials + 2 * (size_t)nb;  // beyond both partial arrays
     if ((st = c21hip_reduce_op(z.p0, nb, 1, stage, minmax_out, stream))) return st;
     return c21hip_reduce_op(z.p1, nb, 2, stage + nb / 1024 + 2, minmax_out + 1, stream);
+}
+
+// Pass Z with the floor-and-scale store of the spin-temperature filter tables
+// (SpinTemperatureBox.c:606-629): out = max(v, min_value) * const_factor into dense rows and
+// stats_out[3] = {min, max, sum} of the stored values on the device.
+// partials: 3 * nx*ny/16 + 2 * (nx*ny/16384 + 2) doubles.
+extern "C" int c21hip_split_z_c2r_stats(const float *split_work, float *real_out,
+                                        long out_zstride, int nx, int ny, int nz,
+                                        double min_value, double const_factor, double *partials,
+                                        double *stats_out, void *stream) {
+    const long nlines = (long)nx * ny;
+    const int nb = (int)(nlines / LZ_PLAIN);
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out = real_out;
+    z.out_zstride = out_zstride;
+    z.out_scale = 1.0f;
+    z.p0 = partials;
+    z.p1 = partials + nb;
+    z.p2 = partials + 2 * (size_t)nb;
+    z.min_value = min_value;
+    z.const_factor = const_factor;
+    int st = dispatch_z_c2r<3>(nz, z, nlines, (hipStream_t)stream);
+    if (st) return st;
+    double *stage = partials + 3 * (size_t)nb;
+    if ((st = c21hip_reduce_op(z.p0, nb, 1, stage, stats_out, stream))) return st;
+    if ((st = c21hip_reduce_op(z.p1, nb, 2, stage + nb / 1024 + 2, stats_out + 1, stream)))
+        return st;
+    return c21hip_reduce_op(z.p2, nb, 0, stage, stats_out + 2, stream);
 }
 
 // Pass Z of the filtered density fused with the CONST-ION-EFF closed-form f_coll(delta_R):

@@ -13,6 +13,7 @@
 
 #include "c21hip.h"
 #include "c21cm_abi.h"
+#include "ms_window.h"
 
 namespace {
 constexpr int kBlock = 256;
@@ -211,7 +212,96 @@ copy_filter_kernel(const float2 *src, float2 *dst, FilterParams p) {  // src may
         dst[i] = v;
     }
 }
+
+// The multiple-scattering window (type 5) has its own kernel: a power series per mode.
+__global__ void __launch_bounds__(kBlock)
+copy_filter_ms_kernel(const float2 *src, float2 *dst, FilterParams p, MsConsts ms) {
+    const size_t total = (size_t)p.nx * p.ny * p.nzc;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * kBlock) {
+        float2 v = src[i];
+        const size_t line = i / (size_t)p.nzc;
+        const int n_z = (int)(i - line * (size_t)p.nzc);
+        const int n_x = (int)(line / (size_t)p.ny);
+        const int n_y = (int)(line - (size_t)n_x * p.ny);
+        const float k_x = k_of(n_x, p.nx, p.dkx);
+        const float k_y = k_of(n_y, p.ny, p.dky);
+        const float k_z = (float)((double)(n_z + p.nz0) * p.dkz);
+        const float k_mag_sq = __fadd_rn(
+            __fadd_rn(__fmul_rn(k_x, k_x), __fmul_rn(k_y, k_y)), __fmul_rn(k_z, k_z));
+        const double w = ms_window(sqrt((double)k_mag_sq), ms);
+        v.x = (float)((double)v.x * w);
+        v.y = (float)((double)v.y * w);
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- floor, scale, statistics
+// out = max(in, min_value) * const_factor per cell (float compared with the double floor,
+// float x double product rounded to float) + min / max / sum of the stored values: the store
+// loop of fill_Rbox_table and one_annular_filter (SpinTemperatureBox.c:606-629,713-731).
+// Rows of `in` are in_zstride floats long (padded or dense); out (dense) may be NULL.
+__global__ void __launch_bounds__(kBlock)
+floor_scale_stats_kernel(const float *__restrict__ in, long in_zstride, float *__restrict__ out,
+                         size_t nlines, int nz, double min_value, double const_factor,
+                         double *__restrict__ pmin, double *__restrict__ pmax,
+                         double *__restrict__ psum) {
+    const size_t total = nlines * (size_t)nz;
+    double lo = 1e300, hi = -1e300, sum = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * kBlock) {
+        const size_t line = i / (size_t)nz;
+        const int k = (int)(i - line * (size_t)nz);
+        float v = in[line * (size_t)in_zstride + k];
+        if ((double)v < min_value) v = (float)min_value;
+        v = (float)((double)v * const_factor);
+        if (out) out[i] = v;
+        lo = fmin(lo, (double)v);
+        hi = fmax(hi, (double)v);
+        sum += (double)v;
+    }
+    __shared__ double slo[kBlock / 64], shi[kBlock / 64], ssum[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, off, 64));
+        hi = fmax(hi, __shfl_down(hi, off, 64));
+        sum += __shfl_down(sum, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+        ssum[threadIdx.x >> 6] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) {
+            lo = fmin(lo, slo[w]);
+            hi = fmax(hi, shi[w]);
+            sum += ssum[w];
+        }
+        pmin[blockIdx.x] = lo;
+        pmax[blockIdx.x] = hi;
+        psum[blockIdx.x] = sum;
+    }
+}
 }  // namespace
+
+// partials: 3 * C21HIP_PARTIALS doubles; stats_out (device): {min, max, sum}
+extern "C" int c21hip_floor_scale_stats(const float *in, long in_zstride, float *out, int nx,
+                                        int ny, int nz, double min_value, double const_factor,
+                                        double *partials, double *stats_out, void *stream) {
+    const size_t nlines = (size_t)nx * ny;
+    const int blocks = grid_for(nlines * (size_t)nz);
+    double *pmin = partials, *pmax = partials + kMaxBlocks, *psum = partials + 2 * kMaxBlocks;
+    hipLaunchKernelGGL(floor_scale_stats_kernel, dim3(blocks), dim3(kBlock), 0,
+                       (hipStream_t)stream, in, in_zstride, out, nlines, nz, min_value,
+                       const_factor, pmin, pmax, psum);
+    LAUNCH_CHECK();
+    int st;
+    if ((st = c21hip_reduce_op(pmin, blocks, 1, NULL, stats_out, stream))) return st;
+    if ((st = c21hip_reduce_op(pmax, blocks, 2, NULL, stats_out + 1, stream))) return st;
+    return c21hip_reduce_op(psum, blocks, 0, NULL, stats_out + 2, stream);
+}
 
 extern "C" int c21hip_pack_clip(const float *dense, float *padded, int nx, int ny, int nz,
                                 double factor, double lo, double hi, void *stream) {
@@ -270,7 +360,15 @@ extern "C" int c21hip_widen(const float *in, double *out, size_t n, void *stream
 
 static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, int nzc, int nz0,
                             double box_len, double box_len_z, int filter_type, float R,
-                            float R_param, int apply, void *stream);
+                            float R_param, int apply, void *stream, float R_star = 0.f);
+
+// filter_box with its full argument list (filtering.c:308): R_star matters for type 5 only
+extern "C" int c21hip_copy_filter_star(const float *src_c, float *dst_c, int nx, int ny, int nz,
+                                       double box_len, double box_len_z, int filter_type, float R,
+                                       float R_param, float R_star, int apply, void *stream) {
+    return copy_filter_impl(src_c, dst_c, nx, ny, nz / 2 + 1, 0, box_len, box_len_z, filter_type, R,
+                            R_param, apply, stream, R_star);
+}
 
 extern "C" int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int ny, int nz,
                                   double box_len, double box_len_z, int filter_type, float R,
@@ -281,8 +379,8 @@ extern "C" int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int 
 
 static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, int nzc, int nz0,
                             double box_len, double box_len_z, int filter_type, float R,
-                            float R_param, int apply, void *stream) {
-    if (apply && (filter_type < 0 || filter_type > 4)) {
+                            float R_param, int apply, void *stream, float R_star) {
+    if (apply && (filter_type < 0 || filter_type > 5)) {
         c21hip_set_error("filter type %d is not implemented on the device", filter_type);
         return C21CM_VALUE_ERROR;
     }
@@ -313,7 +411,12 @@ static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, in
         p.mfp.ts_2 = exp_term * (2 * pow(ratio, 2) + 0.5 * ratio) - 2 * p.mfp.ts_0 * pow(ratio, 2);
     }
     const size_t total = (size_t)nx * ny * p.nzc;
-    if (apply)
+    if (apply && filter_type == 5) {
+        MsConsts ms;
+        ms_fill(ms, R, R_param, R_star);
+        hipLaunchKernelGGL(copy_filter_ms_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
+                           (hipStream_t)stream, (const float2 *)src_c, (float2 *)dst_c, p, ms);
+    } else if (apply)
         hipLaunchKernelGGL(copy_filter_kernel<true>, dim3(grid_for(total)), dim3(kBlock), 0,
                            (hipStream_t)stream, (const float2 *)src_c, (float2 *)dst_c, p);
     else

@@ -396,6 +396,63 @@ int ComputeBrightnessTemp(float redshift, TsBox *spin_temp, IonizedBox *ionized_
                                   box->brightness_temp, box->tau_21, NULL, NULL);
 }
 
+/* reference: src/py21cmfast/src/SpinTemperatureBox.c:748-808 */
+int UpdateXraySourceBox(HaloBox *halobox, double R_inner, double R_outer, int R_ct, double R_star,
+                        XraySourceBox *source_box) {
+    int st = require_globals("UpdateXraySourceBox", 1);
+    if (st) return st;
+    const AstroOptions *ao = astro_options_global;
+    if (!halobox || !source_box || !halobox->halo_sfr || !halobox->halo_xray ||
+        !source_box->filtered_sfr || !source_box->filtered_xray || !source_box->mean_sfr) {
+        c21hip_set_error("UpdateXraySourceBox: halo_sfr / halo_xray and their filtered grids are required");
+        return C21CM_VALUE_ERROR;
+    }
+    if (R_ct < 0 || R_ct >= astro_params_global->N_STEP_TS) {
+        c21hip_set_error("UpdateXraySourceBox: R_ct %d outside [0, N_STEP_TS = %d)", R_ct,
+                         astro_params_global->N_STEP_TS);
+        return C21CM_VALUE_ERROR;
+    }
+    c21cm_annular_spec s;
+    memset(&s, 0, sizeof(s));
+    int dim, dim_z;
+    geometry(&dim, &dim_z, &s.hii_dim, &s.hii_dim_z, &s.box_len, &s.box_len_z);
+    s.R_inner = R_inner;
+    s.R_outer = R_outer;
+    s.R_star = R_star;
+    const size_t off = (size_t)R_ct * s.hii_dim * s.hii_dim * (size_t)s.hii_dim_z;
+    const int lya = ao->LYA_MULTIPLE_SCATTERING ? 5 : 4; /* :755 */
+    const float *in[C21CM_MAX_ANNULAR_GRIDS];
+    float *out[C21CM_MAX_ANNULAR_GRIDS];
+    int n = 0, i_mini = -1;
+    in[n] = halobox->halo_sfr, out[n] = source_box->filtered_sfr + off, s.filter_type[n++] = lya;
+    in[n] = halobox->halo_xray, out[n] = source_box->filtered_xray + off, s.filter_type[n++] = 4;
+    if (ao->USE_MINI_HALOS) {
+        if (!halobox->halo_sfr_mini || !source_box->filtered_sfr_mini || !source_box->mean_sfr_mini ||
+            !source_box->mean_log10_Mcrit_LW ||
+            (ao->LYA_MULTIPLE_SCATTERING &&
+             (!source_box->filtered_sfr_lw || !source_box->filtered_sfr_mini_lw))) {
+            c21hip_set_error("UpdateXraySourceBox: USE_MINI_HALOS needs the mini-halo grids");
+            return C21CM_VALUE_ERROR;
+        }
+        i_mini = n;
+        in[n] = halobox->halo_sfr_mini, out[n] = source_box->filtered_sfr_mini + off, s.filter_type[n++] = lya;
+        if (ao->LYA_MULTIPLE_SCATTERING) { /* LW photons travel in straight lines, :786-796 */
+            in[n] = halobox->halo_sfr, out[n] = source_box->filtered_sfr_lw + off, s.filter_type[n++] = 4;
+            in[n] = halobox->halo_sfr_mini, out[n] = source_box->filtered_sfr_mini_lw + off, s.filter_type[n++] = 4;
+        }
+    }
+    s.n_grids = n;
+    double u_avg[C21CM_MAX_ANNULAR_GRIDS], f_avg[C21CM_MAX_ANNULAR_GRIDS];
+    st = c21cm_annular_filter_grids(&s, in, out, u_avg, f_avg, NULL);
+    if (st) return st;
+    source_box->mean_sfr[R_ct] = f_avg[0];
+    if (i_mini >= 0) {
+        source_box->mean_sfr_mini[R_ct] = f_avg[i_mini];
+        source_box->mean_log10_Mcrit_LW[R_ct] = halobox->log10_Mcrit_MCG_ave;
+    }
+    return 0;
+}
+
 /* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436.  Only the
  * integrated branch without mini-halos, X-ray sources or the extra fields. */
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,

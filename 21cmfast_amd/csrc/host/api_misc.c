@@ -38,7 +38,7 @@ int c21cm_fft_c2r(float *box, int nx, int ny, int nz, void *stream) {
 /* r2c -> /N -> W(kR) -> c2r.  reference: src/py21cmfast/src/filtering.c:397-445 */
 static int filter_common(const float *input, float *out_f32, double *out_f64, int nx, int ny,
                          int nz, double box_len, double box_len_z, int filter_type, double R,
-                         double R_param, void *stream) {
+                         double R_param, double R_star, void *stream) {
     const size_t ntot = (size_t)nx * ny * nz;
     const size_t npad = (size_t)nx * ny * 2 * (size_t)(nz / 2 + 1);
     int st;
@@ -59,16 +59,23 @@ static int filter_common(const float *input, float *out_f32, double *out_f64, in
     if (c21hip_fft_is_native(nx, ny, nz)) {
         /* split-layout transform with the window fused into its first pass */
         if ((st = c21hip_padded_to_split(unf, fil, nx, ny, nz, stream))) return st;
-        if ((st = c21hip_split_filter_c2r(fil, fil, unf, 2 * (long)(nz / 2 + 1), nx, ny, nz,
-                                          box_len, box_len_z, filter_type, (float)R,
-                                          (float)R_param, 1, stream)))
+        if (filter_type == 5) { /* multiple scattering: (R, R_param) = (R_inner, R_outer) */
+            if ((st = c21hip_split_filter_shell(fil, fil, 5, NULL, NULL, 0, 1, nx, ny, nz, box_len,
+                                                box_len_z, (float)R, (float)R_param,
+                                                (float)R_star, 1, stream)))
+                return st;
+            if ((st = c21hip_split_z_c2r(fil, unf, 2 * (long)(nz / 2 + 1), nx, ny, nz, stream)))
+                return st;
+        } else if ((st = c21hip_split_filter_c2r(fil, fil, unf, 2 * (long)(nz / 2 + 1), nx, ny,
+                                                 nz, box_len, box_len_z, filter_type, (float)R,
+                                                 (float)R_param, 1, stream)))
             return st;
         float *swap = unf;
         unf = fil;
         fil = swap;
     } else {
-        if ((st = c21hip_copy_filter(unf, fil, nx, ny, nz, box_len, box_len_z, filter_type,
-                                     (float)R, (float)R_param, 1, stream)))
+        if ((st = c21hip_copy_filter_star(unf, fil, nx, ny, nz, box_len, box_len_z, filter_type,
+                                          (float)R, (float)R_param, (float)R_star, 1, stream)))
             return st;
         if ((st = c21hip_fft_c2r(fil, nx, ny, nz, stream))) return st;
     }
@@ -96,13 +103,12 @@ int c21cm_filter_grid(const float *input, float *output, int nx, int ny, int nz,
                       double box_len_z, int filter_type, double R, double R_param, void *stream) {
     if (!input || !output || nx < 1 || ny < 1 || nz < 2) return C21CM_VALUE_ERROR;
     return filter_common(input, output, NULL, nx, ny, nz, box_len, box_len_z, filter_type, R,
-                         R_param, stream);
+                         R_param, 0., stream);
 }
 
 /* The exported test hook of the reference ABI; geometry from the broadcast globals. */
 int test_filter(float *input_box, double R, double R_param, double R_star, int filter_flag,
                 double *result) {
-    (void)R_star; /* only the multiple-scattering window (type 5, out of scope) uses it */
     if (!simulation_options_global) {
         c21hip_set_error("test_filter: Broadcast_struct_global_all has not been called");
         return C21CM_VALUE_ERROR;
@@ -111,6 +117,7 @@ int test_filter(float *input_box, double R, double R_param, double R_star, int f
     const int n = so->HII_DIM;
     const int nz = (int)(so->NON_CUBIC_FACTOR * so->HII_DIM);
     const float len_z = so->BOX_LEN * so->NON_CUBIC_FACTOR; /* float product, filtering.c:313 */
+    /* R_star: only the multiple-scattering window (type 5) uses it */
     return filter_common(input_box, NULL, result, n, n, nz, (double)so->BOX_LEN, (double)len_z,
-                         filter_flag, R, R_param, NULL);
+                         filter_flag, R, R_param, R_star, NULL);
 }

@@ -279,3 +279,36 @@ def grid_minmax(values, stream=None):
     check(load().c21cm_grid_minmax(_vptr(values), C.c_size_t(n), mm, _stream(stream)),
           "c21cm_grid_minmax")
     return mm[0], mm[1]
+
+
+def fill_Rbox_grids(spec: S.RboxSpec, field, stream=None) -> dict:
+    """prepare_filter_boxes + fill_Rbox_table on the MI355X (reference:
+    src/py21cmfast/src/SpinTemperatureBox.c:502-520,560-636).  Returns dict(result [n_R, ...],
+    min, average, max [n_R]); result lives where ``field`` lives."""
+    n_R = spec.n_R
+    shape = (n_R,) + tuple(field.shape)
+    if _is_torch(field):
+        import torch
+
+        result = torch.zeros(shape, dtype=torch.float32, device=field.device)
+    else:
+        result = np.zeros(shape, np.float32)
+    mn, av, mx = ((C.c_double * n_R)() for _ in range(3))
+    check(load().c21cm_fill_Rbox_grids(C.byref(spec), _vptr(field), _vptr(result), mn, av, mx,
+                                       _stream(stream)), "c21cm_fill_Rbox_grids")
+    return {"result": result, "min": np.array(mn[:]), "average": np.array(av[:]),
+            "max": np.array(mx[:])}
+
+
+def annular_filter_grids(spec: S.AnnularSpec, inputs, stream=None) -> dict:
+    """one_annular_filter for ``spec.n_grids`` grids of one shell on the MI355X (reference:
+    src/py21cmfast/src/SpinTemperatureBox.c:642-742).  Returns dict(outputs [list], u_avg, f_avg)."""
+    n = spec.n_grids
+    assert len(inputs) == n
+    outputs = [_new_like(a, 0.0) for a in inputs]
+    in_p = (C.c_void_p * n)(*[_vptr(a).value if _is_torch(a) else a.ctypes.data for a in inputs])
+    out_p = (C.c_void_p * n)(*[_vptr(a).value if _is_torch(a) else a.ctypes.data for a in outputs])
+    u, f = (C.c_double * n)(), (C.c_double * n)()
+    check(load().c21cm_annular_filter_grids(C.byref(spec), in_p, out_p, u, f, _stream(stream)),
+          "c21cm_annular_filter_grids")
+    return {"outputs": outputs, "u_avg": np.array(u[:]), "f_avg": np.array(f[:])}

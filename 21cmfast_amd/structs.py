@@ -462,3 +462,78 @@ def default_astro_options(**kw) -> AstroOptions:
 def default_cosmo_tables(**kw) -> CosmoTables:
     p = CosmoTables(ps_norm=0.8102, USE_SIGMA_8=True, V_CB_AVG=25.86)
     return p.update(**kw)
+
+
+MAX_TS_RADII = 128
+MAX_ANNULAR_GRIDS = 5
+
+
+class RboxSpec(_Base):
+    """``c21cm_rbox_spec`` (include/c21cm_grid.h)."""
+
+    _fields_ = [
+        ("hii_dim", C.c_int),
+        ("hii_dim_z", C.c_int),
+        ("box_len", C.c_double),
+        ("box_len_z", C.c_double),
+        ("filter_type", C.c_int),
+        ("n_R", C.c_int),
+        ("R", C.c_double * MAX_TS_RADII),
+        ("cell_radius", C.c_double),
+        ("min_value", C.c_double),
+        ("const_factor", C.c_double),
+    ]
+
+
+def rbox_spec(hii_dim, box_len, radii, filter_type=0, min_value=-1.0, const_factor=1.0,
+              hii_dim_z=None, box_len_z=None) -> "RboxSpec":
+    """fill_Rbox_table's arguments; cell_radius = L_FACTOR BOX_LEN / HII_DIM
+    (SpinTemperatureBox.c:585-588, Constants.c:41)."""
+    s = RboxSpec(hii_dim=hii_dim, hii_dim_z=hii_dim_z or hii_dim, box_len=box_len,
+                 box_len_z=box_len_z or box_len, filter_type=filter_type, n_R=len(radii),
+                 cell_radius=0.620350491 * (box_len / hii_dim), min_value=min_value,
+                 const_factor=const_factor)
+    for i, r in enumerate(radii):
+        s.R[i] = float(r)
+    return s
+
+
+class AnnularSpec(_Base):
+    """``c21cm_annular_spec`` (include/c21cm_grid.h)."""
+
+    _fields_ = [
+        ("hii_dim", C.c_int),
+        ("hii_dim_z", C.c_int),
+        ("box_len", C.c_double),
+        ("box_len_z", C.c_double),
+        ("R_inner", C.c_double),
+        ("R_outer", C.c_double),
+        ("R_star", C.c_double),
+        ("n_grids", C.c_int),
+        ("filter_type", C.c_int * MAX_ANNULAR_GRIDS),
+    ]
+
+
+def annular_spec(hii_dim, box_len, R_inner, R_outer, filter_types, R_star=0.0, hii_dim_z=None,
+                 box_len_z=None) -> "AnnularSpec":
+    s = AnnularSpec(hii_dim=hii_dim, hii_dim_z=hii_dim_z or hii_dim, box_len=box_len,
+                    box_len_z=box_len_z or box_len, R_inner=R_inner, R_outer=R_outer,
+                    R_star=R_star, n_grids=len(filter_types))
+    for i, t in enumerate(filter_types):
+        s.filter_type[i] = int(t)
+    return s
+
+
+class XraySourceBoxStruct(_Base):
+    """``XraySourceBox`` (include/c21cm_abi.h; reference _outputstructs_wrapper.h:67-77)."""
+
+    _fields_ = [
+        ("filtered_sfr", c_float_p),
+        ("filtered_xray", c_float_p),
+        ("filtered_sfr_mini", c_float_p),
+        ("filtered_sfr_lw", c_float_p),
+        ("filtered_sfr_mini_lw", c_float_p),
+        ("mean_log10_Mcrit_LW", C.POINTER(C.c_double)),
+        ("mean_sfr", C.POINTER(C.c_double)),
+        ("mean_sfr_mini", C.POINTER(C.c_double)),
+    ]

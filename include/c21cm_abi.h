@@ -265,6 +265,18 @@ typedef struct HaloBox { /* :44-62 ; only n_ion / whalo_sfr / the two averages a
     double log10_Mcrit_MCG_ave;
 } HaloBox;
 
+typedef struct XraySourceBox { /* :67-77 ; [R_ct][HII_TOT_NUM_PIXELS] grids, [N_STEP_TS] means */
+    float *filtered_sfr;
+    float *filtered_xray;
+    float *filtered_sfr_mini;
+    float *filtered_sfr_lw;
+    float *filtered_sfr_mini_lw;
+
+    double *mean_log10_Mcrit_LW;
+    double *mean_sfr;
+    double *mean_sfr_mini;
+} XraySourceBox;
+
 typedef struct TsBox { /* :78-84 */
     float *spin_temperature;
     float *xray_ionised_fraction;
@@ -334,6 +346,20 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
 /* reference: src/py21cmfast/src/BrightnessTemperatureBox.c:22 (_functionprototypes_wrapper.h:28-29) */
 int ComputeBrightnessTemp(float redshift, TsBox *spin_temp, IonizedBox *ionized_box,
                           PerturbedField *perturb_field, BrightnessTemp *box);
+
+/* reference: src/py21cmfast/src/SpinTemperatureBox.c:748-808 (_functionprototypes_wrapper.h:34-35).
+ * One shell of the X-ray / Lyman-alpha source grids: halo_sfr (window 5 with
+ * LYA_MULTIPLE_SCATTERING, else 4) and halo_xray (window 4) between R_inner and R_outer,
+ * negative cells zeroed, stored at [R_ct * HII_TOT_NUM_PIXELS]; with USE_MINI_HALOS also
+ * halo_sfr_mini and, under multiple scattering, the straight-line copies for the LW feedback. */
+int UpdateXraySourceBox(HaloBox *halobox, double R_inner, double R_outer, int R_ct, double R_star,
+                        XraySourceBox *source_box);
+
+/* reference: src/py21cmfast/src/filtering.c:126-160,258-293 (_functionprototypes_wrapper.h:134-136):
+ * the fits mu(x_em), eta(x_em) and the hypergeometric function of the multiple-scattering window */
+double compute_mu_for_multiple_scattering(double x_em);
+double compute_eta_for_multiple_scattering(double x_em);
+double hyper_2F3(double kR, double alpha, double beta);
 
 /* reference: src/py21cmfast/src/filtering.c:397 (_functionprototypes_wrapper.h:130-131).
  * r2c -> /N -> filter_box -> c2r of one HII_DIM^3 box; `result` is float64[N]. */

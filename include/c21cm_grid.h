@@ -225,6 +225,48 @@ int c21cm_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions 
 /* min and max of n floats (host or device array), e.g. the table range of the above */
 int c21cm_grid_minmax(const float *values, size_t n, double out_minmax[2], void *stream);
 
+/* ---- spin-temperature filtering stage --------------------------------------
+ * The two filter loops of the spin-temperature calculation, on the same transform passes as
+ * the excursion-set loop.
+ *
+ * c21cm_fill_Rbox_grids: prepare_filter_boxes + fill_Rbox_table (SpinTemperatureBox.c:502-520,
+ * 560-636).  `input` [N] is transformed once (r2c, / N); for every radius the spectrum is
+ * multiplied by window `filter_type` (HEAT_FILTER) at R -- radii not above `cell_radius`
+ * (L_FACTOR BOX_LEN / HII_DIM) are left unfiltered (:585-588) -- transformed back, floored at
+ * `min_value` (before the constant factor, :617-620), multiplied by `const_factor` and stored
+ * to result[r * N ...]; min_arr / average_arr / max_arr [n_R] get the statistics of the stored
+ * values.  Arrays may be host or device. */
+#define C21CM_MAX_TS_RADII 128
+typedef struct c21cm_rbox_spec {
+    int hii_dim, hii_dim_z;
+    double box_len, box_len_z;
+    int filter_type;
+    int n_R;
+    double R[C21CM_MAX_TS_RADII];
+    double cell_radius;
+    double min_value, const_factor;
+} c21cm_rbox_spec;
+
+int c21cm_fill_Rbox_grids(const c21cm_rbox_spec *spec, const float *input, float *result,
+                          double *min_arr, double *average_arr, double *max_arr, void *stream);
+
+/* c21cm_annular_filter_grids: one_annular_filter (SpinTemperatureBox.c:642-742) for n_grids
+ * grids of one shell: r2c, / N, window filter_type[g] (4 = spherical shell, 5 = multiple
+ * scattering) between R_inner and R_outer unless R_inner <= 0, c2r, negative values (aliasing)
+ * set to zero.  u_avg / f_avg [n_grids]: box averages of the input and of the output. */
+#define C21CM_MAX_ANNULAR_GRIDS 5
+typedef struct c21cm_annular_spec {
+    int hii_dim, hii_dim_z;
+    double box_len, box_len_z;
+    double R_inner, R_outer, R_star;
+    int n_grids;
+    int filter_type[C21CM_MAX_ANNULAR_GRIDS];
+} c21cm_annular_spec;
+
+int c21cm_annular_filter_grids(const c21cm_annular_spec *spec, const float *const *inputs,
+                               float *const *outputs, double *u_avg, double *f_avg,
+                               void *stream);
+
 /* Library management */
 const char *c21cm_version(void);
 int c21cm_device_synchronize(void);

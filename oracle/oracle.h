@@ -35,6 +35,12 @@ void oracle_fft_c2r(float *box, int nx, int ny, int nz);
 double oracle_filter_window(int filter_type, double k, float R, float R_param);
 int oracle_filter_box(float *cbox, int nx, int ny, int nz, double box_len, double box_len_z,
                       int filter_type, float R, float R_param);
+double oracle_ms_mu(double x_em);
+double oracle_ms_eta(double x_em);
+double oracle_hyper_2F3(double kR, double alpha, double beta);
+double oracle_filter_window_ms(double k, float R_inner, float R_outer, float R_star);
+int oracle_filter_box_star(float *cbox, int nx, int ny, int nz, double box_len, double box_len_z,
+                           int filter_type, float R, float R_param, float R_star);
 int oracle_filter_grid(const float *input, float *output, int nx, int ny, int nz, double box_len,
                        double box_len_z, int filter_type, double R, double R_param);
 int oracle_test_filter(const float *input, int nx, int ny, int nz, double box_len,
@@ -65,6 +71,12 @@ int oracle_brightness_grids(const c21cm_brightness_spec *spec, const float *dens
 /* oracle_halobox.c -- reference: src/py21cmfast/src/HaloBox.c:244-436, map_mass.c:62-98,214-344 */
 int oracle_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions *ics,
                          HaloBox *grids);
+
+/* oracle_tsfilter.c -- reference: src/py21cmfast/src/SpinTemperatureBox.c:502-520,560-742 */
+int oracle_fill_Rbox_grids(const c21cm_rbox_spec *spec, const float *input, float *result,
+                           double *min_arr, double *average_arr, double *max_arr);
+int oracle_annular_filter_grids(const c21cm_annular_spec *spec, const float *const *inputs,
+                                float *const *outputs, double *u_avg, double *f_avg);
 
 void oracle_set_threads(int n);
 

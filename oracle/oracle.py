@@ -63,6 +63,16 @@ def load():
         lib.oracle_halobox_grids.argtypes = [vp, vp, vp]
         lib.oracle_brightness_grids.restype = i32
         lib.oracle_brightness_grids.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        lib.oracle_fill_Rbox_grids.restype = i32
+        lib.oracle_fill_Rbox_grids.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.oracle_annular_filter_grids.restype = i32
+        lib.oracle_annular_filter_grids.argtypes = [vp, vp, vp, vp, vp]
+        for nm, at in (("oracle_ms_mu", [f64]), ("oracle_ms_eta", [f64]),
+                       ("oracle_hyper_2F3", [f64, f64, f64])):
+            getattr(lib, nm).restype = f64
+            getattr(lib, nm).argtypes = at
+        lib.oracle_filter_window_ms.restype = f64
+        lib.oracle_filter_window_ms.argtypes = [f64, f32, f32, f32]
         lib.oracle_set_threads.restype = None
         lib.oracle_set_threads.argtypes = [i32]
         for name, argt in (
@@ -243,3 +253,32 @@ def gaussian_pair(counter: int, seed: int):
     a, b = C.c_double(), C.c_double()
     lib.oracle_gaussian_pair(counter, seed, C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def fill_Rbox_grids(spec, field):
+    """Oracle prepare_filter_boxes + fill_Rbox_table; dict(result, min, average, max)."""
+    n_R = spec.n_R
+    result = np.zeros((n_R,) + field.shape, np.float32)
+    mn, av, mx = ((C.c_double * n_R)() for _ in range(3))
+    st = load().oracle_fill_Rbox_grids(C.byref(spec), fptr(field), fptr(result), mn, av, mx)
+    if st:
+        raise RuntimeError(f"oracle_fill_Rbox_grids status {st}")
+    return {"result": result, "min": np.array(mn[:]), "average": np.array(av[:]),
+            "max": np.array(mx[:])}
+
+
+def annular_filter_grids(spec, inputs):
+    """Oracle one_annular_filter for each input grid; dict(outputs, u_avg, f_avg)."""
+    n = spec.n_grids
+    outputs = [np.zeros(a.shape, np.float32) for a in inputs]
+    in_p = (C.c_void_p * n)(*[a.ctypes.data for a in inputs])
+    out_p = (C.c_void_p * n)(*[a.ctypes.data for a in outputs])
+    u, f = (C.c_double * n)(), (C.c_double * n)()
+    st = load().oracle_annular_filter_grids(C.byref(spec), in_p, out_p, u, f)
+    if st:
+        raise RuntimeError(f"oracle_annular_filter_grids status {st}")
+    return {"outputs": outputs, "u_avg": np.array(u[:]), "f_avg": np.array(f[:])}
+
+
+def filter_window_ms(k, R_inner, R_outer, R_star):
+    return load().oracle_filter_window_ms(float(k), R_inner, R_outer, R_star)

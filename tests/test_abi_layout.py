@@ -28,7 +28,9 @@ def test_library_loads_without_gpu_and_exports_every_declared_symbol(pkg):
     names = declared_functions()
     assert {"ComputeInitialConditions", "ComputePerturbedField", "ComputeIonizedBox",
             "Broadcast_struct_global_all", "test_filter", "init_ps", "c21cm_ionize_grids",
-            "c21cm_perturb_grids", "c21cm_ics_grids", "c21cm_ionize_shard_radii"} <= set(names)
+            "c21cm_perturb_grids", "c21cm_ics_grids", "c21cm_ionize_shard_radii",
+            "ComputeBrightnessTemp", "ComputeHaloBox", "UpdateXraySourceBox", "hyper_2F3",
+            "c21cm_fill_Rbox_grids", "c21cm_annular_filter_grids"} <= set(names)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"
     for g in ("simulation_options_global", "matter_options_global", "cosmo_params_global",
@@ -41,11 +43,15 @@ def test_library_loads_without_gpu_and_exports_every_declared_symbol(pkg):
 STRUCTS = ["CosmoParams", "SimulationOptions", "MatterOptions", "AstroParams", "AstroOptions",
            "CosmoTables", "ConfigSettings", "InitialConditions", "PerturbedField", "HaloBox",
            "TsBox", "IonizedBox", "c21cm_ionize_spec", "c21cm_ionize_report", "c21cm_perturb_spec",
-           "c21cm_ics_spec"]
+           "c21cm_ics_spec", "BrightnessTemp", "XraySourceBox", "c21cm_brightness_spec",
+           "c21cm_halobox_spec", "c21cm_rbox_spec", "c21cm_annular_spec"]
 PY_NAMES = {"InitialConditions": "InitialConditionsStruct", "PerturbedField": "PerturbedFieldStruct",
             "HaloBox": "HaloBoxStruct", "TsBox": "TsBoxStruct", "IonizedBox": "IonizedBoxStruct",
             "c21cm_ionize_spec": "IonizeSpec", "c21cm_ionize_report": "IonizeReport",
-            "c21cm_perturb_spec": "PerturbSpec", "c21cm_ics_spec": "IcsSpec"}
+            "c21cm_perturb_spec": "PerturbSpec", "c21cm_ics_spec": "IcsSpec",
+            "BrightnessTemp": "BrightnessTempStruct", "XraySourceBox": "XraySourceBoxStruct",
+            "c21cm_brightness_spec": "BrightnessSpec", "c21cm_halobox_spec": "HaloBoxSpec",
+            "c21cm_rbox_spec": "RboxSpec", "c21cm_annular_spec": "AnnularSpec"}
 
 
 def test_ctypes_mirrors_match_compiler_layout(pkg, tmp_path):

@@ -271,3 +271,30 @@ def test_conditional_nion_against_scipy(host, pkg):
                                             s_c, float(delta), Mturn, C.byref(sc), 1)
         assert tab[k] == pytest.approx(max(math.log(direct), -40.0), rel=2e-6, abs=2e-6)
     assert np.all(np.diff(np.array(tab[:300])) > 0)  # more collapse in denser regions (delta < 0.85)
+
+
+# ---- multiple-scattering window helpers (host-side exports of the drop-in library) -----------
+@pytest.mark.parametrize("x_em", [0.0, 0.1, 0.5, 1.0, 5.0, 10.0, 50.0, 100.0, 500.0])
+def test_exported_hyper_2F3_matches_mpmath_and_oracle(pkg, oracle, x_em):
+    """The reference's own test of its exported helpers (tests/test_filtering.py:369-396) run
+    on the drop-in library's exports, and the same values from the CPU oracle."""
+    mpmath = pytest.importorskip("mpmath")
+    lib, olib = pkg.load(), oracle.load()
+    mu, eta = lib.compute_mu_for_multiple_scattering(x_em), lib.compute_eta_for_multiple_scattering(x_em)
+    assert mu == olib.oracle_ms_mu(x_em) and eta == olib.oracle_ms_eta(x_em)
+    if mu == 0.0 and eta == 0.0:
+        alpha, beta = np.inf, 0.0
+    else:
+        alpha = (1.0 / eta - 1.0) / pow(1.0 / mu - 1.0, 2)
+        beta = (1.0 / eta - 1.0) / (1.0 / mu - 1.0)
+    kR = np.logspace(-1, 3, 100)
+    want = np.array([
+        float(mpmath.hyper([(2.0 + alpha) / 2.0, (3.0 + alpha) / 2.0],
+                           [5.0 / 2.0, (2.0 + alpha + beta) / 2.0, (3.0 + alpha + beta) / 2.0],
+                           -0.25 * x**2))
+        for x in kR
+    ])
+    got = np.array([lib.hyper_2F3(float(x), alpha, beta) for x in kR])
+    np.testing.assert_allclose(want, got, rtol=0.0, atol=2e-3)
+    ora = np.array([olib.oracle_hyper_2F3(float(x), alpha, beta) for x in kR])
+    np.testing.assert_allclose(got, ora, rtol=1e-12, atol=1e-15)
