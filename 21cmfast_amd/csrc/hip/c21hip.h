@@ -265,12 +265,14 @@ int c21hip_any_nonzero(const float *a, size_t n, int *flag_host, void *stream);
 int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
                          const double *mean_dev, unsigned char *first_cross, void *stream);
 /* mask of radii > 0 + radius index 0 + post-loop sweep of the fused Lagrangian path in one pass
- * (IonisationBox.c:1031-1256,1597-1608); partials: 2 * 2048 doubles; writes every z_reion */
+ * (IonisationBox.c:1031-1256,1597-1608); partials: 2 * 2048 doubles; writes every z_reion.
+ * stars_direct = 1: stars_fil is the dense emissivity input (clipped on load) instead of its
+ * padded, window-less transform round trip. */
 int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
                        const unsigned char *first_cross, const float *stars_fil,
                        const float *density, const float *prev_z_reion, float *xH, float *z_reion,
                        float *kinetic_temperature, double *partials, double *sum_stars_out,
-                       double *sum_xh_out, int *flag_out, void *stream);
+                       double *sum_xh_out, int *flag_out, int stars_direct, void *stream);
 /* delta_T (and tau_21) per cell + their sum (BrightnessTemperatureBox.c:58-87); partials: 2048 */
 int c21hip_brightness_temp(const float *density, const float *xH, const float *Ts, float *bt,
                            float *tau, size_t n, float const_factor, float T_rad, double redshift,

@@ -178,6 +178,18 @@ struct Pack<2> {
     }
 };
 
+template <>
+struct Pack<4> {
+    float v[4];
+    __device__ __forceinline__ static Pack load(const float *p, size_t i) {
+        float4 t = reinterpret_cast<const float4 *>(p)[i];
+        return Pack{{t.x, t.y, t.z, t.w}};
+    }
+    __device__ __forceinline__ void store(float *p, size_t i) const {
+        reinterpret_cast<float4 *>(p)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+
 // ---- clip_and_get_extrema ------------------------------------------------------------
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
@@ -468,7 +480,12 @@ finalize_kernel(c21hip_ionize_args a, float stored_z, const float *__restrict__ 
 // -> ionise_stars_kernel<VEC, true, false> -> finalize_kernel, which move xH / z_reion / T_k
 // through HBM three times.  z_reion is written for every cell (-1 where never ionised, the
 // value IonisationBox.c:1372-1378 initialises it to), so the caller need not pre-fill it.
-template <int VEC>
+// DIRECT: `stars_fil` is the dense emissivity INPUT and the clip of prepare_box_for_filtering
+// (0 .. 1e20, IonisationBox.c:1497-1500) is applied on load: at radius index 0 no window is
+// applied (:606), so the reference's filtered grid is c2r(r2c(clipped input)) / N -- the
+// clipped input itself up to the rounding of the transform pair (~1e-7 relative).  All grids
+// are then dense, so rows need no padding arithmetic and VEC = 4 (16-byte accesses) is legal.
+template <int VEC, bool DIRECT>
 __global__ void __launch_bounds__(kBlock)
 final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restrict__ first_cross,
                    const float *__restrict__ stars_fil, const float *__restrict__ density,
@@ -493,14 +510,22 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
             const size_t i = i0 + (size_t)u * kBlock;
             ok[u] = i < p.nitems;
             if (!ok[u]) continue;
-            const auto ci = cell_index<VEC>(i, p.nz_items, p.zpad_items);
+            const auto ci = DIRECT ? CellIndex<VEC>{i, i} : cell_index<VEC>(i, p.nz_items, p.zpad_items);
             st[u] = Pack<VEC>::load(stars_fil, ci.padded);
             de[u] = Pack<VEC>::load(density, ci.dense);
             x0[u] = Pack<VEC>::load(xH, ci.dense);
             if (!a.minimize_memory) T0[u] = Pack<VEC>::load(Tk, ci.dense);
             if (!a.first_snapshot) pz[u] = Pack<VEC>::load(prev_z_reion, ci.dense);
+            if (VEC == 4) {
+                const uchar4 m4 = reinterpret_cast<const uchar4 *>(first_cross)[ci.dense];
+                m[u][0] = m4.x;
+                m[u][1] = m4.y;
+                m[u][2 % VEC] = m4.z;
+                m[u][3 % VEC] = m4.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < VEC; e++) m[u][e] = first_cross[ci.dense * VEC + e];
+                for (int e = 0; e < VEC; e++) m[u][e] = first_cross[ci.dense * VEC + e];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -509,7 +534,8 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
             Pack<VEC> xo, zo, To;
 #pragma unroll
             for (int e = 0; e < VEC; e++) {
-                const float stars = fmaxf(st[u].v[e], 0.f);  // IonisationBox.c:822-823
+                float stars = fmaxf(st[u].v[e], 0.f);  // IonisationBox.c:822-823
+                if (DIRECT) stars = fminf(stars, 1e20f);
                 acc_s += (double)stars;
                 const float dens = de[u].v[e];
                 const double curr_dens = (double)dens * a.photoncons_factor;  // :1048
@@ -876,21 +902,26 @@ extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_red
                                   const float *density, const float *prev_z_reion, float *xH,
                                   float *z_reion, float *kinetic_temperature, double *partials,
                                   double *sum_stars_out, double *sum_xh_out, int *flag_out,
-                                  void *stream) {
-    const int vec = (a->nz % 2 == 0) ? 2 : 1;
-    const IoniseParams p = make_params(a, vec);
+                                  int stars_direct, void *stream) {
+    const size_t ntot = (size_t)a->nx * a->ny * a->nz;
+    const int vec = stars_direct ? ((ntot % 4 == 0) ? 4 : 1) : ((a->nz % 2 == 0) ? 2 : 1);
+    IoniseParams p = make_params(a, vec == 4 ? 2 : vec);
+    if (stars_direct) p.nitems = ntot / vec;  // dense grids: the box is one long row
     const int blocks = grid_for((p.nitems + 1) / 2);
     double *ps = partials, *px = partials + kMaxBlocks;
-    if (vec == 2)
-        hipLaunchKernelGGL(final_sweep_kernel<2>, dim3(blocks), dim3(kBlock), 0,
-                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, stars_fil,
-                           density, prev_z_reion, xH, z_reion, kinetic_temperature, ps, px,
-                           flag_out);
+#define LAUNCH_FINAL(V, D)                                                                       \
+    hipLaunchKernelGGL((final_sweep_kernel<V, D>), dim3(blocks), dim3(kBlock), 0,                \
+                       (hipStream_t)stream, p, (float)stored_redshift, first_cross, stars_fil,   \
+                       density, prev_z_reion, xH, z_reion, kinetic_temperature, ps, px, flag_out)
+    if (stars_direct && vec == 4)
+        LAUNCH_FINAL(4, true);
+    else if (stars_direct)
+        LAUNCH_FINAL(1, true);
+    else if (vec == 2)
+        LAUNCH_FINAL(2, false);
     else
-        hipLaunchKernelGGL(final_sweep_kernel<1>, dim3(blocks), dim3(kBlock), 0,
-                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, stars_fil,
-                           density, prev_z_reion, xH, z_reion, kinetic_temperature, ps, px,
-                           flag_out);
+        LAUNCH_FINAL(1, false);
+#undef LAUNCH_FINAL
     LAUNCH_CHECK();
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, ps,
                        blocks, 0, sum_stars_out);

@@ -623,15 +623,31 @@ static int final_prepare(ion_ctx *c) {
                                    (float)s->mfp_meandens, 0, c->stream);
 }
 
+/* At radius index 0 no window is applied (IonisationBox.c:606), so the reference's filtered
+ * emissivity is the transform round trip of the clipped input: the clipped input itself up to
+ * the rounding of an FFT pair (~1e-7 relative, far inside the 1e-4 tolerance of the path).
+ * The final sweep therefore reads the input directly; C21CM_R0_ROUNDTRIP=1 restores the
+ * round trip through passes X, Y, Z (three extra sweeps of one grid). */
+static int r0_direct(void) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("C21CM_R0_ROUNDTRIP");
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v;
+}
+
 static int final_step(ion_ctx *c, const unsigned char *mask, int stars_ready) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     c21hip_ionize_args args;
     fill_args(&args, s, 0);
-    if (!stars_ready) TRY(final_prepare(c));
-    TRY(c21hip_final_sweep(&args, s->stored_redshift, mask, c->stars_fil, c->density, c->prev_zre,
-                           c->xH, c->zre, c->Tk, c->partials, c->scalars + SC_SUMS,
-                           c->scalars + SC_XHSUM, (int *)(c->scalars + SC_FLAG), c->stream));
+    const int direct = r0_direct();
+    if (!direct && !stars_ready) TRY(final_prepare(c));
+    TRY(c21hip_final_sweep(&args, s->stored_redshift, mask, direct ? c->n_ion : c->stars_fil,
+                           c->density, c->prev_zre, c->xH, c->zre, c->Tk, c->partials,
+                           c->scalars + SC_SUMS, c->scalars + SC_XHSUM,
+                           (int *)(c->scalars + SC_FLAG), direct, c->stream));
     TRY(c21hip_finish_mean(c->scalars + SC_SUMS, (double)c->ntot, s->mass_dep_zeta,
                            s->f_limit_acg, c->scalars + SC_MEANS, c->stream));
     c->finalised = 1;
@@ -820,7 +836,7 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
     /* The rank that will run the finish step has one radius fewer than the busiest ranks: it
      * uses that slack to transform the unfiltered emissivity for the cell-scale step, so that
      * after the reduce only the final sweep remains. */
-    if (c.fused && spec->r_lowest == 0 && rank == (spec->n_radii - 1) % world) {
+    if (c.fused && spec->r_lowest == 0 && rank == (spec->n_radii - 1) % world && !r0_direct()) {
         TRY(final_prepare(&c));
         g_spectra.stars_r0_ready = 1;
     }
@@ -862,7 +878,9 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
     TRY(init_output_grids(&c, previous_ionize_box));
     int stars_ready = 0;
     if (spec->r_lowest == 0) {
-        if (spectra_match(&c, perturbed_field, halos, spin_temp))
+        if (c.fused && r0_direct())
+            stars_ready = 0; /* the final sweep reads the emissivity input itself */
+        else if (spectra_match(&c, perturbed_field, halos, spin_temp))
             stars_ready = g_spectra.stars_r0_ready;
         else
             TRY(preloop(&c));
