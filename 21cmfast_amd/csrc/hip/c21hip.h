@@ -101,6 +101,20 @@ int c21hip_split_z_c2r_stats(const float *split_work, float *real_out, long out_
 int c21hip_floor_scale_stats(const float *in, long in_zstride, float *out, int nx, int ny, int nz,
                              double min_value, double const_factor, double *partials,
                              double *stats_out, void *stream);
+/* pass Z storing v / divisor (0: no division) */
+int c21hip_split_z_c2r_div(const float *split_work, float *real_out, long out_zstride, int nx,
+                           int ny, int nz, float divisor, void *stream);
+int c21hip_split_xblock_log2(int nx); /* 0: plain split layout */
+/* split-layout InitialConditions pipeline (ics_kernels.hip, plain layout only) */
+int c21hip_split_kop(const float *in_split, float *out_split, int nx, int ny, int nz,
+                     double box_len, double box_len_z, int axis0, int axis1, void *stream);
+int c21hip_split_fold(const float *hi_split, float *lo_split, int nx, int ny, int nz, int f,
+                      double box_len, double box_len_z, int axis0, int axis1, void *stream);
+int c21hip_lpt2_source(const float *const diag[3], const float *const off[3], float *out, size_t n,
+                       float norm, void *stream);
+int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny, int nz,
+                             double box_len, double box_len_z, int filter_type, float R,
+                             float R_param, int apply, void *stream);
 int c21hip_split_z_c2r(const float *split_work, float *real_out, long out_zstride, int nx, int ny,
                        int nz, void *stream);
 /* Fused pass Z of delta_R and the filtered emissivity + sum(stars) + ionisation barrier for

@@ -911,6 +911,7 @@ struct ZPassArgs {
     float *out;          // real rows of out_zstride floats
     long out_zstride;
     float out_scale;
+    float out_div;       // != 0: stored value = v / out_div (EPI 0; the gathers of the ICs)
     int ny, lb;          // x-blocked layout: memory line -> logical line (logical_line())
     // epilogues of the Eulerian source models (EPI 1, 2)
     double *p0, *p1;     // per-workgroup partials: EPI 1 min / max, EPI 2 sum (p0)
@@ -1017,6 +1018,10 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         if (a.out_scale != 1.0f) {
             v.x *= a.out_scale;
             v.y *= a.out_scale;
+        }
+        if (EPI == 0 && a.out_div != 0.f) {
+            v.x = __fdiv_rn(v.x, a.out_div);
+            v.y = __fdiv_rn(v.y, a.out_div);
         }
         if (EPI == 3) {
             // float compared with the double floor, float x double product rounded to float
@@ -1927,6 +1932,25 @@ extern "C" int c21hip_split_z_c2r(const float *split_work, float *real_out, long
     z.out_scale = 1.0f;
     return dispatch_z_c2r(nz, z, nlines, (hipStream_t)stream);
 }
+
+// Pass Z with the stored value divided by `divisor` (0: no division): the "/ VOLUME" of the
+// InitialConditions gathers (InitialConditions.c:687,729,356) folded into the store.
+extern "C" int c21hip_split_z_c2r_div(const float *split_work, float *real_out, long out_zstride,
+                                      int nx, int ny, int nz, float divisor, void *stream) {
+    const long nlines = (long)nx * ny;
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out = real_out;
+    z.out_zstride = out_zstride;
+    z.out_scale = 1.0f;
+    z.out_div = divisor;
+    return dispatch_z_c2r(nz, z, nlines, (hipStream_t)stream);
+}
+
+extern "C" int c21hip_split_xblock_log2(int nx) { return split_xb_log2(nx); }
 
 // Pass Z of the filtered density + its extrema (Eulerian source models with a per-radius
 // table).  partials: 2 * nx*ny/16 + 2 * (nx*ny/16384 + 2) doubles; minmax_out[2] on the device.

@@ -362,6 +362,18 @@ static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, in
                             double box_len, double box_len_z, int filter_type, float R,
                             float R_param, int apply, void *stream, float R_star = 0.f);
 
+// filter_box on a spectrum in the plain split layout (main block [nx][ny][nz/2] + Nyquist plane)
+extern "C" int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny,
+                                        int nz, double box_len, double box_len_z, int filter_type,
+                                        float R, float R_param, int apply, void *stream) {
+    const size_t n_main = 2 * (size_t)nx * ny * (nz / 2);
+    int st = copy_filter_impl(src_split, dst_split, nx, ny, nz / 2, 0, box_len, box_len_z,
+                              filter_type, R, R_param, apply, stream);
+    if (st) return st;
+    return copy_filter_impl(src_split + n_main, dst_split + n_main, nx, ny, 1, nz / 2, box_len,
+                            box_len_z, filter_type, R, R_param, apply, stream);
+}
+
 // filter_box with its full argument list (filtering.c:308): R_star matters for type 5 only
 extern "C" int c21hip_copy_filter_star(const float *src_c, float *dst_c, int nx, int ny, int nz,
                                        double box_len, double box_len_z, int filter_type, float R,

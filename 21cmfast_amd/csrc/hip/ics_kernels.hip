@@ -162,6 +162,144 @@ kspace_op_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int nx
     }
 }
 
+
+// ------------------------------------------------------------------ split-layout IC pipeline
+// The k-space side of ComputeInitialConditions on the layout of the native transform
+// (fft_native.hip; plain form, nx <= 512): main[(x ny + y) H + k_z] for k_z < H = nz/2 and the
+// Nyquist plane nyq[x ny + y].  Working here removes the padded <-> split conversion in front of
+// every inverse transform, and lets the low-resolution outputs be computed by FOLDING.
+
+// compute_f_gradient / compute_f_laplacian of one stored mode (InitialConditions.c:240-297)
+__device__ __forceinline__ void kop_factor(int n_x, int n_y, int n_z, int nx, int ny, int nz,
+                                           double len_x, double len_y, double len_z, int axis0,
+                                           int axis1, double *re, double *im) {
+    if (axis0 < 0) {  // identity (density)
+        *re = 1.;
+        *im = 0.;
+        return;
+    }
+    const double kvec[3] = {index_to_k(n_x, len_x, nx), index_to_k(n_y, len_y, ny),
+                            index_to_k(n_z, len_z, nz)};
+    const double k_sq = kvec[0] * kvec[0] + kvec[1] * kvec[1] + kvec[2] * kvec[2];
+    if (n_x == 0 && n_y == 0 && n_z == 0) {
+        *re = 0.;
+        *im = 0.;
+    } else if (axis1 < 0) {  // i k_a / k^2
+        *re = 0.;
+        *im = kvec[axis0] / k_sq;
+    } else {  // -k_a k_b / k^2
+        *re = -kvec[axis0] * kvec[axis1] / k_sq;
+        *im = 0.;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+split_kop_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_nyq,
+                 float2 *__restrict__ out_main, float2 *__restrict__ out_nyq, int nx, int ny,
+                 int nz, double len_x, double len_y, double len_z, int axis0, int axis1) {
+    const int H = nz / 2;
+    const size_t n_main = (size_t)nx * ny * H, total = n_main + (size_t)nx * ny;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const bool is_main = t < n_main;
+        const size_t line = is_main ? t / (size_t)H : t - n_main;
+        const int n_z = is_main ? (int)(t - line * (size_t)H) : H;
+        const int n_x = (int)(line / (size_t)ny), n_y = (int)(line - (size_t)n_x * ny);
+        const float2 v = is_main ? in_main[t] : in_nyq[line];
+        double fr, fi;
+        kop_factor(n_x, n_y, n_z, nx, ny, nz, len_x, len_y, len_z, axis0, axis1, &fr, &fi);
+        const float2 o = make_float2((float)((double)v.x * fr - (double)v.y * fi),
+                                     (float)((double)v.x * fi + (double)v.y * fr));
+        if (is_main)
+            out_main[t] = o;
+        else
+            out_nyq[line] = o;
+    }
+}
+
+// Low-resolution output of a high-resolution spectrum WITHOUT the high-resolution transform.
+// The reference transforms the (filtered) DIM^3 spectrum back and keeps every f-th cell per axis
+// (InitialConditions.c:694-730,318-364).  Decimating the output of an inverse DFT is the
+// inverse DFT of the aliased spectrum,
+//     x[f m] = sum_{q < n/f} ( sum_{a < f} X[q + a n/f] ) exp(2 pi i q m / (n/f)),
+// so the (nx/f)(ny/f)(nz/f) grid follows from ONE read of the stored spectrum (f^3 aliases per
+// output mode, the k-space operator applied to each alias at ITS wavenumber) and a transform
+// f^3 times smaller.  Aliases with k_z above the stored half come from the Hermitian partner
+// conj(X[-k_x, -k_y, nz - k_z]), exactly the element the c2r transform implies there.
+__global__ void __launch_bounds__(kBlock)
+fold_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_nyq,
+            float2 *__restrict__ out_main, float2 *__restrict__ out_nyq, int nx, int ny, int nz,
+            int f, double len_x, double len_y, double len_z, int axis0, int axis1) {
+    const int H = nz / 2, mx = nx / f, my = ny / f, mz = nz / f, Hl = mz / 2;
+    const size_t total = (size_t)mx * my * (Hl + 1);
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const size_t line = t / (size_t)(Hl + 1);
+        const int qz = (int)(t - line * (size_t)(Hl + 1));
+        const int qx = (int)(line / (size_t)my), qy = (int)(line - (size_t)qx * my);
+        double acc_r = 0., acc_i = 0.;
+        for (int a = 0; a < f; a++)
+            for (int b = 0; b < f; b++)
+                for (int c = 0; c < f; c++) {
+                    int sx = qx + a * mx, sy = qy + b * my, sz = qz + c * mz;
+                    const bool partner = sz > H;
+                    if (partner) {
+                        sx = (nx - sx) % nx;
+                        sy = (ny - sy) % ny;
+                        sz = nz - sz;
+                    }
+                    const size_t sl = (size_t)sx * ny + sy;
+                    const float2 v = (sz == H) ? in_nyq[sl] : in_main[sl * (size_t)H + sz];
+                    double fr, fi;
+                    kop_factor(sx, sy, sz, nx, ny, nz, len_x, len_y, len_z, axis0, axis1, &fr, &fi);
+                    const double pr = (double)v.x * fr - (double)v.y * fi;
+                    const double pi = (double)v.x * fi + (double)v.y * fr;
+                    acc_r += pr;
+                    acc_i += partner ? -pi : pi;
+                }
+        const float2 o = make_float2((float)acc_r, (float)acc_i);
+        if (qz == Hl)
+            out_nyq[line] = o;
+        else
+            out_main[line * (size_t)Hl + qz] = o;
+    }
+}
+
+// The 2LPT source from the six second derivatives, all dense (InitialConditions.c:451-493):
+// box = 0; for (i,j) in (0,1),(0,2),(1,2): box += phi_ii phi_jj; box -= phi_ij^2, every step
+// rounded to float as the reference's in-place loops do; then / norm.
+__global__ void __launch_bounds__(kBlock)
+lpt2_source_kernel(const float *__restrict__ d0, const float *__restrict__ d1,
+                   const float *__restrict__ d2, const float *__restrict__ o01,
+                   const float *__restrict__ o02, const float *__restrict__ o12,
+                   float *__restrict__ out, size_t n4, float norm) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * kBlock) {
+        const float4 a0 = reinterpret_cast<const float4 *>(d0)[i];
+        const float4 a1 = reinterpret_cast<const float4 *>(d1)[i];
+        const float4 a2 = reinterpret_cast<const float4 *>(d2)[i];
+        const float4 b01 = reinterpret_cast<const float4 *>(o01)[i];
+        const float4 b02 = reinterpret_cast<const float4 *>(o02)[i];
+        const float4 b12 = reinterpret_cast<const float4 *>(o12)[i];
+        const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w},
+                    x2[4] = {a2.x, a2.y, a2.z, a2.w}, y01[4] = {b01.x, b01.y, b01.z, b01.w},
+                    y02[4] = {b02.x, b02.y, b02.z, b02.w}, y12[4] = {b12.x, b12.y, b12.z, b12.w};
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float acc = 0.f;
+            acc = __fadd_rn(acc, __fmul_rn(x0[e], x1[e]));
+            acc = __fsub_rn(acc, __fmul_rn(y01[e], y01[e]));
+            acc = __fadd_rn(acc, __fmul_rn(x0[e], x2[e]));
+            acc = __fsub_rn(acc, __fmul_rn(y02[e], y02[e]));
+            acc = __fadd_rn(acc, __fmul_rn(x1[e], x2[e]));
+            acc = __fsub_rn(acc, __fmul_rn(y12[e], y12[e]));
+            r[e] = __fdiv_rn(acc, norm);
+        }
+        reinterpret_cast<float4 *>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 // padded = dense * VOLUME / N (float arithmetic, InitialConditions.c:650-651)
 __global__ void __launch_bounds__(kBlock)
 pack_density_kernel(const float *__restrict__ dense, float *__restrict__ padded, size_t nlines,
@@ -234,6 +372,54 @@ extern "C" int c21hip_lpt2_accumulate(float *box, const float *phi_ij_padded, co
     const size_t nlines = (size_t)nx * ny;
     hipLaunchKernelGGL(lpt2_accumulate_kernel, dim3(grid_for(nlines * nz)), dim3(kBlock), 0,
                        (hipStream_t)stream, box, phi_ij_padded, diag_i, diag_j, nlines, nz, zpad);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- split-layout pipeline entry points (plain split layout: nx <= 512)
+extern "C" int c21hip_split_kop(const float *in_split, float *out_split, int nx, int ny, int nz,
+                                double box_len, double box_len_z, int axis0, int axis1,
+                                void *stream) {
+    const size_t n_main = (size_t)nx * ny * (nz / 2);
+    const float2 *im = reinterpret_cast<const float2 *>(in_split);
+    float2 *om = reinterpret_cast<float2 *>(out_split);
+    hipLaunchKernelGGL(split_kop_kernel, dim3(grid_for(n_main + (size_t)nx * ny)), dim3(kBlock), 0,
+                       (hipStream_t)stream, im, im + n_main, om, om + n_main, nx, ny, nz, box_len,
+                       box_len, box_len_z, axis0, axis1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// hi (nx, ny, nz) split spectrum -> lo (nx/f, ny/f, nz/f) split spectrum of the decimated field,
+// the operator (axis0, axis1) applied per alias; axis0 < 0: none
+extern "C" int c21hip_split_fold(const float *hi_split, float *lo_split, int nx, int ny, int nz,
+                                 int f, double box_len, double box_len_z, int axis0, int axis1,
+                                 void *stream) {
+    if (f < 1 || nx % f || ny % f || nz % f || (nz / f) % 2) {
+        c21hip_set_error("fold: %dx%dx%d is not divisible by %d", nx, ny, nz, f);
+        return C21CM_VALUE_ERROR;
+    }
+    const size_t n_main = (size_t)nx * ny * (nz / 2);
+    const int mx = nx / f, my = ny / f, mz = nz / f;
+    const size_t l_main = (size_t)mx * my * (mz / 2);
+    const float2 *im = reinterpret_cast<const float2 *>(hi_split);
+    float2 *om = reinterpret_cast<float2 *>(lo_split);
+    hipLaunchKernelGGL(fold_kernel, dim3(grid_for((size_t)mx * my * (mz / 2 + 1))), dim3(kBlock), 0,
+                       (hipStream_t)stream, im, im + n_main, om, om + l_main, nx, ny, nz, f,
+                       box_len, box_len, box_len_z, axis0, axis1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_lpt2_source(const float *const diag[3], const float *const off[3],
+                                  float *out, size_t n, float norm, void *stream) {
+    if (n % 4) {
+        c21hip_set_error("lpt2 source: cell count must be a multiple of 4");
+        return C21CM_VALUE_ERROR;
+    }
+    hipLaunchKernelGGL(lpt2_source_kernel, dim3(grid_for(n / 4)), dim3(kBlock), 0,
+                       (hipStream_t)stream, diag[0], diag[1], diag[2], off[0], off[1], off[2], out,
+                       n / 4, norm);
     LAUNCH_CHECK();
     return 0;
 }

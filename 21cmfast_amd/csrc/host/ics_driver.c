@@ -9,6 +9,7 @@
  * all resident in HBM.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../hip/c21hip.h"
@@ -56,6 +57,209 @@ static int emit(const float *box, const int hi_dim[3], float *target, const int 
     return 0;
 }
 
+
+/* ---- split-layout pipeline -----------------------------------------------------------------
+ * For grids the native transform covers: the spectra stay in the split layout (no padded <->
+ * split conversion per transform), pass Z stores dense outputs with the "/ VOLUME" folded in (no
+ * gather sweep), the six 2LPT second derivatives meet in one sweep, and every LOW-RESOLUTION
+ * output (lowres_density, lowres_v*, lowres_v*_2LPT: 7 of the 14 inverse transforms of the
+ * default configuration) is the small transform of the FOLDED spectrum (c21hip_split_fold)
+ * instead of a DIM^3 transform followed by subsampling.  C21CM_ICS=padded selects the older
+ * padded-layout pipeline below. */
+enum {
+    WS_IS_SAVED = 70, WS_IS_FILT, WS_IS_WORK, WS_IS_LO, WS_IS_LOWORK, WS_IS_BOX,
+    WS_IS_D0 = 76, /* 77, 78 */
+    WS_IS_O0 = 79, /* 80, 81 */
+    WS_IS_OUT = 82, WS_IS_IN = 83
+};
+
+typedef struct {
+    const c21cm_ics_spec *s;
+    int hi[3], lo[3], f;
+    size_t ntot, sfl_hi, sfl_lo;
+    float *saved, *filt, *work, *lo_k, *lo_work;
+    void *stream;
+} is_ctx;
+
+/* dense output array (host or device) written by pass Z: returns the device pointer to store to */
+static float *out_target(float *target, size_t n, int *is_host) {
+    *is_host = !c21hip_is_device_ptr(target);
+    return *is_host ? (float *)c21hip_ws(WS_IS_OUT, n * sizeof(float)) : target;
+}
+static int out_finish(float *target, const float *dev, size_t n, int is_host, void *stream) {
+    if (!is_host) return 0;
+    int st = c21hip_d2h(target, dev, n * sizeof(float), stream);
+    if (st) return st;
+    return c21hip_sync(stream); /* the staging slot is reused by the next field */
+}
+
+/* full-resolution field: op(spectrum) -> dense real / divisor */
+static int hi_field(is_ctx *c, const float *spec, int axis0, int axis1, float *target,
+                    float divisor) {
+    if (!target) return 0;
+    int status = 0, is_host;
+    float *d_out = out_target(target, c->ntot, &is_host);
+    if (!d_out) return C21CM_MEMORY_ALLOC_ERROR;
+    const c21cm_ics_spec *s = c->s;
+    const float *src = spec;
+    if (axis0 >= 0) {
+        TRY(c21hip_split_kop(spec, c->work, c->hi[0], c->hi[1], c->hi[2], s->box_len, s->box_len_z,
+                             axis0, axis1, c->stream));
+        src = c->work;
+    }
+    TRY(c21hip_split_filter_xy(src, c->work, c->hi[0], c->hi[1], c->hi[2], s->box_len,
+                               s->box_len_z, 0, 0.f, 0.f, 0, c->stream));
+    TRY(c21hip_split_z_c2r_div(c->work, d_out, c->hi[2], c->hi[0], c->hi[1], c->hi[2], divisor,
+                               c->stream));
+    TRY(out_finish(target, d_out, c->ntot, is_host, c->stream));
+done:
+    return status;
+}
+
+/* low-resolution field: fold(op(filtered spectrum)) -> small transform -> dense real / divisor */
+static int lo_field(is_ctx *c, const float *filt_spec, int axis0, int axis1, float *target,
+                    float divisor) {
+    if (!target) return 0;
+    int status = 0, is_host;
+    const size_t nlo = (size_t)c->lo[0] * c->lo[1] * c->lo[2];
+    float *d_out = out_target(target, nlo, &is_host);
+    if (!d_out) return C21CM_MEMORY_ALLOC_ERROR;
+    const c21cm_ics_spec *s = c->s;
+    TRY(c21hip_split_fold(filt_spec, c->lo_k, c->hi[0], c->hi[1], c->hi[2], c->f, s->box_len,
+                          s->box_len_z, axis0, axis1, c->stream));
+    /* the folded spectrum lives on the lo grid of the SAME box: lengths unchanged */
+    TRY(c21hip_split_filter_xy(c->lo_k, c->lo_work, c->lo[0], c->lo[1], c->lo[2], s->box_len,
+                               s->box_len_z, 0, 0.f, 0.f, 0, c->stream));
+    TRY(c21hip_split_z_c2r_div(c->lo_work, d_out, c->lo[2], c->lo[0], c->lo[1], c->lo[2], divisor,
+                               c->stream));
+    TRY(out_finish(target, d_out, nlo, is_host, c->stream));
+done:
+    return status;
+}
+
+static int ics_split_supported(const c21cm_ics_spec *s) {
+    const char *e = getenv("C21CM_ICS");
+    if (e && e[0] == 'p') return 0; /* C21CM_ICS=padded */
+    if (!c21hip_fft_is_native(s->dim, s->dim, s->dim_z) || c21hip_split_xblock_log2(s->dim)) return 0;
+    if (s->dim == s->hii_dim && s->dim_z == s->hii_dim_z) return 1;
+    if (s->perturb_on_high_res && s->dim % s->hii_dim) return 0;
+    const int f = s->dim / s->hii_dim;
+    if ((f != 2 && f != 4) || s->hii_dim * f != s->dim || s->hii_dim_z * f != s->dim_z) return 0;
+    return c21hip_fft_is_native(s->hii_dim, s->hii_dim, s->hii_dim_z) &&
+           !c21hip_split_xblock_log2(s->hii_dim);
+}
+
+static int ics_grids_split(const c21cm_ics_spec *s, InitialConditions *ics, float *const vel[3],
+                           float *const vel2[3], void *stream) {
+    int status = 0;
+    is_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.s = s;
+    c.stream = stream;
+    c.hi[0] = c.hi[1] = s->dim;
+    c.hi[2] = s->dim_z;
+    c.lo[0] = c.lo[1] = s->hii_dim;
+    c.lo[2] = s->hii_dim_z;
+    c.f = s->dim / s->hii_dim;
+    c.ntot = (size_t)c.hi[0] * c.hi[1] * c.hi[2];
+    c.sfl_hi = c21hip_split_floats(c.hi[0], c.hi[1], c.hi[2]);
+    c.sfl_lo = c21hip_split_floats(c.lo[0], c.lo[1], c.lo[2]);
+    const int hires = s->perturb_on_high_res;
+    const int need_filter = (s->dim != s->hii_dim);
+    const int lpt2 = (s->perturb_algorithm == C21CM_PERTURB_2LPT);
+    const float VOLUME = s->volume;
+    const float R_lo = (float)(L_FACTOR * s->box_len / (s->hii_dim + 0.0));
+    c.saved = (float *)c21hip_ws(WS_IS_SAVED, c.sfl_hi * sizeof(float));
+    c.work = (float *)c21hip_ws(WS_IS_WORK, c.sfl_hi * sizeof(float));
+    c.filt = need_filter ? (float *)c21hip_ws(WS_IS_FILT, c.sfl_hi * sizeof(float)) : c.saved;
+    c.lo_k = (float *)c21hip_ws(WS_IS_LO, c.sfl_lo * sizeof(float));
+    c.lo_work = (float *)c21hip_ws(WS_IS_LOWORK, c.sfl_lo * sizeof(float));
+    if (!c.saved || !c.work || !c.filt || !c.lo_k || !c.lo_work) return C21CM_MEMORY_ALLOC_ERROR;
+
+    if (s->density_is_input) {
+        /* InitialConditions.c:636-663: delta_k = r2c(hires_density * VOLUME / N) */
+        const float *d_in = ics->hires_density;
+        if (!c21hip_is_device_ptr(d_in)) {
+            float *tmp = (float *)c21hip_ws(WS_IS_IN, c.ntot * sizeof(float));
+            if (!tmp) return C21CM_MEMORY_ALLOC_ERROR;
+            TRY(c21hip_h2d(tmp, ics->hires_density, c.ntot * sizeof(float), stream));
+            d_in = tmp;
+        }
+        /* the float product / quotient of :650-651 is done on load in double and rounded once */
+        TRY(c21hip_split_r2c(d_in, c.hi[2], c.saved, c.hi[0], c.hi[1], c.hi[2],
+                             (double)VOLUME / (double)(float)c.ntot, 1., -1., 1.0f, stream));
+    } else {
+        /* InitialConditions.c:664-692 */
+        const int n_m = 3 * (s->dim / 2) * (s->dim / 2) + 1;
+        if (!s->pk_by_m || s->n_m < n_m || s->dim != s->dim_z || s->box_len != s->box_len_z) {
+            c21hip_set_error("ics: mode sampling needs a cubic grid and pk_by_m[0..3(DIM/2)^2]");
+            return C21CM_VALUE_ERROR;
+        }
+        double *pk_dev = (double *)c21hip_ws(WS_IC_PK, (size_t)n_m * sizeof(double));
+        /* the sampler writes the FFTW-style padded layout; one conversion per call */
+        float *padded = (float *)c21hip_ws(WS_IS_BOX, (c.ntot + 2 * (size_t)c.hi[0] * c.hi[1]) * sizeof(float));
+        if (!pk_dev || !padded) return C21CM_MEMORY_ALLOC_ERROR;
+        TRY(c21hip_h2d(pk_dev, s->pk_by_m, (size_t)n_m * sizeof(double), stream));
+        TRY(c21hip_sample_modes(padded, c.hi[0], c.hi[1], c.hi[2], pk_dev, VOLUME, s->seed, stream));
+        TRY(c21hip_padded_to_split(padded, c.saved, c.hi[0], c.hi[1], c.hi[2], stream));
+        TRY(hi_field(&c, c.saved, -1, -1, ics->hires_density, VOLUME));
+    }
+    /* the top-hat at the low-resolution cell scale is common to every low-resolution output and
+     * commutes with the k-space operators: applied once (InitialConditions.c:700-703,330-333) */
+    if (need_filter)
+        TRY(c21hip_copy_filter_split(c.saved, c.filt, c.hi[0], c.hi[1], c.hi[2], s->box_len,
+                                     s->box_len_z, 0, R_lo, 0.f, 1, stream));
+    if (need_filter)
+        TRY(lo_field(&c, c.filt, -1, -1, ics->lowres_density, VOLUME));
+    else
+        TRY(hi_field(&c, c.saved, -1, -1, ics->lowres_density, VOLUME));
+
+    /* first-order velocities: InitialConditions.c:299-364 */
+    for (int ii = 0; ii < 3; ii++) {
+        if (hires || !need_filter)
+            TRY(hi_field(&c, c.saved, ii, -1, vel[ii], VOLUME));
+        else
+            TRY(lo_field(&c, c.filt, ii, -1, vel[ii], VOLUME));
+    }
+
+    if (lpt2) {
+        /* InitialConditions.c:366-545 */
+        float *d[3], *o[3];
+        for (int k = 0; k < 3; k++) {
+            d[k] = (float *)c21hip_ws(WS_IS_D0 + k, c.ntot * sizeof(float));
+            o[k] = (float *)c21hip_ws(WS_IS_O0 + k, c.ntot * sizeof(float));
+            if (!d[k] || !o[k]) return C21CM_MEMORY_ALLOC_ERROR;
+        }
+        float *box = (float *)c21hip_ws(WS_IS_BOX, (c.ntot + 2 * (size_t)c.hi[0] * c.hi[1]) * sizeof(float));
+        if (!box) return C21CM_MEMORY_ALLOC_ERROR;
+        static const int dirs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+        for (int k = 0; k < 3; k++) {
+            TRY(hi_field(&c, c.saved, k, k, d[k], 0.f));
+            TRY(hi_field(&c, c.saved, dirs[k][0], dirs[k][1], o[k], 0.f));
+        }
+        /* /= VOLUME*VOLUME*TOT_NUM_PIXELS: float * float * (ull -> float), :493 */
+        const float norm = VOLUME * VOLUME * (float)c.ntot;
+        {
+            const float *dc[3] = {d[0], d[1], d[2]}, *oc[3] = {o[0], o[1], o[2]};
+            TRY(c21hip_lpt2_source(dc, oc, box, c.ntot, norm, stream));
+        }
+        TRY(c21hip_split_r2c(box, c.hi[2], c.saved, c.hi[0], c.hi[1], c.hi[2], 1.0, 1., -1., 1.0f,
+                             stream));
+        if (need_filter && !hires)
+            TRY(c21hip_copy_filter_split(c.saved, c.filt, c.hi[0], c.hi[1], c.hi[2], s->box_len,
+                                         s->box_len_z, 0, R_lo, 0.f, 1, stream));
+        for (int ii = 0; ii < 3; ii++) {
+            if (hires || !need_filter)
+                TRY(hi_field(&c, c.saved, ii, -1, vel2[ii], 0.f));
+            else
+                TRY(lo_field(&c, c.filt, ii, -1, vel2[ii], 0.f));
+        }
+    }
+    TRY(c21hip_sync(stream));
+done:
+    return status;
+}
+
 int c21cm_ics_grids(const c21cm_ics_spec *s, InitialConditions *ics, void *stream) {
     int status = 0;
     if (!s || !ics || !ics->hires_density || !ics->lowres_density) {
@@ -84,6 +288,7 @@ int c21cm_ics_grids(const c21cm_ics_spec *s, InitialConditions *ics, void *strea
         c21hip_set_error("ics: velocity output arrays are missing");
         return C21CM_VALUE_ERROR;
     }
+    if (ics_split_supported(s)) return ics_grids_split(s, ics, vel, vel2, stream);
 
     float *box = (float *)c21hip_ws(WS_IC_BOX, npad * sizeof(float));
     float *saved = (float *)c21hip_ws(WS_IC_SAVED, npad * sizeof(float));

@@ -43,6 +43,49 @@ def test_option_branches(api, oracle, opts):
     compare(api.ics_grids(spec), oracle.ics_grids(spec))
 
 
+@pytest.mark.parametrize("dim,hii_dim,device,opts", [
+    (256, 64, "cuda", {}),                      # fold by 4
+    (128, 64, None, dict(hires=1)),             # hi-res velocities, folded low-res density
+    (128, 64, "cuda", dict(algorithm=1)),       # Zel'dovich only
+    (128, 64, None, dict(hires=1, algorithm=1)),
+    (64, 64, "cuda", {}),                       # DIM == HII_DIM: no filter, no fold
+])
+def test_split_layout_pipeline_matches_oracle(api, oracle, dim, hii_dim, device, opts):
+    """The split-layout pipeline (native transform sizes): spectra in the split layout, dense
+    stores from pass Z, low-resolution outputs from the folded spectrum."""
+    spec = ics_spec(dim, hii_dim, box_len=1.5 * dim, seed=31, **opts)
+    compare(api.ics_grids(spec, device=device), oracle.ics_grids(spec))
+
+
+def test_split_and_padded_pipelines_agree(api, monkeypatch):
+    """C21CM_ICS=padded selects the padded-layout pipeline (full-size transforms + gathers);
+    folding is an exact identity, so the two agree to transform round-off."""
+    spec = ics_spec(128, 64, box_len=192.0, seed=77)
+    a = api.ics_grids(spec, device="cuda")
+    monkeypatch.setenv("C21CM_ICS", "padded")
+    b = api.ics_grids(spec, device="cuda")
+    for k in a:
+        x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
+        np.testing.assert_allclose(x, y, atol=2e-5 * np.abs(y).max(), rtol=1e-4, err_msg=k)
+    assert not all(np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy()) for k in LOWRES_FIELDS)
+
+
+def test_density_input_on_the_split_pipeline(api, oracle):
+    dim, hii = 128, 64
+    spec = ics_spec(dim, hii, box_len=192.0, seed=8)
+    ic = api.ics_grids(spec)
+    spec2 = ics_spec(dim, hii, box_len=192.0, density_is_input=1)
+    start = api.new_ics_arrays(spec2)
+    start["hires_density"][...] = ic["hires_density"]
+    ic2 = api.ics_grids(spec2, start)
+    for name in LOWRES_FIELDS:
+        scale = max(1.0, np.abs(ic[name]).max())
+        np.testing.assert_allclose(ic[name], ic2[name], atol=1e-5 * scale, rtol=0.0, err_msg=name)
+    ref = oracle.new_ics_arrays(spec2)
+    ref["hires_density"][...] = ic["hires_density"]
+    compare(ic2, oracle.ics_grids(spec2, ref), LOWRES_FIELDS)
+
+
 def test_roundtrip_from_own_density_on_device(api, oracle):
     """Reference test tests/test_initial_conditions.py:153-167 on the HIP path."""
     dim, hii = 64, 32
