@@ -124,6 +124,13 @@ int c21hip_split_z_ionise_stars(const float *delta_work, const float *stars_work
                                 unsigned char *first_cross, double *partials, double *sum_out,
                                 int nx, int ny, int nz, int r_index, double rhocrit_omb,
                                 double ion_eff, int mass_dep_zeta, double f_limit, void *stream);
+/* sum_out == NULL in c21hip_split_z_ionise_stars defers the reduction: the partials of every
+ * radius stay at partials + R * stride and ONE launch turns them into sums[R] / means[R] for
+ * R = first, first - step, ... (count radii) */
+int c21hip_z_ionise_partials(int nx, int ny, int nz);
+int c21hip_batched_means(const double *partials, long stride, int n_partials, int first, int step,
+                         int count, double ntot, int mass_dep_zeta, double f_limit, double *sums,
+                         double *means, void *stream);
 /* time `reps` launches of one pass with HIP events on `stream` (bench.py roofline leg);
  * kind: 0 pass X and 1 pass Y as the excursion-set loop launches them (two grids, windows
  * filter_a / filter_b streamed from the per-radius tables), 2 fused pass Z, 3 plain pass Z,

@@ -2077,7 +2077,59 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
     int n_partials = 0;
     int st = dispatch_z_fused(nz, a, nlines, (hipStream_t)stream, &n_partials);
     if (st) return st;
+    if (!sum_out) return 0;  // deferred: the caller reduces the partials of all radii at once
     return c21hip_reduce_sum(partials, n_partials, sum_out, stream);
+}
+
+// workgroup partials the fused pass Z writes for an nx x ny x nz grid
+extern "C" int c21hip_z_ionise_partials(int nx, int ny, int nz) {
+    const long nlines = (long)nx * ny;
+    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0)
+        return (int)(nlines / ZW_LINES);
+    return (int)(nlines / LZ_FUSED);
+}
+
+// The f_coll sums of `count` radii in ONE launch: block i reduces the n_partials doubles at
+// partials + R * stride, R = first - i * step, in a fixed order, then applies the clamp of
+// IonisationBox.c:1566-1576 (sums[R], means[R]).  Nothing in the fused Lagrangian loop reads a
+// radius' mean, so the three small launches per radius leave the critical path.
+__global__ void __launch_bounds__(kBlock)
+batched_means_kernel(const double *__restrict__ partials, long stride, int n_partials, int first,
+                     int step, double ntot, int mass_dep_zeta, double f_limit,
+                     double *__restrict__ sums, double *__restrict__ means) {
+    __shared__ double lds[kBlock];
+    const int R = first - (int)blockIdx.x * step;
+    const double *p = partials + (long)R * stride;
+    double acc = 0.;
+    for (int i = threadIdx.x; i < n_partials; i += kBlock) acc += p[i];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sums[R] = lds[0];
+        double m = lds[0] / ntot;
+        if (mass_dep_zeta) {
+            if (m <= f_limit) m = f_limit;
+        } else if (m <= kFractFloatErr) {
+            m = kFractFloatErr;
+        }
+        means[R] = m;
+    }
+}
+
+extern "C" int c21hip_batched_means(const double *partials, long stride, int n_partials,
+                                    int first, int step, int count, double ntot,
+                                    int mass_dep_zeta, double f_limit, double *sums,
+                                    double *means, void *stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(batched_means_kernel, dim3(count), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, stride, n_partials, first, step, ntot, mass_dep_zeta, f_limit,
+                       sums, means);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 // ------------------------------------------------------------------ single-kernel timing hook

@@ -67,10 +67,10 @@ static int emit(const float *box, const int hi_dim[3], float *target, const int 
  * instead of a DIM^3 transform followed by subsampling.  C21CM_ICS=padded selects the older
  * padded-layout pipeline below. */
 enum {
-    WS_IS_SAVED = 70, WS_IS_FILT, WS_IS_WORK, WS_IS_LO, WS_IS_LOWORK, WS_IS_BOX,
-    WS_IS_D0 = 76, /* 77, 78 */
-    WS_IS_O0 = 79, /* 80, 81 */
-    WS_IS_OUT = 82, WS_IS_IN = 83
+    WS_IS_SAVED = 100, WS_IS_FILT, WS_IS_WORK, WS_IS_LO, WS_IS_LOWORK, WS_IS_BOX,
+    WS_IS_D0 = 106, /* 107, 108 */
+    WS_IS_O0 = 109, /* 110, 111 */
+    WS_IS_OUT = 112, WS_IS_IN = 113
 };
 
 typedef struct {

@@ -48,7 +48,8 @@ enum {
     WS_DELTA_WORK,
     WS_STARS_WORK,
     WS_XE_WORK,
-    WS_PARTIALS
+    WS_PARTIALS,
+    WS_DEF_PARTIALS = 84
 };
 
 #define MAX_COPYBACK 8
@@ -205,6 +206,11 @@ typedef struct {
     float *table_dev;
     unsigned char *mask; /* internal first-crossing mask of the fused single-GPU path */
     int fused;           /* fused pass Z + barrier available for radius index > 0 */
+    /* deferred f_coll sums of the fused radii: partials of radius R at def_partials + R *
+     * def_stride, radii def_first, def_first - def_step, ... (def_count of them) */
+    double *def_partials;
+    long def_stride;
+    int def_first, def_step, def_count;
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
     int eul_mask;        /* Eulerian models on the native passes without an x_e grid: radii > 0
@@ -259,6 +265,15 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
      * barrier test run as one kernel that only updates a uint8 first-crossing mask */
     c->fused = c->native && c->lagrangian && !s->use_ts_fluct;
     c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct;
+    if (c->fused) {
+        const char *e = getenv("C21CM_DEFER_SUMS");
+        if (!(e && e[0] == '0')) {
+            c->def_stride = c21hip_z_ionise_partials(c->nx, c->ny, c->nz);
+            c->def_partials = (double *)c21hip_ws(
+                WS_DEF_PARTIALS, (size_t)s->n_radii * (size_t)c->def_stride * sizeof(double));
+            if (!c->def_partials) return C21CM_MEMORY_ALLOC_ERROR;
+        }
+    }
     c->scalars = (double *)c21hip_ws(WS_SCALARS, SC_COUNT * sizeof(double));
     c->table_dev = (float *)c21hip_ws(WS_TABLE, 2 * C21CM_NDELTA_TABLE * sizeof(float));
     if (!c->scalars || !c->table_dev) return C21CM_MEMORY_ALLOC_ERROR;
@@ -411,6 +426,18 @@ done:
     return status;
 }
 
+/* The f_coll sums and means of the fused radii processed so far, in one launch. */
+static int flush_deferred(ion_ctx *c) {
+    if (!c->def_partials || c->def_count == 0) return 0;
+    const c21cm_ionize_spec *s = c->s;
+    int st = c21hip_batched_means(c->def_partials, c->def_stride, (int)c->def_stride, c->def_first,
+                                  c->def_count > 1 ? c->def_step : 1, c->def_count,
+                                  (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                                  c->scalars + SC_SUMS, c->scalars + SC_MEANS, c->stream);
+    c->def_count = 0;
+    return st;
+}
+
 /* One filter radius: IonisationBox.c:1546-1580.  first_cross != NULL = shard mode.
  * next_R: the radius index this process handles after R_ct (-1: none / unknown). */
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
@@ -446,6 +473,23 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                     c->stream));
         if (g_tab.enabled) TRY(c21hip_event_record(g_tab.ev_used[buf], c->stream));
         c->tab_seq++;
+        if (c->def_partials) {
+            /* no kernel of this loop reads a radius' mean: reduce all of them at the end */
+            if (c->def_count == 0)
+                c->def_first = R_ct;
+            else if (c->def_count == 1)
+                c->def_step = c->def_first - R_ct;
+            else if (R_ct != c->def_first - c->def_count * c->def_step)
+                TRY(flush_deferred(c));
+            if (c->def_count == 0) c->def_first = R_ct;
+            c->def_count++;
+            TRY(c21hip_split_z_ionise_stars(c->delta_work, c->stars_work, first_cross,
+                                            c->def_partials + (long)R_ct * c->def_stride, NULL,
+                                            c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
+                                            s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
+                                            c->stream));
+            goto done;
+        }
         TRY(c21hip_split_z_ionise_stars(c->delta_work, c->stars_work, first_cross, partials,
                                         sum_dev, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
                                         s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
@@ -754,6 +798,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             if (R_ct == 0 && mask_pending) {
                 mask_pending = 0;
                 if (c.fused) {
+                    TRY(flush_deferred(&c));
                     TRY(final_step(&c, c.mask, 0));
                     break;
                 }
@@ -764,6 +809,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             TRY(one_radius(&c, R_ct, (R_ct > 0 && use_mask) ? c.mask : NULL,
                            (R_ct - 1 >= spec->r_lowest) ? R_ct - 1 : -1));
         }
+        TRY(flush_deferred(&c));
         if (mask_pending)
             TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot, spec->redshift,
                                          c.xH, c.zre, c.ntot, stream));
@@ -833,6 +879,7 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
             TRY(one_radius(&c, R_ct, first_cross, R_ct - world));
         }
     }
+    TRY(flush_deferred(&c));
     /* The rank that will run the finish step has one radius fewer than the busiest ranks: it
      * uses that slack to transform the unfiltered emissivity for the cell-scale step, so that
      * after the reduce only the final sweep remains. */
