@@ -453,11 +453,17 @@ __device__ __forceinline__ void window_batch_dual(const FilterParams &pa, const 
 // 128 contiguous bytes).  An earlier version evaluated W inside pass X (once per mirror pair,
 // kept in LDS): the same total time at 512^3, but 28 KB more LDS and 1024-thread workgroups,
 // and no room for a 1024-point tile.
+// Table entries are stored as float: W is evaluated in double and rounded once.  The reference
+// multiplies the float spectrum by the double window ((float)(v * W), 0.5 ulp); with the rounded
+// window the product carries at most one more half-ulp (6e-8 relative, well below the rounding
+// of the transforms themselves), the table traffic -- 0.27 of the 0.54 GB a radius wrote and
+// read back for its two windows at 512^3 -- halves, and pass X multiplies in fp32.
+using wtab_t = float;
 struct WTableArgs {
     FilterParams pa, pb;
     int dual;  // 1: also fill the b tables with window pb
     int nx, ny, nz;
-    double *main_a, *nyq_a, *main_b, *nyq_b;
+    wtab_t *main_a, *nyq_a, *main_b, *nyq_b;
     MsConsts ms_a, ms_b;  // windows of type 5 (multiple scattering), MS kernel variant only
 };
 
@@ -512,14 +518,11 @@ window_table_kernel(WTableArgs t) {
             window_batch<4>(t.pa, kx, ky, kz, wa);
         for (int rep = 0; rep < ((sym && i != j) ? 2 : 1); rep++) {
             const long rr = rep ? rT : r;
-            double2 *oa = reinterpret_cast<double2 *>(t.main_a + rr * H + 4 * l4);
-            oa[0] = make_double2(wa[0], wa[1]);
-            oa[1] = make_double2(wa[2], wa[3]);
-            if (t.dual) {
-                double2 *ob = reinterpret_cast<double2 *>(t.main_b + rr * H + 4 * l4);
-                ob[0] = make_double2(wb[0], wb[1]);
-                ob[1] = make_double2(wb[2], wb[3]);
-            }
+            *reinterpret_cast<float4 *>(t.main_a + rr * H + 4 * l4) =
+                make_float4((float)wa[0], (float)wa[1], (float)wa[2], (float)wa[3]);
+            if (t.dual)
+                *reinterpret_cast<float4 *>(t.main_b + rr * H + 4 * l4) =
+                    make_float4((float)wb[0], (float)wb[1], (float)wb[2], (float)wb[3]);
         }
     } else if (id - n4 < (long)nxh * nyh) {
         const long q = id - n4;
@@ -535,11 +538,11 @@ window_table_kernel(WTableArgs t) {
             window_batch_dual<1>(t.pa, t.pb, kx, ky, kz, wa, wb);
         else
             window_batch<1>(t.pa, kx, ky, kz, wa);
-        t.nyq_a[q] = wa[0];
-        if (t.dual) t.nyq_b[q] = wb[0];
+        t.nyq_a[q] = (wtab_t)wa[0];
+        if (t.dual) t.nyq_b[q] = (wtab_t)wb[0];
         if (sym && i != j) {
-            t.nyq_a[(long)j * nyh + i] = wa[0];
-            if (t.dual) t.nyq_b[(long)j * nyh + i] = wb[0];
+            t.nyq_a[(long)j * nyh + i] = (wtab_t)wa[0];
+            if (t.dual) t.nyq_b[(long)j * nyh + i] = (wtab_t)wb[0];
         }
     }
 }
@@ -573,8 +576,8 @@ struct LinePassArgs {
     int n_y, n_z;  // grid dims for the wavenumbers
     float out_scale;  // applied at store (1 = none)
     // FMODE 3: window tables of this radius (window_table_kernel), per window
-    const double *wt_main[2];  // [ny/2+1][nx/2+1][nz/2]
-    const double *wt_nyq[2];   // [nx/2+1][ny/2+1]
+    const wtab_t *wt_main[2];  // [ny/2+1][nx/2+1][nz/2]
+    const wtab_t *wt_nyq[2];   // [nx/2+1][ny/2+1]
     int dual;                  // FMODE 3: grid 1 uses window 1 (else both grids use window 0)
     FilterParams fp;           // the window of grid 0 (host side: table construction)
 };
@@ -611,7 +614,7 @@ struct LineItem {
     int line_lb, outer_lb;
     int n_outer, filter_axis;
     int og, ct, npair;
-    const double *wt0, *wt1;  // FMODE 3: window tables of this geometry
+    const wtab_t *wt0, *wt1;  // FMODE 3: window tables of this geometry
 };
 
 // FMODE: 0 no window, 3 window streamed from the per-radius tables
@@ -690,32 +693,32 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
-    double2 wpre[NP], wcur[NP], wpre_half, wcur_half;
+    float2 wpre[NP], wcur[NP], wpre_half, wcur_half;
     auto w_reload = [&](const LineItem &it, int m) {
         const int mi = it.npair == 2 ? (m & 1) : 0;
         return m == 0 || (a.dual && mi == 0);
     };
     auto issue_wloads = [&](const LineItem &it, int m) {
-        const double *t = (a.dual && member_grid(it, m)) ? it.wt1 : it.wt0;
+        const wtab_t *t = (a.dual && member_grid(it, m)) ? it.wt1 : it.wt0;
         if (it.filter_axis == 0) {
             const unsigned wc = (unsigned)(a.n_z / 2);
-            const double *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
+            const wtab_t *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
 #pragma unroll
             for (int u = 0; u < NP; u++)
-                wpre[u] = *reinterpret_cast<const double2 *>(b + (unsigned)(r0 + RSTEP * u) * wc);
-            wpre_half = *reinterpret_cast<const double2 *>(b + (unsigned)(N / 2) * wc);
+                wpre[u] = *reinterpret_cast<const float2 *>(b + (unsigned)(r0 + RSTEP * u) * wc);
+            wpre_half = *reinterpret_cast<const float2 *>(b + (unsigned)(N / 2) * wc);
         } else {
             const int c0 = it.ct * TZ + 2 * c4;
             const unsigned nyh = (unsigned)(a.n_y / 2 + 1);
             const unsigned j0 = (unsigned)min(c0, a.n_y - c0), j1 = (unsigned)min(c0 + 1, a.n_y - c0 - 1);
 #pragma unroll
             for (int u = 0; u < NP; u++) {
-                const double *r = t + (unsigned)(r0 + RSTEP * u) * nyh;
-                wpre[u] = make_double2(r[j0], r[j1]);
+                const wtab_t *r = t + (unsigned)(r0 + RSTEP * u) * nyh;
+                wpre[u] = make_float2(r[j0], r[j1]);
             }
             {
-                const double *r = t + (unsigned)(N / 2) * nyh;
-                wpre_half = make_double2(r[j0], r[j1]);
+                const wtab_t *r = t + (unsigned)(N / 2) * nyh;
+                wpre_half = make_float2(r[j0], r[j1]);
             }
         }
     };
@@ -780,11 +783,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             const bool half = (u & 1) && row_a == 0;  // row N/2 has its own |k_x|
             float4 v = reg[u];
             if (FMODE == 3) {
-                const double2 wv = half ? wcur_half : wcur[u >> 1];
-                v.x = (float)((double)v.x * wv.x);
-                v.y = (float)((double)v.y * wv.x);
-                v.z = (float)((double)v.z * wv.y);
-                v.w = (float)((double)v.w * wv.y);
+                const float2 wv = half ? wcur_half : wcur[u >> 1];
+                v.x = __fmul_rn(v.x, wv.x);
+                v.y = __fmul_rn(v.y, wv.x);
+                v.z = __fmul_rn(v.z, wv.y);
+                v.w = __fmul_rn(v.w, wv.y);
             }
             *reinterpret_cast<float4 *>(tile + row * TZ + 2 * c4) = v;
         }
@@ -1752,8 +1755,8 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     if (fmode == 3) {
         const size_t n_main = (size_t)(ny / 2 + 1) * (nx / 2 + 1) * H;
         const size_t n_nyq = (size_t)(nx / 2 + 1) * (ny / 2 + 1);
-        const size_t per = (n_main + n_nyq + 1) & ~(size_t)1;  // keep table b 16-byte aligned
-        double *tab = (double *)c21hip_ws(table_slot ? 46 : 49, sizeof(double) * per * (dual ? 2 : 1));
+        const size_t per = (n_main + n_nyq + 3) & ~(size_t)3;  // keep table b 16-byte aligned
+        wtab_t *tab = (wtab_t *)c21hip_ws(table_slot ? 46 : 49, sizeof(wtab_t) * per * (dual ? 2 : 1));
         if (!tab) return C21CM_MEMORY_ALLOC_ERROR;
         WTableArgs t{};
         t.pa = a.fp;

@@ -101,7 +101,7 @@ PASS_KERNELS = {
     0: "line_pass_kernel<512,+1,3>  (pass X: x-lines of both grids x streamed W(kR) tables)",
     1: "line_pass_kernel<512,+1,0>  (pass Y: y-lines of both grids)",
     2: "zw_ionise_kernel<16>        (wave-level pass Z of both grids + f_coll sum + barrier)",
-    4: "window_table_kernel         (W(kR) of one radius for both windows; fp64 ALU bound)",
+    4: "window_table_kernel         (W(kR) of one radius for both windows, evaluated in fp64, stored as float)",
 }
 
 
@@ -111,7 +111,7 @@ def kernel_roofline(args, spec, torch):
       pass X / pass Y  read + write of both split k-space grids       2 * 2 * S
       fused pass Z     read of both grids + uint8 mask read + write   2 * S + 2 * N
     S = 8 * (N/2 + nx*ny) bytes (split layout), N = cells.  The window tables pass X also
-    reads (2 x 8 (n/2+1)^3 bytes) are overhead, not algorithmic bytes."""
+    reads (2 x 4 (n/2+1)^3 bytes, float entries) are overhead, not algorithmic bytes."""
     import ctypes as C
 
     n = args.hii_dim
