@@ -1555,6 +1555,102 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     }
 }
 
+// Plain pass Z (one grid) on the wave-level transform, with the store epilogues of z_c2r_kernel
+// (EPI 0 store / divide, 1 store + extrema, 2 closed-form f_coll + sum, 3 floor-scale store +
+// statistics).  Sixteen lines per workgroup like the tile kernel, so the partial arrays have the
+// same length either way.
+template <int A, int EPI>
+__global__ void __launch_bounds__(kBlock)
+zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
+              const float2 *__restrict__ twN_global) {
+    constexpr int H = 16 * A, NZ = 2 * H;
+    constexpr int LINE_LDS = A * 17 + 4;
+    __shared__ float2 lines[ZW_LINES * LINE_LDS];
+    __shared__ float2 twH[H], twN[H];
+    for (int t = threadIdx.x; t < H; t += kBlock) {
+        twH[t] = twH_global[t];
+        twN[t] = twN_global[t];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, b = lane & 15;
+    const int lw = wave * 4 + g;
+    const long line = (long)blockIdx.x * ZW_LINES + lw;
+    float2 *L = lines + lw * LINE_LDS;
+    const float2 *src = a.main + line * H;
+    float2 x[A];
+#pragma unroll
+    for (int q = 0; q < A; q++) x[q] = src[16 * q + b];
+    const long lline = logical_line(line, a.ny, a.lb);
+    const float xh = a.nyq[lline].x;
+    __syncthreads();  // twiddle tables
+    wave_c2r<A>(x, xh, L, twH, twN, b);
+
+    double acc0 = 0., acc1 = 0., acc2 = 0.;
+#pragma unroll
+    for (int q = 0; q < A; q++) {
+        const int j = (b + 16 * (q / 16)) + A * (q % 16);  // cells (2j, 2j + 1)
+        float2 v = x[q];
+        if (a.out_scale != 1.0f) {
+            v.x *= a.out_scale;
+            v.y *= a.out_scale;
+        }
+        if (EPI == 0 && a.out_div != 0.f) {
+            v.x = __fdiv_rn(v.x, a.out_div);
+            v.y = __fdiv_rn(v.y, a.out_div);
+        }
+        if (EPI == 3) {
+            if ((double)v.x < a.min_value) v.x = (float)a.min_value;
+            if ((double)v.y < a.min_value) v.y = (float)a.min_value;
+            v.x = (float)((double)v.x * a.const_factor);
+            v.y = (float)((double)v.y * a.const_factor);
+            acc2 += (double)v.x;
+            acc2 += (double)v.y;
+        }
+        if (EPI == 2) {
+            const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
+            const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
+            acc0 += f0;
+            acc0 += f1;
+            reinterpret_cast<float2 *>(a.f_out + lline * NZ)[j] = make_float2((float)f0, (float)f1);
+        } else {
+            reinterpret_cast<float2 *>(a.out + lline * a.out_zstride)[j] = v;
+            if (EPI == 1 || EPI == 3) {
+                const double lo = fmin((double)v.x, (double)v.y), hi = fmax((double)v.x, (double)v.y);
+                acc0 = (q == 0) ? lo : fmin(acc0, lo);
+                acc1 = (q == 0) ? hi : fmax(acc1, hi);
+            }
+        }
+    }
+    if (EPI != 0) {
+        __shared__ double red0[kBlock / 64], red1[kBlock / 64], red2[kBlock / 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
+            acc0 = (EPI == 2) ? acc0 + o0 : fmin(acc0, o0);
+            acc1 = fmax(acc1, o1);
+            if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
+        }
+        if (lane == 0) {
+            red0[wave] = acc0;
+            red1[wave] = acc1;
+            red2[wave] = acc2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r0 = red0[0], r1 = red1[0], r2 = red2[0];
+#pragma unroll
+            for (int w = 1; w < kBlock / 64; w++) {
+                r0 = (EPI == 2) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r1 = fmax(r1, red1[w]);
+                r2 += red2[w];
+            }
+            a.p0[blockIdx.x] = r0;
+            if (EPI == 1 || EPI == 3) a.p1[blockIdx.x] = r1;
+            if (EPI == 3) a.p2[blockIdx.x] = r2;
+        }
+    }
+}
+
 bool zw_enabled() {
     static int cached = -1;
     if (cached < 0) {
@@ -1647,6 +1743,19 @@ int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
 
 template <int EPI = 0>
 int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) {
+    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0 &&
+        (a.out_zstride % 2 == 0)) {
+        const float2 *twH = twiddles(nz / 2);
+        const float2 *twN = twiddles(nz);
+        if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+        const dim3 grid((unsigned)(nlines / ZW_LINES));
+        if (nz == 512)
+            hipLaunchKernelGGL((zw_c2r_kernel<16, EPI>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+        else
+            hipLaunchKernelGGL((zw_c2r_kernel<32, EPI>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+        LAUNCH_CHECK();
+        return 0;
+    }
     switch (nz) {
         case 64: return launch_z_c2r<64, EPI>(a, nlines, stream);
         case 128: return launch_z_c2r<128, EPI>(a, nlines, stream);

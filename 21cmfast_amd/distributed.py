@@ -46,7 +46,7 @@ def sharded_ionize(spec, density, n_ion, buffers, first_cross, rank: int, world:
     from . import grid_api as api
 
     owner = owner_rank(spec.n_radii, world)
-    api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion)
+    api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion, want_report=False)
     reduce_first_cross(first_cross, owner, group)
     if rank == owner:
         _, _, rep = api.ionize_shard_finish(spec, first_cross, density, n_ion, buffers=buffers)

@@ -129,14 +129,17 @@ def ionize_grids(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=None
 
 
 def ionize_shard_radii(spec, rank, world, first_cross, density, n_ion=None, xe=None,
-                       Tneutral=None, prev_z_reion=None, stream=None):
-    """Shard phase: this rank's radii -> ``first_cross`` (uint8 CUDA tensor)."""
+                       Tneutral=None, prev_z_reion=None, stream=None, want_report=True):
+    """Shard phase: this rank's radii -> ``first_cross`` (uint8 CUDA tensor).
+    ``want_report=False`` skips the per-radius f_coll means and with them the host
+    synchronisation at the end of the phase (the call only enqueues work)."""
     pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion)
-    rep = S.IonizeReport()
+    rep = S.IonizeReport() if want_report else None
     check(
         load().c21cm_ionize_shard_radii(C.byref(spec), rank, world, C.byref(pf), C.byref(prev),
                                         C.byref(ts), C.byref(hb),
-                                        C.c_void_p(first_cross.data_ptr()), C.byref(rep),
+                                        C.c_void_p(first_cross.data_ptr()),
+                                        C.byref(rep) if want_report else None,
                                         _stream(stream)),
         "c21cm_ionize_shard_radii",
     )

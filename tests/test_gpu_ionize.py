@@ -135,6 +135,53 @@ def check_512_lines(api, oracle, n=64, nz=512):
     assert 0.05 < (ref["neutral_fraction"] == 0).mean() < 0.95
 
 
+_TABLE_CB = []  # ctypes callbacks must outlive the spec that points at them
+
+
+def _install_table(spec):
+    """A smooth exp-table callback (FCOLL_TABLE_EXP): ln f_coll(delta) per radius."""
+    S = importlib.import_module("21cmfast_amd.structs")
+
+    def table_fn(r_index, dmin, dmax, table, user):
+        x = dmin + (dmax - dmin) / (S.NDELTA_TABLE - 1.0) * np.arange(S.NDELTA_TABLE)
+        y = np.log(0.02 * (1 + np.maximum(x, -0.999)) ** 1.5 / (1 + 0.05 * r_index))
+        for i in range(S.NDELTA_TABLE):
+            table[i] = y[i]
+        return 0
+
+    cb = S.TABLE_FN(table_fn)
+    _TABLE_CB.append(cb)
+    spec.table_fn = cb
+
+
+@pytest.mark.parametrize("mode", ["erfc", "table", "stars_ts"])
+@pytest.mark.parametrize("nz", [512, 1024])
+def test_long_z_lines_plain_pass_parity(api, oracle, mode, nz):
+    """The single-grid pass Z on 512- and 1024-point lines (wave-level kernel with the erfc,
+    extrema and plain-store epilogues) on 64 x 64 x nz boxes."""
+    n = 64
+    oracle.set_threads(32)
+    if mode == "stars_ts":  # x_e grid present: unfused path, plain stores of three grids
+        spec = W.ionize_spec(n, hii_dim_z=nz, r_bubble_max=8.0, use_ts_fluct=1)
+        density = W.density_field_numpy((n, n, nz), seed=5)
+        n_ion = W.nion_from_density(density)
+        rng = np.random.default_rng(3)
+        xe = (0.02 + 0.03 * rng.random((n, n, nz))).astype(np.float32)
+        Tn = (8.0 + 4.0 * rng.random((n, n, nz))).astype(np.float32)
+        ref = oracle.ionize_grids(spec, density, n_ion, xe=xe, Tneutral=Tn)
+        got = run_device(api, spec, density, n_ion, xe=xe, Tneutral=Tn, device_resident=True)
+    else:
+        fmode = W.FCOLL_ERFC if mode == "erfc" else W.FCOLL_TABLE_EXP
+        spec = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=8.0)
+        density = W.density_field_numpy((n, n, nz), seed=6)
+        if mode == "table":
+            _install_table(spec)
+        ref = oracle.ionize_grids(spec, density, need_nion=True)
+        got = run_device(api, spec, density, device_resident=True)
+    compare(got, ref, spec)
+    oracle.set_threads(16)
+
+
 @pytest.mark.parametrize("n", [32, 50, 64])
 def test_const_ion_eff_erfc_parity(api, oracle, n):
     """G = 1 variant: CONST-ION-EFF closed-form erfc, sharp-k filter, fix_mean."""

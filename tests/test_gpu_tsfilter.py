@@ -53,7 +53,8 @@ def _close(got, want, rtol=2e-5):
 
 
 @pytest.mark.parametrize("shape,box_len", [((24, 24, 24), 36.0), ((64, 64, 64), 96.0),
-                                           ((64, 64, 128), 96.0)])
+                                           ((64, 64, 128), 96.0), ((64, 64, 512), 96.0),
+                                           ((64, 64, 1024), 96.0)])
 @pytest.mark.parametrize("filter_type", [0, 1, 2])
 def test_fill_Rbox_matches_oracle(api, oracle, shape, box_len, filter_type):
     import torch
