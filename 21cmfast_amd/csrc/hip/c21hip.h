@@ -108,6 +108,10 @@ int c21hip_split_xblock_log2(int nx); /* 0: plain split layout */
 /* split-layout InitialConditions pipeline (ics_kernels.hip, plain layout only) */
 int c21hip_split_kop(const float *in_split, float *out_split, int nx, int ny, int nz,
                      double box_len, double box_len_z, int axis0, int axis1, void *stream);
+/* passes X, Y of the inverse transform of op(P), P = spectrum / k^2 (c21hip_split_kop with
+ * axis0 = -2): the gradient / second-derivative operator is applied inside pass X */
+int c21hip_split_sepop_xy(const float *split_src, float *split_work, int nx, int ny, int nz,
+                          double box_len, double box_len_z, int axis0, int axis1, void *stream);
 int c21hip_split_fold(const float *hi_split, float *lo_split, int nx, int ny, int nz, int f,
                       double box_len, double box_len_z, int axis0, int axis1, void *stream);
 int c21hip_lpt2_source(const float *const diag[3], const float *const off[3], float *out, size_t n,

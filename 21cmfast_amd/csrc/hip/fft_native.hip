@@ -580,6 +580,13 @@ struct LinePassArgs {
     const wtab_t *wt_nyq[2];   // [nx/2+1][ny/2+1]
     int dual;                  // FMODE 3: grid 1 uses window 1 (else both grids use window 0)
     FilterParams fp;           // the window of grid 0 (host side: table construction)
+    // FMODE 4 (pass X only): separable k-space operator applied on load,
+    //   v *= sign * k_x^ex * k_y^ey * k_z^ez  (times i when imag), k_a = index_to_k(i_a) in double:
+    // the gradient / second-derivative operators of the ICs on a spectrum pre-divided by k^2
+    // (InitialConditions.c:240-297).  Every factor is one-dimensional: a row scalar (k_x), a
+    // tile scalar (k_y) and a column scalar (k_z), so nothing is looked up.
+    int op_ex, op_ey, op_ez, op_imag;
+    double op_sign, op_dkx, op_dky, op_dkz;
 };
 
 static inline int geo_items(const LineGeo &g) {
@@ -617,7 +624,8 @@ struct LineItem {
     const wtab_t *wt0, *wt1;  // FMODE 3: window tables of this geometry
 };
 
-// FMODE: 0 no window, 3 window streamed from the per-radius tables
+// FMODE: 0 no window, 3 window streamed from the per-radius tables, 4 separable k-space
+// operator (pass X of the IC transforms)
 template <int N, int SIGN, int FMODE>
 __global__ void __launch_bounds__((LineThreads<N, FMODE>::value), (LineThreads<N, FMODE>::value / 256))
 line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
@@ -776,12 +784,54 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             for (int u = 0; u < NP; u++) wcur[u] = wpre[u];
             wcur_half = wpre_half;
         }
+        double op_c0 = 1., op_c1 = 1.;  // FMODE 4: sign * k_y^ey * k_z^ez of this thread's columns
+        if (FMODE == 4) {
+            const int c0 = it.ct * TZ + 2 * c4;
+            int kyi0, kyi1, kzi0, kzi1;
+            if (it.filter_axis == 0) {  // columns = k_z (< nz/2), outer = k_y
+                const int mi = it.npair == 2 ? (m & 1) : 0;
+                const int outer = mi == 0 ? it.og : it.n_outer - it.og;
+                kyi0 = kyi1 = (outer <= a.n_y / 2) ? outer : outer - a.n_y;
+                kzi0 = c0;
+                kzi1 = c0 + 1;
+            } else {  // Nyquist plane: columns = k_y, k_z = nz/2
+                kyi0 = (c0 <= a.n_y / 2) ? c0 : c0 - a.n_y;
+                kyi1 = (c0 + 1 <= a.n_y / 2) ? c0 + 1 : c0 + 1 - a.n_y;
+                kzi0 = kzi1 = a.n_z / 2;
+            }
+            const double ky0 = (double)kyi0 * a.op_dky, ky1 = (double)kyi1 * a.op_dky;
+            const double kz0 = (double)kzi0 * a.op_dkz, kz1 = (double)kzi1 * a.op_dkz;
+            const double fy0 = a.op_ey == 0 ? 1. : (a.op_ey == 1 ? ky0 : ky0 * ky0);
+            const double fy1 = a.op_ey == 0 ? 1. : (a.op_ey == 1 ? ky1 : ky1 * ky1);
+            const double fz0 = a.op_ez == 0 ? 1. : (a.op_ez == 1 ? kz0 : kz0 * kz0);
+            const double fz1 = a.op_ez == 0 ? 1. : (a.op_ez == 1 ? kz1 : kz1 * kz1);
+            op_c0 = a.op_sign * fy0 * fz0;
+            op_c1 = a.op_sign * fy1 * fz1;
+        }
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
             const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
             const bool half = (u & 1) && row_a == 0;  // row N/2 has its own |k_x|
             float4 v = reg[u];
+            if (FMODE == 4) {
+                const int kxi = (row <= N / 2) ? row : row - N;
+                const double kx = (double)kxi * a.op_dkx;
+                const double fr = a.op_ex == 0 ? 1. : (a.op_ex == 1 ? kx : kx * kx);
+                const double f0 = fr * op_c0, f1 = fr * op_c1;
+                if (a.op_imag) {  // times i f
+                    const float4 t = v;
+                    v.x = (float)(-(double)t.y * f0);
+                    v.y = (float)((double)t.x * f0);
+                    v.z = (float)(-(double)t.w * f1);
+                    v.w = (float)((double)t.z * f1);
+                } else {
+                    v.x = (float)((double)v.x * f0);
+                    v.y = (float)((double)v.y * f0);
+                    v.z = (float)((double)v.z * f1);
+                    v.w = (float)((double)v.w * f1);
+                }
+            }
             if (FMODE == 3) {
                 const float2 wv = half ? wcur_half : wcur[u >> 1];
                 v.x = __fmul_rn(v.x, wv.x);
@@ -1382,6 +1432,7 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
 template <int N, int SIGN>
 int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
     if (SIGN > 0 && fmode == 3) return launch_line_pass_mode<N, +1, 3>(a, stream);
+    if (SIGN > 0 && fmode == 4) return launch_line_pass_mode<N, +1, 4>(a, stream);
     return launch_line_pass_mode<N, SIGN, 0>(a, stream);
 }
 
@@ -1964,6 +2015,54 @@ extern "C" int c21hip_split_filter_shell(const float *src_a, float *work_a, int 
     const float rp[2] = {R_outer, R_outer};
     return filter_xy(src, work, n_grids, nx, ny, nz, box_len, box_len_z, ft, R_inner, rp, apply,
                      stream_, 7, 0, R_star);
+}
+
+// Passes X and Y of the inverse transform of op(P), P = spectrum / k^2 in the split layout:
+// (axis0, axis1 < 0) -> i k_axis0 P (gradient); (axis0, axis1) -> -k_axis0 k_axis1 P.  The
+// operator is applied inside pass X (FMODE 4).  InitialConditions.c:240-297.
+extern "C" int c21hip_split_sepop_xy(const float *split_src, float *split_work, int nx, int ny,
+                                     int nz, double box_len, double box_len_z, int axis0,
+                                     int axis1, void *stream_) {
+    if (!c21hip_native_fft_supported(nx, ny, nz)) {
+        c21hip_set_error("native FFT does not support %dx%dx%d", nx, ny, nz);
+        return C21CM_VALUE_ERROR;
+    }
+    if (axis0 < 0 || axis0 > 2 || axis1 > 2) return C21CM_VALUE_ERROR;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = nz / 2;
+    const long nlines = (long)nx * ny;
+    LinePassArgs a{};
+    a.fp.type = -1;
+    a.n_y = ny;
+    a.n_z = nz;
+    a.out_scale = 1.0f;
+    int e[3] = {0, 0, 0};
+    e[axis0]++;
+    if (axis1 >= 0) e[axis1]++;
+    a.op_ex = e[0];
+    a.op_ey = e[1];
+    a.op_ez = e[2];
+    a.op_imag = axis1 < 0;
+    a.op_sign = axis1 < 0 ? 1. : -1.;
+    a.op_dkx = 2.0 * M_PI / box_len;
+    a.op_dky = 2.0 * M_PI / box_len;
+    a.op_dkz = 2.0 * M_PI / box_len_z;
+    a.n_geo = 2;
+    a.n_grids = 1;
+    a.g0 = geo_x_main(ny, H, line_tile_cols(nx), split_xb_log2(nx));
+    a.g1 = geo_x_nyq(ny, line_tile_cols(nx));
+    const float2 *src = reinterpret_cast<const float2 *>(split_src);
+    float2 *work = reinterpret_cast<float2 *>(split_work);
+    geo_ptrs(a.g0, 0, src, work);
+    geo_ptrs(a.g1, 0, src + nlines * H, work + nlines * H);
+    int st = dispatch_line_pass<+1>(nx, a, 4, stream);
+    if (st) return st;
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
+    a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
+    a.g1_strided = 1;
+    geo_ptrs(a.g0, 0, work, work);
+    geo_ptrs(a.g1, 0, work + nlines * H, work + nlines * H);
+    return dispatch_line_pass<+1>(ny, a, 0, stream);
 }
 
 // The window tables of one radius for the two-grid sweep, into buffer `table_slot`, on

@@ -173,7 +173,7 @@ kspace_op_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int nx
 __device__ __forceinline__ void kop_factor(int n_x, int n_y, int n_z, int nx, int ny, int nz,
                                            double len_x, double len_y, double len_z, int axis0,
                                            int axis1, double *re, double *im) {
-    if (axis0 < 0) {  // identity (density)
+    if (axis0 == -1) {  // identity (density)
         *re = 1.;
         *im = 0.;
         return;
@@ -183,6 +183,9 @@ __device__ __forceinline__ void kop_factor(int n_x, int n_y, int n_z, int nx, in
     const double k_sq = kvec[0] * kvec[0] + kvec[1] * kvec[1] + kvec[2] * kvec[2];
     if (n_x == 0 && n_y == 0 && n_z == 0) {
         *re = 0.;
+        *im = 0.;
+    } else if (axis0 == -2) {  // 1 / k^2: the common factor of every operator below
+        *re = 1. / k_sq;
         *im = 0.;
     } else if (axis1 < 0) {  // i k_a / k^2
         *re = 0.;

@@ -70,7 +70,7 @@ enum {
     WS_IS_SAVED = 100, WS_IS_FILT, WS_IS_WORK, WS_IS_LO, WS_IS_LOWORK, WS_IS_BOX,
     WS_IS_D0 = 106, /* 107, 108 */
     WS_IS_O0 = 109, /* 110, 111 */
-    WS_IS_OUT = 112, WS_IS_IN = 113
+    WS_IS_OUT = 112, WS_IS_IN = 113, WS_IS_PK2 = 114
 };
 
 typedef struct {
@@ -78,6 +78,8 @@ typedef struct {
     int hi[3], lo[3], f;
     size_t ntot, sfl_hi, sfl_lo;
     float *saved, *filt, *work, *lo_k, *lo_work;
+    float *pk2;   /* spectrum / k^2 of `saved` (lazily built): operand of the fused operators */
+    int pk2_valid;
     void *stream;
 } is_ctx;
 
@@ -101,14 +103,22 @@ static int hi_field(is_ctx *c, const float *spec, int axis0, int axis1, float *t
     float *d_out = out_target(target, c->ntot, &is_host);
     if (!d_out) return C21CM_MEMORY_ALLOC_ERROR;
     const c21cm_ics_spec *s = c->s;
-    const float *src = spec;
     if (axis0 >= 0) {
-        TRY(c21hip_split_kop(spec, c->work, c->hi[0], c->hi[1], c->hi[2], s->box_len, s->box_len_z,
-                             axis0, axis1, c->stream));
-        src = c->work;
+        /* op(delta_k) = separable factor x (delta_k / k^2): the division once per spectrum, the
+         * rest inside pass X */
+        if (!c->pk2_valid) {
+            c->pk2 = (float *)c21hip_ws(WS_IS_PK2, c->sfl_hi * sizeof(float));
+            if (!c->pk2) return C21CM_MEMORY_ALLOC_ERROR;
+            TRY(c21hip_split_kop(spec, c->pk2, c->hi[0], c->hi[1], c->hi[2], s->box_len,
+                                 s->box_len_z, -2, -1, c->stream));
+            c->pk2_valid = 1;
+        }
+        TRY(c21hip_split_sepop_xy(c->pk2, c->work, c->hi[0], c->hi[1], c->hi[2], s->box_len,
+                                  s->box_len_z, axis0, axis1, c->stream));
+    } else {
+        TRY(c21hip_split_filter_xy(spec, c->work, c->hi[0], c->hi[1], c->hi[2], s->box_len,
+                                   s->box_len_z, 0, 0.f, 0.f, 0, c->stream));
     }
-    TRY(c21hip_split_filter_xy(src, c->work, c->hi[0], c->hi[1], c->hi[2], s->box_len,
-                               s->box_len_z, 0, 0.f, 0.f, 0, c->stream));
     TRY(c21hip_split_z_c2r_div(c->work, d_out, c->hi[2], c->hi[0], c->hi[1], c->hi[2], divisor,
                                c->stream));
     TRY(out_finish(target, d_out, c->ntot, is_host, c->stream));
@@ -245,6 +255,7 @@ static int ics_grids_split(const c21cm_ics_spec *s, InitialConditions *ics, floa
         }
         TRY(c21hip_split_r2c(box, c.hi[2], c.saved, c.hi[0], c.hi[1], c.hi[2], 1.0, 1., -1., 1.0f,
                              stream));
+        c.pk2_valid = 0; /* `saved` now holds the 2LPT source */
         if (need_filter && !hires)
             TRY(c21hip_copy_filter_split(c.saved, c.filt, c.hi[0], c.hi[1], c.hi[2], s->box_len,
                                          s->box_len_z, 0, R_lo, 0.f, 1, stream));
