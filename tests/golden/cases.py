@@ -109,3 +109,35 @@ def ics_perturb_outputs(new_ics_arrays, ics_grids, perturb_grids, hires_density)
     out = {f"ic_{k}": np.asarray(ic[k]) for k in IC_LOWRES}
     out.update({f"pt_{k}": np.asarray(v) for k, v in pt.items()})
     return out
+
+
+# ---- spin-temperature filter stage (SpinTemperatureBox.c:560-808) ------------------------------
+TS_N, TS_LEN = 24, 48.0
+TS_RADII = [1.0, 2.5, 5.0, 9.0]
+
+
+def tsfilter_inputs():
+    rng = np.random.default_rng(606)
+    x = np.arange(TS_N)[:, None, None] / TS_N
+    dens = (0.3 * rng.standard_normal((TS_N,) * 3) + 0.5 * np.sin(2 * np.pi * x)).astype(np.float32)
+    sfr = np.abs(rng.standard_normal((TS_N,) * 3)).astype(np.float32)
+    xray = (sfr * sfr).astype(np.float32)
+    return {"ts_density": dens, "ts_sfr": sfr, "ts_xray": xray}
+
+
+def tsfilter_outputs(fill_rbox, annular, inp):
+    """fill_rbox(spec, field) -> dict(result, min, average, max); annular(spec, [grids]) ->
+    dict(outputs, u_avg, f_avg): top-hat table of the density, one straight-line shell and one
+    multiple-scattering shell of (sfr, xray)."""
+    out = {}
+    r = fill_rbox(S.rbox_spec(TS_N, TS_LEN, TS_RADII, filter_type=0, min_value=-1.0,
+                              const_factor=0.2), inp["ts_density"])
+    out["rbox_result"] = np.asarray(r["result"])
+    out["rbox_stats"] = np.stack([r["min"], r["average"], r["max"]])
+    for name, types, r_star in (("sl", [4, 4], 0.0), ("ms", [5, 4], 6.0)):
+        a = annular(S.annular_spec(TS_N, TS_LEN, 4.0, 8.0, types, R_star=r_star),
+                    [inp["ts_sfr"], inp["ts_xray"]])
+        out[f"shell_{name}_sfr"] = np.asarray(a["outputs"][0])
+        out[f"shell_{name}_xray"] = np.asarray(a["outputs"][1])
+        out[f"shell_{name}_avgs"] = np.stack([a["u_avg"], a["f_avg"]])
+    return out

@@ -31,6 +31,9 @@ def main():
     hd = cases.ics_input()
     out = cases.ics_perturb_outputs(oracle.new_ics_arrays, oracle.ics_grids, oracle.perturb_grids, hd)
     np.savez_compressed(HERE / "ics_perturb.npz", hires_density=hd, **out)
+    ts_in = cases.tsfilter_inputs()
+    ts_out = cases.tsfilter_outputs(oracle.fill_Rbox_grids, oracle.annular_filter_grids, ts_in)
+    np.savez_compressed(HERE / "tsfilter.npz", **ts_in, **ts_out)
     for f in sorted(HERE.glob("*.npz")):
         print(f.name, f.stat().st_size, "bytes")
 

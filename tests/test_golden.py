@@ -58,3 +58,16 @@ def test_oracle_ics_perturb_match_golden(oracle):
     for k, v in out.items():
         scale = np.abs(gold[k]).max()
         np.testing.assert_allclose(v, gold[k], rtol=1e-6, atol=1e-6 * scale, err_msg=k)
+
+
+def test_oracle_tsfilter_matches_golden(oracle):
+    gold = np.load(GOLDEN / "tsfilter.npz")
+    inp = {k: gold[k] for k in ("ts_density", "ts_sfr", "ts_xray")}
+    out = cases.tsfilter_outputs(oracle.fill_Rbox_grids, oracle.annular_filter_grids, inp)
+    for k, v in out.items():
+        scale = np.abs(gold[k]).max()
+        np.testing.assert_allclose(v, gold[k], rtol=1e-6, atol=1e-6 * scale, err_msg=k)
+    # the multiple-scattering shell differs from the straight-line one, the x-ray grid (window 4
+    # in both) does not
+    assert not np.allclose(gold["shell_sl_sfr"], gold["shell_ms_sfr"], atol=1e-4)
+    np.testing.assert_array_equal(gold["shell_sl_xray"], gold["shell_ms_xray"])

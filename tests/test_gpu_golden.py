@@ -51,3 +51,12 @@ def test_hip_ics_perturb_match_golden(api):
     for k, v in out.items():
         scale = np.abs(gold[k]).max()
         np.testing.assert_allclose(v, gold[k], rtol=1e-4, atol=3e-5 * scale, err_msg=k)
+
+
+def test_hip_tsfilter_matches_golden(api):
+    gold = np.load(GOLDEN / "tsfilter.npz")
+    inp = {k: gold[k] for k in ("ts_density", "ts_sfr", "ts_xray")}
+    out = cases.tsfilter_outputs(api.fill_Rbox_grids, api.annular_filter_grids, inp)
+    for k, v in out.items():
+        scale = np.abs(gold[k]).max()
+        np.testing.assert_allclose(v, gold[k], rtol=1e-4, atol=2e-5 * scale, err_msg=k)
