@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--cpu-dim", type=int, default=192,
                     help="box size of the CPU-oracle sample (same radii count)")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="run the sharded code path (shard phase, RCCL reduce, finish phase) even "
+                         "with one rank: a smoke test of the multi-GPU plumbing, not a benchmark")
     return ap.parse_args()
 
 
@@ -149,6 +152,12 @@ def pmc_traffic():
 
 def main():
     args = parse_args()
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
+    # version banner through C stdio, flushed at exit, i.e. after anything Python printed), so
+    # file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to the
+    # saved descriptor at the very end.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,10 +168,17 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_shard
+    if sharded:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.force_shard and "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("21cmfast_amd")
     pkg.load(require_gpu=True)
@@ -178,13 +194,13 @@ def main():
     buffers = api.IonizeBuffers(density, need_nion=mode != W.FCOLL_STARS)
     D = importlib.import_module("21cmfast_amd.distributed")
     owner = D.owner_rank(spec.n_radii, world)
-    first_cross = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda") if world > 1 else None
+    first_cross = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda") if sharded else None
     last_report = {}
 
     def step():
-        if world == 1 or rank == owner:  # only the finishing rank owns output grids
+        if not sharded or rank == owner:  # only the finishing rank owns output grids
             buffers.reset()
-        if world == 1:
+        if not sharded:
             _, _, rep = api.ionize_grids(spec, density, n_ion, buffers=buffers)
             last_report["rep"] = rep
         else:
@@ -193,7 +209,7 @@ def main():
                 last_report["rep"] = rep
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -205,13 +221,24 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
     cells = float(n) ** 3
     value = cells / (ms_per_step * 1e-3)
+
+    # the finishing rank holds the result: hand its global x_HI to rank 0 for the JSON line
+    global_xh = None
+    if sharded:
+        rep_o = last_report.get("rep")
+        gx = torch.tensor([rep_o.global_xH if rep_o is not None else 0.0], device="cuda",
+                          dtype=torch.float64)
+        dist.broadcast(gx, src=owner)
+        global_xh = gx.item()
+    elif last_report.get("rep") is not None:
+        global_xh = last_report["rep"].global_xH
 
     out = None
     if rank == 0:
@@ -244,7 +271,7 @@ def main():
         loop = {"alg_bytes": alg_loop,
                 "definition": "R loop of one step, (20G+8)*N algorithmic bytes per radius"
                               + (" for indices > 0, 29N for the index-0 sweep" if r0_direct else "")}
-        if world == 1 and rep is not None and rep.ms_rloop > 0:
+        if not sharded and rep is not None and rep.ms_rloop > 0:
             loop.update({"ms": rep.ms_rloop, "ms_preloop": rep.ms_preloop,
                          "ms_postloop": rep.ms_postloop,
                          "GBs": alg_loop / (rep.ms_rloop * 1e-3) / 1e9})
@@ -265,9 +292,9 @@ def main():
                             f"steps, G={G} ({'delta tophat + n_ion exp-MFP' if G == 2 else 'delta sharp-k, erfc f_coll'}), "
                             "first snapshot, device-resident inputs",
                 "hii_dim": n, "n_radii": spec.n_radii, "filtered_grids": G,
-                "parallelism": "single GPU" if world == 1 else f"R-loop sharded x{world} + RCCL uint8 max-reduce",
+                "parallelism": "single GPU" if not sharded else f"R-loop sharded x{world} + RCCL uint8 max-reduce",
                 "fft": "native" if native else "rocfft",
-                "global_xH": None if rep is None else rep.global_xH,
+                "global_xH": global_xh,
             },
             "roofline": roof,
         }
@@ -276,10 +303,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, W)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

@@ -330,3 +330,28 @@ def test_full_size_properties(api):
     buf2, _, rep2 = api.ionize_grids(spec, density, n_ion * 1.5)
     assert bool(((buf2.neutral_fraction == 0) | (x1 != 0)).all())
     assert rep2.global_xH < g1
+
+
+def test_bench_sharded_plumbing_on_one_rank():
+    """bench.py --force-shard: the multi-GPU code path (shard phase without report, RCCL
+    max-reduce of the uint8 mask, finish phase, x_HI broadcast) on a one-rank RCCL group; the
+    result must equal the single-GPU path's."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    base = [sys.executable, str(root / "bench.py"), "--hii-dim", "128", "--steps", "2", "--warmup",
+            "1", "--no-cpu-baseline", "--no-kernel-roofline"]
+    outs = []
+    for extra in ([], ["--force-shard"]):
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = p.stdout.strip().splitlines()
+        assert len(lines) == 1, p.stdout[-2000:]  # exactly one JSON line, no library banners
+        outs.append(json.loads(lines[0]))
+    single, shard = outs
+    assert "sharded" in shard["config"]["parallelism"] and single["config"]["parallelism"] == "single GPU"
+    assert shard["config"]["global_xH"] == single["config"]["global_xH"]
+    assert 0.05 < single["config"]["global_xH"] < 0.95
