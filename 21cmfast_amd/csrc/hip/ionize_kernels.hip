@@ -122,6 +122,20 @@ __device__ __forceinline__ float partially_ionized_T(float T_HI, float res_xH, f
     return (float)((double)__fmul_rn(T_HI, res_xH) + (double)T_re * (1. - (double)res_xH));
 }
 
+// x^a for x > 0 to float accuracy (~3e-7 relative for |a| <= 3.4; the result is stored as float
+// anyway): x = m 2^e, log2 x = e + log2(m) with the hardware log2 on m in [0.5, 1) (absolute error
+// ~1e-7, kept small by taking the exponent out first), the product split into integer and
+// fraction, hardware exp2.  A libm fp64 pow costs ~200 instructions per call and made the final
+// sweep ALU-bound (85 % of the cells of the benchmark box take one).
+__device__ __forceinline__ float pow_f32acc(double x, double a) {
+    if (!(x > 0.) || !(x < 1e300)) return (float)pow(x, a);
+    int e;
+    const double m = frexp(x, &e);
+    const double t = a * ((double)e + (double)__builtin_amdgcn_logf((float)m));
+    const double n = floor(t);
+    return ldexpf(__builtin_amdgcn_exp2f((float)(t - n)), (int)n);
+}
+
 // reference: thermochem.c:31-56.  pow_Tre = pow(T_re, 1.7) and pow_z = pow(1e4*((1+z)/4), 1.7)
 // do not depend on the cell and are passed in (same double values the reference computes).
 __device__ float fully_ionized_T(float z_re, float z, float delta, double pow_Tre, double pow_z) {
@@ -132,14 +146,14 @@ __device__ float fully_ionized_T(float z_re, float z, float delta, double pow_Tr
         delta_re = (float)((double)delta * (1. + (double)z) / (1. + (double)z_re));
         if (delta_re <= -1.f) delta_re = (float)(-1. + kMinDensityLowLimit);
         if (delta <= -1.f) delta = (float)(-1. + kMinDensityLowLimit);
-        result = (float)pow((1. + (double)delta) / (1. + (double)delta_re), 1.1333);
-        result = (float)((double)result * pow((1. + (double)z) / (1. + (double)z_re), 3.4));
-        result = __fmul_rn(result, expf((float)(pow((1. + (double)z) / 7.1, 2.5) -
-                                                pow((1. + (double)z_re) / 7.1, 2.5))));
+        result = pow_f32acc((1. + (double)delta) / (1. + (double)delta_re), 1.1333);
+        result = (float)((double)result * (double)pow_f32acc((1. + (double)z) / (1. + (double)z_re), 3.4));
+        result = __fmul_rn(result, expf((float)((double)pow_f32acc((1. + (double)z) / 7.1, 2.5) -
+                                                (double)pow_f32acc((1. + (double)z_re) / 7.1, 2.5))));
     }
     result = (float)((double)result * pow_Tre);
     result = (float)((double)result + pow_z * (double)(1.f + delta));
-    result = (float)pow((double)result, 0.5882);
+    result = pow_f32acc((double)result, 0.5882);
     return result;
 }
 
