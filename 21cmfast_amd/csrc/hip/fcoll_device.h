@@ -57,6 +57,15 @@ __device__ __forceinline__ double fgtrm_bias_fast_inv(float del_bias, double inv
     return (double)erfcc_f((float)x);
 }
 
+// exp(u) to float accuracy (2e-7 relative): 2^n * exp2(frac) with the hardware exp2; results
+// that are stored as float do not need the ~40 fp64 instructions of the library routine.
+__device__ __forceinline__ double exp_f32acc(double u) {
+    const double w = u * 1.4426950408889634;  // log2(e)
+    const double n = floor(w);
+    if (!(n > -160.) || !(n < 1000.)) return exp(u);  // underflow / overflow / NaN: exact path
+    return (double)ldexpf(__builtin_amdgcn_exp2f((float)(w - n)), (int)n);
+}
+
 // reference: interpolation.c:123-131
 __device__ __forceinline__ double eval_table_f(double x, double x_min, double x_width,
                                                const float *y_arr) {

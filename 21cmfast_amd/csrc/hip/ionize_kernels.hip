@@ -283,7 +283,7 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
                 } else if (fp.mode == C21CM_FCOLL_TABLE_LINEAR) {
                     f = eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab);
                 } else {
-                    f = exp(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
+                    f = exp_f32acc(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
                 }
                 out.v[e] = (float)f;  // box->unnormalised_nion is float (IonisationBox.c:951)
                 acc += f;
