@@ -186,9 +186,11 @@ int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3], const 
 int c21hip_halobox_scatter(const float *src_density, const int dens_dim[3],
                            const float *const vel[3], const float *const vel2[3],
                            const int vel_dim[3], double *out_nion, double *out_sfr,
-                           const int out_dim[3], double box_len, double box_len_z, double growth,
-                           double init_growth, int lpt2, const float *tables_dev, double tab_min,
-                           double tab_width, double pref_nion, double pref_sfr, void *stream);
+                           double *out_xray /* NULL: two values */, const int out_dim[3],
+                           double box_len, double box_len_z, double growth, double init_growth,
+                           int lpt2, const float *tables_dev /* [2 or 3][NDELTA] */,
+                           double tab_min, double tab_width, double pref_nion, double pref_sfr,
+                           double pref_xray, void *stream);
 int c21hip_narrow(const double *in, float *out, float *out_scaled, double scale, size_t n,
                   void *stream);
 /* {min, max} of n floats into out2 (device); partials: 2 * 2048 doubles */

@@ -132,14 +132,15 @@ struct CicTileParams {
     int nb[3];       // bricks per axis
     int td[3];       // tile extent in output cells (incl. halo and the +1 CIC neighbour)
     int halo;
-    // NV == 2 (ComputeHaloBox, map_mass.c:214-344): per-cell values from two ln-tables of
-    // delta = density * growth; table_dev = [2][C21CM_NDELTA_TABLE] floats (ln N_ion, ln SFRD)
-    double growth, tab_min, tab_width, pref[2];
+    // NV >= 2 (ComputeHaloBox, map_mass.c:214-344): per-cell values from NV ln-tables of
+    // delta = density * growth; table_dev = [NV][C21CM_NDELTA_TABLE] floats (ln N_ion, ln SFRD
+    // and, with USE_TS_FLUCT, ln X-ray emissivity)
+    double growth, tab_min, tab_width, pref[3];
 };
 
 // NV = 1: the deposited value is the particle mass 1 + delta * D_init (PerturbedField).
-// NV = 2: two values per source cell, exp(lerp(table, delta * D)) * prefactor (HaloBox n_ion and
-// halo_sfr), accumulated in two tiles / two output grids.
+// NV = 2, 3: that many values per source cell, exp(lerp(table_v, delta * D)) * prefactor_v
+// (HaloBox n_ion, halo_sfr and halo_xray), accumulated in NV tiles / NV output grids.
 template <int NV>
 __global__ void __launch_bounds__(kBlock)
 cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
@@ -147,14 +148,15 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
                          const float *__restrict__ vz, const float *__restrict__ v2x,
                          const float *__restrict__ v2y, const float *__restrict__ v2z,
                          const float *__restrict__ table_dev, double *__restrict__ out,
-                         double *__restrict__ out_b) {
+                         double *__restrict__ out_b, double *__restrict__ out_c) {
     extern __shared__ double tile[];
     const CicParams &p = q.c;
     const int tcells = q.td[0] * q.td[1] * q.td[2];
-    float *tab = reinterpret_cast<float *>(tile + NV * tcells);  // NV == 2: [2][NDELTA]
-    if (NV == 2) {
-        for (int t = threadIdx.x; t < 2 * C21CM_NDELTA_TABLE; t += kBlock) tab[t] = table_dev[t];
+    float *tab = reinterpret_cast<float *>(tile + NV * tcells);  // NV >= 2: [NV][NDELTA]
+    if (NV >= 2) {
+        for (int t = threadIdx.x; t < NV * C21CM_NDELTA_TABLE; t += kBlock) tab[t] = table_dev[t];
     }
+    double *const outs[3] = {out, out_b, out_c};
     const size_t sy = (size_t)p.out_dim[2], sx = (size_t)p.out_dim[1] * p.out_dim[2];
     const int n_bricks = q.nb[0] * q.nb[1] * q.nb[2];
     const int per_brick = q.sb[0] * q.sb[1] * q.sb[2];
@@ -212,9 +214,10 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
                 val[0] = 1.0 + (double)dens[t] * p.init_growth;
             } else {
                 const double curr_dens = (double)dens[t] * q.growth;  // map_mass.c:283
-                val[0] = exp(eval_table_f(curr_dens, q.tab_min, q.tab_width, tab)) * q.pref[0];
-                val[NV - 1] = exp(eval_table_f(curr_dens, q.tab_min, q.tab_width,
-                                               tab + C21CM_NDELTA_TABLE)) * q.pref[NV - 1];
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+                    val[v] = exp(eval_table_f(curr_dens, q.tab_min, q.tab_width,
+                                              tab + v * C21CM_NDELTA_TABLE)) * q.pref[v];
             }
             const double wx[2] = {w0[0], w1[0]}, wy[2] = {w0[1], w1[1]}, wz[2] = {w0[2], w1[2]};
             if (inside) {
@@ -248,23 +251,30 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
 #pragma unroll
                         for (int a = 0; a < 2; a++) {
                             const double w = wx[a] * wy[b] * wz[c];
-                            unsafeAtomicAdd(out + bx[a] + by[b] + bz[c], val[0] * w);
-                            if (NV == 2) unsafeAtomicAdd(out_b + bx[a] + by[b] + bz[c], val[NV - 1] * w);
+#pragma unroll
+                            for (int v = 0; v < NV; v++)
+                                unsafeAtomicAdd(outs[v] + bx[a] + by[b] + bz[c], val[v] * w);
                         }
             }
         }
         __syncthreads();
         for (int c = threadIdx.x; c < tcells; c += kBlock) {
-            const double v0 = tile[c], v1 = (NV == 2) ? tile[tcells + c] : 0.;
-            if (v0 != 0. || v1 != 0.) {
+            double tv[NV];
+            bool any = false;
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                tv[v] = tile[v * tcells + c];
+                any = any || tv[v] != 0.;
+            }
+            if (any) {
                 const int c2 = c % q.td[2];
                 const int c1 = (c / q.td[2]) % q.td[1];
                 const int c0 = c / (q.td[1] * q.td[2]);
                 const size_t o = (size_t)wrap_idx(t0[0] + c0, p.out_dim[0]) * sx +
                                  (size_t)wrap_idx(t0[1] + c1, p.out_dim[1]) * sy +
                                  (size_t)wrap_idx(t0[2] + c2, p.out_dim[2]);
-                unsafeAtomicAdd(out + o, v0);
-                if (NV == 2) unsafeAtomicAdd(out_b + o, v1);
+#pragma unroll
+                for (int v = 0; v < NV; v++) unsafeAtomicAdd(outs[v] + o, tv[v]);
             }
         }
         __syncthreads();
@@ -460,9 +470,9 @@ bool tile_setup(const CicParams &p, int nv, CicTileParams &q, size_t *lds, int *
         tcells *= (size_t)q.td[a];
         n_bricks *= q.nb[a];
     }
-    *lds = tcells * sizeof(double) * nv + (nv == 2 ? 2 * C21CM_NDELTA_TABLE * sizeof(float) : 0);
+    *lds = tcells * sizeof(double) * nv + (nv >= 2 ? nv * C21CM_NDELTA_TABLE * sizeof(float) : 0);
     *blocks = (int)(n_bricks < 256 * 8 ? n_bricks : 256 * 8);
-    return *lds <= 96 * 1024;
+    return *lds <= (nv == 3 ? 144 : 96) * 1024;  // three tiles need 108 KB of the CU's 160 KB
 }
 
 void fill_cic_params(CicParams &p, const int dens_dim[3], const int vel_dim[3], const int out_dim[3],
@@ -484,21 +494,23 @@ void fill_cic_params(CicParams &p, const int dens_dim[3], const int vel_dim[3], 
 }
 }  // namespace
 
-// ComputeHaloBox deposit (map_mass.c:214-344): two values per source cell from the two
-// ln-tables, CIC-deposited at the displaced positions into two double grids.
+// ComputeHaloBox deposit (map_mass.c:214-344): two or three values per source cell from the
+// ln-tables (out_xray != NULL: three), CIC-deposited at the displaced positions into double grids.
 extern "C" int c21hip_halobox_scatter(const float *src_density, const int dens_dim[3],
                                       const float *const vel[3], const float *const vel2[3],
                                       const int vel_dim[3], double *out_nion, double *out_sfr,
-                                      const int out_dim[3], double box_len, double box_len_z,
-                                      double growth, double init_growth, int lpt2,
+                                      double *out_xray, const int out_dim[3], double box_len,
+                                      double box_len_z, double growth, double init_growth, int lpt2,
                                       const float *tables_dev, double tab_min, double tab_width,
-                                      double pref_nion, double pref_sfr, void *stream) {
+                                      double pref_nion, double pref_sfr, double pref_xray,
+                                      void *stream) {
     CicParams p;
     fill_cic_params(p, dens_dim, vel_dim, out_dim, box_len, box_len_z, growth, init_growth, lpt2);
     CicTileParams q;
     size_t lds;
     int blocks;
-    if (!tile_setup(p, 2, q, &lds, &blocks)) {
+    const int nv = out_xray ? 3 : 2;
+    if (!tile_setup(p, nv, q, &lds, &blocks)) {
         c21hip_set_error("halobox deposit: tile of %zu bytes does not fit the LDS", lds);
         return C21CM_VALUE_ERROR;
     }
@@ -507,16 +519,26 @@ extern "C" int c21hip_halobox_scatter(const float *src_density, const int dens_d
     q.tab_width = tab_width;
     q.pref[0] = pref_nion;
     q.pref[1] = pref_sfr;
+    q.pref[2] = pref_xray;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)cic_scatter_tiled_kernel<2>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void *)cic_scatter_tiled_kernel<3>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(cic_scatter_tiled_kernel<2>, dim3(blocks), dim3(kBlock), lds,
-                       (hipStream_t)stream, q, src_density, vel[0], vel[1], vel[2],
-                       lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr, lpt2 ? vel2[2] : nullptr,
-                       tables_dev, out_nion, out_sfr);
+    if (nv == 3)
+        hipLaunchKernelGGL(cic_scatter_tiled_kernel<3>, dim3(blocks), dim3(kBlock), lds,
+                           (hipStream_t)stream, q, src_density, vel[0], vel[1], vel[2],
+                           lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr,
+                           lpt2 ? vel2[2] : nullptr, tables_dev, out_nion, out_sfr, out_xray);
+    else
+        hipLaunchKernelGGL(cic_scatter_tiled_kernel<2>, dim3(blocks), dim3(kBlock), lds,
+                           (hipStream_t)stream, q, src_density, vel[0], vel[1], vel[2],
+                           lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr,
+                           lpt2 ? vel2[2] : nullptr, tables_dev, out_nion, out_sfr,
+                           (double *)nullptr);
     LAUNCH_CHECK();
     return 0;
 }
@@ -545,7 +567,7 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
                                    (hipStream_t)stream, q, hires_density, vel[0], vel[1], vel[2],
                                    lpt2 ? vel2[0] : nullptr, lpt2 ? vel2[1] : nullptr,
                                    lpt2 ? vel2[2] : nullptr, (const float *)nullptr, out,
-                                   (double *)nullptr);
+                                   (double *)nullptr, (double *)nullptr);
                 LAUNCH_CHECK();
                 return 0;
             }

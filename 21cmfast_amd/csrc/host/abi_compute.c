@@ -454,7 +454,8 @@ int UpdateXraySourceBox(HaloBox *halobox, double R_inner, double R_outer, int R_
 }
 
 /* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436.  Only the
- * integrated branch without mini-halos, X-ray sources or the extra fields. */
+ * integrated branch without mini-halos or the extra fields; with USE_TS_FLUCT the
+ * X-ray emissivity grid halo_xray is filled as well (the input of UpdateXraySourceBox). */
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
                    TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids) {
     (void)halos;
@@ -472,7 +473,6 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
     if (mo->USE_INTERPOLATION_TABLES != C21CM_INTERP_HMF)
         unsupported = "L-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation";
     if (ao->USE_MINI_HALOS) unsupported = "USE_MINI_HALOS";
-    if (ao->USE_TS_FLUCT) unsupported = "USE_TS_FLUCT (X-ray source grid)";
     if (ao->HALO_SCALING_RELATIONS_MEDIAN) unsupported = "HALO_SCALING_RELATIONS_MEDIAN";
     if (ao->INTEGRATION_METHOD_ATOMIC > 1) unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
@@ -536,12 +536,25 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
     s.tab_width = (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.);
     s.ln_nion_table = tab_nion;
     s.ln_sfrd_table = tab_sfrd;
+    if (ao->USE_TS_FLUCT) { /* HaloBox.c:411-414, interp_tables.c:497-560 */
+        static float tab_xray[C21CM_NDELTA_TABLE];
+        if (!grids->halo_xray) {
+            c21hip_set_error("ComputeHaloBox: USE_TS_FLUCT needs HaloBox.halo_xray");
+            return C21CM_VALUE_ERROR;
+        }
+        if ((st = c21_Xray_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
+                                             sigma_cell, min_density, max_density, sc.mturn_a_nofb,
+                                             &sc, method, tab_xray, C21CM_NDELTA_TABLE)))
+            return st;
+        s.ln_xray_table = tab_xray;
+    }
     /* map_mass.c:223-239 */
     const double vol_ratio_out = (double)n_out / (double)n_src;
     const double prefactor_stars = c21_rhocrit() * cosmo_params_global->OMb * sc.fstar_10 * vol_ratio_out;
     s.prefactor_sfr = prefactor_stars / sc.t_star / sc.t_h;
     s.prefactor_nion = prefactor_stars * sc.fesc_10 * sc.pop2_ion;
     s.prefactor_wsfr = 1 / sc.t_h / sc.t_star;
+    s.prefactor_xray = c21_rhocrit() * cosmo_params_global->OMm * vol_ratio_out;
     /* get_log10_turnovers without mini-halos (HaloBox.c:467-470) */
     grids->log10_Mcrit_ACG_ave = log10(sc.mturn_a_nofb);
     grids->log10_Mcrit_MCG_ave = log10(0.);
@@ -551,5 +564,6 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
     }
     HaloBox g = *grids;
     if (ao->RECOMB_MODEL == C21CM_RECOMB_NONE) g.whalo_sfr = NULL; /* map_mass.c:342 */
+    if (!ao->USE_TS_FLUCT) g.halo_xray = NULL;
     return c21cm_halobox_grids(&s, ini_boxes, &g, NULL);
 }

@@ -641,31 +641,115 @@ double c21_Nion_ConditionalM(double growthf, double lnM1, double lnM2, double ln
  * not depend on delta (sigma, d sigma^2/dM, n_ion(M), the barrier expansion) is evaluated once per
  * node, which leaves one exp per (node, delta): the values equal c21_Nion_ConditionalM's to
  * rounding (1e-15). */
+#define S_PER_YR 31556925.9747 /* Constants.c:16 */
+/* per-mass weights of the two table families */
+typedef double (*mass_weight_fn)(double lnM, double Mturn, const c21_scaling_consts *sc);
+
+static double nion_weight(double lnM, double Mturn, const c21_scaling_consts *sc) {
+    const double Fstar = log_pl_limit(lnM, log(sc->fstar_10), sc->alpha_star, 10 * M_LN10, log(sc->Mlim_Fstar));
+    const double Fesc = log_pl_limit(lnM, log(sc->fesc_10), sc->alpha_esc, 10 * M_LN10, log(sc->Mlim_Fesc));
+    return exp(Fstar + Fesc - Mturn / exp(lnM) + lnM);
+}
+
+/* scaling_relations.c:446-467 (Eqs. 14, 15 of arXiv:2504.17254) */
+static double halo_metallicity(double sfr, double stellar, double redshift) {
+    const double redshift_scaling = pow(10, -0.056 * redshift + 0.064);
+    double stellar_term = 1.;
+    if (stellar > 0 && sfr > 0.) {
+        const double M0 = 1.28825e10 * pow(sfr * S_PER_YR, 0.56);
+        stellar_term = pow(1 + pow(stellar / M0, -2.1), -0.148);
+    }
+    return 1.23 * stellar_term * redshift_scaling;
+}
+
+/* scaling_relations.c:236-240,277-283,315-325 */
+static double lx_on_sfr(double metallicity, double lx_constant) {
+    if (!astro_options_global->USE_UPPER_STELLAR_TURNOVER) return lx_constant;
+    const double hi_z_index = -0.64, lo_z_index = 0., z_pivot = 0.05;
+    return lx_constant * 1. /
+           (pow(metallicity / z_pivot, -lo_z_index) + pow(metallicity / z_pivot, -hi_z_index));
+}
+
+/* hmf.c:482-509 with USE_MINI_HALOS off */
+double c21_xray_fraction(double lnM, double Mturn, const c21_scaling_consts *sc) {
+    const double M = exp(lnM);
+    const double ln_norm = log(sc->fstar_10);
+    const double Fstar =
+        exp(log_pl_limit(lnM, ln_norm, sc->alpha_star, 10 * M_LN10, log(sc->Mlim_Fstar)) - Mturn / M + ln_norm);
+    const double stars = M * Fstar * cosmo_params_global->OMb / cosmo_params_global->OMm;
+    const double sfr = stars / (sc->t_star * sc->t_h);
+    const double metallicity = halo_metallicity(sfr, stars, sc->redshift);
+    return S_PER_YR * (sfr * lx_on_sfr(metallicity, sc->l_x));
+}
+
+static int conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                             double sigma_cond, double dmin, double dmax, double Mturn,
+                             const c21_scaling_consts *sc, int method, double ln_floor,
+                             mass_weight_fn weight, float *table, int n_delta);
+
 int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
                                double sigma_cond, double dmin, double dmax, double Mturn,
                                const c21_scaling_consts *sc, int method, double ln_floor,
                                float *table, int n_delta) {
+    return conditional_table(growthf, lnMmin, lnMmax, lnMcond, sigma_cond, dmin, dmax, Mturn, sc,
+                             method, ln_floor, nion_weight, table, n_delta);
+}
+
+int c21_Xray_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                               double sigma_cond, double dmin, double dmax, double Mturn,
+                               const c21_scaling_consts *sc, int method, float *table,
+                               int n_delta) {
+    return conditional_table(growthf, lnMmin, lnMmax, lnMcond, sigma_cond, dmin, dmax, Mturn, sc,
+                             method, -50., c21_xray_fraction, table, n_delta);
+}
+
+/* One weight integrated against the conditional mass function for one overdensity
+ * (hmf.c:1106-1140 / 1142-1177 for weights other than n_ion) */
+struct wcmf_ctx {
+    mass_weight_fn weight;
+    const c21_scaling_consts *sc;
+    double Mturn, growthf, delta, sigma_cond;
+    int hmf;
+};
+static double wcmf_integrand(double lnM, void *ctx) {
+    const struct wcmf_ctx *c = (const struct wcmf_ctx *)ctx;
+    return c->weight(lnM, c->Mturn, c->sc) *
+           conditional_mf(c->growthf, lnM, c->delta, c->sigma_cond, c->hmf);
+}
+static double weighted_ConditionalM(mass_weight_fn weight, double growthf, double lnM1, double lnM2,
+                                    double lnM_cond, double sigma2, double delta2, double Mturn,
+                                    const c21_scaling_consts *sc, int method) {
+    struct wcmf_ctx c = {weight, sc, Mturn, growthf, delta2, sigma2, matter_options_global->HMF};
+    if (lnM1 >= lnM_cond) return 0.;
+    if (delta2 > MAX_DELTAC_FRAC * get_delta_crit(c.hmf, sigma2, growthf)) {
+        if (lnM_cond * (1 - FRACT_FLOAT_ERR) <= lnM2) return weight(lnM_cond, Mturn, sc) / exp(lnM_cond);
+        return 0.;
+    }
+    if (c.hmf != C21CM_HMF_PS && c.hmf != C21CM_HMF_ST) c.hmf = C21CM_HMF_PS;
+    if (method == 1) {
+        initialise_GL(lnM1, lnM2);
+        double integral = 0;
+        for (int i = 1; i < NGL_INT + 1; i++) integral += gl.w[i] * wcmf_integrand(gl.x[i], &c);
+        return integral;
+    }
+    return c21_integrate(wcmf_integrand, &c, lnM1, lnM2, 1e-4);
+}
+
+static int conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                             double sigma_cond, double dmin, double dmax, double Mturn,
+                             const c21_scaling_consts *sc, int method, double ln_floor,
+                             mass_weight_fn weight, float *table, int n_delta) {
     int hmf = matter_options_global->HMF;
     const int fast = (method == 1) && lnMmin < lnMcond;
     double node_pref[NGL_INT + 1], node_factor[NGL_INT + 1], node_barrier[NGL_INT + 1],
         node_sdi[NGL_INT + 1];
     if (hmf != C21CM_HMF_PS && hmf != C21CM_HMF_ST) hmf = C21CM_HMF_PS;
     if (fast) {
-        struct mf_ctx m;
-        memset(&m, 0, sizeof(m));
-        m.ln_fstar_norm = log(sc->fstar_10);
-        m.alpha_star = sc->alpha_star;
-        m.ln_Mlim_star = log(sc->Mlim_Fstar);
-        m.ln_fesc_norm = log(sc->fesc_10);
-        m.alpha_esc = sc->alpha_esc;
-        m.ln_Mlim_esc = log(sc->Mlim_Fesc);
         initialise_GL(lnMmin, lnMmax);
         for (int i = 1; i < NGL_INT + 1; i++) {
             const double lnM = gl.x[i], M = exp(lnM);
             const double sigma1 = c21_sigma_fast(M), dsigmasqdm = dsigmasqdm_fast(M);
-            const double Fstar = log_pl_limit(lnM, m.ln_fstar_norm, m.alpha_star, 10 * M_LN10, m.ln_Mlim_star);
-            const double Fesc = log_pl_limit(lnM, m.ln_fesc_norm, m.alpha_esc, 10 * M_LN10, m.ln_Mlim_esc);
-            const double nion = exp(Fstar + Fesc - Mturn / exp(lnM) + lnM);
+            const double nion = weight(lnM, Mturn, sc);
             if (sigma1 < sigma_cond) { /* conditional_mf returns 0 */
                 node_pref[i] = 0.;
                 node_factor[i] = node_barrier[i] = node_sdi[i] = 0.;
@@ -686,8 +770,8 @@ int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, dou
         const double delta = dmin + (float)k / ((float)n_delta - 1.) * (dmax - dmin);
         double v;
         if (!fast || delta > MAX_DELTAC_FRAC * get_delta_crit(hmf, sigma_cond, growthf)) {
-            v = c21_Nion_ConditionalM(growthf, lnMmin, lnMmax, lnMcond, sigma_cond, delta, Mturn, sc,
-                                      method);
+            v = weighted_ConditionalM(weight, growthf, lnMmin, lnMmax, lnMcond, sigma_cond, delta,
+                                      Mturn, sc, method);
         } else {
             double integral = 0;
             for (int i = 1; i < NGL_INT + 1; i++) {
@@ -765,6 +849,8 @@ int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc) {
     sc->pop3_ion = ap->POP3_ION;
     sc->acg_thresh = c21_TtoM((float)redshift, 1e4, 0.59); /* thermochem.c:277 */
     sc->mturn_a_nofb = ap->M_TURN;
+    sc->l_x = ap->L_X * 1e-38; /* scaling_relations.c:63 */
+    sc->redshift = redshift;
     sc->Mlim_Fstar = mass_limit_bisection(1e5, 1e16, sc->alpha_star, sc->fstar_10, &status);
     sc->Mlim_Fesc = mass_limit_bisection(1e5, 1e16, sc->alpha_esc, sc->fesc_10, &status);
     return status;

@@ -16,6 +16,8 @@ typedef struct c21_scaling_consts {
     double pop2_ion, pop3_ion;
     double acg_thresh, mturn_a_nofb;
     double Mlim_Fstar, Mlim_Fesc;
+    double l_x;      /* L_X * 1e-38 (scaling_relations.c:63) */
+    double redshift; /* the halo metallicity relation depends on it */
 } c21_scaling_consts;
 
 /* exported with the reference's names (bound by py21cmfast's cfuncs layer) */
@@ -52,6 +54,15 @@ int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, dou
                                double sigma_cond, double dmin, double dmax, double Mturn,
                                const c21_scaling_consts *sc, int method, double ln_floor,
                                float *table, int n_delta);
+/* ln of the X-ray emissivity integral over the conditional mass function (ACG only; hmf.c:482-509,
+ * 1142-1177 and interp_tables.c:497-560, floor -50): the same quadrature as the N_ion table with
+ * the per-mass weight  s_per_yr * SFR(M) * L_X/SFR(Z(SFR, M_*, z)) */
+int c21_Xray_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                               double sigma_cond, double dmin, double dmax, double Mturn,
+                               const c21_scaling_consts *sc, int method, float *table,
+                               int n_delta);
+/* the weight itself, per unit ln M (hmf.c:482-509 without mini-halos) */
+double c21_xray_fraction(double lnM, double Mturn, const c21_scaling_consts *sc);
 int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc);
 double c21_minimum_source_mass(double redshift);
 int c21_recfast_load(void);

@@ -17,6 +17,8 @@ enum {
     WS_HB_IN0 = 24,  /* .. +6 staged IC arrays (WS_PT_IN0 ..) */
     WS_HB_OUT0 = 32, /* .. +2 staged outputs */
     WS_HB_ACC1 = 35,
+    WS_HB_ACC2 = 87,
+    WS_HB_OUT3 = 88,
     WS_HB_TABLES = 38,
     WS_HB_PART = 39
 };
@@ -91,34 +93,43 @@ int c21cm_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *ic
         if (s->lpt2) vel2[a] = hb_in(WS_HB_IN0 + 4 + a, vel2_h[a], n_src * sizeof(float), stream, &status);
     }
     if (status) return status;
+    const int xray = s->ln_xray_table && grids->halo_xray;
     double *acc0 = (double *)c21hip_ws(WS_HB_ACC0, n_out * sizeof(double));
     double *acc1 = (double *)c21hip_ws(WS_HB_ACC1, n_out * sizeof(double));
-    float *tables = (float *)c21hip_ws(WS_HB_TABLES, 2 * C21CM_NDELTA_TABLE * sizeof(float));
-    if (!acc0 || !acc1 || !tables) return C21CM_MEMORY_ALLOC_ERROR;
+    double *acc2 = xray ? (double *)c21hip_ws(WS_HB_ACC2, n_out * sizeof(double)) : NULL;
+    float *tables = (float *)c21hip_ws(WS_HB_TABLES, 3 * C21CM_NDELTA_TABLE * sizeof(float));
+    if (!acc0 || !acc1 || !tables || (xray && !acc2)) return C21CM_MEMORY_ALLOC_ERROR;
     TRY(c21hip_memset(acc0, 0, n_out * sizeof(double), stream));
     TRY(c21hip_memset(acc1, 0, n_out * sizeof(double), stream));
+    if (xray) {
+        TRY(c21hip_memset(acc2, 0, n_out * sizeof(double), stream));
+        TRY(c21hip_h2d(tables + 2 * C21CM_NDELTA_TABLE, s->ln_xray_table,
+                       C21CM_NDELTA_TABLE * sizeof(float), stream));
+    }
     TRY(c21hip_h2d(tables, s->ln_nion_table, C21CM_NDELTA_TABLE * sizeof(float), stream));
     TRY(c21hip_h2d(tables + C21CM_NDELTA_TABLE, s->ln_sfrd_table,
                    C21CM_NDELTA_TABLE * sizeof(float), stream));
-    TRY(c21hip_halobox_scatter(dens, src_dim, vel, vel2, src_dim, acc0, acc1, out_dim, s->box_len,
-                               s->box_len_z, s->growth_factor, s->init_growth_factor, s->lpt2,
-                               tables, s->tab_min, s->tab_width, s->prefactor_nion,
-                               s->prefactor_sfr, stream));
+    TRY(c21hip_halobox_scatter(dens, src_dim, vel, vel2, src_dim, acc0, acc1, acc2, out_dim,
+                               s->box_len, s->box_len_z, s->growth_factor, s->init_growth_factor,
+                               s->lpt2, tables, s->tab_min, s->tab_width, s->prefactor_nion,
+                               s->prefactor_sfr, s->prefactor_xray, stream));
     /* narrow into the caller's float grids (staged when they are host arrays) */
     {
-        float *targets[3] = {grids->n_ion, grids->whalo_sfr, grids->halo_sfr};
-        float *dev[3] = {NULL, NULL, NULL};
-        for (int t = 0; t < 3; t++) {
+        float *targets[4] = {grids->n_ion, grids->whalo_sfr, grids->halo_sfr,
+                             xray ? grids->halo_xray : NULL};
+        float *dev[4] = {NULL, NULL, NULL, NULL};
+        for (int t = 0; t < 4; t++) {
             if (!targets[t]) continue;
             dev[t] = c21hip_is_device_ptr(targets[t])
                          ? targets[t]
-                         : (float *)c21hip_ws(WS_HB_OUT0 + t, n_out * sizeof(float));
+                         : (float *)c21hip_ws(t < 3 ? WS_HB_OUT0 + t : WS_HB_OUT3, n_out * sizeof(float));
             if (!dev[t]) return C21CM_MEMORY_ALLOC_ERROR;
         }
         /* whalo_sfr = n_ion / t_h / t_star (map_mass.c:340-346) */
         TRY(c21hip_narrow(acc0, dev[0], dev[1], s->prefactor_wsfr, n_out, stream));
         TRY(c21hip_narrow(acc1, dev[2], NULL, 0., n_out, stream));
-        for (int t = 0; t < 3; t++)
+        if (xray) TRY(c21hip_narrow(acc2, dev[3], NULL, 0., n_out, stream));
+        for (int t = 0; t < 4; t++)
             if (targets[t] && dev[t] != targets[t])
                 TRY(c21hip_d2h(targets[t], dev[t], n_out * sizeof(float), stream));
     }

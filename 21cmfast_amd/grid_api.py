@@ -252,7 +252,8 @@ def brightness_grids(spec: S.BrightnessSpec, density, neutral_fraction, spin_tem
     return out
 
 
-def halobox_grids(spec: S.HaloBoxSpec, ics: dict, with_whalo=False, stream=None) -> dict:
+def halobox_grids(spec: S.HaloBoxSpec, ics: dict, with_whalo=False, with_xray=False,
+                  stream=None) -> dict:
     """ComputeHaloBox's integrated branch on the MI355X (reference: src/py21cmfast/src/HaloBox.c:
     302-436, map_mass.c:214-344).  Outputs live where the source density lives.
     Returns dict(n_ion, halo_sfr[, whalo_sfr])."""
@@ -269,6 +270,8 @@ def halobox_grids(spec: S.HaloBoxSpec, ics: dict, with_whalo=False, stream=None)
     out = {"n_ion": new(), "halo_sfr": new()}
     if with_whalo:
         out["whalo_sfr"] = new()
+    if with_xray:  # needs spec.ln_xray_table (USE_TS_FLUCT: the X-ray emissivity grid)
+        out["halo_xray"] = new()
     hb = S.HaloBoxStruct(**{k: _fptr(v) for k, v in out.items()})
     icss = ics_struct(ics)
     check(load().c21cm_halobox_grids(C.byref(spec), C.byref(icss), C.byref(hb), _stream(stream)),

@@ -264,6 +264,7 @@ class HaloBoxSpec(_Base):
         ("ln_nion_table", c_float_p), ("ln_sfrd_table", c_float_p),
         ("prefactor_nion", C.c_double), ("prefactor_sfr", C.c_double),
         ("prefactor_wsfr", C.c_double),
+        ("ln_xray_table", c_float_p), ("prefactor_xray", C.c_double),
     ]
 
 

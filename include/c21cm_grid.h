@@ -217,6 +217,10 @@ typedef struct c21cm_halobox_spec {
     const float *ln_sfrd_table; /* host, C21CM_NDELTA_TABLE floats */
     double prefactor_nion, prefactor_sfr; /* map_mass.c:228-239 */
     double prefactor_wsfr;                /* 1 / t_h / t_star, used when whalo_sfr != NULL (:340-346) */
+    /* X-ray emissivity grid (USE_TS_FLUCT; HaloBox.c:279-283, map_mass.c:231,316-319): filled
+     * when both the table and HaloBox.halo_xray are given */
+    const float *ln_xray_table; /* host, C21CM_NDELTA_TABLE floats, or NULL */
+    double prefactor_xray;      /* rho_crit Omega_m x volume ratio */
 } c21cm_halobox_spec;
 
 int c21cm_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions *ics,

@@ -217,12 +217,15 @@ def ics_grids(spec, ics: dict | None = None):
     return ics
 
 
-def halobox_grids(spec, ics: dict, with_whalo=False):
-    """Oracle ComputeHaloBox integrated branch; returns dict(n_ion, halo_sfr[, whalo_sfr])."""
+def halobox_grids(spec, ics: dict, with_whalo=False, with_xray=False):
+    """Oracle ComputeHaloBox integrated branch; returns dict(n_ion, halo_sfr[, whalo_sfr,
+    halo_xray])."""
     lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
     out = {"n_ion": np.zeros(lo, np.float32), "halo_sfr": np.zeros(lo, np.float32)}
     if with_whalo:
         out["whalo_sfr"] = np.zeros(lo, np.float32)
+    if with_xray:
+        out["halo_xray"] = np.zeros(lo, np.float32)
     hb = S.HaloBoxStruct(**{k: fptr(v) for k, v in out.items()})
     st = load().oracle_halobox_grids(C.byref(spec), C.byref(ics_struct(ics)), C.byref(hb))
     if st:

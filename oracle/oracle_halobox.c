@@ -67,6 +67,9 @@ int oracle_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *i
         grids->n_ion[i] = 0.f;
         grids->halo_sfr[i] = 0.f;
     }
+    const int xray = s->ln_xray_table && grids->halo_xray; /* USE_TS_FLUCT, HaloBox.c:279-283 */
+    if (xray)
+        for (size_t i = 0; i < n_out; i++) grids->halo_xray[i] = 0.f;
     const double box_size[3] = {s->box_len, s->box_len, s->box_len_z};
     const double dim_ratio_out = (double)out_dim[0] / (double)dens_dim[0];
     const double D = s->growth_factor, Di = s->init_growth_factor;
@@ -93,6 +96,11 @@ int oracle_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *i
                 const double sfrd = exp(table_1d_f(curr_dens, s->tab_min, s->tab_width, s->ln_sfrd_table));
                 cic_float(grids->halo_sfr, pos, out_dim, sfrd * s->prefactor_sfr);
                 cic_float(grids->n_ion, pos, out_dim, nion * s->prefactor_nion);
+                if (xray) { /* map_mass.c:316-319 */
+                    const double lx =
+                        exp(table_1d_f(curr_dens, s->tab_min, s->tab_width, s->ln_xray_table));
+                    cic_float(grids->halo_xray, pos, out_dim, lx * s->prefactor_xray);
+                }
             }
         }
     }

@@ -9,7 +9,7 @@ import importlib
 import numpy as np
 import pytest
 
-from test_oracle_halobox import halobox_spec, make_tables, random_ics
+from test_oracle_halobox import halobox_spec, make_tables, random_ics, with_xray
 
 pytestmark = pytest.mark.gpu
 S = importlib.import_module("21cmfast_amd.structs")
@@ -43,6 +43,67 @@ def test_halobox_matches_oracle(api, oracle, n, N, hires, vscale, device):
         ics = {k: torch.from_numpy(v).cuda() for k, v in ics.items()}
     got = api.halobox_grids(spec, ics, with_whalo=True)
     compare(got, ref)
+
+
+@pytest.mark.parametrize("n,N,hires,vscale,device", [(16, 32, False, 1.0, False),
+                                                     (32, 64, True, 6.0, True),
+                                                     (40, 40, False, 25.0, True)])
+def test_halobox_with_xray_matches_oracle(api, oracle, n, N, hires, vscale, device):
+    """Three values per Lagrangian cell (n_ion, SFR, X-ray emissivity): the NV = 3 deposit."""
+    tables = make_tables()
+    spec = with_xray(halobox_spec(n, N, hires, tables), tables)
+    ics = random_ics(n, N, hires, seed=3 * n + N, vscale=vscale)
+    ref = oracle.halobox_grids(spec, ics, with_whalo=True, with_xray=True)
+    if device:
+        import torch
+
+        ics = {k: torch.from_numpy(v).cuda() for k, v in ics.items()}
+    got = api.halobox_grids(spec, ics, with_whalo=True, with_xray=True)
+    compare(got, ref)
+    assert ref["halo_xray"].max() > 0
+
+
+def test_halobox_to_xray_source_box_chain(gpu_lib, oracle, tmp_path):
+    """USE_TS_FLUCT: ComputeHaloBox fills halo_sfr and halo_xray from the initial conditions and
+    UpdateXraySourceBox filters them into one shell of the XraySourceBox -- both through the
+    reference's entry points; checked against the oracle's annular filter of the same grids."""
+    from test_gpu_abi import Session, fptr
+
+    lib = gpu_lib
+    n, N = 64, 128
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=N, SOURCE_MODEL=2, USE_TS_FLUCT=True, N_STEP_TS=3)
+    z = 9.0
+    ics = random_ics(n, N, False, seed=21)
+    ics["lowres_density"] = (ics["lowres_density"] * 0.4).astype(np.float32)
+    out = {k: np.zeros((n, n, n), np.float32) for k in ("n_ion", "halo_sfr", "halo_xray")}
+    hb = S.HaloBoxStruct(**{k: fptr(v) for k, v in out.items()})
+    icss = S.InitialConditionsStruct(**{k: fptr(v) for k, v in ics.items()})
+    lib.ComputeHaloBox.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
+    assert lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb)) == 0, \
+        lib.c21cm_last_error()
+    assert out["halo_xray"].min() >= 0 and out["halo_xray"].max() > 0
+    # L_X per SFR is bounded by L_X (the metallicity factor is <= 1): xray <= sfr * L_X * s_per_yr,
+    # up to the differing deposit weights of neighbouring cells
+    ratio = out["halo_xray"].sum(dtype=np.float64) / out["halo_sfr"].sum(dtype=np.float64)
+    assert 0 < ratio <= ses.ap.L_X * 1e-38 * 31556925.9747 * 1.0001
+    # without halo_xray the call is refused
+    hb_bad = S.HaloBoxStruct(n_ion=fptr(out["n_ion"]), halo_sfr=fptr(out["halo_sfr"]))
+    assert lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb_bad)) == 3
+    # one shell of the source box
+    ntot = n**3
+    fs, fx = np.zeros(3 * ntot, np.float32), np.zeros(3 * ntot, np.float32)
+    mean_sfr = np.zeros(3, np.float64)
+    xb = S.XraySourceBoxStruct(filtered_sfr=fptr(fs), filtered_xray=fptr(fx),
+                               mean_sfr=mean_sfr.ctypes.data_as(C.POINTER(C.c_double)))
+    assert lib.UpdateXraySourceBox(C.byref(hb), 3.0, 6.0, 1, 0.0, C.byref(xb)) == 0, \
+        lib.c21cm_last_error()
+    want = oracle.annular_filter_grids(S.annular_spec(n, ses.so.BOX_LEN, 3.0, 6.0, [4, 4]),
+                                       [out["halo_sfr"], out["halo_xray"]])
+    for got, ref in ((fs, want["outputs"][0]), (fx, want["outputs"][1])):
+        g = got[ntot:2 * ntot].reshape(n, n, n)
+        np.testing.assert_allclose(g, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    assert mean_sfr[1] == pytest.approx(want["f_avg"][0], rel=1e-5)
 
 
 def test_grid_minmax(api):

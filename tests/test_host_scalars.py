@@ -170,7 +170,7 @@ class ScalingConsts(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("fstar_10", "alpha_star", "fstar_7", "t_h", "t_star", "fesc_10", "alpha_esc",
                  "fesc_7", "pop2_ion", "pop3_ion", "acg_thresh", "mturn_a_nofb", "Mlim_Fstar",
-                 "Mlim_Fesc")]
+                 "Mlim_Fesc", "l_x", "redshift")]
 
 
 def _bind_conditional(lib):
@@ -180,6 +180,11 @@ def _bind_conditional(lib):
     lib.c21_Nion_Conditional_table.restype = C.c_int
     lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int, f64,
                                                            C.POINTER(C.c_float), C.c_int]
+    lib.c21_Xray_Conditional_table.restype = C.c_int
+    lib.c21_Xray_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int,
+                                                           C.POINTER(C.c_float), C.c_int]
+    lib.c21_xray_fraction.restype = f64
+    lib.c21_xray_fraction.argtypes = [f64, f64, C.POINTER(ScalingConsts)]
     lib.c21_set_scaling_constants.restype = C.c_int
     lib.c21_set_scaling_constants.argtypes = [f64, C.POINTER(ScalingConsts)]
 
@@ -271,6 +276,76 @@ def test_conditional_nion_against_scipy(host, pkg):
                                             s_c, float(delta), Mturn, C.byref(sc), 1)
         assert tab[k] == pytest.approx(max(math.log(direct), -40.0), rel=2e-6, abs=2e-6)
     assert np.all(np.diff(np.array(tab[:300])) > 0)  # more collapse in denser regions (delta < 0.85)
+
+
+def test_conditional_xray_against_scipy(host, pkg):
+    """The X-ray emissivity table of the HaloBox (hmf.c:482-509, interp_tables.c:497-560): the
+    per-mass weight s_per_yr * SFR * L_X/SFR(Z) restated here (metallicity relation of
+    arXiv:2504.17254 Eqs. 14-15, double power law in Z with USE_UPPER_STELLAR_TURNOVER) and
+    integrated against the Sheth-Tormen conditional mass function by scipy."""
+    _bind_conditional(host)
+    sc = ScalingConsts()
+    z = 8.0
+    assert host.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    assert sc.redshift == z and sc.l_x == pytest.approx(host._keep["ap"].L_X * 1e-38)
+    D = host.dicke(z)
+    Mmin, Mcond, Mturn = 10**8.7 / 50, host.c21_RtoM(4.0), 10**8.7
+    s_c = host.c21_sigma_fast(Mcond)
+    a, b, c = 0.73, 0.34, 0.81
+    cp = host._keep["cp"]
+    s_per_yr = 31556925.9747
+    upper = bool(host._keep["ao"].USE_UPPER_STELLAR_TURNOVER)
+
+    def weight(lnM):
+        M = math.exp(lnM)
+        ln_norm = math.log(sc.fstar_10)
+        if (sc.alpha_star > 0 and lnM > math.log(sc.Mlim_Fstar)) or \
+                (sc.alpha_star < 0 and lnM < math.log(sc.Mlim_Fstar)):
+            pl = -ln_norm
+        else:
+            pl = sc.alpha_star * (lnM - 10 * math.log(10))
+        fstar = math.exp(pl - Mturn / M + ln_norm)
+        stars = M * fstar * cp.OMb / cp.OMm
+        sfr = stars / (sc.t_star * sc.t_h)
+        zs = 10 ** (-0.056 * z + 0.064)
+        term = 1.0
+        if stars > 0 and sfr > 0:
+            M0 = 1.28825e10 * (sfr * s_per_yr) ** 0.56
+            term = (1 + (stars / M0) ** -2.1) ** -0.148
+        Z = 1.23 * term * zs
+        lx = sc.l_x / (1.0 + (Z / 0.05) ** 0.64) if upper else sc.l_x
+        return s_per_yr * sfr * lx
+
+    for lnM in (math.log(3e8), math.log(1e10), math.log(5e11)):
+        assert host.c21_xray_fraction(lnM, Mturn, C.byref(sc)) == pytest.approx(weight(lnM), rel=1e-12)
+
+    def cmf(lnM, delta):
+        M = math.exp(lnM)
+        s1, ds = host.c21_sigma_fast(M), host.dsigmasqdm_z0(M)
+        if s1 < s_c:
+            return 0.0
+        diff = s1 * s1 - s_c * s_c
+        dl = 1.686 / D
+        term, terms = 1.0, [1.0]
+        for i in range(1, 6):
+            term = term * (-diff) / i * (c - i + 1) / (s1 * s1)
+            terms.append(term)
+        series = sum(reversed(terms))
+        p2 = b * (a * dl * dl / (s1 * s1)) ** (-c)
+        factor = math.sqrt(a) * dl * (1 + p2 * series) - delta / D
+        barrier = math.sqrt(a) * dl * (1 + p2)
+        return (-ds * factor * diff**-1.5 * math.exp(-((barrier - delta / D) ** 2) * 0.5 / diff)
+                / math.sqrt(2 * math.pi))
+
+    tab = (C.c_float * 400)()
+    assert host.c21_Xray_Conditional_table(D, math.log(Mmin), math.log(Mcond), math.log(Mcond), s_c,
+                                           -0.8, 1.4, Mturn, C.byref(sc), 1, tab, 400) == 0
+    for k in (0, 101, 250, 399):
+        delta = float(-0.8 + np.float32(k) / (np.float32(400) - 1.0) * 2.2)
+        want, _ = integrate.quad(lambda x: weight(x) * cmf(x, delta), math.log(Mmin),
+                                 math.log(Mcond), limit=400, epsrel=1e-8)
+        assert tab[k] == pytest.approx(max(math.log(want), -50.0), abs=3e-3), k
+    assert np.all(np.diff(np.array(tab[:300])) > 0)
 
 
 # ---- multiple-scattering window helpers (host-side exports of the drop-in library) -----------

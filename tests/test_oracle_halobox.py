@@ -20,6 +20,21 @@ def make_tables(tab_min=-0.9, tab_max=1.6):
     return tab_min, (tab_max - tab_min) / (S.NDELTA_TABLE - 1.0), ln_nion, ln_sfrd
 
 
+def xray_table(tables):
+    """A third ln-table (X-ray emissivity) on the grid of make_tables()."""
+    tab_min, tab_width = tables[0], tables[1]
+    x = tab_min + tab_width * np.arange(S.NDELTA_TABLE)
+    return (-2.0 + 4.1 * x - 0.6 * x * x).astype(np.float32)
+
+
+def with_xray(spec, tables, prefactor=4.4e3):
+    ln_xray = xray_table(tables)
+    spec.ln_xray_table = ln_xray.ctypes.data_as(S.c_float_p)
+    spec.prefactor_xray = prefactor
+    spec._keep = tuple(spec._keep) + (ln_xray,)
+    return spec
+
+
 def halobox_spec(n, N, hires, tables, lpt2=1, **kw):
     tab_min, tab_width, ln_nion, ln_sfrd = tables
     spec = S.HaloBoxSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=1.5 * n, box_len_z=1.5 * n,
@@ -85,3 +100,31 @@ def test_totals_are_conserved(oracle, hires):
     assert out["n_ion"].astype(np.float64).sum() == pytest.approx(nion.sum(), rel=2e-5)
     assert out["halo_sfr"].astype(np.float64).sum() == pytest.approx(sfr.sum(), rel=2e-5)
     assert out["n_ion"].min() >= 0
+
+
+def test_xray_grid_follows_its_own_table(oracle):
+    """USE_TS_FLUCT: the third value per Lagrangian cell, exp(lerp(ln-xray table)) * prefactor,
+    deposited like the other two (HaloBox.c:279-283, map_mass.c:316-319)."""
+    n = 12
+    tables = make_tables()
+    spec = with_xray(halobox_spec(n, 2 * n, False, tables), tables)
+    ics = random_ics(n, 2 * n, False, seed=4)
+    for k in list(ics):
+        if "_v" in k:
+            ics[k][...] = 0
+    out = oracle.halobox_grids(spec, ics, with_xray=True)
+    x = ics["lowres_density"].astype(np.float64) * spec.growth_factor
+    tab_min, tab_width = tables[0], tables[1]
+    idx = np.floor((x - tab_min) / tab_width).astype(int)
+    t = (x - (tab_min + tab_width * idx.astype(np.float32).astype(np.float64))) / tab_width
+    y = xray_table(tables)
+    want = np.exp(y[idx].astype(np.float64) * (1 - t) + y[idx + 1].astype(np.float64) * t) * 4.4e3
+    np.testing.assert_allclose(out["halo_xray"], want, rtol=2e-6)
+    # the other grids do not change when the X-ray grid is requested
+    base = oracle.halobox_grids(halobox_spec(n, 2 * n, False, tables), ics)
+    np.testing.assert_array_equal(out["n_ion"], base["n_ion"])
+    np.testing.assert_array_equal(out["halo_sfr"], base["halo_sfr"])
+    # displaced: totals conserved
+    ics2 = random_ics(n, 2 * n, False, seed=4)
+    moved = oracle.halobox_grids(spec, ics2, with_xray=True)
+    assert moved["halo_xray"].sum(dtype=np.float64) == pytest.approx(want.sum(), rel=1e-5)
