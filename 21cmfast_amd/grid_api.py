@@ -90,8 +90,9 @@ class IonizeBuffers:
         self.unnormalised_nion = _new_like(density, 0.0) if need_nion else None
 
     def reset(self):
+        """Back to the state of a freshly allocated IonizedBox.  z_reion needs no reset: every
+        ComputeIonizedBox path overwrites it (IonisationBox.c:1372-1378 fills it with -1)."""
         self.neutral_fraction[...] = 1.0
-        self.z_reion[...] = 0.0
         if self.kinetic_temperature is not None:
             self.kinetic_temperature[...] = 0.0
 
