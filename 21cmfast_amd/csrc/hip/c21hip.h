@@ -135,6 +135,18 @@ int c21hip_z_ionise_partials(int nx, int ny, int nz);
 int c21hip_batched_means(const double *partials, long stride, int n_partials, int first, int step,
                          int count, double ntot, int mass_dep_zeta, double f_limit, double *sums,
                          double *means, void *stream);
+/* fused pass Z with the filtered x_e spectrum as a third grid (spin-temperature runs; the
+ * barrier becomes f_coll zeta > 1 - x_e, IonisationBox.c:1118); 512/1024-point z-lines */
+int c21hip_split_z_ionise_stars_xe(const float *delta_work, const float *stars_work,
+                                   const float *xe_work, unsigned char *first_cross,
+                                   double *partials, double *sum_out, int nx, int ny, int nz,
+                                   int r_index, double rhocrit_omb, double ion_eff,
+                                   int mass_dep_zeta, double f_limit, void *stream);
+int c21hip_z_ionise_xe_supported(int nx, int ny, int nz);
+/* passes X, Y of one grid with window a of the two-grid tables in buffer table_slot */
+int c21hip_split_filter_xy_shared(const float *src, float *work, int filter_type, int nx, int ny,
+                                  int nz, double box_len, double box_len_z, float R, int apply,
+                                  int table_slot, void *stream);
 /* time `reps` launches of one pass with HIP events on `stream` (bench.py roofline leg);
  * kind: 0 pass X and 1 pass Y as the excursion-set loop launches them (two grids, windows
  * filter_a / filter_b streamed from the per-radius tables), 2 fused pass Z, 3 plain pass Z,
@@ -294,12 +306,14 @@ int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
 /* mask of radii > 0 + radius index 0 + post-loop sweep of the fused Lagrangian path in one pass
  * (IonisationBox.c:1031-1256,1597-1608); partials: 2 * 2048 doubles; writes every z_reion.
  * stars_direct = 1: stars_fil is the dense emissivity input (clipped on load) instead of its
- * padded, window-less transform round trip. */
+ * padded, window-less transform round trip.  a->use_ts_fluct (stars_direct only): xe_dense and
+ * kinetic_temp_neutral are the dense x_e / T_k inputs of the spin-temperature run. */
 int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
                        const unsigned char *first_cross, const float *stars_fil,
                        const float *density, const float *prev_z_reion, float *xH, float *z_reion,
                        float *kinetic_temperature, double *partials, double *sum_stars_out,
-                       double *sum_xh_out, int *flag_out, int stars_direct, void *stream);
+                       double *sum_xh_out, int *flag_out, int stars_direct, const float *xe_dense,
+                       const float *kinetic_temp_neutral, void *stream);
 /* delta_T (and tau_21) per cell + their sum (BrightnessTemperatureBox.c:58-87); partials: 2048 */
 int c21hip_brightness_temp(const float *density, const float *xH, const float *Ts, float *bt,
                            float *tau, size_t n, float const_factor, float T_rad, double redshift,

@@ -1220,6 +1220,7 @@ z_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
 struct ZFusedArgs {
     const float2 *d_main, *d_nyq;  // filtered density spectrum after passes X, Y
     const float2 *s_main, *s_nyq;  // filtered emissivity spectrum
+    const float2 *x_main, *x_nyq;  // filtered x_e spectrum (USE_TS_FLUCT; wave-level kernel only)
     unsigned char *first_cross;    // [lines][NZ]
     double *partials;              // one per workgroup (nx*ny/LZ_FUSED)
     double rhocrit_omb, ion_eff, f_limit;
@@ -1532,7 +1533,9 @@ __device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, co
 }
 
 // Fused pass Z + f_coll sum + barrier, wave-level transform (A = 16 or 32, see wave_c2r).
-template <int A>
+// TS: a third grid, the filtered x_e of the spin-temperature run, enters the barrier as
+// f_coll zeta > 1 - x_e (IonisationBox.c:1118, clip of :1091-1094).
+template <int A, bool TS>
 __global__ void __launch_bounds__(kBlock)
 zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                  const float2 *__restrict__ twN_global) {
@@ -1574,8 +1577,18 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     }
     wave_fence();
     wave_c2r<A>(xs, sh, L, twH, twN, b);
+    float2 xx[TS ? A : 1];
+    if constexpr (TS) {
+        const float2 *xm = a.x_main + line * H;
+#pragma unroll
+        for (int q = 0; q < A; q++) xx[q] = xm[16 * q + b];
+        const float xh = a.x_nyq[lline].x;
+        wave_fence();
+        wave_c2r<A>(xx, xh, L, twH, twN, b);
+    }
 
-    const bool floor_ionises = a.mass_dep_zeta && (a.f_limit * a.ion_eff > 1.);
+    const double floor_lhs = a.f_limit * a.ion_eff;  // the floored f_coll zeta
+    const bool floor_ionises = !TS && a.mass_dep_zeta && (floor_lhs > 1.);
     const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
     double acc = 0.;
 #pragma unroll
@@ -1585,10 +1598,19 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         const float s0 = fmaxf(xs[q].x, 0.f), s1 = fmaxf(xs[q].y, 0.f);
         acc += (double)s0;
         acc += (double)s1;
-        const double D0 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].x, dmin));
-        const double D1 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].y, dmin));
-        const bool i0 = floor_ionises || ((double)s0 * a.ion_eff > D0);
-        const bool i1 = floor_ionises || ((double)s1 * a.ion_eff > D1);
+        double D0 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].x, dmin));
+        double D1 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].y, dmin));
+        bool f0 = false, f1 = false;
+        if constexpr (TS) {  // f zeta > 1 - x_e with f = max(s / D, f_limit): both sides times D > 0
+            const double n0 = 1. - (double)fminf(fmaxf(xx[q].x, 0.f), 0.999f);
+            const double n1 = 1. - (double)fminf(fmaxf(xx[q].y, 0.f), 0.999f);
+            f0 = a.mass_dep_zeta && floor_lhs > n0;
+            f1 = a.mass_dep_zeta && floor_lhs > n1;
+            D0 *= n0;
+            D1 *= n1;
+        }
+        const bool i0 = floor_ionises || f0 || ((double)s0 * a.ion_eff > D0);
+        const bool i1 = floor_ionises || f1 || ((double)s1 * a.ion_eff > D1);
         uchar2 m = (A == 16) ? old[q % 16] : reinterpret_cast<const uchar2 *>(mrow)[j];
         if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
         if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
@@ -1738,14 +1760,22 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
         const float2 *twN = twiddles(nz);
         if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
         *n_partials = (int)(nlines / ZW_LINES);
-        if (nz == 512)
-            hipLaunchKernelGGL(zw_ionise_kernel<16>, dim3((unsigned)(nlines / ZW_LINES)),
-                               dim3(kBlock), 0, stream, a, twH, twN);
+        const dim3 grid((unsigned)(nlines / ZW_LINES));
+        if (a.x_main) {
+            if (nz == 512)
+                hipLaunchKernelGGL((zw_ionise_kernel<16, true>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+            else
+                hipLaunchKernelGGL((zw_ionise_kernel<32, true>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+        } else if (nz == 512)
+            hipLaunchKernelGGL((zw_ionise_kernel<16, false>), grid, dim3(kBlock), 0, stream, a, twH, twN);
         else
-            hipLaunchKernelGGL(zw_ionise_kernel<32>, dim3((unsigned)(nlines / ZW_LINES)),
-                               dim3(kBlock), 0, stream, a, twH, twN);
+            hipLaunchKernelGGL((zw_ionise_kernel<32, false>), grid, dim3(kBlock), 0, stream, a, twH, twN);
         LAUNCH_CHECK();
         return 0;
+    }
+    if (a.x_main) {
+        c21hip_set_error("fused pass Z with an x_e grid needs 512- or 1024-point z-lines");
+        return C21CM_VALUE_ERROR;
     }
     switch (nz) {
         case 64: return launch_z_fused<64>(a, nlines, stream);
@@ -2270,6 +2300,19 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
                                            double *sum_out, int nx, int ny, int nz, int r_index,
                                            double rhocrit_omb, double ion_eff, int mass_dep_zeta,
                                            double f_limit, void *stream) {
+    return c21hip_split_z_ionise_stars_xe(delta_work, stars_work, NULL, first_cross, partials,
+                                          sum_out, nx, ny, nz, r_index, rhocrit_omb, ion_eff,
+                                          mass_dep_zeta, f_limit, stream);
+}
+
+// The same with the filtered x_e spectrum of a spin-temperature run as a third grid
+// (xe_work == NULL: two grids).  512- and 1024-point z-lines only.
+extern "C" int c21hip_split_z_ionise_stars_xe(const float *delta_work, const float *stars_work,
+                                              const float *xe_work, unsigned char *first_cross,
+                                              double *partials, double *sum_out, int nx, int ny,
+                                              int nz, int r_index, double rhocrit_omb,
+                                              double ion_eff, int mass_dep_zeta, double f_limit,
+                                              void *stream) {
     const long nlines = (long)nx * ny;
     ZFusedArgs a{};
     a.ny = ny;
@@ -2278,6 +2321,10 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
     a.d_nyq = a.d_main + nlines * (nz / 2);
     a.s_main = reinterpret_cast<const float2 *>(stars_work);
     a.s_nyq = a.s_main + nlines * (nz / 2);
+    if (xe_work) {
+        a.x_main = reinterpret_cast<const float2 *>(xe_work);
+        a.x_nyq = a.x_main + nlines * (nz / 2);
+    }
     a.first_cross = first_cross;
     a.partials = partials;
     a.rhocrit_omb = rhocrit_omb;
@@ -2290,6 +2337,26 @@ extern "C" int c21hip_split_z_ionise_stars(const float *delta_work, const float 
     if (st) return st;
     if (!sum_out) return 0;  // deferred: the caller reduces the partials of all radii at once
     return c21hip_reduce_sum(partials, n_partials, sum_out, stream);
+}
+
+// 1: the fused pass Z can take an x_e grid at this z-line length
+extern "C" int c21hip_z_ionise_xe_supported(int nx, int ny, int nz) {
+    return (nz == 512 || nz == 1024) && zw_enabled() && ((long)nx * ny) % ZW_LINES == 0;
+}
+
+// Passes X, Y of ONE grid with window a of the tables built for a two-grid radius
+// (c21hip_window_tables / c21hip_split_filter_xy2, buffer `table_slot`): the x_e grid of a
+// spin-temperature run shares the density grid's HII_FILTER window.
+extern "C" int c21hip_split_filter_xy_shared(const float *src, float *work, int filter_type,
+                                             int nx, int ny, int nz, double box_len,
+                                             double box_len_z, float R, int apply, int table_slot,
+                                             void *stream_) {
+    const float *srcs[2] = {src, nullptr};
+    float *works[2] = {work, nullptr};
+    const int ft[2] = {filter_type, 0};
+    const float rp[2] = {0.f, 0.f};
+    return filter_xy(srcs, works, 1, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_, 6,
+                     table_slot);
 }
 
 // workgroup partials the fused pass Z writes for an nx x ny x nz grid

@@ -503,10 +503,14 @@ template <int VEC, bool DIRECT>
 __global__ void __launch_bounds__(kBlock)
 final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restrict__ first_cross,
                    const float *__restrict__ stars_fil, const float *__restrict__ density,
-                   const float *__restrict__ prev_z_reion, float *__restrict__ xH,
+                   const float *__restrict__ prev_z_reion, const float *__restrict__ xe_dense,
+                   const float *__restrict__ Tneutral, float *__restrict__ xH,
                    float *__restrict__ z_reion, float *__restrict__ Tk,
                    double *__restrict__ partials_stars, double *__restrict__ partials_xh,
                    int *__restrict__ flag) {
+    // a.use_ts_fluct (DIRECT only): the x_e input (clipped like its filtered grid, :1504-1507
+    // and :1091-1094) enters the barrier and the partial ionisation, the neutral-gas
+    // temperature replaces the adiabatic one
     constexpr int U = 2;  // items per thread and trip, loads issued before any arithmetic
     const c21hip_ionize_args &a = p.a;
     const float z_now = (float)a.redshift;
@@ -516,7 +520,7 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
     int bad = 0;
     for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < p.nitems;
          i0 += (size_t)gridDim.x * kBlock * U) {
-        Pack<VEC> st[U], de[U], x0[U], T0[U], pz[U];
+        Pack<VEC> st[U], de[U], x0[U], T0[U], pz[U], xe[U], Tn[U];
         unsigned char m[U][VEC];
         bool ok[U];
 #pragma unroll
@@ -530,6 +534,10 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
             x0[u] = Pack<VEC>::load(xH, ci.dense);
             if (!a.minimize_memory) T0[u] = Pack<VEC>::load(Tk, ci.dense);
             if (!a.first_snapshot) pz[u] = Pack<VEC>::load(prev_z_reion, ci.dense);
+            if (DIRECT && a.use_ts_fluct) {
+                xe[u] = Pack<VEC>::load(xe_dense, ci.dense);
+                if (!a.minimize_memory) Tn[u] = Pack<VEC>::load(Tneutral, ci.dense);
+            }
             if (VEC == 4) {
                 const uchar4 m4 = reinterpret_cast<const uchar4 *>(first_cross)[ci.dense];
                 m[u][0] = m4.x;
@@ -559,17 +567,23 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
                 float x = x0[u].v[e];
                 float T = a.minimize_memory ? 0.f : T0[u].v[e];
                 float zr = -1.f;
-                const bool ionised = m[u][e] != 0 || (curr_fcoll * a.ion_eff_factor > 1.);  // :1118
+                const bool ts = DIRECT && a.use_ts_fluct;
+                const double x_e = ts ? (double)clip_xe(xe[u].v[e]) : 0.;
+                const float T_neutral =
+                    (ts && !a.minimize_memory)
+                        ? Tn[u].v[e]
+                        : (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)dens));
+                const bool ionised =
+                    m[u][e] != 0 || (curr_fcoll * a.ion_eff_factor > (1. - x_e));  // :1118
                 if (ionised) {
                     const float pzv = a.first_snapshot ? -1.f : pz[u].v[e];
                     zr = (pzv < 0.f) ? z_now : pzv;  // :1143-1147
                     x = 0.f;                         // :1151
                 } else if ((double)x > kTiny) {      // :1161
                     double res_xH = 1. - curr_fcoll * a.ion_eff_factor;
-                    if (!a.minimize_memory) {
-                        const float T_HI = (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)dens));
-                        T = partially_ionized_T(T_HI, (float)res_xH, (float)a.T_re);
-                    }
+                    if (!a.minimize_memory)
+                        T = partially_ionized_T(T_neutral, (float)res_xH, (float)a.T_re);
+                    res_xH -= x_e;
                     if (res_xH < 0)
                         res_xH = 0;
                     else if (res_xH > 1)
@@ -580,9 +594,7 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
                 if (!a.minimize_memory) {
                     if (zr > 0.f && (double)x < kTiny) {  // :1218
                         T = fully_ionized_T(zr, stored_z, dens, pow_Tre, pow_z);
-                        const float floorT =
-                            (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)dens));
-                        if (T < floorT) T = floorT;
+                        if (T < T_neutral) T = T_neutral;
                     }
                     if (!isfinite(T)) bad = 1;  // :1245
                 }
@@ -916,7 +928,12 @@ extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_red
                                   const float *density, const float *prev_z_reion, float *xH,
                                   float *z_reion, float *kinetic_temperature, double *partials,
                                   double *sum_stars_out, double *sum_xh_out, int *flag_out,
-                                  int stars_direct, void *stream) {
+                                  int stars_direct, const float *xe_dense,
+                                  const float *kinetic_temp_neutral, void *stream) {
+    if (a->use_ts_fluct && (!stars_direct || !xe_dense || (!a->minimize_memory && !kinetic_temp_neutral))) {
+        c21hip_set_error("final sweep: the x_e path needs the dense inputs (stars_direct)");
+        return C21CM_VALUE_ERROR;
+    }
     const size_t ntot = (size_t)a->nx * a->ny * a->nz;
     const int vec = stars_direct ? ((ntot % 4 == 0) ? 4 : 1) : ((a->nz % 2 == 0) ? 2 : 1);
     IoniseParams p = make_params(a, vec == 4 ? 2 : vec);
@@ -926,7 +943,8 @@ extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_red
 #define LAUNCH_FINAL(V, D)                                                                       \
     hipLaunchKernelGGL((final_sweep_kernel<V, D>), dim3(blocks), dim3(kBlock), 0,                \
                        (hipStream_t)stream, p, (float)stored_redshift, first_cross, stars_fil,   \
-                       density, prev_z_reion, xH, z_reion, kinetic_temperature, ps, px, flag_out)
+                       density, prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion,       \
+                       kinetic_temperature, ps, px, flag_out)
     if (stars_direct && vec == 4)
         LAUNCH_FINAL(4, true);
     else if (stars_direct)

@@ -833,6 +833,8 @@ static float mass_limit_bisection(float Mmin, float Mmax, float PL, float FRAC, 
 }
 
 /* scaling_relations.c:36-119 (fields used by the ionisation path) */
+size_t c21_scaling_consts_size(void) { return sizeof(c21_scaling_consts); }
+
 int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc) {
     int status = 0;
     const AstroParams *ap = astro_params_global;

@@ -2,6 +2,8 @@
 #ifndef C21_COSMOLOGY_H
 #define C21_COSMOLOGY_H
 
+#include <stddef.h>
+
 #include "c21cm_abi.h"
 
 #ifdef __cplusplus
@@ -64,6 +66,7 @@ int c21_Xray_Conditional_table(double growthf, double lnMmin, double lnMmax, dou
 /* the weight itself, per unit ln M (hmf.c:482-509 without mini-halos) */
 double c21_xray_fraction(double lnM, double Mturn, const c21_scaling_consts *sc);
 int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc);
+size_t c21_scaling_consts_size(void); /* for binding layers that mirror the struct */
 double c21_minimum_source_mass(double redshift);
 int c21_recfast_load(void);
 double c21_T_RECFAST(float z);

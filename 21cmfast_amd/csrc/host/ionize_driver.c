@@ -219,6 +219,8 @@ typedef struct {
     copyback_list cb;
 } ion_ctx;
 
+static int r0_direct(void);
+
 static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedField *pf,
                      const IonizedBox *prev, const TsBox *ts, const HaloBox *halos,
                      IonizedBox *box, int need_outputs, void *stream) {
@@ -263,7 +265,11 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     }
     /* Lagrangian grids without the x_e grid: passes Z of both grids, the f_coll sum and the
      * barrier test run as one kernel that only updates a uint8 first-crossing mask */
-    c->fused = c->native && c->lagrangian && !s->use_ts_fluct;
+    /* with an x_e grid (spin-temperature runs) the fused path needs the three-grid pass Z
+     * (512/1024-point z-lines) and the dense-input final sweep */
+    c->fused = c->native && c->lagrangian &&
+               (!s->use_ts_fluct ||
+                (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
     c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct;
     if (c->fused) {
         const char *e = getenv("C21CM_DEFER_SUMS");
@@ -471,6 +477,10 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                     c->stars_work, s->stars_filter, (float)s->mfp_meandens, c->nx,
                                     c->ny, c->nz, s->box_len, s->box_len_z, R, apply, buf, ready,
                                     c->stream));
+        if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
+            TRY(c21hip_split_filter_xy_shared(c->xe_unf, c->xe_work, s->hii_filter, c->nx, c->ny,
+                                              c->nz, s->box_len, s->box_len_z, R, apply, buf,
+                                              c->stream));
         if (g_tab.enabled) TRY(c21hip_event_record(g_tab.ev_used[buf], c->stream));
         c->tab_seq++;
         if (c->def_partials) {
@@ -483,17 +493,17 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                 TRY(flush_deferred(c));
             if (c->def_count == 0) c->def_first = R_ct;
             c->def_count++;
-            TRY(c21hip_split_z_ionise_stars(c->delta_work, c->stars_work, first_cross,
-                                            c->def_partials + (long)R_ct * c->def_stride, NULL,
-                                            c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
-                                            s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
-                                            c->stream));
+            TRY(c21hip_split_z_ionise_stars_xe(
+                c->delta_work, c->stars_work, s->use_ts_fluct ? c->xe_work : NULL, first_cross,
+                c->def_partials + (long)R_ct * c->def_stride, NULL, c->nx, c->ny, c->nz, R_ct,
+                s->rhocrit_omb, s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg, c->stream));
             goto done;
         }
-        TRY(c21hip_split_z_ionise_stars(c->delta_work, c->stars_work, first_cross, partials,
-                                        sum_dev, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
-                                        s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
-                                        c->stream));
+        TRY(c21hip_split_z_ionise_stars_xe(c->delta_work, c->stars_work,
+                                           s->use_ts_fluct ? c->xe_work : NULL, first_cross,
+                                           partials, sum_dev, c->nx, c->ny, c->nz, R_ct,
+                                           s->rhocrit_omb, s->ion_eff_factor, s->mass_dep_zeta,
+                                           s->f_limit_acg, c->stream));
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
         goto done;
@@ -691,7 +701,8 @@ static int final_step(ion_ctx *c, const unsigned char *mask, int stars_ready) {
     TRY(c21hip_final_sweep(&args, s->stored_redshift, mask, direct ? c->n_ion : c->stars_fil,
                            c->density, c->prev_zre, c->xH, c->zre, c->Tk, c->partials,
                            c->scalars + SC_SUMS, c->scalars + SC_XHSUM,
-                           (int *)(c->scalars + SC_FLAG), direct, c->stream));
+                           (int *)(c->scalars + SC_FLAG), direct, c->xe_dense, c->Tneutral,
+                           c->stream));
     TRY(c21hip_finish_mean(c->scalars + SC_SUMS, (double)c->ntot, s->mass_dep_zeta,
                            s->f_limit_acg, c->scalars + SC_MEANS, c->stream));
     c->finalised = 1;

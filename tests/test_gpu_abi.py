@@ -209,12 +209,7 @@ def test_ionized_box_const_ion_eff(gpu_lib, oracle, tmp_path, tables):
     assert np.all(out["prev_z_reion"] == -1)  # the first-snapshot previous box is initialised
 
 
-class ScalingConsts(C.Structure):
-    """mirror of c21_scaling_consts (csrc/host/cosmology.h)"""
-    _fields_ = [(k, C.c_double) for k in
-                ("fstar_10", "alpha_star", "fstar_7", "t_h", "t_star", "fesc_10", "alpha_esc",
-                 "fesc_7", "pop2_ion", "pop3_ion", "acg_thresh", "mturn_a_nofb", "Mlim_Fstar",
-                 "Mlim_Fesc")]
+from test_host_scalars import ScalingConsts  # noqa: E402  (mirror of c21_scaling_consts)
 
 
 def test_ionized_box_e_integral(gpu_lib, oracle, tmp_path):

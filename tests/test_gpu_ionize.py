@@ -154,22 +154,30 @@ def _install_table(spec):
     spec.table_fn = cb
 
 
-@pytest.mark.parametrize("mode", ["erfc", "table", "stars_ts"])
+@pytest.mark.parametrize("mode", ["erfc", "table", "stars_ts", "stars_ts_prev"])
 @pytest.mark.parametrize("nz", [512, 1024])
 def test_long_z_lines_plain_pass_parity(api, oracle, mode, nz):
     """The single-grid pass Z on 512- and 1024-point lines (wave-level kernel with the erfc,
     extrema and plain-store epilogues) on 64 x 64 x nz boxes."""
     n = 64
     oracle.set_threads(32)
-    if mode == "stars_ts":  # x_e grid present: unfused path, plain stores of three grids
-        spec = W.ionize_spec(n, hii_dim_z=nz, r_bubble_max=8.0, use_ts_fluct=1)
+    if mode.startswith("stars_ts"):  # x_e grid present: the three-grid fused pass Z
+        prev = mode.endswith("prev")
+        spec = W.ionize_spec(n, hii_dim_z=nz, r_bubble_max=8.0, use_ts_fluct=1,
+                             first_snapshot=0 if prev else 1)
         density = W.density_field_numpy((n, n, nz), seed=5)
         n_ion = W.nion_from_density(density)
         rng = np.random.default_rng(3)
-        xe = (0.02 + 0.03 * rng.random((n, n, nz))).astype(np.float32)
+        # x_e spans the clips at 0 and 0.999 and is large enough to matter in the barrier
+        xe = (-0.05 + 0.6 * rng.random((n, n, nz)) ** 3).astype(np.float32)
+        xe[::7, ::5, ::3] = 1.2
         Tn = (8.0 + 4.0 * rng.random((n, n, nz))).astype(np.float32)
-        ref = oracle.ionize_grids(spec, density, n_ion, xe=xe, Tneutral=Tn)
-        got = run_device(api, spec, density, n_ion, xe=xe, Tneutral=Tn, device_resident=True)
+        kw = dict(xe=xe, Tneutral=Tn)
+        if prev:
+            kw["prev_z_reion"] = np.where(rng.random((n, n, nz)) < 0.3, 10.5, -1.0).astype(np.float32)
+        ref = oracle.ionize_grids(spec, density, n_ion, **kw)
+        got = run_device(api, spec, density, n_ion, device_resident=True, **kw)
+        assert 0.02 < (ref["neutral_fraction"] == 0).mean() < 0.98
     else:
         fmode = W.FCOLL_ERFC if mode == "erfc" else W.FCOLL_TABLE_EXP
         spec = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=8.0)

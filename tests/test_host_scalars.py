@@ -175,6 +175,8 @@ class ScalingConsts(C.Structure):
 
 def _bind_conditional(lib):
     f64 = C.c_double
+    lib.c21_scaling_consts_size.restype = C.c_size_t
+    assert lib.c21_scaling_consts_size() == C.sizeof(ScalingConsts), "ctypes mirror out of date"
     lib.c21_Nion_ConditionalM.restype = f64
     lib.c21_Nion_ConditionalM.argtypes = [f64] * 7 + [C.POINTER(ScalingConsts), C.c_int]
     lib.c21_Nion_Conditional_table.restype = C.c_int
