@@ -96,6 +96,10 @@ int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_dense, int nx
 int c21hip_split_z_c2r_stats(const float *split_work, float *real_out, long out_zstride, int nx,
                              int ny, int nz, double min_value, double const_factor,
                              double *partials, double *stats_out, void *stream);
+/* stats_out == NULL above defers the reduction: window i keeps its partials (nb = nx*ny/16 minima,
+ * maxima, sums) at partials + i * stride and one launch reduces `count` windows */
+int c21hip_batched_stats(const double *partials, long stride, int nb, int count,
+                         double *stats_out, void *stream);
 /* the same store + statistics from real rows of in_zstride floats (generic sizes; out may be
  * NULL for the statistics alone); partials: 3 * C21HIP_PARTIALS doubles */
 int c21hip_floor_scale_stats(const float *in, long in_zstride, float *out, int nx, int ny, int nz,

@@ -2242,6 +2242,7 @@ extern "C" int c21hip_split_z_c2r_stats(const float *split_work, float *real_out
     z.const_factor = const_factor;
     int st = dispatch_z_c2r<3>(nz, z, nlines, (hipStream_t)stream);
     if (st) return st;
+    if (!stats_out) return 0;  // deferred: c21hip_batched_stats reduces several windows at once
     double *stage = partials + 3 * (size_t)nb;
     if ((st = c21hip_reduce_op(z.p0, nb, 1, stage, stats_out, stream))) return st;
     if ((st = c21hip_reduce_op(z.p1, nb, 2, stage + nb / 1024 + 2, stats_out + 1, stream)))
@@ -2357,6 +2358,47 @@ extern "C" int c21hip_split_filter_xy_shared(const float *src, float *work, int 
     const float rp[2] = {0.f, 0.f};
     return filter_xy(srcs, works, 1, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_, 6,
                      table_slot);
+}
+
+// {min, max, sum} of `count` windows in one launch: window i left its per-workgroup partials
+// (nb minima, nb maxima, nb sums, in that order) at partials + i * stride; stats_out[3 i ..].
+__global__ void __launch_bounds__(kBlock)
+batched_stats_kernel(const double *__restrict__ partials, long stride, int nb,
+                     double *__restrict__ stats_out) {
+    __shared__ double l0[kBlock], l1[kBlock], l2[kBlock];
+    const double *p = partials + (long)blockIdx.x * stride;
+    double lo = p[0], hi = p[nb], sum = 0.;
+    for (int i = threadIdx.x; i < nb; i += kBlock) {
+        lo = fmin(lo, p[i]);
+        hi = fmax(hi, p[nb + i]);
+        sum += p[2 * (long)nb + i];
+    }
+    l0[threadIdx.x] = lo;
+    l1[threadIdx.x] = hi;
+    l2[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            l0[threadIdx.x] = fmin(l0[threadIdx.x], l0[threadIdx.x + s]);
+            l1[threadIdx.x] = fmax(l1[threadIdx.x], l1[threadIdx.x + s]);
+            l2[threadIdx.x] += l2[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats_out[3 * blockIdx.x] = l0[0];
+        stats_out[3 * blockIdx.x + 1] = l1[0];
+        stats_out[3 * blockIdx.x + 2] = l2[0];
+    }
+}
+
+extern "C" int c21hip_batched_stats(const double *partials, long stride, int nb, int count,
+                                    double *stats_out, void *stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(batched_stats_kernel, dim3(count), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, stride, nb, stats_out);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 // workgroup partials the fused pass Z writes for an nx x ny x nz grid

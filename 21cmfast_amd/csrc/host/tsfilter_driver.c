@@ -10,13 +10,14 @@
  * Host arrays are staged through workspace slots, device arrays are used in place.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../hip/c21hip.h"
 #include "c21cm_grid.h"
 
 /* slots 0-63 belong to the other drivers */
-enum { WS_TF_IN = 64, WS_TF_UNF, WS_TF_WORK, WS_TF_OUT, WS_TF_PART, WS_TF_UNF2, WS_TF_WORK2, WS_TF_IN2, WS_TF_OUT2 };
+enum { WS_TF_IN = 64, WS_TF_UNF, WS_TF_WORK, WS_TF_OUT, WS_TF_PART, WS_TF_UNF2, WS_TF_WORK2, WS_TF_IN2, WS_TF_OUT2, WS_TF_RPART };
 
 #define TRY(expr)         \
     do {                  \
@@ -107,6 +108,85 @@ static const float *tf_stage_in(const float *p, size_t bytes, void *stream, int 
     return (const float *)d;
 }
 
+/* Native sizes: the W(kR) table of radius r+1 is built on the library's side stream while
+ * radius r runs its passes (two table buffers, events both ways, as in the excursion-set loop),
+ * and the min / max / sum partials of all radii are reduced by one launch at the end. */
+static struct {
+    int init, ok;
+    void *aux, *ev_table[2], *ev_used[2], *ev_sync;
+} tf_tab;
+
+static void tf_tab_init(void) {
+    if (tf_tab.init) return;
+    tf_tab.init = 1;
+    const char *e = getenv("C21CM_ASYNC_TABLES");
+    if (e && e[0] == '0') return;
+    tf_tab.aux = c21hip_aux_stream();
+    tf_tab.ev_sync = c21hip_event_create();
+    for (int b = 0; b < 2; b++) {
+        tf_tab.ev_table[b] = c21hip_event_create();
+        tf_tab.ev_used[b] = c21hip_event_create();
+    }
+    tf_tab.ok = tf_tab.aux && tf_tab.ev_sync && tf_tab.ev_table[0] && tf_tab.ev_table[1] &&
+                tf_tab.ev_used[0] && tf_tab.ev_used[1];
+}
+
+static int fill_Rbox_native(tf_ctx *c, const c21cm_rbox_spec *s, float *result, int host_out,
+                            float *stage_out) {
+    int status = 0;
+    const size_t bytes = c->ntot * sizeof(float);
+    const long nb = (long)c->nx * c->ny / 16, stride = 3 * nb;
+    double *partials =
+        (double *)c21hip_ws(WS_TF_RPART, (size_t)s->n_R * (size_t)stride * sizeof(double));
+    if (!partials) return C21CM_MEMORY_ALLOC_ERROR;
+    tf_tab_init();
+    int filtered[C21CM_MAX_TS_RADII], n_f = 0; /* radii that need a table, in order */
+    for (int r = 0; r < s->n_R; r++)
+        if (s->R[r] > s->cell_radius) filtered[n_f++] = r;
+    int next = 0; /* index into filtered[] of the next table to build */
+    if (tf_tab.ok && n_f > 0) {
+        TRY(c21hip_event_record(tf_tab.ev_sync, c->stream));
+        TRY(c21hip_stream_wait_event(tf_tab.aux, tf_tab.ev_sync));
+    }
+    for (int r = 0; r < s->n_R; r++) {
+        const int apply = s->R[r] > s->cell_radius;
+        const float R = (float)s->R[r];
+        float *d_out = host_out ? stage_out : result + (size_t)r * c->ntot;
+        if (apply && tf_tab.ok) {
+            const int k = next; /* this radius is filtered[k] */
+            const int buf = k & 1;
+            if (k == 0) {
+                TRY(c21hip_window_tables(buf, s->filter_type, 0.f, s->filter_type, 0.f, c->nx, c->ny,
+                                         c->nz, c->box_len, c->box_len_z, R, tf_tab.aux));
+                TRY(c21hip_event_record(tf_tab.ev_table[buf], tf_tab.aux));
+            }
+            if (k + 1 < n_f) { /* the next filtered radius' table, into the other buffer */
+                const int nb2 = buf ^ 1;
+                if (k >= 1) TRY(c21hip_stream_wait_event(tf_tab.aux, tf_tab.ev_used[nb2]));
+                TRY(c21hip_window_tables(nb2, s->filter_type, 0.f, s->filter_type, 0.f, c->nx,
+                                         c->ny, c->nz, c->box_len, c->box_len_z,
+                                         (float)s->R[filtered[k + 1]], tf_tab.aux));
+                TRY(c21hip_event_record(tf_tab.ev_table[nb2], tf_tab.aux));
+            }
+            TRY(c21hip_stream_wait_event(c->stream, tf_tab.ev_table[buf]));
+            TRY(c21hip_split_filter_xy_shared(c->unf, c->work, s->filter_type, c->nx, c->ny, c->nz,
+                                              c->box_len, c->box_len_z, R, 1, buf, c->stream));
+            TRY(c21hip_event_record(tf_tab.ev_used[buf], c->stream));
+            next++;
+        } else {
+            TRY(c21hip_split_filter_xy(c->unf, c->work, c->nx, c->ny, c->nz, c->box_len,
+                                       c->box_len_z, s->filter_type, R, 0.f, apply, c->stream));
+        }
+        TRY(c21hip_split_z_c2r_stats(c->work, d_out, c->nz, c->nx, c->ny, c->nz, s->min_value,
+                                     s->const_factor, partials + (size_t)r * stride, NULL,
+                                     c->stream));
+        if (host_out) TRY(c21hip_d2h(result + (size_t)r * c->ntot, stage_out, bytes, c->stream));
+    }
+    TRY(c21hip_batched_stats(partials, stride, (int)nb, s->n_R, c->stats, c->stream));
+done:
+    return status;
+}
+
 int c21cm_fill_Rbox_grids(const c21cm_rbox_spec *s, const float *input, float *result,
                           double *min_arr, double *average_arr, double *max_arr, void *stream) {
     int status = 0;
@@ -128,13 +208,17 @@ int c21cm_fill_Rbox_grids(const c21cm_rbox_spec *s, const float *input, float *r
     float *stage_out = host_out ? (float *)c21hip_ws(WS_TF_OUT, bytes) : NULL;
     if (host_out && !stage_out) return C21CM_MEMORY_ALLOC_ERROR;
     TRY(tf_forward(&c, d_in));
-    for (int r = 0; r < s->n_R; r++) {
-        const double R = s->R[r];
-        float *d_out = host_out ? stage_out : result + (size_t)r * c.ntot;
-        TRY(tf_window(&c, s->filter_type, (float)R, 0.f, R > s->cell_radius, s->min_value,
-                      s->const_factor, d_out, c.stats + 3 * r));
-        /* stream order keeps the staging buffer safe: the next radius' store follows the copy */
-        if (host_out) TRY(c21hip_d2h(result + (size_t)r * c.ntot, stage_out, bytes, stream));
+    if (c.native) {
+        TRY(fill_Rbox_native(&c, s, result, host_out, stage_out));
+    } else {
+        for (int r = 0; r < s->n_R; r++) {
+            const double R = s->R[r];
+            float *d_out = host_out ? stage_out : result + (size_t)r * c.ntot;
+            TRY(tf_window(&c, s->filter_type, (float)R, 0.f, R > s->cell_radius, s->min_value,
+                          s->const_factor, d_out, c.stats + 3 * r));
+            /* stream order keeps the staging buffer safe: the next store follows the copy */
+            if (host_out) TRY(c21hip_d2h(result + (size_t)r * c.ntot, stage_out, bytes, stream));
+        }
     }
     {
         double host_stats[3 * C21CM_MAX_TS_RADII];
