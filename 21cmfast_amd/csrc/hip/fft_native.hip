@@ -1724,6 +1724,92 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     }
 }
 
+// ---- forward pass Z (real -> complex) on the wave-level transform ----------------------------
+// The mirror image of wave_c2r.  In: x[16 r + d] = z[(b + 16 r) + A d], z[j] = (cell 2j, cell
+// 2j+1) -- the layout wave_c2r ends in, so the loads are 128-byte runs.  A 16-point DFT over d in
+// registers, the twiddle exp(-2 pi i c b'/H), one transposition through the 17-padded LDS
+// region, a DFT over the A values of c, then the Hermitian post-processing whose partner
+// Zf[H-k] comes back from the line's LDS copy.  Out: x[a] = X[16 a + b] (k < H), *xh = X[H].
+template <int A>
+__device__ __forceinline__ void wave_r2c(float2 (&x)[A], float *xh, float2 *L, const float2 *twH,
+                                         const float2 *twN, int b) {
+    constexpr int H = 16 * A;
+#pragma unroll
+    for (int r = 0; r < A / 16; r++) {
+        Dft<16, -1>::run(x + 16 * r);  // over d: Y_c[b'], c = b + 16 r
+        const int c = b + 16 * r;
+#pragma unroll
+        for (int bb = 0; bb < 16; bb++)
+            L[c * 17 + bb] = (bb == 0) ? x[16 * r] : cmul(x[16 * r + bb], twH[c * bb]);
+    }
+    wave_fence();
+#pragma unroll
+    for (int c = 0; c < A; c++) x[c] = L[c * 17 + b];
+    Dft<A, -1>::run(x);  // over c: Zf[16 a + b]
+    wave_fence();        // the column reads are done before the region is overwritten
+#pragma unroll
+    for (int a = 0; a < A; a++) L[a * 17 + b] = x[a];
+    wave_fence();
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        const int k = 16 * a + b;
+        const int kp = (H - k) & (H - 1);
+        const float2 Z = x[a], B = L[(kp >> 4) * 17 + (kp & 15)];
+        if (k == 0) {
+            x[a] = make_float2(Z.x + Z.y, 0.f);
+            *xh = Z.x - Z.y;
+        } else {
+            const float2 E = make_float2(0.5f * (Z.x + B.x), 0.5f * (Z.y - B.y));
+            const float2 D = make_float2(0.5f * (Z.x - B.x), 0.5f * (Z.y + B.y));
+            const float2 wD = cmul(D, twN[k]);
+            x[a] = make_float2(E.x + wD.y, E.y - wD.x);  // E - i w_k D
+        }
+    }
+}
+
+template <int A>
+__global__ void __launch_bounds__(kBlock)
+zw_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
+              const float2 *__restrict__ twN_global) {
+    constexpr int H = 16 * A;
+    constexpr int LINE_LDS = A * 17 + 4;
+    __shared__ float2 lines[ZW_LINES * LINE_LDS];
+    __shared__ float2 twH[H], twN[H];
+    for (int t = threadIdx.x; t < H; t += kBlock) {
+        twH[t] = twH_global[t];
+        twN[t] = twN_global[t];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, b = lane & 15;
+    const int lw = wave * 4 + g;
+    const long line = (long)blockIdx.x * ZW_LINES + lw;
+    const long lline = logical_line(line, a.ny, a.lb);
+    float2 *L = lines + lw * LINE_LDS;
+    const float2 *src = reinterpret_cast<const float2 *>(a.in + lline * a.in_zstride);
+    const bool clip = a.lo <= a.hi;
+    float2 x[A];
+#pragma unroll
+    for (int q = 0; q < A; q++) {
+        const int j = (b + 16 * (q / 16)) + A * (q % 16);
+        float2 v = src[j];
+        if (clip) {
+            v.x = (float)fmax(fmin((double)v.x * a.factor, a.hi), a.lo);
+            v.y = (float)fmax(fmin((double)v.y * a.factor, a.hi), a.lo);
+        } else if (a.factor != 1.0) {
+            v.x = (float)((double)v.x * a.factor);
+            v.y = (float)((double)v.y * a.factor);
+        }
+        x[q] = v;
+    }
+    __syncthreads();  // twiddle tables
+    float xh = 0.f;
+    wave_r2c<A>(x, &xh, L, twH, twN, b);
+    float2 *dst = a.main + line * H;
+#pragma unroll
+    for (int q = 0; q < A; q++) dst[16 * q + b] = x[q];
+    if (b == 0) a.nyq[lline] = make_float2(xh, 0.f);
+}
+
 bool zw_enabled() {
     static int cached = -1;
     if (cached < 0) {
@@ -1809,6 +1895,19 @@ int launch_z_r2c(const ZFwdArgs &a, long nlines, hipStream_t stream) {
 }
 
 int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
+    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0 &&
+        a.in_zstride % 2 == 0) {
+        const float2 *twH = twiddles(nz / 2);
+        const float2 *twN = twiddles(nz);
+        if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+        const dim3 grid((unsigned)(nlines / ZW_LINES));
+        if (nz == 512)
+            hipLaunchKernelGGL(zw_r2c_kernel<16>, grid, dim3(kBlock), 0, stream, a, twH, twN);
+        else
+            hipLaunchKernelGGL(zw_r2c_kernel<32>, grid, dim3(kBlock), 0, stream, a, twH, twN);
+        LAUNCH_CHECK();
+        return 0;
+    }
     switch (nz) {
         case 64: return launch_z_r2c<64>(a, nlines, stream);
         case 128: return launch_z_r2c<128>(a, nlines, stream);
