@@ -144,7 +144,8 @@ static int fill_Rbox_native(tf_ctx *c, const c21cm_rbox_spec *s, float *result, 
     for (int r = 0; r < s->n_R; r++)
         if (s->R[r] > s->cell_radius) filtered[n_f++] = r;
     int next = 0; /* index into filtered[] of the next table to build */
-    if (tf_tab.ok && n_f > 0) {
+    const int tab_async = tf_tab.ok && c->ntot >= ((size_t)1 << 26); /* see ionize_driver.c */
+    if (tab_async && n_f > 0) {
         TRY(c21hip_event_record(tf_tab.ev_sync, c->stream));
         TRY(c21hip_stream_wait_event(tf_tab.aux, tf_tab.ev_sync));
     }
@@ -152,7 +153,7 @@ static int fill_Rbox_native(tf_ctx *c, const c21cm_rbox_spec *s, float *result, 
         const int apply = s->R[r] > s->cell_radius;
         const float R = (float)s->R[r];
         float *d_out = host_out ? stage_out : result + (size_t)r * c->ntot;
-        if (apply && tf_tab.ok) {
+        if (apply && tab_async) {
             const int k = next; /* this radius is filtered[k] */
             const int buf = k & 1;
             if (k == 0) {
