@@ -108,6 +108,10 @@ int c21hip_floor_scale_stats(const float *in, long in_zstride, float *out, int n
 /* pass Z storing v / divisor (0: no division) */
 int c21hip_split_z_c2r_div(const float *split_work, float *real_out, long out_zstride, int nx,
                            int ny, int nz, float divisor, void *stream);
+/* pass Z storing v * scale / divisor (0: no division), floored at -1 + 1e-7 when floor_density */
+int c21hip_split_z_c2r_out(const float *split_work, float *real_out, long out_zstride, int nx,
+                           int ny, int nz, float scale, float divisor, int floor_density,
+                           void *stream);
 int c21hip_split_xblock_log2(int nx); /* 0: plain split layout */
 /* split-layout InitialConditions pipeline (ics_kernels.hip, plain layout only) */
 int c21hip_split_kop(const float *in_split, float *out_split, int nx, int ny, int nz,

@@ -965,6 +965,7 @@ struct ZPassArgs {
     long out_zstride;
     float out_scale;
     float out_div;       // != 0: stored value = v / out_div (EPI 0; the gathers of the ICs)
+    int out_floor;       // != 0 (EPI 0): stored value >= -1 + 1e-7 (PerturbedField.c:262-264)
     int ny, lb;          // x-blocked layout: memory line -> logical line (logical_line())
     // epilogues of the Eulerian source models (EPI 1, 2)
     double *p0, *p1;     // per-workgroup partials: EPI 1 min / max, EPI 2 sum (p0)
@@ -1075,6 +1076,10 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         if (EPI == 0 && a.out_div != 0.f) {
             v.x = __fdiv_rn(v.x, a.out_div);
             v.y = __fdiv_rn(v.y, a.out_div);
+        }
+        if (EPI == 0 && a.out_floor) {
+            if ((double)v.x < -1.0 + 1e-7) v.x = (float)(-1.0 + 1e-7);
+            if ((double)v.y < -1.0 + 1e-7) v.y = (float)(-1.0 + 1e-7);
         }
         if (EPI == 3) {
             // float compared with the double floor, float x double product rounded to float
@@ -1670,6 +1675,10 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         if (EPI == 0 && a.out_div != 0.f) {
             v.x = __fdiv_rn(v.x, a.out_div);
             v.y = __fdiv_rn(v.y, a.out_div);
+        }
+        if (EPI == 0 && a.out_floor) {
+            if ((double)v.x < -1.0 + 1e-7) v.x = (float)(-1.0 + 1e-7);
+            if ((double)v.y < -1.0 + 1e-7) v.y = (float)(-1.0 + 1e-7);
         }
         if (EPI == 3) {
             if ((double)v.x < a.min_value) v.x = (float)a.min_value;
@@ -2277,6 +2286,15 @@ extern "C" int c21hip_split_z_c2r(const float *split_work, float *real_out, long
 // InitialConditions gathers (InitialConditions.c:687,729,356) folded into the store.
 extern "C" int c21hip_split_z_c2r_div(const float *split_work, float *real_out, long out_zstride,
                                       int nx, int ny, int nz, float divisor, void *stream) {
+    return c21hip_split_z_c2r_out(split_work, real_out, out_zstride, nx, ny, nz, 1.0f, divisor, 0,
+                                  stream);
+}
+
+// Pass Z with the general store: v * scale, then / divisor (0: none), then the density floor
+// -1 + 1e-7 when floor_density != 0 (the "/ N, clip" of PerturbedField.c:251-276).
+extern "C" int c21hip_split_z_c2r_out(const float *split_work, float *real_out, long out_zstride,
+                                      int nx, int ny, int nz, float scale, float divisor,
+                                      int floor_density, void *stream) {
     const long nlines = (long)nx * ny;
     ZPassArgs z{};
     z.ny = ny;
@@ -2285,8 +2303,9 @@ extern "C" int c21hip_split_z_c2r_div(const float *split_work, float *real_out, 
     z.nyq = z.main + nlines * (nz / 2);
     z.out = real_out;
     z.out_zstride = out_zstride;
-    z.out_scale = 1.0f;
+    z.out_scale = scale;
     z.out_div = divisor;
+    z.out_floor = floor_density;
     return dispatch_z_c2r(nz, z, nlines, (hipStream_t)stream);
 }
 

@@ -10,6 +10,7 @@
  *   compute_perturbed_velocities  per axis: k-space multiply, c2r, gather        :284-387
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../hip/c21hip.h"
@@ -23,8 +24,17 @@ enum {
     WS_PT_SAVED,
     WS_PT_RESAMPLED,
     WS_PT_IN0, /* .. +7 staged IC arrays */
-    WS_PT_OUT0 = 32 /* .. +3 staged outputs */
+    WS_PT_OUT0 = 32, /* .. +3 staged outputs */
+    WS_PT_SPLIT = 89 /* .. +2 split-layout spectra */
 };
+
+/* C21CM_PT=padded keeps the k-space part of the low-resolution branch on the padded layout */
+static int pt_split_supported(const int lo_dim[3]) {
+    const char *e = getenv("C21CM_PT");
+    if (e && e[0] == 'p') return 0;
+    return c21hip_fft_is_native(lo_dim[0], lo_dim[1], lo_dim[2]) &&
+           !c21hip_split_xblock_log2(lo_dim[0]);
+}
 
 #define TRY(expr)         \
     do {                  \
@@ -139,6 +149,54 @@ int c21cm_perturb_grids(const c21cm_perturb_spec *s, const InitialConditions *ic
             /* normalise_delta_grid with mass_factor = 1 (PerturbedField.c:188-190): v*1 - 1 */
             TRY(c21hip_add_scalar(lowres, lo_npad, -1.0f, stream));
         }
+    }
+    if (!hires && pt_split_supported(lo_dim)) {
+        /* k-space part on the split layout of the native transform (as the IC pipeline): the
+         * forward transform writes it, the smoothing window is one sweep over it, pass Z stores
+         * the dense outputs with "/ N" and the density floor folded in, and the velocity
+         * operator i k_a / k^2 is applied inside pass X on the spectrum divided by k^2 once. */
+        const size_t sfl = c21hip_split_floats(lo_dim[0], lo_dim[1], lo_dim[2]) * sizeof(float);
+        float *spec = (float *)c21hip_ws(WS_PT_SPLIT, sfl);
+        float *work = (float *)c21hip_ws(WS_PT_SPLIT + 1, sfl);
+        float *pk2 = (float *)c21hip_ws(WS_PT_SPLIT + 2, sfl);
+        if (!spec || !work || !pk2) return C21CM_MEMORY_ALLOC_ERROR;
+        const long zs = 2 * (long)(lo_dim[2] / 2 + 1);
+        TRY(c21hip_split_r2c(lowres, zs, spec, lo_dim[0], lo_dim[1], lo_dim[2], 1.0, 1., -1., 1.0f,
+                             stream));
+        if (s->smooth_evolved_density)
+            TRY(c21hip_copy_filter_split(spec, spec, lo_dim[0], lo_dim[1], lo_dim[2], s->box_len,
+                                         s->box_len_z, 2, (float)s->density_smooth_radius_mpc, 0.f,
+                                         1, stream));
+        float *targets[4] = {pf->density, pf->velocity_x, pf->velocity_y, pf->velocity_z};
+        int pk2_done = 0;
+        for (int t = 0; t < 4; t++) {
+            if (!targets[t]) continue;
+            if (t >= 1 && (s->hii_dim <= 1 || (!s->keep_3d_velocities && t < 3))) continue;
+            float *d_out = targets[t];
+            const int host_out = !c21hip_is_device_ptr(targets[t]);
+            if (host_out) d_out = (float *)c21hip_ws(WS_PT_OUT0 + t, lo_tot * sizeof(float));
+            if (!d_out) return C21CM_MEMORY_ALLOC_ERROR;
+            if (t == 0) { /* /N, clip (PerturbedField.c:251-276,450-464) */
+                TRY(c21hip_split_filter_xy(spec, work, lo_dim[0], lo_dim[1], lo_dim[2], s->box_len,
+                                           s->box_len_z, 0, 0.f, 0.f, 0, stream));
+                TRY(c21hip_split_z_c2r_out(work, d_out, lo_dim[2], lo_dim[0], lo_dim[1], lo_dim[2],
+                                           1.0f, (float)lo_tot, 1, stream));
+            } else { /* v = c2r(delta_k dD/dt/D i k_a / k^2 / N), PerturbedField.c:320-383 */
+                if (!pk2_done) {
+                    TRY(c21hip_split_kop(spec, pk2, lo_dim[0], lo_dim[1], lo_dim[2], s->box_len,
+                                         s->box_len_z, -2, -1, stream));
+                    pk2_done = 1;
+                }
+                TRY(c21hip_split_sepop_xy(pk2, work, lo_dim[0], lo_dim[1], lo_dim[2], s->box_len,
+                                          s->box_len_z, t - 1, -1, stream));
+                TRY(c21hip_split_z_c2r_out(work, d_out, lo_dim[2], lo_dim[0], lo_dim[1], lo_dim[2],
+                                           (float)(s->dDdt_over_D / (double)lo_tot), 0.f, 0,
+                                           stream));
+            }
+            if (host_out) TRY(c21hip_d2h(targets[t], d_out, lo_tot * sizeof(float), stream));
+        }
+        TRY(c21hip_sync(stream));
+        goto done;
     }
     /* ---- smooth_and_clip_density */
     TRY(c21hip_fft_r2c(lowres, lo_dim[0], lo_dim[1], lo_dim[2], stream));

@@ -85,6 +85,29 @@ def test_option_branches(api, oracle, opts):
     compare(api.perturb_grids(spec, ics), oracle.perturb_grids(spec, ics))
 
 
+@pytest.mark.parametrize("opts", [dict(smooth_evolved_density=1), dict(keep_3d_velocities=0),
+                                  dict(perturb_algorithm=1, smooth_evolved_density=1)])
+def test_split_layout_kspace_part(api, oracle, opts, monkeypatch):
+    """Low-resolution branch at a size the native transform covers (64^3 from 128^3): the
+    k-space part runs on the split layout (smoothing window as one sweep, velocity operator in
+    pass X, dense stores with / N and the density floor from pass Z); C21CM_PT=padded selects
+    the padded-layout sequence, and both agree with the oracle."""
+    n, N = 64, 128
+    ics = random_ics(n, N, seed=11)
+    kw = dict(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=96.0, box_len_z=96.0,
+              growth_factor=0.11, init_growth_factor=0.004, dDdt_over_D=2e-17,
+              keep_3d_velocities=1, density_smooth_radius_mpc=0.9 * 96.0 / n)
+    kw.update(opts)
+    algorithm = kw.pop("perturb_algorithm", 2)
+    spec = perturb_spec(algorithm, **kw)
+    ref = oracle.perturb_grids(spec, ics)
+    got = api.perturb_grids(spec, ics)
+    compare(got, ref)
+    monkeypatch.setenv("C21CM_PT", "padded")
+    compare(api.perturb_grids(spec, ics), ref)
+    assert got["density"].min() >= np.float32(-1.0 + 1e-7)
+
+
 def test_full_size_mass_conservation(api):
     """Config 2 (HII_DIM=256, DIM=512): size-independent properties.
     mean(delta) = 0 (mass conservation of the CIC deposit), delta >= -1, zero-mean velocity."""
