@@ -13,7 +13,8 @@ import numpy as np
 S = importlib.import_module("21cmfast_amd.structs")
 W = importlib.import_module("21cmfast_amd.workloads")
 
-N_ION = 32      # IonizeBox cases
+N_ION = 32      # IonizeBox cases (rocFFT path on the device)
+N_ION_NATIVE = 64  # the same at the smallest size of the native split-layout transform
 IC_DIM, IC_HII = 32, 16
 FILTER_N, FILTER_LEN = 32, 64.0
 FILTER_RADII = {0: 5.0, 1: 5.0, 2: 5.0, 3: 5.0, 4: 5.0}
@@ -21,21 +22,21 @@ FILTER_PARAM = {0: 0.0, 1: 0.0, 2: 0.0, 3: 8.0, 4: 7.5}
 
 
 # ---- IonizeBox -----------------------------------------------------------------------------
-def ionize_inputs():
-    density = W.density_field_numpy(N_ION, seed=2024, sigma=0.45)
+def ionize_inputs(n=N_ION):
+    density = W.density_field_numpy(n, seed=2024, sigma=0.45)
     return {"density": density, "n_ion": W.nion_from_density(density).astype(np.float32)}
 
 
-def ionize_spec(kind):
+def ionize_spec(kind, n=N_ION):
     """kind: 'lagrangian' (two filtered grids, top-hat + exp-MFP) or 'erfc' (CONST-ION-EFF)."""
     mode = W.FCOLL_STARS if kind == "lagrangian" else W.FCOLL_ERFC
-    return W.ionize_spec(N_ION, mode=mode, r_bubble_max=14.0)
+    return W.ionize_spec(n, mode=mode, r_bubble_max=14.0)
 
 
 def ionize_outputs(run, kind, inp):
     """run(spec, density, n_ion_or_None, need_nion) -> dict with neutral_fraction, z_reion,
     kinetic_temperature, report (need_nion: the Eulerian models fill unnormalised_nion)"""
-    spec = ionize_spec(kind)
+    spec = ionize_spec(kind, inp["density"].shape[0])
     lag = kind == "lagrangian"
     out = run(spec, inp["density"], inp["n_ion"] if lag else None, not lag)
     n = spec.n_radii
@@ -140,4 +141,23 @@ def tsfilter_outputs(fill_rbox, annular, inp):
         out[f"shell_{name}_sfr"] = np.asarray(a["outputs"][0])
         out[f"shell_{name}_xray"] = np.asarray(a["outputs"][1])
         out[f"shell_{name}_avgs"] = np.stack([a["u_avg"], a["f_avg"]])
+    return out
+
+
+# ---- PerturbedField known-answer geometry (tests/test_perturb.py:52-135 of the reference) ------
+def perturb_roll_outputs(perturb_grids):
+    """perturb_grids(spec, ics) -> dict(density, velocity_z ...) for the one-cell-displacement
+    fake ICs of the reference's test, algorithms 2LPT / Zel'dovich / linear."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import test_oracle_perturb as T
+
+    out = {}
+    for algorithm in (2, 1, 0):
+        ics = T.fake_ics(algorithm)
+        res = perturb_grids(T.perturb_spec(algorithm), ics)
+        out[f"density_alg{algorithm}"] = np.asarray(res["density"])
+        out[f"expected_alg{algorithm}"] = T.expected_density(ics, algorithm).astype(np.float32)
     return out

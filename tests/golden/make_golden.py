@@ -27,6 +27,11 @@ def main():
     for kind in ("lagrangian", "erfc"):
         out = cases.ionize_outputs(lambda s, d, n, nn: oracle.ionize_grids(s, d, n, need_nion=nn), kind, inp)
         np.savez_compressed(HERE / f"ionize_{kind}_{cases.N_ION}.npz", **inp, **out)
+    inp64 = cases.ionize_inputs(cases.N_ION_NATIVE)
+    out64 = cases.ionize_outputs(lambda s, d, n, nn: oracle.ionize_grids(s, d, n, need_nion=nn),
+                                 "lagrangian", inp64)
+    np.savez_compressed(HERE / f"ionize_lagrangian_{cases.N_ION_NATIVE}.npz", **inp64, **out64)
+    np.savez_compressed(HERE / "perturb_roll.npz", **cases.perturb_roll_outputs(oracle.perturb_grids))
     np.savez_compressed(HERE / "filters_delta.npz", **cases.filter_outputs(oracle.filter_grid))
     hd = cases.ics_input()
     out = cases.ics_perturb_outputs(oracle.new_ics_arrays, oracle.ics_grids, oracle.perturb_grids, hd)

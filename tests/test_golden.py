@@ -38,6 +38,25 @@ def test_oracle_ionize_matches_golden(oracle, kind):
     assert 0.05 < (gold["neutral_fraction"] == 0).mean() < 0.95
 
 
+def test_oracle_ionize_native_size_matches_golden(oracle):
+    gold = np.load(GOLDEN / f"ionize_lagrangian_{cases.N_ION_NATIVE}.npz")
+    inp = {"density": gold["density"], "n_ion": gold["n_ion"]}
+    out = cases.ionize_outputs(lambda s, d, n, nn: oracle.ionize_grids(s, d, n, need_nion=nn),
+                               "lagrangian", inp)
+    check_ionize(out, gold, flag_tol=1e-5, rtol=1e-6, atol=1e-8)
+    assert 0.05 < (gold["neutral_fraction"] == 0).mean() < 0.95
+
+
+def test_oracle_perturb_roll_matches_golden(oracle):
+    """The reference's one-cell-displacement test: the fixture holds the oracle's densities next
+    to the analytic answer (rolled IC density x growth factor, atol 1e-3)."""
+    gold = np.load(GOLDEN / "perturb_roll.npz")
+    out = cases.perturb_roll_outputs(oracle.perturb_grids)
+    for alg in (2, 1, 0):
+        np.testing.assert_allclose(out[f"density_alg{alg}"], gold[f"density_alg{alg}"], atol=1e-6)
+        np.testing.assert_allclose(gold[f"density_alg{alg}"], gold[f"expected_alg{alg}"], atol=1e-3)
+
+
 def test_oracle_filters_match_golden(oracle):
     gold = np.load(GOLDEN / "filters_delta.npz")
     out = cases.filter_outputs(oracle.filter_grid)

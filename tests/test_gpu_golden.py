@@ -36,6 +36,28 @@ def test_hip_ionize_matches_golden(api, kind):
     check_ionize(out, gold, flag_tol=2e-4, rtol=1e-4, atol=5e-6)
 
 
+def test_hip_ionize_native_size_matches_golden(api):
+    """64^3: the smallest box on the native split-layout passes and the fused pass Z."""
+    gold = np.load(GOLDEN / f"ionize_lagrangian_{cases.N_ION_NATIVE}.npz")
+    inp = {"density": gold["density"], "n_ion": gold["n_ion"]}
+
+    def run(spec, density, n_ion, need_nion):
+        buf, box, rep = api.ionize_grids(spec, density, n_ion)
+        return {"neutral_fraction": buf.neutral_fraction, "z_reion": buf.z_reion,
+                "kinetic_temperature": buf.kinetic_temperature, "report": rep}
+
+    out = cases.ionize_outputs(run, "lagrangian", inp)
+    check_ionize(out, gold, flag_tol=2e-4, rtol=1e-4, atol=5e-6)
+
+
+def test_hip_perturb_roll_matches_golden(api):
+    gold = np.load(GOLDEN / "perturb_roll.npz")
+    out = cases.perturb_roll_outputs(api.perturb_grids)
+    for alg in (2, 1, 0):
+        np.testing.assert_allclose(out[f"density_alg{alg}"], gold[f"density_alg{alg}"], atol=2e-5)
+        np.testing.assert_allclose(out[f"density_alg{alg}"], gold[f"expected_alg{alg}"], atol=1e-3)
+
+
 def test_hip_filters_match_golden(api):
     gold = np.load(GOLDEN / "filters_delta.npz")
     out = cases.filter_outputs(lambda box, L, ft, R, Rp: api.filter_grid(box, L, ft, R, Rp))
