@@ -173,8 +173,13 @@ def main():
         import torch.distributed as dist
 
         if args.force_shard and "RANK" not in os.environ:
+            import socket
+
+            with socket.socket() as sock:  # any free port: this is a one-rank group
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("MASTER_PORT", str(port))
             dist.init_process_group("nccl", rank=0, world_size=1,
                                     device_id=torch.device("cuda", local_rank))
         else:
