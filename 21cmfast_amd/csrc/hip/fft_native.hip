@@ -1486,7 +1486,10 @@ int launch_z_c2r(const ZPassArgs &a, long nlines, hipStream_t stream) {
 // wave-synchronous -- LDS operations of a wave execute in order -- so there is no workgroup
 // barrier in the transform, and a line costs ~80 LDS operations per lane x 16 lanes against
 // ~2500 lane-operations in the tile version.
-constexpr int ZW_LINES = 16;  // lines per workgroup
+constexpr int ZW_LINES = 16;  // lines per workgroup with 16 lanes per line (P = 16)
+// P lanes own a line (P = 16: 512- and 1024-point lines; P = 8 with 16 points per lane: 256-point
+// lines); a 256-thread workgroup then holds 256 / P lines.
+constexpr int zw_lines(int P) { return kBlock / P; }
 
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1498,20 +1501,21 @@ __device__ __forceinline__ void wave_fence() {
 // In: x[a] = X[16 a + b] (a < A), xh = Re X[H].  Out: x[16 r + d] = z[(b + 16 r) + A d],
 // r < A / 16, d < 16.  L: this line's LDS region (A rows of 17), twH / twN:
 // exp(-2 pi i t / H) and exp(-2 pi i t / 2H), t < H.
-template <int A>
+template <int A, int P = 16>
 __device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, const float2 *twH,
                                          const float2 *twN, int b) {
-    constexpr int H = 16 * A;
+    static_assert(A % P == 0, "rows per lane");
+    constexpr int H = P * A;
 #pragma unroll
-    for (int a = 0; a < A; a++) L[a * 17 + b] = x[a];
+    for (int a = 0; a < A; a++) L[a * (P + 1) + b] = x[a];
     wave_fence();
     // Z[k] = E + i O, E = X[k] + conj(X[H-k]), O = (X[k] - conj(X[H-k])) exp(+2 pi i k / 2H)
 #pragma unroll
     for (int a = 0; a < A; a++) {
-        const int k = 16 * a + b;
+        const int k = P * a + b;
         const int kp = (H - k) & (H - 1);  // k = 0 pairs with the Nyquist value below
         const float2 Xk = x[a];
-        float2 B = L[(kp >> 4) * 17 + (kp & 15)];
+        float2 B = L[(kp / P) * (P + 1) + (kp % P)];
         if (k == 0) B = make_float2(xh, 0.f);
         const float2 E = make_float2(Xk.x + B.x, Xk.y - B.y);
         const float2 D = make_float2(Xk.x - B.x, Xk.y + B.y);
@@ -1526,27 +1530,27 @@ __device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, co
     for (int c = 0; c < A; c++) {
         float2 w = twH[c * b];
         w.y = -w.y;
-        L[c * 17 + b] = (c == 0) ? x[0] : cmul(x[c], w);
+        L[c * (P + 1) + b] = (c == 0) ? x[0] : cmul(x[c], w);
     }
     wave_fence();
 #pragma unroll
-    for (int r = 0; r < A / 16; r++) {  // this lane's rows c = b + 16 r
+    for (int r = 0; r < A / P; r++) {  // this lane's rows c = b + P r
 #pragma unroll
-        for (int bb = 0; bb < 16; bb++) x[16 * r + bb] = L[(b + 16 * r) * 17 + bb];
-        Dft<16, +1>::run(x + 16 * r);  // over b
+        for (int bb = 0; bb < P; bb++) x[P * r + bb] = L[(b + P * r) * (P + 1) + bb];
+        Dft<P, +1>::run(x + P * r);  // over b
     }
 }
 
 // Fused pass Z + f_coll sum + barrier, wave-level transform (A = 16 or 32, see wave_c2r).
 // TS: a third grid, the filtered x_e of the spin-temperature run, enters the barrier as
 // f_coll zeta > 1 - x_e (IonisationBox.c:1118, clip of :1091-1094).
-template <int A, bool TS>
+template <int A, bool TS, int P = 16>
 __global__ void __launch_bounds__(kBlock)
 zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                  const float2 *__restrict__ twN_global) {
-    constexpr int H = 16 * A, NZ = 2 * H;
-    constexpr int LINE_LDS = A * 17 + 4;  // float2 per line region (17-padded rows + skew)
-    __shared__ float2 lines[ZW_LINES * LINE_LDS];
+    constexpr int H = P * A, NZ = 2 * H, ZWL = zw_lines(P);
+    constexpr int LINE_LDS = A * (P + 1) + 4;  // float2 per line region (padded rows + skew)
+    __shared__ float2 lines[ZWL * LINE_LDS];
     __shared__ float2 twH[H], twN[H];
     __shared__ double red[kBlock / 64];
     for (int t = threadIdx.x; t < H; t += kBlock) {
@@ -1554,42 +1558,43 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         twN[t] = twN_global[t];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, b = lane & 15;
-    const int lw = wave * 4 + g;
-    const long line = (long)blockIdx.x * ZW_LINES + lw;
+    const int g = lane / P, b = lane % P;
+    const int lw = wave * (64 / P) + g;
+    const long line = (long)blockIdx.x * ZWL + lw;
     float2 *L = lines + lw * LINE_LDS;
     const float2 *dm = a.d_main + line * H, *sm = a.s_main + line * H;
     float2 xd[A], xs[A];
 #pragma unroll
-    for (int q = 0; q < A; q++) xd[q] = dm[16 * q + b];
+    for (int q = 0; q < A; q++) xd[q] = dm[P * q + b];
     if (A == 16) {  // both grids in flight from the start; A = 32 has no registers to spare
 #pragma unroll
-        for (int q = 0; q < A; q++) xs[q] = sm[16 * q + b];
+        for (int q = 0; q < A; q++) xs[q] = sm[P * q + b];
     }
     const long lline = logical_line(line, a.ny, a.lb);
     const float dh = a.d_nyq[lline].x, sh = a.s_nyq[lline].x;
     unsigned char *mrow = a.first_cross + lline * NZ;
-    uchar2 old[A == 16 ? 16 : 1];
+    uchar2 old[A == 16 ? A : 1];
     if (A == 16) {  // mask rows early too
 #pragma unroll
-        for (int d = 0; d < 16; d++) old[d] = reinterpret_cast<const uchar2 *>(mrow)[b + 16 * d];
+        for (int q = 0; q < A; q++)
+            old[q] = reinterpret_cast<const uchar2 *>(mrow)[(b + P * (q / P)) + A * (q % P)];
     }
     __syncthreads();  // twiddle tables
-    wave_c2r<A>(xd, dh, L, twH, twN, b);
+    wave_c2r<A, P>(xd, dh, L, twH, twN, b);
     if (A != 16) {
 #pragma unroll
-        for (int q = 0; q < A; q++) xs[q] = sm[16 * q + b];
+        for (int q = 0; q < A; q++) xs[q] = sm[P * q + b];
     }
     wave_fence();
-    wave_c2r<A>(xs, sh, L, twH, twN, b);
+    wave_c2r<A, P>(xs, sh, L, twH, twN, b);
     float2 xx[TS ? A : 1];
     if constexpr (TS) {
         const float2 *xm = a.x_main + line * H;
 #pragma unroll
-        for (int q = 0; q < A; q++) xx[q] = xm[16 * q + b];
+        for (int q = 0; q < A; q++) xx[q] = xm[P * q + b];
         const float xh = a.x_nyq[lline].x;
         wave_fence();
-        wave_c2r<A>(xx, xh, L, twH, twN, b);
+        wave_c2r<A, P>(xx, xh, L, twH, twN, b);
     }
 
     const double floor_lhs = a.f_limit * a.ion_eff;  // the floored f_coll zeta
@@ -1598,8 +1603,8 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     double acc = 0.;
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        // x[16 r + d] holds the cells (2j, 2j + 1), j = (b + 16 r) + A d
-        const int j = (b + 16 * (q / 16)) + A * (q % 16);
+        // x[P r + d] holds the cells (2j, 2j + 1), j = (b + P r) + A d
+        const int j = (b + P * (q / P)) + A * (q % P);
         const float s0 = fmaxf(xs[q].x, 0.f), s1 = fmaxf(xs[q].y, 0.f);
         acc += (double)s0;
         acc += (double)s1;
@@ -1616,7 +1621,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         }
         const bool i0 = floor_ionises || f0 || ((double)s0 * a.ion_eff > D0);
         const bool i1 = floor_ionises || f1 || ((double)s1 * a.ion_eff > D1);
-        uchar2 m = (A == 16) ? old[q % 16] : reinterpret_cast<const uchar2 *>(mrow)[j];
+        uchar2 m = (A == 16) ? old[A == 16 ? q : 0] : reinterpret_cast<const uchar2 *>(mrow)[j];
         if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
         if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
         reinterpret_cast<uchar2 *>(mrow)[j] = m;
@@ -1637,36 +1642,36 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
 // (EPI 0 store / divide, 1 store + extrema, 2 closed-form f_coll + sum, 3 floor-scale store +
 // statistics).  Sixteen lines per workgroup like the tile kernel, so the partial arrays have the
 // same length either way.
-template <int A, int EPI>
+template <int A, int EPI, int P = 16>
 __global__ void __launch_bounds__(kBlock)
 zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
               const float2 *__restrict__ twN_global) {
-    constexpr int H = 16 * A, NZ = 2 * H;
-    constexpr int LINE_LDS = A * 17 + 4;
-    __shared__ float2 lines[ZW_LINES * LINE_LDS];
+    constexpr int H = P * A, NZ = 2 * H, ZWL = zw_lines(P);
+    constexpr int LINE_LDS = A * (P + 1) + 4;
+    __shared__ float2 lines[ZWL * LINE_LDS];
     __shared__ float2 twH[H], twN[H];
     for (int t = threadIdx.x; t < H; t += kBlock) {
         twH[t] = twH_global[t];
         twN[t] = twN_global[t];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, b = lane & 15;
-    const int lw = wave * 4 + g;
-    const long line = (long)blockIdx.x * ZW_LINES + lw;
+    const int g = lane / P, b = lane % P;
+    const int lw = wave * (64 / P) + g;
+    const long line = (long)blockIdx.x * ZWL + lw;
     float2 *L = lines + lw * LINE_LDS;
     const float2 *src = a.main + line * H;
     float2 x[A];
 #pragma unroll
-    for (int q = 0; q < A; q++) x[q] = src[16 * q + b];
+    for (int q = 0; q < A; q++) x[q] = src[P * q + b];
     const long lline = logical_line(line, a.ny, a.lb);
     const float xh = a.nyq[lline].x;
     __syncthreads();  // twiddle tables
-    wave_c2r<A>(x, xh, L, twH, twN, b);
+    wave_c2r<A, P>(x, xh, L, twH, twN, b);
 
     double acc0 = 0., acc1 = 0., acc2 = 0.;
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        const int j = (b + 16 * (q / 16)) + A * (q % 16);  // cells (2j, 2j + 1)
+        const int j = (b + P * (q / P)) + A * (q % P);  // cells (2j, 2j + 1)
         float2 v = x[q];
         if (a.out_scale != 1.0f) {
             v.x *= a.out_scale;
@@ -1739,31 +1744,32 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 // registers, the twiddle exp(-2 pi i c b'/H), one transposition through the 17-padded LDS
 // region, a DFT over the A values of c, then the Hermitian post-processing whose partner
 // Zf[H-k] comes back from the line's LDS copy.  Out: x[a] = X[16 a + b] (k < H), *xh = X[H].
-template <int A>
+template <int A, int P = 16>
 __device__ __forceinline__ void wave_r2c(float2 (&x)[A], float *xh, float2 *L, const float2 *twH,
                                          const float2 *twN, int b) {
-    constexpr int H = 16 * A;
+    static_assert(A % P == 0, "rows per lane");
+    constexpr int H = P * A;
 #pragma unroll
-    for (int r = 0; r < A / 16; r++) {
-        Dft<16, -1>::run(x + 16 * r);  // over d: Y_c[b'], c = b + 16 r
-        const int c = b + 16 * r;
+    for (int r = 0; r < A / P; r++) {
+        Dft<P, -1>::run(x + P * r);  // over d: Y_c[b'], c = b + P r
+        const int c = b + P * r;
 #pragma unroll
-        for (int bb = 0; bb < 16; bb++)
-            L[c * 17 + bb] = (bb == 0) ? x[16 * r] : cmul(x[16 * r + bb], twH[c * bb]);
+        for (int bb = 0; bb < P; bb++)
+            L[c * (P + 1) + bb] = (bb == 0) ? x[P * r] : cmul(x[P * r + bb], twH[c * bb]);
     }
     wave_fence();
 #pragma unroll
-    for (int c = 0; c < A; c++) x[c] = L[c * 17 + b];
-    Dft<A, -1>::run(x);  // over c: Zf[16 a + b]
+    for (int c = 0; c < A; c++) x[c] = L[c * (P + 1) + b];
+    Dft<A, -1>::run(x);  // over c: Zf[P a + b]
     wave_fence();        // the column reads are done before the region is overwritten
 #pragma unroll
-    for (int a = 0; a < A; a++) L[a * 17 + b] = x[a];
+    for (int a = 0; a < A; a++) L[a * (P + 1) + b] = x[a];
     wave_fence();
 #pragma unroll
     for (int a = 0; a < A; a++) {
-        const int k = 16 * a + b;
+        const int k = P * a + b;
         const int kp = (H - k) & (H - 1);
-        const float2 Z = x[a], B = L[(kp >> 4) * 17 + (kp & 15)];
+        const float2 Z = x[a], B = L[(kp / P) * (P + 1) + (kp % P)];
         if (k == 0) {
             x[a] = make_float2(Z.x + Z.y, 0.f);
             *xh = Z.x - Z.y;
@@ -1776,22 +1782,22 @@ __device__ __forceinline__ void wave_r2c(float2 (&x)[A], float *xh, float2 *L, c
     }
 }
 
-template <int A>
+template <int A, int P = 16>
 __global__ void __launch_bounds__(kBlock)
 zw_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
               const float2 *__restrict__ twN_global) {
-    constexpr int H = 16 * A;
-    constexpr int LINE_LDS = A * 17 + 4;
-    __shared__ float2 lines[ZW_LINES * LINE_LDS];
+    constexpr int H = P * A, ZWL = zw_lines(P);
+    constexpr int LINE_LDS = A * (P + 1) + 4;
+    __shared__ float2 lines[ZWL * LINE_LDS];
     __shared__ float2 twH[H], twN[H];
     for (int t = threadIdx.x; t < H; t += kBlock) {
         twH[t] = twH_global[t];
         twN[t] = twN_global[t];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, b = lane & 15;
-    const int lw = wave * 4 + g;
-    const long line = (long)blockIdx.x * ZW_LINES + lw;
+    const int g = lane / P, b = lane % P;
+    const int lw = wave * (64 / P) + g;
+    const long line = (long)blockIdx.x * ZWL + lw;
     const long lline = logical_line(line, a.ny, a.lb);
     float2 *L = lines + lw * LINE_LDS;
     const float2 *src = reinterpret_cast<const float2 *>(a.in + lline * a.in_zstride);
@@ -1799,7 +1805,7 @@ zw_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
     float2 x[A];
 #pragma unroll
     for (int q = 0; q < A; q++) {
-        const int j = (b + 16 * (q / 16)) + A * (q % 16);
+        const int j = (b + P * (q / P)) + A * (q % P);
         float2 v = src[j];
         if (clip) {
             v.x = (float)fmax(fmin((double)v.x * a.factor, a.hi), a.lo);
@@ -1812,10 +1818,10 @@ zw_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
     }
     __syncthreads();  // twiddle tables
     float xh = 0.f;
-    wave_r2c<A>(x, &xh, L, twH, twN, b);
+    wave_r2c<A, P>(x, &xh, L, twH, twN, b);
     float2 *dst = a.main + line * H;
 #pragma unroll
-    for (int q = 0; q < A; q++) dst[16 * q + b] = x[q];
+    for (int q = 0; q < A; q++) dst[P * q + b] = x[q];
     if (b == 0) a.nyq[lline] = make_float2(xh, 0.f);
 }
 
@@ -1826,6 +1832,13 @@ bool zw_enabled() {
         cached = (e && e[0] == 't') ? 0 : 1;  // C21CM_ZPASS=tile selects the tile version
     }
     return cached == 1;
+}
+
+// lines per workgroup of the wave-level kernels at this z-line length (0: not covered)
+int zw_lines_of(int nz, long nlines) {
+    if (!zw_enabled()) return 0;
+    const int l = (nz == 512 || nz == 1024) ? zw_lines(16) : (nz == 256 ? zw_lines(8) : 0);
+    return (l && nlines % l == 0) ? l : 0;
 }
 
 template <int NZ>
@@ -1850,26 +1863,33 @@ int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
 // *n_partials: how many workgroup partials of sum(stars) the launch wrote
 int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream, int *n_partials) {
     *n_partials = (int)(nlines / LZ_FUSED);
-    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0) {
+    if (const int zwl = zw_lines_of(nz, nlines)) {
         const float2 *twH = twiddles(nz / 2);
         const float2 *twN = twiddles(nz);
         if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
-        *n_partials = (int)(nlines / ZW_LINES);
-        const dim3 grid((unsigned)(nlines / ZW_LINES));
+        *n_partials = (int)(nlines / zwl);
+        const dim3 grid((unsigned)(nlines / zwl));
+#define ZW_FUSED(A, TS, P) \
+    hipLaunchKernelGGL((zw_ionise_kernel<A, TS, P>), grid, dim3(kBlock), 0, stream, a, twH, twN)
         if (a.x_main) {
-            if (nz == 512)
-                hipLaunchKernelGGL((zw_ionise_kernel<16, true>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+            if (nz == 256)
+                ZW_FUSED(16, true, 8);
+            else if (nz == 512)
+                ZW_FUSED(16, true, 16);
             else
-                hipLaunchKernelGGL((zw_ionise_kernel<32, true>), grid, dim3(kBlock), 0, stream, a, twH, twN);
-        } else if (nz == 512)
-            hipLaunchKernelGGL((zw_ionise_kernel<16, false>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+                ZW_FUSED(32, true, 16);
+        } else if (nz == 256)
+            ZW_FUSED(16, false, 8);
+        else if (nz == 512)
+            ZW_FUSED(16, false, 16);
         else
-            hipLaunchKernelGGL((zw_ionise_kernel<32, false>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+            ZW_FUSED(32, false, 16);
+#undef ZW_FUSED
         LAUNCH_CHECK();
         return 0;
     }
     if (a.x_main) {
-        c21hip_set_error("fused pass Z with an x_e grid needs 512- or 1024-point z-lines");
+        c21hip_set_error("fused pass Z with an x_e grid needs 256-, 512- or 1024-point z-lines");
         return C21CM_VALUE_ERROR;
     }
     switch (nz) {
@@ -1904,16 +1924,17 @@ int launch_z_r2c(const ZFwdArgs &a, long nlines, hipStream_t stream) {
 }
 
 int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
-    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0 &&
-        a.in_zstride % 2 == 0) {
+    if (const int zwl = (a.in_zstride % 2 == 0) ? zw_lines_of(nz, nlines) : 0) {
         const float2 *twH = twiddles(nz / 2);
         const float2 *twN = twiddles(nz);
         if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
-        const dim3 grid((unsigned)(nlines / ZW_LINES));
-        if (nz == 512)
-            hipLaunchKernelGGL(zw_r2c_kernel<16>, grid, dim3(kBlock), 0, stream, a, twH, twN);
+        const dim3 grid((unsigned)(nlines / zwl));
+        if (nz == 256)
+            hipLaunchKernelGGL((zw_r2c_kernel<16, 8>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+        else if (nz == 512)
+            hipLaunchKernelGGL((zw_r2c_kernel<16, 16>), grid, dim3(kBlock), 0, stream, a, twH, twN);
         else
-            hipLaunchKernelGGL(zw_r2c_kernel<32>, grid, dim3(kBlock), 0, stream, a, twH, twN);
+            hipLaunchKernelGGL((zw_r2c_kernel<32, 16>), grid, dim3(kBlock), 0, stream, a, twH, twN);
         LAUNCH_CHECK();
         return 0;
     }
@@ -1932,16 +1953,18 @@ int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
 
 template <int EPI = 0>
 int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) {
-    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0 &&
-        (a.out_zstride % 2 == 0)) {
+    // (partial arrays of the EPI variants are sized for 16 lines per workgroup: P = 16 only)
+    if (const int zwl = (a.out_zstride % 2 == 0 && (EPI == 0 || nz != 256)) ? zw_lines_of(nz, nlines) : 0) {
         const float2 *twH = twiddles(nz / 2);
         const float2 *twN = twiddles(nz);
         if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
-        const dim3 grid((unsigned)(nlines / ZW_LINES));
-        if (nz == 512)
-            hipLaunchKernelGGL((zw_c2r_kernel<16, EPI>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+        const dim3 grid((unsigned)(nlines / zwl));
+        if (nz == 256)
+            hipLaunchKernelGGL((zw_c2r_kernel<16, EPI, 8>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+        else if (nz == 512)
+            hipLaunchKernelGGL((zw_c2r_kernel<16, EPI, 16>), grid, dim3(kBlock), 0, stream, a, twH, twN);
         else
-            hipLaunchKernelGGL((zw_c2r_kernel<32, EPI>), grid, dim3(kBlock), 0, stream, a, twH, twN);
+            hipLaunchKernelGGL((zw_c2r_kernel<32, EPI, 16>), grid, dim3(kBlock), 0, stream, a, twH, twN);
         LAUNCH_CHECK();
         return 0;
     }
@@ -2460,7 +2483,7 @@ extern "C" int c21hip_split_z_ionise_stars_xe(const float *delta_work, const flo
 
 // 1: the fused pass Z can take an x_e grid at this z-line length
 extern "C" int c21hip_z_ionise_xe_supported(int nx, int ny, int nz) {
-    return (nz == 512 || nz == 1024) && zw_enabled() && ((long)nx * ny) % ZW_LINES == 0;
+    return zw_lines_of(nz, (long)nx * ny) != 0;
 }
 
 // Passes X, Y of ONE grid with window a of the tables built for a two-grid radius
@@ -2522,8 +2545,7 @@ extern "C" int c21hip_batched_stats(const double *partials, long stride, int nb,
 // workgroup partials the fused pass Z writes for an nx x ny x nz grid
 extern "C" int c21hip_z_ionise_partials(int nx, int ny, int nz) {
     const long nlines = (long)nx * ny;
-    if ((nz == 512 || nz == 1024) && zw_enabled() && nlines % ZW_LINES == 0)
-        return (int)(nlines / ZW_LINES);
+    if (const int zwl = zw_lines_of(nz, nlines)) return (int)(nlines / zwl);
     return (int)(nlines / LZ_FUSED);
 }
 

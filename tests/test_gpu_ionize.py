@@ -101,7 +101,7 @@ def test_long_lines_non_cubic_parity(api, oracle):
     oracle.set_threads(16)
 
 
-@pytest.mark.parametrize("zpass", ["wave", "tile", "wave1024"])
+@pytest.mark.parametrize("zpass", ["wave", "tile", "wave1024", "wave256"])
 def test_512_point_z_lines_parity(api, oracle, zpass, monkeypatch):
     """The benchmark's z-line length (512 points: the wave-level fused pass Z, or the tile version
     with C21CM_ZPASS=tile) on a 64 x 64 x 512 box the oracle finishes in seconds; and the
@@ -119,7 +119,7 @@ def test_512_point_z_lines_parity(api, oracle, zpass, monkeypatch):
                              env={**__import__("os").environ, "C21CM_ZPASS": "tile"})
         assert "OK-512" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
         return
-    check_512_lines(api, oracle, *((64, 1024) if zpass == "wave1024" else (64, 512)))
+    check_512_lines(api, oracle, *{"wave1024": (64, 1024), "wave256": (64, 256)}.get(zpass, (64, 512)))
 
 
 def check_512_lines(api, oracle, n=64, nz=512):
@@ -155,7 +155,7 @@ def _install_table(spec):
 
 
 @pytest.mark.parametrize("mode", ["erfc", "table", "stars_ts", "stars_ts_prev"])
-@pytest.mark.parametrize("nz", [512, 1024])
+@pytest.mark.parametrize("nz", [256, 512, 1024])
 def test_long_z_lines_plain_pass_parity(api, oracle, mode, nz):
     """The single-grid pass Z on 512- and 1024-point lines (wave-level kernel with the erfc,
     extrema and plain-store epilogues) on 64 x 64 x nz boxes."""
