@@ -1419,7 +1419,8 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
     const int n_work = geo_items(a.g0) + (a.n_geo > 1 ? geo_items(a.g1) : 0);
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
     int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
-    const int by_waves = (LineThreads<N, FMODE>::value >= 512) ? 1 : 2;
+    // lines of 256 points and fewer leave LDS and registers for a second workgroup per CU (2 %)
+    const int by_waves = (LineThreads<N, FMODE>::value >= 512 && N > 256) ? 1 : 2;
     if (per_cu > by_waves) per_cu = by_waves;
     int nblocks = 256 * per_cu;
     if (nblocks > n_work) nblocks = n_work;
