@@ -44,9 +44,17 @@
 namespace {
 constexpr int kBlock = 256;
 constexpr int TZ = 16;  // columns per tile (128 B of float2) for lines up to 512 points
-// 1024-point lines use 8 columns (64-byte row segments): a 16-column tile is 128 KB, and with
-// 1024 threads and the 128-VGPR budget that implies the kernel spilled 300-600 bytes per lane
-constexpr int line_tile_cols(int n) { return n >= 1024 ? 8 : TZ; }
+// 1024-point lines: a 16-column tile is 128 KB of LDS, which fits, but a direct 1024-point
+// Stockham plan holds twice the values per thread between its LDS stages and spills.  The line
+// transform is split instead (line_fft): one in-place radix-2 decimation-in-frequency stage, two
+// 512-point transforms of the halves, and the even/odd interleave folded into the row index of
+// the store; one register set instead of two keeps the kernel inside 256 VGPRs.
+constexpr int line_tile_cols(int n) { return TZ; }
+// LDS row that holds output index g of a line after line_fft
+template <int N>
+__device__ __forceinline__ int fft_out_row(int g) {
+    return (N >= 1024) ? ((g & 1) ? N / 2 + (g >> 1) : (g >> 1)) : g;
+}
 
 // x-blocked split layout.  The main block is stored as [x / XB][y][x % XB][k_z] with
 // XB = 2^xb_log2(nx): 1 (the plain [x][y][k_z]) up to 512-point x-lines, 16 for 1024.  At 1024^3 the
@@ -275,6 +283,31 @@ __device__ __forceinline__ void fft_tile(float2 *tile, const float2 *tw) {
     }
     if (REM == 1) stockham_stage<N, COLS, ROW, 2, SIGN, true, THREADS>(tile, tw, log2s);
     if (REM == 2) stockham_stage<N, COLS, ROW, 4, SIGN, true, THREADS>(tile, tw, log2s);
+}
+
+// Line transform of a whole tile.  N < 1024: the Stockham plan, natural order out.  N = 1024:
+//   a[k] = x[k] + x[k+512],  b[k] = (x[k] - x[k+512]) w^k   (in place, rows k and k + 512)
+//   X[2m] = FFT512(a)[m] -> row m,   X[2m+1] = FFT512(b)[m] -> row 512 + m
+// (fft_out_row gives the row of an output index).  tw: exp(-2 pi i t / N); tw_half: the
+// 512-point table exp(-2 pi i t / 512) = tw[2 t], only read when N = 1024.
+template <int N, int COLS, int SIGN, int THREADS>
+__device__ __forceinline__ void line_fft(float2 *tile, const float2 *tw, const float2 *tw_half) {
+    if constexpr (N < 1024) {
+        fft_tile<N, COLS, COLS, SIGN, THREADS>(tile, tw);
+    } else {
+        constexpr int HN = N / 2;
+        for (int i = threadIdx.x; i < HN * COLS; i += THREADS) {
+            const int col = i % COLS, k = i / COLS;
+            const float2 x0 = tile[k * COLS + col], x1 = tile[(k + HN) * COLS + col];
+            float2 w = tw[k];
+            if (SIGN > 0) w.y = -w.y;
+            tile[k * COLS + col] = cadd(x0, x1);
+            tile[(k + HN) * COLS + col] = cmul(csub(x0, x1), w);
+        }
+        __syncthreads();
+        fft_tile<HN, COLS, COLS, SIGN, THREADS>(tile, tw_half);
+        fft_tile<HN, COLS, COLS, SIGN, THREADS>(tile + HN * COLS, tw_half);
+    }
 }
 
 // ------------------------------------------------------------------ window functions
@@ -637,7 +670,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
     float2 *tw = tile + N * TZ;                          // [N]
+    float2 *tw_half = tw + N;                            // [N/2], N = 1024 only
     for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
+    if (N >= 1024)
+        for (int t = threadIdx.x; t < N / 2; t += kBlock) tw_half[t] = tw_global[2 * t];
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
     const int r0 = threadIdx.x / CPAIR, c4 = threadIdx.x % CPAIR;
@@ -697,7 +733,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // Two register sets: while tile t is transformed in LDS, the loads of tiles t+1 AND t+2
     // are in flight (a single set left HBM idle between a tile's arrival and the issue of the
     // next loads: 4.5 TB/s against the 6.3 TB/s a plain copy reaches).
-    constexpr bool TWO_SETS = true;
+    constexpr bool TWO_SETS = (N < 1024);
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
@@ -850,13 +886,13 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         if (FMODE == 3 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
         issue_loads(reg, refill.it, refill.m);
 
-        fft_tile<N, TZ, TZ, SIGN, kBlock>(tile, tw);
+        line_fft<N, TZ, SIGN, kBlock>(tile, tw, tw_half);
         // ---- store
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
             const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
-            float4 v = *reinterpret_cast<const float4 *>(tile + row * TZ + 2 * c4);
+            float4 v = *reinterpret_cast<const float4 *>(tile + fft_out_row<N>(row) * TZ + 2 * c4);
             if (a.out_scale != 1.0f) {
                 v.x *= a.out_scale;
                 v.y *= a.out_scale;
@@ -928,12 +964,12 @@ main_done:
                     make_float4(e0.x, e0.y, e1.x, e1.y);
             }
             __syncthreads();
-            fft_tile<N, TZ, TZ, SIGN, kBlock>(tile, tw);
+            line_fft<N, TZ, SIGN, kBlock>(tile, tw, tw_half);
 #pragma unroll
             for (int u = 0; u < 2 * NP; u++) {
                 const int row_a = r0 + RSTEP * (u >> 1);
                 const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
-                float4 v = *reinterpret_cast<const float4 *>(tile + row * TZ + 2 * c4);
+                float4 v = *reinterpret_cast<const float4 *>(tile + fft_out_row<N>(row) * TZ + 2 * c4);
                 if (a.out_scale != 1.0f) {
                     v.x *= a.out_scale;
                     v.y *= a.out_scale;
@@ -1415,7 +1451,7 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
         return C21CM_MEMORY_ALLOC_ERROR;
     }
-    const size_t lds = sizeof(float2) * ((size_t)N * line_tile_cols(N) + N);
+    const size_t lds = sizeof(float2) * ((size_t)N * line_tile_cols(N) + N + (N >= 1024 ? N / 2 : 0));
     const int n_work = geo_items(a.g0) + (a.n_geo > 1 ? geo_items(a.g1) : 0);
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
     int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
