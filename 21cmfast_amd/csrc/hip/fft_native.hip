@@ -1862,6 +1862,153 @@ zw_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
     if (b == 0) a.nyq[lline] = make_float2(xh, 0.f);
 }
 
+// ---- 1024-point z-lines: three radix-8 stages across a whole wave -----------------------------
+// H = 512 = 8 x 8 x 8.  One wave owns a line, lane p holds X[64 a + p], a < 8: eight values per
+// grid instead of the 32 of the (A = 32, P = 16) scheme, whose radix-32 butterflies need all 256
+// VGPRs and run one wave per SIMD.  Three 8-point DFTs in registers, two transpositions through
+// the line's LDS region in between (plus the Hermitian pre-processing's partner exchange):
+//   k = 64 a + p,  j = j0 + 8 j1 + 64 j2
+//   stage 1 (lane p):          Y_p[j0]      = sum_a X[64 a + p] w64^(a j0)        x w^(j0 p)
+//   stage 2 (lane 8 j0 + c):   V_j0,c[j1]   = sum_b T_j0[8 b + c] w8^(b j1)       x w^(8 c j1)
+//   stage 3 (lane j0 + 8 j1):  z[j0 + 8 j1 + 64 j2] = sum_c V_j0,c[j1] w8^(c j2)
+// so lane p ends with z[p + 64 j2], j2 < 8: natural order, 512-byte runs per j2.
+// In: x[a] = X[64 a + p], xh = Re X[H].  L: 576 float2 of LDS for this line.
+__device__ __forceinline__ void wave3_c2r(float2 (&x)[8], float xh, float2 *L, const float2 *twH,
+                                          const float2 *twN, int p) {
+    constexpr int H = 512, M1 = 72, M2 = 9;
+#pragma unroll
+    for (int a = 0; a < 8; a++) L[a * M1 + p] = x[a];
+    wave_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const int k = 64 * a + p;
+        const int kp = (H - k) & (H - 1);
+        const float2 Xk = x[a];
+        float2 B = L[(kp >> 6) * M1 + (kp & 63)];
+        if (k == 0) B = make_float2(xh, 0.f);
+        const float2 E = make_float2(Xk.x + B.x, Xk.y - B.y);
+        const float2 D = make_float2(Xk.x - B.x, Xk.y + B.y);
+        float2 w = twN[k];
+        w.y = -w.y;
+        const float2 O = cmul(D, w);
+        x[a] = (k == 0) ? make_float2(Xk.x + xh, Xk.x - xh) : make_float2(E.x - O.y, E.y + O.x);
+    }
+    Dft<8, +1>::run(x);  // over a: Y_p[j0]
+    wave_fence();        // partner reads done
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0++) {
+        float2 w = twH[j0 * p];
+        w.y = -w.y;
+        L[j0 * M1 + p] = (j0 == 0) ? x[0] : cmul(x[j0], w);
+    }
+    wave_fence();
+    {
+        const int j0 = p >> 3, c = p & 7;
+#pragma unroll
+        for (int b = 0; b < 8; b++) x[b] = L[j0 * M1 + 8 * b + c];
+        Dft<8, +1>::run(x);  // over b: V_j0,c[j1]
+        wave_fence();
+#pragma unroll
+        for (int j1 = 0; j1 < 8; j1++) {
+            float2 w = twH[8 * c * j1];
+            w.y = -w.y;
+            L[p * M2 + j1] = (j1 == 0) ? x[0] : cmul(x[j1], w);
+        }
+    }
+    wave_fence();
+    {
+        const int j0 = p & 7, j1 = p >> 3;
+#pragma unroll
+        for (int c = 0; c < 8; c++) x[c] = L[(8 * j0 + c) * M2 + j1];
+        Dft<8, +1>::run(x);  // over c: z[p + 64 j2]
+    }
+}
+
+// Fused pass Z + f_coll sum + barrier for 1024-point z-lines on wave3_c2r: four lines per
+// workgroup, each lane ends with the cells (2j, 2j+1), j = p + 64 j2.
+template <bool TS>
+__global__ void __launch_bounds__(kBlock)
+zw3_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
+                  const float2 *__restrict__ twN_global) {
+    constexpr int H = 512, NZ = 1024, LINE_LDS = 576 + 8;
+    __shared__ float2 lines[(kBlock / 64) * LINE_LDS];
+    __shared__ float2 twH[H], twN[H];
+    __shared__ double red[kBlock / 64];
+    for (int t = threadIdx.x; t < H; t += kBlock) {
+        twH[t] = twH_global[t];
+        twN[t] = twN_global[t];
+    }
+    const int p = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long line = (long)blockIdx.x * (kBlock / 64) + wave;
+    float2 *L = lines + wave * LINE_LDS;
+    const float2 *dm = a.d_main + line * H, *sm = a.s_main + line * H;
+    float2 xd[8], xs[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) xd[q] = dm[64 * q + p];
+#pragma unroll
+    for (int q = 0; q < 8; q++) xs[q] = sm[64 * q + p];
+    const long lline = logical_line(line, a.ny, a.lb);
+    const float dh = a.d_nyq[lline].x, sh = a.s_nyq[lline].x;
+    unsigned char *mrow = a.first_cross + lline * NZ;
+    uchar2 old[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) old[q] = reinterpret_cast<const uchar2 *>(mrow)[p + 64 * q];
+    float2 xx[TS ? 8 : 1];
+    float xeh = 0.f;
+    if constexpr (TS) {
+        const float2 *xm = a.x_main + line * H;
+#pragma unroll
+        for (int q = 0; q < 8; q++) xx[q] = xm[64 * q + p];
+        xeh = a.x_nyq[lline].x;
+    }
+    __syncthreads();  // twiddle tables
+    wave3_c2r(xd, dh, L, twH, twN, p);
+    wave_fence();
+    wave3_c2r(xs, sh, L, twH, twN, p);
+    if constexpr (TS) {
+        wave_fence();
+        wave3_c2r(xx, xeh, L, twH, twN, p);
+    }
+    const double floor_lhs = a.f_limit * a.ion_eff;
+    const bool floor_ionises = !TS && a.mass_dep_zeta && (floor_lhs > 1.);
+    const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
+    double acc = 0.;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int j = p + 64 * q;
+        const float s0 = fmaxf(xs[q].x, 0.f), s1 = fmaxf(xs[q].y, 0.f);
+        acc += (double)s0;
+        acc += (double)s1;
+        double D0 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].x, dmin));
+        double D1 = a.rhocrit_omb * (1. + (double)fmaxf(xd[q].y, dmin));
+        bool f0 = false, f1 = false;
+        if constexpr (TS) {
+            const double n0 = 1. - (double)fminf(fmaxf(xx[q].x, 0.f), 0.999f);
+            const double n1 = 1. - (double)fminf(fmaxf(xx[q].y, 0.f), 0.999f);
+            f0 = a.mass_dep_zeta && floor_lhs > n0;
+            f1 = a.mass_dep_zeta && floor_lhs > n1;
+            D0 *= n0;
+            D1 *= n1;
+        }
+        const bool i0 = floor_ionises || f0 || ((double)s0 * a.ion_eff > D0);
+        const bool i1 = floor_ionises || f1 || ((double)s1 * a.ion_eff > D1);
+        uchar2 m = old[q];
+        if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
+        if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
+        reinterpret_cast<uchar2 *>(mrow)[j] = m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (p == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) sum += red[w];
+        a.partials[blockIdx.x] = sum;
+    }
+}
+
 bool zw_enabled() {
     static int cached = -1;
     if (cached < 0) {
@@ -1869,6 +2016,16 @@ bool zw_enabled() {
         cached = (e && e[0] == 't') ? 0 : 1;  // C21CM_ZPASS=tile selects the tile version
     }
     return cached == 1;
+}
+
+// 1024-point fused pass Z: the three-stage kernel (C21CM_ZPASS=wave32 keeps the A = 32 one)
+bool zw3_selected(int nz, long nlines) {
+    static int w32 = -1;
+    if (w32 < 0) {
+        const char *e = getenv("C21CM_ZPASS");
+        w32 = (e && e[0] == 'w') ? 1 : 0;
+    }
+    return nz == 1024 && zw_enabled() && !w32 && nlines % (kBlock / 64) == 0;
 }
 
 // lines per workgroup of the wave-level kernels at this z-line length (0: not covered)
@@ -1900,6 +2057,19 @@ int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
 // *n_partials: how many workgroup partials of sum(stars) the launch wrote
 int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream, int *n_partials) {
     *n_partials = (int)(nlines / LZ_FUSED);
+    if (zw3_selected(nz, nlines)) {  // 1024-point lines: three radix-8 stages per wave
+        const float2 *twH = twiddles(nz / 2);
+        const float2 *twN = twiddles(nz);
+        if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+        *n_partials = (int)(nlines / (kBlock / 64));
+        const dim3 grid((unsigned)(nlines / (kBlock / 64)));
+        if (a.x_main)
+            hipLaunchKernelGGL(zw3_ionise_kernel<true>, grid, dim3(kBlock), 0, stream, a, twH, twN);
+        else
+            hipLaunchKernelGGL(zw3_ionise_kernel<false>, grid, dim3(kBlock), 0, stream, a, twH, twN);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (const int zwl = zw_lines_of(nz, nlines)) {
         const float2 *twH = twiddles(nz / 2);
         const float2 *twN = twiddles(nz);
@@ -2582,6 +2752,7 @@ extern "C" int c21hip_batched_stats(const double *partials, long stride, int nb,
 // workgroup partials the fused pass Z writes for an nx x ny x nz grid
 extern "C" int c21hip_z_ionise_partials(int nx, int ny, int nz) {
     const long nlines = (long)nx * ny;
+    if (zw3_selected(nz, nlines)) return (int)(nlines / (kBlock / 64));
     if (const int zwl = zw_lines_of(nz, nlines)) return (int)(nlines / zwl);
     return (int)(nlines / LZ_FUSED);
 }
@@ -2660,7 +2831,7 @@ extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, fl
     float *real = (float *)c21hip_ws(60, nf * sizeof(float));
     float *real2 = (float *)c21hip_ws(63, nf * sizeof(float));
     unsigned char *mask = (unsigned char *)c21hip_ws(61, (size_t)n * n * n);
-    double *partials = (double *)c21hip_ws(62, ((size_t)n * n / 4 + 64) * sizeof(double));
+    double *partials = (double *)c21hip_ws(62, ((size_t)n * n / 2 + 128) * sizeof(double));
     if (!a || !b || !real || !real2 || !mask || !partials) return C21CM_MEMORY_ALLOC_ERROR;
     hipLaunchKernelGGL(pattern_fill_kernel, dim3(2048), dim3(kBlock), 0, stream, a, nf);
     hipLaunchKernelGGL(pattern_fill_kernel, dim3(2048), dim3(kBlock), 0, stream, b, nf);
@@ -2688,7 +2859,7 @@ extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, fl
         else if (kind == 5)  // pass X without a window (diagnostic)
             st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 0, stream_, 2);
         else if (kind == 2)
-            st = c21hip_split_z_ionise_stars(a, b, mask, partials, partials + nlines / LZ_FUSED + 40,
+            st = c21hip_split_z_ionise_stars(a, b, mask, partials, partials + nlines / 4 + 40,
                                              n, n, n, 5, 6.2e9, 1.0, 1, 1e-9, stream);
         else {
             ZPassArgs z{};

@@ -257,7 +257,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             return C21CM_MEMORY_ALLOC_ERROR;
     }
     {
-        size_t np = (size_t)c->nx * c->ny / 8;
+        size_t np = (size_t)c->nx * c->ny / 4; /* the most partials a pass-Z variant writes */
         np += np / 512 + 16; /* stage areas of the two-level reductions */
         if (np < C21HIP_PARTIALS) np = C21HIP_PARTIALS;
         c->partials = (double *)c21hip_ws(WS_PARTIALS, np * sizeof(double));
