@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--cpu-dim", type=int, default=192,
                     help="box size of the CPU-oracle sample (same radii count)")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo (host-staged) lets several ranks share "
+                         "one GPU in the plumbing test, nccl = RCCL over xGMI is the real one")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded code path (shard phase, RCCL reduce, finish phase) even "
                          "with one rank: a smoke test of the multi-GPU plumbing, not a benchmark")
@@ -166,6 +169,7 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    local_rank %= max(1, torch.cuda.device_count())  # ranks may share a GPU in the gloo test
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_shard
@@ -180,10 +184,12 @@ def main():
                 port = sock.getsockname()[1]
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(port))
-            dist.init_process_group("nccl", rank=0, world_size=1,
+            dist.init_process_group(args.backend, rank=0, world_size=1,
                                     device_id=torch.device("cuda", local_rank))
-        else:
+        elif args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     pkg = importlib.import_module("21cmfast_amd")
     pkg.load(require_gpu=True)

@@ -363,3 +363,36 @@ def test_bench_sharded_plumbing_on_one_rank():
     assert "sharded" in shard["config"]["parallelism"] and single["config"]["parallelism"] == "single GPU"
     assert shard["config"]["global_xH"] == single["config"]["global_xH"]
     assert 0.05 < single["config"]["global_xH"] < 0.95
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The sharded path with world_size = 2 for real: two processes launched the way the driver
+    launches them (torch.distributed.run), both on the one GPU of the box, exchanging the mask
+    through gloo (RCCL refuses two ranks on one device).  Rank 1 owns radius 0 and finishes;
+    the x_HI it broadcasts must equal the single-process result."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    common = ["--hii-dim", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+              "--no-kernel-roofline"]
+    p = subprocess.run([sys.executable, str(root / "bench.py")] + common, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    single = json.loads(p.stdout.strip())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        str(port), str(root / "bench.py"), "--gpus", "2", "--backend", "gloo"]
+                       + common, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and "sharded x2" in two["config"]["parallelism"]
+    assert two["config"]["global_xH"] == single["config"]["global_xH"]
