@@ -303,7 +303,7 @@ def main():
                             f"steps, G={G} ({'delta tophat + n_ion exp-MFP' if G == 2 else 'delta sharp-k, erfc f_coll'}), "
                             "first snapshot, device-resident inputs",
                 "hii_dim": n, "n_radii": spec.n_radii, "filtered_grids": G,
-                "parallelism": "single GPU" if not sharded else f"R-loop sharded x{world} + RCCL uint8 max-reduce",
+                "parallelism": "single GPU" if not sharded else f"R-loop sharded x{world} + {'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce",
                 "fft": "native" if native else "rocfft",
                 "global_xH": global_xh,
             },
