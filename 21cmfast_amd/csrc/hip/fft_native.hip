@@ -689,7 +689,16 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     auto decode = [&](int w) {
         LineItem it;
         const bool s = w >= n_work0;
-        const int ww = s ? w - n_work0 : w;
+        int ww = s ? w - n_work0 : w;
+        if (FMODE == 3 && !s && ww < (n_work0 & ~15)) {
+            // XCD-aware order.  Workgroups are dealt to the 8 XCDs round robin, and two column
+            // tiles of one k_y that are neighbours share every 128-byte line of the window table
+            // (a tile reads 64 bytes per row).  Within each run of 16 items, workgroups b and
+            // b + 8 -- same XCD, same L2 -- get such a pair, so the second request for a line
+            // hits in that L2 instead of going to HBM a second time.
+            const int r = ww & 15;
+            ww = (ww & ~15) + 2 * (r & 7) + (r >> 3);
+        }
         it.src0 = s ? a.g1.src[0] : a.g0.src[0];
         it.src1 = s ? a.g1.src[1] : a.g0.src[1];
         it.dst0 = s ? a.g1.dst[0] : a.g0.dst[0];
