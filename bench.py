@@ -106,7 +106,7 @@ def cpu_baseline(args, W):
 PASS_KERNELS = {
     0: "line_pass_kernel<512,+1,3>  (pass X: x-lines of both grids x streamed W(kR) tables)",
     1: "line_pass_kernel<512,+1,0>  (pass Y: y-lines of both grids)",
-    2: "zw_ionise_kernel<16,false>  (wave-level pass Z of both grids + f_coll sum + barrier)",
+    2: "zw_ionise_kernel<16,false,16> (wave-level pass Z of both grids + f_coll sum + barrier)",
     4: "window_table_kernel         (W(kR) of one radius for both windows, evaluated in fp64, stored as float)",
 }
 

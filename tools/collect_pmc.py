@@ -19,7 +19,7 @@ from collections import defaultdict
 KERNELS = {
     "pass_x_window": "line_pass_kernel<512, 1, 3>",
     "pass_y": "line_pass_kernel<512, 1, 0>",
-    "pass_z_fused": "zw_ionise_kernel<16, false>",
+    "pass_z_fused": "zw_ionise_kernel<16, false",
     "window_tables": "window_table_kernel",
 }
 
