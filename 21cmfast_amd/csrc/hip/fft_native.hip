@@ -1276,6 +1276,7 @@ struct ZFusedArgs {
     double rhocrit_omb, ion_eff, f_limit;
     int mass_dep_zeta, r_index;
     int ny, lb;  // x-blocked layout (logical_line())
+    int store_all;  // write the mask back even where this radius changed nothing
 };
 
 template <int NZ>
@@ -1330,9 +1331,11 @@ z_c2r_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         const bool i0 = floor_ionises || ((double)s0 * a.ion_eff > D0);
         const bool i1 = floor_ionises || ((double)s1 * a.ion_eff > D1);
         uchar2 m = old[u];
-        if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
-        if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
-        reinterpret_cast<uchar2 *>(a.first_cross + logical_line(l0 + li, a.ny, a.lb) * NZ)[j] = m;
+        const bool n0 = i0 && m.x == 0, n1 = i1 && m.y == 0;
+        if (n0) m.x = (unsigned char)a.r_index;
+        if (n1) m.y = (unsigned char)a.r_index;
+        if (n0 || n1 || a.store_all)
+            reinterpret_cast<uchar2 *>(a.first_cross + logical_line(l0 + li, a.ny, a.lb) * NZ)[j] = m;
     }
     // workgroup partial of sum(stars)
     __shared__ double red[kBlock / 64];
@@ -1668,9 +1671,10 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         const bool i0 = floor_ionises || f0 || ((double)s0 * a.ion_eff > D0);
         const bool i1 = floor_ionises || f1 || ((double)s1 * a.ion_eff > D1);
         uchar2 m = (A == 16) ? old[A == 16 ? q : 0] : reinterpret_cast<const uchar2 *>(mrow)[j];
-        if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
-        if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
-        reinterpret_cast<uchar2 *>(mrow)[j] = m;
+        const bool n0 = i0 && m.x == 0, n1 = i1 && m.y == 0;
+        if (n0) m.x = (unsigned char)a.r_index;
+        if (n1) m.y = (unsigned char)a.r_index;
+        if (n0 || n1 || a.store_all) reinterpret_cast<uchar2 *>(mrow)[j] = m;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -2002,9 +2006,10 @@ zw3_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         const bool i0 = floor_ionises || f0 || ((double)s0 * a.ion_eff > D0);
         const bool i1 = floor_ionises || f1 || ((double)s1 * a.ion_eff > D1);
         uchar2 m = old[q];
-        if (i0 && m.x == 0) m.x = (unsigned char)a.r_index;
-        if (i1 && m.y == 0) m.y = (unsigned char)a.r_index;
-        reinterpret_cast<uchar2 *>(mrow)[j] = m;
+        const bool n0 = i0 && m.x == 0, n1 = i1 && m.y == 0;
+        if (n0) m.x = (unsigned char)a.r_index;
+        if (n1) m.y = (unsigned char)a.r_index;
+        if (n0 || n1 || a.store_all) reinterpret_cast<uchar2 *>(mrow)[j] = m;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -2690,6 +2695,11 @@ extern "C" int c21hip_split_z_ionise_stars_xe(const float *delta_work, const flo
     a.f_limit = f_limit;
     a.mass_dep_zeta = mass_dep_zeta;
     a.r_index = r_index;
+    static const int store_all = [] {
+        const char *e = getenv("C21CM_MASK_STORE_ALL");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    a.store_all = store_all;
     int n_partials = 0;
     int st = dispatch_z_fused(nz, a, nlines, (hipStream_t)stream, &n_partials);
     if (st) return st;
