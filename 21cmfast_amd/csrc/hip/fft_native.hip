@@ -588,6 +588,7 @@ window_table_kernel(WTableArgs t) {
 struct LineGeo {
     const float2 *src[2];  // per grid
     float2 *dst[2];
+    float2 *dst2[2];       // FMODE 5: the second radius' outputs
     // offset of index i along the line / the outer axis: (i >> lb) * bstride + (i & (2^lb - 1)) *
     // stride; lb = 0 (unblocked): i * bstride
     long line_stride, line_bstride;
@@ -612,6 +613,10 @@ struct LinePassArgs {
     const wtab_t *wt_main[2];  // [ny/2+1][nx/2+1][nz/2]
     const wtab_t *wt_nyq[2];   // [nx/2+1][ny/2+1]
     int dual;                  // FMODE 3: grid 1 uses window 1 (else both grids use window 0)
+    // FMODE 5 (pass X only): two radii per sweep -- each source tile is read once, multiplied
+    // by the windows of radius A and transformed into dst, then by those of radius B into dst2
+    const wtab_t *wt2_main[2];
+    const wtab_t *wt2_nyq[2];
     FilterParams fp;           // the window of grid 0 (host side: table construction)
     // FMODE 4 (pass X only): separable k-space operator applied on load,
     //   v *= sign * k_x^ex * k_y^ey * k_z^ez  (times i when imag), k_a = index_to_k(i_a) in double:
@@ -655,10 +660,12 @@ struct LineItem {
     int n_outer, filter_axis;
     int og, ct, npair;
     const wtab_t *wt0, *wt1;  // FMODE 3: window tables of this geometry
+    float2 *dst0b, *dst1b;      // FMODE 5: second radius
+    const wtab_t *wt0b, *wt1b;
 };
 
 // FMODE: 0 no window, 3 window streamed from the per-radius tables, 4 separable k-space
-// operator (pass X of the IC transforms)
+// operator (pass X of the IC transforms), 5 = 3 for two radii at once (one read, two outputs)
 template <int N, int SIGN, int FMODE>
 __global__ void __launch_bounds__((LineThreads<N, FMODE>::value), (LineThreads<N, FMODE>::value / 256))
 line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
@@ -667,6 +674,8 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     constexpr int TZ = line_tile_cols(N);  // shadows the namespace constant: this kernel's tile
     constexpr int CPAIR = TZ / 2;          // float4 (column pairs) per row
     constexpr int RSTEP = kBlock / CPAIR;  // rows covered by one sweep of the workgroup
+    constexpr bool WIN = (FMODE == 3 || FMODE == 5);
+    constexpr int NR = (FMODE == 5) ? 2 : 1;  // radii per sweep
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
     float2 *tw = tile + N * TZ;                          // [N]
@@ -690,7 +699,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         LineItem it;
         const bool s = w >= n_work0;
         int ww = s ? w - n_work0 : w;
-        if (FMODE == 3 && !s && ww < (n_work0 & ~15)) {
+        if (WIN && !s && ww < (n_work0 & ~15)) {
             // XCD-aware order.  Workgroups are dealt to the 8 XCDs round robin, and two column
             // tiles of one k_y that are neighbours share every 128-byte line of the window table
             // (a tile reads 64 bytes per row).  Within each run of 16 items, workgroups b and
@@ -714,6 +723,12 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         it.filter_axis = s ? a.g1.filter_axis : a.g0.filter_axis;
         it.wt0 = (it.filter_axis == 1) ? a.wt_nyq[0] : a.wt_main[0];
         it.wt1 = (it.filter_axis == 1) ? a.wt_nyq[1] : a.wt_main[1];
+        if (FMODE == 5) {
+            it.dst0b = s ? a.g1.dst2[0] : a.g0.dst2[0];
+            it.dst1b = s ? a.g1.dst2[1] : a.g0.dst2[1];
+            it.wt0b = (it.filter_axis == 1) ? a.wt2_nyq[0] : a.wt2_main[0];
+            it.wt1b = (it.filter_axis == 1) ? a.wt2_nyq[1] : a.wt2_main[1];
+        }
         const int nct = s ? a.g1.n_ctiles : a.g0.n_ctiles;
         const int po = s ? a.g1.pair_outer : a.g0.pair_outer;
         it.og = ww / nct;
@@ -746,32 +761,38 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
-    float2 wpre[NP], wcur[NP], wpre_half, wcur_half;
+    float2 wpre[NR][NP], wcur[NR][NP], wpre_half[NR], wcur_half[NR];
     auto w_reload = [&](const LineItem &it, int m) {
         const int mi = it.npair == 2 ? (m & 1) : 0;
         return m == 0 || (a.dual && mi == 0);
     };
     auto issue_wloads = [&](const LineItem &it, int m) {
-        const wtab_t *t = (a.dual && member_grid(it, m)) ? it.wt1 : it.wt0;
-        if (it.filter_axis == 0) {
-            const unsigned wc = (unsigned)(a.n_z / 2);
-            const wtab_t *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
+        const bool second = a.dual && member_grid(it, m);
 #pragma unroll
-            for (int u = 0; u < NP; u++)
-                wpre[u] = *reinterpret_cast<const float2 *>(b + (unsigned)(r0 + RSTEP * u) * wc);
-            wpre_half = *reinterpret_cast<const float2 *>(b + (unsigned)(N / 2) * wc);
-        } else {
-            const int c0 = it.ct * TZ + 2 * c4;
-            const unsigned nyh = (unsigned)(a.n_y / 2 + 1);
-            const unsigned j0 = (unsigned)min(c0, a.n_y - c0), j1 = (unsigned)min(c0 + 1, a.n_y - c0 - 1);
+        for (int rr = 0; rr < NR; rr++) {
+            const wtab_t *t = rr ? (second ? it.wt1b : it.wt0b) : (second ? it.wt1 : it.wt0);
+            if (it.filter_axis == 0) {
+                const unsigned wc = (unsigned)(a.n_z / 2);
+                const wtab_t *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
 #pragma unroll
-            for (int u = 0; u < NP; u++) {
-                const wtab_t *r = t + (unsigned)(r0 + RSTEP * u) * nyh;
-                wpre[u] = make_float2(r[j0], r[j1]);
-            }
-            {
-                const wtab_t *r = t + (unsigned)(N / 2) * nyh;
-                wpre_half = make_float2(r[j0], r[j1]);
+                for (int u = 0; u < NP; u++)
+                    wpre[rr][u] =
+                        *reinterpret_cast<const float2 *>(b + (unsigned)(r0 + RSTEP * u) * wc);
+                wpre_half[rr] = *reinterpret_cast<const float2 *>(b + (unsigned)(N / 2) * wc);
+            } else {
+                const int c0 = it.ct * TZ + 2 * c4;
+                const unsigned nyh = (unsigned)(a.n_y / 2 + 1);
+                const unsigned j0 = (unsigned)min(c0, a.n_y - c0),
+                               j1 = (unsigned)min(c0 + 1, a.n_y - c0 - 1);
+#pragma unroll
+                for (int u = 0; u < NP; u++) {
+                    const wtab_t *r = t + (unsigned)(r0 + RSTEP * u) * nyh;
+                    wpre[rr][u] = make_float2(r[j0], r[j1]);
+                }
+                {
+                    const wtab_t *r = t + (unsigned)(N / 2) * nyh;
+                    wpre_half[rr] = make_float2(r[j0], r[j1]);
+                }
             }
         }
     };
@@ -819,15 +840,16 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                        const TileRef &refill) {
         const LineItem &it = cur.it;
         const int m = cur.m;
-        // store target of the tile now in registers
-        float2 *const st_lo = (member_grid(it, m) ? it.dst1 : it.dst0) + member_base(it, m);
         const long st_half = (long)((N / 2) >> it.line_lb) * it.line_bstride;
         if (!first) __syncthreads();  // the previous tile's LDS reads are done
         first = false;
-        if (FMODE == 3 && w_reload(it, m)) {
+        if (WIN && w_reload(it, m)) {
 #pragma unroll
-            for (int u = 0; u < NP; u++) wcur[u] = wpre[u];
-            wcur_half = wpre_half;
+            for (int rr = 0; rr < NR; rr++) {
+#pragma unroll
+                for (int u = 0; u < NP; u++) wcur[rr][u] = wpre[rr][u];
+                wcur_half[rr] = wpre_half[rr];
+            }
         }
         double op_c0 = 1., op_c1 = 1.;  // FMODE 4: sign * k_y^ey * k_z^ez of this thread's columns
         if (FMODE == 4) {
@@ -854,6 +876,13 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             op_c1 = a.op_sign * fy1 * fz1;
         }
 #pragma unroll
+      for (int rr = 0; rr < NR; rr++) {
+        // store target of the tile now in registers (radius rr of the sweep)
+        float2 *const st_lo = (rr ? (member_grid(it, m) ? it.dst1b : it.dst0b)
+                                  : (member_grid(it, m) ? it.dst1 : it.dst0)) +
+                              member_base(it, m);
+        if (rr) __syncthreads();  // the first radius' LDS reads are done
+#pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
             const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
@@ -877,8 +906,8 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                     v.w = (float)((double)v.w * f1);
                 }
             }
-            if (FMODE == 3) {
-                const float2 wv = half ? wcur_half : wcur[u >> 1];
+            if (WIN) {
+                const float2 wv = half ? wcur_half[rr] : wcur[rr][u >> 1];
                 v.x = __fmul_rn(v.x, wv.x);
                 v.y = __fmul_rn(v.y, wv.x);
                 v.z = __fmul_rn(v.z, wv.y);
@@ -892,8 +921,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         // again -- so that the number of loads in flight is static and the compiler can wait
         // with vmcnt(n > 0) for exactly this register set instead of draining everything)
         // (a TileRef past the end still names the last tile, see next_tile)
-        if (FMODE == 3 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
-        issue_loads(reg, refill.it, refill.m);
+        // (with two radii per sweep: after the second radius has left the registers)
+        if (rr == NR - 1) {
+            if (WIN && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
+            issue_loads(reg, refill.it, refill.m);
+        }
 
         line_fft<N, TZ, SIGN, kBlock>(tile, tw, tw_half);
         // ---- store
@@ -913,6 +945,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             float2 *p = st_lo + ((u & 1) ? st_half : 0);
             *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
         }
+      }
     };
 
     if ((int)blockIdx.x < n_work) {
@@ -921,7 +954,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         ta.valid = 1;
         ta.m = 0;
         ta.it = decode(ta.work);
-        if (FMODE == 3) issue_wloads(ta.it, 0);
+        if (WIN) issue_wloads(ta.it, 0);
         issue_loads(reg_a, ta.it, 0);
         TileRef tb = next_tile(ta);
         if (!TWO_SETS) {  // 1024-point lines: registers for one set only
@@ -1488,6 +1521,8 @@ template <int N, int SIGN>
 int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
     if (SIGN > 0 && fmode == 3) return launch_line_pass_mode<N, +1, 3>(a, stream);
     if (SIGN > 0 && fmode == 4) return launch_line_pass_mode<N, +1, 4>(a, stream);
+    if constexpr (N < 1024)  // two radii per sweep need the tile to stay in registers
+        if (SIGN > 0 && fmode == 5) return launch_line_pass_mode<N, +1, 5>(a, stream);
     return launch_line_pass_mode<N, SIGN, 0>(a, stream);
 }
 
@@ -2264,13 +2299,61 @@ extern "C" int c21hip_padded_to_split(const float *padded_c, float *split, int n
 // [W(kR) x] pass X (src -> work) and pass Y (work, in place) of the inverse transform of one
 // or two split spectra.  src == work is allowed.  Grid g is filtered with window
 // (filter_type[g], R, R_param[g]).
-static int filter_xy(const float *const split_src[2], float *const split_work[2], int n_grids,
-                     int nx, int ny, int nz, double box_len, double box_len_z,
-                     const int filter_type[2], float R, const float R_param[2], int apply,
-                     void *stream_, int phases = 7, int table_slot = 0, float R_star = 0.f) {
-    // phases: 1 window table, 2 pass X, 4 pass Y (the timing hook runs them one at a time; the
-    // excursion-set driver builds the tables of the next radius on a second stream).
-    // table_slot 0 / 1: which of the two table buffers this radius uses.
+// The per-radius window tables of a one- or two-grid sweep in buffer `table_slot` (0..3);
+// build = launch the kernel that fills them.
+struct WinTables {
+    const wtab_t *main[2], *nyq[2];
+    int dual;
+};
+static int win_tables(int table_slot, int n_grids, const int filter_type[2], float R,
+                      const float R_param[2], float R_star, int nx, int ny, int nz, double box_len,
+                      double box_len_z, bool build, hipStream_t stream, WinTables &w) {
+    static const int ws_slot[4] = {49, 46, 94, 95};
+    if (table_slot < 0 || table_slot > 3) return C21CM_VALUE_ERROR;
+    const int H = nz / 2;
+    // the window's parameters beyond (type, R): R_param matters for types 3 and 4 only
+    const bool dual = n_grids == 2 && (filter_type[0] != filter_type[1] ||
+                                       (filter_type[0] >= 3 && R_param[0] != R_param[1]));
+    const size_t n_main = (size_t)(ny / 2 + 1) * (nx / 2 + 1) * H;
+    const size_t n_nyq = (size_t)(nx / 2 + 1) * (ny / 2 + 1);
+    const size_t per = (n_main + n_nyq + 3) & ~(size_t)3;  // keep table b 16-byte aligned
+    wtab_t *tab = (wtab_t *)c21hip_ws(ws_slot[table_slot], sizeof(wtab_t) * per * (dual ? 2 : 1));
+    if (!tab) return C21CM_MEMORY_ALLOC_ERROR;
+    WTableArgs t{};
+    fill_filter(t.pa, filter_type[0], R, R_param[0], box_len, box_len_z);
+    t.dual = dual ? 1 : 0;
+    if (dual) fill_filter(t.pb, filter_type[1], R, R_param[1], box_len, box_len_z);
+    t.nx = nx;
+    t.ny = ny;
+    t.nz = nz;
+    t.main_a = tab;
+    t.nyq_a = tab + n_main;
+    t.main_b = dual ? tab + per : tab;
+    t.nyq_b = t.main_b + n_main;
+    if (build) {
+        const size_t n_threads = n_main / 4 + n_nyq;
+        const bool ms = filter_type[0] == 5 || (dual && filter_type[1] == 5);
+        if (ms) {
+            if (filter_type[0] == 5) ms_fill(t.ms_a, R, R_param[0], R_star);
+            if (dual && filter_type[1] == 5) ms_fill(t.ms_b, R, R_param[1], R_star);
+        }
+        const dim3 tgrid((unsigned)((n_threads + kBlock - 1) / kBlock));
+        if (ms)
+            hipLaunchKernelGGL(window_table_kernel<true>, tgrid, dim3(kBlock), 0, stream, t);
+        else
+            hipLaunchKernelGGL(window_table_kernel<false>, tgrid, dim3(kBlock), 0, stream, t);
+        LAUNCH_CHECK();
+    }
+    w.main[0] = t.main_a;
+    w.nyq[0] = t.nyq_a;
+    w.main[1] = t.main_b;
+    w.nyq[1] = t.nyq_b;
+    w.dual = t.dual;
+    return 0;
+}
+
+static int check_filter_request(int n_grids, int nx, int ny, int nz, const int filter_type[2],
+                                int apply) {
     if (!c21hip_native_fft_supported(nx, ny, nz)) {
         c21hip_set_error("native FFT does not support %dx%dx%d", nx, ny, nz);
         return C21CM_VALUE_ERROR;
@@ -2280,14 +2363,21 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
             c21hip_set_error("filter type %d is not implemented on the device", filter_type[g]);
             return C21CM_VALUE_ERROR;
         }
+    return 0;
+}
+
+static int filter_xy(const float *const split_src[2], float *const split_work[2], int n_grids,
+                     int nx, int ny, int nz, double box_len, double box_len_z,
+                     const int filter_type[2], float R, const float R_param[2], int apply,
+                     void *stream_, int phases = 7, int table_slot = 0, float R_star = 0.f) {
+    // phases: 1 window table, 2 pass X, 4 pass Y (the timing hook runs them one at a time; the
+    // excursion-set driver builds the tables of the next radius on a second stream).
+    // table_slot: which of the table buffers this radius uses.
+    int st = check_filter_request(n_grids, nx, ny, nz, filter_type, apply);
+    if (st) return st;
     hipStream_t stream = (hipStream_t)stream_;
     const int H = nz / 2;
     const long nlines = (long)nx * ny;
-    // the window's parameters beyond (type, R): R_param matters for types 3 and 4 only
-    const bool dual = apply && n_grids == 2 &&
-                      (filter_type[0] != filter_type[1] ||
-                       (filter_type[0] >= 3 && R_param[0] != R_param[1]));
-    int st;
     LinePassArgs a{};
     fill_filter(a.fp, apply ? filter_type[0] : -1, R, R_param[0], box_len, box_len_z);
     a.n_y = ny;
@@ -2295,41 +2385,15 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     a.out_scale = 1.0f;
     const int fmode = apply ? 3 : 0;
     if (fmode == 3) {
-        const size_t n_main = (size_t)(ny / 2 + 1) * (nx / 2 + 1) * H;
-        const size_t n_nyq = (size_t)(nx / 2 + 1) * (ny / 2 + 1);
-        const size_t per = (n_main + n_nyq + 3) & ~(size_t)3;  // keep table b 16-byte aligned
-        wtab_t *tab = (wtab_t *)c21hip_ws(table_slot ? 46 : 49, sizeof(wtab_t) * per * (dual ? 2 : 1));
-        if (!tab) return C21CM_MEMORY_ALLOC_ERROR;
-        WTableArgs t{};
-        t.pa = a.fp;
-        t.dual = dual ? 1 : 0;
-        if (dual) fill_filter(t.pb, filter_type[1], R, R_param[1], box_len, box_len_z);
-        t.nx = nx;
-        t.ny = ny;
-        t.nz = nz;
-        t.main_a = tab;
-        t.nyq_a = tab + n_main;
-        t.main_b = dual ? tab + per : tab;
-        t.nyq_b = t.main_b + n_main;
-        const size_t n_threads = n_main / 4 + n_nyq;
-        const bool ms = filter_type[0] == 5 || (dual && filter_type[1] == 5);
-        if (ms) {
-            if (filter_type[0] == 5) ms_fill(t.ms_a, R, R_param[0], R_star);
-            if (dual && filter_type[1] == 5) ms_fill(t.ms_b, R, R_param[1], R_star);
+        WinTables w;
+        if ((st = win_tables(table_slot, n_grids, filter_type, R, R_param, R_star, nx, ny, nz,
+                             box_len, box_len_z, (phases & 1) != 0, stream, w)))
+            return st;
+        for (int i = 0; i < 2; i++) {
+            a.wt_main[i] = w.main[i];
+            a.wt_nyq[i] = w.nyq[i];
         }
-        if (phases & 1) {
-            const dim3 tgrid((unsigned)((n_threads + kBlock - 1) / kBlock));
-            if (ms)
-                hipLaunchKernelGGL(window_table_kernel<true>, tgrid, dim3(kBlock), 0, stream, t);
-            else
-                hipLaunchKernelGGL(window_table_kernel<false>, tgrid, dim3(kBlock), 0, stream, t);
-            LAUNCH_CHECK();
-        }
-        a.wt_main[0] = t.main_a;
-        a.wt_nyq[0] = t.nyq_a;
-        a.wt_main[1] = t.main_b;
-        a.wt_nyq[1] = t.nyq_b;
-        a.dual = t.dual;
+        a.dual = w.dual;
     }
     if (!(phases & 6)) return 0;
     // ---- pass X: main block + Nyquist plane (x grids) in one launch
@@ -2382,6 +2446,90 @@ extern "C" int c21hip_split_filter_xy2(const float *src_a, float *work_a, int fi
     const float rp[2] = {R_param_a, R_param_b};
     return filter_xy(src, work, 2, nx, ny, nz, box_len, box_len_z, ft, R, rp, apply, stream_,
                      tables_ready ? 6 : 7, table_slot);
+}
+
+// The same for TWO radii R and R2 in one pass-X sweep (FMODE 5: every source tile is read
+// once and transformed twice), followed by a pass Y per radius: work_*/table_slot belong to R,
+// work_*2/table_slot2 to R2.  Lines of 1024 points keep one register set and are not served.
+static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int filter_a,
+                          float R_param_a, const float *src_b, float *work_b, float *work_b2,
+                          int filter_b, float R_param_b, int nx, int ny, int nz, double box_len,
+                          double box_len_z, float R, float R2, int table_slot, int table_slot2,
+                          int phases, void *stream_) {
+    // phases: 1 window tables, 2 pass X, 4 the two passes Y
+    const int tables_ready = !(phases & 1);
+    const int ft[2] = {filter_a, filter_b};
+    const float rp[2] = {R_param_a, R_param_b};
+    int st = check_filter_request(2, nx, ny, nz, ft, 1);
+    if (st) return st;
+    if (nx >= 1024 || table_slot == table_slot2) {
+        c21hip_set_error("two-radius sweep: nx = %d / table slots %d, %d not supported", nx,
+                         table_slot, table_slot2);
+        return C21CM_VALUE_ERROR;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = nz / 2;
+    const long nlines = (long)nx * ny;
+    WinTables w, w2;
+    if ((st = win_tables(table_slot, 2, ft, R, rp, 0.f, nx, ny, nz, box_len, box_len_z,
+                         !tables_ready, stream, w)))
+        return st;
+    if ((st = win_tables(table_slot2, 2, ft, R2, rp, 0.f, nx, ny, nz, box_len, box_len_z,
+                         !tables_ready, stream, w2)))
+        return st;
+    LinePassArgs a{};
+    a.fp.type = -1;
+    a.n_y = ny;
+    a.n_z = nz;
+    a.out_scale = 1.0f;
+    for (int i = 0; i < 2; i++) {
+        a.wt_main[i] = w.main[i];
+        a.wt_nyq[i] = w.nyq[i];
+        a.wt2_main[i] = w2.main[i];
+        a.wt2_nyq[i] = w2.nyq[i];
+    }
+    a.dual = w.dual;
+    a.n_geo = 2;
+    a.n_grids = 2;
+    a.g0 = geo_x_main(ny, H, line_tile_cols(nx), split_xb_log2(nx));
+    a.g1 = geo_x_nyq(ny, line_tile_cols(nx));
+    const float2 *src[2] = {reinterpret_cast<const float2 *>(src_a),
+                            reinterpret_cast<const float2 *>(src_b)};
+    float2 *work[2] = {reinterpret_cast<float2 *>(work_a), reinterpret_cast<float2 *>(work_b)};
+    float2 *work2[2] = {reinterpret_cast<float2 *>(work_a2), reinterpret_cast<float2 *>(work_b2)};
+    for (int g = 0; g < 2; g++) {
+        geo_ptrs(a.g0, g, src[g], work[g]);
+        geo_ptrs(a.g1, g, src[g] + nlines * H, work[g] + nlines * H);
+        a.g0.dst2[g] = work2[g];
+        a.g1.dst2[g] = work2[g] + nlines * H;
+    }
+    if ((phases & 2) && (st = dispatch_line_pass<+1>(nx, a, 5, stream))) return st;
+    if (!(phases & 4)) return 0;
+    // ---- pass Y (in place), one launch per radius
+    for (int r = 0; r < 2; r++) {
+        float2 *const *wk = r ? work2 : work;
+        a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
+        a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
+        a.g1_strided = 1;
+        for (int g = 0; g < 2; g++) {
+            geo_ptrs(a.g0, g, wk[g], wk[g]);
+            geo_ptrs(a.g1, g, wk[g] + nlines * H, wk[g] + nlines * H);
+        }
+        if ((st = dispatch_line_pass<+1>(ny, a, 0, stream))) return st;
+    }
+    return 0;
+}
+
+extern "C" int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, float *work_a2,
+                                            int filter_a, float R_param_a, const float *src_b,
+                                            float *work_b, float *work_b2, int filter_b,
+                                            float R_param_b, int nx, int ny, int nz,
+                                            double box_len, double box_len_z, float R, float R2,
+                                            int table_slot, int table_slot2, int tables_ready,
+                                            void *stream_) {
+    return filter_xy_pair(src_a, work_a, work_a2, filter_a, R_param_a, src_b, work_b, work_b2,
+                          filter_b, R_param_b, nx, ny, nz, box_len, box_len_z, R, R2, table_slot,
+                          table_slot2, tables_ready ? 6 : 7, stream_);
 }
 
 // One or two grids of one shell of the spin-temperature filters: windows 4 (spherical shell)
@@ -2864,6 +3012,15 @@ extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, fl
     int st = 0;
     if (kind == 0)  // tables for pass X
         st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 1);
+    float *pair2[2] = {nullptr, nullptr};
+    if (kind == 6) {  // two-radius pass X: second outputs, tables of R and 0.9 R
+        if (n >= 1024) return C21CM_VALUE_ERROR;
+        pair2[0] = (float *)c21hip_ws(92, nf * sizeof(float));
+        pair2[1] = (float *)c21hip_ws(93, nf * sizeof(float));
+        if (!pair2[0] || !pair2[1]) return C21CM_MEMORY_ALLOC_ERROR;
+        st = filter_xy_pair(a, real, pair2[0], filter_a, 0.f, b, real2, pair2[1], filter_b,
+                            R_param_b, n, n, n, box_len, box_len, R, 0.9f * R, 0, 1, 1, stream_);
+    }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         return C21CM_IO_ERROR;
@@ -2875,6 +3032,10 @@ extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, fl
             st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 4);
         else if (kind == 4)
             st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 1);
+        else if (kind == 6)
+            st = filter_xy_pair(a, real, pair2[0], filter_a, 0.f, b, real2, pair2[1], filter_b,
+                                R_param_b, n, n, n, box_len, box_len, R, 0.9f * R, 0, 1, 2,
+                                stream_);
         else if (kind == 5)  // pass X without a window (diagnostic)
             st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 0, stream_, 2);
         else if (kind == 2)

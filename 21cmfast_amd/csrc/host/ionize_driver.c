@@ -49,7 +49,9 @@ enum {
     WS_STARS_WORK,
     WS_XE_WORK,
     WS_PARTIALS,
-    WS_DEF_PARTIALS = 84
+    WS_DEF_PARTIALS = 84,
+    WS_DELTA_WORK2 = 92, /* second radius of a two-radius sweep */
+    WS_STARS_WORK2 = 93
 };
 
 #define MAX_COPYBACK 8
@@ -197,6 +199,8 @@ typedef struct {
      * real-space grids (padded rows) */
     float *delta_unf, *delta_fil, *stars_unf, *stars_fil, *xe_unf, *xe_fil;
     float *delta_work, *stars_work, *xe_work;
+    float *delta_work2, *stars_work2; /* two radii per pass-X sweep (pair_radii) */
+    int pair_radii;
     /* dense inputs */
     const float *density, *n_ion, *xe_dense, *Tneutral, *prev_zre;
     /* dense outputs */
@@ -271,6 +275,17 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
     c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct;
+    if (c->fused && !s->use_ts_fluct && c->nx < 1024) {
+        /* pass X reads each spectrum tile once for two consecutive radii (C21CM_PAIR_RADII=0:
+         * one radius per sweep) */
+        const char *e = getenv("C21CM_PAIR_RADII");
+        if (!(e && e[0] == '0')) {
+            c->delta_work2 = (float *)c21hip_ws(WS_DELTA_WORK2, gbytes);
+            c->stars_work2 = (float *)c21hip_ws(WS_STARS_WORK2, gbytes);
+            if (!c->delta_work2 || !c->stars_work2) return C21CM_MEMORY_ALLOC_ERROR;
+            c->pair_radii = 1;
+        }
+    }
     if (c->fused) {
         const char *e = getenv("C21CM_DEFER_SUMS");
         if (!(e && e[0] == '0')) {
@@ -402,7 +417,7 @@ done:
  * C21CM_ASYNC_TABLES=0 builds them inline on the caller's stream instead. */
 static struct {
     int init, enabled;
-    void *aux, *ev_table[2], *ev_used[2], *ev_sync;
+    void *aux, *ev_table[4], *ev_used[4], *ev_sync;
 } g_tab;
 
 static void tab_init(void) {
@@ -412,12 +427,12 @@ static void tab_init(void) {
     if (e && e[0] == '0') return;
     g_tab.aux = c21hip_aux_stream();
     g_tab.ev_sync = c21hip_event_create();
-    for (int b = 0; b < 2; b++) {
+    g_tab.enabled = g_tab.aux && g_tab.ev_sync;
+    for (int b = 0; b < 4; b++) {
         g_tab.ev_table[b] = c21hip_event_create();
         g_tab.ev_used[b] = c21hip_event_create();
+        g_tab.enabled = g_tab.enabled && g_tab.ev_table[b] && g_tab.ev_used[b];
     }
-    g_tab.enabled = g_tab.aux && g_tab.ev_sync && g_tab.ev_table[0] && g_tab.ev_table[1] &&
-                    g_tab.ev_used[0] && g_tab.ev_used[1];
 }
 
 static int tab_build_async(ion_ctx *c, int R_ct, int buf) {
@@ -444,6 +459,118 @@ static int flush_deferred(ion_ctx *c) {
     return st;
 }
 
+/* Fused pass Z of one radius (density + emissivity [+ x_e] spectra after passes X, Y): barrier
+ * test into the mask, f_coll sum deferred or reduced now. */
+static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float *swork,
+                           unsigned char *first_cross) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    const float *xwork = s->use_ts_fluct ? c->xe_work : NULL;
+    if (c->def_partials) {
+        /* no kernel of this loop reads a radius' mean: reduce all of them at the end */
+        if (c->def_count == 0)
+            c->def_first = R_ct;
+        else if (c->def_count == 1)
+            c->def_step = c->def_first - R_ct;
+        else if (R_ct != c->def_first - c->def_count * c->def_step)
+            TRY(flush_deferred(c));
+        if (c->def_count == 0) c->def_first = R_ct;
+        c->def_count++;
+        TRY(c21hip_split_z_ionise_stars_xe(dwork, swork, xwork, first_cross,
+                                           c->def_partials + (long)R_ct * c->def_stride, NULL,
+                                           c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
+                                           s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
+                                           c->stream));
+        goto done;
+    }
+    {
+        double *sum_dev = c->scalars + SC_SUMS + R_ct;
+        TRY(c21hip_split_z_ionise_stars_xe(dwork, swork, xwork, first_cross, c->partials, sum_dev,
+                                           c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
+                                           s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
+                                           c->stream));
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               c->scalars + SC_MEANS + R_ct, c->stream));
+    }
+done:
+    return status;
+}
+
+/* One step of the fused R loop: radius R_a, and with R_b >= 1 also radius R_b out of the same
+ * pass-X sweep (each spectrum tile read once, windowed and transformed twice).  next_a / next_b:
+ * the radii of the step after this one (-1: none), whose window tables are built ahead on the
+ * side stream.  Four table buffers: steps alternate between the pairs (0, 1) and (2, 3). */
+static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, int next_a,
+                      int next_b) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    const int set = c->tab_seq & 1;
+    const int buf_a = 2 * set, buf_b = 2 * set + 1;
+    tab_init();
+    /* below ~64 M cells the two cross-stream waits per radius cost more than the table
+     * kernel they hide (256^3: 9.5 vs 9.25 ms per call): build the tables inline there */
+    const int tab_async = g_tab.enabled && c->ntot >= ((size_t)1 << 26);
+    if (tab_async) {
+        if (c->tab_seq == 0) {
+            /* first fused step of this call: order the side stream after whatever the
+             * caller's stream still runs on the table buffers, then build this step's tables */
+            TRY(c21hip_event_record(g_tab.ev_sync, c->stream));
+            TRY(c21hip_stream_wait_event(g_tab.aux, g_tab.ev_sync));
+            TRY(tab_build_async(c, R_a, buf_a));
+            if (R_b >= 1) TRY(tab_build_async(c, R_b, buf_b));
+        }
+        if (next_a >= 1) TRY(tab_build_async(c, next_a, 2 * (set ^ 1)));
+        if (next_b >= 1) TRY(tab_build_async(c, next_b, 2 * (set ^ 1) + 1));
+        TRY(c21hip_stream_wait_event(c->stream, g_tab.ev_table[buf_a]));
+        if (R_b >= 1) TRY(c21hip_stream_wait_event(c->stream, g_tab.ev_table[buf_b]));
+    }
+    if (R_b >= 1) {
+        TRY(c21hip_split_filter_xy2_pair(c->delta_unf, c->delta_work, c->delta_work2, s->hii_filter,
+                                         0.f, c->stars_unf, c->stars_work, c->stars_work2,
+                                         s->stars_filter, (float)s->mfp_meandens, c->nx, c->ny,
+                                         c->nz, s->box_len, s->box_len_z, (float)s->R[R_a],
+                                         (float)s->R[R_b], buf_a, buf_b, tab_async, c->stream));
+    } else {
+        TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->stars_unf,
+                                    c->stars_work, s->stars_filter, (float)s->mfp_meandens, c->nx,
+                                    c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], 1,
+                                    buf_a, tab_async, c->stream));
+        if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
+            TRY(c21hip_split_filter_xy_shared(c->xe_unf, c->xe_work, s->hii_filter, c->nx, c->ny,
+                                              c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], 1,
+                                              buf_a, c->stream));
+    }
+    if (tab_async) {
+        TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
+        if (R_b >= 1) TRY(c21hip_event_record(g_tab.ev_used[buf_b], c->stream));
+    }
+    c->tab_seq++;
+    TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, first_cross));
+    if (R_b >= 1) TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2, first_cross));
+done:
+    return status;
+}
+
+/* The fused R loop over radii first, first - step, ... >= lowest (>= 1), two per sweep where
+ * the context allows it. */
+static int fused_loop(ion_ctx *c, int first, int step, int lowest, unsigned char *first_cross) {
+    int status = 0;
+    if (lowest < 1) lowest = 1;
+    int R_a = first;
+    while (R_a >= lowest) {
+        const int want_b = c->pair_radii && R_a - step >= lowest;
+        const int R_b = want_b ? R_a - step : -1;
+        const int n_a = (want_b ? R_b : R_a) - step;
+        const int next_a = n_a >= lowest ? n_a : -1;
+        const int next_b = (c->pair_radii && next_a >= 1 && next_a - step >= lowest) ? next_a - step
+                                                                                     : -1;
+        TRY(fused_step(c, R_a, R_b, first_cross, next_a, next_b));
+        R_a = n_a;
+    }
+done:
+    return status;
+}
+
 /* One filter radius: IonisationBox.c:1546-1580.  first_cross != NULL = shard mode.
  * next_R: the radius index this process handles after R_ct (-1: none / unknown). */
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
@@ -457,60 +584,8 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
     c21hip_ionize_args args;
     fill_args(&args, s, R_ct);
 
-    if (c->fused && first_cross && R_ct > 0) {
-        int buf = 0, ready = 0;
-        tab_init();
-        /* below ~64 M cells the two cross-stream waits per radius cost more than the table
-         * kernel they hide (256^3: 9.5 vs 9.25 ms per call): build the tables inline there */
-        const int tab_async = g_tab.enabled && c->ntot >= ((size_t)1 << 26);
-        if (tab_async) {
-            buf = c->tab_seq & 1;
-            ready = 1;
-            if (c->tab_seq == 0) {
-                /* first fused radius of this call: order the side stream after whatever the
-                 * caller's stream still runs on the table buffers, then build this radius */
-                TRY(c21hip_event_record(g_tab.ev_sync, c->stream));
-                TRY(c21hip_stream_wait_event(g_tab.aux, g_tab.ev_sync));
-                TRY(tab_build_async(c, R_ct, buf));
-            }
-            if (next_R >= 1) TRY(tab_build_async(c, next_R, buf ^ 1));
-            TRY(c21hip_stream_wait_event(c->stream, g_tab.ev_table[buf]));
-        }
-        TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->stars_unf,
-                                    c->stars_work, s->stars_filter, (float)s->mfp_meandens, c->nx,
-                                    c->ny, c->nz, s->box_len, s->box_len_z, R, apply, buf, ready,
-                                    c->stream));
-        if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
-            TRY(c21hip_split_filter_xy_shared(c->xe_unf, c->xe_work, s->hii_filter, c->nx, c->ny,
-                                              c->nz, s->box_len, s->box_len_z, R, apply, buf,
-                                              c->stream));
-        if (tab_async) TRY(c21hip_event_record(g_tab.ev_used[buf], c->stream));
-        c->tab_seq++;
-        if (c->def_partials) {
-            /* no kernel of this loop reads a radius' mean: reduce all of them at the end */
-            if (c->def_count == 0)
-                c->def_first = R_ct;
-            else if (c->def_count == 1)
-                c->def_step = c->def_first - R_ct;
-            else if (R_ct != c->def_first - c->def_count * c->def_step)
-                TRY(flush_deferred(c));
-            if (c->def_count == 0) c->def_first = R_ct;
-            c->def_count++;
-            TRY(c21hip_split_z_ionise_stars_xe(
-                c->delta_work, c->stars_work, s->use_ts_fluct ? c->xe_work : NULL, first_cross,
-                c->def_partials + (long)R_ct * c->def_stride, NULL, c->nx, c->ny, c->nz, R_ct,
-                s->rhocrit_omb, s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg, c->stream));
-            goto done;
-        }
-        TRY(c21hip_split_z_ionise_stars_xe(c->delta_work, c->stars_work,
-                                           s->use_ts_fluct ? c->xe_work : NULL, first_cross,
-                                           partials, sum_dev, c->nx, c->ny, c->nz, R_ct,
-                                           s->rhocrit_omb, s->ion_eff_factor, s->mass_dep_zeta,
-                                           s->f_limit_acg, c->stream));
-        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
-                               mean_dev, c->stream));
-        goto done;
-    }
+    if (c->fused && first_cross && R_ct > 0)
+        return fused_step(c, R_ct, -1, first_cross, next_R, -1);
     if (c->eul_mask && first_cross && R_ct > 0) {
         const int zs = 2 * (c->nz / 2 + 1);
         TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
@@ -807,6 +882,10 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             TRY(eul_table_loop(&c, radii, n, c.mask));
             R_start = 1; /* only the cell-scale radius is left */
         }
+        if (c.fused) { /* radii n-1 .. 1 through the fused steps; index 0 is the final sweep */
+            TRY(fused_loop(&c, spec->n_radii - 1, 1, spec->r_lowest, c.mask));
+            R_start = 1;
+        }
         for (int R_ct = R_start; R_ct--;) {
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
@@ -887,6 +966,8 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
         for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct -= world)
             radii[n++] = R_ct;
         TRY(eul_table_loop(&c, radii, n, first_cross));
+    } else if (c.fused) {
+        TRY(fused_loop(&c, spec->n_radii - 1 - rank, world, spec->r_lowest, first_cross));
     } else {
         for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
             if (R_ct < spec->r_lowest) break;

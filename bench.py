@@ -104,17 +104,21 @@ def cpu_baseline(args, W):
 
 
 PASS_KERNELS = {
-    0: "line_pass_kernel<512,+1,3>  (pass X: x-lines of both grids x streamed W(kR) tables)",
-    1: "line_pass_kernel<512,+1,0>  (pass Y: y-lines of both grids)",
+    0: "line_pass_kernel<{n},+1,3>  (pass X: x-lines of both grids x streamed W(kR) tables)",
+    1: "line_pass_kernel<{n},+1,0>  (pass Y: y-lines of both grids)",
     2: "zw_ionise_kernel<16,false,16> (wave-level pass Z of both grids + f_coll sum + barrier)",
     4: "window_table_kernel         (W(kR) of one radius for both windows, evaluated in fp64, stored as float)",
+    6: "line_pass_kernel<{n},+1,5>  (pass X of TWO radii: each tile of both grids read once, windowed and transformed twice)",
 }
+# the key of each kernel in profiles/pmc_r01.json
+PMC_KEYS = {0: "pass_x_window", 1: "pass_y", 2: "pass_z_fused", 4: "window_tables", 6: "pass_x_pair"}
 
 
 def kernel_roofline(args, spec, torch):
     """Live HIP-event timing of each hand-written pass kernel of the R loop, on torch's current
     stream (the stream every kernel of the step is launched on), with its ALGORITHMIC bytes:
       pass X / pass Y  read + write of both split k-space grids       2 * 2 * S
+      pass X, 2 radii  one read, two writes of both grids             2 * 3 * S
       fused pass Z     read of both grids + uint8 mask read + write   2 * S + 2 * N
     S = 8 * (N/2 + nx*ny) bytes (split layout), N = cells.  The window tables pass X also
     reads (2 x 4 (n/2+1)^3 bytes, float entries) are overhead, not algorithmic bytes."""
@@ -128,18 +132,23 @@ def kernel_roofline(args, spec, torch):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     N = float(n) ** 3
     S = 8.0 * (N / 2 + n * n)
-    alg = {0: 4 * S, 1: 4 * S, 2: 2 * S + 2 * N, 4: 0.0}
+    alg = {0: 4 * S, 1: 4 * S, 2: 2 * S + 2 * N, 4: 0.0, 6: 6 * S}
+    paired = os.environ.get("C21CM_PAIR_RADII", "1") != "0" and n < 1024
+    n_fused = spec.n_radii - 1  # launches per step (radius index 0 is the final sweep)
+    launches = {0: n_fused % 2 if paired else n_fused, 6: n_fused // 2 if paired else 0,
+                1: n_fused, 2: n_fused, 4: n_fused}
     R_mid = spec.R[spec.n_radii // 2]
     out = {}
-    for kind in (0, 1, 2, 4):
+    for kind in (0, 1, 2, 4) + ((6,) if paired else ()):
         ms = C.c_float()
         st = lib.c21hip_bench_pass(kind, n, int(spec.hii_filter), int(spec.stars_filter), R_mid,
                                    float(spec.mfp_meandens) or 1.0, spec.box_len, 20, stream,
                                    C.byref(ms))
         if st != 0:
             return None
-        out[kind] = {"kernel": PASS_KERNELS[kind], "ms": ms.value, "alg_bytes": alg[kind],
-                     "GBs": alg[kind] / ms.value / 1e6}
+        out[kind] = {"kernel": PASS_KERNELS[kind].replace("{n}", str(n)), "ms": ms.value, "alg_bytes": alg[kind],
+                     "GBs": alg[kind] / ms.value / 1e6, "launches_per_step": launches[kind],
+                     "ms_per_step": ms.value * launches[kind]}
     return out
 
 
@@ -266,16 +275,19 @@ def main():
         kern = None if (world > 1 or args.no_kernel_roofline or not native) else \
             kernel_roofline(args, spec, torch)
         if kern:
-            # dominant kernel = the pass-X line transform of both grids with the window multiply
-            # (one launch per radius; the largest share of the R loop in profiles/)
-            dom = kern[0]
+            # dominant kernel = the one with the largest share of the R loop (launch time x
+            # launches per step; agrees with the kernel-trace stats in profiles/)
+            dom_kind = max((k for k in kern if k != 4), key=lambda k: kern[k]["ms_per_step"])
+            dom = kern[dom_kind]
             roof.update({"kernel": dom["kernel"], "achieved": dom["GBs"],
                          "frac": dom["GBs"] / HBM_PEAK_GBS, "ms_per_launch": dom["ms"],
                          "alg_bytes_per_launch": dom["alg_bytes"],
-                         "other_kernels": [kern[1], kern[2], kern[4]]})
+                         "launches_per_step": dom["launches_per_step"],
+                         "other_kernels": [kern[k] for k in sorted(kern) if k != dom_kind]})
             pmc = pmc_traffic()
             if pmc:
-                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                per = pmc.get("kernels", {}).get(PMC_KEYS[dom_kind])
+                roof["traffic"] = per["hbm_bytes"] if per else None
                 roof["traffic_source"] = pmc.get("source")
         rep = last_report.get("rep")
         # whole R loop against the SURVEY 8(d) contract: (20G + 8) * N bytes per radius

@@ -315,6 +315,41 @@ def test_shard_phases_equal_single_pass(api):
     assert rep.global_xH == rep3.global_xH
 
 
+@pytest.mark.parametrize("n,r_max", [(64, 20.0), (128, 17.0), (64, 9.0)])
+def test_two_radii_per_sweep_equal_one(api, n, r_max, monkeypatch):
+    """Pass X serves two radii per sweep (each spectrum tile read once, windowed and transformed
+    twice; odd counts end on a single-radius step): same bits as one radius per sweep
+    (C21CM_PAIR_RADII=0), single pass and sharded over 2 and 3 ranks (radius strides 2, 3)."""
+    import torch
+
+    spec = W.ionize_spec(n, r_bubble_max=r_max)
+    density = torch.from_numpy(W.density_field_numpy(n, seed=77)).cuda()
+    n_ion = W.nion_from_density(density)
+    monkeypatch.setenv("C21CM_PAIR_RADII", "0")
+    buf0, box0, rep0 = api.ionize_grids(spec, density, n_ion)
+    monkeypatch.delenv("C21CM_PAIR_RADII")
+    buf1, box1, rep1 = api.ionize_grids(spec, density, n_ion)
+    torch.cuda.synchronize()
+    assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
+    for name in ("neutral_fraction", "z_reion", "kinetic_temperature"):
+        assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
+    k = spec.n_radii
+    assert list(rep0.f_coll_grid_mean[:k]) == list(rep1.f_coll_grid_mean[:k])
+    assert rep0.global_xH == rep1.global_xH
+    for world in (2, 3):
+        masks = []
+        for rank in range(world):
+            fc = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
+            api.ionize_shard_radii(spec, rank, world, fc, density, n_ion)
+            masks.append(fc.clone())
+        reduced = torch.stack(masks).max(dim=0).values.contiguous()
+        buf2, _, rep2 = api.ionize_shard_finish(spec, reduced, density, n_ion)
+        torch.cuda.synchronize()
+        assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction), world
+        assert torch.equal(buf0.kinetic_temperature, buf2.kinetic_temperature), world
+        assert rep0.global_xH == rep2.global_xH
+
+
 def test_full_size_properties(api):
     """Config-3 size (512^3, 40 radii): size-independent properties instead of the oracle.
     (1) run-to-run bit reproducibility (deterministic reductions),

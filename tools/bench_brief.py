@@ -6,5 +6,6 @@ d = json.loads(sys.stdin.read())
 r = d["roofline"]
 print(sys.argv[1] if len(sys.argv) > 1 else "", "ms/step", round(d["ms_per_step"], 3), "xH",
       d["config"]["global_xH"], "r_loop ms", round(r["r_loop"]["ms"], 3), "frac",
-      round(r["r_loop"]["frac"], 4), "dominant ms", round(r.get("ms_per_launch", 0), 4),
+      round(r["r_loop"]["frac"], 4), "dominant", r.get("kernel", "")[:27], "frac",
+      round(r.get("frac", 0), 4), "ms", round(r.get("ms_per_launch", 0), 4),
       "others", [round(k["ms"], 4) for k in r.get("other_kernels", [])])
