@@ -652,7 +652,13 @@ struct LineThreads {
 };
 
 // the geometry of one work item, in wave-uniform registers
-struct LineItem {
+struct LineItemSecond {  // FMODE 5: the second radius' outputs and window tables
+    float2 *dst0b, *dst1b;
+    const wtab_t *wt0b, *wt1b;
+};
+struct LineItemNone {};
+template <bool PAIR>
+struct LineItemT : std::conditional_t<PAIR, LineItemSecond, LineItemNone> {
     const float2 *src0, *src1;
     float2 *dst0, *dst1;
     long line_stride, line_bstride, outer_stride, outer_bstride, col_stride;
@@ -660,8 +666,6 @@ struct LineItem {
     int n_outer, filter_axis;
     int og, ct, npair;
     const wtab_t *wt0, *wt1;  // FMODE 3: window tables of this geometry
-    float2 *dst0b, *dst1b;      // FMODE 5: second radius
-    const wtab_t *wt0b, *wt1b;
 };
 
 // FMODE: 0 no window, 3 window streamed from the per-radius tables, 4 separable k-space
@@ -676,9 +680,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     constexpr int RSTEP = kBlock / CPAIR;  // rows covered by one sweep of the workgroup
     constexpr bool WIN = (FMODE == 3 || FMODE == 5);
     constexpr int NR = (FMODE == 5) ? 2 : 1;  // radii per sweep
+    using LineItem = LineItemT<FMODE == 5>;
     extern __shared__ float4 lds_raw[];
-    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
-    float2 *tw = tile + N * TZ;                          // [N]
+    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ] (x 2 radii with FMODE 5)
+    float2 *tw = tile + NR * N * TZ;                     // [N]
     float2 *tw_half = tw + N;                            // [N/2], N = 1024 only
     for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
     if (N >= 1024)
@@ -723,7 +728,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         it.filter_axis = s ? a.g1.filter_axis : a.g0.filter_axis;
         it.wt0 = (it.filter_axis == 1) ? a.wt_nyq[0] : a.wt_main[0];
         it.wt1 = (it.filter_axis == 1) ? a.wt_nyq[1] : a.wt_main[1];
-        if (FMODE == 5) {
+        if constexpr (FMODE == 5) {
             it.dst0b = s ? a.g1.dst2[0] : a.g0.dst2[0];
             it.dst1b = s ? a.g1.dst2[1] : a.g0.dst2[1];
             it.wt0b = (it.filter_axis == 1) ? a.wt2_nyq[0] : a.wt2_main[0];
@@ -770,7 +775,9 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const bool second = a.dual && member_grid(it, m);
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) {
-            const wtab_t *t = rr ? (second ? it.wt1b : it.wt0b) : (second ? it.wt1 : it.wt0);
+            const wtab_t *t = second ? it.wt1 : it.wt0;
+            if constexpr (FMODE == 5)
+                if (rr) t = second ? it.wt1b : it.wt0b;
             if (it.filter_axis == 0) {
                 const unsigned wc = (unsigned)(a.n_z / 2);
                 const wtab_t *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
@@ -875,13 +882,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             op_c0 = a.op_sign * fy0 * fz0;
             op_c1 = a.op_sign * fy1 * fz1;
         }
+        // (two radii per sweep: the tile goes to LDS twice, once under each radius' window)
 #pragma unroll
       for (int rr = 0; rr < NR; rr++) {
-        // store target of the tile now in registers (radius rr of the sweep)
-        float2 *const st_lo = (rr ? (member_grid(it, m) ? it.dst1b : it.dst0b)
-                                  : (member_grid(it, m) ? it.dst1 : it.dst0)) +
-                              member_base(it, m);
-        if (rr) __syncthreads();  // the first radius' LDS reads are done
+        float2 *const tile_r = tile + rr * N * TZ;
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
@@ -913,27 +917,33 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 v.z = __fmul_rn(v.z, wv.y);
                 v.w = __fmul_rn(v.w, wv.y);
             }
-            *reinterpret_cast<float4 *>(tile + row * TZ + 2 * c4) = v;
+            *reinterpret_cast<float4 *>(tile_r + row * TZ + 2 * c4) = v;
         }
+      }
         __syncthreads();
         // ---- the register set is free: put the loads of the tile after next in flight
         // (unconditionally -- past the end of the sequence the last tile is simply read
         // again -- so that the number of loads in flight is static and the compiler can wait
         // with vmcnt(n > 0) for exactly this register set instead of draining everything)
         // (a TileRef past the end still names the last tile, see next_tile)
-        // (with two radii per sweep: after the second radius has left the registers)
-        if (rr == NR - 1) {
-            if (WIN && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
-            issue_loads(reg, refill.it, refill.m);
-        }
+        if (WIN && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
+        issue_loads(reg, refill.it, refill.m);
 
-        line_fft<N, TZ, SIGN, kBlock>(tile, tw, tw_half);
+#pragma unroll
+      for (int rr = 0; rr < NR; rr++) {
+        float2 *const tile_r = tile + rr * N * TZ;
+        // store target of the tile (radius rr of the sweep)
+        float2 *st_lo = member_grid(it, m) ? it.dst1 : it.dst0;
+        if constexpr (FMODE == 5)
+            if (rr) st_lo = member_grid(it, m) ? it.dst1b : it.dst0b;
+        st_lo += member_base(it, m);
+        line_fft<N, TZ, SIGN, kBlock>(tile_r, tw, tw_half);
         // ---- store
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
             const int row = (u & 1) ? mirror_row<N>(row_a) : row_a;
-            float4 v = *reinterpret_cast<const float4 *>(tile + fft_out_row<N>(row) * TZ + 2 * c4);
+            float4 v = *reinterpret_cast<const float4 *>(tile_r + fft_out_row<N>(row) * TZ + 2 * c4);
             if (a.out_scale != 1.0f) {
                 v.x *= a.out_scale;
                 v.y *= a.out_scale;
@@ -1496,7 +1506,8 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
         return C21CM_MEMORY_ALLOC_ERROR;
     }
-    const size_t lds = sizeof(float2) * ((size_t)N * line_tile_cols(N) + N + (N >= 1024 ? N / 2 : 0));
+    const size_t lds = sizeof(float2) * ((size_t)(FMODE == 5 ? 2 : 1) * N * line_tile_cols(N) + N +
+                                         (N >= 1024 ? N / 2 : 0));
     const int n_work = geo_items(a.g0) + (a.n_geo > 1 ? geo_items(a.g1) : 0);
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
     int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
