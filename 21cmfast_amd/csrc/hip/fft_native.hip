@@ -679,8 +679,9 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     constexpr int CPAIR = TZ / 2;          // float4 (column pairs) per row
     constexpr int RSTEP = kBlock / CPAIR;  // rows covered by one sweep of the workgroup
     constexpr bool WIN = (FMODE == 3 || FMODE == 5);
-    constexpr int NR = (FMODE == 5) ? 2 : 1;  // radii per sweep
-    using LineItem = LineItemT<FMODE == 5>;
+    constexpr bool PAIR = (FMODE == 5);
+    constexpr int NR = PAIR ? 2 : 1;     // radii per sweep
+    using LineItem = LineItemT<PAIR>;
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ] (x 2 radii with FMODE 5)
     float2 *tw = tile + NR * N * TZ;                     // [N]
@@ -728,7 +729,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         it.filter_axis = s ? a.g1.filter_axis : a.g0.filter_axis;
         it.wt0 = (it.filter_axis == 1) ? a.wt_nyq[0] : a.wt_main[0];
         it.wt1 = (it.filter_axis == 1) ? a.wt_nyq[1] : a.wt_main[1];
-        if constexpr (FMODE == 5) {
+        if constexpr (PAIR) {
             it.dst0b = s ? a.g1.dst2[0] : a.g0.dst2[0];
             it.dst1b = s ? a.g1.dst2[1] : a.g0.dst2[1];
             it.wt0b = (it.filter_axis == 1) ? a.wt2_nyq[0] : a.wt2_main[0];
@@ -762,7 +763,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // Two register sets: while tile t is transformed in LDS, the loads of tiles t+1 AND t+2
     // are in flight (a single set left HBM idle between a tile's arrival and the issue of the
     // next loads: 4.5 TB/s against the 6.3 TB/s a plain copy reaches).
-    constexpr bool TWO_SETS = (N < 1024);
+    // Two radii per sweep: ONE set.  The next tile's loads go out before the two transforms of
+    // this one, which is the look-ahead two sets buy the single-radius pass; the second set only
+    // cost registers there (256 VGPRs + 84 bytes of scratch; 0.95 against 0.89 ms at 512^3).
+    constexpr bool TWO_SETS = (N < 1024) && !PAIR;
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
@@ -776,7 +780,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) {
             const wtab_t *t = second ? it.wt1 : it.wt0;
-            if constexpr (FMODE == 5)
+            if constexpr (PAIR)
                 if (rr) t = second ? it.wt1b : it.wt0b;
             if (it.filter_axis == 0) {
                 const unsigned wc = (unsigned)(a.n_z / 2);
@@ -934,7 +938,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         float2 *const tile_r = tile + rr * N * TZ;
         // store target of the tile (radius rr of the sweep)
         float2 *st_lo = member_grid(it, m) ? it.dst1 : it.dst0;
-        if constexpr (FMODE == 5)
+        if constexpr (PAIR)
             if (rr) st_lo = member_grid(it, m) ? it.dst1b : it.dst0b;
         st_lo += member_base(it, m);
         line_fft<N, TZ, SIGN, kBlock>(tile_r, tw, tw_half);
@@ -1532,7 +1536,7 @@ template <int N, int SIGN>
 int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
     if (SIGN > 0 && fmode == 3) return launch_line_pass_mode<N, +1, 3>(a, stream);
     if (SIGN > 0 && fmode == 4) return launch_line_pass_mode<N, +1, 4>(a, stream);
-    if constexpr (N < 1024)  // two radii per sweep need the tile to stay in registers
+    if constexpr (N < 1024)  // two radii per sweep: two tiles in LDS
         if (SIGN > 0 && fmode == 5) return launch_line_pass_mode<N, +1, 5>(a, stream);
     return launch_line_pass_mode<N, SIGN, 0>(a, stream);
 }
@@ -2536,11 +2540,13 @@ extern "C" int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, f
                                             float *work_b, float *work_b2, int filter_b,
                                             float R_param_b, int nx, int ny, int nz,
                                             double box_len, double box_len_z, float R, float R2,
-                                            int table_slot, int table_slot2, int tables_ready,
+                                            int table_slot, int table_slot2, int phases,
                                             void *stream_) {
+    // phases: 1 build the window tables, 2 pass X, 4 the two passes Y (the caller may record
+    // an event between X and Y: pass X is the only reader of the tables)
     return filter_xy_pair(src_a, work_a, work_a2, filter_a, R_param_a, src_b, work_b, work_b2,
                           filter_b, R_param_b, nx, ny, nz, box_len, box_len_z, R, R2, table_slot,
-                          table_slot2, tables_ready ? 6 : 7, stream_);
+                          table_slot2, phases, stream_);
 }
 
 // One or two grids of one shell of the spin-temperature filters: windows 4 (spherical shell)

@@ -163,7 +163,17 @@ extern "C" int c21hip_stream_wait_event(void *stream, void *ev) {
 // data of the caller's stream, e.g. the window tables of the next filter radius.
 extern "C" void *c21hip_aux_stream(void) {
     static hipStream_t aux = nullptr;
-    if (!aux && hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) aux = nullptr;
+    if (!aux) {
+        // lowest priority: what runs here (window tables of the coming radii) only fills in
+        // behind the kernels of the caller's stream (C21CM_AUX_PRIO=default: same priority)
+        int least = 0, greatest = 0;
+        const char *e = getenv("C21CM_AUX_PRIO");
+        const bool low = !(e && e[0] == 'd') &&
+                         hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        const hipError_t st = low ? hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, least)
+                                  : hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+        if (st != hipSuccess) aux = nullptr;
+    }
     return aux;
 }
 extern "C" float c21hip_event_elapsed_ms(void *start, void *stop) {
