@@ -84,6 +84,11 @@ int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, float *work_
                                  float *work_b2, int filter_b, float R_param_b, int nx, int ny,
                                  int nz, double box_len, double box_len_z, float R, float R2,
                                  int table_slot, int table_slot2, int phases, void *stream);
+/* one grid, two radii, window a of the tables built for the two-grid sweep of those radii */
+int c21hip_split_filter_xy_shared_pair(const float *src, float *work, float *work2,
+                                       int filter_type, int nx, int ny, int nz, double box_len,
+                                       double box_len_z, float R, float R2, int table_slot,
+                                       int table_slot2, void *stream);
 /* W(kR) tables of one radius for c21hip_split_filter_xy2, on any stream */
 int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
                          float R_param_b, int nx, int ny, int nz, double box_len,

@@ -2470,14 +2470,16 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
                           float R_param_a, const float *src_b, float *work_b, float *work_b2,
                           int filter_b, float R_param_b, int nx, int ny, int nz, double box_len,
                           double box_len_z, float R, float R2, int table_slot, int table_slot2,
-                          int phases, void *stream_) {
+                          int phases, void *stream_, int n_grids = 2) {
     // phases: 1 window tables, 2 pass X, 4 the two passes Y
+    // n_grids = 1: grid a only, with window a of tables built for a two-grid sweep (phases & 1
+    // must be clear)
     const int tables_ready = !(phases & 1);
     const int ft[2] = {filter_a, filter_b};
     const float rp[2] = {R_param_a, R_param_b};
-    int st = check_filter_request(2, nx, ny, nz, ft, 1);
+    int st = check_filter_request(n_grids, nx, ny, nz, ft, 1);
     if (st) return st;
-    if (nx >= 1024 || table_slot == table_slot2) {
+    if (nx >= 1024 || table_slot == table_slot2 || (n_grids != 2 && !tables_ready)) {
         c21hip_set_error("two-radius sweep: nx = %d / table slots %d, %d not supported", nx,
                          table_slot, table_slot2);
         return C21CM_VALUE_ERROR;
@@ -2486,10 +2488,10 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
     const int H = nz / 2;
     const long nlines = (long)nx * ny;
     WinTables w, w2;
-    if ((st = win_tables(table_slot, 2, ft, R, rp, 0.f, nx, ny, nz, box_len, box_len_z,
+    if ((st = win_tables(table_slot, n_grids, ft, R, rp, 0.f, nx, ny, nz, box_len, box_len_z,
                          !tables_ready, stream, w)))
         return st;
-    if ((st = win_tables(table_slot2, 2, ft, R2, rp, 0.f, nx, ny, nz, box_len, box_len_z,
+    if ((st = win_tables(table_slot2, n_grids, ft, R2, rp, 0.f, nx, ny, nz, box_len, box_len_z,
                          !tables_ready, stream, w2)))
         return st;
     LinePassArgs a{};
@@ -2505,14 +2507,14 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
     }
     a.dual = w.dual;
     a.n_geo = 2;
-    a.n_grids = 2;
+    a.n_grids = n_grids;
     a.g0 = geo_x_main(ny, H, line_tile_cols(nx), split_xb_log2(nx));
     a.g1 = geo_x_nyq(ny, line_tile_cols(nx));
     const float2 *src[2] = {reinterpret_cast<const float2 *>(src_a),
                             reinterpret_cast<const float2 *>(src_b)};
     float2 *work[2] = {reinterpret_cast<float2 *>(work_a), reinterpret_cast<float2 *>(work_b)};
     float2 *work2[2] = {reinterpret_cast<float2 *>(work_a2), reinterpret_cast<float2 *>(work_b2)};
-    for (int g = 0; g < 2; g++) {
+    for (int g = 0; g < n_grids; g++) {
         geo_ptrs(a.g0, g, src[g], work[g]);
         geo_ptrs(a.g1, g, src[g] + nlines * H, work[g] + nlines * H);
         a.g0.dst2[g] = work2[g];
@@ -2526,7 +2528,7 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
         a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
         a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
         a.g1_strided = 1;
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < n_grids; g++) {
             geo_ptrs(a.g0, g, wk[g], wk[g]);
             geo_ptrs(a.g1, g, wk[g] + nlines * H, wk[g] + nlines * H);
         }
@@ -2547,6 +2549,18 @@ extern "C" int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, f
     return filter_xy_pair(src_a, work_a, work_a2, filter_a, R_param_a, src_b, work_b, work_b2,
                           filter_b, R_param_b, nx, ny, nz, box_len, box_len_z, R, R2, table_slot,
                           table_slot2, phases, stream_);
+}
+
+// ONE grid, two radii per sweep, with window a of the tables in table_slot / table_slot2 (built
+// for the two-grid sweep of the same radii): the x_e grid of a spin-temperature run.
+extern "C" int c21hip_split_filter_xy_shared_pair(const float *src, float *work, float *work2,
+                                                  int filter_type, int nx, int ny, int nz,
+                                                  double box_len, double box_len_z, float R,
+                                                  float R2, int table_slot, int table_slot2,
+                                                  void *stream_) {
+    return filter_xy_pair(src, work, work2, filter_type, 0.f, nullptr, nullptr, nullptr, 0, 0.f,
+                          nx, ny, nz, box_len, box_len_z, R, R2, table_slot, table_slot2, 6,
+                          stream_, 1);
 }
 
 // One or two grids of one shell of the spin-temperature filters: windows 4 (spherical shell)

@@ -51,7 +51,8 @@ enum {
     WS_PARTIALS,
     WS_DEF_PARTIALS = 84,
     WS_DELTA_WORK2 = 92, /* second radius of a two-radius sweep */
-    WS_STARS_WORK2 = 93
+    WS_STARS_WORK2 = 93,
+    WS_XE_WORK2 = 96
 };
 
 #define MAX_COPYBACK 8
@@ -199,7 +200,7 @@ typedef struct {
      * real-space grids (padded rows) */
     float *delta_unf, *delta_fil, *stars_unf, *stars_fil, *xe_unf, *xe_fil;
     float *delta_work, *stars_work, *xe_work;
-    float *delta_work2, *stars_work2; /* two radii per pass-X sweep (pair_radii) */
+    float *delta_work2, *stars_work2, *xe_work2; /* two radii per pass-X sweep (pair_radii) */
     int pair_radii;
     /* dense inputs */
     const float *density, *n_ion, *xe_dense, *Tneutral, *prev_zre;
@@ -275,7 +276,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
     c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct;
-    if (c->fused && !s->use_ts_fluct && c->nx < 1024) {
+    if (c->fused && c->nx < 1024) {
         /* pass X reads each spectrum tile once for two consecutive radii (C21CM_PAIR_RADII=0:
          * one radius per sweep) */
         const char *e = getenv("C21CM_PAIR_RADII");
@@ -283,6 +284,8 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             c->delta_work2 = (float *)c21hip_ws(WS_DELTA_WORK2, gbytes);
             c->stars_work2 = (float *)c21hip_ws(WS_STARS_WORK2, gbytes);
             if (!c->delta_work2 || !c->stars_work2) return C21CM_MEMORY_ALLOC_ERROR;
+            if (s->use_ts_fluct && !(c->xe_work2 = (float *)c21hip_ws(WS_XE_WORK2, gbytes)))
+                return C21CM_MEMORY_ALLOC_ERROR;
             c->pair_radii = 1;
         }
     }
@@ -462,10 +465,9 @@ static int flush_deferred(ion_ctx *c) {
 /* Fused pass Z of one radius (density + emissivity [+ x_e] spectra after passes X, Y): barrier
  * test into the mask, f_coll sum deferred or reduced now. */
 static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float *swork,
-                           unsigned char *first_cross) {
+                           const float *xwork, unsigned char *first_cross) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
-    const float *xwork = s->use_ts_fluct ? c->xe_work : NULL;
     if (c->def_partials) {
         /* no kernel of this loop reads a radius' mean: reduce all of them at the end */
         if (c->def_count == 0)
@@ -532,6 +534,11 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                 c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a,
                 buf_b, ph ? 4 : (tab_async ? 2 : 3), c->stream));
         }
+        if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
+            TRY(c21hip_split_filter_xy_shared_pair(c->xe_unf, c->xe_work, c->xe_work2,
+                                                   s->hii_filter, c->nx, c->ny, c->nz, s->box_len,
+                                                   s->box_len_z, (float)s->R[R_a],
+                                                   (float)s->R[R_b], buf_a, buf_b, c->stream));
         /* (recording these right after pass X, its only reader, lets the next builds overlap
          * with the passes Y instead of pass Z: measured 4 ms per call slower at 512^3) */
         if (tab_async) {
@@ -550,8 +557,11 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
         if (tab_async) TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
     }
     c->tab_seq++;
-    TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, first_cross));
-    if (R_b >= 1) TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2, first_cross));
+    TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work,
+                        s->use_ts_fluct ? c->xe_work : NULL, first_cross));
+    if (R_b >= 1)
+        TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2,
+                            s->use_ts_fluct ? c->xe_work2 : NULL, first_cross));
 done:
     return status;
 }

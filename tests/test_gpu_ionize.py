@@ -350,6 +350,29 @@ def test_two_radii_per_sweep_equal_one(api, n, r_max, monkeypatch):
         assert rep0.global_xH == rep2.global_xH
 
 
+def test_two_radii_per_sweep_with_xe_grid(api, monkeypatch):
+    """The same with the x_e grid of a spin-temperature run (three spectra per radius; the x_e
+    spectrum rides a one-grid two-radius sweep on window a of both radii's tables)."""
+    import torch
+
+    n, nz = 64, 256
+    spec = W.ionize_spec(n, hii_dim_z=nz, r_bubble_max=8.0, use_ts_fluct=1)
+    rng = np.random.default_rng(11)
+    density = torch.from_numpy(W.density_field_numpy((n, n, nz), seed=5)).cuda()
+    n_ion = W.nion_from_density(density)
+    xe = torch.from_numpy((-0.05 + 0.6 * rng.random((n, n, nz)) ** 3).astype(np.float32)).cuda()
+    Tn = torch.from_numpy((8.0 + 4.0 * rng.random((n, n, nz))).astype(np.float32)).cuda()
+    monkeypatch.setenv("C21CM_PAIR_RADII", "0")
+    buf0, _, rep0 = api.ionize_grids(spec, density, n_ion, xe=xe, Tneutral=Tn)
+    monkeypatch.delenv("C21CM_PAIR_RADII")
+    buf1, _, rep1 = api.ionize_grids(spec, density, n_ion, xe=xe, Tneutral=Tn)
+    torch.cuda.synchronize()
+    assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
+    for name in ("neutral_fraction", "z_reion", "kinetic_temperature"):
+        assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
+    assert rep0.global_xH == rep1.global_xH
+
+
 def test_full_size_properties(api):
     """Config-3 size (512^3, 40 radii): size-independent properties instead of the oracle.
     (1) run-to-run bit reproducibility (deterministic reductions),
