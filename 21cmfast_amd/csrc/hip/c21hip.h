@@ -78,7 +78,7 @@ int c21hip_split_filter_shell(const float *src_a, float *work_a, int filter_a, c
                               double box_len, double box_len_z, float R_inner, float R_outer,
                               float R_star, int apply, void *stream);
 /* the same for two radii out of one pass-X sweep (nx < 1024); table slots 0..3;
- * phases: 1 build the tables, 2 pass X, 4 the passes Y */
+ * phases: 1 build the tables, 2 pass X, 4 / 8 pass Y of the first / second radius */
 int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, float *work_a2, int filter_a,
                                  float R_param_a, const float *src_b, float *work_b,
                                  float *work_b2, int filter_b, float R_param_b, int nx, int ny,
@@ -88,7 +88,7 @@ int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, float *work_
 int c21hip_split_filter_xy_shared_pair(const float *src, float *work, float *work2,
                                        int filter_type, int nx, int ny, int nz, double box_len,
                                        double box_len_z, float R, float R2, int table_slot,
-                                       int table_slot2, void *stream);
+                                       int table_slot2, int phases, void *stream);
 /* W(kR) tables of one radius for c21hip_split_filter_xy2, on any stream */
 int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
                          float R_param_b, int nx, int ny, int nz, double box_len,

@@ -1324,6 +1324,7 @@ struct ZFusedArgs {
     int mass_dep_zeta, r_index;
     int ny, lb;  // x-blocked layout (logical_line())
     int store_all;  // write the mask back even where this radius changed nothing
+    int reverse;    // workgroups walk the lines from the end (see dispatch_z_fused)
 };
 
 template <int NZ>
@@ -1659,7 +1660,10 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / P, b = lane % P;
     const int lw = wave * (64 / P) + g;
-    const long line = (long)blockIdx.x * ZWL + lw;
+    // reverse: start where the pass Y that just ran stopped writing, i.e. with the lines the
+    // 256 MB Infinity Cache still holds
+    const unsigned blk = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const long line = (long)blk * ZWL + lw;
     float2 *L = lines + lw * LINE_LDS;
     const float2 *dm = a.d_main + line * H, *sm = a.s_main + line * H;
     float2 xd[A], xs[A];
@@ -1734,7 +1738,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         double sum = 0.;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; w++) sum += red[w];
-        a.partials[blockIdx.x] = sum;
+        a.partials[blk] = sum;
     }
 }
 
@@ -2471,7 +2475,7 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
                           int filter_b, float R_param_b, int nx, int ny, int nz, double box_len,
                           double box_len_z, float R, float R2, int table_slot, int table_slot2,
                           int phases, void *stream_, int n_grids = 2) {
-    // phases: 1 window tables, 2 pass X, 4 the two passes Y
+    // phases: 1 window tables, 2 pass X, 4 pass Y of the first radius, 8 pass Y of the second
     // n_grids = 1: grid a only, with window a of tables built for a two-grid sweep (phases & 1
     // must be clear)
     const int tables_ready = !(phases & 1);
@@ -2521,9 +2525,10 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
         a.g1.dst2[g] = work2[g] + nlines * H;
     }
     if ((phases & 2) && (st = dispatch_line_pass<+1>(nx, a, 5, stream))) return st;
-    if (!(phases & 4)) return 0;
+    if (!(phases & 12)) return 0;
     // ---- pass Y (in place), one launch per radius
     for (int r = 0; r < 2; r++) {
+        if (!(phases & (4 << r))) continue;
         float2 *const *wk = r ? work2 : work;
         a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
         a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
@@ -2544,8 +2549,7 @@ extern "C" int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, f
                                             double box_len, double box_len_z, float R, float R2,
                                             int table_slot, int table_slot2, int phases,
                                             void *stream_) {
-    // phases: 1 build the window tables, 2 pass X, 4 the two passes Y (the caller may record
-    // an event between X and Y: pass X is the only reader of the tables)
+    // phases: 1 build the window tables, 2 pass X, 4 / 8 pass Y of the first / second radius
     return filter_xy_pair(src_a, work_a, work_a2, filter_a, R_param_a, src_b, work_b, work_b2,
                           filter_b, R_param_b, nx, ny, nz, box_len, box_len_z, R, R2, table_slot,
                           table_slot2, phases, stream_);
@@ -2557,9 +2561,9 @@ extern "C" int c21hip_split_filter_xy_shared_pair(const float *src, float *work,
                                                   int filter_type, int nx, int ny, int nz,
                                                   double box_len, double box_len_z, float R,
                                                   float R2, int table_slot, int table_slot2,
-                                                  void *stream_) {
+                                                  int phases, void *stream_) {
     return filter_xy_pair(src, work, work2, filter_type, 0.f, nullptr, nullptr, nullptr, 0, 0.f,
-                          nx, ny, nz, box_len, box_len_z, R, R2, table_slot, table_slot2, 6,
+                          nx, ny, nz, box_len, box_len_z, R, R2, table_slot, table_slot2, phases,
                           stream_, 1);
 }
 
@@ -2879,6 +2883,11 @@ extern "C" int c21hip_split_z_ionise_stars_xe(const float *delta_work, const flo
         return (e && e[0] == '1') ? 1 : 0;
     }();
     a.store_all = store_all;
+    static const int reverse = [] {
+        const char *e = getenv("C21CM_ZREV");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    a.reverse = reverse;
     int n_partials = 0;
     int st = dispatch_z_fused(nz, a, nlines, (hipStream_t)stream, &n_partials);
     if (st) return st;

@@ -527,24 +527,41 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
         if (R_b >= 1) TRY(c21hip_stream_wait_event(c->stream, g_tab.ev_table[buf_b]));
     }
     if (R_b >= 1) {
-        for (int ph = 0; ph < 2; ph++) {
+        /* X (both radii) -> Y_a -> Z_a -> Y_b -> Z_b: each fused pass Z directly follows the pass
+         * Y that wrote its input and walks the lines backwards, so its first quarter comes out
+         * of the Infinity Cache (C21CM_PAIR_ORDER=yy: both passes Y first) */
+        static int yy = -1;
+        if (yy < 0) {
+            const char *e = getenv("C21CM_PAIR_ORDER");
+            yy = (e && e[0] == 'y') ? 1 : 0;
+        }
+        const float *xw[2] = {s->use_ts_fluct ? c->xe_work : NULL,
+                              s->use_ts_fluct ? c->xe_work2 : NULL};
+        for (int ph = 0; ph < 3; ph++) { /* pass X, pass Y of R_a, pass Y of R_b */
+            const int bits = ph == 0 ? (tab_async ? 2 : 3) : (4 << (ph - 1));
             TRY(c21hip_split_filter_xy2_pair(
                 c->delta_unf, c->delta_work, c->delta_work2, s->hii_filter, 0.f, c->stars_unf,
                 c->stars_work, c->stars_work2, s->stars_filter, (float)s->mfp_meandens, c->nx,
                 c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a,
-                buf_b, ph ? 4 : (tab_async ? 2 : 3), c->stream));
+                buf_b, bits, c->stream));
+            if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
+                TRY(c21hip_split_filter_xy_shared_pair(
+                    c->xe_unf, c->xe_work, c->xe_work2, s->hii_filter, c->nx, c->ny, c->nz,
+                    s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a, buf_b,
+                    bits & ~1, c->stream));
+            /* (the tables are free after pass X, their only reader; releasing them there lets the
+             * next builds run under pass Y, which measured 4 ms per call slower than under pass Z) */
+            if (ph == (yy ? 2 : 1) && tab_async) {
+                TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
+                TRY(c21hip_event_record(g_tab.ev_used[buf_b], c->stream));
+            }
+            if (ph == 1 && !yy)
+                TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
         }
-        if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
-            TRY(c21hip_split_filter_xy_shared_pair(c->xe_unf, c->xe_work, c->xe_work2,
-                                                   s->hii_filter, c->nx, c->ny, c->nz, s->box_len,
-                                                   s->box_len_z, (float)s->R[R_a],
-                                                   (float)s->R[R_b], buf_a, buf_b, c->stream));
-        /* (recording these right after pass X, its only reader, lets the next builds overlap
-         * with the passes Y instead of pass Z: measured 4 ms per call slower at 512^3) */
-        if (tab_async) {
-            TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
-            TRY(c21hip_event_record(g_tab.ev_used[buf_b], c->stream));
-        }
+        c->tab_seq++;
+        if (yy) TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
+        TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2, xw[1], first_cross));
+        goto done;
     } else {
         TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->stars_unf,
                                     c->stars_work, s->stars_filter, (float)s->mfp_meandens, c->nx,
@@ -559,9 +576,6 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
     c->tab_seq++;
     TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work,
                         s->use_ts_fluct ? c->xe_work : NULL, first_cross));
-    if (R_b >= 1)
-        TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2,
-                            s->use_ts_fluct ? c->xe_work2 : NULL, first_cross));
 done:
     return status;
 }
