@@ -19,17 +19,29 @@ for group in \
       python $REPO/tools/time_passes.py 512 > /dev/null 2> $REPO/gpurun_out/pmc_study/g$i.err
 done
 cd $REPO
-python - <<'PY'
+python - <<'PY' | tee gpurun_out/pmc_study_pass_kernels.txt
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_study/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "line_pass_kernel" in n or "z_c2r" in n or "window_table" in n:
+        if any(t in n for t in ("line_pass_kernel", "z_c2r", "zw_", "window_table")):
             key = n.split("(anonymous namespace)::")[1].split("(")[0]
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("# rocprofv3 --pmc study of the pass kernels at 512^3 (tools/pmc_passes.sh over tools/time_passes.py;")
+print("# one run per counter group, mean per launch; line_pass<512,1,0> mixes pass X without window and pass Y)")
 for k, d in sorted(acc.items()):
     print("==", k)
+    m = {}
     for c, v in sorted(d.items()):
-        print(f"   {c:36s} n={len(v):3d} mean={sum(v)/len(v):.4g}")
+        m[c] = sum(v) / len(v)
+        print(f"   {c:36s} launches={len(v):3d} mean={m[c]:.4g}")
+    try:
+        print(f"   -> mean L1->L2 read latency {m['TCP_TCC_READ_REQ_LATENCY_sum'] / m['TCP_TCC_READ_REQ_sum']:.0f} cycles; "
+              f"wait-on-memory share of wave cycles {m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.2f}; "
+              f"LDS-active share {m['SQ_ACTIVE_INST_LDS'] / m['SQ_WAVE_CYCLES']:.3f}; "
+              f"VALU-active share {m['SQ_ACTIVE_INST_VALU'] / m['SQ_WAVE_CYCLES']:.3f}; "
+              f"L2 hit rate {m['TCC_HIT_sum'] / max(1.0, m['TCC_REQ_sum']):.2f}")
+    except (KeyError, ZeroDivisionError):
+        pass
 PY
