@@ -770,7 +770,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
-    float2 wpre[NR][NP], wcur[NR][NP], wpre_half[NR], wcur_half[NR];
+    // Lines of 256 points and fewer load the next window straight into `cur` (it is dead between
+    // a tile's LDS write and the next tile's): 10 % faster there (two workgroups per CU share the
+    // register file), 3-6 % slower at 512 and 1024 points, which keep the separate `pre` set.
+    constexpr bool WPRE = (N >= 512);
+    float2 wpre[NR][WPRE ? NP : 1], wcur[NR][NP], wpre_half[NR], wcur_half[NR];
     auto w_reload = [&](const LineItem &it, int m) {
         const int mi = it.npair == 2 ? (m & 1) : 0;
         return m == 0 || (a.dual && mi == 0);
@@ -787,9 +791,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 const wtab_t *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
 #pragma unroll
                 for (int u = 0; u < NP; u++)
-                    wpre[rr][u] =
+                    (WPRE ? wpre[rr][WPRE ? u : 0] : wcur[rr][u]) =
                         *reinterpret_cast<const float2 *>(b + (unsigned)(r0 + RSTEP * u) * wc);
-                wpre_half[rr] = *reinterpret_cast<const float2 *>(b + (unsigned)(N / 2) * wc);
+                (WPRE ? wpre_half[rr] : wcur_half[rr]) =
+                    *reinterpret_cast<const float2 *>(b + (unsigned)(N / 2) * wc);
             } else {
                 const int c0 = it.ct * TZ + 2 * c4;
                 const unsigned nyh = (unsigned)(a.n_y / 2 + 1);
@@ -798,11 +803,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
 #pragma unroll
                 for (int u = 0; u < NP; u++) {
                     const wtab_t *r = t + (unsigned)(r0 + RSTEP * u) * nyh;
-                    wpre[rr][u] = make_float2(r[j0], r[j1]);
+                    (WPRE ? wpre[rr][WPRE ? u : 0] : wcur[rr][u]) = make_float2(r[j0], r[j1]);
                 }
                 {
                     const wtab_t *r = t + (unsigned)(N / 2) * nyh;
-                    wpre_half[rr] = make_float2(r[j0], r[j1]);
+                    (WPRE ? wpre_half[rr] : wcur_half[rr]) = make_float2(r[j0], r[j1]);
                 }
             }
         }
@@ -854,11 +859,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const long st_half = (long)((N / 2) >> it.line_lb) * it.line_bstride;
         if (!first) __syncthreads();  // the previous tile's LDS reads are done
         first = false;
-        if (WIN && w_reload(it, m)) {
+        if (WIN && WPRE && w_reload(it, m)) {
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
 #pragma unroll
-                for (int u = 0; u < NP; u++) wcur[rr][u] = wpre[rr][u];
+                for (int u = 0; u < NP; u++) wcur[rr][u] = wpre[rr][WPRE ? u : 0];
                 wcur_half[rr] = wpre_half[rr];
             }
         }
