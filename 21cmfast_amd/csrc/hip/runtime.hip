@@ -164,11 +164,12 @@ extern "C" int c21hip_stream_wait_event(void *stream, void *ev) {
 extern "C" void *c21hip_aux_stream(void) {
     static hipStream_t aux = nullptr;
     if (!aux) {
-        // lowest priority: what runs here (window tables of the coming radii) only fills in
-        // behind the kernels of the caller's stream (C21CM_AUX_PRIO=default: same priority)
+        // C21CM_AUX_PRIO=low: lowest stream priority, so that what runs here (window tables of
+        // the coming radii) only fills in behind the caller's kernels.  Measured no difference at
+        // 512^3, so the default stays a plain non-blocking stream.
         int least = 0, greatest = 0;
         const char *e = getenv("C21CM_AUX_PRIO");
-        const bool low = !(e && e[0] == 'd') &&
+        const bool low = e && e[0] == 'l' &&
                          hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
         const hipError_t st = low ? hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, least)
                                   : hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
