@@ -87,8 +87,10 @@ def _declare(lib):
             getattr(lib, name).restype = f64
             getattr(lib, name).argtypes = argt
     if hasattr(lib, "init_ps"):
-        lib.init_ps.restype = f64
+        lib.init_ps.restype = None  # void init_ps(void), include/c21cm_abi.h
+        lib.init_ps.argtypes = []
         lib.free_ps.restype = None
+        lib.free_ps.argtypes = []
     return lib
 
 

@@ -321,7 +321,11 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         box->log10_Mturnover_ave = halos->log10_Mcrit_ACG_ave;
         box->log10_Mturnover_MINI_ave = halos->log10_Mcrit_MCG_ave;
         Mturn_avg = pow(10., halos->log10_Mcrit_ACG_ave);
-    } else {
+    } else if (mass_dep) { /* E-INTEGRAL without mini-halos: the turnover mass, :1446-1449 */
+        Mturn_avg = ap->M_TURN;
+        box->log10_Mturnover_ave = log10(Mturn_avg);
+        box->log10_Mturnover_MINI_ave = 0.0;
+    } else { /* CONST-ION-EFF: "just store the sharp cutoff mass", :1450-1454 */
         Mturn_avg = M_min;
         box->log10_Mturnover_ave = log10(M_min);
         box->log10_Mturnover_MINI_ave = 0.0;

@@ -41,6 +41,7 @@
 static struct {
     double sound_horizon, alpha_nu, beta_c, omhh, f_nu, f_baryon, theta_cmb, sigma_norm;
     int ready;
+    unsigned generation; /* bumped by every init_ps: derived tables key on it */
 } cc;
 
 /* ---------------------------------------------------------------- adaptive quadrature */
@@ -344,6 +345,7 @@ void init_ps(void) {
     } else {
         cc.sigma_norm = 2.0 * M_PI * M_PI;
     }
+    cc.generation++;
     cc.ready = 1;
 }
 
@@ -362,6 +364,7 @@ int c21_ps_ready(void) { return cc.ready; }
 static struct {
     int ready;
     double norm_tag; /* sigma_norm the table was built for */
+    unsigned generation; /* init_ps call it was built after (shape parameters may differ at equal norm) */
     int filter, ps;
     double lnM[SIG_N], lns[SIG_N], lnd[SIG_N], lns2[SIG_N], lnd2[SIG_N];
 } st;
@@ -370,7 +373,7 @@ static void spline_setup(int n, const double *x, const double *y, double *y2);
 static double spline_eval(int n, const double *x, const double *y, const double *y2, double v);
 
 static void sigma_table_build(void) {
-    if (st.ready && st.norm_tag == cc.sigma_norm && st.filter == matter_options_global->FILTER &&
+    if (st.ready && st.generation == cc.generation && st.norm_tag == cc.sigma_norm && st.filter == matter_options_global->FILTER &&
         st.ps == matter_options_global->POWER_SPECTRUM)
         return;
     for (int i = 0; i < SIG_N; i++) {
@@ -382,6 +385,7 @@ static void sigma_table_build(void) {
     spline_setup(SIG_N, st.lnM, st.lns, st.lns2);
     spline_setup(SIG_N, st.lnM, st.lnd, st.lnd2);
     st.norm_tag = cc.sigma_norm;
+    st.generation = cc.generation;
     st.filter = matter_options_global->FILTER;
     st.ps = matter_options_global->POWER_SPECTRUM;
     st.ready = 1;

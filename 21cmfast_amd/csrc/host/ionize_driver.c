@@ -950,6 +950,28 @@ done:
 }
 
 /* ---- R-loop sharding ------------------------------------------------- */
+/* Per-radius f_coll grid means of the shard phase.  Each radius > 0 is owned by exactly one rank,
+ * so the caller sums the report arrays of all ranks (a 2 KB all-reduce) and hands the result to
+ * the finishing rank, whose finish phase starts from a zeroed scalar block.  Without this the
+ * Lagrangian box->mean_f_coll (= the mean of the last radius processed, IonisationBox.c:
+ * 1623-1628) would be lost whenever that radius is not index 0. */
+static struct {
+    int valid, n;
+    double means[C21CM_MAX_RADII];
+} g_shard_means;
+
+int c21cm_ionize_shard_set_means(const double *means, int n_radii) {
+    if (!means || n_radii < 0 || n_radii > C21CM_MAX_RADII) {
+        g_shard_means.valid = 0;
+        return means ? C21CM_VALUE_ERROR : 0;
+    }
+    memset(g_shard_means.means, 0, sizeof(g_shard_means.means));
+    memcpy(g_shard_means.means, means, sizeof(double) * (size_t)n_radii);
+    g_shard_means.n = n_radii;
+    g_shard_means.valid = 1;
+    return 0;
+}
+
 int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
                              const PerturbedField *perturbed_field,
                              const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
@@ -1017,6 +1039,8 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
         TRY(c21hip_d2h(means, c.scalars + SC_MEANS, sizeof(means), stream));
         TRY(c21hip_sync(stream));
         for (int r = 0; r < spec->n_radii; r++) report->f_coll_grid_mean[r] = means[r];
+        /* a single-process run of both phases (world = 1) keeps its own means */
+        if (world == 1) c21cm_ionize_shard_set_means(means, spec->n_radii);
         report->ms_preloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
         report->ms_rloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
         report->ms_postloop = 0.;
@@ -1046,6 +1070,10 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
                   stream));
     for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
     TRY(c21hip_event_record(ev[0], stream));
+    if (g_shard_means.valid && g_shard_means.n == spec->n_radii) /* ctx_setup zeroed the block */
+        TRY(c21hip_h2d(c.scalars + SC_MEANS, g_shard_means.means,
+                       sizeof(double) * (size_t)spec->n_radii, stream));
+    g_shard_means.valid = 0;
     TRY(init_output_grids(&c, previous_ionize_box));
     int stars_ready = 0;
     if (spec->r_lowest == 0) {
@@ -1089,8 +1117,23 @@ int c21cm_neutral_box(const c21cm_ionize_spec *spec, const PerturbedField *pertu
     void *stream = NULL;
     const int ts = spec->use_ts_fluct;
     const float *density = NULL, *xe = NULL, *Tn = NULL;
+    /* the same required arrays as the full path (validate_spec), checked before any launch */
+    if (!box || !box->neutral_fraction || !box->z_reion ||
+        (!spec->minimize_memory && !box->kinetic_temperature)) {
+        c21hip_set_error("ionize (neutral box): neutral_fraction / z_reion%s are required",
+                         spec->minimize_memory ? "" : " / kinetic_temperature");
+        return C21CM_VALUE_ERROR;
+    }
+    if (ts && (!spin_temp || !spin_temp->xray_ionised_fraction ||
+               (!spec->minimize_memory && !spin_temp->kinetic_temp_neutral))) {
+        c21hip_set_error("ionize (neutral box): USE_TS_FLUCT needs the TsBox arrays");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!ts && !spec->minimize_memory && (!perturbed_field || !perturbed_field->density)) {
+        c21hip_set_error("ionize (neutral box): PerturbedField.density is required");
+        return C21CM_VALUE_ERROR;
+    }
     if (ts) {
-        if (!spin_temp || !spin_temp->xray_ionised_fraction) return C21CM_VALUE_ERROR;
         xe = stage_in(WS_XE_DENSE, spin_temp->xray_ionised_fraction, bytes, stream, &status);
         if (!spec->minimize_memory)
             Tn = stage_in(WS_TNEUTRAL, spin_temp->kinetic_temp_neutral, bytes, stream, &status);

@@ -6,13 +6,15 @@
  * Broadcast_struct_global_all (drivers/_global_initialization.py:98-112) and keeps the
  * backing memory alive; the Compute* entry points then read them through these
  * globals.  CosmoTables is the one struct that is deep-copied.  Unlike the reference
- * (which copies the tables only the first time) every broadcast refreshes the copy,
- * so a changed sigma_8 is never missed.
+ * (which copies the tables only the first time) every broadcast refreshes the copy
+ * and invalidates the power-spectrum state, so a changed sigma_8 / cosmology is never missed.
  */
 #include <stdlib.h>
 #include <string.h>
 
 #include "c21cm_abi.h"
+
+void free_ps(void); /* cosmology.c */
 
 SimulationOptions *simulation_options_global = NULL;
 MatterOptions *matter_options_global = NULL;
@@ -65,6 +67,10 @@ void Broadcast_struct_global_all(SimulationOptions *simulation_options,
     cosmo_params_global = cosmo_params;
     astro_params_global = astro_params;
     astro_options_global = astro_options;
+    /* The power-spectrum state (sigma normalisation, EH parameters, the sigma(M) spline keyed on
+     * it) belongs to the cosmology that was broadcast before: drop it, the next Compute* call
+     * (or the caller's own init_ps, as py21cmfast does) rebuilds it for the new structs. */
+    free_ps();
     Free_cosmo_tables_global();
     if (!cosmo_tables) return;
     cosmo_tables_global = (CosmoTables *)calloc(1, sizeof(CosmoTables));
@@ -84,4 +90,5 @@ void Broadcast_struct_global_noastro(SimulationOptions *simulation_options,
     simulation_options_global = simulation_options;
     matter_options_global = matter_options;
     cosmo_params_global = cosmo_params;
+    free_ps(); /* as above: never reuse the previous cosmology's normalisation */
 }

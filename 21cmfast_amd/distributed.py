@@ -41,12 +41,32 @@ def reduce_first_cross(first_cross, owner: int, group=None):
     return first_cross
 
 
-def sharded_ionize(spec, density, n_ion, buffers, first_cross, rank: int, world: int, group=None):
-    """One sharded ComputeIonizedBox pass; returns the report on the owner rank, else None."""
+def sharded_ionize(spec, density, n_ion, buffers, first_cross, rank: int, world: int, group=None,
+                   collect_means: bool | None = None):
+    """One sharded ComputeIonizedBox pass; returns the report on the owner rank, else None.
+
+    ``collect_means``: also combine the per-radius f_coll grid means of all ranks (a 2 KB
+    sum-reduce; costs one host synchronisation per rank) and hand them to the finish step.
+    Default: only when the result depends on them -- a Lagrangian model (``fix_mean == 0``)
+    whose loop stops above index 0 reports the mean of radius ``r_lowest`` as
+    ``box.mean_f_coll`` (reference: IonisationBox.c:1623-1628)."""
     from . import grid_api as api
 
     owner = owner_rank(spec.n_radii, world)
-    api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion, want_report=False)
+    if collect_means is None:
+        collect_means = (not spec.fix_mean) and spec.r_lowest > 0
+    rep = api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion,
+                                 want_report=bool(collect_means))
+    if collect_means:
+        import torch
+        import torch.distributed as dist
+
+        means = torch.tensor(list(rep.f_coll_grid_mean)[: spec.n_radii], dtype=torch.float64,
+                             device=first_cross.device)
+        if world > 1:
+            dist.reduce(means, dst=owner, op=dist.ReduceOp.SUM, group=group)
+        if rank == owner:
+            api.ionize_shard_set_means(means.cpu().numpy())
     reduce_first_cross(first_cross, owner, group)
     if rank == owner:
         _, _, rep = api.ionize_shard_finish(spec, first_cross, density, n_ion, buffers=buffers)

@@ -147,6 +147,16 @@ def ionize_shard_radii(spec, rank, world, first_cross, density, n_ion=None, xe=N
     return rep
 
 
+def ionize_shard_set_means(means):
+    """Hand the rank-summed per-radius f_coll grid means to the next finish step."""
+    m = np.ascontiguousarray(means, np.float64)
+    lib = load()
+    lib.c21cm_ionize_shard_set_means.restype = C.c_int
+    lib.c21cm_ionize_shard_set_means.argtypes = [C.c_void_p, C.c_int]
+    check(lib.c21cm_ionize_shard_set_means(m.ctypes.data_as(C.c_void_p), int(m.size)),
+          "c21cm_ionize_shard_set_means")
+
+
 def ionize_shard_finish(spec, first_cross, density, n_ion=None, xe=None, Tneutral=None,
                         prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None):
     """Finish phase on the owning rank: apply the reduced mask, radius 0, post-loop."""

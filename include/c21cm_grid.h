@@ -128,6 +128,11 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
                              const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                              const HaloBox *halos, unsigned char *first_cross,
                              c21cm_ionize_report *report, void *stream);
+/* Per-radius f_coll grid means for the finish step: the element-wise SUM over ranks of the shard
+ * phases' report->f_coll_grid_mean (each radius > 0 belongs to one rank).  Optional; consumed by
+ * the next c21cm_ionize_shard_finish of this process.  Needed for box->mean_f_coll of Lagrangian
+ * models when r_lowest > 0 (IonisationBox.c:1623-1628) and for a complete report. */
+int c21cm_ionize_shard_set_means(const double *means, int n_radii);
 int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char *first_cross,
                               const PerturbedField *perturbed_field,
                               const IonizedBox *previous_ionize_box, const TsBox *spin_temp,

@@ -240,9 +240,12 @@ def test_ionized_box_e_integral(gpu_lib, oracle, tmp_path):
     spec.fcoll_mode = W.FCOLL_TABLE_EXP
     spec.mass_dep_zeta = 1
     spec.ion_eff_factor = sc.pop2_ion * sc.fstar_10 * sc.fesc_10
-    spec.mean_f_coll = lib.c21_Nion_General(z, math.log(M_min), math.log(1e16), M_min, C.byref(sc))
+    # the global mean is integrated with the turnover mass M_TURN, not with the lower limit
+    # M_TURN/50 (reference: IonisationBox.c:1446-1449, set_mean_fcoll :468-475)
+    M_turn = ses.ap.M_TURN
+    spec.mean_f_coll = lib.c21_Nion_General(z, math.log(M_min), math.log(1e16), M_turn, C.byref(sc))
     spec.f_limit_acg = lib.c21_Nion_General(ses.so.Z_HEAT_MAX, math.log(M_min), math.log(1e16),
-                                            M_min, C.byref(sc))
+                                            M_turn, C.byref(sc))
     spec.sigma_minmass = lib.c21_sigma_fast(M_min)
 
     def table_fn(r_index, dmin, dmax, table, user):
