@@ -244,7 +244,8 @@ int c21hip_velocity_kspace(const float *saved_c, float *grid_c, int nx, int ny, 
 /* ---- ics_kernels.hip ---- */
 /* delta_k = sqrt(V P/2)(a + ib) with Hermitian planes: InitialConditions.c:26-139 */
 int c21hip_sample_modes(float *cbox, int nx, int ny, int nz, const double *pk_by_m_dev,
-                        float volume, unsigned long long seed, void *stream);
+                        float volume, unsigned long long seed, const double *deviates_dev,
+                        void *stream);
 /* axis1 < 0: out = in*i*k_axis0/k^2 (:240-267); else out = -k_axis0*k_axis1*in/k^2 (:269-297) */
 int c21hip_kspace_op(const float *in_c, float *out_c, int nx, int ny, int nz, double box_len,
                      double box_len_z, int axis0, int axis1, void *stream);

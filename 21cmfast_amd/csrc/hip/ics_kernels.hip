@@ -8,11 +8,14 @@
 // (the subsampling gathers and the normalisation divide reuse perturb_kernels.hip /
 //  grid_kernels.hip.)  All are one-read-one-write HBM sweeps over the DIM^3 grid.
 //
-// Random modes: a counter-based Philox-4x32-10 keyed by the seed, counter = linear index
-// of the k-cell, Box-Muller in double.  Being counter-based, the Hermitian partners of
-// the k_z = 0 / Nyquist planes are generated directly from their partner's counter, so
-// the reference's separate symmetrisation pass (adj_complex_conj) disappears, and the
-// realisation does not depend on launch geometry (the reference's depends on N_THREADS).
+// Random modes, two sources for the (a, b) pair of a mode:
+//  * a counter-based Philox-4x32-10 keyed by the seed, counter = linear index of the k-cell,
+//    Box-Muller in double (C21CM_RNG_PHILOX): independent of launch geometry and N_THREADS;
+//  * the reference's own GSL streams drawn on the host in the reference's order
+//    (C21CM_RNG_GSL, csrc/host/gsl_stream.c) and read from `deviates[mode]`.
+// Either way the Hermitian partners of the k_z = 0 / Nyquist planes take their partner's pair
+// (by counter / by index), so the reference's separate symmetrisation pass (adj_complex_conj)
+// disappears.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -89,7 +92,8 @@ __device__ __forceinline__ bool hermitian_source(int i, int j, int nx, int ny, i
 
 __global__ void __launch_bounds__(kBlock)
 sample_modes_kernel(float2 *__restrict__ cbox, int nx, int ny, int nz,
-                    const double *__restrict__ pk_by_m, float volume, uint64_t seed) {
+                    const double *__restrict__ pk_by_m, float volume, uint64_t seed,
+                    const double2 *__restrict__ deviates) {
     const int nzc = nz / 2 + 1, mx = nx / 2, my = ny / 2, mz = nz / 2;
     const size_t total = (size_t)nx * ny * nzc;
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
@@ -113,7 +117,15 @@ sample_modes_kernel(float2 *__restrict__ cbox, int nx, int ny, int nz,
         const double p = pk_by_m[m];
         const uint64_t counter = ((uint64_t)gi * ny + gj) * nzc + n_z;
         double a, b;
-        gaussian_pair(counter, seed, &a, &b);
+        if (deviates) {
+            // the reference's stream, drawn on the host in its own order (gsl_stream.c); a
+            // constrained element takes its partner's pair, which is what adj_complex_conj copies
+            const double2 d = deviates[counter];
+            a = d.x;
+            b = d.y;
+        } else {
+            gaussian_pair(counter, seed, &a, &b);
+        }
         const double amp = sqrt((double)volume * p / 2.0);  // InitialConditions.c:129-130
         float re = (float)(amp * a), im = (float)(amp * b);
         if (conj) im = -im;
@@ -338,11 +350,12 @@ lpt2_accumulate_kernel(float *__restrict__ box, const float *__restrict__ phi_ij
 }  // namespace
 
 extern "C" int c21hip_sample_modes(float *cbox, int nx, int ny, int nz, const double *pk_by_m_dev,
-                                   float volume, unsigned long long seed, void *stream) {
+                                   float volume, unsigned long long seed,
+                                   const double *deviates_dev, void *stream) {
     const size_t total = (size_t)nx * ny * (nz / 2 + 1);
     hipLaunchKernelGGL(sample_modes_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
                        (hipStream_t)stream, (float2 *)cbox, nx, ny, nz, pk_by_m_dev, volume,
-                       (uint64_t)seed);
+                       (uint64_t)seed, (const double2 *)deviates_dev);
     LAUNCH_CHECK();
     return 0;
 }

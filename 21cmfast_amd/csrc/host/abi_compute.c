@@ -108,6 +108,24 @@ int ComputeInitialConditions(unsigned long long random_seed, InitialConditions *
     s.perturb_algorithm = mo->PERTURB_ALGORITHM;
     s.perturb_on_high_res = mo->PERTURB_ON_HIGH_RES;
     s.seed = random_seed;
+    /* Random stream.  Default: the reference's own (seed_rng_threads + gsl_ran_ugaussian in its
+     * loop order, rng.c:31-90, InitialConditions.c:103-139), so that the same random_seed and
+     * N_THREADS give the same universe as upstream; it exists for N_THREADS <= 2 (mt19937 and
+     * gfsr4) and is drawn serially on the host, as upstream draws it.  Beyond two threads, or
+     * with C21CM_IC_RNG=philox, the counter-based device generator is used (a different, equally
+     * valid realisation; ~100x faster at DIM = 512).  C21CM_IC_RNG=gsl insists on the former. */
+    {
+        extern int c21_gsl_stream_supported(int n_threads);
+        const char *e = getenv("C21CM_IC_RNG");
+        const int n_thr = so->N_THREADS > 0 ? so->N_THREADS : 1;
+        s.rng_threads = n_thr;
+        if (e && e[0] == 'p')
+            s.rng_stream = C21CM_RNG_PHILOX;
+        else if (e && e[0] == 'g')
+            s.rng_stream = C21CM_RNG_GSL;
+        else
+            s.rng_stream = c21_gsl_stream_supported(n_thr) ? C21CM_RNG_GSL : C21CM_RNG_PHILOX;
+    }
 
     /* InitialConditions.c:620-634: a non-zero hires_density means "use it as the field" */
     const size_t ntot = (size_t)s.dim * s.dim * s.dim_z;

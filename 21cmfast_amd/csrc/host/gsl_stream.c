@@ -1,0 +1,198 @@
+/*
+ * gsl_stream.c -- the reference's initial-condition random stream, for "same seed, same universe".
+ *
+ * reference call sites:
+ *   src/py21cmfast/src/rng.c:31-90                  seed_rng_threads(r, random_seed)
+ *   src/py21cmfast/src/InitialConditions.c:103-139  sample_ic_modes: per mode two
+ *       gsl_ran_ugaussian(r[omp_get_thread_num()]) inside `#pragma omp for` over n_x
+ *
+ * The generators are GSL's, a dependency of the reference that is neither in its tree nor in
+ * this image; they are written here from their published definitions:
+ *   mt19937  Matsumoto & Nishimura (1998) with the 2002 seeding recurrence
+ *            x_i = 1812433253 (x_{i-1} ^ (x_{i-1} >> 30)) + i, seed 0 meaning 4357
+ *   gfsr4    Ziff (1998): x_n = x_{n-471} ^ x_{n-1586} ^ x_{n-6988} ^ x_{n-9689} on 2^14 words,
+ *            filled bit by bit from the top bit of the LCG x -> 69069 x (mod 2^32), 32 words
+ *            forced to a unit upper-triangular pattern, first output at position 33
+ *   uniform = word / 2^32; uniform_pos rejects 0; uniform_int(n) = word / (0xffffffff / n),
+ *            rejecting values >= n
+ *   choose   selection sampling: item i of n is taken with probability (k - taken)/(n - i)
+ *   shuffle  Fisher-Yates from the last element down, swapping with uniform_int(i + 1)
+ *   ugaussian  polar method: (x, y) = 2 u_pos - 1 until 0 < x^2 + y^2 <= 1, value
+ *            y sqrt(-2 ln r2 / r2); the pair's other value is discarded
+ * Thread t of seed_rng_threads cycles through mt19937, gfsr4, cmrg, mrg, taus2; the first two
+ * are provided, so N_THREADS <= 2 reproduces upstream (every configuration the reference's
+ * fixtures use, tests/produce_integration_test_data.py:62,213-220).  A mode belongs to the
+ * thread that owns its n_x under the default static OpenMP schedule (contiguous blocks, the
+ * first DIM % N_THREADS threads one row longer).
+ *
+ * The stream is serial by definition (the number of words a deviate consumes depends on the
+ * words themselves), so it is drawn on the host, one pass per generator; the device then applies
+ * sqrt(V P(k) / 2) and the Hermitian constraints (ics_kernels.hip: sample_modes_kernel).
+ * Parity: bit-identical deviates to the CPU oracle's independent restatement
+ * (tests/test_gpu_ics.py), which the reference's own HDF5 fixtures pin
+ * (tests/test_reference_fixtures.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../hip/c21hip.h"
+#include "c21cm_grid.h"
+
+/* ---- word sources: both fill a block of raw 32-bit outputs at a time ------------------- */
+typedef struct word_source {
+    uint32_t *buf;
+    int pos, len;
+    void (*refill)(struct word_source *);
+    /* mt19937 */
+    uint32_t mt[624];
+    /* gfsr4 */
+    uint32_t *ring;
+    int nd;
+} word_source;
+
+static void mt_refill(word_source *w) {
+    uint32_t *x = w->mt;
+    for (int i = 0; i < 624; i++) {
+        const uint32_t y = (x[i] & 0x80000000u) | (x[(i + 1) % 624] & 0x7fffffffu);
+        x[i] = x[(i + 397) % 624] ^ (y >> 1) ^ (0x9908b0dfu & (0u - (y & 1u)));
+    }
+    for (int i = 0; i < 624; i++) { /* tempering */
+        uint32_t k = x[i];
+        k ^= k >> 11;
+        k ^= (k << 7) & 0x9d2c5680u;
+        k ^= (k << 15) & 0xefc60000u;
+        k ^= k >> 18;
+        w->buf[i] = k;
+    }
+    w->pos = 0;
+    w->len = 624;
+}
+
+static void gfsr4_refill(word_source *w) {
+    uint32_t *r = w->ring;
+    int nd = w->nd;
+    for (int i = 0; i < 624; i++) {
+        nd = (nd + 1) & 16383;
+        r[nd] = r[(nd + 16384 - 471) & 16383] ^ r[(nd + 16384 - 1586) & 16383] ^
+                r[(nd + 16384 - 6988) & 16383] ^ r[(nd + 16384 - 9689) & 16383];
+        w->buf[i] = r[nd];
+    }
+    w->nd = nd;
+    w->pos = 0;
+    w->len = 624;
+}
+
+static int source_open(word_source *w, int kind, unsigned long seed) {
+    memset(w, 0, sizeof(*w));
+    w->buf = (uint32_t *)malloc(624 * sizeof(uint32_t));
+    if (!w->buf) return C21CM_MEMORY_ALLOC_ERROR;
+    if (seed == 0) seed = 4357;
+    if (kind == 0) {
+        w->mt[0] = (uint32_t)seed;
+        for (uint32_t i = 1; i < 624; i++)
+            w->mt[i] = 1812433253u * (w->mt[i - 1] ^ (w->mt[i - 1] >> 30)) + i;
+        w->refill = mt_refill;
+    } else {
+        w->ring = (uint32_t *)malloc(16384 * sizeof(uint32_t));
+        if (!w->ring) return C21CM_MEMORY_ALLOC_ERROR;
+        uint32_t x = (uint32_t)seed;
+        for (int i = 0; i < 16384; i++) {
+            uint32_t word = 0;
+            for (int b = 31; b >= 0; b--) {
+                x *= 69069u;
+                word |= (x >> 31) << b;
+            }
+            w->ring[i] = word;
+        }
+        for (int i = 0; i < 32; i++) { /* rows 7, 10, 13, ...: zero left of the diagonal, one on it */
+            const uint32_t diag = 0x80000000u >> i;
+            w->ring[7 + 3 * i] = (w->ring[7 + 3 * i] & (0xffffffffu >> i)) | diag;
+        }
+        w->nd = 32;
+        w->refill = gfsr4_refill;
+    }
+    w->pos = w->len = 0;
+    return 0;
+}
+
+static void source_close(word_source *w) {
+    free(w->buf);
+    free(w->ring);
+    w->buf = w->ring = NULL;
+}
+
+static inline uint32_t next_word(word_source *w) {
+    if (w->pos == w->len) w->refill(w);
+    return w->buf[w->pos++];
+}
+
+static inline double next_uniform_pos(word_source *w) {
+    uint32_t v;
+    do v = next_word(w);
+    while (v == 0);
+    return v * (1.0 / 4294967296.0);
+}
+
+static inline double next_ugaussian(word_source *w) {
+    double x, y, r2;
+    do {
+        x = 2 * next_uniform_pos(w) - 1;
+        y = 2 * next_uniform_pos(w) - 1;
+        r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0);
+    return y * sqrt(-2.0 * log(r2) / r2);
+}
+
+/* rng.c:31-56 with src[i] = i: the per-thread seeds */
+int c21_gsl_thread_seeds(unsigned long long seed, int n_threads, unsigned int *seeds) {
+    if (n_threads < 1 || !seeds) return C21CM_VALUE_ERROR;
+    word_source w;
+    int st = source_open(&w, 0, (unsigned long)seed);
+    if (st) return st;
+    const uint64_t n = 2147483647 / 16;
+    uint64_t taken = 0;
+    for (uint64_t i = 0; i < n && taken < (uint64_t)n_threads; i++) {
+        const double u = next_word(&w) * (1.0 / 4294967296.0);
+        if ((double)(n - i) * u < (double)((uint64_t)n_threads - taken)) seeds[taken++] = (unsigned int)i;
+    }
+    for (int i = n_threads - 1; i > 0; i--) {
+        const uint32_t scale = 0xffffffffu / (uint32_t)(i + 1);
+        uint32_t j;
+        do j = next_word(&w) / scale;
+        while (j >= (uint32_t)(i + 1));
+        const unsigned int t = seeds[i];
+        seeds[i] = seeds[j];
+        seeds[j] = t;
+    }
+    source_close(&w);
+    return 0;
+}
+
+int c21_gsl_stream_supported(int n_threads) { return n_threads >= 1 && n_threads <= 2; }
+
+/* The (a, b) deviates of all nx * ny * nzc modes in grid order: ab[2 * mode + {0, 1}]. */
+int c21_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int ny, int nzc,
+                          double *ab) {
+    if (!c21_gsl_stream_supported(n_threads)) {
+        c21hip_set_error(
+            "ics: the reference's random stream is reproduced for N_THREADS <= 2 (mt19937, gfsr4); "
+            "N_THREADS = %d would need GSL's cmrg / mrg / taus2 generators", n_threads);
+        return C21CM_VALUE_ERROR;
+    }
+    unsigned int seeds[2];
+    int st = c21_gsl_thread_seeds(seed, n_threads, seeds);
+    if (st) return st;
+    const int q = nx / n_threads, rem = nx % n_threads;
+    for (int t = 0; t < n_threads; t++) {
+        const int lo = t * q + (t < rem ? t : rem), rows = q + (t < rem ? 1 : 0);
+        word_source w;
+        if ((st = source_open(&w, t, seeds[t]))) return st;
+        double *p = ab + 2 * (size_t)lo * ny * nzc;
+        const size_t count = 2 * (size_t)rows * ny * nzc;
+        for (size_t m = 0; m < count; m++) p[m] = next_ugaussian(&w);
+        source_close(&w);
+    }
+    return 0;
+}

@@ -24,7 +24,8 @@ enum {
     WS_IC_DIAG0, /* +1, +2 */
     WS_IC_PK = 55,
     WS_IC_IN = 56,
-    WS_IC_OUT0 = 57 /* staged outputs, reused one at a time */
+    WS_IC_OUT0 = 57, /* staged outputs, reused one at a time */
+    WS_IC_DEVIATES = 58
 };
 
 #define TRY(expr)         \
@@ -35,6 +36,34 @@ enum {
             goto done;    \
         }                 \
     } while (0)
+
+/* C21CM_RNG_GSL: the reference's random stream (gsl_stream.c) drawn on the host in the
+ * reference's order and staged in HBM for sample_modes_kernel; NULL for the Philox stream. */
+int c21_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int ny, int nzc,
+                          double *ab);
+static int stream_deviates(const c21cm_ics_spec *s, void *stream, const double **dev_ab) {
+    *dev_ab = NULL;
+    if (s->rng_stream == C21CM_RNG_PHILOX) return 0;
+    if (s->rng_stream != C21CM_RNG_GSL) {
+        c21hip_set_error("ics: unknown rng_stream %d", s->rng_stream);
+        return C21CM_VALUE_ERROR;
+    }
+    const int nzc = s->dim_z / 2 + 1;
+    const size_t bytes = 2 * sizeof(double) * (size_t)s->dim * s->dim * nzc;
+    double *host = (double *)malloc(bytes);
+    double *dev = (double *)c21hip_ws(WS_IC_DEVIATES, bytes);
+    if (!host || !dev) {
+        free(host);
+        return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    int st = c21_gsl_mode_deviates(s->seed, s->rng_threads > 0 ? s->rng_threads : 1, s->dim, s->dim,
+                                   nzc, host);
+    if (!st) st = c21hip_h2d(dev, host, bytes, stream);
+    if (!st) st = c21hip_sync(stream); /* `host` is freed below */
+    free(host);
+    *dev_ab = dev;
+    return st;
+}
 
 /* gather a padded hi-res grid into a (host or device) dense output array */
 static int emit(const float *box, const int hi_dim[3], float *target, const int dim[3],
@@ -210,7 +239,10 @@ static int ics_grids_split(const c21cm_ics_spec *s, InitialConditions *ics, floa
         float *padded = (float *)c21hip_ws(WS_IS_BOX, (c.ntot + 2 * (size_t)c.hi[0] * c.hi[1]) * sizeof(float));
         if (!pk_dev || !padded) return C21CM_MEMORY_ALLOC_ERROR;
         TRY(c21hip_h2d(pk_dev, s->pk_by_m, (size_t)n_m * sizeof(double), stream));
-        TRY(c21hip_sample_modes(padded, c.hi[0], c.hi[1], c.hi[2], pk_dev, VOLUME, s->seed, stream));
+        const double *dev_ab = NULL;
+        TRY(stream_deviates(s, stream, &dev_ab));
+        TRY(c21hip_sample_modes(padded, c.hi[0], c.hi[1], c.hi[2], pk_dev, VOLUME, s->seed, dev_ab,
+                                stream));
         TRY(c21hip_padded_to_split(padded, c.saved, c.hi[0], c.hi[1], c.hi[2], stream));
         TRY(hi_field(&c, c.saved, -1, -1, ics->hires_density, VOLUME));
     }
@@ -327,8 +359,10 @@ int c21cm_ics_grids(const c21cm_ics_spec *s, InitialConditions *ics, void *strea
         double *pk_dev = (double *)c21hip_ws(WS_IC_PK, (size_t)n_m * sizeof(double));
         if (!pk_dev) return C21CM_MEMORY_ALLOC_ERROR;
         TRY(c21hip_h2d(pk_dev, s->pk_by_m, (size_t)n_m * sizeof(double), stream));
+        const double *dev_ab = NULL;
+        TRY(stream_deviates(s, stream, &dev_ab));
         TRY(c21hip_sample_modes(saved, hi_dim[0], hi_dim[1], hi_dim[2], pk_dev, VOLUME, s->seed,
-                                stream));
+                                dev_ab, stream));
         TRY(c21hip_d2d(box, saved, npad * sizeof(float), stream));
         TRY(c21hip_fft_c2r(box, hi_dim[0], hi_dim[1], hi_dim[2], stream));
         TRY(emit(box, hi_dim, ics->hires_density, hi_dim, VOLUME, stream));

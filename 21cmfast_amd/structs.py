@@ -391,6 +391,8 @@ class IcsSpec(_Base):
         ("n_m", C.c_int),
         ("pk_by_m", c_double_p),
         ("seed", C.c_ulonglong),
+        ("rng_stream", C.c_int),   # 0 Philox (device), 1 the reference's GSL streams
+        ("rng_threads", C.c_int),  # N_THREADS the GSL streams are laid out for (1 or 2)
     ]
 
 

@@ -183,7 +183,18 @@ typedef struct c21cm_ics_spec {
     int n_m;
     const double *pk_by_m; /* host array */
     unsigned long long seed;
+    /* which random stream turns `seed` into delta_k:
+     *   C21CM_RNG_PHILOX (0)  counter-based Philox-4x32-10 + Box-Muller on the device (counter =
+     *                         mode index: independent of launch geometry and of N_THREADS)
+     *   C21CM_RNG_GSL    (1)  the reference's streams -- seed_rng_threads (rng.c:31-90) and two
+     *                         gsl_ran_ugaussian per mode from the generator of the OpenMP thread
+     *                         that owns the mode's n_x (InitialConditions.c:103-139) -- for
+     *                         N_THREADS = rng_threads (1 or 2): same seed, same universe as upstream.
+     *                         The stream is serial by construction and is drawn on the host. */
+    int rng_stream;
+    int rng_threads;
 } c21cm_ics_spec;
+enum { C21CM_RNG_PHILOX = 0, C21CM_RNG_GSL = 1 };
 
 int c21cm_ics_grids(const c21cm_ics_spec *spec, InitialConditions *ics, void *stream);
 

@@ -63,6 +63,19 @@ int oracle_perturb_grids(const c21cm_perturb_spec *spec, const InitialConditions
 /* oracle_ics.c -- reference: src/py21cmfast/src/InitialConditions.c */
 int oracle_ics_grids(const c21cm_ics_spec *spec, InitialConditions *ics);
 
+/* oracle_gslrng.c -- reference: src/py21cmfast/src/rng.c:31-90, InitialConditions.c:26-139
+ * (GSL's mt19937 / gfsr4 / choose / shuffle / polar gaussian restated from their published
+ * algorithms) */
+struct oracle_gsl_rng;
+struct oracle_gsl_rng *oracle_gsl_rng_alloc(int kind, unsigned long seed); /* 0 mt19937, 1 gfsr4 */
+void oracle_gsl_rng_free(struct oracle_gsl_rng *r);
+unsigned int oracle_gsl_rng_get(struct oracle_gsl_rng *r);
+double oracle_gsl_ran_ugaussian(struct oracle_gsl_rng *r);
+int oracle_gsl_thread_seeds(unsigned long long seed, int n_threads, unsigned int *seeds);
+int oracle_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int ny, int nz,
+                             double *ab);
+int oracle_gsl_sample_modes(const c21cm_ics_spec *s, int n_threads, float *cbox);
+
 /* oracle_brightness.c -- reference: src/py21cmfast/src/BrightnessTemperatureBox.c:22-105 */
 int oracle_brightness_grids(const c21cm_brightness_spec *spec, const float *density,
                             const float *neutral_fraction, const float *spin_temperature,

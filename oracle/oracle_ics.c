@@ -12,12 +12,15 @@
  *   :547-772  ComputeInitialConditions
  *
  * RNG: the reference draws (a, b) from per-OpenMP-thread GSL generators
- * (src/py21cmfast/src/rng.c:31-90), i.e. its realisation depends on N_THREADS and on the
- * (unpinned, absent) GSL build.  That stream is NOT restated: both this oracle and the
- * HIP path use a counter-based Philox-4x32-10 keyed by the seed with the mode index as
- * counter, and a Box-Muller transform in double.  Same-seed parity with upstream is
- * therefore "unpinned"; everything downstream of delta_k is pinned through the
- * `density_is_input` path (reference test: tests/test_initial_conditions.py:153-178).
+ * (src/py21cmfast/src/rng.c:31-90), i.e. its realisation depends on N_THREADS.  Two streams:
+ *   rng_stream = C21CM_RNG_GSL     that stream, restated in oracle_gslrng.c for N_THREADS <= 2
+ *                                  and pinned by the reference's HDF5 fixtures
+ *                                  (tests/test_reference_fixtures.py);
+ *   rng_stream = C21CM_RNG_PHILOX  a counter-based Philox-4x32-10 keyed by the seed with the
+ *                                  mode index as counter + Box-Muller in double (the device's
+ *                                  fast generator; a different realisation for the same seed).
+ * Everything downstream of delta_k is also pinned through the `density_is_input` path
+ * (reference test: tests/test_initial_conditions.py:153-178).
  */
 #include <math.h>
 #include <omp.h>
@@ -186,7 +189,16 @@ int oracle_ics_grids(const c21cm_ics_spec *s, InitialConditions *ics) {
             free(saved);
             return C21CM_VALUE_ERROR;
         }
-        sample_modes(s, box);
+        if (s->rng_stream == C21CM_RNG_GSL) {
+            int gst = oracle_gsl_sample_modes(s, s->rng_threads > 0 ? s->rng_threads : 1, box);
+            if (gst) {
+                free(box);
+                free(saved);
+                return gst;
+            }
+        } else {
+            sample_modes(s, box);
+        }
         memcpy(saved, box, sizeof(float) * npad);
         oracle_fft_c2r(box, hi_dim[0], hi_dim[1], hi_dim[2]);
         subsample(s, box, ics->hires_density, hi_dim, VOLUME);

@@ -1,0 +1,191 @@
+"""Host scalars of the hot path evaluated INDEPENDENTLY of lib21cmfast_hip.so (numpy / scipy).
+
+TEST INFRASTRUCTURE ONLY.  The parity tests drive the oracle with these values so that a wrong
+host scalar inside the library under test cannot cancel out of a comparison (round-1 verdict,
+"What's weak" 3), and the reference-fixture pin (tests/test_reference_fixtures.py) uses them
+to build P(k) and the growth factors without touching the product.
+
+Each function restates the reference's formula and cites it; quadratures use scipy instead of
+GSL QAG (both converge to ~1e-8, far inside every tolerance used).
+reference: src/py21cmfast/src/cosmology.c
+  :52-75    transfer_function_EH      (Eisenstein & Hu 1999 fit, N_nu = 1)
+  :242-254  primordial_curvature_power_spectrum
+  :278-308  power_in_k
+  :355-408  dsigma_dk / sigma_z0
+  :458-503  TFset_parameters
+  :507-558  init_ps (sigma_8 normalisation)
+  :593-616  MtoR / RtoM
+  :670-713  dicke  (Liddle et al. fit for flat LCDM + radiation)
+  :716-727  dtdz
+  :730-735  ddickedt (forward difference with dz = 1e-10f, as the reference evaluates it)
+and src/py21cmfast/src/Constants.h:90-96 (Ho, RHOcrit), Constants.c (physconst).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+from scipy import integrate
+
+G_CGS = 6.6743e-8
+CM_PER_MPC = 3.08567758e24
+MSUN = 1.989e33
+T_CMB = 2.7255
+N_NU = 1.0
+
+
+def _f32(x) -> float:
+    """The C structs hold floats: every parameter reaches the formulae rounded to float."""
+    return float(np.float32(x))
+
+
+@dataclass
+class Cosmo:
+    """CosmoParams as the C side sees it (float fields), Planck18 defaults
+    (reference: src/py21cmfast/wrapper/inputs.py:505-538)."""
+
+    hlittle: float = 0.6766
+    OMm: float = 0.30966
+    OMb: float = 0.04897
+    POWER_INDEX: float = 0.9665
+    OMn: float = 0.0
+    OMr: float = 8.6e-5
+    sigma_8: float = 0.8102
+
+    def __post_init__(self):
+        self.h = _f32(self.hlittle)
+        self.om = _f32(self.OMm)
+        self.ob = _f32(self.OMb)
+        self.ns = _f32(self.POWER_INDEX)
+        self.on = _f32(self.OMn)
+        self.orad = _f32(self.OMr)
+        self.ol = _f32(1.0 - self.OMm)  # OMl = 1 - OMm in Python, stored as float
+        self.s8 = float(self.sigma_8)  # ps_norm is a double in CosmoTables
+        # init_ps :508-513
+        self.omhh = self.om * self.h * self.h
+        self.theta_cmb = T_CMB / 2.7
+        self.f_nu = max(self.on / self.om, 1e-10)
+        self.f_baryon = max(self.ob / self.om, 1e-10)
+        self._tf_set()
+        self.sigma_norm = 1.0
+        R8 = 8.0 / self.h
+        self.sigma_norm = (self.s8 / self.sigma_z0(self.RtoM(R8))) ** 2
+
+    # ---- TFset_parameters :458-503
+    def _tf_set(self):
+        f_nu, f_b, omhh = self.f_nu, self.f_baryon, self.omhh
+        obhh = self.ob * self.h * self.h
+        th = self.theta_cmb
+        z_eq = 25000 * omhh * th**-4 - 1.0
+        k_eq = 0.0746 * omhh / (th * th)
+        z_drag = 0.313 * omhh**-0.419 * (1 + 0.607 * omhh**0.674)
+        z_drag = 1 + z_drag * obhh ** (0.238 * omhh**0.223)
+        z_drag *= 1291 * omhh**0.251 / (1 + 0.659 * omhh**0.828)
+        y_d = (1 + z_eq) / (1.0 + z_drag)
+        R_drag = 31.5 * obhh * th**-4 * 1000 / (1.0 + z_drag)
+        R_eq = 31.5 * obhh * th**-4 * 1000 / (1.0 + z_eq)
+        self.sound_horizon = (2.0 / 3.0 / k_eq * math.sqrt(6.0 / R_eq)
+                              * math.log((math.sqrt(1 + R_drag) + math.sqrt(R_drag + R_eq))
+                                         / (1.0 + math.sqrt(R_eq))))
+        p_c = -(5 - math.sqrt(1 + 24 * (1 - f_nu - f_b))) / 4.0
+        p_cb = -(5 - math.sqrt(1 + 24 * (1 - f_nu))) / 4.0
+        f_c, f_cb, f_nub = 1 - f_nu - f_b, 1 - f_nu, f_nu + f_b
+        a = (f_c / f_cb) * (2 * (p_c + p_cb) + 5) / (4 * p_cb + 5.0)
+        a *= 1 - 0.553 * f_nub + 0.126 * f_nub**3
+        a /= 1 - 0.193 * math.sqrt(f_nu) + 0.169 * f_nu
+        a *= (1 + y_d) ** (p_c - p_cb)
+        a *= 1 + (p_cb - p_c) / 2.0 * (1.0 + 1.0 / (4.0 * p_c + 3.0) / (4.0 * p_cb + 7.0)) / (1.0 + y_d)
+        self.alpha_nu = a
+        self.beta_c = 1.0 / (1.0 - 0.949 * f_nub)
+
+    # ---- transfer_function_EH :52-75 (vectorised)
+    def transfer_eh(self, k):
+        k = np.asarray(k, dtype=np.float64)
+        q = k * self.theta_cmb**2 / self.omhh
+        sa = math.sqrt(self.alpha_nu)
+        gamma_eff = sa + (1.0 - sa) / (1.0 + (0.43 * k * self.sound_horizon) ** 4)
+        q_eff = q / gamma_eff
+        tf = np.log(math.e + 1.84 * self.beta_c * sa * q_eff)
+        tf = tf / (tf + q_eff**2 * (14.4 + 325.0 / (1.0 + 60.5 * q_eff**1.11)))
+        q_nu = 3.92 * q / math.sqrt(self.f_nu / N_NU)
+        with np.errstate(divide="ignore"):
+            tf = tf * (1.0 + (1.2 * self.f_nu**0.64 * N_NU ** (0.3 + 0.6 * self.f_nu))
+                       / (q_nu**-1.6 + q_nu**0.8))
+        return tf
+
+    # ---- power_in_k :278-308 (EH; USE_SIGMA_8: ps_norm = sigma_8 enters only through sigma_norm)
+    def power_in_k(self, k):
+        k = np.asarray(k, dtype=np.float64)
+        out = np.zeros_like(k)
+        nz = k > 0
+        kk = k[nz]
+        T = self.transfer_eh(kk) * kk * kk
+        prim = self.s8 * (kk / 0.05) ** (self.ns - 1.0)
+        out[nz] = self.sigma_norm * prim * T * T / kk**3
+        return out
+
+    # ---- Constants.h:90-96
+    def rhocrit(self) -> float:
+        Ho = self.h * 3.2407e-18
+        return (3.0 * Ho * Ho / (8.0 * math.pi * G_CGS)) * CM_PER_MPC**3 / MSUN
+
+    def RtoM(self, R: float) -> float:  # :606-616, top-hat
+        return (4.0 / 3.0) * math.pi * R**3 * (self.om * self.rhocrit())
+
+    def MtoR(self, M: float) -> float:  # :593-603
+        return (3 * M / (4 * math.pi * self.om * self.rhocrit())) ** (1.0 / 3.0)
+
+    # ---- sigma_z0 :369-408 (real-space top-hat window, filtering.c / cosmology filter_function)
+    def sigma_z0(self, M: float) -> float:
+        R = self.MtoR(M)
+
+        def f(lnk):
+            k = math.exp(lnk)
+            x = k * R
+            w = 3.0 * (math.sin(x) - x * math.cos(x)) / x**3 if x > 1e-4 else 1.0 - x * x / 10.0
+            return k**3 * float(self.power_in_k(np.array([k]))[0]) * w * w / (2.0 * math.pi**2)
+
+        val, _ = integrate.quad(f, math.log(1e-7 / R), math.log(350.0 / R), limit=4000,
+                                epsrel=1e-10)
+        return math.sqrt(val)
+
+    # ---- dicke :670-713 (flat LCDM + radiation branch)
+    def dicke(self, z: float) -> float:
+        om, ol, orad = self.om, self.ol, self.orad
+        omz = om * (1 + z) ** 3 / (ol + om * (1 + z) ** 3 + orad * (1 + z) ** 4)
+        dz_ = 2.5 * omz / (1.0 / 70.0 + omz * (209 - omz) / 140.0 + omz ** (4.0 / 7.0))
+        d0 = 2.5 * om / (1.0 / 70.0 + om * (209 - om) / 140.0 + om ** (4.0 / 7.0))
+        return dz_ / (d0 * (1.0 + z))
+
+    # ---- dtdz :716-727 (argument is a float in the reference)
+    def dtdz(self, z: float) -> float:
+        z = _f32(z)
+        om, ol = self.om, self.ol
+        Ho = self.h * 3.2407e-18
+        x = math.sqrt(ol / om) * (1 + z) ** -1.5
+        dxdz = math.sqrt(ol / om) * (1 + z) ** -2.5 * (-1.5)
+        const1 = 2 * math.sqrt(1 + om / ol) / (3.0 * Ho)
+        numer = dxdz * (1 + x / math.sqrt(x * x + 1))
+        denom = x + math.sqrt(x * x + 1)
+        return const1 * numer / denom
+
+    # ---- ddickedt :730-735: (dicke(z + dz) - dicke(z)) / dz / dtdz(z) with float dz = 1e-10
+    def ddickedt(self, z: float) -> float:
+        dz = _f32(1e-10)
+        return (self.dicke(z + dz) - self.dicke(z)) / dz / self.dtdz(z)
+
+    def hubble(self, z: float) -> float:
+        z = _f32(z)
+        Ho = self.h * 3.2407e-18
+        return Ho * math.sqrt(self.om * (1 + z) ** 3 + self.orad * (1 + z) ** 4 + self.ol)
+
+
+def pk_table(cosmo: Cosmo, dim: int, box_len: float) -> np.ndarray:
+    """P(k) at k = (2 pi / L) sqrt(m), m = 0 .. 3 (dim/2)^2 -- the `pk_by_m` table of
+    c21cm_ics_spec (cubic boxes; the reference evaluates power_in_k per mode,
+    InitialConditions.c:118-124)."""
+    n_m = 3 * (dim // 2) ** 2 + 1
+    k = (2.0 * math.pi / float(box_len)) * np.sqrt(np.arange(n_m, dtype=np.float64))
+    return np.ascontiguousarray(cosmo.power_in_k(k))

@@ -110,7 +110,9 @@ def test_initial_conditions_entry_point(gpu_lib, api, oracle, tmp_path):
     vol = np.float32(np.float32(L) * np.float32(L)) * np.float32(1.0) * np.float32(L)
     ospec = S.IcsSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=L, box_len_z=L,
                       volume=float(vol), perturb_algorithm=2, n_m=n_m,
-                      pk_by_m=pk.ctypes.data_as(S.c_double_p), seed=2026)
+                      pk_by_m=pk.ctypes.data_as(S.c_double_p), seed=2026,
+                      rng_stream=1, rng_threads=ses.so.N_THREADS)  # the entry point's default:
+    # the reference's own stream for N_THREADS <= 2 (abi_compute.c, C21CM_IC_RNG)
     ref = oracle.ics_grids(ospec)
     for k in ref:
         scale = np.abs(ref[k]).max()

@@ -1,0 +1,110 @@
+"""The HIP path against vectors the REFERENCE holds (tests/golden/reference/*.h5).
+
+Same pins as tests/test_reference_fixtures.py, but the fields come from the MI355X:
+* through the drop-in entry points exactly as py21cmfast would call them
+  (Broadcast_struct_global_all with N_THREADS = 2 / 1, ComputeInitialConditions(12345),
+  ComputePerturbedField(z)), i.e. with the LIBRARY's own host scalars (sigma_8-normalised EH
+  power spectrum, growth factors) and its own restatement of the reference's random stream;
+* through the explicit-scalar grid entry points fed from oracle/ref_scalars.py.
+DIM = 150 / HII_DIM = 50 are not powers of two, so this also exercises the rocFFT + padded
+pipeline.  Tolerances: the reference's own (`atol 5e-3, rtol 1e-3`,
+tests/test_integration_features.py:305-308).
+"""
+
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import refpin as RP
+
+pytestmark = pytest.mark.gpu
+S = importlib.import_module("21cmfast_amd.structs")
+
+
+class Broadcast:
+    """Parameter structs of the reference's integration-test default, kept alive while in use
+    (the library stores POINTERS, as the reference does: InputParameters.c:11-20)."""
+
+    def __init__(self, lib, n_threads=2, **matter):
+        self.so = S.default_simulation_options(HII_DIM=RP.HII_DIM, DIM=RP.DIM, BOX_LEN=RP.BOX_LEN,
+                                               N_THREADS=n_threads, ZPRIME_STEP_FACTOR=1.04,
+                                               SAMPLER_MIN_MASS=1e9)
+        self.mo = S.default_matter_options(SOURCE_MODEL=1, **matter)
+        self.cp = S.default_cosmo_params()
+        self.ap = S.default_astro_params()
+        self.ao = S.default_astro_options(USE_EXP_FILTER=False, CELL_RECOMB=False)
+        self.ct = S.default_cosmo_tables()
+        lib.Broadcast_struct_global_all(C.byref(self.so), C.byref(self.mo), C.byref(self.cp),
+                                        C.byref(self.ap), C.byref(self.ao), C.byref(self.ct))
+        lib.init_ps()
+
+
+def fptr(a):
+    return a.ctypes.data_as(S.c_float_p)
+
+
+def run_abi(lib, api, z, n_threads=2, algorithm=2, hires=False):
+    keep = Broadcast(lib, n_threads, PERTURB_ALGORITHM=algorithm, PERTURB_ON_HIGH_RES=hires)
+    spec = S.IcsSpec(dim=RP.DIM, dim_z=RP.DIM, hii_dim=RP.HII_DIM, hii_dim_z=RP.HII_DIM,
+                     perturb_algorithm=algorithm, perturb_on_high_res=int(hires))
+    ics = api.new_ics_arrays(spec)
+    st = lib.ComputeInitialConditions(RP.SEED, C.byref(api.ics_struct(ics)))
+    assert st == 0, lib.c21cm_last_error()
+    dens = np.zeros((RP.HII_DIM,) * 3, np.float32)
+    vz = np.zeros((RP.HII_DIM,) * 3, np.float32)
+    pf = S.PerturbedFieldStruct(density=fptr(dens), velocity_z=fptr(vz))
+    st = lib.ComputePerturbedField(z, C.byref(api.ics_struct(ics)), C.byref(pf))
+    assert st == 0, lib.c21cm_last_error()
+    del keep
+    return ics, dens, vz
+
+
+@pytest.fixture()
+def api(gpu_lib):
+    return importlib.import_module("21cmfast_amd.grid_api")
+
+
+@pytest.mark.parametrize("name", list(RP.PT_CASES))
+def test_entry_points_reproduce_reference_perturb_field_data(gpu_lib, api, name, monkeypatch):
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)  # default = the reference's stream
+    algorithm, hires = RP.PT_CASES[name]
+    _, dens, vz = run_abi(gpu_lib, api, 10.0, 2, algorithm, bool(hires))
+    worst = RP.check_perturb_fixture(name, dens, vz)
+    assert worst < 3e-4
+
+
+@pytest.mark.parametrize("name,n_threads", [("simple", 2), ("sampler_ts_ir_onethread", 1)])
+def test_entry_points_reproduce_reference_coeval_powers(gpu_lib, api, name, n_threads,
+                                                        monkeypatch):
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    ics, dens, vz = run_abi(gpu_lib, api, 18.0, n_threads)
+    worst = RP.check_coeval_fields(name, {
+        "lowres_density": ics["lowres_density"], "lowres_vx": ics["lowres_vx"],
+        "lowres_vx_2LPT": ics["lowres_vx_2LPT"], "density": dens, "velocity_z": vz})
+    assert max(worst.values()) < 4e-4
+
+
+def test_grid_entry_points_match_oracle_on_the_reference_stream(gpu_lib, api, oracle):
+    """c21cm_ics_grids with rng_stream = GSL against the oracle, field by field (same P(k)
+    table from oracle/ref_scalars.py on both sides), then the fixture through both."""
+    spec = RP.ics_spec(2, 0, 2)
+    got = api.ics_grids(spec)
+    ref = oracle.ics_grids(RP.ics_spec(2, 0, 2))
+    for k in ref:
+        scale = np.abs(ref[k]).max()
+        np.testing.assert_allclose(got[k], ref[k], atol=3e-5 * scale, rtol=1e-4, err_msg=k)
+    pf = api.perturb_grids(RP.perturb_spec(10.0), got)
+    RP.check_perturb_fixture("simple", pf["density"], pf["velocity_z"])
+
+
+def test_philox_option_is_another_realisation(gpu_lib, api, monkeypatch):
+    """C21CM_IC_RNG=philox keeps the fast device generator: right P(k), other universe."""
+    monkeypatch.setenv("C21CM_IC_RNG", "philox")
+    ics, _, _ = run_abi(gpu_lib, api, 18.0, 2)
+    p, _ = RP.get_power(ics["lowres_density"], RP.BOX_LEN)
+    ref = RP.fixture("power_spectra", "simple")["coeval/power_lowres_density"]
+    ratio = p / ref
+    assert np.abs(ratio - 1).max() > 0.02          # not the same realisation ...
+    assert 0.8 < np.median(ratio[3:]) < 1.25        # ... of the same power spectrum

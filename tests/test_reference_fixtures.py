@@ -1,0 +1,76 @@
+"""The CPU oracle against vectors the REFERENCE holds (tests/golden/reference/*.h5 -- data files
+of the reference's own test-suite, see the README there).
+
+With the reference's random stream restated (oracle/oracle_gslrng.c), `random_seed = 12345` gives
+the reference's universe, and the chain
+    seed_rng_threads -> sample_ic_modes -> ComputeInitialConditions -> ComputePerturbedField
+of the oracle must reproduce the reference's binned power spectra and PDFs.  The tolerances
+are the reference's own (`atol 5e-3, rtol 1e-3`, tests/test_integration_features.py:305-308);
+observed agreement is ~5e-5 for the density power and ~1e-4 for the velocity power.  A different
+realisation of the same P(k) would scatter by tens of per cent per bin, so these tests fail
+unless the generators, the thread split, the mode order, the Hermitian fix, the k-space
+operators, the filter, the subsampling, the CIC deposit and the growth factors are all right.
+"""
+
+import numpy as np
+import pytest
+
+import refpin as RP
+
+
+def test_powerbox_binning_reproduces_fixture_k():
+    x = np.zeros((RP.HII_DIM,) * 3, np.float32)
+    _, k = RP.get_power(x, RP.BOX_LEN)
+    for kind, name, key in (("perturb_field_data", "simple", "k_dens"),
+                            ("power_spectra", "simple", "coeval/k"),
+                            ("power_spectra", "sampler_ts_ir_onethread", "coeval/k")):
+        np.testing.assert_allclose(k, RP.fixture(kind, name)[key], rtol=1e-12)
+    # z_reion = -1 everywhere at z = 18 in these runs: V * 1 / 7 modes in the first bin
+    p, _ = RP.get_power(-np.ones((RP.HII_DIM,) * 3, np.float32), RP.BOX_LEN)
+    ref = RP.fixture("power_spectra", "fixed_halogrids")["coeval/power_z_reion"]
+    np.testing.assert_allclose(p, ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.fixture(scope="module")
+def ics_cache(oracle):
+    cache = {}
+
+    def get(algorithm, hires, n_threads):
+        key = (algorithm, hires, n_threads)
+        if key not in cache:
+            spec = RP.ics_spec(algorithm, hires, n_threads)
+            cache[key] = oracle.ics_grids(spec, oracle.new_ics_arrays(spec))
+        return cache[key]
+
+    return get
+
+
+@pytest.mark.parametrize("name", list(RP.PT_CASES))
+def test_oracle_reproduces_reference_perturb_field_data(oracle, ics_cache, name):
+    algorithm, hires = RP.PT_CASES[name]
+    ics = ics_cache(algorithm, hires, 2)
+    pf = oracle.perturb_grids(RP.perturb_spec(10.0, algorithm, hires), ics)
+    worst = RP.check_perturb_fixture(name, pf["density"], pf["velocity_z"])
+    assert worst < 2e-4  # far inside the reference's rtol 1e-3
+
+
+@pytest.mark.parametrize("name,n_threads", [("simple", 2), ("no-mdz", 2), ("fixed_halogrids", 2),
+                                            ("sampler_ts_ir_onethread", 1)])
+def test_oracle_reproduces_reference_coeval_powers(oracle, ics_cache, name, n_threads):
+    """IC and PerturbedField fields of the z = 18 coeval fixtures, both the two-generator
+    (mt19937 + gfsr4) and the one-generator stream."""
+    ics = ics_cache(2, 0, n_threads)
+    pf = oracle.perturb_grids(RP.perturb_spec(18.0), ics)
+    worst = RP.check_coeval_fields(name, {
+        "lowres_density": ics["lowres_density"], "lowres_vx": ics["lowres_vx"],
+        "lowres_vx_2LPT": ics["lowres_vx_2LPT"], "density": pf["density"],
+        "velocity_z": pf["velocity_z"]})
+    assert max(worst.values()) < 3e-4
+
+
+def test_wrong_thread_count_is_a_different_universe(oracle, ics_cache):
+    """Sensitivity: the N_THREADS = 1 stream against the N_THREADS = 2 fixture misses by far."""
+    ics = ics_cache(2, 0, 1)
+    p, _ = RP.get_power(ics["lowres_density"], RP.BOX_LEN)
+    ref = RP.fixture("power_spectra", "simple")["coeval/power_lowres_density"]
+    assert np.abs(p / ref - 1).max() > 0.05

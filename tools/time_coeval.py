@@ -56,8 +56,19 @@ lib.ComputePerturbedField.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
 lib.ComputeHaloBox.argtypes = [C.c_double] + [C.c_void_p] * 5
 lib.ComputeBrightnessTemp.argtypes = [C.c_float] + [C.c_void_p] * 4
 res = {"hii_dim": n, "dim": N, "ics_ms": None, "snapshots": []}
-timed(lambda: lib.ComputeInitialConditions(12345, C.byref(icss)))
-res["ics_ms"] = timed(lambda: lib.ComputeInitialConditions(12345, C.byref(icss)))
+import os
+
+
+def fresh_ics(stream):
+    """Sampling run (hires_density zeroed first: a non-zero one means "use it as the field")."""
+    os.environ["C21CM_IC_RNG"] = stream
+    ic["hires_density"].zero_()
+    return timed(lambda: lib.ComputeInitialConditions(12345, C.byref(icss)))
+
+
+fresh_ics("philox")
+res["ics_ms"] = fresh_ics("philox")            # counter-based device generator
+res["ics_ms_reference_stream"] = fresh_ics("gsl")  # upstream's serial host stream (the default)
 for z in (12.0, 10.0, 8.0, 7.0):
     for rep in range(2):
         dens, vz = dev(lo), dev(lo)
