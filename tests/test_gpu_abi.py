@@ -26,8 +26,9 @@ class Session:
     def __init__(self, lib, tmp_path, **over):
         self.lib = lib
         n = over.pop("HII_DIM", 32)
-        self.so = S.default_simulation_options(HII_DIM=n, DIM=over.pop("DIM", 2 * n),
-                                               BOX_LEN=over.pop("BOX_LEN", 1.5 * n))
+        self.so = S.default_simulation_options(
+            HII_DIM=n, DIM=over.pop("DIM", 2 * n), BOX_LEN=over.pop("BOX_LEN", 1.5 * n),
+            **{k: over.pop(k) for k in list(over) if hasattr(S.SimulationOptions, k)})
         self.mo = S.default_matter_options(**{k: over.pop(k) for k in list(over)
                                               if hasattr(S.MatterOptions, k)})
         self.cp = S.default_cosmo_params()

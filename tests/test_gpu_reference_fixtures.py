@@ -108,3 +108,80 @@ def test_philox_option_is_another_realisation(gpu_lib, api, monkeypatch):
     ratio = p / ref
     assert np.abs(ratio - 1).max() > 0.02          # not the same realisation ...
     assert 0.8 < np.median(ratio[3:]) < 1.25        # ... of the same power spectrum
+
+
+# ---- the whole coeval chain against the reference's z = 18 fixtures ------------------------------
+# simple: E-INTEGRAL, no-mdz: CONST-ION-EFF, fixed_halogrids: L-INTEGRAL (HaloBox -> IonizedBox);
+# all with HII_FILTER = real-space top-hat, USE_EXP_FILTER = CELL_RECOMB = False, R_BUBBLE_MAX = 15,
+# N_THREADS = 2 (reference: tests/produce_integration_test_data.py:48-63,83-90,168-173).
+COEVAL_SOURCE = {"simple": 1, "no-mdz": 0, "fixed_halogrids": 2}
+
+
+def run_coeval_abi(lib, api, tmp_path, name):
+    from test_gpu_abi import Session
+
+    z = 18.0
+    ses = Session(lib, tmp_path, HII_DIM=RP.HII_DIM, DIM=RP.DIM, BOX_LEN=RP.BOX_LEN,
+                  N_THREADS=2, ZPRIME_STEP_FACTOR=1.04, SOURCE_MODEL=COEVAL_SOURCE[name],
+                  HII_FILTER=0, USE_EXP_FILTER=False, CELL_RECOMB=False, R_BUBBLE_MAX=15.0,
+                  USE_UPPER_STELLAR_TURNOVER=False)
+    spec = S.IcsSpec(dim=RP.DIM, dim_z=RP.DIM, hii_dim=RP.HII_DIM, hii_dim_z=RP.HII_DIM,
+                     perturb_algorithm=2)
+    ics = api.new_ics_arrays(spec)
+    icss = api.ics_struct(ics)
+    assert lib.ComputeInitialConditions(RP.SEED, C.byref(icss)) == 0, lib.c21cm_last_error()
+    shape = (RP.HII_DIM,) * 3
+    new = lambda v=0.0: np.full(shape, v, np.float32)  # noqa: E731
+    dens, vz = new(), new()
+    pf = S.PerturbedFieldStruct(density=fptr(dens), velocity_z=fptr(vz))
+    assert lib.ComputePerturbedField(z, C.byref(icss), C.byref(pf)) == 0, lib.c21cm_last_error()
+    hb_arrays = {"n_ion": new(), "halo_sfr": new()}
+    hb = S.HaloBoxStruct(**{k: fptr(v) for k, v in hb_arrays.items()})
+    ts, prev_arr = S.TsBoxStruct(), new()
+    prev = S.IonizedBoxStruct(z_reion=fptr(prev_arr))
+    if name == "fixed_halogrids":
+        lib.ComputeHaloBox.restype = C.c_int
+        lib.ComputeHaloBox.argtypes = [C.c_double] + [C.c_void_p] * 5
+        st = lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb))
+        assert st == 0, lib.c21cm_last_error()
+    out = {"neutral_fraction": new(1.0), "z_reion": new(), "kinetic_temperature": new(),
+           "unnormalised_nion": new()}
+    box = S.IonizedBoxStruct(**{k: fptr(v) for k, v in out.items()})
+    st = lib.ComputeIonizedBox(z, 0.0, C.byref(pf), C.byref(pf), C.byref(prev), C.byref(ts),
+                               C.byref(hb), C.byref(icss), C.byref(box))
+    assert st == 0, lib.c21cm_last_error()
+    bt = new()
+    btb = S.BrightnessTempStruct(brightness_temp=fptr(bt))
+    lib.ComputeBrightnessTemp.argtypes = [C.c_float] + [C.c_void_p] * 4
+    st = lib.ComputeBrightnessTemp(z, C.byref(ts), C.byref(box), C.byref(pf), C.byref(btb))
+    assert st == 0, lib.c21cm_last_error()
+    del ses
+    return {"density": dens, "velocity_z": vz, "neutral_fraction": out["neutral_fraction"],
+            "z_reion": out["z_reion"], "brightness_temp": bt,
+            "lowres_density": ics["lowres_density"]}
+
+
+@pytest.mark.parametrize("name", list(COEVAL_SOURCE))
+def test_entry_points_reproduce_reference_coeval_ionization(gpu_lib, api, tmp_path, name,
+                                                            monkeypatch):
+    """IC -> PerturbedField -> [HaloBox ->] IonizedBox -> BrightnessTemp through the reference's
+    entry points, same seed: the binned power of x_HI, z_reion and dT_b of the reference's own
+    run.  At z = 18 only a handful of cells cross the barrier, so power_z_reion is white noise
+    whose level counts the ionised cells: it matches to 1e-6 only if exactly the same cells
+    ionise.  power_neutral_fraction follows the partial ionisations 1 - f_coll zeta of every
+    cell and carries the host quadratures (sigma(M), conditional mass function): 1e-3."""
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    got = run_coeval_abi(gpu_lib, api, tmp_path, name)
+    worst = RP.check_coeval_fields(name, {k: got[k] for k in
+                                          ("lowres_density", "density", "velocity_z")})
+    assert max(worst.values()) < 4e-4
+    f = RP.fixture("power_spectra", name)
+    p_z, _ = RP.get_power(got["z_reion"], RP.BOX_LEN)
+    np.testing.assert_allclose(p_z, f["coeval/power_z_reion"], rtol=1e-5, atol=1e-9)
+    p_x, _ = RP.get_power(got["neutral_fraction"], RP.BOX_LEN)
+    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=2e-3)
+    p_b, _ = RP.get_power(got["brightness_temp"], RP.BOX_LEN)
+    np.testing.assert_allclose(p_b, f["coeval/power_brightness_temp"], rtol=2e-3)
+    # the lightcone's last node is this redshift: its global x_HI is the box mean
+    assert got["neutral_fraction"].mean() == pytest.approx(
+        f["lightcone/global_neutral_fraction"][-1], rel=2e-6)
