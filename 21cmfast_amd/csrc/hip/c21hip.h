@@ -322,6 +322,26 @@ int c21hip_any_nonzero(const float *a, size_t n, int *flag_host, void *stream);
 /* xH/z_reion from a max-reduced first_cross mask (multi-GPU tail). */
 /* Eulerian barrier test on the dense f_coll grid, first crossing into a uint8 mask
  * (radius index > 0, no x_e grid; IonisationBox.c:1022-1027,1077,1118) */
+/* find_ionised_regions with a recombination model (IonisationBox.c:1084-1140): rec in the barrier,
+ * Gamma_12 / mean free path at the first crossing.  src_grid = filtered n_ion (padded real,
+ * lagrangian) or the dense unnormalised_nion grid; nrec_fil padded (no CELL_RECOMB) or prev_nrec
+ * dense (CELL_RECOMB; one value for the homogeneous model).  sum_out (Lagrangian f_coll sum) may
+ * be NULL. */
+int c21hip_ionise_recomb(const c21hip_ionize_args *a, int lagrangian, int inhomo, int cell_recomb,
+                         double R, double gamma_prefactor, const float *delta_fil,
+                         const float *src_grid, const float *sfr_fil, const float *xe_fil,
+                         const float *nrec_fil, const float *prev_nrec, const float *density,
+                         const float *prev_z_reion, const float *kinetic_temp_neutral,
+                         const double *mean_dev, float *xH, float *z_reion,
+                         float *kinetic_temperature, float *G12, float *mfp, double *partials,
+                         double *sum_out, void *stream);
+/* set_recombination_rates, inhomogeneous model (IonisationBox.c:1277-1339); rate_scale =
+ * fabs_dtdz * dz; rr tables on the device */
+int c21hip_recomb_rates(const float *density, const float *G12, const float *xH,
+                        const float *prev_nrec, float *nrec, size_t ntot, double stored_redshift,
+                        double rate_scale, const double *rr_y_dev, const double *rr_c_dev,
+                        int *flag_dev, void *stream);
+int c21hip_sum_float(const float *v, size_t n, double *partials, double *sum_out, void *stream);
 int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
                          const double *mean_dev, unsigned char *first_cross, void *stream);
 /* mask of radii > 0 + radius index 0 + post-loop sweep of the fused Lagrangian path in one pass

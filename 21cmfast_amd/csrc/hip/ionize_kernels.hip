@@ -455,6 +455,160 @@ eulerian_mask_kernel(c21hip_ionize_args a, const float *__restrict__ nion_dense,
     }
 }
 
+// ---- find_ionised_regions with a recombination model -------------------------------------------
+// IonisationBox.c:1031-1200 with RECOMB_MODEL != none: recombinations per baryon enter the barrier,
+//   f zeta > (1 - x_e)(1 + rec),   rec = N_rec / (1 + delta_R)
+// with N_rec the previous snapshot's cumulative_recombinations of the cell (CELL_RECOMB; one
+// number for the homogeneous model) or that grid filtered at R (:1084-1099), and the FIRST
+// crossing of a cell (largest R; neutral_fraction still > 1e-7) records Gamma_12 and the mean free
+// path (:1124-1140).  One general kernel for both source-grid kinds (uniform branches; the
+// recombination models run the unfused per-radius sequence, so this sweep reads padded real grids).
+struct RecombParams {
+    IoniseParams ip;
+    int lagrangian, inhomo, cell_recomb, ts;
+    double R, gamma_prefactor;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+ionise_recomb_kernel(RecombParams q, const float *__restrict__ delta_fil,
+                     const float *__restrict__ src_grid,   // stars_fil (padded) | nion_dense
+                     const float *__restrict__ sfr_fil,    // Lagrangian: filtered whalo_sfr
+                     const float *__restrict__ xe_fil, const float *__restrict__ nrec_fil,
+                     const float *__restrict__ prev_nrec,  // CELL_RECOMB: dense previous N_rec
+                     const float *__restrict__ density, const float *__restrict__ prev_z_reion,
+                     const float *__restrict__ Tneutral, const double *__restrict__ mean_dev,
+                     float *__restrict__ xH, float *__restrict__ z_reion, float *__restrict__ Tk,
+                     float *__restrict__ G12, float *__restrict__ mfp,
+                     double *__restrict__ partials) {
+    const c21hip_ionize_args &a = q.ip.a;
+    const bool LAST = (a.r_index == 0);
+    const double mean_fix = (!q.lagrangian && a.fix_mean) ? a.mean_f_coll / *mean_dev : 1.;
+    const float z_now = (float)a.redshift;
+    double acc = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < q.ip.nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const auto ci = cell_index<VEC>(i, q.ip.nz_items, q.ip.zpad_items);
+        const auto src = Pack<VEC>::load(src_grid, q.lagrangian ? ci.padded : ci.dense);
+        Pack<VEC> dl, xe, de, sf, nr;
+        if (!LAST) dl = Pack<VEC>::load(delta_fil, ci.padded);
+        if (LAST || !a.minimize_memory) de = Pack<VEC>::load(density, ci.dense);
+        if (q.ts) xe = Pack<VEC>::load(xe_fil, ci.padded);
+        if (q.lagrangian) sf = Pack<VEC>::load(sfr_fil, ci.padded);
+        if (!q.cell_recomb)
+            nr = Pack<VEC>::load(nrec_fil, ci.padded);
+        else if (q.inhomo)
+            nr = Pack<VEC>::load(prev_nrec, ci.dense);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const size_t idx = ci.dense * VEC + e;
+            const double curr_dens =
+                LAST ? (double)de.v[e] * a.photoncons_factor
+                     : (double)(q.lagrangian ? clip_delta(dl.v[e]) : clip_delta_eulerian(dl.v[e]));
+            double curr_fcoll;
+            if (q.lagrangian) {
+                const float stars = fmaxf(src.v[e], 0.f);
+                acc += (double)stars;
+                curr_fcoll = (double)stars * (1 / (a.rhocrit_omb * (1 + curr_dens)));
+            } else {
+                curr_fcoll = mean_fix * (double)src.v[e];
+            }
+            if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
+            double rec;
+            if (!q.cell_recomb)
+                rec = (double)fmaxf(nr.v[e], 0.f);  // :806-809
+            else
+                rec = q.inhomo ? (double)nr.v[e] : (double)prev_nrec[0];
+            rec /= (1. + curr_dens);
+            const double x_e = q.ts ? (double)clip_xe(xe.v[e]) : 0.;
+            if (curr_fcoll * a.ion_eff_factor > (1. - x_e) * (1.0 + rec)) {
+                if ((double)xH[idx] > kFractFloatErr) {  // first crossing, :1124-1140
+                    double g;
+                    if (q.lagrangian)
+                        g = q.R * q.gamma_prefactor / (1 + curr_dens) * (double)fmaxf(sf.v[e], 0.f);
+                    else
+                        g = q.R * (q.gamma_prefactor * curr_fcoll);
+                    G12[idx] = (float)g;
+                    if (mfp) mfp[idx] = (float)q.R;
+                }
+                const float pz = a.first_snapshot ? -1.f : prev_z_reion[idx];
+                z_reion[idx] = (pz < 0.f) ? z_now : pz;
+                xH[idx] = 0.f;
+            } else if (LAST) {
+                if ((double)xH[idx] > kTiny) {
+                    double res_xH = 1. - curr_fcoll * a.ion_eff_factor;
+                    if (!a.minimize_memory) {
+                        const float T_HI =
+                            q.ts ? Tneutral[idx]
+                                 : (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)de.v[e]));
+                        Tk[idx] = partially_ionized_T(T_HI, (float)res_xH, (float)a.T_re);
+                    }
+                    res_xH -= x_e;
+                    if (res_xH < 0)
+                        res_xH = 0;
+                    else if (res_xH > 1)
+                        res_xH = 1;
+                    xH[idx] = (float)res_xH;
+                }
+            }
+        }
+    }
+    block_sum_to(acc, partials);
+}
+
+// splined_recombination_rate (recombinations.c:64-92): row z_ct of the table, natural cubic spline
+// in ln Gamma evaluated like gsl_interp_cspline (b, d from the c coefficients, Horner in delta)
+__device__ __forceinline__ double rr_spline(const double *__restrict__ rr_y,
+                                            const double *__restrict__ rr_c, double z_eff,
+                                            double gamma12_bg) {
+    int z_ct = (int)(z_eff / C21CM_RR_DZ + 0.5);
+    double lnGamma = log(gamma12_bg);
+    z_ct = max(0, min(z_ct, C21CM_RR_NZ - 1));
+    const double top = C21CM_RR_LNGAMMA_MIN + C21CM_RR_DLNGAMMA * (C21CM_RR_NGAMMA - 1);
+    if (lnGamma < C21CM_RR_LNGAMMA_MIN) return 0.;
+    if (lnGamma >= top) lnGamma = top - kFractFloatErr;
+    const double *y = rr_y + (size_t)z_ct * C21CM_RR_NGAMMA, *c = rr_c + (size_t)z_ct * C21CM_RR_NGAMMA;
+    auto knot = [](int g) { return C21CM_RR_LNGAMMA_MIN + g * C21CM_RR_DLNGAMMA; };
+    int i = (int)((lnGamma - C21CM_RR_LNGAMMA_MIN) / C21CM_RR_DLNGAMMA);
+    i = min(i, C21CM_RR_NGAMMA - 2);
+    while (i > 0 && lnGamma < knot(i)) i--;
+    while (i < C21CM_RR_NGAMMA - 2 && lnGamma >= knot(i + 1)) i++;
+    const double x_lo = knot(i), dx = knot(i + 1) - x_lo, dy = y[i + 1] - y[i];
+    const double b = (dy / dx) - dx * (c[i + 1] + 2.0 * c[i]) / 3.0;
+    const double d = (c[i + 1] - c[i]) / (3.0 * dx);
+    const double delx = lnGamma - x_lo;
+    return y[i] + delx * (b + delx * (c[i] + delx * d));
+}
+
+// set_recombination_rates, inhomogeneous model (IonisationBox.c:1277-1339): one sweep
+__global__ void __launch_bounds__(kBlock)
+recomb_rates_kernel(const float *__restrict__ density, const float *__restrict__ G12,
+                    const float *__restrict__ xH, const float *__restrict__ prev_nrec,
+                    float *__restrict__ nrec, size_t ntot, double stored_redshift, double rate_scale,
+                    const double *__restrict__ rr_y, const double *__restrict__ rr_c,
+                    int *__restrict__ flag) {
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const double curr_dens = 1.0 + (double)density[i];
+        double z_eff = pow(curr_dens, 1.0 / 3.0);
+        z_eff *= (1 + stored_redshift);
+        const double dNrec =
+            rr_spline(rr_y, rr_c, z_eff - 1., (double)G12[i]) * rate_scale * (1. - (double)xH[i]);
+        if (!isfinite(dNrec)) bad = 1;
+        nrec[i] = (float)((double)prev_nrec[i] + dNrec);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+__global__ void __launch_bounds__(kBlock)
+sum_float_kernel(const float *__restrict__ v, size_t n, double *__restrict__ partials) {
+    double acc = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        acc += (double)v[i];
+    block_sum_to(acc, partials);
+}
+
 // ---- post-loop: ionised temperatures, sum(xH), non-finite flag -------------------------
 __global__ void __launch_bounds__(kBlock)
 finalize_kernel(c21hip_ionize_args a, float stored_z, const float *__restrict__ density,
@@ -893,6 +1047,68 @@ extern "C" int c21hip_ionise_eulerian(const c21hip_ionize_args *a, const float *
     DISPATCH_IONISE(ionise_eulerian_kernel, p, nion_dense, xe_fil, density, prev_z_reion,
                     kinetic_temp_neutral, mean_dev, xH, z_reion, kinetic_temperature,
                     first_cross);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_ionise_recomb(const c21hip_ionize_args *a, int lagrangian, int inhomo,
+                                    int cell_recomb, double R, double gamma_prefactor,
+                                    const float *delta_fil, const float *src_grid,
+                                    const float *sfr_fil, const float *xe_fil,
+                                    const float *nrec_fil, const float *prev_nrec,
+                                    const float *density, const float *prev_z_reion,
+                                    const float *kinetic_temp_neutral, const double *mean_dev,
+                                    float *xH, float *z_reion, float *kinetic_temperature,
+                                    float *G12, float *mfp, double *partials, double *sum_out,
+                                    void *stream) {
+    const int vec = (a->nz % 2 == 0) ? 2 : 1;
+    RecombParams q;
+    q.ip = make_params(a, vec);
+    q.lagrangian = lagrangian;
+    q.inhomo = inhomo;
+    q.cell_recomb = cell_recomb;
+    q.ts = a->use_ts_fluct;
+    q.R = R;
+    q.gamma_prefactor = gamma_prefactor;
+    const int blocks = grid_for(q.ip.nitems);
+    if (vec == 2)
+        hipLaunchKernelGGL((ionise_recomb_kernel<2>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, q, delta_fil, src_grid, sfr_fil, xe_fil, nrec_fil,
+                           prev_nrec, density, prev_z_reion, kinetic_temp_neutral, mean_dev, xH,
+                           z_reion, kinetic_temperature, G12, mfp, partials);
+    else
+        hipLaunchKernelGGL((ionise_recomb_kernel<1>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, q, delta_fil, src_grid, sfr_fil, xe_fil, nrec_fil,
+                           prev_nrec, density, prev_z_reion, kinetic_temp_neutral, mean_dev, xH,
+                           z_reion, kinetic_temperature, G12, mfp, partials);
+    LAUNCH_CHECK();
+    if (sum_out) {
+        hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                           partials, blocks, 0, sum_out);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int c21hip_recomb_rates(const float *density, const float *G12, const float *xH,
+                                   const float *prev_nrec, float *nrec, size_t ntot,
+                                   double stored_redshift, double rate_scale, const double *rr_y_dev,
+                                   const double *rr_c_dev, int *flag_dev, void *stream) {
+    hipLaunchKernelGGL(recomb_rates_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
+                       (hipStream_t)stream, density, G12, xH, prev_nrec, nrec, ntot,
+                       stored_redshift, rate_scale, rr_y_dev, rr_c_dev, flag_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_sum_float(const float *v, size_t n, double *partials, double *sum_out,
+                                void *stream) {
+    const int blocks = grid_for(n);
+    hipLaunchKernelGGL(sum_float_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, v, n,
+                       partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, blocks, 0, sum_out);
     LAUNCH_CHECK();
     return 0;
 }

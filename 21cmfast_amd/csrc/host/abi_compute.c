@@ -19,10 +19,11 @@
  * mass-function tables per radius, PS / ST, Gauss-Legendre or adaptive quadrature; needs
  * USE_INTERPOLATION_TABLES = hmf-interpolation) and the Lagrangian models (L-INTEGRAL /
  * DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all HII_FILTER types,
- * USE_EXP_FILTER, MINIMIZE_MEMORY; ComputeBrightnessTemp with or without spin temperatures.
+ * USE_EXP_FILTER, MINIMIZE_MEMORY, RECOMB_MODEL homogeneous / inhomogeneous with or without
+ * CELL_RECOMB; ComputeBrightnessTemp with or without spin temperatures.
  * Returning ValueError (3) with a message in
  * c21cm_last_error(): E-INTEGRAL without interpolation tables or with the Gamma-function
- * approximation, USE_MINI_HALOS, recombination models, PHOTON_CONS_TYPE != none,
+ * approximation, USE_MINI_HALOS, PHOTON_CONS_TYPE != none,
  * IONISE_ENTIRE_SPHERE, V_CB_MODEL = FLUCTS, CLASS transfer tables.
  */
 #include <math.h>
@@ -242,7 +243,6 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     if (src == C21CM_SOURCE_E_INTEGRAL && ao->INTEGRATION_METHOD_ATOMIC > 1)
         unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
     if (ao->USE_MINI_HALOS) unsupported = "USE_MINI_HALOS";
-    if (ao->RECOMB_MODEL != C21CM_RECOMB_NONE) unsupported = "RECOMB_MODEL != none";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
     if (ao->IONISE_ENTIRE_SPHERE) unsupported = "IONISE_ENTIRE_SPHERE";
     if (unsupported) {
@@ -283,6 +283,10 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     s->minimize_memory = mo->MINIMIZE_MEMORY;
     s->recomb_model = ao->RECOMB_MODEL;
     s->cell_recomb = ao->CELL_RECOMB;
+    if (ao->RECOMB_MODEL != C21CM_RECOMB_NONE) { /* init_MHR's tables (recombinations.c:94-122) */
+        extern int c21_rr_tables(const double **y_out, const double **c_out);
+        if ((st = c21_rr_tables(&s->rr_y, &s->rr_c))) goto done;
+    }
     s->first_snapshot = (prev_redshift < 1);
     if (!ao->USE_TS_FLUCT) {
         if ((st = c21_recfast_load())) goto done;

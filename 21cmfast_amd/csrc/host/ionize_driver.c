@@ -52,10 +52,23 @@ enum {
     WS_DEF_PARTIALS = 84,
     WS_DELTA_WORK2 = 92, /* second radius of a two-radius sweep */
     WS_STARS_WORK2 = 93,
-    WS_XE_WORK2 = 96
+    WS_XE_WORK2 = 96,
+    /* recombination models: filtered whalo_sfr and N_rec grids, staged arrays, rate tables */
+    WS_SFR_UNF = 120,
+    WS_SFR_FIL,
+    WS_SFR_WORK,
+    WS_NREC_UNF,
+    WS_NREC_FIL,
+    WS_NREC_WORK,
+    WS_WSFR,
+    WS_PREV_NREC,
+    WS_G12,
+    WS_MFP,
+    WS_NREC_OUT,
+    WS_RR_TABLES
 };
 
-#define MAX_COPYBACK 8
+#define MAX_COPYBACK 12
 typedef struct {
     void *host[MAX_COPYBACK];
     void *dev[MAX_COPYBACK];
@@ -69,7 +82,8 @@ typedef struct {
 #define SC_MINMAX (SC_MEANS + C21CM_MAX_RADII)
 #define SC_XHSUM (SC_MINMAX + 4) /* two (min, max) pairs: the table loop is double-buffered */
 #define SC_FLAG (SC_XHSUM + 1) /* an int stored in a double-sized cell */
-#define SC_COUNT (SC_FLAG + 1)
+#define SC_G12SUM (SC_FLAG + 1)
+#define SC_COUNT (SC_G12SUM + 1)
 
 #define TRY(expr)                   \
     do {                            \
@@ -129,8 +143,29 @@ static int validate_spec(const c21cm_ionize_spec *s, const PerturbedField *pf,
         return C21CM_VALUE_ERROR;
     }
     if (s->recomb_model != C21CM_RECOMB_NONE) {
-        c21hip_set_error("ionize: recombination models are not implemented on the device yet");
-        return C21CM_VALUE_ERROR;
+        if (s->recomb_model != C21CM_RECOMB_HOMOGENEOUS &&
+            s->recomb_model != C21CM_RECOMB_INHOMOGENEOUS) {
+            c21hip_set_error("ionize: unknown recomb_model %d", s->recomb_model);
+            return C21CM_VALUE_ERROR;
+        }
+        if (!s->rr_y || !s->rr_c) {
+            c21hip_set_error("ionize: a recombination model needs the rr_y / rr_c rate tables");
+            return C21CM_VALUE_ERROR;
+        }
+        if (!box->ionisation_rate_G12 || !box->cumulative_recombinations) {
+            c21hip_set_error("ionize: a recombination model needs ionisation_rate_G12 and "
+                             "cumulative_recombinations");
+            return C21CM_VALUE_ERROR;
+        }
+        if (s->recomb_model == C21CM_RECOMB_HOMOGENEOUS && !s->cell_recomb) {
+            /* the homogeneous N_rec is one number: there is no grid to filter (inputs.py) */
+            c21hip_set_error("ionize: RECOMB_MODEL = homogeneous needs CELL_RECOMB");
+            return C21CM_VALUE_ERROR;
+        }
+        if (s->fcoll_mode == C21CM_FCOLL_STARS_GRID && (!halos || !halos->whalo_sfr)) {
+            c21hip_set_error("ionize: Lagrangian sources with recombinations need HaloBox.whalo_sfr");
+            return C21CM_VALUE_ERROR;
+        }
     }
     if (s->fcoll_mode < C21CM_FCOLL_STARS_GRID || s->fcoll_mode > C21CM_FCOLL_TABLE_EXP) {
         c21hip_set_error("ionize: unknown fcoll_mode %d", s->fcoll_mode);
@@ -201,6 +236,12 @@ typedef struct {
     float *delta_unf, *delta_fil, *stars_unf, *stars_fil, *xe_unf, *xe_fil;
     float *delta_work, *stars_work, *xe_work;
     float *delta_work2, *stars_work2, *xe_work2; /* two radii per pass-X sweep (pair_radii) */
+    /* recombination models (unfused per-radius sequence) */
+    int recomb, inhomo, filter_rec;
+    float *sfr_unf, *sfr_fil, *sfr_work, *nrec_unf, *nrec_fil, *nrec_work;
+    const float *whalo_sfr, *prev_nrec;
+    float *G12, *mfp, *nrec_out;
+    double *rr_dev; /* rr_y then rr_c */
     int pair_radii;
     /* dense inputs */
     const float *density, *n_ion, *xe_dense, *Tneutral, *prev_zre;
@@ -272,10 +313,39 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
      * barrier test run as one kernel that only updates a uint8 first-crossing mask */
     /* with an x_e grid (spin-temperature runs) the fused path needs the three-grid pass Z
      * (512/1024-point z-lines) and the dense-input final sweep */
-    c->fused = c->native && c->lagrangian &&
+    c->recomb = (s->recomb_model != C21CM_RECOMB_NONE);
+    c->inhomo = (s->recomb_model == C21CM_RECOMB_INHOMOGENEOUS);
+    c->filter_rec = c->recomb && !s->cell_recomb; /* IonisationBox.c:156-157 */
+    /* (recombination models take the unfused sequence: up to five filtered grids per radius and
+     * per-cell Gamma_12 / mean-free-path outputs do not fit the fused pass Z) */
+    c->fused = c->native && c->lagrangian && !c->recomb &&
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
-    c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct;
+    c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct && !c->recomb;
+    if (c->recomb && c->lagrangian) {
+        c->sfr_unf = (float *)c21hip_ws(WS_SFR_UNF, gbytes);
+        c->sfr_fil = (float *)c21hip_ws(WS_SFR_FIL, gbytes);
+        if (!c->sfr_unf || !c->sfr_fil) return C21CM_MEMORY_ALLOC_ERROR;
+        if (c->native && !(c->sfr_work = (float *)c21hip_ws(WS_SFR_WORK, gbytes)))
+            return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    if (c->filter_rec) {
+        c->nrec_unf = (float *)c21hip_ws(WS_NREC_UNF, gbytes);
+        c->nrec_fil = (float *)c21hip_ws(WS_NREC_FIL, gbytes);
+        if (!c->nrec_unf || !c->nrec_fil) return C21CM_MEMORY_ALLOC_ERROR;
+        if (c->native && !(c->nrec_work = (float *)c21hip_ws(WS_NREC_WORK, gbytes)))
+            return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    if (c->recomb) {
+        const size_t tb = sizeof(double) * (size_t)C21CM_RR_NZ * C21CM_RR_NGAMMA;
+        c->rr_dev = (double *)c21hip_ws(WS_RR_TABLES, 2 * tb);
+        if (!c->rr_dev) return C21CM_MEMORY_ALLOC_ERROR;
+        status = c21hip_h2d(c->rr_dev, s->rr_y, tb, stream);
+        if (!status)
+            status = c21hip_h2d(c->rr_dev + (size_t)C21CM_RR_NZ * C21CM_RR_NGAMMA, s->rr_c, tb,
+                                stream);
+        if (status) return status;
+    }
     if (c->fused && c->nx < 1024) {
         /* pass X reads each spectrum tile once for two consecutive radii (C21CM_PAIR_RADII=0:
          * one radius per sweep) */
@@ -327,6 +397,29 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     if (!c->lagrangian)
         c->nion_dense = stage_inout(WS_NION_DENSE, box->unnormalised_nion, dbytes, 0, &c->cb,
                                     stream, &status);
+    if (c->recomb) {
+        if (!prev || !prev->cumulative_recombinations) {
+            c21hip_set_error("ionize: a recombination model needs the previous box's "
+                             "cumulative_recombinations");
+            return C21CM_VALUE_ERROR;
+        }
+        const size_t rbytes = c->inhomo ? dbytes : sizeof(float); /* homogeneous: one number */
+        c->prev_nrec = stage_in(WS_PREV_NREC, prev->cumulative_recombinations, rbytes, stream,
+                                &status);
+        if (c->lagrangian)
+            c->whalo_sfr = stage_in(WS_WSFR, halos->whalo_sfr, dbytes, stream, &status);
+        if (need_outputs) {
+            /* Gamma_12 / mean free path keep the caller's values where no barrier is crossed */
+            c->G12 = stage_inout(WS_G12, box->ionisation_rate_G12, dbytes, 1, &c->cb, stream,
+                                 &status);
+            if (!s->minimize_memory && box->mean_free_path)
+                c->mfp = stage_inout(WS_MFP, box->mean_free_path, dbytes, 1, &c->cb, stream,
+                                     &status);
+            if (c->inhomo)
+                c->nrec_out = stage_inout(WS_NREC_OUT, box->cumulative_recombinations, dbytes, 0,
+                                          &c->cb, stream, &status);
+        }
+    }
     return status;
 }
 
@@ -409,6 +502,9 @@ static int preloop(ion_ctx *c) {
                      -1., 1e6));
     if (c->lagrangian) TRY(prepare_grid(c, c->n_ion, c->stars_unf, c->stars_fil, 1., 0., 1e20));
     if (s->use_ts_fluct) TRY(prepare_grid(c, c->xe_dense, c->xe_unf, c->xe_fil, 1., 0., 1.));
+    if (c->recomb && c->lagrangian)
+        TRY(prepare_grid(c, c->whalo_sfr, c->sfr_unf, c->sfr_fil, 1., 0., 1e20));
+    if (c->filter_rec) TRY(prepare_grid(c, c->prev_nrec, c->nrec_unf, c->nrec_fil, 1., 0., 1e20));
 done:
     return status;
 }
@@ -659,7 +755,28 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
     if (s->use_ts_fluct)
         TRY(filter_to_real(c, c->xe_unf, c->xe_work, c->xe_fil, s->hii_filter, R, 0.f, apply));
 
-    if (c->lagrangian) {
+    if (c->recomb) {
+        if (first_cross) {
+            c21hip_set_error("ionize: recombination models are not sharded over radii");
+            status = C21CM_VALUE_ERROR;
+            goto done;
+        }
+        if (c->lagrangian)
+            TRY(filter_to_real(c, c->sfr_unf, c->sfr_work, c->sfr_fil, s->stars_filter, R,
+                               (float)s->mfp_meandens, apply));
+        if (c->filter_rec)
+            TRY(filter_to_real(c, c->nrec_unf, c->nrec_work, c->nrec_fil, s->hii_filter, R, 0.f,
+                               apply));
+    }
+    if (c->recomb && c->lagrangian) {
+        TRY(c21hip_ionise_recomb(&args, 1, c->inhomo, s->cell_recomb, s->R[R_ct],
+                                 s->gamma_prefactor, c->delta_fil, c->stars_fil, c->sfr_fil,
+                                 c->xe_fil, c->nrec_fil, c->prev_nrec, c->density, c->prev_zre,
+                                 c->Tneutral, NULL, c->xH, c->zre, c->Tk, c->G12, c->mfp, partials,
+                                 sum_dev, c->stream));
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               mean_dev, c->stream));
+    } else if (c->lagrangian) {
         TRY(c21hip_ionise_stars(&args, c->delta_fil, c->stars_fil, c->xe_fil, c->density,
                                 c->prev_zre, c->Tneutral, c->xH, c->zre, c->Tk, first_cross,
                                 partials, sum_dev, c->stream));
@@ -693,9 +810,16 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                   c->stream));
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
-        TRY(c21hip_ionise_eulerian(&args, c->nion_dense, c->xe_fil, c->density, c->prev_zre,
-                                   c->Tneutral, mean_dev, c->xH, c->zre, c->Tk, first_cross,
-                                   c->stream));
+        if (c->recomb)
+            TRY(c21hip_ionise_recomb(&args, 0, c->inhomo, s->cell_recomb, s->R[R_ct],
+                                     s->gamma_prefactor, c->delta_fil, c->nion_dense, NULL,
+                                     c->xe_fil, c->nrec_fil, c->prev_nrec, c->density, c->prev_zre,
+                                     c->Tneutral, mean_dev, c->xH, c->zre, c->Tk, c->G12, c->mfp,
+                                     partials, NULL, c->stream));
+        else
+            TRY(c21hip_ionise_eulerian(&args, c->nion_dense, c->xe_fil, c->density, c->prev_zre,
+                                       c->Tneutral, mean_dev, c->xH, c->zre, c->Tk, first_cross,
+                                       c->stream));
     }
 done:
     return status;
@@ -829,6 +953,13 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
         TRY(c21hip_finalize(&args, s->stored_redshift, c->density, c->Tneutral, c->xH, c->zre,
                             c->Tk, c->ntot, c->partials, c->scalars + SC_XHSUM, flag_dev,
                             c->stream));
+    if (c->recomb && c->inhomo) /* set_recombination_rates, IonisationBox.c:1277-1339 */
+        TRY(c21hip_recomb_rates(c->density, c->G12, c->xH, c->prev_nrec, c->nrec_out, c->ntot,
+                                s->stored_redshift, s->fabs_dtdz * s->dz, c->rr_dev,
+                                c->rr_dev + (size_t)C21CM_RR_NZ * C21CM_RR_NGAMMA, flag_dev,
+                                c->stream));
+    if (c->recomb && !c->inhomo) /* the global Gamma_12 of the homogeneous model, :1600-1609 */
+        TRY(c21hip_sum_float(c->G12, c->ntot, c->partials, c->scalars + SC_G12SUM, c->stream));
     TRY(c21hip_d2h(host_sc, c->scalars + SC_SUMS, sizeof(host_sc), c->stream));
     for (int i = 0; i < c->cb.n; i++)
         TRY(c21hip_d2h(c->cb.host[i], c->cb.dev[i], c->cb.bytes[i], c->stream));
@@ -841,9 +972,32 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
         global_xH /= (float)c->ntot; /* IonisationBox.c:1607 */
         if (flag || !isfinite(global_xH)) {
             c21hip_set_error("ionize: non-finite %s",
-                             flag ? "kinetic temperature" : "neutral fraction");
+                             flag ? "kinetic temperature or recombination count" : "neutral fraction");
             status = C21CM_INFINITY_OR_NAN_ERROR;
             goto done;
+        }
+        if (c->recomb && !c->inhomo) { /* IonisationBox.c:1261-1276 */
+            double c21_rr_eval(const double *rr_y, const double *rr_c, double z_eff, double g);
+            const float global_g12 = (float)(host_sc[SC_G12SUM - SC_SUMS] / (float)c->ntot);
+            const float global_xHI = (float)global_xH;
+            float prev0; /* (staged or caller-owned: prev_nrec is a device address either way) */
+            TRY(c21hip_d2h(&prev0, c->prev_nrec, sizeof(float), c->stream));
+            TRY(c21hip_sync(c->stream));
+            const double dNrec = c21_rr_eval(s->rr_y, s->rr_c, s->stored_redshift, global_g12) *
+                                 s->fabs_dtdz * s->dz * (1. - global_xHI);
+            const double cum = (double)prev0 + dNrec;
+            if (!isfinite(cum)) {
+                c21hip_set_error("ionize: non-finite cumulative recombinations");
+                status = C21CM_INFINITY_OR_NAN_ERROR;
+                goto done;
+            }
+            const float cumf = (float)cum;
+            if (c21hip_is_device_ptr(box->cumulative_recombinations)) {
+                TRY(c21hip_h2d(box->cumulative_recombinations, &cumf, sizeof(float), c->stream));
+                TRY(c21hip_sync(c->stream));
+            } else {
+                box->cumulative_recombinations[0] = cumf;
+            }
         }
         const int last = s->r_lowest < s->n_radii ? s->r_lowest : s->n_radii - 1;
         const double mean_out = s->fix_mean ? s->mean_f_coll : means[last];

@@ -83,11 +83,23 @@ class IonizeBuffers:
     """Owns the output arrays of one IonizedBox (what ``IonizedBox.new`` allocates in
     py21cmfast, reference: src/py21cmfast/wrapper/outputs.py:1475-1545)."""
 
-    def __init__(self, density, need_nion: bool = False, minimize_memory: bool = False):
+    def __init__(self, density, need_nion: bool = False, minimize_memory: bool = False,
+                 recomb_model: int = 0):
         self.neutral_fraction = _new_like(density, 1.0)  # initialised to ones (:1524-1527)
         self.z_reion = _new_like(density, 0.0)
         self.kinetic_temperature = None if minimize_memory else _new_like(density, 0.0)
         self.unnormalised_nion = _new_like(density, 0.0) if need_nion else None
+        # recombination models (:1526-1537): Gamma_12 and the mean free path are always part of
+        # the reference's IonizedBox; here they are only allocated when something writes them
+        self.ionisation_rate_G12 = self.mean_free_path = self.cumulative_recombinations = None
+        if recomb_model:
+            self.ionisation_rate_G12 = _new_like(density, 0.0)
+            if not minimize_memory:
+                self.mean_free_path = _new_like(density, 0.0)
+            if recomb_model == 2:
+                self.cumulative_recombinations = _new_like(density, 0.0)
+            else:  # homogeneous: one number, shape (1, 1, 1)
+                self.cumulative_recombinations = _new_like(density[:1, :1, :1], 0.0)
 
     def reset(self):
         """Back to the state of a freshly allocated IonizedBox.  z_reion needs no reset: every
@@ -95,30 +107,42 @@ class IonizeBuffers:
         self.neutral_fraction[...] = 1.0
         if self.kinetic_temperature is not None:
             self.kinetic_temperature[...] = 0.0
+        for a in (self.ionisation_rate_G12, self.mean_free_path, self.cumulative_recombinations):
+            if a is not None:
+                a[...] = 0.0
 
     def struct(self) -> S.IonizedBoxStruct:
         return S.IonizedBoxStruct(
             neutral_fraction=_fptr(self.neutral_fraction), z_reion=_fptr(self.z_reion),
             kinetic_temperature=_fptr(self.kinetic_temperature),
             unnormalised_nion=_fptr(self.unnormalised_nion),
+            ionisation_rate_G12=_fptr(self.ionisation_rate_G12),
+            mean_free_path=_fptr(self.mean_free_path),
+            cumulative_recombinations=_fptr(self.cumulative_recombinations),
         )
 
 
-def _input_structs(density, n_ion, xe, Tneutral, prev_z_reion):
+def _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec=None, whalo_sfr=None):
     pf = S.PerturbedFieldStruct(density=_fptr(density))
-    prev = S.IonizedBoxStruct(z_reion=_fptr(prev_z_reion))
+    prev = S.IonizedBoxStruct(z_reion=_fptr(prev_z_reion),
+                              cumulative_recombinations=_fptr(prev_nrec))
     ts = S.TsBoxStruct(xray_ionised_fraction=_fptr(xe), kinetic_temp_neutral=_fptr(Tneutral))
-    hb = S.HaloBoxStruct(n_ion=_fptr(n_ion))
+    hb = S.HaloBoxStruct(n_ion=_fptr(n_ion), whalo_sfr=_fptr(whalo_sfr))
     return pf, prev, ts, hb
 
 
 def ionize_grids(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=None,
-                 prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None):
-    """One ComputeIonizedBox grid pass on the MI355X.  Returns (buffers, box_struct, report)."""
+                 prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None,
+                 prev_nrec=None, whalo_sfr=None):
+    """One ComputeIonizedBox grid pass on the MI355X.  Returns (buffers, box_struct, report).
+    ``prev_nrec`` (the previous box's cumulative_recombinations) and ``whalo_sfr`` (HaloBox) are
+    the extra inputs of the recombination models."""
     if buffers is None:
         buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
-                                minimize_memory=bool(spec.minimize_memory))
-    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion)
+                                minimize_memory=bool(spec.minimize_memory),
+                                recomb_model=spec.recomb_model)
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec,
+                                      whalo_sfr)
     box = buffers.struct()
     rep = S.IonizeReport()
     check(

@@ -343,7 +343,12 @@ class IonizeSpec(_Base):
         ("T_re", C.c_double),
         ("fabs_dtdz", C.c_double),
         ("dz", C.c_double),
+        ("rr_y", c_double_p),  # recombination-rate table [RR_NZ][RR_NGAMMA] and its spline c's
+        ("rr_c", c_double_p),
     ]
+
+
+RR_NZ, RR_NGAMMA = 300, 250  # include/c21cm_grid.h C21CM_RR_*
 
 
 class IonizeReport(_Base):

@@ -307,7 +307,7 @@ def main():
             roof.update({"kernel": "R loop (all kernels)", "achieved": loop["GBs"],
                          "frac": loop["frac"]})
         out = {
-            "metric": "IonizeBox cells/sec (512^3 HII_DIM, 40 filter radii)",
+            "metric": f"IonizeBox cells/sec ({n}^3 HII_DIM, {spec.n_radii} filter radii)",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -323,6 +323,10 @@ void Broadcast_struct_global_noastro(SimulationOptions *simulation_options,
  * Called by @init_c_state(ps=True) before ComputeInitialConditions. */
 void init_ps(void);
 void free_ps(void);
+/* reference: _functionprototypes_wrapper.h:70,86 (recombinations.c:94-140): the MHR00
+ * recombination-rate tables; built on first use as well, so calling these is optional */
+void init_MHR(void);
+void free_MHR(void);
 
 /* reference: src/py21cmfast/src/InitialConditions.c:547 (_functionprototypes_wrapper.h:6) */
 int ComputeInitialConditions(unsigned long long random_seed, InitialConditions *boxes);

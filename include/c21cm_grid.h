@@ -95,7 +95,20 @@ typedef struct c21cm_ionize_spec {
     double T_re;
     double fabs_dtdz;
     double dz;
+
+    /* recombinations (recomb_model != none): the table behind splined_recombination_rate
+     * (recombinations.c:64-122): rr_y[z_ct * C21CM_RR_NGAMMA + g] = recombination_rate(z_ct * 0.2f,
+     * exp(ln Gamma_g), T4 = 1, case B) with ln Gamma_g = -10 + 0.1f g, and rr_c = the natural cubic
+     * spline's c coefficients (half the second derivatives) of each row in ln Gamma, as
+     * gsl_interp_cspline holds them.  Host arrays; c21_rr_tables() builds them (init_MHR). */
+    const double *rr_y, *rr_c;
 } c21cm_ionize_spec;
+
+#define C21CM_RR_NZ 300       /* recombinations.c:35 RR_Z_NPTS        */
+#define C21CM_RR_NGAMMA 250   /* :39 RR_lnGamma_NPTS                  */
+#define C21CM_RR_DZ 0.2f      /* :38 RR_DEL_Z      (a float upstream) */
+#define C21CM_RR_LNGAMMA_MIN (-10.0) /* :40                            */
+#define C21CM_RR_DLNGAMMA 0.1f       /* :41 RR_DEL_lnGamma (float)     */
 
 /* Per-call diagnostics returned by the grid-level ionisation driver. */
 typedef struct c21cm_ionize_report {

@@ -51,6 +51,8 @@ int oracle_test_filter(const float *input, int nx, int ny, int nz, double box_le
 int oracle_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
                         const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                         const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report);
+double oracle_splined_recombination_rate(const double *rr_y, const double *rr_c, double z_eff,
+                                         double gamma12_bg);
 float oracle_fully_ionized_temperature(float z_re, float z, float delta, float T_re);
 float oracle_partially_ionized_temperature(float T_HI, float res_xH, float T_re);
 double oracle_fgtrm_bias_fast(float growthf, float del_bias, float sig_small, float sig_large,

@@ -137,7 +137,7 @@ def fptr(a):
 
 
 def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion=None,
-                 need_nion=False):
+                 need_nion=False, prev_nrec=None, whalo_sfr=None):
     """Run the oracle's ComputeIonizedBox grid algorithm on numpy inputs.
 
     Returns a dict of output arrays plus the report struct.
@@ -150,14 +150,22 @@ def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion
     }
     if need_nion:
         out["unnormalised_nion"] = np.zeros(shape, np.float32)
+    if spec.recomb_model:  # wrapper/outputs.py:1526-1537
+        out["ionisation_rate_G12"] = np.zeros(shape, np.float32)
+        out["mean_free_path"] = np.zeros(shape, np.float32)
+        out["cumulative_recombinations"] = np.zeros(shape if spec.recomb_model == 2 else (1, 1, 1),
+                                                    np.float32)
     pf = S.PerturbedFieldStruct(density=fptr(density))
-    prev = S.IonizedBoxStruct(z_reion=fptr(prev_z_reion))
+    prev = S.IonizedBoxStruct(z_reion=fptr(prev_z_reion), cumulative_recombinations=fptr(prev_nrec))
     ts = S.TsBoxStruct(xray_ionised_fraction=fptr(xe), kinetic_temp_neutral=fptr(Tneutral))
-    hb = S.HaloBoxStruct(n_ion=fptr(n_ion))
+    hb = S.HaloBoxStruct(n_ion=fptr(n_ion), whalo_sfr=fptr(whalo_sfr))
     box = S.IonizedBoxStruct(
         neutral_fraction=fptr(out["neutral_fraction"]), z_reion=fptr(out["z_reion"]),
         kinetic_temperature=fptr(out["kinetic_temperature"]),
         unnormalised_nion=fptr(out.get("unnormalised_nion")),
+        ionisation_rate_G12=fptr(out.get("ionisation_rate_G12")),
+        mean_free_path=fptr(out.get("mean_free_path")),
+        cumulative_recombinations=fptr(out.get("cumulative_recombinations")),
     )
     rep = S.IonizeReport()
     st = load().oracle_ionize_grids(C.byref(spec), C.byref(pf), C.byref(prev), C.byref(ts),

@@ -17,9 +17,12 @@
  *      src/py21cmfast/src/hmf.c:1187-1241 (erfcc / FgtrM_bias_fast),
  *      src/py21cmfast/src/interpolation.c:123-131 (EvaluateRGTable1D_f).
  *
+ *   :583-663   N_rec / whalo_sfr grids of the recombination models (filtered like delta / n_ion)
+ *   :1084-1140 recombinations in the barrier, Gamma_12 and mean free path at first crossing
+ *   :1258-1340 set_recombination_rates (+ recombinations.c:64-92 splined_recombination_rate)
+ *
  * Not restated (returns C21CM_VALUE_ERROR): USE_MINI_HALOS with Eulerian
- * sources (2-D tables), recombination models (MHR00 splines),
- * IONISE_ENTIRE_SPHERE -- all non-default, SURVEY.md section 2a.
+ * sources (2-D tables), IONISE_ENTIRE_SPHERE -- non-default, SURVEY.md section 2a.
  */
 #include <math.h>
 #include <omp.h>
@@ -96,6 +99,33 @@ static double eval_table_f(double x, double x_min, double x_width, const float *
     return y_arr[idx] * (1 - interp_point) + y_arr[idx + 1] * (interp_point);
 }
 
+/* recombinations.c:64-92: row z_ct of the table, natural cubic spline in ln Gamma evaluated
+ * the way gsl_interp_cspline does (b and d from the c coefficients, Horner in delta) */
+double oracle_splined_recombination_rate(const double *rr_y, const double *rr_c, double z_eff,
+                                         double gamma12_bg) {
+    int z_ct = (int)(z_eff / C21CM_RR_DZ + 0.5);
+    double lnGamma = log(gamma12_bg);
+    if (z_ct < 0)
+        z_ct = 0;
+    else if (z_ct >= C21CM_RR_NZ)
+        z_ct = C21CM_RR_NZ - 1;
+    const double top = C21CM_RR_LNGAMMA_MIN + C21CM_RR_DLNGAMMA * (C21CM_RR_NGAMMA - 1);
+    if (lnGamma < C21CM_RR_LNGAMMA_MIN) return 0;
+    if (lnGamma >= top) lnGamma = top - FRACT_FLOAT_ERR;
+    const double *y = rr_y + (size_t)z_ct * C21CM_RR_NGAMMA, *c = rr_c + (size_t)z_ct * C21CM_RR_NGAMMA;
+#define RRX(g) (C21CM_RR_LNGAMMA_MIN + (g) * C21CM_RR_DLNGAMMA)
+    int i = (int)((lnGamma - C21CM_RR_LNGAMMA_MIN) / C21CM_RR_DLNGAMMA);
+    if (i > C21CM_RR_NGAMMA - 2) i = C21CM_RR_NGAMMA - 2;
+    while (i > 0 && lnGamma < RRX(i)) i--;
+    while (i < C21CM_RR_NGAMMA - 2 && lnGamma >= RRX(i + 1)) i++;
+    const double x_lo = RRX(i), x_hi = RRX(i + 1), dx = x_hi - x_lo, dy = y[i + 1] - y[i];
+#undef RRX
+    const double b = (dy / dx) - dx * (c[i + 1] + 2.0 * c[i]) / 3.0;
+    const double d = (c[i + 1] - c[i]) / (3.0 * dx);
+    const double delx = lnGamma - x_lo;
+    return y[i] + delx * (b + delx * (c[i] + delx * d));
+}
+
 /* IonisationBox.c:323-360 */
 static void prepare_box(const float *input, float *cbox, int nx, int ny, int nz, double factor,
                         double lo, double hi) {
@@ -134,7 +164,15 @@ static int copy_filter_c2r(const float *unfiltered, float *filtered, const c21cm
 int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                         const IonizedBox *prev, const TsBox *ts, const HaloBox *halos,
                         IonizedBox *box, c21cm_ionize_report *report) {
-    if (s->recomb_model != C21CM_RECOMB_NONE) return C21CM_VALUE_ERROR;
+    const int recomb = (s->recomb_model != C21CM_RECOMB_NONE);
+    const int inhomo = (s->recomb_model == C21CM_RECOMB_INHOMOGENEOUS);
+    const int filter_rec = recomb && !s->cell_recomb; /* IonisationBox.c:156-157 */
+    if (recomb && (!s->rr_y || !s->rr_c || !prev || !prev->cumulative_recombinations ||
+                   !box->cumulative_recombinations || !box->ionisation_rate_G12))
+        return C21CM_VALUE_ERROR;
+    if (filter_rec && !inhomo) return C21CM_VALUE_ERROR; /* inputs.py: homogeneous needs CELL_RECOMB */
+    if (recomb && s->fcoll_mode == C21CM_FCOLL_STARS_GRID && (!halos || !halos->whalo_sfr))
+        return C21CM_VALUE_ERROR;
     if (s->n_radii < 1 || s->n_radii > C21CM_MAX_RADII) return C21CM_VALUE_ERROR;
     const int nx = s->hii_dim, ny = s->hii_dim, nz = s->hii_dim_z;
     const size_t zpad = 2 * (size_t)(nz / 2 + 1);
@@ -161,9 +199,18 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
     float *delta_unf = (float *)malloc(sizeof(float) * npad);
     float *delta_fil = (float *)malloc(sizeof(float) * npad);
     float *stars_unf = NULL, *stars_fil = NULL, *xe_unf = NULL, *xe_fil = NULL;
+    float *sfr_unf = NULL, *sfr_fil = NULL, *nrec_unf = NULL, *nrec_fil = NULL;
     if (lagrangian) {
         stars_unf = (float *)malloc(sizeof(float) * npad);
         stars_fil = (float *)malloc(sizeof(float) * npad);
+        if (recomb) {
+            sfr_unf = (float *)malloc(sizeof(float) * npad);
+            sfr_fil = (float *)malloc(sizeof(float) * npad);
+        }
+    }
+    if (filter_rec) {
+        nrec_unf = (float *)malloc(sizeof(float) * npad);
+        nrec_fil = (float *)malloc(sizeof(float) * npad);
     }
     if (s->use_ts_fluct) {
         xe_unf = (float *)malloc(sizeof(float) * npad);
@@ -174,7 +221,10 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
     /* IonisationBox.c:1480-1513 */
     prepare_box(pf->density, delta_unf, nx, ny, nz, s->photoncons_adjustment_factor, -1., 1e6);
     if (lagrangian) prepare_box(halos->n_ion, stars_unf, nx, ny, nz, 1., 0., 1e20);
+    if (lagrangian && recomb) prepare_box(halos->whalo_sfr, sfr_unf, nx, ny, nz, 1., 0., 1e20);
     if (s->use_ts_fluct) prepare_box(ts->xray_ionised_fraction, xe_unf, nx, ny, nz, 1., 0, 1.);
+    if (filter_rec)
+        prepare_box(prev->cumulative_recombinations, nrec_unf, nx, ny, nz, 1., 0, 1e20);
 
     double last_mean = 0.;
     for (int R_ct = s->n_radii; R_ct--;) {
@@ -184,8 +234,12 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
         if (!status && lagrangian)
             status = copy_filter_c2r(stars_unf, stars_fil, s, R_ct, s->stars_filter,
                                      s->mfp_meandens);
+        if (!status && lagrangian && recomb)
+            status = copy_filter_c2r(sfr_unf, sfr_fil, s, R_ct, s->stars_filter, s->mfp_meandens);
         if (!status && s->use_ts_fluct)
             status = copy_filter_c2r(xe_unf, xe_fil, s, R_ct, s->hii_filter, 0.);
+        if (!status && filter_rec)
+            status = copy_filter_c2r(nrec_unf, nrec_fil, s, R_ct, s->hii_filter, 0.);
         if (status) break;
 
         double tab_min = 0., tab_width = 1.;
@@ -219,6 +273,7 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                 const size_t index_f = (size_t)l * zpad + k;
                 const size_t index_r = (size_t)l * nz + k;
                 delta_fil[index_f] = fmaxf(delta_fil[index_f], -1. + FRACT_FLOAT_ERR);
+                if (filter_rec) nrec_fil[index_f] = fmaxf(nrec_fil[index_f], 0.0);
                 if (s->use_ts_fluct) {
                     xe_fil[index_f] = fmaxf(xe_fil[index_f], 0.);
                     xe_fil[index_f] = fminf(xe_fil[index_f], 0.999);
@@ -226,6 +281,7 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                 double Splined_Fcoll;
                 if (lagrangian) {
                     stars_fil[index_f] = fmaxf(stars_fil[index_f], 0.0);
+                    if (recomb) sfr_fil[index_f] = fmaxf(sfr_fil[index_f], 0.0);
                     Splined_Fcoll = stars_fil[index_f];
                 } else {
                     double curr_dens = delta_fil[index_f];
@@ -280,9 +336,27 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                 if (s->mass_dep_zeta) {
                     if (curr_fcoll < s->f_limit_acg) curr_fcoll = s->f_limit_acg;
                 }
+                if (recomb) { /* :1084-1099 */
+                    if (s->cell_recomb)
+                        rec = prev->cumulative_recombinations[inhomo ? index_r : 0];
+                    else
+                        rec = nrec_fil[index_f];
+                    rec /= (1. + curr_dens);
+                }
                 xHII_from_xrays = s->use_ts_fluct ? xe_fil[index_f] : 0.;
 
                 if (curr_fcoll * s->ion_eff_factor > (1. - xHII_from_xrays) * (1.0 + rec)) {
+                    /* first crossing (largest R): Gamma_12 and the mean free path, :1124-1140 */
+                    if (recomb && (box->neutral_fraction[index_r] > FRACT_FLOAT_ERR)) {
+                        if (lagrangian)
+                            box->ionisation_rate_G12[index_r] =
+                                s->R[R_ct] * s->gamma_prefactor / (1 + curr_dens) * sfr_fil[index_f];
+                        else
+                            box->ionisation_rate_G12[index_r] =
+                                s->R[R_ct] * (s->gamma_prefactor * curr_fcoll);
+                        if (!s->minimize_memory && box->mean_free_path)
+                            box->mean_free_path[index_r] = s->R[R_ct];
+                    }
                     float prev_zre = (s->first_snapshot || !prev || !prev->z_reion)
                                          ? -1.0f
                                          : prev->z_reion[index_r];
@@ -346,6 +420,37 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
         for (long ct = 0; ct < (long)ntot; ct++) global_xH += box->neutral_fraction[ct];
         global_xH /= (float)ntot;
         if (isfinite(global_xH) == 0) status = C21CM_INFINITY_OR_NAN_ERROR;
+        if (!status && recomb) { /* set_recombination_rates: IonisationBox.c:1258-1340 */
+            if (!inhomo) {
+                double g12 = 0; /* :1600-1609 (a float reduction upstream) */
+#pragma omp parallel for schedule(static) reduction(+ : g12)
+                for (long ct = 0; ct < (long)ntot; ct++) g12 += box->ionisation_rate_G12[ct];
+                const float global_g12 = (float)(g12 / (float)ntot), global_xHI = (float)global_xH;
+                const double dNrec_global =
+                    oracle_splined_recombination_rate(s->rr_y, s->rr_c, s->stored_redshift,
+                                                      global_g12) *
+                    s->fabs_dtdz * s->dz * (1. - global_xHI);
+                const double cum = prev->cumulative_recombinations[0] + dNrec_global;
+                if (isfinite(cum) == 0) status = C21CM_INFINITY_OR_NAN_ERROR;
+                box->cumulative_recombinations[0] = cum;
+            } else {
+                int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+                for (long idx = 0; idx < (long)ntot; idx++) {
+                    const double curr_dens = 1.0 + (pf->density[idx]);
+                    double z_eff = pow(curr_dens, 1.0 / 3.0);
+                    z_eff *= (1 + s->stored_redshift);
+                    const double dNrec =
+                        oracle_splined_recombination_rate(s->rr_y, s->rr_c, z_eff - 1.,
+                                                          box->ionisation_rate_G12[idx]) *
+                        s->fabs_dtdz * s->dz * (1. - box->neutral_fraction[idx]);
+                    if (isfinite(dNrec) == 0) bad |= 1;
+                    box->cumulative_recombinations[idx] =
+                        prev->cumulative_recombinations[idx] + dNrec;
+                }
+                if (bad) status = C21CM_INFINITY_OR_NAN_ERROR;
+            }
+        }
         if (report) {
             report->global_xH = global_xH;
             /* IonisationBox.c:1623-1628 */
@@ -361,5 +466,9 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
     free(stars_fil);
     free(xe_unf);
     free(xe_fil);
+    free(sfr_unf);
+    free(sfr_fil);
+    free(nrec_unf);
+    free(nrec_fil);
     return status;
 }

@@ -398,6 +398,48 @@ def test_full_size_properties(api):
     assert rep2.global_xH < g1
 
 
+def test_config4_1024_cubed_properties_and_sharding(api):
+    """Config 4 (BASELINE.json: ComputeIonizedBox HII_DIM = 1024, R loop sharded): the whole
+    1024^3 x 40-radii workload -- 1024-point line passes on the x-blocked split layout, the
+    wave-level fused pass Z of 1024-point lines, 28 GB of workspace -- through size-independent
+    properties: (1) global_xH equals mean(neutral_fraction), (2) run-to-run bit reproducibility,
+    (3) the sharded path (two shard phases, uint8 max-reduce, finish phase; world = 2 emulated in
+    one process, reference: IonisationBox.c:1531-1588 is order independent) is BIT-identical to
+    the single pass (neutral fraction, z_reion, global x_HI)."""
+    import torch
+
+    n = 1024
+    spec = W.ionize_spec(n)
+    assert spec.n_radii == 40
+    density = W.density_field_torch(n)
+    n_ion = W.nion_from_density(density)
+    buf, box, rep = api.ionize_grids(spec, density, n_ion)
+    x1 = buf.neutral_fraction.clone()
+    z1 = buf.z_reion.clone()
+    g1 = rep.global_xH
+    assert g1 == pytest.approx(x1.double().mean().item(), rel=1e-6)
+    assert 0.1 < g1 < 0.9
+    buf.reset()
+    buf, box, rep = api.ionize_grids(spec, density, n_ion, buffers=buf)
+    assert torch.equal(x1, buf.neutral_fraction) and rep.global_xH == g1
+    world = 2
+    reduced = None
+    for rank in range(world):
+        fc = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
+        api.ionize_shard_radii(spec, rank, world, fc, density, n_ion, want_report=False)
+        reduced = fc if reduced is None else torch.maximum(reduced, fc)
+        del fc
+    buf.reset()
+    buf, _, rep2 = api.ionize_shard_finish(spec, reduced, density, n_ion, buffers=buf)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, buf.neutral_fraction)
+    assert torch.equal(z1, buf.z_reion)
+    assert rep2.global_xH == g1
+    del reduced, buf, x1, z1, density, n_ion
+    torch.cuda.empty_cache()
+    api.load().c21cm_release_device_cache()  # 28 GB of workspace slots back to the pool
+
+
 def test_bench_sharded_plumbing_on_one_rank():
     """bench.py --force-shard: the multi-GPU code path (shard phase without report, RCCL
     max-reduce of the uint8 mask, finish phase, x_HI broadcast) on a one-rank RCCL group; the

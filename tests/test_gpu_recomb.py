@@ -1,0 +1,108 @@
+"""GPU parity: ComputeIonizedBox with a recombination model on the MI355X vs the CPU oracle
+(reference: IonisationBox.c:583-663 N_rec / whalo_sfr grids, :1084-1140 barrier, Gamma_12, mean
+free path, :1258-1340 set_recombination_rates; recombinations.c:64-92 the splined rate).
+
+Tolerances as in test_gpu_ionize.py for x_HI / z_reion / T_k; on cells whose flag agrees, Gamma_12
+rtol 1e-4 (it is R * prefactor * a filtered grid value), the mean free path exact (it is one of the
+radii), N_rec rtol 2e-4 + atol 1e-7 (a spline of ln Gamma_12 times 1 - x_HI).
+"""
+
+import importlib
+
+import numpy as np
+import pytest
+
+from recomb_helpers import inputs, recomb_spec
+from test_gpu_ionize import compare
+
+pytestmark = pytest.mark.gpu
+W = importlib.import_module("21cmfast_amd.workloads")
+
+
+@pytest.fixture(scope="module")
+def api(gpu_lib):
+    return importlib.import_module("21cmfast_amd.grid_api")
+
+
+def run(api, spec, d, device, lagrangian, ts):
+    kw = dict(prev_nrec=d["prev_nrec"], prev_z_reion=d["prev_z_reion"])
+    if lagrangian:
+        kw.update(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"])
+    if ts:
+        kw.update(xe=d["xe"], Tneutral=d["Tneutral"])
+    dens = d["density"]
+    if device:
+        import torch
+
+        dens = torch.from_numpy(dens).cuda()
+        kw = {k: torch.from_numpy(v).cuda() for k, v in kw.items()}
+    buf, box, rep = api.ionize_grids(spec, dens, **kw)
+    names = ("neutral_fraction", "z_reion", "kinetic_temperature", "ionisation_rate_G12",
+             "mean_free_path", "cumulative_recombinations", "unnormalised_nion")
+    out = {}
+    for k in names:
+        a = getattr(buf, k)
+        if a is not None:
+            out[k] = a.cpu().numpy() if device else a
+    out["report"] = rep
+    return out
+
+
+CASES = [
+    # n or shape, model, cell_recomb, lagrangian, ts, device
+    (32, 2, 1, True, False, False),
+    (64, 2, 0, True, False, True),     # native passes, N_rec and whalo_sfr grids filtered
+    (40, 2, 0, False, False, False),   # rocFFT path, Eulerian closed form, N_rec filtered
+    (64, 2, 1, False, False, True),
+    ((32, 32, 64), 2, 0, True, True, True),   # + x_e grid of a spin-temperature run
+    (32, 1, 1, True, False, True),     # homogeneous: one number
+    (35, 1, 1, False, False, False),
+]
+
+
+@pytest.mark.parametrize("n,model,cell,lagrangian,ts,device", CASES)
+def test_recombination_models_match_oracle(api, oracle, n, model, cell, lagrangian, ts, device):
+    shape = (n, n, n) if isinstance(n, int) else n
+    spec = recomb_spec(shape[0], model=model, cell_recomb=cell, lagrangian=lagrangian,
+                       hii_dim_z=shape[2], ts=int(ts))
+    d = inputs(shape, seed=shape[0] + 3 * model + cell, ts=ts)
+    if model == 1:
+        d["prev_nrec"] = np.full((1, 1, 1), 0.25, np.float32)
+    okw = dict(prev_nrec=d["prev_nrec"], prev_z_reion=d["prev_z_reion"])
+    if lagrangian:
+        okw.update(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"])
+    else:
+        okw.update(need_nion=True)
+    if ts:
+        okw.update(xe=d["xe"], Tneutral=d["Tneutral"])
+    ref = oracle.ionize_grids(spec, d["density"], **okw)
+    got = run(api, spec, d, device, lagrangian, ts)
+    compare(got, ref, spec)
+    ion_g, ion_r = got["neutral_fraction"] == 0, ref["neutral_fraction"] == 0
+    assert 0.03 < ion_r.mean() < 0.97
+    same = ion_g == ion_r
+    np.testing.assert_allclose(got["ionisation_rate_G12"][same], ref["ionisation_rate_G12"][same],
+                               rtol=1e-4, atol=1e-9)
+    np.testing.assert_array_equal(got["mean_free_path"][same], ref["mean_free_path"][same])
+    assert (ref["ionisation_rate_G12"] > 0).any()
+    if model == 2:
+        np.testing.assert_allclose(got["cumulative_recombinations"][same],
+                                   ref["cumulative_recombinations"][same], rtol=2e-4, atol=1e-7)
+        assert (ref["cumulative_recombinations"] > d["prev_nrec"]).any()
+    else:
+        assert got["cumulative_recombinations"].shape == (1, 1, 1)
+        assert float(got["cumulative_recombinations"].ravel()[0]) == pytest.approx(
+            float(ref["cumulative_recombinations"].ravel()[0]), rel=1e-5)
+
+
+def test_recombination_requests_are_validated(api):
+    spec = recomb_spec(16, model=2)
+    d = inputs((16, 16, 16))
+    with pytest.raises(Exception, match="whalo_sfr"):
+        api.ionize_grids(spec, d["density"], d["n_ion"], prev_nrec=d["prev_nrec"])
+    with pytest.raises(Exception, match="cumulative_recombinations"):
+        api.ionize_grids(spec, d["density"], d["n_ion"], whalo_sfr=d["whalo_sfr"])
+    bad = recomb_spec(16, model=1, cell_recomb=0)
+    with pytest.raises(Exception, match="CELL_RECOMB"):
+        api.ionize_grids(bad, d["density"], d["n_ion"], whalo_sfr=d["whalo_sfr"],
+                         prev_nrec=np.zeros((1, 1, 1), np.float32))
