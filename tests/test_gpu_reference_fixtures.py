@@ -185,3 +185,58 @@ def test_entry_points_reproduce_reference_coeval_ionization(gpu_lib, api, tmp_pa
     # the lightcone's last node is this redshift: its global x_HI is the box mean
     assert got["neutral_fraction"].mean() == pytest.approx(
         f["lightcone/global_neutral_fraction"][-1], rel=2e-6)
+
+
+@pytest.mark.parametrize("name,model,cell", [("inhomo", 2, False), ("homo", 1, True)])
+def test_entry_points_reproduce_reference_recombination_chain(gpu_lib, api, tmp_path, name, model,
+                                                              cell, monkeypatch):
+    """run_coeval's evolution for a recombination model through the reference's entry points:
+    18 node redshifts from Z_HEAT_MAX down to 18 (step 1.04), every ComputeIonizedBox receiving
+    the previous snapshot's box (z_reion, cumulative_recombinations).  Pins Gamma_12 at first
+    crossing, the mean free path bookkeeping and the MHR00 recombination-rate tables (init_MHR)
+    against the reference's own run."""
+    from test_gpu_abi import Session
+    from test_reference_fixtures_ionize import check_recomb_fixture, node_redshifts
+
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    lib = gpu_lib
+    ses = Session(lib, tmp_path, HII_DIM=RP.HII_DIM, DIM=RP.DIM, BOX_LEN=RP.BOX_LEN, N_THREADS=2,
+                  ZPRIME_STEP_FACTOR=1.04, SOURCE_MODEL=1, HII_FILTER=0, USE_EXP_FILTER=False,
+                  CELL_RECOMB=cell, R_BUBBLE_MAX=50.0, RECOMB_MODEL=model,
+                  USE_UPPER_STELLAR_TURNOVER=False)
+    lib.init_MHR.restype = None
+    lib.init_MHR()
+    spec = S.IcsSpec(dim=RP.DIM, dim_z=RP.DIM, hii_dim=RP.HII_DIM, hii_dim_z=RP.HII_DIM,
+                     perturb_algorithm=2)
+    ics = api.new_ics_arrays(spec)
+    icss = api.ics_struct(ics)
+    assert lib.ComputeInitialConditions(RP.SEED, C.byref(icss)) == 0, lib.c21cm_last_error()
+    shape = (RP.HII_DIM,) * 3
+    rshape = shape if model == 2 else (1, 1, 1)
+    names = ("neutral_fraction", "z_reion", "kinetic_temperature", "unnormalised_nion",
+             "ionisation_rate_G12", "mean_free_path", "cumulative_recombinations")
+
+    def new_box():
+        arr = {k: np.zeros(rshape if k == "cumulative_recombinations" else shape, np.float32)
+               for k in names}
+        arr["neutral_fraction"][...] = 1.0
+        return arr, S.IonizedBoxStruct(**{k: fptr(v) for k, v in arr.items()})
+
+    prev_arr, prev = new_box()  # the zero-filled "initial" previous box (single_field.py)
+    prev_z, ts, hb = 0.0, S.TsBoxStruct(), S.HaloBoxStruct()
+    for z in node_redshifts():
+        dens, vz = np.zeros(shape, np.float32), np.zeros(shape, np.float32)
+        pf = S.PerturbedFieldStruct(density=fptr(dens), velocity_z=fptr(vz))
+        assert lib.ComputePerturbedField(z, C.byref(icss), C.byref(pf)) == 0
+        arr, box = new_box()
+        st = lib.ComputeIonizedBox(z, prev_z, C.byref(pf), C.byref(pf), C.byref(prev), C.byref(ts),
+                                   C.byref(hb), C.byref(icss), C.byref(box))
+        assert st == 0, lib.c21cm_last_error()
+        prev_arr, prev, prev_z = arr, box, z
+    del ses
+    check_recomb_fixture(name, prev_arr)
+    assert prev_arr["neutral_fraction"].mean() == pytest.approx(
+        RP.fixture("power_spectra", name)["lightcone/global_neutral_fraction"][-1], rel=2e-6)
+    # the mean free path of a crossing cell is one of the filter radii
+    mfp = prev_arr["mean_free_path"]
+    assert (mfp > 0).sum() == (prev_arr["ionisation_rate_G12"] > 0).sum() >= 1

@@ -375,3 +375,75 @@ def test_exported_hyper_2F3_matches_mpmath_and_oracle(pkg, oracle, x_em):
     np.testing.assert_allclose(want, got, rtol=0.0, atol=2e-3)
     ora = np.array([olib.oracle_hyper_2F3(float(x), alpha, beta) for x in kR])
     np.testing.assert_allclose(got, ora, rtol=1e-12, atol=1e-15)
+
+
+# ---- recombination-rate tables (init_MHR) --------------------------------------------------------
+def test_mhr_recombination_rate_against_scipy(host, pkg):
+    """recombination_rate(z, Gamma_12, T4 = 1, case B) (reference: recombinations.c:143-215,
+    thermochem.c:78-110) re-evaluated with scipy from an independent transcription: the MHR00
+    density PDF normalised to unit integral, Rahmati+ 2013 self-shielding, the equilibrium
+    neutral fraction -- and the table behind splined_recombination_rate built from it."""
+    f64 = C.c_double
+    for nm, at in (("c21_recombination_rate", [f64, f64]),
+                   ("c21_recombination_rate_adaptive", [f64, f64]),
+                   ("c21_splined_recombination_rate", [f64, f64])):
+        getattr(host, nm).restype = f64
+        getattr(host, nm).argtypes = at
+    host.init_MHR.restype = None
+    host.init_MHR()
+    cp = host._keep["cp"]
+    h, omb, yhe = float(cp.hlittle), float(cp.OMb), float(cp.Y_He)
+    Ho = h * 3.2407e-18
+    No = 3.0 * Ho * Ho / (8.0 * math.pi * 6.6743e-8) * omb * (1 - yhe) / 1.67262192369e-24
+    C_tab = [0.558, 0.599, 0.611, 0.769, 0.868, 0.930, 0.964, 0.983, 0.993, 0.998, 0.999, 1.00]
+    B_tab = [-2.23, -2.35, -2.48, -2.49, -2.50]
+    C_sp = interpolate.CubicSpline(np.arange(2.0, 14.0), C_tab, bc_type="natural")
+    B_sp = interpolate.CubicSpline(np.arange(2.0, 7.0), B_tab, bc_type="natural")
+
+    def C_MHR(z):
+        return 1.0 if z >= 13 else (0.558 if z <= 2 else float(C_sp(z)))
+
+    def beta_MHR(z):
+        return -2.50 if z >= 6 else (-2.23 if z <= 2 else float(B_sp(z)))
+
+    def pdf_shape(d, z):
+        sig = 2.0 * 7.61 / (3.0 * (1.0 + z))
+        return math.exp(-((d ** (-2.0 / 3.0) - C_MHR(z)) ** 2) / (2 * sig * sig)) * d ** beta_MHR(z)
+
+    zs = np.arange(2.0, 62.0)
+    A_knots = [1.0 / integrate.quad(lambda x: pdf_shape(math.exp(x), z) * math.exp(x), -12, 58,
+                                    limit=400, epsrel=1e-10)[0] for z in zs]
+    A_sp = interpolate.CubicSpline(zs, A_knots, bc_type="natural")
+    corr_He = 1.0 / (4.0 / yhe - 3)
+    alpha_B = 2.59e-13
+
+    def rate(z, gamma_bg):
+        def f(lnD):
+            d = math.exp(lnD)
+            D_ss = 26.7 * ((1 + z) / 10.0) ** -3 * gamma_bg ** (2.0 / 3.0)
+            gam = gamma_bg * (0.98 * (1 + (d / D_ss) ** 1.64) ** -2.28
+                              + 0.02 * (1 + d / D_ss) ** -0.84) * 1e-12
+            nH = No * (1 + z) ** 3 * d
+            chi = (1 + corr_He) * nH * alpha_B / gam
+            if chi >= 1e-5:
+                b = -2 - gam / (nH * (1 + corr_He) * alpha_B)
+                chi = (-b - math.sqrt(b * b - 4)) / 2.0
+            x_e = 1.0 - chi
+            return 1e15 * nH * float(A_sp(z)) * pdf_shape(d, z) * alpha_B * x_e * x_e * d * d
+        return integrate.quad(f, math.log(0.01), math.log(200), limit=400, epsrel=1e-10)[0]
+
+    for z, g in ((6.0, 0.3), (8.0, 0.05), (8.0, 2.0), (12.4, 0.01), (20.0, 1e-3), (3.2, 1.0)):
+        want = rate(z, g)
+        assert host.c21_recombination_rate(z, g) == pytest.approx(want, rel=2e-6)
+        assert host.c21_recombination_rate_adaptive(z, g) == pytest.approx(want, rel=2e-6)
+    # the table is sampled at z_ct * 0.2f and float Gamma values: on a knot the spline returns it
+    z_knot = float(np.float32(41) * np.float32(0.2))
+    g_knot = float(np.float32(math.exp(-10.0 + float(np.float32(70) * np.float32(0.1)))))
+    assert host.c21_splined_recombination_rate(z_knot, g_knot) == pytest.approx(
+        rate(z_knot, g_knot), rel=2e-6)
+    # between knots: within the spline's own error of the integral (smooth in ln Gamma)
+    assert host.c21_splined_recombination_rate(8.2, 0.123) == pytest.approx(rate(8.2, 0.123),
+                                                                           rel=1e-4)
+    # more photons -> more of the gas ionised -> more recombinations; denser universe -> more
+    assert host.c21_recombination_rate(8.0, 1.0) > host.c21_recombination_rate(8.0, 0.1)
+    assert host.c21_recombination_rate(10.0, 0.1) > host.c21_recombination_rate(7.0, 0.1)

@@ -175,3 +175,90 @@ def test_oracle_halobox_chain_reproduces_reference_fixture(oracle, pkg, fields, 
     out = oracle.ionize_grids(spec, pf["density"], hb["n_ion"])
     check_ionization("fixed_halogrids", pf["density"], out["neutral_fraction"], out["z_reion"],
                      oracle, ses.cp)
+
+
+# ---- recombination models: the evolved chain of the "inhomo" / "homo" fixtures -------------------
+def node_redshifts(z_min=18.0, z_max=35.0, step=1.04):
+    """get_logspaced_redshifts (reference: wrapper/inputs.py:1774-1789), descending."""
+    z = 10 ** np.arange(np.log10(1 + z_min), np.log10((1 + z_max) * step), np.log10(step)) - 1
+    return [float(np.float32(v)) for v in z[::-1]]  # ComputeIonizedBox takes float redshifts
+
+
+def recomb_chain_oracle(oracle, pkg, ics, tmp_path, model, cell_recomb):
+    """run_coeval's loop over the node redshifts (Z_HEAT_MAX -> 18, step 1.04) for E-INTEGRAL with
+    a recombination model: every snapshot receives the previous one's z_reion and
+    cumulative_recombinations (reference: IonisationBox.c:1344-1649 per snapshot;
+    produce_integration_test_data.py:142-156 "homo" / "inhomo")."""
+    from test_gpu_abi import Session
+    from test_host_scalars import ScalingConsts
+
+    global Z
+    lib = pkg.load()
+    ses = Session(lib, tmp_path, HII_DIM=RP.HII_DIM, DIM=RP.DIM, BOX_LEN=RP.BOX_LEN, N_THREADS=2,
+                  ZPRIME_STEP_FACTOR=1.04, SOURCE_MODEL=1, HII_FILTER=0, USE_EXP_FILTER=False,
+                  CELL_RECOMB=bool(cell_recomb), R_BUBBLE_MAX=50.0, RECOMB_MODEL=model,
+                  USE_UPPER_STELLAR_TURNOVER=False)
+    dp = C.POINTER(C.c_double)
+    lib.c21_rr_tables.argtypes = [C.POINTER(dp), C.POINTER(dp)]
+    rr_y, rr_c = dp(), dp()
+    assert lib.c21_rr_tables(C.byref(rr_y), C.byref(rr_c)) == 0
+    lib.c21_dtdz.restype = C.c_double
+    lib.c21_dtdz.argtypes = [C.c_float]
+    lib.c21_nb0.restype = C.c_double
+    n = RP.HII_DIM
+    prev_nrec = np.zeros((n, n, n) if model == 2 else (1, 1, 1), np.float32)
+    prev_zre = np.zeros((n, n, n), np.float32)
+    prev_z, out, pf = 0.0, None, None
+    saved_Z = Z
+    try:
+        for z in node_redshifts():
+            Z = z  # eulerian_spec() reads the module-level redshift
+            spec = eulerian_spec(ses, lib, oracle, 1)
+            if spec.mean_f_coll * spec.ion_eff_factor < 1e-5:  # IonisationBox.c:1472-1475
+                prev_z = z
+                prev_zre = np.full((n, n, n), -1.0, np.float32)
+                continue
+            pf = oracle.perturb_grids(RP.perturb_spec(z), ics)
+            sc = ScalingConsts()
+            assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+            spec.recomb_model, spec.cell_recomb = model, cell_recomb
+            spec.rr_y, spec.rr_c = rr_y, rr_c
+            spec.first_snapshot = int(prev_z < 1)
+            spec.dz = (1 + z) * (1.04 - 1) if prev_z < 1 else prev_z - z  # :138-141
+            spec.fabs_dtdz = abs(lib.c21_dtdz(z)) / 1e15
+            spec.gamma_prefactor = ((1 + z) ** 2 * 3.08567758e24 * 6.3e-18 * ses.ap.ALPHA_UVB
+                                    / (ses.ap.ALPHA_UVB + 2.75) * lib.c21_nb0()
+                                    * spec.ion_eff_factor / 1e-12 / (sc.t_h * sc.t_star))
+            out = oracle.ionize_grids(spec, pf["density"], need_nion=True, prev_nrec=prev_nrec,
+                                      prev_z_reion=prev_zre)
+            prev_nrec, prev_zre, prev_z = out["cumulative_recombinations"], out["z_reion"], z
+    finally:
+        Z = saved_Z
+    return out, pf, ses
+
+
+def check_recomb_fixture(name, out):
+    f = RP.fixture("power_spectra", name)
+    n = RP.HII_DIM
+    p_z, _ = RP.get_power(out["z_reion"], RP.BOX_LEN)
+    np.testing.assert_allclose(p_z, f["coeval/power_z_reion"], rtol=1e-5, atol=1e-9)
+    p_x, _ = RP.get_power(out["neutral_fraction"], RP.BOX_LEN)
+    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=2e-3)
+    # Gamma_12 at the first crossing: R * gamma_prefactor * f_coll of the crossing cell(s)
+    p_g, _ = RP.get_power(out["ionisation_rate_G12"], RP.BOX_LEN)
+    np.testing.assert_allclose(p_g, f["coeval/power_ionisation_rate_G12"], rtol=2e-3)
+    assert (out["ionisation_rate_G12"] > 0).sum() >= 1
+    if f"coeval/power_cumulative_recombinations" in f:
+        # N_rec through the MHR00 rate table: the reference integrates it with GSL QAG at 1e-2,
+        # this backend to 1e-7 -- they agree to 2e-4 in power here
+        nrec = out["cumulative_recombinations"]
+        p_n, _ = RP.get_power(np.broadcast_to(nrec, (n, n, n)), RP.BOX_LEN)
+        np.testing.assert_allclose(p_n, f["coeval/power_cumulative_recombinations"], rtol=2e-3)
+
+
+@pytest.mark.parametrize("name,model,cell", [("inhomo", 2, 0), ("homo", 1, 1)])
+def test_oracle_recombination_chain_reproduces_reference_fixture(oracle, pkg, fields, tmp_path,
+                                                                 name, model, cell):
+    ics, _ = fields
+    out, _, _ = recomb_chain_oracle(oracle, pkg, ics, tmp_path, model, cell)
+    check_recomb_fixture(name, out)
