@@ -243,6 +243,12 @@ int c21hip_velocity_kspace(const float *saved_c, float *grid_c, int nx, int ny, 
 
 /* ---- ics_kernels.hip ---- */
 /* delta_k = sqrt(V P/2)(a + ib) with Hermitian planes: InitialConditions.c:26-139 */
+/* compute_relative_velocities (InitialConditions.c:141-238): k-space operator of one component,
+ * and the subsampled sum of squares (sqrt / VOLUME on the last component) into lowres_vcb */
+int c21hip_vcb_op(const float *in_c, float *out_c, int nx, int ny, int nz, double box_len,
+                  double box_len_z, int axis, const double *h_by_m_dev, void *stream);
+int c21hip_vcb_accumulate(const float *src_padded, const int hi_dim[3], float *dst,
+                          const int lo_dim[3], int first, int last, float volume, void *stream);
 int c21hip_sample_modes(float *cbox, int nx, int ny, int nz, const double *pk_by_m_dev,
                         float volume, unsigned long long seed, const double *deviates_dev,
                         void *stream);

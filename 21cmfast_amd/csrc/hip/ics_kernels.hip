@@ -175,6 +175,58 @@ kspace_op_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int nx
 }
 
 
+// compute_relative_velocities (InitialConditions.c:141-238), the k-space part of component `axis`:
+//   out = in * i * k_axis / |k| * sqrt(P_vcb / P) * c_kms,  DC := 0
+// with h(|k|) = sqrt(P_vcb / P) c_kms / |k| tabulated per |k|^2 index m (cubic grids).
+__global__ void __launch_bounds__(kBlock)
+vcb_op_kernel(const float2 *__restrict__ in, float2 *__restrict__ out, int nx, int ny, int nz,
+              double len_x, double len_y, double len_z, int axis,
+              const double *__restrict__ h_by_m) {
+    const int nzc = nz / 2 + 1, mx = nx / 2, my = ny / 2;
+    const size_t total = (size_t)nx * ny * nzc;
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const size_t line = t / (size_t)nzc;
+        const int n_z = (int)(t - line * (size_t)nzc);
+        const int n_x = (int)(line / (size_t)ny);
+        const int n_y = (int)(line - (size_t)n_x * ny);
+        const double kvec[3] = {index_to_k(n_x, len_x, nx), index_to_k(n_y, len_y, ny),
+                                index_to_k(n_z, len_z, nz)};
+        const int ax = n_x <= mx ? n_x : nx - n_x, ay = n_y <= my ? n_y : ny - n_y;
+        const long m = (long)ax * ax + (long)ay * ay + (long)n_z * n_z;
+        float2 o = make_float2(0.f, 0.f);
+        if (t != 0) {
+            const double f = kvec[axis] * h_by_m[m];
+            const float2 v = in[t];
+            o.x = (float)(-((double)v.y * f));
+            o.y = (float)((double)v.x * f);
+        }
+        out[t] = o;
+    }
+}
+
+// :203-222 the subsampled square of one component added to lowres_vcb (first = 1: stored);
+// last = 1 also finishes with sqrt(.) / VOLUME (:225-232)
+__global__ void __launch_bounds__(kBlock)
+vcb_accumulate_kernel(const float *__restrict__ src_padded, float *__restrict__ dst, int hx, int hy,
+                      int hz, int lx, int ly, int lz, int first, int last, float volume) {
+    const size_t total = (size_t)lx * ly * lz, plane = (size_t)ly * lz;
+    const double ratio = (double)hx / (double)lx;
+    const size_t zpad = 2 * (size_t)(hz / 2 + 1);
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const int i = (int)(t / plane);
+        const size_t rem = t - (size_t)i * plane;
+        const int j = (int)(rem / (size_t)lz), k = (int)(rem - (size_t)j * lz);
+        const int hi = (int)((double)i * ratio + 0.5), hj = (int)((double)j * ratio + 0.5),
+                  hk = (int)((double)k * ratio + 0.5);
+        const double v = (double)src_padded[(size_t)hk + zpad * ((size_t)hj + (size_t)hy * hi)];
+        float acc = first ? (float)(v * v) : (float)((double)dst[t] + v * v);
+        if (last) acc = (float)(sqrt((double)acc) / (double)volume);
+        dst[t] = acc;
+    }
+}
+
 // ------------------------------------------------------------------ split-layout IC pipeline
 // The k-space side of ComputeInitialConditions on the layout of the native transform
 // (fft_native.hip; plain form, nx <= 512): main[(x ny + y) H + k_z] for k_z < H = nz/2 and the
@@ -356,6 +408,28 @@ extern "C" int c21hip_sample_modes(float *cbox, int nx, int ny, int nz, const do
     hipLaunchKernelGGL(sample_modes_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
                        (hipStream_t)stream, (float2 *)cbox, nx, ny, nz, pk_by_m_dev, volume,
                        (uint64_t)seed, (const double2 *)deviates_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_vcb_op(const float *in_c, float *out_c, int nx, int ny, int nz,
+                             double box_len, double box_len_z, int axis, const double *h_by_m_dev,
+                             void *stream) {
+    const size_t total = (size_t)nx * ny * (nz / 2 + 1);
+    hipLaunchKernelGGL(vcb_op_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const float2 *)in_c, (float2 *)out_c, nx, ny, nz, box_len, box_len,
+                       box_len_z, axis, h_by_m_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_vcb_accumulate(const float *src_padded, const int hi_dim[3], float *dst,
+                                     const int lo_dim[3], int first, int last, float volume,
+                                     void *stream) {
+    const size_t total = (size_t)lo_dim[0] * lo_dim[1] * lo_dim[2];
+    hipLaunchKernelGGL(vcb_accumulate_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
+                       (hipStream_t)stream, src_padded, dst, hi_dim[0], hi_dim[1], hi_dim[2],
+                       lo_dim[0], lo_dim[1], lo_dim[2], first, last, volume);
     LAUNCH_CHECK();
     return 0;
 }

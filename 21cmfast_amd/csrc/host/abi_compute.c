@@ -48,11 +48,13 @@ static int require_globals(const char *who, int need_astro) {
         c21hip_set_error("%s: Broadcast_struct_global_all has not been called", who);
         return C21CM_VALUE_ERROR;
     }
-    if (matter_options_global->POWER_SPECTRUM == C21CM_PS_CLASS) {
-        c21hip_set_error("%s: CLASS transfer tables are not supported by this backend", who);
-        return C21CM_VALUE_ERROR;
-    }
     return 0;
+}
+
+/* init_ps on demand; fails (ValueError, message set) when the CLASS tables are unusable */
+static int ensure_ps(void) {
+    if (!c21_ps_ready()) init_ps();
+    return c21_ps_ready() ? 0 : C21CM_VALUE_ERROR;
 }
 
 static void geometry(int *dim, int *dim_z, int *hii, int *hii_z, double *len, double *len_z) {
@@ -97,11 +99,17 @@ int ComputeInitialConditions(unsigned long long random_seed, InitialConditions *
     }
     const SimulationOptions *so = simulation_options_global;
     const MatterOptions *mo = matter_options_global;
-    if (mo->V_CB_MODEL == C21CM_VCB_FLUCTS) {
-        c21hip_set_error("ComputeInitialConditions: V_CB_MODEL=FLUCTS needs CLASS tables");
+    const int want_vcb = (mo->V_CB_MODEL == C21CM_VCB_FLUCTS);
+    if (want_vcb && mo->POWER_SPECTRUM != C21CM_PS_CLASS) {
+        c21hip_set_error("ComputeInitialConditions: V_CB_MODEL=FLUCTS needs POWER_SPECTRUM=CLASS "
+                         "(the relative-velocity transfer function)");
         return C21CM_VALUE_ERROR;
     }
-    if (!c21_ps_ready()) init_ps();
+    if (want_vcb && !boxes->lowres_vcb) {
+        c21hip_set_error("ComputeInitialConditions: V_CB_MODEL=FLUCTS needs lowres_vcb");
+        return C21CM_VALUE_ERROR;
+    }
+    if ((st = ensure_ps())) return st;
     c21cm_ics_spec s;
     memset(&s, 0, sizeof(s));
     geometry(&s.dim, &s.dim_z, &s.hii_dim, &s.hii_dim_z, &s.box_len, &s.box_len_z);
@@ -154,8 +162,31 @@ int ComputeInitialConditions(unsigned long long random_seed, InitialConditions *
         for (int m = 0; m < s.n_m; m++) pk[m] = power_in_k(dk * sqrt((double)m));
         s.pk_by_m = pk;
     }
+    double *vcb = NULL;
+    if (want_vcb) { /* compute_relative_velocities, InitialConditions.c:141-238 */
+        if (s.dim != s.dim_z) {
+            free(pk);
+            c21hip_set_error("ComputeInitialConditions: V_CB_MODEL=FLUCTS needs NON_CUBIC_FACTOR = 1");
+            return C21CM_VALUE_ERROR;
+        }
+        const int n_m = 3 * (s.dim / 2) * (s.dim / 2) + 1;
+        vcb = (double *)malloc(sizeof(double) * (size_t)n_m);
+        if (!vcb) {
+            free(pk);
+            return C21CM_MEMORY_ALLOC_ERROR;
+        }
+        const double dk = 2.0 * M_PI / s.box_len;
+        vcb[0] = 0.;
+        for (int m = 1; m < n_m; m++) { /* sqrt(P_vcb / P) c / |k| (:186-187; c in km/s) */
+            const double k = dk * sqrt((double)m);
+            vcb[m] = sqrt(power_in_vcb(k) / power_in_k(k)) * 2.99792458e5 / k;
+        }
+        s.vcb_by_m = vcb;
+        s.n_m = n_m;
+    }
     st = c21cm_ics_grids(&s, boxes, NULL);
     free(pk);
+    free(vcb);
     return st;
 }
 
@@ -249,7 +280,7 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         c21hip_set_error("ComputeIonizedBox: %s is not implemented in this backend yet", unsupported);
         return C21CM_VALUE_ERROR;
     }
-    if (!c21_ps_ready()) init_ps();
+    if ((st = ensure_ps())) return st;
 
     c21cm_ionize_spec *s = (c21cm_ionize_spec *)calloc(1, sizeof(*s));
     if (!s) return C21CM_MEMORY_ALLOC_ERROR;
@@ -509,7 +540,7 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
         c21hip_set_error("ComputeHaloBox: %s is not implemented in this backend yet", unsupported);
         return C21CM_VALUE_ERROR;
     }
-    if (!c21_ps_ready()) init_ps();
+    if ((st = ensure_ps())) return st;
 
     c21cm_halobox_spec s;
     memset(&s, 0, sizeof(s));

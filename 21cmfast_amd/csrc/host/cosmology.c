@@ -260,12 +260,133 @@ static double transfer_other(double k, int which) {
                       (1.0 / pow(gamma, 2)) * k * k);
 }
 
+/* POWER_SPECTRUM = CLASS: the tabulated z = 0 transfer functions of CosmoTables (density, and
+ * the DM-baryon relative velocity at kinematic decoupling), natural cubic splines in k like
+ * gsl_interp_cspline; above the last tabulated k the density one continues with the EH shape
+ * and the velocity one with a log-log line through the last two points: cosmology.c:130-225 */
+static struct {
+    int n_d, n_v; /* 0: not set up */
+    const double *k, *Td, *Tv;
+    double *cd, *cv; /* spline c coefficients (y'' / 2) */
+    double eh_ratio_at_kmax;
+} cls;
+
+static void class_spline_c(int n, const double *x, const double *y, double *c) {
+    double *g = (double *)malloc(sizeof(double) * (size_t)n), *dg = (double *)malloc(sizeof(double) * (size_t)n),
+           *of = (double *)malloc(sizeof(double) * (size_t)n);
+    c[0] = c[n - 1] = 0.;
+    const int m = n - 2;
+    for (int i = 0; i < m; i++) {
+        const double h0 = x[i + 1] - x[i], h1 = x[i + 2] - x[i + 1];
+        of[i] = h1;
+        dg[i] = 2.0 * (h1 + h0);
+        g[i] = 3.0 * ((y[i + 2] - y[i + 1]) / h1 - (y[i + 1] - y[i]) / h0);
+    }
+    for (int i = 1; i < m; i++) {
+        const double w = of[i - 1] / dg[i - 1];
+        dg[i] -= w * of[i - 1];
+        g[i] -= w * g[i - 1];
+    }
+    for (int i = m - 1; i >= 0; i--) c[i + 1] = (g[i] - (i + 1 < m ? of[i] * c[i + 2] : 0.)) / dg[i];
+    free(g);
+    free(dg);
+    free(of);
+}
+
+static double class_spline_eval(int n, const double *x, const double *y, const double *c, double v) {
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (hi + lo) >> 1;
+        if (x[mid] > v)
+            hi = mid;
+        else
+            lo = mid;
+    }
+    const double dx = x[lo + 1] - x[lo], dy = y[lo + 1] - y[lo];
+    const double b = dy / dx - dx * (c[lo + 1] + 2.0 * c[lo]) / 3.0;
+    const double d = (c[lo + 1] - c[lo]) / (3.0 * dx);
+    const double t = v - x[lo];
+    return y[lo] + t * (b + t * (c[lo] + t * d));
+}
+
+static void class_free(void) {
+    free(cls.cd);
+    free(cls.cv);
+    memset(&cls, 0, sizeof(cls));
+}
+
+static int class_setup(void) { /* transfer_function_CLASS(., 0, .) */
+    class_free();
+    const Table1D *td = cosmo_tables_global ? cosmo_tables_global->transfer_density : NULL;
+    if (!td || td->size < 3 || !td->x_values || !td->y_values) {
+        c21hip_set_error("POWER_SPECTRUM = CLASS needs CosmoTables.transfer_density (>= 3 points)");
+        return C21CM_VALUE_ERROR;
+    }
+    cls.n_d = td->size;
+    cls.k = td->x_values;
+    cls.Td = td->y_values;
+    cls.cd = (double *)malloc(sizeof(double) * (size_t)td->size);
+    if (!cls.cd) return C21CM_MEMORY_ALLOC_ERROR;
+    class_spline_c(td->size, cls.k, cls.Td, cls.cd);
+    const double kmax = cls.k[td->size - 1];
+    cls.eh_ratio_at_kmax = cls.Td[td->size - 1] / kmax / kmax / transfer_eh(kmax);
+    if (matter_options_global->V_CB_MODEL == C21CM_VCB_FLUCTS) {
+        const Table1D *tv = cosmo_tables_global->transfer_vcb;
+        if (!tv || tv->size != td->size || !tv->y_values) {
+            c21hip_set_error("V_CB_MODEL = FLUCTS needs CosmoTables.transfer_vcb on the k grid of "
+                             "transfer_density");
+            return C21CM_VALUE_ERROR;
+        }
+        cls.n_v = tv->size;
+        cls.Tv = tv->y_values;
+        cls.cv = (double *)malloc(sizeof(double) * (size_t)tv->size);
+        if (!cls.cv) return C21CM_MEMORY_ALLOC_ERROR;
+        class_spline_c(tv->size, cls.k, cls.Tv, cls.cv);
+    }
+    return 0;
+}
+
+/* flag_dv 0: density, 1: relative velocity */
+static double transfer_class(double k, int flag_dv) {
+    if (flag_dv == 0) {
+        if (!cls.n_d) return NAN;
+        if (k > cls.k[cls.n_d - 1]) return cls.eh_ratio_at_kmax * transfer_eh(k) * k * k;
+        return class_spline_eval(cls.n_d, cls.k, cls.Td, cls.cd, k);
+    }
+    if (!cls.n_v) return NAN;
+    const int n = cls.n_v;
+    if (k > cls.k[n - 1])
+        return exp(log(cls.Tv[n - 1]) + (log(cls.Tv[n - 1]) - log(cls.Tv[n - 2])) /
+                                            (log(cls.k[n - 1]) - log(cls.k[n - 2])) *
+                                            (log(k) - log(cls.k[n - 1])));
+    return class_spline_eval(n, cls.k, cls.Tv, cls.cv, k);
+}
+
 /* z = 0 linear matter power spectrum in Mpc^3: cosmology.c:278-308 */
 double power_in_k(double k) {
     if (k == 0.) return 0.;
     const int which = matter_options_global->POWER_SPECTRUM;
-    double T = (which == C21CM_PS_EH) ? transfer_eh(k) : transfer_other(k, which);
-    T *= k * k; /* analytic fits tend to 1 as k -> 0; convert to the CLASS convention */
+    double T;
+    if (which == C21CM_PS_CLASS) {
+        T = transfer_class(k, 0);
+    } else {
+        T = (which == C21CM_PS_EH) ? transfer_eh(k) : transfer_other(k, which);
+        T *= k * k; /* analytic fits tend to 1 as k -> 0; convert to the CLASS convention */
+    }
+    const double primordial =
+        cosmo_tables_global->ps_norm * pow(k / 0.05, cosmo_params_global->POWER_INDEX - 1.);
+    double p = cc.sigma_norm * primordial * T * T / pow(k, 3);
+    if (which == C21CM_PS_CLASS && matter_options_global->V_CB_MODEL != C21CM_VCB_NONE)
+        /* average suppression by the streaming velocity (:295-300; A 0.24, k_p 300 / Mpc, sigma 0.9) */
+        p *= 1.0 - 0.24 * exp(-pow(log(k / 300.0), 2.0) / (2.0 * 0.9 * 0.9));
+    return p;
+}
+
+/* power spectrum of the DM-baryon relative velocity at kinematic decoupling: cosmology.c:310-333 */
+double power_in_vcb(double k) {
+    if (matter_options_global->POWER_SPECTRUM != C21CM_PS_CLASS) return NAN;
+    if (k == 0.) return 0.;
+    const double T = transfer_class(k, 1);
     const double primordial =
         cosmo_tables_global->ps_norm * pow(k / 0.05, cosmo_params_global->POWER_INDEX - 1.);
     return cc.sigma_norm * primordial * T * T / pow(k, 3);
@@ -333,11 +454,17 @@ double dsigmasqdm_z0(double M) {
 /* cosmology.c:507-558 */
 void init_ps(void) {
     const CosmoParams *c = cosmo_params_global;
+    cc.ready = 0;
     cc.omhh = c->OMm * c->hlittle * c->hlittle;
     cc.theta_cmb = PC_T_CMB / 2.7;
     cc.f_nu = fmax(c->OMn / c->OMm, 1e-10);
     cc.f_baryon = fmax(c->OMb / c->OMm, 1e-10);
     set_eh_parameters();
+    if (matter_options_global->POWER_SPECTRUM == C21CM_PS_CLASS) {
+        if (class_setup()) return; /* cc.ready stays 0: the Compute* entry points report the error */
+    } else {
+        class_free();
+    }
     if (cosmo_tables_global->USE_SIGMA_8) {
         cc.sigma_norm = 1;
         const double R8 = 8.0 / c->hlittle;

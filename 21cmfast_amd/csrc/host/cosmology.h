@@ -29,6 +29,7 @@ double dicke(double z);
 double sigma_z0(double M);
 double dsigmasqdm_z0(double M);
 double power_in_k(double k);
+double power_in_vcb(double k); /* POWER_SPECTRUM = CLASS only (NaN otherwise) */
 
 int c21_ps_ready(void);
 double c21_integrate(double (*f)(double, void *), void *ctx, double a, double b, double rel_tol);

@@ -25,7 +25,8 @@ enum {
     WS_IC_PK = 55,
     WS_IC_IN = 56,
     WS_IC_OUT0 = 57, /* staged outputs, reused one at a time */
-    WS_IC_DEVIATES = 58
+    WS_IC_DEVIATES = 58,
+    WS_IC_VCBTAB = 59
 };
 
 #define TRY(expr)         \
@@ -179,6 +180,7 @@ done:
 static int ics_split_supported(const c21cm_ics_spec *s) {
     const char *e = getenv("C21CM_ICS");
     if (e && e[0] == 'p') return 0; /* C21CM_ICS=padded */
+    if (s->vcb_by_m) return 0; /* relative velocities work on the padded spectrum (rare option) */
     if (!c21hip_fft_is_native(s->dim, s->dim, s->dim_z) || c21hip_split_xblock_log2(s->dim)) return 0;
     if (s->dim == s->hii_dim && s->dim_z == s->hii_dim_z) return 1;
     if (s->perturb_on_high_res && s->dim % s->hii_dim) return 0;
@@ -372,6 +374,34 @@ int c21cm_ics_grids(const c21cm_ics_spec *s, InitialConditions *ics, void *strea
                            R_lo, 0.f, need_filter, stream));
     TRY(c21hip_fft_c2r(box, hi_dim[0], hi_dim[1], hi_dim[2], stream));
     TRY(emit(box, hi_dim, ics->lowres_density, lo_dim, VOLUME, stream));
+
+    if (s->vcb_by_m) { /* compute_relative_velocities: InitialConditions.c:141-238,733 */
+        const int n_m = 3 * (s->dim / 2) * (s->dim / 2) + 1;
+        if (!ics->lowres_vcb || s->dim != s->dim_z || s->n_m < n_m) {
+            c21hip_set_error("ics: relative velocities need lowres_vcb, a cubic grid and vcb_by_m[0..3(DIM/2)^2]");
+            return C21CM_VALUE_ERROR;
+        }
+        double *h_dev = (double *)c21hip_ws(WS_IC_VCBTAB, (size_t)n_m * sizeof(double));
+        const size_t nlo = (size_t)lo_dim[0] * lo_dim[1] * lo_dim[2];
+        float *d_vcb = ics->lowres_vcb;
+        const int vcb_host = !c21hip_is_device_ptr(d_vcb);
+        if (vcb_host) d_vcb = (float *)c21hip_ws(WS_IC_OUT0, nlo * sizeof(float));
+        if (!h_dev || !d_vcb) return C21CM_MEMORY_ALLOC_ERROR;
+        TRY(c21hip_h2d(h_dev, s->vcb_by_m, (size_t)n_m * sizeof(double), stream));
+        for (int ii = 0; ii < 3; ii++) {
+            TRY(c21hip_vcb_op(saved, box, hi_dim[0], hi_dim[1], hi_dim[2], s->box_len, s->box_len_z,
+                              ii, h_dev, stream));
+            if (need_filter) /* "we only care about the lowres vcb box, so we filter it directly" */
+                TRY(c21hip_copy_filter(box, box, hi_dim[0], hi_dim[1], hi_dim[2], s->box_len,
+                                       s->box_len_z, 0, R_lo, 0.f, 1, stream));
+            TRY(c21hip_fft_c2r(box, hi_dim[0], hi_dim[1], hi_dim[2], stream));
+            TRY(c21hip_vcb_accumulate(box, hi_dim, d_vcb, lo_dim, ii == 0, ii == 2, VOLUME, stream));
+        }
+        if (vcb_host) {
+            TRY(c21hip_d2h(ics->lowres_vcb, d_vcb, nlo * sizeof(float), stream));
+            TRY(c21hip_sync(stream));
+        }
+    }
 
     /* first-order velocities: InitialConditions.c:299-364 */
     for (int ii = 0; ii < 3; ii++) {

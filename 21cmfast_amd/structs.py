@@ -398,6 +398,7 @@ class IcsSpec(_Base):
         ("seed", C.c_ulonglong),
         ("rng_stream", C.c_int),   # 0 Philox (device), 1 the reference's GSL streams
         ("rng_threads", C.c_int),  # N_THREADS the GSL streams are laid out for (1 or 2)
+        ("vcb_by_m", c_double_p),  # V_CB_MODEL = FLUCTS: sqrt(P_vcb/P) c / k per |k|^2 index
     ]
 
 
@@ -545,3 +546,26 @@ class XraySourceBoxStruct(_Base):
         ("mean_sfr", C.POINTER(C.c_double)),
         ("mean_sfr_mini", C.POINTER(C.c_double)),
     ]
+
+
+def class_tables(k, transfer_density, transfer_vcb=None, **kw) -> CosmoTables:
+    """CosmoTables holding CLASS-style transfer functions (POWER_SPECTRUM = CLASS): T(k) =
+    delta(k, z=0) / zeta(k) on an ascending k grid [1/Mpc], optionally the DM-baryon relative
+    velocity transfer on the same grid.  The numpy arrays are kept alive on the returned object."""
+    import numpy as np
+
+    k = np.ascontiguousarray(k, np.float64)
+    td = np.ascontiguousarray(transfer_density, np.float64)
+    t1 = Table1D(size=len(k), x_values=k.ctypes.data_as(c_double_p),
+                 y_values=td.ctypes.data_as(c_double_p))
+    ct = default_cosmo_tables(**kw)
+    ct.transfer_density = C.pointer(t1)
+    keep = [k, td, t1]
+    if transfer_vcb is not None:
+        tv = np.ascontiguousarray(transfer_vcb, np.float64)
+        t2 = Table1D(size=len(k), x_values=k.ctypes.data_as(c_double_p),
+                     y_values=tv.ctypes.data_as(c_double_p))
+        ct.transfer_vcb = C.pointer(t2)
+        keep += [tv, t2]
+    ct._keep = keep
+    return ct

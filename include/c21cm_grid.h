@@ -206,6 +206,10 @@ typedef struct c21cm_ics_spec {
      *                         The stream is serial by construction and is drawn on the host. */
     int rng_stream;
     int rng_threads;
+    /* V_CB_MODEL = FLUCTS (compute_relative_velocities, InitialConditions.c:141-238), cubic grids:
+     * sqrt(P_vcb(k) / P(k)) c_kms / k at k = (2 pi / L) sqrt(m), m = 0 .. 3 (DIM/2)^2 (entry 0
+     * unused); NULL = no relative velocities.  Output: InitialConditions.lowres_vcb. */
+    const double *vcb_by_m;
 } c21cm_ics_spec;
 enum { C21CM_RNG_PHILOX = 0, C21CM_RNG_GSL = 1 };
 

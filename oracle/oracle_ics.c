@@ -211,6 +211,56 @@ int oracle_ics_grids(const c21cm_ics_spec *s, InitialConditions *ics) {
     oracle_fft_c2r(box, hi_dim[0], hi_dim[1], hi_dim[2]);
     subsample(s, box, ics->lowres_density, lo_dim, VOLUME);
 
+    /* compute_relative_velocities :141-238 (V_CB_MODEL = FLUCTS), called at :733 */
+    if (s->vcb_by_m) {
+        if (!ics->lowres_vcb || s->dim != s->dim_z) {
+            free(box);
+            free(saved);
+            return C21CM_VALUE_ERROR;
+        }
+        const int nx = hi_dim[0], ny = hi_dim[1], nz = hi_dim[2], nzc = nz / 2 + 1;
+        const size_t nlo = (size_t)lo_dim[0] * lo_dim[1] * lo_dim[2];
+        const double ratio = hi_dim[0] / (double)lo_dim[0];
+        for (size_t t = 0; t < nlo; t++) ics->lowres_vcb[t] = 0.f; /* the caller's zeros */
+        for (int ii = 0; ii < 3; ii++) {
+#pragma omp parallel for schedule(static)
+            for (int n_x = 0; n_x < nx; n_x++) {
+                const double k_x = index_to_k(n_x, s->box_len, nx);
+                for (int n_y = 0; n_y < ny; n_y++) {
+                    const double k_y = index_to_k(n_y, s->box_len, ny);
+                    for (int n_z = 0; n_z < nzc; n_z++) {
+                        const double k_z = index_to_k(n_z, s->box_len_z, nz);
+                        const double kvec[3] = {k_x, k_y, k_z};
+                        const int ax = n_x <= nx / 2 ? n_x : nx - n_x, ay = n_y <= ny / 2 ? n_y : ny - n_y;
+                        const long m = (long)ax * ax + (long)ay * ay + (long)n_z * n_z;
+                        const size_t idx = 2 * (((size_t)n_x * ny + n_y) * nzc + n_z);
+                        if (n_x == 0 && n_y == 0 && n_z == 0) {
+                            box[0] = box[1] = 0.f;
+                        } else { /* saved * I * k_a / |k| * sqrt(p_vcb / p) * c_kms */
+                            const double f = kvec[ii] * s->vcb_by_m[m];
+                            box[idx] = (float)(-((double)saved[idx + 1] * f));
+                            box[idx + 1] = (float)((double)saved[idx] * f);
+                        }
+                    }
+                }
+            }
+            if (need_filter)
+                oracle_filter_box(box, nx, ny, nz, s->box_len, s->box_len_z, 0, R_lo, 0.f);
+            oracle_fft_c2r(box, nx, ny, nz);
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < lo_dim[0]; i++)
+                for (int j = 0; j < lo_dim[1]; j++)
+                    for (int k = 0; k < lo_dim[2]; k++) {
+                        const int hi = (int)(i * ratio + 0.5), hj = (int)(j * ratio + 0.5),
+                                  hk = (int)(k * ratio + 0.5);
+                        const double vcb_i = box[(size_t)hk + zpad * ((size_t)hj + (size_t)ny * hi)];
+                        ics->lowres_vcb[(size_t)k + (size_t)lo_dim[2] * ((size_t)j + (size_t)lo_dim[1] * i)] +=
+                            vcb_i * vcb_i;
+                    }
+        }
+        for (size_t t = 0; t < nlo; t++) ics->lowres_vcb[t] = sqrt(ics->lowres_vcb[t]) / VOLUME;
+    }
+
     /* first-order velocities :299-364 */
     float *vel[3], *vel2[3];
     if (s->perturb_on_high_res) {

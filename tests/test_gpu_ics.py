@@ -121,3 +121,81 @@ def test_full_size_properties(api):
     assert not torch.equal(a["hires_density"], c["hires_density"])
     # sigma of the low-res density is below the hi-res one (top-hat smoothing)
     assert a["lowres_density"].std() < a["hires_density"].std()
+
+
+@pytest.mark.parametrize("dim,hii_dim,device", [(32, 16, None), (64, 32, "cuda"), (30, 10, None),
+                                                (48, 48, "cuda")])
+def test_relative_velocities_match_oracle(api, oracle, dim, hii_dim, device):
+    """V_CB_MODEL = FLUCTS: lowres_vcb = sqrt(sum_a v_a^2) / V of the top-hat-filtered, subsampled
+    relative velocity components (reference: InitialConditions.c:141-238)."""
+    from test_oracle_ics import vcb_table
+
+    S = importlib.import_module("21cmfast_amd.structs")
+    L = 2.0 * hii_dim
+    spec = ics_spec(dim, hii_dim, box_len=L, seed=12)
+    h = vcb_table(dim, L)
+    spec.vcb_by_m = h.ctypes.data_as(S.c_double_p)
+    lo = (hii_dim,) * 3
+    ref_arrays = oracle.new_ics_arrays(spec)
+    ref_arrays["lowres_vcb"] = np.zeros(lo, np.float32)
+    ref = oracle.ics_grids(spec, ref_arrays)
+    got_arrays = api.new_ics_arrays(spec, device)
+    if device:
+        import torch
+
+        got_arrays["lowres_vcb"] = torch.zeros(lo, dtype=torch.float32, device=device)
+    else:
+        got_arrays["lowres_vcb"] = np.zeros(lo, np.float32)
+    got = api.ics_grids(spec, got_arrays)
+    compare(got, ref)
+    assert ref["lowres_vcb"].min() > 0
+
+
+def test_relative_velocities_through_the_entry_point(gpu_lib, api, oracle, tmp_path):
+    """ComputeInitialConditions with POWER_SPECTRUM = CLASS and V_CB_MODEL = FLUCTS: the tabulated
+    transfer functions of CosmoTables feed P(k) and sqrt(P_vcb / P); checked against the oracle
+    driven by the library's exported power_in_k / power_in_vcb."""
+    import ctypes as C
+    import math
+
+    from test_gpu_abi import Session, fptr
+    from test_host_scalars import class_like_tables
+
+    S = importlib.import_module("21cmfast_amd.structs")
+    lib = gpu_lib
+    n, N, L = 16, 32, 48.0
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=N, BOX_LEN=L)      # EH first: shapes the table
+    k, T_d, T_v = class_like_tables(lib)
+    ses.mo = S.default_matter_options(POWER_SPECTRUM=5, V_CB_MODEL=2)
+    ses.ct = S.class_tables(k, T_d, T_v)
+    lib.Broadcast_struct_global_all(C.byref(ses.so), C.byref(ses.mo), C.byref(ses.cp),
+                                    C.byref(ses.ap), C.byref(ses.ao), C.byref(ses.ct))
+    lib.init_ps()
+    lib.power_in_vcb.restype = C.c_double
+    lib.power_in_vcb.argtypes = [C.c_double]
+    spec = S.IcsSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=L, box_len_z=L,
+                     perturb_algorithm=2)
+    ics = api.new_ics_arrays(spec)
+    ics["lowres_vcb"] = np.zeros((n, n, n), np.float32)
+    st = lib.ComputeInitialConditions(2026, C.byref(api.ics_struct(ics)))
+    assert st == 0, lib.c21cm_last_error()
+    n_m = 3 * (N // 2) ** 2 + 1
+    kk = 2 * math.pi / L * np.sqrt(np.arange(n_m, dtype=np.float64))
+    pk = np.array([lib.power_in_k(x) for x in kk])
+    h = np.zeros(n_m)
+    h[1:] = [math.sqrt(lib.power_in_vcb(x) / lib.power_in_k(x)) * 2.99792458e5 / x for x in kk[1:]]
+    vol = np.float32(np.float32(L) * np.float32(L)) * np.float32(1.0) * np.float32(L)
+    ospec = S.IcsSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=L, box_len_z=L,
+                      volume=float(vol), perturb_algorithm=2, n_m=n_m,
+                      pk_by_m=pk.ctypes.data_as(S.c_double_p), seed=2026, rng_stream=1,
+                      rng_threads=1, vcb_by_m=h.ctypes.data_as(S.c_double_p))
+    ref_arrays = oracle.new_ics_arrays(ospec)
+    ref_arrays["lowres_vcb"] = np.zeros((n, n, n), np.float32)
+    ref = oracle.ics_grids(ospec, ref_arrays)
+    compare(ics, ref)
+    assert 1.0 < ref["lowres_vcb"].mean() < 1e3   # km/s, tens for a CLASS-like table
+    # without the array, or without CLASS, the request is refused
+    del ics["lowres_vcb"]
+    ics["hires_density"][...] = 0
+    assert lib.ComputeInitialConditions(2026, C.byref(api.ics_struct(ics))) == 3
+    del ses

@@ -447,3 +447,70 @@ def test_mhr_recombination_rate_against_scipy(host, pkg):
     # more photons -> more of the gas ionised -> more recombinations; denser universe -> more
     assert host.c21_recombination_rate(8.0, 1.0) > host.c21_recombination_rate(8.0, 0.1)
     assert host.c21_recombination_rate(10.0, 0.1) > host.c21_recombination_rate(7.0, 0.1)
+
+
+# ---- POWER_SPECTRUM = CLASS: tabulated transfer functions ------------------------------------------
+def class_like_tables(host):
+    """A CLASS-shaped table made from the EH fit: T_density = T_EH(k) k^2 x const on a log grid,
+    and a smooth relative-velocity transfer with the v_cb bump near k ~ 0.05 - 1 / Mpc."""
+    k = np.logspace(-4, np.log10(40.0), 260)
+    p = np.array([host.power_in_k(x) for x in k])  # EH, sigma_8-normalised (fixture state)
+    T_eh_k2 = np.sqrt(p * k**3 / (k / 0.05) ** (0.9665 - 1.0))  # ~ T k^2 up to a constant
+    T_d = 3.7 * T_eh_k2
+    T_v = 2.0e-4 * T_d / k * np.exp(-0.5 * (np.log(k / 0.3) / 1.6) ** 2)
+    return k, T_d, T_v
+
+
+def test_class_transfer_tables(host, pkg):
+    S = pkg.structs
+    f64 = C.c_double
+    host.power_in_vcb.restype = f64
+    host.power_in_vcb.argtypes = [f64]
+    k, T_d, T_v = class_like_tables(host)
+    p_eh = {x: host.power_in_k(x) for x in (0.003, 0.1, 2.5, 35.0, 90.0)}
+    keep = host._keep
+    try:
+        keep["mo"] = S.default_matter_options(POWER_SPECTRUM=5, V_CB_MODEL=2)
+        keep["ct"] = S.class_tables(k, T_d, T_v)
+        host.Broadcast_struct_global_all(*[C.byref(keep[n]) for n in ("so", "mo", "cp", "ap", "ao",
+                                                                      "ct")])
+        host.init_ps()
+        # sigma_8 normalisation holds whatever the table's overall constant is
+        M8 = host.c21_RtoM(8.0 / float(np.float32(0.6766)))
+        assert host.sigma_z0(M8) == pytest.approx(0.8102, rel=1e-6)
+        # the table is the EH shape times a constant: the normalised P(k) is the EH one times
+        # the average streaming-velocity suppression 1 - 0.24 exp(-ln^2(k/300) / (2 0.9^2))
+        # (reference: cosmology.c:295-300), also beyond the table's last k (EH continuation)
+        for x, want in p_eh.items():
+            supp = 1.0 - 0.24 * math.exp(-math.log(x / 300.0) ** 2 / (2 * 0.9 * 0.9))
+            # (the sigma_8 integral sees the suppression too: compare shapes, ratio to k = 0.1)
+            got = host.power_in_k(x) / host.power_in_k(0.1)
+            ref = want * supp / (p_eh[0.1] * (1.0 - 0.24 * math.exp(-math.log(0.1 / 300.0) ** 2 / 1.62)))
+            assert got == pytest.approx(ref, rel=3e-5), x
+        # spline of the velocity transfer: natural cubic spline in k like gsl_interp_cspline
+        sp = interpolate.CubicSpline(k, T_v, bc_type="natural")
+        spd = interpolate.CubicSpline(k, T_d, bc_type="natural")
+        for x in (0.0123, 0.4, 3.3):
+            ratio = host.power_in_vcb(x) / host.power_in_k(x)
+            supp = 1.0 - 0.24 * math.exp(-math.log(x / 300.0) ** 2 / (2 * 0.9 * 0.9))
+            assert ratio == pytest.approx((float(sp(x)) / float(spd(x))) ** 2 / supp, rel=1e-9)
+        # beyond the table: log-log continuation of the velocity transfer
+        slope = math.log(T_v[-1] / T_v[-2]) / math.log(k[-1] / k[-2])
+        t_ext = T_v[-1] * (80.0 / k[-1]) ** slope
+        t_d_ext = host.power_in_k(80.0)
+        assert host.power_in_vcb(80.0) > 0 and t_d_ext > 0
+        assert host.power_in_vcb(80.0) / host.power_in_vcb(k[-1]) == pytest.approx(
+            (t_ext / T_v[-1]) ** 2 * (80.0 / k[-1]) ** (0.9665 - 1.0 - 3.0), rel=1e-6)
+        # a relative-velocity run without its table is refused, not guessed
+        keep["ct"] = S.class_tables(k, T_d)
+        host.Broadcast_struct_global_all(*[C.byref(keep[n]) for n in ("so", "mo", "cp", "ap", "ao",
+                                                                      "ct")])
+        host.init_ps()
+        host.c21_ps_ready.restype = C.c_int
+        assert host.c21_ps_ready() == 0 and b"transfer_vcb" in host.c21cm_last_error()
+    finally:
+        keep["mo"] = S.default_matter_options()
+        keep["ct"] = S.default_cosmo_tables()
+        host.Broadcast_struct_global_all(*[C.byref(keep[n]) for n in ("so", "mo", "cp", "ap", "ao",
+                                                                      "ct")])
+        host.init_ps()

@@ -109,3 +109,40 @@ def test_gaussian_stream(oracle):
     assert abs((x**4).mean() - 3) < 0.15
     assert oracle.gaussian_pair(7, 42) == oracle.gaussian_pair(7, 42)
     assert oracle.gaussian_pair(7, 42) != oracle.gaussian_pair(7, 43)
+
+
+def vcb_table(dim, box_len, power=-0.6, amp=3.0e-3):
+    """h(|k|) = sqrt(P_vcb / P) c_kms / |k| per |k|^2 index for a toy ratio P_vcb / P ~ k^power."""
+    n_m = 3 * (dim // 2) ** 2 + 1
+    k = 2 * np.pi / box_len * np.sqrt(np.arange(n_m, dtype=np.float64))
+    h = np.zeros(n_m)
+    h[1:] = amp * k[1:] ** (power / 2) * 2.99792458e5 / k[1:]
+    return np.ascontiguousarray(h)
+
+
+def test_relative_velocities_against_numpy(oracle):
+    """compute_relative_velocities (reference: InitialConditions.c:141-238) without filtering or
+    subsampling (DIM == HII_DIM): v_cb = sqrt(sum_a IFFT(i k_a h(k) delta_k)^2) / V x V."""
+    n, L = 16, 40.0
+    spec = ics_spec(n, n, L, algorithm=1)
+    h = vcb_table(n, L)
+    spec.vcb_by_m = h.ctypes.data_as(S.c_double_p)
+    ics = oracle.new_ics_arrays(spec)
+    ics["lowres_vcb"] = np.zeros((n, n, n), np.float32)
+    ic = oracle.ics_grids(spec, ics)
+    delta = ic["hires_density"].astype(np.float64)
+    dk = np.fft.rfftn(delta)
+    kf = 2 * np.pi * np.fft.fftfreq(n, d=L / n)
+    kf[n // 2] = np.pi * n / L
+    kzf = 2 * np.pi * np.fft.rfftfreq(n, d=L / n)
+    kx, ky, kz = np.meshgrid(kf, kf, kzf, indexing="ij")
+    f = np.fft.fftfreq(n, d=1.0 / n)
+    mx, my, mz = np.meshgrid(np.abs(f), np.abs(f), np.arange(n // 2 + 1.0), indexing="ij")
+    hk = h[(mx**2 + my**2 + mz**2).astype(int)]
+    tot = 0.0
+    for kk in (kx, ky, kz):
+        v = np.fft.irfftn(1j * kk * hk * dk, s=(n, n, n), axes=(0, 1, 2))
+        tot = tot + v * v
+    want = np.sqrt(tot)
+    np.testing.assert_allclose(ic["lowres_vcb"], want, rtol=2e-4, atol=2e-5 * want.max())
+    assert want.mean() > 0
