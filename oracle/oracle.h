@@ -94,6 +94,7 @@ int oracle_annular_filter_grids(const c21cm_annular_spec *spec, const float *con
                                 float *const *outputs, double *u_avg, double *f_avg);
 
 void oracle_set_threads(int n);
+void oracle_set_fft_threads(int n); /* 0: follow oracle_set_threads; 1: single-threaded FFTs */
 
 #ifdef __cplusplus
 }

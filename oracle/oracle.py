@@ -93,6 +93,15 @@ def set_threads(n: int) -> None:
     load().oracle_set_threads(int(n))
 
 
+def set_fft_threads(n: int) -> None:
+    """0: the transforms use the threads of the sweeps; 1: single-threaded transforms (the
+    reference's effective behaviour, dft.c:83-85)."""
+    lib = load()
+    lib.oracle_set_fft_threads.restype = None
+    lib.oracle_set_fft_threads.argtypes = [C.c_int]
+    lib.oracle_set_fft_threads(int(n))
+
+
 def _ptr(a: np.ndarray):
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)

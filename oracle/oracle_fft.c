@@ -176,13 +176,21 @@ static void fft_tile(const fft_plan *pl, int sign, long batch, cpx *buf, cpx *sc
     if (x != buf) memcpy(buf, x, sizeof(cpx) * (size_t)pl->n * (size_t)batch);
 }
 
+/* Threads of the transforms, separately from the sweeps: the reference plans its FFTW transforms
+ * without fftwf_plan_with_nthreads taking effect (dft.c:83-85: created per call with
+ * FFTW_ESTIMATE, effectively single-threaded), so the CPU baseline is reported both
+ * ways: 1 = "faithful", 0 = as many as the sweeps use ("charitable"). */
+static int g_fft_threads = 0;
+void oracle_set_fft_threads(int n) { g_fft_threads = n; }
+static inline int fft_threads(void) { return g_fft_threads > 0 ? g_fft_threads : omp_get_max_threads(); }
+
 /* complex FFT along x and y of the half-spectrum grid c[nx][ny][nzc] */
 static void fft_xy(cpx *c, int nx, int ny, int nzc, int sign) {
     fft_plan px, py;
     plan_init(&px, nx);
     plan_init(&py, ny);
     /* y-lines: for each x the sub-array [ny][nzc] is already [n][batch] */
-#pragma omp parallel
+#pragma omp parallel num_threads(fft_threads())
     {
         cpx *buf = (cpx *)malloc(sizeof(cpx) * (size_t)(ny > nx ? ny : nx) * TILE);
         cpx *scr = (cpx *)malloc(sizeof(cpx) * (size_t)(ny > nx ? ny : nx) * TILE);
@@ -223,7 +231,7 @@ void oracle_fft_r2c(float *box, int nx, int ny, int nz) {
     fft_plan pz;
     plan_init(&pz, nz);
     const long nlines = (long)nx * ny;
-#pragma omp parallel
+#pragma omp parallel num_threads(fft_threads())
     {
         cpx *buf = (cpx *)malloc(sizeof(cpx) * (size_t)nz * TILE);
         cpx *scr = (cpx *)malloc(sizeof(cpx) * (size_t)nz * TILE);
@@ -258,7 +266,7 @@ void oracle_fft_c2r(float *box, int nx, int ny, int nz) {
     fft_plan pz;
     plan_init(&pz, nz);
     const long nlines = (long)nx * ny;
-#pragma omp parallel
+#pragma omp parallel num_threads(fft_threads())
     {
         cpx *buf = (cpx *)malloc(sizeof(cpx) * (size_t)nz * TILE);
         cpx *scr = (cpx *)malloc(sizeof(cpx) * (size_t)nz * TILE);

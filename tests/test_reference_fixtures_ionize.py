@@ -64,7 +64,7 @@ def eulerian_spec(ses, lib, oracle, source_model):
     (reference: IonisationBox.c:125-227,468-529,964-1006,1423-1469)."""
     from test_gpu_abi import ionize_spec_from_scalars
 
-    spec = ionize_spec_from_scalars(ses, Z, lagrangian=False, tables=True)
+    spec = ionize_spec_from_scalars(ses, Z, lagrangian=False, tables=True, scalars="lib")
     keep = []
     if source_model == 1:  # E-INTEGRAL
         ScalingConsts = bind(lib)
@@ -167,7 +167,7 @@ def test_oracle_halobox_chain_reproduces_reference_fixture(oracle, pkg, fields, 
         prefactor_nion=pre_stars * sc.fesc_10 * sc.pop2_ion,
         prefactor_sfr=pre_stars / sc.t_star / sc.t_h, prefactor_wsfr=1 / sc.t_h / sc.t_star)
     hb = oracle.halobox_grids(hspec, ics)
-    spec = ionize_spec_from_scalars(ses, Z, lagrangian=True, tables=False)
+    spec = ionize_spec_from_scalars(ses, Z, lagrangian=True, tables=False, scalars="lib")
     lnlo, lnhi = math.log(M_min), math.log(1e16)
     spec.mean_f_coll = lib.c21_Nion_General(Z, lnlo, lnhi, sc.mturn_a_nofb, C.byref(sc))
     spec.f_limit_acg = lib.c21_Nion_General(ses.so.Z_HEAT_MAX, lnlo, lnhi, sc.mturn_a_nofb,
