@@ -347,6 +347,13 @@ int c21hip_recomb_rates(const float *density, const float *G12, const float *xH,
                         const float *prev_nrec, float *nrec, size_t ntot, double stored_redshift,
                         double rate_scale, const double *rr_y_dev, const double *rr_c_dev,
                         int *flag_dev, void *stream);
+/* sharded R loop with a recombination model: (mean free path, Gamma_12) of a rank's first
+ * crossings packed into order-preserving 64-bit keys, and the reduced keys applied to the outputs */
+int c21hip_pack_cross_keys(const float *mfp, const float *G12, unsigned long long *keys,
+                           size_t ntot, void *stream);
+int c21hip_apply_cross_keys(const unsigned long long *keys, const float *prev_z_reion,
+                            int first_snapshot, double redshift, float *xH, float *z_reion,
+                            float *G12, float *mfp, size_t ntot, void *stream);
 int c21hip_sum_float(const float *v, size_t n, double *partials, double *sum_out, void *stream);
 int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
                          const double *mean_dev, unsigned char *first_cross, void *stream);

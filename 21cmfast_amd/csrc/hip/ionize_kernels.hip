@@ -781,6 +781,43 @@ apply_first_cross_kernel(const unsigned char *__restrict__ fc,
     }
 }
 
+// R-loop sharding with a recombination model: a rank's first crossing of a cell is the pair
+// (mean free path = R of the crossing, Gamma_12 at it).  Both are non-negative floats, whose IEEE
+// bit patterns order like the values, so key = bits(mfp) << 32 | bits(G12) and ONE max-reduce of
+// 64-bit keys over the ranks selects the largest radius that ionised the cell together with ITS
+// Gamma_12 (a radius belongs to exactly one rank: no ties).  key = 0: never crossed.
+__global__ void __launch_bounds__(kBlock)
+pack_cross_keys_kernel(const float *__restrict__ mfp, const float *__restrict__ G12,
+                       unsigned long long *__restrict__ keys, size_t ntot) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const float m = mfp[i];
+        keys[i] = (m > 0.f) ? (((unsigned long long)__float_as_uint(m) << 32) |
+                               (unsigned long long)__float_as_uint(fmaxf(G12[i], 0.f)))
+                            : 0ull;
+    }
+}
+
+// the reduced keys -> the state find_ionised_regions leaves after the radii > 0
+// (IonisationBox.c:1124-1151): crossed cells are ionised, carry z_reion, Gamma_12, mean free path
+__global__ void __launch_bounds__(kBlock)
+apply_cross_keys_kernel(const unsigned long long *__restrict__ keys,
+                        const float *__restrict__ prev_z_reion, int first_snapshot, float z_now,
+                        float *__restrict__ xH, float *__restrict__ z_reion,
+                        float *__restrict__ G12, float *__restrict__ mfp, size_t ntot) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const unsigned long long k = keys[i];
+        if (k) {
+            const float pz = first_snapshot ? -1.f : prev_z_reion[i];
+            z_reion[i] = (pz < 0.f) ? z_now : pz;
+            xH[i] = 0.f;
+            G12[i] = __uint_as_float((unsigned)(k & 0xffffffffull));
+            if (mfp) mfp[i] = __uint_as_float((unsigned)(k >> 32));
+        }
+    }
+}
+
 // set_fully_neutral_box: IonisationBox.c:531-565
 __global__ void __launch_bounds__(kBlock)
 neutral_box_kernel(const float *__restrict__ density, const float *__restrict__ xe,
@@ -1201,6 +1238,25 @@ extern "C" int c21hip_apply_first_cross(const unsigned char *first_cross,
     hipLaunchKernelGGL(apply_first_cross_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
                        (hipStream_t)stream, first_cross, prev_z_reion, first_snapshot,
                        (float)redshift, xH, z_reion, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_pack_cross_keys(const float *mfp, const float *G12, unsigned long long *keys,
+                                      size_t ntot, void *stream) {
+    hipLaunchKernelGGL(pack_cross_keys_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
+                       (hipStream_t)stream, mfp, G12, keys, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_apply_cross_keys(const unsigned long long *keys, const float *prev_z_reion,
+                                       int first_snapshot, double redshift, float *xH,
+                                       float *z_reion, float *G12, float *mfp, size_t ntot,
+                                       void *stream) {
+    hipLaunchKernelGGL(apply_cross_keys_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
+                       (hipStream_t)stream, keys, prev_z_reion, first_snapshot, (float)redshift, xH,
+                       z_reion, G12, mfp, ntot);
     LAUNCH_CHECK();
     return 0;
 }

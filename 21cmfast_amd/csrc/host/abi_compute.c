@@ -424,8 +424,19 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         st = c21cm_neutral_box(s, perturbed_field, spin_temp, box, ntot);
         goto done;
     }
-    st = c21cm_ionize_grids(s, perturbed_field, previous_ionize_box, spin_temp, halos, box, NULL,
-                            NULL);
+    {
+        /* one process per GPU with an initialised communicator (c21cm_shard_init): the R loop
+         * is sharded over the ranks and every rank returns the full box (C21CM_SHARD=0: single
+         * GPU per process; C21CM_SHARD_BCAST=0: only the finishing rank's box is filled) */
+        int srank, sworld;
+        const char *e = getenv("C21CM_SHARD"), *b = getenv("C21CM_SHARD_BCAST");
+        if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && !(e && e[0] == '0'))
+            st = c21cm_ionize_sharded(s, perturbed_field, previous_ionize_box, spin_temp, halos,
+                                      box, NULL, !(b && b[0] == '0'), NULL);
+        else
+            st = c21cm_ionize_grids(s, perturbed_field, previous_ionize_box, spin_temp, halos, box,
+                                    NULL, NULL);
+    }
 done:
     free(s);
     return st;

@@ -65,7 +65,12 @@ enum {
     WS_G12,
     WS_MFP,
     WS_NREC_OUT,
-    WS_RR_TABLES
+    WS_RR_TABLES,
+    /* rank-local state of a sharded run with a recombination model */
+    WS_SH_XH,
+    WS_SH_ZRE,
+    WS_SH_G12,
+    WS_SH_MFP
 };
 
 #define MAX_COPYBACK 12
@@ -756,8 +761,8 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
         TRY(filter_to_real(c, c->xe_unf, c->xe_work, c->xe_fil, s->hii_filter, R, 0.f, apply));
 
     if (c->recomb) {
-        if (first_cross) {
-            c21hip_set_error("ionize: recombination models are not sharded over radii");
+        if (first_cross) { /* sharded runs use the key variant (c21cm_ionize_shard_radii_keys) */
+            c21hip_set_error("ionize: a recombination model shards through the 64-bit key phases");
             status = C21CM_VALUE_ERROR;
             goto done;
         }
@@ -1245,6 +1250,123 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
         TRY(c21hip_apply_first_cross(first_cross, c.prev_zre, spec->first_snapshot,
                                      spec->redshift, c.xH, c.zre, c.ntot, stream));
         if (spec->r_lowest == 0) TRY(one_radius(&c, 0, NULL, -1));
+    }
+    TRY(c21hip_event_record(ev[1], stream));
+    TRY(postloop(&c, box, report));
+    TRY(c21hip_event_record(ev[2], stream));
+    if (report) {
+        report->ms_preloop = 0.;
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_postloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+    }
+done:
+    for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}
+
+/* ---- R-loop sharding with a recombination model ----------------------------------------------
+ * The first crossing of a cell carries two floats (the radius = mean free path, and Gamma_12), so
+ * the uint8 index grid is replaced by 64-bit keys bits(mfp) << 32 | bits(G12): the max over ranks
+ * is the crossing at the largest radius together with its own Gamma_12 ("float
+ * G12 candidate for that index"), in ONE reduce of 8 N bytes.  Each rank runs the unfused
+ * recombination sequence for its radii on rank-local x_HI / Gamma_12 / mean-free-path scratch
+ * (the barrier of a radius depends on no other radius: rec comes from the PREVIOUS snapshot). */
+int c21cm_ionize_shard_radii_keys(const c21cm_ionize_spec *spec, int rank, int world,
+                                  const PerturbedField *perturbed_field,
+                                  const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                  const HaloBox *halos, unsigned long long *cross_keys,
+                                  c21cm_ionize_report *report, void *stream) {
+    IonizedBox dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    int status = 0;
+    if (!cross_keys || !c21hip_is_device_ptr(cross_keys) || world < 1 || rank < 0 || rank >= world) {
+        c21hip_set_error("ionize shard: cross_keys must be a device array, 0 <= rank < world");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!spec || spec->recomb_model == C21CM_RECOMB_NONE) {
+        c21hip_set_error("ionize shard: the key phases are for recombination models");
+        return C21CM_VALUE_ERROR;
+    }
+    const size_t ntot = (size_t)spec->hii_dim * spec->hii_dim * spec->hii_dim_z;
+    if (spec->fcoll_mode != C21CM_FCOLL_STARS_GRID)
+        dummy.unnormalised_nion = (float *)c21hip_ws(WS_NION_DENSE, ntot * sizeof(float));
+    {
+        IonizedBox probe = dummy;
+        float sentinel;
+        probe.neutral_fraction = probe.z_reion = probe.kinetic_temperature = &sentinel;
+        probe.ionisation_rate_G12 = probe.cumulative_recombinations = &sentinel;
+        status = validate_spec(spec, perturbed_field, halos, spin_temp, &probe);
+        if (status) return status;
+    }
+    ion_ctx c;
+    void *ev[3] = {NULL, NULL, NULL};
+    TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, &dummy, 0,
+                  stream));
+    c.xH = (float *)c21hip_ws(WS_SH_XH, ntot * sizeof(float));
+    c.zre = (float *)c21hip_ws(WS_SH_ZRE, ntot * sizeof(float));
+    c.G12 = (float *)c21hip_ws(WS_SH_G12, ntot * sizeof(float));
+    c.mfp = (float *)c21hip_ws(WS_SH_MFP, ntot * sizeof(float));
+    if (!c.xH || !c.zre || !c.G12 || !c.mfp) return C21CM_MEMORY_ALLOC_ERROR;
+    for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    TRY(c21hip_fill(c.xH, ntot, 1.0f, stream)); /* a fresh IonizedBox (outputs.py:1524-1527) */
+    TRY(c21hip_memset(c.G12, 0, ntot * sizeof(float), stream));
+    TRY(c21hip_memset(c.mfp, 0, ntot * sizeof(float), stream));
+    g_spectra.valid = 0;
+    TRY(preloop(&c));
+    spectra_remember(&c, perturbed_field, halos, spin_temp);
+    TRY(c21hip_event_record(ev[1], stream));
+    for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
+        if (R_ct < spec->r_lowest) break;
+        TRY(one_radius(&c, R_ct, NULL, R_ct - world));
+    }
+    TRY(c21hip_pack_cross_keys(c.mfp, c.G12, cross_keys, ntot, stream));
+    TRY(c21hip_event_record(ev[2], stream));
+    if (report) {
+        double means[C21CM_MAX_RADII];
+        TRY(c21hip_d2h(means, c.scalars + SC_MEANS, sizeof(means), stream));
+        TRY(c21hip_sync(stream));
+        for (int r = 0; r < spec->n_radii; r++) report->f_coll_grid_mean[r] = means[r];
+        if (world == 1) c21cm_ionize_shard_set_means(means, spec->n_radii);
+        report->ms_preloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+        report->ms_postloop = 0.;
+    }
+done:
+    for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}
+
+int c21cm_ionize_shard_finish_keys(const c21cm_ionize_spec *spec,
+                                   const unsigned long long *cross_keys,
+                                   const PerturbedField *perturbed_field,
+                                   const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                   const HaloBox *halos, IonizedBox *box,
+                                   c21cm_ionize_report *report, void *stream) {
+    int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
+    if (status) return status;
+    if (!cross_keys || !c21hip_is_device_ptr(cross_keys) ||
+        spec->recomb_model == C21CM_RECOMB_NONE) {
+        c21hip_set_error("ionize shard: cross_keys must be a device array (recombination models)");
+        return C21CM_VALUE_ERROR;
+    }
+    ion_ctx c;
+    void *ev[3] = {NULL, NULL, NULL};
+    TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1,
+                  stream));
+    for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    if (g_shard_means.valid && g_shard_means.n == spec->n_radii)
+        TRY(c21hip_h2d(c.scalars + SC_MEANS, g_shard_means.means,
+                       sizeof(double) * (size_t)spec->n_radii, stream));
+    g_shard_means.valid = 0;
+    TRY(init_output_grids(&c, previous_ionize_box));
+    TRY(c21hip_apply_cross_keys(cross_keys, c.prev_zre, spec->first_snapshot, spec->redshift, c.xH,
+                                c.zre, c.G12, c.mfp, c.ntot, stream));
+    if (spec->r_lowest == 0) {
+        if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
+        g_spectra.valid = 0;
+        TRY(one_radius(&c, 0, NULL, -1));
     }
     TRY(c21hip_event_record(ev[1], stream));
     TRY(postloop(&c, box, report));

@@ -1,0 +1,237 @@
+/*
+ * shard_rccl.c -- the R loop of ComputeIonizedBox sharded over the GPUs of one node, with the
+ * exchange behind the C ABI (BASELINE.json north_star: "host/driver code stays
+ * in C ... the R-loop of filter scales is partitioned across the 8 GPUs of one node with an RCCL
+ * all-reduce over xGMI to combine the per-cell ionized mask").
+ *
+ * One process per GPU, every rank holds the (replicated) inputs:
+ *   shard phase   radii n-1-rank, n-1-rank-world, ... > 0 with the fused kernels into a uint8
+ *                 first-crossing grid (c21cm_ionize_shard_radii), or -- with a recombination
+ *                 model -- into 64-bit (mean free path, Gamma_12) keys
+ *                 (c21cm_ionize_shard_radii_keys)
+ *   exchange      ONE ncclReduce(max) of that grid onto the rank that owns radius index 0
+ *                 (N bytes, or 8 N with recombinations); "the largest radius that ionises the
+ *                 cell" is order independent, so the result equals the sequential loop
+ *                 (reference: src/py21cmfast/src/IonisationBox.c:1531-1588)
+ *   finish        that rank applies the reduced grid, runs the cell-scale radius and the
+ *                 post-loop, and (optionally) broadcasts the outputs
+ * A reduce onto the finishing rank replaces the all-reduce of the plan: nobody else needs the
+ * combined grid, and a reduce moves half the bytes of a ring all-reduce over the xGMI links.
+ *
+ * librccl is resolved with dlopen at first use, so the library itself has no RCCL dependency
+ * (CPU-only hosts load it for the host scalars and the ABI checks), and inside a PyTorch process
+ * the SONAME resolves to the copy torch already mapped: one RCCL per process.
+ */
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../hip/c21hip.h"
+#include "c21cm_grid.h"
+
+typedef struct {
+    char internal[C21CM_SHARD_ID_BYTES];
+} rccl_unique_id; /* ncclUniqueId, rccl.h */
+typedef void *rccl_comm;
+enum { RCCL_UINT8 = 1, RCCL_UINT64 = 5, RCCL_FLOAT64 = 8 }; /* ncclDataType_t */
+enum { RCCL_SUM = 0, RCCL_MAX = 2 };                       /* ncclRedOp_t   */
+
+static struct {
+    void *lib;
+    int ready, rank, world;
+    rccl_comm comm;
+    int (*get_unique_id)(rccl_unique_id *);
+    int (*comm_init_rank)(rccl_comm *, int, rccl_unique_id, int);
+    int (*comm_destroy)(rccl_comm);
+    int (*reduce)(const void *, void *, size_t, int, int, int, rccl_comm, void *);
+    int (*broadcast)(const void *, void *, size_t, int, int, rccl_comm, void *);
+    const char *(*error_string)(int);
+} R;
+
+enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142 };
+
+static int rccl_load(void) {
+    if (R.lib) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", NULL};
+    for (int i = 0; names[i] && !R.lib; i++) R.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!R.lib) {
+        c21hip_set_error("shard: librccl could not be loaded (%s)", dlerror());
+        return C21CM_IO_ERROR;
+    }
+    *(void **)&R.get_unique_id = dlsym(R.lib, "ncclGetUniqueId");
+    *(void **)&R.comm_init_rank = dlsym(R.lib, "ncclCommInitRank");
+    *(void **)&R.comm_destroy = dlsym(R.lib, "ncclCommDestroy");
+    *(void **)&R.reduce = dlsym(R.lib, "ncclReduce");
+    *(void **)&R.broadcast = dlsym(R.lib, "ncclBroadcast");
+    *(void **)&R.error_string = dlsym(R.lib, "ncclGetErrorString");
+    if (!R.get_unique_id || !R.comm_init_rank || !R.comm_destroy || !R.reduce || !R.broadcast) {
+        c21hip_set_error("shard: librccl lacks an expected symbol");
+        return C21CM_IO_ERROR;
+    }
+    return 0;
+}
+
+static int rccl_check(int rc, const char *what) {
+    if (rc == 0) return 0;
+    c21hip_set_error("shard: %s failed: %s", what, R.error_string ? R.error_string(rc) : "?");
+    return C21CM_IO_ERROR;
+}
+
+int c21cm_shard_unique_id(void *id128) {
+    int st = rccl_load();
+    if (st) return st;
+    if (!id128) return C21CM_VALUE_ERROR;
+    rccl_unique_id id;
+    if ((st = rccl_check(R.get_unique_id(&id), "ncclGetUniqueId"))) return st;
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int c21cm_shard_init(int rank, int world, const void *id128) {
+    int st = rccl_load();
+    if (st) return st;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) {
+        c21hip_set_error("shard: bad rank %d / world %d", rank, world);
+        return C21CM_VALUE_ERROR;
+    }
+    if (R.ready) c21cm_shard_finalize();
+    rccl_unique_id id;
+    memcpy(&id, id128, sizeof(id));
+    if ((st = rccl_check(R.comm_init_rank(&R.comm, world, id, rank), "ncclCommInitRank"))) return st;
+    R.rank = rank;
+    R.world = world;
+    R.ready = 1;
+    return 0;
+}
+
+int c21cm_shard_finalize(void) {
+    if (R.ready && R.comm) (void)R.comm_destroy(R.comm);
+    R.comm = NULL;
+    R.ready = 0;
+    return 0;
+}
+
+int c21cm_shard_info(int *rank, int *world) {
+    if (!R.ready) return C21CM_VALUE_ERROR;
+    if (rank) *rank = R.rank;
+    if (world) *world = R.world;
+    return 0;
+}
+
+/* the rank the round-robin deal would hand radius index 0 to: it has the fewest shard radii */
+int c21cm_shard_owner(int n_radii, int world) { return world > 0 ? (n_radii - 1) % world : 0; }
+
+/* broadcast one output array (host or device) from `root` */
+static int bcast_array(float *p, size_t bytes, int root, void *stream) {
+    if (!p) return 0;
+    int st = 0;
+    if (c21hip_is_device_ptr(p))
+        return rccl_check(R.broadcast(p, p, bytes, RCCL_UINT8, root, R.comm, stream), "ncclBroadcast");
+    void *d = c21hip_ws(WS_SHARD_STAGE, bytes);
+    if (!d) return C21CM_MEMORY_ALLOC_ERROR;
+    if (R.rank == root && (st = c21hip_h2d(d, p, bytes, stream))) return st;
+    if ((st = rccl_check(R.broadcast(d, d, bytes, RCCL_UINT8, root, R.comm, stream), "ncclBroadcast")))
+        return st;
+    if (R.rank != root && (st = c21hip_d2h(p, d, bytes, stream))) return st;
+    return c21hip_sync(stream); /* the staging slot is reused by the next array */
+}
+
+int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
+                         const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                         const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                         int broadcast, void *stream) {
+    if (!R.ready) {
+        c21hip_set_error("shard: c21cm_shard_init has not been called");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!spec || !box) return C21CM_VALUE_ERROR;
+    int st = 0;
+    const int rank = R.rank, world = R.world;
+    const int owner = c21cm_shard_owner(spec->n_radii, world);
+    const size_t ntot = (size_t)spec->hii_dim * spec->hii_dim * spec->hii_dim_z;
+    const int recomb = (spec->recomb_model != C21CM_RECOMB_NONE);
+    /* the per-radius means matter for the result only when a Lagrangian loop stops above index
+     * 0 (box->mean_f_coll = mean of the last radius, IonisationBox.c:1623-1628) */
+    const int need_means = (!spec->fix_mean && spec->r_lowest > 0);
+    c21cm_ionize_report local;
+    memset(&local, 0, sizeof(local));
+
+    if (!recomb) {
+        unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, ntot);
+        if (!fc) return C21CM_MEMORY_ALLOC_ERROR;
+        if ((st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box,
+                                           spin_temp, halos, fc, need_means ? &local : NULL, stream)))
+            return st;
+        if ((st = rccl_check(R.reduce(fc, fc, ntot, RCCL_UINT8, RCCL_MAX, owner, R.comm, stream),
+                             "ncclReduce(first_cross)")))
+            return st;
+        if (need_means) {
+            double *d = (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean));
+            if (!d) return C21CM_MEMORY_ALLOC_ERROR;
+            if ((st = c21hip_h2d(d, local.f_coll_grid_mean, sizeof(local.f_coll_grid_mean), stream)))
+                return st;
+            if ((st = rccl_check(R.reduce(d, d, C21CM_MAX_RADII, RCCL_FLOAT64, RCCL_SUM, owner,
+                                          R.comm, stream), "ncclReduce(means)")))
+                return st;
+            if (rank == owner) {
+                if ((st = c21hip_d2h(local.f_coll_grid_mean, d, sizeof(local.f_coll_grid_mean), stream)) ||
+                    (st = c21hip_sync(stream)))
+                    return st;
+                c21cm_ionize_shard_set_means(local.f_coll_grid_mean, spec->n_radii);
+            }
+        }
+        if (rank == owner)
+            st = c21cm_ionize_shard_finish(spec, fc, perturbed_field, previous_ionize_box, spin_temp,
+                                           halos, box, report, stream);
+    } else {
+        unsigned long long *keys = (unsigned long long *)c21hip_ws(WS_SHARD_GRID, 8 * ntot);
+        if (!keys) return C21CM_MEMORY_ALLOC_ERROR;
+        if ((st = c21cm_ionize_shard_radii_keys(spec, rank, world, perturbed_field,
+                                                previous_ionize_box, spin_temp, halos, keys, NULL,
+                                                stream)))
+            return st;
+        if ((st = rccl_check(R.reduce(keys, keys, ntot, RCCL_UINT64, RCCL_MAX, owner, R.comm, stream),
+                             "ncclReduce(cross_keys)")))
+            return st;
+        if (rank == owner)
+            st = c21cm_ionize_shard_finish_keys(spec, keys, perturbed_field, previous_ionize_box,
+                                                spin_temp, halos, box, report, stream);
+    }
+    if (st) return st;
+    if (!broadcast) return 0;
+
+    /* every rank returns the finished box */
+    const size_t db = ntot * sizeof(float);
+    if ((st = bcast_array(box->neutral_fraction, db, owner, stream))) return st;
+    if ((st = bcast_array(box->z_reion, db, owner, stream))) return st;
+    if ((st = bcast_array(box->kinetic_temperature, db, owner, stream))) return st;
+    if (spec->fcoll_mode != C21CM_FCOLL_STARS_GRID &&
+        (st = bcast_array(box->unnormalised_nion, db, owner, stream)))
+        return st;
+    if (recomb) {
+        if ((st = bcast_array(box->ionisation_rate_G12, db, owner, stream))) return st;
+        if ((st = bcast_array(box->mean_free_path, db, owner, stream))) return st;
+        if ((st = bcast_array(box->cumulative_recombinations,
+                              spec->recomb_model == C21CM_RECOMB_INHOMOGENEOUS ? db : sizeof(float),
+                              owner, stream)))
+            return st;
+    }
+    {
+        double sc[4] = {box->mean_f_coll, box->mean_f_coll_MINI, report ? report->global_xH : 0.,
+                        report ? report->mean_f_coll_out : 0.};
+        double *d = (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean));
+        if (!d) return C21CM_MEMORY_ALLOC_ERROR;
+        if (rank == owner && (st = c21hip_h2d(d, sc, sizeof(sc), stream))) return st;
+        if ((st = rccl_check(R.broadcast(d, d, sizeof(sc), RCCL_UINT8, owner, R.comm, stream),
+                             "ncclBroadcast(scalars)")))
+            return st;
+        if ((st = c21hip_d2h(sc, d, sizeof(sc), stream)) || (st = c21hip_sync(stream))) return st;
+        box->mean_f_coll = sc[0];
+        box->mean_f_coll_MINI = sc[1];
+        if (report && rank != owner) {
+            report->global_xH = sc[2];
+            report->mean_f_coll_out = sc[3];
+        }
+    }
+    return 0;
+}

@@ -8,8 +8,13 @@ cell-scale radius (partial ionisation) and the post-loop.  "Largest radius that 
 cell" is order independent, so the result is identical to the sequential loop
 (reference: src/py21cmfast/src/IonisationBox.c:1531-1588).
 
-``torch.distributed`` is the plumbing: backend "nccl" (= RCCL over xGMI) on the MI355X
-node, "gloo" in the CPU tests.
+Two implementations of the exchange:
+* ``sharded_ionize_c``  -- the product path: the reduce happens INSIDE the C library through its
+  own RCCL communicator (csrc/host/shard_rccl.c, ``c21cm_ionize_sharded``); torch.distributed
+  only carries the 128-byte unique id once (``grid_api.shard_init_from_torch``).  With the
+  communicator initialised the drop-in ``ComputeIonizedBox`` shards by itself.
+* ``sharded_ionize``    -- the same phases with the reduce through ``torch.distributed``
+  (backend "gloo" in the CPU tests and when several ranks share one GPU, where RCCL refuses).
 """
 
 from __future__ import annotations
@@ -72,3 +77,11 @@ def sharded_ionize(spec, density, n_ion, buffers, first_cross, rank: int, world:
         _, _, rep = api.ionize_shard_finish(spec, first_cross, density, n_ion, buffers=buffers)
         return rep
     return None
+
+
+def sharded_ionize_c(spec, density, n_ion, buffers, rank: int, world: int, **kw):
+    """One sharded pass through c21cm_ionize_sharded; returns the report on the owner, else None."""
+    from . import grid_api as api
+
+    _, _, rep = api.ionize_sharded(spec, density, n_ion, buffers=buffers, **kw)
+    return rep if rank == owner_rank(spec.n_radii, world) else None

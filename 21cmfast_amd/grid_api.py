@@ -199,6 +199,100 @@ def ionize_shard_finish(spec, first_cross, density, n_ion=None, xe=None, Tneutra
     return buffers, box, rep
 
 
+def ionize_shard_radii_keys(spec, rank, world, cross_keys, density, n_ion=None, xe=None,
+                            Tneutral=None, prev_z_reion=None, prev_nrec=None, whalo_sfr=None,
+                            stream=None):
+    """Shard phase of a recombination model: this rank's radii -> ``cross_keys`` (int64 / uint64
+    CUDA tensor of N entries: bits(mean free path) << 32 | bits(Gamma_12), 0 = not crossed)."""
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec,
+                                      whalo_sfr)
+    lib = load()
+    lib.c21cm_ionize_shard_radii_keys.restype = C.c_int
+    check(lib.c21cm_ionize_shard_radii_keys(C.byref(spec), C.c_int(rank), C.c_int(world),
+                                            C.byref(pf), C.byref(prev), C.byref(ts), C.byref(hb),
+                                            C.c_void_p(cross_keys.data_ptr()), None,
+                                            _stream(stream)),
+          "c21cm_ionize_shard_radii_keys")
+
+
+def ionize_shard_finish_keys(spec, cross_keys, density, n_ion=None, xe=None, Tneutral=None,
+                             prev_z_reion=None, prev_nrec=None, whalo_sfr=None,
+                             buffers: IonizeBuffers | None = None, stream=None):
+    """Finish phase of a recombination model on the owning rank (reduced keys in)."""
+    if buffers is None:
+        buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
+                                minimize_memory=bool(spec.minimize_memory),
+                                recomb_model=spec.recomb_model)
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec,
+                                      whalo_sfr)
+    box = buffers.struct()
+    rep = S.IonizeReport()
+    lib = load()
+    lib.c21cm_ionize_shard_finish_keys.restype = C.c_int
+    check(lib.c21cm_ionize_shard_finish_keys(C.byref(spec), C.c_void_p(cross_keys.data_ptr()),
+                                             C.byref(pf), C.byref(prev), C.byref(ts), C.byref(hb),
+                                             C.byref(box), C.byref(rep), _stream(stream)),
+          "c21cm_ionize_shard_finish_keys")
+    return buffers, box, rep
+
+
+def shard_init_from_torch(group=None):
+    """Bootstrap the library's own RCCL communicator from an initialised ``torch.distributed``
+    job: rank 0 draws the unique id in C (c21cm_shard_unique_id), torch broadcasts its 128 bytes,
+    every rank calls c21cm_shard_init.  Afterwards the exchange of the sharded R loop happens
+    inside the C library (c21cm_ionize_sharded, and ComputeIonizedBox itself)."""
+    import torch
+    import torch.distributed as dist
+
+    lib = load(require_gpu=True)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        check(lib.c21cm_shard_unique_id(buf), "c21cm_shard_unique_id")
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0, group=group)
+    raw = bytes(t.cpu().tolist())
+    check(lib.c21cm_shard_init(C.c_int(rank), C.c_int(world), raw), "c21cm_shard_init")
+    return rank, world
+
+
+def shard_init_single():
+    """A one-rank communicator (plumbing tests on a single GPU)."""
+    lib = load(require_gpu=True)
+    buf = (C.c_ubyte * 128)()
+    check(lib.c21cm_shard_unique_id(buf), "c21cm_shard_unique_id")
+    check(lib.c21cm_shard_init(0, 1, bytes(buf)), "c21cm_shard_init")
+
+
+def shard_finalize():
+    load().c21cm_shard_finalize()
+
+
+def ionize_sharded(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=None,
+                   prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None,
+                   prev_nrec=None, whalo_sfr=None, broadcast=False):
+    """One ComputeIonizedBox pass with the R loop sharded over the ranks of the library's RCCL
+    communicator (c21cm_ionize_sharded): shard phase, ONE ncclReduce, finish on the owner rank
+    -- all inside the C library.  Returns (buffers, box_struct, report); without ``broadcast``
+    only the owner's buffers hold the result."""
+    if buffers is None:
+        buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
+                                minimize_memory=bool(spec.minimize_memory),
+                                recomb_model=spec.recomb_model)
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec,
+                                      whalo_sfr)
+    box = buffers.struct()
+    rep = S.IonizeReport()
+    lib = load()
+    lib.c21cm_ionize_sharded.restype = C.c_int
+    check(lib.c21cm_ionize_sharded(C.byref(spec), C.byref(pf), C.byref(prev), C.byref(ts),
+                                   C.byref(hb), C.byref(box), C.byref(rep),
+                                   C.c_int(1 if broadcast else 0), _stream(stream)),
+          "c21cm_ionize_sharded")
+    return buffers, box, rep
+
+
 IC_FIELDS = ("lowres_density", "lowres_vx", "lowres_vy", "lowres_vz", "lowres_vx_2LPT",
              "lowres_vy_2LPT", "lowres_vz_2LPT", "hires_density", "hires_vx", "hires_vy",
              "hires_vz", "hires_vx_2LPT", "hires_vy_2LPT", "hires_vz_2LPT", "lowres_vcb")

@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host-staged) lets several ranks share "
                          "one GPU in the plumbing test, nccl = RCCL over xGMI is the real one")
+    ap.add_argument("--shard-impl", default="c", choices=["c", "torch"],
+                    help="where the mask reduce happens: c = inside the C library through its own "
+                         "RCCL communicator (c21cm_ionize_sharded, the product path; nccl backend "
+                         "only), torch = torch.distributed.reduce between the two C phases")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded code path (shard phase, RCCL reduce, finish phase) even "
                          "with one rank: a smoke test of the multi-GPU plumbing, not a benchmark")
@@ -258,7 +262,11 @@ def main():
     buffers = api.IonizeBuffers(density, need_nion=mode != W.FCOLL_STARS)
     D = importlib.import_module("21cmfast_amd.distributed")
     owner = D.owner_rank(spec.n_radii, world)
-    first_cross = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda") if sharded else None
+    shard_c = sharded and args.shard_impl == "c" and args.backend == "nccl"
+    if shard_c:  # the library's own communicator, bootstrapped once through torch.distributed
+        api.shard_init_from_torch()
+    first_cross = (torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
+                   if sharded and not shard_c else None)
     last_report = {}
 
     def step():
@@ -267,6 +275,10 @@ def main():
         if not sharded:
             _, _, rep = api.ionize_grids(spec, density, n_ion, buffers=buffers)
             last_report["rep"] = rep
+        elif shard_c:
+            rep = D.sharded_ionize_c(spec, density, n_ion, buffers, rank, world)
+            if rep is not None:
+                last_report["rep"] = rep
         else:
             rep = D.sharded_ionize(spec, density, n_ion, buffers, first_cross, rank, world)
             if rep is not None:
@@ -361,7 +373,10 @@ def main():
                             f"steps, G={G} ({'delta tophat + n_ion exp-MFP' if G == 2 else 'delta sharp-k, erfc f_coll'}), "
                             "first snapshot, device-resident inputs",
                 "hii_dim": n, "n_radii": spec.n_radii, "filtered_grids": G,
-                "parallelism": "single GPU" if not sharded else f"R-loop sharded x{world} + {'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce",
+                "parallelism": "single GPU" if not sharded else
+                f"R-loop sharded x{world} + "
+                + ("RCCL uint8 max-reduce inside the C library (c21cm_ionize_sharded)" if shard_c
+                   else f"{'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce via torch.distributed"),
                 "fft": "native" if native else "rocfft",
                 "global_xH": global_xh,
             },
@@ -372,6 +387,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, W)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if shard_c:
+        api.shard_finalize()
     if sharded:
         dist.destroy_process_group()
     if rank == 0:

@@ -152,6 +152,43 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
                               const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
                               void *stream);
 
+/* The same two phases for a recombination model (spec->recomb_model != none): a first crossing
+ * carries the radius (= mean free path) and Gamma_12, so the shard phase leaves 64-bit keys
+ * bits(mfp) << 32 | bits(G12) in `cross_keys[N]` (device) -- non-negative floats order like their
+ * bit patterns -- the caller max-reduces them as unsigned 64-bit integers, and the finish phase
+ * unpacks the winner of every cell (reference: IonisationBox.c:1124-1140). */
+int c21cm_ionize_shard_radii_keys(const c21cm_ionize_spec *spec, int rank, int world,
+                                  const PerturbedField *perturbed_field,
+                                  const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                  const HaloBox *halos, unsigned long long *cross_keys,
+                                  c21cm_ionize_report *report, void *stream);
+int c21cm_ionize_shard_finish_keys(const c21cm_ionize_spec *spec,
+                                   const unsigned long long *cross_keys,
+                                   const PerturbedField *perturbed_field,
+                                   const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                   const HaloBox *halos, IonizedBox *box,
+                                   c21cm_ionize_report *report, void *stream);
+
+/* ---- the sharded R loop behind the C ABI ---------------------------------------------------
+ * One process per GPU; every rank calls c21cm_ionize_sharded with the same (replicated) inputs.
+ * Collectives go through RCCL (librccl resolved at run time with dlopen: inside a PyTorch
+ * process that is torch's own copy, so there is one RCCL per process).  Bootstrap: rank 0
+ * obtains 128 bytes from c21cm_shard_unique_id, the launcher distributes them by any means
+ * (torch.distributed, MPI, a file), every rank calls c21cm_shard_init.  Once initialised,
+ * ComputeIonizedBox itself shards (C21CM_SHARD=0 keeps it single-GPU).
+ * The rank that would own radius index 0 finishes and holds the outputs; with broadcast != 0
+ * they are broadcast so that every rank returns the full box, as a drop-in caller expects. */
+#define C21CM_SHARD_ID_BYTES 128
+int c21cm_shard_unique_id(void *id128);
+int c21cm_shard_init(int rank, int world, const void *id128);
+int c21cm_shard_finalize(void);
+int c21cm_shard_info(int *rank, int *world); /* returns 0 and fills them when initialised */
+int c21cm_shard_owner(int n_radii, int world);
+int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
+                         const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                         const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                         int broadcast, void *stream);
+
 /* filter_box on an explicit geometry: r2c, /N, W(kR) multiply, c2r.
  * reference: src/py21cmfast/src/filtering.c:308-445 (filter_box / test_filter). */
 int c21cm_filter_grid(const float *input, float *output, int nx, int ny, int nz, double box_len,

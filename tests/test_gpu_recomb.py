@@ -111,3 +111,68 @@ def test_recombination_requests_are_validated(api):
         api.ionize_grids(bad, d["density"], d["n_ion"], whalo_sfr=d["whalo_sfr"],
                          prev_nrec=np.zeros((1, 1, 1), np.float32),
                          prev_z_reion=d["prev_z_reion"])
+
+
+@pytest.mark.parametrize("lagrangian,cell", [(True, 0), (False, 1)])
+def test_sharded_key_phases_equal_single_pass(api, lagrangian, cell):
+    """R-loop sharding with a recombination model: each rank's first crossings travel as 64-bit
+    (mean free path, Gamma_12) keys, the max over ranks (emulated here in one process for world =
+    2 and 3) picks the largest ionising radius with ITS Gamma_12, and the finish phase must
+    reproduce the single pass bit for bit."""
+    import torch
+
+    n = 64
+    spec = recomb_spec(n, model=2, cell_recomb=cell, lagrangian=lagrangian)
+    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=21).items()}
+    kw = dict(prev_nrec=d["prev_nrec"], prev_z_reion=d["prev_z_reion"])
+    if lagrangian:
+        kw.update(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"])
+    buf0, _, rep0 = api.ionize_grids(spec, d["density"], **kw)
+    torch.cuda.synchronize()
+    assert 0.03 < float((buf0.mean_free_path > 0).float().mean()) < 0.97
+    for world in (1, 2, 3):
+        reduced = None
+        for rank in range(world):
+            keys = torch.zeros((n, n, n), dtype=torch.int64, device="cuda")
+            api.ionize_shard_radii_keys(spec, rank, world, keys, d["density"], **kw)
+            reduced = keys if reduced is None else torch.maximum(reduced, keys)
+        buf, _, rep = api.ionize_shard_finish_keys(spec, reduced, d["density"], **kw)
+        torch.cuda.synchronize()
+        for name in ("neutral_fraction", "z_reion", "kinetic_temperature", "ionisation_rate_G12",
+                     "mean_free_path", "cumulative_recombinations"):
+            assert torch.equal(getattr(buf0, name), getattr(buf, name)), (world, name)
+        assert rep.global_xH == rep0.global_xH
+
+
+@pytest.mark.parametrize("recomb", [False, True])
+def test_c_level_sharding_on_a_one_rank_communicator(api, recomb):
+    """c21cm_ionize_sharded: shard phase, ncclReduce (RCCL resolved with dlopen, here on a one-rank
+    communicator created through c21cm_shard_unique_id / c21cm_shard_init), finish phase and the
+    output broadcast -- everything the 8-GPU run executes except a second participant."""
+    import torch
+
+    n = 64
+    if recomb:
+        spec = recomb_spec(n, model=2, cell_recomb=0)
+        d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=8).items()}
+        kw = dict(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"], prev_nrec=d["prev_nrec"],
+                  prev_z_reion=d["prev_z_reion"])
+        density = d["density"]
+    else:
+        spec = W.ionize_spec(n, r_bubble_max=12.0)
+        density = torch.from_numpy(W.density_field_numpy(n, seed=3)).cuda()
+        kw = dict(n_ion=W.nion_from_density(density))
+    buf0, _, rep0 = api.ionize_grids(spec, density, **kw)
+    api.shard_init_single()
+    try:
+        buf1, box1, rep1 = api.ionize_sharded(spec, density, broadcast=True, **kw)
+        torch.cuda.synchronize()
+    finally:
+        api.shard_finalize()
+    names = ["neutral_fraction", "z_reion", "kinetic_temperature"]
+    if recomb:
+        names += ["ionisation_rate_G12", "mean_free_path", "cumulative_recombinations"]
+    for name in names:
+        assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
+    assert rep1.global_xH == rep0.global_xH
+    assert 0.03 < float((buf0.neutral_fraction == 0).float().mean()) < 0.97
