@@ -354,6 +354,11 @@ int c21hip_pack_cross_keys(const float *mfp, const float *G12, unsigned long lon
 int c21hip_apply_cross_keys(const unsigned long long *keys, const float *prev_z_reion,
                             int first_snapshot, double redshift, float *xH, float *z_reion,
                             float *G12, float *mfp, size_t ntot, void *stream);
+/* one bit per cell of a first-crossing grid (non-zero -> 1), and the OR of `world` such packed
+ * grids (stride_words apart) expanded back to 0 / 1 bytes: the exchange of a sharded run */
+int c21hip_pack_mask_bits(const unsigned char *fc, unsigned *bits, size_t ntot, void *stream);
+int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
+                               unsigned char *fc, size_t ntot, void *stream);
 int c21hip_sum_float(const float *v, size_t n, double *partials, double *sum_out, void *stream);
 int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
                          const double *mean_dev, unsigned char *first_cross, void *stream);

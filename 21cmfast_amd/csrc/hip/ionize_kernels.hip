@@ -818,6 +818,56 @@ apply_cross_keys_kernel(const unsigned long long *__restrict__ keys,
     }
 }
 
+// The exchange of a sharded run without recombinations only needs "did any radius > 0 ionise the
+// cell" (the finish phase tests the grid for non-zero): one BIT per cell.  pack: 32 cells -> one
+// word (ballot of a half wave would do the same; a word per thread keeps it launch-shape free);
+// or_unpack: the OR of `world` packed grids back into the uint8 grid the finish phase reads.
+__global__ void __launch_bounds__(kBlock)
+pack_mask_bits_kernel(const unsigned char *__restrict__ fc, unsigned *__restrict__ bits,
+                      size_t nwords, size_t ntot) {
+    for (size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x; w < nwords;
+         w += (size_t)gridDim.x * kBlock) {
+        const size_t base = w * 32;
+        unsigned v = 0;
+        if (base + 32 <= ntot) {
+            const uint4 a = reinterpret_cast<const uint4 *>(fc + base)[0];
+            const uint4 b = reinterpret_cast<const uint4 *>(fc + base)[1];
+            const unsigned q[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) v |= ((q[i] >> (8 * j)) & 0xffu) ? (1u << (4 * i + j)) : 0u;
+        } else {
+            for (int i = 0; i < 32 && base + i < ntot; i++) v |= fc[base + i] ? (1u << i) : 0u;
+        }
+        bits[w] = v;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+or_unpack_mask_bits_kernel(const unsigned *__restrict__ bits, size_t stride_words, int world,
+                           unsigned char *__restrict__ fc, size_t nwords, size_t ntot) {
+    for (size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x; w < nwords;
+         w += (size_t)gridDim.x * kBlock) {
+        unsigned v = 0;
+        for (int r = 0; r < world; r++) v |= bits[(size_t)r * stride_words + w];
+        const size_t base = w * 32;
+        if (base + 32 <= ntot) {
+            unsigned q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                q[i] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) q[i] |= ((v >> (4 * i + j)) & 1u) << (8 * j);
+            }
+            reinterpret_cast<uint4 *>(fc + base)[0] = make_uint4(q[0], q[1], q[2], q[3]);
+            reinterpret_cast<uint4 *>(fc + base)[1] = make_uint4(q[4], q[5], q[6], q[7]);
+        } else {
+            for (int i = 0; i < 32 && base + i < ntot; i++) fc[base + i] = (v >> i) & 1u;
+        }
+    }
+}
+
 // set_fully_neutral_box: IonisationBox.c:531-565
 __global__ void __launch_bounds__(kBlock)
 neutral_box_kernel(const float *__restrict__ density, const float *__restrict__ xe,
@@ -1238,6 +1288,24 @@ extern "C" int c21hip_apply_first_cross(const unsigned char *first_cross,
     hipLaunchKernelGGL(apply_first_cross_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
                        (hipStream_t)stream, first_cross, prev_z_reion, first_snapshot,
                        (float)redshift, xH, z_reion, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_pack_mask_bits(const unsigned char *fc, unsigned *bits, size_t ntot,
+                                     void *stream) {
+    const size_t nwords = (ntot + 31) / 32;
+    hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(grid_for(nwords)), dim3(kBlock), 0,
+                       (hipStream_t)stream, fc, bits, nwords, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
+                                          unsigned char *fc, size_t ntot, void *stream) {
+    const size_t nwords = (ntot + 31) / 32;
+    hipLaunchKernelGGL(or_unpack_mask_bits_kernel, dim3(grid_for(nwords)), dim3(kBlock), 0,
+                       (hipStream_t)stream, bits, stride_words, world, fc, nwords, ntot);
     LAUNCH_CHECK();
     return 0;
 }

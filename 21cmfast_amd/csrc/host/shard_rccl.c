@@ -9,10 +9,11 @@
  *                 first-crossing grid (c21cm_ionize_shard_radii), or -- with a recombination
  *                 model -- into 64-bit (mean free path, Gamma_12) keys
  *                 (c21cm_ionize_shard_radii_keys)
- *   exchange      ONE ncclReduce(max) of that grid onto the rank that owns radius index 0
- *                 (N bytes, or 8 N with recombinations); "the largest radius that ionises the
- *                 cell" is order independent, so the result equals the sequential loop
- *                 (reference: src/py21cmfast/src/IonisationBox.c:1531-1588)
+ *   exchange      onto the rank that owns radius index 0: the uint8 grid packed to one bit per
+ *                 cell and gathered point-to-point (N/8 bytes per link, OR on arrival), or
+ *                 ONE ncclReduce(max) of the 64-bit keys with recombinations; "the largest
+ *                 radius that ionises the cell" is order independent, so the result equals the
+ *                 sequential loop (reference: src/py21cmfast/src/IonisationBox.c:1531-1588)
  *   finish        that rank applies the reduced grid, runs the cell-scale radius and the
  *                 post-loop, and (optionally) broadcasts the outputs
  * A reduce onto the finishing rank replaces the all-reduce of the plan: nobody else needs the
@@ -45,10 +46,52 @@ static struct {
     int (*comm_destroy)(rccl_comm);
     int (*reduce)(const void *, void *, size_t, int, int, int, rccl_comm, void *);
     int (*broadcast)(const void *, void *, size_t, int, int, rccl_comm, void *);
+    int (*send)(const void *, size_t, int, int, rccl_comm, void *);
+    int (*recv)(void *, size_t, int, int, rccl_comm, void *);
+    int (*group_start)(void);
+    int (*group_end)(void);
     const char *(*error_string)(int);
 } R;
 
-enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142 };
+enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142, WS_SHARD_BITS = 143 };
+
+static int rccl_check(int rc, const char *what);
+
+/* The exchange of the uint8 first-crossing grid.  The finish phase only tests it for non-zero,
+ * so ONE BIT per cell suffices: every rank packs its grid (N/8 bytes), the finishing rank
+ * receives the packed grids of all others at once -- point-to-point, so its seven xGMI links
+ * carry one grid each in parallel -- and ORs them back into a byte grid.  At 1024^3 that is
+ * 134 MB per link (~1.3 ms at ~100 GB/s) against a 1.07 GB ring reduce whose every step is bound
+ * by one link (~10 ms).  C21CM_SHARD_EXCHANGE=reduce keeps ncclReduce(uint8, max), which also
+ * preserves the radius index in the grid (nothing downstream reads it). */
+static int exchange_mask(unsigned char *fc, size_t ntot, int owner, void *stream) {
+    const char *e = getenv("C21CM_SHARD_EXCHANGE");
+    if ((e && e[0] == 'r') || !R.send || !R.recv || !R.group_start || !R.group_end)
+        return rccl_check(R.reduce(fc, fc, ntot, RCCL_UINT8, RCCL_MAX, owner, R.comm, stream),
+                          "ncclReduce(first_cross)");
+    const size_t nwords = (ntot + 31) / 32;
+    const int slots = (R.rank == owner) ? R.world : 1;
+    unsigned *bits = (unsigned *)c21hip_ws(WS_SHARD_BITS, sizeof(unsigned) * nwords * (size_t)slots);
+    if (!bits) return C21CM_MEMORY_ALLOC_ERROR;
+    int st = c21hip_pack_mask_bits(fc, bits + (R.rank == owner ? (size_t)owner * nwords : 0), ntot,
+                                   stream);
+    if (st) return st;
+    if (R.world == 1) return c21hip_or_unpack_mask_bits(bits, nwords, 1, fc, ntot, stream);
+    if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+    if (R.rank == owner) {
+        for (int r = 0; r < R.world && !st; r++)
+            if (r != owner)
+                st = rccl_check(R.recv(bits + (size_t)r * nwords, nwords * sizeof(unsigned),
+                                       RCCL_UINT8, r, R.comm, stream), "ncclRecv(mask bits)");
+    } else {
+        st = rccl_check(R.send(bits, nwords * sizeof(unsigned), RCCL_UINT8, owner, R.comm, stream),
+                        "ncclSend(mask bits)");
+    }
+    const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+    if (st || st2) return st ? st : st2;
+    if (R.rank == owner) return c21hip_or_unpack_mask_bits(bits, nwords, R.world, fc, ntot, stream);
+    return 0;
+}
 
 static int rccl_load(void) {
     if (R.lib) return 0;
@@ -63,6 +106,10 @@ static int rccl_load(void) {
     *(void **)&R.comm_destroy = dlsym(R.lib, "ncclCommDestroy");
     *(void **)&R.reduce = dlsym(R.lib, "ncclReduce");
     *(void **)&R.broadcast = dlsym(R.lib, "ncclBroadcast");
+    *(void **)&R.send = dlsym(R.lib, "ncclSend");
+    *(void **)&R.recv = dlsym(R.lib, "ncclRecv");
+    *(void **)&R.group_start = dlsym(R.lib, "ncclGroupStart");
+    *(void **)&R.group_end = dlsym(R.lib, "ncclGroupEnd");
     *(void **)&R.error_string = dlsym(R.lib, "ncclGetErrorString");
     if (!R.get_unique_id || !R.comm_init_rank || !R.comm_destroy || !R.reduce || !R.broadcast) {
         c21hip_set_error("shard: librccl lacks an expected symbol");
@@ -162,9 +209,7 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
         if ((st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box,
                                            spin_temp, halos, fc, need_means ? &local : NULL, stream)))
             return st;
-        if ((st = rccl_check(R.reduce(fc, fc, ntot, RCCL_UINT8, RCCL_MAX, owner, R.comm, stream),
-                             "ncclReduce(first_cross)")))
-            return st;
+        if ((st = exchange_mask(fc, ntot, owner, stream))) return st;
         if (need_means) {
             double *d = (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean));
             if (!d) return C21CM_MEMORY_ALLOC_ERROR;
