@@ -375,7 +375,7 @@ def main():
                 "hii_dim": n, "n_radii": spec.n_radii, "filtered_grids": G,
                 "parallelism": "single GPU" if not sharded else
                 f"R-loop sharded x{world} + "
-                + ("RCCL uint8 max-reduce inside the C library (c21cm_ionize_sharded)" if shard_c
+                + ("1-bit mask gather over RCCL inside the C library (c21cm_ionize_sharded)" if shard_c
                    else f"{'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce via torch.distributed"),
                 "fft": "native" if native else "rocfft",
                 "global_xH": global_xh,

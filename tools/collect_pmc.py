@@ -30,7 +30,7 @@ def kernel_sources_sha() -> str:
         h.update((ROOT / rel).read_bytes())
     return h.hexdigest()[:16]
 
-KERNELS = {
+KERNELS = {  # the needles follow rocprofv3's demangled names; N = 512 is the benchmark config
     "pass_x_window": "line_pass_kernel<512, 1, 3>",
     "pass_x_pair": "line_pass_kernel<512, 1, 5>",
     "pass_y": "line_pass_kernel<512, 1, 0>",
