@@ -121,8 +121,8 @@ def cpu_baseline(args, W):
     big = max(args.cpu_dim, 256) if all_cores >= 16 else args.cpu_dim
     variants = {
         "threaded": run(big, all_cores, 0, full.n_radii),
-        "faithful_fft": run(big, all_cores, 1, 6),
-        "one_thread": run(128, 1, 1, 10),
+        "faithful_fft": run(big, all_cores, 1, 12),
+        "one_thread": run(128, 1, 1, full.n_radii),
     }
     best = max(variants, key=lambda k: variants[k]["value"])
     v = variants[best]

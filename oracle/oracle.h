@@ -9,11 +9,19 @@
  *
  * Pinning status: the reference itself cannot be built in this image (FFTW and
  * GSL headers/libraries are absent, Python is 3.10 < 3.12), so
- * the oracle is pinned by the reference's analytic known-answer tests
- * (tests/test_filtering.py:111-236, tests/test_perturb.py:108-135,
- * tests/test_initial_conditions.py:153-178) restated in tests/test_oracle_*.py.
- * Per-cell xH parity with upstream is "parity unpinned" (no upstream test pins
- * per-cell values either).
+ * the oracle is pinned through what the reference HOLDS:
+ *  (1) its HDF5 fixtures (tests/golden/reference/*.h5, copied data files of the
+ *      reference's tests/test_data): with the reference's GSL random stream
+ *      restated (oracle_gslrng.c), seed 12345 gives the reference's universe and
+ *      the chain ICs -> PerturbedField -> [HaloBox ->] IonizedBox -> BrightnessTemp,
+ *      incl. the recombination models evolved over 18 snapshots, reproduces the
+ *      reference's binned power spectra / PDFs at the reference's own tolerances
+ *      (tests/test_reference_fixtures*.py);
+ *  (2) its analytic known-answer tests (tests/test_filtering.py:111-236,
+ *      tests/test_perturb.py:108-135, tests/test_initial_conditions.py:153-178)
+ *      restated in tests/test_oracle_*.py.
+ * Still unpinned: per-cell xH of a mid-reionisation box (no upstream vector
+ * exists; all fixtures are at z = 18).
  *
  * The oracle shares the public struct definitions of include/c21cm_grid.h so
  * that one spec drives both implementations.

@@ -4,8 +4,9 @@ TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` an
 ``cpu_baseline`` leg of ``bench.py``.  Nothing under ``21cmfast_amd/`` imports it.
 
 Parity pinning: see ``oracle/oracle.h`` -- the reference cannot be built or imported in
-this image, so the oracle is pinned by the reference's analytic known-answer tests
-(restated in ``tests/test_oracle_*.py``); per-cell xH parity with upstream is unpinned.
+this image, so the oracle is pinned by the reference's own HDF5 fixtures (same seed, same
+universe: ``tests/test_reference_fixtures*.py``) and by its analytic known-answer tests
+(restated in ``tests/test_oracle_*.py``).
 """
 
 from __future__ import annotations
