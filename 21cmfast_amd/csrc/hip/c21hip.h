@@ -45,6 +45,7 @@ int c21hip_fft_c2r(float *padded, int nx, int ny, int nz, void *stream);
 void c21hip_fft_release(void);
 /* 1 when the hand-written power-of-two transform is used, 0 for rocFFT */
 int c21hip_fft_is_native(int nx, int ny, int nz);
+int c21hip_pair_sweep_supported(int nx); /* two line tiles of nx points fit in LDS */
 
 /* ---- fft_native.hip : power-of-two transform on the split k-space layout ----
  * split layout: complex main[nx][ny][nz/2] followed by the Nyquist plane nyq[nx][ny]. */

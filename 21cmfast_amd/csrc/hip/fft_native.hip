@@ -106,6 +106,19 @@ struct Dft<2, SIGN> {
     }
 };
 template <int SIGN>
+struct Dft<3, SIGN> {
+    __device__ __forceinline__ static void run(float2 *v) {
+        // y0 = a + b + c,  y1,2 = a - (b + c)/2 +- SIGN i (sqrt(3)/2) (b - c)
+        const float2 a = v[0], s = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+        const float h = 0.86602540378443864676f;
+        const float2 m = make_float2(a.x - 0.5f * s.x, a.y - 0.5f * s.y);
+        const float2 r = mul_i<SIGN>(make_float2(h * d.x, h * d.y));
+        v[0] = cadd(a, s);
+        v[1] = cadd(m, r);
+        v[2] = csub(m, r);
+    }
+};
+template <int SIGN>
 struct Dft<4, SIGN> {
     __device__ __forceinline__ static void run(float2 *v) {
         float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
@@ -265,24 +278,30 @@ __device__ __forceinline__ void stockham_stage(float2 *tile, const float2 *tw, i
     __syncthreads();
 }
 
-// Full length-N transform of every column of the tile (radix plan 8,8,..,{4,2}).
+// Full length-N transform of every column of the tile, N = 2^L or 3 * 2^L: radix plan
+// 8,8,..,{4,2} and, for the factor 3 of the reference's default DIM = 3 HII_DIM grids, one radix-3
+// stage LAST -- every earlier stage then has a power-of-two stride s (shift / mask indexing), and
+// the last stage of a Stockham plan has p = 0: no twiddles, outputs in place at b + j N/3.
 template <int N, int COLS, int ROW, int SIGN, int THREADS>
 __device__ __forceinline__ void fft_tile(float2 *tile, const float2 *tw) {
-    static_assert((N & (N - 1)) == 0 && N >= 8, "power-of-two line length");
-    int log2s = 0;
     constexpr int L = __builtin_ctz(N);
+    constexpr int ODD = N >> L;
+    static_assert((ODD == 1 || ODD == 3) && N >= 8, "line length 2^L or 3 * 2^L");
+    int log2s = 0;
     constexpr int N8 = L / 3;   // radix-8 stages
     constexpr int REM = L % 3;  // 0, 1 (radix 2) or 2 (radix 4)
+    constexpr bool P2LAST = (ODD == 1);  // the power-of-two stages end the plan
 #pragma unroll
     for (int st = 0; st < N8; st++) {
-        if (REM == 0 && st == N8 - 1)
+        if (P2LAST && REM == 0 && st == N8 - 1)
             stockham_stage<N, COLS, ROW, 8, SIGN, true, THREADS>(tile, tw, log2s);
         else
             stockham_stage<N, COLS, ROW, 8, SIGN, false, THREADS>(tile, tw, log2s);
         log2s += 3;
     }
-    if (REM == 1) stockham_stage<N, COLS, ROW, 2, SIGN, true, THREADS>(tile, tw, log2s);
-    if (REM == 2) stockham_stage<N, COLS, ROW, 4, SIGN, true, THREADS>(tile, tw, log2s);
+    if (REM == 1) stockham_stage<N, COLS, ROW, 2, SIGN, P2LAST, THREADS>(tile, tw, log2s);
+    if (REM == 2) stockham_stage<N, COLS, ROW, 4, SIGN, P2LAST, THREADS>(tile, tw, log2s);
+    if (ODD == 3) stockham_stage<N, COLS, ROW, 3, SIGN, true, THREADS>(tile, tw, L);
 }
 
 // Line transform of a whole tile.  N < 1024: the Stockham plan, natural order out.  N = 1024:
@@ -651,7 +670,8 @@ struct LineThreads {
 #ifdef C21_EXP_T1024
     static constexpr int value = (N >= 1024) ? 1024 : ((N >= 128) ? 512 : 256);
 #else
-    static constexpr int value = (N >= 128) ? 512 : 256;
+    // (the loader needs N/2 = rows per sweep x row pairs per thread: 192-point lines take 256)
+    static constexpr int value = (N >= 128 && N != 192) ? 512 : 256;
 #endif
 };
 
@@ -1554,7 +1574,7 @@ template <int N, int SIGN>
 int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
     if (SIGN > 0 && fmode == 3) return launch_line_pass_mode<N, +1, 3>(a, stream);
     if (SIGN > 0 && fmode == 4) return launch_line_pass_mode<N, +1, 4>(a, stream);
-    if constexpr (N < 1024)  // two radii per sweep: two tiles in LDS
+    if constexpr (N <= 512)  // two radii per sweep: two tiles in LDS
         if (SIGN > 0 && fmode == 5) return launch_line_pass_mode<N, +1, 5>(a, stream);
     return launch_line_pass_mode<N, SIGN, 0>(a, stream);
 }
@@ -1564,8 +1584,11 @@ int dispatch_line_pass(int n, const LinePassArgs &a, int fmode, hipStream_t stre
     switch (n) {
         case 64: return launch_line_pass<64, SIGN>(a, fmode, stream);
         case 128: return launch_line_pass<128, SIGN>(a, fmode, stream);
+        case 192: return launch_line_pass<192, SIGN>(a, fmode, stream);
         case 256: return launch_line_pass<256, SIGN>(a, fmode, stream);
+        case 384: return launch_line_pass<384, SIGN>(a, fmode, stream);
         case 512: return launch_line_pass<512, SIGN>(a, fmode, stream);
+        case 768: return launch_line_pass<768, SIGN>(a, fmode, stream);
         case 1024: return launch_line_pass<1024, SIGN>(a, fmode, stream);
         default:
             c21hip_set_error("native FFT: unsupported line length %d", n);
@@ -2187,8 +2210,11 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
     switch (nz) {
         case 64: return launch_z_fused<64>(a, nlines, stream);
         case 128: return launch_z_fused<128>(a, nlines, stream);
+        case 192: return launch_z_fused<192>(a, nlines, stream);
         case 256: return launch_z_fused<256>(a, nlines, stream);
+        case 384: return launch_z_fused<384>(a, nlines, stream);
         case 512: return launch_z_fused<512>(a, nlines, stream);
+        case 768: return launch_z_fused<768>(a, nlines, stream);
         case 1024: return launch_z_fused<1024>(a, nlines, stream);
         default:
             c21hip_set_error("native FFT: unsupported z length %d for the fused pass", nz);
@@ -2233,8 +2259,11 @@ int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
     switch (nz) {
         case 64: return launch_z_r2c<64>(a, nlines, stream);
         case 128: return launch_z_r2c<128>(a, nlines, stream);
+        case 192: return launch_z_r2c<192>(a, nlines, stream);
         case 256: return launch_z_r2c<256>(a, nlines, stream);
+        case 384: return launch_z_r2c<384>(a, nlines, stream);
         case 512: return launch_z_r2c<512>(a, nlines, stream);
+        case 768: return launch_z_r2c<768>(a, nlines, stream);
         case 1024: return launch_z_r2c<1024>(a, nlines, stream);
         case 2048: return launch_z_r2c<2048>(a, nlines, stream);
         default:
@@ -2263,8 +2292,11 @@ int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) 
     switch (nz) {
         case 64: return launch_z_c2r<64, EPI>(a, nlines, stream);
         case 128: return launch_z_c2r<128, EPI>(a, nlines, stream);
+        case 192: return launch_z_c2r<192, EPI>(a, nlines, stream);
         case 256: return launch_z_c2r<256, EPI>(a, nlines, stream);
+        case 384: return launch_z_c2r<384, EPI>(a, nlines, stream);
         case 512: return launch_z_c2r<512, EPI>(a, nlines, stream);
+        case 768: return launch_z_c2r<768, EPI>(a, nlines, stream);
         case 1024: return launch_z_c2r<1024, EPI>(a, nlines, stream);
         case 2048: return launch_z_c2r<2048, EPI>(a, nlines, stream);
         default:
@@ -2308,10 +2340,16 @@ void fill_filter(FilterParams &fp, int filter_type, float R, float R_param, doub
 }  // namespace
 
 // nx, ny in {64..1024}, nz in {64..2048}, all powers of two
-extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz) {
-    return pow2(nx) && pow2(ny) && pow2(nz) && nx >= 64 && nx <= 1024 && ny >= 64 &&
-           ny <= 1024 && nz >= 64 && nz <= 2048;
+// line lengths of the native passes: 2^L (64 .. 1024; z-lines up to 2048) and 3 * 2^L for the
+// reference's default DIM = 3 HII_DIM grids (192, 384, 768; 1536 would need a 196 KB tile)
+static bool native_len(int n, int pow2_max) {
+    return (pow2(n) && n >= 64 && n <= pow2_max) || n == 192 || n == 384 || n == 768;
 }
+extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz) {
+    return native_len(nx, 1024) && native_len(ny, 1024) && native_len(nz, 2048);
+}
+// two radii per pass-X sweep need two line tiles in LDS
+extern "C" int c21hip_pair_sweep_supported(int nx) { return nx <= 512; }
 
 extern "C" size_t c21hip_split_floats(int nx, int ny, int nz) {
     return 2 * ((size_t)nx * ny * (size_t)(nz / 2) + (size_t)nx * ny);

@@ -351,7 +351,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
                                 stream);
         if (status) return status;
     }
-    if (c->fused && c->nx < 1024) {
+    if (c->fused && c21hip_pair_sweep_supported(c->nx)) {
         /* pass X reads each spectrum tile once for two consecutive radii (C21CM_PAIR_RADII=0:
          * one radius per sweep) */
         const char *e = getenv("C21CM_PAIR_RADII");

@@ -167,7 +167,7 @@ def kernel_roofline(args, spec, torch):
     N = float(n) ** 3
     S = 8.0 * (N / 2 + n * n)
     alg = {0: 4 * S, 1: 4 * S, 2: 2 * S + 2 * N, 4: 0.0, 6: 6 * S}
-    paired = (os.environ.get("C21CM_PAIR_RADII", "1") != "0" and n < 1024
+    paired = (os.environ.get("C21CM_PAIR_RADII", "1") != "0" and n <= 512
               and spec.fcoll_mode == importlib.import_module("21cmfast_amd.workloads").FCOLL_STARS)
     n_fused = spec.n_radii - 1  # launches per step (radius index 0 is the final sweep)
     launches = {0: n_fused % 2 if paired else n_fused, 6: n_fused // 2 if paired else 0,

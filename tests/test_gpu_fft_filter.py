@@ -16,7 +16,11 @@ def api(gpu_lib):
 
 
 @pytest.mark.parametrize("shape", [(16, 16, 16), (35, 35, 35), (50, 50, 50), (64, 64, 64),
-                                   (70, 70, 35), (128, 128, 128), (150, 150, 150)])
+                                   (70, 70, 35), (128, 128, 128), (150, 150, 150),
+                                   # 3 * 2^L lines of the default DIM = 3 HII_DIM grids: native
+                                   # passes with a final radix-3 stage
+                                   (192, 192, 192), (384, 192, 64), (64, 384, 192),
+                                   (192, 64, 768), (96, 96, 96)])
 def test_fft_roundtrip_and_spectrum(api, oracle, shape):
     import torch
 
@@ -34,6 +38,35 @@ def test_fft_roundtrip_and_spectrum(api, oracle, shape):
     api.fft_c2r(d, nx, ny, nz)
     back = d.cpu().numpy()[:, :, :nz] / (nx * ny * nz)
     np.testing.assert_allclose(back, a, atol=2e-5)
+
+
+def test_radix3_sizes_run_on_the_native_passes(gpu_lib):
+    """192 / 384 / 768-point lines leave rocFFT (the reference's default is DIM = 3 HII_DIM,
+    wrapper/inputs.py:915); 96 and 1536 do not (loader geometry / a 196 KB tile)."""
+    for n in (192, 384, 768):
+        assert gpu_lib.c21hip_fft_is_native(n, n, n)
+        assert gpu_lib.c21hip_fft_is_native(256, n, 64)
+    for n in (96, 1536, 150, 320):
+        assert not gpu_lib.c21hip_fft_is_native(n, n, n)
+
+
+def test_fft_768_against_numpy(api):
+    """A full 768-point transform along every axis (thin box) against numpy in double."""
+    import torch
+
+    shape = (768, 64, 768)
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal(shape).astype(np.float32)
+    pad = np.zeros((shape[0], shape[1], shape[2] + 2), np.float32)
+    pad[:, :, :shape[2]] = a
+    d = torch.from_numpy(pad).cuda()
+    api.fft_r2c(d, *shape)
+    spec = d.cpu().numpy().view(np.complex64).reshape(shape[0], shape[1], shape[2] // 2 + 1)
+    ref = np.fft.rfftn(a.astype(np.float64))
+    assert np.abs(spec - ref).max() <= 3e-5 * np.abs(ref).max()
+    api.fft_c2r(d, *shape)
+    back = d.cpu().numpy()[:, :, :shape[2]] / float(np.prod(shape))
+    np.testing.assert_allclose(back, a, atol=3e-5)
 
 
 def test_fft_linearity_large(api):
@@ -59,7 +92,7 @@ def test_delta_function_known_answer_device(api, filter_type, R):
 
 
 @pytest.mark.parametrize("shape", [(50, 50, 50), (64, 64, 64), (48, 48, 96), (64, 64, 128),
-                                   (128, 128, 64)])
+                                   (128, 128, 64), (192, 192, 64), (64, 64, 192)])
 @pytest.mark.parametrize("filter_type,R,R_param", [(0, 3.0, 0.0), (0, 12.0, 0.0), (1, 6.0, 0.0),
                                                    (2, 4.0, 0.0), (3, 7.5, 37.66), (4, 5.0, 9.0)])
 def test_filter_matches_oracle_random_box(api, oracle, shape, filter_type, R, R_param):

@@ -29,7 +29,8 @@ def compare(got, ref, names=None):
 
 
 @pytest.mark.parametrize("dim,hii_dim,device", [(24, 8, None), (32, 16, "cuda"), (64, 32, "cuda"),
-                                                (128, 64, "cuda"), (20, 10, None)])
+                                                (128, 64, "cuda"), (20, 10, None),
+                                                (192, 64, "cuda")])  # DIM = 3 HII_DIM, native 192
 def test_sampled_ics_match_oracle(api, oracle, dim, hii_dim, device):
     spec = ics_spec(dim, hii_dim, box_len=3.0 * hii_dim, seed=99)
     ref = oracle.ics_grids(spec)

@@ -75,7 +75,7 @@ def run_device(api, spec, density, n_ion=None, device_resident=False, **kw):
 
 
 @pytest.mark.parametrize("n,device_resident", [(32, False), (64, True), (50, False), (35, True),
-                                               (128, True)])
+                                               (128, True), (192, True)])
 def test_lagrangian_two_grid_parity(api, oracle, n, device_resident):
     """Config-3 semantics (G = 2: delta top-hat + n_ion exp-MFP) at oracle-sized boxes,
     including the odd sizes the reference's test-suite uses (35, 50)."""
