@@ -185,7 +185,7 @@ static int ics_split_supported(const c21cm_ics_spec *s) {
     if (s->dim == s->hii_dim && s->dim_z == s->hii_dim_z) return 1;
     if (s->perturb_on_high_res && s->dim % s->hii_dim) return 0;
     const int f = s->dim / s->hii_dim;
-    if ((f != 2 && f != 4) || s->hii_dim * f != s->dim || s->hii_dim_z * f != s->dim_z) return 0;
+    if ((f != 2 && f != 3 && f != 4) || s->hii_dim * f != s->dim || s->hii_dim_z * f != s->dim_z) return 0;
     return c21hip_fft_is_native(s->hii_dim, s->hii_dim, s->hii_dim_z) &&
            !c21hip_split_xblock_log2(s->hii_dim);
 }

@@ -50,6 +50,8 @@ def test_option_branches(api, oracle, opts):
     (128, 64, "cuda", dict(algorithm=1)),       # Zel'dovich only
     (128, 64, None, dict(hires=1, algorithm=1)),
     (64, 64, "cuda", {}),                       # DIM == HII_DIM: no filter, no fold
+    (192, 64, "cuda", {}),                      # the reference's default DIM = 3 HII_DIM: fold by 3
+    (384, 128, None, dict(hires=1)),
 ])
 def test_split_layout_pipeline_matches_oracle(api, oracle, dim, hii_dim, device, opts):
     """The split-layout pipeline (native transform sizes): spectra in the split layout, dense
