@@ -667,12 +667,9 @@ __device__ __forceinline__ int mirror_row(int row_a) {
 // VGPRs: room for the two register sets), else 256.
 template <int N, int FMODE = 0>
 struct LineThreads {
-#ifdef C21_EXP_T1024
-    static constexpr int value = (N >= 1024) ? 1024 : ((N >= 128) ? 512 : 256);
-#else
-    // (the loader needs N/2 = rows per sweep x row pairs per thread: 192-point lines take 256)
+    // (the loader needs N/2 = rows per sweep x row pairs per thread: 192-point lines take 256;
+    //  1024 threads for 1024-point lines spill 13-38 VGPRs at the 128-register budget: DESIGN 8.1)
     static constexpr int value = (N >= 128 && N != 192) ? 512 : 256;
-#endif
 };
 
 // the geometry of one work item, in wave-uniform registers
@@ -790,22 +787,14 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // Two radii per sweep: ONE set.  The next tile's loads go out before the two transforms of
     // this one, which is the look-ahead two sets buy the single-radius pass; the second set only
     // cost registers there (256 VGPRs + 84 bytes of scratch; 0.95 against 0.89 ms at 512^3).
-#ifdef C21_EXP_T1024_2SETS
-    constexpr bool TWO_SETS = !PAIR;
-#else
     constexpr bool TWO_SETS = (N < 1024) && !PAIR;
-#endif
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
     // Lines of 256 points and fewer load the next window straight into `cur` (it is dead between
     // a tile's LDS write and the next tile's): 10 % faster there (two workgroups per CU share the
     // register file), 3-6 % slower at 512 and 1024 points, which keep the separate `pre` set.
-#if defined(C21_EXP_T1024) || defined(C21_EXP_NOWPRE)
-    constexpr bool WPRE = (N == 512);
-#else
     constexpr bool WPRE = (N >= 512);
-#endif
     float2 wpre[NR][WPRE ? NP : 1], wcur[NR][NP], wpre_half[NR], wcur_half[NR];
     auto w_reload = [&](const LineItem &it, int m) {
         const int mi = it.npair == 2 ? (m & 1) : 0;

@@ -2,6 +2,9 @@
 import ctypes as C
 import importlib
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 import torch
 
