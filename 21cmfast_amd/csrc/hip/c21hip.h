@@ -360,6 +360,7 @@ int c21hip_apply_cross_keys(const unsigned long long *keys, const float *prev_z_
 int c21hip_pack_mask_bits(const unsigned char *fc, unsigned *bits, size_t ntot, void *stream);
 int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
                                unsigned char *fc, size_t ntot, void *stream);
+int c21hip_max_into(void *dst, const void *src, size_t count, int bytes_per_element, void *stream);
 int c21hip_sum_float(const float *v, size_t n, double *partials, double *sum_out, void *stream);
 int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
                          const double *mean_dev, unsigned char *first_cross, void *stream);

@@ -1292,6 +1292,31 @@ extern "C" int c21hip_apply_first_cross(const unsigned char *first_cross,
     return 0;
 }
 
+// element-wise max of two device arrays (uint8 or uint64), dst = max(dst, src): the in-process
+// stand-in for ncclReduce(max) of the sharding emulation hook (c21cm_shard_emulate)
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+max_into_kernel(T *__restrict__ dst, const T *__restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+        dst[i] = src[i] > dst[i] ? src[i] : dst[i];
+}
+
+extern "C" int c21hip_max_into(void *dst, const void *src, size_t count, int bytes_per_element,
+                               void *stream) {
+    if (bytes_per_element == 1)
+        hipLaunchKernelGGL((max_into_kernel<unsigned char>), dim3(grid_for(count)), dim3(kBlock), 0,
+                           (hipStream_t)stream, (unsigned char *)dst, (const unsigned char *)src,
+                           count);
+    else if (bytes_per_element == 8)
+        hipLaunchKernelGGL((max_into_kernel<unsigned long long>), dim3(grid_for(count)),
+                           dim3(kBlock), 0, (hipStream_t)stream, (unsigned long long *)dst,
+                           (const unsigned long long *)src, count);
+    else
+        return C21CM_VALUE_ERROR;
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int c21hip_pack_mask_bits(const unsigned char *fc, unsigned *bits, size_t ntot,
                                      void *stream) {
     const size_t nwords = (ntot + 31) / 32;

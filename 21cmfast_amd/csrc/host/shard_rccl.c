@@ -93,8 +93,87 @@ static int exchange_mask(unsigned char *fc, size_t ntot, int owner, void *stream
     return 0;
 }
 
+/* ---- in-process emulation of the transport (test hook) -------------------------------------
+ * The boxes this is developed on have one GPU, and RCCL refuses two ranks on one device.  To
+ * exercise c21cm_ionize_sharded for world > 1 anyway -- the radius deal, the slot arithmetic of
+ * the bit gather, the key reduce, the owner's finish -- the ranks can be run ONE AFTER THE OTHER in
+ * a single process (non-owners first, the owner last) against a device "mailbox":
+ *   send(peer)      copies into the mailbox region of the sending rank
+ *   recv(peer)      copies out of the mailbox region of `peer`
+ *   reduce(max)     non-root: mailbox = max(mailbox, buf);  root: buf = max(buf, mailbox)
+ * (the mailbox must be zeroed before a round).  Only the transport is replaced; everything else
+ * is the code the 8-GPU run executes.  Broadcasts are not emulated (the root would have to run
+ * first). */
+static struct {
+    unsigned char *box;
+    size_t bytes;
+} EMU;
+
+static int emu_region(size_t count_bytes, int rank, unsigned char **p) {
+    if (!EMU.box || (size_t)(rank + 1) * count_bytes > EMU.bytes) {
+        c21hip_set_error("shard emulation: mailbox too small");
+        return 1;
+    }
+    *p = EMU.box + (size_t)rank * count_bytes;
+    return 0;
+}
+static int emu_send(const void *buf, size_t count, int dtype, int peer, rccl_comm comm, void *stream) {
+    (void)dtype, (void)peer, (void)comm;
+    unsigned char *p;
+    if (emu_region(count, R.rank, &p)) return 1;
+    return c21hip_d2d(p, buf, count, stream);
+}
+static int emu_recv(void *buf, size_t count, int dtype, int peer, rccl_comm comm, void *stream) {
+    (void)dtype, (void)comm;
+    unsigned char *p;
+    if (emu_region(count, peer, &p)) return 1;
+    return c21hip_d2d(buf, p, count, stream);
+}
+static int emu_reduce(const void *send, void *recv, size_t count, int dtype, int op, int root,
+                      rccl_comm comm, void *stream) {
+    (void)comm;
+    const int width = dtype == RCCL_UINT8 ? 1 : (dtype == RCCL_UINT64 ? 8 : 0);
+    if (!width || op != RCCL_MAX || send != recv || count * (size_t)width > EMU.bytes) {
+        c21hip_set_error("shard emulation: only in-place max-reduces of uint8 / uint64 fit the mailbox");
+        return 1;
+    }
+    return R.rank == root ? c21hip_max_into(recv, EMU.box, count, width, stream)
+                          : c21hip_max_into(EMU.box, send, count, width, stream);
+}
+static int emu_bcast(const void *s, void *r, size_t n, int t, int root, rccl_comm c, void *st) {
+    (void)s, (void)r, (void)n, (void)t, (void)root, (void)c, (void)st;
+    c21hip_set_error("shard emulation: broadcasts are not emulated");
+    return 1;
+}
+static int emu_group(void) { return 0; }
+static const char *emu_error(int rc) {
+    (void)rc;
+    return "emulated transport";
+}
+
+int c21cm_shard_emulate(int rank, int world, void *mailbox, size_t mailbox_bytes) {
+    if (world < 1 || rank < 0 || rank >= world || !mailbox || !c21hip_is_device_ptr(mailbox)) {
+        c21hip_set_error("shard emulation: bad rank / world / mailbox");
+        return C21CM_VALUE_ERROR;
+    }
+    R.comm = NULL;
+    R.reduce = emu_reduce;
+    R.broadcast = emu_bcast;
+    R.send = emu_send;
+    R.recv = emu_recv;
+    R.group_start = R.group_end = emu_group;
+    R.error_string = emu_error;
+    R.comm_destroy = NULL;
+    EMU.box = (unsigned char *)mailbox;
+    EMU.bytes = mailbox_bytes;
+    R.rank = rank;
+    R.world = world;
+    R.ready = 2; /* emulated */
+    return 0;
+}
+
 static int rccl_load(void) {
-    if (R.lib) return 0;
+    if (R.lib && R.ready != 2 && R.get_unique_id) return 0;
     const char *names[] = {"librccl.so.1", "librccl.so", NULL};
     for (int i = 0; names[i] && !R.lib; i++) R.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!R.lib) {
@@ -125,6 +204,7 @@ static int rccl_check(int rc, const char *what) {
 }
 
 int c21cm_shard_unique_id(void *id128) {
+    if (R.ready == 2) c21cm_shard_finalize(); /* leave the emulated transport first */
     int st = rccl_load();
     if (st) return st;
     if (!id128) return C21CM_VALUE_ERROR;
@@ -135,6 +215,7 @@ int c21cm_shard_unique_id(void *id128) {
 }
 
 int c21cm_shard_init(int rank, int world, const void *id128) {
+    if (R.ready == 2) c21cm_shard_finalize();
     int st = rccl_load();
     if (st) return st;
     if (!id128 || world < 1 || rank < 0 || rank >= world) {
@@ -152,7 +233,12 @@ int c21cm_shard_init(int rank, int world, const void *id128) {
 }
 
 int c21cm_shard_finalize(void) {
-    if (R.ready && R.comm) (void)R.comm_destroy(R.comm);
+    if (R.ready == 1 && R.comm && R.comm_destroy) (void)R.comm_destroy(R.comm);
+    if (R.ready == 2) { /* drop the emulated transport: the next init resolves RCCL again */
+        R.reduce = NULL;
+        R.get_unique_id = NULL;
+        EMU.box = NULL;
+    }
     R.comm = NULL;
     R.ready = 0;
     return 0;

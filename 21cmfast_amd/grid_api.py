@@ -265,6 +265,15 @@ def shard_init_single():
     check(lib.c21cm_shard_init(0, 1, bytes(buf)), "c21cm_shard_init")
 
 
+def shard_emulate(rank: int, world: int, mailbox):
+    """Test hook (c21cm_shard_emulate): run the ranks of a world > 1 job one after the other in
+    this process against the device ``mailbox`` (uint8 CUDA tensor, zeroed per round)."""
+    lib = load(require_gpu=True)
+    lib.c21cm_shard_emulate.restype = C.c_int
+    check(lib.c21cm_shard_emulate(C.c_int(rank), C.c_int(world), C.c_void_p(mailbox.data_ptr()),
+                                  C.c_size_t(mailbox.numel())), "c21cm_shard_emulate")
+
+
 def shard_finalize():
     load().c21cm_shard_finalize()
 

@@ -184,6 +184,10 @@ int c21cm_shard_init(int rank, int world, const void *id128);
 int c21cm_shard_finalize(void);
 int c21cm_shard_info(int *rank, int *world); /* returns 0 and fills them when initialised */
 int c21cm_shard_owner(int n_radii, int world);
+/* Test hook: replace the transport by an in-process device mailbox so that the ranks of a
+ * world > 1 run can be executed one after the other in ONE process (non-owners first, the owner
+ * last; mailbox zeroed before each round, >= world * N/8 + 8 N bytes).  See shard_rccl.c. */
+int c21cm_shard_emulate(int rank, int world, void *mailbox, size_t mailbox_bytes);
 int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
                          const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                          const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,

@@ -176,3 +176,57 @@ def test_c_level_sharding_on_a_one_rank_communicator(api, recomb):
         assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
     assert rep1.global_xH == rep0.global_xH
     assert 0.03 < float((buf0.neutral_fraction == 0).float().mean()) < 0.97
+
+
+@pytest.mark.parametrize("recomb", [False, True])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_c_level_sharding_with_an_emulated_transport(api, recomb, world):
+    """c21cm_ionize_sharded for world = 2, 3, 8 with the transport replaced by an in-process
+    mailbox (c21cm_shard_emulate): the ranks run one after the other, non-owners first.  Covers
+    what a one-GPU box cannot run through RCCL: the radius deal, the per-rank slots of the 1-bit
+    gather, the 64-bit key reduce, the owner's finish phase -- bit-identical to the single pass."""
+    import torch
+
+    D = importlib.import_module("21cmfast_amd.distributed")
+    n = 64
+    if recomb:
+        spec = recomb_spec(n, model=2, cell_recomb=1)
+        d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=5).items()}
+        kw = dict(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"], prev_nrec=d["prev_nrec"],
+                  prev_z_reion=d["prev_z_reion"])
+        density = d["density"]
+    else:
+        spec = W.ionize_spec(n, r_bubble_max=20.0)
+        density = torch.from_numpy(W.density_field_numpy(n, seed=13)).cuda()
+        kw = dict(n_ion=W.nion_from_density(density))
+    buf0, _, rep0 = api.ionize_grids(spec, density, **kw)
+    owner = D.owner_rank(spec.n_radii, world)
+    mailbox = torch.zeros(world * (n**3 // 8 + 64) + 8 * n**3, dtype=torch.uint8, device="cuda")
+    try:
+        for exchange in ("gather", "reduce"):
+            if recomb and exchange == "reduce":
+                continue  # recombination models always reduce their keys
+            import os
+
+            os.environ["C21CM_SHARD_EXCHANGE"] = exchange
+            mailbox.zero_()
+            result = None
+            for rank in [r for r in range(world) if r != owner] + [owner]:
+                api.shard_emulate(rank, world, mailbox)
+                buf, _, rep = api.ionize_sharded(spec, density, **kw)
+                if rank == owner:
+                    result = (buf, rep)
+            torch.cuda.synchronize()
+            buf, rep = result
+            names = ["neutral_fraction", "z_reion", "kinetic_temperature"]
+            if recomb:
+                names += ["ionisation_rate_G12", "mean_free_path", "cumulative_recombinations"]
+            for name in names:
+                assert torch.equal(getattr(buf0, name), getattr(buf, name)), (world, exchange, name)
+            assert rep.global_xH == rep0.global_xH
+    finally:
+        import os
+
+        os.environ.pop("C21CM_SHARD_EXCHANGE", None)
+        api.shard_finalize()
+    assert 0.03 < float((buf0.neutral_fraction == 0).float().mean()) < 0.97
