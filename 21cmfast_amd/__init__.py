@@ -3,8 +3,9 @@
 InitialConditions -> PerturbedField -> IonizedBox as hand-written CDNA4 (gfx950) HIP
 kernels behind the reference's own C ABI (``include/c21cm_abi.h``).  This Python
 package is the thin host-side mirror of py21cmfast's wrapper layer for that path:
-struct definitions and defaults (``structs``), array holders and the single-field
-functions (``single_field``), and the library loader (``_lib``).
+struct definitions and defaults (``structs``), numpy / torch front-ends of the explicit-scalar
+entry points (``grid_api``), the sharded R loop (``distributed``), synthetic benchmark inputs
+(``workloads``) and the library loader (``_lib``).
 
 The directory name starts with a digit, so import it with
 ``importlib.import_module("21cmfast_amd")``.
