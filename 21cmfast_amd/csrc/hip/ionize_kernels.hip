@@ -561,7 +561,7 @@ ionise_recomb_kernel(RecombParams q, const float *__restrict__ delta_fil,
 __device__ __forceinline__ double rr_spline(const double *__restrict__ rr_y,
                                             const double *__restrict__ rr_c, double z_eff,
                                             double gamma12_bg) {
-    int z_ct = (int)(z_eff / C21CM_RR_DZ + 0.5);
+    int z_ct = z_eff > 0 ? (int)(fmin(z_eff, 1e6) / C21CM_RR_DZ + 0.5) : 0;  // NaN -> row 0
     double lnGamma = log(gamma12_bg);
     z_ct = max(0, min(z_ct, C21CM_RR_NZ - 1));
     const double top = C21CM_RR_LNGAMMA_MIN + C21CM_RR_DLNGAMMA * (C21CM_RR_NGAMMA - 1);

@@ -275,7 +275,7 @@ void free_MHR(void) { /* the tables are kept: they depend on three cosmological 
 /* splined_recombination_rate (recombinations.c:64-92) on given tables: the homogeneous model's
  * one evaluation per call happens on the host */
 double c21_rr_eval(const double *y, const double *c, double z_eff, double gamma12_bg) {
-    int z_ct = (int)(z_eff / C21CM_RR_DZ + 0.5);
+    int z_ct = z_eff > 0 ? (int)(fmin(z_eff, 1e6) / C21CM_RR_DZ + 0.5) : 0; /* NaN -> row 0 */
     double lnGamma = log(gamma12_bg);
     if (z_ct < 0) z_ct = 0;
     if (z_ct >= C21CM_RR_NZ) z_ct = C21CM_RR_NZ - 1;

@@ -507,6 +507,65 @@ def rbox_spec(hii_dim, box_len, radii, filter_type=0, min_value=-1.0, const_fact
     return s
 
 
+X_INT_NXHII = 14
+X_INT_XHII = (1.0e-4, 2.318e-4, 4.677e-4, 1.0e-3, 2.318e-3, 4.677e-3, 1.0e-2, 2.318e-2, 4.677e-2,
+              1.0e-1, 0.5, 0.9, 0.99, 0.999)  # elec_interp.c:57-70 (floats upstream)
+LYA_NT, LYA_NGP = 101, 51
+TS_SRC_GRIDS, TS_SRC_SFRD_TABLE = 0, 1
+_PER_SHELL = C.c_double * MAX_TS_RADII
+
+
+class TsSpec(_Base):
+    """``c21cm_ts_spec`` (include/c21cm_grid.h): scalars and tables of the per-cell part of
+    ComputeTsBox."""
+
+    _fields_ = [
+        ("hii_dim", C.c_int), ("hii_dim_z", C.c_int), ("n_step", C.c_int),
+        ("source_mode", C.c_int),
+        ("use_xray_heating", C.c_int), ("use_cmb_heating", C.c_int), ("use_lya_heating", C.c_int),
+        ("no_light", C.c_int),
+        ("redshift", C.c_double), ("dzp", C.c_double), ("growth_ratio", C.c_double),
+        ("No", C.c_double), ("N_b0", C.c_double), ("h_frac", C.c_double), ("he_frac", C.c_double),
+        ("k_B", C.c_double), ("h_p", C.c_double), ("m_p", C.c_double), ("c_cms", C.c_double),
+        ("A10", C.c_double), ("T_21", C.c_double), ("lambda_21", C.c_double),
+        ("nu_Ly_alpha", C.c_double),
+        ("clumping_factor", C.c_double),
+        ("xray_prefactor", C.c_double), ("Trad", C.c_double), ("Ts_prefactor", C.c_double),
+        ("xa_tilde_prefactor", C.c_double), ("xc_inverse", C.c_double),
+        ("dcomp_dzp_prefactor", C.c_double),
+        ("Nb_zp", C.c_double), ("N_zp", C.c_double), ("lya_star_prefactor", C.c_double),
+        ("volunit_inv", C.c_double), ("hubble_zp", C.c_double), ("growth_zp", C.c_double),
+        ("dgrowth_dzp", C.c_double), ("dt_dzp", C.c_double),
+        ("z_edge_factor", _PER_SHELL), ("xray_R_factor", _PER_SHELL),
+        ("starlya_prefactor", _PER_SHELL), ("lya_cont_prefactor", _PER_SHELL),
+        ("lya_inj_prefactor", _PER_SHELL),
+        ("zpp_growth", _PER_SHELL), ("mean_sfr_zpp", _PER_SHELL),
+        ("tab_min", _PER_SHELL), ("tab_width", _PER_SHELL),
+        ("ln_sfrd_tables", c_float_p),
+        ("sfr_scale", C.c_double), ("xray_scale", C.c_double),
+        ("freq_int_heat", c_double_p), ("freq_int_ion", c_double_p), ("freq_int_lya", c_double_p),
+        ("lya_dEC", c_double_p), ("lya_dEI", c_double_p),
+    ]
+
+
+class TsReport(_Base):
+    """``c21cm_ts_report``."""
+
+    _fields_ = [("Ts_ave", C.c_double), ("Tk_ave", C.c_double), ("x_e_ave", C.c_double),
+                ("J_alpha_ave", C.c_double), ("xheat_ave", C.c_double), ("xion_ave", C.c_double),
+                ("ave_sfrd", _PER_SHELL)]
+
+
+class TsFirstSpec(_Base):
+    """``c21cm_ts_first_spec`` (init_first_Ts)."""
+
+    _fields_ = [("hii_dim", C.c_int), ("hii_dim_z", C.c_int), ("redshift", C.c_double),
+                ("perturbed_redshift", C.c_double), ("inverse_growth_factor_z", C.c_float),
+                ("growth_factor_zp", C.c_float), ("xe", C.c_double), ("TK", C.c_double),
+                ("cT_ad", C.c_double), ("No", C.c_double), ("N_b0", C.c_double),
+                ("A10", C.c_double), ("T_21", C.c_double), ("T_cmb", C.c_double)]
+
+
 class AnnularSpec(_Base):
     """``c21cm_annular_spec`` (include/c21cm_grid.h)."""
 

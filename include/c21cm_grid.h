@@ -345,6 +345,93 @@ int c21cm_annular_filter_grids(const c21cm_annular_spec *spec, const float *cons
                                float *const *outputs, double *u_avg, double *f_avg,
                                void *stream);
 
+/* ---- spin temperature: the per-cell part of ComputeTsBox ---------------------------------------
+ * reference: src/py21cmfast/src/SpinTemperatureBox.c
+ *   :892-927    init_first_Ts   (redshift >= Z_HEAT_MAX)      -> c21cm_ts_first_grids
+ *   :1010-1086  calculate_sfrd_from_grid                      -> source_mode SFRD_TABLE
+ *   :1210-1383  get_Ts_fast     (x_e, T_k update and T_s)     -> the cell epilogue
+ *   :1499-1522  x_e interpolation index per cell
+ *   :1541-1784  the R loop: SFR of every shell -> dxheat / dxion / dxlya / dstarlya sums
+ *   :1794-1848  prefactors of the sums, get_Ts_fast, outputs
+ * Everything that depends on the cosmology, on the spectra or on the frequency integrals is a
+ * scalar or a small table of this struct (the host builds them: heating.c); the library kernel
+ * and the oracle evaluate the same formulae on the same numbers.
+ *
+ * source_mode C21CM_TS_SRC_GRIDS: the shells' star-formation and X-ray grids are given
+ *   (XraySourceBox.filtered_sfr / filtered_xray [n_step][N], Lagrangian source models);
+ * source_mode C21CM_TS_SRC_SFRD_TABLE: `filtered_density` [n_step][N] (fill_Rbox_table's
+ *   delNL0, i.e. linearly extrapolated to z = 0) is turned into an SFRD per shell through
+ *   exp(lerp(ln_sfrd_tables[R], delta zpp_growth[R])) (1 + delta zpp_growth[R]), normalised to
+ *   mean_sfr_zpp[R] over the box mean of the table values (avg_fix_term, :1624). */
+#define C21CM_X_INT_NXHII 14 /* elec_interp.h:5 */
+#define C21CM_X_INT_XHII                                                                        \
+    { 1.0e-4f, 2.318e-4f, 4.677e-4f, 1.0e-3f, 2.318e-3f, 4.677e-3f, 1.0e-2f, 2.318e-2f, 4.677e-2f, \
+      1.0e-1f, 0.5f, 0.9f, 0.99f, 0.999f } /* elec_interp.c:57-70 */
+#define C21CM_LYA_NT 101  /* heating_helper_progs.c:50-55: log10 T_k, log10 T_s in [-1, 3] */
+#define C21CM_LYA_NGP 51  /* log10 tau_GP in [1, 7] */
+#define C21CM_TS_MAX_TK 5e4 /* SpinTemperatureBox.c:30 */
+enum { C21CM_TS_SRC_GRIDS = 0, C21CM_TS_SRC_SFRD_TABLE = 1 };
+
+typedef struct c21cm_ts_spec {
+    int hii_dim, hii_dim_z;
+    int n_step;      /* N_STEP_TS, <= C21CM_MAX_TS_RADII */
+    int source_mode; /* C21CM_TS_SRC_* */
+    int use_xray_heating, use_cmb_heating, use_lya_heating;
+    int no_light;    /* global_reion_properties: nothing has formed yet, the sums stay zero */
+    double redshift; /* z' */
+    double dzp;      /* z' - previous z' (negative) */
+    double growth_ratio; /* dicke(z') / dicke(perturbed_field_redshift) */
+    /* constants (Constants.c / Constants.h:98-112 with the run's cosmology) */
+    double No, N_b0, h_frac, he_frac;
+    double k_B, h_p, m_p, c_cms, A10, T_21, lambda_21, nu_Ly_alpha;
+    double clumping_factor;
+    /* set_zp_consts (:1098-1184) */
+    double xray_prefactor, Trad, Ts_prefactor, xa_tilde_prefactor, xc_inverse, dcomp_dzp_prefactor;
+    double Nb_zp, N_zp, lya_star_prefactor, volunit_inv, hubble_zp, growth_zp, dgrowth_dzp, dt_dzp;
+    /* per shell */
+    double z_edge_factor[C21CM_MAX_TS_RADII]; /* :1546-1553 */
+    double xray_R_factor[C21CM_MAX_TS_RADII]; /* (1 + z'')^-X_RAY_SPEC_INDEX */
+    double starlya_prefactor[C21CM_MAX_TS_RADII];  /* dstarlya_dt_prefactor */
+    double lya_cont_prefactor[C21CM_MAX_TS_RADII]; /* dstarlya_cont_dt_prefactor */
+    double lya_inj_prefactor[C21CM_MAX_TS_RADII];  /* dstarlya_inj_dt_prefactor */
+    /* C21CM_TS_SRC_SFRD_TABLE */
+    double zpp_growth[C21CM_MAX_TS_RADII];
+    double mean_sfr_zpp[C21CM_MAX_TS_RADII];
+    double tab_min[C21CM_MAX_TS_RADII], tab_width[C21CM_MAX_TS_RADII];
+    const float *ln_sfrd_tables; /* host, [n_step][C21CM_NDELTA_TABLE] */
+    double sfr_scale;            /* F_STAR10 */
+    double xray_scale;           /* L_X s_per_yr */
+    /* fill_freqint_tables (:810-889): host, [C21CM_X_INT_NXHII][n_step] each */
+    const double *freq_int_heat, *freq_int_ion, *freq_int_lya;
+    /* Energy_Lya_heating's two tables, host, [NT][NT][NGP]; needed with use_lya_heating */
+    const double *lya_dEC, *lya_dEI;
+} c21cm_ts_spec;
+
+typedef struct c21cm_ts_report { /* box means, as the reference logs them at DEBUG level */
+    double Ts_ave, Tk_ave, x_e_ave, J_alpha_ave, xheat_ave, xion_ave;
+    double ave_sfrd[C21CM_MAX_TS_RADII]; /* SFRD_TABLE: mean table value per shell */
+} c21cm_ts_report;
+
+/* `density` [N]: PerturbedField.density; `previous` holds the three boxes of the previous
+ * snapshot; `source_box` (GRIDS) or `filtered_density` (SFRD_TABLE) as described above; `out`
+ * receives spin_temperature, kinetic_temp_neutral, xray_ionised_fraction.  Arrays may be host
+ * or device.  A non-finite spin temperature gives C21CM_INFINITY_OR_NAN_ERROR (:1884-1904). */
+int c21cm_ts_grids(const c21cm_ts_spec *spec, const float *density, const TsBox *previous,
+                   const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
+                   c21cm_ts_report *report, void *stream);
+
+/* init_first_Ts: T_k = TK (1 + cT_ad delta), x_e = xe, T_s from collisions only. */
+typedef struct c21cm_ts_first_spec {
+    int hii_dim, hii_dim_z;
+    double redshift;          /* z' of the requested box */
+    double perturbed_redshift; /* get_Ts is called with this one (:923) */
+    float inverse_growth_factor_z, growth_factor_zp; /* floats upstream (:896-897) */
+    double xe, TK, cT_ad;
+    double No, N_b0, A10, T_21, T_cmb;
+} c21cm_ts_first_spec;
+int c21cm_ts_first_grids(const c21cm_ts_first_spec *spec, const float *density, TsBox *out,
+                         void *stream);
+
 /* Library management */
 const char *c21cm_version(void);
 int c21cm_device_synchronize(void);

@@ -101,6 +101,18 @@ int oracle_fill_Rbox_grids(const c21cm_rbox_spec *spec, const float *input, floa
 int oracle_annular_filter_grids(const c21cm_annular_spec *spec, const float *const *inputs,
                                 float *const *outputs, double *u_avg, double *f_avg);
 
+/* oracle_ts.c -- reference: src/py21cmfast/src/SpinTemperatureBox.c:892-927,1010-1086,1210-1383,
+ * 1499-1848; heating_helper_progs.c:366-760,1210-1313; thermochem.c:66-75 */
+int oracle_ts_grids(const c21cm_ts_spec *spec, const float *density, const TsBox *previous,
+                    const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
+                    c21cm_ts_report *report);
+int oracle_ts_first_grids(const c21cm_ts_first_spec *spec, const float *density, TsBox *out);
+double oracle_kappa_10(double TK);
+double oracle_kappa_10_elec(double T);
+double oracle_kappa_10_pH(double T);
+double oracle_alpha_A(double T);
+double oracle_lya_heating_efficiency(double tk, double ts, double taugp, const double *arrE);
+
 void oracle_set_threads(int n);
 void oracle_set_fft_threads(int n); /* 0: follow oracle_set_threads; 1: single-threaded FFTs */
 

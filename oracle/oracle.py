@@ -68,6 +68,15 @@ def load():
         lib.oracle_fill_Rbox_grids.argtypes = [vp, vp, vp, vp, vp, vp]
         lib.oracle_annular_filter_grids.restype = i32
         lib.oracle_annular_filter_grids.argtypes = [vp, vp, vp, vp, vp]
+        lib.oracle_ts_grids.restype = i32
+        lib.oracle_ts_grids.argtypes = [vp] * 7
+        lib.oracle_ts_first_grids.restype = i32
+        lib.oracle_ts_first_grids.argtypes = [vp, vp, vp]
+        for nm in ("oracle_kappa_10", "oracle_kappa_10_elec", "oracle_kappa_10_pH", "oracle_alpha_A"):
+            getattr(lib, nm).restype = f64
+            getattr(lib, nm).argtypes = [f64]
+        lib.oracle_lya_heating_efficiency.restype = f64
+        lib.oracle_lya_heating_efficiency.argtypes = [f64, f64, f64, vp]
         for nm, at in (("oracle_ms_mu", [f64]), ("oracle_ms_eta", [f64]),
                        ("oracle_hyper_2F3", [f64, f64, f64])):
             getattr(lib, nm).restype = f64
@@ -299,6 +308,35 @@ def annular_filter_grids(spec, inputs):
     if st:
         raise RuntimeError(f"oracle_annular_filter_grids status {st}")
     return {"outputs": outputs, "u_avg": np.array(u[:]), "f_avg": np.array(f[:])}
+
+
+TS_FIELDS = ("spin_temperature", "kinetic_temp_neutral", "xray_ionised_fraction")
+
+
+def ts_grids(spec, density, previous: dict, source: dict | None = None, filtered_density=None):
+    """Oracle per-cell part of ComputeTsBox; dict of the three output boxes + the report."""
+    shape = density.shape
+    out = {k: np.zeros(shape, np.float32) for k in TS_FIELDS}
+    prev = S.TsBoxStruct(**{k: fptr(previous[k]) for k in TS_FIELDS})
+    box = S.TsBoxStruct(**{k: fptr(out[k]) for k in TS_FIELDS})
+    src = S.XraySourceBoxStruct(**{k: fptr(v) for k, v in (source or {}).items()})
+    rep = S.TsReport()
+    st = load().oracle_ts_grids(C.byref(spec), fptr(density), C.byref(prev), C.byref(src),
+                                fptr(filtered_density), C.byref(box), C.byref(rep))
+    if st:
+        raise RuntimeError(f"oracle_ts_grids status {st}")
+    out["report"] = rep
+    return out
+
+
+def ts_first_grids(spec, density):
+    """Oracle init_first_Ts."""
+    out = {k: np.zeros(density.shape, np.float32) for k in TS_FIELDS}
+    box = S.TsBoxStruct(**{k: fptr(out[k]) for k in TS_FIELDS})
+    st = load().oracle_ts_first_grids(C.byref(spec), fptr(density), C.byref(box))
+    if st:
+        raise RuntimeError(f"oracle_ts_first_grids status {st}")
+    return out
 
 
 def filter_window_ms(k, R_inner, R_outer, R_star):

@@ -103,13 +103,15 @@ static double eval_table_f(double x, double x_min, double x_width, const float *
  * the way gsl_interp_cspline does (b and d from the c coefficients, Horner in delta) */
 double oracle_splined_recombination_rate(const double *rr_y, const double *rr_c, double z_eff,
                                          double gamma12_bg) {
-    int z_ct = (int)(z_eff / C21CM_RR_DZ + 0.5);
+    /* a density below -1 (outside PerturbedField's clip) gives a NaN z_eff: row 0, not UB */
+    int z_ct = z_eff > 0 ? (int)(fmin(z_eff, 1e6) / C21CM_RR_DZ + 0.5) : 0;
     double lnGamma = log(gamma12_bg);
     if (z_ct < 0)
         z_ct = 0;
     else if (z_ct >= C21CM_RR_NZ)
         z_ct = C21CM_RR_NZ - 1;
     const double top = C21CM_RR_LNGAMMA_MIN + C21CM_RR_DLNGAMMA * (C21CM_RR_NGAMMA - 1);
+    if (isnan(lnGamma)) return lnGamma; /* gsl_spline_eval hands a NaN through */
     if (lnGamma < C21CM_RR_LNGAMMA_MIN) return 0;
     if (lnGamma >= top) lnGamma = top - FRACT_FLOAT_ERR;
     const double *y = rr_y + (size_t)z_ct * C21CM_RR_NGAMMA, *c = rr_c + (size_t)z_ct * C21CM_RR_NGAMMA;

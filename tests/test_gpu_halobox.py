@@ -179,3 +179,87 @@ def test_l_integral_chain_entry_points(gpu_lib, oracle, tmp_path):
     iref = oracle.ionize_grids(ispec, density, out["n_ion"])
     ion_g, ion_r = got["neutral_fraction"] == 0, iref["neutral_fraction"] == 0
     assert np.mean(ion_g != ion_r) <= 2e-4
+
+
+def test_l_integral_chain_with_recombinations(gpu_lib, oracle, tmp_path):
+    """The reference's default astrophysics on fixed grids: SOURCE_MODEL = L-INTEGRAL with
+    INHOMO_RECO.  ComputeHaloBox also fills whalo_sfr = n_ion / t_h / t_star (map_mass.c:340-346),
+    ComputeIonizedBox filters it next to N_rec and turns it into Gamma_12 at first crossing
+    (IonisationBox.c:1126-1131); the oracle runs on the entry points' own source grids with
+    the recombination constants restated here."""
+    from test_gpu_abi import Session, fptr, ionize_spec_from_scalars, ref_cosmo
+    from test_host_scalars import ScalingConsts
+
+    lib = gpu_lib
+    n, N = 32, 64
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=N, SOURCE_MODEL=2, R_BUBBLE_MAX=12.0,
+                  RECOMB_MODEL=2, CELL_RECOMB=True, USE_EXP_FILTER=True)
+    lib.init_MHR.restype = None
+    lib.init_MHR()
+    z, prev_redshift = 8.0, 8.4
+    ics = random_ics(n, N, False, seed=9)
+    ics["lowres_density"] = (ics["lowres_density"] * 0.5).astype(np.float32)
+    shape = (n, n, n)
+    src = {k: np.zeros(shape, np.float32) for k in ("n_ion", "halo_sfr", "whalo_sfr")}
+    hb = S.HaloBoxStruct(**{k: fptr(v) for k, v in src.items()})
+    icss = S.InitialConditionsStruct(**{k: fptr(v) for k, v in ics.items()})
+    lib.ComputeHaloBox.argtypes = [C.c_double] + [C.c_void_p] * 5
+    assert lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb)) == 0, \
+        lib.c21cm_last_error()
+    sc = ScalingConsts()
+    lib.c21_set_scaling_constants.restype = C.c_int
+    lib.c21_set_scaling_constants.argtypes = [C.c_double, C.POINTER(ScalingConsts)]
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    np.testing.assert_allclose(src["whalo_sfr"], src["n_ion"] / sc.t_h / sc.t_star, rtol=3e-7)
+    assert src["whalo_sfr"].max() > 0
+
+    rng = np.random.default_rng(2)
+    density = np.maximum(0.4 * rng.standard_normal(shape), -0.99).astype(np.float32)
+    names = ("neutral_fraction", "z_reion", "kinetic_temperature", "unnormalised_nion",
+             "ionisation_rate_G12", "mean_free_path", "cumulative_recombinations")
+    arr = {k: np.zeros(shape, np.float32) for k in names}
+    arr["neutral_fraction"][...] = 1.0  # the wrapper's initial value (outputs.py:1475-1545)
+    box = S.IonizedBoxStruct(**{k: fptr(v) for k, v in arr.items()})
+    # a previous snapshot that has already crossed somewhere and has recombined a little
+    prev = {"z_reion": np.where(rng.random(shape) < 0.05, np.float32(prev_redshift),
+                                np.float32(-1)).astype(np.float32),
+            "cumulative_recombinations": (0.1 * rng.random(shape)).astype(np.float32)}
+    prev_in = {k: v.copy() for k, v in prev.items()}
+    prevs = S.IonizedBoxStruct(**{k: fptr(v) for k, v in prev.items()})
+    pf = S.PerturbedFieldStruct(density=fptr(density))
+    ts = S.TsBoxStruct()
+    st = lib.ComputeIonizedBox(z, prev_redshift, C.byref(pf), C.byref(pf), C.byref(prevs),
+                               C.byref(ts), C.byref(hb), C.byref(icss), C.byref(box))
+    assert st == 0, lib.c21cm_last_error()
+
+    spec = ionize_spec_from_scalars(ses, z, lagrangian=True, tables=False)
+    c = ref_cosmo()
+    spec.f_limit_acg = 0.0
+    spec.recomb_model, spec.cell_recomb, spec.first_snapshot = 2, 1, 0
+    spec.dz = prev_redshift - z
+    spec.fabs_dtdz = abs(c.dtdz(z)) / 1e15
+    Y_He, m_p = ses.cp.Y_He, 1.6726219e-24
+    Ho = c.h * 3.2407e-18
+    rho_cgs = 3 * Ho * Ho / (8 * np.pi * 6.6743e-8)
+    n_b0 = rho_cgs * c.ob * (1 - Y_He) / m_p + rho_cgs * c.ob * Y_He / (4 * m_p)
+    a_uvb = ses.ap.ALPHA_UVB
+    spec.gamma_prefactor = ((1 + z) ** 2 * 3.08567758e24 * 6.3e-18 * a_uvb / (a_uvb + 2.75) * n_b0
+                            / 1e-12 / spec.rhocrit_omb)
+    y = C.POINTER(C.c_double)()
+    cc = C.POINTER(C.c_double)()
+    lib.c21_rr_tables.restype = C.c_int
+    assert lib.c21_rr_tables(C.byref(y), C.byref(cc)) == 0  # pinned by tests/test_host_scalars.py
+    spec.rr_y, spec.rr_c = y, cc
+    ref = oracle.ionize_grids(spec, density, src["n_ion"], whalo_sfr=src["whalo_sfr"],
+                              prev_z_reion=prev_in["z_reion"],
+                              prev_nrec=prev_in["cumulative_recombinations"])
+    flag_g, flag_r = arr["mean_free_path"] > 0, ref["mean_free_path"] > 0
+    assert np.mean(flag_g != flag_r) <= 2e-4
+    same = flag_g == flag_r
+    assert 0.02 < flag_r.mean() < 0.98
+    for k in ("neutral_fraction", "ionisation_rate_G12", "mean_free_path",
+              "cumulative_recombinations", "z_reion"):
+        np.testing.assert_allclose(arr[k][same], ref[k][same], rtol=2e-4, atol=5e-6, err_msg=k)
+    assert arr["ionisation_rate_G12"].max() > 0 and arr["cumulative_recombinations"].max() > 0
+    lib.free_MHR.restype = None
+    lib.free_MHR()
