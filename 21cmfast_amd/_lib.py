@@ -75,6 +75,9 @@ def _declare(lib):
         ("UpdateXraySourceBox", [P(S.HaloBoxStruct), f64, f64, i32, f64, P(S.XraySourceBoxStruct)]),
         ("c21cm_fill_Rbox_grids", [P(S.RboxSpec), vp, vp, vp, vp, vp, vp]),
         ("c21cm_annular_filter_grids", [P(S.AnnularSpec), vp, vp, vp, vp, vp]),
+        ("c21cm_ts_grids", [P(S.TsSpec), vp, P(S.TsBoxStruct), P(S.XraySourceBoxStruct), vp,
+                            P(S.TsBoxStruct), P(S.TsReport), vp]),
+        ("c21cm_ts_first_grids", [P(S.TsFirstSpec), vp, P(S.TsBoxStruct), vp]),
     ):
         if hasattr(lib, name):
             fn = getattr(lib, name)

@@ -1,0 +1,497 @@
+// ts_kernels.hip -- the per-cell part of ComputeTsBox on the MI355X.
+//
+// reference: src/py21cmfast/src/SpinTemperatureBox.c
+//   :892-927    init_first_Ts                         -> ts_first_kernel
+//   :1010-1086  calculate_sfrd_from_grid (E-INTEGRAL)  -> sfrd_sum_kernel (+ the table lookup
+//                                                         repeated inside ts_cell_kernel)
+//   :1499-1522  x_e index / weight of a cell           \
+//   :1541-1784  the R loop (largest shell first)        > ts_cell_kernel, one sweep
+//   :1794-1848  prefactors + get_Ts_fast (:1210-1383)  /
+//
+// The reference walks the 40 shells in an outer loop and keeps six double boxes of partial
+// sums between them (6 x 8 B x N read + written 40 times).  Here a cell is a thread: it walks
+// its own 40 shell values (coalesced across the wavefront: grids are [R][N]), keeps the sums in
+// registers, and runs the temperature update at the end -- one read of the source grids, one
+// write of three floats.  HBM-bound: 8 B (GRIDS) or 4 B (SFRD_TABLE) per cell and shell.
+// Per-shell scalars and the 3 x 14 x n_step frequency-integral tables sit in LDS (16 KB for 40
+// shells).  SFRD_TABLE needs the box mean of the table values of every shell before the sums
+// (avg_fix_term), hence one extra sweep over the filtered densities (sfrd_sum_kernel,
+// blockIdx.y = shell).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "c21cm_grid.h"
+#include "c21cm_kappa_tables.h"
+#include "c21hip.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 256 * 8;
+constexpr double kFractFloatErr = 1e-7;
+
+inline int grid_for(size_t work_items) {
+    size_t b = (work_items + kBlock - 1) / kBlock;
+    if (b > (size_t)kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define LAUNCH_CHECK()                                                                  \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            c21hip_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                       \
+            return C21CM_IO_ERROR;                                                      \
+        }                                                                               \
+    } while (0)
+
+__constant__ double kKappaHH[C21CM_KAPPA_NPTS] = C21CM_KAPPA_HH_VALUES;
+__constant__ double kKappaPH[C21CM_KAPPA_NPTS] = C21CM_KAPPA_PH_VALUES;
+__constant__ double kKappaEH[C21CM_KAPPA_NPTS] = C21CM_KAPPA_EH_VALUES;
+__constant__ float kXHII[C21CM_X_INT_NXHII] = C21CM_X_INT_XHII;
+
+// heating_helper_progs.c:366-643: ln kappa on a regular ln T grid, linear between knots
+__device__ inline double kappa_interior(const double *y, double width, double lnT) {
+    int idx = (int)floor(lnT * (1. / width));
+    idx = min(idx, C21CM_KAPPA_NPTS - 2);
+    return y[idx] + (lnT - width * (double)idx) * (y[idx + 1] - y[idx]) * (1. / width);
+}
+
+__device__ inline double kappa_10(double lnT) {
+    double ans;
+    if (lnT < 0.)
+        ans = kKappaHH[0];
+    else if (lnT > C21CM_KAPPA_HH_LNT_MAX)  // power law T^0.381 above the table
+        ans = log(exp(kKappaHH[C21CM_KAPPA_NPTS - 1]) *
+                  pow(exp(lnT) / exp(C21CM_KAPPA_HH_LNT_MAX), 0.381));
+    else
+        ans = kappa_interior(kKappaHH, C21CM_KAPPA_HH_BINWIDTH, lnT);
+    return exp(ans);
+}
+
+__device__ inline double kappa_linear_tail(const double *y, double width, double lnT_max,
+                                           double lnT) {
+    double ans;
+    if (lnT < 0.)
+        ans = y[0];
+    else if (lnT > lnT_max)
+        ans = y[C21CM_KAPPA_NPTS - 1] + (y[C21CM_KAPPA_NPTS - 1] - y[C21CM_KAPPA_NPTS - 2]) /
+                                            (lnT_max - width * (C21CM_KAPPA_NPTS - 2)) *
+                                            (lnT - lnT_max);
+    else
+        ans = kappa_interior(y, width, lnT);
+    return exp(ans);
+}
+
+// thermochem.c:66-75 (Abel et al. 1997), Horner form of the same polynomial in ln(T / 1 eV)
+__device__ inline double alpha_A(double T) {
+    const double x = log(T / 1.1604505e4);
+    const double x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x, x6 = x3 * x3, x7 = x6 * x,
+                 x8 = x4 * x4, x9 = x8 * x;
+    return exp(-28.6130338 - 0.72411256 * x - 2.02604473e-2 * x2 - 2.38086188e-3 * x3 -
+               3.21260521e-4 * x4 - 1.42150291e-5 * x5 + 4.98910892e-6 * x6 +
+               5.75561414e-7 * x7 - 1.85676704e-8 * x8 - 3.07113524e-9 * x9);
+}
+
+// heating_helper_progs.c:1210-1313
+__device__ inline int nearest_point(double lo, double hi, int n, double value) {
+    const double dn = (hi - lo) / (n - 1);
+    if (value <= (lo + dn)) return 0;
+    if (value >= hi) return n - 2;
+    return (int)floor((value - lo) / dn);
+}
+
+__device__ double lya_heating_efficiency(double tk, double ts, double taugp,
+                                         const double *__restrict__ arrE) {
+    const double T_min = -1., T_max = 3., g_min = 1., g_max = 7.;
+    const int nT = C21CM_LYA_NT, ngp = C21CM_LYA_NGP;
+    tk = fmin(fmax(log10(tk), T_min), T_max);
+    ts = fmin(fmax(log10(ts), T_min), T_max);
+    taugp = fmin(fmax(log10(taugp), g_min), g_max);
+    const int itk = nearest_point(T_min, T_max, nT, tk), its = nearest_point(T_min, T_max, nT, ts),
+              igp = nearest_point(g_min, g_max, ngp, taugp);
+    const double x0 = T_min + itk * (T_max - T_min) / (nT - 1),
+                 x1 = T_min + (itk + 1) * (T_max - T_min) / (nT - 1);
+    const double y0 = T_min + its * (T_max - T_min) / (nT - 1),
+                 y1 = T_min + (its + 1) * (T_max - T_min) / (nT - 1);
+    const double z0 = g_min + igp * (g_max - g_min) / (ngp - 1),
+                 z1 = g_min + (igp + 1) * (g_max - g_min) / (ngp - 1);
+    const double xd = (tk - x0) / (x1 - x0), yd = (ts - y0) / (y1 - y0),
+                 zd = (taugp - z0) / (z1 - z0);
+    auto at = [&](int a, int b, int c) { return arrE[((size_t)a * nT + b) * ngp + c]; };
+    const double c00 = at(itk, its, igp) * (1. - xd) + at(itk + 1, its, igp) * xd;
+    const double c01 = at(itk, its, igp + 1) * (1. - xd) + at(itk + 1, its, igp + 1) * xd;
+    const double c10 = at(itk, its + 1, igp) * (1. - xd) + at(itk + 1, its + 1, igp) * xd;
+    const double c11 = at(itk, its + 1, igp + 1) * (1. - xd) + at(itk + 1, its + 1, igp + 1) * xd;
+    const double c0 = c00 * (1. - yd) + c10 * yd, c1 = c01 * (1. - yd) + c11 * yd;
+    return c0 * (1. - zd) + c1 * zd;
+}
+
+// interpolation.c:123-131
+__device__ inline double table_1d(double x, double x_min, double x_width,
+                                  const float *__restrict__ y) {
+    const int idx = (int)floor((x - x_min) / x_width);
+    const double table_val = x_min + x_width * (float)idx;
+    const double interp_point = (x - table_val) / x_width;
+    return y[idx] * (1 - interp_point) + y[idx + 1] * interp_point;
+}
+
+__device__ inline double block_sum(double v, double *lds) {
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+// shell layout of the device table buffer (doubles), n = n_step:
+//   [0..9n)  z_edge_factor, xray_R_factor, starlya, lya_cont, lya_inj, zpp_growth, tab_min,
+//            tab_width, avg_fix_term (written by sfrd_finish_kernel; 1 for GRIDS)
+//   [9n..)   freq_int_heat[14][n], freq_int_ion[14][n], freq_int_lya[14][n]
+enum { SH_ZEDGE = 0, SH_XRAY_R, SH_STARLYA, SH_CONT, SH_INJ, SH_GROWTH, SH_TABMIN, SH_TABWIDTH,
+       SH_AVGFIX, SH_COUNT };
+
+// box sum of the SFRD table values of one shell (blockIdx.y)
+__global__ void __launch_bounds__(kBlock)
+sfrd_sum_kernel(const float *__restrict__ filtered_density, const float *__restrict__ tables,
+                const double *__restrict__ shell, int n_step, size_t ntot,
+                double *__restrict__ partials) {
+    __shared__ double lds[kBlock];
+    const int R = blockIdx.y;
+    const float *dens = filtered_density + (size_t)R * ntot;
+    const float *tab = tables + (size_t)R * C21CM_NDELTA_TABLE;
+    const double growth = shell[SH_GROWTH * n_step + R], tab_min = shell[SH_TABMIN * n_step + R],
+                 tab_width = shell[SH_TABWIDTH * n_step + R];
+    double acc = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock)
+        acc += exp(table_1d((double)dens[i] * growth, tab_min, tab_width, tab));
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[(size_t)R * gridDim.x + blockIdx.x] = acc;
+}
+
+// avg_fix_term = mean_sfr_zpp / (sum / N) per shell (:1624); ave_out keeps the means
+__global__ void __launch_bounds__(kBlock)
+sfrd_finish_kernel(const double *__restrict__ partials, int nblocks,
+                   const double *__restrict__ mean_sfr_zpp, double ntot, int n_step,
+                   double *__restrict__ shell, double *__restrict__ ave_out) {
+    __shared__ double lds[kBlock];
+    const int R = blockIdx.x;
+    double acc = 0.;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += partials[(size_t)R * nblocks + i];
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) {
+        const double ave = acc / ntot;
+        ave_out[R] = ave;
+        shell[SH_AVGFIX * n_step + R] = mean_sfr_zpp[R] / ave;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+ts_cell_kernel(c21hip_ts_args a, const float *__restrict__ density,
+               const float *__restrict__ prev_Ts, const float *__restrict__ prev_Tk,
+               const float *__restrict__ prev_xe, const float *__restrict__ grid_a,  // sfr | delNL0
+               const float *__restrict__ grid_b,                                      // xray
+               const float *__restrict__ tables, const double *__restrict__ dev_tab,
+               const double *__restrict__ lya_dEC, const double *__restrict__ lya_dEI,
+               float *__restrict__ Ts_out, float *__restrict__ Tk_out, float *__restrict__ xe_out,
+               size_t ntot, double *__restrict__ partials, int *__restrict__ flag) {
+    extern __shared__ double sh[];  // (SH_COUNT + 3 * NXHII) * n_step doubles, then kBlock
+    const int n = a.n_step;
+    const int n_tab = (SH_COUNT + 3 * C21CM_X_INT_NXHII) * n;
+    for (int i = threadIdx.x; i < n_tab; i += kBlock) sh[i] = dev_tab[i];
+    double *red = sh + n_tab;
+    __syncthreads();
+    const double *fheat = sh + SH_COUNT * n, *fion = fheat + C21CM_X_INT_NXHII * n,
+                 *flya = fion + C21CM_X_INT_NXHII * n;
+
+    double s_Ts = 0, s_Tk = 0, s_xe = 0, s_Ja = 0, s_heat = 0, s_ion = 0;
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const float pxe = prev_xe[i];
+        // :1499-1514, float arithmetic as upstream
+        float xHII_call = pxe;
+        if (xHII_call > kXHII[C21CM_X_INT_NXHII - 1] * 0.999)
+            xHII_call = (float)(kXHII[C21CM_X_INT_NXHII - 1] * 0.999);
+        else if (xHII_call < kXHII[0])
+            xHII_call = (float)(1.001 * kXHII[0]);
+        int m = C21CM_X_INT_NXHII - 1;
+        while (xHII_call < kXHII[m]) m--;
+        const float inv_diff = (float)(1. / (kXHII[m + 1] - kXHII[m]));
+        const double ival = (double)((xHII_call - kXHII[m]) * inv_diff);
+
+        double dxheat = 0., dxion = 0., dxlya = 0., dstarlya = 0., dcont = 0., dinj = 0.;
+        if (!a.no_light) {
+            for (int R = n; R--;) {
+                const double z_edge = sh[SH_ZEDGE * n + R], xray_R = sh[SH_XRAY_R * n + R];
+                double sfr_term, xray_sfr;
+                if (a.lagrangian) {
+                    sfr_term = (double)grid_a[(size_t)R * ntot + i] * z_edge;
+                    xray_sfr = (double)grid_b[(size_t)R * ntot + i] * z_edge * xray_R * 1e38;
+                } else {
+                    const double curr_dens = (double)grid_a[(size_t)R * ntot + i] * sh[SH_GROWTH * n + R];
+                    const double fcoll =
+                        exp(table_1d(curr_dens, sh[SH_TABMIN * n + R], sh[SH_TABWIDTH * n + R],
+                                     tables + (size_t)R * C21CM_NDELTA_TABLE));
+                    const float sfrd = (float)((1. + curr_dens) * fcoll);  // del_fcoll_Rct is float
+                    sfr_term = (double)sfrd * z_edge * sh[SH_AVGFIX * n + R] * a.sfr_scale;
+                    xray_sfr = sfr_term * a.xray_scale * xray_R;
+                }
+                const int lo = m * n + R, hi = lo + n;
+                if (a.use_xray_heating) dxheat += xray_sfr * ((fheat[hi] - fheat[lo]) * ival + fheat[lo]);
+                dxion += xray_sfr * ((fion[hi] - fion[lo]) * ival + fion[lo]);
+                dxlya += xray_sfr * ((flya[hi] - flya[lo]) * ival + flya[lo]);
+                dstarlya += sfr_term * sh[SH_STARLYA * n + R];
+                if (a.use_lya_heating) {
+                    dcont += sfr_term * sh[SH_CONT * n + R];
+                    dinj += sfr_term * sh[SH_INJ * n + R];
+                }
+            }
+        }
+
+        // :1794-1848
+        double delta = (double)density[i] * a.growth_ratio;
+        if (delta <= -1) delta = -1 + kFractFloatErr;
+        const double dxheat_dt = a.use_xray_heating ? dxheat * a.xray_prefactor * a.volunit_inv : 0.;
+        const double dxion_dt = dxion * a.xray_prefactor * a.volunit_inv;
+        const double dxlya_dt = dxlya * a.xray_prefactor * a.volunit_inv * a.Nb_zp * (1 + delta);
+        const double dstarlya_dt = dstarlya * a.lya_star_prefactor * a.volunit_inv;
+        const double pTs = prev_Ts[i], pTk = prev_Tk[i], pXe = pxe;
+
+        // get_Ts_fast :1210-1383
+        const double zp = a.redshift, dzp = a.dzp;
+        const double tau21 = (3 * a.h_p * a.A10 * a.c_cms * a.lambda_21 * a.lambda_21 / 32. / M_PI /
+                              a.k_B) *
+                             ((1 - pXe) * a.N_zp) / pTs / a.hubble_zp;
+        double xCMB;
+        if (tau21 > 1e-8)
+            xCMB = (1. - exp(-tau21)) / tau21;
+        else
+            xCMB = 1. - tau21 / 2 * (1 - tau21 / 3 * (1 - tau21 / 4));
+        const double dxion_sink_dt =
+            alpha_A(pTk) * a.clumping_factor * pXe * pXe * a.h_frac * a.Nb_zp * (1. + delta);
+        const double dxe_dzp = a.dt_dzp * (dxion_dt - dxion_sink_dt);
+        double dadia_dzp = 3 / (1.0 + zp);
+        if (fabs(delta) > kFractFloatErr)
+            dadia_dzp += a.dgrowth_dzp / (a.growth_zp * (1.0 / delta + 1.0));
+        dadia_dzp *= (2.0 / 3.0) * pTk;
+        const double dspec_dzp = -dxe_dzp * pTk / (1 + pXe);
+        const double dcomp_dzp =
+            a.dcomp_dzp_prefactor * (pXe / (1.0 + pXe + a.he_frac)) * (a.Trad - pTk);
+        double dxheat_dzp = 0.;
+        if (a.use_xray_heating) dxheat_dzp = dxheat_dt * a.dt_dzp * 2.0 / 3.0 / a.k_B / (1.0 + pXe);
+        double dCMBheat_dzp = 0.;
+        if (a.use_cmb_heating) {
+            const double eps_CMB = (3. / 4.) * (a.Trad / a.T_21) * a.A10 * a.h_frac *
+                                   (a.h_p * a.h_p / a.lambda_21 / a.lambda_21 / a.m_p) *
+                                   (1. + 2. * pTk / a.T_21);
+            dCMBheat_dzp = -eps_CMB * (2. / 3. / a.k_B / (1. + pXe)) / a.hubble_zp / (1. + zp);
+        }
+        double eps_Lya_cont = 0., eps_Lya_inj = 0.;
+        if (a.use_lya_heating) {
+            const double tgp = 1.342881e-7 / a.hubble_zp * a.No * pow(1 + zp, 3) * (1.0 + delta) *
+                               (1.0 - pXe);
+            double E_continuum = lya_heating_efficiency(pTk, pTs, tgp, lya_dEC);
+            double E_injected = lya_heating_efficiency(pTk, pTs, tgp, lya_dEI);
+            if (isnan(E_continuum) || isinf(E_continuum)) E_continuum = 0.;
+            if (isnan(E_injected) || isinf(E_injected)) E_injected = 0.;
+            const double cont_dt = dcont * a.lya_star_prefactor * a.volunit_inv;
+            const double inj_dt = dinj * a.lya_star_prefactor * a.volunit_inv;
+            const double Ndot_alpha_cont = (4. * M_PI * a.nu_Ly_alpha) / (a.Nb_zp * (1. + delta)) /
+                                           (1. + zp) / a.c_cms * cont_dt;
+            const double Ndot_alpha_inj = (4. * M_PI * a.nu_Ly_alpha) / (a.Nb_zp * (1. + delta)) /
+                                          (1. + zp) / a.c_cms * inj_dt;
+            eps_Lya_cont = -Ndot_alpha_cont * E_continuum * (2. / 3. / a.k_B / (1. + pXe));
+            eps_Lya_inj = -Ndot_alpha_inj * E_injected * (2. / 3. / a.k_B / (1. + pXe));
+        }
+        double x_e = pXe + (dxe_dzp * dzp);
+        if (x_e > 1)
+            x_e = 1 - kFractFloatErr;
+        else if (x_e < 0)
+            x_e = 0;
+        double Tk = pTk;
+        if (Tk < (double)(float)C21CM_TS_MAX_TK)
+            Tk += (dxheat_dzp + dcomp_dzp + dspec_dzp + dadia_dzp + dCMBheat_dzp + eps_Lya_cont +
+                   eps_Lya_inj) *
+                  dzp;
+        if (Tk < 0) Tk = a.Trad;
+
+        const double J_alpha_tot = dstarlya_dt + dxlya_dt;
+        const double T_inv = 1 / Tk, T_inv_sq = T_inv * T_inv;
+        const double lnTk = log(Tk);
+        const double xc_fast =
+            (1.0 + delta) * a.xc_inverse *
+            ((1.0 - x_e) * a.No * kappa_10(lnTk) +
+             x_e * a.N_b0 *
+                 kappa_linear_tail(kKappaEH, C21CM_KAPPA_EH_BINWIDTH, C21CM_KAPPA_EH_LNT_MAX, lnTk) +
+             x_e * a.No *
+                 kappa_linear_tail(kKappaPH, C21CM_KAPPA_PH_BINWIDTH, C21CM_KAPPA_PH_LNT_MAX, lnTk));
+        const double xi_power = a.Ts_prefactor * cbrt((1.0 + delta) * (1.0 - x_e) * T_inv_sq);
+        const double xa_arg = a.xa_tilde_prefactor * J_alpha_tot /
+                              (1.0 + 2.98394 * xi_power + 1.53583 * xi_power * xi_power +
+                               3.85289 * xi_power * xi_power * xi_power);
+        const double Trad_inv = 1.0 / a.Trad;
+        double TS;
+        if (J_alpha_tot > 1.0e-20) {
+            double TSold = 0.0;
+            TS = a.Trad;
+            int guard = 0;  // the fixed point converges in a handful of steps; NaNs end the loop
+            while (fabs(TS - TSold) / TS > 1.0e-3 && guard++ < 10000) {
+                TSold = TS;
+                const double TS_inv = 1. / TS;
+                const double xa = (1.0 - 0.0631789 * T_inv + 0.115995 * T_inv_sq -
+                                   0.401403 * T_inv * TS_inv + 0.336463 * T_inv_sq * TS_inv) *
+                                  xa_arg;
+                TS = (xCMB + xa + xc_fast) /
+                     (xCMB * Trad_inv +
+                      xa * (T_inv + 0.405535 * T_inv * TS_inv - 0.405535 * T_inv_sq) +
+                      xc_fast * T_inv);
+            }
+        } else {
+            TS = (xCMB + xc_fast) / (xCMB * Trad_inv + xc_fast * T_inv);
+        }
+        TS = fabs(TS);
+        const float Ts_f = (float)TS;
+        Ts_out[i] = Ts_f;
+        Tk_out[i] = (float)Tk;
+        xe_out[i] = (float)x_e;
+        if (!isfinite(Ts_f)) bad = 1;
+        s_Ts += TS;
+        s_Tk += Tk;
+        s_xe += x_e;
+        s_Ja += dxlya_dt + dstarlya_dt;
+        s_heat += dxheat_dt;
+        s_ion += dxion_dt;
+    }
+    if (bad) atomicOr(flag, 1);
+    double sums[6] = {s_Ts, s_Tk, s_xe, s_Ja, s_heat, s_ion};
+    for (int k = 0; k < 6; k++) {
+        const double r = block_sum(sums[k], red);
+        if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = r;
+    }
+}
+
+// the six box sums of ts_cell_kernel's per-block partials
+__global__ void __launch_bounds__(kBlock)
+ts_finish_kernel(const double *__restrict__ partials, int nblocks, double *__restrict__ out) {
+    __shared__ double lds[kBlock];
+    const int k = blockIdx.x;
+    double acc = 0.;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += partials[(size_t)k * nblocks + i];
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) out[k] = acc;
+}
+
+// init_first_Ts (:892-927): T_k = TK (1 + cT_ad delta), x_e, collisional T_s at the mean TK
+__global__ void __launch_bounds__(kBlock)
+ts_first_kernel(const float *__restrict__ density, float inv_growth_z, float growth_zp, double TK,
+                double xe_d, double cT_ad, double xc_per_density, float TKf, double Trad,
+                float *__restrict__ Ts_out, float *__restrict__ Tk_out, float *__restrict__ xe_out,
+                size_t ntot) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const double gdens = (double)(density[i] * inv_growth_z * growth_zp);  // float products
+        Tk_out[i] = (float)(TK * (1.0 + cT_ad * gdens));
+        xe_out[i] = (float)xe_d;
+        const float delta = (float)gdens;
+        const double xc = xc_per_density * (1.0 + delta);
+        Ts_out[i] = (float)((1.0 + xc) / (1.0 / Trad + xc / TKf));
+    }
+}
+}  // namespace
+
+extern "C" size_t c21hip_ts_table_doubles(int n_step) {
+    return (size_t)(SH_COUNT + 3 * C21CM_X_INT_NXHII) * n_step;
+}
+
+extern "C" int c21hip_ts_sfrd_means(const float *filtered_density, const float *tables_dev,
+                                    double *dev_tab, const double *mean_sfr_zpp_dev, int n_step,
+                                    size_t ntot, double *partials, double *ave_out_dev,
+                                    void *stream) {
+    int bx = grid_for(ntot);
+    if (bx > 512) bx = 512;  // n_step rows of blocks fill the chip
+    hipLaunchKernelGGL(sfrd_sum_kernel, dim3(bx, n_step), dim3(kBlock), 0, (hipStream_t)stream,
+                       filtered_density, tables_dev, dev_tab, n_step, ntot, partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sfrd_finish_kernel, dim3(n_step), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, bx, mean_sfr_zpp_dev, (double)ntot, n_step, dev_tab, ave_out_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, const float *prev_Ts,
+                               const float *prev_Tk, const float *prev_xe, const float *grid_a,
+                               const float *grid_b, const float *tables_dev, const double *dev_tab,
+                               const double *lya_dEC_dev, const double *lya_dEI_dev, float *Ts_out,
+                               float *Tk_out, float *xe_out, size_t ntot, double *partials,
+                               double *sums_out_dev, int *flag_dev, void *stream) {
+    const int blocks = grid_for(ntot);
+    const size_t lds = (c21hip_ts_table_doubles(a->n_step) + kBlock) * sizeof(double);
+    if (lds > 64 * 1024) {
+        c21hip_set_error("spin temperature: %d shells do not fit the table cache", a->n_step);
+        return C21CM_VALUE_ERROR;
+    }
+    hipLaunchKernelGGL(ts_cell_kernel, dim3(blocks), dim3(kBlock), lds, (hipStream_t)stream, *a,
+                       density, prev_Ts, prev_Tk, prev_xe, grid_a, grid_b, tables_dev, dev_tab,
+                       lya_dEC_dev, lya_dEI_dev, Ts_out, Tk_out, xe_out, ntot, partials, flag_dev);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ts_finish_kernel, dim3(6), dim3(kBlock), 0, (hipStream_t)stream, partials,
+                       blocks, sums_out_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// host-side collision rates at the mean temperature (get_Ts: float z, TK, xe)
+static double host_kappa(const double *y, double width, double lnT_max, double lnT, int power_law) {
+    double ans;
+    if (lnT < 0.)
+        ans = y[0];
+    else if (lnT > lnT_max) {
+        if (power_law)
+            ans = log(exp(y[C21CM_KAPPA_NPTS - 1]) * pow(exp(lnT) / exp(lnT_max), 0.381));
+        else
+            ans = y[C21CM_KAPPA_NPTS - 1] + (y[C21CM_KAPPA_NPTS - 1] - y[C21CM_KAPPA_NPTS - 2]) /
+                                                (lnT_max - width * (C21CM_KAPPA_NPTS - 2)) *
+                                                (lnT - lnT_max);
+    } else {
+        int idx = (int)floor(lnT * (1. / width));
+        if (idx > C21CM_KAPPA_NPTS - 2) idx = C21CM_KAPPA_NPTS - 2;
+        ans = y[idx] + (lnT - width * (double)idx) * (y[idx + 1] - y[idx]) * (1. / width);
+    }
+    return exp(ans);
+}
+
+extern "C" void c21hip_kappa_rates(double T, double *k_HH, double *k_eH, double *k_pH) {
+    static const double hh[C21CM_KAPPA_NPTS] = C21CM_KAPPA_HH_VALUES;
+    static const double ph[C21CM_KAPPA_NPTS] = C21CM_KAPPA_PH_VALUES;
+    static const double eh[C21CM_KAPPA_NPTS] = C21CM_KAPPA_EH_VALUES;
+    const double lnT = log(T);
+    *k_HH = host_kappa(hh, C21CM_KAPPA_HH_BINWIDTH, C21CM_KAPPA_HH_LNT_MAX, lnT, 1);
+    *k_eH = host_kappa(eh, C21CM_KAPPA_EH_BINWIDTH, C21CM_KAPPA_EH_LNT_MAX, lnT, 0);
+    *k_pH = host_kappa(ph, C21CM_KAPPA_PH_BINWIDTH, C21CM_KAPPA_PH_LNT_MAX, lnT, 0);
+}
+
+extern "C" int c21hip_ts_first(const c21cm_ts_first_spec *s, const float *density, float *Ts_out,
+                               float *Tk_out, float *xe_out, size_t ntot, void *stream) {
+    const float z = (float)s->perturbed_redshift, xe = (float)s->xe, TK = (float)s->TK;
+    const double Trad = s->T_cmb * (1.0 + z);
+    double k_HH, k_eH, k_pH;
+    c21hip_kappa_rates(TK, &k_HH, &k_eH, &k_pH);
+    // xcoll (heating_helper_progs.c:695-728) without its (1 + delta) factor
+    const double cube = pow(1.0 + z, 3.0);
+    const double xc_per_density = s->T_21 / Trad * ((1.0 - xe) * s->No * cube) * k_HH / s->A10 +
+                                  s->T_21 / Trad * (xe * s->N_b0 * cube) * k_eH / s->A10 +
+                                  s->T_21 / Trad * (xe * s->No * cube) * k_pH / s->A10;
+    hipLaunchKernelGGL(ts_first_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0, (hipStream_t)stream,
+                       density, s->inverse_growth_factor_z, s->growth_factor_zp, s->TK, s->xe,
+                       s->cT_ad, xc_per_density, TK, Trad, Ts_out, Tk_out, xe_out, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,258 @@
+/*
+ * ts_driver.c -- C host driver of the per-cell part of ComputeTsBox.
+ *
+ * reference: src/py21cmfast/src/SpinTemperatureBox.c
+ *   :892-927    init_first_Ts                       -> c21cm_ts_first_grids
+ *   :1387-1946  ts_main from the first cell loop on -> c21cm_ts_grids
+ *
+ * The host side only moves tables: the per-shell scalars and the frequency-integral tables
+ * of the spec go to one small device buffer, the SFRD tables / Lyman-alpha heating tables
+ * to their own, and two launches (three with SFRD tables) do the rest (ts_kernels.hip).
+ * Host arrays are staged through workspace slots, device arrays are used in place; the big
+ * [n_step][N] source grids are the only large transfer and are read exactly once.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../hip/c21hip.h"
+#include "c21cm_grid.h"
+
+/* slots 150-169 (0-143 belong to the other drivers) */
+enum {
+    WS_TS_DENS = 150, WS_TS_PTS, WS_TS_PTK, WS_TS_PXE, WS_TS_GRID_A, WS_TS_GRID_B, WS_TS_TAB,
+    WS_TS_SFRDTAB, WS_TS_LYA_C, WS_TS_LYA_I, WS_TS_OTS, WS_TS_OTK, WS_TS_OXE, WS_TS_PART,
+    WS_TS_SMALL, WS_TS_MEANSFR
+};
+
+#define TRY(expr)         \
+    do {                  \
+        int st_ = (expr); \
+        if (st_) {        \
+            status = st_; \
+            goto done;    \
+        }                 \
+    } while (0)
+
+static const void *stage_in(int slot, const void *p, size_t bytes, void *stream, int *status) {
+    if (*status || !p || c21hip_is_device_ptr(p)) return p;
+    void *d = c21hip_ws(slot, bytes);
+    if (!d) {
+        c21hip_set_error("spin temperature: out of device memory staging %zu bytes", bytes);
+        *status = C21CM_MEMORY_ALLOC_ERROR;
+        return NULL;
+    }
+    *status = c21hip_h2d(d, p, bytes, stream);
+    return d;
+}
+
+static float *stage_out(int slot, float *p, size_t bytes, int *status) {
+    if (*status || c21hip_is_device_ptr(p)) return p;
+    float *d = (float *)c21hip_ws(slot, bytes);
+    if (!d) *status = C21CM_MEMORY_ALLOC_ERROR;
+    return d;
+}
+
+static int check_boxes(const char *who, const TsBox *b) {
+    if (!b || !b->spin_temperature || !b->kinetic_temp_neutral || !b->xray_ionised_fraction) {
+        c21hip_set_error("spin temperature: %s needs spin_temperature, kinetic_temp_neutral and "
+                         "xray_ionised_fraction", who);
+        return C21CM_VALUE_ERROR;
+    }
+    return 0;
+}
+
+int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *previous,
+                   const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
+                   c21cm_ts_report *report, void *stream) {
+    int status = 0;
+    if (!s || !density) {
+        c21hip_set_error("spin temperature: spec and density are required");
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->hii_dim < 1 || s->hii_dim_z < 1 || s->n_step < 1 || s->n_step > C21CM_MAX_TS_RADII) {
+        c21hip_set_error("spin temperature: bad geometry %d x %d x %d, %d shells (<= %d)",
+                         s->hii_dim, s->hii_dim, s->hii_dim_z, s->n_step, C21CM_MAX_TS_RADII);
+        return C21CM_VALUE_ERROR;
+    }
+    if ((status = check_boxes("the previous box", previous))) return status;
+    if ((status = check_boxes("the output box", out))) return status;
+    const int lagrangian = s->source_mode == C21CM_TS_SRC_GRIDS;
+    if (!lagrangian && s->source_mode != C21CM_TS_SRC_SFRD_TABLE) {
+        c21hip_set_error("spin temperature: unknown source_mode %d", s->source_mode);
+        return C21CM_VALUE_ERROR;
+    }
+    if (!s->freq_int_heat || !s->freq_int_ion || !s->freq_int_lya) {
+        c21hip_set_error("spin temperature: the three frequency-integral tables are required");
+        return C21CM_VALUE_ERROR;
+    }
+    if (s->use_lya_heating && (!s->lya_dEC || !s->lya_dEI)) {
+        c21hip_set_error("spin temperature: USE_LYA_HEATING needs the two heating-efficiency tables");
+        return C21CM_VALUE_ERROR;
+    }
+    if (lagrangian && (!source_box || !source_box->filtered_sfr || !source_box->filtered_xray)) {
+        c21hip_set_error("spin temperature: Lagrangian sources need XraySourceBox.filtered_sfr and "
+                         "filtered_xray");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!lagrangian && (!filtered_density || !s->ln_sfrd_tables)) {
+        c21hip_set_error("spin temperature: Eulerian sources need the filtered densities and the "
+                         "SFRD tables");
+        return C21CM_VALUE_ERROR;
+    }
+    if (c21hip_device_count() < 1) {
+        c21hip_set_error("spin temperature: no MI355X device visible");
+        return C21CM_IO_ERROR;
+    }
+
+    const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
+    const size_t bytes = ntot * sizeof(float);
+    const int n = s->n_step;
+
+    /* ---- small tables -> one device buffer */
+    const size_t n_tab = c21hip_ts_table_doubles(n);
+    double *host_tab = (double *)malloc(n_tab * sizeof(double));
+    if (!host_tab) return C21CM_MEMORY_ALLOC_ERROR;
+    {
+        const double *rows[C21HIP_TS_SHELL_ROWS] = {
+            s->z_edge_factor, s->xray_R_factor, s->starlya_prefactor, s->lya_cont_prefactor,
+            s->lya_inj_prefactor, s->zpp_growth, s->tab_min, s->tab_width, NULL};
+        for (int r = 0; r < C21HIP_TS_SHELL_ROWS; r++)
+            for (int i = 0; i < n; i++) host_tab[r * n + i] = rows[r] ? rows[r][i] : 1.;
+        double *f = host_tab + (size_t)C21HIP_TS_SHELL_ROWS * n;
+        const size_t fn = (size_t)C21CM_X_INT_NXHII * n;
+        memcpy(f, s->freq_int_heat, fn * sizeof(double));
+        memcpy(f + fn, s->freq_int_ion, fn * sizeof(double));
+        memcpy(f + 2 * fn, s->freq_int_lya, fn * sizeof(double));
+    }
+    double *dev_tab = (double *)c21hip_ws(WS_TS_TAB, n_tab * sizeof(double));
+    double *small = (double *)c21hip_ws(WS_TS_SMALL, (8 + (size_t)n) * sizeof(double) + 64);
+    double *partials = (double *)c21hip_ws(WS_TS_PART, (size_t)(512 * n + 6 * 2048) * sizeof(double));
+    if (!dev_tab || !small || !partials) {
+        status = C21CM_MEMORY_ALLOC_ERROR;
+        goto done;
+    }
+    double *sums_dev = small, *ave_dev = small + 8;
+    int *flag_dev = (int *)(small + 8 + n);
+    TRY(c21hip_h2d(dev_tab, host_tab, n_tab * sizeof(double), stream));
+    TRY(c21hip_memset(flag_dev, 0, sizeof(int), stream));
+
+    const float *tables_dev = NULL;
+    const double *lya_c = NULL, *lya_i = NULL;
+    if (!lagrangian)
+        tables_dev = (const float *)stage_in(WS_TS_SFRDTAB, s->ln_sfrd_tables,
+                                             (size_t)n * C21CM_NDELTA_TABLE * sizeof(float), stream,
+                                             &status);
+    if (s->use_lya_heating) {
+        const size_t lb = (size_t)C21CM_LYA_NT * C21CM_LYA_NT * C21CM_LYA_NGP * sizeof(double);
+        lya_c = (const double *)stage_in(WS_TS_LYA_C, s->lya_dEC, lb, stream, &status);
+        lya_i = (const double *)stage_in(WS_TS_LYA_I, s->lya_dEI, lb, stream, &status);
+    }
+    if (status) goto done;
+
+    /* ---- grids */
+    const float *d_dens = (const float *)stage_in(WS_TS_DENS, density, bytes, stream, &status);
+    const float *d_pts = (const float *)stage_in(WS_TS_PTS, previous->spin_temperature, bytes, stream, &status);
+    const float *d_ptk = (const float *)stage_in(WS_TS_PTK, previous->kinetic_temp_neutral, bytes, stream, &status);
+    const float *d_pxe = (const float *)stage_in(WS_TS_PXE, previous->xray_ionised_fraction, bytes, stream, &status);
+    const float *grid_a = NULL, *grid_b = NULL;
+    if (!s->no_light) {
+        if (lagrangian) {
+            grid_a = (const float *)stage_in(WS_TS_GRID_A, source_box->filtered_sfr, bytes * n, stream, &status);
+            grid_b = (const float *)stage_in(WS_TS_GRID_B, source_box->filtered_xray, bytes * n, stream, &status);
+        } else {
+            grid_a = (const float *)stage_in(WS_TS_GRID_A, filtered_density, bytes * n, stream, &status);
+        }
+    }
+    float *o_ts = stage_out(WS_TS_OTS, out->spin_temperature, bytes, &status);
+    float *o_tk = stage_out(WS_TS_OTK, out->kinetic_temp_neutral, bytes, &status);
+    float *o_xe = stage_out(WS_TS_OXE, out->xray_ionised_fraction, bytes, &status);
+    if (status) goto done;
+
+    c21hip_ts_args a;
+    memset(&a, 0, sizeof(a));
+    a.n_step = n;
+    a.lagrangian = lagrangian;
+    a.use_xray_heating = s->use_xray_heating;
+    a.use_cmb_heating = s->use_cmb_heating;
+    a.use_lya_heating = s->use_lya_heating;
+    a.no_light = s->no_light;
+#define CP(f) a.f = s->f
+    CP(redshift); CP(dzp); CP(growth_ratio); CP(No); CP(N_b0); CP(h_frac); CP(he_frac); CP(k_B);
+    CP(h_p); CP(m_p); CP(c_cms); CP(A10); CP(T_21); CP(lambda_21); CP(nu_Ly_alpha);
+    CP(clumping_factor); CP(xray_prefactor); CP(Trad); CP(Ts_prefactor); CP(xa_tilde_prefactor);
+    CP(xc_inverse); CP(dcomp_dzp_prefactor); CP(Nb_zp); CP(N_zp); CP(lya_star_prefactor);
+    CP(volunit_inv); CP(hubble_zp); CP(growth_zp); CP(dgrowth_dzp); CP(dt_dzp); CP(sfr_scale);
+    CP(xray_scale);
+#undef CP
+
+    if (!lagrangian && !s->no_light) { /* avg_fix_term of every shell (:1621-1626) */
+        double *mean_dev = (double *)c21hip_ws(WS_TS_MEANSFR, (size_t)n * sizeof(double));
+        if (!mean_dev) {
+            status = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+        TRY(c21hip_h2d(mean_dev, s->mean_sfr_zpp, (size_t)n * sizeof(double), stream));
+        TRY(c21hip_ts_sfrd_means(grid_a, tables_dev, dev_tab, mean_dev, n, ntot, partials, ave_dev,
+                                 stream));
+    }
+    TRY(c21hip_ts_cells(&a, d_dens, d_pts, d_ptk, d_pxe, grid_a, grid_b, tables_dev, dev_tab, lya_c,
+                        lya_i, o_ts, o_tk, o_xe, ntot, partials + (size_t)512 * n, sums_dev,
+                        flag_dev, stream));
+
+    if (o_ts != out->spin_temperature) TRY(c21hip_d2h(out->spin_temperature, o_ts, bytes, stream));
+    if (o_tk != out->kinetic_temp_neutral) TRY(c21hip_d2h(out->kinetic_temp_neutral, o_tk, bytes, stream));
+    if (o_xe != out->xray_ionised_fraction) TRY(c21hip_d2h(out->xray_ionised_fraction, o_xe, bytes, stream));
+    {
+        double back[8 + C21CM_MAX_TS_RADII + 8];
+        TRY(c21hip_d2h(back, small, (8 + (size_t)n) * sizeof(double) + sizeof(int), stream));
+        TRY(c21hip_sync(stream));
+        int flag;
+        memcpy(&flag, back + 8 + n, sizeof(int));
+        if (report) {
+            memset(report, 0, sizeof(*report));
+            report->Ts_ave = back[0] / (double)ntot;
+            report->Tk_ave = back[1] / (double)ntot;
+            report->x_e_ave = back[2] / (double)ntot;
+            report->J_alpha_ave = back[3] / (double)ntot;
+            report->xheat_ave = back[4] / (double)ntot;
+            report->xion_ave = back[5] / (double)ntot;
+            if (!lagrangian && !s->no_light)
+                for (int i = 0; i < n; i++) report->ave_sfrd[i] = back[8 + i];
+        }
+        if (flag) {
+            c21hip_set_error("Estimated spin temperature is either infinite or NaN");
+            status = C21CM_INFINITY_OR_NAN_ERROR;
+        }
+    }
+done:
+    free(host_tab);
+    return status;
+}
+
+int c21cm_ts_first_grids(const c21cm_ts_first_spec *s, const float *density, TsBox *out,
+                         void *stream) {
+    int status = 0;
+    if (!s || !density || s->hii_dim < 1 || s->hii_dim_z < 1) {
+        c21hip_set_error("init_first_Ts: spec, density and a grid geometry are required");
+        return C21CM_VALUE_ERROR;
+    }
+    if ((status = check_boxes("the output box", out))) return status;
+    if (c21hip_device_count() < 1) {
+        c21hip_set_error("init_first_Ts: no MI355X device visible");
+        return C21CM_IO_ERROR;
+    }
+    const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z, bytes = ntot * sizeof(float);
+    const float *d_dens = (const float *)stage_in(WS_TS_DENS, density, bytes, stream, &status);
+    float *o_ts = stage_out(WS_TS_OTS, out->spin_temperature, bytes, &status);
+    float *o_tk = stage_out(WS_TS_OTK, out->kinetic_temp_neutral, bytes, &status);
+    float *o_xe = stage_out(WS_TS_OXE, out->xray_ionised_fraction, bytes, &status);
+    if (status) goto done;
+    TRY(c21hip_ts_first(s, d_dens, o_ts, o_tk, o_xe, ntot, stream));
+    if (o_ts != out->spin_temperature) TRY(c21hip_d2h(out->spin_temperature, o_ts, bytes, stream));
+    if (o_tk != out->kinetic_temp_neutral) TRY(c21hip_d2h(out->kinetic_temp_neutral, o_tk, bytes, stream));
+    if (o_xe != out->xray_ionised_fraction) TRY(c21hip_d2h(out->xray_ionised_fraction, o_xe, bytes, stream));
+    TRY(c21hip_sync(stream));
+done:
+    return status;
+}

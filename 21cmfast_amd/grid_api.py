@@ -456,3 +456,35 @@ def annular_filter_grids(spec: S.AnnularSpec, inputs, stream=None) -> dict:
     check(load().c21cm_annular_filter_grids(C.byref(spec), in_p, out_p, u, f, _stream(stream)),
           "c21cm_annular_filter_grids")
     return {"outputs": outputs, "u_avg": np.array(u[:]), "f_avg": np.array(f[:])}
+
+
+TS_FIELDS = ("spin_temperature", "kinetic_temp_neutral", "xray_ionised_fraction")
+
+
+def ts_grids(spec: S.TsSpec, density, previous: dict, source: dict | None = None,
+             filtered_density=None, stream=None) -> dict:
+    """The per-cell part of ComputeTsBox on the MI355X (reference:
+    src/py21cmfast/src/SpinTemperatureBox.c:1387-1946 from the first cell loop on): the R loop
+    over the source grids (``source``: filtered_sfr / filtered_xray [n_step, ...], Lagrangian
+    models) or over the filtered densities (``filtered_density`` [n_step, ...] with the spec's
+    SFRD tables), then the x_e / T_k update and T_s of every cell.  ``previous``: the three boxes
+    of the previous snapshot.  Outputs live where ``density`` lives; ``report`` holds box means."""
+    out = {k: _new_like(density, 0.0) for k in TS_FIELDS}
+    prev = S.TsBoxStruct(**{k: _fptr(previous[k]) for k in TS_FIELDS})
+    box = S.TsBoxStruct(**{k: _fptr(out[k]) for k in TS_FIELDS})
+    src = S.XraySourceBoxStruct(**{k: _fptr(v) for k, v in (source or {}).items()})
+    rep = S.TsReport()
+    check(load().c21cm_ts_grids(C.byref(spec), _vptr(density), C.byref(prev), C.byref(src),
+                                _vptr(filtered_density), C.byref(box), C.byref(rep),
+                                _stream(stream)), "c21cm_ts_grids")
+    out["report"] = rep
+    return out
+
+
+def ts_first_grids(spec: S.TsFirstSpec, density, stream=None) -> dict:
+    """init_first_Ts (SpinTemperatureBox.c:892-927) on the MI355X."""
+    out = {k: _new_like(density, 0.0) for k in TS_FIELDS}
+    box = S.TsBoxStruct(**{k: _fptr(out[k]) for k in TS_FIELDS})
+    check(load().c21cm_ts_first_grids(C.byref(spec), _vptr(density), C.byref(box), _stream(stream)),
+          "c21cm_ts_first_grids")
+    return out

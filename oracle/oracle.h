@@ -10,7 +10,7 @@
  * Pinning status: the reference itself cannot be built in this image (FFTW and
  * GSL headers/libraries are absent, Python is 3.10 < 3.12), so
  * the oracle is pinned through what the reference HOLDS:
- *  (1) its HDF5 fixtures (tests/golden/reference/*.h5, copied data files of the
+ *  (1) its HDF5 fixtures (the .h5 files of tests/golden/reference, copied data files of the
  *      reference's tests/test_data): with the reference's GSL random stream
  *      restated (oracle_gslrng.c), seed 12345 gives the reference's universe and
  *      the chain ICs -> PerturbedField -> [HaloBox ->] IonizedBox -> BrightnessTemp,
