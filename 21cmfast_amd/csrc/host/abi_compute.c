@@ -34,6 +34,7 @@
 #include "../hip/c21hip.h"
 #include "c21cm_grid.h"
 #include "cosmology.h"
+#include "heating.h"
 
 #define L_FACTOR 0.620350491 /* Constants.c:41 */
 #define FRACT_FLOAT_ERR 1e-7
@@ -519,6 +520,115 @@ int UpdateXraySourceBox(HaloBox *halobox, double R_inner, double R_outer, int R_
         source_box->mean_log10_Mcrit_LW[R_ct] = halobox->log10_Mcrit_MCG_ave;
     }
     return 0;
+}
+
+/* Box mean as ts_main takes it (:1479-1489): double sum, divided by (float)N. */
+static int box_mean(const float *v, size_t n, double *mean) {
+    if (c21hip_is_device_ptr(v)) {
+        double *scratch = (double *)c21hip_ws(171, (C21HIP_PARTIALS + 1) * sizeof(double));
+        if (!scratch) return C21CM_MEMORY_ALLOC_ERROR;
+        int st = c21hip_sum_float(v, n, scratch + 1, scratch, NULL);
+        if (st) return st;
+        double sum;
+        if ((st = c21hip_d2h(&sum, scratch, sizeof(double), NULL))) return st;
+        if ((st = c21hip_sync(NULL))) return st;
+        *mean = sum / (float)n;
+        return 0;
+    }
+    double sum = 0;
+    for (size_t i = 0; i < n; i++) sum += v[i];
+    *mean = sum / (float)n;
+    return 0;
+}
+
+/* reference: src/py21cmfast/src/SpinTemperatureBox.c:87-115 (ComputeTsBox) and :1387-1946 (ts_main).
+ * Host: shells, spectral factors, z' constants, N_ion(z) / SFRD(z) tables, tau_X = 1 frequencies
+ * and the frequency-integral tables (heating.c); device: the density filter loop of the Eulerian
+ * source model (tsfilter_driver.c) and the cell sweep (ts_driver.c / ts_kernels.hip).
+ * Supported: SOURCE_MODEL E-INTEGRAL (SFRD from the filtered density) and the Lagrangian models
+ * (XraySourceBox grids), with interpolation tables; not: USE_MINI_HALOS, CONST-ION-EFF. */
+int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
+                 PerturbedField *perturbed_field, XraySourceBox *source_box,
+                 TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp) {
+    (void)cleanup;
+    (void)ini_boxes;
+    int st = require_globals("ComputeTsBox", 1);
+    if (st) return st;
+    if (!perturbed_field || !perturbed_field->density || !this_spin_temp) {
+        c21hip_set_error("ComputeTsBox: the perturbed field and the output box are required");
+        return C21CM_VALUE_ERROR;
+    }
+    if ((st = ensure_ps())) return st;
+    const SimulationOptions *so = simulation_options_global;
+    const AstroOptions *ao = astro_options_global;
+    int dim, dim_z, hii, hii_z;
+    double box_len, box_len_z;
+    geometry(&dim, &dim_z, &hii, &hii_z, &box_len, &box_len_z);
+    const size_t ntot = (size_t)hii * hii * hii_z;
+
+    if (redshift >= so->Z_HEAT_MAX) { /* init_first_Ts :1424-1429 */
+        if ((st = c21_recfast_load())) return st;
+        c21cm_ts_first_spec f;
+        memset(&f, 0, sizeof(f));
+        f.hii_dim = hii, f.hii_dim_z = hii_z;
+        f.redshift = redshift;
+        f.perturbed_redshift = perturbed_field_redshift;
+        f.growth_factor_zp = dicke(redshift);
+        f.inverse_growth_factor_z = 1 / dicke(perturbed_field_redshift);
+        f.xe = c21_xion_RECFAST(redshift);
+        f.TK = c21_T_RECFAST(redshift);
+        f.cT_ad = ao->USE_ADIABATIC_FLUCTUATIONS ? c21_cT_approx(redshift) : 0.;
+        f.N_b0 = c21_nb0();
+        f.No = f.N_b0 * (1 - cosmo_params_global->Y_He) / (1 - 0.75 * cosmo_params_global->Y_He);
+        f.A10 = 2.85e-15, f.T_21 = 0.0682, f.T_cmb = 2.7255; /* Constants.c:24-33 */
+        return c21cm_ts_first_grids(&f, perturbed_field->density, this_spin_temp, NULL);
+    }
+    if (!previous_spin_temp || !previous_spin_temp->xray_ionised_fraction) {
+        c21hip_set_error("ComputeTsBox: below Z_HEAT_MAX the previous spin-temperature box is needed");
+        return C21CM_VALUE_ERROR;
+    }
+    double x_e_ave_p;
+    if ((st = box_mean(previous_spin_temp->xray_ionised_fraction, ntot, &x_e_ave_p))) return st;
+
+    c21cm_ts_spec *spec = (c21cm_ts_spec *)calloc(1, sizeof(*spec));
+    c21_ts_tables *tab = (c21_ts_tables *)calloc(1, sizeof(*tab));
+    if (!spec || !tab) {
+        free(spec), free(tab);
+        return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    const float *filtered = NULL;
+    if ((st = c21_ts_prepare(redshift, prev_redshift, perturbed_field_redshift, x_e_ave_p, spec, tab)))
+        goto done;
+    if (spec->source_mode == C21CM_TS_SRC_SFRD_TABLE && !spec->no_light) {
+        /* prepare_filter_boxes + fill_Rbox_table (:1453-1463): delNL0[R] stays on the device */
+        c21cm_rbox_spec r;
+        memset(&r, 0, sizeof(r));
+        r.hii_dim = hii, r.hii_dim_z = hii_z, r.box_len = box_len, r.box_len_z = box_len_z;
+        r.filter_type = ao->HEAT_FILTER;
+        r.n_R = tab->n_step;
+        for (int i = 0; i < tab->n_step; i++) r.R[i] = tab->R_values[i];
+        r.cell_radius = 0.620350491 * so->BOX_LEN / (float)so->HII_DIM; /* physconst.l_factor */
+        r.min_value = -1;
+        r.const_factor = 1. / dicke(perturbed_field_redshift);
+        float *delNL0 = (float *)c21hip_ws(170, (size_t)tab->n_step * ntot * sizeof(float));
+        if (!delNL0) {
+            c21hip_set_error("ComputeTsBox: out of device memory for %d filtered density grids", tab->n_step);
+            st = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+        double mn[C21CM_MAX_TS_RADII], av[C21CM_MAX_TS_RADII], mx[C21CM_MAX_TS_RADII];
+        if ((st = c21cm_fill_Rbox_grids(&r, perturbed_field->density, delNL0, mn, av, mx, NULL))) goto done;
+        if ((st = c21_ts_sfrd_tables(mn, mx, spec, tab))) goto done;
+        filtered = delNL0;
+    }
+    st = c21cm_ts_grids(spec, perturbed_field->density, previous_spin_temp, source_box, filtered,
+                        this_spin_temp, NULL, NULL);
+    if (!st) this_spin_temp->Q_HI = tab->Q_HI;
+done:
+    c21_ts_tables_free(tab);
+    free(tab);
+    free(spec);
+    return st;
 }
 
 /* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436.  Only the

@@ -90,12 +90,13 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
         c21hip_set_error("spin temperature: USE_LYA_HEATING needs the two heating-efficiency tables");
         return C21CM_VALUE_ERROR;
     }
-    if (lagrangian && (!source_box || !source_box->filtered_sfr || !source_box->filtered_xray)) {
+    if (lagrangian && !s->no_light &&
+        (!source_box || !source_box->filtered_sfr || !source_box->filtered_xray)) {
         c21hip_set_error("spin temperature: Lagrangian sources need XraySourceBox.filtered_sfr and "
                          "filtered_xray");
         return C21CM_VALUE_ERROR;
     }
-    if (!lagrangian && (!filtered_density || !s->ln_sfrd_tables)) {
+    if (!lagrangian && !s->no_light && (!filtered_density || !s->ln_sfrd_tables)) {
         c21hip_set_error("spin temperature: Eulerian sources need the filtered densities and the "
                          "SFRD tables");
         return C21CM_VALUE_ERROR;
@@ -139,7 +140,7 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
 
     const float *tables_dev = NULL;
     const double *lya_c = NULL, *lya_i = NULL;
-    if (!lagrangian)
+    if (!lagrangian && !s->no_light)
         tables_dev = (const float *)stage_in(WS_TS_SFRDTAB, s->ln_sfrd_tables,
                                              (size_t)n * C21CM_NDELTA_TABLE * sizeof(float), stream,
                                              &status);

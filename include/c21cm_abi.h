@@ -341,6 +341,18 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
                       TsBox *spin_temp, HaloBox *halos, InitialConditions *ini_boxes,
                       IonizedBox *box);
 
+/* reference: src/py21cmfast/src/SpinTemperatureBox.c:87 (_functionprototypes_wrapper.h:19-22).
+ * E-INTEGRAL and the Lagrangian source models with interpolation tables; USE_MINI_HALOS and
+ * CONST-ION-EFF return ValueError.  `cleanup` is accepted and ignored (nothing is cached per call
+ * beyond the data tables). */
+int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
+                 PerturbedField *perturbed_field, XraySourceBox *source_box,
+                 TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp);
+/* reference: src/py21cmfast/src/heating_helper_progs.c:58-90 (_functionprototypes_wrapper.h):
+ * read the data tables under config_settings.external_table_path */
+int init_heat(void);
+void destruct_heat(void);
+
 /* reference: src/py21cmfast/src/HaloBox.c:563 (_functionprototypes_wrapper.h:31-32).  Only the
  * integrated branch (SOURCE_MODEL = L-INTEGRAL) is provided; `halos` is not read. */
 typedef struct HaloCatalog HaloCatalog;

@@ -242,7 +242,8 @@ static int ts_check(const c21cm_ts_spec *s) {
         return C21CM_VALUE_ERROR;
     if (!s->freq_int_heat || !s->freq_int_ion || !s->freq_int_lya) return C21CM_VALUE_ERROR;
     if (s->use_lya_heating && (!s->lya_dEC || !s->lya_dEI)) return C21CM_VALUE_ERROR;
-    if (s->source_mode == C21CM_TS_SRC_SFRD_TABLE && !s->ln_sfrd_tables) return C21CM_VALUE_ERROR;
+    if (s->source_mode == C21CM_TS_SRC_SFRD_TABLE && !s->no_light && !s->ln_sfrd_tables)
+        return C21CM_VALUE_ERROR;
     return 0;
 }
 
@@ -256,9 +257,10 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
         !out->kinetic_temp_neutral || !out->xray_ionised_fraction)
         return C21CM_VALUE_ERROR;
     const int lagrangian = s->source_mode == C21CM_TS_SRC_GRIDS;
-    if (lagrangian && (!source_box || !source_box->filtered_sfr || !source_box->filtered_xray))
+    if (lagrangian && !s->no_light &&
+        (!source_box || !source_box->filtered_sfr || !source_box->filtered_xray))
         return C21CM_VALUE_ERROR;
-    if (!lagrangian && !filtered_density) return C21CM_VALUE_ERROR;
+    if (!lagrangian && !s->no_light && !filtered_density) return C21CM_VALUE_ERROR;
 
     const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
     const int nR = s->n_step;

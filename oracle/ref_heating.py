@@ -68,7 +68,8 @@ def densities(c: Cosmo, Y_He: float = 0.24) -> Densities:
     return Densities(No, He, No + He, (1.0 - y) / (1.0 - 3.0 * y / 4.0), (y / 4.0) / (1.0 - 3.0 * y / 4.0))
 
 
-def drdz(c: Cosmo, z: float) -> float:  # cosmology.c:738-741: (1 + z) c dtdz
+def drdz(c: Cosmo, z: float) -> float:  # cosmology.c:778-779: (1 + z) c dtdz, float argument
+    z = _f32(z)
     return (1.0 + z) * PC["c_cms"] * c.dtdz(z)
 
 
@@ -361,17 +362,55 @@ def nu_integrand(tables: XIntTables, d: Densities, nu: float, x_e: float, flag: 
     return s * (nu / (NU_X_THRESH * eV)) ** (-X_RAY_SPEC_INDEX - 1)
 
 
-def integrate_over_nu(tables, d, c: Cosmo, zp, x_e, lower, flag, NU_X_MAX=10000.0, **kw) -> float:
+def integrate_over_nu(tables, d, c: Cosmo, zp, x_e, lower, flag, NU_X_MAX=10000.0, panels=150,
+                      **kw) -> float:
     """integrate_over_nu (:831-858).  The reference stops GSL's adaptive 15-point rule at a
-    relative error ESTIMATE of 1 %; this is the converged integral (the estimate is conservative:
-    the two agree far better than 1 %)."""
-    from scipy import integrate
-
+    relative error ESTIMATE of 1 %; this is the converged integral: composite 8-point
+    Gauss-Legendre over `panels` logarithmic panels (the integrand is piecewise smooth between the
+    258 energy knots of the tables, which an adaptive rule started on the whole range can miss)."""
     upper = NU_X_MAX * PC["eV_to_Hz"]
-    # the tables have kinks at every energy knot and the cross sections jump at the He edges
-    edges = [e for e in (PC["nu_ion_HeII"],) if lower < e < upper]
-    val, _ = integrate.quad(lambda nu: nu_integrand(tables, d, nu, x_e, flag, **kw), lower, upper,
-                            points=edges or None, limit=2000, epsrel=1e-6)
+    x, w = np.polynomial.legendre.leggauss(8)
+    edges = np.linspace(math.log(lower), math.log(upper), panels + 1)
+    val = 0.0
+    for a, b in zip(edges[:-1], edges[1:]):
+        lnnu = 0.5 * (a + b) + 0.5 * (b - a) * x
+        nu = np.exp(lnnu)
+        f = np.array([nu_integrand(tables, d, float(v), x_e, flag, **kw) for v in nu])
+        val += 0.5 * (b - a) * float(np.sum(w * f * nu))
     if flag == 2:
         return val * PC["c_cms"] / (4.0 * math.pi) / PC["nu_Ly_alpha"] / c.hubble(zp)
     return val
+
+
+# ------------------------------------------------------------------ tauX and the tau = 1 frequency
+def tauX(c: Cosmo, d: Densities, nu, x_e, x_e_ave, zp, zpp, ion_eff, nion_of_z) -> float:
+    """tauX (:1007-1059) for the mass-dependent source models: optical depth of the IGM between
+    zpp and zp for a photon received at frequency nu.  nion_of_z: the global collapsed ionising
+    fraction (EvaluateNionTs).  Converged quadrature (the reference stops at a 0.5 % estimate)."""
+    from scipy import integrate
+
+    nu_0 = nu / (1 + zp)
+
+    def f(zhat):
+        drpropdz = PC["c_cms"] * c.dtdz(zhat)
+        n = d.N_b0 * (1 + zhat) ** 3
+        fcoll = nion_of_z(zhat)
+        fill = 1.0 if fcoll < 1e-20 else 1 - ion_eff * fcoll / (1.0 - x_e_ave)
+        fill = max(fill, 1e-4)
+        return drpropdz * n * fill * weighted_cross_section(nu_0 * (1 + zhat), x_e, d)
+
+    val, _ = integrate.quad(f, zpp, zp, epsrel=1e-8, limit=500)
+    return val
+
+
+def nu_tau_one(c, d, zp, zpp, x_e, ion_eff, nion_of_z, NU_X_THRESH=500.0) -> float:
+    """nu_tau_one (:1135-1190): frequency at which tauX = 1, not below the HeI edge."""
+    from scipy import optimize
+
+    if x_e > 0.9999:
+        return NU_X_THRESH
+    lo = PC["nu_ion_HeI"]
+    if tauX(c, d, lo, x_e, x_e, zp, zpp, ion_eff, nion_of_z) < 1:
+        return lo
+    return optimize.brentq(lambda nu: tauX(c, d, nu, x_e, x_e, zp, zpp, ion_eff, nion_of_z) - 1, lo,
+                           1e6 * PC["eV_to_Hz"], rtol=1e-10)
