@@ -24,7 +24,7 @@ api_mod = "21cmfast_amd.grid_api"
 class Session:
     """What py21cmfast's GlobalInitializationManager does (drivers/_global_initialization.py)."""
 
-    def __init__(self, lib, tmp_path, **over):
+    def __init__(self, lib, tmp_path, data_dir=None, **over):
         self.lib = lib
         n = over.pop("HII_DIM", 32)
         self.so = S.default_simulation_options(
@@ -41,13 +41,16 @@ class Session:
         assert not over, over
         lib.Broadcast_struct_global_all(C.byref(self.so), C.byref(self.mo), C.byref(self.cp),
                                         C.byref(self.ap), C.byref(self.ao), C.byref(self.ct))
-        # synthetic RECFAST table (the real one ships with py21cmfast's _data directory)
-        z = np.arange(500, -1, -1.0)
-        with open(tmp_path / "recfast_LCDM.dat", "w") as f:
-            for a in z:
-                tk = 2.725 * (1 + a) ** 2 / 151.0
-                f.write(f"{a:8.2f} {2e-4 + 1e-6 * a:13.5E} {tk:13.5E} {tk:13.5E}\n")
-        self.path = str(tmp_path).encode()
+        if data_dir is not None:  # the reference's own tables (tests/golden/reference/_data)
+            self.path = str(data_dir).encode()
+        else:
+            # synthetic RECFAST table (the real one ships with py21cmfast's _data directory)
+            z = np.arange(500, -1, -1.0)
+            with open(tmp_path / "recfast_LCDM.dat", "w") as f:
+                for a in z:
+                    tk = 2.725 * (1 + a) ** 2 / 151.0
+                    f.write(f"{a:8.2f} {2e-4 + 1e-6 * a:13.5E} {tk:13.5E} {tk:13.5E}\n")
+            self.path = str(tmp_path).encode()
         S.ConfigSettings.in_dll(lib, "config_settings").external_table_path = self.path
         lib.init_ps.restype = None
         lib.init_ps()
