@@ -119,3 +119,107 @@ def test_nan_inputs_are_reported(api):
     d["previous"]["kinetic_temp_neutral"].flat[40] = np.nan
     with pytest.raises(BackendError):
         api.ts_grids(spec, d["density"], d["previous"], d["source"], None)
+
+
+def test_compute_ts_box_lagrangian_entry_point(gpu_lib, oracle, tmp_path):
+    """ComputeTsBox with a Lagrangian source model: the XraySourceBox grids go straight into the
+    cell sweep.  The oracle runs on the spec the library's host side prepared (its scalars are
+    pinned by tests/test_host_heating.py and by the reference fixtures), with and without
+    LYA_MULTIPLE_SCATTERING (which only changes how the source box was filtered)."""
+    import ctypes as C
+    from pathlib import Path
+
+    from test_gpu_abi import Session
+    from test_host_heating import Tables
+
+    lib = gpu_lib
+    n, n_step = 24, 40
+    data = Path(__file__).parent / "golden" / "reference" / "_data"
+    ses = Session(lib, tmp_path, data_dir=data, HII_DIM=n, DIM=2 * n, BOX_LEN=1.5 * n,
+                  SOURCE_MODEL=2, USE_TS_FLUCT=True, USE_LYA_HEATING=False, Z_HEAT_MAX=30.0)
+    rng = np.random.default_rng(8)
+    shape = (n, n, n)
+    z, prev_z = 14.0, 14.6
+    density = H.smooth_field(shape, rng, 0.3)
+    prev = {"xray_ionised_fraction": np.exp(rng.uniform(np.log(1.5e-4), np.log(4e-4), shape)).astype(np.float32),
+            "kinetic_temp_neutral": (9.0 * (1 + 0.6 * density)).astype(np.float32),
+            "spin_temperature": np.full(shape, 30.0, np.float32)}
+    src = {"filtered_sfr": np.empty((n_step,) + shape, np.float32),
+           "filtered_xray": np.empty((n_step,) + shape, np.float32)}
+    for i in range(n_step):  # Msun / yr / Mpc^3 and 1e38 erg / s / Mpc^3, falling with look-back
+        f = np.exp(H.smooth_field(shape, rng, 0.7 / (1 + 0.2 * i)))
+        src["filtered_sfr"][i] = 2e-4 * f * np.exp(-0.12 * i)
+        src["filtered_xray"][i] = 6e-2 * f * np.exp(-0.12 * i)
+    out = {k: np.zeros(shape, np.float32) for k in api_fields()}
+    fp = lambda a: a.ctypes.data_as(S.c_float_p)  # noqa: E731
+    pf = S.PerturbedFieldStruct(density=fp(density))
+    prevs = S.TsBoxStruct(**{k: fp(v) for k, v in prev.items()})
+    outs = S.TsBoxStruct(**{k: fp(v) for k, v in out.items()})
+    srcs = S.XraySourceBoxStruct(**{k: fp(v) for k, v in src.items()})
+    lib.ComputeTsBox.restype = C.c_int
+    lib.ComputeTsBox.argtypes = [C.c_float, C.c_float, C.c_float, C.c_short] + [C.c_void_p] * 5
+    st = lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), C.byref(srcs), C.byref(prevs), None,
+                          C.byref(outs))
+    assert st == 0, lib.c21cm_last_error()
+    assert 0 < outs.Q_HI <= 1
+    # the same spec from the library's host side, the cell algorithm from the oracle
+    spec, tab = S.TsSpec(), Tables()
+    lib.c21_ts_prepare.restype = C.c_int
+    lib.c21_ts_prepare.argtypes = [C.c_float, C.c_float, C.c_float, C.c_double, C.c_void_p, C.c_void_p]
+    x_e_ave = float(prev["xray_ionised_fraction"].sum(dtype=np.float64) / np.float32(density.size))
+    assert lib.c21_ts_prepare(z, prev_z, z, x_e_ave, C.byref(spec), C.byref(tab)) == 0
+    assert spec.source_mode == S.TS_SRC_GRIDS and spec.no_light == 0
+    assert outs.Q_HI == tab.Q_HI
+    ref = oracle.ts_grids(spec, density, prev, src, None)
+    compare({**out, "report": ref["report"]}, ref, spec)
+    # something happened: X-rays ionised and heated, the Lyman-alpha flux coupled T_s to T_k
+    assert ref["report"].xion_ave > 0 and ref["report"].J_alpha_ave > 1e-14
+    lib.c21_ts_tables_free(C.byref(tab))
+    del ses
+
+
+def api_fields():
+    return ("spin_temperature", "kinetic_temp_neutral", "xray_ionised_fraction")
+
+
+def test_compute_ts_box_first_snapshot_and_refusals(gpu_lib, oracle, tmp_path):
+    """redshift >= Z_HEAT_MAX: init_first_Ts from the RECFAST table; unsupported options say so."""
+    import ctypes as C
+    from pathlib import Path
+
+    from test_gpu_abi import Session
+
+    lib = gpu_lib
+    n = 16
+    data = Path(__file__).parent / "golden" / "reference" / "_data"
+    ses = Session(lib, tmp_path, data_dir=data, HII_DIM=n, SOURCE_MODEL=1, USE_TS_FLUCT=True,
+                  USE_LYA_HEATING=False, Z_HEAT_MAX=35.0)
+    shape = (n, n, n)
+    density = H.smooth_field(shape, np.random.default_rng(3), 0.05)
+    out = {k: np.zeros(shape, np.float32) for k in api_fields()}
+    fp = lambda a: a.ctypes.data_as(S.c_float_p)  # noqa: E731
+    pf = S.PerturbedFieldStruct(density=fp(density))
+    outs = S.TsBoxStruct(**{k: fp(v) for k, v in out.items()})
+    lib.ComputeTsBox.restype = C.c_int
+    lib.ComputeTsBox.argtypes = [C.c_float, C.c_float, C.c_float, C.c_short] + [C.c_void_p] * 5
+    z = 36.0
+    assert lib.ComputeTsBox(z, 0.0, z, 0, C.byref(pf), None, None, None, C.byref(outs)) == 0, \
+        lib.c21cm_last_error()
+    xe, TK = lib.c21_xion_RECFAST(z), lib.c21_T_RECFAST(z)
+    assert 1e-4 < xe < 1e-3 and 20 < TK < 40  # RECFAST at z = 36
+    np.testing.assert_allclose(out["xray_ionised_fraction"], np.float32(xe), rtol=1e-7)
+    cT = float(np.float32(0.58 - 0.006 * (np.float32(z) - 10.0)))
+    np.testing.assert_allclose(out["kinetic_temp_neutral"], TK * (1 + cT * density.astype(float)), rtol=3e-6)
+    Trad = 2.7255 * (1 + z)
+    assert np.all((out["spin_temperature"] > out["kinetic_temp_neutral"].min()) & (out["spin_temperature"] < Trad))
+    # below Z_HEAT_MAX the previous box is mandatory
+    assert lib.ComputeTsBox(20.0, 20.8, 20.0, 0, C.byref(pf), None, None, None, C.byref(outs)) == 3
+    prevs = S.TsBoxStruct(**{k: fp(v) for k, v in out.items()})
+    ses.ao.USE_MINI_HALOS = True
+    assert lib.ComputeTsBox(20.0, 20.8, 20.0, 0, C.byref(pf), None, C.byref(prevs), None, C.byref(outs)) == 3
+    assert b"USE_MINI_HALOS" in lib.c21cm_last_error()
+    ses.ao.USE_MINI_HALOS = False
+    ses.mo.SOURCE_MODEL = 0
+    assert lib.ComputeTsBox(20.0, 20.8, 20.0, 0, C.byref(pf), None, C.byref(prevs), None, C.byref(outs)) == 3
+    assert b"CONST-ION-EFF" in lib.c21cm_last_error()
+    del ses
