@@ -30,6 +30,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../hip/c21hip.h"
 #include "c21cm_grid.h"
@@ -522,6 +523,12 @@ int UpdateXraySourceBox(HaloBox *halobox, double R_inner, double R_outer, int R_
     return 0;
 }
 
+static double wall_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
 /* Box mean as ts_main takes it (:1479-1489): double sum, divided by (float)N. */
 static int box_mean(const float *v, size_t n, double *mean) {
     if (c21hip_is_device_ptr(v)) {
@@ -597,8 +604,11 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
         return C21CM_MEMORY_ALLOC_ERROR;
     }
     const float *filtered = NULL;
+    const int timing = getenv("C21CM_TS_TIMING") != NULL; /* stage wall times to stderr */
+    double t_mark = timing ? wall_seconds() : 0., t_prep = 0., t_filter = 0., t_tables = 0.;
     if ((st = c21_ts_prepare(redshift, prev_redshift, perturbed_field_redshift, x_e_ave_p, spec, tab)))
         goto done;
+    if (timing) t_prep = wall_seconds() - t_mark, t_mark = wall_seconds();
     if (spec->source_mode == C21CM_TS_SRC_SFRD_TABLE && !spec->no_light) {
         /* prepare_filter_boxes + fill_Rbox_table (:1453-1463): delNL0[R] stays on the device */
         c21cm_rbox_spec r;
@@ -618,12 +628,18 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
         }
         double mn[C21CM_MAX_TS_RADII], av[C21CM_MAX_TS_RADII], mx[C21CM_MAX_TS_RADII];
         if ((st = c21cm_fill_Rbox_grids(&r, perturbed_field->density, delNL0, mn, av, mx, NULL))) goto done;
+        if (timing) t_filter = wall_seconds() - t_mark, t_mark = wall_seconds();
         if ((st = c21_ts_sfrd_tables(mn, mx, spec, tab))) goto done;
+        if (timing) t_tables = wall_seconds() - t_mark, t_mark = wall_seconds();
         filtered = delNL0;
     }
     st = c21cm_ts_grids(spec, perturbed_field->density, previous_spin_temp, source_box, filtered,
                         this_spin_temp, NULL, NULL);
     if (!st) this_spin_temp->Q_HI = tab->Q_HI;
+    if (timing)
+        fprintf(stderr, "ComputeTsBox z=%.3f: host tables %.1f ms, density filter loop %.1f ms, SFRD tables "
+                        "%.1f ms, cell sweep (incl. staging) %.1f ms\n",
+                redshift, 1e3 * t_prep, 1e3 * t_filter, 1e3 * t_tables, 1e3 * (wall_seconds() - t_mark));
 done:
     c21_ts_tables_free(tab);
     free(tab);

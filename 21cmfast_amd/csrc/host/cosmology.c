@@ -485,9 +485,9 @@ int c21_ps_ready(void) { return cc.ready; }
  * quadrature over k.  Like the reference (interp_tables.c:1135-1170, Sigma_InterpTable) they
  * are tabulated once per power-spectrum normalisation on a ln M grid; unlike the reference's
  * linear float table the lookup is a natural cubic spline of ln sigma, ln(-d sigma^2/dM). */
-#define SIG_N 320
+#define SIG_N 416
 #define SIG_LNM_MIN 6.9   /* ~1e3 Msun  */
-#define SIG_LNM_MAX 39.2  /* ~1e17 Msun */
+#define SIG_LNM_MAX 48.5  /* ~1e21 Msun: RtoM of the outermost spin-temperature shells (R_MAX_TS = 500 Mpc -> 2e19) */
 static struct {
     int ready;
     double norm_tag; /* sigma_norm the table was built for */
@@ -503,6 +503,9 @@ static void sigma_table_build(void) {
     if (st.ready && st.generation == cc.generation && st.norm_tag == cc.sigma_norm && st.filter == matter_options_global->FILTER &&
         st.ps == matter_options_global->POWER_SPECTRUM)
         return;
+    const int n_thr = simulation_options_global && simulation_options_global->N_THREADS > 1
+                          ? simulation_options_global->N_THREADS : 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_thr) /* interp_tables.c:1147-1156 */
     for (int i = 0; i < SIG_N; i++) {
         st.lnM[i] = SIG_LNM_MIN + (SIG_LNM_MAX - SIG_LNM_MIN) * i / (SIG_N - 1.0);
         const double M = exp(st.lnM[i]);
@@ -897,6 +900,12 @@ static int conditional_table(double growthf, double lnMmin, double lnMmax, doubl
                 node_factor[i] = node_barrier[i] = 0.;
         }
     }
+    /* the overdensities are independent: N_THREADS host threads, as upstream (interp_tables.c:340) */
+    int bad = 0;
+    const int n_thr = simulation_options_global && simulation_options_global->N_THREADS > 1
+                          ? simulation_options_global->N_THREADS : 1;
+    if (!fast && method == 1) initialise_GL(lnMmin, lnMmax); /* before the threads share it */
+#pragma omp parallel for schedule(static) num_threads(n_thr) reduction(| : bad)
     for (int k = 0; k < n_delta; k++) {
         const double delta = dmin + (float)k / ((float)n_delta - 1.) * (dmax - dmin);
         double v;
@@ -927,10 +936,10 @@ static int conditional_table(double growthf, double lnMmin, double lnMmax, doubl
         }
         double lv = log(v);
         if (lv < ln_floor) lv = ln_floor;
-        if (!isfinite(lv)) return C21CM_TABLE_GENERATION_ERROR;
+        if (!isfinite(lv)) bad |= 1;
         table[k] = (float)lv;
     }
-    return 0;
+    return bad ? C21CM_TABLE_GENERATION_ERROR : 0;
 }
 
 /* hmf.c:1268-1316: mass beyond which F = FRAC (M/1e10)^PL would exceed 1 (float bisection) */

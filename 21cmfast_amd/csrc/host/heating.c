@@ -582,6 +582,12 @@ double c21_weighted_xray_cross_section(double nu, double x_e) {
            he_frac() * x_e * c21_HeII_ion_crosssec(nu);
 }
 
+/* the host loops below run on N_THREADS threads, as the reference's do */
+static int host_threads(void) {
+    const int n = simulation_options_global ? simulation_options_global->N_THREADS : 1;
+    return n < 1 ? 1 : n;
+}
+
 /* ================================================================ N_ion(z), SFRD(z) tables */
 static struct {
     int ready;
@@ -621,16 +627,20 @@ static int build_z_tables(float zmin, float zmax, const c21_scaling_consts *sc) 
     zt.x_width = (zmax - zmin) / ((double)ZPP_INTERP_POINTS - 1.);
     c21_scaling_consts sc_sfrd = *sc; /* evolve_scaling_constants_sfr */
     sc_sfrd.fesc_10 = 1., sc_sfrd.fesc_7 = 1., sc_sfrd.alpha_esc = 0., sc_sfrd.Mlim_Fesc = 0.;
+    (void)c21_sigma_fast(1e10); /* build the sigma(M) spline before the threads read it */
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(host_threads()) reduction(| : bad)
     for (int i = 0; i < ZPP_INTERP_POINTS; i++) {
         const double z_val = zt.x_min + i * zt.x_width;
         const double lnMmin = log(minimum_source_mass_xray(z_val));
         /* evolve_scaling_constants_to_redshift only changes t_h, which these integrals ignore */
         zt.nion[i] = c21_Nion_General(z_val, lnMmin, lnMmax, sc->mturn_a_nofb, sc);
         zt.sfrd[i] = c21_Nion_General(z_val, lnMmin, lnMmax, sc_sfrd.mturn_a_nofb, &sc_sfrd);
-        if (!isfinite(zt.nion[i]) || !isfinite(zt.sfrd[i])) {
-            c21hip_set_error("spin temperature: infinite or NaN value in the N_ion(z) / SFRD(z) tables");
-            return C21CM_TABLE_GENERATION_ERROR;
-        }
+        if (!isfinite(zt.nion[i]) || !isfinite(zt.sfrd[i])) bad |= 1;
+    }
+    if (bad) {
+        c21hip_set_error("spin temperature: infinite or NaN value in the N_ion(z) / SFRD(z) tables");
+        return C21CM_TABLE_GENERATION_ERROR;
     }
     zt.ready = 1;
     return 0;
@@ -915,22 +925,26 @@ int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_re
     t->freq = (double *)calloc(3 * fn, sizeof(double));
     if (!t->freq) return C21CM_MEMORY_ALLOC_ERROR;
     const double tau_ion_eff = sc.pop2_ion * sc.fstar_10 * sc.fesc_10;
-    for (int R_ct = 0; R_ct < n; R_ct++) {
+    int root_failed = 0, table_bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads()) reduction(| : root_failed, table_bad)
+    for (int R_ct = 0; R_ct < n; R_ct++) { /* the shells are independent (:822-863) */
         int st = 0;
         const double nu1 = c21_nu_tau_one(zp, t->zpp[R_ct], x_e_ave, tau_ion_eff, &st);
-        if (st) return st;
+        if (st) root_failed |= 1;
         const double lower_int_limit = fmax(nu1, (ap->NU_X_THRESH) * PC_EV_TO_HZ);
         t->nu_tau_one[R_ct] = nu1;
         for (int x_e_ct = 0; x_e_ct < C21CM_X_INT_NXHII; x_e_ct++) {
             for (int flag = 0; flag < 3; flag++) {
                 const double v = c21_integrate_over_nu(zp, H.x_int_XHII[x_e_ct], lower_int_limit, flag);
-                if (!isfinite(v)) {
-                    c21hip_set_error("One of the frequency interpolation tables has an infinity or a NaN");
-                    return C21CM_TABLE_GENERATION_ERROR;
-                }
+                if (!isfinite(v)) table_bad |= 1;
                 t->freq[flag * fn + (size_t)x_e_ct * n + R_ct] = v;
             }
         }
+    }
+    if (root_failed) return C21CM_INFINITY_OR_NAN_ERROR;
+    if (table_bad) {
+        c21hip_set_error("One of the frequency interpolation tables has an infinity or a NaN");
+        return C21CM_TABLE_GENERATION_ERROR;
     }
     s->freq_int_heat = t->freq;
     s->freq_int_ion = t->freq + fn;
