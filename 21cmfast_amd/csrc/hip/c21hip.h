@@ -387,6 +387,7 @@ int c21hip_apply_first_cross(const unsigned char *first_cross, const float *prev
  * 1210-1383,1499-1848) ---- */
 typedef struct c21hip_ts_args { /* the scalars of c21cm_ts_spec, passed by value */
     int n_step, lagrangian, use_xray_heating, use_cmb_heating, use_lya_heating, no_light;
+    int table_exp; /* Eulerian: the per-shell table holds ln SFRD (1) or dfcoll/dz itself (0) */
     double redshift, dzp, growth_ratio;
     double No, N_b0, h_frac, he_frac, k_B, h_p, m_p, c_cms, A10, T_21, lambda_21, nu_Ly_alpha;
     double clumping_factor;
@@ -400,9 +401,9 @@ typedef struct c21hip_ts_args { /* the scalars of c21cm_ts_spec, passed by value
 size_t c21hip_ts_table_doubles(int n_step);
 /* SFRD_TABLE: box mean of exp(table) per shell -> avg_fix_term row of dev_tab, means to ave_out;
  * partials: 512 * n_step doubles */
-int c21hip_ts_sfrd_means(const float *filtered_density, const float *tables_dev, double *dev_tab,
-                         const double *mean_sfr_zpp_dev, int n_step, size_t ntot, double *partials,
-                         double *ave_out_dev, void *stream);
+int c21hip_ts_sfrd_means(const float *filtered_density, const float *tables_dev, int table_exp,
+                         double *dev_tab, const double *mean_sfr_zpp_dev, int n_step, size_t ntot,
+                         double *partials, double *ave_out_dev, void *stream);
 /* the cell sweep; grid_a/grid_b = filtered_sfr/filtered_xray (lagrangian) or delNL0/NULL;
  * partials: 6 * 2048 doubles; sums_out_dev: 6 doubles (Ts, Tk, x_e, J_alpha, xheat, xion) */
 int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, const float *prev_Ts,

@@ -160,7 +160,7 @@ enum { SH_ZEDGE = 0, SH_XRAY_R, SH_STARLYA, SH_CONT, SH_INJ, SH_GROWTH, SH_TABMI
 // box sum of the SFRD table values of one shell (blockIdx.y)
 __global__ void __launch_bounds__(kBlock)
 sfrd_sum_kernel(const float *__restrict__ filtered_density, const float *__restrict__ tables,
-                const double *__restrict__ shell, int n_step, size_t ntot,
+                int table_exp, const double *__restrict__ shell, int n_step, size_t ntot,
                 double *__restrict__ partials) {
     __shared__ double lds[kBlock];
     const int R = blockIdx.y;
@@ -170,8 +170,10 @@ sfrd_sum_kernel(const float *__restrict__ filtered_density, const float *__restr
                  tab_width = shell[SH_TABWIDTH * n_step + R];
     double acc = 0.;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
-         i += (size_t)gridDim.x * kBlock)
-        acc += exp(table_1d((double)dens[i] * growth, tab_min, tab_width, tab));
+         i += (size_t)gridDim.x * kBlock) {
+        const double v = table_1d((double)dens[i] * growth, tab_min, tab_width, tab);
+        acc += table_exp ? exp(v) : v;  // ln SFRD table (E-INTEGRAL) | f_coll table (CONST-ION-EFF)
+    }
     acc = block_sum(acc, lds);
     if (threadIdx.x == 0) partials[(size_t)R * gridDim.x + blockIdx.x] = acc;
 }
@@ -237,9 +239,9 @@ ts_cell_kernel(c21hip_ts_args a, const float *__restrict__ density,
                     xray_sfr = (double)grid_b[(size_t)R * ntot + i] * z_edge * xray_R * 1e38;
                 } else {
                     const double curr_dens = (double)grid_a[(size_t)R * ntot + i] * sh[SH_GROWTH * n + R];
-                    const double fcoll =
-                        exp(table_1d(curr_dens, sh[SH_TABMIN * n + R], sh[SH_TABWIDTH * n + R],
-                                     tables + (size_t)R * C21CM_NDELTA_TABLE));
+                    double fcoll = table_1d(curr_dens, sh[SH_TABMIN * n + R], sh[SH_TABWIDTH * n + R],
+                                            tables + (size_t)R * C21CM_NDELTA_TABLE);
+                    if (a.table_exp) fcoll = exp(fcoll);  // else: the dfcoll/dz table itself
                     const float sfrd = (float)((1. + curr_dens) * fcoll);  // del_fcoll_Rct is float
                     sfr_term = (double)sfrd * z_edge * sh[SH_AVGFIX * n + R] * a.sfr_scale;
                     xray_sfr = sfr_term * a.xray_scale * xray_R;
@@ -412,13 +414,14 @@ extern "C" size_t c21hip_ts_table_doubles(int n_step) {
 }
 
 extern "C" int c21hip_ts_sfrd_means(const float *filtered_density, const float *tables_dev,
-                                    double *dev_tab, const double *mean_sfr_zpp_dev, int n_step,
+                                    int table_exp, double *dev_tab,
+                                    const double *mean_sfr_zpp_dev, int n_step,
                                     size_t ntot, double *partials, double *ave_out_dev,
                                     void *stream) {
     int bx = grid_for(ntot);
     if (bx > 512) bx = 512;  // n_step rows of blocks fill the chip
     hipLaunchKernelGGL(sfrd_sum_kernel, dim3(bx, n_step), dim3(kBlock), 0, (hipStream_t)stream,
-                       filtered_density, tables_dev, dev_tab, n_step, ntot, partials);
+                       filtered_density, tables_dev, table_exp, dev_tab, n_step, ntot, partials);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(sfrd_finish_kernel, dim3(n_step), dim3(kBlock), 0, (hipStream_t)stream,
                        partials, bx, mean_sfr_zpp_dev, (double)ntot, n_step, dev_tab, ave_out_dev);

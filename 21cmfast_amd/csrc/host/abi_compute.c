@@ -193,30 +193,7 @@ int ComputeInitialConditions(unsigned long long random_seed, InitialConditions *
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* hmf.c:1187-1241 on the host, for the FgtrM table of CONST-ION-EFF */
-static float erfcc_host(float x) {
-    const double q = fabs(x), t = 1.0 / (1.0 + 0.5 * q);
-    const double ans =
-        t * exp(-q * q - 1.2655122 +
-                t * (1.0000237 +
-                     t * (0.374092 +
-                          t * (0.0967842 +
-                               t * (-0.1862881 +
-                                    t * (0.2788681 +
-                                         t * (-1.13520398 +
-                                              t * (1.4885159 +
-                                                   t * (-0.82215223 + t * 0.17087277)))))))));
-    return x >= 0.0 ? ans : 2.0 - ans;
-}
-
-static double fgtrm_bias_fast_host(float growthf, float del_bias, float sig_small, float sig_large) {
-    if (sig_large > sig_small) return NAN;
-    if (sig_large == sig_small) return 0.;
-    const double sig = sqrt(sig_small * sig_small - sig_large * sig_large);
-    const double del = (1.686 - del_bias) / growthf;
-    const double x = del / (sqrt(2) * sig);
-    return x < 0 ? 1.0 : erfcc_host(x);
-}
+#define fgtrm_bias_fast_host c21_FgtrM_bias_fast /* hmf.c:1221-1241, cosmology.c */
 
 struct fgtrm_table_ctx {
     const c21cm_ionize_spec *spec;
@@ -552,8 +529,9 @@ static int box_mean(const float *v, size_t n, double *mean) {
  * Host: shells, spectral factors, z' constants, N_ion(z) / SFRD(z) tables, tau_X = 1 frequencies
  * and the frequency-integral tables (heating.c); device: the density filter loop of the Eulerian
  * source model (tsfilter_driver.c) and the cell sweep (ts_driver.c / ts_kernels.hip).
- * Supported: SOURCE_MODEL E-INTEGRAL (SFRD from the filtered density) and the Lagrangian models
- * (XraySourceBox grids), with interpolation tables; not: USE_MINI_HALOS, CONST-ION-EFF. */
+ * Supported: the Eulerian source models (E-INTEGRAL: SFRD tables, CONST-ION-EFF: dfcoll/dz tables of
+ * the filtered density) and the Lagrangian ones (XraySourceBox grids), with interpolation tables;
+ * not: USE_MINI_HALOS. */
 int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
                  PerturbedField *perturbed_field, XraySourceBox *source_box,
                  TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp) {
@@ -609,7 +587,7 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
     if ((st = c21_ts_prepare(redshift, prev_redshift, perturbed_field_redshift, x_e_ave_p, spec, tab)))
         goto done;
     if (timing) t_prep = wall_seconds() - t_mark, t_mark = wall_seconds();
-    if (spec->source_mode == C21CM_TS_SRC_SFRD_TABLE && !spec->no_light) {
+    if (spec->source_mode != C21CM_TS_SRC_GRIDS && !spec->no_light) {
         /* prepare_filter_boxes + fill_Rbox_table (:1453-1463): delNL0[R] stays on the device */
         c21cm_rbox_spec r;
         memset(&r, 0, sizeof(r));
@@ -629,7 +607,11 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
         double mn[C21CM_MAX_TS_RADII], av[C21CM_MAX_TS_RADII], mx[C21CM_MAX_TS_RADII];
         if ((st = c21cm_fill_Rbox_grids(&r, perturbed_field->density, delNL0, mn, av, mx, NULL))) goto done;
         if (timing) t_filter = wall_seconds() - t_mark, t_mark = wall_seconds();
-        if ((st = c21_ts_sfrd_tables(mn, mx, spec, tab))) goto done;
+        if (spec->source_mode == C21CM_TS_SRC_SFRD_TABLE)
+            st = c21_ts_sfrd_tables(mn, mx, spec, tab);
+        else
+            st = c21_ts_fcoll_tables(mn, mx, spec, tab);
+        if (st) goto done;
         if (timing) t_tables = wall_seconds() - t_mark, t_mark = wall_seconds();
         filtered = delNL0;
     }

@@ -584,6 +584,41 @@ static int supported_hmf(void) {
     return h == C21CM_HMF_PS || h == C21CM_HMF_ST;
 }
 
+/* hmf.c:1187-1241: erfcc (a 1.2e-7 fit) and the conditional collapsed fraction in terms of
+ * sigmas; float arguments and float return of erfcc as upstream.  NaN for sig_large > sig_small
+ * (the reference throws ValueError there). */
+static float erfcc_f(float x) {
+    const double q = fabs(x), t = 1.0 / (1.0 + 0.5 * q);
+    const double ans =
+        t * exp(-q * q - 1.2655122 +
+                t * (1.0000237 +
+                     t * (0.374092 +
+                          t * (0.0967842 +
+                               t * (-0.1862881 +
+                                    t * (0.2788681 +
+                                         t * (-1.13520398 +
+                                              t * (1.4885159 +
+                                                   t * (-0.82215223 + t * 0.17087277)))))))));
+    return x >= 0.0 ? ans : 2.0 - ans;
+}
+
+double c21_FgtrM_bias_fast(float growthf, float del_bias, float sig_small, float sig_large) {
+    if (sig_large > sig_small) return NAN;
+    if (sig_large == sig_small) return 0.;
+    const double sig = sqrt(sig_small * sig_small - sig_large * sig_large);
+    const double del = (DELTA_C_SPH - del_bias) / growthf;
+    const double x = del / (sqrt(2) * sig);
+    return x < 0 ? 1.0 : erfcc_f(x);
+}
+
+/* hmf.c:1253-1264: central difference over dz = 0.001, float arguments and float result */
+float c21_dfcoll_dz(float z, float sigma_min, float del_bias, float sig_bias) {
+    const double dz = 0.001, z1 = z + dz, z2 = z - dz;
+    const double fc1 = c21_FgtrM_bias_fast(dicke(z1), del_bias, sigma_min, sig_bias);
+    const double fc2 = c21_FgtrM_bias_fast(dicke(z2), del_bias, sigma_min, sig_bias);
+    return (fc1 - fc2) / (2.0 * dz);
+}
+
 /* hmf.c:945-953 */
 double c21_Fcoll_General(double z, double lnM_min, double lnM_max) {
     if (!supported_hmf()) return NAN;

@@ -44,6 +44,8 @@ double c21_dtdz(float z);
 double c21_ddickedt(double z);
 double c21_sigma_fast(double M); /* spline over a cached ln M table */
 double c21_Fcoll_General(double z, double lnM_min, double lnM_max);
+double c21_FgtrM_bias_fast(float growthf, float del_bias, float sig_small, float sig_large);
+float c21_dfcoll_dz(float z, float sigma_min, float del_bias, float sig_bias);
 double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
                         const c21_scaling_consts *sc);
 /* N_ion per unit mass of a region of mass exp(lnM_cond), sigma2 and overdensity delta2

@@ -589,10 +589,11 @@ static int host_threads(void) {
 }
 
 /* ================================================================ N_ion(z), SFRD(z) tables */
+#define ZT_MAX 2048
 static struct {
-    int ready;
+    int ready, n;
     double x_min, x_width;
-    double nion[ZPP_INTERP_POINTS], sfrd[ZPP_INTERP_POINTS];
+    double nion[ZT_MAX], sfrd[ZT_MAX];
 } zt;
 
 static double minimum_source_mass_xray(double redshift) { /* hmf.c:1319-1348 with xray = true */
@@ -642,6 +643,36 @@ static int build_z_tables(float zmin, float zmax, const c21_scaling_consts *sc) 
         c21hip_set_error("spin temperature: infinite or NaN value in the N_ion(z) / SFRD(z) tables");
         return C21CM_TABLE_GENERATION_ERROR;
     }
+    zt.ready = 1;
+    return 0;
+}
+/* init_FcollTable (interp_tables.c:252-284): CONST-ION-EFF keeps ONE table, the collapsed fraction
+ * above the minimum source mass every 0.1 in redshift; N_ion and the "SFRD" both read it
+ * (interp_tables.c:889-895,923-928) */
+static int build_fcoll_z_table(double zmin, double zmax) {
+    zt.ready = 0;
+    zt.x_min = zmin;
+    zt.x_width = 0.1;
+    const int n_z = (int)ceil((zmax - zmin) / zt.x_width) + 1;
+    if (n_z < 2 || n_z > ZT_MAX) {
+        c21hip_set_error("spin temperature: %d redshifts in the collapsed-fraction table", n_z);
+        return C21CM_TABLE_GENERATION_ERROR;
+    }
+    (void)c21_sigma_fast(1e10);
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(host_threads()) reduction(| : bad)
+    for (int i = 0; i < n_z; i++) {
+        const double z_val = zt.x_min + i * zt.x_width;
+        const double M_min = minimum_source_mass_xray(z_val);
+        const double v = c21_Fcoll_General(z_val, log(M_min), log(fmax(M_MAX_INTEGRAL, M_min * 100)));
+        zt.nion[i] = zt.sfrd[i] = v;
+        if (!isfinite(v)) bad |= 1;
+    }
+    if (bad) {
+        c21hip_set_error("spin temperature: infinite or NaN value in the collapsed-fraction table");
+        return C21CM_TABLE_GENERATION_ERROR;
+    }
+    zt.n = n_z;
     zt.ready = 1;
     return 0;
 }
@@ -705,6 +736,8 @@ void c21_ts_tables_free(c21_ts_tables *t) {
     if (!t) return;
     free(t->freq);
     free(t->sfrd_tables);
+    free(t->fcoll_tables);
+    free(t->dfcoll_tables);
     memset(t, 0, sizeof(*t));
 }
 
@@ -849,11 +882,6 @@ int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_re
         c21hip_set_error("ComputeTsBox: USE_MINI_HALOS is not supported by this backend");
         return C21CM_VALUE_ERROR;
     }
-    if (model == C21CM_SOURCE_CONST_ION_EFF) {
-        c21hip_set_error("ComputeTsBox: SOURCE_MODEL = CONST-ION-EFF is not supported by this backend "
-                         "(E-INTEGRAL and the Lagrangian models are)");
-        return C21CM_VALUE_ERROR;
-    }
     if (matter_options_global->USE_INTERPOLATION_TABLES == 0) {
         c21hip_set_error("ComputeTsBox: USE_INTERPOLATION_TABLES = no-interpolation is not supported");
         return C21CM_VALUE_ERROR;
@@ -864,14 +892,16 @@ int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_re
         return C21CM_VALUE_ERROR;
     }
     if ((status = c21_heat_load())) return status;
-    const int lagrangian = model != C21CM_SOURCE_E_INTEGRAL;
+    const int const_zeta = model == C21CM_SOURCE_CONST_ION_EFF;
+    const int lagrangian = model != C21CM_SOURCE_E_INTEGRAL && !const_zeta;
     memset(s, 0, sizeof(*s));
     c21_ts_tables_free(t);
     t->n_step = n;
     s->hii_dim = simulation_options_global->HII_DIM;
     s->hii_dim_z = (int)(simulation_options_global->NON_CUBIC_FACTOR * simulation_options_global->HII_DIM);
     s->n_step = n;
-    s->source_mode = lagrangian ? C21CM_TS_SRC_GRIDS : C21CM_TS_SRC_SFRD_TABLE;
+    s->source_mode = lagrangian ? C21CM_TS_SRC_GRIDS
+                                : (const_zeta ? C21CM_TS_SRC_FCOLL_TABLES : C21CM_TS_SRC_SFRD_TABLE);
     s->use_xray_heating = ao->USE_X_RAY_HEATING;
     s->use_cmb_heating = ao->USE_CMB_HEATING;
     s->use_lya_heating = ao->USE_LYA_HEATING;
@@ -889,10 +919,14 @@ int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_re
         s->lya_inj_prefactor[i] = t->lya_inj_prefactor[i];
         s->zpp_growth[i] = t->zpp_growth[i];
         const double zpp = t->zpp[i];
-        if (lagrangian) /* :1546-1553 */
+        if (const_zeta) /* :1546-1553: the source is dfcoll/dz */
+            s->z_edge_factor[i] = t->dzpp[i];
+        else if (lagrangian)
             s->z_edge_factor[i] = fabs(t->dzpp[i] * t->dtdz[i]);
         else
             s->z_edge_factor[i] = fabs(t->dzpp[i] * t->dtdz[i]) * c21_hubble(zpp) / ap->t_STAR;
+        t->sigma_min[i] = c21_sigma_fast(t->M_min_R[i]); /* :1418-1421 */
+        t->sigma_max[i] = c21_sigma_fast(t->M_max_R[i]);
         s->xray_R_factor[i] = pow(1 + zpp, -(ap->X_RAY_SPEC_INDEX));
     }
     s->sfr_scale = ap->F_STAR10;
@@ -908,10 +942,14 @@ int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_re
     {
         const double determine_zpp_min = zp * 0.999;
         const double determine_zpp_max = t->zpp[n - 1] * 1.001;
-        if ((status = build_z_tables((float)determine_zpp_min, (float)determine_zpp_max, &sc))) return status;
+        if (const_zeta)
+            status = build_fcoll_z_table(determine_zpp_min, determine_zpp_max);
+        else
+            status = build_z_tables((float)determine_zpp_min, (float)determine_zpp_max, &sc);
+        if (status) return status;
     }
     const double sum_nion = c21_EvaluateNionTs(zp);
-    const double ion_eff = ap->F_STAR10 * ap->F_ESC10 * ap->POP2_ION;
+    const double ion_eff = const_zeta ? (double)ap->HII_EFF_FACTOR : ap->F_STAR10 * ap->F_ESC10 * ap->POP2_ION;
     t->Q_HI = 1 - (ion_eff * sum_nion) / (1.0 - x_e_ave);
     t->no_light = sum_nion > 1e-15 ? 0 : 1;
     s->no_light = t->no_light;
@@ -924,7 +962,15 @@ int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_re
     const size_t fn = (size_t)C21CM_X_INT_NXHII * n;
     t->freq = (double *)calloc(3 * fn, sizeof(double));
     if (!t->freq) return C21CM_MEMORY_ALLOC_ERROR;
-    const double tau_ion_eff = sc.pop2_ion * sc.fstar_10 * sc.fesc_10;
+    double tau_ion_eff = sc.pop2_ion * sc.fstar_10 * sc.fesc_10;
+    if (const_zeta) { /* tauX :1030-1040: the efficiency implied by the filling factor at z' */
+        static double PS_ION_EFF; /* kept across calls for the post-reionisation regime, as upstream */
+        if (t->Q_HI > FRACT_FLOAT_ERR) {
+            const double fcoll = c21_EvaluateNionTs(zp);
+            PS_ION_EFF = (1.0 - t->Q_HI) / fcoll * (1.0 - x_e_ave);
+        }
+        tau_ion_eff = PS_ION_EFF;
+    }
     int root_failed = 0, table_bad = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads()) reduction(| : root_failed, table_bad)
     for (int R_ct = 0; R_ct < n; R_ct++) { /* the shells are independent (:822-863) */
@@ -978,5 +1024,42 @@ int c21_ts_sfrd_tables(const double *min_densities, const double *max_densities,
         s->tab_width[R_ct] = (dmax - dmin) / (C21CM_NDELTA_TABLE - 1.);
     }
     s->ln_sfrd_tables = t->sfrd_tables;
+    return 0;
+}
+
+/* initialise_FgtrM_delta_table (interp_tables.c:226-250) for every shell: the conditional collapsed
+ * fraction and its redshift derivative over [min, max] of the shell's filtered density (:1029-1032:
+ * no margin at the upper end) */
+int c21_ts_fcoll_tables(const double *min_densities, const double *max_densities, c21cm_ts_spec *s,
+                        c21_ts_tables *t) {
+    const int n = t->n_step;
+    free(t->fcoll_tables);
+    free(t->dfcoll_tables);
+    t->fcoll_tables = (float *)malloc((size_t)n * C21CM_NDELTA_TABLE * sizeof(float));
+    t->dfcoll_tables = (float *)malloc((size_t)n * C21CM_NDELTA_TABLE * sizeof(float));
+    if (!t->fcoll_tables || !t->dfcoll_tables) return C21CM_MEMORY_ALLOC_ERROR;
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads()) reduction(| : bad)
+    for (int R_ct = 0; R_ct < n; R_ct++) {
+        const double g = t->zpp_growth[R_ct];
+        const double lo = min_densities[R_ct] * g, hi = max_densities[R_ct] * g;
+        const double width = (hi - lo) / (C21CM_NDELTA_TABLE - 1.);
+        for (int i = 0; i < C21CM_NDELTA_TABLE; i++) {
+            const double dens = lo + i * width;
+            const double f = c21_FgtrM_bias_fast(g, dens, t->sigma_min[R_ct], t->sigma_max[R_ct]);
+            if (isnan(f)) bad |= 1;
+            t->fcoll_tables[(size_t)R_ct * C21CM_NDELTA_TABLE + i] = f;
+            t->dfcoll_tables[(size_t)R_ct * C21CM_NDELTA_TABLE + i] =
+                c21_dfcoll_dz(t->zpp[R_ct], t->sigma_min[R_ct], dens, t->sigma_max[R_ct]);
+        }
+        s->tab_min[R_ct] = lo;
+        s->tab_width[R_ct] = width;
+    }
+    if (bad) {
+        c21hip_set_error("Trying to compute FgtrM in region where M_min > M_max");
+        return C21CM_VALUE_ERROR;
+    }
+    s->fcoll_tables = t->fcoll_tables;
+    s->dfcoll_tables = t->dfcoll_tables;
     return 0;
 }

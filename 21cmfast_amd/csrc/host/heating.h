@@ -59,12 +59,16 @@ typedef struct c21_ts_tables {
     double nu_tau_one[C21CM_MAX_TS_RADII];
     double *freq;       /* [3][C21CM_X_INT_NXHII][n_step] */
     float *sfrd_tables; /* [n_step][C21CM_NDELTA_TABLE] */
+    float *fcoll_tables, *dfcoll_tables; /* CONST-ION-EFF, same shape */
+    double sigma_min[C21CM_MAX_TS_RADII], sigma_max[C21CM_MAX_TS_RADII];
 } c21_ts_tables;
 void c21_ts_tables_free(c21_ts_tables *t);
 int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_redshift,
                    double x_e_ave, c21cm_ts_spec *spec, c21_ts_tables *tables);
 int c21_ts_sfrd_tables(const double *min_densities, const double *max_densities,
                        c21cm_ts_spec *spec, c21_ts_tables *tables);
+int c21_ts_fcoll_tables(const double *min_densities, const double *max_densities,
+                        c21cm_ts_spec *spec, c21_ts_tables *tables);
 
 #ifdef __cplusplus
 }

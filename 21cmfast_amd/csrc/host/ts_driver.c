@@ -22,7 +22,7 @@
 enum {
     WS_TS_DENS = 150, WS_TS_PTS, WS_TS_PTK, WS_TS_PXE, WS_TS_GRID_A, WS_TS_GRID_B, WS_TS_TAB,
     WS_TS_SFRDTAB, WS_TS_LYA_C, WS_TS_LYA_I, WS_TS_OTS, WS_TS_OTK, WS_TS_OXE, WS_TS_PART,
-    WS_TS_SMALL, WS_TS_MEANSFR
+    WS_TS_SMALL, WS_TS_MEANSFR, WS_TS_SFRDTAB2
 };
 
 #define TRY(expr)         \
@@ -43,6 +43,21 @@ static const void *stage_in(int slot, const void *p, size_t bytes, void *stream,
         return NULL;
     }
     *status = c21hip_h2d(d, p, bytes, stream);
+    return d;
+}
+
+/* a per-shell table set: copied with one float of slack, because upstream's lookup reads y[idx + 1]
+ * with weight 0 when a cell sits exactly on the last knot (interpolation.c:123-131) */
+static const float *stage_tables(int slot, const float *p, size_t bytes, void *stream, int *status) {
+    if (*status || !p) return p;
+    float *d = (float *)c21hip_ws(slot, bytes + 16);
+    if (!d) {
+        *status = C21CM_MEMORY_ALLOC_ERROR;
+        return NULL;
+    }
+    *status = c21hip_memset((char *)d + bytes, 0, 16, stream);
+    if (!*status)
+        *status = c21hip_is_device_ptr(p) ? c21hip_d2d(d, p, bytes, stream) : c21hip_h2d(d, p, bytes, stream);
     return d;
 }
 
@@ -78,7 +93,8 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     if ((status = check_boxes("the previous box", previous))) return status;
     if ((status = check_boxes("the output box", out))) return status;
     const int lagrangian = s->source_mode == C21CM_TS_SRC_GRIDS;
-    if (!lagrangian && s->source_mode != C21CM_TS_SRC_SFRD_TABLE) {
+    const int fcoll_mode = s->source_mode == C21CM_TS_SRC_FCOLL_TABLES;
+    if (!lagrangian && !fcoll_mode && s->source_mode != C21CM_TS_SRC_SFRD_TABLE) {
         c21hip_set_error("spin temperature: unknown source_mode %d", s->source_mode);
         return C21CM_VALUE_ERROR;
     }
@@ -96,7 +112,8 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
                          "filtered_xray");
         return C21CM_VALUE_ERROR;
     }
-    if (!lagrangian && !s->no_light && (!filtered_density || !s->ln_sfrd_tables)) {
+    if (!lagrangian && !s->no_light &&
+        (!filtered_density || (fcoll_mode ? (!s->fcoll_tables || !s->dfcoll_tables) : !s->ln_sfrd_tables))) {
         c21hip_set_error("spin temperature: Eulerian sources need the filtered densities and the "
                          "SFRD tables");
         return C21CM_VALUE_ERROR;
@@ -138,12 +155,17 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     TRY(c21hip_h2d(dev_tab, host_tab, n_tab * sizeof(double), stream));
     TRY(c21hip_memset(flag_dev, 0, sizeof(int), stream));
 
-    const float *tables_dev = NULL;
+    const float *tables_dev = NULL, *mean_tables_dev = NULL; /* the cell sweep's | the box mean's */
     const double *lya_c = NULL, *lya_i = NULL;
-    if (!lagrangian && !s->no_light)
-        tables_dev = (const float *)stage_in(WS_TS_SFRDTAB, s->ln_sfrd_tables,
-                                             (size_t)n * C21CM_NDELTA_TABLE * sizeof(float), stream,
-                                             &status);
+    if (!lagrangian && !s->no_light) {
+        const size_t tb = (size_t)n * C21CM_NDELTA_TABLE * sizeof(float);
+        if (fcoll_mode) {
+            tables_dev = stage_tables(WS_TS_SFRDTAB, s->dfcoll_tables, tb, stream, &status);
+            mean_tables_dev = stage_tables(WS_TS_SFRDTAB2, s->fcoll_tables, tb, stream, &status);
+        } else {
+            tables_dev = mean_tables_dev = stage_tables(WS_TS_SFRDTAB, s->ln_sfrd_tables, tb, stream, &status);
+        }
+    }
     if (s->use_lya_heating) {
         const size_t lb = (size_t)C21CM_LYA_NT * C21CM_LYA_NT * C21CM_LYA_NGP * sizeof(double);
         lya_c = (const double *)stage_in(WS_TS_LYA_C, s->lya_dEC, lb, stream, &status);
@@ -178,6 +200,7 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     a.use_cmb_heating = s->use_cmb_heating;
     a.use_lya_heating = s->use_lya_heating;
     a.no_light = s->no_light;
+    a.table_exp = !fcoll_mode;
 #define CP(f) a.f = s->f
     CP(redshift); CP(dzp); CP(growth_ratio); CP(No); CP(N_b0); CP(h_frac); CP(he_frac); CP(k_B);
     CP(h_p); CP(m_p); CP(c_cms); CP(A10); CP(T_21); CP(lambda_21); CP(nu_Ly_alpha);
@@ -194,8 +217,8 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
             goto done;
         }
         TRY(c21hip_h2d(mean_dev, s->mean_sfr_zpp, (size_t)n * sizeof(double), stream));
-        TRY(c21hip_ts_sfrd_means(grid_a, tables_dev, dev_tab, mean_dev, n, ntot, partials, ave_dev,
-                                 stream));
+        TRY(c21hip_ts_sfrd_means(grid_a, mean_tables_dev, !fcoll_mode, dev_tab, mean_dev, n, ntot,
+                                 partials, ave_dev, stream));
     }
     TRY(c21hip_ts_cells(&a, d_dens, d_pts, d_ptk, d_pxe, grid_a, grid_b, tables_dev, dev_tab, lya_c,
                         lya_i, o_ts, o_tk, o_xe, ntot, partials + (size_t)512 * n, sums_dev,

@@ -511,7 +511,7 @@ X_INT_NXHII = 14
 X_INT_XHII = (1.0e-4, 2.318e-4, 4.677e-4, 1.0e-3, 2.318e-3, 4.677e-3, 1.0e-2, 2.318e-2, 4.677e-2,
               1.0e-1, 0.5, 0.9, 0.99, 0.999)  # elec_interp.c:57-70 (floats upstream)
 LYA_NT, LYA_NGP = 101, 51
-TS_SRC_GRIDS, TS_SRC_SFRD_TABLE = 0, 1
+TS_SRC_GRIDS, TS_SRC_SFRD_TABLE, TS_SRC_FCOLL_TABLES = 0, 1, 2
 _PER_SHELL = C.c_double * MAX_TS_RADII
 
 
@@ -541,7 +541,7 @@ class TsSpec(_Base):
         ("lya_inj_prefactor", _PER_SHELL),
         ("zpp_growth", _PER_SHELL), ("mean_sfr_zpp", _PER_SHELL),
         ("tab_min", _PER_SHELL), ("tab_width", _PER_SHELL),
-        ("ln_sfrd_tables", c_float_p),
+        ("ln_sfrd_tables", c_float_p), ("fcoll_tables", c_float_p), ("dfcoll_tables", c_float_p),
         ("sfr_scale", C.c_double), ("xray_scale", C.c_double),
         ("freq_int_heat", c_double_p), ("freq_int_ion", c_double_p), ("freq_int_lya", c_double_p),
         ("lya_dEC", c_double_p), ("lya_dEI", c_double_p),

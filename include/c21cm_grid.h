@@ -362,7 +362,10 @@ int c21cm_annular_filter_grids(const c21cm_annular_spec *spec, const float *cons
  * source_mode C21CM_TS_SRC_SFRD_TABLE: `filtered_density` [n_step][N] (fill_Rbox_table's
  *   delNL0, i.e. linearly extrapolated to z = 0) is turned into an SFRD per shell through
  *   exp(lerp(ln_sfrd_tables[R], delta zpp_growth[R])) (1 + delta zpp_growth[R]), normalised to
- *   mean_sfr_zpp[R] over the box mean of the table values (avg_fix_term, :1624). */
+ *   mean_sfr_zpp[R] over the box mean of the table values (avg_fix_term, :1624);
+ * source_mode C21CM_TS_SRC_FCOLL_TABLES (CONST-ION-EFF): two linear tables per shell, the
+ *   conditional collapsed fraction (`fcoll_tables`, its box mean normalises) and its redshift
+ *   derivative (`dfcoll_tables`, the source: (1 + delta) dfcoll/dz, :1067-1072). */
 #define C21CM_X_INT_NXHII 14 /* elec_interp.h:5 */
 #define C21CM_X_INT_XHII                                                                        \
     { 1.0e-4f, 2.318e-4f, 4.677e-4f, 1.0e-3f, 2.318e-3f, 4.677e-3f, 1.0e-2f, 2.318e-2f, 4.677e-2f, \
@@ -370,7 +373,7 @@ int c21cm_annular_filter_grids(const c21cm_annular_spec *spec, const float *cons
 #define C21CM_LYA_NT 101  /* heating_helper_progs.c:50-55: log10 T_k, log10 T_s in [-1, 3] */
 #define C21CM_LYA_NGP 51  /* log10 tau_GP in [1, 7] */
 #define C21CM_TS_MAX_TK 5e4 /* SpinTemperatureBox.c:30 */
-enum { C21CM_TS_SRC_GRIDS = 0, C21CM_TS_SRC_SFRD_TABLE = 1 };
+enum { C21CM_TS_SRC_GRIDS = 0, C21CM_TS_SRC_SFRD_TABLE = 1, C21CM_TS_SRC_FCOLL_TABLES = 2 };
 
 typedef struct c21cm_ts_spec {
     int hii_dim, hii_dim_z;
@@ -399,6 +402,7 @@ typedef struct c21cm_ts_spec {
     double mean_sfr_zpp[C21CM_MAX_TS_RADII];
     double tab_min[C21CM_MAX_TS_RADII], tab_width[C21CM_MAX_TS_RADII];
     const float *ln_sfrd_tables; /* host, [n_step][C21CM_NDELTA_TABLE] */
+    const float *fcoll_tables, *dfcoll_tables; /* C21CM_TS_SRC_FCOLL_TABLES, same shape */
     double sfr_scale;            /* F_STAR10 */
     double xray_scale;           /* L_X s_per_yr */
     /* fill_freqint_tables (:810-889): host, [C21CM_X_INT_NXHII][n_step] each */

@@ -238,7 +238,11 @@ static void ts_cell(const c21cm_ts_spec *s, const rad_terms *rad, double *Ts_out
 static int ts_check(const c21cm_ts_spec *s) {
     if (!s || s->hii_dim < 1 || s->hii_dim_z < 1 || s->n_step < 1 || s->n_step > C21CM_MAX_TS_RADII)
         return C21CM_VALUE_ERROR;
-    if (s->source_mode != C21CM_TS_SRC_GRIDS && s->source_mode != C21CM_TS_SRC_SFRD_TABLE)
+    if (s->source_mode != C21CM_TS_SRC_GRIDS && s->source_mode != C21CM_TS_SRC_SFRD_TABLE &&
+        s->source_mode != C21CM_TS_SRC_FCOLL_TABLES)
+        return C21CM_VALUE_ERROR;
+    if (s->source_mode == C21CM_TS_SRC_FCOLL_TABLES && !s->no_light &&
+        (!s->fcoll_tables || !s->dfcoll_tables))
         return C21CM_VALUE_ERROR;
     if (!s->freq_int_heat || !s->freq_int_ion || !s->freq_int_lya) return C21CM_VALUE_ERROR;
     if (s->use_lya_heating && (!s->lya_dEC || !s->lya_dEI)) return C21CM_VALUE_ERROR;
@@ -298,16 +302,25 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
             const double z_edge_factor = s->z_edge_factor[R_ct];
             const double xray_R_factor = s->xray_R_factor[R_ct];
             double avg_fix_term = 1.;
-            if (!lagrangian) { /* calculate_sfrd_from_grid, E-INTEGRAL with tables */
+            if (!lagrangian) { /* calculate_sfrd_from_grid with tables (:1040-1079) */
                 const float *dens_R = filtered_density + (size_t)R_ct * ntot;
-                const float *tab = s->ln_sfrd_tables + (size_t)R_ct * C21CM_NDELTA_TABLE;
+                const int e_integral = s->source_mode == C21CM_TS_SRC_SFRD_TABLE;
+                const float *tab = (e_integral ? s->ln_sfrd_tables : s->fcoll_tables) +
+                                   (size_t)R_ct * C21CM_NDELTA_TABLE;
+                const float *dtab = e_integral ? NULL : s->dfcoll_tables + (size_t)R_ct * C21CM_NDELTA_TABLE;
                 double ave = 0;
 #pragma omp parallel for schedule(static) reduction(+ : ave)
                 for (long ct = 0; ct < (long)ntot; ct++) {
                     const double curr_dens = dens_R[ct] * s->zpp_growth[R_ct];
-                    const double fcoll =
-                        exp(table_1d(curr_dens, s->tab_min[R_ct], s->tab_width[R_ct], tab));
-                    del_fcoll_Rct[ct] = (1. + curr_dens) * fcoll;
+                    double fcoll = table_1d(curr_dens, s->tab_min[R_ct], s->tab_width[R_ct], tab);
+                    if (e_integral) {
+                        fcoll = exp(fcoll);
+                        del_fcoll_Rct[ct] = (1. + curr_dens) * fcoll;
+                    } else { /* CONST-ION-EFF: the source is dfcoll/dz, the mean is fcoll's */
+                        const double dfcoll =
+                            table_1d(curr_dens, s->tab_min[R_ct], s->tab_width[R_ct], dtab);
+                        del_fcoll_Rct[ct] = (1. + curr_dens) * dfcoll;
+                    }
                     ave += fcoll;
                 }
                 ave /= ntot;

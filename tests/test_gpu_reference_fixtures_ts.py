@@ -37,11 +37,11 @@ def api(gpu_lib):
     return importlib.import_module("21cmfast_amd.grid_api")
 
 
-def evolve(lib, api, tmp_path, **opts):
+def evolve(lib, api, tmp_path, source_model=1, **opts):
     from test_gpu_abi import Session
 
     ses = Session(lib, tmp_path, data_dir=DATA, HII_DIM=RP.HII_DIM, DIM=RP.DIM, BOX_LEN=RP.BOX_LEN,
-                  N_THREADS=2, ZPRIME_STEP_FACTOR=1.04, SOURCE_MODEL=1, HII_FILTER=0,
+                  N_THREADS=2, ZPRIME_STEP_FACTOR=1.04, SOURCE_MODEL=source_model, HII_FILTER=0,
                   USE_EXP_FILTER=False, CELL_RECOMB=False, USE_UPPER_STELLAR_TURNOVER=False,
                   USE_TS_FLUCT=True, USE_LYA_HEATING=False, **opts)
     lib.init_heat.restype = C.c_int
@@ -235,3 +235,48 @@ def test_lagrangian_ts_evolution_reproduces_reference_fixture(gpu_lib, api, tmp_
     for k in TS + ("brightness_temp", "neutral_fraction"):
         assert worst[k] < 2e-3, k
     np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-3)
+
+
+def test_minimize_memory_run_reproduces_reference_fixture(gpu_lib, api, tmp_path, monkeypatch):
+    """power_spectra_minimize_mem.h5: the same physics as inhomo_ts with MINIMIZE_MEMORY -- upstream
+    filters one shell at a time and drops kinetic_temperature / mean_free_path; here the flag only
+    changes what ComputeIonizedBox writes."""
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    gpu_lib.init_MHR.restype = None
+    gpu_lib.init_MHR()
+    got = evolve(gpu_lib, api, tmp_path, RECOMB_MODEL=2, R_BUBBLE_MAX=50.0, MINIMIZE_MEMORY=True)
+    f, worst = report("minimize_mem", got)
+    print("worst relative deviation of the binned power:", worst)
+    for k in TS + ("brightness_temp", "neutral_fraction"):
+        assert worst[k] < 2e-3, k
+    gb = np.array([h[1] for h in got["history"]])
+    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-3)
+
+
+def test_const_ion_eff_ts_evolution_reproduces_reference_fixture(gpu_lib, api, tmp_path, monkeypatch):
+    """power_spectra_ts_nomdz.h5: SOURCE_MODEL = CONST-ION-EFF with USE_TS_FLUCT -- the X-ray and
+    Lyman-alpha sources follow dfcoll/dz of the filtered density (two linear tables per shell), the
+    global tables are the collapsed fraction every 0.1 in z, tau_X takes its efficiency from the
+    filling factor.
+
+    Tolerances: upstream's dfcoll/dz is a central difference over dz = 0.001 of a FLOAT erfc of a
+    float argument (hmf.c:1187-1264), i.e. every table entry carries ~1e-3 of rounding noise whose
+    realisation depends on the last digits of sigma(M_min) and sigma(M(R)).  The reference takes
+    those from a linear interpolation table in float, this library from a spline in double; they
+    agree to ~1e-5, which decorrelates the noise.  It is white in the density, so it shows at high
+    k: changing sigma_min by 1e-6 moves the last bin of the T_k power by 9e-4 (measured), and the
+    two implementations differ by up to 1 % there (growing smoothly with k).  On the five largest
+    scales they agree to 1.4e-3 .. 2.2e-3: the collapsed fraction responds to sigma with a
+    logarithmic slope of ~20-40 at these redshifts, so the ~1e-4 of the reference's sigma table
+    shows (the E-INTEGRAL runs above normalise most of it away through avg_fix_term)."""
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    got = evolve(gpu_lib, api, tmp_path, source_model=0)
+    f = RP.fixture("power_spectra", "ts_nomdz")
+    for k in TS + ("brightness_temp", "neutral_fraction"):
+        p, _ = RP.get_power(got[k], RP.BOX_LEN)
+        dev = np.abs(p / f[f"coeval/power_{k}"] - 1)
+        print(k, "large scales", dev[:5].max(), "all", dev.max())
+        assert dev[:5].max() < 4e-3, k
+        assert dev.max() < 1.5e-2, k
+    gb = np.array([h[1] for h in got["history"]])
+    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=2e-3)  # observed 1.1e-3

@@ -219,7 +219,7 @@ def test_compute_ts_box_first_snapshot_and_refusals(gpu_lib, oracle, tmp_path):
     assert lib.ComputeTsBox(20.0, 20.8, 20.0, 0, C.byref(pf), None, C.byref(prevs), None, C.byref(outs)) == 3
     assert b"USE_MINI_HALOS" in lib.c21cm_last_error()
     ses.ao.USE_MINI_HALOS = False
-    ses.mo.SOURCE_MODEL = 0
+    ses.mo.USE_INTERPOLATION_TABLES = 0
     assert lib.ComputeTsBox(20.0, 20.8, 20.0, 0, C.byref(pf), None, C.byref(prevs), None, C.byref(outs)) == 3
-    assert b"CONST-ION-EFF" in lib.c21cm_last_error()
+    assert b"USE_INTERPOLATION_TABLES" in lib.c21cm_last_error()
     del ses

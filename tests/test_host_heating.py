@@ -165,7 +165,8 @@ class Tables(C.Structure):
         (k, f64 * 128) for k in ("R_values", "zpp_edge", "zpp", "dzpp", "dtdz", "zpp_growth",
                                  "M_min_R", "M_max_R", "starlya_prefactor", "lya_cont_prefactor",
                                  "lya_inj_prefactor", "mean_sfr_zpp", "nu_tau_one")
-    ] + [("freq", C.POINTER(f64)), ("sfrd_tables", C.POINTER(f32))]
+    ] + [("freq", C.POINTER(f64)), ("sfrd_tables", C.POINTER(f32)), ("fcoll_tables", C.POINTER(f32)),
+         ("dfcoll_tables", C.POINTER(f32)), ("sigma_min", f64 * 128), ("sigma_max", f64 * 128)]
 
 
 def test_ts_prepare_against_numpy(heat, pkg):
