@@ -342,8 +342,8 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
                       IonizedBox *box);
 
 /* reference: src/py21cmfast/src/SpinTemperatureBox.c:87 (_functionprototypes_wrapper.h:19-22).
- * E-INTEGRAL and the Lagrangian source models with interpolation tables; USE_MINI_HALOS and
- * CONST-ION-EFF return ValueError.  `cleanup` is accepted and ignored (nothing is cached per call
+ * The Eulerian (CONST-ION-EFF, E-INTEGRAL) and the Lagrangian source models with interpolation
+ * tables; USE_MINI_HALOS returns ValueError.  `cleanup` is accepted and ignored (nothing is cached per call
  * beyond the data tables). */
 int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
                  PerturbedField *perturbed_field, XraySourceBox *source_box,

@@ -74,6 +74,20 @@ def test_cell_sweep_matches_oracle(api, oracle, lagrangian, n, n_step, nz, devic
     assert to_host(got["kinetic_temp_neutral"]).flat[13] == np.float32(6e4)  # frozen above MAX_TK
 
 
+def test_fcoll_table_mode_matches_oracle(api, oracle):
+    """C21CM_TS_SRC_FCOLL_TABLES (CONST-ION-EFF): the source is the dfcoll/dz table, the box mean that
+    normalises it is the f_coll table's; the densest cell sits exactly on the last knot."""
+    spec, d = H.make(n=20, n_step=16, lagrangian=False, fcoll_tables=True)
+    for i in range(spec.n_step):  # upstream's table ends at the maximum itself (no 1.001 margin)
+        fd = d["filtered_density"][i]
+        spec.tab_width[i] = (float(fd.max()) * spec.zpp_growth[i] - spec.tab_min[i]) / (S.NDELTA_TABLE - 1.0)
+    for device in (False, True):
+        got, ref = run_both(api, oracle, spec, d, device)
+        compare(got, ref, spec)
+        np.testing.assert_allclose(np.array(got["report"].ave_sfrd[:16]),
+                                   np.array(ref["report"].ave_sfrd[:16]), rtol=1e-9)
+
+
 @pytest.mark.parametrize("flags", [
     dict(lya_heating=False), dict(xray_heating=False), dict(cmb_heating=False),
     dict(no_light=True), dict(lya_heating=False, xray_heating=False, cmb_heating=False),

@@ -44,7 +44,7 @@ def lya_tables(rng):
 
 
 def make(n=24, n_step=12, lagrangian=True, seed=5, zp=12.0, dzp=-0.3, lya_heating=True,
-         xray_heating=True, cmb_heating=True, no_light=False, hii_dim_z=None):
+         xray_heating=True, cmb_heating=True, no_light=False, hii_dim_z=None, fcoll_tables=False):
     """Returns (spec, inputs dict).  inputs: density, previous (dict of three boxes), source
     (dict) or filtered_density."""
     rng = np.random.default_rng(seed)
@@ -52,7 +52,8 @@ def make(n=24, n_step=12, lagrangian=True, seed=5, zp=12.0, dzp=-0.3, lya_heatin
     shape = (n, n, nz)
     c = Cosmo()
     spec = S.TsSpec(hii_dim=n, hii_dim_z=nz, n_step=n_step,
-                    source_mode=S.TS_SRC_GRIDS if lagrangian else S.TS_SRC_SFRD_TABLE,
+                    source_mode=S.TS_SRC_GRIDS if lagrangian else (
+                        S.TS_SRC_FCOLL_TABLES if fcoll_tables else S.TS_SRC_SFRD_TABLE),
                     use_xray_heating=int(xray_heating), use_cmb_heating=int(cmb_heating),
                     use_lya_heating=int(lya_heating), no_light=int(no_light))
     spec.redshift = float(np.float32(zp))
@@ -119,7 +120,8 @@ def make(n=24, n_step=12, lagrangian=True, seed=5, zp=12.0, dzp=-0.3, lya_heatin
                         for i in range(n_step))
     else:
         fd = np.empty((n_step,) + shape, np.float32)
-        tabs = np.empty((n_step, S.NDELTA_TABLE), np.float32)
+        # one spare row: upstream's lookup touches y[idx + 1] with weight 0 on the last knot
+        tabs = np.zeros((n_step + 1, S.NDELTA_TABLE), np.float32)
         xray_terms = lya_terms = 0.0
         spec.sfr_scale = 0.05
         spec.xray_scale = 1e40 * RH.PC["s_per_yr"]
@@ -131,14 +133,24 @@ def make(n=24, n_step=12, lagrangian=True, seed=5, zp=12.0, dzp=-0.3, lya_heatin
             spec.tab_width[i] = (hi - lo) / (S.NDELTA_TABLE - 1.0)
             x = lo + np.arange(S.NDELTA_TABLE) * spec.tab_width[i]
             tabs[i] = np.maximum(-9.0 + 4.0 * x - 0.5 * x * x - 0.1 * i, -50.0)
-            fc = np.exp(np.interp(fd[i].astype(np.float64) * g, x, tabs[i].astype(np.float64)))
+            if fcoll_tables:  # CONST-ION-EFF: linear tables, f_coll and (here) a multiple of it
+                tabs[i] = np.exp(tabs[i])
+                fc = np.interp(fd[i].astype(np.float64) * g, x, tabs[i].astype(np.float64))
+            else:
+                fc = np.exp(np.interp(fd[i].astype(np.float64) * g, x, tabs[i].astype(np.float64)))
             spec.mean_sfr_zpp[i] = 1.1 * fc.mean() * (1 + 0.05 * math.sin(i))
             sfr_mean = float(((1 + fd[i] * g) * fc).mean()) * 1.1 * (1 + 0.05 * math.sin(i)) * spec.sfr_scale
             xray_terms += (sfr_mean * spec.z_edge_factor[i] * spec.xray_scale * spec.xray_R_factor[i]
                            * fion[7, i])
             lya_terms += sfr_mean * spec.z_edge_factor[i] * spec.starlya_prefactor[i]
         keep["tabs"] = np.ascontiguousarray(tabs)
-        spec.ln_sfrd_tables = keep["tabs"].ctypes.data_as(S.c_float_p)
+        if fcoll_tables:
+            keep["dtabs"] = np.ascontiguousarray(
+                tabs * (1.0 + 0.1 * np.cos(np.arange(n_step + 1))[:, None]), np.float32)
+            spec.fcoll_tables = keep["tabs"].ctypes.data_as(S.c_float_p)
+            spec.dfcoll_tables = keep["dtabs"].ctypes.data_as(S.c_float_p)
+        else:
+            spec.ln_sfrd_tables = keep["tabs"].ctypes.data_as(S.c_float_p)
         inputs["filtered_density"] = fd
     # scale the two radiative prefactors to physical magnitudes (see the module docstring)
     target_xion = 2.5e-4 / (abs(spec.dzp) * abs(spec.dt_dzp))  # delta x_e ~ 2.5e-4 per step
