@@ -263,8 +263,30 @@ def main():
     D = importlib.import_module("21cmfast_amd.distributed")
     owner = D.owner_rank(spec.n_radii, world)
     shard_c = sharded and args.shard_impl == "c" and args.backend == "nccl"
-    if shard_c:  # the library's own communicator, bootstrapped once through torch.distributed
-        api.shard_init_from_torch()
+    shard_note = None
+    if shard_c:
+        # the library's own communicator, bootstrapped once through torch.distributed.  One probe
+        # call decides COLLECTIVELY whether it works here; otherwise every rank takes the
+        # torch.distributed exchange (same kernels, the reduce issued from Python).
+        ok, why = 1, ""
+        try:
+            api.shard_init_from_torch()
+            buffers.reset()
+            D.sharded_ionize_c(spec, density, n_ion, buffers, rank, world)
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001 -- any failure means "use the other exchange"
+            ok, why = 0, f"{type(exc).__name__}: {exc}"
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            shard_c = False
+            shard_note = "torch (C-level RCCL exchange unavailable" + (f": {why}" if why else " on another rank") + ")"
+            print(f"[bench rank {rank}] falling back to the torch.distributed exchange. {why}",
+                  file=sys.stderr, flush=True)
+            try:
+                api.shard_finalize()
+            except Exception:  # noqa: BLE001
+                pass
     first_cross = (torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
                    if sharded and not shard_c else None)
     last_report = {}
@@ -377,6 +399,7 @@ def main():
                 f"R-loop sharded x{world} + "
                 + ("1-bit mask gather over RCCL inside the C library (c21cm_ionize_sharded)" if shard_c
                    else f"{'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce via torch.distributed"),
+                **({"shard_impl_note": shard_note} if shard_note else {}),
                 "fft": "native" if native else "rocfft",
                 "global_xH": global_xh,
             },
