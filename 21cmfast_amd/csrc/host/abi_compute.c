@@ -121,10 +121,10 @@ int ComputeInitialConditions(unsigned long long random_seed, InitialConditions *
     s.seed = random_seed;
     /* Random stream.  Default: the reference's own (seed_rng_threads + gsl_ran_ugaussian in its
      * loop order, rng.c:31-90, InitialConditions.c:103-139), so that the same random_seed and
-     * N_THREADS give the same universe as upstream; it exists for N_THREADS <= 2 (mt19937 and
-     * gfsr4) and is drawn serially on the host, as upstream draws it.  Beyond two threads, or
-     * with C21CM_IC_RNG=philox, the counter-based device generator is used (a different, equally
-     * valid realisation; ~100x faster at DIM = 512).  C21CM_IC_RNG=gsl insists on the former. */
+     * N_THREADS give the same universe as upstream (all five per-thread generators, gsl_stream.c);
+     * it is drawn serially on the host, as upstream draws it.  With C21CM_IC_RNG=philox the
+     * counter-based device generator is used (a different, equally valid realisation; ~100x faster
+     * at DIM = 512).  C21CM_IC_RNG=gsl insists on the former. */
     {
         extern int c21_gsl_stream_supported(int n_threads);
         const char *e = getenv("C21CM_IC_RNG");

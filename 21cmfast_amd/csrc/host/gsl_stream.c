@@ -19,9 +19,20 @@
  *   shuffle  Fisher-Yates from the last element down, swapping with uniform_int(i + 1)
  *   ugaussian  polar method: (x, y) = 2 u_pos - 1 until 0 < x^2 + y^2 <= 1, value
  *            y sqrt(-2 ln r2 / r2); the pair's other value is discarded
- * Thread t of seed_rng_threads cycles through mt19937, gfsr4, cmrg, mrg, taus2; the first two
- * are provided, so N_THREADS <= 2 reproduces upstream (every configuration the reference's
- * fixtures use, tests/produce_integration_test_data.py:62,213-220).  A mode belongs to the
+ *   cmrg     L'Ecuyer (1996) combined multiple recursive generator: two order-3 recurrences
+ *            modulo 2147483647 and 2145483479 (multipliers 63308, -183326 / 86098, -539608, each
+ *            step by Schrage's decomposition), output (x - y) mod m1; seeded from the LCG
+ *            x -> 69069 x (mod 2^32), seven warm-up steps; uniform = value / 2147483647
+ *   mrg      L'Ecuyer, Blouin & Couture (1993) order-5 recurrence modulo 2147483647
+ *            (multipliers 107374182 and 104480), same seeding, six warm-up steps
+ *   taus2    L'Ecuyer (1996/1999) three-component Tausworthe generator with the 1999 seeding
+ *            (components forced >= 2, 8, 16), six warm-up steps; uniform = value / 2^32
+ *   GSL's own self-test values (rng/test.c: the 10000th output for seed 1 is 719452880 for cmrg,
+ *   2064828650 for mrg, 2733957125 for taus2) are reproduced: tests/test_oracle_gslrng.py.
+ * Thread t of seed_rng_threads cycles through mt19937, gfsr4, cmrg, mrg, taus2 (rng.c:58-85), so
+ * any N_THREADS reproduces upstream; the reference's fixtures pin the first two
+ * (tests/produce_integration_test_data.py:62,213-220), the other three rest on GSL's self-test
+ * values.  A mode belongs to the
  * thread that owns its n_x under the default static OpenMP schedule (contiguous blocks, the
  * first DIM % N_THREADS threads one row longer).
  *
@@ -50,7 +61,63 @@ typedef struct word_source {
     /* gfsr4 */
     uint32_t *ring;
     int nd;
+    /* cmrg (x1..x3, y1..y3), mrg (x1..x5), taus2 (s1..s3) */
+    int kind;
+    long int lx[6];
+    uint32_t ts[3];
 } word_source;
+
+/* ---- the three generators without a block structure ------------------------------------ */
+static unsigned long cmrg_get(word_source *w) {
+    const long int m1 = 2147483647, m2 = 2145483479;
+    const long int a2 = 63308, qa2 = 33921, ra2 = 12979, a3 = -183326, qa3 = 11714, ra3 = 2883;
+    const long int b1 = 86098, qb1 = 24919, rb1 = 7417, b3 = -539608, qb3 = 3976, rb3 = 2071;
+    long int *x = w->lx, *y = w->lx + 3;
+    { /* component 1 */
+        const long int h3 = x[2] / qa3, h2 = x[1] / qa2;
+        long int p3 = -a3 * (x[2] - h3 * qa3) - h3 * ra3;
+        long int p2 = a2 * (x[1] - h2 * qa2) - h2 * ra2;
+        if (p3 < 0) p3 += m1;
+        if (p2 < 0) p2 += m1;
+        x[2] = x[1], x[1] = x[0], x[0] = p2 - p3;
+        if (x[0] < 0) x[0] += m1;
+    }
+    { /* component 2 */
+        const long int h3 = y[2] / qb3, h1 = y[0] / qb1;
+        long int p3 = -b3 * (y[2] - h3 * qb3) - h3 * rb3;
+        long int p1 = b1 * (y[0] - h1 * qb1) - h1 * rb1;
+        if (p3 < 0) p3 += m2;
+        if (p1 < 0) p1 += m2;
+        y[2] = y[1], y[1] = y[0], y[0] = p1 - p3;
+        if (y[0] < 0) y[0] += m2;
+    }
+    return x[0] < y[0] ? (unsigned long)(x[0] - y[0] + m1) : (unsigned long)(x[0] - y[0]);
+}
+
+static unsigned long mrg_get(word_source *w) {
+    const long int m = 2147483647, a1 = 107374182, q1 = 20, r1 = 7, a5 = 104480, q5 = 20554, r5 = 1727;
+    long int *x = w->lx;
+    const long int h5 = x[4] / q5, h1 = x[0] / q1;
+    long int p5 = a5 * (x[4] - h5 * q5) - h5 * r5;
+    long int p1 = a1 * (x[0] - h1 * q1) - h1 * r1;
+    if (p5 > 0) p5 -= m;
+    if (p1 < 0) p1 += m;
+    x[4] = x[3], x[3] = x[2], x[2] = x[1], x[1] = x[0], x[0] = p1 + p5;
+    if (x[0] < 0) x[0] += m;
+    return (unsigned long)x[0];
+}
+
+static unsigned long taus2_get(word_source *w) {
+#define TAUSWORTHE(s, a, b, c, d) ((((s) & (c)) << (d)) ^ ((((s) << (a)) ^ (s)) >> (b)))
+    uint32_t *s = w->ts;
+    s[0] = TAUSWORTHE(s[0], 13, 19, 4294967294u, 12);
+    s[1] = TAUSWORTHE(s[1], 2, 25, 4294967288u, 4);
+    s[2] = TAUSWORTHE(s[2], 3, 11, 4294967280u, 17);
+#undef TAUSWORTHE
+    return s[0] ^ s[1] ^ s[2];
+}
+
+
 
 static void mt_refill(word_source *w) {
     uint32_t *x = w->mt;
@@ -88,6 +155,34 @@ static int source_open(word_source *w, int kind, unsigned long seed) {
     memset(w, 0, sizeof(*w));
     w->buf = (uint32_t *)malloc(624 * sizeof(uint32_t));
     if (!w->buf) return C21CM_MEMORY_ALLOC_ERROR;
+    w->kind = kind;
+    if (kind >= 2) { /* cmrg, mrg, taus2: seeded through the LCG x -> 69069 x mod 2^32; 0 means 1 */
+        uint32_t x = seed == 0 ? 1u : (uint32_t)seed;
+#define LCG(n) ((uint32_t)(69069u * (n)))
+        if (kind == 2) {
+            for (int i = 0; i < 6; i++) {
+                x = LCG(x);
+                w->lx[i] = (long int)(x % (i < 3 ? 2147483647u : 2145483479u));
+            }
+            for (int i = 0; i < 7; i++) (void)cmrg_get(w);
+        } else if (kind == 3) {
+            for (int i = 0; i < 5; i++) {
+                x = LCG(x);
+                w->lx[i] = (long int)(x % 2147483647u);
+            }
+            for (int i = 0; i < 6; i++) (void)mrg_get(w);
+        } else {
+            w->ts[0] = LCG(x);
+            if (w->ts[0] < 2) w->ts[0] += 2u;
+            w->ts[1] = LCG(w->ts[0]);
+            if (w->ts[1] < 8) w->ts[1] += 8u;
+            w->ts[2] = LCG(w->ts[1]);
+            if (w->ts[2] < 16) w->ts[2] += 16u;
+            for (int i = 0; i < 6; i++) (void)taus2_get(w);
+        }
+#undef LCG
+        return 0;
+    }
     if (seed == 0) seed = 4357;
     if (kind == 0) {
         w->mt[0] = (uint32_t)seed;
@@ -129,6 +224,18 @@ static inline uint32_t next_word(word_source *w) {
 }
 
 static inline double next_uniform_pos(word_source *w) {
+    if (w->kind >= 2) { /* gsl_rng_uniform_pos: the generator's get_double until it is non-zero */
+        double u;
+        do {
+            if (w->kind == 2)
+                u = cmrg_get(w) / 2147483647.0;
+            else if (w->kind == 3)
+                u = mrg_get(w) / 2147483647.0;
+            else
+                u = taus2_get(w) / 4294967296.0;
+        } while (u == 0);
+        return u;
+    }
     uint32_t v;
     do v = next_word(w);
     while (v == 0);
@@ -170,29 +277,47 @@ int c21_gsl_thread_seeds(unsigned long long seed, int n_threads, unsigned int *s
     return 0;
 }
 
-int c21_gsl_stream_supported(int n_threads) { return n_threads >= 1 && n_threads <= 2; }
+int c21_gsl_stream_supported(int n_threads) { return n_threads >= 1 && n_threads <= 4096; }
+
+/* the n-th raw output of generator `kind` (0 mt19937, 1 gfsr4, 2 cmrg, 3 mrg, 4 taus2) after
+ * gsl_rng_set(seed): what GSL's own self-test compares (rng/test.c) */
+unsigned long c21_gsl_nth_output(int kind, unsigned long seed, int n) {
+    word_source w;
+    if (kind < 0 || kind > 4 || n < 1 || source_open(&w, kind, seed)) return 0;
+    unsigned long v = 0;
+    for (int i = 0; i < n; i++)
+        v = kind == 2 ? cmrg_get(&w) : kind == 3 ? mrg_get(&w) : kind == 4 ? taus2_get(&w) : next_word(&w);
+    source_close(&w);
+    return v;
+}
 
 /* The (a, b) deviates of all nx * ny * nzc modes in grid order: ab[2 * mode + {0, 1}]. */
 int c21_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int ny, int nzc,
                           double *ab) {
     if (!c21_gsl_stream_supported(n_threads)) {
-        c21hip_set_error(
-            "ics: the reference's random stream is reproduced for N_THREADS <= 2 (mt19937, gfsr4); "
-            "N_THREADS = %d would need GSL's cmrg / mrg / taus2 generators", n_threads);
+        c21hip_set_error("ics: N_THREADS = %d is outside 1..4096", n_threads);
         return C21CM_VALUE_ERROR;
     }
-    unsigned int seeds[2];
+    unsigned int *seeds = (unsigned int *)malloc(sizeof(unsigned int) * (size_t)n_threads);
+    if (!seeds) return C21CM_MEMORY_ALLOC_ERROR;
     int st = c21_gsl_thread_seeds(seed, n_threads, seeds);
-    if (st) return st;
+    if (st) {
+        free(seeds);
+        return st;
+    }
     const int q = nx / n_threads, rem = nx % n_threads;
     for (int t = 0; t < n_threads; t++) {
         const int lo = t * q + (t < rem ? t : rem), rows = q + (t < rem ? 1 : 0);
         word_source w;
-        if ((st = source_open(&w, t, seeds[t]))) return st;
+        if ((st = source_open(&w, t % 5, seeds[t]))) { /* rng.c:58-85: the five kinds in turn */
+            free(seeds);
+            return st;
+        }
         double *p = ab + 2 * (size_t)lo * ny * nzc;
         const size_t count = 2 * (size_t)rows * ny * nzc;
         for (size_t m = 0; m < count; m++) p[m] = next_ugaussian(&w);
         source_close(&w);
     }
+    free(seeds);
     return 0;
 }

@@ -26,9 +26,10 @@
  *   gsl_ran_ugaussian = gsl_ran_gaussian(r, 1): polar Box-Muller, x, y = 2 u_pos - 1 until
  *                     0 < r2 <= 1, returns y sqrt(-2 ln r2 / r2) (second value discarded)
  *                                                                          (GSL randist/gauss.c)
- * Threads 0 and 1 of seed_rng_threads use mt19937 and gfsr4; threads 2-4 would use cmrg, mrg
- * and taus2, which are not restated: N_THREADS <= 2 is what every pinnable fixture of the
- * reference uses (tests/produce_integration_test_data.py:62: N_THREADS = 2, :213-220: 1).
+ * Thread t of seed_rng_threads uses generator t mod 5 of (mt19937, gfsr4, cmrg, mrg, taus2).
+ * Every pinnable fixture of the reference uses N_THREADS <= 2
+ * (tests/produce_integration_test_data.py:62: N_THREADS = 2, :213-220: 1); the other three
+ * generators are pinned by GSL's own self-test values (see below).
  *
  * Pinning: mt19937 is checked word for word against numpy's MT19937 bit generator with legacy
  * seeding (the same init_genrand) in tests/test_oracle_gslrng.py; the whole chain
@@ -124,13 +125,70 @@ static inline uint32_t gfsr4_get(gfsr4_state *st) {
                             st->ra[(st->nd + (GF_M + 1 - GF_D)) & GF_M];
 }
 
+/* ------------------------------------------------------------------ cmrg, mrg, taus2
+ * The three remaining generators of seed_rng_threads (rng.c:66-77), written from their defining
+ * recurrences with exact 64-bit modular arithmetic (GSL evaluates the same recurrences in 32-bit
+ * longs by Schrage's decomposition, the library under test follows that route):
+ *   cmrg (L'Ecuyer 1996):  x_n = (63308 x_{n-2} - 183326 x_{n-3}) mod (2^31 - 1),
+ *                          y_n = (86098 y_{n-1} - 539608 y_{n-3}) mod 2145483479,
+ *                          output (x_n - y_n) mod (2^31 - 1); uniform = output / 2147483647
+ *   mrg (L'Ecuyer, Blouin & Couture 1993):
+ *                          x_n = (107374182 x_{n-1} + 104480 x_{n-5}) mod (2^31 - 1)
+ *   taus2 (L'Ecuyer 1996, seeding of 1999): three Tausworthe components, output their XOR;
+ *                          uniform = output / 2^32
+ * all seeded from successive values of the LCG s -> 69069 s (mod 2^32) (seed 0 meaning 1) and
+ * warmed up by 7, 6 and 6 steps.  GSL's self-test values pin them (tests/test_oracle_gslrng.py). */
+typedef struct {
+    int64_t x[3], y[3];
+} cmrg_state;
+typedef struct {
+    int64_t x[5];
+} mrg_state;
+typedef struct {
+    uint32_t s[3];
+} taus_state;
+
+static inline int64_t pmod(int64_t v, int64_t m) {
+    v %= m;
+    return v < 0 ? v + m : v;
+}
+
+static uint32_t cmrg_get(cmrg_state *c) {
+    const int64_t m1 = 2147483647, m2 = 2145483479;
+    const int64_t xn = pmod(63308 * c->x[1] - 183326 * c->x[2], m1);
+    c->x[2] = c->x[1], c->x[1] = c->x[0], c->x[0] = xn;
+    const int64_t yn = pmod(86098 * c->y[0] - 539608 * c->y[2], m2);
+    c->y[2] = c->y[1], c->y[1] = c->y[0], c->y[0] = yn;
+    return (uint32_t)(xn < yn ? xn - yn + m1 : xn - yn);
+}
+
+static uint32_t mrg_get(mrg_state *g) {
+    const int64_t m = 2147483647;
+    const int64_t xn = pmod(107374182 * g->x[0] + 104480 * g->x[4], m);
+    g->x[4] = g->x[3], g->x[3] = g->x[2], g->x[2] = g->x[1], g->x[1] = g->x[0], g->x[0] = xn;
+    return (uint32_t)xn;
+}
+
+static uint32_t taus_get(taus_state *t) {
+    uint32_t *s = t->s;
+    s[0] = ((s[0] & 4294967294u) << 12) ^ (((s[0] << 13) ^ s[0]) >> 19);
+    s[1] = ((s[1] & 4294967288u) << 4) ^ (((s[1] << 2) ^ s[1]) >> 25);
+    s[2] = ((s[2] & 4294967280u) << 17) ^ (((s[2] << 3) ^ s[2]) >> 11);
+    return s[0] ^ s[1] ^ s[2];
+}
+
+static inline uint32_t lcg69069(uint32_t s) { return 69069u * s; }
+
 /* ------------------------------------------------------------------ generic front */
-enum { OGSL_MT19937 = 0, OGSL_GFSR4 = 1 };
+enum { OGSL_MT19937 = 0, OGSL_GFSR4 = 1, OGSL_CMRG = 2, OGSL_MRG = 3, OGSL_TAUS2 = 4 };
 typedef struct oracle_gsl_rng {
     int kind;
     union {
         mt_state mt;
         gfsr4_state gf;
+        cmrg_state cm;
+        mrg_state mr;
+        taus_state ta;
     } u;
 } oracle_gsl_rng;
 
@@ -142,7 +200,25 @@ oracle_gsl_rng *oracle_gsl_rng_alloc(int kind, unsigned long seed) {
         mt_set(&r->u.mt, seed);
     else if (kind == OGSL_GFSR4)
         gfsr4_set(&r->u.gf, seed);
-    else {
+    else if (kind == OGSL_CMRG || kind == OGSL_MRG || kind == OGSL_TAUS2) {
+        uint32_t s = seed == 0 ? 1u : (uint32_t)seed;
+        if (kind == OGSL_CMRG) {
+            for (int i = 0; i < 3; i++) r->u.cm.x[i] = (s = lcg69069(s)) % 2147483647u;
+            for (int i = 0; i < 3; i++) r->u.cm.y[i] = (s = lcg69069(s)) % 2145483479u;
+            for (int i = 0; i < 7; i++) (void)cmrg_get(&r->u.cm);
+        } else if (kind == OGSL_MRG) {
+            for (int i = 0; i < 5; i++) r->u.mr.x[i] = (s = lcg69069(s)) % 2147483647u;
+            for (int i = 0; i < 6; i++) (void)mrg_get(&r->u.mr);
+        } else {
+            const uint32_t floor_[3] = {2u, 8u, 16u};
+            for (int i = 0; i < 3; i++) {
+                s = lcg69069(s);
+                if (s < floor_[i]) s += floor_[i];
+                r->u.ta.s[i] = s;
+            }
+            for (int i = 0; i < 6; i++) (void)taus_get(&r->u.ta);
+        }
+    } else {
         free(r);
         return NULL;
     }
@@ -152,11 +228,20 @@ oracle_gsl_rng *oracle_gsl_rng_alloc(int kind, unsigned long seed) {
 void oracle_gsl_rng_free(oracle_gsl_rng *r) { free(r); }
 
 uint32_t oracle_gsl_rng_get(oracle_gsl_rng *r) {
-    return r->kind == OGSL_MT19937 ? mt_get(&r->u.mt) : gfsr4_get(&r->u.gf);
+    switch (r->kind) {
+        case OGSL_MT19937: return mt_get(&r->u.mt);
+        case OGSL_GFSR4: return gfsr4_get(&r->u.gf);
+        case OGSL_CMRG: return cmrg_get(&r->u.cm);
+        case OGSL_MRG: return mrg_get(&r->u.mr);
+        default: return taus_get(&r->u.ta);
+    }
 }
 
-/* both generators: min 0, max 2^32 - 1, get_double = get / 2^32 */
-static inline double rng_uniform(oracle_gsl_rng *r) { return oracle_gsl_rng_get(r) / 4294967296.0; }
+/* get_double: get / 2^32 for the 32-bit generators, get / (2^31 - 1) for the two modulo that prime */
+static inline double rng_uniform(oracle_gsl_rng *r) {
+    const double range = (r->kind == OGSL_CMRG || r->kind == OGSL_MRG) ? 2147483647.0 : 4294967296.0;
+    return oracle_gsl_rng_get(r) / range;
+}
 
 static inline double rng_uniform_pos(oracle_gsl_rng *r) {
     double x;
@@ -216,14 +301,21 @@ static void omp_static_block(int n, int n_threads, int t, int *lo, int *hi) {
  * generator produces them.  ab = double[nx][ny][nz/2+1][2]. */
 int oracle_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int ny, int nz,
                              double *ab) {
-    if (n_threads < 1 || n_threads > 2) return C21CM_VALUE_ERROR; /* see the file header */
-    unsigned int seeds[2];
+    if (n_threads < 1) return C21CM_VALUE_ERROR;
+    unsigned int *seeds = (unsigned int *)malloc(sizeof(unsigned int) * (size_t)n_threads);
+    if (!seeds) return C21CM_MEMORY_ALLOC_ERROR;
     int st = oracle_gsl_thread_seeds(seed, n_threads, seeds);
-    if (st) return st;
+    if (st) {
+        free(seeds);
+        return st;
+    }
     const int nzc = nz / 2 + 1;
     for (int t = 0; t < n_threads; t++) {
-        oracle_gsl_rng *r = oracle_gsl_rng_alloc(t == 0 ? OGSL_MT19937 : OGSL_GFSR4, seeds[t]);
-        if (!r) return C21CM_MEMORY_ALLOC_ERROR;
+        oracle_gsl_rng *r = oracle_gsl_rng_alloc(t % 5, seeds[t]); /* rng.c:58-85 */
+        if (!r) {
+            free(seeds);
+            return C21CM_MEMORY_ALLOC_ERROR;
+        }
         int lo, hi;
         omp_static_block(nx, n_threads, t, &lo, &hi);
         double *p = ab + (size_t)lo * ny * nzc * 2;
@@ -233,6 +325,7 @@ int oracle_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int
         }
         oracle_gsl_rng_free(r);
     }
+    free(seeds);
     return 0;
 }
 

@@ -13,7 +13,7 @@
  *
  * RNG: the reference draws (a, b) from per-OpenMP-thread GSL generators
  * (src/py21cmfast/src/rng.c:31-90), i.e. its realisation depends on N_THREADS.  Two streams:
- *   rng_stream = C21CM_RNG_GSL     that stream, restated in oracle_gslrng.c for N_THREADS <= 2
+ *   rng_stream = C21CM_RNG_GSL     that stream, restated in oracle_gslrng.c
  *                                  and pinned by the reference's HDF5 fixtures
  *                                  (tests/test_reference_fixtures.py);
  *   rng_stream = C21CM_RNG_PHILOX  a counter-based Philox-4x32-10 keyed by the seed with the

@@ -117,7 +117,7 @@ def test_initial_conditions_entry_point(gpu_lib, api, oracle, tmp_path):
                       volume=float(vol), perturb_algorithm=2, n_m=n_m,
                       pk_by_m=pk.ctypes.data_as(S.c_double_p), seed=2026,
                       rng_stream=1, rng_threads=ses.so.N_THREADS)  # the entry point's default:
-    # the reference's own stream for N_THREADS <= 2 (abi_compute.c, C21CM_IC_RNG)
+    # the reference's own stream (abi_compute.c, C21CM_IC_RNG)
     ref = oracle.ics_grids(ospec)
     for k in ref:
         scale = np.abs(ref[k]).max()

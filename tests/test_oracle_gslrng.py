@@ -70,7 +70,32 @@ def test_polar_gaussian_moments(olib):
     assert abs(x.mean()) < 8e-3 and abs(x.std() - 1) < 6e-3 and abs((x**4).mean() - 3) < 0.06
 
 
-@pytest.mark.parametrize("n_threads,shape", [(1, (12, 12, 12)), (2, (15, 15, 15)), (2, (10, 10, 10))])
+def test_generators_reproduce_gsl_self_test_values(olib, pkg):
+    """GSL's rng/test.c: the n-th output after gsl_rng_set(seed) of each generator upstream's
+    threads use.  Both restatements (oracle: 64-bit modular arithmetic; library: Schrage's
+    decomposition as GSL codes it) must give them."""
+    lib = pkg.load()
+    lib.c21_gsl_nth_output.restype = C.c_ulong
+    lib.c21_gsl_nth_output.argtypes = [C.c_int, C.c_ulong, C.c_int]
+    olib.oracle_gsl_rng_alloc.restype = C.c_void_p
+    olib.oracle_gsl_rng_alloc.argtypes = [C.c_int, C.c_ulong]
+    olib.oracle_gsl_rng_get.restype = C.c_uint32
+    olib.oracle_gsl_rng_get.argtypes = [C.c_void_p]
+    olib.oracle_gsl_rng_free.argtypes = [C.c_void_p]
+    for kind, seed, n, want in ((0, 4357, 1000, 1186927261), (2, 1, 10000, 719452880),
+                                (3, 1, 10000, 2064828650), (4, 1, 10000, 2733957125)):
+        assert lib.c21_gsl_nth_output(kind, seed, n) == want, kind
+        r = olib.oracle_gsl_rng_alloc(kind, seed)
+        v = [olib.oracle_gsl_rng_get(r) for _ in range(n)][-1]
+        olib.oracle_gsl_rng_free(r)
+        assert v == want, kind
+    # seed 0 means the generator's default seed (4357 for mt19937 / gfsr4, 1 for the others)
+    assert lib.c21_gsl_nth_output(2, 0, 100) == lib.c21_gsl_nth_output(2, 1, 100)
+    assert lib.c21_gsl_nth_output(0, 0, 100) == lib.c21_gsl_nth_output(0, 4357, 100)
+
+
+@pytest.mark.parametrize("n_threads,shape", [(1, (12, 12, 12)), (2, (15, 15, 15)), (2, (10, 10, 10)),
+                                             (3, (10, 10, 10)), (5, (12, 8, 8)), (7, (16, 6, 6))])
 def test_product_host_stream_equals_oracle(olib, pkg, n_threads, shape):
     """csrc/host/gsl_stream.c (block-refill word sources) vs oracle/oracle_gslrng.c: the same
     deviates for every mode, including the odd row split of 15 rows over 2 threads."""
@@ -86,6 +111,15 @@ def test_product_host_stream_equals_oracle(olib, pkg, n_threads, shape):
     assert olib.oracle_gsl_mode_deviates(777, n_threads, nx, ny, nz, b.ctypes.data) == 0
     np.testing.assert_array_equal(a, b)
     assert 0.9 < a.std() < 1.1
-    # three threads would need GSL's cmrg: refused, never approximated
-    assert lib.c21_gsl_mode_deviates(777, 3, nx, ny, nzc, a.ctypes.data) == 3
-    assert b"N_THREADS" in lib.c21cm_last_error()
+    # every thread's block is a standard-normal sample of its own generator
+    for t in range(n_threads):
+        q, rem = divmod(nx, n_threads)
+        lo = t * q + min(t, rem)
+        blk = a[lo: lo + q + (1 if t < rem else 0)]
+        assert abs(blk.mean()) < 6 / np.sqrt(blk.size) and 0.8 < blk.std() < 1.2
+    # more threads than rows of modes: the surplus threads of upstream's loop get no iterations
+    a2, b2 = np.zeros_like(a), np.zeros_like(a)
+    assert lib.c21_gsl_mode_deviates(777, nx + 3, nx, ny, nzc, a2.ctypes.data) == 0
+    assert olib.oracle_gsl_mode_deviates(777, nx + 3, nx, ny, nz, b2.ctypes.data) == 0
+    np.testing.assert_array_equal(a2, b2)
+    assert lib.c21_gsl_mode_deviates(777, 0, nx, ny, nzc, a.ctypes.data) == 3
