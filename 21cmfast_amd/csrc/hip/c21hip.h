@@ -395,22 +395,24 @@ typedef struct c21hip_ts_args { /* the scalars of c21cm_ts_spec, passed by value
     double Nb_zp, N_zp, lya_star_prefactor, volunit_inv, hubble_zp, growth_zp, dgrowth_dzp, dt_dzp;
     double sfr_scale, xray_scale;
 } c21hip_ts_args;
-/* device table buffer: 9 per-shell rows (z_edge_factor, xray_R_factor, starlya, lya_cont, lya_inj,
- * zpp_growth, tab_min, tab_width, avg_fix_term) then the three [14][n_step] frequency tables */
-#define C21HIP_TS_SHELL_ROWS 9
+/* device table buffer: 10 per-shell rows (z_edge_factor, xray_R_factor, starlya, lya_cont, lya_inj,
+ * zpp_growth, tab_min, tab_width, avg_fix_term, 1 / tab_width) then the three [14][n_step]
+ * frequency tables */
+#define C21HIP_TS_SHELL_ROWS 10
 size_t c21hip_ts_table_doubles(int n_step);
 /* SFRD_TABLE: box mean of exp(table) per shell -> avg_fix_term row of dev_tab, means to ave_out;
  * partials: 512 * n_step doubles */
 int c21hip_ts_sfrd_means(const float *filtered_density, const float *tables_dev, int table_exp,
                          double *dev_tab, const double *mean_sfr_zpp_dev, int n_step, size_t ntot,
                          double *partials, double *ave_out_dev, void *stream);
-/* the cell sweep; grid_a/grid_b = filtered_sfr/filtered_xray (lagrangian) or delNL0/NULL;
- * partials: 6 * 2048 doubles; sums_out_dev: 6 doubles (Ts, Tk, x_e, J_alpha, xheat, xion) */
+/* the two cell sweeps (R loop into sums_ws = 6 * ntot doubles, then the temperature update);
+ * grid_a/grid_b = filtered_sfr/filtered_xray (lagrangian) or delNL0/NULL; partials: 6 * 2048
+ * doubles; sums_out_dev: 6 doubles (Ts, Tk, x_e, J_alpha, xheat, xion) */
 int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, const float *prev_Ts,
                     const float *prev_Tk, const float *prev_xe, const float *grid_a,
                     const float *grid_b, const float *tables_dev, const double *dev_tab,
                     const double *lya_dEC_dev, const double *lya_dEI_dev, float *Ts_out,
-                    float *Tk_out, float *xe_out, size_t ntot, double *partials,
+                    float *Tk_out, float *xe_out, size_t ntot, double *sums_ws, double *partials,
                     double *sums_out_dev, int *flag_dev, void *stream);
 struct c21cm_ts_first_spec;
 int c21hip_ts_first(const struct c21cm_ts_first_spec *s, const float *density, float *Ts_out,

@@ -4,19 +4,21 @@
 //   :892-927    init_first_Ts                         -> ts_first_kernel
 //   :1010-1086  calculate_sfrd_from_grid (E-INTEGRAL)  -> sfrd_sum_kernel (+ the table lookup
 //                                                         repeated inside ts_cell_kernel)
-//   :1499-1522  x_e index / weight of a cell           \
-//   :1541-1784  the R loop (largest shell first)        > ts_cell_kernel, one sweep
-//   :1794-1848  prefactors + get_Ts_fast (:1210-1383)  /
+//   :1499-1522  x_e index / weight of a cell           \  ts_accumulate_kernel: one sweep over
+//   :1541-1784  the R loop (largest shell first)        /  the shells' grids, six sums per cell
+//   :1794-1848  prefactors + get_Ts_fast (:1210-1383)  -> ts_cell_kernel
 //
 // The reference walks the 40 shells in an outer loop and keeps six double boxes of partial
 // sums between them (6 x 8 B x N read + written 40 times).  Here a cell is a thread: it walks
 // its own 40 shell values (coalesced across the wavefront: grids are [R][N]), keeps the sums in
-// registers, and runs the temperature update at the end -- one read of the source grids, one
-// write of three floats.  HBM-bound: 8 B (GRIDS) or 4 B (SFRD_TABLE) per cell and shell.
-// Per-shell scalars and the 3 x 14 x n_step frequency-integral tables sit in LDS (16 KB for 40
-// shells).  SFRD_TABLE needs the box mean of the table values of every shell before the sums
-// (avg_fix_term), hence one extra sweep over the filtered densities (sfrd_sum_kernel,
-// blockIdx.y = shell).
+// registers and writes them once; a second, short sweep runs the temperature update.  Bytes:
+// 8 B (GRIDS) or 4 B (SFRD / f_coll tables) per cell and shell, read once (twice with tables).
+// The table modes are NOT HBM-bound: the loop costs ~140 fp64-heavy instruction slots per cell
+// and shell (table lookup, exp, three interpolated frequency integrals), 19 ms at 512^3 where
+// the bytes would take 5.  Per-shell scalars and the 3 x 14 x n_step frequency-integral tables
+// sit in LDS (16 KB for 40 shells).  The table modes need the box mean of the table values of
+// every shell before the sums (avg_fix_term), hence one extra sweep over the filtered densities
+// (sfrd_sum_kernel, blockIdx.y = shell).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -24,11 +26,11 @@
 #include "c21cm_grid.h"
 #include "c21cm_kappa_tables.h"
 #include "c21hip.h"
+#include "fcoll_device.h"
 
 namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxBlocks = 256 * 8;
-constexpr double kFractFloatErr = 1e-7;
 
 inline int grid_for(size_t work_items) {
     size_t b = (work_items + kBlock - 1) / kBlock;
@@ -129,12 +131,13 @@ __device__ double lya_heating_efficiency(double tk, double ts, double taugp,
     return c0 * (1. - zd) + c1 * zd;
 }
 
-// interpolation.c:123-131
-__device__ inline double table_1d(double x, double x_min, double x_width,
+// interpolation.c:123-131 with the two divisions by x_width replaced by its reciprocal (one
+// rounding apart; the sweep is fp64-ALU bound on these lookups, not HBM bound)
+__device__ inline double table_1d(double x, double x_min, double x_width, double inv_width,
                                   const float *__restrict__ y) {
-    const int idx = (int)floor((x - x_min) / x_width);
+    const int idx = (int)floor((x - x_min) * inv_width);
     const double table_val = x_min + x_width * (float)idx;
-    const double interp_point = (x - table_val) / x_width;
+    const double interp_point = (x - table_val) * inv_width;
     return y[idx] * (1 - interp_point) + y[idx + 1] * interp_point;
 }
 
@@ -155,7 +158,8 @@ __device__ inline double block_sum(double v, double *lds) {
 //            tab_width, avg_fix_term (written by sfrd_finish_kernel; 1 for GRIDS)
 //   [9n..)   freq_int_heat[14][n], freq_int_ion[14][n], freq_int_lya[14][n]
 enum { SH_ZEDGE = 0, SH_XRAY_R, SH_STARLYA, SH_CONT, SH_INJ, SH_GROWTH, SH_TABMIN, SH_TABWIDTH,
-       SH_AVGFIX, SH_COUNT };
+       SH_AVGFIX, SH_TABINVW, SH_COUNT };
+static_assert(SH_COUNT == C21HIP_TS_SHELL_ROWS, "shell rows of the device table buffer");
 
 // box sum of the SFRD table values of one shell (blockIdx.y)
 __global__ void __launch_bounds__(kBlock)
@@ -167,12 +171,28 @@ sfrd_sum_kernel(const float *__restrict__ filtered_density, const float *__restr
     const float *dens = filtered_density + (size_t)R * ntot;
     const float *tab = tables + (size_t)R * C21CM_NDELTA_TABLE;
     const double growth = shell[SH_GROWTH * n_step + R], tab_min = shell[SH_TABMIN * n_step + R],
-                 tab_width = shell[SH_TABWIDTH * n_step + R];
+                 tab_width = shell[SH_TABWIDTH * n_step + R], inv_w = shell[SH_TABINVW * n_step + R];
     double acc = 0.;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
-         i += (size_t)gridDim.x * kBlock) {
-        const double v = table_1d((double)dens[i] * growth, tab_min, tab_width, tab);
-        acc += table_exp ? exp(v) : v;  // ln SFRD table (E-INTEGRAL) | f_coll table (CONST-ION-EFF)
+    if ((ntot & 3) == 0) {  // four cells per 16-byte load
+        const float4 *d4 = reinterpret_cast<const float4 *>(dens);
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot / 4;
+             i += (size_t)gridDim.x * kBlock) {
+            const float4 t = d4[i];
+            const float c[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const double v = table_1d((double)c[e] * growth, tab_min, tab_width, inv_w, tab);
+                acc += table_exp ? exp_f32acc(v) : v;
+            }
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+             i += (size_t)gridDim.x * kBlock) {
+            const double v = table_1d((double)dens[i] * growth, tab_min, tab_width, inv_w, tab);
+            // ln SFRD table (E-INTEGRAL; the value ends up in a float grid upstream: exp to float
+            // accuracy, fcoll_device.h) | f_coll table (CONST-ION-EFF)
+            acc += table_exp ? exp_f32acc(v) : v;
+        }
     }
     acc = block_sum(acc, lds);
     if (threadIdx.x == 0) partials[(size_t)R * gridDim.x + blockIdx.x] = acc;
@@ -195,187 +215,273 @@ sfrd_finish_kernel(const double *__restrict__ partials, int nblocks,
     }
 }
 
+// One cell's epilogue: prefactors (:1794-1848) and get_Ts_fast (:1210-1383).
+struct CellSums {
+    double heat, ion, lya, starlya, cont, inj;
+};
+struct CellOut {
+    double Ts, Tk, xe, J_alpha, xheat, xion;
+};
+
+__device__ CellOut ts_cell_epilogue(const c21hip_ts_args &a, const CellSums &q, float dens,
+                                    float pTs_f, float pTk_f, float pXe_f,
+                                    const double *__restrict__ lya_dEC,
+                                    const double *__restrict__ lya_dEI) {
+    double delta = (double)dens * a.growth_ratio;
+    if (delta <= -1) delta = -1 + kFractFloatErr;
+    const double dxheat_dt = a.use_xray_heating ? q.heat * a.xray_prefactor * a.volunit_inv : 0.;
+    const double dxion_dt = q.ion * a.xray_prefactor * a.volunit_inv;
+    const double dxlya_dt = q.lya * a.xray_prefactor * a.volunit_inv * a.Nb_zp * (1 + delta);
+    const double dstarlya_dt = q.starlya * a.lya_star_prefactor * a.volunit_inv;
+    const double pTs = pTs_f, pTk = pTk_f, pXe = pXe_f;
+
+    const double zp = a.redshift, dzp = a.dzp;
+    const double tau21 = (3 * a.h_p * a.A10 * a.c_cms * a.lambda_21 * a.lambda_21 / 32. / M_PI /
+                          a.k_B) *
+                         ((1 - pXe) * a.N_zp) / pTs / a.hubble_zp;
+    double xCMB;
+    if (tau21 > 1e-8)
+        xCMB = (1. - exp(-tau21)) / tau21;
+    else
+        xCMB = 1. - tau21 / 2 * (1 - tau21 / 3 * (1 - tau21 / 4));
+    const double dxion_sink_dt =
+        alpha_A(pTk) * a.clumping_factor * pXe * pXe * a.h_frac * a.Nb_zp * (1. + delta);
+    const double dxe_dzp = a.dt_dzp * (dxion_dt - dxion_sink_dt);
+    double dadia_dzp = 3 / (1.0 + zp);
+    if (fabs(delta) > kFractFloatErr)
+        dadia_dzp += a.dgrowth_dzp / (a.growth_zp * (1.0 / delta + 1.0));
+    dadia_dzp *= (2.0 / 3.0) * pTk;
+    const double dspec_dzp = -dxe_dzp * pTk / (1 + pXe);
+    const double dcomp_dzp =
+        a.dcomp_dzp_prefactor * (pXe / (1.0 + pXe + a.he_frac)) * (a.Trad - pTk);
+    double dxheat_dzp = 0.;
+    if (a.use_xray_heating) dxheat_dzp = dxheat_dt * a.dt_dzp * 2.0 / 3.0 / a.k_B / (1.0 + pXe);
+    double dCMBheat_dzp = 0.;
+    if (a.use_cmb_heating) {
+        const double eps_CMB = (3. / 4.) * (a.Trad / a.T_21) * a.A10 * a.h_frac *
+                               (a.h_p * a.h_p / a.lambda_21 / a.lambda_21 / a.m_p) *
+                               (1. + 2. * pTk / a.T_21);
+        dCMBheat_dzp = -eps_CMB * (2. / 3. / a.k_B / (1. + pXe)) / a.hubble_zp / (1. + zp);
+    }
+    double eps_Lya_cont = 0., eps_Lya_inj = 0.;
+    if (a.use_lya_heating) {
+        const double tgp = 1.342881e-7 / a.hubble_zp * a.No * pow(1 + zp, 3) * (1.0 + delta) *
+                           (1.0 - pXe);
+        double E_continuum = lya_heating_efficiency(pTk, pTs, tgp, lya_dEC);
+        double E_injected = lya_heating_efficiency(pTk, pTs, tgp, lya_dEI);
+        if (isnan(E_continuum) || isinf(E_continuum)) E_continuum = 0.;
+        if (isnan(E_injected) || isinf(E_injected)) E_injected = 0.;
+        const double cont_dt = q.cont * a.lya_star_prefactor * a.volunit_inv;
+        const double inj_dt = q.inj * a.lya_star_prefactor * a.volunit_inv;
+        const double Ndot_alpha_cont = (4. * M_PI * a.nu_Ly_alpha) / (a.Nb_zp * (1. + delta)) /
+                                       (1. + zp) / a.c_cms * cont_dt;
+        const double Ndot_alpha_inj = (4. * M_PI * a.nu_Ly_alpha) / (a.Nb_zp * (1. + delta)) /
+                                      (1. + zp) / a.c_cms * inj_dt;
+        eps_Lya_cont = -Ndot_alpha_cont * E_continuum * (2. / 3. / a.k_B / (1. + pXe));
+        eps_Lya_inj = -Ndot_alpha_inj * E_injected * (2. / 3. / a.k_B / (1. + pXe));
+    }
+    double x_e = pXe + (dxe_dzp * dzp);
+    if (x_e > 1)
+        x_e = 1 - kFractFloatErr;
+    else if (x_e < 0)
+        x_e = 0;
+    double Tk = pTk;
+    if (Tk < (double)(float)C21CM_TS_MAX_TK)
+        Tk += (dxheat_dzp + dcomp_dzp + dspec_dzp + dadia_dzp + dCMBheat_dzp + eps_Lya_cont +
+               eps_Lya_inj) *
+              dzp;
+    if (Tk < 0) Tk = a.Trad;
+
+    const double J_alpha_tot = dstarlya_dt + dxlya_dt;
+    const double T_inv = 1 / Tk, T_inv_sq = T_inv * T_inv;
+    const double lnTk = log(Tk);
+    const double xc_fast =
+        (1.0 + delta) * a.xc_inverse *
+        ((1.0 - x_e) * a.No * kappa_10(lnTk) +
+         x_e * a.N_b0 *
+             kappa_linear_tail(kKappaEH, C21CM_KAPPA_EH_BINWIDTH, C21CM_KAPPA_EH_LNT_MAX, lnTk) +
+         x_e * a.No *
+             kappa_linear_tail(kKappaPH, C21CM_KAPPA_PH_BINWIDTH, C21CM_KAPPA_PH_LNT_MAX, lnTk));
+    const double xi_power = a.Ts_prefactor * cbrt((1.0 + delta) * (1.0 - x_e) * T_inv_sq);
+    const double xa_arg = a.xa_tilde_prefactor * J_alpha_tot /
+                          (1.0 + 2.98394 * xi_power + 1.53583 * xi_power * xi_power +
+                           3.85289 * xi_power * xi_power * xi_power);
+    const double Trad_inv = 1.0 / a.Trad;
+    double TS;
+    if (J_alpha_tot > 1.0e-20) {
+        double TSold = 0.0;
+        TS = a.Trad;
+        int guard = 0;  // the fixed point converges in a handful of steps; NaNs end the loop
+        while (fabs(TS - TSold) / TS > 1.0e-3 && guard++ < 10000) {
+            TSold = TS;
+            const double TS_inv = 1. / TS;
+            const double xa = (1.0 - 0.0631789 * T_inv + 0.115995 * T_inv_sq -
+                               0.401403 * T_inv * TS_inv + 0.336463 * T_inv_sq * TS_inv) *
+                              xa_arg;
+            TS = (xCMB + xa + xc_fast) /
+                 (xCMB * Trad_inv + xa * (T_inv + 0.405535 * T_inv * TS_inv - 0.405535 * T_inv_sq) +
+                  xc_fast * T_inv);
+        }
+    } else {
+        TS = (xCMB + xc_fast) / (xCMB * Trad_inv + xc_fast * T_inv);
+    }
+    CellOut o;
+    o.Ts = fabs(TS);
+    o.Tk = Tk;
+    o.xe = x_e;
+    o.J_alpha = dxlya_dt + dstarlya_dt;
+    o.xheat = dxheat_dt;
+    o.xion = dxion_dt;
+    return o;
+}
+
+template <int VEC>
+struct FloatVec;
+template <>
+struct FloatVec<1> {
+    float v[1];
+    __device__ static FloatVec load(const float *p, size_t item) {
+        FloatVec r;
+        r.v[0] = p[item];
+        return r;
+    }
+};
+template <>
+struct FloatVec<2> {
+    float v[2];
+    __device__ static FloatVec load(const float *p, size_t item) {
+        const float2 t = reinterpret_cast<const float2 *>(p)[item];
+        FloatVec r;
+        r.v[0] = t.x, r.v[1] = t.y;
+        return r;
+    }
+};
+// Sweep 1 of 2 -- the R loop.  VEC cells per thread; the next shell's values are requested before
+// the current shell's arithmetic (40 dependent loads per cell around fp64 code are latency-bound
+// otherwise: 53 ms at 512^3 before, 19 ms now).  The six sums of a cell go to `sums` ([6][ntot]
+// doubles): keeping the temperature update in the same kernel costs 250 VGPRs (2 waves per SIMD)
+// for no gain, the round trip moves 48 B per cell.
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
-ts_cell_kernel(c21hip_ts_args a, const float *__restrict__ density,
-               const float *__restrict__ prev_Ts, const float *__restrict__ prev_Tk,
-               const float *__restrict__ prev_xe, const float *__restrict__ grid_a,  // sfr | delNL0
-               const float *__restrict__ grid_b,                                      // xray
-               const float *__restrict__ tables, const double *__restrict__ dev_tab,
-               const double *__restrict__ lya_dEC, const double *__restrict__ lya_dEI,
-               float *__restrict__ Ts_out, float *__restrict__ Tk_out, float *__restrict__ xe_out,
-               size_t ntot, double *__restrict__ partials, int *__restrict__ flag) {
-    extern __shared__ double sh[];  // (SH_COUNT + 3 * NXHII) * n_step doubles, then kBlock
+ts_accumulate_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
+                     const float *__restrict__ grid_a,  // sfr | delNL0
+                     const float *__restrict__ grid_b,  // xray
+                     const float *__restrict__ tables, const double *__restrict__ dev_tab,
+                     double *__restrict__ sums, size_t ntot) {
+    extern __shared__ double sh[];  // (SH_COUNT + 3 * NXHII) * n_step doubles
     const int n = a.n_step;
     const int n_tab = (SH_COUNT + 3 * C21CM_X_INT_NXHII) * n;
     for (int i = threadIdx.x; i < n_tab; i += kBlock) sh[i] = dev_tab[i];
-    double *red = sh + n_tab;
     __syncthreads();
     const double *fheat = sh + SH_COUNT * n, *fion = fheat + C21CM_X_INT_NXHII * n,
                  *flya = fion + C21CM_X_INT_NXHII * n;
-
-    double s_Ts = 0, s_Tk = 0, s_xe = 0, s_Ja = 0, s_heat = 0, s_ion = 0;
-    int bad = 0;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
-         i += (size_t)gridDim.x * kBlock) {
-        const float pxe = prev_xe[i];
-        // :1499-1514, float arithmetic as upstream
-        float xHII_call = pxe;
-        if (xHII_call > kXHII[C21CM_X_INT_NXHII - 1] * 0.999)
-            xHII_call = (float)(kXHII[C21CM_X_INT_NXHII - 1] * 0.999);
-        else if (xHII_call < kXHII[0])
-            xHII_call = (float)(1.001 * kXHII[0]);
-        int m = C21CM_X_INT_NXHII - 1;
-        while (xHII_call < kXHII[m]) m--;
-        const float inv_diff = (float)(1. / (kXHII[m + 1] - kXHII[m]));
-        const double ival = (double)((xHII_call - kXHII[m]) * inv_diff);
-
-        double dxheat = 0., dxion = 0., dxlya = 0., dstarlya = 0., dcont = 0., dinj = 0.;
-        if (!a.no_light) {
-            for (int R = n; R--;) {
-                const double z_edge = sh[SH_ZEDGE * n + R], xray_R = sh[SH_XRAY_R * n + R];
+    const size_t nitems = ntot / VEC;  // ntot % VEC == 0 (launcher)
+    for (size_t it = (size_t)blockIdx.x * kBlock + threadIdx.x; it < nitems;
+         it += (size_t)gridDim.x * kBlock) {
+        const auto pxe = FloatVec<VEC>::load(prev_xe, it);
+        int m[VEC];
+        double ival[VEC];
+        CellSums q[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            // :1499-1514, float arithmetic as upstream
+            float xHII_call = pxe.v[e];
+            if (xHII_call > kXHII[C21CM_X_INT_NXHII - 1] * 0.999)
+                xHII_call = (float)(kXHII[C21CM_X_INT_NXHII - 1] * 0.999);
+            else if (xHII_call < kXHII[0])
+                xHII_call = (float)(1.001 * kXHII[0]);
+            int mm = C21CM_X_INT_NXHII - 1;
+            while (xHII_call < kXHII[mm]) mm--;
+            const float inv_diff = (float)(1. / (kXHII[mm + 1] - kXHII[mm]));
+            m[e] = mm;
+            ival[e] = (double)((xHII_call - kXHII[mm]) * inv_diff);
+            q[e] = CellSums{0., 0., 0., 0., 0., 0.};
+        }
+        FloatVec<VEC> ga = FloatVec<VEC>::load(grid_a, (size_t)(n - 1) * nitems + it), gb = ga;
+        if (a.lagrangian) gb = FloatVec<VEC>::load(grid_b, (size_t)(n - 1) * nitems + it);
+        for (int R = n; R--;) {
+            const FloatVec<VEC> ca = ga, cb = gb;
+            if (R > 0) {  // request the next (smaller) shell now
+                ga = FloatVec<VEC>::load(grid_a, (size_t)(R - 1) * nitems + it);
+                if (a.lagrangian) gb = FloatVec<VEC>::load(grid_b, (size_t)(R - 1) * nitems + it);
+            }
+            const double z_edge = sh[SH_ZEDGE * n + R], xray_R = sh[SH_XRAY_R * n + R];
+            const double starlya = sh[SH_STARLYA * n + R];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
                 double sfr_term, xray_sfr;
                 if (a.lagrangian) {
-                    sfr_term = (double)grid_a[(size_t)R * ntot + i] * z_edge;
-                    xray_sfr = (double)grid_b[(size_t)R * ntot + i] * z_edge * xray_R * 1e38;
+                    sfr_term = (double)ca.v[e] * z_edge;
+                    xray_sfr = (double)cb.v[e] * z_edge * xray_R * 1e38;
                 } else {
-                    const double curr_dens = (double)grid_a[(size_t)R * ntot + i] * sh[SH_GROWTH * n + R];
+                    const double curr_dens = (double)ca.v[e] * sh[SH_GROWTH * n + R];
                     double fcoll = table_1d(curr_dens, sh[SH_TABMIN * n + R], sh[SH_TABWIDTH * n + R],
+                                            sh[SH_TABINVW * n + R],
                                             tables + (size_t)R * C21CM_NDELTA_TABLE);
-                    if (a.table_exp) fcoll = exp(fcoll);  // else: the dfcoll/dz table itself
+                    if (a.table_exp) fcoll = exp_f32acc(fcoll);  // else: the dfcoll/dz table itself
                     const float sfrd = (float)((1. + curr_dens) * fcoll);  // del_fcoll_Rct is float
                     sfr_term = (double)sfrd * z_edge * sh[SH_AVGFIX * n + R] * a.sfr_scale;
                     xray_sfr = sfr_term * a.xray_scale * xray_R;
                 }
-                const int lo = m * n + R, hi = lo + n;
-                if (a.use_xray_heating) dxheat += xray_sfr * ((fheat[hi] - fheat[lo]) * ival + fheat[lo]);
-                dxion += xray_sfr * ((fion[hi] - fion[lo]) * ival + fion[lo]);
-                dxlya += xray_sfr * ((flya[hi] - flya[lo]) * ival + flya[lo]);
-                dstarlya += sfr_term * sh[SH_STARLYA * n + R];
+                const int lo = m[e] * n + R, hi = lo + n;
+                if (a.use_xray_heating)
+                    q[e].heat += xray_sfr * ((fheat[hi] - fheat[lo]) * ival[e] + fheat[lo]);
+                q[e].ion += xray_sfr * ((fion[hi] - fion[lo]) * ival[e] + fion[lo]);
+                q[e].lya += xray_sfr * ((flya[hi] - flya[lo]) * ival[e] + flya[lo]);
+                q[e].starlya += sfr_term * starlya;
                 if (a.use_lya_heating) {
-                    dcont += sfr_term * sh[SH_CONT * n + R];
-                    dinj += sfr_term * sh[SH_INJ * n + R];
+                    q[e].cont += sfr_term * sh[SH_CONT * n + R];
+                    q[e].inj += sfr_term * sh[SH_INJ * n + R];
                 }
             }
         }
-
-        // :1794-1848
-        double delta = (double)density[i] * a.growth_ratio;
-        if (delta <= -1) delta = -1 + kFractFloatErr;
-        const double dxheat_dt = a.use_xray_heating ? dxheat * a.xray_prefactor * a.volunit_inv : 0.;
-        const double dxion_dt = dxion * a.xray_prefactor * a.volunit_inv;
-        const double dxlya_dt = dxlya * a.xray_prefactor * a.volunit_inv * a.Nb_zp * (1 + delta);
-        const double dstarlya_dt = dstarlya * a.lya_star_prefactor * a.volunit_inv;
-        const double pTs = prev_Ts[i], pTk = prev_Tk[i], pXe = pxe;
-
-        // get_Ts_fast :1210-1383
-        const double zp = a.redshift, dzp = a.dzp;
-        const double tau21 = (3 * a.h_p * a.A10 * a.c_cms * a.lambda_21 * a.lambda_21 / 32. / M_PI /
-                              a.k_B) *
-                             ((1 - pXe) * a.N_zp) / pTs / a.hubble_zp;
-        double xCMB;
-        if (tau21 > 1e-8)
-            xCMB = (1. - exp(-tau21)) / tau21;
-        else
-            xCMB = 1. - tau21 / 2 * (1 - tau21 / 3 * (1 - tau21 / 4));
-        const double dxion_sink_dt =
-            alpha_A(pTk) * a.clumping_factor * pXe * pXe * a.h_frac * a.Nb_zp * (1. + delta);
-        const double dxe_dzp = a.dt_dzp * (dxion_dt - dxion_sink_dt);
-        double dadia_dzp = 3 / (1.0 + zp);
-        if (fabs(delta) > kFractFloatErr)
-            dadia_dzp += a.dgrowth_dzp / (a.growth_zp * (1.0 / delta + 1.0));
-        dadia_dzp *= (2.0 / 3.0) * pTk;
-        const double dspec_dzp = -dxe_dzp * pTk / (1 + pXe);
-        const double dcomp_dzp =
-            a.dcomp_dzp_prefactor * (pXe / (1.0 + pXe + a.he_frac)) * (a.Trad - pTk);
-        double dxheat_dzp = 0.;
-        if (a.use_xray_heating) dxheat_dzp = dxheat_dt * a.dt_dzp * 2.0 / 3.0 / a.k_B / (1.0 + pXe);
-        double dCMBheat_dzp = 0.;
-        if (a.use_cmb_heating) {
-            const double eps_CMB = (3. / 4.) * (a.Trad / a.T_21) * a.A10 * a.h_frac *
-                                   (a.h_p * a.h_p / a.lambda_21 / a.lambda_21 / a.m_p) *
-                                   (1. + 2. * pTk / a.T_21);
-            dCMBheat_dzp = -eps_CMB * (2. / 3. / a.k_B / (1. + pXe)) / a.hubble_zp / (1. + zp);
-        }
-        double eps_Lya_cont = 0., eps_Lya_inj = 0.;
-        if (a.use_lya_heating) {
-            const double tgp = 1.342881e-7 / a.hubble_zp * a.No * pow(1 + zp, 3) * (1.0 + delta) *
-                               (1.0 - pXe);
-            double E_continuum = lya_heating_efficiency(pTk, pTs, tgp, lya_dEC);
-            double E_injected = lya_heating_efficiency(pTk, pTs, tgp, lya_dEI);
-            if (isnan(E_continuum) || isinf(E_continuum)) E_continuum = 0.;
-            if (isnan(E_injected) || isinf(E_injected)) E_injected = 0.;
-            const double cont_dt = dcont * a.lya_star_prefactor * a.volunit_inv;
-            const double inj_dt = dinj * a.lya_star_prefactor * a.volunit_inv;
-            const double Ndot_alpha_cont = (4. * M_PI * a.nu_Ly_alpha) / (a.Nb_zp * (1. + delta)) /
-                                           (1. + zp) / a.c_cms * cont_dt;
-            const double Ndot_alpha_inj = (4. * M_PI * a.nu_Ly_alpha) / (a.Nb_zp * (1. + delta)) /
-                                          (1. + zp) / a.c_cms * inj_dt;
-            eps_Lya_cont = -Ndot_alpha_cont * E_continuum * (2. / 3. / a.k_B / (1. + pXe));
-            eps_Lya_inj = -Ndot_alpha_inj * E_injected * (2. / 3. / a.k_B / (1. + pXe));
-        }
-        double x_e = pXe + (dxe_dzp * dzp);
-        if (x_e > 1)
-            x_e = 1 - kFractFloatErr;
-        else if (x_e < 0)
-            x_e = 0;
-        double Tk = pTk;
-        if (Tk < (double)(float)C21CM_TS_MAX_TK)
-            Tk += (dxheat_dzp + dcomp_dzp + dspec_dzp + dadia_dzp + dCMBheat_dzp + eps_Lya_cont +
-                   eps_Lya_inj) *
-                  dzp;
-        if (Tk < 0) Tk = a.Trad;
-
-        const double J_alpha_tot = dstarlya_dt + dxlya_dt;
-        const double T_inv = 1 / Tk, T_inv_sq = T_inv * T_inv;
-        const double lnTk = log(Tk);
-        const double xc_fast =
-            (1.0 + delta) * a.xc_inverse *
-            ((1.0 - x_e) * a.No * kappa_10(lnTk) +
-             x_e * a.N_b0 *
-                 kappa_linear_tail(kKappaEH, C21CM_KAPPA_EH_BINWIDTH, C21CM_KAPPA_EH_LNT_MAX, lnTk) +
-             x_e * a.No *
-                 kappa_linear_tail(kKappaPH, C21CM_KAPPA_PH_BINWIDTH, C21CM_KAPPA_PH_LNT_MAX, lnTk));
-        const double xi_power = a.Ts_prefactor * cbrt((1.0 + delta) * (1.0 - x_e) * T_inv_sq);
-        const double xa_arg = a.xa_tilde_prefactor * J_alpha_tot /
-                              (1.0 + 2.98394 * xi_power + 1.53583 * xi_power * xi_power +
-                               3.85289 * xi_power * xi_power * xi_power);
-        const double Trad_inv = 1.0 / a.Trad;
-        double TS;
-        if (J_alpha_tot > 1.0e-20) {
-            double TSold = 0.0;
-            TS = a.Trad;
-            int guard = 0;  // the fixed point converges in a handful of steps; NaNs end the loop
-            while (fabs(TS - TSold) / TS > 1.0e-3 && guard++ < 10000) {
-                TSold = TS;
-                const double TS_inv = 1. / TS;
-                const double xa = (1.0 - 0.0631789 * T_inv + 0.115995 * T_inv_sq -
-                                   0.401403 * T_inv * TS_inv + 0.336463 * T_inv_sq * TS_inv) *
-                                  xa_arg;
-                TS = (xCMB + xa + xc_fast) /
-                     (xCMB * Trad_inv +
-                      xa * (T_inv + 0.405535 * T_inv * TS_inv - 0.405535 * T_inv_sq) +
-                      xc_fast * T_inv);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const size_t i = it * VEC + e;
+            sums[i] = q[e].heat;
+            sums[ntot + i] = q[e].ion;
+            sums[2 * ntot + i] = q[e].lya;
+            sums[3 * ntot + i] = q[e].starlya;
+            if (a.use_lya_heating) {
+                sums[4 * ntot + i] = q[e].cont;
+                sums[5 * ntot + i] = q[e].inj;
             }
-        } else {
-            TS = (xCMB + xc_fast) / (xCMB * Trad_inv + xc_fast * T_inv);
         }
-        TS = fabs(TS);
-        const float Ts_f = (float)TS;
+    }
+}
+
+// Sweep 2 of 2 -- prefactors and get_Ts_fast per cell; `sums` NULL: nothing has formed yet.
+__global__ void __launch_bounds__(kBlock)
+ts_cell_kernel(c21hip_ts_args a, const float *__restrict__ density,
+               const float *__restrict__ prev_Ts, const float *__restrict__ prev_Tk,
+               const float *__restrict__ prev_xe, const double *__restrict__ sums,
+               const double *__restrict__ lya_dEC, const double *__restrict__ lya_dEI,
+               float *__restrict__ Ts_out, float *__restrict__ Tk_out, float *__restrict__ xe_out,
+               size_t ntot, double *__restrict__ partials, int *__restrict__ flag) {
+    __shared__ double red[kBlock];
+    double s_Ts = 0, s_Tk = 0, s_xe = 0, s_Ja = 0, s_heat = 0, s_ion = 0;
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        CellSums q{0., 0., 0., 0., 0., 0.};
+        if (sums) {
+            q.heat = sums[i], q.ion = sums[ntot + i], q.lya = sums[2 * ntot + i];
+            q.starlya = sums[3 * ntot + i];
+            if (a.use_lya_heating) q.cont = sums[4 * ntot + i], q.inj = sums[5 * ntot + i];
+        }
+        const CellOut o = ts_cell_epilogue(a, q, density[i], prev_Ts[i], prev_Tk[i], prev_xe[i],
+                                           lya_dEC, lya_dEI);
+        const float Ts_f = (float)o.Ts;
         Ts_out[i] = Ts_f;
-        Tk_out[i] = (float)Tk;
-        xe_out[i] = (float)x_e;
+        Tk_out[i] = (float)o.Tk;
+        xe_out[i] = (float)o.xe;
         if (!isfinite(Ts_f)) bad = 1;
-        s_Ts += TS;
-        s_Tk += Tk;
-        s_xe += x_e;
-        s_Ja += dxlya_dt + dstarlya_dt;
-        s_heat += dxheat_dt;
-        s_ion += dxion_dt;
+        s_Ts += o.Ts, s_Tk += o.Tk, s_xe += o.xe, s_Ja += o.J_alpha, s_heat += o.xheat, s_ion += o.xion;
     }
     if (bad) atomicOr(flag, 1);
-    double sums[6] = {s_Ts, s_Tk, s_xe, s_Ja, s_heat, s_ion};
+    double sums6[6] = {s_Ts, s_Tk, s_xe, s_Ja, s_heat, s_ion};
     for (int k = 0; k < 6; k++) {
-        const double r = block_sum(sums[k], red);
+        const double r = block_sum(sums6[k], red);
         if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = r;
     }
 }
@@ -433,17 +539,35 @@ extern "C" int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, co
                                const float *prev_Tk, const float *prev_xe, const float *grid_a,
                                const float *grid_b, const float *tables_dev, const double *dev_tab,
                                const double *lya_dEC_dev, const double *lya_dEI_dev, float *Ts_out,
-                               float *Tk_out, float *xe_out, size_t ntot, double *partials,
-                               double *sums_out_dev, int *flag_dev, void *stream) {
-    const int blocks = grid_for(ntot);
-    const size_t lds = (c21hip_ts_table_doubles(a->n_step) + kBlock) * sizeof(double);
+                               float *Tk_out, float *xe_out, size_t ntot, double *sums_ws,
+                               double *partials, double *sums_out_dev, int *flag_dev, void *stream) {
+    const size_t lds = c21hip_ts_table_doubles(a->n_step) * sizeof(double);
     if (lds > 64 * 1024) {
         c21hip_set_error("spin temperature: %d shells do not fit the table cache", a->n_step);
         return C21CM_VALUE_ERROR;
     }
-    hipLaunchKernelGGL(ts_cell_kernel, dim3(blocks), dim3(kBlock), lds, (hipStream_t)stream, *a,
-                       density, prev_Ts, prev_Tk, prev_xe, grid_a, grid_b, tables_dev, dev_tab,
-                       lya_dEC_dev, lya_dEI_dev, Ts_out, Tk_out, xe_out, ntot, partials, flag_dev);
+    if (!a->no_light) {
+        // two cells per thread (8-byte loads) when the arrays allow it.  Measured at 512^3, 40
+        // shells, SFRD tables: 19.1 ms with one or two cells per thread (78 / 102 VGPRs), 25.6 ms
+        // with four (170 VGPRs): the loop is bound by its ~140 instruction slots per cell and shell
+        // (table lookup, exp, three interpolated frequency integrals in fp64), not by HBM.
+        auto aligned8 = [](const void *p) { return ((size_t)p & 7) == 0; };
+        const bool vec2 = (ntot & 1) == 0 && aligned8(prev_xe) && aligned8(grid_a) && aligned8(grid_b);
+        const int blocks = grid_for(vec2 ? ntot / 2 : ntot);
+        if (vec2)
+            hipLaunchKernelGGL((ts_accumulate_kernel<2>), dim3(blocks), dim3(kBlock), lds,
+                               (hipStream_t)stream, *a, prev_xe, grid_a, grid_b, tables_dev, dev_tab,
+                               sums_ws, ntot);
+        else
+            hipLaunchKernelGGL((ts_accumulate_kernel<1>), dim3(blocks), dim3(kBlock), lds,
+                               (hipStream_t)stream, *a, prev_xe, grid_a, grid_b, tables_dev, dev_tab,
+                               sums_ws, ntot);
+        LAUNCH_CHECK();
+    }
+    const int blocks = grid_for(ntot);
+    hipLaunchKernelGGL(ts_cell_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, *a, density,
+                       prev_Ts, prev_Tk, prev_xe, a->no_light ? nullptr : sums_ws, lya_dEC_dev,
+                       lya_dEI_dev, Ts_out, Tk_out, xe_out, ntot, partials, flag_dev);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(ts_finish_kernel, dim3(6), dim3(kBlock), 0, (hipStream_t)stream, partials,
                        blocks, sums_out_dev);

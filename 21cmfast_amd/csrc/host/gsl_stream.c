@@ -36,8 +36,9 @@
  * thread that owns its n_x under the default static OpenMP schedule (contiguous blocks, the
  * first DIM % N_THREADS threads one row longer).
  *
- * The stream is serial by definition (the number of words a deviate consumes depends on the
- * words themselves), so it is drawn on the host, one pass per generator; the device then applies
+ * Each thread's stream is serial by definition (the number of words a deviate consumes depends
+ * on the words themselves), so they are drawn on the host, one OpenMP thread per stream; the
+ * device then applies
  * sqrt(V P(k) / 2) and the Hermitian constraints (ics_kernels.hip: sample_modes_kernel).
  * Parity: bit-identical deviates to the CPU oracle's independent restatement
  * (tests/test_gpu_ics.py), which the reference's own HDF5 fixtures pin
@@ -306,17 +307,25 @@ int c21_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int ny
         return st;
     }
     const int q = nx / n_threads, rem = nx % n_threads;
+    /* the threads' streams are independent of each other: draw them concurrently, as upstream's
+     * OpenMP loop does (each stream stays serial) */
+    int failed = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 64 ? 64 : n_threads) reduction(| : failed)
     for (int t = 0; t < n_threads; t++) {
         const int lo = t * q + (t < rem ? t : rem), rows = q + (t < rem ? 1 : 0);
         word_source w;
-        if ((st = source_open(&w, t % 5, seeds[t]))) { /* rng.c:58-85: the five kinds in turn */
-            free(seeds);
-            return st;
+        if (source_open(&w, t % 5, seeds[t])) { /* rng.c:58-85: the five kinds in turn */
+            failed |= 1;
+            continue;
         }
         double *p = ab + 2 * (size_t)lo * ny * nzc;
         const size_t count = 2 * (size_t)rows * ny * nzc;
         for (size_t m = 0; m < count; m++) p[m] = next_ugaussian(&w);
         source_close(&w);
+    }
+    if (failed) {
+        free(seeds);
+        return C21CM_MEMORY_ALLOC_ERROR;
     }
     free(seeds);
     return 0;

@@ -22,7 +22,7 @@
 enum {
     WS_TS_DENS = 150, WS_TS_PTS, WS_TS_PTK, WS_TS_PXE, WS_TS_GRID_A, WS_TS_GRID_B, WS_TS_TAB,
     WS_TS_SFRDTAB, WS_TS_LYA_C, WS_TS_LYA_I, WS_TS_OTS, WS_TS_OTK, WS_TS_OXE, WS_TS_PART,
-    WS_TS_SMALL, WS_TS_MEANSFR, WS_TS_SFRDTAB2
+    WS_TS_SMALL, WS_TS_MEANSFR, WS_TS_SFRDTAB2, WS_TS_SUMS
 };
 
 #define TRY(expr)         \
@@ -134,9 +134,11 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     {
         const double *rows[C21HIP_TS_SHELL_ROWS] = {
             s->z_edge_factor, s->xray_R_factor, s->starlya_prefactor, s->lya_cont_prefactor,
-            s->lya_inj_prefactor, s->zpp_growth, s->tab_min, s->tab_width, NULL};
+            s->lya_inj_prefactor, s->zpp_growth, s->tab_min, s->tab_width, NULL, NULL};
         for (int r = 0; r < C21HIP_TS_SHELL_ROWS; r++)
             for (int i = 0; i < n; i++) host_tab[r * n + i] = rows[r] ? rows[r][i] : 1.;
+        for (int i = 0; i < n; i++) /* row 9: reciprocal table spacing (0 for unused shells) */
+            host_tab[9 * n + i] = s->tab_width[i] != 0 ? 1. / s->tab_width[i] : 0.;
         double *f = host_tab + (size_t)C21HIP_TS_SHELL_ROWS * n;
         const size_t fn = (size_t)C21CM_X_INT_NXHII * n;
         memcpy(f, s->freq_int_heat, fn * sizeof(double));
@@ -220,8 +222,18 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
         TRY(c21hip_ts_sfrd_means(grid_a, mean_tables_dev, !fcoll_mode, dev_tab, mean_dev, n, ntot,
                                  partials, ave_dev, stream));
     }
+    double *sums_ws = NULL; /* the six sums of every cell between the two sweeps */
+    if (!s->no_light) {
+        sums_ws = (double *)c21hip_ws(WS_TS_SUMS, 6 * ntot * sizeof(double));
+        if (!sums_ws) {
+            c21hip_set_error("spin temperature: out of device memory for the shell sums (%zu bytes)",
+                             6 * ntot * sizeof(double));
+            status = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+    }
     TRY(c21hip_ts_cells(&a, d_dens, d_pts, d_ptk, d_pxe, grid_a, grid_b, tables_dev, dev_tab, lya_c,
-                        lya_i, o_ts, o_tk, o_xe, ntot, partials + (size_t)512 * n, sums_dev,
+                        lya_i, o_ts, o_tk, o_xe, ntot, sums_ws, partials + (size_t)512 * n, sums_dev,
                         flag_dev, stream));
 
     if (o_ts != out->spin_temperature) TRY(c21hip_d2h(out->spin_temperature, o_ts, bytes, stream));
