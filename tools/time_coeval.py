@@ -14,6 +14,7 @@ import time
 
 import torch
 
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tests"))
 from test_gpu_abi import Session  # noqa: E402
 
