@@ -19,6 +19,8 @@ extern "C" {
 
 /* ---- runtime.hip : memory, residency, workspace, timing ---- */
 int c21hip_device_count(void);
+int c21hip_current_device(void);     /* -1 when there is none */
+int c21hip_use_device(int device);   /* per-thread: for helper threads of the host drivers */
 int c21hip_is_device_ptr(const void *p);     /* 1 = MI355X HBM, 0 = host          */
 void *c21hip_ws(int slot, size_t bytes);     /* cached device scratch, NULL = OOM */
 void c21hip_ws_release(void);

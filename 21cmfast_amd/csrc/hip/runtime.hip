@@ -47,6 +47,26 @@ extern "C" const char *c21hip_get_error(void) { return g_error; }
         }                                                                                 \
     } while (0)
 
+// The current device is a per-thread setting: a helper thread must adopt its creator's.
+extern "C" int c21hip_current_device(void) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return d;
+}
+
+extern "C" int c21hip_use_device(int device) {
+    if (device < 0) return 0;
+    if (hipSetDevice(device) != hipSuccess) {
+        c21hip_set_error("hipSetDevice(%d) failed", device);
+        (void)hipGetLastError();
+        return C21CM_IO_ERROR;
+    }
+    return 0;
+}
+
 extern "C" int c21hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

@@ -27,6 +27,7 @@
  * IONISE_ENTIRE_SPHERE, V_CB_MODEL = FLUCTS, CLASS transfer tables.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -500,6 +501,23 @@ int UpdateXraySourceBox(HaloBox *halobox, double R_inner, double R_outer, int R_
     return 0;
 }
 
+/* the density filter loop of ComputeTsBox as a job for a helper thread */
+struct filter_job {
+    c21cm_rbox_spec spec;
+    const float *input;
+    float *result;
+    double mn[C21CM_MAX_TS_RADII], av[C21CM_MAX_TS_RADII], mx[C21CM_MAX_TS_RADII];
+    int device, status;
+};
+
+static void *filter_job_run(void *arg) {
+    struct filter_job *j = (struct filter_job *)arg;
+    j->status = c21hip_use_device(j->device); /* the current device is per thread */
+    if (!j->status)
+        j->status = c21cm_fill_Rbox_grids(&j->spec, j->input, j->result, j->mn, j->av, j->mx, NULL);
+    return NULL;
+}
+
 static double wall_seconds(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -583,45 +601,61 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
     }
     const float *filtered = NULL;
     const int timing = getenv("C21CM_TS_TIMING") != NULL; /* stage wall times to stderr */
-    double t_mark = timing ? wall_seconds() : 0., t_prep = 0., t_filter = 0., t_tables = 0.;
-    if ((st = c21_ts_prepare(redshift, prev_redshift, perturbed_field_redshift, x_e_ave_p, spec, tab)))
+    double t_mark = timing ? wall_seconds() : 0., t_prep = 0., t_tables = 0.;
+    if ((st = c21_ts_prepare_shells(redshift, prev_redshift, perturbed_field_redshift, spec, tab)))
         goto done;
-    if (timing) t_prep = wall_seconds() - t_mark, t_mark = wall_seconds();
-    if (spec->source_mode != C21CM_TS_SRC_GRIDS && !spec->no_light) {
-        /* prepare_filter_boxes + fill_Rbox_table (:1453-1463): delNL0[R] stays on the device */
-        c21cm_rbox_spec r;
-        memset(&r, 0, sizeof(r));
-        r.hii_dim = hii, r.hii_dim_z = hii_z, r.box_len = box_len, r.box_len_z = box_len_z;
-        r.filter_type = ao->HEAT_FILTER;
-        r.n_R = tab->n_step;
-        for (int i = 0; i < tab->n_step; i++) r.R[i] = tab->R_values[i];
-        r.cell_radius = 0.620350491 * so->BOX_LEN / (float)so->HII_DIM; /* physconst.l_factor */
-        r.min_value = -1;
-        r.const_factor = 1. / dicke(perturbed_field_redshift);
-        float *delNL0 = (float *)c21hip_ws(170, (size_t)tab->n_step * ntot * sizeof(float));
-        if (!delNL0) {
+    if (spec->source_mode != C21CM_TS_SRC_GRIDS) {
+        /* prepare_filter_boxes + fill_Rbox_table (:1453-1463): delNL0[R] stays on the device.  The
+         * loop needs only the shells' radii, so it runs on a helper thread while this one builds
+         * the global tables and the frequency integrals (host work of about the same length at
+         * 256^3).  Before anything has formed (NO_LIGHT) its result is simply not used. */
+        struct filter_job job;
+        memset(&job, 0, sizeof(job));
+        c21cm_rbox_spec *r = &job.spec;
+        r->hii_dim = hii, r->hii_dim_z = hii_z, r->box_len = box_len, r->box_len_z = box_len_z;
+        r->filter_type = ao->HEAT_FILTER;
+        r->n_R = tab->n_step;
+        for (int i = 0; i < tab->n_step; i++) r->R[i] = tab->R_values[i];
+        r->cell_radius = 0.620350491 * so->BOX_LEN / (float)so->HII_DIM; /* physconst.l_factor */
+        r->min_value = -1;
+        r->const_factor = 1. / dicke(perturbed_field_redshift);
+        job.input = perturbed_field->density;
+        job.result = (float *)c21hip_ws(170, (size_t)tab->n_step * ntot * sizeof(float));
+        if (!job.result) {
             c21hip_set_error("ComputeTsBox: out of device memory for %d filtered density grids", tab->n_step);
             st = C21CM_MEMORY_ALLOC_ERROR;
             goto done;
         }
-        double mn[C21CM_MAX_TS_RADII], av[C21CM_MAX_TS_RADII], mx[C21CM_MAX_TS_RADII];
-        if ((st = c21cm_fill_Rbox_grids(&r, perturbed_field->density, delNL0, mn, av, mx, NULL))) goto done;
-        if (timing) t_filter = wall_seconds() - t_mark, t_mark = wall_seconds();
-        if (spec->source_mode == C21CM_TS_SRC_SFRD_TABLE)
-            st = c21_ts_sfrd_tables(mn, mx, spec, tab);
-        else
-            st = c21_ts_fcoll_tables(mn, mx, spec, tab);
+        job.device = c21hip_current_device();
+        pthread_t worker;
+        const int threaded = pthread_create(&worker, NULL, filter_job_run, &job) == 0;
+        if (!threaded) (void)filter_job_run(&job); /* no thread: one after the other */
+        st = c21_ts_prepare_tables(x_e_ave_p, spec, tab);
+        if (timing) t_prep = wall_seconds() - t_mark;
+        if (threaded) pthread_join(worker, NULL);
         if (st) goto done;
+        if ((st = job.status)) goto done;
+        if (timing) t_mark = wall_seconds();
+        if (!spec->no_light) {
+            if (spec->source_mode == C21CM_TS_SRC_SFRD_TABLE)
+                st = c21_ts_sfrd_tables(job.mn, job.mx, spec, tab);
+            else
+                st = c21_ts_fcoll_tables(job.mn, job.mx, spec, tab);
+            if (st) goto done;
+            filtered = job.result;
+        }
         if (timing) t_tables = wall_seconds() - t_mark, t_mark = wall_seconds();
-        filtered = delNL0;
+    } else {
+        if ((st = c21_ts_prepare_tables(x_e_ave_p, spec, tab))) goto done;
+        if (timing) t_prep = wall_seconds() - t_mark, t_mark = wall_seconds();
     }
     st = c21cm_ts_grids(spec, perturbed_field->density, previous_spin_temp, source_box, filtered,
                         this_spin_temp, NULL, NULL);
     if (!st) this_spin_temp->Q_HI = tab->Q_HI;
     if (timing)
-        fprintf(stderr, "ComputeTsBox z=%.3f: host tables %.1f ms, density filter loop %.1f ms, SFRD tables "
-                        "%.1f ms, cell sweep (incl. staging) %.1f ms\n",
-                redshift, 1e3 * t_prep, 1e3 * t_filter, 1e3 * t_tables, 1e3 * (wall_seconds() - t_mark));
+        fprintf(stderr, "ComputeTsBox z=%.3f: host tables beside the density filter loop %.1f ms, SFRD "
+                        "tables %.1f ms, cell sweeps (incl. staging) %.1f ms\n",
+                redshift, 1e3 * t_prep, 1e3 * t_tables, 1e3 * (wall_seconds() - t_mark));
 done:
     c21_ts_tables_free(tab);
     free(tab);

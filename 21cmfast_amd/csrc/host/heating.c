@@ -874,6 +874,14 @@ static void set_zp_consts(double zp, int lagrangian, c21cm_ts_spec *s) {
  * x_e box. */
 int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_redshift,
                    double x_e_ave, c21cm_ts_spec *s, c21_ts_tables *t) {
+    const int status = c21_ts_prepare_shells(redshift, prev_redshift, perturbed_field_redshift, s, t);
+    return status ? status : c21_ts_prepare_tables(x_e_ave, s, t);
+}
+
+/* Part 1, cheap: options, data tables, shells, spectral factors, z' constants.  The density filter
+ * loop only needs the shells' radii, so ComputeTsBox runs part 2 beside it. */
+int c21_ts_prepare_shells(float redshift, float prev_redshift, float perturbed_field_redshift,
+                          c21cm_ts_spec *s, c21_ts_tables *t) {
     int status;
     const AstroParams *ap = astro_params_global;
     const AstroOptions *ao = astro_options_global;
@@ -935,8 +943,19 @@ int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_re
         s->lya_dEC = H.dEC;
         s->lya_dEI = H.dEI;
     }
+    return 0;
+}
 
-    /* ---- global_reion_properties (:930-1008) */
+/* Part 2: the global N_ion / SFRD tables, Q_HI, NO_LIGHT, the mean SFRD per shell, the tau_X = 1
+ * frequencies and the frequency-integral tables (global_reion_properties :930-1008 with
+ * fill_freqint_tables :810-889).  x_e_ave: box mean of the previous x_e box. */
+int c21_ts_prepare_tables(double x_e_ave, c21cm_ts_spec *s, c21_ts_tables *t) {
+    int status;
+    const AstroParams *ap = astro_params_global;
+    const int const_zeta = matter_options_global->SOURCE_MODEL == C21CM_SOURCE_CONST_ION_EFF;
+    const int n = t->n_step;
+    const double zp = s->redshift;
+
     c21_scaling_consts sc;
     if ((status = c21_set_scaling_constants(zp, &sc))) return status;
     {

@@ -65,6 +65,11 @@ typedef struct c21_ts_tables {
 void c21_ts_tables_free(c21_ts_tables *t);
 int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_redshift,
                    double x_e_ave, c21cm_ts_spec *spec, c21_ts_tables *tables);
+/* the two halves of it: shells / spectral factors / z' constants, then the global tables and the
+ * frequency integrals (which ComputeTsBox overlaps with the density filter loop on the device) */
+int c21_ts_prepare_shells(float redshift, float prev_redshift, float perturbed_field_redshift,
+                          c21cm_ts_spec *spec, c21_ts_tables *tables);
+int c21_ts_prepare_tables(double x_e_ave, c21cm_ts_spec *spec, c21_ts_tables *tables);
 int c21_ts_sfrd_tables(const double *min_densities, const double *max_densities,
                        c21cm_ts_spec *spec, c21_ts_tables *tables);
 int c21_ts_fcoll_tables(const double *min_densities, const double *max_densities,
