@@ -1,7 +1,10 @@
-"""Host-side mirror of the part of py21cmfast's driver layer that sits between the C entry points
-of the spin-temperature path for the Lagrangian source models
+"""Host-side mirror of py21cmfast's driver layer for the boxes this backend computes: the evolution
+loop of ``run_coeval`` (reference: src/py21cmfast/drivers/coeval.py:560-890) as ``run_coeval`` /
+``Inputs`` below, and the bookkeeping that sits between the C entry points of the
+spin-temperature path for the Lagrangian source models
 (reference: src/py21cmfast/drivers/single_field.py:382-470 ``interp_halo_boxes`` and :473-636
-``compute_xray_source_field``; the redshift loop that calls them is drivers/coeval.py:749-890).
+``compute_xray_source_field``).  A py21cmfast installation keeps using its own drivers on top of
+the library; this module is for callers without it (tests, tools, stand-alone runs).
 
 The reference does this bookkeeping in Python with astropy: the shells of the X-ray / Lyman-alpha
 light cone are placed in comoving distance, every shell takes the halo grids (``halo_sfr``,
@@ -184,3 +187,203 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
               "UpdateXraySourceBox")
     box["zpp_avg"], box["R_range"], box["R_star"] = zpp_avg, R_range, R_star
     return box
+
+
+# =============================================================================================
+# The evolution loop (reference: src/py21cmfast/drivers/coeval.py:749-890 `_redshift_loop_generator`
+# with `run_coeval`'s set-up :560-745, and drivers/_global_initialization.py for the C state).
+# =============================================================================================
+TS_FIELDS = ("spin_temperature", "kinetic_temp_neutral", "xray_ionised_fraction")
+ION_FIELDS = ("neutral_fraction", "z_reion", "kinetic_temperature", "unnormalised_nion",
+              "ionisation_rate_G12", "mean_free_path", "cumulative_recombinations")
+
+
+def get_logspaced_redshifts(min_redshift, z_step_factor, max_redshift):
+    """The node redshifts of an evolution, descending (wrapper/inputs.py:1774-1789)."""
+    z = 10 ** np.arange(np.log10(1 + min_redshift), np.log10((1 + max_redshift) * z_step_factor),
+                        np.log10(z_step_factor)) - 1
+    return tuple(float(v) for v in z[::-1])
+
+
+class Inputs:
+    """The six parameter structs of a run (InputParameters, wrapper/inputs.py) with the defaults
+    of ``structs.default_*``; keyword arguments are routed to the struct that has the field."""
+
+    def __init__(self, random_seed=1, cosmo_tables=None, **kw):
+        groups = (("simulation_options", S.SimulationOptions, S.default_simulation_options),
+                  ("matter_options", S.MatterOptions, S.default_matter_options),
+                  ("cosmo_params", S.CosmoParams, S.default_cosmo_params),
+                  ("astro_params", S.AstroParams, S.default_astro_params),
+                  ("astro_options", S.AstroOptions, S.default_astro_options))
+        for name, cls, make in groups:
+            names = {f[0] for f in cls._fields_}
+            setattr(self, name, make(**{k: kw.pop(k) for k in list(kw) if k in names}))
+        if kw:
+            raise TypeError(f"unknown parameters: {sorted(kw)}")
+        self.cosmo_tables = cosmo_tables or S.default_cosmo_tables()
+        self.random_seed = int(random_seed)
+
+    @property
+    def evolution_required(self):
+        """Whether a box depends on the previous snapshot (wrapper/inputs.py:1805-1815)."""
+        return bool(self.astro_options.USE_TS_FLUCT or self.astro_options.RECOMB_MODEL != 0)
+
+    def node_redshifts(self, out_redshifts):
+        so = self.simulation_options
+        if not self.evolution_required:
+            return tuple(sorted((float(z) for z in out_redshifts), reverse=True))
+        return get_logspaced_redshifts(min(out_redshifts), so.ZPRIME_STEP_FACTOR, so.Z_HEAT_MAX)
+
+
+def _initialise(lib, inputs: Inputs, data_path):
+    """What GlobalInitializationManager does before the first Compute* call."""
+    i = inputs
+    lib.Broadcast_struct_global_all(*(C.byref(x) for x in (
+        i.simulation_options, i.matter_options, i.cosmo_params, i.astro_params, i.astro_options,
+        i.cosmo_tables)))
+    if data_path is not None:
+        i._data_path = str(data_path).encode()  # kept alive: C holds the pointer
+        S.ConfigSettings.in_dll(lib, "config_settings").external_table_path = i._data_path
+    lib.init_ps()
+    if i.astro_options.USE_TS_FLUCT:
+        lib.init_heat.restype = C.c_int
+        if lib.init_heat() != 0:
+            check(1, "init_heat")
+    elif data_path is not None:
+        lib.c21_recfast_load.restype = C.c_int
+        check(lib.c21_recfast_load(), "recfast")
+    if i.astro_options.RECOMB_MODEL != 0:
+        lib.init_MHR.restype = None
+        lib.init_MHR()
+
+
+def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, lib=None,
+               keep=("density", "velocity_z", "neutral_fraction", "z_reion", "brightness_temp") + TS_FIELDS,
+               progress=None):
+    """Evolve boxes through the library's entry points, mirroring ``run_coeval``: initial
+    conditions once, then from the highest node redshift down: PerturbedField -> [HaloBox ->
+    XraySourceBox ->] [TsBox ->] IonizedBox -> BrightnessTemp, every snapshot receiving the
+    previous one's boxes.  Supported source models: CONST-ION-EFF, E-INTEGRAL, L-INTEGRAL.
+
+    ``device``: a torch device string ("cuda") keeps every array in HBM (zero-copy entry points);
+    None uses numpy arrays that the library stages.  ``data_path``: directory of the reference's
+    data tables (py21cmfast's ``_data``).  Returns ``{redshift: {field: array}}`` for the requested
+    redshifts (fields in ``keep``; plus the scalars ``mean_f_coll`` and ``Q_HI``) and, under the key
+    ``"history"``, the global signal (z, mean dT_b, mean x_HI, mean T_s) of every node."""
+    lib = lib or load(require_gpu=True)
+    from . import grid_api as api
+
+    so, mo, ao, ap = (inputs.simulation_options, inputs.matter_options, inputs.astro_options,
+                      inputs.astro_params)
+    if mo.SOURCE_MODEL not in (0, 1, 2):
+        raise NotImplementedError("SOURCE_MODEL must be CONST-ION-EFF, E-INTEGRAL or L-INTEGRAL "
+                                  "(halo catalogues are not part of this backend)")
+    _initialise(lib, inputs, data_path)
+    n, nz = so.HII_DIM, int(so.NON_CUBIC_FACTOR * so.HII_DIM)
+    shape = (n, n, nz)
+    lagrangian, ts_on, recomb = mo.SOURCE_MODEL == 2, bool(ao.USE_TS_FLUCT), ao.RECOMB_MODEL
+    if device is not None:
+        import torch
+
+        def new(fill=0.0, shp=shape):
+            return torch.full(shp, fill, dtype=torch.float32, device=device)
+
+        def host(a):
+            return a.cpu().numpy()
+    else:
+        def new(fill=0.0, shp=shape):
+            return np.full(shp, fill, np.float32)
+
+        def host(a):
+            return a
+    fp = api._fptr
+
+    spec = S.IcsSpec(dim=so.DIM, dim_z=int(so.NON_CUBIC_FACTOR * so.DIM), hii_dim=n, hii_dim_z=nz,
+                     perturb_algorithm=mo.PERTURB_ALGORITHM, perturb_on_high_res=int(mo.PERTURB_ON_HIGH_RES))
+    ics = api.new_ics_arrays(spec, device=device)
+    if mo.V_CB_MODEL == 1:
+        ics["lowres_vcb"] = new()
+    icss = api.ics_struct(ics)
+    check(lib.ComputeInitialConditions(inputs.random_seed, C.byref(icss)), "ComputeInitialConditions")
+
+    lib.ComputeTsBox.restype = C.c_int
+    lib.ComputeTsBox.argtypes = [C.c_float, C.c_float, C.c_float, C.c_short] + [C.c_void_p] * 5
+    lib.ComputeHaloBox.restype = C.c_int
+    lib.ComputeHaloBox.argtypes = [C.c_double] + [C.c_void_p] * 5
+    lib.ComputeBrightnessTemp.restype = C.c_int
+    lib.ComputeBrightnessTemp.argtypes = [C.c_float] + [C.c_void_p] * 4
+
+    def new_ion():
+        rshape = shape if recomb != 1 else (1, 1, 1)
+        arr = {k: new(1.0 if k == "neutral_fraction" else 0.0,
+                      rshape if k == "cumulative_recombinations" else shape) for k in ION_FIELDS}
+        if mo.MINIMIZE_MEMORY:
+            arr.pop("kinetic_temperature"), arr.pop("mean_free_path")
+        return arr, S.IonizedBoxStruct(**{k: fp(v) for k, v in arr.items()})
+
+    def new_ts():
+        arr = {k: new() for k in TS_FIELDS}
+        return arr, S.TsBoxStruct(**{k: fp(v) for k, v in arr.items()})
+
+    out_redshifts = [float(np.float32(z)) for z in out_redshifts]
+    nodes = [float(np.float32(z)) for z in inputs.node_redshifts(out_redshifts)]
+    wanted = {min(nodes, key=lambda x, z=z: abs(x - z)): z for z in out_redshifts}
+    prev_ion_arr, prev_ion = new_ion()
+    prev_ts_arr, prev_ts = new_ts()
+    prev_pf_arr = None
+    prev_z, prev_xHI = 0.0, None
+    z_halos, hboxes = [], []
+    result, history = {}, []
+    for z in nodes:
+        pf_arr = {"density": new(), "velocity_z": new()}
+        pf = S.PerturbedFieldStruct(**{k: fp(v) for k, v in pf_arr.items()})
+        check(lib.ComputePerturbedField(z, C.byref(icss), C.byref(pf)), "ComputePerturbedField")
+        hb_arr, hb = {}, S.HaloBoxStruct()
+        if lagrangian:
+            names = ["n_ion", "halo_sfr"] + (["halo_xray"] if ts_on else []) + (["whalo_sfr"] if recomb else [])
+            hb_arr = {k: new() for k in names}
+            hb = S.HaloBoxStruct(**{k: fp(v) for k, v in hb_arr.items()})
+            check(lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb)), "ComputeHaloBox")
+        ts_arr, ts = ({}, S.TsBoxStruct())
+        if ts_on:
+            srcs = None
+            if lagrangian:  # the X-ray light cone reads the halo-grid HISTORY (host arrays)
+                hist = {k: host(hb_arr[k]) for k in ("halo_sfr", "halo_xray")}
+                xsrc = compute_xray_source_field(
+                    z_halos + [z], hboxes + [hist], z, simulation_options=so,
+                    cosmo_params=inputs.cosmo_params, astro_params=ap, astro_options=ao,
+                    previous_xHI_mean=prev_xHI, lib=lib)
+                srcs = S.XraySourceBoxStruct(
+                    filtered_sfr=xsrc["filtered_sfr"].ctypes.data_as(S.c_float_p),
+                    filtered_xray=xsrc["filtered_xray"].ctypes.data_as(S.c_float_p))
+                z_halos.append(z)
+                hboxes.append(hist)
+            ts_arr, ts = new_ts()
+            check(lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), C.byref(srcs) if srcs else None,
+                                   C.byref(prev_ts), C.byref(icss), C.byref(ts)), "ComputeTsBox")
+        ion_arr, ion = new_ion()
+        prev_pf = S.PerturbedFieldStruct(**{k: fp(v) for k, v in (prev_pf_arr or pf_arr).items()})
+        check(lib.ComputeIonizedBox(z, prev_z, C.byref(pf), C.byref(prev_pf), C.byref(prev_ion),
+                                    C.byref(ts), C.byref(hb), C.byref(icss), C.byref(ion)),
+              "ComputeIonizedBox")
+        bt_arr = {"brightness_temp": new(), "tau_21": new()}
+        bt = S.BrightnessTempStruct(**{k: fp(v) for k, v in bt_arr.items()})
+        check(lib.ComputeBrightnessTemp(z, C.byref(ts), C.byref(ion), C.byref(pf), C.byref(bt)),
+              "ComputeBrightnessTemp")
+        mean = lambda a: float(a.double().mean()) if device is not None else float(a.mean(dtype=np.float64))  # noqa: E731
+        prev_xHI = mean(ion_arr["neutral_fraction"])
+        history.append((z, mean(bt_arr["brightness_temp"]), prev_xHI,
+                        mean(ts_arr["spin_temperature"]) if ts_on else float("nan")))
+        if progress:
+            progress(history[-1])
+        if z in wanted:
+            boxes = {**pf_arr, **hb_arr, **ts_arr, **ion_arr, **bt_arr}
+            snap = {k: boxes[k] for k in keep if k in boxes}
+            snap["mean_f_coll"], snap["Q_HI"] = ion.mean_f_coll, ts.Q_HI
+            result[wanted[z]] = snap
+        if inputs.evolution_required:  # only then is a snapshot the next one's "previous"
+            prev_ts_arr, prev_ts, prev_ion_arr, prev_ion, prev_pf_arr, prev_z = (
+                ts_arr, ts, ion_arr, ion, pf_arr, z)
+    result["history"] = history
+    result["initial_conditions"] = ics
+    return result

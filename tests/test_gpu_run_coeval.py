@@ -1,0 +1,75 @@
+"""21cmfast_amd.drivers.run_coeval (the evolution loop of the reference's run_coeval, reference:
+src/py21cmfast/drivers/coeval.py:560-890) end to end against the reference's own fixtures: the same
+pins as tests/test_gpu_reference_fixtures*.py, through the packaged driver instead of a loop
+written in the test, with numpy arrays and with arrays resident on the device."""
+
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import refpin as RP
+
+pytestmark = pytest.mark.gpu
+D = importlib.import_module("21cmfast_amd.drivers")
+DATA = Path(__file__).parent / "golden" / "reference" / "_data"
+TESTRUN = dict(HII_DIM=RP.HII_DIM, DIM=RP.DIM, BOX_LEN=RP.BOX_LEN, N_THREADS=2,
+               ZPRIME_STEP_FACTOR=1.04, HII_FILTER=0, USE_EXP_FILTER=False, CELL_RECOMB=False,
+               USE_UPPER_STELLAR_TURNOVER=False, USE_LYA_HEATING=False)  # produce_integration_test_data.py:48-63
+
+
+def powers(name, snap, fields):
+    f = RP.fixture("power_spectra", name)
+    worst = {}
+    for k in fields:
+        a = snap[k]
+        a = a.cpu().numpy() if hasattr(a, "cpu") else a
+        p, _ = RP.get_power(a, RP.BOX_LEN)
+        worst[k] = float(np.max(np.abs(p / f[f"coeval/power_{k}"] - 1)))
+    return f, worst
+
+
+@pytest.mark.parametrize("name,opts,device", [
+    ("simple", dict(SOURCE_MODEL=1), None),
+    ("fixed_halogrids", dict(SOURCE_MODEL=2), "cuda"),
+    ("ts", dict(SOURCE_MODEL=1, USE_TS_FLUCT=True), "cuda"),
+    ("inhomo", dict(SOURCE_MODEL=1, RECOMB_MODEL=2, R_BUBBLE_MAX=50.0), None),
+    ("multiple_scattering", dict(SOURCE_MODEL=2, USE_TS_FLUCT=True, LYA_MULTIPLE_SCATTERING=True), None),
+])
+def test_run_coeval_reproduces_reference_fixture(gpu_lib, monkeypatch, name, opts, device):
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    inputs = D.Inputs(random_seed=RP.SEED, **{**TESTRUN, **opts})
+    res = D.run_coeval(inputs, [18.0], data_path=DATA, device=device, lib=gpu_lib)
+    snap = res[18.0]
+    fields = ["density", "neutral_fraction", "brightness_temp"]
+    if inputs.astro_options.USE_TS_FLUCT:
+        fields += list(D.TS_FIELDS)
+    f, worst = powers(name, snap, fields)
+    print(name, worst)
+    assert worst["density"] < 4e-4
+    for k in fields[1:]:
+        assert worst[k] < 2e-3, k
+    n_nodes = 18 if inputs.evolution_required else 1  # Z_HEAT_MAX = 35 down to 18 in steps of 1.04
+    assert len(res["history"]) == n_nodes
+    if inputs.evolution_required:  # the global signal of every node of the lightcone fixture
+        gb = np.array([h[1] for h in res["history"]])
+        np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-3)
+        gx = np.array([h[2] for h in res["history"]])
+        np.testing.assert_allclose(gx, f["lightcone/global_neutral_fraction"], rtol=2e-5)
+    # E-INTEGRAL: the global collapsed fraction; Lagrangian grids: the box mean of the source grid
+    assert snap["mean_f_coll"] > 0 and (inputs.matter_options.SOURCE_MODEL == 2 or snap["mean_f_coll"] < 1e-2)
+    if inputs.astro_options.USE_TS_FLUCT:
+        assert 0.99 < snap["Q_HI"] <= 1.0
+
+
+def test_inputs_route_parameters_and_node_redshifts():
+    i = D.Inputs(HII_DIM=32, SOURCE_MODEL=1, USE_TS_FLUCT=True, Z_HEAT_MAX=25.0, F_STAR10=0.04)
+    assert i.simulation_options.HII_DIM == 32 and i.matter_options.SOURCE_MODEL == 1
+    assert i.astro_params.F_STAR10 == pytest.approx(0.04) and i.astro_options.USE_TS_FLUCT
+    z = i.node_redshifts([18.0, 20.0])
+    assert z[-1] == pytest.approx(18.0) and z[0] >= 25.0 and all(a > b for a, b in zip(z, z[1:]))
+    np.testing.assert_allclose(np.diff(np.log(1 + np.array(z))), -np.log(1.02), rtol=1e-9)
+    assert D.Inputs(SOURCE_MODEL=1).node_redshifts([8.0, 12.0]) == (12.0, 8.0)
+    with pytest.raises(TypeError, match="NOT_A_FIELD"):
+        D.Inputs(NOT_A_FIELD=1)
