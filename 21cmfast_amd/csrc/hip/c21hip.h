@@ -365,7 +365,8 @@ int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int wo
 int c21hip_max_into(void *dst, const void *src, size_t count, int bytes_per_element, void *stream);
 int c21hip_sum_float(const float *v, size_t n, double *partials, double *sum_out, void *stream);
 int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
-                         const double *mean_dev, unsigned char *first_cross, void *stream);
+                         const float *xe_dense, const double *mean_dev,
+                         unsigned char *first_cross, void *stream);
 /* mask of radii > 0 + radius index 0 + post-loop sweep of the fused Lagrangian path in one pass
  * (IonisationBox.c:1031-1256,1597-1608); partials: 2 * 2048 doubles; writes every z_reion.
  * stars_direct = 1: stars_fil is the dense emissivity input (clipped on load) instead of its

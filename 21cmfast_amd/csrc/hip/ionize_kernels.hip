@@ -420,10 +420,12 @@ ionise_eulerian_kernel(IoniseParams p, const float *__restrict__ nion_dense,
 // Eulerian source models, radius index > 0, no x_e grid: the barrier test of
 // find_ionised_regions (IonisationBox.c:1022-1027,1077,1118) on the dense f_coll grid, recording
 // only the first crossing (uint8 mask) like the fused Lagrangian path.  4 cells per thread.
+// xe_dense (spin-temperature runs): the filtered x_e grid as dense rows; the barrier then is
+// f zeta > 1 - x_e with x_e clipped to [0, 0.999] (:811-813,1118).
 __global__ void __launch_bounds__(kBlock)
 eulerian_mask_kernel(c21hip_ionize_args a, const float *__restrict__ nion_dense,
-                     const double *__restrict__ mean_dev, unsigned char *__restrict__ first_cross,
-                     size_t ntot) {
+                     const float *__restrict__ xe_dense, const double *__restrict__ mean_dev,
+                     unsigned char *__restrict__ first_cross, size_t ntot) {
     const double mean_fix = a.fix_mean ? a.mean_f_coll / *mean_dev : 1.;
     const size_t n4 = ntot / 4;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4;
@@ -431,13 +433,19 @@ eulerian_mask_kernel(c21hip_ionize_args a, const float *__restrict__ nion_dense,
         const float4 f = reinterpret_cast<const float4 *>(nion_dense)[i];
         uchar4 m = reinterpret_cast<const uchar4 *>(first_cross)[i];
         const float fv[4] = {f.x, f.y, f.z, f.w};
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (xe_dense) {
+            const float4 x = reinterpret_cast<const float4 *>(xe_dense)[i];
+            xv[0] = x.x, xv[1] = x.y, xv[2] = x.z, xv[3] = x.w;
+        }
         unsigned char mv[4] = {m.x, m.y, m.z, m.w};
         bool changed = false;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             double curr_fcoll = mean_fix * (double)fv[e];
             if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
-            if (curr_fcoll * a.ion_eff_factor > 1. && mv[e] == 0) {
+            const double x_e = xe_dense ? (double)clip_xe(xv[e]) : 0.;
+            if (curr_fcoll * a.ion_eff_factor > (1. - x_e) && mv[e] == 0) {
                 mv[e] = (unsigned char)a.r_index;
                 changed = true;
             }
@@ -450,7 +458,8 @@ eulerian_mask_kernel(c21hip_ionize_args a, const float *__restrict__ nion_dense,
          i += (size_t)gridDim.x * kBlock) {
         double curr_fcoll = mean_fix * (double)nion_dense[i];
         if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
-        if (curr_fcoll * a.ion_eff_factor > 1. && first_cross[i] == 0)
+        const double x_e = xe_dense ? (double)clip_xe(xe_dense[i]) : 0.;
+        if (curr_fcoll * a.ion_eff_factor > (1. - x_e) && first_cross[i] == 0)
             first_cross[i] = (unsigned char)a.r_index;
     }
 }
@@ -1201,11 +1210,11 @@ extern "C" int c21hip_sum_float(const float *v, size_t n, double *partials, doub
 }
 
 extern "C" int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
-                                    const double *mean_dev, unsigned char *first_cross,
-                                    void *stream) {
+                                    const float *xe_dense, const double *mean_dev,
+                                    unsigned char *first_cross, void *stream) {
     const size_t ntot = (size_t)a->nx * a->ny * a->nz;
     hipLaunchKernelGGL(eulerian_mask_kernel, dim3(grid_for(ntot / 4 + 1)), dim3(kBlock), 0,
-                       (hipStream_t)stream, *a, nion_dense, mean_dev, first_cross, ntot);
+                       (hipStream_t)stream, *a, nion_dense, xe_dense, mean_dev, first_cross, ntot);
     LAUNCH_CHECK();
     return 0;
 }

@@ -53,6 +53,9 @@ enum {
     WS_DELTA_WORK2 = 92, /* second radius of a two-radius sweep */
     WS_STARS_WORK2 = 93,
     WS_XE_WORK2 = 96,
+    WS_EUL_DFIL2 = 97, /* Eulerian table loop: second delta_R buffer, two dense x_e(R) buffers */
+    WS_EUL_XE0 = 98,
+    WS_EUL_XE1 = 99,
     /* recombination models: filtered whalo_sfr and N_rec grids, staged arrays, rate tables */
     WS_SFR_UNF = 120,
     WS_SFR_FIL,
@@ -264,7 +267,8 @@ typedef struct {
     int def_first, def_step, def_count;
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
-    int eul_mask;        /* Eulerian models on the native passes without an x_e grid: radii > 0
+    float *eul_xe[2];    /* dense x_e(R) of the Eulerian mask path (spin-temperature runs) */
+    int eul_mask;        /* Eulerian models on the native passes: radii > 0
                           * run pass Z fused with f_coll (or its extrema) and only update the
                           * first-crossing mask */
     copyback_list cb;
@@ -326,7 +330,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->fused = c->native && c->lagrangian && !c->recomb &&
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
-    c->eul_mask = c->native && !c->lagrangian && !s->use_ts_fluct && !c->recomb;
+    c->eul_mask = c->native && !c->lagrangian && !c->recomb;
     if (c->recomb && c->lagrangian) {
         c->sfr_unf = (float *)c21hip_ws(WS_SFR_UNF, gbytes);
         c->sfr_fil = (float *)c21hip_ws(WS_SFR_FIL, gbytes);
@@ -703,6 +707,14 @@ done:
 
 /* One filter radius: IonisationBox.c:1546-1580.  first_cross != NULL = shard mode.
  * next_R: the radius index this process handles after R_ct (-1: none / unknown). */
+/* the two dense x_e(R) buffers of the Eulerian mask path */
+static int eul_xe_buffers(ion_ctx *c) {
+    if (c->eul_xe[0] && c->eul_xe[1]) return 0;
+    c->eul_xe[0] = (float *)c21hip_ws(WS_EUL_XE0, c->ntot * sizeof(float));
+    c->eul_xe[1] = (float *)c21hip_ws(WS_EUL_XE1, c->ntot * sizeof(float));
+    return (c->eul_xe[0] && c->eul_xe[1]) ? 0 : C21CM_MEMORY_ALLOC_ERROR;
+}
+
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -718,8 +730,18 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
         return fused_step(c, R_ct, -1, first_cross, next_R, -1);
     if (c->eul_mask && first_cross && R_ct > 0) {
         const int zs = 2 * (c->nz / 2 + 1);
-        TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
-                                   s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+        const float *xe_dense = NULL;
+        if (s->use_ts_fluct) { /* delta and x_e through one sweep of passes X / Y (same window) */
+            TRY(eul_xe_buffers(c));
+            TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->xe_unf,
+                                        c->xe_work, s->hii_filter, 0.f, c->nx, c->ny, c->nz,
+                                        s->box_len, s->box_len_z, R, apply, 0, 0, c->stream));
+            TRY(c21hip_split_z_c2r(c->xe_work, c->eul_xe[0], c->nz, c->nx, c->ny, c->nz, c->stream));
+            xe_dense = c->eul_xe[0];
+        } else {
+            TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
+                                       s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+        }
         if (s->fcoll_mode == C21CM_FCOLL_ERFC) {
             TRY(c21hip_split_z_fcoll_erfc(c->delta_work, c->nion_dense, c->nx, c->ny, c->nz,
                                           s->growth_factor, s->sigma_minmass,
@@ -749,7 +771,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
         }
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
-        TRY(c21hip_eulerian_mask(&args, c->nion_dense, mean_dev, first_cross, c->stream));
+        TRY(c21hip_eulerian_mask(&args, c->nion_dense, xe_dense, mean_dev, first_cross, c->stream));
         goto done;
     }
     TRY(filter_to_real(c, c->delta_unf, c->delta_work, c->delta_fil, s->hii_filter, R, 0.f,
@@ -841,8 +863,15 @@ done:
 static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *mm_host, void *ev) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
-    TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
-                               s->box_len_z, s->hii_filter, (float)s->R[R_ct], 0.f, 1, c->stream));
+    if (s->use_ts_fluct) { /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
+        TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->xe_unf,
+                                    c->xe_work, s->hii_filter, 0.f, c->nx, c->ny, c->nz, s->box_len,
+                                    s->box_len_z, (float)s->R[R_ct], 1, 0, 0, c->stream));
+        TRY(c21hip_split_z_c2r(c->xe_work, c->eul_xe[buf], c->nz, c->nx, c->ny, c->nz, c->stream));
+    } else {
+        TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
+                                   s->box_len_z, s->hii_filter, (float)s->R[R_ct], 0.f, 1, c->stream));
+    }
     TRY(c21hip_split_z_c2r_minmax(c->delta_work, delta_fil, 2 * (c->nz / 2 + 1), c->nx, c->ny,
                                   c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf,
                                   c->stream));
@@ -862,11 +891,12 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
     void *ev[2] = {c21hip_event_create(), c21hip_event_create()};
     float *dfil[2] = {c->delta_fil, NULL};
     if (n <= 0) goto done;
-    dfil[1] = (float *)c21hip_ws(WS_XE_FIL, c->npad * sizeof(float)); /* free without an x_e grid */
+    dfil[1] = (float *)c21hip_ws(WS_EUL_DFIL2, c->npad * sizeof(float));
     if (!ev[0] || !ev[1] || !dfil[1] || !mm) {
         status = C21CM_MEMORY_ALLOC_ERROR;
         goto done;
     }
+    if (s->use_ts_fluct) TRY(eul_xe_buffers(c));
     TRY(eul_stage_a(c, radii[0], 0, dfil[0], mm[0], ev[0]));
     for (int i = 0; i < n; i++) {
         const int b = i & 1, R_ct = radii[i];
@@ -891,7 +921,8 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
                                   table_dev, c->partials, sum_dev, c->stream));
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
-        TRY(c21hip_eulerian_mask(&args, c->nion_dense, mean_dev, mask, c->stream));
+        TRY(c21hip_eulerian_mask(&args, c->nion_dense, s->use_ts_fluct ? c->eul_xe[b] : NULL, mean_dev,
+                                 mask, c->stream));
     }
     /* the pinned staging buffer is shared: make sure the last copies have left it */
     TRY(c21hip_sync(c->stream));

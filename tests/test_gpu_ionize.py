@@ -193,6 +193,41 @@ def test_long_z_lines_plain_pass_parity(api, oracle, mode, nz):
     oracle.set_threads(16)
 
 
+@pytest.mark.parametrize("mode", ["erfc", "table"])
+@pytest.mark.parametrize("shape,device_resident", [((64, 64, 64), False), ((32, 32, 128), True)])
+def test_eulerian_sources_with_xe_grid(api, oracle, mode, shape, device_resident):
+    """Spin-temperature runs with Eulerian sources on the native passes: delta and x_e go through
+    passes X / Y together, the barrier of the first-crossing mask reads f zeta > 1 - x_e(R) with the
+    filtered x_e clipped to [0, 0.999]; the cell-scale radius and the post-loop take the partial
+    ionisations and temperatures from the x_e / T_k boxes (IonisationBox.c:811-813,1118,1160-1200)."""
+    n, nz = shape[0], shape[2]
+    fmode = W.FCOLL_ERFC if mode == "erfc" else W.FCOLL_TABLE_EXP
+    for first in (1, 0):
+        spec = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=10.0, use_ts_fluct=1,
+                             first_snapshot=first)
+        if mode == "table":
+            _install_table(spec)
+        density = W.density_field_numpy(shape, seed=6)
+        rng = np.random.default_rng(11)
+        xe = (-0.05 + 0.7 * rng.random(shape) ** 2).astype(np.float32)  # spans both clips
+        xe[::5, ::3, ::7] = 1.3
+        Tn = (8.0 + 4.0 * rng.random(shape)).astype(np.float32)
+        kw = dict(xe=xe, Tneutral=Tn)
+        if not first:
+            kw["prev_z_reion"] = np.where(rng.random(shape) < 0.25, 10.5, -1.0).astype(np.float32)
+        ref = oracle.ionize_grids(spec, density, need_nion=True, **kw)
+        got = run_device(api, spec, density, device_resident=device_resident, **kw)
+        compare(got, ref, spec)
+        assert 0.02 < (ref["neutral_fraction"] == 0).mean() < 0.98
+        # the x_e grid matters: without it fewer cells cross
+        spec0 = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=10.0, first_snapshot=first)
+        if mode == "table":
+            _install_table(spec0)
+        kw0 = {k: v for k, v in kw.items() if k == "prev_z_reion"}
+        ref0 = oracle.ionize_grids(spec0, density, need_nion=True, **kw0)
+        assert (ref["neutral_fraction"] == 0).sum() > (ref0["neutral_fraction"] == 0).sum()
+
+
 @pytest.mark.parametrize("n", [32, 50, 64])
 def test_const_ion_eff_erfc_parity(api, oracle, n):
     """G = 1 variant: CONST-ION-EFF closed-form erfc, sharp-k filter, fix_mean."""

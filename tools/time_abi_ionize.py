@@ -25,10 +25,12 @@ pkg = importlib.import_module("21cmfast_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 src = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 z = float(sys.argv[3]) if len(sys.argv) > 3 else 9.0
+use_ts = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 1: an x_e / T_k box of a spin-temperature run
+hii_filter = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 lib = pkg.load(require_gpu=True)
 tmp = pathlib.Path(tempfile.mkdtemp())
-ses = Session(lib, tmp, HII_DIM=n, SOURCE_MODEL=src, HII_FILTER=1, USE_EXP_FILTER=False,
-              CELL_RECOMB=False, R_BUBBLE_MAX=40.0)
+ses = Session(lib, tmp, HII_DIM=n, SOURCE_MODEL=src, HII_FILTER=hii_filter, USE_EXP_FILTER=False,
+              CELL_RECOMB=False, R_BUBBLE_MAX=40.0, USE_TS_FLUCT=bool(use_ts))
 
 density = W.density_field_torch(n, seed=5, sigma=0.6)
 shape = density.shape
@@ -50,6 +52,11 @@ def run():
     box = S.IonizedBoxStruct(neutral_fraction=p(xH), z_reion=p(zre), kinetic_temperature=p(tk),
                              unnormalised_nion=p(nion))
     ts, hb, ics = S.TsBoxStruct(), S.HaloBoxStruct(), S.InitialConditionsStruct()
+    if use_ts:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        xe = 0.02 + 0.03 * torch.rand(shape, device="cuda", generator=g)
+        tn = 8.0 + 4.0 * torch.rand(shape, device="cuda", generator=g)
+        ts = S.TsBoxStruct(xray_ionised_fraction=p(xe), kinetic_temp_neutral=p(tn))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     st = lib.ComputeIonizedBox(z, 0.0, C.byref(pf), C.byref(pf), C.byref(prevb), C.byref(ts),
@@ -62,5 +69,5 @@ def run():
 
 run()
 times = [run() for _ in range(3)]
-print(json.dumps({"hii_dim": n, "source_model": src, "z": z, "ms": min(t for t, _ in times) * 1e3,
+print(json.dumps({"hii_dim": n, "source_model": src, "z": z, "use_ts_fluct": use_ts, "hii_filter": hii_filter, "ms": min(t for t, _ in times) * 1e3,
                   "global_xH": times[0][1]}))
