@@ -28,7 +28,7 @@
  *   taus2    L'Ecuyer (1996/1999) three-component Tausworthe generator with the 1999 seeding
  *            (components forced >= 2, 8, 16), six warm-up steps; uniform = value / 2^32
  *   GSL's own self-test values (rng/test.c: the 10000th output for seed 1 is 719452880 for cmrg,
- *   2064828650 for mrg, 2733957125 for taus2) are reproduced: tests/test_oracle_gslrng.py.
+ *   2064828650 for mrg, 2733957125 for taus2) are reproduced (the generator tests under tests/).
  * Thread t of seed_rng_threads cycles through mt19937, gfsr4, cmrg, mrg, taus2 (rng.c:58-85), so
  * any N_THREADS reproduces upstream; the reference's fixtures pin the first two
  * (tests/produce_integration_test_data.py:62,213-220), the other three rest on GSL's self-test
