@@ -649,6 +649,35 @@ double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
     return c21_integrate(mf_integrand, &p, lnM_min, lnM_max, 1e-6);
 }
 
+/* hmf.c:470-477: n_ion per halo of the molecularly cooled population: pivot 1e7 Msun, lower
+ * turnover exp(-M_turn/M), upper turnover exp(-M/M_acg) at the atomic cooling threshold */
+static double nion_weight_mini(double lnM, double Mturn, const c21_scaling_consts *sc) {
+    const double Fstar = log_pl_limit(lnM, log(sc->fstar_7), sc->alpha_star_mini, 7 * M_LN10,
+                                      log(sc->Mlim_Fstar_mini));
+    const double Fesc =
+        log_pl_limit(lnM, log(sc->fesc_7), sc->alpha_esc, 7 * M_LN10, log(sc->Mlim_Fesc_mini));
+    const double M = exp(lnM);
+    return exp(Fstar + Fesc - M / sc->acg_thresh - Mturn / M + lnM);
+}
+
+struct mf_mini_ctx {
+    double growthf, Mturn;
+    int hmf;
+    const c21_scaling_consts *sc;
+};
+static double mf_mini_integrand(double lnM, void *ctx) {
+    const struct mf_mini_ctx *p = (const struct mf_mini_ctx *)ctx;
+    return nion_weight_mini(lnM, p->Mturn, p->sc) * unconditional_mf(p->growthf, lnM, p->hmf);
+}
+
+/* hmf.c:973-990 */
+double c21_Nion_General_MINI(double z, double lnM_min, double lnM_max, double Mturn,
+                             const c21_scaling_consts *sc) {
+    if (!supported_hmf()) return NAN;
+    struct mf_mini_ctx p = {dicke(z), Mturn, matter_options_global->HMF, sc};
+    return c21_integrate(mf_mini_integrand, &p, lnM_min, lnM_max, 1e-6);
+}
+
 /* ---------------------------------------------------------------- conditional mass function
  * The E-INTEGRAL source model evaluates, per filter radius, N_ion(delta | M_cond = M(R)) on a
  * grid of 400 overdensities (interp_tables.c:291-405) as a Gauss-Legendre sum over ln M of
@@ -977,6 +1006,106 @@ static int conditional_table(double growthf, double lnMmin, double lnMmax, doubl
     return bad ? C21CM_TABLE_GENERATION_ERROR : 0;
 }
 
+/* hmf.c:1066-1104 */
+double c21_Nion_ConditionalM_MINI(double growthf, double lnM1, double lnM2, double lnM_cond,
+                                  double sigma2, double delta2, double Mturn,
+                                  const c21_scaling_consts *sc, int method) {
+    return weighted_ConditionalM(nion_weight_mini, growthf, lnM1, lnM2, lnM_cond, sigma2, delta2,
+                                 Mturn, sc, method);
+}
+
+/* interp_tables.c:291-405 with USE_MINI_HALOS.  With the Gauss-Legendre method the integrand
+ * factorises per node into (what depends on delta) x (what depends on M_turn), so one table
+ * costs n_delta x NGL exponentials plus n_delta x NGL x n_mturn multiply-adds instead of
+ * n_delta x n_mturn quadratures; values equal the per-entry integrals to rounding. */
+int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                                 double sigma_cond, double dmin, double dmax, double l10mt_min,
+                                 double l10mt_max, const c21_scaling_consts *sc, int mini,
+                                 int method, float *table, int n_delta, int n_mturn) {
+    int hmf = matter_options_global->HMF;
+    const mass_weight_fn weight = mini ? nion_weight_mini : nion_weight;
+    const int fast = (method == 1) && lnMmin < lnMcond;
+    if (n_mturn < 2 || n_mturn > 256) return C21CM_VALUE_ERROR;
+    if (hmf != C21CM_HMF_PS && hmf != C21CM_HMF_ST) hmf = C21CM_HMF_PS;
+    double *mturn = (double *)malloc(sizeof(double) * (size_t)n_mturn);
+    double *wk = (double *)malloc(sizeof(double) * (size_t)(NGL_INT + 1) * (size_t)n_mturn);
+    double node_pref[NGL_INT + 1], node_factor[NGL_INT + 1], node_barrier[NGL_INT + 1],
+        node_sdi[NGL_INT + 1];
+    if (!mturn || !wk) {
+        free(mturn);
+        free(wk);
+        return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    for (int j = 0; j < n_mturn; j++) /* float arithmetic of the ratio as upstream (:353-358) */
+        mturn[j] = pow(10., l10mt_min + (float)j / ((float)n_mturn - 1.) * (l10mt_max - l10mt_min));
+    if (method == 1) initialise_GL(lnMmin, lnMmax);
+    if (fast) {
+        for (int i = 1; i < NGL_INT + 1; i++) {
+            const double lnM = gl.x[i], M = exp(lnM);
+            const double sigma1 = c21_sigma_fast(M), dsigmasqdm = dsigmasqdm_fast(M);
+            if (sigma1 < sigma_cond) { /* conditional_mf returns 0 */
+                node_pref[i] = node_factor[i] = node_barrier[i] = node_sdi[i] = 0.;
+                for (int j = 0; j < n_mturn; j++) wk[(size_t)i * n_mturn + j] = 0.;
+                continue;
+            }
+            const double sdi =
+                sigma1 == sigma_cond ? 1e6 : 1 / (sigma1 * sigma1 - sigma_cond * sigma_cond);
+            node_sdi[i] = sdi;
+            node_pref[i] = dsigmasqdm * pow(sdi, 1.5) / sqrt(2. * M_PI);
+            if (hmf == C21CM_HMF_ST)
+                node_factor[i] = st_taylor_factor(sigma1, sigma_cond, growthf, &node_barrier[i]);
+            else
+                node_factor[i] = node_barrier[i] = 0.;
+            for (int j = 0; j < n_mturn; j++) wk[(size_t)i * n_mturn + j] = weight(lnM, mturn[j], sc);
+        }
+    }
+    int bad = 0;
+    const int n_thr = simulation_options_global && simulation_options_global->N_THREADS > 1
+                          ? simulation_options_global->N_THREADS : 1;
+#pragma omp parallel for schedule(static) num_threads(n_thr) reduction(| : bad)
+    for (int k = 0; k < n_delta; k++) {
+        const double delta = dmin + (float)k / ((float)n_delta - 1.) * (dmax - dmin);
+        float *row = table + (size_t)k * n_mturn;
+        if (!fast || delta > MAX_DELTAC_FRAC * get_delta_crit(hmf, sigma_cond, growthf)) {
+            for (int j = 0; j < n_mturn; j++) {
+                double lv = log(weighted_ConditionalM(weight, growthf, lnMmin, lnMmax, lnMcond,
+                                                      sigma_cond, delta, mturn[j], sc, method));
+                if (lv < -40.) lv = -40.;
+                if (!isfinite(lv)) bad |= 1;
+                row[j] = (float)lv;
+            }
+            continue;
+        }
+        double acc[256];
+        for (int j = 0; j < n_mturn; j++) acc[j] = 0.;
+        for (int i = 1; i < NGL_INT + 1; i++) {
+            if (node_pref[i] == 0.) continue;
+            const double sdi = node_sdi[i];
+            double cmf;
+            if (hmf == C21CM_HMF_ST) {
+                const double delta_0 = delta / growthf;
+                const double B = node_barrier[i];
+                cmf = (node_factor[i] - delta_0) * exp(-(B - delta_0) * (B - delta_0) * 0.5 * sdi);
+            } else {
+                const double del = (DELTA_C_SPH - delta) / growthf;
+                cmf = del * exp(-del * del * 0.5 * sdi);
+            }
+            const double node = gl.w[i] * (-node_pref[i] * cmf);
+            const double *w = wk + (size_t)i * n_mturn;
+            for (int j = 0; j < n_mturn; j++) acc[j] += node * w[j];
+        }
+        for (int j = 0; j < n_mturn; j++) {
+            double lv = log(acc[j]);
+            if (lv < -40.) lv = -40.;
+            if (!isfinite(lv)) bad |= 1;
+            row[j] = (float)lv;
+        }
+    }
+    free(mturn);
+    free(wk);
+    return bad ? C21CM_TABLE_GENERATION_ERROR : 0;
+}
+
 /* hmf.c:1268-1316: mass beyond which F = FRAC (M/1e10)^PL would exceed 1 (float bisection) */
 static float mass_limit(float logM, float PL, float FRAC) { return FRAC * pow(pow(10., logM) / 1e10, PL); }
 
@@ -1030,7 +1159,45 @@ int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc) {
     sc->redshift = redshift;
     sc->Mlim_Fstar = mass_limit_bisection(1e5, 1e16, sc->alpha_star, sc->fstar_10, &status);
     sc->Mlim_Fesc = mass_limit_bisection(1e5, 1e16, sc->alpha_esc, sc->fesc_10, &status);
+    if (astro_options_global->USE_MINI_HALOS) { /* scaling_relations.c:53-54,64,87-118 */
+        sc->alpha_star_mini = ap->ALPHA_STAR_MINI;
+        sc->l_x_mini = ap->L_X_MINI * 1e-38;
+        sc->mturn_a_nofb = fmax(sc->acg_thresh, sc->mturn_a_nofb);
+        switch (matter_options_global->V_CB_MODEL) {
+            case C21CM_VCB_AVG_AUTO:
+                sc->vcb_const = cosmo_tables_global->V_CB_AVG;
+                break;
+            case C21CM_VCB_AVG_DEBUG:
+                sc->vcb_const = ap->V_CB_AVG_DEBUG;
+                break;
+            default: /* none, or the per-cell field */
+                sc->vcb_const = 0.;
+        }
+        sc->mturn_m_nofb = c21_lyman_werner_threshold((float)redshift, 0.f, (float)sc->vcb_const);
+        sc->Mlim_Fstar_mini =
+            mass_limit_bisection(1e5, 1e16, sc->alpha_star_mini,
+                                 sc->fstar_7 * pow(1e3, sc->alpha_star_mini), &status);
+        sc->Mlim_Fesc_mini = mass_limit_bisection(1e5, 1e16, sc->alpha_esc,
+                                                  sc->fesc_7 * pow(1e3, sc->alpha_esc), &status);
+    }
     return status;
+}
+
+/* thermochem.c:281-304: Lyman-Werner + streaming-velocity threshold of molecular cooling */
+double c21_lyman_werner_threshold(float z, float J_21_LW, float vcb) {
+    const AstroParams *ap = astro_params_global;
+    const double mcrit_noLW = 3.314e7 * pow(1. + z, -1.5);
+    const double f_LW = 1.0 + ap->A_LW * pow(J_21_LW, ap->BETA_LW);
+    const double sigma_vcb = cosmo_tables_global->V_CB_AVG * sqrt(3 * M_PI / 8);
+    const double f_vcb = pow(1.0 + ap->A_VCB * vcb / sigma_vcb, ap->BETA_VCB);
+    return mcrit_noLW * f_LW * f_vcb;
+}
+
+/* thermochem.c:306-311 (Sobacchi & Mesinger 2013) */
+double c21_reionization_feedback(float z, float Gamma_halo_HII, float z_IN) {
+    if (z_IN <= 1e-19) return 1e-40;
+    return 3e9 * pow(2.0 * Gamma_halo_HII, 0.17) * pow((1. + z) / 10, -2.1) *
+           pow(1 - pow((1. + z) / (1. + z_IN), 2.0), 2.5);
 }
 
 /* hmf.c:1319-1348 */

@@ -20,6 +20,9 @@ typedef struct c21_scaling_consts {
     double Mlim_Fstar, Mlim_Fesc;
     double l_x;      /* L_X * 1e-38 (scaling_relations.c:63) */
     double redshift; /* the halo metallicity relation depends on it */
+    /* mini-halos (scaling_relations.c:53-54,64,87-118); zero unless USE_MINI_HALOS */
+    double alpha_star_mini, Mlim_Fstar_mini, Mlim_Fesc_mini;
+    double mturn_m_nofb, vcb_const, l_x_mini;
 } c21_scaling_consts;
 
 /* exported with the reference's names (bound by py21cmfast's cfuncs layer) */
@@ -69,6 +72,25 @@ int c21_Xray_Conditional_table(double growthf, double lnMmin, double lnMmax, dou
 /* the weight itself, per unit ln M (hmf.c:482-509 without mini-halos) */
 double c21_xray_fraction(double lnM, double Mturn, const c21_scaling_consts *sc);
 int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc);
+/* thermochem.c:281-311 */
+double c21_lyman_werner_threshold(float z, float J_21_LW, float vcb);
+double c21_reionization_feedback(float z, float Gamma_halo_HII, float z_IN);
+/* hmf.c:973-990, 1066-1104 (molecularly cooled galaxies: pivot 1e7, exp(-M/M_acg) upper turnover) */
+double c21_Nion_General_MINI(double z, double lnM_min, double lnM_max, double Mturn,
+                             const c21_scaling_consts *sc);
+double c21_Nion_ConditionalM_MINI(double growthf, double lnM1, double lnM2, double lnM_cond,
+                                  double sigma2, double delta2, double Mturn,
+                                  const c21_scaling_consts *sc, int method);
+/* interp_tables.c:291-405, USE_MINI_HALOS: table[i * n_mturn + j] = max(ln N_ion(delta_i | M_cond;
+ * M_turn_j), -40) on n_delta overdensities x n_mturn log-spaced turnover masses
+ * (10^l10mt_min .. 10^l10mt_max); mini != 0: the molecularly cooled population */
+#define C21_NMTURN 50           /* interp_tables.c:28 */
+#define C21_LOG10_MTURN_MAX 10. /* interp_tables.c:29-30 */
+#define C21_LOG10_MTURN_MIN (5. - 9e-8)
+int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                                 double sigma_cond, double dmin, double dmax, double l10mt_min,
+                                 double l10mt_max, const c21_scaling_consts *sc, int mini,
+                                 int method, float *table, int n_delta, int n_mturn);
 size_t c21_scaling_consts_size(void); /* for binding layers that mirror the struct */
 double c21_minimum_source_mass(double redshift);
 int c21_recfast_load(void);

@@ -1,0 +1,150 @@
+"""Host-side scalars and tables of the molecularly cooled ("mini-halo") population, against scipy
+and closed forms.  Reference behaviour: scaling_relations.c:36-119, thermochem.c:281-311,
+hmf.c:470-477,973-990,1066-1104, interp_tables.c:291-405 (USE_MINI_HALOS)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+from scipy import integrate
+
+from test_host_scalars import ScalingConsts, _bind_conditional, host  # noqa: F401  (fixture)
+
+f64 = C.c_double
+
+
+def _bind(lib):
+    _bind_conditional(lib)
+    lib.c21_lyman_werner_threshold.restype = f64
+    lib.c21_lyman_werner_threshold.argtypes = [C.c_float] * 3
+    lib.c21_reionization_feedback.restype = f64
+    lib.c21_reionization_feedback.argtypes = [C.c_float] * 3
+    lib.c21_Nion_General_MINI.restype = f64
+    lib.c21_Nion_General_MINI.argtypes = [f64] * 4 + [C.POINTER(ScalingConsts)]
+    lib.c21_Nion_General.restype = f64
+    lib.c21_Nion_General.argtypes = [f64] * 4 + [C.POINTER(ScalingConsts)]
+    lib.c21_Nion_ConditionalM_MINI.restype = f64
+    lib.c21_Nion_ConditionalM_MINI.argtypes = [f64] * 7 + [C.POINTER(ScalingConsts), C.c_int]
+    lib.c21_Nion_Conditional_table2d.restype = C.c_int
+    lib.c21_Nion_Conditional_table2d.argtypes = [f64] * 9 + [C.POINTER(ScalingConsts), C.c_int,
+                                                             C.c_int, C.POINTER(C.c_float),
+                                                             C.c_int, C.c_int]
+
+
+@pytest.fixture()
+def mini(host, pkg):
+    """the host library with USE_MINI_HALOS broadcast (restored afterwards)"""
+    S = pkg.structs
+    keep = host._keep
+    _bind(host)
+
+    def broadcast(ap, ao):
+        keep["mini_structs"] = (ap, ao)
+        host.Broadcast_struct_global_all(C.byref(keep["so"]), C.byref(keep["mo"]),
+                                         C.byref(keep["cp"]), C.byref(ap), C.byref(ao),
+                                         C.byref(keep["ct"]))
+    ap = S.default_astro_params(ALPHA_STAR_MINI=0.5, F_STAR7_MINI=10 ** -2.5)
+    broadcast(ap, S.default_astro_options(USE_MINI_HALOS=True))
+    host.mini_ap = ap
+    yield host
+    broadcast(keep["ap"], keep["ao"])
+
+
+def test_thresholds(mini):
+    ap = mini.mini_ap
+    ct = mini._keep["ct"]
+    z = 17.0
+    # no LW background, no streaming velocity: the molecular-cooling mass of Visbal+15
+    assert mini.c21_lyman_werner_threshold(z, 0.0, 0.0) == pytest.approx(3.314e7 * 18.0**-1.5,
+                                                                        rel=1e-6)
+    j, v = 0.3, 20.0
+    sig = ct.V_CB_AVG * math.sqrt(3 * math.pi / 8)
+    want = (3.314e7 * 18.0**-1.5 * (1 + ap.A_LW * np.float32(j) ** ap.BETA_LW)
+            * (1 + ap.A_VCB * v / sig) ** ap.BETA_VCB)
+    assert mini.c21_lyman_werner_threshold(z, j, v) == pytest.approx(want, rel=1e-6)
+    # Sobacchi & Mesinger 2013: no feedback in cells that were never ionised
+    assert mini.c21_reionization_feedback(8.0, 0.5, -1.0) == 1e-40
+    want = 3e9 * (2 * 0.5) ** 0.17 * (9.0 / 10) ** -2.1 * (1 - (9.0 / 11.0) ** 2) ** 2.5
+    assert mini.c21_reionization_feedback(8.0, 0.5, 10.0) == pytest.approx(want, rel=1e-6)
+
+
+def test_scaling_constants(mini):
+    ap = mini.mini_ap
+    sc = ScalingConsts()
+    assert mini.c21_set_scaling_constants(15.0, C.byref(sc)) == 0
+    assert sc.alpha_star_mini == pytest.approx(ap.ALPHA_STAR_MINI)
+    assert sc.mturn_a_nofb == pytest.approx(max(sc.acg_thresh, ap.M_TURN))
+    assert sc.mturn_m_nofb == pytest.approx(3.314e7 * 16.0**-1.5, rel=1e-6)  # V_CB_MODEL none
+    # f_*(M) = F_STAR7 (M/1e7)^a reaches one at Mlim (float bisection, 1e-3 in log10 M)
+    assert sc.fstar_7 * (sc.Mlim_Fstar_mini / 1e7) ** sc.alpha_star_mini == pytest.approx(1.0, rel=5e-3)
+    # a falling f_esc(M) that is below one already at 1e5 Msun is never capped
+    assert sc.fesc_7 * (1e5 / 1e7) ** sc.alpha_esc < 1 and sc.Mlim_Fesc_mini == 1e5
+
+
+def _weight_mini(sc, lnM, Mturn):
+    def pl(norm, alpha, lim):
+        if (alpha > 0 and lnM > math.log(lim)) or (alpha < 0 and lnM < math.log(lim)):
+            return -math.log(norm)
+        return alpha * (lnM - 7 * math.log(10))
+    M = math.exp(lnM)
+    return math.exp(pl(sc.fstar_7, sc.alpha_star_mini, sc.Mlim_Fstar_mini)
+                    + pl(sc.fesc_7, sc.alpha_esc, sc.Mlim_Fesc_mini)
+                    - M / sc.acg_thresh - Mturn / M + lnM)
+
+
+def test_nion_general_mini_against_scipy(mini):
+    """Sheth-Tormen mass function x the MCG n_ion(M), integrated by scipy with the library's sigma"""
+    sc = ScalingConsts()
+    z = 14.0
+    assert mini.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    D = mini.dicke(z)
+    Mturn = 3e6
+
+    def mf(lnM):
+        M = math.exp(lnM)
+        sig = mini.c21_sigma_fast(M) * D
+        ds = mini.dsigmasqdm_z0(M) * D * D / (2 * sig)
+        nu = math.sqrt(0.73) * 1.686 / sig
+        return (-(ds / sig) * math.sqrt(2 / math.pi) * 0.353 * (1 + nu ** (-2 * 0.175)) * nu
+                * math.exp(-nu * nu / 2))
+
+    lo, hi = math.log(1e5), math.log(1e16)
+    want, _ = integrate.quad(lambda x: _weight_mini(sc, x, Mturn) * mf(x), lo, math.log(1e11),
+                             limit=400, epsrel=1e-9)
+    got = mini.c21_Nion_General_MINI(z, lo, hi, Mturn, C.byref(sc))
+    assert got == pytest.approx(want, rel=2e-4)
+    # a stronger LW background (higher turnover) suppresses the population
+    assert mini.c21_Nion_General_MINI(z, lo, hi, 3e7, C.byref(sc)) < got
+
+
+def test_conditional_tables_2d(mini):
+    sc = ScalingConsts()
+    z = 12.0
+    assert mini.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    D = mini.dicke(z)
+    Mmin, Mcond = 1e5, mini.c21_RtoM(3.0)
+    s_c = mini.c21_sigma_fast(Mcond)
+    lnMmin, lnMc = math.log(Mmin), math.log(Mcond)
+    nd, nm = 400, 50
+    dmin, dmax = -0.9, 1.5
+    for is_mini, (lo, hi) in ((1, (5.1, 7.9)), (0, (8.2, 9.6))):
+        tab = (C.c_float * (nd * nm))()
+        assert mini.c21_Nion_Conditional_table2d(D, lnMmin, lnMc, lnMc, s_c, dmin, dmax, lo, hi,
+                                                 C.byref(sc), is_mini, 1, tab, nd, nm) == 0
+        t = np.array(tab[:]).reshape(nd, nm)
+        fn = mini.c21_Nion_ConditionalM_MINI if is_mini else mini.c21_Nion_ConditionalM
+        for i, j in ((0, 0), (13, 49), (200, 25), (399, 7), (330, 0)):
+            delta = dmin + np.float32(i) / (np.float32(nd) - 1.0) * (dmax - dmin)
+            mt = 10 ** (lo + np.float32(j) / (np.float32(nm) - 1.0) * (hi - lo))
+            direct = fn(D, lnMmin, lnMc, lnMc, s_c, float(delta), float(mt), C.byref(sc), 1)
+            ln_direct = math.log(direct) if direct > 0 else -math.inf  # exp(-M_cond/M_acg) underflows
+            assert t[i, j] == pytest.approx(max(ln_direct, -40.0), rel=3e-6, abs=3e-6), (i, j)
+        # more collapse in denser regions (underdense rows: at high delta the small halos of the MCG
+        # population merge away above the atomic threshold), less with a higher turnover mass
+        assert np.all(np.diff(t[:150], axis=0) > 0)
+        assert np.all(np.diff(t[:300], axis=1) < 0)  # (rows past the collapse threshold sit at -40)
+    # the adaptive (QAG) method agrees with Gauss-Legendre for the MCG integrand
+    for delta in (-0.5, 0.3):
+        a = mini.c21_Nion_ConditionalM_MINI(D, lnMmin, lnMc, lnMc, s_c, delta, 2e6, C.byref(sc), 0)
+        b = mini.c21_Nion_ConditionalM_MINI(D, lnMmin, lnMc, lnMc, s_c, delta, 2e6, C.byref(sc), 1)
+        assert a == pytest.approx(b, rel=3e-3)

@@ -170,7 +170,8 @@ class ScalingConsts(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("fstar_10", "alpha_star", "fstar_7", "t_h", "t_star", "fesc_10", "alpha_esc",
                  "fesc_7", "pop2_ion", "pop3_ion", "acg_thresh", "mturn_a_nofb", "Mlim_Fstar",
-                 "Mlim_Fesc", "l_x", "redshift")]
+                 "Mlim_Fesc", "l_x", "redshift", "alpha_star_mini", "Mlim_Fstar_mini",
+                 "Mlim_Fesc_mini", "mturn_m_nofb", "vcb_const", "l_x_mini")]
 
 
 def _bind_conditional(lib):
