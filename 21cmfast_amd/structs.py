@@ -300,6 +300,11 @@ def brightness_spec(n_cells, redshift, cosmo=None, use_ts_fluct=False) -> "Brigh
 
 
 TABLE_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_double, C.c_double, c_float_p, C.c_void_p)
+# c21cm_table2d_fn: (r_index, prev, dens_min, dens_max, l10mt_min, l10mt_max, l10mt_min_mini,
+# l10mt_max_mini, table_acg, table_mcg, user)
+TABLE2D_FN = C.CFUNCTYPE(C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                         C.c_double, C.c_double, c_float_p, c_float_p, C.c_void_p)
+NDELTA_TABLE, NMTURN_TABLE = 400, 50  # include/c21cm_grid.h
 
 
 class IonizeSpec(_Base):
@@ -345,6 +350,18 @@ class IonizeSpec(_Base):
         ("dz", C.c_double),
         ("rr_y", c_double_p),  # recombination-rate table [RR_NZ][RR_NGAMMA] and its spline c's
         ("rr_c", c_double_p),
+        # mini-halos (E-INTEGRAL with USE_MINI_HALOS)
+        ("use_mini_halos", C.c_int),
+        ("need_prev_ion", C.c_int),
+        ("ion_eff_factor_mini", C.c_double),
+        ("mean_f_coll_mini", C.c_double),
+        ("f_limit_mcg", C.c_double),
+        ("gamma_prefactor_mini", C.c_double),
+        ("prev_density", c_float_p),
+        ("log10_mturn_acg", c_float_p),
+        ("log10_mturn_mcg", c_float_p),
+        ("table2d_fn", TABLE2D_FN),
+        ("table2d_user", C.c_void_p),
     ]
 
 
@@ -359,6 +376,27 @@ class IonizeReport(_Base):
         ("ms_preloop", C.c_double),
         ("ms_rloop", C.c_double),
         ("ms_postloop", C.c_double),
+        ("f_coll_grid_mean_mini", C.c_double * MAX_RADII),
+        ("mean_f_coll_mini_out", C.c_double),
+    ]
+
+
+class MturnSpec(_Base):
+    """``c21cm_mturn_spec`` (include/c21cm_grid.h)."""
+
+    _fields_ = [
+        ("hii_dim", C.c_int),
+        ("hii_dim_z", C.c_int),
+        ("first_snapshot", C.c_int),
+        ("redshift", C.c_double),
+        ("mturn_a_nofb", C.c_double),
+        ("mturn_m_nofb", C.c_double),
+        ("vcb_const", C.c_double),
+        ("A_LW", C.c_double),
+        ("BETA_LW", C.c_double),
+        ("A_VCB", C.c_double),
+        ("BETA_VCB", C.c_double),
+        ("sigma_vcb", C.c_double),
     ]
 
 

@@ -44,6 +44,18 @@ enum c21cm_fcoll_mode {
 typedef int (*c21cm_table_fn)(int r_index, double dens_min, double dens_max, float *table,
                               void *user);
 
+/* USE_MINI_HALOS: the two conditional N_ion tables of one radius are 2-D, overdensity x log10 of
+ * the turnover mass (interp_tables.c:291-405): table[i * C21CM_NMTURN_TABLE + j] = ln N_ion at
+ * delta_i = dens_min + i (dens_max - dens_min)/(NDELTA-1) and turnover 10^(l10mt_min +
+ * j (l10mt_max - l10mt_min)/(NMTURN-1)); `table_acg` for the atomically cooled galaxies (turnover
+ * range l10mt_*), `table_mcg` for the molecularly cooled ones (range l10mt_*_mini).  prev != 0:
+ * the tables at the previous snapshot's redshift (trapezoidal history, IonisationBox.c:752-760). */
+#define C21CM_NMTURN_TABLE 50 /* interp_tables.c:28 */
+typedef int (*c21cm_table2d_fn)(int r_index, int prev, double dens_min, double dens_max,
+                                double l10mt_min, double l10mt_max, double l10mt_min_mini,
+                                double l10mt_max_mini, float *table_acg, float *table_mcg,
+                                void *user);
+
 /* All scalars of one ComputeIonizedBox call.
  * reference: struct IonBoxConstants / RadiusSpec, src/py21cmfast/src/IonisationBox.c:38-102. */
 typedef struct c21cm_ionize_spec {
@@ -102,6 +114,24 @@ typedef struct c21cm_ionize_spec {
      * spline's c coefficients (half the second derivatives) of each row in ln Gamma, as
      * gsl_interp_cspline holds them.  Host arrays; c21_rr_tables() builds them (init_MHR). */
     const double *rr_y, *rr_c;
+
+    /* mini-halos: E-INTEGRAL with USE_MINI_HALOS (need_minihalo_nion, IonisationBox.c:30-31).
+     * Four filtered grids per radius (delta, the previous snapshot's delta and the two log10
+     * turnover-mass grids of c21cm_mturn_grids), f_coll of both populations from the 2-D tables,
+     * accumulated over snapshots per radius (box->unnormalised_nion[_mini][n_radii][N], :908-936):
+     *   f(R) = f_prev_box(R) + f(z, M_turn) - f(z_prev, M_turn)
+     * and the barrier f zeta + f_m zeta_m > (1 - x_e)(1 + rec) (:1118-1120). */
+    int use_mini_halos;
+    int need_prev_ion; /* previous box: mean_f_coll zeta + mean_f_coll_MINI zeta_m > 1e-4 (:1546) */
+    double ion_eff_factor_mini;
+    double mean_f_coll_mini;
+    double f_limit_mcg;
+    double gamma_prefactor_mini;
+    const float *prev_density;    /* previous PerturbedField.density [N]          */
+    const float *log10_mturn_acg; /* [N], calculate_mcrit_boxes (:403-457)        */
+    const float *log10_mturn_mcg;
+    c21cm_table2d_fn table2d_fn;
+    void *table2d_user;
 } c21cm_ionize_spec;
 
 #define C21CM_RR_NZ 300       /* recombinations.c:35 RR_Z_NPTS        */
@@ -116,7 +146,25 @@ typedef struct c21cm_ionize_report {
     double global_xH;
     double mean_f_coll_out; /* what ComputeIonizedBox leaves in box->mean_f_coll */
     double ms_preloop, ms_rloop, ms_postloop; /* device timings (hip events)     */
+    double f_coll_grid_mean_mini[C21CM_MAX_RADII]; /* USE_MINI_HALOS */
+    double mean_f_coll_mini_out;
 } c21cm_ionize_report;
+
+/* calculate_mcrit_boxes (IonisationBox.c:403-457): per cell log10 of the turnover masses
+ *   M_turn,a = max(M_reion-feedback, mturn_a_nofb),  M_turn,m = max(M_rf, M_LW(J_21_LW, v_cb), mturn_m_nofb)
+ * from the previous box's Gamma_12 / z_reion and the TsBox's J_21_LW (vcb == NULL: vcb_const).
+ * Arrays on the host or the device ([N], dense); averages of the two log10 grids returned. */
+typedef struct c21cm_mturn_spec {
+    int hii_dim, hii_dim_z;
+    int first_snapshot; /* previous z_reion is -1 everywhere (no feedback)           */
+    double redshift;
+    double mturn_a_nofb, mturn_m_nofb, vcb_const;
+    double A_LW, BETA_LW, A_VCB, BETA_VCB, sigma_vcb; /* sigma_vcb = V_CB_AVG sqrt(3 pi / 8) */
+} c21cm_mturn_spec;
+int c21cm_mturn_grids(const c21cm_mturn_spec *spec, const float *prev_G12,
+                      const float *prev_z_reion, const float *J_21_LW, const float *vcb,
+                      float *log10_mturn_acg, float *log10_mturn_mcg, double *ave_acg,
+                      double *ave_mcg, void *stream);
 
 /* The whole ComputeIonizedBox grid algorithm (pre-loop r2c, R loop, post-loop).
  * reference: src/py21cmfast/src/IonisationBox.c:1477-1628. */

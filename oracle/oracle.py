@@ -156,9 +156,11 @@ def fptr(a):
 
 
 def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion=None,
-                 need_nion=False, prev_nrec=None, whalo_sfr=None):
+                 need_nion=False, prev_nrec=None, whalo_sfr=None, mini=None):
     """Run the oracle's ComputeIonizedBox grid algorithm on numpy inputs.
 
+    ``mini`` (USE_MINI_HALOS): dict of numpy arrays prev_density, log10_mturn_acg, log10_mturn_mcg
+    [N] and prev_nion, prev_nion_mini [n_radii, N] (the previous box's unnormalised_nion arrays).
     Returns a dict of output arrays plus the report struct.
     """
     shape = density.shape
@@ -169,6 +171,12 @@ def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion
     }
     if need_nion:
         out["unnormalised_nion"] = np.zeros(shape, np.float32)
+    if mini is not None:  # wrapper/outputs.py:1538-1543: one grid per filter radius
+        out["unnormalised_nion"] = np.zeros((spec.n_radii,) + shape, np.float32)
+        out["unnormalised_nion_mini"] = np.zeros((spec.n_radii,) + shape, np.float32)
+        spec.prev_density = fptr(mini["prev_density"])
+        spec.log10_mturn_acg = fptr(mini["log10_mturn_acg"])
+        spec.log10_mturn_mcg = fptr(mini["log10_mturn_mcg"])
     if spec.recomb_model:  # wrapper/outputs.py:1526-1537
         out["ionisation_rate_G12"] = np.zeros(shape, np.float32)
         out["mean_free_path"] = np.zeros(shape, np.float32)
@@ -176,12 +184,16 @@ def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion
                                                     np.float32)
     pf = S.PerturbedFieldStruct(density=fptr(density))
     prev = S.IonizedBoxStruct(z_reion=fptr(prev_z_reion), cumulative_recombinations=fptr(prev_nrec))
+    if mini is not None:
+        prev.unnormalised_nion = fptr(mini["prev_nion"])
+        prev.unnormalised_nion_mini = fptr(mini["prev_nion_mini"])
     ts = S.TsBoxStruct(xray_ionised_fraction=fptr(xe), kinetic_temp_neutral=fptr(Tneutral))
     hb = S.HaloBoxStruct(n_ion=fptr(n_ion), whalo_sfr=fptr(whalo_sfr))
     box = S.IonizedBoxStruct(
         neutral_fraction=fptr(out["neutral_fraction"]), z_reion=fptr(out["z_reion"]),
         kinetic_temperature=fptr(out["kinetic_temperature"]),
         unnormalised_nion=fptr(out.get("unnormalised_nion")),
+        unnormalised_nion_mini=fptr(out.get("unnormalised_nion_mini")),
         ionisation_rate_G12=fptr(out.get("ionisation_rate_G12")),
         mean_free_path=fptr(out.get("mean_free_path")),
         cumulative_recombinations=fptr(out.get("cumulative_recombinations")),
@@ -192,8 +204,25 @@ def ionize_grids(spec, density, n_ion=None, xe=None, Tneutral=None, prev_z_reion
     if st:
         raise RuntimeError(f"oracle_ionize_grids status {st}")
     out["mean_f_coll"] = box.mean_f_coll
+    out["mean_f_coll_MINI"] = box.mean_f_coll_MINI
     out["report"] = rep
     return out
+
+
+def mturn_grids(spec, prev_G12, prev_z_reion, J_21_LW, vcb=None):
+    """calculate_mcrit_boxes on numpy arrays -> (log10 M_turn,a, log10 M_turn,m, <a>, <m>)."""
+    lib = load()
+    lib.oracle_mturn_grids.restype = C.c_int
+    lib.oracle_mturn_grids.argtypes = [C.POINTER(S.MturnSpec)] + [S.c_float_p] * 6 + [
+        C.POINTER(C.c_double)] * 2
+    a = np.zeros(J_21_LW.shape, np.float32)
+    m = np.zeros(J_21_LW.shape, np.float32)
+    ave_a, ave_m = C.c_double(), C.c_double()
+    st = lib.oracle_mturn_grids(C.byref(spec), fptr(prev_G12), fptr(prev_z_reion), fptr(J_21_LW),
+                                fptr(vcb), fptr(a), fptr(m), C.byref(ave_a), C.byref(ave_m))
+    if st:
+        raise RuntimeError(f"oracle_mturn_grids status {st}")
+    return a, m, ave_a.value, ave_m.value
 
 
 IC_FIELDS = ("lowres_density", "lowres_vx", "lowres_vy", "lowres_vz", "lowres_vx_2LPT",

@@ -99,6 +99,79 @@ static double eval_table_f(double x, double x_min, double x_width, const float *
     return y_arr[idx] * (1 - interp_point) + y_arr[idx + 1] * (interp_point);
 }
 
+/* interpolation.c:133-157 (a float table read as doubles) */
+static double eval_table2d_f(double x, double y, double x_min, double x_width, double y_min,
+                             double y_width, const float *z_arr, int ny) {
+    int x_idx = (int)floor((x - x_min) / x_width);
+    int y_idx = (int)floor((y - y_min) / y_width);
+    double x_table = x_min + x_width * (double)x_idx;
+    double y_table = y_min + y_width * (double)y_idx;
+    double interp_point_x = (x - x_table) / x_width;
+    double interp_point_y = (y - y_table) / y_width;
+    double left_edge = z_arr[(size_t)x_idx * ny + y_idx] * (1 - interp_point_y) +
+                       z_arr[(size_t)x_idx * ny + y_idx + 1] * (interp_point_y);
+    double right_edge = z_arr[(size_t)(x_idx + 1) * ny + y_idx] * (1 - interp_point_y) +
+                        z_arr[(size_t)(x_idx + 1) * ny + y_idx + 1] * (interp_point_y);
+    return left_edge * (1 - interp_point_x) + right_edge * (interp_point_x);
+}
+
+/* clip_and_get_extrema: IonisationBox.c:668-699 (extrema of the values before the clip) */
+static void clip_extrema(float *grid, int nx, int ny, int nz, double lower_limit,
+                         double upper_limit, double *grid_min, double *grid_max) {
+    const size_t zpad = 2 * (size_t)(nz / 2 + 1);
+    double min_buf = grid[0], max_buf = grid[0];
+#pragma omp parallel for schedule(static) reduction(max : max_buf) reduction(min : min_buf)
+    for (long l = 0; l < (long)nx * ny; l++) {
+        for (int k = 0; k < nz; k++) {
+            float curr = grid[(size_t)l * zpad + k];
+            grid[(size_t)l * zpad + k] = fmaxf(fmin(curr, upper_limit), lower_limit);
+            if (curr < min_buf) min_buf = curr;
+            if (curr > max_buf) max_buf = curr;
+        }
+    }
+    *grid_min = min_buf;
+    *grid_max = max_buf;
+}
+
+/* thermochem.c:281-311 */
+static double lyman_werner_threshold(const c21cm_mturn_spec *m, float z, float J_21_LW, float vcb) {
+    double mcrit_noLW = 3.314e7 * pow(1. + z, -1.5);
+    double f_LW = 1.0 + m->A_LW * pow(J_21_LW, m->BETA_LW);
+    double f_vcb = pow(1.0 + m->A_VCB * vcb / m->sigma_vcb, m->BETA_VCB);
+    return (mcrit_noLW * f_LW * f_vcb);
+}
+static double reionization_feedback(float z, float Gamma_halo_HII, float z_IN) {
+    if (z_IN <= 1e-19) return 1e-40;
+    return 3e9 * pow(2.0 * Gamma_halo_HII, 0.17) * pow((1. + z) / 10, -2.1) *
+           pow(1 - pow((1. + z) / (1. + z_IN), 2.0), 2.5);
+}
+
+/* calculate_mcrit_boxes: IonisationBox.c:403-457 */
+int oracle_mturn_grids(const c21cm_mturn_spec *m, const float *prev_G12, const float *prev_z_reion,
+                       const float *J_21_LW, const float *vcb, float *log10_mturn_acg,
+                       float *log10_mturn_mcg, double *ave_acg, double *ave_mcg) {
+    const long ntot = (long)m->hii_dim * m->hii_dim * m->hii_dim_z;
+    double ave_a = 0., ave_m = 0.;
+    int bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ave_a, ave_m) reduction(| : bad)
+    for (long i = 0; i < ntot; i++) {
+        double Mcrit_RE = reionization_feedback(m->redshift, prev_G12[i],
+                                                m->first_snapshot ? -1.0f : prev_z_reion[i]);
+        double Mcrit_LW =
+            lyman_werner_threshold(m, m->redshift, J_21_LW[i], vcb ? vcb[i] : (float)m->vcb_const);
+        if (Mcrit_LW != Mcrit_LW || Mcrit_LW == 0) bad |= 1;
+        double curr_Mt = log10(fmax(Mcrit_RE, m->mturn_a_nofb));
+        double curr_Mt_MINI = log10(fmax(Mcrit_RE, fmax(Mcrit_LW, m->mturn_m_nofb)));
+        log10_mturn_acg[i] = curr_Mt;
+        log10_mturn_mcg[i] = curr_Mt_MINI;
+        ave_a += curr_Mt;
+        ave_m += curr_Mt_MINI;
+    }
+    *ave_acg = ave_a / ntot;
+    *ave_mcg = ave_m / ntot;
+    return bad ? C21CM_VALUE_ERROR : C21CM_OK;
+}
+
 /* recombinations.c:64-92: row z_ct of the table, natural cubic spline in ln Gamma evaluated
  * the way gsl_interp_cspline does (b and d from the c coefficients, Horner in delta) */
 double oracle_splined_recombination_rate(const double *rr_y, const double *rr_c, double z_eff,
@@ -183,8 +256,13 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
     const int lagrangian = (s->fcoll_mode == C21CM_FCOLL_STARS_GRID);
     const int use_table =
         (s->fcoll_mode == C21CM_FCOLL_TABLE_LINEAR || s->fcoll_mode == C21CM_FCOLL_TABLE_EXP);
-    if (use_table && !s->table_fn) return C21CM_VALUE_ERROR;
+    if (use_table && !s->use_mini_halos && !s->table_fn) return C21CM_VALUE_ERROR;
     if (!lagrangian && !box->unnormalised_nion) return C21CM_VALUE_ERROR;
+    const int mini = s->use_mini_halos;
+    if (mini && (s->fcoll_mode != C21CM_FCOLL_TABLE_EXP || !s->table2d_fn || !s->prev_density ||
+                 !s->log10_mturn_acg || !s->log10_mturn_mcg || !box->unnormalised_nion_mini ||
+                 !prev || !prev->unnormalised_nion || !prev->unnormalised_nion_mini))
+        return C21CM_VALUE_ERROR;
     int status = C21CM_OK;
 
     /* IonisationBox.c:1372-1378 */
@@ -219,6 +297,24 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
         xe_fil = (float *)malloc(sizeof(float) * npad);
     }
     float table[C21CM_NDELTA_TABLE];
+    float *pdelta_unf = NULL, *pdelta_fil = NULL, *mta_unf = NULL, *mta_fil = NULL, *mtm_unf = NULL,
+          *mtm_fil = NULL, *tab2d = NULL;
+    const size_t t2 = (size_t)C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE;
+    if (mini) {
+        pdelta_unf = (float *)malloc(sizeof(float) * npad);
+        pdelta_fil = (float *)malloc(sizeof(float) * npad);
+        mta_unf = (float *)malloc(sizeof(float) * npad);
+        mta_fil = (float *)malloc(sizeof(float) * npad);
+        mtm_unf = (float *)malloc(sizeof(float) * npad);
+        mtm_fil = (float *)malloc(sizeof(float) * npad);
+        tab2d = (float *)malloc(sizeof(float) * 4 * t2); /* acg, mcg, prev acg, prev mcg */
+        /* IonisationBox.c:1493-1509: previous delta clipped like delta; the turnover grids are
+         * transformed as they are */
+        prepare_box(s->prev_density, pdelta_unf, nx, ny, nz, 1., -1, 1e6);
+        prepare_box(s->log10_mturn_mcg, mtm_unf, nx, ny, nz, 1., -INFINITY, INFINITY);
+        prepare_box(s->log10_mturn_acg, mta_unf, nx, ny, nz, 1., -INFINITY, INFINITY);
+    }
+    double last_mean_mini = 0.;
 
     /* IonisationBox.c:1480-1513 */
     prepare_box(pf->density, delta_unf, nx, ny, nz, s->photoncons_adjustment_factor, -1., 1e6);
@@ -242,9 +338,16 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
             status = copy_filter_c2r(xe_unf, xe_fil, s, R_ct, s->hii_filter, 0.);
         if (!status && filter_rec)
             status = copy_filter_c2r(nrec_unf, nrec_fil, s, R_ct, s->hii_filter, 0.);
+        if (!status && mini) {
+            status = copy_filter_c2r(pdelta_unf, pdelta_fil, s, R_ct, s->hii_filter, 0.);
+            if (!status) status = copy_filter_c2r(mtm_unf, mtm_fil, s, R_ct, s->hii_filter, 0.);
+            if (!status) status = copy_filter_c2r(mta_unf, mta_fil, s, R_ct, s->hii_filter, 0.);
+        }
         if (status) break;
 
         double tab_min = 0., tab_width = 1.;
+        double ptab_min = 0., ptab_width = 1., mta_min = 0., mta_width = 1., mtm_min = 0.,
+               mtm_width = 1.;
         if (!lagrangian) {
             /* clip_and_get_extrema(delta_filtered, -1, 1e6): IonisationBox.c:668-699,711-713 */
             double min_buf = delta_fil[0], max_buf = delta_fil[0];
@@ -258,7 +361,32 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                 }
             }
             double min_density = min_buf - 0.001, max_density = max_buf + 0.001;
-            if (use_table) {
+            if (mini) { /* setup_integration_tables with USE_MINI_HALOS: IonisationBox.c:715-761 */
+                double pmin, pmax, amin, amax, mmin, mmax;
+                clip_extrema(pdelta_fil, nx, ny, nz, -1, 1e6, &pmin, &pmax);
+                clip_extrema(mta_fil, nx, ny, nz, 0., 10., &amin, &amax); /* LOG10_MTURN_MAX */
+                clip_extrema(mtm_fil, nx, ny, nz, 0., 10., &mmin, &mmax);
+                pmin -= 0.001;
+                pmax += 0.001;
+                amin = amin * 0.99;
+                amax = amax * 1.01;
+                mmin = mmin * 0.99;
+                mmax = mmax * 1.01;
+                status = s->table2d_fn(R_ct, 0, min_density, max_density, amin, amax, mmin, mmax,
+                                       tab2d, tab2d + t2, s->table2d_user);
+                if (!status && s->need_prev_ion)
+                    status = s->table2d_fn(R_ct, 1, pmin, pmax, amin, amax, mmin, mmax,
+                                           tab2d + 2 * t2, tab2d + 3 * t2, s->table2d_user);
+                if (status) break;
+                tab_min = min_density;
+                tab_width = (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.);
+                ptab_min = pmin;
+                ptab_width = (pmax - pmin) / (C21CM_NDELTA_TABLE - 1.);
+                mta_min = amin;
+                mta_width = (amax - amin) / (C21CM_NMTURN_TABLE - 1.);
+                mtm_min = mmin;
+                mtm_width = (mmax - mmin) / (C21CM_NMTURN_TABLE - 1.);
+            } else if (use_table) {
                 status = s->table_fn(R_ct, min_density, max_density, table, s->table_user);
                 if (status) break;
                 tab_min = min_density;
@@ -267,9 +395,10 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
         }
 
         /* calculate_fcoll_grid: IonisationBox.c:773-962 */
-        double f_coll_total = 0.;
+        double f_coll_total = 0., f_coll_MINI_total = 0.;
         int bad = 0;
-#pragma omp parallel for schedule(static) reduction(+ : f_coll_total) reduction(| : bad)
+        const size_t roff = mini ? (size_t)R_ct * ntot : 0; /* fc_r_idx, :783-784 */
+#pragma omp parallel for schedule(static) reduction(+ : f_coll_total, f_coll_MINI_total) reduction(| : bad)
         for (long l = 0; l < (long)nx * ny; l++) {
             for (int k = 0; k < nz; k++) {
                 const size_t index_f = (size_t)l * zpad + k;
@@ -287,6 +416,47 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                     Splined_Fcoll = stars_fil[index_f];
                 } else {
                     double curr_dens = delta_fil[index_f];
+                    if (mini) { /* :838-936 */
+                        const int ny2 = C21CM_NMTURN_TABLE;
+                        double log10_Mturnover = mta_fil[index_f];
+                        double log10_Mturnover_MINI = mtm_fil[index_f];
+                        double Splined_Fcoll_MINI =
+                            exp(eval_table2d_f(curr_dens, log10_Mturnover_MINI, tab_min, tab_width,
+                                               mtm_min, mtm_width, tab2d + t2, ny2));
+                        double prev_Splined_Fcoll = 0., prev_Splined_Fcoll_MINI = 0.;
+                        if (s->need_prev_ion) {
+                            double prev_dens = pdelta_fil[index_f];
+                            prev_Splined_Fcoll =
+                                exp(eval_table2d_f(prev_dens, log10_Mturnover, ptab_min, ptab_width,
+                                                   mta_min, mta_width, tab2d + 2 * t2, ny2));
+                            prev_Splined_Fcoll_MINI = exp(
+                                eval_table2d_f(prev_dens, log10_Mturnover_MINI, ptab_min, ptab_width,
+                                               mtm_min, mtm_width, tab2d + 3 * t2, ny2));
+                        }
+                        Splined_Fcoll = exp(eval_table2d_f(curr_dens, log10_Mturnover, tab_min,
+                                                           tab_width, mta_min, mta_width, tab2d, ny2));
+                        if (Splined_Fcoll > 1.) Splined_Fcoll = 1.;
+                        if (Splined_Fcoll < 0.) Splined_Fcoll = 1e-40;
+                        if (prev_Splined_Fcoll > 1.) prev_Splined_Fcoll = 1.;
+                        if (prev_Splined_Fcoll < 0.) prev_Splined_Fcoll = 1e-40;
+                        box->unnormalised_nion[roff + index_r] =
+                            prev->unnormalised_nion[roff + index_r] + Splined_Fcoll -
+                            prev_Splined_Fcoll;
+                        if (box->unnormalised_nion[roff + index_r] > 1.)
+                            box->unnormalised_nion[roff + index_r] = 1.;
+                        f_coll_total += box->unnormalised_nion[roff + index_r];
+                        if (Splined_Fcoll_MINI > 1.) Splined_Fcoll_MINI = 1.;
+                        if (Splined_Fcoll_MINI < 0.) Splined_Fcoll_MINI = 1e-40;
+                        if (prev_Splined_Fcoll_MINI > 1.) prev_Splined_Fcoll_MINI = 1.;
+                        if (prev_Splined_Fcoll_MINI < 0.) prev_Splined_Fcoll_MINI = 1e-40;
+                        box->unnormalised_nion_mini[roff + index_r] =
+                            prev->unnormalised_nion_mini[roff + index_r] + Splined_Fcoll_MINI -
+                            prev_Splined_Fcoll_MINI;
+                        if (box->unnormalised_nion_mini[roff + index_r] > 1.)
+                            box->unnormalised_nion_mini[roff + index_r] = 1.;
+                        f_coll_MINI_total += box->unnormalised_nion_mini[roff + index_r];
+                        continue;
+                    }
                     if (s->fcoll_mode == C21CM_FCOLL_ERFC) {
                         Splined_Fcoll =
                             oracle_fgtrm_bias_fast(s->growth_factor, curr_dens, s->sigma_minmass,
@@ -306,19 +476,28 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
             status = C21CM_VALUE_ERROR;
             break;
         }
+        if (isfinite(f_coll_total) == 0 || isfinite(f_coll_MINI_total) == 0) {
+            status = C21CM_INFINITY_OR_NAN_ERROR;
+            break;
+        }
         double f_coll_grid_mean = f_coll_total / ntot;
+        double f_coll_grid_mean_MINI = f_coll_MINI_total / ntot;
         /* IonisationBox.c:1566-1576 */
         if (s->mass_dep_zeta) {
             if (f_coll_grid_mean <= s->f_limit_acg) f_coll_grid_mean = s->f_limit_acg;
+            if (mini && f_coll_grid_mean_MINI <= s->f_limit_mcg) f_coll_grid_mean_MINI = s->f_limit_mcg;
         } else {
             if (f_coll_grid_mean <= FRACT_FLOAT_ERR) f_coll_grid_mean = FRACT_FLOAT_ERR;
         }
         if (report) report->f_coll_grid_mean[R_ct] = f_coll_grid_mean;
+        if (report && mini) report->f_coll_grid_mean_mini[R_ct] = f_coll_grid_mean_MINI;
         last_mean = f_coll_grid_mean;
+        last_mean_mini = f_coll_grid_mean_MINI;
 
         /* find_ionised_regions: IonisationBox.c:1008-1201 */
-        double mean_fix_term_acg = 1.;
+        double mean_fix_term_acg = 1., mean_fix_term_mcg = 1.;
         if (s->fix_mean) mean_fix_term_acg = s->mean_f_coll / f_coll_grid_mean;
+        if (s->fix_mean && mini) mean_fix_term_mcg = s->mean_f_coll_mini / f_coll_grid_mean_MINI;
 #pragma omp parallel for schedule(static)
         for (long l = 0; l < (long)nx * ny; l++) {
             for (int k = 0; k < nz; k++) {
@@ -332,12 +511,17 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                 if (lagrangian)
                     curr_fcoll = stars_fil[index_f];
                 else
-                    curr_fcoll = box->unnormalised_nion[index_r];
+                    curr_fcoll = box->unnormalised_nion[roff + index_r];
                 curr_fcoll = mean_fix_term_acg * curr_fcoll;
                 if (lagrangian) curr_fcoll *= 1 / (s->rhocrit_omb * (1 + curr_dens));
+                double curr_fcoll_mini = 0.; /* :1068-1074 */
+                if (mini)
+                    curr_fcoll_mini = mean_fix_term_mcg * box->unnormalised_nion_mini[roff + index_r];
                 if (s->mass_dep_zeta) {
                     if (curr_fcoll < s->f_limit_acg) curr_fcoll = s->f_limit_acg;
+                    if (mini && curr_fcoll_mini < s->f_limit_mcg) curr_fcoll_mini = s->f_limit_mcg;
                 }
+                const double zeta_m = mini ? s->ion_eff_factor_mini : 0.;
                 if (recomb) { /* :1084-1099 */
                     if (s->cell_recomb)
                         rec = prev->cumulative_recombinations[inhomo ? index_r : 0];
@@ -347,7 +531,8 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                 }
                 xHII_from_xrays = s->use_ts_fluct ? xe_fil[index_f] : 0.;
 
-                if (curr_fcoll * s->ion_eff_factor > (1. - xHII_from_xrays) * (1.0 + rec)) {
+                if (curr_fcoll * s->ion_eff_factor + curr_fcoll_mini * zeta_m >
+                    (1. - xHII_from_xrays) * (1.0 + rec)) {
                     /* first crossing (largest R): Gamma_12 and the mean free path, :1124-1140 */
                     if (recomb && (box->neutral_fraction[index_r] > FRACT_FLOAT_ERR)) {
                         if (lagrangian)
@@ -355,7 +540,9 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                                 s->R[R_ct] * s->gamma_prefactor / (1 + curr_dens) * sfr_fil[index_f];
                         else
                             box->ionisation_rate_G12[index_r] =
-                                s->R[R_ct] * (s->gamma_prefactor * curr_fcoll);
+                                s->R[R_ct] *
+                                (s->gamma_prefactor * curr_fcoll +
+                                 (mini ? s->gamma_prefactor_mini : 0.) * curr_fcoll_mini);
                         if (!s->minimize_memory && box->mean_free_path)
                             box->mean_free_path[index_r] = s->R[R_ct];
                     }
@@ -368,7 +555,7 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                         box->z_reion[index_r] = prev_zre;
                     box->neutral_fraction[index_r] = 0;
                 } else if (R_ct == 0 && (box->neutral_fraction[index_r] > TINY)) {
-                    res_xH = 1. - curr_fcoll * s->ion_eff_factor;
+                    res_xH = 1. - curr_fcoll * s->ion_eff_factor - curr_fcoll_mini * zeta_m;
                     if (!s->minimize_memory) {
                         if (s->use_ts_fluct) {
                             box->kinetic_temperature[index_r] =
@@ -459,8 +646,16 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
             report->mean_f_coll_out = s->fix_mean ? s->mean_f_coll : last_mean;
         }
         box->mean_f_coll = s->fix_mean ? s->mean_f_coll : last_mean;
-        box->mean_f_coll_MINI = 0.;
+        box->mean_f_coll_MINI = !mini ? 0. : (s->fix_mean ? s->mean_f_coll_mini : last_mean_mini);
+        if (report && mini) report->mean_f_coll_mini_out = box->mean_f_coll_MINI;
     }
+    free(pdelta_unf);
+    free(pdelta_fil);
+    free(mta_unf);
+    free(mta_fil);
+    free(mtm_unf);
+    free(mtm_fil);
+    free(tab2d);
 
     free(delta_unf);
     free(delta_fil);
