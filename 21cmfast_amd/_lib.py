@@ -52,6 +52,8 @@ def _declare(lib):
         P(S.IonizeSpec), P(S.PerturbedFieldStruct), P(S.IonizedBoxStruct), P(S.TsBoxStruct),
         P(S.HaloBoxStruct), P(S.IonizedBoxStruct), P(S.IonizeReport), vp,
     ]
+    lib.c21cm_mturn_grids.restype = i32
+    lib.c21cm_mturn_grids.argtypes = [P(S.MturnSpec), vp, vp, vp, vp, vp, vp, P(f64), P(f64), vp]
     lib.c21cm_ionize_shard_radii.restype = i32
     lib.c21cm_ionize_shard_radii.argtypes = [
         P(S.IonizeSpec), i32, i32, P(S.PerturbedFieldStruct), P(S.IonizedBoxStruct),

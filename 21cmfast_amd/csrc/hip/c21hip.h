@@ -344,6 +344,34 @@ int c21hip_ionise_recomb(const c21hip_ionize_args *a, int lagrangian, int inhomo
                          const double *mean_dev, float *xH, float *z_reion,
                          float *kinetic_temperature, float *G12, float *mfp, double *partials,
                          double *sum_out, void *stream);
+/* USE_MINI_HALOS (E-INTEGRAL).  calculate_mcrit_boxes (IonisationBox.c:403-457): dense [N]
+ * device arrays, sums_out[2] = sum of the two log10 grids, *flag_dev set on a NaN/zero threshold.
+ * partials: >= 2 * 2048 doubles. */
+int c21hip_mturn_grids(size_t ntot, int first_snapshot, double redshift, double mturn_a_nofb,
+                       double mturn_m_nofb, double vcb_const, double A_LW, double BETA_LW,
+                       double A_VCB, double BETA_VCB, double sigma_vcb, const float *prev_G12,
+                       const float *prev_z_reion, const float *J_21_LW, const float *vcb,
+                       float *out_a, float *out_m, double *partials, double *sums_out,
+                       int *flag_dev, void *stream);
+/* calculate_fcoll_grid with both populations and the per-radius history (:838-936).  Filtered
+ * grids padded, history / outputs dense; tables_dev = 4 tables of NDELTA x NMTURN floats (acg, mcg,
+ * previous-redshift acg, mcg); ranges = {delta min, width, prev delta min, width, log10 M_turn,a
+ * min, width, log10 M_turn,m min, width}; sums_out[2] = sum f_a, sum f_m. */
+int c21hip_fcoll_mini(int nx, int ny, int nz, int need_prev, const double *ranges,
+                      const float *delta_fil, const float *pdelta_fil, const float *mta_fil,
+                      const float *mtm_fil, const float *tables_dev, const float *prev_nion,
+                      const float *prev_mini, float *nion_out, float *mini_out, double *partials,
+                      double *sums_out, void *stream);
+/* find_ionised_regions with the two-population barrier (:1068-1200), recombinations optional */
+int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int inhomo, int cell_recomb,
+                       double R, double gamma_prefactor, double gamma_prefactor_mini,
+                       double ion_eff_mini, double f_limit_mcg, double mean_f_coll_mini,
+                       const float *delta_fil, const float *nion_dense, const float *mini_dense,
+                       const float *xe_fil, const float *nrec_fil, const float *prev_nrec,
+                       const float *density, const float *prev_z_reion,
+                       const float *kinetic_temp_neutral, const double *mean_a_dev,
+                       const double *mean_m_dev, float *xH, float *z_reion,
+                       float *kinetic_temperature, float *G12, float *mfp, void *stream);
 /* set_recombination_rates, inhomogeneous model (IonisationBox.c:1277-1339); rate_scale =
  * fabs_dtdz * dz; rr tables on the device */
 int c21hip_recomb_rates(const float *density, const float *G12, const float *xH,

@@ -1385,3 +1385,343 @@ extern "C" int c21hip_any_nonzero(const float *a, size_t n, int *flag_host, void
     if ((st = c21hip_d2h(flag_host, flag, sizeof(int), stream))) return st;
     return c21hip_sync(stream);
 }
+
+// ======================================================================================
+// USE_MINI_HALOS (E-INTEGRAL): turnover-mass boxes, two-population f_coll with the per-radius
+// history, two-population barrier.  reference: IonisationBox.c:403-457, 838-936, 1068-1200.
+// The branch is bound by its four filtered grids per radius, not by these sweeps; they are
+// written for parity first (double exp, one cell per thread item, no LDS tables: the four
+// 400 x 50 tables are 320 kB and stay in L2).
+// ======================================================================================
+namespace {
+struct MturnParams {
+    size_t ntot;
+    int first_snapshot;
+    float z;
+    double mturn_a_nofb, mturn_m_nofb, vcb_const;
+    double A_LW, BETA_LW, A_VCB, BETA_VCB, sigma_vcb;
+};
+
+// calculate_mcrit_boxes (:403-457) with thermochem.c:281-311 inlined
+__global__ void __launch_bounds__(kBlock)
+mturn_kernel(MturnParams m, const float *__restrict__ prev_G12,
+             const float *__restrict__ prev_z_reion, const float *__restrict__ J_21_LW,
+             const float *__restrict__ vcb, float *__restrict__ out_a, float *__restrict__ out_m,
+             double *__restrict__ partials_a, double *__restrict__ partials_m,
+             int *__restrict__ flag) {
+    double acc_a = 0., acc_m = 0.;
+    int bad = 0;
+    const double zp1 = 1. + (double)m.z;
+    const double mcrit_noLW = 3.314e7 * pow(zp1, -1.5);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < m.ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const float z_IN = m.first_snapshot ? -1.f : prev_z_reion[i];
+        double Mcrit_RE = 1e-40;
+        if (!((double)z_IN <= 1e-19))
+            Mcrit_RE = 3e9 * pow(2.0 * (double)prev_G12[i], 0.17) * pow(zp1 / 10, -2.1) *
+                       pow(1 - pow(zp1 / (1. + (double)z_IN), 2.0), 2.5);
+        const float v = vcb ? vcb[i] : (float)m.vcb_const;
+        const double f_LW = 1.0 + m.A_LW * pow((double)J_21_LW[i], m.BETA_LW);
+        const double f_vcb = pow(1.0 + m.A_VCB * (double)v / m.sigma_vcb, m.BETA_VCB);
+        const double Mcrit_LW = mcrit_noLW * f_LW * f_vcb;
+        if (Mcrit_LW != Mcrit_LW || Mcrit_LW == 0) bad = 1;
+        const double curr_Mt = log10(fmax(Mcrit_RE, m.mturn_a_nofb));
+        const double curr_Mt_MINI = log10(fmax(Mcrit_RE, fmax(Mcrit_LW, m.mturn_m_nofb)));
+        out_a[i] = (float)curr_Mt;
+        out_m[i] = (float)curr_Mt_MINI;
+        acc_a += curr_Mt;
+        acc_m += curr_Mt_MINI;
+    }
+    if (bad) atomicOr(flag, 1);
+    block_sum_to(acc_a, partials_a);
+    __syncthreads();
+    block_sum_to(acc_m, partials_m);
+}
+
+// interpolation.c:133-157
+__device__ __forceinline__ double eval_table2d_f(double x, double y, double x_min, double x_width,
+                                                 double y_min, double y_width,
+                                                 const float *__restrict__ z_arr) {
+    const int x_idx = (int)floor((x - x_min) / x_width);
+    const int y_idx = (int)floor((y - y_min) / y_width);
+    const double x_table = x_min + x_width * (double)x_idx;
+    const double y_table = y_min + y_width * (double)y_idx;
+    const double px = (x - x_table) / x_width, py = (y - y_table) / y_width;
+    const float *r0 = z_arr + (size_t)x_idx * C21CM_NMTURN_TABLE + y_idx;
+    const float *r1 = r0 + C21CM_NMTURN_TABLE;
+    const double left_edge = (double)r0[0] * (1 - py) + (double)r0[1] * py;
+    const double right_edge = (double)r1[0] * (1 - py) + (double)r1[1] * py;
+    return left_edge * (1 - px) + right_edge * px;
+}
+
+struct MiniFcollParams {
+    size_t nitems;
+    int nz_items, zpad_items;
+    int need_prev;
+    double tab_min, tab_width, ptab_min, ptab_width;
+    double mta_min, mta_width, mtm_min, mtm_width;
+};
+
+__device__ __forceinline__ double clamp_fcoll(double f) {  // :904-907
+    if (f > 1.) f = 1.;
+    if (f < 0.) f = 1e-40;
+    return f;
+}
+
+// calculate_fcoll_grid with need_minihalo_nion (:838-936): tables = acg | mcg | prev acg | prev mcg
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+fcoll_mini_kernel(MiniFcollParams p, const float *__restrict__ delta_fil,
+                  const float *__restrict__ pdelta_fil, const float *__restrict__ mta_fil,
+                  const float *__restrict__ mtm_fil, const float *__restrict__ tables,
+                  const float *__restrict__ prev_nion, const float *__restrict__ prev_mini,
+                  float *__restrict__ nion_out, float *__restrict__ mini_out,
+                  double *__restrict__ partials_a, double *__restrict__ partials_m) {
+    constexpr size_t t2 = (size_t)C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE;
+    double acc_a = 0., acc_m = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < p.nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const auto ci = cell_index<VEC>(i, p.nz_items, p.zpad_items);
+        const auto dl = Pack<VEC>::load(delta_fil, ci.padded);
+        const auto ma = Pack<VEC>::load(mta_fil, ci.padded);
+        const auto mm = Pack<VEC>::load(mtm_fil, ci.padded);
+        const auto hn = Pack<VEC>::load(prev_nion, ci.dense);
+        const auto hm = Pack<VEC>::load(prev_mini, ci.dense);
+        Pack<VEC> pd, oa, om;
+        if (p.need_prev) pd = Pack<VEC>::load(pdelta_fil, ci.padded);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const double curr_dens = (double)clip_delta_eulerian(dl.v[e]);
+            // clip_and_get_extrema(., 0, LOG10_MTURN_MAX): :722-725
+            const double l10a = (double)fmaxf((float)fmin((double)ma.v[e], 10.), 0.f);
+            const double l10m = (double)fmaxf((float)fmin((double)mm.v[e], 10.), 0.f);
+            double f_m = exp(eval_table2d_f(curr_dens, l10m, p.tab_min, p.tab_width, p.mtm_min,
+                                            p.mtm_width, tables + t2));
+            double pf_a = 0., pf_m = 0.;
+            if (p.need_prev) {
+                const double prev_dens = (double)fmaxf((float)fmin((double)pd.v[e], 1e6), -1.f);
+                pf_a = exp(eval_table2d_f(prev_dens, l10a, p.ptab_min, p.ptab_width, p.mta_min,
+                                          p.mta_width, tables + 2 * t2));
+                pf_m = exp(eval_table2d_f(prev_dens, l10m, p.ptab_min, p.ptab_width, p.mtm_min,
+                                          p.mtm_width, tables + 3 * t2));
+            }
+            double f_a = exp(eval_table2d_f(curr_dens, l10a, p.tab_min, p.tab_width, p.mta_min,
+                                            p.mta_width, tables));
+            f_a = clamp_fcoll(f_a);
+            pf_a = clamp_fcoll(pf_a);
+            float va = (float)((double)hn.v[e] + f_a - pf_a);
+            if ((double)va > 1.) va = 1.f;
+            f_m = clamp_fcoll(f_m);
+            pf_m = clamp_fcoll(pf_m);
+            float vm = (float)((double)hm.v[e] + f_m - pf_m);
+            if ((double)vm > 1.) vm = 1.f;
+            oa.v[e] = va;
+            om.v[e] = vm;
+            acc_a += (double)va;
+            acc_m += (double)vm;
+        }
+        oa.store(nion_out, ci.dense);
+        om.store(mini_out, ci.dense);
+    }
+    block_sum_to(acc_a, partials_a);
+    __syncthreads();
+    block_sum_to(acc_m, partials_m);
+}
+
+struct MiniIoniseParams {
+    IoniseParams ip;
+    int recomb, inhomo, cell_recomb, ts;
+    double R, gamma_prefactor, gamma_prefactor_mini;
+    double ion_eff_mini, f_limit_mcg, mean_f_coll_mini;
+};
+
+// find_ionised_regions with both populations (:1031-1200); recombinations optional
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+ionise_mini_kernel(MiniIoniseParams q, const float *__restrict__ delta_fil,
+                   const float *__restrict__ nion_dense, const float *__restrict__ mini_dense,
+                   const float *__restrict__ xe_fil, const float *__restrict__ nrec_fil,
+                   const float *__restrict__ prev_nrec, const float *__restrict__ density,
+                   const float *__restrict__ prev_z_reion, const float *__restrict__ Tneutral,
+                   const double *__restrict__ mean_a_dev, const double *__restrict__ mean_m_dev,
+                   float *__restrict__ xH, float *__restrict__ z_reion, float *__restrict__ Tk,
+                   float *__restrict__ G12, float *__restrict__ mfp) {
+    const c21hip_ionize_args &a = q.ip.a;
+    const bool LAST = (a.r_index == 0);
+    const double fix_a = a.fix_mean ? a.mean_f_coll / *mean_a_dev : 1.;
+    const double fix_m = a.fix_mean ? q.mean_f_coll_mini / *mean_m_dev : 1.;
+    const float z_now = (float)a.redshift;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < q.ip.nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const auto ci = cell_index<VEC>(i, q.ip.nz_items, q.ip.zpad_items);
+        const auto fa = Pack<VEC>::load(nion_dense, ci.dense);
+        const auto fm = Pack<VEC>::load(mini_dense, ci.dense);
+        Pack<VEC> dl, xe, de, nr;
+        if (!LAST) dl = Pack<VEC>::load(delta_fil, ci.padded);
+        if (LAST || !a.minimize_memory) de = Pack<VEC>::load(density, ci.dense);
+        if (q.ts) xe = Pack<VEC>::load(xe_fil, ci.padded);
+        if (q.recomb) {
+            if (!q.cell_recomb)
+                nr = Pack<VEC>::load(nrec_fil, ci.padded);
+            else if (q.inhomo)
+                nr = Pack<VEC>::load(prev_nrec, ci.dense);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const size_t idx = ci.dense * VEC + e;
+            const double curr_dens = LAST ? (double)de.v[e] * a.photoncons_factor
+                                          : (double)clip_delta_eulerian(dl.v[e]);
+            double curr_fcoll = fix_a * (double)fa.v[e];
+            double curr_fcoll_mini = fix_m * (double)fm.v[e];
+            if (a.mass_dep_zeta) {
+                if (curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
+                if (curr_fcoll_mini < q.f_limit_mcg) curr_fcoll_mini = q.f_limit_mcg;
+            }
+            double rec = 0.;
+            if (q.recomb) {
+                if (!q.cell_recomb)
+                    rec = (double)fmaxf(nr.v[e], 0.f);
+                else
+                    rec = q.inhomo ? (double)nr.v[e] : (double)prev_nrec[0];
+                rec /= (1. + curr_dens);
+            }
+            const double x_e = q.ts ? (double)clip_xe(xe.v[e]) : 0.;
+            if (curr_fcoll * a.ion_eff_factor + curr_fcoll_mini * q.ion_eff_mini >
+                (1. - x_e) * (1.0 + rec)) {
+                if (q.recomb && (double)xH[idx] > kFractFloatErr) {  // first crossing
+                    G12[idx] = (float)(q.R * (q.gamma_prefactor * curr_fcoll +
+                                              q.gamma_prefactor_mini * curr_fcoll_mini));
+                    if (mfp) mfp[idx] = (float)q.R;
+                }
+                const float pz = a.first_snapshot ? -1.f : prev_z_reion[idx];
+                z_reion[idx] = (pz < 0.f) ? z_now : pz;
+                xH[idx] = 0.f;
+            } else if (LAST) {
+                if ((double)xH[idx] > kTiny) {
+                    double res_xH =
+                        1. - curr_fcoll * a.ion_eff_factor - curr_fcoll_mini * q.ion_eff_mini;
+                    if (!a.minimize_memory) {
+                        const float T_HI =
+                            q.ts ? Tneutral[idx]
+                                 : (float)(a.TK_nofluct * (1 + a.adia_TK_term * (double)de.v[e]));
+                        Tk[idx] = partially_ionized_T(T_HI, (float)res_xH, (float)a.T_re);
+                    }
+                    res_xH -= x_e;
+                    if (res_xH < 0)
+                        res_xH = 0;
+                    else if (res_xH > 1)
+                        res_xH = 1;
+                    xH[idx] = (float)res_xH;
+                }
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int c21hip_mturn_grids(size_t ntot, int first_snapshot, double redshift,
+                                  double mturn_a_nofb, double mturn_m_nofb, double vcb_const,
+                                  double A_LW, double BETA_LW, double A_VCB, double BETA_VCB,
+                                  double sigma_vcb, const float *prev_G12,
+                                  const float *prev_z_reion, const float *J_21_LW,
+                                  const float *vcb, float *out_a, float *out_m, double *partials,
+                                  double *sums_out, int *flag_dev, void *stream) {
+    MturnParams m;
+    m.ntot = ntot;
+    m.first_snapshot = first_snapshot;
+    m.z = (float)redshift;  // consts->redshift reaches both thresholds as a float argument
+    m.mturn_a_nofb = mturn_a_nofb;
+    m.mturn_m_nofb = mturn_m_nofb;
+    m.vcb_const = vcb_const;
+    m.A_LW = A_LW;
+    m.BETA_LW = BETA_LW;
+    m.A_VCB = A_VCB;
+    m.BETA_VCB = BETA_VCB;
+    m.sigma_vcb = sigma_vcb;
+    const int blocks = grid_for(ntot);
+    hipLaunchKernelGGL(mturn_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, m,
+                       prev_G12, prev_z_reion, J_21_LW, vcb, out_a, out_m, partials,
+                       partials + kMaxBlocks, flag_dev);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, blocks, 0, sums_out);
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials + kMaxBlocks, blocks, 0, sums_out + 1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_fcoll_mini(int nx, int ny, int nz, int need_prev, const double *ranges,
+                                 const float *delta_fil, const float *pdelta_fil,
+                                 const float *mta_fil, const float *mtm_fil,
+                                 const float *tables_dev, const float *prev_nion,
+                                 const float *prev_mini, float *nion_out, float *mini_out,
+                                 double *partials, double *sums_out, void *stream) {
+    const int vec = (nz % 2 == 0) ? 2 : 1;
+    const int zpad = 2 * (nz / 2 + 1);
+    MiniFcollParams p;
+    p.nz_items = nz / vec;
+    p.zpad_items = zpad / vec;
+    p.nitems = (size_t)nx * ny * p.nz_items;
+    p.need_prev = need_prev;
+    p.tab_min = ranges[0], p.tab_width = ranges[1];
+    p.ptab_min = ranges[2], p.ptab_width = ranges[3];
+    p.mta_min = ranges[4], p.mta_width = ranges[5];
+    p.mtm_min = ranges[6], p.mtm_width = ranges[7];
+    const int blocks = grid_for(p.nitems);
+    if (vec == 2)
+        hipLaunchKernelGGL(fcoll_mini_kernel<2>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           p, delta_fil, pdelta_fil, mta_fil, mtm_fil, tables_dev, prev_nion,
+                           prev_mini, nion_out, mini_out, partials, partials + kMaxBlocks);
+    else
+        hipLaunchKernelGGL(fcoll_mini_kernel<1>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           p, delta_fil, pdelta_fil, mta_fil, mtm_fil, tables_dev, prev_nion,
+                           prev_mini, nion_out, mini_out, partials, partials + kMaxBlocks);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, blocks, 0, sums_out);
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials + kMaxBlocks, blocks, 0, sums_out + 1);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int inhomo,
+                                  int cell_recomb, double R, double gamma_prefactor,
+                                  double gamma_prefactor_mini, double ion_eff_mini,
+                                  double f_limit_mcg, double mean_f_coll_mini,
+                                  const float *delta_fil, const float *nion_dense,
+                                  const float *mini_dense, const float *xe_fil,
+                                  const float *nrec_fil, const float *prev_nrec,
+                                  const float *density, const float *prev_z_reion,
+                                  const float *kinetic_temp_neutral, const double *mean_a_dev,
+                                  const double *mean_m_dev, float *xH, float *z_reion,
+                                  float *kinetic_temperature, float *G12, float *mfp,
+                                  void *stream) {
+    const int vec = (a->nz % 2 == 0) ? 2 : 1;
+    MiniIoniseParams q;
+    q.ip = make_params(a, vec);
+    q.recomb = recomb;
+    q.inhomo = inhomo;
+    q.cell_recomb = cell_recomb;
+    q.ts = a->use_ts_fluct;
+    q.R = R;
+    q.gamma_prefactor = gamma_prefactor;
+    q.gamma_prefactor_mini = gamma_prefactor_mini;
+    q.ion_eff_mini = ion_eff_mini;
+    q.f_limit_mcg = f_limit_mcg;
+    q.mean_f_coll_mini = mean_f_coll_mini;
+    const int blocks = grid_for(q.ip.nitems);
+    if (vec == 2)
+        hipLaunchKernelGGL((ionise_mini_kernel<2>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, q, delta_fil, nion_dense, mini_dense, xe_fil,
+                           nrec_fil, prev_nrec, density, prev_z_reion, kinetic_temp_neutral,
+                           mean_a_dev, mean_m_dev, xH, z_reion, kinetic_temperature, G12, mfp);
+    else
+        hipLaunchKernelGGL((ionise_mini_kernel<1>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, q, delta_fil, nion_dense, mini_dense, xe_fil,
+                           nrec_fil, prev_nrec, density, prev_z_reion, kinetic_temp_neutral,
+                           mean_a_dev, mean_m_dev, xH, z_reion, kinetic_temperature, G12, mfp);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -73,7 +73,26 @@ enum {
     WS_SH_XH,
     WS_SH_ZRE,
     WS_SH_G12,
-    WS_SH_MFP
+    WS_SH_MFP,
+    /* USE_MINI_HALOS: previous delta and the two turnover-mass grids (spectra, scratch, filtered),
+     * staged inputs, 2-D tables, per-radius f_coll history in and out */
+    WS_MINI_PD_UNF = 180,
+    WS_MINI_PD_WORK,
+    WS_MINI_PD_FIL,
+    WS_MINI_MTA_UNF,
+    WS_MINI_MTA_WORK,
+    WS_MINI_MTA_FIL,
+    WS_MINI_MTM_UNF,
+    WS_MINI_MTM_WORK,
+    WS_MINI_MTM_FIL,
+    WS_MINI_PDENS,
+    WS_MINI_MTA,
+    WS_MINI_MTM,
+    WS_MINI_TABLES,
+    WS_MINI_HIST_A,
+    WS_MINI_HIST_M,
+    WS_MINI_OUT_A,
+    WS_MINI_OUT_M
 };
 
 #define MAX_COPYBACK 12
@@ -91,7 +110,13 @@ typedef struct {
 #define SC_XHSUM (SC_MINMAX + 4) /* two (min, max) pairs: the table loop is double-buffered */
 #define SC_FLAG (SC_XHSUM + 1) /* an int stored in a double-sized cell */
 #define SC_G12SUM (SC_FLAG + 1)
-#define SC_COUNT (SC_G12SUM + 1)
+/* USE_MINI_HALOS: sums / means of the molecularly cooled f_coll per radius, extrema of the
+ * previous delta and the two turnover grids, scratch pair of a two-sum reduction */
+#define SC_SUMS_M (SC_G12SUM + 1)
+#define SC_MEANS_M (SC_SUMS_M + C21CM_MAX_RADII)
+#define SC_MINMAX_M (SC_MEANS_M + C21CM_MAX_RADII)
+#define SC_PAIR (SC_MINMAX_M + 6)
+#define SC_COUNT (SC_PAIR + 2)
 
 #define TRY(expr)                   \
     do {                            \
@@ -179,7 +204,19 @@ static int validate_spec(const c21cm_ionize_spec *s, const PerturbedField *pf,
         c21hip_set_error("ionize: unknown fcoll_mode %d", s->fcoll_mode);
         return C21CM_VALUE_ERROR;
     }
-    if (s->fcoll_mode >= C21CM_FCOLL_TABLE_LINEAR && !s->table_fn) {
+    if (s->use_mini_halos) {
+        if (s->fcoll_mode != C21CM_FCOLL_TABLE_EXP || !s->table2d_fn) {
+            c21hip_set_error("ionize: USE_MINI_HALOS runs on the E-INTEGRAL tables (fcoll_mode "
+                             "TABLE_EXP) and needs table2d_fn");
+            return C21CM_VALUE_ERROR;
+        }
+        if (!s->prev_density || !s->log10_mturn_acg || !s->log10_mturn_mcg ||
+            !box->unnormalised_nion_mini) {
+            c21hip_set_error("ionize: USE_MINI_HALOS needs prev_density, the two log10 M_turn "
+                             "grids and IonizedBox.unnormalised_nion_mini");
+            return C21CM_VALUE_ERROR;
+        }
+    } else if (s->fcoll_mode >= C21CM_FCOLL_TABLE_LINEAR && !s->table_fn) {
         c21hip_set_error("ionize: TABLE fcoll_mode needs table_fn");
         return C21CM_VALUE_ERROR;
     }
@@ -268,6 +305,11 @@ typedef struct {
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
     float *eul_xe[2];    /* dense x_e(R) of the Eulerian mask path (spin-temperature runs) */
+    /* USE_MINI_HALOS */
+    int mini;
+    float *pd_unf, *pd_work, *pd_fil, *mta_unf, *mta_work, *mta_fil, *mtm_unf, *mtm_work, *mtm_fil;
+    const float *prev_density, *mta_dense, *mtm_dense, *hist_a, *hist_m;
+    float *mini_tables, *nion_all, *mini_all;
     int eul_mask;        /* Eulerian models on the native passes: radii > 0
                           * run pass Z fused with f_coll (or its extrema) and only update the
                           * first-crossing mask */
@@ -330,7 +372,22 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->fused = c->native && c->lagrangian && !c->recomb &&
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
-    c->eul_mask = c->native && !c->lagrangian && !c->recomb;
+    c->mini = s->use_mini_halos;
+    c->eul_mask = c->native && !c->lagrangian && !c->recomb && !c->mini;
+    if (c->mini) { /* four filtered grids per radius and the 2-D tables: the unfused sequence */
+        const int slots[9] = {WS_MINI_PD_UNF, WS_MINI_PD_WORK, WS_MINI_PD_FIL,
+                              WS_MINI_MTA_UNF, WS_MINI_MTA_WORK, WS_MINI_MTA_FIL,
+                              WS_MINI_MTM_UNF, WS_MINI_MTM_WORK, WS_MINI_MTM_FIL};
+        float **dst[9] = {&c->pd_unf, &c->pd_work, &c->pd_fil, &c->mta_unf, &c->mta_work,
+                          &c->mta_fil, &c->mtm_unf, &c->mtm_work, &c->mtm_fil};
+        for (int i = 0; i < 9; i++) {
+            if (!c->native && i % 3 == 1) continue; /* split-layout scratch */
+            if (!(*dst[i] = (float *)c21hip_ws(slots[i], gbytes))) return C21CM_MEMORY_ALLOC_ERROR;
+        }
+        c->mini_tables = (float *)c21hip_ws(
+            WS_MINI_TABLES, 4 * sizeof(float) * C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE);
+        if (!c->mini_tables) return C21CM_MEMORY_ALLOC_ERROR;
+    }
     if (c->recomb && c->lagrangian) {
         c->sfr_unf = (float *)c21hip_ws(WS_SFR_UNF, gbytes);
         c->sfr_fil = (float *)c21hip_ws(WS_SFR_FIL, gbytes);
@@ -403,7 +460,23 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             c->Tk = stage_inout(WS_TK, box->kinetic_temperature, dbytes, 1, &c->cb, stream,
                                 &status);
     }
-    if (!c->lagrangian)
+    if (c->mini) {
+        if (!prev || !prev->unnormalised_nion || !prev->unnormalised_nion_mini) {
+            c21hip_set_error("ionize: USE_MINI_HALOS needs the previous box's unnormalised_nion "
+                             "and unnormalised_nion_mini histories");
+            return C21CM_VALUE_ERROR;
+        }
+        const size_t hbytes = dbytes * (size_t)s->n_radii; /* one grid per radius (:783-784) */
+        c->prev_density = stage_in(WS_MINI_PDENS, s->prev_density, dbytes, stream, &status);
+        c->mta_dense = stage_in(WS_MINI_MTA, s->log10_mturn_acg, dbytes, stream, &status);
+        c->mtm_dense = stage_in(WS_MINI_MTM, s->log10_mturn_mcg, dbytes, stream, &status);
+        c->hist_a = stage_in(WS_MINI_HIST_A, prev->unnormalised_nion, hbytes, stream, &status);
+        c->hist_m = stage_in(WS_MINI_HIST_M, prev->unnormalised_nion_mini, hbytes, stream, &status);
+        c->nion_all = stage_inout(WS_MINI_OUT_A, box->unnormalised_nion, hbytes, 0, &c->cb, stream,
+                                  &status);
+        c->mini_all = stage_inout(WS_MINI_OUT_M, box->unnormalised_nion_mini, hbytes, 0, &c->cb,
+                                  stream, &status);
+    } else if (!c->lagrangian)
         c->nion_dense = stage_inout(WS_NION_DENSE, box->unnormalised_nion, dbytes, 0, &c->cb,
                                     stream, &status);
     if (c->recomb) {
@@ -514,6 +587,11 @@ static int preloop(ion_ctx *c) {
     if (c->recomb && c->lagrangian)
         TRY(prepare_grid(c, c->whalo_sfr, c->sfr_unf, c->sfr_fil, 1., 0., 1e20));
     if (c->filter_rec) TRY(prepare_grid(c, c->prev_nrec, c->nrec_unf, c->nrec_fil, 1., 0., 1e20));
+    if (c->mini) { /* :1493-1509: the turnover grids are transformed unclipped */
+        TRY(prepare_grid(c, c->prev_density, c->pd_unf, c->pd_fil, 1., -1., 1e6));
+        TRY(prepare_grid(c, c->mtm_dense, c->mtm_unf, c->mtm_fil, 1., -INFINITY, INFINITY));
+        TRY(prepare_grid(c, c->mta_dense, c->mta_unf, c->mta_fil, 1., -INFINITY, INFINITY));
+    }
 done:
     return status;
 }
@@ -715,6 +793,79 @@ static int eul_xe_buffers(ion_ctx *c) {
     return (c->eul_xe[0] && c->eul_xe[1]) ? 0 : C21CM_MEMORY_ALLOC_ERROR;
 }
 
+/* One radius with USE_MINI_HALOS (delta, x_e and N_rec are already filtered): the previous
+ * delta and the two turnover grids, extrema of all four, the 2-D tables of this (and the
+ * previous) redshift from the host callback, both f_coll grids with their history, the
+ * two-population barrier.  reference: IonisationBox.c:595-603,715-761,838-936,1068-1200 */
+static int mini_radius(ion_ctx *c, int R_ct, const c21hip_ionize_args *args, int apply, float R) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    const size_t t2 = (size_t)C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE;
+    const size_t roff = (size_t)R_ct * c->ntot;
+    double mm[8];
+    float *tables = (float *)malloc(sizeof(float) * 4 * t2);
+    if (!tables) return C21CM_MEMORY_ALLOC_ERROR;
+    TRY(filter_to_real(c, c->pd_unf, c->pd_work, c->pd_fil, s->hii_filter, R, 0.f, apply));
+    TRY(filter_to_real(c, c->mtm_unf, c->mtm_work, c->mtm_fil, s->hii_filter, R, 0.f, apply));
+    TRY(filter_to_real(c, c->mta_unf, c->mta_work, c->mta_fil, s->hii_filter, R, 0.f, apply));
+    TRY(c21hip_clip_minmax(c->delta_fil, c->nx, c->ny, c->nz, c->partials, c->scalars + SC_MINMAX,
+                           c->stream));
+    TRY(c21hip_clip_minmax(c->pd_fil, c->nx, c->ny, c->nz, c->partials, c->scalars + SC_MINMAX_M,
+                           c->stream));
+    TRY(c21hip_clip_minmax(c->mta_fil, c->nx, c->ny, c->nz, c->partials,
+                           c->scalars + SC_MINMAX_M + 2, c->stream));
+    TRY(c21hip_clip_minmax(c->mtm_fil, c->nx, c->ny, c->nz, c->partials,
+                           c->scalars + SC_MINMAX_M + 4, c->stream));
+    TRY(c21hip_d2h(mm, c->scalars + SC_MINMAX, 2 * sizeof(double), c->stream));
+    TRY(c21hip_d2h(mm + 2, c->scalars + SC_MINMAX_M, 6 * sizeof(double), c->stream));
+    TRY(c21hip_sync(c->stream));
+    {
+        /* setup_integration_tables: margins of :712-713,735-741 */
+        const double dmin = mm[0] - 0.001, dmax = mm[1] + 0.001;
+        const double pmin = mm[2] - 0.001, pmax = mm[3] + 0.001;
+        const double amin = mm[4] * 0.99, amax = mm[5] * 1.01;
+        const double mmin = mm[6] * 0.99, mmax = mm[7] * 1.01;
+        int tst = s->table2d_fn(R_ct, 0, dmin, dmax, amin, amax, mmin, mmax, tables, tables + t2,
+                                s->table2d_user);
+        if (!tst && s->need_prev_ion)
+            tst = s->table2d_fn(R_ct, 1, pmin, pmax, amin, amax, mmin, mmax, tables + 2 * t2,
+                                tables + 3 * t2, s->table2d_user);
+        if (tst) {
+            c21hip_set_error("ionize: table2d_fn failed with status %d at radius %d", tst, R_ct);
+            status = tst;
+            goto done;
+        }
+        const double ranges[8] = {dmin, (dmax - dmin) / (C21CM_NDELTA_TABLE - 1.),
+                                  pmin, (pmax - pmin) / (C21CM_NDELTA_TABLE - 1.),
+                                  amin, (amax - amin) / (C21CM_NMTURN_TABLE - 1.),
+                                  mmin, (mmax - mmin) / (C21CM_NMTURN_TABLE - 1.)};
+        TRY(c21hip_h2d(c->mini_tables, tables, sizeof(float) * (s->need_prev_ion ? 4 : 2) * t2,
+                       c->stream));
+        TRY(c21hip_sync(c->stream)); /* `tables` is freed below */
+        TRY(c21hip_fcoll_mini(c->nx, c->ny, c->nz, s->need_prev_ion, ranges, c->delta_fil,
+                              c->pd_fil, c->mta_fil, c->mtm_fil, c->mini_tables, c->hist_a + roff,
+                              c->hist_m + roff, c->nion_all + roff, c->mini_all + roff, c->partials,
+                              c->scalars + SC_PAIR, c->stream));
+    }
+    TRY(c21hip_d2d(c->scalars + SC_SUMS + R_ct, c->scalars + SC_PAIR, sizeof(double), c->stream));
+    TRY(c21hip_d2d(c->scalars + SC_SUMS_M + R_ct, c->scalars + SC_PAIR + 1, sizeof(double),
+                   c->stream));
+    TRY(c21hip_finish_mean(c->scalars + SC_SUMS + R_ct, (double)c->ntot, s->mass_dep_zeta,
+                           s->f_limit_acg, c->scalars + SC_MEANS + R_ct, c->stream));
+    TRY(c21hip_finish_mean(c->scalars + SC_SUMS_M + R_ct, (double)c->ntot, s->mass_dep_zeta,
+                           s->f_limit_mcg, c->scalars + SC_MEANS_M + R_ct, c->stream));
+    TRY(c21hip_ionise_mini(args, c->recomb, c->inhomo, s->cell_recomb, s->R[R_ct],
+                           s->gamma_prefactor, s->gamma_prefactor_mini, s->ion_eff_factor_mini,
+                           s->f_limit_mcg, s->mean_f_coll_mini, c->delta_fil,
+                           c->nion_all + roff, c->mini_all + roff, c->xe_fil, c->nrec_fil,
+                           c->prev_nrec, c->density, c->prev_zre, c->Tneutral,
+                           c->scalars + SC_MEANS + R_ct, c->scalars + SC_MEANS_M + R_ct, c->xH,
+                           c->zre, c->Tk, c->G12, c->mfp, c->stream));
+done:
+    free(tables);
+    return status;
+}
+
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -809,6 +960,8 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                 partials, sum_dev, c->stream));
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
+    } else if (c->mini) {
+        TRY(mini_radius(c, R_ct, &args, apply, R));
     } else {
         double tab_min = 0., tab_width = 1.;
         if (s->fcoll_mode >= C21CM_FCOLL_TABLE_LINEAR) {
@@ -1038,11 +1191,17 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
         const int last = s->r_lowest < s->n_radii ? s->r_lowest : s->n_radii - 1;
         const double mean_out = s->fix_mean ? s->mean_f_coll : means[last];
         box->mean_f_coll = mean_out; /* IonisationBox.c:1623-1628 */
-        box->mean_f_coll_MINI = 0.;
+        const double *means_m = host_sc + (SC_MEANS_M - SC_SUMS);
+        const double mean_m_out =
+            !c->mini ? 0. : (s->fix_mean ? s->mean_f_coll_mini : means_m[last]);
+        box->mean_f_coll_MINI = mean_m_out;
         if (report) {
             for (int r = 0; r < s->n_radii; r++) report->f_coll_grid_mean[r] = means[r];
             report->global_xH = global_xH;
             report->mean_f_coll_out = mean_out;
+            if (c->mini)
+                for (int r = 0; r < s->n_radii; r++) report->f_coll_grid_mean_mini[r] = means_m[r];
+            report->mean_f_coll_mini_out = mean_m_out;
         }
     }
 done:
@@ -1140,6 +1299,13 @@ done:
 }
 
 /* ---- R-loop sharding ------------------------------------------------- */
+static int no_mini_shards(void) {
+    /* every radius of a USE_MINI_HALOS run reads and writes its own slice of the f_coll history,
+     * which a rank-local shard would have to exchange as well: not built */
+    c21hip_set_error("ionize: the sharded R loop does not take USE_MINI_HALOS");
+    return C21CM_VALUE_ERROR;
+}
+
 /* Per-radius f_coll grid means of the shard phase.  Each radius > 0 is owned by exactly one rank,
  * so the caller sums the report arrays of all ranks (a 2 KB all-reduce) and hands the result to
  * the finishing rank, whose finish phase starts from a zeroed scalar block.  Without this the
@@ -1188,6 +1354,7 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
         probe.z_reion = &sentinel;
         probe.kinetic_temperature = &sentinel;
         status = validate_spec(spec, perturbed_field, halos, spin_temp, &probe);
+        if (!status && spec->use_mini_halos) status = no_mini_shards();
         if (status) return status;
     }
     ion_ctx c;
@@ -1246,6 +1413,7 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
                               const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
                               void *stream) {
     int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
+    if (!status && spec->use_mini_halos) status = no_mini_shards();
     if (status) return status;
     if (!first_cross || !c21hip_is_device_ptr(first_cross)) {
         c21hip_set_error("ionize shard: first_cross must be a device array");
@@ -1327,6 +1495,7 @@ int c21cm_ionize_shard_radii_keys(const c21cm_ionize_spec *spec, int rank, int w
         probe.neutral_fraction = probe.z_reion = probe.kinetic_temperature = &sentinel;
         probe.ionisation_rate_G12 = probe.cumulative_recombinations = &sentinel;
         status = validate_spec(spec, perturbed_field, halos, spin_temp, &probe);
+        if (!status && spec->use_mini_halos) status = no_mini_shards();
         if (status) return status;
     }
     ion_ctx c;
@@ -1375,6 +1544,7 @@ int c21cm_ionize_shard_finish_keys(const c21cm_ionize_spec *spec,
                                    const HaloBox *halos, IonizedBox *box,
                                    c21cm_ionize_report *report, void *stream) {
     int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
+    if (!status && spec->use_mini_halos) status = no_mini_shards();
     if (status) return status;
     if (!cross_keys || !c21hip_is_device_ptr(cross_keys) ||
         spec->recomb_model == C21CM_RECOMB_NONE) {
@@ -1459,6 +1629,61 @@ int c21cm_neutral_box(const c21cm_ionize_spec *spec, const PerturbedField *pertu
                            spec->adia_TK_term, stream));
     for (int i = 0; i < cb.n; i++) TRY(c21hip_d2h(cb.host[i], cb.dev[i], cb.bytes[i], stream));
     TRY(c21hip_sync(stream));
+done:
+    return status;
+}
+
+/* calculate_mcrit_boxes (IonisationBox.c:403-457): the two log10 turnover-mass grids of a
+ * USE_MINI_HALOS run and their box averages */
+int c21cm_mturn_grids(const c21cm_mturn_spec *spec, const float *prev_G12,
+                      const float *prev_z_reion, const float *J_21_LW, const float *vcb,
+                      float *log10_mturn_acg, float *log10_mturn_mcg, double *ave_acg,
+                      double *ave_mcg, void *stream) {
+    enum { WS_MT_G12 = 197, WS_MT_ZRE, WS_MT_J21, WS_MT_VCB, WS_MT_OUT_A, WS_MT_OUT_M, WS_MT_SC,
+           WS_MT_PART };
+    int status = 0;
+    if (!spec || !prev_G12 || !J_21_LW || !log10_mturn_acg || !log10_mturn_mcg ||
+        (!spec->first_snapshot && !prev_z_reion) || spec->hii_dim < 1 || spec->hii_dim_z < 1) {
+        c21hip_set_error("mturn_grids: previous Gamma_12 / z_reion, J_21_LW and the two output "
+                         "grids are required");
+        return C21CM_VALUE_ERROR;
+    }
+    const size_t ntot = (size_t)spec->hii_dim * spec->hii_dim * spec->hii_dim_z;
+    const size_t dbytes = ntot * sizeof(float);
+    copyback_list cb;
+    cb.n = 0;
+    const float *g12 = stage_in(WS_MT_G12, prev_G12, dbytes, stream, &status);
+    const float *zre = spec->first_snapshot
+                           ? NULL
+                           : stage_in(WS_MT_ZRE, prev_z_reion, dbytes, stream, &status);
+    const float *j21 = stage_in(WS_MT_J21, J_21_LW, dbytes, stream, &status);
+    const float *v = vcb ? stage_in(WS_MT_VCB, vcb, dbytes, stream, &status) : NULL;
+    float *out_a = stage_inout(WS_MT_OUT_A, log10_mturn_acg, dbytes, 0, &cb, stream, &status);
+    float *out_m = stage_inout(WS_MT_OUT_M, log10_mturn_mcg, dbytes, 0, &cb, stream, &status);
+    double *sc = (double *)c21hip_ws(WS_MT_SC, 4 * sizeof(double));
+    double *partials = (double *)c21hip_ws(WS_MT_PART, 2 * C21HIP_PARTIALS * sizeof(double));
+    if (status) return status;
+    if (!sc || !partials) return C21CM_MEMORY_ALLOC_ERROR;
+    double host_sc[3];
+    TRY(c21hip_memset(sc, 0, 4 * sizeof(double), stream));
+    TRY(c21hip_mturn_grids(ntot, spec->first_snapshot, spec->redshift, spec->mturn_a_nofb,
+                           spec->mturn_m_nofb, spec->vcb_const, spec->A_LW, spec->BETA_LW,
+                           spec->A_VCB, spec->BETA_VCB, spec->sigma_vcb, g12, zre, j21, v, out_a,
+                           out_m, partials, sc, (int *)(sc + 2), stream));
+    TRY(c21hip_d2h(host_sc, sc, sizeof(host_sc), stream));
+    for (int i = 0; i < cb.n; i++) TRY(c21hip_d2h(cb.host[i], cb.dev[i], cb.bytes[i], stream));
+    TRY(c21hip_sync(stream));
+    {
+        int flag;
+        memcpy(&flag, &host_sc[2], sizeof(int));
+        if (flag) { /* :425-429 */
+            c21hip_set_error("mturn_grids: Lyman-Werner threshold is NaN or zero (J_21_LW, v_cb)");
+            status = C21CM_VALUE_ERROR;
+            goto done;
+        }
+    }
+    if (ave_acg) *ave_acg = host_sc[0] / ntot;
+    if (ave_mcg) *ave_mcg = host_sc[1] / ntot;
 done:
     return status;
 }

@@ -45,6 +45,15 @@ def _new_like(ref, fill: float, dtype=None):
     return np.full(ref.shape, fill, dtype or np.float32)
 
 
+def _stack_like(ref, n: int):
+    """zeros of shape (n, *ref.shape), float32, where ``ref`` lives"""
+    if _is_torch(ref):
+        import torch
+
+        return torch.zeros((n,) + tuple(ref.shape), dtype=torch.float32, device=ref.device)
+    return np.zeros((n,) + tuple(ref.shape), np.float32)
+
+
 def _stream(stream):
     if stream is not None:
         return C.c_void_p(stream)
@@ -84,11 +93,16 @@ class IonizeBuffers:
     py21cmfast, reference: src/py21cmfast/wrapper/outputs.py:1475-1545)."""
 
     def __init__(self, density, need_nion: bool = False, minimize_memory: bool = False,
-                 recomb_model: int = 0):
+                 recomb_model: int = 0, mini_radii: int = 0):
         self.neutral_fraction = _new_like(density, 1.0)  # initialised to ones (:1524-1527)
         self.z_reion = _new_like(density, 0.0)
         self.kinetic_temperature = None if minimize_memory else _new_like(density, 0.0)
         self.unnormalised_nion = _new_like(density, 0.0) if need_nion else None
+        self.unnormalised_nion_mini = None
+        if mini_radii:  # USE_MINI_HALOS: one f_coll grid per filter radius (:1538-1543)
+            stack = _stack_like(density, mini_radii)
+            self.unnormalised_nion = stack
+            self.unnormalised_nion_mini = _stack_like(density, mini_radii)
         # recombination models (:1526-1537): Gamma_12 and the mean free path are always part of
         # the reference's IonizedBox; here they are only allocated when something writes them
         self.ionisation_rate_G12 = self.mean_free_path = self.cumulative_recombinations = None
@@ -116,6 +130,7 @@ class IonizeBuffers:
             neutral_fraction=_fptr(self.neutral_fraction), z_reion=_fptr(self.z_reion),
             kinetic_temperature=_fptr(self.kinetic_temperature),
             unnormalised_nion=_fptr(self.unnormalised_nion),
+            unnormalised_nion_mini=_fptr(self.unnormalised_nion_mini),
             ionisation_rate_G12=_fptr(self.ionisation_rate_G12),
             mean_free_path=_fptr(self.mean_free_path),
             cumulative_recombinations=_fptr(self.cumulative_recombinations),
@@ -133,16 +148,25 @@ def _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec=None, w
 
 def ionize_grids(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=None,
                  prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None,
-                 prev_nrec=None, whalo_sfr=None):
+                 prev_nrec=None, whalo_sfr=None, mini=None):
     """One ComputeIonizedBox grid pass on the MI355X.  Returns (buffers, box_struct, report).
     ``prev_nrec`` (the previous box's cumulative_recombinations) and ``whalo_sfr`` (HaloBox) are
-    the extra inputs of the recombination models."""
+    the extra inputs of the recombination models.  ``mini`` (USE_MINI_HALOS): dict with
+    prev_density, log10_mturn_acg, log10_mturn_mcg [N] and prev_nion, prev_nion_mini
+    [n_radii, N] (the previous box's per-radius f_coll history), numpy or CUDA tensors."""
     if buffers is None:
         buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
                                 minimize_memory=bool(spec.minimize_memory),
-                                recomb_model=spec.recomb_model)
+                                recomb_model=spec.recomb_model,
+                                mini_radii=spec.n_radii if mini is not None else 0)
     pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec,
                                       whalo_sfr)
+    if mini is not None:
+        spec.prev_density = _fptr(mini["prev_density"])
+        spec.log10_mturn_acg = _fptr(mini["log10_mturn_acg"])
+        spec.log10_mturn_mcg = _fptr(mini["log10_mturn_mcg"])
+        prev.unnormalised_nion = _fptr(mini["prev_nion"])
+        prev.unnormalised_nion_mini = _fptr(mini["prev_nion_mini"])
     box = buffers.struct()
     rep = S.IonizeReport()
     check(
@@ -151,6 +175,20 @@ def ionize_grids(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=None
         "c21cm_ionize_grids",
     )
     return buffers, box, rep
+
+
+def mturn_grids(spec: S.MturnSpec, prev_G12, prev_z_reion, J_21_LW, vcb=None, stream=None):
+    """calculate_mcrit_boxes on the device: (log10 M_turn,a, log10 M_turn,m, <a>, <m>); the
+    grids are allocated like ``J_21_LW`` (numpy array or CUDA tensor)."""
+    a, m = _new_like(J_21_LW, 0.0), _new_like(J_21_LW, 0.0)
+    ave_a, ave_m = C.c_double(), C.c_double()
+    check(
+        load().c21cm_mturn_grids(C.byref(spec), _vptr(prev_G12), _vptr(prev_z_reion),
+                                 _vptr(J_21_LW), _vptr(vcb), _vptr(a), _vptr(m), C.byref(ave_a),
+                                 C.byref(ave_m), _stream(stream)),
+        "c21cm_mturn_grids",
+    )
+    return a, m, ave_a.value, ave_m.value
 
 
 def ionize_shard_radii(spec, rank, world, first_cross, density, n_ion=None, xe=None,
