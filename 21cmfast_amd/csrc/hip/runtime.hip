@@ -17,7 +17,7 @@
 #include "c21cm_abi.h"
 
 namespace {
-constexpr int kMaxSlots = 192;
+constexpr int kMaxSlots = 256;
 struct Slot {
     void *ptr = nullptr;
     size_t bytes = 0;
