@@ -231,12 +231,39 @@ static int nion_table_fn(int r_index, double dmin, double dmax, float *table, vo
                                       &t->sc, t->method, -40., table, C21CM_NDELTA_TABLE);
 }
 
+/* USE_MINI_HALOS: the 2-D tables (overdensity x log10 M_turn) of one radius for both
+ * populations, at this redshift or (prev) at the previous snapshot's growth factor with this
+ * redshift's scaling constants (IonisationBox.c:744-760, interp_tables.c:291-405) */
+struct nion_table2d_ctx {
+    const c21cm_ionize_spec *spec;
+    c21_scaling_consts sc;
+    double lnMmin, prev_growth_factor;
+    int method_atomic, method_mini;
+};
+
+static int nion_table2d_fn(int r_index, int prev, double dmin, double dmax, double l10mt_min,
+                           double l10mt_max, double l10mt_min_mini, double l10mt_max_mini,
+                           float *table_acg, float *table_mcg, void *user) {
+    const struct nion_table2d_ctx *t = (const struct nion_table2d_ctx *)user;
+    const c21cm_ionize_spec *s = t->spec;
+    const double M_max_R = c21_RtoM(s->R[r_index]), lnMc = log(M_max_R);
+    const double growthf = prev ? t->prev_growth_factor : s->growth_factor;
+    const double sigma_c = c21_sigma_fast(M_max_R);
+    int st = c21_Nion_Conditional_table2d(growthf, t->lnMmin, lnMc, lnMc, sigma_c, dmin, dmax,
+                                          l10mt_min, l10mt_max, &t->sc, 0, t->method_atomic,
+                                          table_acg, C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE);
+    if (!st)
+        st = c21_Nion_Conditional_table2d(growthf, t->lnMmin, lnMc, lnMc, sigma_c, dmin, dmax,
+                                          l10mt_min_mini, l10mt_max_mini, &t->sc, 1,
+                                          t->method_mini, table_mcg, C21CM_NDELTA_TABLE,
+                                          C21CM_NMTURN_TABLE);
+    return st;
+}
+
 int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *perturbed_field,
                       PerturbedField *previous_perturbed_field, IonizedBox *previous_ionize_box,
                       TsBox *spin_temp, HaloBox *halos, InitialConditions *ini_boxes,
                       IonizedBox *box) {
-    (void)previous_perturbed_field;
-    (void)ini_boxes;
     int st = require_globals("ComputeIonizedBox", 1);
     if (st) return st;
     const SimulationOptions *so = simulation_options_global;
@@ -253,7 +280,12 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         unsupported = "SOURCE_MODEL=E-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation";
     if (src == C21CM_SOURCE_E_INTEGRAL && ao->INTEGRATION_METHOD_ATOMIC > 1)
         unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
-    if (ao->USE_MINI_HALOS) unsupported = "USE_MINI_HALOS";
+    /* mini-halos: the Eulerian E-INTEGRAL model (need_minihalo_nion, IonisationBox.c:30-31); the
+     * Lagrangian models would take them from a HaloBox that this backend does not fill yet */
+    const int mini = ao->USE_MINI_HALOS;
+    if (mini && src != C21CM_SOURCE_E_INTEGRAL)
+        unsupported = "USE_MINI_HALOS with a SOURCE_MODEL other than E-INTEGRAL";
+    if (mini && ao->INTEGRATION_METHOD_MINI > 1) unsupported = "INTEGRATION_METHOD_MINI=GAMMA-APPROX";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
     if (ao->IONISE_ENTIRE_SPHERE) unsupported = "IONISE_ENTIRE_SPHERE";
     if (unsupported) {
@@ -354,6 +386,59 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         box->log10_Mturnover_ave = halos->log10_Mcrit_ACG_ave;
         box->log10_Mturnover_MINI_ave = halos->log10_Mcrit_MCG_ave;
         Mturn_avg = pow(10., halos->log10_Mcrit_ACG_ave);
+    } else if (mini) { /* calculate_mcrit_boxes, :1432-1445 */
+        if (!previous_ionize_box || !previous_perturbed_field || !previous_perturbed_field->density ||
+            !spin_temp || !spin_temp->J_21_LW || !box->unnormalised_nion_mini ||
+            !previous_ionize_box->ionisation_rate_G12 ||
+            (mo->V_CB_MODEL == C21CM_VCB_FLUCTS && (!ini_boxes || !ini_boxes->lowres_vcb))) {
+            c21hip_set_error("ComputeIonizedBox: USE_MINI_HALOS needs the previous PerturbedField "
+                             "and IonizedBox (Gamma_12, z_reion, f_coll histories), TsBox.J_21_LW "
+                             "and, with V_CB_MODEL = FLUCTS, lowres_vcb");
+            st = C21CM_VALUE_ERROR;
+            goto done;
+        }
+        const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
+        if (s->first_snapshot) { /* setup_first_z_prevbox, :388-400 */
+            previous_ionize_box->mean_f_coll = 0.0;
+            previous_ionize_box->mean_f_coll_MINI = 0.0;
+            float *pd = previous_perturbed_field->density; /* "Makes Fcoll == 0." */
+            if (c21hip_is_device_ptr(pd)) {
+                if ((st = c21hip_fill(pd, ntot, -1.5f, NULL))) goto done;
+            } else {
+                for (size_t i = 0; i < ntot; i++) pd[i] = -1.5f;
+            }
+        }
+        float *mta = (float *)c21hip_ws(205, ntot * sizeof(float));
+        float *mtm = (float *)c21hip_ws(206, ntot * sizeof(float));
+        if (!mta || !mtm) {
+            st = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+        c21cm_mturn_spec ms;
+        memset(&ms, 0, sizeof(ms));
+        ms.hii_dim = s->hii_dim;
+        ms.hii_dim_z = s->hii_dim_z;
+        ms.first_snapshot = s->first_snapshot;
+        ms.redshift = redshift;
+        ms.mturn_a_nofb = sc.mturn_a_nofb;
+        ms.mturn_m_nofb = sc.mturn_m_nofb;
+        ms.vcb_const = sc.vcb_const;
+        ms.A_LW = ap->A_LW;
+        ms.BETA_LW = ap->BETA_LW;
+        ms.A_VCB = ap->A_VCB;
+        ms.BETA_VCB = ap->BETA_VCB;
+        ms.sigma_vcb = cosmo_tables_global->V_CB_AVG * sqrt(3 * M_PI / 8);
+        if ((st = c21cm_mturn_grids(&ms, previous_ionize_box->ionisation_rate_G12,
+                                    previous_ionize_box->z_reion, spin_temp->J_21_LW,
+                                    mo->V_CB_MODEL == C21CM_VCB_FLUCTS ? ini_boxes->lowres_vcb : NULL,
+                                    mta, mtm, &box->log10_Mturnover_ave,
+                                    &box->log10_Mturnover_MINI_ave, NULL)))
+            goto done;
+        Mturn_avg = pow(10., box->log10_Mturnover_ave);
+        s->use_mini_halos = 1;
+        s->prev_density = previous_perturbed_field->density;
+        s->log10_mturn_acg = mta;
+        s->log10_mturn_mcg = mtm;
     } else if (mass_dep) { /* E-INTEGRAL without mini-halos: the turnover mass, :1446-1449 */
         Mturn_avg = ap->M_TURN;
         box->log10_Mturnover_ave = log10(Mturn_avg);
@@ -377,6 +462,47 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     }
     box->mean_f_coll = s->mean_f_coll;
     box->mean_f_coll_MINI = 0.;
+    double exp_global_hii = s->mean_f_coll * ion_eff_factor_gl;
+    struct nion_table2d_ctx n2ctx;
+    if (mini) { /* set_mean_fcoll with the trapezoidal history, :476-501 */
+        const double ion_eff_factor_mini_gl = sc.pop3_ion * sc.fstar_7 * sc.fesc_7;
+        const double Mturn_avg_mini = pow(10., box->log10_Mturnover_MINI_ave);
+        const double f_coll_curr = s->mean_f_coll;
+        if (!(previous_ionize_box->mean_f_coll * ion_eff_factor_gl < 1e-4))
+            s->mean_f_coll = previous_ionize_box->mean_f_coll + f_coll_curr -
+                             c21_Nion_General(prev_redshift, lnMmin, lnMmax_gl, Mturn_avg, &sc);
+        const double f_coll_curr_mini =
+            c21_Nion_General_MINI(redshift, lnMmin, lnMmax_gl, Mturn_avg_mini, &sc);
+        if (previous_ionize_box->mean_f_coll_MINI * ion_eff_factor_gl < 1e-4) /* (sic: zeta of the ACGs) */
+            s->mean_f_coll_mini = f_coll_curr_mini;
+        else
+            s->mean_f_coll_mini =
+                previous_ionize_box->mean_f_coll_MINI + f_coll_curr_mini -
+                c21_Nion_General_MINI(prev_redshift, lnMmin, lnMmax_gl, Mturn_avg_mini, &sc);
+        s->f_limit_mcg = c21_Nion_General_MINI(so->Z_HEAT_MAX, lnMmin, lnMmax_gl, Mturn_avg_mini, &sc);
+        if (!isfinite(s->mean_f_coll) || s->mean_f_coll < 0 || !isfinite(s->mean_f_coll_mini) ||
+            s->mean_f_coll_mini < 0) {
+            c21hip_set_error("ComputeIonizedBox: mean collapse fraction is invalid (%g, mini-halos %g)",
+                             s->mean_f_coll, s->mean_f_coll_mini);
+            st = C21CM_INFINITY_OR_NAN_ERROR;
+            goto done;
+        }
+        box->mean_f_coll = s->mean_f_coll;
+        box->mean_f_coll_MINI = s->mean_f_coll_mini;
+        exp_global_hii = s->mean_f_coll * ion_eff_factor_gl + s->mean_f_coll_mini * ion_eff_factor_mini_gl;
+        s->ion_eff_factor_mini = ion_eff_factor_mini_gl;
+        s->gamma_prefactor_mini = s->gamma_prefactor * s->ion_eff_factor_mini / s->ion_eff_factor;
+        s->need_prev_ion = previous_ionize_box->mean_f_coll_MINI * ion_eff_factor_mini_gl +
+                               previous_ionize_box->mean_f_coll * ion_eff_factor_gl > 1e-4;
+        n2ctx.spec = s;
+        n2ctx.sc = sc;
+        n2ctx.lnMmin = lnMmin;
+        n2ctx.prev_growth_factor = dicke(prev_redshift);
+        n2ctx.method_atomic = ao->INTEGRATION_METHOD_ATOMIC;
+        n2ctx.method_mini = ao->INTEGRATION_METHOD_MINI;
+        s->table2d_fn = nion_table2d_fn;
+        s->table2d_user = &n2ctx;
+    }
 
     struct fgtrm_table_ctx tctx = {s};
     struct nion_table_ctx nctx;
@@ -398,7 +524,7 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         s->fcoll_mode = C21CM_FCOLL_ERFC;
     }
 
-    if (s->mean_f_coll * ion_eff_factor_gl < HII_ROUND_ERR) {
+    if (exp_global_hii < HII_ROUND_ERR) {
         /* set_fully_neutral_box: IonisationBox.c:531-565 */
         const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
         st = c21cm_neutral_box(s, perturbed_field, spin_temp, box, ntot);
@@ -410,7 +536,9 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
          * GPU per process; C21CM_SHARD_BCAST=0: only the finishing rank's box is filled) */
         int srank, sworld;
         const char *e = getenv("C21CM_SHARD"), *b = getenv("C21CM_SHARD_BCAST");
-        if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && !(e && e[0] == '0'))
+        /* (a USE_MINI_HALOS run keeps one f_coll history slice per radius: every rank runs the
+         * whole R loop) */
+        if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && !(e && e[0] == '0') && !mini)
             st = c21cm_ionize_sharded(s, perturbed_field, previous_ionize_box, spin_temp, halos,
                                       box, NULL, !(b && b[0] == '0'), NULL);
         else

@@ -1192,6 +1192,13 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
         const double mean_out = s->fix_mean ? s->mean_f_coll : means[last];
         box->mean_f_coll = mean_out; /* IonisationBox.c:1623-1628 */
         const double *means_m = host_sc + (SC_MEANS_M - SC_SUMS);
+        if (c->mini) /* IonisationBox.c:914,943 */
+            for (int r = s->r_lowest; r < s->n_radii; r++)
+                if (!isfinite(means[r]) || !isfinite(means_m[r])) {
+                    c21hip_set_error("ionize: f_coll is either infinite or NaN at radius %d", r);
+                    status = C21CM_INFINITY_OR_NAN_ERROR;
+                    goto done;
+                }
         const double mean_m_out =
             !c->mini ? 0. : (s->fix_mean ? s->mean_f_coll_mini : means_m[last]);
         box->mean_f_coll_MINI = mean_m_out;

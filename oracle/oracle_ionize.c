@@ -476,7 +476,8 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
             status = C21CM_VALUE_ERROR;
             break;
         }
-        if (isfinite(f_coll_total) == 0 || isfinite(f_coll_MINI_total) == 0) {
+        /* (checked upstream inside the mini-halo branch only, :914,943) */
+        if (mini && (isfinite(f_coll_total) == 0 || isfinite(f_coll_MINI_total) == 0)) {
             status = C21CM_INFINITY_OR_NAN_ERROR;
             break;
         }

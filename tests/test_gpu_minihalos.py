@@ -154,3 +154,198 @@ def test_refusals(api):
     fc = torch.zeros(n ** 3, dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError):
         api.ionize_shard_radii(spec, 0, 2, fc, density)
+
+
+def test_two_population_parity_with_mean_fix(api, oracle):
+    """fix_mean = 1 (what ComputeIonizedBox sets for the Eulerian models): both populations are
+    rescaled to their global means (IonisationBox.c:1022-1027)."""
+    n = 40
+    spec = H.mini_spec(n, need_prev=1, r_bubble_max=10.0)
+    spec.fix_mean = 1
+    spec.mean_f_coll, spec.mean_f_coll_mini = 0.014, 0.002
+    density, mini = H.mini_inputs((n, n, n), spec.n_radii)
+    ref = oracle.ionize_grids(spec, density, mini=mini)
+    got = run_device(api, spec, density, mini, True)
+    compare_mini(got, ref, spec)
+    assert got["mean_f_coll_MINI"] == 0.002 and 0.02 < (ref["neutral_fraction"] == 0).mean() < 0.98
+
+
+def test_compute_ionized_box_with_mini_halos(gpu_lib, oracle, tmp_path):
+    """ComputeIonizedBox with USE_MINI_HALOS over two snapshots (first: no history; second: the
+    trapezoidal history, reionisation feedback from the first box's Gamma_12 / z_reion) against the
+    oracle fed with the host scalars and tables that tests/test_host_minihalos.py checks."""
+    import ctypes as C
+
+    from test_gpu_abi import Session, fptr
+    from test_host_scalars import ScalingConsts
+    import test_host_minihalos as HM
+
+    lib = gpu_lib
+    n = 32
+    shape = (n, n, n)
+    ses = Session(lib, tmp_path, HII_DIM=n, SOURCE_MODEL=1, HII_FILTER=1, USE_EXP_FILTER=False,
+                  R_BUBBLE_MAX=10.0, USE_MINI_HALOS=True, RECOMB_MODEL=2, CELL_RECOMB=True,
+                  ALPHA_STAR_MINI=0.5, F_STAR7_MINI=10 ** -2.0, F_ESC7_MINI=10 ** -1.5,
+                  V_CB_MODEL=3)
+    HM._bind(lib)
+    f64 = C.c_double
+    lib.c21_dtdz.restype = f64
+    lib.c21_dtdz.argtypes = [C.c_float]
+    lib.c21_nb0.restype = f64
+    lib.c21_rr_tables.restype = C.c_int
+    y, cc = C.POINTER(f64)(), C.POINTER(f64)()
+    assert lib.c21_rr_tables(C.byref(y), C.byref(cc)) == 0
+
+    rng = np.random.default_rng(17)
+    dens = {12.5: W.density_field_numpy(n, seed=5, sigma=0.6)}
+    dens[14.0] = (0.9 * dens[12.5]).astype(np.float32)
+    j21 = {z: ((3.0 if z == 12.5 else 1.5) * rng.random(shape) ** 2).astype(np.float32) for z in dens}
+
+    def new_box(n_radii):
+        return {"neutral_fraction": np.ones(shape, np.float32), "z_reion": np.zeros(shape, np.float32),
+                "kinetic_temperature": np.zeros(shape, np.float32),
+                "ionisation_rate_G12": np.zeros(shape, np.float32),
+                "mean_free_path": np.zeros(shape, np.float32),
+                "cumulative_recombinations": np.zeros(shape, np.float32),
+                "unnormalised_nion": np.zeros((n_radii,) + shape, np.float32),
+                "unnormalised_nion_mini": np.zeros((n_radii,) + shape, np.float32)}
+
+    n_radii = W.ionize_spec(n, box_len=ses.so.BOX_LEN, mode=W.FCOLL_TABLE_EXP,
+                            r_bubble_max=ses.ap.R_BUBBLE_MAX).n_radii
+    LN_MAX = math.log(1e16)
+
+    def oracle_snapshot(z, prev_z, prev_arr, prev_means, prev_density):
+        first = prev_z < 1
+        spec = W.ionize_spec(n, box_len=ses.so.BOX_LEN, mode=W.FCOLL_TABLE_EXP,
+                             r_bubble_max=ses.ap.R_BUBBLE_MAX, redshift=z)
+        sc = ScalingConsts()
+        assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+        M_min = lib.c21_minimum_source_mass(z)
+        assert M_min == 1e5  # hmf.c:1327-1329
+        lnMmin = math.log(M_min)
+        spec.hii_filter, spec.stars_filter = 1, 1
+        spec.r_lowest = 0
+        spec.sigma_minmass = lib.c21_sigma_fast(M_min)
+        spec.growth_factor = lib.dicke(z)
+        spec.TK_nofluct = lib.c21_T_RECFAST(z)
+        spec.adia_TK_term = float(np.float32(0.58 - 0.006 * (np.float32(z) - 10.0)))
+        spec.T_re = ses.ap.T_RE
+        spec.rhocrit_omb = lib.c21_rhocrit() * ses.cp.OMb
+        spec.mass_dep_zeta, spec.fix_mean = 1, 1
+        spec.first_snapshot = int(first)
+        spec.recomb_model, spec.cell_recomb = 2, 1
+        spec.rr_y, spec.rr_c = y, cc
+        spec.dz = (1 + z) * (ses.so.ZPRIME_STEP_FACTOR - 1) if first else prev_z - z
+        spec.fabs_dtdz = abs(lib.c21_dtdz(z)) / 1e15
+        zeta = sc.pop2_ion * sc.fstar_10 * sc.fesc_10
+        zeta_m = sc.pop3_ion * sc.fstar_7 * sc.fesc_7
+        spec.ion_eff_factor = zeta
+        a_uvb = ses.ap.ALPHA_UVB
+        spec.gamma_prefactor = ((1 + z) ** 2 * 3.08567758e24 * 6.3e-18 * a_uvb / (a_uvb + 2.75)
+                                * lib.c21_nb0() * zeta / 1e-12 / (sc.t_h * sc.t_star))
+        # calculate_mcrit_boxes
+        ms = S.MturnSpec(hii_dim=n, hii_dim_z=n, first_snapshot=int(first), redshift=z,
+                         mturn_a_nofb=sc.mturn_a_nofb, mturn_m_nofb=sc.mturn_m_nofb,
+                         vcb_const=sc.vcb_const, A_LW=ses.ap.A_LW, BETA_LW=ses.ap.BETA_LW,
+                         A_VCB=ses.ap.A_VCB, BETA_VCB=ses.ap.BETA_VCB,
+                         sigma_vcb=ses.ct.V_CB_AVG * math.sqrt(3 * math.pi / 8))
+        assert sc.vcb_const == ses.ap.V_CB_AVG_DEBUG  # V_CB_MODEL = AVG-DEBUG
+        mta, mtm, ave_a, ave_m = oracle.mturn_grids(ms, prev_arr["ionisation_rate_G12"],
+                                                    prev_arr["z_reion"], j21[z])
+        Mt_a, Mt_m = 10 ** ave_a, 10 ** ave_m
+        # set_mean_fcoll
+        pa, pm = prev_means
+        f_a = lib.c21_Nion_General(z, lnMmin, LN_MAX, Mt_a, C.byref(sc))
+        f_m = lib.c21_Nion_General_MINI(z, lnMmin, LN_MAX, Mt_m, C.byref(sc))
+        if not pa * zeta < 1e-4:
+            f_a = pa + f_a - lib.c21_Nion_General(prev_z, lnMmin, LN_MAX, Mt_a, C.byref(sc))
+        if not pm * zeta < 1e-4:
+            f_m = pm + f_m - lib.c21_Nion_General_MINI(prev_z, lnMmin, LN_MAX, Mt_m, C.byref(sc))
+        spec.mean_f_coll, spec.mean_f_coll_mini = f_a, f_m
+        spec.f_limit_acg = lib.c21_Nion_General(ses.so.Z_HEAT_MAX, lnMmin, LN_MAX, Mt_a, C.byref(sc))
+        spec.f_limit_mcg = lib.c21_Nion_General_MINI(ses.so.Z_HEAT_MAX, lnMmin, LN_MAX, Mt_m,
+                                                     C.byref(sc))
+        spec.use_mini_halos = 1
+        spec.need_prev_ion = int(pm * zeta_m + pa * zeta > 1e-4)
+        spec.ion_eff_factor_mini = zeta_m
+        spec.gamma_prefactor_mini = spec.gamma_prefactor * zeta_m / zeta
+        D_prev = lib.dicke(prev_z)
+
+        def table2d_fn(r_index, prev, dmin, dmax, amin, amax, mmin, mmax, tab_a, tab_m, user):
+            M_R = lib.c21_RtoM(spec.R[r_index])
+            D = D_prev if prev else spec.growth_factor
+            args = (D, lnMmin, math.log(M_R), math.log(M_R), lib.c21_sigma_fast(M_R), dmin, dmax)
+            st = lib.c21_Nion_Conditional_table2d(*args, amin, amax, C.byref(sc), 0, 1, tab_a,
+                                                  S.NDELTA_TABLE, S.NMTURN_TABLE)
+            return st or lib.c21_Nion_Conditional_table2d(*args, mmin, mmax, C.byref(sc), 1, 1,
+                                                          tab_m, S.NDELTA_TABLE, S.NMTURN_TABLE)
+        cb = S.TABLE2D_FN(table2d_fn)
+        spec.table2d_fn = cb
+        mini = dict(prev_density=prev_density, log10_mturn_acg=mta, log10_mturn_mcg=mtm,
+                    prev_nion=prev_arr["unnormalised_nion"],
+                    prev_nion_mini=prev_arr["unnormalised_nion_mini"])
+        ref = oracle.ionize_grids(spec, dens[z], mini=mini, prev_z_reion=prev_arr["z_reion"],
+                                  prev_nrec=prev_arr["cumulative_recombinations"])
+        ref["ave"] = (ave_a, ave_m)
+        ref["spec_means"] = (f_a, f_m)
+        return ref
+
+    def abi_snapshot(z, prev_z, prev_arr, prev_means, prev_density):
+        arr = new_box(n_radii)
+        box = S.IonizedBoxStruct(**{k: fptr(v) for k, v in arr.items()})
+        prevs = S.IonizedBoxStruct(**{k: fptr(v) for k, v in prev_arr.items()})
+        prevs.mean_f_coll, prevs.mean_f_coll_MINI = prev_means
+        pf = S.PerturbedFieldStruct(density=fptr(dens[z]))
+        ppf = S.PerturbedFieldStruct(density=fptr(prev_density))
+        ts = S.TsBoxStruct(J_21_LW=fptr(j21[z]))
+        hb, ics = S.HaloBoxStruct(), S.InitialConditionsStruct()
+        st = lib.ComputeIonizedBox(z, prev_z, C.byref(pf), C.byref(ppf), C.byref(prevs),
+                                   C.byref(ts), C.byref(hb), C.byref(ics), C.byref(box))
+        assert st == 0, lib.c21cm_last_error()
+        arr["means"] = (box.mean_f_coll, box.mean_f_coll_MINI)
+        arr["ave"] = (box.log10_Mturnover_ave, box.log10_Mturnover_MINI_ave)
+        return arr
+
+    def check(got, ref):
+        flag_g, flag_r = got["mean_free_path"] > 0, ref["mean_free_path"] > 0
+        assert np.mean(flag_g != flag_r) <= 2e-4
+        same = flag_g == flag_r
+        for k in ("neutral_fraction", "ionisation_rate_G12", "mean_free_path",
+                  "cumulative_recombinations", "z_reion"):
+            np.testing.assert_allclose(got[k][same], ref[k][same], rtol=2e-4, atol=5e-6, err_msg=k)
+        for k in ("unnormalised_nion", "unnormalised_nion_mini"):
+            # (the real tables fall to the -40 floor above the collapse threshold: a cell whose
+            # float32-filtered delta sits on that cliff moves with the transform's round-off)
+            off = ~np.isclose(got[k], ref[k], rtol=2e-4, atol=2e-7)
+            assert off.mean() <= 1e-5, (k, off.sum())
+            np.testing.assert_allclose(got[k], ref[k], rtol=2e-2, atol=2e-7, err_msg=k)
+        assert got["ave"] == pytest.approx(ref["ave"], rel=1e-7)
+        assert got["means"] == pytest.approx(ref["spec_means"], rel=1e-10)  # fix_mean: kept
+        return flag_r.mean()
+
+    # snapshot 1: no previous box (prev_redshift = 0)
+    zero_prev = new_box(n_radii)
+    pd1 = np.zeros(shape, np.float32)
+    got1 = abi_snapshot(14.0, 0.0, zero_prev, (0.3, 0.3), pd1)  # means are reset to 0 (:389-390)
+    assert (pd1 == -1.5).all() and (zero_prev["z_reion"] == -1).all()
+    ref_prev = new_box(n_radii)
+    ref1 = oracle_snapshot(14.0, 0.0, ref_prev, (0.0, 0.0), np.full(shape, -1.5, np.float32))
+    frac1 = check(got1, ref1)
+    assert got1["unnormalised_nion_mini"].max() > 0
+    # snapshot 2: history + feedback from snapshot 1
+    means1 = got1.pop("means")
+    got1.pop("ave")
+    got2 = abi_snapshot(12.5, 14.0, got1, means1, dens[14.0].copy())
+    ref1_arr = {k: ref1[k] for k in new_box(1)}
+    ref2 = oracle_snapshot(12.5, 14.0, ref1_arr, ref1["spec_means"], dens[14.0])
+    frac2 = check(got2, ref2)
+    assert 0.01 < frac1 < frac2 < 0.98
+    # reionisation feedback of snapshot 1's ionised cells (2.5e7 Msun here) lifts the MCG turnover
+    # above its Lyman-Werner value there; the ACG turnover stays at M_TURN
+    ms_nofb = oracle_snapshot(12.5, 14.0, new_box(n_radii), ref1["spec_means"], dens[14.0])["ave"]
+    assert got2["ave"][0] == pytest.approx(math.log10(ses.ap.M_TURN), rel=1e-7)
+    assert got2["ave"][1] > ms_nofb[1] > 6.0
+    # the trapezoid used the history: means differ from the plain integrals
+    assert got2["means"][0] != pytest.approx(got1["unnormalised_nion"][0].mean(), rel=1e-3)
+    lib.free_MHR.restype = None
+    lib.free_MHR()
