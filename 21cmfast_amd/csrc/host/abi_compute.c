@@ -20,11 +20,12 @@
  * USE_INTERPOLATION_TABLES = hmf-interpolation) and the Lagrangian models (L-INTEGRAL /
  * DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all HII_FILTER types,
  * USE_EXP_FILTER, MINIMIZE_MEMORY, RECOMB_MODEL homogeneous / inhomogeneous with or without
- * CELL_RECOMB; ComputeBrightnessTemp with or without spin temperatures.
+ * CELL_RECOMB, USE_MINI_HALOS with E-INTEGRAL (turnover-mass boxes, 2-D tables, f_coll history);
+ * ComputeBrightnessTemp with or without spin temperatures.
  * Returning ValueError (3) with a message in
  * c21cm_last_error(): E-INTEGRAL without interpolation tables or with the Gamma-function
- * approximation, USE_MINI_HALOS, PHOTON_CONS_TYPE != none,
- * IONISE_ENTIRE_SPHERE, V_CB_MODEL = FLUCTS, CLASS transfer tables.
+ * approximation, USE_MINI_HALOS with the other source models or in ComputeHaloBox / ComputeTsBox,
+ * PHOTON_CONS_TYPE != none, IONISE_ENTIRE_SPHERE.
  */
 #include <math.h>
 #include <pthread.h>
