@@ -251,12 +251,12 @@ static int nion_table2d_fn(int r_index, int prev, double dmin, double dmax, doub
     const double growthf = prev ? t->prev_growth_factor : s->growth_factor;
     const double sigma_c = c21_sigma_fast(M_max_R);
     int st = c21_Nion_Conditional_table2d(growthf, t->lnMmin, lnMc, lnMc, sigma_c, dmin, dmax,
-                                          l10mt_min, l10mt_max, &t->sc, 0, t->method_atomic,
+                                          l10mt_min, l10mt_max, &t->sc, 0, t->method_atomic, -40., 0,
                                           table_acg, C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE);
     if (!st)
         st = c21_Nion_Conditional_table2d(growthf, t->lnMmin, lnMc, lnMc, sigma_c, dmin, dmax,
                                           l10mt_min_mini, l10mt_max_mini, &t->sc, 1,
-                                          t->method_mini, table_mcg, C21CM_NDELTA_TABLE,
+                                          t->method_mini, -40., 0, table_mcg, C21CM_NDELTA_TABLE,
                                           C21CM_NMTURN_TABLE);
     return st;
 }

@@ -1006,6 +1006,83 @@ static int conditional_table(double growthf, double lnMmin, double lnMmax, doubl
     return bad ? C21CM_TABLE_GENERATION_ERROR : 0;
 }
 
+/* The redshift tables of the molecularly cooled population for the spin temperature
+ * (initialise_Nion_Ts_spline / initialise_SFRD_spline with USE_MINI_HALOS, interp_tables.c:96-232):
+ *   nion[i * n_mturn + j] = Nion_General_MINI(z_i, ln M_min, ln M_max, 10^(l10_min + j l10_width), sc_z)
+ *   sfrd[...]             = the same with f_esc = 1 (evolve_scaling_constants_sfr)
+ * with sc_z the constants evolved to z_i (only the upper turnover exp(-M / M_acg(z)) matters).
+ * Upstream: 2 x n_z x n_mturn adaptive integrals.  Here one 100-point Gauss-Legendre rule in
+ * ln M over [M_min, 200 M_acg(z_min)] shared by all of them: sigma(M) and the two scaling-relation
+ * factors per node once, exp(-M_turn_j / M) per (node, j) once, the mass function and the upper
+ * turnover per (z, node) -- then a (n_z x nodes) x (nodes x n_mturn) product.  Agreement with the
+ * adaptive integrals: tests/test_host_minihalos.py. */
+int c21_Nion_z_tables_mini(int n_z, double z_min, double z_width, double lnMmin,
+                           const c21_scaling_consts *sc, int n_mturn, double l10_min,
+                           double l10_width, double *nion, double *sfrd) {
+    enum { NQ = 100 };
+    if (!supported_hmf()) return C21CM_VALUE_ERROR;
+    if (n_mturn < 1 || n_mturn > 256) return C21CM_VALUE_ERROR;
+    const int hmf = matter_options_global->HMF;
+    const double acg_lo_z = c21_TtoM((float)z_min, 1e4, 0.59); /* the largest threshold of the range */
+    double lnMmax = log(200. * acg_lo_z);
+    if (lnMmax > log(1e16)) lnMmax = log(1e16);
+    double x[NQ + 1], w[NQ + 1], sig[NQ + 1], dsig[NQ + 1], base_n[NQ + 1], base_s[NQ + 1];
+    double *E = (double *)malloc(sizeof(double) * (size_t)(NQ + 1) * n_mturn);
+    if (!E) return C21CM_MEMORY_ALLOC_ERROR;
+    gauleg(lnMmin, lnMmax, x, w, NQ);
+    const c21_scaling_consts sc_s = c21_scaling_consts_sfr(sc);
+    for (int i = 1; i <= NQ; i++) {
+        const double lnM = x[i], M = exp(lnM);
+        sig[i] = c21_sigma_fast(M);
+        dsig[i] = dsigmasqdm_fast(M);
+        /* nion_weight_mini without its two turnover factors */
+        base_n[i] = exp(log_pl_limit(lnM, log(sc->fstar_7), sc->alpha_star_mini, 7 * M_LN10,
+                                     log(sc->Mlim_Fstar_mini)) +
+                        log_pl_limit(lnM, log(sc->fesc_7), sc->alpha_esc, 7 * M_LN10,
+                                     log(sc->Mlim_Fesc_mini)) + lnM);
+        base_s[i] = exp(log_pl_limit(lnM, log(sc_s.fstar_7), sc_s.alpha_star_mini, 7 * M_LN10,
+                                     log(sc_s.Mlim_Fstar_mini)) +
+                        log_pl_limit(lnM, log(sc_s.fesc_7), sc_s.alpha_esc, 7 * M_LN10,
+                                     log(sc_s.Mlim_Fesc_mini)) + lnM);
+        for (int j = 0; j < n_mturn; j++)
+            E[(size_t)i * n_mturn + j] = exp(-pow(10, l10_min + j * l10_width) / M);
+    }
+    const int n_thr = simulation_options_global && simulation_options_global->N_THREADS > 1
+                          ? simulation_options_global->N_THREADS : 1;
+    int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(n_thr) reduction(| : bad)
+    for (int k = 0; k < n_z; k++) {
+        const double z = z_min + k * z_width, growthf = dicke(z);
+        const double acg = c21_TtoM((float)z, 1e4, 0.59);
+        double *rn = nion + (size_t)k * n_mturn, *rs = sfrd + (size_t)k * n_mturn;
+        for (int j = 0; j < n_mturn; j++) rn[j] = rs[j] = 0.;
+        for (int i = 1; i <= NQ; i++) {
+            const double sigma = sig[i] * growthf;
+            const double dsigmadm = dsig[i] * (growthf * growthf / (2. * sigma));
+            double mf;
+            if (hmf == C21CM_HMF_PS) {
+                mf = -(dsigmadm / sigma) * sqrt(2. / M_PI) * (DELTA_C_SPH / sigma) *
+                     exp(-(DELTA_C_SPH * DELTA_C_SPH) / (2 * sigma * sigma));
+            } else {
+                const double nuhat = sqrt(SHETH_a) * DELTA_C_SPH / sigma;
+                mf = -(dsigmadm / sigma) * sqrt(2. / M_PI) * SHETH_A * (1 + pow(nuhat, -2 * SHETH_p)) *
+                     nuhat * exp(-nuhat * nuhat / 2.0);
+            }
+            const double g = w[i] * mf * exp(-exp(x[i]) / acg);
+            const double gn = g * base_n[i], gs = g * base_s[i];
+            const double *e = E + (size_t)i * n_mturn;
+            for (int j = 0; j < n_mturn; j++) {
+                rn[j] += gn * e[j];
+                rs[j] += gs * e[j];
+            }
+        }
+        for (int j = 0; j < n_mturn; j++)
+            if (!isfinite(rn[j]) || !isfinite(rs[j])) bad |= 1;
+    }
+    free(E);
+    return bad ? C21CM_TABLE_GENERATION_ERROR : 0;
+}
+
 /* hmf.c:1066-1104 */
 double c21_Nion_ConditionalM_MINI(double growthf, double lnM1, double lnM2, double lnM_cond,
                                   double sigma2, double delta2, double Mturn,
@@ -1021,7 +1098,8 @@ double c21_Nion_ConditionalM_MINI(double growthf, double lnM1, double lnM2, doub
 int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, double lnMcond,
                                  double sigma_cond, double dmin, double dmax, double l10mt_min,
                                  double l10mt_max, const c21_scaling_consts *sc, int mini,
-                                 int method, float *table, int n_delta, int n_mturn) {
+                                 int method, double ln_floor, int float_mturn, float *table,
+                                 int n_delta, int n_mturn) {
     int hmf = matter_options_global->HMF;
     const mass_weight_fn weight = mini ? nion_weight_mini : nion_weight;
     const int fast = (method == 1) && lnMmin < lnMcond;
@@ -1038,6 +1116,8 @@ int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, d
     }
     for (int j = 0; j < n_mturn; j++) /* float arithmetic of the ratio as upstream (:353-358) */
         mturn[j] = pow(10., l10mt_min + (float)j / ((float)n_mturn - 1.) * (l10mt_max - l10mt_min));
+    if (float_mturn) /* the SFRD tables keep the turnover masses in a float array (:431-435) */
+        for (int j = 0; j < n_mturn; j++) mturn[j] = (double)(float)mturn[j];
     if (method == 1) initialise_GL(lnMmin, lnMmax);
     if (fast) {
         for (int i = 1; i < NGL_INT + 1; i++) {
@@ -1070,7 +1150,7 @@ int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, d
             for (int j = 0; j < n_mturn; j++) {
                 double lv = log(weighted_ConditionalM(weight, growthf, lnMmin, lnMmax, lnMcond,
                                                       sigma_cond, delta, mturn[j], sc, method));
-                if (lv < -40.) lv = -40.;
+                if (lv < ln_floor) lv = ln_floor;
                 if (!isfinite(lv)) bad |= 1;
                 row[j] = (float)lv;
             }
@@ -1096,7 +1176,7 @@ int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, d
         }
         for (int j = 0; j < n_mturn; j++) {
             double lv = log(acc[j]);
-            if (lv < -40.) lv = -40.;
+            if (lv < ln_floor) lv = ln_floor;
             if (!isfinite(lv)) bad |= 1;
             row[j] = (float)lv;
         }
@@ -1181,6 +1261,32 @@ int c21_set_scaling_constants(double redshift, c21_scaling_consts *sc) {
                                                   sc->fesc_7 * pow(1e3, sc->alpha_esc), &status);
     }
     return status;
+}
+
+/* scaling_relations.c:132-165 (without the photon-conservation fits) */
+c21_scaling_consts c21_scaling_consts_at_z(double redshift, const c21_scaling_consts *sc) {
+    c21_scaling_consts sc_z = *sc;
+    sc_z.redshift = redshift;
+    sc_z.t_h = 1.0 / c21_hubble((float)redshift);
+    sc_z.acg_thresh = c21_TtoM((float)redshift, 1e4, 0.59);
+    sc_z.mturn_a_nofb = astro_params_global->M_TURN;
+    sc_z.mturn_m_nofb = 0.;
+    if (astro_options_global->USE_MINI_HALOS) {
+        sc_z.mturn_a_nofb = fmax(sc_z.acg_thresh, sc_z.mturn_a_nofb);
+        sc_z.mturn_m_nofb = c21_lyman_werner_threshold((float)redshift, 0.f, (float)sc_z.vcb_const);
+    }
+    return sc_z;
+}
+
+/* scaling_relations.c:121-130 */
+c21_scaling_consts c21_scaling_consts_sfr(const c21_scaling_consts *sc) {
+    c21_scaling_consts sc_sfrd = *sc;
+    sc_sfrd.fesc_10 = 1.;
+    sc_sfrd.fesc_7 = 1.;
+    sc_sfrd.alpha_esc = 0.;
+    sc_sfrd.Mlim_Fesc = 0.;
+    sc_sfrd.Mlim_Fesc_mini = 0.;
+    return sc_sfrd;
 }
 
 /* thermochem.c:281-304: Lyman-Werner + streaming-velocity threshold of molecular cooling */

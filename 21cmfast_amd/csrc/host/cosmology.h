@@ -82,15 +82,26 @@ double c21_Nion_ConditionalM_MINI(double growthf, double lnM1, double lnM2, doub
                                   double sigma2, double delta2, double Mturn,
                                   const c21_scaling_consts *sc, int method);
 /* interp_tables.c:291-405, USE_MINI_HALOS: table[i * n_mturn + j] = max(ln N_ion(delta_i | M_cond;
- * M_turn_j), -40) on n_delta overdensities x n_mturn log-spaced turnover masses
- * (10^l10mt_min .. 10^l10mt_max); mini != 0: the molecularly cooled population */
+ * M_turn_j), ln_floor) on n_delta overdensities x n_mturn log-spaced turnover masses
+ * (10^l10mt_min .. 10^l10mt_max); mini != 0: the molecularly cooled population.  ln_floor = -40
+ * for the N_ion tables, -50 and float_mturn = 1 for the SFRD tables (interp_tables.c:415-494) */
 #define C21_NMTURN 50           /* interp_tables.c:28 */
 #define C21_LOG10_MTURN_MAX 10. /* interp_tables.c:29-30 */
 #define C21_LOG10_MTURN_MIN (5. - 9e-8)
 int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, double lnMcond,
                                  double sigma_cond, double dmin, double dmax, double l10mt_min,
                                  double l10mt_max, const c21_scaling_consts *sc, int mini,
-                                 int method, float *table, int n_delta, int n_mturn);
+                                 int method, double ln_floor, int float_mturn, float *table,
+                                 int n_delta, int n_mturn);
+/* Nion_General_MINI on a (redshift x log10 turnover) grid, with and without the escape fraction
+ * (the spin temperature's Nion_z_table_MINI / SFRD_z_table_MINI, interp_tables.c:96-232) */
+int c21_Nion_z_tables_mini(int n_z, double z_min, double z_width, double lnMmin,
+                           const c21_scaling_consts *sc, int n_mturn, double l10_min,
+                           double l10_width, double *nion, double *sfrd);
+/* the scaling constants moved to another redshift (evolve_scaling_constants_to_redshift,
+ * scaling_relations.c:132-165) and their star-formation variant (f_esc = 1, :121-130) */
+c21_scaling_consts c21_scaling_consts_at_z(double redshift, const c21_scaling_consts *sc);
+c21_scaling_consts c21_scaling_consts_sfr(const c21_scaling_consts *sc);
 size_t c21_scaling_consts_size(void); /* for binding layers that mirror the struct */
 double c21_minimum_source_mass(double redshift);
 int c21_recfast_load(void);

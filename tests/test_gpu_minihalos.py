@@ -275,10 +275,11 @@ def test_compute_ionized_box_with_mini_halos(gpu_lib, oracle, tmp_path):
             M_R = lib.c21_RtoM(spec.R[r_index])
             D = D_prev if prev else spec.growth_factor
             args = (D, lnMmin, math.log(M_R), math.log(M_R), lib.c21_sigma_fast(M_R), dmin, dmax)
-            st = lib.c21_Nion_Conditional_table2d(*args, amin, amax, C.byref(sc), 0, 1, tab_a,
-                                                  S.NDELTA_TABLE, S.NMTURN_TABLE)
+            st = lib.c21_Nion_Conditional_table2d(*args, amin, amax, C.byref(sc), 0, 1, -40.0, 0,
+                                                  tab_a, S.NDELTA_TABLE, S.NMTURN_TABLE)
             return st or lib.c21_Nion_Conditional_table2d(*args, mmin, mmax, C.byref(sc), 1, 1,
-                                                          tab_m, S.NDELTA_TABLE, S.NMTURN_TABLE)
+                                                          -40.0, 0, tab_m, S.NDELTA_TABLE,
+                                                          S.NMTURN_TABLE)
         cb = S.TABLE2D_FN(table2d_fn)
         spec.table2d_fn = cb
         mini = dict(prev_density=prev_density, log10_mturn_acg=mta, log10_mturn_mcg=mtm,

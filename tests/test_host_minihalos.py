@@ -27,8 +27,8 @@ def _bind(lib):
     lib.c21_Nion_ConditionalM_MINI.argtypes = [f64] * 7 + [C.POINTER(ScalingConsts), C.c_int]
     lib.c21_Nion_Conditional_table2d.restype = C.c_int
     lib.c21_Nion_Conditional_table2d.argtypes = [f64] * 9 + [C.POINTER(ScalingConsts), C.c_int,
-                                                             C.c_int, C.POINTER(C.c_float),
-                                                             C.c_int, C.c_int]
+                                                             C.c_int, f64, C.c_int,
+                                                             C.POINTER(C.c_float), C.c_int, C.c_int]
 
 
 @pytest.fixture()
@@ -130,7 +130,7 @@ def test_conditional_tables_2d(mini):
     for is_mini, (lo, hi) in ((1, (5.1, 7.9)), (0, (8.2, 9.6))):
         tab = (C.c_float * (nd * nm))()
         assert mini.c21_Nion_Conditional_table2d(D, lnMmin, lnMc, lnMc, s_c, dmin, dmax, lo, hi,
-                                                 C.byref(sc), is_mini, 1, tab, nd, nm) == 0
+                                                 C.byref(sc), is_mini, 1, -40.0, 0, tab, nd, nm) == 0
         t = np.array(tab[:]).reshape(nd, nm)
         fn = mini.c21_Nion_ConditionalM_MINI if is_mini else mini.c21_Nion_ConditionalM
         for i, j in ((0, 0), (13, 49), (200, 25), (399, 7), (330, 0)):
@@ -148,3 +148,40 @@ def test_conditional_tables_2d(mini):
         a = mini.c21_Nion_ConditionalM_MINI(D, lnMmin, lnMc, lnMc, s_c, delta, 2e6, C.byref(sc), 0)
         b = mini.c21_Nion_ConditionalM_MINI(D, lnMmin, lnMc, lnMc, s_c, delta, 2e6, C.byref(sc), 1)
         assert a == pytest.approx(b, rel=3e-3)
+
+
+def test_redshift_tables_of_the_mini_population(mini):
+    """The shared Gauss-Legendre rule behind Nion_z_table_MINI / SFRD_z_table_MINI against the
+    adaptive Nion_General_MINI integrals with the constants evolved to each redshift."""
+    lib = mini
+    lib.c21_Nion_z_tables_mini.restype = C.c_int
+    lib.c21_Nion_z_tables_mini.argtypes = [C.c_int, f64, f64, f64, C.POINTER(ScalingConsts), C.c_int,
+                                           f64, f64, C.POINTER(f64), C.POINTER(f64)]
+    lib.c21_scaling_consts_at_z.restype = ScalingConsts
+    lib.c21_scaling_consts_at_z.argtypes = [f64, C.POINTER(ScalingConsts)]
+    lib.c21_scaling_consts_sfr.restype = ScalingConsts
+    lib.c21_scaling_consts_sfr.argtypes = [C.POINTER(ScalingConsts)]
+    sc = ScalingConsts()
+    assert lib.c21_set_scaling_constants(12.0, C.byref(sc)) == 0
+    nz, nm = 40, 50
+    z_min, z_w = 11.9, 0.55
+    l10_min, l10_w = 5.0 - 9e-8, (10.0 - (5.0 - 9e-8)) / 49.0
+    nion = (f64 * (nz * nm))()
+    sfrd = (f64 * (nz * nm))()
+    lnMmin, lnMmax = math.log(1e5), math.log(1e16)
+    assert lib.c21_Nion_z_tables_mini(nz, z_min, z_w, lnMmin, C.byref(sc), nm, l10_min, l10_w,
+                                      nion, sfrd) == 0
+    tn = np.array(nion[:]).reshape(nz, nm)
+    ts = np.array(sfrd[:]).reshape(nz, nm)
+    for k, j in ((0, 0), (0, 49), (7, 12), (20, 30), (39, 5), (39, 44)):
+        z = z_min + k * z_w
+        mt = 10 ** (l10_min + j * l10_w)
+        sc_z = lib.c21_scaling_consts_at_z(z, C.byref(sc))
+        assert sc_z.acg_thresh < sc.acg_thresh or z <= 12.0
+        want = lib.c21_Nion_General_MINI(z, lnMmin, lnMmax, mt, C.byref(sc_z))
+        assert tn[k, j] == pytest.approx(want, rel=2e-5, abs=1e-300), (k, j)
+        sc_s = lib.c21_scaling_consts_sfr(C.byref(sc_z))
+        assert sc_s.fesc_7 == 1.0 and sc_s.alpha_esc == 0.0
+        want_s = lib.c21_Nion_General_MINI(z, lnMmin, lnMmax, mt, C.byref(sc_s))
+        assert ts[k, j] == pytest.approx(want_s, rel=2e-5, abs=1e-300), (k, j)
+    assert np.all(np.diff(tn, axis=0) < 0) and np.all(np.diff(tn, axis=1) < 0)
