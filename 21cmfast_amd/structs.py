@@ -583,6 +583,15 @@ class TsSpec(_Base):
         ("sfr_scale", C.c_double), ("xray_scale", C.c_double),
         ("freq_int_heat", c_double_p), ("freq_int_ion", c_double_p), ("freq_int_lya", c_double_p),
         ("lya_dEC", c_double_p), ("lya_dEI", c_double_p),
+        # USE_MINI_HALOS (SFRD_TABLE mode)
+        ("use_mini_halos", C.c_int),
+        ("starlya_prefactor_mini", _PER_SHELL), ("lya_cont_prefactor_mini", _PER_SHELL),
+        ("lya_inj_prefactor_mini", _PER_SHELL), ("lw_prefactor", _PER_SHELL),
+        ("lw_prefactor_mini", _PER_SHELL), ("mean_sfr_zpp_mini", _PER_SHELL),
+        ("ln_sfrd_tables_mini", c_float_p),
+        ("mturn_tab_min", C.c_double), ("mturn_tab_width", C.c_double),
+        ("sfr_scale_mini", C.c_double), ("xray_scale_mini", C.c_double),
+        ("filtered_log10_mcrit", c_float_p),
     ]
 
 
@@ -591,7 +600,7 @@ class TsReport(_Base):
 
     _fields_ = [("Ts_ave", C.c_double), ("Tk_ave", C.c_double), ("x_e_ave", C.c_double),
                 ("J_alpha_ave", C.c_double), ("xheat_ave", C.c_double), ("xion_ave", C.c_double),
-                ("ave_sfrd", _PER_SHELL)]
+                ("ave_sfrd", _PER_SHELL), ("ave_sfrd_mini", _PER_SHELL)]
 
 
 class TsFirstSpec(_Base):

@@ -457,12 +457,34 @@ typedef struct c21cm_ts_spec {
     const double *freq_int_heat, *freq_int_ion, *freq_int_lya;
     /* Energy_Lya_heating's two tables, host, [NT][NT][NGP]; needed with use_lya_heating */
     const double *lya_dEC, *lya_dEI;
+    /* USE_MINI_HALOS with C21CM_TS_SRC_SFRD_TABLE (SpinTemperatureBox.c:1011-1075,1642-1716): the
+     * molecularly cooled population adds, per shell, a star-formation term from a 2-D table
+     * (overdensity x log10 of the shell-filtered Lyman-Werner turnover mass), its own Lyman-alpha
+     * prefactors and X-ray luminosity, and both populations feed the Lyman-Werner background
+     * written to TsBox.J_21_LW (:1843-1845). */
+    int use_mini_halos;
+    double starlya_prefactor_mini[C21CM_MAX_TS_RADII];
+    double lya_cont_prefactor_mini[C21CM_MAX_TS_RADII], lya_inj_prefactor_mini[C21CM_MAX_TS_RADII];
+    double lw_prefactor[C21CM_MAX_TS_RADII], lw_prefactor_mini[C21CM_MAX_TS_RADII];
+    double mean_sfr_zpp_mini[C21CM_MAX_TS_RADII];
+    const float *ln_sfrd_tables_mini; /* host, [n_step][C21CM_NDELTA_TABLE][C21CM_NMTURN_TABLE] */
+    double mturn_tab_min, mturn_tab_width; /* LOG10_MTURN_MIN and the bin width (interp_tables.c:29-30) */
+    double sfr_scale_mini;  /* F_STAR7_MINI   */
+    double xray_scale_mini; /* L_X_MINI s_per_yr */
+    const float *filtered_log10_mcrit; /* [n_step][N]: fill_Rbox_table of log10 M_crit,LW (:1459-1466) */
 } c21cm_ts_spec;
 
 typedef struct c21cm_ts_report { /* box means, as the reference logs them at DEBUG level */
     double Ts_ave, Tk_ave, x_e_ave, J_alpha_ave, xheat_ave, xion_ave;
     double ave_sfrd[C21CM_MAX_TS_RADII]; /* SFRD_TABLE: mean table value per shell */
+    double ave_sfrd_mini[C21CM_MAX_TS_RADII]; /* USE_MINI_HALOS */
 } c21cm_ts_report;
+
+/* prepare_filter_boxes with USE_MINI_HALOS (SpinTemperatureBox.c:535-565): per cell
+ * log10(max(M_LW(z, J_21_LW, v_cb), M_TURN)) from the previous TsBox's J_21_LW (vcb NULL:
+ * vcb_const); the spec's reionisation / no-feedback fields are not read. */
+int c21cm_ts_mcrit_grid(const c21cm_mturn_spec *spec, double m_turn, const float *J_21_LW,
+                        const float *vcb, float *log10_mcrit, void *stream);
 
 /* `density` [N]: PerturbedField.density; `previous` holds the three boxes of the previous
  * snapshot; `source_box` (GRIDS) or `filtered_density` (SFRD_TABLE) as described above; `out`

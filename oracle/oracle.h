@@ -107,6 +107,8 @@ int oracle_annular_filter_grids(const c21cm_annular_spec *spec, const float *con
 
 /* oracle_ts.c -- reference: src/py21cmfast/src/SpinTemperatureBox.c:892-927,1010-1086,1210-1383,
  * 1499-1848; heating_helper_progs.c:366-760,1210-1313; thermochem.c:66-75 */
+int oracle_ts_mcrit_grid(const c21cm_mturn_spec *spec, double m_turn, const float *J_21_LW,
+                         const float *vcb, float *log10_mcrit);
 int oracle_ts_grids(const c21cm_ts_spec *spec, const float *density, const TsBox *previous,
                     const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
                     c21cm_ts_report *report);

@@ -343,11 +343,15 @@ TS_FIELDS = ("spin_temperature", "kinetic_temp_neutral", "xray_ionised_fraction"
 
 
 def ts_grids(spec, density, previous: dict, source: dict | None = None, filtered_density=None):
-    """Oracle per-cell part of ComputeTsBox; dict of the three output boxes + the report."""
+    """Oracle per-cell part of ComputeTsBox; dict of the three output boxes + the report
+    (+ J_21_LW with spec.use_mini_halos)."""
     shape = density.shape
     out = {k: np.zeros(shape, np.float32) for k in TS_FIELDS}
     prev = S.TsBoxStruct(**{k: fptr(previous[k]) for k in TS_FIELDS})
     box = S.TsBoxStruct(**{k: fptr(out[k]) for k in TS_FIELDS})
+    if spec.use_mini_halos:
+        out["J_21_LW"] = np.zeros(shape, np.float32)
+        box.J_21_LW = fptr(out["J_21_LW"])
     src = S.XraySourceBoxStruct(**{k: fptr(v) for k, v in (source or {}).items()})
     rep = S.TsReport()
     st = load().oracle_ts_grids(C.byref(spec), fptr(density), C.byref(prev), C.byref(src),
@@ -355,6 +359,19 @@ def ts_grids(spec, density, previous: dict, source: dict | None = None, filtered
     if st:
         raise RuntimeError(f"oracle_ts_grids status {st}")
     out["report"] = rep
+    return out
+
+
+def ts_mcrit_grid(spec, m_turn, J_21_LW, vcb=None):
+    """log10 of the Lyman-Werner turnover mass per cell (prepare_filter_boxes)."""
+    lib = load()
+    lib.oracle_ts_mcrit_grid.restype = C.c_int
+    lib.oracle_ts_mcrit_grid.argtypes = [C.POINTER(S.MturnSpec), C.c_double, S.c_float_p,
+                                         S.c_float_p, S.c_float_p]
+    out = np.zeros(J_21_LW.shape, np.float32)
+    st = lib.oracle_ts_mcrit_grid(C.byref(spec), float(m_turn), fptr(J_21_LW), fptr(vcb), fptr(out))
+    if st:
+        raise RuntimeError(f"oracle_ts_mcrit_grid status {st}")
     return out
 
 

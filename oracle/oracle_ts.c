@@ -251,6 +251,42 @@ static int ts_check(const c21cm_ts_spec *s) {
     return 0;
 }
 
+/* interpolation.c:133-157 */
+static double table_2d_f(double x, double y, double x_min, double x_width, double y_min,
+                         double y_width, const float *z_arr, int ny) {
+    int x_idx = (int)floor((x - x_min) / x_width);
+    int y_idx = (int)floor((y - y_min) / y_width);
+    double x_table = x_min + x_width * (double)x_idx;
+    double y_table = y_min + y_width * (double)y_idx;
+    double interp_point_x = (x - x_table) / x_width;
+    double interp_point_y = (y - y_table) / y_width;
+    double left_edge = z_arr[(size_t)x_idx * ny + y_idx] * (1 - interp_point_y) +
+                       z_arr[(size_t)x_idx * ny + y_idx + 1] * (interp_point_y);
+    double right_edge = z_arr[(size_t)(x_idx + 1) * ny + y_idx] * (1 - interp_point_y) +
+                        z_arr[(size_t)(x_idx + 1) * ny + y_idx + 1] * (interp_point_y);
+    return left_edge * (1 - interp_point_x) + right_edge * (interp_point_x);
+}
+
+/* prepare_filter_boxes with USE_MINI_HALOS (SpinTemperatureBox.c:535-565) */
+int oracle_ts_mcrit_grid(const c21cm_mturn_spec *m, double m_turn, const float *J_21_LW,
+                         const float *vcb, float *log10_mcrit) {
+    const long ntot = (long)m->hii_dim * m->hii_dim * m->hii_dim_z;
+    const float z = (float)m->redshift;
+#pragma omp parallel for schedule(static)
+    for (long ct = 0; ct < ntot; ct++) {
+        const float curr_vcb = vcb ? vcb[ct] : (float)m->vcb_const;
+        const float curr_j21 = J_21_LW[ct];
+        /* lyman_werner_threshold(float z, float J_21_LW, float vcb): thermochem.c:281-304 */
+        double mcrit_noLW = 3.314e7 * pow(1. + z, -1.5);
+        double f_LW = 1.0 + m->A_LW * pow(curr_j21, m->BETA_LW);
+        double f_vcb = pow(1.0 + m->A_VCB * curr_vcb / m->sigma_vcb, m->BETA_VCB);
+        double M_buf = mcrit_noLW * f_LW * f_vcb;
+        M_buf = fmax(M_buf, m_turn);
+        log10_mcrit[ct] = log10(M_buf);
+    }
+    return C21CM_OK;
+}
+
 int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *previous,
                     const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
                     c21cm_ts_report *report) {
@@ -265,6 +301,10 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
         (!source_box || !source_box->filtered_sfr || !source_box->filtered_xray))
         return C21CM_VALUE_ERROR;
     if (!lagrangian && !s->no_light && !filtered_density) return C21CM_VALUE_ERROR;
+    const int mini = s->use_mini_halos;
+    if (mini && (s->source_mode != C21CM_TS_SRC_SFRD_TABLE || !out->J_21_LW ||
+                 (!s->no_light && (!s->ln_sfrd_tables_mini || !s->filtered_log10_mcrit))))
+        return C21CM_VALUE_ERROR;
 
     const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
     const int nR = s->n_step;
@@ -274,15 +314,17 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
 
     int *m_xHII_low_box = (int *)malloc(ntot * sizeof(int));
     float *inverse_val_box = (float *)malloc(ntot * sizeof(float));
-    double *acc = (double *)calloc(6 * ntot, sizeof(double));
+    double *acc = (double *)calloc(7 * ntot, sizeof(double));
     float *del_fcoll_Rct = lagrangian ? NULL : (float *)malloc(ntot * sizeof(float));
-    if (!m_xHII_low_box || !inverse_val_box || !acc || (!lagrangian && !del_fcoll_Rct)) {
+    float *del_fcoll_Rct_MINI = mini ? (float *)malloc(ntot * sizeof(float)) : NULL;
+    if (!m_xHII_low_box || !inverse_val_box || !acc || (!lagrangian && !del_fcoll_Rct) ||
+        (mini && !del_fcoll_Rct_MINI)) {
         status = C21CM_MEMORY_ALLOC_ERROR;
         goto done;
     }
     double *dxheat_dt_box = acc, *dxion_source_dt_box = acc + ntot, *dxlya_dt_box = acc + 2 * ntot,
            *dstarlya_dt_box = acc + 3 * ntot, *dstarlya_cont_dt_box = acc + 4 * ntot,
-           *dstarlya_inj_dt_box = acc + 5 * ntot;
+           *dstarlya_inj_dt_box = acc + 5 * ntot, *dstarlyLW_dt_box = acc + 6 * ntot;
 
 #pragma omp parallel for schedule(static)
     for (long ct = 0; ct < (long)ntot; ct++) { /* :1499-1522 */
@@ -301,7 +343,28 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
         for (int R_ct = nR; R_ct--;) {
             const double z_edge_factor = s->z_edge_factor[R_ct];
             const double xray_R_factor = s->xray_R_factor[R_ct];
-            double avg_fix_term = 1.;
+            double avg_fix_term = 1., avg_fix_term_MINI = 1.;
+            if (mini) { /* calculate_sfrd_from_grid, the molecularly cooled term (:1048-1073) */
+                const float *dens_R = filtered_density + (size_t)R_ct * ntot;
+                const float *mcrit_R = s->filtered_log10_mcrit + (size_t)R_ct * ntot;
+                const float *tab2 = s->ln_sfrd_tables_mini +
+                                    (size_t)R_ct * C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE;
+                double ave_m = 0;
+#pragma omp parallel for schedule(static) reduction(+ : ave_m)
+                for (long ct = 0; ct < (long)ntot; ct++) {
+                    const double curr_dens = dens_R[ct] * s->zpp_growth[R_ct];
+                    const double curr_mcrit = mcrit_R[ct];
+                    const double fcoll_MINI =
+                        exp(table_2d_f(curr_dens, curr_mcrit, s->tab_min[R_ct], s->tab_width[R_ct],
+                                       s->mturn_tab_min, s->mturn_tab_width, tab2,
+                                       C21CM_NMTURN_TABLE));
+                    del_fcoll_Rct_MINI[ct] = (1. + curr_dens) * fcoll_MINI;
+                    ave_m += fcoll_MINI;
+                }
+                ave_m /= ntot;
+                if (report) report->ave_sfrd_mini[R_ct] = ave_m;
+                avg_fix_term_MINI = s->mean_sfr_zpp_mini[R_ct] / ave_m; /* :1617-1618 */
+            }
             if (!lagrangian) { /* calculate_sfrd_from_grid with tables (:1040-1079) */
                 const float *dens_R = filtered_density + (size_t)R_ct * ntot;
                 const int e_integral = s->source_mode == C21CM_TS_SRC_SFRD_TABLE;
@@ -339,6 +402,19 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
                     sfr_term = del_fcoll_Rct[ct] * z_edge_factor * avg_fix_term * s->sfr_scale;
                     xray_sfr = sfr_term * s->xray_scale * xray_R_factor;
                 }
+                double sfr_term_mini = 0;
+                if (mini) { /* :1702-1716 */
+                    sfr_term_mini =
+                        del_fcoll_Rct_MINI[ct] * z_edge_factor * avg_fix_term_MINI * s->sfr_scale_mini;
+                    xray_sfr += sfr_term_mini * s->xray_scale_mini * xray_R_factor;
+                    dstarlyLW_dt_box[ct] += sfr_term * s->lw_prefactor[R_ct] +
+                                            sfr_term_mini * s->lw_prefactor_mini[R_ct];
+                }
+                const double starlya_factor_mini = mini ? s->starlya_prefactor_mini[R_ct] : 0.;
+                const double lyacont_factor_mini =
+                    (mini && s->use_lya_heating) ? s->lya_cont_prefactor_mini[R_ct] : 0.;
+                const double lyainj_factor_mini =
+                    (mini && s->use_lya_heating) ? s->lya_inj_prefactor_mini[R_ct] : 0.;
                 const int xidx = m_xHII_low_box[ct];
                 const double ival = inverse_val_box[ct];
 #define FREQ(tbl) \
@@ -347,10 +423,13 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
                 dxion_source_dt_box[ct] += xray_sfr * FREQ(freq_int_ion);
                 dxlya_dt_box[ct] += xray_sfr * FREQ(freq_int_lya);
 #undef FREQ
-                dstarlya_dt_box[ct] += sfr_term * s->starlya_prefactor[R_ct];
+                dstarlya_dt_box[ct] +=
+                    sfr_term * s->starlya_prefactor[R_ct] + sfr_term_mini * starlya_factor_mini;
                 if (s->use_lya_heating) {
-                    dstarlya_cont_dt_box[ct] += sfr_term * s->lya_cont_prefactor[R_ct];
-                    dstarlya_inj_dt_box[ct] += sfr_term * s->lya_inj_prefactor[R_ct];
+                    dstarlya_cont_dt_box[ct] += sfr_term * s->lya_cont_prefactor[R_ct] +
+                                                sfr_term_mini * lyacont_factor_mini;
+                    dstarlya_inj_dt_box[ct] += sfr_term * s->lya_inj_prefactor[R_ct] +
+                                               sfr_term_mini * lyainj_factor_mini;
                 }
             }
         }
@@ -382,6 +461,9 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
         out->spin_temperature[ct] = Ts;
         out->kinetic_temp_neutral[ct] = Tk;
         out->xray_ionised_fraction[ct] = xe;
+        if (mini) /* :1843-1845, 1324 */
+            out->J_21_LW[ct] =
+                dstarlyLW_dt_box[ct] * s->lya_star_prefactor * s->volunit_inv * s->h_p * 1e21;
         if (isfinite(out->spin_temperature[ct]) == 0) bad |= 1;
         J_alpha_ave += rad.dxlya_dt + rad.dstarlya_dt;
         xheat_ave += rad.dxheat_dt;
@@ -404,6 +486,7 @@ done:
     free(inverse_val_box);
     free(acc);
     free(del_fcoll_Rct);
+    free(del_fcoll_Rct_MINI);
     return status;
 }
 

@@ -172,3 +172,44 @@ def first_spec(n=24, z=30.0, hii_dim_z=None):
 
 def c_array(values, ctype=C.c_double):
     return (ctype * len(values))(*values)
+
+
+def add_minis(spec, inputs, seed=11, strength=1.0):
+    """Switch the molecularly cooled population on for an SFRD_TABLE workload of make(): smooth
+    2-D ln SFRD tables (overdensity x log10 M_crit,LW), shell-filtered turnover grids with
+    structure, Pop-III Lyman-alpha / Lyman-Werner prefactors.  strength = 0 keeps the tables but
+    gives the population no light (the run must then reproduce the one-population result)."""
+    assert spec.source_mode == S.TS_SRC_SFRD_TABLE
+    rng = np.random.default_rng(seed)
+    n_step = spec.n_step
+    shape = inputs["density"].shape
+    fd = inputs["filtered_density"]
+    nd, nm = S.NDELTA_TABLE, S.NMTURN_TABLE
+    spec.use_mini_halos = 1
+    spec.mturn_tab_min = 5.0 - 9e-8
+    spec.mturn_tab_width = (10.0 - spec.mturn_tab_min) / (nm - 1.0)
+    spec.sfr_scale_mini = 0.01 * strength
+    spec.xray_scale_mini = 3e40 * RH.PC["s_per_yr"]
+    mcrit = np.empty((n_step,) + shape, np.float32)
+    tabs = np.zeros((n_step + 1, nd, nm), np.float32)  # one spare table like the 1-D case
+    y = (spec.mturn_tab_min + spec.mturn_tab_width * np.arange(nm))[None, :]
+    for i in range(n_step):
+        mcrit[i] = (6.0 + 0.5 * np.tanh(smooth_field(shape, rng, 1.0)) / (1 + 0.1 * i)
+                    + 0.02 * i).astype(np.float32)
+        x = (spec.tab_min[i] + np.arange(nd) * spec.tab_width[i])[:, None]
+        tabs[i] = np.maximum(-10.0 + 3.0 * x - 0.4 * x * x - 0.1 * i - 1.2 * (y - 6.0), -50.0)
+        g = spec.zpp_growth[i]
+        d = fd[i].astype(np.float64) * g
+        fc = np.exp(-10.0 + 3.0 * d - 0.4 * d * d - 0.1 * i - 1.2 * (mcrit[i].astype(np.float64) - 6.0))
+        spec.mean_sfr_zpp_mini[i] = 0.9 * fc.mean() * (1 + 0.05 * math.cos(i))
+        spec.starlya_prefactor_mini[i] = 0.7 * spec.starlya_prefactor[i]
+        spec.lya_cont_prefactor_mini[i] = 0.5 * spec.starlya_prefactor_mini[i]
+        spec.lya_inj_prefactor_mini[i] = 0.5 * spec.starlya_prefactor_mini[i]
+        spec.lw_prefactor[i] = 2.5e7 * (1 + 0.2 * math.sin(i)) * (i < n_step - 3)
+        spec.lw_prefactor_mini[i] = 1.8 * spec.lw_prefactor[i]
+    spec._keep["tabs_mini"] = np.ascontiguousarray(tabs)
+    spec._keep["mcrit"] = mcrit
+    spec.ln_sfrd_tables_mini = spec._keep["tabs_mini"].ctypes.data_as(S.c_float_p)
+    spec.filtered_log10_mcrit = mcrit.ctypes.data_as(S.c_float_p)
+    inputs["filtered_log10_mcrit"] = mcrit
+    return spec, inputs
