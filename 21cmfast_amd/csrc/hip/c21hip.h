@@ -425,7 +425,28 @@ typedef struct c21hip_ts_args { /* the scalars of c21cm_ts_spec, passed by value
     double xray_prefactor, Trad, Ts_prefactor, xa_tilde_prefactor, xc_inverse, dcomp_dzp_prefactor;
     double Nb_zp, N_zp, lya_star_prefactor, volunit_inv, hubble_zp, growth_zp, dgrowth_dzp, dt_dzp;
     double sfr_scale, xray_scale;
+    int sums_ready; /* the shell loop already ran (USE_MINI_HALOS: c21hip_ts_accumulate_mini) */
 } c21hip_ts_args;
+/* USE_MINI_HALOS (E-INTEGRAL).  Mini shell buffer: 6 per-shell rows (starlya, lya_cont, lya_inj of
+ * the molecularly cooled population, the Lyman-Werner prefactors of both populations,
+ * avg_fix_term_MINI written by c21hip_ts_sfrd_means_mini). */
+#define C21HIP_TS_MINI_ROWS 6
+int c21hip_ts_mcrit_grid(const float *J_21_LW, const float *vcb, double vcb_const, double redshift,
+                         double A_LW, double BETA_LW, double A_VCB, double BETA_VCB,
+                         double sigma_vcb, double m_turn, float *out, size_t ntot, void *stream);
+int c21hip_ts_sfrd_means_mini(const float *filtered_density, const float *filtered_mcrit,
+                              const float *tables2_dev, const double *dev_tab,
+                              double *mini_shell_dev, const double *mean_sfr_mini_dev, int n_step,
+                              size_t ntot, double mt_min, double mt_width, double *partials,
+                              double *ave_out_dev, void *stream);
+/* the shell loop with both populations: sums_ws (6 * ntot doubles) and J_21_LW; follow with
+ * c21hip_ts_cells(a with sums_ready = 1, ...) */
+int c21hip_ts_accumulate_mini(const c21hip_ts_args *a, double sfr_scale_mini,
+                              double xray_scale_mini, double mt_min, double mt_width,
+                              const float *prev_xe, const float *delNL0, const float *mcrit,
+                              const float *tables_dev, const float *tables2_dev,
+                              const double *dev_tab, const double *mini_shell_dev, double *sums_ws,
+                              float *J_21_LW, size_t ntot, void *stream);
 /* device table buffer: 10 per-shell rows (z_edge_factor, xray_R_factor, starlya, lya_cont, lya_inj,
  * zpp_growth, tab_min, tab_width, avg_fix_term, 1 / tab_width) then the three [14][n_step]
  * frequency tables */

@@ -546,7 +546,7 @@ extern "C" int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, co
         c21hip_set_error("spin temperature: %d shells do not fit the table cache", a->n_step);
         return C21CM_VALUE_ERROR;
     }
-    if (!a->no_light) {
+    if (!a->no_light && !a->sums_ready) {
         // two cells per thread (8-byte loads) when the arrays allow it.  Measured at 512^3, 40
         // shells, SFRD tables: 19.1 ms with one or two cells per thread (78 / 102 VGPRs), 25.6 ms
         // with four (170 VGPRs): the loop is bound by its ~140 instruction slots per cell and shell
@@ -619,6 +619,217 @@ extern "C" int c21hip_ts_first(const c21cm_ts_first_spec *s, const float *densit
     hipLaunchKernelGGL(ts_first_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0, (hipStream_t)stream,
                        density, s->inverse_growth_factor_z, s->growth_factor_zp, s->TK, s->xe,
                        s->cT_ad, xc_per_density, TK, Trad, Ts_out, Tk_out, xe_out, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ======================================================================================
+// USE_MINI_HALOS (E-INTEGRAL): the molecularly cooled population in the shell loop
+// (SpinTemperatureBox.c:1011-1075, 1642-1733, 1843-1845).  Separate kernels: the tuned
+// one-population loop above keeps its register budget; this branch adds a 2-D table lookup and a
+// second exponential per cell and shell, and is written for parity first.
+// ======================================================================================
+namespace {
+// rows of the mini shell buffer (doubles, n = n_step)
+enum { MS_STARLYA = 0, MS_CONT, MS_INJ, MS_LW, MS_LW_MINI, MS_AVGFIX, MS_COUNT };
+static_assert(MS_COUNT == C21HIP_TS_MINI_ROWS, "rows of the mini shell buffer");
+
+// interpolation.c:133-157
+__device__ __forceinline__ double table_2d(double x, double y, double x_min, double x_width,
+                                           double y_min, double y_width,
+                                           const float *__restrict__ z_arr) {
+    const int x_idx = (int)floor((x - x_min) / x_width);
+    const int y_idx = (int)floor((y - y_min) / y_width);
+    const double px = (x - (x_min + x_width * (double)x_idx)) / x_width;
+    const double py = (y - (y_min + y_width * (double)y_idx)) / y_width;
+    const float *r0 = z_arr + (size_t)x_idx * C21CM_NMTURN_TABLE + y_idx;
+    const float *r1 = r0 + C21CM_NMTURN_TABLE;
+    const double left_edge = (double)r0[0] * (1 - py) + (double)r0[1] * py;
+    const double right_edge = (double)r1[0] * (1 - py) + (double)r1[1] * py;
+    return left_edge * (1 - px) + right_edge * px;
+}
+
+// box sum of the mini SFRD table values of one shell (blockIdx.y)
+__global__ void __launch_bounds__(kBlock)
+sfrd_sum_mini_kernel(const float *__restrict__ filtered_density,
+                     const float *__restrict__ filtered_mcrit, const float *__restrict__ tables2,
+                     const double *__restrict__ shell, int n_step, size_t ntot, double mt_min,
+                     double mt_width, double *__restrict__ partials) {
+    __shared__ double lds[kBlock];
+    const int R = blockIdx.y;
+    const float *dens = filtered_density + (size_t)R * ntot;
+    const float *mcrit = filtered_mcrit + (size_t)R * ntot;
+    const float *tab = tables2 + (size_t)R * C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE;
+    const double growth = shell[SH_GROWTH * n_step + R], tab_min = shell[SH_TABMIN * n_step + R],
+                 tab_width = shell[SH_TABWIDTH * n_step + R];
+    double acc = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock)
+        acc += exp(table_2d((double)dens[i] * growth, (double)mcrit[i], tab_min, tab_width, mt_min,
+                            mt_width, tab));
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[(size_t)R * gridDim.x + blockIdx.x] = acc;
+}
+
+// avg_fix_term_MINI = mean_sfr_zpp_mini / (sum / N) per shell (:1617-1618)
+__global__ void __launch_bounds__(kBlock)
+sfrd_finish_mini_kernel(const double *__restrict__ partials, int nblocks,
+                        const double *__restrict__ mean_sfr_zpp_mini, double ntot, int n_step,
+                        double *__restrict__ mini_shell, double *__restrict__ ave_out) {
+    __shared__ double lds[kBlock];
+    const int R = blockIdx.x;
+    double acc = 0.;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) acc += partials[(size_t)R * nblocks + i];
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) {
+        const double ave = acc / ntot;
+        ave_out[R] = ave;
+        mini_shell[MS_AVGFIX * n_step + R] = mean_sfr_zpp_mini[R] / ave;
+    }
+}
+
+struct MiniScalars {
+    double sfr_scale_mini, xray_scale_mini, mt_min, mt_width, lw_scale;
+};
+
+// the shell loop with both populations: six sums to `sums`, the Lyman-Werner background to J_21_LW
+__global__ void __launch_bounds__(kBlock)
+ts_accumulate_mini_kernel(c21hip_ts_args a, MiniScalars ms, const float *__restrict__ prev_xe,
+                          const float *__restrict__ delNL0, const float *__restrict__ mcrit,
+                          const float *__restrict__ tables, const float *__restrict__ tables2,
+                          const double *__restrict__ dev_tab, const double *__restrict__ mini_shell,
+                          double *__restrict__ sums, float *__restrict__ J_21_LW, size_t ntot) {
+    extern __shared__ double sh[];  // the one-population table buffer, then the mini rows
+    const int n = a.n_step;
+    const int n_tab = (SH_COUNT + 3 * C21CM_X_INT_NXHII) * n;
+    for (int i = threadIdx.x; i < n_tab; i += kBlock) sh[i] = dev_tab[i];
+    double *shm = sh + n_tab;
+    for (int i = threadIdx.x; i < MS_COUNT * n; i += kBlock) shm[i] = mini_shell[i];
+    __syncthreads();
+    const double *fheat = sh + SH_COUNT * n, *fion = fheat + C21CM_X_INT_NXHII * n,
+                 *flya = fion + C21CM_X_INT_NXHII * n;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        float xHII_call = prev_xe[i];  // :1499-1514
+        if (xHII_call > kXHII[C21CM_X_INT_NXHII - 1] * 0.999)
+            xHII_call = (float)(kXHII[C21CM_X_INT_NXHII - 1] * 0.999);
+        else if (xHII_call < kXHII[0])
+            xHII_call = (float)(1.001 * kXHII[0]);
+        int mm = C21CM_X_INT_NXHII - 1;
+        while (xHII_call < kXHII[mm]) mm--;
+        const float inv_diff = (float)(1. / (kXHII[mm + 1] - kXHII[mm]));
+        const double ival = (double)((xHII_call - kXHII[mm]) * inv_diff);
+        CellSums q{0., 0., 0., 0., 0., 0.};
+        double lw = 0.;
+        for (int R = n; R--;) {
+            const double z_edge = sh[SH_ZEDGE * n + R], xray_R = sh[SH_XRAY_R * n + R];
+            const double curr_dens = (double)delNL0[(size_t)R * ntot + i] * sh[SH_GROWTH * n + R];
+            const double tab_min = sh[SH_TABMIN * n + R], tab_width = sh[SH_TABWIDTH * n + R];
+            const double fcoll = exp_f32acc(table_1d(curr_dens, tab_min, tab_width,
+                                                     sh[SH_TABINVW * n + R],
+                                                     tables + (size_t)R * C21CM_NDELTA_TABLE));
+            const float sfrd = (float)((1. + curr_dens) * fcoll);
+            const double sfr_term = (double)sfrd * z_edge * sh[SH_AVGFIX * n + R] * a.sfr_scale;
+            const double fcoll_mini =
+                exp(table_2d(curr_dens, (double)mcrit[(size_t)R * ntot + i], tab_min, tab_width,
+                             ms.mt_min, ms.mt_width,
+                             tables2 + (size_t)R * C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE));
+            const float sfrd_mini = (float)((1. + curr_dens) * fcoll_mini);
+            const double sfr_term_mini =
+                (double)sfrd_mini * z_edge * shm[MS_AVGFIX * n + R] * ms.sfr_scale_mini;
+            double xray_sfr = sfr_term * a.xray_scale * xray_R;
+            xray_sfr += sfr_term_mini * ms.xray_scale_mini * xray_R;
+            lw += sfr_term * shm[MS_LW * n + R] + sfr_term_mini * shm[MS_LW_MINI * n + R];
+            const int lo = mm * n + R, hi = lo + n;
+            if (a.use_xray_heating) q.heat += xray_sfr * ((fheat[hi] - fheat[lo]) * ival + fheat[lo]);
+            q.ion += xray_sfr * ((fion[hi] - fion[lo]) * ival + fion[lo]);
+            q.lya += xray_sfr * ((flya[hi] - flya[lo]) * ival + flya[lo]);
+            q.starlya += sfr_term * sh[SH_STARLYA * n + R] + sfr_term_mini * shm[MS_STARLYA * n + R];
+            if (a.use_lya_heating) {
+                q.cont += sfr_term * sh[SH_CONT * n + R] + sfr_term_mini * shm[MS_CONT * n + R];
+                q.inj += sfr_term * sh[SH_INJ * n + R] + sfr_term_mini * shm[MS_INJ * n + R];
+            }
+        }
+        sums[i] = q.heat;
+        sums[ntot + i] = q.ion;
+        sums[2 * ntot + i] = q.lya;
+        sums[3 * ntot + i] = q.starlya;
+        if (a.use_lya_heating) {
+            sums[4 * ntot + i] = q.cont;
+            sums[5 * ntot + i] = q.inj;
+        }
+        J_21_LW[i] = (float)(lw * ms.lw_scale);  // :1843-1845
+    }
+}
+
+// prepare_filter_boxes with USE_MINI_HALOS (:535-565)
+__global__ void __launch_bounds__(kBlock)
+ts_mcrit_kernel(const float *__restrict__ J_21_LW, const float *__restrict__ vcb, float vcb_const,
+                float z, double A_LW, double BETA_LW, double A_VCB, double BETA_VCB,
+                double sigma_vcb, double m_turn, float *__restrict__ out, size_t ntot) {
+    const double mcrit_noLW = 3.314e7 * pow(1. + (double)z, -1.5);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const float v = vcb ? vcb[i] : vcb_const;
+        const double f_LW = 1.0 + A_LW * pow((double)J_21_LW[i], BETA_LW);
+        const double f_vcb = pow(1.0 + A_VCB * (double)v / sigma_vcb, BETA_VCB);
+        out[i] = (float)log10(fmax(mcrit_noLW * f_LW * f_vcb, m_turn));
+    }
+}
+}  // namespace
+
+extern "C" int c21hip_ts_mcrit_grid(const float *J_21_LW, const float *vcb, double vcb_const,
+                                    double redshift, double A_LW, double BETA_LW, double A_VCB,
+                                    double BETA_VCB, double sigma_vcb, double m_turn, float *out,
+                                    size_t ntot, void *stream) {
+    hipLaunchKernelGGL(ts_mcrit_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0, (hipStream_t)stream,
+                       J_21_LW, vcb, (float)vcb_const, (float)redshift, A_LW, BETA_LW, A_VCB,
+                       BETA_VCB, sigma_vcb, m_turn, out, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_ts_sfrd_means_mini(const float *filtered_density, const float *filtered_mcrit,
+                                         const float *tables2_dev, const double *dev_tab,
+                                         double *mini_shell_dev, const double *mean_sfr_mini_dev,
+                                         int n_step, size_t ntot, double mt_min, double mt_width,
+                                         double *partials, double *ave_out_dev, void *stream) {
+    int bx = grid_for(ntot);
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(sfrd_sum_mini_kernel, dim3(bx, n_step), dim3(kBlock), 0, (hipStream_t)stream,
+                       filtered_density, filtered_mcrit, tables2_dev, dev_tab, n_step, ntot, mt_min,
+                       mt_width, partials);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(sfrd_finish_mini_kernel, dim3(n_step), dim3(kBlock), 0, (hipStream_t)stream,
+                       partials, bx, mean_sfr_mini_dev, (double)ntot, n_step, mini_shell_dev,
+                       ave_out_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_ts_accumulate_mini(const c21hip_ts_args *a, double sfr_scale_mini,
+                                         double xray_scale_mini, double mt_min, double mt_width,
+                                         const float *prev_xe, const float *delNL0,
+                                         const float *mcrit, const float *tables_dev,
+                                         const float *tables2_dev, const double *dev_tab,
+                                         const double *mini_shell_dev, double *sums_ws,
+                                         float *J_21_LW, size_t ntot, void *stream) {
+    const size_t lds =
+        (c21hip_ts_table_doubles(a->n_step) + (size_t)MS_COUNT * a->n_step) * sizeof(double);
+    if (lds > 64 * 1024) {
+        c21hip_set_error("spin temperature: %d shells do not fit the table cache", a->n_step);
+        return C21CM_VALUE_ERROR;
+    }
+    MiniScalars ms;
+    ms.sfr_scale_mini = sfr_scale_mini;
+    ms.xray_scale_mini = xray_scale_mini;
+    ms.mt_min = mt_min;
+    ms.mt_width = mt_width;
+    ms.lw_scale = a->lya_star_prefactor * a->volunit_inv * a->h_p * 1e21;
+    hipLaunchKernelGGL(ts_accumulate_mini_kernel, dim3(grid_for(ntot)), dim3(kBlock), lds,
+                       (hipStream_t)stream, *a, ms, prev_xe, delNL0, mcrit, tables_dev, tables2_dev,
+                       dev_tab, mini_shell_dev, sums_ws, J_21_LW, ntot);
     LAUNCH_CHECK();
     return 0;
 }

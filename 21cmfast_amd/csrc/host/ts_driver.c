@@ -24,6 +24,9 @@ enum {
     WS_TS_SFRDTAB, WS_TS_LYA_C, WS_TS_LYA_I, WS_TS_OTS, WS_TS_OTK, WS_TS_OXE, WS_TS_PART,
     WS_TS_SMALL, WS_TS_MEANSFR, WS_TS_SFRDTAB2, WS_TS_SUMS
 };
+/* USE_MINI_HALOS: 2-D tables, filtered turnover grids, mini shell rows, J_21_LW staging */
+enum { WS_TS_MINI_TAB = 208, WS_TS_MINI_MCRIT, WS_TS_MINI_SHELL, WS_TS_MINI_J21, WS_TS_MINI_MEAN,
+       WS_TS_MCRIT_J21, WS_TS_MCRIT_VCB, WS_TS_MCRIT_OUT };
 
 #define TRY(expr)         \
     do {                  \
@@ -116,6 +119,13 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
         (!filtered_density || (fcoll_mode ? (!s->fcoll_tables || !s->dfcoll_tables) : !s->ln_sfrd_tables))) {
         c21hip_set_error("spin temperature: Eulerian sources need the filtered densities and the "
                          "SFRD tables");
+        return C21CM_VALUE_ERROR;
+    }
+    const int mini = s->use_mini_halos;
+    if (mini && (s->source_mode != C21CM_TS_SRC_SFRD_TABLE || !out->J_21_LW ||
+                 (!s->no_light && (!s->ln_sfrd_tables_mini || !s->filtered_log10_mcrit)))) {
+        c21hip_set_error("spin temperature: USE_MINI_HALOS runs on the E-INTEGRAL tables and needs "
+                         "the 2-D SFRD tables, the filtered log10 M_crit grids and TsBox.J_21_LW");
         return C21CM_VALUE_ERROR;
     }
     if (c21hip_device_count() < 1) {
@@ -232,6 +242,53 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
             goto done;
         }
     }
+    float *o_j21 = NULL;
+    double *ave_mini_dev = NULL;
+    if (mini) { /* the shell loop with both populations, J_21_LW (:1011-1075,1642-1733,1843) */
+        o_j21 = stage_out(WS_TS_MINI_J21, out->J_21_LW, bytes, &status);
+        if (status) goto done;
+        if (s->no_light) {
+            TRY(c21hip_memset(o_j21, 0, bytes, stream));
+        } else {
+            const size_t t2b = (size_t)n * C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE * sizeof(float);
+            /* (slack: one more row of the last table for the weight-0 reads on the last knots) */
+            float *tab2 = (float *)c21hip_ws(WS_TS_MINI_TAB, t2b + 2 * C21CM_NMTURN_TABLE * sizeof(float));
+            double *mini_shell = (double *)c21hip_ws(
+                WS_TS_MINI_SHELL, (size_t)(C21HIP_TS_MINI_ROWS + 2) * n * sizeof(double));
+            if (!tab2 || !mini_shell) {
+                status = C21CM_MEMORY_ALLOC_ERROR;
+                goto done;
+            }
+            TRY(c21hip_memset((char *)tab2 + t2b, 0, 2 * C21CM_NMTURN_TABLE * sizeof(float), stream));
+            if (c21hip_is_device_ptr(s->ln_sfrd_tables_mini))
+                TRY(c21hip_d2d(tab2, s->ln_sfrd_tables_mini, t2b, stream));
+            else
+                TRY(c21hip_h2d(tab2, s->ln_sfrd_tables_mini, t2b, stream));
+            const float *d_mcrit = (const float *)stage_in(WS_TS_MINI_MCRIT, s->filtered_log10_mcrit,
+                                                           bytes * n, stream, &status);
+            if (status) goto done;
+            double rows[(C21HIP_TS_MINI_ROWS + 2) * C21CM_MAX_TS_RADII];
+            const double *src[C21HIP_TS_MINI_ROWS] = {
+                s->starlya_prefactor_mini, s->lya_cont_prefactor_mini, s->lya_inj_prefactor_mini,
+                s->lw_prefactor, s->lw_prefactor_mini, NULL};
+            for (int r = 0; r < C21HIP_TS_MINI_ROWS; r++)
+                for (int i = 0; i < n; i++) rows[r * n + i] = src[r] ? src[r][i] : 1.;
+            for (int i = 0; i < n; i++) rows[C21HIP_TS_MINI_ROWS * n + i] = s->mean_sfr_zpp_mini[i];
+            TRY(c21hip_h2d(mini_shell, rows, (size_t)(C21HIP_TS_MINI_ROWS + 1) * n * sizeof(double),
+                           stream));
+            TRY(c21hip_sync(stream)); /* `rows` is a stack buffer */
+            ave_mini_dev = mini_shell + (size_t)(C21HIP_TS_MINI_ROWS + 1) * n;
+            TRY(c21hip_ts_sfrd_means_mini(grid_a, d_mcrit, tab2, dev_tab, mini_shell,
+                                          mini_shell + (size_t)C21HIP_TS_MINI_ROWS * n, n, ntot,
+                                          s->mturn_tab_min, s->mturn_tab_width, partials,
+                                          ave_mini_dev, stream));
+            TRY(c21hip_ts_accumulate_mini(&a, s->sfr_scale_mini, s->xray_scale_mini,
+                                          s->mturn_tab_min, s->mturn_tab_width, d_pxe, grid_a,
+                                          d_mcrit, tables_dev, tab2, dev_tab, mini_shell, sums_ws,
+                                          o_j21, ntot, stream));
+            a.sums_ready = 1;
+        }
+    }
     TRY(c21hip_ts_cells(&a, d_dens, d_pts, d_ptk, d_pxe, grid_a, grid_b, tables_dev, dev_tab, lya_c,
                         lya_i, o_ts, o_tk, o_xe, ntot, sums_ws, partials + (size_t)512 * n, sums_dev,
                         flag_dev, stream));
@@ -239,6 +296,9 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     if (o_ts != out->spin_temperature) TRY(c21hip_d2h(out->spin_temperature, o_ts, bytes, stream));
     if (o_tk != out->kinetic_temp_neutral) TRY(c21hip_d2h(out->kinetic_temp_neutral, o_tk, bytes, stream));
     if (o_xe != out->xray_ionised_fraction) TRY(c21hip_d2h(out->xray_ionised_fraction, o_xe, bytes, stream));
+    if (mini && o_j21 != out->J_21_LW) TRY(c21hip_d2h(out->J_21_LW, o_j21, bytes, stream));
+    double back_mini[C21CM_MAX_TS_RADII];
+    if (ave_mini_dev) TRY(c21hip_d2h(back_mini, ave_mini_dev, (size_t)n * sizeof(double), stream));
     {
         double back[8 + C21CM_MAX_TS_RADII + 8];
         TRY(c21hip_d2h(back, small, (8 + (size_t)n) * sizeof(double) + sizeof(int), stream));
@@ -255,6 +315,8 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
             report->xion_ave = back[5] / (double)ntot;
             if (!lagrangian && !s->no_light)
                 for (int i = 0; i < n; i++) report->ave_sfrd[i] = back[8 + i];
+            if (ave_mini_dev)
+                for (int i = 0; i < n; i++) report->ave_sfrd_mini[i] = back_mini[i];
         }
         if (flag) {
             c21hip_set_error("Estimated spin temperature is either infinite or NaN");
@@ -289,6 +351,30 @@ int c21cm_ts_first_grids(const c21cm_ts_first_spec *s, const float *density, TsB
     if (o_tk != out->kinetic_temp_neutral) TRY(c21hip_d2h(out->kinetic_temp_neutral, o_tk, bytes, stream));
     if (o_xe != out->xray_ionised_fraction) TRY(c21hip_d2h(out->xray_ionised_fraction, o_xe, bytes, stream));
     TRY(c21hip_sync(stream));
+done:
+    return status;
+}
+
+/* prepare_filter_boxes with USE_MINI_HALOS (SpinTemperatureBox.c:535-565) */
+int c21cm_ts_mcrit_grid(const c21cm_mturn_spec *spec, double m_turn, const float *J_21_LW,
+                        const float *vcb, float *log10_mcrit, void *stream) {
+    int status = 0;
+    if (!spec || !J_21_LW || !log10_mcrit || spec->hii_dim < 1 || spec->hii_dim_z < 1) {
+        c21hip_set_error("ts_mcrit_grid: spec, J_21_LW and the output grid are required");
+        return C21CM_VALUE_ERROR;
+    }
+    const size_t ntot = (size_t)spec->hii_dim * spec->hii_dim * spec->hii_dim_z;
+    const size_t bytes = ntot * sizeof(float);
+    const float *j21 = (const float *)stage_in(WS_TS_MCRIT_J21, J_21_LW, bytes, stream, &status);
+    const float *v = vcb ? (const float *)stage_in(WS_TS_MCRIT_VCB, vcb, bytes, stream, &status) : NULL;
+    float *o = stage_out(WS_TS_MCRIT_OUT, log10_mcrit, bytes, &status);
+    if (status) goto done;
+    TRY(c21hip_ts_mcrit_grid(j21, v, spec->vcb_const, spec->redshift, spec->A_LW, spec->BETA_LW,
+                             spec->A_VCB, spec->BETA_VCB, spec->sigma_vcb, m_turn, o, ntot, stream));
+    if (o != log10_mcrit) {
+        TRY(c21hip_d2h(log10_mcrit, o, bytes, stream));
+        TRY(c21hip_sync(stream));
+    }
 done:
     return status;
 }

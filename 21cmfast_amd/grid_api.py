@@ -506,16 +506,34 @@ def ts_grids(spec: S.TsSpec, density, previous: dict, source: dict | None = None
     over the source grids (``source``: filtered_sfr / filtered_xray [n_step, ...], Lagrangian
     models) or over the filtered densities (``filtered_density`` [n_step, ...] with the spec's
     SFRD tables), then the x_e / T_k update and T_s of every cell.  ``previous``: the three boxes
-    of the previous snapshot.  Outputs live where ``density`` lives; ``report`` holds box means."""
+    of the previous snapshot.  Outputs live where ``density`` lives; ``report`` holds box means.
+    With ``spec.use_mini_halos`` (2-D tables and ``spec.filtered_log10_mcrit`` set by the caller)
+    the result also holds ``J_21_LW``."""
     out = {k: _new_like(density, 0.0) for k in TS_FIELDS}
     prev = S.TsBoxStruct(**{k: _fptr(previous[k]) for k in TS_FIELDS})
     box = S.TsBoxStruct(**{k: _fptr(out[k]) for k in TS_FIELDS})
+    if spec.use_mini_halos:
+        out["J_21_LW"] = _new_like(density, 0.0)
+        box.J_21_LW = _fptr(out["J_21_LW"])
     src = S.XraySourceBoxStruct(**{k: _fptr(v) for k, v in (source or {}).items()})
     rep = S.TsReport()
     check(load().c21cm_ts_grids(C.byref(spec), _vptr(density), C.byref(prev), C.byref(src),
                                 _vptr(filtered_density), C.byref(box), C.byref(rep),
                                 _stream(stream)), "c21cm_ts_grids")
     out["report"] = rep
+    return out
+
+
+def ts_mcrit_grid(spec: S.MturnSpec, m_turn: float, J_21_LW, vcb=None, stream=None):
+    """log10 of the Lyman-Werner turnover mass per cell from the previous TsBox's J_21_LW
+    (prepare_filter_boxes, SpinTemperatureBox.c:535-565); allocated like ``J_21_LW``."""
+    out = _new_like(J_21_LW, 0.0)
+    lib = load()
+    lib.c21cm_ts_mcrit_grid.restype = C.c_int
+    lib.c21cm_ts_mcrit_grid.argtypes = [C.POINTER(S.MturnSpec), C.c_double, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+    check(lib.c21cm_ts_mcrit_grid(C.byref(spec), float(m_turn), _vptr(J_21_LW), _vptr(vcb),
+                                  _vptr(out), _stream(stream)), "c21cm_ts_mcrit_grid")
     return out
 
 
