@@ -23,7 +23,6 @@ def run_both(api, oracle, spec, d, device):
         import torch
         spec._keep["mcrit_dev"] = torch.from_numpy(host_mcrit).cuda()
         spec._keep["tabs_mini_dev"] = torch.from_numpy(spec._keep["tabs_mini"]).cuda()
-        spec.filtered_log10_mcrit = S.c_float_p.from_address(0)  # replaced below
         import ctypes as C
         spec.filtered_log10_mcrit = C.cast(spec._keep["mcrit_dev"].data_ptr(), S.c_float_p)
         spec.ln_sfrd_tables_mini = C.cast(spec._keep["tabs_mini_dev"].data_ptr(), S.c_float_p)
