@@ -52,6 +52,7 @@
 #define PC_CM_PER_MPC 3.08567758e24
 #define PC_EV_TO_HZ 2.417989e14
 #define PC_NU_ION_HI 3.288465e15
+#define PC_NU_LW_THRESH 2.70331197e15 /* Constants.c:23 */
 #define PC_NU_ION_HEI 5.945836e15
 #define PC_NU_ION_HEII 1.3153862e16
 #define PC_NU_LY_ALPHA 2.46606727e15
@@ -459,6 +460,20 @@ double c21_spectral_emissivity(double nu_norm, int pop) {
     return N0[i] * pow(nu_norm, al[i]) / PC_NU_LY_ALPHA;
 }
 
+/* spectral_emissivity(nu_norm, 2, Population) :284-302: photons between nu_norm and the next
+ * Lyman line, (1 - F_H2_SHIELD) applied by the caller; outside the tabulated bands the reference
+ * falls through to its (re)initialisation branch and returns 0 */
+double c21_spectral_emissivity_lw(double nu_norm, int pop) {
+    const float *N0 = pop == 2 ? H.N0_2 : H.N0_3, *al = pop == 2 ? H.alpha_S_2 : H.alpha_S_3;
+    for (int i = 1; i < (NSPEC_MAX - 1); i++)
+        if ((nu_norm >= H.nu_n[i]) && (nu_norm < H.nu_n[i + 1])) {
+            const double result =
+                N0[i] / (al[i] + 1) * (pow(H.nu_n[i + 1], al[i] + 1) - pow(nu_norm, al[i] + 1));
+            return result > 0 ? result : 1e-40;
+        }
+    return 0.0;
+}
+
 /* ================================================================ elec_interp.c */
 static int locate_energy_index(float En) {
     if (En < 1008.88) return (int)(log(En / 10.0) / 1.98026273e-2);
@@ -594,6 +609,9 @@ static struct {
     int ready, n;
     double x_min, x_width;
     double nion[ZT_MAX], sfrd[ZT_MAX];
+    /* USE_MINI_HALOS: [ZPP_INTERP_POINTS][C21_NMTURN] on the fixed turnover grid */
+    double *nion_mini, *sfrd_mini;
+    double y_min, y_width;
 } zt;
 
 static double minimum_source_mass_xray(double redshift) { /* hmf.c:1319-1348 with xray = true */
@@ -626,18 +644,36 @@ static int build_z_tables(float zmin, float zmax, const c21_scaling_consts *sc) 
     zt.ready = 0;
     zt.x_min = zmin;
     zt.x_width = (zmax - zmin) / ((double)ZPP_INTERP_POINTS - 1.);
-    c21_scaling_consts sc_sfrd = *sc; /* evolve_scaling_constants_sfr */
-    sc_sfrd.fesc_10 = 1., sc_sfrd.fesc_7 = 1., sc_sfrd.alpha_esc = 0., sc_sfrd.Mlim_Fesc = 0.;
+    const c21_scaling_consts sc_sfrd = c21_scaling_consts_sfr(sc);
     (void)c21_sigma_fast(1e10); /* build the sigma(M) spline before the threads read it */
     int bad = 0;
+    const int mini = astro_options_global->USE_MINI_HALOS;
 #pragma omp parallel for schedule(dynamic, 8) num_threads(host_threads()) reduction(| : bad)
     for (int i = 0; i < ZPP_INTERP_POINTS; i++) {
         const double z_val = zt.x_min + i * zt.x_width;
         const double lnMmin = log(minimum_source_mass_xray(z_val));
-        /* evolve_scaling_constants_to_redshift only changes t_h, which these integrals ignore */
-        zt.nion[i] = c21_Nion_General(z_val, lnMmin, lnMmax, sc->mturn_a_nofb, sc);
-        zt.sfrd[i] = c21_Nion_General(z_val, lnMmin, lnMmax, sc_sfrd.mturn_a_nofb, &sc_sfrd);
+        /* evolve_scaling_constants_to_redshift changes t_h, which these integrals ignore, and with
+         * mini-halos the atomic turnover max(M_acg(z), M_TURN) */
+        const double mturn_a = mini ? c21_scaling_consts_at_z(z_val, sc).mturn_a_nofb : sc->mturn_a_nofb;
+        zt.nion[i] = c21_Nion_General(z_val, lnMmin, lnMmax, mturn_a, sc);
+        zt.sfrd[i] = c21_Nion_General(z_val, lnMmin, lnMmax, mturn_a, &sc_sfrd);
         if (!isfinite(zt.nion[i]) || !isfinite(zt.sfrd[i])) bad |= 1;
+    }
+    if (mini && !bad) { /* Nion_z_table_MINI / SFRD_z_table_MINI, interp_tables.c:105-116,174-195 */
+        if (!zt.nion_mini) {
+            zt.nion_mini = (double *)malloc(sizeof(double) * 2 * ZPP_INTERP_POINTS * C21_NMTURN);
+            if (!zt.nion_mini) return C21CM_MEMORY_ALLOC_ERROR;
+            zt.sfrd_mini = zt.nion_mini + (size_t)ZPP_INTERP_POINTS * C21_NMTURN;
+        }
+        zt.y_min = C21_LOG10_MTURN_MIN;
+        zt.y_width = (C21_LOG10_MTURN_MAX - C21_LOG10_MTURN_MIN) / ((double)C21_NMTURN - 1.);
+        int st = c21_Nion_z_tables_mini(ZPP_INTERP_POINTS, zt.x_min, zt.x_width,
+                                        log(minimum_source_mass_xray(zt.x_min)), sc, C21_NMTURN,
+                                        zt.y_min, zt.y_width, zt.nion_mini, zt.sfrd_mini);
+        if (st) {
+            c21hip_set_error("spin temperature: the mini-halo N_ion(z) / SFRD(z) tables failed (%d)", st);
+            return st;
+        }
     }
     if (bad) {
         c21hip_set_error("spin temperature: infinite or NaN value in the N_ion(z) / SFRD(z) tables");
@@ -678,10 +714,26 @@ static int build_fcoll_z_table(double zmin, double zmax) {
 }
 double c21_EvaluateNionTs(double z) { return table_1d(z, zt.x_min, zt.x_width, zt.nion); }
 double c21_EvaluateSFRD(double z) { return table_1d(z, zt.x_min, zt.x_width, zt.sfrd); }
+/* interpolation.c:96-120 */
+static double table_2d(double x, double y, const double *z_arr) {
+    const int x_idx = (int)floor((x - zt.x_min) / zt.x_width);
+    const int y_idx = (int)floor((y - zt.y_min) / zt.y_width);
+    const double x_table = zt.x_min + zt.x_width * (double)x_idx;
+    const double y_table = zt.y_min + zt.y_width * (double)y_idx;
+    const double px = (x - x_table) / zt.x_width, py = (y - y_table) / zt.y_width;
+    const double *r0 = z_arr + (size_t)x_idx * C21_NMTURN + y_idx, *r1 = r0 + C21_NMTURN;
+    const double left_edge = r0[0] * (1 - py) + r0[1] * py;
+    const double right_edge = r1[0] * (1 - py) + r1[1] * py;
+    return left_edge * (1 - px) + right_edge * px;
+}
+double c21_EvaluateNionTs_MINI(double z, double l10mt) { return table_2d(z, l10mt, zt.nion_mini); }
+double c21_EvaluateSFRD_MINI(double z, double l10mt) { return table_2d(z, l10mt, zt.sfrd_mini); }
 
 /* ================================================================ tauX, nu_tau_one */
 typedef struct {
     double nu_0, x_e, x_e_ave, ion_eff;
+    int mini; /* tauX_integrand_MINI (:901-941) */
+    double ion_eff_mini, log10_mturn_mini;
 } taux_params;
 
 static double tauX_integrand(double zhat, void *params) { /* :943-975 */
@@ -689,39 +741,61 @@ static double tauX_integrand(double zhat, void *params) { /* :943-975 */
     const double drpropdz = PC_C_CMS * c21_dtdz(zhat);
     const double n = c21_nb0() * pow(1 + zhat, 3);
     const double nuhat = p->nu_0 * (1 + zhat);
-    double fcoll;
+    double fcoll, fcoll_mini = 0.;
     if (simulation_options_global->HII_DIM == 1 &&
-        p->x_e_ave < simulation_options_global->MIN_XE_FOR_FCOLL_IN_TAUX)
+        p->x_e_ave < simulation_options_global->MIN_XE_FOR_FCOLL_IN_TAUX) {
         fcoll = 0.;
-    else
+    } else {
         fcoll = c21_EvaluateNionTs(zhat);
+        if (p->mini) fcoll_mini = c21_EvaluateNionTs_MINI(zhat, p->log10_mturn_mini);
+    }
     double HI_filling_factor_zhat;
-    if (fcoll < 1e-20)
+    if (fcoll < 1e-20 && (!p->mini || fcoll_mini < 1e-20))
         HI_filling_factor_zhat = 1;
     else
-        HI_filling_factor_zhat = 1 - p->ion_eff * fcoll / (1.0 - p->x_e_ave);
+        HI_filling_factor_zhat =
+            1 - (p->ion_eff * fcoll + (p->mini ? p->ion_eff_mini * fcoll_mini : 0.)) / (1.0 - p->x_e_ave);
     if (HI_filling_factor_zhat < 1e-4) HI_filling_factor_zhat = 1e-4;
     return drpropdz * n * HI_filling_factor_zhat * c21_weighted_xray_cross_section(nuhat, p->x_e);
 }
 
-double c21_tauX(double nu, double x_e, double x_e_ave, double zp, double zpp, double ion_eff) {
-    taux_params p = {nu / (1 + zp), x_e, x_e_ave, ion_eff};
+static double tauX_both(double nu, double x_e, double x_e_ave, double zp, double zpp, double ion_eff,
+                        int mini, double ion_eff_mini, double log10_mturn_mini) {
+    taux_params p = {nu / (1 + zp), x_e, x_e_ave, ion_eff, mini, ion_eff_mini, log10_mturn_mini};
     return c21_qag15(tauX_integrand, &p, zpp, zp, 0.005, NULL, NULL);
+}
+double c21_tauX(double nu, double x_e, double x_e_ave, double zp, double zpp, double ion_eff) {
+    return tauX_both(nu, x_e, x_e_ave, zp, zpp, ion_eff, 0, 0., 0.);
 }
 
 typedef struct {
     double x_e, zp, zpp, ion_eff;
+    int mini;
+    double ion_eff_mini, log10_mturn_mini;
 } tau_one_params;
 static double nu_tau_one_helper(double nu, void *params) {
     const tau_one_params *p = (const tau_one_params *)params;
-    return c21_tauX(nu, p->x_e, p->x_e, p->zp, p->zpp, p->ion_eff) - 1;
+    return tauX_both(nu, p->x_e, p->x_e, p->zp, p->zpp, p->ion_eff, p->mini, p->ion_eff_mini,
+                     p->log10_mturn_mini) - 1;
 }
 
+static double nu_tau_one_both(double zp, double zpp, double x_e, double ion_eff, int mini,
+                              double ion_eff_mini, double log10_mturn_mini, int *status);
 double c21_nu_tau_one(double zp, double zpp, double x_e, double ion_eff, int *status) { /* :1135-1190 */
+    return nu_tau_one_both(zp, zpp, x_e, ion_eff, 0, 0., 0., status);
+}
+/* nu_tau_one_MINI (:1094-1160): the same root with both populations in the filling factor */
+double c21_nu_tau_one_MINI(double zp, double zpp, double x_e, double ion_eff, double ion_eff_mini,
+                           double log10_mturn_mini, int *status) {
+    return nu_tau_one_both(zp, zpp, x_e, ion_eff, 1, ion_eff_mini, log10_mturn_mini, status);
+}
+static double nu_tau_one_both(double zp, double zpp, double x_e, double ion_eff, int mini,
+                              double ion_eff_mini, double log10_mturn_mini, int *status) {
     if (status) *status = 0;
     if (x_e > 0.9999) return astro_params_global->NU_X_THRESH; /* sic: eV, not Hz (:1146-1149) */
-    if (c21_tauX(PC_NU_ION_HEI, x_e, x_e, zp, zpp, ion_eff) < 1) return PC_NU_ION_HEI;
-    tau_one_params p = {x_e, zp, zpp, ion_eff};
+    if (tauX_both(PC_NU_ION_HEI, x_e, x_e, zp, zpp, ion_eff, mini, ion_eff_mini, log10_mturn_mini) < 1)
+        return PC_NU_ION_HEI;
+    tau_one_params p = {x_e, zp, zpp, ion_eff, mini, ion_eff_mini, log10_mturn_mini};
     int st = 0;
     const double r = c21_brent_root(nu_tau_one_helper, &p, PC_NU_ION_HEI, 1e6 * PC_EV_TO_HZ, 0.02, 100, &st);
     if (!isfinite(r) || st == 1) {
@@ -738,6 +812,7 @@ void c21_ts_tables_free(c21_ts_tables *t) {
     free(t->sfrd_tables);
     free(t->fcoll_tables);
     free(t->dfcoll_tables);
+    free(t->sfrd_tables_mini);
     memset(t, 0, sizeof(*t));
 }
 
@@ -780,17 +855,40 @@ static void spectral_factors(double zp, c21_ts_tables *t) {
     int first_radii = 1, first_zero = 1;
     const int n_pts_radii = 1000;
     double weight = 0., sum_lyn_prev = 0., sum_ly2_prev = 0., sum_lynto2_prev = 0., prev_zpp = 0;
+    double sum_lyn_prev_MINI = 0., sum_ly2_prev_MINI = 0., sum_lynto2_prev_MINI = 0.;
+    const int mini = astro_options_global->USE_MINI_HALOS;
+    const double lw_edge = PC_NU_LW_THRESH / PC_NU_ION_HI;
+    const double shield = 1. - astro_params_global->F_H2_SHIELD;
     for (int R_ct = 0; R_ct < t->n_step; R_ct++) {
         const double zpp = t->zpp[R_ct];
         double sum_lynto2_val = 0., sum_ly2_val = 0.;
+        double sum_lynto2_val_MINI = 0., sum_ly2_val_MINI = 0., sum_lyLW_val = 0., sum_lyLW_val_MINI = 0.;
         double nuprime = c21_nu_n(2) * (1. + zpp) / (1. + zp);
-        if (zpp < c21_zmax(zp, 2)) sum_ly2_val = c21_frecycle(2) * c21_spectral_emissivity(nuprime, 2);
+        if (zpp < c21_zmax(zp, 2)) {
+            sum_ly2_val = c21_frecycle(2) * c21_spectral_emissivity(nuprime, 2);
+            if (mini) { /* :397-410 (nuprime < nu_n(3) holds by the definition of zmax) */
+                sum_ly2_val_MINI = c21_frecycle(2) * c21_spectral_emissivity(nuprime, 3);
+                if (nuprime < lw_edge) nuprime = lw_edge;
+                if (nuprime < c21_nu_n(3)) {
+                    sum_lyLW_val += shield * c21_spectral_emissivity_lw(nuprime, 2);
+                    sum_lyLW_val_MINI += shield * c21_spectral_emissivity_lw(nuprime, 3);
+                }
+            }
+        }
         for (int n_ct = NSPEC_MAX; n_ct >= 3; n_ct--) {
             if (zpp > c21_zmax(zp, n_ct)) continue;
             nuprime = c21_nu_n(n_ct) * (1 + zpp) / (1.0 + zp);
             sum_lynto2_val += c21_frecycle(n_ct) * c21_spectral_emissivity(nuprime, 2);
+            if (mini) { /* :418-429 */
+                sum_lynto2_val_MINI += c21_frecycle(n_ct) * c21_spectral_emissivity(nuprime, 3);
+                if (nuprime < lw_edge) nuprime = lw_edge;
+                if (nuprime >= c21_nu_n(n_ct + 1)) continue;
+                sum_lyLW_val += shield * c21_spectral_emissivity_lw(nuprime, 2);
+                sum_lyLW_val_MINI += shield * c21_spectral_emissivity_lw(nuprime, 3);
+            }
         }
         double sum_lyn_val = sum_ly2_val + sum_lynto2_val;
+        double sum_lyn_val_MINI = sum_ly2_val_MINI + sum_lynto2_val_MINI;
         if (R_ct > 1 && sum_lyn_val == 0.0 && sum_lyn_prev > 0. && first_radii) {
             for (int ii = 0; ii < n_pts_radii; ii++) {
                 const double trial_zpp = prev_zpp + (zpp - prev_zpp) * (float)ii / ((float)n_pts_radii - 1.);
@@ -807,15 +905,30 @@ static void spectral_factors(double zp, c21_ts_tables *t) {
             sum_lyn_val = weight * sum_lyn_prev;
             sum_ly2_val = weight * sum_ly2_prev;
             sum_lynto2_val = weight * sum_lynto2_prev;
+            if (mini) {
+                sum_lyn_val_MINI = weight * sum_lyn_prev_MINI;
+                sum_ly2_val_MINI = weight * sum_ly2_prev_MINI;
+                sum_lynto2_val_MINI = weight * sum_lynto2_prev_MINI;
+            }
             first_radii = 0;
         }
         const double zpp_integrand = (pow(1 + zp, 2) * (1 + zpp));
         t->starlya_prefactor[R_ct] = zpp_integrand * sum_lyn_val;
         t->lya_cont_prefactor[R_ct] = zpp_integrand * sum_ly2_val;
         t->lya_inj_prefactor[R_ct] = zpp_integrand * sum_lynto2_val;
+        if (mini) { /* :475-482 */
+            t->starlya_prefactor_mini[R_ct] = zpp_integrand * sum_lyn_val_MINI;
+            t->lw_prefactor[R_ct] = zpp_integrand * sum_lyLW_val;
+            t->lw_prefactor_mini[R_ct] = zpp_integrand * sum_lyLW_val_MINI;
+            t->lya_cont_prefactor_mini[R_ct] = zpp_integrand * sum_ly2_val_MINI;
+            t->lya_inj_prefactor_mini[R_ct] = zpp_integrand * sum_lynto2_val_MINI;
+        }
         sum_lyn_prev = sum_lyn_val;
         sum_ly2_prev = sum_ly2_val;
         sum_lynto2_prev = sum_lynto2_val;
+        sum_lyn_prev_MINI = sum_lyn_val_MINI;
+        sum_ly2_prev_MINI = sum_ly2_val_MINI;
+        sum_lynto2_prev_MINI = sum_lynto2_val_MINI;
         prev_zpp = zpp;
     }
 }
@@ -886,8 +999,10 @@ int c21_ts_prepare_shells(float redshift, float prev_redshift, float perturbed_f
     const AstroParams *ap = astro_params_global;
     const AstroOptions *ao = astro_options_global;
     const int model = matter_options_global->SOURCE_MODEL;
-    if (ao->USE_MINI_HALOS) {
-        c21hip_set_error("ComputeTsBox: USE_MINI_HALOS is not supported by this backend");
+    if (ao->USE_MINI_HALOS && (model != C21CM_SOURCE_E_INTEGRAL || matter_options_global->MINIMIZE_MEMORY ||
+                               ao->INTEGRATION_METHOD_MINI > 1)) {
+        c21hip_set_error("ComputeTsBox: USE_MINI_HALOS is built for SOURCE_MODEL = E-INTEGRAL without "
+                         "MINIMIZE_MEMORY (Gauss-Legendre or adaptive integrals)");
         return C21CM_VALUE_ERROR;
     }
     if (matter_options_global->USE_INTERPOLATION_TABLES == 0) {
@@ -939,6 +1054,20 @@ int c21_ts_prepare_shells(float redshift, float prev_redshift, float perturbed_f
     }
     s->sfr_scale = ap->F_STAR10;
     s->xray_scale = ap->L_X * PC_S_PER_YR;
+    if (ao->USE_MINI_HALOS) {
+        s->use_mini_halos = 1;
+        s->sfr_scale_mini = ap->F_STAR7_MINI;
+        s->xray_scale_mini = ap->L_X_MINI * PC_S_PER_YR;
+        s->mturn_tab_min = C21_LOG10_MTURN_MIN;
+        s->mturn_tab_width = (C21_LOG10_MTURN_MAX - C21_LOG10_MTURN_MIN) / (C21_NMTURN - 1.);
+        for (int i = 0; i < n; i++) {
+            s->starlya_prefactor_mini[i] = t->starlya_prefactor_mini[i];
+            s->lya_cont_prefactor_mini[i] = t->lya_cont_prefactor_mini[i];
+            s->lya_inj_prefactor_mini[i] = t->lya_inj_prefactor_mini[i];
+            s->lw_prefactor[i] = t->lw_prefactor[i];
+            s->lw_prefactor_mini[i] = t->lw_prefactor_mini[i];
+        }
+    }
     if (s->use_lya_heating) {
         s->lya_dEC = H.dEC;
         s->lya_dEI = H.dEI;
@@ -967,14 +1096,22 @@ int c21_ts_prepare_tables(double x_e_ave, c21cm_ts_spec *s, c21_ts_tables *t) {
             status = build_z_tables((float)determine_zpp_min, (float)determine_zpp_max, &sc);
         if (status) return status;
     }
+    const int mini = astro_options_global->USE_MINI_HALOS;
     const double sum_nion = c21_EvaluateNionTs(zp);
+    /* global_reion_properties (:973-1007): both populations in Q_HI and in NO_LIGHT */
+    const double sum_nion_mini = mini ? c21_EvaluateNionTs_MINI(zp, t->ave_log10_mturn[0]) : 0.;
     const double ion_eff = const_zeta ? (double)ap->HII_EFF_FACTOR : ap->F_STAR10 * ap->F_ESC10 * ap->POP2_ION;
-    t->Q_HI = 1 - (ion_eff * sum_nion) / (1.0 - x_e_ave);
-    t->no_light = sum_nion > 1e-15 ? 0 : 1;
+    const double ion_eff_mini = mini ? ap->F_STAR7_MINI * ap->F_ESC7_MINI * ap->POP3_ION : 0.;
+    t->Q_HI = 1 - (ion_eff * sum_nion + ion_eff_mini * sum_nion_mini) / (1.0 - x_e_ave);
+    t->no_light = sum_nion + sum_nion_mini > 1e-15 ? 0 : 1;
     s->no_light = t->no_light;
     for (int i = 0; i < n; i++) {
         t->mean_sfr_zpp[i] = c21_EvaluateSFRD(t->zpp[i]);
         s->mean_sfr_zpp[i] = t->mean_sfr_zpp[i];
+        if (mini) {
+            t->mean_sfr_zpp_mini[i] = c21_EvaluateSFRD_MINI(t->zpp[i], t->ave_log10_mturn[i]);
+            s->mean_sfr_zpp_mini[i] = t->mean_sfr_zpp_mini[i];
+        }
     }
 
     /* ---- fill_freqint_tables (:810-889); tauX's efficiency: pop2_ion fstar_10 fesc_10 (:1027-1029) */
@@ -994,7 +1131,11 @@ int c21_ts_prepare_tables(double x_e_ave, c21cm_ts_spec *s, c21_ts_tables *t) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads()) reduction(| : root_failed, table_bad)
     for (int R_ct = 0; R_ct < n; R_ct++) { /* the shells are independent (:822-863) */
         int st = 0;
-        const double nu1 = c21_nu_tau_one(zp, t->zpp[R_ct], x_e_ave, tau_ion_eff, &st);
+        /* :833-842: with mini-halos the root uses each shell's mean turnover mass */
+        const double nu1 =
+            mini ? c21_nu_tau_one_MINI(zp, t->zpp[R_ct], x_e_ave, tau_ion_eff,
+                                       sc.pop3_ion * sc.fstar_7 * sc.fesc_7, t->ave_log10_mturn[R_ct], &st)
+                 : c21_nu_tau_one(zp, t->zpp[R_ct], x_e_ave, tau_ion_eff, &st);
         if (st) root_failed |= 1;
         const double lower_int_limit = fmax(nu1, (ap->NU_X_THRESH) * PC_EV_TO_HZ);
         t->nu_tau_one[R_ct] = nu1;
@@ -1025,11 +1166,18 @@ int c21_ts_sfrd_tables(const double *min_densities, const double *max_densities,
     free(t->sfrd_tables);
     t->sfrd_tables = (float *)malloc((size_t)n * C21CM_NDELTA_TABLE * sizeof(float));
     if (!t->sfrd_tables) return C21CM_MEMORY_ALLOC_ERROR;
+    const int mini = astro_options_global->USE_MINI_HALOS;
+    if (mini) {
+        free(t->sfrd_tables_mini);
+        t->sfrd_tables_mini =
+            (float *)malloc((size_t)n * C21CM_NDELTA_TABLE * C21_NMTURN * sizeof(float));
+        if (!t->sfrd_tables_mini) return C21CM_MEMORY_ALLOC_ERROR;
+    }
     for (int R_ct = 0; R_ct < n; R_ct++) {
         c21_scaling_consts sc; /* set_scaling_constants(zpp) (:1558), then the SFRD variant */
         int status = c21_set_scaling_constants(t->zpp[R_ct], &sc);
         if (status) return status;
-        sc.fesc_10 = 1., sc.fesc_7 = 1., sc.alpha_esc = 0., sc.Mlim_Fesc = 0.;
+        sc = c21_scaling_consts_sfr(&sc);
         const double g = t->zpp_growth[R_ct];
         const double dmin = min_densities[R_ct] * g, dmax = max_densities[R_ct] * g * 1.001;
         const double lnMcond = log(t->M_max_R[R_ct]);
@@ -1039,10 +1187,20 @@ int c21_ts_sfrd_tables(const double *min_densities, const double *max_densities,
                                             t->sfrd_tables + (size_t)R_ct * C21CM_NDELTA_TABLE,
                                             C21CM_NDELTA_TABLE);
         if (status) return status;
+        if (mini) { /* SFRD_conditional_table_MINI on the fixed turnover grid (:440-475) */
+            status = c21_Nion_Conditional_table2d(
+                dicke(t->zpp[R_ct]), log(t->M_min_R[R_ct]), lnMcond, lnMcond,
+                (float)c21_sigma_fast(t->M_max_R[R_ct]), dmin, dmax, C21_LOG10_MTURN_MIN,
+                C21_LOG10_MTURN_MAX, &sc, 1, astro_options_global->INTEGRATION_METHOD_MINI, -50., 1,
+                t->sfrd_tables_mini + (size_t)R_ct * C21CM_NDELTA_TABLE * C21_NMTURN,
+                C21CM_NDELTA_TABLE, C21_NMTURN);
+            if (status) return status;
+        }
         s->tab_min[R_ct] = dmin;
         s->tab_width[R_ct] = (dmax - dmin) / (C21CM_NDELTA_TABLE - 1.);
     }
     s->ln_sfrd_tables = t->sfrd_tables;
+    if (mini) s->ln_sfrd_tables_mini = t->sfrd_tables_mini;
     return 0;
 }
 

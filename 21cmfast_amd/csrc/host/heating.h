@@ -30,6 +30,9 @@ double c21_frecycle(int n);
 double c21_nu_n(int n);
 float c21_zmax(float z, int n);
 double c21_spectral_emissivity(double nu_norm, int pop);
+double c21_spectral_emissivity_lw(double nu_norm, int pop); /* flag 2: the Lyman-Werner band integral */
+double c21_EvaluateNionTs_MINI(double z, double log10_mturn); /* valid after c21_ts_prepare_tables */
+double c21_EvaluateSFRD_MINI(double z, double log10_mturn);
 float c21_interp_fheat(float En, float xHII);
 float c21_interp_n_Lya(float En, float xHII);
 float c21_interp_nion_HI(float En, float xHII);
@@ -61,6 +64,13 @@ typedef struct c21_ts_tables {
     float *sfrd_tables; /* [n_step][C21CM_NDELTA_TABLE] */
     float *fcoll_tables, *dfcoll_tables; /* CONST-ION-EFF, same shape */
     double sigma_min[C21CM_MAX_TS_RADII], sigma_max[C21CM_MAX_TS_RADII];
+    /* USE_MINI_HALOS: the caller fills ave_log10_mturn (box mean of each shell's filtered
+     * log10 M_crit,LW, fill_Rbox_table's average_arr) before c21_ts_prepare_tables */
+    double ave_log10_mturn[C21CM_MAX_TS_RADII], mean_sfr_zpp_mini[C21CM_MAX_TS_RADII];
+    double starlya_prefactor_mini[C21CM_MAX_TS_RADII], lya_cont_prefactor_mini[C21CM_MAX_TS_RADII];
+    double lya_inj_prefactor_mini[C21CM_MAX_TS_RADII];
+    double lw_prefactor[C21CM_MAX_TS_RADII], lw_prefactor_mini[C21CM_MAX_TS_RADII];
+    float *sfrd_tables_mini; /* [n_step][C21CM_NDELTA_TABLE][C21CM_NMTURN_TABLE] */
 } c21_ts_tables;
 void c21_ts_tables_free(c21_ts_tables *t);
 int c21_ts_prepare(float redshift, float prev_redshift, float perturbed_field_redshift,

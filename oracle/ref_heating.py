@@ -189,6 +189,16 @@ class StellarSpectra:
         i = NSPEC_MAX - 1
         return float(self.N0[pop][i]) * nu_norm ** float(self.alpha[pop][i]) / PC["nu_Ly_alpha"]
 
+    def emissivity_lw(self, nu_norm: float, pop: int = 2) -> float:
+        """spectral_emissivity(nu, 2, pop) (:284-302): photons between nu and the next Lyman
+        line; outside the tabulated bands the C code falls through and returns 0"""
+        for i in range(1, NSPEC_MAX - 1):
+            if self.nu[i] <= nu_norm < self.nu[i + 1]:
+                a1 = float(self.alpha[pop][i]) + 1
+                r = float(self.N0[pop][i]) / a1 * (float(self.nu[i + 1]) ** a1 - nu_norm ** a1)
+                return r if r > 0 else 1e-40
+        return 0.0
+
 
 def spectral_factors(spec: StellarSpectra, zp: float, zpp_list) -> dict:
     """calculate_spectral_factors (:364-499) without mini-halos: dstarlya_dt_prefactor and its

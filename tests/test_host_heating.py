@@ -166,7 +166,11 @@ class Tables(C.Structure):
                                  "M_min_R", "M_max_R", "starlya_prefactor", "lya_cont_prefactor",
                                  "lya_inj_prefactor", "mean_sfr_zpp", "nu_tau_one")
     ] + [("freq", C.POINTER(f64)), ("sfrd_tables", C.POINTER(f32)), ("fcoll_tables", C.POINTER(f32)),
-         ("dfcoll_tables", C.POINTER(f32)), ("sigma_min", f64 * 128), ("sigma_max", f64 * 128)]
+         ("dfcoll_tables", C.POINTER(f32)), ("sigma_min", f64 * 128), ("sigma_max", f64 * 128)] + [
+        (k, f64 * 128) for k in ("ave_log10_mturn", "mean_sfr_zpp_mini", "starlya_prefactor_mini",
+                                 "lya_cont_prefactor_mini", "lya_inj_prefactor_mini", "lw_prefactor",
+                                 "lw_prefactor_mini")
+    ] + [("sfrd_tables_mini", C.POINTER(f32))]
 
 
 def test_ts_prepare_against_numpy(heat, pkg):
@@ -240,10 +244,12 @@ def test_unsupported_options_and_missing_tables(heat, pkg, tmp_path):
     S = pkg.structs
     spec, tab = S.TsSpec(), Tables()
     keep = heat._keep
-    keep["ao"].USE_MINI_HALOS = True
+    keep["ao"].USE_MINI_HALOS = True  # built for E-INTEGRAL with all shells in memory
+    keep["mo"].MINIMIZE_MEMORY = True
     assert heat.c21_ts_prepare(18.0, 18.7, 18.0, 2e-4, C.byref(spec), C.byref(tab)) == 3
     assert "USE_MINI_HALOS" in pkg.last_error()
     keep["ao"].USE_MINI_HALOS = False
+    keep["mo"].MINIMIZE_MEMORY = False
     keep["ao"].USE_LYA_HEATING = True  # the table is not part of the reference checkout
     assert heat.c21_ts_prepare(18.0, 18.7, 18.0, 2e-4, C.byref(spec), C.byref(tab)) == 1
     assert "Lyman_alpha_heating_table" in pkg.last_error()
