@@ -678,12 +678,11 @@ static int box_mean(const float *v, size_t n, double *mean) {
  * source model (tsfilter_driver.c) and the cell sweep (ts_driver.c / ts_kernels.hip).
  * Supported: the Eulerian source models (E-INTEGRAL: SFRD tables, CONST-ION-EFF: dfcoll/dz tables of
  * the filtered density) and the Lagrangian ones (XraySourceBox grids), with interpolation tables;
- * not: USE_MINI_HALOS. */
+ * USE_MINI_HALOS: with SOURCE_MODEL = E-INTEGRAL (2-D tables, the Lyman-Werner grid and J_21_LW). */
 int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
                  PerturbedField *perturbed_field, XraySourceBox *source_box,
                  TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp) {
     (void)cleanup;
-    (void)ini_boxes;
     int st = require_globals("ComputeTsBox", 1);
     if (st) return st;
     if (!perturbed_field || !perturbed_field->density || !this_spin_temp) {
@@ -713,6 +712,14 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
         f.N_b0 = c21_nb0();
         f.No = f.N_b0 * (1 - cosmo_params_global->Y_He) / (1 - 0.75 * cosmo_params_global->Y_He);
         f.A10 = 2.85e-15, f.T_21 = 0.0682, f.T_cmb = 2.7255; /* Constants.c:24-33 */
+        if (ao->USE_MINI_HALOS && this_spin_temp->J_21_LW) { /* no sources yet: no LW background */
+            float *j = this_spin_temp->J_21_LW;
+            if (c21hip_is_device_ptr(j)) {
+                if ((st = c21hip_fill(j, ntot, 0.f, NULL))) return st;
+            } else {
+                memset(j, 0, ntot * sizeof(float));
+            }
+        }
         return c21cm_ts_first_grids(&f, perturbed_field->density, this_spin_temp, NULL);
     }
     if (!previous_spin_temp || !previous_spin_temp->xray_ionised_fraction) {
@@ -754,6 +761,48 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
             c21hip_set_error("ComputeTsBox: out of device memory for %d filtered density grids", tab->n_step);
             st = C21CM_MEMORY_ALLOC_ERROR;
             goto done;
+        }
+        if (spec->use_mini_halos) {
+            /* prepare_filter_boxes + fill_Rbox_table of log10 M_crit,LW (:535-565,1459-1466): the
+             * turnover grid from the previous box's J_21_LW, filtered at every shell radius and
+             * floored at the threshold without a background; its box means feed the global tables,
+             * so this loop runs before them */
+            if (!previous_spin_temp->J_21_LW || !this_spin_temp->J_21_LW ||
+                (matter_options_global->V_CB_MODEL == C21CM_VCB_FLUCTS &&
+                 (!ini_boxes || !ini_boxes->lowres_vcb))) {
+                c21hip_set_error("ComputeTsBox: USE_MINI_HALOS needs J_21_LW in the previous and the new "
+                                 "box and, with V_CB_MODEL = FLUCTS, lowres_vcb");
+                st = C21CM_VALUE_ERROR;
+                goto done;
+            }
+            c21_scaling_consts sc;
+            if ((st = c21_set_scaling_constants(redshift, &sc))) goto done;
+            c21cm_mturn_spec ms;
+            memset(&ms, 0, sizeof(ms));
+            ms.hii_dim = hii, ms.hii_dim_z = hii_z;
+            ms.redshift = redshift;
+            ms.vcb_const = sc.vcb_const;
+            ms.A_LW = astro_params_global->A_LW, ms.BETA_LW = astro_params_global->BETA_LW;
+            ms.A_VCB = astro_params_global->A_VCB, ms.BETA_VCB = astro_params_global->BETA_VCB;
+            ms.sigma_vcb = cosmo_tables_global->V_CB_AVG * sqrt(3 * M_PI / 8);
+            float *mcrit = (float *)c21hip_ws(172, ntot * sizeof(float));
+            float *mcrit_R = (float *)c21hip_ws(173, (size_t)tab->n_step * ntot * sizeof(float));
+            if (!mcrit || !mcrit_R) {
+                st = C21CM_MEMORY_ALLOC_ERROR;
+                goto done;
+            }
+            if ((st = c21cm_ts_mcrit_grid(&ms, astro_params_global->M_TURN, previous_spin_temp->J_21_LW,
+                                          matter_options_global->V_CB_MODEL == C21CM_VCB_FLUCTS
+                                              ? ini_boxes->lowres_vcb : NULL,
+                                          mcrit, NULL)))
+                goto done;
+            c21cm_rbox_spec rm = job.spec;
+            rm.min_value = log10(c21_lyman_werner_threshold(redshift, 0.f, 0.f));
+            rm.const_factor = 1.;
+            double mn[C21CM_MAX_TS_RADII], mx[C21CM_MAX_TS_RADII];
+            if ((st = c21cm_fill_Rbox_grids(&rm, mcrit, mcrit_R, mn, tab->ave_log10_mturn, mx, NULL)))
+                goto done;
+            spec->filtered_log10_mcrit = mcrit_R;
         }
         job.device = c21hip_current_device();
         pthread_t worker;

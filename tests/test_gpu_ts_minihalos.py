@@ -95,3 +95,92 @@ def test_refusals(api):
     spec.use_mini_halos = 1
     with pytest.raises(RuntimeError, match="E-INTEGRAL"):
         api.ts_grids(spec, d["density"], d["previous"], d["source"], None)
+
+
+def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path):
+    """ComputeTsBox, E-INTEGRAL with USE_MINI_HALOS: the Lyman-Werner turnover grid from the previous
+    box's J_21_LW, its shell-filtered copies, both populations in the shell loop, J_21_LW out.  The
+    oracle runs on the spec and tables the library's host side prepares (checked on their own in
+    tests/test_host_heating_minihalos.py), with its own filter loops."""
+    import ctypes as C
+    from pathlib import Path
+
+    from test_gpu_abi import Session
+    from test_host_heating import Tables
+
+    lib = gpu_lib
+    n = 24
+    data = Path(__file__).parent / "golden" / "reference" / "_data"
+    ses = Session(lib, tmp_path, data_dir=data, HII_DIM=n, DIM=2 * n, BOX_LEN=2.0 * n, SOURCE_MODEL=1,
+                  USE_TS_FLUCT=True, USE_LYA_HEATING=False, Z_HEAT_MAX=30.0, USE_MINI_HALOS=True,
+                  ALPHA_STAR_MINI=0.5, F_STAR7_MINI=10 ** -2.2, L_X_MINI=10 ** 40.8, V_CB_MODEL=3)
+    rng = np.random.default_rng(8)
+    shape = (n, n, n)
+    z, prev_z = 16.0, 16.7
+    density = H.smooth_field(shape, rng, 0.25)
+    prev = {"xray_ionised_fraction": np.exp(rng.uniform(np.log(1.5e-4), np.log(4e-4), shape)).astype(np.float32),
+            "kinetic_temp_neutral": (9.0 * (1 + 0.6 * density)).astype(np.float32),
+            "spin_temperature": np.full(shape, 30.0, np.float32),
+            "J_21_LW": (0.4 * np.exp(H.smooth_field(shape, rng, 0.8))).astype(np.float32)}
+    fields = ("spin_temperature", "kinetic_temp_neutral", "xray_ionised_fraction", "J_21_LW")
+    out = {k: np.zeros(shape, np.float32) for k in fields}
+    fp = lambda a: a.ctypes.data_as(S.c_float_p)  # noqa: E731
+    pf = S.PerturbedFieldStruct(density=fp(density))
+    prevs = S.TsBoxStruct(**{k: fp(v) for k, v in prev.items()})
+    outs = S.TsBoxStruct(**{k: fp(v) for k, v in out.items()})
+    lib.ComputeTsBox.restype = C.c_int
+    lib.ComputeTsBox.argtypes = [C.c_float, C.c_float, C.c_float, C.c_short] + [C.c_void_p] * 5
+    st = lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), None, C.byref(prevs), None, C.byref(outs))
+    assert st == 0, lib.c21cm_last_error()
+
+    # ---- the oracle on the library's host tables
+    f64, f32, i32 = C.c_double, C.c_float, C.c_int
+    for name, res, args in (("c21_ts_prepare_shells", i32, [f32, f32, f32, C.c_void_p, C.c_void_p]),
+                            ("c21_ts_prepare_tables", i32, [f64, C.c_void_p, C.c_void_p]),
+                            ("c21_ts_sfrd_tables", i32, [C.POINTER(f64), C.POINTER(f64), C.c_void_p,
+                                                         C.c_void_p]),
+                            ("c21_lyman_werner_threshold", f64, [f32, f32, f32])):
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = args
+    spec, tab = S.TsSpec(), Tables()
+    assert lib.c21_ts_prepare_shells(z, prev_z, z, C.byref(spec), C.byref(tab)) == 0
+    n_step = tab.n_step
+    ms = S.MturnSpec(hii_dim=n, hii_dim_z=n, redshift=z, vcb_const=ses.ap.V_CB_AVG_DEBUG,
+                     A_LW=ses.ap.A_LW, BETA_LW=ses.ap.BETA_LW, A_VCB=ses.ap.A_VCB,
+                     BETA_VCB=ses.ap.BETA_VCB, sigma_vcb=ses.ct.V_CB_AVG * math.sqrt(3 * math.pi / 8))
+    mcrit = oracle.ts_mcrit_grid(ms, ses.ap.M_TURN, prev["J_21_LW"])
+    rs = S.RboxSpec(hii_dim=n, hii_dim_z=n, box_len=ses.so.BOX_LEN, box_len_z=ses.so.BOX_LEN,
+                    filter_type=ses.ao.HEAT_FILTER, n_R=n_step,
+                    cell_radius=0.620350491 * ses.so.BOX_LEN / np.float32(n))
+    for i in range(n_step):
+        rs.R[i] = tab.R_values[i]
+    rs.min_value, rs.const_factor = math.log10(lib.c21_lyman_werner_threshold(z, 0.0, 0.0)), 1.0
+    fm = oracle.fill_Rbox_grids(rs, mcrit)
+    for i in range(n_step):
+        tab.ave_log10_mturn[i] = fm["average"][i]
+    x_e_ave = float(prev["xray_ionised_fraction"].sum(dtype=np.float64) / np.float32(density.size))
+    assert lib.c21_ts_prepare_tables(x_e_ave, C.byref(spec), C.byref(tab)) == 0, lib.c21cm_last_error()
+    assert spec.no_light == 0 and outs.Q_HI == pytest.approx(tab.Q_HI, rel=1e-6)
+    rs.min_value, rs.const_factor = -1.0, 1.0 / lib.dicke(z)
+    fd = oracle.fill_Rbox_grids(rs, density)
+    mn = (f64 * 128)(*fd["min"], *([0.0] * (128 - n_step)))
+    mx = (f64 * 128)(*fd["max"], *([0.0] * (128 - n_step)))
+    assert lib.c21_ts_sfrd_tables(mn, mx, C.byref(spec), C.byref(tab)) == 0, lib.c21cm_last_error()
+    keep = np.ascontiguousarray(fm["result"])
+    spec.filtered_log10_mcrit = keep.ctypes.data_as(S.c_float_p)
+    ref = oracle.ts_grids(spec, density, prev, None, fd["result"])
+    compare({**out, "report": ref["report"]}, ref, spec)
+    # J_21_LW: float32 transforms move the filtered inputs by ~1e-6, the tables are steep in delta
+    np.testing.assert_allclose(out["J_21_LW"], ref["J_21_LW"], rtol=3e-4)
+    assert 1e-4 < out["J_21_LW"].mean() < 1e3
+    assert ref["report"].ave_sfrd_mini[0] > 0
+    # the molecularly cooled population matters at z = 16: without it the gas is ionised less
+    ses.ao.USE_MINI_HALOS = False
+    out0 = {k: np.zeros(shape, np.float32) for k in fields[:3]}
+    outs0 = S.TsBoxStruct(**{k: fp(v) for k, v in out0.items()})
+    prevs0 = S.TsBoxStruct(**{k: fp(prev[k]) for k in fields[:3]})
+    assert lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), None, C.byref(prevs0), None,
+                            C.byref(outs0)) == 0, lib.c21cm_last_error()
+    assert out["xray_ionised_fraction"].mean() > out0["xray_ionised_fraction"].mean()
+    lib.c21_ts_tables_free(C.byref(tab))
+    del ses
