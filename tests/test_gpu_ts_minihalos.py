@@ -100,8 +100,10 @@ def test_refusals(api):
 def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path):
     """ComputeTsBox, E-INTEGRAL with USE_MINI_HALOS: the Lyman-Werner turnover grid from the previous
     box's J_21_LW, its shell-filtered copies, both populations in the shell loop, J_21_LW out.  The
-    oracle runs on the spec and tables the library's host side prepares (checked on their own in
-    tests/test_host_heating_minihalos.py), with its own filter loops."""
+    oracle's cell algorithm runs on the spec and tables the library's host side prepares (checked
+    on their own in tests/test_host_heating_minihalos.py) and on the grids of the device's filter
+    loops (parity of those: tests/test_gpu_tsfilter.py) -- the tau_X = 1 roots are bracketed to 2 %
+    like upstream's, so the host tables are only reproducible from bit-identical box averages."""
     import ctypes as C
     from pathlib import Path
 
@@ -148,21 +150,25 @@ def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path):
     ms = S.MturnSpec(hii_dim=n, hii_dim_z=n, redshift=z, vcb_const=ses.ap.V_CB_AVG_DEBUG,
                      A_LW=ses.ap.A_LW, BETA_LW=ses.ap.BETA_LW, A_VCB=ses.ap.A_VCB,
                      BETA_VCB=ses.ap.BETA_VCB, sigma_vcb=ses.ct.V_CB_AVG * math.sqrt(3 * math.pi / 8))
-    mcrit = oracle.ts_mcrit_grid(ms, ses.ap.M_TURN, prev["J_21_LW"])
+    api = importlib.import_module("21cmfast_amd.grid_api")
+    mcrit = api.ts_mcrit_grid(ms, ses.ap.M_TURN, prev["J_21_LW"])
+    np.testing.assert_allclose(mcrit, oracle.ts_mcrit_grid(ms, ses.ap.M_TURN, prev["J_21_LW"]), rtol=3e-7)
     rs = S.RboxSpec(hii_dim=n, hii_dim_z=n, box_len=ses.so.BOX_LEN, box_len_z=ses.so.BOX_LEN,
                     filter_type=ses.ao.HEAT_FILTER, n_R=n_step,
-                    cell_radius=0.620350491 * ses.so.BOX_LEN / np.float32(n))
+                    cell_radius=0.620350491 * ses.so.BOX_LEN / float(n))
     for i in range(n_step):
         rs.R[i] = tab.R_values[i]
     rs.min_value, rs.const_factor = math.log10(lib.c21_lyman_werner_threshold(z, 0.0, 0.0)), 1.0
-    fm = oracle.fill_Rbox_grids(rs, mcrit)
+    fm = api.fill_Rbox_grids(rs, mcrit)
+    fm_o = oracle.fill_Rbox_grids(rs, mcrit)
+    np.testing.assert_allclose(fm["result"], fm_o["result"], rtol=2e-6)
     for i in range(n_step):
         tab.ave_log10_mturn[i] = fm["average"][i]
     x_e_ave = float(prev["xray_ionised_fraction"].sum(dtype=np.float64) / np.float32(density.size))
     assert lib.c21_ts_prepare_tables(x_e_ave, C.byref(spec), C.byref(tab)) == 0, lib.c21cm_last_error()
     assert spec.no_light == 0 and outs.Q_HI == pytest.approx(tab.Q_HI, rel=1e-6)
     rs.min_value, rs.const_factor = -1.0, 1.0 / lib.dicke(z)
-    fd = oracle.fill_Rbox_grids(rs, density)
+    fd = api.fill_Rbox_grids(rs, density)
     mn = (f64 * 128)(*fd["min"], *([0.0] * (128 - n_step)))
     mx = (f64 * 128)(*fd["max"], *([0.0] * (128 - n_step)))
     assert lib.c21_ts_sfrd_tables(mn, mx, C.byref(spec), C.byref(tab)) == 0, lib.c21cm_last_error()
