@@ -198,6 +198,21 @@ ION_FIELDS = ("neutral_fraction", "z_reion", "kinetic_temperature", "unnormalise
               "ionisation_rate_G12", "mean_free_path", "cumulative_recombinations")
 
 
+def ionisation_radii(so, ap, lagrangian: bool) -> int:
+    """Number of filter radii of the excursion set (setup_radii, IonisationBox.c:964-1006): the
+    length of IonizedBox.unnormalised_nion[_mini] with USE_MINI_HALOS."""
+    L_FACTOR = 0.620350491
+    pixel = float(so.BOX_LEN) / float(so.HII_DIM)
+    r_max = min(float(ap.R_BUBBLE_MAX), L_FACTOR * float(so.BOX_LEN))
+    cell_factor = 1.0 if (lagrangian and pixel < 1) else L_FACTOR
+    r_min = max(float(ap.R_BUBBLE_MIN), cell_factor * pixel)
+    n_radii = int(math.log(r_max / r_min) / math.log(float(ap.DELTA_R_HII_FACTOR)) + 1)
+    for i in range(n_radii):
+        if r_min * float(ap.DELTA_R_HII_FACTOR) ** i > r_max - 1e-7:
+            return i + 1
+    return n_radii
+
+
 def get_logspaced_redshifts(min_redshift, z_step_factor, max_redshift):
     """The node redshifts of an evolution, descending (wrapper/inputs.py:1774-1789)."""
     z = 10 ** np.arange(np.log10(1 + min_redshift), np.log10((1 + max_redshift) * z_step_factor),
@@ -278,10 +293,15 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
     if mo.SOURCE_MODEL not in (0, 1, 2):
         raise NotImplementedError("SOURCE_MODEL must be CONST-ION-EFF, E-INTEGRAL or L-INTEGRAL "
                                   "(halo catalogues are not part of this backend)")
+    mini = bool(ao.USE_MINI_HALOS)
+    if mini and not (mo.SOURCE_MODEL == 1 and ao.USE_TS_FLUCT):
+        raise NotImplementedError("USE_MINI_HALOS runs with SOURCE_MODEL = E-INTEGRAL and "
+                                  "USE_TS_FLUCT (the Lyman-Werner background comes from the TsBox)")
     _initialise(lib, inputs, data_path)
     n, nz = so.HII_DIM, int(so.NON_CUBIC_FACTOR * so.HII_DIM)
     shape = (n, n, nz)
     lagrangian, ts_on, recomb = mo.SOURCE_MODEL == 2, bool(ao.USE_TS_FLUCT), ao.RECOMB_MODEL
+    n_radii = ionisation_radii(so, ap, lagrangian)
     if device is not None:
         import torch
 
@@ -317,12 +337,15 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
         rshape = shape if recomb != 1 else (1, 1, 1)
         arr = {k: new(1.0 if k == "neutral_fraction" else 0.0,
                       rshape if k == "cumulative_recombinations" else shape) for k in ION_FIELDS}
+        if mini:  # one f_coll grid per filter radius and population (wrapper/outputs.py:1538-1543)
+            arr["unnormalised_nion"] = new(0.0, (n_radii,) + shape)
+            arr["unnormalised_nion_mini"] = new(0.0, (n_radii,) + shape)
         if mo.MINIMIZE_MEMORY:
             arr.pop("kinetic_temperature"), arr.pop("mean_free_path")
         return arr, S.IonizedBoxStruct(**{k: fp(v) for k, v in arr.items()})
 
     def new_ts():
-        arr = {k: new() for k in TS_FIELDS}
+        arr = {k: new() for k in TS_FIELDS + (("J_21_LW",) if mini else ())}
         return arr, S.TsBoxStruct(**{k: fp(v) for k, v in arr.items()})
 
     out_redshifts = [float(np.float32(z)) for z in out_redshifts]
@@ -332,6 +355,7 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
     prev_ts_arr, prev_ts = new_ts()
     prev_pf_arr = None
     prev_z, prev_xHI = 0.0, None
+    prev_means = (0.0, 0.0)
     z_halos, hboxes = [], []
     result, history = {}, []
     for z in nodes:
@@ -362,6 +386,12 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
             check(lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), C.byref(srcs) if srcs else None,
                                    C.byref(prev_ts), C.byref(icss), C.byref(ts)), "ComputeTsBox")
         ion_arr, ion = new_ion()
+        if prev_pf_arr is None and mini:
+            # the first snapshot's "previous" field is a dummy that ComputeIonizedBox overwrites
+            # with -1.5 (IonisationBox.c:394-398): it must not alias the current density
+            prev_pf_arr = {"density": new(), "velocity_z": new()}
+        if mini:  # the trapezoidal means live in the structs (set_mean_fcoll, :476-501)
+            prev_ion.mean_f_coll, prev_ion.mean_f_coll_MINI = prev_means
         prev_pf = S.PerturbedFieldStruct(**{k: fp(v) for k, v in (prev_pf_arr or pf_arr).items()})
         check(lib.ComputeIonizedBox(z, prev_z, C.byref(pf), C.byref(prev_pf), C.byref(prev_ion),
                                     C.byref(ts), C.byref(hb), C.byref(icss), C.byref(ion)),
@@ -380,7 +410,12 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
             boxes = {**pf_arr, **hb_arr, **ts_arr, **ion_arr, **bt_arr}
             snap = {k: boxes[k] for k in keep if k in boxes}
             snap["mean_f_coll"], snap["Q_HI"] = ion.mean_f_coll, ts.Q_HI
+            if mini:
+                snap["mean_f_coll_MINI"] = ion.mean_f_coll_MINI
+                snap["log10_Mturnover_ave"] = ion.log10_Mturnover_ave
+                snap["log10_Mturnover_MINI_ave"] = ion.log10_Mturnover_MINI_ave
             result[wanted[z]] = snap
+        prev_means = (ion.mean_f_coll, ion.mean_f_coll_MINI)
         if inputs.evolution_required:  # only then is a snapshot the next one's "previous"
             prev_ts_arr, prev_ts, prev_ion_arr, prev_ion, prev_pf_arr, prev_z = (
                 ts_arr, ts, ion_arr, ion, pf_arr, z)

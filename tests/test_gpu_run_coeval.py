@@ -73,3 +73,46 @@ def test_inputs_route_parameters_and_node_redshifts():
     assert D.Inputs(SOURCE_MODEL=1).node_redshifts([8.0, 12.0]) == (12.0, 8.0)
     with pytest.raises(TypeError, match="NOT_A_FIELD"):
         D.Inputs(NOT_A_FIELD=1)
+
+
+def test_run_coeval_with_mini_halos(gpu_lib, monkeypatch):
+    """E-INTEGRAL with USE_MINI_HALOS end to end (TsBox -> J_21_LW -> turnover masses of the
+    IonizedBox -> f_coll histories), device-resident.  No reference pin exists for it here (the
+    reference's `mini` fixtures need CLASS transfer tables), so this checks the couplings: a
+    growing Lyman-Werner background, turnover masses that follow it, earlier heating and
+    ionisation than the same run without the molecularly cooled population."""
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    common = dict(HII_DIM=32, DIM=64, BOX_LEN=64.0, N_THREADS=8, ZPRIME_STEP_FACTOR=1.1,
+                  Z_HEAT_MAX=25.0, HII_FILTER=0, USE_EXP_FILTER=False, CELL_RECOMB=False,
+                  USE_UPPER_STELLAR_TURNOVER=False, USE_LYA_HEATING=False, SOURCE_MODEL=1,
+                  USE_TS_FLUCT=True, R_BUBBLE_MAX=20.0, M_TURN=10 ** 5.0, RECOMB_MODEL=2)
+    keep = ("neutral_fraction", "brightness_temp", "J_21_LW", "xray_ionised_fraction",
+            "kinetic_temp_neutral", "unnormalised_nion_mini", "ionisation_rate_G12")
+    zs = [16.0, 10.0]
+    res = D.run_coeval(D.Inputs(random_seed=7, USE_MINI_HALOS=True, ALPHA_STAR_MINI=0.5,
+                                F_STAR7_MINI=10 ** -2.0, F_ESC7_MINI=10 ** -1.5, V_CB_MODEL=3,
+                                **common),
+                       zs, data_path=DATA, device="cuda", lib=gpu_lib, keep=keep)
+    base = D.run_coeval(D.Inputs(random_seed=7, **common), zs, data_path=DATA, device="cuda",
+                        lib=gpu_lib, keep=keep)
+    host = lambda a: a.cpu().numpy()  # noqa: E731
+    hi, lo = res[16.0], res[10.0]
+    for snap in (hi, lo):
+        for k in keep:
+            assert np.isfinite(host(snap[k])).all(), k
+    j_hi, j_lo = host(hi["J_21_LW"]), host(lo["J_21_LW"])
+    assert 0 < j_hi.mean() < j_lo.mean()  # the LW background builds up
+    # the molecular turnover follows the background; the atomic one sits at the cooling threshold
+    assert lo["log10_Mturnover_MINI_ave"] > hi["log10_Mturnover_MINI_ave"] > 5.0
+    assert 7.0 < hi["log10_Mturnover_ave"] < lo["log10_Mturnover_ave"] < 9.0
+    nR = D.ionisation_radii(res and D.Inputs(**common).simulation_options,
+                            D.Inputs(**common).astro_params, False)
+    assert host(lo["unnormalised_nion_mini"]).shape == (nR, 32, 32, 32)
+    assert host(lo["unnormalised_nion_mini"]).max() > 0 and lo["mean_f_coll_MINI"] > 0
+    # earlier X-ray heating / ionisation and reionisation than without the mini-halos
+    assert host(hi["xray_ionised_fraction"]).mean() > host(base[16.0]["xray_ionised_fraction"]).mean()
+    assert host(hi["kinetic_temp_neutral"]).mean() > host(base[16.0]["kinetic_temp_neutral"]).mean()
+    x_m, x_b = host(lo["neutral_fraction"]).mean(), host(base[10.0]["neutral_fraction"]).mean()
+    assert x_m < x_b and 0.0 <= x_m < 1.0
+    hist = np.array(res["history"])
+    assert np.all(np.diff(hist[:, 2]) <= 1e-6)  # the global neutral fraction only falls
