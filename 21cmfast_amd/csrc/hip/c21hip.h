@@ -372,6 +372,11 @@ int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int inhomo, int 
                        const float *kinetic_temp_neutral, const double *mean_a_dev,
                        const double *mean_m_dev, float *xH, float *z_reion,
                        float *kinetic_temperature, float *G12, float *mfp, void *stream);
+/* IONISE_ENTIRE_SPHERE (IonisationBox.c:1150-1158): every cell of the first-crossing mask flags
+ * the cells closer than its radius; rsq_dev[r] = (R_r in cells)^2 as update_in_sphere forms it
+ * (float), compared strictly with the integer distances (bubble_helper_progs.c:292-325) */
+int c21hip_paint_spheres(const unsigned char *first_cross, const float *rsq_dev, float *xH, int nx,
+                         int ny, int nz, void *stream);
 /* set_recombination_rates, inhomogeneous model (IonisationBox.c:1277-1339); rate_scale =
  * fabs_dtdz * dz; rr tables on the device */
 int c21hip_recomb_rates(const float *density, const float *G12, const float *xH,

@@ -1725,3 +1725,69 @@ extern "C" int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int i
     LAUNCH_CHECK();
     return 0;
 }
+
+// ======================================================================================
+// IONISE_ENTIRE_SPHERE (IonisationBox.c:1150-1158, bubble_helper_progs.c:262-418): a cell that
+// crosses the barrier at radius R flags every cell closer than R as ionised,
+//   x_HI(x) = 0  for  |x - c|^2 (nearest periodic image, in cells) < Rsq(R)   [strict, floats]
+// (update_in_sphere's inner cube lies inside that sphere).  A cell's larger radii contain its
+// smaller ones, so the first-crossing mask (largest radius index per cell) describes the whole
+// union.  One wavefront per crossing cell: lanes take the (dx, dy) columns of the bounding
+// square and store the run of z cells inside the sphere.  Stores of 0.f need no atomics.
+// ======================================================================================
+namespace {
+__global__ void __launch_bounds__(kBlock)
+paint_spheres_kernel(const unsigned char *__restrict__ first_cross,
+                     const float *__restrict__ rsq_of_index,  // [n_radii] Rsq in cells^2
+                     float *__restrict__ xH, int nx, int ny, int nz) {
+    const size_t ntot = (size_t)nx * ny * nz;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * kBlock) >> 6;
+    for (size_t base = wave * 64; base < ntot; base += n_waves * 64) {
+        const size_t mine = base + lane;
+        const int r = mine < ntot ? (int)first_cross[mine] : 0;
+        unsigned long long todo = __ballot(r > 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const size_t c = base + src;
+            const int rc = __shfl(r, src, 64);
+            const float Rsq = rsq_of_index[rc];
+            const int cz = (int)(c % nz), cy = (int)((c / nz) % ny), cx = (int)(c / ((size_t)nz * ny));
+            const int Ri = (int)ceilf(sqrtf(Rsq));  // bounding half-width (>= ceil(R dim))
+            const int side = 2 * Ri + 1;
+            for (int t = lane; t < side * side; t += 64) {
+                const int dx = t / side - Ri, dy = t % side - Ri;
+                const float rem = Rsq - (float)(dx * dx + dy * dy);  // exact: small integers
+                if (!(rem > 0.f)) continue;                          // Rsq > d^2 needs dz^2 < rem
+                int dzmax = (int)sqrtf(rem);
+                while ((float)(dzmax * dzmax) >= rem) dzmax--;        // strict inequality
+                while ((float)((dzmax + 1) * (dzmax + 1)) < rem) dzmax++;
+                int x = (cx + dx) % nx, y = (cy + dy) % ny;
+                if (x < 0) x += nx;
+                if (y < 0) y += ny;
+                float *line = xH + ((size_t)x * ny + y) * nz;
+                if (2 * dzmax + 1 >= nz) {
+                    for (int z = 0; z < nz; z++) line[z] = 0.f;
+                } else {
+                    for (int dz = -dzmax; dz <= dzmax; dz++) {
+                        int z = (cz + dz) % nz;
+                        if (z < 0) z += nz;
+                        line[z] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int c21hip_paint_spheres(const unsigned char *first_cross, const float *rsq_dev,
+                                    float *xH, int nx, int ny, int nz, void *stream) {
+    const size_t ntot = (size_t)nx * ny * nz;
+    hipLaunchKernelGGL(paint_spheres_kernel, dim3(grid_for((ntot + 63) / 64 * 64)), dim3(kBlock), 0,
+                       (hipStream_t)stream, first_cross, rsq_dev, xH, nx, ny, nz);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -92,7 +92,8 @@ enum {
     WS_MINI_HIST_A,
     WS_MINI_HIST_M,
     WS_MINI_OUT_A,
-    WS_MINI_OUT_M
+    WS_MINI_OUT_M,
+    WS_SPHERE_RSQ = 216
 };
 
 #define MAX_COPYBACK 12
@@ -163,6 +164,15 @@ static float *stage_inout(int slot, float *p, size_t bytes, int upload, copyback
     return (float *)d;
 }
 
+/* (R in cells)^2 as update_in_sphere forms it: float R = rspec.R / BOX_LEN, float product with
+ * the grid size, squared in double, stored as float (IonisationBox.c:1153-1158,
+ * bubble_helper_progs.c:342,384-385) */
+static float sphere_rsq(const c21cm_ionize_spec *s, int r) {
+    const float Rf = (float)(s->R[r] / (double)(float)s->box_len);
+    const float Rd = Rf * s->hii_dim;
+    return (float)pow((double)Rd, 2);
+}
+
 static int validate_spec(const c21cm_ionize_spec *s, const PerturbedField *pf,
                          const HaloBox *halos, const TsBox *ts, const IonizedBox *box) {
     if (!s || !pf || !box) {
@@ -219,6 +229,17 @@ static int validate_spec(const c21cm_ionize_spec *s, const PerturbedField *pf,
     } else if (s->fcoll_mode >= C21CM_FCOLL_TABLE_LINEAR && !s->table_fn) {
         c21hip_set_error("ionize: TABLE fcoll_mode needs table_fn");
         return C21CM_VALUE_ERROR;
+    }
+    if (s->ionise_entire_sphere) {
+        if (s->recomb_model != C21CM_RECOMB_NONE || s->use_mini_halos) {
+            c21hip_set_error("ionize: IONISE_ENTIRE_SPHERE with a recombination model or mini-halos "
+                             "is not built (upstream's result depends on its thread order there)");
+            return C21CM_VALUE_ERROR;
+        }
+        if (sphere_rsq(s, 0) > 1.f) {
+            c21hip_set_error("ionize: IONISE_ENTIRE_SPHERE needs a cell-scale radius below one cell");
+            return C21CM_VALUE_ERROR;
+        }
     }
     if (!pf->density || !box->neutral_fraction || !box->z_reion) {
         c21hip_set_error("ionize: density / neutral_fraction / z_reion arrays are required");
@@ -305,6 +326,7 @@ typedef struct {
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
     float *eul_xe[2];    /* dense x_e(R) of the Eulerian mask path (spin-temperature runs) */
+    int sphere;          /* IONISE_ENTIRE_SPHERE: radii > 0 only record the mask, spheres follow */
     /* USE_MINI_HALOS */
     int mini;
     float *pd_unf, *pd_work, *pd_fil, *mta_unf, *mta_work, *mta_fil, *mtm_unf, *mtm_work, *mtm_fil;
@@ -372,6 +394,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->fused = c->native && c->lagrangian && !c->recomb &&
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
+    c->sphere = s->ionise_entire_sphere;
     c->mini = s->use_mini_halos;
     c->eul_mask = c->native && !c->lagrangian && !c->recomb && !c->mini;
     if (c->mini) { /* four filtered grids per radius and the 2-D tables: the unfused sequence */
@@ -1232,6 +1255,21 @@ done:
     return status;
 }
 
+/* IONISE_ENTIRE_SPHERE: the spheres of all first crossings (IonisationBox.c:1150-1158) */
+static int paint_spheres(ion_ctx *c, const unsigned char *mask) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    float rsq[C21CM_MAX_RADII];
+    for (int r = 0; r < s->n_radii; r++) rsq[r] = sphere_rsq(s, r);
+    float *rsq_dev = (float *)c21hip_ws(WS_SPHERE_RSQ, sizeof(rsq));
+    if (!rsq_dev) return C21CM_MEMORY_ALLOC_ERROR;
+    TRY(c21hip_h2d(rsq_dev, rsq, sizeof(rsq), c->stream));
+    TRY(c21hip_sync(c->stream)); /* `rsq` is a stack buffer */
+    TRY(c21hip_paint_spheres(mask, rsq_dev, c->xH, c->nx, c->ny, c->nz, c->stream));
+done:
+    return status;
+}
+
 int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
                        const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                        const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
@@ -1248,7 +1286,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
     TRY(init_output_grids(&c, previous_ionize_box));
     TRY(preloop(&c));
     TRY(c21hip_event_record(ev[1], stream));
-    if (c.fused || c.eul_mask) {
+    if (c.fused || c.eul_mask || c.sphere) {
         c.mask = (unsigned char *)c21hip_ws(WS_FIRST_CROSS, c.ntot);
         if (!c.mask) {
             status = C21CM_MEMORY_ALLOC_ERROR;
@@ -1257,7 +1295,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         TRY(c21hip_memset(c.mask, 0, c.ntot, stream));
     }
     {
-        const int use_mask = c.fused || c.eul_mask;
+        const int use_mask = c.fused || c.eul_mask || c.sphere;
         int mask_pending = use_mask;
         int R_start = spec->n_radii;
         if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC) {
@@ -1275,22 +1313,26 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
                 mask_pending = 0;
-                if (c.fused) {
+                if (c.fused && !c.sphere) {
                     TRY(flush_deferred(&c));
                     TRY(final_step(&c, c.mask, 0));
                     break;
                 }
+                if (c.fused) TRY(flush_deferred(&c));
                 /* the cell-scale radius tests xH > TINY: materialise the mask first */
                 TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot,
                                              spec->redshift, c.xH, c.zre, c.ntot, stream));
+                if (c.sphere) TRY(paint_spheres(&c, c.mask));
             }
             TRY(one_radius(&c, R_ct, (R_ct > 0 && use_mask) ? c.mask : NULL,
                            (R_ct - 1 >= spec->r_lowest) ? R_ct - 1 : -1));
         }
         TRY(flush_deferred(&c));
-        if (mask_pending)
+        if (mask_pending) {
             TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot, spec->redshift,
                                          c.xH, c.zre, c.ntot, stream));
+            if (c.sphere) TRY(paint_spheres(&c, c.mask));
+        }
     }
     TRY(c21hip_event_record(ev[2], stream));
     TRY(postloop(&c, box, report));
@@ -1442,7 +1484,7 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
     TRY(init_output_grids(&c, previous_ionize_box));
     int stars_ready = 0;
     if (spec->r_lowest == 0) {
-        if (c.fused && r0_direct())
+        if (c.fused && r0_direct() && !c.sphere)
             stars_ready = 0; /* the final sweep reads the emissivity input itself */
         else if (spectra_match(&c, perturbed_field, halos, spin_temp))
             stars_ready = g_spectra.stars_r0_ready;
@@ -1450,11 +1492,12 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
             TRY(preloop(&c));
         g_spectra.valid = 0;
     }
-    if (c.fused && spec->r_lowest == 0) {
+    if (c.fused && spec->r_lowest == 0 && !c.sphere) {
         TRY(final_step(&c, first_cross, stars_ready));
     } else {
         TRY(c21hip_apply_first_cross(first_cross, c.prev_zre, spec->first_snapshot,
                                      spec->redshift, c.xH, c.zre, c.ntot, stream));
+        if (c.sphere) TRY(paint_spheres(&c, first_cross));
         if (spec->r_lowest == 0) TRY(one_radius(&c, 0, NULL, -1));
     }
     TRY(c21hip_event_record(ev[1], stream));

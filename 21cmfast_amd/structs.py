@@ -362,6 +362,7 @@ class IonizeSpec(_Base):
         ("log10_mturn_mcg", c_float_p),
         ("table2d_fn", TABLE2D_FN),
         ("table2d_user", C.c_void_p),
+        ("ionise_entire_sphere", C.c_int),
     ]
 
 

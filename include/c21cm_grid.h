@@ -132,6 +132,12 @@ typedef struct c21cm_ionize_spec {
     const float *log10_mturn_mcg;
     c21cm_table2d_fn table2d_fn;
     void *table2d_user;
+
+    /* AstroOptions.IONISE_ENTIRE_SPHERE (IonisationBox.c:1150-1158): a crossing cell flags all
+     * cells within R as ionised (x_HI only; z_reion stays with the centres).  Without a
+     * recombination model and without mini-halos (upstream's result then depends on the order in
+     * which its threads paint), and with a cell-scale radius below one cell. */
+    int ionise_entire_sphere;
 } c21cm_ionize_spec;
 
 #define C21CM_RR_NZ 300       /* recombinations.c:35 RR_Z_NPTS        */

@@ -133,6 +133,76 @@ static void clip_extrema(float *grid, int nx, int ny, int nz, double lower_limit
     *grid_max = max_buf;
 }
 
+/* bubble_helper_progs.c:262-330 (check_region) and :341-418 (update_in_sphere) */
+static void wrap3(int idx[3], const int size[3]) {
+    for (int a = 0; a < 3; a++) {
+        while (idx[a] >= size[a]) idx[a] -= size[a];
+        while (idx[a] < 0) idx[a] += size[a];
+    }
+}
+static void check_region(float *box, int dimensions, int dimensions_ncf, float Rsq_curr_index, int x,
+                         int y, int z, int x_min, int x_max, int y_min, int y_max, int z_min,
+                         int z_max) {
+    const int box_dim[3] = {dimensions, dimensions, dimensions_ncf};
+    for (int x_curr = x_min; x_curr <= x_max; x_curr++)
+        for (int y_curr = y_min; y_curr <= y_max; y_curr++)
+            for (int z_curr = z_min; z_curr <= z_max; z_curr++) {
+                int index_arr[3] = {x_curr, y_curr, z_curr};
+                wrap3(index_arr, box_dim);
+                const size_t index =
+                    (size_t)index_arr[2] + (size_t)box_dim[2] * ((size_t)index_arr[1] + (size_t)box_dim[1] * index_arr[0]);
+                if (box[index]) { /* all 27 reflections */
+                    const float sq[3][3] = {
+                        {powf(x - index_arr[0], 2), powf(x - index_arr[0] + dimensions, 2),
+                         powf(x - index_arr[0] - dimensions, 2)},
+                        {powf(y - index_arr[1], 2), powf(y - index_arr[1] + dimensions, 2),
+                         powf(y - index_arr[1] - dimensions, 2)},
+                        {powf(z - index_arr[2], 2), powf(z - index_arr[2] + dimensions_ncf, 2),
+                         powf(z - index_arr[2] - dimensions_ncf, 2)}};
+                    int inside = 0;
+                    for (int a = 0; a < 3; a++)
+                        for (int b = 0; b < 3; b++)
+                            for (int c = 0; c < 3; c++)
+                                if (Rsq_curr_index > (sq[0][a] + sq[1][b] + sq[2][c])) inside = 1;
+                    if (inside) box[index] = 0;
+                }
+            }
+}
+static void update_in_sphere(float *box, int dimensions, int dimensions_ncf, float R, float xf,
+                             float yf, float zf) {
+    const int box_dim[3] = {dimensions, dimensions, dimensions_ncf};
+    if (R < 0) return;
+    const int x = (int)(xf * dimensions + 0.5), y = (int)(yf * dimensions + 0.5),
+              z = (int)(zf * dimensions_ncf + 0.5);
+    int R_index = ceil(R / sqrt(3.0) * dimensions) - 1; /* the inner cube is painted outright */
+    const int xl_min = x - R_index, xl_max = x + R_index, yl_min = y - R_index,
+              yl_max = y + R_index, zl_min = z - R_index, zl_max = z + R_index;
+    for (int x_curr = xl_min; x_curr <= xl_max; x_curr++)
+        for (int y_curr = yl_min; y_curr <= yl_max; y_curr++)
+            for (int z_curr = zl_min; z_curr <= zl_max; z_curr++) {
+                int index_arr[3] = {x_curr, y_curr, z_curr};
+                wrap3(index_arr, box_dim);
+                box[(size_t)index_arr[2] +
+                    (size_t)box_dim[2] * ((size_t)index_arr[1] + (size_t)box_dim[1] * index_arr[0])] = 0;
+            }
+    R_index = ceil(R * dimensions);
+    const float Rsq_curr_index = pow(R * dimensions, 2);
+    const int xb_min = x - R_index, xb_max = x + R_index, yb_min = y - R_index,
+              yb_max = y + R_index, zb_min = z - R_index, zb_max = z + R_index;
+    check_region(box, dimensions, dimensions_ncf, Rsq_curr_index, x, y, z, xb_min, xl_min, yb_min,
+                 yb_max, zb_min, zb_max);
+    check_region(box, dimensions, dimensions_ncf, Rsq_curr_index, x, y, z, xl_max, xb_max, yb_min,
+                 yb_max, zb_min, zb_max);
+    check_region(box, dimensions, dimensions_ncf, Rsq_curr_index, x, y, z, xb_min, xb_max, yb_min,
+                 yl_min, zb_min, zb_max);
+    check_region(box, dimensions, dimensions_ncf, Rsq_curr_index, x, y, z, xb_min, xb_max, yl_max,
+                 yb_max, zb_min, zb_max);
+    check_region(box, dimensions, dimensions_ncf, Rsq_curr_index, x, y, z, xb_min, xb_max, yb_min,
+                 yb_max, zb_min, zl_min);
+    check_region(box, dimensions, dimensions_ncf, Rsq_curr_index, x, y, z, xb_min, xb_max, yb_min,
+                 yb_max, zl_max, zb_max);
+}
+
 /* thermochem.c:281-311 */
 static double lyman_werner_threshold(const c21cm_mturn_spec *m, float z, float J_21_LW, float vcb) {
     double mcrit_noLW = 3.314e7 * pow(1. + z, -1.5);
@@ -258,6 +328,8 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
         (s->fcoll_mode == C21CM_FCOLL_TABLE_LINEAR || s->fcoll_mode == C21CM_FCOLL_TABLE_EXP);
     if (use_table && !s->use_mini_halos && !s->table_fn) return C21CM_VALUE_ERROR;
     if (!lagrangian && !box->unnormalised_nion) return C21CM_VALUE_ERROR;
+    if (s->ionise_entire_sphere && (recomb || s->use_mini_halos))
+        return C21CM_VALUE_ERROR; /* thread-order dependent upstream: not restated */
     const int mini = s->use_mini_halos;
     if (mini && (s->fcoll_mode != C21CM_FCOLL_TABLE_EXP || !s->table2d_fn || !s->prev_density ||
                  !s->log10_mturn_acg || !s->log10_mturn_mcg || !box->unnormalised_nion_mini ||
@@ -554,7 +626,12 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                         box->z_reion[index_r] = s->redshift;
                     else
                         box->z_reion[index_r] = prev_zre;
-                    box->neutral_fraction[index_r] = 0;
+                    if (!s->ionise_entire_sphere) /* center method, :1150-1158 */
+                        box->neutral_fraction[index_r] = 0;
+                    else /* sphere method (the stores of 0 from several threads commute) */
+                        update_in_sphere(box->neutral_fraction, nx, nz,
+                                         s->R[R_ct] / (double)(float)s->box_len, (l / ny) / (nx + 0.0),
+                                         (l % ny) / (nx + 0.0), k / (nz + 0.0));
                 } else if (R_ct == 0 && (box->neutral_fraction[index_r] > TINY)) {
                     res_xH = 1. - curr_fcoll * s->ion_eff_factor - curr_fcoll_mini * zeta_m;
                     if (!s->minimize_memory) {

@@ -534,3 +534,109 @@ def test_bench_two_ranks_on_one_gpu():
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and "sharded x2" in two["config"]["parallelism"]
     assert two["config"]["global_xH"] == single["config"]["global_xH"]
+
+
+@pytest.mark.parametrize("mode,n,nz,device_resident", [
+    ("stars", 64, None, True),     # native sizes: fused radii > 0, unfused cell-scale radius
+    ("stars", 50, None, False),    # generic (rocFFT) per-radius sequence with the mask
+    ("erfc", 64, 128, True),       # Eulerian mask path, non-cubic
+    ("table", 48, None, False),
+    ("stars_ts", 64, None, True),
+])
+def test_ionise_entire_sphere(api, oracle, mode, n, nz, device_resident):
+    """AstroOptions.IONISE_ENTIRE_SPHERE: every cell that crosses the barrier at radius R flags
+    the cells closer than R (strict, nearest periodic image) as ionised; z_reion stays with the
+    centres (IonisationBox.c:1150-1158, bubble_helper_progs.c:262-418).  The spheres make the
+    comparison with the oracle unforgiving -- a centre whose barrier test flips in the float32
+    transform noise moves a whole sphere -- so the workloads keep a margin around the barrier."""
+    fmode = {"stars": W.FCOLL_STARS, "stars_ts": W.FCOLL_STARS, "erfc": W.FCOLL_ERFC,
+             "table": W.FCOLL_TABLE_EXP}[mode]
+    kw = {}
+    spec = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=12.0,
+                         use_ts_fluct=int(mode == "stars_ts"))
+    spec.ionise_entire_sphere = 1
+    shape = (n, n, nz or n)
+    density = W.density_field_numpy(shape, seed=21)
+    n_ion = W.nion_from_density(density, fbar=0.45) if fmode == W.FCOLL_STARS else None
+    if mode == "table":
+        _install_table(spec)
+    if fmode != W.FCOLL_STARS:
+        spec.mean_f_coll *= 0.5  # fewer crossings: spheres with room around them
+    if mode == "stars_ts":
+        rng = np.random.default_rng(3)
+        kw = dict(xe=(0.3 * rng.random(shape) ** 3).astype(np.float32),
+                  Tneutral=(8.0 + 4.0 * rng.random(shape)).astype(np.float32))
+    ref = oracle.ionize_grids(spec, density, n_ion, need_nion=fmode != W.FCOLL_STARS, **kw)
+    got = run_device(api, spec, density, n_ion, device_resident=device_resident, **kw)
+    ion_g, ion_r = got["neutral_fraction"] == 0, ref["neutral_fraction"] == 0
+    assert 0.03 < ion_r.mean() < 0.97
+    assert np.mean(ion_g != ion_r) <= 1e-3
+    # the centres (cells that crossed themselves) carry z_reion; they agree like the plain method
+    cen_g, cen_r = got["z_reion"] > 0, ref["z_reion"] > 0
+    assert np.mean(cen_g != cen_r) <= 2e-4
+    assert cen_r.sum() < ion_r.sum()  # spheres ionise more than their centres
+    assert not (cen_r & ~ion_r).any() and not (cen_g & ~ion_g).any()
+    same = ion_g == ion_r
+    np.testing.assert_allclose(got["neutral_fraction"][same], ref["neutral_fraction"][same],
+                               rtol=1e-4, atol=5e-6)
+    # against the centre method: a superset of its ionised cells, identical centres
+    spec.ionise_entire_sphere = 0
+    plain = oracle.ionize_grids(spec, density, n_ion, need_nion=fmode != W.FCOLL_STARS, **kw)
+    assert not ((plain["neutral_fraction"] == 0) & ~ion_r & (plain["z_reion"] > 0)).any()
+    np.testing.assert_array_equal(plain["z_reion"] > 0, cen_r)
+
+
+def test_ionise_entire_sphere_shape(api):
+    """One crossing cell: the flagged cells are exactly |x - c|^2 < (R in cells)^2 over the nearest
+    periodic images, with R formed in float as update_in_sphere does."""
+    n, nz = 32, 48
+    spec = W.ionize_spec(n, hii_dim_z=nz, mode=W.FCOLL_ERFC, r_bubble_max=12.0)
+    spec.ionise_entire_sphere = 1
+    spec.hii_filter = 0
+    # a single steep peak near a corner (wraps in all three axes) on an empty, underdense box
+    density = np.full((n, n, nz), -0.9, np.float32)
+    c = (1, n - 2, nz - 1)
+    density[c] = 40.0
+    spec.mean_f_coll = 1e-4
+    spec.fix_mean = 0
+    got = run_device(api, spec, density)
+    ion = got["neutral_fraction"] == 0
+    cen = np.argwhere(got["z_reion"] > 0)
+    assert len(cen) >= 1 and ion.sum() > len(cen)
+    # reconstruct: every centre's largest crossing radius is unknown, but the union must be a
+    # union of strict lattice spheres around centres with radii from the ladder
+    rsq = [float(np.float32(np.float32(np.float32(spec.R[r] / np.float32(spec.box_len)) * n)) ** 2)
+           for r in range(spec.n_radii)]
+    ii, jj, kk = np.meshgrid(np.arange(n), np.arange(n), np.arange(nz), indexing="ij")
+    best = None
+    for r in range(spec.n_radii - 1, -1, -1):  # the peak's own sphere: the largest radius that fits
+        d2 = np.zeros((n, n, nz))
+        for ax, (g, m, cc) in enumerate(((ii, n, c[0]), (jj, n, c[1]), (kk, nz, c[2]))):
+            d = np.abs(g - cc)
+            d2 += np.minimum(d, m - d) ** 2
+        sphere = d2 < rsq[r]
+        if not (sphere & ~ion).any():
+            best = sphere
+            break
+    assert best is not None and best.sum() > 7
+    # all flagged cells lie in the union of spheres around the centres: check the peak's sphere is
+    # fully flagged and nothing beyond the largest ladder radius from any centre is
+    far = np.ones((n, n, nz), bool)
+    for cx, cy, cz in cen:
+        d2 = np.zeros((n, n, nz))
+        for g, m, cc in ((ii, n, cx), (jj, n, cy), (kk, nz, cz)):
+            d = np.abs(g - cc)
+            d2 += np.minimum(d, m - d) ** 2
+        far &= d2 >= rsq[-1]
+    assert not (ion & far).any()
+
+
+def test_ionise_entire_sphere_refusals(api):
+    from recomb_helpers import recomb_spec
+    spec = recomb_spec(16, model=2)
+    spec.ionise_entire_sphere = 1
+    density = W.density_field_numpy(16, seed=1)
+    with pytest.raises(RuntimeError, match="IONISE_ENTIRE_SPHERE"):
+        api.ionize_grids(spec, density, W.nion_from_density(density),
+                         prev_nrec=np.zeros_like(density), whalo_sfr=np.zeros_like(density),
+                         prev_z_reion=np.zeros_like(density))
