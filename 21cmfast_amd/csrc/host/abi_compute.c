@@ -20,12 +20,13 @@
  * USE_INTERPOLATION_TABLES = hmf-interpolation) and the Lagrangian models (L-INTEGRAL /
  * DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all HII_FILTER types,
  * USE_EXP_FILTER, MINIMIZE_MEMORY, RECOMB_MODEL homogeneous / inhomogeneous with or without
- * CELL_RECOMB, USE_MINI_HALOS with E-INTEGRAL (turnover-mass boxes, 2-D tables, f_coll history);
+ * CELL_RECOMB, USE_MINI_HALOS with E-INTEGRAL (turnover-mass boxes, 2-D tables, f_coll history),
+ * IONISE_ENTIRE_SPHERE;
  * ComputeBrightnessTemp with or without spin temperatures.
  * Returning ValueError (3) with a message in
  * c21cm_last_error(): E-INTEGRAL without interpolation tables or with the Gamma-function
  * approximation, USE_MINI_HALOS with the other source models or in ComputeHaloBox / ComputeTsBox,
- * PHOTON_CONS_TYPE != none, IONISE_ENTIRE_SPHERE.
+ * PHOTON_CONS_TYPE != none, IONISE_ENTIRE_SPHERE together with recombinations or mini-halos.
  */
 #include <math.h>
 #include <pthread.h>
@@ -288,7 +289,9 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         unsupported = "USE_MINI_HALOS with a SOURCE_MODEL other than E-INTEGRAL";
     if (mini && ao->INTEGRATION_METHOD_MINI > 1) unsupported = "INTEGRATION_METHOD_MINI=GAMMA-APPROX";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
-    if (ao->IONISE_ENTIRE_SPHERE) unsupported = "IONISE_ENTIRE_SPHERE";
+    if (ao->IONISE_ENTIRE_SPHERE && (ao->RECOMB_MODEL != C21CM_RECOMB_NONE || mini))
+        unsupported = "IONISE_ENTIRE_SPHERE with a recombination model or mini-halos (thread-order "
+                      "dependent upstream)";
     if (unsupported) {
         c21hip_set_error("ComputeIonizedBox: %s is not implemented in this backend yet", unsupported);
         return C21CM_VALUE_ERROR;
@@ -332,6 +335,7 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         if ((st = c21_rr_tables(&s->rr_y, &s->rr_c))) goto done;
     }
     s->first_snapshot = (prev_redshift < 1);
+    s->ionise_entire_sphere = ao->IONISE_ENTIRE_SPHERE;
     if (!ao->USE_TS_FLUCT) {
         if ((st = c21_recfast_load())) goto done;
         s->TK_nofluct = c21_T_RECFAST(redshift);
@@ -350,7 +354,7 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     {
         const double maximum_radius = fmin(ap->R_BUBBLE_MAX, L_FACTOR * so->BOX_LEN);
         double cell_length_factor = L_FACTOR;
-        if (lagrangian && pixel_length < 1) cell_length_factor = 1.;
+        if (lagrangian && !ao->IONISE_ENTIRE_SPHERE && pixel_length < 1) cell_length_factor = 1.;
         const double minimum_radius = fmax(ap->R_BUBBLE_MIN, cell_length_factor * pixel_length);
         int n_radii = (int)(log(maximum_radius / minimum_radius) / log(ap->DELTA_R_HII_FACTOR) + 1);
         if (n_radii < 1 || n_radii > 255) {

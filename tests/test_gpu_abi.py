@@ -336,6 +336,40 @@ def test_ionized_box_lagrangian(gpu_lib, oracle, tmp_path):
     assert out["mean_f_coll"] == pytest.approx(ref["mean_f_coll"], rel=1e-5)
 
 
+def test_ionized_box_ionise_entire_sphere(gpu_lib, oracle, tmp_path):
+    """AstroOptions.IONISE_ENTIRE_SPHERE through ComputeIonizedBox (Lagrangian grids; the
+    cell-scale radius keeps the L_FACTOR pixel even below 1 Mpc cells, IonisationBox.c:970-972)."""
+    ses = Session(gpu_lib, tmp_path, HII_DIM=32, BOX_LEN=24.0, SOURCE_MODEL=2, R_BUBBLE_MAX=6.0,
+                  IONISE_ENTIRE_SPHERE=True)
+    z = 9.0
+    density = W.density_field_numpy(32, seed=11)
+    n_ion = W.nion_from_density(density, fbar=0.7)
+    out = call_ionize(gpu_lib, z, density, n_ion=n_ion)
+    assert out["status"] == 0, gpu_lib.c21cm_last_error()
+    spec = ionize_spec_from_scalars(ses, z, lagrangian=True, tables=False)
+    # setup_radii with the sphere method: minimum radius L_FACTOR x pixel although pixel < 1 Mpc
+    radii = W.radii_ladder(32, 24.0, 6.0, r_bubble_min=ses.ap.R_BUBBLE_MIN, lagrangian=False)
+    assert radii[0] == pytest.approx(0.620350491, rel=1e-6)  # not the 0.75 Mpc pixel
+    spec.n_radii = len(radii)
+    for i, R in enumerate(radii):
+        spec.R[i] = R
+        spec.sigma_maxmass[i] = 1.0
+    spec.f_limit_acg = 0.0
+    spec.ionise_entire_sphere = 1
+    ref = oracle.ionize_grids(spec, density, n_ion)
+    ion_g, ion_r = out["neutral_fraction"] == 0, ref["neutral_fraction"] == 0
+    assert 0.03 < ion_r.mean() < 0.97 and (ref["z_reion"] > 0).sum() < ion_r.sum()
+    assert np.mean(ion_g != ion_r) <= 1e-3
+    np.testing.assert_array_equal(out["z_reion"] > 0, ref["z_reion"] > 0)
+    # refused together with a recombination model
+    ses2 = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=2, IONISE_ENTIRE_SPHERE=True,
+                   RECOMB_MODEL=2)
+    bad = call_ionize(gpu_lib, z, W.density_field_numpy(16, seed=1),
+                      n_ion=W.nion_from_density(W.density_field_numpy(16, seed=1)))
+    assert bad["status"] == 3 and b"IONISE_ENTIRE_SPHERE" in gpu_lib.c21cm_last_error()
+    del ses, ses2
+
+
 def test_ionized_box_early_exit_and_errors(gpu_lib, tmp_path):
     ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=0, HII_EFF_FACTOR=1e-4)
     density = W.density_field_numpy(16, seed=1)

@@ -557,11 +557,13 @@ def test_ionise_entire_sphere(api, oracle, mode, n, nz, device_resident):
     spec.ionise_entire_sphere = 1
     shape = (n, n, nz or n)
     density = W.density_field_numpy(shape, seed=21)
-    n_ion = W.nion_from_density(density, fbar=0.45) if fmode == W.FCOLL_STARS else None
+    n_ion = W.nion_from_density(density, fbar=0.7) if fmode == W.FCOLL_STARS else None
     if mode == "table":
         _install_table(spec)
-    if fmode != W.FCOLL_STARS:
-        spec.mean_f_coll *= 0.5  # fewer crossings: spheres with room around them
+    if fmode == W.FCOLL_ERFC:
+        spec.mean_f_coll *= 0.6  # fewer crossings: spheres with room around them
+    elif fmode == W.FCOLL_TABLE_EXP:
+        spec.mean_f_coll *= 1.3
     if mode == "stars_ts":
         rng = np.random.default_rng(3)
         kw = dict(xe=(0.3 * rng.random(shape) ** 3).astype(np.float32),
