@@ -801,7 +801,10 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
                                           mcrit, NULL)))
                 goto done;
             c21cm_rbox_spec rm = job.spec;
-            rm.min_value = log10(c21_lyman_werner_threshold(redshift, 0.f, 0.f));
+            /* (MINIMIZE_MEMORY filters one shell at a time upstream, with a floor of 0: :1588-1594) */
+            rm.min_value = matter_options_global->MINIMIZE_MEMORY
+                               ? 0.
+                               : log10(c21_lyman_werner_threshold(redshift, 0.f, 0.f));
             rm.const_factor = 1.;
             double mn[C21CM_MAX_TS_RADII], mx[C21CM_MAX_TS_RADII];
             if ((st = c21cm_fill_Rbox_grids(&rm, mcrit, mcrit_R, mn, tab->ave_log10_mturn, mx, NULL)))

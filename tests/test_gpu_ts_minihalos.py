@@ -97,7 +97,8 @@ def test_refusals(api):
         api.ts_grids(spec, d["density"], d["previous"], d["source"], None)
 
 
-def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path):
+@pytest.mark.parametrize("minimize_memory", [False, True])
+def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path, minimize_memory):
     """ComputeTsBox, E-INTEGRAL with USE_MINI_HALOS: the Lyman-Werner turnover grid from the previous
     box's J_21_LW, its shell-filtered copies, both populations in the shell loop, J_21_LW out.  The
     oracle's cell algorithm runs on the spec and tables the library's host side prepares (checked
@@ -115,7 +116,8 @@ def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path):
     data = Path(__file__).parent / "golden" / "reference" / "_data"
     ses = Session(lib, tmp_path, data_dir=data, HII_DIM=n, DIM=2 * n, BOX_LEN=2.0 * n, SOURCE_MODEL=1,
                   USE_TS_FLUCT=True, USE_LYA_HEATING=False, Z_HEAT_MAX=30.0, USE_MINI_HALOS=True,
-                  ALPHA_STAR_MINI=0.5, F_STAR7_MINI=10 ** -2.2, L_X_MINI=10 ** 40.8, V_CB_MODEL=3)
+                  ALPHA_STAR_MINI=0.5, F_STAR7_MINI=10 ** -2.2, L_X_MINI=10 ** 40.8, V_CB_MODEL=3,
+                  MINIMIZE_MEMORY=minimize_memory)
     rng = np.random.default_rng(8)
     shape = (n, n, n)
     z, prev_z = 16.0, 16.7
@@ -158,7 +160,10 @@ def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path):
                     cell_radius=0.620350491 * ses.so.BOX_LEN / float(n))
     for i in range(n_step):
         rs.R[i] = tab.R_values[i]
-    rs.min_value, rs.const_factor = math.log10(lib.c21_lyman_werner_threshold(z, 0.0, 0.0)), 1.0
+    # (upstream floors the turnover grid at the no-background threshold, or at 0 when it filters one
+    # shell at a time under MINIMIZE_MEMORY: SpinTemperatureBox.c:1463-1466,1591-1594)
+    rs.min_value = 0.0 if minimize_memory else math.log10(lib.c21_lyman_werner_threshold(z, 0.0, 0.0))
+    rs.const_factor = 1.0
     fm = api.fill_Rbox_grids(rs, mcrit)
     fm_o = oracle.fill_Rbox_grids(rs, mcrit)
     np.testing.assert_allclose(fm["result"], fm_o["result"], rtol=2e-6)

@@ -244,12 +244,12 @@ def test_unsupported_options_and_missing_tables(heat, pkg, tmp_path):
     S = pkg.structs
     spec, tab = S.TsSpec(), Tables()
     keep = heat._keep
-    keep["ao"].USE_MINI_HALOS = True  # built for E-INTEGRAL with all shells in memory
-    keep["mo"].MINIMIZE_MEMORY = True
+    keep["ao"].USE_MINI_HALOS = True  # built for E-INTEGRAL
+    keep["mo"].SOURCE_MODEL = 0
     assert heat.c21_ts_prepare(18.0, 18.7, 18.0, 2e-4, C.byref(spec), C.byref(tab)) == 3
     assert "USE_MINI_HALOS" in pkg.last_error()
     keep["ao"].USE_MINI_HALOS = False
-    keep["mo"].MINIMIZE_MEMORY = False
+    keep["mo"].SOURCE_MODEL = 1
     keep["ao"].USE_LYA_HEATING = True  # the table is not part of the reference checkout
     assert heat.c21_ts_prepare(18.0, 18.7, 18.0, 2e-4, C.byref(spec), C.byref(tab)) == 1
     assert "Lyman_alpha_heating_table" in pkg.last_error()
