@@ -21,8 +21,18 @@
  *   :1084-1140 recombinations in the barrier, Gamma_12 and mean free path at first crossing
  *   :1258-1340 set_recombination_rates (+ recombinations.c:64-92 splined_recombination_rate)
  *
- * Not restated (returns C21CM_VALUE_ERROR): USE_MINI_HALOS with Eulerian
- * sources (2-D tables), IONISE_ENTIRE_SPHERE -- non-default, SURVEY.md section 2a.
+ *   :403-457   calculate_mcrit_boxes      (USE_MINI_HALOS: turnover-mass boxes)
+ *   :595-603,715-761  previous delta + turnover grids filtered, 2-D table ranges
+ *   :838-936   per-radius f_coll history of both populations; :1068-1158 two-population barrier
+ *   :1150-1158 IONISE_ENTIRE_SPHERE with bubble_helper_progs.c:262-418 (update_in_sphere)
+ *
+ * PINS.  The one-population paths are pinned to the reference's fixtures (tests/golden/reference,
+ * DESIGN.md section 3).  The USE_MINI_HALOS and IONISE_ENTIRE_SPHERE branches are PARITY
+ * UNPINNED: the reference holds no vector for them that this image can reproduce (its `mini`
+ * fixtures need CLASS transfer tables; none uses the sphere method).  They are tied to the pinned
+ * path by construction tests only (tests/test_oracle_minihalos.py).
+ * Not restated (returns C21CM_VALUE_ERROR): IONISE_ENTIRE_SPHERE with a recombination model or
+ * mini-halos (thread-order dependent upstream).
  */
 #include <math.h>
 #include <omp.h>

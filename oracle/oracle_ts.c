@@ -19,6 +19,10 @@
  *   :736-760    get_Ts (collisions-only branch, used by init_first_Ts)
  *   :1227-1313  interpolate_heating_efficiencies (tri-linear, clamped)
  * src/py21cmfast/src/thermochem.c:66-75 alpha_A; src/py21cmfast/src/interpolation.c:123-131.
+ *   :535-565,1011-1075,1642-1733,1843-1845  USE_MINI_HALOS (E-INTEGRAL): turnover grid, 2-D SFRD
+ *               tables, both populations in the shell loop, J_21_LW.  PARITY UNPINNED: no
+ *               reproducible reference vector (the `mini` fixtures need CLASS transfer tables);
+ *               tied to the pinned one-population path by tests/test_oracle_ts_minihalos.py.
  */
 #include <math.h>
 #include <omp.h>
