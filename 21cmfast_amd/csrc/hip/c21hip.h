@@ -444,6 +444,13 @@ int c21hip_ts_sfrd_means_mini(const float *filtered_density, const float *filter
                               double *mini_shell_dev, const double *mean_sfr_mini_dev, int n_step,
                               size_t ntot, double mt_min, double mt_width, double *partials,
                               double *ave_out_dev, void *stream);
+/* Lagrangian source grids with mini-halos: sfr_lw / sfr_mini_lw NULL unless the straight-line
+ * copies exist (LYA_MULTIPLE_SCATTERING); same outputs and follow-up as the next function */
+int c21hip_ts_accumulate_grids_mini(const c21hip_ts_args *a, const float *prev_xe, const float *sfr,
+                                    const float *xray, const float *sfr_mini, const float *sfr_lw,
+                                    const float *sfr_mini_lw, const double *dev_tab,
+                                    const double *mini_shell_dev, double *sums_ws, float *J_21_LW,
+                                    size_t ntot, void *stream);
 /* the shell loop with both populations: sums_ws (6 * ntot doubles) and J_21_LW; follow with
  * c21hip_ts_cells(a with sums_ready = 1, ...) */
 int c21hip_ts_accumulate_mini(const c21hip_ts_args *a, double sfr_scale_mini,

@@ -763,6 +763,71 @@ ts_accumulate_mini_kernel(c21hip_ts_args a, MiniScalars ms, const float *__restr
     }
 }
 
+// Lagrangian source grids with USE_MINI_HALOS (:1657-1701): filtered_xray already holds both
+// populations; the molecularly cooled star formation adds its Lyman-alpha terms, and the
+// Lyman-Werner sums read the straight-line copies when those exist (LYA_MULTIPLE_SCATTERING)
+__global__ void __launch_bounds__(kBlock)
+ts_accumulate_grids_mini_kernel(c21hip_ts_args a, double lw_scale,
+                                const float *__restrict__ prev_xe, const float *__restrict__ sfr,
+                                const float *__restrict__ xray, const float *__restrict__ sfr_mini,
+                                const float *__restrict__ sfr_lw,
+                                const float *__restrict__ sfr_mini_lw,
+                                const double *__restrict__ dev_tab,
+                                const double *__restrict__ mini_shell, double *__restrict__ sums,
+                                float *__restrict__ J_21_LW, size_t ntot) {
+    extern __shared__ double sh[];
+    const int n = a.n_step;
+    const int n_tab = (SH_COUNT + 3 * C21CM_X_INT_NXHII) * n;
+    for (int i = threadIdx.x; i < n_tab; i += kBlock) sh[i] = dev_tab[i];
+    double *shm = sh + n_tab;
+    for (int i = threadIdx.x; i < MS_COUNT * n; i += kBlock) shm[i] = mini_shell[i];
+    __syncthreads();
+    const double *fheat = sh + SH_COUNT * n, *fion = fheat + C21CM_X_INT_NXHII * n,
+                 *flya = fion + C21CM_X_INT_NXHII * n;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        float xHII_call = prev_xe[i];
+        if (xHII_call > kXHII[C21CM_X_INT_NXHII - 1] * 0.999)
+            xHII_call = (float)(kXHII[C21CM_X_INT_NXHII - 1] * 0.999);
+        else if (xHII_call < kXHII[0])
+            xHII_call = (float)(1.001 * kXHII[0]);
+        int mm = C21CM_X_INT_NXHII - 1;
+        while (xHII_call < kXHII[mm]) mm--;
+        const float inv_diff = (float)(1. / (kXHII[mm + 1] - kXHII[mm]));
+        const double ival = (double)((xHII_call - kXHII[mm]) * inv_diff);
+        CellSums q{0., 0., 0., 0., 0., 0.};
+        double lw = 0.;
+        for (int R = n; R--;) {
+            const size_t o = (size_t)R * ntot + i;
+            const double z_edge = sh[SH_ZEDGE * n + R];
+            const double sfr_term = (double)sfr[o] * z_edge;
+            const double xray_sfr = (double)xray[o] * z_edge * sh[SH_XRAY_R * n + R] * 1e38;
+            const double sfr_term_mini = (double)sfr_mini[o] * z_edge;
+            const double sfr_term_lw = sfr_lw ? (double)sfr_lw[o] * z_edge : sfr_term;
+            const double sfr_term_mini_lw = sfr_lw ? (double)sfr_mini_lw[o] * z_edge : sfr_term_mini;
+            lw += sfr_term_lw * shm[MS_LW * n + R] + sfr_term_mini_lw * shm[MS_LW_MINI * n + R];
+            const int lo = mm * n + R, hi = lo + n;
+            if (a.use_xray_heating) q.heat += xray_sfr * ((fheat[hi] - fheat[lo]) * ival + fheat[lo]);
+            q.ion += xray_sfr * ((fion[hi] - fion[lo]) * ival + fion[lo]);
+            q.lya += xray_sfr * ((flya[hi] - flya[lo]) * ival + flya[lo]);
+            q.starlya += sfr_term * sh[SH_STARLYA * n + R] + sfr_term_mini * shm[MS_STARLYA * n + R];
+            if (a.use_lya_heating) {
+                q.cont += sfr_term * sh[SH_CONT * n + R] + sfr_term_mini * shm[MS_CONT * n + R];
+                q.inj += sfr_term * sh[SH_INJ * n + R] + sfr_term_mini * shm[MS_INJ * n + R];
+            }
+        }
+        sums[i] = q.heat;
+        sums[ntot + i] = q.ion;
+        sums[2 * ntot + i] = q.lya;
+        sums[3 * ntot + i] = q.starlya;
+        if (a.use_lya_heating) {
+            sums[4 * ntot + i] = q.cont;
+            sums[5 * ntot + i] = q.inj;
+        }
+        J_21_LW[i] = (float)(lw * lw_scale);
+    }
+}
+
 // prepare_filter_boxes with USE_MINI_HALOS (:535-565)
 __global__ void __launch_bounds__(kBlock)
 ts_mcrit_kernel(const float *__restrict__ J_21_LW, const float *__restrict__ vcb, float vcb_const,
@@ -830,6 +895,26 @@ extern "C" int c21hip_ts_accumulate_mini(const c21hip_ts_args *a, double sfr_sca
     hipLaunchKernelGGL(ts_accumulate_mini_kernel, dim3(grid_for(ntot)), dim3(kBlock), lds,
                        (hipStream_t)stream, *a, ms, prev_xe, delNL0, mcrit, tables_dev, tables2_dev,
                        dev_tab, mini_shell_dev, sums_ws, J_21_LW, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_ts_accumulate_grids_mini(const c21hip_ts_args *a, const float *prev_xe,
+                                               const float *sfr, const float *xray,
+                                               const float *sfr_mini, const float *sfr_lw,
+                                               const float *sfr_mini_lw, const double *dev_tab,
+                                               const double *mini_shell_dev, double *sums_ws,
+                                               float *J_21_LW, size_t ntot, void *stream) {
+    const size_t lds =
+        (c21hip_ts_table_doubles(a->n_step) + (size_t)MS_COUNT * a->n_step) * sizeof(double);
+    if (lds > 64 * 1024) {
+        c21hip_set_error("spin temperature: %d shells do not fit the table cache", a->n_step);
+        return C21CM_VALUE_ERROR;
+    }
+    const double lw_scale = a->lya_star_prefactor * a->volunit_inv * a->h_p * 1e21;
+    hipLaunchKernelGGL(ts_accumulate_grids_mini_kernel, dim3(grid_for(ntot)), dim3(kBlock), lds,
+                       (hipStream_t)stream, *a, lw_scale, prev_xe, sfr, xray, sfr_mini, sfr_lw,
+                       sfr_mini_lw, dev_tab, mini_shell_dev, sums_ws, J_21_LW, ntot);
     LAUNCH_CHECK();
     return 0;
 }

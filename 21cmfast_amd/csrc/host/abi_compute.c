@@ -682,7 +682,8 @@ static int box_mean(const float *v, size_t n, double *mean) {
  * source model (tsfilter_driver.c) and the cell sweep (ts_driver.c / ts_kernels.hip).
  * Supported: the Eulerian source models (E-INTEGRAL: SFRD tables, CONST-ION-EFF: dfcoll/dz tables of
  * the filtered density) and the Lagrangian ones (XraySourceBox grids), with interpolation tables;
- * USE_MINI_HALOS: with SOURCE_MODEL = E-INTEGRAL (2-D tables, the Lyman-Werner grid and J_21_LW). */
+ * USE_MINI_HALOS: E-INTEGRAL (2-D tables, the Lyman-Werner grid) and source grids
+ * (XraySourceBox.filtered_sfr_mini [+ the LW copies]); J_21_LW out. */
 int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
                  PerturbedField *perturbed_field, XraySourceBox *source_box,
                  TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp) {
@@ -831,6 +832,17 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
         }
         if (timing) t_tables = wall_seconds() - t_mark, t_mark = wall_seconds();
     } else {
+        if (spec->use_mini_halos) { /* :1479-1483: the shells' mean turnover masses come with the grids */
+            if (!source_box || !source_box->mean_log10_Mcrit_LW || !source_box->filtered_sfr_mini ||
+                !this_spin_temp->J_21_LW) {
+                c21hip_set_error("ComputeTsBox: USE_MINI_HALOS with source grids needs "
+                                 "XraySourceBox.filtered_sfr_mini, mean_log10_Mcrit_LW and TsBox.J_21_LW");
+                st = C21CM_VALUE_ERROR;
+                goto done;
+            }
+            for (int i = 0; i < tab->n_step; i++)
+                tab->ave_log10_mturn[i] = source_box->mean_log10_Mcrit_LW[i];
+        }
         if ((st = c21_ts_prepare_tables(x_e_ave_p, spec, tab))) goto done;
         if (timing) t_prep = wall_seconds() - t_mark, t_mark = wall_seconds();
     }

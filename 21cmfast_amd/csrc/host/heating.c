@@ -999,9 +999,9 @@ int c21_ts_prepare_shells(float redshift, float prev_redshift, float perturbed_f
     const AstroParams *ap = astro_params_global;
     const AstroOptions *ao = astro_options_global;
     const int model = matter_options_global->SOURCE_MODEL;
-    if (ao->USE_MINI_HALOS && (model != C21CM_SOURCE_E_INTEGRAL || ao->INTEGRATION_METHOD_MINI > 1)) {
-        c21hip_set_error("ComputeTsBox: USE_MINI_HALOS is built for SOURCE_MODEL = E-INTEGRAL "
-                         "(Gauss-Legendre or adaptive integrals)");
+    if (ao->USE_MINI_HALOS && (model == C21CM_SOURCE_CONST_ION_EFF || ao->INTEGRATION_METHOD_MINI > 1)) {
+        c21hip_set_error("ComputeTsBox: USE_MINI_HALOS needs a mass-dependent SOURCE_MODEL and the "
+                         "Gauss-Legendre or adaptive integrals");
         return C21CM_VALUE_ERROR;
     }
     if (matter_options_global->USE_INTERPOLATION_TABLES == 0) {

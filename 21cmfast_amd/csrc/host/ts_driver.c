@@ -122,10 +122,12 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
         return C21CM_VALUE_ERROR;
     }
     const int mini = s->use_mini_halos;
-    if (mini && (s->source_mode != C21CM_TS_SRC_SFRD_TABLE || !out->J_21_LW ||
-                 (!s->no_light && (!s->ln_sfrd_tables_mini || !s->filtered_log10_mcrit)))) {
-        c21hip_set_error("spin temperature: USE_MINI_HALOS runs on the E-INTEGRAL tables and needs "
-                         "the 2-D SFRD tables, the filtered log10 M_crit grids and TsBox.J_21_LW");
+    if (mini && (fcoll_mode || !out->J_21_LW ||
+                 (!lagrangian && !s->no_light && (!s->ln_sfrd_tables_mini || !s->filtered_log10_mcrit)) ||
+                 (lagrangian && !s->no_light && !source_box->filtered_sfr_mini))) {
+        c21hip_set_error("spin temperature: USE_MINI_HALOS needs TsBox.J_21_LW and either the "
+                         "E-INTEGRAL inputs (2-D SFRD tables, filtered log10 M_crit grids) or, with "
+                         "source grids, XraySourceBox.filtered_sfr_mini");
         return C21CM_VALUE_ERROR;
     }
     if (c21hip_device_count() < 1) {
@@ -249,6 +251,34 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
         if (status) goto done;
         if (s->no_light) {
             TRY(c21hip_memset(o_j21, 0, bytes, stream));
+        } else if (lagrangian) { /* source grids: :1657-1701 */
+            double *mini_shell = (double *)c21hip_ws(
+                WS_TS_MINI_SHELL, (size_t)(C21HIP_TS_MINI_ROWS + 2) * n * sizeof(double));
+            if (!mini_shell) {
+                status = C21CM_MEMORY_ALLOC_ERROR;
+                goto done;
+            }
+            double rows[C21HIP_TS_MINI_ROWS * C21CM_MAX_TS_RADII];
+            const double *src[C21HIP_TS_MINI_ROWS] = {
+                s->starlya_prefactor_mini, s->lya_cont_prefactor_mini, s->lya_inj_prefactor_mini,
+                s->lw_prefactor, s->lw_prefactor_mini, NULL};
+            for (int r = 0; r < C21HIP_TS_MINI_ROWS; r++)
+                for (int i = 0; i < n; i++) rows[r * n + i] = src[r] ? src[r][i] : 1.;
+            TRY(c21hip_h2d(mini_shell, rows, (size_t)C21HIP_TS_MINI_ROWS * n * sizeof(double), stream));
+            TRY(c21hip_sync(stream)); /* `rows` is a stack buffer */
+            const float *g_mini = (const float *)stage_in(WS_TS_MINI_MCRIT, source_box->filtered_sfr_mini,
+                                                          bytes * n, stream, &status);
+            const float *g_lw = NULL, *g_mini_lw = NULL;
+            if (source_box->filtered_sfr_lw && source_box->filtered_sfr_mini_lw) {
+                g_lw = (const float *)stage_in(WS_TS_MINI_TAB, source_box->filtered_sfr_lw, bytes * n,
+                                               stream, &status);
+                g_mini_lw = (const float *)stage_in(WS_TS_MINI_MEAN, source_box->filtered_sfr_mini_lw,
+                                                    bytes * n, stream, &status);
+            }
+            if (status) goto done;
+            TRY(c21hip_ts_accumulate_grids_mini(&a, d_pxe, grid_a, grid_b, g_mini, g_lw, g_mini_lw,
+                                                dev_tab, mini_shell, sums_ws, o_j21, ntot, stream));
+            a.sums_ready = 1;
         } else {
             const size_t t2b = (size_t)n * C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE * sizeof(float);
             /* (slack: one more row of the last table for the weight-0 reads on the last knots) */

@@ -306,9 +306,14 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
         return C21CM_VALUE_ERROR;
     if (!lagrangian && !s->no_light && !filtered_density) return C21CM_VALUE_ERROR;
     const int mini = s->use_mini_halos;
-    if (mini && (s->source_mode != C21CM_TS_SRC_SFRD_TABLE || !out->J_21_LW ||
-                 (!s->no_light && (!s->ln_sfrd_tables_mini || !s->filtered_log10_mcrit))))
+    const int mini_tab = mini && !lagrangian; /* E-INTEGRAL: 2-D tables; GRIDS: the mini grids */
+    if (mini && (s->source_mode == C21CM_TS_SRC_FCOLL_TABLES || !out->J_21_LW)) return C21CM_VALUE_ERROR;
+    if (mini_tab && !s->no_light && (!s->ln_sfrd_tables_mini || !s->filtered_log10_mcrit))
         return C21CM_VALUE_ERROR;
+    if (mini && lagrangian && !s->no_light && !source_box->filtered_sfr_mini) return C21CM_VALUE_ERROR;
+    /* LYA_MULTIPLE_SCATTERING: the Lyman-Werner sums read the straight-line copies (:1667-1697) */
+    const int lw_grids = mini && lagrangian && source_box && source_box->filtered_sfr_lw &&
+                         source_box->filtered_sfr_mini_lw;
 
     const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
     const int nR = s->n_step;
@@ -320,9 +325,9 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
     float *inverse_val_box = (float *)malloc(ntot * sizeof(float));
     double *acc = (double *)calloc(7 * ntot, sizeof(double));
     float *del_fcoll_Rct = lagrangian ? NULL : (float *)malloc(ntot * sizeof(float));
-    float *del_fcoll_Rct_MINI = mini ? (float *)malloc(ntot * sizeof(float)) : NULL;
+    float *del_fcoll_Rct_MINI = mini_tab ? (float *)malloc(ntot * sizeof(float)) : NULL;
     if (!m_xHII_low_box || !inverse_val_box || !acc || (!lagrangian && !del_fcoll_Rct) ||
-        (mini && !del_fcoll_Rct_MINI)) {
+        (mini_tab && !del_fcoll_Rct_MINI)) {
         status = C21CM_MEMORY_ALLOC_ERROR;
         goto done;
     }
@@ -348,7 +353,7 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
             const double z_edge_factor = s->z_edge_factor[R_ct];
             const double xray_R_factor = s->xray_R_factor[R_ct];
             double avg_fix_term = 1., avg_fix_term_MINI = 1.;
-            if (mini) { /* calculate_sfrd_from_grid, the molecularly cooled term (:1048-1073) */
+            if (mini_tab) { /* calculate_sfrd_from_grid, the molecularly cooled term (:1048-1073) */
                 const float *dens_R = filtered_density + (size_t)R_ct * ntot;
                 const float *mcrit_R = s->filtered_log10_mcrit + (size_t)R_ct * ntot;
                 const float *tab2 = s->ln_sfrd_tables_mini +
@@ -407,7 +412,16 @@ int oracle_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *p
                     xray_sfr = sfr_term * s->xray_scale * xray_R_factor;
                 }
                 double sfr_term_mini = 0;
-                if (mini) { /* :1702-1716 */
+                if (mini && lagrangian) { /* :1692-1701: mini-halo X-rays are already in filtered_xray */
+                    const size_t o = (size_t)R_ct * ntot + ct;
+                    sfr_term_mini = source_box->filtered_sfr_mini[o] * z_edge_factor;
+                    const double sfr_term_lw =
+                        lw_grids ? source_box->filtered_sfr_lw[o] * z_edge_factor : sfr_term;
+                    const double sfr_term_mini_lw =
+                        lw_grids ? source_box->filtered_sfr_mini_lw[o] * z_edge_factor : sfr_term_mini;
+                    dstarlyLW_dt_box[ct] += sfr_term_lw * s->lw_prefactor[R_ct] +
+                                            sfr_term_mini_lw * s->lw_prefactor_mini[R_ct];
+                } else if (mini) { /* :1702-1716 */
                     sfr_term_mini =
                         del_fcoll_Rct_MINI[ct] * z_edge_factor * avg_fix_term_MINI * s->sfr_scale_mini;
                     xray_sfr += sfr_term_mini * s->xray_scale_mini * xray_R_factor;

@@ -66,6 +66,19 @@ def test_dark_mini_population_matches_the_tuned_one_population_kernel(api, oracl
         np.testing.assert_allclose(got[k], base[k], rtol=1e-6)
 
 
+@pytest.mark.parametrize("device", [False, True])
+@pytest.mark.parametrize("lw_copies", [False, True])
+def test_source_grids_with_mini_halos(api, oracle, device, lw_copies):
+    spec, d = H.make(n=20, n_step=12, lagrangian=True, hii_dim_z=28)
+    H.add_minis_grids(spec, d, lw_copies=lw_copies)
+    ref = oracle.ts_grids(spec, d["density"], d["previous"], d["source"], None)
+    got = api.ts_grids(spec, to_device(d["density"], device), to_device(d["previous"], device),
+                       to_device(d["source"], device), None)
+    compare(got, ref, spec)
+    np.testing.assert_allclose(to_host(got["J_21_LW"]), ref["J_21_LW"], rtol=2e-6, atol=1e-30)
+    assert ref["J_21_LW"].mean() > 1e-3
+
+
 def test_no_light(api, oracle):
     spec, d = H.make(n=16, n_step=8, lagrangian=False, no_light=True)
     H.add_minis(spec, d)
@@ -92,8 +105,8 @@ def test_mcrit_grid_parity(api, oracle):
 
 def test_refusals(api):
     spec, d = H.make(n=12, n_step=6, lagrangian=True)
-    spec.use_mini_halos = 1
-    with pytest.raises(RuntimeError, match="E-INTEGRAL"):
+    spec.use_mini_halos = 1  # source grids without filtered_sfr_mini
+    with pytest.raises(RuntimeError, match="filtered_sfr_mini"):
         api.ts_grids(spec, d["density"], d["previous"], d["source"], None)
 
 
@@ -193,5 +206,78 @@ def test_compute_ts_box_with_mini_halos(gpu_lib, oracle, tmp_path, minimize_memo
     assert lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), None, C.byref(prevs0), None,
                             C.byref(outs0)) == 0, lib.c21cm_last_error()
     assert out["xray_ionised_fraction"].mean() > out0["xray_ionised_fraction"].mean()
+    lib.c21_ts_tables_free(C.byref(tab))
+    del ses
+
+
+@pytest.mark.parametrize("multiple_scattering", [False, True])
+def test_compute_ts_box_source_grids_with_mini_halos(gpu_lib, oracle, tmp_path, multiple_scattering):
+    """ComputeTsBox with a Lagrangian source model and USE_MINI_HALOS: XraySourceBox supplies the
+    molecularly cooled star-formation grids, the shells' mean turnover masses (tau_X) and, under
+    LYA_MULTIPLE_SCATTERING, the straight-line copies for the Lyman-Werner sums."""
+    import ctypes as C
+    from pathlib import Path
+
+    from test_gpu_abi import Session
+    from test_host_heating import Tables
+
+    lib = gpu_lib
+    n, n_step = 20, 40
+    data = Path(__file__).parent / "golden" / "reference" / "_data"
+    ses = Session(lib, tmp_path, data_dir=data, HII_DIM=n, DIM=2 * n, BOX_LEN=1.5 * n, SOURCE_MODEL=2,
+                  USE_TS_FLUCT=True, USE_LYA_HEATING=False, Z_HEAT_MAX=30.0, USE_MINI_HALOS=True,
+                  ALPHA_STAR_MINI=0.5, LYA_MULTIPLE_SCATTERING=multiple_scattering)
+    rng = np.random.default_rng(8)
+    shape = (n, n, n)
+    z, prev_z = 14.0, 14.6
+    density = H.smooth_field(shape, rng, 0.3)
+    prev = {"xray_ionised_fraction": np.exp(rng.uniform(np.log(1.5e-4), np.log(4e-4), shape)).astype(np.float32),
+            "kinetic_temp_neutral": (9.0 * (1 + 0.6 * density)).astype(np.float32),
+            "spin_temperature": np.full(shape, 30.0, np.float32)}
+    src = {k: np.empty((n_step,) + shape, np.float32)
+           for k in ("filtered_sfr", "filtered_xray", "filtered_sfr_mini")}
+    for i in range(n_step):
+        f = np.exp(H.smooth_field(shape, rng, 0.7 / (1 + 0.2 * i)))
+        src["filtered_sfr"][i] = 2e-4 * f * np.exp(-0.12 * i)
+        src["filtered_xray"][i] = 6e-2 * f * np.exp(-0.12 * i)
+        src["filtered_sfr_mini"][i] = 5e-5 * f ** 0.7 * np.exp(-0.05 * i)
+    if multiple_scattering:
+        src["filtered_sfr_lw"] = (src["filtered_sfr"] * 0.9).astype(np.float32)
+        src["filtered_sfr_mini_lw"] = (src["filtered_sfr_mini"] * 1.1).astype(np.float32)
+    mean_mcrit = np.ascontiguousarray(5.8 + 0.01 * np.arange(n_step), np.float64)
+    fields = ("spin_temperature", "kinetic_temp_neutral", "xray_ionised_fraction", "J_21_LW")
+    out = {k: np.zeros(shape, np.float32) for k in fields}
+    fp = lambda a: a.ctypes.data_as(S.c_float_p)  # noqa: E731
+    pf = S.PerturbedFieldStruct(density=fp(density))
+    prevs = S.TsBoxStruct(**{k: fp(v) for k, v in prev.items()})
+    outs = S.TsBoxStruct(**{k: fp(v) for k, v in out.items()})
+    srcs = S.XraySourceBoxStruct(**{k: fp(v) for k, v in src.items()})
+    srcs.mean_log10_Mcrit_LW = mean_mcrit.ctypes.data_as(C.POINTER(C.c_double))
+    lib.ComputeTsBox.restype = C.c_int
+    lib.ComputeTsBox.argtypes = [C.c_float, C.c_float, C.c_float, C.c_short] + [C.c_void_p] * 5
+    st = lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), C.byref(srcs), C.byref(prevs), None,
+                          C.byref(outs))
+    assert st == 0, lib.c21cm_last_error()
+    f64, f32, i32 = C.c_double, C.c_float, C.c_int
+    lib.c21_ts_prepare_shells.restype = i32
+    lib.c21_ts_prepare_shells.argtypes = [f32, f32, f32, C.c_void_p, C.c_void_p]
+    lib.c21_ts_prepare_tables.restype = i32
+    lib.c21_ts_prepare_tables.argtypes = [f64, C.c_void_p, C.c_void_p]
+    spec, tab = S.TsSpec(), Tables()
+    assert lib.c21_ts_prepare_shells(z, prev_z, z, C.byref(spec), C.byref(tab)) == 0
+    assert spec.source_mode == S.TS_SRC_GRIDS and spec.use_mini_halos == 1
+    for i in range(n_step):
+        tab.ave_log10_mturn[i] = mean_mcrit[i]
+    x_e_ave = float(prev["xray_ionised_fraction"].sum(dtype=np.float64) / np.float32(density.size))
+    assert lib.c21_ts_prepare_tables(x_e_ave, C.byref(spec), C.byref(tab)) == 0, lib.c21cm_last_error()
+    assert outs.Q_HI == tab.Q_HI
+    ref = oracle.ts_grids(spec, density, prev, src, None)
+    compare({**out, "report": ref["report"]}, ref, spec)
+    np.testing.assert_allclose(out["J_21_LW"], ref["J_21_LW"], rtol=2e-6)
+    assert out["J_21_LW"].min() > 0  # (the synthetic source grids carry no physical normalisation)
+    # without the mean turnover masses the call is refused
+    srcs.mean_log10_Mcrit_LW = None
+    assert lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), C.byref(srcs), C.byref(prevs), None,
+                            C.byref(outs)) == 3
     lib.c21_ts_tables_free(C.byref(tab))
     del ses

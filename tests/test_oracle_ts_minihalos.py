@@ -61,6 +61,34 @@ def test_lyman_werner_background_and_heating(oracle):
     assert got["xray_ionised_fraction"].mean() > base["xray_ionised_fraction"].mean()
 
 
+def test_source_grids_with_mini_halos(oracle):
+    """Lagrangian source grids: J_21_LW from the analytic sums, the straight-line copies replace
+    the scattering-filtered grids in the Lyman-Werner term only."""
+    spec, inp = T.make(n=14, n_step=7, lagrangian=True)
+    base = run(oracle, spec, inp)
+    T.add_minis_grids(spec, inp)
+    got = run(oracle, spec, inp)
+    src = inp["source"]
+    scale = spec.lya_star_prefactor * spec.volunit_inv * spec.h_p * 1e21
+    lw = sum((src["filtered_sfr"][i].astype(np.float64) * spec.lw_prefactor[i]
+              + src["filtered_sfr_mini"][i].astype(np.float64) * spec.lw_prefactor_mini[i])
+             * spec.z_edge_factor[i] for i in range(spec.n_step))
+    np.testing.assert_allclose(got["J_21_LW"], lw * scale, rtol=3e-6)
+    # X-rays come from filtered_xray alone (both populations are in it upstream): x_e unchanged;
+    # the extra Lyman-alpha photons couple T_s closer to T_k
+    np.testing.assert_array_equal(got["xray_ionised_fraction"], base["xray_ionised_fraction"])
+    assert got["report"].J_alpha_ave > base["report"].J_alpha_ave
+    spec2, inp2 = T.make(n=14, n_step=7, lagrangian=True)
+    T.add_minis_grids(spec2, inp2, lw_copies=True)
+    got2 = run(oracle, spec2, inp2)
+    s2 = inp2["source"]
+    lw2 = sum((s2["filtered_sfr_lw"][i].astype(np.float64) * spec2.lw_prefactor[i]
+               + s2["filtered_sfr_mini_lw"][i].astype(np.float64) * spec2.lw_prefactor_mini[i])
+              * spec2.z_edge_factor[i] for i in range(spec2.n_step))
+    np.testing.assert_allclose(got2["J_21_LW"], lw2 * scale, rtol=3e-6)
+    np.testing.assert_array_equal(got2["spin_temperature"], got["spin_temperature"])
+
+
 def test_mcrit_grid(oracle):
     shape = (10, 10, 14)
     rng = np.random.default_rng(3)

@@ -213,3 +213,28 @@ def add_minis(spec, inputs, seed=11, strength=1.0):
     spec.filtered_log10_mcrit = mcrit.ctypes.data_as(S.c_float_p)
     inputs["filtered_log10_mcrit"] = mcrit
     return spec, inputs
+
+
+def add_minis_grids(spec, inputs, seed=13, lw_copies=False):
+    """The molecularly cooled population for a source-grid (Lagrangian) workload of make():
+    a filtered_sfr_mini grid per shell, Pop-III prefactors, optionally the straight-line copies
+    the Lyman-Werner sums read under LYA_MULTIPLE_SCATTERING."""
+    assert spec.source_mode == S.TS_SRC_GRIDS
+    rng = np.random.default_rng(seed)
+    n_step = spec.n_step
+    src = inputs["source"]
+    shape = src["filtered_sfr"].shape[1:]
+    spec.use_mini_halos = 1
+    mini = np.empty_like(src["filtered_sfr"])
+    for i in range(n_step):
+        mini[i] = 3e-3 * np.exp(smooth_field(shape, rng, 0.6 / (1 + 0.3 * i)))
+        spec.starlya_prefactor_mini[i] = 0.7 * spec.starlya_prefactor[i]
+        spec.lya_cont_prefactor_mini[i] = 0.5 * spec.starlya_prefactor_mini[i]
+        spec.lya_inj_prefactor_mini[i] = 0.5 * spec.starlya_prefactor_mini[i]
+        spec.lw_prefactor[i] = 2.5e7 * (1 + 0.2 * math.sin(i)) * (i < n_step - 3)
+        spec.lw_prefactor_mini[i] = 1.8 * spec.lw_prefactor[i]
+    src["filtered_sfr_mini"] = mini
+    if lw_copies:
+        src["filtered_sfr_lw"] = (src["filtered_sfr"] * (0.8 + 0.4 * rng.random(mini.shape))).astype(np.float32)
+        src["filtered_sfr_mini_lw"] = (mini * (0.8 + 0.4 * rng.random(mini.shape))).astype(np.float32)
+    return spec, inputs
