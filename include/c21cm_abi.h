@@ -343,8 +343,8 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
 
 /* reference: src/py21cmfast/src/SpinTemperatureBox.c:87 (_functionprototypes_wrapper.h:19-22).
  * The Eulerian (CONST-ION-EFF, E-INTEGRAL) and the Lagrangian source models with interpolation
- * tables; USE_MINI_HALOS with E-INTEGRAL (previous J_21_LW in, J_21_LW out), ValueError with the
- * other source models.  `cleanup` is accepted and ignored (nothing is cached per call beyond the
+ * tables; USE_MINI_HALOS with E-INTEGRAL (previous J_21_LW in) or with source grids
+ * (XraySourceBox.filtered_sfr_mini and mean_log10_Mcrit_LW), J_21_LW out.  `cleanup` is accepted and ignored (nothing is cached per call beyond the
  * data tables). */
 int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
                  PerturbedField *perturbed_field, XraySourceBox *source_box,
