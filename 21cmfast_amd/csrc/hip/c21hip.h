@@ -362,8 +362,12 @@ int c21hip_fcoll_mini(int nx, int ny, int nz, int need_prev, const double *range
                       const float *mtm_fil, const float *tables_dev, const float *prev_nion,
                       const float *prev_mini, float *nion_out, float *mini_out, double *partials,
                       double *sums_out, void *stream);
-/* find_ionised_regions with the two-population barrier (:1068-1200), recombinations optional */
-int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int inhomo, int cell_recomb,
+/* find_ionised_regions with the two-population barrier (:1068-1200), recombinations optional.
+ * lagrangian: nion_dense = stars_fil and mini_dense = sfr_fil (padded rows; sfr_fil only with a
+ * recombination model), the second population contributes its floor f_limit_mcg only, and the sum
+ * of the source grid goes to sum_out (partials: C21HIP_PARTIALS doubles). */
+int c21hip_ionise_mini(const c21hip_ionize_args *a, int lagrangian, int recomb, int inhomo,
+                       int cell_recomb,
                        double R, double gamma_prefactor, double gamma_prefactor_mini,
                        double ion_eff_mini, double f_limit_mcg, double mean_f_coll_mini,
                        const float *delta_fil, const float *nion_dense, const float *mini_dense,
@@ -371,7 +375,8 @@ int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int inhomo, int 
                        const float *density, const float *prev_z_reion,
                        const float *kinetic_temp_neutral, const double *mean_a_dev,
                        const double *mean_m_dev, float *xH, float *z_reion,
-                       float *kinetic_temperature, float *G12, float *mfp, void *stream);
+                       float *kinetic_temperature, float *G12, float *mfp, double *partials,
+                       double *sum_out, void *stream);
 /* IONISE_ENTIRE_SPHERE (IonisationBox.c:1150-1158): every cell of the first-crossing mask flags
  * the cells closer than its radius; rsq_dev[r] = (R_r in cells)^2 as update_in_sphere forms it
  * (float), compared strictly with the integer distances (bubble_helper_progs.c:292-325) */

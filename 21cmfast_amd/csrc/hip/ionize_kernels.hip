@@ -1530,6 +1530,8 @@ fcoll_mini_kernel(MiniFcollParams p, const float *__restrict__ delta_fil,
 
 struct MiniIoniseParams {
     IoniseParams ip;
+    int lagrangian;  // source grid = filtered HaloBox.n_ion (mini-halos inside): only the floor
+                     // f_limit_mcg of the second population enters (:1068-1082)
     int recomb, inhomo, cell_recomb, ts;
     double R, gamma_prefactor, gamma_prefactor_mini;
     double ion_eff_mini, f_limit_mcg, mean_f_coll_mini;
@@ -1539,23 +1541,29 @@ struct MiniIoniseParams {
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 ionise_mini_kernel(MiniIoniseParams q, const float *__restrict__ delta_fil,
-                   const float *__restrict__ nion_dense, const float *__restrict__ mini_dense,
+                   const float *__restrict__ nion_dense,  // Lagrangian: stars_fil (padded rows)
+                   const float *__restrict__ mini_dense,  // Lagrangian: sfr_fil (padded) or NULL
                    const float *__restrict__ xe_fil, const float *__restrict__ nrec_fil,
                    const float *__restrict__ prev_nrec, const float *__restrict__ density,
                    const float *__restrict__ prev_z_reion, const float *__restrict__ Tneutral,
                    const double *__restrict__ mean_a_dev, const double *__restrict__ mean_m_dev,
                    float *__restrict__ xH, float *__restrict__ z_reion, float *__restrict__ Tk,
-                   float *__restrict__ G12, float *__restrict__ mfp) {
+                   float *__restrict__ G12, float *__restrict__ mfp,
+                   double *__restrict__ partials) {
     const c21hip_ionize_args &a = q.ip.a;
     const bool LAST = (a.r_index == 0);
-    const double fix_a = a.fix_mean ? a.mean_f_coll / *mean_a_dev : 1.;
-    const double fix_m = a.fix_mean ? q.mean_f_coll_mini / *mean_m_dev : 1.;
+    const bool LAG = q.lagrangian;
+    const double fix_a = (!LAG && a.fix_mean) ? a.mean_f_coll / *mean_a_dev : 1.;
+    const double fix_m = (!LAG && a.fix_mean) ? q.mean_f_coll_mini / *mean_m_dev : 1.;
     const float z_now = (float)a.redshift;
+    double acc = 0.;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < q.ip.nitems;
          i += (size_t)gridDim.x * kBlock) {
         const auto ci = cell_index<VEC>(i, q.ip.nz_items, q.ip.zpad_items);
-        const auto fa = Pack<VEC>::load(nion_dense, ci.dense);
-        const auto fm = Pack<VEC>::load(mini_dense, ci.dense);
+        const auto fa = Pack<VEC>::load(nion_dense, LAG ? ci.padded : ci.dense);
+        Pack<VEC> fm, sf;
+        if (!LAG) fm = Pack<VEC>::load(mini_dense, ci.dense);
+        if (LAG && q.recomb) sf = Pack<VEC>::load(mini_dense, ci.padded);
         Pack<VEC> dl, xe, de, nr;
         if (!LAST) dl = Pack<VEC>::load(delta_fil, ci.padded);
         if (LAST || !a.minimize_memory) de = Pack<VEC>::load(density, ci.dense);
@@ -1569,10 +1577,19 @@ ionise_mini_kernel(MiniIoniseParams q, const float *__restrict__ delta_fil,
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
             const size_t idx = ci.dense * VEC + e;
-            const double curr_dens = LAST ? (double)de.v[e] * a.photoncons_factor
-                                          : (double)clip_delta_eulerian(dl.v[e]);
-            double curr_fcoll = fix_a * (double)fa.v[e];
-            double curr_fcoll_mini = fix_m * (double)fm.v[e];
+            const double curr_dens =
+                LAST ? (double)de.v[e] * a.photoncons_factor
+                     : (double)(LAG ? clip_delta(dl.v[e]) : clip_delta_eulerian(dl.v[e]));
+            double curr_fcoll, curr_fcoll_mini;
+            if (LAG) {
+                const float stars = fmaxf(fa.v[e], 0.f);
+                acc += (double)stars;
+                curr_fcoll = (double)stars * (1 / (a.rhocrit_omb * (1 + curr_dens)));
+                curr_fcoll_mini = 0.;
+            } else {
+                curr_fcoll = fix_a * (double)fa.v[e];
+                curr_fcoll_mini = fix_m * (double)fm.v[e];
+            }
             if (a.mass_dep_zeta) {
                 if (curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;
                 if (curr_fcoll_mini < q.f_limit_mcg) curr_fcoll_mini = q.f_limit_mcg;
@@ -1589,8 +1606,12 @@ ionise_mini_kernel(MiniIoniseParams q, const float *__restrict__ delta_fil,
             if (curr_fcoll * a.ion_eff_factor + curr_fcoll_mini * q.ion_eff_mini >
                 (1. - x_e) * (1.0 + rec)) {
                 if (q.recomb && (double)xH[idx] > kFractFloatErr) {  // first crossing
-                    G12[idx] = (float)(q.R * (q.gamma_prefactor * curr_fcoll +
-                                              q.gamma_prefactor_mini * curr_fcoll_mini));
+                    if (LAG)
+                        G12[idx] = (float)(q.R * q.gamma_prefactor / (1 + curr_dens) *
+                                           (double)fmaxf(sf.v[e], 0.f));
+                    else
+                        G12[idx] = (float)(q.R * (q.gamma_prefactor * curr_fcoll +
+                                                  q.gamma_prefactor_mini * curr_fcoll_mini));
                     if (mfp) mfp[idx] = (float)q.R;
                 }
                 const float pz = a.first_snapshot ? -1.f : prev_z_reion[idx];
@@ -1616,6 +1637,7 @@ ionise_mini_kernel(MiniIoniseParams q, const float *__restrict__ delta_fil,
             }
         }
     }
+    if (LAG) block_sum_to(acc, partials);
 }
 }  // namespace
 
@@ -1686,8 +1708,8 @@ extern "C" int c21hip_fcoll_mini(int nx, int ny, int nz, int need_prev, const do
     return 0;
 }
 
-extern "C" int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int inhomo,
-                                  int cell_recomb, double R, double gamma_prefactor,
+extern "C" int c21hip_ionise_mini(const c21hip_ionize_args *a, int lagrangian, int recomb,
+                                  int inhomo, int cell_recomb, double R, double gamma_prefactor,
                                   double gamma_prefactor_mini, double ion_eff_mini,
                                   double f_limit_mcg, double mean_f_coll_mini,
                                   const float *delta_fil, const float *nion_dense,
@@ -1697,10 +1719,11 @@ extern "C" int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int i
                                   const float *kinetic_temp_neutral, const double *mean_a_dev,
                                   const double *mean_m_dev, float *xH, float *z_reion,
                                   float *kinetic_temperature, float *G12, float *mfp,
-                                  void *stream) {
+                                  double *partials, double *sum_out, void *stream) {
     const int vec = (a->nz % 2 == 0) ? 2 : 1;
     MiniIoniseParams q;
     q.ip = make_params(a, vec);
+    q.lagrangian = lagrangian;
     q.recomb = recomb;
     q.inhomo = inhomo;
     q.cell_recomb = cell_recomb;
@@ -1716,13 +1739,20 @@ extern "C" int c21hip_ionise_mini(const c21hip_ionize_args *a, int recomb, int i
         hipLaunchKernelGGL((ionise_mini_kernel<2>), dim3(blocks), dim3(kBlock), 0,
                            (hipStream_t)stream, q, delta_fil, nion_dense, mini_dense, xe_fil,
                            nrec_fil, prev_nrec, density, prev_z_reion, kinetic_temp_neutral,
-                           mean_a_dev, mean_m_dev, xH, z_reion, kinetic_temperature, G12, mfp);
+                           mean_a_dev, mean_m_dev, xH, z_reion, kinetic_temperature, G12, mfp,
+                           partials);
     else
         hipLaunchKernelGGL((ionise_mini_kernel<1>), dim3(blocks), dim3(kBlock), 0,
                            (hipStream_t)stream, q, delta_fil, nion_dense, mini_dense, xe_fil,
                            nrec_fil, prev_nrec, density, prev_z_reion, kinetic_temp_neutral,
-                           mean_a_dev, mean_m_dev, xH, z_reion, kinetic_temperature, G12, mfp);
+                           mean_a_dev, mean_m_dev, xH, z_reion, kinetic_temperature, G12, mfp,
+                           partials);
     LAUNCH_CHECK();
+    if (lagrangian && sum_out) {  // sum of the filtered source grid (f_coll_grid_mean, :946-961)
+        hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                           partials, blocks, 0, sum_out);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
 

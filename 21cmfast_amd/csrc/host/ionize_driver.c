@@ -214,7 +214,9 @@ static int validate_spec(const c21cm_ionize_spec *s, const PerturbedField *pf,
         c21hip_set_error("ionize: unknown fcoll_mode %d", s->fcoll_mode);
         return C21CM_VALUE_ERROR;
     }
-    if (s->use_mini_halos) {
+    if (s->use_mini_halos && s->fcoll_mode == C21CM_FCOLL_STARS_GRID) {
+        /* Lagrangian grids: the mini-halos are inside HaloBox.n_ion, only f_limit_mcg enters */
+    } else if (s->use_mini_halos) {
         if (s->fcoll_mode != C21CM_FCOLL_TABLE_EXP || !s->table2d_fn) {
             c21hip_set_error("ionize: USE_MINI_HALOS runs on the E-INTEGRAL tables (fcoll_mode "
                              "TABLE_EXP) and needs table2d_fn");
@@ -327,8 +329,8 @@ typedef struct {
     int finalised;       /* the post-loop sweep already ran inside final_step() */
     float *eul_xe[2];    /* dense x_e(R) of the Eulerian mask path (spin-temperature runs) */
     int sphere;          /* IONISE_ENTIRE_SPHERE: radii > 0 only record the mask, spheres follow */
-    /* USE_MINI_HALOS */
-    int mini;
+    /* USE_MINI_HALOS: Eulerian tables + history (mini) | Lagrangian grids, floor only (lag_mini) */
+    int mini, lag_mini;
     float *pd_unf, *pd_work, *pd_fil, *mta_unf, *mta_work, *mta_fil, *mtm_unf, *mtm_work, *mtm_fil;
     const float *prev_density, *mta_dense, *mtm_dense, *hist_a, *hist_m;
     float *mini_tables, *nion_all, *mini_all;
@@ -395,7 +397,9 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
     c->sphere = s->ionise_entire_sphere;
-    c->mini = s->use_mini_halos;
+    c->mini = s->use_mini_halos && !c->lagrangian;
+    c->lag_mini = s->use_mini_halos && c->lagrangian;
+    if (c->lag_mini) c->fused = 0; /* the generic sequence carries the extra barrier term */
     c->eul_mask = c->native && !c->lagrangian && !c->recomb && !c->mini;
     if (c->mini) { /* four filtered grids per radius and the 2-D tables: the unfused sequence */
         const int slots[9] = {WS_MINI_PD_UNF, WS_MINI_PD_WORK, WS_MINI_PD_FIL,
@@ -877,13 +881,13 @@ static int mini_radius(ion_ctx *c, int R_ct, const c21hip_ionize_args *args, int
                            s->f_limit_acg, c->scalars + SC_MEANS + R_ct, c->stream));
     TRY(c21hip_finish_mean(c->scalars + SC_SUMS_M + R_ct, (double)c->ntot, s->mass_dep_zeta,
                            s->f_limit_mcg, c->scalars + SC_MEANS_M + R_ct, c->stream));
-    TRY(c21hip_ionise_mini(args, c->recomb, c->inhomo, s->cell_recomb, s->R[R_ct],
+    TRY(c21hip_ionise_mini(args, 0, c->recomb, c->inhomo, s->cell_recomb, s->R[R_ct],
                            s->gamma_prefactor, s->gamma_prefactor_mini, s->ion_eff_factor_mini,
                            s->f_limit_mcg, s->mean_f_coll_mini, c->delta_fil,
                            c->nion_all + roff, c->mini_all + roff, c->xe_fil, c->nrec_fil,
                            c->prev_nrec, c->density, c->prev_zre, c->Tneutral,
                            c->scalars + SC_MEANS + R_ct, c->scalars + SC_MEANS_M + R_ct, c->xH,
-                           c->zre, c->Tk, c->G12, c->mfp, c->stream));
+                           c->zre, c->Tk, c->G12, c->mfp, c->partials, NULL, c->stream));
 done:
     free(tables);
     return status;
@@ -969,7 +973,20 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
             TRY(filter_to_real(c, c->nrec_unf, c->nrec_work, c->nrec_fil, s->hii_filter, R, 0.f,
                                apply));
     }
-    if (c->recomb && c->lagrangian) {
+    if (c->lag_mini) {
+        if (first_cross) {
+            c21hip_set_error("ionize: USE_MINI_HALOS does not run through the first-crossing mask");
+            status = C21CM_VALUE_ERROR;
+            goto done;
+        }
+        TRY(c21hip_ionise_mini(&args, 1, c->recomb, c->inhomo, s->cell_recomb, s->R[R_ct],
+                               s->gamma_prefactor, 0., s->ion_eff_factor_mini, s->f_limit_mcg, 0.,
+                               c->delta_fil, c->stars_fil, c->sfr_fil, c->xe_fil, c->nrec_fil,
+                               c->prev_nrec, c->density, c->prev_zre, c->Tneutral, NULL, NULL, c->xH,
+                               c->zre, c->Tk, c->G12, c->mfp, partials, sum_dev, c->stream));
+        TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                               mean_dev, c->stream));
+    } else if (c->recomb && c->lagrangian) {
         TRY(c21hip_ionise_recomb(&args, 1, c->inhomo, s->cell_recomb, s->R[R_ct],
                                  s->gamma_prefactor, c->delta_fil, c->stars_fil, c->sfr_fil,
                                  c->xe_fil, c->nrec_fil, c->prev_nrec, c->density, c->prev_zre,
@@ -1222,8 +1239,12 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
                     status = C21CM_INFINITY_OR_NAN_ERROR;
                     goto done;
                 }
-        const double mean_m_out =
-            !c->mini ? 0. : (s->fix_mean ? s->mean_f_coll_mini : means_m[last]);
+        /* (Lagrangian grids: the grid mean of the second population is 0, clamped to its floor,
+         * IonisationBox.c:1570-1573) */
+        const double lag_floor = s->mass_dep_zeta ? s->f_limit_mcg : 0.;
+        const double mean_m_out = c->lag_mini ? (s->fix_mean ? s->mean_f_coll_mini : lag_floor)
+                                  : !c->mini  ? 0.
+                                              : (s->fix_mean ? s->mean_f_coll_mini : means_m[last]);
         box->mean_f_coll_MINI = mean_m_out;
         if (report) {
             for (int r = 0; r < s->n_radii; r++) report->f_coll_grid_mean[r] = means[r];
@@ -1231,6 +1252,8 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
             report->mean_f_coll_out = mean_out;
             if (c->mini)
                 for (int r = 0; r < s->n_radii; r++) report->f_coll_grid_mean_mini[r] = means_m[r];
+            if (c->lag_mini)
+                for (int r = s->r_lowest; r < s->n_radii; r++) report->f_coll_grid_mean_mini[r] = lag_floor;
             report->mean_f_coll_mini_out = mean_m_out;
         }
     }

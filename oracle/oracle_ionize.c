@@ -340,7 +340,11 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
     if (!lagrangian && !box->unnormalised_nion) return C21CM_VALUE_ERROR;
     if (s->ionise_entire_sphere && (recomb || s->use_mini_halos))
         return C21CM_VALUE_ERROR; /* thread-order dependent upstream: not restated */
-    const int mini = s->use_mini_halos;
+    /* USE_MINI_HALOS: Eulerian sources carry their own f_coll history (need_minihalo_nion,
+     * IonisationBox.c:30-31); with Lagrangian grids the mini-halos are inside HaloBox.n_ion and only
+     * the floor f_limit_mcg enters the barrier (:1068-1082 with ion_eff_factor_mini = 1, :49-50) */
+    const int mini_any = s->use_mini_halos;
+    const int mini = mini_any && !lagrangian;
     if (mini && (s->fcoll_mode != C21CM_FCOLL_TABLE_EXP || !s->table2d_fn || !s->prev_density ||
                  !s->log10_mturn_acg || !s->log10_mturn_mcg || !box->unnormalised_nion_mini ||
                  !prev || !prev->unnormalised_nion || !prev->unnormalised_nion_mini))
@@ -568,12 +572,12 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
         /* IonisationBox.c:1566-1576 */
         if (s->mass_dep_zeta) {
             if (f_coll_grid_mean <= s->f_limit_acg) f_coll_grid_mean = s->f_limit_acg;
-            if (mini && f_coll_grid_mean_MINI <= s->f_limit_mcg) f_coll_grid_mean_MINI = s->f_limit_mcg;
+            if (mini_any && f_coll_grid_mean_MINI <= s->f_limit_mcg) f_coll_grid_mean_MINI = s->f_limit_mcg;
         } else {
             if (f_coll_grid_mean <= FRACT_FLOAT_ERR) f_coll_grid_mean = FRACT_FLOAT_ERR;
         }
         if (report) report->f_coll_grid_mean[R_ct] = f_coll_grid_mean;
-        if (report && mini) report->f_coll_grid_mean_mini[R_ct] = f_coll_grid_mean_MINI;
+        if (report && mini_any) report->f_coll_grid_mean_mini[R_ct] = f_coll_grid_mean_MINI;
         last_mean = f_coll_grid_mean;
         last_mean_mini = f_coll_grid_mean_MINI;
 
@@ -602,9 +606,9 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
                     curr_fcoll_mini = mean_fix_term_mcg * box->unnormalised_nion_mini[roff + index_r];
                 if (s->mass_dep_zeta) {
                     if (curr_fcoll < s->f_limit_acg) curr_fcoll = s->f_limit_acg;
-                    if (mini && curr_fcoll_mini < s->f_limit_mcg) curr_fcoll_mini = s->f_limit_mcg;
+                    if (mini_any && curr_fcoll_mini < s->f_limit_mcg) curr_fcoll_mini = s->f_limit_mcg;
                 }
-                const double zeta_m = mini ? s->ion_eff_factor_mini : 0.;
+                const double zeta_m = mini_any ? s->ion_eff_factor_mini : 0.;
                 if (recomb) { /* :1084-1099 */
                     if (s->cell_recomb)
                         rec = prev->cumulative_recombinations[inhomo ? index_r : 0];
@@ -734,8 +738,8 @@ int oracle_ionize_grids(const c21cm_ionize_spec *s, const PerturbedField *pf,
             report->mean_f_coll_out = s->fix_mean ? s->mean_f_coll : last_mean;
         }
         box->mean_f_coll = s->fix_mean ? s->mean_f_coll : last_mean;
-        box->mean_f_coll_MINI = !mini ? 0. : (s->fix_mean ? s->mean_f_coll_mini : last_mean_mini);
-        if (report && mini) report->mean_f_coll_mini_out = box->mean_f_coll_MINI;
+        box->mean_f_coll_MINI = !mini_any ? 0. : (s->fix_mean ? s->mean_f_coll_mini : last_mean_mini);
+        if (report && mini_any) report->mean_f_coll_mini_out = box->mean_f_coll_MINI;
     }
     free(pdelta_unf);
     free(pdelta_fil);

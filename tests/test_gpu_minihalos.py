@@ -350,3 +350,51 @@ def test_compute_ionized_box_with_mini_halos(gpu_lib, oracle, tmp_path):
     assert got2["means"][0] != pytest.approx(got1["unnormalised_nion"][0].mean(), rel=1e-3)
     lib.free_MHR.restype = None
     lib.free_MHR()
+
+
+@pytest.mark.parametrize("n,recomb,device_resident", [(64, 0, True), (50, 0, False), (40, 2, True)])
+def test_lagrangian_grids_with_mini_halo_floor(api, oracle, n, recomb, device_resident):
+    """Lagrangian source grids under USE_MINI_HALOS: the molecularly cooled photons are inside
+    HaloBox.n_ion, the barrier only gains the floor f_limit_mcg x ion_eff_factor_mini (= 1 for
+    these models) and box->mean_f_coll_MINI returns that floor (IonisationBox.c:49-50,1068-1082,
+    1570-1573).  The floor is exaggerated here so that it decides cells."""
+    from test_gpu_ionize import run_device as run_plain
+    if recomb:
+        from recomb_helpers import inputs, recomb_spec
+        spec = recomb_spec(n, model=recomb)
+        d = inputs((n, n, n))
+        kw = dict(prev_nrec=d["prev_nrec"], whalo_sfr=d["whalo_sfr"], prev_z_reion=d["prev_z_reion"])
+        density, n_ion = d["density"], d["n_ion"]
+    else:
+        spec = W.ionize_spec(n, r_bubble_max=12.0)
+        density = W.density_field_numpy(n, seed=12)
+        n_ion = W.nion_from_density(density, fbar=0.7)
+        kw = {}
+    base = oracle.ionize_grids(spec, density, n_ion, **kw)
+    spec.use_mini_halos = 1
+    spec.ion_eff_factor_mini = 1.0
+    spec.f_limit_mcg = 0.08
+    ref = oracle.ionize_grids(spec, density, n_ion, **kw)
+    if recomb:
+        import torch
+        dev = (lambda a: torch.from_numpy(a).cuda()) if device_resident else (lambda a: a)  # noqa: E731
+        buf, box, rep = api.ionize_grids(spec, dev(density), dev(n_ion),
+                                         **{k: dev(v) for k, v in kw.items()})
+        host = (lambda a: a.cpu().numpy()) if device_resident else (lambda a: a)  # noqa: E731
+        got = {k: host(getattr(buf, k)) for k in ("neutral_fraction", "z_reion", "kinetic_temperature",
+                                                  "ionisation_rate_G12", "mean_free_path")}
+        got["report"], mean_m = rep, box.mean_f_coll_MINI
+        flags = (got["mean_free_path"] > 0, ref["mean_free_path"] > 0)
+        compare(got, ref, spec, flags=flags)
+        same = flags[0] == flags[1]
+        np.testing.assert_allclose(got["ionisation_rate_G12"][same], ref["ionisation_rate_G12"][same],
+                                   rtol=2e-4, atol=1e-7)
+    else:
+        got = run_plain(api, spec, density, n_ion, device_resident=device_resident)
+        compare(got, ref, spec)
+        mean_m = None
+    n_r = spec.n_radii
+    assert list(ref["report"].f_coll_grid_mean_mini[:n_r]) == [0.08] * n_r
+    assert list(got["report"].f_coll_grid_mean_mini[:n_r]) == [0.08] * n_r
+    assert ref["mean_f_coll_MINI"] == 0.08 and (mean_m is None or mean_m == 0.08)
+    assert (ref["neutral_fraction"] == 0).sum() > (base["neutral_fraction"] == 0).sum()
