@@ -20,12 +20,13 @@
  * USE_INTERPOLATION_TABLES = hmf-interpolation) and the Lagrangian models (L-INTEGRAL /
  * DEXM-ESF / CHMF-SAMPLER: HaloBox.n_ion supplied), USE_TS_FLUCT, all HII_FILTER types,
  * USE_EXP_FILTER, MINIMIZE_MEMORY, RECOMB_MODEL homogeneous / inhomogeneous with or without
- * CELL_RECOMB, USE_MINI_HALOS with E-INTEGRAL (turnover-mass boxes, 2-D tables, f_coll history),
+ * CELL_RECOMB, USE_MINI_HALOS with E-INTEGRAL (turnover-mass boxes, 2-D tables, f_coll history)
+ * and with the Lagrangian grids (HaloBox.n_ion holds both populations; global means and floors),
  * IONISE_ENTIRE_SPHERE;
  * ComputeBrightnessTemp with or without spin temperatures.
  * Returning ValueError (3) with a message in
  * c21cm_last_error(): E-INTEGRAL without interpolation tables or with the Gamma-function
- * approximation, USE_MINI_HALOS with the other source models or in ComputeHaloBox / ComputeTsBox,
+ * approximation, USE_MINI_HALOS in ComputeHaloBox,
  * PHOTON_CONS_TYPE != none, IONISE_ENTIRE_SPHERE together with recombinations or mini-halos.
  */
 #include <math.h>
@@ -285,8 +286,8 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     /* mini-halos: the Eulerian E-INTEGRAL model (need_minihalo_nion, IonisationBox.c:30-31); the
      * Lagrangian models would take them from a HaloBox that this backend does not fill yet */
     const int mini = ao->USE_MINI_HALOS;
-    if (mini && src != C21CM_SOURCE_E_INTEGRAL)
-        unsupported = "USE_MINI_HALOS with a SOURCE_MODEL other than E-INTEGRAL";
+    if (mini && src == C21CM_SOURCE_CONST_ION_EFF)
+        unsupported = "USE_MINI_HALOS with SOURCE_MODEL = CONST-ION-EFF";
     if (mini && ao->INTEGRATION_METHOD_MINI > 1) unsupported = "INTEGRATION_METHOD_MINI=GAMMA-APPROX";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
     if (ao->IONISE_ENTIRE_SPHERE && (ao->RECOMB_MODEL != C21CM_RECOMB_NONE || mini))
@@ -391,6 +392,28 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         box->log10_Mturnover_ave = halos->log10_Mcrit_ACG_ave;
         box->log10_Mturnover_MINI_ave = halos->log10_Mcrit_MCG_ave;
         Mturn_avg = pow(10., halos->log10_Mcrit_ACG_ave);
+        if (mini) { /* the HaloBox holds both populations: only the global means and floors remain */
+            if (!previous_ionize_box) {
+                c21hip_set_error("ComputeIonizedBox: USE_MINI_HALOS needs the previous IonizedBox "
+                                 "(its mean collapsed fractions)");
+                st = C21CM_VALUE_ERROR;
+                goto done;
+            }
+            if (s->first_snapshot) { /* setup_first_z_prevbox, :388-400 */
+                previous_ionize_box->mean_f_coll = 0.0;
+                previous_ionize_box->mean_f_coll_MINI = 0.0;
+                if (previous_perturbed_field && previous_perturbed_field->density) {
+                    const size_t ntot = (size_t)s->hii_dim * s->hii_dim * s->hii_dim_z;
+                    float *pd = previous_perturbed_field->density;
+                    if (c21hip_is_device_ptr(pd)) {
+                        if ((st = c21hip_fill(pd, ntot, -1.5f, NULL))) goto done;
+                    } else {
+                        for (size_t i = 0; i < ntot; i++) pd[i] = -1.5f;
+                    }
+                }
+            }
+            s->use_mini_halos = 1;
+        }
     } else if (mini) { /* calculate_mcrit_boxes, :1432-1445 */
         if (!previous_ionize_box || !previous_perturbed_field || !previous_perturbed_field->density ||
             !spin_temp || !spin_temp->J_21_LW || !box->unnormalised_nion_mini ||
@@ -495,7 +518,7 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         box->mean_f_coll = s->mean_f_coll;
         box->mean_f_coll_MINI = s->mean_f_coll_mini;
         exp_global_hii = s->mean_f_coll * ion_eff_factor_gl + s->mean_f_coll_mini * ion_eff_factor_mini_gl;
-        s->ion_eff_factor_mini = ion_eff_factor_mini_gl;
+        s->ion_eff_factor_mini = lagrangian ? 1. : ion_eff_factor_mini_gl; /* :49-53 */
         s->gamma_prefactor_mini = s->gamma_prefactor * s->ion_eff_factor_mini / s->ion_eff_factor;
         s->need_prev_ion = previous_ionize_box->mean_f_coll_MINI * ion_eff_factor_mini_gl +
                                previous_ionize_box->mean_f_coll * ion_eff_factor_gl > 1e-4;

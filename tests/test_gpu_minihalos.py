@@ -398,3 +398,57 @@ def test_lagrangian_grids_with_mini_halo_floor(api, oracle, n, recomb, device_re
     assert list(got["report"].f_coll_grid_mean_mini[:n_r]) == [0.08] * n_r
     assert ref["mean_f_coll_MINI"] == 0.08 and (mean_m is None or mean_m == 0.08)
     assert (ref["neutral_fraction"] == 0).sum() > (base["neutral_fraction"] == 0).sum()
+
+
+def test_compute_ionized_box_lagrangian_with_mini_halos(gpu_lib, oracle, tmp_path):
+    """ComputeIonizedBox, Lagrangian grids + USE_MINI_HALOS: HaloBox.n_ion already holds both
+    populations; the call adds the floor of the second one to the barrier, returns it as
+    mean_f_coll_MINI, takes the turnover averages from the HaloBox and resets the first
+    snapshot's previous box as upstream does."""
+    import ctypes as C
+
+    from test_gpu_abi import Session, fptr, ionize_spec_from_scalars
+    from test_host_scalars import ScalingConsts
+    import test_host_minihalos as HM
+
+    lib = gpu_lib
+    n = 32
+    ses = Session(lib, tmp_path, HII_DIM=n, SOURCE_MODEL=2, R_BUBBLE_MAX=12.0, USE_MINI_HALOS=True,
+                  ALPHA_STAR_MINI=0.5, Z_HEAT_MAX=20.0)
+    HM._bind(lib)
+    z = 9.0
+    shape = (n, n, n)
+    density = W.density_field_numpy(n, seed=11)
+    n_ion = W.nion_from_density(density, fbar=0.75)
+    out = {"neutral_fraction": np.ones(shape, np.float32), "z_reion": np.zeros(shape, np.float32),
+           "kinetic_temperature": np.zeros(shape, np.float32)}
+    prev_z = np.zeros(shape, np.float32)
+    prev_density = np.zeros(shape, np.float32)
+    pf = S.PerturbedFieldStruct(density=fptr(density))
+    ppf = S.PerturbedFieldStruct(density=fptr(prev_density))
+    prev = S.IonizedBoxStruct(z_reion=fptr(prev_z), mean_f_coll=0.4, mean_f_coll_MINI=0.4)
+    hb = S.HaloBoxStruct(n_ion=fptr(n_ion), log10_Mcrit_ACG_ave=8.9, log10_Mcrit_MCG_ave=5.4)
+    box = S.IonizedBoxStruct(**{k: fptr(v) for k, v in out.items()})
+    ts, ics = S.TsBoxStruct(), S.InitialConditionsStruct()
+    st = lib.ComputeIonizedBox(z, 0.0, C.byref(pf), C.byref(ppf), C.byref(prev), C.byref(ts),
+                               C.byref(hb), C.byref(ics), C.byref(box))
+    assert st == 0, lib.c21cm_last_error()
+    assert (prev_density == -1.5).all() and prev.mean_f_coll == 0 and prev.mean_f_coll_MINI == 0
+    assert box.log10_Mturnover_ave == 8.9 and box.log10_Mturnover_MINI_ave == 5.4
+    sc = ScalingConsts()
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    lnMmin, lnMmax = math.log(1e5), math.log(1e16)
+    f_limit_mcg = lib.c21_Nion_General_MINI(ses.so.Z_HEAT_MAX, lnMmin, lnMmax, 10 ** 5.4, C.byref(sc))
+    assert f_limit_mcg > 0 and box.mean_f_coll_MINI == pytest.approx(f_limit_mcg, rel=1e-12)
+    spec = ionize_spec_from_scalars(ses, z, lagrangian=True, tables=False, scalars="lib")
+    spec.r_lowest = 0  # M_min = 1e5 Msun with mini-halos: every radius is processed
+    spec.f_limit_acg = lib.c21_Nion_General(ses.so.Z_HEAT_MAX, lnMmin, lnMmax, 10 ** 8.9, C.byref(sc))
+    spec.use_mini_halos, spec.ion_eff_factor_mini, spec.f_limit_mcg = 1, 1.0, f_limit_mcg
+    ref = oracle.ionize_grids(spec, density, n_ion)
+    ion_g, ion_r = out["neutral_fraction"] == 0, ref["neutral_fraction"] == 0
+    assert 0.02 < ion_r.mean() < 0.98 and np.mean(ion_g != ion_r) <= 2e-4
+    same = ion_g == ion_r
+    np.testing.assert_allclose(out["neutral_fraction"][same], ref["neutral_fraction"][same],
+                               rtol=1e-4, atol=5e-6)
+    assert box.mean_f_coll == pytest.approx(ref["mean_f_coll"], rel=1e-5)
+    del ses
