@@ -226,6 +226,28 @@ int c21hip_halobox_scatter(const float *src_density, const int dens_dim[3],
                            int lpt2, const float *tables_dev /* [2 or 3][NDELTA] */,
                            double tab_min, double tab_width, double pref_nion, double pref_sfr,
                            double pref_xray, void *stream);
+/* ComputeHaloBox with USE_MINI_HALOS.  get_log10_turnovers (HaloBox.c:465-516): n_chunks = the
+ * N_THREADS shares over which upstream's running maximum of the atomic turnover restarts;
+ * sums_dev[2] (zeroed by the caller) receive the sums of the two log10 grids. */
+int c21hip_halobox_turnovers(size_t ntot, int n_chunks, int below_z_heat_max, double redshift,
+                             double mturn_a_nofb, double m_turn, double vcb_const, double A_LW,
+                             double BETA_LW, double A_VCB, double BETA_VCB, double sigma_vcb,
+                             const float *prev_G12, const float *prev_z_reion, const float *J_21_LW,
+                             const float *vcb, float *out_a, float *out_m, double *sums_dev,
+                             void *stream);
+/* move_grid_galprops with mini-halos (map_mass.c:285-321): low-resolution sources; ranges =
+ * {delta min, width, log10 M_turn,a min, width, log10 M_turn,m min, width, fixed turnover grid
+ * min, width}; prefactors = {nion, nion_mini, sfr, sfr_mini, xray}; out_xray / tab_xray may be
+ * NULL; double accumulation grids */
+int c21hip_halobox_scatter_mini(const float *src_density, const int dim[3],
+                                const float *const vel[3], const float *const vel2[3],
+                                const float *mturn_a, const float *mturn_m, double *out_nion,
+                                double *out_sfr, double *out_sfr_mini, double *out_xray,
+                                double box_len, double box_len_z, double growth, double init_growth,
+                                int lpt2, const float *tab_sfrd, const float *tab_nion_a,
+                                const float *tab_nion_m, const float *tab_sfrd_m,
+                                const float *tab_xray, const double *ranges,
+                                const double *prefactors, void *stream);
 int c21hip_narrow(const double *in, float *out, float *out_scaled, double scale, size_t n,
                   void *stream);
 /* {min, max} of n floats into out2 (device); partials: 2 * 2048 doubles */

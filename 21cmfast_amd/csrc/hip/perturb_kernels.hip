@@ -631,3 +631,238 @@ extern "C" int c21hip_velocity_kspace(const float *saved_c, float *grid_c, int n
     LAUNCH_CHECK();
     return 0;
 }
+
+// ======================================================================================
+// ComputeHaloBox with USE_MINI_HALOS (HaloBox.c:245-283,465-516, map_mass.c:285-321)
+// ======================================================================================
+namespace {
+struct TurnoverParams {
+    size_t ntot;
+    int n_chunks, below_z_heat_max;
+    float z;
+    double mturn_a_nofb, m_turn, vcb_const, A_LW, BETA_LW, A_VCB, BETA_VCB, sigma_vcb;
+};
+
+// get_log10_turnovers.  Upstream's atomic turnover is a running maximum within each OpenMP
+// thread's share of the cells (HaloBox.c:481,497), so one workgroup walks one share (libgomp's
+// static schedule: the first N mod T shares are one cell longer) 256 cells at a time with a
+// wave-level inclusive max-scan and a carry.
+__global__ void __launch_bounds__(kBlock)
+halobox_turnover_kernel(TurnoverParams m, const float *__restrict__ prev_G12,
+                        const float *__restrict__ prev_z_reion, const float *__restrict__ J_21_LW,
+                        const float *__restrict__ vcb, float *__restrict__ out_a,
+                        float *__restrict__ out_m, double *__restrict__ sums) {
+    __shared__ double wmax[kBlock / 64];
+    __shared__ double red[2][kBlock / 64];
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t q = m.ntot / m.n_chunks, r = m.ntot % m.n_chunks;
+    const size_t start = q * t + ((size_t)t < r ? (size_t)t : r);
+    const size_t len = q + ((size_t)t < r ? 1 : 0);
+    const double zp1 = 1. + (double)m.z;
+    const double mcrit_noLW = 3.314e7 * pow(zp1, -1.5);
+    double carry = m.mturn_a_nofb, acc_a = 0., acc_m = 0.;
+    for (size_t base = start; base < start + len; base += kBlock) {
+        const size_t i = base + threadIdx.x;
+        const bool valid = i < start + len;
+        double v = -1., M_turn_m = 1.;
+        if (valid) {
+            float j = 0.f, g = 0.f, zin = 0.f;
+            if (m.below_z_heat_max) {
+                j = J_21_LW[i];
+                g = prev_G12[i];
+                zin = prev_z_reion[i];
+            }
+            const float vc = vcb ? vcb[i] : (float)m.vcb_const;
+            M_turn_m = mcrit_noLW * (1.0 + m.A_LW * pow((double)j, m.BETA_LW)) *
+                       pow(1.0 + m.A_VCB * (double)vc / m.sigma_vcb, m.BETA_VCB);
+            double M_turn_r = 1e-40;
+            if (!((double)zin <= 1e-19))
+                M_turn_r = 3e9 * pow(2.0 * (double)g, 0.17) * pow(zp1 / 10, -2.1) *
+                           pow(1 - pow(zp1 / (1. + (double)zin), 2.0), 2.5);
+            v = fmax(M_turn_r, m.m_turn);
+            M_turn_m = fmax(M_turn_m, v);
+        }
+        double s = v;  // inclusive max-scan within the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double o = __shfl_up(s, off, 64);
+            if (lane >= off) s = fmax(s, o);
+        }
+        if (lane == 63) wmax[wave] = s;
+        __syncthreads();
+        double before = carry;
+        for (int w = 0; w < wave; w++) before = fmax(before, wmax[w]);
+        const double M_turn_a = fmax(before, s);
+        double block_max = carry;
+        for (int w = 0; w < kBlock / 64; w++) block_max = fmax(block_max, wmax[w]);
+        carry = block_max;
+        __syncthreads();
+        if (valid) {
+            const double la = log10(M_turn_a), lm = log10(M_turn_m);
+            out_a[i] = (float)la;
+            out_m[i] = (float)lm;
+            acc_a += la;
+            acc_m += lm;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc_a += __shfl_down(acc_a, off, 64);
+        acc_m += __shfl_down(acc_m, off, 64);
+    }
+    if (lane == 0) red[0][wave] = acc_a, red[1][wave] = acc_m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0., b = 0.;
+        for (int w = 0; w < kBlock / 64; w++) a += red[0][w], b += red[1][w];
+        unsafeAtomicAdd(sums, a);
+        unsafeAtomicAdd(sums + 1, b);
+    }
+}
+
+__device__ __forceinline__ double hb_table_2d(double x, double y, double x_min, double x_width,
+                                              double y_min, double y_width,
+                                              const float *__restrict__ z_arr) {
+    const int x_idx = (int)floor((x - x_min) / x_width);
+    const int y_idx = (int)floor((y - y_min) / y_width);
+    const double px = (x - (x_min + x_width * (double)x_idx)) / x_width;
+    const double py = (y - (y_min + y_width * (double)y_idx)) / y_width;
+    const float *r0 = z_arr + (size_t)x_idx * C21CM_NMTURN_TABLE + y_idx;
+    const float *r1 = r0 + C21CM_NMTURN_TABLE;
+    const double left_edge = (double)r0[0] * (1 - py) + (double)r0[1] * py;
+    const double right_edge = (double)r1[0] * (1 - py) + (double)r1[1] * py;
+    return left_edge * (1 - px) + right_edge * px;
+}
+
+struct HaloMiniParams {
+    CicParams c;
+    double growth, tab_min, tab_width, mta_min, mta_width, mtm_min, mtm_width, mtf_min, mtf_width;
+    double pref_nion, pref_nion_mini, pref_sfr, pref_sfr_mini, pref_xray;
+};
+
+// move_grid_galprops with USE_MINI_HALOS: four values per source cell, CIC-deposited with plain
+// fp64 global atomics (this branch is bound by its table lookups and is not the tuned path)
+__global__ void __launch_bounds__(kBlock)
+halobox_scatter_mini_kernel(HaloMiniParams h, const float *__restrict__ dens,
+                            const float *__restrict__ vx, const float *__restrict__ vy,
+                            const float *__restrict__ vz, const float *__restrict__ v2x,
+                            const float *__restrict__ v2y, const float *__restrict__ v2z,
+                            const float *__restrict__ mturn_a, const float *__restrict__ mturn_m,
+                            const float *__restrict__ tab_sfrd,    // [NDELTA]
+                            const float *__restrict__ tab_nion_a,  // [NDELTA][NMTURN] ...
+                            const float *__restrict__ tab_nion_m, const float *__restrict__ tab_sfrd_m,
+                            const float *__restrict__ tab_xray, double *__restrict__ out_nion,
+                            double *__restrict__ out_sfr, double *__restrict__ out_sfr_mini,
+                            double *__restrict__ out_xray) {
+    const CicParams &p = h.c;
+    const size_t total = (size_t)p.dens_dim[0] * p.dens_dim[1] * p.dens_dim[2];
+    const size_t plane = (size_t)p.dens_dim[1] * p.dens_dim[2];
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * kBlock) {
+        const int i = (int)(t / plane);
+        const size_t rem = t - (size_t)i * plane;
+        const int j = (int)(rem / (size_t)p.dens_dim[2]);
+        const int k = (int)(rem - (size_t)j * p.dens_dim[2]);
+        const int src[3] = {i, j, k};
+        const float v[3] = {vx[t], vy[t], vz[t]};  // velocities on the density grid (low-res sources)
+        float v2[3] = {0.f, 0.f, 0.f};
+        if (p.lpt2) v2[0] = v2x[t], v2[1] = v2y[t], v2[2] = v2z[t];
+        int i0[3], i1[3];
+        double w0[3], w1[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            double pos = (double)src[a];
+            pos += (double)v[a] * p.vdf[a];
+            if (p.lpt2) pos -= (double)v2[a] * p.vdf2[a];
+            pos *= p.dim_ratio_out;
+            const int ipos = (int)floor(pos);
+            const double dist = pos - (double)ipos;
+            i0[a] = wrap_idx(ipos, p.out_dim[a]);
+            i1[a] = wrap_idx(ipos + 1, p.out_dim[a]);
+            w0[a] = 1. - dist;
+            w1[a] = dist;
+        }
+        const double curr_dens = (double)dens[t] * h.growth;
+        const double la = (double)mturn_a[t], lm = (double)mturn_m[t];
+        const int idx = (int)floor((curr_dens - h.tab_min) / h.tab_width);
+        const double ip1 = (curr_dens - (h.tab_min + h.tab_width * (double)(float)idx)) / h.tab_width;
+        const double sfrd = exp((double)tab_sfrd[idx] * (1 - ip1) + (double)tab_sfrd[idx + 1] * ip1);
+        const double nion_a = exp(hb_table_2d(curr_dens, la, h.tab_min, h.tab_width, h.mta_min, h.mta_width, tab_nion_a));
+        const double nion_m = exp(hb_table_2d(curr_dens, lm, h.tab_min, h.tab_width, h.mtm_min, h.mtm_width, tab_nion_m));
+        const double sfrd_m = exp(hb_table_2d(curr_dens, lm, h.tab_min, h.tab_width, h.mtf_min, h.mtf_width, tab_sfrd_m));
+        const double val[4] = {nion_a * h.pref_nion + nion_m * h.pref_nion_mini, sfrd * h.pref_sfr,
+                               sfrd_m * h.pref_sfr_mini,
+                               out_xray ? exp(hb_table_2d(curr_dens, lm, h.tab_min, h.tab_width, h.mtf_min,
+                                                          h.mtf_width, tab_xray)) * h.pref_xray
+                                        : 0.};
+        double *outs[4] = {out_nion, out_sfr, out_sfr_mini, out_xray};
+        const size_t sy = (size_t)p.out_dim[2], sx = (size_t)p.out_dim[1] * p.out_dim[2];
+        const size_t bx[2] = {(size_t)i0[0] * sx, (size_t)i1[0] * sx};
+        const size_t by[2] = {(size_t)i0[1] * sy, (size_t)i1[1] * sy};
+        const size_t bz[2] = {(size_t)i0[2], (size_t)i1[2]};
+        const double wx[2] = {w0[0], w1[0]}, wy[2] = {w0[1], w1[1]}, wz[2] = {w0[2], w1[2]};
+        for (int g = 0; g < 4; g++) {
+            if (!outs[g]) continue;
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int a = 0; a < 2; a++)
+                        unsafeAtomicAdd(outs[g] + bx[a] + by[b] + bz[c], val[g] * (wx[a] * wy[b] * wz[c]));
+        }
+    }
+}
+}  // namespace
+
+extern "C" int c21hip_halobox_turnovers(size_t ntot, int n_chunks, int below_z_heat_max,
+                                        double redshift, double mturn_a_nofb, double m_turn,
+                                        double vcb_const, double A_LW, double BETA_LW, double A_VCB,
+                                        double BETA_VCB, double sigma_vcb, const float *prev_G12,
+                                        const float *prev_z_reion, const float *J_21_LW,
+                                        const float *vcb, float *out_a, float *out_m,
+                                        double *sums_dev, void *stream) {
+    TurnoverParams m;
+    m.ntot = ntot;
+    m.n_chunks = n_chunks < 1 ? 1 : n_chunks;
+    m.below_z_heat_max = below_z_heat_max;
+    m.z = (float)redshift;
+    m.mturn_a_nofb = mturn_a_nofb;
+    m.m_turn = m_turn;
+    m.vcb_const = vcb_const;
+    m.A_LW = A_LW, m.BETA_LW = BETA_LW, m.A_VCB = A_VCB, m.BETA_VCB = BETA_VCB;
+    m.sigma_vcb = sigma_vcb;
+    hipLaunchKernelGGL(halobox_turnover_kernel, dim3(m.n_chunks), dim3(kBlock), 0,
+                       (hipStream_t)stream, m, prev_G12, prev_z_reion, J_21_LW, vcb, out_a, out_m,
+                       sums_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_halobox_scatter_mini(const float *src_density, const int dim[3],
+                                           const float *const vel[3], const float *const vel2[3],
+                                           const float *mturn_a, const float *mturn_m,
+                                           double *out_nion, double *out_sfr, double *out_sfr_mini,
+                                           double *out_xray, double box_len, double box_len_z,
+                                           double growth, double init_growth, int lpt2,
+                                           const float *tab_sfrd, const float *tab_nion_a,
+                                           const float *tab_nion_m, const float *tab_sfrd_m,
+                                           const float *tab_xray, const double *ranges,
+                                           const double *prefactors, void *stream) {
+    HaloMiniParams h;
+    fill_cic_params(h.c, dim, dim, dim, box_len, box_len_z, growth, init_growth, lpt2);
+    h.growth = growth;
+    h.tab_min = ranges[0], h.tab_width = ranges[1];
+    h.mta_min = ranges[2], h.mta_width = ranges[3];
+    h.mtm_min = ranges[4], h.mtm_width = ranges[5];
+    h.mtf_min = ranges[6], h.mtf_width = ranges[7];
+    h.pref_nion = prefactors[0], h.pref_nion_mini = prefactors[1], h.pref_sfr = prefactors[2];
+    h.pref_sfr_mini = prefactors[3], h.pref_xray = prefactors[4];
+    const size_t total = (size_t)dim[0] * dim[1] * dim[2];
+    hipLaunchKernelGGL(halobox_scatter_mini_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
+                       (hipStream_t)stream, h, src_density, vel[0], vel[1], vel[2], vel2[0], vel2[1],
+                       vel2[2], mturn_a, mturn_m, tab_sfrd, tab_nion_a, tab_nion_m, tab_sfrd_m,
+                       tab_xray, out_nion, out_sfr, out_sfr_mini, out_xray);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -880,6 +880,23 @@ double c21_xray_fraction(double lnM, double Mturn, const c21_scaling_consts *sc)
     return S_PER_YR * (sfr * lx_on_sfr(metallicity, sc->l_x));
 }
 
+/* hmf.c:482-509 with USE_MINI_HALOS: both populations' X-ray luminosity of a halo; `Mturn` is the
+ * molecular turnover, the atomic one is sc->mturn_a_nofb (Xray_ConditionalM :1142-1165) */
+static double xray_fraction_mini(double lnM, double Mturn, const c21_scaling_consts *sc) {
+    const double M = exp(lnM);
+    const double ln_norm = log(sc->fstar_10), ln_norm_m = log(sc->fstar_7);
+    const double Fstar = exp(log_pl_limit(lnM, ln_norm, sc->alpha_star, 10 * M_LN10, log(sc->Mlim_Fstar)) -
+                             sc->mturn_a_nofb / M + ln_norm);
+    const double Fstar_mini =
+        exp(log_pl_limit(lnM, ln_norm_m, sc->alpha_star_mini, 7 * M_LN10, log(sc->Mlim_Fstar_mini)) -
+            Mturn / M - M / sc->acg_thresh + ln_norm_m);
+    const double b = cosmo_params_global->OMb / cosmo_params_global->OMm;
+    const double stars = M * Fstar * b, stars_mini = M * Fstar_mini * b;
+    const double sfr = stars / (sc->t_star * sc->t_h), sfr_mini = stars_mini / (sc->t_star * sc->t_h);
+    const double metallicity = halo_metallicity(sfr + sfr_mini, stars + stars_mini, sc->redshift);
+    return S_PER_YR * (sfr * lx_on_sfr(metallicity, sc->l_x) + sfr_mini * lx_on_sfr(metallicity, sc->l_x_mini));
+}
+
 static int conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
                              double sigma_cond, double dmin, double dmax, double Mturn,
                              const c21_scaling_consts *sc, int method, double ln_floor,
@@ -1101,7 +1118,9 @@ int c21_Nion_Conditional_table2d(double growthf, double lnMmin, double lnMmax, d
                                  int method, double ln_floor, int float_mturn, float *table,
                                  int n_delta, int n_mturn) {
     int hmf = matter_options_global->HMF;
-    const mass_weight_fn weight = mini ? nion_weight_mini : nion_weight;
+    /* mini: 0 atomically cooled N_ion, 1 molecularly cooled N_ion, 2 X-ray luminosity of both
+     * populations over the molecular turnover (interp_tables.c:497-560) */
+    const mass_weight_fn weight = mini == 2 ? xray_fraction_mini : (mini ? nion_weight_mini : nion_weight);
     const int fast = (method == 1) && lnMmin < lnMcond;
     if (n_mturn < 2 || n_mturn > 256) return C21CM_VALUE_ERROR;
     if (hmf != C21CM_HMF_PS && hmf != C21CM_HMF_ST) hmf = C21CM_HMF_PS;

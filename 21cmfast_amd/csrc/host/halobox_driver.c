@@ -57,9 +57,138 @@ done:
     return status;
 }
 
+/* USE_MINI_HALOS (HaloBox.c:245-283, map_mass.c:285-321) */
+enum { WS_HBM_MTA = 217, WS_HBM_MTM, WS_HBM_TAB, WS_HBM_ACC3, WS_HBM_OUT4, WS_HBM_G12, WS_HBM_ZRE,
+       WS_HBM_J21, WS_HBM_VCB, WS_HBM_OUTA, WS_HBM_OUTM, WS_HBM_SUMS };
+
+static int halobox_grids_mini(const c21cm_halobox_spec *s, const InitialConditions *ics,
+                              HaloBox *grids, void *stream) {
+    int status = 0;
+    if (s->perturb_on_high_res) {
+        c21hip_set_error("halobox: USE_MINI_HALOS with PERTURB_ON_HIGH_RES is not built (upstream "
+                         "indexes the low-resolution turnover grids with the high-resolution cell index)");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!s->log10_mturn_acg || !s->log10_mturn_mcg || !s->ln_sfrd_table || !s->ln_nion_table2d ||
+        !s->ln_nion_mini_table2d || !s->ln_sfrd_mini_table2d || !grids->halo_sfr_mini ||
+        !(s->tab_width > 0)) {
+        c21hip_set_error("halobox: USE_MINI_HALOS needs the turnover grids, the 1-D SFRD table, the "
+                         "three 2-D tables and HaloBox.halo_sfr_mini");
+        return C21CM_VALUE_ERROR;
+    }
+    const int dim[3] = {s->hii_dim, s->hii_dim, s->hii_dim_z};
+    const size_t n = (size_t)dim[0] * dim[1] * dim[2], fb = n * sizeof(float);
+    const float *vel_h[3] = {ics->lowres_vx, ics->lowres_vy, ics->lowres_vz};
+    const float *vel2_h[3] = {ics->lowres_vx_2LPT, ics->lowres_vy_2LPT, ics->lowres_vz_2LPT};
+    if (!ics->lowres_density || !vel_h[0] || !vel_h[1] || !vel_h[2] ||
+        (s->lpt2 && (!vel2_h[0] || !vel2_h[1] || !vel2_h[2]))) {
+        c21hip_set_error("halobox: required InitialConditions arrays are missing");
+        return C21CM_VALUE_ERROR;
+    }
+    const float *dens = hb_in(WS_HB_IN0, ics->lowres_density, fb, stream, &status);
+    const float *vel[3], *vel2[3] = {NULL, NULL, NULL};
+    for (int a = 0; a < 3; a++) {
+        vel[a] = hb_in(WS_HB_IN0 + 1 + a, vel_h[a], fb, stream, &status);
+        if (s->lpt2) vel2[a] = hb_in(WS_HB_IN0 + 4 + a, vel2_h[a], fb, stream, &status);
+    }
+    const float *mta = hb_in(WS_HBM_MTA, s->log10_mturn_acg, fb, stream, &status);
+    const float *mtm = hb_in(WS_HBM_MTM, s->log10_mturn_mcg, fb, stream, &status);
+    if (status) return status;
+    const int xray = s->ln_xray_table2d && grids->halo_xray;
+    const size_t t1 = C21CM_NDELTA_TABLE, t2 = (size_t)C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE;
+    /* one float of slack per table row set: the lookups read [idx + 1] with weight 0 on the last knot */
+    float *tab = (float *)c21hip_ws(WS_HBM_TAB, (t1 + 4 * t2 + 2 * C21CM_NMTURN_TABLE + 16) * sizeof(float));
+    double *acc[4] = {(double *)c21hip_ws(WS_HB_ACC0, n * sizeof(double)),
+                      (double *)c21hip_ws(WS_HB_ACC1, n * sizeof(double)),
+                      (double *)c21hip_ws(WS_HBM_ACC3, n * sizeof(double)),
+                      xray ? (double *)c21hip_ws(WS_HB_ACC2, n * sizeof(double)) : NULL};
+    if (!tab || !acc[0] || !acc[1] || !acc[2] || (xray && !acc[3])) return C21CM_MEMORY_ALLOC_ERROR;
+    TRY(c21hip_memset(tab, 0, (t1 + 4 * t2 + 2 * C21CM_NMTURN_TABLE + 16) * sizeof(float), stream));
+    float *tab_sfrd = tab + 4 * t2 + C21CM_NMTURN_TABLE, *tab_na = tab, *tab_nm = tab + t2,
+          *tab_sm = tab + 2 * t2, *tab_x = tab + 3 * t2;
+    TRY(c21hip_h2d(tab_sfrd, s->ln_sfrd_table, t1 * sizeof(float), stream));
+    TRY(c21hip_h2d(tab_na, s->ln_nion_table2d, t2 * sizeof(float), stream));
+    TRY(c21hip_h2d(tab_nm, s->ln_nion_mini_table2d, t2 * sizeof(float), stream));
+    TRY(c21hip_h2d(tab_sm, s->ln_sfrd_mini_table2d, t2 * sizeof(float), stream));
+    if (xray) TRY(c21hip_h2d(tab_x, s->ln_xray_table2d, t2 * sizeof(float), stream));
+    for (int g = 0; g < 4; g++)
+        if (acc[g]) TRY(c21hip_memset(acc[g], 0, n * sizeof(double), stream));
+    const double ranges[8] = {s->tab_min, s->tab_width, s->mta_min, s->mta_width,
+                              s->mtm_min, s->mtm_width, s->mt_fixed_min, s->mt_fixed_width};
+    const double pref[5] = {s->prefactor_nion, s->prefactor_nion_mini, s->prefactor_sfr,
+                            s->prefactor_sfr_mini, s->prefactor_xray};
+    TRY(c21hip_halobox_scatter_mini(dens, dim, vel, vel2, mta, mtm, acc[0], acc[1], acc[2], acc[3],
+                                    s->box_len, s->box_len_z, s->growth_factor,
+                                    s->init_growth_factor, s->lpt2, tab_sfrd, tab_na, tab_nm, tab_sm,
+                                    xray ? tab_x : NULL, ranges, pref, stream));
+    {
+        float *targets[5] = {grids->n_ion, grids->whalo_sfr, grids->halo_sfr,
+                             xray ? grids->halo_xray : NULL, grids->halo_sfr_mini};
+        const int slots[5] = {WS_HB_OUT0, WS_HB_OUT0 + 1, WS_HB_OUT0 + 2, WS_HB_OUT3, WS_HBM_OUT4};
+        float *dev[5] = {NULL, NULL, NULL, NULL, NULL};
+        for (int t = 0; t < 5; t++) {
+            if (!targets[t]) continue;
+            dev[t] = c21hip_is_device_ptr(targets[t]) ? targets[t] : (float *)c21hip_ws(slots[t], fb);
+            if (!dev[t]) return C21CM_MEMORY_ALLOC_ERROR;
+        }
+        TRY(c21hip_narrow(acc[0], dev[0], dev[1], s->prefactor_wsfr, n, stream));
+        TRY(c21hip_narrow(acc[1], dev[2], NULL, 0., n, stream));
+        TRY(c21hip_narrow(acc[2], dev[4], NULL, 0., n, stream));
+        if (xray) TRY(c21hip_narrow(acc[3], dev[3], NULL, 0., n, stream));
+        for (int t = 0; t < 5; t++)
+            if (targets[t] && dev[t] != targets[t]) TRY(c21hip_d2h(targets[t], dev[t], fb, stream));
+    }
+    TRY(c21hip_sync(stream));
+done:
+    return status;
+}
+
+/* get_log10_turnovers (HaloBox.c:465-516); see c21hip_halobox_turnovers for n_threads */
+int c21cm_halobox_turnovers(const c21cm_mturn_spec *m, double m_turn, int below_z_heat_max,
+                            int n_threads, const float *prev_G12, const float *prev_z_reion,
+                            const float *J_21_LW, const float *vcb, float *log10_mturn_acg,
+                            float *log10_mturn_mcg, double averages[2], void *stream) {
+    int status = 0;
+    if (!m || !log10_mturn_acg || !log10_mturn_mcg ||
+        (below_z_heat_max && (!prev_G12 || !prev_z_reion || !J_21_LW))) {
+        c21hip_set_error("halobox turnovers: output grids and, below Z_HEAT_MAX, the previous "
+                         "Gamma_12 / z_reion / J_21_LW grids are required");
+        return C21CM_VALUE_ERROR;
+    }
+    const size_t n = (size_t)m->hii_dim * m->hii_dim * m->hii_dim_z, fb = n * sizeof(float);
+    const float *g12 = below_z_heat_max ? hb_in(WS_HBM_G12, prev_G12, fb, stream, &status) : NULL;
+    const float *zre = below_z_heat_max ? hb_in(WS_HBM_ZRE, prev_z_reion, fb, stream, &status) : NULL;
+    const float *j21 = below_z_heat_max ? hb_in(WS_HBM_J21, J_21_LW, fb, stream, &status) : NULL;
+    const float *v = vcb ? hb_in(WS_HBM_VCB, vcb, fb, stream, &status) : NULL;
+    if (status) return status;
+    float *oa = c21hip_is_device_ptr(log10_mturn_acg) ? log10_mturn_acg : (float *)c21hip_ws(WS_HBM_OUTA, fb);
+    float *om = c21hip_is_device_ptr(log10_mturn_mcg) ? log10_mturn_mcg : (float *)c21hip_ws(WS_HBM_OUTM, fb);
+    double *sums = (double *)c21hip_ws(WS_HBM_SUMS, 2 * sizeof(double));
+    if (!oa || !om || !sums) return C21CM_MEMORY_ALLOC_ERROR;
+    TRY(c21hip_memset(sums, 0, 2 * sizeof(double), stream));
+    TRY(c21hip_halobox_turnovers(n, n_threads, below_z_heat_max, m->redshift, m->mturn_a_nofb, m_turn,
+                                 m->vcb_const, m->A_LW, m->BETA_LW, m->A_VCB, m->BETA_VCB,
+                                 m->sigma_vcb, g12, zre, j21, v, oa, om, sums, stream));
+    double host_sums[2];
+    TRY(c21hip_d2h(host_sums, sums, sizeof(host_sums), stream));
+    if (oa != log10_mturn_acg) TRY(c21hip_d2h(log10_mturn_acg, oa, fb, stream));
+    if (om != log10_mturn_mcg) TRY(c21hip_d2h(log10_mturn_mcg, om, fb, stream));
+    TRY(c21hip_sync(stream));
+    if (averages) averages[0] = host_sums[0] / n, averages[1] = host_sums[1] / n;
+done:
+    return status;
+}
+
 int c21cm_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *ics, HaloBox *grids,
                         void *stream) {
     int status = 0;
+    if (s && s->use_mini_halos) {
+        if (!ics || !grids || !grids->n_ion || !grids->halo_sfr) {
+            c21hip_set_error("halobox: NULL spec / ics / n_ion / halo_sfr");
+            return C21CM_VALUE_ERROR;
+        }
+        return halobox_grids_mini(s, ics, grids, stream);
+    }
     if (!s || !ics || !grids || !grids->n_ion || !grids->halo_sfr) {
         c21hip_set_error("halobox: NULL spec / ics / n_ion / halo_sfr");
         return C21CM_VALUE_ERROR;

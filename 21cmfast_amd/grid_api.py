@@ -448,6 +448,8 @@ def halobox_grids(spec: S.HaloBoxSpec, ics: dict, with_whalo=False, with_xray=Fa
         out["whalo_sfr"] = new()
     if with_xray:  # needs spec.ln_xray_table (USE_TS_FLUCT: the X-ray emissivity grid)
         out["halo_xray"] = new()
+    if spec.use_mini_halos:  # the molecularly cooled star formation (HaloBox.c:271-277)
+        out["halo_sfr_mini"] = new()
     hb = S.HaloBoxStruct(**{k: _fptr(v) for k, v in out.items()})
     icss = ics_struct(ics)
     check(load().c21cm_halobox_grids(C.byref(spec), C.byref(icss), C.byref(hb), _stream(stream)),
@@ -461,6 +463,24 @@ def grid_minmax(values, stream=None):
     check(load().c21cm_grid_minmax(_vptr(values), C.c_size_t(n), mm, _stream(stream)),
           "c21cm_grid_minmax")
     return mm[0], mm[1]
+
+
+def halobox_turnovers(spec: S.MturnSpec, m_turn, below_z_heat_max, n_threads, prev_G12,
+                      prev_z_reion, J_21_LW, vcb=None, like=None, stream=None):
+    """get_log10_turnovers (HaloBox.c:465-516) on the MI355X: (log10 M_turn,a, log10 M_turn,m,
+    (<a>, <m>)); grids allocated like ``like`` (default: ``J_21_LW``)."""
+    ref = J_21_LW if like is None else like
+    a, m = _new_like(ref, 0.0), _new_like(ref, 0.0)
+    ave = (C.c_double * 2)()
+    lib = load()
+    lib.c21cm_halobox_turnovers.restype = C.c_int
+    lib.c21cm_halobox_turnovers.argtypes = [C.POINTER(S.MturnSpec), C.c_double, C.c_int, C.c_int] + [
+        C.c_void_p] * 6 + [C.POINTER(C.c_double), C.c_void_p]
+    check(lib.c21cm_halobox_turnovers(C.byref(spec), float(m_turn), int(below_z_heat_max),
+                                      int(n_threads), _vptr(prev_G12), _vptr(prev_z_reion),
+                                      _vptr(J_21_LW), _vptr(vcb), _vptr(a), _vptr(m), ave,
+                                      _stream(stream)), "c21cm_halobox_turnovers")
+    return a, m, (ave[0], ave[1])
 
 
 def fill_Rbox_grids(spec: S.RboxSpec, field, stream=None) -> dict:

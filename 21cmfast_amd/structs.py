@@ -265,6 +265,15 @@ class HaloBoxSpec(_Base):
         ("prefactor_nion", C.c_double), ("prefactor_sfr", C.c_double),
         ("prefactor_wsfr", C.c_double),
         ("ln_xray_table", c_float_p), ("prefactor_xray", C.c_double),
+        # USE_MINI_HALOS
+        ("use_mini_halos", C.c_int),
+        ("log10_mturn_acg", c_float_p), ("log10_mturn_mcg", c_float_p),
+        ("ln_nion_table2d", c_float_p), ("ln_nion_mini_table2d", c_float_p),
+        ("mta_min", C.c_double), ("mta_width", C.c_double),
+        ("mtm_min", C.c_double), ("mtm_width", C.c_double),
+        ("ln_sfrd_mini_table2d", c_float_p), ("ln_xray_table2d", c_float_p),
+        ("mt_fixed_min", C.c_double), ("mt_fixed_width", C.c_double),
+        ("prefactor_nion_mini", C.c_double), ("prefactor_sfr_mini", C.c_double),
     ]
 
 

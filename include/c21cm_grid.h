@@ -349,10 +349,33 @@ typedef struct c21cm_halobox_spec {
      * when both the table and HaloBox.halo_xray are given */
     const float *ln_xray_table; /* host, C21CM_NDELTA_TABLE floats, or NULL */
     double prefactor_xray;      /* rho_crit Omega_m x volume ratio */
+    /* USE_MINI_HALOS (HaloBox.c:245-283, map_mass.c:285-321): per source cell the turnover masses
+     * of the cell (grids at the OUTPUT resolution, indexed with the source-cell index as upstream
+     * does, map_mass.c:291-292: low-resolution sources only), N_ion of both populations from 2-D
+     * tables over (delta, log10 M_turn) on the grids' own ranges, the molecularly cooled SFRD and
+     * the X-ray luminosity from 2-D tables on the fixed turnover grid; halo_sfr_mini is filled and
+     * n_ion sums both populations.  Tables: host, [NDELTA][NMTURN] floats (ln values). */
+    int use_mini_halos;
+    const float *log10_mturn_acg, *log10_mturn_mcg; /* [N out], host or device */
+    const float *ln_nion_table2d, *ln_nion_mini_table2d;
+    double mta_min, mta_width, mtm_min, mtm_width;
+    const float *ln_sfrd_mini_table2d, *ln_xray_table2d; /* the second one NULL without halo_xray */
+    double mt_fixed_min, mt_fixed_width;
+    double prefactor_nion_mini, prefactor_sfr_mini;
 } c21cm_halobox_spec;
 
 int c21cm_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions *ics,
                         HaloBox *grids, void *stream);
+
+/* get_log10_turnovers (HaloBox.c:465-516): the two log10 turnover grids of a USE_MINI_HALOS HaloBox
+ * and their averages.  Atomic: max(M_acg, M_TURN, reionisation feedback) -- upstream keeps this one
+ * as a RUNNING maximum within each OpenMP thread's share of the cells (:481,497), which `n_threads`
+ * reproduces for libgomp's static schedule; molecular: max(M_LW, M_TURN, feedback) per cell.
+ * The spec's mturn_m_nofb and first_snapshot are not read; below_z_heat_max: :488-492. */
+int c21cm_halobox_turnovers(const c21cm_mturn_spec *spec, double m_turn, int below_z_heat_max,
+                            int n_threads, const float *prev_G12, const float *prev_z_reion,
+                            const float *J_21_LW, const float *vcb, float *log10_mturn_acg,
+                            float *log10_mturn_mcg, double averages[2], void *stream);
 
 /* min and max of n floats (host or device array), e.g. the table range of the above */
 int c21cm_grid_minmax(const float *values, size_t n, double out_minmax[2], void *stream);

@@ -56,6 +56,10 @@ int oracle_test_filter(const float *input, int nx, int ny, int nz, double box_le
                        double *result);
 
 /* oracle_ionize.c -- reference: src/py21cmfast/src/IonisationBox.c:323-360,572-1256,1477-1628 */
+int oracle_halobox_turnovers(const c21cm_mturn_spec *m, double m_turn, int below_z_heat_max,
+                             int n_threads, const float *prev_G12, const float *prev_z_reion,
+                             const float *J_21_LW, const float *vcb, float *mturn_a_grid,
+                             float *mturn_m_grid, double averages[2]);
 int oracle_mturn_grids(const c21cm_mturn_spec *spec, const float *prev_G12,
                        const float *prev_z_reion, const float *J_21_LW, const float *vcb,
                        float *log10_mturn_acg, float *log10_mturn_mcg, double *ave_acg,

@@ -282,11 +282,31 @@ def halobox_grids(spec, ics: dict, with_whalo=False, with_xray=False):
         out["whalo_sfr"] = np.zeros(lo, np.float32)
     if with_xray:
         out["halo_xray"] = np.zeros(lo, np.float32)
+    if spec.use_mini_halos:
+        out["halo_sfr_mini"] = np.zeros(lo, np.float32)
     hb = S.HaloBoxStruct(**{k: fptr(v) for k, v in out.items()})
     st = load().oracle_halobox_grids(C.byref(spec), C.byref(ics_struct(ics)), C.byref(hb))
     if st:
         raise RuntimeError(f"oracle_halobox_grids status {st}")
     return out
+
+
+def halobox_turnovers(spec, m_turn, below_z_heat_max, n_threads, prev_G12, prev_z_reion, J_21_LW,
+                      vcb=None, shape=None):
+    """get_log10_turnovers with upstream's per-thread running maximum of the atomic turnover."""
+    lib = load()
+    lib.oracle_halobox_turnovers.restype = C.c_int
+    lib.oracle_halobox_turnovers.argtypes = [C.POINTER(S.MturnSpec), C.c_double, C.c_int, C.c_int] + [
+        S.c_float_p] * 6 + [C.POINTER(C.c_double)]
+    shape = shape or J_21_LW.shape
+    a, m = np.zeros(shape, np.float32), np.zeros(shape, np.float32)
+    ave = (C.c_double * 2)()
+    st = lib.oracle_halobox_turnovers(C.byref(spec), float(m_turn), int(below_z_heat_max),
+                                      int(n_threads), fptr(prev_G12), fptr(prev_z_reion),
+                                      fptr(J_21_LW), fptr(vcb), fptr(a), fptr(m), ave)
+    if st:
+        raise RuntimeError(f"oracle_halobox_turnovers status {st}")
+    return a, m, (ave[0], ave[1])
 
 
 def brightness_grids(spec, density, neutral_fraction, spin_temperature=None):
