@@ -26,7 +26,7 @@
  * ComputeBrightnessTemp with or without spin temperatures.
  * Returning ValueError (3) with a message in
  * c21cm_last_error(): E-INTEGRAL without interpolation tables or with the Gamma-function
- * approximation, USE_MINI_HALOS in ComputeHaloBox,
+ * approximation, USE_MINI_HALOS in ComputeHaloBox with PERTURB_ON_HIGH_RES,
  * PHOTON_CONS_TYPE != none, IONISE_ENTIRE_SPHERE together with recombinations or mini-halos.
  */
 #include <math.h>
@@ -889,8 +889,6 @@ done:
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
                    TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids) {
     (void)halos;
-    (void)previous_spin_temp;
-    (void)previous_ionize_box;
     int st = require_globals("ComputeHaloBox", 1);
     if (st) return st;
     if (!ini_boxes || !grids) return C21CM_VALUE_ERROR;
@@ -902,7 +900,11 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
         unsupported = "a SOURCE_MODEL other than L-INTEGRAL (halo catalogues)";
     if (mo->USE_INTERPOLATION_TABLES != C21CM_INTERP_HMF)
         unsupported = "L-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation";
-    if (ao->USE_MINI_HALOS) unsupported = "USE_MINI_HALOS";
+    if (ao->USE_MINI_HALOS && mo->PERTURB_ON_HIGH_RES)
+        unsupported = "USE_MINI_HALOS with PERTURB_ON_HIGH_RES (upstream indexes the low-resolution "
+                      "turnover grids with the high-resolution cell index, map_mass.c:291-292)";
+    if (ao->USE_MINI_HALOS && ao->INTEGRATION_METHOD_MINI > 1)
+        unsupported = "INTEGRATION_METHOD_MINI=GAMMA-APPROX";
     if (ao->HALO_SCALING_RELATIONS_MEDIAN) unsupported = "HALO_SCALING_RELATIONS_MEDIAN";
     if (ao->INTEGRATION_METHOD_ATOMIC > 1) unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
@@ -928,11 +930,7 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
 
     c21_scaling_consts sc, sc_sfrd;
     if ((st = c21_set_scaling_constants(redshift, &sc))) return st;
-    sc_sfrd = sc; /* scaling_relations.c:122-131 */
-    sc_sfrd.fesc_10 = 1.;
-    sc_sfrd.fesc_7 = 1.;
-    sc_sfrd.alpha_esc = 0.;
-    sc_sfrd.Mlim_Fesc = 0.;
+    sc_sfrd = c21_scaling_consts_sfr(&sc); /* scaling_relations.c:122-131 */
 
     const double M_min = c21_minimum_source_mass(redshift), M_max = M_MAX_INTEGRAL;
     const size_t n_src = s.perturb_on_high_res ? (size_t)dim * dim * dim_z
@@ -987,7 +985,88 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
     s.prefactor_xray = c21_rhocrit() * cosmo_params_global->OMm * vol_ratio_out;
     /* get_log10_turnovers without mini-halos (HaloBox.c:467-470) */
     grids->log10_Mcrit_ACG_ave = log10(sc.mturn_a_nofb);
-    grids->log10_Mcrit_MCG_ave = log10(0.);
+    grids->log10_Mcrit_MCG_ave = log10(sc.mturn_m_nofb);
+    static float *tab2[4]; /* N_ion (ACG, MCG), SFRD_MINI, X-ray: [NDELTA + 1][NMTURN] each */
+    if (ao->USE_MINI_HALOS) {
+        const int below = redshift < so->Z_HEAT_MAX; /* HaloBox.c:488-492 */
+        if (!grids->halo_sfr_mini ||
+            (below && (!previous_spin_temp || !previous_spin_temp->J_21_LW || !previous_ionize_box ||
+                       !previous_ionize_box->ionisation_rate_G12 || !previous_ionize_box->z_reion)) ||
+            (mo->V_CB_MODEL == C21CM_VCB_FLUCTS && !ini_boxes->lowres_vcb)) {
+            c21hip_set_error("ComputeHaloBox: USE_MINI_HALOS needs HaloBox.halo_sfr_mini and, below "
+                             "Z_HEAT_MAX, the previous TsBox.J_21_LW and IonizedBox Gamma_12 / z_reion "
+                             "(with V_CB_MODEL = FLUCTS also lowres_vcb)");
+            return C21CM_VALUE_ERROR;
+        }
+        float *mta = (float *)c21hip_ws(229, n_out * sizeof(float));
+        float *mtm = (float *)c21hip_ws(230, n_out * sizeof(float));
+        if (!mta || !mtm) return C21CM_MEMORY_ALLOC_ERROR;
+        c21cm_mturn_spec ms;
+        memset(&ms, 0, sizeof(ms));
+        ms.hii_dim = s.hii_dim, ms.hii_dim_z = s.hii_dim_z;
+        ms.redshift = redshift;
+        ms.mturn_a_nofb = sc.mturn_a_nofb;
+        ms.vcb_const = sc.vcb_const;
+        ms.A_LW = astro_params_global->A_LW, ms.BETA_LW = astro_params_global->BETA_LW;
+        ms.A_VCB = astro_params_global->A_VCB, ms.BETA_VCB = astro_params_global->BETA_VCB;
+        ms.sigma_vcb = cosmo_tables_global->V_CB_AVG * sqrt(3 * M_PI / 8);
+        double ave[2];
+        if ((st = c21cm_halobox_turnovers(
+                 &ms, astro_params_global->M_TURN, below, so->N_THREADS,
+                 below ? previous_ionize_box->ionisation_rate_G12 : NULL,
+                 below ? previous_ionize_box->z_reion : NULL, below ? previous_spin_temp->J_21_LW : NULL,
+                 mo->V_CB_MODEL == C21CM_VCB_FLUCTS ? ini_boxes->lowres_vcb : NULL, mta, mtm, ave, NULL)))
+            return st;
+        grids->log10_Mcrit_ACG_ave = ave[0];
+        grids->log10_Mcrit_MCG_ave = ave[1];
+        /* table ranges of the turnover grids (HaloBox.c:316-319,372-390) */
+        double ra[2], rm[2];
+        if ((st = c21cm_grid_minmax(mta, n_out, ra, NULL))) return st;
+        if ((st = c21cm_grid_minmax(mtm, n_out, rm, NULL))) return st;
+        const double l10_max_int = log10(M_MAX_INTEGRAL), l10_mturn = log10(astro_params_global->M_TURN);
+        const double a_lo = fmin(l10_max_int, ra[0]) * 0.999, a_hi = fmax(l10_mturn, ra[1]) * 1.001;
+        const double m_lo = fmin(l10_max_int, rm[0]) * 0.999, m_hi = fmax(l10_mturn, rm[1]) * 1.001;
+        const size_t t2 = (size_t)(C21CM_NDELTA_TABLE + 1) * C21CM_NMTURN_TABLE;
+        for (int k = 0; k < 4; k++)
+            if (!tab2[k] && !(tab2[k] = (float *)calloc(t2, sizeof(float)))) return C21CM_MEMORY_ALLOC_ERROR;
+        const double lnMmin = log(M_min), lnMmax = log(M_max), lnMc = log(M_cell);
+        const int m_a = ao->INTEGRATION_METHOD_ATOMIC, m_m = ao->INTEGRATION_METHOD_MINI;
+        /* initialise_Nion_Conditional_spline (interp_tables.c:291-405) on the grids' ranges */
+        if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
+                                               min_density, max_density, a_lo, a_hi, &sc, 0, m_a, -40.,
+                                               0, tab2[0], C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE)))
+            return st;
+        if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
+                                               min_density, max_density, m_lo, m_hi, &sc, 1, m_m, -40.,
+                                               0, tab2[1], C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE)))
+            return st;
+        /* SFRD_conditional_table_MINI / Xray_conditional_table_2D on the fixed turnover grid
+         * (interp_tables.c:440-475,497-560; float condition sigma and turnover masses) */
+        if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, (float)sigma_cell,
+                                               min_density, max_density, C21_LOG10_MTURN_MIN,
+                                               C21_LOG10_MTURN_MAX, &sc_sfrd, 1, m_m, -50., 1, tab2[2],
+                                               C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE)))
+            return st;
+        s.use_mini_halos = 1;
+        s.log10_mturn_acg = mta, s.log10_mturn_mcg = mtm;
+        s.ln_nion_table2d = tab2[0], s.ln_nion_mini_table2d = tab2[1], s.ln_sfrd_mini_table2d = tab2[2];
+        s.mta_min = a_lo, s.mta_width = (a_hi - a_lo) / (C21CM_NMTURN_TABLE - 1.);
+        s.mtm_min = m_lo, s.mtm_width = (m_hi - m_lo) / (C21CM_NMTURN_TABLE - 1.);
+        s.mt_fixed_min = C21_LOG10_MTURN_MIN;
+        s.mt_fixed_width = (C21_LOG10_MTURN_MAX - C21_LOG10_MTURN_MIN) / (C21CM_NMTURN_TABLE - 1.);
+        if (ao->USE_TS_FLUCT) {
+            if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
+                                                   min_density, max_density, C21_LOG10_MTURN_MIN,
+                                                   C21_LOG10_MTURN_MAX, &sc, 2, m_m, -50., 1, tab2[3],
+                                                   C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE)))
+                return st;
+            s.ln_xray_table2d = tab2[3];
+        }
+        const double prefactor_stars_mini =
+            c21_rhocrit() * cosmo_params_global->OMb * sc.fstar_7 * vol_ratio_out; /* map_mass.c:228-237 */
+        s.prefactor_sfr_mini = prefactor_stars_mini / sc.t_star / sc.t_h;
+        s.prefactor_nion_mini = prefactor_stars_mini * sc.fesc_7 * sc.pop3_ion;
+    }
     if (!(M_min < M_max)) { /* :619 -- nothing to integrate: the grids stay zero */
         c21hip_set_error("ComputeHaloBox: M_min >= M_max");
         return C21CM_VALUE_ERROR;
