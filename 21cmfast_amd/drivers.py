@@ -123,6 +123,9 @@ def interp_halo_boxes(z_halos, boxes, fields, redshift):
     t = (redshift - z_halos[idx_desc]) / (z_halos[idx_prog] - z_halos[idx_desc])
     out = {}
     for f in fields:
+        if np.ndim(boxes[idx_desc][f]) == 0:  # box-level scalars (log10_Mcrit_MCG_ave)
+            out[f] = (1 - t) * boxes[idx_desc][f] + t * boxes[idx_prog][f]
+            continue
         interp = np.zeros_like(boxes[idx_desc][f])
         interp[...] = (1 - t) * boxes[idx_desc][f] + t * boxes[idx_prog][f]
         out[f] = interp
@@ -143,13 +146,15 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
                               astro_params, astro_options, previous_xHI_mean=None, lib=None):
     """XraySourceBox for `redshift` from the halo-grid history (compute_xray_source_field,
     single_field.py:473-636).  `z_halos` / `hboxes`: redshifts (descending, as the evolution
-    produces them, the current one last) and dicts with ``halo_sfr`` and ``halo_xray`` grids.
+    produces them, the current one last) and dicts with ``halo_sfr`` and ``halo_xray`` grids (with
+    USE_MINI_HALOS also ``halo_sfr_mini`` and the scalar ``log10_Mcrit_MCG_ave``).
     The process-global parameters must have been broadcast to the library.  Returns a dict with
-    ``filtered_sfr``, ``filtered_xray`` [N_STEP_TS, ...] and ``mean_sfr`` [N_STEP_TS]."""
+    ``filtered_sfr``, ``filtered_xray`` [N_STEP_TS, ...] and ``mean_sfr`` [N_STEP_TS] (mini-halos:
+    ``filtered_sfr_mini``, ``mean_log10_Mcrit_LW`` and, under LYA_MULTIPLE_SCATTERING, the
+    straight-line copies ``filtered_sfr_lw`` / ``filtered_sfr_mini_lw``)."""
     lib = lib or load(require_gpu=True)
     so, cp, ap, ao = simulation_options, cosmo_params, astro_params, astro_options
-    if ao.USE_MINI_HALOS:
-        raise NotImplementedError("USE_MINI_HALOS is not supported by this backend")
+    mini = bool(ao.USE_MINI_HALOS)
     n_step = ap.N_STEP_TS
     shape = hboxes[0]["halo_sfr"].shape
     cosmo = FlatCosmology(cp.hlittle, cp.OMm)
@@ -164,9 +169,16 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
            "filtered_xray": np.zeros((n_step,) + shape, np.float32),
            "mean_sfr": np.zeros(n_step), "mean_sfr_mini": np.zeros(n_step),
            "mean_log10_Mcrit_LW": np.zeros(n_step)}
+    extra = {}
+    if mini:
+        names = ["filtered_sfr_mini"] + (["filtered_sfr_lw", "filtered_sfr_mini_lw"]
+                                         if ao.LYA_MULTIPLE_SCATTERING else [])
+        for k in names:
+            box[k] = np.zeros((n_step,) + shape, np.float32)
+            extra[k] = box[k].ctypes.data_as(S.c_float_p)
     src = S.XraySourceBoxStruct(
         filtered_sfr=box["filtered_sfr"].ctypes.data_as(S.c_float_p),
-        filtered_xray=box["filtered_xray"].ctypes.data_as(S.c_float_p),
+        filtered_xray=box["filtered_xray"].ctypes.data_as(S.c_float_p), **extra,
         mean_sfr=box["mean_sfr"].ctypes.data_as(C.POINTER(C.c_double)),
         mean_sfr_mini=box["mean_sfr_mini"].ctypes.data_as(C.POINTER(C.c_double)),
         mean_log10_Mcrit_LW=box["mean_log10_Mcrit_LW"].ctypes.data_as(C.POINTER(C.c_double)))
@@ -177,12 +189,20 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
         R_inner = float(R_range[i - 1]) if i > 0 else 0.0
         R_outer = float(R_range[i])
         if zpp_avg[i] >= z_max:  # above Z_HEAT_MAX or the first snapshot: nothing shines yet
+            if mini:  # "minimum" (single_field.py:591; upstream's M_TURN is the log10 there)
+                box["mean_log10_Mcrit_LW"][i] = math.log10(ap.M_TURN)
             continue
-        hb = interp_halo_boxes(z_sorted, b_sorted, ("halo_sfr", "halo_xray"), float(zpp_avg[i]))
-        if np.all(hb["halo_sfr"] == 0):
+        fields = ("halo_sfr", "halo_xray") + (("halo_sfr_mini", "log10_Mcrit_MCG_ave") if mini else ())
+        hb = interp_halo_boxes(z_sorted, b_sorted, fields, float(zpp_avg[i]))
+        if np.all(hb["halo_sfr"] == 0) and (not mini or np.all(hb["halo_sfr_mini"] == 0)):
+            if mini:
+                box["mean_log10_Mcrit_LW"][i] = hb["log10_Mcrit_MCG_ave"]
             continue
         hbs = S.HaloBoxStruct(halo_sfr=hb["halo_sfr"].ctypes.data_as(S.c_float_p),
                               halo_xray=hb["halo_xray"].ctypes.data_as(S.c_float_p))
+        if mini:
+            hbs.halo_sfr_mini = hb["halo_sfr_mini"].ctypes.data_as(S.c_float_p)
+            hbs.log10_Mcrit_MCG_ave = float(hb["log10_Mcrit_MCG_ave"])
         check(lib.UpdateXraySourceBox(C.byref(hbs), R_inner, R_outer, i, R_star, C.byref(src)),
               "UpdateXraySourceBox")
     box["zpp_avg"], box["R_range"], box["R_star"] = zpp_avg, R_range, R_star
@@ -294,9 +314,9 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
         raise NotImplementedError("SOURCE_MODEL must be CONST-ION-EFF, E-INTEGRAL or L-INTEGRAL "
                                   "(halo catalogues are not part of this backend)")
     mini = bool(ao.USE_MINI_HALOS)
-    if mini and not (mo.SOURCE_MODEL == 1 and ao.USE_TS_FLUCT):
-        raise NotImplementedError("USE_MINI_HALOS runs with SOURCE_MODEL = E-INTEGRAL and "
-                                  "USE_TS_FLUCT (the Lyman-Werner background comes from the TsBox)")
+    if mini and not (mo.SOURCE_MODEL in (1, 2) and ao.USE_TS_FLUCT):
+        raise NotImplementedError("USE_MINI_HALOS runs with SOURCE_MODEL = E-INTEGRAL or L-INTEGRAL "
+                                  "and USE_TS_FLUCT (the Lyman-Werner background comes from the TsBox)")
     _initialise(lib, inputs, data_path)
     n, nz = so.HII_DIM, int(so.NON_CUBIC_FACTOR * so.HII_DIM)
     shape = (n, n, nz)
@@ -337,7 +357,7 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
         rshape = shape if recomb != 1 else (1, 1, 1)
         arr = {k: new(1.0 if k == "neutral_fraction" else 0.0,
                       rshape if k == "cumulative_recombinations" else shape) for k in ION_FIELDS}
-        if mini:  # one f_coll grid per filter radius and population (wrapper/outputs.py:1538-1543)
+        if mini and not lagrangian:  # one f_coll grid per radius and population (outputs.py:1538-1543)
             arr["unnormalised_nion"] = new(0.0, (n_radii,) + shape)
             arr["unnormalised_nion_mini"] = new(0.0, (n_radii,) + shape)
         if mo.MINIMIZE_MEMORY:
@@ -364,15 +384,22 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
         check(lib.ComputePerturbedField(z, C.byref(icss), C.byref(pf)), "ComputePerturbedField")
         hb_arr, hb = {}, S.HaloBoxStruct()
         if lagrangian:
-            names = ["n_ion", "halo_sfr"] + (["halo_xray"] if ts_on else []) + (["whalo_sfr"] if recomb else [])
+            names = (["n_ion", "halo_sfr"] + (["halo_xray"] if ts_on else [])
+                     + (["whalo_sfr"] if recomb else []) + (["halo_sfr_mini"] if mini else []))
             hb_arr = {k: new() for k in names}
             hb = S.HaloBoxStruct(**{k: fp(v) for k, v in hb_arr.items()})
-            check(lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb)), "ComputeHaloBox")
+            # (mini-halos: turnover masses from the previous snapshot's J_21_LW, Gamma_12, z_reion)
+            check(lib.ComputeHaloBox(z, C.byref(icss), None, C.byref(prev_ts) if mini else None,
+                                     C.byref(prev_ion) if mini else None, C.byref(hb)),
+                  "ComputeHaloBox")
         ts_arr, ts = ({}, S.TsBoxStruct())
         if ts_on:
             srcs = None
             if lagrangian:  # the X-ray light cone reads the halo-grid HISTORY (host arrays)
-                hist = {k: host(hb_arr[k]) for k in ("halo_sfr", "halo_xray")}
+                hist = {k: host(hb_arr[k]) for k in ("halo_sfr", "halo_xray")
+                        + (("halo_sfr_mini",) if mini else ())}
+                if mini:
+                    hist["log10_Mcrit_MCG_ave"] = hb.log10_Mcrit_MCG_ave
                 xsrc = compute_xray_source_field(
                     z_halos + [z], hboxes + [hist], z, simulation_options=so,
                     cosmo_params=inputs.cosmo_params, astro_params=ap, astro_options=ao,
@@ -380,6 +407,12 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
                 srcs = S.XraySourceBoxStruct(
                     filtered_sfr=xsrc["filtered_sfr"].ctypes.data_as(S.c_float_p),
                     filtered_xray=xsrc["filtered_xray"].ctypes.data_as(S.c_float_p))
+                if mini:
+                    for k in ("filtered_sfr_mini", "filtered_sfr_lw", "filtered_sfr_mini_lw"):
+                        if k in xsrc:
+                            setattr(srcs, k, xsrc[k].ctypes.data_as(S.c_float_p))
+                    srcs.mean_log10_Mcrit_LW = xsrc["mean_log10_Mcrit_LW"].ctypes.data_as(
+                        C.POINTER(C.c_double))
                 z_halos.append(z)
                 hboxes.append(hist)
             ts_arr, ts = new_ts()

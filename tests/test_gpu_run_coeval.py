@@ -118,3 +118,37 @@ def test_run_coeval_with_mini_halos(gpu_lib, monkeypatch):
     assert 0.0 < x_m < 0.9 and host(lo["ionisation_rate_G12"]).max() > 0
     hist = np.array(res["history"])
     assert np.all(np.diff(hist[:, 2]) <= 1e-6)  # the global neutral fraction only falls
+
+
+@pytest.mark.parametrize("multiple_scattering", [False, True])
+def test_run_coeval_l_integral_with_mini_halos(gpu_lib, monkeypatch, multiple_scattering):
+    """The Lagrangian chain with USE_MINI_HALOS end to end: ComputeHaloBox (turnover masses from the
+    previous TsBox / IonizedBox, halo_sfr_mini) -> UpdateXraySourceBox (mini and LW grids) ->
+    ComputeTsBox (source grids, J_21_LW) -> ComputeIonizedBox (both populations in n_ion)."""
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    common = dict(HII_DIM=32, DIM=64, BOX_LEN=64.0, N_THREADS=8, ZPRIME_STEP_FACTOR=1.1,
+                  Z_HEAT_MAX=25.0, USE_UPPER_STELLAR_TURNOVER=False, USE_LYA_HEATING=False,
+                  SOURCE_MODEL=2, USE_TS_FLUCT=True, R_BUBBLE_MAX=20.0, M_TURN=10 ** 5.0,
+                  RECOMB_MODEL=2, PERTURB_ON_HIGH_RES=False,
+                  LYA_MULTIPLE_SCATTERING=multiple_scattering)
+    keep = ("neutral_fraction", "brightness_temp", "J_21_LW", "xray_ionised_fraction",
+            "kinetic_temp_neutral", "halo_sfr_mini", "n_ion", "ionisation_rate_G12")
+    zs = [16.0, 10.0]
+    res = D.run_coeval(D.Inputs(random_seed=7, USE_MINI_HALOS=True, ALPHA_STAR_MINI=0.5,
+                                F_STAR7_MINI=10 ** -2.0, F_ESC7_MINI=10 ** -1.5, V_CB_MODEL=3,
+                                **common),
+                       zs, data_path=DATA, device="cuda", lib=gpu_lib, keep=keep)
+    host = lambda a: a.cpu().numpy()  # noqa: E731
+    hi, lo = res[16.0], res[10.0]
+    for snap in (hi, lo):
+        for k in keep:
+            assert np.isfinite(host(snap[k])).all(), k
+    assert host(hi["halo_sfr_mini"]).max() > 0 and host(lo["halo_sfr_mini"]).max() > 0
+    assert 0 < host(hi["J_21_LW"]).mean() < host(lo["J_21_LW"]).mean()
+    assert lo["log10_Mturnover_MINI_ave"] > hi["log10_Mturnover_MINI_ave"] > 5.0
+    assert 7.0 < hi["log10_Mturnover_ave"] <= lo["log10_Mturnover_ave"] < 10.0
+    assert lo["mean_f_coll_MINI"] > 0  # the floor of the second population
+    x = host(lo["neutral_fraction"]).mean()
+    assert 0.0 < x < 0.95
+    hist = np.array(res["history"])
+    assert np.all(np.diff(hist[:, 2]) <= 1e-6)
