@@ -884,8 +884,9 @@ done:
 }
 
 /* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436.  Only the
- * integrated branch without mini-halos or the extra fields; with USE_TS_FLUCT the
- * X-ray emissivity grid halo_xray is filled as well (the input of UpdateXraySourceBox). */
+ * integrated branch without the extra fields; with USE_TS_FLUCT the X-ray emissivity
+ * grid halo_xray is filled as well (the input of UpdateXraySourceBox); with USE_MINI_HALOS the
+ * turnover grids (get_log10_turnovers :465-516), the 2-D tables and halo_sfr_mini. */
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
                    TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids) {
     (void)halos;

@@ -355,7 +355,9 @@ int init_heat(void);
 void destruct_heat(void);
 
 /* reference: src/py21cmfast/src/HaloBox.c:563 (_functionprototypes_wrapper.h:31-32).  Only the
- * integrated branch (SOURCE_MODEL = L-INTEGRAL) is provided; `halos` is not read. */
+ * integrated branch (SOURCE_MODEL = L-INTEGRAL) is provided; `halos` is not read.  USE_MINI_HALOS
+ * (low-resolution sources): the previous TsBox.J_21_LW and IonizedBox Gamma_12 / z_reion set the
+ * turnover masses below Z_HEAT_MAX; halo_sfr_mini is filled, n_ion holds both populations. */
 typedef struct HaloCatalog HaloCatalog;
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
                    TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids);
