@@ -185,3 +185,72 @@ def test_redshift_tables_of_the_mini_population(mini):
         want_s = lib.c21_Nion_General_MINI(z, lnMmin, lnMmax, mt, C.byref(sc_s))
         assert ts[k, j] == pytest.approx(want_s, rel=2e-5, abs=1e-300), (k, j)
     assert np.all(np.diff(tn, axis=0) < 0) and np.all(np.diff(tn, axis=1) < 0)
+
+
+def test_xray_table_of_both_populations_against_scipy(mini):
+    """Xray_conditional_table_2D (interp_tables.c:497-560, hmf.c:482-509): the halo X-ray luminosity
+    of both populations (metallicity from the summed star formation) against scipy quadrature of
+    the Sheth-Tormen conditional mass function with the library's sigma(M)."""
+    lib = mini
+    sc = ScalingConsts()
+    z = 12.0
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    D = lib.dicke(z)
+    Mmin, Mcond = 1e5, lib.c21_RtoM(3.0)
+    s_c = lib.c21_sigma_fast(Mcond)
+    nd, nm = 400, 50
+    dmin, dmax = -0.9, 1.2
+    lo, hi = 5.0 - 9e-8, 10.0
+    tab = (C.c_float * (nd * nm))()
+    assert lib.c21_Nion_Conditional_table2d(D, math.log(Mmin), math.log(Mcond), math.log(Mcond), s_c,
+                                            dmin, dmax, lo, hi, C.byref(sc), 2, 1, -50.0, 1, tab,
+                                            nd, nm) == 0
+    t = np.array(tab[:]).reshape(nd, nm)
+    ob_om = lib._keep["cp"].OMb / lib._keep["cp"].OMm
+    a, b, c = 0.73, 0.34, 0.81
+
+    def cmf(lnM, delta):
+        M = math.exp(lnM)
+        s1, ds = lib.c21_sigma_fast(M), lib.dsigmasqdm_z0(M)
+        if s1 < s_c:
+            return 0.0
+        diff = s1 * s1 - s_c * s_c
+        dl = 1.686 / D
+        terms, term = [1.0], 1.0
+        for i in range(1, 6):
+            term = term * (-diff) / i * (c - i + 1) / (s1 * s1)
+            terms.append(term)
+        p2 = b * (a * dl * dl / (s1 * s1)) ** (-c)
+        factor = math.sqrt(a) * dl * (1 + p2 * sum(reversed(terms))) - delta / D
+        barrier = math.sqrt(a) * dl * (1 + p2)
+        return (-ds * factor * diff ** -1.5 * math.exp(-((barrier - delta / D) ** 2) * 0.5 / diff)
+                / math.sqrt(2 * math.pi))
+
+    def lx(lnM, mt):
+        M = math.exp(lnM)
+
+        def pl(norm, alpha, piv, lim):
+            if (alpha > 0 and lnM > math.log(lim)) or (alpha < 0 and lnM < math.log(lim)):
+                return -math.log(norm)
+            return alpha * (lnM - piv * math.log(10))
+        fs = math.exp(pl(sc.fstar_10, sc.alpha_star, 10, sc.Mlim_Fstar) - sc.mturn_a_nofb / M) * sc.fstar_10
+        fm = math.exp(pl(sc.fstar_7, sc.alpha_star_mini, 7, sc.Mlim_Fstar_mini) - mt / M
+                      - M / sc.acg_thresh) * sc.fstar_7
+        stars, stars_m = M * fs * ob_om, M * fm * ob_om
+        sfr, sfr_m = stars / (sc.t_star * sc.t_h), stars_m / (sc.t_star * sc.t_h)
+        zscale = 10 ** (-0.056 * z + 0.064)
+        st = 1.0
+        if stars + stars_m > 0 and sfr + sfr_m > 0:
+            M0 = 1.28825e10 * ((sfr + sfr_m) * 31556925.9747) ** 0.56
+            st = (1 + ((stars + stars_m) / M0) ** -2.1) ** -0.148
+        met = 1.23 * st * zscale
+        ratio = 1.0 / ((met / 0.05) ** 0.0 + (met / 0.05) ** 0.64)  # USE_UPPER_STELLAR_TURNOVER
+        return 31556925.9747 * (sfr * sc.l_x * ratio + sfr_m * sc.l_x_mini * ratio)
+
+    for i, j in ((40, 5), (200, 20), (330, 35)):
+        delta = dmin + np.float32(i) / (np.float32(nd) - 1.0) * (dmax - dmin)
+        mt = float(np.float32(10 ** (lo + np.float32(j) / (np.float32(nm) - 1.0) * (hi - lo))))
+        want, _ = integrate.quad(lambda x: lx(x, mt) * cmf(x, float(delta)), math.log(Mmin),
+                                 math.log(Mcond), limit=400, epsrel=1e-8)
+        assert t[i, j] == pytest.approx(math.log(want), abs=3e-3), (i, j)
+    assert np.all(np.diff(t[:150], axis=0) > 0)
