@@ -126,8 +126,12 @@ def interp_halo_boxes(z_halos, boxes, fields, redshift):
         if np.ndim(boxes[idx_desc][f]) == 0:  # box-level scalars (log10_Mcrit_MCG_ave)
             out[f] = (1 - t) * boxes[idx_desc][f] + t * boxes[idx_prog][f]
             continue
-        interp = np.zeros_like(boxes[idx_desc][f])
-        interp[...] = (1 - t) * boxes[idx_desc][f] + t * boxes[idx_prog][f]
+        a, b = boxes[idx_desc][f], boxes[idx_prog][f]
+        if hasattr(a, "is_cuda"):  # torch tensors: the history stays in HBM
+            out[f] = ((1 - t) * a + t * b).contiguous()
+            continue
+        interp = np.zeros_like(a)
+        interp[...] = (1 - t) * a + t * b
         out[f] = interp
     return out
 
@@ -156,7 +160,30 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
     so, cp, ap, ao = simulation_options, cosmo_params, astro_params, astro_options
     mini = bool(ao.USE_MINI_HALOS)
     n_step = ap.N_STEP_TS
-    shape = hboxes[0]["halo_sfr"].shape
+    shape = tuple(hboxes[0]["halo_sfr"].shape)
+    on_device = hasattr(hboxes[0]["halo_sfr"], "is_cuda")  # torch history: zero-copy entry points
+    if on_device:
+        import torch
+
+        dev = hboxes[0]["halo_sfr"].device
+
+        def grid_stack():
+            return torch.zeros((n_step,) + shape, dtype=torch.float32, device=dev)
+
+        def fptr(a):
+            return C.cast(a.data_ptr(), S.c_float_p)
+
+        def all_zero(a):
+            return not bool(torch.any(a != 0))
+    else:
+        def grid_stack():
+            return np.zeros((n_step,) + shape, np.float32)
+
+        def fptr(a):
+            return a.ctypes.data_as(S.c_float_p)
+
+        def all_zero(a):
+            return bool(np.all(a == 0))
     cosmo = FlatCosmology(cp.hlittle, cp.OMm)
     R_range, zpp_avg = xray_shells(redshift, so.HII_DIM, so.BOX_LEN, n_step, ap.R_MAX_TS, cosmo)
     z_max = min(max(z_halos), so.Z_HEAT_MAX)
@@ -165,8 +192,7 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
         R_star = lya_diffusion_scale(redshift, x_HI, cp.hlittle, cp.OMm, cp.OMb, cp.Y_He, cosmo)
     else:
         R_star = 0.0
-    box = {"filtered_sfr": np.zeros((n_step,) + shape, np.float32),
-           "filtered_xray": np.zeros((n_step,) + shape, np.float32),
+    box = {"filtered_sfr": grid_stack(), "filtered_xray": grid_stack(),
            "mean_sfr": np.zeros(n_step), "mean_sfr_mini": np.zeros(n_step),
            "mean_log10_Mcrit_LW": np.zeros(n_step)}
     extra = {}
@@ -174,11 +200,10 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
         names = ["filtered_sfr_mini"] + (["filtered_sfr_lw", "filtered_sfr_mini_lw"]
                                          if ao.LYA_MULTIPLE_SCATTERING else [])
         for k in names:
-            box[k] = np.zeros((n_step,) + shape, np.float32)
-            extra[k] = box[k].ctypes.data_as(S.c_float_p)
+            box[k] = grid_stack()
+            extra[k] = fptr(box[k])
     src = S.XraySourceBoxStruct(
-        filtered_sfr=box["filtered_sfr"].ctypes.data_as(S.c_float_p),
-        filtered_xray=box["filtered_xray"].ctypes.data_as(S.c_float_p), **extra,
+        filtered_sfr=fptr(box["filtered_sfr"]), filtered_xray=fptr(box["filtered_xray"]), **extra,
         mean_sfr=box["mean_sfr"].ctypes.data_as(C.POINTER(C.c_double)),
         mean_sfr_mini=box["mean_sfr_mini"].ctypes.data_as(C.POINTER(C.c_double)),
         mean_log10_Mcrit_LW=box["mean_log10_Mcrit_LW"].ctypes.data_as(C.POINTER(C.c_double)))
@@ -194,14 +219,13 @@ def compute_xray_source_field(z_halos, hboxes, redshift, *, simulation_options, 
             continue
         fields = ("halo_sfr", "halo_xray") + (("halo_sfr_mini", "log10_Mcrit_MCG_ave") if mini else ())
         hb = interp_halo_boxes(z_sorted, b_sorted, fields, float(zpp_avg[i]))
-        if np.all(hb["halo_sfr"] == 0) and (not mini or np.all(hb["halo_sfr_mini"] == 0)):
+        if all_zero(hb["halo_sfr"]) and (not mini or all_zero(hb["halo_sfr_mini"])):
             if mini:
                 box["mean_log10_Mcrit_LW"][i] = hb["log10_Mcrit_MCG_ave"]
             continue
-        hbs = S.HaloBoxStruct(halo_sfr=hb["halo_sfr"].ctypes.data_as(S.c_float_p),
-                              halo_xray=hb["halo_xray"].ctypes.data_as(S.c_float_p))
+        hbs = S.HaloBoxStruct(halo_sfr=fptr(hb["halo_sfr"]), halo_xray=fptr(hb["halo_xray"]))
         if mini:
-            hbs.halo_sfr_mini = hb["halo_sfr_mini"].ctypes.data_as(S.c_float_p)
+            hbs.halo_sfr_mini = fptr(hb["halo_sfr_mini"])
             hbs.log10_Mcrit_MCG_ave = float(hb["log10_Mcrit_MCG_ave"])
         check(lib.UpdateXraySourceBox(C.byref(hbs), R_inner, R_outer, i, R_star, C.byref(src)),
               "UpdateXraySourceBox")
@@ -396,7 +420,8 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
         if ts_on:
             srcs = None
             if lagrangian:  # the X-ray light cone reads the halo-grid HISTORY (host arrays)
-                hist = {k: host(hb_arr[k]) for k in ("halo_sfr", "halo_xray")
+                # (device runs keep the history in HBM: interpolation and filtering never leave it)
+                hist = {k: hb_arr[k] for k in ("halo_sfr", "halo_xray")
                         + (("halo_sfr_mini",) if mini else ())}
                 if mini:
                     hist["log10_Mcrit_MCG_ave"] = hb.log10_Mcrit_MCG_ave
@@ -404,13 +429,12 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
                     z_halos + [z], hboxes + [hist], z, simulation_options=so,
                     cosmo_params=inputs.cosmo_params, astro_params=ap, astro_options=ao,
                     previous_xHI_mean=prev_xHI, lib=lib)
-                srcs = S.XraySourceBoxStruct(
-                    filtered_sfr=xsrc["filtered_sfr"].ctypes.data_as(S.c_float_p),
-                    filtered_xray=xsrc["filtered_xray"].ctypes.data_as(S.c_float_p))
+                srcs = S.XraySourceBoxStruct(filtered_sfr=fp(xsrc["filtered_sfr"]),
+                                             filtered_xray=fp(xsrc["filtered_xray"]))
                 if mini:
                     for k in ("filtered_sfr_mini", "filtered_sfr_lw", "filtered_sfr_mini_lw"):
                         if k in xsrc:
-                            setattr(srcs, k, xsrc[k].ctypes.data_as(S.c_float_p))
+                            setattr(srcs, k, fp(xsrc[k]))
                     srcs.mean_log10_Mcrit_LW = xsrc["mean_log10_Mcrit_LW"].ctypes.data_as(
                         C.POINTER(C.c_double))
                 z_halos.append(z)

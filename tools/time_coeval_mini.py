@@ -1,4 +1,4 @@
-"""Wall time of an E-INTEGRAL evolution with and without USE_MINI_HALOS through
+"""Wall time of E-INTEGRAL and L-INTEGRAL evolutions with and without USE_MINI_HALOS through
 drivers.run_coeval, arrays resident on the device (diagnostic; GPU box only).
 
     PYTHONPATH=. python tools/time_coeval_mini.py [HII_DIM] [z_end] [N_THREADS]
@@ -21,11 +21,13 @@ common = dict(HII_DIM=n, DIM=2 * n, BOX_LEN=1.5 * n, N_THREADS=n_threads, ZPRIME
               USE_LYA_HEATING=False, SOURCE_MODEL=1, USE_TS_FLUCT=True, R_BUBBLE_MAX=30.0,
               M_TURN=10 ** 5.0)
 out = {"hii_dim": n, "z_end": z_end, "n_threads": n_threads}
-for label, extra in (("no_mini", {}), ("mini", dict(USE_MINI_HALOS=True, ALPHA_STAR_MINI=0.5,
-                                                     V_CB_MODEL=3))):
+MINI = dict(USE_MINI_HALOS=True, ALPHA_STAR_MINI=0.5, V_CB_MODEL=3)
+LAG = dict(SOURCE_MODEL=2, HII_FILTER=0, USE_EXP_FILTER=True, CELL_RECOMB=True, PERTURB_ON_HIGH_RES=False)
+for label, extra in (("e_integral", {}), ("e_integral_mini", MINI), ("l_integral", LAG),
+                     ("l_integral_mini", {**LAG, **MINI})):
     marks = []
     t0 = time.perf_counter()
-    res = D.run_coeval(D.Inputs(random_seed=3, **common, **extra), [z_end], data_path=DATA,
+    res = D.run_coeval(D.Inputs(random_seed=3, **{**common, **extra}), [z_end], data_path=DATA,
                        device="cuda", keep=("neutral_fraction",),
                        progress=lambda h: marks.append(time.perf_counter()))
     total = time.perf_counter() - t0
