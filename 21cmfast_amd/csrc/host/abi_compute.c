@@ -906,7 +906,6 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
                       "turnover grids with the high-resolution cell index, map_mass.c:291-292)";
     if (ao->USE_MINI_HALOS && ao->INTEGRATION_METHOD_MINI > 1)
         unsupported = "INTEGRATION_METHOD_MINI=GAMMA-APPROX";
-    if (ao->HALO_SCALING_RELATIONS_MEDIAN) unsupported = "HALO_SCALING_RELATIONS_MEDIAN";
     if (ao->INTEGRATION_METHOD_ATOMIC > 1) unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
     if (ao->PHOTON_CONS_TYPE != C21CM_PHOTONCONS_NONE) unsupported = "PHOTON_CONS_TYPE != none";
     if (config_settings.EXTRA_HALOBOX_FIELDS) unsupported = "EXTRA_HALOBOX_FIELDS";
@@ -931,6 +930,8 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
 
     c21_scaling_consts sc, sc_sfrd;
     if ((st = c21_set_scaling_constants(redshift, &sc))) return st;
+    /* set_fixed_grids :300-308: median relations -> raised normalisations in the sub-grid integrals */
+    if (ao->HALO_SCALING_RELATIONS_MEDIAN && (st = c21_scaling_consts_mimic_scatter(&sc))) return st;
     sc_sfrd = c21_scaling_consts_sfr(&sc); /* scaling_relations.c:122-131 */
 
     const double M_min = c21_minimum_source_mass(redshift), M_max = M_MAX_INTEGRAL;

@@ -1308,6 +1308,24 @@ c21_scaling_consts c21_scaling_consts_sfr(const c21_scaling_consts *sc) {
     return sc_sfrd;
 }
 
+/* mimic_scatter_in_consts (scaling_relations.c:170-197): HALO_SCALING_RELATIONS_MEDIAN -- the
+ * means of the log-normal relations sit above their medians, which the integrated grids mimic by
+ * raised normalisations (and re-derived f_* mass limits) */
+int c21_scaling_consts_mimic_scatter(c21_scaling_consts *sc) {
+    int status = 0;
+    const AstroParams *ap = astro_params_global;
+    sc->fstar_10 *= exp(0.5 * pow(ap->SIGMA_STAR, 2));
+    sc->fstar_7 *= exp(0.5 * pow(ap->SIGMA_STAR, 2));
+    sc->l_x *= exp(0.5 * pow(ap->SIGMA_LX, 2));
+    sc->l_x_mini *= exp(0.5 * pow(ap->SIGMA_LX, 2));
+    sc->t_star /= exp(0.5 * pow(ap->SIGMA_SFR_LIM, 2));
+    sc->Mlim_Fstar = mass_limit_bisection(1e5, 1e16, sc->alpha_star, sc->fstar_10, &status);
+    if (astro_options_global->USE_MINI_HALOS)
+        sc->Mlim_Fstar_mini = mass_limit_bisection(1e5, 1e16, sc->alpha_star_mini,
+                                                   sc->fstar_7 * pow(1e3, sc->alpha_star_mini), &status);
+    return status;
+}
+
 /* thermochem.c:281-304: Lyman-Werner + streaming-velocity threshold of molecular cooling */
 double c21_lyman_werner_threshold(float z, float J_21_LW, float vcb) {
     const AstroParams *ap = astro_params_global;

@@ -102,6 +102,8 @@ int c21_Nion_z_tables_mini(int n_z, double z_min, double z_width, double lnMmin,
  * scaling_relations.c:132-165) and their star-formation variant (f_esc = 1, :121-130) */
 c21_scaling_consts c21_scaling_consts_at_z(double redshift, const c21_scaling_consts *sc);
 c21_scaling_consts c21_scaling_consts_sfr(const c21_scaling_consts *sc);
+/* mimic_scatter_in_consts (scaling_relations.c:170-197), in place */
+int c21_scaling_consts_mimic_scatter(c21_scaling_consts *sc);
 size_t c21_scaling_consts_size(void); /* for binding layers that mirror the struct */
 double c21_minimum_source_mass(double redshift);
 int c21_recfast_load(void);

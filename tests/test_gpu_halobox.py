@@ -114,14 +114,18 @@ def test_grid_minmax(api):
     assert api.grid_minmax(torch.from_numpy(a).cuda()) == (float(a.min()), float(a.max()))
 
 
-def test_l_integral_chain_entry_points(gpu_lib, oracle, tmp_path):
+@pytest.mark.parametrize("median", [False, True])
+def test_l_integral_chain_entry_points(gpu_lib, oracle, tmp_path, median):
     """SOURCE_MODEL = L-INTEGRAL: ComputeHaloBox fills n_ion from the initial conditions, and
-    ComputeIonizedBox consumes it (two filtered grids, the benchmark path)."""
+    ComputeIonizedBox consumes it (two filtered grids, the benchmark path).  median:
+    HALO_SCALING_RELATIONS_MEDIAN raises the normalisations of the sub-grid integrals
+    (mimic_scatter_in_consts, scaling_relations.c:170-197; checked in tests/test_host_scalars.py)."""
     from test_gpu_abi import Session, call_ionize, fptr, ionize_spec_from_scalars
 
     lib = gpu_lib
     n, N = 32, 64
-    ses = Session(lib, tmp_path, HII_DIM=n, DIM=N, SOURCE_MODEL=2, R_BUBBLE_MAX=12.0)
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=N, SOURCE_MODEL=2, R_BUBBLE_MAX=12.0,
+                  HALO_SCALING_RELATIONS_MEDIAN=median)
     z = 8.0
     ics = random_ics(n, N, False, seed=9)
     ics["lowres_density"] = (ics["lowres_density"] * 0.5).astype(np.float32)
@@ -147,6 +151,11 @@ def test_l_integral_chain_entry_points(gpu_lib, oracle, tmp_path):
     lib.sigma_z0.argtypes = [f64]
     sc = ScalingConsts()
     assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    if median:
+        lib.c21_scaling_consts_mimic_scatter.restype = C.c_int
+        lib.c21_scaling_consts_mimic_scatter.argtypes = [C.POINTER(ScalingConsts)]
+        f0 = sc.fstar_10
+        assert lib.c21_scaling_consts_mimic_scatter(C.byref(sc)) == 0 and sc.fstar_10 > f0
     sc_sfrd = ScalingConsts.from_buffer_copy(sc)
     sc_sfrd.fesc_10, sc_sfrd.fesc_7, sc_sfrd.alpha_esc, sc_sfrd.Mlim_Fesc = 1.0, 1.0, 0.0, 0.0
     D = lib.dicke(z)

@@ -515,3 +515,26 @@ def test_class_transfer_tables(host, pkg):
         host.Broadcast_struct_global_all(*[C.byref(keep[n]) for n in ("so", "mo", "cp", "ap", "ao",
                                                                       "ct")])
         host.init_ps()
+
+
+def test_mimic_scatter_in_consts(host, pkg):
+    """HALO_SCALING_RELATIONS_MEDIAN: mean / median of a log-normal = exp(sigma^2 / 2) in the
+    normalisations, the star-formation time-scale lowered by the SSFR scatter, f_* limit re-derived
+    (scaling_relations.c:170-197)."""
+    _bind_conditional(host)
+    host.c21_scaling_consts_mimic_scatter.restype = C.c_int
+    host.c21_scaling_consts_mimic_scatter.argtypes = [C.POINTER(ScalingConsts)]
+    ap = host._keep["ap"]
+    sc, ev = ScalingConsts(), ScalingConsts()
+    assert host.c21_set_scaling_constants(9.0, C.byref(sc)) == 0
+    assert host.c21_set_scaling_constants(9.0, C.byref(ev)) == 0
+    assert host.c21_scaling_consts_mimic_scatter(C.byref(ev)) == 0
+    up_star, up_x = math.exp(0.5 * ap.SIGMA_STAR ** 2), math.exp(0.5 * ap.SIGMA_LX ** 2)
+    assert ev.fstar_10 == pytest.approx(sc.fstar_10 * up_star, rel=1e-12)
+    assert ev.fstar_7 == pytest.approx(sc.fstar_7 * up_star, rel=1e-12)
+    assert ev.l_x == pytest.approx(sc.l_x * up_x, rel=1e-12)
+    assert ev.t_star == pytest.approx(sc.t_star / math.exp(0.5 * ap.SIGMA_SFR_LIM ** 2), rel=1e-12)
+    # f_*(M) = f_*10 (M / 1e10)^alpha reaches one at the new, lower limit
+    assert ev.Mlim_Fstar < sc.Mlim_Fstar
+    assert ev.fstar_10 * (ev.Mlim_Fstar / 1e10) ** ev.alpha_star == pytest.approx(1.0, rel=5e-3)
+    assert (ev.fesc_10, ev.alpha_esc, ev.Mlim_Fesc, ev.t_h) == (sc.fesc_10, sc.alpha_esc, sc.Mlim_Fesc, sc.t_h)
