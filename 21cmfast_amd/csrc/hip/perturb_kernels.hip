@@ -866,3 +866,192 @@ extern "C" int c21hip_halobox_scatter_mini(const float *src_density, const int d
     LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Halo catalogue -> HaloBox grids: move_halo_galprops (map_mass.c:346-476) with
+// set_halo_properties (HaloBox.c:62-102) and the per-halo scaling relations
+// (scaling_relations.c:277-283,331-500).  One thread per halo: displace the halo with the
+// velocities of its Lagrangian cell, evaluate the relations in double, deposit up to five values
+// into eight cells each with fp64 atomics (per unit cell volume: upstream scales the float grids
+// afterwards).  Upstream adds into FLOAT grids in thread order; the double accumulation here
+// agrees with its N_THREADS = 1 result to float rounding of the per-cell sums.
+namespace {
+constexpr double kSecPerYr = 31556925.9747;  // physconst.s_per_yr
+
+struct HaloDepositParams {
+    c21cm_halo_consts c;
+    unsigned long long n_halos;
+    int vel_dim[3], out_dim[3];
+    double cell_size_inv_v;  // vel_dim[0] / BOX_LEN for every axis (:355)
+    double vdf, vdf2;        // D - D_i and the 2LPT analogue: Mpc per velocity unit (:368-370)
+    double box_size[3];      // pos * out_dim / box_size (:409-411)
+    double cell_vol_inv;
+    int lpt2;
+};
+
+__device__ __forceinline__ double cic_read(const float *__restrict__ box, const size_t idx[8],
+                                            const double w[8]) {
+    double sum = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) sum += w[c] * (double)box[idx[c]];
+    return sum;
+}
+
+// scaling_relations.c:277-283 through get_lx_on_sfr :315-325
+__device__ __forceinline__ double halo_lx_on_sfr(double metallicity, double lx_constant, int upper) {
+    if (!upper) return lx_constant;
+    const double hi_z_index = -0.64, lo_z_index = 0., z_pivot = 0.05;
+    return lx_constant *
+           (1. / (pow(metallicity / z_pivot, -lo_z_index) + pow(metallicity / z_pivot, -hi_z_index)));
+}
+
+__global__ void __launch_bounds__(kBlock)
+halo_deposit_kernel(HaloDepositParams h, const float *__restrict__ masses,
+                    const float *__restrict__ coords, const float *__restrict__ star_rng,
+                    const float *__restrict__ sfr_rng, const float *__restrict__ xray_rng,
+                    const float *__restrict__ vx, const float *__restrict__ vy,
+                    const float *__restrict__ vz, const float *__restrict__ v2x,
+                    const float *__restrict__ v2y, const float *__restrict__ v2z,
+                    const float *__restrict__ mturn_a, const float *__restrict__ mturn_m,
+                    double *__restrict__ out_nion, double *__restrict__ out_sfr,
+                    double *__restrict__ out_sfr_mini, double *__restrict__ out_xray,
+                    double *__restrict__ out_wsfr) {
+    const c21cm_halo_consts &c = h.c;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; t < h.n_halos;
+         t += (unsigned long long)gridDim.x * kBlock) {
+        const double hmass = (double)masses[t];
+        if (hmass == 0.) continue;  // halos cut from the catalogue (:388-390)
+        double pos[3] = {(double)coords[3 * t], (double)coords[3 * t + 1], (double)coords[3 * t + 2]};
+        int ip[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            ip[a] = wrap_idx((int)(pos[a] * h.cell_size_inv_v + 0.5), h.vel_dim[a]);
+        const size_t vi =
+            (size_t)ip[2] + (size_t)h.vel_dim[2] * ((size_t)ip[1] + (size_t)h.vel_dim[1] * ip[0]);
+        const float v[3] = {vx[vi], vy[vi], vz[vi]};
+        float v2[3] = {0.f, 0.f, 0.f};
+        if (h.lpt2) v2[0] = v2x[vi], v2[1] = v2y[vi], v2[2] = v2z[vi];
+        size_t idx[8];
+        double w[8];
+        {
+            int i0[3], i1[3];
+            double d[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                pos[a] += (double)v[a] * h.vdf;
+                if (h.lpt2) pos[a] -= (double)v2[a] * h.vdf2;
+                pos[a] = pos[a] * h.out_dim[a] / h.box_size[a];
+                const int ipos = (int)floor(pos[a]);
+                d[a] = pos[a] - (double)ipos;
+                i0[a] = wrap_idx(ipos, h.out_dim[a]);
+                i1[a] = wrap_idx(ipos + 1, h.out_dim[a]);
+            }
+            const size_t sy = (size_t)h.out_dim[2], sx = (size_t)h.out_dim[1] * h.out_dim[2];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                idx[k] = (size_t)((k & 1) ? i1[0] : i0[0]) * sx + (size_t)((k & 2) ? i1[1] : i0[1]) * sy +
+                         (size_t)((k & 4) ? i1[2] : i0[2]);
+                w[k] = ((k & 1) ? d[0] : 1. - d[0]) * ((k & 2) ? d[1] : 1. - d[1]) *
+                       ((k & 4) ? d[2] : 1. - d[2]);
+            }
+        }
+        double M_turn_a = c.mturn_a_nofb, M_turn_m = c.mturn_m_nofb;
+        if (c.use_mini_halos) {  // the turnover grids, CIC-read at the halo (:413-416)
+            M_turn_a = pow(10., cic_read(mturn_a, idx, w));
+            M_turn_m = pow(10., cic_read(mturn_m, idx, w));
+        }
+        // get_halo_stellarmass (scaling_relations.c:331-400)
+        const double adj_star = c.scaling_median ? 0. : c.sigma_star * c.sigma_star / 2.;
+        double mu_fstar;
+        if (c.upper_stellar_turnover && c.alpha_star > c.alpha_upper)
+            mu_fstar = c.fstar_10 * (c.upper_pivot_ratio / (pow(hmass / c.pivot_upper, -c.alpha_star) +
+                                                            pow(hmass / c.pivot_upper, -c.alpha_upper)));
+        else
+            mu_fstar = c.fstar_10 * pow(hmass / 1e10, c.alpha_star);
+        const double s_rng = (double)star_rng[t];
+        double f_sample = mu_fstar * exp(-M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
+        if (f_sample > 1.) f_sample = 1.;
+        const double stars = f_sample * hmass * c.baryon_ratio;
+        double stars_mini = 0.;
+        if (c.use_mini_halos) {
+            const double mu_mini = c.fstar_7 * pow(hmass / 1e7, c.alpha_star_mini);
+            double f_mini = mu_mini * exp(-M_turn_m / hmass - hmass / c.acg_thresh +
+                                          s_rng * c.sigma_star - adj_star);
+            if (f_mini > 1.) f_mini = 1.;
+            stars_mini = f_mini * hmass * c.baryon_ratio;
+        }
+        // get_halo_sfr (:402-444): the scatter widens towards low stellar masses
+        double sigma_sfr = 0.;
+        if (c.sigma_sfr_lim > 0.) {
+            sigma_sfr = c.sigma_sfr_idx * log10((stars + stars_mini) / 1e10) + c.sigma_sfr_lim;
+            if (sigma_sfr < c.sigma_sfr_lim) sigma_sfr = c.sigma_sfr_lim;
+        }
+        const double adj_sfr = c.scaling_median ? 0. : sigma_sfr * sigma_sfr / 2.;
+        const double sfr_fac = exp((double)sfr_rng[t] * sigma_sfr - adj_sfr);
+        const double sfr = stars / (c.t_star * c.t_h) * sfr_fac;
+        const double sfr_mini = c.use_mini_halos ? stars_mini / (c.t_star * c.t_h) * sfr_fac : 0.;
+        // get_halo_metallicity, get_halo_xray (:446-500)
+        double xray = 0.;
+        if (c.use_xray) {
+            const double sfr_t = sfr + sfr_mini, stars_t = stars + stars_mini;
+            double stellar_term = 1.;
+            if (stars_t > 0 && sfr_t > 0.) {
+                const double M0 = 1.28825e10 * pow(sfr_t * kSecPerYr, 0.56);
+                stellar_term = pow(1 + pow(stars_t / M0, -2.1), -0.148);
+            }
+            const double metallicity = 1.23 * stellar_term * pow(10., -0.056 * c.redshift + 0.064);
+            double mu_x = halo_lx_on_sfr(metallicity, c.l_x, c.upper_stellar_turnover) * (sfr * kSecPerYr);
+            if (c.use_mini_halos)
+                mu_x += halo_lx_on_sfr(metallicity, c.l_x_mini, c.upper_stellar_turnover) *
+                        (sfr_mini * kSecPerYr);
+            const double adj_x = c.scaling_median ? 0. : c.sigma_xray * c.sigma_xray / 2.;
+            xray = mu_x * exp((double)xray_rng[t] * c.sigma_xray - adj_x);
+        }
+        const double fesc = fmin(c.fesc_10 * pow(hmass / 1e10, c.alpha_esc), 1.);
+        const double fesc_mini = c.use_mini_halos ? fmin(c.fesc_7 * pow(hmass / 1e7, c.alpha_esc), 1.) : 0.;
+        const double n_ion = stars * c.pop2_ion * fesc + stars_mini * c.pop3_ion * fesc_mini;
+        const double wsfr = sfr * c.pop2_ion * fesc + sfr_mini * c.pop3_ion * fesc_mini;
+        const double val[5] = {n_ion, sfr, sfr_mini, xray, wsfr};
+        double *outs[5] = {out_nion, out_sfr, out_sfr_mini, out_xray, out_wsfr};
+        for (int g = 0; g < 5; g++) {
+            if (!outs[g]) continue;
+            const double vg = val[g] * h.cell_vol_inv;
+#pragma unroll
+            for (int k = 0; k < 8; k++) unsafeAtomicAdd(outs[g] + idx[k], vg * w[k]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int c21hip_halo_deposit(const c21cm_halo_consts *consts, unsigned long long n_halos,
+                                   const float *masses, const float *coords, const float *star_rng,
+                                   const float *sfr_rng, const float *xray_rng,
+                                   const float *const vel[3], const float *const vel2[3],
+                                   const int vel_dim[3], const int out_dim[3], double box_len,
+                                   double box_len_z, double growth, double init_growth, int lpt2,
+                                   const float *mturn_a, const float *mturn_m, double *out_nion,
+                                   double *out_sfr, double *out_sfr_mini, double *out_xray,
+                                   double *out_wsfr, void *stream) {
+    if (!n_halos) return 0;
+    HaloDepositParams h;
+    h.c = *consts;
+    h.n_halos = n_halos;
+    const double box[3] = {box_len, box_len, box_len_z};
+    for (int a = 0; a < 3; a++) {
+        h.vel_dim[a] = vel_dim[a];
+        h.out_dim[a] = out_dim[a];
+        h.box_size[a] = box[a];
+    }
+    h.cell_size_inv_v = vel_dim[0] / box_len;
+    h.vdf = growth - init_growth;
+    h.vdf2 = -(3.0 / 7.0) * growth * growth - (-(3.0 / 7.0) * init_growth * init_growth);
+    const double cell_size_inv_o = out_dim[0] / box_len;
+    h.cell_vol_inv = cell_size_inv_o * cell_size_inv_o * cell_size_inv_o;
+    h.lpt2 = lpt2;
+    hipLaunchKernelGGL(halo_deposit_kernel, dim3(grid_for((size_t)n_halos)), dim3(kBlock), 0,
+                       (hipStream_t)stream, h, masses, coords, star_rng, sfr_rng, xray_rng, vel[0],
+                       vel[1], vel[2], vel2[0], vel2[1], vel2[2], mturn_a, mturn_m, out_nion, out_sfr,
+                       out_sfr_mini, out_xray, out_wsfr);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -883,13 +883,12 @@ done:
     return st;
 }
 
-/* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436.  Only the
- * integrated branch without the extra fields; with USE_TS_FLUCT the X-ray emissivity
- * grid halo_xray is filled as well (the input of UpdateXraySourceBox); with USE_MINI_HALOS the
- * turnover grids (get_log10_turnovers :465-516), the 2-D tables and halo_sfr_mini. */
+/* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436 and
+ * sum_halos_onto_grid :518-560, without the extra fields; with USE_TS_FLUCT the X-ray
+ * emissivity grid halo_xray is filled as well (the input of UpdateXraySourceBox); with USE_MINI_HALOS
+ * the turnover grids (get_log10_turnovers :465-516), the 2-D tables and halo_sfr_mini. */
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
                    TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids) {
-    (void)halos;
     int st = require_globals("ComputeHaloBox", 1);
     if (st) return st;
     if (!ini_boxes || !grids) return C21CM_VALUE_ERROR;
@@ -897,8 +896,14 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
     const MatterOptions *mo = matter_options_global;
     const AstroOptions *ao = astro_options_global;
     const char *unsupported = NULL;
-    if (mo->SOURCE_MODEL != C21CM_SOURCE_L_INTEGRAL)
-        unsupported = "a SOURCE_MODEL other than L-INTEGRAL (halo catalogues)";
+    const int sampled = mo->SOURCE_MODEL == C21CM_SOURCE_DEXM_ESF ||
+                        mo->SOURCE_MODEL == C21CM_SOURCE_CHMF_SAMPLER; /* InputParameters.h:76-79 */
+    if (mo->SOURCE_MODEL != C21CM_SOURCE_L_INTEGRAL && !sampled)
+        unsupported = "an Eulerian SOURCE_MODEL (no HaloBox)";
+    if (sampled && !halos) {
+        c21hip_set_error("ComputeHaloBox: SOURCE_MODEL = DEXM-ESF / CHMF-SAMPLER needs a halo catalogue");
+        return C21CM_VALUE_ERROR;
+    }
     if (mo->USE_INTERPOLATION_TABLES != C21CM_INTERP_HMF)
         unsupported = "L-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation";
     if (ao->USE_MINI_HALOS && mo->PERTURB_ON_HIGH_RES)
@@ -930,11 +935,37 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
 
     c21_scaling_consts sc, sc_sfrd;
     if ((st = c21_set_scaling_constants(redshift, &sc))) return st;
+    /* the halos of a catalogue take the unadjusted constants (hbox_consts, :599-600,623-624) */
+    const AstroParams *ap = astro_params_global;
+    c21cm_halo_consts hc;
+    memset(&hc, 0, sizeof(hc));
+    hc.redshift = redshift;
+    hc.fstar_10 = sc.fstar_10, hc.alpha_star = sc.alpha_star, hc.sigma_star = ap->SIGMA_STAR;
+    hc.alpha_upper = ap->UPPER_STELLAR_TURNOVER_INDEX, hc.pivot_upper = ap->UPPER_STELLAR_TURNOVER_MASS;
+    hc.upper_pivot_ratio = pow(hc.pivot_upper / 1e10, hc.alpha_star) + pow(hc.pivot_upper / 1e10, hc.alpha_upper);
+    hc.fstar_7 = sc.fstar_7, hc.alpha_star_mini = sc.alpha_star_mini, hc.acg_thresh = sc.acg_thresh;
+    hc.baryon_ratio = cosmo_params_global->OMb / cosmo_params_global->OMm;
+    hc.t_h = sc.t_h, hc.t_star = sc.t_star;
+    hc.sigma_sfr_lim = ap->SIGMA_SFR_LIM, hc.sigma_sfr_idx = ap->SIGMA_SFR_INDEX;
+    hc.l_x = sc.l_x, hc.l_x_mini = sc.l_x_mini, hc.sigma_xray = ap->SIGMA_LX;
+    hc.fesc_10 = sc.fesc_10, hc.fesc_7 = sc.fesc_7, hc.alpha_esc = sc.alpha_esc;
+    hc.pop2_ion = sc.pop2_ion, hc.pop3_ion = sc.pop3_ion;
+    hc.mturn_a_nofb = sc.mturn_a_nofb, hc.mturn_m_nofb = sc.mturn_m_nofb;
+    hc.scaling_median = ao->HALO_SCALING_RELATIONS_MEDIAN;
+    hc.upper_stellar_turnover = ao->USE_UPPER_STELLAR_TURNOVER;
+    hc.use_mini_halos = ao->USE_MINI_HALOS, hc.use_xray = ao->USE_TS_FLUCT;
     /* set_fixed_grids :300-308: median relations -> raised normalisations in the sub-grid integrals */
     if (ao->HALO_SCALING_RELATIONS_MEDIAN && (st = c21_scaling_consts_mimic_scatter(&sc))) return st;
     sc_sfrd = c21_scaling_consts_sfr(&sc); /* scaling_relations.c:122-131 */
 
-    const double M_min = c21_minimum_source_mass(redshift), M_max = M_MAX_INTEGRAL;
+    /* the integrated part ends where the catalogue begins (:626-634) */
+    const double M_min = c21_minimum_source_mass(redshift);
+    const double M_max = mo->SOURCE_MODEL == C21CM_SOURCE_CHMF_SAMPLER ? so->SAMPLER_MIN_MASS
+                         : mo->SOURCE_MODEL == C21CM_SOURCE_DEXM_ESF
+                             ? c21_RtoM(L_FACTOR * so->BOX_LEN / so->DIM)
+                             : M_MAX_INTEGRAL;
+    const int integral = M_min < M_max; /* :635 */
+    if (sampled) s.halos = halos, s.halo_consts = &hc, s.skip_integral = !integral;
     const size_t n_src = s.perturb_on_high_res ? (size_t)dim * dim * dim_z
                                                 : (size_t)s.hii_dim * s.hii_dim * s.hii_dim_z;
     const size_t n_out = (size_t)s.hii_dim * s.hii_dim * s.hii_dim_z;
@@ -947,18 +978,20 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
         return C21CM_VALUE_ERROR;
     }
     /* table range: extrema of density * D, seeded with 0, widened by 0.1 % (HaloBox.c:303-381) */
-    double mm[2];
-    if ((st = c21cm_grid_minmax(dens, n_src, mm, NULL))) return st;
+    double mm[2] = {0., 0.};
+    if (integral && (st = c21cm_grid_minmax(dens, n_src, mm, NULL))) return st;
     double min_density = fmin(0., mm[0] * s.growth_factor) * 1.001;
     double max_density = fmax(0., mm[1] * s.growth_factor) * 1.001;
     if (!(max_density > min_density)) max_density = min_density + 1e-6;
     static float tab_nion[C21CM_NDELTA_TABLE], tab_sfrd[C21CM_NDELTA_TABLE];
     const int method = ao->INTEGRATION_METHOD_ATOMIC;
-    if ((st = c21_Nion_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
+    if (integral &&
+        (st = c21_Nion_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
                                          sigma_cell, min_density, max_density, sc.mturn_a_nofb, &sc,
                                          method, -40., tab_nion, C21CM_NDELTA_TABLE)))
         return st;
-    if ((st = c21_Nion_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
+    if (integral &&
+        (st = c21_Nion_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
                                          sigma_cell, min_density, max_density, sc_sfrd.mturn_a_nofb,
                                          &sc_sfrd, method, -50., tab_sfrd, C21CM_NDELTA_TABLE)))
         return st;
@@ -972,11 +1005,12 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
             c21hip_set_error("ComputeHaloBox: USE_TS_FLUCT needs HaloBox.halo_xray");
             return C21CM_VALUE_ERROR;
         }
-        if ((st = c21_Xray_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
+        if (integral &&
+            (st = c21_Xray_Conditional_table(s.growth_factor, log(M_min), log(M_max), log(M_cell),
                                              sigma_cell, min_density, max_density, sc.mturn_a_nofb,
                                              &sc, method, tab_xray, C21CM_NDELTA_TABLE)))
             return st;
-        s.ln_xray_table = tab_xray;
+        if (integral) s.ln_xray_table = tab_xray;
     }
     /* map_mass.c:223-239 */
     const double vol_ratio_out = (double)n_out / (double)n_src;
@@ -1034,17 +1068,20 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
         const double lnMmin = log(M_min), lnMmax = log(M_max), lnMc = log(M_cell);
         const int m_a = ao->INTEGRATION_METHOD_ATOMIC, m_m = ao->INTEGRATION_METHOD_MINI;
         /* initialise_Nion_Conditional_spline (interp_tables.c:291-405) on the grids' ranges */
-        if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
+        if (integral &&
+            (st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
                                                min_density, max_density, a_lo, a_hi, &sc, 0, m_a, -40.,
                                                0, tab2[0], C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE)))
             return st;
-        if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
+        if (integral &&
+            (st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
                                                min_density, max_density, m_lo, m_hi, &sc, 1, m_m, -40.,
                                                0, tab2[1], C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE)))
             return st;
         /* SFRD_conditional_table_MINI / Xray_conditional_table_2D on the fixed turnover grid
          * (interp_tables.c:440-475,497-560; float condition sigma and turnover masses) */
-        if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, (float)sigma_cell,
+        if (integral &&
+            (st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, (float)sigma_cell,
                                                min_density, max_density, C21_LOG10_MTURN_MIN,
                                                C21_LOG10_MTURN_MAX, &sc_sfrd, 1, m_m, -50., 1, tab2[2],
                                                C21CM_NDELTA_TABLE, C21CM_NMTURN_TABLE)))
@@ -1056,7 +1093,7 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
         s.mtm_min = m_lo, s.mtm_width = (m_hi - m_lo) / (C21CM_NMTURN_TABLE - 1.);
         s.mt_fixed_min = C21_LOG10_MTURN_MIN;
         s.mt_fixed_width = (C21_LOG10_MTURN_MAX - C21_LOG10_MTURN_MIN) / (C21CM_NMTURN_TABLE - 1.);
-        if (ao->USE_TS_FLUCT) {
+        if (ao->USE_TS_FLUCT && integral) {
             if ((st = c21_Nion_Conditional_table2d(s.growth_factor, lnMmin, lnMmax, lnMc, sigma_cell,
                                                    min_density, max_density, C21_LOG10_MTURN_MIN,
                                                    C21_LOG10_MTURN_MAX, &sc, 2, m_m, -50., 1, tab2[3],
@@ -1069,7 +1106,7 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
         s.prefactor_sfr_mini = prefactor_stars_mini / sc.t_star / sc.t_h;
         s.prefactor_nion_mini = prefactor_stars_mini * sc.fesc_7 * sc.pop3_ion;
     }
-    if (!(M_min < M_max)) { /* :619 -- nothing to integrate: the grids stay zero */
+    if (!integral && !sampled) { /* :635 -- nothing to integrate: the grids stay zero */
         c21hip_set_error("ComputeHaloBox: M_min >= M_max");
         return C21CM_VALUE_ERROR;
     }

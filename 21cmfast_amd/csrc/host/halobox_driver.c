@@ -57,6 +57,38 @@ done:
     return status;
 }
 
+/* Halo-catalogue branch: sum_halos_onto_grid (HaloBox.c:518-560) -> move_halo_galprops
+ * (map_mass.c:346-476) into the zeroed accumulation grids, before the integrated deposit adds the
+ * sources below the catalogue's mass limit.  acc = {n_ion, halo_sfr, halo_sfr_mini, halo_xray,
+ * whalo_sfr}; entries may be NULL. */
+enum { WS_HC_MASS = 231, WS_HC_COORD, WS_HC_RNG0, WS_HC_RNG1, WS_HC_RNG2, WS_HC_WSFR };
+
+static int deposit_halos(const c21cm_halobox_spec *s, const float *const vel[3],
+                         const float *const vel2[3], const int vel_dim[3], const float *mta,
+                         const float *mtm, double *const acc[5], void *stream) {
+    const HaloCatalog *h = s->halos;
+    if (!h || !h->n_halos) return 0;
+    const c21cm_halo_consts *c = s->halo_consts;
+    if (!c || !h->halo_masses || !h->halo_coords || !h->star_rng || !h->sfr_rng ||
+        (c->use_xray && !h->xray_rng) || (c->use_mini_halos && (!mta || !mtm))) {
+        c21hip_set_error("halobox: the halo catalogue needs its constants, masses, coordinates and the "
+                         "random deviates of the scaling relations");
+        return C21CM_VALUE_ERROR;
+    }
+    int status = 0;
+    const size_t nh = (size_t)h->n_halos, fb = nh * sizeof(float);
+    const float *mass = hb_in(WS_HC_MASS, h->halo_masses, fb, stream, &status);
+    const float *coord = hb_in(WS_HC_COORD, h->halo_coords, 3 * fb, stream, &status);
+    const float *r0 = hb_in(WS_HC_RNG0, h->star_rng, fb, stream, &status);
+    const float *r1 = hb_in(WS_HC_RNG1, h->sfr_rng, fb, stream, &status);
+    const float *r2 = c->use_xray ? hb_in(WS_HC_RNG2, h->xray_rng, fb, stream, &status) : NULL;
+    if (status) return status;
+    const int out_dim[3] = {s->hii_dim, s->hii_dim, s->hii_dim_z};
+    return c21hip_halo_deposit(c, h->n_halos, mass, coord, r0, r1, r2, vel, vel2, vel_dim, out_dim,
+                               s->box_len, s->box_len_z, s->growth_factor, s->init_growth_factor,
+                               s->lpt2, mta, mtm, acc[0], acc[1], acc[2], acc[3], acc[4], stream);
+}
+
 /* USE_MINI_HALOS (HaloBox.c:245-283, map_mass.c:285-321) */
 enum { WS_HBM_MTA = 217, WS_HBM_MTM, WS_HBM_TAB, WS_HBM_ACC3, WS_HBM_OUT4, WS_HBM_G12, WS_HBM_ZRE,
        WS_HBM_J21, WS_HBM_VCB, WS_HBM_OUTA, WS_HBM_OUTM, WS_HBM_SUMS };
@@ -69,9 +101,10 @@ static int halobox_grids_mini(const c21cm_halobox_spec *s, const InitialConditio
                          "indexes the low-resolution turnover grids with the high-resolution cell index)");
         return C21CM_VALUE_ERROR;
     }
-    if (!s->log10_mturn_acg || !s->log10_mturn_mcg || !s->ln_sfrd_table || !s->ln_nion_table2d ||
-        !s->ln_nion_mini_table2d || !s->ln_sfrd_mini_table2d || !grids->halo_sfr_mini ||
-        !(s->tab_width > 0)) {
+    const int integral = !s->skip_integral;
+    if (!s->log10_mturn_acg || !s->log10_mturn_mcg || !grids->halo_sfr_mini ||
+        (integral && (!s->ln_sfrd_table || !s->ln_nion_table2d || !s->ln_nion_mini_table2d ||
+                      !s->ln_sfrd_mini_table2d || !(s->tab_width > 0)))) {
         c21hip_set_error("halobox: USE_MINI_HALOS needs the turnover grids, the 1-D SFRD table, the "
                          "three 2-D tables and HaloBox.halo_sfr_mini");
         return C21CM_VALUE_ERROR;
@@ -94,7 +127,8 @@ static int halobox_grids_mini(const c21cm_halobox_spec *s, const InitialConditio
     const float *mta = hb_in(WS_HBM_MTA, s->log10_mturn_acg, fb, stream, &status);
     const float *mtm = hb_in(WS_HBM_MTM, s->log10_mturn_mcg, fb, stream, &status);
     if (status) return status;
-    const int xray = s->ln_xray_table2d && grids->halo_xray;
+    const int xray = grids->halo_xray && (integral ? s->ln_xray_table2d != NULL
+                                                    : (s->halo_consts && s->halo_consts->use_xray));
     const size_t t1 = C21CM_NDELTA_TABLE, t2 = (size_t)C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE;
     /* one float of slack per table row set: the lookups read [idx + 1] with weight 0 on the last knot */
     float *tab = (float *)c21hip_ws(WS_HBM_TAB, (t1 + 4 * t2 + 2 * C21CM_NMTURN_TABLE + 16) * sizeof(float));
@@ -106,21 +140,33 @@ static int halobox_grids_mini(const c21cm_halobox_spec *s, const InitialConditio
     TRY(c21hip_memset(tab, 0, (t1 + 4 * t2 + 2 * C21CM_NMTURN_TABLE + 16) * sizeof(float), stream));
     float *tab_sfrd = tab + 4 * t2 + C21CM_NMTURN_TABLE, *tab_na = tab, *tab_nm = tab + t2,
           *tab_sm = tab + 2 * t2, *tab_x = tab + 3 * t2;
-    TRY(c21hip_h2d(tab_sfrd, s->ln_sfrd_table, t1 * sizeof(float), stream));
-    TRY(c21hip_h2d(tab_na, s->ln_nion_table2d, t2 * sizeof(float), stream));
-    TRY(c21hip_h2d(tab_nm, s->ln_nion_mini_table2d, t2 * sizeof(float), stream));
-    TRY(c21hip_h2d(tab_sm, s->ln_sfrd_mini_table2d, t2 * sizeof(float), stream));
-    if (xray) TRY(c21hip_h2d(tab_x, s->ln_xray_table2d, t2 * sizeof(float), stream));
+    if (integral) {
+        TRY(c21hip_h2d(tab_sfrd, s->ln_sfrd_table, t1 * sizeof(float), stream));
+        TRY(c21hip_h2d(tab_na, s->ln_nion_table2d, t2 * sizeof(float), stream));
+        TRY(c21hip_h2d(tab_nm, s->ln_nion_mini_table2d, t2 * sizeof(float), stream));
+        TRY(c21hip_h2d(tab_sm, s->ln_sfrd_mini_table2d, t2 * sizeof(float), stream));
+        if (xray) TRY(c21hip_h2d(tab_x, s->ln_xray_table2d, t2 * sizeof(float), stream));
+    }
     for (int g = 0; g < 4; g++)
         if (acc[g]) TRY(c21hip_memset(acc[g], 0, n * sizeof(double), stream));
+    double *acc_w = NULL; /* whalo_sfr of the halos: only kept without the integrated part */
+    if (s->halos) {
+        if (!integral && grids->whalo_sfr) {
+            if (!(acc_w = (double *)c21hip_ws(WS_HC_WSFR, n * sizeof(double)))) return C21CM_MEMORY_ALLOC_ERROR;
+            TRY(c21hip_memset(acc_w, 0, n * sizeof(double), stream));
+        }
+        double *const hacc[5] = {acc[0], acc[1], acc[2], acc[3], acc_w};
+        TRY(deposit_halos(s, vel, vel2, dim, mta, mtm, hacc, stream));
+    }
     const double ranges[8] = {s->tab_min, s->tab_width, s->mta_min, s->mta_width,
                               s->mtm_min, s->mtm_width, s->mt_fixed_min, s->mt_fixed_width};
     const double pref[5] = {s->prefactor_nion, s->prefactor_nion_mini, s->prefactor_sfr,
                             s->prefactor_sfr_mini, s->prefactor_xray};
-    TRY(c21hip_halobox_scatter_mini(dens, dim, vel, vel2, mta, mtm, acc[0], acc[1], acc[2], acc[3],
-                                    s->box_len, s->box_len_z, s->growth_factor,
-                                    s->init_growth_factor, s->lpt2, tab_sfrd, tab_na, tab_nm, tab_sm,
-                                    xray ? tab_x : NULL, ranges, pref, stream));
+    if (integral)
+        TRY(c21hip_halobox_scatter_mini(dens, dim, vel, vel2, mta, mtm, acc[0], acc[1], acc[2], acc[3],
+                                        s->box_len, s->box_len_z, s->growth_factor,
+                                        s->init_growth_factor, s->lpt2, tab_sfrd, tab_na, tab_nm, tab_sm,
+                                        xray ? tab_x : NULL, ranges, pref, stream));
     {
         float *targets[5] = {grids->n_ion, grids->whalo_sfr, grids->halo_sfr,
                              xray ? grids->halo_xray : NULL, grids->halo_sfr_mini};
@@ -131,7 +177,8 @@ static int halobox_grids_mini(const c21cm_halobox_spec *s, const InitialConditio
             dev[t] = c21hip_is_device_ptr(targets[t]) ? targets[t] : (float *)c21hip_ws(slots[t], fb);
             if (!dev[t]) return C21CM_MEMORY_ALLOC_ERROR;
         }
-        TRY(c21hip_narrow(acc[0], dev[0], dev[1], s->prefactor_wsfr, n, stream));
+        TRY(c21hip_narrow(acc[0], dev[0], acc_w ? NULL : dev[1], s->prefactor_wsfr, n, stream));
+        if (acc_w) TRY(c21hip_narrow(acc_w, dev[1], NULL, 0., n, stream));
         TRY(c21hip_narrow(acc[1], dev[2], NULL, 0., n, stream));
         TRY(c21hip_narrow(acc[2], dev[4], NULL, 0., n, stream));
         if (xray) TRY(c21hip_narrow(acc[3], dev[3], NULL, 0., n, stream));
@@ -193,7 +240,8 @@ int c21cm_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *ic
         c21hip_set_error("halobox: NULL spec / ics / n_ion / halo_sfr");
         return C21CM_VALUE_ERROR;
     }
-    if (!s->ln_nion_table || !s->ln_sfrd_table || !(s->tab_width > 0)) {
+    const int integral = !s->skip_integral;
+    if (integral && (!s->ln_nion_table || !s->ln_sfrd_table || !(s->tab_width > 0))) {
         c21hip_set_error("halobox: the two ln-tables and a positive bin width are required");
         return C21CM_VALUE_ERROR;
     }
@@ -222,7 +270,8 @@ int c21cm_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *ic
         if (s->lpt2) vel2[a] = hb_in(WS_HB_IN0 + 4 + a, vel2_h[a], n_src * sizeof(float), stream, &status);
     }
     if (status) return status;
-    const int xray = s->ln_xray_table && grids->halo_xray;
+    const int xray = grids->halo_xray && (integral ? s->ln_xray_table != NULL
+                                                    : (s->halo_consts && s->halo_consts->use_xray));
     double *acc0 = (double *)c21hip_ws(WS_HB_ACC0, n_out * sizeof(double));
     double *acc1 = (double *)c21hip_ws(WS_HB_ACC1, n_out * sizeof(double));
     double *acc2 = xray ? (double *)c21hip_ws(WS_HB_ACC2, n_out * sizeof(double)) : NULL;
@@ -230,18 +279,28 @@ int c21cm_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *ic
     if (!acc0 || !acc1 || !tables || (xray && !acc2)) return C21CM_MEMORY_ALLOC_ERROR;
     TRY(c21hip_memset(acc0, 0, n_out * sizeof(double), stream));
     TRY(c21hip_memset(acc1, 0, n_out * sizeof(double), stream));
-    if (xray) {
-        TRY(c21hip_memset(acc2, 0, n_out * sizeof(double), stream));
-        TRY(c21hip_h2d(tables + 2 * C21CM_NDELTA_TABLE, s->ln_xray_table,
-                       C21CM_NDELTA_TABLE * sizeof(float), stream));
+    if (xray) TRY(c21hip_memset(acc2, 0, n_out * sizeof(double), stream));
+    double *acc_w = NULL; /* whalo_sfr of the halos: only kept without the integrated part */
+    if (s->halos) {
+        if (!integral && grids->whalo_sfr) {
+            if (!(acc_w = (double *)c21hip_ws(WS_HC_WSFR, n_out * sizeof(double)))) return C21CM_MEMORY_ALLOC_ERROR;
+            TRY(c21hip_memset(acc_w, 0, n_out * sizeof(double), stream));
+        }
+        double *const hacc[5] = {acc0, acc1, NULL, acc2, acc_w};
+        TRY(deposit_halos(s, vel, vel2, src_dim, NULL, NULL, hacc, stream));
     }
-    TRY(c21hip_h2d(tables, s->ln_nion_table, C21CM_NDELTA_TABLE * sizeof(float), stream));
-    TRY(c21hip_h2d(tables + C21CM_NDELTA_TABLE, s->ln_sfrd_table,
-                   C21CM_NDELTA_TABLE * sizeof(float), stream));
-    TRY(c21hip_halobox_scatter(dens, src_dim, vel, vel2, src_dim, acc0, acc1, acc2, out_dim,
-                               s->box_len, s->box_len_z, s->growth_factor, s->init_growth_factor,
-                               s->lpt2, tables, s->tab_min, s->tab_width, s->prefactor_nion,
-                               s->prefactor_sfr, s->prefactor_xray, stream));
+    if (integral) {
+        if (xray)
+            TRY(c21hip_h2d(tables + 2 * C21CM_NDELTA_TABLE, s->ln_xray_table,
+                           C21CM_NDELTA_TABLE * sizeof(float), stream));
+        TRY(c21hip_h2d(tables, s->ln_nion_table, C21CM_NDELTA_TABLE * sizeof(float), stream));
+        TRY(c21hip_h2d(tables + C21CM_NDELTA_TABLE, s->ln_sfrd_table,
+                       C21CM_NDELTA_TABLE * sizeof(float), stream));
+        TRY(c21hip_halobox_scatter(dens, src_dim, vel, vel2, src_dim, acc0, acc1, acc2, out_dim,
+                                   s->box_len, s->box_len_z, s->growth_factor, s->init_growth_factor,
+                                   s->lpt2, tables, s->tab_min, s->tab_width, s->prefactor_nion,
+                                   s->prefactor_sfr, s->prefactor_xray, stream));
+    }
     /* narrow into the caller's float grids (staged when they are host arrays) */
     {
         float *targets[4] = {grids->n_ion, grids->whalo_sfr, grids->halo_sfr,
@@ -255,7 +314,8 @@ int c21cm_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *ic
             if (!dev[t]) return C21CM_MEMORY_ALLOC_ERROR;
         }
         /* whalo_sfr = n_ion / t_h / t_star (map_mass.c:340-346) */
-        TRY(c21hip_narrow(acc0, dev[0], dev[1], s->prefactor_wsfr, n_out, stream));
+        TRY(c21hip_narrow(acc0, dev[0], acc_w ? NULL : dev[1], s->prefactor_wsfr, n_out, stream));
+        if (acc_w) TRY(c21hip_narrow(acc_w, dev[1], NULL, 0., n_out, stream));
         TRY(c21hip_narrow(acc1, dev[2], NULL, 0., n_out, stream));
         if (xray) TRY(c21hip_narrow(acc2, dev[3], NULL, 0., n_out, stream));
         for (int t = 0; t < 4; t++)

@@ -252,6 +252,45 @@ class IonizedBoxStruct(_Base):
     ]
 
 
+class HaloCatalogStruct(_Base):
+    """``HaloCatalog`` (include/c21cm_abi.h; reference _outputstructs_wrapper.h:18-28)."""
+
+    _fields_ = [
+        ("n_halos", C.c_ulonglong), ("buffer_size", C.c_ulonglong),
+        ("halo_masses", c_float_p), ("halo_coords", c_float_p),
+        ("star_rng", c_float_p), ("sfr_rng", c_float_p), ("xray_rng", c_float_p),
+    ]
+
+
+def halo_catalog(masses, coords, star_rng, sfr_rng, xray_rng=None) -> "HaloCatalogStruct":
+    """A HaloCatalog over float32 numpy arrays (masses [n], coords [n, 3] in Mpc, the standard-normal
+    deviates of the three scaling relations); the arrays are kept alive on the struct."""
+    import numpy as np
+
+    arrs = [np.ascontiguousarray(a, np.float32) if a is not None else None
+            for a in (masses, coords, star_rng, sfr_rng, xray_rng)]
+    n = arrs[0].size
+    if arrs[1].size != 3 * n or any(a is not None and a.size != n for a in arrs[2:]):
+        raise ValueError("halo catalogue arrays of different lengths")
+    cat = HaloCatalogStruct(n_halos=n, buffer_size=n)
+    for name, a in zip(("halo_masses", "halo_coords", "star_rng", "sfr_rng", "xray_rng"), arrs):
+        if a is not None:
+            setattr(cat, name, a.ctypes.data_as(c_float_p))
+    cat._keep = arrs
+    return cat
+
+
+class HaloConsts(_Base):
+    """``c21cm_halo_consts`` (include/c21cm_grid.h)."""
+
+    _fields_ = [(k, C.c_double) for k in (
+        "redshift", "fstar_10", "alpha_star", "sigma_star", "alpha_upper", "pivot_upper",
+        "upper_pivot_ratio", "fstar_7", "alpha_star_mini", "acg_thresh", "baryon_ratio", "t_h", "t_star",
+        "sigma_sfr_lim", "sigma_sfr_idx", "l_x", "l_x_mini", "sigma_xray", "fesc_10", "fesc_7",
+        "alpha_esc", "pop2_ion", "pop3_ion", "mturn_a_nofb", "mturn_m_nofb")] + [
+        (k, C.c_int) for k in ("scaling_median", "upper_stellar_turnover", "use_mini_halos", "use_xray")]
+
+
 class HaloBoxSpec(_Base):
     """``c21cm_halobox_spec`` (include/c21cm_grid.h)."""
 
@@ -274,6 +313,9 @@ class HaloBoxSpec(_Base):
         ("ln_sfrd_mini_table2d", c_float_p), ("ln_xray_table2d", c_float_p),
         ("mt_fixed_min", C.c_double), ("mt_fixed_width", C.c_double),
         ("prefactor_nion_mini", C.c_double), ("prefactor_sfr_mini", C.c_double),
+        # halo-catalogue branch
+        ("halos", C.POINTER(HaloCatalogStruct)), ("halo_consts", C.POINTER(HaloConsts)),
+        ("skip_integral", C.c_int),
     ]
 
 

@@ -354,11 +354,25 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
 int init_heat(void);
 void destruct_heat(void);
 
-/* reference: src/py21cmfast/src/HaloBox.c:563 (_functionprototypes_wrapper.h:31-32).  Only the
- * integrated branch (SOURCE_MODEL = L-INTEGRAL) is provided; `halos` is not read.  USE_MINI_HALOS
+/* reference: src/py21cmfast/src/HaloBox.c:563 (_functionprototypes_wrapper.h:31-32).
+ * SOURCE_MODEL = L-INTEGRAL: the integrated branch, `halos` is not read.  SOURCE_MODEL = DEXM-ESF /
+ * CHMF-SAMPLER: the halos of a (perturbed-position-free) catalogue get their galaxy properties
+ * (set_halo_properties, HaloBox.c:62-102), are moved with the 1LPT/2LPT displacement of their
+ * Lagrangian cell and CIC-deposited (move_halo_galprops, map_mass.c:346-476); the sources below
+ * the catalogue's mass limit are added by the integrated branch.  The catalogue itself comes from
+ * the caller (the halo finder / sampler are not part of this backend).  USE_MINI_HALOS
  * (low-resolution sources): the previous TsBox.J_21_LW and IonizedBox Gamma_12 / z_reion set the
  * turnover masses below Z_HEAT_MAX; halo_sfr_mini is filled, n_ion holds both populations. */
-typedef struct HaloCatalog HaloCatalog;
+/* reference: src/py21cmfast/src/_outputstructs_wrapper.h:18-28 */
+typedef struct HaloCatalog {
+    unsigned long long int n_halos;
+    unsigned long long int buffer_size;
+    float *halo_masses;
+    float *halo_coords; /* [3 n_halos], Mpc */
+    float *star_rng;    /* standard-normal deviates of the three scaling relations */
+    float *sfr_rng;
+    float *xray_rng;
+} HaloCatalog;
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
                    TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids);
 

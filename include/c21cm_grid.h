@@ -362,7 +362,33 @@ typedef struct c21cm_halobox_spec {
     const float *ln_sfrd_mini_table2d, *ln_xray_table2d; /* the second one NULL without halo_xray */
     double mt_fixed_min, mt_fixed_width;
     double prefactor_nion_mini, prefactor_sfr_mini;
+    /* Halo-catalogue branch (sum_halos_onto_grid, HaloBox.c:518-560; move_halo_galprops,
+     * map_mass.c:346-476): every halo of non-zero mass is displaced with the velocities of its
+     * Lagrangian cell, gets its properties (set_halo_properties, HaloBox.c:62-102; with mini-halos
+     * the turnover masses CIC-read at its position) and is CIC-deposited per unit cell volume; the
+     * integrated branch above then adds the sources below the catalogue's mass limit unless
+     * `skip_integral` (HaloBox.c:635: M_min >= the limit; the tables are not read then and, with a
+     * recombination model, whalo_sfr comes from the halos instead of n_ion). */
+    const HaloCatalog *halos; /* NULL: integrated branch only; arrays host or device */
+    const struct c21cm_halo_consts *halo_consts;
+    int skip_integral;
 } c21cm_halobox_spec;
+
+/* the ScalingConstants read by set_halo_properties (scaling_relations.c:29-118,331-500) */
+typedef struct c21cm_halo_consts {
+    double redshift;
+    double fstar_10, alpha_star, sigma_star;
+    double alpha_upper, pivot_upper, upper_pivot_ratio;
+    double fstar_7, alpha_star_mini, acg_thresh;
+    double baryon_ratio; /* OMb / OMm */
+    double t_h, t_star, sigma_sfr_lim, sigma_sfr_idx;
+    double l_x, l_x_mini, sigma_xray; /* L_X in 1e38 erg/s */
+    double fesc_10, fesc_7, alpha_esc, pop2_ion, pop3_ion;
+    double mturn_a_nofb, mturn_m_nofb; /* the turnovers without mini-halos */
+    int scaling_median;                /* HALO_SCALING_RELATIONS_MEDIAN */
+    int upper_stellar_turnover;        /* USE_UPPER_STELLAR_TURNOVER */
+    int use_mini_halos, use_xray;      /* USE_MINI_HALOS, USE_TS_FLUCT */
+} c21cm_halo_consts;
 
 int c21cm_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions *ics,
                         HaloBox *grids, void *stream);

@@ -5,8 +5,13 @@
  *   src/py21cmfast/src/map_mass.c:62-98     do_cic_interpolation_float (float boxes, atomic adds)
  *   src/py21cmfast/src/HaloBox.c:244-262    get_cell_integrals (no mini-halos / X-rays)
  *   src/py21cmfast/src/interp_tables.c:960-1001 + interpolation.c:123-131  exp(lerp(ln-table))
+ *   src/py21cmfast/src/map_mass.c:346-476   move_halo_galprops (halo catalogue -> grids)
+ *   src/py21cmfast/src/HaloBox.c:62-102     set_halo_properties
+ *   src/py21cmfast/src/scaling_relations.c:277-283,315-325,331-500  per-halo scaling relations
  * The two ln-tables come in through the spec (the host quadrature that fills them is pinned
- * separately, tests/test_host_scalars.py).
+ * separately, tests/test_host_scalars.py).  The halo-catalogue branch runs in catalogue order
+ * (upstream with N_THREADS = 1; its float adds depend on the thread order otherwise) and is
+ * PARITY UNPINNED: the reference holds no HaloBox vector.
  */
 #include <math.h>
 #include <stddef.h>
@@ -64,6 +69,135 @@ static void cic_float(float *box, const double pos[3], const int dim[3], double 
     }
 }
 
+static double cic_read_f(const float *box, const double pos[3], const int dim[3]) { /* map_mass.c:102-139 */
+    int ipos[3], iposp1[3];
+    double dist[3], sum = 0;
+    for (int a = 0; a < 3; a++) {
+        ipos[a] = (int)floor(pos[a]);
+        iposp1[a] = ipos[a] + 1;
+        dist[a] = pos[a] - ipos[a];
+        ipos[a] = wrapi(ipos[a], dim[a]);
+        iposp1[a] = wrapi(iposp1[a], dim[a]);
+    }
+    for (int c = 0; c < 8; c++) {
+        const int ix = (c & 1) ? iposp1[0] : ipos[0];
+        const int iy = (c & 2) ? iposp1[1] : ipos[1];
+        const int iz = (c & 4) ? iposp1[2] : ipos[2];
+        const double w = ((c & 1) ? dist[0] : 1. - dist[0]) * ((c & 2) ? dist[1] : 1. - dist[1]) *
+                         ((c & 4) ? dist[2] : 1. - dist[2]);
+        sum += w * box[(size_t)iz + (size_t)dim[2] * ((size_t)iy + (size_t)dim[1] * ix)];
+    }
+    return sum;
+}
+
+static double lx_on_sfr(double metallicity, double lx_constant, int upper) { /* scaling_relations.c:277-283,315-325 */
+    if (!upper) return lx_constant;
+    const double hi_z_index = -0.64, lo_z_index = 0., z_pivot = 0.05;
+    return lx_constant * (1. / (pow(metallicity / z_pivot, -lo_z_index) + pow(metallicity / z_pivot, -hi_z_index)));
+}
+
+typedef struct {
+    double n_ion, sfr, sfr_mini, xray, wsfr;
+} halo_props;
+
+/* set_halo_properties (HaloBox.c:62-102) */
+static halo_props halo_properties(double M, double M_turn_a, double M_turn_m, const c21cm_halo_consts *c,
+                                  const double rng[3]) {
+    const double s_per_yr = 31556925.9747; /* Constants.c:16 */
+    /* get_halo_stellarmass (scaling_relations.c:331-400) */
+    const double adj_star = c->scaling_median ? 0 : c->sigma_star * c->sigma_star / 2.;
+    double mu_fstar;
+    if (c->upper_stellar_turnover && c->alpha_star > c->alpha_upper)
+        mu_fstar = c->fstar_10 * (c->upper_pivot_ratio / (pow(M / c->pivot_upper, -c->alpha_star) +
+                                                          pow(M / c->pivot_upper, -c->alpha_upper)));
+    else
+        mu_fstar = c->fstar_10 * pow(M / 1e10, c->alpha_star);
+    double f = mu_fstar * exp(-M_turn_a / M + rng[0] * c->sigma_star - adj_star);
+    if (f > 1.) f = 1.;
+    const double stars = f * M * c->baryon_ratio;
+    double stars_mini = 0.;
+    if (c->use_mini_halos) {
+        double fm = c->fstar_7 * pow(M / 1e7, c->alpha_star_mini) *
+                    exp(-M_turn_m / M - M / c->acg_thresh + rng[0] * c->sigma_star - adj_star);
+        if (fm > 1.) fm = 1.;
+        stars_mini = fm * M * c->baryon_ratio;
+    }
+    /* get_halo_sfr (:402-444) */
+    double sigma_sfr = 0.;
+    if (c->sigma_sfr_lim > 0.) {
+        sigma_sfr = c->sigma_sfr_idx * log10((stars + stars_mini) / 1e10) + c->sigma_sfr_lim;
+        if (sigma_sfr < c->sigma_sfr_lim) sigma_sfr = c->sigma_sfr_lim;
+    }
+    const double adj_sfr = c->scaling_median ? 0 : sigma_sfr * sigma_sfr / 2.;
+    halo_props p;
+    p.sfr = stars / (c->t_star * c->t_h) * exp(rng[1] * sigma_sfr - adj_sfr);
+    p.sfr_mini = c->use_mini_halos ? stars_mini / (c->t_star * c->t_h) * exp(rng[1] * sigma_sfr - adj_sfr) : 0.;
+    p.xray = 0.;
+    if (c->use_xray) { /* get_halo_metallicity, get_halo_xray (:446-500) */
+        const double sfr_t = p.sfr + p.sfr_mini, stars_t = stars + stars_mini;
+        double stellar_term = 1.;
+        if (stars_t > 0 && sfr_t > 0.) {
+            const double M0 = 1.28825e10 * pow(sfr_t * s_per_yr, 0.56);
+            stellar_term = pow(1 + pow(stars_t / M0, -2.1), -0.148);
+        }
+        const double Z = 1.23 * stellar_term * pow(10, -0.056 * c->redshift + 0.064);
+        double mu_x = lx_on_sfr(Z, c->l_x, c->upper_stellar_turnover) * (p.sfr * s_per_yr);
+        if (c->use_mini_halos) mu_x += lx_on_sfr(Z, c->l_x_mini, c->upper_stellar_turnover) * (p.sfr_mini * s_per_yr);
+        const double adj_x = c->scaling_median ? 0 : c->sigma_xray * c->sigma_xray / 2.;
+        p.xray = mu_x * exp(rng[2] * c->sigma_xray - adj_x);
+    }
+    const double fesc = fmin(c->fesc_10 * pow(M / 1e10, c->alpha_esc), 1);
+    const double fesc_mini = c->use_mini_halos ? fmin(c->fesc_7 * pow(M / 1e7, c->alpha_esc), 1) : 0.;
+    p.n_ion = stars * c->pop2_ion * fesc + stars_mini * c->pop3_ion * fesc_mini;
+    p.wsfr = p.sfr * c->pop2_ion * fesc + p.sfr_mini * c->pop3_ion * fesc_mini;
+    return p;
+}
+
+/* move_halo_galprops (map_mass.c:346-476) */
+static void deposit_halos(const c21cm_halobox_spec *s, const float *const vel[3], const float *const vel2[3],
+                          const int vel_dim[3], const int out_dim[3], HaloBox *grids, int xray) {
+    const HaloCatalog *h = s->halos;
+    const c21cm_halo_consts *c = s->halo_consts;
+    const double box_size[3] = {s->box_len, s->box_len, s->box_len_z};
+    const double cell_size_inv_v = vel_dim[0] / s->box_len, cell_size_inv_o = out_dim[0] / s->box_len;
+    const double cell_vol_inv = cell_size_inv_o * cell_size_inv_o * cell_size_inv_o;
+    const double D = s->growth_factor, Di = s->init_growth_factor;
+    const double vdf = D - Di, vdf2 = -(3.0 / 7.0) * D * D - (-(3.0 / 7.0) * Di * Di);
+    for (unsigned long long i = 0; i < h->n_halos; i++) {
+        const double hmass = h->halo_masses[i];
+        if (hmass == 0.) continue;
+        double pos[3] = {h->halo_coords[3 * i], h->halo_coords[3 * i + 1], h->halo_coords[3 * i + 2]};
+        int ip[3];
+        for (int a = 0; a < 3; a++) ip[a] = wrapi((int)(pos[a] * cell_size_inv_v + 0.5), vel_dim[a]);
+        const size_t vi = (size_t)ip[2] + (size_t)vel_dim[2] * ((size_t)ip[1] + (size_t)vel_dim[1] * ip[0]);
+        for (int a = 0; a < 3; a++) {
+            pos[a] += vel[a][vi] * vdf;
+            if (s->lpt2) pos[a] -= vel2[a][vi] * vdf2;
+        }
+        for (int a = 0; a < 3; a++) pos[a] = pos[a] * out_dim[a] / box_size[a];
+        double M_turn_a = c->mturn_a_nofb, M_turn_m = c->mturn_m_nofb;
+        if (c->use_mini_halos) {
+            M_turn_a = pow(10, cic_read_f(s->log10_mturn_acg, pos, out_dim));
+            M_turn_m = pow(10, cic_read_f(s->log10_mturn_mcg, pos, out_dim));
+        }
+        const double rng[3] = {h->star_rng[i], h->sfr_rng[i], xray ? h->xray_rng[i] : 0.};
+        const halo_props p = halo_properties(hmass, M_turn_a, M_turn_m, c, rng);
+        cic_float(grids->halo_sfr, pos, out_dim, p.sfr);
+        cic_float(grids->n_ion, pos, out_dim, p.n_ion);
+        if (c->use_mini_halos) cic_float(grids->halo_sfr_mini, pos, out_dim, p.sfr_mini);
+        if (xray) cic_float(grids->halo_xray, pos, out_dim, p.xray);
+        if (grids->whalo_sfr) cic_float(grids->whalo_sfr, pos, out_dim, p.wsfr);
+    }
+    const size_t n_out = (size_t)out_dim[0] * out_dim[1] * out_dim[2];
+    for (size_t i = 0; i < n_out; i++) {
+        grids->n_ion[i] *= cell_vol_inv;
+        grids->halo_sfr[i] *= cell_vol_inv;
+        if (xray) grids->halo_xray[i] *= cell_vol_inv;
+        if (grids->whalo_sfr) grids->whalo_sfr[i] *= cell_vol_inv;
+        if (c->use_mini_halos) grids->halo_sfr_mini[i] *= cell_vol_inv;
+    }
+}
+
 int oracle_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *ics,
                          HaloBox *grids) {
     if (!s || !ics || !grids || !grids->n_ion || !grids->halo_sfr) return C21CM_VALUE_ERROR;
@@ -85,14 +219,23 @@ int oracle_halobox_grids(const c21cm_halobox_spec *s, const InitialConditions *i
         grids->halo_sfr[i] = 0.f;
     }
     const int mini = s->use_mini_halos; /* HaloBox.c:271-277, map_mass.c:289-293,312-315 */
-    if (mini && (hires || !s->log10_mturn_acg || !s->log10_mturn_mcg || !s->ln_nion_table2d ||
-                 !s->ln_nion_mini_table2d || !s->ln_sfrd_mini_table2d || !grids->halo_sfr_mini))
+    const int integral = !s->skip_integral;
+    if (mini && (hires || !s->log10_mturn_acg || !s->log10_mturn_mcg || !grids->halo_sfr_mini ||
+                 (integral && (!s->ln_nion_table2d || !s->ln_nion_mini_table2d || !s->ln_sfrd_mini_table2d))))
         return C21CM_VALUE_ERROR;
     if (mini)
         for (size_t i = 0; i < n_out; i++) grids->halo_sfr_mini[i] = 0.f;
-    const int xray = (mini ? s->ln_xray_table2d : s->ln_xray_table) && grids->halo_xray; /* USE_TS_FLUCT, HaloBox.c:279-283 */
+    const int xray = grids->halo_xray && (integral ? (mini ? s->ln_xray_table2d : s->ln_xray_table) != NULL
+                                                    : (s->halo_consts && s->halo_consts->use_xray)); /* USE_TS_FLUCT, HaloBox.c:279-283 */
     if (xray)
         for (size_t i = 0; i < n_out; i++) grids->halo_xray[i] = 0.f;
+    if (grids->whalo_sfr)
+        for (size_t i = 0; i < n_out; i++) grids->whalo_sfr[i] = 0.f;
+    if (s->halos && s->halos->n_halos) { /* HaloBox.c:622-625 */
+        if (!s->halo_consts) return C21CM_VALUE_ERROR;
+        deposit_halos(s, vel, vel2, dens_dim, out_dim, grids, xray);
+    }
+    if (!integral) return 0; /* :635 */
     const double box_size[3] = {s->box_len, s->box_len, s->box_len_z};
     const double dim_ratio_out = (double)out_dim[0] / (double)dens_dim[0];
     const double D = s->growth_factor, Di = s->init_growth_factor;

@@ -1,0 +1,48 @@
+"""Synthetic halo catalogues and scaling constants for the halo-catalogue branch of ComputeHaloBox
+(sum_halos_onto_grid, HaloBox.c:518-560; move_halo_galprops, map_mass.c:346-476)."""
+
+import ctypes as C
+import importlib
+
+import numpy as np
+
+S = importlib.import_module("21cmfast_amd.structs")
+
+
+def random_catalogue(n_halos, box_len, seed, cut_fraction=0.02, box_len_z=None):
+    """Masses log-uniform in [1e8, 1e13], a few cut to zero (skipped upstream, map_mass.c:388-390);
+    positions anywhere in the box, including its faces; standard-normal deviates."""
+    rng = np.random.default_rng(seed)
+    masses = (10.0 ** rng.uniform(8.0, 13.0, n_halos)).astype(np.float32)
+    masses[rng.random(n_halos) < cut_fraction] = 0.0
+    coords = (rng.random((n_halos, 3)) * [box_len, box_len, box_len_z or box_len]).astype(np.float32)
+    coords[:4] = [[0, 0, 0], [box_len, 0, 0], [0, box_len * 0.999999, 0], [0.25, 0.5, 0.75]]
+    return dict(masses=masses, coords=coords,
+                star_rng=rng.standard_normal(n_halos).astype(np.float32),
+                sfr_rng=rng.standard_normal(n_halos).astype(np.float32),
+                xray_rng=rng.standard_normal(n_halos).astype(np.float32))
+
+
+def halo_consts(z=8.0, **kw):
+    """Values of the reference's default astrophysics (sigmas already in base e)."""
+    c = dict(redshift=z, fstar_10=10 ** -1.3, alpha_star=0.5, sigma_star=0.25 * np.log(10.0),
+             alpha_upper=-0.61, pivot_upper=10 ** 11.447, fstar_7=10 ** -2.0, alpha_star_mini=0.5,
+             acg_thresh=5.5e7, baryon_ratio=0.049 / 0.31, t_h=2.0e16, t_star=0.5,
+             sigma_sfr_lim=0.19 * np.log(10.0), sigma_sfr_idx=-0.12, l_x=10 ** 2.5, l_x_mini=10 ** 2.6,
+             sigma_xray=0.5 * np.log(10.0), fesc_10=0.1, fesc_7=0.05, alpha_esc=-0.3, pop2_ion=5000.0,
+             pop3_ion=44021.0, mturn_a_nofb=10 ** 8.7, mturn_m_nofb=2.0e6, scaling_median=0,
+             upper_stellar_turnover=1, use_mini_halos=0, use_xray=1)
+    c.update(kw)
+    c["upper_pivot_ratio"] = ((c["pivot_upper"] / 1e10) ** c["alpha_star"] +
+                              (c["pivot_upper"] / 1e10) ** c["alpha_upper"])
+    return S.HaloConsts(**c)
+
+
+def attach(spec, cat, consts, skip_integral=False):
+    """Point a HaloBoxSpec at a catalogue dict (random_catalogue) and its constants."""
+    hc = S.halo_catalog(cat["masses"], cat["coords"], cat["star_rng"], cat["sfr_rng"], cat["xray_rng"])
+    spec.halos = C.pointer(hc)
+    spec.halo_consts = C.pointer(consts)
+    spec.skip_integral = int(skip_integral)
+    spec._keep = tuple(getattr(spec, "_keep", ())) + (hc, consts)
+    return spec

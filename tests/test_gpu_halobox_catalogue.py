@@ -1,0 +1,182 @@
+"""GPU: the halo-catalogue branch of ComputeHaloBox (sum_halos_onto_grid, HaloBox.c:518-560;
+move_halo_galprops, map_mass.c:346-476) on the MI355X against the oracle, which deposits in
+catalogue order into float grids like upstream with N_THREADS = 1 (the device accumulates in double
+and narrows once: tolerances of tests/test_gpu_halobox.py), and through the entry point with
+SOURCE_MODEL = CHMF-SAMPLER."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import halobox_mini_helpers as HM
+from halo_catalogue_helpers import attach, halo_consts, random_catalogue
+from test_gpu_halobox import api, compare  # noqa: F401  (fixture)
+from test_oracle_halobox import halobox_spec, make_tables, random_ics, with_xray
+
+pytestmark = pytest.mark.gpu
+S = importlib.import_module("21cmfast_amd.structs")
+
+
+@pytest.mark.parametrize("n,N,hires,n_halos,skip,device,kw", [
+    (16, 32, False, 5000, False, False, {}),
+    (32, 64, True, 200000, False, True, {}),
+    (24, 72, True, 30000, True, False, {}),
+    (40, 40, False, 100000, True, True, dict(scaling_median=1)),
+    (33, 66, False, 40000, False, False, dict(upper_stellar_turnover=0, sigma_sfr_lim=0.0)),
+])
+def test_catalogue_matches_oracle(api, oracle, n, N, hires, n_halos, skip, device, kw):
+    tables = make_tables()
+
+    def spec():
+        s = with_xray(halobox_spec(n, N, hires, tables), tables)
+        return attach(s, cat, halo_consts(**kw), skip_integral=skip)
+
+    cat = random_catalogue(n_halos, 1.5 * n, seed=n + n_halos)
+    ics = random_ics(n, N, hires, seed=n + N, vscale=4.0)
+    ref = oracle.halobox_grids(spec(), ics, with_whalo=True, with_xray=True)
+    if device:
+        import torch
+
+        ics = {k: torch.from_numpy(v).cuda() for k, v in ics.items()}
+    got = api.halobox_grids(spec(), ics, with_whalo=True, with_xray=True)
+    compare(got, ref)
+    assert all(ref[k].max() > 0 for k in ref)
+    if skip:  # whalo_sfr comes from the halos, not from n_ion / t_h / t_star
+        assert not np.allclose(ref["whalo_sfr"], ref["n_ion"] * 0.37, rtol=1e-3)
+
+
+def test_device_resident_catalogue(api, oracle):
+    """Catalogue arrays already in HBM are used in place."""
+    import torch
+
+    n = 24
+    tables = make_tables()
+    cat = random_catalogue(50000, 1.5 * n, seed=3)
+    ics = random_ics(n, n, False, seed=3, vscale=2.0)
+    ref = oracle.halobox_grids(attach(halobox_spec(n, n, False, tables), cat, halo_consts(use_xray=0)), ics)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in cat.items()}
+    hc = S.HaloCatalogStruct(n_halos=50000, buffer_size=50000,
+                             **{f: C.cast(dev[k].data_ptr(), S.c_float_p) for f, k in (
+                                 ("halo_masses", "masses"), ("halo_coords", "coords"), ("star_rng", "star_rng"),
+                                 ("sfr_rng", "sfr_rng"), ("xray_rng", "xray_rng"))})
+    spec = halobox_spec(n, n, False, tables)
+    consts = halo_consts(use_xray=0)
+    spec.halos, spec.halo_consts = C.pointer(hc), C.pointer(consts)
+    compare(api.halobox_grids(spec, ics), ref)
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_catalogue_with_mini_halos(api, oracle, skip):
+    """USE_MINI_HALOS: turnover masses CIC-read at the displaced halo, both populations in n_ion,
+    the molecularly cooled star formation in halo_sfr_mini."""
+    n = 24
+    cat = random_catalogue(60000, 1.5 * n, seed=8)
+    cat["masses"] = (cat["masses"] * np.where(np.arange(60000) % 2, 1e-3, 1.0)).astype(np.float32)  # 1e5..1e13
+    ics = random_ics(n, n, False, seed=n, vscale=5.0)
+    consts = dict(use_mini_halos=1)
+    ref = oracle.halobox_grids(attach(HM.mini_spec(n), cat, halo_consts(**consts), skip_integral=skip), ics,
+                               with_whalo=True, with_xray=True)
+    got = api.halobox_grids(attach(HM.mini_spec(n), cat, halo_consts(**consts), skip_integral=skip), ics,
+                            with_whalo=True, with_xray=True)
+    assert "halo_sfr_mini" in got and ref["halo_sfr_mini"].max() > 0
+    compare(got, ref)
+    # the molecular population matters: without it n_ion is lower
+    no_mini = oracle.halobox_grids(attach(halobox_spec(n, n, False, make_tables()), cat, halo_consts(),
+                                          skip_integral=True), ics)
+    if skip:
+        assert ref["n_ion"].sum(dtype=np.float64) > 1.0001 * no_mini["n_ion"].sum(dtype=np.float64)
+
+
+def test_missing_catalogue_arrays_are_refused(api):
+    n = 16
+    spec = halobox_spec(n, n, False, make_tables())
+    cat = random_catalogue(100, 1.5 * n, seed=1)
+    attach(spec, cat, halo_consts())
+    spec.halos.contents.sfr_rng = None
+    with pytest.raises(Exception, match="catalogue"):
+        api.halobox_grids(spec, random_ics(n, n, False, seed=1))
+
+
+@pytest.mark.parametrize("sampler_min_mass", [1e8, 1e6])
+def test_entry_point_with_a_catalogue(gpu_lib, oracle, tmp_path, sampler_min_mass):
+    """ComputeHaloBox, SOURCE_MODEL = CHMF-SAMPLER: the catalogue's halos with the library's own
+    scaling constants plus the integral below SAMPLER_MIN_MASS (1e6 < M_min: halos only), against
+    the oracle fed with constants and tables restated here."""
+    from test_gpu_abi import Session, fptr
+    from test_host_scalars import ScalingConsts
+
+    lib = gpu_lib
+    n, N = 32, 64
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=N, SOURCE_MODEL=4, SAMPLER_MIN_MASS=sampler_min_mass,
+                  USE_TS_FLUCT=True, RECOMB_MODEL=2, M_TURN=10 ** 8.7)
+    z = 8.0
+    ics = random_ics(n, N, False, seed=9)
+    ics["lowres_density"] = (ics["lowres_density"] * 0.5).astype(np.float32)
+    cat = random_catalogue(80000, ses.so.BOX_LEN, seed=12)
+    cat["masses"] = np.where(cat["masses"] > 0, np.maximum(cat["masses"], sampler_min_mass), 0).astype(np.float32)
+    hc = S.halo_catalog(cat["masses"], cat["coords"], cat["star_rng"], cat["sfr_rng"], cat["xray_rng"])
+    keys = ("n_ion", "halo_sfr", "halo_xray", "whalo_sfr")
+    out = {k: np.zeros((n, n, n), np.float32) for k in keys}
+    hb = S.HaloBoxStruct(**{k: fptr(v) for k, v in out.items()})
+    icss = S.InitialConditionsStruct(**{k: fptr(v) for k, v in ics.items()})
+    lib.ComputeHaloBox.argtypes = [C.c_double] + [C.c_void_p] * 5
+    assert lib.ComputeHaloBox(z, C.byref(icss), None, None, None, C.byref(hb)) == 3  # no catalogue
+    st = lib.ComputeHaloBox(z, C.byref(icss), C.byref(hc), None, None, C.byref(hb))
+    assert st == 0, lib.c21cm_last_error()
+
+    f64 = C.c_double
+    lib.c21_set_scaling_constants.restype = C.c_int
+    lib.c21_set_scaling_constants.argtypes = [f64, C.POINTER(ScalingConsts)]
+    sc = ScalingConsts()
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    ap = ses.ap
+    consts = halo_consts(
+        z, fstar_10=sc.fstar_10, alpha_star=sc.alpha_star, sigma_star=ap.SIGMA_STAR,
+        alpha_upper=ap.UPPER_STELLAR_TURNOVER_INDEX, pivot_upper=ap.UPPER_STELLAR_TURNOVER_MASS,
+        fstar_7=sc.fstar_7, alpha_star_mini=sc.alpha_star_mini, acg_thresh=sc.acg_thresh,
+        baryon_ratio=ses.cp.OMb / ses.cp.OMm, t_h=sc.t_h, t_star=sc.t_star, sigma_sfr_lim=ap.SIGMA_SFR_LIM,
+        sigma_sfr_idx=ap.SIGMA_SFR_INDEX, l_x=sc.l_x, l_x_mini=sc.l_x_mini, sigma_xray=ap.SIGMA_LX,
+        fesc_10=sc.fesc_10, fesc_7=sc.fesc_7, alpha_esc=sc.alpha_esc, pop2_ion=sc.pop2_ion,
+        pop3_ion=sc.pop3_ion, mturn_a_nofb=sc.mturn_a_nofb, mturn_m_nofb=sc.mturn_m_nofb,
+        scaling_median=0, upper_stellar_turnover=int(ses.ao.USE_UPPER_STELLAR_TURNOVER), use_xray=1)
+    D = lib.dicke(z)
+    M_min = lib.c21_minimum_source_mass(z)
+    skip = not (M_min < sampler_min_mass)
+    assert skip == (sampler_min_mass < 1e7)  # both branches of HaloBox.c:635 are covered
+    spec = S.HaloBoxSpec(dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=ses.so.BOX_LEN,
+                         box_len_z=ses.so.BOX_LEN, perturb_on_high_res=0, lpt2=1, growth_factor=D,
+                         init_growth_factor=lib.dicke(ses.so.INITIAL_REDSHIFT))
+    keep = []
+    if not skip:
+        lib.c21_Nion_Conditional_table.restype = C.c_int
+        lib.c21_Nion_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int, f64,
+                                                               C.POINTER(C.c_float), C.c_int]
+        lib.c21_Xray_Conditional_table.restype = C.c_int
+        lib.c21_Xray_Conditional_table.argtypes = [f64] * 8 + [C.POINTER(ScalingConsts), C.c_int,
+                                                               C.POINTER(C.c_float), C.c_int]
+        lib.sigma_z0.restype = f64
+        lib.sigma_z0.argtypes = [f64]
+        sc_sfrd = ScalingConsts.from_buffer_copy(sc)
+        sc_sfrd.fesc_10, sc_sfrd.fesc_7, sc_sfrd.alpha_esc, sc_sfrd.Mlim_Fesc = 1.0, 1.0, 0.0, 0.0
+        d = ics["lowres_density"].astype(np.float64) * D
+        dmin, dmax = min(0.0, d.min()) * 1.001, max(0.0, d.max()) * 1.001
+        M_cell = lib.c21_rhocrit() * ses.cp.OMm * ses.so.BOX_LEN**3 / n**3
+        tabs = [(C.c_float * S.NDELTA_TABLE)() for _ in range(3)]
+        lims = (D, np.log(M_min), np.log(float(np.float32(sampler_min_mass))), np.log(M_cell),
+                lib.sigma_z0(M_cell), dmin, dmax, sc.mturn_a_nofb)
+        assert lib.c21_Nion_Conditional_table(*lims, C.byref(sc), 1, -40.0, tabs[0], S.NDELTA_TABLE) == 0
+        assert lib.c21_Nion_Conditional_table(*lims, C.byref(sc_sfrd), 1, -50.0, tabs[1], S.NDELTA_TABLE) == 0
+        assert lib.c21_Xray_Conditional_table(*lims, C.byref(sc), 1, tabs[2], S.NDELTA_TABLE) == 0
+        pre_stars = lib.c21_rhocrit() * ses.cp.OMb * sc.fstar_10
+        spec.update(tab_min=dmin, tab_width=(dmax - dmin) / (S.NDELTA_TABLE - 1.0),
+                    ln_nion_table=C.cast(tabs[0], S.c_float_p), ln_sfrd_table=C.cast(tabs[1], S.c_float_p),
+                    ln_xray_table=C.cast(tabs[2], S.c_float_p),
+                    prefactor_nion=pre_stars * sc.fesc_10 * sc.pop2_ion,
+                    prefactor_sfr=pre_stars / sc.t_star / sc.t_h, prefactor_wsfr=1 / sc.t_h / sc.t_star,
+                    prefactor_xray=lib.c21_rhocrit() * ses.cp.OMm)
+        keep.append(tabs)
+    attach(spec, cat, consts, skip_integral=skip)
+    ref = oracle.halobox_grids(spec, ics, with_whalo=True, with_xray=True)
+    compare(out, ref)
+    assert all(ref[k].max() > 0 for k in keys)
