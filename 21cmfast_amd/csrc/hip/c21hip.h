@@ -248,9 +248,11 @@ int c21hip_halobox_scatter_mini(const float *src_density, const int dim[3],
                                 const float *tab_nion_m, const float *tab_sfrd_m,
                                 const float *tab_xray, const double *ranges,
                                 const double *prefactors, void *stream);
-/* move_halo_galprops (map_mass.c:346-476): one thread per halo of the catalogue (device arrays),
- * fp64 atomics into the accumulation grids, values per unit output-cell volume; out_sfr_mini /
- * out_xray / out_wsfr and (without mini-halos) the turnover grids may be NULL */
+/* move_halo_galprops (map_mass.c:346-476) for a catalogue in device arrays: fp64 accumulation
+ * grids, values per unit output-cell volume; out_sfr_mini / out_xray / out_wsfr and (without
+ * mini-halos) the turnover grids may be NULL.  scratch: c21hip_halo_deposit_scratch_ints() ints
+ * for the binned, LDS-tiled path (NULL or C21CM_HALO_DEPOSIT=direct: global atomics only). */
+size_t c21hip_halo_deposit_scratch_ints(unsigned long long n_halos, const int out_dim[3]);
 struct c21cm_halo_consts;
 int c21hip_halo_deposit(const struct c21cm_halo_consts *consts, unsigned long long n_halos,
                         const float *masses, const float *coords, const float *star_rng,
@@ -258,7 +260,8 @@ int c21hip_halo_deposit(const struct c21cm_halo_consts *consts, unsigned long lo
                         const float *const vel2[3], const int vel_dim[3], const int out_dim[3],
                         double box_len, double box_len_z, double growth, double init_growth, int lpt2,
                         const float *mturn_a, const float *mturn_m, double *out_nion, double *out_sfr,
-                        double *out_sfr_mini, double *out_xray, double *out_wsfr, void *stream);
+                        double *out_sfr_mini, double *out_xray, double *out_wsfr, int *scratch,
+                        void *stream);
 int c21hip_narrow(const double *in, float *out, float *out_scaled, double scale, size_t n,
                   void *stream);
 /* {min, max} of n floats into out2 (device); partials: 2 * 2048 doubles */

@@ -886,6 +886,9 @@ struct HaloDepositParams {
     double vdf, vdf2;        // D - D_i and the 2LPT analogue: Mpc per velocity unit (:368-370)
     double box_size[3];      // pos * out_dim / box_size (:409-411)
     double cell_vol_inv;
+    // logarithms of constants of the scaling relations, taken once on the host
+    double ln_pivot_upper, ln_tstar_th, ln_s_per_yr, ln_m0_norm;
+    double ln_z_norm;  // ln(1.23 * 10^(-0.056 z + 0.064) / 0.05): metallicity over the L_X pivot
     int lpt2;
 };
 
@@ -897,131 +900,321 @@ __device__ __forceinline__ double cic_read(const float *__restrict__ box, const 
     return sum;
 }
 
-// scaling_relations.c:277-283 through get_lx_on_sfr :315-325
-__device__ __forceinline__ double halo_lx_on_sfr(double metallicity, double lx_constant, int upper) {
-    if (!upper) return lx_constant;
-    const double hi_z_index = -0.64, lo_z_index = 0., z_pivot = 0.05;
-    return lx_constant *
-           (1. / (pow(metallicity / z_pivot, -lo_z_index) + pow(metallicity / z_pivot, -hi_z_index)));
+struct HaloArrays {
+    const float *masses, *coords, *star_rng, *sfr_rng, *xray_rng;
+    const float *vx, *vy, *vz, *v2x, *v2y, *v2z;
+    const float *mturn_a, *mturn_m;
+};
+struct HaloOutputs {
+    double *g[5];  // n_ion, SFR, SFR_mini, L_X, f_esc-weighted SFR; NULL = not wanted
+};
+
+// One halo: displaced position (ipos_out: its unwrapped output cell; idx / w: the eight cells and
+// CIC weights) and the five values per unit cell volume.  false: the halo was cut (mass 0).
+__device__ __forceinline__ bool halo_eval(const HaloDepositParams &h, const HaloArrays &A,
+                                          unsigned long long t, int ipos_out[3], size_t idx[8],
+                                          double w[8], double val[5]) {
+    const c21cm_halo_consts &c = h.c;
+    const double hmass = (double)A.masses[t];
+    if (hmass == 0.) return false;  // halos cut from the catalogue (:388-390)
+    double pos[3] = {(double)A.coords[3 * t], (double)A.coords[3 * t + 1], (double)A.coords[3 * t + 2]};
+    int ip[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        ip[a] = wrap_idx((int)(pos[a] * h.cell_size_inv_v + 0.5), h.vel_dim[a]);
+    const size_t vi =
+        (size_t)ip[2] + (size_t)h.vel_dim[2] * ((size_t)ip[1] + (size_t)h.vel_dim[1] * ip[0]);
+    const float v[3] = {A.vx[vi], A.vy[vi], A.vz[vi]};
+    float v2[3] = {0.f, 0.f, 0.f};
+    if (h.lpt2) v2[0] = A.v2x[vi], v2[1] = A.v2y[vi], v2[2] = A.v2z[vi];
+    {
+        int i0[3], i1[3];
+        double d[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            pos[a] += (double)v[a] * h.vdf;
+            if (h.lpt2) pos[a] -= (double)v2[a] * h.vdf2;
+            pos[a] = pos[a] * h.out_dim[a] / h.box_size[a];
+            const int ipos = (int)floor(pos[a]);
+            ipos_out[a] = ipos;
+            d[a] = pos[a] - (double)ipos;
+            i0[a] = wrap_idx(ipos, h.out_dim[a]);
+            i1[a] = wrap_idx(ipos + 1, h.out_dim[a]);
+        }
+        const size_t sy = (size_t)h.out_dim[2], sx = (size_t)h.out_dim[1] * h.out_dim[2];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            idx[k] = (size_t)((k & 1) ? i1[0] : i0[0]) * sx + (size_t)((k & 2) ? i1[1] : i0[1]) * sy +
+                     (size_t)((k & 4) ? i1[2] : i0[2]);
+            w[k] = ((k & 1) ? d[0] : 1. - d[0]) * ((k & 2) ? d[1] : 1. - d[1]) *
+                   ((k & 4) ? d[2] : 1. - d[2]);
+        }
+    }
+    double M_turn_a = c.mturn_a_nofb, M_turn_m = c.mturn_m_nofb;
+    if (c.use_mini_halos) {  // the turnover grids, CIC-read at the halo (:413-416)
+        M_turn_a = pow(10., cic_read(A.mturn_a, idx, w));
+        M_turn_m = pow(10., cic_read(A.mturn_m, idx, w));
+    }
+    // The power laws below are evaluated as exp(index * ln x) on shared logarithms (one log of
+    // the halo mass, one of the stellar mass, one of the SFR) instead of one pow() each: the
+    // kernel is bound by its fp64 transcendentals, and the rounding difference (1e-14) is far
+    // below the float grids' resolution.
+    const double lnM = log(hmass), l10 = lnM - 10. * M_LN10;
+    // get_halo_stellarmass (scaling_relations.c:331-400)
+    const double adj_star = c.scaling_median ? 0. : c.sigma_star * c.sigma_star / 2.;
+    const double s_rng = (double)A.star_rng[t];
+    double f_sample;
+    if (c.upper_stellar_turnover && c.alpha_star > c.alpha_upper) {
+        const double lp = lnM - h.ln_pivot_upper;
+        f_sample = c.fstar_10 * (c.upper_pivot_ratio / (exp(-c.alpha_star * lp) + exp(-c.alpha_upper * lp))) *
+                   exp(-M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
+    } else {
+        f_sample = c.fstar_10 * exp(c.alpha_star * l10 - M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
+    }
+    if (f_sample > 1.) f_sample = 1.;
+    const double stars = f_sample * hmass * c.baryon_ratio;
+    double stars_mini = 0.;
+    if (c.use_mini_halos) {
+        double f_mini = c.fstar_7 * exp(c.alpha_star_mini * (lnM - 7. * M_LN10) - M_turn_m / hmass -
+                                        hmass / c.acg_thresh + s_rng * c.sigma_star - adj_star);
+        if (f_mini > 1.) f_mini = 1.;
+        stars_mini = f_mini * hmass * c.baryon_ratio;
+    }
+    const double stars_t = stars + stars_mini;
+    const double ln_stars = log(stars_t);  // -inf for an empty halo: handled where it is used
+    // get_halo_sfr (:402-444): the scatter widens towards low stellar masses
+    double sigma_sfr = 0.;
+    if (c.sigma_sfr_lim > 0.) {
+        sigma_sfr = c.sigma_sfr_idx * ((ln_stars - 10. * M_LN10) * M_LOG10E) + c.sigma_sfr_lim;
+        if (!(sigma_sfr >= c.sigma_sfr_lim)) sigma_sfr = c.sigma_sfr_lim;
+    }
+    const double adj_sfr = c.scaling_median ? 0. : sigma_sfr * sigma_sfr / 2.;
+    const double ln_sfr_fac = (double)A.sfr_rng[t] * sigma_sfr - adj_sfr;
+    const double sfr_fac = exp(ln_sfr_fac);
+    const double sfr = stars / (c.t_star * c.t_h) * sfr_fac;
+    const double sfr_mini = c.use_mini_halos ? stars_mini / (c.t_star * c.t_h) * sfr_fac : 0.;
+    // get_halo_metallicity, get_halo_xray (:446-500)
+    double xray = 0.;
+    if (c.use_xray) {
+        const double sfr_t = sfr + sfr_mini;
+        double ln_stellar_term = 0.;
+        if (stars_t > 0 && sfr_t > 0.) {
+            // M0 = 1.28825e10 (SFR s_per_yr)^0.56;  (1 + (M*/M0)^-2.1)^-0.148
+            const double ln_sfr_yr = ln_stars - h.ln_tstar_th + ln_sfr_fac + h.ln_s_per_yr;
+            const double ln_ratio = ln_stars - (h.ln_m0_norm + 0.56 * ln_sfr_yr);
+            ln_stellar_term = -0.148 * log1p(exp(-2.1 * ln_ratio));
+        }
+        double lx_a = c.l_x, lx_m = c.l_x_mini;
+        if (c.upper_stellar_turnover) {  // double power law in Z, flat below Z = 0.05 (:277-283)
+            const double dpl = 1. / (1. + exp(0.64 * (h.ln_z_norm + ln_stellar_term)));
+            lx_a *= dpl, lx_m *= dpl;
+        }
+        double mu_x = lx_a * (sfr * kSecPerYr);
+        if (c.use_mini_halos) mu_x += lx_m * (sfr_mini * kSecPerYr);
+        const double adj_x = c.scaling_median ? 0. : c.sigma_xray * c.sigma_xray / 2.;
+        xray = mu_x * exp((double)A.xray_rng[t] * c.sigma_xray - adj_x);
+    }
+    const double fesc = fmin(c.fesc_10 * exp(c.alpha_esc * l10), 1.);
+    const double fesc_mini = c.use_mini_halos ? fmin(c.fesc_7 * exp(c.alpha_esc * (lnM - 7. * M_LN10)), 1.) : 0.;
+    const double n_ion = stars * c.pop2_ion * fesc + stars_mini * c.pop3_ion * fesc_mini;
+    const double wsfr = sfr * c.pop2_ion * fesc + sfr_mini * c.pop3_ion * fesc_mini;
+    val[0] = n_ion * h.cell_vol_inv;
+    val[1] = sfr * h.cell_vol_inv;
+    val[2] = sfr_mini * h.cell_vol_inv;
+    val[3] = xray * h.cell_vol_inv;
+    val[4] = wsfr * h.cell_vol_inv;
+    return true;
 }
 
+// direct path: eight global fp64 atomics per value and halo (~35 G atomics/s on the MI355X)
 __global__ void __launch_bounds__(kBlock)
-halo_deposit_kernel(HaloDepositParams h, const float *__restrict__ masses,
-                    const float *__restrict__ coords, const float *__restrict__ star_rng,
-                    const float *__restrict__ sfr_rng, const float *__restrict__ xray_rng,
-                    const float *__restrict__ vx, const float *__restrict__ vy,
-                    const float *__restrict__ vz, const float *__restrict__ v2x,
-                    const float *__restrict__ v2y, const float *__restrict__ v2z,
-                    const float *__restrict__ mturn_a, const float *__restrict__ mturn_m,
-                    double *__restrict__ out_nion, double *__restrict__ out_sfr,
-                    double *__restrict__ out_sfr_mini, double *__restrict__ out_xray,
-                    double *__restrict__ out_wsfr) {
-    const c21cm_halo_consts &c = h.c;
+halo_deposit_kernel(HaloDepositParams h, HaloArrays A, HaloOutputs O) {
     for (unsigned long long t = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; t < h.n_halos;
          t += (unsigned long long)gridDim.x * kBlock) {
-        const double hmass = (double)masses[t];
-        if (hmass == 0.) continue;  // halos cut from the catalogue (:388-390)
-        double pos[3] = {(double)coords[3 * t], (double)coords[3 * t + 1], (double)coords[3 * t + 2]};
-        int ip[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-            ip[a] = wrap_idx((int)(pos[a] * h.cell_size_inv_v + 0.5), h.vel_dim[a]);
-        const size_t vi =
-            (size_t)ip[2] + (size_t)h.vel_dim[2] * ((size_t)ip[1] + (size_t)h.vel_dim[1] * ip[0]);
-        const float v[3] = {vx[vi], vy[vi], vz[vi]};
-        float v2[3] = {0.f, 0.f, 0.f};
-        if (h.lpt2) v2[0] = v2x[vi], v2[1] = v2y[vi], v2[2] = v2z[vi];
+        int ipos[3];
         size_t idx[8];
-        double w[8];
-        {
-            int i0[3], i1[3];
-            double d[3];
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                pos[a] += (double)v[a] * h.vdf;
-                if (h.lpt2) pos[a] -= (double)v2[a] * h.vdf2;
-                pos[a] = pos[a] * h.out_dim[a] / h.box_size[a];
-                const int ipos = (int)floor(pos[a]);
-                d[a] = pos[a] - (double)ipos;
-                i0[a] = wrap_idx(ipos, h.out_dim[a]);
-                i1[a] = wrap_idx(ipos + 1, h.out_dim[a]);
-            }
-            const size_t sy = (size_t)h.out_dim[2], sx = (size_t)h.out_dim[1] * h.out_dim[2];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                idx[k] = (size_t)((k & 1) ? i1[0] : i0[0]) * sx + (size_t)((k & 2) ? i1[1] : i0[1]) * sy +
-                         (size_t)((k & 4) ? i1[2] : i0[2]);
-                w[k] = ((k & 1) ? d[0] : 1. - d[0]) * ((k & 2) ? d[1] : 1. - d[1]) *
-                       ((k & 4) ? d[2] : 1. - d[2]);
-            }
-        }
-        double M_turn_a = c.mturn_a_nofb, M_turn_m = c.mturn_m_nofb;
-        if (c.use_mini_halos) {  // the turnover grids, CIC-read at the halo (:413-416)
-            M_turn_a = pow(10., cic_read(mturn_a, idx, w));
-            M_turn_m = pow(10., cic_read(mturn_m, idx, w));
-        }
-        // get_halo_stellarmass (scaling_relations.c:331-400)
-        const double adj_star = c.scaling_median ? 0. : c.sigma_star * c.sigma_star / 2.;
-        double mu_fstar;
-        if (c.upper_stellar_turnover && c.alpha_star > c.alpha_upper)
-            mu_fstar = c.fstar_10 * (c.upper_pivot_ratio / (pow(hmass / c.pivot_upper, -c.alpha_star) +
-                                                            pow(hmass / c.pivot_upper, -c.alpha_upper)));
-        else
-            mu_fstar = c.fstar_10 * pow(hmass / 1e10, c.alpha_star);
-        const double s_rng = (double)star_rng[t];
-        double f_sample = mu_fstar * exp(-M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
-        if (f_sample > 1.) f_sample = 1.;
-        const double stars = f_sample * hmass * c.baryon_ratio;
-        double stars_mini = 0.;
-        if (c.use_mini_halos) {
-            const double mu_mini = c.fstar_7 * pow(hmass / 1e7, c.alpha_star_mini);
-            double f_mini = mu_mini * exp(-M_turn_m / hmass - hmass / c.acg_thresh +
-                                          s_rng * c.sigma_star - adj_star);
-            if (f_mini > 1.) f_mini = 1.;
-            stars_mini = f_mini * hmass * c.baryon_ratio;
-        }
-        // get_halo_sfr (:402-444): the scatter widens towards low stellar masses
-        double sigma_sfr = 0.;
-        if (c.sigma_sfr_lim > 0.) {
-            sigma_sfr = c.sigma_sfr_idx * log10((stars + stars_mini) / 1e10) + c.sigma_sfr_lim;
-            if (sigma_sfr < c.sigma_sfr_lim) sigma_sfr = c.sigma_sfr_lim;
-        }
-        const double adj_sfr = c.scaling_median ? 0. : sigma_sfr * sigma_sfr / 2.;
-        const double sfr_fac = exp((double)sfr_rng[t] * sigma_sfr - adj_sfr);
-        const double sfr = stars / (c.t_star * c.t_h) * sfr_fac;
-        const double sfr_mini = c.use_mini_halos ? stars_mini / (c.t_star * c.t_h) * sfr_fac : 0.;
-        // get_halo_metallicity, get_halo_xray (:446-500)
-        double xray = 0.;
-        if (c.use_xray) {
-            const double sfr_t = sfr + sfr_mini, stars_t = stars + stars_mini;
-            double stellar_term = 1.;
-            if (stars_t > 0 && sfr_t > 0.) {
-                const double M0 = 1.28825e10 * pow(sfr_t * kSecPerYr, 0.56);
-                stellar_term = pow(1 + pow(stars_t / M0, -2.1), -0.148);
-            }
-            const double metallicity = 1.23 * stellar_term * pow(10., -0.056 * c.redshift + 0.064);
-            double mu_x = halo_lx_on_sfr(metallicity, c.l_x, c.upper_stellar_turnover) * (sfr * kSecPerYr);
-            if (c.use_mini_halos)
-                mu_x += halo_lx_on_sfr(metallicity, c.l_x_mini, c.upper_stellar_turnover) *
-                        (sfr_mini * kSecPerYr);
-            const double adj_x = c.scaling_median ? 0. : c.sigma_xray * c.sigma_xray / 2.;
-            xray = mu_x * exp((double)xray_rng[t] * c.sigma_xray - adj_x);
-        }
-        const double fesc = fmin(c.fesc_10 * pow(hmass / 1e10, c.alpha_esc), 1.);
-        const double fesc_mini = c.use_mini_halos ? fmin(c.fesc_7 * pow(hmass / 1e7, c.alpha_esc), 1.) : 0.;
-        const double n_ion = stars * c.pop2_ion * fesc + stars_mini * c.pop3_ion * fesc_mini;
-        const double wsfr = sfr * c.pop2_ion * fesc + sfr_mini * c.pop3_ion * fesc_mini;
-        const double val[5] = {n_ion, sfr, sfr_mini, xray, wsfr};
-        double *outs[5] = {out_nion, out_sfr, out_sfr_mini, out_xray, out_wsfr};
+        double w[8], val[5];
+        if (!halo_eval(h, A, t, ipos, idx, w, val)) continue;
         for (int g = 0; g < 5; g++) {
-            if (!outs[g]) continue;
-            const double vg = val[g] * h.cell_vol_inv;
+            if (!O.g[g]) continue;
 #pragma unroll
-            for (int k = 0; k < 8; k++) unsafeAtomicAdd(outs[g] + idx[k], vg * w[k]);
+            for (int k = 0; k < 8; k++) unsafeAtomicAdd(O.g[g] + idx[k], val[g] * w[k]);
         }
     }
 }
+
+// ---- LDS-tiled path -------------------------------------------------------------------------
+// The halos are binned by the brick of kHaloBrick^3 OUTPUT cells their catalogue position lies in
+// (count, scan, fill: two int atomics per halo, aggregated over runs of equal bricks within a
+// wavefront, so that a catalogue in cell order costs one atomic per run); a workgroup then owns a
+// brick, deposits its halos into fp64 tiles in LDS (brick + kHaloMargin cells of margin for the
+// displacement) and flushes each touched cell with one global atomic per value.  Halos displaced
+// beyond the margin take the direct path, so the result does not depend on the geometry.
+constexpr int kHaloBrick = 8, kHaloMargin = 2, kHaloTile = kHaloBrick + 2 * kHaloMargin + 1;
+constexpr int kHaloTileCells = kHaloTile * kHaloTile * kHaloTile;
+
+struct HaloBrickGeom {
+    int nb[3];
+    int n_bricks;
+};
+
+// brick of a halo from its catalogue position (-1: cut halo); ucell: the wrapped output cell,
+// ufloor: the unwrapped one
+__device__ __forceinline__ int halo_brick(const HaloDepositParams &h, const HaloBrickGeom &g,
+                                          const HaloArrays &A, unsigned long long t, int ucell[3],
+                                          int ufloor[3]) {
+    if (A.masses[t] == 0.f) return -1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double pos = (double)A.coords[3 * t + a] * h.out_dim[a] / h.box_size[a];
+        ufloor[a] = (int)floor(pos);
+        ucell[a] = wrap_idx(ufloor[a], h.out_dim[a]);
+    }
+    return ((ucell[0] / kHaloBrick) * g.nb[1] + ucell[1] / kHaloBrick) * g.nb[2] + ucell[2] / kHaloBrick;
+}
+
+// atomicAdd(&counters[key], 1) for every lane with key >= 0, one atomic per run of equal keys in
+// the wavefront; returns the lane's slot.  All 64 lanes must call it.
+__device__ __forceinline__ int wave_run_increment(int *counters, int key) {
+    const int lane = (int)__lane_id();
+    const int prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+    const int start = 63 - __clzll((long long)(heads & upto));
+    const unsigned long long above = heads & ~upto;
+    const int end = above ? __ffsll((long long)above) - 1 : 64;
+    int base = 0;
+    if (head && key >= 0) base = atomicAdd(&counters[key], end - start);
+    base = __shfl(base, start);
+    return base + (lane - start);
+}
+
+__global__ void __launch_bounds__(kBlock)
+halo_brick_count_kernel(HaloDepositParams h, HaloBrickGeom g, HaloArrays A, int *counts) {
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < h.n_halos;
+         base += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long t = base + threadIdx.x;
+        int uc[3], uf[3];
+        const int key = t < h.n_halos ? halo_brick(h, g, A, t, uc, uf) : -1;
+        (void)wave_run_increment(counts, key);
+    }
+}
+
+// exclusive scan of n counts into offsets[n + 1] and a working copy cursor[n]; one workgroup
+__global__ void __launch_bounds__(1024)
+halo_brick_scan_kernel(const int *__restrict__ counts, int *__restrict__ offsets,
+                       int *__restrict__ cursor, int n) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, chunk = (n + 1023) / 1024;
+    const int lo = tid * chunk < n ? tid * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += counts[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = lo; i < hi; i++) {
+        offsets[i] = run;
+        cursor[i] = run;
+        run += counts[i];
+    }
+    if (tid == 1023) offsets[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(kBlock)
+halo_brick_fill_kernel(HaloDepositParams h, HaloBrickGeom g, HaloArrays A, int *cursor,
+                       unsigned int *__restrict__ order) {
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < h.n_halos;
+         base += (unsigned long long)gridDim.x * kBlock) {
+        const unsigned long long t = base + threadIdx.x;
+        int uc[3], uf[3];
+        const int key = t < h.n_halos ? halo_brick(h, g, A, t, uc, uf) : -1;
+        const int slot = wave_run_increment(cursor, key);
+        if (key >= 0) order[slot] = (unsigned int)t;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+halo_deposit_tiled_kernel(HaloDepositParams h, HaloBrickGeom g, HaloArrays A, HaloOutputs O,
+                          const int *__restrict__ offsets, const unsigned int *__restrict__ order) {
+    extern __shared__ double tile[];  // [nv][kHaloTileCells]
+    int slot_of[5], nv = 0;
+#pragma unroll
+    for (int v = 0; v < 5; v++) slot_of[v] = O.g[v] ? nv++ : -1;
+    const size_t sy = (size_t)h.out_dim[2], sx = (size_t)h.out_dim[1] * h.out_dim[2];
+    for (int brick = blockIdx.x; brick < g.n_bricks; brick += gridDim.x) {
+        const int lo = offsets[brick], hi = offsets[brick + 1];
+        if (lo == hi) continue;  // uniform over the workgroup
+        const int b0 = brick / (g.nb[1] * g.nb[2]), b1 = (brick / g.nb[2]) % g.nb[1], b2 = brick % g.nb[2];
+        const int t0[3] = {b0 * kHaloBrick - kHaloMargin, b1 * kHaloBrick - kHaloMargin,
+                           b2 * kHaloBrick - kHaloMargin};
+        for (int c = threadIdx.x; c < nv * kHaloTileCells; c += kBlock) tile[c] = 0.;
+        __syncthreads();
+        for (int e = lo + (int)threadIdx.x; e < hi; e += kBlock) {
+            const unsigned long long t = order[e];
+            int ipos[3], uc[3], uf[3];
+            size_t idx[8];
+            double w[8], val[5];
+            if (!halo_eval(h, A, t, ipos, idx, w, val)) continue;
+            (void)halo_brick(h, g, A, t, uc, uf);
+            int rel[3];
+            bool inside = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                rel[a] = (ipos[a] - uf[a]) + (uc[a] - t0[a]);
+                inside = inside && rel[a] >= 0 && rel[a] + 1 < kHaloTile;
+            }
+            if (inside) {
+                const int base = (rel[0] * kHaloTile + rel[1]) * kHaloTile + rel[2];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int cell = base + (((k & 1) ? kHaloTile : 0) + ((k & 2) ? 1 : 0)) * kHaloTile +
+                                     ((k & 4) ? 1 : 0);
+#pragma unroll
+                    for (int v = 0; v < 5; v++)
+                        if (slot_of[v] >= 0)
+                            __hip_atomic_fetch_add(&tile[slot_of[v] * kHaloTileCells + cell], val[v] * w[k],
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 5; v++) {
+                    if (!O.g[v]) continue;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) unsafeAtomicAdd(O.g[v] + idx[k], val[v] * w[k]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < kHaloTileCells; c += kBlock) {
+            const int c2 = c % kHaloTile, c1 = (c / kHaloTile) % kHaloTile, c0 = c / (kHaloTile * kHaloTile);
+            const size_t o = (size_t)wrap_idx(t0[0] + c0, h.out_dim[0]) * sx +
+                             (size_t)wrap_idx(t0[1] + c1, h.out_dim[1]) * sy +
+                             (size_t)wrap_idx(t0[2] + c2, h.out_dim[2]);
+#pragma unroll
+            for (int v = 0; v < 5; v++) {
+                if (slot_of[v] < 0) continue;
+                const double tv = tile[slot_of[v] * kHaloTileCells + c];
+                if (tv != 0.) unsafeAtomicAdd(O.g[v] + o, tv);
+            }
+        }
+        __syncthreads();
+    }
+}
 }  // namespace
+
+// ints of scratch the tiled path wants: counts, offsets (+1), cursors per brick and one slot per halo
+extern "C" size_t c21hip_halo_deposit_scratch_ints(unsigned long long n_halos, const int out_dim[3]) {
+    size_t n_bricks = 1;
+    for (int a = 0; a < 3; a++) n_bricks *= (size_t)((out_dim[a] + kHaloBrick - 1) / kHaloBrick);
+    return 3 * (n_bricks + 1) + (size_t)n_halos;
+}
 
 extern "C" int c21hip_halo_deposit(const c21cm_halo_consts *consts, unsigned long long n_halos,
                                    const float *masses, const float *coords, const float *star_rng,
@@ -1031,7 +1224,7 @@ extern "C" int c21hip_halo_deposit(const c21cm_halo_consts *consts, unsigned lon
                                    double box_len_z, double growth, double init_growth, int lpt2,
                                    const float *mturn_a, const float *mturn_m, double *out_nion,
                                    double *out_sfr, double *out_sfr_mini, double *out_xray,
-                                   double *out_wsfr, void *stream) {
+                                   double *out_wsfr, int *scratch, void *stream) {
     if (!n_halos) return 0;
     HaloDepositParams h;
     h.c = *consts;
@@ -1048,10 +1241,59 @@ extern "C" int c21hip_halo_deposit(const c21cm_halo_consts *consts, unsigned lon
     const double cell_size_inv_o = out_dim[0] / box_len;
     h.cell_vol_inv = cell_size_inv_o * cell_size_inv_o * cell_size_inv_o;
     h.lpt2 = lpt2;
-    hipLaunchKernelGGL(halo_deposit_kernel, dim3(grid_for((size_t)n_halos)), dim3(kBlock), 0,
-                       (hipStream_t)stream, h, masses, coords, star_rng, sfr_rng, xray_rng, vel[0],
-                       vel[1], vel[2], vel2[0], vel2[1], vel2[2], mturn_a, mturn_m, out_nion, out_sfr,
-                       out_sfr_mini, out_xray, out_wsfr);
+    h.ln_pivot_upper = log(consts->pivot_upper);
+    h.ln_tstar_th = log(consts->t_star * consts->t_h);
+    h.ln_s_per_yr = log(kSecPerYr);
+    h.ln_m0_norm = log(1.28825e10);
+    h.ln_z_norm = log(1.23 * pow(10., -0.056 * consts->redshift + 0.064) / 0.05);
+    const HaloArrays A = {masses, coords, star_rng, sfr_rng, xray_rng, vel[0], vel[1], vel[2],
+                          vel2[0], vel2[1], vel2[2], mturn_a, mturn_m};
+    const HaloOutputs O = {{out_nion, out_sfr, out_sfr_mini, out_xray, out_wsfr}};
+    hipStream_t st = (hipStream_t)stream;
+    HaloBrickGeom g;
+    size_t n_bricks = 1;
+    for (int a = 0; a < 3; a++) {
+        g.nb[a] = (out_dim[a] + kHaloBrick - 1) / kHaloBrick;
+        n_bricks *= (size_t)g.nb[a];
+    }
+    static int direct = -1;  // C21CM_HALO_DEPOSIT=direct: eight global atomics per value and halo
+    if (direct < 0) {
+        const char *e = getenv("C21CM_HALO_DEPOSIT");
+        direct = e && e[0] == 'd';
+    }
+    if (direct || !scratch || n_halos >= (1ull << 31) || n_bricks >= (1ull << 30)) {
+        hipLaunchKernelGGL(halo_deposit_kernel, dim3(grid_for((size_t)n_halos)), dim3(kBlock), 0, st,
+                           h, A, O);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    g.n_bricks = (int)n_bricks;
+    int *counts = scratch, *offsets = counts + n_bricks + 1, *cursor = offsets + n_bricks + 1;
+    unsigned int *order = (unsigned int *)(cursor + n_bricks + 1);
+    int status = c21hip_memset(counts, 0, n_bricks * sizeof(int), stream);
+    if (status) return status;
+    hipLaunchKernelGGL(halo_brick_count_kernel, dim3(grid_for((size_t)n_halos)), dim3(kBlock), 0, st,
+                       h, g, A, counts);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(halo_brick_scan_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, cursor,
+                       g.n_bricks);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(halo_brick_fill_kernel, dim3(grid_for((size_t)n_halos)), dim3(kBlock), 0, st,
+                       h, g, A, cursor, order);
+    LAUNCH_CHECK();
+    int nv = 0;
+    for (int v = 0; v < 5; v++) nv += O.g[v] != nullptr;
+    const size_t lds = (size_t)nv * kHaloTileCells * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)halo_deposit_tiled_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  5 * kHaloTileCells * (int)sizeof(double));
+        attr_done = true;
+    }
+    const int blocks = (int)(n_bricks < 256 * 16 ? n_bricks : 256 * 16);
+    hipLaunchKernelGGL(halo_deposit_tiled_kernel, dim3(blocks), dim3(kBlock), lds, st, h, g, A, O,
+                       offsets, order);
     LAUNCH_CHECK();
     return 0;
 }

@@ -61,7 +61,7 @@ done:
  * (map_mass.c:346-476) into the zeroed accumulation grids, before the integrated deposit adds the
  * sources below the catalogue's mass limit.  acc = {n_ion, halo_sfr, halo_sfr_mini, halo_xray,
  * whalo_sfr}; entries may be NULL. */
-enum { WS_HC_MASS = 231, WS_HC_COORD, WS_HC_RNG0, WS_HC_RNG1, WS_HC_RNG2, WS_HC_WSFR };
+enum { WS_HC_MASS = 231, WS_HC_COORD, WS_HC_RNG0, WS_HC_RNG1, WS_HC_RNG2, WS_HC_WSFR, WS_HC_BINS };
 
 static int deposit_halos(const c21cm_halobox_spec *s, const float *const vel[3],
                          const float *const vel2[3], const int vel_dim[3], const float *mta,
@@ -84,9 +84,11 @@ static int deposit_halos(const c21cm_halobox_spec *s, const float *const vel[3],
     const float *r2 = c->use_xray ? hb_in(WS_HC_RNG2, h->xray_rng, fb, stream, &status) : NULL;
     if (status) return status;
     const int out_dim[3] = {s->hii_dim, s->hii_dim, s->hii_dim_z};
+    int *bins = (int *)c21hip_ws(WS_HC_BINS, c21hip_halo_deposit_scratch_ints(h->n_halos, out_dim) * sizeof(int));
+    if (!bins) return C21CM_MEMORY_ALLOC_ERROR;
     return c21hip_halo_deposit(c, h->n_halos, mass, coord, r0, r1, r2, vel, vel2, vel_dim, out_dim,
                                s->box_len, s->box_len_z, s->growth_factor, s->init_growth_factor,
-                               s->lpt2, mta, mtm, acc[0], acc[1], acc[2], acc[3], acc[4], stream);
+                               s->lpt2, mta, mtm, acc[0], acc[1], acc[2], acc[3], acc[4], bins, stream);
 }
 
 /* USE_MINI_HALOS (HaloBox.c:245-283, map_mass.c:285-321) */

@@ -17,6 +17,7 @@ def random_catalogue(n_halos, box_len, seed, cut_fraction=0.02, box_len_z=None):
     masses[rng.random(n_halos) < cut_fraction] = 0.0
     coords = (rng.random((n_halos, 3)) * [box_len, box_len, box_len_z or box_len]).astype(np.float32)
     coords[:4] = [[0, 0, 0], [box_len, 0, 0], [0, box_len * 0.999999, 0], [0.25, 0.5, 0.75]]
+    coords[4:6] = [[-0.3, box_len + 0.7, 2 * box_len + 0.1], [-box_len - 0.2, 0.1, -1e-4]]  # wrapped
     return dict(masses=masses, coords=coords,
                 star_rng=rng.standard_normal(n_halos).astype(np.float32),
                 sfr_rng=rng.standard_normal(n_halos).astype(np.float32),
