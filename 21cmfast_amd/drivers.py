@@ -318,11 +318,14 @@ def _initialise(lib, inputs: Inputs, data_path):
 
 def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, lib=None,
                keep=("density", "velocity_z", "neutral_fraction", "z_reion", "brightness_temp") + TS_FIELDS,
-               progress=None):
+               progress=None, halo_catalogs=None):
     """Evolve boxes through the library's entry points, mirroring ``run_coeval``: initial
     conditions once, then from the highest node redshift down: PerturbedField -> [HaloBox ->
     XraySourceBox ->] [TsBox ->] IonizedBox -> BrightnessTemp, every snapshot receiving the
-    previous one's boxes.  Supported source models: CONST-ION-EFF, E-INTEGRAL, L-INTEGRAL.
+    previous one's boxes.  Supported source models: CONST-ION-EFF, E-INTEGRAL, L-INTEGRAL and,
+    with catalogues from the caller, DEXM-ESF / CHMF-SAMPLER: ``halo_catalogs(z)`` returns the
+    catalogue of node redshift z as ``structs.HaloCatalogStruct`` (``structs.halo_catalog``; numpy or
+    device arrays) -- finding and sampling halos is not part of this backend.
 
     ``device``: a torch device string ("cuda") keeps every array in HBM (zero-copy entry points);
     None uses numpy arrays that the library stages.  ``data_path``: directory of the reference's
@@ -334,17 +337,17 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
 
     so, mo, ao, ap = (inputs.simulation_options, inputs.matter_options, inputs.astro_options,
                       inputs.astro_params)
-    if mo.SOURCE_MODEL not in (0, 1, 2):
-        raise NotImplementedError("SOURCE_MODEL must be CONST-ION-EFF, E-INTEGRAL or L-INTEGRAL "
-                                  "(halo catalogues are not part of this backend)")
+    if mo.SOURCE_MODEL in (3, 4) and halo_catalogs is None:
+        raise NotImplementedError("SOURCE_MODEL = DEXM-ESF / CHMF-SAMPLER needs halo_catalogs(z): the halo "
+                                  "finder and sampler are not part of this backend")
     mini = bool(ao.USE_MINI_HALOS)
-    if mini and not (mo.SOURCE_MODEL in (1, 2) and ao.USE_TS_FLUCT):
+    if mini and not (mo.SOURCE_MODEL in (1, 2, 3, 4) and ao.USE_TS_FLUCT):
         raise NotImplementedError("USE_MINI_HALOS runs with SOURCE_MODEL = E-INTEGRAL or L-INTEGRAL "
                                   "and USE_TS_FLUCT (the Lyman-Werner background comes from the TsBox)")
     _initialise(lib, inputs, data_path)
     n, nz = so.HII_DIM, int(so.NON_CUBIC_FACTOR * so.HII_DIM)
     shape = (n, n, nz)
-    lagrangian, ts_on, recomb = mo.SOURCE_MODEL == 2, bool(ao.USE_TS_FLUCT), ao.RECOMB_MODEL
+    lagrangian, ts_on, recomb = mo.SOURCE_MODEL >= 2, bool(ao.USE_TS_FLUCT), ao.RECOMB_MODEL
     n_radii = ionisation_radii(so, ap, lagrangian)
     if device is not None:
         import torch
@@ -413,7 +416,9 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
             hb_arr = {k: new() for k in names}
             hb = S.HaloBoxStruct(**{k: fp(v) for k, v in hb_arr.items()})
             # (mini-halos: turnover masses from the previous snapshot's J_21_LW, Gamma_12, z_reion)
-            check(lib.ComputeHaloBox(z, C.byref(icss), None, C.byref(prev_ts) if mini else None,
+            cat = halo_catalogs(z) if mo.SOURCE_MODEL in (3, 4) else None
+            check(lib.ComputeHaloBox(z, C.byref(icss), C.byref(cat) if cat is not None else None,
+                                     C.byref(prev_ts) if mini else None,
                                      C.byref(prev_ion) if mini else None, C.byref(hb)),
                   "ComputeHaloBox")
         ts_arr, ts = ({}, S.TsBoxStruct())

@@ -152,3 +152,50 @@ def test_run_coeval_l_integral_with_mini_halos(gpu_lib, monkeypatch, multiple_sc
     assert 0.0 < x < 0.95
     hist = np.array(res["history"])
     assert np.all(np.diff(hist[:, 2]) <= 1e-6)
+
+
+def test_run_coeval_with_halo_catalogues(gpu_lib, monkeypatch):
+    """SOURCE_MODEL = CHMF-SAMPLER with catalogues from the caller.  (i) An empty catalogue and a
+    sampler limit at the top of the mass range is the L-INTEGRAL run (the integrated branch covers
+    every halo).  (ii) A catalogue of bright halos on top of the integral below SAMPLER_MIN_MASS
+    ionises more, most around the halos."""
+    monkeypatch.delenv("C21CM_IC_RNG", raising=False)
+    S = importlib.import_module("21cmfast_amd.structs")
+    common = dict(HII_DIM=32, DIM=64, BOX_LEN=64.0, N_THREADS=8, ZPRIME_STEP_FACTOR=1.15,
+                  Z_HEAT_MAX=20.0, USE_LYA_HEATING=False, USE_TS_FLUCT=True, R_BUBBLE_MAX=20.0,
+                  RECOMB_MODEL=2, PERTURB_ON_HIGH_RES=False)
+    keep = ("neutral_fraction", "n_ion", "halo_sfr", "halo_xray", "brightness_temp")
+    host = lambda a: a.cpu().numpy()  # noqa: E731
+    z = 9.0
+    ref = D.run_coeval(D.Inputs(random_seed=5, SOURCE_MODEL=2, **common), [z], data_path=DATA,
+                       device="cuda", lib=gpu_lib, keep=keep)
+    empty = S.halo_catalog(np.zeros(0), np.zeros((0, 3)), np.zeros(0), np.zeros(0), np.zeros(0))
+    same = D.run_coeval(D.Inputs(random_seed=5, SOURCE_MODEL=4, SAMPLER_MIN_MASS=1e16, **common), [z],
+                        data_path=DATA, device="cuda", lib=gpu_lib, keep=keep,
+                        halo_catalogs=lambda zz: empty)
+    for k in ("n_ion", "halo_sfr", "halo_xray"):  # float(1e16) is 2.7e-10 above M_MAX_INTEGRAL
+        np.testing.assert_allclose(host(same[z][k]), host(ref[z][k]), rtol=1e-5, err_msg=k)
+    assert abs(host(same[z]["neutral_fraction"]).mean() - host(ref[z]["neutral_fraction"]).mean()) < 1e-4
+    # (ii) 400 halos of 1e11..1e12 Msun in one octant of the box
+    rng = np.random.default_rng(3)
+    nh = 400
+    m0, xyz = 10.0 ** rng.uniform(11, 12, nh), rng.random((nh, 3)) * 32.0
+    dev = [rng.standard_normal(nh) for _ in range(3)]
+    calls = []
+
+    def catalogue(zz):  # the same halos at every node, growing like (1 + z)^-4
+        calls.append(zz)
+        return S.halo_catalog(m0 * ((1 + z) / (1 + zz)) ** 4, xyz, *dev)
+
+    got = D.run_coeval(D.Inputs(random_seed=5, SOURCE_MODEL=4, SAMPLER_MIN_MASS=1e10, **common), [z],
+                       data_path=DATA, device="cuda", lib=gpu_lib, keep=keep, halo_catalogs=catalogue)
+    assert len(calls) == len(got["history"])
+    xs, xr = host(got[z]["neutral_fraction"]), host(ref[z]["neutral_fraction"])
+    assert np.isfinite(host(got[z]["brightness_temp"])).all()
+    assert host(got[z]["halo_xray"]).sum() > 0
+    assert xs[:16, :16, :16].mean() < xs[16:, 16:, 16:].mean() - 0.02  # the octant with the halos
+    assert np.all(np.diff(np.array(got["history"])[:, 2]) <= 1e-6)
+    with pytest.raises(NotImplementedError, match="halo_catalogs"):
+        D.run_coeval(D.Inputs(random_seed=5, SOURCE_MODEL=4, **common), [z], data_path=DATA,
+                     device="cuda", lib=gpu_lib)
+    del xr
