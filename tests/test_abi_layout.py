@@ -44,14 +44,19 @@ STRUCTS = ["CosmoParams", "SimulationOptions", "MatterOptions", "AstroParams", "
            "CosmoTables", "ConfigSettings", "InitialConditions", "PerturbedField", "HaloBox",
            "TsBox", "IonizedBox", "c21cm_ionize_spec", "c21cm_ionize_report", "c21cm_perturb_spec",
            "c21cm_ics_spec", "BrightnessTemp", "XraySourceBox", "c21cm_brightness_spec",
-           "c21cm_halobox_spec", "c21cm_rbox_spec", "c21cm_annular_spec"]
+           "c21cm_halobox_spec", "c21cm_rbox_spec", "c21cm_annular_spec", "HaloCatalog",
+           "c21cm_halo_consts", "c21cm_mturn_spec", "c21cm_ts_spec", "c21cm_ts_report",
+           "c21cm_ts_first_spec"]
 PY_NAMES = {"InitialConditions": "InitialConditionsStruct", "PerturbedField": "PerturbedFieldStruct",
             "HaloBox": "HaloBoxStruct", "TsBox": "TsBoxStruct", "IonizedBox": "IonizedBoxStruct",
             "c21cm_ionize_spec": "IonizeSpec", "c21cm_ionize_report": "IonizeReport",
             "c21cm_perturb_spec": "PerturbSpec", "c21cm_ics_spec": "IcsSpec",
             "BrightnessTemp": "BrightnessTempStruct", "XraySourceBox": "XraySourceBoxStruct",
             "c21cm_brightness_spec": "BrightnessSpec", "c21cm_halobox_spec": "HaloBoxSpec",
-            "c21cm_rbox_spec": "RboxSpec", "c21cm_annular_spec": "AnnularSpec"}
+            "c21cm_rbox_spec": "RboxSpec", "c21cm_annular_spec": "AnnularSpec",
+            "HaloCatalog": "HaloCatalogStruct", "c21cm_halo_consts": "HaloConsts",
+            "c21cm_mturn_spec": "MturnSpec", "c21cm_ts_spec": "TsSpec", "c21cm_ts_report": "TsReport",
+            "c21cm_ts_first_spec": "TsFirstSpec"}
 
 
 def test_ctypes_mirrors_match_compiler_layout(pkg, tmp_path):
