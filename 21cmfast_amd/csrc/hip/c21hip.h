@@ -252,8 +252,16 @@ int c21hip_halobox_scatter_mini(const float *src_density, const int dim[3],
  * grids, values per unit output-cell volume; out_sfr_mini / out_xray / out_wsfr and (without
  * mini-halos) the turnover grids may be NULL.  scratch: c21hip_halo_deposit_scratch_ints() ints
  * for the binned, LDS-tiled path (NULL or C21CM_HALO_DEPOSIT=direct: global atomics only). */
-size_t c21hip_halo_deposit_scratch_ints(unsigned long long n_halos, const int out_dim[3]);
 struct c21cm_halo_consts;
+size_t c21hip_halo_deposit_scratch_ints(unsigned long long n_halos, const int out_dim[3]);
+/* test_halo_props (HaloBox.c:658-779): twelve floats per halo; lw = {A_LW, BETA_LW, A_VCB,
+ * BETA_VCB, sigma_vcb, vcb_const, M_TURN}; the grids are read with mini-halos only */
+int c21hip_halo_props(const struct c21cm_halo_consts *consts, unsigned long long n_halos,
+                      const float *masses, const float *coords, const float *star_rng,
+                      const float *sfr_rng, const float *xray_rng, const int dim[3],
+                      double cell_length, double redshift, int below_z_heat_max, int vcb_flucts,
+                      const double lw[7], const float *vcb, const float *J21, const float *z_re,
+                      const float *G12, float *out, void *stream);
 int c21hip_halo_deposit(const struct c21cm_halo_consts *consts, unsigned long long n_halos,
                         const float *masses, const float *coords, const float *star_rng,
                         const float *sfr_rng, const float *xray_rng, const float *const vel[3],

@@ -909,6 +909,87 @@ struct HaloOutputs {
     double *g[5];  // n_ion, SFR, SFR_mini, L_X, f_esc-weighted SFR; NULL = not wanted
 };
 
+struct HaloProps {  // HaloProperties of HaloBox.h, per halo (not per volume)
+    double stars, stars_mini, sfr, sfr_mini, xray, n_ion, wsfr, metallicity;
+};
+
+// set_halo_properties (HaloBox.c:62-102) with the scaling relations of scaling_relations.c:331-500
+__device__ __forceinline__ HaloProps halo_relations(const HaloDepositParams &h, double hmass,
+                                                    double r_star, double r_sfr, double r_xray,
+                                                    double M_turn_a, double M_turn_m) {
+    const c21cm_halo_consts &c = h.c;
+    // The power laws below are evaluated as exp(index * ln x) on shared logarithms (one log of
+    // the halo mass, one of the stellar mass, one of the SFR) instead of one pow() each: the
+    // kernel is bound by its fp64 transcendentals, and the rounding difference (1e-14) is far
+    // below the float grids' resolution.
+    const double lnM = log(hmass), l10 = lnM - 10. * M_LN10;
+    // get_halo_stellarmass (scaling_relations.c:331-400)
+    const double adj_star = c.scaling_median ? 0. : c.sigma_star * c.sigma_star / 2.;
+    const double s_rng = r_star;
+    double f_sample;
+    if (c.upper_stellar_turnover && c.alpha_star > c.alpha_upper) {
+        const double lp = lnM - h.ln_pivot_upper;
+        f_sample = c.fstar_10 * (c.upper_pivot_ratio / (exp(-c.alpha_star * lp) + exp(-c.alpha_upper * lp))) *
+                   exp(-M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
+    } else {
+        f_sample = c.fstar_10 * exp(c.alpha_star * l10 - M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
+    }
+    if (f_sample > 1.) f_sample = 1.;
+    const double stars = f_sample * hmass * c.baryon_ratio;
+    double stars_mini = 0.;
+    if (c.use_mini_halos) {
+        double f_mini = c.fstar_7 * exp(c.alpha_star_mini * (lnM - 7. * M_LN10) - M_turn_m / hmass -
+                                        hmass / c.acg_thresh + s_rng * c.sigma_star - adj_star);
+        if (f_mini > 1.) f_mini = 1.;
+        stars_mini = f_mini * hmass * c.baryon_ratio;
+    }
+    const double stars_t = stars + stars_mini;
+    const double ln_stars = log(stars_t);  // -inf for an empty halo: handled where it is used
+    // get_halo_sfr (:402-444): the scatter widens towards low stellar masses
+    // A halo so far below its turnover that exp(-M_turn / M) underflows has no stars: upstream
+    // then multiplies 0 by exp(r * inf - inf) and writes NaN for deviates r >= 0 (0 for r < 0);
+    // here such halos (M* < 1e-290 Msun, where the CPU's product underflows to 0 anyway) get SFR 0.
+    double sigma_sfr = 0.;
+    if (c.sigma_sfr_lim > 0.) {
+        sigma_sfr = c.sigma_sfr_idx * ((ln_stars - 10. * M_LN10) * M_LOG10E) + c.sigma_sfr_lim;
+        if (!(sigma_sfr >= c.sigma_sfr_lim) || !(stars_t > 1e-290)) sigma_sfr = c.sigma_sfr_lim;
+    }
+    const bool starless = !(stars_t > 1e-290);
+    const double adj_sfr = c.scaling_median ? 0. : sigma_sfr * sigma_sfr / 2.;
+    const double ln_sfr_fac = r_sfr * sigma_sfr - adj_sfr;
+    const double sfr_fac = starless ? 0. : exp(ln_sfr_fac);
+    const double sfr = stars / (c.t_star * c.t_h) * sfr_fac;
+    const double sfr_mini = c.use_mini_halos ? stars_mini / (c.t_star * c.t_h) * sfr_fac : 0.;
+    // get_halo_metallicity, get_halo_xray (:446-500)
+    double xray = 0., metallicity = 0.;
+    if (c.use_xray) {
+        const double sfr_t = sfr + sfr_mini;
+        double ln_stellar_term = 0.;
+        if (stars_t > 0 && sfr_t > 0.) {
+            // M0 = 1.28825e10 (SFR s_per_yr)^0.56;  (1 + (M*/M0)^-2.1)^-0.148
+            const double ln_sfr_yr = ln_stars - h.ln_tstar_th + ln_sfr_fac + h.ln_s_per_yr;
+            const double ln_ratio = ln_stars - (h.ln_m0_norm + 0.56 * ln_sfr_yr);
+            ln_stellar_term = -0.148 * log1p(exp(-2.1 * ln_ratio));
+        }
+        metallicity = 0.05 * exp(h.ln_z_norm + ln_stellar_term);
+        double lx_a = c.l_x, lx_m = c.l_x_mini;
+        if (c.upper_stellar_turnover) {  // double power law in Z, flat below Z = 0.05 (:277-283)
+            const double dpl = 1. / (1. + exp(0.64 * (h.ln_z_norm + ln_stellar_term)));
+            lx_a *= dpl, lx_m *= dpl;
+        }
+        double mu_x = lx_a * (sfr * kSecPerYr);
+        if (c.use_mini_halos) mu_x += lx_m * (sfr_mini * kSecPerYr);
+        const double adj_x = c.scaling_median ? 0. : c.sigma_xray * c.sigma_xray / 2.;
+        xray = mu_x * exp(r_xray * c.sigma_xray - adj_x);
+    }
+    const double fesc = fmin(c.fesc_10 * exp(c.alpha_esc * l10), 1.);
+    const double fesc_mini = c.use_mini_halos ? fmin(c.fesc_7 * exp(c.alpha_esc * (lnM - 7. * M_LN10)), 1.) : 0.;
+    const double n_ion = stars * c.pop2_ion * fesc + stars_mini * c.pop3_ion * fesc_mini;
+    const double wsfr = sfr * c.pop2_ion * fesc + sfr_mini * c.pop3_ion * fesc_mini;
+    HaloProps p = {stars, stars_mini, sfr, sfr_mini, xray, n_ion, wsfr, metallicity};
+    return p;
+}
+
 // One halo: displaced position (ipos_out: its unwrapped output cell; idx / w: the eight cells and
 // CIC weights) and the five values per unit cell volume.  false: the halo was cut (mass 0).
 __device__ __forceinline__ bool halo_eval(const HaloDepositParams &h, const HaloArrays &A,
@@ -955,69 +1036,9 @@ __device__ __forceinline__ bool halo_eval(const HaloDepositParams &h, const Halo
         M_turn_a = pow(10., cic_read(A.mturn_a, idx, w));
         M_turn_m = pow(10., cic_read(A.mturn_m, idx, w));
     }
-    // The power laws below are evaluated as exp(index * ln x) on shared logarithms (one log of
-    // the halo mass, one of the stellar mass, one of the SFR) instead of one pow() each: the
-    // kernel is bound by its fp64 transcendentals, and the rounding difference (1e-14) is far
-    // below the float grids' resolution.
-    const double lnM = log(hmass), l10 = lnM - 10. * M_LN10;
-    // get_halo_stellarmass (scaling_relations.c:331-400)
-    const double adj_star = c.scaling_median ? 0. : c.sigma_star * c.sigma_star / 2.;
-    const double s_rng = (double)A.star_rng[t];
-    double f_sample;
-    if (c.upper_stellar_turnover && c.alpha_star > c.alpha_upper) {
-        const double lp = lnM - h.ln_pivot_upper;
-        f_sample = c.fstar_10 * (c.upper_pivot_ratio / (exp(-c.alpha_star * lp) + exp(-c.alpha_upper * lp))) *
-                   exp(-M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
-    } else {
-        f_sample = c.fstar_10 * exp(c.alpha_star * l10 - M_turn_a / hmass + s_rng * c.sigma_star - adj_star);
-    }
-    if (f_sample > 1.) f_sample = 1.;
-    const double stars = f_sample * hmass * c.baryon_ratio;
-    double stars_mini = 0.;
-    if (c.use_mini_halos) {
-        double f_mini = c.fstar_7 * exp(c.alpha_star_mini * (lnM - 7. * M_LN10) - M_turn_m / hmass -
-                                        hmass / c.acg_thresh + s_rng * c.sigma_star - adj_star);
-        if (f_mini > 1.) f_mini = 1.;
-        stars_mini = f_mini * hmass * c.baryon_ratio;
-    }
-    const double stars_t = stars + stars_mini;
-    const double ln_stars = log(stars_t);  // -inf for an empty halo: handled where it is used
-    // get_halo_sfr (:402-444): the scatter widens towards low stellar masses
-    double sigma_sfr = 0.;
-    if (c.sigma_sfr_lim > 0.) {
-        sigma_sfr = c.sigma_sfr_idx * ((ln_stars - 10. * M_LN10) * M_LOG10E) + c.sigma_sfr_lim;
-        if (!(sigma_sfr >= c.sigma_sfr_lim)) sigma_sfr = c.sigma_sfr_lim;
-    }
-    const double adj_sfr = c.scaling_median ? 0. : sigma_sfr * sigma_sfr / 2.;
-    const double ln_sfr_fac = (double)A.sfr_rng[t] * sigma_sfr - adj_sfr;
-    const double sfr_fac = exp(ln_sfr_fac);
-    const double sfr = stars / (c.t_star * c.t_h) * sfr_fac;
-    const double sfr_mini = c.use_mini_halos ? stars_mini / (c.t_star * c.t_h) * sfr_fac : 0.;
-    // get_halo_metallicity, get_halo_xray (:446-500)
-    double xray = 0.;
-    if (c.use_xray) {
-        const double sfr_t = sfr + sfr_mini;
-        double ln_stellar_term = 0.;
-        if (stars_t > 0 && sfr_t > 0.) {
-            // M0 = 1.28825e10 (SFR s_per_yr)^0.56;  (1 + (M*/M0)^-2.1)^-0.148
-            const double ln_sfr_yr = ln_stars - h.ln_tstar_th + ln_sfr_fac + h.ln_s_per_yr;
-            const double ln_ratio = ln_stars - (h.ln_m0_norm + 0.56 * ln_sfr_yr);
-            ln_stellar_term = -0.148 * log1p(exp(-2.1 * ln_ratio));
-        }
-        double lx_a = c.l_x, lx_m = c.l_x_mini;
-        if (c.upper_stellar_turnover) {  // double power law in Z, flat below Z = 0.05 (:277-283)
-            const double dpl = 1. / (1. + exp(0.64 * (h.ln_z_norm + ln_stellar_term)));
-            lx_a *= dpl, lx_m *= dpl;
-        }
-        double mu_x = lx_a * (sfr * kSecPerYr);
-        if (c.use_mini_halos) mu_x += lx_m * (sfr_mini * kSecPerYr);
-        const double adj_x = c.scaling_median ? 0. : c.sigma_xray * c.sigma_xray / 2.;
-        xray = mu_x * exp((double)A.xray_rng[t] * c.sigma_xray - adj_x);
-    }
-    const double fesc = fmin(c.fesc_10 * exp(c.alpha_esc * l10), 1.);
-    const double fesc_mini = c.use_mini_halos ? fmin(c.fesc_7 * exp(c.alpha_esc * (lnM - 7. * M_LN10)), 1.) : 0.;
-    const double n_ion = stars * c.pop2_ion * fesc + stars_mini * c.pop3_ion * fesc_mini;
-    const double wsfr = sfr * c.pop2_ion * fesc + sfr_mini * c.pop3_ion * fesc_mini;
+    const HaloProps p = halo_relations(h, hmass, (double)A.star_rng[t], (double)A.sfr_rng[t],
+                                       c.use_xray ? (double)A.xray_rng[t] : 0., M_turn_a, M_turn_m);
+    const double n_ion = p.n_ion, sfr = p.sfr, sfr_mini = p.sfr_mini, xray = p.xray, wsfr = p.wsfr;
     val[0] = n_ion * h.cell_vol_inv;
     val[1] = sfr * h.cell_vol_inv;
     val[2] = sfr_mini * h.cell_vol_inv;
@@ -1294,6 +1315,101 @@ extern "C" int c21hip_halo_deposit(const c21cm_halo_consts *consts, unsigned lon
     const int blocks = (int)(n_bricks < 256 * 16 ? n_bricks : 256 * 16);
     hipLaunchKernelGGL(halo_deposit_tiled_kernel, dim3(blocks), dim3(kBlock), lds, st, h, g, A, O,
                        offsets, order);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// test_halo_props (HaloBox.c:658-779): the twelve properties of every halo of a catalogue, with
+// the turnover masses of the cell the halo sits in (no displacement, no CIC read).
+namespace {
+struct HaloPropsParams {
+    HaloDepositParams h;
+    int dim[3];
+    double cell_length;
+    float z;
+    int below_z_heat_max, vcb_flucts;
+    double m_turn, vcb_const, A_LW, BETA_LW, A_VCB, BETA_VCB, sigma_vcb;
+};
+
+__global__ void __launch_bounds__(kBlock)
+halo_props_kernel(HaloPropsParams q, const float *__restrict__ masses,
+                  const float *__restrict__ coords, const float *__restrict__ star_rng,
+                  const float *__restrict__ sfr_rng, const float *__restrict__ xray_rng,
+                  const float *__restrict__ vcb, const float *__restrict__ J21,
+                  const float *__restrict__ z_re, const float *__restrict__ G12,
+                  float *__restrict__ out) {
+    const c21cm_halo_consts &c = q.h.c;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; t < q.h.n_halos;
+         t += (unsigned long long)gridDim.x * kBlock) {
+        const double m = (double)masses[t];
+        if (m == 0.) continue;  // :693-695
+        double M_turn_a = c.mturn_a_nofb, M_turn_m = c.mturn_m_nofb, M_turn_r = 0.;
+        if (c.use_mini_halos) {
+            int cell[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                double pos = (double)coords[3 * t + a] / q.cell_length;
+                if (pos == (double)(float)q.dim[0]) pos = (double)((float)q.dim[0] - 0.1);  // :700-703
+                cell[a] = wrap_idx((int)pos, q.dim[a]);
+            }
+            const size_t i = (size_t)cell[2] + (size_t)q.dim[2] * ((size_t)cell[1] + (size_t)q.dim[1] * cell[0]);
+            const double vc = q.vcb_flucts ? (double)vcb[i] : (double)(float)q.vcb_const;  // float arguments
+            double j = 0., g = 0., zin = 0.;
+            if (q.below_z_heat_max) j = (double)J21[i], g = (double)G12[i], zin = (double)z_re[i];
+            const double zp1 = 1. + (double)q.z;
+            M_turn_m = 3.314e7 * pow(zp1, -1.5) * (1.0 + q.A_LW * pow(j, q.BETA_LW)) *
+                       pow(1.0 + q.A_VCB * vc / q.sigma_vcb, q.BETA_VCB);
+            M_turn_r = 1e-40;
+            if (!(zin <= 1e-19))
+                M_turn_r = 3e9 * pow(2.0 * g, 0.17) * pow(zp1 / 10, -2.1) *
+                           pow(1 - pow(zp1 / (1. + zin), 2.0), 2.5);
+            M_turn_a = fmax(M_turn_a, fmax(M_turn_r, q.m_turn));
+            M_turn_m = fmax(M_turn_m, fmax(M_turn_r, q.m_turn));
+        }
+        const HaloProps p = halo_relations(q.h, m, (double)star_rng[t], (double)sfr_rng[t],
+                                           (double)xray_rng[t], M_turn_a, M_turn_m);
+        float *o = out + 12 * t;
+        o[0] = (float)m, o[1] = (float)p.stars, o[2] = (float)p.sfr, o[3] = (float)p.xray;
+        o[4] = (float)p.n_ion, o[5] = (float)p.wsfr, o[6] = (float)p.stars_mini, o[7] = (float)p.sfr_mini;
+        o[8] = (float)M_turn_a, o[9] = (float)M_turn_m, o[10] = (float)M_turn_r, o[11] = (float)p.metallicity;
+    }
+}
+
+void fill_relation_constants(HaloDepositParams &h, const c21cm_halo_consts *consts) {
+    h.c = *consts;
+    h.ln_pivot_upper = log(consts->pivot_upper);
+    h.ln_tstar_th = log(consts->t_star * consts->t_h);
+    h.ln_s_per_yr = log(kSecPerYr);
+    h.ln_m0_norm = log(1.28825e10);
+    h.ln_z_norm = log(1.23 * pow(10., -0.056 * consts->redshift + 0.064) / 0.05);
+}
+}  // namespace
+
+// lw = {A_LW, BETA_LW, A_VCB, BETA_VCB, sigma_vcb, vcb_const, M_TURN}; grids may be NULL without
+// mini-halos (vcb only read with vcb_flucts, the other three only below Z_HEAT_MAX)
+extern "C" int c21hip_halo_props(const c21cm_halo_consts *consts, unsigned long long n_halos,
+                                 const float *masses, const float *coords, const float *star_rng,
+                                 const float *sfr_rng, const float *xray_rng, const int dim[3],
+                                 double cell_length, double redshift, int below_z_heat_max,
+                                 int vcb_flucts, const double lw[7], const float *vcb,
+                                 const float *J21, const float *z_re, const float *G12, float *out,
+                                 void *stream) {
+    if (!n_halos) return 0;
+    HaloPropsParams q;
+    fill_relation_constants(q.h, consts);
+    q.h.n_halos = n_halos;
+    q.h.cell_vol_inv = 1.;
+    for (int a = 0; a < 3; a++) q.dim[a] = dim[a];
+    q.cell_length = cell_length;
+    q.z = (float)redshift;
+    q.below_z_heat_max = below_z_heat_max;
+    q.vcb_flucts = vcb_flucts;
+    q.A_LW = lw[0], q.BETA_LW = lw[1], q.A_VCB = lw[2], q.BETA_VCB = lw[3], q.sigma_vcb = lw[4];
+    q.vcb_const = lw[5], q.m_turn = lw[6];
+    hipLaunchKernelGGL(halo_props_kernel, dim3(grid_for((size_t)n_halos)), dim3(kBlock), 0,
+                       (hipStream_t)stream, q, masses, coords, star_rng, sfr_rng, xray_rng, vcb, J21,
+                       z_re, G12, out);
     LAUNCH_CHECK();
     return 0;
 }

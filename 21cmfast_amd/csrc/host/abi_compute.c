@@ -883,6 +883,96 @@ done:
     return st;
 }
 
+/* the ScalingConstants read by set_halo_properties (scaling_relations.c:29-118) */
+static void fill_halo_consts(double redshift, const c21_scaling_consts *sc, c21cm_halo_consts *hc) {
+    const AstroParams *ap = astro_params_global;
+    const AstroOptions *ao = astro_options_global;
+    memset(hc, 0, sizeof(*hc));
+    hc->redshift = redshift;
+    hc->fstar_10 = sc->fstar_10, hc->alpha_star = sc->alpha_star, hc->sigma_star = ap->SIGMA_STAR;
+    hc->alpha_upper = ap->UPPER_STELLAR_TURNOVER_INDEX, hc->pivot_upper = ap->UPPER_STELLAR_TURNOVER_MASS;
+    hc->upper_pivot_ratio = pow(hc->pivot_upper / 1e10, hc->alpha_star) + pow(hc->pivot_upper / 1e10, hc->alpha_upper);
+    hc->fstar_7 = sc->fstar_7, hc->alpha_star_mini = sc->alpha_star_mini, hc->acg_thresh = sc->acg_thresh;
+    hc->baryon_ratio = cosmo_params_global->OMb / cosmo_params_global->OMm;
+    hc->t_h = sc->t_h, hc->t_star = sc->t_star;
+    hc->sigma_sfr_lim = ap->SIGMA_SFR_LIM, hc->sigma_sfr_idx = ap->SIGMA_SFR_INDEX;
+    hc->l_x = sc->l_x, hc->l_x_mini = sc->l_x_mini, hc->sigma_xray = ap->SIGMA_LX;
+    hc->fesc_10 = sc->fesc_10, hc->fesc_7 = sc->fesc_7, hc->alpha_esc = sc->alpha_esc;
+    hc->pop2_ion = sc->pop2_ion, hc->pop3_ion = sc->pop3_ion;
+    hc->mturn_a_nofb = sc->mturn_a_nofb, hc->mturn_m_nofb = sc->mturn_m_nofb;
+    hc->scaling_median = ao->HALO_SCALING_RELATIONS_MEDIAN;
+    hc->upper_stellar_turnover = ao->USE_UPPER_STELLAR_TURNOVER;
+    hc->use_mini_halos = ao->USE_MINI_HALOS, hc->use_xray = ao->USE_TS_FLUCT;
+}
+
+/* reference: src/py21cmfast/src/HaloBox.c:658-779 (_functionprototypes_wrapper.h:127-130): the twelve
+ * properties of every halo (mass, M*, SFR, L_X, n_ion, f_esc-weighted SFR, M*_mini, SFR_mini, the
+ * three turnover masses, metallicity); halos of zero mass are left untouched */
+int test_halo_props(double redshift, float *vcb_grid, float *J21_LW_grid, float *z_re_grid,
+                    float *Gamma12_ion_grid, unsigned long long n_halos, float *halo_masses,
+                    float *halo_coords, float *star_rng, float *sfr_rng, float *xray_rng,
+                    float *halo_props_out) {
+    int st = require_globals("test_halo_props", 1);
+    if (st) return st;
+    if (!n_halos) return 0;
+    const SimulationOptions *so = simulation_options_global;
+    const AstroOptions *ao = astro_options_global;
+    const int mini = ao->USE_MINI_HALOS, below = redshift < so->Z_HEAT_MAX;
+    const int flucts = matter_options_global->V_CB_MODEL == C21CM_VCB_FLUCTS;
+    if (!halo_masses || !halo_coords || !star_rng || !sfr_rng || !xray_rng || !halo_props_out ||
+        (mini && ((flucts && !vcb_grid) || (below && (!J21_LW_grid || !z_re_grid || !Gamma12_ion_grid))))) {
+        c21hip_set_error("test_halo_props: NULL catalogue array or feedback grid");
+        return C21CM_VALUE_ERROR;
+    }
+    if ((st = ensure_ps())) return st;
+    c21_scaling_consts sc;
+    if ((st = c21_set_scaling_constants(redshift, &sc))) return st;
+    c21cm_halo_consts hc;
+    fill_halo_consts(redshift, &sc, &hc);
+    int dim, dim_z, hii[3];
+    double bl, blz;
+    geometry(&dim, &dim_z, &hii[0], &hii[2], &bl, &blz);
+    hii[1] = hii[0];
+    const size_t nh = (size_t)n_halos, fb = nh * sizeof(float);
+    const size_t gb = (size_t)hii[0] * hii[1] * hii[2] * sizeof(float);
+    enum { WS_HP0 = 238 };
+    const float *in[5] = {halo_masses, halo_coords, star_rng, sfr_rng, xray_rng};
+    const float *grid_in[4] = {vcb_grid, J21_LW_grid, z_re_grid, Gamma12_ion_grid};
+    const float *dev[5], *gdev[4] = {NULL, NULL, NULL, NULL};
+    for (int k = 0; k < 5; k++) {
+        dev[k] = in[k];
+        if (!c21hip_is_device_ptr(in[k])) {
+            void *d = c21hip_ws(WS_HP0 + k, k == 1 ? 3 * fb : fb);
+            if (!d) return C21CM_MEMORY_ALLOC_ERROR;
+            if ((st = c21hip_h2d(d, in[k], k == 1 ? 3 * fb : fb, NULL))) return st;
+            dev[k] = (const float *)d;
+        }
+    }
+    for (int k = 0; k < 4 && mini; k++) {
+        if (!grid_in[k] || (k == 0 ? !flucts : !below)) continue;
+        gdev[k] = grid_in[k];
+        if (!c21hip_is_device_ptr(grid_in[k])) {
+            void *d = c21hip_ws(WS_HP0 + 5 + k, gb);
+            if (!d) return C21CM_MEMORY_ALLOC_ERROR;
+            if ((st = c21hip_h2d(d, grid_in[k], gb, NULL))) return st;
+            gdev[k] = (const float *)d;
+        }
+    }
+    float *out = halo_props_out;
+    if (!c21hip_is_device_ptr(out)) {
+        if (!(out = (float *)c21hip_ws(WS_HP0 + 9, 12 * fb))) return C21CM_MEMORY_ALLOC_ERROR;
+        if ((st = c21hip_h2d(out, halo_props_out, 12 * fb, NULL))) return st; /* cut halos keep their rows */
+    }
+    const double lw[7] = {astro_params_global->A_LW, astro_params_global->BETA_LW, astro_params_global->A_VCB,
+                          astro_params_global->BETA_VCB, cosmo_tables_global->V_CB_AVG * sqrt(3 * M_PI / 8),
+                          sc.vcb_const, astro_params_global->M_TURN};
+    if ((st = c21hip_halo_props(&hc, n_halos, dev[0], dev[1], dev[2], dev[3], dev[4], hii, bl / hii[0],
+                                redshift, below, flucts, lw, gdev[0], gdev[1], gdev[2], gdev[3], out, NULL)))
+        return st;
+    if (out != halo_props_out && (st = c21hip_d2h(halo_props_out, out, 12 * fb, NULL))) return st;
+    return c21hip_sync(NULL);
+}
+
 /* reference: src/py21cmfast/src/HaloBox.c:563-653 with set_fixed_grids :302-436 and
  * sum_halos_onto_grid :518-560, without the extra fields; with USE_TS_FLUCT the X-ray
  * emissivity grid halo_xray is filled as well (the input of UpdateXraySourceBox); with USE_MINI_HALOS
@@ -936,24 +1026,8 @@ int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *h
     c21_scaling_consts sc, sc_sfrd;
     if ((st = c21_set_scaling_constants(redshift, &sc))) return st;
     /* the halos of a catalogue take the unadjusted constants (hbox_consts, :599-600,623-624) */
-    const AstroParams *ap = astro_params_global;
     c21cm_halo_consts hc;
-    memset(&hc, 0, sizeof(hc));
-    hc.redshift = redshift;
-    hc.fstar_10 = sc.fstar_10, hc.alpha_star = sc.alpha_star, hc.sigma_star = ap->SIGMA_STAR;
-    hc.alpha_upper = ap->UPPER_STELLAR_TURNOVER_INDEX, hc.pivot_upper = ap->UPPER_STELLAR_TURNOVER_MASS;
-    hc.upper_pivot_ratio = pow(hc.pivot_upper / 1e10, hc.alpha_star) + pow(hc.pivot_upper / 1e10, hc.alpha_upper);
-    hc.fstar_7 = sc.fstar_7, hc.alpha_star_mini = sc.alpha_star_mini, hc.acg_thresh = sc.acg_thresh;
-    hc.baryon_ratio = cosmo_params_global->OMb / cosmo_params_global->OMm;
-    hc.t_h = sc.t_h, hc.t_star = sc.t_star;
-    hc.sigma_sfr_lim = ap->SIGMA_SFR_LIM, hc.sigma_sfr_idx = ap->SIGMA_SFR_INDEX;
-    hc.l_x = sc.l_x, hc.l_x_mini = sc.l_x_mini, hc.sigma_xray = ap->SIGMA_LX;
-    hc.fesc_10 = sc.fesc_10, hc.fesc_7 = sc.fesc_7, hc.alpha_esc = sc.alpha_esc;
-    hc.pop2_ion = sc.pop2_ion, hc.pop3_ion = sc.pop3_ion;
-    hc.mturn_a_nofb = sc.mturn_a_nofb, hc.mturn_m_nofb = sc.mturn_m_nofb;
-    hc.scaling_median = ao->HALO_SCALING_RELATIONS_MEDIAN;
-    hc.upper_stellar_turnover = ao->USE_UPPER_STELLAR_TURNOVER;
-    hc.use_mini_halos = ao->USE_MINI_HALOS, hc.use_xray = ao->USE_TS_FLUCT;
+    fill_halo_consts(redshift, &sc, &hc);
     /* set_fixed_grids :300-308: median relations -> raised normalisations in the sub-grid integrals */
     if (ao->HALO_SCALING_RELATIONS_MEDIAN && (st = c21_scaling_consts_mimic_scatter(&sc))) return st;
     sc_sfrd = c21_scaling_consts_sfr(&sc); /* scaling_relations.c:122-131 */

@@ -376,6 +376,17 @@ typedef struct HaloCatalog {
 int ComputeHaloBox(double redshift, InitialConditions *ini_boxes, HaloCatalog *halos,
                    TsBox *previous_spin_temp, IonizedBox *previous_ionize_box, HaloBox *grids);
 
+/* reference: src/py21cmfast/src/HaloBox.c:658-779 (_functionprototypes_wrapper.h:127-130; bound by
+ * py21cmfast's cfuncs.convert_halo_properties).  Twelve floats per halo: mass, M*, SFR, L_X
+ * [1e38 erg/s], n_ion, f_esc-weighted SFR, M*_mini, SFR_mini, M_turn (atomic, molecular,
+ * reionisation), metallicity; the feedback grids [HII_DIM^3] are read with USE_MINI_HALOS only
+ * (J_21_LW, z_re, Gamma_12 below Z_HEAT_MAX; vcb with V_CB_MODEL = FLUCTS).  Rows of halos with
+ * zero mass are left as they are.  Arrays host or device. */
+int test_halo_props(double redshift, float *vcb_grid, float *J21_LW_grid, float *z_re_grid,
+                    float *Gamma12_ion_grid, unsigned long long n_halos, float *halo_masses,
+                    float *halo_coords, float *star_rng, float *sfr_rng, float *xray_rng,
+                    float *halo_props_out);
+
 /* reference: src/py21cmfast/src/BrightnessTemperatureBox.c:22 (_functionprototypes_wrapper.h:28-29) */
 int ComputeBrightnessTemp(float redshift, TsBox *spin_temp, IonizedBox *ionized_box,
                           PerturbedField *perturb_field, BrightnessTemp *box);

@@ -100,6 +100,11 @@ int oracle_brightness_grids(const c21cm_brightness_spec *spec, const float *dens
                             float *brightness_temp, float *tau_21, double *mean_out);
 
 /* oracle_halobox.c -- reference: src/py21cmfast/src/HaloBox.c:244-436, map_mass.c:62-98,214-344 */
+int oracle_halo_props(const c21cm_halo_consts *c, unsigned long long n_halos, const float *masses,
+                      const float *coords, const float *star_rng, const float *sfr_rng,
+                      const float *xray_rng, const int dim[3], double cell_length, double redshift,
+                      int below_z_heat_max, int vcb_flucts, const double lw[7], const float *vcb,
+                      const float *J21, const float *z_re, const float *G12, float *out);
 int oracle_halobox_grids(const c21cm_halobox_spec *spec, const InitialConditions *ics,
                          HaloBox *grids);
 

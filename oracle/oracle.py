@@ -407,3 +407,26 @@ def ts_first_grids(spec, density):
 
 def filter_window_ms(k, R_inner, R_outer, R_star):
     return load().oracle_filter_window_ms(float(k), R_inner, R_outer, R_star)
+
+
+def halo_props(consts, cat, dim, cell_length, redshift, below_z_heat_max=0, vcb_flucts=0, lw=None,
+               vcb=None, J21=None, z_re=None, G12=None):
+    """test_halo_props (HaloBox.c:658-779): [n_halos, 12] floats; cat: dict(masses, coords, star_rng,
+    sfr_rng, xray_rng); lw = (A_LW, BETA_LW, A_VCB, BETA_VCB, sigma_vcb, vcb_const, M_TURN)."""
+    lib = load()
+    fp = C.POINTER(C.c_float)
+    lib.oracle_halo_props.restype = C.c_int
+    lib.oracle_halo_props.argtypes = [C.c_void_p, C.c_ulonglong] + [fp] * 5 + [
+        C.POINTER(C.c_int), C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double)] + [fp] * 5
+    arr = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+    ins = [arr(cat[k]) for k in ("masses", "coords", "star_rng", "sfr_rng", "xray_rng")]
+    grids = [arr(g) for g in (vcb, J21, z_re, G12)]
+    n = ins[0].size
+    out = np.zeros((n, 12), np.float32)
+    ptr = lambda a: None if a is None else a.ctypes.data_as(fp)  # noqa: E731
+    st = lib.oracle_halo_props(C.byref(consts), n, *[ptr(a) for a in ins], (C.c_int * 3)(*dim),
+                               float(cell_length), float(redshift), int(below_z_heat_max), int(vcb_flucts),
+                               (C.c_double * 7)(*(lw or (0.0,) * 7)), *[ptr(g) for g in grids], ptr(out))
+    if st:
+        raise RuntimeError(f"oracle_halo_props status {st}")
+    return out

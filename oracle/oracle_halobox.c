@@ -97,7 +97,7 @@ static double lx_on_sfr(double metallicity, double lx_constant, int upper) { /* 
 }
 
 typedef struct {
-    double n_ion, sfr, sfr_mini, xray, wsfr;
+    double n_ion, sfr, sfr_mini, xray, wsfr, stars, stars_mini, metallicity;
 } halo_props;
 
 /* set_halo_properties (HaloBox.c:62-102) */
@@ -132,7 +132,8 @@ static halo_props halo_properties(double M, double M_turn_a, double M_turn_m, co
     halo_props p;
     p.sfr = stars / (c->t_star * c->t_h) * exp(rng[1] * sigma_sfr - adj_sfr);
     p.sfr_mini = c->use_mini_halos ? stars_mini / (c->t_star * c->t_h) * exp(rng[1] * sigma_sfr - adj_sfr) : 0.;
-    p.xray = 0.;
+    p.xray = 0., p.metallicity = 0.;
+    p.stars = stars, p.stars_mini = stars_mini;
     if (c->use_xray) { /* get_halo_metallicity, get_halo_xray (:446-500) */
         const double sfr_t = p.sfr + p.sfr_mini, stars_t = stars + stars_mini;
         double stellar_term = 1.;
@@ -141,6 +142,7 @@ static halo_props halo_properties(double M, double M_turn_a, double M_turn_m, co
             stellar_term = pow(1 + pow(stars_t / M0, -2.1), -0.148);
         }
         const double Z = 1.23 * stellar_term * pow(10, -0.056 * c->redshift + 0.064);
+        p.metallicity = Z;
         double mu_x = lx_on_sfr(Z, c->l_x, c->upper_stellar_turnover) * (p.sfr * s_per_yr);
         if (c->use_mini_halos) mu_x += lx_on_sfr(Z, c->l_x_mini, c->upper_stellar_turnover) * (p.sfr_mini * s_per_yr);
         const double adj_x = c->scaling_median ? 0 : c->sigma_xray * c->sigma_xray / 2.;
@@ -341,5 +343,46 @@ int oracle_halobox_turnovers(const c21cm_mturn_spec *m, double m_turn, int below
     }
     averages[0] = log10_mturn_a_avg / ntot;
     averages[1] = log10_mturn_m_avg / ntot;
+    return 0;
+}
+
+/* test_halo_props (HaloBox.c:658-779).  lw = {A_LW, BETA_LW, A_VCB, BETA_VCB, sigma_vcb, vcb_const,
+ * M_TURN}; lyman_werner_threshold / reionization_feedback as in thermochem.c (float arguments). */
+int oracle_halo_props(const c21cm_halo_consts *c, unsigned long long n_halos, const float *masses,
+                      const float *coords, const float *star_rng, const float *sfr_rng,
+                      const float *xray_rng, const int dim[3], double cell_length, double redshift,
+                      int below_z_heat_max, int vcb_flucts, const double lw[7], const float *vcb,
+                      const float *J21, const float *z_re, const float *G12, float *out) {
+    for (unsigned long long i = 0; i < n_halos; i++) {
+        const double m = masses[i];
+        if (m == 0.) continue;
+        double M_turn_a = c->mturn_a_nofb, M_turn_m = c->mturn_m_nofb, M_turn_r = 0.;
+        if (c->use_mini_halos) {
+            int cell[3];
+            for (int a = 0; a < 3; a++) {
+                double pos = coords[a + 3 * i] / cell_length;
+                if (pos == (float)dim[0]) pos = (float)dim[0] - 0.1;
+                cell[a] = (int)pos;
+            }
+            const size_t ic = (size_t)cell[2] + (size_t)dim[2] * ((size_t)cell[1] + (size_t)dim[1] * cell[0]);
+            const float vc = vcb_flucts ? vcb[ic] : (float)lw[5];
+            float j = 0.f, g = 0.f, zin = 0.f;
+            if (below_z_heat_max) j = J21[ic], g = G12[ic], zin = z_re[ic];
+            const float z = (float)redshift;
+            M_turn_m = 3.314e7 * pow(1. + z, -1.5) * (1.0 + lw[0] * pow(j, lw[1])) *
+                       pow(1.0 + lw[2] * vc / lw[4], lw[3]);
+            M_turn_r = zin <= 1e-19 ? 1e-40
+                                    : 3e9 * pow(2.0 * g, 0.17) * pow((1. + z) / 10, -2.1) *
+                                          pow(1 - pow((1. + z) / (1. + zin), 2.0), 2.5);
+            M_turn_a = fmax(M_turn_a, fmax(M_turn_r, lw[6]));
+            M_turn_m = fmax(M_turn_m, fmax(M_turn_r, lw[6]));
+        }
+        const double rng[3] = {star_rng[i], sfr_rng[i], xray_rng[i]};
+        const halo_props p = halo_properties(m, M_turn_a, M_turn_m, c, rng);
+        float *o = out + 12 * i;
+        o[0] = m, o[1] = p.stars, o[2] = p.sfr, o[3] = p.xray, o[4] = p.n_ion, o[5] = p.wsfr;
+        o[6] = p.stars_mini, o[7] = p.sfr_mini, o[8] = M_turn_a, o[9] = M_turn_m, o[10] = M_turn_r;
+        o[11] = p.metallicity;
+    }
     return 0;
 }

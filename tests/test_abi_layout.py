@@ -29,7 +29,7 @@ def test_library_loads_without_gpu_and_exports_every_declared_symbol(pkg):
     assert {"ComputeInitialConditions", "ComputePerturbedField", "ComputeIonizedBox",
             "Broadcast_struct_global_all", "test_filter", "init_ps", "c21cm_ionize_grids",
             "c21cm_perturb_grids", "c21cm_ics_grids", "c21cm_ionize_shard_radii",
-            "ComputeBrightnessTemp", "ComputeHaloBox", "UpdateXraySourceBox", "hyper_2F3",
+            "ComputeBrightnessTemp", "ComputeHaloBox", "test_halo_props", "UpdateXraySourceBox", "hyper_2F3",
             "c21cm_fill_Rbox_grids", "c21cm_annular_filter_grids"} <= set(names)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/*.h but not exported: {missing}"

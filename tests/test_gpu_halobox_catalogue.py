@@ -180,3 +180,117 @@ def test_entry_point_with_a_catalogue(gpu_lib, oracle, tmp_path, sampler_min_mas
     ref = oracle.halobox_grids(spec, ics, with_whalo=True, with_xray=True)
     compare(out, ref)
     assert all(ref[k].max() > 0 for k in keys)
+
+
+def _bind_test_halo_props(lib):
+    fp = C.POINTER(C.c_float)
+    lib.test_halo_props.restype = C.c_int
+    lib.test_halo_props.argtypes = [C.c_double] + [fp] * 4 + [C.c_ulonglong] + [fp] * 6
+    return lambda a: None if a is None else a.ctypes.data_as(fp)
+
+
+def _consts_from_library(lib, ses, z, **kw):
+    from test_host_scalars import ScalingConsts
+
+    lib.c21_set_scaling_constants.restype = C.c_int
+    lib.c21_set_scaling_constants.argtypes = [C.c_double, C.POINTER(ScalingConsts)]
+    sc = ScalingConsts()
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    ap = ses.ap
+    return sc, halo_consts(
+        z, fstar_10=sc.fstar_10, alpha_star=sc.alpha_star, sigma_star=ap.SIGMA_STAR,
+        alpha_upper=ap.UPPER_STELLAR_TURNOVER_INDEX, pivot_upper=ap.UPPER_STELLAR_TURNOVER_MASS,
+        fstar_7=sc.fstar_7, alpha_star_mini=sc.alpha_star_mini, acg_thresh=sc.acg_thresh,
+        baryon_ratio=ses.cp.OMb / ses.cp.OMm, t_h=sc.t_h, t_star=sc.t_star, sigma_sfr_lim=ap.SIGMA_SFR_LIM,
+        sigma_sfr_idx=ap.SIGMA_SFR_INDEX, l_x=sc.l_x, l_x_mini=sc.l_x_mini, sigma_xray=ap.SIGMA_LX,
+        fesc_10=sc.fesc_10, fesc_7=sc.fesc_7, alpha_esc=sc.alpha_esc, pop2_ion=sc.pop2_ion,
+        pop3_ion=sc.pop3_ion, mturn_a_nofb=sc.mturn_a_nofb, mturn_m_nofb=sc.mturn_m_nofb,
+        scaling_median=int(ses.ao.HALO_SCALING_RELATIONS_MEDIAN),
+        upper_stellar_turnover=int(ses.ao.USE_UPPER_STELLAR_TURNOVER), use_xray=int(ses.ao.USE_TS_FLUCT), **kw)
+
+
+def test_halo_props_entry_point_reference_known_answers(gpu_lib, tmp_path):
+    """test_halo_props (the C function behind py21cmfast's convert_halo_properties) on the case of the
+    reference's own test_halo_prop_sampling (tests/test_halo_sampler.py:148-237): same masses,
+    deviates, parameters and tolerances; H(z) from the library instead of astropy."""
+    from test_gpu_abi import Session
+    from test_oracle_halobox_catalogue import reference_kat_catalogue, reference_kat_expectations
+
+    lib = gpu_lib
+    ses = Session(lib, tmp_path, HII_DIM=16, DIM=32, USE_TS_FLUCT=True, USE_UPPER_STELLAR_TURNOVER=False,
+                  M_TURN=1e5, F_STAR10=0.1, ALPHA_STAR=0.0, t_STAR=0.1, L_X=1e40)
+    z = 10.0
+    masses, rng, cat = reference_kat_catalogue()
+    ptr = _bind_test_halo_props(lib)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
+    m, xyz, r = f32(masses), f32(cat["coords"]), f32(rng)
+    out = np.zeros((m.size, 12), np.float32)
+    st = lib.test_halo_props(z, None, None, None, None, m.size, ptr(m), ptr(xyz), ptr(r), ptr(r), ptr(r), ptr(out))
+    assert st == 0, lib.c21cm_last_error()
+    sc, c = _consts_from_library(lib, ses, z)
+    assert c.l_x == pytest.approx(100.0) and c.mturn_a_nofb == 1e5 and c.t_star == pytest.approx(0.1)
+    shmr, ssfr, lx = reference_kat_expectations(masses, rng, c, 1.0 / sc.t_h)
+    np.testing.assert_allclose(out[:, 1] / out[:, 0], shmr, rtol=1e-4)
+    np.testing.assert_allclose(out[:, 2] / out[:, 1], ssfr, rtol=1e-4)
+    np.testing.assert_allclose(out[:, 3] / (out[:, 2] * 31556925.9747), lx, rtol=1e-4)
+    lib.c21_hubble.restype, lib.c21_hubble.argtypes = C.c_double, [C.c_float]
+    assert 1.0 / sc.t_h == pytest.approx(lib.c21_hubble(z), rel=1e-12)
+
+
+@pytest.mark.parametrize("below,flucts", [(True, True), (True, False), (False, False)])
+def test_halo_props_with_feedback_grids_matches_oracle(gpu_lib, oracle, tmp_path, below, flucts):
+    """USE_MINI_HALOS: Lyman-Werner / relative-velocity / reionisation feedback of the halo's cell;
+    cut halos keep their rows; device-resident arrays give the same numbers."""
+    import torch
+    from test_gpu_abi import Session
+
+    lib = gpu_lib
+    n = 16
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=2 * n, USE_TS_FLUCT=True, USE_MINI_HALOS=True,
+                  Z_HEAT_MAX=35.0 if below else 5.0, V_CB_MODEL=2 if flucts else 3, SOURCE_MODEL=2,
+                  HALO_SCALING_RELATIONS_MEDIAN=not flucts)
+    z = 11.0
+    cat = random_catalogue(20000, ses.so.BOX_LEN * 0.9999, seed=21)
+    cat["masses"] = (cat["masses"] * np.where(np.arange(20000) % 2, 1e-3, 1.0)).astype(np.float32)
+    cat["coords"] = np.abs(cat["coords"]) % np.float32(ses.so.BOX_LEN * 0.9999)  # in the box, as upstream needs
+    cat["coords"][7] = [ses.so.BOX_LEN, 0.0, ses.so.BOX_LEN]  # the edge case of HaloBox.c:700-703
+    rng = np.random.default_rng(4)
+    vcb = (rng.random((n, n, n)) * 40).astype(np.float32)
+    j21 = (10 ** rng.uniform(-3, 1, (n, n, n))).astype(np.float32)
+    g12 = (10 ** rng.uniform(-2, 0, (n, n, n))).astype(np.float32)
+    zre = np.where(rng.random((n, n, n)) < 0.5, rng.uniform(11.5, 16, (n, n, n)), -1.0).astype(np.float32)
+    ptr = _bind_test_halo_props(lib)
+    out = np.full((20000, 12), -7.0, np.float32)
+    arrs = [cat[k] for k in ("masses", "coords", "star_rng", "sfr_rng", "xray_rng")]
+    st = lib.test_halo_props(z, ptr(vcb), ptr(j21), ptr(zre), ptr(g12), 20000, *[ptr(a) for a in arrs], ptr(out))
+    assert st == 0, lib.c21cm_last_error()
+    sc, c = _consts_from_library(lib, ses, z, use_mini_halos=1)
+    lw = (ses.ap.A_LW, ses.ap.BETA_LW, ses.ap.A_VCB, ses.ap.BETA_VCB,
+          ses.ct.V_CB_AVG * np.sqrt(3 * np.pi / 8), sc.vcb_const, ses.ap.M_TURN)
+    ref = oracle.halo_props(c, cat, (n, n, n), ses.so.BOX_LEN / n, z, below, flucts, lw, vcb, j21, zre, g12)
+    cut = cat["masses"] == 0
+    assert cut.any() and np.all(out[cut] == -7.0)
+    # halos without stars (exp(-M_turn / M) underflows): upstream's 0 * exp(r inf - inf) is NaN for
+    # r >= 0; the device writes 0 there (DESIGN 7c)
+    assert np.isnan(ref).any() and np.isfinite(out[~cut]).all()
+    np.testing.assert_array_equal(out[np.isnan(ref)], 0.0)
+    ok = ~cut
+    want = np.nan_to_num(ref, nan=0.0)
+    for col in range(12):
+        # the metallicity of halos whose stellar mass is below float range is computed from a
+        # denormal SFR on the CPU (a few mantissa bits: 1e-4 off); compared where there are stars
+        rows = ok & (ref[:, 1] + ref[:, 6] > 0) if col == 11 else ok
+        bad = rows & ~np.isclose(out[:, col], want[:, col], rtol=3e-6, atol=1e-36)
+        assert not bad.any(), (col, int(bad.sum()), out[bad][:4, col], ref[bad][:4, col], out[bad][:4, [1, 2, 6, 7]],
+                               ref[bad][:4, [1, 2, 6, 7]])
+    assert (ref[~cut, 6] > 0).any() and (ref[~cut, 10] > 1).any() == below
+    # device-resident
+    dev = [torch.from_numpy(a).cuda() for a in arrs + [vcb, j21, zre, g12]]
+    out_d = torch.zeros((20000, 12), dtype=torch.float32, device="cuda")
+    fp = C.POINTER(C.c_float)
+    dp = lambda t: C.cast(t.data_ptr(), fp)  # noqa: E731
+    assert lib.test_halo_props(z, dp(dev[5]), dp(dev[6]), dp(dev[7]), dp(dev[8]), 20000,
+                               *[dp(t) for t in dev[:5]], dp(out_d)) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out_d.cpu().numpy()[~cut], out[~cut])
+    del ok

@@ -87,3 +87,42 @@ def test_displacement_conserves_totals_and_adds_to_the_integral(oracle, hires):
     for k in ("n_ion", "halo_sfr"):
         np.testing.assert_allclose(both[k], halos_only[k].astype(np.float64) + integral[k], rtol=3e-5,
                                    atol=3e-6 * both[k].max())
+
+
+def reference_kat_expectations(masses, rng, c, H_z):
+    """The expectations of the reference's own known-answer test of the scaling relations
+    (/root/reference/tests/test_halo_sampler.py:148-237, test_halo_prop_sampling: no upper
+    turnover, no mini-halos, L_X/SFR constant), restated on the constants struct."""
+    shmr = c.fstar_10 * (masses / 1e10) ** c.alpha_star * np.exp(
+        -c.mturn_a_nofb / masses + rng * c.sigma_star - c.sigma_star**2 / 2)
+    shmr = np.minimum(shmr, 1) * c.baryon_ratio
+    sig = np.maximum(c.sigma_sfr_lim + c.sigma_sfr_idx * np.log10(shmr * masses / 1e10), c.sigma_sfr_lim)
+    ssfr = H_z / c.t_star * np.exp(rng * sig - sig**2 / 2)
+    lx = c.l_x * np.exp(rng * c.sigma_xray - c.sigma_xray**2 / 2)
+    return shmr, ssfr, lx
+
+
+def reference_kat_catalogue():
+    masses, rng = np.meshgrid(np.array([1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12]),
+                              np.array([-3.0, -2, -1, 0, 1, 2, 3]), indexing="ij")
+    masses, rng = masses.ravel(), rng.ravel()
+    return masses, rng, dict(masses=masses, coords=np.zeros((masses.size, 3)), star_rng=rng, sfr_rng=rng,
+                             xray_rng=rng)
+
+
+def test_scaling_relations_against_the_references_known_answers(oracle):
+    """Pins set_halo_properties of the oracle to the reference's test_halo_prop_sampling: same halo
+    masses (1e5..1e12), same deviates (-3..3 on the diagonal), same parameters (M_TURN 1e5,
+    F_STAR10 0.1, ALPHA_STAR 0, t_STAR 0.1, L_X 1e40), same tolerances (1e-4; the reference allows
+    3e-3 on the SSFR because its expectation takes H(z) from astropy)."""
+    masses, rng, cat = reference_kat_catalogue()
+    t_h = 1.0 / 5.3e-17
+    c = halo_consts(10.0, upper_stellar_turnover=0, mturn_a_nofb=1e5, fstar_10=0.1, alpha_star=0.0,
+                    t_star=0.1, t_h=t_h, l_x=1e40 * 1e-38)
+    out = oracle.halo_props(c, cat, (8, 8, 8), 1.5, 10.0)
+    shmr, ssfr, lx = reference_kat_expectations(masses, rng, c, 1.0 / t_h)
+    np.testing.assert_array_equal(out[:, 0], masses.astype(np.float32))
+    np.testing.assert_allclose(out[:, 1] / out[:, 0], shmr, rtol=1e-4)
+    np.testing.assert_allclose(out[:, 2] / out[:, 1], ssfr, rtol=1e-4)
+    np.testing.assert_allclose(out[:, 3] / (out[:, 2] * S_PER_YR), lx, rtol=1e-4)
+    assert np.all(out[:, 8] == np.float32(1e5)) and np.all(out[:, 6:8] == 0) and np.all(out[:, 10] == 0)
