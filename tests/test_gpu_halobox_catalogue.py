@@ -294,3 +294,47 @@ def test_halo_props_with_feedback_grids_matches_oracle(gpu_lib, oracle, tmp_path
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out_d.cpu().numpy()[~cut], out[~cut])
     del ok
+
+
+def test_grid_totals_equal_the_sum_over_halos_at_scale(gpu_lib, tmp_path):
+    """Size-independent property at 256^3 with 5e6 halos: the CIC weights of a halo sum to one, so
+    every HaloBox grid times the cell volume integrates to the sum of that property over the
+    catalogue -- the grids from ComputeHaloBox (halos only: SAMPLER_MIN_MASS below M_min), the
+    per-halo values from test_halo_props; two entry points, two kernels."""
+    import torch
+    from test_gpu_abi import Session, fptr
+
+    lib = gpu_lib
+    n, nh = 256, 5_000_000
+    ses = Session(lib, tmp_path, HII_DIM=n, DIM=n, BOX_LEN=384.0, SOURCE_MODEL=4, SAMPLER_MIN_MASS=1e6,
+                  USE_TS_FLUCT=True, RECOMB_MODEL=2, PERTURB_ON_HIGH_RES=False)
+    z = 9.0
+    cat = random_catalogue(nh, 384.0, seed=31)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in cat.items()}
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ics = {k: torch.randn((n, n, n), device="cuda", generator=g) * s for k, s in (
+        ("lowres_density", 1.0), ("lowres_vx", 3.0), ("lowres_vy", 3.0), ("lowres_vz", 3.0),
+        ("lowres_vx_2LPT", 1.0), ("lowres_vy_2LPT", 1.0), ("lowres_vz_2LPT", 1.0))}
+    fp = C.POINTER(C.c_float)
+    dp = lambda t: C.cast(t.data_ptr(), fp)  # noqa: E731
+    hc = S.HaloCatalogStruct(n_halos=nh, buffer_size=nh, halo_masses=dp(dev["masses"]),
+                             halo_coords=dp(dev["coords"]), star_rng=dp(dev["star_rng"]),
+                             sfr_rng=dp(dev["sfr_rng"]), xray_rng=dp(dev["xray_rng"]))
+    keys = ("n_ion", "halo_sfr", "halo_xray", "whalo_sfr")
+    out = {k: torch.zeros((n, n, n), device="cuda") for k in keys}
+    hb = S.HaloBoxStruct(**{k: dp(v) for k, v in out.items()})
+    icss = S.InitialConditionsStruct(**{k: dp(v) for k, v in ics.items()})
+    lib.ComputeHaloBox.argtypes = [C.c_double] + [C.c_void_p] * 5
+    assert lib.ComputeHaloBox(z, C.byref(icss), C.byref(hc), None, None, C.byref(hb)) == 0, lib.c21cm_last_error()
+    _bind_test_halo_props(lib)
+    props = torch.zeros((nh, 12), device="cuda")
+    assert lib.test_halo_props(z, None, None, None, None, nh, dp(dev["masses"]), dp(dev["coords"]),
+                               dp(dev["star_rng"]), dp(dev["sfr_rng"]), dp(dev["xray_rng"]), dp(props)) == 0
+    torch.cuda.synchronize()
+    cell_volume = (384.0 / n) ** 3
+    for key, col in (("n_ion", 4), ("halo_sfr", 2), ("halo_xray", 3), ("whalo_sfr", 5)):
+        total = float(out[key].double().sum()) * cell_volume
+        want = float(props[:, col].double().sum())
+        assert want > 0 and total == pytest.approx(want, rel=2e-6), key
+        assert float(out[key].min()) >= 0
+    del fptr
