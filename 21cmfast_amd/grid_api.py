@@ -430,9 +430,11 @@ def brightness_grids(spec: S.BrightnessSpec, density, neutral_fraction, spin_tem
 
 def halobox_grids(spec: S.HaloBoxSpec, ics: dict, with_whalo=False, with_xray=False,
                   stream=None) -> dict:
-    """ComputeHaloBox's integrated branch on the MI355X (reference: src/py21cmfast/src/HaloBox.c:
-    302-436, map_mass.c:214-344).  Outputs live where the source density lives.
-    Returns dict(n_ion, halo_sfr[, whalo_sfr])."""
+    """ComputeHaloBox's grids on the MI355X (reference: src/py21cmfast/src/HaloBox.c:302-436,518-560,
+    map_mass.c:214-476): the integrated branch and, when ``spec.halos`` / ``spec.halo_consts`` point at a
+    catalogue (structs.halo_catalog, structs.HaloConsts), the halos deposited first
+    (``spec.skip_integral``: halos only).  Outputs live where the source density lives.
+    Returns dict(n_ion, halo_sfr[, whalo_sfr][, halo_xray][, halo_sfr_mini])."""
     ref = ics["hires_density" if spec.perturb_on_high_res else "lowres_density"]
     lo = (spec.hii_dim, spec.hii_dim, spec.hii_dim_z)
 
