@@ -55,6 +55,18 @@ for label, skip, halos in (("integral_only", False, False), ("halos_only", True,
     torch.cuda.synchronize()
     out[label + "_ms"] = round(1e3 * (time.perf_counter() - t0) / reps, 3)
     out[label + "_n_ion_sum"] = float(res["n_ion"].double().sum())
+# the same call with the catalogue in (pageable) host memory: 28 B per halo over PCIe first
+host_cat = S.halo_catalog(cat["masses"], cat["coords"], cat["star_rng"], cat["sfr_rng"], cat["xray_rng"])
+spec = with_xray(halobox_spec(n, n, False, tables), tables)
+consts = halo_consts()
+spec.halos, spec.halo_consts = C.pointer(host_cat), C.pointer(consts)
+api.halobox_grids(spec, ics, with_whalo=True, with_xray=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    api.halobox_grids(spec, ics, with_whalo=True, with_xray=True)
+torch.cuda.synchronize()
+out["halos_and_integral_host_catalogue_ms"] = round(1e3 * (time.perf_counter() - t0) / reps, 3)
 out["halo_part_ms"] = round(out["halos_and_integral_ms"] - out["integral_only_ms"], 3)
 out["halos_per_s"] = round(n_halos / (1e-3 * out["halo_part_ms"]), 0)
 # three grids x 8 cells of fp64 atomics per halo (n_ion, SFR, L_X)
