@@ -19,7 +19,9 @@ from pathlib import Path
 from . import structs as S
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib21cmfast_hip.so"
+# C21CM_LIB: another build of the same library (kernel A/B experiments, tools/build_variant.sh);
+# the default is the in-tree build next to this file.
+LIB_PATH = Path(os.environ["C21CM_LIB"]) if os.environ.get("C21CM_LIB") else _HERE / "lib21cmfast_hip.so"
 
 _lib = None
 

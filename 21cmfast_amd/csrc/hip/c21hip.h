@@ -92,6 +92,13 @@ int c21hip_split_filter_xy_shared_pair(const float *src, float *work, float *wor
                                        int filter_type, int nx, int ny, int nz, double box_len,
                                        double box_len_z, float R, float R2, int table_slot,
                                        int table_slot2, int phases, void *stream);
+/* Node tables of W(x) for the radii of one excursion-set call: when *enabled comes back 1 the
+ * passes X of these radii (c21hip_split_filter_xy2[_pair], _xy_shared[_pair]) evaluate their
+ * windows in the kernel and c21hip_window_tables need not be called; c21hip_wev_release ends it */
+int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, float R_param_b, int n_grids,
+                       const float *R, int n_R, int nx, int ny, int nz, double box_len,
+                       double box_len_z, int pair, int *enabled, void *stream);
+void c21hip_wev_release(void);
 /* W(kR) tables of one radius for c21hip_split_filter_xy2, on any stream */
 int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
                          float R_param_b, int nx, int ny, int nz, double box_len,

@@ -41,6 +41,23 @@
 #include "ms_window.h"
 #include "c21cm_abi.h"
 
+// experiment switches (tools/build_variant.sh; the defaults are the shipped configuration)
+#ifndef C21X_XPAIR_THREADS
+#define C21X_XPAIR_THREADS 512
+#endif
+#ifndef C21X_XPAIR_TWO_SETS
+#define C21X_XPAIR_TWO_SETS 0
+#endif
+#ifndef C21X_XPAIR_NOWIN
+#define C21X_XPAIR_NOWIN 0
+#endif
+#ifndef C21X_ZW_OCC       // min waves per SIMD requested for the fused pass Z (0: compiler's choice)
+#define C21X_ZW_OCC 0
+#endif
+#ifndef C21X_ZW_LATE      // 1: second grid and mask rows requested after the first transform
+#define C21X_ZW_LATE 0
+#endif
+
 namespace {
 constexpr int kBlock = 256;
 constexpr int TZ = 16;  // columns per tile (128 B of float2) for lines up to 512 points
@@ -599,6 +616,53 @@ window_table_kernel(WTableArgs t) {
     }
 }
 
+// ------------------------------------------------------------------ node tables of W(x)
+// The windows of the excursion-set loop are functions of x = kR alone: the real-space top-hat
+// (filtering.c:357-361; the SAME function for every radius) and the top-hat x exp(-r/mfp) window
+// (:80-104; one function per radius, through R/mfp).  Instead of a 3-D table of W per radius
+// (0.14 GB per window, written by one kernel and streamed by pass X: 10-14 % of the R loop's HBM
+// traffic at 512^3) pass X can interpolate W from nodes 1/4 apart held in LDS: per node
+// (W, W' h, W'' h^2/2), quintic Hermite between neighbours.  This kernel fills the node tables of
+// one call: table 0 = top-hat, tables 1.. = the exp-MFP window of each radius.  Values in double
+// exactly as filter_box evaluates them; the derivatives by 8th-order central differences with step
+// h/16 (both windows are even in x; truncation ~1e-17, rounding ~1e-13 of the envelope).
+struct WNodeArgs {
+    float *out;        // [n_tabs][n_nodes][3]
+    int n_nodes, n_tabs;
+    int first_type;    // type of table 0 (0 or 3); tables 1.. are type 3
+    const ExpMfpConsts *mfp;  // device array, one per type-3 table in table order
+};
+__device__ __forceinline__ double wnode_value(int type, const ExpMfpConsts &c, double x) {
+    x = fabs(x);
+    double sn, cs;
+    sincos(x, &sn, &cs);
+    return type == 0 ? w_tophat(x, sn, cs) : w_expmfp(c, x, sn, cs);
+}
+__global__ void __launch_bounds__(kBlock)
+window_nodes_kernel(WNodeArgs a) {
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= a.n_nodes * a.n_tabs) return;
+    const int tab = id / a.n_nodes, n = id - tab * a.n_nodes;
+    const int type = (tab == 0) ? a.first_type : 3;
+    ExpMfpConsts c{};
+    if (type == 3) c = a.mfp[a.first_type == 3 ? tab : tab - 1];
+    const double h = 0.25, s = h / 16., x = h * (double)n;
+    const double c1[4] = {4. / 5., -1. / 5., 4. / 105., -1. / 280.};
+    const double c2[4] = {8. / 5., -1. / 5., 8. / 315., -1. / 560.};
+    const double f0 = wnode_value(type, c, x);
+    double d1 = 0., d2 = -205. / 72. * f0;
+#pragma unroll
+    for (int k = 1; k <= 4; k++) {
+        const double fp = wnode_value(type, c, x + k * s), fm = wnode_value(type, c, x - k * s);
+        d1 += c1[k - 1] * (fp - fm);
+        d2 += c2[k - 1] * (fp + fm);
+    }
+    float *o = a.out + 3 * (size_t)id;
+    o[0] = (float)f0;
+    o[1] = (float)(d1 / s * h);
+    o[2] = (float)(d2 / (s * s) * h * h * 0.5);
+}
+
 // ------------------------------------------------------------------ pass X / pass Y
 // One launch covers up to two GEOMETRIES (the main block [nx][ny][nz/2] and the k_z = nz/2
 // Nyquist plane [nx][ny]) and up to two GRIDS of identical shape (density and emissivity
@@ -644,6 +708,16 @@ struct LinePassArgs {
     // tile scalar (k_y) and a column scalar (k_z), so nothing is looked up.
     int op_ex, op_ey, op_ez, op_imag;
     double op_sign, op_dkx, op_dky, op_dkz;
+    // FMODE 6 / 7 (pass X): windows evaluated IN the kernel from node tables of W(x), x = kR, held
+    // in LDS (window_nodes_kernel): no 3-D table is built, written or streamed.  wev_src[t]: the
+    // node tables staged into LDS (wev_n_nodes nodes of 3 floats each); wev_tab[radius][window]:
+    // which staged table serves (sweep member, window), -1 = sharp-k (evaluated directly).
+    const float *wev_src[3];
+    int wev_n_tabs, wev_n_nodes;
+    int wev_tab[2][2];
+    int wev_type[2];   // window type of grid 0 / grid 1 (0 top-hat, 1 sharp-k, 3 exp-MFP)
+    float wev_R[2];    // filter radius of sweep member 0 / 1
+    double wev_dkx, wev_dky, wev_dkz;
 };
 
 static inline int geo_items(const LineGeo &g) {
@@ -669,7 +743,9 @@ template <int N, int FMODE = 0>
 struct LineThreads {
     // (the loader needs N/2 = rows per sweep x row pairs per thread: 192-point lines take 256;
     //  1024 threads for 1024-point lines spill 13-38 VGPRs at the 128-register budget: DESIGN 8.1)
-    static constexpr int value = (N >= 128 && N != 192) ? 512 : 256;
+    static constexpr int value =
+        ((FMODE == 5 || FMODE == 7) && N == 512) ? C21X_XPAIR_THREADS
+                                                 : ((N >= 128 && N != 192) ? 512 : 256);
 };
 
 // the geometry of one work item, in wave-uniform registers
@@ -699,17 +775,28 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     constexpr int TZ = line_tile_cols(N);  // shadows the namespace constant: this kernel's tile
     constexpr int CPAIR = TZ / 2;          // float4 (column pairs) per row
     constexpr int RSTEP = kBlock / CPAIR;  // rows covered by one sweep of the workgroup
-    constexpr bool WIN = (FMODE == 3 || FMODE == 5);
-    constexpr bool PAIR = (FMODE == 5);
+    constexpr bool WEVAL = (FMODE == 6 || FMODE == 7);  // windows from node tables in LDS
+    constexpr bool WIN = (FMODE == 3 || (FMODE == 5 && !C21X_XPAIR_NOWIN) || WEVAL);
+    constexpr bool PAIR = (FMODE == 5 || FMODE == 7);
     constexpr int NR = PAIR ? 2 : 1;     // radii per sweep
     using LineItem = LineItemT<PAIR>;
     extern __shared__ float4 lds_raw[];
     float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ] (x 2 radii with FMODE 5)
     float2 *tw = tile + NR * N * TZ;                     // [N]
     float2 *tw_half = tw + N;                            // [N/2], N = 1024 only
+    float *wnodes = reinterpret_cast<float *>(tw_half + (N >= 1024 ? N / 2 : 0));  // WEVAL
     for (int t = threadIdx.x; t < N; t += kBlock) tw[t] = tw_global[t];
     if (N >= 1024)
         for (int t = threadIdx.x; t < N / 2; t += kBlock) tw_half[t] = tw_global[2 * t];
+    if constexpr (WEVAL) {
+        const int per = 3 * a.wev_n_nodes;
+        for (int t = threadIdx.x; t < per; t += kBlock) {
+            wnodes[t] = a.wev_src[0][t];
+            if (a.wev_n_tabs > 1) wnodes[per + t] = a.wev_src[1][t];
+            if (a.wev_n_tabs > 2) wnodes[2 * per + t] = a.wev_src[2][t];
+        }
+        __syncthreads();
+    }
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
     const int r0 = threadIdx.x / CPAIR, c4 = threadIdx.x % CPAIR;
@@ -787,7 +874,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // Two radii per sweep: ONE set.  The next tile's loads go out before the two transforms of
     // this one, which is the look-ahead two sets buy the single-radius pass; the second set only
     // cost registers there (256 VGPRs + 84 bytes of scratch; 0.95 against 0.89 ms at 512^3).
-    constexpr bool TWO_SETS = (N < 1024) && !PAIR;
+    constexpr bool TWO_SETS = (N < 1024) && (!PAIR || C21X_XPAIR_TWO_SETS);
     float4 reg_a[2 * NP], reg_b[2 * NP];
     // FMODE 3: window values of this thread's row pairs x 2 columns; `pre` is in flight ahead
     // of the member that starts a new window, `cur` serves the members after it
@@ -800,7 +887,101 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const int mi = it.npair == 2 ? (m & 1) : 0;
         return m == 0 || (a.dual && mi == 0);
     };
+    // WEVAL: window values from node tables, all in fp32 with two-float (hi + lo) steps where the
+    // reference works in double.  |k| as filter_box forms it (filtering.c:347-352: float squares
+    // summed in float, root in double): kh = sqrt_f32(ksq), kl = (ksq - kh^2) / (2 kh) with the
+    // residual from one FMA -- kh + kl is the double root to ~1e-14.  x = k R: ph = fl(kh R),
+    // e = (kh R - ph) + kl R (FMA residual), so x0 = fl(ph + e) is the reference's kR rounded to
+    // float (top-hat and sharp-k, :331,357,364) and d = (ph - x0) + e its rounding residual: the
+    // exp-MFP window takes kR in double (:83), i.e. the interpolant at x0 plus d times its slope.
+    // Quintic Hermite on nodes 1/4 apart: within 1.2e-7 of the window's envelope of the double
+    // evaluation (tools/window_interp_check.py).
+    struct KAbs {
+        float kh, kl;
+    };
+    auto k_abs = [](float kx, float ky, float kz) -> KAbs {
+        const float ksq = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), __fmul_rn(ky, ky)), __fmul_rn(kz, kz));
+        KAbs k;
+        k.kh = __builtin_amdgcn_sqrtf(ksq);
+        const float r = __fmaf_rn(-k.kh, k.kh, ksq);
+        k.kl = (k.kh > 0.f) ? __fmul_rn(r, __fmul_rn(0.5f, __builtin_amdgcn_rcpf(k.kh))) : 0.f;
+        return k;
+    };
+    auto weval_one = [&](const KAbs &k, float R, int type, const float *tab) -> float {
+        const float ph = __fmul_rn(k.kh, R);
+        const float e = __fmaf_rn(k.kl, R, __fmaf_rn(k.kh, R, -ph));
+        const float x0 = __fadd_rn(ph, e);
+        if (type == 1) return ((double)x0 * 0.413566994 > 1) ? 0.f : 1.f;
+        const float u = x0 * 4.0f;  // nodes at multiples of 1/4: exact
+        const int n = min((int)u, a.wev_n_nodes - 2);
+        const float t = u - (float)n;
+        const float *nd = tab + 3 * n;
+        const float f0 = nd[0], g0 = nd[1], q0 = nd[2], f1 = nd[3], g1 = nd[4], q1 = nd[5];
+        const float A = ((f1 - f0) - g0) - q0, B = (g1 - g0) - 2.f * q0, C = q1 - q0;
+        const float a3 = 10.f * A - 4.f * B + C, a4 = -15.f * A + 7.f * B - 2.f * C,
+                    a5 = 6.f * A - 3.f * B + C;
+        float p = fmaf(fmaf(fmaf(fmaf(fmaf(a5, t, a4), t, a3), t, q0), t, g0), t, f0);
+        if (type == 3) {
+            const float d = __fadd_rn(__fsub_rn(ph, x0), e);
+            const float dp = fmaf(fmaf(fmaf(fmaf(5.f * a5, t, 4.f * a4), t, 3.f * a3), t, 2.f * q0), t, g0);
+            p = fmaf(d * 4.0f, dp, p);
+        }
+        return p;
+    };
+    // k_x of this thread's rows (fixed for the whole kernel) -- float((double) index * dk), k_of()
+    float wev_kx[WEVAL ? NP : 1];
+    float wev_kx_half = 0.f;
+    if constexpr (WEVAL) {
+#pragma unroll
+        for (int u = 0; u < NP; u++) wev_kx[u] = (float)((double)(r0 + RSTEP * u) * a.wev_dkx);
+        wev_kx_half = (float)((double)(N / 2) * a.wev_dkx);
+    }
+    auto eval_windows = [&](const LineItem &it, int m) {
+        const int wsel = (a.dual && member_grid(it, m)) ? 1 : 0;
+        const int type = wsel ? a.wev_type[1] : a.wev_type[0];
+        const int per = 3 * a.wev_n_nodes;
+        float kyc[2], kzc[2];  // the two columns of this thread
+        if (it.filter_axis == 0) {
+            kyc[0] = kyc[1] = (float)((double)it.og * a.wev_dky);  // og <= ny/2
+            const int l0 = it.ct * TZ + 2 * c4;
+            kzc[0] = (float)((double)l0 * a.wev_dkz);
+            kzc[1] = (float)((double)(l0 + 1) * a.wev_dkz);
+        } else {
+            const int c0 = it.ct * TZ + 2 * c4;
+            kyc[0] = (float)((double)min(c0, a.n_y - c0) * a.wev_dky);
+            kyc[1] = (float)((double)min(c0 + 1, a.n_y - c0 - 1) * a.wev_dky);
+            kzc[0] = kzc[1] = (float)((double)(a.n_z / 2) * a.wev_dkz);
+        }
+        const float *tab0 = wnodes + max(wsel ? a.wev_tab[0][1] : a.wev_tab[0][0], 0) * per;
+        const float *tab1 = wnodes + max(wsel ? a.wev_tab[1][1] : a.wev_tab[1][0], 0) * per;
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            const KAbs k0 = k_abs(wev_kx[WEVAL ? u : 0], kyc[0], kzc[0]);
+            const KAbs k1 = k_abs(wev_kx[WEVAL ? u : 0], kyc[1], kzc[1]);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                const float R = rr ? a.wev_R[1] : a.wev_R[0];
+                const float *tab = rr ? tab1 : tab0;
+                (WPRE ? wpre[rr][WPRE ? u : 0] : wcur[rr][u]) =
+                    make_float2(weval_one(k0, R, type, tab), weval_one(k1, R, type, tab));
+            }
+        }
+        if (r0 == 0) {  // row N/2 (the mirror partner of row 0) belongs to the threads with r0 = 0
+            const KAbs k0 = k_abs(wev_kx_half, kyc[0], kzc[0]), k1 = k_abs(wev_kx_half, kyc[1], kzc[1]);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                const float R = rr ? a.wev_R[1] : a.wev_R[0];
+                const float *tab = rr ? tab1 : tab0;
+                (WPRE ? wpre_half[rr] : wcur_half[rr]) =
+                    make_float2(weval_one(k0, R, type, tab), weval_one(k1, R, type, tab));
+            }
+        }
+    };
     auto issue_wloads = [&](const LineItem &it, int m) {
+        if constexpr (WEVAL) {
+            eval_windows(it, m);
+            return;
+        }
         const bool second = a.dual && member_grid(it, m);
 #pragma unroll
         for (int rr = 0; rr < NR; rr++) {
@@ -956,8 +1137,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         // again -- so that the number of loads in flight is static and the compiler can wait
         // with vmcnt(n > 0) for exactly this register set instead of draining everything)
         // (a TileRef past the end still names the last tile, see next_tile)
-        if (WIN && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
+        if (WIN && !WEVAL && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
         issue_loads(reg, refill.it, refill.m);
+        // (evaluated windows: ALU + LDS work only, placed behind the loads it can hide)
+        if (WEVAL && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
 
 #pragma unroll
       for (int rr = 0; rr < NR; rr++) {
@@ -994,8 +1177,9 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         ta.valid = 1;
         ta.m = 0;
         ta.it = decode(ta.work);
-        if (WIN) issue_wloads(ta.it, 0);
+        if (WIN && !WEVAL) issue_wloads(ta.it, 0);
         issue_loads(reg_a, ta.it, 0);
+        if (WEVAL) issue_wloads(ta.it, 0);
         TileRef tb = next_tile(ta);
         if (!TWO_SETS) {  // 1024-point lines: registers for one set only
             while (true) {
@@ -1537,8 +1721,13 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
         return C21CM_MEMORY_ALLOC_ERROR;
     }
-    const size_t lds = sizeof(float2) * ((size_t)(FMODE == 5 ? 2 : 1) * N * line_tile_cols(N) + N +
-                                         (N >= 1024 ? N / 2 : 0));
+    const size_t lds = sizeof(float2) * ((size_t)((FMODE == 5 || FMODE == 7) ? 2 : 1) * N * line_tile_cols(N) +
+                                         N + (N >= 1024 ? N / 2 : 0)) +
+                       ((FMODE == 6 || FMODE == 7) ? sizeof(float) * 3 * (size_t)a.wev_n_nodes * a.wev_n_tabs : 0);
+    if (lds > 160 * 1024) {
+        c21hip_set_error("native FFT: %zu bytes of LDS for a %d-point line pass (mode %d)", lds, N, FMODE);
+        return C21CM_VALUE_ERROR;
+    }
     const int n_work = geo_items(a.g0) + (a.n_geo > 1 ? geo_items(a.g1) : 0);
     // persistent grid: as many workgroups as fit (LDS-limited), each striding over the work
     int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
@@ -1547,11 +1736,11 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
     if (per_cu > by_waves) per_cu = by_waves;
     int nblocks = 256 * per_cu;
     if (nblocks > n_work) nblocks = n_work;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static size_t attr_lds = 0;  // (the evaluated-window modes size their LDS by the node count)
+    if (lds > attr_lds) {
         (void)hipFuncSetAttribute((const void *)line_pass_kernel<N, SIGN, FMODE>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+        attr_lds = lds;
     }
     hipLaunchKernelGGL((line_pass_kernel<N, SIGN, FMODE>), dim3((unsigned)nblocks),
                        dim3(LineThreads<N, FMODE>::value), lds, stream, a, tw);
@@ -1565,6 +1754,15 @@ int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
     if (SIGN > 0 && fmode == 4) return launch_line_pass_mode<N, +1, 4>(a, stream);
     if constexpr (N <= 512)  // two radii per sweep: two tiles in LDS
         if (SIGN > 0 && fmode == 5) return launch_line_pass_mode<N, +1, 5>(a, stream);
+    if constexpr (N >= 128 && (N & (N - 1)) == 0) {  // windows evaluated in the kernel
+        if (SIGN > 0 && fmode == 6) return launch_line_pass_mode<N, +1, 6>(a, stream);
+        if constexpr (N <= 512)
+            if (SIGN > 0 && fmode == 7) return launch_line_pass_mode<N, +1, 7>(a, stream);
+    }
+    if (fmode == 6 || fmode == 7) {
+        c21hip_set_error("native FFT: evaluated windows are not built for %d-point lines", N);
+        return C21CM_VALUE_ERROR;
+    }
     return launch_line_pass_mode<N, SIGN, 0>(a, stream);
 }
 
@@ -1674,7 +1872,12 @@ __device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, co
 // TS: a third grid, the filtered x_e of the spin-temperature run, enters the barrier as
 // f_coll zeta > 1 - x_e (IonisationBox.c:1118, clip of :1091-1094).
 template <int A, bool TS, int P = 16>
-__global__ void __launch_bounds__(kBlock)
+__global__ void
+#if C21X_ZW_OCC
+__launch_bounds__(kBlock, (A == 16 && !TS) ? C21X_ZW_OCC : 1)
+#else
+__launch_bounds__(kBlock)
+#endif
 zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                  const float2 *__restrict__ twN_global) {
     constexpr int H = P * A, NZ = 2 * H, ZWL = zw_lines(P);
@@ -1695,25 +1898,26 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     const long line = (long)blk * ZWL + lw;
     float2 *L = lines + lw * LINE_LDS;
     const float2 *dm = a.d_main + line * H, *sm = a.s_main + line * H;
+    constexpr bool EARLY = (A == 16) && !C21X_ZW_LATE;
     float2 xd[A], xs[A];
 #pragma unroll
     for (int q = 0; q < A; q++) xd[q] = dm[P * q + b];
-    if (A == 16) {  // both grids in flight from the start; A = 32 has no registers to spare
+    if (EARLY) {  // both grids in flight from the start; A = 32 has no registers to spare
 #pragma unroll
         for (int q = 0; q < A; q++) xs[q] = sm[P * q + b];
     }
     const long lline = logical_line(line, a.ny, a.lb);
     const float dh = a.d_nyq[lline].x, sh = a.s_nyq[lline].x;
     unsigned char *mrow = a.first_cross + lline * NZ;
-    uchar2 old[A == 16 ? A : 1];
-    if (A == 16) {  // mask rows early too
+    uchar2 old[EARLY ? A : 1];
+    if (EARLY) {  // mask rows early too
 #pragma unroll
         for (int q = 0; q < A; q++)
             old[q] = reinterpret_cast<const uchar2 *>(mrow)[(b + P * (q / P)) + A * (q % P)];
     }
     __syncthreads();  // twiddle tables
     wave_c2r<A, P>(xd, dh, L, twH, twN, b);
-    if (A != 16) {
+    if (!EARLY) {
 #pragma unroll
         for (int q = 0; q < A; q++) xs[q] = sm[P * q + b];
     }
@@ -1753,7 +1957,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         }
         const bool i0 = floor_ionises || f0 || ((double)s0 * a.ion_eff > D0);
         const bool i1 = floor_ionises || f1 || ((double)s1 * a.ion_eff > D1);
-        uchar2 m = (A == 16) ? old[A == 16 ? q : 0] : reinterpret_cast<const uchar2 *>(mrow)[j];
+        uchar2 m = EARLY ? old[EARLY ? q : 0] : reinterpret_cast<const uchar2 *>(mrow)[j];
         const bool n0 = i0 && m.x == 0, n1 = i1 && m.y == 0;
         if (n0) m.x = (unsigned char)a.r_index;
         if (n1) m.y = (unsigned char)a.r_index;
@@ -2415,6 +2619,90 @@ static int win_tables(int table_slot, int n_grids, const int filter_type[2], flo
     return 0;
 }
 
+// ---- the prepared node-table set of one excursion-set call (c21hip_wev_prepare)
+struct WevSet {
+    bool active = false;
+    int filter[2] = {-1, -1};
+    float R_param[2] = {0.f, 0.f};
+    int nx = 0, ny = 0, nz = 0;
+    double box_len = 0, box_len_z = 0;
+    std::vector<float> R;
+    float *nodes = nullptr;  // device: [n_tabs][n_nodes][3]
+    int n_nodes = 0, n_tabs = 0;
+    int first_type = 0;      // type of table 0
+    // table of (window w, radius index r); -1: evaluated directly (sharp-k)
+    int table(int w, int r) const {
+        const int t = filter[w];
+        if (t == 1) return -1;
+        if (t == 0) return 0;
+        // type 3: tables follow the top-hat table (if any); window b's follow window a's
+        int base = (first_type == 0) ? 1 : 0;
+        if (w == 1 && filter[0] == 3) base += (int)R.size();
+        return base + r;
+    }
+    int find(float radius) const {
+        for (size_t i = 0; i < R.size(); i++)
+            if (R[i] == radius) return (int)i;
+        return -1;
+    }
+};
+WevSet g_wev;
+
+static bool wev_type_ok(int t) { return t == 0 || t == 1 || t == 3; }
+// LDS of a pass-X launch with evaluated windows (bytes)
+static size_t wev_lds(int n, bool pair, int n_tabs, int n_nodes) {
+    return sizeof(float2) * ((size_t)(pair ? 2 : 1) * n * TZ + n + (n >= 1024 ? n / 2 : 0)) +
+           sizeof(float) * 3 * (size_t)n_nodes * n_tabs;
+}
+// Fill the evaluated-window members of `a` for radii R (and R2 when pair) of the active set;
+// false: this launch cannot use them (the caller streams tables instead).
+static bool wev_use(LinePassArgs &a, int n_grids, const int filter_type[2], const float R_param[2],
+                    float R, float R2, bool pair, int nx, int ny, int nz, double box_len,
+                    double box_len_z) {
+    const WevSet &w = g_wev;
+    if (!w.active || w.nx != nx || w.ny != ny || w.nz != nz || w.box_len != box_len ||
+        w.box_len_z != box_len_z)
+        return false;
+    // a launch may carry window a alone (the x_e grid of a spin-temperature run) or both
+    if (filter_type[0] != w.filter[0] || (filter_type[0] == 3 && R_param[0] != w.R_param[0])) return false;
+    if (n_grids == 2 &&
+        (filter_type[1] != w.filter[1] || (filter_type[1] == 3 && R_param[1] != w.R_param[1])))
+        return false;
+    const int ra = w.find(R), rb = pair ? w.find(R2) : ra;
+    if (ra < 0 || rb < 0) return false;
+    // distinct tables of this launch -> staged LDS slots
+    int ids[4], n_ids = 0;
+    auto slot = [&](int id) {
+        if (id < 0) return -1;
+        for (int i = 0; i < n_ids; i++)
+            if (ids[i] == id) return i;
+        ids[n_ids] = id;
+        return n_ids++;
+    };
+    const int rr[2] = {ra, rb};
+    for (int m = 0; m < 2; m++)
+        for (int win = 0; win < 2; win++)
+            a.wev_tab[m][win] = (win < n_grids && (m == 0 || pair)) ? slot(w.table(win, rr[m])) : -1;
+    if (n_ids > 3) return false;
+    if (wev_lds(nx, pair, n_ids, w.n_nodes) > 160 * 1024) return false;
+    for (int i = 0; i < 3; i++)
+        a.wev_src[i] = w.nodes + 3 * (size_t)w.n_nodes * (i < n_ids ? ids[i] : ids[0 < n_ids ? 0 : 0]);
+    a.wev_n_tabs = n_ids > 0 ? n_ids : 1;
+    if (n_ids == 0) a.wev_src[0] = a.wev_src[1] = a.wev_src[2] = w.nodes;  // sharp-k only
+    a.wev_n_nodes = w.n_nodes;
+    a.wev_type[0] = filter_type[0];
+    a.wev_type[1] = n_grids == 2 ? filter_type[1] : filter_type[0];
+    a.wev_R[0] = R;
+    a.wev_R[1] = pair ? R2 : R;
+    a.wev_dkx = 2.0 * M_PI / box_len;
+    a.wev_dky = 2.0 * M_PI / box_len;
+    a.wev_dkz = 2.0 * M_PI / box_len_z;
+    a.dual = (n_grids == 2 && (filter_type[0] != filter_type[1] ||
+                               (filter_type[0] >= 3 && R_param[0] != R_param[1])))
+                 ? 1 : 0;
+    return true;
+}
+
 static int check_filter_request(int n_grids, int nx, int ny, int nz, const int filter_type[2],
                                 int apply) {
     if (!c21hip_native_fft_supported(nx, ny, nz)) {
@@ -2446,7 +2734,10 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     a.n_y = ny;
     a.n_z = nz;
     a.out_scale = 1.0f;
-    const int fmode = apply ? 3 : 0;
+    int fmode = apply ? 3 : 0;
+    if (fmode == 3 && filter_type[0] != 5 && wev_use(a, n_grids, filter_type, R_param, R, R, false, nx,
+                                                      ny, nz, box_len, box_len_z))
+        fmode = 6;  // windows evaluated in pass X: no table is built or read
     if (fmode == 3) {
         WinTables w;
         if ((st = win_tables(table_slot, n_grids, filter_type, R, R_param, R_star, nx, ny, nz,
@@ -2535,25 +2826,28 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
     hipStream_t stream = (hipStream_t)stream_;
     const int H = nz / 2;
     const long nlines = (long)nx * ny;
-    WinTables w, w2;
-    if ((st = win_tables(table_slot, n_grids, ft, R, rp, 0.f, nx, ny, nz, box_len, box_len_z,
-                         !tables_ready, stream, w)))
-        return st;
-    if ((st = win_tables(table_slot2, n_grids, ft, R2, rp, 0.f, nx, ny, nz, box_len, box_len_z,
-                         !tables_ready, stream, w2)))
-        return st;
     LinePassArgs a{};
     a.fp.type = -1;
     a.n_y = ny;
     a.n_z = nz;
     a.out_scale = 1.0f;
-    for (int i = 0; i < 2; i++) {
-        a.wt_main[i] = w.main[i];
-        a.wt_nyq[i] = w.nyq[i];
-        a.wt2_main[i] = w2.main[i];
-        a.wt2_nyq[i] = w2.nyq[i];
+    const bool evaluated = wev_use(a, n_grids, ft, rp, R, R2, true, nx, ny, nz, box_len, box_len_z);
+    if (!evaluated) {
+        WinTables w, w2;
+        if ((st = win_tables(table_slot, n_grids, ft, R, rp, 0.f, nx, ny, nz, box_len, box_len_z,
+                             !tables_ready, stream, w)))
+            return st;
+        if ((st = win_tables(table_slot2, n_grids, ft, R2, rp, 0.f, nx, ny, nz, box_len, box_len_z,
+                             !tables_ready, stream, w2)))
+            return st;
+        for (int i = 0; i < 2; i++) {
+            a.wt_main[i] = w.main[i];
+            a.wt_nyq[i] = w.nyq[i];
+            a.wt2_main[i] = w2.main[i];
+            a.wt2_nyq[i] = w2.nyq[i];
+        }
+        a.dual = w.dual;
     }
-    a.dual = w.dual;
     a.n_geo = 2;
     a.n_grids = n_grids;
     a.g0 = geo_x_main(ny, H, line_tile_cols(nx), split_xb_log2(nx));
@@ -2568,7 +2862,7 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
         a.g0.dst2[g] = work2[g];
         a.g1.dst2[g] = work2[g] + nlines * H;
     }
-    if ((phases & 2) && (st = dispatch_line_pass<+1>(nx, a, 5, stream))) return st;
+    if ((phases & 2) && (st = dispatch_line_pass<+1>(nx, a, evaluated ? 7 : 5, stream))) return st;
     if (!(phases & 12)) return 0;
     // ---- pass Y (in place), one launch per radius
     for (int r = 0; r < 2; r++) {
@@ -2686,6 +2980,91 @@ extern "C" int c21hip_window_tables(int table_slot, int filter_a, float R_param_
     return filter_xy(src, work, 2, nx, ny, nz, box_len, box_len_z, ft, R, rp, 1, stream_, 1,
                      table_slot);
 }
+
+// Prepare the node tables of W(x) for the radii R[0..n_R) of one excursion-set call (windows a / b
+// as in c21hip_split_filter_xy2).  *enabled = 1: passes X of these radii evaluate their windows
+// in the kernel and no 3-D window table is built or read (c21hip_window_tables becomes a no-op
+// the caller can skip); 0: not applicable here (filter types other than top-hat / sharp-k /
+// exp-MFP, line lengths without the kernel, node tables that do not fit in LDS beside the tiles,
+// or C21CM_WINDOWS=table) and the table path stays.  c21hip_wev_release() ends the set.
+extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, float R_param_b,
+                                  int n_grids, const float *R, int n_R, int nx, int ny, int nz,
+                                  double box_len, double box_len_z, int pair, int *enabled,
+                                  void *stream_) {
+    *enabled = 0;
+    g_wev.active = false;
+    const char *env = getenv("C21CM_WINDOWS");  // read per call: tests switch it
+    const int by_table = (env && env[0] == 't') ? 1 : 0;
+    if (by_table || n_R < 1 || !wev_type_ok(filter_a) || (n_grids == 2 && !wev_type_ok(filter_b)))
+        return 0;
+    // 1024-point lines keep the tables: with one register set already spilling, the evaluation costs
+    // more there than the table traffic it saves (5.07 against 4.84 ms per pass X at 1024^3)
+    static const int allow_1024 = getenv("C21CM_WINDOWS_1024") != nullptr;
+    if (nx < 128 || (nx & (nx - 1)) || nx > (allow_1024 ? 1024 : 512) ||
+        !c21hip_native_fft_supported(nx, ny, nz))
+        return 0;
+    WevSet &w = g_wev;
+    w.filter[0] = filter_a;
+    w.filter[1] = n_grids == 2 ? filter_b : filter_a;
+    w.R_param[0] = R_param_a;
+    w.R_param[1] = n_grids == 2 ? R_param_b : R_param_a;
+    w.nx = nx, w.ny = ny, w.nz = nz;
+    w.box_len = box_len, w.box_len_z = box_len_z;
+    w.R.assign(R, R + n_R);
+    float R_max = 0.f;
+    for (int i = 0; i < n_R; i++) R_max = R[i] > R_max ? R[i] : R_max;
+    const double kx = M_PI * nx / box_len, ky = M_PI * ny / box_len, kz = M_PI * nz / box_len_z;
+    const double x_max = sqrt(kx * kx + ky * ky + kz * kz) * R_max * (1. + 1e-6);
+    w.n_nodes = (int)(x_max * 4.) + 3;
+    const bool any_tophat = (w.filter[0] == 0) || (n_grids == 2 && w.filter[1] == 0);
+    const int n_mfp_windows = (w.filter[0] == 3 ? 1 : 0) + (n_grids == 2 && w.filter[1] == 3 ? 1 : 0);
+    w.first_type = any_tophat ? 0 : 3;
+    w.n_tabs = (any_tophat ? 1 : 0) + n_mfp_windows * n_R;
+    // the largest launch: one top-hat table + one exp-MFP table per window and sweep member
+    const int worst = (any_tophat ? 1 : 0) + n_mfp_windows * (pair && nx <= 512 ? 2 : 1);
+    if (worst > 3 || wev_lds(nx, pair && nx <= 512, worst > 0 ? worst : 1, w.n_nodes) > 160 * 1024)
+        return 0;
+    if (w.n_tabs == 0) {  // sharp-k only: nothing to tabulate, one dummy node table
+        w.n_tabs = 1;
+        w.first_type = 0;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    w.nodes = (float *)c21hip_ws(96, sizeof(float) * 3 * (size_t)w.n_nodes * w.n_tabs);
+    const int n_mfp = n_mfp_windows * n_R;
+    ExpMfpConsts *mfp_dev = (ExpMfpConsts *)c21hip_ws(97, sizeof(ExpMfpConsts) * (size_t)(n_mfp > 0 ? n_mfp : 1));
+    if (!w.nodes || !mfp_dev) return C21CM_MEMORY_ALLOC_ERROR;
+    if (n_mfp > 0) {
+        static std::vector<ExpMfpConsts> host;  // must outlive the asynchronous copy
+        host.resize(n_mfp);
+        int o = 0;
+        for (int win = 0; win < (n_grids == 2 ? 2 : 1); win++) {
+            if (w.filter[win] != 3) continue;
+            for (int i = 0; i < n_R; i++) {
+                FilterParams fp;
+                fill_filter(fp, 3, R[i], w.R_param[win], box_len, box_len_z);
+                host[o++] = fp.mfp;
+            }
+        }
+        if (hipMemcpyAsync(mfp_dev, host.data(), sizeof(ExpMfpConsts) * n_mfp, hipMemcpyHostToDevice,
+                           stream) != hipSuccess)
+            return C21CM_IO_ERROR;
+        if (hipStreamSynchronize(stream) != hipSuccess) return C21CM_IO_ERROR;
+    }
+    WNodeArgs a{};
+    a.out = w.nodes;
+    a.n_nodes = w.n_nodes;
+    a.n_tabs = w.n_tabs;
+    a.first_type = w.first_type;
+    a.mfp = mfp_dev;
+    const int total = w.n_nodes * w.n_tabs;
+    hipLaunchKernelGGL(window_nodes_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, stream, a);
+    LAUNCH_CHECK();
+    w.active = true;
+    *enabled = 1;
+    return 0;
+}
+extern "C" void c21hip_wev_release(void) { g_wev.active = false; }
 
 // Forward transform into the split layout: real rows (in_zstride floats, scale-and-clip on
 // load; pass lo > hi to disable the clip) -> pass Z r2c -> pass Y -> pass X, the result
@@ -3105,13 +3484,30 @@ extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, fl
         st = filter_xy_pair(a, real, pair2[0], filter_a, 0.f, b, real2, pair2[1], filter_b,
                             R_param_b, n, n, n, box_len, box_len, R, 0.9f * R, 0, 1, 1, stream_);
     }
+    if (kind == 7 || kind == 8) {  // the same passes X with the windows evaluated in the kernel
+        if (kind == 8 && n >= 1024) return C21CM_VALUE_ERROR;
+        const float radii[2] = {R, 0.9f * R};
+        int enabled = 0;
+        st = c21hip_wev_prepare(filter_a, 0.f, filter_b, R_param_b, 2, radii, kind == 8 ? 2 : 1, n, n,
+                                n, box_len, box_len, kind == 8, &enabled, stream_);
+        if (!st && !enabled) st = C21CM_VALUE_ERROR;
+        if (kind == 8) {
+            pair2[0] = (float *)c21hip_ws(92, nf * sizeof(float));
+            pair2[1] = (float *)c21hip_ws(93, nf * sizeof(float));
+            if (!pair2[0] || !pair2[1]) return C21CM_MEMORY_ALLOC_ERROR;
+        }
+    }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         return C21CM_IO_ERROR;
     for (int r = -2; r < reps && !st; r++) {  // two warm-up launches
         if (r == 0) (void)hipEventRecord(e0, stream);
-        if (kind == 0)
+        if (kind == 0 || kind == 7)
             st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 2);
+        else if (kind == 8)
+            st = filter_xy_pair(a, real, pair2[0], filter_a, 0.f, b, real2, pair2[1], filter_b,
+                                R_param_b, n, n, n, box_len, box_len, R, 0.9f * R, 0, 1, 2,
+                                stream_);
         else if (kind == 1)
             st = filter_xy(src, work, 2, n, n, n, box_len, box_len, ft, R, rp, 1, stream_, 4);
         else if (kind == 4)
@@ -3144,6 +3540,7 @@ extern "C" int c21hip_bench_pass(int kind, int n, int filter_a, int filter_b, fl
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms_out = ms / (float)reps;
+    if (kind == 7 || kind == 8) c21hip_wev_release();
     return st;
 }
 

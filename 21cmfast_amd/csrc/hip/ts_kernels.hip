@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "c21cm_grid.h"
 #include "c21cm_kappa_tables.h"
@@ -48,6 +49,12 @@ inline int grid_for(size_t work_items) {
             return C21CM_IO_ERROR;                                                      \
         }                                                                               \
     } while (0)
+
+// C21CM_TS_LOOP=v1: the round-2 shell loop (fp64 lookups) instead of the folded fp32 one
+inline bool ts_loop_v1() {
+    const char *e = getenv("C21CM_TS_LOOP");
+    return e && e[0] == 'v' && e[1] == '1';
+}
 
 __constant__ double kKappaHH[C21CM_KAPPA_NPTS] = C21CM_KAPPA_HH_VALUES;
 __constant__ double kKappaPH[C21CM_KAPPA_NPTS] = C21CM_KAPPA_PH_VALUES;
@@ -450,6 +457,208 @@ ts_accumulate_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
     }
 }
 
+// ------------------------------------------------------------------ the shell loop, round 3
+// The loop above costs ~140 instruction slots per cell and shell, nearly all of it fp64: the table
+// lookup + exp, five dependent double products per source term, three two-point interpolations of
+// the frequency integrals with per-shell scalars fetched from LDS one by one.  Everything that does
+// not depend on the cell is folded per shell ONCE per workgroup instead:
+//   c1[R] = z_edge avg_fix sfr_scale                      (Lagrangian grids: z_edge)
+//   c2[R] = c1[R] xray_scale xray_R                       (Lagrangian: z_edge xray_R 1e38)
+//   W[R][k][m] = c2[R] freq_int_k[m][R],  S[R][j] = c1[R] {starlya, lya_cont, lya_inj}[R]
+// and, the interpolation weight of a cell being the same for every shell,
+//   sum_R x_R ((f[m+1][R] - f[m][R]) ival + f[m][R]) = lo + ival (hi - lo),
+//   lo = sum_R x_R W[R][k][m],  hi = sum_R x_R W[R][k][m+1]
+// so a cell and shell cost seven fp64 FMAs.  The source term itself is a float upstream
+// (del_fcoll_Rct, :1040-1079) and is evaluated to float accuracy in fp32: bin index and weight
+// from one FMA, the table difference times the weight added to an EXACT float knot inside a
+// two-term base-2 reduction (so the argument of the hardware exp2 carries ~5e-8, not the 1e-6 a
+// float holding ln SFRD ~ -20 would), (1 + delta) exp(.) in fp32.  Against the double evaluation
+// rounded to float once that is <= 3e-7 per term, random in sign; x_e and T_k move by a few 1e-8
+// (parity bound 2e-6, tests/test_gpu_ts.py).  ~45 slots per cell and shell: the sweep is within
+// reach of the 4 B it reads (19.2 -> see DESIGN for the measured figure).  C21CM_TS_LOOP=v1
+// selects the kernels above for A/B runs.
+struct ShellLookup {
+    float gw, off;  // t = delta * gw + off,  gw = growth / width, off = -tab_min / width
+    float growth;
+};
+
+// value of the per-shell table at the cell (E-INTEGRAL: exp of the ln SFRD table) in fp32
+template <bool EXP>
+__device__ __forceinline__ float shell_table_f32(float dens, const ShellLookup &L,
+                                                 const float *__restrict__ y, float *curr_dens) {
+    const float x = __fmul_rn(dens, L.growth);
+    *curr_dens = x;
+    const float t = __fmaf_rn(dens, L.gw, L.off);
+    // the cells that define the table range sit on its first / last knot: keep the bin inside
+    // [0, NDELTA - 2] whatever the last bit of t says (upstream reads y[idx + 1] with weight 0 there)
+    const int idx = min(max((int)floorf(t), 0), C21CM_NDELTA_TABLE - 2);
+    const float ip = t - (float)idx;
+    const float y0 = y[idx], y1 = y[idx + 1];
+    const float r = __fmul_rn(ip, y1 - y0);
+    if (!EXP) return y0 + r;
+    // exp(y0 + r) = 2^n 2^f,  n = rint(y0 log2e),  f = (y0 L_hi - n) + y0 L_lo + r L_hi
+    const float L_hi = 1.44269502162933349609375f, L_lo = 1.925963033500011e-8f;
+    const float n = rintf(__fmul_rn(y0, L_hi));
+    const float f = __fmaf_rn(y0, L_hi, -n) + __fmaf_rn(y0, L_lo, __fmul_rn(r, L_hi));
+    // (n < -126 - 24: the float result is zero anyway; ldexpf handles the subnormal range)
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)fmaxf(n, -200.f));
+}
+
+// box sum of the table values of one shell (blockIdx.y), fp32 lookup, fp64 accumulation
+template <bool EXP>
+__global__ void __launch_bounds__(kBlock)
+sfrd_sum2_kernel(const float *__restrict__ filtered_density, const float *__restrict__ tables,
+                 const double *__restrict__ shell, int n_step, size_t ntot,
+                 double *__restrict__ partials) {
+    __shared__ double lds[kBlock];
+    const int R = blockIdx.y;
+    const float *tab = tables + (size_t)R * C21CM_NDELTA_TABLE;
+    const double inv_w = shell[SH_TABINVW * n_step + R];
+    ShellLookup L;
+    L.growth = (float)shell[SH_GROWTH * n_step + R];
+    L.gw = (float)(shell[SH_GROWTH * n_step + R] * inv_w);
+    L.off = (float)(-shell[SH_TABMIN * n_step + R] * inv_w);
+    const float4 *d4 = reinterpret_cast<const float4 *>(filtered_density + (size_t)R * ntot);
+    double acc = 0.;
+    const size_t n4 = ntot / 4;  // ntot % 4 == 0 (launcher)
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4;
+         i += (size_t)gridDim.x * kBlock) {
+        const float4 c = d4[i];
+        float cd;
+        const float a0 = shell_table_f32<EXP>(c.x, L, tab, &cd);
+        const float a1 = shell_table_f32<EXP>(c.y, L, tab, &cd);
+        const float a2 = shell_table_f32<EXP>(c.z, L, tab, &cd);
+        const float a3 = shell_table_f32<EXP>(c.w, L, tab, &cd);
+        // pairwise in fp32 (four values of similar size), then into the double
+        acc += (double)((a0 + a1) + (a2 + a3));
+    }
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) partials[(size_t)R * gridDim.x + blockIdx.x] = acc;
+}
+
+// LDS image of the folded per-shell constants: [n][NW] doubles then [n] ShellLookup
+constexpr int kW_STAR = 3 * C21CM_X_INT_NXHII;  // W rows: heat[14], ion[14], lya[14], then S
+constexpr int kNW = kW_STAR + 3;                 // + starlya, cont, inj
+
+template <int VEC, int MODE>  // MODE 0: Lagrangian grids, 1: ln SFRD tables, 2: dfcoll/dz tables
+__global__ void __launch_bounds__(kBlock)
+ts_accumulate2_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
+                      const float *__restrict__ grid_a, const float *__restrict__ grid_b,
+                      const float *__restrict__ tables, const double *__restrict__ dev_tab,
+                      double *__restrict__ sums, size_t ntot) {
+    extern __shared__ double sh[];
+    const int n = a.n_step;
+    double *W = sh;                                                  // [n][kNW]
+    ShellLookup *LK = reinterpret_cast<ShellLookup *>(sh + n * kNW);  // [n]
+    {
+        const double *fheat = dev_tab + SH_COUNT * n, *fion = fheat + C21CM_X_INT_NXHII * n,
+                     *flya = fion + C21CM_X_INT_NXHII * n;
+        for (int i = threadIdx.x; i < n * kNW; i += kBlock) {
+            const int R = i / kNW, j = i - R * kNW;
+            const double z_edge = dev_tab[SH_ZEDGE * n + R], xray_R = dev_tab[SH_XRAY_R * n + R];
+            double c1, c2;
+            if (MODE == 0) {
+                c1 = z_edge;
+                c2 = z_edge * xray_R * 1e38;
+            } else {
+                c1 = z_edge * dev_tab[SH_AVGFIX * n + R] * a.sfr_scale;
+                c2 = c1 * a.xray_scale * xray_R;
+            }
+            double v;
+            if (j < kW_STAR) {
+                const int k = j / C21CM_X_INT_NXHII, m = j - k * C21CM_X_INT_NXHII;
+                const double *f = k == 0 ? fheat : (k == 1 ? fion : flya);
+                v = c2 * f[m * n + R];
+            } else {
+                const int row = j == kW_STAR ? SH_STARLYA : (j == kW_STAR + 1 ? SH_CONT : SH_INJ);
+                v = c1 * dev_tab[row * n + R];
+            }
+            W[i] = v;
+        }
+        for (int R = threadIdx.x; R < n; R += kBlock) {
+            const double inv_w = dev_tab[SH_TABINVW * n + R];
+            LK[R].growth = (float)dev_tab[SH_GROWTH * n + R];
+            LK[R].gw = (float)(dev_tab[SH_GROWTH * n + R] * inv_w);
+            LK[R].off = (float)(-dev_tab[SH_TABMIN * n + R] * inv_w);
+        }
+    }
+    __syncthreads();
+    const size_t nitems = ntot / VEC;  // ntot % VEC == 0 (launcher)
+    for (size_t it = (size_t)blockIdx.x * kBlock + threadIdx.x; it < nitems;
+         it += (size_t)gridDim.x * kBlock) {
+        const auto pxe = FloatVec<VEC>::load(prev_xe, it);
+        int m[VEC];
+        double ival[VEC];
+        double lo[VEC][3], hi[VEC][3], star[VEC], cont[VEC], inj[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            // :1499-1514, float arithmetic as upstream
+            float xHII_call = pxe.v[e];
+            if (xHII_call > kXHII[C21CM_X_INT_NXHII - 1] * 0.999)
+                xHII_call = (float)(kXHII[C21CM_X_INT_NXHII - 1] * 0.999);
+            else if (xHII_call < kXHII[0])
+                xHII_call = (float)(1.001 * kXHII[0]);
+            int mm = C21CM_X_INT_NXHII - 1;
+            while (xHII_call < kXHII[mm]) mm--;
+            const float inv_diff = (float)(1. / (kXHII[mm + 1] - kXHII[mm]));
+            m[e] = mm;
+            ival[e] = (double)((xHII_call - kXHII[mm]) * inv_diff);
+#pragma unroll
+            for (int k = 0; k < 3; k++) lo[e][k] = hi[e][k] = 0.;
+            star[e] = cont[e] = inj[e] = 0.;
+        }
+        FloatVec<VEC> ga = FloatVec<VEC>::load(grid_a, (size_t)(n - 1) * nitems + it), gb = ga;
+        if (MODE == 0) gb = FloatVec<VEC>::load(grid_b, (size_t)(n - 1) * nitems + it);
+        for (int R = n; R--;) {
+            const FloatVec<VEC> ca = ga, cb = gb;
+            if (R > 0) {  // request the next (smaller) shell now
+                ga = FloatVec<VEC>::load(grid_a, (size_t)(R - 1) * nitems + it);
+                if (MODE == 0) gb = FloatVec<VEC>::load(grid_b, (size_t)(R - 1) * nitems + it);
+            }
+            const double *Wr = W + R * kNW;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                double xs, xx;  // the star-formation term / the X-ray term before their constants
+                if (MODE == 0) {
+                    xs = (double)ca.v[e];
+                    xx = (double)cb.v[e];
+                } else {
+                    float cd;
+                    const float tv = shell_table_f32<MODE == 1>(
+                        ca.v[e], LK[R], tables + (size_t)R * C21CM_NDELTA_TABLE, &cd);
+                    xs = xx = (double)__fmul_rn(1.f + cd, tv);  // del_fcoll_Rct is a float
+                }
+                const double *w = Wr + m[e];
+                if (a.use_xray_heating) {
+                    lo[e][0] = fma(xx, w[0], lo[e][0]);
+                    hi[e][0] = fma(xx, w[1], hi[e][0]);
+                }
+                lo[e][1] = fma(xx, w[C21CM_X_INT_NXHII], lo[e][1]);
+                hi[e][1] = fma(xx, w[C21CM_X_INT_NXHII + 1], hi[e][1]);
+                lo[e][2] = fma(xx, w[2 * C21CM_X_INT_NXHII], lo[e][2]);
+                hi[e][2] = fma(xx, w[2 * C21CM_X_INT_NXHII + 1], hi[e][2]);
+                star[e] = fma(xs, Wr[kW_STAR], star[e]);
+                if (a.use_lya_heating) {
+                    cont[e] = fma(xs, Wr[kW_STAR + 1], cont[e]);
+                    inj[e] = fma(xs, Wr[kW_STAR + 2], inj[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const size_t i = it * VEC + e;
+            sums[i] = lo[e][0] + ival[e] * (hi[e][0] - lo[e][0]);
+            sums[ntot + i] = lo[e][1] + ival[e] * (hi[e][1] - lo[e][1]);
+            sums[2 * ntot + i] = lo[e][2] + ival[e] * (hi[e][2] - lo[e][2]);
+            sums[3 * ntot + i] = star[e];
+            if (a.use_lya_heating) {
+                sums[4 * ntot + i] = cont[e];
+                sums[5 * ntot + i] = inj[e];
+            }
+        }
+    }
+}
+
 // Sweep 2 of 2 -- prefactors and get_Ts_fast per cell; `sums` NULL: nothing has formed yet.
 __global__ void __launch_bounds__(kBlock)
 ts_cell_kernel(c21hip_ts_args a, const float *__restrict__ density,
@@ -526,8 +735,18 @@ extern "C" int c21hip_ts_sfrd_means(const float *filtered_density, const float *
                                     void *stream) {
     int bx = grid_for(ntot);
     if (bx > 512) bx = 512;  // n_step rows of blocks fill the chip
-    hipLaunchKernelGGL(sfrd_sum_kernel, dim3(bx, n_step), dim3(kBlock), 0, (hipStream_t)stream,
-                       filtered_density, tables_dev, table_exp, dev_tab, n_step, ntot, partials);
+    const bool v2 = !ts_loop_v1() && (ntot & 3) == 0 && ((size_t)filtered_density & 15) == 0;
+    if (v2 && table_exp)
+        hipLaunchKernelGGL((sfrd_sum2_kernel<true>), dim3(bx, n_step), dim3(kBlock), 0,
+                           (hipStream_t)stream, filtered_density, tables_dev, dev_tab, n_step, ntot,
+                           partials);
+    else if (v2)
+        hipLaunchKernelGGL((sfrd_sum2_kernel<false>), dim3(bx, n_step), dim3(kBlock), 0,
+                           (hipStream_t)stream, filtered_density, tables_dev, dev_tab, n_step, ntot,
+                           partials);
+    else
+        hipLaunchKernelGGL(sfrd_sum_kernel, dim3(bx, n_step), dim3(kBlock), 0, (hipStream_t)stream,
+                           filtered_density, tables_dev, table_exp, dev_tab, n_step, ntot, partials);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(sfrd_finish_kernel, dim3(n_step), dim3(kBlock), 0, (hipStream_t)stream,
                        partials, bx, mean_sfr_zpp_dev, (double)ntot, n_step, dev_tab, ave_out_dev);
@@ -554,7 +773,24 @@ extern "C" int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, co
         auto aligned8 = [](const void *p) { return ((size_t)p & 7) == 0; };
         const bool vec2 = (ntot & 1) == 0 && aligned8(prev_xe) && aligned8(grid_a) && aligned8(grid_b);
         const int blocks = grid_for(vec2 ? ntot / 2 : ntot);
-        if (vec2)
+        const size_t lds2 = (size_t)a->n_step * (kNW * sizeof(double) + sizeof(ShellLookup));
+        if (!ts_loop_v1()) {
+            const int mode = a->lagrangian ? 0 : (a->table_exp ? 1 : 2);
+#define TS_ACC2(V, M)                                                                              \
+    hipLaunchKernelGGL((ts_accumulate2_kernel<V, M>), dim3(blocks), dim3(kBlock), lds2,            \
+                       (hipStream_t)stream, *a, prev_xe, grid_a, grid_b, tables_dev, dev_tab,      \
+                       sums_ws, ntot)
+            if (vec2) {
+                if (mode == 0) TS_ACC2(2, 0);
+                else if (mode == 1) TS_ACC2(2, 1);
+                else TS_ACC2(2, 2);
+            } else {
+                if (mode == 0) TS_ACC2(1, 0);
+                else if (mode == 1) TS_ACC2(1, 1);
+                else TS_ACC2(1, 2);
+            }
+#undef TS_ACC2
+        } else if (vec2)
             hipLaunchKernelGGL((ts_accumulate_kernel<2>), dim3(blocks), dim3(kBlock), lds,
                                (hipStream_t)stream, *a, prev_xe, grid_a, grid_b, tables_dev, dev_tab,
                                sums_ws, ntot);

@@ -326,6 +326,7 @@ typedef struct {
     long def_stride;
     int def_first, def_step, def_count;
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
+    int wev;             /* 1: this loop's passes X evaluate their windows in the kernel */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
     float *eul_xe[2];    /* dense x_e(R) of the Eulerian mask path (spin-temperature runs) */
     int sphere;          /* IONISE_ENTIRE_SPHERE: radii > 0 only record the mask, spheres follow */
@@ -652,6 +653,11 @@ static int tab_build_async(ion_ctx *c, int R_ct, int buf) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     TRY(c21hip_stream_wait_event(g_tab.aux, g_tab.ev_used[buf]));
+    /* C21CM_DIAG_SKIP_TABLES=1 (timing diagnostic, WRONG results): no table kernels after the first
+     * step -- what the R loop would cost if the windows came for free */
+    static int skip = -1;
+    if (skip < 0) skip = getenv("C21CM_DIAG_SKIP_TABLES") != NULL;
+    if (!(skip && c->tab_seq > 0))
     TRY(c21hip_window_tables(buf, s->hii_filter, 0.f, s->stars_filter, (float)s->mfp_meandens,
                              c->nx, c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_ct],
                              g_tab.aux));
@@ -721,7 +727,7 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
     tab_init();
     /* below ~64 M cells the two cross-stream waits per radius cost more than the table
      * kernel they hide (256^3: 9.5 vs 9.25 ms per call): build the tables inline there */
-    const int tab_async = g_tab.enabled && c->ntot >= ((size_t)1 << 26);
+    const int tab_async = !c->wev && g_tab.enabled && c->ntot >= ((size_t)1 << 26);
     if (tab_async) {
         if (c->tab_seq == 0) {
             /* first fused step of this call: order the side stream after whatever the
@@ -795,6 +801,19 @@ done:
 static int fused_loop(ion_ctx *c, int first, int step, int lowest, unsigned char *first_cross) {
     int status = 0;
     if (lowest < 1) lowest = 1;
+    /* Windows evaluated inside pass X from node tables of W(kR) (fft_native.hip: c21hip_wev_prepare)
+     * where the filter types and the line length allow it: then no 3-D window table is built,
+     * written or streamed for these radii (C21CM_WINDOWS=table keeps the tables). */
+    c->wev = 0;
+    {
+        float radii[C21CM_MAX_RADII];
+        int n = 0;
+        for (int R = first; R >= lowest && n < C21CM_MAX_RADII; R -= step) radii[n++] = (float)c->s->R[R];
+        if (n > 0)
+            TRY(c21hip_wev_prepare(c->s->hii_filter, 0.f, c->s->stars_filter, (float)c->s->mfp_meandens,
+                                   2, radii, n, c->nx, c->ny, c->nz, c->s->box_len, c->s->box_len_z,
+                                   c->pair_radii, &c->wev, c->stream));
+    }
     int R_a = first;
     while (R_a >= lowest) {
         const int want_b = c->pair_radii && R_a - step >= lowest;
@@ -807,6 +826,8 @@ static int fused_loop(ion_ctx *c, int first, int step, int lowest, unsigned char
         R_a = n_a;
     }
 done:
+    c21hip_wev_release();
+    c->wev = 0;
     return status;
 }
 
@@ -1321,6 +1342,19 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         const int use_mask = c.fused || c.eul_mask || c.sphere;
         int mask_pending = use_mask;
         int R_start = spec->n_radii;
+        /* Eulerian source models on the native passes: the density (and x_e) windows of every radius
+         * evaluated inside pass X (top-hat / sharp-k HII_FILTER), no window tables.  The fused
+         * Lagrangian loop prepares its own set; grids with other windows keep their tables. */
+        if (c.native && !c.fused) {
+            float radii[C21CM_MAX_RADII];
+            int n = 0, on = 0;
+            for (int R_ct = spec->n_radii - 1; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct--)
+                radii[n++] = (float)spec->R[R_ct];
+            if (n > 0)
+                TRY(c21hip_wev_prepare(spec->hii_filter, 0.f, spec->hii_filter, 0.f,
+                                       spec->use_ts_fluct ? 2 : 1, radii, n, c.nx, c.ny, c.nz,
+                                       spec->box_len, spec->box_len_z, 0, &on, stream));
+        }
         if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC) {
             int radii[C21CM_MAX_RADII], n = 0;
             for (int R_ct = spec->n_radii - 1; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct--)
@@ -1357,6 +1391,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             if (c.sphere) TRY(paint_spheres(&c, c.mask));
         }
     }
+    c21hip_wev_release();
     TRY(c21hip_event_record(ev[2], stream));
     TRY(postloop(&c, box, report));
     TRY(c21hip_event_record(ev[3], stream));
@@ -1366,6 +1401,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         report->ms_postloop = c21hip_event_elapsed_ms(ev[2], ev[3]);
     }
 done:
+    c21hip_wev_release();
     for (int i = 0; i < 4; i++) c21hip_event_destroy(ev[i]);
     return status;
 }

@@ -144,7 +144,29 @@ static int fill_Rbox_native(tf_ctx *c, const c21cm_rbox_spec *s, float *result, 
     for (int r = 0; r < s->n_R; r++)
         if (s->R[r] > s->cell_radius) filtered[n_f++] = r;
     int next = 0; /* index into filtered[] of the next table to build */
-    const int tab_async = tf_tab.ok && c->ntot >= ((size_t)1 << 26); /* see ionize_driver.c */
+    /* Top-hat / sharp-k windows on 256- and 512-point lines: evaluated inside pass X from node
+     * tables of W(kR) (fft_native.hip: c21hip_wev_prepare) -- no 3-D window table is built or read,
+     * and two radii share one pass-X sweep of the spectrum (read once, windowed and transformed
+     * twice into work / work2), as in the excursion-set loop. */
+    int wev = 0;
+    if (n_f > 0) {
+        float radii[C21CM_MAX_TS_RADII];
+        for (int k = 0; k < n_f; k++) radii[k] = (float)s->R[filtered[k]];
+        const int pair_ok = c21hip_pair_sweep_supported(c->nx);
+        TRY(c21hip_wev_prepare(s->filter_type, 0.f, s->filter_type, 0.f, 1, radii, n_f, c->nx, c->ny,
+                               c->nz, c->box_len, c->box_len_z, pair_ok, &wev, c->stream));
+    }
+    float *work2 = NULL;
+    if (wev && c21hip_pair_sweep_supported(c->nx)) {
+        static int pair = -1;
+        if (pair < 0) {
+            const char *e = getenv("C21CM_PAIR_RADII");
+            pair = (e && e[0] == '0') ? 0 : 1;
+        }
+        if (pair)
+            work2 = (float *)c21hip_ws(WS_TF_WORK2, c21hip_split_floats(c->nx, c->ny, c->nz) * sizeof(float));
+    }
+    const int tab_async = !wev && tf_tab.ok && c->ntot >= ((size_t)1 << 26); /* see ionize_driver.c */
     if (tab_async && n_f > 0) {
         TRY(c21hip_event_record(tf_tab.ev_sync, c->stream));
         TRY(c21hip_stream_wait_event(tf_tab.aux, tf_tab.ev_sync));
@@ -153,6 +175,27 @@ static int fill_Rbox_native(tf_ctx *c, const c21cm_rbox_spec *s, float *result, 
         const int apply = s->R[r] > s->cell_radius;
         const float R = (float)s->R[r];
         float *d_out = host_out ? stage_out : result + (size_t)r * c->ntot;
+        if (apply && work2 && r + 1 < s->n_R && s->R[r + 1] > s->cell_radius) {
+            /* radii r and r + 1 out of one pass-X sweep; pass Y and pass Z per radius */
+            const float R2 = (float)s->R[r + 1];
+            TRY(c21hip_split_filter_xy_shared_pair(c->unf, c->work, work2, s->filter_type, c->nx, c->ny,
+                                                   c->nz, c->box_len, c->box_len_z, R, R2, 0, 1, 2 | 4,
+                                                   c->stream));
+            TRY(c21hip_split_z_c2r_stats(c->work, d_out, c->nz, c->nx, c->ny, c->nz, s->min_value,
+                                         s->const_factor, partials + (size_t)r * stride, NULL,
+                                         c->stream));
+            if (host_out) TRY(c21hip_d2h(result + (size_t)r * c->ntot, stage_out, bytes, c->stream));
+            r++;
+            d_out = host_out ? stage_out : result + (size_t)r * c->ntot;
+            TRY(c21hip_split_filter_xy_shared_pair(c->unf, c->work, work2, s->filter_type, c->nx, c->ny,
+                                                   c->nz, c->box_len, c->box_len_z, R, R2, 0, 1, 8,
+                                                   c->stream));
+            TRY(c21hip_split_z_c2r_stats(work2, d_out, c->nz, c->nx, c->ny, c->nz, s->min_value,
+                                         s->const_factor, partials + (size_t)r * stride, NULL,
+                                         c->stream));
+            if (host_out) TRY(c21hip_d2h(result + (size_t)r * c->ntot, stage_out, bytes, c->stream));
+            continue;
+        }
         if (apply && tab_async) {
             const int k = next; /* this radius is filtered[k] */
             const int buf = k & 1;
@@ -185,6 +228,7 @@ static int fill_Rbox_native(tf_ctx *c, const c21cm_rbox_spec *s, float *result, 
     }
     TRY(c21hip_batched_stats(partials, stride, (int)nb, s->n_R, c->stats, c->stream));
 done:
+    c21hip_wev_release();
     return status;
 }
 

@@ -242,13 +242,14 @@ ION_FIELDS = ("neutral_fraction", "z_reion", "kinetic_temperature", "unnormalise
               "ionisation_rate_G12", "mean_free_path", "cumulative_recombinations")
 
 
-def ionisation_radii(so, ap, lagrangian: bool) -> int:
+def ionisation_radii(so, ap, lagrangian: bool, ionise_entire_sphere: bool = False) -> int:
     """Number of filter radii of the excursion set (setup_radii, IonisationBox.c:964-1006): the
     length of IonizedBox.unnormalised_nion[_mini] with USE_MINI_HALOS."""
     L_FACTOR = 0.620350491
     pixel = float(so.BOX_LEN) / float(so.HII_DIM)
     r_max = min(float(ap.R_BUBBLE_MAX), L_FACTOR * float(so.BOX_LEN))
-    cell_factor = 1.0 if (lagrangian and pixel < 1) else L_FACTOR
+    # setup_radii, IonisationBox.c:968-972: the unit cell factor only without IONISE_ENTIRE_SPHERE
+    cell_factor = 1.0 if (lagrangian and pixel < 1 and not ionise_entire_sphere) else L_FACTOR
     r_min = max(float(ap.R_BUBBLE_MIN), cell_factor * pixel)
     n_radii = int(math.log(r_max / r_min) / math.log(float(ap.DELTA_R_HII_FACTOR)) + 1)
     for i in range(n_radii):
@@ -294,6 +295,23 @@ class Inputs:
         return get_logspaced_redshifts(min(out_redshifts), so.ZPRIME_STEP_FACTOR, so.Z_HEAT_MAX)
 
 
+
+def required_redshifts(inputs: "Inputs", out_redshifts):
+    """_get_required_redshifts_coeval (coeval.py:971-992): the node redshifts above the lowest
+    requested one plus the requested redshifts themselves, descending and unique (float32 values,
+    as the C entry points take them).  A requested redshift that is not a node is an extra
+    snapshot computed at exactly that z; it does NOT become the next snapshot's "previous" box
+    and its halo grids do not enter the history (coeval.py:880-884).  Returns (all_redshifts,
+    set of those that are nodes)."""
+    outs = [float(np.float32(z)) for z in out_redshifts]
+    nodes = [float(np.float32(z)) for z in inputs.node_redshifts(outs)]
+    if not inputs.evolution_required:
+        allz = sorted(set(outs), reverse=True)
+        return allz, set(allz)
+    nodes = [z for z in nodes if z > min(outs)]
+    return sorted(set(nodes) | set(outs), reverse=True), set(nodes)
+
+
 def _initialise(lib, inputs: Inputs, data_path):
     """What GlobalInitializationManager does before the first Compute* call."""
     i = inputs
@@ -330,8 +348,10 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
     ``device``: a torch device string ("cuda") keeps every array in HBM (zero-copy entry points);
     None uses numpy arrays that the library stages.  ``data_path``: directory of the reference's
     data tables (py21cmfast's ``_data``).  Returns ``{redshift: {field: array}}`` for the requested
-    redshifts (fields in ``keep``; plus the scalars ``mean_f_coll`` and ``Q_HI``) and, under the key
-    ``"history"``, the global signal (z, mean dT_b, mean x_HI, mean T_s) of every node."""
+    redshifts (fields in ``keep``; plus the scalars ``mean_f_coll`` and ``Q_HI``), keyed by the
+    requested redshift as float32 -- a requested redshift between two nodes is computed AT that
+    redshift from the last node above it, like upstream -- and, under the key ``"history"``, the
+    global signal (z, mean dT_b, mean x_HI, mean T_s) of every snapshot computed."""
     lib = lib or load(require_gpu=True)
     from . import grid_api as api
 
@@ -348,7 +368,7 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
     n, nz = so.HII_DIM, int(so.NON_CUBIC_FACTOR * so.HII_DIM)
     shape = (n, n, nz)
     lagrangian, ts_on, recomb = mo.SOURCE_MODEL >= 2, bool(ao.USE_TS_FLUCT), ao.RECOMB_MODEL
-    n_radii = ionisation_radii(so, ap, lagrangian)
+    n_radii = ionisation_radii(so, ap, lagrangian, bool(ao.IONISE_ENTIRE_SPHERE))
     if device is not None:
         import torch
 
@@ -396,8 +416,8 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
         return arr, S.TsBoxStruct(**{k: fp(v) for k, v in arr.items()})
 
     out_redshifts = [float(np.float32(z)) for z in out_redshifts]
-    nodes = [float(np.float32(z)) for z in inputs.node_redshifts(out_redshifts)]
-    wanted = {min(nodes, key=lambda x, z=z: abs(x - z)): z for z in out_redshifts}
+    all_redshifts, is_node = required_redshifts(inputs, out_redshifts)
+    wanted = set(out_redshifts)
     prev_ion_arr, prev_ion = new_ion()
     prev_ts_arr, prev_ts = new_ts()
     prev_pf_arr = None
@@ -405,7 +425,7 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
     prev_means = (0.0, 0.0)
     z_halos, hboxes = [], []
     result, history = {}, []
-    for z in nodes:
+    for z in all_redshifts:
         pf_arr = {"density": new(), "velocity_z": new()}
         pf = S.PerturbedFieldStruct(**{k: fp(v) for k, v in pf_arr.items()})
         check(lib.ComputePerturbedField(z, C.byref(icss), C.byref(pf)), "ComputePerturbedField")
@@ -442,8 +462,9 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
                             setattr(srcs, k, fp(xsrc[k]))
                     srcs.mean_log10_Mcrit_LW = xsrc["mean_log10_Mcrit_LW"].ctypes.data_as(
                         C.POINTER(C.c_double))
-                z_halos.append(z)
-                hboxes.append(hist)
+                if z in is_node:  # hbox_arr grows on the nodes only (coeval.py:880-884)
+                    z_halos.append(z)
+                    hboxes.append(hist)
             ts_arr, ts = new_ts()
             check(lib.ComputeTsBox(z, prev_z, z, 0, C.byref(pf), C.byref(srcs) if srcs else None,
                                    C.byref(prev_ts), C.byref(icss), C.byref(ts)), "ComputeTsBox")
@@ -476,9 +497,10 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
                 snap["mean_f_coll_MINI"] = ion.mean_f_coll_MINI
                 snap["log10_Mturnover_ave"] = ion.log10_Mturnover_ave
                 snap["log10_Mturnover_MINI_ave"] = ion.log10_Mturnover_MINI_ave
-            result[wanted[z]] = snap
-        prev_means = (ion.mean_f_coll, ion.mean_f_coll_MINI)
-        if inputs.evolution_required:  # only then is a snapshot the next one's "previous"
+            result[z] = snap
+        if z in is_node:
+            prev_means = (ion.mean_f_coll, ion.mean_f_coll_MINI)
+        if inputs.evolution_required and z in is_node:  # only nodes are the next one's "previous"
             prev_ts_arr, prev_ts, prev_ion_arr, prev_ion, prev_pf_arr, prev_z = (
                 ts_arr, ts, ion_arr, ion, pf_arr, z)
     result["history"] = history

@@ -74,3 +74,29 @@ def test_lya_diffusion_scale():
     n_H = 0.76 * c.rho_crit0 * 0.04897 / D.M_P
     want = 3 * D.C_CMS**4 * 6.25e8**2 * n_H * 19.0 / (32 * math.pi**3 * 2.46606727e15**4 * c.H0_cgs**2 * 0.30966)
     assert r == pytest.approx(want / D.MPC_CM, rel=1e-12)
+
+
+def test_required_redshifts_insert_requested_snapshots_between_nodes():
+    """a requested redshift between two nodes is computed AT that redshift and never
+    becomes a "previous" box; two requests near one node do not overwrite each other
+    (reference: drivers/coeval.py:971-992, 880-884)."""
+    i = D.Inputs(SOURCE_MODEL=1, USE_TS_FLUCT=True, Z_HEAT_MAX=20.0, ZPRIME_STEP_FACTOR=1.1)
+    allz, nodes = D.required_redshifts(i, [12.0, 12.3, 9.0])
+    assert allz == sorted(allz, reverse=True) and len(set(allz)) == len(allz)
+    for z in (12.0, 12.3, 9.0):
+        assert float(np.float32(z)) in allz
+    assert float(np.float32(12.3)) not in nodes and float(np.float32(12.0)) not in nodes
+    # the nodes are the log-spaced ladder from the lowest request up to Z_HEAT_MAX
+    ladder = sorted(nodes, reverse=True)
+    np.testing.assert_allclose(np.diff(np.log1p(ladder)), -np.log(1.1), rtol=1e-6)
+    assert ladder[0] >= 20.0 and min(nodes) > 9.0
+    # the lowest request closes the run; it is the ladder's own end point, so the evolution up to
+    # it went through nodes only
+    assert allz[-1] == 9.0
+    # no evolution: just the requests
+    allz, nodes = D.required_redshifts(D.Inputs(SOURCE_MODEL=1), [8.0, 12.0, 8.0])
+    assert allz == [12.0, 8.0] and nodes == {12.0, 8.0}
+    # IONISE_ENTIRE_SPHERE keeps L_FACTOR x pixel as the smallest radius (IonisationBox.c:968-972)
+    so, ap = D.S.default_simulation_options(HII_DIM=64, BOX_LEN=32.0), D.S.default_astro_params()
+    assert D.ionisation_radii(so, ap, True, True) == D.ionisation_radii(so, ap, False)
+    assert D.ionisation_radii(so, ap, True, False) <= D.ionisation_radii(so, ap, True, True)
