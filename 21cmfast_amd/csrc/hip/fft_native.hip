@@ -717,6 +717,9 @@ struct LinePassArgs {
     int wev_tab[2][2];
     int wev_type[2];   // window type of grid 0 / grid 1 (0 top-hat, 1 sharp-k, 3 exp-MFP)
     float wev_R[2];    // filter radius of sweep member 0 / 1
+    // exp-MFP constants (ratio, ratio^2, ratio^3, exp(-1/ratio)) of sweep member 0 / 1: used beyond
+    // the node tables' range (x >= (wev_n_nodes - 2) / 4), where the window is evaluated directly
+    float wev_mfp[2][4];
     double wev_dkx, wev_dky, wev_dkz;
 };
 
@@ -744,7 +747,7 @@ struct LineThreads {
     // (the loader needs N/2 = rows per sweep x row pairs per thread: 192-point lines take 256;
     //  1024 threads for 1024-point lines spill 13-38 VGPRs at the 128-register budget: DESIGN 8.1)
     static constexpr int value =
-        ((FMODE == 5 || FMODE == 7) && N == 512) ? C21X_XPAIR_THREADS
+        ((FMODE == 5 || FMODE == 7 || FMODE == 9) && N == 512) ? C21X_XPAIR_THREADS
                                                  : ((N >= 128 && N != 192) ? 512 : 256);
 };
 
@@ -775,9 +778,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     constexpr int TZ = line_tile_cols(N);  // shadows the namespace constant: this kernel's tile
     constexpr int CPAIR = TZ / 2;          // float4 (column pairs) per row
     constexpr int RSTEP = kBlock / CPAIR;  // rows covered by one sweep of the workgroup
-    constexpr bool WEVAL = (FMODE == 6 || FMODE == 7);  // windows from node tables in LDS
+    constexpr bool WEVAL = (FMODE >= 6 && FMODE <= 9);  // windows from node tables in LDS
+    constexpr bool WDIRECT = (FMODE == 8 || FMODE == 9);  // ... and directly beyond the tables' range
     constexpr bool WIN = (FMODE == 3 || (FMODE == 5 && !C21X_XPAIR_NOWIN) || WEVAL);
-    constexpr bool PAIR = (FMODE == 5 || FMODE == 7);
+    constexpr bool PAIR = (FMODE == 5 || FMODE == 7 || FMODE == 9);
     constexpr int NR = PAIR ? 2 : 1;     // radii per sweep
     using LineItem = LineItemT<PAIR>;
     extern __shared__ float4 lds_raw[];
@@ -907,13 +911,46 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         k.kl = (k.kh > 0.f) ? __fmul_rn(r, __fmul_rn(0.5f, __builtin_amdgcn_rcpf(k.kh))) : 0.f;
         return k;
     };
-    auto weval_one = [&](const KAbs &k, float R, int type, const float *tab) -> float {
+    // Beyond the node tables (large radii of the spin-temperature shells; the tables are sized by
+    // the LDS left beside the tiles) the windows are evaluated directly in fp32: Cody-Waite
+    // reduction of the float kR with two FMAs, minimax sin / cos, W = 3 (sin - x cos) / x^3 (and
+    // the exp-MFP form with sin / cos rotated through the residual d).  There |W| < 3 / x^2 and
+    // the result is within 5e-7 of that envelope (tools/window_interp_check.py).
+    auto weval_direct = [&](float x0, float d, int type, int rr) -> float {
+        const float n = rintf(x0 * 0.6366197723675814f);
+        float r = __fmaf_rn(-n, 1.5707963705062866f, x0);
+        r = __fmaf_rn(-n, -4.371138828673793e-08f, r);
+        const float z = r * r;
+        const float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+        const float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z,
+                                  4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+        const int q = (int)n & 3;
+        const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+        float sn = (q & 2) ? -ss : ss, cs = ((q + 1) & 2) ? -cc : cc;
+        const float inv = __builtin_amdgcn_rcpf(x0);
+        if (type == 0) return 3.f * (sn - x0 * cs) * (inv * inv) * inv;
+        const float s0 = sn, c0 = cs;
+        sn = fmaf(d, c0, s0);
+        cs = fmaf(-d, s0, c0);
+        const float ra = rr ? a.wev_mfp[1][0] : a.wev_mfp[0][0], r2 = rr ? a.wev_mfp[1][1] : a.wev_mfp[0][1],
+                    r3 = rr ? a.wev_mfp[1][2] : a.wev_mfp[0][2], et = rr ? a.wev_mfp[1][3] : a.wev_mfp[0][3];
+        const float xx = fmaf(2.f * x0, d, x0 * x0);
+        float f = fmaf(xx, r2, fmaf(2.f, ra, 1.f)) * ra * cs;
+        f = fmaf(fmaf(xx, r2 - r3, ra + 1.f) * sn, __builtin_amdgcn_rcpf(x0 + d), f);
+        f = fmaf(f, et, -2.f * r2);
+        const float dd = fmaf(xx, r2, 1.f);
+        return f * (-3.f * ra * __builtin_amdgcn_rcpf(dd * dd));
+    };
+    auto weval_one = [&](const KAbs &k, float R, int type, const float *tab, int rr) -> float {
         const float ph = __fmul_rn(k.kh, R);
         const float e = __fmaf_rn(k.kl, R, __fmaf_rn(k.kh, R, -ph));
         const float x0 = __fadd_rn(ph, e);
         if (type == 1) return ((double)x0 * 0.413566994 > 1) ? 0.f : 1.f;
         const float u = x0 * 4.0f;  // nodes at multiples of 1/4: exact
-        const int n = min((int)u, a.wev_n_nodes - 2);
+        if constexpr (WDIRECT)
+            if (u >= (float)(a.wev_n_nodes - 2))
+                return weval_direct(x0, __fadd_rn(__fsub_rn(ph, x0), e), type, rr);
+        const int n = WDIRECT ? (int)u : min((int)u, a.wev_n_nodes - 2);
         const float t = u - (float)n;
         const float *nd = tab + 3 * n;
         const float f0 = nd[0], g0 = nd[1], q0 = nd[2], f1 = nd[3], g1 = nd[4], q1 = nd[5];
@@ -963,7 +1000,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 const float R = rr ? a.wev_R[1] : a.wev_R[0];
                 const float *tab = rr ? tab1 : tab0;
                 (WPRE ? wpre[rr][WPRE ? u : 0] : wcur[rr][u]) =
-                    make_float2(weval_one(k0, R, type, tab), weval_one(k1, R, type, tab));
+                    make_float2(weval_one(k0, R, type, tab, rr), weval_one(k1, R, type, tab, rr));
             }
         }
         if (r0 == 0) {  // row N/2 (the mirror partner of row 0) belongs to the threads with r0 = 0
@@ -973,7 +1010,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 const float R = rr ? a.wev_R[1] : a.wev_R[0];
                 const float *tab = rr ? tab1 : tab0;
                 (WPRE ? wpre_half[rr] : wcur_half[rr]) =
-                    make_float2(weval_one(k0, R, type, tab), weval_one(k1, R, type, tab));
+                    make_float2(weval_one(k0, R, type, tab, rr), weval_one(k1, R, type, tab, rr));
             }
         }
     };
@@ -1721,9 +1758,9 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
         c21hip_set_error("native FFT: twiddle table allocation failed");
         return C21CM_MEMORY_ALLOC_ERROR;
     }
-    const size_t lds = sizeof(float2) * ((size_t)((FMODE == 5 || FMODE == 7) ? 2 : 1) * N * line_tile_cols(N) +
-                                         N + (N >= 1024 ? N / 2 : 0)) +
-                       ((FMODE == 6 || FMODE == 7) ? sizeof(float) * 3 * (size_t)a.wev_n_nodes * a.wev_n_tabs : 0);
+    const size_t lds = sizeof(float2) * ((size_t)((FMODE == 5 || FMODE == 7 || FMODE == 9) ? 2 : 1) * N *
+                                             line_tile_cols(N) + N + (N >= 1024 ? N / 2 : 0)) +
+                       ((FMODE >= 6 && FMODE <= 9) ? sizeof(float) * 3 * (size_t)a.wev_n_nodes * a.wev_n_tabs : 0);
     if (lds > 160 * 1024) {
         c21hip_set_error("native FFT: %zu bytes of LDS for a %d-point line pass (mode %d)", lds, N, FMODE);
         return C21CM_VALUE_ERROR;
@@ -1756,10 +1793,13 @@ int launch_line_pass(const LinePassArgs &a, int fmode, hipStream_t stream) {
         if (SIGN > 0 && fmode == 5) return launch_line_pass_mode<N, +1, 5>(a, stream);
     if constexpr (N >= 128 && (N & (N - 1)) == 0) {  // windows evaluated in the kernel
         if (SIGN > 0 && fmode == 6) return launch_line_pass_mode<N, +1, 6>(a, stream);
-        if constexpr (N <= 512)
+        if (SIGN > 0 && fmode == 8) return launch_line_pass_mode<N, +1, 8>(a, stream);
+        if constexpr (N <= 512) {
             if (SIGN > 0 && fmode == 7) return launch_line_pass_mode<N, +1, 7>(a, stream);
+            if (SIGN > 0 && fmode == 9) return launch_line_pass_mode<N, +1, 9>(a, stream);
+        }
     }
-    if (fmode == 6 || fmode == 7) {
+    if (fmode >= 6 && fmode <= 9) {
         c21hip_set_error("native FFT: evaluated windows are not built for %d-point lines", N);
         return C21CM_VALUE_ERROR;
     }
@@ -2629,6 +2669,7 @@ struct WevSet {
     std::vector<float> R;
     float *nodes = nullptr;  // device: [n_tabs][n_nodes][3]
     int n_nodes = 0, n_tabs = 0;
+    bool covers = true;      // the node tables reach the largest kR of the set (else: direct beyond)
     int first_type = 0;      // type of table 0
     // table of (window w, radius index r); -1: evaluated directly (sharp-k)
     int table(int w, int r) const {
@@ -2694,6 +2735,16 @@ static bool wev_use(LinePassArgs &a, int n_grids, const int filter_type[2], cons
     a.wev_type[1] = n_grids == 2 ? filter_type[1] : filter_type[0];
     a.wev_R[0] = R;
     a.wev_R[1] = pair ? R2 : R;
+    for (int m = 0; m < 2; m++) {  // the exp-MFP window's constants per sweep member (filtering.c:320-322)
+        const int win = (filter_type[0] == 3) ? 0 : ((n_grids == 2 && filter_type[1] == 3) ? 1 : -1);
+        if (win < 0) break;
+        const float Rm = m ? a.wev_R[1] : a.wev_R[0];
+        const double ratio = (double)R_param[win] / (double)Rm;
+        a.wev_mfp[m][0] = (float)ratio;
+        a.wev_mfp[m][1] = (float)(ratio * ratio);
+        a.wev_mfp[m][2] = (float)(ratio * ratio * ratio);
+        a.wev_mfp[m][3] = (float)exp((double)(-Rm / R_param[win]));
+    }
     a.wev_dkx = 2.0 * M_PI / box_len;
     a.wev_dky = 2.0 * M_PI / box_len;
     a.wev_dkz = 2.0 * M_PI / box_len_z;
@@ -2737,7 +2788,7 @@ static int filter_xy(const float *const split_src[2], float *const split_work[2]
     int fmode = apply ? 3 : 0;
     if (fmode == 3 && filter_type[0] != 5 && wev_use(a, n_grids, filter_type, R_param, R, R, false, nx,
                                                       ny, nz, box_len, box_len_z))
-        fmode = 6;  // windows evaluated in pass X: no table is built or read
+        fmode = g_wev.covers ? 6 : 8;  // windows evaluated in pass X: no table is built or read
     if (fmode == 3) {
         WinTables w;
         if ((st = win_tables(table_slot, n_grids, filter_type, R, R_param, R_star, nx, ny, nz,
@@ -2862,7 +2913,9 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
         a.g0.dst2[g] = work2[g];
         a.g1.dst2[g] = work2[g] + nlines * H;
     }
-    if ((phases & 2) && (st = dispatch_line_pass<+1>(nx, a, evaluated ? 7 : 5, stream))) return st;
+    if ((phases & 2) &&
+        (st = dispatch_line_pass<+1>(nx, a, evaluated ? (g_wev.covers ? 7 : 9) : 5, stream)))
+        return st;
     if (!(phases & 12)) return 0;
     // ---- pass Y (in place), one launch per radius
     for (int r = 0; r < 2; r++) {
@@ -3022,8 +3075,18 @@ extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, f
     w.n_tabs = (any_tophat ? 1 : 0) + n_mfp_windows * n_R;
     // the largest launch: one top-hat table + one exp-MFP table per window and sweep member
     const int worst = (any_tophat ? 1 : 0) + n_mfp_windows * (pair && nx <= 512 ? 2 : 1);
-    if (worst > 3 || wev_lds(nx, pair && nx <= 512, worst > 0 ? worst : 1, w.n_nodes) > 160 * 1024)
-        return 0;
+    if (worst > 3 || n_mfp_windows > 1) return 0;
+    {   // node tables as long as the LDS beside the tiles allows (the windows beyond their range
+        // are evaluated directly); at least x = 32
+        const size_t fixed = wev_lds(nx, pair && nx <= 512, 0, 0);
+        const size_t room = fixed < 158 * 1024 ? 158 * 1024 - fixed : 0;
+        const int cap = (int)(room / (sizeof(float) * 3 * (size_t)(worst > 0 ? worst : 1)));
+        if (cap < 32 * 4 + 3) return 0;
+        const int need = w.n_nodes;
+        if (w.n_nodes > cap) w.n_nodes = cap;
+        if (w.n_nodes > 4096) w.n_nodes = 4096;
+        w.covers = (w.n_nodes == need);
+    }
     if (w.n_tabs == 0) {  // sharp-k only: nothing to tabulate, one dummy node table
         w.n_tabs = 1;
         w.first_type = 0;

@@ -659,6 +659,151 @@ ts_accumulate2_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
     }
 }
 
+// ---- table modes, third version: everything a shell needs sits in LDS -- the 400-knot tables of
+// all shells (64 KB for 40), the folded frequency-integral weights as (w[m], w[m+1]) pairs (one
+// 16-byte read per integral) -- so a workgroup is 1024 threads, one per CU (16 waves: the loop is
+// issue-bound, not occupancy-bound, at ~40 slots per cell and shell); two cells per thread with the
+// lookup written on 2-vectors so that the compiler emits packed fp32 instructions for both cells.
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kAccBlock = 1024;
+constexpr int kWP = 3 * C21CM_X_INT_NXHII;  // (w[m], w[m+1]) pairs per shell: heat, ion, lya
+
+template <int MODE>  // 1: ln SFRD tables (exp), 2: dfcoll/dz tables
+__global__ void __launch_bounds__(kAccBlock)
+ts_accumulate3_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
+                      const float *__restrict__ grid_a, const float *__restrict__ tables,
+                      const double *__restrict__ dev_tab, double *__restrict__ sums, size_t ntot) {
+    extern __shared__ double sh[];
+    const int n = a.n_step;
+    double2 *WP = reinterpret_cast<double2 *>(sh);                    // [n][kWP]
+    double *SS = sh + 2 * (size_t)n * kWP;                            // [n][3]: starlya, cont, inj
+    ShellLookup *LK = reinterpret_cast<ShellLookup *>(SS + 3 * n);    // [n]
+    float *TAB = reinterpret_cast<float *>(LK + n);                   // [n][NDELTA + 1]
+    constexpr int TS = C21CM_NDELTA_TABLE + 1;  // odd row pitch; one slack float per table
+    {
+        const double *fheat = dev_tab + SH_COUNT * n, *fion = fheat + C21CM_X_INT_NXHII * n,
+                     *flya = fion + C21CM_X_INT_NXHII * n;
+        for (int i = threadIdx.x; i < n * kWP; i += kAccBlock) {
+            const int R = i / kWP, j = i - R * kWP;
+            const double c1 = dev_tab[SH_ZEDGE * n + R] * dev_tab[SH_AVGFIX * n + R] * a.sfr_scale;
+            const double c2 = c1 * a.xray_scale * dev_tab[SH_XRAY_R * n + R];
+            const int k = j / C21CM_X_INT_NXHII, m = j - k * C21CM_X_INT_NXHII;
+            const double *f = k == 0 ? fheat : (k == 1 ? fion : flya);
+            const int m1 = min(m + 1, C21CM_X_INT_NXHII - 1);  // (m <= NXHII - 2 for every cell)
+            WP[i] = make_double2(c2 * f[m * n + R], c2 * f[m1 * n + R]);
+        }
+        for (int i = threadIdx.x; i < 3 * n; i += kAccBlock) {
+            const int R = i / 3, j = i - 3 * R;
+            const double c1 = dev_tab[SH_ZEDGE * n + R] * dev_tab[SH_AVGFIX * n + R] * a.sfr_scale;
+            const int row = j == 0 ? SH_STARLYA : (j == 1 ? SH_CONT : SH_INJ);
+            SS[i] = c1 * dev_tab[row * n + R];
+        }
+        for (int R = threadIdx.x; R < n; R += kAccBlock) {
+            const double inv_w = dev_tab[SH_TABINVW * n + R];
+            LK[R].growth = (float)dev_tab[SH_GROWTH * n + R];
+            LK[R].gw = (float)(dev_tab[SH_GROWTH * n + R] * inv_w);
+            LK[R].off = (float)(-dev_tab[SH_TABMIN * n + R] * inv_w);
+        }
+        for (int i = threadIdx.x; i < n * TS; i += kAccBlock) {
+            const int R = i / TS, j = i - R * TS;
+            TAB[i] = j < C21CM_NDELTA_TABLE ? tables[(size_t)R * C21CM_NDELTA_TABLE + j] : 0.f;
+        }
+    }
+    __syncthreads();
+    const size_t nitems = ntot / 2;  // ntot even (launcher)
+    const float2 *ga2 = reinterpret_cast<const float2 *>(grid_a);
+    for (size_t it = (size_t)blockIdx.x * kAccBlock + threadIdx.x; it < nitems;
+         it += (size_t)gridDim.x * kAccBlock) {
+        const float2 pxe = reinterpret_cast<const float2 *>(prev_xe)[it];
+        const float pxv[2] = {pxe.x, pxe.y};
+        int m[2];
+        double ival[2];
+        double lo[2][3], hi[2][3], star[2], cont[2], inj[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            // :1499-1514, float arithmetic as upstream
+            float xHII_call = pxv[e];
+            if (xHII_call > kXHII[C21CM_X_INT_NXHII - 1] * 0.999)
+                xHII_call = (float)(kXHII[C21CM_X_INT_NXHII - 1] * 0.999);
+            else if (xHII_call < kXHII[0])
+                xHII_call = (float)(1.001 * kXHII[0]);
+            int mm = C21CM_X_INT_NXHII - 1;
+            while (xHII_call < kXHII[mm]) mm--;
+            const float inv_diff = (float)(1. / (kXHII[mm + 1] - kXHII[mm]));
+            m[e] = mm;
+            ival[e] = (double)((xHII_call - kXHII[mm]) * inv_diff);
+#pragma unroll
+            for (int k = 0; k < 3; k++) lo[e][k] = hi[e][k] = 0.;
+            star[e] = cont[e] = inj[e] = 0.;
+        }
+        float2 g = ga2[(size_t)(n - 1) * nitems + it];
+        for (int R = n; R--;) {
+            const float2 c = g;
+            if (R > 0) g = ga2[(size_t)(R - 1) * nitems + it];  // the next (smaller) shell
+            const ShellLookup L = LK[R];
+            const float *y = TAB + R * TS;
+            const v2f d = {c.x, c.y};
+            const v2f x = d * L.growth;
+            const v2f t = __builtin_elementwise_fma(d, (v2f){L.gw, L.gw}, (v2f){L.off, L.off});
+            const int i0 = min(max((int)floorf(t.x), 0), C21CM_NDELTA_TABLE - 2);
+            const int i1 = min(max((int)floorf(t.y), 0), C21CM_NDELTA_TABLE - 2);
+            const v2f ip = t - (v2f){(float)i0, (float)i1};
+            const v2f y0 = {y[i0], y[i1]}, y1 = {y[i0 + 1], y[i1 + 1]};
+            const v2f r = ip * (y1 - y0);
+            v2f tv;
+            if (MODE == 1) {
+                const float L_hi = 1.44269502162933349609375f, L_lo = 1.925963033500011e-8f;
+                const v2f w = y0 * L_hi;
+                const v2f nn = {rintf(w.x), rintf(w.y)};
+                const v2f f = __builtin_elementwise_fma(y0, (v2f){L_hi, L_hi}, -nn) +
+                              __builtin_elementwise_fma(y0, (v2f){L_lo, L_lo}, r * L_hi);
+                tv.x = ldexpf(__builtin_amdgcn_exp2f(f.x), (int)fmaxf(nn.x, -200.f));
+                tv.y = ldexpf(__builtin_amdgcn_exp2f(f.y), (int)fmaxf(nn.y, -200.f));
+            } else {
+                tv = y0 + r;
+            }
+            const v2f sf = (x + 1.0f) * tv;  // del_fcoll_Rct is a float upstream
+            const double xs[2] = {(double)sf.x, (double)sf.y};
+            const double2 *wr = WP + R * kWP;
+            const double *sr = SS + 3 * R;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                if (a.use_xray_heating) {
+                    const double2 w0 = wr[m[e]];
+                    lo[e][0] = fma(xs[e], w0.x, lo[e][0]);
+                    hi[e][0] = fma(xs[e], w0.y, hi[e][0]);
+                }
+                const double2 w1 = wr[C21CM_X_INT_NXHII + m[e]], w2 = wr[2 * C21CM_X_INT_NXHII + m[e]];
+                lo[e][1] = fma(xs[e], w1.x, lo[e][1]);
+                hi[e][1] = fma(xs[e], w1.y, hi[e][1]);
+                lo[e][2] = fma(xs[e], w2.x, lo[e][2]);
+                hi[e][2] = fma(xs[e], w2.y, hi[e][2]);
+                star[e] = fma(xs[e], sr[0], star[e]);
+                if (a.use_lya_heating) {
+                    cont[e] = fma(xs[e], sr[1], cont[e]);
+                    inj[e] = fma(xs[e], sr[2], inj[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const size_t i = it * 2 + e;
+            sums[i] = lo[e][0] + ival[e] * (hi[e][0] - lo[e][0]);
+            sums[ntot + i] = lo[e][1] + ival[e] * (hi[e][1] - lo[e][1]);
+            sums[2 * ntot + i] = lo[e][2] + ival[e] * (hi[e][2] - lo[e][2]);
+            sums[3 * ntot + i] = star[e];
+            if (a.use_lya_heating) {
+                sums[4 * ntot + i] = cont[e];
+                sums[5 * ntot + i] = inj[e];
+            }
+        }
+    }
+}
+inline size_t ts_acc3_lds(int n) {
+    return (size_t)n * (kWP * sizeof(double2) + 3 * sizeof(double) + sizeof(ShellLookup) +
+                        (C21CM_NDELTA_TABLE + 1) * sizeof(float));
+}
+
 // Sweep 2 of 2 -- prefactors and get_Ts_fast per cell; `sums` NULL: nothing has formed yet.
 __global__ void __launch_bounds__(kBlock)
 ts_cell_kernel(c21hip_ts_args a, const float *__restrict__ density,
@@ -774,7 +919,28 @@ extern "C" int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, co
         const bool vec2 = (ntot & 1) == 0 && aligned8(prev_xe) && aligned8(grid_a) && aligned8(grid_b);
         const int blocks = grid_for(vec2 ? ntot / 2 : ntot);
         const size_t lds2 = (size_t)a->n_step * (kNW * sizeof(double) + sizeof(ShellLookup));
-        if (!ts_loop_v1()) {
+        const char *loop_env = getenv("C21CM_TS_LOOP");
+        const bool v3 = !ts_loop_v1() && !(loop_env && loop_env[0] == 'v' && loop_env[1] == '2') &&
+                        vec2 && !a->lagrangian && ts_acc3_lds(a->n_step) <= 160 * 1024;
+        if (v3) {
+            const size_t lds3 = ts_acc3_lds(a->n_step);
+            static size_t attr3 = 0;
+            if (lds3 > attr3) {
+                (void)hipFuncSetAttribute((const void *)ts_accumulate3_kernel<1>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                (void)hipFuncSetAttribute((const void *)ts_accumulate3_kernel<2>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                attr3 = lds3;
+            }
+            int nb = (int)((ntot / 2 + kAccBlock - 1) / kAccBlock);
+            if (nb > 256) nb = 256;  // one 1024-thread workgroup per CU
+            if (a->table_exp)
+                hipLaunchKernelGGL((ts_accumulate3_kernel<1>), dim3(nb), dim3(kAccBlock), lds3,
+                                   (hipStream_t)stream, *a, prev_xe, grid_a, tables_dev, dev_tab, sums_ws, ntot);
+            else
+                hipLaunchKernelGGL((ts_accumulate3_kernel<2>), dim3(nb), dim3(kAccBlock), lds3,
+                                   (hipStream_t)stream, *a, prev_xe, grid_a, tables_dev, dev_tab, sums_ws, ntot);
+        } else if (!ts_loop_v1()) {
             const int mode = a->lagrangian ? 0 : (a->table_exp ? 1 : 2);
 #define TS_ACC2(V, M)                                                                              \
     hipLaunchKernelGGL((ts_accumulate2_kernel<V, M>), dim3(blocks), dim3(kBlock), lds2,            \

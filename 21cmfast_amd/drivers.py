@@ -336,7 +336,7 @@ def _initialise(lib, inputs: Inputs, data_path):
 
 def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, lib=None,
                keep=("density", "velocity_z", "neutral_fraction", "z_reion", "brightness_temp") + TS_FIELDS,
-               progress=None, halo_catalogs=None):
+               progress=None, halo_catalogs=None, inspect=None):
     """Evolve boxes through the library's entry points, mirroring ``run_coeval``: initial
     conditions once, then from the highest node redshift down: PerturbedField -> [HaloBox ->
     XraySourceBox ->] [TsBox ->] IonizedBox -> BrightnessTemp, every snapshot receiving the
@@ -351,7 +351,9 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
     redshifts (fields in ``keep``; plus the scalars ``mean_f_coll`` and ``Q_HI``), keyed by the
     requested redshift as float32 -- a requested redshift between two nodes is computed AT that
     redshift from the last node above it, like upstream -- and, under the key ``"history"``, the
-    global signal (z, mean dT_b, mean x_HI, mean T_s) of every snapshot computed."""
+    global signal (z, mean dT_b, mean x_HI, mean T_s) of every snapshot computed.
+    ``inspect(z, ctx)``: test hook called after every snapshot with the structs its
+    ComputeIonizedBox call was given (``ctx["new_ion"]()`` allocates another output box)."""
     lib = lib or load(require_gpu=True)
     from . import grid_api as api
 
@@ -489,6 +491,10 @@ def run_coeval(inputs: Inputs, out_redshifts, *, data_path=None, device=None, li
                         mean(ts_arr["spin_temperature"]) if ts_on else float("nan")))
         if progress:
             progress(history[-1])
+        if inspect:  # test hook: the structs of this snapshot's ComputeIonizedBox call, before they age
+            inspect(z, dict(prev_z=prev_z, pf=pf, prev_pf=prev_pf, prev_ion=prev_ion, ts=ts, hb=hb,
+                            icss=icss, ion=ion, ion_arr=ion_arr, ts_arr=ts_arr, pf_arr=pf_arr,
+                            new_ion=new_ion))
         if z in wanted:
             boxes = {**pf_arr, **hb_arr, **ts_arr, **ion_arr, **bt_arr}
             snap = {k: boxes[k] for k in keep if k in boxes}

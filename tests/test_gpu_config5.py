@@ -1,0 +1,132 @@
+"""BASELINE.json config 5 -- "Full coeval z = [12, 10, 8, 6] with USE_TS_FLUCT spin-temperature box,
+HII_DIM = 512" -- as a test: the whole evolution IC -> [PerturbedField -> TsBox -> IonizedBox ->
+BrightnessTemp] x 84 node redshifts from Z_HEAT_MAX = 35 (ZPRIME_STEP_FACTOR = 1.02, the reference's
+default; drivers/coeval.py:560-890) through the drop-in entry points on arrays resident in HBM, at
+the configuration's own grid (HII_DIM = 512, DIM = 1024: 4.3 GB per high-resolution field).
+
+No oracle runs at this size; like config 4 (test_gpu_ionize.py::test_config4_...) the run is held
+to size-independent properties:
+  * every output finite, x_HI in [0, 1], T_k, T_s > 0;
+  * the global history behaves like reionisation: x_HI falls monotonically once sources form, the mean x_e and T_k of
+    the neutral gas rise, the global 21-cm signal is in absorption (< -50 mK) at z = 12, still in
+    absorption but weaker by z = 10, and the box is more than half ionised by z = 6;
+  * same seed, same universe: a second evolution on the same node ladder reproduces the z = 12 boxes (the
+    deposit's fp64 atomics may reorder: a few per cent of the cells differ in their last float bits);
+  * the sharded R loop of the last snapshot's ComputeIonizedBox (world = 2, emulated transport) is
+    bit-identical to the single pass (IonisationBox.c:1531-1588 is order independent).
+The per-entry-point timings of the same evolution are recorded by tools/time_coeval_ts.py
+(profiles/r03_config5_timing.json)."""
+
+import ctypes as C
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+D = importlib.import_module("21cmfast_amd.drivers")
+S = importlib.import_module("21cmfast_amd.structs")
+DATA = Path(__file__).parent / "golden" / "reference" / "_data"
+
+
+def test_config5_coeval_with_spin_temperature_512(gpu_lib, monkeypatch):
+    import torch
+
+    api = importlib.import_module("21cmfast_amd.grid_api")
+    dist = importlib.import_module("21cmfast_amd.distributed")
+    monkeypatch.setenv("C21CM_IC_RNG", "philox")  # the device generator: the test is about the chain
+    n = 512
+    common = dict(HII_DIM=n, DIM=2 * n, BOX_LEN=1.5 * n, SOURCE_MODEL=1, USE_TS_FLUCT=True,
+                  USE_LYA_HEATING=False, HII_FILTER=0, USE_EXP_FILTER=False, CELL_RECOMB=False,
+                  R_BUBBLE_MAX=30.0, ZPRIME_STEP_FACTOR=1.02, Z_HEAT_MAX=35.0, N_THREADS=16)
+    zs = [12.0, 10.0, 8.0, 6.0]
+    keep = ("neutral_fraction", "brightness_temp", "spin_temperature", "kinetic_temp_neutral",
+            "xray_ionised_fraction", "density")
+    shard_check = {}
+
+    def inspect(z, ctx):
+        if z != 6.0:
+            return
+        # the same ComputeIonizedBox call, R loop sharded over an emulated world of 2
+        lib = gpu_lib
+        world = 2
+        n_radii = D.ionisation_radii(S.default_simulation_options(**{k: common[k] for k in ("HII_DIM", "DIM", "BOX_LEN")}),
+                                     S.default_astro_params(R_BUBBLE_MAX=common["R_BUBBLE_MAX"]), False)
+        owner = dist.owner_rank(n_radii, world)
+        mailbox = torch.zeros(world * (n**3 // 8 + 64) + 8 * n**3, dtype=torch.uint8, device="cuda")
+        monkeypatch.setenv("C21CM_SHARD_BCAST", "0")  # the ranks run one after the other: no broadcast
+        try:
+            for rank in [r for r in range(world) if r != owner] + [owner]:
+                api.shard_emulate(rank, world, mailbox)
+                arr, box = ctx["new_ion"]()
+                st = lib.ComputeIonizedBox(z, ctx["prev_z"], C.byref(ctx["pf"]), C.byref(ctx["prev_pf"]),
+                                           C.byref(ctx["prev_ion"]), C.byref(ctx["ts"]), C.byref(ctx["hb"]),
+                                           C.byref(ctx["icss"]), C.byref(box))
+                assert st == 0, lib.c21cm_last_error()
+                if rank == owner:
+                    shard_check["xH"] = torch.equal(arr["neutral_fraction"], ctx["ion_arr"]["neutral_fraction"])
+                    shard_check["zre"] = torch.equal(arr["z_reion"], ctx["ion_arr"]["z_reion"])
+        finally:
+            api.shard_finalize()
+            monkeypatch.delenv("C21CM_SHARD_BCAST")
+
+    res = D.run_coeval(D.Inputs(random_seed=2026, **common), zs, data_path=DATA, device="cuda",
+                       lib=gpu_lib, keep=keep, inspect=inspect)
+    hist = np.array(res["history"])  # z, <dT_b>, <x_HI>, <T_s>
+    assert len(hist) >= 84
+    assert np.all(np.isfinite(hist))
+    # (before the first sources the residual electrons still recombine: x_HI creeps UP by ~1e-6 a step)
+    assert np.all(np.diff(hist[:, 2]) <= 2e-6), "x_HI must fall monotonically once sources form"
+    assert np.all(np.diff(hist[hist[:, 0] < 15.0, 2]) < 0)
+    glob = {}
+    for z in zs:
+        snap = res[z]
+        for k in keep:
+            a = snap[k]
+            assert bool(torch.isfinite(a).all()), (z, k)
+        x = snap["neutral_fraction"]
+        assert float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+        assert float(snap["kinetic_temp_neutral"].min()) > 0 and float(snap["spin_temperature"].min()) > 0
+        glob[z] = dict(xH=float(x.double().mean()), Tb=float(snap["brightness_temp"].double().mean()),
+                       Tk=float(snap["kinetic_temp_neutral"].double().mean()),
+                       xe=float(snap["xray_ionised_fraction"].double().mean()))
+    print("config 5 globals:", glob)
+    assert glob[12.0]["xH"] > glob[10.0]["xH"] > glob[8.0]["xH"] > glob[6.0]["xH"]
+    assert glob[12.0]["xH"] > 0.9 and glob[6.0]["xH"] < 0.5
+    assert glob[12.0]["Tk"] < glob[10.0]["Tk"] < glob[8.0]["Tk"] < glob[6.0]["Tk"]
+    assert glob[12.0]["xe"] < glob[10.0]["xe"] < glob[8.0]["xe"] < glob[6.0]["xe"]
+    assert glob[12.0]["Tb"] < -50.0 and glob[12.0]["Tb"] < glob[10.0]["Tb"]
+    assert abs(glob[6.0]["Tb"]) < 30.0
+    assert shard_check == {"xH": True, "zre": True}, shard_check
+    # ---- same seed, same universe: the same ladder of node redshifts again, stopped at z = 12
+    z12 = {k: res[12.0][k].clone() for k in ("neutral_fraction", "kinetic_temp_neutral", "density")}
+    del res
+    torch.cuda.empty_cache()
+
+    class Reached(Exception):
+        pass
+
+    again = {}
+
+    def stop_at_12(z, ctx):
+        if z == 12.0:
+            again.update(neutral_fraction=ctx["ion_arr"]["neutral_fraction"],
+                         kinetic_temp_neutral=ctx["ts_arr"]["kinetic_temp_neutral"],
+                         density=ctx["pf_arr"]["density"])
+            raise Reached
+
+    with pytest.raises(Reached):
+        D.run_coeval(D.Inputs(random_seed=2026, **common), zs, data_path=DATA, device="cuda",
+                     lib=gpu_lib, keep=keep, inspect=stop_at_12)
+    for k, a in z12.items():
+        b = again[k]
+        differ = float((a != b).float().mean())
+        worst = float((a - b).abs().max()) / float(a.abs().max())
+        print(f"rerun {k}: {differ:.2e} of the cells differ, by at most {worst:.2e} of the field's maximum")
+        # not bit for bit: the fp64 atomics of the mass deposit reorder, a density's last float bit
+        # flips in a few cells per snapshot and 50 snapshots of evolution carry that along
+        assert differ <= 0.1 and worst <= 2e-6, (k, differ, worst)
+    del again, z12
+    torch.cuda.empty_cache()
+    gpu_lib.c21cm_release_device_cache()

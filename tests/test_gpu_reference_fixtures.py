@@ -114,7 +114,9 @@ def test_philox_option_is_another_realisation(gpu_lib, api, monkeypatch):
 # simple: E-INTEGRAL, no-mdz: CONST-ION-EFF, fixed_halogrids: L-INTEGRAL (HaloBox -> IonizedBox);
 # all with HII_FILTER = real-space top-hat, USE_EXP_FILTER = CELL_RECOMB = False, R_BUBBLE_MAX = 15,
 # N_THREADS = 2 (reference: tests/produce_integration_test_data.py:48-63,83-90,168-173).
-COEVAL_SOURCE = {"simple": 1, "no-mdz": 0, "fixed_halogrids": 2}
+# fftw_wisdom: the options of `simple` with USE_FFTW_WISDOM (:251) -- accepted and ignored here, and
+# upstream's own transform results do not depend on the planner's choice beyond round-off
+COEVAL_SOURCE = {"simple": 1, "no-mdz": 0, "fixed_halogrids": 2, "fftw_wisdom": 1}
 
 
 def run_coeval_abi(lib, api, tmp_path, name):
@@ -124,7 +126,7 @@ def run_coeval_abi(lib, api, tmp_path, name):
     ses = Session(lib, tmp_path, HII_DIM=RP.HII_DIM, DIM=RP.DIM, BOX_LEN=RP.BOX_LEN,
                   N_THREADS=2, ZPRIME_STEP_FACTOR=1.04, SOURCE_MODEL=COEVAL_SOURCE[name],
                   HII_FILTER=0, USE_EXP_FILTER=False, CELL_RECOMB=False, R_BUBBLE_MAX=15.0,
-                  USE_UPPER_STELLAR_TURNOVER=False)
+                  USE_UPPER_STELLAR_TURNOVER=False, USE_FFTW_WISDOM=(name == "fftw_wisdom"))
     spec = S.IcsSpec(dim=RP.DIM, dim_z=RP.DIM, hii_dim=RP.HII_DIM, hii_dim_z=RP.HII_DIM,
                      perturb_algorithm=2)
     ics = api.new_ics_arrays(spec)

@@ -114,7 +114,7 @@ def check_ionization(name, density, xh, z_reion, oracle, cp):
     assert bt["mean"] == pytest.approx(f["lightcone/global_brightness_temp"][-1], rel=1e-3)
 
 
-@pytest.mark.parametrize("name,source_model", [("simple", 1), ("no-mdz", 0)])
+@pytest.mark.parametrize("name,source_model", [("simple", 1), ("no-mdz", 0), ("fftw_wisdom", 1)])
 def test_oracle_ionized_box_reproduces_reference_fixture(oracle, pkg, fields, tmp_path, name,
                                                          source_model):
     _, pf = fields

@@ -71,3 +71,73 @@ if __name__ == "__main__":
         ex = expmfp(x0.astype(ld), ratio).astype(np.float64)
         e = np.abs(interp32(tab, x0, h).astype(np.float64) - ex)
         print(f"exp-MFP ratio {ratio:7.3f}: max |err| {e.max():.3e} (max |W| {np.abs(ex).max():.3f})")
+
+
+# ---- direct fp32 evaluation beyond the node tables (weval_one, x >= X_SWITCH) ----------------
+def sincos32(x):
+    """fp32 sin / cos as the kernel forms them: n = rint(x 2/pi), two-constant Cody-Waite reduction
+    with FMA (emulated in float64 then rounded: an FMA rounds once), cephes minimax kernels."""
+    f32 = np.float32
+    x = x.astype(f32)
+    n = np.rint(x * f32(0.6366197723675814)).astype(f32)
+    hi, lo = f32(1.5707963705062866), f32(-4.371138828673793e-08)
+    r = (x.astype(np.float64) - n.astype(np.float64) * np.float64(hi)).astype(f32)  # fma
+    r = (r.astype(np.float64) - n.astype(np.float64) * np.float64(lo)).astype(f32)  # fma
+    z = (r * r).astype(f32)
+    s = ((f32(-1.9515295891e-4) * z + f32(8.3321608736e-3)) * z + f32(-1.6666654611e-1)).astype(f32)
+    s = (s * z * r + r).astype(f32)
+    c = ((f32(2.443315711809948e-5) * z + f32(-1.388731625493765e-3)) * z + f32(4.166664568298827e-2)).astype(f32)
+    c = (c * z * z - f32(0.5) * z + f32(1.0)).astype(f32)
+    q = n.astype(np.int64) & 3
+    sn = np.where(q == 0, s, np.where(q == 1, c, np.where(q == 2, -s, -c))).astype(f32)
+    cs = np.where(q == 0, c, np.where(q == 1, -s, np.where(q == 2, -c, s))).astype(f32)
+    return sn, cs
+
+
+def tophat_direct32(x0):
+    f32 = np.float32
+    x = x0.astype(f32)
+    sn, cs = sincos32(x)
+    inv = (f32(1) / x).astype(f32)
+    return (f32(3) * (sn - x * cs).astype(f32) * (inv * inv).astype(f32) * inv).astype(f32)
+
+
+def expmfp_direct32(x0, d, ratio):
+    """x = x0 + d (d: the rounding residual of kR); constants rounded to float."""
+    f32 = np.float32
+    ratio64 = np.float64(ratio)
+    e = np.exp(-1 / ratio64)
+    r, r2, r3, et = f32(ratio64), f32(ratio64**2), f32(ratio64**3), f32(e)
+    x = x0.astype(f32)
+    s0, c0 = sincos32(x)
+    sn = (s0 + d * c0).astype(f32)
+    cs = (c0 - d * s0).astype(f32)
+    xx = (x * x + f32(2) * x * d).astype(f32)  # (x0 + d)^2 to first order
+    f = ((xx * r2 + (f32(2) * r + f32(1))) * r * cs).astype(f32)
+    f = (f + (xx * (r2 - r3) + (r + f32(1))) * sn / (x + d)).astype(f32)
+    f = (f * et - f32(2) * r2).astype(f32)
+    dd = (xx * r2 + f32(1)).astype(f32)
+    return (f * (f32(-3) * r / (dd * dd))).astype(f32)
+
+
+def check_direct():
+    rng = np.random.default_rng(2)
+    x0 = rng.uniform(12, 2000, 1000000).astype(np.float32)
+    env = 3 / x0.astype(np.float64) ** 2
+    err = np.abs(tophat_direct32(x0).astype(np.float64) - tophat(x0.astype(ld)).astype(np.float64)) / env
+    print(f"top-hat direct fp32, x in [12, 2000]: max |err| / envelope {err.max():.3e}, rms {np.sqrt((err**2).mean()):.3e}")
+    for ratio in (27.4, 2.548, 0.671, 0.05):
+        xd = rng.uniform(12, 2000, 400000)
+        x0 = xd.astype(np.float32)
+        d = (xd - x0.astype(np.float64)).astype(np.float32)
+        ex = expmfp(xd.astype(ld), ratio).astype(np.float64)
+        got = expmfp_direct32(x0, d, ratio).astype(np.float64)
+        # envelope: the running maximum of |W| towards larger x
+        o = np.argsort(xd)
+        envr = np.maximum.accumulate(np.abs(ex[o])[::-1])[::-1]
+        e = np.abs(got - ex)[o] / envr
+        print(f"exp-MFP direct fp32 ratio {ratio:6.3f}: max |err| / envelope {e.max():.3e}, rms {np.sqrt((e**2).mean()):.3e}")
+
+
+if __name__ == "__main__":
+    check_direct()
