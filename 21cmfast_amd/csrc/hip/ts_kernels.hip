@@ -911,6 +911,28 @@ extern "C" int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, co
         return C21CM_VALUE_ERROR;
     }
     if (!a->no_light && !a->sums_ready) {
+        int st = c21hip_ts_shell_loop(a, prev_xe, grid_a, grid_b, tables_dev, dev_tab, sums_ws, ntot,
+                                      stream);
+        if (st) return st;
+    }
+    const int blocks = grid_for(ntot);
+    hipLaunchKernelGGL(ts_cell_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, *a, density,
+                       prev_Ts, prev_Tk, prev_xe, a->no_light ? nullptr : sums_ws, lya_dEC_dev,
+                       lya_dEI_dev, Ts_out, Tk_out, xe_out, ntot, partials, flag_dev);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ts_finish_kernel, dim3(6), dim3(kBlock), 0, (hipStream_t)stream, partials,
+                       blocks, sums_out_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// The shell loop alone: the six sums of every cell into sums_ws ([6][ntot] doubles)
+extern "C" int c21hip_ts_shell_loop(const c21hip_ts_args *a, const float *prev_xe,
+                                    const float *grid_a, const float *grid_b,
+                                    const float *tables_dev, const double *dev_tab, double *sums_ws,
+                                    size_t ntot, void *stream) {
+    const size_t lds = c21hip_ts_table_doubles(a->n_step) * sizeof(double);
+    {
         // two cells per thread (8-byte loads) when the arrays allow it.  Measured at 512^3, 40
         // shells, SFRD tables: 19.1 ms with one or two cells per thread (78 / 102 VGPRs), 25.6 ms
         // with four (170 VGPRs): the loop is bound by its ~140 instruction slots per cell and shell
@@ -966,14 +988,6 @@ extern "C" int c21hip_ts_cells(const c21hip_ts_args *a, const float *density, co
                                sums_ws, ntot);
         LAUNCH_CHECK();
     }
-    const int blocks = grid_for(ntot);
-    hipLaunchKernelGGL(ts_cell_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, *a, density,
-                       prev_Ts, prev_Tk, prev_xe, a->no_light ? nullptr : sums_ws, lya_dEC_dev,
-                       lya_dEI_dev, Ts_out, Tk_out, xe_out, ntot, partials, flag_dev);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(ts_finish_kernel, dim3(6), dim3(kBlock), 0, (hipStream_t)stream, partials,
-                       blocks, sums_out_dev);
-    LAUNCH_CHECK();
     return 0;
 }
 
@@ -1317,6 +1331,80 @@ extern "C" int c21hip_ts_accumulate_grids_mini(const c21hip_ts_args *a, const fl
     hipLaunchKernelGGL(ts_accumulate_grids_mini_kernel, dim3(grid_for(ntot)), dim3(kBlock), lds,
                        (hipStream_t)stream, *a, lw_scale, prev_xe, sfr, xray, sfr_mini, sfr_lw,
                        sfr_mini_lw, dev_tab, mini_shell_dev, sums_ws, J_21_LW, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- sharded shell sums: slabs of the partial sums to / from the exchange buffers ---------------
+// pack: out[(p * rows + k) * maxlen + i] = sums[k * ntot + c0(p) + i] for every peer p != rank
+// (as double or rounded to float); combine: the complete sums of this rank's slab, ranks added in
+// rank order (own partial from `sums`, the others from the receive buffer, same layout as pack).
+namespace {
+__device__ __forceinline__ size_t slab_begin(size_t ntot, int world, int r) {
+    return (ntot / 4 * (size_t)r / (size_t)world) * 4;  // multiples of 4 cells; slab world ends at ntot
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+ts_pack_slabs_kernel(const double *__restrict__ sums, size_t ntot, int world, int rank, int rows,
+                     size_t maxlen, T *__restrict__ out) {
+    const int p = blockIdx.y;  // peer slot: ranks other than `rank` in ascending order
+    const int peer = p < rank ? p : p + 1;
+    const size_t c0 = slab_begin(ntot, world, peer);
+    const size_t len = (peer + 1 == world ? ntot : slab_begin(ntot, world, peer + 1)) - c0;
+    for (int k = 0; k < rows; k++)
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock)
+            out[((size_t)p * rows + k) * maxlen + i] = (T)sums[(size_t)k * ntot + c0 + i];
+}
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+ts_combine_slab_kernel(const double *__restrict__ sums, size_t ntot, int world, int rank, int rows,
+                       size_t maxlen, const T *__restrict__ recv, double *__restrict__ out) {
+    const size_t c0 = slab_begin(ntot, world, rank);
+    const size_t len = (rank + 1 == world ? ntot : slab_begin(ntot, world, rank + 1)) - c0;
+    for (int k = 0; k < rows; k++)
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
+            double acc = 0.;
+            for (int r = 0; r < world; r++) {
+                if (r == rank) {
+                    const double own = sums[(size_t)k * ntot + c0 + i];
+                    acc += sizeof(T) == 4 ? (double)(float)own : own;  // every partial in one precision
+                } else {
+                    const int p = r < rank ? r : r - 1;
+                    acc += (double)recv[((size_t)p * rows + k) * maxlen + i];
+                }
+            }
+            out[(size_t)k * len + i] = acc;
+        }
+}
+}  // namespace
+
+extern "C" size_t c21hip_ts_slab_begin(size_t ntot, int world, int r) {
+    return r >= world ? ntot : (ntot / 4 * (size_t)r / (size_t)world) * 4;
+}
+extern "C" int c21hip_ts_pack_slabs(const double *sums, size_t ntot, int world, int rank, int rows,
+                                    size_t maxlen, int as_float, void *out, void *stream) {
+    if (world < 2) return 0;
+    const dim3 grid(512, (unsigned)(world - 1));
+    if (as_float)
+        hipLaunchKernelGGL((ts_pack_slabs_kernel<float>), grid, dim3(kBlock), 0, (hipStream_t)stream, sums,
+                           ntot, world, rank, rows, maxlen, (float *)out);
+    else
+        hipLaunchKernelGGL((ts_pack_slabs_kernel<double>), grid, dim3(kBlock), 0, (hipStream_t)stream, sums,
+                           ntot, world, rank, rows, maxlen, (double *)out);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int c21hip_ts_combine_slab(const double *sums, size_t ntot, int world, int rank, int rows,
+                                      size_t maxlen, int as_float, const void *recv, double *out,
+                                      void *stream) {
+    if (as_float)
+        hipLaunchKernelGGL((ts_combine_slab_kernel<float>), dim3(1024), dim3(kBlock), 0,
+                           (hipStream_t)stream, sums, ntot, world, rank, rows, maxlen,
+                           (const float *)recv, out);
+    else
+        hipLaunchKernelGGL((ts_combine_slab_kernel<double>), dim3(1024), dim3(kBlock), 0,
+                           (hipStream_t)stream, sums, ntot, world, rank, rows, maxlen,
+                           (const double *)recv, out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -566,7 +566,9 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         const char *e = getenv("C21CM_SHARD"), *b = getenv("C21CM_SHARD_BCAST");
         /* (a USE_MINI_HALOS run keeps one f_coll history slice per radius: every rank runs the
          * whole R loop) */
-        if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && !(e && e[0] == '0') && !mini)
+        /* (C21CM_SHARD_TS=force: also on a one-rank communicator -- the plumbing test of a 1-GPU box) */
+    if (c21cm_shard_info(&srank, &sworld) == 0 && (sworld > 1 || (e && e[0] == 'f')) &&
+        !(e && e[0] == '0') && !mini)
             st = c21cm_ionize_sharded(s, perturbed_field, previous_ionize_box, spin_temp, halos,
                                       box, NULL, !(b && b[0] == '0'), NULL);
         else
@@ -707,10 +709,94 @@ static int box_mean(const float *v, size_t n, double *mean) {
  * the filtered density) and the Lagrangian ones (XraySourceBox grids), with interpolation tables;
  * USE_MINI_HALOS: E-INTEGRAL (2-D tables, the Lyman-Werner grid) and source grids
  * (XraySourceBox.filtered_sfr_mini [+ the LW copies]); J_21_LW out. */
+/* ---- sharding of ComputeTsBox over the ranks of a node ----------------------
+ * The N_STEP_TS shells are independent until their sums meet in the cell (SpinTemperatureBox.c:
+ * 1541-1784 is linear in the shells), so they are dealt round-robin like the radii of the
+ * excursion set: rank r takes shells n-1-r, n-1-r-world, ...  Each rank filters the density at
+ * ITS shells' radii only (the costly part: one pass X/Y/Z per shell), builds their tables, takes
+ * their box means and runs the shell loop over them: six partial sums per cell.  One exchange
+ * (reduce-scatter by cell slabs: every rank ends up with the COMPLETE sums of N / world cells), the
+ * temperature update on that slab, one all-gather of the three output boxes.  ts_shard_* below are
+ * the two compute phases; shard_rccl.c carries the exchange. */
+enum { TS_RUN_ALL = 0, TS_RUN_SHARD_SUMS = 1, TS_RUN_SHARD_FINISH = 2 };
+typedef struct {
+    int mode, rank, world;
+    double *sums;        /* SHARD_SUMS: out [6][N]; SHARD_FINISH: in [6][ncell] (device) */
+    size_t cell0, ncell; /* SHARD_FINISH */
+    int n_rows;          /* out: rows of `sums` in use (4, or 6 with USE_LYA_HEATING) */
+} ts_shard_args;
+
+static int ts_box_run(float redshift, float prev_redshift, float perturbed_field_redshift,
+                      PerturbedField *perturbed_field, XraySourceBox *source_box,
+                      TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp,
+                      ts_shard_args *sh);
+
 int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
                  PerturbedField *perturbed_field, XraySourceBox *source_box,
                  TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp) {
     (void)cleanup;
+    /* one process per GPU with a communicator (c21cm_shard_init): shells dealt over the ranks,
+     * every rank returns the full boxes (C21CM_SHARD_TS=0 keeps the replicated computation) */
+    int srank = 0, sworld = 1;
+    const char *e = getenv("C21CM_SHARD_TS");
+    if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && !(e && e[0] == '0') &&
+        c21cm_ts_shardable(redshift, perturbed_field, previous_spin_temp, this_spin_temp))
+        return c21cm_ts_box_sharded(redshift, prev_redshift, perturbed_field_redshift,
+                                    perturbed_field, previous_spin_temp, this_spin_temp);
+    ts_shard_args all = {TS_RUN_ALL, 0, 1, NULL, 0, 0, 0};
+    return ts_box_run(redshift, prev_redshift, perturbed_field_redshift, perturbed_field, source_box,
+                      previous_spin_temp, ini_boxes, this_spin_temp, &all);
+}
+
+/* the shells of `rank` (descending), as c21cm_ts_box_shard_sums deals them */
+int c21cm_ts_shard_shells(int n_step, int rank, int world, int *idx) {
+    int n = 0;
+    for (int r = n_step - 1 - rank; r >= 0; r -= world) idx[n++] = r;
+    return n;
+}
+
+/* 1: this call can be sharded (Eulerian table models on device arrays, below Z_HEAT_MAX, no
+ * mini-halos) */
+int c21cm_ts_shardable(float redshift, const PerturbedField *pf, const TsBox *prev, const TsBox *out) {
+    if (!simulation_options_global || !astro_options_global || !matter_options_global) return 0;
+    if (redshift >= simulation_options_global->Z_HEAT_MAX || astro_options_global->USE_MINI_HALOS) return 0;
+    const int model = matter_options_global->SOURCE_MODEL;
+    if (!(model == C21CM_SOURCE_E_INTEGRAL || model == C21CM_SOURCE_CONST_ION_EFF)) return 0;
+    return pf && pf->density && prev && prev->xray_ionised_fraction && out && out->spin_temperature &&
+           c21hip_is_device_ptr(pf->density) && c21hip_is_device_ptr(prev->xray_ionised_fraction) &&
+           c21hip_is_device_ptr(prev->spin_temperature) && c21hip_is_device_ptr(prev->kinetic_temp_neutral) &&
+           c21hip_is_device_ptr(out->spin_temperature) && c21hip_is_device_ptr(out->kinetic_temp_neutral) &&
+           c21hip_is_device_ptr(out->xray_ionised_fraction);
+}
+
+/* phase 1 of rank `rank` of `world`: partial sums of its shells into sums_dev ([6][N] doubles on the
+ * device; *n_rows of them in use) */
+int c21cm_ts_box_shard_sums(float redshift, float prev_redshift, float perturbed_field_redshift,
+                            PerturbedField *perturbed_field, TsBox *previous_spin_temp, int rank,
+                            int world, double *sums_dev, int *n_rows) {
+    ts_shard_args sh = {TS_RUN_SHARD_SUMS, rank, world, sums_dev, 0, 0, 0};
+    TsBox out = *previous_spin_temp; /* not written in this phase */
+    int st = ts_box_run(redshift, prev_redshift, perturbed_field_redshift, perturbed_field, NULL,
+                        previous_spin_temp, NULL, &out, &sh);
+    if (n_rows) *n_rows = sh.n_rows;
+    return st;
+}
+
+/* phase 2: the temperature update of cells [cell0, cell0 + ncell) from their complete sums
+ * ([n_rows][ncell] doubles on the device, rows as phase 1 wrote them) */
+int c21cm_ts_box_shard_finish(float redshift, float prev_redshift, float perturbed_field_redshift,
+                              PerturbedField *perturbed_field, TsBox *previous_spin_temp,
+                              const double *slab_sums, size_t cell0, size_t ncell,
+                              TsBox *this_spin_temp) {
+    ts_shard_args sh = {TS_RUN_SHARD_FINISH, 0, 1, (double *)slab_sums, cell0, ncell, 0};
+    return ts_box_run(redshift, prev_redshift, perturbed_field_redshift, perturbed_field, NULL,
+                      previous_spin_temp, NULL, this_spin_temp, &sh);
+}
+
+static int ts_box_run(float redshift, float prev_redshift, float perturbed_field_redshift,
+                      PerturbedField *perturbed_field, XraySourceBox *source_box,
+                      TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp,
+                      ts_shard_args *sh) {
     int st = require_globals("ComputeTsBox", 1);
     if (st) return st;
     if (!perturbed_field || !perturbed_field->density || !this_spin_temp) {
@@ -768,6 +854,14 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
     double t_mark = timing ? wall_seconds() : 0., t_prep = 0., t_tables = 0.;
     if ((st = c21_ts_prepare_shells(redshift, prev_redshift, perturbed_field_redshift, spec, tab)))
         goto done;
+    if (sh->mode == TS_RUN_SHARD_FINISH) {
+        /* the slab's temperature update from the ranks' combined sums: host tables only */
+        if ((st = c21_ts_prepare_tables(x_e_ave_p, spec, tab))) goto done;
+        st = c21cm_ts_cells_from_sums(spec, perturbed_field->density, previous_spin_temp, sh->sums,
+                                      sh->cell0, sh->ncell, this_spin_temp, NULL);
+        if (!st) this_spin_temp->Q_HI = tab->Q_HI;
+        goto done;
+    }
     if (spec->source_mode != C21CM_TS_SRC_GRIDS) {
         /* prepare_filter_boxes + fill_Rbox_table (:1453-1463): delNL0[R] stays on the device.  The
          * loop needs only the shells' radii, so it runs on a helper thread while this one builds
@@ -780,6 +874,14 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
         r->filter_type = ao->HEAT_FILTER;
         r->n_R = tab->n_step;
         for (int i = 0; i < tab->n_step; i++) r->R[i] = tab->R_values[i];
+        int local[C21CM_MAX_TS_RADII], n_local = tab->n_step;
+        if (sh->mode == TS_RUN_SHARD_SUMS) { /* this rank's shells only, in ascending radius */
+            int desc[C21CM_MAX_TS_RADII];
+            n_local = c21cm_ts_shard_shells(tab->n_step, sh->rank, sh->world, desc);
+            for (int i = 0; i < n_local; i++) local[i] = desc[n_local - 1 - i];
+            r->n_R = n_local;
+            for (int i = 0; i < n_local; i++) r->R[i] = tab->R_values[local[i]];
+        }
         r->cell_radius = 0.620350491 * so->BOX_LEN / (float)so->HII_DIM; /* physconst.l_factor */
         r->min_value = -1;
         r->const_factor = 1. / dicke(perturbed_field_redshift);
@@ -845,6 +947,45 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
         if (st) goto done;
         if ((st = job.status)) goto done;
         if (timing) t_mark = wall_seconds();
+        if (sh->mode == TS_RUN_SHARD_SUMS) {
+            sh->n_rows = spec->use_lya_heating ? 6 : 4;
+            if (spec->no_light) { /* nothing has formed: every partial sum is zero */
+                st = c21hip_memset(sh->sums, 0, (size_t)sh->n_rows * ntot * sizeof(double), NULL);
+                if (!st) st = c21hip_sync(NULL);
+                goto done;
+            }
+            /* the per-shell members of spec / tab compacted to this rank's shells */
+            double *fq = (double *)malloc(3 * (size_t)C21CM_X_INT_NXHII * n_local * sizeof(double));
+            if (!fq) {
+                st = C21CM_MEMORY_ALLOC_ERROR;
+                goto done;
+            }
+            const int nf = tab->n_step;
+            for (int k = 0; k < 3; k++) {
+                const double *src = k == 0 ? spec->freq_int_heat : (k == 1 ? spec->freq_int_ion : spec->freq_int_lya);
+                for (int m = 0; m < C21CM_X_INT_NXHII; m++)
+                    for (int i = 0; i < n_local; i++)
+                        fq[((size_t)k * C21CM_X_INT_NXHII + m) * n_local + i] = src[(size_t)m * nf + local[i]];
+            }
+#define GATHER(arr)                                                \
+    do {                                                           \
+        double tmp_[C21CM_MAX_TS_RADII];                           \
+        for (int i = 0; i < n_local; i++) tmp_[i] = arr[local[i]]; \
+        for (int i = 0; i < n_local; i++) arr[i] = tmp_[i];        \
+    } while (0)
+            GATHER(spec->z_edge_factor); GATHER(spec->xray_R_factor); GATHER(spec->starlya_prefactor);
+            GATHER(spec->lya_cont_prefactor); GATHER(spec->lya_inj_prefactor); GATHER(spec->zpp_growth);
+            GATHER(spec->mean_sfr_zpp);
+            GATHER(tab->zpp); GATHER(tab->zpp_growth); GATHER(tab->M_min_R); GATHER(tab->M_max_R);
+            GATHER(tab->sigma_min); GATHER(tab->sigma_max); GATHER(tab->R_values);
+#undef GATHER
+            free(tab->freq); /* spec's three pointers pointed into it */
+            tab->freq = fq;
+            spec->freq_int_heat = fq;
+            spec->freq_int_ion = fq + (size_t)C21CM_X_INT_NXHII * n_local;
+            spec->freq_int_lya = fq + 2 * (size_t)C21CM_X_INT_NXHII * n_local;
+            spec->n_step = tab->n_step = n_local;
+        }
         if (!spec->no_light) {
             if (spec->source_mode == C21CM_TS_SRC_SFRD_TABLE)
                 st = c21_ts_sfrd_tables(job.mn, job.mx, spec, tab);
@@ -852,6 +993,11 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
                 st = c21_ts_fcoll_tables(job.mn, job.mx, spec, tab);
             if (st) goto done;
             filtered = job.result;
+        }
+        if (sh->mode == TS_RUN_SHARD_SUMS) {
+            st = c21cm_ts_shell_sums(spec, perturbed_field->density, previous_spin_temp, NULL, filtered,
+                                     sh->sums, NULL);
+            goto done;
         }
         if (timing) t_tables = wall_seconds() - t_mark, t_mark = wall_seconds();
     } else {

@@ -29,6 +29,7 @@
 
 #include "../hip/c21hip.h"
 #include "c21cm_grid.h"
+#include "c21cm_abi.h"
 
 typedef struct {
     char internal[C21CM_SHARD_ID_BYTES];
@@ -366,3 +367,89 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
     }
     return 0;
 }
+
+/* ---- ComputeTsBox sharded over the ranks (abi_compute.c: ts_box_run) ---------------------------
+ * phase 1 on every rank (its shells' partial sums) -> reduce-scatter by cell slabs, point to point:
+ * rank r sends peer p the rows of p's slab (one message per peer over their direct xGMI link, all
+ * seven at once) and receives its own slab's rows from everybody -> the complete sums of the slab,
+ * ranks added in rank order -> temperature update of the slab -> all-gather of the three output
+ * boxes (again one message per peer and box).  Volumes at 512^3, 8 ranks, 4 rows: 537 MB per link
+ * for the sums in double (C21CM_TS_SHARD_EXCHANGE=f32: partials rounded to float, 268 MB), 3 x 67 MB
+ * per link for the outputs. */
+enum { WS_TSS_SUMS = 216, WS_TSS_SEND = 217, WS_TSS_RECV = 218, WS_TSS_SLAB = 219 };
+
+int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_field_redshift,
+                         PerturbedField *perturbed_field, TsBox *previous_spin_temp,
+                         TsBox *this_spin_temp) {
+    if (!R.ready || R.ready == 2) {
+        c21hip_set_error("shard: ComputeTsBox shards over an RCCL communicator (c21cm_shard_init)");
+        return C21CM_VALUE_ERROR;
+    }
+    const int rank = R.rank, world = R.world;
+    const size_t ntot = (size_t)simulation_options_global->HII_DIM * simulation_options_global->HII_DIM *
+                        (size_t)(simulation_options_global->NON_CUBIC_FACTOR * simulation_options_global->HII_DIM);
+    int st = 0, rows = 0;
+    double *sums = (double *)c21hip_ws(WS_TSS_SUMS, 6 * ntot * sizeof(double));
+    if (!sums) return C21CM_MEMORY_ALLOC_ERROR;
+    if ((st = c21cm_ts_box_shard_sums(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
+                                      previous_spin_temp, rank, world, sums, &rows)))
+        return st;
+    const char *e = getenv("C21CM_TS_SHARD_EXCHANGE");
+    const int f32 = (e && e[0] == 'f' && e[1] == '3') ? 1 : 0;
+    const size_t esz = f32 ? sizeof(float) : sizeof(double);
+    size_t maxlen = 0;
+    for (int r = 0; r < world; r++) {
+        const size_t len = c21hip_ts_slab_begin(ntot, world, r + 1) - c21hip_ts_slab_begin(ntot, world, r);
+        if (len > maxlen) maxlen = len;
+    }
+    const size_t c0 = c21hip_ts_slab_begin(ntot, world, rank);
+    const size_t len = c21hip_ts_slab_begin(ntot, world, rank + 1) - c0;
+    const size_t per_peer = (size_t)rows * maxlen * esz;
+    char *sendb = NULL, *recvb = NULL;
+    if (world > 1) {
+        sendb = (char *)c21hip_ws(WS_TSS_SEND, per_peer * (size_t)(world - 1));
+        recvb = (char *)c21hip_ws(WS_TSS_RECV, per_peer * (size_t)(world - 1));
+        if (!sendb || !recvb) return C21CM_MEMORY_ALLOC_ERROR;
+        if ((st = c21hip_ts_pack_slabs(sums, ntot, world, rank, rows, maxlen, f32, sendb, NULL))) return st;
+        if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+        for (int p = 0; p < world - 1 && !st; p++) {
+            const int peer = p < rank ? p : p + 1;
+            st = rccl_check(R.send(sendb + (size_t)p * per_peer, per_peer, RCCL_UINT8, peer, R.comm, NULL),
+                            "ncclSend(shell sums)");
+            if (!st)
+                st = rccl_check(R.recv(recvb + (size_t)p * per_peer, per_peer, RCCL_UINT8, peer, R.comm, NULL),
+                                "ncclRecv(shell sums)");
+        }
+        const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+        if (st || st2) return st ? st : st2;
+    }
+    double *slab = (double *)c21hip_ws(WS_TSS_SLAB, (size_t)rows * len * sizeof(double));
+    if (!slab) return C21CM_MEMORY_ALLOC_ERROR;
+    if ((st = c21hip_ts_combine_slab(sums, ntot, world, rank, rows, maxlen, f32, recvb, slab, NULL)))
+        return st;
+    if ((st = c21cm_ts_box_shard_finish(redshift, prev_redshift, perturbed_field_redshift,
+                                        perturbed_field, previous_spin_temp, slab, c0, len,
+                                        this_spin_temp)))
+        return st;
+    if (world > 1) { /* all-gather: every rank ends with the full boxes */
+        float *boxes[3] = {this_spin_temp->spin_temperature, this_spin_temp->kinetic_temp_neutral,
+                           this_spin_temp->xray_ionised_fraction};
+        if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+        for (int b = 0; b < 3 && !st; b++)
+            for (int peer = 0; peer < world && !st; peer++) {
+                if (peer == rank) continue;
+                const size_t p0 = c21hip_ts_slab_begin(ntot, world, peer);
+                const size_t plen = c21hip_ts_slab_begin(ntot, world, peer + 1) - p0;
+                st = rccl_check(R.send(boxes[b] + c0, len * sizeof(float), RCCL_UINT8, peer, R.comm, NULL),
+                                "ncclSend(Ts slab)");
+                if (!st)
+                    st = rccl_check(R.recv(boxes[b] + p0, plen * sizeof(float), RCCL_UINT8, peer, R.comm, NULL),
+                                    "ncclRecv(Ts slab)");
+            }
+        const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+        if (st || st2) return st ? st : st2;
+    }
+    return c21hip_sync(NULL);
+}
+
+size_t c21cm_ts_slab_begin(size_t ntot, int world, int r) { return c21hip_ts_slab_begin(ntot, world, r); }

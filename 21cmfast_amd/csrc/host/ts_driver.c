@@ -80,9 +80,50 @@ static int check_boxes(const char *who, const TsBox *b) {
     return 0;
 }
 
+/* mode 0: the whole cell part.  Sharded runs (the shells dealt over ranks, ts_shard.c):
+ * mode 1 = "shell sums only": box means + shell loop over THIS spec's shells, the six sums of every
+ * cell copied to `sums_io` ([6][ntot] doubles, device), no temperature update;
+ * mode 2 = "cells from sums": the temperature update of cells [cell0, cell0 + ncell) from the
+ * combined sums in `sums_io` ([6][ncell] doubles, device); grids must be device arrays. */
+static int ts_grids_impl(const c21cm_ts_spec *s, const float *density, const TsBox *previous,
+                         const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
+                         c21cm_ts_report *report, void *stream, int mode, double *sums_io,
+                         size_t cell0, size_t ncell);
+
 int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *previous,
                    const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
                    c21cm_ts_report *report, void *stream) {
+    return ts_grids_impl(s, density, previous, source_box, filtered_density, out, report, stream, 0,
+                         NULL, 0, 0);
+}
+
+int c21cm_ts_shell_sums(const c21cm_ts_spec *s, const float *density, const TsBox *previous,
+                        const XraySourceBox *source_box, const float *filtered_density,
+                        double *sums_dev, void *stream) {
+    if (!sums_dev || !c21hip_is_device_ptr(sums_dev)) {
+        c21hip_set_error("spin temperature: the shell sums go to a device buffer of 6 N doubles");
+        return C21CM_VALUE_ERROR;
+    }
+    TsBox dummy = *previous; /* outputs are not written in this mode */
+    return ts_grids_impl(s, density, previous, source_box, filtered_density, &dummy, NULL, stream, 1,
+                         sums_dev, 0, 0);
+}
+
+int c21cm_ts_cells_from_sums(const c21cm_ts_spec *s, const float *density, const TsBox *previous,
+                             const double *sums_dev, size_t cell0, size_t ncell, TsBox *out,
+                             void *stream) {
+    if (!sums_dev || !c21hip_is_device_ptr(sums_dev) || ncell < 1) {
+        c21hip_set_error("spin temperature: cells_from_sums needs device sums and a cell range");
+        return C21CM_VALUE_ERROR;
+    }
+    return ts_grids_impl(s, density, previous, NULL, NULL, out, NULL, stream, 2, (double *)sums_dev,
+                         cell0, ncell);
+}
+
+static int ts_grids_impl(const c21cm_ts_spec *s, const float *density, const TsBox *previous,
+                         const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
+                         c21cm_ts_report *report, void *stream, int mode, double *sums_io,
+                         size_t cell0, size_t ncell) {
     int status = 0;
     if (!s || !density) {
         c21hip_set_error("spin temperature: spec and density are required");
@@ -109,13 +150,23 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
         c21hip_set_error("spin temperature: USE_LYA_HEATING needs the two heating-efficiency tables");
         return C21CM_VALUE_ERROR;
     }
-    if (lagrangian && !s->no_light &&
+    if (mode == 2) {
+        if (!c21hip_is_device_ptr(density) || !c21hip_is_device_ptr(previous->spin_temperature) ||
+            !c21hip_is_device_ptr(out->spin_temperature) || s->use_mini_halos) {
+            c21hip_set_error("spin temperature: cells_from_sums takes device arrays (no mini-halos)");
+            return C21CM_VALUE_ERROR;
+        }
+    } else if (mode == 1 && (s->use_mini_halos || s->no_light)) {
+        c21hip_set_error("spin temperature: shell_sums without mini-halos, after the first sources");
+        return C21CM_VALUE_ERROR;
+    }
+    if (mode != 2 && lagrangian && !s->no_light &&
         (!source_box || !source_box->filtered_sfr || !source_box->filtered_xray)) {
         c21hip_set_error("spin temperature: Lagrangian sources need XraySourceBox.filtered_sfr and "
                          "filtered_xray");
         return C21CM_VALUE_ERROR;
     }
-    if (!lagrangian && !s->no_light &&
+    if (mode != 2 && !lagrangian && !s->no_light &&
         (!filtered_density || (fcoll_mode ? (!s->fcoll_tables || !s->dfcoll_tables) : !s->ln_sfrd_tables))) {
         c21hip_set_error("spin temperature: Eulerian sources need the filtered densities and the "
                          "SFRD tables");
@@ -171,7 +222,7 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
 
     const float *tables_dev = NULL, *mean_tables_dev = NULL; /* the cell sweep's | the box mean's */
     const double *lya_c = NULL, *lya_i = NULL;
-    if (!lagrangian && !s->no_light) {
+    if (mode != 2 && !lagrangian && !s->no_light) {
         const size_t tb = (size_t)n * C21CM_NDELTA_TABLE * sizeof(float);
         if (fcoll_mode) {
             tables_dev = stage_tables(WS_TS_SFRDTAB, s->dfcoll_tables, tb, stream, &status);
@@ -192,8 +243,11 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     const float *d_pts = (const float *)stage_in(WS_TS_PTS, previous->spin_temperature, bytes, stream, &status);
     const float *d_ptk = (const float *)stage_in(WS_TS_PTK, previous->kinetic_temp_neutral, bytes, stream, &status);
     const float *d_pxe = (const float *)stage_in(WS_TS_PXE, previous->xray_ionised_fraction, bytes, stream, &status);
+    if (mode == 2) { /* the slab [cell0, cell0 + ncell) of device arrays */
+        d_dens += cell0, d_pts += cell0, d_ptk += cell0, d_pxe += cell0;
+    }
     const float *grid_a = NULL, *grid_b = NULL;
-    if (!s->no_light) {
+    if (mode != 2 && !s->no_light) {
         if (lagrangian) {
             grid_a = (const float *)stage_in(WS_TS_GRID_A, source_box->filtered_sfr, bytes * n, stream, &status);
             grid_b = (const float *)stage_in(WS_TS_GRID_B, source_box->filtered_xray, bytes * n, stream, &status);
@@ -205,6 +259,7 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     float *o_tk = stage_out(WS_TS_OTK, out->kinetic_temp_neutral, bytes, &status);
     float *o_xe = stage_out(WS_TS_OXE, out->xray_ionised_fraction, bytes, &status);
     if (status) goto done;
+    if (mode == 2) o_ts += cell0, o_tk += cell0, o_xe += cell0;
 
     c21hip_ts_args a;
     memset(&a, 0, sizeof(a));
@@ -224,7 +279,7 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
     CP(xray_scale);
 #undef CP
 
-    if (!lagrangian && !s->no_light) { /* avg_fix_term of every shell (:1621-1626) */
+    if (mode != 2 && !lagrangian && !s->no_light) { /* avg_fix_term of every shell (:1621-1626) */
         double *mean_dev = (double *)c21hip_ws(WS_TS_MEANSFR, (size_t)n * sizeof(double));
         if (!mean_dev) {
             status = C21CM_MEMORY_ALLOC_ERROR;
@@ -235,7 +290,12 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
                                  partials, ave_dev, stream));
     }
     double *sums_ws = NULL; /* the six sums of every cell between the two sweeps */
-    if (!s->no_light) {
+    if (mode == 2) {
+        sums_ws = sums_io; /* combined over the ranks' shells by the caller: [6][ncell] */
+        a.sums_ready = 1;
+    } else if (mode == 1) {
+        sums_ws = sums_io; /* straight into the caller's buffer */
+    } else if (!s->no_light) {
         sums_ws = (double *)c21hip_ws(WS_TS_SUMS, 6 * ntot * sizeof(double));
         if (!sums_ws) {
             c21hip_set_error("spin temperature: out of device memory for the shell sums (%zu bytes)",
@@ -319,13 +379,20 @@ int c21cm_ts_grids(const c21cm_ts_spec *s, const float *density, const TsBox *pr
             a.sums_ready = 1;
         }
     }
+    if (mode == 1) { /* the shell loop only: its sums are the result */
+        TRY(c21hip_ts_shell_loop(&a, d_pxe, grid_a, grid_b, tables_dev, dev_tab, sums_ws, ntot, stream));
+        TRY(c21hip_sync(stream));
+        goto done;
+    }
     TRY(c21hip_ts_cells(&a, d_dens, d_pts, d_ptk, d_pxe, grid_a, grid_b, tables_dev, dev_tab, lya_c,
-                        lya_i, o_ts, o_tk, o_xe, ntot, sums_ws, partials + (size_t)512 * n, sums_dev,
-                        flag_dev, stream));
+                        lya_i, o_ts, o_tk, o_xe, mode == 2 ? ncell : ntot, sums_ws,
+                        partials + (size_t)512 * n, sums_dev, flag_dev, stream));
 
-    if (o_ts != out->spin_temperature) TRY(c21hip_d2h(out->spin_temperature, o_ts, bytes, stream));
-    if (o_tk != out->kinetic_temp_neutral) TRY(c21hip_d2h(out->kinetic_temp_neutral, o_tk, bytes, stream));
-    if (o_xe != out->xray_ionised_fraction) TRY(c21hip_d2h(out->xray_ionised_fraction, o_xe, bytes, stream));
+    if (mode != 2) { /* (a slab of device arrays was written in place) */
+        if (o_ts != out->spin_temperature) TRY(c21hip_d2h(out->spin_temperature, o_ts, bytes, stream));
+        if (o_tk != out->kinetic_temp_neutral) TRY(c21hip_d2h(out->kinetic_temp_neutral, o_tk, bytes, stream));
+        if (o_xe != out->xray_ionised_fraction) TRY(c21hip_d2h(out->xray_ionised_fraction, o_xe, bytes, stream));
+    }
     if (mini && o_j21 != out->J_21_LW) TRY(c21hip_d2h(out->J_21_LW, o_j21, bytes, stream));
     double back_mini[C21CM_MAX_TS_RADII];
     if (ave_mini_dev) TRY(c21hip_d2h(back_mini, ave_mini_dev, (size_t)n * sizeof(double), stream));

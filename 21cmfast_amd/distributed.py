@@ -85,3 +85,78 @@ def sharded_ionize_c(spec, density, n_ion, buffers, rank: int, world: int, **kw)
 
     _, _, rep = api.ionize_sharded(spec, density, n_ion, buffers=buffers, **kw)
     return rep if rank == owner_rank(spec.n_radii, world) else None
+
+
+# ---- ComputeTsBox: the N_STEP_TS shells dealt over the ranks (csrc/host/abi_compute.c: ts_box_run) ----
+def shells_of_rank(n_step: int, rank: int, world: int) -> list[int]:
+    """Shell indices (descending) of `rank`: n_step-1-rank, -world, ... (c21cm_ts_shard_shells)."""
+    return list(range(n_step - 1 - rank, -1, -world))
+
+
+def ts_slab(ntot: int, rank: int, world: int) -> tuple[int, int]:
+    """Cell range [begin, end) whose temperature update `rank` runs (c21cm_ts_slab_begin: slab
+    boundaries at multiples of 4 cells, the last slab ends at ntot)."""
+    def begin(r):
+        return ntot if r >= world else (ntot // 4 * r // world) * 4
+    return begin(rank), begin(rank + 1)
+
+
+def ts_reduce_scatter(partial, rank: int, world: int, group=None):
+    """The exchange of the sharded ComputeTsBox through torch.distributed: `partial` [rows][N]
+    (this rank's shells' sums); returns the complete sums of this rank's slab [rows][len], the
+    ranks added in rank order (what c21cm_ts_box_sharded does over RCCL point to point)."""
+    import torch
+    import torch.distributed as dist
+
+    rows, ntot = partial.shape
+    mine = ts_slab(ntot, rank, world)
+    recv = [torch.empty((rows, mine[1] - mine[0]), dtype=partial.dtype, device=partial.device)
+            for _ in range(world)]
+    send = [partial[:, slice(*ts_slab(ntot, p, world))].contiguous() for p in range(world)]
+    dist.all_to_all(recv, send, group=group) if dist.get_backend(group) != "gloo" else _all_to_all_p2p(
+        recv, send, rank, world, group)
+    out = torch.zeros_like(recv[0])
+    for r in range(world):  # rank order: the result does not depend on who computes it
+        out += recv[r]
+    return out
+
+
+def _all_to_all_p2p(recv, send, rank, world, group):
+    """gloo has no all_to_all on every build: the same exchange with isend / irecv."""
+    import torch.distributed as dist
+
+    recv[rank].copy_(send[rank])
+    reqs = []
+    for p in range(world):
+        if p == rank:
+            continue
+        reqs.append(dist.isend(send[p], dst=p, group=group))
+        reqs.append(dist.irecv(recv[p], src=p, group=group))
+    for q in reqs:
+        q.wait()
+
+
+def ts_all_gather(box, rank: int, world: int, group=None):
+    """Every rank's slab of an output box (flat view of length N, filled on [slab) by its owner)
+    to everybody, in place."""
+    import torch.distributed as dist
+
+    ntot = box.numel()
+    flat = box.view(-1)
+    reqs = []
+    b, e = ts_slab(ntot, rank, world)
+    mine = flat[b:e].clone()
+    bufs = {}
+    for p in range(world):
+        if p == rank:
+            continue
+        pb, pe = ts_slab(ntot, p, world)
+        bufs[p] = flat[pb:pe].clone()
+        reqs.append(dist.isend(mine, dst=p, group=group))
+        reqs.append(dist.irecv(bufs[p], src=p, group=group))
+    for q in reqs:
+        q.wait()
+    for p, t in bufs.items():
+        pb, pe = ts_slab(ntot, p, world)
+        flat[pb:pe] = t
+    return box

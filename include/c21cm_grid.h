@@ -237,6 +237,31 @@ int c21cm_shard_unique_id(void *id128);
 int c21cm_shard_init(int rank, int world, const void *id128);
 int c21cm_shard_finalize(void);
 int c21cm_shard_info(int *rank, int *world); /* returns 0 and fills them when initialised */
+
+/* ---- ComputeTsBox sharded over the same communicator (the N_STEP_TS shells dealt round-robin;
+ * reference: SpinTemperatureBox.c:1541-1784 is linear in the shells).  With a communicator in place
+ * ComputeTsBox shards by itself for the Eulerian table models on device arrays (C21CM_SHARD_TS=0
+ * opts out); the two compute phases are exported for tests and other transports:
+ *   c21cm_ts_box_shard_sums    rank's shells: density filter loop, tables, box means, shell loop ->
+ *                              partial sums [6][N] doubles (device), *n_rows of them in use
+ *   (exchange)                 sum the partials over the ranks; rank r needs cells
+ *                              [c21cm_ts_slab_begin(N, world, r), c21cm_ts_slab_begin(N, world, r + 1))
+ *   c21cm_ts_box_shard_finish  temperature update of a cell range from its complete sums
+ *                              ([n_rows][ncell] doubles, device) into the output boxes
+ * Parameters come from the broadcast globals like ComputeTsBox's. */
+int c21cm_ts_shardable(float redshift, const PerturbedField *pf, const TsBox *prev, const TsBox *out);
+int c21cm_ts_shard_shells(int n_step, int rank, int world, int *idx);
+size_t c21cm_ts_slab_begin(size_t ntot, int world, int r);
+int c21cm_ts_box_shard_sums(float redshift, float prev_redshift, float perturbed_field_redshift,
+                            PerturbedField *perturbed_field, TsBox *previous_spin_temp, int rank,
+                            int world, double *sums_dev, int *n_rows);
+int c21cm_ts_box_shard_finish(float redshift, float prev_redshift, float perturbed_field_redshift,
+                              PerturbedField *perturbed_field, TsBox *previous_spin_temp,
+                              const double *slab_sums, size_t cell0, size_t ncell,
+                              TsBox *this_spin_temp);
+int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_field_redshift,
+                         PerturbedField *perturbed_field, TsBox *previous_spin_temp,
+                         TsBox *this_spin_temp);
 int c21cm_shard_owner(int n_radii, int world);
 /* Test hook: replace the transport by an in-process device mailbox so that the ranks of a
  * world > 1 run can be executed one after the other in ONE process (non-owners first, the owner
@@ -548,6 +573,14 @@ int c21cm_ts_mcrit_grid(const c21cm_mturn_spec *spec, double m_turn, const float
 int c21cm_ts_grids(const c21cm_ts_spec *spec, const float *density, const TsBox *previous,
                    const XraySourceBox *source_box, const float *filtered_density, TsBox *out,
                    c21cm_ts_report *report, void *stream);
+/* the cell part alone (ts_driver.c): the shell loop of a spec's shells into sums_dev ([6][N]), and
+ * the temperature update of cells [cell0, cell0 + ncell) from sums ([6][ncell]) */
+int c21cm_ts_shell_sums(const c21cm_ts_spec *spec, const float *density, const TsBox *previous,
+                        const XraySourceBox *source_box, const float *filtered_density,
+                        double *sums_dev, void *stream);
+int c21cm_ts_cells_from_sums(const c21cm_ts_spec *spec, const float *density, const TsBox *previous,
+                             const double *sums_dev, size_t cell0, size_t ncell, TsBox *out,
+                             void *stream);
 
 /* init_first_Ts: T_k = TK (1 + cT_ad delta), x_e = xe, T_s from collisions only. */
 typedef struct c21cm_ts_first_spec {
