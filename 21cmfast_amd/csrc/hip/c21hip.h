@@ -99,6 +99,29 @@ int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, float R_para
                        const float *R, int n_R, int nx, int ny, int nz, double box_len,
                        double box_len_z, int pair, int *enabled, void *stream);
 void c21hip_wev_release(void);
+int c21hip_wev_applicable(int filter_a, int filter_b, int n_grids, int nx, int ny, int nz);
+/* one grid, two radii per pass-X sweep, under window a or b of the prepared set (phases: 2 pass X,
+ * 4 / 8 pass Y of the first / second radius) */
+int c21hip_split_filter_xy_single_pair(const float *src, float *work, float *work2, int filter_type,
+                                       float R_param, int nx, int ny, int nz, double box_len,
+                                       double box_len_z, float R, float R2, int phases, void *stream);
+/* fused pass Z with a recombination model (CELL_RECOMB): barrier (1 + N_rec / (1 + delta)), delta_R
+ * of a first crossing left in the Gamma_12 grid */
+int c21hip_split_z_ionise_recomb(const float *delta_work, const float *stars_work, const float *nrec,
+                                 double rec0, float *g12, unsigned char *first_cross,
+                                 double *partials, int nx, int ny, int nz, int r_index,
+                                 double rhocrit_omb, double ion_eff, int mass_dep_zeta,
+                                 double f_limit, void *stream);
+/* ... followed, per radius, by the pass Z of the filtered whalo_sfr: first crossings of r_index
+ * (g12 holds their delta_R) receive Gamma_12 = g12_scale / (1 + delta_R) max(sfr_R, 0) */
+int c21hip_split_z_sfr_gamma12(const float *sfr_work, const unsigned char *first_cross, float *g12,
+                               int nx, int ny, int nz, int r_index, double g12_scale, void *stream);
+int c21hip_z_ionise_recomb_supported(int nx, int ny, int nz);
+/* first-crossing mask + Gamma_12 grid of the fused recombination loop -> x_HI = 0, z_reion,
+ * mean free path = R[index] (R_dev: float per radius index) */
+int c21hip_apply_first_cross_recomb(const unsigned char *first_cross, const float *R_dev,
+                                    const float *prev_z_reion, int first_snapshot, double redshift,
+                                    float *xH, float *z_reion, float *mfp, size_t ntot, void *stream);
 /* W(kR) tables of one radius for c21hip_split_filter_xy2, on any stream */
 int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filter_b,
                          float R_param_b, int nx, int ny, int nz, double box_len,

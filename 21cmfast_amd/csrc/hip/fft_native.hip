@@ -1315,6 +1315,11 @@ struct ZPassArgs {
     // out = max(v, min_value) * const_factor, partials p0 min / p1 max / p2 sum of out
     double *p2;
     double min_value, const_factor;
+    // EPI 4 (fused recombination loop): v = filtered whalo_sfr; where mask == r_index the dense
+    // grid `out` holds delta_R of the crossing and receives
+    // Gamma_12 = const_factor / (1 + delta_R) * max(v, 0)   (IonisationBox.c:1124-1140)
+    const unsigned char *mask;
+    int r_index;
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -1572,6 +1577,15 @@ struct ZFusedArgs {
     int ny, lb;  // x-blocked layout (logical_line())
     int store_all;  // write the mask back even where this radius changed nothing
     int reverse;    // workgroups walk the lines from the end (see dispatch_z_fused)
+    // Recombination models with CELL_RECOMB (wave-level kernel, RC = true): the third spectrum
+    // (x_main / x_nyq) is the filtered HaloBox.whalo_sfr; the barrier gains (1 + rec),
+    // rec = N_rec / (1 + delta_R) with the cell's own previous N_rec (`nrec`, dense; NULL: the
+    // homogeneous model's one number `rec0`), and a cell's FIRST crossing records
+    // Gamma_12 = R gamma_prefactor / (1 + delta_R) max(sfr_R, 0)  (IonisationBox.c:1084-1140)
+    int rc;
+    const float *nrec;
+    double rec0;
+    float *g12;  // dense [lines][NZ]: a first crossing leaves delta_R here (-> zw_c2r_kernel EPI 4)
 };
 
 template <int NZ>
@@ -1911,7 +1925,7 @@ __device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, co
 // Fused pass Z + f_coll sum + barrier, wave-level transform (A = 16 or 32, see wave_c2r).
 // TS: a third grid, the filtered x_e of the spin-temperature run, enters the barrier as
 // f_coll zeta > 1 - x_e (IonisationBox.c:1118, clip of :1091-1094).
-template <int A, bool TS, int P = 16>
+template <int A, bool TS, int P = 16, bool RC = false>
 __global__ void
 #if C21X_ZW_OCC
 __launch_bounds__(kBlock, (A == 16 && !TS) ? C21X_ZW_OCC : 1)
@@ -1955,6 +1969,19 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         for (int q = 0; q < A; q++)
             old[q] = reinterpret_cast<const uchar2 *>(mrow)[(b + P * (q / P)) + A * (q % P)];
     }
+    // RC: the cells' previous N_rec.  Loads inside the barrier loop would each wait for HBM (636
+    // instead of ~370 us per radius at 512^3), all sixteen requested here cost the second wave per
+    // SIMD (256 VGPRs): the first half is requested now, the second half at the head of the barrier
+    // loop, eight iterations ahead of its use.
+    constexpr int NRH = (RC && A == 16) ? A / 2 : 1;
+    float2 nr_lo[NRH], nr_hi[NRH];
+    if constexpr (RC && A == 16) {
+        if (a.nrec) {
+#pragma unroll
+            for (int q = 0; q < NRH; q++)
+                nr_lo[q] = reinterpret_cast<const float2 *>(a.nrec + lline * NZ)[(b + P * (q / P)) + A * (q % P)];
+        }
+    }
     __syncthreads();  // twiddle tables
     wave_c2r<A, P>(xd, dh, L, twH, twN, b);
     if (!EARLY) {
@@ -1963,8 +1990,11 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     }
     wave_fence();
     wave_c2r<A, P>(xs, sh, L, twH, twN, b);
+    static_assert(!(TS && RC), "x_e and recombinations together take the unfused sequence");
+    // (RC: the filtered whalo_sfr is only needed where a cell crosses for the first time; it gets
+    //  its own pass Z right after this kernel, which looks the crossings of this radius up in the mask)
     float2 xx[TS ? A : 1];
-    if constexpr (TS) {
+    if constexpr (TS) {  // third grid: x_e
         const float2 *xm = a.x_main + line * H;
 #pragma unroll
         for (int q = 0; q < A; q++) xx[q] = xm[P * q + b];
@@ -1973,6 +2003,15 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         wave_c2r<A, P>(xx, xh, L, twH, twN, b);
     }
 
+    if constexpr (RC && A == 16) {
+        if (a.nrec) {
+#pragma unroll
+            for (int q = 0; q < NRH; q++) {
+                const int qq = q + NRH;
+                nr_hi[q] = reinterpret_cast<const float2 *>(a.nrec + lline * NZ)[(b + P * (qq / P)) + A * (qq % P)];
+            }
+        }
+    }
     const double floor_lhs = a.f_limit * a.ion_eff;  // the floored f_coll zeta
     const bool floor_ionises = !TS && a.mass_dep_zeta && (floor_lhs > 1.);
     const float dmin = (float)(-1. + 1e-7);  // IonisationBox.c:803
@@ -1995,13 +2034,38 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
             D0 *= n0;
             D1 *= n1;
         }
-        const bool i0 = floor_ionises || f0 || ((double)s0 * a.ion_eff > D0);
-        const bool i1 = floor_ionises || f1 || ((double)s1 * a.ion_eff > D1);
+        double opd0 = 1., opd1 = 1.;  // RC: 1 + delta_R of the two cells
+        if constexpr (RC) {
+            // f zeta > 1 + rec, rec = N_rec / (1 + delta): both sides times rho (1 + delta) > 0,
+            // f = max(s / (rho (1 + delta)), f_limit)
+            opd0 = 1. + (double)fmaxf(xd[q].x, dmin);
+            opd1 = 1. + (double)fmaxf(xd[q].y, dmin);
+            double r0 = a.rec0, r1 = a.rec0;
+            if (a.nrec) {
+                const float2 nr = (A == 16) ? (q < NRH ? nr_lo[(A == 16 && q < NRH) ? q : 0]
+                                                       : nr_hi[(A == 16 && q >= NRH) ? q - NRH : 0])
+                                            : reinterpret_cast<const float2 *>(a.nrec + lline * NZ)[j];
+                r0 = (double)nr.x, r1 = (double)nr.y;
+            }
+            D0 = a.rhocrit_omb * (opd0 + r0);
+            D1 = a.rhocrit_omb * (opd1 + r1);
+            f0 = a.mass_dep_zeta && floor_lhs * opd0 > opd0 + r0;
+            f1 = a.mass_dep_zeta && floor_lhs * opd1 > opd1 + r1;
+        }
+        const bool i0 = (!RC && floor_ionises) || f0 || ((double)s0 * a.ion_eff > D0);
+        const bool i1 = (!RC && floor_ionises) || f1 || ((double)s1 * a.ion_eff > D1);
         uchar2 m = EARLY ? old[EARLY ? q : 0] : reinterpret_cast<const uchar2 *>(mrow)[j];
         const bool n0 = i0 && m.x == 0, n1 = i1 && m.y == 0;
         if (n0) m.x = (unsigned char)a.r_index;
         if (n1) m.y = (unsigned char)a.r_index;
         if (n0 || n1 || a.store_all) reinterpret_cast<uchar2 *>(mrow)[j] = m;
+        if constexpr (RC) {
+            // a first crossing leaves its delta_R in the Gamma_12 grid; the whalo_sfr pass of this
+            // radius (zw_c2r_kernel, EPI 4) turns it into Gamma_12 = R pref / (1 + delta_R) sfr_R
+            float *grow = a.g12 + lline * NZ + 2 * j;
+            if (n0 && a.rc != 2) grow[0] = fmaxf(xd[q].x, dmin);
+            if (n1 && a.rc != 2) grow[1] = fmaxf(xd[q].y, dmin);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -2070,7 +2134,14 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             acc2 += (double)v.x;
             acc2 += (double)v.y;
         }
-        if (EPI == 2) {
+        if (EPI == 4) {
+            const uchar2 m = reinterpret_cast<const uchar2 *>(a.mask + lline * NZ)[j];
+            float *grow = a.out + lline * NZ + 2 * j;
+            if (m.x == (unsigned char)a.r_index)
+                grow[0] = (float)(a.const_factor / (1. + (double)grow[0]) * (double)fmaxf(v.x, 0.f));
+            if (m.y == (unsigned char)a.r_index)
+                grow[1] = (float)(a.const_factor / (1. + (double)grow[1]) * (double)fmaxf(v.y, 0.f));
+        } else if (EPI == 2) {
             const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
             const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
             acc0 += f0;
@@ -2085,7 +2156,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             }
         }
     }
-    if (EPI != 0) {
+    if (EPI != 0 && EPI != 4) {
         __shared__ double red0[kBlock / 64], red1[kBlock / 64], red2[kBlock / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -2398,6 +2469,10 @@ int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
 // *n_partials: how many workgroup partials of sum(stars) the launch wrote
 int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream, int *n_partials) {
     *n_partials = (int)(nlines / LZ_FUSED);
+    if (a.rc && (zw3_selected(nz, nlines) || !zw_lines_of(nz, nlines))) {
+        c21hip_set_error("fused pass Z with recombinations needs the 16-lane wave kernel (z-lines of 256 / 512 points)");
+        return C21CM_VALUE_ERROR;
+    }
     if (zw3_selected(nz, nlines)) {  // 1024-point lines: three radix-8 stages per wave
         const float2 *twH = twiddles(nz / 2);
         const float2 *twN = twiddles(nz);
@@ -2419,7 +2494,16 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
         const dim3 grid((unsigned)(nlines / zwl));
 #define ZW_FUSED(A, TS, P) \
     hipLaunchKernelGGL((zw_ionise_kernel<A, TS, P>), grid, dim3(kBlock), 0, stream, a, twH, twN)
-        if (a.x_main) {
+#define ZW_FUSED_RC(A, P) \
+    hipLaunchKernelGGL((zw_ionise_kernel<A, false, P, true>), grid, dim3(kBlock), 0, stream, a, twH, twN)
+        if (a.rc) {
+            if (nz == 256)
+                ZW_FUSED_RC(16, 8);
+            else if (nz == 512)
+                ZW_FUSED_RC(16, 16);
+            else
+                ZW_FUSED_RC(32, 16);
+        } else if (a.x_main) {
             if (nz == 256)
                 ZW_FUSED(16, true, 8);
             else if (nz == 512)
@@ -2433,6 +2517,7 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
         else
             ZW_FUSED(32, false, 16);
 #undef ZW_FUSED
+#undef ZW_FUSED_RC
         LAUNCH_CHECK();
         return 0;
     }
@@ -2704,11 +2789,18 @@ static bool wev_use(LinePassArgs &a, int n_grids, const int filter_type[2], cons
     if (!w.active || w.nx != nx || w.ny != ny || w.nz != nz || w.box_len != box_len ||
         w.box_len_z != box_len_z)
         return false;
-    // a launch may carry window a alone (the x_e grid of a spin-temperature run) or both
-    if (filter_type[0] != w.filter[0] || (filter_type[0] == 3 && R_param[0] != w.R_param[0])) return false;
-    if (n_grids == 2 &&
-        (filter_type[1] != w.filter[1] || (filter_type[1] == 3 && R_param[1] != w.R_param[1])))
-        return false;
+    // a launch may carry both windows, or ONE grid under window a (the x_e grid of a
+    // spin-temperature run) or under window b (whalo_sfr of a recombination run)
+    int win0 = 0;
+    auto matches = [&](int g, int win) {
+        return filter_type[g] == w.filter[win] && (filter_type[g] != 3 || R_param[g] == w.R_param[win]);
+    };
+    if (n_grids == 2) {
+        if (!matches(0, 0) || !matches(1, 1)) return false;
+    } else if (!matches(0, 0)) {
+        if (!matches(0, 1)) return false;
+        win0 = 1;
+    }
     const int ra = w.find(R), rb = pair ? w.find(R2) : ra;
     if (ra < 0 || rb < 0) return false;
     // distinct tables of this launch -> staged LDS slots
@@ -2723,7 +2815,8 @@ static bool wev_use(LinePassArgs &a, int n_grids, const int filter_type[2], cons
     const int rr[2] = {ra, rb};
     for (int m = 0; m < 2; m++)
         for (int win = 0; win < 2; win++)
-            a.wev_tab[m][win] = (win < n_grids && (m == 0 || pair)) ? slot(w.table(win, rr[m])) : -1;
+            a.wev_tab[m][win] =
+                (win < n_grids && (m == 0 || pair)) ? slot(w.table(win == 0 ? win0 : win, rr[m])) : -1;
     if (n_ids > 3) return false;
     if (wev_lds(nx, pair, n_ids, w.n_nodes) > 160 * 1024) return false;
     for (int i = 0; i < 3; i++)
@@ -3092,9 +3185,9 @@ extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, f
         w.first_type = 0;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    w.nodes = (float *)c21hip_ws(96, sizeof(float) * 3 * (size_t)w.n_nodes * w.n_tabs);
+    w.nodes = (float *)c21hip_ws(240, sizeof(float) * 3 * (size_t)w.n_nodes * w.n_tabs);
     const int n_mfp = n_mfp_windows * n_R;
-    ExpMfpConsts *mfp_dev = (ExpMfpConsts *)c21hip_ws(97, sizeof(ExpMfpConsts) * (size_t)(n_mfp > 0 ? n_mfp : 1));
+    ExpMfpConsts *mfp_dev = (ExpMfpConsts *)c21hip_ws(241, sizeof(ExpMfpConsts) * (size_t)(n_mfp > 0 ? n_mfp : 1));
     if (!w.nodes || !mfp_dev) return C21CM_MEMORY_ALLOC_ERROR;
     if (n_mfp > 0) {
         static std::vector<ExpMfpConsts> host;  // must outlive the asynchronous copy
@@ -3128,6 +3221,27 @@ extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, f
     return 0;
 }
 extern "C" void c21hip_wev_release(void) { g_wev.active = false; }
+// 1: c21hip_wev_prepare would enable evaluated windows for these filters on this grid
+extern "C" int c21hip_wev_applicable(int filter_a, int filter_b, int n_grids, int nx, int ny, int nz) {
+    const char *env = getenv("C21CM_WINDOWS");
+    if (env && env[0] == 't') return 0;
+    if (!wev_type_ok(filter_a) || (n_grids == 2 && !wev_type_ok(filter_b))) return 0;
+    if (n_grids == 2 && filter_a == 3 && filter_b == 3) return 0;
+    return nx >= 128 && !(nx & (nx - 1)) && nx <= 512 && c21hip_native_fft_supported(nx, ny, nz);
+}
+// ONE grid, two radii per sweep, under a window of the prepared set (a or b: matched by type
+// and parameter); evaluated windows only
+extern "C" int c21hip_split_filter_xy_single_pair(const float *src, float *work, float *work2,
+                                                  int filter_type, float R_param, int nx, int ny,
+                                                  int nz, double box_len, double box_len_z, float R,
+                                                  float R2, int phases, void *stream_) {
+    if (!g_wev.active) {
+        c21hip_set_error("single-grid pair sweep: needs a prepared window set (c21hip_wev_prepare)");
+        return C21CM_VALUE_ERROR;
+    }
+    return filter_xy_pair(src, work, work2, filter_type, R_param, nullptr, nullptr, nullptr, 0, 0.f,
+                          nx, ny, nz, box_len, box_len_z, R, R2, 0, 1, phases & ~1, stream_, 1);
+}
 
 // Forward transform into the split layout: real rows (in_zstride floats, scale-and-clip on
 // load; pass lo > hi to disable the clip) -> pass Z r2c -> pass Y -> pass X, the result
@@ -3379,6 +3493,73 @@ extern "C" int c21hip_split_z_ionise_stars_xe(const float *delta_work, const flo
     if (st) return st;
     if (!sum_out) return 0;  // deferred: the caller reduces the partials of all radii at once
     return c21hip_reduce_sum(partials, n_partials, sum_out, stream);
+}
+
+// The same with a recombination model (CELL_RECOMB): sfr_work = passes X, Y of HaloBox.whalo_sfr;
+// nrec: the previous box's cumulative_recombinations (dense; NULL: homogeneous, rec0), g12: dense
+// Gamma_12 grid written at first crossings.
+extern "C" int c21hip_split_z_ionise_recomb(const float *delta_work, const float *stars_work,
+                                            const float *nrec, double rec0, float *g12,
+                                            unsigned char *first_cross,
+                                            double *partials, int nx, int ny, int nz, int r_index,
+                                            double rhocrit_omb, double ion_eff, int mass_dep_zeta,
+                                            double f_limit, void *stream) {
+    const long nlines = (long)nx * ny;
+    ZFusedArgs a{};
+    a.ny = ny;
+    a.lb = split_xb_log2(nx);
+    a.d_main = reinterpret_cast<const float2 *>(delta_work);
+    a.d_nyq = a.d_main + nlines * (nz / 2);
+    a.s_main = reinterpret_cast<const float2 *>(stars_work);
+    a.s_nyq = a.s_main + nlines * (nz / 2);
+    a.first_cross = first_cross;
+    a.partials = partials;
+    a.rhocrit_omb = rhocrit_omb;
+    a.ion_eff = ion_eff;
+    a.f_limit = f_limit;
+    a.mass_dep_zeta = mass_dep_zeta;
+    a.r_index = r_index;
+    a.rc = getenv("C21CM_DIAG_RC_NOSTORE") ? 2 : 1;  // (2: timing diagnostic, no Gamma_12 stores)
+    a.nrec = nrec;
+    a.rec0 = rec0;
+    a.g12 = g12;
+    a.reverse = 1;
+    int n_partials = 0;
+    return dispatch_z_fused(nz, a, nlines, (hipStream_t)stream, &n_partials);
+}
+// Pass Z of the filtered whalo_sfr of radius r_index: where the first-crossing mask holds r_index,
+// g12 (which holds delta_R there, left by c21hip_split_z_ionise_recomb) becomes Gamma_12.
+extern "C" int c21hip_split_z_sfr_gamma12(const float *sfr_work, const unsigned char *first_cross,
+                                          float *g12, int nx, int ny, int nz, int r_index,
+                                          double g12_scale, void *stream) {
+    const long nlines = (long)nx * ny;
+    const int zwl = zw_lines_of(nz, nlines);
+    if (!zwl || zw3_selected(nz, nlines) || nz > 512) return C21CM_VALUE_ERROR;
+    const float2 *twH = twiddles(nz / 2);
+    const float2 *twN = twiddles(nz);
+    if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(sfr_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out = g12;
+    z.out_zstride = nz;
+    z.out_scale = 1.0f;
+    z.const_factor = g12_scale;
+    z.mask = first_cross;
+    z.r_index = r_index;
+    const dim3 grid((unsigned)(nlines / zwl));
+    if (nz == 256)
+        hipLaunchKernelGGL((zw_c2r_kernel<16, 4, 8>), grid, dim3(kBlock), 0, (hipStream_t)stream, z, twH, twN);
+    else
+        hipLaunchKernelGGL((zw_c2r_kernel<16, 4, 16>), grid, dim3(kBlock), 0, (hipStream_t)stream, z, twH, twN);
+    LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int c21hip_z_ionise_recomb_supported(int nx, int ny, int nz) {
+    const long nlines = (long)nx * ny;
+    return zw_lines_of(nz, nlines) != 0 && !zw3_selected(nz, nlines) && nz <= 512;
 }
 
 // 1: the fused pass Z can take an x_e grid at this z-line length

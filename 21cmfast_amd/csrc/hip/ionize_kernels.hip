@@ -790,6 +790,25 @@ apply_first_cross_kernel(const unsigned char *__restrict__ fc,
     }
 }
 
+// fused recombination loop: the mask holds the radius index of the first crossing, Gamma_12 was
+// written by the fused pass Z; what is left is x_HI, z_reion and the mean free path R[index]
+__global__ void __launch_bounds__(kBlock)
+apply_first_cross_recomb_kernel(const unsigned char *__restrict__ fc, const float *__restrict__ R_dev,
+                                const float *__restrict__ prev_z_reion, int first_snapshot,
+                                float z_now, float *__restrict__ xH, float *__restrict__ z_reion,
+                                float *__restrict__ mfp, size_t ntot) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot;
+         i += (size_t)gridDim.x * kBlock) {
+        const unsigned char r = fc[i];
+        if (r) {
+            const float pz = first_snapshot ? -1.f : prev_z_reion[i];
+            z_reion[i] = (pz < 0.f) ? z_now : pz;
+            xH[i] = 0.f;
+            if (mfp) mfp[i] = R_dev[r];
+        }
+    }
+}
+
 // R-loop sharding with a recombination model: a rank's first crossing of a cell is the pair
 // (mean free path = R of the crossing, Gamma_12 at it).  Both are non-negative floats, whose IEEE
 // bit patterns order like the values, so key = bits(mfp) << 32 | bits(G12) and ONE max-reduce of
@@ -1297,6 +1316,17 @@ extern "C" int c21hip_apply_first_cross(const unsigned char *first_cross,
     hipLaunchKernelGGL(apply_first_cross_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
                        (hipStream_t)stream, first_cross, prev_z_reion, first_snapshot,
                        (float)redshift, xH, z_reion, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_apply_first_cross_recomb(const unsigned char *first_cross, const float *R_dev,
+                                               const float *prev_z_reion, int first_snapshot,
+                                               double redshift, float *xH, float *z_reion,
+                                               float *mfp, size_t ntot, void *stream) {
+    hipLaunchKernelGGL(apply_first_cross_recomb_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
+                       (hipStream_t)stream, first_cross, R_dev, prev_z_reion, first_snapshot,
+                       (float)redshift, xH, z_reion, mfp, ntot);
     LAUNCH_CHECK();
     return 0;
 }

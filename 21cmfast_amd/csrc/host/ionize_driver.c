@@ -93,7 +93,9 @@ enum {
     WS_MINI_HIST_M,
     WS_MINI_OUT_A,
     WS_MINI_OUT_M,
-    WS_SPHERE_RSQ = 216
+    WS_SPHERE_RSQ = 216,
+    WS_SFR_WORK2 = 246, /* fused recombination loop: whalo_sfr of the second radius of a sweep */
+    WS_R_DEV = 247      /* float R per radius index (mean free path of a first crossing) */
 };
 
 #define MAX_COPYBACK 12
@@ -327,6 +329,9 @@ typedef struct {
     int def_first, def_step, def_count;
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     int wev;             /* 1: this loop's passes X evaluate their windows in the kernel */
+    int fused_rc;        /* fused loop with a recombination model (CELL_RECOMB, no x_e grid) */
+    float *sfr_work2;
+    double rec0;         /* homogeneous model: the one previous N_rec */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
     float *eul_xe[2];    /* dense x_e(R) of the Eulerian mask path (spin-temperature runs) */
     int sphere;          /* IONISE_ENTIRE_SPHERE: radii > 0 only record the mask, spheres follow */
@@ -342,6 +347,8 @@ typedef struct {
 } ion_ctx;
 
 static int r0_direct(void);
+
+static int g_single_pass; /* set by c21cm_ionize_grids around its ctx_setup: not a shard phase */
 
 static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedField *pf,
                      const IonizedBox *prev, const TsBox *ts, const HaloBox *halos,
@@ -397,6 +404,20 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->fused = c->native && c->lagrangian && !c->recomb &&
                (!s->use_ts_fluct ||
                 (c21hip_z_ionise_xe_supported(c->nx, c->ny, c->nz) && r0_direct()));
+    /* Recombination models with CELL_RECOMB and no x_e grid ride the fused loop too (round 3): the
+     * filtered whalo_sfr is a third spectrum of passes X / Y and of the wave-level pass Z, the
+     * barrier gains (1 + N_rec / (1 + delta)), Gamma_12 is written at first crossings and the
+     * mean free path follows from the first-crossing index; the cell-scale radius and the
+     * post-loop stay on the general kernels.  Needs the evaluated windows (whalo_sfr takes window
+     * b alone).  C21CM_RECOMB_FUSED=0: the unfused per-radius sequence. */
+    c->fused_rc = 0;
+    if (c->native && c->lagrangian && c->recomb && s->cell_recomb && !s->use_ts_fluct &&
+        !s->use_mini_halos && !s->ionise_entire_sphere && g_single_pass) {
+        const char *e = getenv("C21CM_RECOMB_FUSED");
+        if (!(e && e[0] == '0') && c21hip_z_ionise_recomb_supported(c->nx, c->ny, c->nz) &&
+            c21hip_wev_applicable(s->hii_filter, s->stars_filter, 2, c->nx, c->ny, c->nz))
+            c->fused_rc = c->fused = 1;
+    }
     c->sphere = s->ionise_entire_sphere;
     c->mini = s->use_mini_halos && !c->lagrangian;
     c->lag_mini = s->use_mini_halos && c->lagrangian;
@@ -449,6 +470,8 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             c->stars_work2 = (float *)c21hip_ws(WS_STARS_WORK2, gbytes);
             if (!c->delta_work2 || !c->stars_work2) return C21CM_MEMORY_ALLOC_ERROR;
             if (s->use_ts_fluct && !(c->xe_work2 = (float *)c21hip_ws(WS_XE_WORK2, gbytes)))
+                return C21CM_MEMORY_ALLOC_ERROR;
+            if (c->fused_rc && !(c->sfr_work2 = (float *)c21hip_ws(WS_SFR_WORK2, gbytes)))
                 return C21CM_MEMORY_ALLOC_ERROR;
             c->pair_radii = 1;
         }
@@ -684,6 +707,31 @@ static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float
                            const float *xwork, unsigned char *first_cross) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
+    if (c->fused_rc) { /* xwork: the filtered whalo_sfr; sums always deferred or reduced below */
+        double *part = c->def_partials ? c->def_partials + (long)R_ct * c->def_stride : c->partials;
+        if (c->def_partials) {
+            if (c->def_count == 0)
+                c->def_first = R_ct;
+            else if (c->def_count == 1)
+                c->def_step = c->def_first - R_ct;
+            else if (R_ct != c->def_first - c->def_count * c->def_step)
+                TRY(flush_deferred(c));
+            if (c->def_count == 0) c->def_first = R_ct;
+            c->def_count++;
+        }
+        TRY(c21hip_split_z_ionise_recomb(dwork, swork, c->inhomo ? c->prev_nrec : NULL, c->rec0, c->G12,
+                                         first_cross, part, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
+                                         s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg, c->stream));
+        TRY(c21hip_split_z_sfr_gamma12(xwork, first_cross, c->G12, c->nx, c->ny, c->nz, R_ct,
+                                       s->R[R_ct] * s->gamma_prefactor, c->stream));
+        if (!c->def_partials) {
+            double *sum_dev = c->scalars + SC_SUMS + R_ct;
+            TRY(c21hip_reduce_sum(part, c21hip_z_ionise_partials(c->nx, c->ny, c->nz), sum_dev, c->stream));
+            TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                                   c->scalars + SC_MEANS + R_ct, c->stream));
+        }
+        goto done;
+    }
     if (c->def_partials) {
         /* no kernel of this loop reads a radius' mean: reduce all of them at the end */
         if (c->def_count == 0)
@@ -751,8 +799,8 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
             const char *e = getenv("C21CM_PAIR_ORDER");
             yy = (e && e[0] == 'y') ? 1 : 0;
         }
-        const float *xw[2] = {s->use_ts_fluct ? c->xe_work : NULL,
-                              s->use_ts_fluct ? c->xe_work2 : NULL};
+        const float *xw[2] = {s->use_ts_fluct ? c->xe_work : (c->fused_rc ? c->sfr_work : NULL),
+                              s->use_ts_fluct ? c->xe_work2 : (c->fused_rc ? c->sfr_work2 : NULL)};
         for (int ph = 0; ph < 3; ph++) { /* pass X, pass Y of R_a, pass Y of R_b */
             const int bits = ph == 0 ? (tab_async ? 2 : 3) : (4 << (ph - 1));
             TRY(c21hip_split_filter_xy2_pair(
@@ -765,6 +813,11 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                     c->xe_unf, c->xe_work, c->xe_work2, s->hii_filter, c->nx, c->ny, c->nz,
                     s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a, buf_b,
                     bits & ~1, c->stream));
+            if (c->fused_rc) /* whalo_sfr under the emissivity window (IonisationBox.c:583-663) */
+                TRY(c21hip_split_filter_xy_single_pair(
+                    c->sfr_unf, c->sfr_work, c->sfr_work2, s->stars_filter, (float)s->mfp_meandens,
+                    c->nx, c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a],
+                    (float)s->R[R_b], bits & ~1, c->stream));
             /* (the tables are free after pass X, their only reader; releasing them there lets the
              * next builds run under pass Y, which measured 4 ms per call slower than under pass Z) */
             if (ph == (yy ? 2 : 1) && tab_async) {
@@ -787,11 +840,15 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
             TRY(c21hip_split_filter_xy_shared(c->xe_unf, c->xe_work, s->hii_filter, c->nx, c->ny,
                                               c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], 1,
                                               buf_a, c->stream));
+        if (c->fused_rc)
+            TRY(c21hip_split_filter_xy(c->sfr_unf, c->sfr_work, c->nx, c->ny, c->nz, s->box_len,
+                                       s->box_len_z, s->stars_filter, (float)s->R[R_a],
+                                       (float)s->mfp_meandens, 1, c->stream));
         if (tab_async) TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
     }
     c->tab_seq++;
     TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work,
-                        s->use_ts_fluct ? c->xe_work : NULL, first_cross));
+                        s->use_ts_fluct ? c->xe_work : (c->fused_rc ? c->sfr_work : NULL), first_cross));
 done:
     return status;
 }
@@ -813,6 +870,24 @@ static int fused_loop(ion_ctx *c, int first, int step, int lowest, unsigned char
             TRY(c21hip_wev_prepare(c->s->hii_filter, 0.f, c->s->stars_filter, (float)c->s->mfp_meandens,
                                    2, radii, n, c->nx, c->ny, c->nz, c->s->box_len, c->s->box_len_z,
                                    c->pair_radii, &c->wev, c->stream));
+    }
+    if (c->fused_rc) {
+        if (!c->wev) {
+            c21hip_set_error("ionize: the fused recombination loop needs the evaluated windows");
+            status = C21CM_VALUE_ERROR;
+            goto done;
+        }
+        c->rec0 = 0.;
+        if (!c->inhomo) { /* the homogeneous model's one number (outputs.py:1526-1537) */
+            float r0 = 0.f;
+            if (c21hip_is_device_ptr(c->prev_nrec)) {
+                TRY(c21hip_d2h(&r0, c->prev_nrec, sizeof(float), c->stream));
+                TRY(c21hip_sync(c->stream));
+            } else {
+                r0 = c->prev_nrec[0];
+            }
+            c->rec0 = (double)r0;
+        }
     }
     int R_a = first;
     while (R_a >= lowest) {
@@ -1286,7 +1361,8 @@ static int init_output_grids(ion_ctx *c, const IonizedBox *prev) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     /* IonisationBox.c:1372-1378 (final_step writes every cell, -1 included) */
-    if (!(c->fused && s->r_lowest == 0)) TRY(c21hip_fill(c->zre, c->ntot, -1.0f, c->stream));
+    if (!(c->fused && !c->fused_rc && !c->sphere && s->r_lowest == 0))
+        TRY(c21hip_fill(c->zre, c->ntot, -1.0f, c->stream));
     /* IonisationBox.c:365-386: the caller's zeroed previous box receives z_reion = -1 */
     if (s->first_snapshot && prev && prev->z_reion) {
         if (c21hip_is_device_ptr(prev->z_reion)) {
@@ -1323,8 +1399,10 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
     ion_ctx c;
     void *ev[4] = {NULL, NULL, NULL, NULL};
     g_spectra.valid = 0;
-    TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1,
-                  stream));
+    g_single_pass = 1;
+    status = ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1, stream);
+    g_single_pass = 0;
+    if (status) goto done;
     for (int i = 0; i < 4; i++) ev[i] = c21hip_event_create();
     TRY(c21hip_event_record(ev[0], stream));
     TRY(init_output_grids(&c, previous_ionize_box));
@@ -1370,12 +1448,27 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
                 mask_pending = 0;
-                if (c.fused && !c.sphere) {
+                if (c.fused && !c.sphere && !c.fused_rc) {
                     TRY(flush_deferred(&c));
                     TRY(final_step(&c, c.mask, 0));
                     break;
                 }
                 if (c.fused) TRY(flush_deferred(&c));
+                if (c.fused_rc) { /* first crossings -> x_HI, z_reion, mean free path (Gamma_12 is in place) */
+                    float Rf[C21CM_MAX_RADII];
+                    for (int r = 0; r < C21CM_MAX_RADII; r++) Rf[r] = r < spec->n_radii ? (float)spec->R[r] : 0.f;
+                    float *R_dev = (float *)c21hip_ws(WS_R_DEV, sizeof(Rf));
+                    if (!R_dev) {
+                        status = C21CM_MEMORY_ALLOC_ERROR;
+                        goto done;
+                    }
+                    TRY(c21hip_h2d(R_dev, Rf, sizeof(Rf), stream));
+                    TRY(c21hip_sync(stream)); /* `Rf` is a stack buffer */
+                    TRY(c21hip_apply_first_cross_recomb(c.mask, R_dev, c.prev_zre, spec->first_snapshot,
+                                                        spec->redshift, c.xH, c.zre, c.mfp, c.ntot, stream));
+                    TRY(one_radius(&c, 0, NULL, -1));
+                    continue;
+                }
                 /* the cell-scale radius tests xH > TINY: materialise the mask first */
                 TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot,
                                              spec->redshift, c.xH, c.zre, c.ntot, stream));

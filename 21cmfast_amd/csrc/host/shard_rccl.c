@@ -376,7 +376,7 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
  * boxes (again one message per peer and box).  Volumes at 512^3, 8 ranks, 4 rows: 537 MB per link
  * for the sums in double (C21CM_TS_SHARD_EXCHANGE=f32: partials rounded to float, 268 MB), 3 x 67 MB
  * per link for the outputs. */
-enum { WS_TSS_SUMS = 216, WS_TSS_SEND = 217, WS_TSS_RECV = 218, WS_TSS_SLAB = 219 };
+enum { WS_TSS_SUMS = 242, WS_TSS_SEND = 243, WS_TSS_RECV = 244, WS_TSS_SLAB = 245 };
 
 int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_field_redshift,
                          PerturbedField *perturbed_field, TsBox *previous_spin_temp,

@@ -57,6 +57,9 @@ CASES = [
     ((32, 32, 64), 2, 0, True, True, True),   # + x_e grid of a spin-temperature run
     (32, 1, 1, True, False, True),     # homogeneous: one number
     (35, 1, 1, False, False, False),
+    # 256-point z-lines, windows evaluated in pass X: the FUSED recombination loop (round 3)
+    ((128, 128, 256), 2, 1, True, False, True),
+    ((128, 128, 256), 1, 1, True, False, True),
 ]
 
 
@@ -83,8 +86,19 @@ def test_recombination_models_match_oracle(api, oracle, n, model, cell, lagrangi
     compare(got, ref, spec, flags=(ion_g, ion_r))
     assert 0.03 < ion_r.mean() < 0.97
     same = ion_g == ion_r
+    big = ion_r.size > 10**6
+    if big:
+        # 4 M cells: the float transforms leave ~3e-7 of a field's rms as noise (device and oracle
+        # alike, tools/scratch/diag_win2.py), which is 1e-5 .. 1e-4 of the LOCAL emissivity in the
+        # voids; there a cell within that of the barrier crosses one radius earlier or later, and
+        # Gamma_12 -- a filtered grid value over (1 + delta) -- inherits the local relative noise.
+        # Same bound as the ionisation flags for the crossing radius, then Gamma_12 where it agrees.
+        same_R = same & (got["mean_free_path"] == ref["mean_free_path"])
+        assert np.mean(~same_R & same) <= 2e-4
+        same = same_R
     np.testing.assert_allclose(got["ionisation_rate_G12"][same], ref["ionisation_rate_G12"][same],
-                               rtol=1e-4, atol=1e-9)
+                               rtol=2e-3 if big else 1e-4,
+                               atol=2e-6 * float(ref["ionisation_rate_G12"].max()) if big else 1e-9)
     np.testing.assert_array_equal(got["mean_free_path"][same], ref["mean_free_path"][same])
     assert (ref["ionisation_rate_G12"] > 0).any()
     if model == 2:
@@ -230,3 +244,45 @@ def test_c_level_sharding_with_an_emulated_transport(api, recomb, world):
         os.environ.pop("C21CM_SHARD_EXCHANGE", None)
         api.shard_finalize()
     assert 0.03 < float((buf0.neutral_fraction == 0).float().mean()) < 0.97
+
+
+@pytest.mark.parametrize("model", [2, 1])
+def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, model):
+    """CELL_RECOMB runs ride the fused loop (whalo_sfr as a third spectrum of the wave-level pass Z,
+    (1 + N_rec / (1 + delta)) in the barrier, Gamma_12 at first crossings, the mean free path from
+    the first-crossing index); C21CM_RECOMB_FUSED=0 is the per-radius sequence of round 2.  Same
+    crossings (up to cells within float round-off of the barrier), same Gamma_12 / N_rec."""
+    import torch
+
+    n = 256
+    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0)
+    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=77).items()}
+    if model == 1:
+        d["prev_nrec"] = torch.full((1, 1, 1), 0.25, dtype=torch.float32, device="cuda")
+    kw = dict(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"], prev_nrec=d["prev_nrec"],
+              prev_z_reion=d["prev_z_reion"])
+    monkeypatch.setenv("C21CM_RECOMB_FUSED", "0")
+    b0, _, r0 = api.ionize_grids(spec, d["density"], **kw)
+    monkeypatch.delenv("C21CM_RECOMB_FUSED")
+    b1, _, r1 = api.ionize_grids(spec, d["density"], **kw)
+    torch.cuda.synchronize()
+    c0, c1 = b0.mean_free_path > 0, b1.mean_free_path > 0
+    mism = float((c0 != c1).float().mean())
+    assert mism <= 1e-5, mism
+    # the crossing RADIUS of a cell within float noise of a barrier may differ by one step (two
+    # transform pipelines, ~3e-7 of a field's rms apart: 1e-5 .. 1e-4 of the local value in voids)
+    same = (c0 == c1) & (b0.mean_free_path == b1.mean_free_path)
+    assert float((~same).float().mean()) <= 2e-4
+    assert torch.equal(b0.z_reion[same], b1.z_reion[same])
+    a, b = b0.neutral_fraction[same], b1.neutral_fraction[same]
+    assert float((a - b).abs().max()) <= 6e-6
+    a, b = b0.ionisation_rate_G12[same], b1.ionisation_rate_G12[same]
+    assert bool(((a - b).abs() <= 1e-3 * a.abs() + 1e-5 * float(a.max())).all())
+    if model == 2:
+        a, b = b0.cumulative_recombinations[same], b1.cumulative_recombinations[same]
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+    assert abs(r0.global_xH - r1.global_xH) < 1e-6
+    n_r = spec.n_radii
+    np.testing.assert_allclose(np.array(r1.f_coll_grid_mean[:n_r]), np.array(r0.f_coll_grid_mean[:n_r]),
+                               rtol=1e-6)
+    assert 0.03 < float(c1.float().mean()) < 0.97
