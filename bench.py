@@ -143,9 +143,12 @@ PASS_KERNELS = {
     2: "zw_ionise_kernel<16,false,16> (wave-level pass Z of both grids + f_coll sum + barrier)",
     4: "window_table_kernel         (W(kR) of one radius for both windows, evaluated in fp64, stored as float)",
     6: "line_pass_kernel<{n},+1,5>  (pass X of TWO radii: each tile of both grids read once, windowed and transformed twice)",
+    7: "line_pass_kernel<{n},+1,6>  (pass X: x-lines of both grids, W(kR) evaluated in the kernel from node tables in LDS)",
+    8: "line_pass_kernel<{n},+1,7>  (pass X of TWO radii, W(kR) evaluated in the kernel: no window tables)",
 }
-# the key of each kernel in profiles/pmc_r01.json
-PMC_KEYS = {0: "pass_x_window", 1: "pass_y", 2: "pass_z_fused", 4: "window_tables", 6: "pass_x_pair"}
+# the key of each kernel in profiles/pmc_rNN.json
+PMC_KEYS = {0: "pass_x_window", 1: "pass_y", 2: "pass_z_fused", 4: "window_tables", 6: "pass_x_pair",
+            7: "pass_x_eval", 8: "pass_x_pair_eval"}
 
 
 def kernel_roofline(args, spec, torch):
@@ -166,15 +169,21 @@ def kernel_roofline(args, spec, torch):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     N = float(n) ** 3
     S = 8.0 * (N / 2 + n * n)
-    alg = {0: 4 * S, 1: 4 * S, 2: 2 * S + 2 * N, 4: 0.0, 6: 6 * S}
+    alg = {0: 4 * S, 1: 4 * S, 2: 2 * S + 2 * N, 4: 0.0, 6: 6 * S, 7: 4 * S, 8: 6 * S}
+    # windows evaluated inside pass X (round 3; C21CM_WINDOWS=table keeps the streamed tables):
+    # the step then runs kernels 7 / 8 instead of 0 / 6 and launches no table kernel
+    lib.c21hip_wev_applicable.restype = C.c_int
+    evaluated = bool(lib.c21hip_wev_applicable(int(spec.hii_filter), int(spec.stars_filter), 2, n, n, n))
     paired = (os.environ.get("C21CM_PAIR_RADII", "1") != "0" and n <= 512
               and spec.fcoll_mode == importlib.import_module("21cmfast_amd.workloads").FCOLL_STARS)
     n_fused = spec.n_radii - 1  # launches per step (radius index 0 is the final sweep)
     launches = {0: n_fused % 2 if paired else n_fused, 6: n_fused // 2 if paired else 0,
                 1: n_fused, 2: n_fused, 4: n_fused}
+    launches[7], launches[8] = launches[0], launches[6]
     R_mid = spec.R[spec.n_radii // 2]
     out = {}
-    for kind in (0, 1, 2, 4) + ((6,) if paired else ()):
+    kinds = ((7, 1, 2) + ((8,) if paired else ())) if evaluated else ((0, 1, 2, 4) + ((6,) if paired else ()))
+    for kind in kinds:
         ms = C.c_float()
         st = lib.c21hip_bench_pass(kind, n, int(spec.hii_filter), int(spec.stars_filter), R_mid,
                                    float(spec.mfp_meandens) or 1.0, spec.box_len, 20, stream,

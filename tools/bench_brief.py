@@ -2,7 +2,7 @@
 import json
 import sys
 
-d = json.loads(sys.stdin.read())
+d = json.loads(open(sys.argv[1]).read() if len(sys.argv) > 1 and sys.argv[1] != "/dev/stdin" else sys.stdin.read())
 r = d["roofline"]
 print(sys.argv[1] if len(sys.argv) > 1 else "", "ms/step", round(d["ms_per_step"], 3), "xH",
       d["config"]["global_xH"], "r_loop ms", round(r["r_loop"]["ms"], 3), "frac",

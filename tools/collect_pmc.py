@@ -33,6 +33,8 @@ def kernel_sources_sha() -> str:
 KERNELS = {  # the needles follow rocprofv3's demangled names; N = 512 is the benchmark config
     "pass_x_window": "line_pass_kernel<512, 1, 3>",
     "pass_x_pair": "line_pass_kernel<512, 1, 5>",
+    "pass_x_eval": "line_pass_kernel<512, 1, 6>",
+    "pass_x_pair_eval": "line_pass_kernel<512, 1, 7>",
     "pass_y": "line_pass_kernel<512, 1, 0>",
     "pass_z_fused": "zw_ionise_kernel<16, false",
     "window_tables": "window_table_kernel",
