@@ -17,6 +17,8 @@
 // inside L2; summation order is the only non-determinism (1e-16 relative).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cmath>
 #include <cstdlib>
 
@@ -1277,12 +1279,29 @@ extern "C" int c21hip_halo_deposit(const c21cm_halo_consts *consts, unsigned lon
         g.nb[a] = (out_dim[a] + kHaloBrick - 1) / kHaloBrick;
         n_bricks *= (size_t)g.nb[a];
     }
-    static int direct = -1;  // C21CM_HALO_DEPOSIT=direct: eight global atomics per value and halo
-    if (direct < 0) {
+    static std::once_flag once;
+    static int direct = 0;    // C21CM_HALO_DEPOSIT=direct: eight global atomics per value and halo
+    static size_t lds_cap = 0;  // dynamic LDS the tiled kernel may ask for on this device
+    std::call_once(once, [] {
         const char *e = getenv("C21CM_HALO_DEPOSIT");
         direct = e && e[0] == 'd';
-    }
-    if (direct || !scratch || n_halos >= (1ull << 31) || n_bricks >= (1ull << 30)) {
+        int dev = 0, max_lds = 0;
+        const int want = 5 * kHaloTileCells * (int)sizeof(double);
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess) {
+            const int ask = want < max_lds ? want : max_lds;
+            if (hipFuncSetAttribute((const void *)halo_deposit_tiled_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ask) == hipSuccess)
+                lds_cap = (size_t)ask;
+        }
+        (void)hipGetLastError();
+    });
+    int nv_tiles = 0;
+    for (int v = 0; v < 5; v++) nv_tiles += O.g[v] != nullptr;
+    // (a device with less LDS than the tiles of this call need -- 88 KB for five grids -- takes the
+    //  direct deposit instead of failing the launch: ADVICE r2)
+    const bool tiles_fit = (size_t)nv_tiles * kHaloTileCells * sizeof(double) <= lds_cap;
+    if (direct || !tiles_fit || !scratch || n_halos >= (1ull << 31) || n_bricks >= (1ull << 30)) {
         hipLaunchKernelGGL(halo_deposit_kernel, dim3(grid_for((size_t)n_halos)), dim3(kBlock), 0, st,
                            h, A, O);
         LAUNCH_CHECK();
@@ -1305,13 +1324,6 @@ extern "C" int c21hip_halo_deposit(const c21cm_halo_consts *consts, unsigned lon
     int nv = 0;
     for (int v = 0; v < 5; v++) nv += O.g[v] != nullptr;
     const size_t lds = (size_t)nv * kHaloTileCells * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)halo_deposit_tiled_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  5 * kHaloTileCells * (int)sizeof(double));
-        attr_done = true;
-    }
     const int blocks = (int)(n_bricks < 256 * 16 ? n_bricks : 256 * 16);
     hipLaunchKernelGGL(halo_deposit_tiled_kernel, dim3(blocks), dim3(kBlock), lds, st, h, g, A, O,
                        offsets, order);

@@ -58,6 +58,37 @@ void Free_cosmo_tables_global(void) {
     cosmo_tables_global = NULL;
 }
 
+/* What the power-spectrum state (sigma normalisation, transfer function, the sigma(M) spline keyed
+ * on it) depends on: the cosmology, the matter options and the tables' normalisation / contents.
+ * py21cmfast broadcasts the structs before EVERY Compute* call; dropping the state each time made
+ * every snapshot rebuild the 416-knot sigma(M) spline.  It is dropped only when this
+ * fingerprint changes (FNV-1a over the bytes; padding that differs only costs a rebuild). */
+static unsigned long long fnv(unsigned long long h, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+static unsigned long long ps_fingerprint(const MatterOptions *mo, const CosmoParams *cp,
+                                         const CosmoTables *ct) {
+    unsigned long long h = 14695981039346656037ull;
+    if (cp) h = fnv(h, cp, sizeof(*cp));
+    if (mo) h = fnv(h, mo, sizeof(*mo));
+    if (ct) {
+        h = fnv(h, &ct->ps_norm, sizeof(ct->ps_norm));
+        h = fnv(h, &ct->USE_SIGMA_8, sizeof(ct->USE_SIGMA_8));
+        h = fnv(h, &ct->V_CB_AVG, sizeof(ct->V_CB_AVG));
+        const Table1D *tabs[2] = {ct->transfer_density, ct->transfer_vcb};
+        for (int i = 0; i < 2; i++)
+            if (tabs[i] && tabs[i]->size > 0 && tabs[i]->x_values && tabs[i]->y_values) {
+                h = fnv(h, &tabs[i]->size, sizeof(tabs[i]->size));
+                h = fnv(h, tabs[i]->x_values, sizeof(double) * (size_t)tabs[i]->size);
+                h = fnv(h, tabs[i]->y_values, sizeof(double) * (size_t)tabs[i]->size);
+            }
+    }
+    return h ? h : 1;
+}
+static unsigned long long g_ps_print; /* 0: nothing broadcast yet */
+
 void Broadcast_struct_global_all(SimulationOptions *simulation_options,
                                  MatterOptions *matter_options, CosmoParams *cosmo_params,
                                  AstroParams *astro_params, AstroOptions *astro_options,
@@ -70,7 +101,15 @@ void Broadcast_struct_global_all(SimulationOptions *simulation_options,
     /* The power-spectrum state (sigma normalisation, EH parameters, the sigma(M) spline keyed on
      * it) belongs to the cosmology that was broadcast before: drop it, the next Compute* call
      * (or the caller's own init_ps, as py21cmfast does) rebuilds it for the new structs. */
-    free_ps();
+    {
+        const unsigned long long print = ps_fingerprint(matter_options, cosmo_params, cosmo_tables);
+        const int same = (print == g_ps_print) && cosmo_tables_global && cosmo_tables;
+        if (print != g_ps_print) free_ps();
+        g_ps_print = print;
+        /* unchanged: the deep copy made at the last broadcast stays (init_ps's CLASS splines point
+         * into it), a changed one is replaced together with the state that was built on it */
+        if (same) return;
+    }
     Free_cosmo_tables_global();
     if (!cosmo_tables) return;
     cosmo_tables_global = (CosmoTables *)calloc(1, sizeof(CosmoTables));
@@ -90,5 +129,9 @@ void Broadcast_struct_global_noastro(SimulationOptions *simulation_options,
     simulation_options_global = simulation_options;
     matter_options_global = matter_options;
     cosmo_params_global = cosmo_params;
-    free_ps(); /* as above: never reuse the previous cosmology's normalisation */
+    {   /* as above; the tables of the last full broadcast stay in place */
+        const unsigned long long print = ps_fingerprint(matter_options, cosmo_params, cosmo_tables_global);
+        if (print != g_ps_print) free_ps();
+        g_ps_print = print;
+    }
 }

@@ -45,6 +45,8 @@ static struct {
     int (*get_unique_id)(rccl_unique_id *);
     int (*comm_init_rank)(rccl_comm *, int, rccl_unique_id, int);
     int (*comm_destroy)(rccl_comm);
+    int (*comm_count)(rccl_comm, int *);
+    int (*all_reduce)(const void *, void *, size_t, int, int, rccl_comm, void *);
     int (*reduce)(const void *, void *, size_t, int, int, int, rccl_comm, void *);
     int (*broadcast)(const void *, void *, size_t, int, int, rccl_comm, void *);
     int (*send)(const void *, size_t, int, int, rccl_comm, void *);
@@ -184,6 +186,8 @@ static int rccl_load(void) {
     *(void **)&R.get_unique_id = dlsym(R.lib, "ncclGetUniqueId");
     *(void **)&R.comm_init_rank = dlsym(R.lib, "ncclCommInitRank");
     *(void **)&R.comm_destroy = dlsym(R.lib, "ncclCommDestroy");
+    *(void **)&R.comm_count = dlsym(R.lib, "ncclCommCount");
+    *(void **)&R.all_reduce = dlsym(R.lib, "ncclAllReduce");
     *(void **)&R.reduce = dlsym(R.lib, "ncclReduce");
     *(void **)&R.broadcast = dlsym(R.lib, "ncclBroadcast");
     *(void **)&R.send = dlsym(R.lib, "ncclSend");
@@ -270,6 +274,46 @@ static int bcast_array(float *p, size_t bytes, int root, void *stream) {
     return c21hip_sync(stream); /* the staging slot is reused by the next array */
 }
 
+/* Every rank learns whether ANY rank failed its local phase before the data collectives start
+ * (a rank that returned early left the others blocked in ncclReduce / ncclRecv for
+ * ever): a max-all-reduce of one int32.  Returns the rank's own status if it failed, a generic
+ * error if another rank did, 0 otherwise.  Emulated transports run the ranks one by one: skipped. */
+enum { RCCL_INT32 = 2 };
+static int agree_status(int st_local, void *stream) {
+    if (R.ready != 1 || R.world < 2 || !R.all_reduce) return st_local;
+    int *d = (int *)c21hip_ws(WS_SHARD_SCALARS, sizeof(double) * C21CM_MAX_RADII);
+    int flag = st_local ? 1 : 0;
+    if (!d) return st_local ? st_local : C21CM_MEMORY_ALLOC_ERROR;
+    if (c21hip_h2d(d, &flag, sizeof(int), stream) ||
+        rccl_check(R.all_reduce(d, d, 1, RCCL_INT32, RCCL_MAX, R.comm, stream), "ncclAllReduce(status)") ||
+        c21hip_d2h(&flag, d, sizeof(int), stream) || c21hip_sync(stream))
+        return st_local ? st_local : C21CM_IO_ERROR;
+    if (st_local) return st_local;
+    if (flag) {
+        c21hip_set_error("shard: another rank failed its local phase; this call is abandoned on every rank");
+        return C21CM_IO_ERROR;
+    }
+    return 0;
+}
+
+/* Device time of the three phases of this rank's last c21cm_ionize_sharded call (ms: shard phase,
+ * exchange, finish; synchronises on the last mark).  The exchange entry includes the wait for the
+ * slowest peer.  Returns 0, or C21CM_VALUE_ERROR when no sharded call has completed. */
+static void *g_phase_ev[4];
+static int g_phase_valid;
+int c21cm_shard_last_phases(double ms[3]) {
+    if (!g_phase_valid || !g_phase_ev[0] || !g_phase_ev[3]) return C21CM_VALUE_ERROR;
+    if (c21hip_event_synchronize(g_phase_ev[3])) return C21CM_IO_ERROR;
+    for (int i = 0; i < 3; i++) ms[i] = c21hip_event_elapsed_ms(g_phase_ev[i], g_phase_ev[i + 1]);
+    return 0;
+}
+/* ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount); 0: none / emulated */
+int c21cm_shard_comm_count(void) {
+    int n = 0;
+    if (R.ready == 1 && R.comm && R.comm_count && R.comm_count(R.comm, &n) == 0) return n;
+    return 0;
+}
+
 int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
                          const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                          const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
@@ -289,14 +333,22 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
     const int need_means = (!spec->fix_mean && spec->r_lowest > 0);
     c21cm_ionize_report local;
     memset(&local, 0, sizeof(local));
+    /* phase marks on the caller's stream: shard phase | exchange | finish (c21cm_shard_last_phases) */
+    for (int i = 0; i < 4; i++)
+        if (!g_phase_ev[i]) g_phase_ev[i] = c21hip_event_create();
+    g_phase_valid = 0;
+#define MARK(i) do { if (g_phase_ev[i]) (void)c21hip_event_record(g_phase_ev[i], stream); } while (0)
+    MARK(0);
 
     if (!recomb) {
         unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, ntot);
         if (!fc) return C21CM_MEMORY_ALLOC_ERROR;
-        if ((st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box,
-                                           spin_temp, halos, fc, need_means ? &local : NULL, stream)))
-            return st;
+        st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box, spin_temp,
+                                      halos, fc, need_means ? &local : NULL, stream);
+        if ((st = agree_status(st, stream))) return st;
+        MARK(1);
         if ((st = exchange_mask(fc, ntot, owner, stream))) return st;
+        MARK(2);
         if (need_means) {
             double *d = (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean));
             if (!d) return C21CM_MEMORY_ALLOC_ERROR;
@@ -318,19 +370,24 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
     } else {
         unsigned long long *keys = (unsigned long long *)c21hip_ws(WS_SHARD_GRID, 8 * ntot);
         if (!keys) return C21CM_MEMORY_ALLOC_ERROR;
-        if ((st = c21cm_ionize_shard_radii_keys(spec, rank, world, perturbed_field,
-                                                previous_ionize_box, spin_temp, halos, keys, NULL,
-                                                stream)))
-            return st;
+        st = c21cm_ionize_shard_radii_keys(spec, rank, world, perturbed_field, previous_ionize_box,
+                                           spin_temp, halos, keys, NULL, stream);
+        if ((st = agree_status(st, stream))) return st;
+        MARK(1);
         if ((st = rccl_check(R.reduce(keys, keys, ntot, RCCL_UINT64, RCCL_MAX, owner, R.comm, stream),
                              "ncclReduce(cross_keys)")))
             return st;
+        MARK(2);
         if (rank == owner)
             st = c21cm_ionize_shard_finish_keys(spec, keys, perturbed_field, previous_ionize_box,
                                                 spin_temp, halos, box, report, stream);
     }
-    if (st) return st;
-    if (!broadcast) return 0;
+    MARK(3);
+    g_phase_valid = 1;
+#undef MARK
+    if (!broadcast) return st;
+    /* the owner's finish step may have failed: nobody enters the broadcasts then */
+    if ((st = agree_status(st, stream))) return st;
 
     /* every rank returns the finished box */
     const size_t db = ntot * sizeof(float);
@@ -391,9 +448,9 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
     int st = 0, rows = 0;
     double *sums = (double *)c21hip_ws(WS_TSS_SUMS, 6 * ntot * sizeof(double));
     if (!sums) return C21CM_MEMORY_ALLOC_ERROR;
-    if ((st = c21cm_ts_box_shard_sums(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
-                                      previous_spin_temp, rank, world, sums, &rows)))
-        return st;
+    st = c21cm_ts_box_shard_sums(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
+                                 previous_spin_temp, rank, world, sums, &rows);
+    if ((st = agree_status(st, NULL))) return st;
     const char *e = getenv("C21CM_TS_SHARD_EXCHANGE");
     const int f32 = (e && e[0] == 'f' && e[1] == '3') ? 1 : 0;
     const size_t esz = f32 ? sizeof(float) : sizeof(double);
@@ -427,10 +484,9 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
     if (!slab) return C21CM_MEMORY_ALLOC_ERROR;
     if ((st = c21hip_ts_combine_slab(sums, ntot, world, rank, rows, maxlen, f32, recvb, slab, NULL)))
         return st;
-    if ((st = c21cm_ts_box_shard_finish(redshift, prev_redshift, perturbed_field_redshift,
-                                        perturbed_field, previous_spin_temp, slab, c0, len,
-                                        this_spin_temp)))
-        return st;
+    st = c21cm_ts_box_shard_finish(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
+                                   previous_spin_temp, slab, c0, len, this_spin_temp);
+    if ((st = agree_status(st, NULL))) return st;
     if (world > 1) { /* all-gather: every rank ends with the full boxes */
         float *boxes[3] = {this_spin_temp->spin_temperature, this_spin_temp->kinetic_temp_neutral,
                            this_spin_temp->xray_ionised_fraction};

@@ -336,6 +336,24 @@ def main():
     cells = float(n) ** 3
     value = cells / (ms_per_step * 1e-3)
 
+    # per-rank phase times of the last sharded step (C-level exchange): shard phase / exchange /
+    # finish on every rank, gathered to rank 0, so that a SCALE line can be read
+    shard_phases, rccl_ranks = None, None
+    if sharded and shard_c:
+        import ctypes as C
+
+        lib = pkg.load()
+        lib.c21cm_shard_last_phases.restype = C.c_int
+        lib.c21cm_shard_comm_count.restype = C.c_int
+        ph = (C.c_double * 3)()
+        ok = lib.c21cm_shard_last_phases(ph) == 0
+        mine = torch.tensor([ph[0], ph[1], ph[2]] if ok else [float("nan")] * 3, device="cuda",
+                            dtype=torch.float64)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        shard_phases = [[round(float(v), 3) for v in t.tolist()] for t in allp]
+        rccl_ranks = int(lib.c21cm_shard_comm_count())
+
     # the finishing rank holds the result: hand its global x_HI to rank 0 for the JSON line
     global_xh = None
     if sharded:
@@ -409,6 +427,9 @@ def main():
                 + ("1-bit mask gather over RCCL inside the C library (c21cm_ionize_sharded)" if shard_c
                    else f"{'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce via torch.distributed"),
                 **({"shard_impl_note": shard_note} if shard_note else {}),
+                **({"shard_phases_ms_per_rank": shard_phases, "shard_phases": "shard phase, exchange "
+                    "(incl. waiting for the slowest peer), finish -- device time of the last step",
+                    "rccl_comm_count": rccl_ranks} if shard_phases is not None else {}),
                 "fft": "native" if native else "rocfft",
                 "global_xH": global_xh,
             },

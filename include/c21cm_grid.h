@@ -237,6 +237,10 @@ int c21cm_shard_unique_id(void *id128);
 int c21cm_shard_init(int rank, int world, const void *id128);
 int c21cm_shard_finalize(void);
 int c21cm_shard_info(int *rank, int *world); /* returns 0 and fills them when initialised */
+/* device time (ms) of this rank's last c21cm_ionize_sharded call: shard phase, exchange (includes
+ * the wait for the slowest peer), finish; and the rank count RCCL itself reports (ncclCommCount) */
+int c21cm_shard_last_phases(double ms[3]);
+int c21cm_shard_comm_count(void);
 
 /* ---- ComputeTsBox sharded over the same communicator (the N_STEP_TS shells dealt round-robin;
  * reference: SpinTemperatureBox.c:1541-1784 is linear in the shells).  With a communicator in place
