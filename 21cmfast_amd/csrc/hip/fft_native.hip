@@ -54,6 +54,9 @@
 #ifndef C21X_ZW_OCC       // min waves per SIMD requested for the fused pass Z (0: compiler's choice)
 #define C21X_ZW_OCC 0
 #endif
+#ifndef C21X_ZW_BLOCK     // threads per workgroup of the fused pass Z on 512-point lines (64, 128, 256)
+#define C21X_ZW_BLOCK 256
+#endif
 #ifndef C21X_ZW_LATE      // 1: second grid and mask rows requested after the first transform
 #define C21X_ZW_LATE 0
 #endif
@@ -66,7 +69,10 @@ constexpr int TZ = 16;  // columns per tile (128 B of float2) for lines up to 51
 // transform is split instead (line_fft): one in-place radix-2 decimation-in-frequency stage, two
 // 512-point transforms of the halves, and the even/odd interleave folded into the row index of
 // the store; one register set instead of two keeps the kernel inside 256 VGPRs.
-constexpr int line_tile_cols(int n) { return TZ; }
+// 1536-point lines (the reference's default DIM = 3 HII_DIM at HII_DIM = 512): a 16-column tile
+// would be 196 KB; 8 columns (64-byte row segments) are 98 KB and take the split transform of the
+// 1024-point lines -- one radix-2 stage, two 768-point (= 3 x 2^8) transforms.
+constexpr int line_tile_cols(int n) { return n == 1536 ? TZ / 2 : TZ; }
 // LDS row that holds output index g of a line after line_fft
 template <int N>
 __device__ __forceinline__ int fft_out_row(int g) {
@@ -1831,6 +1837,7 @@ int dispatch_line_pass(int n, const LinePassArgs &a, int fmode, hipStream_t stre
         case 512: return launch_line_pass<512, SIGN>(a, fmode, stream);
         case 768: return launch_line_pass<768, SIGN>(a, fmode, stream);
         case 1024: return launch_line_pass<1024, SIGN>(a, fmode, stream);
+        case 1536: return launch_line_pass<1536, SIGN>(a, fmode, stream);
         default:
             c21hip_set_error("native FFT: unsupported line length %d", n);
             return C21CM_VALUE_ERROR;
@@ -1930,16 +1937,17 @@ __global__ void
 #if C21X_ZW_OCC
 __launch_bounds__(kBlock, (A == 16 && !TS) ? C21X_ZW_OCC : 1)
 #else
-__launch_bounds__(kBlock)
+__launch_bounds__((A == 16 && P == 16) ? C21X_ZW_BLOCK : kBlock)
 #endif
 zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                  const float2 *__restrict__ twN_global) {
-    constexpr int H = P * A, NZ = 2 * H, ZWL = zw_lines(P);
+    constexpr int ZBLK = (A == 16 && P == 16) ? C21X_ZW_BLOCK : kBlock;  // threads of this workgroup
+    constexpr int H = P * A, NZ = 2 * H, ZWL = ZBLK / P;
     constexpr int LINE_LDS = A * (P + 1) + 4;  // float2 per line region (padded rows + skew)
     __shared__ float2 lines[ZWL * LINE_LDS];
     __shared__ float2 twH[H], twN[H];
-    __shared__ double red[kBlock / 64];
-    for (int t = threadIdx.x; t < H; t += kBlock) {
+    __shared__ double red[ZBLK / 64];
+    for (int t = threadIdx.x; t < H; t += ZBLK) {
         twH[t] = twH_global[t];
         twN[t] = twN_global[t];
     }
@@ -2074,7 +2082,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     if (threadIdx.x == 0) {
         double sum = 0.;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) sum += red[w];
+        for (int w = 0; w < ZBLK / 64; w++) sum += red[w];
         a.partials[blk] = sum;
     }
 }
@@ -2486,16 +2494,18 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
         LAUNCH_CHECK();
         return 0;
     }
-    if (const int zwl = zw_lines_of(nz, nlines)) {
+    if (int zwl = zw_lines_of(nz, nlines)) {
         const float2 *twH = twiddles(nz / 2);
         const float2 *twN = twiddles(nz);
         if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+        const int zblk = (nz == 512) ? C21X_ZW_BLOCK : kBlock;  // (A = 16, P = 16)
+        if (nz == 512) zwl = zblk / 16;
         *n_partials = (int)(nlines / zwl);
         const dim3 grid((unsigned)(nlines / zwl));
 #define ZW_FUSED(A, TS, P) \
-    hipLaunchKernelGGL((zw_ionise_kernel<A, TS, P>), grid, dim3(kBlock), 0, stream, a, twH, twN)
+    hipLaunchKernelGGL((zw_ionise_kernel<A, TS, P>), grid, dim3(zblk), 0, stream, a, twH, twN)
 #define ZW_FUSED_RC(A, P) \
-    hipLaunchKernelGGL((zw_ionise_kernel<A, false, P, true>), grid, dim3(kBlock), 0, stream, a, twH, twN)
+    hipLaunchKernelGGL((zw_ionise_kernel<A, false, P, true>), grid, dim3(zblk), 0, stream, a, twH, twN)
         if (a.rc) {
             if (nz == 256)
                 ZW_FUSED_RC(16, 8);
@@ -2534,6 +2544,7 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
         case 512: return launch_z_fused<512>(a, nlines, stream);
         case 768: return launch_z_fused<768>(a, nlines, stream);
         case 1024: return launch_z_fused<1024>(a, nlines, stream);
+        case 1536: return launch_z_fused<1536>(a, nlines, stream);
         default:
             c21hip_set_error("native FFT: unsupported z length %d for the fused pass", nz);
             return C21CM_VALUE_ERROR;
@@ -2583,6 +2594,7 @@ int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
         case 512: return launch_z_r2c<512>(a, nlines, stream);
         case 768: return launch_z_r2c<768>(a, nlines, stream);
         case 1024: return launch_z_r2c<1024>(a, nlines, stream);
+        case 1536: return launch_z_r2c<1536>(a, nlines, stream);
         case 2048: return launch_z_r2c<2048>(a, nlines, stream);
         default:
             c21hip_set_error("native FFT: unsupported z length %d", nz);
@@ -2616,6 +2628,7 @@ int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) 
         case 512: return launch_z_c2r<512, EPI>(a, nlines, stream);
         case 768: return launch_z_c2r<768, EPI>(a, nlines, stream);
         case 1024: return launch_z_c2r<1024, EPI>(a, nlines, stream);
+        case 1536: return launch_z_c2r<1536, EPI>(a, nlines, stream);
         case 2048: return launch_z_c2r<2048, EPI>(a, nlines, stream);
         default:
             c21hip_set_error("native FFT: unsupported z length %d", nz);
@@ -2659,9 +2672,9 @@ void fill_filter(FilterParams &fp, int filter_type, float R, float R_param, doub
 
 // nx, ny in {64..1024}, nz in {64..2048}, all powers of two
 // line lengths of the native passes: 2^L (64 .. 1024; z-lines up to 2048) and 3 * 2^L for the
-// reference's default DIM = 3 HII_DIM grids (192, 384, 768; 1536 would need a 196 KB tile)
+// reference's default DIM = 3 HII_DIM grids (192, 384, 768, 1536)
 static bool native_len(int n, int pow2_max) {
-    return (pow2(n) && n >= 64 && n <= pow2_max) || n == 192 || n == 384 || n == 768;
+    return (pow2(n) && n >= 64 && n <= pow2_max) || n == 192 || n == 384 || n == 768 || n == 1536;
 }
 extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz) {
     return native_len(nx, 1024) && native_len(ny, 1024) && native_len(nz, 2048);
@@ -3627,7 +3640,7 @@ extern "C" int c21hip_batched_stats(const double *partials, long stride, int nb,
 extern "C" int c21hip_z_ionise_partials(int nx, int ny, int nz) {
     const long nlines = (long)nx * ny;
     if (zw3_selected(nz, nlines)) return (int)(nlines / (kBlock / 64));
-    if (const int zwl = zw_lines_of(nz, nlines)) return (int)(nlines / zwl);
+    if (const int zwl = zw_lines_of(nz, nlines)) return (int)(nlines / (nz == 512 ? C21X_ZW_BLOCK / 16 : zwl));
     return (int)(nlines / LZ_FUSED);
 }
 

@@ -42,19 +42,22 @@ def test_fft_roundtrip_and_spectrum(api, oracle, shape):
 
 def test_radix3_sizes_run_on_the_native_passes(gpu_lib):
     """192 / 384 / 768-point lines leave rocFFT (the reference's default is DIM = 3 HII_DIM,
-    wrapper/inputs.py:915); 96 and 1536 do not (loader geometry / a 196 KB tile)."""
+    wrapper/inputs.py:915), and since round 3 so do 1536-point lines (8-column tiles, one radix-2
+    stage + two 768-point transforms); 96 does not (loader geometry)."""
     for n in (192, 384, 768):
         assert gpu_lib.c21hip_fft_is_native(n, n, n)
         assert gpu_lib.c21hip_fft_is_native(256, n, 64)
-    for n in (96, 1536, 150, 320):
+    assert gpu_lib.c21hip_fft_is_native(1536, 64, 1536) and gpu_lib.c21hip_fft_is_native(256, 1536, 64)
+    for n in (96, 150, 320):
         assert not gpu_lib.c21hip_fft_is_native(n, n, n)
 
 
-def test_fft_768_against_numpy(api):
-    """A full 768-point transform along every axis (thin box) against numpy in double."""
+@pytest.mark.parametrize("shape", [(768, 64, 768), (1536, 64, 1536), (64, 1536, 192)])
+def test_fft_768_and_1536_against_numpy(api, shape):
+    """Full 768- and 1536-point transforms along every axis (thin boxes) against numpy in double;
+    1536 = the reference's default DIM at HII_DIM = 512."""
     import torch
 
-    shape = (768, 64, 768)
     rng = np.random.default_rng(9)
     a = rng.standard_normal(shape).astype(np.float32)
     pad = np.zeros((shape[0], shape[1], shape[2] + 2), np.float32)
