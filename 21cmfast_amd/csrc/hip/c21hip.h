@@ -475,6 +475,10 @@ int c21hip_pack_mask_bits(const unsigned char *fc, unsigned *bits, size_t ntot, 
 int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
                                unsigned char *fc, size_t ntot, void *stream);
 int c21hip_max_into(void *dst, const void *src, size_t count, int bytes_per_element, void *stream);
+/* sharded fused recombination loop: own slab (mask, g12; in place) against n_peers received slabs
+ * of `stride` cells each -- larger first-crossing index wins, with its Gamma_12 */
+int c21hip_combine_cross_g12(unsigned char *mask, float *g12, const unsigned char *peer_mask,
+                             const float *peer_g12, int n_peers, size_t stride, size_t n, void *stream);
 int c21hip_sum_float(const float *v, size_t n, double *partials, double *sum_out, void *stream);
 int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *nion_dense,
                          const float *xe_dense, const double *mean_dev,

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 
 #include "c21hip.h"
 #include "c21cm_abi.h"
@@ -1389,6 +1390,64 @@ extern "C" int c21hip_apply_cross_keys(const unsigned long long *keys, const flo
     hipLaunchKernelGGL(apply_cross_keys_kernel, dim3(grid_for(ntot)), dim3(kBlock), 0,
                        (hipStream_t)stream, keys, prev_z_reion, first_snapshot, (float)redshift, xH,
                        z_reion, G12, mfp, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// Sharded fused recombination loop: the winner of a cell is the rank with the larger
+// first-crossing index (an index > 0 belongs to one rank), together with ITS Gamma_12.  The own
+// slab (mask / g12, in place) against `n_peers` received slabs of `stride` cells each; four cells
+// per thread (slab bounds are multiples of 4 cells).
+__global__ void __launch_bounds__(kBlock)
+combine_cross_g12_kernel(unsigned char *__restrict__ mask, float *__restrict__ g12,
+                         const unsigned char *__restrict__ peer_mask, const float *__restrict__ peer_g12,
+                         int n_peers, size_t stride, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+        uchar4 m = reinterpret_cast<uchar4 *>(mask)[i];
+        float4 g = reinterpret_cast<float4 *>(g12)[i];
+        bool touched = false;
+        for (int q = 0; q < n_peers; q++) {
+            const uchar4 pm = reinterpret_cast<const uchar4 *>(peer_mask + q * stride)[i];
+            if (pm.x > m.x || pm.y > m.y || pm.z > m.z || pm.w > m.w) {
+                const float4 pg = reinterpret_cast<const float4 *>(peer_g12 + q * stride)[i];
+                if (pm.x > m.x) { m.x = pm.x; g.x = pg.x; }
+                if (pm.y > m.y) { m.y = pm.y; g.y = pg.y; }
+                if (pm.z > m.z) { m.z = pm.z; g.z = pg.z; }
+                if (pm.w > m.w) { m.w = pm.w; g.w = pg.w; }
+                touched = true;
+            }
+        }
+        if (touched) {
+            reinterpret_cast<uchar4 *>(mask)[i] = m;
+            reinterpret_cast<float4 *>(g12)[i] = g;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail of the last slab
+        const size_t i = n4 * 4 + threadIdx.x;
+        unsigned char m = mask[i];
+        float g = g12[i];
+        for (int q = 0; q < n_peers; q++)
+            if (peer_mask[q * stride + i] > m) {
+                m = peer_mask[q * stride + i];
+                g = peer_g12[q * stride + i];
+            }
+        mask[i] = m;
+        g12[i] = g;
+    }
+}
+
+extern "C" int c21hip_combine_cross_g12(unsigned char *mask, float *g12, const unsigned char *peer_mask,
+                                        const float *peer_g12, int n_peers, size_t stride, size_t n,
+                                        void *stream) {
+    if (n_peers < 1 || n == 0) return 0;
+    if (((uintptr_t)mask & 3) || ((uintptr_t)g12 & 15) || ((uintptr_t)peer_mask & 3) ||
+        ((uintptr_t)peer_g12 & 15) || (stride & 3)) {
+        c21hip_set_error("combine_cross_g12: slabs must start at multiples of 4 cells");
+        return C21CM_VALUE_ERROR;
+    }
+    hipLaunchKernelGGL(combine_cross_g12_kernel, dim3(grid_for(n / 4 + 1)), dim3(kBlock), 0,
+                       (hipStream_t)stream, mask, g12, peer_mask, peer_g12, n_peers, stride, n);
     LAUNCH_CHECK();
     return 0;
 }

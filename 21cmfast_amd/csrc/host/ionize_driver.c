@@ -349,6 +349,7 @@ typedef struct {
 static int r0_direct(void);
 
 static int g_single_pass; /* set by c21cm_ionize_grids around its ctx_setup: not a shard phase */
+static int g_rc_phase;    /* set by the (first crossing, Gamma_12) shard phases around their ctx_setup */
 
 static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedField *pf,
                      const IonizedBox *prev, const TsBox *ts, const HaloBox *halos,
@@ -412,7 +413,8 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
      * b alone).  C21CM_RECOMB_FUSED=0: the unfused per-radius sequence. */
     c->fused_rc = 0;
     if (c->native && c->lagrangian && c->recomb && s->cell_recomb && !s->use_ts_fluct &&
-        !s->use_mini_halos && !s->ionise_entire_sphere && g_single_pass) {
+        !s->use_mini_halos && !s->ionise_entire_sphere && s->r_lowest == 0 &&
+        (g_single_pass || g_rc_phase)) {
         const char *e = getenv("C21CM_RECOMB_FUSED");
         if (!(e && e[0] == '0') && c21hip_z_ionise_recomb_supported(c->nx, c->ny, c->nz) &&
             c21hip_wev_applicable(s->hii_filter, s->stars_filter, 2, c->nx, c->ny, c->nz))
@@ -858,6 +860,7 @@ done:
 static int fused_loop(ion_ctx *c, int first, int step, int lowest, unsigned char *first_cross) {
     int status = 0;
     if (lowest < 1) lowest = 1;
+    if (first < lowest) return 0; /* a rank beyond the number of radii has nothing to do */
     /* Windows evaluated inside pass X from node tables of W(kR) (fft_native.hip: c21hip_wev_prepare)
      * where the filter types and the line length allow it: then no 3-D window table is built,
      * written or streamed for these radii (C21CM_WINDOWS=table keeps the tables). */
@@ -1771,6 +1774,149 @@ int c21cm_ionize_shard_finish_keys(const c21cm_ionize_spec *spec,
         g_spectra.valid = 0;
         TRY(one_radius(&c, 0, NULL, -1));
     }
+    TRY(c21hip_event_record(ev[1], stream));
+    TRY(postloop(&c, box, report));
+    TRY(c21hip_event_record(ev[2], stream));
+    if (report) {
+        report->ms_preloop = 0.;
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_postloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+    }
+done:
+    for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}
+
+/* ---- R-loop sharding of the FUSED recombination loop (round 3) ---------------------------------
+ * CELL_RECOMB runs without an x_e grid ride the fused loop (ctx_setup: fused_rc), whose state after
+ * the radii is the uint8 first-crossing index plus Gamma_12 at the crossing -- the mean free path
+ * IS the radius of that index.  A rank's radii therefore leave 5 bytes per cell instead of the
+ * 8-byte key, the winner of a cell is the rank with the larger index (indices > 0 are owned by
+ * one rank each) together with ITS Gamma_12 (c21hip_combine_cross_g12), and the finish phase is
+ * the tail of the single pass: first crossings -> x_HI / z_reion / mean free path, the cell-scale
+ * radius, the post-loop.  c21cm_ionize_shard_rc_supported tells whether a spec takes this route;
+ * everything else with a recombination model keeps the 64-bit keys above.
+ * reference: src/py21cmfast/src/IonisationBox.c:1084-1140,1531-1588 */
+int c21cm_ionize_shard_rc_supported(const c21cm_ionize_spec *s) {
+    if (!s || s->recomb_model == C21CM_RECOMB_NONE || !s->cell_recomb || s->use_ts_fluct ||
+        s->use_mini_halos || s->ionise_entire_sphere || s->r_lowest != 0 ||
+        s->fcoll_mode != C21CM_FCOLL_STARS_GRID)
+        return 0;
+    const char *e = getenv("C21CM_RECOMB_FUSED");
+    if (e && e[0] == '0') return 0;
+    const int nx = s->hii_dim, ny = s->hii_dim, nz = s->hii_dim_z;
+    return c21hip_fft_is_native(nx, ny, nz) && c21hip_z_ionise_recomb_supported(nx, ny, nz) &&
+           c21hip_wev_applicable(s->hii_filter, s->stars_filter, 2, nx, ny, nz);
+}
+
+int c21cm_ionize_shard_radii_rc(const c21cm_ionize_spec *spec, int rank, int world,
+                                const PerturbedField *perturbed_field,
+                                const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                const HaloBox *halos, unsigned char *first_cross, float *cross_g12,
+                                c21cm_ionize_report *report, void *stream) {
+    IonizedBox dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    int status = 0;
+    if (!first_cross || !cross_g12 || !c21hip_is_device_ptr(first_cross) ||
+        !c21hip_is_device_ptr(cross_g12) || world < 1 || rank < 0 || rank >= world) {
+        c21hip_set_error("ionize shard: first_cross / cross_g12 must be device arrays, 0 <= rank < world");
+        return C21CM_VALUE_ERROR;
+    }
+    if (!c21cm_ionize_shard_rc_supported(spec)) {
+        c21hip_set_error("ionize shard: this spec does not take the fused recombination loop "
+                         "(c21cm_ionize_shard_rc_supported); use the 64-bit key phases");
+        return C21CM_VALUE_ERROR;
+    }
+    {
+        IonizedBox probe = dummy;
+        float sentinel;
+        probe.neutral_fraction = probe.z_reion = probe.kinetic_temperature = &sentinel;
+        probe.ionisation_rate_G12 = probe.cumulative_recombinations = &sentinel;
+        status = validate_spec(spec, perturbed_field, halos, spin_temp, &probe);
+        if (status) return status;
+    }
+    ion_ctx c;
+    void *ev[3] = {NULL, NULL, NULL};
+    g_rc_phase = 1;
+    status = ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, &dummy, 0,
+                       stream);
+    g_rc_phase = 0;
+    if (status) return status;
+    if (!c.fused_rc) {
+        c21hip_set_error("ionize shard: the fused recombination loop is not available for this box");
+        return C21CM_VALUE_ERROR;
+    }
+    c.G12 = cross_g12;
+    for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    TRY(c21hip_memset(first_cross, 0, c.ntot, stream));
+    TRY(c21hip_memset(cross_g12, 0, c.ntot * sizeof(float), stream));
+    g_spectra.valid = 0;
+    TRY(preloop(&c));
+    spectra_remember(&c, perturbed_field, halos, spin_temp);
+    TRY(c21hip_event_record(ev[1], stream));
+    TRY(fused_loop(&c, spec->n_radii - 1 - rank, world, 1, first_cross));
+    TRY(flush_deferred(&c));
+    TRY(c21hip_event_record(ev[2], stream));
+    if (report) {
+        double means[C21CM_MAX_RADII];
+        TRY(c21hip_d2h(means, c.scalars + SC_MEANS, sizeof(means), stream));
+        TRY(c21hip_sync(stream));
+        for (int r = 0; r < spec->n_radii; r++) report->f_coll_grid_mean[r] = means[r];
+        if (world == 1) c21cm_ionize_shard_set_means(means, spec->n_radii);
+        report->ms_preloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+        report->ms_postloop = 0.;
+    }
+done:
+    c21hip_wev_release();
+    for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}
+
+int c21cm_ionize_shard_finish_rc(const c21cm_ionize_spec *spec, const unsigned char *first_cross,
+                                 const float *cross_g12, const PerturbedField *perturbed_field,
+                                 const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                 const HaloBox *halos, IonizedBox *box,
+                                 c21cm_ionize_report *report, void *stream) {
+    int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
+    if (status) return status;
+    if (!first_cross || !cross_g12 || !c21hip_is_device_ptr(first_cross) ||
+        !c21hip_is_device_ptr(cross_g12) || !c21cm_ionize_shard_rc_supported(spec)) {
+        c21hip_set_error("ionize shard: first_cross / cross_g12 must be device arrays of a spec that "
+                         "takes the fused recombination loop");
+        return C21CM_VALUE_ERROR;
+    }
+    ion_ctx c;
+    void *ev[3] = {NULL, NULL, NULL};
+    g_rc_phase = 1;
+    status = ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1, stream);
+    g_rc_phase = 0;
+    if (status) return status;
+    for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    if (g_shard_means.valid && g_shard_means.n == spec->n_radii)
+        TRY(c21hip_h2d(c.scalars + SC_MEANS, g_shard_means.means,
+                       sizeof(double) * (size_t)spec->n_radii, stream));
+    g_shard_means.valid = 0;
+    TRY(init_output_grids(&c, previous_ionize_box));
+    TRY(c21hip_d2d(c.G12, cross_g12, c.ntot * sizeof(float), stream));
+    {
+        float Rf[C21CM_MAX_RADII];
+        for (int r = 0; r < C21CM_MAX_RADII; r++) Rf[r] = r < spec->n_radii ? (float)spec->R[r] : 0.f;
+        float *R_dev = (float *)c21hip_ws(WS_R_DEV, sizeof(Rf));
+        if (!R_dev) {
+            status = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+        TRY(c21hip_h2d(R_dev, Rf, sizeof(Rf), stream));
+        TRY(c21hip_sync(stream)); /* `Rf` is a stack buffer */
+        TRY(c21hip_apply_first_cross_recomb(first_cross, R_dev, c.prev_zre, spec->first_snapshot,
+                                            spec->redshift, c.xH, c.zre, c.mfp, c.ntot, stream));
+    }
+    if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
+    g_spectra.valid = 0;
+    TRY(one_radius(&c, 0, NULL, -1));
     TRY(c21hip_event_record(ev[1], stream));
     TRY(postloop(&c, box, report));
     TRY(c21hip_event_record(ev[2], stream));

@@ -96,6 +96,91 @@ static int exchange_mask(unsigned char *fc, size_t ntot, int owner, void *stream
     return 0;
 }
 
+/* The exchange of the fused recombination loop: uint8 first-crossing index + float Gamma_12 per
+ * cell, the winner being the rank with the larger index.  Two hops over direct links, both moving
+ * 5 N / world bytes per link (at 1024^3 x 8: 671 MB, ~7-10 ms each, against the 8.6 GB the
+ * ncclReduce(uint64, max) of the keys pushes through a ring):
+ *   1. reduce-scatter by cell slabs: rank r sends peer p the (contiguous) slab p of both grids and
+ *      receives its own slab from everybody; c21hip_combine_cross_g12 keeps the winners;
+ *   2. the finishing rank receives every combined slab in place.
+ * Slab bounds as for the TsBox sums (multiples of 4 cells). */
+enum { WS_SHARD_RC_MASK = 248, WS_SHARD_RC_G12 = 249 };
+static int exchange_cross_g12(unsigned char *fc, float *g12, size_t ntot, int owner, void *stream) {
+    const int rank = R.rank, world = R.world;
+    if (world == 1) return 0;
+    if (!R.send || !R.recv || !R.group_start || !R.group_end) {
+        c21hip_set_error("shard: this librccl has no ncclSend / ncclRecv");
+        return C21CM_IO_ERROR;
+    }
+    size_t maxlen = 0;
+    for (int r = 0; r < world; r++) {
+        const size_t len = c21hip_ts_slab_begin(ntot, world, r + 1) - c21hip_ts_slab_begin(ntot, world, r);
+        if (len > maxlen) maxlen = len;
+    }
+    maxlen = (maxlen + 15) & ~(size_t)15;
+    const size_t c0 = c21hip_ts_slab_begin(ntot, world, rank);
+    const size_t len = c21hip_ts_slab_begin(ntot, world, rank + 1) - c0;
+    unsigned char *pm = (unsigned char *)c21hip_ws(WS_SHARD_RC_MASK, maxlen * (size_t)(world - 1));
+    float *pg = (float *)c21hip_ws(WS_SHARD_RC_G12, maxlen * (size_t)(world - 1) * sizeof(float));
+    if (!pm || !pg) return C21CM_MEMORY_ALLOC_ERROR;
+    int st = 0;
+    if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+    for (int p = 0, slot = 0; p < world && !st; p++) {
+        if (p == rank) continue;
+        const size_t p0 = c21hip_ts_slab_begin(ntot, world, p);
+        const size_t plen = c21hip_ts_slab_begin(ntot, world, p + 1) - p0;
+        if (plen) {
+            st = rccl_check(R.send(fc + p0, plen, RCCL_UINT8, p, R.comm, stream), "ncclSend(cross slab)");
+            if (!st)
+                st = rccl_check(R.send(g12 + p0, plen * sizeof(float), RCCL_UINT8, p, R.comm, stream),
+                                "ncclSend(G12 slab)");
+        }
+        if (len && !st) {
+            st = rccl_check(R.recv(pm + (size_t)slot * maxlen, len, RCCL_UINT8, p, R.comm, stream),
+                            "ncclRecv(cross slab)");
+            if (!st)
+                st = rccl_check(R.recv(pg + (size_t)slot * maxlen, len * sizeof(float), RCCL_UINT8, p,
+                                       R.comm, stream), "ncclRecv(G12 slab)");
+        }
+        slot++;
+    }
+    {
+        const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+        if (st || st2) return st ? st : st2;
+    }
+    if ((st = c21hip_combine_cross_g12(fc + c0, g12 + c0, pm, pg, world - 1, maxlen, len, stream)))
+        return st;
+    if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+    if (rank == owner) {
+        for (int p = 0; p < world && !st; p++) {
+            if (p == owner) continue;
+            const size_t p0 = c21hip_ts_slab_begin(ntot, world, p);
+            const size_t plen = c21hip_ts_slab_begin(ntot, world, p + 1) - p0;
+            if (!plen) continue;
+            st = rccl_check(R.recv(fc + p0, plen, RCCL_UINT8, p, R.comm, stream), "ncclRecv(combined slab)");
+            if (!st)
+                st = rccl_check(R.recv(g12 + p0, plen * sizeof(float), RCCL_UINT8, p, R.comm, stream),
+                                "ncclRecv(combined G12)");
+        }
+    } else if (len) {
+        st = rccl_check(R.send(fc + c0, len, RCCL_UINT8, owner, R.comm, stream), "ncclSend(combined slab)");
+        if (!st)
+            st = rccl_check(R.send(g12 + c0, len * sizeof(float), RCCL_UINT8, owner, R.comm, stream),
+                            "ncclSend(combined G12)");
+    }
+    {
+        const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+        if (st || st2) return st ? st : st2;
+    }
+    return 0;
+}
+
+int c21cm_shard_combine_cross_g12(unsigned char *mask, float *g12, const unsigned char *peer_mask,
+                                  const float *peer_g12, int n_peers, size_t stride, size_t n,
+                                  void *stream) {
+    return c21hip_combine_cross_g12(mask, g12, peer_mask, peer_g12, n_peers, stride, n, stream);
+}
+
 /* ---- in-process emulation of the transport (test hook) -------------------------------------
  * The boxes this is developed on have one GPU, and RCCL refuses two ranks on one device.  To
  * exercise c21cm_ionize_sharded for world > 1 anyway -- the radius deal, the slot arithmetic of
@@ -314,6 +399,12 @@ int c21cm_shard_comm_count(void) {
     return 0;
 }
 
+/* C21CM_SHARD_EXCHANGE=keys keeps the 64-bit key reduce for every recombination model */
+static int shard_rc_exchange(void) {
+    const char *e = getenv("C21CM_SHARD_EXCHANGE");
+    return !(e && e[0] == 'k');
+}
+
 int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
                          const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                          const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
@@ -367,6 +458,21 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
         if (rank == owner)
             st = c21cm_ionize_shard_finish(spec, fc, perturbed_field, previous_ionize_box, spin_temp,
                                            halos, box, report, stream);
+    } else if (R.ready == 1 && c21cm_ionize_shard_rc_supported(spec) && shard_rc_exchange()) {
+        /* the fused recombination loop: first-crossing index + Gamma_12, 5 bytes per cell by slabs
+         * (the emulated transport runs its ranks one after the other and keeps the keys) */
+        unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, 5 * ntot);
+        if (!fc) return C21CM_MEMORY_ALLOC_ERROR;
+        float *g12 = (float *)(fc + ntot); /* ntot is a multiple of 16 for every supported box */
+        st = c21cm_ionize_shard_radii_rc(spec, rank, world, perturbed_field, previous_ionize_box,
+                                         spin_temp, halos, fc, g12, NULL, stream);
+        if ((st = agree_status(st, stream))) return st;
+        MARK(1);
+        if ((st = exchange_cross_g12(fc, g12, ntot, owner, stream))) return st;
+        MARK(2);
+        if (rank == owner)
+            st = c21cm_ionize_shard_finish_rc(spec, fc, g12, perturbed_field, previous_ionize_box,
+                                              spin_temp, halos, box, report, stream);
     } else {
         unsigned long long *keys = (unsigned long long *)c21hip_ws(WS_SHARD_GRID, 8 * ntot);
         if (!keys) return C21CM_MEMORY_ALLOC_ERROR;

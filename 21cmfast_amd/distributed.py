@@ -160,3 +160,52 @@ def ts_all_gather(box, rank: int, world: int, group=None):
         pb, pe = ts_slab(ntot, p, world)
         flat[pb:pe] = t
     return box
+
+
+def cross_g12_exchange(first_cross, g12, rank: int, world: int, owner: int, group=None):
+    """The exchange of the sharded FUSED recombination loop through torch.distributed (what
+    c21cm_ionize_sharded does over RCCL point to point): per cell the entry of the rank with the
+    larger first-crossing index wins, with ITS Gamma_12.  Hop 1: reduce-scatter by cell slabs
+    (``ts_slab`` bounds) and combine; hop 2: the owner receives every combined slab in place.
+    `first_cross` uint8 [N], `g12` float32 [N] (flat views; modified in place on the owner)."""
+    import torch
+    import torch.distributed as dist
+
+    ntot = first_cross.numel()
+    fc, g = first_cross.view(-1), g12.view(-1)
+    lo, hi = ts_slab(ntot, rank, world)
+    for t in (fc, g):
+        recv = [torch.empty(hi - lo, dtype=t.dtype, device=t.device) for _ in range(world)]
+        send = [t[slice(*ts_slab(ntot, p, world))].contiguous() for p in range(world)]
+        _all_to_all_p2p(recv, send, rank, world, group)
+        if t is fc:
+            masks = recv
+        else:
+            vals = recv
+    m, v = masks[rank].clone(), vals[rank].clone()
+    for q in range(world):
+        win = masks[q] > m
+        m = torch.where(win, masks[q], m)
+        v = torch.where(win, vals[q], v)
+    fc[lo:hi], g[lo:hi] = m, v
+    reqs = []
+    if rank == owner:
+        bufs = {}
+        for p in range(world):
+            if p == owner:
+                continue
+            a, b = ts_slab(ntot, p, world)
+            if b > a:
+                bufs[p] = (torch.empty(b - a, dtype=fc.dtype, device=fc.device),
+                           torch.empty(b - a, dtype=g.dtype, device=g.device))
+                reqs += [dist.irecv(bufs[p][0], src=p, group=group), dist.irecv(bufs[p][1], src=p, group=group)]
+        for q in reqs:
+            q.wait()
+        for p, (bm, bg) in bufs.items():
+            a, b = ts_slab(ntot, p, world)
+            fc[a:b], g[a:b] = bm, bg
+    elif hi > lo:
+        reqs = [dist.isend(m, dst=owner, group=group), dist.isend(v, dst=owner, group=group)]
+        for q in reqs:
+            q.wait()
+    return first_cross, g12

@@ -274,6 +274,62 @@ def ionize_shard_finish_keys(spec, cross_keys, density, n_ion=None, xe=None, Tne
     return buffers, box, rep
 
 
+def shard_rc_supported(spec) -> bool:
+    """Does a recombination spec shard through the fused loop (first-crossing index + Gamma_12,
+    5 bytes per cell) rather than through the 64-bit keys?  c21cm_ionize_shard_rc_supported."""
+    return bool(load().c21cm_ionize_shard_rc_supported(C.byref(spec)))
+
+
+def ionize_shard_radii_rc(spec, rank, world, first_cross, cross_g12, density, n_ion=None,
+                          prev_z_reion=None, prev_nrec=None, whalo_sfr=None, stream=None):
+    """Shard phase of the fused recombination loop: this rank's radii -> ``first_cross`` (uint8
+    CUDA tensor, radius index of the first crossing, 0 = none) and ``cross_g12`` (float32,
+    Gamma_12 at that crossing)."""
+    pf, prev, ts, hb = _input_structs(density, n_ion, None, None, prev_z_reion, prev_nrec, whalo_sfr)
+    lib = load()
+    lib.c21cm_ionize_shard_radii_rc.restype = C.c_int
+    check(lib.c21cm_ionize_shard_radii_rc(C.byref(spec), C.c_int(rank), C.c_int(world), C.byref(pf),
+                                          C.byref(prev), C.byref(ts), C.byref(hb),
+                                          C.c_void_p(first_cross.data_ptr()),
+                                          C.c_void_p(cross_g12.data_ptr()), None, _stream(stream)),
+          "c21cm_ionize_shard_radii_rc")
+
+
+def ionize_shard_finish_rc(spec, first_cross, cross_g12, density, n_ion=None, prev_z_reion=None,
+                           prev_nrec=None, whalo_sfr=None, buffers: IonizeBuffers | None = None,
+                           stream=None):
+    """Finish phase of the fused recombination loop on the owning rank (combined grids in)."""
+    if buffers is None:
+        buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
+                                minimize_memory=bool(spec.minimize_memory),
+                                recomb_model=spec.recomb_model)
+    pf, prev, ts, hb = _input_structs(density, n_ion, None, None, prev_z_reion, prev_nrec, whalo_sfr)
+    box = buffers.struct()
+    rep = S.IonizeReport()
+    lib = load()
+    lib.c21cm_ionize_shard_finish_rc.restype = C.c_int
+    check(lib.c21cm_ionize_shard_finish_rc(C.byref(spec), C.c_void_p(first_cross.data_ptr()),
+                                           C.c_void_p(cross_g12.data_ptr()), C.byref(pf),
+                                           C.byref(prev), C.byref(ts), C.byref(hb), C.byref(box),
+                                           C.byref(rep), _stream(stream)),
+          "c21cm_ionize_shard_finish_rc")
+    return buffers, box, rep
+
+
+def combine_cross_g12(mask, g12, peer_mask, peer_g12, stream=None):
+    """c21cm_shard_combine_cross_g12: own slab (uint8 / float32 CUDA tensors, in place) against
+    the peers' slabs ``peer_mask`` [n_peers, stride] / ``peer_g12`` [n_peers, stride]."""
+    lib = load()
+    lib.c21cm_shard_combine_cross_g12.restype = C.c_int
+    n_peers, stride = peer_mask.shape
+    check(lib.c21cm_shard_combine_cross_g12(C.c_void_p(mask.data_ptr()), C.c_void_p(g12.data_ptr()),
+                                            C.c_void_p(peer_mask.data_ptr()),
+                                            C.c_void_p(peer_g12.data_ptr()), C.c_int(n_peers),
+                                            C.c_size_t(stride), C.c_size_t(mask.numel()),
+                                            _stream(stream)),
+          "c21cm_shard_combine_cross_g12")
+
+
 def shard_init_from_torch(group=None):
     """Bootstrap the library's own RCCL communicator from an initialised ``torch.distributed``
     job: rank 0 draws the unique id in C (c21cm_shard_unique_id), torch broadcasts its 128 bytes,

@@ -223,6 +223,30 @@ int c21cm_ionize_shard_finish_keys(const c21cm_ionize_spec *spec,
                                    const HaloBox *halos, IonizedBox *box,
                                    c21cm_ionize_report *report, void *stream);
 
+/* The fused recombination loop sharded (CELL_RECOMB, no x_e grid, native line lengths with the
+ * windows evaluated in pass X: c21cm_ionize_shard_rc_supported != 0): a rank's radii leave the
+ * uint8 first-crossing index and Gamma_12 at the crossing -- 5 bytes per cell instead of the
+ * 8-byte key; the mean free path is the radius of the index.  Between the phases the caller keeps,
+ * per cell, the entry of the rank with the LARGER index (an index > 0 is owned by one rank):
+ * c21cm_ionize_sharded does it with a reduce-scatter by cell slabs + a gather (5 N / world bytes
+ * per link and hop).  reference: IonisationBox.c:1084-1140,1531-1588 */
+int c21cm_ionize_shard_rc_supported(const c21cm_ionize_spec *spec);
+int c21cm_ionize_shard_radii_rc(const c21cm_ionize_spec *spec, int rank, int world,
+                                const PerturbedField *perturbed_field,
+                                const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                const HaloBox *halos, unsigned char *first_cross, float *cross_g12,
+                                c21cm_ionize_report *report, void *stream);
+int c21cm_ionize_shard_finish_rc(const c21cm_ionize_spec *spec, const unsigned char *first_cross,
+                                 const float *cross_g12, const PerturbedField *perturbed_field,
+                                 const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                 const HaloBox *halos, IonizedBox *box,
+                                 c21cm_ionize_report *report, void *stream);
+/* device helper of that exchange (own slab in place against n_peers received slabs of `stride`
+ * cells; all starts at multiples of 4 cells) */
+int c21cm_shard_combine_cross_g12(unsigned char *mask, float *g12, const unsigned char *peer_mask,
+                                  const float *peer_g12, int n_peers, size_t stride, size_t n,
+                                  void *stream);
+
 /* ---- the sharded R loop behind the C ABI ---------------------------------------------------
  * One process per GPU; every rank calls c21cm_ionize_sharded with the same (replicated) inputs.
  * Collectives go through RCCL (librccl resolved at run time with dlopen: inside a PyTorch

@@ -286,3 +286,99 @@ def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, 
     np.testing.assert_allclose(np.array(r1.f_coll_grid_mean[:n_r]), np.array(r0.f_coll_grid_mean[:n_r]),
                                rtol=1e-6)
     assert 0.03 < float(c1.float().mean()) < 0.97
+
+
+@pytest.mark.parametrize("model", [2, 1])
+def test_sharded_fused_recombination_phases_equal_single_pass(api, model):
+    """The fused recombination loop sharded (round 3): a rank's radii leave the uint8 first-crossing
+    index + Gamma_12 (5 bytes per cell instead of the 8-byte keys); per cell the rank with the larger
+    index wins with ITS Gamma_12 (c21cm_shard_combine_cross_g12, slab by slab as the RCCL exchange
+    does it); the finish phase must reproduce the single pass bit for bit.  World = 1, 2, 3, 8
+    emulated in one process."""
+    import torch
+
+    D = importlib.import_module("21cmfast_amd.distributed")
+    n = 256
+    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0)
+    assert api.shard_rc_supported(spec)
+    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=31).items()}
+    if model == 1:
+        d["prev_nrec"] = torch.full((1, 1, 1), 0.21, dtype=torch.float32, device="cuda")
+    kw = dict(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"], prev_nrec=d["prev_nrec"],
+              prev_z_reion=d["prev_z_reion"])
+    buf0, _, rep0 = api.ionize_grids(spec, d["density"], **kw)
+    torch.cuda.synchronize()
+    names = ("neutral_fraction", "z_reion", "kinetic_temperature", "ionisation_rate_G12",
+             "mean_free_path", "cumulative_recombinations")
+    ref = {k: getattr(buf0, k).clone() for k in names}
+    assert 0.03 < float((ref["mean_free_path"] > 0).float().mean()) < 0.97
+    ntot = n**3
+    for world in (1, 2, 3, 8):
+        masks, vals = [], []
+        for rank in range(world):
+            fc = torch.empty(ntot, dtype=torch.uint8, device="cuda")
+            g = torch.empty(ntot, dtype=torch.float32, device="cuda")
+            api.ionize_shard_radii_rc(spec, rank, world, fc, g, d["density"], **kw)
+            masks.append(fc)
+            vals.append(g)
+        # every radius index > 0 is owned by exactly one rank
+        if world > 1:
+            stacked = torch.stack(masks)
+            top = stacked.max(0).values
+            assert int(((stacked == top) & (top > 0)).sum(0).max()) == 1
+        owner = D.owner_rank(spec.n_radii, world)
+        fc, g = masks[owner].clone(), vals[owner].clone()
+        for r in range(world):  # the combined slab of rank r, as hop 1 of the exchange leaves it
+            lo, hi = D.ts_slab(ntot, r, world)
+            if hi == lo:
+                continue
+            m, v = masks[r][lo:hi].clone(), vals[r][lo:hi].clone()
+            peers = [q for q in range(world) if q != r]
+            if peers:
+                stride = (hi - lo + 15) // 16 * 16
+                pm = torch.zeros((len(peers), stride), dtype=torch.uint8, device="cuda")
+                pg = torch.zeros((len(peers), stride), dtype=torch.float32, device="cuda")
+                for i, q in enumerate(peers):
+                    pm[i, : hi - lo], pg[i, : hi - lo] = masks[q][lo:hi], vals[q][lo:hi]
+                api.combine_cross_g12(m, v, pm, pg)
+            fc[lo:hi], g[lo:hi] = m, v
+        want = torch.stack(masks).max(0).values
+        assert torch.equal(fc, want)
+        buf, _, rep = api.ionize_shard_finish_rc(spec, fc, g, d["density"], **kw)
+        torch.cuda.synchronize()
+        for name in names:
+            assert torch.equal(ref[name], getattr(buf, name)), (world, name)
+        assert rep.global_xH == rep0.global_xH
+
+
+def test_c_level_sharding_of_the_fused_recombination_loop_on_one_rank(api, monkeypatch):
+    """c21cm_ionize_sharded on a one-rank RCCL communicator takes the (first crossing, Gamma_12)
+    route for a spec the fused recombination loop supports, the key reduce with
+    C21CM_SHARD_EXCHANGE=keys: both equal the single pass (the keys through the unfused sequence:
+    same crossings up to float round-off of the barrier)."""
+    import torch
+
+    n = 256
+    spec = recomb_spec(n, model=2, cell_recomb=1, r_bubble_max=20.0)
+    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=9).items()}
+    kw = dict(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"], prev_nrec=d["prev_nrec"],
+              prev_z_reion=d["prev_z_reion"])
+    buf0, _, rep0 = api.ionize_grids(spec, d["density"], **kw)
+    names = ["neutral_fraction", "z_reion", "kinetic_temperature", "ionisation_rate_G12",
+             "mean_free_path", "cumulative_recombinations"]
+    ref = {k: getattr(buf0, k).clone() for k in names}
+    api.shard_init_single()
+    try:
+        buf1, _, rep1 = api.ionize_sharded(spec, d["density"], broadcast=True, **kw)
+        torch.cuda.synchronize()
+        for name in names:
+            assert torch.equal(ref[name], getattr(buf1, name)), name
+        assert rep1.global_xH == rep0.global_xH
+        monkeypatch.setenv("C21CM_SHARD_EXCHANGE", "keys")
+        buf2, _, rep2 = api.ionize_sharded(spec, d["density"], broadcast=True, **kw)
+        torch.cuda.synchronize()
+        flipped = float(((ref["neutral_fraction"] == 0) != (buf2.neutral_fraction == 0)).float().mean())
+        assert flipped < 2e-4
+        assert abs(rep2.global_xH - rep0.global_xH) < 2e-4
+    finally:
+        api.shard_finalize()
