@@ -46,6 +46,7 @@ static struct {
 
 /* ---------------------------------------------------------------- adaptive quadrature */
 typedef double (*integrand_fn)(double x, void *ctx);
+double c21_qag61(integrand_fn f, void *ctx, double a, double b, double epsrel, double *abserr, int *status); /* heating.c */
 
 static const double gk_x[8] = {0.991455371120812639206854697526329, 0.949107912342758524526189684047851,
                                0.864864423359769072789712788640926, 0.741531185599394439863864773280788,
@@ -521,8 +522,89 @@ static void sigma_table_build(void) {
     st.ready = 1;
 }
 
+/* The reference's own table, restated (C21CM_SIGMA_TABLE=reference): 300 FLOAT entries of
+ * sigma_z0 and log10(-dsigmasqdm_z0) at float masses on a uniform ln M grid between the float
+ * arguments 5e2 and 1e20 of _global_initialization.py:131-134, looked up by LINEAR interpolation
+ * (interp_tables.c:32,1135-1180; interpolation.c:123-131).  Its interpolation error (up to a few
+ * 1e-4 of sigma between nodes) is part of every mass-function integral of the reference, so the
+ * x_HI / dT_b fields of the reference's fixtures are reproduced more closely with it than with the
+ * converged spline above.  The entries are this file's converged quadratures rounded to float; the
+ * reference's come from one QAG(61-point) call at epsrel 1e-6, i.e. agree to better than the float
+ * rounding except for an occasional last-bit flip. */
+#define REF_SIG_N 300
+static struct {
+    int ready;
+    double norm_tag;
+    unsigned generation;
+    int filter, ps;
+    double x_min, x_width;
+    float sig[REF_SIG_N], l10d[REF_SIG_N];
+} rt;
+
+/* C21CM_HOST_MODE=reference: the host quadratures as the reference STOPS them, not converged --
+ * this float sigma(M) table, and gsl_integration_qag(61-point rule, epsrel 1e-3) for the
+ * unconditional mass-function integrals (hmf.c:612-655,896-900: Fcoll_General, Nion_General,
+ * Nion_General_MINI all go through IntegratedNdM with method 0).  The normalisation of the
+ * excursion set (set_mean_fcoll, IonisationBox.c:468-529) inherits that quadrature's error.
+ * C21CM_HOST_MODE=converged: every quadrature to 1e-6 or better. */
+int c21_host_reference_mode(void) {
+    const char *e = getenv("C21CM_HOST_MODE");
+    if (e && e[0] == 'r') return 1;
+    if (e && e[0] == 'c') return 0;
+    return 0;
+}
+static int sigma_reference_mode(void) {
+    const char *e = getenv("C21CM_SIGMA_TABLE"); /* finer switch for diagnostics: r / c */
+    if (e && (e[0] == 'r' || e[0] == 'c')) return e[0] == 'r';
+    return c21_host_reference_mode();
+}
+static int mf_quad_reference_mode(void) {
+    const char *e = getenv("C21CM_MF_QUAD");
+    if (e && (e[0] == 'r' || e[0] == 'c')) return e[0] == 'r';
+    return c21_host_reference_mode();
+}
+
+static void sigma_reference_build(void) {
+    if (rt.ready && rt.generation == cc.generation && rt.norm_tag == cc.sigma_norm &&
+        rt.filter == matter_options_global->FILTER && rt.ps == matter_options_global->POWER_SPECTRUM)
+        return;
+    const float M_min = 5e2f, M_max = 1e20f;
+    rt.x_min = log(M_min);
+    rt.x_width = (log(M_max) - log(M_min)) / (REF_SIG_N - 1.);
+    const int n_thr = simulation_options_global && simulation_options_global->N_THREADS > 1
+                          ? simulation_options_global->N_THREADS : 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_thr)
+    for (int i = 0; i < REF_SIG_N; i++) {
+        const float Mass = (float)exp(rt.x_min + i * rt.x_width);
+        rt.sig[i] = (float)sigma_z0(Mass);
+        rt.l10d[i] = (float)log10(-dsigmasqdm_z0(Mass));
+    }
+    rt.norm_tag = cc.sigma_norm;
+    rt.generation = cc.generation;
+    rt.filter = matter_options_global->FILTER;
+    rt.ps = matter_options_global->POWER_SPECTRUM;
+    rt.ready = 1;
+}
+
+/* EvaluateRGTable1D_f (interpolation.c:123-131) */
+static double reference_lookup(const float *y, double x) {
+    const int idx = (int)floor((x - rt.x_min) / rt.x_width);
+    const double table_val = rt.x_min + rt.x_width * (float)idx;
+    const double t = (x - table_val) / rt.x_width;
+    return y[idx] * (1 - t) + y[idx + 1] * t;
+}
+
+static int reference_in_range(double lnM) {
+    return lnM >= rt.x_min && lnM < rt.x_min + rt.x_width * (REF_SIG_N - 1);
+}
+
 double c21_sigma_fast(double M) {
     const double lnM = log(M);
+    if (sigma_reference_mode()) {
+        sigma_reference_build();
+        if (reference_in_range(lnM)) return reference_lookup(rt.sig, lnM);
+        return sigma_z0(M); /* (the reference reads past its table there) */
+    }
     if (lnM < SIG_LNM_MIN || lnM > SIG_LNM_MAX) return sigma_z0(M);
     sigma_table_build();
     return exp(spline_eval(SIG_N, st.lnM, st.lns, st.lns2, lnM));
@@ -530,6 +612,11 @@ double c21_sigma_fast(double M) {
 
 static double dsigmasqdm_fast(double M) {
     const double lnM = log(M);
+    if (sigma_reference_mode()) {
+        sigma_reference_build();
+        if (reference_in_range(lnM)) return -pow(10., reference_lookup(rt.l10d, lnM));
+        return dsigmasqdm_z0(M);
+    }
     if (lnM < SIG_LNM_MIN || lnM > SIG_LNM_MAX) return dsigmasqdm_z0(M);
     sigma_table_build();
     return -exp(spline_eval(SIG_N, st.lnM, st.lnd, st.lnd2, lnM));
@@ -577,6 +664,15 @@ static double mf_integrand(double lnM, void *ctx) {
     const double Fstar = log_pl_limit(lnM, p->ln_fstar_norm, p->alpha_star, 10 * M_LN10, p->ln_Mlim_star);
     const double Fesc = log_pl_limit(lnM, p->ln_fesc_norm, p->alpha_esc, 10 * M_LN10, p->ln_Mlim_esc);
     return exp(Fstar + Fesc - p->Mturn / exp(lnM) + lnM) * mf;
+}
+
+/* IntegratedNdM with method 0 (hmf.c:612-655): converged, or stopped as the reference stops it */
+static double mf_integral(integrand_fn f, void *ctx, double lnM_min, double lnM_max) {
+    if (mf_quad_reference_mode()) {
+        (void)c21_sigma_fast(1e10); /* the table is built outside the integrand */
+        return c21_qag61(f, ctx, lnM_min, lnM_max, 1e-3, NULL, NULL);
+    }
+    return c21_integrate(f, ctx, lnM_min, lnM_max, 1e-6);
 }
 
 static int supported_hmf(void) {
@@ -627,7 +723,7 @@ double c21_Fcoll_General(double z, double lnM_min, double lnM_max) {
     p.growthf = dicke(z);
     p.hmf = matter_options_global->HMF;
     p.kind = 0;
-    return c21_integrate(mf_integrand, &p, lnM_min, lnM_max, 1e-6);
+    return mf_integral(mf_integrand, &p, lnM_min, lnM_max);
 }
 
 /* hmf.c:955-971 */
@@ -646,7 +742,7 @@ double c21_Nion_General(double z, double lnM_min, double lnM_max, double Mturn,
     p.alpha_esc = sc->alpha_esc;
     p.ln_Mlim_esc = log(sc->Mlim_Fesc);
     p.Mturn = Mturn;
-    return c21_integrate(mf_integrand, &p, lnM_min, lnM_max, 1e-6);
+    return mf_integral(mf_integrand, &p, lnM_min, lnM_max);
 }
 
 /* hmf.c:470-477: n_ion per halo of the molecularly cooled population: pivot 1e7 Msun, lower
@@ -675,7 +771,7 @@ double c21_Nion_General_MINI(double z, double lnM_min, double lnM_max, double Mt
                              const c21_scaling_consts *sc) {
     if (!supported_hmf()) return NAN;
     struct mf_mini_ctx p = {dicke(z), Mturn, matter_options_global->HMF, sc};
-    return c21_integrate(mf_mini_integrand, &p, lnM_min, lnM_max, 1e-6);
+    return mf_integral(mf_mini_integrand, &p, lnM_min, lnM_max);
 }
 
 /* ---------------------------------------------------------------- conditional mass function

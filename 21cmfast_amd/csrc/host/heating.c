@@ -95,40 +95,44 @@ static double rescale_error(double err, double result_abs, double result_asc) {
     return err;
 }
 
-static void qk15(c21_fn f, void *ctx, double a, double b, double *result, double *abserr,
-                 double *resabs, double *resasc) {
-    const int n = 8;
-    double fv1[8], fv2[8];
+#include "gk61_tables.h" /* xgk61, wgk61, wg30: the 61-point rule (GSL_INTEG_GAUSS61) */
+
+/* gsl_integration_qk: n = number of Kronrod abscissae on [0, 1] including the centre (8 for the
+ * 15-point rule, 31 for the 61-point rule) */
+static void qk_rule(int n, const double *xgk, const double *wg, const double *wgk, c21_fn f, void *ctx,
+                    double a, double b, double *result, double *abserr, double *resabs,
+                    double *resasc) {
+    double fv1[31], fv2[31];
     const double center = 0.5 * (a + b), half_length = 0.5 * (b - a);
     const double abs_half_length = fabs(half_length);
     const double f_center = f(center, ctx);
-    double result_gauss = f_center * wg7[n / 2 - 1]; /* n even */
-    double result_kronrod = f_center * wgk15[n - 1];
+    double result_gauss = (n % 2 == 0) ? f_center * wg[n / 2 - 1] : 0.;
+    double result_kronrod = f_center * wgk[n - 1];
     double result_abs = fabs(result_kronrod);
     for (int j = 0; j < (n - 1) / 2; j++) {
         const int jtw = j * 2 + 1;
-        const double abscissa = half_length * xgk15[jtw];
+        const double abscissa = half_length * xgk[jtw];
         const double fval1 = f(center - abscissa, ctx), fval2 = f(center + abscissa, ctx);
         const double fsum = fval1 + fval2;
         fv1[jtw] = fval1;
         fv2[jtw] = fval2;
-        result_gauss += wg7[j] * fsum;
-        result_kronrod += wgk15[jtw] * fsum;
-        result_abs += wgk15[jtw] * (fabs(fval1) + fabs(fval2));
+        result_gauss += wg[j] * fsum;
+        result_kronrod += wgk[jtw] * fsum;
+        result_abs += wgk[jtw] * (fabs(fval1) + fabs(fval2));
     }
     for (int j = 0; j < n / 2; j++) {
         const int jtwm1 = j * 2;
-        const double abscissa = half_length * xgk15[jtwm1];
+        const double abscissa = half_length * xgk[jtwm1];
         const double fval1 = f(center - abscissa, ctx), fval2 = f(center + abscissa, ctx);
         fv1[jtwm1] = fval1;
         fv2[jtwm1] = fval2;
-        result_kronrod += wgk15[jtwm1] * (fval1 + fval2);
-        result_abs += wgk15[jtwm1] * (fabs(fval1) + fabs(fval2));
+        result_kronrod += wgk[jtwm1] * (fval1 + fval2);
+        result_abs += wgk[jtwm1] * (fabs(fval1) + fabs(fval2));
     }
     const double mean = result_kronrod * 0.5;
-    double result_asc = wgk15[n - 1] * fabs(f_center - mean);
+    double result_asc = wgk[n - 1] * fabs(f_center - mean);
     for (int j = 0; j < n - 1; j++)
-        result_asc += wgk15[j] * (fabs(fv1[j] - mean) + fabs(fv2[j] - mean));
+        result_asc += wgk[j] * (fabs(fv1[j] - mean) + fabs(fv2[j] - mean));
     const double err = (result_kronrod - result_gauss) * half_length;
     result_kronrod *= half_length;
     result_abs *= abs_half_length;
@@ -139,9 +143,37 @@ static void qk15(c21_fn f, void *ctx, double a, double b, double *result, double
     *abserr = rescale_error(err, result_abs, result_asc);
 }
 
+static _Thread_local int qag_key61; /* rule of the running c21_qag call */
+static void qk15(c21_fn f, void *ctx, double a, double b, double *result, double *abserr,
+                 double *resabs, double *resasc) {
+    if (qag_key61)
+        qk_rule(31, xgk61, wg30, wgk61, f, ctx, a, b, result, abserr, resabs, resasc);
+    else
+        qk_rule(8, xgk15, wg7, wgk15, f, ctx, a, b, result, abserr, resabs, resasc);
+}
+
 #define QAG_LIMIT 1000
+static double qag_run(c21_fn f, void *ctx, double a, double b, double epsrel, double *abserr_out,
+                      int *status_out);
 double c21_qag15(c21_fn f, void *ctx, double a, double b, double epsrel, double *abserr_out,
                  int *status_out) {
+    const int saved = qag_key61;
+    qag_key61 = 0;
+    const double r = qag_run(f, ctx, a, b, epsrel, abserr_out, status_out);
+    qag_key61 = saved;
+    return r;
+}
+/* gsl_integration_qag(..., epsabs 0, epsrel, limit 1000, GSL_INTEG_GAUSS61, ...) */
+double c21_qag61(c21_fn f, void *ctx, double a, double b, double epsrel, double *abserr_out,
+                 int *status_out) {
+    const int saved = qag_key61;
+    qag_key61 = 1;
+    const double r = qag_run(f, ctx, a, b, epsrel, abserr_out, status_out);
+    qag_key61 = saved;
+    return r;
+}
+static double qag_run(c21_fn f, void *ctx, double a, double b, double epsrel, double *abserr_out,
+                      int *status_out) {
     static _Thread_local double al[QAG_LIMIT], bl[QAG_LIMIT], rl[QAG_LIMIT], el[QAG_LIMIT];
     double result0, abserr0, resabs0, resasc0;
     int status = 0;

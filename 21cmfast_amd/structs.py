@@ -497,9 +497,19 @@ class IcsSpec(_Base):
 # reference: src/py21cmfast/wrapper/inputs.py:492-601 (cosmo), :1014-1111 (simulation),
 #            :766-830 (matter), :1302-1355 (astro options), :1569-1680 (astro params).
 # --------------------------------------------------------------------------------------
+# The reference's Planck18 is astropy's Planck15 with Om0 = (0.02242 + 0.11933) / 0.6766^2 and
+# Ob0 = 0.02242 / 0.6766^2 (inputs.py:126-134: Planck 2018 Table 2, last column) -- NOT the rounded
+# 0.30966 / 0.04897 of astropy's own Planck18.  The reference's golden power spectra tell the two
+# apart: a tilt of 1e-4 over the k range of the 100 Mpc box (tests/test_reference_fixtures.py).
+PLANCK18_H = 0.6766
+PLANCK18_OMM = (0.02242 + 0.11933) / 0.6766**2
+PLANCK18_OMB = 0.02242 / 0.6766**2
+
+
 def default_cosmo_params(**kw) -> CosmoParams:
     p = CosmoParams(
-        hlittle=0.6766, OMm=0.30966, OMl=1.0 - 0.30966, OMb=0.04897, POWER_INDEX=0.9665,
+        hlittle=PLANCK18_H, OMm=PLANCK18_OMM, OMl=1.0 - PLANCK18_OMM, OMb=PLANCK18_OMB,
+        POWER_INDEX=0.9665,
         OMn=0.0, OMk=0.0, OMr=8.6e-5, OMtot=1.0, Y_He=0.24, wl=-1.0,
     )
     return p.update(**kw)

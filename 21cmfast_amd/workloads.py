@@ -22,8 +22,9 @@ L_FACTOR = 0.620350491  # reference: src/py21cmfast/src/Constants.c:41
 DELTA_C = 1.686  # reference: Constants.c:42
 FCOLL_STARS, FCOLL_ERFC, FCOLL_TABLE_LINEAR, FCOLL_TABLE_EXP = 0, 1, 2, 3
 
-# Planck18 values of SURVEY.md Appendix A
-HLITTLE, OMM, OMB = 0.6766, 0.30966, 0.04897
+# The reference's Planck18 (inputs.py:126-134: Om0 = (0.02242 + 0.11933) / h^2, Ob0 = 0.02242 / h^2)
+HLITTLE = 0.6766
+OMM, OMB = (0.02242 + 0.11933) / HLITTLE**2, 0.02242 / HLITTLE**2
 
 
 def rho_crit(hlittle: float = HLITTLE) -> float:

@@ -47,8 +47,8 @@ class Cosmo:
     (reference: src/py21cmfast/wrapper/inputs.py:505-538)."""
 
     hlittle: float = 0.6766
-    OMm: float = 0.30966
-    OMb: float = 0.04897
+    OMm: float = (0.02242 + 0.11933) / 0.6766**2  # inputs.py:126-134 (Planck 2018 Table 2)
+    OMb: float = 0.02242 / 0.6766**2
     POWER_INDEX: float = 0.9665
     OMn: float = 0.0
     OMr: float = 8.6e-5

@@ -96,6 +96,10 @@ def test_recombination_models_match_oracle(api, oracle, n, model, cell, lagrangi
         same_R = same & (got["mean_free_path"] == ref["mean_free_path"])
         assert np.mean(~same_R & same) <= 2e-4
         same = same_R
+    else:  # the small boxes: at most a couple of cells on a barrier cross one radius apart
+        same_R = same & (got["mean_free_path"] == ref["mean_free_path"])
+        assert np.sum(~same_R & same) <= 2
+        same = same_R
     np.testing.assert_allclose(got["ionisation_rate_G12"][same], ref["ionisation_rate_G12"][same],
                                rtol=2e-3 if big else 1e-4,
                                atol=2e-6 * float(ref["ionisation_rate_G12"].max()) if big else 1e-9)

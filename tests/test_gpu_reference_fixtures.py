@@ -72,7 +72,7 @@ def test_entry_points_reproduce_reference_perturb_field_data(gpu_lib, api, name,
     algorithm, hires = RP.PT_CASES[name]
     _, dens, vz = run_abi(gpu_lib, api, 10.0, 2, algorithm, bool(hires))
     worst = RP.check_perturb_fixture(name, dens, vz)
-    assert worst < 3e-4
+    assert worst < 2e-6  # density power (observed <= 6e-7); the reference asserts rtol 1e-3
 
 
 @pytest.mark.parametrize("name,n_threads", [("simple", 2), ("sampler_ts_ir_onethread", 1)])
@@ -83,7 +83,9 @@ def test_entry_points_reproduce_reference_coeval_powers(gpu_lib, api, name, n_th
     worst = RP.check_coeval_fields(name, {
         "lowres_density": ics["lowres_density"], "lowres_vx": ics["lowres_vx"],
         "lowres_vx_2LPT": ics["lowres_vx_2LPT"], "density": dens, "velocity_z": vz})
-    assert max(worst.values()) < 4e-4
+    velocity = worst.pop("velocity_z")  # the reference's dD/dt is quantised in steps of 3.9e-5 here
+    assert max(worst.values()) < 5e-6, worst  # (tests/test_reference_fixtures.py); observed 8e-5
+    assert velocity < 3e-4
 
 
 def test_grid_entry_points_match_oracle_on_the_reference_stream(gpu_lib, api, oracle):
@@ -171,19 +173,22 @@ def test_entry_points_reproduce_reference_coeval_ionization(gpu_lib, api, tmp_pa
     run.  At z = 18 only a handful of cells cross the barrier, so power_z_reion is white noise
     whose level counts the ionised cells: it matches to 1e-6 only if exactly the same cells
     ionise.  power_neutral_fraction follows the partial ionisations 1 - f_coll zeta of every
-    cell and carries the host quadratures (sigma(M), conditional mass function): 1e-3."""
+    cell and carries the host quadratures (sigma(M), conditional mass function): inside the 1e-4
+    the reference prints its own comparison at (tests/test_integration_features.py:69-81)."""
     monkeypatch.delenv("C21CM_IC_RNG", raising=False)
     got = run_coeval_abi(gpu_lib, api, tmp_path, name)
     worst = RP.check_coeval_fields(name, {k: got[k] for k in
                                           ("lowres_density", "density", "velocity_z")})
-    assert max(worst.values()) < 4e-4
+    velocity = worst.pop("velocity_z")  # the reference's dD/dt is quantised in steps of 3.9e-5 here
+    assert max(worst.values()) < 5e-6, worst  # (tests/test_reference_fixtures.py); observed 8e-5
+    assert velocity < 3e-4
     f = RP.fixture("power_spectra", name)
     p_z, _ = RP.get_power(got["z_reion"], RP.BOX_LEN)
     np.testing.assert_allclose(p_z, f["coeval/power_z_reion"], rtol=1e-5, atol=1e-9)
     p_x, _ = RP.get_power(got["neutral_fraction"], RP.BOX_LEN)
-    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=2e-3)
+    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=1e-4)  # observed <= 5e-5
     p_b, _ = RP.get_power(got["brightness_temp"], RP.BOX_LEN)
-    np.testing.assert_allclose(p_b, f["coeval/power_brightness_temp"], rtol=2e-3)
+    np.testing.assert_allclose(p_b, f["coeval/power_brightness_temp"], rtol=1e-5)  # observed <= 2.1e-6
     # the lightcone's last node is this redshift: its global x_HI is the box mean
     assert got["neutral_fraction"].mean() == pytest.approx(
         f["lightcone/global_neutral_fraction"][-1], rel=2e-6)

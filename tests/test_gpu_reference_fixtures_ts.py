@@ -112,18 +112,19 @@ def test_ts_evolution_reproduces_reference_fixture(gpu_lib, api, tmp_path, monke
     got = evolve(gpu_lib, api, tmp_path)
     f, worst = report("ts", got)
     print("worst relative deviation of the binned power:", worst)
-    # observed on the MI355X: x_e 4.6e-4, T_k 1.4e-4, T_s 6.5e-4, dT_b 6.6e-4, x_HI 7.8e-4
+    # observed on the MI355X (round 3, with the reference's own Planck18 Om0 / Ob0):
+    # x_e 5.6e-5, T_k 1.2e-4, T_s 9.2e-5, dT_b 2.0e-4, x_HI 5.1e-5
     # x_e: X-ray ionisation through the frequency integrals and the SFRD tables
-    assert worst["xray_ionised_fraction"] < 2e-3
+    assert worst["xray_ionised_fraction"] < 2e-4
     # T_k, T_s: heating on top of the RECFAST initial state (mode 0 is the mean squared)
-    assert worst["kinetic_temp_neutral"] < 2e-3
-    assert worst["spin_temperature"] < 2e-3
-    assert worst["brightness_temp"] < 2e-3
-    assert worst["neutral_fraction"] < 2e-3
+    assert worst["kinetic_temp_neutral"] < 3e-4
+    assert worst["spin_temperature"] < 3e-4
+    assert worst["brightness_temp"] < 5e-4
+    assert worst["neutral_fraction"] < 1e-4
     # the lightcone's global signal at its node redshifts
     gb = np.array([h[1] for h in got["history"]])  # both run from Z_HEAT_MAX down to 18
     print("global dT_b deviation:", np.abs(gb / f["lightcone/global_brightness_temp"] - 1).max())
-    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-3)  # observed 3.3e-4
+    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-4)  # observed 2.7e-5
 
 
 def test_ts_with_inhomogeneous_recombinations_reproduces_reference_fixture(gpu_lib, api, tmp_path,
@@ -138,13 +139,13 @@ def test_ts_with_inhomogeneous_recombinations_reproduces_reference_fixture(gpu_l
     f, worst = report("inhomo_ts", got)
     print("worst relative deviation of the binned power:", worst)
     for k in TS + ("brightness_temp", "neutral_fraction"):
-        assert worst[k] < 2e-3, k
+        assert worst[k] < 5e-4, k  # observed <= 2.0e-4 (dT_b)
     p_z, _ = RP.get_power(got["z_reion"], RP.BOX_LEN)
     np.testing.assert_allclose(p_z, f["coeval/power_z_reion"], rtol=1e-5, atol=1e-9)
     p_g, _ = RP.get_power(got["ionisation_rate_G12"], RP.BOX_LEN)
-    np.testing.assert_allclose(p_g, f["coeval/power_ionisation_rate_G12"], rtol=2e-3)
+    np.testing.assert_allclose(p_g, f["coeval/power_ionisation_rate_G12"], rtol=1e-4)  # observed 5.7e-5
     gb = np.array([h[1] for h in got["history"]])
-    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-3)
+    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-4)  # observed 2.7e-5
     gx = np.array([h[2] for h in got["history"]])
     np.testing.assert_allclose(gx, f["lightcone/global_neutral_fraction"], rtol=1e-5)
 
@@ -231,10 +232,11 @@ def test_lagrangian_ts_evolution_reproduces_reference_fixture(gpu_lib, api, tmp_
     print("worst relative deviation of the binned power:", worst)
     gb = np.array([h[1] for h in got["history"]])
     print("global dT_b deviation:", np.abs(gb / f["lightcone/global_brightness_temp"] - 1).max())
-    # observed on the MI355X: T_s 6.0e-4, T_k 1.5e-4, x_e 3.7e-4, dT_b 7.1e-4, x_HI 9.6e-4; global 3.6e-4
+    # observed on the MI355X (round 3): T_s 5.7e-5, T_k 1.2e-4, x_e 6.2e-6, dT_b 1.2e-4, x_HI 1.0e-5;
+    # global 8.9e-6
     for k in TS + ("brightness_temp", "neutral_fraction"):
-        assert worst[k] < 2e-3, k
-    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-3)
+        assert worst[k] < 3e-4, k
+    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-4)
 
 
 def test_minimize_memory_run_reproduces_reference_fixture(gpu_lib, api, tmp_path, monkeypatch):
@@ -248,9 +250,9 @@ def test_minimize_memory_run_reproduces_reference_fixture(gpu_lib, api, tmp_path
     f, worst = report("minimize_mem", got)
     print("worst relative deviation of the binned power:", worst)
     for k in TS + ("brightness_temp", "neutral_fraction"):
-        assert worst[k] < 2e-3, k
+        assert worst[k] < 5e-4, k  # observed <= 2.0e-4
     gb = np.array([h[1] for h in got["history"]])
-    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-3)
+    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=1e-4)
 
 
 def test_const_ion_eff_ts_evolution_reproduces_reference_fixture(gpu_lib, api, tmp_path, monkeypatch):
@@ -267,8 +269,10 @@ def test_const_ion_eff_ts_evolution_reproduces_reference_fixture(gpu_lib, api, t
     k: changing sigma_min by 1e-6 moves the last bin of the T_k power by 9e-4 (measured), and the
     two implementations differ by up to 1 % there (growing smoothly with k).  On the five largest
     scales they agree to 1.4e-3 .. 2.2e-3: the collapsed fraction responds to sigma with a
-    logarithmic slope of ~20-40 at these redshifts, so the ~1e-4 of the reference's sigma table
-    shows (the E-INTEGRAL runs above normalise most of it away through avg_fix_term)."""
+    logarithmic slope of ~20-40 at these redshifts (the E-INTEGRAL runs above normalise most of it
+    away through avg_fix_term).  Restating the reference's float sigma(M) table
+    (C21CM_HOST_MODE=reference) moves these numbers by less than 1e-4 (measured, round 3): what is
+    left is the realisation of the float dfcoll/dz noise, not the table."""
     monkeypatch.delenv("C21CM_IC_RNG", raising=False)
     got = evolve(gpu_lib, api, tmp_path, source_model=0)
     f = RP.fixture("power_spectra", "ts_nomdz")
@@ -279,4 +283,4 @@ def test_const_ion_eff_ts_evolution_reproduces_reference_fixture(gpu_lib, api, t
         assert dev[:5].max() < 4e-3, k
         assert dev.max() < 1.5e-2, k
     gb = np.array([h[1] for h in got["history"]])
-    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=2e-3)  # observed 1.1e-3
+    np.testing.assert_allclose(gb, f["lightcone/global_brightness_temp"], rtol=2e-3)  # observed 9.5e-4

@@ -85,8 +85,9 @@ def test_power_spectrum_shape(host):
 
 def test_growth_factor(host):
     """dicke is the Carroll-Press-Turner / Liddle fit: within 1% of the exact LCDM growth."""
-    om, orad = float(np.float32(0.30966)), float(np.float32(8.6e-5))
-    ol = float(np.float32(1 - np.float32(0.30966)))
+    om0 = (0.02242 + 0.11933) / 0.6766**2  # the reference's Planck18 (inputs.py:126-134)
+    om, orad = float(np.float32(om0)), float(np.float32(8.6e-5))
+    ol = float(np.float32(1 - om0))
 
     def E(a):
         return math.sqrt(om / a**3 + orad / a**4 + ol)
@@ -538,3 +539,75 @@ def test_mimic_scatter_in_consts(host, pkg):
     assert ev.Mlim_Fstar < sc.Mlim_Fstar
     assert ev.fstar_10 * (ev.Mlim_Fstar / 1e10) ** ev.alpha_star == pytest.approx(1.0, rel=5e-3)
     assert (ev.fesc_10, ev.alpha_esc, ev.Mlim_Fesc, ev.t_h) == (sc.fesc_10, sc.alpha_esc, sc.Mlim_Fesc, sc.t_h)
+
+
+# ---- C21CM_HOST_MODE=reference: the reference's stopping rules restated --------------------------
+def test_gauss_kronrod_61_rule_and_qag(pkg):
+    """The generated 61-point rule (tools/gen_gk61.py; QUADPACK dqk61 = GSL_INTEG_GAUSS61) is exact
+    to degree 91 in ONE application, and c21_qag61 bisects like gsl_integration_qag."""
+    lib = pkg.load()
+    FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
+    lib.c21_qag61.restype = C.c_double
+    lib.c21_qag61.argtypes = [FN, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                              C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    calls = [0]
+
+    def run(f, a, b, epsrel):
+        calls[0] = 0
+
+        def wrapped(x, _):
+            calls[0] += 1
+            return f(x)
+
+        err, st = C.c_double(), C.c_int()
+        val = lib.c21_qag61(FN(wrapped), None, a, b, epsrel, C.byref(err), C.byref(st))
+        return val, err.value, st.value, calls[0]
+
+    # (epsrel 1: the error estimate K61 - G30 is large for this degree, one application is forced)
+    val, err, st, n = run(lambda x: x**90 + x**91, -1.0, 1.0, 1.0)
+    assert n == 61 and st == 0
+    assert val == pytest.approx(2.0 / 91.0, rel=1e-13)
+    val, _, _, n = run(lambda x: (x - 0.25) ** 91, 0.0, 2.0, 1.0)  # an unsymmetric interval
+    assert n == 61 and val == pytest.approx((1.75**92 - 0.25**92) / 92.0, rel=1e-12)
+    # an integrand one rule cannot resolve to 1e-9 is bisected; same answer as scipy's QAGS
+    f = lambda x: math.exp(-50 * (x - 0.3) ** 2) * math.cos(40 * x)  # noqa: E731
+    val, err, st, n = run(f, -2.0, 3.0, 1e-9)
+    want, _ = integrate.quad(f, -2.0, 3.0, epsabs=0, epsrel=1e-12, limit=200)
+    assert st == 0 and n > 61 and n % 61 == 0
+    assert val == pytest.approx(want, rel=1e-9) and err <= 1e-9 * abs(val)
+    # epsrel 1e-3 stops early (the reference's mass-function integrals): fewer evaluations
+    assert run(f, -2.0, 3.0, 1e-3)[3] < n
+
+
+def test_host_reference_mode_restates_the_float_sigma_table(host, monkeypatch):
+    """C21CM_HOST_MODE=reference: sigma(M) from 300 float entries on a uniform ln M grid between the
+    floats 5e2 and 1e20, linear interpolation (interp_tables.c:1135-1180, interpolation.c:123-131):
+    equal to the float-rounded quadrature at the nodes, up to a few 1e-4 off in between."""
+    x_min, x_max = math.log(float(np.float32(5e2))), math.log(float(np.float32(1e20)))
+    width = (x_max - x_min) / 299.0
+    monkeypatch.setenv("C21CM_HOST_MODE", "reference")
+    worst = 0.0
+    for i in (3, 57, 120, 201, 250):
+        m_node = float(np.float32(math.exp(x_min + i * width)))
+        node = float(np.float32(host.sigma_z0(m_node)))
+        nxt = float(np.float32(host.sigma_z0(float(np.float32(math.exp(x_min + (i + 1) * width))))))
+        # at a node's own abscissa (up to the float rounding of the mass): the stored float
+        assert host.c21_sigma_fast(math.exp(x_min + i * width + 1e-9)) == pytest.approx(node, rel=1e-7)
+        mid = host.c21_sigma_fast(math.exp(x_min + (i + 0.5) * width))
+        assert mid == pytest.approx(0.5 * (node + nxt), rel=1e-7)
+        worst = max(worst, abs(mid / host.sigma_z0(math.exp(x_min + (i + 0.5) * width)) - 1))
+    assert 1e-6 < worst < 1e-3
+    monkeypatch.setenv("C21CM_HOST_MODE", "converged")
+    m = math.exp(x_min + 120.5 * width)
+    assert host.c21_sigma_fast(m) == pytest.approx(host.sigma_z0(m), rel=2e-7)
+
+
+def test_host_reference_mode_stops_the_mass_function_integrals_early(host, monkeypatch):
+    """Fcoll_General through QAG(61 points, epsrel 1e-3) on the float table differs from the
+    converged integral by more than its rounding and by less than the requested 1e-3."""
+    lo, hi = math.log(1e8), math.log(1e16)
+    monkeypatch.setenv("C21CM_HOST_MODE", "converged")
+    conv = host.c21_Fcoll_General(10.0, lo, hi)
+    monkeypatch.setenv("C21CM_HOST_MODE", "reference")
+    ref = host.c21_Fcoll_General(10.0, lo, hi)
+    assert 1e-7 < abs(ref / conv - 1) < 1e-3

@@ -48,7 +48,8 @@ def test_oracle_brightness_matches_formula(oracle, use_ts):
 def test_const_factor_value():
     """27 (Ob h^2 / 0.023) sqrt(0.15 / (Om h^2) (1+z)/10) mK for Planck18 at z = 9."""
     spec = S.brightness_spec(1, 9.0)
-    h, om, ob = 0.6766, 0.30966, 0.04897
+    h = 0.6766  # the reference's Planck18: inputs.py:126-134
+    om, ob = (0.02242 + 0.11933) / h**2, 0.02242 / h**2
     want = 27 * (ob * h * h / 0.023) * np.sqrt(0.15 / (om * h * h) * 10.0 / 10.0)
     assert spec.const_factor == pytest.approx(want, rel=1e-6)
     assert spec.T_rad == pytest.approx(27.255, rel=1e-6)

@@ -6,7 +6,12 @@ the reference's universe, and the chain
     seed_rng_threads -> sample_ic_modes -> ComputeInitialConditions -> ComputePerturbedField
 of the oracle must reproduce the reference's binned power spectra and PDFs.  The tolerances
 are the reference's own (`atol 5e-3, rtol 1e-3`, tests/test_integration_features.py:305-308);
-observed agreement is ~5e-5 for the density power and ~1e-4 for the velocity power.  A different
+observed agreement is 4e-7 .. 2e-6 for the density / IC-velocity powers; the PerturbedField
+velocity power sits 3e-5 .. 2.4e-4 off because the reference's dD/dt is a forward difference of
+doubles over dz = 1e-10 (cosmology.c:724-730), i.e. quantised in steps of 1 / 25460 = 3.9e-5 of
+itself at z = 18 -- the fixtures are one such step away from this libm's.  (Until round 3 all of
+these sat near 1e-4: the defaults here were astropy's rounded Planck18, not the reference's
+Om0 = (0.02242 + 0.11933) / h^2, Ob0 = 0.02242 / h^2 of inputs.py:126-134.)  A different
 realisation of the same P(k) would scatter by tens of per cent per bin, so these tests fail
 unless the generators, the thread split, the mode order, the Hermitian fix, the k-space
 operators, the filter, the subsampling, the CIC deposit and the growth factors are all right.
@@ -51,7 +56,7 @@ def test_oracle_reproduces_reference_perturb_field_data(oracle, ics_cache, name)
     ics = ics_cache(algorithm, hires, 2)
     pf = oracle.perturb_grids(RP.perturb_spec(10.0, algorithm, hires), ics)
     worst = RP.check_perturb_fixture(name, pf["density"], pf["velocity_z"])
-    assert worst < 2e-4  # far inside the reference's rtol 1e-3
+    assert worst < 2e-6  # density power; the reference asserts rtol 1e-3
 
 
 @pytest.mark.parametrize("name,n_threads", [("simple", 2), ("no-mdz", 2), ("fixed_halogrids", 2),
@@ -65,7 +70,9 @@ def test_oracle_reproduces_reference_coeval_powers(oracle, ics_cache, name, n_th
         "lowres_density": ics["lowres_density"], "lowres_vx": ics["lowres_vx"],
         "lowres_vx_2LPT": ics["lowres_vx_2LPT"], "density": pf["density"],
         "velocity_z": pf["velocity_z"]})
-    assert max(worst.values()) < 3e-4
+    velocity = worst.pop("velocity_z")
+    assert max(worst.values()) < 5e-6, worst
+    assert velocity < 3e-4  # the quantised dD/dt, see the module docstring
 
 
 def test_wrong_thread_count_is_a_different_universe(oracle, ics_cache):

@@ -9,8 +9,12 @@ so power_z_reion is white noise at the level set by the number of ionised cells 
 1e-6 only if exactly the reference's cells ionise -- while power_neutral_fraction and
 power_brightness_temp follow the partial ionisations 1 - f_coll(delta_R) zeta of all cells.
 The reference itself only prints these comparisons at rtol 1e-4
-(tests/test_integration_features.py:69-81); observed here: 4-8e-4 for x_HI (the reference's
-sigma(M) comes from a float interpolation table and GSL QAG at 1e-3..1e-6), asserted at 2e-3.
+(tests/test_integration_features.py:69-81); observed here: <= 5.2e-5 for x_HI, 5.9e-5 for Gamma_12,
+7e-6 for N_rec, 2.5e-6 for dT_b, asserted at the reference's printed 1e-4 (dT_b: 1e-5).  What is
+left in x_HI is the host quadratures: the reference stops gsl_integration_qag(61 points) at epsrel
+1e-3 and interpolates sigma(M) linearly in a 300-entry float table, this library converges them --
+C21CM_HOST_MODE=reference restates both and brings `simple` to 1.7e-5
+(test_host_reference_mode_*).
 """
 
 import ctypes as C
@@ -104,14 +108,13 @@ def check_ionization(name, density, xh, z_reion, oracle, cp):
     p_z, _ = RP.get_power(z_reion, RP.BOX_LEN)
     np.testing.assert_allclose(p_z, f["coeval/power_z_reion"], rtol=1e-5, atol=1e-9)
     p_x, _ = RP.get_power(xh, RP.BOX_LEN)
-    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=2e-3)
+    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=1e-4)
     assert xh.mean() == pytest.approx(f["lightcone/global_neutral_fraction"][-1], rel=2e-6)
     bt = oracle.brightness_grids(S.brightness_spec(density.size, Z, cosmo=cp), density, xh)
     p_b, _ = RP.get_power(bt["brightness_temp"], RP.BOX_LEN)
-    np.testing.assert_allclose(p_b, f["coeval/power_brightness_temp"], rtol=2e-3)
-    # (the lightcone's global dT_b at its last node: 1.3e-4 off, consistent with the 2.5e-4
-    # offset of the power; the reference asserts lightcone globals at rtol 1e-3, :160-161)
-    assert bt["mean"] == pytest.approx(f["lightcone/global_brightness_temp"][-1], rel=1e-3)
+    np.testing.assert_allclose(p_b, f["coeval/power_brightness_temp"], rtol=1e-5)
+    # the lightcone's global dT_b at its last node (the reference asserts rtol 1e-3, :160-161)
+    assert bt["mean"] == pytest.approx(f["lightcone/global_brightness_temp"][-1], rel=1e-6)
 
 
 @pytest.mark.parametrize("name,source_model", [("simple", 1), ("no-mdz", 0), ("fftw_wisdom", 1)])
@@ -125,6 +128,27 @@ def test_oracle_ionized_box_reproduces_reference_fixture(oracle, pkg, fields, tm
     check_ionization(name, pf["density"], out["neutral_fraction"], out["z_reion"], oracle, ses.cp)
     n_ionised = int((out["neutral_fraction"] == 0).sum())
     assert n_ionised >= 1  # the white-noise level of power_z_reion counts exactly these cells
+
+
+def test_host_reference_mode_brings_the_mass_dependent_model_closer(oracle, pkg, fields, tmp_path,
+                                                                    monkeypatch):
+    """`simple` (E-INTEGRAL) normalises its excursion set with Nion_General, which the reference
+    integrates with QAG(61 points) stopped at epsrel 1e-3 over a linearly interpolated float
+    sigma(M) table (hmf.c:612-655,955-971; interp_tables.c:1135-1180).  With those two restated
+    (C21CM_HOST_MODE=reference) the x_HI power is within 3e-5 of the reference's run, against 5.1e-5
+    with converged quadratures."""
+    _, pf = fields
+    dev = {}
+    for mode in ("converged", "reference"):
+        monkeypatch.setenv("C21CM_HOST_MODE", mode)
+        ses = session(pkg, tmp_path, 1)
+        spec = eulerian_spec(ses, pkg.load(), oracle, 1)
+        out = oracle.ionize_grids(spec, pf["density"], need_nion=True)
+        p_x, _ = RP.get_power(out["neutral_fraction"], RP.BOX_LEN)
+        ref = RP.fixture("power_spectra", "simple")["coeval/power_neutral_fraction"]
+        dev[mode] = float(np.abs(p_x / ref - 1).max())
+        del ses
+    assert dev["reference"] < 3e-5 < dev["converged"] < 1e-4, dev
 
 
 def test_oracle_halobox_chain_reproduces_reference_fixture(oracle, pkg, fields, tmp_path):
@@ -243,17 +267,17 @@ def check_recomb_fixture(name, out):
     p_z, _ = RP.get_power(out["z_reion"], RP.BOX_LEN)
     np.testing.assert_allclose(p_z, f["coeval/power_z_reion"], rtol=1e-5, atol=1e-9)
     p_x, _ = RP.get_power(out["neutral_fraction"], RP.BOX_LEN)
-    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=2e-3)
+    np.testing.assert_allclose(p_x, f["coeval/power_neutral_fraction"], rtol=1e-4)
     # Gamma_12 at the first crossing: R * gamma_prefactor * f_coll of the crossing cell(s)
     p_g, _ = RP.get_power(out["ionisation_rate_G12"], RP.BOX_LEN)
-    np.testing.assert_allclose(p_g, f["coeval/power_ionisation_rate_G12"], rtol=2e-3)
+    np.testing.assert_allclose(p_g, f["coeval/power_ionisation_rate_G12"], rtol=1e-4)
     assert (out["ionisation_rate_G12"] > 0).sum() >= 1
     if f"coeval/power_cumulative_recombinations" in f:
         # N_rec through the MHR00 rate table: the reference integrates it with GSL QAG at 1e-2,
         # this backend to 1e-7 -- they agree to 2e-4 in power here
         nrec = out["cumulative_recombinations"]
         p_n, _ = RP.get_power(np.broadcast_to(nrec, (n, n, n)), RP.BOX_LEN)
-        np.testing.assert_allclose(p_n, f["coeval/power_cumulative_recombinations"], rtol=2e-3)
+        np.testing.assert_allclose(p_n, f["coeval/power_cumulative_recombinations"], rtol=1e-4)
 
 
 @pytest.mark.parametrize("name,model,cell", [("inhomo", 2, 0), ("homo", 1, 1)])
