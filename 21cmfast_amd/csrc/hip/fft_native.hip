@@ -85,7 +85,13 @@ __device__ __forceinline__ int fft_out_row(int g) {
 // the pass's L1-TLB requests missed; blocked, 16 consecutive x are 4 KB apart and a tile
 // touches 64 pages instead of 1024.  Memory line m = (x / XB * ny + y) * XB + x % XB holds the
 // k_z row of the logical line x * ny + y; the Nyquist plane stays [x][y].
-__host__ __device__ constexpr int split_xb_log2(int nx) { return nx >= 1024 ? 4 : 0; }
+#ifndef C21X_XB_MIN   // experiment switches: shortest x-line stored blocked, log2 of the block
+#define C21X_XB_MIN 1024
+#endif
+#ifndef C21X_XB_LOG2
+#define C21X_XB_LOG2 4
+#endif
+__host__ __device__ constexpr int split_xb_log2(int nx) { return nx >= C21X_XB_MIN ? C21X_XB_LOG2 : 0; }
 __host__ __device__ __forceinline__ long logical_line(long m, int ny, int lb) {
     if (lb == 0) return m;
     const long blk = (long)ny << lb;
