@@ -174,7 +174,8 @@ def kernel_roofline(args, spec, torch):
     # the step then runs kernels 7 / 8 instead of 0 / 6 and launches no table kernel
     lib.c21hip_wev_applicable.restype = C.c_int
     evaluated = bool(lib.c21hip_wev_applicable(int(spec.hii_filter), int(spec.stars_filter), 2, n, n, n))
-    paired = (os.environ.get("C21CM_PAIR_RADII", "1") != "0" and n <= 512
+    lib.c21hip_pair_sweep_supported.restype = C.c_int
+    paired = (os.environ.get("C21CM_PAIR_RADII", "1") != "0" and bool(lib.c21hip_pair_sweep_supported(n))
               and spec.fcoll_mode == importlib.import_module("21cmfast_amd.workloads").FCOLL_STARS)
     n_fused = spec.n_radii - 1  # launches per step (radius index 0 is the final sweep)
     launches = {0: n_fused % 2 if paired else n_fused, 6: n_fused // 2 if paired else 0,

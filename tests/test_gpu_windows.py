@@ -139,3 +139,4 @@ def test_node_table_interpolation_accuracy():
         tab = C.node_tables(lambda x: C.expmfp(x, ratio), h, nmax)  # noqa: B023
         ex = C.expmfp(x0.astype(np.longdouble), ratio).astype(np.float64)
         assert np.abs(C.interp32(tab, x0, h).astype(np.float64) - ex).max() < 8e-8
+
