@@ -45,6 +45,12 @@
 #ifndef C21X_XPAIR_THREADS
 #define C21X_XPAIR_THREADS 512
 #endif
+#ifndef C21X_FUSE512  // 512-point line passes: first and last radix-8 stage in registers (one LDS stage)
+#define C21X_FUSE512 1
+#endif
+#ifndef C21X_XPAIR_SKIP_FFT  // diagnostic (wrong results): 1 = the two-radius pass X skips its transforms,
+#define C21X_XPAIR_SKIP_FFT 0  // 2 = it also skips the second LDS write + store (i.e. moves R + W only)
+#endif
 #ifndef C21X_XPAIR_TWO_SETS
 #define C21X_XPAIR_TWO_SETS 0
 #endif
@@ -897,8 +903,19 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // Lines of 256 points and fewer load the next window straight into `cur` (it is dead between
     // a tile's LDS write and the next tile's): 10 % faster there (two workgroups per CU share the
     // register file), 3-6 % slower at 512 and 1024 points, which keep the separate `pre` set.
-    constexpr bool WPRE = (N >= 512);
-    float2 wpre[NR][WPRE ? NP : 1], wcur[NR][NP], wpre_half[NR], wcur_half[NR];
+    // F512 (round 3): 512-point lines, no window or evaluated windows.  A thread owns the eight rows
+    // b + 64 k of its two columns -- one complete input set of the first radix-8 Stockham stage and
+    // one complete output set of the last -- so the first stage runs on the registers before the
+    // tile goes to LDS and the last on the values read back for the store: ONE stage in LDS instead
+    // of three.  Half the LDS traffic (256 instead of 512 KB per tile) and three barriers instead
+    // of seven; LDS and global memory share a CU's data path to the registers, so the LDS bytes
+    // were on the critical path (the two-radius pass X without its transforms ran at 5.0 TB/s,
+    // with them at 3.6).  Mirror rows are no longer in one thread: eight window values per column
+    // instead of four.
+    constexpr bool F512 = C21X_FUSE512 && N == 512 && kBlock == 512 && (FMODE == 0 || WEVAL);
+    constexpr int NW = F512 ? 2 * NP : NP;  // window values (rows) per thread and column
+    constexpr bool WPRE = (N >= 512) && !F512;
+    float2 wpre[NR][WPRE ? NP : 1], wcur[NR][NW], wpre_half[NR], wcur_half[NR];
     auto w_reload = [&](const LineItem &it, int m) {
         const int mi = it.npair == 2 ? (m & 1) : 0;
         return m == 0 || (a.dual && mi == 0);
@@ -978,11 +995,14 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         return p;
     };
     // k_x of this thread's rows (fixed for the whole kernel) -- float((double) index * dk), k_of()
-    float wev_kx[WEVAL ? NP : 1];
+    float wev_kx[WEVAL ? NW : 1];
     float wev_kx_half = 0.f;
     if constexpr (WEVAL) {
 #pragma unroll
-        for (int u = 0; u < NP; u++) wev_kx[u] = (float)((double)(r0 + RSTEP * u) * a.wev_dkx);
+        for (int u = 0; u < NW; u++) {
+            const int row = r0 + RSTEP * u;  // F512: u runs over all eight rows, |k_x| index = min(row, N - row)
+            wev_kx[u] = (float)((double)(F512 ? min(row, N - row) : row) * a.wev_dkx);
+        }
         wev_kx_half = (float)((double)(N / 2) * a.wev_dkx);
     }
     auto eval_windows = [&](const LineItem &it, int m) {
@@ -1004,7 +1024,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const float *tab0 = wnodes + max(wsel ? a.wev_tab[0][1] : a.wev_tab[0][0], 0) * per;
         const float *tab1 = wnodes + max(wsel ? a.wev_tab[1][1] : a.wev_tab[1][0], 0) * per;
 #pragma unroll
-        for (int u = 0; u < NP; u++) {
+        for (int u = 0; u < NW; u++) {
+            // F512: rows r0 + 64 u, u >= 4, are the mirror rows of thread (64 - r0, c4): it evaluates
+            // them (as its u' = 7 - u) and hands them over below; row N/2 stays with r0 = 0
+            if (F512 && u >= NP && !(u == NP && r0 == 0)) continue;
             const KAbs k0 = k_abs(wev_kx[WEVAL ? u : 0], kyc[0], kzc[0]);
             const KAbs k1 = k_abs(wev_kx[WEVAL ? u : 0], kyc[1], kzc[1]);
 #pragma unroll
@@ -1015,7 +1038,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                     make_float2(weval_one(k0, R, type, tab, rr), weval_one(k1, R, type, tab, rr));
             }
         }
-        if (r0 == 0) {  // row N/2 (the mirror partner of row 0) belongs to the threads with r0 = 0
+        if (!F512 && r0 == 0) {  // row N/2 (the mirror partner of row 0) belongs to the threads with r0 = 0
             const KAbs k0 = k_abs(wev_kx_half, kyc[0], kzc[0]), k1 = k_abs(wev_kx_half, kyc[1], kzc[1]);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
@@ -1024,6 +1047,24 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 (WPRE ? wpre_half[rr] : wcur_half[rr]) =
                     make_float2(weval_one(k0, R, type, tab, rr), weval_one(k1, R, type, tab, rr));
             }
+        }
+        if constexpr (F512) {  // the mirror halves change hands through the first tile buffer (free here)
+            float2 *const exch = tile;
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+                for (int u = 0; u < NP; u++) exch[((int)threadIdx.x * NP + u) * NR + rr] = wcur[rr][u];
+            __syncthreads();
+            const int src = (((RSTEP - r0) & (RSTEP - 1)) * CPAIR + c4) * NP;
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+                for (int u = NP; u < NW; u++)
+                    // row r0 + 64 u mirrors to (64 - r0) + 64 (7 - u); for r0 = 0 that is 64 (8 - u)
+                    if (!(u == NP && r0 == 0))
+                        wcur[rr][u] = exch[(src + (NW - (r0 == 0 ? 0 : 1) - u)) * NR + rr];
+            __syncthreads();
         }
     };
     auto issue_wloads = [&](const LineItem &it, int m) {
@@ -1068,6 +1109,12 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const float2 *hi = lo + (long)((N / 2) >> it.line_lb) * it.line_bstride;
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
+            if constexpr (F512) {  // rows r0 + 64 u, the upper half addressed from the row-N/2 base
+                const int row = r0 + RSTEP * u;
+                const unsigned roff = row_off(it, row < N / 2 ? row : row - N / 2);
+                reg[u] = *reinterpret_cast<const float4 *>((row < N / 2 ? lo : hi) + (roff + 2u * c4));
+                continue;
+            }
             const int row_a = r0 + RSTEP * (u >> 1);
             // mirror row N - row_a = N/2 + (N/2 - row_a); row_a = 0 pairs with N/2 itself
             const unsigned roff = (u & 1) ? (row_a == 0 ? 0u : row_off(it, N / 2 - row_a))
@@ -1146,6 +1193,47 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
 #pragma unroll
       for (int rr = 0; rr < NR; rr++) {
         float2 *const tile_r = tile + rr * N * TZ;
+        if constexpr (F512) {
+            // first Stockham stage (s = 1, butterfly b = r0: inputs rows r0 + 64 k, outputs rows
+            // 8 r0 + j times tw[r0 j]) on the registers, both columns
+            float2 c0[8], c1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                float4 v = reg[u];
+                if (WIN) {
+                    const float2 wv = wcur[rr][u];
+                    v.x = __fmul_rn(v.x, wv.x);
+                    v.y = __fmul_rn(v.y, wv.x);
+                    v.z = __fmul_rn(v.z, wv.y);
+                    v.w = __fmul_rn(v.w, wv.y);
+                }
+                c0[u] = make_float2(v.x, v.y);
+                c1[u] = make_float2(v.z, v.w);
+            }
+            Dft<8, SIGN>::run(c0);
+            Dft<8, SIGN>::run(c1);
+            float2 wj[8];
+            wj[1] = tw[r0];
+            wj[2] = tw[2 * r0];
+            wj[4] = tw[4 * r0];
+            wj[3] = cmul(wj[1], wj[2]);
+            wj[5] = cmul(wj[1], wj[4]);
+            wj[6] = cmul(wj[2], wj[4]);
+            wj[7] = cmul(wj[3], wj[4]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float2 o0 = c0[j], o1 = c1[j];
+                if (j > 0) {
+                    float2 w = wj[j];
+                    if (SIGN > 0) w.y = -w.y;
+                    o0 = cmul(o0, w);
+                    o1 = cmul(o1, w);
+                }
+                *reinterpret_cast<float4 *>(tile_r + (8 * r0 + j) * TZ + 2 * c4) =
+                    make_float4(o0.x, o0.y, o1.x, o1.y);
+            }
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
             const int row_a = r0 + RSTEP * (u >> 1);
@@ -1188,8 +1276,9 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         // (a TileRef past the end still names the last tile, see next_tile)
         if (WIN && !WEVAL && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
         issue_loads(reg, refill.it, refill.m);
-        // (evaluated windows: ALU + LDS work only, placed behind the loads it can hide)
-        if (WEVAL && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
+        // (evaluated windows: ALU + LDS work only, placed behind the loads it can hide; F512: at the
+        // end of the tile, where the first tile buffer is free for the exchange of the mirror halves)
+        if (WEVAL && !F512 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
 
 #pragma unroll
       for (int rr = 0; rr < NR; rr++) {
@@ -1199,7 +1288,37 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         if constexpr (PAIR)
             if (rr) st_lo = member_grid(it, m) ? it.dst1b : it.dst0b;
         st_lo += member_base(it, m);
-        line_fft<N, TZ, SIGN, kBlock>(tile_r, tw, tw_half);
+        if constexpr (F512) {
+            // second stage in LDS (s = 8), third (s = 64, no twiddles: inputs rows r0 + 64 k,
+            // outputs rows r0 + 64 j) on the values read back for the store
+            stockham_stage<N, TZ, TZ, 8, SIGN, false, kBlock>(tile_r, tw, 3);
+            float2 c0[8], c1[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float4 t = *reinterpret_cast<const float4 *>(tile_r + (r0 + RSTEP * k) * TZ + 2 * c4);
+                c0[k] = make_float2(t.x, t.y);
+                c1[k] = make_float2(t.z, t.w);
+            }
+            Dft<8, SIGN>::run(c0);
+            Dft<8, SIGN>::run(c1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float4 v = make_float4(c0[j].x, c0[j].y, c1[j].x, c1[j].y);
+                if (a.out_scale != 1.0f) {
+                    v.x *= a.out_scale;
+                    v.y *= a.out_scale;
+                    v.z *= a.out_scale;
+                    v.w *= a.out_scale;
+                }
+                const int row = r0 + RSTEP * j;
+                const unsigned roff = row_off(it, row < N / 2 ? row : row - N / 2);
+                float2 *p = st_lo + (row < N / 2 ? 0 : st_half);
+                *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
+            }
+            continue;
+        }
+        if (!(PAIR && C21X_XPAIR_SKIP_FFT)) line_fft<N, TZ, SIGN, kBlock>(tile_r, tw, tw_half);
+        if (PAIR && C21X_XPAIR_SKIP_FFT == 2 && rr == 1) continue;
         // ---- store
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
@@ -1218,6 +1337,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
         }
       }
+        if (WEVAL && F512 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
     };
 
     if ((int)blockIdx.x < n_work) {
@@ -1230,12 +1350,17 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         issue_loads(reg_a, ta.it, 0);
         if (WEVAL) issue_wloads(ta.it, 0);
         TileRef tb = next_tile(ta);
-        if (!TWO_SETS) {  // 1024-point lines: registers for one set only
-            while (true) {
-                process(reg_a, ta, tb, tb);
-                if (!tb.valid) break;
+        if (!TWO_SETS) {  // 1024-point lines, two radii per sweep: registers for one set only
+            // The first tile is peeled here as well: at the loop head the operations in flight are
+            // then the same on entry and on the back edge (this set's loads, then the stores of the
+            // tile before), and the compiler waits for the loads alone.  Without it the merge of
+            // "loads only" (entry) with "loads + stores" (back edge) made every tile start with
+            // s_waitcnt vmcnt(0), i.e. with the drain of the previous tile's stores (round 3).
+            process(reg_a, ta, tb, tb);
+            while (tb.valid) {
                 ta = tb;
                 tb = next_tile(ta);
+                process(reg_a, ta, tb, tb);
             }
             goto main_done;
         }
