@@ -822,6 +822,28 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
     const int r0 = threadIdx.x / CPAIR, c4 = threadIdx.x % CPAIR;
+    // F512: the butterfly index of this thread is r0 in all three stages, so the twiddles of the
+    // first (tw[r0 j]) and second stage (tw[(r0 & ~7) j]) are constants of the kernel
+    constexpr bool F512_ = C21X_FUSE512 && N == 512 && kBlock == 512 && (FMODE == 0 || WEVAL);
+    float2 twd1[F512_ ? 8 : 1], twd2[F512_ ? 8 : 1];
+    if constexpr (F512_) {
+        __syncthreads();  // tw is in LDS
+        auto fill = [&](float2(&t)[8], int ps) {
+            t[0] = make_float2(1.f, 0.f);
+            t[1] = tw[ps];
+            t[2] = tw[2 * ps];
+            t[4] = tw[4 * ps];
+            t[3] = cmul(t[1], t[2]);
+            t[5] = cmul(t[1], t[4]);
+            t[6] = cmul(t[2], t[4]);
+            t[7] = cmul(t[3], t[4]);
+            if (SIGN > 0)
+#pragma unroll
+                for (int j = 1; j < 8; j++) t[j].y = -t[j].y;
+        };
+        fill(twd1, r0);
+        fill(twd2, r0 & ~7);
+    }
     const int n_work0 = (a.g0.pair_outer ? (a.g0.n_outer / 2 + 1) : a.g0.n_outer) * a.g0.n_ctiles;
     const int n_work1 =
         (a.n_geo > 1) ? (a.g1.pair_outer ? (a.g1.n_outer / 2 + 1) : a.g1.n_outer) * a.g1.n_ctiles : 0;
@@ -1212,22 +1234,12 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             }
             Dft<8, SIGN>::run(c0);
             Dft<8, SIGN>::run(c1);
-            float2 wj[8];
-            wj[1] = tw[r0];
-            wj[2] = tw[2 * r0];
-            wj[4] = tw[4 * r0];
-            wj[3] = cmul(wj[1], wj[2]);
-            wj[5] = cmul(wj[1], wj[4]);
-            wj[6] = cmul(wj[2], wj[4]);
-            wj[7] = cmul(wj[3], wj[4]);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 float2 o0 = c0[j], o1 = c1[j];
                 if (j > 0) {
-                    float2 w = wj[j];
-                    if (SIGN > 0) w.y = -w.y;
-                    o0 = cmul(o0, w);
-                    o1 = cmul(o1, w);
+                    o0 = cmul(o0, twd1[F512_ ? j : 0]);
+                    o1 = cmul(o1, twd1[F512_ ? j : 0]);
                 }
                 *reinterpret_cast<float4 *>(tile_r + (8 * r0 + j) * TZ + 2 * c4) =
                     make_float4(o0.x, o0.y, o1.x, o1.y);
@@ -1280,6 +1292,39 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         // end of the tile, where the first tile buffer is free for the exchange of the mirror halves)
         if (WEVAL && !F512 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
 
+        if constexpr (F512) {
+            // second Stockham stage (s = 8) of all tiles of the sweep between ONE pair of barriers:
+            // butterfly r0 of columns 2 c4, 2 c4 + 1: inputs rows r0 + 64 k, outputs rows
+            // (r0 & 7) + 64 (r0 >> 3) + 8 j times tw[(r0 & ~7) j]
+            float2 s0[NR][8], s1[NR][8];
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float4 t = *reinterpret_cast<const float4 *>(tile + rr * N * TZ +
+                                                                       (r0 + RSTEP * k) * TZ + 2 * c4);
+                    s0[rr][k] = make_float2(t.x, t.y);
+                    s1[rr][k] = make_float2(t.z, t.w);
+                }
+            __syncthreads();
+            const int obase = (r0 & 7) + 64 * (r0 >> 3);
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                Dft<8, SIGN>::run(s0[rr]);
+                Dft<8, SIGN>::run(s1[rr]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float2 o0 = s0[rr][j], o1 = s1[rr][j];
+                    if (j > 0) {
+                        o0 = cmul(o0, twd2[F512_ ? j : 0]);
+                        o1 = cmul(o1, twd2[F512_ ? j : 0]);
+                    }
+                    *reinterpret_cast<float4 *>(tile + rr * N * TZ + (obase + 8 * j) * TZ + 2 * c4) =
+                        make_float4(o0.x, o0.y, o1.x, o1.y);
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
       for (int rr = 0; rr < NR; rr++) {
         float2 *const tile_r = tile + rr * N * TZ;
@@ -1289,9 +1334,8 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             if (rr) st_lo = member_grid(it, m) ? it.dst1b : it.dst0b;
         st_lo += member_base(it, m);
         if constexpr (F512) {
-            // second stage in LDS (s = 8), third (s = 64, no twiddles: inputs rows r0 + 64 k,
-            // outputs rows r0 + 64 j) on the values read back for the store
-            stockham_stage<N, TZ, TZ, 8, SIGN, false, kBlock>(tile_r, tw, 3);
+            // third stage (s = 64, no twiddles: inputs rows r0 + 64 k, outputs rows r0 + 64 j) on the
+            // values read back for the store
             float2 c0[8], c1[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
