@@ -48,6 +48,12 @@
 #ifndef C21X_FUSE512  // 512-point line passes: first and last radix-8 stage in registers (one LDS stage)
 #define C21X_FUSE512 1
 #endif
+#ifndef C21X_F512_MERGE   // 1: second stage of both tiles of a two-radius sweep between one pair of barriers
+#define C21X_F512_MERGE 1
+#endif
+#ifndef C21X_F512_HOIST2  // 1: second-stage twiddles kept in registers for the whole kernel (12-30 spilled
+#define C21X_F512_HOIST2 0  // VGPRs in the two-radius kernels, no faster)
+#endif
 #ifndef C21X_XPAIR_SKIP_FFT  // diagnostic (wrong results): 1 = the two-radius pass X skips its transforms,
 #define C21X_XPAIR_SKIP_FFT 0  // 2 = it also skips the second LDS write + store (i.e. moves R + W only)
 #endif
@@ -842,7 +848,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 for (int j = 1; j < 8; j++) t[j].y = -t[j].y;
         };
         fill(twd1, r0);
-        fill(twd2, r0 & ~7);
+        if (C21X_F512_HOIST2) fill(twd2, r0 & ~7);
     }
     const int n_work0 = (a.g0.pair_outer ? (a.g0.n_outer / 2 + 1) : a.g0.n_outer) * a.g0.n_ctiles;
     const int n_work1 =
@@ -1296,34 +1302,53 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             // second Stockham stage (s = 8) of all tiles of the sweep between ONE pair of barriers:
             // butterfly r0 of columns 2 c4, 2 c4 + 1: inputs rows r0 + 64 k, outputs rows
             // (r0 & 7) + 64 (r0 >> 3) + 8 j times tw[(r0 & ~7) j]
-            float2 s0[NR][8], s1[NR][8];
-#pragma unroll
-            for (int rr = 0; rr < NR; rr++)
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const float4 t = *reinterpret_cast<const float4 *>(tile + rr * N * TZ +
-                                                                       (r0 + RSTEP * k) * TZ + 2 * c4);
-                    s0[rr][k] = make_float2(t.x, t.y);
-                    s1[rr][k] = make_float2(t.z, t.w);
-                }
-            __syncthreads();
+            constexpr int GRP = C21X_F512_MERGE ? NR : 1;  // tiles per barrier pair
             const int obase = (r0 & 7) + 64 * (r0 >> 3);
 #pragma unroll
-            for (int rr = 0; rr < NR; rr++) {
-                Dft<8, SIGN>::run(s0[rr]);
-                Dft<8, SIGN>::run(s1[rr]);
+            for (int g = 0; g < NR; g += GRP) {
+                float2 s0[GRP][8], s1[GRP][8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    float2 o0 = s0[rr][j], o1 = s1[rr][j];
-                    if (j > 0) {
-                        o0 = cmul(o0, twd2[F512_ ? j : 0]);
-                        o1 = cmul(o1, twd2[F512_ ? j : 0]);
+                for (int rr = 0; rr < GRP; rr++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const float4 t = *reinterpret_cast<const float4 *>(tile + (g + rr) * N * TZ +
+                                                                           (r0 + RSTEP * k) * TZ + 2 * c4);
+                        s0[rr][k] = make_float2(t.x, t.y);
+                        s1[rr][k] = make_float2(t.z, t.w);
                     }
-                    *reinterpret_cast<float4 *>(tile + rr * N * TZ + (obase + 8 * j) * TZ + 2 * c4) =
-                        make_float4(o0.x, o0.y, o1.x, o1.y);
+                __syncthreads();
+                float2 w2[8];
+                if (!C21X_F512_HOIST2) {
+                    const int ps = r0 & ~7;
+                    w2[1] = tw[ps];
+                    w2[2] = tw[2 * ps];
+                    w2[4] = tw[4 * ps];
+                    w2[3] = cmul(w2[1], w2[2]);
+                    w2[5] = cmul(w2[1], w2[4]);
+                    w2[6] = cmul(w2[2], w2[4]);
+                    w2[7] = cmul(w2[3], w2[4]);
+                    if (SIGN > 0)
+#pragma unroll
+                        for (int j = 1; j < 8; j++) w2[j].y = -w2[j].y;
                 }
+#pragma unroll
+                for (int rr = 0; rr < GRP; rr++) {
+                    Dft<8, SIGN>::run(s0[rr]);
+                    Dft<8, SIGN>::run(s1[rr]);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        float2 o0 = s0[rr][j], o1 = s1[rr][j];
+                        if (j > 0) {
+                            const float2 w = C21X_F512_HOIST2 ? twd2[F512_ ? j : 0] : w2[j];
+                            o0 = cmul(o0, w);
+                            o1 = cmul(o1, w);
+                        }
+                        *reinterpret_cast<float4 *>(tile + (g + rr) * N * TZ + (obase + 8 * j) * TZ + 2 * c4) =
+                            make_float4(o0.x, o0.y, o1.x, o1.y);
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
 #pragma unroll
       for (int rr = 0; rr < NR; rr++) {
