@@ -48,6 +48,9 @@
 #ifndef C21X_FUSE512  // 512-point line passes: first and last radix-8 stage in registers (one LDS stage)
 #define C21X_FUSE512 1
 #endif
+#ifndef C21X_FUSE1024  // the same for 1024-point lines (radix-2 split + the first stage of both halves in registers)
+#define C21X_FUSE1024 1
+#endif
 #ifndef C21X_F512_MERGE   // 1: second stage of both tiles of a two-radius sweep between one pair of barriers
 #define C21X_F512_MERGE 1
 #endif
@@ -92,7 +95,7 @@ __device__ __forceinline__ int fft_out_row(int g) {
 }
 
 // x-blocked split layout.  The main block is stored as [x / XB][y][x % XB][k_z] with
-// XB = 2^xb_log2(nx): 1 (the plain [x][y][k_z]) up to 512-point x-lines, 16 for 1024.  At 1024^3 the
+// XB = 2^xb_log2(nx): 1 (the plain [x][y][k_z]) up to 512-point x-lines, 8 for 1024.  At 1024^3 the
 // rows of a pass-X tile would otherwise lie ny*nz/2*8 B = 4 MB apart, one page each, and 42 % of
 // the pass's L1-TLB requests missed; blocked, 16 consecutive x are 4 KB apart and a tile
 // touches 64 pages instead of 1024.  Memory line m = (x / XB * ny + y) * XB + x % XB holds the
@@ -100,8 +103,8 @@ __device__ __forceinline__ int fft_out_row(int g) {
 #ifndef C21X_XB_MIN   // experiment switches: shortest x-line stored blocked, log2 of the block
 #define C21X_XB_MIN 1024
 #endif
-#ifndef C21X_XB_LOG2
-#define C21X_XB_LOG2 4
+#ifndef C21X_XB_LOG2  // 8 planes per block: pass Y's rows lie 32 KB apart instead of 64 (437 against 447 ms per
+#define C21X_XB_LOG2 3  // 1024^3 call; blocks of 4: 448, of 32: 467)
 #endif
 __host__ __device__ constexpr int split_xb_log2(int nx) { return nx >= C21X_XB_MIN ? C21X_XB_LOG2 : 0; }
 __host__ __device__ __forceinline__ long logical_line(long m, int ny, int lb) {
@@ -941,8 +944,15 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // with them at 3.6).  Mirror rows are no longer in one thread: eight window values per column
     // instead of four.
     constexpr bool F512 = C21X_FUSE512 && N == 512 && kBlock == 512 && (FMODE == 0 || WEVAL);
-    constexpr int NW = F512 ? 2 * NP : NP;  // window values (rows) per thread and column
-    constexpr bool WPRE = (N >= 512) && !F512;
+    // F1024: the same for 1024-point lines (16 rows r0 + 64 u per thread): the radix-2 split
+    // a = x[k] + x[k + 512], b = (x[k] - x[k + 512]) w^k and the first stage of both 512-point halves
+    // on the registers, the second stage of both halves in LDS, the third on the way out, where
+    // A[m] = X[2 m] and B[m] = X[2 m + 1] go to adjacent rows.  Streamed window tables (FMODE 3) are
+    // read per row (row and mirror row name the same table row; the partner thread's read hits L1).
+    constexpr bool F1024 = C21X_FUSE1024 && N == 1024 && kBlock == 512 && (FMODE == 0 || FMODE == 3 || WEVAL);
+    constexpr bool FUSED = F512 || F1024;
+    constexpr int NW = FUSED ? 2 * NP : NP;  // window values (rows) per thread and column
+    constexpr bool WPRE = (N >= 512) && !FUSED;
     float2 wpre[NR][WPRE ? NP : 1], wcur[NR][NW], wpre_half[NR], wcur_half[NR];
     auto w_reload = [&](const LineItem &it, int m) {
         const int mi = it.npair == 2 ? (m & 1) : 0;
@@ -1029,7 +1039,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
 #pragma unroll
         for (int u = 0; u < NW; u++) {
             const int row = r0 + RSTEP * u;  // F512: u runs over all eight rows, |k_x| index = min(row, N - row)
-            wev_kx[u] = (float)((double)(F512 ? min(row, N - row) : row) * a.wev_dkx);
+            wev_kx[u] = (float)((double)(FUSED ? min(row, N - row) : row) * a.wev_dkx);
         }
         wev_kx_half = (float)((double)(N / 2) * a.wev_dkx);
     }
@@ -1055,7 +1065,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         for (int u = 0; u < NW; u++) {
             // F512: rows r0 + 64 u, u >= 4, are the mirror rows of thread (64 - r0, c4): it evaluates
             // them (as its u' = 7 - u) and hands them over below; row N/2 stays with r0 = 0
-            if (F512 && u >= NP && !(u == NP && r0 == 0)) continue;
+            if (FUSED && u >= NP && !(u == NP && r0 == 0)) continue;
             const KAbs k0 = k_abs(wev_kx[WEVAL ? u : 0], kyc[0], kzc[0]);
             const KAbs k1 = k_abs(wev_kx[WEVAL ? u : 0], kyc[1], kzc[1]);
 #pragma unroll
@@ -1066,7 +1076,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                     make_float2(weval_one(k0, R, type, tab, rr), weval_one(k1, R, type, tab, rr));
             }
         }
-        if (!F512 && r0 == 0) {  // row N/2 (the mirror partner of row 0) belongs to the threads with r0 = 0
+        if (!FUSED && r0 == 0) {  // row N/2 (the mirror partner of row 0) belongs to the threads with r0 = 0
             const KAbs k0 = k_abs(wev_kx_half, kyc[0], kzc[0]), k1 = k_abs(wev_kx_half, kyc[1], kzc[1]);
 #pragma unroll
             for (int rr = 0; rr < NR; rr++) {
@@ -1076,7 +1086,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                     make_float2(weval_one(k0, R, type, tab, rr), weval_one(k1, R, type, tab, rr));
             }
         }
-        if constexpr (F512) {  // the mirror halves change hands through the first tile buffer (free here)
+        if constexpr (FUSED) {  // the mirror halves change hands through the first tile buffer (free here)
             float2 *const exch = tile;
             __syncthreads();
 #pragma unroll
@@ -1109,6 +1119,14 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             if (it.filter_axis == 0) {
                 const unsigned wc = (unsigned)(a.n_z / 2);
                 const wtab_t *b = t + (long)it.og * (N / 2 + 1) * wc + (it.ct * TZ + 2 * c4);
+                if constexpr (FUSED) {  // one table row per tile row: index min(row, N - row)
+#pragma unroll
+                    for (int u = 0; u < NW; u++) {
+                        const int row = r0 + RSTEP * u;
+                        wcur[rr][u] = *reinterpret_cast<const float2 *>(b + (unsigned)min(row, N - row) * wc);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < NP; u++)
                     (WPRE ? wpre[rr][WPRE ? u : 0] : wcur[rr][u]) =
@@ -1120,6 +1138,15 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 const unsigned nyh = (unsigned)(a.n_y / 2 + 1);
                 const unsigned j0 = (unsigned)min(c0, a.n_y - c0),
                                j1 = (unsigned)min(c0 + 1, a.n_y - c0 - 1);
+                if constexpr (FUSED) {
+#pragma unroll
+                    for (int u = 0; u < NW; u++) {
+                        const int row = r0 + RSTEP * u;
+                        const wtab_t *r = t + (unsigned)min(row, N - row) * nyh;
+                        wcur[rr][u] = make_float2(r[j0], r[j1]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < NP; u++) {
                     const wtab_t *r = t + (unsigned)(r0 + RSTEP * u) * nyh;
@@ -1137,7 +1164,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const float2 *hi = lo + (long)((N / 2) >> it.line_lb) * it.line_bstride;
 #pragma unroll
         for (int u = 0; u < 2 * NP; u++) {
-            if constexpr (F512) {  // rows r0 + 64 u, the upper half addressed from the row-N/2 base
+            if constexpr (FUSED) {  // rows r0 + 64 u, the upper half addressed from the row-N/2 base
                 const int row = r0 + RSTEP * u;
                 const unsigned roff = row_off(it, row < N / 2 ? row : row - N / 2);
                 reg[u] = *reinterpret_cast<const float4 *>((row < N / 2 ? lo : hi) + (roff + 2u * c4));
@@ -1221,6 +1248,63 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
 #pragma unroll
       for (int rr = 0; rr < NR; rr++) {
         float2 *const tile_r = tile + rr * N * TZ;
+        if constexpr (F1024) {
+            // radix-2 split, then the first stage of the two 512-point halves (tw_half[r0 j]):
+            // a -> rows 8 r0 + j, b -> rows 512 + 8 r0 + j
+            float2 wj[8];
+            wj[1] = tw_half[r0];
+            wj[2] = tw_half[2 * r0];
+            wj[4] = tw_half[4 * r0];
+            wj[3] = cmul(wj[1], wj[2]);
+            wj[5] = cmul(wj[1], wj[4]);
+            wj[6] = cmul(wj[2], wj[4]);
+            wj[7] = cmul(wj[3], wj[4]);
+            if (SIGN > 0)
+#pragma unroll
+                for (int j = 1; j < 8; j++) wj[j].y = -wj[j].y;
+            float2 a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                float4 lo4 = reg[u], hi4 = reg[u + 8];
+                if (WIN) {
+                    const float2 wl = wcur[rr][u], wh = wcur[rr][u + 8];
+                    lo4.x = __fmul_rn(lo4.x, wl.x);
+                    lo4.y = __fmul_rn(lo4.y, wl.x);
+                    lo4.z = __fmul_rn(lo4.z, wl.y);
+                    lo4.w = __fmul_rn(lo4.w, wl.y);
+                    hi4.x = __fmul_rn(hi4.x, wh.x);
+                    hi4.y = __fmul_rn(hi4.y, wh.x);
+                    hi4.z = __fmul_rn(hi4.z, wh.y);
+                    hi4.w = __fmul_rn(hi4.w, wh.y);
+                }
+                float2 w = tw[r0 + RSTEP * u];
+                if (SIGN > 0) w.y = -w.y;
+                const float2 x0 = make_float2(lo4.x, lo4.y), x1 = make_float2(hi4.x, hi4.y);
+                const float2 y0 = make_float2(lo4.z, lo4.w), y1 = make_float2(hi4.z, hi4.w);
+                a0[u] = cadd(x0, x1);
+                b0[u] = cmul(csub(x0, x1), w);
+                a1[u] = cadd(y0, y1);
+                b1[u] = cmul(csub(y0, y1), w);
+            }
+            Dft<8, SIGN>::run(a0);
+            Dft<8, SIGN>::run(a1);
+            Dft<8, SIGN>::run(b0);
+            Dft<8, SIGN>::run(b1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float2 p0 = a0[j], p1 = a1[j], q0 = b0[j], q1 = b1[j];
+                if (j > 0) {
+                    p0 = cmul(p0, wj[j]);
+                    p1 = cmul(p1, wj[j]);
+                    q0 = cmul(q0, wj[j]);
+                    q1 = cmul(q1, wj[j]);
+                }
+                *reinterpret_cast<float4 *>(tile_r + (8 * r0 + j) * TZ + 2 * c4) = make_float4(p0.x, p0.y, p1.x, p1.y);
+                *reinterpret_cast<float4 *>(tile_r + (N / 2 + 8 * r0 + j) * TZ + 2 * c4) =
+                    make_float4(q0.x, q0.y, q1.x, q1.y);
+            }
+            continue;
+        }
         if constexpr (F512) {
             // first Stockham stage (s = 1, butterfly b = r0: inputs rows r0 + 64 k, outputs rows
             // 8 r0 + j times tw[r0 j]) on the registers, both columns
@@ -1296,8 +1380,52 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         issue_loads(reg, refill.it, refill.m);
         // (evaluated windows: ALU + LDS work only, placed behind the loads it can hide; F512: at the
         // end of the tile, where the first tile buffer is free for the exchange of the mirror halves)
-        if (WEVAL && !F512 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
+        if (WEVAL && !FUSED && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
 
+        if constexpr (F1024) {
+            // second stage (s = 8) of both 512-point halves of the tile between one pair of barriers
+            const int obase = (r0 & 7) + 64 * (r0 >> 3);
+            float2 s0[2][8], s1[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float4 t = *reinterpret_cast<const float4 *>(tile + (h * (N / 2) + r0 + RSTEP * k) * TZ + 2 * c4);
+                    s0[h][k] = make_float2(t.x, t.y);
+                    s1[h][k] = make_float2(t.z, t.w);
+                }
+            __syncthreads();
+            float2 w2[8];
+            {
+                const int ps = r0 & ~7;
+                w2[1] = tw_half[ps];
+                w2[2] = tw_half[2 * ps];
+                w2[4] = tw_half[4 * ps];
+                w2[3] = cmul(w2[1], w2[2]);
+                w2[5] = cmul(w2[1], w2[4]);
+                w2[6] = cmul(w2[2], w2[4]);
+                w2[7] = cmul(w2[3], w2[4]);
+                if (SIGN > 0)
+#pragma unroll
+                    for (int j = 1; j < 8; j++) w2[j].y = -w2[j].y;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                Dft<8, SIGN>::run(s0[h]);
+                Dft<8, SIGN>::run(s1[h]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float2 o0 = s0[h][j], o1 = s1[h][j];
+                    if (j > 0) {
+                        o0 = cmul(o0, w2[j]);
+                        o1 = cmul(o1, w2[j]);
+                    }
+                    *reinterpret_cast<float4 *>(tile + (h * (N / 2) + obase + 8 * j) * TZ + 2 * c4) =
+                        make_float4(o0.x, o0.y, o1.x, o1.y);
+                }
+            }
+            __syncthreads();
+        }
         if constexpr (F512) {
             // second Stockham stage (s = 8) of all tiles of the sweep between ONE pair of barriers:
             // butterfly r0 of columns 2 c4, 2 c4 + 1: inputs rows r0 + 64 k, outputs rows
@@ -1358,6 +1486,37 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         if constexpr (PAIR)
             if (rr) st_lo = member_grid(it, m) ? it.dst1b : it.dst0b;
         st_lo += member_base(it, m);
+        if constexpr (F1024) {
+            // third stage of both halves on the values read back; A[m] = X[2 m], B[m] = X[2 m + 1],
+            // m = r0 + 64 j: adjacent rows 2 m, 2 m + 1 of the line
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float2 c0[8], c1[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float4 t = *reinterpret_cast<const float4 *>(tile_r + (h * (N / 2) + r0 + RSTEP * k) * TZ + 2 * c4);
+                    c0[k] = make_float2(t.x, t.y);
+                    c1[k] = make_float2(t.z, t.w);
+                }
+                Dft<8, SIGN>::run(c0);
+                Dft<8, SIGN>::run(c1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float4 v = make_float4(c0[j].x, c0[j].y, c1[j].x, c1[j].y);
+                    if (a.out_scale != 1.0f) {
+                        v.x *= a.out_scale;
+                        v.y *= a.out_scale;
+                        v.z *= a.out_scale;
+                        v.w *= a.out_scale;
+                    }
+                    const int row = 2 * (r0 + RSTEP * j) + h;
+                    const unsigned roff = row_off(it, row < N / 2 ? row : row - N / 2);
+                    float2 *p = st_lo + (row < N / 2 ? 0 : st_half);
+                    *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
+                }
+            }
+            continue;
+        }
         if constexpr (F512) {
             // third stage (s = 64, no twiddles: inputs rows r0 + 64 k, outputs rows r0 + 64 j) on the
             // values read back for the store
@@ -1406,7 +1565,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             *reinterpret_cast<float4 *>(p + (roff + 2u * c4)) = v;
         }
       }
-        if (WEVAL && F512 && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
+        if (WEVAL && FUSED && w_reload(nxt.it, nxt.m)) issue_wloads(nxt.it, nxt.m);
     };
 
     if ((int)blockIdx.x < n_work) {
@@ -3356,10 +3515,10 @@ extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, f
     const int by_table = (env && env[0] == 't') ? 1 : 0;
     if (by_table || n_R < 1 || !wev_type_ok(filter_a) || (n_grids == 2 && !wev_type_ok(filter_b)))
         return 0;
-    // 1024-point lines keep the tables: with one register set already spilling, the evaluation costs
-    // more there than the table traffic it saves (5.07 against 4.84 ms per pass X at 1024^3)
-    static const int allow_1024 = getenv("C21CM_WINDOWS_1024") != nullptr;
-    if (nx < 128 || (nx & (nx - 1)) || nx > (allow_1024 ? 1024 : 512) ||
+    // (1024-point lines kept the tables until the fused first / last stages freed their registers:
+    // the evaluating kernel now spills 5 VGPRs, the table-streaming one 111 -- 3.9 against 4.65 ms per
+    // pass X at 1024^3, 417 against 461-484 ms per call; C21CM_WINDOWS=table keeps the tables)
+    if (nx < 128 || (nx & (nx - 1)) || nx > 1024 ||
         !c21hip_native_fft_supported(nx, ny, nz))
         return 0;
     WevSet &w = g_wev;
@@ -3440,7 +3599,7 @@ extern "C" int c21hip_wev_applicable(int filter_a, int filter_b, int n_grids, in
     if (env && env[0] == 't') return 0;
     if (!wev_type_ok(filter_a) || (n_grids == 2 && !wev_type_ok(filter_b))) return 0;
     if (n_grids == 2 && filter_a == 3 && filter_b == 3) return 0;
-    return nx >= 128 && !(nx & (nx - 1)) && nx <= 512 && c21hip_native_fft_supported(nx, ny, nz);
+    return nx >= 128 && !(nx & (nx - 1)) && nx <= 1024 && c21hip_native_fft_supported(nx, ny, nz);
 }
 // ONE grid, two radii per sweep, under a window of the prepared set (a or b: matched by type
 // and parameter); evaluated windows only
