@@ -474,6 +474,11 @@ int c21hip_apply_cross_keys(const unsigned long long *keys, const float *prev_z_
 int c21hip_pack_mask_bits(const unsigned char *fc, unsigned *bits, size_t ntot, void *stream);
 int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
                                unsigned char *fc, size_t ntot, void *stream);
+/* in-loop kernel timing (bench.py): HIP events around every pass launch on its stream while enabled;
+ * kinds as in c21hip_bench_pass (1 pass Y, 2 fused pass Z, 7 / 8 pass X / two-radius pass X with
+ * evaluated windows, 0 / 6 with streamed tables, 9 forward line passes) */
+void c21hip_ktime_enable(int on);
+int c21hip_ktime_report(int kind, double *ms_total, int *count);
 int c21hip_max_into(void *dst, const void *src, size_t count, int bytes_per_element, void *stream);
 /* sharded fused recombination loop: own slab (mask, g12; in place) against n_peers received slabs
  * of `stride` cells each -- larger first-crossing index wins, with its Gamma_12 */

@@ -2130,6 +2130,36 @@ LineGeo geo_y_nyq(int nx, int ny, int tz) {  // Nyquist plane: lines along y con
     return g;
 }
 
+// ---- in-loop kernel timing (bench.py): with c21hip_ktime_enable(1) every pass launch is bracketed
+// by two HIP events on ITS stream; c21hip_ktime_report sums them per kernel kind.  Kinds are those
+// of c21hip_bench_pass: 0 pass X with streamed tables, 1 pass Y, 2 fused pass Z, 6 two-radius pass X
+// with tables, 7 / 8 pass X / two-radius pass X with evaluated windows, 9 forward line passes.
+struct KTimeRec {
+    int kind;
+    hipEvent_t e0, e1;
+};
+std::vector<KTimeRec> g_ktime;
+int g_ktime_on = 0;
+struct KTimeScope {
+    KTimeRec r{-1, nullptr, nullptr};
+    hipStream_t stream;
+    KTimeScope(int kind, hipStream_t s) : stream(s) {
+        if (!g_ktime_on) return;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+        r.kind = kind;
+        (void)hipEventRecord(r.e0, stream);
+    }
+    ~KTimeScope() {
+        if (r.kind < 0) return;
+        (void)hipEventRecord(r.e1, stream);
+        g_ktime.push_back(r);
+    }
+};
+constexpr int ktime_kind(int sign, int fmode) {
+    return sign < 0 ? 9 : (fmode == 0 ? 1 : fmode == 3 ? 0 : fmode == 5 ? 6 : (fmode == 6 || fmode == 8) ? 7
+                                                              : (fmode == 7 || fmode == 9) ? 8 : 10);
+}
+
 template <int N, int SIGN, int FMODE>
 int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
     const float2 *tw = twiddles(N);
@@ -2158,6 +2188,7 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
+    KTimeScope kt(ktime_kind(SIGN, FMODE), stream);
     hipLaunchKernelGGL((line_pass_kernel<N, SIGN, FMODE>), dim3((unsigned)nblocks),
                        dim3(LineThreads<N, FMODE>::value), lds, stream, a, tw);
     LAUNCH_CHECK();
@@ -2835,6 +2866,7 @@ int launch_z_fused(const ZFusedArgs &a, long nlines, hipStream_t stream) {
 
 // *n_partials: how many workgroup partials of sum(stars) the launch wrote
 int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t stream, int *n_partials) {
+    KTimeScope kt(2, stream);
     *n_partials = (int)(nlines / LZ_FUSED);
     if (a.rc && (zw3_selected(nz, nlines) || !zw_lines_of(nz, nlines))) {
         c21hip_set_error("fused pass Z with recombinations needs the 16-lane wave kernel (z-lines of 256 / 512 points)");
@@ -3040,6 +3072,32 @@ extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz) {
 }
 // two radii per pass-X sweep need two line tiles in LDS
 extern "C" int c21hip_pair_sweep_supported(int nx) { return nx <= 512; }
+
+// in-loop kernel timing, see KTimeScope
+extern "C" void c21hip_ktime_enable(int on) {
+    for (auto &r : g_ktime) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_ktime.clear();
+    g_ktime_on = on ? 1 : 0;
+}
+// total device time (ms) and launch count of kind `kind` since c21hip_ktime_enable(1); synchronises
+extern "C" int c21hip_ktime_report(int kind, double *ms_total, int *count) {
+    double t = 0.;
+    int n = 0;
+    for (auto &r : g_ktime) {
+        if (r.kind != kind) continue;
+        if (hipEventSynchronize(r.e1) != hipSuccess) return C21CM_IO_ERROR;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return C21CM_IO_ERROR;
+        t += ms;
+        n++;
+    }
+    if (ms_total) *ms_total = t;
+    if (count) *count = n;
+    return 0;
+}
 
 extern "C" size_t c21hip_split_floats(int nx, int ny, int nz) {
     return 2 * ((size_t)nx * ny * (size_t)(nz / 2) + (size_t)nx * ny);
