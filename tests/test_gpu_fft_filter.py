@@ -131,3 +131,36 @@ def test_exported_test_filter_hook(gpu_lib, oracle, pkg):
     # undefined filter -> ValueError code 3 (reference Throw(ValueError), filtering.c:42-44)
     assert gpu_lib.test_filter(box.ctypes.data_as(C.c_void_p), 5.0, 0.0, 0.0, 7,
                                res.ctypes.data_as(C.c_void_p)) == 3
+
+
+def test_in_loop_kernel_timing_hook(gpu_lib):
+    """c21hip_ktime_enable / _report (bench.py's in-loop launch durations): events around every pass
+    launch while enabled, summed per kernel kind; off by default and cleared on enable."""
+    import ctypes as C
+
+    import torch
+
+    lib = gpu_lib
+    lib.c21hip_ktime_report.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.c21hip_bench_pass.restype = C.c_int
+    lib.c21hip_bench_pass.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms = C.c_float()
+
+    def count(kind):
+        tot, cnt = C.c_double(), C.c_int()
+        assert lib.c21hip_ktime_report(kind, C.byref(tot), C.byref(cnt)) == 0
+        return cnt.value, tot.value
+
+    lib.c21hip_ktime_enable(0)
+    assert lib.c21hip_bench_pass(1, 128, 0, 3, 5.0, 37.0, 192.0, 3, stream, C.byref(ms)) == 0
+    assert count(1)[0] == 0
+    lib.c21hip_ktime_enable(1)
+    assert lib.c21hip_bench_pass(1, 128, 0, 3, 5.0, 37.0, 192.0, 3, stream, C.byref(ms)) == 0
+    n, total = count(1)
+    assert n == 5 and total > 0  # two warm-up launches + three timed ones of pass Y
+    assert total / n == pytest.approx(ms.value, rel=0.5)
+    assert count(2)[0] == 0
+    lib.c21hip_ktime_enable(0)
+    assert count(1)[0] == 0
