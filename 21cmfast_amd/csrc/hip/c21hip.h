@@ -117,6 +117,14 @@ int c21hip_split_z_ionise_recomb(const float *delta_work, const float *stars_wor
 int c21hip_split_z_sfr_gamma12(const float *sfr_work, const unsigned char *first_cross, float *g12,
                                int nx, int ny, int nz, int r_index, double g12_scale, void *stream);
 int c21hip_z_ionise_recomb_supported(int nx, int ny, int nz);
+/* Eulerian source models with an x_e grid: pass Z of the filtered x_e spectrum with the barrier
+ * f_coll zeta > 1 - x_e(R) fused in (nion_dense: the radius' dense f_coll, *mean_dev its mean);
+ * first crossings go into the mask, x_e(R) is never stored (IonisationBox.c:1091-1118) */
+int c21hip_z_xe_mask_supported(int nx, int ny, int nz);
+int c21hip_split_z_xe_mask(const float *xe_work, const float *nion_dense, const double *mean_dev,
+                           unsigned char *first_cross, int nx, int ny, int nz, int r_index,
+                           double mean_f_coll, int fix_mean, int mass_dep_zeta, double f_limit,
+                           double ion_eff, void *stream);
 /* first-crossing mask + Gamma_12 grid of the fused recombination loop -> x_HI = 0, z_reion,
  * mean free path = R[index] (R_dev: float per radius index) */
 int c21hip_apply_first_cross_recomb(const unsigned char *first_cross, const float *R_dev,

@@ -1685,6 +1685,13 @@ struct ZPassArgs {
     // Gamma_12 = const_factor / (1 + delta_R) * max(v, 0)   (IonisationBox.c:1124-1140)
     const unsigned char *mask;
     int r_index;
+    // EPI 5 (Eulerian source models with an x_e grid): v = filtered x_e of the cell, f_out holds the
+    // radius' dense f_coll grid, *mean_dev its mean; the barrier of eulerian_mask_kernel
+    // (IonisationBox.c:1091-1118) goes straight into the first-crossing mask -- x_e(R) is never stored
+    unsigned char *mask_rw;
+    const double *mean_dev;
+    double mean_f_coll, f_limit, ion_eff;
+    int fix_mean, mass_dep_zeta;
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -2532,7 +2539,19 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             acc2 += (double)v.x;
             acc2 += (double)v.y;
         }
-        if (EPI == 4) {
+        if (EPI == 5) {
+            const double mean_fix = a.fix_mean ? a.mean_f_coll / *a.mean_dev : 1.;
+            const float2 f = reinterpret_cast<const float2 *>(a.f_out + lline * NZ)[j];
+            uchar2 m = reinterpret_cast<const uchar2 *>(a.mask_rw + lline * NZ)[j];
+            double c0 = mean_fix * (double)f.x, c1 = mean_fix * (double)f.y;
+            if (a.mass_dep_zeta && c0 < a.f_limit) c0 = a.f_limit;
+            if (a.mass_dep_zeta && c1 < a.f_limit) c1 = a.f_limit;
+            const double x0 = (double)fminf(fmaxf(v.x, 0.f), 0.999f), x1 = (double)fminf(fmaxf(v.y, 0.f), 0.999f);
+            const bool h0 = c0 * a.ion_eff > (1. - x0) && m.x == 0, h1 = c1 * a.ion_eff > (1. - x1) && m.y == 0;
+            if (h0) m.x = (unsigned char)a.r_index;
+            if (h1) m.y = (unsigned char)a.r_index;
+            if (h0 || h1) reinterpret_cast<uchar2 *>(a.mask_rw + lline * NZ)[j] = m;
+        } else if (EPI == 4) {
             const uchar2 m = reinterpret_cast<const uchar2 *>(a.mask + lline * NZ)[j];
             float *grow = a.out + lline * NZ + 2 * j;
             if (m.x == (unsigned char)a.r_index)
@@ -2554,7 +2573,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             }
         }
     }
-    if (EPI != 0 && EPI != 4) {
+    if (EPI != 0 && EPI != 4 && EPI != 5) {
         __shared__ double red0[kBlock / 64], red1[kBlock / 64], red2[kBlock / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -3984,6 +4003,49 @@ extern "C" int c21hip_split_z_sfr_gamma12(const float *sfr_work, const unsigned 
         hipLaunchKernelGGL((zw_c2r_kernel<16, 4, 8>), grid, dim3(kBlock), 0, (hipStream_t)stream, z, twH, twN);
     else
         hipLaunchKernelGGL((zw_c2r_kernel<16, 4, 16>), grid, dim3(kBlock), 0, (hipStream_t)stream, z, twH, twN);
+    LAUNCH_CHECK();
+    return 0;
+}
+// Pass Z of the filtered x_e grid of an Eulerian source model with the barrier of the radius fused
+// in (EPI 5): f_coll zeta > 1 - x_e(R) into the first-crossing mask; x_e(R) is not written.
+extern "C" int c21hip_z_xe_mask_supported(int nx, int ny, int nz) {
+    const long nlines = (long)nx * ny;
+    return zw_lines_of(nz, nlines) != 0 && !zw3_selected(nz, nlines) && (nz == 256 || nz == 512);
+}
+extern "C" int c21hip_split_z_xe_mask(const float *xe_work, const float *nion_dense, const double *mean_dev,
+                                      unsigned char *first_cross, int nx, int ny, int nz, int r_index,
+                                      double mean_f_coll, int fix_mean, int mass_dep_zeta, double f_limit,
+                                      double ion_eff, void *stream) {
+    if (!c21hip_z_xe_mask_supported(nx, ny, nz)) return C21CM_VALUE_ERROR;
+    const long nlines = (long)nx * ny;
+    const int zwl = zw_lines_of(nz, nlines);
+    const float2 *twH = twiddles(nz / 2);
+    const float2 *twN = twiddles(nz);
+    if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(xe_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out_zstride = nz;
+    z.out_scale = 1.0f;
+    z.f_out = const_cast<float *>(nion_dense);
+    z.mask_rw = first_cross;
+    z.mean_dev = mean_dev;
+    z.mean_f_coll = mean_f_coll;
+    z.fix_mean = fix_mean;
+    z.mass_dep_zeta = mass_dep_zeta;
+    z.f_limit = f_limit;
+    z.ion_eff = ion_eff;
+    z.r_index = r_index;
+    KTimeScope kt(11, (hipStream_t)stream);
+    const dim3 grid((unsigned)(nlines / zwl));
+    if (nz == 256)
+        hipLaunchKernelGGL((zw_c2r_kernel<16, 5, 8>), grid, dim3(kBlock), 0, (hipStream_t)stream, z, twH, twN);
+    else if (nz == 512)
+        hipLaunchKernelGGL((zw_c2r_kernel<16, 5, 16>), grid, dim3(kBlock), 0, (hipStream_t)stream, z, twH, twN);
+    else
+        return C21CM_VALUE_ERROR;
     LAUNCH_CHECK();
     return 0;
 }

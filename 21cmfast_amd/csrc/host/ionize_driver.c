@@ -1152,14 +1152,28 @@ done:
  * host waits for this radius' extrema and builds its table, so the GPU transforms while the
  * host integrates; stage B (f_coll sweep, mean, barrier into the mask) follows in radius
  * order.  Barrier results only depend on the radius order of stage B, which is unchanged. */
+/* x_e grids of a spin-temperature run: where the wave-level pass Z serves the line length, the x_e
+ * spectrum of a radius stays in k-space (two work buffers, one per pipeline stage) until the
+ * radius' f_coll mean is known, and its pass Z applies the barrier itself
+ * (c21hip_split_z_xe_mask): x_e(R) is never written or read back as a grid, and
+ * eulerian_mask_kernel is not launched (C21CM_XE_MASK_FUSED=0: the dense x_e(R) buffers). */
+static int eul_xe_fused(const ion_ctx *c) {
+    const char *e = getenv("C21CM_XE_MASK_FUSED");
+    return c->s->use_ts_fluct && !(e && e[0] == '0') && c->xe_work2 != NULL &&
+           c21hip_z_xe_mask_supported(c->nx, c->ny, c->nz);
+}
+
 static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *mm_host, void *ev) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     if (s->use_ts_fluct) { /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
+        const int fused = eul_xe_fused(c);
+        float *xe_work = (fused && buf) ? c->xe_work2 : c->xe_work;
         TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->xe_unf,
-                                    c->xe_work, s->hii_filter, 0.f, c->nx, c->ny, c->nz, s->box_len,
+                                    xe_work, s->hii_filter, 0.f, c->nx, c->ny, c->nz, s->box_len,
                                     s->box_len_z, (float)s->R[R_ct], 1, 0, 0, c->stream));
-        TRY(c21hip_split_z_c2r(c->xe_work, c->eul_xe[buf], c->nz, c->nx, c->ny, c->nz, c->stream));
+        if (!fused)
+            TRY(c21hip_split_z_c2r(c->xe_work, c->eul_xe[buf], c->nz, c->nx, c->ny, c->nz, c->stream));
     } else {
         TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
                                    s->box_len_z, s->hii_filter, (float)s->R[R_ct], 0.f, 1, c->stream));
@@ -1188,7 +1202,12 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
         status = C21CM_MEMORY_ALLOC_ERROR;
         goto done;
     }
-    if (s->use_ts_fluct) TRY(eul_xe_buffers(c));
+    if (s->use_ts_fluct) {
+        /* the second k-space buffer of the x_e grid (shared with the two-radius sweep's, idle here) */
+        if (!c->xe_work2)
+            c->xe_work2 = (float *)c21hip_ws(WS_XE_WORK2, c21hip_split_floats(c->nx, c->ny, c->nz) * sizeof(float));
+        if (!eul_xe_fused(c)) TRY(eul_xe_buffers(c));
+    }
     TRY(eul_stage_a(c, radii[0], 0, dfil[0], mm[0], ev[0]));
     for (int i = 0; i < n; i++) {
         const int b = i & 1, R_ct = radii[i];
@@ -1213,8 +1232,13 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
                                   table_dev, c->partials, sum_dev, c->stream));
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
-        TRY(c21hip_eulerian_mask(&args, c->nion_dense, s->use_ts_fluct ? c->eul_xe[b] : NULL, mean_dev,
-                                 mask, c->stream));
+        if (eul_xe_fused(c))
+            TRY(c21hip_split_z_xe_mask(b ? c->xe_work2 : c->xe_work, c->nion_dense, mean_dev, mask, c->nx,
+                                       c->ny, c->nz, R_ct, s->mean_f_coll, s->fix_mean, s->mass_dep_zeta,
+                                       s->f_limit_acg, s->ion_eff_factor, c->stream));
+        else
+            TRY(c21hip_eulerian_mask(&args, c->nion_dense, s->use_ts_fluct ? c->eul_xe[b] : NULL, mean_dev,
+                                     mask, c->stream));
     }
     /* the pinned staging buffer is shared: make sure the last copies have left it */
     TRY(c21hip_sync(c->stream));

@@ -670,3 +670,45 @@ def test_ionise_entire_sphere_shard_phases_equal_single_pass(api, n):
     assert rep.global_xH == rep2.global_xH
     ion = (buf.neutral_fraction == 0).float().mean().item()
     assert 0.03 < ion < 0.97 and (buf.z_reion > 0).sum() < (buf.neutral_fraction == 0).sum()
+
+
+def test_eulerian_table_model_with_xe_grid_fused_mask_pass(api, oracle, pkg, monkeypatch):
+    """Config 5's IonizedBox (Eulerian f_coll table + the x_e grid of a spin-temperature run) at a
+    size the wave-level pass Z serves: the x_e spectrum stays in k-space until the radius' f_coll
+    mean is known and its pass Z applies the barrier itself (c21hip_split_z_xe_mask, round 3) --
+    bit-identical to the path that stores x_e(R) and runs eulerian_mask_kernel
+    (C21CM_XE_MASK_FUSED=0), and equal to the oracle like the other table tests."""
+    import torch
+
+    S = pkg.structs
+    n = 256
+
+    def table_fn(r_index, dmin, dmax, table, user):
+        x = dmin + (dmax - dmin) / (S.NDELTA_TABLE - 1.0) * np.arange(S.NDELTA_TABLE)
+        y = np.log(0.02 * (1 + np.maximum(x, -0.999)) ** 1.5 / (1 + 0.05 * r_index))
+        for i in range(S.NDELTA_TABLE):
+            table[i] = y[i]
+        return 0
+
+    cb = S.TABLE_FN(table_fn)
+    spec = W.ionize_spec(n, mode=W.FCOLL_TABLE_EXP, r_bubble_max=20.0, use_ts_fluct=1)
+    spec.hii_filter = 0
+    spec.table_fn = cb
+    rng = np.random.default_rng(11)
+    density = W.density_field_numpy(n, seed=7)
+    xe = (0.3 * rng.random((n, n, n))).astype(np.float32)
+    Tn = (50 + 10 * rng.random((n, n, n))).astype(np.float32)
+    d, x, t = (torch.from_numpy(a).cuda() for a in (density, xe, Tn))
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("C21CM_XE_MASK_FUSED", fused)
+        buf, _, rep = api.ionize_grids(spec, d, None, xe=x, Tneutral=t)
+        torch.cuda.synchronize()
+        out[fused] = (buf.neutral_fraction.clone(), buf.z_reion.clone(), rep.global_xH)
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+    assert out["0"][2] == out["1"][2]
+    assert 0.01 < float((out["1"][0] == 0).float().mean()) < 0.99
+    ref = oracle.ionize_grids(spec, density, xe=xe, Tneutral=Tn, need_nion=True)
+    got = out["1"][0].cpu().numpy()
+    assert np.mean((got == 0) != (ref["neutral_fraction"] == 0)) <= 2e-4
+    assert out["1"][2] == pytest.approx(ref["report"].global_xH, abs=2e-4)
