@@ -72,6 +72,9 @@
 #ifndef C21X_ZW_BLOCK     // threads per workgroup of the fused pass Z on 512-point lines (64, 128, 256)
 #define C21X_ZW_BLOCK 256
 #endif
+#ifndef C21X_ZW_DPP       // 1: the mirror partner X[H-k] of the c2r pre-processing through DPP lane moves
+#define C21X_ZW_DPP 0     //    (16 lanes per line) instead of a round trip through LDS: 230 instead of 184
+#endif                    //    VGPRs, fused pass Z 0.304 ms in the loop either way (354 against 315 us alone)
 #ifndef C21X_ZW_LATE      // 1: second grid and mask rows requested after the first transform
 #define C21X_ZW_LATE 0
 #endif
@@ -2291,16 +2294,36 @@ __device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, co
                                          const float2 *twN, int b) {
     static_assert(A % P == 0, "rows per lane");
     constexpr int H = P * A;
+    // The mirror partner X[H - k] of k = P a + b lives in lane (P - b) % P, register A - 1 - a
+    // (b = 0: the own lane, register (A - a) % A).  With 16 lanes per line that lane permutation is
+    // row_mirror followed by row_ror:1 -- two DPP moves per register instead of an LDS write and
+    // read of the whole line (LDS bytes count like global bytes inside a CU: 8 -> 4 KB of LDS
+    // traffic per 2 KB line).
+    constexpr bool DPP = C21X_ZW_DPP && P == 16;
+    float2 part[DPP ? A : 1];
+    if constexpr (DPP) {
 #pragma unroll
-    for (int a = 0; a < A; a++) L[a * (P + 1) + b] = x[a];
-    wave_fence();
+        for (int a = 0; a < A; a++) {
+            const float2 src = x[A - 1 - a];
+            int px = __builtin_amdgcn_update_dpp(0, __float_as_int(src.x), 0x140, 0xf, 0xf, false);
+            int py = __builtin_amdgcn_update_dpp(0, __float_as_int(src.y), 0x140, 0xf, 0xf, false);
+            px = __builtin_amdgcn_update_dpp(0, px, 0x121, 0xf, 0xf, false);
+            py = __builtin_amdgcn_update_dpp(0, py, 0x121, 0xf, 0xf, false);
+            const float2 own = x[(A - a) % A];
+            part[a] = (b == 0) ? own : make_float2(__int_as_float(px), __int_as_float(py));
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < A; a++) L[a * (P + 1) + b] = x[a];
+        wave_fence();
+    }
     // Z[k] = E + i O, E = X[k] + conj(X[H-k]), O = (X[k] - conj(X[H-k])) exp(+2 pi i k / 2H)
 #pragma unroll
     for (int a = 0; a < A; a++) {
         const int k = P * a + b;
         const int kp = (H - k) & (H - 1);  // k = 0 pairs with the Nyquist value below
         const float2 Xk = x[a];
-        float2 B = L[(kp / P) * (P + 1) + (kp % P)];
+        float2 B = DPP ? part[DPP ? a : 0] : L[(kp / P) * (P + 1) + (kp % P)];
         if (k == 0) B = make_float2(xh, 0.f);
         const float2 E = make_float2(Xk.x + B.x, Xk.y - B.y);
         const float2 D = make_float2(Xk.x - B.x, Xk.y + B.y);
