@@ -52,10 +52,15 @@ def test_radix3_sizes_run_on_the_native_passes(gpu_lib):
         assert not gpu_lib.c21hip_fft_is_native(n, n, n)
 
 
-@pytest.mark.parametrize("shape", [(768, 64, 768), (1536, 64, 1536), (64, 1536, 192)])
+@pytest.mark.parametrize("shape", [(768, 64, 768), (1536, 64, 1536), (64, 1536, 192),
+                                   # 512- and 1024-point x / y lines: the passes whose first and last
+                                   # Stockham stages run on the registers (round 3), both directions,
+                                   # with short and long z-lines beside them
+                                   (512, 64, 128), (64, 512, 1024), (1024, 64, 64), (128, 1024, 256),
+                                   (512, 1024, 64)])
 def test_fft_768_and_1536_against_numpy(api, shape):
-    """Full 768- and 1536-point transforms along every axis (thin boxes) against numpy in double;
-    1536 = the reference's default DIM at HII_DIM = 512."""
+    """Full 512-, 768-, 1024- and 1536-point transforms along every axis (thin boxes) against numpy in
+    double; 1536 = the reference's default DIM at HII_DIM = 512."""
     import torch
 
     rng = np.random.default_rng(9)
