@@ -134,6 +134,8 @@ struct CicTileParams {
     int nb[3];       // bricks per axis
     int td[3];       // tile extent in output cells (incl. halo and the +1 CIC neighbour)
     int halo;
+    int zstride4;    // lanes four source cells apart along z (see the kernel)
+    int sb_shift[2]; // log2 of sb[1] * sb[2] and of sb[2] when both are powers of two, else -1
     // NV >= 2 (ComputeHaloBox, map_mass.c:214-344): per-cell values from NV ln-tables of
     // delta = density * growth; table_dev = [NV][C21CM_NDELTA_TABLE] floats (ln N_ion, ln SFRD
     // and, with USE_TS_FLUCT, ln X-ray emissivity)
@@ -172,10 +174,31 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
         for (int a = 0; a < 3; a++) t0[a] = (int)floor((double)s0[a] * p.dim_ratio_out) - q.halo;
         for (int c = threadIdx.x; c < NV * tcells; c += kBlock) tile[c] = 0.;
         __syncthreads();
-        for (int e = threadIdx.x; e < per_brick; e += kBlock) {
-            const int l0 = e / (q.sb[1] * q.sb[2]);
-            const int l1 = (e / q.sb[2]) % q.sb[1];
-            const int l2 = e % q.sb[2];
+        // C21CM_CIC_STRIDE=4 (experiment, off): lanes of one instruction take particles FOUR source
+        // cells apart along z (a thread walks its four neighbours one after the other), so that
+        // neighbouring particles -- which deposit into the same output cells -- are not in the same
+        // LDS atomic instruction.  Not faster: the atomics are not what bounds the kernel.
+        const int zs = (q.zstride4 && q.sb[2] % 4 == 0 && per_brick % (4 * kBlock) == 0) ? 4 : 1;
+        for (int e4 = threadIdx.x; e4 < per_brick; e4 += kBlock) {
+            // e4 = (group g, member j) with j slowest inside a sweep of the workgroup
+            const int sweep = e4 / kBlock;              // kBlock particles per sweep
+            const int j = sweep % zs;
+            const int g = (sweep / zs) * kBlock + (int)threadIdx.x;  // group index among per_brick / zs
+            const int e = (zs == 1) ? e4 : (g / (q.sb[2] / 4)) * q.sb[2] + (g % (q.sb[2] / 4)) * 4 + j;
+            if (e >= per_brick) continue;
+            // (the kernel is bound by its instruction count, not by the LDS atomics -- ds_add_f64 runs
+            // at 7 per clock and CU, tools/scratch/lds_atomic_rate.hip -- so the index arithmetic
+            // avoids runtime integer divisions where the brick is a power of two)
+            int l0, l1, l2;
+            if (q.sb_shift[0] >= 0) {
+                l0 = e >> q.sb_shift[0];
+                l1 = (e >> q.sb_shift[1]) & (q.sb[1] - 1);
+                l2 = e & (q.sb[2] - 1);
+            } else {
+                l0 = e / (q.sb[1] * q.sb[2]);
+                l1 = (e / q.sb[2]) % q.sb[1];
+                l2 = e % q.sb[2];
+            }
             const int src[3] = {s0[0] + l0, s0[1] + l1, s0[2] + l2};
             if (src[0] >= p.dens_dim[0] || src[1] >= p.dens_dim[1] || src[2] >= p.dens_dim[2])
                 continue;  // ragged last brick
@@ -184,7 +207,10 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
             int ip[3];
 #pragma unroll
             for (int a = 0; a < 3; a++)
-                ip[a] = wrap_idx((int)((double)src[a] * p.dim_ratio_vel + 0.5), p.vel_dim[a]);
+            {  // 0 <= src < dens_dim, so the rounded index is in [0, vel_dim]: one conditional wraps it
+                ip[a] = (int)((double)src[a] * p.dim_ratio_vel + 0.5);
+                if (ip[a] >= p.vel_dim[a]) ip[a] -= p.vel_dim[a];
+            }
             const size_t vi = (size_t)ip[2] +
                               (size_t)p.vel_dim[2] * ((size_t)ip[1] + (size_t)p.vel_dim[1] * ip[0]);
             const float v[3] = {vx[vi], vy[vi], vz[vi]};
@@ -460,6 +486,14 @@ namespace {
 bool tile_setup(const CicParams &p, int nv, CicTileParams &q, size_t *lds, int *blocks) {
     q.c = p;
     q.halo = 2;
+    {
+        static const int strided = [] {  // measured: 13.4 ms against 12.8 ms consecutive (DIM 1024 -> 512)
+            const char *e = getenv("C21CM_CIC_STRIDE");
+            return (e && e[0] == '4') ? 1 : 0;
+        }();
+        q.zstride4 = strided;
+    }
+    q.sb_shift[0] = q.sb_shift[1] = -1;
     const int ob[3] = {8, 8, 16};
     size_t tcells = 1;
     long n_bricks = 1;
@@ -471,6 +505,10 @@ bool tile_setup(const CicParams &p, int nv, CicTileParams &q, size_t *lds, int *
         q.td[a] = (int)ceil(q.sb[a] * p.dim_ratio_out) + 2 + 2 * q.halo;
         tcells *= (size_t)q.td[a];
         n_bricks *= q.nb[a];
+    }
+    if (!(q.sb[1] & (q.sb[1] - 1)) && !(q.sb[2] & (q.sb[2] - 1))) {
+        q.sb_shift[1] = __builtin_ctz(q.sb[2]);
+        q.sb_shift[0] = q.sb_shift[1] + __builtin_ctz(q.sb[1]);
     }
     *lds = tcells * sizeof(double) * nv + (nv >= 2 ? nv * C21CM_NDELTA_TABLE * sizeof(float) : 0);
     *blocks = (int)(n_bricks < 256 * 8 ? n_bricks : 256 * 8);
