@@ -309,6 +309,261 @@ cic_scatter_tiled_kernel(CicTileParams q, const float *__restrict__ dens,
     }
 }
 
+// ---- the deposit per VELOCITY cell (round 4) --------------------------------------------------
+// With DIM = F * HII_DIM the F^3 particles whose resample_index is velocity cell m -- sources
+// F m + lo + j, j < F, lo = -(F / 2): (int)(i / F + 0.5) == m, checked on the host for every i --
+// share ONE displacement.  A thread owns a velocity cell: three (six) velocity loads and one
+// displacement product per axis instead of F^3 of each, F positions / floors per axis instead of
+// F^3, the F^3 densities requested together, and lanes of one ds_add_f64 are neighbouring
+// velocity cells, whose targets are DIFFERENT tile cells (neighbouring particles, half an output
+// cell apart, collide on the same address).  Positions, floors and weights are the reference's
+// doubles (map_mass.c:23-33,180-196); the cell's 8 F^3 terms curr_dens * wx * wy * wz are summed
+// in registers onto the 27 tile cells they reach before they go to LDS, i.e. in another order and
+// grouping than the reference's atomics (which have no defined order either): 1e-16 relative on a
+// double grid that is rounded to float next.  Cells with a particle beyond the tile are queued
+// in LDS and leave through global atomics afterwards, so a wavefront with one far-flung lane no
+// longer drags all its lanes through the slow path.
+struct CicCellParams {
+    CicParams c;
+    int lo;           // first source offset of a velocity cell: src = F m + lo + j
+    int vb[3];        // brick in velocity cells (powers of two)
+    int vb_shift[2];  // log2(vb[1] * vb[2]), log2(vb[2])
+    int nb[3];        // bricks per axis
+    int td[3];        // tile extent in output cells
+    int halo, lead;   // lead = 1 when lo < 0: the brick's first particles sit in output cell m0 - 1
+};
+
+template <int F, bool LPT2, int DIAG>
+__global__ void __launch_bounds__(kBlock)
+cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__restrict__ vx,
+                const float *__restrict__ vy, const float *__restrict__ vz,
+                const float *__restrict__ v2x, const float *__restrict__ v2y,
+                const float *__restrict__ v2z, double *__restrict__ out) {
+    extern __shared__ double tile[];
+    __shared__ int nq;
+    const CicParams &p = q.c;
+    const int tcells = q.td[0] * q.td[1] * q.td[2];
+    const int per_brick = q.vb[0] * q.vb[1] * q.vb[2];
+    int *queue = reinterpret_cast<int *>(tile + tcells);  // per_brick entries
+    const size_t sy = (size_t)p.out_dim[2], sx = (size_t)p.out_dim[1] * p.out_dim[2];
+    const size_t d2 = (size_t)p.dens_dim[2], d1 = (size_t)p.dens_dim[1];
+    const int n_bricks = q.nb[0] * q.nb[1] * q.nb[2];
+    constexpr int F3 = F * F * F;
+    for (int brick = blockIdx.x; brick < n_bricks; brick += gridDim.x) {
+        const int b0 = brick / (q.nb[1] * q.nb[2]);
+        const int b1 = (brick / q.nb[2]) % q.nb[1];
+        const int b2 = brick % q.nb[2];
+        const int m0[3] = {b0 * q.vb[0], b1 * q.vb[1], b2 * q.vb[2]};
+        const int t0[3] = {m0[0] - q.lead - q.halo, m0[1] - q.lead - q.halo,
+                           m0[2] - q.lead - q.halo};
+        for (int c = threadIdx.x; c < tcells; c += kBlock) tile[c] = 0.;
+        if (threadIdx.x == 0) nq = 0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < per_brick; e += kBlock) {
+            const int m[3] = {m0[0] + (e >> q.vb_shift[0]),
+                              m0[1] + ((e >> q.vb_shift[1]) & (q.vb[1] - 1)),
+                              m0[2] + (e & (q.vb[2] - 1))};
+            if (m[0] >= p.vel_dim[0] || m[1] >= p.vel_dim[1] || m[2] >= p.vel_dim[2]) continue;
+            const size_t vi = (size_t)m[2] +
+                              (size_t)p.vel_dim[2] * ((size_t)m[1] + (size_t)p.vel_dim[1] * m[0]);
+            const float v[3] = {vx[vi], vy[vi], vz[vi]};
+            float v2[3] = {0.f, 0.f, 0.f};
+            if (LPT2) {
+                v2[0] = v2x[vi];
+                v2[1] = v2y[vi];
+                v2[2] = v2z[vi];
+            }
+            int sw[3][F];  // wrapped source index (m = 0 owns the last source planes)
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int j = 0; j < F; j++) {
+                    const int s = F * m[a] + q.lo + j;
+                    sw[a][j] = s < 0 ? s + p.dens_dim[a] : s;
+                }
+            float dn[F][F][F];
+#pragma unroll
+            for (int jx = 0; jx < F; jx++)
+#pragma unroll
+                for (int jy = 0; jy < F; jy++) {
+                    const size_t row = ((size_t)sw[0][jx] * d1 + (size_t)sw[1][jy]) * d2;
+#pragma unroll
+                    for (int jz = 0; jz < F; jz++) dn[jx][jy][jz] = dens[row + sw[2][jz]];
+                }
+            int rel[3][F];
+            double w1[3][F];
+            bool inside = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const double disp = (double)v[a] * p.vdf[a];
+                const double disp2 = LPT2 ? (double)v2[a] * p.vdf2[a] : 0.;
+#pragma unroll
+                for (int j = 0; j < F; j++) {
+                    double pos = (double)sw[a][j];  // map_mass.c:180-196
+                    pos += disp;
+                    if (LPT2) pos -= disp2;
+                    pos *= p.dim_ratio_out;
+                    const double fl = floor(pos);
+                    const int ip = (int)fl;
+                    w1[a][j] = pos - (double)ip;
+                    int r = ip - t0[a];
+                    if (r >= p.out_dim[a]) r -= p.out_dim[a];
+                    else if (r < 0) r += p.out_dim[a];
+                    rel[a][j] = r;
+                    inside = inside && r >= 0 && r + 1 < q.td[a] &&
+                             (unsigned)(r - rel[a][0]) <= 1u;
+                }
+            }
+            if (!inside) {
+                queue[atomicAdd(&nq, 1)] = e;
+                continue;
+            }
+            // The F particles of an axis are 1 / F output cells apart: rel[a][j] - rel[a][0] is 0 or
+            // 1 (part of `inside`), so the cell's 8 F^3 terms land in 3 x 3 x 3 tile cells.  Per
+            // axis a particle's weights become a 3-vector (w0, w1, 0) or (0, w0, w1), and the sums
+            // are formed z first, then y, then x: 27 LDS atomics per velocity cell instead of
+            // 8 F^3 (the atomics were 3.4 of the kernel's 5.9 ms at DIM = 1024).
+            double W[3][F][3];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int j = 0; j < F; j++) {
+                    const double wlo = 1. - w1[a][j], whi = w1[a][j];
+                    if (j == 0) {
+                        W[a][j][0] = wlo;
+                        W[a][j][1] = whi;
+                        W[a][j][2] = 0.;
+                    } else {
+                        const bool sh = rel[a][j] != rel[a][0];
+                        W[a][j][0] = sh ? 0. : wlo;
+                        W[a][j][1] = sh ? wlo : whi;
+                        W[a][j][2] = sh ? whi : 0.;
+                    }
+                }
+            double acc[3][3][3];
+#pragma unroll
+            for (int jx = 0; jx < F; jx++) {
+                double Y[3][3];
+#pragma unroll
+                for (int jy = 0; jy < F; jy++) {
+                    double Z[3];
+#pragma unroll
+                    for (int jz = 0; jz < F; jz++) {
+                        const double mass = 1.0 + (double)dn[jx][jy][jz] * p.init_growth;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            if (jz == 0) Z[c] = (c == 2) ? 0. : mass * W[2][0][c];
+                            else Z[c] = fma(mass, W[2][jz][c], Z[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 3; b++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            if (jy == 0) Y[b][c] = (b == 2) ? 0. : W[1][0][b] * Z[c];
+                            else Y[b][c] = fma(W[1][jy][b], Z[c], Y[b][c]);
+                        }
+                }
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            if (jx == 0) acc[a][b][c] = (a == 2) ? 0. : W[0][0][a] * Y[b][c];
+                            else acc[a][b][c] = fma(W[0][jx][a], Y[b][c], acc[a][b][c]);
+                        }
+            }
+            const int base = (rel[0][0] * q.td[1] + rel[1][0]) * q.td[2] + rel[2][0];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        if (F == 1 && (a == 2 || b == 2 || c == 2)) continue;
+                        const double term = acc[a][b][c];
+                        if (DIAG & 1) {  // diagnostic build only: no LDS atomics
+                            if (term == 1.2345e300) tile[0] = term;
+                        } else if (term != 0.) {  // a third of the 27 are empty: -0.35 ms of 3.7
+                            __hip_atomic_fetch_add(&tile[base + (a * q.td[1] + b) * q.td[2] + c], term,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+        }
+        __syncthreads();
+        // queued cells: one particle per thread through the global path
+        const int nqueued = nq;
+        for (int t = threadIdx.x; t < nqueued * F3; t += kBlock) {
+            const int e = queue[t / F3];
+            const int jj = t % F3;
+            const int j[3] = {jj / (F * F), (jj / F) % F, jj % F};
+            const int m[3] = {m0[0] + (e >> q.vb_shift[0]),
+                              m0[1] + ((e >> q.vb_shift[1]) & (q.vb[1] - 1)),
+                              m0[2] + (e & (q.vb[2] - 1))};
+            const size_t vi = (size_t)m[2] +
+                              (size_t)p.vel_dim[2] * ((size_t)m[1] + (size_t)p.vel_dim[1] * m[0]);
+            const float v[3] = {vx[vi], vy[vi], vz[vi]};
+            float v2[3] = {0.f, 0.f, 0.f};
+            if (LPT2) {
+                v2[0] = v2x[vi];
+                v2[1] = v2y[vi];
+                v2[2] = v2z[vi];
+            }
+            int s[3];
+            size_t bo[3][2];
+            double w[3][2];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                s[a] = F * m[a] + q.lo + j[a];
+                if (s[a] < 0) s[a] += p.dens_dim[a];
+                double pos = (double)s[a];
+                pos += (double)v[a] * p.vdf[a];
+                if (LPT2) pos -= (double)v2[a] * p.vdf2[a];
+                pos *= p.dim_ratio_out;
+                const double fl = floor(pos);
+                const int ip = (int)fl;
+                const double dist = pos - (double)ip;
+                w[a][0] = 1. - dist;
+                w[a][1] = dist;
+                const size_t stride = a == 0 ? sx : (a == 1 ? sy : (size_t)1);
+                bo[a][0] = (size_t)wrap_idx(ip, p.out_dim[a]) * stride;
+                bo[a][1] = (size_t)wrap_idx(ip + 1, p.out_dim[a]) * stride;
+            }
+            const double mass =
+                1.0 + (double)dens[((size_t)s[0] * d1 + (size_t)s[1]) * d2 + s[2]] * p.init_growth;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+                        unsafeAtomicAdd(out + bo[0][a] + bo[1][b] + bo[2][c],
+                                        mass * ((w[0][a] * w[1][b]) * w[2][c]));
+        }
+        // flush: rows of the tile are runs of td[2] cells along z
+        if (!(DIAG & 2)) {
+            const int rows = q.td[0] * q.td[1];
+            for (int c = threadIdx.x; c < tcells; c += kBlock) {
+                const double tv = tile[c];
+                if (tv != 0.) {
+                    const int row = c / q.td[2];
+                    const int c2 = c - row * q.td[2];
+                    const int c0 = row / q.td[1];
+                    const int c1 = row - c0 * q.td[1];
+                    int o0 = t0[0] + c0, o1 = t0[1] + c1, o2 = t0[2] + c2;
+                    if (o0 < 0) o0 += p.out_dim[0]; else if (o0 >= p.out_dim[0]) o0 -= p.out_dim[0];
+                    if (o1 < 0) o1 += p.out_dim[1]; else if (o1 >= p.out_dim[1]) o1 -= p.out_dim[1];
+                    if (o2 < 0) o2 += p.out_dim[2]; else if (o2 >= p.out_dim[2]) o2 -= p.out_dim[2];
+                    unsafeAtomicAdd(out + (size_t)o0 * sx + (size_t)o1 * sy + (size_t)o2, tv);
+                }
+            }
+            (void)rows;
+        }
+        __syncthreads();
+    }
+}
+
 // double grid -> padded float, then (optionally) *= mass_factor; -= 1
 __global__ void __launch_bounds__(kBlock)
 widen_normalise_kernel(const double *__restrict__ in, float *__restrict__ padded, size_t nlines,
@@ -583,6 +838,77 @@ extern "C" int c21hip_halobox_scatter(const float *src_density, const int dens_d
     return 0;
 }
 
+namespace {
+// geometry of the per-velocity-cell deposit; false when the grids do not have its structure
+// (DIM = F * velocity grid = F * output grid, F <= 4, every source's resample_index as assumed)
+bool cell_setup(const CicParams &p, CicCellParams &q, size_t *lds, int *blocks, int *f_out) {
+    const int f = p.dens_dim[0] / (p.vel_dim[0] > 0 ? p.vel_dim[0] : 1);
+    if (f < 1 || f > 4) return false;
+    q.c = p;
+    q.lo = -(f / 2);
+    q.lead = q.lo < 0 ? 1 : 0;
+    // 3 output cells of halo: at a displacement rms of 0.8 cells per axis (z ~ 7 on 1.5 Mpc cells)
+    // as fast as 2 (3.75 against 3.70 ms at DIM = 1024 -> 512), at 1.5 cells 5.0 against 12.9 ms
+    q.halo = 3;
+    if (const char *e = getenv("C21CM_CIC_HALO")) {  // experiment
+        const int h = atoi(e);
+        if (h >= 1 && h <= 8) q.halo = h;
+    }
+    int vb[3] = {8, 8, 16};
+    if (const char *e = getenv("C21CM_CIC_BRICK")) {  // experiment: "x,y,z" (powers of two)
+        int a, b, c;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0 && !(a & (a - 1)) &&
+            !(b & (b - 1)) && !(c & (c - 1))) {
+            vb[0] = a;
+            vb[1] = b;
+            vb[2] = c;
+        }
+    }
+    size_t tcells = 1;
+    long n_bricks = 1, per_brick = 1;
+    for (int a = 0; a < 3; a++) {
+        if (p.dens_dim[a] != f * p.vel_dim[a] || p.out_dim[a] != p.vel_dim[a]) return false;
+        for (int i = 0; i < p.dens_dim[a]; i++) {  // resample_index + wrap_coord, indexing.h:110-114
+            int ip = (int)((double)i * p.dim_ratio_vel + 0.5) % p.vel_dim[a];
+            if (ip != ((i - q.lo) / f) % p.vel_dim[a]) return false;
+        }
+        q.vb[a] = vb[a];
+        q.nb[a] = (p.vel_dim[a] + vb[a] - 1) / vb[a];
+        q.td[a] = vb[a] + q.lead + 1 + 2 * q.halo;
+        if (p.out_dim[a] < q.td[a]) return false;
+        tcells *= (size_t)q.td[a];
+        n_bricks *= q.nb[a];
+        per_brick *= vb[a];
+    }
+    q.vb_shift[1] = __builtin_ctz(vb[2]);
+    q.vb_shift[0] = q.vb_shift[1] + __builtin_ctz(vb[1]);
+    *lds = tcells * sizeof(double) + (size_t)per_brick * sizeof(int);
+    *blocks = (int)(n_bricks < 256 * 8 ? n_bricks : 256 * 8);
+    *f_out = f;
+    return *lds <= 96 * 1024;
+}
+
+template <int F, int DIAG>
+void launch_cell(const CicCellParams &q, size_t lds, int blocks, int lpt2, const float *dens,
+                 const float *const vel[3], const float *const vel2[3], double *out,
+                 hipStream_t stream) {
+    if (lpt2) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)cic_cell_kernel<F, true, DIAG>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipLaunchKernelGGL((cic_cell_kernel<F, true, DIAG>), dim3(blocks), dim3(kBlock), lds, stream,
+                           q, dens, vel[0], vel[1], vel[2], vel2[0], vel2[1], vel2[2], out);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)cic_cell_kernel<F, false, DIAG>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipLaunchKernelGGL((cic_cell_kernel<F, false, DIAG>), dim3(blocks), dim3(kBlock), lds,
+                           stream, q, dens, vel[0], vel[1], vel[2], (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, out);
+    }
+}
+}  // namespace
+
 extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3],
                                   const float *const vel[3], const float *const vel2[3],
                                   const int vel_dim[3], double *out, const int out_dim[3],
@@ -592,11 +918,38 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
     fill_cic_params(p, dens_dim, vel_dim, out_dim, box_len, box_len_z, growth, init_growth, lpt2);
     const size_t total = (size_t)dens_dim[0] * dens_dim[1] * dens_dim[2];
     {
-        // LDS-tiled deposit unless disabled (C21CM_CIC=direct) or the grids are tiny
-        static int direct = -1;
-        if (direct < 0) {
-            const char *e = getenv("C21CM_CIC");
-            direct = (e && e[0] == 'd') ? 1 : 0;
+        // C21CM_CIC = cell (default: per velocity cell, LDS tile) | tiled (per particle, LDS tile;
+        // rounds 1-3) | direct (global atomics); tiny grids take the direct kernel
+        const char *e = getenv("C21CM_CIC");
+        const int direct = (e && e[0] == 'd') ? 1 : 0;
+        const int tiled = (e && e[0] == 't') ? 1 : 0;
+        if (!direct && !tiled && total >= (size_t)1 << 15) {
+            CicCellParams q;
+            size_t lds;
+            int blocks, f;
+            if (cell_setup(p, q, &lds, &blocks, &f)) {
+#ifdef C21X_CIC_DIAG
+                const char *dg = getenv("C21CM_CIC_DIAG");
+                const int diag = dg ? atoi(dg) : 0;
+                if (f == 2 && diag == 1)
+                    launch_cell<2, 1>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                else if (f == 2 && diag == 2)
+                    launch_cell<2, 2>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                else if (f == 2 && diag == 3)
+                    launch_cell<2, 3>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                else
+#endif
+                if (f == 1)
+                    launch_cell<1, 0>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                else if (f == 2)
+                    launch_cell<2, 0>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                else if (f == 3)
+                    launch_cell<3, 0>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                else
+                    launch_cell<4, 0>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                LAUNCH_CHECK();
+                return 0;
+            }
         }
         if (!direct && total >= (size_t)1 << 15) {
             CicTileParams q;

@@ -148,3 +148,39 @@ def test_deposit_paths_large_displacements(api, oracle, vscale):
     got = api.perturb_grids(spec, ics)
     compare(got, ref)
     assert ref["density"].std() > 0
+
+
+@pytest.mark.parametrize("n,N,nz,hires", [(48, 96, 64, False), (32, 96, 32, False),
+                                          (32, 128, 48, False), (40, 40, 40, True)])
+def test_deposit_implementations_agree(api, n, N, nz, hires, monkeypatch):
+    """The three deposits -- per velocity cell with 27 merged LDS atomics (default; DIM / HII_DIM
+    = 1 ... 4), per particle into the LDS tile (rounds 1-3) and plain global atomics -- sum the same
+    doubles in different orders: the float densities agree to rounding, also on a non-cubic box,
+    with the first velocity plane's sources wrapping around the box and with a tail of particles
+    far beyond the tile halo."""
+    f = N // n
+    Nz = nz * f
+    rng = np.random.default_rng(n + N)
+    vshape = (N, N, Nz) if hires else (n, n, nz)
+    pre = "hires" if hires else "lowres"
+    ics = {}
+    for ax in "xyz":
+        v = 1.5 * rng.standard_normal(vshape)
+        v[rng.random(vshape) < 0.02] *= 8.0  # a few far-flung cells: the queued global path
+        ics[f"{pre}_v{ax}"] = v.astype(np.float32)
+        ics[f"{pre}_v{ax}_2LPT"] = (0.8 * rng.standard_normal(vshape)).astype(np.float32)
+    d = (2.0 * rng.standard_normal((N, N, Nz))).astype(np.float32)
+    ics["hires_density"] = d - d.mean()
+    spec = perturb_spec(2, dim=N, dim_z=Nz, hii_dim=n, hii_dim_z=nz, box_len=1.5 * n,
+                        box_len_z=1.5 * nz, growth_factor=0.12, init_growth_factor=0.0042,
+                        keep_3d_velocities=0, dDdt_over_D=2.1e-17,
+                        perturb_on_high_res=1 if hires else 0)
+    out = {}
+    for mode in ("cell", "tiled", "direct"):
+        monkeypatch.setenv("C21CM_CIC", mode)
+        out[mode] = api.perturb_grids(spec, ics)["density"]
+    scale = np.abs(out["direct"]).max()
+    assert out["direct"].std() > 0
+    for mode in ("cell", "tiled"):
+        np.testing.assert_allclose(out[mode], out["direct"], atol=3e-7 * scale, rtol=2e-6,
+                                   err_msg=mode)
