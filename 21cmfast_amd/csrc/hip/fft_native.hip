@@ -3605,6 +3605,32 @@ extern "C" int c21hip_window_tables(int table_slot, int filter_a, float R_param_
 // the caller can skip); 0: not applicable here (filter types other than top-hat / sharp-k /
 // exp-MFP, line lengths without the kernel, node tables that do not fit in LDS beside the tiles,
 // or C21CM_WINDOWS=table) and the table path stays.  c21hip_wev_release() ends the set.
+// The static half of that decision -- filter types, line lengths, the number of node tables a
+// launch stages and the LDS left for them beside the tiles -- shared by c21hip_wev_prepare and
+// c21hip_wev_applicable so that "applicable" can never promise what "prepare" then declines
+// (ADVICE r3).  *cap = nodes per table that fit; *worst = tables of the largest launch.
+static bool wev_static_ok(int filter_a, int filter_b, int n_grids, int nx, int ny, int nz, int pair,
+                          int *worst_out, int *cap_out) {
+    if (!wev_type_ok(filter_a) || (n_grids == 2 && !wev_type_ok(filter_b))) return false;
+    if (nx < 128 || (nx & (nx - 1)) || nx > 1024 || !c21hip_native_fft_supported(nx, ny, nz))
+        return false;
+    const int f1 = n_grids == 2 ? filter_b : filter_a;
+    const bool any_tophat = (filter_a == 0) || (n_grids == 2 && f1 == 0);
+    const int n_mfp_windows = (filter_a == 3 ? 1 : 0) + (n_grids == 2 && f1 == 3 ? 1 : 0);
+    // the largest launch: one top-hat table + one exp-MFP table per window and sweep member
+    const int worst = (any_tophat ? 1 : 0) + n_mfp_windows * (pair && nx <= 512 ? 2 : 1);
+    if (worst > 3 || n_mfp_windows > 1) return false;
+    // node tables as long as the LDS beside the tiles allows (the windows beyond their range are
+    // evaluated directly); at least x = 32
+    const size_t fixed = wev_lds(nx, pair && nx <= 512, 0, 0);
+    const size_t room = fixed < 158 * 1024 ? 158 * 1024 - fixed : 0;
+    const int cap = (int)(room / (sizeof(float) * 3 * (size_t)(worst > 0 ? worst : 1)));
+    if (cap < 32 * 4 + 3) return false;
+    if (worst_out) *worst_out = worst;
+    if (cap_out) *cap_out = cap;
+    return true;
+}
+
 extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, float R_param_b,
                                   int n_grids, const float *R, int n_R, int nx, int ny, int nz,
                                   double box_len, double box_len_z, int pair, int *enabled,
@@ -3613,13 +3639,11 @@ extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, f
     g_wev.active = false;
     const char *env = getenv("C21CM_WINDOWS");  // read per call: tests switch it
     const int by_table = (env && env[0] == 't') ? 1 : 0;
-    if (by_table || n_R < 1 || !wev_type_ok(filter_a) || (n_grids == 2 && !wev_type_ok(filter_b)))
-        return 0;
     // (1024-point lines kept the tables until the fused first / last stages freed their registers:
     // the evaluating kernel now spills 5 VGPRs, the table-streaming one 111 -- 3.9 against 4.65 ms per
     // pass X at 1024^3, 417 against 461-484 ms per call; C21CM_WINDOWS=table keeps the tables)
-    if (nx < 128 || (nx & (nx - 1)) || nx > 1024 ||
-        !c21hip_native_fft_supported(nx, ny, nz))
+    int worst = 0, cap = 0;
+    if (by_table || n_R < 1 || !wev_static_ok(filter_a, filter_b, n_grids, nx, ny, nz, pair, &worst, &cap))
         return 0;
     WevSet &w = g_wev;
     w.filter[0] = filter_a;
@@ -3638,15 +3662,7 @@ extern "C" int c21hip_wev_prepare(int filter_a, float R_param_a, int filter_b, f
     const int n_mfp_windows = (w.filter[0] == 3 ? 1 : 0) + (n_grids == 2 && w.filter[1] == 3 ? 1 : 0);
     w.first_type = any_tophat ? 0 : 3;
     w.n_tabs = (any_tophat ? 1 : 0) + n_mfp_windows * n_R;
-    // the largest launch: one top-hat table + one exp-MFP table per window and sweep member
-    const int worst = (any_tophat ? 1 : 0) + n_mfp_windows * (pair && nx <= 512 ? 2 : 1);
-    if (worst > 3 || n_mfp_windows > 1) return 0;
-    {   // node tables as long as the LDS beside the tiles allows (the windows beyond their range
-        // are evaluated directly); at least x = 32
-        const size_t fixed = wev_lds(nx, pair && nx <= 512, 0, 0);
-        const size_t room = fixed < 158 * 1024 ? 158 * 1024 - fixed : 0;
-        const int cap = (int)(room / (sizeof(float) * 3 * (size_t)(worst > 0 ? worst : 1)));
-        if (cap < 32 * 4 + 3) return 0;
+    {
         const int need = w.n_nodes;
         if (w.n_nodes > cap) w.n_nodes = cap;
         if (w.n_nodes > 4096) w.n_nodes = 4096;
@@ -3697,9 +3713,9 @@ extern "C" void c21hip_wev_release(void) { g_wev.active = false; }
 extern "C" int c21hip_wev_applicable(int filter_a, int filter_b, int n_grids, int nx, int ny, int nz) {
     const char *env = getenv("C21CM_WINDOWS");
     if (env && env[0] == 't') return 0;
-    if (!wev_type_ok(filter_a) || (n_grids == 2 && !wev_type_ok(filter_b))) return 0;
-    if (n_grids == 2 && filter_a == 3 && filter_b == 3) return 0;
-    return nx >= 128 && !(nx & (nx - 1)) && nx <= 1024 && c21hip_native_fft_supported(nx, ny, nz);
+    // with the two-radius sweep assumed (the larger LDS footprint): whatever this accepts,
+    // c21hip_wev_prepare accepts with pair = 0 or 1
+    return wev_static_ok(filter_a, filter_b, n_grids, nx, ny, nz, 1, nullptr, nullptr) ? 1 : 0;
 }
 // ONE grid, two radii per sweep, under a window of the prepared set (a or b: matched by type
 // and parameter); evaluated windows only

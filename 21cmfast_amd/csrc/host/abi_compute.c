@@ -566,9 +566,9 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         const char *e = getenv("C21CM_SHARD"), *b = getenv("C21CM_SHARD_BCAST");
         /* (a USE_MINI_HALOS run keeps one f_coll history slice per radius: every rank runs the
          * whole R loop) */
-        /* (C21CM_SHARD_TS=force: also on a one-rank communicator -- the plumbing test of a 1-GPU box) */
-    if (c21cm_shard_info(&srank, &sworld) == 0 && (sworld > 1 || (e && e[0] == 'f')) &&
-        !(e && e[0] == '0') && !mini)
+        /* (C21CM_SHARD=force: also on a one-rank communicator -- the plumbing test of a 1-GPU box) */
+        if (c21cm_shard_info(&srank, &sworld) == 0 && (sworld > 1 || (e && e[0] == 'f')) &&
+            !(e && e[0] == '0') && !mini)
             st = c21cm_ionize_sharded(s, perturbed_field, previous_ionize_box, spin_temp, halos,
                                       box, NULL, !(b && b[0] == '0'), NULL);
         else
@@ -735,12 +735,17 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
                  PerturbedField *perturbed_field, XraySourceBox *source_box,
                  TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp) {
     (void)cleanup;
-    /* one process per GPU with a communicator (c21cm_shard_init): shells dealt over the ranks,
-     * every rank returns the full boxes (C21CM_SHARD_TS=0 keeps the replicated computation) */
+    /* one process per GPU with an RCCL communicator (c21cm_shard_init): shells dealt over the
+     * ranks, every rank returns the full boxes (C21CM_SHARD_TS=0 keeps the replicated
+     * computation, which is also what an emulated transport gets: c21cm_ts_box_sharded needs real
+     * point-to-point transfers).  Whether THIS call can be sharded depends on the caller's arrays
+     * (device pointers), so the ranks agree on it before any of them takes the path. */
     int srank = 0, sworld = 1;
     const char *e = getenv("C21CM_SHARD_TS");
-    if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && !(e && e[0] == '0') &&
-        c21cm_ts_shardable(redshift, perturbed_field, previous_spin_temp, this_spin_temp))
+    if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && c21cm_shard_is_rccl() &&
+        !(e && e[0] == '0') &&
+        c21cm_shard_all_agree(
+            c21cm_ts_shardable(redshift, perturbed_field, previous_spin_temp, this_spin_temp)))
         return c21cm_ts_box_sharded(redshift, prev_redshift, perturbed_field_redshift,
                                     perturbed_field, previous_spin_temp, this_spin_temp);
     ts_shard_args all = {TS_RUN_ALL, 0, 1, NULL, 0, 0, 0};

@@ -588,7 +588,9 @@ static void sigma_reference_build(void) {
 
 /* EvaluateRGTable1D_f (interpolation.c:123-131) */
 static double reference_lookup(const float *y, double x) {
-    const int idx = (int)floor((x - rt.x_min) / rt.x_width);
+    int idx = (int)floor((x - rt.x_min) / rt.x_width);
+    if (idx > REF_SIG_N - 2) idx = REF_SIG_N - 2; /* the quotient can round up to N - 1 at the upper edge */
+    if (idx < 0) idx = 0;
     const double table_val = rt.x_min + rt.x_width * (float)idx;
     const double t = (x - table_val) / rt.x_width;
     return y[idx] * (1 - t) + y[idx + 1] * t;

