@@ -485,6 +485,17 @@ int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int wo
 /* in-loop kernel timing (bench.py): HIP events around every pass launch on its stream while enabled;
  * kinds as in c21hip_bench_pass (1 pass Y, 2 fused pass Z, 7 / 8 pass X / two-radius pass X with
  * evaluated windows, 0 / 6 with streamed tables, 9 forward line passes) */
+/* ---- plane_yz.hip: pass Y + fused pass Z of one radius in one persistent kernel, the x-plane between
+ * them handed over through the XCD's L2 (512^3, two Lagrangian grids).  The Nyquist planes of the work
+ * spectra take their y-transform separately (c21hip_split_y_nyq) BEFORE the fused launch. */
+int c21hip_plane_yz_supported(int nx, int ny, int nz);
+int c21hip_split_y_nyq(float *work_a, float *work_b, int nx, int ny, int nz, void *stream);
+int c21hip_plane_yz_ionise(const float *delta_work, const float *stars_work, unsigned char *first_cross,
+                           double *partials, int nx, int ny, int nz, int r_index, double rhocrit_omb,
+                           double ion_eff, int mass_dep_zeta, double f_limit, int store_all, void *stream);
+/* after a synchronisation: bit 0 = a launch ran write-through (workgroups off their XCD), bit 1 = a
+ * wait timed out (results invalid); < 0: the query failed.  Clears the flags. */
+int c21hip_plane_yz_status(void *stream);
 void c21hip_ktime_enable(int on);
 int c21hip_ktime_report(int kind, double *ms_total, int *count);
 int c21hip_max_into(void *dst, const void *src, size_t count, int bytes_per_element, void *stream);
