@@ -485,6 +485,15 @@ int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int wo
 /* in-loop kernel timing (bench.py): HIP events around every pass launch on its stream while enabled;
  * kinds as in c21hip_bench_pass (1 pass Y, 2 fused pass Z, 7 / 8 pass X / two-radius pass X with
  * evaluated windows, 0 / 6 with streamed tables, 9 forward line passes) */
+/* closed-form Eulerian loop: pass Z + f_coll of a radius with the barrier of the PREVIOUS radius of the
+ * loop (its dense grid, its mean, its index) applied in the same sweep */
+int c21hip_z_fcoll_erfc_mask_supported(int nx, int ny, int nz);
+int c21hip_split_z_fcoll_erfc_mask(const float *split_work, float *nion_dense, const float *nion_prev,
+                                   const double *mean_prev_dev, unsigned char *first_cross, int r_index_prev,
+                                   int fix_mean, double mean_f_coll, int mass_dep_zeta, double f_limit,
+                                   double ion_eff, int nx, int ny, int nz, double growthf, double sigma_min,
+                                   double sigma_max, double delta_c, double *partials, double *sum_out,
+                                   void *stream);
 /* ---- plane_yz.hip: pass Y + fused pass Z of one radius in one persistent kernel, the x-plane between
  * them handed over through the XCD's L2 (512^3, two Lagrangian grids).  The Nyquist planes of the work
  * spectra take their y-transform separately (c21hip_split_y_nyq) BEFORE the fused launch. */

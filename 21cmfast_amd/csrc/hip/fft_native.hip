@@ -1561,6 +1561,12 @@ struct ZPassArgs {
     const double *mean_dev;
     double mean_f_coll, f_limit, ion_eff;
     int fix_mean, mass_dep_zeta;
+    // EPI 6 (closed-form Eulerian loop): EPI 2 for THIS radius plus the barrier of the PREVIOUS radius
+    // of the loop -- its dense f_coll grid `f_prev`, its mean *mean_dev, its index r_index -- into
+    // mask_rw.  A radius' barrier needs the box mean of its f_coll grid (IonisationBox.c:1022-1027), i.e.
+    // a second sweep; riding the next radius' pass Z, which is bound by its butterflies and the erfc,
+    // that sweep's 6 N bytes cost no time of their own (eulerian_mask_kernel: 0.15 ms per radius).
+    const float *f_prev;
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -1696,7 +1702,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
-            acc0 = (EPI == 2) ? acc0 + o0 : fmin(acc0, o0);
+            acc0 = (EPI == 2 || EPI == 6) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
             if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
@@ -1710,7 +1716,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
-                r0 = (EPI == 2) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r0 = (EPI == 2 || EPI == 6) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
@@ -2330,6 +2336,16 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     for (int q = 0; q < A; q++) x[q] = src[P * q + b];
     const long lline = logical_line(line, a.ny, a.lb);
     const float xh = a.nyq[lline].x;
+    float2 fprev[EPI == 6 ? A : 1];
+    uchar2 mprev[EPI == 6 ? A : 1];
+    if constexpr (EPI == 6) {  // the previous radius' f_coll and the mask rows, in flight under the transform
+#pragma unroll
+        for (int q = 0; q < A; q++) {
+            const int j = (b + P * (q / P)) + A * (q % P);
+            fprev[q] = reinterpret_cast<const float2 *>(a.f_prev + lline * NZ)[j];
+            mprev[q] = reinterpret_cast<const uchar2 *>(a.mask_rw + lline * NZ)[j];
+        }
+    }
     __syncthreads();  // twiddle tables
     wave_c2r<A, P>(x, xh, L, twH, twN, b);
 
@@ -2377,12 +2393,24 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
                 grow[0] = (float)(a.const_factor / (1. + (double)grow[0]) * (double)fmaxf(v.x, 0.f));
             if (m.y == (unsigned char)a.r_index)
                 grow[1] = (float)(a.const_factor / (1. + (double)grow[1]) * (double)fmaxf(v.y, 0.f));
-        } else if (EPI == 2) {
+        } else if (EPI == 2 || EPI == 6) {
             const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
             const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
             acc0 += f0;
             acc0 += f1;
             reinterpret_cast<float2 *>(a.f_out + lline * NZ)[j] = make_float2((float)f0, (float)f1);
+            if constexpr (EPI == 6) {  // eulerian_mask_kernel's statements for the previous radius
+                const double mean_fix = a.fix_mean ? a.mean_f_coll / *a.mean_dev : 1.;
+                const float2 f = fprev[EPI == 6 ? q : 0];
+                uchar2 m = mprev[EPI == 6 ? q : 0];
+                double c0 = mean_fix * (double)f.x, c1 = mean_fix * (double)f.y;
+                if (a.mass_dep_zeta && c0 < a.f_limit) c0 = a.f_limit;
+                if (a.mass_dep_zeta && c1 < a.f_limit) c1 = a.f_limit;
+                const bool h0 = c0 * a.ion_eff > (1. - 0.) && m.x == 0, h1 = c1 * a.ion_eff > (1. - 0.) && m.y == 0;
+                if (h0) m.x = (unsigned char)a.r_index;
+                if (h1) m.y = (unsigned char)a.r_index;
+                if (h0 || h1) reinterpret_cast<uchar2 *>(a.mask_rw + lline * NZ)[j] = m;
+            }
         } else {
             reinterpret_cast<float2 *>(a.out + lline * a.out_zstride)[j] = v;
             if (EPI == 1 || EPI == 3) {
@@ -2397,7 +2425,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
-            acc0 = (EPI == 2) ? acc0 + o0 : fmin(acc0, o0);
+            acc0 = (EPI == 2 || EPI == 6) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
             if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
@@ -2411,7 +2439,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
-                r0 = (EPI == 2) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r0 = (EPI == 2 || EPI == 6) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
@@ -2848,6 +2876,10 @@ int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) 
         LAUNCH_CHECK();
         return 0;
     }
+    if constexpr (EPI == 6) {
+        c21hip_set_error("pass Z with the deferred barrier (EPI 6) needs the wave-level kernel");
+        return C21CM_VALUE_ERROR;
+    } else
     switch (nz) {
         case 64: return launch_z_c2r<64, EPI>(a, nlines, stream);
         case 128: return launch_z_c2r<128, EPI>(a, nlines, stream);
@@ -3743,6 +3775,59 @@ extern "C" int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_de
             z.sig = 1.0 / ((double)(float)growthf * (sqrt(2.) * sqrt((double)(ss * ss - sl * sl))));
     }
     int st = dispatch_z_c2r<2>(nz, z, nlines, (hipStream_t)stream);
+    if (st) return st;
+    return c21hip_reduce_sum(partials, (int)(nlines / LZ_PLAIN), sum_out, stream);
+}
+
+// 1: c21hip_split_z_fcoll_erfc_mask serves this box (z-lines on the 16-lane wave kernel)
+extern "C" int c21hip_z_fcoll_erfc_mask_supported(int nx, int ny, int nz) {
+    return (nz == 512 || nz == 1024) && zw_lines_of(nz, (long)nx * ny) != 0;
+}
+// c21hip_split_z_fcoll_erfc of THIS radius + the barrier of the previous radius of the loop
+// (eulerian_mask_kernel's test on `nion_prev` with its mean *mean_prev_dev, index r_index_prev) in the
+// same sweep.  nion_dense and nion_prev are different buffers.
+extern "C" int c21hip_split_z_fcoll_erfc_mask(const float *split_work, float *nion_dense,
+                                              const float *nion_prev, const double *mean_prev_dev,
+                                              unsigned char *first_cross, int r_index_prev, int fix_mean,
+                                              double mean_f_coll, int mass_dep_zeta, double f_limit,
+                                              double ion_eff, int nx, int ny, int nz, double growthf,
+                                              double sigma_min, double sigma_max, double delta_c,
+                                              double *partials, double *sum_out, void *stream) {
+    if (!c21hip_z_fcoll_erfc_mask_supported(nx, ny, nz) || nion_prev == nion_dense) {
+        c21hip_set_error("pass Z with the deferred barrier: unsupported box or aliased f_coll grids");
+        return C21CM_VALUE_ERROR;
+    }
+    const long nlines = (long)nx * ny;
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out_scale = 1.0f;
+    z.f_out = nion_dense;
+    z.f_prev = nion_prev;
+    z.mean_dev = mean_prev_dev;
+    z.mask_rw = first_cross;
+    z.r_index = r_index_prev;
+    z.fix_mean = fix_mean;
+    z.mean_f_coll = mean_f_coll;
+    z.mass_dep_zeta = mass_dep_zeta;
+    z.f_limit = f_limit;
+    z.ion_eff = ion_eff;
+    z.p0 = partials;
+    z.delta_c = delta_c;
+    z.sig = -1.;
+    {
+        const float ss = (float)sigma_min, sl = (float)sigma_max;  // hmf.c:1221-1232, as above
+        if (sl > ss) {
+            c21hip_set_error("FgtrM requested in a region where M_min > M_max (sigma %g > %g)",
+                             (double)sl, (double)ss);
+            return C21CM_VALUE_ERROR;
+        }
+        if (sl != ss)
+            z.sig = 1.0 / ((double)(float)growthf * (sqrt(2.) * sqrt((double)(ss * ss - sl * sl))));
+    }
+    int st = dispatch_z_c2r<6>(nz, z, nlines, (hipStream_t)stream);
     if (st) return st;
     return c21hip_reduce_sum(partials, (int)(nlines / LZ_PLAIN), sum_out, stream);
 }

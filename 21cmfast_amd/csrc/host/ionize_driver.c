@@ -95,7 +95,8 @@ enum {
     WS_MINI_OUT_M,
     WS_SPHERE_RSQ = 216,
     WS_SFR_WORK2 = 246, /* fused recombination loop: whalo_sfr of the second radius of a sweep */
-    WS_R_DEV = 247      /* float R per radius index (mean free path of a first crossing) */
+    WS_R_DEV = 247,     /* float R per radius index (mean free path of a first crossing) */
+    WS_NION_DENSE2 = 254 /* closed-form Eulerian loop: second dense f_coll buffer (deferred barrier) */
 };
 
 #define MAX_COPYBACK 12
@@ -330,6 +331,10 @@ typedef struct {
     int tab_seq;         /* fused radii done so far: the window-table buffer alternates */
     int wev;             /* 1: this loop's passes X evaluate their windows in the kernel */
     int fused_rc;        /* fused loop with a recombination model (CELL_RECOMB, no x_e grid) */
+    /* closed-form Eulerian loop: the barrier of a radius rides the NEXT radius' pass Z (EPI 6) */
+    int eul_pend, eul_pend_buf;      /* radius index whose barrier is still owed (-1: none), its f_coll buffer */
+    unsigned char *eul_pend_mask;
+    float *nion_dense2;
     int yz;              /* pass Y + fused pass Z as ONE plane-fused kernel (plane_yz.hip: 512^3, two grids) */
     int yz_now;          /* ... for the radius z_ionise_radius is called for (its main blocks skipped pass Y) */
     int yz_used;         /* a plane-fused launch happened in this call: its status is checked at the end */
@@ -426,6 +431,10 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     /* Plane-fused pass Y + Z (round 4): the two-grid loop without a third spectrum at 512^3 */
     c->yz = c->fused && !c->fused_rc && !s->use_ts_fluct && c21hip_plane_yz_supported(c->nx, c->ny, c->nz);
     c->yz_now = c->yz_used = 0;
+    c->eul_pend = -1;
+    c->eul_pend_buf = 0;
+    c->eul_pend_mask = NULL;
+    c->nion_dense2 = NULL;
     c->sphere = s->ionise_entire_sphere;
     c->mini = s->use_mini_halos && !c->lagrangian;
     c->lag_mini = s->use_mini_halos && c->lagrangian;
@@ -697,8 +706,28 @@ done:
     return status;
 }
 
+/* The barrier the closed-form Eulerian loop still owes (its last radius had no successor to ride on). */
+static int eul_flush_pending(ion_ctx *c, int last) {
+    if (c->eul_pend < 0) return 0;
+    c21hip_ionize_args args;
+    fill_args(&args, c->s, c->eul_pend);
+    const int R = c->eul_pend;
+    c->eul_pend = -1;
+    int st = c21hip_eulerian_mask(&args, c->eul_pend_buf ? c->nion_dense2 : c->nion_dense, NULL,
+                                  c->scalars + SC_MEANS + R, c->eul_pend_mask, c->stream);
+    /* `last`: no further radius writes the f_coll grid, and box->unnormalised_nion is that of the
+     * last radius processed (IonisationBox.c:773-962 overwrite it per radius) */
+    if (!st && last && c->eul_pend_buf)
+        st = c21hip_d2d(c->nion_dense, c->nion_dense2, c->ntot * sizeof(float), c->stream);
+    return st;
+}
+
 /* The f_coll sums and means of the fused radii processed so far, in one launch. */
 static int flush_deferred(ion_ctx *c) {
+    {
+        const int st_e = eul_flush_pending(c, 1);
+        if (st_e) return st_e;
+    }
     if (!c->def_partials || c->def_count == 0) return 0;
     const c21cm_ionize_spec *s = c->s;
     int st = c21hip_batched_means(c->def_partials, c->def_stride, (int)c->def_stride, c->def_first,
@@ -1027,6 +1056,19 @@ done:
     return status;
 }
 
+/* C21CM_EUL_DEFER=1: the barrier of a radius rides the next radius' pass Z (EPI 6) instead of its own
+ * sweep (eulerian_mask_kernel).  OFF by default: bit-identical, but measured slower -- 44.3 against
+ * 42.6 ms per 512^3 x 40-radii call; the extra 6 N bytes and 48 registers cost the pass Z (336 us,
+ * not purely instruction-bound after all) more than the 153 us sweep they replace. */
+static int eul_defer_ok(ion_ctx *c) {
+    const char *e = getenv("C21CM_EUL_DEFER");
+    if (!(e && e[0] == '1')) return 0;
+    if (!c21hip_z_fcoll_erfc_mask_supported(c->nx, c->ny, c->nz)) return 0;
+    if (!c->nion_dense2)
+        c->nion_dense2 = (float *)c21hip_ws(WS_NION_DENSE2, c->ntot * sizeof(float));
+    return c->nion_dense2 != NULL;
+}
+
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -1053,6 +1095,34 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
         } else {
             TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
                                        s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+        }
+        if (s->fcoll_mode == C21CM_FCOLL_ERFC && !s->use_ts_fluct && eul_defer_ok(c)) {
+            /* f_coll of this radius into one of two dense buffers; the barrier of the radius before
+             * it (whose mean is known by now) in the same sweep; this radius' barrier follows with
+             * the next radius, or with eul_flush_pending() when the mask is needed */
+            const int cur = c->eul_pend >= 0 ? (c->eul_pend_buf ^ 1) : 0;
+            float *nion_cur = cur ? c->nion_dense2 : c->nion_dense;
+            if (c->eul_pend >= 0 && c->eul_pend_mask == first_cross) {
+                TRY(c21hip_split_z_fcoll_erfc_mask(
+                    c->delta_work, nion_cur, c->eul_pend_buf ? c->nion_dense2 : c->nion_dense,
+                    c->scalars + SC_MEANS + c->eul_pend, first_cross, c->eul_pend, s->fix_mean,
+                    s->mean_f_coll, s->mass_dep_zeta, s->f_limit_acg, s->ion_eff_factor, c->nx, c->ny,
+                    c->nz, s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct], s->delta_c,
+                    partials, sum_dev, c->stream));
+                c->eul_pend = -1;
+            } else {
+                TRY(eul_flush_pending(c, 0));
+                TRY(c21hip_split_z_fcoll_erfc(c->delta_work, nion_cur, c->nx, c->ny, c->nz,
+                                              s->growth_factor, s->sigma_minmass,
+                                              s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev,
+                                              c->stream));
+            }
+            TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                                   mean_dev, c->stream));
+            c->eul_pend = R_ct;
+            c->eul_pend_buf = cur;
+            c->eul_pend_mask = first_cross;
+            goto done;
         }
         if (s->fcoll_mode == C21CM_FCOLL_ERFC) {
             TRY(c21hip_split_z_fcoll_erfc(c->delta_work, c->nion_dense, c->nx, c->ny, c->nz,
@@ -1510,6 +1580,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
                 mask_pending = 0;
+                TRY(eul_flush_pending(&c, 0)); /* the last radius' barrier of the closed-form loop */
                 if (c.fused && !c.sphere && !c.fused_rc) {
                     TRY(flush_deferred(&c));
                     TRY(final_step(&c, c.mask, 0));

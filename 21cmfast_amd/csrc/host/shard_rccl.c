@@ -105,7 +105,7 @@ static struct {
 } R;
 
 enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142, WS_SHARD_BITS = 143,
-       WS_SHARD_STATUS = 247 };
+       WS_SHARD_STATUS = 253 };
 
 static int rccl_check(int rc, const char *what);
 

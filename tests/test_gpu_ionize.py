@@ -777,3 +777,40 @@ def test_plane_fused_pass_yz_equals_separate_passes(api, gpu_lib, monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction)
     assert rep0.global_xH == rep2.global_xH
+
+
+@pytest.mark.parametrize("r_lowest", [0, 2])
+def test_closed_form_loop_deferred_barrier_equals_separate_sweep(api, r_lowest, monkeypatch):
+    """CONST-ION-EFF closed form on the wave-level pass Z: the barrier of a radius (which needs the box
+    mean of its f_coll grid) rides the NEXT radius' pass Z on a second dense buffer instead of its own
+    sweep.  Same statements on the same floats: every output -- the f_coll grid of the last radius
+    included, whichever buffer it was computed in -- equals the separate-sweep sequence
+    (the default; C21CM_EUL_DEFER=1 selects the deferred form) bit for bit, single pass and sharded over 2 ranks."""
+    import torch
+
+    n, nz = 64, 512
+    spec = W.ionize_spec(n, hii_dim_z=nz, mode=W.FCOLL_ERFC, r_bubble_max=9.0)
+    spec.r_lowest = r_lowest
+    density = torch.from_numpy(W.density_field_numpy((n, n, nz), seed=21)).cuda()
+    buf0, _, rep0 = api.ionize_grids(spec, density)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("C21CM_EUL_DEFER", "1")  # opt-in: measured slower than the separate sweep
+    buf1, _, rep1 = api.ionize_grids(spec, density)
+    torch.cuda.synchronize()
+    assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
+    for name in ("neutral_fraction", "z_reion", "kinetic_temperature", "unnormalised_nion"):
+        assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
+    k = spec.n_radii
+    assert list(rep0.f_coll_grid_mean[:k]) == list(rep1.f_coll_grid_mean[:k])
+    assert rep0.global_xH == rep1.global_xH
+    if r_lowest == 0:
+        world, masks = 2, []
+        for rank in range(world):
+            fc = torch.zeros((n, n, nz), dtype=torch.uint8, device="cuda")
+            api.ionize_shard_radii(spec, rank, world, fc, density)
+            masks.append(fc)
+        reduced = torch.maximum(masks[0], masks[1]).contiguous()
+        buf2, _, rep2 = api.ionize_shard_finish(spec, reduced, density)
+        torch.cuda.synchronize()
+        assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction)
+        assert rep0.global_xH == rep2.global_xH
