@@ -12,6 +12,7 @@
 #include <cmath>
 
 #include "c21hip.h"
+#include "split_layout.h"
 #include "c21cm_abi.h"
 #include "ms_window.h"
 
@@ -152,6 +153,7 @@ __device__ __forceinline__ double w_shell(double k, double R_inner, double R_out
 struct FilterParams {
     int nx, ny, nzc;
     int nz0;  // k_z index of column 0 (non-zero for the Nyquist plane of the split layout)
+    int lb;   // x-blocked main block of a split spectrum (split_layout.h); 0: lines are x * ny + y
     int type;
     float R, R_param;
     double dkx, dky, dkz;
@@ -195,8 +197,9 @@ copy_filter_kernel(const float2 *src, float2 *dst, FilterParams p) {  // src may
          i += (size_t)gridDim.x * kBlock) {
         float2 v = src[i];
         if (APPLY) {
-            const size_t line = i / (size_t)p.nzc;
-            const int n_z = (int)(i - line * (size_t)p.nzc);
+            const size_t mline = i / (size_t)p.nzc;
+            const int n_z = (int)(i - mline * (size_t)p.nzc);
+            const size_t line = (size_t)c21_logical_line((long)mline, p.ny, p.lb);
             const int n_x = (int)(line / (size_t)p.ny);
             const int n_y = (int)(line - (size_t)n_x * p.ny);
             const float k_x = k_of(n_x, p.nx, p.dkx);
@@ -360,15 +363,20 @@ extern "C" int c21hip_widen(const float *in, double *out, size_t n, void *stream
 
 static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, int nzc, int nz0,
                             double box_len, double box_len_z, int filter_type, float R,
-                            float R_param, int apply, void *stream, float R_star = 0.f);
+                            float R_param, int apply, void *stream, float R_star = 0.f, int lb = 0);
 
-// filter_box on a spectrum in the plain split layout (main block [nx][ny][nz/2] + Nyquist plane)
+// filter_box on a spectrum in the split layout (main block [nx][ny][nz/2], x-blocked where
+// fft_native.hip blocks it, + Nyquist plane)
 extern "C" int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny,
                                         int nz, double box_len, double box_len_z, int filter_type,
                                         float R, float R_param, int apply, void *stream) {
     const size_t n_main = 2 * (size_t)nx * ny * (nz / 2);
+    if (filter_type == 5 && c21hip_split_xblock_log2(nx)) {
+        c21hip_set_error("copy_filter_split: the multiple-scattering window is not built for x-blocked spectra");
+        return C21CM_VALUE_ERROR;
+    }
     int st = copy_filter_impl(src_split, dst_split, nx, ny, nz / 2, 0, box_len, box_len_z,
-                              filter_type, R, R_param, apply, stream);
+                              filter_type, R, R_param, apply, stream, 0.f, c21hip_split_xblock_log2(nx));
     if (st) return st;
     return copy_filter_impl(src_split + n_main, dst_split + n_main, nx, ny, 1, nz / 2, box_len,
                             box_len_z, filter_type, R, R_param, apply, stream);
@@ -391,12 +399,13 @@ extern "C" int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int 
 
 static int copy_filter_impl(const float *src_c, float *dst_c, int nx, int ny, int nzc, int nz0,
                             double box_len, double box_len_z, int filter_type, float R,
-                            float R_param, int apply, void *stream, float R_star) {
+                            float R_param, int apply, void *stream, float R_star, int lb) {
     if (apply && (filter_type < 0 || filter_type > 5)) {
         c21hip_set_error("filter type %d is not implemented on the device", filter_type);
         return C21CM_VALUE_ERROR;
     }
     FilterParams p;
+    p.lb = lb;
     p.nx = nx;
     p.ny = ny;
     p.nzc = nzc;

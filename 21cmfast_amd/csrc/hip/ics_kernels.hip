@@ -23,6 +23,7 @@
 
 #include "c21hip.h"
 #include "c21cm_abi.h"
+#include "split_layout.h"
 
 namespace {
 constexpr int kBlock = 256;
@@ -263,15 +264,16 @@ __device__ __forceinline__ void kop_factor(int n_x, int n_y, int n_z, int nx, in
 __global__ void __launch_bounds__(kBlock)
 split_kop_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_nyq,
                  float2 *__restrict__ out_main, float2 *__restrict__ out_nyq, int nx, int ny,
-                 int nz, double len_x, double len_y, double len_z, int axis0, int axis1) {
+                 int nz, double len_x, double len_y, double len_z, int axis0, int axis1, int lb) {
     const int H = nz / 2;
     const size_t n_main = (size_t)nx * ny * H, total = n_main + (size_t)nx * ny;
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
          t += (size_t)gridDim.x * kBlock) {
         const bool is_main = t < n_main;
-        const size_t line = is_main ? t / (size_t)H : t - n_main;
+        const size_t line = is_main ? t / (size_t)H : t - n_main;  // memory line (main) | logical (Nyquist)
         const int n_z = is_main ? (int)(t - line * (size_t)H) : H;
-        const int n_x = (int)(line / (size_t)ny), n_y = (int)(line - (size_t)n_x * ny);
+        const size_t ll = is_main ? (size_t)c21_logical_line((long)line, ny, lb) : line;
+        const int n_x = (int)(ll / (size_t)ny), n_y = (int)(ll - (size_t)n_x * ny);
         const float2 v = is_main ? in_main[t] : in_nyq[line];
         double fr, fi;
         kop_factor(n_x, n_y, n_z, nx, ny, nz, len_x, len_y, len_z, axis0, axis1, &fr, &fi);
@@ -296,7 +298,8 @@ split_kop_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ 
 __global__ void __launch_bounds__(kBlock)
 fold_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_nyq,
             float2 *__restrict__ out_main, float2 *__restrict__ out_nyq, int nx, int ny, int nz,
-            int f, double len_x, double len_y, double len_z, int axis0, int axis1) {
+            int f, double len_x, double len_y, double len_z, int axis0, int axis1, int lb_in,
+            int lb_out) {
     const int H = nz / 2, mx = nx / f, my = ny / f, mz = nz / f, Hl = mz / 2;
     const size_t total = (size_t)mx * my * (Hl + 1);
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
@@ -316,7 +319,8 @@ fold_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_ny
                         sz = nz - sz;
                     }
                     const size_t sl = (size_t)sx * ny + sy;
-                    const float2 v = (sz == H) ? in_nyq[sl] : in_main[sl * (size_t)H + sz];
+                    const float2 v = (sz == H) ? in_nyq[sl]
+                                               : in_main[(size_t)c21_memory_line((long)sl, ny, lb_in) * (size_t)H + sz];
                     double fr, fi;
                     kop_factor(sx, sy, sz, nx, ny, nz, len_x, len_y, len_z, axis0, axis1, &fr, &fi);
                     const double pr = (double)v.x * fr - (double)v.y * fi;
@@ -328,7 +332,7 @@ fold_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_ny
         if (qz == Hl)
             out_nyq[line] = o;
         else
-            out_main[line * (size_t)Hl + qz] = o;
+            out_main[(size_t)c21_memory_line((long)line, my, lb_out) * (size_t)Hl + qz] = o;
     }
 }
 
@@ -466,7 +470,7 @@ extern "C" int c21hip_lpt2_accumulate(float *box, const float *phi_ij_padded, co
     return 0;
 }
 
-// ---- split-layout pipeline entry points (plain split layout: nx <= 512)
+// ---- split-layout pipeline entry points (plain layout, or x-blocked where fft_native.hip blocks: nx >= 1024)
 extern "C" int c21hip_split_kop(const float *in_split, float *out_split, int nx, int ny, int nz,
                                 double box_len, double box_len_z, int axis0, int axis1,
                                 void *stream) {
@@ -475,7 +479,7 @@ extern "C" int c21hip_split_kop(const float *in_split, float *out_split, int nx,
     float2 *om = reinterpret_cast<float2 *>(out_split);
     hipLaunchKernelGGL(split_kop_kernel, dim3(grid_for(n_main + (size_t)nx * ny)), dim3(kBlock), 0,
                        (hipStream_t)stream, im, im + n_main, om, om + n_main, nx, ny, nz, box_len,
-                       box_len, box_len_z, axis0, axis1);
+                       box_len, box_len_z, axis0, axis1, c21hip_split_xblock_log2(nx));
     LAUNCH_CHECK();
     return 0;
 }
@@ -496,7 +500,8 @@ extern "C" int c21hip_split_fold(const float *hi_split, float *lo_split, int nx,
     float2 *om = reinterpret_cast<float2 *>(lo_split);
     hipLaunchKernelGGL(fold_kernel, dim3(grid_for((size_t)mx * my * (mz / 2 + 1))), dim3(kBlock), 0,
                        (hipStream_t)stream, im, im + n_main, om, om + l_main, nx, ny, nz, f,
-                       box_len, box_len, box_len_z, axis0, axis1);
+                       box_len, box_len, box_len_z, axis0, axis1, c21hip_split_xblock_log2(nx),
+                       c21hip_split_xblock_log2(mx));
     LAUNCH_CHECK();
     return 0;
 }

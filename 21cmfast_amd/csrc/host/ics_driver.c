@@ -181,13 +181,14 @@ static int ics_split_supported(const c21cm_ics_spec *s) {
     const char *e = getenv("C21CM_ICS");
     if (e && e[0] == 'p') return 0; /* C21CM_ICS=padded */
     if (s->vcb_by_m) return 0; /* relative velocities work on the padded spectrum (rare option) */
-    if (!c21hip_fft_is_native(s->dim, s->dim, s->dim_z) || c21hip_split_xblock_log2(s->dim)) return 0;
+    /* (DIM >= 1024: the main blocks are x-blocked; the element-wise kernels of this pipeline map
+     * memory lines to wavenumbers through split_layout.h -- round 4, DIM = 1536 / HII_DIM = 512) */
+    if (!c21hip_fft_is_native(s->dim, s->dim, s->dim_z)) return 0;
     if (s->dim == s->hii_dim && s->dim_z == s->hii_dim_z) return 1;
     if (s->perturb_on_high_res && s->dim % s->hii_dim) return 0;
     const int f = s->dim / s->hii_dim;
     if ((f != 2 && f != 3 && f != 4) || s->hii_dim * f != s->dim || s->hii_dim_z * f != s->dim_z) return 0;
-    return c21hip_fft_is_native(s->hii_dim, s->hii_dim, s->hii_dim_z) &&
-           !c21hip_split_xblock_log2(s->hii_dim);
+    return c21hip_fft_is_native(s->hii_dim, s->hii_dim, s->hii_dim_z);
 }
 
 static int ics_grids_split(const c21cm_ics_spec *s, InitialConditions *ics, float *const vel[3],

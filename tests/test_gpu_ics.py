@@ -202,3 +202,38 @@ def test_relative_velocities_through_the_entry_point(gpu_lib, api, oracle, tmp_p
     ics["hires_density"][...] = 0
     assert lib.ComputeInitialConditions(2026, C.byref(api.ics_struct(ics))) == 3
     del ses
+
+
+@pytest.mark.parametrize("dim,hii,dim_z,hii_z", [(1024, 512, 128, 64), (1536, 512, 192, 64)])
+def test_split_pipeline_on_x_blocked_spectra(api, monkeypatch, dim, hii, dim_z, hii_z):
+    """DIM >= 1024: the main block of a split spectrum is stored x-blocked ([x / 8][y][x % 8][k_z]); the
+    element-wise kernels of the split IC pipeline (k^2 division, top-hat, fold by 2 and by 3 -- the
+    reference's default DIM = 3 HII_DIM at HII_DIM = 512) map memory lines to wavenumbers through
+    split_layout.h.  On a thin 1024 x 1024 x 128 / 1536 x 1536 x 192 box with a given density the
+    split pipeline agrees with the padded one (rocFFT, full-size transforms + gathers) to transform
+    round-off, for every output."""
+    import torch
+
+    L = 1.5 * hii
+    spec = ics_spec(dim, hii, box_len=L, density_is_input=1)
+    spec.dim_z, spec.hii_dim_z = dim_z, hii_z
+    spec.box_len_z = L * dim_z / dim
+    spec.volume = float(np.float32(L) * np.float32(L) * np.float32(spec.box_len_z))
+    g = torch.Generator(device="cuda").manual_seed(dim)
+    dens = torch.randn((dim, dim, dim_z), device="cuda", generator=g)
+    # smooth it a little so that derivatives and the fold see structure on all scales
+    dens = (dens + torch.roll(dens, 1, 0) + torch.roll(dens, 1, 1) + torch.roll(dens, 1, 2)).contiguous()
+    out = {}
+    for mode in ("split", "padded"):
+        if mode == "padded":
+            monkeypatch.setenv("C21CM_ICS", "padded")
+        start = api.new_ics_arrays(spec, device="cuda")
+        start["hires_density"].copy_(dens)
+        out[mode] = {k: v.cpu().numpy() for k, v in api.ics_grids(spec, start, device="cuda").items()}
+        del start
+        torch.cuda.empty_cache()
+    for k in LOWRES_FIELDS:
+        x, y = out["split"][k], out["padded"][k]
+        assert np.abs(y).max() > 0, k
+        np.testing.assert_allclose(x, y, atol=3e-5 * np.abs(y).max(), rtol=1e-4, err_msg=k)
+    api.load().c21cm_release_device_cache()
