@@ -295,6 +295,62 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
     block_sum_to(acc, partials);
 }
 
+// E-INTEGRAL without interpolation tables (C21CM_FCOLL_NODES): Nion_ConditionalM of every cell
+// (IonisationBox.c:889-893 -> hmf.c:1106-1140, Gauss-Legendre) from the radius' node data in LDS:
+// one exp and a handful of multiply-adds per (cell, node), all in double like the host integral.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+fcoll_nodes_kernel(const float *__restrict__ delta_fil, float *__restrict__ nion_dense, size_t nitems,
+                   int nz_items, int zpad_items, const double *__restrict__ nodes_dev,
+                   double *__restrict__ partials) {
+    __shared__ double nd[C21CM_NODE_DOUBLES];
+    for (int t = threadIdx.x; t < C21CM_NODE_DOUBLES; t += kBlock) nd[t] = nodes_dev[t];
+    __syncthreads();
+    const int n = (int)nd[0];
+    const bool st = nd[1] != 0.;
+    const double inv_growth = 1. / nd[2], limit = nd[3], collapsed = nd[4];
+    const bool empty = nd[5] != 0.;
+    double acc = 0.;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nitems;
+         i += (size_t)gridDim.x * kBlock) {
+        const Pack<VEC> d = Pack<VEC>::load(delta_fil, cell_index<VEC>(i, nz_items, zpad_items).padded);
+        Pack<VEC> out;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const double delta = (double)clip_delta_eulerian(d.v[e]);
+            double f = 0.;
+            if (!empty) {
+                if (delta > limit) {
+                    f = collapsed;
+                } else {
+                    // (delta / growthf as the host writes it: a division, not a reciprocal product,
+                    //  would cost a double division per cell; the 1-ulp difference of d0 is far below the
+                    //  float the result is stored in)
+                    const double d0 = delta * inv_growth;
+                    const double del = (1.686 - delta) * inv_growth;
+                    for (int k = 0; k < n; k++) {
+                        const double w = nd[8 + 4 * k];
+                        if (w == 0.) continue;
+                        const double sdi = nd[8 + 4 * k + 3];
+                        double cmf;
+                        if (st) {
+                            const double B = nd[8 + 4 * k + 2] - d0;
+                            cmf = (nd[8 + 4 * k + 1] - d0) * exp(-B * B * 0.5 * sdi);
+                        } else {
+                            cmf = del * exp(-del * del * 0.5 * sdi);
+                        }
+                        f += w * cmf;
+                    }
+                }
+            }
+            out.v[e] = (float)f;  // box->unnormalised_nion is float (IonisationBox.c:951)
+            acc += f;
+        }
+        out.store(nion_dense, i);
+    }
+    block_sum_to(acc, partials);
+}
+
 // ---- find_ionised_regions ---------------------------------------------------------------
 struct IoniseParams {
     c21hip_ionize_args a;
@@ -1009,6 +1065,21 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
     const int vec = (nz % 2 == 0) ? 2 : 1;
     const int zpad = 2 * (nz / 2 + 1);
     const size_t nitems = (size_t)nx * ny * (nz / vec);
+    if (mode == C21CM_FCOLL_NODES) {  // table_dev: C21CM_NODE_DOUBLES doubles of the radius
+        const int nb = grid_for(nitems);
+        const double *nodes = reinterpret_cast<const double *>(table_dev);
+        if (vec == 2)
+            hipLaunchKernelGGL(fcoll_nodes_kernel<2>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                               delta_fil, nion_dense, nitems, nz / 2, zpad / 2, nodes, partials);
+        else
+            hipLaunchKernelGGL(fcoll_nodes_kernel<1>, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream,
+                               delta_fil, nion_dense, nitems, nz, zpad, nodes, partials);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
+                           partials, nb, 0, sum_out);
+        LAUNCH_CHECK();
+        return 0;
+    }
     const int blocks = grid_for((nitems + 3) / 4);
     if (vec == 2)
         hipLaunchKernelGGL(fcoll_eulerian_kernel<2>, dim3(blocks), dim3(kBlock), 0,

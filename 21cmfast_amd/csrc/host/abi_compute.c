@@ -225,6 +225,16 @@ struct nion_table_ctx {
     int method;
 };
 
+/* C21CM_FCOLL_NODES: the same integrand's node data for the per-cell sums (no interpolation tables) */
+static int nion_nodes_fn(int r_index, double dmin, double dmax, float *table, void *user) {
+    (void)dmin, (void)dmax;
+    const struct nion_table_ctx *t = (const struct nion_table_ctx *)user;
+    const c21cm_ionize_spec *s = t->spec;
+    const double M_max_R = c21_RtoM(s->R[r_index]);
+    return c21_Nion_Conditional_nodes(s->growth_factor, t->lnMmin, log(M_max_R), log(M_max_R),
+                                      c21_sigma_fast(M_max_R), t->sc.mturn_a_nofb, &t->sc, (double *)table);
+}
+
 static int nion_table_fn(int r_index, double dmin, double dmax, float *table, void *user) {
     const struct nion_table_ctx *t = (const struct nion_table_ctx *)user;
     const c21cm_ionize_spec *s = t->spec;
@@ -279,8 +289,15 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     const int lagrangian = !(src == C21CM_SOURCE_E_INTEGRAL || src == C21CM_SOURCE_CONST_ION_EFF);
     const int mass_dep = src != C21CM_SOURCE_CONST_ION_EFF;
     const char *unsupported = NULL;
-    if (src == C21CM_SOURCE_E_INTEGRAL && mo->USE_INTERPOLATION_TABLES != C21CM_INTERP_HMF)
-        unsupported = "SOURCE_MODEL=E-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation";
+    /* E-INTEGRAL without interpolation tables: the per-cell conditional integral runs on the device
+     * with the Gauss-Legendre rule (round 4); an adaptive rule per cell does not */
+    const int no_tables = src == C21CM_SOURCE_E_INTEGRAL && mo->USE_INTERPOLATION_TABLES != C21CM_INTERP_HMF;
+    if (no_tables && ao->INTEGRATION_METHOD_ATOMIC != 1)
+        unsupported = "SOURCE_MODEL=E-INTEGRAL without USE_INTERPOLATION_TABLES=hmf-interpolation unless "
+                      "INTEGRATION_METHOD_ATOMIC=GAUSS-LEGENDRE";
+    if (no_tables && (ao->USE_MINI_HALOS || ao->USE_TS_FLUCT))
+        unsupported = "SOURCE_MODEL=E-INTEGRAL without interpolation tables together with USE_MINI_HALOS "
+                      "or USE_TS_FLUCT";
     if (src == C21CM_SOURCE_E_INTEGRAL && ao->INTEGRATION_METHOD_ATOMIC > 1)
         unsupported = "INTEGRATION_METHOD_ATOMIC=GAMMA-APPROX";
     /* mini-halos: the Eulerian E-INTEGRAL model (need_minihalo_nion, IonisationBox.c:30-31); the
@@ -541,8 +558,8 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
         nctx.sc = sc;
         nctx.lnMmin = lnMmin;
         nctx.method = ao->INTEGRATION_METHOD_ATOMIC;
-        s->fcoll_mode = C21CM_FCOLL_TABLE_EXP;
-        s->table_fn = nion_table_fn;
+        s->fcoll_mode = no_tables ? C21CM_FCOLL_NODES : C21CM_FCOLL_TABLE_EXP;
+        s->table_fn = no_tables ? nion_nodes_fn : nion_table_fn;
         s->table_user = &nctx;
     } else if (mo->USE_INTERPOLATION_TABLES == C21CM_INTERP_HMF) {
         s->fcoll_mode = C21CM_FCOLL_TABLE_LINEAR;

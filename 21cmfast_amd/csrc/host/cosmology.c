@@ -19,6 +19,7 @@
  * sigma_z0, dsigmasqdm_z0, power_in_k.
  */
 #include "cosmology.h"
+#include "c21cm_grid.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -1119,6 +1120,40 @@ static int conditional_table(double growthf, double lnMmin, double lnMmax, doubl
         table[k] = (float)lv;
     }
     return bad ? C21CM_TABLE_GENERATION_ERROR : 0;
+}
+
+/* E-INTEGRAL without interpolation tables: Nion_ConditionalM of EVERY cell (IonisationBox.c:889-893,
+ * hmf.c:1106-1140).  With the Gauss-Legendre method the integrand factorises exactly as in
+ * conditional_table() above; this fills the delta-independent node data of one radius
+ * (include/c21cm_grid.h: C21CM_FCOLL_NODES) and the device sums over the nodes per cell.  The
+ * per-cell values equal c21_Nion_ConditionalM(..., method = 1) to rounding. */
+int c21_Nion_Conditional_nodes(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                               double sigma_cond, double Mturn, const c21_scaling_consts *sc,
+                               double *nodes) {
+    int hmf = matter_options_global->HMF;
+    if (hmf != C21CM_HMF_PS && hmf != C21CM_HMF_ST) hmf = C21CM_HMF_PS;
+    memset(nodes, 0, sizeof(double) * C21CM_NODE_DOUBLES);
+    nodes[0] = NGL_INT;
+    nodes[1] = hmf == C21CM_HMF_ST ? 1. : 0.;
+    nodes[2] = growthf;
+    nodes[3] = MAX_DELTAC_FRAC * get_delta_crit(matter_options_global->HMF, sigma_cond, growthf);
+    nodes[4] = (lnMcond * (1 - FRACT_FLOAT_ERR) <= lnMmax) ? nion_weight(lnMcond, Mturn, sc) / exp(lnMcond) : 0.;
+    nodes[5] = (lnMmin >= lnMcond) ? 1. : 0.;
+    if (nodes[5] != 0.) return 0;
+    initialise_GL(lnMmin, lnMmax);
+    for (int i = 1; i < NGL_INT + 1; i++) {
+        double *nd = nodes + 8 + 4 * (i - 1);
+        const double lnM = gl.x[i], M = exp(lnM);
+        const double sigma1 = c21_sigma_fast(M), dsigmasqdm = dsigmasqdm_fast(M);
+        if (sigma1 < sigma_cond) continue; /* conditional_mf returns 0: the node's weight stays 0 */
+        const double sdi = sigma1 == sigma_cond ? 1e6 : 1 / (sigma1 * sigma1 - sigma_cond * sigma_cond);
+        const double pref = nion_weight(lnM, Mturn, sc) * dsigmasqdm * pow(sdi, 1.5) / sqrt(2. * M_PI);
+        nd[0] = gl.w[i] * (-pref);
+        if (hmf == C21CM_HMF_ST) nd[1] = st_taylor_factor(sigma1, sigma_cond, growthf, &nd[2]);
+        nd[3] = sdi;
+        if (!isfinite(nd[0]) || !isfinite(nd[1]) || !isfinite(nd[2])) return C21CM_TABLE_GENERATION_ERROR;
+    }
+    return 0;
 }
 
 /* The redshift tables of the molecularly cooled population for the spin temperature

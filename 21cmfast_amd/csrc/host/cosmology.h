@@ -58,6 +58,9 @@ double c21_Nion_ConditionalM(double growthf, double lnM1, double lnM2, double ln
                              const c21_scaling_consts *sc, int method);
 /* ln N_ion(delta | M_cond) on n_delta overdensities in [dmin, dmax], floored at ln_floor
  * (interp_tables.c:291-405 with -40; the SFRD table :415-494 is the same with f_esc = 1, -50) */
+int c21_Nion_Conditional_nodes(double growthf, double lnMmin, double lnMmax, double lnMcond,
+                               double sigma_cond, double Mturn, const c21_scaling_consts *sc,
+                               double *nodes /* C21CM_NODE_DOUBLES */);
 int c21_Nion_Conditional_table(double growthf, double lnMmin, double lnMmax, double lnMcond,
                                double sigma_cond, double dmin, double dmax, double Mturn,
                                const c21_scaling_consts *sc, int method, double ln_floor,

@@ -213,7 +213,7 @@ static int validate_spec(const c21cm_ionize_spec *s, const PerturbedField *pf,
             return C21CM_VALUE_ERROR;
         }
     }
-    if (s->fcoll_mode < C21CM_FCOLL_STARS_GRID || s->fcoll_mode > C21CM_FCOLL_TABLE_EXP) {
+    if (s->fcoll_mode < C21CM_FCOLL_STARS_GRID || s->fcoll_mode > C21CM_FCOLL_NODES) {
         c21hip_set_error("ionize: unknown fcoll_mode %d", s->fcoll_mode);
         return C21CM_VALUE_ERROR;
     }
@@ -503,7 +503,8 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
         }
     }
     c->scalars = (double *)c21hip_ws(WS_SCALARS, SC_COUNT * sizeof(double));
-    c->table_dev = (float *)c21hip_ws(WS_TABLE, 2 * C21CM_NDELTA_TABLE * sizeof(float));
+    /* two float tables (the pipelined table loop), or the node data of C21CM_FCOLL_NODES */
+    c->table_dev = (float *)c21hip_ws(WS_TABLE, 2 * C21CM_NDELTA_TABLE * sizeof(float) + C21CM_NODE_DOUBLES * sizeof(double));
     if (!c->scalars || !c->table_dev) return C21CM_MEMORY_ALLOC_ERROR;
     status = c21hip_memset(c->scalars, 0, SC_COUNT * sizeof(double), stream);
     if (status) return status;
@@ -1056,6 +1057,27 @@ done:
     return status;
 }
 
+/* C21CM_FCOLL_NODES: node data of radius R_ct from the host callback -> device -> per-cell sums of
+ * delta_fil into nion_dense (+ the f_coll sum) */
+static int fcoll_nodes(ion_ctx *c, int R_ct, double *partials, double *sum_dev) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    double nodes[C21CM_NODE_DOUBLES];
+    const int tst = s->table_fn(R_ct, 0., 0., (float *)nodes, s->table_user);
+    if (tst) {
+        c21hip_set_error("ionize: table_fn (node data) failed with status %d at radius %d", tst, R_ct);
+        return tst;
+    }
+    double *nodes_dev = (double *)(c->table_dev + 2 * C21CM_NDELTA_TABLE);
+    TRY(c21hip_h2d(nodes_dev, nodes, sizeof(nodes), c->stream));
+    TRY(c21hip_sync(c->stream)); /* `nodes` is a stack buffer */
+    TRY(c21hip_fcoll_eulerian(c->delta_fil, c->nion_dense, c->nx, c->ny, c->nz, C21CM_FCOLL_NODES,
+                              s->growth_factor, 0., 0., s->delta_c, 0., 1., (const float *)nodes_dev,
+                              partials, sum_dev, c->stream));
+done:
+    return status;
+}
+
 /* C21CM_EUL_DEFER=1: the barrier of a radius rides the next radius' pass Z (EPI 6) instead of its own
  * sweep (eulerian_mask_kernel).  OFF by default: bit-identical, but measured slower -- 44.3 against
  * 42.6 ms per 512^3 x 40-radii call; the extra 6 N bytes and 48 registers cost the pass Z (336 us,
@@ -1129,6 +1151,11 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                           s->growth_factor, s->sigma_minmass,
                                           s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev,
                                           c->stream));
+        } else if (s->fcoll_mode == C21CM_FCOLL_NODES) {
+            /* E-INTEGRAL without interpolation tables: the conditional integral per cell from the
+             * radius' Gauss-Legendre node data (no extrema, no table) */
+            TRY(c21hip_split_z_c2r(c->delta_work, c->delta_fil, zs, c->nx, c->ny, c->nz, c->stream));
+            TRY(fcoll_nodes(c, R_ct, partials, sum_dev));
         } else {
             double mm[2];
             float table[C21CM_NDELTA_TABLE];
@@ -1208,6 +1235,12 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
         TRY(mini_radius(c, R_ct, &args, apply, R));
     } else {
         double tab_min = 0., tab_width = 1.;
+        if (s->fcoll_mode == C21CM_FCOLL_NODES) {
+            TRY(fcoll_nodes(c, R_ct, partials, sum_dev));
+            TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                                   mean_dev, c->stream));
+            goto nodes_done;
+        }
         if (s->fcoll_mode >= C21CM_FCOLL_TABLE_LINEAR) {
             /* setup_integration_tables: IonisationBox.c:702-768 */
             double mm[2];
@@ -1234,6 +1267,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                   c->stream));
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
+    nodes_done:
         if (c->recomb)
             TRY(c21hip_ionise_recomb(&args, 0, c->inhomo, s->cell_recomb, s->R[R_ct],
                                      s->gamma_prefactor, c->delta_fil, c->nion_dense, NULL,
@@ -1565,7 +1599,7 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
                                        spec->use_ts_fluct ? 2 : 1, radii, n, c.nx, c.ny, c.nz,
                                        spec->box_len, spec->box_len_z, 0, &on, stream));
         }
-        if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC) {
+        if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC && spec->fcoll_mode != C21CM_FCOLL_NODES) {
             int radii[C21CM_MAX_RADII], n = 0;
             for (int R_ct = spec->n_radii - 1; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct--)
                 radii[n++] = R_ct;
@@ -1712,7 +1746,7 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
     spectra_remember(&c, perturbed_field, halos, spin_temp);
     TRY(c21hip_event_record(ev[1], stream));
     /* radii n-1 .. 1 dealt round-robin, largest first; index 0 belongs to the finish step */
-    if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC) {
+    if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC && spec->fcoll_mode != C21CM_FCOLL_NODES) {
         int radii[C21CM_MAX_RADII], n = 0;
         for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct -= world)
             radii[n++] = R_ct;

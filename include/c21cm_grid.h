@@ -34,13 +34,26 @@ enum c21cm_fcoll_mode {
     C21CM_FCOLL_STARS_GRID = 0,   /* Lagrangian source grids: f = filtered HaloBox.n_ion    */
     C21CM_FCOLL_ERFC = 1,         /* CONST-ION-EFF, no tables: FgtrM_bias_fast closed form  */
     C21CM_FCOLL_TABLE_LINEAR = 2, /* CONST-ION-EFF with tables: lerp(table, delta)          */
-    C21CM_FCOLL_TABLE_EXP = 3     /* E-INTEGRAL: exp(lerp(table, delta))                    */
+    C21CM_FCOLL_TABLE_EXP = 3,    /* E-INTEGRAL: exp(lerp(table, delta))                    */
+    C21CM_FCOLL_NODES = 4         /* E-INTEGRAL WITHOUT interpolation tables: the conditional integral
+                                   * Nion_ConditionalM per cell (IonisationBox.c:889-893, hmf.c:1106-1140)
+                                   * on the Gauss-Legendre nodes of the radius, see below          */
 };
 
 /* Host callback used by the two TABLE modes: fill `table[C21CM_NDELTA_TABLE]`
  * (float, like the reference's RGTable1D_f) for filter radius index `r_index`
  * on the regular delta grid x_i = dens_min + i*(dens_max-dens_min)/(NDELTA-1).
  * reference: src/py21cmfast/src/IonisationBox.c:702-768. */
+/* Mode C21CM_FCOLL_NODES: table_fn is called as table_fn(r_index, 0, 0, (float *)nodes, user) and fills
+ * C21CM_NODE_DOUBLES DOUBLES instead of a float table -- everything of the integrand that does not
+ * depend on the cell's overdensity:
+ *   nodes[0] number of Gauss-Legendre nodes n (<= 100)   nodes[1] 0: extended Press-Schechter, 1: Sheth-Tormen
+ *   nodes[2] growth factor                                nodes[3] delta above which the cell has collapsed
+ *   nodes[4] the value returned for such a cell           nodes[5] != 0: the integral is empty (M_min >= M_cond)
+ *   nodes[8 + 4 i ..]  (w_i x prefactor_i, barrier-expansion factor_i, barrier_i, 1 / (sigma_i^2 - sigma_c^2))
+ * and the device sums  - w_i pref_i (factor_i - d0) exp(-(barrier_i - d0)^2 sdi_i / 2),  d0 = delta / D
+ * (ST), or the same with (delta_c - delta) / D for both factors (PS), over the nodes. */
+#define C21CM_NODE_DOUBLES 408
 typedef int (*c21cm_table_fn)(int r_index, double dens_min, double dens_max, float *table,
                               void *user);
 

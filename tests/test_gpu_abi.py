@@ -383,7 +383,10 @@ def test_ionized_box_early_exit_and_errors(gpu_lib, tmp_path):
     # unsupported options return ValueError (3), never crash
     # (the Session must stay alive: the library stores POINTERS to its structs, as the
     #  reference does -- InputParameters.c:11-20)
-    ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=1, USE_INTERPOLATION_TABLES=0)
+    # (E-INTEGRAL without tables runs since round 4 with the Gauss-Legendre rule; the adaptive rule
+    #  per cell is still refused)
+    ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=1, USE_INTERPOLATION_TABLES=0,
+                  INTEGRATION_METHOD_ATOMIC=0)
     assert call_ionize(gpu_lib, 9.0, density, need_nion=True)["status"] == 3
     assert b"E-INTEGRAL" in gpu_lib.c21cm_last_error()
     ses = Session(gpu_lib, tmp_path, HII_DIM=16, SOURCE_MODEL=0, RECOMB_MODEL=2)
@@ -412,3 +415,51 @@ def test_coeval_chain(gpu_lib, api, tmp_path):
     assert 0.01 < xh.mean() < 0.999
     # ionised cells sit in over-dense regions on average (inside-out reionisation)
     assert dens[xh == 0].mean() > dens[xh > 0.5].mean()
+
+
+def test_ionized_box_e_integral_without_interpolation_tables(gpu_lib, tmp_path):
+    """SOURCE_MODEL = E-INTEGRAL with USE_INTERPOLATION_TABLES = no-interpolation: the reference then
+    evaluates Nion_ConditionalM for every cell and radius (IonisationBox.c:889-893 ->
+    hmf.c:1106-1140, Gauss-Legendre).  Here the delta-independent node data of a radius come from the
+    host and the device sums them per cell (C21CM_FCOLL_NODES).  Pinned two ways: the f_coll grid the
+    call returns (that of the cell-scale radius) equals the library's host integral
+    c21_Nion_ConditionalM cell by cell, and the box agrees with the interpolation-table run of the
+    same inputs up to the tables' interpolation error."""
+    lib = gpu_lib
+    n, z = 32, 9.0
+    density = W.density_field_numpy(n, seed=5, sigma=0.6)
+    kw = dict(HII_DIM=n, SOURCE_MODEL=1, HII_FILTER=1, USE_EXP_FILTER=False, CELL_RECOMB=False,
+              R_BUBBLE_MAX=12.0)
+    ses = Session(lib, tmp_path, USE_INTERPOLATION_TABLES=2, **kw)
+    tab = call_ionize(lib, z, density, need_nion=True)
+    assert tab["status"] == 0, lib.c21cm_last_error()
+    ses = Session(lib, tmp_path, USE_INTERPOLATION_TABLES=0, **kw)
+    out = call_ionize(lib, z, density, need_nion=True)
+    assert out["status"] == 0, lib.c21cm_last_error()
+    f64 = C.c_double
+    lib.c21_set_scaling_constants.restype = C.c_int
+    lib.c21_set_scaling_constants.argtypes = [f64, C.POINTER(ScalingConsts)]
+    lib.c21_Nion_ConditionalM.restype = f64
+    lib.c21_Nion_ConditionalM.argtypes = [f64] * 7 + [C.POINTER(ScalingConsts), C.c_int]
+    sc = ScalingConsts()
+    assert lib.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    M_min = lib.c21_minimum_source_mass(z)
+    R0 = W.radii_ladder(n, ses.so.BOX_LEN, 12.0, lagrangian=False)[0]
+    M_R = lib.c21_RtoM(R0)
+    sig_R, growth = lib.c21_sigma_fast(M_R), lib.dicke(z)
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, n**3, 300)
+    got = out["unnormalised_nion"].ravel()[idx]
+    dens = np.maximum(density.ravel()[idx], np.float32(-1.0 + 1e-7))
+    ref = np.array([lib.c21_Nion_ConditionalM(growth, math.log(M_min), math.log(M_R), math.log(M_R), sig_R,
+                                              float(d), sc.mturn_a_nofb, C.byref(sc), 1) for d in dens])
+    assert ref.max() > 0 and np.ptp(ref) > 0
+    # the cell-scale radius applies no window: delta_R is the input up to a transform round trip (1e-7)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-12)
+    # against the table run: 400-bin interpolation of ln N_ion
+    ion_a, ion_b = out["neutral_fraction"] == 0, tab["neutral_fraction"] == 0
+    assert 0.02 < ion_a.mean() < 0.98
+    assert np.mean(ion_a != ion_b) < 2e-3
+    rel = np.abs(out["unnormalised_nion"] / tab["unnormalised_nion"] - 1)
+    assert np.mean(rel > 2e-3) < 2e-3 and rel.max() < 5e-2  # (the tails of the 400-bin tables)
+    assert abs(out["neutral_fraction"].mean() - tab["neutral_fraction"].mean()) < 2e-3
