@@ -36,6 +36,10 @@ int c21hip_event_record(void *ev, void *stream);
 int c21hip_stream_wait_event(void *stream, void *ev);
 int c21hip_event_synchronize(void *ev); /* host waits for the event */
 void *c21hip_pinned_host(size_t bytes);  /* library-owned pinned staging buffer (one, reused) */
+void *c21hip_pinned_alloc(size_t bytes); /* caller-owned pinned blocks (c21hip_pinned_free) */
+void c21hip_pinned_free(void *p);
+void *c21hip_stream_create(void);        /* caller-owned non-blocking stream */
+void c21hip_stream_destroy(void *s);
 void *c21hip_aux_stream(void); /* library-owned non-blocking side stream, NULL on failure */
 float c21hip_event_elapsed_ms(void *start, void *stop); /* synchronises on stop */
 void c21hip_set_error(const char *fmt, ...);
@@ -246,6 +250,11 @@ int c21hip_copy_filter(const float *src_c, float *dst_c, int nx, int ny, int nz,
 int c21hip_copy_filter_star(const float *src_c, float *dst_c, int nx, int ny, int nz,
                             double box_len, double box_len_z, int filter_type, float R,
                             float R_param, float R_star, int apply, void *stream);
+
+/* ics_kernels.hip: the raw word pairs of the reference's IC random stream (gsl_stream.c: two accepted
+ * 32-bit outputs per deviate, generator kind per x-row) -> gsl_ran_ugaussian deviates, in place */
+int c21hip_gsl_words_to_deviates(void *buf, size_t n_deviates, const unsigned char *row_kind_dev,
+                                 size_t deviates_per_row, void *stream);
 
 /* ---- perturb_kernels.hip ---- */
 /* move_grid_masses: map_mass.c:146-208.  `out` (double[out_dim]) must be zeroed by the caller. */

@@ -470,6 +470,34 @@ extern "C" int c21hip_lpt2_accumulate(float *box, const float *phi_ij_padded, co
     return 0;
 }
 
+// ---- the reference's random stream: raw words -> deviates (gsl_stream.c) --------------------------
+// gsl_ran_ugaussian (polar method): x = 2 u1 - 1, y = 2 u2 - 1, r2 = x^2 + y^2 (accepted on the host),
+// value y sqrt(-2 ln r2 / r2).  u = word / 2^32 (mt19937, gfsr4, taus2) or value / 2147483647 (cmrg,
+// mrg): the same IEEE double operations as the host's, so x, y, r2 are the host's bits; ln and sqrt
+// are the device's (<= 1 ulp from libm's: the deviate can differ in its last bit).
+__global__ void __launch_bounds__(kBlock)
+gsl_words_kernel(unsigned long long *__restrict__ buf, size_t n, const unsigned char *__restrict__ row_kind,
+                 size_t per_row) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+        const unsigned long long w = buf[i];
+        const unsigned kind = row_kind[i / per_row];
+        const double a = (double)(unsigned)(w & 0xffffffffu), b = (double)(unsigned)(w >> 32);
+        const double u1 = (kind == 2 || kind == 3) ? a / 2147483647.0 : a * (1.0 / 4294967296.0);
+        const double u2 = (kind == 2 || kind == 3) ? b / 2147483647.0 : b * (1.0 / 4294967296.0);
+        const double x = 2 * u1 - 1, y = 2 * u2 - 1;
+        const double r2 = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+        reinterpret_cast<double *>(buf)[i] = y * sqrt(-2.0 * log(r2) / r2);
+    }
+}
+
+extern "C" int c21hip_gsl_words_to_deviates(void *buf, size_t n_deviates, const unsigned char *row_kind_dev,
+                                            size_t deviates_per_row, void *stream) {
+    hipLaunchKernelGGL(gsl_words_kernel, dim3(grid_for(n_deviates)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (unsigned long long *)buf, n_deviates, row_kind_dev, deviates_per_row);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- split-layout pipeline entry points (plain layout, or x-blocked where fft_native.hip blocks: nx >= 1024)
 extern "C" int c21hip_split_kop(const float *in_split, float *out_split, int nx, int ny, int nz,
                                 double box_len, double box_len_z, int axis0, int axis1,

@@ -171,6 +171,27 @@ extern "C" void *c21hip_pinned_host(size_t bytes) {
     }
     return buf;
 }
+// pinned host blocks and extra streams for the helper threads of the host drivers (the IC random
+// stream stages its words chunk by chunk while it is still being drawn)
+extern "C" void *c21hip_pinned_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void c21hip_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+extern "C" void *c21hip_stream_create(void) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
+extern "C" void c21hip_stream_destroy(void *s) {
+    if (s) (void)hipStreamDestroy((hipStream_t)s);
+}
 extern "C" int c21hip_event_synchronize(void *ev) {
     HIP_TRY(hipEventSynchronize((hipEvent_t)ev));
     return 0;

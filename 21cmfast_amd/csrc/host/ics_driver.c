@@ -42,6 +42,8 @@ enum {
  * reference's order and staged in HBM for sample_modes_kernel; NULL for the Philox stream. */
 int c21_gsl_mode_deviates(unsigned long long seed, int n_threads, int nx, int ny, int nzc,
                           double *ab);
+int c21_gsl_mode_deviates_device(unsigned long long seed, int n_threads, int nx, int ny, int nzc,
+                                 double *dev_ab, void *stream);
 static int stream_deviates(const c21cm_ics_spec *s, void *stream, const double **dev_ab) {
     *dev_ab = NULL;
     if (s->rng_stream == C21CM_RNG_PHILOX) return 0;
@@ -51,6 +53,18 @@ static int stream_deviates(const c21cm_ics_spec *s, void *stream, const double *
     }
     const int nzc = s->dim_z / 2 + 1;
     const size_t bytes = 2 * sizeof(double) * (size_t)s->dim * s->dim * nzc;
+    {
+        /* default: raw words staged chunk by chunk while the streams are drawn, ln / sqrt on the
+         * device (C21CM_GSL_DEVIATES=host: the deviates computed on the host, one blocking copy) */
+        const char *e = getenv("C21CM_GSL_DEVIATES");
+        if (!(e && e[0] == 'h')) {
+            double *dev = (double *)c21hip_ws(WS_IC_DEVIATES, bytes);
+            if (!dev) return C21CM_MEMORY_ALLOC_ERROR;
+            *dev_ab = dev;
+            return c21_gsl_mode_deviates_device(s->seed, s->rng_threads > 0 ? s->rng_threads : 1, s->dim,
+                                                s->dim, nzc, dev, stream);
+        }
+    }
     double *host = (double *)malloc(bytes);
     double *dev = (double *)c21hip_ws(WS_IC_DEVIATES, bytes);
     if (!host || !dev) {
