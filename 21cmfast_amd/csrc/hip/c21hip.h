@@ -111,6 +111,12 @@ int c21hip_split_filter_xy_single_pair(const float *src, float *work, float *wor
                                        double box_len_z, float R, float R2, int phases, void *stream);
 /* fused pass Z with a recombination model (CELL_RECOMB): barrier (1 + N_rec / (1 + delta)), delta_R
  * of a first crossing left in the Gamma_12 grid */
+int c21hip_z_ionise_recomb_xe_supported(int nx, int ny, int nz);
+int c21hip_split_z_ionise_recomb_xe(const float *delta_work, const float *stars_work, const float *xe_work,
+                                    const float *nrec, double rec0, float *g12, unsigned char *first_cross,
+                                    double *partials, int nx, int ny, int nz, int r_index,
+                                    double rhocrit_omb, double ion_eff, int mass_dep_zeta, double f_limit,
+                                    void *stream);
 int c21hip_split_z_ionise_recomb(const float *delta_work, const float *stars_work, const float *nrec,
                                  double rec0, float *g12, unsigned char *first_cross,
                                  double *partials, int nx, int ny, int nz, int r_index,

@@ -2220,7 +2220,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     }
     wave_fence();
     wave_c2r<A, P>(xs, sh, L, twH, twN, b);
-    static_assert(!(TS && RC), "x_e and recombinations together take the unfused sequence");
+    static_assert(!(TS && RC) || A == 16, "x_e + recombinations: 16 points per lane only (registers)");
     // (RC: the filtered whalo_sfr is only needed where a cell crosses for the first time; it gets
     //  its own pass Z right after this kernel, which looks the crossings of this radius up in the mask)
     float2 xx[TS ? A : 1];
@@ -2266,8 +2266,8 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         }
         double opd0 = 1., opd1 = 1.;  // RC: 1 + delta_R of the two cells
         if constexpr (RC) {
-            // f zeta > 1 + rec, rec = N_rec / (1 + delta): both sides times rho (1 + delta) > 0,
-            // f = max(s / (rho (1 + delta)), f_limit)
+            // f zeta > (1 - x_e)(1 + rec), rec = N_rec / (1 + delta): both sides times rho (1 + delta) > 0,
+            // f = max(s / (rho (1 + delta)), f_limit); without an x_e grid (1 - x_e) = 1
             opd0 = 1. + (double)fmaxf(xd[q].x, dmin);
             opd1 = 1. + (double)fmaxf(xd[q].y, dmin);
             double r0 = a.rec0, r1 = a.rec0;
@@ -2277,10 +2277,15 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                                             : reinterpret_cast<const float2 *>(a.nrec + lline * NZ)[j];
                 r0 = (double)nr.x, r1 = (double)nr.y;
             }
-            D0 = a.rhocrit_omb * (opd0 + r0);
-            D1 = a.rhocrit_omb * (opd1 + r1);
-            f0 = a.mass_dep_zeta && floor_lhs * opd0 > opd0 + r0;
-            f1 = a.mass_dep_zeta && floor_lhs * opd1 > opd1 + r1;
+            double n0 = 1., n1 = 1.;
+            if constexpr (TS) {
+                n0 = 1. - (double)fminf(fmaxf(xx[q].x, 0.f), 0.999f);
+                n1 = 1. - (double)fminf(fmaxf(xx[q].y, 0.f), 0.999f);
+            }
+            D0 = a.rhocrit_omb * ((opd0 + r0) * n0);
+            D1 = a.rhocrit_omb * ((opd1 + r1) * n1);
+            f0 = a.mass_dep_zeta && floor_lhs * opd0 > (opd0 + r0) * n0;
+            f1 = a.mass_dep_zeta && floor_lhs * opd1 > (opd1 + r1) * n1;
         }
         const bool i0 = (!RC && floor_ionises) || f0 || ((double)s0 * a.ion_eff > D0);
         const bool i1 = (!RC && floor_ionises) || f1 || ((double)s1 * a.ion_eff > D1);
@@ -2763,7 +2768,16 @@ int dispatch_z_fused(int nz, const ZFusedArgs &a, long nlines, hipStream_t strea
     hipLaunchKernelGGL((zw_ionise_kernel<A, TS, P>), grid, dim3(zblk), 0, stream, a, twH, twN)
 #define ZW_FUSED_RC(A, P) \
     hipLaunchKernelGGL((zw_ionise_kernel<A, false, P, true>), grid, dim3(zblk), 0, stream, a, twH, twN)
-        if (a.rc) {
+        if (a.rc && a.x_main) {  // recombinations AND the x_e grid of a spin-temperature run (round 4)
+            if (nz == 256)
+                hipLaunchKernelGGL((zw_ionise_kernel<16, true, 8, true>), grid, dim3(zblk), 0, stream, a, twH, twN);
+            else if (nz == 512)
+                hipLaunchKernelGGL((zw_ionise_kernel<16, true, 16, true>), grid, dim3(zblk), 0, stream, a, twH, twN);
+            else {
+                c21hip_set_error("fused pass Z with recombinations and an x_e grid: 256- / 512-point z-lines only");
+                return C21CM_VALUE_ERROR;
+            }
+        } else if (a.rc) {
             if (nz == 256)
                 ZW_FUSED_RC(16, 8);
             else if (nz == 512)
@@ -3902,14 +3916,36 @@ extern "C" int c21hip_split_z_ionise_stars_xe(const float *delta_work, const flo
 // The same with a recombination model (CELL_RECOMB): sfr_work = passes X, Y of HaloBox.whalo_sfr;
 // nrec: the previous box's cumulative_recombinations (dense; NULL: homogeneous, rec0), g12: dense
 // Gamma_12 grid written at first crossings.
+extern "C" int c21hip_split_z_ionise_recomb_xe(const float *delta_work, const float *stars_work,
+                                               const float *xe_work, const float *nrec, double rec0,
+                                               float *g12, unsigned char *first_cross, double *partials,
+                                               int nx, int ny, int nz, int r_index, double rhocrit_omb,
+                                               double ion_eff, int mass_dep_zeta, double f_limit,
+                                               void *stream);
 extern "C" int c21hip_split_z_ionise_recomb(const float *delta_work, const float *stars_work,
                                             const float *nrec, double rec0, float *g12,
                                             unsigned char *first_cross,
                                             double *partials, int nx, int ny, int nz, int r_index,
                                             double rhocrit_omb, double ion_eff, int mass_dep_zeta,
                                             double f_limit, void *stream) {
+    return c21hip_split_z_ionise_recomb_xe(delta_work, stars_work, nullptr, nrec, rec0, g12, first_cross,
+                                           partials, nx, ny, nz, r_index, rhocrit_omb, ion_eff,
+                                           mass_dep_zeta, f_limit, stream);
+}
+// ... with the filtered x_e spectrum of a spin-temperature run as a third line of the barrier kernel
+// (xe_work == NULL: none): f zeta > (1 - x_e)(1 + rec), IonisationBox.c:1084-1118
+extern "C" int c21hip_split_z_ionise_recomb_xe(const float *delta_work, const float *stars_work,
+                                               const float *xe_work, const float *nrec, double rec0,
+                                               float *g12, unsigned char *first_cross, double *partials,
+                                               int nx, int ny, int nz, int r_index, double rhocrit_omb,
+                                               double ion_eff, int mass_dep_zeta, double f_limit,
+                                               void *stream) {
     const long nlines = (long)nx * ny;
     ZFusedArgs a{};
+    if (xe_work) {
+        a.x_main = reinterpret_cast<const float2 *>(xe_work);
+        a.x_nyq = a.x_main + nlines * (nz / 2);
+    }
     a.ny = ny;
     a.lb = split_xb_log2(nx);
     a.d_main = reinterpret_cast<const float2 *>(delta_work);
@@ -4007,6 +4043,11 @@ extern "C" int c21hip_split_z_xe_mask(const float *xe_work, const float *nion_de
 extern "C" int c21hip_z_ionise_recomb_supported(int nx, int ny, int nz) {
     const long nlines = (long)nx * ny;
     return zw_lines_of(nz, nlines) != 0 && !zw3_selected(nz, nlines) && nz <= 512;
+}
+
+// 1: ... also with the x_e grid of a spin-temperature run (16 points per lane: 256- / 512-point z-lines)
+extern "C" int c21hip_z_ionise_recomb_xe_supported(int nx, int ny, int nz) {
+    return c21hip_z_ionise_recomb_supported(nx, ny, nz) && (nz == 256 || nz == 512);
 }
 
 // 1: the fused pass Z can take an x_e grid at this z-line length

@@ -335,6 +335,7 @@ typedef struct {
     int eul_pend, eul_pend_buf;      /* radius index whose barrier is still owed (-1: none), its f_coll buffer */
     unsigned char *eul_pend_mask;
     float *nion_dense2;
+    const float *cur_xe; /* fused recombination loop with an x_e grid: its work spectrum of the radius in hand */
     int yz;              /* pass Y + fused pass Z as ONE plane-fused kernel (plane_yz.hip: 512^3, two grids) */
     int yz_now;          /* ... for the radius z_ionise_radius is called for (its main blocks skipped pass Y) */
     int yz_used;         /* a plane-fused launch happened in this call: its status is checked at the end */
@@ -420,11 +421,16 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
      * post-loop stay on the general kernels.  Needs the evaluated windows (whalo_sfr takes window
      * b alone).  C21CM_RECOMB_FUSED=0: the unfused per-radius sequence. */
     c->fused_rc = 0;
-    if (c->native && c->lagrangian && c->recomb && s->cell_recomb && !s->use_ts_fluct &&
+    if (c->native && c->lagrangian && c->recomb && s->cell_recomb &&
         !s->use_mini_halos && !s->ionise_entire_sphere && s->r_lowest == 0 &&
-        (g_single_pass || g_rc_phase)) {
-        const char *e = getenv("C21CM_RECOMB_FUSED");
-        if (!(e && e[0] == '0') && c21hip_z_ionise_recomb_supported(c->nx, c->ny, c->nz) &&
+        (g_single_pass || (g_rc_phase && !s->use_ts_fluct))) {
+        /* (round 4: with the x_e grid of a spin-temperature run too -- a third line of the barrier
+         * kernel; C21CM_RECOMB_FUSED_TS=0 keeps such runs on the unfused sequence) */
+        const char *e = getenv("C21CM_RECOMB_FUSED"), *et = getenv("C21CM_RECOMB_FUSED_TS");
+        const int ts_ok = !s->use_ts_fluct ||
+                          (!(et && et[0] == '0') && r0_direct() &&
+                           c21hip_z_ionise_recomb_xe_supported(c->nx, c->ny, c->nz));
+        if (!(e && e[0] == '0') && ts_ok && c21hip_z_ionise_recomb_supported(c->nx, c->ny, c->nz) &&
             c21hip_wev_applicable(s->hii_filter, s->stars_filter, 2, c->nx, c->ny, c->nz))
             c->fused_rc = c->fused = 1;
     }
@@ -757,9 +763,10 @@ static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float
             if (c->def_count == 0) c->def_first = R_ct;
             c->def_count++;
         }
-        TRY(c21hip_split_z_ionise_recomb(dwork, swork, c->inhomo ? c->prev_nrec : NULL, c->rec0, c->G12,
-                                         first_cross, part, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
-                                         s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg, c->stream));
+        TRY(c21hip_split_z_ionise_recomb_xe(dwork, swork, s->use_ts_fluct ? c->cur_xe : NULL,
+                                            c->inhomo ? c->prev_nrec : NULL, c->rec0, c->G12, first_cross,
+                                            part, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
+                                            s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg, c->stream));
         TRY(c21hip_split_z_sfr_gamma12(xwork, first_cross, c->G12, c->nx, c->ny, c->nz, R_ct,
                                        s->R[R_ct] * s->gamma_prefactor, c->stream));
         if (!c->def_partials) {
@@ -850,8 +857,11 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
             const char *e = getenv("C21CM_PAIR_ORDER");
             yy = (e && e[0] == 'y') ? 1 : 0;
         }
-        const float *xw[2] = {s->use_ts_fluct ? c->xe_work : (c->fused_rc ? c->sfr_work : NULL),
-                              s->use_ts_fluct ? c->xe_work2 : (c->fused_rc ? c->sfr_work2 : NULL)};
+        /* third spectrum handed to z_ionise_radius: whalo_sfr on the fused recombination loop (the
+         * x_e spectrum of such a run travels in c->cur_xe), else x_e */
+        const float *xw[2] = {c->fused_rc ? c->sfr_work : (s->use_ts_fluct ? c->xe_work : NULL),
+                              c->fused_rc ? c->sfr_work2 : (s->use_ts_fluct ? c->xe_work2 : NULL)};
+        const float *xe_of[2] = {s->use_ts_fluct ? c->xe_work : NULL, s->use_ts_fluct ? c->xe_work2 : NULL};
         c->yz_now = c->yz;
         if (c->yz) c->yz_used = 1;
         for (int ph = 0; ph < 3; ph++) { /* pass X, pass Y of R_a, pass Y of R_b */
@@ -865,8 +875,10 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                     TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
                     TRY(c21hip_event_record(g_tab.ev_used[buf_b], c->stream));
                 }
-                if (ph == 1 && !yy)
+                if (ph == 1 && !yy) {
+                    c->cur_xe = xe_of[0];
                     TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
+                }
                 continue;
             }
             TRY(c21hip_split_filter_xy2_pair(
@@ -890,11 +902,17 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                 TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
                 TRY(c21hip_event_record(g_tab.ev_used[buf_b], c->stream));
             }
-            if (ph == 1 && !yy)
+            if (ph == 1 && !yy) {
+                c->cur_xe = xe_of[0];
                 TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
+            }
         }
         c->tab_seq++;
-        if (yy) TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
+        if (yy) {
+            c->cur_xe = xe_of[0];
+            TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
+        }
+        c->cur_xe = xe_of[1];
         TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2, xw[1], first_cross));
         c->yz_now = 0;
         goto done;
@@ -914,8 +932,9 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
         if (tab_async) TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
     }
     c->tab_seq++;
+    c->cur_xe = s->use_ts_fluct ? c->xe_work : NULL;
     TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work,
-                        s->use_ts_fluct ? c->xe_work : (c->fused_rc ? c->sfr_work : NULL), first_cross));
+                        c->fused_rc ? c->sfr_work : (s->use_ts_fluct ? c->xe_work : NULL), first_cross));
 done:
     return status;
 }

@@ -250,21 +250,25 @@ def test_c_level_sharding_with_an_emulated_transport(api, recomb, world):
     assert 0.03 < float((buf0.neutral_fraction == 0).float().mean()) < 0.97
 
 
-@pytest.mark.parametrize("model", [2, 1])
-def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, model):
+@pytest.mark.parametrize("model,ts", [(2, False), (1, False), (2, True), (1, True)])
+def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, model, ts):
     """CELL_RECOMB runs ride the fused loop (whalo_sfr as a third spectrum of the wave-level pass Z,
     (1 + N_rec / (1 + delta)) in the barrier, Gamma_12 at first crossings, the mean free path from
     the first-crossing index); C21CM_RECOMB_FUSED=0 is the per-radius sequence of round 2.  Same
     crossings (up to cells within float round-off of the barrier), same Gamma_12 / N_rec."""
     import torch
 
+    # ts (round 4): with the x_e grid of a spin-temperature run the filtered x_e is a third line of the
+    # barrier kernel, f zeta > (1 - x_e)(1 + rec) (IonisationBox.c:1084-1118)
     n = 256
-    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0)
-    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=77).items()}
+    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0, ts=int(ts))
+    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=77, ts=ts).items()}
     if model == 1:
         d["prev_nrec"] = torch.full((1, 1, 1), 0.25, dtype=torch.float32, device="cuda")
     kw = dict(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"], prev_nrec=d["prev_nrec"],
               prev_z_reion=d["prev_z_reion"])
+    if ts:
+        kw.update(xe=d["xe"], Tneutral=d["Tneutral"])
     monkeypatch.setenv("C21CM_RECOMB_FUSED", "0")
     b0, _, r0 = api.ionize_grids(spec, d["density"], **kw)
     monkeypatch.delenv("C21CM_RECOMB_FUSED")

@@ -27,16 +27,21 @@ whalo = (n_ion * (0.8 + 0.4 * torch.rand(density.shape, device="cuda", generator
 prev_nrec = (0.6 * torch.rand(density.shape, device="cuda", generator=g) ** 2).float()
 prev_zre = torch.where(torch.rand(density.shape, device="cuda", generator=g) < 0.1, 11.5, -1.0).float()
 out = {"hii_dim": n}
-for name, model, cell in (("none", 0, 1), ("homogeneous", 1, 1), ("inhomogeneous_cell", 2, 1),
-                          ("inhomogeneous_filtered", 2, 0)):
+xe = (0.02 + 0.2 * torch.rand(density.shape, device="cuda", generator=g) ** 3).float()
+Tn = (8.0 + 4.0 * torch.rand(density.shape, device="cuda", generator=g)).float()
+for name, model, cell, ts_on in (("none", 0, 1, 0), ("homogeneous", 1, 1, 0), ("inhomogeneous_cell", 2, 1, 0),
+                                 ("inhomogeneous_filtered", 2, 0, 0), ("inhomogeneous_cell_xe", 2, 1, 1),
+                                 ("homogeneous_xe", 1, 1, 1)):
     if only and name != only:
         continue
     if model == 0:
         spec = W.ionize_spec(n)
         kw = dict(n_ion=n_ion)
     else:
-        spec = RH.recomb_spec(n, model=model, cell_recomb=cell, r_bubble_max=40.0)
+        spec = RH.recomb_spec(n, model=model, cell_recomb=cell, r_bubble_max=40.0, ts=ts_on)
         kw = dict(n_ion=n_ion, whalo_sfr=whalo, prev_nrec=prev_nrec, prev_z_reion=prev_zre)
+        if ts_on:  # the x_e / T_k boxes of a spin-temperature run
+            kw.update(xe=xe, Tneutral=Tn)
     buf = None
     ts = []
     for r in range(reps + 1):
