@@ -416,10 +416,432 @@ plane_yz_kernel(YzArgs a, const float2 *__restrict__ tw_global, const float2 *__
         __hip_atomic_store((gu32 *)&a.status->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- the same plane protocol with the two passes on SEPARATE WAVES of one workgroup ---------------
+// plane_yz_kernel runs pass Y and pass Z of a plane one after the other in all eight waves, and a
+// plane costs the SUM of their instruction streams plus every wait (13.4 us).  Here a
+// workgroup is 1024 threads: waves 0-7 are the Y role (the tile pipeline above, one tile per plane),
+// waves 8-15 the Z role (rows of the planes behind it), each role with its own loop, linked only
+// through the XCD's two counters exactly like two workgroups would be -- the waits of one role lie
+// under the arithmetic of the other and four waves per SIMD hide the LDS round trips of the wave-level
+// transform.
+// No s_barrier after the prologue (it would tie the roles together): the eight waves of a role meet at
+// software barriers on LDS counters (monotonic epochs; the LDS operations of a wave execute in issue
+// order, so its counter increment follows its data writes), the last wave to drain its stores / loads
+// arrives on the XCD's counter for the workgroup, one lane polls the other counter and publishes it.
+// In the Z role every wave carries BOTH grids of two rows (lanes 0-31 density, 32-63 emissivity), so the
+// two values of a cell meet inside the wave and no Z wave ever waits for another.
+// Measured (MI355X, tools/time_yz.py): 0.79-0.84 ms per radius, the separate passes 0.47 + 0.34 (+ 0.03
+// for the Nyquist planes' pass Y, which this kernel needs too): at parity, bit-identical.  Per plane and
+// CU (C21X_YZ_PROF): Y role 5.3 us of transform (2.7 us when it has the SIMDs to itself), 1.3 us of
+// stores, the rest waiting; Z role 0.6 us row loads, 2.9 us transform, 1.8 us barrier test, the rest
+// waiting.  Without the tile reads from HBM (timing experiment) 0.68 ms = 9.3 us per plane, of which
+// ~8 us are the two instruction streams sharing the four SIMDs: the kernel is bound by instruction
+// issue, not by the hand-off, and cannot reach the ~0.45 ms its HBM bytes would allow.  Also measured:
+// polling through the scalar data path (slower: 0.97 ms), wave priorities (no change), and one HBM effect
+// -- tile columns whose 128-byte lines lie at 384 (mod 1024) of the address arrive ~2.5 us later than the
+// others, whichever workgroup reads them (it moves with the base address) and gate every plane.
+constexpr int WG2 = 1024;
+#ifndef C21X_YZ_PRIO
+#define C21X_YZ_PRIO 1
+#endif
+#ifndef C21X_YZ_SRC_AUX
+#define C21X_YZ_SRC_AUX 2  // cache policy of the tile reads: 2 = nt (streamed)
+#endif
+#ifndef C21X_YZ_SCALAR_POLL
+#define C21X_YZ_SCALAR_POLL 0
+#endif
+#if C21X_YZ_PROF
+#define YZ2_TICK(slot)                                     \
+    do {                                                   \
+        if (threadIdx.x == 0 || threadIdx.x == 512) { \
+            const unsigned long long t_ = wall_clock64();  \
+            prof_acc[slot] += t_ - prof_t;                 \
+            prof_t = t_;                                   \
+        }                                                  \
+    } while (0)
+#else
+#define YZ2_TICK(slot) do { } while (0)
+#endif
+struct Roles {            // LDS words of the software synchronisation, all monotonic
+    int y_bar;            // Y role: stage barriers (8 arrivals per barrier)
+    int y_go;             // Y role: epoch for which "slot free" has been seen by the polling lane
+    int y_stored;         // Y role: waves whose slot stores have drained
+    int z_go;             // Z role: epoch for which "plane complete" has been seen
+    int z_loaded;         // Z role: waves whose row loads have landed
+    int z_red;            // Z role: waves whose per-lane f_coll sums of the plane are in LDS
+    int dead;             // a wait timed out somewhere: nobody waits any more
+    int safe;
+};
+
+// (LDS pointers carry their address space: a poll through a generic pointer is a FLAT load, which
+//  counts on vmcnt as well and so waits for every global load in flight -- the prefetched tile)
+typedef int __attribute__((address_space(3))) lds_int;
+__device__ __forceinline__ int lds_peek(int *p) {
+    return __hip_atomic_load((lds_int *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_poke(int *p, int v) {
+    __hip_atomic_store((lds_int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int lds_bump(int *p) {
+    return __hip_atomic_fetch_add((lds_int *)p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool lds_wait_ge(int *cnt, int target, int *dead) {
+    unsigned spins = 0;
+    while (lds_peek(cnt) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0 && (lds_peek(dead) || spins > (1u << 24))) {
+            lds_poke(dead, 1);
+            return false;
+        }
+    }
+    return true;
+}
+// barrier among the `n` waves of a role: every lane waits, lane 0 of each wave arrives
+__device__ __forceinline__ void role_barrier(int *cnt, int target, int *dead) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if ((threadIdx.x & 63) == 0) (void)lds_bump(cnt);
+    (void)lds_wait_ge(cnt, target, dead);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void role_arrive(int *cnt) {  // split barrier: arrival ...
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if ((threadIdx.x & 63) == 0) (void)lds_bump(cnt);
+}
+__device__ __forceinline__ void role_wait(int *cnt, int target, int *dead) {  // ... and the wait
+    (void)lds_wait_ge(cnt, target, dead);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// A counter of the XCD read through the SCALAR data path (glc: past the scalar cache, from the L2).  A
+// vector load would queue in the CU's texture path behind the tile prefetch and the slot stores of all
+// sixteen waves and come back microseconds later; the scalar path is idle here.
+__device__ __forceinline__ unsigned scalar_peek(const unsigned *p) {
+#if C21X_YZ_SCALAR_POLL
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+#else
+    return __hip_atomic_load((gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void global_wait_ge(unsigned *cnt, unsigned target, YzSync *sync, int *dead) {
+    unsigned spins = 0;
+    while (scalar_peek(cnt) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0 &&
+            (lds_peek(dead) || spins > (1u << 21) ||
+             __hip_atomic_load((gu32 *)&sync->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store((gu32 *)&sync->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_poke(dead, 1);
+            break;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WG2)
+plane_yz2_kernel(YzArgs a, const float2 *__restrict__ tw_global, const float2 *__restrict__ twH_global,
+                 const float2 *__restrict__ twN_global) {
+    extern __shared__ float4 lds_raw[];
+    float2 *tile = reinterpret_cast<float2 *>(lds_raw);  // [N][TZ]
+    float2 *tw = tile + N * TZ;
+    float2 *twH = tw + N;
+    float2 *twN = twH + H;
+    float2 *lines = twN + H;
+    Roles *R = reinterpret_cast<Roles *>(lines + 32 * LINE_LDS);
+    for (int t = threadIdx.x; t < N; t += WG2) tw[t] = tw_global[t];
+    for (int t = threadIdx.x; t < H; t += WG2) {
+        twH[t] = twH_global[t];
+        twN[t] = twN_global[t];
+    }
+    if (threadIdx.x < (int)(sizeof(Roles) / sizeof(int))) reinterpret_cast<int *>(R)[threadIdx.x] = 0;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    YzSync *sync = a.sync;
+    // ---- placement check and start barrier (the only s_barriers of the kernel)
+    if (threadIdx.x == 0) {
+        const unsigned id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;  // HW_REG_XCC_ID
+        if ((int)id != xcd || a.force_safe) {
+            __hip_atomic_store((gu32 *)&sync->mismatch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32 *)&a.status->mismatch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add((gu32 *)&sync->start[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        global_wait_ge(&sync->start[0], gridDim.x, sync, &R->dead);
+        lds_poke(&R->safe, (int)__hip_atomic_load((gu32 *)&sync->mismatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __syncthreads();
+    const bool safe = lds_peek(&R->safe) != 0;
+    unsigned *ycnt = &sync->y_done[xcd][0], *zcnt = &sync->z_done[xcd][0];
+    constexpr int n_planes = N / 8;
+    float2 *slot0 = a.ring + (size_t)xcd * 2 * PLANE;
+    const __amdgpu_buffer_rsrc_t slot_rs = make_rsrc(slot0, (unsigned)(2 * PLANE * sizeof(float2)));
+#if C21X_YZ_PROF
+    unsigned long long prof_acc[4] = {0, 0, 0, 0}, prof_t = wall_clock64();  // Y role: slots 0-3, Z role: 4-7
+#endif
+
+    if (threadIdx.x < 512) {
+        // ===================== Y role: one tile per plane (line_pass_kernel<512, +1, 0>, F512)
+        const int r0 = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+        const bool poller = threadIdx.x == 0;
+        const int yg = k >> 4, yct = k & 15;
+        const __amdgpu_buffer_rsrc_t src_rs = make_rsrc(yg ? a.main[1] : a.main[0], (unsigned)(N * PLANE * sizeof(float2)));
+        const unsigned src_lane = (unsigned)(((size_t)r0 * H + yct * TZ + 2 * c4) * sizeof(float2));
+        const unsigned slot_store = (unsigned)(((size_t)yg * PLANE + (size_t)r0 * H + yct * TZ + 2 * c4) * sizeof(float2));
+        float4 reg[8];
+        {
+            const unsigned base = (unsigned)((size_t)xcd * PLANE * sizeof(float2)) + src_lane;
+#pragma unroll
+            for (int u = 0; u < 8; u++) reg[u] = ld16<C21X_YZ_SRC_AUX>(src_rs, base + (unsigned)(u * 64 * H * sizeof(float2)));
+        }
+        int bar = 0;  // barriers of this role so far
+        for (int i = 0; i < n_planes; i++) {
+            {
+                float2 c0[8], c1[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    c0[u] = make_float2(reg[u].x, reg[u].y);
+                    c1[u] = make_float2(reg[u].z, reg[u].w);
+                }
+                Dft<8, +1>::run(c0);
+                Dft<8, +1>::run(c1);
+                if (i > 0) role_wait(&R->y_bar, 8 * bar, &R->dead);  // every wave has read stage 3 of the last tile
+                float2 twd1[8];  // (rebuilt per tile: 128 registers per lane at four waves per SIMD)
+                twd1[1] = tw[r0];
+                twd1[2] = tw[2 * r0];
+                twd1[4] = tw[4 * r0];
+                twd1[3] = cmul(twd1[1], twd1[2]);
+                twd1[5] = cmul(twd1[1], twd1[4]);
+                twd1[6] = cmul(twd1[2], twd1[4]);
+                twd1[7] = cmul(twd1[3], twd1[4]);
+#pragma unroll
+                for (int j = 1; j < 8; j++) twd1[j].y = -twd1[j].y;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float2 o0 = c0[j], o1 = c1[j];
+                    if (j > 0) {
+                        o0 = cmul(o0, twd1[j]);
+                        o1 = cmul(o1, twd1[j]);
+                    }
+                    *reinterpret_cast<float4 *>(tile + (8 * r0 + j) * TZ + 2 * c4) = make_float4(o0.x, o0.y, o1.x, o1.y);
+                }
+            }
+            role_barrier(&R->y_bar, 8 * ++bar, &R->dead);
+            {
+                const int xn = xcd + 8 * ((i + 1 < n_planes) ? i + 1 : i);
+                const unsigned base = (unsigned)((size_t)xn * PLANE * sizeof(float2)) + src_lane;
+#pragma unroll
+                for (int u = 0; u < 8; u++) reg[u] = ld16<C21X_YZ_SRC_AUX>(src_rs, base + (unsigned)(u * 64 * H * sizeof(float2)));
+            }
+            float4 outv[8];
+            {
+                const int obase = (r0 & 7) + 64 * (r0 >> 3);
+                float2 s0[8], s1[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const float4 t = *reinterpret_cast<const float4 *>(tile + (r0 + 64 * kk) * TZ + 2 * c4);
+                    s0[kk] = make_float2(t.x, t.y);
+                    s1[kk] = make_float2(t.z, t.w);
+                }
+                role_barrier(&R->y_bar, 8 * ++bar, &R->dead);
+                float2 w2[8];
+                {
+                    const int ps = r0 & ~7;
+                    w2[1] = tw[ps];
+                    w2[2] = tw[2 * ps];
+                    w2[4] = tw[4 * ps];
+                    w2[3] = cmul(w2[1], w2[2]);
+                    w2[5] = cmul(w2[1], w2[4]);
+                    w2[6] = cmul(w2[2], w2[4]);
+                    w2[7] = cmul(w2[3], w2[4]);
+#pragma unroll
+                    for (int j = 1; j < 8; j++) w2[j].y = -w2[j].y;
+                }
+                Dft<8, +1>::run(s0);
+                Dft<8, +1>::run(s1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float2 o0 = s0[j], o1 = s1[j];
+                    if (j > 0) {
+                        o0 = cmul(o0, w2[j]);
+                        o1 = cmul(o1, w2[j]);
+                    }
+                    *reinterpret_cast<float4 *>(tile + (obase + 8 * j) * TZ + 2 * c4) = make_float4(o0.x, o0.y, o1.x, o1.y);
+                }
+                role_barrier(&R->y_bar, 8 * ++bar, &R->dead);
+            }
+            {
+                float2 c0[8], c1[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; kk++) {
+                    const float4 t = *reinterpret_cast<const float4 *>(tile + (r0 + 64 * kk) * TZ + 2 * c4);
+                    c0[kk] = make_float2(t.x, t.y);
+                    c1[kk] = make_float2(t.z, t.w);
+                }
+                role_arrive(&R->y_bar);  // (split barrier: the wait is before the next tile's stage-1 writes)
+                ++bar;
+                Dft<8, +1>::run(c0);
+                Dft<8, +1>::run(c1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) outv[j] = make_float4(c0[j].x, c0[j].y, c1[j].x, c1[j].y);
+            }
+            YZ2_TICK(0);  // Y: the three stages of the tile
+            // slot free?  (every workgroup of the XCD has read plane i - 1)
+            if (poller) {
+                if (i > 0) global_wait_ge(zcnt, (unsigned)GROUP * i, sync, &R->dead);
+                lds_poke(&R->y_go, i + 1);
+            }
+            (void)lds_wait_ge(&R->y_go, i + 1, &R->dead);
+            YZ2_TICK(1);  // Y: wait, slot free
+            if (!safe) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) st16<0>(outv[j], slot_rs, slot_store + (unsigned)(j * 64 * H * sizeof(float2)));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) st16<17>(outv[j], slot_rs, slot_store + (unsigned)(j * 64 * H * sizeof(float2)));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores (and the prefetch) have completed
+            // the last of the eight waves to get here arrives for the workgroup (no wave can be a plane
+            // ahead: plane i + 1's stores wait for the z-counter, which waits for this arrival)
+            if ((threadIdx.x & 63) == 0 &&
+                lds_bump(&R->y_stored) == 8 * (i + 1) - 1)
+                __hip_atomic_fetch_add((gu32 *)ycnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            YZ2_TICK(2);  // Y: slot stores, drain, arrival
+        }
+    } else {
+        // ===================== Z role: rows 16 k .. 16 k + 15 of every plane (zw_ionise_kernel<16, false>)
+        // Every wave carries BOTH grids of two rows: lanes 0-31 the density lines of rows 2 w, 2 w + 1,
+        // lanes 32-63 the emissivity lines of the same rows, so the two values of a cell meet inside the
+        // wave (through its own LDS regions, no flag between waves) and each half tests half of the
+        // row's cells: the density lanes cells of q = 0..7, the emissivity lanes those of q = 8..15.
+        const int zt = threadIdx.x - 512;
+        const int lane = zt & 63, wave = zt >> 6;
+        const int grp = lane >> 4, b = lane & 15;
+        const int role = grp >> 1, lw = 2 * wave + (grp & 1);
+        const bool poller = zt == 0;
+#if C21X_YZ_PRIO
+        __builtin_amdgcn_s_setprio(2);  // (the Z role is the critical chain of a plane; the Y role has slack)
+#endif
+        float2 *L = lines + (wave * 4 + grp) * LINE_LDS;
+        const float2 *Lpartner = lines + (wave * 4 + (grp ^ 2)) * LINE_LDS;
+        const unsigned slot_load = (unsigned)(((size_t)role * PLANE + (size_t)(16 * k + lw) * H + b) * sizeof(float2));
+        const double floor_lhs = a.f_limit * a.ion_eff;
+        const bool floor_ionises = a.mass_dep_zeta && (floor_lhs > 1.);
+        const float dmin = (float)(-1. + 1e-7);
+        // f_coll partial sum of the block in zw_ionise_kernel's order: there emissivity wave v holds rows
+        // 4 v .. 4 v + 3, lane (row % 4) * 16 + b the sum of its 32 cells, a shuffle tree over the 64 lanes,
+        // then the four waves in order.  Here the per-lane sums go to `accs` in that arrangement and the
+        // last wave to arrive runs the four trees.
+        double *accs = reinterpret_cast<double *>(R + 1);  // [2 (plane parity)][4][64]
+        const int acc_slot = (lw >> 2) * 64 + (lw & 3) * 16 + b;
+        // (nothing from HBM may be outstanding at the poll: its vmcnt(0) would wait for that too -- the
+        //  Nyquist coefficient of a line is fetched one plane ahead, the mask rows after the arrival)
+        float nyq_next = (role ? a.nyq[1] : a.nyq[0])[(long)xcd * N + 16 * k + lw].x;
+        for (int i = 0; i < n_planes; i++) {
+            const int x = xcd + 8 * i;
+            const long lline = (long)x * N + 16 * k + lw;
+            uchar2 *mrow = reinterpret_cast<uchar2 *>(a.first_cross + lline * N) + b + A * 8 * role;
+            uchar2 old[A / 2];
+            const float nyq_re = nyq_next;
+            if (poller) {
+                global_wait_ge(ycnt, (unsigned)GROUP * (i + 1), sync, &R->dead);
+                lds_poke(&R->z_go, i + 1);
+            }
+            (void)lds_wait_ge(&R->z_go, i + 1, &R->dead);
+            YZ2_TICK(0);  // Z: wait, plane complete
+            float2 xv[A];
+            if (!safe) {
+#pragma unroll
+                for (int q = 0; q < A; q++) xv[q] = ld8<16>(slot_rs, slot_load + (unsigned)(P * q * sizeof(float2)));
+            } else {
+#pragma unroll
+                for (int q = 0; q < A; q++) xv[q] = ld8<17>(slot_rs, slot_load + (unsigned)(P * q * sizeof(float2)));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the rows have landed
+            if (lane == 0 && lds_bump(&R->z_loaded) == 8 * (i + 1) - 1)
+                __hip_atomic_fetch_add((gu32 *)zcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            YZ2_TICK(1);  // Z: row loads from the slot, arrival
+#pragma unroll
+            for (int q = 0; q < A / 2; q++) old[q] = mrow[A * q];  // (their latency lies under the transform)
+            nyq_next = (role ? a.nyq[1] : a.nyq[0])[lline + (i + 1 < n_planes ? 8 * N : 0)].x;
+            // (the lane index made opaque per plane: otherwise the ~40 LDS addresses of the transform's
+            //  exchange steps are hoisted out of the plane loop, and at 128 registers per lane spilled)
+            int bq = b;
+            asm volatile("" : "+v"(bq));
+            wave_c2r<A, P>(xv, nyq_re, L, twH, twN, bq);
+            YZ2_TICK(2);  // Z: wave-level c2r
+            double *accp = accs + 256 * (i & 1);  // (two planes apart is safe: a wave cannot load plane i + 2
+                                                  //  before every wave of this workgroup has loaded i + 1)
+            wave_fence();
+            if (role == 1) {
+                double acc = 0.;
+#pragma unroll
+                for (int q = 0; q < A; q++) {
+                    const float s0 = fmaxf(xv[q].x, 0.f), s1 = fmaxf(xv[q].y, 0.f);
+                    acc += (double)s0;
+                    acc += (double)s1;
+                }
+                accp[acc_slot] = acc;
+            }
+            // the half of its line a lane does not test goes to the partner lane
+#pragma unroll
+            for (int q = 0; q < A / 2; q++) {
+                // (selects of VALUES: `role ? xv[q] : xv[q + 8]` on the array elements themselves is a
+                //  select of addresses and sends the whole array to scratch)
+                const float2 lo = xv[q], hi = xv[q + A / 2];
+                L[q * P + bq] = make_float2(role ? lo.x : hi.x, role ? lo.y : hi.y);
+            }
+            wave_fence();
+#pragma unroll
+            for (int q = 0; q < A / 2; q++) {
+                const float2 lo = xv[q], hi = xv[q + A / 2], other = Lpartner[q * P + bq];
+                const float2 own = make_float2(role ? hi.x : lo.x, role ? hi.y : lo.y);
+                const float2 dn = make_float2(role ? other.x : own.x, role ? other.y : own.y);
+                const float2 xs = make_float2(role ? own.x : other.x, role ? own.y : other.y);
+                const float s0 = fmaxf(xs.x, 0.f), s1 = fmaxf(xs.y, 0.f);
+                const double D0 = a.rhocrit_omb * (1. + (double)fmaxf(dn.x, dmin));
+                const double D1 = a.rhocrit_omb * (1. + (double)fmaxf(dn.y, dmin));
+                const bool i0 = floor_ionises || ((double)s0 * a.ion_eff > D0);
+                const bool i1 = floor_ionises || ((double)s1 * a.ion_eff > D1);
+                uchar2 m = old[q];
+                const bool n0 = i0 && m.x == 0, n1 = i1 && m.y == 0;
+                if (n0) m.x = (unsigned char)a.r_index;
+                if (n1) m.y = (unsigned char)a.r_index;
+                if (n0 || n1 || a.store_all) mrow[A * q] = m;
+            }
+            wave_fence();  // (the regions are the next transform's)
+            // the block's partial sum: by the last wave to get here
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            int arrived = 0;
+            if (lane == 0) arrived = lds_bump(&R->z_red);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            if (arrived == 8 * (i + 1) - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                double sum = 0.;
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    double t = accp[v * 64 + lane];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+                    sum += t;
+                }
+                if (lane == 0) a.partials[(long)x * GROUP + k] = sum;
+            }
+            YZ2_TICK(3);  // Z: exchange, barrier test, mask stores, partial sum
+        }
+    }
+#if C21X_YZ_PROF
+    if ((threadIdx.x == 0 || threadIdx.x == 512) && a.prof)
+        for (int t = 0; t < 4; t++) a.prof[blockIdx.x * 8 + (threadIdx.x >> 9) * 4 + t] = prof_acc[t];
+#endif
+    if ((threadIdx.x & 511) == 0 && lds_peek(&R->dead))
+        __hip_atomic_store((gu32 *)&a.status->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct YzState {
     float2 *ring = nullptr;
     YzSync *sync = nullptr, *status = nullptr;
-    int attr_done = 0;
+    int attr_done = 0, attr2_done = 0;
     int usable = -1;
 } g_yz;
 }  // namespace
@@ -436,7 +858,7 @@ extern "C" void c21hip_ktime_end(void *scope);
 // one after the other, where the separate pass Z overlaps four workgroups per CU.
 extern "C" int c21hip_plane_yz_supported(int nx, int ny, int nz) {
     const char *e = getenv("C21CM_YZ");
-    if (!(e && e[0] == '1')) return 0;
+    if (!(e && (e[0] == '1' || e[0] == '2'))) return 0;  // 2: the role-split kernel
     if (nx != N || ny != N || nz != N) return 0;
     if (g_yz.usable < 0) {
         int dev = 0, cus = 0;
@@ -461,11 +883,11 @@ extern "C" int c21hip_plane_yz_ionise(const float *delta_work, const float *star
     hipStream_t stream = (hipStream_t)stream_;
     {   // workspace slots (c21cm_release_device_cache frees them: ask every call)
         g_yz.ring = (float2 *)c21hip_ws(250, 8 * 2 * PLANE * sizeof(float2));
-        YzSync *sy = (YzSync *)c21hip_ws(251, 2 * sizeof(YzSync));
+        YzSync *sy = (YzSync *)c21hip_ws(251, 2 * sizeof(YzSync) + 8192);
         if (!g_yz.ring || !sy) return C21CM_MEMORY_ALLOC_ERROR;
         if (sy != g_yz.sync) {  // new allocation: the sticky status starts clean
             g_yz.sync = sy;
-            g_yz.status = sy + 1;
+            g_yz.status = (YzSync *)((char *)sy + sizeof(YzSync) + 4096);
             if (hipMemsetAsync(g_yz.status, 0, sizeof(YzSync), stream) != hipSuccess) return C21CM_IO_ERROR;
         }
     }
@@ -509,9 +931,24 @@ extern "C" int c21hip_plane_yz_ionise(const float *delta_work, const float *star
         }
         g_yz.attr_done = 1;
     }
-    if (hipMemsetAsync(g_yz.sync, 0, sizeof(YzSync), stream) != hipSuccess) return C21CM_IO_ERROR;
+    const size_t lds2 = sizeof(float2) * ((size_t)N * TZ + N + 2 * H + 32 * LINE_LDS) + sizeof(Roles) +
+                        2 * 4 * 64 * sizeof(double);
+    const char *mode = getenv("C21CM_YZ");
+    const bool split = mode && mode[0] == '2';
+    if (split && !g_yz.attr2_done) {
+        if (hipFuncSetAttribute((const void *)plane_yz2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds2) != hipSuccess) {
+            c21hip_set_error("plane-fused pass Y + Z: %zu bytes of LDS refused", lds2);
+            return C21CM_IO_ERROR;
+        }
+        g_yz.attr2_done = 1;
+    }
+    if (hipMemsetAsync(a.sync, 0, sizeof(YzSync), stream) != hipSuccess) return C21CM_IO_ERROR;
     void *kt = c21hip_ktime_begin(11, stream);
-    hipLaunchKernelGGL(plane_yz_kernel, dim3(8 * GROUP), dim3(WG), lds, stream, a, tw, twH, tw);
+    if (split)
+        hipLaunchKernelGGL(plane_yz2_kernel, dim3(8 * GROUP), dim3(WG2), lds2, stream, a, tw, twH, tw);
+    else
+        hipLaunchKernelGGL(plane_yz_kernel, dim3(8 * GROUP), dim3(WG), lds, stream, a, tw, twH, tw);
     c21hip_ktime_end(kt);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) {

@@ -733,7 +733,8 @@ def test_eulerian_table_model_with_xe_grid_fused_mask_pass(api, oracle, pkg, mon
     assert out["1"][2] == pytest.approx(ref["report"].global_xH, abs=2e-4)
 
 
-def test_plane_fused_pass_yz_equals_separate_passes(api, gpu_lib, monkeypatch):
+@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_plane_fused_pass_yz_equals_separate_passes(api, gpu_lib, monkeypatch, kernel):
     """512^3, two Lagrangian grids: pass Y and the fused pass Z of a radius run as ONE persistent
     kernel that hands every x-plane over through the XCD's L2 (plane_yz.hip) -- same butterflies per
     thread, same lane-to-cell map, same order of the f_coll partial sums as the separate kernels, so
@@ -744,7 +745,7 @@ def test_plane_fused_pass_yz_equals_separate_passes(api, gpu_lib, monkeypatch):
     import torch
 
     n = 512
-    monkeypatch.setenv("C21CM_YZ", "1")  # opt-in: slower than the separate passes so far
+    monkeypatch.setenv("C21CM_YZ", kernel)  # opt-in; 2 = pass Y and pass Z on separate waves
     if not gpu_lib.c21hip_plane_yz_supported(n, n, n):
         pytest.skip("device is not 8 XCDs x 32 CUs")
     spec = W.ionize_spec(n, r_bubble_max=40.0)
@@ -753,7 +754,7 @@ def test_plane_fused_pass_yz_equals_separate_passes(api, gpu_lib, monkeypatch):
     monkeypatch.setenv("C21CM_YZ", "0")
     buf0, _, rep0 = api.ionize_grids(spec, density, n_ion)
     torch.cuda.synchronize()
-    monkeypatch.setenv("C21CM_YZ", "1")
+    monkeypatch.setenv("C21CM_YZ", kernel)
     k = spec.n_radii
     assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
     for mode in ("fast", "safe"):

@@ -5,6 +5,7 @@ where a workgroup's time goes.  GPU box only."""
 import ctypes as C
 import importlib
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -19,8 +20,8 @@ nfl.restype = C.c_size_t
 nfl.argtypes = [C.c_int] * 3
 fl = nfl(n, n, n)
 g = torch.Generator(device="cuda").manual_seed(3)
-wa = torch.randn(fl, device="cuda", generator=g)
-wb = torch.randn(fl, device="cuda", generator=g).abs()
+wa = torch.randn(fl + 4096, device="cuda", generator=g)
+wb = torch.randn(fl + 4096, device="cuda", generator=g).abs()
 mask = torch.zeros(n**3, dtype=torch.uint8, device="cuda")
 partials = torch.zeros(n * n // 4 + 64, dtype=torch.float64, device="cuda")
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -34,7 +35,8 @@ lib.c21hip_bench_pass.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
 
 
 def yz():
-    st = lib.c21hip_plane_yz_ionise(wa.data_ptr(), wb.data_ptr(), mask.data_ptr(), partials.data_ptr(), n, n, n,
+    sh = int(os.environ.get("C21CM_YZ_SHIFT", "0"))  # timing experiment: shifted base addresses (bytes)
+    st = lib.c21hip_plane_yz_ionise(wa.data_ptr() + sh, wb.data_ptr() + sh, mask.data_ptr(), partials.data_ptr(), n, n, n,
                                     5, 6.2e9, 1.0, 1, 1e-9, -1, stream)
     assert st == 0
 
@@ -64,7 +66,14 @@ if hasattr(lib, "c21hip_plane_yz_profile"):
     if lib.c21hip_plane_yz_profile(buf) == 0:
         t = torch.tensor(list(buf), dtype=torch.float64).view(256, 8) * 1e-2 / 64  # us per plane
         names = ["y_compute", "wait_slot_free", "store_arrive", "wait_plane", "rowload_arrive", "z_compute"]
+        if os.environ.get("C21CM_YZ") == "2":  # role-split kernel: Y role 0-3, Z role (a density wave) 4-7
+            names = ["y_compute", "y_wait_slot_free", "y_store_arrive", "-", "z_wait_plane", "z_rowload_arrive",
+                     "z_c2r", "z_exchange_barrier_mask_sum"]
         out["us_per_plane_mean"] = {nm: round(float(t[:, i].mean()), 3) for i, nm in enumerate(names)}
         out["us_per_plane_max"] = {nm: round(float(t[:, i].max()), 3) for i, nm in enumerate(names)}
+        if os.environ.get("C21CM_YZ_DUMP"):  # [k][xcd] of one phase (blockIdx = 8 k + xcd)
+            col = int(os.environ["C21CM_YZ_DUMP"])
+            out["dump"] = [[round(float(v), 2) for v in row] for row in t[:, col].view(32, 8)]
         out["us_per_plane_total_mean"] = round(float(t.sum(dim=1).mean()), 3)
+        out["us_per_plane_roles"] = [round(float(t[:, :3].sum(dim=1).mean()), 3), round(float(t[:, 4:].sum(dim=1).mean()), 3)]
 print(json.dumps(out))
