@@ -509,6 +509,28 @@ int c21hip_split_z_fcoll_erfc_mask(const float *split_work, float *nion_dense, c
                                    double ion_eff, int nx, int ny, int nz, double growthf, double sigma_min,
                                    double sigma_max, double delta_c, double *partials, double *sum_out,
                                    void *stream);
+/* closed-form Eulerian loop, banded barrier: the barrier of a radius decided inside its own pass Z
+ * wherever it does not depend on the exact box mean.  The barrier test is monotone in the cell's f_coll,
+ * i.e. a threshold; band_dev[0] / band_dev[1] = the thresholds at the two ends of the predicted band of
+ * mean_f_coll / mean (at or above [0]: crosses for sure; below [1]: does not).  Cells in between carry
+ * the marker 255 in first_cross and their f_coll in f_pend until the next radius' sweep (r_prev,
+ * thr_prev_dev = its exact threshold) or c21hip_eul_resolve_pending settles them.  c21hip_eul_band =
+ * finish_mean of r_cur + its exact threshold (thr_dev[r_cur]) + the check of r_cur's band (*fail_dev =
+ * the largest radius index whose band missed; c21hip_eul_rewind clears what that radius and the ones
+ * after it wrote) + the band of r_next. */
+int c21hip_split_z_fcoll_erfc_band(const float *split_work, float *f_pend, const double *band_dev,
+                                   const double *thr_prev_dev, unsigned char *first_cross, int r_index,
+                                   int r_prev, int nx, int ny, int nz, double growthf, double sigma_min,
+                                   double sigma_max, double delta_c, double *partials, double *sum_out,
+                                   void *stream);
+int c21hip_eul_band(const double *sum_dev, double ntot, int mass_dep_zeta, double f_limit,
+                    double *means_dev, int r_cur, int r_p1, int r_p2, double t_cur, double t_next,
+                    int r_next, int cur_banded, int fix_mean, double mean_f_coll, double ion_eff,
+                    double min_rel, double shift, double *band_dev, double *thr_dev, int *fail_dev,
+                    void *stream);
+int c21hip_eul_rewind(unsigned char *first_cross, int r_fail, size_t ntot, void *stream);
+int c21hip_eul_resolve_pending(int r_index, const float *f_pend, const double *thr_dev,
+                               unsigned char *first_cross, size_t ntot, void *stream);
 /* ---- plane_yz.hip: pass Y + fused pass Z of one radius in one persistent kernel, the x-plane between
  * them handed over through the XCD's L2 (512^3, two Lagrangian grids).  The Nyquist planes of the work
  * spectra take their y-transform separately (c21hip_split_y_nyq) BEFORE the fused launch. */

@@ -1567,6 +1567,16 @@ struct ZPassArgs {
     // a second sweep; riding the next radius' pass Z, which is bound by its butterflies and the erfc,
     // that sweep's 6 N bytes cost no time of their own (eulerian_mask_kernel: 0.15 ms per radius).
     const float *f_prev;
+    // EPI 7 (closed-form Eulerian loop, banded barrier): EPI 2 for THIS radius whose barrier is decided in
+    // the same sweep wherever it does not depend on the exact box mean: the correction mean_f_coll / mean
+    // is known to lie in a band (predicted from the means of the radii before it, eul_band_kernel), the
+    // barrier is monotone in it and in the cell's f_coll, so each end of the band is a threshold on the
+    // float f_coll: band[0] (at or above: crosses for sure), band[1] (below: does not).  The cells in
+    // between get the marker 255 in mask_rw and their f_coll in f_out (a sparse write: f_out is NOT a
+    // complete grid), and are settled with the exact threshold by the next radius' sweep (r_prev >= 0: the
+    // radius whose markers are outstanding, *mean_dev ITS EXACT THRESHOLD) or by eul_resolve_pending_kernel.
+    const double *band;
+    int r_prev;
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -1702,7 +1712,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
-            acc0 = (EPI == 2 || EPI == 6) ? acc0 + o0 : fmin(acc0, o0);
+            acc0 = (EPI == 2 || EPI == 6 || EPI == 7) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
             if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
@@ -1716,7 +1726,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
-                r0 = (EPI == 2 || EPI == 6) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r0 = (EPI == 2 || EPI == 6 || EPI == 7) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
@@ -2324,7 +2334,8 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
               const float2 *__restrict__ twN_global) {
     constexpr int H = P * A, NZ = 2 * H, ZWL = zw_lines(P);
     constexpr int LINE_LDS = A * (P + 1) + 4;
-    __shared__ float2 lines[ZWL * LINE_LDS];
+    static_assert(LINE_LDS % 2 == 0, "16-byte aligned line regions (EPI 7)");
+    __shared__ __attribute__((aligned(16))) float2 lines[ZWL * LINE_LDS];
     __shared__ float2 twH[H], twN[H];
     for (int t = threadIdx.x; t < H; t += kBlock) {
         twH[t] = twH_global[t];
@@ -2343,6 +2354,15 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     const float xh = a.nyq[lline].x;
     float2 fprev[EPI == 6 ? A : 1];
     uchar2 mprev[EPI == 6 ? A : 1];
+    // EPI 7: the mask row of the line as 2 A contiguous bytes per lane (16-byte loads, in flight under
+    // the transform); the lanes' (cell 2j, 2j + 1) pairs are picked out of the line's LDS region afterwards
+    constexpr int MV = (EPI == 7) ? A / 8 : 1;
+    uint4 mreg[MV];
+    if constexpr (EPI == 7) {
+#pragma unroll
+        for (int v = 0; v < MV; v++)
+            mreg[v] = reinterpret_cast<const uint4 *>(a.mask_rw + lline * NZ)[b * MV + v];
+    }
     if constexpr (EPI == 6) {  // the previous radius' f_coll and the mask rows, in flight under the transform
 #pragma unroll
         for (int q = 0; q < A; q++) {
@@ -2353,8 +2373,19 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     }
     __syncthreads();  // twiddle tables
     wave_c2r<A, P>(x, xh, L, twH, twN, b);
+    if constexpr (EPI == 7) {
+        wave_fence();  // the transform's last reads of the region
+#pragma unroll
+        for (int v = 0; v < MV; v++) reinterpret_cast<uint4 *>(L)[b * MV + v] = mreg[v];
+        wave_fence();
+    }
 
     double acc0 = 0., acc1 = 0., acc2 = 0.;
+    float t_sure = 0.f, t_maybe = 0.f;
+    if constexpr (EPI == 7) {
+        t_sure = (float)a.band[0];
+        t_maybe = (float)a.band[1];
+    }
 #pragma unroll
     for (int q = 0; q < A; q++) {
         const int j = (b + P * (q / P)) + A * (q % P);  // cells (2j, 2j + 1)
@@ -2398,6 +2429,34 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
                 grow[0] = (float)(a.const_factor / (1. + (double)grow[0]) * (double)fmaxf(v.x, 0.f));
             if (m.y == (unsigned char)a.r_index)
                 grow[1] = (float)(a.const_factor / (1. + (double)grow[1]) * (double)fmaxf(v.y, 0.f));
+        } else if (EPI == 7) {
+            const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
+            const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
+            acc0 += f0;
+            acc0 += f1;
+            const float g0 = (float)f0, g1 = (float)f1;  // what the dense grid of EPI 2 would hold
+            uchar2 m = reinterpret_cast<const uchar2 *>(L)[j];
+            float *frow = a.f_out + lline * NZ + 2 * j;
+            bool ch = false;
+            if (a.r_prev >= 0 && (m.x == 255 || m.y == 255)) {  // the previous radius' undecided cells
+                const float t_prev = (float)*a.mean_dev;
+                if (m.x == 255) m.x = (frow[0] >= t_prev) ? (unsigned char)a.r_prev : (unsigned char)0;
+                if (m.y == 255) m.y = (frow[1] >= t_prev) ? (unsigned char)a.r_prev : (unsigned char)0;
+                ch = true;
+            }
+            if (m.x == 0 && g0 >= t_maybe) {
+                const bool sure = g0 >= t_sure;
+                m.x = sure ? (unsigned char)a.r_index : (unsigned char)255;
+                if (!sure) frow[0] = g0;
+                ch = true;
+            }
+            if (m.y == 0 && g1 >= t_maybe) {
+                const bool sure = g1 >= t_sure;
+                m.y = sure ? (unsigned char)a.r_index : (unsigned char)255;
+                if (!sure) frow[1] = g1;
+                ch = true;
+            }
+            if (ch) reinterpret_cast<uchar2 *>(L)[j] = m;
         } else if (EPI == 2 || EPI == 6) {
             const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
             const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
@@ -2425,12 +2484,21 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             }
         }
     }
+    if constexpr (EPI == 7) {  // changed 16-byte pieces of the mask row back to the grid
+        wave_fence();
+#pragma unroll
+        for (int v = 0; v < MV; v++) {
+            const uint4 n = reinterpret_cast<const uint4 *>(L)[b * MV + v], o = mreg[v];
+            if (n.x != o.x || n.y != o.y || n.z != o.z || n.w != o.w)
+                reinterpret_cast<uint4 *>(a.mask_rw + lline * NZ)[b * MV + v] = n;
+        }
+    }
     if (EPI != 0 && EPI != 4 && EPI != 5) {
         __shared__ double red0[kBlock / 64], red1[kBlock / 64], red2[kBlock / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
-            acc0 = (EPI == 2 || EPI == 6) ? acc0 + o0 : fmin(acc0, o0);
+            acc0 = (EPI == 2 || EPI == 6 || EPI == 7) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
             if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
@@ -2444,7 +2512,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
-                r0 = (EPI == 2 || EPI == 6) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r0 = (EPI == 2 || EPI == 6 || EPI == 7) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
@@ -2601,6 +2669,111 @@ __device__ __forceinline__ void wave3_c2r(float2 (&x)[8], float xh, float2 *L, c
 #pragma unroll
         for (int c = 0; c < 8; c++) x[c] = L[(8 * j0 + c) * M2 + j1];
         Dft<8, +1>::run(x);  // over c: z[p + 64 j2]
+    }
+}
+
+// The forward counterpart (round 4): the mirror image of wave3_c2r, same LDS arrangements walked
+// backwards.  j = j0 + 8 j1 + 64 j2, k = c + 8 b + 64 a, w = exp(-2 pi i / 512):
+//   stage 1 (lane j0 + 8 j1):  U_j0,j1[c] = sum_j2 z[j] w8^(j2 c)                 x w^(8 j1 c)
+//   stage 2 (lane 8 j0 + c):   V_j0,c[b]  = sum_j1 U_j0,j1[c] w8^(j1 b)           x w^(j0 (c + 8 b))
+//   stage 3 (lane c + 8 b):    Zf[64 a + c + 8 b] = sum_j0 V_j0,c[b] w8^(j0 a)
+// then the Hermitian post-processing of wave_r2c with the partner Zf[H - k] from the line's LDS copy.
+// In: x[j2] = z[p + 64 j2] (512-byte runs).  Out: x[a] = X[64 a + p] (k < H), *xh = X[H] -- the layout
+// wave3_c2r starts from.  Eight values per lane instead of the 32 of wave_r2c<32, 16>, whose radix-32
+// butterflies fill the register file (one wave per SIMD: 3.55 ms per 1024^3 grid, 2.4 TB/s).
+__device__ __forceinline__ void wave3_r2c(float2 (&x)[8], float *xh, float2 *L, const float2 *twH,
+                                          const float2 *twN, int p) {
+    constexpr int H = 512, M1 = 72, M2 = 9;
+    Dft<8, -1>::run(x);  // over j2: U[c]
+    {
+        const int j0 = p & 7, j1 = p >> 3;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            L[(8 * j0 + c) * M2 + j1] = (c == 0) ? x[0] : cmul(x[c], twH[8 * j1 * c]);
+    }
+    wave_fence();
+    {
+        const int j0 = p >> 3, c = p & 7;
+#pragma unroll
+        for (int j1 = 0; j1 < 8; j1++) x[j1] = L[p * M2 + j1];
+        Dft<8, -1>::run(x);  // over j1: V[b]
+        wave_fence();        // the reads of the M2 arrangement are done before the M1 one overwrites it
+#pragma unroll
+        for (int b = 0; b < 8; b++) L[j0 * M1 + 8 * b + c] = cmul(x[b], twH[j0 * (c + 8 * b)]);
+    }
+    wave_fence();
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0++) x[j0] = L[j0 * M1 + p];
+    Dft<8, -1>::run(x);  // over j0: Zf[64 a + p]
+    wave_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) L[a * M1 + p] = x[a];
+    wave_fence();
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const int k = 64 * a + p;
+        const int kp = (H - k) & (H - 1);
+        const float2 Z = x[a], B = L[(kp >> 6) * M1 + (kp & 63)];
+        if (k == 0) {
+            x[a] = make_float2(Z.x + Z.y, 0.f);
+            *xh = Z.x - Z.y;
+        } else {
+            const float2 E = make_float2(0.5f * (Z.x + B.x), 0.5f * (Z.y - B.y));
+            const float2 D = make_float2(0.5f * (Z.x - B.x), 0.5f * (Z.y + B.y));
+            const float2 wD = cmul(D, twN[k]);
+            x[a] = make_float2(E.x + wD.y, E.y - wD.x);  // E - i w_k D
+        }
+    }
+}
+
+// Forward pass Z of 1024-point z-lines on wave3_r2c: LPW lines per wave one after the other (the loads
+// of all of them in flight first), four waves per workgroup.
+template <int LPW>
+__global__ void __launch_bounds__(kBlock)
+zw3_r2c_kernel(ZFwdArgs a, const float2 *__restrict__ twH_global,
+               const float2 *__restrict__ twN_global) {
+    constexpr int H = 512, LINE_LDS = 576 + 8;
+    __shared__ float2 lines[(kBlock / 64) * LINE_LDS];
+    __shared__ float2 twH[H], twN[H];
+    for (int t = threadIdx.x; t < H; t += kBlock) {
+        twH[t] = twH_global[t];
+        twN[t] = twN_global[t];
+    }
+    const int p = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *L = lines + wave * LINE_LDS;
+    const bool clip = a.lo <= a.hi;
+    float2 x[LPW][8];
+    long line[LPW], lline[LPW];
+#pragma unroll
+    for (int u = 0; u < LPW; u++) {
+        line[u] = ((long)blockIdx.x * (kBlock / 64) + wave) * LPW + u;
+        lline[u] = logical_line(line[u], a.ny, a.lb);
+        const float2 *src = reinterpret_cast<const float2 *>(a.in + lline[u] * a.in_zstride);
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[u][q] = src[p + 64 * q];
+    }
+    __syncthreads();  // twiddle tables
+#pragma unroll
+    for (int u = 0; u < LPW; u++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            float2 v = x[u][q];
+            if (clip) {
+                v.x = (float)fmax(fmin((double)v.x * a.factor, a.hi), a.lo);
+                v.y = (float)fmax(fmin((double)v.y * a.factor, a.hi), a.lo);
+            } else if (a.factor != 1.0) {
+                v.x = (float)((double)v.x * a.factor);
+                v.y = (float)((double)v.y * a.factor);
+            }
+            x[u][q] = v;
+        }
+        float xh = 0.f;
+        if (u > 0) wave_fence();  // the previous line's partner reads
+        wave3_r2c(x[u], &xh, L, twH, twN, p);
+        float2 *dst = a.main + line[u] * H;
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[64 * q + p] = x[u][q];
+        if (p == 0) a.nyq[lline[u]] = make_float2(xh, 0.f);
     }
 }
 
@@ -2841,7 +3014,23 @@ int launch_z_r2c(const ZFwdArgs &a, long nlines, hipStream_t stream) {
     return 0;
 }
 
+// C21CM_Z_R2C=w: 1024-point forward z-lines on the 32-values-per-lane kernel (A/B switch)
+bool zw3_r2c_on() {
+    const char *e = getenv("C21CM_Z_R2C");
+    return !(e && e[0] == 'w');
+}
+
 int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
+    if (nz == 1024 && a.in_zstride % 2 == 0 && zw3_selected(nz, nlines) && nlines % (2 * (kBlock / 64)) == 0 &&
+        zw3_r2c_on()) {
+        const float2 *twH = twiddles(nz / 2);
+        const float2 *twN = twiddles(nz);
+        if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+        hipLaunchKernelGGL((zw3_r2c_kernel<2>), dim3((unsigned)(nlines / (2 * (kBlock / 64)))), dim3(kBlock), 0,
+                           stream, a, twH, twN);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (const int zwl = (a.in_zstride % 2 == 0) ? zw_lines_of(nz, nlines) : 0) {
         const float2 *twH = twiddles(nz / 2);
         const float2 *twN = twiddles(nz);
@@ -2890,8 +3079,8 @@ int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) 
         LAUNCH_CHECK();
         return 0;
     }
-    if constexpr (EPI == 6) {
-        c21hip_set_error("pass Z with the deferred barrier (EPI 6) needs the wave-level kernel");
+    if constexpr (EPI == 6 || EPI == 7) {
+        c21hip_set_error("pass Z with the deferred / banded barrier (EPI 6, 7) needs the wave-level kernel");
         return C21CM_VALUE_ERROR;
     } else
     switch (nz) {
@@ -3842,6 +4031,51 @@ extern "C" int c21hip_split_z_fcoll_erfc_mask(const float *split_work, float *ni
             z.sig = 1.0 / ((double)(float)growthf * (sqrt(2.) * sqrt((double)(ss * ss - sl * sl))));
     }
     int st = dispatch_z_c2r<6>(nz, z, nlines, (hipStream_t)stream);
+    if (st) return st;
+    return c21hip_reduce_sum(partials, (int)(nlines / LZ_PLAIN), sum_out, stream);
+}
+
+// c21hip_split_z_fcoll_erfc of THIS radius with its barrier decided in the same sweep wherever the
+// decision does not depend on the exact box mean (EPI 7): band_dev = the two thresholds of this radius
+// (eul_band_kernel), f_pend receives the f_coll of the undecided cells (marker 255 in first_cross);
+// r_prev >= 0: the radius whose markers are still outstanding, *thr_prev_dev its exact threshold.
+extern "C" int c21hip_split_z_fcoll_erfc_band(const float *split_work, float *f_pend,
+                                              const double *band_dev, const double *thr_prev_dev,
+                                              unsigned char *first_cross, int r_index, int r_prev, int nx,
+                                              int ny, int nz, double growthf, double sigma_min,
+                                              double sigma_max, double delta_c, double *partials,
+                                              double *sum_out, void *stream) {
+    if (!c21hip_z_fcoll_erfc_mask_supported(nx, ny, nz) || r_index <= 0 || r_index >= 255 || r_prev >= 255) {
+        c21hip_set_error("pass Z with the banded barrier: unsupported box or radius index");
+        return C21CM_VALUE_ERROR;
+    }
+    const long nlines = (long)nx * ny;
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out_scale = 1.0f;
+    z.f_out = f_pend;
+    z.band = band_dev;
+    z.mean_dev = thr_prev_dev;
+    z.mask_rw = first_cross;
+    z.r_index = r_index;
+    z.r_prev = r_prev;
+    z.p0 = partials;
+    z.delta_c = delta_c;
+    z.sig = -1.;
+    {
+        const float ss = (float)sigma_min, sl = (float)sigma_max;  // hmf.c:1221-1232, as above
+        if (sl > ss) {
+            c21hip_set_error("FgtrM requested in a region where M_min > M_max (sigma %g > %g)",
+                             (double)sl, (double)ss);
+            return C21CM_VALUE_ERROR;
+        }
+        if (sl != ss)
+            z.sig = 1.0 / ((double)(float)growthf * (sqrt(2.) * sqrt((double)(ss * ss - sl * sl))));
+    }
+    int st = dispatch_z_c2r<7>(nz, z, nlines, (hipStream_t)stream);
     if (st) return st;
     return c21hip_reduce_sum(partials, (int)(nlines / LZ_PLAIN), sum_out, stream);
 }

@@ -521,6 +521,134 @@ eulerian_mask_kernel(c21hip_ionize_args a, const float *__restrict__ nion_dense,
     }
 }
 
+// ---- closed-form Eulerian loop, banded barrier (pass Z EPI 7, fft_native.hip) --------------------
+// eulerian_mask_kernel's test on one cell: f (the float the dense grid holds) against the barrier with
+// the mean fix `mf`.
+__device__ __forceinline__ bool eul_barrier(double mf, float f, int mass_dep_zeta, double f_limit,
+                                            double ion_eff) {
+    double c = mf * (double)f;
+    if (mass_dep_zeta && c < f_limit) c = f_limit;
+    return c * ion_eff > (1. - 0.);
+}
+// The test is monotone in f >= 0 (rounded products of non-negative factors are), so it IS a threshold:
+// the smallest non-negative float that passes, found by bisection on the bit pattern (+inf: none does;
+// 0: all do).  A sweep then decides a cell with one float comparison instead of the fp64 sequence.
+__device__ float eul_threshold(double mf, int mass_dep_zeta, double f_limit, double ion_eff) {
+    if (eul_barrier(mf, 0.f, mass_dep_zeta, f_limit, ion_eff)) return 0.f;
+    unsigned lo = 0u, hi = 0x7f800000u;  // barrier(lo) false; hi = +inf stands for "none"
+    if (!eul_barrier(mf, __uint_as_float(hi), mass_dep_zeta, f_limit, ion_eff)) return __uint_as_float(hi);
+    while (hi - lo > 1u) {
+        const unsigned mid = lo + (hi - lo) / 2u;
+        if (eul_barrier(mf, __uint_as_float(mid), mass_dep_zeta, f_limit, ion_eff))
+            hi = mid;
+        else
+            lo = mid;
+    }
+    return __uint_as_float(hi);
+}
+// finish_mean_kernel for the radius r_cur just summed, then (i) thr[r_cur] = the exact threshold of its
+// barrier (mean fix mean_f_coll / mean); if r_cur was itself decided on a band: does the exact threshold
+// lie between the band's two?  If not the definite decisions of its sweep cannot be trusted: *fail = the
+// largest such radius index, and the host reruns the loop from that radius on with the dense sweeps
+// (eul_rewind_kernel restores the grid to what it was before that radius); (ii) the band of the next
+// radius r_next: its mean extrapolated linearly in ln R from the last two means (t = the step ratio),
+// widened by min_rel of itself and by 8 x the error the same extrapolation made for r_cur; band[2 r] =
+// threshold at the lower end of mean_f_coll / mean (cells at or above it cross whatever the exact mean
+// turns out to be), band[2 r + 1] = threshold at the upper end (cells below it do not).
+__global__ void eul_band_kernel(const double *sum, double ntot, int mass_dep_zeta, double f_limit,
+                                double *means, int r_cur, int r_p1, int r_p2, double t_cur, double t_next,
+                                int r_next, int cur_banded, int fix_mean, double mean_f_coll,
+                                double ion_eff, double min_rel, double shift, double *band, double *thr,
+                                int *fail) {
+    double m = *sum / ntot;
+    if (mass_dep_zeta) {
+        if (m <= f_limit) m = f_limit;
+    } else {
+        if (m <= kFractFloatErr) m = kFractFloatErr;
+    }
+    means[r_cur] = m;
+    const float t_exact = eul_threshold(fix_mean ? mean_f_coll / m : 1., mass_dep_zeta, f_limit, ion_eff);
+    thr[r_cur] = (double)t_exact;
+    if (cur_banded) {
+        if (!((float)band[2 * r_cur + 1] <= t_exact && t_exact <= (float)band[2 * r_cur]) && *fail < r_cur)
+            *fail = r_cur;
+    }
+    if (r_next < 0) return;
+    double lo = 1., hi = 1.;
+    if (fix_mean) {
+        const double m1 = r_p1 >= 0 ? means[r_p1] : m;
+        const double pred = (m + (m - m1) * t_next) * (1. + shift);
+        double err = fabs(m - m1);
+        if (r_p2 >= 0) err = fabs(m - (m1 + (m1 - means[r_p2]) * t_cur));
+        const double w = fmax(min_rel * fabs(pred), 8. * err);
+        const double mean_lo = pred - w, mean_hi = pred + w;
+        lo = mean_f_coll / mean_hi;
+        hi = mean_lo > 0. ? mean_f_coll / mean_lo : (double)INFINITY;
+    }
+    band[2 * r_next] = (double)eul_threshold(lo, mass_dep_zeta, f_limit, ion_eff);
+    band[2 * r_next + 1] = (double)eul_threshold(hi, mass_dep_zeta, f_limit, ion_eff);
+}
+
+// First-crossing grid as it was before radius index r_fail of a descending loop: crossings of that and
+// of later (smaller) radii and outstanding markers cleared.
+__global__ void __launch_bounds__(kBlock)
+eul_rewind_kernel(unsigned char *__restrict__ first_cross, int r_fail, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock) {
+        uint4 w = reinterpret_cast<const uint4 *>(first_cross)[i];
+        unsigned wv[4] = {w.x, w.y, w.z, w.w};
+        bool ch = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            unsigned v = wv[e];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned m = (v >> (8 * k)) & 0xffu;
+                if (m != 0 && (m <= (unsigned)r_fail || m == 255u)) {
+                    v &= ~(0xffu << (8 * k));
+                    ch = true;
+                }
+            }
+            wv[e] = v;
+        }
+        if (ch) reinterpret_cast<uint4 *>(first_cross)[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+}
+
+// The markers (255) a banded sweep left in the first-crossing grid and no later sweep settled:
+// eulerian_mask_kernel's test on those cells with the exact mean of radius r_index, as the threshold
+// *thr_dev that test amounts to (eul_band_kernel).
+__global__ void __launch_bounds__(kBlock)
+eul_resolve_pending_kernel(int r_index, const float *__restrict__ f_pend,
+                           const double *__restrict__ thr_dev, unsigned char *__restrict__ first_cross,
+                           size_t n16) {
+    const float t = (float)*thr_dev;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock) {
+        uint4 w = reinterpret_cast<const uint4 *>(first_cross)[i];
+        unsigned wv[4] = {w.x, w.y, w.z, w.w};
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const unsigned v = wv[e];
+            if ((v & 0xffu) == 0xffu || (v & 0xff00u) == 0xff00u || (v & 0xff0000u) == 0xff0000u ||
+                (v & 0xff000000u) == 0xff000000u)
+                any = true;
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            unsigned v = wv[e];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (((v >> (8 * k)) & 0xffu) != 0xffu) continue;
+                const unsigned r = (f_pend[i * 16 + e * 4 + k] >= t) ? (unsigned)r_index : 0u;
+                v = (v & ~(0xffu << (8 * k))) | (r << (8 * k));
+            }
+            wv[e] = v;
+        }
+        reinterpret_cast<uint4 *>(first_cross)[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+}
+
 // ---- find_ionised_regions with a recombination model -------------------------------------------
 // IonisationBox.c:1031-1200 with RECOMB_MODEL != none: recombinations per baryon enter the barrier,
 //   f zeta > (1 - x_e)(1 + rec),   rec = N_rec / (1 + delta_R)
@@ -1306,6 +1434,42 @@ extern "C" int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *ni
     const size_t ntot = (size_t)a->nx * a->ny * a->nz;
     hipLaunchKernelGGL(eulerian_mask_kernel, dim3(grid_for(ntot / 4 + 1)), dim3(kBlock), 0,
                        (hipStream_t)stream, *a, nion_dense, xe_dense, mean_dev, first_cross, ntot);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_eul_band(const double *sum_dev, double ntot, int mass_dep_zeta, double f_limit,
+                               double *means_dev, int r_cur, int r_p1, int r_p2, double t_cur,
+                               double t_next, int r_next, int cur_banded, int fix_mean,
+                               double mean_f_coll, double ion_eff, double min_rel, double shift,
+                               double *band_dev, double *thr_dev, int *fail_dev, void *stream) {
+    hipLaunchKernelGGL(eul_band_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sum_dev, ntot,
+                       mass_dep_zeta, f_limit, means_dev, r_cur, r_p1, r_p2, t_cur, t_next, r_next,
+                       cur_banded, fix_mean, mean_f_coll, ion_eff, min_rel, shift, band_dev, thr_dev,
+                       fail_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_eul_rewind(unsigned char *first_cross, int r_fail, size_t ntot, void *stream) {
+    if (ntot % 16) {
+        c21hip_set_error("banded barrier: the box is not a multiple of 16 cells");
+        return C21CM_VALUE_ERROR;
+    }
+    hipLaunchKernelGGL(eul_rewind_kernel, dim3(grid_for(ntot / 16)), dim3(kBlock), 0, (hipStream_t)stream,
+                       first_cross, r_fail, ntot / 16);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_eul_resolve_pending(int r_index, const float *f_pend, const double *thr_dev,
+                                          unsigned char *first_cross, size_t ntot, void *stream) {
+    if (ntot % 16) {
+        c21hip_set_error("banded barrier: the box is not a multiple of 16 cells");
+        return C21CM_VALUE_ERROR;
+    }
+    hipLaunchKernelGGL(eul_resolve_pending_kernel, dim3(grid_for(ntot / 16)), dim3(kBlock), 0,
+                       (hipStream_t)stream, r_index, f_pend, thr_dev, first_cross, ntot / 16);
     LAUNCH_CHECK();
     return 0;
 }

@@ -120,7 +120,11 @@ typedef struct {
 #define SC_MEANS_M (SC_SUMS_M + C21CM_MAX_RADII)
 #define SC_MINMAX_M (SC_MEANS_M + C21CM_MAX_RADII)
 #define SC_PAIR (SC_MINMAX_M + 6)
-#define SC_COUNT (SC_PAIR + 2)
+/* closed-form Eulerian loop, banded barrier: the two thresholds of a radius' band, failure flag */
+#define SC_BAND (SC_PAIR + 2)
+#define SC_BANDX (SC_BAND + 2 * C21CM_MAX_RADII) /* exact threshold of every radius */
+#define SC_BANDFAIL (SC_BANDX + C21CM_MAX_RADII) /* an int stored in a double-sized cell */
+#define SC_COUNT (SC_BANDFAIL + 1)
 
 #define TRY(expr)                   \
     do {                            \
@@ -335,6 +339,14 @@ typedef struct {
     int eul_pend, eul_pend_buf;      /* radius index whose barrier is still owed (-1: none), its f_coll buffer */
     unsigned char *eul_pend_mask;
     float *nion_dense2;
+    /* closed-form Eulerian loop, banded barrier (pass Z EPI 7): the barrier of a radius decided inside
+     * its own pass Z from a predicted band of the mean fix; see eul_band_ok() */
+    int band_off;        /* 1: a band missed in this call -- the loop reruns on the dense sweeps */
+    int band_used;       /* a banded sweep ran: the failure flag is read before the mask is used */
+    int band_next;       /* radius index the device holds a band for (-1: none) */
+    int band_pend;       /* radius whose markers (255) are outstanding in band_mask (-1: none) */
+    int band_h1, band_h2, band_hn; /* the last two radii of this loop with a mean on the device */
+    unsigned char *band_mask;
     const float *cur_xe; /* fused recombination loop with an x_e grid: its work spectrum of the radius in hand */
     int yz;              /* pass Y + fused pass Z as ONE plane-fused kernel (plane_yz.hip: 512^3, two grids) */
     int yz_now;          /* ... for the radius z_ionise_radius is called for (its main blocks skipped pass Y) */
@@ -441,6 +453,10 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->eul_pend_buf = 0;
     c->eul_pend_mask = NULL;
     c->nion_dense2 = NULL;
+    c->band_off = c->band_used = 0;
+    c->band_next = c->band_pend = c->band_h1 = c->band_h2 = -1;
+    c->band_hn = 0;
+    c->band_mask = NULL;
     c->sphere = s->ionise_entire_sphere;
     c->mini = s->use_mini_halos && !c->lagrangian;
     c->lag_mini = s->use_mini_halos && c->lagrangian;
@@ -1110,6 +1126,68 @@ static int eul_defer_ok(ion_ctx *c) {
     return c->nion_dense2 != NULL;
 }
 
+/* Banded barrier of the closed-form Eulerian loop (default where the wave-level pass Z serves the
+ * z-lines; C21CM_EUL_BAND=0: the dense f_coll grid + eulerian_mask_kernel of every radius).
+ * The barrier of a radius needs the box mean of its f_coll grid (IonisationBox.c:1022-1027), which is
+ * what forces a second sweep per radius.  But the test  f mean_f_coll / mean zeta > 1  is monotone in
+ * the correction, and the mean is a smooth function of ln R: extrapolated from the two radii before it,
+ * it is known to a fraction of a per cent BEFORE the sweep.  Pass Z (EPI 7) therefore decides every cell
+ * on which both ends of the band agree, and leaves a marker + the cell's f_coll for the others (a few
+ * per mille), which the next radius' sweep settles with the exact mean.  eul_band_kernel checks that the
+ * exact correction fell inside the band; if it ever does not, the whole loop is rerun on the dense
+ * sweeps -- the result is the same first-crossing grid bit for bit either way
+ * (test_closed_form_loop_banded_barrier_equals_dense_sweeps).  The first two radii of a loop, radii
+ * whose sigmas coincide and the last radius of a loop that stops above index 0 (its dense grid is
+ * box->unnormalised_nion) take the dense sweeps. */
+static int eul_band_ok(ion_ctx *c) {
+    const char *e = getenv("C21CM_EUL_BAND");
+    if ((e && e[0] == '0') || c->band_off || c->s->n_radii >= 255) return 0;
+    return c21hip_z_fcoll_erfc_mask_supported(c->nx, c->ny, c->nz);
+}
+
+/* settle the markers a banded sweep left behind (no later sweep of the loop did) */
+static int eul_band_flush(ion_ctx *c) {
+    if (c->band_pend < 0) return 0;
+    const int R = c->band_pend;
+    c->band_pend = -1;
+    return c21hip_eul_resolve_pending(R, c->nion_dense, c->scalars + SC_BANDX + R, c->band_mask, c->ntot,
+                                      c->stream);
+}
+
+/* End of a loop with banded sweeps: markers settled, then did every band hold?  *redo = the largest
+ * radius index whose band missed (0: none): the first-crossing grid is rewound to its state before that
+ * radius and the caller runs its radii <= *redo again (band_off is set: dense sweeps). */
+static int eul_band_finish(ion_ctx *c, unsigned char *mask, int *redo) {
+    *redo = 0;
+    int st = eul_band_flush(c);
+    if (st || !c->band_used) return st;
+    double cell;
+    int fail;
+    if ((st = c21hip_d2h(&cell, c->scalars + SC_BANDFAIL, sizeof(cell), c->stream))) return st;
+    if ((st = c21hip_sync(c->stream))) return st;
+    memcpy(&fail, &cell, sizeof(int));
+    if (getenv("C21CM_EUL_BAND_DEBUG")) {
+        double b[2 * C21CM_MAX_RADII], t[C21CM_MAX_RADII], m[C21CM_MAX_RADII];
+        if (!c21hip_d2h(b, c->scalars + SC_BAND, sizeof(b), c->stream) &&
+            !c21hip_d2h(t, c->scalars + SC_BANDX, sizeof(t), c->stream) &&
+            !c21hip_d2h(m, c->scalars + SC_MEANS, sizeof(m), c->stream) && !c21hip_sync(c->stream))
+            for (int r = c->s->n_radii - 1; r >= 1; r--)
+                fprintf(stderr, "band r=%3d mean=%.9e threshold=%.9e sure>=%.9e maybe>=%.9e rel=[%+.2e, %+.2e]\n",
+                        r, m[r], t[r], b[2 * r], b[2 * r + 1], b[2 * r] / t[r] - 1., b[2 * r + 1] / t[r] - 1.);
+        fprintf(stderr, "band fail=%d\n", fail);
+    }
+    c->band_used = 0;
+    c->band_next = c->band_h1 = c->band_h2 = -1;
+    c->band_hn = 0;
+    if (fail > 0) {
+        c->band_off = 1;
+        *redo = fail;
+        if ((st = c21hip_memset(c->scalars + SC_BANDFAIL, 0, sizeof(double), c->stream))) return st;
+        return c21hip_eul_rewind(mask, fail, c->ntot, c->stream);
+    }
+    return 0;
+}
+
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -1163,6 +1241,61 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
             c->eul_pend = R_ct;
             c->eul_pend_buf = cur;
             c->eul_pend_mask = first_cross;
+            goto done;
+        }
+        if (s->fcoll_mode == C21CM_FCOLL_ERFC && !s->use_ts_fluct && eul_band_ok(c)) {
+            const char *e_rel = getenv("C21CM_EUL_BAND_MINREL"), *e_shift = getenv("C21CM_EUL_BAND_SHIFT");
+            double min_rel = e_rel ? atof(e_rel) : 0.003;
+            if (!(min_rel >= 0.)) min_rel = 0.003;
+            const double shift = e_shift ? atof(e_shift) : 0.; /* test hook: a prediction off by this fraction */
+            const int sig_ok = (float)s->sigma_maxmass[R_ct] != (float)s->sigma_minmass;
+            /* (index 1 sits a step above the cell scale, where the mean leaves the curve the larger radii
+             * drew -- 1.6 % at 512^3 against the < 0.1 % of every other step: dense) */
+            const int banded = c->band_next == R_ct && sig_ok && R_ct >= 2 &&
+                               (R_ct > s->r_lowest || s->r_lowest == 0) &&
+                               (c->band_pend < 0 || c->band_mask == first_cross);
+            if (banded) {
+                TRY(c21hip_split_z_fcoll_erfc_band(
+                    c->delta_work, c->nion_dense, c->scalars + SC_BAND + 2 * R_ct,
+                    c->scalars + SC_BANDX + (c->band_pend >= 0 ? c->band_pend : 0), first_cross, R_ct,
+                    c->band_pend, c->nx, c->ny, c->nz, s->growth_factor, s->sigma_minmass,
+                    s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev, c->stream));
+                c->band_pend = R_ct;
+                c->band_mask = first_cross;
+                c->band_used = 1;
+            } else {
+                TRY(eul_band_flush(c)); /* the dense sweep overwrites the marked cells' f_coll */
+                TRY(c21hip_split_z_fcoll_erfc(c->delta_work, c->nion_dense, c->nx, c->ny, c->nz,
+                                              s->growth_factor, s->sigma_minmass,
+                                              s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev,
+                                              c->stream));
+            }
+            {
+                const int h1 = c->band_h1, h2 = c->band_h2;
+                const int will_next = next_R >= 1 && c->band_hn >= 1 && sig_ok;
+                double t_cur = 0., t_next = 0.;
+                if (h1 >= 0) {
+                    const double d1 = log(s->R[R_ct]) - log(s->R[h1]);
+                    if (next_R >= 1) t_next = (log(s->R[next_R]) - log(s->R[R_ct])) / d1;
+                    if (h2 >= 0) t_cur = d1 / (log(s->R[h1]) - log(s->R[h2]));
+                }
+                TRY(c21hip_eul_band(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                                    c->scalars + SC_MEANS, R_ct, h1, h2, t_cur, t_next,
+                                    will_next ? next_R : -1, banded, s->fix_mean, s->mean_f_coll,
+                                    s->ion_eff_factor, min_rel, shift, c->scalars + SC_BAND,
+                                    c->scalars + SC_BANDX, (int *)(c->scalars + SC_BANDFAIL), c->stream));
+                c->band_next = will_next ? next_R : -1;
+                if (sig_ok) {
+                    c->band_h2 = h1;
+                    c->band_h1 = R_ct;
+                    c->band_hn++;
+                } else { /* a radius without sources: its clamped mean is no point of the curve */
+                    c->band_h1 = c->band_h2 = -1;
+                    c->band_hn = 0;
+                }
+            }
+            if (!banded)
+                TRY(c21hip_eulerian_mask(&args, c->nion_dense, NULL, mean_dev, first_cross, c->stream));
             goto done;
         }
         if (s->fcoll_mode == C21CM_FCOLL_ERFC) {
@@ -1632,8 +1765,16 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         for (int R_ct = R_start; R_ct--;) {
             if (R_ct < spec->r_lowest) break; /* IonisationBox.c:1537-1541 */
             if (R_ct == 0 && mask_pending) {
-                mask_pending = 0;
                 TRY(eul_flush_pending(&c, 0)); /* the last radius' barrier of the closed-form loop */
+                {
+                    int redo = 0; /* banded barrier: markers settled; a missed band reruns its radii */
+                    TRY(eul_band_finish(&c, c.mask, &redo));
+                    if (redo) {
+                        R_ct = redo + 1;
+                        continue;
+                    }
+                }
+                mask_pending = 0;
                 if (c.fused && !c.sphere && !c.fused_rc) {
                     TRY(flush_deferred(&c));
                     TRY(final_step(&c, c.mask, 0));
@@ -1665,6 +1806,13 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         }
         TRY(flush_deferred(&c));
         if (mask_pending) {
+            int redo = 0; /* a loop that stopped above index 0 (r_lowest): same check as above */
+            TRY(eul_band_finish(&c, c.mask, &redo));
+            if (redo) {
+                for (int R_ct = redo; R_ct >= spec->r_lowest && R_ct >= 1; R_ct--)
+                    TRY(one_radius(&c, R_ct, c.mask, (R_ct - 1 >= spec->r_lowest) ? R_ct - 1 : -1));
+                TRY(flush_deferred(&c));
+            }
             TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot, spec->redshift,
                                          c.xH, c.zre, c.ntot, stream));
             if (c.sphere) TRY(paint_spheres(&c, c.mask));
@@ -1773,9 +1921,17 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
     } else if (c.fused) {
         TRY(fused_loop(&c, spec->n_radii - 1 - rank, world, spec->r_lowest, first_cross));
     } else {
-        for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
-            if (R_ct < spec->r_lowest) break;
-            TRY(one_radius(&c, R_ct, first_cross, R_ct - world));
+        for (int attempt = 0, from = spec->n_radii; attempt < 2; attempt++) {
+            int redo = 0;
+            for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
+                if (R_ct < spec->r_lowest) break;
+                if (R_ct > from) continue; /* second attempt: from the radius whose band missed */
+                TRY(one_radius(&c, R_ct, first_cross, R_ct - world));
+            }
+            TRY(eul_flush_pending(&c, 1));
+            TRY(eul_band_finish(&c, first_cross, &redo)); /* banded barrier: markers settled, bands checked */
+            if (!redo) break;
+            from = redo;
         }
     }
     TRY(flush_deferred(&c));

@@ -815,3 +815,71 @@ def test_closed_form_loop_deferred_barrier_equals_separate_sweep(api, r_lowest, 
         torch.cuda.synchronize()
         assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction)
         assert rep0.global_xH == rep2.global_xH
+
+
+@pytest.mark.parametrize("r_lowest", [0, 2])
+@pytest.mark.parametrize("mass_dep_zeta", [False, True])
+def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, r_lowest, mass_dep_zeta, monkeypatch, capfd):
+    """CONST-ION-EFF closed form on the wave-level pass Z (the default): the barrier of a radius is decided
+    INSIDE its own pass Z from a predicted band of the mean fix (monotone test: cells on which both ends
+    agree are final, the others carry a marker until the exact mean is known).  Every output equals the
+    dense-sweep sequence (C21CM_EUL_BAND=0: dense f_coll grid + eulerian_mask_kernel per radius) bit for
+    bit, single pass and sharded over 2 and 3 ranks; a prediction that is off (test hook
+    C21CM_EUL_BAND_SHIFT) is detected on the device, the grid is rewound to its state before that radius and the
+    loop reruns from there on the dense sweeps."""
+    import torch
+
+    n, nz = 64, 512
+    spec = W.ionize_spec(n, hii_dim_z=nz, mode=W.FCOLL_ERFC, r_bubble_max=9.0)
+    spec.r_lowest = r_lowest
+    if mass_dep_zeta:
+        spec.mass_dep_zeta = 1
+        spec.f_limit_acg = 1e-4
+    density = torch.from_numpy(W.density_field_numpy((n, n, nz), seed=21)).cuda()
+    monkeypatch.setenv("C21CM_EUL_BAND", "0")
+    buf0, _, rep0 = api.ionize_grids(spec, density)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("C21CM_EUL_BAND")
+    monkeypatch.setenv("C21CM_EUL_BAND_DEBUG", "1")
+    buf1, _, rep1 = api.ionize_grids(spec, density)
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    assert "band fail=0" in err, err  # the banded sweeps ran and every band held
+    monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
+    assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
+    names = ["neutral_fraction", "z_reion", "kinetic_temperature"]
+    if r_lowest > 0:
+        names.append("unnormalised_nion")  # the last radius' dense grid (index 0 rewrites it otherwise)
+    for name in names:
+        assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
+    k = spec.n_radii
+    assert list(rep0.f_coll_grid_mean[:k]) == list(rep1.f_coll_grid_mean[:k])
+    assert rep0.global_xH == rep1.global_xH
+    # a band that misses: detected, rerun on the dense sweeps, same box
+    monkeypatch.setenv("C21CM_EUL_BAND_SHIFT", "0.2")
+    monkeypatch.setenv("C21CM_EUL_BAND_DEBUG", "1")
+    buf3, _, rep3 = api.ionize_grids(spec, density)
+    torch.cuda.synchronize()
+    import re
+
+    assert re.search(r"band fail=[1-9]", capfd.readouterr().err)  # the index of the radius that missed
+    monkeypatch.delenv("C21CM_EUL_BAND_SHIFT")
+    monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
+    for name in names:
+        assert torch.equal(getattr(buf0, name), getattr(buf3, name)), name
+    assert rep0.global_xH == rep3.global_xH
+    if r_lowest == 0:
+        for world in (2, 3):
+            masks = []
+            for rank in range(world):
+                fc = torch.zeros((n, n, nz), dtype=torch.uint8, device="cuda")
+                api.ionize_shard_radii(spec, rank, world, fc, density)
+                masks.append(fc)
+            reduced = masks[0]
+            for m in masks[1:]:
+                reduced = torch.maximum(reduced, m)
+            assert int((reduced == 255).sum()) == 0  # no marker survives a shard phase
+            buf2, _, rep2 = api.ionize_shard_finish(spec, reduced.contiguous(), density)
+            torch.cuda.synchronize()
+            assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction)
+            assert rep0.global_xH == rep2.global_xH
