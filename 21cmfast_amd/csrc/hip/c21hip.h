@@ -515,7 +515,7 @@ int c21hip_split_z_fcoll_erfc_mask(const float *split_work, float *nion_dense, c
  * mean_f_coll / mean (at or above [0]: crosses for sure; below [1]: does not).  Cells in between carry
  * the marker 255 in first_cross and their f_coll in f_pend until the next radius' sweep (r_prev,
  * thr_prev_dev = its exact threshold) or c21hip_eul_resolve_pending settles them.  c21hip_eul_band =
- * finish_mean of r_cur + its exact threshold (thr_dev[r_cur]) + the check of r_cur's band (*fail_dev =
+ * [the sum of the pass-Z partials, c21hip_reduce_sum's arithmetic, when partials != NULL +] finish_mean of r_cur + its exact threshold (thr_dev[r_cur]) + the check of r_cur's band (*fail_dev =
  * the largest radius index whose band missed; c21hip_eul_rewind clears what that radius and the ones
  * after it wrote) + the band of r_next. */
 int c21hip_split_z_fcoll_erfc_band(const float *split_work, float *f_pend, const double *band_dev,
@@ -523,11 +523,11 @@ int c21hip_split_z_fcoll_erfc_band(const float *split_work, float *f_pend, const
                                    int r_prev, int nx, int ny, int nz, double growthf, double sigma_min,
                                    double sigma_max, double delta_c, double *partials, double *sum_out,
                                    void *stream);
-int c21hip_eul_band(const double *sum_dev, double ntot, int mass_dep_zeta, double f_limit,
-                    double *means_dev, int r_cur, int r_p1, int r_p2, double t_cur, double t_next,
-                    int r_next, int cur_banded, int fix_mean, double mean_f_coll, double ion_eff,
-                    double min_rel, double shift, double *band_dev, double *thr_dev, int *fail_dev,
-                    void *stream);
+int c21hip_eul_band(const double *partials, int n, double *sum_dev, double ntot, int mass_dep_zeta,
+                    double f_limit, double *means_dev, int r_cur, int r_p1, int r_p2, double t_cur,
+                    double t_next, int r_next, int cur_banded, int fix_mean, double mean_f_coll,
+                    double ion_eff, double min_rel, double shift, double *band_dev, double *thr_dev,
+                    int *fail_dev, unsigned *counter_dev, void *stream);
 int c21hip_eul_rewind(unsigned char *first_cross, int r_fail, size_t ntot, void *stream);
 int c21hip_eul_resolve_pending(int r_index, const float *f_pend, const double *thr_dev,
                                unsigned char *first_cross, size_t ntot, void *stream);

@@ -555,12 +555,20 @@ __device__ float eul_threshold(double mf, int mass_dep_zeta, double f_limit, dou
 // widened by min_rel of itself and by 8 x the error the same extrapolation made for r_cur; band[2 r] =
 // threshold at the lower end of mean_f_coll / mean (cells at or above it cross whatever the exact mean
 // turns out to be), band[2 r + 1] = threshold at the upper end (cells below it do not).
-__global__ void eul_band_kernel(const double *sum, double ntot, int mass_dep_zeta, double f_limit,
-                                double *means, int r_cur, int r_p1, int r_p2, double t_cur, double t_next,
-                                int r_next, int cur_banded, int fix_mean, double mean_f_coll,
-                                double ion_eff, double min_rel, double shift, double *band, double *thr,
-                                int *fail) {
-    double m = *sum / ntot;
+struct EulBandArgs {
+    double ntot, f_limit, t_cur, t_next, mean_f_coll, ion_eff, min_rel, shift;
+    int mass_dep_zeta, r_cur, r_p1, r_p2, r_next, cur_banded, fix_mean;
+    double *means, *band, *thr;
+    int *fail;
+};
+__device__ void eul_band_step(double sum_value, const EulBandArgs &a) {
+    const double ntot = a.ntot, f_limit = a.f_limit, t_cur = a.t_cur, t_next = a.t_next;
+    const double mean_f_coll = a.mean_f_coll, ion_eff = a.ion_eff, min_rel = a.min_rel, shift = a.shift;
+    const int mass_dep_zeta = a.mass_dep_zeta, r_cur = a.r_cur, r_p1 = a.r_p1, r_p2 = a.r_p2;
+    const int r_next = a.r_next, cur_banded = a.cur_banded, fix_mean = a.fix_mean;
+    double *means = a.means, *band = a.band, *thr = a.thr;
+    int *fail = a.fail;
+    double m = sum_value / ntot;
     if (mass_dep_zeta) {
         if (m <= f_limit) m = f_limit;
     } else {
@@ -587,6 +595,57 @@ __global__ void eul_band_kernel(const double *sum, double ntot, int mass_dep_zet
     }
     band[2 * r_next] = (double)eul_threshold(lo, mass_dep_zeta, f_limit, ion_eff);
     band[2 * r_next + 1] = (double)eul_threshold(hi, mass_dep_zeta, f_limit, ion_eff);
+}
+// c21hip_reduce_sum's arithmetic (1024-partial chunks summed like chunk_reduce_kernel, one workgroup per
+// chunk; the chunk sums like finish_reduce_kernel, by the workgroup that arrives last: the same additions
+// in the same order, so the same double) followed by eul_band_step: one launch per radius instead of
+// three.  n <= 4096: one workgroup, finish_reduce_kernel's order over the partials themselves.
+// stage: >= gridDim.x doubles; *counter: 0 on entry, 0 again on exit.
+__global__ void __launch_bounds__(kBlock)
+eul_sum_band_kernel(const double *__restrict__ partials, int n, double *stage, unsigned *counter,
+                    double *sum_out, EulBandArgs a) {
+    __shared__ double lds[kBlock];
+    __shared__ int is_last;
+    const int chunk = 1024;
+    const int two_level = gridDim.x > 1;
+    if (n > 0) {
+        const int lo = two_level ? blockIdx.x * chunk : 0;
+        const int hi = two_level ? min(n, lo + chunk) : n;
+        double acc = 0.;
+        for (int i = lo + threadIdx.x; i < hi; i += kBlock) acc = acc + partials[i];
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = kBlock / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s) lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + s];
+            __syncthreads();
+        }
+    }
+    if (two_level) {
+        if (threadIdx.x == 0) {
+            stage[blockIdx.x] = lds[0];
+            __threadfence();
+            is_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!is_last) return;
+        __threadfence();
+        double acc = 0.;  // finish_reduce_kernel over the chunk sums
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
+            acc = acc + __builtin_nontemporal_load(stage + i);
+        __syncthreads();
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = kBlock / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s) lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *counter = 0u;
+    }
+    if (threadIdx.x == 0) {
+        const double total = (n == 0) ? *sum_out : lds[0];
+        *sum_out = total;
+        eul_band_step(total, a);
+    }
 }
 
 // First-crossing grid as it was before radius index r_fail of a descending loop: crossings of that and
@@ -1438,15 +1497,24 @@ extern "C" int c21hip_eulerian_mask(const c21hip_ionize_args *a, const float *ni
     return 0;
 }
 
-extern "C" int c21hip_eul_band(const double *sum_dev, double ntot, int mass_dep_zeta, double f_limit,
-                               double *means_dev, int r_cur, int r_p1, int r_p2, double t_cur,
-                               double t_next, int r_next, int cur_banded, int fix_mean,
-                               double mean_f_coll, double ion_eff, double min_rel, double shift,
-                               double *band_dev, double *thr_dev, int *fail_dev, void *stream) {
-    hipLaunchKernelGGL(eul_band_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sum_dev, ntot,
-                       mass_dep_zeta, f_limit, means_dev, r_cur, r_p1, r_p2, t_cur, t_next, r_next,
-                       cur_banded, fix_mean, mean_f_coll, ion_eff, min_rel, shift, band_dev, thr_dev,
-                       fail_dev);
+// partials != NULL: the n per-workgroup partial sums of the radius' pass Z are reduced here (the
+// arithmetic of c21hip_reduce_sum; its staging area is partials + n, like there) into *sum_dev first;
+// NULL: *sum_dev already holds the sum.  counter_dev: a zeroed word the launches share.
+extern "C" int c21hip_eul_band(const double *partials, int n, double *sum_dev, double ntot,
+                               int mass_dep_zeta, double f_limit, double *means_dev, int r_cur, int r_p1,
+                               int r_p2, double t_cur, double t_next, int r_next, int cur_banded,
+                               int fix_mean, double mean_f_coll, double ion_eff, double min_rel,
+                               double shift, double *band_dev, double *thr_dev, int *fail_dev,
+                               unsigned *counter_dev, void *stream) {
+    EulBandArgs a;
+    a.ntot = ntot, a.f_limit = f_limit, a.t_cur = t_cur, a.t_next = t_next, a.mean_f_coll = mean_f_coll;
+    a.ion_eff = ion_eff, a.min_rel = min_rel, a.shift = shift, a.mass_dep_zeta = mass_dep_zeta;
+    a.r_cur = r_cur, a.r_p1 = r_p1, a.r_p2 = r_p2, a.r_next = r_next, a.cur_banded = cur_banded;
+    a.fix_mean = fix_mean, a.means = means_dev, a.band = band_dev, a.thr = thr_dev, a.fail = fail_dev;
+    const int nn = partials ? n : 0;
+    const int nb = nn > 4096 ? (nn + 1023) / 1024 : 1;
+    hipLaunchKernelGGL(eul_sum_band_kernel, dim3(nb), dim3(kBlock), 0, (hipStream_t)stream, partials, nn,
+                       const_cast<double *>(partials) + nn, counter_dev, sum_dev, a);
     LAUNCH_CHECK();
     return 0;
 }

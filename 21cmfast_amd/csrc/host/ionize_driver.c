@@ -124,7 +124,8 @@ typedef struct {
 #define SC_BAND (SC_PAIR + 2)
 #define SC_BANDX (SC_BAND + 2 * C21CM_MAX_RADII) /* exact threshold of every radius */
 #define SC_BANDFAIL (SC_BANDX + C21CM_MAX_RADII) /* an int stored in a double-sized cell */
-#define SC_COUNT (SC_BANDFAIL + 1)
+#define SC_BANDCTR (SC_BANDFAIL + 1) /* arrival counter of eul_sum_band_kernel (an unsigned, zero between launches) */
+#define SC_COUNT (SC_BANDCTR + 1)
 
 #define TRY(expr)                   \
     do {                            \
@@ -1259,7 +1260,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                     c->delta_work, c->nion_dense, c->scalars + SC_BAND + 2 * R_ct,
                     c->scalars + SC_BANDX + (c->band_pend >= 0 ? c->band_pend : 0), first_cross, R_ct,
                     c->band_pend, c->nx, c->ny, c->nz, s->growth_factor, s->sigma_minmass,
-                    s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev, c->stream));
+                    s->sigma_maxmass[R_ct], s->delta_c, partials, NULL, c->stream));
                 c->band_pend = R_ct;
                 c->band_mask = first_cross;
                 c->band_used = 1;
@@ -1267,7 +1268,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                 TRY(eul_band_flush(c)); /* the dense sweep overwrites the marked cells' f_coll */
                 TRY(c21hip_split_z_fcoll_erfc(c->delta_work, c->nion_dense, c->nx, c->ny, c->nz,
                                               s->growth_factor, s->sigma_minmass,
-                                              s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev,
+                                              s->sigma_maxmass[R_ct], s->delta_c, partials, NULL,
                                               c->stream));
             }
             {
@@ -1279,11 +1280,17 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                     if (next_R >= 1) t_next = (log(s->R[next_R]) - log(s->R[R_ct])) / d1;
                     if (h2 >= 0) t_cur = d1 / (log(s->R[h1]) - log(s->R[h2]));
                 }
-                TRY(c21hip_eul_band(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
+                /* the partial sums of the sweep, the mean, its threshold, the next band: one launch */
+                const char *e_sb = getenv("C21CM_EUL_SUMBAND"); /* 0: c21hip_reduce_sum's own launches (A/B) */
+                const int n_part = (int)((long)c->nx * c->ny / 16);
+                const int split = e_sb && e_sb[0] == '0';
+                if (split) TRY(c21hip_reduce_sum(partials, n_part, sum_dev, c->stream));
+                TRY(c21hip_eul_band(split ? NULL : partials, n_part, sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                     c->scalars + SC_MEANS, R_ct, h1, h2, t_cur, t_next,
                                     will_next ? next_R : -1, banded, s->fix_mean, s->mean_f_coll,
                                     s->ion_eff_factor, min_rel, shift, c->scalars + SC_BAND,
-                                    c->scalars + SC_BANDX, (int *)(c->scalars + SC_BANDFAIL), c->stream));
+                                    c->scalars + SC_BANDX, (int *)(c->scalars + SC_BANDFAIL),
+                                    (unsigned *)(c->scalars + SC_BANDCTR), c->stream));
                 c->band_next = will_next ? next_R : -1;
                 if (sig_ok) {
                     c->band_h2 = h1;
