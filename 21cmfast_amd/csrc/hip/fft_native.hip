@@ -75,6 +75,9 @@
 #ifndef C21X_ZW_DPP       // 1: the mirror partner X[H-k] of the c2r pre-processing through DPP lane moves
 #define C21X_ZW_DPP 0     //    (16 lanes per line) instead of a round trip through LDS: 230 instead of 184
 #endif                    //    VGPRs, fused pass Z 0.304 ms in the loop either way (354 against 315 us alone)
+#ifndef C21X_ZW_MASK16    // 1: mask rows of the fused pass Z as 16-byte loads / stores through the line's LDS region (measured: 312 vs 306 us, off)
+#define C21X_ZW_MASK16 0
+#endif
 #ifndef C21X_ZW_LATE      // 1: second grid and mask rows requested after the first transform
 #define C21X_ZW_LATE 0
 #endif
@@ -2176,7 +2179,8 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     constexpr int ZBLK = (A == 16 && P == 16) ? C21X_ZW_BLOCK : kBlock;  // threads of this workgroup
     constexpr int H = P * A, NZ = 2 * H, ZWL = ZBLK / P;
     constexpr int LINE_LDS = A * (P + 1) + 4;  // float2 per line region (padded rows + skew)
-    __shared__ float2 lines[ZWL * LINE_LDS];
+    static_assert(LINE_LDS % 2 == 0, "16-byte aligned line regions (mask rows)");
+    __shared__ __attribute__((aligned(16))) float2 lines[ZWL * LINE_LDS];
     __shared__ float2 twH[H], twN[H];
     __shared__ double red[ZBLK / 64];
     for (int t = threadIdx.x; t < H; t += ZBLK) {
@@ -2203,8 +2207,18 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     const long lline = logical_line(line, a.ny, a.lb);
     const float dh = a.d_nyq[lline].x, sh = a.s_nyq[lline].x;
     unsigned char *mrow = a.first_cross + lline * NZ;
-    uchar2 old[EARLY ? A : 1];
-    if (EARLY) {  // mask rows early too
+    // MASK16: the line's mask row as 2 A contiguous bytes per lane (16-byte loads in flight with the
+    // spectra); after the transforms the row goes through the line's LDS region, where the lanes pick
+    // their (cell 2j, 2j + 1) pairs and leave the changes; changed 16-byte pieces go back to the grid.
+    // Sixteen 2-byte loads and up to sixteen 2-byte stores per lane otherwise.
+    constexpr bool MASK16 = EARLY && C21X_ZW_MASK16;
+    constexpr int MV = MASK16 ? A / 8 : 1;
+    uint4 mreg[MV];
+    uchar2 old[(EARLY && !MASK16) ? A : 1];
+    if constexpr (MASK16) {
+#pragma unroll
+        for (int v = 0; v < MV; v++) mreg[v] = reinterpret_cast<const uint4 *>(mrow)[b * MV + v];
+    } else if (EARLY) {  // mask rows early too
 #pragma unroll
         for (int q = 0; q < A; q++)
             old[q] = reinterpret_cast<const uchar2 *>(mrow)[(b + P * (q / P)) + A * (q % P)];
@@ -2251,6 +2265,12 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                 nr_hi[q] = reinterpret_cast<const float2 *>(a.nrec + lline * NZ)[(b + P * (qq / P)) + A * (qq % P)];
             }
         }
+    }
+    if constexpr (MASK16) {
+        wave_fence();  // the last transform's reads of the region
+#pragma unroll
+        for (int v = 0; v < MV; v++) reinterpret_cast<uint4 *>(L)[b * MV + v] = mreg[v];
+        wave_fence();
     }
     const double floor_lhs = a.f_limit * a.ion_eff;  // the floored f_coll zeta
     const bool floor_ionises = !TS && a.mass_dep_zeta && (floor_lhs > 1.);
@@ -2299,17 +2319,30 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         }
         const bool i0 = (!RC && floor_ionises) || f0 || ((double)s0 * a.ion_eff > D0);
         const bool i1 = (!RC && floor_ionises) || f1 || ((double)s1 * a.ion_eff > D1);
-        uchar2 m = EARLY ? old[EARLY ? q : 0] : reinterpret_cast<const uchar2 *>(mrow)[j];
+        uchar2 m = MASK16 ? reinterpret_cast<const uchar2 *>(L)[j]
+                          : (EARLY ? old[(EARLY && !MASK16) ? q : 0] : reinterpret_cast<const uchar2 *>(mrow)[j]);
         const bool n0 = i0 && m.x == 0, n1 = i1 && m.y == 0;
         if (n0) m.x = (unsigned char)a.r_index;
         if (n1) m.y = (unsigned char)a.r_index;
-        if (n0 || n1 || a.store_all) reinterpret_cast<uchar2 *>(mrow)[j] = m;
+        if constexpr (MASK16) {
+            if (n0 || n1) reinterpret_cast<uchar2 *>(L)[j] = m;
+        } else if (n0 || n1 || a.store_all)
+            reinterpret_cast<uchar2 *>(mrow)[j] = m;
         if constexpr (RC) {
             // a first crossing leaves its delta_R in the Gamma_12 grid; the whalo_sfr pass of this
             // radius (zw_c2r_kernel, EPI 4) turns it into Gamma_12 = R pref / (1 + delta_R) sfr_R
             float *grow = a.g12 + lline * NZ + 2 * j;
             if (n0 && a.rc != 2) grow[0] = fmaxf(xd[q].x, dmin);
             if (n1 && a.rc != 2) grow[1] = fmaxf(xd[q].y, dmin);
+        }
+    }
+    if constexpr (MASK16) {
+        wave_fence();
+#pragma unroll
+        for (int v = 0; v < MV; v++) {
+            const uint4 n = reinterpret_cast<const uint4 *>(L)[b * MV + v], o = mreg[v];
+            if (a.store_all || n.x != o.x || n.y != o.y || n.z != o.z || n.w != o.w)
+                reinterpret_cast<uint4 *>(mrow)[b * MV + v] = n;
         }
     }
 #pragma unroll
