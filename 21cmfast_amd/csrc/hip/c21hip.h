@@ -117,6 +117,11 @@ int c21hip_split_z_ionise_recomb_xe(const float *delta_work, const float *stars_
                                     double *partials, int nx, int ny, int nz, int r_index,
                                     double rhocrit_omb, double ion_eff, int mass_dep_zeta, double f_limit,
                                     void *stream);
+/* ... with N_rec of the previous snapshot filtered at this radius as the third line (CELL_RECOMB = false) */
+int c21hip_split_z_ionise_recomb_nrec(const float *delta_work, const float *stars_work, const float *nrec_work,
+                                      float *g12, unsigned char *first_cross, double *partials, int nx,
+                                      int ny, int nz, int r_index, double rhocrit_omb, double ion_eff,
+                                      int mass_dep_zeta, double f_limit, void *stream);
 int c21hip_split_z_ionise_recomb(const float *delta_work, const float *stars_work, const float *nrec,
                                  double rec0, float *g12, unsigned char *first_cross,
                                  double *partials, int nx, int ny, int nz, int r_index,

@@ -1845,6 +1845,9 @@ struct ZFusedArgs {
     int rc;
     const float *nrec;
     double rec0;
+    // the third line (x_main) is not x_e but the previous snapshot's N_rec filtered at this radius
+    // (CELL_RECOMB = false, IonisationBox.c:583-663,808-809,1093): rec = max(N_rec(R), 0) / (1 + delta_R)
+    int x_is_nrec;
     float *g12;  // dense [lines][NZ]: a first crossing leaves delta_R here (-> zw_c2r_kernel EPI 4)
 };
 
@@ -2309,8 +2312,13 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
             }
             double n0 = 1., n1 = 1.;
             if constexpr (TS) {
-                n0 = 1. - (double)fminf(fmaxf(xx[q].x, 0.f), 0.999f);
-                n1 = 1. - (double)fminf(fmaxf(xx[q].y, 0.f), 0.999f);
+                if (a.x_is_nrec) {  // the third line is N_rec(R), clipped at zero (:808-809)
+                    r0 = (double)fmaxf(xx[q].x, 0.f);
+                    r1 = (double)fmaxf(xx[q].y, 0.f);
+                } else {
+                    n0 = 1. - (double)fminf(fmaxf(xx[q].x, 0.f), 0.999f);
+                    n1 = 1. - (double)fminf(fmaxf(xx[q].y, 0.f), 0.999f);
+                }
             }
             D0 = a.rhocrit_omb * ((opd0 + r0) * n0);
             D1 = a.rhocrit_omb * ((opd1 + r1) * n1);
@@ -4229,6 +4237,38 @@ extern "C" int c21hip_split_z_ionise_recomb_xe(const float *delta_work, const fl
     a.rc = getenv("C21CM_DIAG_RC_NOSTORE") ? 2 : 1;  // (2: timing diagnostic, no Gamma_12 stores)
     a.nrec = nrec;
     a.rec0 = rec0;
+    a.g12 = g12;
+    a.reverse = 1;
+    int n_partials = 0;
+    return dispatch_z_fused(nz, a, nlines, (hipStream_t)stream, &n_partials);
+}
+// ... with the previous snapshot's N_rec FILTERED at this radius (CELL_RECOMB = false) as the third line
+// instead of a dense per-cell N_rec: f zeta > 1 + max(N_rec(R), 0) / (1 + delta_R)
+extern "C" int c21hip_split_z_ionise_recomb_nrec(const float *delta_work, const float *stars_work,
+                                                 const float *nrec_work, float *g12,
+                                                 unsigned char *first_cross, double *partials, int nx,
+                                                 int ny, int nz, int r_index, double rhocrit_omb,
+                                                 double ion_eff, int mass_dep_zeta, double f_limit,
+                                                 void *stream) {
+    const long nlines = (long)nx * ny;
+    ZFusedArgs a{};
+    a.x_main = reinterpret_cast<const float2 *>(nrec_work);
+    a.x_nyq = a.x_main + nlines * (nz / 2);
+    a.x_is_nrec = 1;
+    a.ny = ny;
+    a.lb = split_xb_log2(nx);
+    a.d_main = reinterpret_cast<const float2 *>(delta_work);
+    a.d_nyq = a.d_main + nlines * (nz / 2);
+    a.s_main = reinterpret_cast<const float2 *>(stars_work);
+    a.s_nyq = a.s_main + nlines * (nz / 2);
+    a.first_cross = first_cross;
+    a.partials = partials;
+    a.rhocrit_omb = rhocrit_omb;
+    a.ion_eff = ion_eff;
+    a.f_limit = f_limit;
+    a.mass_dep_zeta = mass_dep_zeta;
+    a.r_index = r_index;
+    a.rc = 1;
     a.g12 = g12;
     a.reverse = 1;
     int n_partials = 0;

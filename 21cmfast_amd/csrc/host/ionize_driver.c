@@ -349,6 +349,10 @@ typedef struct {
     int band_h1, band_h2, band_hn; /* the last two radii of this loop with a mean on the device */
     unsigned char *band_mask;
     const float *cur_xe; /* fused recombination loop with an x_e grid: its work spectrum of the radius in hand */
+    /* third HII-window spectrum of the fused loop: the x_e grid, or -- on the fused recombination loop
+     * with CELL_RECOMB = false -- the previous snapshot's N_rec (x3_nrec) */
+    int x3_on, x3_nrec;
+    float *x3_unf, *x3_work, *x3_work2;
     int yz;              /* pass Y + fused pass Z as ONE plane-fused kernel (plane_yz.hip: 512^3, two grids) */
     int yz_now;          /* ... for the radius z_ionise_radius is called for (its main blocks skipped pass Y) */
     int yz_used;         /* a plane-fused launch happened in this call: its status is checked at the end */
@@ -434,7 +438,16 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
      * post-loop stay on the general kernels.  Needs the evaluated windows (whalo_sfr takes window
      * b alone).  C21CM_RECOMB_FUSED=0: the unfused per-radius sequence. */
     c->fused_rc = 0;
-    if (c->native && c->lagrangian && c->recomb && s->cell_recomb &&
+    /* (round 4, late: CELL_RECOMB = false without an x_e grid as well -- N_rec filtered at the radius is
+     * the barrier kernel's third line where the x_e grid would be; single pass only.
+     * C21CM_RECOMB_FUSED_NREC=0 keeps such runs on the unfused sequence) */
+    const char *e_nr = getenv("C21CM_RECOMB_FUSED_NREC");
+    const int nrec_ok = s->cell_recomb ||
+                        (c->inhomo && !s->use_ts_fluct && g_single_pass && !(e_nr && e_nr[0] == '0') &&
+                         c21hip_z_ionise_recomb_xe_supported(c->nx, c->ny, c->nz));
+    c->x3_on = c->x3_nrec = 0;
+    c->x3_unf = c->x3_work = c->x3_work2 = NULL;
+    if (c->native && c->lagrangian && c->recomb && nrec_ok &&
         !s->use_mini_halos && !s->ionise_entire_sphere && s->r_lowest == 0 &&
         (g_single_pass || (g_rc_phase && !s->use_ts_fluct))) {
         /* (round 4: with the x_e grid of a spin-temperature run too -- a third line of the barrier
@@ -509,12 +522,20 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             c->delta_work2 = (float *)c21hip_ws(WS_DELTA_WORK2, gbytes);
             c->stars_work2 = (float *)c21hip_ws(WS_STARS_WORK2, gbytes);
             if (!c->delta_work2 || !c->stars_work2) return C21CM_MEMORY_ALLOC_ERROR;
-            if (s->use_ts_fluct && !(c->xe_work2 = (float *)c21hip_ws(WS_XE_WORK2, gbytes)))
-                return C21CM_MEMORY_ALLOC_ERROR;
+            if ((s->use_ts_fluct || (c->fused_rc && c->filter_rec)) &&
+                !(c->xe_work2 = (float *)c21hip_ws(WS_XE_WORK2, gbytes)))
+                return C21CM_MEMORY_ALLOC_ERROR; /* (the second work spectrum of N_rec on the fused loop too) */
             if (c->fused_rc && !(c->sfr_work2 = (float *)c21hip_ws(WS_SFR_WORK2, gbytes)))
                 return C21CM_MEMORY_ALLOC_ERROR;
             c->pair_radii = 1;
         }
+    }
+    if (c->fused && s->use_ts_fluct) {
+        c->x3_on = 1;
+        c->x3_unf = c->xe_unf, c->x3_work = c->xe_work, c->x3_work2 = c->xe_work2;
+    } else if (c->fused_rc && c->filter_rec) {
+        c->x3_on = c->x3_nrec = 1;
+        c->x3_unf = c->nrec_unf, c->x3_work = c->nrec_work, c->x3_work2 = c->xe_work2;
     }
     if (c->fused) {
         const char *e = getenv("C21CM_DEFER_SUMS");
@@ -780,6 +801,11 @@ static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float
             if (c->def_count == 0) c->def_first = R_ct;
             c->def_count++;
         }
+        if (c->x3_nrec) /* CELL_RECOMB = false: N_rec filtered at the radius is the third line */
+            TRY(c21hip_split_z_ionise_recomb_nrec(dwork, swork, c->cur_xe, c->G12, first_cross, part, c->nx,
+                                                  c->ny, c->nz, R_ct, s->rhocrit_omb, s->ion_eff_factor,
+                                                  s->mass_dep_zeta, s->f_limit_acg, c->stream));
+        else
         TRY(c21hip_split_z_ionise_recomb_xe(dwork, swork, s->use_ts_fluct ? c->cur_xe : NULL,
                                             c->inhomo ? c->prev_nrec : NULL, c->rec0, c->G12, first_cross,
                                             part, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
@@ -878,7 +904,7 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
          * x_e spectrum of such a run travels in c->cur_xe), else x_e */
         const float *xw[2] = {c->fused_rc ? c->sfr_work : (s->use_ts_fluct ? c->xe_work : NULL),
                               c->fused_rc ? c->sfr_work2 : (s->use_ts_fluct ? c->xe_work2 : NULL)};
-        const float *xe_of[2] = {s->use_ts_fluct ? c->xe_work : NULL, s->use_ts_fluct ? c->xe_work2 : NULL};
+        const float *xe_of[2] = {c->x3_on ? c->x3_work : NULL, c->x3_on ? c->x3_work2 : NULL};
         c->yz_now = c->yz;
         if (c->yz) c->yz_used = 1;
         for (int ph = 0; ph < 3; ph++) { /* pass X, pass Y of R_a, pass Y of R_b */
@@ -903,9 +929,9 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                 c->stars_work, c->stars_work2, s->stars_filter, (float)s->mfp_meandens, c->nx,
                 c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a,
                 buf_b, bits, c->stream));
-            if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
+            if (c->x3_on) /* x_e (N_rec) shares the density grid's window (IonisationBox.c:1551-1553, :613) */
                 TRY(c21hip_split_filter_xy_shared_pair(
-                    c->xe_unf, c->xe_work, c->xe_work2, s->hii_filter, c->nx, c->ny, c->nz,
+                    c->x3_unf, c->x3_work, c->x3_work2, s->hii_filter, c->nx, c->ny, c->nz,
                     s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a, buf_b,
                     bits & ~1, c->stream));
             if (c->fused_rc) /* whalo_sfr under the emissivity window (IonisationBox.c:583-663) */
@@ -938,8 +964,8 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                                     c->stars_work, s->stars_filter, (float)s->mfp_meandens, c->nx,
                                     c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], 1,
                                     buf_a, tab_async, c->stream));
-        if (s->use_ts_fluct) /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
-            TRY(c21hip_split_filter_xy_shared(c->xe_unf, c->xe_work, s->hii_filter, c->nx, c->ny,
+        if (c->x3_on) /* x_e (N_rec) shares the density grid's window (IonisationBox.c:1551-1553, :613) */
+            TRY(c21hip_split_filter_xy_shared(c->x3_unf, c->x3_work, s->hii_filter, c->nx, c->ny,
                                               c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], 1,
                                               buf_a, c->stream));
         if (c->fused_rc)
@@ -949,7 +975,7 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
         if (tab_async) TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
     }
     c->tab_seq++;
-    c->cur_xe = s->use_ts_fluct ? c->xe_work : NULL;
+    c->cur_xe = c->x3_on ? c->x3_work : NULL;
     TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work,
                         c->fused_rc ? c->sfr_work : (s->use_ts_fluct ? c->xe_work : NULL), first_cross));
 done:

@@ -250,8 +250,9 @@ def test_c_level_sharding_with_an_emulated_transport(api, recomb, world):
     assert 0.03 < float((buf0.neutral_fraction == 0).float().mean()) < 0.97
 
 
-@pytest.mark.parametrize("model,ts", [(2, False), (1, False), (2, True), (1, True)])
-def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, model, ts):
+@pytest.mark.parametrize("model,ts,cell_recomb", [(2, False, 1), (1, False, 1), (2, True, 1), (1, True, 1),
+                                                  (2, False, 0)])
+def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, model, ts, cell_recomb):
     """CELL_RECOMB runs ride the fused loop (whalo_sfr as a third spectrum of the wave-level pass Z,
     (1 + N_rec / (1 + delta)) in the barrier, Gamma_12 at first crossings, the mean free path from
     the first-crossing index); C21CM_RECOMB_FUSED=0 is the per-radius sequence of round 2.  Same
@@ -260,8 +261,10 @@ def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, 
 
     # ts (round 4): with the x_e grid of a spin-temperature run the filtered x_e is a third line of the
     # barrier kernel, f zeta > (1 - x_e)(1 + rec) (IonisationBox.c:1084-1118)
+    # cell_recomb = 0 (round 4): N_rec of the previous snapshot filtered at the radius takes the third
+    # line, f zeta > 1 + max(N_rec(R), 0) / (1 + delta_R) (IonisationBox.c:583-663,808-809,1093)
     n = 256
-    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0, ts=int(ts))
+    spec = recomb_spec(n, model=model, cell_recomb=cell_recomb, r_bubble_max=20.0, ts=int(ts))
     d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=77, ts=ts).items()}
     if model == 1:
         d["prev_nrec"] = torch.full((1, 1, 1), 0.25, dtype=torch.float32, device="cuda")
