@@ -534,6 +534,12 @@ int c21hip_eul_band(const double *partials, int n, double *sum_dev, double ntot,
                     double ion_eff, double min_rel, double shift, double *band_dev, double *thr_dev,
                     int *fail_dev, unsigned *counter_dev, void *stream);
 int c21hip_eul_rewind(unsigned char *first_cross, int r_fail, size_t ntot, void *stream);
+/* the same for the table modes: c21hip_fcoll_eulerian with the barrier decided in the sweep; the dense
+ * f_coll grid is not written, *n_partials_out partial sums stay in `partials` for c21hip_eul_band */
+int c21hip_fcoll_eulerian_band(const float *delta_fil, float *f_pend, unsigned char *first_cross, int nx,
+                               int ny, int nz, int mode, double tab_min, double tab_width,
+                               const float *table_dev, const double *band_dev, const double *thr_prev_dev,
+                               int r_index, int r_prev, double *partials, int *n_partials_out, void *stream);
 int c21hip_eul_resolve_pending(int r_index, const float *f_pend, const double *thr_dev,
                                unsigned char *first_cross, size_t ntot, void *stream);
 /* ---- plane_yz.hip: pass Y + fused pass Z of one radius in one persistent kernel, the x-plane between

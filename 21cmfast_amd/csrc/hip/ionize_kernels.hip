@@ -295,6 +295,71 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
     block_sum_to(acc, partials);
 }
 
+// fcoll_eulerian_kernel<2> of a table mode with the radius' barrier decided in the same sweep wherever
+// it does not depend on the exact box mean (the banded barrier of the closed-form loop, pass Z EPI 7 in
+// fft_native.hip, for the loops whose f_coll comes from a per-radius table): band[0] / band[1] = the two
+// float thresholds of this radius (eul_band_step), cells in between get the marker 255 in first_cross
+// and their f_coll in f_pend (a sparse write: NOT a complete grid); r_prev >= 0: the radius whose
+// markers are outstanding, *thr_prev its exact threshold.  The dense f_coll grid is never written and
+// eulerian_mask_kernel not launched: 4 N + 1 N bytes read instead of (4 + 4) N + 6 N per radius.
+__global__ void __launch_bounds__(kBlock)
+fcoll_eulerian_band_kernel(const float *__restrict__ delta_fil, float *__restrict__ f_pend,
+                           unsigned char *__restrict__ first_cross, size_t nitems, int nz_items,
+                           int zpad_items, FcollParams fp, const float *__restrict__ table,
+                           const double *__restrict__ band, const double *__restrict__ thr_prev,
+                           int r_index, int r_prev, double *__restrict__ partials) {
+    __shared__ float tab[C21CM_NDELTA_TABLE];
+    for (int t = threadIdx.x; t < C21CM_NDELTA_TABLE; t += kBlock) tab[t] = table[t];
+    __syncthreads();
+    const float t_sure = (float)band[0], t_maybe = (float)band[1];
+    const float t_prev = r_prev >= 0 ? (float)*thr_prev : 0.f;
+    double acc = 0.;
+    constexpr int U = 4;
+    for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < nitems;
+         i0 += (size_t)gridDim.x * kBlock * U) {
+        Pack<2> d[U];
+        uchar2 mk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = i0 + (size_t)u * kBlock;
+            if (i < nitems) {
+                d[u] = Pack<2>::load(delta_fil, cell_index<2>(i, nz_items, zpad_items).padded);
+                mk[u] = reinterpret_cast<const uchar2 *>(first_cross)[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = i0 + (size_t)u * kBlock;
+            if (i >= nitems) continue;
+            unsigned char mv[2] = {mk[u].x, mk[u].y};
+            bool ch = false;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float dens = clip_delta_eulerian(d[u].v[e]);
+                double f;
+                if (fp.mode == C21CM_FCOLL_TABLE_LINEAR)
+                    f = eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab);
+                else
+                    f = exp_f32acc(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
+                acc += f;
+                const float g = (float)f;  // what the dense grid would hold
+                if (mv[e] == 255) {        // the previous radius' undecided cell
+                    mv[e] = (f_pend[2 * i + e] >= t_prev) ? (unsigned char)r_prev : (unsigned char)0;
+                    ch = true;
+                }
+                if (mv[e] == 0 && g >= t_maybe) {
+                    const bool sure = g >= t_sure;
+                    mv[e] = sure ? (unsigned char)r_index : (unsigned char)255;
+                    if (!sure) f_pend[2 * i + e] = g;
+                    ch = true;
+                }
+            }
+            if (ch) reinterpret_cast<uchar2 *>(first_cross)[i] = make_uchar2(mv[0], mv[1]);
+        }
+    }
+    block_sum_to(acc, partials);
+}
+
 // E-INTEGRAL without interpolation tables (C21CM_FCOLL_NODES): Nion_ConditionalM of every cell
 // (IonisationBox.c:889-893 -> hmf.c:1106-1140, Gauss-Legendre) from the radius' node data in LDS:
 // one exp and a handful of multiply-adds per (cell, node), all in double like the host integral.
@@ -1280,6 +1345,36 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream,
                        partials, blocks, 0, sum_out);
     LAUNCH_CHECK();
+    return 0;
+}
+
+// Table modes with the banded barrier (fcoll_eulerian_band_kernel): *n_partials_out partial sums are left
+// in `partials` for c21hip_eul_band (the order of c21hip_fcoll_eulerian's own reduction).
+extern "C" int c21hip_fcoll_eulerian_band(const float *delta_fil, float *f_pend, unsigned char *first_cross,
+                                          int nx, int ny, int nz, int mode, double tab_min,
+                                          double tab_width, const float *table_dev, const double *band_dev,
+                                          const double *thr_prev_dev, int r_index, int r_prev,
+                                          double *partials, int *n_partials_out, void *stream) {
+    if (nz % 2 || (mode != C21CM_FCOLL_TABLE_LINEAR && mode != C21CM_FCOLL_TABLE_EXP) || r_index <= 0 ||
+        r_index >= 255 || r_prev >= 255) {
+        c21hip_set_error("banded barrier of a table mode: unsupported box, mode or radius index");
+        return C21CM_VALUE_ERROR;
+    }
+    FcollParams fp;
+    fp.mode = mode;
+    fp.growthf = 0.f;
+    fp.delta_c = 0.;
+    fp.tab_min = tab_min;
+    fp.tab_width = tab_width;
+    fp.sig = -1.;
+    const int zpad = 2 * (nz / 2 + 1);
+    const size_t nitems = (size_t)nx * ny * (nz / 2);
+    const int blocks = grid_for((nitems + 3) / 4);
+    hipLaunchKernelGGL(fcoll_eulerian_band_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                       delta_fil, f_pend, first_cross, nitems, nz / 2, zpad / 2, fp, table_dev, band_dev,
+                       thr_prev_dev, r_index, r_prev, partials);
+    LAUNCH_CHECK();
+    *n_partials_out = blocks;
     return 0;
 }
 

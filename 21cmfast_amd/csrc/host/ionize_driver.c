@@ -1215,6 +1215,56 @@ static int eul_band_finish(ion_ctx *c, unsigned char *mask, int *redo) {
     return 0;
 }
 
+/* Is radius R_ct of a descending loop decided on a band (the device holds one for it)?  */
+static int eul_band_this(ion_ctx *c, int R_ct, unsigned char *first_cross, int sig_ok) {
+    const c21cm_ionize_spec *s = c->s;
+    /* (index 1 sits a step above the cell scale, where the mean leaves the curve the larger radii
+     * drew -- 1.6 % at 512^3 against the < 0.1 % of every other step: dense) */
+    return c->band_next == R_ct && sig_ok && R_ct >= 2 && (R_ct > s->r_lowest || s->r_lowest == 0) &&
+           (c->band_pend < 0 || c->band_mask == first_cross);
+}
+
+/* After the sweep of radius R_ct (banded or dense) left n_part partial sums of its f_coll grid: their
+ * sum, the mean, its exact threshold, the check of R_ct's band and the band of next_R -- one launch
+ * (partials NULL: *sum_dev holds the sum already). */
+static int eul_band_after(ion_ctx *c, int R_ct, int next_R, int banded, int sig_ok, const double *partials,
+                          int n_part, double *sum_dev) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    const char *e_rel = getenv("C21CM_EUL_BAND_MINREL"), *e_shift = getenv("C21CM_EUL_BAND_SHIFT");
+    double min_rel = e_rel ? atof(e_rel) : 0.003;
+    if (!(min_rel >= 0.)) min_rel = 0.003;
+    const double shift = e_shift ? atof(e_shift) : 0.; /* test hook: a prediction off by this fraction */
+    const int h1 = c->band_h1, h2 = c->band_h2;
+    const int will_next = next_R >= 1 && c->band_hn >= 1 && sig_ok;
+    double t_cur = 0., t_next = 0.;
+    if (h1 >= 0) {
+        const double d1 = log(s->R[R_ct]) - log(s->R[h1]);
+        if (next_R >= 1) t_next = (log(s->R[next_R]) - log(s->R[R_ct])) / d1;
+        if (h2 >= 0) t_cur = d1 / (log(s->R[h1]) - log(s->R[h2]));
+    }
+    const char *e_sb = getenv("C21CM_EUL_SUMBAND"); /* 0: c21hip_reduce_sum's own launches (A/B) */
+    const int split = partials && e_sb && e_sb[0] == '0';
+    if (split) TRY(c21hip_reduce_sum(partials, n_part, sum_dev, c->stream));
+    TRY(c21hip_eul_band(split ? NULL : partials, n_part, sum_dev, (double)c->ntot, s->mass_dep_zeta,
+                        s->f_limit_acg, c->scalars + SC_MEANS, R_ct, h1, h2, t_cur, t_next,
+                        will_next ? next_R : -1, banded, s->fix_mean, s->mean_f_coll, s->ion_eff_factor,
+                        min_rel, shift, c->scalars + SC_BAND, c->scalars + SC_BANDX,
+                        (int *)(c->scalars + SC_BANDFAIL), (unsigned *)(c->scalars + SC_BANDCTR),
+                        c->stream));
+    c->band_next = will_next ? next_R : -1;
+    if (sig_ok) {
+        c->band_h2 = h1;
+        c->band_h1 = R_ct;
+        c->band_hn++;
+    } else { /* a radius without sources: its clamped mean is no point of the curve */
+        c->band_h1 = c->band_h2 = -1;
+        c->band_hn = 0;
+    }
+done:
+    return status;
+}
+
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -1271,16 +1321,8 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
             goto done;
         }
         if (s->fcoll_mode == C21CM_FCOLL_ERFC && !s->use_ts_fluct && eul_band_ok(c)) {
-            const char *e_rel = getenv("C21CM_EUL_BAND_MINREL"), *e_shift = getenv("C21CM_EUL_BAND_SHIFT");
-            double min_rel = e_rel ? atof(e_rel) : 0.003;
-            if (!(min_rel >= 0.)) min_rel = 0.003;
-            const double shift = e_shift ? atof(e_shift) : 0.; /* test hook: a prediction off by this fraction */
             const int sig_ok = (float)s->sigma_maxmass[R_ct] != (float)s->sigma_minmass;
-            /* (index 1 sits a step above the cell scale, where the mean leaves the curve the larger radii
-             * drew -- 1.6 % at 512^3 against the < 0.1 % of every other step: dense) */
-            const int banded = c->band_next == R_ct && sig_ok && R_ct >= 2 &&
-                               (R_ct > s->r_lowest || s->r_lowest == 0) &&
-                               (c->band_pend < 0 || c->band_mask == first_cross);
+            const int banded = eul_band_this(c, R_ct, first_cross, sig_ok);
             if (banded) {
                 TRY(c21hip_split_z_fcoll_erfc_band(
                     c->delta_work, c->nion_dense, c->scalars + SC_BAND + 2 * R_ct,
@@ -1297,36 +1339,9 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                               s->sigma_maxmass[R_ct], s->delta_c, partials, NULL,
                                               c->stream));
             }
-            {
-                const int h1 = c->band_h1, h2 = c->band_h2;
-                const int will_next = next_R >= 1 && c->band_hn >= 1 && sig_ok;
-                double t_cur = 0., t_next = 0.;
-                if (h1 >= 0) {
-                    const double d1 = log(s->R[R_ct]) - log(s->R[h1]);
-                    if (next_R >= 1) t_next = (log(s->R[next_R]) - log(s->R[R_ct])) / d1;
-                    if (h2 >= 0) t_cur = d1 / (log(s->R[h1]) - log(s->R[h2]));
-                }
-                /* the partial sums of the sweep, the mean, its threshold, the next band: one launch */
-                const char *e_sb = getenv("C21CM_EUL_SUMBAND"); /* 0: c21hip_reduce_sum's own launches (A/B) */
-                const int n_part = (int)((long)c->nx * c->ny / 16);
-                const int split = e_sb && e_sb[0] == '0';
-                if (split) TRY(c21hip_reduce_sum(partials, n_part, sum_dev, c->stream));
-                TRY(c21hip_eul_band(split ? NULL : partials, n_part, sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
-                                    c->scalars + SC_MEANS, R_ct, h1, h2, t_cur, t_next,
-                                    will_next ? next_R : -1, banded, s->fix_mean, s->mean_f_coll,
-                                    s->ion_eff_factor, min_rel, shift, c->scalars + SC_BAND,
-                                    c->scalars + SC_BANDX, (int *)(c->scalars + SC_BANDFAIL),
-                                    (unsigned *)(c->scalars + SC_BANDCTR), c->stream));
-                c->band_next = will_next ? next_R : -1;
-                if (sig_ok) {
-                    c->band_h2 = h1;
-                    c->band_h1 = R_ct;
-                    c->band_hn++;
-                } else { /* a radius without sources: its clamped mean is no point of the curve */
-                    c->band_h1 = c->band_h2 = -1;
-                    c->band_hn = 0;
-                }
-            }
+            /* the partial sums of the sweep, the mean, its threshold, the next band: one launch */
+            TRY(eul_band_after(c, R_ct, next_R, banded, sig_ok, partials, (int)((long)c->nx * c->ny / 16),
+                               sum_dev));
             if (!banded)
                 TRY(c21hip_eulerian_mask(&args, c->nion_dense, NULL, mean_dev, first_cross, c->stream));
             goto done;
@@ -1532,6 +1547,10 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
             c->xe_work2 = (float *)c21hip_ws(WS_XE_WORK2, c21hip_split_floats(c->nx, c->ny, c->nz) * sizeof(float));
         if (!eul_xe_fused(c)) TRY(eul_xe_buffers(c));
     }
+    /* banded barrier: table modes without an x_e grid (its barrier needs x_e(R) of the cell, which only
+     * the x_e grid's own pass Z holds).  (nz even: the kernel's two-cell items) */
+    const int use_band = !s->use_ts_fluct && c->nz % 2 == 0 && c->ntot % 16 == 0 && s->n_radii < 255 &&
+                         !c->band_off && !(getenv("C21CM_EUL_BAND") && getenv("C21CM_EUL_BAND")[0] == '0');
     TRY(eul_stage_a(c, radii[0], 0, dfil[0], mm[0], ev[0]));
     for (int i = 0; i < n; i++) {
         const int b = i & 1, R_ct = radii[i];
@@ -1549,6 +1568,34 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
         double *sum_dev = c->scalars + SC_SUMS + R_ct, *mean_dev = c->scalars + SC_MEANS + R_ct;
         c21hip_ionize_args args;
         fill_args(&args, s, R_ct);
+        if (use_band) {
+            /* banded barrier (see eul_band_ok): the table sweep decides the cells itself, no dense
+             * f_coll grid, no barrier sweep */
+            const int banded = eul_band_this(c, R_ct, mask, 1);
+            int n_part = 0;
+            if (banded) {
+                TRY(c21hip_fcoll_eulerian_band(dfil[b], c->nion_dense, mask, c->nx, c->ny, c->nz,
+                                               s->fcoll_mode, min_density,
+                                               (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
+                                               table_dev, c->scalars + SC_BAND + 2 * R_ct,
+                                               c->scalars + SC_BANDX + (c->band_pend >= 0 ? c->band_pend : 0),
+                                               R_ct, c->band_pend, c->partials, &n_part, c->stream));
+                c->band_pend = R_ct;
+                c->band_mask = mask;
+                c->band_used = 1;
+                TRY(eul_band_after(c, R_ct, i + 1 < n ? radii[i + 1] : -1, 1, 1, c->partials, n_part, sum_dev));
+            } else {
+                TRY(eul_band_flush(c)); /* the dense sweep overwrites the marked cells' f_coll */
+                TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
+                                          s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
+                                          s->delta_c, min_density,
+                                          (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
+                                          table_dev, c->partials, sum_dev, c->stream));
+                TRY(eul_band_after(c, R_ct, i + 1 < n ? radii[i + 1] : -1, 0, 1, NULL, 0, sum_dev));
+                TRY(c21hip_eulerian_mask(&args, c->nion_dense, NULL, mean_dev, mask, c->stream));
+            }
+            continue;
+        }
         TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
                                   s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
                                   s->delta_c, min_density,
@@ -1951,6 +1998,16 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
         for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct -= world)
             radii[n++] = R_ct;
         TRY(eul_table_loop(&c, radii, n, first_cross));
+        {
+            int redo = 0; /* banded barrier: markers settled; a missed band reruns its radii (dense) */
+            TRY(eul_band_finish(&c, first_cross, &redo));
+            if (redo) {
+                int m = 0;
+                for (int i = 0; i < n; i++)
+                    if (radii[i] <= redo) radii[m++] = radii[i];
+                TRY(eul_table_loop(&c, radii, m, first_cross));
+            }
+        }
     } else if (c.fused) {
         TRY(fused_loop(&c, spec->n_radii - 1 - rank, world, spec->r_lowest, first_cross));
     } else {

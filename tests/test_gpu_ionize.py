@@ -817,9 +817,11 @@ def test_closed_form_loop_deferred_barrier_equals_separate_sweep(api, r_lowest, 
         assert rep0.global_xH == rep2.global_xH
 
 
+@pytest.mark.parametrize("fmode", [W.FCOLL_ERFC, W.FCOLL_TABLE_EXP, W.FCOLL_TABLE_LINEAR])
 @pytest.mark.parametrize("r_lowest", [0, 2])
 @pytest.mark.parametrize("mass_dep_zeta", [False, True])
-def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, r_lowest, mass_dep_zeta, monkeypatch, capfd):
+def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, fmode, r_lowest, mass_dep_zeta, monkeypatch,
+                                                             capfd):
     """CONST-ION-EFF closed form on the wave-level pass Z (the default): the barrier of a radius is decided
     INSIDE its own pass Z from a predicted band of the mean fix (monotone test: cells on which both ends
     agree are final, the others carry a marker until the exact mean is known).  Every output equals the
@@ -829,9 +831,27 @@ def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, r_lowest, mass
     loop reruns from there on the dense sweeps."""
     import torch
 
+    # fmode: the same for the loops whose f_coll comes from a per-radius table (E-INTEGRAL / CONST-ION-EFF
+    # with interpolation tables): there the table sweep (fcoll_eulerian_band_kernel) decides the cells
     n, nz = 64, 512
-    spec = W.ionize_spec(n, hii_dim_z=nz, mode=W.FCOLL_ERFC, r_bubble_max=9.0)
+    spec = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=9.0)
     spec.r_lowest = r_lowest
+    if fmode != W.FCOLL_ERFC:
+        S = importlib.import_module("21cmfast_amd.structs")
+
+        def table_fn(r_index, dmin, dmax, table, user):
+            x = dmin + (dmax - dmin) / (S.NDELTA_TABLE - 1.0) * np.arange(S.NDELTA_TABLE)
+            y = 0.03 * (1 + np.maximum(x, -0.999)) ** 1.5 / (1 + 0.05 * r_index)
+            if fmode == W.FCOLL_TABLE_EXP:
+                y = np.log(y)
+            for i in range(S.NDELTA_TABLE):
+                table[i] = y[i]
+            return 0
+
+        cb = S.TABLE_FN(table_fn)
+        _TABLE_CB.append(cb)
+        spec.table_fn = cb
+        spec.mean_f_coll *= 1.6  # (the mean fix rescales the table: this is what sets the ionised fraction)
     if mass_dep_zeta:
         spec.mass_dep_zeta = 1
         spec.f_limit_acg = 1e-4
