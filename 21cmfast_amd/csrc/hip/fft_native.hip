@@ -4234,7 +4234,11 @@ extern "C" int c21hip_split_z_ionise_recomb_xe(const float *delta_work, const fl
     a.f_limit = f_limit;
     a.mass_dep_zeta = mass_dep_zeta;
     a.r_index = r_index;
-    a.rc = getenv("C21CM_DIAG_RC_NOSTORE") ? 2 : 1;  // (2: timing diagnostic, no Gamma_12 stores)
+#ifdef C21CM_DIAG_BUILD  // (make EXTRA=-DC21CM_DIAG_BUILD: timing diagnostics that change results)
+    a.rc = getenv("C21CM_DIAG_RC_NOSTORE") ? 2 : 1;  // (2: no Gamma_12 stores)
+#else
+    a.rc = 1;
+#endif
     a.nrec = nrec;
     a.rec0 = rec0;
     a.g12 = g12;

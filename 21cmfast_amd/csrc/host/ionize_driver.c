@@ -738,11 +738,13 @@ static int tab_build_async(ion_ctx *c, int R_ct, int buf) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     TRY(c21hip_stream_wait_event(g_tab.aux, g_tab.ev_used[buf]));
-    /* C21CM_DIAG_SKIP_TABLES=1 (timing diagnostic, WRONG results): no table kernels after the first
-     * step -- what the R loop would cost if the windows came for free */
+#ifdef C21CM_DIAG_BUILD /* (make EXTRA=-DC21CM_DIAG_BUILD: timing diagnostics that change results) */
+    /* C21CM_DIAG_SKIP_TABLES=1 (WRONG results): no table kernels after the first step -- what the R
+     * loop would cost if the windows came for free */
     static int skip = -1;
     if (skip < 0) skip = getenv("C21CM_DIAG_SKIP_TABLES") != NULL;
     if (!(skip && c->tab_seq > 0))
+#endif
     TRY(c21hip_window_tables(buf, s->hii_filter, 0.f, s->stars_filter, (float)s->mfp_meandens,
                              c->nx, c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_ct],
                              g_tab.aux));
