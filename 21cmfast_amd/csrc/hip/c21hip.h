@@ -532,7 +532,20 @@ int c21hip_eul_band(const double *partials, int n, double *sum_dev, double ntot,
                     double f_limit, double *means_dev, int r_cur, int r_p1, int r_p2, double t_cur,
                     double t_next, int r_next, int cur_banded, int fix_mean, double mean_f_coll,
                     double ion_eff, double min_rel, double shift, double *band_dev, double *thr_dev,
-                    int *fail_dev, unsigned *counter_dev, void *stream);
+                    int *fail_dev, unsigned *counter_dev, int mf_space, int quad, double *pred_dev,
+                    void *stream);
+/* the same for the table models WITH an x_e grid (mf_space = 1: the band and thr_dev hold the mean fix
+ * itself -- the barrier f mf zeta > 1 - x_e has no single threshold): pass Z of the filtered x_e + the
+ * table sweep of the dense filtered density + the barrier in one launch (512-point z-lines) */
+int c21hip_z_xe_fcoll_band_supported(int nx, int ny, int nz);
+int c21hip_split_z_xe_fcoll_band(const float *xe_work, const float *delta_fil, long delta_zstride, float *f_pend,
+                                 float *xe_pend, const double *band_dev, const double *mf_prev_dev,
+                                 unsigned char *first_cross, int r_index, int r_prev, int mode, double tab_min,
+                                 double tab_width, const float *table_dev, int mass_dep_zeta, double f_limit,
+                                 double ion_eff, int nx, int ny, int nz, double *partials, void *stream);
+int c21hip_eul_resolve_pending_xe(int r_index, const float *f_pend, const float *xe_pend, const double *mf_dev,
+                                  int mass_dep_zeta, double f_limit, double ion_eff, unsigned char *first_cross,
+                                  size_t ntot, void *stream);
 int c21hip_eul_rewind(unsigned char *first_cross, int r_fail, size_t ntot, void *stream);
 /* the same for the table modes: c21hip_fcoll_eulerian with the barrier decided in the sweep; the dense
  * f_coll grid is not written, *n_partials_out partial sums stay in `partials` for c21hip_eul_band */

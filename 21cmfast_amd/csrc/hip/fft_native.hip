@@ -40,6 +40,7 @@
 #include "fcoll_device.h"
 #include "ms_window.h"
 #include "c21cm_abi.h"
+#include "c21cm_grid.h"
 
 // experiment switches (tools/build_variant.sh; the defaults are the shipped configuration)
 #ifndef C21X_XPAIR_THREADS
@@ -1580,6 +1581,19 @@ struct ZPassArgs {
     // radius whose markers are outstanding, *mean_dev ITS EXACT THRESHOLD) or by eul_resolve_pending_kernel.
     const double *band;
     int r_prev;
+    // EPI 8 (Eulerian table models with an x_e grid, banded barrier): EPI 5 and fcoll_eulerian_kernel in
+    // ONE sweep.  v = filtered x_e of the cell; delta_fil = the radius' dense (padded, out_zstride floats
+    // per row) filtered density, table / tab_min / tab_width / tab_mode its f_coll table; the f_coll sum
+    // goes to p0 like EPI 2; the barrier f mf zeta > 1 - x_e is monotone in the mean fix mf, which is
+    // known to lie in [band[0], band[1]] (eul_band_step, mf space): cells both ends agree on are final,
+    // the others get the marker 255 and leave (f, clipped x_e) in f_out / xe_pend (sparse, dense layout)
+    // for the next radius' sweep (r_prev >= 0, *mean_dev = ITS EXACT mean fix) or
+    // eul_resolve_pending_xe_kernel.  The dense f_coll grid is neither written nor read.
+    const float *delta_fil;
+    const float *table;
+    float *xe_pend;
+    double tab_min, tab_width;
+    int tab_mode;
 };
 
 // --- building blocks shared by the plain and the fused pass-Z kernels
@@ -1715,7 +1729,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
-            acc0 = (EPI == 2 || EPI == 6 || EPI == 7) ? acc0 + o0 : fmin(acc0, o0);
+            acc0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
             if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
@@ -1729,7 +1743,7 @@ z_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
-                r0 = (EPI == 2 || EPI == 6 || EPI == 7) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
@@ -2397,12 +2411,22 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     uchar2 mprev[EPI == 6 ? A : 1];
     // EPI 7: the mask row of the line as 2 A contiguous bytes per lane (16-byte loads, in flight under
     // the transform); the lanes' (cell 2j, 2j + 1) pairs are picked out of the line's LDS region afterwards
-    constexpr int MV = (EPI == 7) ? A / 8 : 1;
+    constexpr int MV = (EPI == 7 || EPI == 8) ? A / 8 : 1;
     uint4 mreg[MV];
-    if constexpr (EPI == 7) {
+    if constexpr (EPI == 7 || EPI == 8) {
 #pragma unroll
         for (int v = 0; v < MV; v++)
             mreg[v] = reinterpret_cast<const uint4 *>(a.mask_rw + lline * NZ)[b * MV + v];
+    }
+    __shared__ float ftab[EPI == 8 ? C21CM_NDELTA_TABLE : 1];
+    float2 dreg[EPI == 8 ? A : 1];
+    if constexpr (EPI == 8) {  // the radius' f_coll table and the cells' filtered density
+        for (int t = threadIdx.x; t < C21CM_NDELTA_TABLE; t += kBlock) ftab[t] = a.table[t];
+#pragma unroll
+        for (int q = 0; q < A; q++) {
+            const int j = (b + P * (q / P)) + A * (q % P);
+            dreg[q] = reinterpret_cast<const float2 *>(a.delta_fil + lline * a.out_zstride)[j];
+        }
     }
     if constexpr (EPI == 6) {  // the previous radius' f_coll and the mask rows, in flight under the transform
 #pragma unroll
@@ -2414,7 +2438,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     }
     __syncthreads();  // twiddle tables
     wave_c2r<A, P>(x, xh, L, twH, twN, b);
-    if constexpr (EPI == 7) {
+    if constexpr (EPI == 7 || EPI == 8) {
         wave_fence();  // the transform's last reads of the region
 #pragma unroll
         for (int v = 0; v < MV; v++) reinterpret_cast<uint4 *>(L)[b * MV + v] = mreg[v];
@@ -2470,6 +2494,61 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
                 grow[0] = (float)(a.const_factor / (1. + (double)grow[0]) * (double)fmaxf(v.x, 0.f));
             if (m.y == (unsigned char)a.r_index)
                 grow[1] = (float)(a.const_factor / (1. + (double)grow[1]) * (double)fmaxf(v.y, 0.f));
+        } else if (EPI == 8) {
+            const float2 dd = dreg[EPI == 8 ? q : 0];
+            const float d0 = clip_delta_eulerian(dd.x), d1 = clip_delta_eulerian(dd.y);
+            double f0 = eval_table_f((double)d0, a.tab_min, a.tab_width, ftab);
+            double f1 = eval_table_f((double)d1, a.tab_min, a.tab_width, ftab);
+            if (a.tab_mode != C21CM_FCOLL_TABLE_LINEAR) {
+                f0 = exp_f32acc(f0);
+                f1 = exp_f32acc(f1);
+            }
+            acc0 += f0;
+            acc0 += f1;
+            const float g0 = (float)f0, g1 = (float)f1;  // what the dense grid would hold
+            const float xc0 = fminf(fmaxf(v.x, 0.f), 0.999f), xc1 = fminf(fmaxf(v.y, 0.f), 0.999f);
+            uchar2 m = reinterpret_cast<const uchar2 *>(L)[j];
+            float *frow = a.f_out + lline * NZ + 2 * j, *xrow = a.xe_pend + lline * NZ + 2 * j;
+            bool ch = false;
+            if (a.r_prev >= 0 && (m.x == 255 || m.y == 255)) {  // the previous radius' undecided cells
+                const double mf_prev = *a.mean_dev;
+                if (m.x == 255) {
+                    double c0 = mf_prev * (double)frow[0];
+                    if (a.mass_dep_zeta && c0 < a.f_limit) c0 = a.f_limit;
+                    m.x = (c0 * a.ion_eff > (1. - (double)xrow[0])) ? (unsigned char)a.r_prev : (unsigned char)0;
+                }
+                if (m.y == 255) {
+                    double c1 = mf_prev * (double)frow[1];
+                    if (a.mass_dep_zeta && c1 < a.f_limit) c1 = a.f_limit;
+                    m.y = (c1 * a.ion_eff > (1. - (double)xrow[1])) ? (unsigned char)a.r_prev : (unsigned char)0;
+                }
+                ch = true;
+            }
+            if (m.x == 0 || m.y == 0) {
+                const double mf_lo = a.band[0], mf_hi = a.band[1];
+                double l0 = mf_lo * (double)g0, l1 = mf_lo * (double)g1;
+                double h0 = mf_hi * (double)g0, h1 = mf_hi * (double)g1;
+                if (a.mass_dep_zeta) {
+                    if (l0 < a.f_limit) l0 = a.f_limit;
+                    if (l1 < a.f_limit) l1 = a.f_limit;
+                    if (h0 < a.f_limit) h0 = a.f_limit;
+                    if (h1 < a.f_limit) h1 = a.f_limit;
+                }
+                const double n0 = 1. - (double)xc0, n1 = 1. - (double)xc1;
+                if (m.x == 0 && h0 * a.ion_eff > n0) {
+                    const bool sure = l0 * a.ion_eff > n0;
+                    m.x = sure ? (unsigned char)a.r_index : (unsigned char)255;
+                    if (!sure) frow[0] = g0, xrow[0] = xc0;
+                    ch = true;
+                }
+                if (m.y == 0 && h1 * a.ion_eff > n1) {
+                    const bool sure = l1 * a.ion_eff > n1;
+                    m.y = sure ? (unsigned char)a.r_index : (unsigned char)255;
+                    if (!sure) frow[1] = g1, xrow[1] = xc1;
+                    ch = true;
+                }
+            }
+            if (ch) reinterpret_cast<uchar2 *>(L)[j] = m;
         } else if (EPI == 7) {
             const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
             const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
@@ -2525,7 +2604,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             }
         }
     }
-    if constexpr (EPI == 7) {  // changed 16-byte pieces of the mask row back to the grid
+    if constexpr (EPI == 7 || EPI == 8) {  // changed 16-byte pieces of the mask row back to the grid
         wave_fence();
 #pragma unroll
         for (int v = 0; v < MV; v++) {
@@ -2539,7 +2618,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
-            acc0 = (EPI == 2 || EPI == 6 || EPI == 7) ? acc0 + o0 : fmin(acc0, o0);
+            acc0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
             if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
@@ -2553,7 +2632,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
-                r0 = (EPI == 2 || EPI == 6 || EPI == 7) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
@@ -4348,6 +4427,60 @@ extern "C" int c21hip_split_z_xe_mask(const float *xe_work, const float *nion_de
         hipLaunchKernelGGL((zw_c2r_kernel<16, 5, 16>), grid, dim3(kBlock), 0, (hipStream_t)stream, z, twH, twN);
     else
         return C21CM_VALUE_ERROR;
+    LAUNCH_CHECK();
+    return 0;
+}
+// Eulerian table models with an x_e grid, banded barrier (EPI 8): pass Z of the filtered x_e + the table
+// sweep of the radius' dense filtered density + the barrier, in one launch.  band_dev = [mf_lo, mf_hi] of
+// this radius, mf_prev_dev = the exact mean fix of radius r_prev (whose markers are outstanding; < 0:
+// none); f_pend / xe_pend receive (f_coll, clipped x_e) of the undecided cells; nx*ny/16 partial sums of
+// f_coll are left in `partials` for c21hip_eul_band.  512-point z-lines.
+extern "C" int c21hip_z_xe_fcoll_band_supported(int nx, int ny, int nz) {
+    return nz == 512 && zw_lines_of(nz, (long)nx * ny) != 0;
+}
+extern "C" int c21hip_split_z_xe_fcoll_band(const float *xe_work, const float *delta_fil, long delta_zstride,
+                                            float *f_pend, float *xe_pend, const double *band_dev,
+                                            const double *mf_prev_dev, unsigned char *first_cross,
+                                            int r_index, int r_prev, int mode, double tab_min,
+                                            double tab_width, const float *table_dev, int mass_dep_zeta,
+                                            double f_limit, double ion_eff, int nx, int ny, int nz,
+                                            double *partials, void *stream) {
+    if (!c21hip_z_xe_fcoll_band_supported(nx, ny, nz) || r_index <= 0 || r_index >= 255 || r_prev >= 255 ||
+        (mode != C21CM_FCOLL_TABLE_LINEAR && mode != C21CM_FCOLL_TABLE_EXP) || delta_zstride % 2) {
+        c21hip_set_error("x_e pass Z with the banded barrier: unsupported box, mode or radius index");
+        return C21CM_VALUE_ERROR;
+    }
+    const long nlines = (long)nx * ny;
+    const int zwl = zw_lines_of(nz, nlines);
+    const float2 *twH = twiddles(nz / 2);
+    const float2 *twN = twiddles(nz);
+    if (!twH || !twN) return C21CM_MEMORY_ALLOC_ERROR;
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(xe_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out_zstride = delta_zstride;
+    z.out_scale = 1.0f;
+    z.delta_fil = delta_fil;
+    z.table = table_dev;
+    z.tab_min = tab_min;
+    z.tab_width = tab_width;
+    z.tab_mode = mode;
+    z.f_out = f_pend;
+    z.xe_pend = xe_pend;
+    z.band = band_dev;
+    z.mean_dev = mf_prev_dev;
+    z.mask_rw = first_cross;
+    z.mass_dep_zeta = mass_dep_zeta;
+    z.f_limit = f_limit;
+    z.ion_eff = ion_eff;
+    z.r_index = r_index;
+    z.r_prev = r_prev;
+    z.p0 = partials;
+    KTimeScope kt(11, (hipStream_t)stream);
+    hipLaunchKernelGGL((zw_c2r_kernel<16, 8, 16>), dim3((unsigned)(nlines / zwl)), dim3(kBlock), 0,
+                       (hipStream_t)stream, z, twH, twN);
     LAUNCH_CHECK();
     return 0;
 }

@@ -623,6 +623,9 @@ __device__ float eul_threshold(double mf, int mass_dep_zeta, double f_limit, dou
 struct EulBandArgs {
     double ntot, f_limit, t_cur, t_next, mean_f_coll, ion_eff, min_rel, shift;
     int mass_dep_zeta, r_cur, r_p1, r_p2, r_next, cur_banded, fix_mean;
+    int mf_space;  // 1: band[] / thr[] hold the mean fix itself, not thresholds (barriers with an x_e grid)
+    int quad;      // 1: the last three radii and the next are equally spaced in ln R: quadratic extrapolation
+    double *pred;  // [radius]: the mean predicted for it (0: none), the error of which widens the next band
     double *means, *band, *thr;
     int *fail;
 };
@@ -640,23 +643,38 @@ __device__ void eul_band_step(double sum_value, const EulBandArgs &a) {
         if (m <= kFractFloatErr) m = kFractFloatErr;
     }
     means[r_cur] = m;
-    const float t_exact = eul_threshold(fix_mean ? mean_f_coll / m : 1., mass_dep_zeta, f_limit, ion_eff);
-    thr[r_cur] = (double)t_exact;
-    if (cur_banded) {
-        if (!((float)band[2 * r_cur + 1] <= t_exact && t_exact <= (float)band[2 * r_cur]) && *fail < r_cur)
-            *fail = r_cur;
+    if (a.mf_space) {  // the barrier also depends on the cell's x_e: no single threshold; the band is one of mf
+        const double mf = fix_mean ? mean_f_coll / m : 1.;
+        thr[r_cur] = mf;
+        if (cur_banded && !(band[2 * r_cur] <= mf && mf <= band[2 * r_cur + 1]) && *fail < r_cur) *fail = r_cur;
+    } else {
+        const float t_exact = eul_threshold(fix_mean ? mean_f_coll / m : 1., mass_dep_zeta, f_limit, ion_eff);
+        thr[r_cur] = (double)t_exact;
+        if (cur_banded) {
+            if (!((float)band[2 * r_cur + 1] <= t_exact && t_exact <= (float)band[2 * r_cur]) && *fail < r_cur)
+                *fail = r_cur;
+        }
     }
     if (r_next < 0) return;
     double lo = 1., hi = 1.;
     if (fix_mean) {
         const double m1 = r_p1 >= 0 ? means[r_p1] : m;
-        const double pred = (m + (m - m1) * t_next) * (1. + shift);
+        double pred = m + (m - m1) * t_next;
+        if (a.quad && r_p2 >= 0) pred = 3. * m - 3. * m1 + means[r_p2];  // equal steps in ln R
+        pred *= 1. + shift;
         double err = fabs(m - m1);
         if (r_p2 >= 0) err = fabs(m - (m1 + (m1 - means[r_p2]) * t_cur));
+        if (a.pred[r_cur] > 0.) err = fabs(m - a.pred[r_cur]);  // what the rule in use was off by this time
+        a.pred[r_next] = pred;
         const double w = fmax(min_rel * fabs(pred), 8. * err);
         const double mean_lo = pred - w, mean_hi = pred + w;
         lo = mean_f_coll / mean_hi;
         hi = mean_lo > 0. ? mean_f_coll / mean_lo : (double)INFINITY;
+    }
+    if (a.mf_space) {
+        band[2 * r_next] = lo;
+        band[2 * r_next + 1] = hi;
+        return;
     }
     band[2 * r_next] = (double)eul_threshold(lo, mass_dep_zeta, f_limit, ion_eff);
     band[2 * r_next + 1] = (double)eul_threshold(hi, mass_dep_zeta, f_limit, ion_eff);
@@ -765,6 +783,44 @@ eul_resolve_pending_kernel(int r_index, const float *__restrict__ f_pend,
             for (int k = 0; k < 4; k++) {
                 if (((v >> (8 * k)) & 0xffu) != 0xffu) continue;
                 const unsigned r = (f_pend[i * 16 + e * 4 + k] >= t) ? (unsigned)r_index : 0u;
+                v = (v & ~(0xffu << (8 * k))) | (r << (8 * k));
+            }
+            wv[e] = v;
+        }
+        reinterpret_cast<uint4 *>(first_cross)[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+}
+
+// ... with an x_e grid: the undecided cells left (f_coll, clipped x_e); eulerian_mask_kernel's statements
+// with the exact mean fix *mf_dev of radius r_index.
+__global__ void __launch_bounds__(kBlock)
+eul_resolve_pending_xe_kernel(int r_index, const float *__restrict__ f_pend,
+                              const float *__restrict__ xe_pend, const double *__restrict__ mf_dev,
+                              int mass_dep_zeta, double f_limit, double ion_eff,
+                              unsigned char *__restrict__ first_cross, size_t n16) {
+    const double mf = *mf_dev;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (size_t)gridDim.x * kBlock) {
+        uint4 w = reinterpret_cast<const uint4 *>(first_cross)[i];
+        unsigned wv[4] = {w.x, w.y, w.z, w.w};
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const unsigned v = wv[e];
+            if ((v & 0xffu) == 0xffu || (v & 0xff00u) == 0xff00u || (v & 0xff0000u) == 0xff0000u ||
+                (v & 0xff000000u) == 0xff000000u)
+                any = true;
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            unsigned v = wv[e];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (((v >> (8 * k)) & 0xffu) != 0xffu) continue;
+                const size_t cell = i * 16 + e * 4 + k;
+                double c = mf * (double)f_pend[cell];
+                if (mass_dep_zeta && c < f_limit) c = f_limit;
+                const unsigned r = (c * ion_eff > (1. - (double)xe_pend[cell])) ? (unsigned)r_index : 0u;
                 v = (v & ~(0xffu << (8 * k))) | (r << (8 * k));
             }
             wv[e] = v;
@@ -1600,8 +1656,12 @@ extern "C" int c21hip_eul_band(const double *partials, int n, double *sum_dev, d
                                int r_p2, double t_cur, double t_next, int r_next, int cur_banded,
                                int fix_mean, double mean_f_coll, double ion_eff, double min_rel,
                                double shift, double *band_dev, double *thr_dev, int *fail_dev,
-                               unsigned *counter_dev, void *stream) {
+                               unsigned *counter_dev, int mf_space, int quad, double *pred_dev,
+                               void *stream) {
     EulBandArgs a;
+    a.mf_space = mf_space;
+    a.quad = quad;
+    a.pred = pred_dev;
     a.ntot = ntot, a.f_limit = f_limit, a.t_cur = t_cur, a.t_next = t_next, a.mean_f_coll = mean_f_coll;
     a.ion_eff = ion_eff, a.min_rel = min_rel, a.shift = shift, a.mass_dep_zeta = mass_dep_zeta;
     a.r_cur = r_cur, a.r_p1 = r_p1, a.r_p2 = r_p2, a.r_next = r_next, a.cur_banded = cur_banded;
@@ -1633,6 +1693,21 @@ extern "C" int c21hip_eul_resolve_pending(int r_index, const float *f_pend, cons
     }
     hipLaunchKernelGGL(eul_resolve_pending_kernel, dim3(grid_for(ntot / 16)), dim3(kBlock), 0,
                        (hipStream_t)stream, r_index, f_pend, thr_dev, first_cross, ntot / 16);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int c21hip_eul_resolve_pending_xe(int r_index, const float *f_pend, const float *xe_pend,
+                                             const double *mf_dev, int mass_dep_zeta, double f_limit,
+                                             double ion_eff, unsigned char *first_cross, size_t ntot,
+                                             void *stream) {
+    if (ntot % 16) {
+        c21hip_set_error("banded barrier: the box is not a multiple of 16 cells");
+        return C21CM_VALUE_ERROR;
+    }
+    hipLaunchKernelGGL(eul_resolve_pending_xe_kernel, dim3(grid_for(ntot / 16)), dim3(kBlock), 0,
+                       (hipStream_t)stream, r_index, f_pend, xe_pend, mf_dev, mass_dep_zeta, f_limit, ion_eff,
+                       first_cross, ntot / 16);
     LAUNCH_CHECK();
     return 0;
 }

@@ -96,6 +96,7 @@ enum {
     WS_SPHERE_RSQ = 216,
     WS_SFR_WORK2 = 246, /* fused recombination loop: whalo_sfr of the second radius of a sweep */
     WS_R_DEV = 247,     /* float R per radius index (mean free path of a first crossing) */
+    WS_EUL_XEPEND = 253, /* banded barrier with an x_e grid: clipped x_e of the undecided cells (sparse) */
     WS_NION_DENSE2 = 254 /* closed-form Eulerian loop: second dense f_coll buffer (deferred barrier) */
 };
 
@@ -125,7 +126,8 @@ typedef struct {
 #define SC_BANDX (SC_BAND + 2 * C21CM_MAX_RADII) /* exact threshold of every radius */
 #define SC_BANDFAIL (SC_BANDX + C21CM_MAX_RADII) /* an int stored in a double-sized cell */
 #define SC_BANDCTR (SC_BANDFAIL + 1) /* arrival counter of eul_sum_band_kernel (an unsigned, zero between launches) */
-#define SC_COUNT (SC_BANDCTR + 1)
+#define SC_BANDP (SC_BANDCTR + 1)    /* the mean predicted for every radius (0: none) */
+#define SC_COUNT (SC_BANDP + C21CM_MAX_RADII)
 
 #define TRY(expr)                   \
     do {                            \
@@ -348,6 +350,8 @@ typedef struct {
     int band_pend;       /* radius whose markers (255) are outstanding in band_mask (-1: none) */
     int band_h1, band_h2, band_hn; /* the last two radii of this loop with a mean on the device */
     unsigned char *band_mask;
+    int band_mf;         /* 1: this loop's bands live in mean-fix space (barriers with an x_e grid) */
+    float *band_xe_pend; /* ... and its undecided cells leave their clipped x_e here */
     const float *cur_xe; /* fused recombination loop with an x_e grid: its work spectrum of the radius in hand */
     /* third HII-window spectrum of the fused loop: the x_e grid, or -- on the fused recombination loop
      * with CELL_RECOMB = false -- the previous snapshot's N_rec (x3_nrec) */
@@ -471,6 +475,8 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->band_next = c->band_pend = c->band_h1 = c->band_h2 = -1;
     c->band_hn = 0;
     c->band_mask = NULL;
+    c->band_mf = 0;
+    c->band_xe_pend = NULL;
     c->sphere = s->ionise_entire_sphere;
     c->mini = s->use_mini_halos && !c->lagrangian;
     c->lag_mini = s->use_mini_halos && c->lagrangian;
@@ -1179,6 +1185,10 @@ static int eul_band_flush(ion_ctx *c) {
     if (c->band_pend < 0) return 0;
     const int R = c->band_pend;
     c->band_pend = -1;
+    if (c->band_mf)
+        return c21hip_eul_resolve_pending_xe(R, c->nion_dense, c->band_xe_pend, c->scalars + SC_BANDX + R,
+                                             c->s->mass_dep_zeta, c->s->f_limit_acg, c->s->ion_eff_factor,
+                                             c->band_mask, c->ntot, c->stream);
     return c21hip_eul_resolve_pending(R, c->nion_dense, c->scalars + SC_BANDX + R, c->band_mask, c->ntot,
                                       c->stream);
 }
@@ -1245,6 +1255,11 @@ static int eul_band_after(ion_ctx *c, int R_ct, int next_R, int banded, int sig_
         if (next_R >= 1) t_next = (log(s->R[next_R]) - log(s->R[R_ct])) / d1;
         if (h2 >= 0) t_cur = d1 / (log(s->R[h1]) - log(s->R[h2]));
     }
+    /* three equally spaced points in ln R (the ladder is geometric; a rank's share of it too): quadratic
+     * extrapolation -- the E-INTEGRAL mean doubles over the ladder and bends (C21CM_EUL_BAND_QUAD=0: linear) */
+    const char *e_q = getenv("C21CM_EUL_BAND_QUAD");
+    const int quad = h1 >= 0 && h2 >= 0 && next_R >= 1 && fabs(t_next - 1.) < 1e-6 && fabs(t_cur - 1.) < 1e-6 &&
+                     !(e_q && e_q[0] == '0');
     const char *e_sb = getenv("C21CM_EUL_SUMBAND"); /* 0: c21hip_reduce_sum's own launches (A/B) */
     const int split = partials && e_sb && e_sb[0] == '0';
     if (split) TRY(c21hip_reduce_sum(partials, n_part, sum_dev, c->stream));
@@ -1253,7 +1268,7 @@ static int eul_band_after(ion_ctx *c, int R_ct, int next_R, int banded, int sig_
                         will_next ? next_R : -1, banded, s->fix_mean, s->mean_f_coll, s->ion_eff_factor,
                         min_rel, shift, c->scalars + SC_BAND, c->scalars + SC_BANDX,
                         (int *)(c->scalars + SC_BANDFAIL), (unsigned *)(c->scalars + SC_BANDCTR),
-                        c->stream));
+                        c->band_mf, quad, c->scalars + SC_BANDP, c->stream));
     c->band_next = will_next ? next_R : -1;
     if (sig_ok) {
         c->band_h2 = h1;
@@ -1551,8 +1566,22 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
     }
     /* banded barrier: table modes without an x_e grid (its barrier needs x_e(R) of the cell, which only
      * the x_e grid's own pass Z holds).  (nz even: the kernel's two-cell items) */
-    const int use_band = !s->use_ts_fluct && c->nz % 2 == 0 && c->ntot % 16 == 0 && s->n_radii < 255 &&
-                         !c->band_off && !(getenv("C21CM_EUL_BAND") && getenv("C21CM_EUL_BAND")[0] == '0');
+    const int band_on = c->nz % 2 == 0 && c->ntot % 16 == 0 && s->n_radii < 255 && !c->band_off &&
+                        !(getenv("C21CM_EUL_BAND") && getenv("C21CM_EUL_BAND")[0] == '0');
+    const int use_band = band_on && !s->use_ts_fluct;
+    /* ... and WITH an x_e grid (round 4, late): the x_e grid's pass Z does the table sweep as well and
+     * decides the cells on a band of the mean fix itself (the barrier f mf zeta > 1 - x_e is monotone in
+     * mf but has no single threshold); undecided cells leave (f, x_e).  Needs the fused x_e sweep. */
+    const int use_band_xe = band_on && s->use_ts_fluct && eul_xe_fused(c) &&
+                            c21hip_z_xe_fcoll_band_supported(c->nx, c->ny, c->nz);
+    if (use_band_xe) {
+        c->band_mf = 1;
+        c->band_xe_pend = (float *)c21hip_ws(WS_EUL_XEPEND, c->ntot * sizeof(float));
+        if (!c->band_xe_pend) {
+            status = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+    }
     TRY(eul_stage_a(c, radii[0], 0, dfil[0], mm[0], ev[0]));
     for (int i = 0; i < n; i++) {
         const int b = i & 1, R_ct = radii[i];
@@ -1570,6 +1599,36 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
         double *sum_dev = c->scalars + SC_SUMS + R_ct, *mean_dev = c->scalars + SC_MEANS + R_ct;
         c21hip_ionize_args args;
         fill_args(&args, s, R_ct);
+        if (use_band_xe) {
+            const int banded = eul_band_this(c, R_ct, mask, 1);
+            const float *xw = b ? c->xe_work2 : c->xe_work;
+            if (banded) {
+                TRY(c21hip_split_z_xe_fcoll_band(
+                    xw, dfil[b], 2 * (long)(c->nz / 2 + 1), c->nion_dense, c->band_xe_pend,
+                    c->scalars + SC_BAND + 2 * R_ct,
+                    c->scalars + SC_BANDX + (c->band_pend >= 0 ? c->band_pend : 0), mask, R_ct, c->band_pend,
+                    s->fcoll_mode, min_density, (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
+                    table_dev, s->mass_dep_zeta, s->f_limit_acg, s->ion_eff_factor, c->nx, c->ny, c->nz,
+                    c->partials, c->stream));
+                c->band_pend = R_ct;
+                c->band_mask = mask;
+                c->band_used = 1;
+                TRY(eul_band_after(c, R_ct, i + 1 < n ? radii[i + 1] : -1, 1, 1, c->partials,
+                                   (int)((long)c->nx * c->ny / 16), sum_dev));
+            } else {
+                TRY(eul_band_flush(c)); /* the dense sweep overwrites the marked cells' f_coll */
+                TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
+                                          s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
+                                          s->delta_c, min_density,
+                                          (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
+                                          table_dev, c->partials, sum_dev, c->stream));
+                TRY(eul_band_after(c, R_ct, i + 1 < n ? radii[i + 1] : -1, 0, 1, NULL, 0, sum_dev));
+                TRY(c21hip_split_z_xe_mask(xw, c->nion_dense, mean_dev, mask, c->nx, c->ny, c->nz, R_ct,
+                                           s->mean_f_coll, s->fix_mean, s->mass_dep_zeta, s->f_limit_acg,
+                                           s->ion_eff_factor, c->stream));
+            }
+            continue;
+        }
         if (use_band) {
             /* banded barrier (see eul_band_ok): the table sweep decides the cells itself, no dense
              * f_coll grid, no barrier sweep */
@@ -1790,6 +1849,27 @@ done:
     return status;
 }
 
+/* Eulerian source models (and every other loop off the fused path) on the native passes: the density
+ * (and x_e) windows of the radii first, first - step, ... evaluated inside pass X (top-hat / sharp-k
+ * HII_FILTER), no window tables.  The single pass AND the shard phases call this, so that a rank's
+ * radii see the very arithmetic of the single pass: the evaluated windows (quintic Hermite in float)
+ * and the table fallback (fp64, rounded) differ by an ulp or two of W, which is enough to flip a cell
+ * within float noise of a barrier -- the sharded result is only bit-identical by construction if both
+ * use the same one (round 4: the shard phases did not, and test_gpu_config5's comparison failed on about
+ * one box in three). */
+static int native_wev_prepare(ion_ctx *c, int first, int step, void *stream) {
+    const c21cm_ionize_spec *spec = c->s;
+    if (!c->native || c->fused) return 0;
+    float radii[C21CM_MAX_RADII];
+    int n = 0, on = 0;
+    for (int R_ct = first; R_ct >= 1 && R_ct >= spec->r_lowest && n < C21CM_MAX_RADII; R_ct -= step)
+        radii[n++] = (float)spec->R[R_ct];
+    if (n == 0) return 0;
+    return c21hip_wev_prepare(spec->hii_filter, 0.f, spec->hii_filter, 0.f, spec->use_ts_fluct ? 2 : 1,
+                              radii, n, c->nx, c->ny, c->nz, spec->box_len, spec->box_len_z, 0, &on,
+                              stream);
+}
+
 int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
                        const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                        const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
@@ -1820,19 +1900,8 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
         const int use_mask = c.fused || c.eul_mask || c.sphere;
         int mask_pending = use_mask;
         int R_start = spec->n_radii;
-        /* Eulerian source models on the native passes: the density (and x_e) windows of every radius
-         * evaluated inside pass X (top-hat / sharp-k HII_FILTER), no window tables.  The fused
-         * Lagrangian loop prepares its own set; grids with other windows keep their tables. */
-        if (c.native && !c.fused) {
-            float radii[C21CM_MAX_RADII];
-            int n = 0, on = 0;
-            for (int R_ct = spec->n_radii - 1; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct--)
-                radii[n++] = (float)spec->R[R_ct];
-            if (n > 0)
-                TRY(c21hip_wev_prepare(spec->hii_filter, 0.f, spec->hii_filter, 0.f,
-                                       spec->use_ts_fluct ? 2 : 1, radii, n, c.nx, c.ny, c.nz,
-                                       spec->box_len, spec->box_len_z, 0, &on, stream));
-        }
+        /* (the fused Lagrangian loop prepares its own set; grids with other windows keep their tables) */
+        TRY(native_wev_prepare(&c, spec->n_radii - 1, 1, stream));
         if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC && spec->fcoll_mode != C21CM_FCOLL_NODES) {
             int radii[C21CM_MAX_RADII], n = 0;
             for (int R_ct = spec->n_radii - 1; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct--)
@@ -1994,6 +2063,7 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
     TRY(preloop(&c));
     spectra_remember(&c, perturbed_field, halos, spin_temp);
     TRY(c21hip_event_record(ev[1], stream));
+    TRY(native_wev_prepare(&c, spec->n_radii - 1, 1, stream)); /* the single pass' node tables: the whole ladder */
     /* radii n-1 .. 1 dealt round-robin, largest first; index 0 belongs to the finish step */
     if (c.eul_mask && spec->fcoll_mode != C21CM_FCOLL_ERFC && spec->fcoll_mode != C21CM_FCOLL_NODES) {
         int radii[C21CM_MAX_RADII], n = 0;
@@ -2056,6 +2126,7 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
         report->ms_postloop = 0.;
     }
 done:
+    c21hip_wev_release();
     for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
     return status;
 }
@@ -2170,6 +2241,7 @@ int c21cm_ionize_shard_radii_keys(const c21cm_ionize_spec *spec, int rank, int w
     TRY(preloop(&c));
     spectra_remember(&c, perturbed_field, halos, spin_temp);
     TRY(c21hip_event_record(ev[1], stream));
+    TRY(native_wev_prepare(&c, spec->n_radii - 1, 1, stream)); /* the single pass' node tables: the whole ladder */
     for (int R_ct = spec->n_radii - 1 - rank; R_ct >= 1; R_ct -= world) {
         if (R_ct < spec->r_lowest) break;
         TRY(one_radius(&c, R_ct, NULL, R_ct - world));
@@ -2187,6 +2259,7 @@ int c21cm_ionize_shard_radii_keys(const c21cm_ionize_spec *spec, int rank, int w
         report->ms_postloop = 0.;
     }
 done:
+    c21hip_wev_release();
     for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
     return status;
 }

@@ -903,3 +903,80 @@ def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, fmode, r_lowes
             torch.cuda.synchronize()
             assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction)
             assert rep0.global_xH == rep2.global_xH
+
+
+@pytest.mark.parametrize("fmode", [W.FCOLL_TABLE_EXP, W.FCOLL_TABLE_LINEAR])
+def test_table_loop_with_xe_grid_banded_barrier_equals_dense_sweeps(api, fmode, monkeypatch, capfd):
+    """Eulerian table models WITH an x_e grid (spin-temperature runs: config 5's ComputeIonizedBox): the
+    x_e grid's pass Z also does the radius' table sweep and decides the cells on a predicted band of the
+    mean fix (the barrier f mf zeta > 1 - x_e is monotone in mf); undecided cells leave (f, x_e) for the
+    next sweep.  No dense f_coll grid, no fcoll_eulerian_kernel.  Same first crossings as the dense
+    sequence (C21CM_EUL_BAND=0) -- the f_coll sums are added in another order, so the means agree to the
+    last bits of a double and a cell would have to sit within 1e-16 of its barrier to differ --, single pass
+    and sharded over 2 and 3 ranks; a forced miss (C21CM_EUL_BAND_SHIFT) is detected and rerun."""
+    import re
+
+    import torch
+
+    S = importlib.import_module("21cmfast_amd.structs")
+    n, nz = 64, 512
+
+    def table_fn(r_index, dmin, dmax, table, user):
+        x = dmin + (dmax - dmin) / (S.NDELTA_TABLE - 1.0) * np.arange(S.NDELTA_TABLE)
+        y = 0.03 * (1 + np.maximum(x, -0.999)) ** 1.5 / (1 + 0.05 * r_index)
+        if fmode == W.FCOLL_TABLE_EXP:
+            y = np.log(y)
+        for i in range(S.NDELTA_TABLE):
+            table[i] = y[i]
+        return 0
+
+    cb = S.TABLE_FN(table_fn)
+    _TABLE_CB.append(cb)
+    spec = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=9.0, use_ts_fluct=1)
+    spec.table_fn = cb
+    spec.mean_f_coll *= 1.6
+    rng = np.random.default_rng(5)
+    density = torch.from_numpy(W.density_field_numpy((n, n, nz), seed=21)).cuda()
+    xe = torch.from_numpy((0.3 * rng.random((n, n, nz)) ** 2).astype(np.float32)).cuda()
+    Tn = torch.from_numpy((50 + 10 * rng.random((n, n, nz))).astype(np.float32)).cuda()
+    kw = dict(xe=xe, Tneutral=Tn)
+    monkeypatch.setenv("C21CM_EUL_BAND", "0")
+    buf0, _, rep0 = api.ionize_grids(spec, density, None, **kw)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("C21CM_EUL_BAND")
+    monkeypatch.setenv("C21CM_EUL_BAND_DEBUG", "1")
+    buf1, _, rep1 = api.ionize_grids(spec, density, None, **kw)
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    assert "band fail=0" in err, err  # the banded sweeps ran and every band held
+    monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
+    assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
+    names = ["neutral_fraction", "z_reion", "kinetic_temperature"]
+    for name in names:
+        assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
+    k = spec.n_radii
+    np.testing.assert_allclose(np.array(rep1.f_coll_grid_mean[:k]), np.array(rep0.f_coll_grid_mean[:k]), rtol=1e-13)
+    assert rep0.global_xH == rep1.global_xH
+    monkeypatch.setenv("C21CM_EUL_BAND_SHIFT", "0.2")
+    monkeypatch.setenv("C21CM_EUL_BAND_DEBUG", "1")
+    buf3, _, rep3 = api.ionize_grids(spec, density, None, **kw)
+    torch.cuda.synchronize()
+    assert re.search(r"band fail=[1-9]", capfd.readouterr().err)
+    monkeypatch.delenv("C21CM_EUL_BAND_SHIFT")
+    monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
+    for name in names:
+        assert torch.equal(getattr(buf0, name), getattr(buf3, name)), name
+    for world in (2, 3):
+        masks = []
+        for rank in range(world):
+            fc = torch.zeros((n, n, nz), dtype=torch.uint8, device="cuda")
+            api.ionize_shard_radii(spec, rank, world, fc, density, None, **kw)
+            masks.append(fc)
+        reduced = masks[0]
+        for m in masks[1:]:
+            reduced = torch.maximum(reduced, m)
+        assert int((reduced == 255).sum()) == 0  # no marker survives a shard phase
+        buf2, _, rep2 = api.ionize_shard_finish(spec, reduced.contiguous(), density, None, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction)
+        assert rep0.global_xH == rep2.global_xH
