@@ -616,8 +616,8 @@ __device__ float eul_threshold(double mf, int mass_dep_zeta, double f_limit, dou
 // lie between the band's two?  If not the definite decisions of its sweep cannot be trusted: *fail = the
 // largest such radius index, and the host reruns the loop from that radius on with the dense sweeps
 // (eul_rewind_kernel restores the grid to what it was before that radius); (ii) the band of the next
-// radius r_next: its mean extrapolated linearly in ln R from the last two means (t = the step ratio),
-// widened by min_rel of itself and by 8 x the error the same extrapolation made for r_cur; band[2 r] =
+// radius r_next: ln(mean) extrapolated in ln R from the last two (three, where equally spaced) means,
+// widened by min_rel of itself and by 8 x the relative error the same rule made for r_cur; band[2 r] =
 // threshold at the lower end of mean_f_coll / mean (cells at or above it cross whatever the exact mean
 // turns out to be), band[2 r + 1] = threshold at the upper end (cells below it do not).
 struct EulBandArgs {
@@ -625,7 +625,8 @@ struct EulBandArgs {
     int mass_dep_zeta, r_cur, r_p1, r_p2, r_next, cur_banded, fix_mean;
     int mf_space;  // 1: band[] / thr[] hold the mean fix itself, not thresholds (barriers with an x_e grid)
     int quad;      // 1: the last three radii and the next are equally spaced in ln R: quadratic extrapolation
-    double *pred;  // [radius]: the mean predicted for it (0: none), the error of which widens the next band
+    double *pred;  // [radius][2]: the mean the linear / the quadratic rule predicted for it (0: none); then
+                   // [radius]: the relative error measure in force after it
     double *means, *band, *thr;
     int *fail;
 };
@@ -658,14 +659,32 @@ __device__ void eul_band_step(double sum_value, const EulBandArgs &a) {
     if (r_next < 0) return;
     double lo = 1., hi = 1.;
     if (fix_mean) {
+        // ln <f> against ln R: the mean spans decades over the ladder at high redshift (512^3, z = 15: a
+        // factor of 50) and bends.  Two rules -- the straight line through the last two points and, where
+        // three radii and the next are equally spaced in ln R, the parabola through the last three -- are
+        // both evaluated for every radius; the one that predicted the CURRENT radius better is believed for
+        // the next (smooth, curved ladders: the parabola; small noisy boxes: the line), and what it was off
+        // by is the measure of the band.  (means are > 0: clamped above)
         const double m1 = r_p1 >= 0 ? means[r_p1] : m;
-        double pred = m + (m - m1) * t_next;
-        if (a.quad && r_p2 >= 0) pred = 3. * m - 3. * m1 + means[r_p2];  // equal steps in ln R
-        pred *= 1. + shift;
-        double err = fabs(m - m1);
-        if (r_p2 >= 0) err = fabs(m - (m1 + (m1 - means[r_p2]) * t_cur));
-        if (a.pred[r_cur] > 0.) err = fabs(m - a.pred[r_cur]);  // what the rule in use was off by this time
-        a.pred[r_next] = pred;
+        const double l0 = log(m), l1 = log(m1);
+        const double lpl = l0 + (l0 - l1) * t_next;
+        const bool have_q = a.quad && r_p2 >= 0;
+        const double lpq = have_q ? 3. * l0 - 3. * l1 + log(means[r_p2]) : lpl;
+        const double pl = a.pred[2 * r_cur], pq = a.pred[2 * r_cur + 1];
+        const double el = pl > 0. ? fabs(m - pl) / m : (double)INFINITY;
+        const double eq = pq > 0. ? fabs(m - pq) / m : (double)INFINITY;
+        const bool use_q = have_q && eq < el;
+        double err = use_q ? eq : el;
+        if (!(err < (double)INFINITY)) err = fabs(m - m1) / m;  // no prediction yet: the step itself
+        // the curve is not equally smooth everywhere (at high redshift the mean hangs on a few peaks and
+        // jumps by several per cent between radii), and an error that happens to be small says little
+        // about the next: the measure is the largest recent error, forgotten at 20 % a radius
+        if (r_p1 >= 0) err = fmax(err, 0.8 * a.pred[2 * C21CM_MAX_RADII + r_p1]);
+        a.pred[2 * C21CM_MAX_RADII + r_cur] = err;
+        const double pred = exp(use_q ? lpq : lpl) * (1. + shift);
+        a.pred[2 * r_next] = exp(lpl);
+        a.pred[2 * r_next + 1] = have_q ? exp(lpq) : 0.;
+        err *= fabs(pred);
         const double w = fmax(min_rel * fabs(pred), 8. * err);
         const double mean_lo = pred - w, mean_hi = pred + w;
         lo = mean_f_coll / mean_hi;

@@ -126,8 +126,8 @@ typedef struct {
 #define SC_BANDX (SC_BAND + 2 * C21CM_MAX_RADII) /* exact threshold of every radius */
 #define SC_BANDFAIL (SC_BANDX + C21CM_MAX_RADII) /* an int stored in a double-sized cell */
 #define SC_BANDCTR (SC_BANDFAIL + 1) /* arrival counter of eul_sum_band_kernel (an unsigned, zero between launches) */
-#define SC_BANDP (SC_BANDCTR + 1)    /* the mean predicted for every radius (0: none) */
-#define SC_COUNT (SC_BANDP + C21CM_MAX_RADII)
+#define SC_BANDP (SC_BANDCTR + 1)    /* the mean the two rules predicted for every radius (0: none), the error measure after it */
+#define SC_COUNT (SC_BANDP + 3 * C21CM_MAX_RADII)
 
 #define TRY(expr)                   \
     do {                            \
@@ -351,6 +351,8 @@ typedef struct {
     int band_h1, band_h2, band_hn; /* the last two radii of this loop with a mean on the device */
     unsigned char *band_mask;
     int band_mf;         /* 1: this loop's bands live in mean-fix space (barriers with an x_e grid) */
+    int band_skip;       /* radius index that takes the dense sweeps whatever band exists (-1: none) */
+    short band_hist[C21CM_MAX_RADII][3]; /* band_h1 / _h2 / _hn as they were BEFORE radius r was processed */
     float *band_xe_pend; /* ... and its undecided cells leave their clipped x_e here */
     const float *cur_xe; /* fused recombination loop with an x_e grid: its work spectrum of the radius in hand */
     /* third HII-window spectrum of the fused loop: the x_e grid, or -- on the fused recombination loop
@@ -476,6 +478,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->band_hn = 0;
     c->band_mask = NULL;
     c->band_mf = 0;
+    c->band_skip = -1;
     c->band_xe_pend = NULL;
     c->sphere = s->ionise_entire_sphere;
     c->mini = s->use_mini_halos && !c->lagrangian;
@@ -1232,8 +1235,8 @@ static int eul_band_this(ion_ctx *c, int R_ct, unsigned char *first_cross, int s
     const c21cm_ionize_spec *s = c->s;
     /* (index 1 sits a step above the cell scale, where the mean leaves the curve the larger radii
      * drew -- 1.6 % at 512^3 against the < 0.1 % of every other step: dense) */
-    return c->band_next == R_ct && sig_ok && R_ct >= 2 && (R_ct > s->r_lowest || s->r_lowest == 0) &&
-           (c->band_pend < 0 || c->band_mask == first_cross);
+    return c->band_next == R_ct && R_ct != c->band_skip && sig_ok && R_ct >= 2 &&
+           (R_ct > s->r_lowest || s->r_lowest == 0) && (c->band_pend < 0 || c->band_mask == first_cross);
 }
 
 /* After the sweep of radius R_ct (banded or dense) left n_part partial sums of its f_coll grid: their
@@ -1244,11 +1247,15 @@ static int eul_band_after(ion_ctx *c, int R_ct, int next_R, int banded, int sig_
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     const char *e_rel = getenv("C21CM_EUL_BAND_MINREL"), *e_shift = getenv("C21CM_EUL_BAND_SHIFT");
-    double min_rel = e_rel ? atof(e_rel) : 0.003;
-    if (!(min_rel >= 0.)) min_rel = 0.003;
+    double min_rel = e_rel ? atof(e_rel) : 0.005;
+    if (!(min_rel >= 0.)) min_rel = 0.005;
     const double shift = e_shift ? atof(e_shift) : 0.; /* test hook: a prediction off by this fraction */
     const int h1 = c->band_h1, h2 = c->band_h2;
-    const int will_next = next_R >= 1 && c->band_hn >= 1 && sig_ok;
+    c->band_hist[R_ct][0] = (short)h1, c->band_hist[R_ct][1] = (short)h2, c->band_hist[R_ct][2] = (short)c->band_hn;
+    /* a band for the next radius only once a prediction has been checked against a radius -- from the
+     * fourth radius of a loop on */
+    const int will_next = next_R >= 1 && c->band_hn >= 2 && sig_ok;
+    const int predict_next = next_R >= 1 && c->band_hn >= 1 && sig_ok; /* the prediction alone: its error is the next band's width */
     double t_cur = 0., t_next = 0.;
     if (h1 >= 0) {
         const double d1 = log(s->R[R_ct]) - log(s->R[h1]);
@@ -1265,7 +1272,7 @@ static int eul_band_after(ion_ctx *c, int R_ct, int next_R, int banded, int sig_
     if (split) TRY(c21hip_reduce_sum(partials, n_part, sum_dev, c->stream));
     TRY(c21hip_eul_band(split ? NULL : partials, n_part, sum_dev, (double)c->ntot, s->mass_dep_zeta,
                         s->f_limit_acg, c->scalars + SC_MEANS, R_ct, h1, h2, t_cur, t_next,
-                        will_next ? next_R : -1, banded, s->fix_mean, s->mean_f_coll, s->ion_eff_factor,
+                        predict_next ? next_R : -1, banded, s->fix_mean, s->mean_f_coll, s->ion_eff_factor,
                         min_rel, shift, c->scalars + SC_BAND, c->scalars + SC_BANDX,
                         (int *)(c->scalars + SC_BANDFAIL), (unsigned *)(c->scalars + SC_BANDCTR),
                         c->band_mf, quad, c->scalars + SC_BANDP, c->stream));
@@ -1543,13 +1550,35 @@ done:
     return status;
 }
 
+/* A band missed at radius index `fail` and the host knows before the loop is over (the table loop waits
+ * for every radius' extrema anyway, and the failure word travels with them): the stream drained, the
+ * first-crossing grid rewound to its state before that radius, the band history put back to what it was
+ * when that radius was entered; the caller restarts its pipeline AT that radius, which then takes the
+ * dense sweeps (band_skip) -- the radii after it are banded again, with the miss in their error term.
+ * A miss costs the two or three radii that were in flight, not the rest of the loop. */
+static int eul_band_recover(ion_ctx *c, unsigned char *mask, int fail) {
+    int status = 0;
+    TRY(c21hip_sync(c->stream));
+    TRY(c21hip_memset(c->scalars + SC_BANDFAIL, 0, sizeof(double), c->stream));
+    TRY(c21hip_eul_rewind(mask, fail, c->ntot, c->stream));
+    c->band_h1 = c->band_hist[fail][0], c->band_h2 = c->band_hist[fail][1], c->band_hn = c->band_hist[fail][2];
+    c->band_next = -1;
+    c->band_pend = -1;
+    c->band_skip = fail;
+    if (getenv("C21CM_EUL_BAND_DEBUG")) fprintf(stderr, "band miss at r=%d: recovered in the loop\n", fail);
+done:
+    return status;
+}
+
 static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *mask) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     /* pinned host staging: [2][2] extrema, then [2][NDELTA] table floats */
     double(*mm)[2] = (double(*)[2])c21hip_pinned_host(4 * sizeof(double) +
-                                                      2 * C21CM_NDELTA_TABLE * sizeof(float));
+                                                      2 * C21CM_NDELTA_TABLE * sizeof(float) + 2 * sizeof(double));
     float(*table)[C21CM_NDELTA_TABLE] = mm ? (float(*)[C21CM_NDELTA_TABLE])(mm + 2) : NULL;
+    /* the banded barrier's failure word, copied out behind every radius' band step: [2] by stage */
+    volatile int *fail_host = table ? (volatile int *)(table + 2) : NULL;
     void *ev[2] = {c21hip_event_create(), c21hip_event_create()};
     float *dfil[2] = {c->delta_fil, NULL};
     if (n <= 0) goto done;
@@ -1582,11 +1611,27 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
             goto done;
         }
     }
-    TRY(eul_stage_a(c, radii[0], 0, dfil[0], mm[0], ev[0]));
-    for (int i = 0; i < n; i++) {
+    int i0 = 0;
+    if (fail_host) fail_host[0] = fail_host[2] = 0;
+restart:
+    TRY(eul_stage_a(c, radii[i0], i0 & 1, dfil[i0 & 1], mm[i0 & 1], ev[i0 & 1]));
+    for (int i = i0; i < n; i++) {
         const int b = i & 1, R_ct = radii[i];
         if (i + 1 < n) TRY(eul_stage_a(c, radii[i + 1], b ^ 1, dfil[b ^ 1], mm[b ^ 1], ev[b ^ 1]));
         TRY(c21hip_event_synchronize(ev[b]));
+        if ((use_band || use_band_xe) && (fail_host[0] > 0 || fail_host[2] > 0)) {
+            /* (the word copied behind the band step of radius i - 2 or earlier has arrived with this event) */
+            const int fail = fail_host[0] > fail_host[2] ? fail_host[0] : fail_host[2];
+            TRY(eul_band_recover(c, mask, fail));
+            fail_host[0] = fail_host[2] = 0;
+            for (i0 = 0; i0 < n && radii[i0] != fail; i0++) {}
+            if (i0 == n) { /* (cannot happen: the word names a radius of this loop) */
+                c21hip_set_error("ionize: banded barrier reported a radius outside the loop");
+                status = C21CM_VALUE_ERROR;
+                goto done;
+            }
+            goto restart;
+        }
         const double min_density = mm[b][0] - 0.001, max_density = mm[b][1] + 0.001;
         int tst = s->table_fn(R_ct, min_density, max_density, table[b], s->table_user);
         if (tst) {
@@ -1627,6 +1672,7 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
                                            s->mean_f_coll, s->fix_mean, s->mass_dep_zeta, s->f_limit_acg,
                                            s->ion_eff_factor, c->stream));
             }
+            TRY(c21hip_d2h((void *)(fail_host + 2 * b), c->scalars + SC_BANDFAIL, sizeof(int), c->stream));
             continue;
         }
         if (use_band) {
@@ -1655,6 +1701,7 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
                 TRY(eul_band_after(c, R_ct, i + 1 < n ? radii[i + 1] : -1, 0, 1, NULL, 0, sum_dev));
                 TRY(c21hip_eulerian_mask(&args, c->nion_dense, NULL, mean_dev, mask, c->stream));
             }
+            TRY(c21hip_d2h((void *)(fail_host + 2 * b), c->scalars + SC_BANDFAIL, sizeof(int), c->stream));
             continue;
         }
         TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
@@ -1907,6 +1954,17 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
             for (int R_ct = spec->n_radii - 1; R_ct >= 1 && R_ct >= spec->r_lowest; R_ct--)
                 radii[n++] = R_ct;
             TRY(eul_table_loop(&c, radii, n, c.mask));
+            {
+                int redo = 0; /* banded barrier: markers settled; a missed band reruns its radii on the
+                               * dense sweeps, through the pipelined loop again */
+                TRY(eul_band_finish(&c, c.mask, &redo));
+                if (redo) {
+                    int m = 0;
+                    for (int i = 0; i < n; i++)
+                        if (radii[i] <= redo) radii[m++] = radii[i];
+                    TRY(eul_table_loop(&c, radii, m, c.mask));
+                }
+            }
             R_start = 1; /* only the cell-scale radius is left */
         }
         if (c.fused) { /* radii n-1 .. 1 through the fused steps; index 0 is the final sweep */

@@ -564,6 +564,20 @@ def main():
                     k["ms_per_step"] = tot.value
                     k["timing"] = "HIP events around each launch inside one step of the R loop"
             lib.c21hip_ktime_enable(0)
+            if G == 1:
+                # one filtered grid (--mode erfc): the line passes of this loop move ONE split spectrum
+                # (read + write: 2 S), and the two-grid fused pass Z is not part of it -- its pass Z is
+                # zw_c2r_kernel<16, 7, 16> (closed form + banded barrier), whose launches carry no event
+                # pair; its rocprofv3 average is in profiles/rNN_erfc_kernel_stats.csv
+                S1 = 8.0 * (cells / 2 + n * n)
+                for kind in list(kern):
+                    k = kern[kind]
+                    if "timing" not in k:
+                        del kern[kind]
+                        continue
+                    k["alg_bytes"] = 2 * S1
+                    k["GBs"] = k["alg_bytes"] / k["ms"] / 1e6
+                    k["kernel"] = k["kernel"].replace("of both grids", "of the one grid")
             # dominant kernel = the one with the largest share of the R loop (launch time x
             # launches per step; agrees with the kernel-trace stats in profiles/)
             dom_kind = max((k for k in kern if k != 4), key=lambda k: kern[k]["ms_per_step"])
@@ -573,7 +587,7 @@ def main():
                          "alg_bytes_per_launch": dom["alg_bytes"],
                          "launches_per_step": dom["launches_per_step"],
                          "other_kernels": [kern[k] for k in sorted(kern) if k != dom_kind]})
-            pmc = pmc_traffic()
+            pmc = pmc_traffic() if G == 2 else None  # (the PMC passes profile the two-grid launches)
             if pmc:
                 per = pmc.get("kernels", {}).get(PMC_KEYS[dom_kind])
                 roof["traffic"] = per["hbm_bytes"] if per else None

@@ -864,7 +864,7 @@ def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, fmode, r_lowes
     buf1, _, rep1 = api.ionize_grids(spec, density)
     torch.cuda.synchronize()
     err = capfd.readouterr().err
-    assert "band fail=0" in err, err  # the banded sweeps ran and every band held
+    assert "band fail=0" in err, err  # the banded sweeps ran (a miss, if any, was recovered inside the loop)
     monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
     assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
     names = ["neutral_fraction", "z_reion", "kinetic_temperature"]
@@ -882,7 +882,8 @@ def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, fmode, r_lowes
     torch.cuda.synchronize()
     import re
 
-    assert re.search(r"band fail=[1-9]", capfd.readouterr().err)  # the index of the radius that missed
+    # (the closed form learns of a miss at the end of the loop, the table loops while they run)
+    assert re.search(r"band fail=[1-9]|band miss at r=", capfd.readouterr().err)
     monkeypatch.delenv("C21CM_EUL_BAND_SHIFT")
     monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
     for name in names:
@@ -948,7 +949,7 @@ def test_table_loop_with_xe_grid_banded_barrier_equals_dense_sweeps(api, fmode, 
     buf1, _, rep1 = api.ionize_grids(spec, density, None, **kw)
     torch.cuda.synchronize()
     err = capfd.readouterr().err
-    assert "band fail=0" in err, err  # the banded sweeps ran and every band held
+    assert "band fail=0" in err, err  # the banded sweeps ran (a miss, if any, was recovered inside the loop)
     monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
     assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
     names = ["neutral_fraction", "z_reion", "kinetic_temperature"]
@@ -961,7 +962,7 @@ def test_table_loop_with_xe_grid_banded_barrier_equals_dense_sweeps(api, fmode, 
     monkeypatch.setenv("C21CM_EUL_BAND_DEBUG", "1")
     buf3, _, rep3 = api.ionize_grids(spec, density, None, **kw)
     torch.cuda.synchronize()
-    assert re.search(r"band fail=[1-9]", capfd.readouterr().err)
+    assert re.search(r"band fail=[1-9]|band miss at r=", capfd.readouterr().err)
     monkeypatch.delenv("C21CM_EUL_BAND_SHIFT")
     monkeypatch.delenv("C21CM_EUL_BAND_DEBUG")
     for name in names:
