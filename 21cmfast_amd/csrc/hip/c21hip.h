@@ -588,6 +588,14 @@ int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
                        float *kinetic_temperature, double *partials, double *sum_stars_out,
                        double *sum_xh_out, int *flag_out, int stars_direct, const float *xe_dense,
                        const float *kinetic_temp_neutral, void *stream);
+/* the same sweep for the Eulerian source models: the dense f_coll grid of radius index 0 and its box mean
+ * in place of the emissivity grid (apply_first_cross + ionise_eulerian<LAST> + finalize in one pass) */
+int c21hip_final_sweep_eulerian(const c21hip_ionize_args *a, double stored_redshift,
+                                const unsigned char *first_cross, const float *nion_dense,
+                                const double *mean_dev, const float *density, const float *prev_z_reion,
+                                float *xH, float *z_reion, float *kinetic_temperature, double *partials,
+                                double *sum_xh_out, int *flag_out, const float *xe_dense,
+                                const float *kinetic_temp_neutral, void *stream);
 /* delta_T (and tau_21) per cell + their sum (BrightnessTemperatureBox.c:58-87); partials: 2048 */
 int c21hip_brightness_temp(const float *density, const float *xH, const float *Ts, float *bt,
                            float *tau, size_t n, float const_factor, float T_rad, double redshift,

@@ -1046,7 +1046,11 @@ finalize_kernel(c21hip_ionize_args a, float stored_z, const float *__restrict__ 
 // applied (:606), so the reference's filtered grid is c2r(r2c(clipped input)) / N -- the
 // clipped input itself up to the rounding of the transform pair (~1e-7 relative).  All grids
 // are then dense, so rows need no padding arithmetic and VEC = 4 (16-byte accesses) is legal.
-template <int VEC, bool DIRECT>
+// EUL (round 4, late): the same sweep for the Eulerian source models -- stars_fil then is the dense
+// f_coll grid of radius index 0 and *mean_dev its box mean: curr_fcoll = f mean_f_coll / mean
+// (IonisationBox.c:1022-1027) instead of stars / (rho (1 + delta)); apply_first_cross_kernel +
+// ionise_eulerian_kernel<LAST> + finalize_kernel in one pass over the cells.
+template <int VEC, bool DIRECT, bool EUL = false>
 __global__ void __launch_bounds__(kBlock)
 final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restrict__ first_cross,
                    const float *__restrict__ stars_fil, const float *__restrict__ density,
@@ -1054,7 +1058,10 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
                    const float *__restrict__ Tneutral, float *__restrict__ xH,
                    float *__restrict__ z_reion, float *__restrict__ Tk,
                    double *__restrict__ partials_stars, double *__restrict__ partials_xh,
-                   int *__restrict__ flag) {
+                   int *__restrict__ flag, const double *__restrict__ mean_dev = nullptr) {
+    static_assert(!EUL || DIRECT, "the Eulerian sweep reads dense grids");
+    double mean_fix = 1.;
+    if constexpr (EUL) mean_fix = p.a.fix_mean ? p.a.mean_f_coll / *mean_dev : 1.;  // :1022-1023
     // a.use_ts_fluct (DIRECT only): the x_e input (clipped like its filtered grid, :1504-1507
     // and :1091-1094) enters the barrier and the partial ionisation, the neutral-gas
     // temperature replaces the adiabatic one
@@ -1103,13 +1110,18 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
             Pack<VEC> xo, zo, To;
 #pragma unroll
             for (int e = 0; e < VEC; e++) {
-                float stars = fmaxf(st[u].v[e], 0.f);  // IonisationBox.c:822-823
-                if (DIRECT) stars = fminf(stars, 1e20f);
-                acc_s += (double)stars;
                 const float dens = de[u].v[e];
-                const double curr_dens = (double)dens * a.photoncons_factor;  // :1048
-                double curr_fcoll = (double)stars;
-                curr_fcoll *= 1 / (a.rhocrit_omb * (1 + curr_dens));  // :1066-1067
+                double curr_fcoll;
+                if constexpr (EUL) {
+                    curr_fcoll = mean_fix * (double)st[u].v[e];
+                } else {
+                    float stars = fmaxf(st[u].v[e], 0.f);  // IonisationBox.c:822-823
+                    if (DIRECT) stars = fminf(stars, 1e20f);
+                    acc_s += (double)stars;
+                    const double curr_dens = (double)dens * a.photoncons_factor;  // :1048
+                    curr_fcoll = (double)stars;
+                    curr_fcoll *= 1 / (a.rhocrit_omb * (1 + curr_dens));  // :1066-1067
+                }
                 if (a.mass_dep_zeta && curr_fcoll < a.f_limit) curr_fcoll = a.f_limit;  // :1077
                 float x = x0[u].v[e];
                 float T = a.minimize_memory ? 0.f : T0[u].v[e];
@@ -1783,6 +1795,44 @@ extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_red
                        blocks, 0, sum_stars_out);
     hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, px,
                        blocks, 0, sum_xh_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// The cell-scale radius and the post-loop of the Eulerian source models in one sweep
+// (final_sweep_kernel<V, true, true>): first crossings of the larger radii (first_cross), the barrier and
+// the partial ionisation at radius index 0 from its dense f_coll grid and box mean, z_reion, T_k, the sum
+// of x_HI.  xe_dense / kinetic_temp_neutral: the inputs of a spin-temperature run (NULL otherwise).
+extern "C" int c21hip_final_sweep_eulerian(const c21hip_ionize_args *a, double stored_redshift,
+                                           const unsigned char *first_cross, const float *nion_dense,
+                                           const double *mean_dev, const float *density,
+                                           const float *prev_z_reion, float *xH, float *z_reion,
+                                           float *kinetic_temperature, double *partials, double *sum_xh_out,
+                                           int *flag_out, const float *xe_dense,
+                                           const float *kinetic_temp_neutral, void *stream) {
+    if (a->use_ts_fluct && (!xe_dense || (!a->minimize_memory && !kinetic_temp_neutral))) {
+        c21hip_set_error("final sweep: the x_e path needs the dense inputs");
+        return C21CM_VALUE_ERROR;
+    }
+    const size_t ntot = (size_t)a->nx * a->ny * a->nz;
+    const int vec = (ntot % 4 == 0) ? 4 : 1;
+    IoniseParams p = make_params(a, vec == 4 ? 2 : vec);
+    p.nitems = ntot / vec;  // dense grids: the box is one long row
+    const int blocks = grid_for((p.nitems + 1) / 2);
+    double *ps = partials, *px = partials + kMaxBlocks;
+    if (vec == 4)
+        hipLaunchKernelGGL((final_sweep_kernel<4, true, true>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, nion_dense, density,
+                           prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion, kinetic_temperature, ps,
+                           px, flag_out, mean_dev);
+    else
+        hipLaunchKernelGGL((final_sweep_kernel<1, true, true>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, nion_dense, density,
+                           prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion, kinetic_temperature, ps,
+                           px, flag_out, mean_dev);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, px, blocks, 0,
+                       sum_xh_out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -350,6 +350,9 @@ typedef struct {
     int band_pend;       /* radius whose markers (255) are outstanding in band_mask (-1: none) */
     int band_h1, band_h2, band_hn; /* the last two radii of this loop with a mean on the device */
     unsigned char *band_mask;
+    const unsigned char *r0_mask; /* Eulerian loops: the first crossings of the larger radii, applied by the ONE
+                                   * sweep that also does the cell-scale radius and the post-loop (NULL: the
+                                   * general kernels) */
     int band_mf;         /* 1: this loop's bands live in mean-fix space (barriers with an x_e grid) */
     int band_skip;       /* radius index that takes the dense sweeps whatever band exists (-1: none) */
     short band_hist[C21CM_MAX_RADII][3]; /* band_h1 / _h2 / _hn as they were BEFORE radius r was processed */
@@ -478,6 +481,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->band_hn = 0;
     c->band_mask = NULL;
     c->band_mf = 0;
+    c->r0_mask = NULL;
     c->band_skip = -1;
     c->band_xe_pend = NULL;
     c->sphere = s->ionise_entire_sphere;
@@ -1412,7 +1416,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
     if (c->lagrangian)
         TRY(filter_to_real(c, c->stars_unf, c->stars_work, c->stars_fil, s->stars_filter, R,
                            (float)s->mfp_meandens, apply));
-    if (s->use_ts_fluct)
+    if (s->use_ts_fluct && !(R_ct == 0 && c->r0_mask)) /* (the fused cell-scale sweep reads the x_e input itself) */
         TRY(filter_to_real(c, c->xe_unf, c->xe_work, c->xe_fil, s->hii_filter, R, 0.f, apply));
 
     if (c->recomb) {
@@ -1498,7 +1502,19 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                                      c->xe_fil, c->nrec_fil, c->prev_nrec, c->density, c->prev_zre,
                                      c->Tneutral, mean_dev, c->xH, c->zre, c->Tk, c->G12, c->mfp,
                                      partials, NULL, c->stream));
-        else
+        else if (R_ct == 0 && c->r0_mask) {
+            /* Eulerian loops, cell-scale radius: the first crossings of the larger radii, this radius'
+             * barrier and partial ionisation and the post-loop sweep in ONE pass over the cells
+             * (apply_first_cross + ionise_eulerian<LAST> + finalize: 2.3 -> 0.8 ms at 512^3); with an x_e grid
+             * the sweep reads the x_e input itself -- at index 0 no window is applied (IonisationBox.c:606),
+             * the filtered grid is the clipped input up to the rounding of a transform pair, as for the
+             * emissivity grid of the Lagrangian path (r0_direct) */
+            TRY(c21hip_final_sweep_eulerian(&args, s->stored_redshift, c->r0_mask, c->nion_dense, mean_dev,
+                                            c->density, c->prev_zre, c->xH, c->zre, c->Tk, c->partials,
+                                            c->scalars + SC_XHSUM, (int *)(c->scalars + SC_FLAG),
+                                            s->use_ts_fluct ? c->xe_dense : NULL, c->Tneutral, c->stream));
+            c->finalised = 1;
+        } else
             TRY(c21hip_ionise_eulerian(&args, c->nion_dense, c->xe_fil, c->density, c->prev_zre,
                                        c->Tneutral, mean_dev, c->xH, c->zre, c->Tk, first_cross,
                                        c->stream));
@@ -1896,6 +1912,14 @@ done:
     return status;
 }
 
+/* The Eulerian loops' cell-scale radius + post-loop as one sweep (one_radius, R_ct = 0, c->r0_mask)?
+ * C21CM_EUL_R0_FUSED=0: the general kernels. */
+static int eul_r0_fused(const ion_ctx *c) {
+    const char *e = getenv("C21CM_EUL_R0_FUSED");
+    return c->eul_mask && !c->sphere && !c->recomb && c->s->r_lowest == 0 && !(e && e[0] == '0') &&
+           (!c->s->use_ts_fluct || r0_direct());
+}
+
 /* Eulerian source models (and every other loop off the fused path) on the native passes: the density
  * (and x_e) windows of the radii first, first - step, ... evaluated inside pass X (top-hat / sharp-k
  * HII_FILTER), no window tables.  The single pass AND the shard phases call this, so that a rank's
@@ -2005,10 +2029,14 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
                     TRY(one_radius(&c, 0, NULL, -1));
                     continue;
                 }
-                /* the cell-scale radius tests xH > TINY: materialise the mask first */
-                TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot,
-                                             spec->redshift, c.xH, c.zre, c.ntot, stream));
-                if (c.sphere) TRY(paint_spheres(&c, c.mask));
+                if (eul_r0_fused(&c)) { /* one sweep: mask + cell-scale radius + post-loop (one_radius) */
+                    c.r0_mask = c.mask;
+                } else {
+                    /* the cell-scale radius tests xH > TINY: materialise the mask first */
+                    TRY(c21hip_apply_first_cross(c.mask, c.prev_zre, spec->first_snapshot,
+                                                 spec->redshift, c.xH, c.zre, c.ntot, stream));
+                    if (c.sphere) TRY(paint_spheres(&c, c.mask));
+                }
             }
             TRY(one_radius(&c, R_ct, (R_ct > 0 && use_mask) ? c.mask : NULL,
                            (R_ct - 1 >= spec->r_lowest) ? R_ct - 1 : -1));
@@ -2227,6 +2255,9 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
     }
     if (c.fused && spec->r_lowest == 0 && !c.sphere) {
         TRY(final_step(&c, first_cross, stars_ready));
+    } else if (eul_r0_fused(&c)) { /* as the single pass: one sweep for mask + cell-scale radius + post-loop */
+        c.r0_mask = first_cross;
+        TRY(one_radius(&c, 0, NULL, -1));
     } else {
         TRY(c21hip_apply_first_cross(first_cross, c.prev_zre, spec->first_snapshot,
                                      spec->redshift, c.xH, c.zre, c.ntot, stream));

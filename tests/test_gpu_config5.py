@@ -125,8 +125,12 @@ def test_config5_coeval_with_spin_temperature_512(gpu_lib, monkeypatch):
         worst = float((a - b).abs().max()) / float(a.abs().max())
         print(f"rerun {k}: {differ:.2e} of the cells differ, by at most {worst:.2e} of the field's maximum")
         # not bit for bit: the fp64 atomics of the mass deposit reorder, a density's last float bit
-        # flips in a few cells per snapshot and 50 snapshots of evolution carry that along
-        assert differ <= 0.1 and worst <= 2e-6, (k, differ, worst)
+        # flips in a few cells per snapshot and 50 snapshots of evolution carry that along.  Mostly a few
+        # per cent of the cells differ; about one run in twelve (2 of 24 repeats on one box, round 4) the
+        # flipped cell is the one that holds an extremum of a filtered density, the per-radius f_coll
+        # table is then laid out on a grid one ulp apart (IonisationBox.c:702-765) and every partially
+        # ionised cell -- 12.9 % of the box at z = 12 -- moves in its last bits (2.3e-6 of the maximum)
+        assert differ <= 0.3 and worst <= 5e-6, (k, differ, worst)
     del again, z12
     torch.cuda.empty_cache()
     gpu_lib.c21cm_release_device_cache()
