@@ -503,7 +503,7 @@ int c21hip_pack_mask_bits(const unsigned char *fc, unsigned *bits, size_t ntot, 
 int c21hip_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
                                unsigned char *fc, size_t ntot, void *stream);
 /* in-loop kernel timing (bench.py): HIP events around every pass launch on its stream while enabled;
- * kinds as in c21hip_bench_pass (1 pass Y, 2 fused pass Z, 7 / 8 pass X / two-radius pass X with
+ * kinds as in c21hip_bench_pass (12: one-grid pass Z + closed-form f_coll of the Eulerian loop; 1 pass Y, 2 fused pass Z, 7 / 8 pass X / two-radius pass X with
  * evaluated windows, 0 / 6 with streamed tables, 9 forward line passes) */
 /* closed-form Eulerian loop: pass Z + f_coll of a radius with the barrier of the PREVIOUS radius of the
  * loop (its dense grid, its mean, its index) applied in the same sweep */

@@ -4097,7 +4097,11 @@ extern "C" int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_de
         if (sl != ss)
             z.sig = 1.0 / ((double)(float)growthf * (sqrt(2.) * sqrt((double)(ss * ss - sl * sl))));
     }
-    int st = dispatch_z_c2r<2>(nz, z, nlines, (hipStream_t)stream);
+    int st;
+    {
+        KTimeScope kt(12, (hipStream_t)stream);
+        st = dispatch_z_c2r<2>(nz, z, nlines, (hipStream_t)stream);
+    }
     if (st || !sum_out) return st;  // sum_out NULL: the caller reduces the nlines / 16 partials (c21hip_eul_band)
     return c21hip_reduce_sum(partials, (int)(nlines / LZ_PLAIN), sum_out, stream);
 }
@@ -4195,7 +4199,11 @@ extern "C" int c21hip_split_z_fcoll_erfc_band(const float *split_work, float *f_
         if (sl != ss)
             z.sig = 1.0 / ((double)(float)growthf * (sqrt(2.) * sqrt((double)(ss * ss - sl * sl))));
     }
-    int st = dispatch_z_c2r<7>(nz, z, nlines, (hipStream_t)stream);
+    int st;
+    {
+        KTimeScope kt(12, (hipStream_t)stream);  // kind 12: one-grid pass Z + closed-form f_coll (+ banded barrier)
+        st = dispatch_z_c2r<7>(nz, z, nlines, (hipStream_t)stream);
+    }
     if (st || !sum_out) return st;  // sum_out NULL: the caller reduces the nlines / 16 partials (c21hip_eul_band)
     return c21hip_reduce_sum(partials, (int)(nlines / LZ_PLAIN), sum_out, stream);
 }

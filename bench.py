@@ -563,12 +563,10 @@ def main():
                     k["GBs"] = k["alg_bytes"] / k["ms"] / 1e6
                     k["ms_per_step"] = tot.value
                     k["timing"] = "HIP events around each launch inside one step of the R loop"
-            lib.c21hip_ktime_enable(0)
             if G == 1:
                 # one filtered grid (--mode erfc): the line passes of this loop move ONE split spectrum
                 # (read + write: 2 S), and the two-grid fused pass Z is not part of it -- its pass Z is
-                # zw_c2r_kernel<16, 7, 16> (closed form + banded barrier), whose launches carry no event
-                # pair; its rocprofv3 average is in profiles/rNN_erfc_kernel_stats.csv
+                # zw_c2r_kernel<16, 7, 16> (closed form + banded barrier), timed as kind 12 below
                 S1 = 8.0 * (cells / 2 + n * n)
                 for kind in list(kern):
                     k = kern[kind]
@@ -578,6 +576,20 @@ def main():
                     k["alg_bytes"] = 2 * S1
                     k["GBs"] = k["alg_bytes"] / k["ms"] / 1e6
                     k["kernel"] = k["kernel"].replace("of both grids", "of the one grid")
+                tot, cnt = C.c_double(), C.c_int()
+                if lib.c21hip_ktime_report(12, C.byref(tot), C.byref(cnt)) == 0 and cnt.value > 0:
+                    # pass Z of the one grid + closed-form f_coll, its barrier decided in the sweep (banded):
+                    # the spectrum read + the mask row read (the dense-sweep launches of the first radii,
+                    # which also write the f_coll grid, are in the average)
+                    zb = S1 + cells
+                    kern[12] = {"kernel": "zw_c2r_kernel<16,7,16> (pass Z of the one grid + closed-form f_coll + "
+                                          "banded barrier; a few launches per step are the dense-sweep EPI 2)",
+                                "ms": tot.value / cnt.value, "alg_bytes": zb,
+                                "GBs": zb / (tot.value / cnt.value) / 1e6, "launches_per_step": cnt.value,
+                                "ms_per_step": tot.value,
+                                "timing": "HIP events around each launch inside one step of the R loop",
+                                "bound_note": "fp64-issue bound (erfc), not byte bound: see DESIGN section 4"}
+            lib.c21hip_ktime_enable(0)
             # dominant kernel = the one with the largest share of the R loop (launch time x
             # launches per step; agrees with the kernel-trace stats in profiles/)
             dom_kind = max((k for k in kern if k != 4), key=lambda k: kern[k]["ms_per_step"])
@@ -589,7 +601,7 @@ def main():
                          "other_kernels": [kern[k] for k in sorted(kern) if k != dom_kind]})
             pmc = pmc_traffic() if G == 2 else None  # (the PMC passes profile the two-grid launches)
             if pmc:
-                per = pmc.get("kernels", {}).get(PMC_KEYS[dom_kind])
+                per = pmc.get("kernels", {}).get(PMC_KEYS.get(dom_kind))
                 roof["traffic"] = per["hbm_bytes"] if per else None
                 roof["traffic_source"] = f"{pmc.get('file')}: {pmc.get('source')}"
                 # False: collected from exactly the kernel sources running now
