@@ -268,11 +268,14 @@ int c21hip_gsl_words_to_deviates(void *buf, size_t n_deviates, const unsigned ch
                                  size_t deviates_per_row, void *stream);
 
 /* ---- perturb_kernels.hip ---- */
-/* move_grid_masses: map_mass.c:146-208.  `out` (double[out_dim]) must be zeroed by the caller. */
+/* move_grid_masses: map_mass.c:146-208.  `out` (double[out_dim]) must be zeroed by the caller.
+ * fixed_out != NULL: the deposit may leave 64-bit FIXED-POINT integers (scale 2^44) in `out` instead of
+ * doubles -- deterministic whatever the order of the atomics -- and says so in *fixed_out;
+ * c21hip_widen_normalise(fixed = 1) reads them.  NULL: doubles. */
 int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3], const float *const vel[3],
                        const float *const vel2[3], const int vel_dim[3], double *out,
                        const int out_dim[3], double box_len, double box_len_z, double growth,
-                       double init_growth, int lpt2, void *stream);
+                       double init_growth, int lpt2, int *fixed_out, void *stream);
 /* double grid -> padded float [, *= mass_factor, -= 1]: PerturbedField.c:115-128,180-210 */
 /* ComputeHaloBox deposit (map_mass.c:214-344): exp(lerp(ln-table, delta*D)) * prefactor for the
  * two tables in tables_dev[2][NDELTA], CIC-deposited at the displaced positions (double grids) */
@@ -333,7 +336,7 @@ int c21hip_narrow(const double *in, float *out, float *out_scaled, double scale,
 /* {min, max} of n floats into out2 (device); partials: 2 * 2048 doubles */
 int c21hip_minmax_dense(const float *a, size_t n, double *partials, double *out2, void *stream);
 int c21hip_widen_normalise(const double *in, float *padded, int nx, int ny, int nz, int normalise,
-                           double mass_factor, void *stream);
+                           double mass_factor, int fixed, void *stream);
 /* padded = (float)(factor * dense): PerturbedField.c:64-80 */
 int c21hip_scale_pack(const float *dense, float *padded, int nx, int ny, int nz, double factor,
                       void *stream);
@@ -588,6 +591,27 @@ int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
                        float *kinetic_temperature, double *partials, double *sum_stars_out,
                        double *sum_xh_out, int *flag_out, int stars_direct, const float *xe_dense,
                        const float *kinetic_temp_neutral, void *stream);
+/* The final sweep walks the box in CHUNKS of contiguous cells, one workgroup each; the chunking depends on
+ * the box alone.  _chunks: their number and size (dense: the sweep reads dense grids); _range: chunks
+ * [chunk_begin, chunk_end) only (chunk_end < 0: all), partials left at partials[chunk] (stars) and
+ * partials[2048 + chunk] (x_HI), no reduce; _reduce: the fixed-order reduce over ALL chunk partials.
+ * A rank that sweeps a slab of whole chunks leaves the partials the single pass leaves there (sharded
+ * finish phase, c21cm_ionize_shard_finish_slab). */
+int c21hip_final_sweep_chunks(const c21hip_ionize_args *a, int dense, int *n_chunks, size_t *chunk_cells);
+int c21hip_final_sweep_range(const c21hip_ionize_args *a, double stored_redshift,
+                             const unsigned char *first_cross, const float *stars_fil,
+                             const float *density, const float *prev_z_reion, float *xH, float *z_reion,
+                             float *kinetic_temperature, double *partials, int *flag_out, int stars_direct,
+                             const float *xe_dense, const float *kinetic_temp_neutral, int chunk_begin,
+                             int chunk_end, void *stream);
+int c21hip_final_sweep_reduce(const c21hip_ionize_args *a, int dense, double *partials,
+                              double *sum_stars_out, double *sum_xh_out, void *stream);
+int c21hip_final_sweep_eulerian_range(const c21hip_ionize_args *a, double stored_redshift,
+                                      const unsigned char *first_cross, const float *nion_dense,
+                                      const double *mean_dev, const float *density, const float *prev_z_reion,
+                                      float *xH, float *z_reion, float *kinetic_temperature, double *partials,
+                                      int *flag_out, const float *xe_dense, const float *kinetic_temp_neutral,
+                                      int chunk_begin, int chunk_end, void *stream);
 /* the same sweep for the Eulerian source models: the dense f_coll grid of radius index 0 and its box mean
  * in place of the emissivity grid (apply_first_cross + ionise_eulerian<LAST> + finalize in one pass) */
 int c21hip_final_sweep_eulerian(const c21hip_ionize_args *a, double stored_redshift,

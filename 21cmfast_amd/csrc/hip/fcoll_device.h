@@ -74,6 +74,20 @@ __device__ __forceinline__ double eval_table_f(double x, double x_min, double x_
     const double interp_point = (x - table_val) / x_width;
     return (double)y_arr[idx] * (1 - interp_point) + (double)y_arr[idx + 1] * interp_point;
 }
+// The same with the two cell-independent divisions as multiplications by inv_width = 1 / x_width
+// (round 5; the f_coll sweeps of the table modes were bound by them: two IEEE double divisions are ~35 of
+// the ~100 fp64 instructions a cell cost, 336 us per 512^3 sweep where its bytes need 130).  The quotients
+// agree with the divisions to 2 ulp of a double: the interpolation weight moves by 3e-16, i.e. the float
+// the result is stored / compared as differs for about one cell in 1e8 -- and an index that lands on the
+// other side of a node (x exactly on it) interpolates to the same value from the neighbouring interval.
+// All three table sweeps (dense, banded, pass Z EPI 8) use this form, so they still agree bit for bit.
+__device__ __forceinline__ double eval_table_f_inv(double x, double x_min, double x_width, double inv_width,
+                                                   const float *y_arr) {
+    const int idx = (int)floor((x - x_min) * inv_width);
+    const double table_val = x_min + x_width * (double)(float)idx;
+    const double interp_point = (x - table_val) * inv_width;
+    return (double)y_arr[idx] * (1 - interp_point) + (double)y_arr[idx + 1] * interp_point;
+}
 
 // both clips applied to the filtered density, IonisationBox.c:689 then :803
 __device__ __forceinline__ float clip_delta_eulerian(float v) {

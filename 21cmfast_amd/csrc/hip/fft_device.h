@@ -9,17 +9,96 @@
 #endif
 
 // ------------------------------------------------------------------ complex helpers
+// Round 5: what the SLP vectoriser made of this scalar arithmetic cost the transforms a quarter of their
+// vector instructions -- it packs pairs of additions / multiplications into v_pk_add_f32 / v_pk_mul_f32 and
+// builds the operand pairs with v_mov (four moves per complex product in the c2r pre-processing; 300 of
+// the fused pass Z's 2050 vector instructions were moves).  Two ways out, both bit-identical to the old
+// code (same multiplications, additions and roundings; -ffp-contract=off), both measured:
+//   C21X_PKASM = 1: the complex products and the multiplications by +-i hand-written as the packed
+//     instructions they are (op_sel and neg modifiers: a complex product is three instructions, no move):
+//     fused pass Z 2047 -> 1496 vector instructions, 0.309 -> 0.27 ms per 512^3 radius;
+//   the default build: NO packing at all (-fno-slp-vectorize, Makefile): 1976 vector instructions, all
+//     plain -- and as fast (0.26-0.27 ms), 3 % faster at 1024^3, because a packed fp32 instruction issues in
+//     ~8 cycles per wave on gfx950 where a plain one takes ~2.7 (tools/valu_rate_probe.hip).  No inline
+//     assembly in the default build.
+#ifndef C21X_PKASM
+#define C21X_PKASM 0  // measured equal to the scalar forms built with -fno-slp-vectorize (the default build)
+#endif
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+#if C21X_PKASM
+// a b = (a.x b.x - a.y b.y, a.y b.x + a.x b.y):  t = (a.x, a.y) b.x,  u = (a.y, a.x) b.y,  t -+ u
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    float2 t, u, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(u) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t), "v"(u));
+    return r;
+}
+// a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y): bitwise cmul(a, (b.x, -b.y))
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+    float2 t, u, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(u) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(t), "v"(u));
+    return r;
+}
+// a + i b = (a.x - b.y, a.y + b.x),  a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ float2 cadd_i(float2 a, float2 b) {
+    float2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float2 csub_i(float2 a, float2 b) {
+    float2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.x + b.x, a.y - b.y) and (a.x - b.x, a.y + b.y): X + conj(B), X - conj(B)
+__device__ __forceinline__ float2 cadd_c(float2 a, float2 b) {
+    float2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float2 csub_c(float2 a, float2 b) {
+    float2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// h a, -h a for a real h
+__device__ __forceinline__ float2 cscale(float h, float2 a) {
+    float2 r, hh = make_float2(h, h);
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(hh), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float2 cscale_neg(float h, float2 a) {
+    float2 r, hh = make_float2(h, h);
+    asm("v_pk_mul_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(hh), "v"(a));
+    return r;
+}
+#else
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return cmul(a, make_float2(b.x, -b.y)); }
+__device__ __forceinline__ float2 cadd_i(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }
+__device__ __forceinline__ float2 csub_i(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }
+__device__ __forceinline__ float2 cadd_c(float2 a, float2 b) { return make_float2(a.x + b.x, a.y - b.y); }
+__device__ __forceinline__ float2 csub_c(float2 a, float2 b) { return make_float2(a.x - b.x, a.y + b.y); }
+__device__ __forceinline__ float2 cscale(float h, float2 a) { return make_float2(h * a.x, h * a.y); }
+__device__ __forceinline__ float2 cscale_neg(float h, float2 a) { return make_float2(-h * a.x, -h * a.y); }
+#endif
 // multiply by +i (SIGN > 0) or -i (SIGN < 0)
 template <int SIGN>
 __device__ __forceinline__ float2 mul_i(float2 a) {
     return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
+// a + SIGN i b, a - SIGN i b
+template <int SIGN>
+__device__ __forceinline__ float2 cadd_si(float2 a, float2 b) { return SIGN > 0 ? cadd_i(a, b) : csub_i(a, b); }
+template <int SIGN>
+__device__ __forceinline__ float2 csub_si(float2 a, float2 b) { return SIGN > 0 ? csub_i(a, b) : cadd_i(a, b); }
 
 // Small DFTs, y_j = sum_k a_k exp(SIGN * 2 pi i j k / R), outputs in natural order.
 template <int R, int SIGN>
@@ -48,12 +127,13 @@ struct Dft<3, SIGN> {
 template <int SIGN>
 struct Dft<4, SIGN> {
     __device__ __forceinline__ static void run(float2 *v) {
+        // (t1 +- SIGN i d: the same additions as t1 +- mul_i(d), x + (-y) = x - y bit for bit)
         float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-        float2 t2 = cadd(v[1], v[3]), t3 = mul_i<SIGN>(csub(v[1], v[3]));
+        float2 t2 = cadd(v[1], v[3]), d = csub(v[1], v[3]);
         v[0] = cadd(t0, t2);
         v[2] = csub(t0, t2);
-        v[1] = cadd(t1, t3);
-        v[3] = csub(t1, t3);
+        v[1] = cadd_si<SIGN>(t1, d);
+        v[3] = csub_si<SIGN>(t1, d);
     }
 };
 template <int SIGN>
@@ -65,23 +145,72 @@ struct Dft<8, SIGN> {
         Dft<4, SIGN>::run(o);
         const float h = 0.70710678118654752440f;
         // W8^1 = (1 + SIGN i)/sqrt2, W8^2 = SIGN i, W8^3 = (-1 + SIGN i)/sqrt2
-        float2 o1 = SIGN > 0 ? make_float2(h * (o[1].x - o[1].y), h * (o[1].x + o[1].y))
-                             : make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
-        float2 o2 = mul_i<SIGN>(o[2]);
-        float2 o3 = SIGN > 0 ? make_float2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y))
-                             : make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+        //   SIGN > 0: o1 = h (x - y, x + y) = h (o + i o),  o3 = (-h (x + y), h (x - y)) = -h (o - i o)
+        //   SIGN < 0: o1 = h (x + y, y - x) = h (o - i o),  o3 = (h (y - x), -h (x + y)) = -h (o + i o)
+        // (y - x = -(x - y) and (-h) s = -(h s) bit for bit)
+        const float2 op = cadd_i(o[1], o[1]), om = csub_i(o[1], o[1]);
+        const float2 pp = cadd_i(o[3], o[3]), pm = csub_i(o[3], o[3]);
+        const float2 o1 = SIGN > 0 ? cscale(h, op) : cscale(h, om);
+        const float2 o3 = SIGN > 0 ? cscale_neg(h, pm) : cscale_neg(h, pp);
         v[0] = cadd(e[0], o[0]);
         v[4] = csub(e[0], o[0]);
         v[1] = cadd(e[1], o1);
         v[5] = csub(e[1], o1);
-        v[2] = cadd(e[2], o2);
-        v[6] = csub(e[2], o2);
+        v[2] = cadd_si<SIGN>(e[2], o[2]);
+        v[6] = csub_si<SIGN>(e[2], o[2]);
         v[3] = cadd(e[3], o3);
         v[7] = csub(e[3], o3);
     }
 };
 
-// ------------------------------------------------------------------ Stockham stages in LDS
+// ------------------------------------------------------------------ constant twiddles
+// a w for w = (sx W[IX], sy W[IY]) taken out of ONE register pair W = (cos, sin): the twiddles of the 16-
+// and 32-point DFTs are (c, s), (s, c), (-s, c), (-c, s) of three angles, so three pairs (and h) serve
+// them all through op_sel / neg modifiers.  NX / NY: negate the real / imaginary part of w.
+#if C21X_PKASM
+template <int IX, int NX, int IY, int NY>
+__device__ __forceinline__ float2 cmul_k(float2 a, float2 W) {
+    float2 t, u, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,%3] op_sel_hi:[1,%3] neg_lo:[0,%4] neg_hi:[0,%4]"
+        : "=v"(t) : "v"(a), "v"(W), "n"(IX), "n"(NX));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,%3] op_sel_hi:[0,%3] neg_lo:[0,%4] neg_hi:[0,%4]"
+        : "=v"(u) : "v"(a), "v"(W), "n"(IY), "n"(NY));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t), "v"(u));
+    return r;
+}
+// (sa t.x + sb t.y, sc t.x + sd t.y) in one instruction (N* = 1: minus)
+template <int NA, int NB, int NC, int ND>
+__device__ __forceinline__ float2 cmix(float2 t) {
+    float2 r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[%2,%3] neg_hi:[%4,%5]"
+        : "=v"(r) : "v"(t), "n"(NA), "n"(NB), "n"(NC), "n"(ND));
+    return r;
+}
+#else
+template <int IX, int NX, int IY, int NY>
+__device__ __forceinline__ float2 cmul_k(float2 a, float2 W) {
+    const float wx = IX ? W.y : W.x, wy = IY ? W.y : W.x;
+    return cmul(a, make_float2(NX ? -wx : wx, NY ? -wy : wy));
+}
+template <int NA, int NB, int NC, int ND>
+__device__ __forceinline__ float2 cmix(float2 t) {
+    return make_float2((NA ? -t.x : t.x) + (NB ? -t.y : t.y), (NC ? -t.x : t.x) + (ND ? -t.y : t.y));
+}
+#endif
+// a (h + SIGN i h) and a (-h + SIGN i h) from t = h a:
+//   (h, h): (t.x - t.y, t.x + t.y);  (h, -h): (t.x + t.y, t.y - t.x);
+//   (-h, h): (-t.x - t.y, t.x - t.y);  (-h, -h): (t.y - t.x, -t.x - t.y)
+template <int SIGN>
+__device__ __forceinline__ float2 cmul_hh(float2 a, float h) {
+    const float2 t = cscale(h, a);
+    return SIGN > 0 ? cadd_i(t, t) : csub_i(t, t);
+}
+template <int SIGN>
+__device__ __forceinline__ float2 cmul_mhh(float2 a, float h) {
+    const float2 t = cscale(h, a);
+    return SIGN > 0 ? cmix<1, 1, 0, 1>(t) : cmix<1, 0, 1, 1>(t);
+}
+
 template <int SIGN>
 struct Dft<16, SIGN> {
     __device__ __forceinline__ static void run(float2 *v) {
@@ -93,17 +222,28 @@ struct Dft<16, SIGN> {
         }
         Dft<8, SIGN>::run(e);
         Dft<8, SIGN>::run(o);
-        // W16^k = exp(SIGN 2 pi i k / 16), k = 0..7
-        const float c = 0.92387953251128675613f, s = 0.38268343236508977173f;
+        // W16^k = exp(SIGN 2 pi i k / 16), k = 0..7:
+        //   (1, 0), (c, s), (h, h), (s, c), (0, 1), (-s, c), (-h, h), (-c, s) with the imaginary parts times SIGN
+        const float2 W = make_float2(0.92387953251128675613f, 0.38268343236508977173f);
         const float h = 0.70710678118654752440f;
-        const float wr[8] = {1.f, c, h, s, 0.f, -s, -h, -c};
-        const float wi[8] = {0.f, s, h, c, 1.f, c, h, s};
+        constexpr int NY = SIGN > 0 ? 0 : 1;
+        float2 t[8];
+        t[0] = o[0];
+        t[1] = cmul_k<0, 0, 1, NY>(o[1], W);
+        t[2] = cmul_hh<SIGN>(o[2], h);
+        t[3] = cmul_k<1, 0, 0, NY>(o[3], W);
+        t[5] = cmul_k<1, 1, 0, NY>(o[5], W);
+        t[6] = cmul_mhh<SIGN>(o[6], h);
+        t[7] = cmul_k<0, 1, 1, NY>(o[7], W);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const float2 w = make_float2(wr[k], SIGN > 0 ? wi[k] : -wi[k]);
-            const float2 t = (k == 0) ? o[0] : cmul(o[k], w);
-            v[k] = cadd(e[k], t);
-            v[k + 8] = csub(e[k], t);
+            if (k == 4) {  // W = SIGN i (multiplications by 0 and 1 dropped: the sign of a zero at most)
+                v[4] = cadd_si<SIGN>(e[4], o[4]);
+                v[12] = csub_si<SIGN>(e[4], o[4]);
+                continue;
+            }
+            v[k] = cadd(e[k], t[k]);
+            v[k + 8] = csub(e[k], t[k]);
         }
     }
 };
@@ -119,27 +259,37 @@ struct Dft<32, SIGN> {
         }
         Dft<16, SIGN>::run(e);
         Dft<16, SIGN>::run(o);
-        // W32^k = exp(SIGN 2 pi i k / 32), k = 0..15
-        const float wr[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f,
-                              0.83146961230254523708f, 0.70710678118654752440f,
-                              0.55557023301960222474f, 0.38268343236508977173f,
-                              0.19509032201612826785f, 0.f, -0.19509032201612826785f,
-                              -0.38268343236508977173f, -0.55557023301960222474f,
-                              -0.70710678118654752440f, -0.83146961230254523708f,
-                              -0.92387953251128675613f, -0.98078528040323044913f};
-        const float wi[16] = {0.f, 0.19509032201612826785f, 0.38268343236508977173f,
-                              0.55557023301960222474f, 0.70710678118654752440f,
-                              0.83146961230254523708f, 0.92387953251128675613f,
-                              0.98078528040323044913f, 1.f, 0.98078528040323044913f,
-                              0.92387953251128675613f, 0.83146961230254523708f,
-                              0.70710678118654752440f, 0.55557023301960222474f,
-                              0.38268343236508977173f, 0.19509032201612826785f};
+        // W32^k = exp(SIGN 2 pi i k / 32), k = 0..15, out of three (cos, sin) pairs and h
+        const float2 W1 = make_float2(0.98078528040323044913f, 0.19509032201612826785f);
+        const float2 W2 = make_float2(0.92387953251128675613f, 0.38268343236508977173f);
+        const float2 W3 = make_float2(0.83146961230254523708f, 0.55557023301960222474f);
+        const float h = 0.70710678118654752440f;
+        constexpr int NY = SIGN > 0 ? 0 : 1;
+        float2 t[16];
+        t[0] = o[0];
+        t[1] = cmul_k<0, 0, 1, NY>(o[1], W1);
+        t[2] = cmul_k<0, 0, 1, NY>(o[2], W2);
+        t[3] = cmul_k<0, 0, 1, NY>(o[3], W3);
+        t[4] = cmul_hh<SIGN>(o[4], h);
+        t[5] = cmul_k<1, 0, 0, NY>(o[5], W3);
+        t[6] = cmul_k<1, 0, 0, NY>(o[6], W2);
+        t[7] = cmul_k<1, 0, 0, NY>(o[7], W1);
+        t[9] = cmul_k<1, 1, 0, NY>(o[9], W1);
+        t[10] = cmul_k<1, 1, 0, NY>(o[10], W2);
+        t[11] = cmul_k<1, 1, 0, NY>(o[11], W3);
+        t[12] = cmul_mhh<SIGN>(o[12], h);
+        t[13] = cmul_k<0, 1, 1, NY>(o[13], W3);
+        t[14] = cmul_k<0, 1, 1, NY>(o[14], W2);
+        t[15] = cmul_k<0, 1, 1, NY>(o[15], W1);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const float2 w = make_float2(wr[k], SIGN > 0 ? wi[k] : -wi[k]);
-            const float2 t = (k == 0) ? o[0] : cmul(o[k], w);
-            v[k] = cadd(e[k], t);
-            v[k + 16] = csub(e[k], t);
+            if (k == 8) {
+                v[8] = cadd_si<SIGN>(e[8], o[8]);
+                v[24] = csub_si<SIGN>(e[8], o[8]);
+                continue;
+            }
+            v[k] = cadd(e[k], t[k]);
+            v[k + 16] = csub(e[k], t[k]);
         }
     }
 };
@@ -191,20 +341,16 @@ __device__ __forceinline__ void wave_c2r(float2 (&x)[A], float xh, float2 *L, co
         const float2 Xk = x[a];
         float2 B = DPP ? part[DPP ? a : 0] : L[(kp / P) * (P + 1) + (kp % P)];
         if (k == 0) B = make_float2(xh, 0.f);
-        const float2 E = make_float2(Xk.x + B.x, Xk.y - B.y);
-        const float2 D = make_float2(Xk.x - B.x, Xk.y + B.y);
-        float2 w = twN[k];
-        w.y = -w.y;
-        const float2 O = cmul(D, w);
-        x[a] = (k == 0) ? make_float2(Xk.x + xh, Xk.x - xh) : make_float2(E.x - O.y, E.y + O.x);
+        const float2 E = cadd_c(Xk, B);
+        const float2 D = csub_c(Xk, B);
+        const float2 O = cmulc(D, twN[k]);
+        x[a] = (k == 0) ? make_float2(Xk.x + xh, Xk.x - xh) : cadd_i(E, O);
     }
     Dft<A, +1>::run(x);  // over a: Y_b[c]
     wave_fence();        // the partner reads are done before the region is overwritten
 #pragma unroll
     for (int c = 0; c < A; c++) {
-        float2 w = twH[c * b];
-        w.y = -w.y;
-        L[c * (P + 1) + b] = (c == 0) ? x[0] : cmul(x[c], w);
+        L[c * (P + 1) + b] = (c == 0) ? x[0] : cmulc(x[c], twH[c * b]);
     }
     wave_fence();
 #pragma unroll

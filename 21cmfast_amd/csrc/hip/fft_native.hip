@@ -621,6 +621,12 @@ struct LinePassArgs {
     // the node tables' range (x >= (wev_n_nodes - 2) / 4), where the window is evaluated directly
     float wev_mfp[2][4];
     double wev_dkx, wev_dky, wev_dkz;
+    // Item order of the main geometry (round 5 experiment): 0 = outer-major (k_y, then
+    // the k_z column tiles).  Pass X, 1: column-tile-major -- the LAST items written are then whole
+    // (x, column tile) tiles of pass Y.  Pass Y, k > 0: the last k column tiles first (all x, the tile
+    // written last first), the rest outer-major as before (so that the fused pass Z still finds the
+    // planes written last).
+    int item_order;
 };
 
 static inline int geo_items(const LineGeo &g) {
@@ -739,7 +745,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         LineItem it;
         const bool s = w >= n_work0;
         int ww = s ? w - n_work0 : w;
-        if (WIN && !s && ww < (n_work0 & ~15)) {
+        if (WIN && !s && ww < (n_work0 & ~15) && a.item_order == 0) {
             // XCD-aware order.  Workgroups are dealt to the 8 XCDs round robin, and two column
             // tiles of one k_y that are neighbours share every 128-byte line of the window table
             // (a tile reads 64 bytes per row).  Within each run of 16 items, workgroups b and
@@ -773,6 +779,34 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
         const int po = s ? a.g1.pair_outer : a.g0.pair_outer;
         it.og = ww / nct;
         it.ct = ww - it.og * nct;
+        if (a.item_order == 3 || a.item_order == -1) {
+            // (only where a trip covers whole rows of column tiles, so that the rotation permutes the items
+            //  of a trip: boxes with 6, 24 or 48 column tiles -- 192-, 768-, 1536-point z-lines -- keep the
+            //  plain order)
+            if (!s && (int)gridDim.x % nct == 0)
+            // rotate: with 256 workgroups and 16 (32) column tiles a workgroup would meet the SAME column
+            // tile on every trip (256 = 0 mod 16), and the tiles whose lines sit in the slow phase of the
+            // HBM channel map always stall the same workgroups; trip j takes column tile (ct + j) instead
+                it.ct = (it.ct + w / (int)gridDim.x) % nct;
+        } else if (a.item_order != 0 && !s) {
+            const int nog = n_work0 / nct;  // outer groups of the main geometry
+            if (FMODE != 0) {               // pass X: column-tile-major
+                it.ct = ww / nog;
+                it.og = ww - it.ct * nog;
+            } else {                        // pass Y: the last k column tiles first
+                const int k = a.item_order < nct ? a.item_order : nct;
+                const int head = k * nog;
+                if (ww < head) {
+                    const int c = ww / nog;
+                    it.ct = nct - 1 - c;
+                    it.og = ww - c * nog;
+                } else {
+                    const int v = ww - head, m = nct - k;
+                    it.og = v / m;
+                    it.ct = v - it.og * m;
+                }
+            }
+        }
         it.npair = (po && it.og != 0 && 2 * it.og != it.n_outer) ? 2 : 1;
         return it;
     };
@@ -2072,6 +2106,9 @@ constexpr int ktime_kind(int sign, int fmode) {
                                                               : (fmode == 7 || fmode == 9) ? 8 : 10);
 }
 
+#ifndef C21X_XORDER_DEFAULT
+#define C21X_XORDER_DEFAULT 3
+#endif
 template <int N, int SIGN, int FMODE>
 int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
     const float2 *tw = twiddles(N);
@@ -2100,9 +2137,23 @@ int launch_line_pass_mode(const LinePassArgs &a, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
+    LinePassArgs ao = a;
+    {
+        // item order of the main geometry: rotate the column tile with the trip (default, round 5: a
+        // workgroup no longer meets the same column tile on every trip -- pass Y 0.476 -> 0.447 ms at
+        // 512^3, 3.45 -> 2.97 ms at 1024^3); C21CM_YORDER / C21CM_XORDER = 0 restore the plain order,
+        // 1 / k select the experimental orders of DESIGN section 8
+        static int xo = -99, yo = -99;
+        if (xo == -99) {
+            const char *ex = getenv("C21CM_XORDER"), *ey = getenv("C21CM_YORDER");
+            xo = ex ? atoi(ex) : C21X_XORDER_DEFAULT;
+            yo = ey ? atoi(ey) : -1;
+        }
+        ao.item_order = (FMODE == 0) ? yo : xo;
+    }
     KTimeScope kt(ktime_kind(SIGN, FMODE), stream);
     hipLaunchKernelGGL((line_pass_kernel<N, SIGN, FMODE>), dim3((unsigned)nblocks),
-                       dim3(LineThreads<N, FMODE>::value), lds, stream, a, tw);
+                       dim3(LineThreads<N, FMODE>::value), lds, stream, ao, tw);
     LAUNCH_CHECK();
     return 0;
 }
@@ -2497,8 +2548,9 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
         } else if (EPI == 8) {
             const float2 dd = dreg[EPI == 8 ? q : 0];
             const float d0 = clip_delta_eulerian(dd.x), d1 = clip_delta_eulerian(dd.y);
-            double f0 = eval_table_f((double)d0, a.tab_min, a.tab_width, ftab);
-            double f1 = eval_table_f((double)d1, a.tab_min, a.tab_width, ftab);
+            const double inv_w = 1. / a.tab_width;  // (loop invariant: hoisted)
+            double f0 = eval_table_f_inv((double)d0, a.tab_min, a.tab_width, inv_w, ftab);
+            double f1 = eval_table_f_inv((double)d1, a.tab_min, a.tab_width, inv_w, ftab);
             if (a.tab_mode != C21CM_FCOLL_TABLE_LINEAR) {
                 f0 = exp_f32acc(f0);
                 f1 = exp_f32acc(f1);

@@ -173,6 +173,18 @@ __device__ __forceinline__ CellIndex<VEC> cell_index(size_t i, int nz_items, int
     return CellIndex<VEC>{line * (size_t)zpad_items + k, i};
 }
 
+// rows of a power-of-two number of items: the 64-bit division becomes a shift (sh = log2(nz_items), -1: divide)
+template <int VEC>
+__device__ __forceinline__ CellIndex<VEC> cell_index_sh(size_t i, int nz_items, int zpad_items, int sh) {
+    if (sh < 0) return cell_index<VEC>(i, nz_items, zpad_items);
+    const size_t line = i >> sh;
+    const int k = (int)(i & (size_t)(nz_items - 1));
+    return CellIndex<VEC>{line * (size_t)zpad_items + k, i};
+}
+__device__ __forceinline__ int row_shift(int nz_items) {
+    return (nz_items > 0 && (nz_items & (nz_items - 1)) == 0) ? __builtin_ctz(nz_items) : -1;
+}
+
 template <int VEC>
 struct Pack;
 template <>
@@ -261,6 +273,8 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
         __syncthreads();
     }
     double acc = 0.;
+    const double inv_w = 1. / fp.tab_width;
+    const int sh = row_shift(nz_items);
     constexpr int U = 4;  // items per thread and trip, loads issued before the arithmetic
     for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < nitems;
          i0 += (size_t)gridDim.x * kBlock * U) {
@@ -268,7 +282,7 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t i = i0 + (size_t)u * kBlock;
-            if (i < nitems) d[u] = Pack<VEC>::load(delta_fil, cell_index<VEC>(i, nz_items, zpad_items).padded);
+            if (i < nitems) d[u] = Pack<VEC>::load(delta_fil, cell_index_sh<VEC>(i, nz_items, zpad_items, sh).padded);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -282,9 +296,9 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
                 if (fp.mode == C21CM_FCOLL_ERFC) {
                     f = (fp.sig < 0) ? 0. : fgtrm_bias_fast(fp.growthf, dens, fp.sig, fp.delta_c);
                 } else if (fp.mode == C21CM_FCOLL_TABLE_LINEAR) {
-                    f = eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab);
+                    f = eval_table_f_inv((double)dens, fp.tab_min, fp.tab_width, inv_w, tab);
                 } else {
-                    f = exp_f32acc(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
+                    f = exp_f32acc(eval_table_f_inv((double)dens, fp.tab_min, fp.tab_width, inv_w, tab));
                 }
                 out.v[e] = (float)f;  // box->unnormalised_nion is float (IonisationBox.c:951)
                 acc += f;
@@ -314,6 +328,8 @@ fcoll_eulerian_band_kernel(const float *__restrict__ delta_fil, float *__restric
     const float t_sure = (float)band[0], t_maybe = (float)band[1];
     const float t_prev = r_prev >= 0 ? (float)*thr_prev : 0.f;
     double acc = 0.;
+    const double inv_w = 1. / fp.tab_width;
+    const int sh = row_shift(nz_items);
     constexpr int U = 4;
     for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < nitems;
          i0 += (size_t)gridDim.x * kBlock * U) {
@@ -323,7 +339,7 @@ fcoll_eulerian_band_kernel(const float *__restrict__ delta_fil, float *__restric
         for (int u = 0; u < U; u++) {
             const size_t i = i0 + (size_t)u * kBlock;
             if (i < nitems) {
-                d[u] = Pack<2>::load(delta_fil, cell_index<2>(i, nz_items, zpad_items).padded);
+                d[u] = Pack<2>::load(delta_fil, cell_index_sh<2>(i, nz_items, zpad_items, sh).padded);
                 mk[u] = reinterpret_cast<const uchar2 *>(first_cross)[i];
             }
         }
@@ -338,9 +354,9 @@ fcoll_eulerian_band_kernel(const float *__restrict__ delta_fil, float *__restric
                 const float dens = clip_delta_eulerian(d[u].v[e]);
                 double f;
                 if (fp.mode == C21CM_FCOLL_TABLE_LINEAR)
-                    f = eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab);
+                    f = eval_table_f_inv((double)dens, fp.tab_min, fp.tab_width, inv_w, tab);
                 else
-                    f = exp_f32acc(eval_table_f((double)dens, fp.tab_min, fp.tab_width, tab));
+                    f = exp_f32acc(eval_table_f_inv((double)dens, fp.tab_min, fp.tab_width, inv_w, tab));
                 acc += f;
                 const float g = (float)f;  // what the dense grid would hold
                 if (mv[e] == 255) {        // the previous radius' undecided cell
@@ -1058,7 +1074,8 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
                    const float *__restrict__ Tneutral, float *__restrict__ xH,
                    float *__restrict__ z_reion, float *__restrict__ Tk,
                    double *__restrict__ partials_stars, double *__restrict__ partials_xh,
-                   int *__restrict__ flag, const double *__restrict__ mean_dev = nullptr) {
+                   int *__restrict__ flag, size_t chunk_items, int chunk0,
+                   const double *__restrict__ mean_dev = nullptr) {
     static_assert(!EUL || DIRECT, "the Eulerian sweep reads dense grids");
     double mean_fix = 1.;
     if constexpr (EUL) mean_fix = p.a.fix_mean ? p.a.mean_f_coll / *mean_dev : 1.;  // :1022-1023
@@ -1072,15 +1089,22 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
     const double pow_z = pow(1e4 * ((1. + (double)stored_z) / 4.), 1.7);
     double acc_s = 0., acc_x = 0.;
     int bad = 0;
-    for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < p.nitems;
-         i0 += (size_t)gridDim.x * kBlock * U) {
+    // Workgroup b sweeps the CONTIGUOUS item range [chunk b, chunk b + 1) (round 5): a chunk's partial
+    // sums then depend on the chunk alone, not on how many workgroups the launch has -- a rank that
+    // sweeps only its slab of chunks (c21cm_ionize_shard_finish_slab) leaves the very partials the
+    // single pass leaves there, and the fixed-order reduce over all chunks gives the same sums to the
+    // last bit whoever computed which chunk.
+    const int chunk = chunk0 + (int)blockIdx.x;
+    const size_t c_begin = (size_t)chunk * chunk_items;
+    const size_t c_end = (c_begin + chunk_items < p.nitems) ? c_begin + chunk_items : p.nitems;
+    for (size_t i0 = c_begin + threadIdx.x; i0 < c_end; i0 += (size_t)kBlock * U) {
         Pack<VEC> st[U], de[U], x0[U], T0[U], pz[U], xe[U], Tn[U];
         unsigned char m[U][VEC];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t i = i0 + (size_t)u * kBlock;
-            ok[u] = i < p.nitems;
+            ok[u] = i < c_end;
             if (!ok[u]) continue;
             const auto ci = DIRECT ? CellIndex<VEC>{i, i} : cell_index<VEC>(i, p.nz_items, p.zpad_items);
             st[u] = Pack<VEC>::load(stars_fil, ci.padded);
@@ -1167,9 +1191,9 @@ final_sweep_kernel(IoniseParams p, float stored_z, const unsigned char *__restri
         }
     }
     if (bad) atomicOr(flag, 1);
-    block_sum_to(acc_s, partials_stars);
+    block_sum_to(acc_s, partials_stars + chunk0);
     __syncthreads();
-    block_sum_to(acc_x, partials_xh);
+    block_sum_to(acc_x, partials_xh + chunk0);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1759,28 +1783,83 @@ extern "C" int c21hip_finalize(const c21hip_ionize_args *a, double stored_redshi
     return 0;
 }
 
-extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
-                                  const unsigned char *first_cross, const float *stars_fil,
-                                  const float *density, const float *prev_z_reion, float *xH,
-                                  float *z_reion, float *kinetic_temperature, double *partials,
-                                  double *sum_stars_out, double *sum_xh_out, int *flag_out,
-                                  int stars_direct, const float *xe_dense,
-                                  const float *kinetic_temp_neutral, void *stream) {
+// The final sweep's chunks (round 5): workgroup b owns the contiguous items [b, b + 1) * chunk_items.
+// The chunking depends on the box alone, so a sharded finish (every rank sweeps a slab of whole chunks,
+// c21cm_ionize_shard_finish_slab) leaves chunk partials identical to the single pass', and one
+// fixed-order reduce over all of them gives the same sums whoever swept which chunk.
+namespace {
+struct FinalChunks {
+    size_t chunk_items;
+    int n_chunks, vec;
+    size_t nitems;
+};
+FinalChunks final_chunks(const c21hip_ionize_args *a, int dense) {
+    FinalChunks c;
+    const size_t ntot = (size_t)a->nx * a->ny * a->nz;
+    c.vec = dense ? ((ntot % 4 == 0) ? 4 : 1) : ((a->nz % 2 == 0) ? 2 : 1);
+    c.nitems = dense ? ntot / c.vec : (size_t)a->nx * a->ny * (a->nz / c.vec);
+    const int blocks = grid_for((c.nitems + 1) / 2);
+    const size_t q = (size_t)kBlock * 2;  // one trip of a workgroup (U = 2)
+    c.chunk_items = ((c.nitems + blocks - 1) / blocks + q - 1) / q * q;
+    c.n_chunks = (int)((c.nitems + c.chunk_items - 1) / c.chunk_items);
+    return c;
+}
+}  // namespace
+
+// chunk count and cells per chunk of the final sweep of this box (dense: the sweep reads dense grids --
+// the direct Lagrangian sweep and the Eulerian one); the last chunk may be short
+extern "C" int c21hip_final_sweep_chunks(const c21hip_ionize_args *a, int dense, int *n_chunks,
+                                         size_t *chunk_cells) {
+    const FinalChunks c = final_chunks(a, dense);
+    if (n_chunks) *n_chunks = c.n_chunks;
+    if (chunk_cells) *chunk_cells = c.chunk_items * (size_t)c.vec;
+    return 0;
+}
+
+// the fixed-order reduce over ALL chunk partials of a final sweep (stars: Lagrangian sweeps only)
+extern "C" int c21hip_final_sweep_reduce(const c21hip_ionize_args *a, int dense, double *partials,
+                                         double *sum_stars_out, double *sum_xh_out, void *stream) {
+    const FinalChunks c = final_chunks(a, dense);
+    double *ps = partials, *px = partials + kMaxBlocks;
+    if (sum_stars_out)
+        hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, ps,
+                           c.n_chunks, 0, sum_stars_out);
+    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, px,
+                       c.n_chunks, 0, sum_xh_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// chunks [chunk_begin, chunk_end) of the final sweep (chunk_end < 0: all); leaves their partials in
+// partials[chunk] (stars) and partials[kMaxBlocks + chunk] (x_HI); no reduce
+extern "C" int c21hip_final_sweep_range(const c21hip_ionize_args *a, double stored_redshift,
+                                        const unsigned char *first_cross, const float *stars_fil,
+                                        const float *density, const float *prev_z_reion, float *xH,
+                                        float *z_reion, float *kinetic_temperature, double *partials,
+                                        int *flag_out, int stars_direct, const float *xe_dense,
+                                        const float *kinetic_temp_neutral, int chunk_begin, int chunk_end,
+                                        void *stream) {
     if (a->use_ts_fluct && (!stars_direct || !xe_dense || (!a->minimize_memory && !kinetic_temp_neutral))) {
         c21hip_set_error("final sweep: the x_e path needs the dense inputs (stars_direct)");
         return C21CM_VALUE_ERROR;
     }
-    const size_t ntot = (size_t)a->nx * a->ny * a->nz;
-    const int vec = stars_direct ? ((ntot % 4 == 0) ? 4 : 1) : ((a->nz % 2 == 0) ? 2 : 1);
+    const FinalChunks c = final_chunks(a, stars_direct);
+    const int vec = c.vec;
     IoniseParams p = make_params(a, vec == 4 ? 2 : vec);
-    if (stars_direct) p.nitems = ntot / vec;  // dense grids: the box is one long row
-    const int blocks = grid_for((p.nitems + 1) / 2);
+    if (stars_direct) p.nitems = c.nitems;  // dense grids: the box is one long row
+    if (chunk_end < 0) chunk_begin = 0, chunk_end = c.n_chunks;
+    if (chunk_begin < 0 || chunk_end > c.n_chunks || chunk_begin > chunk_end) {
+        c21hip_set_error("final sweep: chunk range [%d, %d) outside [0, %d)", chunk_begin, chunk_end, c.n_chunks);
+        return C21CM_VALUE_ERROR;
+    }
+    const int blocks = chunk_end - chunk_begin;
+    if (blocks == 0) return 0;
     double *ps = partials, *px = partials + kMaxBlocks;
 #define LAUNCH_FINAL(V, D)                                                                       \
     hipLaunchKernelGGL((final_sweep_kernel<V, D>), dim3(blocks), dim3(kBlock), 0,                \
                        (hipStream_t)stream, p, (float)stored_redshift, first_cross, stars_fil,   \
                        density, prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion,       \
-                       kinetic_temperature, ps, px, flag_out)
+                       kinetic_temperature, ps, px, flag_out, c.chunk_items, chunk_begin)
     if (stars_direct && vec == 4)
         LAUNCH_FINAL(4, true);
     else if (stars_direct)
@@ -1791,18 +1870,65 @@ extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_red
         LAUNCH_FINAL(1, false);
 #undef LAUNCH_FINAL
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, ps,
-                       blocks, 0, sum_stars_out);
-    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, px,
-                       blocks, 0, sum_xh_out);
-    LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int c21hip_final_sweep(const c21hip_ionize_args *a, double stored_redshift,
+                                  const unsigned char *first_cross, const float *stars_fil,
+                                  const float *density, const float *prev_z_reion, float *xH,
+                                  float *z_reion, float *kinetic_temperature, double *partials,
+                                  double *sum_stars_out, double *sum_xh_out, int *flag_out,
+                                  int stars_direct, const float *xe_dense,
+                                  const float *kinetic_temp_neutral, void *stream) {
+    const int st = c21hip_final_sweep_range(a, stored_redshift, first_cross, stars_fil, density, prev_z_reion,
+                                            xH, z_reion, kinetic_temperature, partials, flag_out, stars_direct,
+                                            xe_dense, kinetic_temp_neutral, 0, -1, stream);
+    if (st) return st;
+    return c21hip_final_sweep_reduce(a, stars_direct, partials, sum_stars_out, sum_xh_out, stream);
 }
 
 // The cell-scale radius and the post-loop of the Eulerian source models in one sweep
 // (final_sweep_kernel<V, true, true>): first crossings of the larger radii (first_cross), the barrier and
 // the partial ionisation at radius index 0 from its dense f_coll grid and box mean, z_reion, T_k, the sum
 // of x_HI.  xe_dense / kinetic_temp_neutral: the inputs of a spin-temperature run (NULL otherwise).
+// chunk_begin / chunk_end as c21hip_final_sweep_range (no reduce); c21hip_final_sweep_eulerian: all + reduce.
+extern "C" int c21hip_final_sweep_eulerian_range(const c21hip_ionize_args *a, double stored_redshift,
+                                                 const unsigned char *first_cross, const float *nion_dense,
+                                                 const double *mean_dev, const float *density,
+                                                 const float *prev_z_reion, float *xH, float *z_reion,
+                                                 float *kinetic_temperature, double *partials, int *flag_out,
+                                                 const float *xe_dense, const float *kinetic_temp_neutral,
+                                                 int chunk_begin, int chunk_end, void *stream) {
+    if (a->use_ts_fluct && (!xe_dense || (!a->minimize_memory && !kinetic_temp_neutral))) {
+        c21hip_set_error("final sweep: the x_e path needs the dense inputs");
+        return C21CM_VALUE_ERROR;
+    }
+    const FinalChunks c = final_chunks(a, 1);
+    const int vec = c.vec;
+    IoniseParams p = make_params(a, vec == 4 ? 2 : vec);
+    p.nitems = c.nitems;  // dense grids: the box is one long row
+    if (chunk_end < 0) chunk_begin = 0, chunk_end = c.n_chunks;
+    if (chunk_begin < 0 || chunk_end > c.n_chunks || chunk_begin > chunk_end) {
+        c21hip_set_error("final sweep: chunk range [%d, %d) outside [0, %d)", chunk_begin, chunk_end, c.n_chunks);
+        return C21CM_VALUE_ERROR;
+    }
+    const int blocks = chunk_end - chunk_begin;
+    if (blocks == 0) return 0;
+    double *ps = partials, *px = partials + kMaxBlocks;
+    if (vec == 4)
+        hipLaunchKernelGGL((final_sweep_kernel<4, true, true>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, nion_dense, density,
+                           prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion, kinetic_temperature, ps,
+                           px, flag_out, c.chunk_items, chunk_begin, mean_dev);
+    else
+        hipLaunchKernelGGL((final_sweep_kernel<1, true, true>), dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, nion_dense, density,
+                           prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion, kinetic_temperature, ps,
+                           px, flag_out, c.chunk_items, chunk_begin, mean_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int c21hip_final_sweep_eulerian(const c21hip_ionize_args *a, double stored_redshift,
                                            const unsigned char *first_cross, const float *nion_dense,
                                            const double *mean_dev, const float *density,
@@ -1810,31 +1936,12 @@ extern "C" int c21hip_final_sweep_eulerian(const c21hip_ionize_args *a, double s
                                            float *kinetic_temperature, double *partials, double *sum_xh_out,
                                            int *flag_out, const float *xe_dense,
                                            const float *kinetic_temp_neutral, void *stream) {
-    if (a->use_ts_fluct && (!xe_dense || (!a->minimize_memory && !kinetic_temp_neutral))) {
-        c21hip_set_error("final sweep: the x_e path needs the dense inputs");
-        return C21CM_VALUE_ERROR;
-    }
-    const size_t ntot = (size_t)a->nx * a->ny * a->nz;
-    const int vec = (ntot % 4 == 0) ? 4 : 1;
-    IoniseParams p = make_params(a, vec == 4 ? 2 : vec);
-    p.nitems = ntot / vec;  // dense grids: the box is one long row
-    const int blocks = grid_for((p.nitems + 1) / 2);
-    double *ps = partials, *px = partials + kMaxBlocks;
-    if (vec == 4)
-        hipLaunchKernelGGL((final_sweep_kernel<4, true, true>), dim3(blocks), dim3(kBlock), 0,
-                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, nion_dense, density,
-                           prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion, kinetic_temperature, ps,
-                           px, flag_out, mean_dev);
-    else
-        hipLaunchKernelGGL((final_sweep_kernel<1, true, true>), dim3(blocks), dim3(kBlock), 0,
-                           (hipStream_t)stream, p, (float)stored_redshift, first_cross, nion_dense, density,
-                           prev_z_reion, xe_dense, kinetic_temp_neutral, xH, z_reion, kinetic_temperature, ps,
-                           px, flag_out, mean_dev);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(finish_reduce_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, px, blocks, 0,
-                       sum_xh_out);
-    LAUNCH_CHECK();
-    return 0;
+    const int st = c21hip_final_sweep_eulerian_range(a, stored_redshift, first_cross, nion_dense, mean_dev,
+                                                     density, prev_z_reion, xH, z_reion, kinetic_temperature,
+                                                     partials, flag_out, xe_dense, kinetic_temp_neutral, 0, -1,
+                                                     stream);
+    if (st) return st;
+    return c21hip_final_sweep_reduce(a, 1, partials, nullptr, sum_xh_out, stream);
 }
 
 extern "C" int c21hip_brightness_temp(const float *density, const float *xH, const float *Ts,

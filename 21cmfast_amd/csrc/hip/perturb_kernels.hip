@@ -333,7 +333,29 @@ struct CicCellParams {
     int halo, lead;   // lead = 1 when lo < 0: the brick's first particles sit in output cell m0 - 1
 };
 
-template <int F, bool LPT2, int DIAG>
+// FIXED (round 5): the masses accumulate as 64-bit FIXED-POINT integers (scale 2^44) in the LDS tile and in
+// the grid -- integer additions commute, so the deposit no longer depends on the order in which the
+// hardware serves the atomics: two calls give the same bits (the fp64 atomics of rounds 1-4 did not:
+// about one ComputePerturbedField in twelve differed from the previous one in the last bit of a cell,
+// which was enough to move a filtered extremum and with it a whole f_coll table).  A term is rounded to
+// 2^-44 = 5.7e-14 of the mean particle mass, a cell collects a few hundred of them: 1e-12 relative on a
+// grid that is rounded to float (6e-8) next, i.e. the float differs from the fp64 sum's in about one cell
+// in 1e5 (at 2^36 it was one in 500, which a 40^3 test noticed).  A cell holds up to 2^19 = 524288
+// particle masses before the 63 bits overflow.  The reference's OpenMP atomics have no defined order
+// either (map_mass.c:197-206).
+constexpr double kFixScale = 17592186044416.;       // 2^44
+constexpr double kFixMagic = 6755399441055744.;     // 1.5 * 2^52: x + magic holds rint(x) in its low bits
+constexpr long long kFixMagicBits = 0x4338000000000000LL;
+constexpr double kFixFastLimit = 128.;              // |term| 2^44 < 2^51: the magic-number conversion is exact
+__device__ __forceinline__ long long to_fixed_fast(double term) {  // one fma and an integer subtraction
+    return __double_as_longlong(fma(term, kFixScale, kFixMagic)) - kFixMagicBits;
+}
+__device__ __forceinline__ long long to_fixed(double term) {
+    if (fabs(term) < kFixFastLimit) return to_fixed_fast(term);
+    return __double2ll_rn(term * kFixScale);
+}
+
+template <int F, bool LPT2, int DIAG, bool FIXED>
 __global__ void __launch_bounds__(kBlock)
 cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__restrict__ vx,
                 const float *__restrict__ vy, const float *__restrict__ vz,
@@ -441,6 +463,16 @@ cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__
                     }
                 }
             double acc[3][3][3];
+            float dmax = 0.f;  // FIXED: bound of the cell's particle masses
+            if constexpr (FIXED) {
+#pragma unroll
+                for (int jx = 0; jx < F; jx++)
+#pragma unroll
+                    for (int jy = 0; jy < F; jy++)
+#pragma unroll
+                        for (int jz = 0; jz < F; jz++) dmax = fmaxf(dmax, fabsf(dn[jx][jy][jz]));
+            }
+            const bool small = (1.0 + (double)dmax * fabs(p.init_growth)) * (double)F3 < kFixFastLimit;
 #pragma unroll
             for (int jx = 0; jx < F; jx++) {
                 double Y[3][3];
@@ -486,8 +518,16 @@ cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__
                         if (DIAG & 1) {  // diagnostic build only: no LDS atomics
                             if (term == 1.2345e300) tile[0] = term;
                         } else if (term != 0.) {  // a third of the 27 are empty: -0.35 ms of 3.7
-                            __hip_atomic_fetch_add(&tile[base + (a * q.td[1] + b) * q.td[2] + c], term,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if constexpr (FIXED)
+                                // (a term is at most the F^3 particle masses of the cell: `small` decided once
+                                //  per cell; the slow conversion is there for IC cells whose F^3 masses exceed 128 only)
+                                __hip_atomic_fetch_add(
+                                    reinterpret_cast<long long *>(tile) + base + (a * q.td[1] + b) * q.td[2] + c,
+                                    small ? to_fixed_fast(term) : to_fixed(term), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_WORKGROUP);
+                            else
+                                __hip_atomic_fetch_add(&tile[base + (a * q.td[1] + b) * q.td[2] + c], term,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
         }
@@ -537,16 +577,21 @@ cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__
 #pragma unroll
                 for (int b = 0; b < 2; b++)
 #pragma unroll
-                    for (int c = 0; c < 2; c++)
-                        unsafeAtomicAdd(out + bo[0][a] + bo[1][b] + bo[2][c],
-                                        mass * ((w[0][a] * w[1][b]) * w[2][c]));
+                    for (int c = 0; c < 2; c++) {
+                        const double term = mass * ((w[0][a] * w[1][b]) * w[2][c]);
+                        if constexpr (FIXED)
+                            atomicAdd(reinterpret_cast<unsigned long long *>(out) + bo[0][a] + bo[1][b] + bo[2][c],
+                                      (unsigned long long)to_fixed(term));
+                        else
+                            unsafeAtomicAdd(out + bo[0][a] + bo[1][b] + bo[2][c], term);
+                    }
         }
         // flush: rows of the tile are runs of td[2] cells along z
         if (!(DIAG & 2)) {
             const int rows = q.td[0] * q.td[1];
             for (int c = threadIdx.x; c < tcells; c += kBlock) {
-                const double tv = tile[c];
-                if (tv != 0.) {
+                const double tv = tile[c];  // (FIXED: the integer's bit pattern; 0 is 0 either way)
+                if (__double_as_longlong(tv) != 0) {
                     const int row = c / q.td[2];
                     const int c2 = c - row * q.td[2];
                     const int c0 = row / q.td[1];
@@ -555,7 +600,12 @@ cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__
                     if (o0 < 0) o0 += p.out_dim[0]; else if (o0 >= p.out_dim[0]) o0 -= p.out_dim[0];
                     if (o1 < 0) o1 += p.out_dim[1]; else if (o1 >= p.out_dim[1]) o1 -= p.out_dim[1];
                     if (o2 < 0) o2 += p.out_dim[2]; else if (o2 >= p.out_dim[2]) o2 -= p.out_dim[2];
-                    unsafeAtomicAdd(out + (size_t)o0 * sx + (size_t)o1 * sy + (size_t)o2, tv);
+                    const size_t o = (size_t)o0 * sx + (size_t)o1 * sy + (size_t)o2;
+                    if constexpr (FIXED)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(out) + o,
+                                  (unsigned long long)__double_as_longlong(tv));
+                    else
+                        unsafeAtomicAdd(out + o, tv);
                 }
             }
             (void)rows;
@@ -567,7 +617,7 @@ cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__
 // double grid -> padded float, then (optionally) *= mass_factor; -= 1
 __global__ void __launch_bounds__(kBlock)
 widen_normalise_kernel(const double *__restrict__ in, float *__restrict__ padded, size_t nlines,
-                       int nz, int zpad, int normalise, double mass_factor) {
+                       int nz, int zpad, int normalise, double mass_factor, int fixed) {
     const size_t total = nlines * (size_t)zpad;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
          i += (size_t)gridDim.x * kBlock) {
@@ -575,7 +625,10 @@ widen_normalise_kernel(const double *__restrict__ in, float *__restrict__ padded
         const int k = (int)(i - line * (size_t)zpad);
         float v = 0.f;
         if (k < nz) {
-            v = (float)in[line * (size_t)nz + k];  // PerturbedField.c:124
+            const double acc = in[line * (size_t)nz + k];
+            // (fixed: the deposit's 2^44 fixed-point integer; exact in a double below 2^53 = 512 particle masses,
+            //  rounded to double above: the float next to it does not see that)
+            v = (float)(fixed ? (double)__double_as_longlong(acc) * (1. / kFixScale) : acc);  // PerturbedField.c:124
             if (normalise) {
                 v = (float)((double)v * mass_factor);  // :201
                 v = v - 1.f;                           // :202
@@ -888,21 +941,21 @@ bool cell_setup(const CicParams &p, CicCellParams &q, size_t *lds, int *blocks, 
     return *lds <= 96 * 1024;
 }
 
-template <int F, int DIAG>
+template <int F, int DIAG, bool FIXED = false>
 void launch_cell(const CicCellParams &q, size_t lds, int blocks, int lpt2, const float *dens,
                  const float *const vel[3], const float *const vel2[3], double *out,
                  hipStream_t stream) {
     if (lpt2) {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)cic_cell_kernel<F, true, DIAG>,
+            (void)hipFuncSetAttribute((const void *)cic_cell_kernel<F, true, DIAG, FIXED>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipLaunchKernelGGL((cic_cell_kernel<F, true, DIAG>), dim3(blocks), dim3(kBlock), lds, stream,
+        hipLaunchKernelGGL((cic_cell_kernel<F, true, DIAG, FIXED>), dim3(blocks), dim3(kBlock), lds, stream,
                            q, dens, vel[0], vel[1], vel[2], vel2[0], vel2[1], vel2[2], out);
     } else {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)cic_cell_kernel<F, false, DIAG>,
+            (void)hipFuncSetAttribute((const void *)cic_cell_kernel<F, false, DIAG, FIXED>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipLaunchKernelGGL((cic_cell_kernel<F, false, DIAG>), dim3(blocks), dim3(kBlock), lds,
+        hipLaunchKernelGGL((cic_cell_kernel<F, false, DIAG, FIXED>), dim3(blocks), dim3(kBlock), lds,
                            stream, q, dens, vel[0], vel[1], vel[2], (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, out);
     }
@@ -913,10 +966,11 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
                                   const float *const vel[3], const float *const vel2[3],
                                   const int vel_dim[3], double *out, const int out_dim[3],
                                   double box_len, double box_len_z, double growth,
-                                  double init_growth, int lpt2, void *stream) {
+                                  double init_growth, int lpt2, int *fixed_out, void *stream) {
     CicParams p;
     fill_cic_params(p, dens_dim, vel_dim, out_dim, box_len, box_len_z, growth, init_growth, lpt2);
     const size_t total = (size_t)dens_dim[0] * dens_dim[1] * dens_dim[2];
+    if (fixed_out) *fixed_out = 0;
     {
         // C21CM_CIC = cell (default: per velocity cell, LDS tile) | tiled (per particle, LDS tile;
         // rounds 1-3) | direct (global atomics); tiny grids take the direct kernel
@@ -939,6 +993,22 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
                     launch_cell<2, 3>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
                 else
 #endif
+                // C21CM_CIC_ACC = fixed (default where the caller can read it: deterministic 64-bit
+                // fixed-point accumulation) | double (fp64 atomics, rounds 1-4)
+                const char *ea = getenv("C21CM_CIC_ACC");
+                if (fixed_out && !(ea && ea[0] == 'd')) {
+                    *fixed_out = 1;
+                    if (f == 1)
+                        launch_cell<1, 0, true>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                    else if (f == 2)
+                        launch_cell<2, 0, true>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                    else if (f == 3)
+                        launch_cell<3, 0, true>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                    else
+                        launch_cell<4, 0, true>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
+                    LAUNCH_CHECK();
+                    return 0;
+                }
                 if (f == 1)
                     launch_cell<1, 0>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
                 else if (f == 2)
@@ -975,11 +1045,11 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
 }
 
 extern "C" int c21hip_widen_normalise(const double *in, float *padded, int nx, int ny, int nz,
-                                      int normalise, double mass_factor, void *stream) {
+                                      int normalise, double mass_factor, int fixed, void *stream) {
     const int zpad = 2 * (nz / 2 + 1);
     const size_t nlines = (size_t)nx * ny;
     hipLaunchKernelGGL(widen_normalise_kernel, dim3(grid_for(nlines * zpad)), dim3(kBlock), 0,
-                       (hipStream_t)stream, in, padded, nlines, nz, zpad, normalise, mass_factor);
+                       (hipStream_t)stream, in, padded, nlines, nz, zpad, normalise, mass_factor, fixed);
     LAUNCH_CHECK();
     return 0;
 }

@@ -17,7 +17,7 @@
 #include "c21cm_abi.h"
 
 namespace {
-constexpr int kMaxSlots = 256;
+constexpr int kMaxSlots = 288;  // ids 256.. : shard_rccl.c (status word, slab exchange)
 struct Slot {
     void *ptr = nullptr;
     size_t bytes = 0;

@@ -273,10 +273,28 @@ static int nion_table2d_fn(int r_index, int prev, double dmin, double dmax, doub
     return st;
 }
 
+/* Where the time of the last ComputeIonizedBox of this process went (diagnostic):
+ * [0] host ms before the device driver is entered (scalars, sigma(M) and f_coll tables, the spec),
+ * [1] device pre-loop, [2] R loop, [3] post-loop (HIP events of c21cm_ionize_grids; 0 on the sharded
+ * path), [4] wall ms of the whole call, [5] number of filter radii. */
+static double g_ion_timing[6];
+int c21cm_last_ionize_timing(double out[6]) {
+    if (!out) return C21CM_VALUE_ERROR;
+    memcpy(out, g_ion_timing, sizeof(g_ion_timing));
+    return 0;
+}
+static double wall_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *perturbed_field,
                       PerturbedField *previous_perturbed_field, IonizedBox *previous_ionize_box,
                       TsBox *spin_temp, HaloBox *halos, InitialConditions *ini_boxes,
                       IonizedBox *box) {
+    const double t_enter = wall_ms();
+    memset(g_ion_timing, 0, sizeof(g_ion_timing));
     int st = require_globals("ComputeIonizedBox", 1);
     if (st) return st;
     const SimulationOptions *so = simulation_options_global;
@@ -577,22 +595,40 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     }
     {
         /* one process per GPU with an initialised communicator (c21cm_shard_init): the R loop
-         * is sharded over the ranks and every rank returns the full box (C21CM_SHARD=0: single
-         * GPU per process; C21CM_SHARD_BCAST=0: only the finishing rank's box is filled) */
+         * is sharded over the ranks (C21CM_SHARD=0: single GPU per process).  What the output arrays
+         * hold afterwards (round 5): where the finish phase runs by cell slabs (the fused Lagrangian
+         * loop) every rank holds ITS slab of the box (c21cm_ionize_shard_slab) and the complete scalars
+         * -- downstream per-cell work (the next snapshot's ComputeIonizedBox, ComputeBrightnessTemp on
+         * the slab) needs no more, and the metric is cells per second, not copies; whole boxes on every
+         * rank cost an all-gather of 12 bytes per cell and are opt-in: C21CM_SHARD_OUTPUT=all (or
+         * c21cm_shard_set_output(1); the old C21CM_SHARD_BCAST=1 means the same).  Models that finish
+         * on one rank keep broadcasting its box unless C21CM_SHARD_OUTPUT=none / C21CM_SHARD_BCAST=0. */
         int srank, sworld;
-        const char *e = getenv("C21CM_SHARD"), *b = getenv("C21CM_SHARD_BCAST");
+        const char *e = getenv("C21CM_SHARD");
+        const int out_mode = c21cm_shard_output_mode();
         /* (a USE_MINI_HALOS run keeps one f_coll history slice per radius: every rank runs the
          * whole R loop) */
         /* (C21CM_SHARD=force: also on a one-rank communicator -- the plumbing test of a 1-GPU box) */
         if (c21cm_shard_info(&srank, &sworld) == 0 && (sworld > 1 || (e && e[0] == 'f')) &&
             !(e && e[0] == '0') && !mini)
             st = c21cm_ionize_sharded(s, perturbed_field, previous_ionize_box, spin_temp, halos,
-                                      box, NULL, !(b && b[0] == '0'), NULL);
-        else
+                                      box, NULL, out_mode, NULL);
+        else {
+            c21cm_ionize_report *rep = (c21cm_ionize_report *)calloc(1, sizeof(*rep));
+            g_ion_timing[0] = wall_ms() - t_enter;
+            g_ion_timing[5] = s->n_radii;
             st = c21cm_ionize_grids(s, perturbed_field, previous_ionize_box, spin_temp, halos, box,
-                                    NULL, NULL);
+                                    rep, NULL);
+            if (rep) {
+                g_ion_timing[1] = rep->ms_preloop;
+                g_ion_timing[2] = rep->ms_rloop;
+                g_ion_timing[3] = rep->ms_postloop;
+                free(rep);
+            }
+        }
     }
 done:
+    g_ion_timing[4] = wall_ms() - t_enter;
     free(s);
     return st;
 }

@@ -379,6 +379,9 @@ typedef struct {
                           * run pass Z fused with f_coll (or its extrema) and only update the
                           * first-crossing mask */
     copyback_list cb;
+    /* sharded finish by cell slabs: the host copies of staged per-cell outputs cover [cb_cell0, cb_cell0 +
+     * cb_ncell) only (cb_ncell = 0: the whole arrays) */
+    size_t cb_cell0, cb_ncell;
 } ion_ctx;
 
 static int r0_direct(void);
@@ -1769,21 +1772,42 @@ static int r0_direct(void) {
     return v;
 }
 
-static int final_step(ion_ctx *c, const unsigned char *mask, int stars_ready) {
+/* chunks [chunk_begin, chunk_end) of the final sweep (chunk_end < 0: all): their partial sums stay in
+ * c->partials; final_step_sums() reduces ALL chunks in a fixed order */
+static int final_step_range(ion_ctx *c, const unsigned char *mask, int stars_ready, int chunk_begin,
+                            int chunk_end) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     c21hip_ionize_args args;
     fill_args(&args, s, 0);
     const int direct = r0_direct();
     if (!direct && !stars_ready) TRY(final_prepare(c));
-    TRY(c21hip_final_sweep(&args, s->stored_redshift, mask, direct ? c->n_ion : c->stars_fil,
-                           c->density, c->prev_zre, c->xH, c->zre, c->Tk, c->partials,
-                           c->scalars + SC_SUMS, c->scalars + SC_XHSUM,
-                           (int *)(c->scalars + SC_FLAG), direct, c->xe_dense, c->Tneutral,
-                           c->stream));
+    TRY(c21hip_final_sweep_range(&args, s->stored_redshift, mask, direct ? c->n_ion : c->stars_fil,
+                                 c->density, c->prev_zre, c->xH, c->zre, c->Tk, c->partials,
+                                 (int *)(c->scalars + SC_FLAG), direct, c->xe_dense, c->Tneutral,
+                                 chunk_begin, chunk_end, c->stream));
+done:
+    return status;
+}
+
+static int final_step_sums(ion_ctx *c) {
+    int status = 0;
+    const c21cm_ionize_spec *s = c->s;
+    c21hip_ionize_args args;
+    fill_args(&args, s, 0);
+    TRY(c21hip_final_sweep_reduce(&args, r0_direct(), c->partials, c->scalars + SC_SUMS,
+                                  c->scalars + SC_XHSUM, c->stream));
     TRY(c21hip_finish_mean(c->scalars + SC_SUMS, (double)c->ntot, s->mass_dep_zeta,
                            s->f_limit_acg, c->scalars + SC_MEANS, c->stream));
     c->finalised = 1;
+done:
+    return status;
+}
+
+static int final_step(ion_ctx *c, const unsigned char *mask, int stars_ready) {
+    int status = 0;
+    TRY(final_step_range(c, mask, stars_ready, 0, -1));
+    TRY(final_step_sums(c));
 done:
     return status;
 }
@@ -1808,8 +1832,14 @@ static int postloop(ion_ctx *c, IonizedBox *box, c21cm_ionize_report *report) {
     if (c->recomb && !c->inhomo) /* the global Gamma_12 of the homogeneous model, :1600-1609 */
         TRY(c21hip_sum_float(c->G12, c->ntot, c->partials, c->scalars + SC_G12SUM, c->stream));
     TRY(c21hip_d2h(host_sc, c->scalars + SC_SUMS, sizeof(host_sc), c->stream));
-    for (int i = 0; i < c->cb.n; i++)
+    for (int i = 0; i < c->cb.n; i++) {
+        if (c->cb_ncell && c->cb.bytes[i] == c->ntot * sizeof(float)) { /* a rank's slab of a per-cell grid */
+            TRY(c21hip_d2h((float *)c->cb.host[i] + c->cb_cell0, (float *)c->cb.dev[i] + c->cb_cell0,
+                           c->cb_ncell * sizeof(float), c->stream));
+            continue;
+        }
         TRY(c21hip_d2h(c->cb.host[i], c->cb.dev[i], c->cb.bytes[i], c->stream));
+    }
     TRY(c21hip_sync(c->stream));
     {
         const double *means = host_sc + (SC_MEANS - SC_SUMS);
@@ -2273,6 +2303,123 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
         report->ms_postloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
     }
 done:
+    for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
+    return status;
+}
+
+/* ---- the finish phase split by cell slabs (round 5) -------------------------------------------
+ * The cell-scale radius and the post-loop are per cell (IonisationBox.c:1031-1256), and every rank holds
+ * the replicated inputs: rank r sweeps the cells of chunks [n r / W, n (r + 1) / W) of the final sweep
+ * -- its slab -- from the combined first crossings of THAT slab alone (so the exchange before it moves
+ * 1 / W of each rank's packed grid per link instead of whole grids onto one rank), leaves the chunks'
+ * partial sums where the single pass leaves them, the ranks all-gather those (2 x n doubles) and every
+ * rank reduces all of them in the single pass' fixed order: sum(x_HI), the f_coll mean of index 0 and
+ * with them global_xH / mean_f_coll are the single pass' to the last bit on every rank, with no scalar
+ * broadcast.  The outputs stay slab-resident unless the exchange callback gathers them.
+ * Supported: the fused Lagrangian loop down to index 0 with the direct cell-scale sweep (no recombination
+ * model, no IONISE_ENTIRE_SPHERE, no mini-halos); everything else finishes on the owner rank. */
+int c21cm_ionize_shard_slab_supported(const c21cm_ionize_spec *s) {
+    if (!s) return 0;
+    const int nz = s->hii_dim_z;
+    return s->fcoll_mode == C21CM_FCOLL_STARS_GRID && s->recomb_model == C21CM_RECOMB_NONE &&
+           !s->use_mini_halos && !s->ionise_entire_sphere && s->r_lowest == 0 && r0_direct() &&
+           c21hip_fft_is_native(s->hii_dim, s->hii_dim, nz) &&
+           (!s->use_ts_fluct || c21hip_z_ionise_xe_supported(s->hii_dim, s->hii_dim, nz));
+}
+
+/* chunks and cells of `rank`'s slab (whole chunks of the final sweep, dealt evenly; cell bounds are
+ * multiples of 512 cells except the box end) */
+int c21cm_ionize_shard_slab(const c21cm_ionize_spec *spec, int rank, int world, int *chunk_begin,
+                            int *chunk_end, size_t *cell_begin, size_t *cell_end, int *n_chunks_out,
+                            size_t *chunk_cells_out) {
+    if (!spec || world < 1 || rank < 0 || rank >= world) return C21CM_VALUE_ERROR;
+    c21hip_ionize_args args;
+    fill_args(&args, spec, 0);
+    int n_chunks = 0;
+    size_t chunk_cells = 0;
+    c21hip_final_sweep_chunks(&args, 1, &n_chunks, &chunk_cells);
+    const size_t ntot = (size_t)spec->hii_dim * spec->hii_dim * spec->hii_dim_z;
+    const int b = (int)((long)n_chunks * rank / world), e = (int)((long)n_chunks * (rank + 1) / world);
+    size_t cb = (size_t)b * chunk_cells, ce = (size_t)e * chunk_cells;
+    if (cb > ntot) cb = ntot;
+    if (ce > ntot || e == n_chunks) ce = ntot;
+    if (chunk_begin) *chunk_begin = b;
+    if (chunk_end) *chunk_end = e;
+    if (cell_begin) *cell_begin = cb;
+    if (cell_end) *cell_end = ce;
+    if (n_chunks_out) *n_chunks_out = n_chunks;
+    if (chunk_cells_out) *chunk_cells_out = chunk_cells;
+    return 0;
+}
+
+int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned char *first_cross,
+                                   int rank, int world, const PerturbedField *perturbed_field,
+                                   const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                   const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                                   c21cm_shard_slab_exchange_fn exchange, void *exchange_user,
+                                   int outputs_gathered, void *stream) {
+    /* `exchange` is entered exactly once whatever happens locally (with the local status), so that a
+     * rank which fails here still joins the agreement its peers wait in */
+    c21cm_shard_slab_state st;
+    memset(&st, 0, sizeof(st));
+    st.rank = rank;
+    st.world = world;
+    ion_ctx c;
+    void *ev[3] = {NULL, NULL, NULL};
+    int entered = 0;
+    int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
+    if (!status && !c21cm_ionize_shard_slab_supported(spec)) {
+        c21hip_set_error("ionize shard: this model does not finish by slabs (c21cm_ionize_shard_slab_supported)");
+        status = C21CM_VALUE_ERROR;
+    }
+    if (!status && (!first_cross || !c21hip_is_device_ptr(first_cross) || world < 1 || rank < 0 ||
+                    rank >= world)) {
+        c21hip_set_error("ionize shard: first_cross must be a device array, 0 <= rank < world");
+        status = C21CM_VALUE_ERROR;
+    }
+    if (status) goto done;
+    TRY(c21cm_ionize_shard_slab(spec, rank, world, &st.chunk_begin, &st.chunk_end, &st.cell_begin,
+                                &st.cell_end, &st.n_chunks, &st.chunk_cells));
+    TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1, stream));
+    if (!c.fused || c.sphere) { /* (slab_supported mirrors ctx_setup; this cannot happen) */
+        c21hip_set_error("ionize shard: the slab finish needs the fused Lagrangian loop");
+        status = C21CM_VALUE_ERROR;
+        goto done;
+    }
+    st.ntot = c.ntot;
+    for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
+    TRY(c21hip_event_record(ev[0], stream));
+    TRY(init_output_grids(&c, previous_ionize_box));
+    g_spectra.valid = 0;
+    g_shard_means.valid = 0;
+    TRY(final_step_range(&c, first_cross, 0, st.chunk_begin, st.chunk_end));
+    st.partials_stars = c.partials;
+    st.partials_xh = c.partials + C21HIP_PARTIALS / 2;
+    st.flag = (int *)(c.scalars + SC_FLAG);
+    st.out[0] = c.xH;
+    st.out[1] = c.zre;
+    st.out[2] = c.Tk;
+    entered = 1;
+    if (exchange) TRY(exchange(exchange_user, &st, 0, stream));
+    TRY(final_step_sums(&c));
+    TRY(c21hip_event_record(ev[1], stream));
+    if (!outputs_gathered) { /* slab-resident outputs: the host copies of staged grids cover the slab */
+        c.cb_cell0 = st.cell_begin;
+        c.cb_ncell = st.cell_end - st.cell_begin;
+        if (!c.cb_ncell) c.cb.n = 0;
+    }
+    TRY(postloop(&c, box, report));
+    TRY(c21hip_event_record(ev[2], stream));
+    if (report) {
+        report->ms_preloop = 0.;
+        report->ms_rloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
+        report->ms_postloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
+    }
+done:
+    if (!entered && exchange) {
+        const int st2 = exchange(exchange_user, &st, status ? status : C21CM_VALUE_ERROR, stream);
+        if (!status) status = st2;
+    }
     for (int i = 0; i < 3; i++) c21hip_event_destroy(ev[i]);
     return status;
 }

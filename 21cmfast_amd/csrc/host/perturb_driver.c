@@ -128,13 +128,14 @@ int c21cm_perturb_grids(const c21cm_perturb_spec *s, const InitialConditions *ic
         double *resampled = (double *)c21hip_ws(WS_PT_RESAMPLED, b_tot * sizeof(double));
         if (!resampled) return C21CM_MEMORY_ALLOC_ERROR;
         TRY(c21hip_memset(resampled, 0, b_tot * sizeof(double), stream));
+        int fixed = 0; /* 1: the deposit left 2^44 fixed-point integers (order-independent sums) */
         TRY(c21hip_cic_scatter(d_dens, hi_dim, vel, vel2, box_dim, resampled, box_dim, s->box_len,
-                               s->box_len_z, s->growth_factor, s->init_growth_factor, lpt2,
+                               s->box_len_z, s->growth_factor, s->init_growth_factor, lpt2, &fixed,
                                stream));
         /* widen (+ normalise when the deposit already happened on the output grid) */
         const double mass_factor = lo_tot / (double)hi_tot;
         TRY(c21hip_widen_normalise(resampled, grid, box_dim[0], box_dim[1], box_dim[2],
-                                   !hires /* normalise_delta_grid */, mass_factor, stream));
+                                   !hires /* normalise_delta_grid */, mass_factor, fixed, stream));
     }
     if (hires) {
         /* ---- assign_to_lowres_grid */

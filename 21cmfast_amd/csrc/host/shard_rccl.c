@@ -104,8 +104,10 @@ static struct {
     const char *(*error_string)(int);
 } R;
 
+/* (ids 256 and up are this file's alone: 253 collided with the Eulerian loop's sparse x_e buffer,
+ * whose reallocation freed the status word a rank out of memory still needs -- ADVICE r4) */
 enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142, WS_SHARD_BITS = 143,
-       WS_SHARD_STATUS = 253 };
+       WS_SHARD_STATUS = 256, WS_SHARD_SLABBITS = 257 };
 
 static int rccl_check(int rc, const char *what);
 
@@ -492,6 +494,162 @@ int c21cm_shard_comm_count(void) {
     return 0;
 }
 
+/* ---- finish phase by cell slabs (round 5; ionize_driver.c: c21cm_ionize_shard_finish_slab) -------------
+ * exchange 1 (before the finish): every rank packs its first-crossing grid to one bit per cell and sends
+ *   peer p the words of p's slab -- all W - 1 messages in one group over the direct links (17 MB per
+ *   link at 1024^3 x 8 where the gather onto one rank moved 134) -- and ORs what it receives into the
+ *   bytes of its own slab;
+ * exchange 2 (inside the finish, after the slab's sweep): all-gather of the chunks' partial sums
+ *   (2 x 8 bytes per chunk, <= 32 KB in all), max-all-reduce of the non-finite flag, and -- only when the
+ *   caller wants whole boxes on every rank -- the all-gather of the output slabs.
+ * C21CM_SHARD_FINISH=owner keeps the finish on one rank (gather of whole packed grids). */
+static int slab_finish_wanted(const c21cm_ionize_spec *spec) {
+    const char *e = getenv("C21CM_SHARD_FINISH");
+    if (e && e[0] == 'o') return 0;
+    if (!R.send || !R.recv || !R.group_start || !R.group_end) return 0;
+    if (R.ready == 2) return 0; /* the emulated transport runs its ranks one after the other */
+    return c21cm_ionize_shard_slab_supported(spec);
+}
+static size_t slab_words(const c21cm_ionize_spec *spec, int r, int world, size_t *word0) {
+    size_t c0 = 0, c1 = 0;
+    (void)c21cm_ionize_shard_slab(spec, r, world, NULL, NULL, &c0, &c1, NULL, NULL);
+    if (word0) *word0 = c0 / 32; /* slab starts are multiples of 512 cells */
+    return (c1 - c0 + 31) / 32;
+}
+typedef struct {
+    int gather_outputs;
+    const c21cm_ionize_spec *spec;
+} slab_exchange_arg;
+static int slab_exchange_rccl(void *user, const c21cm_shard_slab_state *s, int local_status, void *stream) {
+    const slab_exchange_arg *arg = (const slab_exchange_arg *)user;
+    int st = agree_status(local_status, stream);
+    if (st) return st;
+    const int rank = R.rank, world = R.world;
+    if (world < 2) return 0;
+    if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+    for (int p = 0; p < world && !st; p++) {
+        if (p == rank) continue;
+        int pb = 0, pe = 0;
+        (void)c21cm_ionize_shard_slab(arg->spec, p, world, &pb, &pe, NULL, NULL, NULL, NULL);
+        const size_t mine = (size_t)(s->chunk_end - s->chunk_begin) * sizeof(double);
+        const size_t theirs = (size_t)(pe - pb) * sizeof(double);
+        if (mine) {
+            st = rccl_check(R.send(s->partials_stars + s->chunk_begin, mine, RCCL_UINT8, p, R.comm, stream),
+                            "ncclSend(chunk sums)");
+            if (!st)
+                st = rccl_check(R.send(s->partials_xh + s->chunk_begin, mine, RCCL_UINT8, p, R.comm, stream),
+                                "ncclSend(chunk sums)");
+        }
+        if (theirs && !st) {
+            st = rccl_check(R.recv(s->partials_stars + pb, theirs, RCCL_UINT8, p, R.comm, stream),
+                            "ncclRecv(chunk sums)");
+            if (!st)
+                st = rccl_check(R.recv(s->partials_xh + pb, theirs, RCCL_UINT8, p, R.comm, stream),
+                                "ncclRecv(chunk sums)");
+        }
+    }
+    {
+        const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+        if (st || st2) return st ? st : st2;
+    }
+    if ((st = rccl_check(R.all_reduce(s->flag, s->flag, 1, RCCL_INT32, RCCL_MAX, R.comm, stream),
+                         "ncclAllReduce(flag)")))
+        return st;
+    if (!arg->gather_outputs) return 0;
+    if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+    for (int b = 0; b < 3 && !st; b++) {
+        if (!s->out[b]) continue;
+        for (int p = 0; p < world && !st; p++) {
+            if (p == rank) continue;
+            size_t p0 = 0, p1 = 0;
+            (void)c21cm_ionize_shard_slab(arg->spec, p, world, NULL, NULL, &p0, &p1, NULL, NULL);
+            if (s->cell_end > s->cell_begin)
+                st = rccl_check(R.send(s->out[b] + s->cell_begin, (s->cell_end - s->cell_begin) * sizeof(float),
+                                       RCCL_UINT8, p, R.comm, stream), "ncclSend(output slab)");
+            if (p1 > p0 && !st)
+                st = rccl_check(R.recv(s->out[b] + p0, (p1 - p0) * sizeof(float), RCCL_UINT8, p, R.comm, stream),
+                                "ncclRecv(output slab)");
+        }
+    }
+    {
+        const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+        if (st || st2) return st ? st : st2;
+    }
+    return 0;
+}
+/* exchange 1: local half (buffers + pack, before the agreement) and the transfers */
+static int slab_mask_local(const c21cm_ionize_spec *spec, const unsigned char *fc, size_t ntot,
+                           unsigned **send_out, unsigned **recv_out, void *stream) {
+    const int rank = R.rank, world = R.world;
+    const size_t nwords = (ntot + 31) / 32;
+    size_t w0 = 0;
+    const size_t mine = slab_words(spec, rank, world, &w0);
+    unsigned *sendb = (unsigned *)c21hip_ws(WS_SHARD_BITS, sizeof(unsigned) * nwords);
+    unsigned *recvb = (unsigned *)c21hip_ws(WS_SHARD_SLABBITS, sizeof(unsigned) * (mine ? mine : 1) * (size_t)world);
+    if (!sendb || !recvb) return C21CM_MEMORY_ALLOC_ERROR;
+    *send_out = sendb;
+    *recv_out = recvb;
+    int st = c21hip_pack_mask_bits(fc, sendb, ntot, stream);
+    if (!st && mine) /* the own piece joins the received ones */
+        st = c21hip_d2d(recvb + (size_t)rank * mine, sendb + w0, mine * sizeof(unsigned), stream);
+    return st;
+}
+static int slab_mask_exchange(const c21cm_ionize_spec *spec, unsigned char *fc, unsigned *sendb,
+                              unsigned *recvb, void *stream) {
+    const int rank = R.rank, world = R.world;
+    size_t w0 = 0, c0 = 0, c1 = 0;
+    const size_t mine = slab_words(spec, rank, world, &w0);
+    (void)c21cm_ionize_shard_slab(spec, rank, world, NULL, NULL, &c0, &c1, NULL, NULL);
+    int st = 0;
+    if (world > 1) {
+        if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
+        for (int p = 0; p < world && !st; p++) {
+            if (p == rank) continue;
+            size_t pw0 = 0;
+            const size_t theirs = slab_words(spec, p, world, &pw0);
+            if (theirs)
+                st = rccl_check(R.send(sendb + pw0, theirs * sizeof(unsigned), RCCL_UINT8, p, R.comm, stream),
+                                "ncclSend(slab bits)");
+            if (mine && !st)
+                st = rccl_check(R.recv(recvb + (size_t)p * mine, mine * sizeof(unsigned), RCCL_UINT8, p,
+                                       R.comm, stream), "ncclRecv(slab bits)");
+        }
+        const int st2 = rccl_check(R.group_end(), "ncclGroupEnd");
+        if (st || st2) return st ? st : st2;
+    }
+    if (!mine) return 0;
+    return c21hip_or_unpack_mask_bits(recvb, mine, world, fc + c0, c1 - c0, stream);
+}
+int c21cm_shard_pack_mask_bits(const unsigned char *first_cross, unsigned *bits, size_t n, void *stream) {
+    return c21hip_pack_mask_bits(first_cross, bits, n, stream);
+}
+int c21cm_shard_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
+                                    unsigned char *first_cross, size_t n, void *stream) {
+    return c21hip_or_unpack_mask_bits(bits, stride_words, world, first_cross, n, stream);
+}
+/* What a sharded ComputeIonizedBox leaves in the output arrays (the `broadcast` argument of
+ * c21cm_ionize_sharded): 1 = whole boxes on every rank, 0 = nothing beyond what the finish leaves (a
+ * rank's slab / the owner's box), -1 = auto: slab-resident where the finish runs by slabs, the owner's
+ * box broadcast otherwise.  c21cm_shard_set_output() or the environment (C21CM_SHARD_OUTPUT = all |
+ * none | auto; C21CM_SHARD_BCAST = 1 | 0 as before round 5); default auto. */
+static int g_output_mode = -2;
+int c21cm_shard_set_output(int mode) {
+    if (mode < -1 || mode > 1) return C21CM_VALUE_ERROR;
+    g_output_mode = mode;
+    return 0;
+}
+int c21cm_shard_output_mode(void) {
+    if (g_output_mode != -2) return g_output_mode;
+    const char *o = getenv("C21CM_SHARD_OUTPUT"), *b = getenv("C21CM_SHARD_BCAST");
+    if (o && o[0] == 'a' && o[1] == 'l') return 1;
+    if (o && o[0] == 'n') return 0;
+    if (b && b[0] == '1') return 1;
+    if (b && b[0] == '0') return 0;
+    return -1;
+}
+static int g_last_finish_slab;
+int c21cm_shard_last_finish_was_slab(void) { return g_last_finish_slab; }
+
 /* C21CM_SHARD_EXCHANGE=keys keeps the 64-bit key reduce for every recombination model */
 static int shard_rc_exchange(void) {
     const char *e = getenv("C21CM_SHARD_EXCHANGE");
@@ -524,6 +682,37 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
 #define MARK(i) do { if (g_phase_ev[i]) (void)c21hip_event_record(g_phase_ev[i], stream); } while (0)
     MARK(0);
 
+    g_last_finish_slab = 0;
+    if (!recomb && !need_means && slab_finish_wanted(spec)) {
+        /* shard phase -> slab exchange of the packed first crossings -> every rank finishes its slab */
+        unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, ntot);
+        unsigned *sendb = NULL, *recvb = NULL;
+        slab_exchange_arg arg = {broadcast > 0 ? 1 : 0, spec};
+        st = fc ? 0 : C21CM_MEMORY_ALLOC_ERROR;
+        if (!st)
+            st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box,
+                                          spin_temp, halos, fc, NULL, stream);
+        if (!st) st = slab_mask_local(spec, fc, ntot, &sendb, &recvb, stream);
+        if ((st = agree_status(st, stream))) return st;
+        MARK(1);
+        st = slab_mask_exchange(spec, fc, sendb, recvb, stream);
+        MARK(2);
+        /* (a failed exchange is this rank's local status of the finish: its peers learn of it in the
+         * agreement the finish phase enters) */
+        if (st) {
+            c21cm_shard_slab_state none;
+            memset(&none, 0, sizeof(none));
+            const int st2 = slab_exchange_rccl(&arg, &none, st, stream);
+            return st2 ? st2 : st;
+        }
+        st = c21cm_ionize_shard_finish_slab(spec, fc, rank, world, perturbed_field, previous_ionize_box,
+                                            spin_temp, halos, box, report, slab_exchange_rccl, &arg,
+                                            arg.gather_outputs, stream);
+        MARK(3);
+        g_phase_valid = 1;
+        g_last_finish_slab = 1;
+        return st;
+    }
     if (!recomb) {
         unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, ntot);
         unsigned *bits = NULL;
@@ -588,7 +777,7 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
     MARK(3);
     g_phase_valid = 1;
 #undef MARK
-    if (!broadcast) return st;
+    if (!broadcast) return st; /* (-1, auto: these models finish on one rank, whose box is broadcast) */
     /* The owner's finish step may have failed: nobody enters the broadcasts then.  Whatever the
      * broadcasts need locally (the staging buffer of host arrays, the scalar slot) is allocated
      * before this agreement; between it and the last broadcast no rank returns early -- a local

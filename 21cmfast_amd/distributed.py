@@ -79,6 +79,138 @@ def sharded_ionize(spec, density, n_ion, buffers, first_cross, rank: int, world:
     return None
 
 
+def slab_mask_exchange(first_cross, spec, rank: int, world: int, group=None):
+    """Exchange 1 of the slab finish through torch.distributed (what c21cm_ionize_sharded does over RCCL
+    point to point): every rank packs its uint8 first crossings to one bit per cell, sends peer p the
+    words of p's slab and ORs what it receives into the bytes of its own slab (in place)."""
+    import torch
+    from . import grid_api as api
+
+    fc = first_cross.view(-1)
+    on_gpu = fc.is_cuda
+    slabs = [api.shard_slab(spec, p, world) for p in range(world)]
+    if on_gpu:
+        bits = api.shard_pack_mask_bits(fc)
+    else:  # CPU plan test (gloo): the same packing in torch
+        pad = (-fc.numel()) % 32
+        b = torch.nn.functional.pad((fc != 0).to(torch.int64), (0, pad)).view(-1, 32)
+        w = (b << torch.arange(32, dtype=torch.int64)).sum(dim=1)
+        bits = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+    def words(p):
+        return slabs[p]["cell_begin"] // 32, (slabs[p]["cell_end"] + 31) // 32
+
+    import torch.distributed as dist
+
+    lo, hi = words(rank)
+    # (gloo moves CPU tensors: ranks sharing one GPU in the plumbing test stage through the host)
+    xdev = "cpu" if dist.get_backend(group) == "gloo" else fc.device
+    recv = [torch.empty(hi - lo, dtype=torch.int32, device=xdev) for _ in range(world)]
+    send = [bits[slice(*words(p))].contiguous().to(xdev) for p in range(world)]
+    _all_to_all_p2p(recv, send, rank, world, group)
+    mine = fc[slabs[rank]["cell_begin"]:slabs[rank]["cell_end"]]
+    pieces = torch.stack(recv).contiguous().to(fc.device)
+    if on_gpu:
+        api.shard_or_unpack_mask_bits(pieces, mine)
+    else:
+        v = pieces[0].clone()
+        for q in range(1, world):
+            v |= pieces[q]
+        cells = ((v.to(torch.int64).view(-1, 1) >> torch.arange(32, dtype=torch.int64)) & 1).view(-1)
+        mine.copy_(cells[: mine.numel()].to(torch.uint8))
+    return first_cross
+
+
+def slab_sums_exchange(stars, xh, flag, outs, spec, rank: int, world: int, group=None,
+                       gather_outputs: bool = False):
+    """Exchange 2 of the slab finish: all-gather of the chunk partial sums (`stars`, `xh`: float64
+    [n_chunks], this rank's chunk range filled), max of the non-finite flag, and -- only with
+    ``gather_outputs`` -- the all-gather of the output slabs (`outs`: flat float32 grids), all in
+    place."""
+    import torch
+    import torch.distributed as dist
+    from . import grid_api as api
+
+    slabs = [api.shard_slab(spec, p, world) for p in range(world)]
+    for t in (stars, xh):
+        mine = t[slabs[rank]["chunk_begin"]:slabs[rank]["chunk_end"]].clone()
+        reqs, bufs = [], {}
+        for p in range(world):
+            if p == rank:
+                continue
+            bufs[p] = torch.empty(slabs[p]["chunk_end"] - slabs[p]["chunk_begin"], dtype=t.dtype,
+                                  device=t.device)
+            reqs.append(dist.isend(mine, dst=p, group=group))
+            reqs.append(dist.irecv(bufs[p], src=p, group=group))
+        for q in reqs:
+            q.wait()
+        for p, b in bufs.items():
+            t[slabs[p]["chunk_begin"]:slabs[p]["chunk_end"]] = b
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if gather_outputs:
+        for o in outs:
+            if o is None:
+                continue
+            mine = o[slabs[rank]["cell_begin"]:slabs[rank]["cell_end"]].clone()
+            reqs, bufs = [], {}
+            for p in range(world):
+                if p == rank:
+                    continue
+                bufs[p] = torch.empty(slabs[p]["cell_end"] - slabs[p]["cell_begin"], dtype=o.dtype,
+                                      device=o.device)
+                reqs.append(dist.isend(mine, dst=p, group=group))
+                reqs.append(dist.irecv(bufs[p], src=p, group=group))
+            for q in reqs:
+                q.wait()
+            for p, b in bufs.items():
+                o[slabs[p]["cell_begin"]:slabs[p]["cell_end"]] = b
+
+
+def sharded_ionize_slabs(spec, density, n_ion, buffers, first_cross, rank: int, world: int, group=None,
+                         gather_outputs: bool = False, **kw):
+    """One sharded ComputeIonizedBox pass with the finish phase by cell slabs and both exchanges through
+    torch.distributed (the C phases are the ones c21cm_ionize_sharded runs).  Every rank returns the
+    report -- the scalars are complete everywhere; the outputs are the rank's slab unless
+    ``gather_outputs``."""
+    from . import grid_api as api
+
+    api.ionize_shard_radii(spec, rank, world, first_cross, density, n_ion, want_report=False, **kw)
+    slab_mask_exchange(first_cross, spec, rank, world, group)
+
+    def exchange(st, local_status):
+        import torch
+        import torch.distributed as dist
+
+        gloo = dist.get_backend(group) == "gloo"
+        bad = torch.tensor([1 if local_status else 0], dtype=torch.int32,
+                           device="cpu" if gloo else first_cross.device)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if int(bad.item()):
+            return local_status or 3
+        stars = api.device_view(st.partials_stars, st.n_chunks, "f8")
+        xh = api.device_view(st.partials_xh, st.n_chunks, "f8")
+        flag = api.device_view(st.flag, 1, "i4")
+        outs = [api.device_view(st.out[i], st.ntot, "f4") if st.out[i] else None for i in range(3)]
+        if gloo:  # host-staged: gloo moves CPU tensors
+            hs, hx, hf = stars.cpu(), xh.cpu(), flag.cpu()
+            ho = [o.cpu() if (o is not None and gather_outputs) else None for o in outs]
+            slab_sums_exchange(hs, hx, hf, ho, spec, rank, world, group, gather_outputs)
+            stars.copy_(hs), xh.copy_(hx), flag.copy_(hf)
+            for o, h in zip(outs, ho):
+                if h is not None:
+                    o.copy_(h)
+        else:
+            slab_sums_exchange(stars, xh, flag, outs, spec, rank, world, group, gather_outputs)
+        return 0
+
+    _, _, rep = api.ionize_shard_finish_slab(spec, first_cross, rank, world, density, n_ion,
+                                             buffers=buffers, exchange=exchange,
+                                             outputs_gathered=gather_outputs, **kw)
+    return rep
+
+
 def sharded_ionize_c(spec, density, n_ion, buffers, rank: int, world: int, **kw):
     """One sharded pass through c21cm_ionize_sharded; returns the report on the owner, else None."""
     from . import grid_api as api

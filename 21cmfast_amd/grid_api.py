@@ -237,6 +237,115 @@ def ionize_shard_finish(spec, first_cross, density, n_ion=None, xe=None, Tneutra
     return buffers, box, rep
 
 
+class ShardSlabState(C.Structure):
+    """c21cm_shard_slab_state (include/c21cm_grid.h): what the exchange callback of the slab finish sees."""
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("n_chunks", C.c_int), ("chunk_begin", C.c_int),
+                ("chunk_end", C.c_int), ("chunk_cells", C.c_size_t), ("cell_begin", C.c_size_t),
+                ("cell_end", C.c_size_t), ("ntot", C.c_size_t), ("partials_stars", C.c_void_p),
+                ("partials_xh", C.c_void_p), ("flag", C.c_void_p), ("out", C.c_void_p * 3)]
+
+
+SLAB_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(ShardSlabState), C.c_int, C.c_void_p)
+
+
+def shard_slab_supported(spec) -> bool:
+    """Does the finish phase of this model run by cell slabs (c21cm_ionize_shard_slab_supported)?"""
+    lib = load()
+    lib.c21cm_ionize_shard_slab_supported.restype = C.c_int
+    return bool(lib.c21cm_ionize_shard_slab_supported(C.byref(spec)))
+
+
+def shard_slab(spec, rank: int, world: int) -> dict:
+    """Chunks and cells of `rank`'s slab of the final sweep (c21cm_ionize_shard_slab)."""
+    lib = load()
+    lib.c21cm_ionize_shard_slab.restype = C.c_int
+    cb, ce, nch = C.c_int(), C.c_int(), C.c_int()
+    c0, c1, cc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(lib.c21cm_ionize_shard_slab(C.byref(spec), C.c_int(rank), C.c_int(world), C.byref(cb),
+                                      C.byref(ce), C.byref(c0), C.byref(c1), C.byref(nch), C.byref(cc)),
+          "c21cm_ionize_shard_slab")
+    return {"chunk_begin": cb.value, "chunk_end": ce.value, "cell_begin": c0.value,
+            "cell_end": c1.value, "n_chunks": nch.value, "chunk_cells": cc.value}
+
+
+class _DevView:
+    """A raw device address as a CUDA array (torch.as_tensor reads __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2}
+
+
+def device_view(ptr: int, n: int, kind: str):
+    """torch view (no copy) of n elements at a device address; kind: 'f8', 'f4', 'i4'."""
+    import torch
+
+    return torch.as_tensor(_DevView(ptr, n, "<" + kind), device="cuda")
+
+
+def ionize_shard_finish_slab(spec, first_cross, rank, world, density, n_ion=None, xe=None,
+                             Tneutral=None, prev_z_reion=None, buffers: IonizeBuffers | None = None,
+                             exchange=None, outputs_gathered=False, stream=None):
+    """Finish phase of `rank` by cell slabs (c21cm_ionize_shard_finish_slab): the final sweep over the
+    rank's chunks from the combined first crossings of that slab, `exchange(state, local_status)`
+    (a Python callable: all-gathers the chunk sums -- and the output slabs if the caller wants whole
+    boxes -- and returns the agreed status), then the fixed-order reduce and the post-loop on every
+    rank.  Returns (buffers, box_struct, report); the outputs are valid on the rank's slab
+    (everywhere with ``outputs_gathered``)."""
+    if buffers is None:
+        buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
+                                minimize_memory=bool(spec.minimize_memory))
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion)
+    box = buffers.struct()
+    rep = S.IonizeReport()
+    lib = load()
+    lib.c21cm_ionize_shard_finish_slab.restype = C.c_int
+    err = []
+
+    def _cb(user, state, local_status, strm):
+        try:
+            return int(exchange(state.contents, local_status) or 0)
+        except Exception as e:  # an exception must not unwind through the C frames
+            err.append(e)
+            return 3
+
+    cb = SLAB_EXCHANGE_FN(_cb) if exchange is not None else C.cast(None, SLAB_EXCHANGE_FN)
+    st = lib.c21cm_ionize_shard_finish_slab(
+        C.byref(spec), C.c_void_p(first_cross.data_ptr()), C.c_int(rank), C.c_int(world), C.byref(pf),
+        C.byref(prev), C.byref(ts), C.byref(hb), C.byref(box), C.byref(rep), cb, None,
+        C.c_int(1 if outputs_gathered else 0), _stream(stream))
+    if err:
+        raise err[0]
+    check(st, "c21cm_ionize_shard_finish_slab")
+    return buffers, box, rep
+
+
+def shard_pack_mask_bits(first_cross, stream=None):
+    """uint8 first crossings -> one bit per cell (uint32 words; c21cm_shard_pack_mask_bits)."""
+    import torch
+
+    n = first_cross.numel()
+    bits = torch.empty((n + 31) // 32, dtype=torch.int32, device=first_cross.device)
+    lib = load()
+    lib.c21cm_shard_pack_mask_bits.restype = C.c_int
+    check(lib.c21cm_shard_pack_mask_bits(C.c_void_p(first_cross.data_ptr()), C.c_void_p(bits.data_ptr()),
+                                         C.c_size_t(n), _stream(stream)), "c21cm_shard_pack_mask_bits")
+    return bits
+
+
+def shard_or_unpack_mask_bits(pieces, first_cross_slab, stream=None):
+    """OR of the packed pieces (2-D int32 [world][words]) into the uint8 cells of a slab
+    (c21cm_shard_or_unpack_mask_bits)."""
+    lib = load()
+    lib.c21cm_shard_or_unpack_mask_bits.restype = C.c_int
+    world, words = pieces.shape
+    check(lib.c21cm_shard_or_unpack_mask_bits(C.c_void_p(pieces.data_ptr()), C.c_size_t(words),
+                                              C.c_int(world), C.c_void_p(first_cross_slab.data_ptr()),
+                                              C.c_size_t(first_cross_slab.numel()), _stream(stream)),
+          "c21cm_shard_or_unpack_mask_bits")
+    return first_cross_slab
+
+
 def ionize_shard_radii_keys(spec, rank, world, cross_keys, density, n_ion=None, xe=None,
                             Tneutral=None, prev_z_reion=None, prev_nrec=None, whalo_sfr=None,
                             stream=None):
@@ -376,9 +485,11 @@ def ionize_sharded(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=No
                    prev_z_reion=None, buffers: IonizeBuffers | None = None, stream=None,
                    prev_nrec=None, whalo_sfr=None, broadcast=False):
     """One ComputeIonizedBox pass with the R loop sharded over the ranks of the library's RCCL
-    communicator (c21cm_ionize_sharded): shard phase, ONE ncclReduce, finish on the owner rank
-    -- all inside the C library.  Returns (buffers, box_struct, report); without ``broadcast``
-    only the owner's buffers hold the result."""
+    communicator (c21cm_ionize_sharded), all inside the C library: shard phase, exchange, finish.
+    Where the finish phase runs by cell slabs (``shard_slab_supported``) every rank finishes its slab
+    and holds the complete scalars; otherwise the owner rank finishes.  Returns (buffers, box_struct,
+    report); ``broadcast``: whole boxes on every rank (False: a rank's slab / the owner's box; None:
+    the library's default, c21cm_shard_output_mode)."""
     if buffers is None:
         buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
                                 minimize_memory=bool(spec.minimize_memory),
@@ -391,7 +502,8 @@ def ionize_sharded(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=No
     lib.c21cm_ionize_sharded.restype = C.c_int
     check(lib.c21cm_ionize_sharded(C.byref(spec), C.byref(pf), C.byref(prev), C.byref(ts),
                                    C.byref(hb), C.byref(box), C.byref(rep),
-                                   C.c_int(1 if broadcast else 0), _stream(stream)),
+                                   C.c_int(-1 if broadcast is None else (1 if broadcast else 0)),
+                                   _stream(stream)),
           "c21cm_ionize_sharded")
     return buffers, box, rep
 

@@ -46,7 +46,13 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--hii-dim", type=int, default=512)
     ap.add_argument("--r-bubble-max", type=float, default=40.0)
-    ap.add_argument("--mode", choices=["stars", "erfc"], default="stars")
+    ap.add_argument("--mode", choices=["stars", "erfc", "icpf"], default="stars",
+                    help="stars: the headline (ComputeIonizedBox, G = 2); erfc: its G = 1 closed form; "
+                         "icpf: BASELINE config 2 -- InitialConditions + PerturbedField at "
+                         "HII_DIM = --hii-dim / 2 (default 256), DIM = 2 HII_DIM, one GPU")
+    ap.add_argument("--achievable-gbs", type=float, default=6200.0,
+                    help="what a plain float4 copy kernel moves on these boxes (tools/copy_bench.hip, "
+                         "profiles/r05_copy_bench.txt): printed next to the 8 TB/s peak in `roofline`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dim", type=int, default=192,
                     help="box size of the CPU-oracle samples on hosts with < 16 cores (256 otherwise)")
@@ -301,6 +307,92 @@ def pmc_traffic():
     return pmc
 
 
+def run_icpf(args, torch, pkg):
+    """BASELINE config 2: InitialConditions + PerturbedField (HII_DIM = 256, DIM = 512 by default; device
+    arrays, Philox modes -- the reference's own random stream is a host-serial draw), one step = both
+    calls.  Roofline on SURVEY 8(d)'s figures: the IC pipeline is 15 hi-res FFTs + 12 k-sweeps + 7 filter
+    sweeps + 9 gathers = 68 passes over a DIM^3 spectrum (36.7 GB at DIM = 512), the deposit nominally
+    N_h (4 + 8 x 16) B (one read and eight fp64 read-modify-writes per particle)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    api = importlib.import_module("21cmfast_amd.grid_api")
+    from test_oracle_ics import ics_spec
+    from test_oracle_perturb import perturb_spec
+
+    hii = args.hii_dim // 2 if args.hii_dim == 512 else args.hii_dim
+    dim = 2 * hii
+    L = 1.5 * hii
+    spec = ics_spec(dim, hii, box_len=L, seed=12345)
+    pspec = perturb_spec(2, dim=dim, dim_z=dim, hii_dim=hii, hii_dim_z=hii, box_len=L, box_len_z=L,
+                         growth_factor=0.127, init_growth_factor=0.0042, dDdt_over_D=2e-17)
+    state = {"ics": api.ics_grids(spec, device="cuda")}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_ic, t_pf = [], []
+
+    def step(record):
+        ev[0].record()
+        state["ics"] = api.ics_grids(spec, state["ics"], device="cuda")
+        ev[1].record()
+        state["out"] = api.perturb_grids(pspec, state["ics"])
+        ev[2].record()
+        if record:
+            torch.cuda.synchronize()
+            t_ic.append(ev[0].elapsed_time(ev[1]))
+            t_pf.append(ev[1].elapsed_time(ev[2]))
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    ic_ms, pf_ms = sum(t_ic) / len(t_ic), sum(t_pf) / len(t_pf)
+    nk = dim * dim * (dim // 2 + 1)
+    ic_bytes = 68 * 8.0 * nk
+    cic_bytes = float(dim) ** 3 * (4 + 8 * 16)
+    out = {
+        "metric": f"InitialConditions + PerturbField hi-res cells/sec (HII_DIM={hii}, DIM={dim})",
+        "value": float(dim) ** 3 / (ms * 1e-3), "unit": "cells/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: InitialConditions + PerturbedField, HII_DIM={hii}, DIM={dim}, "
+                               "2LPT, device-resident arrays, counter-based (Philox) modes",
+                   "hii_dim": hii, "dim": dim, "ics_ms": ic_ms, "perturb_ms": pf_ms,
+                   "density_std": float(state["out"]["density"].std())},
+        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achievable_GBs": args.achievable_gbs,
+                     "kernel": "the InitialConditions pipeline as a whole (native line passes, k-space "
+                               "operators in pass X; 68 passes of SURVEY 8(d))",
+                     "alg_bytes_per_launch": ic_bytes, "ms_per_launch": ic_ms,
+                     "achieved": ic_bytes / (ic_ms * 1e-3) / 1e9, "frac": ic_bytes / (ic_ms * 1e-3) / 8e12,
+                     "traffic": None,
+                     "perturb_field": {"nominal_cic_bytes": cic_bytes, "ms": pf_ms,
+                                       "note": "SURVEY 8(d)'s nominal N_h (4 + 8 x 16) B: the per-velocity-cell "
+                                               "deposit keeps its read-modify-writes in LDS (PMC summary: "
+                                               "profiles/r04_pmc_cic.json)",
+                                       "nominal_GBs": cic_bytes / (pf_ms * 1e-3) / 1e9}},
+    }
+    if not args.no_cpu_baseline:
+        oracle = importlib.import_module("oracle.oracle")
+        cores = min(os.cpu_count() or 1, 64)
+        oracle.set_threads(cores)
+        chii = hii if cores >= 16 else hii // 2
+        cspec = ics_spec(2 * chii, chii, box_len=1.5 * chii, seed=12345)
+        cps = perturb_spec(2, dim=2 * chii, dim_z=2 * chii, hii_dim=chii, hii_dim_z=chii, box_len=1.5 * chii,
+                           box_len_z=1.5 * chii, growth_factor=0.127, init_growth_factor=0.0042,
+                           dDdt_over_D=2e-17)
+        t0 = time.perf_counter()
+        ref = oracle.ics_grids(cspec)
+        oracle.perturb_grids(cps, ref)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": float(2 * chii) ** 3 / dt, "unit": "cells/s", "cores": cores,
+                               "kind": "port", "seconds": dt,
+                               "sample": f"the CPU oracle's InitialConditions + PerturbedField at HII_DIM={chii}, "
+                                         f"DIM={2 * chii}, {cores} threads"}
+        out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
 def main():
     args = parse_args()
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
@@ -341,6 +433,12 @@ def main():
 
     pkg = importlib.import_module("21cmfast_amd")
     pkg.load(require_gpu=True)
+    if args.mode == "icpf":  # config 2: a single-GPU line of its own
+        out = run_icpf(args, torch, pkg)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.close(real_stdout)
+        return
     W = importlib.import_module("21cmfast_amd.workloads")
     api = importlib.import_module("21cmfast_amd.grid_api")
     D = importlib.import_module("21cmfast_amd.distributed")
@@ -368,16 +466,27 @@ def main():
             _, _, rep = api.ionize_grids(self.spec, self.density, self.n_ion, buffers=self.buffers)
             self.report["rep"] = rep
 
-        def step_sharded(self, shard_c):
-            if rank == self.owner:  # only the finishing rank owns output grids
+        def step_sharded(self, shard_c, gather=False):
+            # finish phase by cell slabs (round 5): every rank finishes the cells of its slab and holds
+            # the complete scalars; the outputs stay slab-resident unless `gather` (all-gather of the
+            # output slabs: whole boxes on every rank)
+            self.slab = api.shard_slab_supported(self.spec) and os.environ.get("C21CM_SHARD_FINISH", "")[:1] != "o"
+            if self.slab or rank == self.owner:
                 self.buffers.reset()
             if shard_c:
-                rep = D.sharded_ionize_c(self.spec, self.density, self.n_ion, self.buffers, rank, world)
+                rep = D.sharded_ionize_c(self.spec, self.density, self.n_ion, self.buffers, rank, world,
+                                         broadcast=gather)
             else:
                 if self.first_cross is None:
                     self.first_cross = torch.zeros((self.n,) * 3, dtype=torch.uint8, device="cuda")
-                rep = D.sharded_ionize(self.spec, self.density, self.n_ion, self.buffers,
-                                       self.first_cross, rank, world)
+                if self.slab:
+                    rep = D.sharded_ionize_slabs(self.spec, self.density, self.n_ion, self.buffers,
+                                                 self.first_cross, rank, world, gather_outputs=gather)
+                    if rank != self.owner:
+                        rep = None
+                else:
+                    rep = D.sharded_ionize(self.spec, self.density, self.n_ion, self.buffers,
+                                           self.first_cross, rank, world)
             if rep is not None:
                 self.report["rep"] = rep
 
@@ -505,6 +614,8 @@ def main():
             k4 = max(1, args.config4_steps)
             ms4 = timed(lambda: wl4.step_sharded(shard_c), k4, 1)
             ph4, cnt4 = shard_phase_report() if shard_c else (None, None)
+            # the same with whole boxes on every rank (all-gather of the three output slabs)
+            ms4_gather = timed(lambda: wl4.step_sharded(shard_c, gather=True), k4, 1) if wl4.slab else None
             gx4 = torch.tensor([wl4.report["rep"].global_xH if wl4.report.get("rep") is not None else 0.0],
                                device="cuda", dtype=torch.float64)
             dist.broadcast(gx4, src=wl4.owner)
@@ -517,6 +628,9 @@ def main():
                 "ms_per_step": ms4, "value": float(n4) ** 3 / (ms4 * 1e-3), "unit": "cells/s",
                 "single_gpu_same_run": {"ms_per_step": ms4_single, "steps": max(1, min(k4, 3))},
                 "speedup": ms4_single / ms4,
+                "finish": "by cell slabs, outputs slab-resident" if wl4.slab else "on the owner rank",
+                **({"ms_per_step_outputs_gathered": ms4_gather,
+                    "speedup_outputs_gathered": ms4_single / ms4_gather} if ms4_gather else {}),
                 "global_xH": gx4.item(), "global_xH_single_gpu": gx4_single,
                 **({"shard_phases_ms_per_rank": ph4, "rccl_comm_count": cnt4} if ph4 is not None else {}),
             }
@@ -634,8 +748,12 @@ def main():
                 "hii_dim": n, "n_radii": spec.n_radii, "filtered_grids": G,
                 "parallelism": "single GPU" if not sharded else
                 f"R-loop sharded x{world} + "
-                + ("1-bit mask gather over RCCL inside the C library (c21cm_ionize_sharded)" if shard_c
-                   else f"{'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce via torch.distributed"),
+                + (("packed first crossings by slab + slab finish on every rank, over RCCL inside the C "
+                    "library (c21cm_ionize_sharded)" if getattr(wl, "slab", False) else
+                    "1-bit mask gather over RCCL inside the C library (c21cm_ionize_sharded)") if shard_c
+                   else (f"slab exchange + slab finish via torch.distributed ({args.backend})"
+                         if getattr(wl, "slab", False) else
+                         f"{'RCCL' if args.backend == 'nccl' else 'gloo'} uint8 max-reduce via torch.distributed")),
                 **({"shard_impl_note": shard_note} if shard_note else {}),
                 **({"shard_phases_ms_per_rank": shard_phases, "shard_phases": "shard phase, exchange "
                     "(incl. waiting for the slowest peer), finish -- device time of the last step",

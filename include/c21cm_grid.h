@@ -219,6 +219,47 @@ int c21cm_ionize_shard_finish(const c21cm_ionize_spec *spec, const unsigned char
                               const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
                               void *stream);
 
+/* The finish phase split by cell slabs (round 5).  The cell-scale radius and the post-loop are per cell
+ * (IonisationBox.c:1031-1256,1597-1608) and every rank holds the replicated inputs, so rank r finishes
+ * the cells of ITS slab only -- whole chunks of the final sweep, c21cm_ionize_shard_slab -- from the
+ * combined first crossings of that slab (first_cross is read on [cell_begin, cell_end) only: the
+ * exchange before it moves 1 / world of each rank's packed grid per link instead of whole grids onto one
+ * rank).  The sweep leaves the chunks' partial sums where the single pass leaves them; `exchange` then
+ * all-gathers them (and, if the caller wants full boxes on every rank, the output slabs), after which
+ * every rank reduces ALL chunks in the single pass' fixed order: global_xH and mean_f_coll are the
+ * single pass' to the last bit on every rank, without a scalar broadcast.
+ *   exchange(user, state, local_status, stream) is entered exactly once per call whatever happened
+ *   locally (local_status != 0: this rank failed before its sweep; `state` may then be incomplete) and
+ *   returns the status the ranks agreed on; NULL on a one-rank run.
+ *   outputs_gathered != 0: the callback gathered the output slabs, host arrays receive whole grids;
+ *   0: the outputs are slab-resident (host arrays receive this rank's slab only). */
+typedef struct c21cm_shard_slab_state {
+    int rank, world;
+    int n_chunks, chunk_begin, chunk_end; /* this rank's chunks of the final sweep */
+    size_t chunk_cells, cell_begin, cell_end, ntot;
+    double *partials_stars, *partials_xh; /* device, n_chunks each; [chunk_begin, chunk_end) filled */
+    int *flag;                            /* device: non-finite flag of this rank's slab (combine: max) */
+    float *out[3]; /* device addresses of neutral_fraction, z_reion, kinetic_temperature (NULL: absent) */
+} c21cm_shard_slab_state;
+typedef int (*c21cm_shard_slab_exchange_fn)(void *user, const c21cm_shard_slab_state *state,
+                                            int local_status, void *stream);
+int c21cm_ionize_shard_slab_supported(const c21cm_ionize_spec *spec);
+int c21cm_ionize_shard_slab(const c21cm_ionize_spec *spec, int rank, int world, int *chunk_begin,
+                            int *chunk_end, size_t *cell_begin, size_t *cell_end, int *n_chunks,
+                            size_t *chunk_cells);
+int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned char *first_cross,
+                                   int rank, int world, const PerturbedField *perturbed_field,
+                                   const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
+                                   const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,
+                                   c21cm_shard_slab_exchange_fn exchange, void *exchange_user,
+                                   int outputs_gathered, void *stream);
+/* device helpers of the slab exchange of the packed first crossings (one bit per cell):
+ * pack the uint8 grid (n cells, n and the grid's start multiples of 32 cells or the box end);
+ * OR `world` packed pieces (`stride_words` apart) into n bytes at `first_cross` */
+int c21cm_shard_pack_mask_bits(const unsigned char *first_cross, unsigned *bits, size_t n, void *stream);
+int c21cm_shard_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, int world,
+                                    unsigned char *first_cross, size_t n, void *stream);
+
 /* The same two phases for a recombination model (spec->recomb_model != none): a first crossing
  * carries the radius (= mean free path) and Gamma_12, so the shard phase leaves 64-bit keys
  * bits(mfp) << 32 | bits(G12) in `cross_keys[N]` (device) -- non-negative floats order like their
@@ -316,6 +357,23 @@ int c21cm_shard_owner(int n_radii, int world);
  * world > 1 run can be executed one after the other in ONE process (non-owners first, the owner
  * last; mailbox zeroed before each round, >= world * N/8 + 8 N bytes).  See shard_rccl.c. */
 int c21cm_shard_emulate(int rank, int world, void *mailbox, size_t mailbox_bytes);
+/* Diagnostic: where the time of this process' last ComputeIonizedBox went -- out[0] host ms before the
+ * device driver (scalars, tables, spec), [1] device pre-loop, [2] R loop, [3] post-loop, [4] wall ms of
+ * the call, [5] number of filter radii. */
+int c21cm_last_ionize_timing(double out[6]);
+
+/* What a sharded call leaves in the output arrays -- `broadcast` of c21cm_ionize_sharded, and what the
+ * drop-in ComputeIonizedBox passes (c21cm_shard_output_mode: c21cm_shard_set_output, else the environment
+ * C21CM_SHARD_OUTPUT = all | none | auto, default auto):
+ *    1  whole boxes on every rank (all-gather of the output slabs, or a broadcast of the owner's box)
+ *    0  what the finish leaves: every rank its slab (c21cm_ionize_shard_slab) where the finish phase runs
+ *       by cell slabs, the owner's box otherwise; scalars (global_xH, mean_f_coll) complete on every rank
+ *       of a slab finish
+ *   -1  auto: slab-resident where the finish runs by slabs, the owner's box broadcast otherwise
+ * c21cm_shard_last_finish_was_slab(): 1 if this process' last c21cm_ionize_sharded finished by slabs. */
+int c21cm_shard_set_output(int mode);
+int c21cm_shard_output_mode(void);
+int c21cm_shard_last_finish_was_slab(void);
 int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,
                          const IonizedBox *previous_ionize_box, const TsBox *spin_temp,
                          const HaloBox *halos, IonizedBox *box, c21cm_ionize_report *report,

@@ -456,6 +456,26 @@ def test_ionized_box_e_integral_without_interpolation_tables(gpu_lib, tmp_path):
     assert ref.max() > 0 and np.ptp(ref) > 0
     # the cell-scale radius applies no window: delta_R is the input up to a transform round trip (1e-7)
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-12)
+    # ... and the ORACLE's restatement of that integral (oracle/ref_nion.py: hmf.c:1106-1140 with the
+    # Gauss-Legendre rule of hmf.c:659-730, sigma(M) from the oracle's own Eisenstein-Hu spectrum by
+    # scipy): nothing of the library under test enters `want` (VERDICT r4 item 7 -- the check above is the
+    # product against its own host function)
+    ref_nion = importlib.import_module("oracle.ref_nion")
+    ref_scalars = importlib.import_module("oracle.ref_scalars")
+    cosmo = ref_scalars.Cosmo()
+    ap = ses.ap
+    osc = dict(fstar_10=ap.F_STAR10, alpha_star=ap.ALPHA_STAR, fesc_10=ap.F_ESC10, alpha_esc=ap.ALPHA_ESC,
+               Mlim_Fstar=ref_nion.mass_limit_bisection(ap.ALPHA_STAR, ap.F_STAR10),  # hmf.c:1268-1311
+               Mlim_Fesc=ref_nion.mass_limit_bisection(ap.ALPHA_ESC, ap.F_ESC10))
+    o_Mmin = ap.M_TURN / 50.0  # minimum_source_mass (hmf.c:1319-1348): M_MIN_in_Mass, mass-dependent model
+    o_MR = cosmo.RtoM(R0)
+    assert o_Mmin == pytest.approx(M_min, rel=1e-6) and o_MR == pytest.approx(M_R, rel=1e-5)
+    cond = ref_nion.ConditionalNion(cosmo, cosmo.dicke(z), o_Mmin, o_MR, osc, ap.M_TURN)
+    want = cond(dens.astype(np.float64))
+    assert want.max() > 0 and np.ptp(want) > 0
+    # (the library's sigma(M) is a spline of its own quadrature: 1e-4 between two sigma(M) evaluations shows
+    #  up as a few 1e-4 in the exponentially sensitive integrand)
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=1e-12)
     # against the table run: 400-bin interpolation of ln N_ion
     ion_a, ion_b = out["neutral_fraction"] == 0, tab["neutral_fraction"] == 0
     assert 0.02 < ion_a.mean() < 0.98

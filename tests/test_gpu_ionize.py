@@ -353,6 +353,164 @@ def test_shard_phases_equal_single_pass(api):
     assert rep.global_xH == rep3.global_xH
 
 
+def _emulated_slab_finish(api, spec, world, density, n_ion, **kw):
+    """The sharded pass with the finish phase by cell slabs, the ranks of `world` run one after the
+    other on the one GPU: every rank's shard phase, exchange 1 (packed first crossings by slab, through
+    the library's pack / OR-unpack kernels), every rank's slab finish with exchange 2 done by copying
+    the chunk sums between the ranks' calls.  Two rounds of finishes: the first collects every rank's
+    chunk sums, the second hands every rank all of them (what the all-gather does).  Returns the box
+    assembled from the ranks' slabs and every rank's report."""
+    import torch
+
+    ntot = density.numel()
+    slabs = [api.shard_slab(spec, r, world) for r in range(world)]
+    assert slabs[0]["cell_begin"] == 0 and slabs[-1]["cell_end"] == ntot
+    for a, b in zip(slabs[:-1], slabs[1:]):
+        assert a["cell_end"] == b["cell_begin"] and a["chunk_end"] == b["chunk_begin"]
+        assert a["cell_end"] % 512 == 0
+    packed = []
+    for rank in range(world):
+        fc = torch.zeros(density.shape, dtype=torch.uint8, device="cuda")
+        api.ionize_shard_radii(spec, rank, world, fc, density, n_ion, want_report=False, **kw)
+        packed.append(api.shard_pack_mask_bits(fc))
+        del fc
+    saved = {}
+    bufs, reps = [None] * world, [None] * world
+    for rnd in range(2):
+        for rank in range(world):
+            sl = slabs[rank]
+            w0, w1 = sl["cell_begin"] // 32, (sl["cell_end"] + 31) // 32
+            # only the slab's cells of first_cross are valid: everything else is poisoned
+            fc = torch.full((ntot,), 7, dtype=torch.uint8, device="cuda")
+            pieces = torch.stack([packed[q][w0:w1] for q in range(world)]).contiguous()
+            if sl["cell_end"] > sl["cell_begin"]:
+                api.shard_or_unpack_mask_bits(pieces, fc[sl["cell_begin"]:sl["cell_end"]])
+
+            def exchange(st, local_status, rank=rank, rnd=rnd):
+                assert local_status == 0 and st.rank == rank and st.world == world
+                assert (st.chunk_begin, st.chunk_end) == (slabs[rank]["chunk_begin"], slabs[rank]["chunk_end"])
+                stars = api.device_view(st.partials_stars, st.n_chunks, "f8")
+                xh = api.device_view(st.partials_xh, st.n_chunks, "f8")
+                if rnd == 0:
+                    saved[rank] = (stars[st.chunk_begin:st.chunk_end].clone(),
+                                   xh[st.chunk_begin:st.chunk_end].clone())
+                    stars.zero_(), xh.zero_()  # nothing of this rank's own may survive by accident
+                else:
+                    stars.fill_(float("nan")), xh.fill_(float("nan"))
+                    for q in range(world):
+                        stars[slabs[q]["chunk_begin"]:slabs[q]["chunk_end"]] = saved[q][0]
+                        xh[slabs[q]["chunk_begin"]:slabs[q]["chunk_end"]] = saved[q][1]
+                return 0
+
+            buf = api.IonizeBuffers(density, minimize_memory=bool(spec.minimize_memory))
+            buf.z_reion[...] = 123.0  # the sweep writes its slab only
+            bufs[rank], _, reps[rank] = api.ionize_shard_finish_slab(
+                spec, fc, rank, world, density, n_ion, buffers=buf, exchange=exchange, **kw)
+            torch.cuda.synchronize()
+            sl0, sl1 = sl["cell_begin"], sl["cell_end"]
+            z = buf.z_reion.view(-1)
+            assert bool((z[:sl0] == 123.0).all()) and bool((z[sl1:] == 123.0).all())
+    box = {}
+    for name in ("neutral_fraction", "z_reion", "kinetic_temperature"):
+        if getattr(bufs[0], name) is None:
+            continue
+        box[name] = torch.cat([getattr(bufs[r], name).view(-1)[slabs[r]["cell_begin"]:slabs[r]["cell_end"]]
+                               for r in range(world)])
+    return box, reps
+
+
+@pytest.mark.parametrize("n,world", [(64, 2), (64, 3), (64, 8), (128, 8), (64, 5)])
+def test_slab_finish_equals_single_pass(api, n, world):
+    """Round 5: the finish phase split by cell slabs (every rank sweeps the chunks of its slab from the
+    combined first crossings of that slab; the chunk sums are all-gathered and reduced in the single
+    pass' order on every rank) is BIT-identical to the single pass -- x_HI, z_reion, T_k, and global_xH
+    / mean_f_coll on every rank (reference: IonisationBox.c:1031-1256 is per cell, :1531-1588 order
+    independent)."""
+    import torch
+
+    spec = W.ionize_spec(n, r_bubble_max=20.0)
+    assert api.shard_slab_supported(spec)
+    density = torch.from_numpy(W.density_field_numpy(n, seed=11)).cuda()
+    n_ion = W.nion_from_density(density)
+    buf, box, rep = api.ionize_grids(spec, density, n_ion)
+    got, reps = _emulated_slab_finish(api, spec, world, density, n_ion)
+    assert torch.equal(buf.neutral_fraction.view(-1), got["neutral_fraction"])
+    assert torch.equal(buf.z_reion.view(-1), got["z_reion"])
+    assert torch.equal(buf.kinetic_temperature.view(-1), got["kinetic_temperature"])
+    assert 0.02 < rep.global_xH < 0.98
+    for r in reps:
+        assert r.global_xH == rep.global_xH
+        assert r.mean_f_coll_out == rep.mean_f_coll_out
+        assert list(r.f_coll_grid_mean)[:1] == list(rep.f_coll_grid_mean)[:1]
+
+
+def test_slab_finish_with_xe_grid_and_previous_snapshot(api):
+    """The slab finish of a spin-temperature run that is not the first snapshot: the x_e and T_k inputs
+    and the previous z_reion are read per cell of the slab."""
+    import torch
+
+    n, world = 64, 3
+    z_dim = 256  # the three-grid pass Z serves 256/512/1024-point z-lines
+    spec = W.ionize_spec(n, r_bubble_max=12.0, hii_dim_z=z_dim, use_ts_fluct=1, first_snapshot=0)
+    if not api.shard_slab_supported(spec):
+        pytest.skip("no fused x_e path at this line length")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shape = (n, n, z_dim)
+    density = torch.from_numpy(W.density_field_numpy(shape, seed=4)).cuda()
+    n_ion = W.nion_from_density(density)
+    xe = (0.05 * torch.rand(shape, generator=g)).float().cuda()
+    Tn = (20.0 + 5.0 * torch.rand(shape, generator=g)).float().cuda()
+    prev_z = torch.where(torch.rand(shape, generator=g) < 0.2, torch.tensor(11.5), torch.tensor(-1.0)).float().cuda()
+    kw = dict(xe=xe, Tneutral=Tn, prev_z_reion=prev_z)
+    buf, box, rep = api.ionize_grids(spec, density, n_ion, **kw)
+    got, reps = _emulated_slab_finish(api, spec, world, density, n_ion, **kw)
+    assert torch.equal(buf.neutral_fraction.view(-1), got["neutral_fraction"])
+    assert torch.equal(buf.z_reion.view(-1), got["z_reion"])
+    assert torch.equal(buf.kinetic_temperature.view(-1), got["kinetic_temperature"])
+    assert all(r.global_xH == rep.global_xH for r in reps)
+
+
+def test_c_level_slab_finish_on_one_rank_communicator(api):
+    """c21cm_ionize_sharded on a one-rank RCCL communicator takes the slab path (pack, OR-unpack, slab
+    finish, the agreement) and equals the single pass; C21CM_SHARD_FINISH=owner keeps the owner finish."""
+    import os
+    import torch
+
+    n = 64
+    spec = W.ionize_spec(n, r_bubble_max=20.0)
+    density = torch.from_numpy(W.density_field_numpy(n, seed=11)).cuda()
+    n_ion = W.nion_from_density(density)
+    buf, box, rep = api.ionize_grids(spec, density, n_ion)
+    lib = api.load()
+    api.shard_init_single()
+    try:
+        for bc in (False, True, None):
+            b2, _, r2 = api.ionize_sharded(spec, density, n_ion, broadcast=bc)
+            torch.cuda.synchronize()
+            assert lib.c21cm_shard_last_finish_was_slab() == 1
+            assert torch.equal(buf.neutral_fraction, b2.neutral_fraction)
+            assert torch.equal(buf.z_reion, b2.z_reion)
+            assert torch.equal(buf.kinetic_temperature, b2.kinetic_temperature)
+            assert r2.global_xH == rep.global_xH
+        os.environ["C21CM_SHARD_FINISH"] = "owner"
+        b3, _, r3 = api.ionize_sharded(spec, density, n_ion)
+        torch.cuda.synchronize()
+        assert lib.c21cm_shard_last_finish_was_slab() == 0
+        assert torch.equal(buf.neutral_fraction, b3.neutral_fraction) and r3.global_xH == rep.global_xH
+        # host (numpy) arrays through the slab finish: staged, the slab copied back
+        import numpy as np
+
+        dn, nn = density.cpu().numpy(), n_ion.cpu().numpy()
+        os.environ.pop("C21CM_SHARD_FINISH")
+        b4, _, r4 = api.ionize_sharded(spec, dn, nn)
+        assert lib.c21cm_shard_last_finish_was_slab() == 1
+        np.testing.assert_array_equal(b4.neutral_fraction, buf.neutral_fraction.cpu().numpy())
+        assert r4.global_xH == rep.global_xH
+    finally:
+        os.environ.pop("C21CM_SHARD_FINISH", None)
+        api.shard_finalize()
+
+
 @pytest.mark.parametrize("n,r_max", [(64, 20.0), (128, 17.0), (64, 9.0)])
 def test_two_radii_per_sweep_equal_one(api, n, r_max, monkeypatch):
     """Pass X serves two radii per sweep (each spectrum tile read once, windowed and transformed

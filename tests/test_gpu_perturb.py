@@ -131,6 +131,37 @@ def test_full_size_mass_conservation(api):
     assert abs(out["velocity_z"].double().mean().item()) < 1e-9
 
 
+@pytest.mark.parametrize("n,N,vscale", [(256, 512, 2.0), (512, 1024, 2.0), (128, 256, 40.0), (128, 384, 3.0)])
+def test_deposit_is_deterministic(api, n, N, vscale, monkeypatch):
+    """Round 5: the deposit accumulates 64-bit fixed-point integers (scale 2^44) in LDS and in the grid --
+    integer additions commute, so repeated calls give the SAME BITS whatever order the hardware serves
+    the atomics in (the fp64 atomics of rounds 1-4 flipped last bits between calls; upstream's OpenMP
+    atomics are unordered too, map_mass.c:197-206).  The large-displacement case sends cells through the
+    queued global path as well.  Against the fp64 accumulation the densities agree to a float ulp."""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ics = {}
+    for ax in "xyz":
+        ics[f"lowres_v{ax}"] = vscale * torch.randn((n,) * 3, generator=g, device="cuda")
+        ics[f"lowres_v{ax}_2LPT"] = 0.5 * vscale * torch.randn((n,) * 3, generator=g, device="cuda")
+    d = torch.randn((N,) * 3, generator=g, device="cuda")
+    ics["hires_density"] = (d - d.mean()).contiguous()
+    spec = perturb_spec(2, dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=1.5 * n, box_len_z=1.5 * n,
+                        growth_factor=0.127, init_growth_factor=0.0042, dDdt_over_D=2e-17)
+    first = api.perturb_grids(spec, ics)["density"].clone()
+    for _ in range(4):
+        again = api.perturb_grids(spec, ics)["density"]
+        torch.cuda.synchronize()
+        assert torch.equal(first, again)
+    monkeypatch.setenv("C21CM_CIC_ACC", "double")
+    dbl = api.perturb_grids(spec, ics)["density"]
+    torch.cuda.synchronize()
+    scale = float((1 + first).abs().max())
+    assert float((first - dbl).abs().max()) <= 2.5e-7 * scale
+    assert abs(first.double().mean().item()) < 1e-5
+
+
 @pytest.mark.parametrize("vscale", [1.0, 12.0, 60.0])
 def test_deposit_paths_large_displacements(api, oracle, vscale):
     """The LDS-tiled deposit keeps particles that leave the tile halo (2 output cells) on a

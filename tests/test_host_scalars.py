@@ -282,6 +282,44 @@ def test_conditional_nion_against_scipy(host, pkg):
     assert np.all(np.diff(np.array(tab[:300])) > 0)  # more collapse in denser regions (delta < 0.85)
 
 
+def test_conditional_nion_oracle_restatement(host, pkg):
+    """oracle/ref_nion.py (the per-cell integral of E-INTEGRAL without interpolation tables: hmf.c:1106-1140
+    with the Gauss-Legendre rule of hmf.c:659-730, on the oracle's own sigma(M)) against the library's host
+    integral with the same rule: the two restatements meet at the accuracy of their sigma(M), incl. the
+    one-halo branch above MAX_DELTAC_FRAC of the barrier and the gauleg nodes against numpy's."""
+    import importlib
+
+    _bind_conditional(host)
+    ref_nion = importlib.import_module("oracle.ref_nion")
+    ref_scalars = importlib.import_module("oracle.ref_scalars")
+    x, w = ref_nion.gauleg(-1.0, 1.0)
+    xn, wn = np.polynomial.legendre.leggauss(ref_nion.NGL_INT)
+    assert np.abs(x - xn).max() < 1e-14 and np.abs(w - wn).max() < 1e-11
+    z = 9.0
+    sc = ScalingConsts()
+    assert host.c21_set_scaling_constants(z, C.byref(sc)) == 0
+    osc = dict(fstar_10=sc.fstar_10, alpha_star=sc.alpha_star, fesc_10=sc.fesc_10, alpha_esc=sc.alpha_esc,
+               Mlim_Fstar=ref_nion.mass_limit_bisection(sc.alpha_star, sc.fstar_10),
+               Mlim_Fesc=ref_nion.mass_limit_bisection(sc.alpha_esc, sc.fesc_10))
+    assert osc["Mlim_Fstar"] == pytest.approx(sc.Mlim_Fstar, rel=1e-6)
+    assert osc["Mlim_Fesc"] == pytest.approx(sc.Mlim_Fesc, rel=1e-6)
+    cosmo = ref_scalars.Cosmo()
+    Mmin, Mturn = 10**8.7 / 50, 10**8.7
+    Mcond = cosmo.RtoM(1.2)
+    assert Mcond == pytest.approx(host.c21_RtoM(1.2), rel=1e-5)
+    D = cosmo.dicke(z)
+    assert D == pytest.approx(host.dicke(z), rel=1e-6)
+    cond = ref_nion.ConditionalNion(cosmo, D, Mmin, Mcond, osc, Mturn)
+    deltas = np.array([-0.9, -0.5, 0.0, 0.4, 1.0, 1.5, 1.68, 2.5])
+    want = cond(deltas)
+    s_c = host.c21_sigma_fast(Mcond)
+    got = np.array([host.c21_Nion_ConditionalM(host.dicke(z), math.log(Mmin), math.log(Mcond), math.log(Mcond),
+                                               s_c, float(d), Mturn, C.byref(sc), 1) for d in deltas])
+    assert want[0] > 0 and np.all(np.diff(want[:6]) > 0)
+    assert want[-1] == want[-2] == pytest.approx(got[-1], rel=1e-5)  # one halo of the condition mass
+    np.testing.assert_allclose(got, want, rtol=2e-3)
+
+
 def test_conditional_xray_against_scipy(host, pkg):
     """The X-ray emissivity table of the HaloBox (hmf.c:482-509, interp_tables.c:497-560): the
     per-mass weight s_per_yr * SFR * L_X/SFR(Z) restated here (metallicity relation of

@@ -64,10 +64,15 @@ def run():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert st == 0, lib.c21cm_last_error()
-    return dt, float(xH.mean())
+    tm = (C.c_double * 6)()
+    lib.c21cm_last_ionize_timing(tm)
+    return dt, float(xH.mean()), list(tm)
 
 
 run()
 times = [run() for _ in range(3)]
-print(json.dumps({"hii_dim": n, "source_model": src, "z": z, "use_ts_fluct": use_ts, "hii_filter": hii_filter, "ms": min(t for t, _ in times) * 1e3,
-                  "global_xH": times[0][1]}))
+best = min(times, key=lambda r: r[0])
+print(json.dumps({"hii_dim": n, "source_model": src, "z": z, "use_ts_fluct": use_ts, "hii_filter": hii_filter, "ms": best[0] * 1e3,
+                  "global_xH": times[0][1], "host_ms": round(best[2][0], 3), "device_preloop_ms": round(best[2][1], 3),
+                  "device_rloop_ms": round(best[2][2], 3), "device_postloop_ms": round(best[2][3], 3),
+                  "call_wall_ms": round(best[2][4], 3), "n_radii": int(best[2][5])}))

@@ -47,15 +47,20 @@ I3 = C.c_int * 3
 P3 = C.c_void_p * 3
 lib.c21hip_cic_scatter.restype = C.c_int
 lib.c21hip_cic_scatter.argtypes = [C.c_void_p, I3, P3, P3, I3, C.c_void_p, I3, C.c_double, C.c_double,
-                                   C.c_double, C.c_double, C.c_int, C.c_void_p]
+                                   C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_void_p]
+FIXED = os.environ.get("C21CM_CIC_ACC", "fixed")[:1] != "d"  # 64-bit fixed-point accumulation (round 5)
 
 
 def run(lpt2):
     st = lib.c21hip_cic_scatter(dens.data_ptr(), I3(dim, dim, dim), P3(*[v.data_ptr() for v in vel]),
                                 P3(*[v.data_ptr() for v in vel2]), I3(hii, hii, hii), out.data_ptr(),
                                 I3(hii, hii, hii), box_len, box_len, growth, init_growth, lpt2,
+                                C.byref(run.fixed) if FIXED else None,
                                 torch.cuda.current_stream().cuda_stream)
     assert st == 0, importlib.import_module("21cmfast_amd._lib").last_error()
+
+
+run.fixed = C.c_int(0)
 
 
 def timed(mode, lpt2, reps=5, extra=None):
@@ -65,7 +70,8 @@ def timed(mode, lpt2, reps=5, extra=None):
     out.zero_()
     run(lpt2)
     torch.cuda.synchronize()
-    res = out.clone()
+    # (the cell kernel may have left 2^44 fixed-point integers in the grid)
+    res = out.view(torch.int64).double() / 2.0**44 if run.fixed.value else out.clone()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
