@@ -24,6 +24,7 @@ int c21hip_use_device(int device);   /* per-thread: for helper threads of the ho
 int c21hip_is_device_ptr(const void *p);     /* 1 = MI355X HBM, 0 = host          */
 void *c21hip_ws(int slot, size_t bytes);     /* cached device scratch, NULL = OOM */
 void c21hip_ws_release(void);
+unsigned long c21hip_ws_generation(void); /* counts c21hip_ws_release calls */
 int c21hip_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int c21hip_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int c21hip_d2d(void *dst, const void *src, size_t bytes, void *stream);
@@ -405,6 +406,11 @@ int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, int nx, int
                           double delta_c, double tab_min, double tab_width,
                           const float *table_dev, double *partials, double *sum_out,
                           void *stream);
+/* the same on rows of `zstride` floats: 2 (nz / 2 + 1) (padded) or nz (dense: 16-byte pieces when nz % 4 == 0) */
+int c21hip_fcoll_eulerian_zs(const float *delta_fil, long zstride, float *nion_dense, int nx, int ny, int nz,
+                             int mode, double growthf, double sigma_min, double sigma_max, double delta_c,
+                             double tab_min, double tab_width, const float *table_dev, double *partials,
+                             double *sum_out, void *stream);
 /* Lagrangian source grids: sum(stars) + barrier test + partial ionisation, one sweep.
  * first_cross != NULL switches to shard mode (records the radius index instead of
  * touching xH / z_reion).  reference: IonisationBox.c:821-837,1008-1201 */
@@ -552,8 +558,8 @@ int c21hip_eul_resolve_pending_xe(int r_index, const float *f_pend, const float 
 int c21hip_eul_rewind(unsigned char *first_cross, int r_fail, size_t ntot, void *stream);
 /* the same for the table modes: c21hip_fcoll_eulerian with the barrier decided in the sweep; the dense
  * f_coll grid is not written, *n_partials_out partial sums stay in `partials` for c21hip_eul_band */
-int c21hip_fcoll_eulerian_band(const float *delta_fil, float *f_pend, unsigned char *first_cross, int nx,
-                               int ny, int nz, int mode, double tab_min, double tab_width,
+int c21hip_fcoll_eulerian_band(const float *delta_fil, long zstride, float *f_pend, unsigned char *first_cross,
+                               int nx, int ny, int nz, int mode, double tab_min, double tab_width,
                                const float *table_dev, const double *band_dev, const double *thr_prev_dev,
                                int r_index, int r_prev, double *partials, int *n_partials_out, void *stream);
 int c21hip_eul_resolve_pending(int r_index, const float *f_pend, const double *thr_dev,

@@ -705,8 +705,14 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             if (a.wev_n_tabs > 1) wnodes[per + t] = a.wev_src[1][t];
             if (a.wev_n_tabs > 2) wnodes[2 * per + t] = a.wev_src[2][t];
         }
-        __syncthreads();
     }
+    // The twiddles (and node tables) are in LDS before anybody reads them.  Round 5: this barrier was
+    // missing where neither the evaluated windows nor the 512-point path brought their own -- pass Y and the
+    // forward passes of 1024-point lines read tw / tw_half for the register stage of a workgroup's FIRST
+    // tile, which skips the loop's barrier: a wave that ran ahead of the wave that loads an entry read
+    // stale LDS.  Invisible in isolation (the waves of a workgroup start together), it showed as one wrong
+    // x-plane in about one 1024^3 call in thirty once four processes shared the GPU.
+    __syncthreads();
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
     const int r0 = threadIdx.x / CPAIR, c4 = threadIdx.x % CPAIR;

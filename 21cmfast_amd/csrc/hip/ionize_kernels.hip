@@ -316,6 +316,7 @@ fcoll_eulerian_kernel(const float *__restrict__ delta_fil, float *__restrict__ n
 // and their f_coll in f_pend (a sparse write: NOT a complete grid); r_prev >= 0: the radius whose
 // markers are outstanding, *thr_prev its exact threshold.  The dense f_coll grid is never written and
 // eulerian_mask_kernel not launched: 4 N + 1 N bytes read instead of (4 + 4) N + 6 N per radius.
+template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 fcoll_eulerian_band_kernel(const float *__restrict__ delta_fil, float *__restrict__ f_pend,
                            unsigned char *__restrict__ first_cross, size_t nitems, int nz_items,
@@ -333,24 +334,32 @@ fcoll_eulerian_band_kernel(const float *__restrict__ delta_fil, float *__restric
     constexpr int U = 4;
     for (size_t i0 = (size_t)blockIdx.x * kBlock * U + threadIdx.x; i0 < nitems;
          i0 += (size_t)gridDim.x * kBlock * U) {
-        Pack<2> d[U];
-        uchar2 mk[U];
+        Pack<VEC> d[U];
+        unsigned char mk[U][VEC];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t i = i0 + (size_t)u * kBlock;
             if (i < nitems) {
-                d[u] = Pack<2>::load(delta_fil, cell_index_sh<2>(i, nz_items, zpad_items, sh).padded);
-                mk[u] = reinterpret_cast<const uchar2 *>(first_cross)[i];
+                d[u] = Pack<VEC>::load(delta_fil, cell_index_sh<VEC>(i, nz_items, zpad_items, sh).padded);
+                if constexpr (VEC == 4) {
+                    const uchar4 m4 = reinterpret_cast<const uchar4 *>(first_cross)[i];
+                    mk[u][0] = m4.x, mk[u][1] = m4.y, mk[u][2 % VEC] = m4.z, mk[u][3 % VEC] = m4.w;
+                } else {
+                    const uchar2 m2 = reinterpret_cast<const uchar2 *>(first_cross)[i];
+                    mk[u][0] = m2.x, mk[u][1] = m2.y;
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t i = i0 + (size_t)u * kBlock;
             if (i >= nitems) continue;
-            unsigned char mv[2] = {mk[u].x, mk[u].y};
+            unsigned char mv[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) mv[e] = mk[u][e];
             bool ch = false;
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
+            for (int e = 0; e < VEC; e++) {
                 const float dens = clip_delta_eulerian(d[u].v[e]);
                 double f;
                 if (fp.mode == C21CM_FCOLL_TABLE_LINEAR)
@@ -360,17 +369,22 @@ fcoll_eulerian_band_kernel(const float *__restrict__ delta_fil, float *__restric
                 acc += f;
                 const float g = (float)f;  // what the dense grid would hold
                 if (mv[e] == 255) {        // the previous radius' undecided cell
-                    mv[e] = (f_pend[2 * i + e] >= t_prev) ? (unsigned char)r_prev : (unsigned char)0;
+                    mv[e] = (f_pend[VEC * i + e] >= t_prev) ? (unsigned char)r_prev : (unsigned char)0;
                     ch = true;
                 }
                 if (mv[e] == 0 && g >= t_maybe) {
                     const bool sure = g >= t_sure;
                     mv[e] = sure ? (unsigned char)r_index : (unsigned char)255;
-                    if (!sure) f_pend[2 * i + e] = g;
+                    if (!sure) f_pend[VEC * i + e] = g;
                     ch = true;
                 }
             }
-            if (ch) reinterpret_cast<uchar2 *>(first_cross)[i] = make_uchar2(mv[0], mv[1]);
+            if (ch) {
+                if constexpr (VEC == 4)
+                    reinterpret_cast<uchar4 *>(first_cross)[i] = make_uchar4(mv[0], mv[1], mv[2 % VEC], mv[3 % VEC]);
+                else
+                    reinterpret_cast<uchar2 *>(first_cross)[i] = make_uchar2(mv[0], mv[1]);
+            }
         }
     }
     block_sum_to(acc, partials);
@@ -1400,11 +1414,28 @@ extern "C" int c21hip_clip_minmax(float *delta_fil, int nx, int ny, int nz, doub
     return 0;
 }
 
+// zstride: row length of delta_fil in floats -- 2 (nz / 2 + 1) (padded rows, the transforms' layout) or nz
+// (dense rows: with nz a multiple of 4 the sweep then moves 16-byte pieces; the table loop writes its
+// delta_R that way, round 5).  c21hip_fcoll_eulerian: padded rows.
+extern "C" int c21hip_fcoll_eulerian_zs(const float *delta_fil, long zstride, float *nion_dense, int nx, int ny,
+                                        int nz, int mode, double growthf, double sigma_min,
+                                        double sigma_max, double delta_c, double tab_min,
+                                        double tab_width, const float *table_dev, double *partials,
+                                        double *sum_out, void *stream);
 extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, int nx, int ny,
                                      int nz, int mode, double growthf, double sigma_min,
                                      double sigma_max, double delta_c, double tab_min,
                                      double tab_width, const float *table_dev, double *partials,
                                      double *sum_out, void *stream) {
+    return c21hip_fcoll_eulerian_zs(delta_fil, 2 * (long)(nz / 2 + 1), nion_dense, nx, ny, nz, mode, growthf,
+                                    sigma_min, sigma_max, delta_c, tab_min, tab_width, table_dev, partials,
+                                    sum_out, stream);
+}
+extern "C" int c21hip_fcoll_eulerian_zs(const float *delta_fil, long zstride, float *nion_dense, int nx, int ny,
+                                        int nz, int mode, double growthf, double sigma_min,
+                                        double sigma_max, double delta_c, double tab_min,
+                                        double tab_width, const float *table_dev, double *partials,
+                                        double *sum_out, void *stream) {
     FcollParams fp;
     fp.mode = mode;
     fp.growthf = (float)growthf;
@@ -1425,8 +1456,13 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
             fp.sig = sqrt((double)d);
         }
     }
-    const int vec = (nz % 2 == 0) ? 2 : 1;
-    const int zpad = 2 * (nz / 2 + 1);
+    const bool dense4 = (zstride == (long)nz && nz % 4 == 0 && mode != C21CM_FCOLL_NODES);
+    if (zstride != (long)nz && zstride != 2 * (long)(nz / 2 + 1)) {
+        c21hip_set_error("f_coll sweep: rows of %ld floats for nz = %d", zstride, nz);
+        return C21CM_VALUE_ERROR;
+    }
+    const int vec = dense4 ? 4 : ((nz % 2 == 0) ? 2 : 1);
+    const int zpad = (int)zstride;
     const size_t nitems = (size_t)nx * ny * (nz / vec);
     if (mode == C21CM_FCOLL_NODES) {  // table_dev: C21CM_NODE_DOUBLES doubles of the radius
         const int nb = grid_for(nitems);
@@ -1444,7 +1480,11 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
         return 0;
     }
     const int blocks = grid_for((nitems + 3) / 4);
-    if (vec == 2)
+    if (vec == 4)
+        hipLaunchKernelGGL(fcoll_eulerian_kernel<4>, dim3(blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, delta_fil, nion_dense, nitems, nz / 4, zpad / 4, fp,
+                           table_dev, partials);
+    else if (vec == 2)
         hipLaunchKernelGGL(fcoll_eulerian_kernel<2>, dim3(blocks), dim3(kBlock), 0,
                            (hipStream_t)stream, delta_fil, nion_dense, nitems, nz / 2, zpad / 2, fp,
                            table_dev, partials);
@@ -1461,12 +1501,13 @@ extern "C" int c21hip_fcoll_eulerian(const float *delta_fil, float *nion_dense, 
 
 // Table modes with the banded barrier (fcoll_eulerian_band_kernel): *n_partials_out partial sums are left
 // in `partials` for c21hip_eul_band (the order of c21hip_fcoll_eulerian's own reduction).
-extern "C" int c21hip_fcoll_eulerian_band(const float *delta_fil, float *f_pend, unsigned char *first_cross,
+extern "C" int c21hip_fcoll_eulerian_band(const float *delta_fil, long zstride, float *f_pend,
+                                          unsigned char *first_cross,
                                           int nx, int ny, int nz, int mode, double tab_min,
                                           double tab_width, const float *table_dev, const double *band_dev,
                                           const double *thr_prev_dev, int r_index, int r_prev,
                                           double *partials, int *n_partials_out, void *stream) {
-    if (nz % 2 || (mode != C21CM_FCOLL_TABLE_LINEAR && mode != C21CM_FCOLL_TABLE_EXP) || r_index <= 0 ||
+    if ((zstride != (long)nz && zstride != 2 * (long)(nz / 2 + 1)) || nz % 2 || (mode != C21CM_FCOLL_TABLE_LINEAR && mode != C21CM_FCOLL_TABLE_EXP) || r_index <= 0 ||
         r_index >= 255 || r_prev >= 255) {
         c21hip_set_error("banded barrier of a table mode: unsupported box, mode or radius index");
         return C21CM_VALUE_ERROR;
@@ -1478,12 +1519,21 @@ extern "C" int c21hip_fcoll_eulerian_band(const float *delta_fil, float *f_pend,
     fp.tab_min = tab_min;
     fp.tab_width = tab_width;
     fp.sig = -1.;
-    const int zpad = 2 * (nz / 2 + 1);
-    const size_t nitems = (size_t)nx * ny * (nz / 2);
+    // (the same items-to-threads map as c21hip_fcoll_eulerian_zs on the same rows: the partial sums of the
+    //  banded and the dense sweep of a radius add up in the same order)
+    const bool dense4 = (zstride == (long)nz && nz % 4 == 0);
+    const int vec = dense4 ? 4 : 2;
+    const int zpad = (int)zstride;
+    const size_t nitems = (size_t)nx * ny * (nz / vec);
     const int blocks = grid_for((nitems + 3) / 4);
-    hipLaunchKernelGGL(fcoll_eulerian_band_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
-                       delta_fil, f_pend, first_cross, nitems, nz / 2, zpad / 2, fp, table_dev, band_dev,
-                       thr_prev_dev, r_index, r_prev, partials);
+    if (dense4)
+        hipLaunchKernelGGL(fcoll_eulerian_band_kernel<4>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           delta_fil, f_pend, first_cross, nitems, nz / 4, zpad / 4, fp, table_dev, band_dev,
+                           thr_prev_dev, r_index, r_prev, partials);
+    else
+        hipLaunchKernelGGL(fcoll_eulerian_band_kernel<2>, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                           delta_fil, f_pend, first_cross, nitems, nz / 2, zpad / 2, fp, table_dev, band_dev,
+                           thr_prev_dev, r_index, r_prev, partials);
     LAUNCH_CHECK();
     *n_partials_out = blocks;
     return 0;

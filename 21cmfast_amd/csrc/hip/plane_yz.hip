@@ -47,6 +47,21 @@
 #include "c21cm_abi.h"
 #include "c21cm_grid.h"
 
+// EXPERIMENTAL (round 5): the two kernels of this file are bit-identical to the separate passes and were
+// measured at parity or slower in rounds 4 and 5 (DESIGN.md, appendix of dead ends), so the default
+// library does not carry them: build with EXTRA=-DC21CM_EXPERIMENTAL (tools/build_variant.sh) to get
+// C21CM_YZ=1|2 back.  Without it c21hip_plane_yz_supported() is 0 and the driver never comes here.
+#ifndef C21CM_EXPERIMENTAL
+extern "C" int c21hip_plane_yz_supported(int, int, int) { return 0; }
+extern "C" int c21hip_plane_yz_ionise(const float *, const float *, unsigned char *, double *, int, int, int, int,
+                                      double, double, int, double, int, void *) {
+    c21hip_set_error("plane-fused pass Y + Z: not in this build (EXTRA=-DC21CM_EXPERIMENTAL)");
+    return C21CM_VALUE_ERROR;
+}
+extern "C" int c21hip_plane_yz_status(void *) { return 0; }
+extern "C" int c21hip_plane_yz_profile(unsigned long long *) { return -1; }
+#else
+
 namespace {
 #include "fft_device.h"
 
@@ -842,7 +857,8 @@ struct YzState {
     float2 *ring = nullptr;
     YzSync *sync = nullptr, *status = nullptr;
     int attr_done = 0, attr2_done = 0;
-    int usable = -1;
+    int usable = -1, resident = -1;
+    unsigned long gen = 0;
 } g_yz;
 }  // namespace
 
@@ -885,7 +901,11 @@ extern "C" int c21hip_plane_yz_ionise(const float *delta_work, const float *star
         g_yz.ring = (float2 *)c21hip_ws(250, 8 * 2 * PLANE * sizeof(float2));
         YzSync *sy = (YzSync *)c21hip_ws(251, 2 * sizeof(YzSync) + 8192);
         if (!g_yz.ring || !sy) return C21CM_MEMORY_ALLOC_ERROR;
-        if (sy != g_yz.sync) {  // new allocation: the sticky status starts clean
+        // (a released and re-allocated slot can come back at the same address: the release generation of
+        //  the workspace decides, not the pointer -- ADVICE r4)
+        const unsigned long gen = c21hip_ws_generation();
+        if (sy != g_yz.sync || gen != g_yz.gen) {  // new allocation: the sticky status starts clean
+            g_yz.gen = gen;
             g_yz.sync = sy;
             g_yz.status = (YzSync *)((char *)sy + sizeof(YzSync) + 4096);
             if (hipMemsetAsync(g_yz.status, 0, sizeof(YzSync), stream) != hipSuccess) return C21CM_IO_ERROR;
@@ -894,6 +914,20 @@ extern "C" int c21hip_plane_yz_ionise(const float *delta_work, const float *star
     const float2 *tw = (const float2 *)c21hip_twiddles_dev(N);
     const float2 *twH = (const float2 *)c21hip_twiddles_dev(H);
     if (!tw || !twH) return C21CM_MEMORY_ALLOC_ERROR;
+    if (g_yz.resident < 0) {
+        // the plane protocol needs all 256 workgroups resident at once: one per CU must fit (a CU
+        // mask or a shared device can still defeat it, which the bounded spins report as a timeout)
+        int nb = 0;
+        const size_t l1 = sizeof(float2) * ((size_t)N * TZ + N + 2 * H + 32 * LINE_LDS) + sizeof(Roles) +
+                          2 * 4 * 64 * sizeof(double);
+        (void)hipFuncSetAttribute((const void *)plane_yz2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+        g_yz.resident = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, plane_yz2_kernel, WG2, l1) == hipSuccess &&
+                         nb >= 1) ? 1 : 0;
+    }
+    if (!g_yz.resident) {
+        c21hip_set_error("plane-fused pass Y + Z: a workgroup does not fit a CU on this device");
+        return C21CM_VALUE_ERROR;
+    }
     YzArgs a{};
     const long nlines = (long)nx * ny;
     a.main[0] = reinterpret_cast<const float2 *>(delta_work);
@@ -983,3 +1017,4 @@ extern "C" int c21hip_plane_yz_profile(unsigned long long *out2048) {
     return -1;
 #endif
 }
+#endif  // C21CM_EXPERIMENTAL

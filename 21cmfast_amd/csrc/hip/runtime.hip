@@ -110,8 +110,13 @@ extern "C" void *c21hip_ws(int slot, size_t bytes) {
     return p;
 }
 
+static unsigned long g_ws_generation = 0;
+// incremented by every release of the workspace: owners of sticky state inside a slot compare it
+extern "C" unsigned long c21hip_ws_generation(void) { return g_ws_generation; }
+
 extern "C" void c21hip_ws_release(void) {
     std::lock_guard<std::mutex> lock(g_mutex);
+    g_ws_generation++;
     for (auto &s : g_slots) {
         if (s.ptr) (void)hipFree(s.ptr);
         s.ptr = nullptr;

@@ -795,7 +795,9 @@ int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_reds
      * (device pointers), so the ranks agree on it before any of them takes the path. */
     int srank = 0, sworld = 1;
     const char *e = getenv("C21CM_SHARD_TS");
-    if (c21cm_shard_info(&srank, &sworld) == 0 && sworld > 1 && c21cm_shard_is_rccl() &&
+    /* (C21CM_SHARD_TS=force: also on a one-rank communicator -- the plumbing test of a 1-GPU box, as
+     * C21CM_SHARD=force for ComputeIonizedBox) */
+    if (c21cm_shard_info(&srank, &sworld) == 0 && (sworld > 1 || (e && e[0] == 'f')) && c21cm_shard_is_rccl() &&
         !(e && e[0] == '0') &&
         c21cm_shard_all_agree(
             c21cm_ts_shardable(redshift, perturbed_field, previous_spin_temp, this_spin_temp)))

@@ -1545,6 +1545,15 @@ static int eul_xe_fused(const ion_ctx *c) {
            c21hip_z_xe_mask_supported(c->nx, c->ny, c->nz);
 }
 
+/* Row length of the table loop's delta_R grids: dense rows (nz floats) where only the f_coll sweeps read
+ * them -- they then move 16-byte pieces (round 5: 269 -> ... us per 512^3 sweep) -- padded rows with an x_e
+ * grid, whose pass Z reads delta_R next to its own lines */
+static long eul_dfil_stride(const ion_ctx *c) {
+    const char *e = getenv("C21CM_EUL_DENSE_ROWS");
+    if (!c->s->use_ts_fluct && c->nz % 4 == 0 && !(e && e[0] == '0')) return c->nz;
+    return 2 * (long)(c->nz / 2 + 1);
+}
+
 static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *mm_host, void *ev) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -1560,7 +1569,7 @@ static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *
         TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
                                    s->box_len_z, s->hii_filter, (float)s->R[R_ct], 0.f, 1, c->stream));
     }
-    TRY(c21hip_split_z_c2r_minmax(c->delta_work, delta_fil, 2 * (c->nz / 2 + 1), c->nx, c->ny,
+    TRY(c21hip_split_z_c2r_minmax(c->delta_work, delta_fil, eul_dfil_stride(c), c->nx, c->ny,
                                   c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf,
                                   c->stream));
     TRY(c21hip_d2h(mm_host, c->scalars + SC_MINMAX + 2 * buf, 2 * sizeof(double), c->stream));
@@ -1668,7 +1677,7 @@ restart:
             const float *xw = b ? c->xe_work2 : c->xe_work;
             if (banded) {
                 TRY(c21hip_split_z_xe_fcoll_band(
-                    xw, dfil[b], 2 * (long)(c->nz / 2 + 1), c->nion_dense, c->band_xe_pend,
+                    xw, dfil[b], eul_dfil_stride(c), c->nion_dense, c->band_xe_pend,
                     c->scalars + SC_BAND + 2 * R_ct,
                     c->scalars + SC_BANDX + (c->band_pend >= 0 ? c->band_pend : 0), mask, R_ct, c->band_pend,
                     s->fcoll_mode, min_density, (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
@@ -1681,7 +1690,7 @@ restart:
                                    (int)((long)c->nx * c->ny / 16), sum_dev));
             } else {
                 TRY(eul_band_flush(c)); /* the dense sweep overwrites the marked cells' f_coll */
-                TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
+                TRY(c21hip_fcoll_eulerian_zs(dfil[b], eul_dfil_stride(c), c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
                                           s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
                                           s->delta_c, min_density,
                                           (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
@@ -1700,7 +1709,7 @@ restart:
             const int banded = eul_band_this(c, R_ct, mask, 1);
             int n_part = 0;
             if (banded) {
-                TRY(c21hip_fcoll_eulerian_band(dfil[b], c->nion_dense, mask, c->nx, c->ny, c->nz,
+                TRY(c21hip_fcoll_eulerian_band(dfil[b], eul_dfil_stride(c), c->nion_dense, mask, c->nx, c->ny, c->nz,
                                                s->fcoll_mode, min_density,
                                                (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
                                                table_dev, c->scalars + SC_BAND + 2 * R_ct,
@@ -1712,7 +1721,7 @@ restart:
                 TRY(eul_band_after(c, R_ct, i + 1 < n ? radii[i + 1] : -1, 1, 1, c->partials, n_part, sum_dev));
             } else {
                 TRY(eul_band_flush(c)); /* the dense sweep overwrites the marked cells' f_coll */
-                TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
+                TRY(c21hip_fcoll_eulerian_zs(dfil[b], eul_dfil_stride(c), c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
                                           s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
                                           s->delta_c, min_density,
                                           (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
@@ -1723,7 +1732,7 @@ restart:
             TRY(c21hip_d2h((void *)(fail_host + 2 * b), c->scalars + SC_BANDFAIL, sizeof(int), c->stream));
             continue;
         }
-        TRY(c21hip_fcoll_eulerian(dfil[b], c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
+        TRY(c21hip_fcoll_eulerian_zs(dfil[b], eul_dfil_stride(c), c->nion_dense, c->nx, c->ny, c->nz, s->fcoll_mode,
                                   s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct],
                                   s->delta_c, min_density,
                                   (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),

@@ -557,7 +557,7 @@ static int slab_exchange_rccl(void *user, const c21cm_shard_slab_state *s, int l
         return st;
     if (!arg->gather_outputs) return 0;
     if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
-    for (int b = 0; b < 3 && !st; b++) {
+    for (int b = 0; b < (arg->gather_outputs == 2 ? 1 : 3) && !st; b++) { /* (2: the neutral fraction alone) */
         if (!s->out[b]) continue;
         for (int p = 0; p < world && !st; p++) {
             if (p == rank) continue;
@@ -628,13 +628,14 @@ int c21cm_shard_or_unpack_mask_bits(const unsigned *bits, size_t stride_words, i
     return c21hip_or_unpack_mask_bits(bits, stride_words, world, first_cross, n, stream);
 }
 /* What a sharded ComputeIonizedBox leaves in the output arrays (the `broadcast` argument of
- * c21cm_ionize_sharded): 1 = whole boxes on every rank, 0 = nothing beyond what the finish leaves (a
- * rank's slab / the owner's box), -1 = auto: slab-resident where the finish runs by slabs, the owner's
+ * c21cm_ionize_sharded): 1 = whole boxes on every rank, 2 = the whole neutral-fraction box on every rank
+ * (what ComputeBrightnessTemp and a power spectrum need: 4 of the 12 bytes per cell), z_reion and T_k
+ * slab-resident, 0 = nothing beyond what the finish leaves (a rank's slab / the owner's box), -1 = auto: slab-resident where the finish runs by slabs, the owner's
  * box broadcast otherwise.  c21cm_shard_set_output() or the environment (C21CM_SHARD_OUTPUT = all |
- * none | auto; C21CM_SHARD_BCAST = 1 | 0 as before round 5); default auto. */
+ * xH | none | auto; C21CM_SHARD_BCAST = 1 | 0 as before round 5); default auto. */
 static int g_output_mode = -2;
 int c21cm_shard_set_output(int mode) {
-    if (mode < -1 || mode > 1) return C21CM_VALUE_ERROR;
+    if (mode < -1 || mode > 2) return C21CM_VALUE_ERROR;
     g_output_mode = mode;
     return 0;
 }
@@ -642,6 +643,7 @@ int c21cm_shard_output_mode(void) {
     if (g_output_mode != -2) return g_output_mode;
     const char *o = getenv("C21CM_SHARD_OUTPUT"), *b = getenv("C21CM_SHARD_BCAST");
     if (o && o[0] == 'a' && o[1] == 'l') return 1;
+    if (o && o[0] == 'x') return 2; /* xH: whole neutral-fraction boxes, z_reion / T_k slab-resident */
     if (o && o[0] == 'n') return 0;
     if (b && b[0] == '1') return 1;
     if (b && b[0] == '0') return 0;
@@ -687,7 +689,7 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
         /* shard phase -> slab exchange of the packed first crossings -> every rank finishes its slab */
         unsigned char *fc = (unsigned char *)c21hip_ws(WS_SHARD_GRID, ntot);
         unsigned *sendb = NULL, *recvb = NULL;
-        slab_exchange_arg arg = {broadcast > 0 ? 1 : 0, spec};
+        slab_exchange_arg arg = {broadcast > 0 ? broadcast : 0, spec};
         st = fc ? 0 : C21CM_MEMORY_ALLOC_ERROR;
         if (!st)
             st = c21cm_ionize_shard_radii(spec, rank, world, perturbed_field, previous_ionize_box,
@@ -707,7 +709,7 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
         }
         st = c21cm_ionize_shard_finish_slab(spec, fc, rank, world, perturbed_field, previous_ionize_box,
                                             spin_temp, halos, box, report, slab_exchange_rccl, &arg,
-                                            arg.gather_outputs, stream);
+                                            arg.gather_outputs == 1, stream);
         MARK(3);
         g_phase_valid = 1;
         g_last_finish_slab = 1;
@@ -835,9 +837,14 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
  * per link for the outputs. */
 enum { WS_TSS_SUMS = 242, WS_TSS_SEND = 243, WS_TSS_RECV = 244, WS_TSS_SLAB = 245 };
 
+/* how many times this process took the sharded ComputeTsBox (tests: did the call shard?) */
+static int g_ts_sharded_calls;
+int c21cm_ts_box_sharded_calls(void) { return g_ts_sharded_calls; }
+
 int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_field_redshift,
                          PerturbedField *perturbed_field, TsBox *previous_spin_temp,
                          TsBox *this_spin_temp) {
+    g_ts_sharded_calls++;
     if (!R.ready || R.ready == 2) {
         c21hip_set_error("shard: ComputeTsBox shards over an RCCL communicator (c21cm_shard_init)");
         return C21CM_VALUE_ERROR;

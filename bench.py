@@ -648,7 +648,12 @@ def main():
         alg_loop = algorithmic_bytes_per_radius(cells, G) * (spec.n_radii - (1 if r0_direct else 0))
         if r0_direct:
             alg_loop += 29.0 * cells
-        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None}
+        # `achievable_GBs`: what a plain float4 copy kernel moves on these boxes (tools/copy_bench.hip,
+        # profiles/r05_copy_bench.txt: 6.2 TB/s read + write; 5.4-5.8 with 4-8 float4 per thread,
+        # 4.7 through hipMemcpy) -- the ceiling a streaming kernel can be held against; `frac` stays
+        # against the 8 TB/s peak as the contract says
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achievable_GBs": args.achievable_gbs,
+                "traffic": None}
         kern = None if (world > 1 or args.no_kernel_roofline or not native) else \
             kernel_roofline(args, spec, torch)
         if kern:

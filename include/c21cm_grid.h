@@ -352,6 +352,7 @@ int c21cm_ts_box_shard_finish(float redshift, float prev_redshift, float perturb
 int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_field_redshift,
                          PerturbedField *perturbed_field, TsBox *previous_spin_temp,
                          TsBox *this_spin_temp);
+int c21cm_ts_box_sharded_calls(void); /* calls of c21cm_ts_box_sharded in this process (tests) */
 int c21cm_shard_owner(int n_radii, int world);
 /* Test hook: replace the transport by an in-process device mailbox so that the ranks of a
  * world > 1 run can be executed one after the other in ONE process (non-owners first, the owner
@@ -366,6 +367,8 @@ int c21cm_last_ionize_timing(double out[6]);
  * drop-in ComputeIonizedBox passes (c21cm_shard_output_mode: c21cm_shard_set_output, else the environment
  * C21CM_SHARD_OUTPUT = all | none | auto, default auto):
  *    1  whole boxes on every rank (all-gather of the output slabs, or a broadcast of the owner's box)
+ *    2  (slab finish) the whole neutral-fraction box on every rank, z_reion and T_k slab-resident:
+ *       4 of the 12 bytes per cell of mode 1 (C21CM_SHARD_OUTPUT=xH); device arrays only
  *    0  what the finish leaves: every rank its slab (c21cm_ionize_shard_slab) where the finish phase runs
  *       by cell slabs, the owner's box otherwise; scalars (global_xH, mean_f_coll) complete on every rank
  *       of a slab finish

@@ -89,6 +89,10 @@ def per_kernel_csv(directory, counter, out):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    if len(sys.argv) > 5 and sys.argv[5] == "1024":  # config 4's kernels (one radius per sweep, whole-wave pass Z)
+        KERNELS.clear()
+        KERNELS.update({"pass_x_eval": "line_pass_kernel<1024, 1, 6>", "pass_y": "line_pass_kernel<1024, 1, 0>",
+                        "pass_z_fused": "zw3_ionise_kernel<false>"})
     if len(sys.argv) > 4:  # prefix for the compact per-kernel CSVs
         per_kernel_csv(fetch_dir, "FETCH_SIZE", f"{sys.argv[4]}_FETCH_SIZE_per_kernel.csv")
         per_kernel_csv(write_dir, "WRITE_SIZE", f"{sys.argv[4]}_WRITE_SIZE_per_kernel.csv")
