@@ -97,7 +97,8 @@ enum {
     WS_SFR_WORK2 = 246, /* fused recombination loop: whalo_sfr of the second radius of a sweep */
     WS_R_DEV = 247,     /* float R per radius index (mean free path of a first crossing) */
     WS_EUL_XEPEND = 253, /* banded barrier with an x_e grid: clipped x_e of the undecided cells (sparse) */
-    WS_NION_DENSE2 = 254 /* closed-form Eulerian loop: second dense f_coll buffer (deferred barrier) */
+    WS_NION_DENSE2 = 254, /* closed-form Eulerian loop: second dense f_coll buffer (deferred barrier) */
+    WS_ARENA = 258        /* experiment: the spectra of the two-grid loop out of one allocation (C21CM_ARENA) */
 };
 
 #define MAX_COPYBACK 12
@@ -405,16 +406,29 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     const size_t gbytes = c->npad * sizeof(float), dbytes = c->ntot * sizeof(float);
 
     c->native = c21hip_fft_is_native(c->nx, c->ny, c->nz);
-    c->delta_unf = (float *)c21hip_ws(WS_DELTA_UNF, gbytes);
+    /* experiment (round 5): the four spectra of the two-grid loop out of ONE allocation, `skew` bytes
+     * between consecutive buffers (C21CM_ARENA=skew; default: separate workspace slots) */
+    char *arena = NULL;
+    size_t astep = 0;
+    {
+        const char *e = getenv("C21CM_ARENA");
+        if (e && c->lagrangian) {
+            const size_t skew = (size_t)atol(e);
+            astep = ((gbytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1)) + skew;
+            arena = (char *)c21hip_ws(WS_ARENA, 4 * astep);
+            if (!arena) return C21CM_MEMORY_ALLOC_ERROR;
+        }
+    }
+    c->delta_unf = arena ? (float *)arena : (float *)c21hip_ws(WS_DELTA_UNF, gbytes);
     c->delta_fil = (float *)c21hip_ws(WS_DELTA_FIL, gbytes);
     if (!c->delta_unf || !c->delta_fil) return C21CM_MEMORY_ALLOC_ERROR;
-    if (c->native && !(c->delta_work = (float *)c21hip_ws(WS_DELTA_WORK, gbytes)))
+    if (c->native && !(c->delta_work = arena ? (float *)(arena + 2 * astep) : (float *)c21hip_ws(WS_DELTA_WORK, gbytes)))
         return C21CM_MEMORY_ALLOC_ERROR;
     if (c->lagrangian) {
-        c->stars_unf = (float *)c21hip_ws(WS_STARS_UNF, gbytes);
+        c->stars_unf = arena ? (float *)(arena + astep) : (float *)c21hip_ws(WS_STARS_UNF, gbytes);
         c->stars_fil = (float *)c21hip_ws(WS_STARS_FIL, gbytes);
         if (!c->stars_unf || !c->stars_fil) return C21CM_MEMORY_ALLOC_ERROR;
-        if (c->native && !(c->stars_work = (float *)c21hip_ws(WS_STARS_WORK, gbytes)))
+        if (c->native && !(c->stars_work = arena ? (float *)(arena + 3 * astep) : (float *)c21hip_ws(WS_STARS_WORK, gbytes)))
             return C21CM_MEMORY_ALLOC_ERROR;
     }
     if (s->use_ts_fluct) {

@@ -284,12 +284,12 @@ def kernel_roofline(args, spec, torch):
     return out
 
 
-def pmc_traffic():
+def pmc_traffic(n=512):
     """HBM bytes per launch of the pass kernels from the newest committed rocprofv3 PMC passes
     (profiles/pmc_rNN.json, produced by tools/collect_pmc.py on the GPU box); None if absent.
     The profile records a hash of the kernel sources it was collected from; `stale` tells
     whether the kernels running now are those."""
-    files = sorted((ROOT / "profiles").glob("pmc_r*.json"))
+    files = sorted((ROOT / "profiles").glob("pmc_r*.json" if n == 512 else f"pmc{n}_r*.json"))
     if not files:
         return None
     try:
@@ -718,7 +718,7 @@ def main():
                          "alg_bytes_per_launch": dom["alg_bytes"],
                          "launches_per_step": dom["launches_per_step"],
                          "other_kernels": [kern[k] for k in sorted(kern) if k != dom_kind]})
-            pmc = pmc_traffic() if G == 2 else None  # (the PMC passes profile the two-grid launches)
+            pmc = pmc_traffic(n) if G == 2 else None  # (the PMC passes profile the two-grid launches)
             if pmc:
                 per = pmc.get("kernels", {}).get(PMC_KEYS.get(dom_kind))
                 roof["traffic"] = per["hbm_bytes"] if per else None

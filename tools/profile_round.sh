@@ -22,4 +22,5 @@ F=$(dirname $(find gpurun_out/pmc_FETCH_SIZE -name pmc_counter_collection.csv | 
 W=$(dirname $(find gpurun_out/pmc_WRITE_SIZE -name pmc_counter_collection.csv | head -1))
 python tools/collect_pmc.py $F $W gpurun_out/pmc_$TAG.json gpurun_out/${TAG}_pmc
 find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.csv" -size +2M -delete
+cp gpurun_out/pmc_$TAG.json profiles/   # (on the GPU box: the bench line below reads the counters of THIS run's kernels)
 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_final.json 2> gpurun_out/bench_final.err
