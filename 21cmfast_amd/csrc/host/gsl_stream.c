@@ -368,7 +368,13 @@ int c21_gsl_mode_deviates_device(unsigned long long seed, int n_threads, int nx,
     const int q = nx / n_threads, rem = nx % n_threads;
     const size_t per_row = 2 * (size_t)ny * nzc; /* deviates per x-row */
     const int device = c21hip_current_device();
-    const size_t CH = (size_t)1 << 22; /* deviates per staging chunk: 32 MB */
+    /* deviates per staging chunk: 32 MB each, two per stream -- but no more than 512 MB of pinned memory
+     * over all concurrently drawing streams (64 streams of 2 x 32 MB were 4 GB: ADVICE r4) */
+    size_t CH = (size_t)1 << 22;
+    {
+        const int streams = n_threads > 64 ? 64 : n_threads;
+        while (CH > ((size_t)1 << 16) && 2 * CH * sizeof(uint64_t) * (size_t)streams > ((size_t)512 << 20)) CH >>= 1;
+    }
     int failed = 0;
     /* everything queued on the caller's stream before this call has to be done with dev_ab */
     if ((st = c21hip_sync(stream))) {
