@@ -712,7 +712,11 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
     // tile, which skips the loop's barrier: a wave that ran ahead of the wave that loads an entry read
     // stale LDS.  Invisible in isolation (the waves of a workgroup start together), it showed as one wrong
     // x-plane in about one 1024^3 call in thirty once four processes shared the GPU.
-    __syncthreads();
+    // (C21X_NO_TW_BARRIER=1: the bug back in, to validate tests/test_gpu_contention.py against it)
+#ifndef C21X_NO_TW_BARRIER
+#define C21X_NO_TW_BARRIER 0
+#endif
+    if (!C21X_NO_TW_BARRIER || WEVAL) __syncthreads();
 
     constexpr int NP = (N / 2) / RSTEP;  // row pairs per thread
     const int r0 = threadIdx.x / CPAIR, c4 = threadIdx.x % CPAIR;

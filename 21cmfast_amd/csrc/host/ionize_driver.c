@@ -354,6 +354,7 @@ typedef struct {
     const unsigned char *r0_mask; /* Eulerian loops: the first crossings of the larger radii, applied by the ONE
                                    * sweep that also does the cell-scale radius and the post-loop (NULL: the
                                    * general kernels) */
+    int r0_slab, r0_cb, r0_ce; /* sharded finish by slabs: the one sweep covers chunks [r0_cb, r0_ce) only, no reduce */
     int band_mf;         /* 1: this loop's bands live in mean-fix space (barriers with an x_e grid) */
     int band_skip;       /* radius index that takes the dense sweeps whatever band exists (-1: none) */
     short band_hist[C21CM_MAX_RADII][3]; /* band_h1 / _h2 / _hn as they were BEFORE radius r was processed */
@@ -1526,6 +1527,13 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
              * the sweep reads the x_e input itself -- at index 0 no window is applied (IonisationBox.c:606),
              * the filtered grid is the clipped input up to the rounding of a transform pair, as for the
              * emissivity grid of the Lagrangian path (r0_direct) */
+            if (c->r0_slab) /* a rank's slab of the sweep; the caller exchanges the chunk sums and reduces them */
+                TRY(c21hip_final_sweep_eulerian_range(&args, s->stored_redshift, c->r0_mask, c->nion_dense,
+                                                      mean_dev, c->density, c->prev_zre, c->xH, c->zre, c->Tk,
+                                                      c->partials, (int *)(c->scalars + SC_FLAG),
+                                                      s->use_ts_fluct ? c->xe_dense : NULL, c->Tneutral,
+                                                      c->r0_cb, c->r0_ce, c->stream));
+            else
             TRY(c21hip_final_sweep_eulerian(&args, s->stored_redshift, c->r0_mask, c->nion_dense, mean_dev,
                                             c->density, c->prev_zre, c->xH, c->zre, c->Tk, c->partials,
                                             c->scalars + SC_XHSUM, (int *)(c->scalars + SC_FLAG),
@@ -1936,7 +1944,9 @@ static int init_output_grids(ion_ctx *c, const IonizedBox *prev) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     /* IonisationBox.c:1372-1378 (final_step writes every cell, -1 included) */
-    if (!(c->fused && !c->fused_rc && !c->sphere && s->r_lowest == 0))
+    /* (... and the slab finish of the Eulerian models: its one sweep writes every z_reion of the slab, the
+     * rest of the array is not this rank's) */
+    if (!(c->fused && !c->fused_rc && !c->sphere && s->r_lowest == 0) && !c->r0_slab)
         TRY(c21hip_fill(c->zre, c->ntot, -1.0f, c->stream));
     /* IonisationBox.c:365-386: the caller's zeroed previous box receives z_reion = -1 */
     if (s->first_snapshot && prev && prev->z_reion) {
@@ -2344,10 +2354,18 @@ done:
 int c21cm_ionize_shard_slab_supported(const c21cm_ionize_spec *s) {
     if (!s) return 0;
     const int nz = s->hii_dim_z;
-    return s->fcoll_mode == C21CM_FCOLL_STARS_GRID && s->recomb_model == C21CM_RECOMB_NONE &&
-           !s->use_mini_halos && !s->ionise_entire_sphere && s->r_lowest == 0 && r0_direct() &&
-           c21hip_fft_is_native(s->hii_dim, s->hii_dim, nz) &&
-           (!s->use_ts_fluct || c21hip_z_ionise_xe_supported(s->hii_dim, s->hii_dim, nz));
+    if (s->recomb_model != C21CM_RECOMB_NONE || s->use_mini_halos || s->ionise_entire_sphere ||
+        s->r_lowest != 0 || !c21hip_fft_is_native(s->hii_dim, s->hii_dim, nz))
+        return 0;
+    if (s->fcoll_mode == C21CM_FCOLL_STARS_GRID)
+        return r0_direct() && (!s->use_ts_fluct || c21hip_z_ionise_xe_supported(s->hii_dim, s->hii_dim, nz));
+    /* Eulerian models: the cell-scale radius' f_coll grid and its box mean are computed by every rank
+     * (replicated sweeps of one grid), the ONE sweep that applies mask + barrier + post-loop
+     * (eul_r0_fused) runs on the rank's slab */
+    {
+        const char *e = getenv("C21CM_EUL_R0_FUSED");
+        return !(e && e[0] == '0') && (!s->use_ts_fluct || r0_direct());
+    }
 }
 
 /* chunks and cells of `rank`'s slab (whole chunks of the final sweep, dealt evenly; cell bounds are
@@ -2404,18 +2422,35 @@ int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned
     TRY(c21cm_ionize_shard_slab(spec, rank, world, &st.chunk_begin, &st.chunk_end, &st.cell_begin,
                                 &st.cell_end, &st.n_chunks, &st.chunk_cells));
     TRY(ctx_setup(&c, spec, perturbed_field, previous_ionize_box, spin_temp, halos, box, 1, stream));
-    if (!c.fused || c.sphere) { /* (slab_supported mirrors ctx_setup; this cannot happen) */
-        c21hip_set_error("ionize shard: the slab finish needs the fused Lagrangian loop");
+    const int eul = !c.lagrangian;
+    if ((!eul && (!c.fused || c.sphere)) || (eul && !eul_r0_fused(&c))) { /* (slab_supported mirrors ctx_setup) */
+        c21hip_set_error("ionize shard: the slab finish needs the fused Lagrangian loop or the one-sweep "
+                         "cell-scale radius of the Eulerian loops");
         status = C21CM_VALUE_ERROR;
         goto done;
     }
     st.ntot = c.ntot;
     for (int i = 0; i < 3; i++) ev[i] = c21hip_event_create();
     TRY(c21hip_event_record(ev[0], stream));
+    c.r0_slab = eul;
     TRY(init_output_grids(&c, previous_ionize_box));
-    g_spectra.valid = 0;
     g_shard_means.valid = 0;
-    TRY(final_step_range(&c, first_cross, 0, st.chunk_begin, st.chunk_end));
+    if (eul) {
+        /* the cell-scale radius' f_coll grid on every rank (its spectra: left by this process' shard phase,
+         * else recomputed), then the rank's slab of the one sweep */
+        if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
+        g_spectra.valid = 0;
+        TRY(native_wev_prepare(&c, spec->n_radii - 1, 1, stream));
+        c.r0_mask = first_cross;
+        c.r0_slab = 1;
+        c.r0_cb = st.chunk_begin;
+        c.r0_ce = st.chunk_end;
+        TRY(one_radius(&c, 0, NULL, -1));
+        c21hip_wev_release();
+    } else {
+        g_spectra.valid = 0;
+        TRY(final_step_range(&c, first_cross, 0, st.chunk_begin, st.chunk_end));
+    }
     st.partials_stars = c.partials;
     st.partials_xh = c.partials + C21HIP_PARTIALS / 2;
     st.flag = (int *)(c.scalars + SC_FLAG);
@@ -2424,7 +2459,13 @@ int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned
     st.out[2] = c.Tk;
     entered = 1;
     if (exchange) TRY(exchange(exchange_user, &st, 0, stream));
-    TRY(final_step_sums(&c));
+    if (eul) {
+        c21hip_ionize_args args0;
+        fill_args(&args0, spec, 0);
+        TRY(c21hip_final_sweep_reduce(&args0, 1, c.partials, NULL, c.scalars + SC_XHSUM, stream));
+    } else {
+        TRY(final_step_sums(&c));
+    }
     TRY(c21hip_event_record(ev[1], stream));
     if (!outputs_gathered) { /* slab-resident outputs: the host copies of staged grids cover the slab */
         c.cb_cell0 = st.cell_begin;

@@ -402,7 +402,8 @@ def _emulated_slab_finish(api, spec, world, density, n_ion, **kw):
                         xh[slabs[q]["chunk_begin"]:slabs[q]["chunk_end"]] = saved[q][1]
                 return 0
 
-            buf = api.IonizeBuffers(density, minimize_memory=bool(spec.minimize_memory))
+            buf = api.IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
+                                    minimize_memory=bool(spec.minimize_memory))
             buf.z_reion[...] = 123.0  # the sweep writes its slab only
             bufs[rank], _, reps[rank] = api.ionize_shard_finish_slab(
                 spec, fc, rank, world, density, n_ion, buffers=buf, exchange=exchange, **kw)
@@ -416,6 +417,8 @@ def _emulated_slab_finish(api, spec, world, density, n_ion, **kw):
             continue
         box[name] = torch.cat([getattr(bufs[r], name).view(-1)[slabs[r]["cell_begin"]:slabs[r]["cell_end"]]
                                for r in range(world)])
+    if bufs[0].unnormalised_nion is not None:  # Eulerian models: the f_coll grid of index 0, whole on every rank
+        box["unnormalised_nion"] = [b.unnormalised_nion.view(-1) for b in bufs]
     return box, reps
 
 
@@ -468,6 +471,39 @@ def test_slab_finish_with_xe_grid_and_previous_snapshot(api):
     assert torch.equal(buf.z_reion.view(-1), got["z_reion"])
     assert torch.equal(buf.kinetic_temperature.view(-1), got["kinetic_temperature"])
     assert all(r.global_xH == rep.global_xH for r in reps)
+
+
+@pytest.mark.parametrize("mode,ts", [("erfc", 0), ("table", 0), ("erfc", 1), ("table", 1)])
+def test_slab_finish_of_the_eulerian_models(api, mode, ts):
+    """The Eulerian source models (closed form and table modes, with and without the x_e grid of a
+    spin-temperature run) through the finish by cell slabs: every rank computes the cell-scale radius'
+    f_coll grid and its box mean (replicated sweeps of one grid), the ONE sweep that applies mask + barrier +
+    post-loop runs on the rank's slab.  Bit-identical to the single pass incl. global x_HI on every rank; the
+    f_coll grid of index 0 (box->unnormalised_nion) is whole on every rank."""
+    import torch
+
+    n, nz, world = 64, 256, 3
+    fmode = W.FCOLL_ERFC if mode == "erfc" else W.FCOLL_TABLE_EXP
+    spec = W.ionize_spec(n, hii_dim_z=nz, mode=fmode, r_bubble_max=10.0, use_ts_fluct=ts)
+    if mode == "table":
+        _install_table(spec)
+    assert api.shard_slab_supported(spec)
+    shape = (n, n, nz)
+    density = torch.from_numpy(W.density_field_numpy(shape, seed=6)).cuda()
+    kw = {}
+    if ts:
+        rng = np.random.default_rng(11)
+        kw["xe"] = torch.from_numpy((-0.05 + 0.7 * rng.random(shape) ** 2).astype(np.float32)).cuda()
+        kw["Tneutral"] = torch.from_numpy((8.0 + 4.0 * rng.random(shape)).astype(np.float32)).cuda()
+    buf, box, rep = api.ionize_grids(spec, density, None, **kw)
+    got, reps = _emulated_slab_finish(api, spec, world, density, None, **kw)
+    assert 0.005 < float((buf.neutral_fraction == 0).float().mean()) < 0.98
+    assert float((buf.neutral_fraction < 1).float().mean()) > 0.5  # partial ionisations at the cell scale
+    for name in ("neutral_fraction", "z_reion", "kinetic_temperature"):
+        assert torch.equal(getattr(buf, name).view(-1), got[name]), name
+    for r in range(world):
+        assert torch.equal(buf.unnormalised_nion.view(-1), got["unnormalised_nion"][r])
+        assert reps[r].global_xH == rep.global_xH
 
 
 def test_c_level_slab_finish_on_one_rank_communicator(api):
