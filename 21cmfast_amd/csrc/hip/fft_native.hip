@@ -70,6 +70,18 @@
 #ifndef C21X_ZW_OCC       // min waves per SIMD requested for the fused pass Z (0: compiler's choice)
 #define C21X_ZW_OCC 0
 #endif
+#ifndef C21X_ZW_TSRC_OCC  // waves per SIMD asked of the three-line barrier kernel of the recombination loop
+#define C21X_ZW_TSRC_OCC 1
+#endif
+#ifndef C21X_EPI4_MASK16
+#define C21X_EPI4_MASK16 1
+#endif
+#ifndef C21X_ZW_TSRC_LEAN  // three-line barrier kernel: mask rows as 16-byte pieces, N_rec rows parked in LDS
+#define C21X_ZW_TSRC_LEAN 1
+#endif
+#ifndef C21X_ZW_TSRC_FENCE
+#define C21X_ZW_TSRC_FENCE 1
+#endif
 #ifndef C21X_ZW_BLOCK     // threads per workgroup of the fused pass Z on 512-point lines (64, 128, 256)
 #define C21X_ZW_BLOCK 256
 #endif
@@ -2250,7 +2262,7 @@ __global__ void
 #if C21X_ZW_OCC
 __launch_bounds__(kBlock, (A == 16 && !TS) ? C21X_ZW_OCC : 1)
 #else
-__launch_bounds__((A == 16 && P == 16) ? C21X_ZW_BLOCK : kBlock)
+__launch_bounds__((A == 16 && P == 16) ? C21X_ZW_BLOCK : kBlock, (TS && RC && A == 16 && P == 16) ? C21X_ZW_TSRC_OCC : 1)
 #endif
 zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
                  const float2 *__restrict__ twN_global) {
@@ -2289,7 +2301,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     // spectra); after the transforms the row goes through the line's LDS region, where the lanes pick
     // their (cell 2j, 2j + 1) pairs and leave the changes; changed 16-byte pieces go back to the grid.
     // Sixteen 2-byte loads and up to sixteen 2-byte stores per lane otherwise.
-    constexpr bool MASK16 = EARLY && C21X_ZW_MASK16;
+    constexpr bool MASK16 = EARLY && (C21X_ZW_MASK16 || (TS && RC && C21X_ZW_TSRC_LEAN));
     constexpr int MV = MASK16 ? A / 8 : 1;
     uint4 mreg[MV];
     uchar2 old[(EARLY && !MASK16) ? A : 1];
@@ -2305,9 +2317,23 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     // instead of ~370 us per radius at 512^3), all sixteen requested here cost the second wave per
     // SIMD (256 VGPRs): the first half is requested now, the second half at the head of the barrier
     // loop, eight iterations ahead of its use.
-    constexpr int NRH = (RC && A == 16) ? A / 2 : 1;
+    // Three lines + N_rec (x_e grid of a spin-temperature run + CELL_RECOMB): 318 registers and one wave
+    // per SIMD that way.  STASH: the line's N_rec row is requested as 16-byte pieces with the spectra,
+    // parked in LDS after the first transform (2 KB per line) and read from there in the barrier loop.
+    constexpr bool STASH = TS && RC && A == 16 && P == 16 && C21X_ZW_TSRC_LEAN;
+    constexpr int NRH = (RC && A == 16 && !STASH) ? A / 2 : 1;
     float2 nr_lo[NRH], nr_hi[NRH];
-    if constexpr (RC && A == 16) {
+    __shared__ __attribute__((aligned(16))) float nstash[STASH ? ZWL * NZ : 4];
+    uint4 nreg[STASH ? NZ / (4 * P) : 1];
+    if constexpr (STASH) {
+#pragma unroll
+        for (int v = 0; v < NZ / (4 * P); v++) nreg[v] = make_uint4(0u, 0u, 0u, 0u);
+        if (a.nrec) {
+#pragma unroll
+            for (int v = 0; v < NZ / (4 * P); v++)
+                nreg[v] = reinterpret_cast<const uint4 *>(a.nrec + lline * NZ)[v * P + b];
+        }
+    } else if constexpr (RC && A == 16) {
         if (a.nrec) {
 #pragma unroll
             for (int q = 0; q < NRH; q++)
@@ -2316,6 +2342,13 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
     }
     __syncthreads();  // twiddle tables
     wave_c2r<A, P>(xd, dh, L, twH, twN, b);
+    if constexpr (STASH) {
+        if (a.nrec) {
+#pragma unroll
+            for (int v = 0; v < NZ / (4 * P); v++)
+                reinterpret_cast<uint4 *>(nstash + lw * NZ)[v * P + b] = nreg[v];
+        }
+    }
     if (!EARLY) {
 #pragma unroll
         for (int q = 0; q < A; q++) xs[q] = sm[P * q + b];
@@ -2335,7 +2368,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         wave_c2r<A, P>(xx, xh, L, twH, twN, b);
     }
 
-    if constexpr (RC && A == 16) {
+    if constexpr (RC && A == 16 && !STASH) {
         if (a.nrec) {
 #pragma unroll
             for (int q = 0; q < NRH; q++) {
@@ -2380,9 +2413,10 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
             opd1 = 1. + (double)fmaxf(xd[q].y, dmin);
             double r0 = a.rec0, r1 = a.rec0;
             if (a.nrec) {
-                const float2 nr = (A == 16) ? (q < NRH ? nr_lo[(A == 16 && q < NRH) ? q : 0]
-                                                       : nr_hi[(A == 16 && q >= NRH) ? q - NRH : 0])
-                                            : reinterpret_cast<const float2 *>(a.nrec + lline * NZ)[j];
+                const float2 nr = STASH ? reinterpret_cast<const float2 *>(nstash + lw * NZ)[j]
+                                  : (A == 16) ? (q < NRH ? nr_lo[(A == 16 && !STASH && q < NRH) ? q : 0]
+                                                         : nr_hi[(A == 16 && !STASH && q >= NRH) ? q - NRH : 0])
+                                              : reinterpret_cast<const float2 *>(a.nrec + lline * NZ)[j];
                 r0 = (double)nr.x, r1 = (double)nr.y;
             }
             double n0 = 1., n1 = 1.;
@@ -2418,6 +2452,11 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
             if (n0 && a.rc != 2) grow[0] = fmaxf(xd[q].x, dmin);
             if (n1 && a.rc != 2) grow[1] = fmaxf(xd[q].y, dmin);
         }
+#if C21X_ZW_TSRC_FENCE
+        // three lines + N_rec: keep the iterations apart, or the scheduler's hoisting across the
+        // unrolled loop costs the second wave per SIMD (318 registers)
+        if constexpr (TS && RC) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if constexpr (MASK16) {
         wave_fence();
@@ -2472,12 +2511,15 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     uchar2 mprev[EPI == 6 ? A : 1];
     // EPI 7: the mask row of the line as 2 A contiguous bytes per lane (16-byte loads, in flight under
     // the transform); the lanes' (cell 2j, 2j + 1) pairs are picked out of the line's LDS region afterwards
-    constexpr int MV = (EPI == 7 || EPI == 8) ? A / 8 : 1;
+    // (EPI 4 reads the rows the same way -- sixteen 2-byte loads per lane issued after the transform
+    //  made the Gamma_12 pass slower than a pass Z that stores its whole grid: 0.30 against 0.25 ms)
+    constexpr bool MROW = (EPI == 7 || EPI == 8 || (EPI == 4 && C21X_EPI4_MASK16));
+    constexpr int MV = MROW ? A / 8 : 1;
     uint4 mreg[MV];
-    if constexpr (EPI == 7 || EPI == 8) {
+    if constexpr (MROW) {
+        const uint4 *mrow = reinterpret_cast<const uint4 *>(((EPI == 4) ? a.mask : a.mask_rw) + lline * NZ) + b * MV;
 #pragma unroll
-        for (int v = 0; v < MV; v++)
-            mreg[v] = reinterpret_cast<const uint4 *>(a.mask_rw + lline * NZ)[b * MV + v];
+        for (int v = 0; v < MV; v++) mreg[v] = mrow[v];
     }
     __shared__ float ftab[EPI == 8 ? C21CM_NDELTA_TABLE : 1];
     float2 dreg[EPI == 8 ? A : 1];
@@ -2499,7 +2541,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     }
     __syncthreads();  // twiddle tables
     wave_c2r<A, P>(x, xh, L, twH, twN, b);
-    if constexpr (EPI == 7 || EPI == 8) {
+    if constexpr (MROW) {
         wave_fence();  // the transform's last reads of the region
 #pragma unroll
         for (int v = 0; v < MV; v++) reinterpret_cast<uint4 *>(L)[b * MV + v] = mreg[v];
@@ -2549,7 +2591,9 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             if (h1) m.y = (unsigned char)a.r_index;
             if (h0 || h1) reinterpret_cast<uchar2 *>(a.mask_rw + lline * NZ)[j] = m;
         } else if (EPI == 4) {
-            const uchar2 m = reinterpret_cast<const uchar2 *>(a.mask + lline * NZ)[j];
+            // (requesting the crossings' delta_R before the transform was tried: 0.289 against 0.252 ms)
+            const uchar2 m = MROW ? reinterpret_cast<const uchar2 *>(L)[j]
+                                  : reinterpret_cast<const uchar2 *>(a.mask + lline * NZ)[j];
             float *grow = a.out + lline * NZ + 2 * j;
             if (m.x == (unsigned char)a.r_index)
                 grow[0] = (float)(a.const_factor / (1. + (double)grow[0]) * (double)fmaxf(v.x, 0.f));

@@ -962,16 +962,32 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                 c->stars_work, c->stars_work2, s->stars_filter, (float)s->mfp_meandens, c->nx,
                 c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a,
                 buf_b, bits, c->stream));
-            if (c->x3_on) /* x_e (N_rec) shares the density grid's window (IonisationBox.c:1551-1553, :613) */
+            /* x_e (N_rec) shares the density grid's window (IonisationBox.c:1551-1553, :613), whalo_sfr
+             * the emissivity's (IonisationBox.c:583-663): together they are a second two-grid sweep
+             * with the same window pair (one pass X, one pass Y per radius instead of two each) */
+            static int merge34 = -1;
+            if (merge34 < 0) {
+                const char *e = getenv("C21CM_RECOMB_MERGE34");
+                merge34 = (e && e[0] == '0') ? 0 : 1;
+            }
+            if (c->x3_on && c->fused_rc && c->wev && merge34) {
+                TRY(c21hip_split_filter_xy2_pair(
+                    c->x3_unf, c->x3_work, c->x3_work2, s->hii_filter, 0.f, c->sfr_unf, c->sfr_work,
+                    c->sfr_work2, s->stars_filter, (float)s->mfp_meandens, c->nx, c->ny, c->nz,
+                    s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a, buf_b,
+                    bits & ~1, c->stream));
+            } else {
+            if (c->x3_on)
                 TRY(c21hip_split_filter_xy_shared_pair(
                     c->x3_unf, c->x3_work, c->x3_work2, s->hii_filter, c->nx, c->ny, c->nz,
                     s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a, buf_b,
                     bits & ~1, c->stream));
-            if (c->fused_rc) /* whalo_sfr under the emissivity window (IonisationBox.c:583-663) */
+            if (c->fused_rc)
                 TRY(c21hip_split_filter_xy_single_pair(
                     c->sfr_unf, c->sfr_work, c->sfr_work2, s->stars_filter, (float)s->mfp_meandens,
                     c->nx, c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a],
                     (float)s->R[R_b], bits & ~1, c->stream));
+            }
             /* (the tables are free after pass X, their only reader; releasing them there lets the
              * next builds run under pass Y, which measured 4 ms per call slower than under pass Z) */
             if (ph == (yy ? 2 : 1) && tab_async) {
