@@ -123,6 +123,13 @@ int c21hip_split_z_ionise_recomb_nrec(const float *delta_work, const float *star
                                       float *g12, unsigned char *first_cross, double *partials, int nx,
                                       int ny, int nz, int r_index, double rhocrit_omb, double ion_eff,
                                       int mass_dep_zeta, double f_limit, void *stream);
+/* ... and with both: the x_e grid of a spin-temperature run AND the filtered N_rec (four spectra, nz = 512) */
+int c21hip_z_ionise_recomb_xe_nrec_supported(int nx, int ny, int nz);
+int c21hip_split_z_ionise_recomb_xe_nrec(const float *delta_work, const float *stars_work, const float *xe_work,
+                                         const float *nrec_work, float *g12, unsigned char *first_cross,
+                                         double *partials, int nx, int ny, int nz, int r_index,
+                                         double rhocrit_omb, double ion_eff, int mass_dep_zeta, double f_limit,
+                                         void *stream);
 int c21hip_split_z_ionise_recomb(const float *delta_work, const float *stars_work, const float *nrec,
                                  double rec0, float *g12, unsigned char *first_cross,
                                  double *partials, int nx, int ny, int nz, int r_index,

@@ -1918,6 +1918,9 @@ struct ZFusedArgs {
     // the third line (x_main) is not x_e but the previous snapshot's N_rec filtered at this radius
     // (CELL_RECOMB = false, IonisationBox.c:583-663,808-809,1093): rec = max(N_rec(R), 0) / (1 + delta_R)
     int x_is_nrec;
+    // ... or BOTH: x_main is x_e and n_main the filtered N_rec, a fourth spectrum whose transform is
+    // parked (clipped at zero) in the LDS rows that hold the dense N_rec otherwise (512-point lines)
+    const float2 *n_main, *n_nyq;
     float *g12;  // dense [lines][NZ]: a first crossing leaves delta_R here (-> zw_c2r_kernel EPI 4)
 };
 
@@ -2341,6 +2344,22 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
         }
     }
     __syncthreads();  // twiddle tables
+    if constexpr (STASH) {
+        if (a.n_main) {  // fourth line: N_rec filtered at this radius, clipped at zero (IonisationBox.c:808-809)
+            float2 xn[A];
+            const float2 *nm = a.n_main + line * H;
+#pragma unroll
+            for (int q = 0; q < A; q++) xn[q] = nm[P * q + b];
+            wave_c2r<A, P>(xn, a.n_nyq[lline].x, L, twH, twN, b);
+#pragma unroll
+            for (int q = 0; q < A; q++) {
+                const int j = (b + P * (q / P)) + A * (q % P);
+                reinterpret_cast<float2 *>(nstash + lw * NZ)[j] =
+                    make_float2(fmaxf(xn[q].x, 0.f), fmaxf(xn[q].y, 0.f));
+            }
+            wave_fence();
+        }
+    }
     wave_c2r<A, P>(xd, dh, L, twH, twN, b);
     if constexpr (STASH) {
         if (a.nrec) {
@@ -2412,7 +2431,7 @@ zw_ionise_kernel(ZFusedArgs a, const float2 *__restrict__ twH_global,
             opd0 = 1. + (double)fmaxf(xd[q].x, dmin);
             opd1 = 1. + (double)fmaxf(xd[q].y, dmin);
             double r0 = a.rec0, r1 = a.rec0;
-            if (a.nrec) {
+            if (a.nrec || (STASH && a.n_main)) {
                 const float2 nr = STASH ? reinterpret_cast<const float2 *>(nstash + lw * NZ)[j]
                                   : (A == 16) ? (q < NRH ? nr_lo[(A == 16 && !STASH && q < NRH) ? q : 0]
                                                          : nr_hi[(A == 16 && !STASH && q >= NRH) ? q - NRH : 0])
@@ -4597,6 +4616,47 @@ extern "C" int c21hip_split_z_xe_fcoll_band(const float *xe_work, const float *d
                        (hipStream_t)stream, z, twH, twN);
     LAUNCH_CHECK();
     return 0;
+}
+// ... and with BOTH: the x_e grid of a spin-temperature run and the filtered N_rec of CELL_RECOMB = false
+// (four spectra; 512-point z-lines)
+extern "C" int c21hip_split_z_ionise_recomb_xe_nrec(const float *delta_work, const float *stars_work,
+                                                    const float *xe_work, const float *nrec_work, float *g12,
+                                                    unsigned char *first_cross, double *partials, int nx,
+                                                    int ny, int nz, int r_index, double rhocrit_omb,
+                                                    double ion_eff, int mass_dep_zeta, double f_limit,
+                                                    void *stream) {
+    if (nz != 512 || !C21X_ZW_TSRC_LEAN) {
+        c21hip_set_error("fused pass Z with an x_e grid and a filtered N_rec: 512-point z-lines only");
+        return C21CM_VALUE_ERROR;
+    }
+    const long nlines = (long)nx * ny;
+    ZFusedArgs a{};
+    a.x_main = reinterpret_cast<const float2 *>(xe_work);
+    a.x_nyq = a.x_main + nlines * (nz / 2);
+    a.n_main = reinterpret_cast<const float2 *>(nrec_work);
+    a.n_nyq = a.n_main + nlines * (nz / 2);
+    a.ny = ny;
+    a.lb = split_xb_log2(nx);
+    a.d_main = reinterpret_cast<const float2 *>(delta_work);
+    a.d_nyq = a.d_main + nlines * (nz / 2);
+    a.s_main = reinterpret_cast<const float2 *>(stars_work);
+    a.s_nyq = a.s_main + nlines * (nz / 2);
+    a.first_cross = first_cross;
+    a.partials = partials;
+    a.rhocrit_omb = rhocrit_omb;
+    a.ion_eff = ion_eff;
+    a.f_limit = f_limit;
+    a.mass_dep_zeta = mass_dep_zeta;
+    a.r_index = r_index;
+    a.rc = 1;
+    a.g12 = g12;
+    a.reverse = 1;
+    int n_partials = 0;
+    return dispatch_z_fused(nz, a, nlines, (hipStream_t)stream, &n_partials);
+}
+extern "C" int c21hip_z_ionise_recomb_xe_nrec_supported(int nx, int ny, int nz) {
+    const long nlines = (long)nx * ny;
+    return C21X_ZW_TSRC_LEAN && nz == 512 && zw_lines_of(nz, nlines) != 0 && !zw3_selected(nz, nlines);
 }
 extern "C" int c21hip_z_ionise_recomb_supported(int nx, int ny, int nz) {
     const long nlines = (long)nx * ny;

@@ -98,6 +98,7 @@ enum {
     WS_R_DEV = 247,     /* float R per radius index (mean free path of a first crossing) */
     WS_EUL_XEPEND = 253, /* banded barrier with an x_e grid: clipped x_e of the undecided cells (sparse) */
     WS_NION_DENSE2 = 254, /* closed-form Eulerian loop: second dense f_coll buffer (deferred barrier) */
+    WS_NREC_WORK2 = 259, /* fused recombination loop with x_e AND a filtered N_rec: N_rec of the second radius */
     WS_ARENA = 258        /* experiment: the spectra of the two-grid loop out of one allocation (C21CM_ARENA) */
 };
 
@@ -364,6 +365,11 @@ typedef struct {
      * with CELL_RECOMB = false -- the previous snapshot's N_rec (x3_nrec) */
     int x3_on, x3_nrec;
     float *x3_unf, *x3_work, *x3_work2;
+    /* ... and a fourth: N_rec when the third is the x_e grid (round 5; barrier kernel with the N_rec
+     * transform parked in LDS) */
+    int x4_on;
+    float *x4_unf, *x4_work, *x4_work2;
+    const float *cur_x4;
     int yz;              /* pass Y + fused pass Z as ONE plane-fused kernel (plane_yz.hip: 512^3, two grids) */
     int yz_now;          /* ... for the radius z_ionise_radius is called for (its main blocks skipped pass Y) */
     int yz_used;         /* a plane-fused launch happened in this call: its status is checked at the end */
@@ -388,6 +394,10 @@ typedef struct {
 
 static int r0_direct(void);
 
+/* which R loop the last context set up (tests, timing tools): 1 fused, 2 fused recombination loop, 4 third
+ * spectrum, 8 ... which is N_rec, 16 fourth spectrum (x_e + N_rec), 32 two radii per sweep */
+static int g_loop_flags;
+int c21cm_ionize_last_loop_flags(void) { return g_loop_flags; }
 static int g_single_pass; /* set by c21cm_ionize_grids around its ctx_setup: not a shard phase */
 static int g_rc_phase;    /* set by the (first crossing, Gamma_12) shard phases around their ctx_setup */
 
@@ -470,10 +480,14 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
      * C21CM_RECOMB_FUSED_NREC=0 keeps such runs on the unfused sequence) */
     const char *e_nr = getenv("C21CM_RECOMB_FUSED_NREC");
     const int nrec_ok = s->cell_recomb ||
-                        (c->inhomo && !s->use_ts_fluct && g_single_pass && !(e_nr && e_nr[0] == '0') &&
-                         c21hip_z_ionise_recomb_xe_supported(c->nx, c->ny, c->nz));
+                        (c->inhomo && g_single_pass && !(e_nr && e_nr[0] == '0') &&
+                         (s->use_ts_fluct ? c21hip_z_ionise_recomb_xe_nrec_supported(c->nx, c->ny, c->nz)
+                                          : c21hip_z_ionise_recomb_xe_supported(c->nx, c->ny, c->nz)));
     c->x3_on = c->x3_nrec = 0;
     c->x3_unf = c->x3_work = c->x3_work2 = NULL;
+    c->x4_on = 0;
+    c->x4_unf = c->x4_work = c->x4_work2 = NULL;
+    c->cur_x4 = NULL;
     if (c->native && c->lagrangian && c->recomb && nrec_ok &&
         !s->use_mini_halos && !s->ionise_entire_sphere && s->r_lowest == 0 &&
         (g_single_pass || (g_rc_phase && !s->use_ts_fluct))) {
@@ -558,16 +572,25 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
                 return C21CM_MEMORY_ALLOC_ERROR; /* (the second work spectrum of N_rec on the fused loop too) */
             if (c->fused_rc && !(c->sfr_work2 = (float *)c21hip_ws(WS_SFR_WORK2, gbytes)))
                 return C21CM_MEMORY_ALLOC_ERROR;
+            if (c->fused_rc && c->filter_rec && s->use_ts_fluct &&
+                !(c->x4_work2 = (float *)c21hip_ws(WS_NREC_WORK2, gbytes)))
+                return C21CM_MEMORY_ALLOC_ERROR;
             c->pair_radii = 1;
         }
     }
     if (c->fused && s->use_ts_fluct) {
         c->x3_on = 1;
         c->x3_unf = c->xe_unf, c->x3_work = c->xe_work, c->x3_work2 = c->xe_work2;
+        if (c->fused_rc && c->filter_rec) {
+            c->x4_on = 1;
+            c->x4_unf = c->nrec_unf, c->x4_work = c->nrec_work;
+        }
     } else if (c->fused_rc && c->filter_rec) {
         c->x3_on = c->x3_nrec = 1;
         c->x3_unf = c->nrec_unf, c->x3_work = c->nrec_work, c->x3_work2 = c->xe_work2;
     }
+    g_loop_flags = (c->fused ? 1 : 0) | (c->fused_rc ? 2 : 0) | (c->x3_on ? 4 : 0) | (c->x3_nrec ? 8 : 0) |
+                   (c->x4_on ? 16 : 0) | (c->pair_radii ? 32 : 0);
     if (c->fused) {
         const char *e = getenv("C21CM_DEFER_SUMS");
         if (!(e && e[0] == '0')) {
@@ -834,7 +857,12 @@ static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float
             if (c->def_count == 0) c->def_first = R_ct;
             c->def_count++;
         }
-        if (c->x3_nrec) /* CELL_RECOMB = false: N_rec filtered at the radius is the third line */
+        if (c->x4_on) /* CELL_RECOMB = false with an x_e grid: four spectra */
+            TRY(c21hip_split_z_ionise_recomb_xe_nrec(dwork, swork, c->cur_xe, c->cur_x4, c->G12, first_cross,
+                                                     part, c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
+                                                     s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
+                                                     c->stream));
+        else if (c->x3_nrec) /* CELL_RECOMB = false: N_rec filtered at the radius is the third line */
             TRY(c21hip_split_z_ionise_recomb_nrec(dwork, swork, c->cur_xe, c->G12, first_cross, part, c->nx,
                                                   c->ny, c->nz, R_ct, s->rhocrit_omb, s->ion_eff_factor,
                                                   s->mass_dep_zeta, s->f_limit_acg, c->stream));
@@ -988,6 +1016,11 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
                     c->nx, c->ny, c->nz, s->box_len, s->box_len_z, (float)s->R[R_a],
                     (float)s->R[R_b], bits & ~1, c->stream));
             }
+            if (c->x4_on) /* N_rec under the density grid's window too (IonisationBox.c:613) */
+                TRY(c21hip_split_filter_xy_shared_pair(
+                    c->x4_unf, c->x4_work, c->x4_work2, s->hii_filter, c->nx, c->ny, c->nz,
+                    s->box_len, s->box_len_z, (float)s->R[R_a], (float)s->R[R_b], buf_a, buf_b,
+                    bits & ~1, c->stream));
             /* (the tables are free after pass X, their only reader; releasing them there lets the
              * next builds run under pass Y, which measured 4 ms per call slower than under pass Z) */
             if (ph == (yy ? 2 : 1) && tab_async) {
@@ -996,15 +1029,18 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
             }
             if (ph == 1 && !yy) {
                 c->cur_xe = xe_of[0];
+                c->cur_x4 = c->x4_work;
                 TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
             }
         }
         c->tab_seq++;
         if (yy) {
             c->cur_xe = xe_of[0];
+            c->cur_x4 = c->x4_work;
             TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
         }
         c->cur_xe = xe_of[1];
+        c->cur_x4 = c->x4_work2;
         TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2, xw[1], first_cross));
         c->yz_now = 0;
         goto done;
@@ -1021,10 +1057,15 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
             TRY(c21hip_split_filter_xy(c->sfr_unf, c->sfr_work, c->nx, c->ny, c->nz, s->box_len,
                                        s->box_len_z, s->stars_filter, (float)s->R[R_a],
                                        (float)s->mfp_meandens, 1, c->stream));
+        if (c->x4_on)
+            TRY(c21hip_split_filter_xy_shared(c->x4_unf, c->x4_work, s->hii_filter, c->nx, c->ny,
+                                              c->nz, s->box_len, s->box_len_z, (float)s->R[R_a], 1,
+                                              buf_a, c->stream));
         if (tab_async) TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
     }
     c->tab_seq++;
     c->cur_xe = c->x3_on ? c->x3_work : NULL;
+    c->cur_x4 = c->x4_work;
     TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work,
                         c->fused_rc ? c->sfr_work : (s->use_ts_fluct ? c->xe_work : NULL), first_cross));
 done:

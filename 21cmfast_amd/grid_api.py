@@ -383,6 +383,15 @@ def ionize_shard_finish_keys(spec, cross_keys, density, n_ion=None, xe=None, Tne
     return buffers, box, rep
 
 
+def ionize_last_loop_flags() -> int:
+    """Which R loop the last ionisation call set up (c21cm_ionize_last_loop_flags): 1 fused, 2 fused
+    recombination loop, 4 third spectrum in the barrier kernel, 8 ... which is the filtered N_rec, 16 a
+    fourth spectrum (x_e and filtered N_rec), 32 two radii per sweep."""
+    lib = load()
+    lib.c21cm_ionize_last_loop_flags.restype = C.c_int
+    return int(lib.c21cm_ionize_last_loop_flags())
+
+
 def shard_rc_supported(spec) -> bool:
     """Does a recombination spec shard through the fused loop (first-crossing index + Gamma_12,
     5 bytes per cell) rather than through the 64-bit keys?  c21cm_ionize_shard_rc_supported."""

@@ -362,6 +362,10 @@ int c21cm_shard_emulate(int rank, int world, void *mailbox, size_t mailbox_bytes
  * device driver (scalars, tables, spec), [1] device pre-loop, [2] R loop, [3] post-loop, [4] wall ms of
  * the call, [5] number of filter radii. */
 int c21cm_last_ionize_timing(double out[6]);
+/* diagnostic: which R loop the last ionisation call set up -- 1 fused loop, 2 fused recombination loop,
+ * 4 a third spectrum in the barrier kernel, 8 ... which is the filtered N_rec, 16 a fourth spectrum
+ * (x_e AND filtered N_rec), 32 two radii per pass-X sweep */
+int c21cm_ionize_last_loop_flags(void);
 
 /* What a sharded call leaves in the output arrays -- `broadcast` of c21cm_ionize_sharded, and what the
  * drop-in ComputeIonizedBox passes (c21cm_shard_output_mode: c21cm_shard_set_output, else the environment

@@ -250,9 +250,10 @@ def test_c_level_sharding_with_an_emulated_transport(api, recomb, world):
     assert 0.03 < float((buf0.neutral_fraction == 0).float().mean()) < 0.97
 
 
-@pytest.mark.parametrize("model,ts,cell_recomb", [(2, False, 1), (1, False, 1), (2, True, 1), (1, True, 1),
-                                                  (2, False, 0)])
-def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, model, ts, cell_recomb):
+@pytest.mark.parametrize("model,ts,cell_recomb,n", [(2, False, 1, 256), (1, False, 1, 256), (2, True, 1, 256),
+                                                    (1, True, 1, 256), (2, False, 0, 256), (2, True, 0, 512),
+                                                    (2, True, 1, 512)])
+def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, model, ts, cell_recomb, n):
     """CELL_RECOMB runs ride the fused loop (whalo_sfr as a third spectrum of the wave-level pass Z,
     (1 + N_rec / (1 + delta)) in the barrier, Gamma_12 at first crossings, the mean free path from
     the first-crossing index); C21CM_RECOMB_FUSED=0 is the per-radius sequence of round 2.  Same
@@ -263,7 +264,8 @@ def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, 
     # barrier kernel, f zeta > (1 - x_e)(1 + rec) (IonisationBox.c:1084-1118)
     # cell_recomb = 0 (round 4): N_rec of the previous snapshot filtered at the radius takes the third
     # line, f zeta > 1 + max(N_rec(R), 0) / (1 + delta_R) (IonisationBox.c:583-663,808-809,1093)
-    n = 256
+    # cell_recomb = 0 WITH an x_e grid (round 5, the last variant): four spectra, the N_rec transform parked
+    # in LDS where the dense N_rec rows of CELL_RECOMB wait (512-point z-lines)
     spec = recomb_spec(n, model=model, cell_recomb=cell_recomb, r_bubble_max=20.0, ts=int(ts))
     d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=77, ts=ts).items()}
     if model == 1:
@@ -274,8 +276,12 @@ def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, 
         kw.update(xe=d["xe"], Tneutral=d["Tneutral"])
     monkeypatch.setenv("C21CM_RECOMB_FUSED", "0")
     b0, _, r0 = api.ionize_grids(spec, d["density"], **kw)
+    assert api.ionize_last_loop_flags() & 3 == 0
     monkeypatch.delenv("C21CM_RECOMB_FUSED")
     b1, _, r1 = api.ionize_grids(spec, d["density"], **kw)
+    flags = api.ionize_last_loop_flags()
+    assert flags & 2, flags  # the fused recombination loop ran
+    assert bool(flags & 4) == (ts or not cell_recomb) and bool(flags & 16) == (ts and not cell_recomb), flags
     torch.cuda.synchronize()
     c0, c1 = b0.mean_free_path > 0, b1.mean_free_path > 0
     mism = float((c0 != c1).float().mean())

@@ -31,7 +31,7 @@ xe = (0.02 + 0.2 * torch.rand(density.shape, device="cuda", generator=g) ** 3).f
 Tn = (8.0 + 4.0 * torch.rand(density.shape, device="cuda", generator=g)).float()
 for name, model, cell, ts_on in (("none", 0, 1, 0), ("homogeneous", 1, 1, 0), ("inhomogeneous_cell", 2, 1, 0),
                                  ("inhomogeneous_filtered", 2, 0, 0), ("inhomogeneous_cell_xe", 2, 1, 1),
-                                 ("homogeneous_xe", 1, 1, 1)):
+                                 ("homogeneous_xe", 1, 1, 1), ("inhomogeneous_filtered_xe", 2, 0, 1)):
     if only and name != only:
         continue
     if model == 0:
@@ -53,6 +53,7 @@ for name, model, cell, ts_on in (("none", 0, 1, 0), ("homogeneous", 1, 1, 0), ("
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
     out[name] = {"ms": round(float(np.median(ts[1:])), 2), "n_radii": spec.n_radii,
+                 "loop_flags": api.ionize_last_loop_flags(),
                  "global_xH": round(rep.global_xH, 5)}
     print(name, out[name], flush=True)
 print(json.dumps(out))
