@@ -1600,6 +1600,7 @@ struct ZPassArgs {
     float out_div;       // != 0: stored value = v / out_div (EPI 0; the gathers of the ICs)
     int out_floor;       // != 0 (EPI 0): stored value >= -1 + 1e-7 (PerturbedField.c:262-264)
     int ny, lb;          // x-blocked layout: memory line -> logical line (logical_line())
+    int reverse;         // wave-level kernel: workgroups walk the lines from the end
     // epilogues of the Eulerian source models (EPI 1, 2)
     double *p0, *p1;     // per-workgroup partials: EPI 1 min / max, EPI 2 sum (p0)
     float *f_out;        // EPI 2: dense f_coll grid [lines][NZ]
@@ -2518,7 +2519,10 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / P, b = lane % P;
     const int lw = wave * (64 / P) + g;
-    const long line = (long)blockIdx.x * ZWL + lw;
+    // reverse: start with the lines the pass Y that just ran wrote last (Infinity Cache), and leave the
+    // head of the real grid there for the sweep that follows (Eulerian loops)
+    const unsigned blk = a.reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const long line = (long)blk * ZWL + lw;
     float2 *L = lines + lw * LINE_LDS;
     const float2 *src = a.main + line * H;
     float2 x[A];
@@ -2761,9 +2765,9 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
-            a.p0[blockIdx.x] = r0;
-            if (EPI == 1 || EPI == 3) a.p1[blockIdx.x] = r1;
-            if (EPI == 3) a.p2[blockIdx.x] = r2;
+            a.p0[blk] = r0;
+            if (EPI == 1 || EPI == 3) a.p1[blk] = r1;
+            if (EPI == 3) a.p2[blk] = r2;
         }
     }
 }
@@ -3307,8 +3311,21 @@ int dispatch_z_r2c(int nz, const ZFwdArgs &a, long nlines, hipStream_t stream) {
     }
 }
 
+// single-grid pass Z walks the lines backwards (C21CM_ZW_REVERSE=0: forwards): 0.268 -> 0.251 ms for the
+// closed-form pass Z at 512^3, 0.243 -> 0.219 ms for the store + extrema pass
+static int zw_reverse_default() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("C21CM_ZW_REVERSE");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
 template <int EPI = 0>
-int dispatch_z_c2r(int nz, const ZPassArgs &a, long nlines, hipStream_t stream) {
+int dispatch_z_c2r(int nz, const ZPassArgs &a_, long nlines, hipStream_t stream) {
+    ZPassArgs a = a_;
+    a.reverse = zw_reverse_default();  // (every caller runs this right after the pass Y of the same spectrum)
     // (partial arrays of the EPI variants are sized for 16 lines per workgroup: P = 16 only)
     if (const int zwl = (a.out_zstride % 2 == 0 && (EPI == 0 || nz != 256)) ? zw_lines_of(nz, nlines) : 0) {
         const float2 *twH = twiddles(nz / 2);
@@ -4612,6 +4629,7 @@ extern "C" int c21hip_split_z_xe_fcoll_band(const float *xe_work, const float *d
     z.r_prev = r_prev;
     z.p0 = partials;
     KTimeScope kt(11, (hipStream_t)stream);
+    z.reverse = zw_reverse_default();
     hipLaunchKernelGGL((zw_c2r_kernel<16, 8, 16>), dim3((unsigned)(nlines / zwl)), dim3(kBlock), 0,
                        (hipStream_t)stream, z, twH, twN);
     LAUNCH_CHECK();

@@ -1,13 +1,13 @@
 #!/bin/bash
-# kernel breakdown of the recombination loops (which launches separate 124 ms from 2 x 44)
+# kernel breakdown of the Eulerian table modes through the ABI (CONST-ION-EFF with tables, E-INTEGRAL)
 REPO=$PWD
 export TMPDIR=/tmp
 mkdir -p $REPO/gpurun_out
-for v in inhomogeneous_cell_xe inhomogeneous_cell homogeneous; do
+for m in 0 1; do
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_rec_$v -o q -- \
-      python $REPO/tools/time_recomb.py 512 3 $v > $REPO/gpurun_out/prof_rec_$v.out 2> $REPO/gpurun_out/prof_rec_$v.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_eul_$m -o q -- \
+      python $REPO/tools/time_abi_ionize.py 512 $m > $REPO/gpurun_out/prof_eul_$m.out 2> $REPO/gpurun_out/prof_eul_$m.err
   cd $REPO
-  echo "== $v"; tail -2 gpurun_out/prof_rec_$v.out
-  timeout 20 python tools/kernel_stats_brief.py gpurun_out/prof_rec_$v/q_kernel_stats.csv 16
+  echo "== source model $m"; tail -1 gpurun_out/prof_eul_$m.out | cut -c1-400
+  timeout 20 python tools/kernel_stats_brief.py gpurun_out/prof_eul_$m/q_kernel_stats.csv 12
 done
