@@ -1,6 +1,8 @@
 #!/bin/bash
-# full GPU suite under xdist after the recombination / reverse pass Z changes, then config 2 and config 5 timings
-python -m pytest tests -x -q -m gpu -n 6 > gpurun_out/full_tests.out 2>&1
-echo "rc=$?"; grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" gpurun_out/full_tests.out | tail -6
-python bench.py --mode icpf --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-600
-python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-300
+# two-line recombination barrier kernel with the lean loads (N_rec rows parked in LDS, 16-byte mask rows): A/B
+for v in default rclean default rclean; do
+  lib=$PWD/variants/$v/lib21cmfast_hip.so; [ $v = default ] && lib=$PWD/21cmfast_amd/lib21cmfast_hip.so
+  echo "== $v"
+  C21CM_LIB=$lib python tools/time_recomb.py 512 3 inhomogeneous_cell 2>&1 | tail -1
+  C21CM_LIB=$lib python tools/time_recomb.py 512 3 homogeneous 2>&1 | tail -1
+done
