@@ -490,7 +490,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->cur_x4 = NULL;
     if (c->native && c->lagrangian && c->recomb && nrec_ok &&
         !s->use_mini_halos && !s->ionise_entire_sphere && s->r_lowest == 0 &&
-        (g_single_pass || (g_rc_phase && !s->use_ts_fluct))) {
+        (g_single_pass || g_rc_phase)) {
         /* (round 4: with the x_e grid of a spin-temperature run too -- a third line of the barrier
          * kernel; C21CM_RECOMB_FUSED_TS=0 keeps such runs on the unfused sequence) */
         const char *e = getenv("C21CM_RECOMB_FUSED"), *et = getenv("C21CM_RECOMB_FUSED_TS");
@@ -2677,13 +2677,18 @@ done:
  * everything else with a recombination model keeps the 64-bit keys above.
  * reference: src/py21cmfast/src/IonisationBox.c:1084-1140,1531-1588 */
 int c21cm_ionize_shard_rc_supported(const c21cm_ionize_spec *s) {
-    if (!s || s->recomb_model == C21CM_RECOMB_NONE || !s->cell_recomb || s->use_ts_fluct ||
+    if (!s || s->recomb_model == C21CM_RECOMB_NONE || !s->cell_recomb ||
         s->use_mini_halos || s->ionise_entire_sphere || s->r_lowest != 0 ||
         s->fcoll_mode != C21CM_FCOLL_STARS_GRID)
         return 0;
     const char *e = getenv("C21CM_RECOMB_FUSED");
     if (e && e[0] == '0') return 0;
     const int nx = s->hii_dim, ny = s->hii_dim, nz = s->hii_dim_z;
+    if (s->use_ts_fluct) { /* round 5: with the x_e grid of a spin-temperature run too (the same conditions
+                            * as the single pass: ctx_setup) */
+        const char *et = getenv("C21CM_RECOMB_FUSED_TS");
+        if ((et && et[0] == '0') || !r0_direct() || !c21hip_z_ionise_recomb_xe_supported(nx, ny, nz)) return 0;
+    }
     return c21hip_fft_is_native(nx, ny, nz) && c21hip_z_ionise_recomb_supported(nx, ny, nz) &&
            c21hip_wev_applicable(s->hii_filter, s->stars_filter, 2, nx, ny, nz);
 }

@@ -399,11 +399,12 @@ def shard_rc_supported(spec) -> bool:
 
 
 def ionize_shard_radii_rc(spec, rank, world, first_cross, cross_g12, density, n_ion=None,
-                          prev_z_reion=None, prev_nrec=None, whalo_sfr=None, stream=None):
+                          prev_z_reion=None, prev_nrec=None, whalo_sfr=None, xe=None, Tneutral=None,
+                          stream=None):
     """Shard phase of the fused recombination loop: this rank's radii -> ``first_cross`` (uint8
     CUDA tensor, radius index of the first crossing, 0 = none) and ``cross_g12`` (float32,
-    Gamma_12 at that crossing)."""
-    pf, prev, ts, hb = _input_structs(density, n_ion, None, None, prev_z_reion, prev_nrec, whalo_sfr)
+    Gamma_12 at that crossing).  ``xe`` / ``Tneutral``: the TsBox grids of a spin-temperature run."""
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec, whalo_sfr)
     lib = load()
     lib.c21cm_ionize_shard_radii_rc.restype = C.c_int
     check(lib.c21cm_ionize_shard_radii_rc(C.byref(spec), C.c_int(rank), C.c_int(world), C.byref(pf),
@@ -415,13 +416,13 @@ def ionize_shard_radii_rc(spec, rank, world, first_cross, cross_g12, density, n_
 
 def ionize_shard_finish_rc(spec, first_cross, cross_g12, density, n_ion=None, prev_z_reion=None,
                            prev_nrec=None, whalo_sfr=None, buffers: IonizeBuffers | None = None,
-                           stream=None):
+                           xe=None, Tneutral=None, stream=None):
     """Finish phase of the fused recombination loop on the owning rank (combined grids in)."""
     if buffers is None:
         buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
                                 minimize_memory=bool(spec.minimize_memory),
                                 recomb_model=spec.recomb_model)
-    pf, prev, ts, hb = _input_structs(density, n_ion, None, None, prev_z_reion, prev_nrec, whalo_sfr)
+    pf, prev, ts, hb = _input_structs(density, n_ion, xe, Tneutral, prev_z_reion, prev_nrec, whalo_sfr)
     box = buffers.struct()
     rep = S.IonizeReport()
     lib = load()

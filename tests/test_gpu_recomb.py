@@ -305,8 +305,8 @@ def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, 
     assert 0.03 < float(c1.float().mean()) < 0.97
 
 
-@pytest.mark.parametrize("model", [2, 1])
-def test_sharded_fused_recombination_phases_equal_single_pass(api, model):
+@pytest.mark.parametrize("model,ts", [(2, False), (1, False), (2, True)])
+def test_sharded_fused_recombination_phases_equal_single_pass(api, model, ts):
     """The fused recombination loop sharded (round 3): a rank's radii leave the uint8 first-crossing
     index + Gamma_12 (5 bytes per cell instead of the 8-byte keys); per cell the rank with the larger
     index wins with ITS Gamma_12 (c21cm_shard_combine_cross_g12, slab by slab as the RCCL exchange
@@ -315,15 +315,20 @@ def test_sharded_fused_recombination_phases_equal_single_pass(api, model):
     import torch
 
     D = importlib.import_module("21cmfast_amd.distributed")
+    # ts (round 5): with the x_e grid of a spin-temperature run the shard phases ride the fused loop too
+    # (the filtered x_e only enters the barrier; what a rank leaves is still 5 bytes per cell)
     n = 256
-    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0)
+    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0, ts=int(ts))
     assert api.shard_rc_supported(spec)
-    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=31).items()}
+    d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=31, ts=ts).items()}
     if model == 1:
         d["prev_nrec"] = torch.full((1, 1, 1), 0.21, dtype=torch.float32, device="cuda")
     kw = dict(n_ion=d["n_ion"], whalo_sfr=d["whalo_sfr"], prev_nrec=d["prev_nrec"],
               prev_z_reion=d["prev_z_reion"])
+    if ts:
+        kw.update(xe=d["xe"], Tneutral=d["Tneutral"])
     buf0, _, rep0 = api.ionize_grids(spec, d["density"], **kw)
+    assert api.ionize_last_loop_flags() & 2
     torch.cuda.synchronize()
     names = ("neutral_fraction", "z_reion", "kinetic_temperature", "ionisation_rate_G12",
              "mean_free_path", "cumulative_recombinations")
