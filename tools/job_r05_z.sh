@@ -1,8 +1,7 @@
 #!/bin/bash
-# two-line recombination barrier kernel with the lean loads (N_rec rows parked in LDS, 16-byte mask rows): A/B
-for v in default rclean default rclean; do
-  lib=$PWD/variants/$v/lib21cmfast_hip.so; [ $v = default ] && lib=$PWD/21cmfast_amd/lib21cmfast_hip.so
-  echo "== $v"
-  C21CM_LIB=$lib python tools/time_recomb.py 512 3 inhomogeneous_cell 2>&1 | tail -1
-  C21CM_LIB=$lib python tools/time_recomb.py 512 3 homogeneous 2>&1 | tail -1
-done
+# what the driver runs at round end: smoke(), the gpu suite without xdist (time it), the default bench line
+( time python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) 2>&1 | tail -5
+( time python -m pytest tests/ -x -q -m gpu > gpurun_out/suite_serial.out 2>&1 ) 2>&1 | tail -4
+grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" gpurun_out/suite_serial.out | tail -3
+( time python bench.py > gpurun_out/bench_default.json 2>/dev/null ) 2>&1 | tail -4
+cut -c1-250 gpurun_out/bench_default.json
