@@ -480,7 +480,7 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
      * C21CM_RECOMB_FUSED_NREC=0 keeps such runs on the unfused sequence) */
     const char *e_nr = getenv("C21CM_RECOMB_FUSED_NREC");
     const int nrec_ok = s->cell_recomb ||
-                        (c->inhomo && g_single_pass && !(e_nr && e_nr[0] == '0') &&
+                        (c->inhomo && (g_single_pass || g_rc_phase) && !(e_nr && e_nr[0] == '0') &&
                          (s->use_ts_fluct ? c21hip_z_ionise_recomb_xe_nrec_supported(c->nx, c->ny, c->nz)
                                           : c21hip_z_ionise_recomb_xe_supported(c->nx, c->ny, c->nz)));
     c->x3_on = c->x3_nrec = 0;
@@ -2677,7 +2677,7 @@ done:
  * everything else with a recombination model keeps the 64-bit keys above.
  * reference: src/py21cmfast/src/IonisationBox.c:1084-1140,1531-1588 */
 int c21cm_ionize_shard_rc_supported(const c21cm_ionize_spec *s) {
-    if (!s || s->recomb_model == C21CM_RECOMB_NONE || !s->cell_recomb ||
+    if (!s || s->recomb_model == C21CM_RECOMB_NONE ||
         s->use_mini_halos || s->ionise_entire_sphere || s->r_lowest != 0 ||
         s->fcoll_mode != C21CM_FCOLL_STARS_GRID)
         return 0;
@@ -2688,6 +2688,13 @@ int c21cm_ionize_shard_rc_supported(const c21cm_ionize_spec *s) {
                             * as the single pass: ctx_setup) */
         const char *et = getenv("C21CM_RECOMB_FUSED_TS");
         if ((et && et[0] == '0') || !r0_direct() || !c21hip_z_ionise_recomb_xe_supported(nx, ny, nz)) return 0;
+    }
+    if (!s->cell_recomb) { /* round 5: the filtered N_rec of the previous snapshot is an input every rank holds */
+        const char *en = getenv("C21CM_RECOMB_FUSED_NREC");
+        if ((en && en[0] == '0') || s->recomb_model != C21CM_RECOMB_INHOMOGENEOUS) return 0;
+        if (!(s->use_ts_fluct ? c21hip_z_ionise_recomb_xe_nrec_supported(nx, ny, nz)
+                              : c21hip_z_ionise_recomb_xe_supported(nx, ny, nz)))
+            return 0;
     }
     return c21hip_fft_is_native(nx, ny, nz) && c21hip_z_ionise_recomb_supported(nx, ny, nz) &&
            c21hip_wev_applicable(s->hii_filter, s->stars_filter, 2, nx, ny, nz);

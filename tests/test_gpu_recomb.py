@@ -305,8 +305,9 @@ def test_fused_recombination_loop_equals_the_unfused_sequence(api, monkeypatch, 
     assert 0.03 < float(c1.float().mean()) < 0.97
 
 
-@pytest.mark.parametrize("model,ts", [(2, False), (1, False), (2, True)])
-def test_sharded_fused_recombination_phases_equal_single_pass(api, model, ts):
+@pytest.mark.parametrize("model,ts,cell_recomb,n", [(2, False, 1, 256), (1, False, 1, 256), (2, True, 1, 256),
+                                                    (2, False, 0, 256), (2, True, 0, 512)])
+def test_sharded_fused_recombination_phases_equal_single_pass(api, model, ts, cell_recomb, n):
     """The fused recombination loop sharded (round 3): a rank's radii leave the uint8 first-crossing
     index + Gamma_12 (5 bytes per cell instead of the 8-byte keys); per cell the rank with the larger
     index wins with ITS Gamma_12 (c21cm_shard_combine_cross_g12, slab by slab as the RCCL exchange
@@ -317,8 +318,9 @@ def test_sharded_fused_recombination_phases_equal_single_pass(api, model, ts):
     D = importlib.import_module("21cmfast_amd.distributed")
     # ts (round 5): with the x_e grid of a spin-temperature run the shard phases ride the fused loop too
     # (the filtered x_e only enters the barrier; what a rank leaves is still 5 bytes per cell)
-    n = 256
-    spec = recomb_spec(n, model=model, cell_recomb=1, r_bubble_max=20.0, ts=int(ts))
+    # cell_recomb = 0 (round 5): the filtered N_rec is an input every rank holds; with an x_e grid as well it
+    # is the four-spectrum kernel (512-point z-lines)
+    spec = recomb_spec(n, model=model, cell_recomb=cell_recomb, r_bubble_max=20.0, ts=int(ts))
     assert api.shard_rc_supported(spec)
     d = {k: torch.from_numpy(v).cuda() for k, v in inputs((n, n, n), seed=31, ts=ts).items()}
     if model == 1:
@@ -335,7 +337,7 @@ def test_sharded_fused_recombination_phases_equal_single_pass(api, model, ts):
     ref = {k: getattr(buf0, k).clone() for k in names}
     assert 0.03 < float((ref["mean_free_path"] > 0).float().mean()) < 0.97
     ntot = n**3
-    for world in (1, 2, 3, 8):
+    for world in ((1, 2, 3, 8) if n == 256 else (1, 3)):
         masks, vals = [], []
         for rank in range(world):
             fc = torch.empty(ntot, dtype=torch.uint8, device="cuda")
