@@ -23,6 +23,15 @@ int c21hip_current_device(void);     /* -1 when there is none */
 int c21hip_use_device(int device);   /* per-thread: for helper threads of the host drivers */
 int c21hip_is_device_ptr(const void *p);     /* 1 = MI355X HBM, 0 = host          */
 void *c21hip_ws(int slot, size_t bytes);     /* cached device scratch, NULL = OOM */
+/* placement shopping (ionize_driver.c: place_work_partner): what a slot holds, a buffer handed to a slot, plain
+ * allocations outside the workspace, free device memory; the timed two-grid pass Y that tells whether two work
+ * spectra sit well together (fft_native.hip) */
+void *c21hip_ws_peek(int slot, size_t *bytes);
+int c21hip_ws_adopt(int slot, void *ptr, size_t bytes);
+void *c21hip_raw_alloc(size_t bytes);
+void c21hip_raw_free(void *p);
+size_t c21hip_free_bytes(void);
+int c21hip_probe_pass_y2(float *work_a, float *work_b, int nx, int ny, int nz, int reps, float *ms, void *stream);
 void c21hip_ws_release(void);
 unsigned long c21hip_ws_generation(void); /* counts c21hip_ws_release calls */
 int c21hip_h2d(void *dst, const void *src, size_t bytes, void *stream);

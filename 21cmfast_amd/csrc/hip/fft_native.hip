@@ -3443,6 +3443,52 @@ extern "C" int c21hip_split_y_nyq(float *work_a, float *work_b, int nx, int ny, 
     return dispatch_line_pass<+1>(ny, a, 0, (hipStream_t)stream_);
 }
 
+// Placement probe (ionize_driver.c: place_work_partner): pass Y of two work spectra in one launch, in place on
+// whatever the buffers hold, `reps` launches timed with events on the stream -> *ms per launch.  Which physical
+// region of the HBM two buffers written by one launch sit in decides 10-20 % of that launch's time
+// (profiles/r05_placement_study.txt); the addresses do not tell, a timed launch does.
+extern "C" int c21hip_probe_pass_y2(float *work_a, float *work_b, int nx, int ny, int nz, int reps, float *ms,
+                                    void *stream_) {
+    if (!c21hip_native_fft_supported(nx, ny, nz) || !work_a || !work_b || reps < 1 || !ms) return C21CM_VALUE_ERROR;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = nz / 2;
+    const long nlines = (long)nx * ny;
+    LinePassArgs a{};
+    a.fp.type = -1;
+    a.n_y = ny;
+    a.n_z = nz;
+    a.out_scale = 1.0f;
+    a.n_geo = 2;
+    a.n_grids = 2;
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
+    a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
+    a.g1_strided = 1;
+    float2 *wk[2] = {reinterpret_cast<float2 *>(work_a), reinterpret_cast<float2 *>(work_b)};
+    for (int g = 0; g < 2; g++) {
+        geo_ptrs(a.g0, g, wk[g], wk[g]);
+        geo_ptrs(a.g1, g, wk[g] + nlines * H, wk[g] + nlines * H);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        return C21CM_IO_ERROR;
+    }
+    int st = dispatch_line_pass<+1>(ny, a, 0, stream);  // warm-up (first touch of the pages)
+    (void)hipEventRecord(e0, stream);
+    for (int r = 0; r < reps && !st; r++) st = dispatch_line_pass<+1>(ny, a, 0, stream);
+    (void)hipEventRecord(e1, stream);
+    float t = 0.f;
+    if (!st && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess)) {
+        (void)hipGetLastError();
+        st = C21CM_IO_ERROR;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (float)reps;
+    return st;
+}
+
 // in-loop kernel timing, see KTimeScope
 extern "C" void c21hip_ktime_enable(int on) {
     for (auto &r : g_ktime) {

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "c21hip.h"
 #include "c21cm_abi.h"
@@ -21,9 +22,94 @@ constexpr int kMaxSlots = 288;  // ids 256.. : shard_rccl.c (status word, slab e
 struct Slot {
     void *ptr = nullptr;
     size_t bytes = 0;
+    // scattered placement (C21CM_WS_ALLOC=scatter): a reserved address range backed by 2 MB chunks mapped in a
+    // shuffled order
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    size_t va_bytes = 0;
 };
 Slot g_slots[kMaxSlots];
 std::mutex g_mutex;
+
+void slot_free(Slot &s) {
+    if (!s.ptr) return;
+    if (s.va_bytes) {
+        (void)hipMemUnmap(s.ptr, s.va_bytes);
+        for (auto h : s.chunks) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(s.ptr, s.va_bytes);
+        s.chunks.clear();
+        s.va_bytes = 0;
+    } else {
+        (void)hipFree(s.ptr);
+    }
+    s.ptr = nullptr;
+    s.bytes = 0;
+}
+
+// Large workspace buffers whose 2 MB pages are NOT in physical order.  On a GPU whose memory is unfragmented
+// hipMalloc hands out physically contiguous ranges, and the line passes that walk rows at a power-of-two pitch
+// (pass Y: 128-byte pieces every 2 / 4 KB) then run 8-20 % slower than on a box whose memory has been churned
+// (profiles/r05_placement_study.txt): the regular address-to-channel map serves such a walk from a subset of the
+// HBM channels at a time.  Chunks of the allocation granularity are created in order and mapped at a
+// pseudo-randomly permuted position of a reserved address range.
+void *scatter_alloc(Slot &s, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const size_t chunk = gran < ((size_t)2 << 20) ? ((size_t)2 << 20) / gran * gran : gran;
+    const size_t n = (bytes + chunk - 1) / chunk, total = n * chunk;
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::vector<hipMemGenericAllocationHandle_t> hs(n);
+    size_t made = 0;
+    bool ok = true;
+    for (; made < n; made++)
+        if (hipMemCreate(&hs[made], chunk, &prop, 0) != hipSuccess) {
+            ok = false;
+            break;
+        }
+    // position of chunk i: a fixed odd multiplier modulo a power of two >= n, cycled into range (a permutation)
+    size_t m = 1;
+    while (m < n) m <<= 1;
+    size_t mapped = 0;
+    if (ok) {
+        size_t pos = 0;
+        for (size_t i = 0; i < m && ok; i++) {
+            const size_t j = (i * 0x9E3779B1ull + 12345u) & (m - 1);  // odd multiplier: a bijection on [0, m)
+            if (j >= n) continue;
+            if (hipMemMap((char *)va + j * chunk, chunk, 0, hs[pos++], 0) != hipSuccess) ok = false;
+            else mapped++;
+        }
+        ok = ok && mapped == n;
+    }
+    if (ok) {
+        hipMemAccessDesc acc{};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(va, total, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        if (mapped) (void)hipMemUnmap(va, total);
+        for (size_t i = 0; i < made; i++) (void)hipMemRelease(hs[i]);
+        (void)hipMemAddressFree(va, total);
+        return nullptr;
+    }
+    s.chunks.swap(hs);
+    s.va_bytes = total;
+    return va;
+}
 thread_local char g_error[512] = "";
 }  // namespace
 
@@ -92,13 +178,28 @@ extern "C" void *c21hip_ws(int slot, size_t bytes) {
     std::lock_guard<std::mutex> lock(g_mutex);
     Slot &s = g_slots[slot];
     if (s.bytes >= bytes && s.ptr) return s.ptr;
-    if (s.ptr) {
-        (void)hipFree(s.ptr);
-        s.ptr = nullptr;
-        s.bytes = 0;
-    }
+    slot_free(s);
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    // C21CM_WS_ALLOC=contig: large buffers physically contiguous (hipDeviceMallocContiguous) -- placement study
+    // of the two speeds of the line passes (DESIGN Appendix B.0); anything else: plain hipMalloc
+    static int contig = -1;
+    if (contig < 0) {
+        const char *e = getenv("C21CM_WS_ALLOC");
+        contig = (e && e[0] == 'c') ? 1 : ((e && e[0] == 's') ? 2 : 0);
+    }
+    hipError_t e = hipErrorUnknown;
+    if (contig == 2 && bytes >= ((size_t)64 << 20)) {
+        p = scatter_alloc(s, bytes);
+        if (p) e = hipSuccess;
+    }
+    if (contig == 1 && bytes >= ((size_t)64 << 20)) {
+        e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+    }
+    if (e != hipSuccess) e = hipMalloc(&p, bytes ? bytes : 16);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         c21hip_set_error("hipMalloc of %zu bytes for workspace slot %d failed: %s", bytes, slot,
@@ -107,7 +208,48 @@ extern "C" void *c21hip_ws(int slot, size_t bytes) {
     }
     s.ptr = p;
     s.bytes = bytes;
+    {
+        static int trace = -1;  // C21CM_WS_TRACE=1: where the workspace buffers land (placement studies)
+        if (trace < 0) trace = getenv("C21CM_WS_TRACE") ? 1 : 0;
+        if (trace) fprintf(stderr, "[c21hip_ws] slot %d bytes %zu ptr %p\n", slot, bytes, p);
+    }
     return p;
+}
+
+// What a slot holds now (nullptr / 0: nothing), and a buffer allocated elsewhere (plain hipMalloc) handed to a
+// slot that is empty or smaller: the workspace owns it from then on (placement shopping, ionize_driver.c).
+extern "C" void *c21hip_ws_peek(int slot, size_t *bytes) {
+    if (slot < 0 || slot >= kMaxSlots) return nullptr;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (bytes) *bytes = g_slots[slot].bytes;
+    return g_slots[slot].ptr;
+}
+extern "C" int c21hip_ws_adopt(int slot, void *ptr, size_t bytes) {
+    if (slot < 0 || slot >= kMaxSlots || !ptr) return C21CM_VALUE_ERROR;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    slot_free(g_slots[slot]);
+    g_slots[slot].ptr = ptr;
+    g_slots[slot].bytes = bytes;
+    return 0;
+}
+extern "C" void *c21hip_raw_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void c21hip_raw_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+extern "C" size_t c21hip_free_bytes(void) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return fr;
 }
 
 static unsigned long g_ws_generation = 0;
@@ -118,9 +260,7 @@ extern "C" void c21hip_ws_release(void) {
     std::lock_guard<std::mutex> lock(g_mutex);
     g_ws_generation++;
     for (auto &s : g_slots) {
-        if (s.ptr) (void)hipFree(s.ptr);
-        s.ptr = nullptr;
-        s.bytes = 0;
+        slot_free(s);
     }
 }
 

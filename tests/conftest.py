@@ -4,7 +4,15 @@ import importlib
 import sys
 from pathlib import Path
 
+import os
+
 import pytest
+
+# placement shopping of the work spectra (ionize_driver.c: place_work_partner) walks up to 48 GB of free memory
+# per process; xdist workers share one GPU: keep their walks short
+if os.environ.get("PYTEST_XDIST_WORKER"):
+    os.environ.setdefault("C21CM_WS_PLACE_GB", "10")
+
 
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
