@@ -616,18 +616,23 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             WS_MINI_TABLES, 4 * sizeof(float) * C21CM_NDELTA_TABLE * C21CM_NMTURN_TABLE);
         if (!c->mini_tables) return C21CM_MEMORY_ALLOC_ERROR;
     }
-    if (c->recomb && c->lagrangian) {
-        c->sfr_unf = (float *)c21hip_ws(WS_SFR_UNF, gbytes);
-        c->sfr_fil = (float *)c21hip_ws(WS_SFR_FIL, gbytes);
-        if (!c->sfr_unf || !c->sfr_fil) return C21CM_MEMORY_ALLOC_ERROR;
-        if (c->native && !(c->sfr_work = (float *)c21hip_ws(WS_SFR_WORK, gbytes)))
-            return C21CM_MEMORY_ALLOC_ERROR;
-    }
     if (c->filter_rec) {
         c->nrec_unf = (float *)c21hip_ws(WS_NREC_UNF, gbytes);
         c->nrec_fil = (float *)c21hip_ws(WS_NREC_FIL, gbytes);
         if (!c->nrec_unf || !c->nrec_fil) return C21CM_MEMORY_ALLOC_ERROR;
         if (c->native && !(c->nrec_work = (float *)c21hip_ws(WS_NREC_WORK, gbytes)))
+            return C21CM_MEMORY_ALLOC_ERROR;
+    }
+    if (c->recomb && c->lagrangian) {
+        c->sfr_unf = (float *)c21hip_ws(WS_SFR_UNF, gbytes);
+        c->sfr_fil = (float *)c21hip_ws(WS_SFR_FIL, gbytes);
+        if (!c->sfr_unf || !c->sfr_fil) return C21CM_MEMORY_ALLOC_ERROR;
+        /* (on the fused loop whalo_sfr shares a two-grid sweep with the x_e / N_rec spectrum: placed against it) */
+        const int x3_slot = s->use_ts_fluct ? WS_XE_WORK : (c->filter_rec ? WS_NREC_WORK : -1);
+        if (c->native &&
+            !(c->sfr_work = (c->fused_rc && x3_slot >= 0)
+                                ? place_work_partner(x3_slot, WS_SFR_WORK, gbytes, c->nx, c->ny, c->nz, stream)
+                                : (float *)c21hip_ws(WS_SFR_WORK, gbytes)))
             return C21CM_MEMORY_ALLOC_ERROR;
     }
     if (c->recomb) {
@@ -653,7 +658,9 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             if ((s->use_ts_fluct || (c->fused_rc && c->filter_rec)) &&
                 !(c->xe_work2 = (float *)c21hip_ws(WS_XE_WORK2, gbytes)))
                 return C21CM_MEMORY_ALLOC_ERROR; /* (the second work spectrum of N_rec on the fused loop too) */
-            if (c->fused_rc && !(c->sfr_work2 = (float *)c21hip_ws(WS_SFR_WORK2, gbytes)))
+            if (c->fused_rc && !(c->sfr_work2 = c->xe_work2 ? place_work_partner(WS_XE_WORK2, WS_SFR_WORK2, gbytes, c->nx,
+                                                                                  c->ny, c->nz, stream)
+                                                             : (float *)c21hip_ws(WS_SFR_WORK2, gbytes)))
                 return C21CM_MEMORY_ALLOC_ERROR;
             if (c->fused_rc && c->filter_rec && s->use_ts_fluct &&
                 !(c->x4_work2 = (float *)c21hip_ws(WS_NREC_WORK2, gbytes)))
