@@ -32,6 +32,9 @@ void *c21hip_raw_alloc(size_t bytes);
 void c21hip_raw_free(void *p);
 size_t c21hip_free_bytes(void);
 int c21hip_probe_pass_y2(float *work_a, float *work_b, int nx, int ny, int nz, int reps, float *ms, void *stream);
+/* host/placement.c: the workspace slot `slot_new` (bytes) filled with a buffer that sits well with the one in
+ * `slot_partner` for two-grid launches; plain c21hip_ws where the walk does not apply */
+float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int nx, int ny, int nz, void *stream);
 void c21hip_ws_release(void);
 unsigned long c21hip_ws_generation(void); /* counts c21hip_ws_release calls */
 int c21hip_h2d(void *dst, const void *src, size_t bytes, void *stream);

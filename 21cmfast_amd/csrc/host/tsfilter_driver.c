@@ -313,7 +313,7 @@ int c21cm_annular_filter_grids(const c21cm_annular_spec *s, const float *const *
         int host_out[2] = {0, 0};
         if (np == 2) {
             unf[1] = (float *)c21hip_ws(WS_TF_UNF2, sbytes);
-            work[1] = (float *)c21hip_ws(WS_TF_WORK2, sbytes);
+            work[1] = c21_place_work_partner(WS_TF_WORK, WS_TF_WORK2, sbytes, c.nx, c.ny, c.nz, stream);
             if (!unf[1] || !work[1]) return C21CM_MEMORY_ALLOC_ERROR;
         }
         for (int p = 0; p < np; p++) {
