@@ -1,7 +1,7 @@
 #!/bin/bash
-# x_e work spectrum of the Eulerian models and the second grid of the spin-temperature filter stage placed against
-# their sweep partners: tests, then E-INTEGRAL + x_e through the ABI and config 5 with / without
+# full GPU suite with the two-phase placement walk: xdist (short walks), then serially (full walks), timed
 python -m pytest tests -x -q -m gpu -n 6 > gpurun_out/full_tests.out 2>&1
-echo "rc=$?"; grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" gpurun_out/full_tests.out | tail -3
-for pl in 1 0 1 0; do echo "== C21CM_WS_PLACE=$pl"; C21CM_WS_PLACE=$pl PYTHONPATH=. python tools/time_abi_ionize.py 512 1 9.0 1 2>/dev/null | tail -1 | cut -c1-330; done
-for pl in 1 0; do echo "== C21CM_WS_PLACE=$pl"; C21CM_WS_PLACE=$pl python tools/time_coeval_ts.py 512 1024 6.0 2>/dev/null | tail -1 | cut -c1-330; done
+echo "rc=$?"; grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" gpurun_out/full_tests.out | tail -2
+( time python -m pytest tests -x -q -m gpu > gpurun_out/suite_serial.out 2>&1 ) 2>&1 | grep real
+grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" gpurun_out/suite_serial.out | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
