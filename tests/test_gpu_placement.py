@@ -1,0 +1,59 @@
+"""Placement walk of the work spectra (round 5, csrc/host/placement.c): where a buffer sits in HBM must change
+the time of a launch and nothing else.
+
+Two spectra written by one launch are 10-21 % slower when they come from the same physical region of the HBM
+(profiles/r05_placement_study.txt); the second work spectrum of a two-grid sweep is
+therefore chosen among candidates by timed launches.  A process reads C21CM_WS_PLACE once, so the two settings
+run in processes of their own: same bits out, and the walk must have looked at candidates when it is on."""
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = r"""
+import hashlib, importlib, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+W = importlib.import_module("21cmfast_amd.workloads")
+api = importlib.import_module("21cmfast_amd.grid_api")
+n = 512
+spec = W.ionize_spec(n, r_bubble_max=8.0)
+density = W.density_field_torch(n, seed=4)
+n_ion = W.nion_from_density(density)
+for _ in range(2):  # the second call reuses the placed workspace
+    buf, box, rep = api.ionize_grids(spec, density, n_ion)
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for name in ("neutral_fraction", "z_reion", "kinetic_temperature"):
+        h.update(getattr(buf, name).cpu().numpy().tobytes())
+    print("HASH", h.hexdigest(), repr(rep.global_xH), spec.n_radii, api.ionize_last_loop_flags())
+"""
+
+
+def _run(tmp_path, place):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, C21CM_WS_PLACE=place, C21CM_WS_TRACE="1")
+    p = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    hashes = [ln for ln in p.stdout.splitlines() if ln.startswith("HASH")]
+    assert len(hashes) == 2 and hashes[0] == hashes[1], hashes
+    return hashes[0], p.stderr
+
+
+def test_placement_changes_nothing_but_time(tmp_path):
+    off, err_off = _run(tmp_path, "0")
+    on, err_on = _run(tmp_path, "1")
+    assert on == off
+    assert int(on.split()[-1]) & 33 == 33  # the fused loop with two radii per sweep: four work spectra
+    assert "[place]" not in err_off
+    # the walk timed at least two chunks for each of the two second work spectra (both radii of a sweep)
+    chunks = [ln for ln in err_on.splitlines() if ln.startswith("[place]") and " chunk " in ln]
+    assert len(chunks) >= 4, err_on[-1500:]
