@@ -41,6 +41,8 @@ def _run(tmp_path, place):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, C21CM_WS_PLACE=place, C21CM_WS_TRACE="1")
+    if os.environ.get("PYTEST_XDIST_WORKER"):  # workers share the GPU: do not hold most of its memory
+        env["C21CM_WS_PLACE_GB"] = "96"
     p = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     hashes = [ln for ln in p.stdout.splitlines() if ln.startswith("HASH")]
