@@ -63,7 +63,9 @@ void *scatter_alloc(Slot &s, size_t bytes) {
         (void)hipGetLastError();
         return nullptr;
     }
-    const size_t chunk = gran < ((size_t)2 << 20) ? ((size_t)2 << 20) / gran * gran : gran;
+    size_t want = (size_t)2 << 20;  // C21CM_WS_SCATTER_MB: chunk size of the experiment (default 2 MB)
+    if (const char *e = getenv("C21CM_WS_SCATTER_MB")) want = (size_t)atol(e) << 20;
+    const size_t chunk = (want + gran - 1) / gran * gran;
     const size_t n = (bytes + chunk - 1) / chunk, total = n * chunk;
     void *va = nullptr;
     if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) {
