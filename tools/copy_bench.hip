@@ -62,5 +62,34 @@ int main() {
     timeit("copy 8 float4/thread nt (r+w)", 2.0 * bytes, [&] { hipLaunchKernelGGL(copyU_nt<8>, dim3(n / 2048), dim3(256), 0, 0, a, b, n); });
     timeit("read only", 1.0 * bytes, [&] { hipLaunchKernelGGL(readk, dim3(n / 2048), dim3(256), 0, 0, a, o, n); });
     timeit("write only", 1.0 * bytes, [&] { hipLaunchKernelGGL(writek, dim3(n / 2048), dim3(256), 0, 0, b, n); });
+    // ---- does a copy care where source and destination sit?  K buffers of 1 GiB with 24 GiB spacers between
+    // them (held), matrix of copy1 rates source i -> destination j (round 5: the regions of DESIGN 4.1)
+    {
+        const int K = 8;
+        float4 *buf[K];
+        void *spacer[K];
+        int got = 0;
+        for (int i = 0; i < K; i++) {
+            if (hipMalloc(&buf[i], bytes) != hipSuccess) break;
+            hipMemset(buf[i], i, bytes);
+            got++;
+            if (hipMalloc(&spacer[i], (size_t)24 << 30) != hipSuccess) { spacer[i] = nullptr; }
+        }
+        printf("copy 1 float4/thread, source i (row) -> destination j (column), GB/s; buffers 25 GiB apart in allocation order\n");
+        for (int i = 0; i < got; i++) {
+            for (int j = 0; j < got; j++) {
+                if (i == j) { printf("    -  "); continue; }
+                float ms = 0;
+                for (int rep = 0; rep < 2; rep++) {
+                    hipEventRecord(e0);
+                    for (int k = 0; k < 10; k++) hipLaunchKernelGGL(copy1, dim3(n / 256), dim3(256), 0, 0, buf[i], buf[j], n);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    hipEventElapsedTime(&ms, e0, e1);
+                }
+                printf(" %6.0f", 2.0 * bytes / (ms / 10) / 1e6);
+            }
+            printf("\n");
+        }
+    }
     return 0;
 }
