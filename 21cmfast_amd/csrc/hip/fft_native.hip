@@ -3489,6 +3489,95 @@ extern "C" int c21hip_probe_pass_y2(float *work_a, float *work_b, int nx, int ny
     return st;
 }
 
+// Diagnostic: pass Y of ONE spectrum from `src` to `dst` (the same pointer: in place, what the product runs),
+// timed like c21hip_probe_pass_y2 (tools/scratch/placement_probe5.py: is an out-of-place pass Y into another region
+// of the HBM faster than the in-place one?)
+extern "C" int c21hip_probe_pass_y1(const float *src, float *dst, int nx, int ny, int nz, int reps, float *ms,
+                                    void *stream_) {
+    if (!c21hip_native_fft_supported(nx, ny, nz) || !src || !dst || reps < 1 || !ms) return C21CM_VALUE_ERROR;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = nz / 2;
+    const long nlines = (long)nx * ny;
+    LinePassArgs a{};
+    a.fp.type = -1;
+    a.n_y = ny;
+    a.n_z = nz;
+    a.out_scale = 1.0f;
+    a.n_geo = 2;
+    a.n_grids = 1;
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
+    a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
+    a.g1_strided = 1;
+    const float2 *s2 = reinterpret_cast<const float2 *>(src);
+    float2 *d2 = reinterpret_cast<float2 *>(dst);
+    geo_ptrs(a.g0, 0, s2, d2);
+    geo_ptrs(a.g1, 0, s2 + nlines * H, d2 + nlines * H);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        return C21CM_IO_ERROR;
+    }
+    int st = dispatch_line_pass<+1>(ny, a, 0, stream);
+    (void)hipEventRecord(e0, stream);
+    for (int r = 0; r < reps && !st; r++) st = dispatch_line_pass<+1>(ny, a, 0, stream);
+    (void)hipEventRecord(e1, stream);
+    float t = 0.f;
+    if (!st && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess)) {
+        (void)hipGetLastError();
+        st = C21CM_IO_ERROR;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (float)reps;
+    return st;
+}
+
+// ... and of TWO spectra, each from its source to its destination (diagnostic)
+extern "C" int c21hip_probe_pass_y2o(const float *src_a, float *dst_a, const float *src_b, float *dst_b, int nx, int ny,
+                                     int nz, int reps, float *ms, void *stream_) {
+    if (!c21hip_native_fft_supported(nx, ny, nz) || !src_a || !dst_a || !src_b || !dst_b || reps < 1 || !ms)
+        return C21CM_VALUE_ERROR;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int H = nz / 2;
+    const long nlines = (long)nx * ny;
+    LinePassArgs a{};
+    a.fp.type = -1;
+    a.n_y = ny;
+    a.n_z = nz;
+    a.out_scale = 1.0f;
+    a.n_geo = 2;
+    a.n_grids = 2;
+    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
+    a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
+    a.g1_strided = 1;
+    const float2 *sp[2] = {reinterpret_cast<const float2 *>(src_a), reinterpret_cast<const float2 *>(src_b)};
+    float2 *dp[2] = {reinterpret_cast<float2 *>(dst_a), reinterpret_cast<float2 *>(dst_b)};
+    for (int g = 0; g < 2; g++) {
+        geo_ptrs(a.g0, g, sp[g], dp[g]);
+        geo_ptrs(a.g1, g, sp[g] + nlines * H, dp[g] + nlines * H);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        return C21CM_IO_ERROR;
+    }
+    int st = dispatch_line_pass<+1>(ny, a, 0, stream);
+    (void)hipEventRecord(e0, stream);
+    for (int r = 0; r < reps && !st; r++) st = dispatch_line_pass<+1>(ny, a, 0, stream);
+    (void)hipEventRecord(e1, stream);
+    float t = 0.f;
+    if (!st && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess)) {
+        (void)hipGetLastError();
+        st = C21CM_IO_ERROR;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (float)reps;
+    return st;
+}
+
 // in-loop kernel timing, see KTimeScope
 extern "C" void c21hip_ktime_enable(int on) {
     for (auto &r : g_ktime) {
