@@ -764,6 +764,9 @@ def main():
                     "(incl. waiting for the slowest peer), finish -- device time of the last step",
                     "rccl_comm_count": rccl_ranks} if shard_phases is not None else {}),
                 "fft": "native" if native else "rocfft",
+                # where the work spectra sit in HBM (csrc/host/placement.c; decided once, in the warm-up)
+                "work_spectra_placement": "plain hipMalloc" if os.environ.get("C21CM_WS_PLACE", "1")[:1] == "0"
+                else "second spectrum of each two-grid sweep chosen by timed launches",
                 "global_xH": global_xh,
             },
             "roofline": roof,
