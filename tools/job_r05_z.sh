@@ -1,12 +1,10 @@
 #!/bin/bash
-# placement walk: a few processes on whatever box this is
-for rep in 1 2 3; do
-  python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-abi 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('512', 'ms', round(d['ms_per_step'],2), r['kernel'][:26], round(r['ms_per_launch'],4), [round(k['ms'],4) for k in r['other_kernels']])"
-done
-python bench.py --hii-dim 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-abi 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('1024', 'ms', round(d['ms_per_step'],1), r['kernel'][:26], round(r['ms_per_launch'],3), [round(k['ms'],3) for k in r['other_kernels']])"
+# what the driver runs at round end: smoke(), the gpu suite without xdist (timed), the default bench line
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+( time python -m pytest tests/ -x -q -m gpu > gpurun_out/suite_serial.out 2>&1 ) 2>&1 | grep real
+grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" gpurun_out/suite_serial.out | tail -2
+( time python bench.py > gpurun_out/bench_default.json 2>/dev/null ) 2>&1 | grep real
+python -c "
+import json
+d=json.loads(open('gpurun_out/bench_default.json').read().strip().splitlines()[-1]); r=d['roofline']
+print(round(d['ms_per_step'],2), r['kernel'][:30], round(r['ms_per_launch'],4), round(r['frac'],3), r.get('traffic_profile_stale'), 'rloop', round(r['r_loop']['frac'],3), 'cpu', d['cpu_baseline']['value'], d['config']['work_spectra_placement'])"
