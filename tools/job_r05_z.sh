@@ -1,10 +1,11 @@
 #!/bin/bash
-# what the driver runs at round end: smoke(), the gpu suite without xdist (timed), the default bench line
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-( time python -m pytest tests/ -x -q -m gpu > gpurun_out/suite_serial.out 2>&1 ) 2>&1 | grep real
-grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" gpurun_out/suite_serial.out | tail -2
-( time python bench.py > gpurun_out/bench_default.json 2>/dev/null ) 2>&1 | grep real
-python -c "
-import json
-d=json.loads(open('gpurun_out/bench_default.json').read().strip().splitlines()[-1]); r=d['roofline']
-print(round(d['ms_per_step'],2), r['kernel'][:30], round(r['ms_per_launch'],4), round(r['frac'],3), r.get('traffic_profile_stale'), 'rloop', round(r['r_loop']['frac'],3), 'cpu', d['cpu_baseline']['value'], d['config']['work_spectra_placement'])"
+# single-grid pass Y out of place (pass X into a scratch spectrum, pass Y from there into the work spectrum): A/B
+for rep in 1 2; do for o in 1 0; do
+  echo "== C21CM_Y_OOP=$o"
+  C21CM_Y_OOP=$o python bench.py --mode erfc --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('erfc ms', round(d['ms_per_step'],2), r['kernel'][:30], round(r['ms_per_launch'],4), [(k['kernel'][:24], round(k['ms'],4)) for k in r['other_kernels']], 'xH', d['config'].get('global_xH'))"
+  C21CM_Y_OOP=$o PYTHONPATH=. python tools/time_abi_ionize.py 512 0 2>/dev/null | tail -1 | cut -c1-150
+done; done
+for o in 1 0; do echo "== C21CM_Y_OOP=$o"; C21CM_Y_OOP=$o python tools/time_coeval_ts.py 512 1024 6.0 2>/dev/null | tail -1 | cut -c1-260; done
