@@ -664,6 +664,9 @@ ts_accumulate2_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
 // 16-byte read per integral) -- so a workgroup is 1024 threads, one per CU (16 waves: the loop is
 // issue-bound, not occupancy-bound, at ~40 slots per cell and shell); two cells per thread with the
 // lookup written on 2-vectors so that the compiler emits packed fp32 instructions for both cells.
+#ifndef C21X_TS_PACKED
+#define C21X_TS_PACKED 0
+#endif
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kAccBlock = 1024;
 constexpr int kWP = 3 * C21CM_X_INT_NXHII;  // (w[m], w[m+1]) pairs per shell: heat, ion, lya
@@ -742,6 +745,7 @@ ts_accumulate3_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
             if (R > 0) g = ga2[(size_t)(R - 1) * nitems + it];  // the next (smaller) shell
             const ShellLookup L = LK[R];
             const float *y = TAB + R * TS;
+#if C21X_TS_PACKED  // (the round-3 form: 2-vectors so that the compiler emits packed fp32 instructions)
             const v2f d = {c.x, c.y};
             const v2f x = d * L.growth;
             const v2f t = __builtin_elementwise_fma(d, (v2f){L.gw, L.gw}, (v2f){L.off, L.off});
@@ -763,6 +767,37 @@ ts_accumulate3_kernel(c21hip_ts_args a, const float *__restrict__ prev_xe,
                 tv = y0 + r;
             }
             const v2f sf = (x + 1.0f) * tv;  // del_fcoll_Rct is a float upstream
+#else
+            // the same arithmetic on scalars (round 5: a packed fp32 instruction issues in 8 cycles per wave on
+            // gfx950, a plain one in 2.7 -- tools/valu_rate_probe.hip; the operations and their order are those of
+            // the packed form, so the sums are the same bits)
+            float2 sf;
+            {
+                const float cc[2] = {c.x, c.y};
+                float sv[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float dd = cc[e];
+                    const float xg = __fmul_rn(dd, L.growth);
+                    const float tt = __fmaf_rn(dd, L.gw, L.off);
+                    const int ii = min(max((int)floorf(tt), 0), C21CM_NDELTA_TABLE - 2);
+                    const float ipf = __fsub_rn(tt, (float)ii);
+                    const float ya = y[ii], yb = y[ii + 1];
+                    const float rr = __fmul_rn(ipf, __fsub_rn(yb, ya));
+                    float tvv;
+                    if (MODE == 1) {
+                        const float L_hi = 1.44269502162933349609375f, L_lo = 1.925963033500011e-8f;
+                        const float nn = rintf(__fmul_rn(ya, L_hi));
+                        const float ff = __fadd_rn(__fmaf_rn(ya, L_hi, -nn), __fmaf_rn(ya, L_lo, __fmul_rn(rr, L_hi)));
+                        tvv = ldexpf(__builtin_amdgcn_exp2f(ff), (int)fmaxf(nn, -200.f));
+                    } else {
+                        tvv = __fadd_rn(ya, rr);
+                    }
+                    sv[e] = __fmul_rn(__fadd_rn(xg, 1.0f), tvv);  // del_fcoll_Rct is a float upstream
+                }
+                sf = make_float2(sv[0], sv[1]);
+            }
+#endif
             const double xs[2] = {(double)sf.x, (double)sf.y};
             const double2 *wr = WP + R * kWP;
             const double *sr = SS + 3 * R;

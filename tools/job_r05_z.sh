@@ -1,11 +1,13 @@
 #!/bin/bash
-# single-grid pass Y out of place (pass X into a scratch spectrum, pass Y from there into the work spectrum): A/B
-for rep in 1 2; do for o in 1 0; do
-  echo "== C21CM_Y_OOP=$o"
-  C21CM_Y_OOP=$o python bench.py --mode erfc --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('erfc ms', round(d['ms_per_step'],2), r['kernel'][:30], round(r['ms_per_launch'],4), [(k['kernel'][:24], round(k['ms'],4)) for k in r['other_kernels']], 'xH', d['config'].get('global_xH'))"
-  C21CM_Y_OOP=$o PYTHONPATH=. python tools/time_abi_ionize.py 512 0 2>/dev/null | tail -1 | cut -c1-150
-done; done
-for o in 1 0; do echo "== C21CM_Y_OOP=$o"; C21CM_Y_OOP=$o python tools/time_coeval_ts.py 512 1024 6.0 2>/dev/null | tail -1 | cut -c1-260; done
+# spin-temperature accumulate kernel: scalar lookup (default now) against the packed 2-vector form (variants/tspk)
+python -m pytest tests/test_gpu_ts.py tests/test_gpu_ts_shard.py tests/test_gpu_config5.py -x -q -m gpu 2>&1 | grep -v "^HIP version\|^ROCm version\|^Hostname\|^Librccl\|^RCCL" | tail -3
+REPO=$PWD; export TMPDIR=/tmp
+for v in default tspk; do
+  lib=$REPO/variants/$v/lib21cmfast_hip.so; [ $v = default ] && lib=$REPO/21cmfast_amd/lib21cmfast_hip.so
+  cd /tmp
+  C21CM_LIB=$lib timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_ts_$v -o q -- \
+      python $REPO/tools/time_coeval_ts.py 512 1024 12.0 > $REPO/gpurun_out/prof_ts_$v.out 2>/dev/null
+  cd $REPO
+  echo "== $v"; tail -1 gpurun_out/prof_ts_$v.out | cut -c1-230
+  python tools/kernel_stats_brief.py gpurun_out/prof_ts_$v/q_kernel_stats.csv 40 | grep "ts_accumulate\|sfrd_sum\|ts_cell"
+done
