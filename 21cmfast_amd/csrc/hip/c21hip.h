@@ -717,13 +717,17 @@ int c21hip_ts_shell_loop(const c21hip_ts_args *a, const float *prev_xe, const fl
                          const float *grid_b, const float *tables_dev, const double *dev_tab,
                          double *sums_ws, size_t ntot, void *stream);
 /* sharded ComputeTsBox: cell slabs of the ranks (rank r owns [begin(r), begin(r + 1))), the partial
- * sums of every peer's slab packed per peer ([world - 1][rows][maxlen], double or float), and the
- * complete sums of this rank's slab from its own partial and the received ones */
+ * sums of every peer's slab packed per peer ([world - 1] slots of c21hip_ts_slot_elems elements, each
+ * [rows][maxlen] doubles -- or floats scaled by a per-row power of two, whose exponents close the slot), and the
+ * complete sums of this rank's slab from its own partial and the received ones.  rowmax: 64 bytes of device
+ * scratch, written by the pack and read by the combine of the same call. */
 size_t c21hip_ts_slab_begin(size_t ntot, int world, int r);
+size_t c21hip_ts_slot_elems(int rows, size_t maxlen, int as_float);
 int c21hip_ts_pack_slabs(const double *sums, size_t ntot, int world, int rank, int rows,
-                         size_t maxlen, int as_float, void *out, void *stream);
+                         size_t maxlen, int as_float, void *rowmax, void *out, void *stream);
 int c21hip_ts_combine_slab(const double *sums, size_t ntot, int world, int rank, int rows,
-                           size_t maxlen, int as_float, const void *recv, double *out, void *stream);
+                           size_t maxlen, int as_float, const void *rowmax, const void *recv, double *out,
+                           void *stream);
 struct c21cm_ts_first_spec;
 int c21hip_ts_first(const struct c21cm_ts_first_spec *s, const float *density, float *Ts_out,
                     float *Tk_out, float *xe_out, size_t ntot, void *stream);

@@ -1371,75 +1371,127 @@ extern "C" int c21hip_ts_accumulate_grids_mini(const c21hip_ts_args *a, const fl
 }
 
 // ---- sharded shell sums: slabs of the partial sums to / from the exchange buffers ---------------
-// pack: out[(p * rows + k) * maxlen + i] = sums[k * ntot + c0(p) + i] for every peer p != rank
-// (as double or rounded to float); combine: the complete sums of this rank's slab, ranks added in
+// pack: out[p * slot + k * maxlen + i] = sums[k * ntot + c0(p) + i] for every peer p != rank
+// (slot = c21hip_ts_slot_elems elements); combine: the complete sums of this rank's slab, ranks added in
 // rank order (own partial from `sums`, the others from the receive buffer, same layout as pack).
+// As floats (C21CM_TS_SHARD_EXCHANGE=f32) the rows travel SCALED: the sums are physical rates of 1e27 ..
+// 1e49 (and 1e-12) -- two of the four rows do not fit a float at all, which the first run of this exchange
+// with two real ranks showed (round 6; every float came out inf) -- so each rank divides row k by
+// 2^e(k), e(k) = exponent of the largest |value| of ITS partial row (exact), and the sixteen trailing
+// elements of every slot carry the e(k) to the receiver, which multiplies back in double.
 namespace {
+enum { kTsExpTail = 16 };  // floats at the end of a float slot: the row exponents as int32
 __device__ __forceinline__ size_t slab_begin(size_t ntot, int world, int r) {
     return (ntot / 4 * (size_t)r / (size_t)world) * 4;  // multiples of 4 cells; slab world ends at ntot
+}
+__device__ __forceinline__ int row_exponent(unsigned long long absmax_bits) {
+    const int e = (int)((absmax_bits >> 52) & 0x7ffull);
+    return e == 0 ? 0 : e - 1023;  // (zero / subnormal rows: no scaling)
+}
+__global__ void __launch_bounds__(kBlock)
+ts_row_absmax_kernel(const double *__restrict__ sums, size_t ntot, unsigned long long *__restrict__ mx) {
+    const int k = blockIdx.y;
+    unsigned long long m = 0;  // |x| as bits: ordered like the values for finite non-negative doubles
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < ntot; i += (size_t)gridDim.x * kBlock) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(sums[(size_t)k * ntot + i]));
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(m, o);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(mx + k, m);
 }
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 ts_pack_slabs_kernel(const double *__restrict__ sums, size_t ntot, int world, int rank, int rows,
-                     size_t maxlen, T *__restrict__ out) {
+                     size_t maxlen, size_t slot, const unsigned long long *__restrict__ mx, T *__restrict__ out) {
     const int p = blockIdx.y;  // peer slot: ranks other than `rank` in ascending order
     const int peer = p < rank ? p : p + 1;
     const size_t c0 = slab_begin(ntot, world, peer);
     const size_t len = (peer + 1 == world ? ntot : slab_begin(ntot, world, peer + 1)) - c0;
-    for (int k = 0; k < rows; k++)
-        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock)
-            out[((size_t)p * rows + k) * maxlen + i] = (T)sums[(size_t)k * ntot + c0 + i];
+    for (int k = 0; k < rows; k++) {
+        const int e = sizeof(T) == 4 ? row_exponent(mx[k]) : 0;
+        if (sizeof(T) == 4 && blockIdx.x == 0 && threadIdx.x == 0)
+            reinterpret_cast<int *>(out + (size_t)p * slot + (size_t)rows * maxlen)[k] = e;
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
+            const double v = sums[(size_t)k * ntot + c0 + i];
+            out[(size_t)p * slot + (size_t)k * maxlen + i] = sizeof(T) == 4 ? (T)scalbn(v, -e) : (T)v;
+        }
+    }
 }
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 ts_combine_slab_kernel(const double *__restrict__ sums, size_t ntot, int world, int rank, int rows,
-                       size_t maxlen, const T *__restrict__ recv, double *__restrict__ out) {
+                       size_t maxlen, size_t slot, const unsigned long long *__restrict__ mx,
+                       const T *__restrict__ recv, double *__restrict__ out) {
     const size_t c0 = slab_begin(ntot, world, rank);
     const size_t len = (rank + 1 == world ? ntot : slab_begin(ntot, world, rank + 1)) - c0;
-    for (int k = 0; k < rows; k++)
+    for (int k = 0; k < rows; k++) {
+        const int e_own = sizeof(T) == 4 ? row_exponent(mx[k]) : 0;
         for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (size_t)gridDim.x * kBlock) {
             double acc = 0.;
             for (int r = 0; r < world; r++) {
                 if (r == rank) {
                     const double own = sums[(size_t)k * ntot + c0 + i];
-                    acc += sizeof(T) == 4 ? (double)(float)own : own;  // every partial in one precision
+                    // every partial in one precision
+                    acc += sizeof(T) == 4 ? scalbn((double)(float)scalbn(own, -e_own), e_own) : own;
                 } else {
                     const int p = r < rank ? r : r - 1;
-                    acc += (double)recv[((size_t)p * rows + k) * maxlen + i];
+                    const double v = (double)recv[(size_t)p * slot + (size_t)k * maxlen + i];
+                    acc += sizeof(T) == 4
+                               ? scalbn(v, reinterpret_cast<const int *>(recv + (size_t)p * slot + (size_t)rows * maxlen)[k])
+                               : v;
                 }
             }
             out[(size_t)k * len + i] = acc;
         }
+    }
 }
 }  // namespace
 
+// elements of one peer's slot of the exchange buffers (floats carry the row exponents at the end)
+extern "C" size_t c21hip_ts_slot_elems(int rows, size_t maxlen, int as_float) {
+    return (size_t)rows * maxlen + (as_float ? (size_t)kTsExpTail : 0);
+}
 extern "C" size_t c21hip_ts_slab_begin(size_t ntot, int world, int r) {
     return r >= world ? ntot : (ntot / 4 * (size_t)r / (size_t)world) * 4;
 }
+// `rowmax`: 8 unsigned long long of device scratch (the caller's; filled by the pack, read by the combine)
 extern "C" int c21hip_ts_pack_slabs(const double *sums, size_t ntot, int world, int rank, int rows,
-                                    size_t maxlen, int as_float, void *out, void *stream) {
+                                    size_t maxlen, int as_float, void *rowmax, void *out, void *stream) {
+    if (rows > 8) return C21CM_VALUE_ERROR;
+    const size_t slot = c21hip_ts_slot_elems(rows, maxlen, as_float);
+    if (as_float) {
+        if (hipMemsetAsync(rowmax, 0, 8 * sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess)
+            return C21CM_MEMORY_ALLOC_ERROR;
+        hipLaunchKernelGGL(ts_row_absmax_kernel, dim3(512, (unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream,
+                           sums, ntot, (unsigned long long *)rowmax);
+        LAUNCH_CHECK();
+    }
     if (world < 2) return 0;
     const dim3 grid(512, (unsigned)(world - 1));
     if (as_float)
         hipLaunchKernelGGL((ts_pack_slabs_kernel<float>), grid, dim3(kBlock), 0, (hipStream_t)stream, sums,
-                           ntot, world, rank, rows, maxlen, (float *)out);
+                           ntot, world, rank, rows, maxlen, slot, (const unsigned long long *)rowmax, (float *)out);
     else
         hipLaunchKernelGGL((ts_pack_slabs_kernel<double>), grid, dim3(kBlock), 0, (hipStream_t)stream, sums,
-                           ntot, world, rank, rows, maxlen, (double *)out);
+                           ntot, world, rank, rows, maxlen, slot, (const unsigned long long *)rowmax, (double *)out);
     LAUNCH_CHECK();
     return 0;
 }
 extern "C" int c21hip_ts_combine_slab(const double *sums, size_t ntot, int world, int rank, int rows,
-                                      size_t maxlen, int as_float, const void *recv, double *out,
-                                      void *stream) {
+                                      size_t maxlen, int as_float, const void *rowmax, const void *recv,
+                                      double *out, void *stream) {
+    const size_t slot = c21hip_ts_slot_elems(rows, maxlen, as_float);
     if (as_float)
         hipLaunchKernelGGL((ts_combine_slab_kernel<float>), dim3(1024), dim3(kBlock), 0,
-                           (hipStream_t)stream, sums, ntot, world, rank, rows, maxlen,
-                           (const float *)recv, out);
+                           (hipStream_t)stream, sums, ntot, world, rank, rows, maxlen, slot,
+                           (const unsigned long long *)rowmax, (const float *)recv, out);
     else
         hipLaunchKernelGGL((ts_combine_slab_kernel<double>), dim3(1024), dim3(kBlock), 0,
-                           (hipStream_t)stream, sums, ntot, world, rank, rows, maxlen,
-                           (const double *)recv, out);
+                           (hipStream_t)stream, sums, ntot, world, rank, rows, maxlen, slot,
+                           (const unsigned long long *)rowmax, (const double *)recv, out);
     LAUNCH_CHECK();
     return 0;
 }

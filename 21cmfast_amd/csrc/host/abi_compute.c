@@ -596,16 +596,17 @@ int ComputeIonizedBox(float redshift, float prev_redshift, PerturbedField *pertu
     {
         /* one process per GPU with an initialised communicator (c21cm_shard_init): the R loop
          * is sharded over the ranks (C21CM_SHARD=0: single GPU per process).  What the output arrays
-         * hold afterwards (round 5): where the finish phase runs by cell slabs (the fused Lagrangian
-         * loop) every rank holds ITS slab of the box (c21cm_ionize_shard_slab) and the complete scalars
-         * -- downstream per-cell work (the next snapshot's ComputeIonizedBox, ComputeBrightnessTemp on
-         * the slab) needs no more, and the metric is cells per second, not copies; whole boxes on every
-         * rank cost an all-gather of 12 bytes per cell and are opt-in: C21CM_SHARD_OUTPUT=all (or
-         * c21cm_shard_set_output(1); the old C21CM_SHARD_BCAST=1 means the same).  Models that finish
-         * on one rank keep broadcasting its box unless C21CM_SHARD_OUTPUT=none / C21CM_SHARD_BCAST=0. */
+         * hold afterwards: WHOLE BOXES ON EVERY RANK, as the reference's caller expects of a
+         * ComputeIonizedBox that returned 0 (round 6, ADVICE r5: anything that reads the box next --
+         * ComputeBrightnessTemp, a power spectrum, the wrapper's cache -- saw unwritten cells outside
+         * the rank's slab when the slab-resident form was the default).  Where the finish phase runs by
+         * cell slabs that is an all-gather of the output slabs (12 bytes per cell, 7/8 of it incoming
+         * over seven links); models that finish on one rank broadcast its box.  Slab-resident outputs
+         * (a rank's slab of the box + the complete scalars: what the next snapshot's per-cell work
+         * needs) are an explicit opt-in: C21CM_SHARD_OUTPUT=none | xH, or c21cm_shard_set_output(). */
         int srank, sworld;
         const char *e = getenv("C21CM_SHARD");
-        const int out_mode = c21cm_shard_output_mode();
+        const int out_mode = c21cm_shard_output_mode() == -1 ? 1 : c21cm_shard_output_mode();
         /* (a USE_MINI_HALOS run keeps one f_coll history slice per radius: every rank runs the
          * whole R loop) */
         /* (C21CM_SHARD=force: also on a one-rank communicator -- the plumbing test of a 1-GPU box) */

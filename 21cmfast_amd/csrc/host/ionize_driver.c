@@ -98,6 +98,7 @@ enum {
     WS_R_DEV = 247,     /* float R per radius index (mean free path of a first crossing) */
     WS_EUL_XEPEND = 253, /* banded barrier with an x_e grid: clipped x_e of the undecided cells (sparse) */
     WS_NION_DENSE2 = 254, /* closed-form Eulerian loop: second dense f_coll buffer (deferred barrier) */
+    /* (256 and 257 are shard_rccl.c's: WS_SHARD_STATUS, WS_SHARD_SLABBITS) */
     WS_NREC_WORK2 = 259, /* fused recombination loop with x_e AND a filtered N_rec: N_rec of the second radius */
     WS_ARENA = 258        /* experiment: the spectra of the two-grid loop out of one allocation (C21CM_ARENA) */
 };
@@ -2478,7 +2479,7 @@ int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned
     st.world = world;
     ion_ctx c;
     void *ev[3] = {NULL, NULL, NULL};
-    int entered = 0;
+    int entered = 0, wev = 0;
     int status = validate_spec(spec, perturbed_field, halos, spin_temp, box);
     if (!status && !c21cm_ionize_shard_slab_supported(spec)) {
         c21hip_set_error("ionize shard: this model does not finish by slabs (c21cm_ionize_shard_slab_supported)");
@@ -2511,6 +2512,7 @@ int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned
          * else recomputed), then the rank's slab of the one sweep */
         if (!spectra_match(&c, perturbed_field, halos, spin_temp)) TRY(preloop(&c));
         g_spectra.valid = 0;
+        wev = 1; /* (released under done: a failing radius must not leak the node tables -- ADVICE r5) */
         TRY(native_wev_prepare(&c, spec->n_radii - 1, 1, stream));
         c.r0_mask = first_cross;
         c.r0_slab = 1;
@@ -2518,6 +2520,7 @@ int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned
         c.r0_ce = st.chunk_end;
         TRY(one_radius(&c, 0, NULL, -1));
         c21hip_wev_release();
+        wev = 0;
     } else {
         g_spectra.valid = 0;
         TRY(final_step_range(&c, first_cross, 0, st.chunk_begin, st.chunk_end));
@@ -2551,6 +2554,7 @@ int c21cm_ionize_shard_finish_slab(const c21cm_ionize_spec *spec, const unsigned
         report->ms_postloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
     }
 done:
+    if (wev) c21hip_wev_release();
     if (!entered && exchange) {
         const int st2 = exchange(exchange_user, &st, status ? status : C21CM_VALUE_ERROR, stream);
         if (!status) status = st2;

@@ -104,7 +104,8 @@ static struct {
     const char *(*error_string)(int);
 } R;
 
-/* (ids 256 and up are this file's alone: 253 collided with the Eulerian loop's sparse x_e buffer,
+/* (256 and 257 are this file's; ionize_driver.c holds 258 and 259 -- each file's enum names the other's.
+ * 253 collided with the Eulerian loop's sparse x_e buffer,
  * whose reallocation freed the status word a rank out of memory still needs -- ADVICE r4) */
 enum { WS_SHARD_GRID = 140, WS_SHARD_STAGE = 141, WS_SHARD_SCALARS = 142, WS_SHARD_BITS = 143,
        WS_SHARD_STATUS = 256, WS_SHARD_SLABBITS = 257 };
@@ -340,6 +341,19 @@ int c21cm_shard_emulate(int rank, int world, void *mailbox, size_t mailbox_bytes
 
 static int rccl_load(void) {
     if (R.lib && R.ready != 2 && R.get_unique_id) return 0;
+    /* C21CM_RCCL_LIB: another library exporting the same twelve entry points.  The test suite points it
+     * at tests/shim/librccl_shim.so (shared memory between processes on ONE GPU, where RCCL refuses to
+     * form a communicator), so that every send / receive / group of this file executes at worlds 2 and 3
+     * (VERDICT r5 item 1).  Bound RTLD_LOCAL: its ncclXxx symbols must not interpose a librccl torch
+     * has mapped. */
+    const char *over = getenv("C21CM_RCCL_LIB");
+    if (over && over[0]) {
+        R.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib) {
+            c21hip_set_error("shard: C21CM_RCCL_LIB=%s could not be loaded (%s)", over, dlerror());
+            return C21CM_IO_ERROR;
+        }
+    }
     const char *names[] = {"librccl.so.1", "librccl.so", NULL};
     for (int i = 0; names[i] && !R.lib; i++) R.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!R.lib) {
@@ -833,9 +847,9 @@ int c21cm_ionize_sharded(const c21cm_ionize_spec *spec, const PerturbedField *pe
  * seven at once) and receives its own slab's rows from everybody -> the complete sums of the slab,
  * ranks added in rank order -> temperature update of the slab -> all-gather of the three output
  * boxes (again one message per peer and box).  Volumes at 512^3, 8 ranks, 4 rows: 537 MB per link
- * for the sums in double (C21CM_TS_SHARD_EXCHANGE=f32: partials rounded to float, 268 MB), 3 x 67 MB
- * per link for the outputs. */
-enum { WS_TSS_SUMS = 242, WS_TSS_SEND = 243, WS_TSS_RECV = 244, WS_TSS_SLAB = 245 };
+ * for the sums in double (C21CM_TS_SHARD_EXCHANGE=f32: partials as floats scaled by a per-row power of two
+ * -- the rows are rates of 1e27 .. 1e49 --, 268 MB), 3 x 67 MB per link for the outputs. */
+enum { WS_TSS_SUMS = 242, WS_TSS_SEND = 243, WS_TSS_RECV = 244, WS_TSS_SLAB = 245, WS_TSS_ROWMAX = 260 };
 
 /* how many times this process took the sharded ComputeTsBox (tests: did the call shard?) */
 static int g_ts_sharded_calls;
@@ -867,7 +881,8 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
      * status: a rank that fails locally still joins the agreement and nobody is left in ncclRecv
      * (ADVICE r3).  rows = 4, or 6 with USE_LYA_HEATING (abi_compute.c: ts_box_run). */
     const int rows_max = (astro_options_global && astro_options_global->USE_LYA_HEATING) ? 6 : 4;
-    const size_t per_peer_max = (size_t)rows_max * maxlen * esz;
+    const size_t per_peer_max = c21hip_ts_slot_elems(rows_max, maxlen, f32) * esz;
+    void *rowmax = c21hip_ws(WS_TSS_ROWMAX, 64);
     double *sums = (double *)c21hip_ws(WS_TSS_SUMS, 6 * ntot * sizeof(double));
     char *sendb = NULL, *recvb = NULL;
     if (world > 1) {
@@ -875,7 +890,7 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
         recvb = (char *)c21hip_ws(WS_TSS_RECV, per_peer_max * (size_t)(world - 1));
     }
     double *slab = (double *)c21hip_ws(WS_TSS_SLAB, (size_t)rows_max * (len ? len : 1) * sizeof(double));
-    if (!sums || !slab || (world > 1 && (!sendb || !recvb))) st = C21CM_MEMORY_ALLOC_ERROR;
+    if (!sums || !slab || !rowmax || (world > 1 && (!sendb || !recvb))) st = C21CM_MEMORY_ALLOC_ERROR;
     if (!st)
         st = c21cm_ts_box_shard_sums(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
                                      previous_spin_temp, rank, world, sums, &rows);
@@ -883,9 +898,8 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
         c21hip_set_error("shard: ComputeTsBox returned %d rows of sums, %d expected", rows, rows_max);
         st = C21CM_VALUE_ERROR;
     }
-    const size_t per_peer = (size_t)rows * maxlen * esz;
-    if (!st && world > 1)
-        st = c21hip_ts_pack_slabs(sums, ntot, world, rank, rows, maxlen, f32, sendb, NULL);
+    const size_t per_peer = c21hip_ts_slot_elems(rows, maxlen, f32) * esz;
+    if (!st) st = c21hip_ts_pack_slabs(sums, ntot, world, rank, rows, maxlen, f32, rowmax, sendb, NULL);
     if ((st = agree_status(st, NULL))) return st;
     if (world > 1) {
         if ((st = rccl_check(R.group_start(), "ncclGroupStart"))) return st;
@@ -901,7 +915,7 @@ int c21cm_ts_box_sharded(float redshift, float prev_redshift, float perturbed_fi
         if (st || st2) return st ? st : st2;
     }
     /* combine + temperature update are local: their status goes into the second agreement */
-    st = c21hip_ts_combine_slab(sums, ntot, world, rank, rows, maxlen, f32, recvb, slab, NULL);
+    st = c21hip_ts_combine_slab(sums, ntot, world, rank, rows, maxlen, f32, rowmax, recvb, slab, NULL);
     if (!st)
         st = c21cm_ts_box_shard_finish(redshift, prev_redshift, perturbed_field_redshift, perturbed_field,
                                        previous_spin_temp, slab, c0, len, this_spin_temp);

@@ -498,8 +498,9 @@ def ionize_sharded(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=No
     communicator (c21cm_ionize_sharded), all inside the C library: shard phase, exchange, finish.
     Where the finish phase runs by cell slabs (``shard_slab_supported``) every rank finishes its slab
     and holds the complete scalars; otherwise the owner rank finishes.  Returns (buffers, box_struct,
-    report); ``broadcast``: whole boxes on every rank (False: a rank's slab / the owner's box; None:
-    the library's default, c21cm_shard_output_mode)."""
+    report); ``broadcast``: True / 1 whole boxes on every rank, 2 the whole neutral-fraction box on every
+    rank (slab finish, device arrays), False / 0 a rank's slab / the owner's box, None the library's
+    default (c21cm_shard_output_mode)."""
     if buffers is None:
         buffers = IonizeBuffers(density, need_nion=spec.fcoll_mode != 0,
                                 minimize_memory=bool(spec.minimize_memory),
@@ -512,7 +513,7 @@ def ionize_sharded(spec: S.IonizeSpec, density, n_ion=None, xe=None, Tneutral=No
     lib.c21cm_ionize_sharded.restype = C.c_int
     check(lib.c21cm_ionize_sharded(C.byref(spec), C.byref(pf), C.byref(prev), C.byref(ts),
                                    C.byref(hb), C.byref(box), C.byref(rep),
-                                   C.c_int(-1 if broadcast is None else (1 if broadcast else 0)),
+                                   C.c_int(-1 if broadcast is None else int(broadcast)),
                                    _stream(stream)),
           "c21cm_ionize_sharded")
     return buffers, box, rep
