@@ -31,6 +31,9 @@ int c21hip_ws_adopt(int slot, void *ptr, size_t bytes);
 void *c21hip_raw_alloc(size_t bytes);
 void c21hip_raw_free(void *p);
 size_t c21hip_free_bytes(void);
+size_t c21hip_total_bytes(void);
+/* processes holding memory on the current device, this one included (KFD sysfs); -1: unknown */
+int c21hip_device_tenants(void);
 int c21hip_probe_pass_y2(float *work_a, float *work_b, int nx, int ny, int nz, int reps, float *ms, void *stream);
 /* host/placement.c: the workspace slot `slot_new` (bytes) filled with a buffer that sits well with the one in
  * `slot_partner` for two-grid launches; plain c21hip_ws where the walk does not apply */

@@ -8,6 +8,8 @@
 // next call; c21cm_release_device_cache() returns them.
 #include <hip/hip_runtime.h>
 
+#include <dirent.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -252,6 +254,75 @@ extern "C" size_t c21hip_free_bytes(void) {
         return 0;
     }
     return fr;
+}
+
+extern "C" size_t c21hip_total_bytes(void) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return tot;
+}
+
+// How many processes hold memory on the current device (this one included), from the KFD's per-process
+// accounting: /sys/class/kfd/kfd/proc/<pid>/vram_<gpu_id>, the gpu_id found by matching the device's PCI
+// location against /sys/class/kfd/kfd/topology/nodes/*/properties.  -1: unknown (no sysfs, container without
+// it, ...).  The placement walk (csrc/host/placement.c) holds a large part of the free memory for some
+// milliseconds: it only does so when this says the process has the device to itself.
+extern "C" int c21hip_device_tenants(void) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    const long want_loc = ((long)prop.pciBusID << 8) | ((long)prop.pciDeviceID << 3);
+    const long want_dom = prop.pciDomainID;
+    long gpu_id = -1;
+    int n_gpu_nodes = 0;
+    long only_gpu_id = -1;
+    for (int node = 0; node < 64 && gpu_id < 0; node++) {
+        char path[160];
+        snprintf(path, sizeof(path), "/sys/class/kfd/kfd/topology/nodes/%d/gpu_id", node);
+        FILE *f = fopen(path, "r");
+        if (!f) break;
+        long id = 0;
+        const int ok = fscanf(f, "%ld", &id) == 1;
+        fclose(f);
+        if (!ok || id == 0) continue;  // (CPU nodes, and GPUs this container may not see, read 0)
+        n_gpu_nodes++;
+        only_gpu_id = id;
+        snprintf(path, sizeof(path), "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+        f = fopen(path, "r");
+        if (!f) continue;
+        char key[64];
+        long val = 0, loc = -1, dom = 0;
+        while (fscanf(f, "%63s %ld", key, &val) == 2) {
+            if (!strcmp(key, "location_id")) loc = val;
+            if (!strcmp(key, "domain")) dom = val;
+        }
+        fclose(f);
+        if ((loc & ~7L) == want_loc && dom == want_dom) gpu_id = id;
+    }
+    if (gpu_id < 0 && n_gpu_nodes == 1) gpu_id = only_gpu_id;  // one visible GPU: it is this one
+    if (gpu_id < 0) return -1;
+    DIR *d = opendir("/sys/class/kfd/kfd/proc");
+    if (!d) return -1;
+    int tenants = 0;
+    struct dirent *e;
+    while ((e = readdir(d)) != NULL) {
+        if (e->d_name[0] < '0' || e->d_name[0] > '9') continue;
+        char path[200];
+        snprintf(path, sizeof(path), "/sys/class/kfd/kfd/proc/%s/vram_%ld", e->d_name, gpu_id);
+        FILE *f = fopen(path, "r");
+        if (!f) continue;
+        unsigned long long bytes = 0;
+        if (fscanf(f, "%llu", &bytes) == 1 && bytes > (64ull << 20)) tenants++;  // (a bare context holds a few MB)
+        fclose(f);
+    }
+    closedir(d);
+    return tenants;
 }
 
 static unsigned long g_ws_generation = 0;

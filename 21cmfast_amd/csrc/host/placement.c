@@ -1,18 +1,21 @@
-/* Placement of work spectra in HBM (round 5): see the comment of c21_place_work_partner. */
+/* Placement of work spectra in HBM (round 5; made safe for shared devices in round 6): see c21_place_work_partner. */
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <sys/file.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "c21cm_grid.h"
 #include "../hip/c21hip.h"
 
-/* Placement of the second work spectrum of a two-grid launch (round 5, late).  Two buffers that one launch
- * WRITES (pass X's outputs, pass Y in place) must not sit in the same physical region of the HBM: a pair from one
- * region costs pass Y 17-21 % at 1024^3 and 10-13 % at 512^3 (pair matrices in profiles/r05_placement_study.txt:
- * classes contiguous in allocation order; on an empty GPU the other class starts 77-136 GB into a linear walk, on
- * a used one after 32 GB; reads do not care, neither do single-grid launches).  hipMalloc carves consecutive
- * allocations out of one region, so the default is the slow pair more often than not -- the "two speeds" of the
- * line passes since round 3.  The class turned out to be the parity of the 32 GiB stripe of PHYSICAL memory a
- * buffer lies in (study, section 12); virtual addresses do not tell it; a timed launch does:
+/* Placement of the second work spectrum of a two-grid launch.  Two buffers that one launch WRITES (pass X's
+ * outputs, pass Y in place) must not sit in 32 GiB stripes of PHYSICAL memory of equal parity: such a pair costs
+ * pass Y 17-21 % at 1024^3 and 10-13 % at 512^3 (profiles/r05_placement_study.txt, sections 1, 11, 12; reads do not
+ * care, neither do single-grid launches).  hipMalloc carves consecutive allocations out of one stripe, so the
+ * default is the slow pair more often than not -- the "two speeds" of the line passes since round 3.  Virtual
+ * addresses do not tell the stripe; a timed launch does:
  *   phase 1: chunks of 16 GB (at least the buffer's size) are allocated one after the other and all held; the head
  *            of each is timed with the partner in the two-grid pass Y (c21hip_probe_pass_y2) until two chunks
  *            differ by 8 % (the classes are 13-17 % apart): the faster one marks a good region;
@@ -20,73 +23,174 @@
  *            fast: small requests are served from the small holes first -- next to the partner, as a rule -- and
  *            from the freed chunk once those are filled;
  *   then everything but the chosen buffer is freed and the workspace slot adopts it.
- * Up to C21CM_WS_PLACE_GB (default 200) GB are held for some milliseconds, three quarters of what is free at most;
- * nothing found: a plain allocation.  Once per slot and size (the workspace keeps the buffer); C21CM_WS_PLACE=0:
- * plain allocation; C21CM_WS_TRACE=1 prints the candidates. */
+ *
+ * The walk holds memory it does not need (for some tens of milliseconds), so it only runs where that cannot hurt
+ * anybody (round 6):
+ *   - only when THIS process is the only one holding memory on the device (the KFD's per-process accounting,
+ *     c21hip_device_tenants); another tenant -- a second pytest-xdist worker, a second bench.py, somebody's
+ *     notebook -- means a plain allocation.  Where the accounting cannot be read the walk is bounded to four
+ *     buffers and skipped if more than half of the device is in use;
+ *   - one walker at a time per device (a non-blocking flock; the loser allocates plainly);
+ *   - everything held, in BOTH phases, counts against the budget: C21CM_WS_PLACE_GB (default 200) GB and three
+ *     quarters of what is free at most (phase 2 used to run on until hipMalloc failed);
+ *   - a walk that found nothing is not repeated for that slot and size; a decision stands while the slot and its
+ *     partner hold the buffers it was taken for, and is retaken when either changed (a slot first allocated plainly,
+ *     or placed against another partner, is placed then).
+ * C21CM_WS_PLACE=0: never; =force: also with other tenants (benchmarks that know better); C21CM_WS_TRACE=1 prints
+ * the candidates.  c21cm_placement_report() tells what the last call decided and what it cost. */
+
+enum { PLACE_SLOTS = 384, MAXH = 128 };
+enum {
+    PL_PLACED = 0,       /* a faster region was found and adopted */
+    PL_OFF = 1,          /* C21CM_WS_PLACE=0 / no partner / small buffer */
+    PL_TENANTS = 2,      /* another process holds memory on the device */
+    PL_LOCKED = 3,       /* another process is walking */
+    PL_NOTHING = 4,      /* no candidate differed within the budget */
+    PL_REMEMBERED = 5,   /* an earlier walk for this slot and size found nothing */
+    PL_BUSY_DEVICE = 6,  /* tenancy unknown and more than half of the device in use */
+};
+typedef struct {
+    size_t bytes;
+    void *partner, *ptr;
+    int decided;
+    size_t failed_bytes; /* a walk for this size found nothing */
+} place_rec;
+static place_rec g_rec[PLACE_SLOTS];
+static struct {
+    int outcome, probes, tenants, walks, slot;
+    double held_gb, wall_ms;
+    float chosen_ms, first_ms;
+} g_last = {-1, 0, -1, 0, -1, 0., 0., 0.f, 0.f};
+
+static double wall_ms_now(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
+
+/* {outcome, GB held at the peak, timed probes, ms of the chosen pair, ms of the first candidate, wall ms of the
+ * decision, tenants seen (-1 unknown), walks so far} of the last c21_place_work_partner call that had to decide */
+int c21cm_placement_report(double out[8]) {
+    if (!out || g_last.outcome < 0) return C21CM_VALUE_ERROR;
+    out[0] = g_last.outcome, out[1] = g_last.held_gb, out[2] = g_last.probes, out[3] = g_last.chosen_ms;
+    out[4] = g_last.first_ms, out[5] = g_last.wall_ms, out[6] = g_last.tenants, out[7] = g_last.walks;
+    return 0;
+}
+
+static float *plain(place_rec *rec, int slot_new, size_t bytes, void *partner, int outcome, double t0) {
+    float *p = (float *)c21hip_ws(slot_new, bytes); /* (keeps a buffer the slot already holds) */
+    if (rec) {
+        rec->bytes = bytes, rec->partner = partner, rec->ptr = p, rec->decided = 1;
+    }
+    g_last.outcome = outcome, g_last.slot = slot_new;
+    g_last.wall_ms = wall_ms_now() - t0;
+    return p;
+}
+
 float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int nx, int ny, int nz, void *stream) {
-    size_t have = 0;
+    size_t have = 0, phave = 0;
     float *cur = (float *)c21hip_ws_peek(slot_new, &have);
-    if (cur && have >= bytes) return cur; /* placed before */
-    static int on = -1;
-    static double max_gb = 200.;
-    if (on < 0) {
-        const char *e = getenv("C21CM_WS_PLACE"), *g = getenv("C21CM_WS_PLACE_GB");
-        on = (e && e[0] == '0') ? 0 : 1;
-        if (g && atof(g) > 0.) max_gb = atof(g);
-    }
-    float *partner = (float *)c21hip_ws_peek(slot_partner, &have);
-    if (!on || !partner || have < bytes || bytes < ((size_t)256 << 20)) return (float *)c21hip_ws(slot_new, bytes);
-    enum { MAXH = 128 };
-    void *held[MAXH];
-    int n_held = 0;
+    float *partner = (float *)c21hip_ws_peek(slot_partner, &phave);
+    place_rec *rec = (slot_new >= 0 && slot_new < PLACE_SLOTS) ? &g_rec[slot_new] : NULL;
+    if (cur && have >= bytes && (!rec || (rec->decided && rec->ptr == (void *)cur && rec->partner == (void *)partner)))
+        return cur; /* the decision taken for this pair of buffers stands */
+    const double t0 = wall_ms_now();
+    const char *e = getenv("C21CM_WS_PLACE"), *g = getenv("C21CM_WS_PLACE_GB");
+    const int off = e && e[0] == '0', force = e && e[0] == 'f';
+    const double max_gb = (g && atof(g) > 0.) ? atof(g) : 200.;
+    g_last.probes = 0, g_last.held_gb = 0., g_last.chosen_ms = g_last.first_ms = 0.f, g_last.tenants = -1;
+    if (off || !partner || phave < bytes || bytes < ((size_t)256 << 20))
+        return plain(rec, slot_new, bytes, partner, PL_OFF, t0);
+    if (rec && rec->failed_bytes == bytes && !force) return plain(rec, slot_new, bytes, partner, PL_REMEMBERED, t0);
+
+    const int tenants = c21hip_device_tenants();
+    g_last.tenants = tenants;
+    if (tenants > 1 && !force) return plain(rec, slot_new, bytes, partner, PL_TENANTS, t0);
+    const size_t free_now = c21hip_free_bytes(), total = c21hip_total_bytes();
     size_t budget = (size_t)(max_gb * 1073741824.);
-    {
-        const size_t fr = c21hip_free_bytes() / 4 * 3;
-        if (fr < budget) budget = fr;
+    if (free_now / 4 * 3 < budget) budget = free_now / 4 * 3;
+    if (tenants < 0 && !force) { /* nobody can tell who else is here: stay small, stay away from a busy device */
+        if (total && total - free_now > total / 2) return plain(rec, slot_new, bytes, partner, PL_BUSY_DEVICE, t0);
+        if (budget > 4 * bytes) budget = 4 * bytes;
     }
+    /* one walker per device at a time */
+    char lock_path[64];
+    snprintf(lock_path, sizeof(lock_path), "/tmp/c21cm_place_dev%d.lock", c21hip_current_device());
+    const int lock_fd = open(lock_path, O_CREAT | O_RDWR, 0666);
+    if (lock_fd >= 0 && flock(lock_fd, LOCK_EX | LOCK_NB) != 0) {
+        close(lock_fd);
+        return plain(rec, slot_new, bytes, partner, PL_LOCKED, t0);
+    }
+
+    void *held[MAXH];
+    float t_of[MAXH];
+    int n_held = 0;
     const int trace = getenv("C21CM_WS_TRACE") != NULL;
     const int reps = 3;
     size_t chunk = (size_t)16 << 30;
-    if (chunk > budget / 4) chunk = budget / 4; /* (a short walk, e.g. under pytest-xdist: smaller steps) */
+    if (chunk > budget / 4) chunk = budget / 4; /* (a short walk: smaller steps) */
     if (chunk < bytes) chunk = bytes;
-    size_t used = 0;
-    /* ---- phase 1 */
+    size_t used = 0, peak = 0;
     int i_best = -1, i_worst = -1;
-    float t_of[MAXH];
+    float t_cur = -1.f;
+    g_last.walks++;
+    /* a buffer the slot already holds (allocated plainly earlier, or placed against another partner) is the
+     * first candidate: if it is of the fast class nothing has to move */
+    if (cur && have >= bytes) {
+        float t = 0.f;
+        if (!c21hip_probe_pass_y2(partner, cur, nx, ny, nz, reps, &t, stream) && t > 0.f) t_cur = t;
+        g_last.probes++;
+        if (trace) fprintf(stderr, "[place] slot %d current buffer: %.4f ms\n", slot_new, t);
+    }
+    /* ---- phase 1 */
     while (n_held < MAXH / 2 && used + chunk <= budget) {
         void *p = c21hip_raw_alloc(chunk);
         if (!p) break;
         used += chunk;
+        if (used > peak) peak = used;
         held[n_held] = p;
         float t = 0.f;
         const int st = c21hip_probe_pass_y2(partner, (float *)p, nx, ny, nz, reps, &t, stream);
+        g_last.probes++;
         t_of[n_held] = (st || !(t > 0.f)) ? -1.f : t;
         n_held++;
         if (t_of[n_held - 1] < 0.f) break;
         if (trace)
             fprintf(stderr, "[place] slot %d chunk %d (%.0f GB in): %.4f ms\n", slot_new, n_held - 1, used / 1073741824., t);
+        if (n_held == 1) g_last.first_ms = t;
         if (i_best < 0 || t < t_of[i_best]) i_best = n_held - 1;
         if (i_worst < 0 || t > t_of[i_worst]) i_worst = n_held - 1;
-        if (t_of[i_worst] > 1.08f * t_of[i_best]) break; /* both classes seen */
+        if (t_cur > 0.f && t_cur < 0.96f * t) break;                /* the current buffer is of the fast class */
+        if (t_of[i_worst] > 1.08f * t_of[i_best]) break;            /* both classes seen */
     }
     void *chosen = NULL;
-    if (i_best >= 0 && i_worst >= 0 && t_of[i_worst] > 1.08f * t_of[i_best]) {
+    int keep_current = 0;
+    if (t_cur > 0.f && i_worst >= 0 && t_cur < 0.96f * t_of[i_worst]) {
+        keep_current = 1; /* nothing faster to be had than what the slot holds */
+        g_last.chosen_ms = t_cur;
+    } else if (i_best >= 0 && i_worst >= 0 && t_of[i_worst] > 1.08f * t_of[i_best]) {
         const float t_good = t_of[i_best];
         if (chunk == bytes) { /* (boxes whose spectra are chunk-sized: the chunk is the buffer) */
             chosen = held[i_best];
             held[i_best] = NULL;
+            g_last.chosen_ms = t_good;
         } else {
             /* ---- phase 2 */
             c21hip_raw_free(held[i_best]);
             held[i_best] = NULL;
-            while (n_held < MAXH) {
+            used -= chunk;
+            while (n_held < MAXH && used + bytes <= budget) {
                 void *p = c21hip_raw_alloc(bytes);
                 if (!p) break;
+                used += bytes;
+                if (used > peak) peak = used;
                 float t = 0.f;
                 const int st = c21hip_probe_pass_y2(partner, (float *)p, nx, ny, nz, reps, &t, stream);
+                g_last.probes++;
                 if (trace) fprintf(stderr, "[place] slot %d exact-size candidate: %.4f ms\n", slot_new, t);
                 if (!st && t > 0.f && t < 1.04f * t_good) {
                     chosen = p;
+                    g_last.chosen_ms = t;
                     break;
                 }
                 held[n_held++] = p;
@@ -96,10 +200,25 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
     }
     for (int i = 0; i < n_held; i++)
         if (held[i]) c21hip_raw_free(held[i]);
-    if (!chosen) return (float *)c21hip_ws(slot_new, bytes);
+    if (lock_fd >= 0) {
+        (void)flock(lock_fd, LOCK_UN);
+        close(lock_fd);
+    }
+    g_last.held_gb = (double)peak / 1073741824.;
+    if (keep_current) {
+        float *p = plain(rec, slot_new, bytes, partner, PL_PLACED, t0);
+        return p;
+    }
+    if (!chosen) {
+        if (rec) rec->failed_bytes = bytes;
+        return plain(rec, slot_new, bytes, partner, PL_NOTHING, t0);
+    }
     if (c21hip_ws_adopt(slot_new, chosen, bytes)) {
         c21hip_raw_free(chosen);
-        return (float *)c21hip_ws(slot_new, bytes);
+        return plain(rec, slot_new, bytes, partner, PL_NOTHING, t0);
     }
+    if (rec) rec->bytes = bytes, rec->partner = partner, rec->ptr = chosen, rec->decided = 1;
+    g_last.outcome = PL_PLACED, g_last.slot = slot_new;
+    g_last.wall_ms = wall_ms_now() - t0;
     return (float *)chosen;
 }

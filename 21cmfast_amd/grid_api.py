@@ -449,6 +449,24 @@ def combine_cross_g12(mask, g12, peer_mask, peer_g12, stream=None):
           "c21cm_shard_combine_cross_g12")
 
 
+PLACEMENT_OUTCOMES = ("placed against the partner by timed launches", "off / not applicable",
+                      "other tenants on the device", "another process was walking", "no faster candidate in the budget",
+                      "an earlier walk for this size found nothing", "tenancy unknown and the device is busy")
+
+
+def placement_report():
+    """What the last placement decision of a work spectrum was and what it cost (csrc/host/placement.c:
+    c21cm_placement_report); None before any."""
+    lib = load()
+    out = (C.c_double * 8)()
+    lib.c21cm_placement_report.restype = C.c_int
+    if lib.c21cm_placement_report(out) != 0:
+        return None
+    return {"outcome": PLACEMENT_OUTCOMES[int(out[0])], "held_GB": round(out[1], 2), "probes": int(out[2]),
+            "chosen_ms": round(out[3], 4), "first_candidate_ms": round(out[4], 4), "decision_wall_ms": round(out[5], 2),
+            "tenants": int(out[6]), "walks": int(out[7])}
+
+
 def shard_init_from_torch(group=None):
     """Bootstrap the library's own RCCL communicator from an initialised ``torch.distributed``
     job: rank 0 draws the unique id in C (c21cm_shard_unique_id), torch broadcasts its 128 bytes,

@@ -714,6 +714,13 @@ int c21cm_device_synchronize(void);
 void c21cm_release_device_cache(void); /* drop cached rocFFT plans and scratch */
 const char *c21cm_last_error(void);
 
+/* Placement of the second work spectrum of a two-grid sweep (csrc/host/placement.c): what the last decision was.
+ * out = {outcome (0 placed by timed launches, 1 off / not applicable, 2 other tenants on the device, 3 another
+ * process walking, 4 nothing faster within the budget, 5 remembered failure, 6 tenancy unknown + busy device),
+ * GB held at the peak of the walk, timed probes, ms of the chosen pair, ms of the first candidate, wall ms of the
+ * decision, tenants seen (-1 unknown), walks of this process so far}.  C21CM_VALUE_ERROR before any decision. */
+int c21cm_placement_report(double out[8]);
+
 #ifdef __cplusplus
 }
 #endif

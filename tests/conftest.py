@@ -8,13 +8,6 @@ import os
 
 import pytest
 
-# the placement walk of the work spectra (csrc/host/placement.c) holds up to 200 GB of free memory for some
-# milliseconds and decides by timed launches: xdist workers share one GPU (noisy timings, one pool of memory), so
-# they allocate plainly; a serial run (what the driver does) exercises the walk
-if os.environ.get("PYTEST_XDIST_WORKER"):
-    os.environ.setdefault("C21CM_WS_PLACE", "0")
-
-
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

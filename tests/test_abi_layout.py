@@ -82,6 +82,44 @@ def test_ctypes_mirrors_match_compiler_layout(pkg, tmp_path):
             assert getattr(cls, field).offset == int(value), f"{name}.{field}"
 
 
+def test_boundary_matches_the_reference_headers_layout(tmp_path):
+    """(b) pinned to the REFERENCE, not to this repo: tests/golden/abi_layout.json holds
+    sizeof and every field's offset / size as gcc lays out the reference's own cffi headers
+    (_inputparams_wrapper.h:6-202, _outputstructs_wrapper.h:6-105; written in the build container by
+    tests/golden/make_abi_layout.py).  include/c21cm_abi.h compiled here must give the same numbers for every
+    struct of the path -- a field added, dropped, reordered or retyped on either side fails this test.  Exported
+    entry points the reference's prototypes name must keep their argument counts."""
+    import json
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    import make_abi_layout as M
+
+    doc = json.loads((ROOT / "tests" / "golden" / "abi_layout.json").read_text())
+    ref = doc["structs"]
+    # outside SURVEY section 8 (the discrete halo sampler's catalogue of perturbed halos): not in the drop-in header
+    out_of_scope = {"PerturbedHaloCatalog"}
+    ours_text = (ROOT / "include" / "c21cm_abi.h").read_text()
+    ours = dict(M.parse_structs(ours_text))
+    wanted = [(name, [f[0] for f in rec["fields"]]) for name, rec in sorted(ref.items()) if name not in out_of_scope]
+    missing = [name for name, _ in wanted if name not in ours]
+    assert not missing, f"structs of the reference boundary absent from include/c21cm_abi.h: {missing}"
+    for name, fields in wanted:  # same field NAMES in the same order
+        assert ours[name] == fields, f"{name}: fields {ours[name]} != reference {fields}"
+    got = M.layout_of(["c21cm_abi.h"], wanted, include_dirs=[str(ROOT / "include")])
+    for name, _ in wanted:
+        assert got[name]["size"] == ref[name]["size"], f"sizeof({name})"
+        assert got[name]["fields"] == ref[name]["fields"], f"{name}: offsets / sizes differ"
+    # prototypes: every reference-named function the header declares has the reference's argument count
+    ours_protos = M.parse_prototypes(ours_text)
+    shared = sorted(set(ours_protos) & set(doc["prototype_arg_counts"]))
+    assert {"ComputeInitialConditions", "ComputePerturbedField", "ComputeIonizedBox", "ComputeTsBox",
+            "ComputeBrightnessTemp", "ComputeHaloBox", "UpdateXraySourceBox",
+            "Broadcast_struct_global_all"} <= set(shared)
+    for fn in shared:
+        assert ours_protos[fn] == doc["prototype_arg_counts"][fn], fn
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under 21cmfast_amd/ may reference it."""
     for path in (ROOT / "21cmfast_amd").rglob("*"):

@@ -630,6 +630,40 @@ def test_full_size_properties(api):
     assert rep2.global_xH < g1
 
 
+@pytest.mark.parametrize("mode", ["stars", "erfc"])
+def test_config3_full_size_vs_oracle(api, oracle, mode):
+    """BASELINE config 3 AT ITS OWN SIZE against the oracle: 512^3, 40 radii, the same
+    density (and n_ion) realisation on both sides -- the fields are made on the GPU and copied to the host.
+    Tolerances as everywhere (bench.parity_object): flag mismatch <= 2e-4, x_HI rtol 1e-4 / atol 5e-6 and z_reion
+    equal on the agreeing cells, per-radius f_coll means rtol 1e-5, global x_HI to 2e-4.  G = 2 is the
+    benchmark's Lagrangian model, G = 1 the closed-form erfc mode.  Reference: IonisationBox.c:773-1201."""
+    import os
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+
+    n = 512
+    fmode = W.FCOLL_STARS if mode == "stars" else W.FCOLL_ERFC
+    spec = W.ionize_spec(n, mode=fmode)
+    assert spec.n_radii == 40
+    density = W.density_field_torch(n)
+    n_ion = W.nion_from_density(density) if mode == "stars" else None
+    buf, _, rep = api.ionize_grids(spec, density, n_ion)
+    torch.cuda.synchronize()
+    got = {"neutral_fraction": buf.neutral_fraction.cpu().numpy(), "z_reion": buf.z_reion.cpu().numpy(), "report": rep}
+    oracle.set_threads(min(os.cpu_count() or 1, 64))
+    ref = oracle.ionize_grids(spec, density.cpu().numpy(), None if n_ion is None else n_ion.cpu().numpy(),
+                              need_nion=mode != "stars")
+    par = bench.parity_object(got, ref, spec.n_radii)
+    assert 0.05 < par["ionised_fraction"] < 0.95, par
+    assert par["pass"], par
+    assert abs(par["d_global_xH"]) < 2e-4, par
+
+
 def test_config4_1024_cubed_properties_and_sharding(api):
     """Config 4 (BASELINE.json: ComputeIonizedBox HII_DIM = 1024, R loop sharded): the whole
     1024^3 x 40-radii workload -- 1024-point line passes on the x-blocked split layout, the

@@ -72,3 +72,39 @@ def test_ts_box_exchanges_with_real_ranks(world, tmp_path):
     cases = ("ts",)
     p, results = launch(world, cases, tmp_path)
     check(p, results, world, cases)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_ranks_through_the_c_exchange(world):
+    """bench.py launched the way the driver launches it, N ranks on the one GPU: with the stand-in transport the
+    sharded step runs INSIDE the C library (c21cm_ionize_sharded) -- the line carries one phase triple per rank
+    and the communicator's own rank count -- and global x_HI equals the single-GPU run's."""
+    from test_gpu_ionize import check_sharded_bench_objects
+
+    common = ["--hii-dim", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-roofline",
+              "--no-abi", "--config4-dim", "256"]
+    env = dict(os.environ, C21CM_WS_PLACE="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py")] + common, capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    single = json.loads(p.stdout.strip())
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.update(C21CM_RCCL_LIB=str(SHIM), RCCL_SHIM_TIMEOUT_S="90")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                        "--gpus", str(world), "--backend", "gloo"] + common,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == world and "c21cm_ionize_sharded" in cfg["parallelism"] and "shard_impl_note" not in cfg
+    assert len(cfg["shard_phases_ms_per_rank"]) == world and cfg["rccl_comm_count"] == world
+    assert all(len(t) == 3 and all(v >= 0 for v in t) for t in cfg["shard_phases_ms_per_rank"])
+    assert cfg["global_xH"] == single["config"]["global_xH"]
+    assert cfg["shard_outputs"].startswith("whole boxes") and cfg["ms_per_step_slab_resident"] > 0
+    check_sharded_bench_objects(line, world=world, config4_dim=256)
+    assert len(line["config4"]["shard_phases_ms_per_rank"]) == world
