@@ -29,6 +29,10 @@ void *c21hip_ws(int slot, size_t bytes);     /* cached device scratch, NULL = OO
 void *c21hip_ws_peek(int slot, size_t *bytes);
 int c21hip_ws_adopt(int slot, void *ptr, size_t bytes);
 void *c21hip_raw_alloc(size_t bytes);
+/* physical memory with only its head mapped (placement walk); the workspace adopts a fully mapped one */
+void *c21hip_vmm_chunk(size_t phys_bytes, size_t map_bytes, void **va_out);
+void c21hip_vmm_chunk_free(void *chunk);
+int c21hip_ws_adopt_vmm(int slot, void *chunk, size_t bytes);
 void c21hip_raw_free(void *p);
 size_t c21hip_free_bytes(void);
 size_t c21hip_total_bytes(void);

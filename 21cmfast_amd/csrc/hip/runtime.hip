@@ -236,6 +236,87 @@ extern "C" int c21hip_ws_adopt(int slot, void *ptr, size_t bytes) {
     g_slots[slot].bytes = bytes;
     return 0;
 }
+// ---- physical memory without (much of) a mapping: the placement walk's chunks (csrc/host/placement.c) ----------
+// hipMalloc of 16 GB costs ~0.6 s on this driver (38-45 ms per GB, profiles/r06_alloc_cost.txt) and the walk holds
+// up to eight of them; hipMemCreate hands out the physical range for nothing, and only the head the probe
+// launches touch is mapped.  A chunk is {handle, reserved range, mapped bytes}; the workspace can adopt one whose
+// physical size equals its mapping (slot_free knows how to undo it).
+struct VmmChunk {
+    hipMemGenericAllocationHandle_t handle;
+    void *va;
+    size_t map_bytes, phys_bytes;
+};
+extern "C" void *c21hip_vmm_chunk(size_t phys_bytes, size_t map_bytes, void **va_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (gran < ((size_t)2 << 20)) gran = (size_t)2 << 20;
+    phys_bytes = (phys_bytes + gran - 1) / gran * gran;
+    map_bytes = (map_bytes + gran - 1) / gran * gran;
+    if (map_bytes > phys_bytes) map_bytes = phys_bytes;
+    VmmChunk *c = new VmmChunk{};
+    c->phys_bytes = phys_bytes;
+    c->map_bytes = map_bytes;
+    if (hipMemCreate(&c->handle, phys_bytes, &prop, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return nullptr;
+    }
+    bool ok = hipMemAddressReserve(&c->va, map_bytes, gran, nullptr, 0) == hipSuccess;
+    bool mapped = false;
+    if (ok) {
+        mapped = hipMemMap(c->va, map_bytes, 0, c->handle, 0) == hipSuccess;
+        ok = mapped;
+    }
+    if (ok) {
+        hipMemAccessDesc acc{};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(c->va, map_bytes, &acc, 1) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        if (mapped) (void)hipMemUnmap(c->va, map_bytes);
+        if (c->va) (void)hipMemAddressFree(c->va, map_bytes);
+        (void)hipMemRelease(c->handle);
+        delete c;
+        return nullptr;
+    }
+    if (va_out) *va_out = c->va;
+    return c;
+}
+extern "C" void c21hip_vmm_chunk_free(void *chunk) {
+    VmmChunk *c = (VmmChunk *)chunk;
+    if (!c) return;
+    (void)hipMemUnmap(c->va, c->map_bytes);
+    (void)hipMemAddressFree(c->va, c->map_bytes);
+    (void)hipMemRelease(c->handle);
+    delete c;
+}
+// the slot takes the chunk over (its mapping must cover the physical range: nothing is held that is not used)
+extern "C" int c21hip_ws_adopt_vmm(int slot, void *chunk, size_t bytes) {
+    VmmChunk *c = (VmmChunk *)chunk;
+    if (slot < 0 || slot >= kMaxSlots || !c || c->map_bytes != c->phys_bytes || c->map_bytes < bytes)
+        return C21CM_VALUE_ERROR;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    slot_free(g_slots[slot]);
+    g_slots[slot].ptr = c->va;
+    g_slots[slot].bytes = bytes;
+    g_slots[slot].chunks.assign(1, c->handle);
+    g_slots[slot].va_bytes = c->map_bytes;
+    delete c;
+    return 0;
+}
+
 extern "C" void *c21hip_raw_alloc(size_t bytes) {
     void *p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {

@@ -39,7 +39,7 @@
  * C21CM_WS_PLACE=0: never; =force: also with other tenants (benchmarks that know better); C21CM_WS_TRACE=1 prints
  * the candidates.  c21cm_placement_report() tells what the last call decided and what it cost. */
 
-enum { PLACE_SLOTS = 384, MAXH = 128 };
+enum { PLACE_SLOTS = 384, MAXH = 128, PLACE_VMM_DEFAULT = 0 };
 enum {
     PL_PLACED = 0,       /* a faster region was found and adopted */
     PL_OFF = 1,          /* C21CM_WS_PLACE=0 / no partner / small buffer */
@@ -75,6 +75,27 @@ int c21cm_placement_report(double out[8]) {
     out[0] = g_last.outcome, out[1] = g_last.held_gb, out[2] = g_last.probes, out[3] = g_last.chosen_ms;
     out[4] = g_last.first_ms, out[5] = g_last.wall_ms, out[6] = g_last.tenants, out[7] = g_last.walks;
     return 0;
+}
+
+/* a candidate region: hipMalloc'ed, or (C21CM_WS_PLACE_ALLOC=vmm) physical memory from hipMemCreate with only the
+ * head the probe touches mapped -- hipMalloc pays 38-45 ms per GB on this driver (profiles/r06_alloc_cost.txt), the
+ * walk's 16 GB chunks cost 0.6 s each that way */
+typedef struct {
+    void *ptr, *vmm;
+} cand;
+static int cand_alloc(cand *c, size_t phys_bytes, size_t map_bytes, int vmm) {
+    c->ptr = c->vmm = NULL;
+    if (vmm) {
+        c->vmm = c21hip_vmm_chunk(phys_bytes, map_bytes, &c->ptr);
+        return c->vmm ? 0 : 1;
+    }
+    c->ptr = c21hip_raw_alloc(phys_bytes);
+    return c->ptr ? 0 : 1;
+}
+static void cand_free(cand *c) {
+    if (c->vmm) c21hip_vmm_chunk_free(c->vmm);
+    else if (c->ptr) c21hip_raw_free(c->ptr);
+    c->ptr = c->vmm = NULL;
 }
 
 static float *plain(place_rec *rec, int slot_new, size_t bytes, void *partner, int outcome, double t0) {
@@ -122,8 +143,10 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
         return plain(rec, slot_new, bytes, partner, PL_LOCKED, t0);
     }
 
-    void *held[MAXH];
+    cand held[MAXH];
     float t_of[MAXH];
+    const char *ea = getenv("C21CM_WS_PLACE_ALLOC");
+    const int vmm = ea ? (ea[0] == 'v') : PLACE_VMM_DEFAULT;
     int n_held = 0;
     const int trace = getenv("C21CM_WS_TRACE") != NULL;
     const int reps = 3;
@@ -144,13 +167,11 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
     }
     /* ---- phase 1 */
     while (n_held < MAXH / 2 && used + chunk <= budget) {
-        void *p = c21hip_raw_alloc(chunk);
-        if (!p) break;
+        if (cand_alloc(&held[n_held], chunk, bytes, vmm)) break;
         used += chunk;
         if (used > peak) peak = used;
-        held[n_held] = p;
         float t = 0.f;
-        const int st = c21hip_probe_pass_y2(partner, (float *)p, nx, ny, nz, reps, &t, stream);
+        const int st = c21hip_probe_pass_y2(partner, (float *)held[n_held].ptr, nx, ny, nz, reps, &t, stream);
         g_last.probes++;
         t_of[n_held] = (st || !(t > 0.f)) ? -1.f : t;
         n_held++;
@@ -163,29 +184,30 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
         if (t_cur > 0.f && t_cur < 0.96f * t) break;                /* the current buffer is of the fast class */
         if (t_of[i_worst] > 1.08f * t_of[i_best]) break;            /* both classes seen */
     }
-    void *chosen = NULL;
+    cand chosen = {NULL, NULL};
     int keep_current = 0;
     if (t_cur > 0.f && i_worst >= 0 && t_cur < 0.96f * t_of[i_worst]) {
         keep_current = 1; /* nothing faster to be had than what the slot holds */
         g_last.chosen_ms = t_cur;
     } else if (i_best >= 0 && i_worst >= 0 && t_of[i_worst] > 1.08f * t_of[i_best]) {
         const float t_good = t_of[i_best];
-        if (chunk == bytes) { /* (boxes whose spectra are chunk-sized: the chunk is the buffer) */
+        if (chunk == bytes && !held[i_best].vmm) { /* (boxes whose spectra are chunk-sized: the chunk is the buffer) */
             chosen = held[i_best];
-            held[i_best] = NULL;
+            held[i_best].ptr = held[i_best].vmm = NULL;
             g_last.chosen_ms = t_good;
         } else {
             /* ---- phase 2 */
-            c21hip_raw_free(held[i_best]);
-            held[i_best] = NULL;
+            cand_free(&held[i_best]);
             used -= chunk;
             while (n_held < MAXH && used + bytes <= budget) {
-                void *p = c21hip_raw_alloc(bytes);
-                if (!p) break;
+                cand p;
+                /* always hipMalloc: a buffer mapped through hipMemMap runs the passes of the loop slower than
+                 * one from hipMalloc even where the probe times the pair fast (profiles/r06_placement_vmm.txt) */
+                if (cand_alloc(&p, bytes, bytes, 0)) break;
                 used += bytes;
                 if (used > peak) peak = used;
                 float t = 0.f;
-                const int st = c21hip_probe_pass_y2(partner, (float *)p, nx, ny, nz, reps, &t, stream);
+                const int st = c21hip_probe_pass_y2(partner, (float *)p.ptr, nx, ny, nz, reps, &t, stream);
                 g_last.probes++;
                 if (trace) fprintf(stderr, "[place] slot %d exact-size candidate: %.4f ms\n", slot_new, t);
                 if (!st && t > 0.f && t < 1.04f * t_good) {
@@ -198,8 +220,7 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
             }
         }
     }
-    for (int i = 0; i < n_held; i++)
-        if (held[i]) c21hip_raw_free(held[i]);
+    for (int i = 0; i < n_held; i++) cand_free(&held[i]);
     if (lock_fd >= 0) {
         (void)flock(lock_fd, LOCK_UN);
         close(lock_fd);
@@ -209,16 +230,16 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
         float *p = plain(rec, slot_new, bytes, partner, PL_PLACED, t0);
         return p;
     }
-    if (!chosen) {
+    if (!chosen.ptr) {
         if (rec) rec->failed_bytes = bytes;
         return plain(rec, slot_new, bytes, partner, PL_NOTHING, t0);
     }
-    if (c21hip_ws_adopt(slot_new, chosen, bytes)) {
-        c21hip_raw_free(chosen);
+    if (chosen.vmm ? c21hip_ws_adopt_vmm(slot_new, chosen.vmm, bytes) : c21hip_ws_adopt(slot_new, chosen.ptr, bytes)) {
+        cand_free(&chosen);
         return plain(rec, slot_new, bytes, partner, PL_NOTHING, t0);
     }
-    if (rec) rec->bytes = bytes, rec->partner = partner, rec->ptr = chosen, rec->decided = 1;
+    if (rec) rec->bytes = bytes, rec->partner = partner, rec->ptr = chosen.ptr, rec->decided = 1;
     g_last.outcome = PL_PLACED, g_last.slot = slot_new;
     g_last.wall_ms = wall_ms_now() - t0;
-    return (float *)chosen;
+    return (float *)chosen.ptr;
 }
