@@ -111,6 +111,11 @@ int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, float *work_
                                  float *work_b2, int filter_b, float R_param_b, int nx, int ny,
                                  int nz, double box_len, double box_len_z, float R, float R2,
                                  int table_slot, int table_slot2, int phases, void *stream);
+/* one grid, two radii, windows evaluated in the kernel (the Eulerian loops' filtered density; phases 2 / 4 / 8 as
+ * above, calls without 2 run the pass Y alone); C21CM_VALUE_ERROR when the evaluated set does not cover it */
+int c21hip_split_filter_x_pair1(const float *src, float *work, float *work2, int filter_type, int nx, int ny,
+                                int nz, double box_len, double box_len_z, float R, float R2, int phases,
+                                void *stream);
 /* one grid, two radii, window a of the tables built for the two-grid sweep of those radii */
 int c21hip_split_filter_xy_shared_pair(const float *src, float *work, float *work2,
                                        int filter_type, int nx, int ny, int nz, double box_len,
@@ -180,6 +185,16 @@ int c21hip_window_tables(int table_slot, int filter_a, float R_param_a, int filt
  * partials: 2 * nx*ny/16 doubles (IonisationBox.c:668-699) */
 int c21hip_split_z_c2r_minmax(const float *split_work, float *real_out, long out_zstride, int nx,
                               int ny, int nz, double *partials, double *minmax_out, void *stream);
+/* Eulerian table loop without the delta_R round trip (round 6): the extrema alone (nothing stored), then the
+ * table sweep + banded barrier as the epilogue of a SECOND pass Z of the same spectrum (nx*ny/16 partial sums of
+ * f_coll left in `partials` for c21hip_eul_band) */
+int c21hip_z_table_band_supported(int nx, int ny, int nz);
+int c21hip_split_z_minmax_only(const float *split_work, int nx, int ny, int nz, double *partials,
+                               double *minmax_out, void *stream);
+int c21hip_split_z_fcoll_table_band(const float *split_work, float *f_pend, const double *band_dev,
+                                    const double *thr_prev_dev, unsigned char *first_cross, int r_index,
+                                    int r_prev, int nx, int ny, int nz, int mode, double tab_min, double tab_width,
+                                    const float *table_dev, double *partials, void *stream);
 /* pass Z fused with the CONST-ION-EFF closed-form f_coll(delta_R): dense f_coll grid + sum
  * (IonisationBox.c:785-961, hmf.c:1205-1241); partials: 2 * nx*ny/16 doubles */
 int c21hip_split_z_fcoll_erfc(const float *split_work, float *nion_dense, int nx, int ny, int nz,

@@ -2536,7 +2536,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
     // the transform); the lanes' (cell 2j, 2j + 1) pairs are picked out of the line's LDS region afterwards
     // (EPI 4 reads the rows the same way -- sixteen 2-byte loads per lane issued after the transform
     //  made the Gamma_12 pass slower than a pass Z that stores its whole grid: 0.30 against 0.25 ms)
-    constexpr bool MROW = (EPI == 7 || EPI == 8 || (EPI == 4 && C21X_EPI4_MASK16));
+    constexpr bool MROW = (EPI == 7 || EPI == 8 || EPI == 9 || (EPI == 4 && C21X_EPI4_MASK16));
     constexpr int MV = MROW ? A / 8 : 1;
     uint4 mreg[MV];
     if constexpr (MROW) {
@@ -2544,8 +2544,10 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 #pragma unroll
         for (int v = 0; v < MV; v++) mreg[v] = mrow[v];
     }
-    __shared__ float ftab[EPI == 8 ? C21CM_NDELTA_TABLE : 1];
+    __shared__ float ftab[(EPI == 8 || EPI == 9) ? C21CM_NDELTA_TABLE : 1];
     float2 dreg[EPI == 8 ? A : 1];
+    if constexpr (EPI == 9)  // the radius' f_coll table (the filtered density is this transform's own output)
+        for (int t = threadIdx.x; t < C21CM_NDELTA_TABLE; t += kBlock) ftab[t] = a.table[t];
     if constexpr (EPI == 8) {  // the radius' f_coll table and the cells' filtered density
         for (int t = threadIdx.x; t < C21CM_NDELTA_TABLE; t += kBlock) ftab[t] = a.table[t];
 #pragma unroll
@@ -2573,7 +2575,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 
     double acc0 = 0., acc1 = 0., acc2 = 0.;
     float t_sure = 0.f, t_maybe = 0.f;
-    if constexpr (EPI == 7) {
+    if constexpr (EPI == 7 || EPI == 9) {
         t_sure = (float)a.band[0];
         t_maybe = (float)a.band[1];
     }
@@ -2678,9 +2680,20 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
                 }
             }
             if (ch) reinterpret_cast<uchar2 *>(L)[j] = m;
-        } else if (EPI == 7) {
-            const double f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
-            const double f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
+        } else if (EPI == 7 || EPI == 9) {
+            double f0, f1;
+            if constexpr (EPI == 9) {  // fcoll_eulerian_band_kernel's statements on the value the store pass would have written
+                const double inv_w = 1. / a.tab_width;
+                f0 = eval_table_f_inv((double)clip_delta_eulerian(v.x), a.tab_min, a.tab_width, inv_w, ftab);
+                f1 = eval_table_f_inv((double)clip_delta_eulerian(v.y), a.tab_min, a.tab_width, inv_w, ftab);
+                if (a.tab_mode != C21CM_FCOLL_TABLE_LINEAR) {
+                    f0 = exp_f32acc(f0);
+                    f1 = exp_f32acc(f1);
+                }
+            } else {
+                f0 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.x), a.sig, a.delta_c);
+                f1 = (a.sig < 0) ? 0. : fgtrm_bias_fast_inv(clip_delta_eulerian(v.y), a.sig, a.delta_c);
+            }
             acc0 += f0;
             acc0 += f1;
             const float g0 = (float)f0, g1 = (float)f1;  // what the dense grid of EPI 2 would hold
@@ -2725,15 +2738,15 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
                 if (h0 || h1) reinterpret_cast<uchar2 *>(a.mask_rw + lline * NZ)[j] = m;
             }
         } else {
-            reinterpret_cast<float2 *>(a.out + lline * a.out_zstride)[j] = v;
-            if (EPI == 1 || EPI == 3) {
+            if (EPI != 10) reinterpret_cast<float2 *>(a.out + lline * a.out_zstride)[j] = v;  // (10: the extrema alone)
+            if (EPI == 1 || EPI == 3 || EPI == 10) {
                 const double lo = fmin((double)v.x, (double)v.y), hi = fmax((double)v.x, (double)v.y);
                 acc0 = (q == 0) ? lo : fmin(acc0, lo);
                 acc1 = (q == 0) ? hi : fmax(acc1, hi);
             }
         }
     }
-    if constexpr (EPI == 7 || EPI == 8) {  // changed 16-byte pieces of the mask row back to the grid
+    if constexpr (EPI == 7 || EPI == 8 || EPI == 9) {  // changed 16-byte pieces of the mask row back to the grid
         wave_fence();
 #pragma unroll
         for (int v = 0; v < MV; v++) {
@@ -2747,7 +2760,7 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const double o0 = __shfl_down(acc0, off, 64), o1 = __shfl_down(acc1, off, 64);
-            acc0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8) ? acc0 + o0 : fmin(acc0, o0);
+            acc0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8 || EPI == 9) ? acc0 + o0 : fmin(acc0, o0);
             acc1 = fmax(acc1, o1);
             if (EPI == 3) acc2 += __shfl_down(acc2, off, 64);
         }
@@ -2761,12 +2774,12 @@ zw_c2r_kernel(ZPassArgs a, const float2 *__restrict__ twH_global,
             double r0 = red0[0], r1 = red1[0], r2 = red2[0];
 #pragma unroll
             for (int w = 1; w < kBlock / 64; w++) {
-                r0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8) ? r0 + red0[w] : fmin(r0, red0[w]);
+                r0 = (EPI == 2 || EPI == 6 || EPI == 7 || EPI == 8 || EPI == 9) ? r0 + red0[w] : fmin(r0, red0[w]);
                 r1 = fmax(r1, red1[w]);
                 r2 += red2[w];
             }
             a.p0[blk] = r0;
-            if (EPI == 1 || EPI == 3) a.p1[blk] = r1;
+            if (EPI == 1 || EPI == 3 || EPI == 10) a.p1[blk] = r1;
             if (EPI == 3) a.p2[blk] = r2;
         }
     }
@@ -3341,8 +3354,8 @@ int dispatch_z_c2r(int nz, const ZPassArgs &a_, long nlines, hipStream_t stream)
         LAUNCH_CHECK();
         return 0;
     }
-    if constexpr (EPI == 6 || EPI == 7) {
-        c21hip_set_error("pass Z with the deferred / banded barrier (EPI 6, 7) needs the wave-level kernel");
+    if constexpr (EPI == 6 || EPI == 7 || EPI == 9 || EPI == 10) {
+        c21hip_set_error("pass Z with the deferred / banded barrier (EPI 6, 7, 9) or the extrema alone (10) needs the wave-level kernel");
         return C21CM_VALUE_ERROR;
     } else
     switch (nz) {
@@ -3888,7 +3901,7 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
                           float R_param_a, const float *src_b, float *work_b, float *work_b2,
                           int filter_b, float R_param_b, int nx, int ny, int nz, double box_len,
                           double box_len_z, float R, float R2, int table_slot, int table_slot2,
-                          int phases, void *stream_, int n_grids = 2) {
+                          int phases, void *stream_, int n_grids = 2, bool must_eval = false) {
     // phases: 1 window tables, 2 pass X, 4 pass Y of the first radius, 8 pass Y of the second
     // n_grids = 1: grid a only, with window a of tables built for a two-grid sweep (phases & 1
     // must be clear)
@@ -3910,7 +3923,16 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
     a.n_y = ny;
     a.n_z = nz;
     a.out_scale = 1.0f;
-    const bool evaluated = wev_use(a, n_grids, ft, rp, R, R2, true, nx, ny, nz, box_len, box_len_z);
+    // (must_eval: the one-grid sweep of the Eulerian loops -- no tables were built for it; its pass-Y-only calls
+    //  need no window at all)
+    const bool evaluated = (must_eval && !(phases & 2))
+                               ? true
+                               : wev_use(a, n_grids, ft, rp, R, R2, true, nx, ny, nz, box_len, box_len_z);
+    if (must_eval && !evaluated) {
+        c21hip_set_error("two-radius sweep of one grid: the evaluated windows do not cover radii %g, %g", (double)R,
+                         (double)R2);
+        return C21CM_VALUE_ERROR;
+    }
     if (!evaluated) {
         WinTables w, w2;
         if ((st = win_tables(table_slot, n_grids, ft, R, rp, 0.f, nx, ny, nz, box_len, box_len_z,
@@ -3935,7 +3957,7 @@ static int filter_xy_pair(const float *src_a, float *work_a, float *work_a2, int
                             reinterpret_cast<const float2 *>(src_b)};
     float2 *work[2] = {reinterpret_cast<float2 *>(work_a), reinterpret_cast<float2 *>(work_b)};
     float2 *work2[2] = {reinterpret_cast<float2 *>(work_a2), reinterpret_cast<float2 *>(work_b2)};
-    for (int g = 0; g < n_grids; g++) {
+    for (int g = 0; g < n_grids && (phases & 2); g++) {
         geo_ptrs(a.g0, g, src[g], work[g]);
         geo_ptrs(a.g1, g, src[g] + nlines * H, work[g] + nlines * H);
         a.g0.dst2[g] = work2[g];
@@ -3984,6 +4006,18 @@ extern "C" int c21hip_split_filter_xy_shared_pair(const float *src, float *work,
     return filter_xy_pair(src, work, work2, filter_type, 0.f, nullptr, nullptr, nullptr, 0, 0.f,
                           nx, ny, nz, box_len, box_len_z, R, R2, table_slot, table_slot2, phases,
                           stream_, 1);
+}
+
+// ONE grid, two radii per sweep, windows EVALUATED in the kernel (c21hip_wev_prepare with pair = 1): the
+// filtered density of the Eulerian loops (round 6) -- pass X reads the unfiltered spectrum once for two radii
+// (3 S instead of 4 S).  phases: 2 pass X into work / work2, 4 pass Y of `work`, 8 pass Y of `work2`; a call
+// without 2 needs no source and no window (the parked second spectrum's pass Y, one radius later).
+// C21CM_VALUE_ERROR (with the error text set) when the active set does not cover the launch.
+extern "C" int c21hip_split_filter_x_pair1(const float *src, float *work, float *work2, int filter_type,
+                                           int nx, int ny, int nz, double box_len, double box_len_z, float R,
+                                           float R2, int phases, void *stream_) {
+    return filter_xy_pair(src, work, work2, filter_type, 0.f, nullptr, nullptr, nullptr, 0, 0.f, nx, ny, nz,
+                          box_len, box_len_z, R, R2, 0, 1, phases & ~1, stream_, 1, true);
 }
 
 // One or two grids of one shell of the spin-temperature filters: windows 4 (spherical shell)
@@ -4311,6 +4345,75 @@ extern "C" int c21hip_split_z_c2r_minmax(const float *split_work, float *real_ou
     double *stage = partials + 2 * (size_t)nb;  // beyond both partial arrays
     if ((st = c21hip_reduce_op(z.p0, nb, 1, stage, minmax_out, stream))) return st;
     return c21hip_reduce_op(z.p1, nb, 2, stage + nb / 1024 + 2, minmax_out + 1, stream);
+}
+
+// ... the extrema ALONE (EPI 10: nothing is stored), and the table sweep of the same spectrum with the banded
+// barrier (EPI 9) -- round 6, the Eulerian table loop without its delta_R round trip: the c2r runs twice from
+// k-space (4 N + 4 N + 1 N bytes read per radius where the store pass, the sweep and the barrier moved
+// 4 N + 4 N written + 4 N + 1 N).  Reference: IonisationBox.c:668-699 (extrema), :773-962 (f_coll from the
+// table), :1008-1200 (barrier).  Same shapes as the closed form's banded pass Z.
+extern "C" int c21hip_z_table_band_supported(int nx, int ny, int nz) {
+    return c21hip_z_fcoll_erfc_mask_supported(nx, ny, nz);
+}
+extern "C" int c21hip_split_z_minmax_only(const float *split_work, int nx, int ny, int nz, double *partials,
+                                          double *minmax_out, void *stream) {
+    if (!c21hip_z_table_band_supported(nx, ny, nz)) {
+        c21hip_set_error("pass Z, extrema only: unsupported box");
+        return C21CM_VALUE_ERROR;
+    }
+    const long nlines = (long)nx * ny;
+    const int nb = (int)(nlines / LZ_PLAIN);
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out_zstride = nz;
+    z.out_scale = 1.0f;
+    z.p0 = partials;
+    z.p1 = partials + nb;
+    int st;
+    {
+        KTimeScope kt(13, (hipStream_t)stream);  // kind 13: one-grid pass Z, extrema only
+        st = dispatch_z_c2r<10>(nz, z, nlines, (hipStream_t)stream);
+    }
+    if (st) return st;
+    double *stage = partials + 2 * (size_t)nb;  // beyond both partial arrays
+    if ((st = c21hip_reduce_op(z.p0, nb, 1, stage, minmax_out, stream))) return st;
+    return c21hip_reduce_op(z.p1, nb, 2, stage + nb / 1024 + 2, minmax_out + 1, stream);
+}
+// nx*ny/16 partial sums of f_coll are left in `partials` for c21hip_eul_band (as the closed form's EPI 7 leaves them)
+extern "C" int c21hip_split_z_fcoll_table_band(const float *split_work, float *f_pend, const double *band_dev,
+                                               const double *thr_prev_dev, unsigned char *first_cross,
+                                               int r_index, int r_prev, int nx, int ny, int nz, int mode,
+                                               double tab_min, double tab_width, const float *table_dev,
+                                               double *partials, void *stream) {
+    if (!c21hip_z_table_band_supported(nx, ny, nz) || r_index <= 0 || r_index >= 255 || r_prev >= 255 ||
+        (mode != C21CM_FCOLL_TABLE_LINEAR && mode != C21CM_FCOLL_TABLE_EXP)) {
+        c21hip_set_error("pass Z with the table sweep and the banded barrier: unsupported box, mode or radius index");
+        return C21CM_VALUE_ERROR;
+    }
+    const long nlines = (long)nx * ny;
+    ZPassArgs z{};
+    z.ny = ny;
+    z.lb = split_xb_log2(nx);
+    z.main = reinterpret_cast<const float2 *>(split_work);
+    z.nyq = z.main + nlines * (nz / 2);
+    z.out_zstride = nz;
+    z.out_scale = 1.0f;
+    z.f_out = f_pend;
+    z.band = band_dev;
+    z.mean_dev = thr_prev_dev;
+    z.mask_rw = first_cross;
+    z.r_index = r_index;
+    z.r_prev = r_prev;
+    z.p0 = partials;
+    z.table = table_dev;
+    z.tab_min = tab_min;
+    z.tab_width = tab_width;
+    z.tab_mode = mode;
+    KTimeScope kt(14, (hipStream_t)stream);  // kind 14: one-grid pass Z + table f_coll + banded barrier
+    return dispatch_z_c2r<9>(nz, z, nlines, (hipStream_t)stream);
 }
 
 // Pass Z with the floor-and-scale store of the spin-temperature filter tables

@@ -100,6 +100,8 @@ enum {
     WS_NION_DENSE2 = 254, /* closed-form Eulerian loop: second dense f_coll buffer (deferred barrier) */
     /* (256 and 257 are shard_rccl.c's: WS_SHARD_STATUS, WS_SHARD_SLABBITS) */
     WS_NREC_WORK2 = 259, /* fused recombination loop with x_e AND a filtered N_rec: N_rec of the second radius */
+    WS_EUL_WORK3 = 261,   /* Eulerian table loop, two radii per pass-X sweep: the second set of k-space buffers */
+    WS_EUL_WORK4 = 262,
     WS_ARENA = 258        /* experiment: the spectra of the two-grid loop out of one allocation (C21CM_ARENA) */
 };
 
@@ -378,6 +380,10 @@ typedef struct {
     double rec0;         /* homogeneous model: the one previous N_rec */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
     float *eul_xe[2];    /* dense x_e(R) of the Eulerian mask path (spin-temperature runs) */
+    /* Eulerian loops, one filtered grid: pass X serves two radii per sweep where the evaluated windows allow it
+     * (round 6, eul_filter_density): the spectrum of radius pairx_R waits in pairx_buf for its pass Y */
+    int wev_pair, pairx_R;
+    float *pairx_buf;
     int sphere;          /* IONISE_ENTIRE_SPHERE: radii > 0 only record the mask, spheres follow */
     /* USE_MINI_HALOS: Eulerian tables + history (mini) | Lagrangian grids, floor only (lag_mini) */
     int mini, lag_mini;
@@ -513,6 +519,9 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
     c->eul_pend = -1;
     c->eul_pend_buf = 0;
     c->eul_pend_mask = NULL;
+    c->wev_pair = 0;
+    c->pairx_R = -1;
+    c->pairx_buf = NULL;
     c->nion_dense2 = NULL;
     c->band_off = c->band_used = 0;
     c->band_next = c->band_pend = c->band_h1 = c->band_h2 = -1;
@@ -1383,6 +1392,33 @@ done:
     return status;
 }
 
+/* The filtered density spectrum of radius R_ct into `dst` (passes X and Y; Eulerian loops, one grid).
+ * Round 6: where the evaluated windows serve two radii per sweep (c->wev_pair), pass X also produces the spectrum
+ * of next_R -- the radius this loop takes next -- into dst_next, where it waits for the call that asks for next_R
+ * with that buffer and then only runs its pass Y: the unfiltered spectrum is read once for two radii (3 S
+ * instead of 4 S per pair; 0.24 -> 0.18 ms per radius at 512^3).  The window of a radius is the same arithmetic
+ * whoever its partner is (fft_native.hip: FMODE 6 / 7), so the pairing changes no bit.
+ * Reference: IonisationBox.c:577-631 (copy + filter_box per radius), filtering.c:327-391. */
+static int eul_filter_density(ion_ctx *c, int R_ct, int next_R, float *dst, float *dst_next) {
+    const c21cm_ionize_spec *s = c->s;
+    const float R = (float)s->R[R_ct];
+    if (c->pairx_R == R_ct && c->pairx_buf == dst) { /* parked by the radius before: its pass Y is left */
+        c->pairx_R = -1;
+        return c21hip_split_filter_x_pair1(NULL, dst, NULL, s->hii_filter, c->nx, c->ny, c->nz, s->box_len,
+                                           s->box_len_z, R, 0.f, 4, c->stream);
+    }
+    c->pairx_R = -1;
+    if (c->wev_pair && R_ct > 0 && next_R > 0 && dst_next && dst_next != dst &&
+        !c21hip_split_filter_x_pair1(c->delta_unf, dst, dst_next, s->hii_filter, c->nx, c->ny, c->nz, s->box_len,
+                                     s->box_len_z, R, (float)s->R[next_R], 2 | 4, c->stream)) {
+        c->pairx_R = next_R;
+        c->pairx_buf = dst_next;
+        return 0;
+    }
+    return c21hip_split_filter_xy(c->delta_unf, dst, c->nx, c->ny, c->nz, s->box_len, s->box_len_z, s->hii_filter,
+                                  R, 0.f, R_ct > 0, c->stream);
+}
+
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -1399,6 +1435,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
     if (c->eul_mask && first_cross && R_ct > 0) {
         const int zs = 2 * (c->nz / 2 + 1);
         const float *xe_dense = NULL;
+        float *dw = c->delta_work; /* where this radius' filtered density spectrum is */
         if (s->use_ts_fluct) { /* delta and x_e through one sweep of passes X / Y (same window) */
             TRY(eul_xe_buffers(c));
             TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->xe_unf,
@@ -1407,8 +1444,15 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
             TRY(c21hip_split_z_c2r(c->xe_work, c->eul_xe[0], c->nz, c->nx, c->ny, c->nz, c->stream));
             xe_dense = c->eul_xe[0];
         } else {
-            TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
-                                       s->box_len_z, s->hii_filter, R, 0.f, apply, c->stream));
+            /* (two radii per pass-X sweep: this radius' spectrum may be waiting in the other work buffer) */
+            if (c->wev_pair && c->pairx_R == R_ct && c->pairx_buf) dw = c->pairx_buf;
+            float *park = NULL;
+            if (c->wev_pair) {
+                if (!c->delta_work2)
+                    c->delta_work2 = (float *)c21hip_ws(WS_DELTA_WORK2, c21hip_split_floats(c->nx, c->ny, c->nz) * sizeof(float));
+                park = (dw == c->delta_work) ? c->delta_work2 : c->delta_work;
+            }
+            TRY(eul_filter_density(c, R_ct, next_R, dw, park));
         }
         if (s->fcoll_mode == C21CM_FCOLL_ERFC && !s->use_ts_fluct && eul_defer_ok(c)) {
             /* f_coll of this radius into one of two dense buffers; the barrier of the radius before
@@ -1418,7 +1462,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
             float *nion_cur = cur ? c->nion_dense2 : c->nion_dense;
             if (c->eul_pend >= 0 && c->eul_pend_mask == first_cross) {
                 TRY(c21hip_split_z_fcoll_erfc_mask(
-                    c->delta_work, nion_cur, c->eul_pend_buf ? c->nion_dense2 : c->nion_dense,
+                    dw, nion_cur, c->eul_pend_buf ? c->nion_dense2 : c->nion_dense,
                     c->scalars + SC_MEANS + c->eul_pend, first_cross, c->eul_pend, s->fix_mean,
                     s->mean_f_coll, s->mass_dep_zeta, s->f_limit_acg, s->ion_eff_factor, c->nx, c->ny,
                     c->nz, s->growth_factor, s->sigma_minmass, s->sigma_maxmass[R_ct], s->delta_c,
@@ -1426,7 +1470,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                 c->eul_pend = -1;
             } else {
                 TRY(eul_flush_pending(c, 0));
-                TRY(c21hip_split_z_fcoll_erfc(c->delta_work, nion_cur, c->nx, c->ny, c->nz,
+                TRY(c21hip_split_z_fcoll_erfc(dw, nion_cur, c->nx, c->ny, c->nz,
                                               s->growth_factor, s->sigma_minmass,
                                               s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev,
                                               c->stream));
@@ -1443,7 +1487,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
             const int banded = eul_band_this(c, R_ct, first_cross, sig_ok);
             if (banded) {
                 TRY(c21hip_split_z_fcoll_erfc_band(
-                    c->delta_work, c->nion_dense, c->scalars + SC_BAND + 2 * R_ct,
+                    dw, c->nion_dense, c->scalars + SC_BAND + 2 * R_ct,
                     c->scalars + SC_BANDX + (c->band_pend >= 0 ? c->band_pend : 0), first_cross, R_ct,
                     c->band_pend, c->nx, c->ny, c->nz, s->growth_factor, s->sigma_minmass,
                     s->sigma_maxmass[R_ct], s->delta_c, partials, NULL, c->stream));
@@ -1452,7 +1496,7 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
                 c->band_used = 1;
             } else {
                 TRY(eul_band_flush(c)); /* the dense sweep overwrites the marked cells' f_coll */
-                TRY(c21hip_split_z_fcoll_erfc(c->delta_work, c->nion_dense, c->nx, c->ny, c->nz,
+                TRY(c21hip_split_z_fcoll_erfc(dw, c->nion_dense, c->nx, c->ny, c->nz,
                                               s->growth_factor, s->sigma_minmass,
                                               s->sigma_maxmass[R_ct], s->delta_c, partials, NULL,
                                               c->stream));
@@ -1465,19 +1509,19 @@ static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next
             goto done;
         }
         if (s->fcoll_mode == C21CM_FCOLL_ERFC) {
-            TRY(c21hip_split_z_fcoll_erfc(c->delta_work, c->nion_dense, c->nx, c->ny, c->nz,
+            TRY(c21hip_split_z_fcoll_erfc(dw, c->nion_dense, c->nx, c->ny, c->nz,
                                           s->growth_factor, s->sigma_minmass,
                                           s->sigma_maxmass[R_ct], s->delta_c, partials, sum_dev,
                                           c->stream));
         } else if (s->fcoll_mode == C21CM_FCOLL_NODES) {
             /* E-INTEGRAL without interpolation tables: the conditional integral per cell from the
              * radius' Gauss-Legendre node data (no extrema, no table) */
-            TRY(c21hip_split_z_c2r(c->delta_work, c->delta_fil, zs, c->nx, c->ny, c->nz, c->stream));
+            TRY(c21hip_split_z_c2r(dw, c->delta_fil, zs, c->nx, c->ny, c->nz, c->stream));
             TRY(fcoll_nodes(c, R_ct, partials, sum_dev));
         } else {
             double mm[2];
             float table[C21CM_NDELTA_TABLE];
-            TRY(c21hip_split_z_c2r_minmax(c->delta_work, c->delta_fil, zs, c->nx, c->ny, c->nz,
+            TRY(c21hip_split_z_c2r_minmax(dw, c->delta_fil, zs, c->nx, c->ny, c->nz,
                                           partials, c->scalars + SC_MINMAX, c->stream));
             TRY(c21hip_d2h(mm, c->scalars + SC_MINMAX, sizeof(mm), c->stream));
             TRY(c21hip_sync(c->stream));
@@ -1648,7 +1692,10 @@ static long eul_dfil_stride(const ion_ctx *c) {
     return 2 * (long)(c->nz / 2 + 1);
 }
 
-static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *mm_host, void *ev) {
+/* `work`: the k-space buffer this radius' filtered density spectrum goes to; `store` = 0: the extrema alone
+ * (the radius is expected to take the fused table sweep, which transforms `work` again) */
+static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *mm_host, void *ev, float *work,
+                       int store, int next_R, float *work_next) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     if (s->use_ts_fluct) { /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
@@ -1660,12 +1707,15 @@ static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *
         if (!fused)
             TRY(c21hip_split_z_c2r(c->xe_work, c->eul_xe[buf], c->nz, c->nx, c->ny, c->nz, c->stream));
     } else {
-        TRY(c21hip_split_filter_xy(c->delta_unf, c->delta_work, c->nx, c->ny, c->nz, s->box_len,
-                                   s->box_len_z, s->hii_filter, (float)s->R[R_ct], 0.f, 1, c->stream));
+        /* (pass X for this radius and the next where two radii ride one sweep: work_next != NULL) */
+        TRY(eul_filter_density(c, R_ct, next_R, work, work_next));
     }
-    TRY(c21hip_split_z_c2r_minmax(c->delta_work, delta_fil, eul_dfil_stride(c), c->nx, c->ny,
-                                  c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf,
-                                  c->stream));
+    if (!store)
+        TRY(c21hip_split_z_minmax_only(work, c->nx, c->ny, c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf,
+                                       c->stream));
+    else
+        TRY(c21hip_split_z_c2r_minmax(s->use_ts_fluct ? c->delta_work : work, delta_fil, eul_dfil_stride(c), c->nx,
+                                      c->ny, c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf, c->stream));
     TRY(c21hip_d2h(mm_host, c->scalars + SC_MINMAX + 2 * buf, 2 * sizeof(double), c->stream));
     TRY(c21hip_event_record(ev, c->stream));
 done:
@@ -1733,13 +1783,58 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
             goto done;
         }
     }
+    /* Round 6: the table sweep + banded barrier as the epilogue of a second pass Z of the radius' spectrum
+     * (pass Z EPI 9) -- delta_R is neither written nor read back (13 N -> 9 N bytes behind pass Y per radius;
+     * DESIGN 4.3).  The radius' spectrum then has to outlive the stage A of the NEXT radius, which is enqueued
+     * first: two k-space buffers, alternating.  Whether a radius will be banded is only known once the radius
+     * before it has been swept; stage A predicts it (a band exists from the third radius of a run on) and stores
+     * delta_R if it expects the dense sweeps; a wrong "no store" costs that radius one more pass Z.
+     * C21CM_EUL_TABLE_FUSED=0: the store pass + sweep of round 5. */
+    /* k-space buffers of the loop.  Fused table sweep: a radius' spectrum is transformed a second time AFTER the
+     * stage A of the next radius has been enqueued -- two buffers, alternating; with two radii per pass-X sweep the
+     * second radius of a pair is written (pass X) one radius early, while the radius before the pair still waits
+     * for its table sweep -- four buffers, the pairs alternating between two sets. */
+    float *wbuf[4] = {c->delta_work, c->delta_work, c->delta_work, c->delta_work};
+    int stored[2] = {1, 1};
+    const char *ef = getenv("C21CM_EUL_TABLE_FUSED");
+    const int fuse_table = use_band && !(ef && ef[0] == '0') && c21hip_z_table_band_supported(c->nx, c->ny, c->nz);
+    const int pair_x = fuse_table && c->wev_pair;
+    if (fuse_table) {
+        const size_t wb = c21hip_split_floats(c->nx, c->ny, c->nz) * sizeof(float);
+        if (!c->delta_work2) c->delta_work2 = (float *)c21hip_ws(WS_DELTA_WORK2, wb);
+        wbuf[1] = c->delta_work2;
+        if (pair_x) {
+            wbuf[2] = (float *)c21hip_ws(WS_EUL_WORK3, wb);
+            wbuf[3] = (float *)c21hip_ws(WS_EUL_WORK4, wb);
+        } else {
+            wbuf[2] = wbuf[0], wbuf[3] = wbuf[1];
+        }
+        if (!wbuf[1] || !wbuf[2] || !wbuf[3]) {
+            status = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+    }
+#define EUL_EXPECT_BAND(i_) (fuse_table && (i_) - i0 >= 2 && radii[i_] >= 2 && radii[i_] != c->band_skip && \
+                             (radii[i_] > s->r_lowest || s->r_lowest == 0))
+    /* buffer of the radius at position i_ of this run (j = i_ - i0: pair j / 2 in set (j / 2) % 2, member j % 2) */
+#define EUL_WORK(i_) (pair_x ? wbuf[(((((i_) - i0) >> 1) & 1) << 1) | (((i_) - i0) & 1)] : wbuf[((i_) - i0) & 1])
+    /* the partner the pass X of position i_ also serves: the next radius, when i_ opens a pair */
+#define EUL_NEXT_R(i_) ((pair_x && !(((i_) - i0) & 1) && (i_) + 1 < n) ? radii[(i_) + 1] : -1)
+#define EUL_STAGE_A(i_) eul_stage_a(c, radii[i_], (i_) & 1, dfil[(i_) & 1], mm[(i_) & 1], ev[(i_) & 1], EUL_WORK(i_), \
+                                    stored[(i_) & 1], EUL_NEXT_R(i_), EUL_NEXT_R(i_) >= 0 ? EUL_WORK((i_) + 1) : NULL)
     int i0 = 0;
     if (fail_host) fail_host[0] = fail_host[2] = 0;
 restart:
-    TRY(eul_stage_a(c, radii[i0], i0 & 1, dfil[i0 & 1], mm[i0 & 1], ev[i0 & 1]));
+    c->pairx_R = -1;
+    stored[i0 & 1] = !EUL_EXPECT_BAND(i0);
+    TRY(EUL_STAGE_A(i0));
     for (int i = i0; i < n; i++) {
         const int b = i & 1, R_ct = radii[i];
-        if (i + 1 < n) TRY(eul_stage_a(c, radii[i + 1], b ^ 1, dfil[b ^ 1], mm[b ^ 1], ev[b ^ 1]));
+        float *const work_i = EUL_WORK(i);
+        if (i + 1 < n) {
+            stored[b ^ 1] = !EUL_EXPECT_BAND(i + 1);
+            TRY(EUL_STAGE_A(i + 1));
+        }
         TRY(c21hip_event_synchronize(ev[b]));
         if ((use_band || use_band_xe) && (fail_host[0] > 0 || fail_host[2] > 0)) {
             /* (the word copied behind the band step of radius i - 2 or earlier has arrived with this event) */
@@ -1802,6 +1897,26 @@ restart:
              * f_coll grid, no barrier sweep */
             const int banded = eul_band_this(c, R_ct, mask, 1);
             int n_part = 0;
+            if (banded && !stored[b]) {
+                /* the second pass Z of the radius' spectrum: table sweep + banded barrier in its epilogue */
+                TRY(c21hip_split_z_fcoll_table_band(work_i, c->nion_dense, c->scalars + SC_BAND + 2 * R_ct,
+                                                    c->scalars + SC_BANDX + (c->band_pend >= 0 ? c->band_pend : 0),
+                                                    mask, R_ct, c->band_pend, c->nx, c->ny, c->nz, s->fcoll_mode,
+                                                    min_density, (max_density - min_density) / (C21CM_NDELTA_TABLE - 1.),
+                                                    table_dev, c->partials, c->stream));
+                c->band_pend = R_ct;
+                c->band_mask = mask;
+                c->band_used = 1;
+                TRY(eul_band_after(c, R_ct, i + 1 < n ? radii[i + 1] : -1, 1, 1, c->partials,
+                                   (int)((long)c->nx * c->ny / 16), sum_dev));
+                TRY(c21hip_d2h((void *)(fail_host + 2 * b), c->scalars + SC_BANDFAIL, sizeof(int), c->stream));
+                continue;
+            }
+            if (!stored[b]) { /* expected a band, got none: delta_R after all (the spectrum is still in work[b]) */
+                TRY(c21hip_split_z_c2r_minmax(work_i, dfil[b], eul_dfil_stride(c), c->nx, c->ny, c->nz, c->partials,
+                                              c->scalars + SC_MINMAX + 2 * b, c->stream));
+                stored[b] = 1;
+            }
             if (banded) {
                 TRY(c21hip_fcoll_eulerian_band(dfil[b], eul_dfil_stride(c), c->nion_dense, mask, c->nx, c->ny, c->nz,
                                                s->fcoll_mode, min_density,
@@ -1843,6 +1958,10 @@ restart:
     }
     /* the pinned staging buffer is shared: make sure the last copies have left it */
     TRY(c21hip_sync(c->stream));
+#undef EUL_EXPECT_BAND
+#undef EUL_WORK
+#undef EUL_NEXT_R
+#undef EUL_STAGE_A
 done:
     c21hip_event_destroy(ev[0]);
     c21hip_event_destroy(ev[1]);
@@ -2071,9 +2190,14 @@ static int native_wev_prepare(ion_ctx *c, int first, int step, void *stream) {
     for (int R_ct = first; R_ct >= 1 && R_ct >= spec->r_lowest && n < C21CM_MAX_RADII; R_ct -= step)
         radii[n++] = (float)spec->R[R_ct];
     if (n == 0) return 0;
-    return c21hip_wev_prepare(spec->hii_filter, 0.f, spec->hii_filter, 0.f, spec->use_ts_fluct ? 2 : 1,
-                              radii, n, c->nx, c->ny, c->nz, spec->box_len, spec->box_len_z, 0, &on,
-                              stream);
+    /* one filtered grid: two radii per pass-X sweep where two line tiles fit the LDS (C21CM_EUL_PAIR=0: one) */
+    const char *ep = getenv("C21CM_EUL_PAIR");
+    const int pair = !spec->use_ts_fluct && c->eul_mask && !(ep && ep[0] == '0') && c21hip_pair_sweep_supported(c->nx);
+    const int st = c21hip_wev_prepare(spec->hii_filter, 0.f, spec->hii_filter, 0.f, spec->use_ts_fluct ? 2 : 1,
+                                      radii, n, c->nx, c->ny, c->nz, spec->box_len, spec->box_len_z, pair, &on,
+                                      stream);
+    c->wev_pair = !st && on && pair;
+    return st;
 }
 
 int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *perturbed_field,

@@ -1101,7 +1101,13 @@ def test_closed_form_loop_banded_barrier_equals_dense_sweeps(api, fmode, r_lowes
     for name in names:
         assert torch.equal(getattr(buf0, name), getattr(buf1, name)), name
     k = spec.n_radii
-    assert list(rep0.f_coll_grid_mean[:k]) == list(rep1.f_coll_grid_mean[:k])
+    if fmode == W.FCOLL_ERFC:
+        assert list(rep0.f_coll_grid_mean[:k]) == list(rep1.f_coll_grid_mean[:k])
+    else:
+        # round 6: the banded table sweep is the epilogue of a second pass Z of the radius' spectrum (no delta_R
+        # round trip) -- the same f_coll values as the dense sweep reads them, added per line block instead of per
+        # sweep block: the means agree to the last bits of a double
+        np.testing.assert_allclose(rep0.f_coll_grid_mean[:k], rep1.f_coll_grid_mean[:k], rtol=1e-14, atol=0)
     assert rep0.global_xH == rep1.global_xH
     # a band that misses: detected, rerun on the dense sweeps, same box
     monkeypatch.setenv("C21CM_EUL_BAND_SHIFT", "0.2")
