@@ -116,6 +116,11 @@ int c21hip_split_filter_xy2_pair(const float *src_a, float *work_a, float *work_
 int c21hip_split_filter_x_pair1(const float *src, float *work, float *work2, int filter_type, int nx, int ny,
                                 int nz, double box_len, double box_len_z, float R, float R2, int phases,
                                 void *stream);
+/* ... two grids (delta and x_e of a spin-temperature run's Eulerian loop), same rules */
+int c21hip_split_filter_xy2_pair_eval(const float *src_a, float *work_a, float *work_a2, int filter_a,
+                                      const float *src_b, float *work_b, float *work_b2, int filter_b, int nx,
+                                      int ny, int nz, double box_len, double box_len_z, float R, float R2,
+                                      int phases, void *stream);
 /* one grid, two radii, window a of the tables built for the two-grid sweep of those radii */
 int c21hip_split_filter_xy_shared_pair(const float *src, float *work, float *work2,
                                        int filter_type, int nx, int ny, int nz, double box_len,

@@ -4020,6 +4020,18 @@ extern "C" int c21hip_split_filter_x_pair1(const float *src, float *work, float 
                           box_len, box_len_z, R, R2, 0, 1, phases & ~1, stream_, 1, true);
 }
 
+// ... and TWO grids under their evaluated windows (delta and x_e of the Eulerian table loop of a spin-temperature
+// run): c21hip_split_filter_xy2_pair without tables -- an error instead of a silent table lookup when the
+// evaluated set does not cover the launch; calls without phase 2 run pass Y alone on (work_a, work_b) [4] or
+// (work_a2, work_b2) [8].
+extern "C" int c21hip_split_filter_xy2_pair_eval(const float *src_a, float *work_a, float *work_a2, int filter_a,
+                                                 const float *src_b, float *work_b, float *work_b2, int filter_b,
+                                                 int nx, int ny, int nz, double box_len, double box_len_z, float R,
+                                                 float R2, int phases, void *stream_) {
+    return filter_xy_pair(src_a, work_a, work_a2, filter_a, 0.f, src_b, work_b, work_b2, filter_b, 0.f, nx, ny, nz,
+                          box_len, box_len_z, R, R2, 0, 1, phases & ~1, stream_, 2, true);
+}
+
 // One or two grids of one shell of the spin-temperature filters: windows 4 (spherical shell)
 // or 5 (multiple scattering) between R_inner and R_outer (SpinTemperatureBox.c:698-700).
 extern "C" int c21hip_split_filter_shell(const float *src_a, float *work_a, int filter_a,

@@ -1419,6 +1419,30 @@ static int eul_filter_density(ion_ctx *c, int R_ct, int next_R, float *dst, floa
                                   R, 0.f, R_ct > 0, c->stream);
 }
 
+/* The same for the two grids of a spin-temperature run's Eulerian loop (delta and x_e under one window): the
+ * pair's second radius waits in (dst_next, xdst_next). */
+static int eul_filter_density_xe(ion_ctx *c, int R_ct, int next_R, float *dst, float *dst_next, float *xdst,
+                                 float *xdst_next) {
+    const c21cm_ionize_spec *s = c->s;
+    const float R = (float)s->R[R_ct];
+    if (c->pairx_R == R_ct && c->pairx_buf == dst) {
+        c->pairx_R = -1;
+        return c21hip_split_filter_xy2_pair_eval(NULL, dst, NULL, s->hii_filter, NULL, xdst, NULL, s->hii_filter, c->nx,
+                                                 c->ny, c->nz, s->box_len, s->box_len_z, R, 0.f, 4, c->stream);
+    }
+    c->pairx_R = -1;
+    if (c->wev_pair && R_ct > 0 && next_R > 0 && dst_next && xdst_next && dst_next != dst && xdst_next != xdst &&
+        !c21hip_split_filter_xy2_pair_eval(c->delta_unf, dst, dst_next, s->hii_filter, c->xe_unf, xdst, xdst_next,
+                                           s->hii_filter, c->nx, c->ny, c->nz, s->box_len, s->box_len_z, R,
+                                           (float)s->R[next_R], 2 | 4, c->stream)) {
+        c->pairx_R = next_R;
+        c->pairx_buf = dst_next;
+        return 0;
+    }
+    return c21hip_split_filter_xy2(c->delta_unf, dst, s->hii_filter, 0.f, c->xe_unf, xdst, s->hii_filter, 0.f, c->nx,
+                                   c->ny, c->nz, s->box_len, s->box_len_z, R, R_ct > 0, 0, 0, c->stream);
+}
+
 static int one_radius(ion_ctx *c, int R_ct, unsigned char *first_cross, int next_R) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
@@ -1695,15 +1719,14 @@ static long eul_dfil_stride(const ion_ctx *c) {
 /* `work`: the k-space buffer this radius' filtered density spectrum goes to; `store` = 0: the extrema alone
  * (the radius is expected to take the fused table sweep, which transforms `work` again) */
 static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *mm_host, void *ev, float *work,
-                       int store, int next_R, float *work_next) {
+                       int store, int next_R, float *work_next, float *xwork, float *xwork_next) {
     int status = 0;
     const c21cm_ionize_spec *s = c->s;
     if (s->use_ts_fluct) { /* x_e shares the density grid's window (IonisationBox.c:1551-1553) */
         const int fused = eul_xe_fused(c);
-        float *xe_work = (fused && buf) ? c->xe_work2 : c->xe_work;
-        TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->xe_unf,
-                                    xe_work, s->hii_filter, 0.f, c->nx, c->ny, c->nz, s->box_len,
-                                    s->box_len_z, (float)s->R[R_ct], 1, 0, 0, c->stream));
+        float *xe_work = xwork ? xwork : ((fused && buf) ? c->xe_work2 : c->xe_work);
+        /* (work: delta_work, or delta_work2 for the second radius of a pass-X pair) */
+        TRY(eul_filter_density_xe(c, R_ct, next_R, work, work_next, xe_work, xwork_next));
         if (!fused)
             TRY(c21hip_split_z_c2r(c->xe_work, c->eul_xe[buf], c->nz, c->nx, c->ny, c->nz, c->stream));
     } else {
@@ -1714,8 +1737,8 @@ static int eul_stage_a(ion_ctx *c, int R_ct, int buf, float *delta_fil, double *
         TRY(c21hip_split_z_minmax_only(work, c->nx, c->ny, c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf,
                                        c->stream));
     else
-        TRY(c21hip_split_z_c2r_minmax(s->use_ts_fluct ? c->delta_work : work, delta_fil, eul_dfil_stride(c), c->nx,
-                                      c->ny, c->nz, c->partials, c->scalars + SC_MINMAX + 2 * buf, c->stream));
+        TRY(c21hip_split_z_c2r_minmax(work, delta_fil, eul_dfil_stride(c), c->nx, c->ny, c->nz, c->partials,
+                                      c->scalars + SC_MINMAX + 2 * buf, c->stream));
     TRY(c21hip_d2h(mm_host, c->scalars + SC_MINMAX + 2 * buf, 2 * sizeof(double), c->stream));
     TRY(c21hip_event_record(ev, c->stream));
 done:
@@ -1798,7 +1821,27 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
     int stored[2] = {1, 1};
     const char *ef = getenv("C21CM_EUL_TABLE_FUSED");
     const int fuse_table = use_band && !(ef && ef[0] == '0') && c21hip_z_table_band_supported(c->nx, c->ny, c->nz);
-    const int pair_x = fuse_table && c->wev_pair;
+    /* ... with an x_e grid (banded, fused x_e sweep): delta's spectrum only lives inside stage A (two buffers for the
+     * two members of a pair), the x_e spectrum until the radius' sweep (four) */
+    const int pair_xe = use_band_xe && c->wev_pair && !(ef && ef[0] == '0');
+    float *xbuf[4] = {c->xe_work, c->xe_work2, c->xe_work, c->xe_work2};
+    if (pair_xe) {
+        const size_t wb = c21hip_split_floats(c->nx, c->ny, c->nz) * sizeof(float);
+        if (!c->delta_work2) c->delta_work2 = (float *)c21hip_ws(WS_DELTA_WORK2, wb);
+        /* every x_e spectrum shares its in-place pass Y with one of the two delta spectra: placed against it
+         * (csrc/host/placement.c; plain allocations where the walk does not apply) */
+        if (c->delta_work2) {
+            xbuf[1] = c->xe_work2 = c21_place_work_partner(WS_DELTA_WORK2, WS_XE_WORK2, wb, c->nx, c->ny, c->nz, c->stream);
+            xbuf[2] = c21_place_work_partner(WS_DELTA_WORK, WS_EUL_WORK3, wb, c->nx, c->ny, c->nz, c->stream);
+            xbuf[3] = c21_place_work_partner(WS_DELTA_WORK2, WS_EUL_WORK4, wb, c->nx, c->ny, c->nz, c->stream);
+        }
+        if (!c->delta_work2 || !xbuf[1] || !xbuf[2] || !xbuf[3]) {
+            status = C21CM_MEMORY_ALLOC_ERROR;
+            goto done;
+        }
+        wbuf[1] = wbuf[3] = c->delta_work2; /* (member 1 of either set) */
+    }
+    const int pair_x = (fuse_table && c->wev_pair) || pair_xe;
     if (fuse_table) {
         const size_t wb = c21hip_split_floats(c->nx, c->ny, c->nz) * sizeof(float);
         if (!c->delta_work2) c->delta_work2 = (float *)c21hip_ws(WS_DELTA_WORK2, wb);
@@ -1820,8 +1863,11 @@ static int eul_table_loop(ion_ctx *c, const int *radii, int n, unsigned char *ma
 #define EUL_WORK(i_) (pair_x ? wbuf[(((((i_) - i0) >> 1) & 1) << 1) | (((i_) - i0) & 1)] : wbuf[((i_) - i0) & 1])
     /* the partner the pass X of position i_ also serves: the next radius, when i_ opens a pair */
 #define EUL_NEXT_R(i_) ((pair_x && !(((i_) - i0) & 1) && (i_) + 1 < n) ? radii[(i_) + 1] : -1)
+#define EUL_XWORK(i_) (pair_xe ? xbuf[(((((i_) - i0) >> 1) & 1) << 1) | (((i_) - i0) & 1)] : xbuf[(i_) & 1])
 #define EUL_STAGE_A(i_) eul_stage_a(c, radii[i_], (i_) & 1, dfil[(i_) & 1], mm[(i_) & 1], ev[(i_) & 1], EUL_WORK(i_), \
-                                    stored[(i_) & 1], EUL_NEXT_R(i_), EUL_NEXT_R(i_) >= 0 ? EUL_WORK((i_) + 1) : NULL)
+                                    stored[(i_) & 1], EUL_NEXT_R(i_), EUL_NEXT_R(i_) >= 0 ? EUL_WORK((i_) + 1) : NULL, \
+                                    s->use_ts_fluct && eul_xe_fused(c) ? EUL_XWORK(i_) : NULL,                           \
+                                    (pair_xe && EUL_NEXT_R(i_) >= 0) ? EUL_XWORK((i_) + 1) : NULL)
     int i0 = 0;
     if (fail_host) fail_host[0] = fail_host[2] = 0;
 restart:
@@ -1863,7 +1909,7 @@ restart:
         fill_args(&args, s, R_ct);
         if (use_band_xe) {
             const int banded = eul_band_this(c, R_ct, mask, 1);
-            const float *xw = b ? c->xe_work2 : c->xe_work;
+            const float *xw = EUL_XWORK(i);
             if (banded) {
                 TRY(c21hip_split_z_xe_fcoll_band(
                     xw, dfil[b], eul_dfil_stride(c), c->nion_dense, c->band_xe_pend,
@@ -1949,7 +1995,7 @@ restart:
         TRY(c21hip_finish_mean(sum_dev, (double)c->ntot, s->mass_dep_zeta, s->f_limit_acg,
                                mean_dev, c->stream));
         if (eul_xe_fused(c))
-            TRY(c21hip_split_z_xe_mask(b ? c->xe_work2 : c->xe_work, c->nion_dense, mean_dev, mask, c->nx,
+            TRY(c21hip_split_z_xe_mask(EUL_XWORK(i), c->nion_dense, mean_dev, mask, c->nx,
                                        c->ny, c->nz, R_ct, s->mean_f_coll, s->fix_mean, s->mass_dep_zeta,
                                        s->f_limit_acg, s->ion_eff_factor, c->stream));
         else
@@ -1960,6 +2006,7 @@ restart:
     TRY(c21hip_sync(c->stream));
 #undef EUL_EXPECT_BAND
 #undef EUL_WORK
+#undef EUL_XWORK
 #undef EUL_NEXT_R
 #undef EUL_STAGE_A
 done:
@@ -2192,7 +2239,7 @@ static int native_wev_prepare(ion_ctx *c, int first, int step, void *stream) {
     if (n == 0) return 0;
     /* one filtered grid: two radii per pass-X sweep where two line tiles fit the LDS (C21CM_EUL_PAIR=0: one) */
     const char *ep = getenv("C21CM_EUL_PAIR");
-    const int pair = !spec->use_ts_fluct && c->eul_mask && !(ep && ep[0] == '0') && c21hip_pair_sweep_supported(c->nx);
+    const int pair = c->eul_mask && !(ep && ep[0] == '0') && c21hip_pair_sweep_supported(c->nx);
     const int st = c21hip_wev_prepare(spec->hii_filter, 0.f, spec->hii_filter, 0.f, spec->use_ts_fluct ? 2 : 1,
                                       radii, n, c->nx, c->ny, c->nz, spec->box_len, spec->box_len_z, pair, &on,
                                       stream);
