@@ -610,17 +610,6 @@ int c21hip_fcoll_eulerian_band(const float *delta_fil, long zstride, float *f_pe
                                int r_index, int r_prev, double *partials, int *n_partials_out, void *stream);
 int c21hip_eul_resolve_pending(int r_index, const float *f_pend, const double *thr_dev,
                                unsigned char *first_cross, size_t ntot, void *stream);
-/* ---- plane_yz.hip: pass Y + fused pass Z of one radius in one persistent kernel, the x-plane between
- * them handed over through the XCD's L2 (512^3, two Lagrangian grids).  The Nyquist planes of the work
- * spectra take their y-transform separately (c21hip_split_y_nyq) BEFORE the fused launch. */
-int c21hip_plane_yz_supported(int nx, int ny, int nz);
-int c21hip_split_y_nyq(float *work_a, float *work_b, int nx, int ny, int nz, void *stream);
-int c21hip_plane_yz_ionise(const float *delta_work, const float *stars_work, unsigned char *first_cross,
-                           double *partials, int nx, int ny, int nz, int r_index, double rhocrit_omb,
-                           double ion_eff, int mass_dep_zeta, double f_limit, int store_all, void *stream);
-/* after a synchronisation: bit 0 = a launch ran write-through (workgroups off their XCD), bit 1 = a
- * wait timed out (results invalid); < 0: the query failed.  Clears the flags. */
-int c21hip_plane_yz_status(void *stream);
 void c21hip_ktime_enable(int on);
 int c21hip_ktime_report(int kind, double *ms_total, int *count);
 int c21hip_max_into(void *dst, const void *src, size_t count, int bytes_per_element, void *stream);

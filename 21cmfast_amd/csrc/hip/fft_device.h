@@ -1,5 +1,5 @@
-// fft_device.h -- device-side building blocks shared by the transform kernels of fft_native.hip and
-// the plane-fused pass Y + Z of plane_yz.hip: complex helpers, the small DFTs in registers and the
+// fft_device.h -- device-side building blocks of the transform kernels of fft_native.hip (and of experimental
+// kernels kept outside the product tree): complex helpers, the small DFTs in registers and the
 // wave-level complex-to-real line transform.  Included INSIDE each translation unit's anonymous
 // namespace; the arithmetic of a line is the same instruction sequence wherever it is instantiated
 // (-ffp-contract=off), which is what keeps the fused and the unfused passes bit-identical.

@@ -3421,40 +3421,13 @@ extern "C" int c21hip_native_fft_supported(int nx, int ny, int nz) {
 // two radii per pass-X sweep need two line tiles in LDS
 extern "C" int c21hip_pair_sweep_supported(int nx) { return nx <= 512; }
 
-// ---- for plane_yz.hip (the plane-fused pass Y + Z): the twiddle tables and the timing hook of this file
+// ---- the timing hook of this file for launches issued elsewhere (bench.py: c21hip_ktime_*)
 extern "C" const void *c21hip_twiddles_dev(int n) { return twiddles(n); }
 extern "C" void *c21hip_ktime_begin(int kind, void *stream) {
     return g_ktime_on ? new KTimeScope(kind, (hipStream_t)stream) : nullptr;
 }
 extern "C" void c21hip_ktime_end(void *scope) { delete static_cast<KTimeScope *>(scope); }
 
-// The y-transform of the Nyquist planes of up to two work spectra alone (pass Y's strided epilogue
-// tiles: 2 x nx / 16 of them), for callers whose main blocks take another route through pass Y.
-extern "C" int c21hip_split_y_nyq(float *work_a, float *work_b, int nx, int ny, int nz, void *stream_) {
-    if (!c21hip_native_fft_supported(nx, ny, nz)) {
-        c21hip_set_error("Nyquist-plane pass Y: unsupported box");
-        return C21CM_VALUE_ERROR;
-    }
-    const int H = nz / 2;
-    const long nlines = (long)nx * ny;
-    LinePassArgs a{};
-    a.fp.type = -1;
-    a.n_y = ny;
-    a.n_z = nz;
-    a.out_scale = 1.0f;
-    a.n_geo = 2;
-    a.n_grids = work_b ? 2 : 1;
-    a.g0 = geo_y_main(nx, ny, H, line_tile_cols(ny), split_xb_log2(nx));
-    a.g0.n_outer = 0;  // no main-block items: only the strided tiles of g1 run
-    a.g1 = geo_y_nyq(nx, ny, line_tile_cols(ny));
-    a.g1_strided = 1;
-    float2 *wk[2] = {reinterpret_cast<float2 *>(work_a), reinterpret_cast<float2 *>(work_b)};
-    for (int g = 0; g < a.n_grids; g++) {
-        geo_ptrs(a.g0, g, wk[g], wk[g]);
-        geo_ptrs(a.g1, g, wk[g] + nlines * H, wk[g] + nlines * H);
-    }
-    return dispatch_line_pass<+1>(ny, a, 0, (hipStream_t)stream_);
-}
 
 // Placement probe (ionize_driver.c: place_work_partner): pass Y of two work spectra in one launch, in place on
 // whatever the buffers hold, `reps` launches timed with events on the stream -> *ms per launch.  Which physical

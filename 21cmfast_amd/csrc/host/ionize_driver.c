@@ -373,9 +373,6 @@ typedef struct {
     int x4_on;
     float *x4_unf, *x4_work, *x4_work2;
     const float *cur_x4;
-    int yz;              /* pass Y + fused pass Z as ONE plane-fused kernel (plane_yz.hip: 512^3, two grids) */
-    int yz_now;          /* ... for the radius z_ionise_radius is called for (its main blocks skipped pass Y) */
-    int yz_used;         /* a plane-fused launch happened in this call: its status is checked at the end */
     float *sfr_work2;
     double rec0;         /* homogeneous model: the one previous N_rec */
     int finalised;       /* the post-loop sweep already ran inside final_step() */
@@ -513,9 +510,6 @@ static int ctx_setup(ion_ctx *c, const c21cm_ionize_spec *s, const PerturbedFiel
             c21hip_wev_applicable(s->hii_filter, s->stars_filter, 2, c->nx, c->ny, c->nz))
             c->fused_rc = c->fused = 1;
     }
-    /* Plane-fused pass Y + Z (round 4): the two-grid loop without a third spectrum at 512^3 */
-    c->yz = c->fused && !c->fused_rc && !s->use_ts_fluct && c21hip_plane_yz_supported(c->nx, c->ny, c->nz);
-    c->yz_now = c->yz_used = 0;
     c->eul_pend = -1;
     c->eul_pend_buf = 0;
     c->eul_pend_mask = NULL;
@@ -915,12 +909,6 @@ static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float
             TRY(flush_deferred(c));
         if (c->def_count == 0) c->def_first = R_ct;
         c->def_count++;
-        if (c->yz_now && !xwork)
-            TRY(c21hip_plane_yz_ionise(dwork, swork, first_cross,
-                                       c->def_partials + (long)R_ct * c->def_stride, c->nx, c->ny, c->nz,
-                                       R_ct, s->rhocrit_omb, s->ion_eff_factor, s->mass_dep_zeta,
-                                       s->f_limit_acg, -1, c->stream));
-        else
         TRY(c21hip_split_z_ionise_stars_xe(dwork, swork, xwork, first_cross,
                                            c->def_partials + (long)R_ct * c->def_stride, NULL,
                                            c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
@@ -930,13 +918,6 @@ static int z_ionise_radius(ion_ctx *c, int R_ct, const float *dwork, const float
     }
     {
         double *sum_dev = c->scalars + SC_SUMS + R_ct;
-        if (c->yz_now && !xwork) {
-            TRY(c21hip_plane_yz_ionise(dwork, swork, first_cross, c->partials, c->nx, c->ny, c->nz, R_ct,
-                                       s->rhocrit_omb, s->ion_eff_factor, s->mass_dep_zeta,
-                                       s->f_limit_acg, -1, c->stream));
-            TRY(c21hip_reduce_sum(c->partials, c21hip_z_ionise_partials(c->nx, c->ny, c->nz), sum_dev,
-                                  c->stream));
-        } else
         TRY(c21hip_split_z_ionise_stars_xe(dwork, swork, xwork, first_cross, c->partials, sum_dev,
                                            c->nx, c->ny, c->nz, R_ct, s->rhocrit_omb,
                                            s->ion_eff_factor, s->mass_dep_zeta, s->f_limit_acg,
@@ -990,25 +971,8 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
         const float *xw[2] = {c->fused_rc ? c->sfr_work : (s->use_ts_fluct ? c->xe_work : NULL),
                               c->fused_rc ? c->sfr_work2 : (s->use_ts_fluct ? c->xe_work2 : NULL)};
         const float *xe_of[2] = {c->x3_on ? c->x3_work : NULL, c->x3_on ? c->x3_work2 : NULL};
-        c->yz_now = c->yz;
-        if (c->yz) c->yz_used = 1;
         for (int ph = 0; ph < 3; ph++) { /* pass X, pass Y of R_a, pass Y of R_b */
             const int bits = ph == 0 ? (tab_async ? 2 : 3) : (4 << (ph - 1));
-            if (c->yz && ph > 0) {
-                /* plane-fused pass Y + Z (z_ionise_radius): only the Nyquist planes take pass Y here */
-                TRY(c21hip_split_y_nyq(ph == 1 ? c->delta_work : c->delta_work2,
-                                       ph == 1 ? c->stars_work : c->stars_work2, c->nx, c->ny, c->nz,
-                                       c->stream));
-                if (ph == (yy ? 2 : 1) && tab_async) {
-                    TRY(c21hip_event_record(g_tab.ev_used[buf_a], c->stream));
-                    TRY(c21hip_event_record(g_tab.ev_used[buf_b], c->stream));
-                }
-                if (ph == 1 && !yy) {
-                    c->cur_xe = xe_of[0];
-                    TRY(z_ionise_radius(c, R_a, c->delta_work, c->stars_work, xw[0], first_cross));
-                }
-                continue;
-            }
             TRY(c21hip_split_filter_xy2_pair(
                 c->delta_unf, c->delta_work, c->delta_work2, s->hii_filter, 0.f, c->stars_unf,
                 c->stars_work, c->stars_work2, s->stars_filter, (float)s->mfp_meandens, c->nx,
@@ -1066,7 +1030,6 @@ static int fused_step(ion_ctx *c, int R_a, int R_b, unsigned char *first_cross, 
         c->cur_xe = xe_of[1];
         c->cur_x4 = c->x4_work2;
         TRY(z_ionise_radius(c, R_b, c->delta_work2, c->stars_work2, xw[1], first_cross));
-        c->yz_now = 0;
         goto done;
     } else {
         TRY(c21hip_split_filter_xy2(c->delta_unf, c->delta_work, s->hii_filter, 0.f, c->stars_unf,
@@ -2365,15 +2328,6 @@ int c21cm_ionize_grids(const c21cm_ionize_spec *spec, const PerturbedField *pert
     TRY(c21hip_event_record(ev[2], stream));
     TRY(postloop(&c, box, report));
     TRY(c21hip_event_record(ev[3], stream));
-    if (c.yz_used) { /* the plane-fused launches waited on each other: did any wait time out? */
-        const int yzf = c21hip_plane_yz_status(stream);
-        if (yzf < 0 || (yzf & 2)) {
-            c21hip_set_error("ionize: the plane-fused pass Y + Z timed out waiting for its workgroups "
-                             "(C21CM_YZ=0 selects the separate passes)");
-            status = C21CM_IO_ERROR;
-            goto done;
-        }
-    }
     if (report) {
         report->ms_preloop = c21hip_event_elapsed_ms(ev[0], ev[1]);
         report->ms_rloop = c21hip_event_elapsed_ms(ev[1], ev[2]);
@@ -2497,15 +2451,6 @@ int c21cm_ionize_shard_radii(const c21cm_ionize_spec *spec, int rank, int world,
         g_spectra.stars_r0_ready = 1;
     }
     TRY(c21hip_event_record(ev[2], stream));
-    if (c.yz_used) { /* the plane-fused launches waited on each other: did any wait time out? */
-        const int yzf = c21hip_plane_yz_status(stream);
-        if (yzf < 0 || (yzf & 2)) {
-            c21hip_set_error("ionize: the plane-fused pass Y + Z timed out waiting for its workgroups "
-                             "(C21CM_YZ=0 selects the separate passes)");
-            status = C21CM_IO_ERROR;
-            goto done;
-        }
-    }
     if (report) {
         double means[C21CM_MAX_RADII];
         TRY(c21hip_d2h(means, c.scalars + SC_MEANS, sizeof(means), stream));

@@ -961,52 +961,6 @@ def test_eulerian_table_model_with_xe_grid_fused_mask_pass(api, oracle, pkg, mon
     assert out["1"][2] == pytest.approx(ref["report"].global_xH, abs=2e-4)
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
-def test_plane_fused_pass_yz_equals_separate_passes(api, gpu_lib, monkeypatch, kernel):
-    """512^3, two Lagrangian grids: pass Y and the fused pass Z of a radius run as ONE persistent
-    kernel that hands every x-plane over through the XCD's L2 (plane_yz.hip) -- same butterflies per
-    thread, same lane-to-cell map, same order of the f_coll partial sums as the separate kernels, so
-    every output is bit-identical to them (the default; C21CM_YZ=1 selects the fused kernel), single
-    pass and sharded over 3 ranks; the
-    write-through fallback of a launch whose workgroups are not where their index implies
-    (C21CM_YZ_FORCE_SAFE=1) gives the same bits again."""
-    import torch
-
-    n = 512
-    monkeypatch.setenv("C21CM_YZ", kernel)  # opt-in (DESIGN 8); 2 = pass Y and pass Z on separate waves
-    if not gpu_lib.c21hip_plane_yz_supported(n, n, n):
-        pytest.skip("device is not 8 XCDs x 32 CUs")
-    spec = W.ionize_spec(n, r_bubble_max=40.0)
-    density = W.density_field_torch(n, seed=4321)
-    n_ion = W.nion_from_density(density)
-    monkeypatch.setenv("C21CM_YZ", "0")
-    buf0, _, rep0 = api.ionize_grids(spec, density, n_ion)
-    torch.cuda.synchronize()
-    monkeypatch.setenv("C21CM_YZ", kernel)
-    k = spec.n_radii
-    assert 0.02 < float((buf0.neutral_fraction == 0).float().mean()) < 0.98
-    for mode in ("fast", "safe"):
-        if mode == "safe":
-            monkeypatch.setenv("C21CM_YZ_FORCE_SAFE", "1")
-        buf1, _, rep1 = api.ionize_grids(spec, density, n_ion)
-        torch.cuda.synchronize()
-        for name in ("neutral_fraction", "z_reion", "kinetic_temperature"):
-            assert torch.equal(getattr(buf0, name), getattr(buf1, name)), (mode, name)
-        assert list(rep0.f_coll_grid_mean[:k]) == list(rep1.f_coll_grid_mean[:k]), mode
-        assert rep0.global_xH == rep1.global_xH
-        del buf1
-    monkeypatch.delenv("C21CM_YZ_FORCE_SAFE")
-    world = 3
-    reduced = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
-    for rank in range(world):
-        fc = torch.zeros((n, n, n), dtype=torch.uint8, device="cuda")
-        api.ionize_shard_radii(spec, rank, world, fc, density, n_ion)
-        reduced = torch.maximum(reduced, fc)
-    buf2, _, rep2 = api.ionize_shard_finish(spec, reduced.contiguous(), density, n_ion)
-    torch.cuda.synchronize()
-    assert torch.equal(buf0.neutral_fraction, buf2.neutral_fraction)
-    assert rep0.global_xH == rep2.global_xH
-
 
 @pytest.mark.parametrize("r_lowest", [0, 2])
 def test_closed_form_loop_deferred_barrier_equals_separate_sweep(api, r_lowest, monkeypatch):
