@@ -36,10 +36,16 @@
  *   - a walk that found nothing is not repeated for that slot and size; a decision stands while the slot and its
  *     partner hold the buffers it was taken for, and is retaken when either changed (a slot first allocated plainly,
  *     or placed against another partner, is placed then).
- * C21CM_WS_PLACE=0: never; =force: also with other tenants (benchmarks that know better); C21CM_WS_TRACE=1 prints
- * the candidates.  c21cm_placement_report() tells what the last call decided and what it cost. */
+ *   - a time budget: C21CM_WS_PLACE_MS per walk (default 300 ms), five times that per process.
+ * And it is OPT-IN (round 6, late): what a walk costs is erratic on this driver -- an allocation of 16 GB returns in
+ * 0.1 ms or in 2 s, whichever API hands it out (the memory is cleared when it was dirty) -- and a config-5
+ * evolution whose ComputeIonizedBox calls take 3.3 s in all spent another 2-14 s walking for its four x_e
+ * spectra (profiles/r06_placement_vmm.txt section 5): a drop-in library does not take that decision for its
+ * caller.  C21CM_WS_PLACE=1 or c21cm_placement_set(1) turn it on (steady-state throughput runs: bench.py does, and
+ * says so in its line), =force / 2 also with other tenants; C21CM_WS_TRACE=1 prints the candidates;
+ * c21cm_placement_report() tells what the last call decided and what it cost. */
 
-enum { PLACE_SLOTS = 384, MAXH = 128, PLACE_VMM_DEFAULT = 0 };
+enum { PLACE_SLOTS = 384, MAXH = 128, PLACE_VMM_DEFAULT = 1 };
 enum {
     PL_PLACED = 0,       /* a faster region was found and adopted */
     PL_OFF = 1,          /* C21CM_WS_PLACE=0 / no partner / small buffer */
@@ -48,11 +54,12 @@ enum {
     PL_NOTHING = 4,      /* no candidate differed within the budget */
     PL_REMEMBERED = 5,   /* an earlier walk for this slot and size found nothing */
     PL_BUSY_DEVICE = 6,  /* tenancy unknown and more than half of the device in use */
+    PL_TIME = 7,         /* the walk's time budget ran out (this walk's, or the process') */
 };
 typedef struct {
     size_t bytes;
     void *partner, *ptr;
-    int decided;
+    int decided, mode_gen;
     size_t failed_bytes; /* a walk for this size found nothing */
 } place_rec;
 static place_rec g_rec[PLACE_SLOTS];
@@ -61,6 +68,7 @@ static struct {
     double held_gb, wall_ms;
     float chosen_ms, first_ms;
 } g_last = {-1, 0, -1, 0, -1, 0., 0., 0.f, 0.f};
+static double g_walk_ms_total; /* wall time this process has spent walking */
 
 static double wall_ms_now(void) {
     struct timespec t;
@@ -98,10 +106,27 @@ static void cand_free(cand *c) {
     c->ptr = c->vmm = NULL;
 }
 
+/* Whether the walk runs at all.  OFF unless asked for (round 6): c21cm_placement_set(1) / C21CM_WS_PLACE=1 turn it
+ * on, 2 / "force" also with other tenants on the device, 0 off; -1 back to the environment.  A change of the
+ * setting re-opens the decisions taken under the old one. */
+static int g_mode = -1, g_mode_gen = 0;
+int c21cm_placement_set(int mode) {
+    if (mode < -1 || mode > 2) return C21CM_VALUE_ERROR;
+    if (mode != g_mode) g_mode_gen++;
+    g_mode = mode;
+    return 0;
+}
+static int placement_mode(void) {
+    if (g_mode >= 0) return g_mode;
+    const char *e = getenv("C21CM_WS_PLACE");
+    if (!e || !e[0] || e[0] == '0') return 0;
+    return e[0] == 'f' ? 2 : 1;
+}
+
 static float *plain(place_rec *rec, int slot_new, size_t bytes, void *partner, int outcome, double t0) {
     float *p = (float *)c21hip_ws(slot_new, bytes); /* (keeps a buffer the slot already holds) */
     if (rec) {
-        rec->bytes = bytes, rec->partner = partner, rec->ptr = p, rec->decided = 1;
+        rec->bytes = bytes, rec->partner = partner, rec->ptr = p, rec->decided = 1, rec->mode_gen = g_mode_gen;
     }
     g_last.outcome = outcome, g_last.slot = slot_new;
     g_last.wall_ms = wall_ms_now() - t0;
@@ -113,11 +138,12 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
     float *cur = (float *)c21hip_ws_peek(slot_new, &have);
     float *partner = (float *)c21hip_ws_peek(slot_partner, &phave);
     place_rec *rec = (slot_new >= 0 && slot_new < PLACE_SLOTS) ? &g_rec[slot_new] : NULL;
-    if (cur && have >= bytes && (!rec || (rec->decided && rec->ptr == (void *)cur && rec->partner == (void *)partner)))
+    if (cur && have >= bytes &&
+        (!rec || (rec->decided && rec->mode_gen == g_mode_gen && rec->ptr == (void *)cur && rec->partner == (void *)partner)))
         return cur; /* the decision taken for this pair of buffers stands */
     const double t0 = wall_ms_now();
-    const char *e = getenv("C21CM_WS_PLACE"), *g = getenv("C21CM_WS_PLACE_GB");
-    const int off = e && e[0] == '0', force = e && e[0] == 'f';
+    const char *g = getenv("C21CM_WS_PLACE_GB");
+    const int off = placement_mode() == 0, force = placement_mode() == 2;
     const double max_gb = (g && atof(g) > 0.) ? atof(g) : 200.;
     g_last.probes = 0, g_last.held_gb = 0., g_last.chosen_ms = g_last.first_ms = 0.f, g_last.tenants = -1;
     if (off || !partner || phave < bytes || bytes < ((size_t)256 << 20))
@@ -143,6 +169,22 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
         return plain(rec, slot_new, bytes, partner, PL_LOCKED, t0);
     }
 
+    /* Time budget (round 6): the walk buys 1-4 ms per 512^3 call, and what it costs is erratic -- the driver
+     * clears memory it hands out when it was dirty, 38-45 ms per GB: a config-5 evolution spent 16 of its 21 s
+     * walking before this (profiles/r06_placement_vmm.txt section 5).  C21CM_WS_PLACE_MS per walk (default 300),
+     * five times that per process; phase 1 takes its chunks from hipMemCreate with only the probed head mapped
+     * (no clearing, ~0.1 ms per chunk), only the exact-size candidates of phase 2 come from hipMalloc. */
+    const char *etm = getenv("C21CM_WS_PLACE_MS");
+    const double walk_ms = (etm && atof(etm) > 0.) ? atof(etm) : 300.;
+    if (g_walk_ms_total > 5. * walk_ms && !force) {
+        if (lock_fd >= 0) {
+            (void)flock(lock_fd, LOCK_UN);
+            close(lock_fd);
+        }
+        return plain(rec, slot_new, bytes, partner, PL_TIME, t0);
+    }
+    const double deadline = t0 + walk_ms;
+    int timed_out = 0;
     cand held[MAXH];
     float t_of[MAXH];
     const char *ea = getenv("C21CM_WS_PLACE_ALLOC");
@@ -183,6 +225,10 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
         if (i_worst < 0 || t > t_of[i_worst]) i_worst = n_held - 1;
         if (t_cur > 0.f && t_cur < 0.96f * t) break;                /* the current buffer is of the fast class */
         if (t_of[i_worst] > 1.08f * t_of[i_best]) break;            /* both classes seen */
+        if (wall_ms_now() > deadline) {
+            timed_out = 1;
+            break;
+        }
     }
     cand chosen = {NULL, NULL};
     int keep_current = 0;
@@ -200,6 +246,10 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
             cand_free(&held[i_best]);
             used -= chunk;
             while (n_held < MAXH && used + bytes <= budget) {
+                if (wall_ms_now() > deadline) {
+                    timed_out = 1;
+                    break;
+                }
                 cand p;
                 /* always hipMalloc: a buffer mapped through hipMemMap runs the passes of the loop slower than
                  * one from hipMalloc even where the probe times the pair fast (profiles/r06_placement_vmm.txt) */
@@ -226,19 +276,20 @@ float *c21_place_work_partner(int slot_partner, int slot_new, size_t bytes, int 
         close(lock_fd);
     }
     g_last.held_gb = (double)peak / 1073741824.;
+    g_walk_ms_total += wall_ms_now() - t0;
     if (keep_current) {
         float *p = plain(rec, slot_new, bytes, partner, PL_PLACED, t0);
         return p;
     }
     if (!chosen.ptr) {
-        if (rec) rec->failed_bytes = bytes;
-        return plain(rec, slot_new, bytes, partner, PL_NOTHING, t0);
+        if (rec) rec->failed_bytes = bytes; /* (not repeated for this size, whether nothing differed or time ran out) */
+        return plain(rec, slot_new, bytes, partner, timed_out ? PL_TIME : PL_NOTHING, t0);
     }
     if (chosen.vmm ? c21hip_ws_adopt_vmm(slot_new, chosen.vmm, bytes) : c21hip_ws_adopt(slot_new, chosen.ptr, bytes)) {
         cand_free(&chosen);
         return plain(rec, slot_new, bytes, partner, PL_NOTHING, t0);
     }
-    if (rec) rec->bytes = bytes, rec->partner = partner, rec->ptr = chosen.ptr, rec->decided = 1;
+    if (rec) rec->bytes = bytes, rec->partner = partner, rec->ptr = chosen.ptr, rec->decided = 1, rec->mode_gen = g_mode_gen;
     g_last.outcome = PL_PLACED, g_last.slot = slot_new;
     g_last.wall_ms = wall_ms_now() - t0;
     return (float *)chosen.ptr;

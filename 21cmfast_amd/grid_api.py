@@ -451,7 +451,8 @@ def combine_cross_g12(mask, g12, peer_mask, peer_g12, stream=None):
 
 PLACEMENT_OUTCOMES = ("placed against the partner by timed launches", "off / not applicable",
                       "other tenants on the device", "another process was walking", "no faster candidate in the budget",
-                      "an earlier walk for this size found nothing", "tenancy unknown and the device is busy")
+                      "an earlier walk for this size found nothing", "tenancy unknown and the device is busy",
+                      "the walk's time budget ran out")
 
 
 def placement_report():
@@ -465,6 +466,14 @@ def placement_report():
     return {"outcome": PLACEMENT_OUTCOMES[int(out[0])], "held_GB": round(out[1], 2), "probes": int(out[2]),
             "chosen_ms": round(out[3], 4), "first_candidate_ms": round(out[4], 4), "decision_wall_ms": round(out[5], 2),
             "tenants": int(out[6]), "walks": int(out[7])}
+
+
+def placement_set(mode: int):
+    """Opt into (1; 2 = also on a shared device) or out of (0) the placement walk of the work spectra; -1: the
+    environment's C21CM_WS_PLACE (unset: off).  csrc/host/placement.c."""
+    lib = load()
+    lib.c21cm_placement_set.restype = C.c_int
+    check(lib.c21cm_placement_set(C.c_int(mode)), "c21cm_placement_set")
 
 
 def shard_init_from_torch(group=None):

@@ -421,6 +421,18 @@ def run_icpf(args, torch, pkg):
                                                "profiles/r04_pmc_cic.json)",
                                        "nominal_GBs": cic_bytes / (pf_ms * 1e-3) / 1e9}},
     }
+    # HBM bytes of one IC + PerturbedField step from the PMC passes of this command (tools/job_profiles.sh ->
+    # profiles/pmc_icpf_rNN.json; None when no such profile is in the tree)
+    pmc_files = sorted((ROOT / "profiles").glob("pmc_icpf_r*.json"))
+    if pmc_files:
+        try:
+            pmc = json.loads(pmc_files[-1].read_text())
+            out["roofline"]["traffic"] = pmc["hbm_bytes_per_step"]
+            out["roofline"]["traffic_scope"] = ("one step = InitialConditions + PerturbedField (all kernels), "
+                                                f"profiles/{pmc_files[-1].name}: {pmc['source']}")
+            out["roofline"]["actual_hbm_frac"] = pmc["hbm_bytes_per_step"] / (ms * 1e-3) / 8e12
+        except (OSError, ValueError, KeyError):
+            pass
     if not args.no_cpu_baseline:
         oracle = importlib.import_module("oracle.oracle")
         cores = min(os.cpu_count() or 1, 64)
@@ -630,12 +642,27 @@ def main():
             # ADVICE r5); the slab-resident opt-in is timed beside it
             wl.step_sharded(shard_c, gather=True)
 
-    # the first call of a size pays for the workspace allocations, the node tables and -- where the process has
-    # the device to itself -- the placement walk of the work spectra (csrc/host/placement.c): reported, not timed
+    # the first call of a size pays for the workspace allocations and the node tables: reported, not timed
     t_cold = time.perf_counter()
     step()
     torch.cuda.synchronize()
     first_call_ms = (time.perf_counter() - t_cold) * 1e3
+    # Where the work spectra sit in HBM (csrc/host/placement.c).  The library allocates plainly unless asked (a walk
+    # costs 0.01-5 s once per process and box size and buys 1-4 ms per 512^3 call: the caller's decision).  This
+    # benchmark measures steady-state throughput, so it asks -- after timing the library's default as well:
+    # `default_allocation` = plain hipMalloc, the headline = with the second spectrum of each two-grid sweep placed
+    # by timed launches (C21CM_WS_PLACE=0 in the environment keeps the plain allocations for the headline too).
+    default_alloc = None
+    if os.environ.get("C21CM_WS_PLACE", "") == "" and not sharded:
+        ms_plain = timed(step, max(3, args.steps // 2), 1)
+        default_alloc = {"ms_per_step": ms_plain, "value": float(n) ** 3 / (ms_plain * 1e-3), "unit": "cells/s",
+                         "what": "the library's default: plain allocations, no placement walk"}
+        os.environ.setdefault("C21CM_WS_PLACE_MS", "20000")  # (a throughput run waits for its walk; default 300 ms)
+        api.placement_set(1)
+        t_walk = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        default_alloc["placement_call_ms"] = (time.perf_counter() - t_walk) * 1e3
     placement = api.placement_report()
     ms_per_step = timed(step, args.steps, args.warmup)
     ms_slab_resident = None
@@ -857,13 +884,16 @@ def main():
                     "rccl_comm_count": rccl_ranks} if shard_phases is not None else {}),
                 "fft": "native" if native else "rocfft",
                 # where the work spectra sit in HBM (csrc/host/placement.c; decided once, in the warm-up)
-                "work_spectra_placement": "plain hipMalloc" if os.environ.get("C21CM_WS_PLACE", "1")[:1] == "0"
-                else "second spectrum of each two-grid sweep chosen by timed launches",
+                "work_spectra_placement": "plain hipMalloc (the library's default)"
+                if (placement or {}).get("outcome", "").startswith(("off", "other", "another")) or not placement
+                else "second spectrum of each two-grid sweep chosen by timed launches (opt-in: c21cm_placement_set(1)); "
+                     "the library's default is timed in default_allocation",
                 "global_xH": global_xh,
             },
             "roofline": roof,
             "first_call_ms": first_call_ms,
             "placement": placement,
+            **({"default_allocation": default_alloc} if default_alloc else {}),
         }
         if same_run is not None:
             out["single_gpu_same_run"] = same_run

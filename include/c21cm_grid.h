@@ -716,10 +716,13 @@ const char *c21cm_last_error(void);
 
 /* Placement of the second work spectrum of a two-grid sweep (csrc/host/placement.c): what the last decision was.
  * out = {outcome (0 placed by timed launches, 1 off / not applicable, 2 other tenants on the device, 3 another
- * process walking, 4 nothing faster within the budget, 5 remembered failure, 6 tenancy unknown + busy device),
+ * process walking, 4 nothing faster within the budget, 5 remembered failure, 6 tenancy unknown + busy device, 7 time budget exhausted),
  * GB held at the peak of the walk, timed probes, ms of the chosen pair, ms of the first candidate, wall ms of the
  * decision, tenants seen (-1 unknown), walks of this process so far}.  C21CM_VALUE_ERROR before any decision. */
 int c21cm_placement_report(double out[8]);
+/* The walk is opt-in: 1 on, 2 on even with other tenants on the device, 0 off, -1 the environment's C21CM_WS_PLACE
+ * (unset: off).  Changing the setting re-opens the decisions taken under the old one. */
+int c21cm_placement_set(int mode);
 
 #ifdef __cplusplus
 }

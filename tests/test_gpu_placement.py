@@ -42,6 +42,7 @@ def _run(tmp_path, place):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, C21CM_WS_PLACE=place, C21CM_WS_TRACE="1")
+    env["C21CM_WS_PLACE_MS"] = "30000"  # (the time budget of a walk is not under test here)
     if place == "force":  # (this pytest process may hold device memory: the walk would see a second tenant and stay
         env["C21CM_WS_PLACE_GB"] = "96"  # out; forced here, with a budget that leaves room for xdist neighbours)
     p = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, env=env, timeout=900)
@@ -72,8 +73,7 @@ def test_walk_stays_out_when_the_device_is_shared(tmp_path, gpu_lib):
     torch.cuda.synchronize()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, C21CM_WS_TRACE="1")
-    env.pop("C21CM_WS_PLACE", None)
+    env = dict(os.environ, C21CM_WS_TRACE="1", C21CM_WS_PLACE="1")  # opted in -- but not alone on the device
     p = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     rep = eval([ln for ln in p.stdout.splitlines() if ln.startswith("PLACEMENT")][-1][len("PLACEMENT "):])
@@ -84,6 +84,22 @@ def test_walk_stays_out_when_the_device_is_shared(tmp_path, gpu_lib):
     off, _ = _run(tmp_path, "0")
     assert [ln for ln in p.stdout.splitlines() if ln.startswith("HASH")][0] == off
     del hold
+
+
+def test_the_walk_is_opt_in(tmp_path):
+    """The library's default allocates plainly (round 6: what a walk costs is erratic -- 0.01 to 5 s -- and is the
+    caller's decision): no candidate timed, nothing held, same bits."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, C21CM_WS_TRACE="1")
+    env.pop("C21CM_WS_PLACE", None)
+    p = subprocess.run([sys.executable, str(script), str(ROOT)], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rep = eval([ln for ln in p.stdout.splitlines() if ln.startswith("PLACEMENT")][-1][len("PLACEMENT "):])
+    assert rep["outcome"] == "off / not applicable" and rep["held_GB"] == 0 and rep["probes"] == 0
+    assert "[place]" not in p.stderr
+    off, _ = _run(tmp_path, "0")
+    assert [ln for ln in p.stdout.splitlines() if ln.startswith("HASH")][0] == off
 
 
 def test_two_benches_at_once_on_one_gpu():

@@ -87,7 +87,37 @@ def per_kernel_csv(directory, counter, out):
             w.writerow([name, len(v), f"{sum(v) / len(v):.1f}", f"{sum(v):.1f}"])
 
 
+def totals(fetch_dir, write_dir, out, n_steps, prefix=None):
+    """Every kernel of a run (e.g. bench.py --mode icpf with n_steps steps in all): HBM bytes per step and the
+    kernels that move most of them.  Same units and correction as the per-kernel form."""
+    if prefix:
+        per_kernel_csv(fetch_dir, "FETCH_SIZE", f"{prefix}_FETCH_SIZE_per_kernel.csv")
+        per_kernel_csv(write_dir, "WRITE_SIZE", f"{prefix}_WRITE_SIZE_per_kernel.csv")
+    fetch, write = defaultdict(float), defaultdict(float)
+    calls = defaultdict(int)
+    for row in rows(fetch_dir, "FETCH_SIZE"):
+        k = short_name(row["Kernel_Name"])
+        fetch[k] += float(row["Counter_Value"]) * 1024 * 2
+        calls[k] += 1
+    for row in rows(write_dir, "WRITE_SIZE"):
+        write[short_name(row["Kernel_Name"])] += float(row["Counter_Value"]) * 1024
+    names = sorted(set(fetch) | set(write), key=lambda k: -(fetch[k] + write[k]))
+    result = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB -> bytes, "
+                        "FETCH_SIZE x2 (gfx950 wide-read correction), summed over every kernel of the run",
+              "steps_in_run": n_steps,
+              "fetch_bytes_per_step": sum(fetch.values()) / n_steps,
+              "write_bytes_per_step": sum(write.values()) / n_steps,
+              "hbm_bytes_per_step": (sum(fetch.values()) + sum(write.values())) / n_steps,
+              "top_kernels": [{"kernel": k, "launches_per_step": calls[k] / n_steps,
+                               "hbm_bytes_per_step": (fetch[k] + write[k]) / n_steps} for k in names[:16]]}
+    with open(out, "w") as f:
+        json.dump(result, f, indent=1)
+    print(json.dumps(result, indent=1)[:1500])
+
+
 def main():
+    if len(sys.argv) > 5 and sys.argv[5].startswith("total:"):
+        return totals(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[5].split(":")[1]), sys.argv[4] or None)
     fetch_dir, write_dir, out = sys.argv[1:4]
     if len(sys.argv) > 5 and sys.argv[5] == "1024":  # config 4's kernels (one radius per sweep, whole-wave pass Z)
         KERNELS.clear()
