@@ -237,6 +237,11 @@ int c21hip_split_sepop_xy(const float *split_src, float *split_work, int nx, int
                           double box_len, double box_len_z, int axis0, int axis1, void *stream);
 int c21hip_split_fold(const float *hi_split, float *lo_split, int nx, int ny, int nz, int f,
                       double box_len, double box_len_z, int axis0, int axis1, void *stream);
+/* ... up to four folded spectra of one hi spectrum in one read: ops[k] = -1 identity, 0 / 1 / 2 gradient axis;
+ * tophat_R > 0: the top-hat of that radius applied to the stored elements on the way (the filtered spectrum is
+ * never written) */
+int c21hip_split_fold_multi(const float *hi_split, float *const lo_split[4], const int ops[4], int n_out, int nx,
+                            int ny, int nz, int f, double box_len, double box_len_z, float tophat_R, void *stream);
 int c21hip_lpt2_source(const float *const diag[3], const float *const off[3], float *out, size_t n,
                        float norm, void *stream);
 int c21hip_copy_filter_split(const float *src_split, float *dst_split, int nx, int ny, int nz,
@@ -407,6 +412,9 @@ int c21hip_vcb_accumulate(const float *src_padded, const int hi_dim[3], float *d
 int c21hip_sample_modes(float *cbox, int nx, int ny, int nz, const double *pk_by_m_dev,
                         float volume, unsigned long long seed, const double *deviates_dev,
                         void *stream);
+/* ... straight into the split layout of the native transforms */
+int c21hip_sample_modes_split(float *split, int nx, int ny, int nz, const double *pk_by_m_dev, float volume,
+                              unsigned long long seed, const double *deviates_dev, void *stream);
 /* axis1 < 0: out = in*i*k_axis0/k^2 (:240-267); else out = -k_axis0*k_axis1*in/k^2 (:269-297) */
 int c21hip_kspace_op(const float *in_c, float *out_c, int nx, int ny, int nz, double box_len,
                      double box_len_z, int axis0, int axis1, void *stream);

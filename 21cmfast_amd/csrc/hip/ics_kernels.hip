@@ -94,7 +94,7 @@ __device__ __forceinline__ bool hermitian_source(int i, int j, int nx, int ny, i
 __global__ void __launch_bounds__(kBlock)
 sample_modes_kernel(float2 *__restrict__ cbox, int nx, int ny, int nz,
                     const double *__restrict__ pk_by_m, float volume, uint64_t seed,
-                    const double2 *__restrict__ deviates) {
+                    const double2 *__restrict__ deviates, float2 *__restrict__ split_nyq, int lb) {
     const int nzc = nz / 2 + 1, mx = nx / 2, my = ny / 2, mz = nz / 2;
     const size_t total = (size_t)nx * ny * nzc;
     for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total;
@@ -134,7 +134,14 @@ sample_modes_kernel(float2 *__restrict__ cbox, int nx, int ny, int nz,
                    cz = (n_z == 0 || n_z == mz);
         if (cx && cy && cz) im = 0.f;  // the 7 self-conjugate modes are real (:46-48)
         if (t == 0) re = 0.f;          // zero mode (:50)
-        cbox[t] = make_float2(re, im);
+        // split_nyq != NULL: cbox is the main block of a split spectrum (round 6: the sampler writes the layout
+        // the transforms read -- no padded copy, no conversion sweep)
+        if (!split_nyq)
+            cbox[t] = make_float2(re, im);
+        else if (n_z == mz)
+            split_nyq[line] = make_float2(re, im);
+        else
+            cbox[(size_t)c21_memory_line((long)line, ny, lb) * (size_t)mz + n_z] = make_float2(re, im);
     }
 }
 
@@ -336,6 +343,98 @@ fold_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_ny
     }
 }
 
+// The same for up to FOUR outputs of one spectrum in one read (round 6): the low-resolution density and the three
+// velocity components are folds of the SAME filtered spectrum under the operators 1, i k_x / k^2, i k_y / k^2,
+// i k_z / k^2 (InitialConditions.c:299-364,694-730) -- seven fold launches per 2LPT call read the DIM^3 spectrum
+// seven times (0.28 ms each at DIM = 512), two of these read it twice.  ops[k]: -1 identity, 0 / 1 / 2 the gradient
+// along that axis.  1 / k^2 is formed once per alias (a reciprocal where kop_factor divides per axis: the factor
+// moves by at most an ulp of a double before the product is rounded to float).
+struct FoldOuts {
+    float2 *main[4], *nyq[4];
+    int op[4];
+    int n;
+};
+__global__ void __launch_bounds__(kBlock)
+fold_multi_kernel(const float2 *__restrict__ in_main, const float2 *__restrict__ in_nyq, FoldOuts o, int nx,
+                  int ny, int nz, int f, double len_x, double len_y, double len_z, int lb_in, int lb_out,
+                  float tophat_R) {
+    const int H = nz / 2, mx = nx / f, my = ny / f, mz = nz / f, Hl = mz / 2;
+    const size_t total = (size_t)mx * my * (Hl + 1);
+    for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+        const size_t line = t / (size_t)(Hl + 1);
+        const int qz = (int)(t - line * (size_t)(Hl + 1));
+        const int qx = (int)(line / (size_t)my), qy = (int)(line - (size_t)qx * my);
+        double acc_r[4] = {0., 0., 0., 0.}, acc_i[4] = {0., 0., 0., 0.};
+        for (int a = 0; a < f; a++)
+            for (int b = 0; b < f; b++)
+                for (int c = 0; c < f; c++) {
+                    int sx = qx + a * mx, sy = qy + b * my, sz = qz + c * mz;
+                    const bool partner = sz > H;
+                    if (partner) {
+                        sx = (nx - sx) % nx;
+                        sy = (ny - sy) % ny;
+                        sz = nz - sz;
+                    }
+                    const size_t sl = (size_t)sx * ny + sy;
+                    float2 v = (sz == H) ? in_nyq[sl]
+                                         : in_main[(size_t)c21_memory_line((long)sl, ny, lb_in) * (size_t)H + sz];
+                    if (tophat_R > 0.f) {
+                        // the real-space top-hat at the low-resolution cell scale on the stored element, as the copy +
+                        // filter_box sweep applies it (filtering.c:327-369: float wavenumbers, float squares summed in
+                        // float, kR held in float, the window in double, the product rounded to float) -- the
+                        // filtered spectrum is then never written (InitialConditions.c:700-703)
+                        const float kx = (sx > nx / 2) ? (float)((double)(sx - nx) * (2.0 * M_PI / len_x))
+                                                       : (float)((double)sx * (2.0 * M_PI / len_x));
+                        const float ky = (sy > ny / 2) ? (float)((double)(sy - ny) * (2.0 * M_PI / len_y))
+                                                       : (float)((double)sy * (2.0 * M_PI / len_y));
+                        const float kz = (float)((double)sz * (2.0 * M_PI / len_z));
+                        const float ksq = __fadd_rn(__fadd_rn(__fmul_rn(kx, kx), __fmul_rn(ky, ky)), __fmul_rn(kz, kz));
+                        const float kRf = (float)(sqrt((double)ksq) * (double)tophat_R);
+                        const double kR = (double)kRf;
+                        double w;
+                        if (kR < 1e-4) {
+                            w = 1 - kR * kR / 10;
+                        } else {
+                            double sn, cs;
+                            sincos(kR, &sn, &cs);
+                            w = 3.0 / (kR * kR * kR) * (sn - cs * kR);
+                        }
+                        v.x = (float)((double)v.x * w);
+                        v.y = (float)((double)v.y * w);
+                    }
+                    const double kvec[3] = {index_to_k(sx, len_x, nx), index_to_k(sy, len_y, ny),
+                                            index_to_k(sz, len_z, nz)};
+                    const double k_sq = kvec[0] * kvec[0] + kvec[1] * kvec[1] + kvec[2] * kvec[2];
+                    const bool dc = (sx == 0 && sy == 0 && sz == 0);
+                    const double inv = dc ? 0. : 1. / k_sq;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k >= o.n) break;
+                        double pr, pi;
+                        if (o.op[k] < 0) {
+                            pr = (double)v.x;
+                            pi = (double)v.y;
+                        } else {  // times i g, g = k_a / k^2
+                            const double g = kvec[o.op[k]] * inv;
+                            pr = -(double)v.y * g;
+                            pi = (double)v.x * g;
+                        }
+                        acc_r[k] += pr;
+                        acc_i[k] += partner ? -pi : pi;
+                    }
+                }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= o.n) break;
+            const float2 r = make_float2((float)acc_r[k], (float)acc_i[k]);
+            if (qz == Hl)
+                o.nyq[k][line] = r;
+            else
+                o.main[k][(size_t)c21_memory_line((long)line, my, lb_out) * (size_t)Hl + qz] = r;
+        }
+    }
+}
+
 // The 2LPT source from the six second derivatives, all dense (InitialConditions.c:451-493):
 // box = 0; for (i,j) in (0,1),(0,2),(1,2): box += phi_ii phi_jj; box -= phi_ij^2, every step
 // rounded to float as the reference's in-place loops do; then / norm.
@@ -411,7 +510,19 @@ extern "C" int c21hip_sample_modes(float *cbox, int nx, int ny, int nz, const do
     const size_t total = (size_t)nx * ny * (nz / 2 + 1);
     hipLaunchKernelGGL(sample_modes_kernel, dim3(grid_for(total)), dim3(kBlock), 0,
                        (hipStream_t)stream, (float2 *)cbox, nx, ny, nz, pk_by_m_dev, volume,
-                       (uint64_t)seed, (const double2 *)deviates_dev);
+                       (uint64_t)seed, (const double2 *)deviates_dev, (float2 *)nullptr, 0);
+    LAUNCH_CHECK();
+    return 0;
+}
+// the same modes written straight into the split layout (main [lines][nz/2] + Nyquist plane [lines])
+extern "C" int c21hip_sample_modes_split(float *split, int nx, int ny, int nz, const double *pk_by_m_dev,
+                                         float volume, unsigned long long seed, const double *deviates_dev,
+                                         void *stream) {
+    const size_t total = (size_t)nx * ny * (nz / 2 + 1);
+    float2 *main = (float2 *)split;
+    hipLaunchKernelGGL(sample_modes_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, main, nx,
+                       ny, nz, pk_by_m_dev, volume, (uint64_t)seed, (const double2 *)deviates_dev,
+                       main + (size_t)nx * ny * (nz / 2), c21hip_split_xblock_log2(nx));
     LAUNCH_CHECK();
     return 0;
 }
@@ -530,6 +641,37 @@ extern "C" int c21hip_split_fold(const float *hi_split, float *lo_split, int nx,
                        (hipStream_t)stream, im, im + n_main, om, om + l_main, nx, ny, nz, f,
                        box_len, box_len, box_len_z, axis0, axis1, c21hip_split_xblock_log2(nx),
                        c21hip_split_xblock_log2(mx));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// hi spectrum -> n_out (<= 4) folded lo spectra, ops[k] = -1 (identity) or the gradient axis 0 / 1 / 2
+// tophat_R > 0: the top-hat window of that radius is applied to every stored element first (fold(filter(X)))
+extern "C" int c21hip_split_fold_multi(const float *hi_split, float *const lo_split[4], const int ops[4], int n_out,
+                                       int nx, int ny, int nz, int f, double box_len, double box_len_z,
+                                       float tophat_R, void *stream) {
+    if (f < 1 || nx % f || ny % f || nz % f || (nz / f) % 2 || n_out < 1 || n_out > 4) {
+        c21hip_set_error("fold: %dx%dx%d / %d with %d outputs is not supported", nx, ny, nz, f, n_out);
+        return C21CM_VALUE_ERROR;
+    }
+    const size_t n_main = (size_t)nx * ny * (nz / 2);
+    const int mx = nx / f, my = ny / f, mz = nz / f;
+    const size_t l_main = (size_t)mx * my * (mz / 2);
+    const float2 *im = reinterpret_cast<const float2 *>(hi_split);
+    FoldOuts o{};
+    o.n = n_out;
+    for (int k = 0; k < n_out; k++) {
+        if (ops[k] < -1 || ops[k] > 2 || !lo_split[k]) {
+            c21hip_set_error("fold: operator %d / NULL output", ops[k]);
+            return C21CM_VALUE_ERROR;
+        }
+        o.main[k] = reinterpret_cast<float2 *>(lo_split[k]);
+        o.nyq[k] = o.main[k] + l_main;
+        o.op[k] = ops[k];
+    }
+    hipLaunchKernelGGL(fold_multi_kernel, dim3(grid_for((size_t)mx * my * (mz / 2 + 1))), dim3(kBlock), 0,
+                       (hipStream_t)stream, im, im + n_main, o, nx, ny, nz, f, box_len, box_len, box_len_z,
+                       c21hip_split_xblock_log2(nx), c21hip_split_xblock_log2(mx), tophat_R);
     LAUNCH_CHECK();
     return 0;
 }

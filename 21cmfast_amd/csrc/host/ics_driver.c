@@ -114,7 +114,8 @@ enum {
     WS_IS_SAVED = 100, WS_IS_FILT, WS_IS_WORK, WS_IS_LO, WS_IS_LOWORK, WS_IS_BOX,
     WS_IS_D0 = 106, /* 107, 108 */
     WS_IS_O0 = 109, /* 110, 111 */
-    WS_IS_OUT = 112, WS_IS_IN = 113, WS_IS_PK2 = 114
+    WS_IS_OUT = 112, WS_IS_IN = 113, WS_IS_PK2 = 114,
+    WS_IS_LO1 = 115 /* 116, 117: the folded spectra of one fused fold (lo_fields) */
 };
 
 typedef struct {
@@ -191,6 +192,46 @@ done:
     return status;
 }
 
+/* Several low-resolution fields of ONE filtered spectrum (the density and / or the three velocity components):
+ * one fold launch reads the DIM^3 spectrum for all of them (round 6; C21CM_ICS_FOLD=single: one launch each). */
+static int lo_fields(is_ctx *c, const float *filt_spec, int n, const int ops[4], float *const targets[4],
+                     float divisor, float tophat_R) {
+    int status = 0;
+    const c21cm_ics_spec *s = c->s;
+    const char *e = getenv("C21CM_ICS_FOLD");
+    int m = 0, use_ops[4];
+    float *use_t[4], *lo_k[4];
+    for (int k = 0; k < n; k++)
+        if (targets[k]) use_ops[m] = ops[k], use_t[m] = targets[k], m++;
+    if (m == 0) return 0;
+    if (m == 1 || (e && e[0] == 's')) {
+        if (tophat_R > 0.f) { /* the separate sweep of round 5: the filtered spectrum written, then read per field */
+            TRY(c21hip_copy_filter_split(filt_spec, c->filt, c->hi[0], c->hi[1], c->hi[2], s->box_len, s->box_len_z, 0,
+                                         tophat_R, 0.f, 1, c->stream));
+            filt_spec = c->filt;
+        }
+        for (int k = 0; k < m; k++) TRY(lo_field(c, filt_spec, use_ops[k], -1, use_t[k], divisor));
+        return 0;
+    }
+    lo_k[0] = c->lo_k;
+    for (int k = 1; k < m; k++)
+        if (!(lo_k[k] = (float *)c21hip_ws(WS_IS_LO1 + k - 1, c->sfl_lo * sizeof(float)))) return C21CM_MEMORY_ALLOC_ERROR;
+    TRY(c21hip_split_fold_multi(filt_spec, lo_k, use_ops, m, c->hi[0], c->hi[1], c->hi[2], c->f, s->box_len,
+                                s->box_len_z, tophat_R, c->stream));
+    const size_t nlo = (size_t)c->lo[0] * c->lo[1] * c->lo[2];
+    for (int k = 0; k < m; k++) {
+        int is_host;
+        float *d_out = out_target(use_t[k], nlo, &is_host);
+        if (!d_out) return C21CM_MEMORY_ALLOC_ERROR;
+        TRY(c21hip_split_filter_xy(lo_k[k], c->lo_work, c->lo[0], c->lo[1], c->lo[2], s->box_len, s->box_len_z, 0,
+                                   0.f, 0.f, 0, c->stream));
+        TRY(c21hip_split_z_c2r_div(c->lo_work, d_out, c->lo[2], c->lo[0], c->lo[1], c->lo[2], divisor, c->stream));
+        TRY(out_finish(use_t[k], d_out, nlo, is_host, c->stream));
+    }
+done:
+    return status;
+}
+
 static int ics_split_supported(const c21cm_ics_spec *s) {
     const char *e = getenv("C21CM_ICS");
     if (e && e[0] == 'p') return 0; /* C21CM_ICS=padded */
@@ -252,33 +293,32 @@ static int ics_grids_split(const c21cm_ics_spec *s, InitialConditions *ics, floa
             return C21CM_VALUE_ERROR;
         }
         double *pk_dev = (double *)c21hip_ws(WS_IC_PK, (size_t)n_m * sizeof(double));
-        /* the sampler writes the FFTW-style padded layout; one conversion per call */
-        float *padded = (float *)c21hip_ws(WS_IS_BOX, (c.ntot + 2 * (size_t)c.hi[0] * c.hi[1]) * sizeof(float));
-        if (!pk_dev || !padded) return C21CM_MEMORY_ALLOC_ERROR;
+        if (!pk_dev) return C21CM_MEMORY_ALLOC_ERROR;
         TRY(c21hip_h2d(pk_dev, s->pk_by_m, (size_t)n_m * sizeof(double), stream));
         const double *dev_ab = NULL;
         TRY(stream_deviates(s, stream, &dev_ab));
-        TRY(c21hip_sample_modes(padded, c.hi[0], c.hi[1], c.hi[2], pk_dev, VOLUME, s->seed, dev_ab,
-                                stream));
-        TRY(c21hip_padded_to_split(padded, c.saved, c.hi[0], c.hi[1], c.hi[2], stream));
+        /* (round 6: the sampler writes the split layout itself -- no padded copy, no conversion sweep) */
+        TRY(c21hip_sample_modes_split(c.saved, c.hi[0], c.hi[1], c.hi[2], pk_dev, VOLUME, s->seed, dev_ab, stream));
         TRY(hi_field(&c, c.saved, -1, -1, ics->hires_density, VOLUME));
     }
     /* the top-hat at the low-resolution cell scale is common to every low-resolution output and
      * commutes with the k-space operators: applied once (InitialConditions.c:700-703,330-333) */
-    if (need_filter)
+    if (need_filter && hires)
         TRY(c21hip_copy_filter_split(c.saved, c.filt, c.hi[0], c.hi[1], c.hi[2], s->box_len,
                                      s->box_len_z, 0, R_lo, 0.f, 1, stream));
-    if (need_filter)
-        TRY(lo_field(&c, c.filt, -1, -1, ics->lowres_density, VOLUME));
-    else
-        TRY(hi_field(&c, c.saved, -1, -1, ics->lowres_density, VOLUME));
-
-    /* first-order velocities: InitialConditions.c:299-364 */
-    for (int ii = 0; ii < 3; ii++) {
-        if (hires || !need_filter)
-            TRY(hi_field(&c, c.saved, ii, -1, vel[ii], VOLUME));
+    if (need_filter && !hires) {
+        /* lowres_density and the three first-order velocities (InitialConditions.c:299-364): folds of one spectrum,
+         * the top-hat applied to the aliases on the way (round 6: no filtered copy of the DIM^3 spectrum) */
+        const int ops[4] = {-1, 0, 1, 2};
+        float *const tg[4] = {ics->lowres_density, vel[0], vel[1], vel[2]};
+        TRY(lo_fields(&c, c.saved, 4, ops, tg, VOLUME, R_lo));
+    } else {
+        if (need_filter)
+            TRY(lo_field(&c, c.filt, -1, -1, ics->lowres_density, VOLUME));
         else
-            TRY(lo_field(&c, c.filt, ii, -1, vel[ii], VOLUME));
+            TRY(hi_field(&c, c.saved, -1, -1, ics->lowres_density, VOLUME));
+        /* first-order velocities: InitialConditions.c:299-364 */
+        for (int ii = 0; ii < 3; ii++) TRY(hi_field(&c, c.saved, ii, -1, vel[ii], VOLUME));
     }
 
     if (lpt2) {
@@ -305,14 +345,12 @@ static int ics_grids_split(const c21cm_ics_spec *s, InitialConditions *ics, floa
         TRY(c21hip_split_r2c(box, c.hi[2], c.saved, c.hi[0], c.hi[1], c.hi[2], 1.0, 1., -1., 1.0f,
                              stream));
         c.pk2_valid = 0; /* `saved` now holds the 2LPT source */
-        if (need_filter && !hires)
-            TRY(c21hip_copy_filter_split(c.saved, c.filt, c.hi[0], c.hi[1], c.hi[2], s->box_len,
-                                         s->box_len_z, 0, R_lo, 0.f, 1, stream));
-        for (int ii = 0; ii < 3; ii++) {
-            if (hires || !need_filter)
-                TRY(hi_field(&c, c.saved, ii, -1, vel2[ii], 0.f));
-            else
-                TRY(lo_field(&c, c.filt, ii, -1, vel2[ii], 0.f));
+        if (hires || !need_filter) {
+            for (int ii = 0; ii < 3; ii++) TRY(hi_field(&c, c.saved, ii, -1, vel2[ii], 0.f));
+        } else {
+            const int ops[4] = {0, 1, 2, -1};
+            float *const tg[4] = {vel2[0], vel2[1], vel2[2], NULL};
+            TRY(lo_fields(&c, c.saved, 3, ops, tg, 0.f, R_lo));
         }
     }
     TRY(c21hip_sync(stream));
