@@ -511,8 +511,10 @@ sfrd_sum2_kernel(const float *__restrict__ filtered_density, const float *__rest
                  const double *__restrict__ shell, int n_step, size_t ntot,
                  double *__restrict__ partials) {
     __shared__ double lds[kBlock];
+    __shared__ float tab[C21CM_NDELTA_TABLE];  // (round 6: the shell's table in LDS -- the per-lane gathers went to L1)
     const int R = blockIdx.y;
-    const float *tab = tables + (size_t)R * C21CM_NDELTA_TABLE;
+    for (int t = threadIdx.x; t < C21CM_NDELTA_TABLE; t += kBlock) tab[t] = tables[(size_t)R * C21CM_NDELTA_TABLE + t];
+    __syncthreads();
     const double inv_w = shell[SH_TABINVW * n_step + R];
     ShellLookup L;
     L.growth = (float)shell[SH_GROWTH * n_step + R];

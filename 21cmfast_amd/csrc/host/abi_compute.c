@@ -785,6 +785,54 @@ static int ts_box_run(float redshift, float prev_redshift, float perturbed_field
                       TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp,
                       ts_shard_args *sh);
 
+/* The host preparation of a snapshot (shells, spectral factors, global tables: 3-8 ms on 16-64 threads) handed
+ * from phase 1 of a sharded ComputeTsBox to its phase 2, which used to build all of it again for a slab whose
+ * device work is 0.7 ms (round 6).  Keyed on the redshifts, the box mean of the previous x_e and every byte of the
+ * installed parameter structs; the spec / tables as they were BEFORE phase 1 compacted them to its shells. */
+unsigned long long c21_params_fingerprint(void); /* params.c */
+static struct {
+    int valid;
+    float z, prev_z, pf_z;
+    double x_e_ave;
+    unsigned long long params;
+    c21cm_ts_spec spec;
+    c21_ts_tables tab;
+    size_t freq_doubles;
+    double *freq;
+} g_ts_prep;
+static int ts_prep_matches(float z, float prev_z, float pf_z, double x_e_ave) {
+    return g_ts_prep.valid && g_ts_prep.z == z && g_ts_prep.prev_z == prev_z && g_ts_prep.pf_z == pf_z &&
+           g_ts_prep.x_e_ave == x_e_ave && g_ts_prep.params == c21_params_fingerprint();
+}
+static void ts_prep_store(float z, float prev_z, float pf_z, double x_e_ave, const c21cm_ts_spec *spec,
+                          const c21_ts_tables *tab) {
+    g_ts_prep.valid = 0;
+    const size_t nd = 3 * (size_t)C21CM_X_INT_NXHII * tab->n_step;
+    if (!tab->freq || tab->sfrd_tables || tab->sfrd_tables_mini || tab->fcoll_tables || tab->dfcoll_tables) return; /* (only the state right after prepare_tables) */
+    double *f = (double *)realloc(g_ts_prep.freq, nd * sizeof(double));
+    if (!f) return;
+    memcpy(f, tab->freq, nd * sizeof(double));
+    g_ts_prep.freq = f, g_ts_prep.freq_doubles = nd;
+    g_ts_prep.spec = *spec, g_ts_prep.tab = *tab;
+    g_ts_prep.tab.freq = NULL, g_ts_prep.tab.shell_mask = NULL;
+    g_ts_prep.z = z, g_ts_prep.prev_z = prev_z, g_ts_prep.pf_z = pf_z, g_ts_prep.x_e_ave = x_e_ave;
+    g_ts_prep.params = c21_params_fingerprint();
+    g_ts_prep.valid = 1;
+}
+/* spec / tab <- the stored preparation (tab owns a copy of the frequency integrals); 0: nothing stored for this call */
+static int ts_prep_load(float z, float prev_z, float pf_z, double x_e_ave, c21cm_ts_spec *spec, c21_ts_tables *tab) {
+    if (!ts_prep_matches(z, prev_z, pf_z, x_e_ave)) return 0;
+    double *f = (double *)malloc(g_ts_prep.freq_doubles * sizeof(double));
+    if (!f) return 0;
+    memcpy(f, g_ts_prep.freq, g_ts_prep.freq_doubles * sizeof(double));
+    c21_ts_tables_free(tab);
+    *spec = g_ts_prep.spec, *tab = g_ts_prep.tab;
+    tab->freq = f;
+    const size_t fn = (size_t)C21CM_X_INT_NXHII * tab->n_step;
+    spec->freq_int_heat = f, spec->freq_int_ion = f + fn, spec->freq_int_lya = f + 2 * fn;
+    return 1;
+}
+
 int ComputeTsBox(float redshift, float prev_redshift, float perturbed_field_redshift, short cleanup,
                  PerturbedField *perturbed_field, XraySourceBox *source_box,
                  TsBox *previous_spin_temp, InitialConditions *ini_boxes, TsBox *this_spin_temp) {
@@ -913,11 +961,26 @@ static int ts_box_run(float redshift, float prev_redshift, float perturbed_field
     const float *filtered = NULL;
     const int timing = getenv("C21CM_TS_TIMING") != NULL; /* stage wall times to stderr */
     double t_mark = timing ? wall_seconds() : 0., t_prep = 0., t_tables = 0.;
+    if (sh->mode == TS_RUN_SHARD_FINISH &&
+        ts_prep_load(redshift, prev_redshift, perturbed_field_redshift, x_e_ave_p, spec, tab)) {
+        /* phase 1 of this call prepared the snapshot in this process */
+        st = c21cm_ts_cells_from_sums(spec, perturbed_field->density, previous_spin_temp, sh->sums, sh->cell0,
+                                      sh->ncell, this_spin_temp, NULL);
+        if (!st) this_spin_temp->Q_HI = tab->Q_HI;
+        goto done;
+    }
     if ((st = c21_ts_prepare_shells(redshift, prev_redshift, perturbed_field_redshift, spec, tab)))
         goto done;
     if (sh->mode == TS_RUN_SHARD_FINISH) {
-        /* the slab's temperature update from the ranks' combined sums: host tables only */
-        if ((st = c21_ts_prepare_tables(x_e_ave_p, spec, tab))) goto done;
+        /* the slab's temperature update from the ranks' combined sums: host tables only -- and of those the
+         * global ones (Q_HI, NO_LIGHT, the mean SFRDs): the frequency integrals went into the sums (round 6: an
+         * empty shell mask; they were 4-12 ms of a phase whose device work is 0.7 ms) */
+        unsigned char no_shells[C21CM_MAX_TS_RADII];
+        memset(no_shells, 0, sizeof(no_shells));
+        tab->shell_mask = no_shells;
+        st = c21_ts_prepare_tables(x_e_ave_p, spec, tab);
+        tab->shell_mask = NULL;
+        if (st) goto done;
         st = c21cm_ts_cells_from_sums(spec, perturbed_field->density, previous_spin_temp, sh->sums,
                                       sh->cell0, sh->ncell, this_spin_temp, NULL);
         if (!st) this_spin_temp->Q_HI = tab->Q_HI;
@@ -998,17 +1061,25 @@ static int ts_box_run(float redshift, float prev_redshift, float perturbed_field
                 goto done;
             spec->filtered_log10_mcrit = mcrit_R;
         }
+        unsigned char shell_mask[C21CM_MAX_TS_RADII];
+        if (sh->mode == TS_RUN_SHARD_SUMS) { /* the frequency integrals of this rank's shells only */
+            memset(shell_mask, 0, sizeof(shell_mask));
+            for (int i = 0; i < n_local; i++) shell_mask[local[i]] = 1;
+            tab->shell_mask = shell_mask;
+        }
         job.device = c21hip_current_device();
         pthread_t worker;
         const int threaded = pthread_create(&worker, NULL, filter_job_run, &job) == 0;
         if (!threaded) (void)filter_job_run(&job); /* no thread: one after the other */
         st = c21_ts_prepare_tables(x_e_ave_p, spec, tab);
         if (timing) t_prep = wall_seconds() - t_mark;
+        tab->shell_mask = NULL; /* (points into this frame) */
         if (threaded) pthread_join(worker, NULL);
         if (st) goto done;
         if ((st = job.status)) goto done;
         if (timing) t_mark = wall_seconds();
         if (sh->mode == TS_RUN_SHARD_SUMS) {
+            ts_prep_store(redshift, prev_redshift, perturbed_field_redshift, x_e_ave_p, spec, tab);
             sh->n_rows = spec->use_lya_heating ? 6 : 4;
             if (spec->no_light) { /* nothing has formed: every partial sum is zero */
                 st = c21hip_memset(sh->sums, 0, (size_t)sh->n_rows * ntot * sizeof(double), NULL);

@@ -1159,8 +1159,16 @@ int c21_ts_prepare_tables(double x_e_ave, c21cm_ts_spec *s, c21_ts_tables *t) {
         tau_ion_eff = PS_ION_EFF;
     }
     int root_failed = 0, table_bad = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads()) reduction(| : root_failed, table_bad)
-    for (int R_ct = 0; R_ct < n; R_ct++) { /* the shells are independent (:822-863) */
+    /* the shells are independent (:822-863); a rank of a sharded ComputeTsBox only does its own (shell_mask).
+     * Two loops -- the tau_X = 1 roots per shell, then the (shell, x_e) pairs of the integrals -- so that five
+     * shells still fill the host threads (the integrand sequence of an integral is unchanged) */
+    int todo[C21CM_MAX_TS_RADII], n_todo = 0;
+    double lower_lim[C21CM_MAX_TS_RADII];
+    for (int R_ct = 0; R_ct < n; R_ct++)
+        if (!t->shell_mask || t->shell_mask[R_ct]) todo[n_todo++] = R_ct;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(host_threads()) reduction(| : root_failed)
+    for (int k = 0; k < n_todo; k++) {
+        const int R_ct = todo[k];
         int st = 0;
         /* :833-842: with mini-halos the root uses each shell's mean turnover mass */
         const double nu1 =
@@ -1168,11 +1176,15 @@ int c21_ts_prepare_tables(double x_e_ave, c21cm_ts_spec *s, c21_ts_tables *t) {
                                        sc.pop3_ion * sc.fstar_7 * sc.fesc_7, t->ave_log10_mturn[R_ct], &st)
                  : c21_nu_tau_one(zp, t->zpp[R_ct], x_e_ave, tau_ion_eff, &st);
         if (st) root_failed |= 1;
-        const double lower_int_limit = fmax(nu1, (ap->NU_X_THRESH) * PC_EV_TO_HZ);
+        lower_lim[R_ct] = fmax(nu1, (ap->NU_X_THRESH) * PC_EV_TO_HZ);
         t->nu_tau_one[R_ct] = nu1;
+    }
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(host_threads()) reduction(| : table_bad)
+    for (int k = 0; k < n_todo; k++) {
         for (int x_e_ct = 0; x_e_ct < C21CM_X_INT_NXHII; x_e_ct++) {
+            const int R_ct = todo[k];
             for (int flag = 0; flag < 3; flag++) {
-                const double v = c21_integrate_over_nu(zp, H.x_int_XHII[x_e_ct], lower_int_limit, flag);
+                const double v = c21_integrate_over_nu(zp, H.x_int_XHII[x_e_ct], lower_lim[R_ct], flag);
                 if (!isfinite(v)) table_bad |= 1;
                 t->freq[flag * fn + (size_t)x_e_ct * n + R_ct] = v;
             }

@@ -87,6 +87,16 @@ static unsigned long long ps_fingerprint(const MatterOptions *mo, const CosmoPar
     }
     return h ? h : 1;
 }
+/* every byte of the five installed parameter structs (callers may change them in place between calls): the key of
+ * state that is valid for one configuration only (abi_compute.c: the prepared tables a sharded ComputeTsBox hands
+ * from its first phase to its second) */
+unsigned long long c21_params_fingerprint(void) {
+    unsigned long long h = ps_fingerprint(matter_options_global, cosmo_params_global, cosmo_tables_global);
+    if (simulation_options_global) h = fnv(h, simulation_options_global, sizeof(*simulation_options_global));
+    if (astro_params_global) h = fnv(h, astro_params_global, sizeof(*astro_params_global));
+    if (astro_options_global) h = fnv(h, astro_options_global, sizeof(*astro_options_global));
+    return h;
+}
 static unsigned long long g_ps_print; /* 0: nothing broadcast yet */
 
 void Broadcast_struct_global_all(SimulationOptions *simulation_options,

@@ -170,7 +170,7 @@ class Tables(C.Structure):
         (k, f64 * 128) for k in ("ave_log10_mturn", "mean_sfr_zpp_mini", "starlya_prefactor_mini",
                                  "lya_cont_prefactor_mini", "lya_inj_prefactor_mini", "lw_prefactor",
                                  "lw_prefactor_mini")
-    ] + [("sfrd_tables_mini", C.POINTER(f32))]
+    ] + [("sfrd_tables_mini", C.POINTER(f32)), ("shell_mask", C.c_void_p)]
 
 
 def test_ts_prepare_against_numpy(heat, pkg):
