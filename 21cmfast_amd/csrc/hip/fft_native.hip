@@ -58,8 +58,8 @@
 #ifndef C21X_F512_HOIST2  // 1: second-stage twiddles kept in registers for the whole kernel (12-30 spilled
 #define C21X_F512_HOIST2 0  // VGPRs in the two-radius kernels, no faster)
 #endif
-#ifndef C21X_XPAIR_SKIP_FFT  // diagnostic (wrong results): 1 = the two-radius pass X skips its transforms,
-#define C21X_XPAIR_SKIP_FFT 0  // 2 = it also skips the second LDS write + store (i.e. moves R + W only)
+#ifndef C21X_XPAIR_SKIP_FFT  // diagnostic (wrong results): 1 = the two-radius pass X skips its transforms (512-point
+#define C21X_XPAIR_SKIP_FFT 0  // lines: windows + one LDS round trip stay), 3 = registers straight back out (R + 2 W only)
 #endif
 #ifndef C21X_XPAIR_TWO_SETS
 #define C21X_XPAIR_TWO_SETS 0
@@ -1251,12 +1251,28 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 c0[u] = make_float2(v.x, v.y);
                 c1[u] = make_float2(v.z, v.w);
             }
-            Dft<8, SIGN>::run(c0);
-            Dft<8, SIGN>::run(c1);
+            if constexpr (PAIR && C21X_XPAIR_SKIP_FFT == 3) {
+                // diagnostic (wrong results): the tile leaves as it came -- one read, two writes in this kernel's
+                // access pattern, no LDS, no arithmetic: the data-movement ceiling of the two-radius pass X
+                float2 *stp = member_grid(it, m) ? (rr ? it.dst1b : it.dst1) : (rr ? it.dst0b : it.dst0);
+                stp += member_base(it, m);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int row = r0 + RSTEP * u;
+                    const unsigned roff = row_off(it, row < N / 2 ? row : row - N / 2);
+                    float2 *pp = stp + (row < N / 2 ? 0 : st_half);
+                    *reinterpret_cast<float4 *>(pp + (roff + 2u * c4)) = reg[u];
+                }
+                continue;
+            }
+            if (!(PAIR && C21X_XPAIR_SKIP_FFT)) {
+                Dft<8, SIGN>::run(c0);
+                Dft<8, SIGN>::run(c1);
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 float2 o0 = c0[j], o1 = c1[j];
-                if (j > 0) {
+                if (j > 0 && !(PAIR && C21X_XPAIR_SKIP_FFT)) {
                     o0 = cmul(o0, twd1[F512_ ? j : 0]);
                     o1 = cmul(o1, twd1[F512_ ? j : 0]);
                 }
@@ -1355,7 +1371,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             }
             __syncthreads();
         }
-        if constexpr (F512) {
+        if constexpr (F512 && !(PAIR && C21X_XPAIR_SKIP_FFT)) {
             // second Stockham stage (s = 8) of all tiles of the sweep between ONE pair of barriers:
             // butterfly r0 of columns 2 c4, 2 c4 + 1: inputs rows r0 + 64 k, outputs rows
             // (r0 & 7) + 64 (r0 >> 3) + 8 j times tw[(r0 & ~7) j]
@@ -1447,6 +1463,7 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
             continue;
         }
         if constexpr (F512) {
+            if constexpr (PAIR && C21X_XPAIR_SKIP_FFT == 3) continue;
             // third stage (s = 64, no twiddles: inputs rows r0 + 64 k, outputs rows r0 + 64 j) on the
             // values read back for the store
             float2 c0[8], c1[8];
@@ -1456,8 +1473,10 @@ line_pass_kernel(LinePassArgs a, const float2 *__restrict__ tw_global) {
                 c0[k] = make_float2(t.x, t.y);
                 c1[k] = make_float2(t.z, t.w);
             }
-            Dft<8, SIGN>::run(c0);
-            Dft<8, SIGN>::run(c1);
+            if (!(PAIR && C21X_XPAIR_SKIP_FFT)) {
+                Dft<8, SIGN>::run(c0);
+                Dft<8, SIGN>::run(c1);
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 float4 v = make_float4(c0[j].x, c0[j].y, c1[j].x, c1[j].y);
