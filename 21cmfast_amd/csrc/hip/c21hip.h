@@ -328,6 +328,9 @@ int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3], const 
                        const float *const vel2[3], const int vel_dim[3], double *out,
                        const int out_dim[3], double box_len, double box_len_z, double growth,
                        double init_growth, int lpt2, int *fixed_out, void *stream);
+/* after a fixed-point deposit: *bad = 1 when a particle mass was non-finite or beyond what the 63 bits hold
+ * (synchronises the stream) */
+int c21hip_cic_fixed_status(int *bad, void *stream);
 /* double grid -> padded float [, *= mass_factor, -= 1]: PerturbedField.c:115-128,180-210 */
 /* ComputeHaloBox deposit (map_mass.c:214-344): exp(lerp(ln-table, delta*D)) * prefactor for the
  * two tables in tables_dev[2][NDELTA], CIC-deposited at the displaced positions (double grids) */

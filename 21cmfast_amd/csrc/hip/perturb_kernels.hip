@@ -343,6 +343,10 @@ struct CicCellParams {
 // in 1e5 (at 2^36 it was one in 500, which a 40^3 test noticed).  A cell holds up to 2^19 = 524288
 // particle masses before the 63 bits overflow.  The reference's OpenMP atomics have no defined order
 // either (map_mass.c:197-206).
+// (the integers wrap silently where the fp64 atomics carried NaN / Inf through to the output's non-finite
+//  checks.  A non-finite particle mass, or a cell's masses beyond what 63 bits hold, raise this flag; the launcher
+//  clears it, c21hip_cic_fixed_status reads it back and the driver turns it into C21CM_INFINITY_OR_NAN_ERROR.)
+__device__ int g_cic_fixed_bad;
 constexpr double kFixScale = 17592186044416.;       // 2^44
 constexpr double kFixMagic = 6755399441055744.;     // 1.5 * 2^52: x + magic holds rint(x) in its low bits
 constexpr long long kFixMagicBits = 0x4338000000000000LL;
@@ -471,6 +475,16 @@ cic_cell_kernel(CicCellParams q, const float *__restrict__ dens, const float *__
                     for (int jy = 0; jy < F; jy++)
 #pragma unroll
                         for (int jz = 0; jz < F; jz++) dmax = fmaxf(dmax, fabsf(dn[jx][jy][jz]));
+                float dsum = 0.f;  // (fmaxf drops a NaN, a sum keeps it; Inf stays Inf)
+#pragma unroll
+                for (int jx = 0; jx < F; jx++)
+#pragma unroll
+                    for (int jy = 0; jy < F; jy++)
+#pragma unroll
+                        for (int jz = 0; jz < F; jz++) dsum += fabsf(dn[jx][jy][jz]);
+                // 2^18 mean particle masses in ONE velocity cell's particles: no physical field gets near it
+                if (!(dsum < 3.0e38f) || (1.0 + (double)dmax * fabs(p.init_growth)) * (double)F3 > 262144.)
+                    atomicOr(&g_cic_fixed_bad, 1);
             }
             const bool small = (1.0 + (double)dmax * fabs(p.init_growth)) * (double)F3 < kFixFastLimit;
 #pragma unroll
@@ -962,6 +976,19 @@ void launch_cell(const CicCellParams &q, size_t lds, int blocks, int lpt2, const
 }
 }  // namespace
 
+// 1: the last fixed-point deposit met a non-finite or absurdly large particle mass (synchronises `stream`)
+extern "C" int c21hip_cic_fixed_status(int *bad, void *stream) {
+    int v = 0;
+    if (hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_cic_fixed_bad), sizeof(int), 0, hipMemcpyDeviceToHost,
+                                 (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return C21CM_IO_ERROR;
+    }
+    *bad = v;
+    return 0;
+}
+
 extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim[3],
                                   const float *const vel[3], const float *const vel2[3],
                                   const int vel_dim[3], double *out, const int out_dim[3],
@@ -998,6 +1025,11 @@ extern "C" int c21hip_cic_scatter(const float *hires_density, const int dens_dim
                 const char *ea = getenv("C21CM_CIC_ACC");
                 if (fixed_out && !(ea && ea[0] == 'd')) {
                     *fixed_out = 1;
+                    {
+                        const int zero = 0;  // (c21hip_cic_fixed_status reads it back after the deposit)
+                        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cic_fixed_bad), &zero, sizeof(int), 0,
+                                                     hipMemcpyHostToDevice, (hipStream_t)stream);
+                    }
                     if (f == 1)
                         launch_cell<1, 0, true>(q, lds, blocks, lpt2, hires_density, vel, vel2, out, (hipStream_t)stream);
                     else if (f == 2)

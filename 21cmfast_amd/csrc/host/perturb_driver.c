@@ -132,6 +132,14 @@ int c21cm_perturb_grids(const c21cm_perturb_spec *s, const InitialConditions *ic
         TRY(c21hip_cic_scatter(d_dens, hi_dim, vel, vel2, box_dim, resampled, box_dim, s->box_len,
                                s->box_len_z, s->growth_factor, s->init_growth_factor, lpt2, &fixed,
                                stream));
+        if (fixed) { /* the integers would wrap silently where the fp64 sums carried NaN / Inf to the caller */
+            int bad = 0;
+            TRY(c21hip_cic_fixed_status(&bad, stream));
+            if (bad) {
+                c21hip_set_error("perturb: non-finite (or absurdly large) hi-res density / displacement in the mass deposit");
+                return C21CM_INFINITY_OR_NAN_ERROR;
+            }
+        }
         /* widen (+ normalise when the deposit already happened on the output grid) */
         const double mass_factor = lo_tot / (double)hi_tot;
         TRY(c21hip_widen_normalise(resampled, grid, box_dim[0], box_dim[1], box_dim[2],

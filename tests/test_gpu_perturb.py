@@ -162,6 +162,33 @@ def test_deposit_is_deterministic(api, n, N, vscale, monkeypatch):
     assert abs(first.double().mean().item()) < 1e-5
 
 
+def test_non_finite_density_is_an_error_not_a_finite_wrong_field(api):
+    """the fixed-point integers of the deposit wrap silently -- a NaN / Inf hi-res density used to come
+    back as a finite, wrong density grid.  The deposit flags it and the call returns the reference's
+    InfinityorNaNError status (7)."""
+    import torch
+
+    n, N = 64, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for poison in (float("nan"), float("inf")):
+        ics = {}
+        for ax in "xyz":
+            ics[f"lowres_v{ax}"] = torch.randn((n,) * 3, generator=g, device="cuda")
+            ics[f"lowres_v{ax}_2LPT"] = 0.5 * torch.randn((n,) * 3, generator=g, device="cuda")
+        d = torch.randn((N,) * 3, generator=g, device="cuda")
+        d[17, 40, 99] = poison
+        ics["hires_density"] = d.contiguous()
+        spec = perturb_spec(2, dim=N, dim_z=N, hii_dim=n, hii_dim_z=n, box_len=1.5 * n, box_len_z=1.5 * n,
+                            growth_factor=0.127, init_growth_factor=0.0042, dDdt_over_D=2e-17)
+        with pytest.raises(RuntimeError, match="status 7"):
+            api.perturb_grids(spec, ics)
+    # and the library is fine afterwards
+    d = torch.randn((N,) * 3, generator=g, device="cuda")
+    ics["hires_density"] = (d - d.mean()).contiguous()
+    out = api.perturb_grids(spec, ics)["density"]
+    assert bool(torch.isfinite(out).all())
+
+
 @pytest.mark.parametrize("vscale", [1.0, 12.0, 60.0])
 def test_deposit_paths_large_displacements(api, oracle, vscale):
     """The LDS-tiled deposit keeps particles that leave the tile halo (2 output cells) on a
