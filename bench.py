@@ -663,6 +663,12 @@ def main():
         step()
         torch.cuda.synchronize()
         default_alloc["placement_call_ms"] = (time.perf_counter() - t_walk) * 1e3
+    elif os.environ.get("C21CM_WS_PLACE", "") == "":
+        # sharded: every rank opts in for its own device (a walk only happens where the rank has the GPU to itself)
+        os.environ.setdefault("C21CM_WS_PLACE_MS", "20000")
+        api.placement_set(1)
+        step()
+        torch.cuda.synchronize()
     placement = api.placement_report()
     ms_per_step = timed(step, args.steps, args.warmup)
     ms_slab_resident = None
