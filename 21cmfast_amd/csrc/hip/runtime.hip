@@ -237,7 +237,7 @@ extern "C" int c21hip_ws_adopt(int slot, void *ptr, size_t bytes) {
     return 0;
 }
 // ---- physical memory without (much of) a mapping: the placement walk's chunks (csrc/host/placement.c) ----------
-// hipMalloc of 16 GB costs ~0.6 s on this driver (38-45 ms per GB, profiles/r06_alloc_cost.txt) and the walk holds
+// hipMalloc of 16 GB costs ~0.6 s on this driver (38-45 ms per GB, profiles/r06_placement_vmm.txt section 1) and the walk holds
 // up to eight of them; hipMemCreate hands out the physical range for nothing, and only the head the probe
 // launches touch is mapped.  A chunk is {handle, reserved range, mapped bytes}; the workspace can adopt one whose
 // physical size equals its mapping (slot_free knows how to undo it).

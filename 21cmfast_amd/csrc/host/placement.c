@@ -86,7 +86,7 @@ int c21cm_placement_report(double out[8]) {
 }
 
 /* a candidate region: hipMalloc'ed, or (C21CM_WS_PLACE_ALLOC=vmm) physical memory from hipMemCreate with only the
- * head the probe touches mapped -- hipMalloc pays 38-45 ms per GB on this driver (profiles/r06_alloc_cost.txt), the
+ * head the probe touches mapped -- hipMalloc pays 38-45 ms per GB on this driver (profiles/r06_placement_vmm.txt section 1), the
  * walk's 16 GB chunks cost 0.6 s each that way */
 typedef struct {
     void *ptr, *vmm;

@@ -1,4 +1,4 @@
-// how expensive are the allocations of the placement walk?  (tools/scratch6; results: profiles/r06_alloc_cost.txt)
+// how expensive are the allocations of the placement walk?  (results: profiles/r06_placement_vmm.txt section 1; build: hipcc --offload-arch=gfx950 -O2 tools/alloc_cost.hip -o tools/bin/alloc_cost)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
