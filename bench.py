@@ -408,6 +408,10 @@ def run_icpf(args, torch, pkg):
         "config": {"workload": f"BASELINE config 2: InitialConditions + PerturbedField, HII_DIM={hii}, DIM={dim}, "
                                "2LPT, device-resident arrays, counter-based (Philox) modes",
                    "hii_dim": hii, "dim": dim, "ics_ms": ic_ms, "perturb_ms": pf_ms,
+                   "random_stream": "Philox-4x32-10 counters on the device; the reference-compatible GSL streams "
+                                    "(same seed -> upstream's universe) are drawn serially on the host as upstream "
+                                    "draws them and are NOT what this line times: 1.5 s at DIM = 1024 "
+                                    "(profiles/r06_config5_timing.json: ics_ms)",
                    "density_std": float(state["out"]["density"].std())},
         "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "achievable_GBs": args.achievable_gbs,
                      "kernel": "the InitialConditions pipeline as a whole (native line passes, k-space "
