@@ -8,7 +8,7 @@ recombination loop, the output broadcasts, the status agreement, and ComputeTsBo
 Each case compares this rank's sharded result with the single pass computed by the same process (bit for bit
 for ComputeIonizedBox: "the largest radius that ionises the cell" is order independent, reference
 IonisationBox.c:1531-1588, and the finish is per cell, :1031-1256,1597-1608).  Failures are collected, not
-raised, so that every rank keeps entering the collectives; the last line printed is "RESULT <json>"."""
+raised, so that every rank keeps entering the collectives; the result goes to <tmp>/result_rank<r>.json."""
 
 import ctypes as C
 import importlib
@@ -335,8 +335,11 @@ def main():
             break  # the other ranks may be inside a collective this rank left: stop here (the shim times out)
     stats = c.stats()
     api.shard_finalize()
-    print("RESULT " + json.dumps({"rank": c.rank, "world": c.world, "failures": c.failures, "done": c.done,
-                                  "stats": stats, "info": c.info}), flush=True)
+    # (a file per rank: eight ranks printing at once interleave their lines on the launcher's stdout)
+    result = json.dumps({"rank": c.rank, "world": c.world, "failures": c.failures, "done": c.done, "stats": stats,
+                         "info": c.info})
+    Path(tmp, f"result_rank{c.rank}.json").write_text(result)
+    print("RESULT " + result, flush=True)
     try:
         dist.barrier()
         dist.destroy_process_group()
