@@ -81,12 +81,12 @@ if has eul; then
     stats abi_e_integral_xe env PYTHONPATH=$REPO python $REPO/tools/time_abi_ionize.py 512 1 9.0 1
 fi
 if has shard; then
-    # the sharded code path: one rank over real RCCL, 2 and 3 ranks on the one GPU over the test transport
+    # the sharded code path: one rank over real RCCL; 2, 3 and 8 ranks on the one GPU over the test transport
     timeout 600 python bench.py --force-shard --steps 5 --warmup 2 --no-cpu-baseline --no-abi --config4-dim 1024 --config4-steps 2 \
         > $OUT/bench_${TAG}_force_shard_one_rank.json 2> gpurun_out/bench_force_shard.err
     make -C tests/shim > /dev/null
-    for N in 2 3; do
-      C21CM_RCCL_LIB=$REPO/tests/shim/librccl_shim.so C21CM_WS_PLACE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N \
+    for N in 2 3 8; do
+      C21CM_RCCL_LIB=$REPO/tests/shim/librccl_shim.so RCCL_SHIM_SLOT_KB=256 C21CM_WS_PLACE=0 timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N \
         --master-addr 127.0.0.1 --master-port $((29500 + N)) bench.py --gpus $N --backend gloo --steps 3 --warmup 1 --no-cpu-baseline \
         --no-abi --no-kernel-roofline --config4-dim 256 2> gpurun_out/bench_shim_$N.err | grep "^{" > $OUT/bench_${TAG}_shim_transport_${N}_ranks_one_gpu.json
     done
