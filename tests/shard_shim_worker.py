@@ -264,8 +264,12 @@ def case_abi(c, tmp):
         got = call_ionize(lib, 8.0, density, need_nion=True)
         c.check("ABI sharded status", one["status"] == 0 and got["status"] == 0, str(lib.c21cm_last_error()))
         for k in FIELDS:
-            c.check("ABI ComputeIonizedBox whole boxes", np.array_equal(one[k], got[k]),
-                    f"{k}: {int((one[k] != got[k]).sum())} cells differ")
+            if not np.array_equal(one[k], got[k]):
+                bad = np.flatnonzero(one[k].reshape(-1) != got[k].reshape(-1))
+                i0 = int(bad[0])
+                c.check("ABI ComputeIonizedBox whole boxes", False,
+                        f"{k}: {bad.size} cells differ, flat indices {i0}..{int(bad[-1])}, first: single "
+                        f"{one[k].reshape(-1)[i0]!r} sharded {got[k].reshape(-1)[i0]!r} (rank {c.rank})")
         c.check("ABI mean_f_coll", one["mean_f_coll"] == got["mean_f_coll"])
         ion = float((one["neutral_fraction"] == 0).mean())
         c.check("ABI workload", 0.02 < ion < 0.98, f"{ion}")
@@ -323,8 +327,11 @@ def case_ts(c, tmp):
 
 def main():
     cases = sys.argv[1].split(",")
-    tmp = sys.argv[2]
     c = Ctx()
+    # (a directory of its own per rank: the sessions of the ABI / TsBox cases write their synthetic RECFAST table there,
+    #  and eight ranks writing and reading ONE file raced -- a rank loaded a half-written table)
+    tmp = str(Path(sys.argv[2]) / f"rank{c.rank}")
+    Path(tmp).mkdir(parents=True, exist_ok=True)
     table = {"lagrangian": case_lagrangian, "means": case_means, "eulerian": case_eulerian, "recomb": case_recomb,
              "failure": case_failure, "abi": lambda c_: case_abi(c_, tmp), "ts": lambda c_: case_ts(c_, tmp)}
     for name in cases:
@@ -338,7 +345,7 @@ def main():
     # (a file per rank: eight ranks printing at once interleave their lines on the launcher's stdout)
     result = json.dumps({"rank": c.rank, "world": c.world, "failures": c.failures, "done": c.done, "stats": stats,
                          "info": c.info})
-    Path(tmp, f"result_rank{c.rank}.json").write_text(result)
+    Path(sys.argv[2], f"result_rank{c.rank}.json").write_text(result)
     print("RESULT " + result, flush=True)
     try:
         dist.barrier()
