@@ -67,7 +67,8 @@ if has sizes; then
     python tools/collect_pmc.py $PMC_F $PMC_W $OUT/pmc1024_$TAG.json $OUT/${TAG}_1024_pmc 1024
     pmc_clean 1024
     cp $OUT/pmc1024_$TAG.json profiles/
-    timeout 400 python bench.py --hii-dim 1024 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_${TAG}_1024.json 2> gpurun_out/bench_1024.err
+    # (with the CPU leg: the oracle runs the 1024^3 box on the same fields -> parity_1024 in the line; ~3 min on 64 threads)
+    timeout 2000 python bench.py --hii-dim 1024 --steps 3 --warmup 1 --no-abi > $OUT/bench_${TAG}_1024.json 2> gpurun_out/bench_1024.err
 fi
 if has eul; then
     # Eulerian models through the drop-in entry point: fused table sweep + pair sweeps (default), round 5's loop
